@@ -122,7 +122,7 @@ def gen_fusion(mods):
         # name, llm, d_txt, H, B, N, T, C, lengths, t_hat_1d
         ("tiny_h1", "TOY16", 8, 1, 4, 5, 6, 3, [5, 3, 1, 2], False),
         ("tiny_h2", "TOY16", 8, 2, 4, 5, 6, 3, [5, 3, 1, 2], True),
-        ("noproj_h2", "TOY16", None, 2, 3, 4, 5, 2, [4, 2, 3], False),
+        ("noproj_h2", "TOY16", None, 2, 3, 4, 5, 5, [4, 2, 3], False),
         ("mid_h4", "TOY48", 32, 4, 3, 7, 5, 4, [7, 1, 4], False),
     ]
     for (name, llm, d_txt, H, B, N, T, C, lengths, t1d) in cases:

@@ -1,0 +1,282 @@
+// Ragged single-query cross-attention (TTF_T2V_XAttn) and row softmax (+attention-weight dropout) kernels.
+//
+// TTF_T2V_XAttn's query is one learned vector (fusions/TTF_T2V_XAttn.py:91,143), so per window b and head h the
+// scores are a mat-vec of the window's packed keys with the scaled query, the softmax runs over that window's
+// n_b notes only (offsets[b]..offsets[b+1]) -- no -inf padding, no T-fold copy of K/V (the reference materialises
+// T copies, :150-159) -- and only the attention-weight dropout makes the T output rows differ.
+#include "attn.hpp"
+
+namespace {
+
+constexpr int TT = 32;   // forecast steps accumulated per pass in registers
+
+// grid (B, H, ceil(hd/256)), 256 threads; LDS: sc[N] | atile[TT*64] | red[16]
+__global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                               const int* __restrict__ rowmap,
+                                                               const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                               float* __restrict__ P, float* __restrict__ ctx, DropCfg drop,
+                                                               uint64_t site) {
+    extern __shared__ float lds[];
+    float* sc = lds;
+    float* atile = lds + dm.N;
+    float* red = atile + TT * 64;
+    const int b = blockIdx.x, h = blockIdx.y, ez = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
+    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    const int e = ez * 256 + tid;
+    const bool valid = e < hd;
+    if (n == 0) {   // no notes: the caller zeroes the row after out_proj anyway (M_txt); keep ctx defined
+        if (valid) for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = 0.f;
+        return;
+    }
+    for (int i = wave; i < n; i += 4) {
+        const float* kr = KVp + (size_t)(o0 + i) * ld + h * hd;
+        float a = 0.f;
+        for (int c = lane; c < hd; c += 64) a = fmaf(qs[h * hd + c], kr[c], a);
+        a = wave_sum(a);
+        if (lane == 0) sc[i] = a;
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, sc[i]);
+    m = block_max(m, red);
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) { const float p = expf(sc[i] - m); sc[i] = p; sum += p; }
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    for (int i = tid; i < n; i += 256) {
+        const float p = sc[i] * inv;
+        sc[i] = p;
+        if (ez == 0) P[(size_t)(o0 + i) * dm.H + h] = p;
+    }
+    __syncthreads();
+
+    const float* vbase = KVp + (size_t)o0 * ld + d + h * hd + e;
+    if (drop.p <= 0.f) {   // every forecast step sees the same weights
+        if (!valid) return;
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc = fmaf(sc[i], vbase[(size_t)i * ld], acc);
+        for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = acc;
+        return;
+    }
+    for (int t0 = 0; t0 < T; t0 += TT) {
+        float acc[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc[tt] = 0.f;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            __syncthreads();
+            for (int x = tid; x < TT * 64; x += 256) {
+                const int tt = x >> 6, ii = x & 63, t = t0 + tt, i = i0 + ii;
+                float a = 0.f;
+                if (t < T && i < n) {
+                    const int n_orig = rowmap[o0 + i] - b * dm.N;
+                    const uint64_t idx = ((uint64_t)(b * T + t) * dm.H + h) * dm.N + n_orig;
+                    a = sc[i] * dropout_scale(drop.seed, site, idx, drop.p, drop.inv_keep);
+                }
+                atile[x] = a;
+            }
+            __syncthreads();
+            if (valid) {
+                const int cnt = min(64, n - i0);
+                for (int ii = 0; ii < cnt; ++ii) {
+                    const float v = vbase[(size_t)(i0 + ii) * ld];
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) acc[tt] = fmaf(atile[tt * 64 + ii], v, acc[tt]);
+                }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+                if (t0 + tt < T) ctx[(size_t)(b * T + t0 + tt) * d + h * hd + e] = acc[tt];
+        }
+    }
+}
+
+constexpr int MT = 4;   // backward keeps the dropout scales of up to MT*64 forecast steps in registers
+
+// grid (B, H), 256 threads; LDS: dp[N] | ps[N] | G[hd] | red[16]
+__global__ __launch_bounds__(256) void ragged_attn_bwd_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                               const int* __restrict__ rowmap,
+                                                               const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                               const float* __restrict__ P, const float* __restrict__ dctx,
+                                                               float* __restrict__ dKVp, float* __restrict__ dqs_part,
+                                                               DropCfg drop, uint64_t site) {
+    extern __shared__ float lds[];
+    float* dp = lds;
+    float* ps = lds + dm.N;
+    float* G = ps + dm.N;
+    float* red = G + dm.hd;
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
+    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    if (n == 0) {
+        for (int c = tid; c < hd; c += 256) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
+        return;
+    }
+    for (int i = tid; i < n; i += 256) ps[i] = P[(size_t)(o0 + i) * dm.H + h];
+    const float* dc = dctx + (size_t)b * T * d + h * hd;   // row t at dc + t*d
+    if (drop.p <= 0.f) {
+        for (int c = tid; c < hd; c += 256) {
+            float g = 0.f;
+            for (int t = 0; t < T; ++t) g += dc[(size_t)t * d + c];
+            G[c] = g;
+        }
+        __syncthreads();
+        for (int i = wave; i < n; i += 4) {
+            const float* vr = KVp + (size_t)(o0 + i) * ld + d + h * hd;
+            float* dvr = dKVp + (size_t)(o0 + i) * ld + d + h * hd;
+            const float pi = ps[i];
+            float a = 0.f;
+            for (int c = lane; c < hd; c += 64) {
+                const float g = G[c];
+                a = fmaf(g, vr[c], a);
+                dvr[c] = pi * g;
+            }
+            a = wave_sum(a);
+            if (lane == 0) dp[i] = a;
+        }
+    } else {
+        __syncthreads();
+        for (int i = wave; i < n; i += 4) {
+            const int n_orig = rowmap[o0 + i] - b * dm.N;
+            float mreg[MT];
+#pragma unroll
+            for (int k = 0; k < MT; ++k) {
+                const int t = k * 64 + lane;
+                mreg[k] = 0.f;
+                if (t < T) {
+                    const uint64_t idx = ((uint64_t)(b * T + t) * dm.H + h) * dm.N + n_orig;
+                    mreg[k] = dropout_scale(drop.seed, site, idx, drop.p, drop.inv_keep);
+                }
+            }
+            const float* vr = KVp + (size_t)(o0 + i) * ld + d + h * hd;
+            float* dvr = dKVp + (size_t)(o0 + i) * ld + d + h * hd;
+            const float pi = ps[i];
+            float a = 0.f;
+            for (int c0 = 0; c0 < hd; c0 += 64) {     // uniform trip count: the shuffles below need all 64 lanes
+                const int c = c0 + lane;
+                float g = 0.f;
+#pragma unroll
+                for (int k = 0; k < MT; ++k) {
+                    const int tcnt = min(64, T - k * 64);
+                    for (int tt = 0; tt < tcnt; ++tt) {
+                        const float mt = __shfl(mreg[k], tt, 64);
+                        if (c < hd) g = fmaf(mt, dc[(size_t)(k * 64 + tt) * d + c], g);
+                    }
+                }
+                if (c < hd) {
+                    a = fmaf(g, vr[c], a);
+                    dvr[c] = pi * g;
+                }
+            }
+            a = wave_sum(a);
+            if (lane == 0) dp[i] = a;
+        }
+    }
+    __syncthreads();
+    float part = 0.f;
+    for (int i = tid; i < n; i += 256) part = fmaf(ps[i], dp[i], part);
+    const float dot = block_sum(part, red);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) dp[i] = ps[i] * (dp[i] - dot);   // dp now holds ds
+    __syncthreads();
+    for (int i = wave; i < n; i += 4) {
+        float* dkr = dKVp + (size_t)(o0 + i) * ld + h * hd;
+        const float dsi = dp[i];
+        for (int c = lane; c < hd; c += 64) dkr[c] = dsi * qs[h * hd + c];
+    }
+    for (int c = tid; c < hd; c += 256) {
+        const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
+        float a = 0.f;
+        for (int i = 0; i < n; ++i) a = fmaf(dp[i], kc[(size_t)i * ld], a);
+        dqs_part[(size_t)b * d + h * hd + c] = a;
+    }
+}
+
+// ---- dense attention rows: one wave per (b,h,l) row of length S ---------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ sc, float* __restrict__ A, int rows, int HL,
+                                                                int S, const unsigned char* __restrict__ live, DropCfg drop,
+                                                                uint64_t site) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = sc + (size_t)row * S;
+    float* a = A + (size_t)row * S;
+    if (live && !live[row / HL]) {
+        for (int i = lane; i < S; i += 64) { p[i] = 0.f; a[i] = 0.f; }
+        return;
+    }
+    float m = -INFINITY;
+    for (int i = lane; i < S; i += 64) m = fmaxf(m, p[i]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int i = lane; i < S; i += 64) sum += expf(p[i] - m);
+    const float inv = 1.f / wave_sum(sum);
+    for (int i = lane; i < S; i += 64) {
+        const float v = expf(p[i] - m) * inv;
+        p[i] = v;
+        a[i] = v * dropout_scale(drop.seed, site, (uint64_t)row * S + i, drop.p, drop.inv_keep);
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(float* __restrict__ dA, const float* __restrict__ P, int rows,
+                                                                int S, DropCfg drop, uint64_t site) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* g = dA + (size_t)row * S;
+    const float* p = P + (size_t)row * S;
+    float dot = 0.f;
+    for (int i = lane; i < S; i += 64) {
+        const float dpv = g[i] * dropout_scale(drop.seed, site, (uint64_t)row * S + i, drop.p, drop.inv_keep);
+        g[i] = dpv;
+        dot = fmaf(p[i], dpv, dot);
+    }
+    dot = wave_sum(dot);
+    for (int i = lane; i < S; i += 64) g[i] = p[i] * (g[i] - dot);
+}
+
+}  // namespace
+
+int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s) {
+    if (dm.B <= 0) return IMMTSF_OK;
+    const size_t lds = (size_t)(dm.N + TT * 64 + 16) * sizeof(float);
+    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+    hipLaunchKernelGGL(ragged_attn_fwd_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
+                       P, ctx, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           const float* P, const float* dctx, float* dKVp, float* dqs_part, DropCfg drop, uint64_t site,
+                           hipStream_t s) {
+    if (dm.B <= 0) return IMMTSF_OK;
+    if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
+    const size_t lds = (size_t)(2 * dm.N + dm.hd + 16) * sizeof(float);
+    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+    hipLaunchKernelGGL(ragged_attn_bwd_kernel, dim3(dm.B, dm.H), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs, P, dctx, dKVp,
+                       dqs_part, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, const unsigned char* live, DropCfg drop,
+                            uint64_t site, hipStream_t s) {
+    const int rows = B * H * L;
+    if (rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, sc, A, rows, H * L, S, live, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int S, DropCfg drop, uint64_t site,
+                            hipStream_t s) {
+    const int rows = B * H * L;
+    if (rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dA, P, rows, S, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}

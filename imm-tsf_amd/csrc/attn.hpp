@@ -1,0 +1,25 @@
+// Attention-specific kernels: the single-query ragged cross-attention of TTF_T2V_XAttn (one learned query per
+// window against that window's packed notes) and the row softmax used by the dense T x T attention of
+// MMF_XAttn_Add / FullAttention (whose QK^T and A*V contractions run on the batched MFMA GEMM).
+#pragma once
+#include "common.hpp"
+
+struct RaggedAttnDims {
+    int B, T, H, hd, N;   // N = padded notes per window (only used for the dropout index)
+};
+
+// forward: KVp packed rows [R, 2d] = (k | v); qs = scaled query [d]; P out [R, H]; ctx out [B*T, d]
+int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s);
+// backward: dctx [B*T, d] -> dKVp [R, 2d] (dk | dv), dqs_part [B, d]
+int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           const float* P, const float* dctx, float* dKVp, float* dqs_part, DropCfg drop, uint64_t site,
+                           hipStream_t s);
+
+// rows = B*H*L, each of length S.  In place on `sc`: P = softmax(sc) (0 where !live[b]); A = P*dropscale
+// written to `A` (may alias sc when drop.p == 0).
+int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, const unsigned char* live, DropCfg drop,
+                            uint64_t site, hipStream_t s);
+// dA -> dS in place: dP = dA*dropscale; dS = P*(dP - sum(P*dP))
+int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int S, DropCfg drop, uint64_t site,
+                            hipStream_t s);

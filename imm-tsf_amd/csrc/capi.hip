@@ -1,0 +1,112 @@
+// extern "C" wrappers of the building-block kernels (tests, layers/ mirror, loss, optimizer).
+#include "../../include/immtsf.h"
+#include "attn.hpp"
+#include "gemm.hpp"
+#include "rowops.hpp"
+#include "tail.hpp"
+#include "block_util.hpp"
+
+namespace {
+inline DropCfg mk_drop(float p, uint64_t seed) {
+    DropCfg d;
+    d.seed = seed;
+    d.p = p > 0.f ? p : 0.f;
+    d.inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    return d;
+}
+}  // namespace
+
+extern "C" {
+
+int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
+                int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
+                int32_t act, immtsf_stream_t stream) {
+    if (!A || !B || !C || layout < 0 || layout > 2) return IMMTSF_EINVAL;
+    GemmArgs g = gemm_args(M, N, K, lda, ldb, ldc);
+    set_problem(g, 0, A, B, C, bias);
+    g.alpha = alpha;
+    g.accumulate = accumulate;
+    g.act = act;
+    return immtsf_launch_gemm(layout, precision, g, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
+                        const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,
+                        int64_t sC_i, int32_t n_outer, int32_t n_inner, int32_t M, int32_t N, int32_t K, float alpha,
+                        immtsf_stream_t stream) {
+    if (!A || !B || !C || layout < 0 || layout > 2 || n_outer <= 0 || n_inner <= 0) return IMMTSF_EINVAL;
+    GemmArgs g = gemm_args(M, N, K, lda, ldb, ldc);
+    set_problem(g, 0, A, B, C, nullptr);
+    g.alpha = alpha;
+    g.nbatch = n_outer * n_inner;
+    g.batch_inner = n_inner;
+    g.sA_o = sA_o; g.sA_i = sA_i; g.sB_o = sB_o; g.sB_i = sB_i; g.sC_o = sC_o; g.sC_i = sC_i;
+    if (g.nbatch == 1) { g.nbatch = 1; }
+    return immtsf_launch_gemm(layout, precision, g, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_softmax_rows_forward(float* sc, float* A, int32_t B, int32_t H, int32_t L, int32_t S, const uint8_t* live,
+                                float p_drop, uint64_t seed, uint64_t site, immtsf_stream_t stream) {
+    if (!sc || !A) return IMMTSF_EINVAL;
+    return launch_softmax_rows_fwd(sc, A, B, H, L, S, live, mk_drop(p_drop, seed), site, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H, int32_t L, int32_t S, float p_drop,
+                                 uint64_t seed, uint64_t site, immtsf_stream_t stream) {
+    if (!dA || !P) return IMMTSF_EINVAL;
+    return launch_softmax_rows_bwd(dA, P, B, H, L, S, mk_drop(p_drop, seed), site, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
+                             float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,
+                             immtsf_stream_t stream) {
+    if (!x || !gamma || !beta || !z || d <= 0) return IMMTSF_EINVAL;
+    return launch_layernorm_fwd(x, rows, d, gamma, beta, eps, xhat, rstd, z, mk_drop(p_drop, seed), site,
+                                static_cast<hipStream_t>(stream));
+}
+
+int immtsf_layernorm_backward(float* dz_dy, int32_t rows, int32_t d, const float* gamma, const float* xhat,
+                              const float* rstd, float* dx, float* dgamma, float* dbeta, float* scratch, float p_drop,
+                              uint64_t seed, uint64_t site, immtsf_stream_t stream) {
+    if (!dz_dy || !gamma || !xhat || !rstd || !dx || d <= 0) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    CHECK(launch_layernorm_bwd(dz_dy, rows, d, gamma, xhat, rstd, dx, mk_drop(p_drop, seed), site, s));
+    if (dgamma) {
+        if (!scratch) return IMMTSF_EINVAL;
+        CHECK(launch_colsum(dz_dy, xhat, rows, nullptr, d, d, dgamma, 0, scratch, s));
+    }
+    if (dbeta) {
+        if (!scratch) return IMMTSF_EINVAL;
+        CHECK(launch_colsum(dz_dy, nullptr, rows, nullptr, d, d, dbeta, 0, scratch, s));
+    }
+    return IMMTSF_OK;
+}
+
+int immtsf_dropout_mask(uint64_t seed, uint64_t site, uint64_t n, float p_drop, uint8_t* out, immtsf_stream_t stream) {
+    if (!out) return IMMTSF_EINVAL;
+    return launch_dropout_mask(seed, site, (size_t)n, p_drop, out, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
+                           float* err_sum, float* cnt, immtsf_stream_t stream) {
+    if (!truth || !pred || !mask || !err_sum || !cnt || rows < 0 || C <= 0) return IMMTSF_EINVAL;
+    return launch_mse_sums(truth, pred, mask, rows, C, err_sum, cnt, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
+                             const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
+                             immtsf_stream_t stream) {
+    if (!truth || !pred || !mask || !err_sum || !cnt || rows < 0 || C <= 0) return IMMTSF_EINVAL;
+    return launch_mse_finish(truth, pred, mask, rows, C, err_sum, cnt, loss, dpred, grad_scale,
+                             static_cast<hipStream_t>(stream));
+}
+
+int immtsf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                     float* norm_scratch, immtsf_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !norm_scratch || step < 1) return IMMTSF_EINVAL;
+    return launch_adam(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, max_norm,
+                       norm_scratch, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the IMM-TSF fusion hot path.
+// Wavefront = 64 lanes everywhere; nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IMMTSF_WAVE 64
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// ---- status codes of the C ABI (see include/immtsf.h) ------------------------------------------
+#define IMMTSF_OK 0
+#define IMMTSF_EINVAL (-1)
+#define IMMTSF_EWORKSPACE (-2)
+#define IMMTSF_EUNSUPPORTED (-3)
+
+#define IMMTSF_LAUNCH_CHECK()                           \
+    do {                                                \
+        hipError_t e__ = hipGetLastError();             \
+        if (e__ != hipSuccess) return (int)e__;         \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- wave / block reductions ----------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` is >= 16 floats of LDS.
+// Every thread gets the result.  Contains two barriers.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+// ---- Philox4x32-10 counter RNG for in-kernel dropout ------------------------------------------------
+// One call yields 4 x 32 random bits for (seed, subsequence = dropout site, counter = element/4).
+// The same (seed, site, element) always gives the same bit, so backward recomputes masks instead of
+// storing them, and tests can export them (immtsf_dropout_mask).
+struct Philox4 { uint32_t x, y, z, w; };
+
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint64_t seed, uint64_t site, uint64_t ctr) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = (uint32_t)site, c3 = (uint32_t)(site >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+
+// keep-probability test for element `idx` of dropout site `site`: returns 1.f/(1-p) or 0.f.
+// p == 0 never calls the generator.  The uniform is the top 24 bits so that the comparison is exact
+// in float on both host and device.
+__host__ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t site, uint64_t idx, float p,
+                                                        float inv_keep) {
+    if (p <= 0.f) return 1.f;
+    const Philox4 r = philox4x32_10(seed, site, idx >> 2);
+    const uint32_t lane = (uint32_t)(idx & 3);
+    const uint32_t bits = lane == 0 ? r.x : lane == 1 ? r.y : lane == 2 ? r.z : r.w;
+    const float u = (float)(bits >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
+struct DropCfg {
+    uint64_t seed;
+    float p;          // drop probability (0 => identity)
+    float inv_keep;   // 1/(1-p)
+};
+
+// dropout sites (Philox subsequence ids) -- one per dropout call of the reference modules
+enum : uint64_t {
+    SITE_T2V_ATTN = 1,   // fusions/TTF_T2V_XAttn.py:79-84  (attention-weight dropout inside MHA)
+    SITE_T2V_OUT = 2,    // fusions/TTF_T2V_XAttn.py:179
+    SITE_REC_OUT = 3,    // fusions/TTF_RecAvg.py:106
+    SITE_XADD_ATTN = 4,  // fusions/MMF_XAttn_Add.py:42-47
+    SITE_XADD_OUT = 5,   // fusions/MMF_XAttn_Add.py:95
+    SITE_GR_OUT = 6,     // fusions/MMF_GR_Add.py:51
+    SITE_LAYER_BASE = 16 // layers/* dropout sites: SITE_LAYER_BASE + caller-chosen id
+};

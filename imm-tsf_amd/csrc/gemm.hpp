@@ -1,0 +1,47 @@
+// MFMA GEMM used by every projection of the fusion path (forward NT, data-gradient NN, weight-gradient TN).
+#pragma once
+#include "common.hpp"
+
+#define IMMTSF_GEMM_MAX_PROBLEMS 4
+
+struct GemmProblem {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // length N, may be null
+    float* bias_grad;    // TN + ones_col: length M, receives sum_k opA(m,k)
+};
+
+// C[m,n] = epilogue( alpha * sum_k opA(m,k) * opB(n,k) )
+//   opA(m,k) = TA ? A[k*lda + m] : A[m*lda + k]        (TA: reduction index is the slow one)
+//   opB(n,k) = TB ? B[k*ldb + n] : B[n*ldb + k]
+// epilogue(v) = act( rowflag(v + bias[n]) + add_vec[n] ) (+ C_old if accumulate)
+struct GemmArgs {
+    GemmProblem p[IMMTSF_GEMM_MAX_PROBLEMS];
+    int nprob;
+    int M, N, K;
+    int lda, ldb, ldc;
+    const int* dyn;        // device int overriding M (dyn_which==0) or K (dyn_which==1); may be null
+    int dyn_which;
+    const int* a_rowmap;   // !TA: source row of A for logical row m.  TA: source row for reduction index k
+    const int* b_rowmap;   // TB only: source row of B for reduction index k
+    float alpha;
+    int accumulate;
+    const unsigned char* row_flag;   // optional: rows with row_flag[m / row_flag_div] == 0 are zeroed
+    int row_flag_div;
+    const float* add_vec;  // optional, length N
+    int act;               // 0 none, 1 relu, 2 gelu(erf)
+    int vecA, vecB;        // host-verified: 16-byte aligned base and ld % 4 == 0
+    // batched form (dense attention): grid.z = nprob * nbatch; batch index bi -> (bo, bin) = (bi / batch_inner,
+    // bi % batch_inner); each operand pointer advances by bo*s?_o + bin*s?_i elements.  nbatch <= 1: no batching.
+    int nbatch, batch_inner;
+    long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
+    // TN only: when p[i].bias_grad != null the B operand gets a virtual all-ones column N, whose result
+    // (= column sums of A over the reduction index, i.e. the bias gradient) is written to bias_grad[m].
+    int ones_col;
+};
+
+enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+
+// precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);

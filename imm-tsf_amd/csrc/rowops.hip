@@ -1,0 +1,408 @@
+// HBM-bound row kernels: ragged index (note mask -> lengths/offsets/rowmap), Time2Vec, LayerNorm(+dropout),
+// column reductions and a few tiny vector helpers.  64-lane wavefronts: a "row" is normally owned by one wave,
+// loads are 16 B per lane whenever the row is 16-byte aligned.
+#include "rowops.hpp"
+
+namespace {
+
+constexpr int kSlabs = 32;   // row slabs of the two-stage column reductions (deterministic, no atomics)
+
+// ------------------------------------------------------------------------------------------- note mask
+// reference: note_mask = (V.abs().sum(dim=2) > 0)  fusions/TTF_T2V_XAttn.py:107, fusions/TTF_RecAvg.py:69
+__global__ __launch_bounds__(256) void note_mask_kernel(const float* __restrict__ V, int rows, int d_m,
+                                                         unsigned char* __restrict__ mask, int* nan_flag, int vec) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = V + (size_t)row * d_m;
+    float s = 0.f;
+    bool bad = false;
+    if (vec) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int i = lane; i < d_m / 4; i += 64) {
+            const float4 v = p4[i];
+            s += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+            bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+        }
+    } else {
+        for (int i = lane; i < d_m; i += 64) {
+            const float v = p[i];
+            s += fabsf(v);
+            bad |= (v != v);
+        }
+    }
+    s = wave_sum(s);
+    const bool anybad = __any(bad);
+    if (lane == 0) {
+        mask[row] = (s > 0.f) ? 1 : 0;   // NaN sum compares false, like torch
+        if (anybad && nan_flag) atomicOr(nan_flag, 1);
+    }
+}
+
+// one block (1024 threads = 16 waves).  Phase 1: a wave per window counts its notes (ballot/popcount);
+// phase 2: block scan of the lengths; phase 3: a wave per window writes the compacted row indices.
+__global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char* __restrict__ mask, int B, int N,
+                                                            int* __restrict__ lengths, int* __restrict__ offsets,
+                                                            int* __restrict__ rowmap, int* __restrict__ seg,
+                                                            unsigned char* __restrict__ mtxt) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = wave; b < B; b += 16) {
+        int cnt = 0;
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int n = n0 + lane;
+            const bool m = (n < N) && mask[(size_t)b * N + n] != 0;
+            cnt += __popcll(__ballot(m));
+        }
+        if (lane == 0) { lengths[b] = cnt; mtxt[b] = cnt > 0 ? 1 : 0; }
+    }
+    if (tid == 0) carry = 0;
+    __syncthreads();   // lengths[] written by this block are visible after the barrier (same CU)
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + tid;
+        const int len = (b < B) ? lengths[b] : 0;
+        sh[tid] = len;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = (tid >= off) ? sh[tid - off] : 0;
+            __syncthreads();
+            sh[tid] += v;
+            __syncthreads();
+        }
+        if (b < B) offsets[b] = carry + sh[tid] - len;
+        __syncthreads();
+        if (tid == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) offsets[B] = carry;
+    __syncthreads();
+    for (int b = wave; b < B; b += 16) {
+        int pos = offsets[b];
+        for (int n0 = 0; n0 < N; n0 += 64) {
+            const int n = n0 + lane;
+            const bool m = (n < N) && mask[(size_t)b * N + n] != 0;
+            const unsigned long long bal = __ballot(m);
+            if (m) {
+                const int k = pos + __popcll(bal & ((1ull << lane) - 1ull));
+                rowmap[k] = b * N + n;
+                seg[k] = b;
+            }
+            pos += __popcll(bal);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src,
+                                                           const int* __restrict__ rowmap, const int* __restrict__ total,
+                                                           int width, float* __restrict__ dst, int ld_dst) {
+    const int r = blockIdx.x;
+    if (r >= *total) return;
+    const float* s = src + (size_t)rowmap[r] * ld_src;
+    float* d = dst + (size_t)r * ld_dst;
+    for (int i = threadIdx.x; i < width; i += blockDim.x) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------- Time2Vec
+// reference: fusions/TTF_T2V_XAttn.py:7-24  (applied to RAW tau, :136)
+__global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
+                                                            const int* __restrict__ total, int d_tau,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ dst, int ld_dst) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int r = (int)(idx / d_tau), j = (int)(idx % d_tau);
+    if (r >= *total) return;
+    const float t = tau_pad[rowmap[r]];
+    dst[(size_t)r * ld_dst + j] = (j == 0) ? fmaf(w0[0], t, b0[0]) : sinf(fmaf(w[j - 1], t, b[j - 1]));
+}
+
+// partial[slab][0][j] = sum_r g*tau, partial[slab][1][j] = sum_r g,  g = dfeat[r,j] * (j ? cos(w tau + b) : 1)
+__global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
+                                                            const int* __restrict__ total, int d_tau,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ dfeat, int ld,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx, slab = blockIdx.y;
+    const int M = *total, rps = (M + kSlabs - 1) / kSlabs;
+    const int r0 = slab * rps, r1 = min(M, r0 + rps);
+    float aw = 0.f, ab = 0.f;
+    if (j < d_tau) {
+        const float wj = j ? w[j - 1] : 0.f, bj = j ? b[j - 1] : 0.f;
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const float t = tau_pad[rowmap[r]];
+            float g = dfeat[(size_t)r * ld + j];
+            if (j) g *= cosf(fmaf(wj, t, bj));
+            aw = fmaf(g, t, aw);
+            ab += g;
+        }
+    }
+    red[0][ty][tx] = aw;
+    red[1][ty][tx] = ab;
+    __syncthreads();
+    if (ty == 0 && j < d_tau) {
+        partial[((size_t)slab * 2 + 0) * d_tau + j] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        partial[((size_t)slab * 2 + 1) * d_tau + j] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    }
+}
+
+__global__ __launch_bounds__(256) void time2vec_bwd_final_kernel(const float* __restrict__ partial, int d_tau,
+                                                                  float* dw0, float* db0, float* dw, float* db) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d_tau) return;
+    float aw = 0.f, ab = 0.f;
+    for (int s = 0; s < kSlabs; ++s) {
+        aw += partial[((size_t)s * 2 + 0) * d_tau + j];
+        ab += partial[((size_t)s * 2 + 1) * d_tau + j];
+    }
+    if (j == 0) { dw0[0] = aw; db0[0] = ab; }
+    else { dw[j - 1] = aw; db[j - 1] = ab; }
+}
+
+// ------------------------------------------------------------------------------------------- column sums
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                              int M, const int* __restrict__ dyn, int N, int ld,
+                                                              float* __restrict__ partial) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, slab = blockIdx.y;
+    if (dyn) M = *dyn;
+    const int rps = (M + kSlabs - 1) / kSlabs;
+    const int r0 = slab * rps, r1 = min(M, r0 + rps);
+    float a = 0.f;
+    if (n < N) {
+        if (Y) for (int r = r0 + ty; r < r1; r += 4) a = fmaf(X[(size_t)r * ld + n], Y[(size_t)r * ld + n], a);
+        else   for (int r = r0 + ty; r < r1; r += 4) a += X[(size_t)r * ld + n];
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && n < N) partial[(size_t)slab * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out,
+                                                            int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int s = 0; s < kSlabs; ++s) a += partial[(size_t)s * N + n];
+    out[n] = accumulate ? out[n] + a : a;
+}
+
+// ------------------------------------------------------------------------------------------- LayerNorm
+// one wave per row; two-pass statistics like torch (mean, then mean of squared deviations), eps inside sqrt.
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int rows, int d,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, float* __restrict__ xhat, float* __restrict__ rstd,
+                                                             float* __restrict__ z, DropCfg drop, uint64_t site) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + (size_t)row * d;
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += p[i];
+    const float mu = wave_sum(s) / (float)d;
+    float v = 0.f;
+    for (int i = lane; i < d; i += 64) { const float c = p[i] - mu; v = fmaf(c, c, v); }
+    const float rs = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    if (lane == 0 && rstd) rstd[row] = rs;
+    for (int i = lane; i < d; i += 64) {
+        const float h = (p[i] - mu) * rs;
+        if (xhat) xhat[(size_t)row * d + i] = h;
+        const float y = fmaf(h, gamma[i], beta[i]);
+        z[(size_t)row * d + i] = y * dropout_scale(drop.seed, site, (uint64_t)row * d + i, drop.p, drop.inv_keep);
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dz_dy, int rows, int d,
+                                                             const float* __restrict__ gamma, const float* __restrict__ xhat,
+                                                             const float* __restrict__ rstd, float* __restrict__ dx,
+                                                             DropCfg drop, uint64_t site) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* g = dz_dy + (size_t)row * d;
+    const float* h = xhat + (size_t)row * d;
+    float c1 = 0.f, c2 = 0.f;
+    for (int i = lane; i < d; i += 64) {
+        const float dy = g[i] * dropout_scale(drop.seed, site, (uint64_t)row * d + i, drop.p, drop.inv_keep);
+        g[i] = dy;
+        const float t = dy * gamma[i];
+        c1 += t;
+        c2 = fmaf(t, h[i], c2);
+    }
+    c1 = wave_sum(c1) / (float)d;
+    c2 = wave_sum(c2) / (float)d;
+    const float rs = rstd[row];
+    for (int i = lane; i < d; i += 64) dx[(size_t)row * d + i] = rs * (g[i] * gamma[i] - c1 - h[i] * c2);
+}
+
+// ------------------------------------------------------------------------------------------- tiny vector ops
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                                      const float* __restrict__ b, int rows, int cols,
+                                                      float* __restrict__ y, float* __restrict__ ys, float scale) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a = 0.f;
+    for (int j = lane; j < cols; j += 64) a = fmaf(W[(size_t)row * ldw + j], x[j], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+        if (b) a += b[row];
+        if (y) y[row] = a;
+        if (ys) ys[row] = a * scale;
+    }
+}
+
+__global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                                        int rows, int cols, float* __restrict__ y, int accumulate) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float a = 0.f;
+    for (int i = 0; i < rows; ++i) a = fmaf(W[(size_t)i * ldw + j], x[i], a);
+    y[j] = accumulate ? y[j] + a : a;
+}
+
+__global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
+                                                     int cols, float* __restrict__ out, int ld) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)rows * cols) return;
+    const int i = (int)(idx / cols), j = (int)(idx % cols);
+    out[(size_t)i * ld + j] = a[i] * b[j];
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src, float alpha, float* __restrict__ dst, int n,
+                                                    int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = alpha * src[i];
+    dst[i] = accumulate ? dst[i] + v : v;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ dst, float v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint64_t seed, uint64_t site, size_t n, float p,
+                                                            unsigned char* __restrict__ out) {
+    const float inv = 1.f / (1.f - p);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = dropout_scale(seed, site, i, p, inv) != 0.f ? 1 : 0;
+}
+
+}  // namespace
+
+int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int* nan_flag, hipStream_t s) {
+    if (rows <= 0) return IMMTSF_OK;
+    const int vec = ((d_m % 4) == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(note_mask_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, V, rows, d_m, mask, nan_flag, vec);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
+                        unsigned char* mtxt, hipStream_t s) {
+    hipLaunchKernelGGL(ragged_index_kernel, dim3(1), dim3(1024), 0, s, mask, B, N, lengths, offsets, rowmap, seg, mtxt);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const int* total, int max_rows, int width,
+                       float* dst, int ld_dst, hipStream_t s) {
+    if (max_rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(max_rows), dim3(256), 0, s, src, ld_src, rowmap, total, width, dst, ld_dst);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                        const float* w0, const float* b0, const float* w, const float* b, float* dst, int ld_dst,
+                        hipStream_t s) {
+    if (max_rows <= 0) return IMMTSF_OK;
+    const long n = (long)max_rows * d_tau;
+    hipLaunchKernelGGL(time2vec_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tau_pad, rowmap, total, d_tau,
+                       w0, b0, w, b, dst, ld_dst);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                        const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
+                        float* db, float* scratch, hipStream_t s) {
+    (void)max_rows;
+    hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), kSlabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
+                       dfeat, ld, scratch);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 256)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
+                  float* scratch, hipStream_t s) {
+    if (N <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, dyn, N, ld, scratch);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s) {
+    if (rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
+                       drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
+                         float* dx, DropCfg drop, uint64_t site, hipStream_t s) {
+    if (rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop,
+                       site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
+                  float scale, hipStream_t s) {
+    hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, W, ldw, x, b, rows, cols, y, ys, scale);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols, float* y, int accumulate,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, W, ldw, x, rows, cols, y, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_outer(const float* a, const float* b, int rows, int cols, float* out, int ld, hipStream_t s) {
+    const long n = (long)rows * cols;
+    hipLaunchKernelGGL(outer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, rows, cols, out, ld);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_axpy(const float* src, float alpha, float* dst, int n, int accumulate, hipStream_t s) {
+    if (n <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, alpha, dst, n, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_fill(float* dst, float v, size_t n, hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, dst, v, n);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_dropout_mask(uint64_t seed, uint64_t site, size_t n, float p, unsigned char* out, hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, s, seed, site, n, p, out);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}

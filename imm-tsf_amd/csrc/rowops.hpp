@@ -1,0 +1,43 @@
+// Row-wise / ragged-index kernels of the fusion path (HBM-bound pieces).  All launchers are asynchronous
+// on `stream`, own no memory and return 0 or an error code.
+#pragma once
+#include "common.hpp"
+
+// a2: note_mask[b,n] = (sum_e |V[b,n,e]|) > 0 ; nan_flag (device int, may be null) |= 1 if any NaN in V
+int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int* nan_flag, hipStream_t s);
+// lengths/offsets/rowmap/seg/M_txt from the mask.  offsets has B+1 entries, offsets[B] = total notes.
+int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
+                        unsigned char* mtxt, hipStream_t s);
+// gather packed rows: dst[r, 0:d_m] = src[rowmap[r], 0:d_m]   (r < *total)
+int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const int* total, int max_rows, int width,
+                       float* dst, int ld_dst, hipStream_t s);
+// a3 Time2Vec on packed rows: dst[r, j] = j==0 ? w0*tau+b0 : sin(w[j-1]*tau+b[j-1]),  tau = tau_pad[rowmap[r]]
+int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                        const float* w0, const float* b0, const float* w, const float* b, float* dst, int ld_dst,
+                        hipStream_t s);
+// Time2Vec parameter gradients from dFeat (packed rows, ld): scratch >= 2*32*d_tau floats
+int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                        const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
+                        float* db, float* scratch, hipStream_t s);
+// out[n] = sum_{m < M} X[m,n] * (Y ? Y[m,n] : 1)   (M may come from *dyn).  scratch >= 32*N floats.
+int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
+                  float* scratch, hipStream_t s);
+// LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
+int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s);
+// in: dz (grad wrt z).  out: dy written IN PLACE over dz (dy = dz*dropscale), dx.
+int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
+                         float* dx, DropCfg drop, uint64_t site, hipStream_t s);
+// y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale
+int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
+                  float scale, hipStream_t s);
+// y[j] = sum_i W[i,j] x[i]   (transposed mat-vec)
+int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols, float* y, int accumulate,
+                    hipStream_t s);
+// out[i,j] = a[i]*b[j]
+int launch_outer(const float* a, const float* b, int rows, int cols, float* out, int ld, hipStream_t s);
+// dst = alpha*src (n elements)  /  dst += alpha*src
+int launch_axpy(const float* src, float alpha, float* dst, int n, int accumulate, hipStream_t s);
+int launch_fill(float* dst, float v, size_t n, hipStream_t s);
+// keep-mask export for tests: out[i] = 1 if element i of `site` is kept
+int launch_dropout_mask(uint64_t seed, uint64_t site, size_t n, float p, unsigned char* out, hipStream_t s);

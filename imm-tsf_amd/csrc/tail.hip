@@ -1,0 +1,200 @@
+// Fused tails of the MMF blocks + loss + optimizer.  All HBM/latency-bound: one thread or one wave per row.
+#include "tail.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, int rows, int d,
+                                                         const unsigned char* __restrict__ flag, int div) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows || flag[row / div]) return;
+    for (int i = lane; i < d; i += 64) x[(size_t)row * d + i] = 0.f;
+}
+
+// reference: fusions/MMF_XAttn_Add.py:93-102
+__global__ __launch_bounds__(256) void ln_blend_fwd_kernel(const float* __restrict__ delta, const float* __restrict__ Y,
+                                                            const unsigned char* __restrict__ mtxt, int BT, int T, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float kappa, float* __restrict__ xhat, float* __restrict__ rstd,
+                                                            float* __restrict__ Yout, DropCfg drop, uint64_t site) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= BT) return;
+    const bool live = mtxt[row / T] != 0;
+    const float* x = delta + (size_t)row * C;
+    float mu = 0.f;
+    for (int c = 0; c < C; ++c) mu += x[c];
+    mu /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) { const float t = x[c] - mu; var = fmaf(t, t, var); }
+    const float rs = 1.0f / sqrtf(var / (float)C + 1e-5f);
+    rstd[row] = rs;
+    const float inv = 1.f / (1.f + kappa);
+    for (int c = 0; c < C; ++c) {
+        const float h = (x[c] - mu) * rs;
+        xhat[(size_t)row * C + c] = h;
+        float y = fmaf(h, gamma[c], beta[c]) * dropout_scale(drop.seed, site, (uint64_t)row * C + c, drop.p, drop.inv_keep);
+        if (!live) y = 0.f;
+        Yout[(size_t)row * C + c] = (Y[(size_t)row * C + c] + kappa * y) * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_blend_bwd_kernel(const float* __restrict__ dYout, const unsigned char* __restrict__ mtxt,
+                                                            int BT, int T, int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                            float kappa, float* __restrict__ dY, float* __restrict__ dn,
+                                                            float* __restrict__ ddelta, DropCfg drop, uint64_t site) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= BT) return;
+    const float live = mtxt[row / T] ? 1.f : 0.f;
+    const float inv = 1.f / (1.f + kappa), kk = kappa * inv * live;
+    const float* g = dYout + (size_t)row * C;
+    const float* h = xhat + (size_t)row * C;
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float gn = kk * g[c] * dropout_scale(drop.seed, site, (uint64_t)row * C + c, drop.p, drop.inv_keep);
+        dn[(size_t)row * C + c] = gn;
+        dY[(size_t)row * C + c] = g[c] * inv;
+        const float t = gn * gamma[c];
+        c1 += t;
+        c2 = fmaf(t, h[c], c2);
+    }
+    c1 /= (float)C;
+    c2 /= (float)C;
+    const float rs = rstd[row];
+    for (int c = 0; c < C; ++c)
+        ddelta[(size_t)row * C + c] = rs * (dn[(size_t)row * C + c] * gamma[c] - c1 - h[c] * c2);
+}
+
+// ---- masked MSE (lib/evaluation.py:17-62, func="MSE", reduce="mean") -------------------------------------
+__global__ __launch_bounds__(1024) void mse_sums_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
+                                                         const float* __restrict__ mask, int rows, int C,
+                                                         float* __restrict__ err_sum, float* __restrict__ cnt) {
+    __shared__ float re[16][64], rc[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
+    float e = 0.f, n = 0.f;
+    if (c < C)
+        for (int r = ty; r < rows; r += 16) {
+            const size_t i = (size_t)r * C + c;
+            const float dlt = truth[i] - pred[i], m = mask[i];
+            e = fmaf(dlt * dlt, m, e);
+            n += m;
+        }
+    re[ty][tx] = e;
+    rc[ty][tx] = n;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float se = 0.f, sn = 0.f;
+        for (int k = 0; k < 16; ++k) { se += re[k][tx]; sn += rc[k][tx]; }
+        err_sum[c] = se;
+        cnt[c] = sn;
+    }
+}
+
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
+                                                          const float* __restrict__ mask, int rows, int C,
+                                                          const float* __restrict__ err_sum, const float* __restrict__ cnt,
+                                                          float* __restrict__ loss, float* __restrict__ dpred, float grad_scale) {
+    // every block recomputes the (tiny) per-variable reduction; block 0 writes the loss
+    float tot = 0.f, navail = 0.f;
+    for (int c = 0; c < C; ++c) {
+        tot += err_sum[c] / (cnt[c] + 1e-8f);
+        navail += (cnt[c] != 0.f) ? 1.f : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) loss[0] = tot / navail;
+    if (!dpred) return;
+    const size_t n = (size_t)rows * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        dpred[i] = grad_scale * 2.f * (pred[i] - truth[i]) * mask[i] / ((cnt[c] + 1e-8f) * navail);
+    }
+}
+
+// ---- clip_grad_norm_ + Adam (main.py:1024,1098-1101) on one flat buffer -------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a = fmaf(g[i], g[i], a);
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2s, float max_norm,
+                                                    const float* __restrict__ part, int nparts) {
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
+    const float total = sqrtf(block_sum(a, red));
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(1.f, max_norm / (total + 1e-6f));
+    const float step = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float gi = g[i] * coef;
+        if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
+        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+}  // namespace
+
+int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s) {
+    if (rows <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, flag, div);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ln_blend_fwd(const float* delta, const float* Y, const unsigned char* mtxt, int BT, int T, int C,
+                        const float* gamma, const float* beta, float kappa, float* xhat, float* rstd, float* Yout,
+                        DropCfg drop, uint64_t site, hipStream_t s) {
+    if (BT <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(ln_blend_fwd_kernel, dim3(cdiv(BT, 256)), dim3(256), 0, s, delta, Y, mtxt, BT, T, C, gamma, beta, kappa,
+                       xhat, rstd, Yout, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, int T, int C, const float* gamma,
+                        const float* xhat, const float* rstd, float kappa, float* dY, float* dn, float* ddelta,
+                        DropCfg drop, uint64_t site, hipStream_t s) {
+    if (BT <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(ln_blend_bwd_kernel, dim3(cdiv(BT, 256)), dim3(256), 0, s, dYout, mtxt, BT, T, C, gamma, xhat, rstd, kappa,
+                       dY, dn, ddelta, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
+                    float* cnt, hipStream_t s) {
+    hipLaunchKernelGGL(mse_sums_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, truth, pred, mask, rows, C, err_sum, cnt);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_mse_finish(const float* truth, const float* pred, const float* mask, int rows, int C, const float* err_sum,
+                      const float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s) {
+    const size_t n = (size_t)rows * C;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : ((n + 255) / 256 ? (n + 255) / 256 : 1));
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(blocks), dim3(256), 0, s, truth, pred, mask, rows, C, err_sum, cnt, loss, dpred,
+                       grad_scale);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                float wd, int step, float max_norm, float* norm_scratch, hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const int nparts = 1024;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, norm_scratch);
+    IMMTSF_LAUNCH_CHECK();
+    const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
+                       norm_scratch, nparts);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}

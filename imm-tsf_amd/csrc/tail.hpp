@@ -1,0 +1,23 @@
+// Small fused epilogue kernels of the MMF blocks, the masked-MSE loss and the fused clip+Adam update.
+#pragma once
+#include "common.hpp"
+
+// zero the rows m whose window flag[m / div] == 0
+int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s);
+
+// MMF_XAttn_Add tail (fusions/MMF_XAttn_Add.py:93-102): LN over C, dropout, zero no-text windows, kappa blend
+int launch_ln_blend_fwd(const float* delta, const float* Y, const unsigned char* mtxt, int BT, int T, int C,
+                        const float* gamma, const float* beta, float kappa, float* xhat, float* rstd, float* Yout,
+                        DropCfg drop, uint64_t site, hipStream_t s);
+// dYout -> dY (= dYout/(1+kappa)), dn (grad wrt LN output, for the gamma/beta column sums), ddelta
+int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, int T, int C, const float* gamma,
+                        const float* xhat, const float* rstd, float kappa, float* dY, float* dn, float* ddelta,
+                        DropCfg drop, uint64_t site, hipStream_t s);
+
+int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
+                    float* cnt, hipStream_t s);
+int launch_mse_finish(const float* truth, const float* pred, const float* mask, int rows, int C, const float* err_sum,
+                      const float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
+
+int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                float wd, int step, float max_norm, float* norm_scratch, hipStream_t s);

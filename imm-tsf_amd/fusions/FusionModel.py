@@ -1,0 +1,66 @@
+"""FusionModel on MI355X: TTF (text-timestamp fusion) followed by MMF (modality fusion).
+
+Same registry, constructor (reads the same `args.*` attributes) and forward signature as the reference
+(fusions/FusionModel.py:14-113); `args.TTF_module` / `args.MMF_module` may be a registry string or a class.
+The NaN guards of the reference (three `torch.isnan(x).any()` host syncs per step, :103-112) are honoured
+according to `immtsf.config.nan_check`: "sync" (default, reference behaviour), "deferred" (no sync; call
+`check_nan()`), or "off".
+"""
+import torch
+import torch.nn as nn
+
+from fusions.MMF_GR_Add import MMF_GR_Add
+from fusions.MMF_XAttn_Add import MMF_XAttn_Add
+from fusions.TTF_RecAvg import TTF_RecAvg
+from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+from immtsf import config
+
+_TTF_CLASSES = {"TTF_RecAvg": TTF_RecAvg, "TTF_T2V_XAttn": TTF_T2V_XAttn}
+_MMF_CLASSES = {"MMF_GR_Add": MMF_GR_Add, "MMF_XAttn_Add": MMF_XAttn_Add}
+
+
+def _resolve(ref, table):
+    return table.get(ref, ref) if isinstance(ref, str) else ref
+
+
+class FusionModel(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        ttf_cls = _resolve(args.TTF_module, _TTF_CLASSES)
+        mmf_cls = _resolve(args.MMF_module, _MMF_CLASSES)
+        print(f"Using TTF module: {args.TTF_module}")
+        print(f"Using MMF module: {args.MMF_module}")
+        common = dict(max_length=args.max_length, device=args.device, use_text_embeddings=args.use_text_embeddings,
+                      dropout=args.dropout, d_txt=args.d_txt)
+        if ttf_cls is TTF_RecAvg:
+            self.ttf = ttf_cls(args.llm_model_fusion, args.llm_layers_fusion, recency_sigma=args.recency_sigma, **common)
+        else:
+            self.ttf = ttf_cls(args.llm_model_fusion, args.llm_layers_fusion, n_heads_fusion=args.n_heads_fusion, **common)
+        d_txt = self.ttf.d_txt
+        if mmf_cls is MMF_GR_Add:
+            self.mmf = mmf_cls(d_txt=d_txt, C=args.C, hidden_dim=args.C, dropout=args.dropout)
+        else:
+            self.mmf = mmf_cls(d_txt=d_txt, C=args.C, d_attn=d_txt, n_heads_fusion=args.n_heads_fusion,
+                               dropout=args.dropout, kappa=args.kappa)
+        precision = getattr(args, "immtsf_precision", None)
+        if precision is not None:
+            self.ttf.precision = precision
+            self.mmf.precision = precision
+
+    def forward(self, notes_input, tau, t_hat, Y_ts):
+        sync = config.nan_check == "sync"
+        if sync and torch.isnan(Y_ts).any():
+            print(f"Y_ts: {Y_ts}")
+            raise ValueError("Y_ts contains NaN values.")
+        E_txt, M_txt = self.ttf(notes_input, tau, t_hat)
+        if sync and torch.isnan(E_txt).any():
+            raise ValueError("E_txt contains NaN values.")
+        Y_out = self.mmf(Y_ts, E_txt, M_txt)
+        if sync and torch.isnan(Y_out).any():
+            raise ValueError("Y_out contains NaN values.")
+        return Y_out
+
+    def check_nan(self):
+        """deferred-mode check of the note-embedding NaN flag set by the kernels."""
+        if hasattr(self.ttf, "check_nan"):
+            self.ttf.check_nan()

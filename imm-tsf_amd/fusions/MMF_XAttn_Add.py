@@ -1,0 +1,51 @@
+"""MMF_XAttn_Add on MI355X: cross-attention from the time-series forecast (queries) to the time-aligned text
+embedding (keys/values), residual head, LayerNorm(C), dropout and a fixed-kappa convex blend.
+
+Interface/state_dict follow the reference (fusions/MMF_XAttn_Add.py:9-103); computed by
+`immtsf_mmf_xattn_add_forward/backward` (grouped MFMA GEMMs for the projections, batched MFMA GEMMs for QK^T and
+A*V over (window, head), fused softmax+dropout rows, fused LN/blend tail).  Quirk kept: a window without text
+returns Y_ts/(1+kappa).
+"""
+import torch
+import torch.nn as nn
+
+from fusions._common import f32, resolve_precision
+from immtsf import config
+from immtsf.ops import MMFXAttnAddFn
+
+
+class MMF_XAttn_Add(nn.Module):
+    def __init__(self, d_txt: int, C: int, d_attn: int, n_heads_fusion: int = 1, dropout: float = 0.1,
+                 kappa: float = 1.0):
+        super().__init__()
+        if d_attn != d_txt:
+            # FusionModel always passes d_attn=d_txt (fusions/FusionModel.py:88-91); the HIP block assumes it
+            raise NotImplementedError("MMF_XAttn_Add on MI355X requires d_attn == d_txt")
+        self.C = C
+        self.d_attn = d_attn
+        self.kappa = kappa
+        self.n_heads = n_heads_fusion
+        self.p_drop = float(dropout)
+        self.proj_q = nn.Linear(C, d_attn, bias=False)
+        self.proj_k = nn.Linear(d_txt, d_attn, bias=False)
+        self.proj_v = nn.Linear(d_txt, d_attn, bias=False)
+        self.attn = nn.MultiheadAttention(embed_dim=d_attn, num_heads=n_heads_fusion, dropout=dropout, batch_first=True)
+        self.residual_head = nn.Linear(d_attn, C)
+        self.layer_norm = nn.LayerNorm(C)
+        self.dropout = nn.Dropout(dropout)
+        self.precision = None
+        self.last_seed = 0
+
+    def _params(self):
+        return (self.proj_q.weight, self.proj_k.weight, self.proj_v.weight, self.attn.in_proj_weight,
+                self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.residual_head.weight,
+                self.residual_head.bias, self.layer_norm.weight, self.layer_norm.bias)
+
+    def forward(self, Y_ts, E_txt, M_txt):
+        """Y_ts (B,T,C), E_txt (B,T,d_txt), M_txt (B,1)|(B,) bool -> (B,T,C)"""
+        B = Y_ts.shape[0]
+        M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
+        training = self.training and self.p_drop > 0.0
+        self.last_seed = config.next_seed() if training else 0
+        return MMFXAttnAddFn.apply(f32(Y_ts), f32(E_txt), M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
+                                   resolve_precision(self), self.last_seed, *self._params())

@@ -1,0 +1,149 @@
+"""ctypes binding of libimmtsf_hip.so (the C ABI declared in include/immtsf.h).
+
+There is deliberately no CPU fallback: if the shared library is missing or a call fails, the product modules
+raise.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
+
+ABI_VERSION = 1
+
+
+class ImmtsfError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "IMMTSF_EINVAL (bad dimension / null pointer)", -2: "IMMTSF_EWORKSPACE (workspace too small)",
+        -3: "IMMTSF_EUNSUPPORTED (shape outside kernel limits)"}
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_u8p = C.c_void_p
+c_i32p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class FusionCfg(C.Structure):
+    _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("d_m", C.c_int32),
+                ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
+                ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, C.c_void_p) for f in fields], "FIELDS": tuple(fields)})
+
+
+T2VParams = _ptr_struct("T2VParams", [
+    "Q_param", "input_proj_w", "input_proj_b", "t2v_lin_w", "t2v_lin_b", "t2v_per_w", "t2v_per_b", "kv_w", "kv_b",
+    "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "ln_w", "ln_b", "proj_out_w", "proj_out_b"])
+RecAvgParams = _ptr_struct("RecAvgParams", [
+    "log_recency_sigma", "input_proj_w", "input_proj_b", "ln_w", "ln_b", "proj_w", "proj_b"])
+XAddParams = _ptr_struct("XAddParams", [
+    "proj_q_w", "proj_k_w", "proj_v_w", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "res_w", "res_b",
+    "ln_w", "ln_b"])
+GRParams = _ptr_struct("GRParams", [
+    "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
+
+# name -> (restype, argtypes).  Must list EVERY function include/immtsf.h declares (tests/test_abi.py checks).
+_P = C.POINTER
+_PROTOS = {
+    "immtsf_abi_version": (C.c_int, []),
+    "immtsf_ragged_index": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_u8p, c_i32p, c_i32p, c_i32p, c_i32p,
+                                      c_u8p, c_i32p, c_stream]),
+    "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_ttf_t2v_xattn_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_ttf_t2v_xattn_forward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, c_u8p, C.c_void_p,
+                                               C.c_size_t, c_i32p, c_stream]),
+    "immtsf_ttf_t2v_xattn_backward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p, C.c_size_t, _P(T2VParams), c_stream]),
+    "immtsf_ttf_recavg_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_ttf_recavg_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_ttf_recavg_forward": (C.c_int, [_P(FusionCfg), _P(RecAvgParams), c_f32p, c_f32p, c_f32p, c_f32p, c_u8p,
+                                            C.c_void_p, C.c_size_t, c_i32p, c_stream]),
+    "immtsf_ttf_recavg_backward": (C.c_int, [_P(FusionCfg), _P(RecAvgParams), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                             C.c_size_t, C.c_void_p, C.c_size_t, _P(RecAvgParams), c_stream]),
+    "immtsf_mmf_xattn_add_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_add_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_add_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
+                                               C.c_size_t, c_stream]),
+    "immtsf_mmf_xattn_add_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
+                                                c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
+                                                c_stream]),
+    "immtsf_mmf_gr_add_workspace_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_gr_add_scratch_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_gr_add_forward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,
+                                            C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_gr_add_backward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,
+                                             c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             _P(GRParams), c_stream]),
+    "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "immtsf_masked_mse_finish": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                           C.c_float, c_stream]),
+    "immtsf_gemm": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p,
+                              C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_stream]),
+    "immtsf_gemm_batched": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int64, C.c_int64, c_f32p, C.c_int32,
+                                      C.c_int64, C.c_int64, c_f32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, c_stream]),
+    "immtsf_softmax_rows_forward": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_u8p,
+                                              C.c_float, C.c_uint64, C.c_uint64, c_stream]),
+    "immtsf_softmax_rows_backward": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                               C.c_uint64, C.c_uint64, c_stream]),
+    "immtsf_layernorm_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p,
+                                           c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_stream]),
+    "immtsf_layernorm_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                            c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_stream]),
+    "immtsf_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_u8p, c_stream]),
+    "immtsf_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                   C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and attach prototypes.  Raises ImmtsfError when it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImmtsfError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C imm-tsf_amd/csrc`.  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImmtsfError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.immtsf_abi_version() != ABI_VERSION:
+        raise ImmtsfError("libimmtsf_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_PROTOS)
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ImmtsfError(f"{what}: {_ERR.get(rc, rc)}")
+    raise ImmtsfError(f"{what}: hipError_t {rc}")
+
+
+def ptr(t):
+    """device pointer of a tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

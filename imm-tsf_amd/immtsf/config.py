@@ -1,0 +1,52 @@
+"""Process-wide knobs of the HIP path."""
+import os
+import threading
+
+_PRECISIONS = {"fp32": 0, "bf16": 1}
+
+# "fp32": exact-fp32 MFMA (parity with the reference's fp32 CPU path); "bf16": bf16 MFMA operands, fp32 accumulate.
+precision = os.environ.get("IMMTSF_PRECISION", "fp32")
+
+# How the reference's `torch.isnan(x).any()` guards (fusions/FusionModel.py:103-112, TTF_*.py:116/75) are honoured:
+#   "sync"     -- like the reference: check (and host-sync) inside forward, raise ValueError immediately
+#   "deferred" -- OR a device flag in-kernel, no host sync; `FusionModel.check_nan()` raises later
+#   "off"      -- no checks
+nan_check = os.environ.get("IMMTSF_NAN_CHECK", "sync")
+
+
+def precision_code(p=None) -> int:
+    p = precision if p is None else p
+    if p not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {p!r}")
+    return _PRECISIONS[p]
+
+
+# dropout seeds: (base seed, call counter) -> one 64-bit Philox key per forward call
+_lock = threading.Lock()
+_base_seed = None
+_counter = 0
+
+
+def manual_seed(seed: int):
+    global _base_seed, _counter
+    with _lock:
+        _base_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        _counter = 0
+
+
+def next_seed() -> int:
+    """A fresh Philox key; deterministic after torch.manual_seed()/immtsf.config.manual_seed()."""
+    global _base_seed, _counter
+    with _lock:
+        if _base_seed is None:
+            import torch
+            _base_seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+        _counter += 1
+        x = (_base_seed + 0x9E3779B97F4A7C15 * _counter) & 0xFFFFFFFFFFFFFFFF
+        # splitmix64 finaliser
+        x ^= x >> 30
+        x = (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 27
+        x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 31
+        return x

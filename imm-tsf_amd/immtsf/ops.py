@@ -1,0 +1,255 @@
+"""torch.autograd.Function wrappers around the block-level C ABI (include/immtsf.h).
+
+Every Function enqueues on torch's current HIP stream; the forward workspace (which holds the saved-for-backward
+state) is a torch uint8 tensor kept on `ctx`; gradients are written by the HIP backward into one flat buffer
+and returned as views.  Inputs must be fp32, contiguous and on the GPU: there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, config
+from ._lib import FusionCfg, GRParams, RecAvgParams, T2VParams, XAddParams, check, ptr, stream_ptr
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ImmtsfError("immtsf ops need tensors on the GPU (HIP); there is no CPU fallback")
+        if t.dtype not in (torch.float32, torch.uint8, torch.bool, torch.int32):
+            raise _lib.ImmtsfError(f"unsupported dtype {t.dtype}; the HIP path takes fp32 tensors")
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _struct(cls, tensors):
+    s = cls()
+    for name, t in zip(cls.FIELDS, tensors):
+        setattr(s, name, None if t is None else t.data_ptr())
+    return s
+
+
+def _grad_buffers(params):
+    """one flat allocation, a view per (non-None) parameter"""
+    n = sum(p.numel() for p in params if p is not None)
+    dev = next(p.device for p in params if p is not None)
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    views, off = [], 0
+    for p in params:
+        if p is None:
+            views.append(None)
+        else:
+            views.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+    return views
+
+
+def _bytes(n, dev):
+    return torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev)
+
+
+def make_cfg(B, N, T, Cc, d_m, d, H, precision, training, p_drop, kappa, seed):
+    return FusionCfg(B, N, T, Cc, d_m, d, H, precision, 1 if training else 0, float(p_drop), float(kappa),
+                     int(seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+# ------------------------------------------------------------------------------------------------ TTF_T2V_XAttn
+class TTFT2VXAttnFn(torch.autograd.Function):
+    """(notes (B,N,d_m), tau (B,N)) -> (E_txt (B,T,d), M_txt uint8 (B)).  params in immtsf_t2v_params order."""
+
+    @staticmethod
+    def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, *params):
+        lib = _lib.load()
+        notes, tau = _c(notes), _c(tau)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(notes, tau, *params)
+        B, N, d_m = notes.shape
+        d = params[0].numel()
+        cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed)
+        ws = _bytes(lib.immtsf_ttf_t2v_xattn_workspace_bytes(C.byref(cfg)), notes.device)
+        E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
+        M = torch.empty(B, dtype=torch.uint8, device=notes.device)
+        ps = _struct(T2VParams, params)
+        check(lib.immtsf_ttf_t2v_xattn_forward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(E), ptr(M), ptr(ws),
+                                               ws.numel(), ptr(nan_flag), stream_ptr()), "ttf_t2v_xattn_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
+        ctx.none_mask = [p is None for p in params]
+        ctx.mark_non_differentiable(M)
+        return E, M
+
+    @staticmethod
+    def backward(ctx, dE, _dM):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        notes, tau = saved[0], saved[1]
+        params = [None if isnone else p for p, isnone in zip(saved[2:], ctx.none_mask)]
+        dE = dE.contiguous()
+        grads = _grad_buffers(params)
+        sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
+        ps, gs = _struct(T2VParams, params), _struct(T2VParams, grads)
+        check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
+                                                ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+              "ttf_t2v_xattn_backward")
+        return (None,) * 9 + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ TTF_RecAvg
+class TTFRecAvgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, notes, tau, t_hat, p_drop, training, precision, seed, nan_flag, *params):
+        lib = _lib.load()
+        notes, tau, t_hat = _c(notes), _c(tau), _c(t_hat)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(notes, tau, t_hat, *params)
+        B, N, d_m = notes.shape
+        T = t_hat.shape[1]
+        d = params[3].numel()      # ln_w
+        cfg = make_cfg(B, N, T, 0, d_m, d, 1, precision, training, p_drop, 0.0, seed)
+        ws = _bytes(lib.immtsf_ttf_recavg_workspace_bytes(C.byref(cfg)), notes.device)
+        E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
+        M = torch.empty(B, dtype=torch.uint8, device=notes.device)
+        ps = _struct(RecAvgParams, params)
+        check(lib.immtsf_ttf_recavg_forward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(t_hat), ptr(E), ptr(M),
+                                            ptr(ws), ws.numel(), ptr(nan_flag), stream_ptr()), "ttf_recavg_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(notes, tau, t_hat, *[p if p is not None else notes.new_empty(0) for p in params])
+        ctx.none_mask = [p is None for p in params]
+        ctx.mark_non_differentiable(M)
+        return E, M
+
+    @staticmethod
+    def backward(ctx, dE, _dM):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        notes, tau, t_hat = saved[:3]
+        params = [None if isnone else p for p, isnone in zip(saved[3:], ctx.none_mask)]
+        dE = dE.contiguous()
+        grads = _grad_buffers(params)
+        sc = _bytes(lib.immtsf_ttf_recavg_scratch_bytes(C.byref(ctx.cfg)), notes.device)
+        ps, gs = _struct(RecAvgParams, params), _struct(RecAvgParams, grads)
+        check(lib.immtsf_ttf_recavg_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(t_hat), ptr(dE),
+                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+              "ttf_recavg_backward")
+        return (None,) * 8 + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ MMF_XAttn_Add
+class MMFXAttnAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, E, M_u8, H, kappa, p_drop, training, precision, seed, *params):
+        lib = _lib.load()
+        Y, E, M_u8 = _c(Y), _c(E), _c(M_u8)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(Y, E, M_u8, *params)
+        B, T, Cc = Y.shape
+        d = E.shape[2]
+        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed)
+        ws = _bytes(lib.immtsf_mmf_xattn_add_workspace_bytes(C.byref(cfg)), Y.device)
+        out = torch.empty_like(Y)
+        ps = _struct(XAddParams, params)
+        check(lib.immtsf_mmf_xattn_add_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(out), ptr(ws),
+                                               ws.numel(), stream_ptr()), "mmf_xattn_add_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.save_for_backward(Y, E, M_u8, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        Y, E, M_u8, *params = ctx.saved_tensors
+        dout = dout.contiguous()
+        grads = _grad_buffers(params)
+        dY, dE = torch.empty_like(Y), torch.empty_like(E)
+        sc = _bytes(lib.immtsf_mmf_xattn_add_scratch_bytes(C.byref(ctx.cfg)), Y.device)
+        ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
+        check(lib.immtsf_mmf_xattn_add_backward(C.byref(ctx.cfg), C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(dout), ptr(dY),
+                                                ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
+                                                stream_ptr()), "mmf_xattn_add_backward")
+        return (dY, dE, None, None, None, None, None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ MMF_GR_Add
+class MMFGRAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, E, M_u8, hidden, p_drop, training, precision, seed, *params):
+        lib = _lib.load()
+        Y, E, M_u8 = _c(Y), _c(E), _c(M_u8)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(Y, E, M_u8, *params)
+        B, T, Cc = Y.shape
+        d = E.shape[2]
+        cfg = make_cfg(B, 0, T, Cc, 0, d, 1, precision, training, p_drop, 0.0, seed)
+        ws = _bytes(lib.immtsf_mmf_gr_add_workspace_bytes(C.byref(cfg), hidden), Y.device)
+        out = torch.empty_like(Y)
+        ps = _struct(GRParams, params)
+        check(lib.immtsf_mmf_gr_add_forward(C.byref(cfg), hidden, C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(out), ptr(ws),
+                                            ws.numel(), stream_ptr()), "mmf_gr_add_forward")
+        ctx.cfg, ctx.ws, ctx.hidden = cfg, ws, hidden
+        ctx.save_for_backward(Y, E, M_u8, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        Y, E, M_u8, *params = ctx.saved_tensors
+        dout = dout.contiguous()
+        grads = _grad_buffers(params)
+        dY, dE = torch.empty_like(Y), torch.empty_like(E)
+        sc = _bytes(lib.immtsf_mmf_gr_add_scratch_bytes(C.byref(ctx.cfg), ctx.hidden), Y.device)
+        ps, gs = _struct(GRParams, params), _struct(GRParams, grads)
+        check(lib.immtsf_mmf_gr_add_backward(C.byref(ctx.cfg), ctx.hidden, C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(dout),
+                                             ptr(dY), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
+                                             stream_ptr()), "mmf_gr_add_backward")
+        return (dY, dE, None, None, None, None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class MaskedMSEFn(torch.autograd.Function):
+    """compute_error(truth, pred, mask, "MSE", "mean") (lib/evaluation.py:17-62) with a fused backward.
+
+    With `group` (a torch.distributed process group) the per-variable (sum, count) pair is all-reduced before the
+    divide, so every rank sees the loss of the global batch and sum-reduced gradients equal the single-process ones."""
+
+    @staticmethod
+    def forward(ctx, pred, truth, mask, group):
+        lib = _lib.load()
+        pred, truth, mask = _c(pred), _c(truth), _c(mask)
+        _need_gpu(pred, truth, mask)
+        Cc = pred.shape[-1]
+        rows = pred.numel() // Cc
+        sums = torch.empty(2, Cc, dtype=torch.float32, device=pred.device)
+        check(lib.immtsf_masked_mse_sums(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]),
+                                         stream_ptr()), "masked_mse_sums")
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group)
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        check(lib.immtsf_masked_mse_finish(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]), ptr(loss),
+                                           ptr(dpred), 1.0, stream_ptr()), "masked_mse_finish")
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dpred,) = ctx.saved_tensors
+        return dpred * dloss, None, None, None
+
+
+def masked_mse(pred, truth, mask, group=None):
+    return MaskedMSEFn.apply(pred, truth, mask, group)
+
+
+def dropout_keep_mask(seed: int, site: int, n: int, p: float, device) -> torch.Tensor:
+    """uint8 keep-mask of `n` consecutive elements of a dropout site (for tests / mask export)."""
+    lib = _lib.load()
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    check(lib.immtsf_dropout_mask(int(seed) & 0xFFFFFFFFFFFFFFFF, site, n, float(p), ptr(out), stream_ptr()), "dropout_mask")
+    return out

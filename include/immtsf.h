@@ -1,0 +1,200 @@
+/* immtsf.h -- C ABI of libimmtsf_hip.so: the MI355X (gfx950) implementation of IMM-TSF's multimodal-fusion
+ * forward/backward hot path.
+ *
+ * The reference (blacksnail789521/IMM-TSF) is pure Python/PyTorch and has NO native interface; the seams this
+ * library sits behind are the nn.Module methods listed next to each entry point (file:line into the reference).
+ * The Python host side in imm-tsf_amd/ (fusions/, layers/, models/, lib/) keeps those classes' constructor and
+ * forward signatures and state_dict keys and calls the functions below through ctypes (imm-tsf_amd/immtsf/_lib.py);
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless said otherwise; fp32 row-major tensors.
+ *  - the caller owns every buffer, including workspaces (size them with the *_workspace_bytes functions) and the
+ *    saved-for-backward state, which lives inside the forward workspace: keep it alive until backward has run.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*, NULL = default stream); nothing
+ *    synchronises, allocates or frees, so the calls can be captured into a hipGraph.
+ *  - return value: 0 = ok; <0 = IMMTSF_E*; >0 = hipError_t of a failed launch.  Nothing throws.
+ *  - no global state; re-entrant; thread-safe as long as two calls do not share output/workspace buffers.
+ *  - precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32; parity mode), 1 = bf16 MFMA operands with fp32
+ *    accumulation (v_mfma_f32_16x16x32_bf16; tensors in memory stay fp32).
+ */
+#ifndef IMMTSF_H
+#define IMMTSF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMMTSF_ABI_VERSION 1
+
+#define IMMTSF_OK 0
+#define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
+#define IMMTSF_EWORKSPACE (-2)   /* workspace too small */
+#define IMMTSF_EUNSUPPORTED (-3) /* shape outside what the kernels implement (documented per call) */
+
+typedef void* immtsf_stream_t;
+
+int immtsf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Shape/config of one fusion call.  B windows, N padded notes per window, T padded forecast steps, C channels,
+ * d_m = LLM embedding width, d = d_txt, H = n_heads_fusion.  Dropout is active iff training != 0 && p_drop > 0;
+ * masks come from Philox4x32-10 keyed by (seed, site, element index) so backward regenerates them.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct immtsf_fusion_cfg {
+    int32_t B, N, T, C, d_m, d, H;
+    int32_t precision;
+    int32_t training;
+    float p_drop;
+    float kappa;
+    uint64_t seed;
+} immtsf_fusion_cfg;
+
+/* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)
+ * fusions/TTF_T2V_XAttn.py:107,124,146 ; fusions/TTF_RecAvg.py:69,110.
+ * notes (B,N,d_m) -> note_mask u8 (B,N), lengths i32 (B), offsets i32 (B+1), rowmap i32 (B*N; first offsets[B]
+ * valid, value b*N+n), seg i32 (B*N; window of each packed row), m_txt u8 (B).  nan_flag (device int32, may be
+ * NULL) is OR-ed with 1 if any input element is NaN (the reference raises ValueError, TTF_*.py:116 / :75). */
+int immtsf_ragged_index(const float* notes, int32_t B, int32_t N, int32_t d_m, uint8_t* note_mask, int32_t* lengths,
+                        int32_t* offsets, int32_t* rowmap, int32_t* seg, uint8_t* m_txt, int32_t* nan_flag,
+                        immtsf_stream_t stream);
+
+/* ---- a3/a4/a8: TTF_T2V_XAttn.forward  (fusions/TTF_T2V_XAttn.py:93-184; Time2Vec :7-24; MHA semantics of
+ * torch.nn.MultiheadAttention at :79-84,161-166).  Parameter pointers use the module's state_dict order. */
+typedef struct immtsf_t2v_params {
+    float* Q_param;                     /* (d)            Q_param (1,1,d) */
+    float *input_proj_w, *input_proj_b; /* (d,d_m),(d)    NULL,NULL when d_txt=None (then d == d_m) */
+    float *t2v_lin_w, *t2v_lin_b;       /* (1),(1)        time2vec.linear */
+    float *t2v_per_w, *t2v_per_b;       /* (d/2-1),(d/2-1) time2vec.periodic */
+    float *kv_w, *kv_b;                 /* (d, d+d/2),(d) KV_proj */
+    float *attn_in_w, *attn_in_b;       /* (3d,d),(3d)    attn.in_proj_* */
+    float *attn_out_w, *attn_out_b;     /* (d,d),(d)      attn.out_proj.* */
+    float *ln_w, *ln_b;                 /* (d),(d)        layer_norm */
+    float *proj_out_w, *proj_out_b;     /* (d,d),(d)      proj_out */
+} immtsf_t2v_params;
+
+size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg);
+size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg);
+/* notes (B,N,d_m), tau (B,N)  ->  E_txt (B,T,d), M_txt u8 (B).  t_hat's values do not enter this block (only T). */
+int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
+                                 const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,
+                                 int32_t* nan_flag, immtsf_stream_t stream);
+/* dE_txt (B,T,d) -> every parameter gradient (overwritten, not accumulated).  `workspace` is the forward's. */
+int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
+                                  const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
+                                  void* scratch, size_t scratch_bytes, const immtsf_t2v_params* grads,
+                                  immtsf_stream_t stream);
+
+/* ---- a5: TTF_RecAvg.forward (fusions/TTF_RecAvg.py:54-112) */
+typedef struct immtsf_recavg_params {
+    float* log_recency_sigma;           /* ()  */
+    float *input_proj_w, *input_proj_b; /* (d,d_m),(d) or NULL */
+    float *ln_w, *ln_b;                 /* (d) */
+    float *proj_w, *proj_b;             /* (d,d),(d) */
+} immtsf_recavg_params;
+
+size_t immtsf_ttf_recavg_workspace_bytes(const immtsf_fusion_cfg* cfg);
+size_t immtsf_ttf_recavg_scratch_bytes(const immtsf_fusion_cfg* cfg);
+/* t_hat (B,T) (the caller broadcasts a (T,) vector) */
+int immtsf_ttf_recavg_forward(const immtsf_fusion_cfg* cfg, const immtsf_recavg_params* p, const float* notes,
+                              const float* tau, const float* t_hat, float* E_txt, uint8_t* M_txt, void* workspace,
+                              size_t workspace_bytes, int32_t* nan_flag, immtsf_stream_t stream);
+int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg_params* p, const float* notes,
+                               const float* tau, const float* t_hat, const float* dE_txt, void* workspace,
+                               size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                               const immtsf_recavg_params* grads, immtsf_stream_t stream);
+
+/* ---- a6/a8: MMF_XAttn_Add.forward (fusions/MMF_XAttn_Add.py:56-103) */
+typedef struct immtsf_xadd_params {
+    float *proj_q_w, *proj_k_w, *proj_v_w; /* (d,C),(d,d),(d,d) no bias */
+    float *attn_in_w, *attn_in_b;          /* (3d,d),(3d) */
+    float *attn_out_w, *attn_out_b;        /* (d,d),(d) */
+    float *res_w, *res_b;                  /* (C,d),(C)  residual_head */
+    float *ln_w, *ln_b;                    /* (C) */
+} immtsf_xadd_params;
+
+size_t immtsf_mmf_xattn_add_workspace_bytes(const immtsf_fusion_cfg* cfg);
+size_t immtsf_mmf_xattn_add_scratch_bytes(const immtsf_fusion_cfg* cfg);
+/* Y_ts (B,T,C), E_txt (B,T,d), M_txt u8 (B) -> Y_out (B,T,C) */
+int immtsf_mmf_xattn_add_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
+                                 const float* E_txt, const uint8_t* M_txt, float* Y_out, void* workspace,
+                                 size_t workspace_bytes, immtsf_stream_t stream);
+/* dY_out -> dY_ts (B,T,C), dE_txt (B,T,d), parameter grads (all overwritten) */
+int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
+                                  const float* E_txt, const uint8_t* M_txt, const float* dY_out, float* dY_ts,
+                                  float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
+                                  size_t scratch_bytes, const immtsf_xadd_params* grads, immtsf_stream_t stream);
+
+/* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
+typedef struct immtsf_gr_params {
+    float *w_ih, *w_hh, *b_ih, *b_hh; /* (3Hd, C+d),(3Hd,Hd),(3Hd),(3Hd)  gru.*_l0 */
+    float *res_w, *res_b;             /* (C,Hd),(C) */
+    float *gate_w, *gate_b;           /* (C, C+d),(C) */
+    float *ln_w, *ln_b;               /* (C) */
+} immtsf_gr_params;
+
+size_t immtsf_mmf_gr_add_workspace_bytes(const immtsf_fusion_cfg* cfg, int32_t hidden);
+size_t immtsf_mmf_gr_add_scratch_bytes(const immtsf_fusion_cfg* cfg, int32_t hidden);
+int immtsf_mmf_gr_add_forward(const immtsf_fusion_cfg* cfg, int32_t hidden, const immtsf_gr_params* p,
+                              const float* Y_ts, const float* E_txt, const uint8_t* M_txt, float* Y_out, void* workspace,
+                              size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t hidden, const immtsf_gr_params* p,
+                               const float* Y_ts, const float* E_txt, const uint8_t* M_txt, const float* dY_out,
+                               float* dY_ts, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
+                               size_t scratch_bytes, const immtsf_gr_params* grads, immtsf_stream_t stream);
+
+/* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
+ * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data
+ * parallelism the caller all-reduces them before calling _finish).  loss: device scalar.  dpred: (rows, C). */
+int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
+                           float* err_sum, float* cnt, immtsf_stream_t stream);
+int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
+                             const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
+                             immtsf_stream_t stream);
+
+/* ---- building blocks exported for tests and for the layers/ mirror ------------------------------------------- */
+/* C = act(alpha * op(A) op(B)^T + bias); layout 0 = NT (A:(M,K), B:(N,K)), 1 = NN (B:(K,N)), 2 = TN (A:(K,M), B:(K,N)) */
+int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
+                int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
+                int32_t act, immtsf_stream_t stream);
+/* batched over (outer, inner) with element strides, used by FullAttention (layers/SelfAttention_Family.py:50-77) */
+int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
+                        const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,
+                        int64_t sC_i, int32_t n_outer, int32_t n_inner, int32_t M, int32_t N, int32_t K, float alpha,
+                        immtsf_stream_t stream);
+/* softmax over the last dim of (B,H,L,S) scores in place (-> P), A = dropout(P) (A may alias sc when p == 0) */
+int immtsf_softmax_rows_forward(float* sc, float* A, int32_t B, int32_t H, int32_t L, int32_t S, const uint8_t* live,
+                                float p_drop, uint64_t seed, uint64_t site, immtsf_stream_t stream);
+int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H, int32_t L, int32_t S, float p_drop,
+                                 uint64_t seed, uint64_t site, immtsf_stream_t stream);
+/* LayerNorm(+dropout) rows: xhat,rstd may be NULL in forward when no backward follows */
+int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
+                             float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,
+                             immtsf_stream_t stream);
+int immtsf_layernorm_backward(float* dz_dy, int32_t rows, int32_t d, const float* gamma, const float* xhat,
+                              const float* rstd, float* dx, float* dgamma, float* dbeta, float* scratch,
+                              float p_drop, uint64_t seed, uint64_t site, immtsf_stream_t stream);
+/* keep-mask (1 = kept) of `n` consecutive elements of a dropout site: lets tests feed the oracle identical masks */
+int immtsf_dropout_mask(uint64_t seed, uint64_t site, uint64_t n, float p_drop, uint8_t* out, immtsf_stream_t stream);
+/* dropout site ids used by the fusion blocks */
+#define IMMTSF_SITE_T2V_ATTN 1  /* index ((b*T+t)*H+h)*N+n */
+#define IMMTSF_SITE_T2V_OUT 2   /* index (b*T+t)*d+e */
+#define IMMTSF_SITE_REC_OUT 3   /* index (b*T+t)*d+e */
+#define IMMTSF_SITE_XADD_ATTN 4 /* index ((b*H+h)*T+l)*T+s */
+#define IMMTSF_SITE_XADD_OUT 5  /* index (b*T+t)*C+c */
+#define IMMTSF_SITE_GR_OUT 6    /* index (b*T+t)*C+c */
+#define IMMTSF_SITE_LAYER_BASE 16
+
+/* fused clip-by-global-norm + Adam on a flat parameter buffer (main.py:1098-1101: clip_grad_norm_(1.0) then
+ * Adam(lr, weight_decay) with torch's L2-style weight decay).  norm_scratch: >= 1024 floats. */
+int immtsf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                     float* norm_scratch, immtsf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMMTSF_H */

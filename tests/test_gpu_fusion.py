@@ -1,0 +1,352 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP fusion path, called through the drop-in modules
+(i.e. through the C ABI), against (a) the committed golden vectors of the real reference and (b) the CPU oracle
+on seeded synthetic batches up to the benchmark shape.
+
+Tolerances (relative to the tensor's max magnitude, floor 1e-3 for gradients that are ~0):
+  fp32 mode  outputs 1e-4 (north_star), gradients 2e-4 (reduction order differs: MFMA k-chains vs. MKL)
+  bf16 mode  outputs/gradients 4e-2 (operands rounded to 8 significant bits, fp32 accumulation)
+Index/bool tensors: bit-exact.
+"""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b, floor=1e-3):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def _check(errs, tol):
+    bad = {k: v for k, v in errs.items() if not (v <= tol)}
+    assert not bad, f"tolerance {tol}: " + ", ".join(f"{k}={v:.2e}" for k, v in sorted(bad.items(), key=lambda kv: -kv[1])[:12])
+
+
+def _args(ttf, mmf, llm, d_txt, H, C, dropout=0.0, kappa=0.5, sigma=1.3):
+    return types.SimpleNamespace(TTF_module=ttf, MMF_module=mmf, llm_model_fusion=llm, llm_layers_fusion=6,
+                                 max_length=1024, device="cuda", use_text_embeddings=True, recency_sigma=sigma,
+                                 n_heads_fusion=H, dropout=dropout, d_txt=d_txt, C=C, kappa=kappa)
+
+
+def _setup_toys():
+    from fusions.load_llm import register_d_model
+    register_d_model("TOY16", 16)
+    register_d_model("TOY48", 48)
+
+
+def _split_name(path):
+    name = os.path.basename(path)[len("fusion_"):-4]
+    ttf = "TTF_T2V_XAttn" if name.startswith("TTF_T2V_XAttn") else "TTF_RecAvg"
+    rest = name[len(ttf) + 1:]
+    mmf = "MMF_XAttn_Add" if rest.startswith("MMF_XAttn_Add") else "MMF_GR_Add"
+    case = rest[len(mmf) + 1:]
+    return ttf, mmf, case
+
+
+# ------------------------------------------------------------------------------------------ golden vectors
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "fusion_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[7:-4])
+def test_fusion_model_vs_reference_golden(path):
+    dev = _dev()
+    _setup_toys()
+    from fusions.FusionModel import FusionModel
+    from immtsf import config
+    config.precision = "fp32"
+    z = np.load(path)
+    ttf, mmf, case = _split_name(path)
+    llm = "TOY48" if int(z["d_m"]) == 48 else "TOY16"
+    d_txt = None if int(z["d_txt"]) < 0 else int(z["d_txt"])
+    C = z["Y_ts"].shape[2]
+    m = FusionModel(_args(ttf, mmf, llm, d_txt, int(z["H"]), C, kappa=float(z["kappa"]))).to(dev)
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    m.load_state_dict(sd, strict=True)
+    notes, tau, t_hat = [torch.from_numpy(z[k]).to(dev) for k in ("notes", "tau", "t_hat")]
+    Y = torch.from_numpy(z["Y_ts"]).to(dev).requires_grad_(True)
+    m.eval()
+    with torch.no_grad():
+        out = m(notes, tau, t_hat, Y)
+    errs = {"out_eval": _relerr(out, torch.from_numpy(z["out_eval.0"]))}
+    if case == "zeronote":
+        m.train()
+        out = m(notes, tau, t_hat, Y)
+        out.sum().backward()     # the reference yields NaN grads here; ours must be finite
+        for k, p in m.named_parameters():
+            assert torch.isfinite(p.grad).all(), k
+        _check(errs, 1e-4)
+        return
+    m.train()
+    out = m(notes, tau, t_hat, Y)
+    errs["out_train"] = _relerr(out, torch.from_numpy(z["out_train.0"]))
+    (out * torch.from_numpy(z["upstream"]).to(dev)).sum().backward()
+    gerrs = {"gY": _relerr(Y.grad, torch.from_numpy(z["gin.3"]))}
+    for k, p in m.named_parameters():
+        gerrs["g." + k] = _relerr(p.grad, torch.from_numpy(z["g." + k]))
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+
+
+@pytest.mark.parametrize("case", ["tiny_h1", "tiny_h2", "noproj_h2", "mid_h4"])
+def test_ragged_index_bit_exact(case):
+    dev = _dev()
+    from immtsf import _lib
+    lib = _lib.load()
+    z = np.load(os.path.join(GOLDEN, f"ttf_t2v_{case}.npz"))
+    notes = torch.from_numpy(z["notes"]).to(dev)
+    B, N, d_m = notes.shape
+    mask = torch.zeros(B * N, dtype=torch.uint8, device=dev)
+    lengths = torch.zeros(B, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    rowmap = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+    seg = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+    mtxt = torch.zeros(B, dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.immtsf_ragged_index(_lib.ptr(notes), B, N, d_m, _lib.ptr(mask), _lib.ptr(lengths), _lib.ptr(offsets),
+                                       _lib.ptr(rowmap), _lib.ptr(seg), _lib.ptr(mtxt), _lib.ptr(flag), _lib.stream_ptr()),
+               "ragged_index")
+    torch.cuda.synchronize()
+    assert np.array_equal(mask.cpu().numpy().reshape(B, N).astype(bool), z["note_mask"])
+    assert np.array_equal(offsets.cpu().numpy(), z["offsets"])
+    assert np.array_equal(lengths.cpu().numpy(), z["lengths"])
+    tot = int(z["offsets"][-1])
+    exp = [b * N + n for b in range(B) for n in range(N) if z["note_mask"][b, n]]
+    assert np.array_equal(rowmap.cpu().numpy()[:tot], np.asarray(exp, np.int32))
+    assert np.array_equal(seg.cpu().numpy()[:tot], np.asarray([e // N for e in exp], np.int32))
+    assert int(flag.item()) == 0
+
+
+# ------------------------------------------------------------------------------------------ oracle, synthetic
+def _synthetic(seed, B, N, T, C, d_m, dev, min_notes=1, scatter_masks=False):
+    g = torch.Generator().manual_seed(seed)
+    notes = torch.randn(B, N, d_m, generator=g)
+    lengths = torch.randint(min_notes, N + 1, (B,), generator=g)
+    tau = torch.zeros(B, N)
+    for b in range(B):
+        L = int(lengths[b])
+        notes[b, L:] = 0
+        tau[b, :L] = torch.sort(torch.rand(L, generator=g) * 24.0).values
+    if scatter_masks:     # masked notes need not be a suffix: knock out one interior note of window 0
+        notes[0, 0] = 0
+    t_hat = torch.sort(torch.rand(B, T, generator=g), dim=1).values
+    Y = torch.randn(B, T, C, generator=g)
+    up = torch.randn(B, T, C, generator=g)
+    return notes, tau, t_hat, Y, up
+
+
+def _run_pair(ttf, mmf, B, N, T, C, d_m, d_txt, H, precision, seed=0, llm="GPT2", min_notes=1, scatter=False):
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    from oracle import fusion_ref as R
+    register_d_model("SYN", d_m)
+    config.precision = precision
+    torch.manual_seed(seed)
+    m = FusionModel(_args(ttf, mmf, "SYN", d_txt, H, C)).to(dev)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "layer_norm" in k:
+                p.uniform_(0.5, 1.5) if k.endswith("weight") else p.uniform_(-0.3, 0.3)
+    notes, tau, t_hat, Y, up = _synthetic(seed + 1, B, N, T, C, d_m, dev, min_notes, scatter)
+    m.train()
+    Yg = Y.to(dev).requires_grad_(True)
+    out = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Yg)
+    (out * up.to(dev)).sum().backward()
+    # oracle on the CPU with the same weights
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Yc = Y.clone().requires_grad_(True)
+    ref = R.fusion_forward(ttf, mmf, p, notes, tau, t_hat, Yc, H=H, kappa=0.5, expand_T=False)
+    (ref * up).sum().backward()
+    errs = {"out": _relerr(out, ref)}
+    gerrs = {"gY": _relerr(Yg.grad, Yc.grad)}
+    for k, prm in m.named_parameters():
+        g = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        gerrs["g." + k] = _relerr(prm.grad, g)
+    config.precision = "fp32"
+    return errs, gerrs
+
+
+PAIRS = [("TTF_T2V_XAttn", "MMF_XAttn_Add"), ("TTF_T2V_XAttn", "MMF_GR_Add"), ("TTF_RecAvg", "MMF_XAttn_Add"),
+         ("TTF_RecAvg", "MMF_GR_Add")]
+
+
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
+def test_pairs_fp32_small_odd_shapes(ttf, mmf):
+    # dims that are not multiples of any tile: exercises every edge path of the GEMM and the row kernels
+    errs, gerrs = _run_pair(ttf, mmf, B=5, N=7, T=9, C=5, d_m=52, d_txt=36, H=3, precision="fp32", scatter=True)
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+
+
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
+def test_pairs_fp32_benchmark_shape(ttf, mmf):
+    # BASELINE config 2 shape: B=64, N<=32, T=32, C=8, d_m=d=768, H=1
+    errs, gerrs = _run_pair(ttf, mmf, B=64, N=32, T=32, C=8, d_m=768, d_txt=768, H=1, precision="fp32")
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+
+
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
+def test_pairs_bf16_benchmark_shape(ttf, mmf):
+    errs, gerrs = _run_pair(ttf, mmf, B=64, N=32, T=32, C=8, d_m=768, d_txt=768, H=1, precision="bf16")
+    _check(errs, 4e-2)
+    _check(gerrs, 4e-2)
+
+
+def test_llama_dims_multihead_fp32():
+    # config 3/5 flavour: d_m=4096 -> d=768, H=4, fewer windows so the CPU oracle stays quick
+    errs, gerrs = _run_pair("TTF_T2V_XAttn", "MMF_XAttn_Add", B=6, N=40, T=16, C=6, d_m=4096, d_txt=768, H=4,
+                            precision="fp32")
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+
+
+# ------------------------------------------------------------------------------------------ dropout
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
+def test_dropout_with_exported_masks(ttf, mmf):
+    """train mode, p=0.25: export the Philox keep-masks the kernels used and feed them to the oracle."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config, ops
+    from oracle import fusion_ref as R
+    B, N, T, C, d_m, d, H, pd = 6, 9, 7, 4, 40, 32, 2, 0.25
+    register_d_model("SYN", d_m)
+    config.precision = "fp32"
+    config.manual_seed(1234)
+    torch.manual_seed(3)
+    a = _args(ttf, mmf, "SYN", d, H, C, dropout=pd)
+    m = FusionModel(a).to(dev)
+    notes, tau, t_hat, Y, up = _synthetic(5, B, N, T, C, d_m, dev)
+    m.train()
+    Yg = Y.to(dev).requires_grad_(True)
+    out = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Yg)
+    (out * up.to(dev)).sum().backward()
+
+    def keep(seed, site, shape):
+        n = int(np.prod(shape))
+        return ops.dropout_keep_mask(seed, site, n, pd, dev).cpu().view(*shape).float()
+
+    drop = {"ttf": {}, "mmf": {}}
+    if ttf == "TTF_T2V_XAttn":
+        drop["ttf"]["attn"] = keep(m.ttf.last_seed, 1, (B, T, H, N))
+        drop["ttf"]["out"] = keep(m.ttf.last_seed, 2, (B, T, d))
+    else:
+        drop["ttf"]["out"] = keep(m.ttf.last_seed, 3, (B, T, d))
+    if mmf == "MMF_XAttn_Add":
+        drop["mmf"]["attn"] = keep(m.mmf.last_seed, 4, (B, H, T, T))
+        drop["mmf"]["out"] = keep(m.mmf.last_seed, 5, (B, T, C))
+    else:
+        drop["mmf"]["out"] = keep(m.mmf.last_seed, 6, (B, T, C))
+    for grp in drop.values():           # the masks must look like Bernoulli(1-p)
+        for k, v in grp.items():
+            assert abs(float(v.mean()) - (1 - pd)) < 0.08, (k, float(v.mean()))
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Yc = Y.clone().requires_grad_(True)
+    ref = R.fusion_forward(ttf, mmf, p, notes, tau, t_hat, Yc, H=H, kappa=0.5, drop=drop, p_drop=pd, expand_T=True)
+    (ref * up).sum().backward()
+    errs = {"out": _relerr(out, ref)}
+    gerrs = {"gY": _relerr(Yg.grad, Yc.grad)}
+    for k, prm in m.named_parameters():
+        g = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        gerrs["g." + k] = _relerr(prm.grad, g)
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+    # eval mode ignores dropout and is deterministic
+    m.eval()
+    with torch.no_grad():
+        o1 = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))
+        o2 = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))
+    assert torch.equal(o1, o2)
+    ref_eval = R.fusion_forward(ttf, mmf, {k: v.detach() for k, v in p.items()}, notes, tau, t_hat, Y, H=H, kappa=0.5)
+    _check({"eval": _relerr(o1, ref_eval)}, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ error behaviour, properties
+def test_nan_and_shape_errors():
+    dev = _dev()
+    _setup_toys()
+    from fusions.FusionModel import FusionModel
+    from immtsf import config
+    config.nan_check = "sync"
+    m = FusionModel(_args("TTF_T2V_XAttn", "MMF_XAttn_Add", "TOY16", 8, 2, 3)).to(dev)
+    notes, tau, t_hat, Y, _ = _synthetic(0, 4, 5, 6, 3, 16, dev)
+    bad = notes.clone()
+    bad[1, 0, 3] = float("nan")
+    with pytest.raises(ValueError, match="NaN"):
+        m(bad.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))
+    Yb = Y.clone()
+    Yb[0, 0, 0] = float("nan")
+    with pytest.raises(ValueError, match="Y_ts contains NaN"):
+        m(notes.to(dev), tau.to(dev), t_hat.to(dev), Yb.to(dev))
+    with pytest.raises(ValueError, match="Expected t_hat shape"):
+        m(notes.to(dev), tau.to(dev), t_hat[:2].to(dev), Y.to(dev))
+    out1 = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))       # still usable afterwards
+    out2 = m(notes.to(dev), tau.to(dev), t_hat[0].to(dev), Y.to(dev))    # 1-D t_hat broadcasts
+    assert out1.shape == out2.shape == (4, 6, 3)
+    config.nan_check = "deferred"
+    m(bad.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))                 # no raise in forward ...
+    with pytest.raises(ValueError, match="NaN"):
+        m.check_nan()                                                      # ... but the flag was set
+    config.nan_check = "sync"
+    with pytest.raises(Exception):
+        m(notes, tau, t_hat, Y)      # CPU tensors: no silent fallback
+
+
+def test_padding_invariance_and_window_independence():
+    """size-independent properties at the full benchmark shape: (1) extra zero padding of the note axis changes
+    nothing (the ragged pack ignores it); (2) a window's output does not depend on the other windows."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    register_d_model("SYN", 768)
+    config.precision = "fp32"
+    torch.manual_seed(0)
+    m = FusionModel(_args("TTF_T2V_XAttn", "MMF_XAttn_Add", "SYN", 768, 1, 8)).to(dev).eval()
+    notes, tau, t_hat, Y, _ = _synthetic(1, 64, 32, 32, 8, 768, dev)
+    notes, tau, t_hat, Y = notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev)
+    with torch.no_grad():
+        base = m(notes, tau, t_hat, Y)
+        padded = m(torch.cat([notes, torch.zeros(64, 9, 768, device=dev)], 1),
+                   torch.cat([tau, torch.zeros(64, 9, device=dev)], 1), t_hat, Y)
+        half = m(notes[:32], tau[:32], t_hat[:32], Y[:32])
+    assert torch.equal(base, padded)
+    assert _relerr(half, base[:32]) < 1e-6
+
+
+def test_masked_mse_matches_oracle():
+    dev = _dev()
+    from immtsf.ops import masked_mse
+    from oracle import fusion_ref as R
+    z = np.load(os.path.join(GOLDEN, "loss_mse.npz"))
+    pred = torch.from_numpy(z["pred"]).to(dev).requires_grad_(True)
+    loss = masked_mse(pred, torch.from_numpy(z["truth"]).to(dev), torch.from_numpy(z["mask"]).to(dev))
+    (loss * 3.0).backward()
+    assert _relerr(loss, torch.from_numpy(z["loss"])) < 1e-6
+    assert _relerr(pred.grad, 3.0 * torch.from_numpy(z["dpred"])) < 1e-5
+    g = torch.Generator().manual_seed(0)
+    t, p = torch.randn(64, 32, 8, generator=g), torch.randn(64, 32, 8, generator=g)
+    mk = (torch.rand(64, 32, 8, generator=g) < 0.7).float()
+    pc = p.clone().requires_grad_(True)
+    R.masked_mse(t, pc, mk).backward()
+    pg = p.to(dev).requires_grad_(True)
+    l2 = masked_mse(pg, t.to(dev), mk.to(dev))
+    l2.backward()
+    assert _relerr(l2, R.masked_mse(t, p, mk)) < 1e-5
+    assert _relerr(pg.grad, pc.grad) < 1e-5

@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- forecast windows/sec of the multimodal-fusion training step on MI355X.
+
+Workload (BASELINE.json configs[1]): tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT-2 sized note embeddings
+(d_m = d_txt = 768, H = 1), a ragged batch of 64 windows (one per entity) PER GPU, bf16 MFMA operands with fp32
+accumulation, train mode with the reference's default dropout 0.1.  One step = backbone forecast -> fusion ->
+masked-MSE loss -> backward -> (N>1: RCCL gradient all-reduce) -> clip_grad_norm(1.0) + Adam.  Inputs are
+synthetic, generated once and resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+For N>1 the driver launches one rank per GPU with torch.distributed.run; entities shard across ranks (weak
+scaling: 64 windows per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "imm-tsf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# ---- workload constants ---------------------------------------------------------------
+B_PER_GPU, C, M_PATCH, L_PATCH, N_MAX, T_MAX, D_M, D_TXT, H = 64, 8, 2, 32, 32, 32, 768, 768, 1
+P_DROP, KAPPA = 0.1, 0.5
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def model_args(device):
+    return types.SimpleNamespace(
+        device=device, hid_dim=32, C=C, npatch=M_PATCH, nlayer=1, te_dim=10, n_heads=1, tf_layer=1, node_dim=10, hop=1,
+        outlayer="Linear", TTF_module="TTF_T2V_XAttn", MMF_module="MMF_XAttn_Add", llm_model_fusion="GPT2",
+        llm_layers_fusion=6, max_length=1024, use_text_embeddings=True, recency_sigma=1.0, n_heads_fusion=H,
+        dropout=P_DROP, d_txt=D_TXT, kappa=KAPPA, batch_size=B_PER_GPU)
+
+
+def synth_batch(seed, B):
+    """cfg2-shaped ragged batch: all fp32, CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    # history, patched (B, M, L, C): ragged observation counts, 30 % empty patches
+    cnt = rng.integers(1, L_PATCH + 1, size=(B, M_PATCH, C))
+    cnt[rng.random((B, M_PATCH, C)) < 0.3] = 0
+    l_idx = np.arange(L_PATCH).reshape(1, 1, L_PATCH, 1)
+    obs_mask = torch.from_numpy((l_idx < cnt[:, :, None, :]).astype(np.float32))
+    X = torch.randn(B, M_PATCH, L_PATCH, C, generator=g) * obs_mask
+    tt = torch.sort(torch.rand(B, M_PATCH, L_PATCH, C, generator=g), dim=2).values * obs_mask
+    # notes
+    n_notes = torch.from_numpy(rng.integers(1, N_MAX + 1, size=B))
+    notes = torch.randn(B, N_MAX, D_M, generator=g)
+    tau = torch.sort(torch.rand(B, N_MAX, generator=g) * 24.0, dim=1).values
+    keep = (torch.arange(N_MAX).view(1, -1) < n_notes.view(-1, 1))
+    notes = notes * keep.unsqueeze(-1)
+    tau = tau * keep
+    # horizon
+    t_len = torch.from_numpy(rng.integers(8, T_MAX + 1, size=B))
+    tvalid = (torch.arange(T_MAX).view(1, -1) < t_len.view(-1, 1))
+    t_hat = torch.sort(24.0 + 24.0 * torch.rand(B, T_MAX, generator=g), dim=1).values / 48.0 * tvalid
+    truth = torch.randn(B, T_MAX, C, generator=g)
+    tmask = (torch.rand(B, T_MAX, C, generator=g) < 0.7).float()
+    tmask[:, 0, :] = torch.maximum(tmask[:, 0, :], (tmask.sum(1) == 0).float())     # >= 1 observation per row
+    tmask = tmask * tvalid.unsqueeze(-1)
+    return dict(observed_data=X, observed_tp=tt, observed_mask=obs_mask, tp_to_predict=t_hat, notes_embeddings=notes,
+                tau=tau, data_to_predict=truth * tmask, mask_predicted_data=tmask), int(n_notes.sum())
+
+
+def fusion_flops_per_window(sum_n, B):
+    """SURVEY 8d algorithmic FLOPs (fwd+bwd = 3x fwd for the GEMM terms), per window, cfg2."""
+    d, dt, T, nbar = D_TXT, D_TXT // 2, T_MAX, sum_n / B
+    f_t2v = sum_n * (2 * D_M * d + 2 * (d + dt) * d + 4 * d * d) + B * T * (4 * nbar * d + 2 * d * d) + B * T * 2 * d * d
+    f_xadd = B * T * (12 * d * d + 4 * T * d + 4 * C * d)
+    return 3.0 * (f_t2v + f_xadd) / B
+
+
+def cpu_baseline(batch, steps=5, warmup=1):
+    """The oracle (CPU restatement, op-for-op incl. the T-fold K/V expansion) timed on this box's host cores: same
+    batch, same region (backbone fwd -> fusion fwd -> masked MSE -> backward -> clip -> Adam), dropout masks drawn on
+    the CPU each step like torch's dropout does."""
+    from models.tPatchGNN import tPatchGNN
+    from oracle import fusion_ref as R
+    from fusions.FusionModel import FusionModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    a = model_args("cpu")
+    a.immtsf_patch_encoder = "torch"
+    model = tPatchGNN(a).train()
+    fus = FusionModel(a)          # parameter container only; the arithmetic below is the oracle's
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in fus.state_dict().items()}
+    opt = torch.optim.Adam(list(model.parameters()) + list(params.values()), lr=1e-3)
+    B, T = batch["tp_to_predict"].shape
+    keep = 1.0 - P_DROP
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = model.forecasting(batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
+        drop = {"ttf": {"attn": torch.bernoulli(torch.full((B, T, H, N_MAX), keep)),
+                        "out": torch.bernoulli(torch.full((B, T, D_TXT), keep))},
+                "mmf": {"attn": torch.bernoulli(torch.full((B, H, T, T), keep)),
+                        "out": torch.bernoulli(torch.full((B, T, C), keep))}}
+        out = R.fusion_forward("TTF_T2V_XAttn", "MMF_XAttn_Add", params, batch["notes_embeddings"], batch["tau"],
+                               batch["tp_to_predict"], pred, H=H, kappa=KAPPA, drop=drop, p_drop=P_DROP, expand_T=True)
+        loss = R.masked_mse(batch["data_to_predict"], out, batch["mask_predicted_data"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(model.parameters()) + list(params.values()), 1.0)
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(B / med, 2), "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of the same {B}-window cfg2 batch after {warmup} warm-up (median {med*1e3:.0f} ms/step), "
+                      f"oracle/fusion_ref.py with the T-expanded K/V + torch-CPU tPatchGNN, fp32, dropout {P_DROP}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        group = dist.group.WORLD
+
+    from fusions.FusionModel import FusionModel
+    from immtsf import _lib, config
+    from immtsf.ops import masked_mse
+    from immtsf.train import FlatTrainer
+    from models.tPatchGNN import tPatchGNN
+    lib = _lib.load()
+    config.precision = args.precision
+    config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
+    config.manual_seed(1234 + rank)
+
+    torch.manual_seed(0)                # identical initial weights on every rank
+    a = model_args(str(dev))
+    model = tPatchGNN(a).to(dev).train()
+    fusion = FusionModel(a).to(dev).train()
+    trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1))
+    cpu_batch, sum_n = synth_batch(100 + rank, B_PER_GPU)
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+
+    def step():
+        trainer.zero_grad()
+        pred = model.forecasting(batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
+        out = fusion(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"], pred)
+        loss = masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], group)
+        loss.backward()
+        trainer.sync_grads()
+        trainer.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fusion.check_nan()
+    assert torch.isfinite(loss).all(), "loss is not finite"
+    ms_per_step = elapsed / args.steps * 1e3
+    windows_per_s = B_PER_GPU * world * args.steps / elapsed
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # dominant kernel = the MFMA GEMM (all projections).  HIP events bracket every GEMM launch on torch's current
+        # stream (the stream the library launches on) over a further block of identical steps.
+        k2 = min(args.steps, 20)
+        lib.immtsf_timing_enable(1)
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        cap = 16384
+        meta = (ctypes.c_int32 * (8 * cap))()
+        ms = (ctypes.c_float * cap)()
+        n = lib.immtsf_timing_collect(cap, meta, ms)
+        lib.immtsf_timing_enable(0)
+        groups = {}
+        for i in range(n):
+            key = tuple(meta[8 * i:8 * i + 8])
+            groups.setdefault(key, []).append(ms[i])
+        rows = []
+        for key, v in groups.items():
+            layout, prec, Mm, Nn, Kk, nprob, nbatch, dyn = key
+            if dyn == 1:
+                Mm = sum_n
+            elif dyn == 2:
+                Kk = sum_n
+            fl = 2.0 * Mm * Nn * Kk * nprob * nbatch
+            rows.append(dict(key=key, launches=len(v), avg_us=1e3 * float(np.mean(v)), total_ms=float(np.sum(v)), flops=fl))
+        rows.sort(key=lambda r: -r["total_ms"])
+        gemm_ms = sum(r["total_ms"] for r in rows) / k2
+        top = rows[0]
+        ach = top["flops"] / (top["avg_us"] * 1e-6) / 1e12
+        allfl = sum(r["flops"] * r["launches"] for r in rows) / sum(r["total_ms"] for r in rows) / 1e9
+        lay = {0: "NT", 1: "NN", 2: "TN"}[top["key"][0]]
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
+                    "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 5),
+                    "traffic": None,
+                    "kernel": f"gemm_kernel {lay} M={top['key'][2]} N={top['key'][3]} K={top['key'][4]} x{top['key'][5] * top['key'][6]}",
+                    "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches"] // k2,
+                    "all_gemm_ms_per_step": round(gemm_ms, 4), "all_gemm_tflops": round(allfl, 2),
+                    "gemm_launches_per_step": sum(r["launches"] for r in rows) // k2}
+
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(cpu_batch)
+
+    if rank == 0:
+        fl_win = fusion_flops_per_window(sum_n, B_PER_GPU)
+        line = {
+            "metric": "forecast windows/sec (train fwd+bwd) on ragged 64-entity batch", "value": round(windows_per_s, 1),
+            "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "cfg2: tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT2 dims (d_m=d_txt=768, H=1), "
+                                   "64 ragged windows per GPU (N_b~U{1..32}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
+                       "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",
+                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "sum_notes_rank0": sum_n,
+                       "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),
+                       "fusion_algorithmic_tflops_at_step_time": round(fl_win * B_PER_GPU * world / (ms_per_step * 1e-3) / 1e12, 2),
+                       "grad_bytes": trainer.grad_bytes()},
+            "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -256,7 +256,55 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, hipStream_t stream) {
 
 }  // namespace
 
+// ---- optional per-launch timing tap (bench.py's roofline leg): hipEvents bracket every GEMM launch on the
+// stream it is launched on.  Off by default; the only process-global state in the library.
+namespace {
+struct TapRec { hipEvent_t e0, e1; int meta[8]; };
+constexpr int kTapCap = 16384;
+TapRec* g_tap = nullptr;
+int g_tap_n = 0, g_tap_on = 0, g_tap_events = 0;
+}  // namespace
+
+static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t stream);
+
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
+    if (!g_tap_on || g_tap_n >= kTapCap) return launch_gemm_impl(layout, precision, g, stream);
+    TapRec& r = g_tap[g_tap_n];
+    if (g_tap_n >= g_tap_events) {
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return launch_gemm_impl(layout, precision, g, stream);
+        g_tap_events = g_tap_n + 1;
+    }
+    const int m[8] = {layout, precision, g.M, g.N, g.K, g.nprob, g.nbatch > 1 ? g.nbatch : 1, g.dyn ? 1 + g.dyn_which : 0};
+    for (int i = 0; i < 8; ++i) r.meta[i] = m[i];
+    (void)hipEventRecord(r.e0, stream);
+    const int rc = launch_gemm_impl(layout, precision, g, stream);
+    (void)hipEventRecord(r.e1, stream);
+    ++g_tap_n;
+    return rc;
+}
+
+extern "C" int immtsf_timing_enable(int on) {
+    if (on && !g_tap) g_tap = new TapRec[kTapCap];
+    g_tap_on = on ? 1 : 0;
+    g_tap_n = 0;
+    return 0;
+}
+
+// host arrays: meta[8*max] (layout, precision, M, N, K, nprob, nbatch, dyn), ms[max]; returns the record count
+extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
+    const int n = g_tap_n < max ? g_tap_n : max;
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventSynchronize(g_tap[i].e1);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_tap[i].e0, g_tap[i].e1);
+        ms[i] = t;
+        for (int k = 0; k < 8; ++k) meta[8 * i + k] = g_tap[i].meta[k];
+    }
+    g_tap_n = 0;
+    return n;
+}
+
+static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t stream) {
     if (g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS) return IMMTSF_EINVAL;
     if (g.M < 0 || g.N < 0 || g.K < 0) return IMMTSF_EINVAL;
     if (g.M == 0 || g.N == 0) return IMMTSF_OK;

@@ -35,19 +35,39 @@ def _struct(cls, tensors):
     return s
 
 
-def _grad_buffers(params):
-    """one flat allocation, a view per (non-None) parameter"""
-    n = sum(p.numel() for p in params if p is not None)
+def _sinks_of(params):
+    """Gradient sinks registered by immtsf.train.FlatTrainer: a parameter carrying `_immtsf_grad_sink` (a view into
+    the trainer's flat gradient buffer) gets its gradient written there directly by the HIP backward, and autograd
+    is handed None for it (no AccumulateGrad add kernel, no per-parameter allocation)."""
+    return [None if p is None else getattr(p, "_immtsf_grad_sink", None) for p in params]
+
+
+def _grad_buffers(params, sinks=None):
+    """(buffers the HIP backward writes, gradients to return to autograd).  One flat allocation for the
+    parameters without a sink."""
+    sinks = sinks or [None] * len(params)
+    n = sum(p.numel() for p, s in zip(params, sinks) if p is not None and s is None)
     dev = next(p.device for p in params if p is not None)
-    flat = torch.empty(n, dtype=torch.float32, device=dev)
-    views, off = [], 0
-    for p in params:
+    flat = torch.empty(n, dtype=torch.float32, device=dev) if n else None
+    bufs, rets, off = [], [], 0
+    for p, s in zip(params, sinks):
         if p is None:
-            views.append(None)
+            bufs.append(None)
+            rets.append(None)
+        elif s is not None:
+            bufs.append(s)
+            rets.append(None)
         else:
-            views.append(flat[off:off + p.numel()].view(p.shape))
+            v = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
-    return views
+            bufs.append(v)
+            rets.append(v)
+    return bufs, rets
+
+
+def _fire(hook):
+    if hook is not None:
+        hook()
 
 
 def _bytes(n, dev):
@@ -81,6 +101,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
+        ctx.sinks = _sinks_of(params)
+        ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
         return E, M
 
@@ -91,13 +113,14 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         notes, tau = saved[0], saved[1]
         params = [None if isnone else p for p, isnone in zip(saved[2:], ctx.none_mask)]
         dE = dE.contiguous()
-        grads = _grad_buffers(params)
+        grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
         ps, gs = _struct(T2VParams, params), _struct(T2VParams, grads)
         check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
                                                 ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
               "ttf_t2v_xattn_backward")
-        return (None,) * 9 + tuple(grads)
+        _fire(ctx.done_hook)
+        return (None,) * 9 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ TTF_RecAvg
@@ -121,6 +144,8 @@ class TTFRecAvgFn(torch.autograd.Function):
         ctx.cfg, ctx.ws = cfg, ws
         ctx.save_for_backward(notes, tau, t_hat, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
+        ctx.sinks = _sinks_of(params)
+        ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
         return E, M
 
@@ -131,13 +156,14 @@ class TTFRecAvgFn(torch.autograd.Function):
         notes, tau, t_hat = saved[:3]
         params = [None if isnone else p for p, isnone in zip(saved[3:], ctx.none_mask)]
         dE = dE.contiguous()
-        grads = _grad_buffers(params)
+        grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_recavg_scratch_bytes(C.byref(ctx.cfg)), notes.device)
         ps, gs = _struct(RecAvgParams, params), _struct(RecAvgParams, grads)
         check(lib.immtsf_ttf_recavg_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(t_hat), ptr(dE),
                                              ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
               "ttf_recavg_backward")
-        return (None,) * 8 + tuple(grads)
+        _fire(ctx.done_hook)
+        return (None,) * 8 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ MMF_XAttn_Add
@@ -157,6 +183,8 @@ class MMFXAttnAddFn(torch.autograd.Function):
         check(lib.immtsf_mmf_xattn_add_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(out), ptr(ws),
                                                ws.numel(), stream_ptr()), "mmf_xattn_add_forward")
         ctx.cfg, ctx.ws = cfg, ws
+        ctx.sinks = _sinks_of(params)
+        ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.save_for_backward(Y, E, M_u8, *params)
         return out
 
@@ -165,14 +193,15 @@ class MMFXAttnAddFn(torch.autograd.Function):
         lib = _lib.load()
         Y, E, M_u8, *params = ctx.saved_tensors
         dout = dout.contiguous()
-        grads = _grad_buffers(params)
+        grads, rets = _grad_buffers(params, ctx.sinks)
         dY, dE = torch.empty_like(Y), torch.empty_like(E)
         sc = _bytes(lib.immtsf_mmf_xattn_add_scratch_bytes(C.byref(ctx.cfg)), Y.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
         check(lib.immtsf_mmf_xattn_add_backward(C.byref(ctx.cfg), C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(dout), ptr(dY),
                                                 ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
                                                 stream_ptr()), "mmf_xattn_add_backward")
-        return (dY, dE, None, None, None, None, None, None, None) + tuple(grads)
+        _fire(ctx.done_hook)
+        return (dY, dE, None, None, None, None, None, None, None) + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ MMF_GR_Add
@@ -192,6 +221,8 @@ class MMFGRAddFn(torch.autograd.Function):
         check(lib.immtsf_mmf_gr_add_forward(C.byref(cfg), hidden, C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(out), ptr(ws),
                                             ws.numel(), stream_ptr()), "mmf_gr_add_forward")
         ctx.cfg, ctx.ws, ctx.hidden = cfg, ws, hidden
+        ctx.sinks = _sinks_of(params)
+        ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.save_for_backward(Y, E, M_u8, *params)
         return out
 
@@ -200,14 +231,15 @@ class MMFGRAddFn(torch.autograd.Function):
         lib = _lib.load()
         Y, E, M_u8, *params = ctx.saved_tensors
         dout = dout.contiguous()
-        grads = _grad_buffers(params)
+        grads, rets = _grad_buffers(params, ctx.sinks)
         dY, dE = torch.empty_like(Y), torch.empty_like(E)
         sc = _bytes(lib.immtsf_mmf_gr_add_scratch_bytes(C.byref(ctx.cfg), ctx.hidden), Y.device)
         ps, gs = _struct(GRParams, params), _struct(GRParams, grads)
         check(lib.immtsf_mmf_gr_add_backward(C.byref(ctx.cfg), ctx.hidden, C.byref(ps), ptr(Y), ptr(E), ptr(M_u8), ptr(dout),
                                              ptr(dY), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
                                              stream_ptr()), "mmf_gr_add_backward")
-        return (dY, dE, None, None, None, None, None, None) + tuple(grads)
+        _fire(ctx.done_hook)
+        return (dY, dE, None, None, None, None, None, None) + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ loss

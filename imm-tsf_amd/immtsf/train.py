@@ -1,0 +1,139 @@
+"""Data-parallel training step plumbing for the fusion hot path (new: the reference is single-process).
+
+`FlatTrainer` owns one flat fp32 buffer for all parameters, one for all gradients and two for Adam's moments:
+  * parameters become views into the flat buffer (state_dict keys/shapes unchanged);
+  * the HIP backward of every fusion block writes its parameter gradients straight into the flat gradient
+    buffer (`_immtsf_grad_sink`), backbone gradients are accumulated there by autograd (`p.grad` is a view);
+  * entities shard across ranks (pure data parallel); the only collective is the gradient all-reduce (RCCL
+    over xGMI via torch.distributed, backend "nccl"; gloo in the CPU tests), issued per BUCKET on a side stream
+    as soon as a bucket's gradients are final -- MMF bucket while the TTF backward still runs, TTF bucket while
+    the backbone backward runs -- and joined before the optimizer step;
+  * clip_grad_norm_(max_norm) + Adam (main.py:1024,1098-1101) is one fused HIP kernel pair over the flat buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """contiguous entity shard of rank `rank`: [lo, hi) (rank r gets entities r*(E/W) .. (r+1)*(E/W)-1)."""
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+class FlatTrainer:
+    def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
+                 betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
+                 sink_buckets: Sequence[int] = ()):
+        """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
+        sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks)."""
+        self.group = group
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.step_count = 0
+        seen, self.buckets = set(), []
+        for b in buckets:
+            ps = [p for p in b if p.requires_grad and id(p) not in seen]
+            seen.update(id(p) for p in ps)
+            self.buckets.append(ps)
+        params = [p for b in self.buckets for p in b]
+        if not params:
+            raise ValueError("no trainable parameters")
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.norm_scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.ranges = []
+        off = 0
+        for bi, b in enumerate(self.buckets):
+            start = off
+            for p in b:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + k].view(p.shape)
+                gview = self.flat_grad[off:off + k].view(p.shape)
+                if bi in sink_buckets:
+                    p._immtsf_grad_sink = gview
+                    p.grad = gview          # so optimizers / clip utilities that look at .grad still work
+                else:
+                    p.grad = gview
+                off += k
+            self.ranges.append((start, off))
+        self.sink_buckets = set(sink_buckets)
+        self.world = 1
+        if group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(group)
+        self.overlap = overlap and self.world > 1 and dev.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._pending: List = []
+        self._reduced = [False] * len(self.buckets)
+        if self.overlap:
+            for bi in self.sink_buckets:
+                head = self.buckets[bi][0]
+                head._immtsf_bwd_hook = (lambda i=bi: self._bucket_ready(i))
+
+    # ---------------------------------------------------------------------------------------------- step pieces
+    def zero_grad(self):
+        """sink buckets are overwritten by the HIP backward every step; only autograd-accumulated ranges are zeroed."""
+        for bi, (lo, hi) in enumerate(self.ranges):
+            if bi not in self.sink_buckets and hi > lo:
+                self.flat_grad[lo:hi].zero_()
+        self._reduced = [False] * len(self.buckets)
+
+    def _bucket_ready(self, bi: int):
+        if self.world == 1 or self._reduced[bi]:
+            return
+        import torch.distributed as dist
+        lo, hi = self.ranges[bi]
+        if hi == lo:
+            self._reduced[bi] = True
+            return
+        if self.overlap:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(self.flat_grad[lo:hi], group=self.group)
+        else:
+            dist.all_reduce(self.flat_grad[lo:hi], group=self.group)
+        self._reduced[bi] = True
+
+    def sync_grads(self):
+        """all-reduce (sum) whatever has not been reduced yet and join the communication stream.  The loss is
+        normalised over the GLOBAL batch (immtsf.ops.masked_mse with `group`), so the sum of the ranks' gradients
+        is exactly the single-process full-batch gradient."""
+        if self.world > 1:
+            for bi in range(len(self.buckets)):
+                self._bucket_ready(bi)
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def step(self):
+        self.step_count += 1
+        if self.flat_param.is_cuda:
+            lib = _lib.load()
+            _lib.check(lib.immtsf_adam_step(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                            _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0],
+                                            self.betas[1], self.eps, self.wd, self.step_count, self.max_norm,
+                                            _lib.ptr(self.norm_scratch), _lib.stream_ptr()), "adam_step")
+        else:   # CPU (gloo tests of the DP logic only): same arithmetic in torch ops
+            g = self.flat_grad
+            if self.max_norm and self.max_norm > 0:
+                g = g * torch.clamp(self.max_norm / (g.norm() + 1e-6), max=1.0)
+            if self.wd:
+                g = g + self.wd * self.flat_param
+            b1, b2 = self.betas
+            self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
+
+    def grad_bytes(self) -> int:
+        return self.flat_grad.numel() * 4

@@ -1,0 +1,70 @@
+"""Loss / train-step functions with the reference's names and semantics (lib/evaluation.py:17-164).
+
+`compute_error(..., "MSE", "mean")` on GPU tensors that require grad goes through the fused HIP masked-MSE
+(immtsf.ops.masked_mse: per-variable sums -> optional all-reduce -> loss and d(pred) in one more kernel); every
+other combination is evaluated with plain torch ops (metrics only, off the hot path).
+"""
+import torch
+
+from immtsf import config
+from immtsf.ops import masked_mse
+
+
+def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None):
+    if func == "MSE" and reduce == "mean" and pred_y.is_cuda and norm_dict is None and pred_y.dim() == 3:
+        return masked_mse(pred_y, truth, mask.to(pred_y.dtype), group)
+    if pred_y.dim() == 3:
+        pred_y = pred_y.unsqueeze(0)
+    n_dim = pred_y.shape[-1]
+    truth_r = truth.unsqueeze(0).expand_as(pred_y)
+    mask = mask.unsqueeze(0).expand_as(pred_y)
+    if func == "MSE":
+        error = (truth_r - pred_y) ** 2 * mask
+    elif func == "MAE":
+        error = (truth_r - pred_y).abs() * mask
+    elif func == "MAPE":
+        if norm_dict is None:
+            mask = (truth_r != 0) * mask
+            error = (truth_r - pred_y).abs() / (truth_r + (truth_r == 0) * 1e-8) * mask
+        else:
+            lo, hi = norm_dict["data_min"], norm_dict["data_max"]
+            t, p = truth_r * (hi - lo) + lo, pred_y * (hi - lo) + lo
+            mask = (t != 0) * mask
+            error = (t - p).abs() / (t + (t == 0) * 1e-8) * mask
+    else:
+        raise Exception("Error function not specified")
+    err_sum = error.reshape(-1, n_dim).sum(dim=0)
+    cnt = mask.reshape(-1, n_dim).sum(dim=0)
+    if reduce == "mean":
+        return (err_sum / (cnt + 1e-8)).sum() / torch.count_nonzero(cnt)
+    if reduce == "sum":
+        return err_sum, cnt
+    raise Exception("Reduce argument not specified!")
+
+
+def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_embeddings=True, group=None):
+    """One training-step forward: backbone forecast -> fusion -> masked MSE (lib/evaluation.py:72-164).
+    The reference's per-step host syncs (NaN checks, per-row mask loop, .item()) follow immtsf.config.nan_check:
+    in "sync" mode they are all performed; otherwise the loss stays on the device (results["mse"] is a tensor)."""
+    sync = config.nan_check == "sync"
+    pred_y = model.forecasting(batch_dict["tp_to_predict"], batch_dict["observed_data"], batch_dict["observed_tp"],
+                               batch_dict["observed_mask"])
+    if sync and torch.isnan(pred_y).any():
+        raise ValueError("pred_y contains NaN values.")
+    if enable_text and fusion is not None:
+        notes = batch_dict["notes_embeddings"] if use_text_embeddings else batch_dict["notes_text"]
+        pred_y = fusion(notes, batch_dict["tau"], batch_dict["tp_to_predict"], pred_y)
+    if sync:
+        if torch.isnan(pred_y).any():
+            raise ValueError("pred_y contains NaN values.")
+        if torch.isnan(batch_dict["data_to_predict"]).any():
+            raise ValueError("data_to_predict contains NaN values.")
+        empty = batch_dict["mask_predicted_data"].flatten(1).sum(1) == 0      # one sync instead of B
+        if bool(empty.any()):
+            i = int(torch.nonzero(empty)[0])
+            raise ValueError(f"mask_predicted_data for sample {i} is all zeros: {batch_dict['mask_predicted_data'][i]}")
+    mse = compute_error(batch_dict["data_to_predict"], pred_y, mask=batch_dict["mask_predicted_data"], func="MSE",
+                        reduce="mean", group=group)
+    if sync and torch.isnan(mse).any():
+        raise ValueError("MSE is NaN")
+    return {"loss": mse, "mse": mse.item() if sync else mse.detach()}

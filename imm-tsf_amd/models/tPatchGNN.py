@@ -1,0 +1,185 @@
+"""tPatchGNN backbone with the reference's constructor / forecasting signature and state_dict keys
+(models/tPatchGNN.py:86-293), device-agnostic (the reference hard-codes .cuda() for the node vectors, :131-132).
+
+On the hot path is the time-aware patch encoder: LearnableTE (:176-180) + TTCN
+(:182-195), a masked softmax over each patch's irregular observations.  `patch_encoder = "hip"` routes it through
+the fused HIP kernel (immtsf.ops.ttcn_patch_encode); the per-patch transformer, the adaptive-graph GCN and the
+decoder MLP are tiny (hid_dim = 32) and run as stock PyTorch-ROCm ops.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class nconv(nn.Module):
+    def forward(self, x, A):            # x (B,F,N,M), A (B,M,N,V) -> (B,F,V,M)
+        return torch.einsum("bfnm,bmnv->bfvm", x, A).contiguous()
+
+
+class linear(nn.Module):
+    def __init__(self, c_in, c_out):
+        super().__init__()
+        self.mlp = nn.Conv2d(c_in, c_out, kernel_size=(1, 1), padding=(0, 0), stride=(1, 1), bias=True)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class gcn(nn.Module):
+    def __init__(self, c_in, c_out, dropout, support_len=3, order=2):
+        super().__init__()
+        self.nconv = nconv()
+        self.mlp = linear((order * support_len + 1) * c_in, c_out)
+        self.dropout = dropout
+        self.order = order
+
+    def forward(self, x, support):
+        feats = [x]
+        for a in support:
+            xk = x
+            for _ in range(self.order):
+                xk = self.nconv(xk, a)
+                feats.append(xk)
+        return F.relu(self.mlp(torch.cat(feats, dim=1)))
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, max_len=512):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        self.register_buffer("pe", pe.unsqueeze(0))
+
+    def forward(self, x):
+        return x + self.pe[:, :x.size(1), :]
+
+
+class tPatchGNN(nn.Module):
+    def __init__(self, args, supports=None, dropout=0):
+        super().__init__()
+        self.device = args.device
+        self.hid_dim = args.hid_dim
+        self.N = args.C
+        self.M = args.npatch
+        self.batch_size = None
+        self.supports = supports if supports is not None else []
+        self.n_layer = args.nlayer
+        self.te_dim = args.te_dim
+
+        self.te_scale = nn.Linear(1, 1)
+        self.te_periodic = nn.Linear(1, args.te_dim - 1)
+
+        input_dim = 1 + args.te_dim
+        ttcn_dim = args.hid_dim - 1
+        self.ttcn_dim = ttcn_dim
+        self.Filter_Generators = nn.Sequential(
+            nn.Linear(input_dim, ttcn_dim, bias=True), nn.ReLU(inplace=True),
+            nn.Linear(ttcn_dim, ttcn_dim, bias=True), nn.ReLU(inplace=True),
+            nn.Linear(ttcn_dim, input_dim * ttcn_dim, bias=True))
+        self.T_bias = nn.Parameter(torch.randn(1, ttcn_dim))
+
+        d_model = args.hid_dim
+        self.ADD_PE = PositionalEncoding(d_model)
+        self.transformer_encoder = nn.ModuleList()
+        for _ in range(self.n_layer):
+            layer = nn.TransformerEncoderLayer(d_model=d_model, nhead=args.n_heads, batch_first=True)
+            self.transformer_encoder.append(nn.TransformerEncoder(layer, num_layers=args.tf_layer))
+
+        self.supports_len = len(self.supports) + 1
+        self.nodevec_dim = args.node_dim
+        self.nodevec1 = nn.Parameter(torch.randn(self.N, args.node_dim), requires_grad=True)
+        self.nodevec2 = nn.Parameter(torch.randn(args.node_dim, self.N), requires_grad=True)
+        self.nodevec_linear1 = nn.ModuleList()
+        self.nodevec_linear2 = nn.ModuleList()
+        self.nodevec_gate1 = nn.ModuleList()
+        self.nodevec_gate2 = nn.ModuleList()
+        for _ in range(self.n_layer):
+            self.nodevec_linear1.append(nn.Linear(args.hid_dim, args.node_dim))
+            self.nodevec_linear2.append(nn.Linear(args.hid_dim, args.node_dim))
+            self.nodevec_gate1.append(nn.Sequential(nn.Linear(args.hid_dim + args.node_dim, 1), nn.Tanh(), nn.ReLU()))
+            self.nodevec_gate2.append(nn.Sequential(nn.Linear(args.hid_dim + args.node_dim, 1), nn.Tanh(), nn.ReLU()))
+        self.gconv = nn.ModuleList(
+            [gcn(d_model, d_model, dropout, support_len=self.supports_len, order=args.hop) for _ in range(self.n_layer)])
+
+        self.outlayer = args.outlayer
+        enc_dim = args.hid_dim
+        if self.outlayer == "Linear":
+            self.temporal_agg = nn.Sequential(nn.Linear(args.hid_dim * self.M, enc_dim))
+        elif self.outlayer == "CNN":
+            self.temporal_agg = nn.Sequential(nn.Conv1d(d_model, enc_dim, kernel_size=self.M))
+        self.decoder = nn.Sequential(
+            nn.Linear(enc_dim + args.te_dim, args.hid_dim), nn.ReLU(inplace=True),
+            nn.Linear(args.hid_dim, args.hid_dim), nn.ReLU(inplace=True),
+            nn.Linear(args.hid_dim, 1))
+        # "hip": fused TE+TTCN kernel on the GPU; "torch": eager ops (any device)
+        self.patch_encoder = getattr(args, "immtsf_patch_encoder", "torch")
+
+    # ---- time-aware patch encoder ---------------------------------------------------------------
+    def LearnableTE(self, tt):
+        return torch.cat([self.te_scale(tt), torch.sin(self.te_periodic(tt))], -1)
+
+    def TTCN(self, X_int, mask_X):
+        """X_int (P,L,F), mask_X (P,L,1) -> (P, ttcn_dim): meta-filter pooling with a masked softmax over L."""
+        P, L, Fin = X_int.shape
+        filt = self.Filter_Generators(X_int)
+        filt = filt * mask_X + (1 - mask_X) * (-1e8)
+        sm = F.softmax(filt, dim=-2).view(P, L, self.ttcn_dim, Fin)
+        pooled = torch.einsum("plf,plkf->pk", X_int, sm)
+        return torch.relu(pooled + self.T_bias)
+
+    def _encode_patches(self, x, tt, mask):
+        """x, tt, mask: (P, L) -> (P, hid_dim) patch embedding incl. the patch-non-empty flag."""
+        use_hip = self.patch_encoder == "hip" or (self.patch_encoder == "auto" and x.is_cuda)
+        if use_hip:
+            from immtsf.ops import ttcn_patch_encode
+            lin = self.Filter_Generators
+            h = ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
+                                  self.te_periodic.bias, lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias,
+                                  lin[4].weight, lin[4].bias, self.T_bias)
+        else:
+            te = self.LearnableTE(tt.unsqueeze(-1))
+            h = self.TTCN(torch.cat([x.unsqueeze(-1), te], -1), mask.unsqueeze(-1))
+        flag = (mask.sum(dim=1, keepdim=True) > 0).to(h.dtype)
+        return torch.cat([h, flag], dim=-1)
+
+    # ---- transformer + adaptive-graph GCN over (variables x patches) ------------------------------
+    def IMTS_Model(self, x_patch):
+        B, N, M, D = x_patch.shape
+        x = x_patch
+        for layer in range(self.n_layer):
+            x_last = x if layer > 0 else None
+            x = self.transformer_encoder[layer](self.ADD_PE(x.reshape(B * N, M, D))).view(B, N, M, D)
+            nv1 = self.nodevec1.view(1, 1, N, self.nodevec_dim).expand(B, M, N, self.nodevec_dim)
+            nv2 = self.nodevec2.view(1, 1, self.nodevec_dim, N).expand(B, M, self.nodevec_dim, N)
+            g1 = self.nodevec_gate1[layer](torch.cat([x, nv1.permute(0, 2, 1, 3)], dim=-1))
+            g2 = self.nodevec_gate2[layer](torch.cat([x, nv2.permute(0, 3, 1, 2)], dim=-1))
+            p1 = g1 * self.nodevec_linear1[layer](x)
+            p2 = g2 * self.nodevec_linear2[layer](x)
+            nv1 = nv1 + p1.permute(0, 2, 1, 3)
+            nv2 = nv2 + p2.permute(0, 2, 3, 1)
+            adp = F.softmax(F.relu(torch.matmul(nv1, nv2)), dim=-1)
+            x = self.gconv[layer](x.permute(0, 3, 1, 2), self.supports + [adp]).permute(0, 2, 3, 1)
+            if x_last is not None:
+                x = x_last + x
+        if self.outlayer == "CNN":
+            x = self.temporal_agg(x.reshape(B * N, M, -1).permute(0, 2, 1)).view(B, N, -1)
+        else:
+            x = self.temporal_agg(x.reshape(B, N, -1))
+        return x
+
+    def forecasting(self, time_steps_to_predict, X, truth_time_steps, mask=None):
+        """time_steps_to_predict (B,Lp); X, truth_time_steps, mask (B,M,L,N) -> (B,Lp,N)"""
+        B, M, L, N = X.shape
+        self.batch_size = B
+        flat = lambda t: t.permute(0, 3, 1, 2).reshape(B * N * M, L)    # noqa: E731
+        x_patch = self._encode_patches(flat(X), flat(truth_time_steps), flat(mask)).view(B, N, M, -1)
+        h = self.IMTS_Model(x_patch)                                     # (B,N,hid)
+        Lp = time_steps_to_predict.shape[-1]
+        te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1).expand(B, N, Lp, 1))
+        h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
+        return self.decoder(h).squeeze(-1).permute(0, 2, 1)

@@ -194,6 +194,13 @@ int immtsf_adam_step(float* param, const float* grad, float* exp_avg, float* exp
                      float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                      float* norm_scratch, immtsf_stream_t stream);
 
+/* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
+ * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[8*max] = (layout,
+ * precision, M, N, K, nprob, nbatch, dyn) and ms[max]; returns the number of records and resets the tap.
+ * This tap is the library's only process-global state; it is off by default. */
+int immtsf_timing_enable(int32_t on);
+int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);
+
 #ifdef __cplusplus
 }
 #endif

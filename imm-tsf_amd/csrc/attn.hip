@@ -96,51 +96,29 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
 
 constexpr int MT = 4;   // backward keeps the dropout scales of up to MT*64 forecast steps in registers
 
-// grid (B, H), 256 threads; LDS: dp[N] | ps[N] | G[hd] | red[16]
-__global__ __launch_bounds__(256) void ragged_attn_bwd_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
-                                                               const int* __restrict__ rowmap,
-                                                               const float* __restrict__ KVp, const float* __restrict__ qs,
-                                                               const float* __restrict__ P, const float* __restrict__ dctx,
-                                                               float* __restrict__ dKVp, float* __restrict__ dqs_part,
-                                                               DropCfg drop, uint64_t site) {
-    extern __shared__ float lds[];
-    float* dp = lds;
-    float* ps = lds + dm.N;
-    float* G = ps + dm.N;
-    float* red = G + dm.hd;
-    const int b = blockIdx.x, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Backward, part 1.  grid (B, H, ceil(hd/64)), 256 threads: every workgroup owns 64 head columns of one window,
+// its 4 waves take the window's notes round-robin, one column per lane:
+//   g[c]      = sum_t m[t,i] * dctx[b,t,h,c]            (m = dropout scale of the attention weight, 1 if p = 0)
+//   dv[i,c]   = p[i] * g[c]
+//   dp[i]    += sum_c g[c] * v[i,c]                     (fp32 atomic: hd/64 partial sums per note)
+__global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                                  const int* __restrict__ rowmap,
+                                                                  const float* __restrict__ KVp, const float* __restrict__ P,
+                                                                  const float* __restrict__ dctx, float* __restrict__ dKVp,
+                                                                  float* __restrict__ dp_buf, DropCfg drop, uint64_t site) {
+    const int b = blockIdx.x, h = blockIdx.y, c = blockIdx.z * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
     const int o0 = offsets[b], n = offsets[b + 1] - o0;
-    if (n == 0) {
-        for (int c = tid; c < hd; c += 256) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
-        return;
-    }
-    for (int i = tid; i < n; i += 256) ps[i] = P[(size_t)(o0 + i) * dm.H + h];
-    const float* dc = dctx + (size_t)b * T * d + h * hd;   // row t at dc + t*d
-    if (drop.p <= 0.f) {
-        for (int c = tid; c < hd; c += 256) {
-            float g = 0.f;
-            for (int t = 0; t < T; ++t) g += dc[(size_t)t * d + c];
-            G[c] = g;
-        }
-        __syncthreads();
-        for (int i = wave; i < n; i += 4) {
-            const float* vr = KVp + (size_t)(o0 + i) * ld + d + h * hd;
-            float* dvr = dKVp + (size_t)(o0 + i) * ld + d + h * hd;
-            const float pi = ps[i];
-            float a = 0.f;
-            for (int c = lane; c < hd; c += 64) {
-                const float g = G[c];
-                a = fmaf(g, vr[c], a);
-                dvr[c] = pi * g;
-            }
-            a = wave_sum(a);
-            if (lane == 0) dp[i] = a;
-        }
-    } else {
-        __syncthreads();
-        for (int i = wave; i < n; i += 4) {
+    if (n == 0) return;
+    const bool valid = c < hd;
+    const float* dc = dctx + (size_t)b * T * d + h * hd + c;   // row t at dc + t*d
+    float gsum = 0.f;
+    if (drop.p <= 0.f && valid)
+        for (int t = 0; t < T; ++t) gsum += dc[(size_t)t * d];
+    for (int i = wave; i < n; i += 4) {
+        float g = gsum;
+        if (drop.p > 0.f) {
             const int n_orig = rowmap[o0 + i] - b * dm.N;
             float mreg[MT];
 #pragma unroll
@@ -152,46 +130,63 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_kernel(RaggedAttnDims dm,
                     mreg[k] = dropout_scale(drop.seed, site, idx, drop.p, drop.inv_keep);
                 }
             }
-            const float* vr = KVp + (size_t)(o0 + i) * ld + d + h * hd;
-            float* dvr = dKVp + (size_t)(o0 + i) * ld + d + h * hd;
-            const float pi = ps[i];
-            float a = 0.f;
-            for (int c0 = 0; c0 < hd; c0 += 64) {     // uniform trip count: the shuffles below need all 64 lanes
-                const int c = c0 + lane;
-                float g = 0.f;
+            g = 0.f;
 #pragma unroll
-                for (int k = 0; k < MT; ++k) {
-                    const int tcnt = min(64, T - k * 64);
-                    for (int tt = 0; tt < tcnt; ++tt) {
-                        const float mt = __shfl(mreg[k], tt, 64);
-                        if (c < hd) g = fmaf(mt, dc[(size_t)(k * 64 + tt) * d + c], g);
-                    }
-                }
-                if (c < hd) {
-                    a = fmaf(g, vr[c], a);
-                    dvr[c] = pi * g;
+            for (int k = 0; k < MT; ++k) {
+                const int tcnt = min(64, T - k * 64);
+                for (int tt = 0; tt < tcnt; ++tt) {
+                    const float mt = __shfl(mreg[k], tt, 64);
+                    if (valid) g = fmaf(mt, dc[(size_t)(k * 64 + tt) * d], g);
                 }
             }
-            a = wave_sum(a);
-            if (lane == 0) dp[i] = a;
         }
+        float a = 0.f;
+        if (valid) {
+            const size_t off = (size_t)(o0 + i) * ld + d + h * hd + c;
+            a = g * KVp[off];
+            dKVp[off] = P[(size_t)(o0 + i) * dm.H + h] * g;
+        }
+        a = wave_sum(a);
+        if (lane == 0) atomicAdd(dp_buf + (size_t)(o0 + i) * dm.H + h, a);
     }
-    __syncthreads();
+}
+
+// Backward, part 2.  grid (B, H), 256 threads; LDS: ds[N] | red[16].
+//   ds[i] = p[i] (dp[i] - sum_j p[j] dp[j]);  dk[i,:] = ds[i] * qs_h;  dqs_part[b, h, :] = sum_i ds[i] k[i,:]
+__global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                                  const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                                  const float* __restrict__ P, const float* __restrict__ dp_buf,
+                                                                  float* __restrict__ dKVp, float* __restrict__ dqs_part) {
+    extern __shared__ float lds[];
+    float* ds = lds;
+    float* red = lds + dm.N;
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d;
+    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    if (n == 0) {
+        for (int c = tid; c < hd; c += 256) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
+        return;
+    }
     float part = 0.f;
-    for (int i = tid; i < n; i += 256) part = fmaf(ps[i], dp[i], part);
+    for (int i = tid; i < n; i += 256) {
+        const float p = P[(size_t)(o0 + i) * dm.H + h], g = dp_buf[(size_t)(o0 + i) * dm.H + h];
+        ds[i] = g;
+        part = fmaf(p, g, part);
+    }
     const float dot = block_sum(part, red);
     __syncthreads();
-    for (int i = tid; i < n; i += 256) dp[i] = ps[i] * (dp[i] - dot);   // dp now holds ds
+    for (int i = tid; i < n; i += 256) ds[i] = P[(size_t)(o0 + i) * dm.H + h] * (ds[i] - dot);
     __syncthreads();
     for (int i = wave; i < n; i += 4) {
         float* dkr = dKVp + (size_t)(o0 + i) * ld + h * hd;
-        const float dsi = dp[i];
+        const float dsi = ds[i];
         for (int c = lane; c < hd; c += 64) dkr[c] = dsi * qs[h * hd + c];
     }
     for (int c = tid; c < hd; c += 256) {
         const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
         float a = 0.f;
-        for (int i = 0; i < n; ++i) a = fmaf(dp[i], kc[(size_t)i * ld], a);
+        for (int i = 0; i < n; ++i) a = fmaf(ds[i], kc[(size_t)i * ld], a);
         dqs_part[(size_t)b * d + h * hd + c] = a;
     }
 }
@@ -251,14 +246,19 @@ int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* row
 }
 
 int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           const float* P, const float* dctx, float* dKVp, float* dqs_part, DropCfg drop, uint64_t site,
-                           hipStream_t s) {
+                           const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
+                           uint64_t site, hipStream_t s) {
     if (dm.B <= 0) return IMMTSF_OK;
     if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
-    const size_t lds = (size_t)(2 * dm.N + dm.hd + 16) * sizeof(float);
+    const size_t lds = (size_t)(dm.N + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(ragged_attn_bwd_kernel, dim3(dm.B, dm.H), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs, P, dctx, dKVp,
-                       dqs_part, drop, site);
+    hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
+                       dctx, dKVp, dp_buf, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B, dm.H), dim3(256), lds, s, dm, offsets, KVp, qs, P, dp_buf, dKVp,
+                       dqs_part);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

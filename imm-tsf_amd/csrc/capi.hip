@@ -88,9 +88,9 @@ int immtsf_dropout_mask(uint64_t seed, uint64_t site, uint64_t n, float p_drop, 
 }
 
 int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
-                           float* err_sum, float* cnt, immtsf_stream_t stream) {
-    if (!truth || !pred || !mask || !err_sum || !cnt || rows < 0 || C <= 0) return IMMTSF_EINVAL;
-    return launch_mse_sums(truth, pred, mask, rows, C, err_sum, cnt, static_cast<hipStream_t>(stream));
+                           float* err_sum, float* cnt, float* scratch, immtsf_stream_t stream) {
+    if (!truth || !pred || !mask || !err_sum || !cnt || !scratch || rows < 0 || C <= 0) return IMMTSF_EINVAL;
+    return launch_mse_sums(truth, pred, mask, rows, C, err_sum, cnt, scratch, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,

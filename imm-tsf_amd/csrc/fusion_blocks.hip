@@ -44,7 +44,7 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     return w;
 }
 struct T2VScratch {
-    float *dz, *dx, *dctx, *dKVp, *dKV, *dXcat, *dqs_part, *dqs, *dq, *red;
+    float *dz, *dx, *dctx, *dKVp, *dKV, *dXcat, *dqs_part, *dqs, *dq, *dp, *red;
     size_t bytes;
 };
 T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
@@ -60,6 +60,7 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dqs_part = k.take<float>(B * d);
     s.dqs = k.take<float>(d);
     s.dq = k.take<float>(d);
+    s.dp = k.take<float>(R * c->H);
     s.red = k.take<float>(64 * (d + dt + 8));
     s.bytes = k.bytes();
     return s;
@@ -180,7 +181,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp, sc.dqs_part, drop,
+    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp, sc.dqs_part, sc.dp, drop,
                                  SITE_T2V_ATTN, s));
     // query path: q = W_q Q_param + b_q, qs = q * scale
     CHECK(launch_colsum(sc.dqs_part, nullptr, B, nullptr, d, d, sc.dqs, 0, sc.red, s));

@@ -3,35 +3,53 @@
 //   precision 0: exact fp32 on v_mfma_f32_16x16x4_f32   (parity mode: k-ordered fmaf chain, no rounding of inputs)
 //   precision 1: bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16 (operands are rounded RNE while
 //                they are staged into LDS; HBM tensors stay fp32)
-// Tiles are staged global -> registers -> LDS with the next tile's global loads issued before the current
-// tile's MFMAs (issue-early / write-late), 64-lane wavefronts, each wave owning a (BM/WM)x(BN/WN) block of
-// 16x16 accumulators.  Both LDS images are [row][k] with k contiguous, so the MFMA fragment of a lane is one
-// ds_read_b128 (bf16) / ds_read_b32 (fp32); rows are padded by one access width against bank conflicts.
-// Arbitrary M/N/K are supported by zero-filling the tile edges; M or K may live in device memory (ragged
-// note count) so that no host synchronisation is needed to size the launch.
+//
+// Structure (64-lane wavefronts, WM x WN waves per workgroup, each wave owning a (BM/WM)x(BN/WN) block of 16x16
+// accumulators):
+//   * tiles go global -> registers -> LDS; LDS is double-buffered so a K-step costs ONE barrier, and the global
+//     loads of tile t+2 are in flight while tile t+1 is being computed;
+//   * an operand whose reduction index is contiguous in memory is staged as [row][k] (k contiguous, padded by one
+//     16-byte slot) and its MFMA fragment is one ds_read_b128;
+//   * an operand whose reduction index is the SLOW one (TN/NN layouts) is staged untransposed as [k][row] with
+//     8-byte LDS writes and its fragment is fetched with two ds_read_b64_tr_b16 (hardware transpose read) -- no
+//     scattered 2-byte LDS writes;
+//   * small outputs with a long reduction (weight gradients) are split along K over blockIdx.y and combined with
+//     fp32 atomics into a zero-initialised C (the launcher zero-fills);
+//   * arbitrary M/N/K by zero-filling tile edges; M or K may live in device memory (ragged note count), so no host
+//     synchronisation is needed to size the launch.
 #include "gemm.hpp"
 
 namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <bool BF16> struct LdsElem { typedef float T; };
 template <> struct LdsElem<true> { typedef bf16_t T; };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
+// LDS image of one operand tile: R = [rows][BK+pad] (k contiguous), KM = [BK][rows+8] (row contiguous, bf16 only)
+template <bool BF16, bool TR, int ROWS, int BK> struct TileGeom {
+    static constexpr bool kmajor = BF16 && TR;
+    static constexpr int pad = BF16 ? 8 : 1;
+    static constexpr int pitch = kmajor ? (ROWS + 8) : (BK + pad);
+    static constexpr int elems = kmajor ? BK * pitch : ROWS * pitch;
+};
+
 template <bool BF16, bool TA, bool TB, int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     typedef typename LdsElem<BF16>::T T;
+    typedef TileGeom<BF16, TA, BM, BK> GA;
+    typedef TileGeom<BF16, TB, BN, BK> GB;
     constexpr int NT = WM * WN * 64;
-    constexpr int PAD = BF16 ? 8 : 1;
-    constexpr int LDK = BK + PAD;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int CA = (BM * BK / 4) / NT, CB = (BN * BK / 4) / NT;
     static_assert(CA >= 1 && CB >= 1, "tile too small for the thread count");
     static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "chunking must be exact");
+    constexpr int BUF = ((GA::elems + GB::elems) * (int)sizeof(T) + 15) / 16 * 16 / (int)sizeof(T);
 
-    __shared__ __attribute__((aligned(16))) T smem[(BM + BN) * LDK];
-    T* As = smem;
-    T* Bs = smem + BM * LDK;
+    __shared__ __attribute__((aligned(16))) T smem[2 * BUF];
 
     const int nb = g.nbatch > 1 ? g.nbatch : 1;
     const GemmProblem P = g.p[blockIdx.z / nb];
@@ -61,7 +79,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
     float4 ra[CA], rb[CB];
 
-    auto load_tile = [&](int k0) {
+    auto load_slow = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             const int c = tid + i * NT;
@@ -133,10 +151,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         }
     };
 
-    auto put4 = [&](T* base, bool transposed, int BR, int c, const float4& v) {
+    // ---- fast path: straight-line 16-byte loads, no bounds checks, addresses = uniform base + per-lane 32-bit
+    // offset + uniform k advance.  Valid when both operands are 16-byte aligned, the contiguous dimension of every
+    // chunk is fully inside the matrix and the K tile is full.  Rows past M / N of a row-major operand are clamped
+    // to the last valid row (their products only feed output rows/cols that are never stored).
+    bool fast = g.vecA && g.vecB && !(TA && g.a_rowmap) && !(TB && g.b_rowmap) && !(TA && TB && g.ones_col && col0 + BN > Nreal);
+    if (TA) fast = fast && (row0 + BM <= M);
+    if (TB) fast = fast && (col0 + BN <= Nreal);
+    unsigned oa[CA], ob[CB];
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int c = tid + i * NT;
+            if (!TA) {
+                const int r = min(row0 + c / (BK / 4), M - 1), kq = c % (BK / 4);
+                const int srow = g.a_rowmap ? g.a_rowmap[r] : r;
+                oa[i] = (unsigned)srow * (unsigned)g.lda + kq * 4;
+            } else {
+                oa[i] = (unsigned)(c / (BM / 4)) * (unsigned)g.lda + row0 + (c % (BM / 4)) * 4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int c = tid + i * NT;
+            if (!TB) {
+                const int r = min(col0 + c / (BK / 4), Nreal - 1), kq = c % (BK / 4);
+                ob[i] = (unsigned)r * (unsigned)g.ldb + kq * 4;
+            } else {
+                ob[i] = (unsigned)(c / (BN / 4)) * (unsigned)g.ldb + col0 + (c % (BN / 4)) * 4;
+            }
+        }
+    }
+    auto load_fast = [&](int k0) {
+        const unsigned ka = TA ? (unsigned)k0 * (unsigned)g.lda : (unsigned)k0;
+        const unsigned kb = TB ? (unsigned)k0 * (unsigned)g.ldb : (unsigned)k0;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (oa[i] + ka));
+#pragma unroll
+        for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + (ob[i] + kb));
+    };
+    // write one 4-element chunk of a staged tile.  `transposed`: the 4 values run along the tile's ROW index.
+    auto put4 = [&](T* base, bool transposed, bool kmajor, int pitch, int BR, int c, const float4& v) {
         if (!transposed) {
             const int r = c / (BK / 4), kq = c % (BK / 4);
-            T* dst = base + r * LDK + kq * 4;
+            T* dst = base + r * pitch + kq * 4;
             if (BF16) {
                 bf16x4 h;
                 h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
@@ -144,17 +202,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             } else {
                 dst[0] = (T)v.x; dst[1] = (T)v.y; dst[2] = (T)v.z; dst[3] = (T)v.w;
             }
-        } else {
+        } else if (kmajor) {   // [k][row]: rows contiguous -> one 8-byte write
             const int kk = c / (BR / 4), rq = c % (BR / 4);
-            T* dst = base + (rq * 4) * LDK + kk;
-            dst[0] = (T)v.x; dst[LDK] = (T)v.y; dst[2 * LDK] = (T)v.z; dst[3 * LDK] = (T)v.w;
+            bf16x4 h;
+            h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+            *reinterpret_cast<bf16x4*>(base + kk * pitch + rq * 4) = h;
+        } else {               // fp32 parity mode: scattered transposing writes into [row][k]
+            const int kk = c / (BR / 4), rq = c % (BR / 4);
+            T* dst = base + (rq * 4) * pitch + kk;
+            dst[0] = (T)v.x; dst[pitch] = (T)v.y; dst[2 * pitch] = (T)v.z; dst[3 * pitch] = (T)v.w;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        T* As = smem + buf * BUF;
+        T* Bs = As + GA::elems;
 #pragma unroll
-        for (int i = 0; i < CA; ++i) put4(As, TA, BM, tid + i * NT, ra[i]);
+        for (int i = 0; i < CA; ++i) put4(As, TA, GA::kmajor, GA::pitch, BM, tid + i * NT, ra[i]);
 #pragma unroll
-        for (int i = 0; i < CB; ++i) put4(Bs, TB, BN, tid + i * NT, rb[i]);
+        for (int i = 0; i < CB; ++i) put4(Bs, TB, GB::kmajor, GB::pitch, BN, tid + i * NT, rb[i]);
     };
 
     f32x4 acc[TM][TN];
@@ -164,22 +229,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
-    const int nk = (K + BK - 1) / BK;
-    load_tile(0);
-    store_tile();
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile((t + 1) * BK);
+    // hardware-transpose read of a 16(row) x 8(k) bf16 fragment from a [k][row] image (T10 of the CDNA4 guide):
+    // within each 16-lane group, lane 4q+p supplies the address of k-line q, rows 4p..4p+3; lane i receives row i.
+    auto frag_kmajor = [&](const T* tile, int pitch, int rbase, int kbase) -> bf16x8 {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int q = fr >> 2, p = fr & 3;
+        const T* a0 = tile + (kbase + fq * 8 + q) * pitch + rbase + 4 * p;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+        const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    auto compute = [&](int buf) {
+        const T* As = smem + buf * BUF;
+        const T* Bs = As + GA::elems;
         if (BF16) {
 #pragma unroll
             for (int kk = 0; kk < BK / 32; ++kk) {
                 bf16x8 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    a[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(As) + (wm0 + i * 16 + fr) * LDK + kk * 32 + fq * 8);
+                for (int i = 0; i < TM; ++i) {
+                    if (GA::kmajor) a[i] = frag_kmajor(As, GA::pitch, wm0 + i * 16, kk * 32);
+                    else a[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(As) + (wm0 + i * 16 + fr) * GA::pitch + kk * 32 + fq * 8);
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    b[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(Bs) + (wn0 + j * 16 + fr) * LDK + kk * 32 + fq * 8);
+                for (int j = 0; j < TN; ++j) {
+                    if (GB::kmajor) b[j] = frag_kmajor(Bs, GB::pitch, wn0 + j * 16, kk * 32);
+                    else b[j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(Bs) + (wn0 + j * 16 + fr) * GB::pitch + kk * 32 + fq * 8);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,9 +269,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             for (int kk = 0; kk < BK / 4; ++kk) {
                 float a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = reinterpret_cast<const float*>(As)[(wm0 + i * 16 + fr) * LDK + kk * 4 + fq];
+                for (int i = 0; i < TM; ++i) a[i] = reinterpret_cast<const float*>(As)[(wm0 + i * 16 + fr) * GA::pitch + kk * 4 + fq];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = reinterpret_cast<const float*>(Bs)[(wn0 + j * 16 + fr) * LDK + kk * 4 + fq];
+                for (int j = 0; j < TN; ++j) b[j] = reinterpret_cast<const float*>(Bs)[(wn0 + j * 16 + fr) * GB::pitch + kk * 4 + fq];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -201,15 +279,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
+    };
+
+    // K range of this split (in BK tiles).  The fast pipeline covers the FULL tiles; a ragged last tile (dynamic
+    // K = note count) is handled after the loop with the checked loader, so the hot loop stays straight-line.
+    const int nk_total = (K + BK - 1) / BK;
+    const int splits = gridDim.y;
+    const int per = (nk_total + splits - 1) / splits;
+    const int kt0 = blockIdx.y * per, kt1 = min(nk_total, kt0 + per);
+    if (splits > 1 && kt0 >= kt1) return;     // nothing to add
+
+    auto pipeline = [&](int t0, int t1, auto&& loader) {
+        if (t0 < t1) {
+            loader(t0 * BK);
+            store_tile(0);
+        }
         __syncthreads();
-        if (t + 1 < nk) {
-            store_tile();
+        for (int t = t0; t < t1; ++t) {
+            const int cur = (t - t0) & 1;
+            if (t + 1 < t1) loader((t + 1) * BK);            // issue early: in flight under this tile's MFMAs
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);                // keep the LDS writes (and their vmcnt wait) behind the MFMAs
+            if (t + 1 < t1) store_tile(cur ^ 1);              // other buffer: last read one barrier ago
             __syncthreads();
         }
+    };
+    if (fast) {
+        const int kfull = min(kt1, K / BK);                   // tiles [kt0, kfull) are complete
+        pipeline(kt0, kfull, load_fast);
+        if (kfull < kt1) pipeline(kfull > kt0 ? kfull : kt0, kt1, load_slow);   // at most one ragged tile
+    } else {
+        pipeline(kt0, kt1, load_slow);
     }
 
     // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* __restrict__ C = P.C + offC;
+    const bool first = blockIdx.y == 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -222,27 +327,34 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
                 const int col = col0 + wn0 + j * 16 + fr;
                 if (col >= N) continue;
                 if (col >= Nreal) {   // virtual ones column: bias gradient
-                    if (P.bias_grad) P.bias_grad[row] = g.alpha * acc[i][j][r];
+                    if (P.bias_grad) {
+                        if (splits > 1) atomicAdd(P.bias_grad + row, g.alpha * acc[i][j][r]);
+                        else P.bias_grad[row] = g.alpha * acc[i][j][r];
+                    }
                     continue;
                 }
                 float v = g.alpha * acc[i][j][r];
-                if (P.bias) v += P.bias[col];
+                if (P.bias && first) v += P.bias[col];
                 if (!live) v = 0.f;
-                if (g.add_vec) v += g.add_vec[col];
-                if (g.act == 1) v = fmaxf(v, 0.f);
-                else if (g.act == 2) v = gelu_erf(v);
+                if (g.add_vec && first) v += g.add_vec[col];
                 float* dst = C + (size_t)row * g.ldc + col;
-                if (g.accumulate) v += *dst;
-                *dst = v;
+                if (splits > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    else if (g.act == 2) v = gelu_erf(v);
+                    if (g.accumulate) v += *dst;
+                    *dst = v;
+                }
             }
         }
     }
 }
 
 template <bool BF16, int BM, int BN, int BK, int WM, int WN>
-int launch_cfg(int layout, const GemmArgs& g, int Mmax, hipStream_t stream) {
+int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
     const int Nlog = g.N + ((layout == GEMM_TN && g.ones_col) ? 1 : 0);
-    dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), 1, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block(WM * WN * 64);
+    dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), splits, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block(WM * WN * 64);
     if (grid.x == 0) return IMMTSF_OK;
     switch (layout) {
         case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BF16, false, false, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
@@ -254,7 +366,16 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, hipStream_t stream) {
     return IMMTSF_OK;
 }
 
+// tuning override for tools/gemm_bench.py (0 = heuristic)
+int g_variant = 0, g_splitk = 0;
+
 }  // namespace
+
+extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
+    g_variant = variant;
+    g_splitk = splitk;
+    return 0;
+}
 
 // ---- optional per-launch timing tap (bench.py's roofline leg): hipEvents bracket every GEMM launch on the
 // stream it is launched on.  Off by default; the only process-global state in the library.
@@ -324,14 +445,55 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     if (g.nbatch > 1 && g.batch_inner <= 0) return IMMTSF_EINVAL;
     if (g.ones_col && layout != GEMM_TN) return IMMTSF_EINVAL;
     const int Mmax = g.M;   // g.M is the allocation-time upper bound when `dyn` overrides M
-    const long tiles128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
+    const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
+
+    // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
+    const bool can_split = !g.accumulate && g.act == 0 && g.nbatch <= 1 && g.ldc == g.N && !(g.dyn && g.dyn_which == 0);
+    int splits = 1;
+    if (can_split) {
+        if (g_splitk > 0) splits = g_splitk;
+        else {
+            const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * nbz;
+            const int ksteps = cdiv(g.K, 64);
+            if (tiles < 256 && ksteps >= 8) {
+                splits = (int)((512 + tiles - 1) / tiles);
+                if (splits > ksteps / 2) splits = ksteps / 2;
+                if (splits > 16) splits = 16;
+                if (splits < 1) splits = 1;
+            }
+        }
+    }
+    if (splits > 1) {
+        for (int i = 0; i < g.nprob; ++i) {
+            hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
+            if (e != hipSuccess) return (int)e;
+            if (g.p[i].bias_grad) {
+                e = hipMemsetAsync(g.p[i].bias_grad, 0, (size_t)Mmax * sizeof(float), stream);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+    }
+
     if (precision == 1) {
-        if (tiles128 >= 512) return launch_cfg<true, 128, 128, 64, 2, 2>(layout, g, Mmax, stream);
-        return launch_cfg<true, 64, 64, 64, 2, 2>(layout, g, Mmax, stream);
+        int v = g_variant;
+        if (v == 0) {
+            const long tiles128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * nbz;
+            v = tiles128 >= 512 ? 4 : 1;
+        }
+        switch (v) {
+            case 1: return launch_cfg<true, 64, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 2: return launch_cfg<true, 64, 64, 128, 2, 2>(layout, g, Mmax, splits, stream);
+            case 3: return launch_cfg<true, 128, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 4: return launch_cfg<true, 128, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 5: return launch_cfg<true, 32, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 6: return launch_cfg<true, 64, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            default: return IMMTSF_EINVAL;
+        }
     }
     if (precision == 0) {
-        if (tiles128 >= 512) return launch_cfg<false, 128, 128, 16, 2, 2>(layout, g, Mmax, stream);
-        return launch_cfg<false, 64, 64, 16, 2, 2>(layout, g, Mmax, stream);
+        const long tiles128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * nbz;
+        if (tiles128 >= 512) return launch_cfg<false, 128, 128, 16, 2, 2>(layout, g, Mmax, splits, stream);
+        return launch_cfg<false, 64, 64, 16, 2, 2>(layout, g, Mmax, splits, stream);
     }
     return IMMTSF_EINVAL;
 }

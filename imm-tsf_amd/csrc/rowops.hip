@@ -251,13 +251,21 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
     }
 }
 
-__global__ __launch_bounds__(256) void matvec_t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
-                                                        int rows, int cols, float* __restrict__ y, int accumulate) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
+// y[j] = sum_i W[i,j] x[i]: 64 columns x 16 row lanes per workgroup, rows strided (coalesced over j)
+__global__ __launch_bounds__(1024) void matvec_t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                                         int rows, int cols, float* __restrict__ y, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
     float a = 0.f;
-    for (int i = 0; i < rows; ++i) a = fmaf(W[(size_t)i * ldw + j], x[i], a);
-    y[j] = accumulate ? y[j] + a : a;
+    if (j < cols)
+        for (int i = ty; i < rows; i += 16) a = fmaf(W[(size_t)i * ldw + j], x[i], a);
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && j < cols) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        y[j] = accumulate ? y[j] + t : t;
+    }
 }
 
 __global__ __launch_bounds__(256) void outer_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
@@ -372,7 +380,7 @@ int launch_matvec(const float* W, int ldw, const float* x, const float* b, int r
 
 int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols, float* y, int accumulate,
                     hipStream_t s) {
-    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, W, ldw, x, rows, cols, y, accumulate);
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, W, ldw, x, rows, cols, y, accumulate);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -65,28 +65,50 @@ __global__ __launch_bounds__(256) void ln_blend_bwd_kernel(const float* __restri
 }
 
 // ---- masked MSE (lib/evaluation.py:17-62, func="MSE", reduce="mean") -------------------------------------
-__global__ __launch_bounds__(1024) void mse_sums_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
-                                                         const float* __restrict__ mask, int rows, int C,
-                                                         float* __restrict__ err_sum, float* __restrict__ cnt) {
-    __shared__ float re[16][64], rc[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
-    float e = 0.f, n = 0.f;
-    if (c < C)
-        for (int r = ty; r < rows; r += 16) {
-            const size_t i = (size_t)r * C + c;
-            const float dlt = truth[i] - pred[i], m = mask[i];
-            e = fmaf(dlt * dlt, m, e);
-            n += m;
+// stage 1: grid = 64 row slabs; block = CT column lanes x (256/CT) row lanes (CT = pow2 >= min(C,64)), so one
+// wave-instruction reads whole contiguous rows.  partial[slab][0][c] = sum err, partial[slab][1][c] = sum mask.
+constexpr int kMseSlabs = 64;
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
+                                                           const float* __restrict__ mask, int rows, int C, int CT,
+                                                           float* __restrict__ partial) {
+    __shared__ float re[256], rc[256];
+    const int RT = 256 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const int rps = (rows + kMseSlabs - 1) / kMseSlabs;
+    const int r0 = blockIdx.x * rps, r1 = min(rows, r0 + rps);
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int c = c0 + tx;
+        float e = 0.f, n = 0.f;
+        if (c < C)
+            for (int r = r0 + ty; r < r1; r += RT) {
+                const size_t i = (size_t)r * C + c;
+                const float dlt = truth[i] - pred[i], m = mask[i];
+                e = fmaf(dlt * dlt, m, e);
+                n += m;
+            }
+        re[threadIdx.x] = e;
+        rc[threadIdx.x] = n;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            float se = 0.f, sn = 0.f;
+            for (int k = 0; k < RT; ++k) { se += re[k * CT + tx]; sn += rc[k * CT + tx]; }
+            partial[((size_t)blockIdx.x * 2 + 0) * C + c] = se;
+            partial[((size_t)blockIdx.x * 2 + 1) * C + c] = sn;
         }
-    re[ty][tx] = e;
-    rc[ty][tx] = n;
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        float se = 0.f, sn = 0.f;
-        for (int k = 0; k < 16; ++k) { se += re[k][tx]; sn += rc[k][tx]; }
-        err_sum[c] = se;
-        cnt[c] = sn;
+        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void mse_sums_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ err_sum,
+                                                              float* __restrict__ cnt) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float se = 0.f, sn = 0.f;
+    for (int s = 0; s < kMseSlabs; ++s) {
+        se += partial[((size_t)s * 2 + 0) * C + c];
+        sn += partial[((size_t)s * 2 + 1) * C + c];
+    }
+    err_sum[c] = se;
+    cnt[c] = sn;
 }
 
 __global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
@@ -169,8 +191,12 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
 }
 
 int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
-                    float* cnt, hipStream_t s) {
-    hipLaunchKernelGGL(mse_sums_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, truth, pred, mask, rows, C, err_sum, cnt);
+                    float* cnt, float* scratch, hipStream_t s) {
+    int CT = 1;
+    while (CT < C && CT < 64) CT <<= 1;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(kMseSlabs), dim3(256), 0, s, truth, pred, mask, rows, C, CT, scratch);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mse_sums_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, scratch, C, err_sum, cnt);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -15,7 +15,7 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
                         DropCfg drop, uint64_t site, hipStream_t s);
 
 int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
-                    float* cnt, hipStream_t s);
+                    float* cnt, float* scratch, hipStream_t s);
 int launch_mse_finish(const float* truth, const float* pred, const float* mask, int rows, int C, const float* err_sum,
                       const float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
 

@@ -1,0 +1,377 @@
+// tPatchGNN time-aware patch encoder on MI355X: LearnableTE + TTCN (reference models/tPatchGNN.py:176-195) fused
+// into one forward and one backward kernel.
+//
+// Per patch p (one variable's observations inside one time patch; L padded slots, mask marks the real ones):
+//   te[l]   = [ws*t+bs ; sin(wp*t+bp)]                  (te_dim)         LearnableTE
+//   X[l]    = [x[l] ; te[l]]                             (F = 1+te_dim)
+//   filt[l] = W3 relu(W2 relu(W1 X[l] + b1) + b2) + b3   (F*K, K = ttcn_dim)   Filter_Generators
+//   v[l,c]  = mask[l] ? filt[l,c] : -1e8 ; sm = softmax over l (per column c)
+//   out[k]  = relu( sum_f sum_l X[l,f] * sm[l, k*F+f] + T_bias[k] )
+// The reference materialises filt/sm as (P, L, F*K) tensors in HBM (45 MB at the benchmark shape) and runs ~20
+// eager kernels over them; here a workgroup keeps a patch in LDS/registers: thread c owns filter column c, streams
+// over l with an online softmax, and never writes filt.  An all-masked (empty) patch gives the uniform softmax over
+// identical pad rows, exactly like the reference.
+//
+// Backward recomputes the filter columns (cheap) and accumulates every parameter gradient in registers across the
+// patches a workgroup owns; each workgroup writes one partial gradient row, a column sum over workgroups finishes
+// (deterministic, no atomics).
+#include "ttcn.hpp"
+
+namespace {
+
+constexpr int LC = 32;        // observations processed per LDS chunk
+constexpr int KMAX = 64;      // ttcn_dim upper bound (registers hold one W3 row per thread; KP = 32 or 64 is the padded K)
+constexpr int FMAX = 32;      // 1 + te_dim upper bound
+
+struct TtcnDims { int P, L, F, K; };   // F = 1 + te_dim, K = ttcn_dim, filter columns = F*K
+
+// LDS layout shared by forward and backward: X[LC][F] | h1[LC][K] | h2[LC][K] | mk[LC] | misc
+__device__ __forceinline__ void encode_chunk(const TtcnDims& dm, int l0, int lcnt, const float* __restrict__ x,
+                                             const float* __restrict__ tt, const float* __restrict__ mask,
+                                             const TtcnParams& w, float* X, float* h1, float* h2, float* mk) {
+    const int tid = threadIdx.x, nt = blockDim.x, F = dm.F, K = dm.K;
+    for (int i = tid; i < lcnt * F; i += nt) {
+        const int l = i / F, f = i % F;
+        const float t = tt[l0 + l];
+        float v;
+        if (f == 0) v = x[l0 + l];
+        else if (f == 1) v = fmaf(w.te_ws[0], t, w.te_bs[0]);
+        else v = sinf(fmaf(w.te_wp[f - 2], t, w.te_bp[f - 2]));
+        X[l * F + f] = v;
+    }
+    for (int l = tid; l < lcnt; l += nt) mk[l] = mask[l0 + l];
+    __syncthreads();
+    for (int i = tid; i < lcnt * K; i += nt) {
+        const int l = i / K, j = i % K;
+        float a = w.b1[j];
+        for (int f = 0; f < F; ++f) a = fmaf(w.W1[j * F + f], X[l * F + f], a);
+        h1[l * K + j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int i = tid; i < lcnt * K; i += nt) {
+        const int l = i / K, j = i % K;
+        float a = w.b2[j];
+        for (int q = 0; q < K; ++q) a = fmaf(w.W2[j * K + q], h1[l * K + q], a);
+        h2[l * K + j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+}
+
+// grid = P patches, block = ceil(F*K/64)*64 threads
+template <int KP, int MAXT>
+__global__ __launch_bounds__(MAXT) void ttcn_fwd_kernel(TtcnDims dm, const float* __restrict__ x, const float* __restrict__ tt,
+                                const float* __restrict__ mask, TtcnParams w, float* __restrict__ out,
+                                float* __restrict__ stat /* [P][3][F*K]: max, sum, contribution */) {
+    extern __shared__ float lds[];
+    const int F = dm.F, K = dm.K, NC = F * K, L = dm.L;
+    float* X = lds;
+    float* h1 = X + LC * F;
+    float* h2 = h1 + LC * K;
+    float* mk = h2 + LC * K;
+    float* contr = mk + LC;      // [NC]
+    const int p = blockIdx.x, c = threadIdx.x;
+    const bool col = c < NC;
+    const int fc = col ? c % F : 0;
+    float w3[KP];
+    float b3c = 0.f;
+    if (col) {
+        b3c = w.b3[c];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) w3[j] = (j < K) ? w.W3[(size_t)c * K + j] : 0.f;
+    }
+    float m = -INFINITY, s = 0.f, acc = 0.f;
+    const float* xp = x + (size_t)p * L;
+    const float* tp = tt + (size_t)p * L;
+    const float* mp = mask + (size_t)p * L;
+    for (int l0 = 0; l0 < L; l0 += LC) {
+        const int lcnt = min(LC, L - l0);
+        __syncthreads();
+        encode_chunk(dm, l0, lcnt, xp, tp, mp, w, X, h1, h2, mk);
+        if (col) {
+            for (int l = 0; l < lcnt; ++l) {
+                float v = b3c;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) if (j < K) v = fmaf(w3[j], h2[l * K + j], v);
+                const float mkv = mk[l];
+                v = v * mkv + (1.f - mkv) * (-1e8f);
+                const float mn = fmaxf(m, v);
+                const float sc = expf(m - mn), e = expf(v - mn);
+                s = s * sc + e;
+                acc = acc * sc + e * X[l * F + fc];
+                m = mn;
+            }
+        }
+    }
+    __syncthreads();
+    if (col) {
+        const float ct = acc / s;
+        contr[c] = ct;
+        float* st = stat + (size_t)p * 3 * NC;
+        st[c] = m; st[NC + c] = s; st[2 * NC + c] = ct;
+    }
+    __syncthreads();
+    if (c < K) {
+        float a = w.T_bias[c];
+        for (int f = 0; f < F; ++f) a += contr[c * F + f];
+        out[(size_t)p * K + c] = fmaxf(a, 0.f);
+    }
+}
+
+// persistent: grid = NB workgroups, each walks patches p = blockIdx.x, += gridDim.x and writes ONE partial gradient
+// row partial[blk][G].  Layout of a gradient row: W3[NC*K] | b3[NC] | W2[K*K] | b2[K] | W1[K*F] | b1[K] | Tb[K] |
+// ws, bs | wp[F-2] | bp[F-2]
+template <int KP, int MAXT>
+__global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float* __restrict__ x, const float* __restrict__ tt,
+                                const float* __restrict__ mask, TtcnParams w, const float* __restrict__ out,
+                                const float* __restrict__ stat, const float* __restrict__ dout,
+                                float* __restrict__ partial, int G) {
+    extern __shared__ float lds[];
+    const int F = dm.F, K = dm.K, NC = F * K, L = dm.L;
+    float* X = lds;
+    float* h1 = X + LC * F;
+    float* h2 = h1 + LC * K;
+    float* mk = h2 + LC * K;
+    float* dpool = mk + LC;            // [K]
+    float* dfl = dpool + KMAX;         // [LC][NC]  dfilt of the chunk
+    float* smt = dfl + LC * NC;        // [LC][NC]  softmax weight * dpool of the chunk
+    float* dz2 = smt + LC * NC;        // [LC][K]
+    float* dz1 = dz2 + LC * K;         // [LC][K]
+    float* dX = dz1 + LC * K;          // [LC][F]
+    const int c = threadIdx.x, nt = blockDim.x;
+    const bool col = c < NC;
+    const int fc = col ? c % F : 0, kc = col ? c / F : 0;
+    float w3[KP], gw3[KP];
+    float b3c = 0.f, gb3 = 0.f;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) { w3[j] = 0.f; gw3[j] = 0.f; }
+    if (col) {
+        b3c = w.b3[c];
+#pragma unroll
+        for (int j = 0; j < KP; ++j) if (j < K) w3[j] = w.W3[(size_t)c * K + j];
+    }
+    // small-matrix gradient owners: thread i owns entries i, i+nt, ... of [W2 | b2 | W1 | b1 | Tb | te params]
+    const int nW2 = K * K, nW1 = K * F, nTE = 2 + 2 * (F - 2);
+    const int nsmall = nW2 + K + nW1 + K + K + nTE;
+    constexpr int SMAX = 8;            // entries per thread (nsmall <= SMAX * blockDim)
+    float gs[SMAX];
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i) gs[i] = 0.f;
+
+    for (int p = blockIdx.x; p < dm.P; p += gridDim.x) {
+        const float* xp = x + (size_t)p * L;
+        const float* tp = tt + (size_t)p * L;
+        const float* mp = mask + (size_t)p * L;
+        const float* st = stat + (size_t)p * 3 * NC;
+        __syncthreads();
+        if (c < K) dpool[c] = (out[(size_t)p * K + c] > 0.f) ? dout[(size_t)p * K + c] : 0.f;
+        const float mc = col ? st[c] : 0.f, sc_ = col ? st[NC + c] : 1.f, ctc = col ? st[2 * NC + c] : 0.f;
+        for (int l0 = 0; l0 < L; l0 += LC) {
+            const int lcnt = min(LC, L - l0);
+            __syncthreads();
+            encode_chunk(dm, l0, lcnt, xp, tp, mp, w, X, h1, h2, mk);
+            // filter column c over the chunk: softmax weight sm, d filt (-> W3/b3 gradient) and sm*dpool (-> dX)
+            if (col) {
+                const float dpk = dpool[kc];
+                for (int l = 0; l < lcnt; ++l) {
+                    float v = b3c;
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) if (j < K) v = fmaf(w3[j], h2[l * K + j], v);
+                    const float mkv = mk[l];
+                    v = v * mkv + (1.f - mkv) * (-1e8f);
+                    const float smd = expf(v - mc) / sc_ * dpk;
+                    const float df = smd * (X[l * F + fc] - ctc) * mkv;
+                    dfl[l * NC + c] = df;
+                    smt[l * NC + c] = smd;
+                    gb3 += df;
+#pragma unroll
+                    for (int j = 0; j < KP; ++j) if (j < K) gw3[j] = fmaf(df, h2[l * K + j], gw3[j]);
+                }
+            }
+            __syncthreads();
+            // pooling path: dX[l,f] = sum_k dpool[k] * sm[l, k*F+f]
+            for (int i = c; i < lcnt * F; i += nt) {
+                const int l = i / F, f = i % F;
+                float a = 0.f;
+                for (int k = 0; k < K; ++k) a += smt[l * NC + k * F + f];
+                dX[l * F + f] = a;
+            }
+            // dh2[l,j] = sum_c dfilt[l,c] W3[c,j] ; relu'
+            for (int i = c; i < lcnt * K; i += nt) {
+                const int l = i / K, j = i % K;
+                float a = 0.f;
+                for (int cc = 0; cc < NC; ++cc) a = fmaf(dfl[l * NC + cc], w.W3[(size_t)cc * K + j], a);
+                dz2[l * K + j] = (h2[l * K + j] > 0.f) ? a : 0.f;
+            }
+            __syncthreads();
+            for (int i = c; i < lcnt * K; i += nt) {
+                const int l = i / K, q = i % K;
+                float a = 0.f;
+                for (int j = 0; j < K; ++j) a = fmaf(dz2[l * K + j], w.W2[j * K + q], a);
+                dz1[l * K + q] = (h1[l * K + q] > 0.f) ? a : 0.f;
+            }
+            __syncthreads();
+            for (int i = c; i < lcnt * F; i += nt) {
+                const int l = i / F, f = i % F;
+                float a = dX[l * F + f];
+                for (int j = 0; j < K; ++j) a = fmaf(dz1[l * K + j], w.W1[j * F + f], a);
+                dX[l * F + f] = a;
+            }
+            __syncthreads();
+            // small-matrix gradients owned by this thread
+#pragma unroll
+            for (int u = 0; u < SMAX; ++u) {
+                int e = c + u * nt;
+                if (e >= nsmall) continue;
+                float a = 0.f;
+                if (e < nW2) {                         // dW2[j][q] += sum_l dz2[l,j] h1[l,q]
+                    const int j = e / K, q = e % K;
+                    for (int l = 0; l < lcnt; ++l) a = fmaf(dz2[l * K + j], h1[l * K + q], a);
+                } else if ((e -= nW2) < K) {           // db2
+                    for (int l = 0; l < lcnt; ++l) a += dz2[l * K + e];
+                } else if ((e -= K) < nW1) {           // dW1[j][f] += sum_l dz1[l,j] X[l,f]
+                    const int j = e / F, f = e % F;
+                    for (int l = 0; l < lcnt; ++l) a = fmaf(dz1[l * K + j], X[l * F + f], a);
+                } else if ((e -= nW1) < K) {           // db1
+                    for (int l = 0; l < lcnt; ++l) a += dz1[l * K + e];
+                } else if ((e -= K) < K) {             // dT_bias (once per patch: add on the first chunk)
+                    if (l0 == 0) a = dpool[e];
+                } else {                               // time-embedding parameters
+                    e -= K;
+                    if (e == 0) { for (int l = 0; l < lcnt; ++l) a = fmaf(dX[l * F + 1], tp[l0 + l], a); }
+                    else if (e == 1) { for (int l = 0; l < lcnt; ++l) a += dX[l * F + 1]; }
+                    else {
+                        const int nper = F - 2;
+                        const int j = (e - 2) % nper;
+                        const bool is_w = (e - 2) < nper;
+                        for (int l = 0; l < lcnt; ++l) {
+                            const float t = tp[l0 + l];
+                            const float gq = dX[l * F + 2 + j] * cosf(fmaf(w.te_wp[j], t, w.te_bp[j]));
+                            a += is_w ? gq * t : gq;
+                        }
+                    }
+                }
+                gs[u] += a;
+            }
+        }
+    }
+    // one partial gradient row per workgroup
+    float* row = partial + (size_t)blockIdx.x * G;
+    if (col) {
+#pragma unroll
+        for (int j = 0; j < KP; ++j) if (j < K) row[(size_t)c * K + j] = gw3[j];
+        row[(size_t)NC * K + c] = gb3;
+    }
+    const int base = NC * K + NC;
+#pragma unroll
+    for (int u = 0; u < SMAX; ++u) {
+        const int e = c + u * nt;
+        if (e < nsmall) row[base + e] = gs[u];
+    }
+}
+
+inline size_t fwd_lds(const TtcnDims& d) { return (size_t)(LC * d.F + 2 * LC * d.K + LC + d.F * d.K) * sizeof(float); }
+inline size_t bwd_lds(const TtcnDims& d) {
+    return (size_t)(LC * d.F + 2 * LC * d.K + LC + KMAX + 2 * LC * d.F * d.K + 2 * LC * d.K + LC * d.F) * sizeof(float);
+}
+
+}  // namespace
+
+int ttcn_grad_len(int F, int K) { return F * K * K + F * K + K * K + K + K * F + K + K + 2 + 2 * (F - 2); }
+
+int launch_ttcn_fwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const TtcnParams& w,
+                    float* out, float* stat, hipStream_t s) {
+    if (P <= 0) return IMMTSF_OK;
+    if (K > KMAX || F > FMAX || F < 3 || F * K > 1024) return IMMTSF_EUNSUPPORTED;
+    TtcnDims dm{P, L, F, K};
+    const int threads = cdiv(F * K, 64) * 64;
+    if (K <= 32 && threads <= 512)
+        hipLaunchKernelGGL((ttcn_fwd_kernel<32, 512>), dim3(P), dim3(threads), fwd_lds(dm), s, dm, x, tt, mask, w, out, stat);
+    else
+        hipLaunchKernelGGL((ttcn_fwd_kernel<64, 1024>), dim3(P), dim3(threads), fwd_lds(dm), s, dm, x, tt, mask, w, out, stat);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ttcn_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const TtcnParams& w,
+                    const float* out, const float* stat, const float* dout, float* partial, int nblocks, hipStream_t s) {
+    if (P <= 0) return IMMTSF_OK;
+    if (K > KMAX || F > FMAX || F < 3 || F * K > 1024) return IMMTSF_EUNSUPPORTED;
+    TtcnDims dm{P, L, F, K};
+    const int threads = cdiv(F * K, 64) * 64;
+    const int nsmall = K * K + K + K * F + K + K + 2 + 2 * (F - 2);
+    if (nsmall > 8 * threads) return IMMTSF_EUNSUPPORTED;
+    if (bwd_lds(dm) > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+    if (K <= 32 && threads <= 512)
+        hipLaunchKernelGGL((ttcn_bwd_kernel<32, 512>), dim3(nblocks), dim3(threads), bwd_lds(dm), s, dm, x, tt, mask, w, out, stat,
+                           dout, partial, ttcn_grad_len(F, K));
+    else
+        hipLaunchKernelGGL((ttcn_bwd_kernel<64, 1024>), dim3(nblocks), dim3(threads), bwd_lds(dm), s, dm, x, tt, mask, w, out, stat,
+                           dout, partial, ttcn_grad_len(F, K));
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- C ABI
+#include "../../include/immtsf.h"
+#include "rowops.hpp"
+
+namespace {
+constexpr int kTtcnBlocks = 256;   // persistent backward workgroups (one per CU)
+
+struct UnpackArgs { float* dst[11]; int len[11]; };
+__global__ __launch_bounds__(256) void ttcn_unpack_kernel(const float* __restrict__ row, UnpackArgs a) {
+    int off = 0;
+    for (int s = 0; s < 11; ++s) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.len[s]; i += gridDim.x * 256) a.dst[s][i] = row[off + i];
+        off += a.len[s];
+    }
+}
+
+inline TtcnParams to_params(const immtsf_ttcn_params* p) {
+    TtcnParams w;
+    w.te_ws = p->te_scale_w; w.te_bs = p->te_scale_b; w.te_wp = p->te_per_w; w.te_bp = p->te_per_b;
+    w.W1 = p->W1; w.b1 = p->b1; w.W2 = p->W2; w.b2 = p->b2; w.W3 = p->W3; w.b3 = p->b3; w.T_bias = p->T_bias;
+    return w;
+}
+}  // namespace
+
+extern "C" {
+
+size_t immtsf_ttcn_scratch_bytes(int32_t te_dim, int32_t ttcn_dim) {
+    const int G = ttcn_grad_len(1 + te_dim, ttcn_dim);
+    return (size_t)(kTtcnBlocks + 32 + 1) * G * sizeof(float) + 1024;
+}
+
+int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
+                        const float* mask, const immtsf_ttcn_params* p, float* out, float* stat, immtsf_stream_t stream) {
+    if (!x || !tt || !mask || !p || !out || !stat || P < 0 || L <= 0 || te_dim < 2 || ttcn_dim < 1) return IMMTSF_EINVAL;
+    return launch_ttcn_fwd(P, L, 1 + te_dim, ttcn_dim, x, tt, mask, to_params(p), out, stat, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
+                         const float* mask, const immtsf_ttcn_params* p, const float* out, const float* stat,
+                         const float* dout, const immtsf_ttcn_params* gr, void* scratch, size_t scratch_bytes,
+                         immtsf_stream_t stream) {
+    if (!x || !tt || !mask || !p || !out || !stat || !dout || !gr || !scratch || P < 0 || L <= 0 || te_dim < 2 || ttcn_dim < 1)
+        return IMMTSF_EINVAL;
+    if (scratch_bytes < immtsf_ttcn_scratch_bytes(te_dim, ttcn_dim)) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int F = 1 + te_dim, K = ttcn_dim, G = ttcn_grad_len(F, K);
+    float* partial = static_cast<float*>(scratch);           // [kTtcnBlocks][G]
+    float* red = partial + (size_t)kTtcnBlocks * G;          // [32][G] column-sum scratch
+    float* row = red + (size_t)32 * G;                       // [G]
+    const int nb = P < kTtcnBlocks ? (P > 0 ? P : 1) : kTtcnBlocks;
+    int rc = launch_ttcn_bwd(P, L, F, K, x, tt, mask, to_params(p), out, stat, dout, partial, nb, s);
+    if (rc) return rc;
+    rc = launch_colsum(partial, nullptr, nb, nullptr, G, G, row, 0, red, s);
+    if (rc) return rc;
+    UnpackArgs a;
+    float* dst[11] = {gr->W3, gr->b3, gr->W2, gr->b2, gr->W1, gr->b1, gr->T_bias, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b};
+    const int len[11] = {F * K * K, F * K, K * K, K, K * F, K, K, 1, 1, F - 2, F - 2};
+    for (int i = 0; i < 11; ++i) { a.dst[i] = dst[i]; a.len[i] = len[i]; }
+    hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(16), dim3(256), 0, s, row, a);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+}  // extern "C"

@@ -45,6 +45,8 @@ RecAvgParams = _ptr_struct("RecAvgParams", [
 XAddParams = _ptr_struct("XAddParams", [
     "proj_q_w", "proj_k_w", "proj_v_w", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b", "res_w", "res_b",
     "ln_w", "ln_b"])
+TTCNParams = _ptr_struct("TTCNParams", [
+    "te_scale_w", "te_scale_b", "te_per_w", "te_per_b", "W1", "b1", "W2", "b2", "W3", "b3", "T_bias"])
 GRParams = _ptr_struct("GRParams", [
     "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
 
@@ -80,7 +82,12 @@ _PROTOS = {
     "immtsf_mmf_gr_add_backward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,
                                              c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                              _P(GRParams), c_stream]),
-    "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_stream]),
+    "immtsf_ttcn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "immtsf_ttcn_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, _P(TTCNParams),
+                                      c_f32p, c_f32p, c_stream]),
+    "immtsf_ttcn_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, _P(TTCNParams),
+                                       c_f32p, c_f32p, c_f32p, _P(TTCNParams), C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_masked_mse_finish": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                            C.c_float, c_stream]),
     "immtsf_gemm": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p,
@@ -98,6 +105,7 @@ _PROTOS = {
                                             c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_stream]),
     "immtsf_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_u8p, c_stream]),
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
+    "immtsf_debug_gemm_config": (C.c_int, [C.c_int32, C.c_int32]),
     "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),
     "immtsf_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),

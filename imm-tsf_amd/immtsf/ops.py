@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib, config
-from ._lib import FusionCfg, GRParams, RecAvgParams, T2VParams, XAddParams, check, ptr, stream_ptr
+from ._lib import FusionCfg, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
 
 
 def _need_gpu(*ts):
@@ -242,6 +242,49 @@ class MMFGRAddFn(torch.autograd.Function):
         return (dY, dE, None, None, None, None, None, None) + tuple(rets)
 
 
+# ------------------------------------------------------------------------------------------------ tPatchGNN TE + TTCN
+class TTCNPatchEncodeFn(torch.autograd.Function):
+    """(x, tt, mask: (P,L)) -> (P, ttcn_dim).  params in immtsf_ttcn_params order."""
+
+    @staticmethod
+    def forward(ctx, x, tt, mask, *params):
+        lib = _lib.load()
+        x, tt, mask = _c(x), _c(tt), _c(mask)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(x, tt, mask, *params)
+        P, L = x.shape
+        te_dim = params[2].numel() + 1
+        K = params[10].numel()
+        out = torch.empty(P, K, dtype=torch.float32, device=x.device)
+        stat = torch.empty(P, 3, (1 + te_dim) * K, dtype=torch.float32, device=x.device)
+        ps = _struct(TTCNParams, params)
+        check(lib.immtsf_ttcn_forward(P, L, te_dim, K, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(stat),
+                                      stream_ptr()), "ttcn_forward")
+        ctx.dims = (P, L, te_dim, K)
+        ctx.sinks = _sinks_of(params)
+        ctx.save_for_backward(x, tt, mask, out, stat, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, tt, mask, out, stat, *params = ctx.saved_tensors
+        P, L, te_dim, K = ctx.dims
+        dout = dout.contiguous()
+        grads, rets = _grad_buffers(params, ctx.sinks)
+        sc = _bytes(lib.immtsf_ttcn_scratch_bytes(te_dim, K), x.device)
+        ps, gs = _struct(TTCNParams, params), _struct(TTCNParams, grads)
+        check(lib.immtsf_ttcn_backward(P, L, te_dim, K, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(stat), ptr(dout),
+                                       C.byref(gs), ptr(sc), sc.numel(), stream_ptr()), "ttcn_backward")
+        return (None, None, None) + tuple(rets)
+
+
+def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias):
+    """Fused LearnableTE + TTCN of tPatchGNN (models/tPatchGNN.py:176-195) on (P, L) patch tensors."""
+    return TTCNPatchEncodeFn.apply(x.float(), tt.float(), mask.float(), te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2,
+                                   b2, W3, b3, T_bias)
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class MaskedMSEFn(torch.autograd.Function):
     """compute_error(truth, pred, mask, "MSE", "mean") (lib/evaluation.py:17-62) with a fused backward.
@@ -256,9 +299,10 @@ class MaskedMSEFn(torch.autograd.Function):
         _need_gpu(pred, truth, mask)
         Cc = pred.shape[-1]
         rows = pred.numel() // Cc
-        sums = torch.empty(2, Cc, dtype=torch.float32, device=pred.device)
+        buf = torch.empty(2 + 128, Cc, dtype=torch.float32, device=pred.device)
+        sums = buf[:2]
         check(lib.immtsf_masked_mse_sums(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]),
-                                         stream_ptr()), "masked_mse_sums")
+                                         ptr(buf[2]), stream_ptr()), "masked_mse_sums")
         if group is not None:
             import torch.distributed as dist
             dist.all_reduce(sums, group=group)

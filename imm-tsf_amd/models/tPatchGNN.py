@@ -117,7 +117,7 @@ class tPatchGNN(nn.Module):
             nn.Linear(args.hid_dim, args.hid_dim), nn.ReLU(inplace=True),
             nn.Linear(args.hid_dim, 1))
         # "hip": fused TE+TTCN kernel on the GPU; "torch": eager ops (any device)
-        self.patch_encoder = getattr(args, "immtsf_patch_encoder", "torch")
+        self.patch_encoder = getattr(args, "immtsf_patch_encoder", "auto")
 
     # ---- time-aware patch encoder ---------------------------------------------------------------
     def LearnableTE(self, tt):

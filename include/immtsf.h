@@ -146,11 +146,34 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t hidden, con
                                float* dY_ts, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
                                size_t scratch_bytes, const immtsf_gr_params* grads, immtsf_stream_t stream);
 
+/* ---- a14: tPatchGNN time-aware patch encoder, LearnableTE + TTCN (models/tPatchGNN.py:176-195), fused.
+ * x, tt, mask: (P, L) with P = B*N*M patches (the reference's (B*N*M, L, 1) tensors); F = 1 + te_dim,
+ * K = ttcn_dim = hid_dim - 1.  out: (P, K) = relu(pooled + T_bias).  stat: (P, 3, F*K) saved for backward.
+ * Limits: K <= 64, F <= 32, F*K <= 1024 (IMMTSF_EUNSUPPORTED otherwise). */
+typedef struct immtsf_ttcn_params {
+    float *te_scale_w, *te_scale_b; /* (1),(1)          te_scale */
+    float *te_per_w, *te_per_b;     /* (te_dim-1) each  te_periodic */
+    float *W1, *b1;                 /* (K,F),(K)        Filter_Generators.0 */
+    float *W2, *b2;                 /* (K,K),(K)        Filter_Generators.2 */
+    float *W3, *b3;                 /* (F*K,K),(F*K)    Filter_Generators.4 */
+    float* T_bias;                  /* (K)              T_bias (1,K) */
+} immtsf_ttcn_params;
+
+size_t immtsf_ttcn_scratch_bytes(int32_t te_dim, int32_t ttcn_dim);
+int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
+                        const float* mask, const immtsf_ttcn_params* p, float* out, float* stat, immtsf_stream_t stream);
+/* dout (P,K) -> every parameter gradient (overwritten).  No gradient flows to x / tt / mask (data). */
+int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
+                         const float* mask, const immtsf_ttcn_params* p, const float* out, const float* stat,
+                         const float* dout, const immtsf_ttcn_params* grads, void* scratch, size_t scratch_bytes,
+                         immtsf_stream_t stream);
+
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data
- * parallelism the caller all-reduces them before calling _finish).  loss: device scalar.  dpred: (rows, C). */
+ * parallelism the caller all-reduces them before calling _finish).  scratch: >= 128*C floats.  loss: device scalar.
+ * dpred: (rows, C). */
 int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
-                           float* err_sum, float* cnt, immtsf_stream_t stream);
+                           float* err_sum, float* cnt, float* scratch, immtsf_stream_t stream);
 int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
                              const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
                              immtsf_stream_t stream);
@@ -199,6 +222,8 @@ int immtsf_adam_step(float* param, const float* grad, float* exp_avg, float* exp
  * precision, M, N, K, nprob, nbatch, dyn) and ms[max]; returns the number of records and resets the tap.
  * This tap is the library's only process-global state; it is off by default. */
 int immtsf_timing_enable(int32_t on);
+/* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */
+int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);
 int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);
 
 #ifdef __cplusplus

@@ -1,0 +1,100 @@
+"""GPU parity of the time-aware patch encoder and the tPatchGNN drop-in: fused HIP TE+TTCN kernel
+vs. the golden vectors of the real reference and vs. the eager formulation at the benchmark dimensions.
+Tolerance: 1e-4 outputs / 2e-4 gradients relative to max (fp32 both sides)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b, floor=1e-3):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def _golden_model(dev, encoder):
+    from models.tPatchGNN import tPatchGNN
+    z = np.load(os.path.join(GOLDEN, "model_tpatchgnn.npz"))
+    args = types.SimpleNamespace(device=str(dev), hid_dim=8, C=3, npatch=2, nlayer=1, te_dim=4, n_heads=1, tf_layer=1,
+                                 node_dim=4, hop=1, outlayer="Linear", immtsf_patch_encoder=encoder)
+    m = tPatchGNN(args).to(dev)
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}, strict=True)
+    return m.eval(), z
+
+
+def test_ttcn_vs_reference_golden():
+    dev = _dev()
+    m, z = _golden_model(dev, "hip")
+    X, tt, mask = [torch.from_numpy(z[k]).to(dev) for k in ("X", "tt", "mask")]
+    B, M, L, N = X.shape
+    flat = lambda t: t.permute(0, 3, 1, 2).reshape(B * N * M, L)    # noqa: E731
+    h = m._encode_patches(flat(X), flat(tt), flat(mask))[:, :-1]
+    assert _rel(h, torch.from_numpy(z["ttcn_out"])) < 1e-4
+    (h * torch.from_numpy(z["ttcn_upstream"]).to(dev)).sum().backward()
+    errs = {}
+    for k, p in m.named_parameters():
+        if f"g_ttcn.{k}" in z.files:
+            errs[k] = _rel(p.grad, torch.from_numpy(z[f"g_ttcn.{k}"]))
+    assert len(errs) == 11, sorted(errs)
+    bad = {k: v for k, v in errs.items() if v > 2e-4}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("encoder", ["hip", "torch"])
+def test_tpatchgnn_forecasting_vs_reference_golden(encoder):
+    dev = _dev()
+    m, z = _golden_model(dev, encoder)
+    out = m.forecasting(*[torch.from_numpy(z[k]).to(dev) for k in ("tp", "X", "tt", "mask")])
+    assert out.shape == z["out"].shape
+    assert _rel(out, torch.from_numpy(z["out"])) < 1e-4
+    (out * torch.from_numpy(z["upstream"]).to(dev)).sum().backward()
+    bad = {}
+    for k, p in m.named_parameters():
+        e = _rel(p.grad, torch.from_numpy(z["g." + k]))
+        if e > 3e-4:
+            bad[k] = e
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("L", [32, 45])
+def test_ttcn_benchmark_dims_vs_eager(L):
+    """P = 64*8*2 patches, te_dim 10, hid_dim 32 (BASELINE cfg2); L = 45 exercises the 32-observation LDS chunking;
+    30 % of the patches are empty."""
+    dev = _dev()
+    from models.tPatchGNN import tPatchGNN
+    args = types.SimpleNamespace(device=str(dev), hid_dim=32, C=8, npatch=2, nlayer=1, te_dim=10, n_heads=1, tf_layer=1,
+                                 node_dim=10, hop=1, outlayer="Linear", immtsf_patch_encoder="hip")
+    torch.manual_seed(0)
+    m = tPatchGNN(args).to(dev)
+    g = torch.Generator().manual_seed(1)
+    P = 64 * 8 * 2
+    cnt = torch.randint(1, L + 1, (P, 1), generator=g)
+    cnt[torch.rand(P, 1, generator=g) < 0.3] = 0
+    mask = (torch.arange(L).view(1, -1) < cnt).float().to(dev)
+    x = torch.randn(P, L, generator=g).to(dev) * mask
+    tt = torch.rand(P, L, generator=g).to(dev) * mask
+    up = torch.randn(P, 32, generator=g).to(dev)
+    m.patch_encoder = "hip"
+    h = m._encode_patches(x, tt, mask)
+    (h * up).sum().backward()
+    g_hip = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad()
+    m.patch_encoder = "torch"
+    h2 = m._encode_patches(x, tt, mask)
+    (h2 * up).sum().backward()
+    assert _rel(h, h2) < 1e-4
+    bad = {k: _rel(g_hip[k], p.grad) for k, p in m.named_parameters() if p.grad is not None}
+    bad = {k: v for k, v in bad.items() if v > 3e-4}
+    assert not bad, bad

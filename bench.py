@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -179,20 +180,58 @@ def main():
     a = model_args(str(dev))
     model = tPatchGNN(a).to(dev).train()
     fusion = FusionModel(a).to(dev).train()
+    use_graph = not args.no_graph
     trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
-                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1))
+                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1),
+                          overlap=not use_graph, device_step=use_graph)
     cpu_batch, sum_n = synth_batch(100 + rank, B_PER_GPU)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    # per-variable observation counts of the GLOBAL batch: a property of the data (mask), reduced once when the batch
+    # is built, so the step itself has no collective besides the gradient all-reduce
+    global_cnt = batch["mask_predicted_data"].reshape(-1, C).sum(0)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(global_cnt)
 
-    def step():
+    def fwd_bwd():
         trainer.zero_grad()
         pred = model.forecasting(batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
         out = fusion(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"], pred)
-        loss = masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], group)
+        loss = masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], None, global_cnt)
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
         trainer.sync_grads()
         trainer.step()
         return loss
+
+    if use_graph:
+        # hipGraph capture (HIP streams + graphs instead of a tracing compiler): graph A = zero-grad, backbone + fusion
+        # forward, loss, backward; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam, which also
+        # bumps the device-side Adam step and dropout-key counters so every replay is a NEW training step.
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_a):
+            static_loss = fwd_bwd()
+        with torch.cuda.graph(graph_b):
+            trainer.step()
+
+        def step():
+            graph_a.replay()
+            trainer._reduced = [False] * len(trainer.buckets)
+            trainer.sync_grads()
+            graph_b.replay()
+            return static_loss
+    else:
+        step = eager_step
 
     def barrier():
         if world > 1:
@@ -225,7 +264,7 @@ def main():
         k2 = min(args.steps, 20)
         lib.immtsf_timing_enable(1)
         for _ in range(k2):
-            step()
+            eager_step()      # the tap records at launch time, so this leg launches eagerly (same kernels, same shapes)
         torch.cuda.synchronize()
         cap = 16384
         meta = (ctypes.c_int32 * (8 * cap))()
@@ -270,6 +309,7 @@ def main():
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            "launch": "hipGraph replay (2 graphs/step)" if use_graph else "eager",
             "config": {"workload": "cfg2: tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT2 dims (d_m=d_txt=768, H=1), "
                                    "64 ragged windows per GPU (N_b~U{1..32}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
                 if (t < T && i < n) {
                     const int n_orig = rowmap[o0 + i] - b * dm.N;
                     const uint64_t idx = ((uint64_t)(b * T + t) * dm.H + h) * dm.N + n_orig;
-                    a = sc[i] * dropout_scale(drop.seed, site, idx, drop.p, drop.inv_keep);
+                    a = sc[i] * dropout_scale(drop, site, idx);
                 }
                 atile[x] = a;
             }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
                 mreg[k] = 0.f;
                 if (t < T) {
                     const uint64_t idx = ((uint64_t)(b * T + t) * dm.H + h) * dm.N + n_orig;
-                    mreg[k] = dropout_scale(drop.seed, site, idx, drop.p, drop.inv_keep);
+                    mreg[k] = dropout_scale(drop, site, idx);
                 }
             }
             g = 0.f;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict
     for (int i = lane; i < S; i += 64) {
         const float v = expf(p[i] - m) * inv;
         p[i] = v;
-        a[i] = v * dropout_scale(drop.seed, site, (uint64_t)row * S + i, drop.p, drop.inv_keep);
+        a[i] = v * dropout_scale(drop, site, (uint64_t)row * S + i);
     }
 }
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(float* __restrict
     const float* p = P + (size_t)row * S;
     float dot = 0.f;
     for (int i = lane; i < S; i += 64) {
-        const float dpv = g[i] * dropout_scale(drop.seed, site, (uint64_t)row * S + i, drop.p, drop.inv_keep);
+        const float dpv = g[i] * dropout_scale(drop, site, (uint64_t)row * S + i);
         g[i] = dpv;
         dot = fmaf(p[i], dpv, dot);
     }

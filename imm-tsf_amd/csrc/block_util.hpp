@@ -24,6 +24,7 @@ inline DropCfg drop_of(const immtsf_fusion_cfg* c) {
     d.seed = c->seed;
     d.p = (c->training && c->p_drop > 0.f) ? c->p_drop : 0.f;
     d.inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    d.seed_dev = c->seed_step_dev;
     return d;
 }
 

@@ -103,7 +103,16 @@ struct DropCfg {
     uint64_t seed;
     float p;          // drop probability (0 => identity)
     float inv_keep;   // 1/(1-p)
+    // optional DEVICE counter added to `seed` at run time: lets a captured hipGraph draw fresh masks on every
+    // replay (the host-side seed is baked into the graph's kernel arguments, the counter is not)
+    const uint64_t* seed_dev;
 };
+
+__device__ __forceinline__ float dropout_scale(const DropCfg& d, uint64_t site, uint64_t idx) {
+    if (d.p <= 0.f) return 1.f;
+    const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
+    return dropout_scale(seed, site, idx, d.p, d.inv_keep);
+}
 
 // dropout sites (Philox subsequence ids) -- one per dropout call of the reference modules
 enum : uint64_t {

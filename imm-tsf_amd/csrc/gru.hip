@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void gr_tail_fwd_kernel(int BT, int T, int C, 
         const size_t i = (size_t)row * C + c;
         const float hh = (xh[c] - mu) * rs;
         xh[c] = hh;
-        const float dd = fmaf(hh, gamma[c], beta[c]) * dropout_scale(drop.seed, site, i, drop.p, drop.inv_keep);
+        const float dd = fmaf(hh, gamma[c], beta[c]) * dropout_scale(drop, site, i);
         const float g = live ? sigmoidf_(gl[i]) : 1.f;
         g_out[i] = g;
         dd_out[i] = dd;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gr_tail_bwd_kernel(int BT, int T, int C, 
         const float go = dYout[i], g = g_i[i];
         // out = y + (1-g)*dd
         dgl[i] = live ? (-dd_i[i] * go) * g * (1.f - g) : 0.f;
-        const float gn = (1.f - g) * go * dropout_scale(drop.seed, site, i, drop.p, drop.inv_keep);
+        const float gn = (1.f - g) * go * dropout_scale(drop, site, i);
         dn[i] = gn;
         const float t = gn * gamma[c];
         c1 += t;

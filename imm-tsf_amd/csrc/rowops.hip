@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const float h = (p[i] - mu) * rs;
         if (xhat) xhat[(size_t)row * d + i] = h;
         const float y = fmaf(h, gamma[i], beta[i]);
-        z[(size_t)row * d + i] = y * dropout_scale(drop.seed, site, (uint64_t)row * d + i, drop.p, drop.inv_keep);
+        z[(size_t)row * d + i] = y * dropout_scale(drop, site, (uint64_t)row * d + i);
     }
 }
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
     const float* h = xhat + (size_t)row * d;
     float c1 = 0.f, c2 = 0.f;
     for (int i = lane; i < d; i += 64) {
-        const float dy = g[i] * dropout_scale(drop.seed, site, (uint64_t)row * d + i, drop.p, drop.inv_keep);
+        const float dy = g[i] * dropout_scale(drop, site, (uint64_t)row * d + i);
         g[i] = dy;
         const float t = dy * gamma[i];
         c1 += t;

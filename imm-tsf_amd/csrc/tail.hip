@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void ln_blend_fwd_kernel(const float* __restri
     for (int c = 0; c < C; ++c) {
         const float h = (x[c] - mu) * rs;
         xhat[(size_t)row * C + c] = h;
-        float y = fmaf(h, gamma[c], beta[c]) * dropout_scale(drop.seed, site, (uint64_t)row * C + c, drop.p, drop.inv_keep);
+        float y = fmaf(h, gamma[c], beta[c]) * dropout_scale(drop, site, (uint64_t)row * C + c);
         if (!live) y = 0.f;
         Yout[(size_t)row * C + c] = (Y[(size_t)row * C + c] + kappa * y) * inv;
     }
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_blend_bwd_kernel(const float* __restri
     const float* h = xhat + (size_t)row * C;
     float c1 = 0.f, c2 = 0.f;
     for (int c = 0; c < C; ++c) {
-        const float gn = kk * g[c] * dropout_scale(drop.seed, site, (uint64_t)row * C + c, drop.p, drop.inv_keep);
+        const float gn = kk * g[c] * dropout_scale(drop, site, (uint64_t)row * C + c);
         dn[(size_t)row * C + c] = gn;
         dY[(size_t)row * C + c] = g[c] * inv;
         const float t = gn * gamma[c];
@@ -139,11 +139,24 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
     if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
+__global__ void bump_counters_kernel(long long* step_dev, unsigned long long* drop_dev) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        step_dev[0] += 1;
+        if (drop_dev) drop_dev[0] += 1;
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
-                                                    const float* __restrict__ part, int nparts) {
+                                                    const float* __restrict__ part, int nparts,
+                                                    const long long* __restrict__ step_dev) {
     __shared__ float red[16];
+    if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)
+        const float st = (float)step_dev[0];
+        bc1 = 1.f - powf(b1, st);
+        bc2s = sqrtf(1.f - powf(b2, st));
+    }
     float a = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) a += part[i];
     const float total = sqrtf(block_sum(a, red));
@@ -220,7 +233,23 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
     const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, nparts);
+                       norm_scratch, nparts, (const long long*)nullptr);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                    float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
+                    hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const int nparts = 1024;
+    hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, s, step_dev, drop_dev);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, norm_scratch);
+    IMMTSF_LAUNCH_CHECK();
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
+                       norm_scratch, nparts, (const long long*)step_dev);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -21,3 +21,6 @@ int launch_mse_finish(const float* truth, const float* pred, const float* mask, 
 
 int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 float wd, int step, float max_norm, float* norm_scratch, hipStream_t s);
+int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                    float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
+                    hipStream_t s);

@@ -26,9 +26,23 @@ constexpr int FMAX = 32;      // 1 + te_dim upper bound
 struct TtcnDims { int P, L, F, K; };   // F = 1 + te_dim, K = ttcn_dim, filter columns = F*K
 
 // LDS layout shared by forward and backward: X[LC][F] | h1[LC][K] | h2[LC][K] | mk[LC] | misc
+// W1s/b1s/W2s/b2s: the two small filter-generator layers staged in LDS by stage_small()
+struct SmallW { const float *W1, *b1, *W2, *b2; };
+__device__ __forceinline__ SmallW stage_small(const TtcnDims& dm, const TtcnParams& w, float* dst) {
+    const int F = dm.F, K = dm.K;
+    float* W1s = dst;
+    float* b1s = W1s + K * F;
+    float* W2s = b1s + K;
+    float* b2s = W2s + K * K;
+    for (int i = threadIdx.x; i < K * F; i += blockDim.x) W1s[i] = w.W1[i];
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) W2s[i] = w.W2[i];
+    for (int i = threadIdx.x; i < K; i += blockDim.x) { b1s[i] = w.b1[i]; b2s[i] = w.b2[i]; }
+    SmallW r; r.W1 = W1s; r.b1 = b1s; r.W2 = W2s; r.b2 = b2s;
+    return r;
+}
 __device__ __forceinline__ void encode_chunk(const TtcnDims& dm, int l0, int lcnt, const float* __restrict__ x,
                                              const float* __restrict__ tt, const float* __restrict__ mask,
-                                             const TtcnParams& w, float* X, float* h1, float* h2, float* mk) {
+                                             const TtcnParams& w, const SmallW& sw, float* X, float* h1, float* h2, float* mk) {
     const int tid = threadIdx.x, nt = blockDim.x, F = dm.F, K = dm.K;
     for (int i = tid; i < lcnt * F; i += nt) {
         const int l = i / F, f = i % F;
@@ -43,15 +57,15 @@ __device__ __forceinline__ void encode_chunk(const TtcnDims& dm, int l0, int lcn
     __syncthreads();
     for (int i = tid; i < lcnt * K; i += nt) {
         const int l = i / K, j = i % K;
-        float a = w.b1[j];
-        for (int f = 0; f < F; ++f) a = fmaf(w.W1[j * F + f], X[l * F + f], a);
+        float a = sw.b1[j];
+        for (int f = 0; f < F; ++f) a = fmaf(sw.W1[j * F + f], X[l * F + f], a);
         h1[l * K + j] = fmaxf(a, 0.f);
     }
     __syncthreads();
     for (int i = tid; i < lcnt * K; i += nt) {
         const int l = i / K, j = i % K;
-        float a = w.b2[j];
-        for (int q = 0; q < K; ++q) a = fmaf(w.W2[j * K + q], h1[l * K + q], a);
+        float a = sw.b2[j];
+        for (int q = 0; q < K; ++q) a = fmaf(sw.W2[j * K + q], h1[l * K + q], a);
         h2[l * K + j] = fmaxf(a, 0.f);
     }
     __syncthreads();
@@ -69,6 +83,7 @@ __global__ __launch_bounds__(MAXT) void ttcn_fwd_kernel(TtcnDims dm, const float
     float* h2 = h1 + LC * K;
     float* mk = h2 + LC * K;
     float* contr = mk + LC;      // [NC]
+    const SmallW sw = stage_small(dm, w, contr + NC);
     const int p = blockIdx.x, c = threadIdx.x;
     const bool col = c < NC;
     const int fc = col ? c % F : 0;
@@ -86,7 +101,7 @@ __global__ __launch_bounds__(MAXT) void ttcn_fwd_kernel(TtcnDims dm, const float
     for (int l0 = 0; l0 < L; l0 += LC) {
         const int lcnt = min(LC, L - l0);
         __syncthreads();
-        encode_chunk(dm, l0, lcnt, xp, tp, mp, w, X, h1, h2, mk);
+        encode_chunk(dm, l0, lcnt, xp, tp, mp, w, sw, X, h1, h2, mk);
         if (col) {
             for (int l = 0; l < lcnt; ++l) {
                 float v = b3c;
@@ -137,6 +152,9 @@ __global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float
     float* dz2 = smt + LC * NC;        // [LC][K]
     float* dz1 = dz2 + LC * K;         // [LC][K]
     float* dX = dz1 + LC * K;          // [LC][F]
+    float* W3s = dX + LC * F;          // [NC][K] staged once per workgroup
+    const SmallW sw = stage_small(dm, w, W3s + NC * K);
+    for (int i = threadIdx.x; i < NC * K; i += blockDim.x) W3s[i] = w.W3[i];
     const int c = threadIdx.x, nt = blockDim.x;
     const bool col = c < NC;
     const int fc = col ? c % F : 0, kc = col ? c / F : 0;
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float
         for (int l0 = 0; l0 < L; l0 += LC) {
             const int lcnt = min(LC, L - l0);
             __syncthreads();
-            encode_chunk(dm, l0, lcnt, xp, tp, mp, w, X, h1, h2, mk);
+            encode_chunk(dm, l0, lcnt, xp, tp, mp, w, sw, X, h1, h2, mk);
             // filter column c over the chunk: softmax weight sm, d filt (-> W3/b3 gradient) and sm*dpool (-> dX)
             if (col) {
                 const float dpk = dpool[kc];
@@ -198,22 +216,29 @@ __global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float
             // dh2[l,j] = sum_c dfilt[l,c] W3[c,j] ; relu'
             for (int i = c; i < lcnt * K; i += nt) {
                 const int l = i / K, j = i % K;
-                float a = 0.f;
-                for (int cc = 0; cc < NC; ++cc) a = fmaf(dfl[l * NC + cc], w.W3[(size_t)cc * K + j], a);
-                dz2[l * K + j] = (h2[l * K + j] > 0.f) ? a : 0.f;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                int cc = 0;
+                for (; cc + 3 < NC; cc += 4) {
+                    a0 = fmaf(dfl[l * NC + cc], W3s[cc * K + j], a0);
+                    a1 = fmaf(dfl[l * NC + cc + 1], W3s[(cc + 1) * K + j], a1);
+                    a2 = fmaf(dfl[l * NC + cc + 2], W3s[(cc + 2) * K + j], a2);
+                    a3 = fmaf(dfl[l * NC + cc + 3], W3s[(cc + 3) * K + j], a3);
+                }
+                for (; cc < NC; ++cc) a0 = fmaf(dfl[l * NC + cc], W3s[cc * K + j], a0);
+                dz2[l * K + j] = (h2[l * K + j] > 0.f) ? (a0 + a1) + (a2 + a3) : 0.f;
             }
             __syncthreads();
             for (int i = c; i < lcnt * K; i += nt) {
                 const int l = i / K, q = i % K;
                 float a = 0.f;
-                for (int j = 0; j < K; ++j) a = fmaf(dz2[l * K + j], w.W2[j * K + q], a);
+                for (int j = 0; j < K; ++j) a = fmaf(dz2[l * K + j], sw.W2[j * K + q], a);
                 dz1[l * K + q] = (h1[l * K + q] > 0.f) ? a : 0.f;
             }
             __syncthreads();
             for (int i = c; i < lcnt * F; i += nt) {
                 const int l = i / F, f = i % F;
                 float a = dX[l * F + f];
-                for (int j = 0; j < K; ++j) a = fmaf(dz1[l * K + j], w.W1[j * F + f], a);
+                for (int j = 0; j < K; ++j) a = fmaf(dz1[l * K + j], sw.W1[j * F + f], a);
                 dX[l * F + f] = a;
             }
             __syncthreads();
@@ -269,9 +294,10 @@ __global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float
     }
 }
 
-inline size_t fwd_lds(const TtcnDims& d) { return (size_t)(LC * d.F + 2 * LC * d.K + LC + d.F * d.K) * sizeof(float); }
+inline size_t small_len(const TtcnDims& d) { return (size_t)(d.K * d.F + d.K * d.K + 2 * d.K); }
+inline size_t fwd_lds(const TtcnDims& d) { return (size_t)(LC * d.F + 2 * LC * d.K + LC + d.F * d.K + small_len(d)) * sizeof(float); }
 inline size_t bwd_lds(const TtcnDims& d) {
-    return (size_t)(LC * d.F + 2 * LC * d.K + LC + KMAX + 2 * LC * d.F * d.K + 2 * LC * d.K + LC * d.F) * sizeof(float);
+    return (size_t)(LC * d.F + 2 * LC * d.K + LC + KMAX + 2 * LC * d.F * d.K + 2 * LC * d.K + LC * d.F + d.F * d.K * d.K + small_len(d)) * sizeof(float);
 }
 
 }  // namespace

@@ -30,7 +30,7 @@ c_stream = C.c_void_p
 class FusionCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("d_m", C.c_int32),
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
-                ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64)]
+                ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p)]
 
 
 def _ptr_struct(name, fields):
@@ -107,6 +107,8 @@ _PROTOS = {
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
     "immtsf_debug_gemm_config": (C.c_int, [C.c_int32, C.c_int32]),
     "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),
+    "immtsf_adam_step_dev": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
     "immtsf_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),
 }

@@ -50,3 +50,33 @@ def next_seed() -> int:
         x = (x * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         x ^= x >> 31
         return x
+
+
+# ---- device-side step counters (hipGraph replay) -----------------------------------------------------------
+# When a training step is captured into a hipGraph every host-side scalar is frozen into the graph.  Two scalars
+# must still change per replay: the dropout key and Adam's step number.  With device counters enabled the fusion
+# kernels add *dropout_step to their Philox key and the fused Adam kernel reads/increments *adam_step.
+_device_counters = {}
+
+
+def enable_device_counters(device):
+    """-> (adam_step int64[1], dropout_step int64[1]) tensors on `device`; from now on every fusion forward on that
+    device passes the dropout counter to the kernels."""
+    import torch
+    key = str(device)
+    if key not in _device_counters:
+        _device_counters[key] = (torch.zeros(1, dtype=torch.int64, device=device),
+                                 torch.zeros(1, dtype=torch.int64, device=device))
+    return _device_counters[key]
+
+
+def disable_device_counters(device=None):
+    if device is None:
+        _device_counters.clear()
+    else:
+        _device_counters.pop(str(device), None)
+
+
+def dropout_counter_ptr(device):
+    c = _device_counters.get(str(device))
+    return None if c is None else c[1].data_ptr()

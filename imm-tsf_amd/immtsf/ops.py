@@ -74,9 +74,9 @@ def _bytes(n, dev):
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev)
 
 
-def make_cfg(B, N, T, Cc, d_m, d, H, precision, training, p_drop, kappa, seed):
+def make_cfg(B, N, T, Cc, d_m, d, H, precision, training, p_drop, kappa, seed, device=None):
     return FusionCfg(B, N, T, Cc, d_m, d, H, precision, 1 if training else 0, float(p_drop), float(kappa),
-                     int(seed) & 0xFFFFFFFFFFFFFFFF)
+                     int(seed) & 0xFFFFFFFFFFFFFFFF, None if device is None else config.dropout_counter_ptr(device))
 
 
 # ------------------------------------------------------------------------------------------------ TTF_T2V_XAttn
@@ -91,7 +91,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         _need_gpu(notes, tau, *params)
         B, N, d_m = notes.shape
         d = params[0].numel()
-        cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed)
+        cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed, notes.device)
         ws = _bytes(lib.immtsf_ttf_t2v_xattn_workspace_bytes(C.byref(cfg)), notes.device)
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)
@@ -134,7 +134,7 @@ class TTFRecAvgFn(torch.autograd.Function):
         B, N, d_m = notes.shape
         T = t_hat.shape[1]
         d = params[3].numel()      # ln_w
-        cfg = make_cfg(B, N, T, 0, d_m, d, 1, precision, training, p_drop, 0.0, seed)
+        cfg = make_cfg(B, N, T, 0, d_m, d, 1, precision, training, p_drop, 0.0, seed, notes.device)
         ws = _bytes(lib.immtsf_ttf_recavg_workspace_bytes(C.byref(cfg)), notes.device)
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)
@@ -176,7 +176,7 @@ class MMFXAttnAddFn(torch.autograd.Function):
         _need_gpu(Y, E, M_u8, *params)
         B, T, Cc = Y.shape
         d = E.shape[2]
-        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed)
+        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed, Y.device)
         ws = _bytes(lib.immtsf_mmf_xattn_add_workspace_bytes(C.byref(cfg)), Y.device)
         out = torch.empty_like(Y)
         ps = _struct(XAddParams, params)
@@ -214,7 +214,7 @@ class MMFGRAddFn(torch.autograd.Function):
         _need_gpu(Y, E, M_u8, *params)
         B, T, Cc = Y.shape
         d = E.shape[2]
-        cfg = make_cfg(B, 0, T, Cc, 0, d, 1, precision, training, p_drop, 0.0, seed)
+        cfg = make_cfg(B, 0, T, Cc, 0, d, 1, precision, training, p_drop, 0.0, seed, Y.device)
         ws = _bytes(lib.immtsf_mmf_gr_add_workspace_bytes(C.byref(cfg), hidden), Y.device)
         out = torch.empty_like(Y)
         ps = _struct(GRParams, params)
@@ -293,7 +293,7 @@ class MaskedMSEFn(torch.autograd.Function):
     divide, so every rank sees the loss of the global batch and sum-reduced gradients equal the single-process ones."""
 
     @staticmethod
-    def forward(ctx, pred, truth, mask, group):
+    def forward(ctx, pred, truth, mask, group, global_cnt):
         lib = _lib.load()
         pred, truth, mask = _c(pred), _c(truth), _c(mask)
         _need_gpu(pred, truth, mask)
@@ -303,12 +303,15 @@ class MaskedMSEFn(torch.autograd.Function):
         sums = buf[:2]
         check(lib.immtsf_masked_mse_sums(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]),
                                          ptr(buf[2]), stream_ptr()), "masked_mse_sums")
-        if group is not None:
+        cnt = sums[1]
+        if global_cnt is not None:
+            cnt = _c(global_cnt.to(torch.float32))
+        elif group is not None:
             import torch.distributed as dist
             dist.all_reduce(sums, group=group)
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
         dpred = torch.empty_like(pred)
-        check(lib.immtsf_masked_mse_finish(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]), ptr(loss),
+        check(lib.immtsf_masked_mse_finish(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(cnt), ptr(loss),
                                            ptr(dpred), 1.0, stream_ptr()), "masked_mse_finish")
         ctx.save_for_backward(dpred)
         return loss
@@ -316,11 +319,16 @@ class MaskedMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dpred,) = ctx.saved_tensors
-        return dpred * dloss, None, None, None
+        return dpred * dloss, None, None, None, None
 
 
-def masked_mse(pred, truth, mask, group=None):
-    return MaskedMSEFn.apply(pred, truth, mask, group)
+def masked_mse(pred, truth, mask, group=None, global_cnt=None):
+    """Data parallel, two ways to get single-process-equivalent gradients:
+      group=...       all-reduce the per-variable (sum, count) inside the call (loss = global loss on every rank);
+      global_cnt=...  per-variable observation counts of the GLOBAL batch, reduced once when the batch is built
+                      (they depend on the mask only): no collective inside the step, the returned value is this
+                      rank's share of the global loss (the shares add up to it)."""
+    return MaskedMSEFn.apply(pred, truth, mask, group, global_cnt)
 
 
 def dropout_keep_mask(seed: int, site: int, n: int, p: float, device) -> torch.Tensor:

@@ -30,7 +30,7 @@ def shard_range(n_items: int, rank: int, world: int):
 class FlatTrainer:
     def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
-                 sink_buckets: Sequence[int] = ()):
+                 sink_buckets: Sequence[int] = (), device_step: bool = False):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
         sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks)."""
         self.group = group
@@ -68,6 +68,12 @@ class FlatTrainer:
                 off += k
             self.ranges.append((start, off))
         self.sink_buckets = set(sink_buckets)
+        # device_step: Adam's step number (and the dropout key offset) live in device memory so that a captured
+        # hipGraph advances them on every replay (immtsf.config.enable_device_counters)
+        self.device_step = device_step and dev.type == "cuda"
+        if self.device_step:
+            from . import config
+            self.step_dev, self.drop_dev = config.enable_device_counters(dev)
         self.world = 1
         if group is not None:
             import torch.distributed as dist
@@ -117,7 +123,14 @@ class FlatTrainer:
 
     def step(self):
         self.step_count += 1
-        if self.flat_param.is_cuda:
+        if self.flat_param.is_cuda and self.device_step:
+            lib = _lib.load()
+            _lib.check(lib.immtsf_adam_step_dev(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                                _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0],
+                                                self.betas[1], self.eps, self.wd, _lib.ptr(self.step_dev), self.max_norm,
+                                                _lib.ptr(self.norm_scratch), _lib.ptr(self.drop_dev), _lib.stream_ptr()),
+                       "adam_step_dev")
+        elif self.flat_param.is_cuda:
             lib = _lib.load()
             _lib.check(lib.immtsf_adam_step(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
                                             _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0],

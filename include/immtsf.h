@@ -51,6 +51,8 @@ typedef struct immtsf_fusion_cfg {
     float p_drop;
     float kappa;
     uint64_t seed;
+    const uint64_t* seed_step_dev; /* optional device counter added to `seed` when the kernels run (NULL = 0): a captured
+                                      hipGraph bumps it once per replay so every step draws fresh dropout masks */
 } immtsf_fusion_cfg;
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)
@@ -216,6 +218,11 @@ int immtsf_dropout_mask(uint64_t seed, uint64_t site, uint64_t n, float p_drop, 
 int immtsf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
                      float* norm_scratch, immtsf_stream_t stream);
+/* graph-friendly form: *step_dev (device int64, >= 0) is incremented by the kernel and used as the step number;
+ * dropout_step_dev (device uint64, may be NULL) is incremented too (see immtsf_fusion_cfg.seed_step_dev). */
+int immtsf_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm,
+                         float* norm_scratch, uint64_t* dropout_step_dev, immtsf_stream_t stream);
 
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[8*max] = (layout,

@@ -1,0 +1,150 @@
+"""Data-parallel path on CPU (gloo, world_size 2): entity sharding + globally-normalised masked MSE + bucketed
+gradient all-reduce (immtsf.train.FlatTrainer) must reproduce the single-process full-batch gradient and the same
+clip+Adam update (sum of shard grads == full-batch grads to 1e-5).  The arithmetic inside each rank is
+the CPU oracle (the HIP ops need a GPU); what is under test is the distributed logic that bench.py uses for N>1."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(seed, B, N, T, C, d_m):
+    g = torch.Generator().manual_seed(seed)
+    notes = torch.randn(B, N, d_m, generator=g)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    tau = torch.rand(B, N, generator=g) * 24
+    for b in range(B):
+        notes[b, int(lengths[b]):] = 0
+        tau[b, int(lengths[b]):] = 0
+    t_hat = torch.sort(torch.rand(B, T, generator=g), 1).values
+    Y = torch.randn(B, T, C, generator=g)
+    truth = torch.randn(B, T, C, generator=g)
+    mask = (torch.rand(B, T, C, generator=g) < 0.6).float()
+    mask[:, 0, 0] = 1
+    return notes, tau, t_hat, Y, truth, mask
+
+
+def _loss(params, batch, cnt_global, H):
+    from oracle import fusion_ref as R
+    notes, tau, t_hat, Y, truth, mask = batch
+    out = R.fusion_forward("TTF_T2V_XAttn", "MMF_XAttn_Add", params, notes, tau, t_hat, Y, H=H, kappa=0.5, expand_T=False)
+    es, _ = R.masked_err_sums(truth, out, mask)
+    return (es / (cnt_global + 1e-8)).sum() / torch.count_nonzero(cnt_global)
+
+
+def _params(z):
+    from oracle import fusion_ref as R
+    return {k: torch.nn.Parameter(v.clone()) for k, v in R.params_from_npz(z).items()}
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from immtsf.train import FlatTrainer, shard_range
+    z = np.load(os.path.join(GOLDEN, "fusion_TTF_T2V_XAttn_MMF_XAttn_Add_tiny_h2.npz"))
+    H = int(z["H"])
+    params = _params(z)
+    full = _batch(7, 6, 5, 6, 3, 16)
+    lo, hi = shard_range(6, rank, world)
+    shard = tuple(t[lo:hi] for t in full)
+    cnt = shard[5].reshape(-1, 3).sum(0)
+    dist.all_reduce(cnt)                              # counts of the global batch: data only, reduced once
+    ttf = [p for k, p in params.items() if k.startswith("ttf.")]
+    mmf = [p for k, p in params.items() if k.startswith("mmf.")]
+    tr = FlatTrainer([mmf, ttf], lr=1e-2, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD)
+    tr.zero_grad()
+    loss = _loss(params, shard, cnt, H)
+    loss.backward()
+    tr.sync_grads()
+    g_dp = tr.flat_grad.clone()
+    loss_sum = loss.detach().clone()
+    dist.all_reduce(loss_sum)                         # the ranks' shares add up to the global loss
+    tr.step()
+    p_dp = tr.flat_param.clone()
+    if rank == 0:
+        # single-process reference on the full batch
+        ref = _params(z)
+        cnt_full = full[5].reshape(-1, 3).sum(0)
+        l_ref = _loss(ref, full, cnt_full, H)
+        l_ref.backward()
+        order = [k for k in ref if k.startswith("mmf.")] + [k for k in ref if k.startswith("ttf.")]
+        g_ref = torch.cat([ref[k].grad.reshape(-1) for k in order])
+        opt = torch.optim.Adam([ref[k] for k in order], lr=1e-2, weight_decay=1e-3)
+        torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)
+        opt.step()
+        p_ref = torch.cat([ref[k].detach().reshape(-1) for k in order])
+        q.put({"gerr": float((g_dp - g_ref).abs().max() / g_ref.abs().max()),
+               "perr": float((p_dp - p_ref).abs().max()),
+               "lerr": float((loss_sum - l_ref.detach()).abs()),
+               "views": all(params[k].data_ptr() >= tr.flat_param.data_ptr() for k in params)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_match_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["gerr"] < 1e-5, res
+    assert res["perr"] < 1e-6, res
+    assert res["lerr"] < 1e-6, res
+    assert res["views"]
+
+
+def test_shard_range_covers_everything_once():
+    from immtsf.train import shard_range
+    for n in (1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            seen = []
+            for r in range(w):
+                lo, hi = shard_range(n, r, w)
+                assert 0 <= lo <= hi <= n
+                seen += list(range(lo, hi))
+            assert seen == list(range(n))
+
+
+def test_flat_trainer_cpu_adam_matches_torch():
+    from immtsf.train import FlatTrainer
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    tr = FlatTrainer([a], lr=3e-3, weight_decay=0.0, max_norm=1.0)
+    opt = torch.optim.Adam(b, lr=3e-3)
+    for step in range(3):
+        tr.zero_grad()
+        opt.zero_grad()
+        (a[0].sin().sum() * 3 + (a[1] ** 2).sum()).backward()
+        (b[0].sin().sum() * 3 + (b[1] ** 2).sum()).backward()
+        torch.nn.utils.clip_grad_norm_(b, 1.0)
+        tr.sync_grads()
+        tr.step()
+        opt.step()
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, atol=1e-6), step

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
 // ---- dense attention rows: one wave per (b,h,l) row of length S ---------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ sc, float* __restrict__ A, int rows, int HL,
                                                                 int S, const unsigned char* __restrict__ live, DropCfg drop,
-                                                                uint64_t site) {
+                                                                uint64_t site, int causal_L) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float* p = sc + (size_t)row * S;
@@ -203,14 +203,16 @@ __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict
         for (int i = lane; i < S; i += 64) { p[i] = 0.f; a[i] = 0.f; }
         return;
     }
+    // causal_L > 0: TriangularCausalMask (utils/masking.py): query l = row % L may only see keys s <= l
+    const int Sv = causal_L > 0 ? min(S, (row % causal_L) + 1) : S;
     float m = -INFINITY;
-    for (int i = lane; i < S; i += 64) m = fmaxf(m, p[i]);
+    for (int i = lane; i < Sv; i += 64) m = fmaxf(m, p[i]);
     m = wave_max(m);
     float sum = 0.f;
-    for (int i = lane; i < S; i += 64) sum += expf(p[i] - m);
+    for (int i = lane; i < Sv; i += 64) sum += expf(p[i] - m);
     const float inv = 1.f / wave_sum(sum);
     for (int i = lane; i < S; i += 64) {
-        const float v = expf(p[i] - m) * inv;
+        const float v = (i < Sv) ? expf(p[i] - m) * inv : 0.f;
         p[i] = v;
         a[i] = v * dropout_scale(drop, site, (uint64_t)row * S + i);
     }
@@ -264,10 +266,11 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
 }
 
 int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, const unsigned char* live, DropCfg drop,
-                            uint64_t site, hipStream_t s) {
+                            uint64_t site, int causal, hipStream_t s) {
     const int rows = B * H * L;
     if (rows <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, sc, A, rows, H * L, S, live, drop, site);
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, sc, A, rows, H * L, S, live, drop, site,
+                       causal ? L : 0);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

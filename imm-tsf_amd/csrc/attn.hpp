@@ -19,7 +19,7 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
 // rows = B*H*L, each of length S.  In place on `sc`: P = softmax(sc) (0 where !live[b]); A = P*dropscale
 // written to `A` (may alias sc when drop.p == 0).
 int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, const unsigned char* live, DropCfg drop,
-                            uint64_t site, hipStream_t s);
+                            uint64_t site, int causal, hipStream_t s);
 // dA -> dS in place: dP = dA*dropscale; dS = P*(dP - sum(P*dP))
 int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int S, DropCfg drop, uint64_t site,
                             hipStream_t s);

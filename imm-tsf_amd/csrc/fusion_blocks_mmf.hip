@@ -113,7 +113,7 @@ int immtsf_mmf_xattn_add_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
         batch_bh(g, B, H, (long)T * d, hd, (long)T * d, hd, (long)H * TT2, TT2);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    CHECK(launch_softmax_rows_fwd(w.Pm, w.Am, B, H, T, T, M_txt, drop, SITE_XADD_ATTN, s));
+    CHECK(launch_softmax_rows_fwd(w.Pm, w.Am, B, H, T, T, M_txt, drop, SITE_XADD_ATTN, 0, s));
     {   // O_h = A V_h
         GemmArgs g = gemm_args(T, hd, T, T, d, d);
         set_problem(g, 0, w.Am, w.Vi, w.O, nullptr);

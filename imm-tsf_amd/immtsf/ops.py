@@ -285,6 +285,145 @@ def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W
                                    b2, W3, b3, T_bias)
 
 
+# ------------------------------------------------------------------------------------------------ layer primitives
+_ACT = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+
+
+def _gemm(layout, prec, A, lda, B, ldb, Cm, ldc, bias, M, N, K, alpha=1.0, accumulate=0, act=0):
+    lib = _lib.load()
+    check(lib.immtsf_gemm(layout, prec, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, ptr(bias), M, N, K, alpha, accumulate, act,
+                          stream_ptr()), "gemm")
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMM (NT forward, NN data gradient, TN weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, precision):
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        W = _c(W)
+        _need_gpu(x2, W, b)
+        M, K = x2.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _gemm(0, precision, x2, K, W, K, y, N, b, M, N, K)
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias, ctx.precision, ctx.shape = b is not None, precision, x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        M, K = x2.shape
+        N = W.shape[0]
+        dy2 = dy.contiguous().reshape(M, N)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            _gemm(1, ctx.precision, dy2, N, W, K, dx, K, None, M, K, N)
+            dx = dx.view(ctx.shape)
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+            _gemm(2, ctx.precision, dy2, N, x2, K, dW, K, None, N, K, M)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0)
+        return dx, dW, db, None
+
+
+def linear(x, W, b=None, precision=None):
+    return LinearFn.apply(x.float(), W, b, config.precision_code(precision))
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        lib = _lib.load()
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        _need_gpu(x2, gamma, beta)
+        rows, d = x2.shape
+        xhat = torch.empty_like(x2)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        z = torch.empty_like(x2)
+        check(lib.immtsf_layernorm_forward(ptr(x2), rows, d, ptr(gamma), ptr(beta), float(eps), ptr(xhat), ptr(rstd), ptr(z),
+                                           0.0, 0, 0, stream_ptr()), "layernorm_forward")
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.shape = x.shape
+        return z.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib.load()
+        xhat, rstd, gamma = ctx.saved_tensors
+        rows, d = xhat.shape
+        g = dz.contiguous().reshape(rows, d).clone()
+        dx = torch.empty_like(xhat)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        scratch = torch.empty(32 * d, dtype=torch.float32, device=dz.device)
+        check(lib.immtsf_layernorm_backward(ptr(g), rows, d, ptr(gamma), ptr(xhat), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                            ptr(scratch), 0.0, 0, 0, stream_ptr()), "layernorm_backward")
+        return dx.view(ctx.shape), dgamma, dbeta, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x.float(), gamma, beta, eps)
+
+
+class FullAttentionFn(torch.autograd.Function):
+    """softmax(scale * Q K^T) V per (batch, head) for (B,L,H,E)/(B,S,H,E)/(B,S,H,D) tensors
+    (layers/SelfAttention_Family.py:50-77): batched MFMA GEMMs + fused softmax/dropout rows."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, p_drop, training, seed, site, causal, precision):
+        lib = _lib.load()
+        q, k, v = _c(q), _c(k), _c(v)
+        _need_gpu(q, k, v)
+        B, L, H, E = q.shape
+        S, D = k.shape[1], v.shape[3]
+        dev = q.device
+        P = torch.empty(B, H, L, S, dtype=torch.float32, device=dev)
+        check(lib.immtsf_gemm_batched(0, precision, ptr(q), H * E, L * H * E, E, ptr(k), H * E, S * H * E, E, ptr(P), S,
+                                      H * L * S, L * S, B, H, L, S, E, float(scale), stream_ptr()), "qk^T")
+        p = float(p_drop) if training else 0.0
+        A = torch.empty_like(P) if p > 0 else P
+        check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), B, H, L, S, None, p, seed, site, 1 if causal else 0,
+                                              stream_ptr()), "softmax")
+        out = torch.empty(B, L, H, D, dtype=torch.float32, device=dev)
+        check(lib.immtsf_gemm_batched(1, precision, ptr(A), S, H * L * S, L * S, ptr(v), H * D, S * H * D, D, ptr(out), H * D,
+                                      L * H * D, D, B, H, L, D, S, 1.0, stream_ptr()), "a.v")
+        ctx.save_for_backward(q, k, v, P, A)
+        ctx.cfg = (scale, p, seed, site, precision)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, P, A = ctx.saved_tensors
+        scale, p, seed, site, precision = ctx.cfg
+        B, L, H, E = q.shape
+        S, D = k.shape[1], v.shape[3]
+        dout = dout.contiguous()
+        dA = torch.empty_like(P)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        st = stream_ptr()
+        # dA = dO V^T ; dV = A^T dO
+        check(lib.immtsf_gemm_batched(0, precision, ptr(dout), H * D, L * H * D, D, ptr(v), H * D, S * H * D, D, ptr(dA), S,
+                                      H * L * S, L * S, B, H, L, S, D, 1.0, st), "dA")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(A), S, H * L * S, L * S, ptr(dout), H * D, L * H * D, D, ptr(dv), H * D,
+                                      S * H * D, D, B, H, S, D, L, 1.0, st), "dV")
+        check(lib.immtsf_softmax_rows_backward(ptr(dA), ptr(P), B, H, L, S, p, seed, site, st), "softmax_bwd")
+        # dQ = scale dS K ; dK = scale dS^T Q
+        check(lib.immtsf_gemm_batched(1, precision, ptr(dA), S, H * L * S, L * S, ptr(k), H * E, S * H * E, E, ptr(dq), H * E,
+                                      L * H * E, E, B, H, L, E, S, float(scale), st), "dQ")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(dA), S, H * L * S, L * S, ptr(q), H * E, L * H * E, E, ptr(dk), H * E,
+                                      S * H * E, E, B, H, S, E, L, float(scale), st), "dK")
+        return dq, dk, dv, None, None, None, None, None, None, None
+
+
+def full_attention(q, k, v, scale, p_drop=0.0, training=False, seed=0, site=16, causal=False, precision=None):
+    return FullAttentionFn.apply(q.float(), k.float(), v.float(), scale, p_drop, training, seed, site, causal,
+                                 config.precision_code(precision))
+
+
 # ------------------------------------------------------------------------------------------------ loss
 class MaskedMSEFn(torch.autograd.Function):
     """compute_error(truth, pred, mask, "MSE", "mean") (lib/evaluation.py:17-62) with a fused backward.

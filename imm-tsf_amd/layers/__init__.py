@@ -1,0 +1,3 @@
+"""Drop-in `layers` package: the attention / embedding layers the configured backbones use,
+same class names, constructor and forward signatures and state_dict keys as the reference, contractions on the HIP
+MFMA GEMM."""

@@ -1,0 +1,75 @@
+"""TimesNet backbone (reference models/TimesNet.py:9-152): DataEmbedding(2C+1 -> d_model) on [value; mask; time],
+FFT period selection, 2-D Inception convolutions per period, adaptive aggregation.  Same signature/state_dict;
+DataEmbedding's token convolution and the two Linear maps run on the HIP GEMM, the Inception convs on MIOpen."""
+import torch
+import torch.fft
+import torch.nn as nn
+import torch.nn.functional as F
+
+from immtsf.ops import layer_norm, linear
+from layers.Conv_Blocks import Inception_Block_V1
+from layers.Embed import DataEmbedding
+from models._common import pad_history, plain_instance_norm
+
+
+def FFT_for_Period(x, k=2):
+    xf = torch.fft.rfft(x, dim=1)
+    amp = xf.abs()
+    freq = amp.mean(0).mean(-1)
+    freq[0] = 0
+    top = torch.topk(freq, k).indices.detach().cpu().numpy()      # host sync, as in the reference (:13-16)
+    return x.shape[1] // top, amp.mean(-1)[:, top]
+
+
+class TimesBlock(nn.Module):
+    def __init__(self, configs):
+        super().__init__()
+        self.seq_len, self.pred_len, self.k = configs.input_len, configs.pred_len, configs.top_k
+        self.conv = nn.Sequential(Inception_Block_V1(configs.d_model, configs.d_ff, num_kernels=configs.num_kernels),
+                                  nn.GELU(),
+                                  Inception_Block_V1(configs.d_ff, configs.d_model, num_kernels=configs.num_kernels))
+
+    def forward(self, x):
+        B, T, N = x.size()
+        total = self.seq_len + self.pred_len
+        periods, weight = FFT_for_Period(x, self.k)
+        res = []
+        for period in periods:
+            period = int(period)
+            length = total if total % period == 0 else (total // period + 1) * period
+            out = F.pad(x, (0, 0, 0, length - total)) if length != total else x
+            out = out.reshape(B, length // period, period, N).permute(0, 3, 1, 2).contiguous()
+            out = self.conv(out).permute(0, 2, 3, 1).reshape(B, -1, N)
+            res.append(out[:, :total, :])
+        res = torch.stack(res, dim=-1)
+        w = F.softmax(weight, dim=1).unsqueeze(1).unsqueeze(1)
+        return (res * w).sum(-1) + x
+
+
+class TimesNet(nn.Module):
+    def __init__(self, configs):
+        super().__init__()
+        self.configs = configs
+        self.input_len = self.seq_len = configs.input_len
+        self.pred_len = configs.pred_len
+        print("seq len:", self.seq_len, self.pred_len)
+        self.model = nn.ModuleList([TimesBlock(configs) for _ in range(configs.e_layers)])
+        self.enc_embedding = DataEmbedding(2 * configs.enc_in + 1, configs.d_model, configs.embed, configs.freq, configs.dropout)
+        self.layer = configs.e_layers
+        self.layer_norm = nn.LayerNorm(configs.d_model)
+        self.predict_linear = nn.Linear(self.seq_len + self.pred_len, self.pred_len + self.seq_len)
+        self.projection = nn.Linear(configs.d_model, configs.c_out, bias=True)
+        self.zeros_pad = torch.zeros(configs.batch_size, max(configs.input_len, configs.pred_len), configs.enc_in).to(configs.device)
+
+    def forecasting(self, tp_to_predict, observed_data, observed_tp, observed_mask):
+        tp_to_predict, data, tp, mask, Lp = pad_history(self.zeros_pad, self.input_len, self.pred_len, tp_to_predict,
+                                                        observed_data, observed_tp, observed_mask)
+        x, means, stdev = plain_instance_norm(data)
+        enc = self.enc_embedding(torch.cat([x, mask, tp.unsqueeze(-1)], dim=-1))             # (B, L, d_model)
+        enc = torch.cat([enc, tp_to_predict.unsqueeze(-1).expand(-1, -1, enc.size(-1))], dim=1)
+        enc = linear(enc.permute(0, 2, 1), self.predict_linear.weight, self.predict_linear.bias).permute(0, 2, 1)
+        for i in range(self.layer):
+            enc = layer_norm(self.model[i](enc), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        dec = linear(enc, self.projection.weight, self.projection.bias)
+        dec = dec * stdev[:, 0, :].unsqueeze(1) + means[:, 0, :].unsqueeze(1)
+        return dec[:, -self.pred_len:, :][:, :Lp, :]

@@ -116,7 +116,7 @@ class tPatchGNN(nn.Module):
             nn.Linear(enc_dim + args.te_dim, args.hid_dim), nn.ReLU(inplace=True),
             nn.Linear(args.hid_dim, args.hid_dim), nn.ReLU(inplace=True),
             nn.Linear(args.hid_dim, 1))
-        # "hip": fused TE+TTCN kernel on the GPU; "torch": eager ops (any device)
+        # "auto"/"hip": fused TE+TTCN HIP kernel; "torch": explicit opt-in to the eager formulation (CPU baseline, tests)
         self.patch_encoder = getattr(args, "immtsf_patch_encoder", "auto")
 
     # ---- time-aware patch encoder ---------------------------------------------------------------
@@ -134,8 +134,7 @@ class tPatchGNN(nn.Module):
 
     def _encode_patches(self, x, tt, mask):
         """x, tt, mask: (P, L) -> (P, hid_dim) patch embedding incl. the patch-non-empty flag."""
-        use_hip = self.patch_encoder == "hip" or (self.patch_encoder == "auto" and x.is_cuda)
-        if use_hip:
+        if self.patch_encoder != "torch":      # "auto"/"hip": the fused kernel (raises on CPU tensors: no silent fallback)
             from immtsf.ops import ttcn_patch_encode
             lin = self.Filter_Generators
             h = ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,

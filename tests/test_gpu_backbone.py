@@ -102,3 +102,30 @@ def test_ttcn_benchmark_dims_vs_eager(L):
     bad = {k: _rel(g_hip[k], p.grad, floor=1e-2 * gmax) for k, p in m.named_parameters() if p.grad is not None}
     bad = {k: v for k, v in bad.items() if v > 3e-4}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["PatchTST", "DLinear", "TimesNet"])
+def test_backbone_wrappers_vs_reference_golden(name):
+    """a15: Model(args).forecasting(tp_to_predict, observed_data, observed_tp, observed_mask) -> (B, Lp, C) for the
+    other configured backbones, history shorter than input_len (padding path), B < args.batch_size."""
+    dev = _dev()
+    import importlib
+    z = np.load(os.path.join(GOLDEN, f"model_{name.lower()}.npz"))
+    cfg = types.SimpleNamespace(input_len=8, pred_len=6, d_model=8, d_ff=16, n_heads=2, e_layers=1, dropout=0.0, factor=5,
+                                activation="gelu", enc_in=3, c_out=3, batch_size=4, device=str(dev), moving_avg=5, top_k=2,
+                                num_kernels=2, embed="fixed", freq="h")
+    m = getattr(importlib.import_module(f"models.{name}"), name)(cfg).to(dev)
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}, strict=True)
+    m.train()
+    out = m.forecasting(*[torch.from_numpy(z[k]).to(dev) for k in ("tpp", "data", "tp", "mask")])
+    assert out.shape == z["out"].shape
+    assert _rel(out, torch.from_numpy(z["out"])) < 1e-4
+    (out * torch.from_numpy(z["upstream"]).to(dev)).sum().backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("g."))
+    bad = {}
+    for k, p in m.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        e = _rel(g, torch.from_numpy(z["g." + k]), floor=1e-2 * gmax)
+        if e > 3e-4:
+            bad[k] = e
+    assert not bad, bad

@@ -1,0 +1,137 @@
+"""GPU parity of the layers/ mirror against golden vectors captured from the real reference:
+FullAttention, AttentionLayer, Encoder/EncoderLayer (gelu, d_ff), PatchEmbedding, DataEmbedding.  fp32 mode,
+1e-4 outputs / 2e-4 gradients relative to max."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _z(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.asarray(a)).to(dev)
+
+
+def _rel(a, b, floor=1e-3):
+    a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor))
+
+
+def test_full_attention():
+    dev = _dev()
+    from layers.SelfAttention_Family import FullAttention
+    z = _z("layer_full_attention")
+    q, k, v = [_t(z[n], dev).requires_grad_(True) for n in ("q", "k", "v")]
+    fa = FullAttention(False, attention_dropout=0.0)
+    o, attn = fa(q, k, v, None)
+    assert attn is None and _rel(o, z["out"]) < 1e-4
+    (o * _t(z["upstream"], dev)).sum().backward()
+    assert _rel(q.grad, z["gq"]) < 2e-4 and _rel(k.grad, z["gk"]) < 2e-4 and _rel(v.grad, z["gv"]) < 2e-4
+
+
+def test_full_attention_causal_and_dropout_vs_torch():
+    dev = _dev()
+    from immtsf import config, ops
+    from layers.SelfAttention_Family import FullAttention
+    g = torch.Generator().manual_seed(0)
+    B, L, H, E = 3, 37, 2, 24
+    q, k, v = [torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True) for _ in range(3)]
+    fa = FullAttention(True, attention_dropout=0.0).to(dev)
+    o, _ = fa(q, k, v, None)
+    s = torch.einsum("blhe,bshe->bhls", q, k) / E ** 0.5
+    s = s.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool, device=dev), 1), float("-inf"))
+    ref = torch.einsum("bhls,bshd->blhd", torch.softmax(s, -1), v)
+    assert _rel(o, ref.detach().cpu()) < 1e-4
+    # dropout: export the mask the kernel used and replay it in torch
+    config.manual_seed(5)
+    fd = FullAttention(False, attention_dropout=0.3).to(dev).train()
+    o2, _ = fd(q, k, v, None)
+    config.manual_seed(5)
+    seed = config.next_seed()
+    keep = ops.dropout_keep_mask(seed, fd.site, B * H * L * L, 0.3, dev).view(B, H, L, L).float()
+    a = torch.softmax(torch.einsum("blhe,bshe->bhls", q, k) / E ** 0.5, -1) * keep / 0.7
+    ref2 = torch.einsum("bhls,bshd->blhd", a, v)
+    assert _rel(o2, ref2.detach().cpu()) < 1e-4
+    up = torch.randn(o2.shape, generator=g).to(dev)
+    gq = torch.autograd.grad((o2 * up).sum(), q, retain_graph=True)[0]
+    gq_ref = torch.autograd.grad((ref2 * up).sum(), q)[0]
+    assert _rel(gq, gq_ref.cpu()) < 2e-4
+
+
+def _load(mod, z):
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
+    missing = mod.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+
+
+def test_attention_layer():
+    dev = _dev()
+    from layers.SelfAttention_Family import AttentionLayer, FullAttention
+    z = _z("layer_attention_layer")
+    al = AttentionLayer(FullAttention(False, attention_dropout=0.0), 8, int(z["H"])).to(dev)
+    _load(al, z)
+    x = _t(z["x"], dev).requires_grad_(True)
+    o, _ = al(x, x, x, None)
+    assert _rel(o, z["out"]) < 1e-4
+    (o * _t(z["upstream"], dev)).sum().backward()
+    assert _rel(x.grad, z["gx"]) < 2e-4
+    for k, p in al.named_parameters():
+        assert _rel(p.grad, z["g." + k]) < 2e-4, k
+
+
+def test_encoder_stack():
+    dev = _dev()
+    from layers.SelfAttention_Family import AttentionLayer, FullAttention
+    from layers.Transformer_EncDec import Encoder, EncoderLayer
+    z = _z("layer_encoder")
+    H = int(z["H"])
+    enc = Encoder([EncoderLayer(AttentionLayer(FullAttention(False, attention_dropout=0.0), 8, H), 8, 16, dropout=0.0,
+                                activation="gelu") for _ in range(2)], norm_layer=torch.nn.LayerNorm(8)).to(dev)
+    _load(enc, z)
+    x = _t(z["x"], dev).requires_grad_(True)
+    o, attns = enc(x)
+    assert len(attns) == 2 and _rel(o, z["out"]) < 1e-4
+    (o * _t(z["upstream"], dev)).sum().backward()
+    assert _rel(x.grad, z["gx"]) < 3e-4
+    for k, p in enc.named_parameters():
+        assert _rel(p.grad, z["g." + k]) < 3e-4, k
+
+
+def test_patch_embedding():
+    dev = _dev()
+    from layers.Embed import PatchEmbedding
+    z = _z("layer_patch_embedding")
+    pe = PatchEmbedding(8, int(z["patch_len"]), int(z["stride"]), int(z["stride"]), 0.0).to(dev)
+    pe.value_embedding.weight.data = _t(z["w"], dev)
+    x = _t(z["x"], dev).requires_grad_(True)
+    o, n_vars = pe(x)
+    assert n_vars == int(z["n_vars"]) and _rel(o, z["out"]) < 1e-4
+    (o * _t(z["upstream"], dev)).sum().backward()
+    assert _rel(x.grad, z["gx"]) < 2e-4 and _rel(pe.value_embedding.weight.grad, z["gw"]) < 2e-4
+
+
+def test_data_embedding():
+    dev = _dev()
+    from layers.Embed import DataEmbedding
+    z = _z("layer_data_embedding")
+    de = DataEmbedding(5, 8, dropout=0.0).to(dev)
+    de.value_embedding.tokenConv.weight.data = _t(z["w"], dev)
+    x = _t(z["x"], dev).requires_grad_(True)
+    o = de(x, None)
+    assert _rel(o, z["out"]) < 1e-4
+    (o * _t(z["upstream"], dev)).sum().backward()
+    assert _rel(x.grad, z["gx"]) < 2e-4 and _rel(de.value_embedding.tokenConv.weight.grad, z["gw"]) < 2e-4

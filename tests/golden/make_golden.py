@@ -357,9 +357,38 @@ def gen_tpatchgnn():
     save("model_tpatchgnn", **arrs)
 
 
+def gen_models():
+    """PatchTST / DLinear / TimesNet forecasting (eval-equivalent: dropout 0) on a short ragged history."""
+    _install_shims()
+    g = torch.Generator().manual_seed(51)
+    B, L, Lp, K = 3, 6, 4, 3
+    data = torch.randn(B, L, K, generator=g)
+    mask = (torch.rand(B, L, K, generator=g) < 0.7).float()
+    data = data * mask
+    tp = torch.sort(torch.rand(B, L, generator=g), 1).values
+    tpp = torch.sort(torch.rand(B, Lp, generator=g), 1).values
+    base = dict(input_len=8, pred_len=6, d_model=8, d_ff=16, n_heads=2, e_layers=1, dropout=0.0, factor=5,
+                activation="gelu", enc_in=K, c_out=K, batch_size=4, device="cpu", moving_avg=5, top_k=2, num_kernels=2,
+                embed="fixed", freq="h")
+    for name in ["PatchTST", "DLinear", "TimesNet"]:
+        mod = importlib.import_module(f"models.{name}")
+        torch.manual_seed(53)
+        m = getattr(mod, name)(types.SimpleNamespace(**base))
+        m.train()
+        out = m.forecasting(tpp, data.clone(), tp, mask)
+        up = torch.randn(out.shape, generator=g)
+        (out * up).sum().backward()
+        arrs = dict(data=_np(data), mask=_np(mask), tp=_np(tp), tpp=_np(tpp), out=_np(out), upstream=_np(up))
+        for k, v in m.state_dict().items():
+            arrs[f"p.{k}"] = _np(v)
+        for k, p_ in m.named_parameters():
+            arrs[f"g.{k}"] = _np(p_.grad) if p_.grad is not None else np.zeros(tuple(p_.shape), np.float32)
+        save(f"model_{name.lower()}", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["fusion", "loss", "layers", "tpatchgnn"]
+    which = sys.argv[1:] or ["fusion", "loss", "layers", "tpatchgnn", "models"]
     if "fusion" in which:
         gen_fusion(_ref_modules())
     if "loss" in which:
@@ -368,3 +397,5 @@ if __name__ == "__main__":
         gen_layers()
     if "tpatchgnn" in which:
         gen_tpatchgnn()
+    if "models" in which:
+        gen_models()

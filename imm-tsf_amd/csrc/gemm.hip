@@ -343,6 +343,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
                 } else {
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = gelu_erf(v);
+                    if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col] <= 0.f) v = 0.f;   // relu backward mask
                     if (g.accumulate) v += *dst;
                     *dst = v;
                 }
@@ -448,7 +449,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
-    const bool can_split = !g.accumulate && g.act == 0 && g.nbatch <= 1 && g.ldc == g.N && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = !g.accumulate && g.act == 0 && !g.relu_ref && g.nbatch <= 1 && g.ldc == g.N && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     if (can_split) {
         if (g_splitk > 0) splits = g_splitk;

@@ -39,6 +39,9 @@ struct GemmArgs {
     // TN only: when p[i].bias_grad != null the B operand gets a virtual all-ones column N, whose result
     // (= column sums of A over the reduction index, i.e. the bias gradient) is written to bias_grad[m].
     int ones_col;
+    // optional relu-backward mask: results whose relu_ref[m*ld_ref + n] <= 0 are zeroed (relu_ref = forward output)
+    const float* relu_ref;
+    int ld_ref;
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

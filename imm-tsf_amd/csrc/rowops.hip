@@ -121,17 +121,17 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
                                                             const int* __restrict__ total, int d_tau,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             const float* __restrict__ dfeat, int ld,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, int max_rows) {
     __shared__ float red[2][4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tx, slab = blockIdx.y;
-    const int M = *total, rps = (M + kSlabs - 1) / kSlabs;
+    const int M = total ? *total : max_rows, rps = (M + kSlabs - 1) / kSlabs;
     const int r0 = slab * rps, r1 = min(M, r0 + rps);
     float aw = 0.f, ab = 0.f;
     if (j < d_tau) {
         const float wj = j ? w[j - 1] : 0.f, bj = j ? b[j - 1] : 0.f;
         for (int r = r0 + ty; r < r1; r += 4) {
-            const float t = tau_pad[rowmap[r]];
+            const float t = tau_pad[rowmap ? rowmap[r] : r];
             float g = dfeat[(size_t)r * ld + j];
             if (j) g *= cosf(fmaf(wj, t, bj));
             aw = fmaf(g, t, aw);
@@ -334,9 +334,8 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
                         float* db, float* scratch, hipStream_t s) {
-    (void)max_rows;
     hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), kSlabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
-                       dfeat, ld, scratch);
+                       dfeat, ld, scratch, max_rows);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 256)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db);
     IMMTSF_LAUNCH_CHECK();

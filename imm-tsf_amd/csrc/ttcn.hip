@@ -1,5 +1,4 @@
-// tPatchGNN time-aware patch encoder on MI355X: LearnableTE + TTCN (reference models/tPatchGNN.py:176-195) fused
-// into one forward and one backward kernel.
+// tPatchGNN time-aware patch encoder on MI355X: LearnableTE + TTCN (reference models/tPatchGNN.py:176-195).
 //
 // Per patch p (one variable's observations inside one time patch; L padded slots, mask marks the real ones):
 //   te[l]   = [ws*t+bs ; sin(wp*t+bp)]                  (te_dim)         LearnableTE
@@ -7,397 +6,297 @@
 //   filt[l] = W3 relu(W2 relu(W1 X[l] + b1) + b2) + b3   (F*K, K = ttcn_dim)   Filter_Generators
 //   v[l,c]  = mask[l] ? filt[l,c] : -1e8 ; sm = softmax over l (per column c)
 //   out[k]  = relu( sum_f sum_l X[l,f] * sm[l, k*F+f] + T_bias[k] )
-// The reference materialises filt/sm as (P, L, F*K) tensors in HBM (45 MB at the benchmark shape) and runs ~20
-// eager kernels over them; here a workgroup keeps a patch in LDS/registers: thread c owns filter column c, streams
-// over l with an online softmax, and never writes filt.  An all-masked (empty) patch gives the uniform softmax over
-// identical pad rows, exactly like the reference.
 //
-// Backward recomputes the filter columns (cheap) and accumulates every parameter gradient in registers across the
-// patches a workgroup owns; each workgroup writes one partial gradient row, a column sum over workgroups finishes
-// (deterministic, no atomics).
+// Mapping to the machine: the three filter-generator layers are row-wise linear maps over ALL R = P*L observation
+// slots, so they (and their six backward products) run on the MFMA GEMM with the small weights zero-padded to
+// 16-byte-aligned leading dimensions (F->Fp, K->Kp, F*K->NCp); what is specific to TTCN -- the masked softmax over
+// each patch's slots and the meta-filter pooling -- is two HBM-bound streaming kernels over the (R, NCp) filter
+// tensor (softmax weights overwrite the logits in place, the backward overwrites them with d(logits)).
+// An all-masked (empty) patch gives the uniform softmax over identical pad rows, exactly like the reference.
 #include "ttcn.hpp"
-
-namespace {
-
-constexpr int LC = 32;        // observations processed per LDS chunk
-constexpr int KMAX = 64;      // ttcn_dim upper bound (registers hold one W3 row per thread; KP = 32 or 64 is the padded K)
-constexpr int FMAX = 32;      // 1 + te_dim upper bound
-
-struct TtcnDims { int P, L, F, K; };   // F = 1 + te_dim, K = ttcn_dim, filter columns = F*K
-
-// LDS layout shared by forward and backward: X[LC][F] | h1[LC][K] | h2[LC][K] | mk[LC] | misc
-// W1s/b1s/W2s/b2s: the two small filter-generator layers staged in LDS by stage_small()
-struct SmallW { const float *W1, *b1, *W2, *b2; };
-__device__ __forceinline__ SmallW stage_small(const TtcnDims& dm, const TtcnParams& w, float* dst) {
-    const int F = dm.F, K = dm.K;
-    float* W1s = dst;
-    float* b1s = W1s + K * F;
-    float* W2s = b1s + K;
-    float* b2s = W2s + K * K;
-    for (int i = threadIdx.x; i < K * F; i += blockDim.x) W1s[i] = w.W1[i];
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x) W2s[i] = w.W2[i];
-    for (int i = threadIdx.x; i < K; i += blockDim.x) { b1s[i] = w.b1[i]; b2s[i] = w.b2[i]; }
-    SmallW r; r.W1 = W1s; r.b1 = b1s; r.W2 = W2s; r.b2 = b2s;
-    return r;
-}
-__device__ __forceinline__ void encode_chunk(const TtcnDims& dm, int l0, int lcnt, const float* __restrict__ x,
-                                             const float* __restrict__ tt, const float* __restrict__ mask,
-                                             const TtcnParams& w, const SmallW& sw, float* X, float* h1, float* h2, float* mk) {
-    const int tid = threadIdx.x, nt = blockDim.x, F = dm.F, K = dm.K;
-    for (int i = tid; i < lcnt * F; i += nt) {
-        const int l = i / F, f = i % F;
-        const float t = tt[l0 + l];
-        float v;
-        if (f == 0) v = x[l0 + l];
-        else if (f == 1) v = fmaf(w.te_ws[0], t, w.te_bs[0]);
-        else v = sinf(fmaf(w.te_wp[f - 2], t, w.te_bp[f - 2]));
-        X[l * F + f] = v;
-    }
-    for (int l = tid; l < lcnt; l += nt) mk[l] = mask[l0 + l];
-    __syncthreads();
-    for (int i = tid; i < lcnt * K; i += nt) {
-        const int l = i / K, j = i % K;
-        float a = sw.b1[j];
-        for (int f = 0; f < F; ++f) a = fmaf(sw.W1[j * F + f], X[l * F + f], a);
-        h1[l * K + j] = fmaxf(a, 0.f);
-    }
-    __syncthreads();
-    for (int i = tid; i < lcnt * K; i += nt) {
-        const int l = i / K, j = i % K;
-        float a = sw.b2[j];
-        for (int q = 0; q < K; ++q) a = fmaf(sw.W2[j * K + q], h1[l * K + q], a);
-        h2[l * K + j] = fmaxf(a, 0.f);
-    }
-    __syncthreads();
-}
-
-// grid = P patches, block = ceil(F*K/64)*64 threads
-template <int KP, int MAXT>
-__global__ __launch_bounds__(MAXT) void ttcn_fwd_kernel(TtcnDims dm, const float* __restrict__ x, const float* __restrict__ tt,
-                                const float* __restrict__ mask, TtcnParams w, float* __restrict__ out,
-                                float* __restrict__ stat /* [P][3][F*K]: max, sum, contribution */) {
-    extern __shared__ float lds[];
-    const int F = dm.F, K = dm.K, NC = F * K, L = dm.L;
-    float* X = lds;
-    float* h1 = X + LC * F;
-    float* h2 = h1 + LC * K;
-    float* mk = h2 + LC * K;
-    float* contr = mk + LC;      // [NC]
-    const SmallW sw = stage_small(dm, w, contr + NC);
-    const int p = blockIdx.x, c = threadIdx.x;
-    const bool col = c < NC;
-    const int fc = col ? c % F : 0;
-    float w3[KP];
-    float b3c = 0.f;
-    if (col) {
-        b3c = w.b3[c];
-#pragma unroll
-        for (int j = 0; j < KP; ++j) w3[j] = (j < K) ? w.W3[(size_t)c * K + j] : 0.f;
-    }
-    float m = -INFINITY, s = 0.f, acc = 0.f;
-    const float* xp = x + (size_t)p * L;
-    const float* tp = tt + (size_t)p * L;
-    const float* mp = mask + (size_t)p * L;
-    for (int l0 = 0; l0 < L; l0 += LC) {
-        const int lcnt = min(LC, L - l0);
-        __syncthreads();
-        encode_chunk(dm, l0, lcnt, xp, tp, mp, w, sw, X, h1, h2, mk);
-        if (col) {
-            for (int l = 0; l < lcnt; ++l) {
-                float v = b3c;
-#pragma unroll
-                for (int j = 0; j < KP; ++j) if (j < K) v = fmaf(w3[j], h2[l * K + j], v);
-                const float mkv = mk[l];
-                v = v * mkv + (1.f - mkv) * (-1e8f);
-                const float mn = fmaxf(m, v);
-                const float sc = expf(m - mn), e = expf(v - mn);
-                s = s * sc + e;
-                acc = acc * sc + e * X[l * F + fc];
-                m = mn;
-            }
-        }
-    }
-    __syncthreads();
-    if (col) {
-        const float ct = acc / s;
-        contr[c] = ct;
-        float* st = stat + (size_t)p * 3 * NC;
-        st[c] = m; st[NC + c] = s; st[2 * NC + c] = ct;
-    }
-    __syncthreads();
-    if (c < K) {
-        float a = w.T_bias[c];
-        for (int f = 0; f < F; ++f) a += contr[c * F + f];
-        out[(size_t)p * K + c] = fmaxf(a, 0.f);
-    }
-}
-
-// persistent: grid = NB workgroups, each walks patches p = blockIdx.x, += gridDim.x and writes ONE partial gradient
-// row partial[blk][G].  Layout of a gradient row: W3[NC*K] | b3[NC] | W2[K*K] | b2[K] | W1[K*F] | b1[K] | Tb[K] |
-// ws, bs | wp[F-2] | bp[F-2]
-template <int KP, int MAXT>
-__global__ __launch_bounds__(MAXT) void ttcn_bwd_kernel(TtcnDims dm, const float* __restrict__ x, const float* __restrict__ tt,
-                                const float* __restrict__ mask, TtcnParams w, const float* __restrict__ out,
-                                const float* __restrict__ stat, const float* __restrict__ dout,
-                                float* __restrict__ partial, int G) {
-    extern __shared__ float lds[];
-    const int F = dm.F, K = dm.K, NC = F * K, L = dm.L;
-    float* X = lds;
-    float* h1 = X + LC * F;
-    float* h2 = h1 + LC * K;
-    float* mk = h2 + LC * K;
-    float* dpool = mk + LC;            // [K]
-    float* dfl = dpool + KMAX;         // [LC][NC]  dfilt of the chunk
-    float* smt = dfl + LC * NC;        // [LC][NC]  softmax weight * dpool of the chunk
-    float* dz2 = smt + LC * NC;        // [LC][K]
-    float* dz1 = dz2 + LC * K;         // [LC][K]
-    float* dX = dz1 + LC * K;          // [LC][F]
-    float* W3s = dX + LC * F;          // [NC][K] staged once per workgroup
-    const SmallW sw = stage_small(dm, w, W3s + NC * K);
-    for (int i = threadIdx.x; i < NC * K; i += blockDim.x) W3s[i] = w.W3[i];
-    const int c = threadIdx.x, nt = blockDim.x;
-    const bool col = c < NC;
-    const int fc = col ? c % F : 0, kc = col ? c / F : 0;
-    float w3[KP], gw3[KP];
-    float b3c = 0.f, gb3 = 0.f;
-#pragma unroll
-    for (int j = 0; j < KP; ++j) { w3[j] = 0.f; gw3[j] = 0.f; }
-    if (col) {
-        b3c = w.b3[c];
-#pragma unroll
-        for (int j = 0; j < KP; ++j) if (j < K) w3[j] = w.W3[(size_t)c * K + j];
-    }
-    // small-matrix gradient owners: thread i owns entries i, i+nt, ... of [W2 | b2 | W1 | b1 | Tb | te params]
-    const int nW2 = K * K, nW1 = K * F, nTE = 2 + 2 * (F - 2);
-    const int nsmall = nW2 + K + nW1 + K + K + nTE;
-    constexpr int SMAX = 8;            // entries per thread (nsmall <= SMAX * blockDim)
-    float gs[SMAX];
-#pragma unroll
-    for (int i = 0; i < SMAX; ++i) gs[i] = 0.f;
-
-    for (int p = blockIdx.x; p < dm.P; p += gridDim.x) {
-        const float* xp = x + (size_t)p * L;
-        const float* tp = tt + (size_t)p * L;
-        const float* mp = mask + (size_t)p * L;
-        const float* st = stat + (size_t)p * 3 * NC;
-        __syncthreads();
-        if (c < K) dpool[c] = (out[(size_t)p * K + c] > 0.f) ? dout[(size_t)p * K + c] : 0.f;
-        const float mc = col ? st[c] : 0.f, sc_ = col ? st[NC + c] : 1.f, ctc = col ? st[2 * NC + c] : 0.f;
-        for (int l0 = 0; l0 < L; l0 += LC) {
-            const int lcnt = min(LC, L - l0);
-            __syncthreads();
-            encode_chunk(dm, l0, lcnt, xp, tp, mp, w, sw, X, h1, h2, mk);
-            // filter column c over the chunk: softmax weight sm, d filt (-> W3/b3 gradient) and sm*dpool (-> dX)
-            if (col) {
-                const float dpk = dpool[kc];
-                for (int l = 0; l < lcnt; ++l) {
-                    float v = b3c;
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) if (j < K) v = fmaf(w3[j], h2[l * K + j], v);
-                    const float mkv = mk[l];
-                    v = v * mkv + (1.f - mkv) * (-1e8f);
-                    const float smd = expf(v - mc) / sc_ * dpk;
-                    const float df = smd * (X[l * F + fc] - ctc) * mkv;
-                    dfl[l * NC + c] = df;
-                    smt[l * NC + c] = smd;
-                    gb3 += df;
-#pragma unroll
-                    for (int j = 0; j < KP; ++j) if (j < K) gw3[j] = fmaf(df, h2[l * K + j], gw3[j]);
-                }
-            }
-            __syncthreads();
-            // pooling path: dX[l,f] = sum_k dpool[k] * sm[l, k*F+f]
-            for (int i = c; i < lcnt * F; i += nt) {
-                const int l = i / F, f = i % F;
-                float a = 0.f;
-                for (int k = 0; k < K; ++k) a += smt[l * NC + k * F + f];
-                dX[l * F + f] = a;
-            }
-            // dh2[l,j] = sum_c dfilt[l,c] W3[c,j] ; relu'
-            for (int i = c; i < lcnt * K; i += nt) {
-                const int l = i / K, j = i % K;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                int cc = 0;
-                for (; cc + 3 < NC; cc += 4) {
-                    a0 = fmaf(dfl[l * NC + cc], W3s[cc * K + j], a0);
-                    a1 = fmaf(dfl[l * NC + cc + 1], W3s[(cc + 1) * K + j], a1);
-                    a2 = fmaf(dfl[l * NC + cc + 2], W3s[(cc + 2) * K + j], a2);
-                    a3 = fmaf(dfl[l * NC + cc + 3], W3s[(cc + 3) * K + j], a3);
-                }
-                for (; cc < NC; ++cc) a0 = fmaf(dfl[l * NC + cc], W3s[cc * K + j], a0);
-                dz2[l * K + j] = (h2[l * K + j] > 0.f) ? (a0 + a1) + (a2 + a3) : 0.f;
-            }
-            __syncthreads();
-            for (int i = c; i < lcnt * K; i += nt) {
-                const int l = i / K, q = i % K;
-                float a = 0.f;
-                for (int j = 0; j < K; ++j) a = fmaf(dz2[l * K + j], sw.W2[j * K + q], a);
-                dz1[l * K + q] = (h1[l * K + q] > 0.f) ? a : 0.f;
-            }
-            __syncthreads();
-            for (int i = c; i < lcnt * F; i += nt) {
-                const int l = i / F, f = i % F;
-                float a = dX[l * F + f];
-                for (int j = 0; j < K; ++j) a = fmaf(dz1[l * K + j], sw.W1[j * F + f], a);
-                dX[l * F + f] = a;
-            }
-            __syncthreads();
-            // small-matrix gradients owned by this thread
-#pragma unroll
-            for (int u = 0; u < SMAX; ++u) {
-                int e = c + u * nt;
-                if (e >= nsmall) continue;
-                float a = 0.f;
-                if (e < nW2) {                         // dW2[j][q] += sum_l dz2[l,j] h1[l,q]
-                    const int j = e / K, q = e % K;
-                    for (int l = 0; l < lcnt; ++l) a = fmaf(dz2[l * K + j], h1[l * K + q], a);
-                } else if ((e -= nW2) < K) {           // db2
-                    for (int l = 0; l < lcnt; ++l) a += dz2[l * K + e];
-                } else if ((e -= K) < nW1) {           // dW1[j][f] += sum_l dz1[l,j] X[l,f]
-                    const int j = e / F, f = e % F;
-                    for (int l = 0; l < lcnt; ++l) a = fmaf(dz1[l * K + j], X[l * F + f], a);
-                } else if ((e -= nW1) < K) {           // db1
-                    for (int l = 0; l < lcnt; ++l) a += dz1[l * K + e];
-                } else if ((e -= K) < K) {             // dT_bias (once per patch: add on the first chunk)
-                    if (l0 == 0) a = dpool[e];
-                } else {                               // time-embedding parameters
-                    e -= K;
-                    if (e == 0) { for (int l = 0; l < lcnt; ++l) a = fmaf(dX[l * F + 1], tp[l0 + l], a); }
-                    else if (e == 1) { for (int l = 0; l < lcnt; ++l) a += dX[l * F + 1]; }
-                    else {
-                        const int nper = F - 2;
-                        const int j = (e - 2) % nper;
-                        const bool is_w = (e - 2) < nper;
-                        for (int l = 0; l < lcnt; ++l) {
-                            const float t = tp[l0 + l];
-                            const float gq = dX[l * F + 2 + j] * cosf(fmaf(w.te_wp[j], t, w.te_bp[j]));
-                            a += is_w ? gq * t : gq;
-                        }
-                    }
-                }
-                gs[u] += a;
-            }
-        }
-    }
-    // one partial gradient row per workgroup
-    float* row = partial + (size_t)blockIdx.x * G;
-    if (col) {
-#pragma unroll
-        for (int j = 0; j < KP; ++j) if (j < K) row[(size_t)c * K + j] = gw3[j];
-        row[(size_t)NC * K + c] = gb3;
-    }
-    const int base = NC * K + NC;
-#pragma unroll
-    for (int u = 0; u < SMAX; ++u) {
-        const int e = c + u * nt;
-        if (e < nsmall) row[base + e] = gs[u];
-    }
-}
-
-inline size_t small_len(const TtcnDims& d) { return (size_t)(d.K * d.F + d.K * d.K + 2 * d.K); }
-inline size_t fwd_lds(const TtcnDims& d) { return (size_t)(LC * d.F + 2 * LC * d.K + LC + d.F * d.K + small_len(d)) * sizeof(float); }
-inline size_t bwd_lds(const TtcnDims& d) {
-    return (size_t)(LC * d.F + 2 * LC * d.K + LC + KMAX + 2 * LC * d.F * d.K + 2 * LC * d.K + LC * d.F + d.F * d.K * d.K + small_len(d)) * sizeof(float);
-}
-
-}  // namespace
-
-int ttcn_grad_len(int F, int K) { return F * K * K + F * K + K * K + K + K * F + K + K + 2 + 2 * (F - 2); }
-
-int launch_ttcn_fwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const TtcnParams& w,
-                    float* out, float* stat, hipStream_t s) {
-    if (P <= 0) return IMMTSF_OK;
-    if (K > KMAX || F > FMAX || F < 3 || F * K > 1024) return IMMTSF_EUNSUPPORTED;
-    TtcnDims dm{P, L, F, K};
-    const int threads = cdiv(F * K, 64) * 64;
-    if (K <= 32 && threads <= 512)
-        hipLaunchKernelGGL((ttcn_fwd_kernel<32, 512>), dim3(P), dim3(threads), fwd_lds(dm), s, dm, x, tt, mask, w, out, stat);
-    else
-        hipLaunchKernelGGL((ttcn_fwd_kernel<64, 1024>), dim3(P), dim3(threads), fwd_lds(dm), s, dm, x, tt, mask, w, out, stat);
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-
-int launch_ttcn_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const TtcnParams& w,
-                    const float* out, const float* stat, const float* dout, float* partial, int nblocks, hipStream_t s) {
-    if (P <= 0) return IMMTSF_OK;
-    if (K > KMAX || F > FMAX || F < 3 || F * K > 1024) return IMMTSF_EUNSUPPORTED;
-    TtcnDims dm{P, L, F, K};
-    const int threads = cdiv(F * K, 64) * 64;
-    const int nsmall = K * K + K + K * F + K + K + 2 + 2 * (F - 2);
-    if (nsmall > 8 * threads) return IMMTSF_EUNSUPPORTED;
-    if (bwd_lds(dm) > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    if (K <= 32 && threads <= 512)
-        hipLaunchKernelGGL((ttcn_bwd_kernel<32, 512>), dim3(nblocks), dim3(threads), bwd_lds(dm), s, dm, x, tt, mask, w, out, stat,
-                           dout, partial, ttcn_grad_len(F, K));
-    else
-        hipLaunchKernelGGL((ttcn_bwd_kernel<64, 1024>), dim3(nblocks), dim3(threads), bwd_lds(dm), s, dm, x, tt, mask, w, out, stat,
-                           dout, partial, ttcn_grad_len(F, K));
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------- C ABI
 #include "../../include/immtsf.h"
+#include "block_util.hpp"
 #include "rowops.hpp"
 
 namespace {
-constexpr int kTtcnBlocks = 256;   // persistent backward workgroups (one per CU)
 
-struct UnpackArgs { float* dst[11]; int len[11]; };
-__global__ __launch_bounds__(256) void ttcn_unpack_kernel(const float* __restrict__ row, UnpackArgs a) {
-    int off = 0;
-    for (int s = 0; s < 11; ++s) {
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.len[s]; i += gridDim.x * 256) a.dst[s][i] = row[off + i];
-        off += a.len[s];
+constexpr int LC = 32;   // slots per LDS chunk in the pooling backward
+
+struct Dims { int P, L, F, K, NC, Fp, Kp, NCp, R; };
+inline int r4(int x) { return (x + 3) / 4 * 4; }
+inline Dims mk_dims(int P, int L, int te_dim, int K) {
+    Dims d;
+    d.P = P; d.L = L; d.F = 1 + te_dim; d.K = K; d.NC = d.F * K;
+    d.Fp = r4(d.F); d.Kp = r4(K); d.NCp = r4(d.NC); d.R = P * L;
+    return d;
+}
+
+// X[r, 0] = x ; X[r, 1] = ws*t+bs ; X[r, 1+j] = sin(wp_j t + bp_j) ; padded columns = 0
+__global__ __launch_bounds__(256) void build_x_kernel(Dims d, const float* __restrict__ x, const float* __restrict__ tt,
+                                                       const float* ws, const float* bs, const float* __restrict__ wp,
+                                                       const float* __restrict__ bp, float* __restrict__ X) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)d.R * d.Fp) return;
+    const int r = (int)(idx / d.Fp), f = (int)(idx % d.Fp);
+    const float t = tt[r];
+    float v = 0.f;
+    if (f == 0) v = x[r];
+    else if (f == 1) v = fmaf(ws[0], t, bs[0]);
+    else if (f < d.F) v = sinf(fmaf(wp[f - 2], t, bp[f - 2]));
+    X[idx] = v;
+}
+
+// zero-padded, aligned copies of the small weights: W1p (Kp,Fp) b1p (Kp) W2p (Kp,Kp) b2p (Kp) W3p (NCp,Kp) b3p (NCp)
+struct PackPtrs { const float *W1, *b1, *W2, *b2, *W3, *b3; float *W1p, *b1p, *W2p, *b2p, *W3p, *b3p; };
+__global__ __launch_bounds__(256) void pack_w_kernel(Dims d, PackPtrs q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n1 = d.Kp * d.Fp, n2 = d.Kp * d.Kp, n3 = d.NCp * d.Kp;
+    if (i < n1) { const int r = i / d.Fp, c = i % d.Fp; q.W1p[i] = (r < d.K && c < d.F) ? q.W1[r * d.F + c] : 0.f; }
+    if (i < n2) { const int r = i / d.Kp, c = i % d.Kp; q.W2p[i] = (r < d.K && c < d.K) ? q.W2[r * d.K + c] : 0.f; }
+    if (i < n3) { const int r = i / d.Kp, c = i % d.Kp; q.W3p[i] = (r < d.NC && c < d.K) ? q.W3[(size_t)r * d.K + c] : 0.f; }
+    if (i < d.Kp) { q.b1p[i] = i < d.K ? q.b1[i] : 0.f; q.b2p[i] = i < d.K ? q.b2[i] : 0.f; }
+    if (i < d.NCp) q.b3p[i] = i < d.NC ? q.b3[i] : 0.f;
+}
+// gradients back from the padded layout
+struct UnpackPtrs { const float *gW1p, *gb1p, *gW2p, *gb2p, *gW3p, *gb3p; float *gW1, *gb1, *gW2, *gb2, *gW3, *gb3; };
+__global__ __launch_bounds__(256) void unpack_g_kernel(Dims d, UnpackPtrs q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.K * d.F) q.gW1[i] = q.gW1p[(i / d.F) * d.Fp + i % d.F];
+    if (i < d.K * d.K) q.gW2[i] = q.gW2p[(i / d.K) * d.Kp + i % d.K];
+    if (i < d.NC * d.K) q.gW3[i] = q.gW3p[(size_t)(i / d.K) * d.Kp + i % d.K];
+    if (i < d.K) { q.gb1[i] = q.gb1p[i]; q.gb2[i] = q.gb2p[i]; }
+    if (i < d.NC) q.gb3[i] = q.gb3p[i];
+}
+
+// Pooling forward.  grid = P, block = ceil(NC/64)*64; thread c owns filter column c.  S (R, NCp): logits in, softmax
+// weights out (in place).  ctr (P, NC) = sum_l sm*X, out (P, K) = relu(sum_f ctr + T_bias).
+__global__ void pool_fwd_kernel(Dims d, float* __restrict__ S, const float* __restrict__ X, const float* __restrict__ mask,
+                                const float* __restrict__ Tb, float* __restrict__ ctr, float* __restrict__ out) {
+    extern __shared__ float lds[];   // [NC] contributions
+    const int p = blockIdx.x, c = threadIdx.x;
+    const bool col = c < d.NC;
+    const int fc = col ? c % d.F : 0;
+    float* Sp = S + (size_t)p * d.L * d.NCp + c;
+    const float* Xp = X + (size_t)p * d.L * d.Fp + fc;
+    const float* mp = mask + (size_t)p * d.L;
+    if (col) {
+        float m = -INFINITY, s = 0.f;
+        for (int l = 0; l < d.L; ++l) {
+            const float mk = mp[l];
+            const float v = Sp[(size_t)l * d.NCp] * mk + (1.f - mk) * (-1e8f);
+            const float mn = fmaxf(m, v);
+            s = s * expf(m - mn) + expf(v - mn);
+            m = mn;
+        }
+        const float inv = 1.f / s;
+        float acc = 0.f;
+        for (int l = 0; l < d.L; ++l) {
+            const float mk = mp[l];
+            const float v = Sp[(size_t)l * d.NCp] * mk + (1.f - mk) * (-1e8f);
+            const float sm = expf(v - m) * inv;
+            Sp[(size_t)l * d.NCp] = sm;
+            acc = fmaf(sm, Xp[(size_t)l * d.Fp], acc);
+        }
+        lds[c] = acc;
+        ctr[(size_t)p * d.NC + c] = acc;
+    }
+    __syncthreads();
+    if (c < d.K) {
+        float a = Tb[c];
+        for (int f = 0; f < d.F; ++f) a += lds[c * d.F + f];
+        out[(size_t)p * d.K + c] = fmaxf(a, 0.f);
     }
 }
 
-inline TtcnParams to_params(const immtsf_ttcn_params* p) {
-    TtcnParams w;
-    w.te_ws = p->te_scale_w; w.te_bs = p->te_scale_b; w.te_wp = p->te_per_w; w.te_bp = p->te_per_b;
-    w.W1 = p->W1; w.b1 = p->b1; w.W2 = p->W2; w.b2 = p->b2; w.W3 = p->W3; w.b3 = p->b3; w.T_bias = p->T_bias;
+// Pooling backward.  S: softmax weights in, d(logits) out (in place).  dX (R, Fp) = pooling-path gradient of X.
+// dpool (P, K) = dout * [out > 0] is also written (for the T_bias column sum).
+__global__ void pool_bwd_kernel(Dims d, float* __restrict__ S, const float* __restrict__ X, const float* __restrict__ mask,
+                                const float* __restrict__ ctr, const float* __restrict__ out, const float* __restrict__ dout,
+                                float* __restrict__ dX, float* __restrict__ dpool) {
+    extern __shared__ float lds[];   // dp[K] | smt[LC][NC]
+    float* dp = lds;
+    float* smt = lds + d.K;
+    const int p = blockIdx.x, c = threadIdx.x, nt = blockDim.x;
+    const bool col = c < d.NC;
+    const int fc = col ? c % d.F : 0, kc = col ? c / d.F : 0;
+    if (c < d.K) {
+        const float g = out[(size_t)p * d.K + c] > 0.f ? dout[(size_t)p * d.K + c] : 0.f;
+        dp[c] = g;
+        dpool[(size_t)p * d.K + c] = g;
+    }
+    __syncthreads();
+    const float dpk = col ? dp[kc] : 0.f, ct = col ? ctr[(size_t)p * d.NC + c] : 0.f;
+    float* Sp = S + (size_t)p * d.L * d.NCp + c;
+    const float* Xp = X + (size_t)p * d.L * d.Fp;
+    const float* mp = mask + (size_t)p * d.L;
+    for (int l0 = 0; l0 < d.L; l0 += LC) {
+        const int lcnt = min(LC, d.L - l0);
+        if (col) {
+            for (int l = 0; l < lcnt; ++l) {
+                const float smd = Sp[(size_t)(l0 + l) * d.NCp] * dpk;
+                smt[l * d.NC + c] = smd;
+                Sp[(size_t)(l0 + l) * d.NCp] = smd * (Xp[(size_t)(l0 + l) * d.Fp + fc] - ct) * mp[l0 + l];
+            }
+        }
+        __syncthreads();
+        for (int i = c; i < lcnt * d.Fp; i += nt) {
+            const int l = i / d.Fp, f = i % d.Fp;
+            float a = 0.f;
+            if (f < d.F) for (int k = 0; k < d.K; ++k) a += smt[l * d.NC + k * d.F + f];
+            dX[((size_t)p * d.L + l0 + l) * d.Fp + f] = a;
+        }
+        __syncthreads();
+    }
+}
+
+struct Ws {   // forward workspace = saved for backward
+    float *X, *h1, *h2, *S, *ctr, *W1p, *b1p, *W2p, *b2p, *W3p, *b3p;
+    size_t bytes;
+};
+Ws carve_ws(const Dims& d, void* base) {
+    Carver k(base);
+    Ws w;
+    w.X = k.take<float>((size_t)d.R * d.Fp);
+    w.h1 = k.take<float>((size_t)d.R * d.Kp);
+    w.h2 = k.take<float>((size_t)d.R * d.Kp);
+    w.S = k.take<float>((size_t)d.R * d.NCp);
+    w.ctr = k.take<float>((size_t)d.P * d.NC);
+    w.W1p = k.take<float>(d.Kp * d.Fp);
+    w.b1p = k.take<float>(d.Kp);
+    w.W2p = k.take<float>(d.Kp * d.Kp);
+    w.b2p = k.take<float>(d.Kp);
+    w.W3p = k.take<float>((size_t)d.NCp * d.Kp);
+    w.b3p = k.take<float>(d.NCp);
+    w.bytes = k.bytes();
     return w;
 }
+struct Sc {
+    float *dX, *dpool, *dz2, *dz1, *gW1p, *gb1p, *gW2p, *gb2p, *gW3p, *gb3p, *red;
+    size_t bytes;
+};
+Sc carve_sc(const Dims& d, void* base) {
+    Carver k(base);
+    Sc s;
+    s.dX = k.take<float>((size_t)d.R * d.Fp);
+    s.dpool = k.take<float>((size_t)d.P * d.K);
+    s.dz2 = k.take<float>((size_t)d.R * d.Kp);
+    s.dz1 = k.take<float>((size_t)d.R * d.Kp);
+    s.gW1p = k.take<float>(d.Kp * d.Fp);
+    s.gb1p = k.take<float>(d.Kp);
+    s.gW2p = k.take<float>(d.Kp * d.Kp);
+    s.gb2p = k.take<float>(d.Kp);
+    s.gW3p = k.take<float>((size_t)d.NCp * d.Kp);
+    s.gb3p = k.take<float>(d.NCp);
+    s.red = k.take<float>(64 * (d.NCp + 64));
+    s.bytes = k.bytes();
+    return s;
+}
+
+bool bad_dims(int P, int L, int te_dim, int K) { return P < 0 || L <= 0 || te_dim < 2 || K < 1 || (1 + te_dim) * K > 1024; }
+
 }  // namespace
 
 extern "C" {
 
-size_t immtsf_ttcn_scratch_bytes(int32_t te_dim, int32_t ttcn_dim) {
-    const int G = ttcn_grad_len(1 + te_dim, ttcn_dim);
-    return (size_t)(kTtcnBlocks + 32 + 1) * G * sizeof(float) + 1024;
+size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim) {
+    return bad_dims(P, L, te_dim, ttcn_dim) ? 0 : carve_ws(mk_dims(P, L, te_dim, ttcn_dim), nullptr).bytes;
+}
+size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim) {
+    return bad_dims(P, L, te_dim, ttcn_dim) ? 0 : carve_sc(mk_dims(P, L, te_dim, ttcn_dim), nullptr).bytes;
 }
 
-int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
-                        const float* mask, const immtsf_ttcn_params* p, float* out, float* stat, immtsf_stream_t stream) {
-    if (!x || !tt || !mask || !p || !out || !stat || P < 0 || L <= 0 || te_dim < 2 || ttcn_dim < 1) return IMMTSF_EINVAL;
-    return launch_ttcn_fwd(P, L, 1 + te_dim, ttcn_dim, x, tt, mask, to_params(p), out, stat, static_cast<hipStream_t>(stream));
-}
-
-int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
-                         const float* mask, const immtsf_ttcn_params* p, const float* out, const float* stat,
-                         const float* dout, const immtsf_ttcn_params* gr, void* scratch, size_t scratch_bytes,
-                         immtsf_stream_t stream) {
-    if (!x || !tt || !mask || !p || !out || !stat || !dout || !gr || !scratch || P < 0 || L <= 0 || te_dim < 2 || ttcn_dim < 1)
-        return IMMTSF_EINVAL;
-    if (scratch_bytes < immtsf_ttcn_scratch_bytes(te_dim, ttcn_dim)) return IMMTSF_EWORKSPACE;
+int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
+                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, void* workspace,
+                        size_t workspace_bytes, immtsf_stream_t stream) {
+    if (!x || !tt || !mask || !p || !out || !workspace) return IMMTSF_EINVAL;
+    if (bad_dims(P, L, te_dim, ttcn_dim)) return (1 + te_dim) * ttcn_dim > 1024 ? IMMTSF_EUNSUPPORTED : IMMTSF_EINVAL;
+    if (P == 0) return IMMTSF_OK;
+    const Dims d = mk_dims(P, L, te_dim, ttcn_dim);
+    Ws w = carve_ws(d, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int F = 1 + te_dim, K = ttcn_dim, G = ttcn_grad_len(F, K);
-    float* partial = static_cast<float*>(scratch);           // [kTtcnBlocks][G]
-    float* red = partial + (size_t)kTtcnBlocks * G;          // [32][G] column-sum scratch
-    float* row = red + (size_t)32 * G;                       // [G]
-    const int nb = P < kTtcnBlocks ? (P > 0 ? P : 1) : kTtcnBlocks;
-    int rc = launch_ttcn_bwd(P, L, F, K, x, tt, mask, to_params(p), out, stat, dout, partial, nb, s);
-    if (rc) return rc;
-    rc = launch_colsum(partial, nullptr, nb, nullptr, G, G, row, 0, red, s);
-    if (rc) return rc;
-    UnpackArgs a;
-    float* dst[11] = {gr->W3, gr->b3, gr->W2, gr->b2, gr->W1, gr->b1, gr->T_bias, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b};
-    const int len[11] = {F * K * K, F * K, K * K, K, K * F, K, K, 1, 1, F - 2, F - 2};
-    for (int i = 0; i < 11; ++i) { a.dst[i] = dst[i]; a.len[i] = len[i]; }
-    hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(16), dim3(256), 0, s, row, a);
+    PackPtrs q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, w.W1p, w.b1p, w.W2p, w.b2p, w.W3p, w.b3p};
+    hipLaunchKernelGGL(pack_w_kernel, dim3(cdiv(d.NCp * d.Kp, 256)), dim3(256), 0, s, d, q);
+    IMMTSF_LAUNCH_CHECK();
+    const long nx = (long)d.R * d.Fp;
+    hipLaunchKernelGGL(build_x_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, s, d, x, tt, p->te_scale_w, p->te_scale_b,
+                       p->te_per_w, p->te_per_b, w.X);
+    IMMTSF_LAUNCH_CHECK();
+    {   // h1 = relu(X W1^T + b1)
+        GemmArgs g = gemm_args(d.R, d.Kp, d.Fp, d.Fp, d.Fp, d.Kp);
+        set_problem(g, 0, w.X, w.W1p, w.h1, w.b1p);
+        g.act = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
+    }
+    {   // h2 = relu(h1 W2^T + b2)
+        GemmArgs g = gemm_args(d.R, d.Kp, d.Kp, d.Kp, d.Kp, d.Kp);
+        set_problem(g, 0, w.h1, w.W2p, w.h2, w.b2p);
+        g.act = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
+    }
+    {   // filt = h2 W3^T + b3
+        GemmArgs g = gemm_args(d.R, d.NCp, d.Kp, d.Kp, d.Kp, d.NCp);
+        set_problem(g, 0, w.h2, w.W3p, w.S, w.b3p);
+        CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
+    }
+    const int threads = cdiv(d.NC, 64) * 64;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(P), dim3(threads), d.NC * sizeof(float), s, d, w.S, w.X, mask, p->T_bias, w.ctr, out);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+
+int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
+                         const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
+                         const float* dout, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                         const immtsf_ttcn_params* gr, immtsf_stream_t stream) {
+    (void)x;
+    if (!tt || !mask || !p || !out || !dout || !gr || !workspace || !scratch) return IMMTSF_EINVAL;
+    if (bad_dims(P, L, te_dim, ttcn_dim)) return IMMTSF_EINVAL;
+    if (P == 0) return IMMTSF_OK;
+    const Dims d = mk_dims(P, L, te_dim, ttcn_dim);
+    Ws w = carve_ws(d, workspace);
+    Sc sc = carve_sc(d, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int threads = cdiv(d.NC, 64) * 64;
+    const size_t lds = (size_t)(d.K + LC * d.NC) * sizeof(float);
+    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, sc.dX, sc.dpool);
+    IMMTSF_LAUNCH_CHECK();
+    CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
+    {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
+        GemmArgs h = gemm_args(d.NCp, d.Kp, d.R, d.NCp, d.Kp, d.Kp);
+        set_problem(h, 0, w.S, w.h2, sc.gW3p, nullptr, sc.gb3p);
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        GemmArgs g = gemm_args(d.R, d.Kp, d.NCp, d.NCp, d.Kp, d.Kp);
+        set_problem(g, 0, w.S, w.W3p, sc.dz2, nullptr);
+        g.relu_ref = w.h2; g.ld_ref = d.Kp;
+        CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
+    }
+    {   // layer 2
+        GemmArgs h = gemm_args(d.Kp, d.Kp, d.R, d.Kp, d.Kp, d.Kp);
+        set_problem(h, 0, sc.dz2, w.h1, sc.gW2p, nullptr, sc.gb2p);
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        GemmArgs g = gemm_args(d.R, d.Kp, d.Kp, d.Kp, d.Kp, d.Kp);
+        set_problem(g, 0, sc.dz2, w.W2p, sc.dz1, nullptr);
+        g.relu_ref = w.h1; g.ld_ref = d.Kp;
+        CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
+    }
+    {   // layer 1: dW1 = dz1^T X (+db1) ; dX += dz1 W1
+        GemmArgs h = gemm_args(d.Kp, d.Fp, d.R, d.Kp, d.Fp, d.Fp);
+        set_problem(h, 0, sc.dz1, w.X, sc.gW1p, nullptr, sc.gb1p);
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        GemmArgs g = gemm_args(d.R, d.Fp, d.Kp, d.Kp, d.Fp, d.Fp);
+        set_problem(g, 0, sc.dz1, w.W1p, sc.dX, nullptr);
+        g.accumulate = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
+    }
+    UnpackPtrs u{sc.gW1p, sc.gb1p, sc.gW2p, sc.gb2p, sc.gW3p, sc.gb3p, gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3};
+    hipLaunchKernelGGL(unpack_g_kernel, dim3(cdiv(d.NC * d.K, 256)), dim3(256), 0, s, d, u);
+    IMMTSF_LAUNCH_CHECK();
+    // time-embedding parameters: same reduction as Time2Vec's backward, on dX[:, 1:F] with the slot times
+    return launch_time2vec_bwd(tt, nullptr, nullptr, d.R, d.F - 1, p->te_per_w, p->te_per_b, sc.dX + 1, d.Fp, gr->te_scale_w,
+                               gr->te_scale_b, gr->te_per_w, gr->te_per_b, sc.red, s);
 }
 
 }  // extern "C"

@@ -150,8 +150,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t hidden, con
 
 /* ---- a14: tPatchGNN time-aware patch encoder, LearnableTE + TTCN (models/tPatchGNN.py:176-195), fused.
  * x, tt, mask: (P, L) with P = B*N*M patches (the reference's (B*N*M, L, 1) tensors); F = 1 + te_dim,
- * K = ttcn_dim = hid_dim - 1.  out: (P, K) = relu(pooled + T_bias).  stat: (P, 3, F*K) saved for backward.
- * Limits: K <= 64, F <= 32, F*K <= 1024 (IMMTSF_EUNSUPPORTED otherwise). */
+ * K = ttcn_dim = hid_dim - 1.  out: (P, K) = relu(pooled + T_bias).  Limit: F*K <= 1024 (IMMTSF_EUNSUPPORTED). */
 typedef struct immtsf_ttcn_params {
     float *te_scale_w, *te_scale_b; /* (1),(1)          te_scale */
     float *te_per_w, *te_per_b;     /* (te_dim-1) each  te_periodic */
@@ -161,14 +160,19 @@ typedef struct immtsf_ttcn_params {
     float* T_bias;                  /* (K)              T_bias (1,K) */
 } immtsf_ttcn_params;
 
-size_t immtsf_ttcn_scratch_bytes(int32_t te_dim, int32_t ttcn_dim);
-int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
-                        const float* mask, const immtsf_ttcn_params* p, float* out, float* stat, immtsf_stream_t stream);
-/* dout (P,K) -> every parameter gradient (overwritten).  No gradient flows to x / tt / mask (data). */
-int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, const float* x, const float* tt,
-                         const float* mask, const immtsf_ttcn_params* p, const float* out, const float* stat,
-                         const float* dout, const immtsf_ttcn_params* grads, void* scratch, size_t scratch_bytes,
-                         immtsf_stream_t stream);
+size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
+size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
+/* the three filter-generator layers run on the MFMA GEMM over all P*L slots (`precision` as everywhere), the masked
+ * softmax + pooling are streaming kernels; `workspace` holds the saved-for-backward state */
+int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
+                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, void* workspace,
+                        size_t workspace_bytes, immtsf_stream_t stream);
+/* dout (P,K) -> every parameter gradient (overwritten).  No gradient flows to x / tt / mask (data).
+ * NOTE: consumes the workspace (the saved softmax weights are overwritten): one backward per forward. */
+int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
+                         const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
+                         const float* dout, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                         const immtsf_ttcn_params* grads, immtsf_stream_t stream);
 
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data

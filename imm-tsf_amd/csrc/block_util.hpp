@@ -40,6 +40,7 @@ inline GemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc) {
     g.batch_inner = 1;
     return g;
 }
+inline void prezeroed(GemmArgs& g, const immtsf_fusion_cfg* c) { g.c_prezeroed = c->grads_prezeroed ? 1 : 0; }
 inline void set_problem(GemmArgs& g, int i, const float* A, const float* B, float* C, const float* bias, float* bias_grad = nullptr) {
     g.p[i].A = A; g.p[i].B = B; g.p[i].C = C; g.p[i].bias = bias; g.p[i].bias_grad = bias_grad;
     if (bias_grad) g.ones_col = 1;

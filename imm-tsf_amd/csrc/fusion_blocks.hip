@@ -164,6 +164,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, dE_txt, w.z, gr->proj_out_w, nullptr, gr->proj_out_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
@@ -178,6 +179,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, sc.dx, w.ctx, gr->attn_out_w, nullptr, gr->attn_out_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
@@ -197,6 +199,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
         set_problem(h, 0, sc.dKVp, w.KV, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
         h.dyn = total; h.dyn_which = 1;
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // KV_proj
@@ -207,16 +210,18 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
         set_problem(h, 0, sc.dKV, w.Xcat, gr->kv_w, nullptr, gr->kv_b);
         h.dyn = total; h.dyn_which = 1;
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = w.rowmap;
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     return launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
-                               gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, s);
+                               gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, 0, s);
 }
 
 }  // extern "C"

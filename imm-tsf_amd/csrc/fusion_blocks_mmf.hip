@@ -162,6 +162,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
         set_problem(h, 0, sc.ddelta, w.U, gr->res_w, nullptr, gr->res_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // out_proj
@@ -170,6 +171,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, sc.dU, w.O, gr->attn_out_w, nullptr, gr->attn_out_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
@@ -180,6 +182,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         GemmArgs h = gemm_args(T, hd, T, T, d, d);
         set_problem(h, 0, w.Am, sc.dO, sc.dVi, nullptr);
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_softmax_rows_bwd(sc.dA, w.Pm, B, H, T, T, drop, SITE_XADD_ATTN, s));
@@ -193,6 +196,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         set_problem(h, 0, sc.dA, w.Qi, sc.dKi, nullptr);
         h.alpha = scale;
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // MHA in-projections
@@ -207,6 +211,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         set_problem(h, 0, sc.dQi, w.Q0, gr->attn_in_w, nullptr, gr->attn_in_b);
         set_problem(h, 1, sc.dKi, w.K0, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
         set_problem(h, 2, sc.dVi, w.V0, gr->attn_in_w + (size_t)2 * d * d, nullptr, gr->attn_in_b + 2 * d);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // proj_q: dY += dQ0 W_q ; dW_q = dQ0^T Y
@@ -216,6 +221,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, C, BT, d, C, C);
         set_problem(h, 0, sc.dQ0, Y_ts, gr->proj_q_w, nullptr);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // proj_k / proj_v: dE = dK0 W_k + dV0 W_v ; dW_k = dK0^T E ; dW_v = dV0^T E
@@ -230,6 +236,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         h.nprob = 2;
         set_problem(h, 0, sc.dK0, E_txt, gr->proj_k_w, nullptr);
         set_problem(h, 1, sc.dV0, E_txt, gr->proj_v_w, nullptr);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     return IMMTSF_OK;

@@ -156,6 +156,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, dE_txt, w.z, gr->proj_w, nullptr, gr->proj_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
@@ -168,6 +169,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         GemmArgs h = gemm_args(d, cfg->d_m, R, d, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dVp, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = w.rowmap;
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     return IMMTSF_OK;
@@ -225,17 +227,20 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     {   // residual_head: dW_r = ddelta^T h ; db_r
         GemmArgs h = gemm_args(C, Hd, BT, C, Hd, Hd);
         set_problem(h, 0, sc.ddelta, w.h, gr->res_w, nullptr, gr->res_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_gru_bwd(B, T, Hd, sc.dh_in, p->w_hh, w.r, w.z, w.n, w.hn, w.hprev, sc.dgi, sc.dgh, s));
     {   // recurrent weights: dW_hh = dgh^T h_prev ; db_hh
         GemmArgs h = gemm_args(3 * Hd, Hd, BT, 3 * Hd, Hd, Hd);
         set_problem(h, 0, sc.dgh, w.hprev, gr->w_hh, nullptr, gr->b_hh);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     {   // input weights: dW_ih = dgi^T x ; db_ih ; dx = dgi W_ih
         GemmArgs h = gemm_args(3 * Hd, I, BT, 3 * Hd, I, I);
         set_problem(h, 0, sc.dgi, w.x, gr->w_ih, nullptr, gr->b_ih);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
         GemmArgs g = gemm_args(BT, I, 3 * Hd, 3 * Hd, I, I);
         set_problem(g, 0, sc.dgi, p->w_ih, sc.dx, nullptr);
@@ -244,6 +249,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     {   // gate net: dW_g = dgl^T x ; db_g ; dx += dgl W_g
         GemmArgs h = gemm_args(C, I, BT, C, I, I);
         set_problem(h, 0, sc.dgl, w.x, gr->gate_w, nullptr, gr->gate_b);
+        prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
         GemmArgs g = gemm_args(BT, I, C, C, I, I);
         set_problem(g, 0, sc.dgl, p->gate_w, sc.dx, nullptr);

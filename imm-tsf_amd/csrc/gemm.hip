@@ -315,6 +315,50 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* __restrict__ C = P.C + offC;
     const bool first = blockIdx.y == 0;
+
+    // ---- vector epilogue: stage the accumulator tile through LDS (free after the last barrier) and store whole
+    // 16-byte chunks of C rows -- 16 lanes cover one 256-byte row segment instead of 64-byte slivers.
+    constexpr int CP = BN + 4;
+    constexpr bool kCtFits = (size_t)BM * CP * sizeof(float) <= (size_t)2 * BUF * sizeof(T);
+    if (kCtFits && g.vecC && splits == 1 && !(TA && TB && g.ones_col)) {
+        float* Ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Ct[(wm0 + i * 16 + fq * 4 + r) * CP + wn0 + j * 16 + fr] = acc[i][j][r];
+        __syncthreads();
+        constexpr int NCH = BM * BN / 4;
+        for (int q = tid; q < NCH; q += NT) {
+            const int rl = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
+            const int row = row0 + rl, col = col0 + c4;
+            if (row >= M || col >= N) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(Ct + rl * CP + c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const bool live = g.row_flag ? (g.row_flag[row / g.row_flag_div] != 0) : true;
+            const int nv = min(4, N - col);
+            float* dst = C + (size_t)row * g.ldc + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= nv) break;
+                float x = g.alpha * v[e];
+                if (P.bias) x += P.bias[col + e];
+                if (!live) x = 0.f;
+                if (g.add_vec) x += g.add_vec[col + e];
+                if (g.act == 1) x = fmaxf(x, 0.f);
+                else if (g.act == 2) x = gelu_erf(x);
+                if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col + e] <= 0.f) x = 0.f;
+                if (g.accumulate) x += dst[e];
+                v[e] = x;
+            }
+            if (nv == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int e = 0; e < nv; ++e) dst[e] = v[e];
+        }
+        return;
+    }
+
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -442,6 +486,10 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     }
     g.vecA = va ? 1 : 0;
     g.vecB = vb ? 1 : 0;
+    bool vc = (g.ldc % 4) == 0;
+    for (int i = 0; i < g.nprob; ++i) vc = vc && ((reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0);
+    if (g.nbatch > 1) vc = vc && (g.sC_o % 4 == 0) && (g.sC_i % 4 == 0);
+    g.vecC = vc ? 1 : 0;
     if (g.row_flag && g.row_flag_div <= 0) return IMMTSF_EINVAL;
     if (g.nbatch > 1 && g.batch_inner <= 0) return IMMTSF_EINVAL;
     if (g.ones_col && layout != GEMM_TN) return IMMTSF_EINVAL;
@@ -459,12 +507,12 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             if (tiles < 256 && ksteps >= 8) {
                 splits = (int)((512 + tiles - 1) / tiles);
                 if (splits > ksteps / 2) splits = ksteps / 2;
-                if (splits > 16) splits = 16;
+                if (splits > 512) splits = 512;
                 if (splits < 1) splits = 1;
             }
         }
     }
-    if (splits > 1) {
+    if (splits > 1 && !g.c_prezeroed) {
         for (int i = 0; i < g.nprob; ++i) {
             hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
             if (e != hipSuccess) return (int)e;

@@ -31,7 +31,7 @@ struct GemmArgs {
     int row_flag_div;
     const float* add_vec;  // optional, length N
     int act;               // 0 none, 1 relu, 2 gelu(erf)
-    int vecA, vecB;        // host-verified: 16-byte aligned base and ld % 4 == 0
+    int vecA, vecB, vecC;  // host-verified: 16-byte aligned base and ld % 4 == 0
     // batched form (dense attention): grid.z = nprob * nbatch; batch index bi -> (bo, bin) = (bi / batch_inner,
     // bi % batch_inner); each operand pointer advances by bo*s?_o + bin*s?_i elements.  nbatch <= 1: no batching.
     int nbatch, batch_inner;
@@ -42,6 +42,8 @@ struct GemmArgs {
     // optional relu-backward mask: results whose relu_ref[m*ld_ref + n] <= 0 are zeroed (relu_ref = forward output)
     const float* relu_ref;
     int ld_ref;
+    // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
+    int c_prezeroed;
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
                                                             float* __restrict__ partial, int max_rows) {
     __shared__ float red[2][4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx, slab = blockIdx.y;
-    const int M = total ? *total : max_rows, rps = (M + kSlabs - 1) / kSlabs;
+    const int j = blockIdx.x * 64 + tx, slab = blockIdx.y, nsl = gridDim.y;
+    const int M = total ? *total : max_rows, rps = (M + nsl - 1) / nsl;
     const int r0 = slab * rps, r1 = min(M, r0 + rps);
     float aw = 0.f, ab = 0.f;
     if (j < d_tau) {
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void time2vec_bwd_final_kernel(const float* __restrict__ partial, int d_tau,
-                                                                  float* dw0, float* db0, float* dw, float* db) {
+                                                                  float* dw0, float* db0, float* dw, float* db, int nsl) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= d_tau) return;
     float aw = 0.f, ab = 0.f;
-    for (int s = 0; s < kSlabs; ++s) {
+    for (int s = 0; s < nsl; ++s) {
         aw += partial[((size_t)s * 2 + 0) * d_tau + j];
         ab += partial[((size_t)s * 2 + 1) * d_tau + j];
     }
@@ -333,11 +333,12 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
-                        float* db, float* scratch, hipStream_t s) {
-    hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), kSlabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
+                        float* db, float* scratch, int nslabs, hipStream_t s) {
+    if (nslabs < 1) nslabs = kSlabs;
+    hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), nslabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
                        dfeat, ld, scratch, max_rows);
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 256)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db);
+    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 256)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -15,10 +15,11 @@ int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const in
 int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w0, const float* b0, const float* w, const float* b, float* dst, int ld_dst,
                         hipStream_t s);
-// Time2Vec parameter gradients from dFeat (packed rows, ld): scratch >= 2*32*d_tau floats
+// Time2Vec parameter gradients from dFeat (packed rows, ld): nslabs row slabs (0 = 32), scratch >= 2*nslabs*d_tau floats;
+// rowmap/total may be null (rows 0..max_rows-1 used directly)
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
-                        float* db, float* scratch, hipStream_t s);
+                        float* db, float* scratch, int nslabs, hipStream_t s);
 // out[n] = sum_{m < M} X[m,n] * (Y ? Y[m,n] : 1)   (M may come from *dyn).  scratch >= 32*N floats.
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
                   float* scratch, hipStream_t s);

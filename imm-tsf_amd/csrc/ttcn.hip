@@ -187,7 +187,7 @@ Sc carve_sc(const Dims& d, void* base) {
     s.gb2p = k.take<float>(d.Kp);
     s.gW3p = k.take<float>((size_t)d.NCp * d.Kp);
     s.gb3p = k.take<float>(d.NCp);
-    s.red = k.take<float>(64 * (d.NCp + 64));
+    s.red = k.take<float>(64 * (d.NCp + 64) + 2 * 256 * d.F);
     s.bytes = k.bytes();
     return s;
 }
@@ -264,9 +264,15 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, sc.dX, sc.dpool);
     IMMTSF_LAUNCH_CHECK();
     CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
+    {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once for the split-K GEMMs
+        const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
+        hipError_t e = hipMemsetAsync(sc.gW1p, 0, nbytes, s);
+        if (e != hipSuccess) return (int)e;
+    }
     {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
         GemmArgs h = gemm_args(d.NCp, d.Kp, d.R, d.NCp, d.Kp, d.Kp);
         set_problem(h, 0, w.S, w.h2, sc.gW3p, nullptr, sc.gb3p);
+        h.c_prezeroed = 1;
         CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
         GemmArgs g = gemm_args(d.R, d.Kp, d.NCp, d.NCp, d.Kp, d.Kp);
         set_problem(g, 0, w.S, w.W3p, sc.dz2, nullptr);
@@ -276,6 +282,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     {   // layer 2
         GemmArgs h = gemm_args(d.Kp, d.Kp, d.R, d.Kp, d.Kp, d.Kp);
         set_problem(h, 0, sc.dz2, w.h1, sc.gW2p, nullptr, sc.gb2p);
+        h.c_prezeroed = 1;
         CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
         GemmArgs g = gemm_args(d.R, d.Kp, d.Kp, d.Kp, d.Kp, d.Kp);
         set_problem(g, 0, sc.dz2, w.W2p, sc.dz1, nullptr);
@@ -285,6 +292,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     {   // layer 1: dW1 = dz1^T X (+db1) ; dX += dz1 W1
         GemmArgs h = gemm_args(d.Kp, d.Fp, d.R, d.Kp, d.Fp, d.Fp);
         set_problem(h, 0, sc.dz1, w.X, sc.gW1p, nullptr, sc.gb1p);
+        h.c_prezeroed = 1;
         CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
         GemmArgs g = gemm_args(d.R, d.Fp, d.Kp, d.Kp, d.Fp, d.Fp);
         set_problem(g, 0, sc.dz1, w.W1p, sc.dX, nullptr);
@@ -296,7 +304,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     IMMTSF_LAUNCH_CHECK();
     // time-embedding parameters: same reduction as Time2Vec's backward, on dX[:, 1:F] with the slot times
     return launch_time2vec_bwd(tt, nullptr, nullptr, d.R, d.F - 1, p->te_per_w, p->te_per_b, sc.dX + 1, d.Fp, gr->te_scale_w,
-                               gr->te_scale_b, gr->te_per_w, gr->te_per_b, sc.red, s);
+                               gr->te_scale_b, gr->te_per_w, gr->te_per_b, sc.red, 256, s);
 }
 
 }  // extern "C"

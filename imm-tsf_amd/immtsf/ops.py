@@ -42,6 +42,12 @@ def _sinks_of(params):
     return [None if p is None else getattr(p, "_immtsf_grad_sink", None) for p in params]
 
 
+def _prezeroed(params, sinks):
+    """1 when every gradient of the block goes to a sink that its owner zero-fills each step (FlatTrainer)."""
+    ok = all(p is None or (s is not None and getattr(p, "_immtsf_grad_prezeroed", False)) for p, s in zip(params, sinks))
+    return 1 if ok else 0
+
+
 def _grad_buffers(params, sinks=None):
     """(buffers the HIP backward writes, gradients to return to autograd).  One flat allocation for the
     parameters without a sink."""
@@ -102,6 +108,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
         ctx.sinks = _sinks_of(params)
+        ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
         return E, M
@@ -145,6 +152,7 @@ class TTFRecAvgFn(torch.autograd.Function):
         ctx.save_for_backward(notes, tau, t_hat, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
         ctx.sinks = _sinks_of(params)
+        ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
         return E, M
@@ -184,6 +192,7 @@ class MMFXAttnAddFn(torch.autograd.Function):
                                                ws.numel(), stream_ptr()), "mmf_xattn_add_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.sinks = _sinks_of(params)
+        ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.save_for_backward(Y, E, M_u8, *params)
         return out
@@ -222,6 +231,7 @@ class MMFGRAddFn(torch.autograd.Function):
                                             ws.numel(), stream_ptr()), "mmf_gr_add_forward")
         ctx.cfg, ctx.ws, ctx.hidden = cfg, ws, hidden
         ctx.sinks = _sinks_of(params)
+        ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.save_for_backward(Y, E, M_u8, *params)
         return out

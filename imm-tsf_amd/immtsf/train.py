@@ -52,20 +52,24 @@ class FlatTrainer:
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.ranges = []
+        self._views = []
+        self._collected = True
         off = 0
         for bi, b in enumerate(self.buckets):
             start = off
+            views = []
             for p in b:
                 k = p.numel()
                 self.flat_param[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_param[off:off + k].view(p.shape)
                 gview = self.flat_grad[off:off + k].view(p.shape)
+                views.append(gview)
                 if bi in sink_buckets:
                     p._immtsf_grad_sink = gview
-                    p.grad = gview          # so optimizers / clip utilities that look at .grad still work
-                else:
-                    p.grad = gview
+                    p._immtsf_grad_prezeroed = True   # zero_grad() memsets the whole flat buffer every step
+                p.grad = gview              # optimizers / clip utilities that look at .grad still work
                 off += k
+            self._views.append(views)
             self.ranges.append((start, off))
         self.sink_buckets = set(sink_buckets)
         # device_step: Adam's step number (and the dropout key offset) live in device memory so that a captured
@@ -89,16 +93,39 @@ class FlatTrainer:
 
     # ---------------------------------------------------------------------------------------------- step pieces
     def zero_grad(self):
-        """sink buckets are overwritten by the HIP backward every step; only autograd-accumulated ranges are zeroed."""
-        for bi, (lo, hi) in enumerate(self.ranges):
-            if bi not in self.sink_buckets and hi > lo:
-                self.flat_grad[lo:hi].zero_()
+        """ONE memset of the whole flat gradient buffer.  The HIP backward of the sink buckets then overwrites (or, for
+        split-K weight gradients, atomically accumulates onto the zeros: `grads_prezeroed`) its ranges; autograd-owned
+        parameters get `.grad = None` so that AccumulateGrad adopts the incoming tensor instead of launching one add
+        kernel per parameter -- `_collect_autograd_grads` copies them into the flat buffer with one multi-tensor copy."""
+        self.flat_grad.zero_()
+        for bi, b in enumerate(self.buckets):
+            if bi not in self.sink_buckets:
+                for p in b:
+                    p.grad = None
         self._reduced = [False] * len(self.buckets)
+        self._collected = False
+
+    def _collect_autograd_grads(self):
+        if self._collected:
+            return
+        self._collected = True
+        dst, src = [], []
+        for bi, b in enumerate(self.buckets):
+            if bi in self.sink_buckets:
+                continue
+            for p, v in zip(b, self._views[bi]):
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    dst.append(v)
+                    src.append(p.grad.reshape(v.shape))
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _bucket_ready(self, bi: int):
         if self.world == 1 or self._reduced[bi]:
             return
         import torch.distributed as dist
+        if bi not in self.sink_buckets:
+            self._collect_autograd_grads()
         lo, hi = self.ranges[bi]
         if hi == lo:
             self._reduced[bi] = True
@@ -115,6 +142,7 @@ class FlatTrainer:
         """all-reduce (sum) whatever has not been reduced yet and join the communication stream.  The loss is
         normalised over the GLOBAL batch (immtsf.ops.masked_mse with `group`), so the sum of the ranks' gradients
         is exactly the single-process full-batch gradient."""
+        self._collect_autograd_grads()
         if self.world > 1:
             for bi in range(len(self.buckets)):
                 self._bucket_ready(bi)

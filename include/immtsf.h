@@ -53,6 +53,9 @@ typedef struct immtsf_fusion_cfg {
     uint64_t seed;
     const uint64_t* seed_step_dev; /* optional device counter added to `seed` when the kernels run (NULL = 0): a captured
                                       hipGraph bumps it once per replay so every step draws fresh dropout masks */
+    int32_t grads_prezeroed;       /* backward only: every gradient buffer passed in `grads` is already zero (e.g. one
+                                      memset of a flat gradient buffer per step), so split-K weight-gradient GEMMs skip
+                                      their own zero-fill */
 } immtsf_fusion_cfg;
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)

@@ -47,15 +47,20 @@ int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32
 }
 
 int immtsf_softmax_rows_forward(float* sc, float* A, int32_t B, int32_t H, int32_t L, int32_t S, const uint8_t* live,
-                                float p_drop, uint64_t seed, uint64_t site, int32_t causal, immtsf_stream_t stream) {
+                                float p_drop, uint64_t seed, uint64_t site, int32_t causal, const uint64_t* seed_step_dev,
+                                immtsf_stream_t stream) {
     if (!sc || !A) return IMMTSF_EINVAL;
-    return launch_softmax_rows_fwd(sc, A, B, H, L, S, live, mk_drop(p_drop, seed), site, causal, static_cast<hipStream_t>(stream));
+    DropCfg d = mk_drop(p_drop, seed);
+    d.seed_dev = seed_step_dev;
+    return launch_softmax_rows_fwd(sc, A, B, H, L, S, live, d, site, causal, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H, int32_t L, int32_t S, float p_drop,
-                                 uint64_t seed, uint64_t site, immtsf_stream_t stream) {
+                                 uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, immtsf_stream_t stream) {
     if (!dA || !P) return IMMTSF_EINVAL;
-    return launch_softmax_rows_bwd(dA, P, B, H, L, S, mk_drop(p_drop, seed), site, static_cast<hipStream_t>(stream));
+    DropCfg d = mk_drop(p_drop, seed);
+    d.seed_dev = seed_step_dev;
+    return launch_softmax_rows_bwd(dA, P, B, H, L, S, d, site, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,

@@ -69,7 +69,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         if (g.dyn_which == 0) M = dv; else K = dv;
     }
     const int tiles_n = (N + BN - 1) / BN;
-    const int row0 = (blockIdx.x / tiles_n) * BM, col0 = (blockIdx.x % tiles_n) * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (bid % 8 labels the L2 they share), so
+    // give every XCD one CONTIGUOUS range of tile indices -- a few tile rows of A plus the whole B panel then fit its
+    // 4 MiB L2 instead of all eight L2s streaming all of A and B from the Infinity Cache.  Bijective for any grid size.
+    int lin = blockIdx.x;
+    if (g.xcd_remap) {
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    }
+    const int row0 = (lin / tiles_n) * BM, col0 = (lin % tiles_n) * BN;
     if (row0 >= M) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -412,12 +420,13 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 }
 
 // tuning override for tools/gemm_bench.py (0 = heuristic)
-int g_variant = 0, g_splitk = 0;
+int g_variant = 0, g_splitk = 0, g_xcd = 1;
 
 }  // namespace
 
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
-    g_variant = variant;
+    g_variant = variant & 0xff;
+    g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
     g_splitk = splitk;
     return 0;
 }
@@ -490,6 +499,11 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     for (int i = 0; i < g.nprob; ++i) vc = vc && ((reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0);
     if (g.nbatch > 1) vc = vc && (g.sC_o % 4 == 0) && (g.sC_i % 4 == 0);
     g.vecC = vc ? 1 : 0;
+    {   // XCD-aware order pays when several L2s would otherwise stream the same mid-sized operands; it hurts once
+        // the grid is large enough that the default order already keeps every XCD on its own tile rows
+        const long gx = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
+        g.xcd_remap = (g_xcd && gx >= 64 && gx < 2048 && g.N >= 256) ? 1 : 0;
+    }
     if (g.row_flag && g.row_flag_div <= 0) return IMMTSF_EINVAL;
     if (g.nbatch > 1 && g.batch_inner <= 0) return IMMTSF_EINVAL;
     if (g.ones_col && layout != GEMM_TN) return IMMTSF_EINVAL;

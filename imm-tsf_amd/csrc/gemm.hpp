@@ -44,6 +44,7 @@ struct GemmArgs {
     int ld_ref;
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
+    int xcd_remap;         // set by the launcher
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

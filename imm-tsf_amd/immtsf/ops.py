@@ -397,20 +397,21 @@ class FullAttentionFn(torch.autograd.Function):
                                       H * L * S, L * S, B, H, L, S, E, float(scale), stream_ptr()), "qk^T")
         p = float(p_drop) if training else 0.0
         A = torch.empty_like(P) if p > 0 else P
-        check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), B, H, L, S, None, p, seed, site, 1 if causal else 0,
+        cnt = config.dropout_counter_ptr(dev) if p > 0 else None
+        check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), B, H, L, S, None, p, seed, site, 1 if causal else 0, cnt,
                                               stream_ptr()), "softmax")
         out = torch.empty(B, L, H, D, dtype=torch.float32, device=dev)
         check(lib.immtsf_gemm_batched(1, precision, ptr(A), S, H * L * S, L * S, ptr(v), H * D, S * H * D, D, ptr(out), H * D,
                                       L * H * D, D, B, H, L, D, S, 1.0, stream_ptr()), "a.v")
         ctx.save_for_backward(q, k, v, P, A)
-        ctx.cfg = (scale, p, seed, site, precision)
+        ctx.cfg = (scale, p, seed, site, precision, cnt)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
         q, k, v, P, A = ctx.saved_tensors
-        scale, p, seed, site, precision = ctx.cfg
+        scale, p, seed, site, precision, cnt = ctx.cfg
         B, L, H, E = q.shape
         S, D = k.shape[1], v.shape[3]
         dout = dout.contiguous()
@@ -422,7 +423,7 @@ class FullAttentionFn(torch.autograd.Function):
                                       H * L * S, L * S, B, H, L, S, D, 1.0, st), "dA")
         check(lib.immtsf_gemm_batched(2, precision, ptr(A), S, H * L * S, L * S, ptr(dout), H * D, L * H * D, D, ptr(dv), H * D,
                                       S * H * D, D, B, H, S, D, L, 1.0, st), "dV")
-        check(lib.immtsf_softmax_rows_backward(ptr(dA), ptr(P), B, H, L, S, p, seed, site, st), "softmax_bwd")
+        check(lib.immtsf_softmax_rows_backward(ptr(dA), ptr(P), B, H, L, S, p, seed, site, cnt, st), "softmax_bwd")
         # dQ = scale dS K ; dK = scale dS^T Q
         check(lib.immtsf_gemm_batched(1, precision, ptr(dA), S, H * L * S, L * S, ptr(k), H * E, S * H * E, E, ptr(dq), H * E,
                                       L * H * E, E, B, H, L, E, S, float(scale), st), "dQ")

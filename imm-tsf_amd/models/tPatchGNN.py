@@ -147,12 +147,47 @@ class tPatchGNN(nn.Module):
         return torch.cat([h, flag], dim=-1)
 
     # ---- transformer + adaptive-graph GCN over (variables x patches) ------------------------------
+    def _encoder_layer_hip(self, lyr, x):
+        """one post-norm nn.TransformerEncoderLayer (relu FFN, batch_first) evaluated from ITS parameters on the HIP
+        GEMM / LayerNorm / attention kernels: at d_model=32 with dim_feedforward=2048 the stock path spends its time
+        in badly-shaped library GEMMs.  Dropout uses torch's generator exactly like the stock layer."""
+        from immtsf.ops import full_attention, layer_norm, linear
+        Bs, S, D = x.shape
+        at = lyr.self_attn
+        H = at.num_heads
+        qkv = linear(x, at.in_proj_weight, at.in_proj_bias).view(Bs, S, 3, H, D // H)
+        p_att = at.dropout if self.training else 0.0
+        from immtsf import config
+        a = full_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(D // H), p_att, self.training,
+                           config.next_seed() if p_att > 0 else 0, 900)
+        sa = linear(a.reshape(Bs, S, D), at.out_proj.weight, at.out_proj.bias)
+        x = layer_norm(x + lyr.dropout1(sa), lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps)
+        ff = linear(lyr.dropout(F.relu(linear(x, lyr.linear1.weight, lyr.linear1.bias))), lyr.linear2.weight, lyr.linear2.bias)
+        return layer_norm(x + lyr.dropout2(ff), lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps)
+
+    def _transformer(self, layer, x):
+        enc = self.transformer_encoder[layer]
+        if self.patch_encoder == "torch":
+            return enc(x)
+        for lyr in enc.layers:
+            x = self._encoder_layer_hip(lyr, x)
+        return x if enc.norm is None else enc.norm(x)
+
+    def _mlp(self, seq, x):
+        """nn.Sequential of Linear/ReLU evaluated on the HIP GEMM (eager torch when patch_encoder == 'torch')"""
+        if self.patch_encoder == "torch":
+            return seq(x)
+        from immtsf.ops import linear
+        for m in seq:
+            x = linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+        return x
+
     def IMTS_Model(self, x_patch):
         B, N, M, D = x_patch.shape
         x = x_patch
         for layer in range(self.n_layer):
             x_last = x if layer > 0 else None
-            x = self.transformer_encoder[layer](self.ADD_PE(x.reshape(B * N, M, D))).view(B, N, M, D)
+            x = self._transformer(layer, self.ADD_PE(x.reshape(B * N, M, D))).view(B, N, M, D)
             nv1 = self.nodevec1.view(1, 1, N, self.nodevec_dim).expand(B, M, N, self.nodevec_dim)
             nv2 = self.nodevec2.view(1, 1, self.nodevec_dim, N).expand(B, M, self.nodevec_dim, N)
             g1 = self.nodevec_gate1[layer](torch.cat([x, nv1.permute(0, 2, 1, 3)], dim=-1))
@@ -168,7 +203,7 @@ class tPatchGNN(nn.Module):
         if self.outlayer == "CNN":
             x = self.temporal_agg(x.reshape(B * N, M, -1).permute(0, 2, 1)).view(B, N, -1)
         else:
-            x = self.temporal_agg(x.reshape(B, N, -1))
+            x = self._mlp(self.temporal_agg, x.reshape(B, N, -1))
         return x
 
     def forecasting(self, time_steps_to_predict, X, truth_time_steps, mask=None):
@@ -181,4 +216,4 @@ class tPatchGNN(nn.Module):
         Lp = time_steps_to_predict.shape[-1]
         te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1).expand(B, N, Lp, 1))
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
-        return self.decoder(h).squeeze(-1).permute(0, 2, 1)
+        return self._mlp(self.decoder, h).squeeze(-1).permute(0, 2, 1)

@@ -198,11 +198,13 @@ int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32
                         int64_t sC_i, int32_t n_outer, int32_t n_inner, int32_t M, int32_t N, int32_t K, float alpha,
                         immtsf_stream_t stream);
 /* softmax over the last dim of (B,H,L,S) scores in place (-> P), A = dropout(P) (A may alias sc when p == 0);
- * causal != 0 applies the TriangularCausalMask of utils/masking.py (key s visible to query l iff s <= l) */
+ * causal != 0 applies the TriangularCausalMask of utils/masking.py (key s visible to query l iff s <= l);
+ * seed_step_dev: optional device counter added to `seed` (see immtsf_fusion_cfg.seed_step_dev) */
 int immtsf_softmax_rows_forward(float* sc, float* A, int32_t B, int32_t H, int32_t L, int32_t S, const uint8_t* live,
-                                float p_drop, uint64_t seed, uint64_t site, int32_t causal, immtsf_stream_t stream);
+                                float p_drop, uint64_t seed, uint64_t site, int32_t causal, const uint64_t* seed_step_dev,
+                                immtsf_stream_t stream);
 int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H, int32_t L, int32_t S, float p_drop,
-                                 uint64_t seed, uint64_t site, immtsf_stream_t stream);
+                                 uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, immtsf_stream_t stream);
 /* LayerNorm(+dropout) rows: xhat,rstd may be NULL in forward when no backward follows */
 int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
                              float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,

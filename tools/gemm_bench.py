@@ -57,6 +57,8 @@ for layout, M, N, K in SHAPES:
     tag = f"{['NT','NN','TN'][layout]} M={M:5d} N={N:5d} K={K:5d}"
     us, err = bench(layout, M, N, K, 0, 0)
     print(f"{tag}  auto       {us:9.1f} us  {2.0*M*N*K/us/1e6:8.2f} TFLOP/s  relerr {err:.1e}", flush=True)
+    us, err = bench(layout, M, N, K, 0x100, 0)
+    print(f"{tag}  auto-noxcd {us:9.1f} us  {2.0*M*N*K/us/1e6:8.2f} TFLOP/s  relerr {err:.1e}", flush=True)
     if sweep and prec == 1:
         for v, name in VARIANTS.items():
             for sk in ((1, 2, 4, 8) if M * N <= 2048 * 1536 else (1,)):

@@ -317,11 +317,11 @@ class LinearFn(torch.autograd.Function):
         _need_gpu(x2, W, b)
         M, K = x2.shape
         N = W.shape[0]
-        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)   # not a view: callers may relu_ it
         _gemm(0, precision, x2, K, W, K, y, N, b, M, N, K)
         ctx.save_for_backward(x2, W)
         ctx.has_bias, ctx.precision, ctx.shape = b is not None, precision, x.shape
-        return y.view(*x.shape[:-1], N)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -355,12 +355,12 @@ class LayerNormFn(torch.autograd.Function):
         rows, d = x2.shape
         xhat = torch.empty_like(x2)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-        z = torch.empty_like(x2)
+        z = torch.empty(x.shape, dtype=torch.float32, device=x.device)
         check(lib.immtsf_layernorm_forward(ptr(x2), rows, d, ptr(gamma), ptr(beta), float(eps), ptr(xhat), ptr(rstd), ptr(z),
                                            0.0, 0, 0, stream_ptr()), "layernorm_forward")
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.shape = x.shape
-        return z.view(x.shape)
+        return z
 
     @staticmethod
     def backward(ctx, dz):

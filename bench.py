@@ -285,6 +285,12 @@ def main():
             fl = 2.0 * Mm * Nn * Kk * nprob * nbatch
             rows.append(dict(key=key, launches=len(v), avg_us=1e3 * float(np.mean(v)), total_ms=float(np.sum(v)), flops=fl))
         rows.sort(key=lambda r: -r["total_ms"])
+        if os.environ.get("IMMTSF_BENCH_GEMM_TABLE"):
+            for r in rows:
+                k = r["key"]
+                print(f"# gemm {['NT','NN','TN'][k[0]]} M={k[2]:6d} N={k[3]:5d} K={k[4]:6d} prob={k[5]} batch={k[6]:4d} dyn={k[7]} "
+                      f"launches/step={r['launches']/k2:5.1f} avg_us={r['avg_us']:7.1f} us/step={r['total_ms']*1e3/k2:7.1f} "
+                      f"TF={r['flops']/(r['avg_us']*1e-6)/1e12:7.2f}", file=sys.stderr)
         gemm_ms = sum(r["total_ms"] for r in rows) / k2
         top = rows[0]
         ach = top["flops"] / (top["avg_us"] * 1e-6) / 1e12

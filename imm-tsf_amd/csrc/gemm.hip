@@ -511,7 +511,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
-    const bool can_split = !g.accumulate && g.act == 0 && !g.relu_ref && g.nbatch <= 1 && g.ldc == g.N && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     if (can_split) {
         if (g_splitk > 0) splits = g_splitk;
@@ -526,7 +526,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             }
         }
     }
-    if (splits > 1 && !g.c_prezeroed) {
+    if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
             hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
             if (e != hipSuccess) return (int)e;
@@ -542,6 +542,9 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         if (v == 0) {
             const long tiles128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * nbz;
             v = tiles128 >= 512 ? 4 : 1;
+            // reductions that are a multiple of 32 but not of 64 (padded small-model dims): 32-deep K tiles keep every
+            // tile on the straight-line loader
+            if (!(g.dyn && g.dyn_which == 1) && (g.K % 64) != 0 && (g.K % 32) == 0 && g.K <= 512) v = 7;
         }
         switch (v) {
             case 1: return launch_cfg<true, 64, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
@@ -550,6 +553,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             case 4: return launch_cfg<true, 128, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 5: return launch_cfg<true, 32, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 6: return launch_cfg<true, 64, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 7: return launch_cfg<true, 64, 64, 32, 2, 2>(layout, g, Mmax, splits, stream);
             default: return IMMTSF_EINVAL;
         }
     }

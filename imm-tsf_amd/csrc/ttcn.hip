@@ -23,7 +23,7 @@ namespace {
 constexpr int LC = 32;   // slots per LDS chunk in the pooling backward
 
 struct Dims { int P, L, F, K, NC, Fp, Kp, NCp, R; };
-inline int r4(int x) { return (x + 3) / 4 * 4; }
+inline int r4(int x) { return (x + 31) / 32 * 32; }   // pad to 32: 16-byte aligned rows AND whole 32-deep GEMM K tiles
 inline Dims mk_dims(int P, int L, int te_dim, int K) {
     Dims d;
     d.P = P; d.L = L; d.F = 1 + te_dim; d.K = K; d.NC = d.F * K;

@@ -46,6 +46,63 @@ inline void set_problem(GemmArgs& g, int i, const float* A, const float* B, floa
     if (bias_grad) g.ones_col = 1;
 }
 
+// ---- fork/join onto a library-owned side stream ---------------------------------------------------------------
+// A linear layer's two backward GEMMs (data gradient NN, weight gradient TN) are independent and each under-fills
+// the 256 CUs at the fusion shapes, so the weight-gradient GEMM is enqueued on a side stream that is forked from and
+// joined back into the caller's stream inside the same call (works eagerly and under hipGraph capture: the side
+// stream joins the capture through the event wait and is merged back before the call returns).  From the caller's
+// point of view everything is still ordered on `stream`.
+struct SideStream {
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int device = -1;
+    bool ok = false;
+};
+inline SideStream& side_stream_state() {
+    static SideStream st[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    SideStream& s = st[dev & 15];
+    if (!s.ok && s.device != -2) {
+        s.device = -2;   // tried
+        if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&s.ev_fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s.ev_join, hipEventDisableTiming) == hipSuccess)
+            s.ok = true;
+    }
+    return s;
+}
+extern "C" int immtsf_side_stream_enabled(void);
+class Fork {
+public:
+    explicit Fork(hipStream_t main) : main_(main), st_(side_stream_state()), used_(false) {
+        active_ = st_.ok && immtsf_side_stream_enabled();
+    }
+    // stream for work that may run concurrently with what follows on the main stream; everything enqueued on the main
+    // stream so far is a dependency
+    hipStream_t fork() {
+        if (!active_) return main_;
+        if (hipEventRecord(st_.ev_fork, main_) != hipSuccess || hipStreamWaitEvent(st_.side, st_.ev_fork, 0) != hipSuccess) {
+            active_ = false;
+            return main_;
+        }
+        used_ = true;
+        return st_.side;
+    }
+    // main stream waits for all side work
+    int join() {
+        if (!used_) return 0;
+        used_ = false;
+        hipError_t e = hipEventRecord(st_.ev_join, st_.side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_, st_.ev_join, 0);
+        return e == hipSuccess ? 0 : (int)e;
+    }
+private:
+    hipStream_t main_;
+    SideStream& st_;
+    bool active_, used_;
+};
+
 #define CHECK(x) do { int rc__ = (x); if (rc__ != 0) return rc__; } while (0)
 
 inline bool bad_cfg(const immtsf_fusion_cfg* c) {

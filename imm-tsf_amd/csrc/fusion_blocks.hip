@@ -157,6 +157,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
     const float scale = sqrtf(1.0f / (float)hd);
+    Fork fk(s);   // weight-gradient GEMMs run on the side stream, joined before returning
 
     {   // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -165,7 +166,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, dE_txt, w.z, gr->proj_out_w, nullptr, gr->proj_out_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
     CHECK(launch_colsum(sc.dz, w.xhat, BT, nullptr, d, d, gr->ln_w, 0, sc.red, s));
@@ -180,7 +181,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, sc.dx, w.ctx, gr->attn_out_w, nullptr, gr->attn_out_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
     CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp, sc.dqs_part, sc.dp, drop,
@@ -200,7 +201,7 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         set_problem(h, 0, sc.dKVp, w.KV, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
         h.dyn = total; h.dyn_which = 1;
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // KV_proj
         GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
@@ -211,17 +212,18 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
         set_problem(h, 0, sc.dKV, w.Xcat, gr->kv_w, nullptr, gr->kv_b);
         h.dyn = total; h.dyn_which = 1;
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = w.rowmap;
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    return launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
-                               gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, 0, s);
+    CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
+                              gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, 0, s));
+    return fk.join();
 }
 
 }  // extern "C"

@@ -150,6 +150,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
     const DropCfg drop = drop_of(cfg);
     const long TT2 = (long)T * T;
     const float scale = sqrtf(1.0f / (float)hd);
+    Fork fk(s);   // weight-gradient GEMMs run on the side stream, joined before returning
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
@@ -163,7 +164,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
         set_problem(h, 0, sc.ddelta, w.U, gr->res_w, nullptr, gr->res_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // out_proj
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -172,7 +173,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, sc.dU, w.O, gr->attn_out_w, nullptr, gr->attn_out_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
         GemmArgs g = gemm_args(T, T, hd, d, d, T);
@@ -182,8 +183,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         GemmArgs h = gemm_args(T, hd, T, T, d, d);
         set_problem(h, 0, w.Am, sc.dO, sc.dVi, nullptr);
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));      // consumed by the in-projection GEMMs below: main stream
     }
     CHECK(launch_softmax_rows_bwd(sc.dA, w.Pm, B, H, T, T, drop, SITE_XADD_ATTN, s));
     {   // dQ_h = scale dS K_h ; dK_h = scale dS^T Q_h
@@ -196,8 +196,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         set_problem(h, 0, sc.dA, w.Qi, sc.dKi, nullptr);
         h.alpha = scale;
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));      // consumed by the in-projection GEMMs below: main stream
     }
     {   // MHA in-projections
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -212,7 +211,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         set_problem(h, 1, sc.dKi, w.K0, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
         set_problem(h, 2, sc.dVi, w.V0, gr->attn_in_w + (size_t)2 * d * d, nullptr, gr->attn_in_b + 2 * d);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // proj_q: dY += dQ0 W_q ; dW_q = dQ0^T Y
         GemmArgs g = gemm_args(BT, C, d, d, C, C);
@@ -222,7 +221,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         GemmArgs h = gemm_args(d, C, BT, d, C, C);
         set_problem(h, 0, sc.dQ0, Y_ts, gr->proj_q_w, nullptr);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // proj_k / proj_v: dE = dK0 W_k + dV0 W_v ; dW_k = dK0^T E ; dW_v = dV0^T E
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -237,9 +236,9 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
         set_problem(h, 0, sc.dK0, E_txt, gr->proj_k_w, nullptr);
         set_problem(h, 1, sc.dV0, E_txt, gr->proj_v_w, nullptr);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    return IMMTSF_OK;
+    return fk.join();
 }
 
 }  // extern "C"

@@ -150,6 +150,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, R = B * N, BT = B * T, prec = cfg->precision;
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
+    Fork fk(s);
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem(g, 0, dE_txt, p->proj_w, sc.dz, nullptr);
@@ -157,7 +158,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem(h, 0, dE_txt, w.z, gr->proj_w, nullptr, gr->proj_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
     CHECK(launch_colsum(sc.dz, w.xhat, BT, nullptr, d, d, gr->ln_w, 0, sc.red, s));
@@ -170,9 +171,9 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         set_problem(h, 0, sc.dVp, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = w.rowmap;
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    return IMMTSF_OK;
+    return fk.join();
 }
 
 size_t immtsf_mmf_gr_add_workspace_bytes(const immtsf_fusion_cfg* cfg, int32_t hidden) {
@@ -220,6 +221,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = cfg->B, T = cfg->T, d = cfg->d, C = cfg->C, BT = B * T, I = C + d, prec = cfg->precision;
     const DropCfg drop = drop_of(cfg);
+    Fork fk(s);
     CHECK(launch_gr_tail_bwd(BT, T, C, Hd, dY_out, p->res_w, p->ln_w, w.xhat, w.rstd, w.g, w.dd, M_txt, sc.dn, sc.ddelta,
                              sc.dgl, sc.dh_in, drop, SITE_GR_OUT, s));
     CHECK(launch_colsum(sc.dn, w.xhat, BT, nullptr, C, C, gr->ln_w, 0, sc.red, s));
@@ -228,20 +230,20 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
         GemmArgs h = gemm_args(C, Hd, BT, C, Hd, Hd);
         set_problem(h, 0, sc.ddelta, w.h, gr->res_w, nullptr, gr->res_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_gru_bwd(B, T, Hd, sc.dh_in, p->w_hh, w.r, w.z, w.n, w.hn, w.hprev, sc.dgi, sc.dgh, s));
     {   // recurrent weights: dW_hh = dgh^T h_prev ; db_hh
         GemmArgs h = gemm_args(3 * Hd, Hd, BT, 3 * Hd, Hd, Hd);
         set_problem(h, 0, sc.dgh, w.hprev, gr->w_hh, nullptr, gr->b_hh);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // input weights: dW_ih = dgi^T x ; db_ih ; dx = dgi W_ih
         GemmArgs h = gemm_args(3 * Hd, I, BT, 3 * Hd, I, I);
         set_problem(h, 0, sc.dgi, w.x, gr->w_ih, nullptr, gr->b_ih);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
         GemmArgs g = gemm_args(BT, I, 3 * Hd, 3 * Hd, I, I);
         set_problem(g, 0, sc.dgi, p->w_ih, sc.dx, nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
@@ -250,7 +252,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
         GemmArgs h = gemm_args(C, I, BT, C, I, I);
         set_problem(h, 0, sc.dgl, w.x, gr->gate_w, nullptr, gr->gate_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
         GemmArgs g = gemm_args(BT, I, C, C, I, I);
         set_problem(g, 0, sc.dgl, p->gate_w, sc.dx, nullptr);
         g.accumulate = 1;
@@ -259,7 +261,8 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     // dY = dYout (direct path: out = Y + (1-g) dd) + dx[:, :C] ; dE = dx[:, C:]
     hipError_t e = hipMemcpyAsync(dY_ts, dY_out, (size_t)BT * C * sizeof(float), hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
-    return launch_split2(sc.dx, C, d, BT, dY_ts, 1, dE_txt, s);
+    CHECK(launch_split2(sc.dx, C, d, BT, dY_ts, 1, dE_txt, s));
+    return fk.join();
 }
 
 }  // extern "C"

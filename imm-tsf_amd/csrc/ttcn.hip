@@ -263,6 +263,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
     hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, sc.dX, sc.dpool);
     IMMTSF_LAUNCH_CHECK();
+    Fork fk(s);
     CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
     {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once for the split-K GEMMs
         const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
@@ -273,7 +274,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
         GemmArgs h = gemm_args(d.NCp, d.Kp, d.R, d.NCp, d.Kp, d.Kp);
         set_problem(h, 0, w.S, w.h2, sc.gW3p, nullptr, sc.gb3p);
         h.c_prezeroed = 1;
-        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, fk.fork()));
         GemmArgs g = gemm_args(d.R, d.Kp, d.NCp, d.NCp, d.Kp, d.Kp);
         set_problem(g, 0, w.S, w.W3p, sc.dz2, nullptr);
         g.relu_ref = w.h2; g.ld_ref = d.Kp;
@@ -283,7 +284,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
         GemmArgs h = gemm_args(d.Kp, d.Kp, d.R, d.Kp, d.Kp, d.Kp);
         set_problem(h, 0, sc.dz2, w.h1, sc.gW2p, nullptr, sc.gb2p);
         h.c_prezeroed = 1;
-        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, fk.fork()));
         GemmArgs g = gemm_args(d.R, d.Kp, d.Kp, d.Kp, d.Kp, d.Kp);
         set_problem(g, 0, sc.dz2, w.W2p, sc.dz1, nullptr);
         g.relu_ref = w.h1; g.ld_ref = d.Kp;
@@ -293,12 +294,13 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
         GemmArgs h = gemm_args(d.Kp, d.Fp, d.R, d.Kp, d.Fp, d.Fp);
         set_problem(h, 0, sc.dz1, w.X, sc.gW1p, nullptr, sc.gb1p);
         h.c_prezeroed = 1;
-        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, fk.fork()));
         GemmArgs g = gemm_args(d.R, d.Fp, d.Kp, d.Kp, d.Fp, d.Fp);
         set_problem(g, 0, sc.dz1, w.W1p, sc.dX, nullptr);
         g.accumulate = 1;
         CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
     }
+    CHECK(fk.join());      // the padded weight gradients come from the side stream
     UnpackPtrs u{sc.gW1p, sc.gb1p, sc.gW2p, sc.gb2p, sc.gW3p, sc.gb3p, gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3};
     hipLaunchKernelGGL(unpack_g_kernel, dim3(cdiv(d.NC * d.K, 256)), dim3(256), 0, s, d, u);
     IMMTSF_LAUNCH_CHECK();

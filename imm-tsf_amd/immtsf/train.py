@@ -144,6 +144,10 @@ class FlatTrainer:
         is exactly the single-process full-batch gradient."""
         self._collect_autograd_grads()
         if self.world > 1:
+            if not self.overlap and not any(self._reduced):
+                import torch.distributed as dist
+                dist.all_reduce(self.flat_grad, group=self.group)      # one collective for the whole flat buffer
+                self._reduced = [True] * len(self.buckets)
             for bi in range(len(self.buckets)):
                 self._bucket_ready(bi)
             if self.overlap:

@@ -239,6 +239,10 @@ int immtsf_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
  * precision, M, N, K, nprob, nbatch, dyn) and ms[max]; returns the number of records and resets the tap.
  * This tap is the library's only process-global state; it is off by default. */
 int immtsf_timing_enable(int32_t on);
+/* Backward calls enqueue weight-gradient GEMMs on a library-owned side stream forked from / joined into `stream`
+ * inside the call (concurrency with the data-gradient GEMMs; valid under hipGraph capture).  0 disables it. */
+int immtsf_set_side_stream(int32_t on);
+int immtsf_side_stream_enabled(void);
 /* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);
 int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);

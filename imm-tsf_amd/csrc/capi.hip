@@ -17,7 +17,7 @@ inline DropCfg mk_drop(float p, uint64_t seed) {
 }
 }  // namespace
 
-namespace { int g_side_enabled = 1; }
+namespace { int g_side_enabled = 0; }   // measured slower under hipGraph replay at the cfg2 shapes (3.18 vs 2.64 ms/step): off by default
 
 extern "C" {
 

@@ -267,17 +267,17 @@ def main():
             eager_step()      # the tap records at launch time, so this leg launches eagerly (same kernels, same shapes)
         torch.cuda.synchronize()
         cap = 16384
-        meta = (ctypes.c_int32 * (8 * cap))()
+        meta = (ctypes.c_int32 * (10 * cap))()
         ms = (ctypes.c_float * cap)()
         n = lib.immtsf_timing_collect(cap, meta, ms)
         lib.immtsf_timing_enable(0)
         groups = {}
         for i in range(n):
-            key = tuple(meta[8 * i:8 * i + 8])
+            key = tuple(meta[10 * i:10 * i + 9])
             groups.setdefault(key, []).append(ms[i])
         rows = []
         for key, v in groups.items():
-            layout, prec, Mm, Nn, Kk, nprob, nbatch, dyn = key
+            layout, prec, Mm, Nn, Kk, nprob, nbatch, dyn, grid_threads = key
             if dyn == 1:
                 Mm = sum_n
             elif dyn == 2:
@@ -296,9 +296,22 @@ def main():
         ach = top["flops"] / (top["avg_us"] * 1e-6) / 1e12
         allfl = sum(r["flops"] * r["launches"] for r in rows) / sum(r["total_ms"] for r in rows) / 1e9
         lay = {0: "NT", 1: "NN", 2: "TN"}[top["key"][0]]
+        # HBM traffic of that kernel instance from the committed rocprofv3 PMC passes (tools/pmc_summary.py): matched by
+        # kernel template + launch grid
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            tag = {0: "<true, false, false", 1: "<true, false, true", 2: "<true, true, true"}[top["key"][0]]
+            for kr in pmc["kernels"]:
+                if "gemm_kernel" + tag in kr["kernel"] and kr["grid_threads"] == top["key"][8]:
+                    traffic = kr["fetch_bytes_per_launch"] + (kr["write_bytes_per_launch"] or 0)
+                    break
+        except Exception:
+            traffic = None
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
                     "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 5),
-                    "traffic": None,
+                    "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                    "algorithmic_bytes": 4 * (top["key"][2] * top["key"][4] + top["key"][3] * top["key"][4] + top["key"][2] * top["key"][3]) * top["key"][5],
                     "kernel": f"gemm_kernel {lay} M={top['key'][2]} N={top['key'][3]} K={top['key'][4]} x{top['key'][5] * top['key'][6]}",
                     "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches"] // k2,
                     "all_gemm_ms_per_step": round(gemm_ms, 4), "all_gemm_tflops": round(allfl, 2),

@@ -404,11 +404,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+long g_last_grid_threads = 0;   // for the timing tap: lets bench.py match a launch with rocprof's Grid_Size
+
 template <bool BF16, int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
     const int Nlog = g.N + ((layout == GEMM_TN && g.ones_col) ? 1 : 0);
     dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), splits, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block(WM * WN * 64);
     if (grid.x == 0) return IMMTSF_OK;
+    g_last_grid_threads = (long)grid.x * grid.y * grid.z * block.x;
     switch (layout) {
         case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BF16, false, false, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
         case GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BF16, false, true, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
@@ -434,7 +437,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
 // ---- optional per-launch timing tap (bench.py's roofline leg): hipEvents bracket every GEMM launch on the
 // stream it is launched on.  Off by default; the only process-global state in the library.
 namespace {
-struct TapRec { hipEvent_t e0, e1; int meta[8]; };
+struct TapRec { hipEvent_t e0, e1; int meta[10]; };
 constexpr int kTapCap = 16384;
 TapRec* g_tap = nullptr;
 int g_tap_n = 0, g_tap_on = 0, g_tap_events = 0;
@@ -454,6 +457,8 @@ int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t strea
     (void)hipEventRecord(r.e0, stream);
     const int rc = launch_gemm_impl(layout, precision, g, stream);
     (void)hipEventRecord(r.e1, stream);
+    r.meta[8] = (int)g_last_grid_threads;
+    r.meta[9] = 0;
     ++g_tap_n;
     return rc;
 }
@@ -465,7 +470,7 @@ extern "C" int immtsf_timing_enable(int on) {
     return 0;
 }
 
-// host arrays: meta[8*max] (layout, precision, M, N, K, nprob, nbatch, dyn), ms[max]; returns the record count
+// host arrays: meta[10*max] (layout, precision, M, N, K, nprob, nbatch, dyn, grid threads, 0), ms[max]
 extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
     const int n = g_tap_n < max ? g_tap_n : max;
     for (int i = 0; i < n; ++i) {
@@ -473,7 +478,7 @@ extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
         float t = 0.f;
         (void)hipEventElapsedTime(&t, g_tap[i].e0, g_tap[i].e1);
         ms[i] = t;
-        for (int k = 0; k < 8; ++k) meta[8 * i + k] = g_tap[i].meta[k];
+        for (int k = 0; k < 10; ++k) meta[10 * i + k] = g_tap[i].meta[k];
     }
     g_tap_n = 0;
     return n;

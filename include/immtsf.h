@@ -235,8 +235,8 @@ int immtsf_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
                          float* norm_scratch, uint64_t* dropout_step_dev, immtsf_stream_t stream);
 
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
- * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[8*max] = (layout,
- * precision, M, N, K, nprob, nbatch, dyn) and ms[max]; returns the number of records and resets the tap.
+ * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
+ * precision, M, N, K, nprob, nbatch, dyn, grid threads, 0) and ms[max]; returns the number of records and resets the tap.
  * This tap is the library's only process-global state; it is off by default. */
 int immtsf_timing_enable(int32_t on);
 /* Backward calls enqueue weight-gradient GEMMs on a library-owned side stream forked from / joined into `stream`

@@ -147,17 +147,22 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
     }
 }
 
+// one wave per feature column: lanes stride over the slabs, shuffle-reduce
 __global__ __launch_bounds__(256) void time2vec_bwd_final_kernel(const float* __restrict__ partial, int d_tau,
                                                                   float* dw0, float* db0, float* dw, float* db, int nsl) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= d_tau) return;
     float aw = 0.f, ab = 0.f;
-    for (int s = 0; s < nsl; ++s) {
+    for (int s = lane; s < nsl; s += 64) {
         aw += partial[((size_t)s * 2 + 0) * d_tau + j];
         ab += partial[((size_t)s * 2 + 1) * d_tau + j];
     }
-    if (j == 0) { dw0[0] = aw; db0[0] = ab; }
-    else { dw[j - 1] = aw; db[j - 1] = ab; }
+    aw = wave_sum(aw);
+    ab = wave_sum(ab);
+    if (lane == 0) {
+        if (j == 0) { dw0[0] = aw; db0[0] = ab; }
+        else { dw[j - 1] = aw; db[j - 1] = ab; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- column sums
@@ -338,7 +343,7 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
     hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), nslabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
                        dfeat, ld, scratch, max_rows);
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 256)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs);
+    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 4)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

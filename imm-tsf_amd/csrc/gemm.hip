@@ -305,10 +305,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
         for (int t = t0; t < t1; ++t) {
             const int cur = (t - t0) & 1;
-            if (t + 1 < t1) loader((t + 1) * BK);            // issue early: in flight under this tile's MFMAs
-            compute(cur);
+            if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);   // issue early: in flight under this tile's MFMAs
+            if (!(g.dbg & 1)) compute(cur);
             __builtin_amdgcn_sched_barrier(0);                // keep the LDS writes (and their vmcnt wait) behind the MFMAs
-            if (t + 1 < t1) store_tile(cur ^ 1);              // other buffer: last read one barrier ago
+            if (t + 1 < t1 && !(g.dbg & 4)) store_tile(cur ^ 1);    // other buffer: last read one barrier ago
             __syncthreads();
         }
     };
@@ -423,13 +423,14 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 }
 
 // tuning override for tools/gemm_bench.py (0 = heuristic)
-int g_variant = 0, g_splitk = 0, g_xcd = 1;
+int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0;
 
 }  // namespace
 
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_variant = variant & 0xff;
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
+    g_dbg = (variant >> 9) & 7;             // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
     g_splitk = splitk;
     return 0;
 }
@@ -504,6 +505,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     for (int i = 0; i < g.nprob; ++i) vc = vc && ((reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0);
     if (g.nbatch > 1) vc = vc && (g.sC_o % 4 == 0) && (g.sC_i % 4 == 0);
     g.vecC = vc ? 1 : 0;
+    g.dbg = g_dbg;
     {   // XCD-aware order pays when several L2s would otherwise stream the same mid-sized operands; it hurts once
         // the grid is large enough that the default order already keeps every XCD on its own tile rows
         const long gx = (long)cdiv(g.M, 64) * cdiv(g.N, 64);

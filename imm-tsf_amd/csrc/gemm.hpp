@@ -45,6 +45,7 @@ struct GemmArgs {
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
     int xcd_remap;         // set by the launcher
+    int dbg;               // ablation flags (tools/gemm_bench.py), 0 in production
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

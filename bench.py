@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -193,10 +194,12 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(global_cnt)
 
+    from lib.evaluation import forecast_and_fuse
+    backbone_stream = None if args.no_overlap else torch.cuda.Stream(device=dev)
+
     def fwd_bwd():
         trainer.zero_grad()
-        pred = model.forecasting(batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
-        out = fusion(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"], pred)
+        out = forecast_and_fuse(model, fusion, batch, backbone_stream)
         loss = masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], None, global_cnt)
         loss.backward()
         return loss
@@ -365,7 +368,8 @@ def main():
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "launch": "hipGraph replay (2 graphs/step)" if use_graph else "eager",
+            "launch": ("hipGraph replay (2 graphs/step)" if use_graph else "eager") +
+                      ("" if args.no_overlap else ", backbone on a second HIP stream beside TTF"),
             "config": {"workload": "cfg2: tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT2 dims (d_m=d_txt=768, H=1), "
                                    "64 ragged windows per GPU (N_b~U{1..32}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",

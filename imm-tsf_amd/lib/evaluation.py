@@ -42,6 +42,26 @@ def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None)
     raise Exception("Reduce argument not specified!")
 
 
+def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
+    """backbone forecast -> fusion.  The backbone and the text-timestamp fusion (TTF) do not depend on each other
+    -- only the modality fusion (MMF) needs both -- so with `side_stream` the backbone is enqueued on that HIP stream
+    while TTF runs on the current one, joined before MMF.  autograd replays each backward on its forward's stream, so
+    the two backward halves overlap the same way.  Both halves are latency-bound at 64 windows; overlapping them is
+    worth more than any single kernel."""
+    notes, tau, tp = batch_dict["notes_embeddings"], batch_dict["tau"], batch_dict["tp_to_predict"]
+    fc_args = (tp, batch_dict["observed_data"], batch_dict["observed_tp"], batch_dict["observed_mask"])
+    if side_stream is None or not hasattr(fusion, "ttf"):
+        return fusion(notes, tau, tp, model.forecasting(*fc_args))
+    main = torch.cuda.current_stream()
+    side_stream.wait_stream(main)
+    with torch.cuda.stream(side_stream):
+        pred_y = model.forecasting(*fc_args)
+    E_txt, M_txt = fusion.ttf(notes, tau, tp)
+    main.wait_stream(side_stream)
+    pred_y.record_stream(main)
+    return fusion.mmf(pred_y, E_txt, M_txt)
+
+
 def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_embeddings=True, group=None):
     """One training-step forward: backbone forecast -> fusion -> masked MSE (lib/evaluation.py:72-164).
     The reference's per-step host syncs (NaN checks, per-row mask loop, .item()) follow immtsf.config.nan_check:

@@ -36,6 +36,38 @@ int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, 
     return immtsf_launch_gemm(layout, precision, g, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_linear_backward(int32_t precision, const float* x, const float* W, const float* dy, int32_t M, int32_t N,
+                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, immtsf_stream_t stream) {
+    if (!dy || M <= 0 || N <= 0 || K <= 0 || (db && !dW) || (dx && !W) || (dW && !x)) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dx) {                   // dx (M,K) = dy (M,N) @ W (N,K)
+        GemmArgs g = gemm_args(M, K, N, N, K, K);
+        set_problem(g, 0, dy, W, dx, nullptr);
+        g.relu_ref = relu_x;
+        g.ld_ref = K;
+        if (int rc = immtsf_launch_gemm(GEMM_NN, precision, g, s)) return rc;
+    }
+    if (dW) {                   // dW (N,K) = dy^T (N,M) @ x (M,K); db = dy^T 1
+        GemmArgs g = gemm_args(N, K, M, N, K, K);
+        set_problem(g, 0, dy, x, dW, nullptr, db);
+        if (int rc = immtsf_launch_gemm(GEMM_TN, precision, g, s)) return rc;
+    }
+    return IMMTSF_OK;
+}
+
+int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float* w0, const float* b0, const float* w,
+                            const float* b, float* out, immtsf_stream_t stream) {
+    if (!t || !w0 || !b0 || !out || d < 1 || (d > 1 && (!w || !b))) return IMMTSF_EINVAL;
+    return launch_time2vec_fwd(t, nullptr, nullptr, rows, d, w0, b0, w, b, out, d, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const float* w, const float* b, const float* dout,
+                             float* dw0, float* db0, float* dw, float* db, float* scratch, immtsf_stream_t stream) {
+    if (!t || !dout || !dw0 || !db0 || !scratch || d < 1 || (d > 1 && (!w || !b || !dw || !db))) return IMMTSF_EINVAL;
+    return launch_time2vec_bwd(t, nullptr, nullptr, rows, d, w, b, dout, d, dw0, db0, dw, db, scratch, 64,
+                               static_cast<hipStream_t>(stream));
+}
+
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,
                         int64_t sC_i, int32_t n_outer, int32_t n_inner, int32_t M, int32_t N, int32_t K, float alpha,

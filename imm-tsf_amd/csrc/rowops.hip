@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restri
                                                             const int* __restrict__ total, int d_tau,
                                                             const float* __restrict__ w0, const float* __restrict__ b0,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ dst, int ld_dst) {
+                                                            float* __restrict__ dst, int ld_dst, int max_rows) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int r = (int)(idx / d_tau), j = (int)(idx % d_tau);
-    if (r >= *total) return;
-    const float t = tau_pad[rowmap[r]];
+    if (r >= (total ? *total : max_rows)) return;
+    const float t = tau_pad[rowmap ? rowmap[r] : r];
     dst[(size_t)r * ld_dst + j] = (j == 0) ? fmaf(w0[0], t, b0[0]) : sinf(fmaf(w[j - 1], t, b[j - 1]));
 }
 
@@ -331,7 +331,7 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
     if (max_rows <= 0) return IMMTSF_OK;
     const long n = (long)max_rows * d_tau;
     hipLaunchKernelGGL(time2vec_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tau_pad, rowmap, total, d_tau,
-                       w0, b0, w, b, dst, ld_dst);
+                       w0, b0, w, b, dst, ld_dst, max_rows);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

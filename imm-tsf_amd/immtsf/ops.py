@@ -308,42 +308,134 @@ def _gemm(layout, prec, A, lda, B, ldb, Cm, ldc, bias, M, N, K, alpha=1.0, accum
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x W^T + b on the MFMA GEMM (NT forward, NN data gradient, TN weight gradient)."""
+    """y = act(x W^T + b) on the MFMA GEMM (NT forward with the bias / ReLU epilogue; backward = one
+    immtsf_linear_backward call: NN data gradient, TN weight gradient with the bias gradient folded in)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, precision):
+    def forward(ctx, x, W, b, precision, relu):
         x2 = _c(x).reshape(-1, x.shape[-1])
         W = _c(W)
         _need_gpu(x2, W, b)
         M, K = x2.shape
         N = W.shape[0]
         y = torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=x.device)   # not a view: callers may relu_ it
-        _gemm(0, precision, x2, K, W, K, y, N, b, M, N, K)
-        ctx.save_for_backward(x2, W)
+        _gemm(0, precision, x2, K, W, K, y, N, b, M, N, K, act=1 if relu else 0)
+        ctx.save_for_backward(x2, W, y if relu else None)
         ctx.has_bias, ctx.precision, ctx.shape = b is not None, precision, x.shape
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W = ctx.saved_tensors
+        lib = _lib.load()
+        x2, W, y = ctx.saved_tensors
         M, K = x2.shape
         N = W.shape[0]
         dy2 = dy.contiguous().reshape(M, N)
-        dx = dW = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            _gemm(1, ctx.precision, dy2, N, W, K, dx, K, None, M, K, N)
-            dx = dx.view(ctx.shape)
-        if ctx.needs_input_grad[1]:
-            dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-            _gemm(2, ctx.precision, dy2, N, x2, K, dW, K, None, N, K, M)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(0)
-        return dx, dW, db, None
+        if y is not None:
+            dy2 = torch.ops.aten.threshold_backward(dy2, y.reshape(M, N), 0.0)
+        need_w = ctx.needs_input_grad[1]
+        dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        dW = torch.empty(N, K, dtype=torch.float32, device=dy.device) if need_w else None
+        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (need_w and ctx.has_bias) else None
+        check(lib.immtsf_linear_backward(ctx.precision, ptr(x2), ptr(W), ptr(dy2), M, N, K, ptr(dx), None, ptr(dW), ptr(db),
+                                         stream_ptr()), "linear_backward")
+        return (dx.view(ctx.shape) if dx is not None else None), dW, db, None, None
 
 
-def linear(x, W, b=None, precision=None):
-    return LinearFn.apply(x.float(), W, b, config.precision_code(precision))
+def linear(x, W, b=None, precision=None, relu=False):
+    return LinearFn.apply(x.float(), W, b, config.precision_code(precision), relu)
+
+
+class MLPFn(torch.autograd.Function):
+    """Linear (ReLU Linear)* chain, e.g. tPatchGNN's decoder (models/tPatchGNN.py:158-163): one GEMM per layer forward
+    (bias + ReLU in the epilogue), two per layer backward -- the ReLU mask is applied in the epilogue of the NEXT
+    layer's data-gradient GEMM and the bias gradient rides the weight-gradient GEMM as a ones column."""
+
+    @staticmethod
+    def forward(ctx, x, precision, has_bias, *params):
+        nl = len(has_bias)
+        Ws = [_c(w) for w in params[:nl]]
+        bs = list(params[nl:])
+        acts = [_c(x).reshape(-1, x.shape[-1])]
+        _need_gpu(acts[0], *Ws)
+        for i, W in enumerate(Ws):
+            M, K = acts[-1].shape
+            N = W.shape[0]
+            shape = (M, N) if i + 1 < nl else (*x.shape[:-1], N)
+            y = torch.empty(shape, dtype=torch.float32, device=x.device)
+            _gemm(0, precision, acts[-1], K, W, K, y, N, bs[i], M, N, K, act=1 if i + 1 < nl else 0)
+            acts.append(y)
+        ctx.save_for_backward(*acts[:-1], *Ws)
+        ctx.nl, ctx.has_bias, ctx.precision, ctx.shape = nl, has_bias, precision, x.shape
+        return acts[-1]
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        nl = ctx.nl
+        acts, Ws = ctx.saved_tensors[:nl], ctx.saved_tensors[nl:]
+        dWs, dbs = [None] * nl, [None] * nl
+        g = dy.contiguous().reshape(-1, Ws[-1].shape[0])
+        dev = dy.device
+        for i in reversed(range(nl)):
+            x, W = acts[i], Ws[i]
+            M, K = x.shape
+            N = W.shape[0]
+            need_x = i > 0 or ctx.needs_input_grad[0]
+            need_w = ctx.needs_input_grad[3 + i]
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev) if need_x else None
+            if need_w:
+                dWs[i] = torch.empty(N, K, dtype=torch.float32, device=dev)
+                if ctx.has_bias[i]:
+                    dbs[i] = torch.empty(N, dtype=torch.float32, device=dev)
+            check(lib.immtsf_linear_backward(ctx.precision, ptr(x), ptr(W), ptr(g), M, N, K, ptr(dx),
+                                             ptr(x) if i > 0 else None, ptr(dWs[i]), ptr(dbs[i]), stream_ptr()),
+                  "linear_backward")
+            g = dx
+        return (g.view(ctx.shape) if g is not None else None), None, None, *dWs, *dbs
+
+
+def mlp(x, weights, biases, precision=None):
+    """weights[i] (N_i, K_i), biases[i] (N_i) or None; ReLU between layers, none after the last."""
+    return MLPFn.apply(x.float(), config.precision_code(precision), tuple(b is not None for b in biases), *weights, *biases)
+
+
+class Time2VecFn(torch.autograd.Function):
+    """[w0 t + b0, sin(w t + b)] rows (Time2Vec / tPatchGNN.LearnableTE); t is data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, t, w0, b0, w, b):
+        lib = _lib.load()
+        t1 = _c(t).reshape(-1)
+        _need_gpu(t1, w0, b0)
+        d = 1 + (w.numel() if w is not None else 0)
+        out = torch.empty(*t.shape, d, dtype=torch.float32, device=t.device)
+        check(lib.immtsf_time2vec_forward(ptr(t1), t1.numel(), d, ptr(w0), ptr(b0), ptr(w), ptr(b), ptr(out), stream_ptr()),
+              "time2vec_forward")
+        ctx.save_for_backward(t1, w0, b0, w, b)
+        ctx.d = d
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        t1, w0, b0, w, b = ctx.saved_tensors
+        d = ctx.d
+        g = dout.contiguous().reshape(-1, d)
+        dw0, db0 = torch.empty_like(w0), torch.empty_like(b0)
+        dw = torch.empty_like(w) if w is not None else None
+        db = torch.empty_like(b) if b is not None else None
+        scratch = torch.empty(2 * 64 * d, dtype=torch.float32, device=g.device)
+        check(lib.immtsf_time2vec_backward(ptr(t1), t1.numel(), d, ptr(w), ptr(b), ptr(g), ptr(dw0), ptr(db0), ptr(dw), ptr(db),
+                                           ptr(scratch), stream_ptr()), "time2vec_backward")
+        return None, dw0, db0, dw, db
+
+
+def time2vec(t, w0, b0, w, b):
+    """t (...,) -> (..., 1 + len(w)); w0/b0 = Linear(1,1) weight/bias, w/b = Linear(1,d-1) weight (d-1,1) / bias."""
+    if t.requires_grad:
+        raise RuntimeError("immtsf.time2vec: timestamps are data; no gradient is produced for them")
+    return Time2VecFn.apply(t.float(), _c(w0), _c(b0), None if w is None else _c(w), None if b is None else _c(b))
 
 
 class LayerNormFn(torch.autograd.Function):

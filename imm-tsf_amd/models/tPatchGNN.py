@@ -121,6 +121,10 @@ class tPatchGNN(nn.Module):
 
     # ---- time-aware patch encoder ---------------------------------------------------------------
     def LearnableTE(self, tt):
+        if self.patch_encoder != "torch":      # one HIP kernel forward, two backward (vs. 4 + two K=1 library GEMMs)
+            from immtsf.ops import time2vec
+            return time2vec(tt.squeeze(-1), self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
+                            self.te_periodic.bias)
         return torch.cat([self.te_scale(tt), torch.sin(self.te_periodic(tt))], -1)
 
     def TTCN(self, X_int, mask_X):
@@ -162,7 +166,7 @@ class tPatchGNN(nn.Module):
                            config.next_seed() if p_att > 0 else 0, 900)
         sa = linear(a.reshape(Bs, S, D), at.out_proj.weight, at.out_proj.bias)
         x = layer_norm(x + lyr.dropout1(sa), lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps)
-        ff = linear(lyr.dropout(F.relu(linear(x, lyr.linear1.weight, lyr.linear1.bias))), lyr.linear2.weight, lyr.linear2.bias)
+        ff = linear(lyr.dropout(linear(x, lyr.linear1.weight, lyr.linear1.bias, relu=True)), lyr.linear2.weight, lyr.linear2.bias)
         return layer_norm(x + lyr.dropout2(ff), lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps)
 
     def _transformer(self, layer, x):
@@ -177,8 +181,12 @@ class tPatchGNN(nn.Module):
         """nn.Sequential of Linear/ReLU evaluated on the HIP GEMM (eager torch when patch_encoder == 'torch')"""
         if self.patch_encoder == "torch":
             return seq(x)
-        from immtsf.ops import linear
-        for m in seq:
+        from immtsf.ops import linear, mlp
+        mods = list(seq)
+        if all(isinstance(m, nn.Linear if i % 2 == 0 else nn.ReLU) for i, m in enumerate(mods)) and len(mods) % 2 == 1:
+            lins = mods[0::2]
+            return mlp(x, [m.weight for m in lins], [m.bias for m in lins])
+        for m in mods:
             x = linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
         return x
 
@@ -214,6 +222,8 @@ class tPatchGNN(nn.Module):
         x_patch = self._encode_patches(flat(X), flat(truth_time_steps), flat(mask)).view(B, N, M, -1)
         h = self.IMTS_Model(x_patch)                                     # (B,N,hid)
         Lp = time_steps_to_predict.shape[-1]
-        te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1).expand(B, N, Lp, 1))
+        # the reference repeats the prediction times over the N variables before embedding them (:283-285); the
+        # embedding is the same for every variable, so embed once and broadcast (expand's backward sums over N)
+        te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1)).expand(B, N, Lp, self.te_dim)
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
         return self._mlp(self.decoder, h).squeeze(-1).permute(0, 2, 1)

@@ -192,6 +192,18 @@ int immtsf_masked_mse_finish(const float* truth, const float* pred, const float*
 int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                 int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,
                 int32_t act, immtsf_stream_t stream);
+/* nn.Linear autograd in one call (x:(M,K), W:(N,K), dy:(M,N)): dx = dy W, optionally masked with relu_x (dx[m,k] = 0
+ * where relu_x[m,k] <= 0: x was a ReLU output, so dx is the gradient of the PRE-activation); dW = dy^T x; db = column
+ * sums of dy (folded into the dW GEMM as a virtual ones column).  Any of dx / dW+db may be NULL; db needs dW. */
+int immtsf_linear_backward(int32_t precision, const float* x, const float* W, const float* dy, int32_t M, int32_t N,
+                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, immtsf_stream_t stream);
+/* Time2Vec / tPatchGNN LearnableTE rows (fusions/TTF_T2V_XAttn.py:7-24, models/tPatchGNN.py:176-180):
+ * out[r,0] = w0*t[r]+b0, out[r,j] = sin(w[j-1]*t[r]+b[j-1]).  backward: parameter gradients from dout (t is data);
+ * scratch >= 2*64*d floats. */
+int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float* w0, const float* b0, const float* w,
+                            const float* b, float* out, immtsf_stream_t stream);
+int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const float* w, const float* b, const float* dout,
+                             float* dw0, float* db0, float* dw, float* db, float* scratch, immtsf_stream_t stream);
 /* batched over (outer, inner) with element strides, used by FullAttention (layers/SelfAttention_Family.py:50-77) */
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,

@@ -135,3 +135,61 @@ def test_data_embedding():
     assert _rel(o, z["out"]) < 1e-4
     (o * _t(z["upstream"], dev)).sum().backward()
     assert _rel(x.grad, z["gx"]) < 2e-4 and _rel(de.value_embedding.tokenConv.weight.grad, z["gw"]) < 2e-4
+
+
+@pytest.mark.parametrize("rows,dims", [(16384, (42, 32, 32, 1)), (512, (64, 32)), (1000, (19, 31, 7))])
+def test_mlp_chain_vs_torch(rows, dims):
+    """Linear (ReLU Linear)* on the HIP GEMM (ReLU mask in the next layer's dgrad epilogue, bias gradient as a ones
+    column of the wgrad GEMM) against the same nn.Sequential in eager torch: fp32, 1e-4 / 2e-4."""
+    dev = _dev()
+    from immtsf import config, ops
+    config.precision = "fp32"
+    torch.manual_seed(rows)
+    mods = []
+    for i in range(len(dims) - 1):
+        mods += [torch.nn.Linear(dims[i], dims[i + 1]), torch.nn.ReLU()]
+    seq = torch.nn.Sequential(*mods[:-1]).to(dev)
+    lins = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    x = torch.randn(rows // 8, 8, dims[0], device=dev)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    up = torch.randn(rows // 8, 8, dims[-1], device=dev)
+    ref = seq(xa)
+    (ref * up).sum().backward()
+    ref_g = [p.grad.clone() for p in seq.parameters()]
+    seq.zero_grad()
+    out = ops.mlp(xb, [m.weight for m in lins], [m.bias for m in lins])
+    (out * up).sum().backward()
+    assert _rel(out, ref.detach().cpu()) < 1e-4
+    assert _rel(xb.grad, xa.grad.cpu()) < 2e-4
+    for p, g in zip(seq.parameters(), ref_g):
+        assert _rel(p.grad, g.cpu()) < 2e-4
+    # single Linear with the fused ReLU epilogue
+    seq.zero_grad()
+    xc = x.clone().requires_grad_(True)
+    y = ops.linear(xc, lins[0].weight, lins[0].bias, relu=True)
+    yr = torch.relu(torch.nn.functional.linear(x, lins[0].weight.detach(), lins[0].bias.detach()))
+    assert _rel(y, yr.cpu()) < 1e-4
+    y.sum().backward()
+    assert _rel(lins[0].bias.grad, (yr > 0).float().reshape(-1, dims[1]).sum(0).cpu()) < 2e-4
+
+
+def test_time2vec_vs_torch():
+    dev = _dev()
+    from immtsf import ops
+    torch.manual_seed(3)
+    for rows, d in [((64, 1, 32), 10), ((7,), 1), ((2048, 3), 33)]:
+        lin0, lin = torch.nn.Linear(1, 1).to(dev), (torch.nn.Linear(1, d - 1).to(dev) if d > 1 else None)
+        t = torch.rand(*rows, device=dev) * 3
+        parts = [lin0(t.unsqueeze(-1))] + ([torch.sin(lin(t.unsqueeze(-1)))] if lin is not None else [])
+        ref = torch.cat(parts, -1)
+        up = torch.randn_like(ref)
+        ps = list(lin0.parameters()) + (list(lin.parameters()) if lin is not None else [])
+        gref = torch.autograd.grad((ref * up).sum(), ps)
+        out = ops.time2vec(t, lin0.weight, lin0.bias, lin.weight if lin is not None else None,
+                           lin.bias if lin is not None else None)
+        g = torch.autograd.grad((out * up).sum(), ps)
+        assert out.shape == ref.shape and _rel(out, ref.detach().cpu()) < 1e-5
+        for a, b in zip(g, gref):
+            assert _rel(a, b.cpu()) < 2e-4
+    with pytest.raises(RuntimeError):
+        ops.time2vec(t.requires_grad_(True), lin0.weight, lin0.bias, None, None)

@@ -47,6 +47,9 @@ XAddParams = _ptr_struct("XAddParams", [
     "ln_w", "ln_b"])
 TTCNParams = _ptr_struct("TTCNParams", [
     "te_scale_w", "te_scale_b", "te_per_w", "te_per_b", "W1", "b1", "W2", "b2", "W3", "b3", "T_bias"])
+GCNParams = _ptr_struct("GCNParams", [
+    "nodevec1", "nodevec2", "gate1_w", "gate1_b", "gate2_w", "gate2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
+    "mlp_w", "mlp_b"])
 GRParams = _ptr_struct("GRParams", [
     "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
 
@@ -92,6 +95,10 @@ _PROTOS = {
     "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_masked_mse_finish": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                            C.c_float, c_stream]),
+    "immtsf_tpatchgnn_gcn_lds_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "immtsf_tpatchgnn_gcn_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_stream]),
+    "immtsf_tpatchgnn_gcn_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams),
+                                                c_stream]),
     "immtsf_gemm": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_stream]),
     "immtsf_linear_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,

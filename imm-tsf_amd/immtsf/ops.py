@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib, config
-from ._lib import FusionCfg, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
+from ._lib import FusionCfg, GCNParams, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
 
 
 def _need_gpu(*ts):
@@ -295,6 +295,55 @@ def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W
     """Fused LearnableTE + TTCN of tPatchGNN (models/tPatchGNN.py:176-195) on (P, L) patch tensors."""
     return TTCNPatchEncodeFn.apply(x.float(), tt.float(), mask.float(), config.precision_code(precision), te_scale_w,
                                    te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias)
+
+
+class GCNAdaptiveFn(torch.autograd.Function):
+    """tPatchGNN's adaptive-graph stage on (B,N,M,D): one workgroup per (window, patch) cell, params in
+    immtsf_gcn_params order.  Backward recomputes the cell in LDS; parameter gradients accumulate by atomics into one
+    zeroed flat buffer whose slices are returned."""
+
+    @staticmethod
+    def forward(ctx, x, order, *params):
+        lib = _lib.load()
+        x = _c(x)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(x, *params)
+        B, N, M, D = x.shape
+        nd = params[0].shape[1]
+        out = torch.empty_like(x)
+        ps = _struct(GCNParams, params)
+        check(lib.immtsf_tpatchgnn_gcn_forward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out), stream_ptr()),
+              "tpatchgnn_gcn_forward")
+        ctx.dims = (B, N, M, D, nd, order)
+        ctx.save_for_backward(x, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, *params = ctx.saved_tensors
+        B, N, M, D, nd, order = ctx.dims
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=x.device)
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        ps, gs = _struct(GCNParams, params), _struct(GCNParams, grads)
+        check(lib.immtsf_tpatchgnn_gcn_backward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs),
+                                                stream_ptr()), "tpatchgnn_gcn_backward")
+        return (dx, None) + tuple(grads)
+
+
+def gcn_adaptive_supported(N, D, nd, order):
+    return _lib.load().immtsf_tpatchgnn_gcn_lds_bytes(N, D, nd, order) > 0
+
+
+def gcn_adaptive(x, order, nodevec1, nodevec2, gate1, gate2, lin1, lin2, mlp_conv):
+    """x (B,N,M,D) -> (B,N,M,D); gate*: nn.Linear(D+nd,1), lin*: nn.Linear(D,nd), mlp_conv: the 1x1 nn.Conv2d."""
+    return GCNAdaptiveFn.apply(x.float(), int(order), nodevec1, nodevec2, gate1.weight, gate1.bias, gate2.weight, gate2.bias,
+                               lin1.weight, lin1.bias, lin2.weight, lin2.bias, mlp_conv.weight, mlp_conv.bias)
 
 
 # ------------------------------------------------------------------------------------------------ layer primitives

@@ -190,22 +190,34 @@ class tPatchGNN(nn.Module):
             x = linear(x, m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
         return x
 
+    def _graph_stage(self, layer, x):
+        """node-vector gating -> adaptive adjacency -> graph convolution -> 1x1 mixing (reference :212-236), (B,N,M,D)"""
+        B, N, M, D = x.shape
+        gc = self.gconv[layer]
+        if self.patch_encoder != "torch" and not self.supports:
+            from immtsf.ops import gcn_adaptive, gcn_adaptive_supported
+            if gcn_adaptive_supported(N, D, self.nodevec_dim, gc.order):     # one cell's operands fit a CU's LDS
+                return gcn_adaptive(x, gc.order, self.nodevec1, self.nodevec2, self.nodevec_gate1[layer][0],
+                                    self.nodevec_gate2[layer][0], self.nodevec_linear1[layer],
+                                    self.nodevec_linear2[layer], gc.mlp.mlp)
+        nv1 = self.nodevec1.view(1, 1, N, self.nodevec_dim).expand(B, M, N, self.nodevec_dim)
+        nv2 = self.nodevec2.view(1, 1, self.nodevec_dim, N).expand(B, M, self.nodevec_dim, N)
+        g1 = self.nodevec_gate1[layer](torch.cat([x, nv1.permute(0, 2, 1, 3)], dim=-1))
+        g2 = self.nodevec_gate2[layer](torch.cat([x, nv2.permute(0, 3, 1, 2)], dim=-1))
+        p1 = g1 * self.nodevec_linear1[layer](x)
+        p2 = g2 * self.nodevec_linear2[layer](x)
+        nv1 = nv1 + p1.permute(0, 2, 1, 3)
+        nv2 = nv2 + p2.permute(0, 2, 3, 1)
+        adp = F.softmax(F.relu(torch.matmul(nv1, nv2)), dim=-1)
+        return gc(x.permute(0, 3, 1, 2), self.supports + [adp]).permute(0, 2, 3, 1)
+
     def IMTS_Model(self, x_patch):
         B, N, M, D = x_patch.shape
         x = x_patch
         for layer in range(self.n_layer):
             x_last = x if layer > 0 else None
             x = self._transformer(layer, self.ADD_PE(x.reshape(B * N, M, D))).view(B, N, M, D)
-            nv1 = self.nodevec1.view(1, 1, N, self.nodevec_dim).expand(B, M, N, self.nodevec_dim)
-            nv2 = self.nodevec2.view(1, 1, self.nodevec_dim, N).expand(B, M, self.nodevec_dim, N)
-            g1 = self.nodevec_gate1[layer](torch.cat([x, nv1.permute(0, 2, 1, 3)], dim=-1))
-            g2 = self.nodevec_gate2[layer](torch.cat([x, nv2.permute(0, 3, 1, 2)], dim=-1))
-            p1 = g1 * self.nodevec_linear1[layer](x)
-            p2 = g2 * self.nodevec_linear2[layer](x)
-            nv1 = nv1 + p1.permute(0, 2, 1, 3)
-            nv2 = nv2 + p2.permute(0, 2, 3, 1)
-            adp = F.softmax(F.relu(torch.matmul(nv1, nv2)), dim=-1)
-            x = self.gconv[layer](x.permute(0, 3, 1, 2), self.supports + [adp]).permute(0, 2, 3, 1)
+            x = self._graph_stage(layer, x)
             if x_last is not None:
                 x = x_last + x
         if self.outlayer == "CNN":

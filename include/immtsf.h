@@ -177,6 +177,26 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
                          const float* dout, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                          const immtsf_ttcn_params* grads, immtsf_stream_t stream);
 
+/* ---- tPatchGNN adaptive-graph stage (models/tPatchGNN.py:205-238; gcn/nconv/linear :29-84), one (window, patch)
+ * cell per workgroup, everything in LDS.  x, out, dout, dx: (B, N, M, D) contiguous.  Pointers in state_dict order. */
+typedef struct immtsf_gcn_params {
+    float *nodevec1, *nodevec2;     /* (N,nd), (nd,N) */
+    float *gate1_w, *gate1_b;       /* (1,D+nd),(1)   nodevec_gate1[l].0 */
+    float *gate2_w, *gate2_b;       /*                nodevec_gate2[l].0 */
+    float *lin1_w, *lin1_b;         /* (nd,D),(nd)    nodevec_linear1[l] */
+    float *lin2_w, *lin2_b;         /*                nodevec_linear2[l] */
+    float *mlp_w, *mlp_b;           /* (D,(order+1)*D[,1,1]),(D)  gconv[l].mlp.mlp (adaptive support only) */
+} immtsf_gcn_params;
+/* LDS bytes one cell needs, 0 when it does not fit a CU's 160 KB (the caller keeps its own formulation then) */
+size_t immtsf_tpatchgnn_gcn_lds_bytes(int32_t N, int32_t D, int32_t nd, int32_t order);
+int immtsf_tpatchgnn_gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                 const immtsf_gcn_params* p, float* out, immtsf_stream_t stream);
+/* recomputes the cell's forward from x; dx overwritten; parameter gradients are ACCUMULATED (atomics) into `grads`,
+ * which the caller zeroes (or lets run on as a running sum) */
+int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                  const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
+                                  immtsf_stream_t stream);
+
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data
  * parallelism the caller all-reduces them before calling _finish).  scratch: >= 128*C floats.  loss: device scalar.

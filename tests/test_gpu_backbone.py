@@ -129,3 +129,34 @@ def test_backbone_wrappers_vs_reference_golden(name):
         if e > 3e-4:
             bad[k] = e
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,N,M,D,nd,hop", [(64, 8, 2, 32, 10, 1), (3, 5, 3, 16, 4, 2), (2, 41, 2, 64, 10, 1), (1, 1, 1, 8, 2, 3)])
+def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
+    """the one-workgroup-per-cell adaptive-graph kernel (forward, and the recomputing backward with atomically
+    accumulated parameter gradients) against the eager formulation in the same module; fp32, 1e-4 / 2e-4."""
+    dev = _dev()
+    from models.tPatchGNN import tPatchGNN
+    torch.manual_seed(B * 100 + N)
+    args = types.SimpleNamespace(device=str(dev), hid_dim=D, C=N, npatch=M, nlayer=1, te_dim=4, n_heads=1, tf_layer=1,
+                                 node_dim=nd, hop=hop, outlayer="Linear", immtsf_patch_encoder="hip")
+    m = tPatchGNN(args).to(dev)
+    names = ["nodevec1", "nodevec2", "nodevec_gate1.0.0.weight", "nodevec_gate1.0.0.bias", "nodevec_gate2.0.0.weight",
+             "nodevec_gate2.0.0.bias", "nodevec_linear1.0.weight", "nodevec_linear1.0.bias", "nodevec_linear2.0.weight",
+             "nodevec_linear2.0.bias", "gconv.0.mlp.mlp.weight", "gconv.0.mlp.mlp.bias"]
+    ps = dict(m.named_parameters())
+    x = torch.randn(B, N, M, D, device=dev)
+    up = torch.randn(B, N, M, D, device=dev)
+    res = {}
+    for mode in ("torch", "hip"):
+        m.patch_encoder = mode
+        m.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        out = m._graph_stage(0, xi)
+        (out * up).sum().backward()
+        res[mode] = (out.detach(), xi.grad.clone(), {n: ps[n].grad.clone() for n in names})
+    assert _rel(res["hip"][0], res["torch"][0]) < 1e-4
+    assert _rel(res["hip"][1], res["torch"][1]) < 2e-4
+    gmax = max(float(g.abs().max()) for g in res["torch"][2].values())
+    for n in names:
+        assert _rel(res["hip"][2][n], res["torch"][2][n], floor=1e-3 * gmax) < 2e-4, n

@@ -430,7 +430,7 @@ int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0;
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_variant = variant & 0xff;
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
-    g_dbg = (variant >> 9) & 7;             // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
+    g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
     g_splitk = splitk;
     return 0;
 }
@@ -548,10 +548,16 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         int v = g_variant;
         if (v == 0) {
             const long tiles128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * nbz;
-            v = tiles128 >= 512 ? 4 : 1;
+            const bool dyn_k = g.dyn && g.dyn_which == 1;
+            // below ~512 big tiles the grid cannot fill 256 CUs with 128x128 tiles: 64x64 tiles with EIGHT waves
+            // (more wavefronts per CU to cover the load -> LDS -> MFMA latency chain), 128-deep K tiles when every
+            // K tile is then full (r01g sweep: 10-25 % over the 4-wave 64x64x64 tile at the fusion shapes)
+            if (tiles128 >= 512) v = 4;
+            else if (layout == GEMM_TN || dyn_k || (g.K % 128) != 0) v = 11;
+            else v = 14;
             // reductions that are a multiple of 32 but not of 64 (padded small-model dims): 32-deep K tiles keep every
             // tile on the straight-line loader
-            if (!(g.dyn && g.dyn_which == 1) && (g.K % 64) != 0 && (g.K % 32) == 0 && g.K <= 512) v = 7;
+            if (!dyn_k && (g.K % 64) != 0 && (g.K % 32) == 0 && g.K <= 512) v = 7;
         }
         switch (v) {
             case 1: return launch_cfg<true, 64, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
@@ -561,6 +567,13 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             case 5: return launch_cfg<true, 32, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 6: return launch_cfg<true, 64, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 7: return launch_cfg<true, 64, 64, 32, 2, 2>(layout, g, Mmax, splits, stream);
+            case 8: return launch_cfg<true, 64, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 9: return launch_cfg<true, 96, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 10: return launch_cfg<true, 96, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 11: return launch_cfg<true, 64, 64, 64, 2, 4>(layout, g, Mmax, splits, stream);
+            case 12: return launch_cfg<true, 128, 64, 64, 4, 2>(layout, g, Mmax, splits, stream);
+            case 13: return launch_cfg<true, 128, 128, 64, 4, 2>(layout, g, Mmax, splits, stream);
+            case 14: return launch_cfg<true, 64, 64, 128, 2, 4>(layout, g, Mmax, splits, stream);
             default: return IMMTSF_EINVAL;
         }
     }

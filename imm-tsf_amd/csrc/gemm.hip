@@ -249,6 +249,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         return __builtin_bit_cast(bf16x8, v);
     };
 
+    // fragments of one staged tile (all BK/32 k-groups) -> registers.  Split from the MFMAs so that, for the k-major
+    // images, the hardware-transpose reads can be issued BEFORE the next tile's global loads: the compiler guards
+    // ds_read_b64_tr_b16 with a conservative s_waitcnt vmcnt(0), which would otherwise drain those loads in front of
+    // the MFMAs they are meant to overlap (seen in the r01f ISA of the NN/TN kernels).
+    constexpr int KG = BF16 ? BK / 32 : 1;
+    auto read_frags = [&](int buf, bf16x8 (&a)[KG][TM], bf16x8 (&b)[KG][TN]) {
+        const T* As = smem + buf * BUF;
+        const T* Bs = As + GA::elems;
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (GA::kmajor) a[kk][i] = frag_kmajor(As, GA::pitch, wm0 + i * 16, kk * 32);
+                else a[kk][i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(As) + (wm0 + i * 16 + fr) * GA::pitch + kk * 32 + fq * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (GB::kmajor) b[kk][j] = frag_kmajor(Bs, GB::pitch, wn0 + j * 16, kk * 32);
+                else b[kk][j] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(Bs) + (wn0 + j * 16 + fr) * GB::pitch + kk * 32 + fq * 8);
+            }
+        }
+    };
+    auto mfma_frags = [&](const bf16x8 (&a)[KG][TM], const bf16x8 (&b)[KG][TN]) {
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+    };
     auto compute = [&](int buf) {
         const T* As = smem + buf * BUF;
         const T* Bs = As + GA::elems;
@@ -305,8 +336,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         __syncthreads();
         for (int t = t0; t < t1; ++t) {
             const int cur = (t - t0) & 1;
-            if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);   // issue early: in flight under this tile's MFMAs
-            if (!(g.dbg & 1)) compute(cur);
+            if (BF16 && (GA::kmajor || GB::kmajor) && KG <= 2) {   // deeper K tiles: too many live fragments
+                bf16x8 fa[KG][TM], fb[KG][TN];
+                read_frags(cur, fa, fb);
+                __builtin_amdgcn_sched_barrier(0);               // fragment reads stay in front of the global loads
+                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);
+                if (!(g.dbg & 1)) mfma_frags(fa, fb);
+            } else {
+                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);   // issue early: in flight under this tile's MFMAs
+                if (!(g.dbg & 1)) compute(cur);
+            }
             __builtin_amdgcn_sched_barrier(0);                // keep the LDS writes (and their vmcnt wait) behind the MFMAs
             if (t + 1 < t1 && !(g.dbg & 4)) store_tile(cur ^ 1);    // other buffer: last read one barrier ago
             __syncthreads();
@@ -525,7 +564,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         else {
             const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * nbz;
             const int ksteps = cdiv(g.K, 64);
-            if (tiles < 256 && ksteps >= 8) {
+            if ((tiles < 192 && ksteps >= 8) || (tiles < 256 && ksteps >= 32)) {   // r01g: at 200+ tiles the 8-wave tiles beat split-K
                 splits = (int)((512 + tiles - 1) / tiles);
                 if (splits > ksteps / 2) splits = ksteps / 2;
                 if (splits > 512) splits = 512;

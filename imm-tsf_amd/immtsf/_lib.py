@@ -53,6 +53,11 @@ GCNParams = _ptr_struct("GCNParams", [
 GRParams = _ptr_struct("GRParams", [
     "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
 
+class Store(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("tt", "vals", "mask", "row_off", "hist_len", "note_tau", "note_src", "note_off",
+                                           "emb")] + [("C", C.c_int32), ("d_m", C.c_int32)]
+
+
 # name -> (restype, argtypes).  Must list EVERY function include/immtsf.h declares (tests/test_abi.py checks).
 _P = C.POINTER
 _PROTOS = {
@@ -99,6 +104,11 @@ _PROTOS = {
     "immtsf_tpatchgnn_gcn_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_stream]),
     "immtsf_tpatchgnn_gcn_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams),
                                                 c_stream]),
+    "immtsf_collate_series": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_float] + [c_f32p] * 6 + [c_stream]),
+    "immtsf_collate_patches": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                         C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),
+    "immtsf_collate_notes": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_i32p, c_i32p, C.c_void_p,
+                                       c_stream]),
     "immtsf_gemm": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_stream]),
     "immtsf_linear_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,

@@ -207,6 +207,39 @@ int immtsf_masked_mse_finish(const float* truth, const float* pred, const float*
                              const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
                              immtsf_stream_t stream);
 
+/* ---- device-side batch builder: the reference's collate functions over a dataset that is
+ * resident in HBM.  Replaces lib/parse_datasets.py:252-295 (variable_time_collate_fn), :298-366 +
+ * lib/utils.py:359-413 (patch_variable_time_collate_fn / split_and_patch_batch) and :764-824 (multimodal wrapper).
+ * All arrays are device memory owned by the caller; window w owns rows row_off[w]..row_off[w+1]) of tt/vals/mask
+ * (times ascending, chunk-relative; the first hist_len[w] rows have tt < history) and notes
+ * note_off[w]..note_off[w+1]) of note_tau/note_src (note_src = row of the note in the resident matrix `emb`). */
+typedef struct immtsf_store {
+    const float* tt;            /* [rows] */
+    const float* vals;          /* [rows, C] */
+    const float* mask;          /* [rows, C] 0/1 */
+    const int64_t* row_off;     /* [W+1] */
+    const int32_t* hist_len;    /* [W] */
+    const float* note_tau;      /* [notes] chunk-relative note times */
+    const int64_t* note_src;    /* [notes] */
+    const int64_t* note_off;    /* [W+1] */
+    const float* emb;           /* [*, d_m] resident text-embedding matrix */
+    int32_t C, d_m;
+} immtsf_store;
+/* outputs zero-padded like pad_sequence: obs_* (B,Lmax[,C]) (all three NULL to skip, as tPatchGNN does),
+ * pred_* (B,Lpmax[,C]); times divided by time_max (= history + pred_window) as normalize_masked_tp does */
+int immtsf_collate_series(const immtsf_store* s, const int32_t* window_ids, int32_t B, int32_t Lmax, int32_t Lpmax,
+                          float time_max, float* obs_tp, float* obs_data, float* obs_mask, float* pred_tp,
+                          float* pred_data, float* pred_mask, immtsf_stream_t stream);
+/* tPatchGNN patches: out (B,npatch,Lp,C); patch i covers [i*stride, i*stride+size), the last one up to `history`;
+ * per (b,i,c) the observed points in time order in slots 0.., zeros behind */
+int immtsf_collate_patches(const immtsf_store* s, const int32_t* window_ids, int32_t B, int32_t npatch, float patch_size,
+                           float patch_stride, float history, int32_t Lp, float time_max, float* obs_tp, float* obs_data,
+                           float* obs_mask, immtsf_stream_t stream);
+/* tau (B,Nmax), notes (B,Nmax,d_m) zero padded (either may be NULL), and the packed ragged index: lengths[B],
+ * offsets[B+1] (int32, bit-exact with immtsf_ragged_index on the padded tensor), rowmap[sum] -> row in `emb` (or NULL) */
+int immtsf_collate_notes(const immtsf_store* s, const int32_t* window_ids, int32_t B, int32_t Nmax, float* tau, float* notes,
+                         int32_t* lengths, int32_t* offsets, int64_t* rowmap, immtsf_stream_t stream);
+
 /* ---- building blocks exported for tests and for the layers/ mirror ------------------------------------------- */
 /* C = act(alpha * op(A) op(B)^T + bias); layout 0 = NT (A:(M,K), B:(N,K)), 1 = NN (B:(K,N)), 2 = TN (A:(K,M), B:(K,N)) */
 int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,

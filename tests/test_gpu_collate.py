@@ -1,0 +1,93 @@
+"""GPU parity of the device-side batch builder: ResidentStore.collate against the batches the
+REAL reference's loaders produced (tests/golden/collate_*.npz) -- every tensor bit-exact -- and the packed ragged
+note index against immtsf_ragged_index run on the padded embeddings it replaces."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _chunks(name):
+    """the reference dataset's chunk list rebuilt from the fixture: (id, tt, vals, mask, [(t, emb_row_view)])"""
+    from oracle import collate_ref as R
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    zs = np.load(os.path.join(GOLDEN, "collate_standard.npz"))
+    emb = {int(k[8:10]): torch.from_numpy(zs[k]) for k in zs.files if k.startswith("file.ent") and k.endswith("/emb")}
+    chunks = []
+    for c in R.chunks_from_golden(z):
+        texts = [(float(t), emb[int(e)][int(r)]) for t, e, r in zip(c["note_t"], c["note_ent"], c["note_row"])]
+        chunks.append((c["id"], torch.from_numpy(c["tt"]), torch.from_numpy(c["vals"]), torch.from_numpy(c["mask"]), texts))
+    return z, chunks
+
+
+@pytest.mark.parametrize("name", ["collate_standard", "collate_patch"])
+def test_collate_bit_exact_vs_reference_batches(name):
+    dev = _dev()
+    from immtsf.data import ResidentStore
+    z, chunks = _chunks(name)
+    store = ResidentStore.from_chunks(chunks, float(z["history"]), float(z["pred_window"]), dev)
+    twice = ResidentStore.from_chunks(chunks + chunks[:9], float(z["history"]), float(z["pred_window"]), dev)
+    assert twice.d["emb"].shape[0] == store.d["emb"].shape[0]            # rows of one embedding matrix are stored once
+    patch = None if name == "collate_standard" else tuple(int(v) for v in z["patch"])
+    for b in range(int(z["n_batches"])):
+        got = store.collate(z[f"b{b}.window_ids"], patch=patch)
+        keys = [k[len(f"b{b}."):] for k in z.files if k.startswith(f"b{b}.") and not k.endswith("window_ids")]
+        for k in keys:
+            exp = z[f"b{b}.{k}"]
+            g = got[k].cpu().numpy()
+            assert g.shape == exp.shape and g.dtype == exp.dtype and np.array_equal(g, exp), (name, b, k)
+
+
+def test_packed_note_index_matches_ragged_index_of_padded_tensor():
+    dev = _dev()
+    from immtsf import _lib
+    from immtsf.data import ResidentStore
+    lib = _lib.load()
+    z, chunks = _chunks("collate_standard")
+    store = ResidentStore.from_chunks(chunks, float(z["history"]), float(z["pred_window"]), dev)
+    ids = np.array([0, 7, 13, 21, 34, 58, 2, 2], dtype=np.int64)
+    got = store.collate(ids)
+    notes = got["notes_embeddings"]
+    B, N, d_m = notes.shape
+    mask = torch.zeros(B * N, dtype=torch.uint8, device=dev)
+    lengths = torch.zeros(B, dtype=torch.int32, device=dev)
+    offsets = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    rowmap = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+    seg = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+    mtxt = torch.zeros(B, dtype=torch.uint8, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.immtsf_ragged_index(_lib.ptr(notes), B, N, d_m, _lib.ptr(mask), _lib.ptr(lengths), _lib.ptr(offsets),
+                                       _lib.ptr(rowmap), _lib.ptr(seg), _lib.ptr(mtxt), _lib.ptr(flag), _lib.stream_ptr()),
+               "ragged_index")
+    assert torch.equal(lengths, got["note_lengths"]) and torch.equal(offsets, got["note_offsets"])
+    tot = int(offsets[-1])
+    packed_from_padded = notes.reshape(B * N, d_m)[rowmap[:tot].long()]
+    packed_from_store = store.d["emb"][got["note_rowmap"]]
+    assert torch.equal(packed_from_padded, packed_from_store)
+    # without the padded tensor
+    lean = store.collate(ids, padded_notes=False)
+    assert "notes_embeddings" not in lean and torch.equal(lean["note_rowmap"], got["note_rowmap"])
+    assert torch.equal(lean["tau"], got["tau"])
+
+
+def test_collate_edge_cases():
+    dev = _dev()
+    from immtsf.data import ResidentStore
+    z, chunks = _chunks("collate_standard")
+    store = ResidentStore.from_chunks(chunks, float(z["history"]), float(z["pred_window"]), dev)
+    one = store.collate([5])
+    assert one["observed_tp"].shape[0] == 1 and one["tau"].shape[1] == int(store.n_notes[5])
+    with pytest.raises(IndexError):
+        store.collate([len(chunks)])
+    empty = store.collate([])
+    assert empty["observed_data"].shape == (0, 0, store.C) and empty["note_offsets"].cpu().tolist() == [0]

@@ -112,14 +112,14 @@ __global__ __launch_bounds__(256) void note_index_kernel(immtsf_store s, const i
 // grid (B, chunks): tau / padded embeddings / packed row map
 __global__ __launch_bounds__(256) void collate_notes_kernel(immtsf_store s, const int32_t* __restrict__ wid, int Nmax,
                                                              const int32_t* __restrict__ offsets, float* __restrict__ tau,
-                                                             float* __restrict__ notes, int64_t* __restrict__ rowmap) {
+                                                             float* __restrict__ notes, int32_t* __restrict__ rowmap) {
     const int b = blockIdx.x, w = wid[b], d_m = s.d_m;
     const long n0 = s.note_off[w];
     const int n = (int)(s.note_off[w + 1] - n0);
     const int stride = gridDim.y * 256, t0 = blockIdx.y * 256 + threadIdx.x;
     for (int i = t0; i < Nmax; i += stride) {
         if (tau) tau[(size_t)b * Nmax + i] = i < n ? s.note_tau[n0 + i] : 0.f;
-        if (rowmap && i < n) rowmap[offsets[b] + i] = s.note_src[n0 + i];
+        if (rowmap && i < n) rowmap[offsets[b] + i] = (int32_t)s.note_src[n0 + i];
     }
     if (notes) {
         const int q = d_m / 4;
@@ -177,7 +177,7 @@ int immtsf_collate_patches(const immtsf_store* s, const int32_t* window_ids, int
 }
 
 int immtsf_collate_notes(const immtsf_store* s, const int32_t* window_ids, int32_t B, int32_t Nmax, float* tau, float* notes,
-                         int32_t* lengths, int32_t* offsets, int64_t* rowmap, immtsf_stream_t stream) {
+                         int32_t* lengths, int32_t* offsets, int32_t* rowmap, immtsf_stream_t stream) {
     if (!s || !s->note_off || !s->note_tau || !s->note_src || !window_ids || B < 0 || Nmax < 0 || !lengths || !offsets)
         return IMMTSF_EINVAL;
     if (notes && (!s->emb || s->d_m <= 0)) return IMMTSF_EINVAL;

@@ -85,9 +85,12 @@ int immtsf_ragged_index(const float* notes, int32_t B, int32_t N, int32_t d_m, u
 size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) ? 0 : carve_t2v(cfg, nullptr).bytes; }
 size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) ? 0 : carve_t2v_scratch(cfg, nullptr).bytes; }
 
-int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
-                                 const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,
-                                 int32_t* nan_flag, immtsf_stream_t stream) {
+// `src_rows` == null: `notes` is the zero-padded (B,N,d_m) tensor and the ragged index is derived from it (reference
+// semantics).  Otherwise `notes` is the resident embedding matrix, src_rows[packed row] its row and `lengths_in` the
+// per-window note counts from the batch builder: no padded tensor, no |V|-sum scan.
+static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes, const int32_t* src_rows,
+                       const int32_t* lengths_in, const float* tau, float* E_txt, uint8_t* M_txt, void* workspace,
+                       size_t workspace_bytes, int32_t* nan_flag, immtsf_stream_t stream) {
     if (bad_cfg(cfg) || !p || !notes || !tau || !E_txt || !M_txt || !workspace) return IMMTSF_EINVAL;
     if (cfg->d < 4 || cfg->N <= 0 || cfg->d_m <= 0) return IMMTSF_EINVAL;
     if (!p->input_proj_w && cfg->d != cfg->d_m) return IMMTSF_EINVAL;
@@ -99,16 +102,18 @@ int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
 
-    CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
+    if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
+    else CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
     CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s));
+    const int* gather = src_rows ? src_rows : w.rowmap;
     // [input_proj(V) ; time2vec(tau)] on the packed rows
     if (p->input_proj_w) {
         GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, dcat);
         set_problem(g, 0, notes, p->input_proj_w, w.Xcat, p->input_proj_b);
-        g.dyn = total; g.dyn_which = 0; g.a_rowmap = w.rowmap;
+        g.dyn = total; g.dyn_which = 0; g.a_rowmap = gather;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     } else {
-        CHECK(launch_gather_rows(notes, cfg->d_m, w.rowmap, total, R, d, w.Xcat, dcat, s));
+        CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, d, w.Xcat, dcat, s));
     }
     CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b,
                               w.Xcat + d, dcat, s));
@@ -143,10 +148,23 @@ int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_
     return e == hipSuccess ? IMMTSF_OK : (int)e;
 }
 
-int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
-                                  const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
-                                  void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
-                                  immtsf_stream_t stream) {
+int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
+                                 const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,
+                                 int32_t* nan_flag, immtsf_stream_t stream) {
+    return t2v_forward(cfg, p, notes, nullptr, nullptr, tau, E_txt, M_txt, workspace, workspace_bytes, nan_flag, stream);
+}
+
+int immtsf_ttf_t2v_xattn_forward_packed(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* emb,
+                                        const int32_t* src_rows, const int32_t* lengths, const float* tau, float* E_txt,
+                                        uint8_t* M_txt, void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+    if (!src_rows || !lengths) return IMMTSF_EINVAL;
+    return t2v_forward(cfg, p, emb, src_rows, lengths, tau, E_txt, M_txt, workspace, workspace_bytes, nullptr, stream);
+}
+
+static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes, const int32_t* src_rows,
+                        const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
+                        void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
+                        immtsf_stream_t stream) {
     if (bad_cfg(cfg) || !p || !gr || !notes || !tau || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
     T2VWs w = carve_t2v(cfg, workspace);
     T2VScratch sc = carve_t2v_scratch(cfg, scratch);
@@ -217,13 +235,28 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
     if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
-        h.dyn = total; h.dyn_which = 1; h.b_rowmap = w.rowmap;
+        h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
                               gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, 0, s));
     return fk.join();
+}
+
+int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
+                                  const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
+                                  void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
+                                  immtsf_stream_t stream) {
+    return t2v_backward(cfg, p, notes, nullptr, tau, dE_txt, workspace, workspace_bytes, scratch, scratch_bytes, gr, stream);
+}
+
+int immtsf_ttf_t2v_xattn_backward_packed(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* emb,
+                                         const int32_t* src_rows, const float* tau, const float* dE_txt, void* workspace,
+                                         size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                         const immtsf_t2v_params* gr, immtsf_stream_t stream) {
+    if (!src_rows) return IMMTSF_EINVAL;
+    return t2v_backward(cfg, p, emb, src_rows, tau, dE_txt, workspace, workspace_bytes, scratch, scratch_bytes, gr, stream);
 }
 
 }  // extern "C"

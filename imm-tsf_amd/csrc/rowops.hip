@@ -40,6 +40,12 @@ __global__ __launch_bounds__(256) void note_mask_kernel(const float* __restrict_
 
 // one block (1024 threads = 16 waves).  Phase 1: a wave per window counts its notes (ballot/popcount);
 // phase 2: block scan of the lengths; phase 3: a wave per window writes the compacted row indices.
+__global__ __launch_bounds__(256) void mask_from_lengths_kernel(const int* __restrict__ lengths, int B, int N,
+                                                                unsigned char* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < B * N) mask[i] = (i % N) < lengths[i / N] ? 1 : 0;
+}
+
 __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char* __restrict__ mask, int B, int N,
                                                             int* __restrict__ lengths, int* __restrict__ offsets,
                                                             int* __restrict__ rowmap, int* __restrict__ seg,
@@ -313,6 +319,13 @@ int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int
 int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
                         unsigned char* mtxt, hipStream_t s) {
     hipLaunchKernelGGL(ragged_index_kernel, dim3(1), dim3(1024), 0, s, mask, B, N, lengths, offsets, rowmap, seg, mtxt);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_mask_from_lengths(const int* lengths, int B, int N, unsigned char* mask, hipStream_t s) {
+    if (B * N <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(mask_from_lengths_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, s, lengths, B, N, mask);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

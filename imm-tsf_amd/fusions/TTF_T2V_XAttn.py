@@ -15,7 +15,7 @@ import torch.nn as nn
 from fusions._common import NanFlag, f32, prep_t_hat, resolve_precision
 from fusions.load_llm import get_d_model, load_llm
 from immtsf import config
-from immtsf.ops import TTFT2VXAttnFn
+from immtsf.ops import PackedNotes, TTFT2VXAttnFn
 
 
 class Time2Vec(nn.Module):
@@ -72,12 +72,14 @@ class TTF_T2V_XAttn(nn.Module):
                 self.layer_norm.bias, self.proj_out.weight, self.proj_out.bias)
 
     def forward(self, notes_input, tau: torch.Tensor, t_hat: torch.Tensor):
-        """notes_input (B,N,d_model) zero-padded embeddings, tau (B,N), t_hat (B,T) or (T,)
-        -> E_txt (B,T,d_txt), M_txt (B,1) bool."""
+        """notes_input (B,N,d_model) zero-padded embeddings -- or a PackedNotes over a resident embedding matrix
+        (immtsf.data.ResidentStore.collate: no padded tensor, no note-mask re-derivation) --, tau (B,N),
+        t_hat (B,T) or (T,) -> E_txt (B,T,d_txt), M_txt (B,1) bool."""
         if not self.use_text_embeddings:
             raise NotImplementedError("raw-text mode is not part of the MI355X hot path")
-        V = f32(notes_input)
-        B = V.shape[0]
+        packed = notes_input if isinstance(notes_input, PackedNotes) else None
+        V = packed.emb if packed is not None else f32(notes_input)
+        B = tau.shape[0]
         t_hat = prep_t_hat(t_hat, B)
         T = t_hat.shape[1]
         training = self.training and self.p_drop > 0.0
@@ -85,7 +87,8 @@ class TTF_T2V_XAttn(nn.Module):
         mode = config.nan_check
         flag = None if mode == "off" else self._nan.get(V.device)
         E_txt, M = TTFT2VXAttnFn.apply(V, f32(tau), T, self.n_heads, self.p_drop, training, resolve_precision(self),
-                                       self.last_seed, flag, *self._params())
+                                       self.last_seed, flag, None if packed is None else packed.src_rows,
+                                       None if packed is None else packed.lengths, *self._params())
         if mode == "sync":
             self._nan.raise_if_set("Input embeddings V contain NaN values.")
         return E_txt, M.view(torch.bool).view(B, 1)

@@ -70,6 +70,11 @@ _PROTOS = {
                                                C.c_size_t, c_i32p, c_stream]),
     "immtsf_ttf_t2v_xattn_backward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p, C.c_size_t, _P(T2VParams), c_stream]),
+    "immtsf_ttf_t2v_xattn_forward_packed": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_i32p, c_i32p, c_f32p, c_f32p,
+                                                      c_u8p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_ttf_t2v_xattn_backward_packed": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_i32p, c_f32p, c_f32p,
+                                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(T2VParams),
+                                                       c_stream]),
     "immtsf_ttf_recavg_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_recavg_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_recavg_forward": (C.c_int, [_P(FusionCfg), _P(RecAvgParams), c_f32p, c_f32p, c_f32p, c_f32p, c_u8p,

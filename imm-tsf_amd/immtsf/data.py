@@ -124,7 +124,7 @@ class ResidentStore:
                        observed_mask=torch.empty(shp, dtype=f32, device=dev), tau=torch.empty(0, 0, dtype=f32, device=dev),
                        note_lengths=torch.empty(0, dtype=torch.int32, device=dev),
                        note_offsets=torch.zeros(1, dtype=torch.int32, device=dev),
-                       note_rowmap=torch.empty(0, dtype=torch.int64, device=dev))
+                       note_rowmap=torch.empty(0, dtype=torch.int32, device=dev))
             if padded_notes and self.d_m:
                 out["notes_embeddings"] = torch.empty(0, 0, self.d_m, dtype=f32, device=dev)
             return out
@@ -151,10 +151,13 @@ class ResidentStore:
         out["tau"] = torch.empty(B, Nmax, dtype=f32, device=dev)
         out["note_lengths"] = torch.empty(B, dtype=torch.int32, device=dev)
         out["note_offsets"] = torch.empty(B + 1, dtype=torch.int32, device=dev)
-        out["note_rowmap"] = torch.empty(total, dtype=torch.int64, device=dev)
+        out["note_rowmap"] = torch.empty(total, dtype=torch.int32, device=dev)
         notes = None
         if padded_notes and self.d_m:
             notes = out["notes_embeddings"] = torch.empty(B, Nmax, self.d_m, dtype=f32, device=dev)
         check(lib.immtsf_collate_notes(st, ptr(ids_dev), B, Nmax, ptr(out["tau"]), ptr(notes), ptr(out["note_lengths"]),
                                        ptr(out["note_offsets"]), ptr(out["note_rowmap"]), stream_ptr()), "collate_notes")
+        if self.d_m:
+            from .ops import PackedNotes
+            out["notes_packed"] = PackedNotes(self.d["emb"], out["note_rowmap"], out["note_lengths"], Nmax)
         return out

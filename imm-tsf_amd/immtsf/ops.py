@@ -86,25 +86,46 @@ def make_cfg(B, N, T, Cc, d_m, d, H, precision, training, p_drop, kappa, seed, d
 
 
 # ------------------------------------------------------------------------------------------------ TTF_T2V_XAttn
+class PackedNotes:
+    """A batch's notes in packed-ragged form over a resident embedding matrix (immtsf.data.ResidentStore.collate):
+    emb [rows, d_m] fp32, src_rows [sum_n] int32 (row of each note, window-major), lengths [B] int32, N = padded width
+    of the accompanying tau (B,N).  Accepted by TTF_T2V_XAttn.forward in place of the zero-padded (B,N,d_m) tensor."""
+
+    def __init__(self, emb, src_rows, lengths, N):
+        if emb.numel() >= 2 ** 32:
+            raise ValueError("resident embedding matrix must stay below 2^32 elements (32-bit gather offsets)")
+        self.emb, self.src_rows, self.lengths, self.N = emb, src_rows, lengths, int(N)
+        self.shape = (lengths.shape[0], self.N, emb.shape[1])
+        self.device = emb.device
+
+
 class TTFT2VXAttnFn(torch.autograd.Function):
-    """(notes (B,N,d_m), tau (B,N)) -> (E_txt (B,T,d), M_txt uint8 (B)).  params in immtsf_t2v_params order."""
+    """(notes (B,N,d_m) | resident emb + src_rows + lengths, tau (B,N)) -> (E_txt (B,T,d), M_txt uint8 (B)).
+    params in immtsf_t2v_params order."""
 
     @staticmethod
-    def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, *params):
+    def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, src_rows, lengths, *params):
         lib = _lib.load()
         notes, tau = _c(notes), _c(tau)
         params = tuple(_c(p) for p in params)
         _need_gpu(notes, tau, *params)
-        B, N, d_m = notes.shape
+        packed = src_rows is not None
+        B, N = tau.shape
+        d_m = notes.shape[-1]
         d = params[0].numel()
         cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed, notes.device)
         ws = _bytes(lib.immtsf_ttf_t2v_xattn_workspace_bytes(C.byref(cfg)), notes.device)
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)
         ps = _struct(T2VParams, params)
-        check(lib.immtsf_ttf_t2v_xattn_forward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(E), ptr(M), ptr(ws),
-                                               ws.numel(), ptr(nan_flag), stream_ptr()), "ttf_t2v_xattn_forward")
-        ctx.cfg, ctx.ws = cfg, ws
+        if packed:
+            check(lib.immtsf_ttf_t2v_xattn_forward_packed(C.byref(cfg), C.byref(ps), ptr(notes), ptr(src_rows), ptr(lengths),
+                                                          ptr(tau), ptr(E), ptr(M), ptr(ws), ws.numel(), stream_ptr()),
+                  "ttf_t2v_xattn_forward_packed")
+        else:
+            check(lib.immtsf_ttf_t2v_xattn_forward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(E), ptr(M), ptr(ws),
+                                                   ws.numel(), ptr(nan_flag), stream_ptr()), "ttf_t2v_xattn_forward")
+        ctx.cfg, ctx.ws, ctx.src_rows = cfg, ws, src_rows
         ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
         ctx.sinks = _sinks_of(params)
@@ -123,11 +144,16 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
         ps, gs = _struct(T2VParams, params), _struct(T2VParams, grads)
-        check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
-                                                ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
-              "ttf_t2v_xattn_backward")
+        if ctx.src_rows is not None:
+            check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
+                                                           ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
+                                                           C.byref(gs), stream_ptr()), "ttf_t2v_xattn_backward_packed")
+        else:
+            check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
+                                                    ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+                  "ttf_t2v_xattn_backward")
         _fire(ctx.done_hook)
-        return (None,) * 9 + tuple(rets)
+        return (None,) * 11 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ TTF_RecAvg

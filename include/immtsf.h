@@ -92,6 +92,17 @@ int immtsf_ttf_t2v_xattn_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v
                                   const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
                                   void* scratch, size_t scratch_bytes, const immtsf_t2v_params* grads,
                                   immtsf_stream_t stream);
+/* packed-input variants: the notes stay in the resident embedding matrix `emb` [*, d_m];
+ * src_rows[offsets[b] + i] is the row of window b's i-th note and lengths[b] its note count, both as emitted by
+ * immtsf_collate_notes.  tau stays (B,N) padded (N = cfg->N >= max lengths).  No padded embedding tensor is read
+ * and the note mask is not re-derived from |V|.  Same workspace / scratch sizes as the padded entry points. */
+int immtsf_ttf_t2v_xattn_forward_packed(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* emb,
+                                        const int32_t* src_rows, const int32_t* lengths, const float* tau, float* E_txt,
+                                        uint8_t* M_txt, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_ttf_t2v_xattn_backward_packed(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* emb,
+                                         const int32_t* src_rows, const float* tau, const float* dE_txt, void* workspace,
+                                         size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                         const immtsf_t2v_params* grads, immtsf_stream_t stream);
 
 /* ---- a5: TTF_RecAvg.forward (fusions/TTF_RecAvg.py:54-112) */
 typedef struct immtsf_recavg_params {
@@ -238,7 +249,7 @@ int immtsf_collate_patches(const immtsf_store* s, const int32_t* window_ids, int
 /* tau (B,Nmax), notes (B,Nmax,d_m) zero padded (either may be NULL), and the packed ragged index: lengths[B],
  * offsets[B+1] (int32, bit-exact with immtsf_ragged_index on the padded tensor), rowmap[sum] -> row in `emb` (or NULL) */
 int immtsf_collate_notes(const immtsf_store* s, const int32_t* window_ids, int32_t B, int32_t Nmax, float* tau, float* notes,
-                         int32_t* lengths, int32_t* offsets, int64_t* rowmap, immtsf_stream_t stream);
+                         int32_t* lengths, int32_t* offsets, int32_t* rowmap, immtsf_stream_t stream);
 
 /* ---- building blocks exported for tests and for the layers/ mirror ------------------------------------------- */
 /* C = act(alpha * op(A) op(B)^T + bias); layout 0 = NT (A:(M,K), B:(N,K)), 1 = NN (B:(K,N)), 2 = TN (A:(K,M), B:(K,N)) */

@@ -91,3 +91,38 @@ def test_collate_edge_cases():
         store.collate([len(chunks)])
     empty = store.collate([])
     assert empty["observed_data"].shape == (0, 0, store.C) and empty["note_offsets"].cpu().tolist() == [0]
+
+
+@pytest.mark.parametrize("d_txt", [16, 8])       # d_txt == d_m: no input projection (gather only); 8: input_proj GEMM
+def test_ttf_on_packed_notes_equals_padded(d_txt):
+    """TTF_T2V_XAttn fed the packed ragged form (resident matrix + row map from the batch builder) must give the
+    same E_txt / M_txt / parameter gradients as on the zero-padded tensor it replaces (same kernels, different
+    gather source): tolerance 1e-6 (atomics order in split-K only)."""
+    dev = _dev()
+    import types
+    from fusions.load_llm import register_d_model
+    from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+    from immtsf import config
+    from immtsf.data import ResidentStore
+    config.precision = "fp32"
+    z, chunks = _chunks("collate_standard")
+    store = ResidentStore.from_chunks(chunks, float(z["history"]), float(z["pred_window"]), dev)
+    batch = store.collate(np.array([3, 11, 12, 40, 41, 57], dtype=np.int64))
+    register_d_model("TOY16", 16)
+    torch.manual_seed(0)
+    ttf = TTF_T2V_XAttn("TOY16", None, 1024, str(dev), True, n_heads_fusion=2, dropout=0.0,
+                        d_txt=None if d_txt == 16 else d_txt).to(dev).train()
+    t_hat = batch["tp_to_predict"]
+    up = torch.randn(t_hat.shape[0], t_hat.shape[1], ttf.d_txt, device=dev)
+    res = []
+    for notes in (batch["notes_embeddings"], batch["notes_packed"]):
+        ttf.zero_grad()
+        E, M = ttf(notes, batch["tau"], t_hat)
+        (E * up).sum().backward()
+        res.append((E.detach().clone(), M.clone(), {n: p.grad.clone() for n, p in ttf.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][1], res[1][1])
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6 * float(res[0][0].abs().max())
+    assert res[0][2].keys() == res[1][2].keys() and len(res[0][2]) >= 12
+    for n in res[0][2]:
+        a, b = res[0][2][n], res[1][2][n]
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), n

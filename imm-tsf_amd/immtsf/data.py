@@ -81,6 +81,95 @@ class ResidentStore:
                    np.array(note_tau, np.float32), np.array(note_src, np.int64), np.array(note_off, np.int64), emb,
                    history, pred_window, device)
 
+    @classmethod
+    def from_dataset_dir(cls, root, history, pred_window, stride, device, time_unit="days", llm_model_fusion="GPT2",
+                         llm_layers_fusion=None, max_length=1024, rec_ids=None):
+        """Build the store from the reference's on-disk layout:
+            <root>/processed/<entity>/time_series.csv                       date_time, record_id, <features...>
+            <root>/processed/<entity>/text_embeddings_model={llm}_layers={n|full}_maxlen={L}.pt
+                                                                            {embeddings [n,d_m] f32, rel_times [n] f32}
+        and window it exactly like ChunkedTimeSeriesDataset (lib/parse_datasets.py:17-245): per-entity z-scored
+        features (pandas mean / std, as there), times in `time_unit` from the entity's first observation, windows
+        [st, st + history + pred_window) stepped by `stride` that hold >= 2 observations, an observed value on both
+        sides of `history` and at least one note in [st, st + history).  The windows are found with searchsorted over
+        the sorted times instead of a scan per window; each entity's embedding matrix goes to the device once.
+        Returns (store, window_ids) with the reference's chunk ids ("<entity>_chunk<k>")."""
+        import os
+        import pandas as pd
+        unit = {"seconds": 1.0, "minutes": 60.0, "hours": 3600.0, "days": 86400.0, "weeks": 604800.0}[time_unit]
+        proc = os.path.join(root, "processed")
+        ents = sorted(d for d in os.listdir(proc) if os.path.isdir(os.path.join(proc, d))) if rec_ids is None else list(rec_ids)
+        total = history + pred_window
+        tt_all, vals_all, mask_all, row_off, ids = [], [], [], [0], []
+        tau_all, src_all, note_off, embs, emb_base = [], [], [0], [], 0
+        for ent in ents:
+            ts_path = os.path.join(proc, ent, "time_series.csv")
+            if not os.path.isfile(ts_path):
+                continue
+            df = pd.read_csv(ts_path)
+            when = pd.to_datetime(df["date_time"])
+            df = df.assign(_when=when).sort_values("_when")
+            feats = [c for c in df.columns if c not in ("date_time", "record_id", "_when")]
+            x = df[feats]
+            mu, sd = x.mean(), x.std()
+            x = (x - mu) / sd.where(sd != 0, 1.0)              # z-score; constant columns are only centred
+            secs = (df["_when"] - df["_when"].min()).dt.total_seconds()
+            tt = (secs / unit).values.astype(np.float32)
+            v32 = x.values.astype(np.float32)
+            mask = (~np.isnan(v32)).astype(np.float32)
+            vals = np.nan_to_num(v32, nan=0.0, posinf=np.finfo(np.float32).max, neginf=np.finfo(np.float32).min)
+            if mask.sum() == 0:
+                raise ValueError(f"Mask for {ent} is all zeros")
+            fname = f"text_embeddings_model={llm_model_fusion}_layers={llm_layers_fusion or 'full'}_maxlen={max_length}.pt"
+            path = os.path.join(proc, ent, fname)
+            if not os.path.isfile(path):
+                raise FileNotFoundError(f"Missing text embeddings file: {path}")
+            blob = torch.load(path, map_location="cpu")
+            emb = blob["embeddings"].float().numpy()
+            if np.isnan(emb).any():
+                raise ValueError("text embeddings contains NaN values.")
+            rel = blob["rel_times"].float().numpy().astype(np.float64)      # what `.item()` of the fp32 times yields
+            embs.append(emb)
+            # ---- windows: st_k = t_min + k * stride while st_k + total <= t_max
+            t_min, t_max = float(tt.min()), float(tt.max())
+            k, cnt = 0, 0
+            order_ok = np.all(np.diff(tt) >= 0)
+            while t_min + k * stride + total <= t_max:
+                st = t_min + k * stride
+                k += 1
+                st32 = np.float32(st)
+                if order_ok:
+                    a, b = np.searchsorted(tt, st32, "left"), np.searchsorted(tt, np.float32(st + total), "left")
+                    sel = np.arange(a, b)
+                else:
+                    sel = np.flatnonzero((tt >= st32) & (tt < np.float32(st + total)))
+                if len(sel) < 2:
+                    continue
+                sub_tt = tt[sel] - st32
+                hist = sub_tt < np.float32(history)
+                if mask[sel][hist].sum() == 0 or mask[sel][~hist].sum() == 0:
+                    continue
+                notes = np.flatnonzero((rel >= st) & (rel < st + history))
+                this = cnt
+                cnt += 1
+                if len(notes) == 0:          # windows without text are dropped, but they still consume a chunk number
+                    continue
+                ids.append(f"{ent}_chunk{this}")
+                tt_all.append(sub_tt)
+                vals_all.append(vals[sel])
+                mask_all.append(mask[sel])
+                row_off.append(row_off[-1] + len(sel))
+                tau_all.append((rel[notes] - st).astype(np.float32))
+                src_all.append(notes.astype(np.int64) + emb_base)
+                note_off.append(note_off[-1] + len(notes))
+            emb_base += len(emb)
+        if not ids:
+            raise RuntimeError("No chunks created; check history/pred_window/stride")
+        store = cls(np.concatenate(tt_all), np.concatenate(vals_all), np.concatenate(mask_all), np.array(row_off, np.int64),
+                    np.concatenate(tau_all), np.concatenate(src_all), np.array(note_off, np.int64), np.concatenate(embs),
+                    history, pred_window, device)
+        return store, ids
+
     # ------------------------------------------------------------------------------------------ batches
     def _ids(self, window_ids):
         ids = np.asarray(window_ids, dtype=np.int32)

@@ -50,3 +50,34 @@ def test_ragged_index_of_notes():
     # the padded tensor's non-zero rows are exactly the first lengths[b] rows (what the fusion's note_mask re-derives)
     nz = (np.abs(out["notes_embeddings"]).sum(-1) > 0).sum(1)
     assert np.array_equal(nz, out["lengths"])
+
+
+def test_on_disk_loader_matches_reference_chunks(tmp_path):
+    """ResidentStore.from_dataset_dir on the synthetic dataset (its bytes are in the fixture) must reproduce the chunk
+    list the reference's ChunkedTimeSeriesDataset built from the same files: ids, times, values, masks, note times and
+    note rows -- bit-exact."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "imm-tsf_amd"))
+    from immtsf.data import ResidentStore
+    z = np.load(os.path.join(GOLDEN, "collate_standard.npz"))
+    ents = sorted({k.split("/")[0][5:] for k in z.files if k.startswith("file.")})
+    base = {}
+    for i, e in enumerate(ents):
+        d = tmp_path / "SYN" / "processed" / e
+        d.mkdir(parents=True)
+        (d / "time_series.csv").write_bytes(z[f"file.{e}/time_series.csv"].tobytes())
+        torch.save({"embeddings": torch.from_numpy(z[f"file.{e}/emb"]), "rel_times": torch.from_numpy(z[f"file.{e}/rel"])},
+                   str(d / "text_embeddings_model=TOY16_layers=full_maxlen=1024.pt"))
+        base[int(e[3:])] = sum(len(z[f"file.{x}/emb"]) for x in ents[:i])
+    store, ids = ResidentStore.from_dataset_dir(str(tmp_path / "SYN"), 24, 24, 24, "cpu", time_unit="hours",
+                                                llm_model_fusion="TOY16")
+    assert ids == [str(s) for s in z["chunks.ids"]]
+    assert np.array_equal(store.d["row_off"].numpy(), z["chunks.tt_off"])
+    for k, g in (("tt", "tt"), ("vals", "vals"), ("mask", "mask")):
+        assert np.array_equal(store.d[k].numpy(), z["chunks." + g]), k
+    assert np.array_equal(store.d["note_off"].numpy(), z["chunks.note_off"])
+    assert np.array_equal(store.d["note_tau"].numpy(), z["chunks.note_t"].astype(np.float32))
+    exp_src = np.array([base[int(e)] + int(r) for e, r in zip(z["chunks.note_ent"], z["chunks.note_row"])], dtype=np.int64)
+    assert np.array_equal(store.d["note_src"].numpy(), exp_src)
+    assert np.array_equal(store.d["emb"].numpy(), np.concatenate([z[f"file.{e}/emb"] for e in ents]))

@@ -126,3 +126,24 @@ def test_ttf_on_packed_notes_equals_padded(d_txt):
     for n in res[0][2]:
         a, b = res[0][2][n], res[1][2][n]
         assert float((a - b).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-3), n
+
+
+def test_disk_to_batch_end_to_end(tmp_path):
+    """files on disk -> ResidentStore.from_dataset_dir -> device collate == the reference loaders' batches (bit-exact)"""
+    dev = _dev()
+    from immtsf.data import ResidentStore
+    z = np.load(os.path.join(GOLDEN, "collate_patch.npz"))
+    zs = np.load(os.path.join(GOLDEN, "collate_standard.npz"))
+    for e in sorted({k.split("/")[0][5:] for k in zs.files if k.startswith("file.")}):
+        d = tmp_path / "SYN" / "processed" / e
+        d.mkdir(parents=True)
+        (d / "time_series.csv").write_bytes(zs[f"file.{e}/time_series.csv"].tobytes())
+        torch.save({"embeddings": torch.from_numpy(zs[f"file.{e}/emb"]), "rel_times": torch.from_numpy(zs[f"file.{e}/rel"])},
+                   str(d / "text_embeddings_model=TOY16_layers=full_maxlen=1024.pt"))
+    store, ids = ResidentStore.from_dataset_dir(str(tmp_path / "SYN"), 24, 24, 24, dev, time_unit="hours", llm_model_fusion="TOY16")
+    assert len(ids) == int(z["chunks.n"])
+    patch = tuple(int(v) for v in z["patch"])
+    for b in range(int(z["n_batches"])):
+        got = store.collate(z[f"b{b}.window_ids"], patch=patch)
+        for k in [k[len(f"b{b}."):] for k in z.files if k.startswith(f"b{b}.") and not k.endswith("window_ids")]:
+            assert np.array_equal(got[k].cpu().numpy(), z[f"b{b}.{k}"]), (b, k)

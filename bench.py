@@ -170,7 +170,7 @@ def main():
     from fusions.FusionModel import FusionModel
     from immtsf import _lib, config
     from immtsf.ops import masked_mse
-    from immtsf.train import FlatTrainer
+    from immtsf.train import FlatTrainer, GraphedStep
     from models.tPatchGNN import tPatchGNN
     lib = _lib.load()
     config.precision = args.precision
@@ -197,44 +197,21 @@ def main():
     from lib.evaluation import forecast_and_fuse
     backbone_stream = None if args.no_overlap else torch.cuda.Stream(device=dev)
 
-    def fwd_bwd():
-        trainer.zero_grad()
+    def loss_fn():
         out = forecast_and_fuse(model, fusion, batch, backbone_stream)
-        loss = masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], None, global_cnt)
-        loss.backward()
-        return loss
+        return masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], None, global_cnt)
 
     def eager_step():
-        loss = fwd_bwd()
+        trainer.zero_grad()
+        loss = loss_fn()
+        loss.backward()
         trainer.sync_grads()
         trainer.step()
         return loss
 
-    if use_graph:
-        # hipGraph capture (HIP streams + graphs instead of a tracing compiler): graph A = zero-grad, backbone + fusion
-        # forward, loss, backward; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam, which also
-        # bumps the device-side Adam step and dropout-key counters so every replay is a NEW training step.
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph_a, graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_a):
-            static_loss = fwd_bwd()
-        with torch.cuda.graph(graph_b):
-            trainer.step()
-
-        def step():
-            graph_a.replay()
-            trainer._reduced = [False] * len(trainer.buckets)
-            trainer.sync_grads()
-            graph_b.replay()
-            return static_loss
-    else:
-        step = eager_step
+    # hipGraph replay (immtsf.train.GraphedStep): graph A = zero-grad, backbone + fusion forward, loss, backward, gradient
+    # collection; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam + device-side counters
+    step = GraphedStep(trainer, loss_fn) if use_graph else eager_step
 
     def barrier():
         if world > 1:

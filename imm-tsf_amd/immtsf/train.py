@@ -77,7 +77,8 @@ class FlatTrainer:
         self.device_step = device_step and dev.type == "cuda"
         if self.device_step:
             from . import config
-            self.step_dev, self.drop_dev = config.enable_device_counters(dev)
+            _, self.drop_dev = config.enable_device_counters(dev)      # dropout key counter: shared by the device's modules
+            self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)    # Adam's step number: this trainer's own
         self.world = 1
         if group is not None:
             import torch.distributed as dist
@@ -119,6 +120,12 @@ class FlatTrainer:
                     src.append(p.grad.reshape(v.shape))
         if dst:
             torch._foreach_copy_(dst, src)
+
+    def collect_grads(self):
+        """copy the autograd-owned gradients (backbone) into the flat buffer NOW.  Call right after backward() when the
+        step is being captured into a hipGraph, so that the copy is part of the graph and runs on every replay."""
+        self._collected = False
+        self._collect_autograd_grads()
 
     def _bucket_ready(self, bi: int):
         if self.world == 1 or self._reduced[bi]:
@@ -182,3 +189,46 @@ class FlatTrainer:
 
     def grad_bytes(self) -> int:
         return self.flat_grad.numel() * 4
+
+
+class GraphedStep:
+    """One training step as two hipGraphs (HIP streams + graphs instead of a tracing compiler):
+        graph A = zero-grad, forward, loss, backward, gradient collection into the flat buffer
+        [world > 1: eager RCCL all-reduce of the flat gradient between the graphs]
+        graph B = clip + Adam, which also bumps the device-side Adam step and dropout-key counters, so every replay
+                  is a NEW training step (needs FlatTrainer(device_step=True)).
+    `loss_fn()` runs the forward and returns the scalar loss; inputs must be static device tensors."""
+
+    def __init__(self, trainer: FlatTrainer, loss_fn, warmup: int = 3):
+        if not trainer.device_step:
+            raise ValueError("GraphedStep needs FlatTrainer(device_step=True): host-side step counters would freeze in the graph")
+        self.trainer, self.loss_fn = trainer, loss_fn
+        side = torch.cuda.Stream(device=trainer.flat_param.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up off the default stream: allocator pools, lazy inits
+            for _ in range(warmup):
+                self._fwd_bwd()
+                trainer.sync_grads()
+                trainer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+        with torch.cuda.graph(self.graph_b):
+            trainer.step()
+
+    def _fwd_bwd(self):
+        self.trainer.zero_grad()
+        loss = self.loss_fn()
+        loss.backward()
+        self.trainer.collect_grads()
+        return loss
+
+    def __call__(self):
+        t = self.trainer
+        self.graph_a.replay()
+        t._reduced = [False] * len(t.buckets)
+        t.sync_grads()
+        self.graph_b.replay()
+        return self.loss

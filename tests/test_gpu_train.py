@@ -1,0 +1,105 @@
+"""GPU tests of the training-step plumbing: hipGraph replay (immtsf.train.GraphedStep) must train exactly like the
+eager step -- including the autograd-owned backbone gradients, which have to be collected INSIDE the graph -- and the
+two-stream backbone/TTF overlap must not change results."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _setup(dev, dropout, seed=0):
+    import bench
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    from immtsf.train import FlatTrainer
+    from models.tPatchGNN import tPatchGNN
+    register_d_model("TOY48", 48)
+    config.precision = "fp32"
+    config.nan_check = "deferred"
+    config.manual_seed(77)
+    torch.manual_seed(seed)
+    a = types.SimpleNamespace(
+        device=str(dev), hid_dim=16, C=bench.C, npatch=bench.M_PATCH, nlayer=1, te_dim=6, n_heads=1, tf_layer=1, node_dim=5,
+        hop=1, outlayer="Linear", TTF_module="TTF_T2V_XAttn", MMF_module="MMF_XAttn_Add", llm_model_fusion="TOY48",
+        llm_layers_fusion=6, max_length=1024, use_text_embeddings=True, recency_sigma=1.0, n_heads_fusion=2,
+        dropout=dropout, d_txt=32, kappa=0.5, batch_size=8)
+    model = tPatchGNN(a).to(dev).train()
+    fusion = FusionModel(a).to(dev).train()
+    for m in model.modules():           # the stock transformer layer's dropout draws from torch's generator
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    for lyr in model.transformer_encoder:
+        for l in lyr.layers:
+            l.self_attn.dropout = 0.0
+    trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+                          lr=1e-2, eps=1e-3, max_norm=1.0, sink_buckets=(0, 1), overlap=False, device_step=True)   # eps: Adam's sign-like first
+    # steps would otherwise turn 1e-9 atomic-order noise on ~zero gradients into +-lr parameter differences
+    cpu_batch, _ = bench.synth_batch(5, 8)
+    batch = {k: v.to(dev) for k, v in cpu_batch.items()}
+    batch["notes_embeddings"] = batch["notes_embeddings"][..., :48].contiguous()
+    return model, fusion, trainer, batch
+
+
+def _loss_fn(model, fusion, batch, stream=None):
+    from immtsf.ops import masked_mse
+    from lib.evaluation import forecast_and_fuse
+
+    def f():
+        out = forecast_and_fuse(model, fusion, batch, stream)
+        return masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"])
+    return f
+
+
+def test_graph_replay_trains_like_eager_incl_backbone():
+    dev = _dev()
+    from immtsf.train import GraphedStep
+    steps = 4
+    # eager
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    f = _loss_fn(model, fusion, batch)
+    for _ in range(3 + steps):          # GraphedStep warms up with 3 real steps
+        tr.zero_grad()
+        f().backward()
+        tr.sync_grads()
+        tr.step()
+    ref = tr.flat_param.clone()
+    lo, hi = tr.ranges[2]               # the autograd-owned backbone bucket
+    # graphs
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    g = GraphedStep(tr, _loss_fn(model, fusion, batch))
+    after_warm = tr.flat_param.clone()
+    losses = [float(g().detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert losses[-1] < losses[0]
+    assert float((tr.flat_param[lo:hi] - after_warm[lo:hi]).abs().max()) > 1e-3     # the backbone keeps training
+    err = float((tr.flat_param - ref).abs().max() / ref.abs().max())
+    assert err < 2e-4, err
+
+
+def test_two_stream_overlap_same_result_and_dropout_advances():
+    dev = _dev()
+    from immtsf.train import GraphedStep
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    a = _loss_fn(model, fusion, batch)()
+    b = _loss_fn(model, fusion, batch, torch.cuda.Stream(device=dev))()
+    torch.cuda.synchronize()
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
+    # with dropout on, every replay must draw new masks (device-side seed counter): frozen weights -> different losses
+    model, fusion, tr, batch = _setup(dev, 0.3)
+    tr.lr = 0.0
+    g = GraphedStep(tr, _loss_fn(model, fusion, batch, torch.cuda.Stream(device=dev)))
+    ls = [float(g().detach()) for _ in range(4)]
+    assert len({round(v, 7) for v in ls}) == 4, ls

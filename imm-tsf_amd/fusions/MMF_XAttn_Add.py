@@ -2,7 +2,7 @@
 embedding (keys/values), residual head, LayerNorm(C), dropout and a fixed-kappa convex blend.
 
 Interface/state_dict follow the reference (fusions/MMF_XAttn_Add.py:9-103); computed by
-`immtsf_mmf_xattn_add_forward/backward` (grouped MFMA GEMMs for the projections, batched MFMA GEMMs for QK^T and
+`immtsf_mmf_xattn_{kv,q}_forward/backward` (the block as a key/value half and a query half; grouped MFMA GEMMs for the projections, batched MFMA GEMMs for QK^T and
 A*V over (window, head), fused softmax+dropout rows, fused LN/blend tail).  Quirk kept: a window without text
 returns Y_ts/(1+kappa).
 """
@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from fusions._common import f32, resolve_precision
 from immtsf import config
-from immtsf.ops import MMFXAttnAddFn
+from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn
 
 
 class MMF_XAttn_Add(nn.Module):
@@ -41,11 +41,21 @@ class MMF_XAttn_Add(nn.Module):
                 self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.residual_head.weight,
                 self.residual_head.bias, self.layer_norm.weight, self.layer_norm.bias)
 
-    def forward(self, Y_ts, E_txt, M_txt):
-        """Y_ts (B,T,C), E_txt (B,T,d_txt), M_txt (B,1)|(B,) bool -> (B,T,C)"""
+    def project_kv(self, E_txt):
+        """key/value half (proj_k / proj_v + their MHA in-projections): depends only on the text side, so a caller
+        can run it on the text stream while the backbone is still producing Y_ts (lib.evaluation.forecast_and_fuse)"""
+        return MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
+                                  getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
+                                  self.attn.in_proj_weight, self.attn.in_proj_bias)
+
+    def forward(self, Y_ts, E_txt, M_txt, kv=None):
+        """Y_ts (B,T,C), E_txt (B,T,d_txt), M_txt (B,1)|(B,) bool -> (B,T,C).  kv: the result of project_kv(E_txt)
+        when the caller computed it ahead of time."""
         B = Y_ts.shape[0]
         M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
         training = self.training and self.p_drop > 0.0
         self.last_seed = config.next_seed() if training else 0
-        return MMFXAttnAddFn.apply(f32(Y_ts), f32(E_txt), M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
-                                   resolve_precision(self), self.last_seed, *self._params())
+        Ki, Vi = self.project_kv(E_txt) if kv is None else kv
+        p = self._params()
+        return MMFXAttnQFn.apply(f32(Y_ts), Ki, Vi, M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
+                                 resolve_precision(self), self.last_seed, p[0], *p[3:])

@@ -88,6 +88,19 @@ _PROTOS = {
     "immtsf_mmf_xattn_add_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
                                                 c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
                                                 c_stream]),
+    "immtsf_mmf_xattn_kv_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_kv_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_q_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_q_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_kv_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                              c_stream]),
+    "immtsf_mmf_xattn_kv_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                               C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
+    "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
+                                             C.c_size_t, c_stream]),
+    "immtsf_mmf_xattn_q_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
+                                              c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
+                                              c_stream]),
     "immtsf_mmf_gr_add_workspace_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
     "immtsf_mmf_gr_add_scratch_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
     "immtsf_mmf_gr_add_forward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,

@@ -57,9 +57,10 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
     with torch.cuda.stream(side_stream):
         pred_y = model.forecasting(*fc_args)
     E_txt, M_txt = fusion.ttf(notes, tau, tp)
+    kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
     main.wait_stream(side_stream)
     pred_y.record_stream(main)
-    return fusion.mmf(pred_y, E_txt, M_txt)
+    return fusion.mmf(pred_y, E_txt, M_txt) if kv is None else fusion.mmf(pred_y, E_txt, M_txt, kv=kv)
 
 
 def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_embeddings=True, group=None):

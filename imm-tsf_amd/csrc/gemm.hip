@@ -37,16 +37,29 @@ template <bool BF16, bool TR, int ROWS, int BK> struct TileGeom {
     static constexpr int elems = kmajor ? BK * pitch : ROWS * pitch;
 };
 
-template <bool BF16, bool TA, bool TB, int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
+// SPEC (wave specialisation): the workgroup has 2*WM*WN waves.  Waves [0, WM*WN) only read fragments and issue MFMAs;
+// waves [WM*WN, 2*WM*WN) only move data (global -> registers -> bf16 -> LDS), two tiles ahead in two register sets.
+// The phases of one K step (load wait, convert + LDS fill, LDS fragment reads + MFMA) then overlap across waves
+// instead of running back to back in every wave between two barriers (r01f/r01g ablations: at 2048x768x768 the three
+// phases cost 2.4 + 1.1 + 2.0 us and simply add up in the unspecialised kernel).
+// BBF: the B operand is read from its bf16 twin (GemmProblem::Bh): half as many 16-byte load instructions through the
+// L1 -- the resource that bounds the K loop at the fusion shapes (r01g: time is linear in K at 11.8 ns per K unit for
+// 2048x768xK whatever the tile shape, wave count or overlap scheme) -- no conversion, one 16-byte LDS write per chunk.
+template <bool BF16, bool TA, bool TB, int BM, int BN, int BK, int WM, int WN, bool SPEC = false, bool BBF = false>
+__global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(const GemmArgs g) {
+    static_assert(!BBF || (BF16 && !SPEC), "bf16-twin operands: bf16 MFMA path, unspecialised pipeline");
     typedef typename LdsElem<BF16>::T T;
     typedef TileGeom<BF16, TA, BM, BK> GA;
     typedef TileGeom<BF16, TB, BN, BK> GB;
-    constexpr int NT = WM * WN * 64;
+    constexpr int NTC = WM * WN * 64;                 // compute threads
+    constexpr int NT = SPEC ? 2 * NTC : NTC;          // all threads
+    constexpr int NL = NTC;                           // loader threads (SPEC: the upper half; else everybody)
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int CA = (BM * BK / 4) / NT, CB = (BN * BK / 4) / NT;
+    constexpr int CA = (BM * BK / 4) / NL, CB = (BN * BK / 4) / NL;
+    constexpr int CBH = BBF ? (BN * BK / 8) / NL : 1;      // 8-element (16-byte) chunks of a bf16 operand per thread
+    static_assert(!BBF || ((BN * BK / 8) % NL == 0 && CBH >= 1), "bf16 chunking must be exact");
     static_assert(CA >= 1 && CB >= 1, "tile too small for the thread count");
-    static_assert((BM * BK / 4) % NT == 0 && (BN * BK / 4) % NT == 0, "chunking must be exact");
+    static_assert((BM * BK / 4) % NL == 0 && (BN * BK / 4) % NL == 0, "chunking must be exact");
     constexpr int BUF = ((GA::elems + GB::elems) * (int)sizeof(T) + 15) / 16 * 16 / (int)sizeof(T);
 
     __shared__ __attribute__((aligned(16))) T smem[2 * BUF];
@@ -81,16 +94,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     if (row0 >= M) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const bool is_loader = !SPEC || tid >= NTC, is_compute = !SPEC || tid < NTC;
+    const int ltid = SPEC ? (is_loader ? tid - NTC : 0) : tid;        // loader-relative thread index
+    const int wm0 = ((wave % (WM * WN)) / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
     const float* __restrict__ A = P.A + offA;
     const float* __restrict__ Bp = P.B + offB;
+    const bf16_t* __restrict__ Bh = reinterpret_cast<const bf16_t*>(P.Bh) + offB;      // BBF only
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rbh[CBH];
+    bool b_h = false;          // the staged B registers currently hold bf16 chunks (rbh) rather than floats (rb)
 
     float4 ra[CA], rb[CB];
 
-    auto load_slow = [&](int k0) {
+    auto load_slow = [&](int k0, float4 (&ra)[CA], float4 (&rb)[CB]) {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
-            const int c = tid + i * NT;
+            const int c = ltid + i * NL;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TA) {
                 const int r = c / (BK / 4), kq = c % (BK / 4);
@@ -125,12 +144,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            const int c = tid + i * NT;
+            const int c = ltid + i * NL;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!TB) {
                 const int r = c / (BK / 4), kq = c % (BK / 4);
                 const int gcol = col0 + r, gk = k0 + kq * 4;
-                if (gcol < N && gk < K) {
+                if (BBF && gcol < N && gk < K) {
+                    const bf16_t* src = Bh + (size_t)gcol * g.ldb + gk;
+                    v.x = (float)src[0];
+                    if (gk + 1 < K) v.y = (float)src[1];
+                    if (gk + 2 < K) v.z = (float)src[2];
+                    if (gk + 3 < K) v.w = (float)src[3];
+                } else if (gcol < N && gk < K) {
                     const float* src = Bp + (size_t)gcol * g.ldb + gk;
                     if (g.vecB && gk + 3 < K) v = *reinterpret_cast<const float4*>(src);
                     else {
@@ -143,7 +168,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             } else {
                 const int kk = c / (BN / 4), rq = c % (BN / 4);
                 const int gk = k0 + kk, gcol = col0 + rq * 4;
-                if (gk < K && gcol < N) {
+                if (BBF && gk < K && gcol < N) {
+                    const int sk = g.b_rowmap ? g.b_rowmap[gk] : gk;
+                    const bf16_t* src = Bh + (size_t)sk * g.ldb + gcol;
+                    v.x = (float)src[0];
+                    if (gcol + 1 < N) v.y = (float)src[1];
+                    if (gcol + 2 < N) v.z = (float)src[2];
+                    if (gcol + 3 < N) v.w = (float)src[3];
+                } else if (gk < K && gcol < N) {
                     const int sk = g.b_rowmap ? g.b_rowmap[gk] : gk;
                     const float* src = Bp + (size_t)sk * g.ldb + gcol;
                     if (g.vecB && gcol + 3 < Nreal) v = *reinterpret_cast<const float4*>(src);
@@ -157,6 +189,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             }
             rb[i] = v;
         }
+        b_h = false;
     };
 
     // ---- fast path: straight-line 16-byte loads, no bounds checks, addresses = uniform base + per-lane 32-bit
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     if (fast) {
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
-            const int c = tid + i * NT;
+            const int c = ltid + i * NL;
             if (!TA) {
                 const int r = min(row0 + c / (BK / 4), M - 1), kq = c % (BK / 4);
                 const int srow = g.a_rowmap ? g.a_rowmap[r] : r;
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int i = 0; i < CB; ++i) {
-            const int c = tid + i * NT;
+            const int c = ltid + i * NL;
             if (!TB) {
                 const int r = min(col0 + c / (BK / 4), Nreal - 1), kq = c % (BK / 4);
                 ob[i] = (unsigned)r * (unsigned)g.ldb + kq * 4;
@@ -190,13 +223,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             }
         }
     }
-    auto load_fast = [&](int k0) {
+    unsigned obh[CBH];
+    if (BBF && fast) {
+#pragma unroll
+        for (int i = 0; i < CBH; ++i) {
+            const int c = ltid + i * NL;
+            if (!TB) {
+                const int r = min(col0 + c / (BK / 8), Nreal - 1), kq = c % (BK / 8);
+                obh[i] = (unsigned)r * (unsigned)g.ldb + kq * 8;
+            } else {
+                obh[i] = (unsigned)(c / (BN / 8)) * (unsigned)g.ldb + col0 + (c % (BN / 8)) * 8;
+            }
+        }
+    }
+    auto load_fast = [&](int k0, float4 (&ra)[CA], float4 (&rb)[CB]) {
         const unsigned ka = TA ? (unsigned)k0 * (unsigned)g.lda : (unsigned)k0;
         const unsigned kb = TB ? (unsigned)k0 * (unsigned)g.ldb : (unsigned)k0;
+#ifdef IMMTSF_EXPERIMENT_HALF_BYTES     // measurement only (tools/gemm_halfbytes.py): fetch half the bytes, as if the
+                                        // operands were stored as bf16; the results are garbage
+#pragma unroll
+        for (int i = 0; i < CA; ++i) { const float2 t = *reinterpret_cast<const float2*>(A + ((oa[i] + ka) >> 1)); ra[i] = make_float4(t.x, t.y, t.x, t.y); }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) { const float2 t = *reinterpret_cast<const float2*>(Bp + ((ob[i] + kb) >> 1)); rb[i] = make_float4(t.x, t.y, t.x, t.y); }
+#else
 #pragma unroll
         for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (oa[i] + ka));
+        if (BBF) {
 #pragma unroll
-        for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + (ob[i] + kb));
+            for (int i = 0; i < CBH; ++i) rbh[i] = *reinterpret_cast<const u32x4*>(Bh + (obh[i] + kb));
+            b_h = true;
+        } else {
+#pragma unroll
+            for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + (ob[i] + kb));
+        }
+#endif
     };
     // write one 4-element chunk of a staged tile.  `transposed`: the 4 values run along the tile's ROW index.
     auto put4 = [&](T* base, bool transposed, bool kmajor, int pitch, int BR, int c, const float4& v) {
@@ -221,13 +281,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
             dst[0] = (T)v.x; dst[pitch] = (T)v.y; dst[2 * pitch] = (T)v.z; dst[3 * pitch] = (T)v.w;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const float4 (&ra)[CA], const float4 (&rb)[CB]) {
         T* As = smem + buf * BUF;
         T* Bs = As + GA::elems;
 #pragma unroll
-        for (int i = 0; i < CA; ++i) put4(As, TA, GA::kmajor, GA::pitch, BM, tid + i * NT, ra[i]);
+        for (int i = 0; i < CA; ++i) put4(As, TA, GA::kmajor, GA::pitch, BM, ltid + i * NL, ra[i]);
+        if (BBF && b_h) {          // bf16 chunks go to LDS as they are: one 16-byte write each
 #pragma unroll
-        for (int i = 0; i < CB; ++i) put4(Bs, TB, GB::kmajor, GB::pitch, BN, tid + i * NT, rb[i]);
+            for (int i = 0; i < CBH; ++i) {
+                const int c = ltid + i * NL;
+                bf16_t* dst = reinterpret_cast<bf16_t*>(Bs) +
+                              (TB ? (c / (BN / 8)) * GB::pitch + (c % (BN / 8)) * 8 : (c / (BK / 8)) * GB::pitch + (c % (BK / 8)) * 8);
+                *reinterpret_cast<u32x4*>(dst) = rbh[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CB; ++i) put4(Bs, TB, GB::kmajor, GB::pitch, BN, ltid + i * NL, rb[i]);
+        }
     };
 
     f32x4 acc[TM][TN];
@@ -330,8 +400,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
     auto pipeline = [&](int t0, int t1, auto&& loader) {
         if (t0 < t1) {
-            loader(t0 * BK);
-            store_tile(0);
+            loader(t0 * BK, ra, rb);
+            store_tile(0, ra, rb);
         }
         __syncthreads();
         for (int t = t0; t < t1; ++t) {
@@ -340,18 +410,86 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
                 bf16x8 fa[KG][TM], fb[KG][TN];
                 read_frags(cur, fa, fb);
                 __builtin_amdgcn_sched_barrier(0);               // fragment reads stay in front of the global loads
-                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);
+                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK, ra, rb);
                 if (!(g.dbg & 1)) mfma_frags(fa, fb);
             } else {
-                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK);   // issue early: in flight under this tile's MFMAs
+                if (t + 1 < t1 && !(g.dbg & 2)) loader((t + 1) * BK, ra, rb);   // issue early: in flight under this tile's MFMAs
                 if (!(g.dbg & 1)) compute(cur);
             }
             __builtin_amdgcn_sched_barrier(0);                // keep the LDS writes (and their vmcnt wait) behind the MFMAs
-            if (t + 1 < t1 && !(g.dbg & 4)) store_tile(cur ^ 1);    // other buffer: last read one barrier ago
+            if (t + 1 < t1 && !(g.dbg & 4)) store_tile(cur ^ 1, ra, rb);    // other buffer: last read one barrier ago
             __syncthreads();
         }
     };
-    if (fast) {
+    // wave-specialised pipeline over the full tiles [t0, t1): producers keep two tiles in flight (register sets ra/rb and
+    // ra2/rb2), consumers only see LDS.  One barrier per K step; buffer (t+1)&1 is filled while buffer t&1 is read.
+    auto pipeline_spec = [&](int t0, int t1) {
+        float4 ra2[CA], rb2[CB];
+        if (is_loader) {
+            if (t0 < t1) {
+                load_fast(t0 * BK, ra, rb);
+                store_tile(0, ra, rb);
+            }
+            if (t0 + 1 < t1) load_fast((t0 + 1) * BK, ra2, rb2);          // tile t0+1 -> set 2
+        }
+        __syncthreads();
+        int t = t0;
+        for (; t + 3 < t1; t += 2) {       // steady state: no conditionals between the loads and their consumers
+            if (is_loader) {
+                load_fast((t + 2) * BK, ra, rb);       // two tiles ahead
+                store_tile(1, ra2, rb2);               // tile t+1 (in flight since the previous step)
+            } else {
+                compute(0);
+            }
+            __syncthreads();
+            if (is_loader) {
+                load_fast((t + 3) * BK, ra2, rb2);
+                store_tile(0, ra, rb);                 // tile t+2
+            } else {
+                compute(1);
+            }
+            __syncthreads();
+        }
+        // drain: at most 3 tiles left (t .. t1-1); tile t is in buffer 0, tile t+1 (if any) is in set 2
+        for (int u = t; u < t1; ++u) {
+            const int cur = (u - t) & 1;
+            if (is_loader) {
+                if (u + 1 < t1) {
+                    if (cur == 0) {
+                        if (u + 2 < t1) load_fast((u + 2) * BK, ra, rb);
+                        store_tile(1, ra2, rb2);
+                    } else {
+                        store_tile(0, ra, rb);
+                    }
+                }
+            } else {
+                compute(cur);
+            }
+            __syncthreads();
+        }
+    };
+    // tiles the fast loader cannot take (ragged K tail, edge tiles of transposed operands, unaligned operands) in a
+    // specialised workgroup: producers fill, barrier, consumers compute, barrier -- correct, not overlapped, rare
+    auto pipeline_spec_slow = [&](int t0, int t1) {
+        for (int t = t0; t < t1; ++t) {
+            if (is_loader) {
+                load_slow(t * BK, ra, rb);
+                store_tile(0, ra, rb);
+            }
+            __syncthreads();
+            if (is_compute) compute(0);
+            __syncthreads();
+        }
+    };
+    if (SPEC) {
+        if (fast) {
+            const int kfull = min(kt1, K / BK);
+            pipeline_spec(kt0, kfull);
+            if (kfull < kt1) pipeline_spec_slow(kfull > kt0 ? kfull : kt0, kt1);
+        } else {
+            pipeline_spec_slow(kt0, kt1);
+        }
+    } else if (fast) {
         const int kfull = min(kt1, K / BK);                   // tiles [kt0, kfull) are complete
         pipeline(kt0, kfull, load_fast);
         if (kfull < kt1) pipeline(kfull > kt0 ? kfull : kt0, kt1, load_slow);   // at most one ragged tile
@@ -369,13 +507,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
     constexpr bool kCtFits = (size_t)BM * CP * sizeof(float) <= (size_t)2 * BUF * sizeof(T);
     if (kCtFits && g.vecC && splits == 1 && !(TA && TB && g.ones_col)) {
         float* Ct = reinterpret_cast<float*>(smem);
+        if (is_compute) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Ct[(wm0 + i * 16 + fq * 4 + r) * CP + wn0 + j * 16 + fr] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r)
+                        Ct[(wm0 + i * 16 + fq * 4 + r) * CP + wn0 + j * 16 + fr] = acc[i][j][r];
+        }
         __syncthreads();
         constexpr int NCH = BM * BN / 4;
         for (int q = tid; q < NCH; q += NT) {
@@ -405,6 +545,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
         }
         return;
     }
+    if (!is_compute) return;
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -445,16 +586,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmArgs g) {
 
 long g_last_grid_threads = 0;   // for the timing tap: lets bench.py match a launch with rocprof's Grid_Size
 
-template <bool BF16, int BM, int BN, int BK, int WM, int WN>
+template <bool BF16, int BM, int BN, int BK, int WM, int WN, bool SPEC = false, bool BBF = false>
 int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
     const int Nlog = g.N + ((layout == GEMM_TN && g.ones_col) ? 1 : 0);
-    dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), splits, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block(WM * WN * 64);
+    dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), splits, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block((SPEC ? 2 : 1) * WM * WN * 64);
     if (grid.x == 0) return IMMTSF_OK;
     g_last_grid_threads = (long)grid.x * grid.y * grid.z * block.x;
     switch (layout) {
-        case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BF16, false, false, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
-        case GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BF16, false, true, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
-        case GEMM_TN: hipLaunchKernelGGL((gemm_kernel<BF16, true, true, BM, BN, BK, WM, WN>), grid, block, 0, stream, g); break;
+        case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BF16, false, false, BM, BN, BK, WM, WN, SPEC, BBF>), grid, block, 0, stream, g); break;
+        case GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BF16, false, true, BM, BN, BK, WM, WN, SPEC, BBF>), grid, block, 0, stream, g); break;
+        case GEMM_TN:
+            if (BBF) return IMMTSF_EINVAL;      // weights are never the B operand of a weight-gradient GEMM
+            hipLaunchKernelGGL((gemm_kernel<BF16, true, true, BM, BN, BK, WM, WN, SPEC, false>), grid, block, 0, stream, g);
+            break;
         default: return IMMTSF_EINVAL;
     }
     IMMTSF_LAUNCH_CHECK();
@@ -484,6 +628,41 @@ int g_tap_n = 0, g_tap_on = 0, g_tap_events = 0;
 }  // namespace
 
 static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t stream);
+
+// ---- bf16 twin registry (process-global, like the timing tap): a handful of ranges, linear lookup
+namespace {
+struct TwinRange { const float* base; const unsigned short* twin; size_t count; };
+constexpr int kMaxTwins = 16;
+TwinRange g_twins[kMaxTwins];
+int g_ntwins = 0;
+int g_twins_on = 1;
+}  // namespace
+
+const void* immtsf_twin_lookup(const float* p, size_t min_elems) {
+    if (!g_twins_on) return nullptr;
+    for (int i = 0; i < g_ntwins; ++i) {
+        const TwinRange& r = g_twins[i];
+        if (p >= r.base && p + min_elems <= r.base + r.count) return r.twin + (p - r.base);
+    }
+    return nullptr;
+}
+
+extern "C" int immtsf_bf16_twin_register(const float* base, void* twin, size_t count) {
+    if (!base || !twin || count == 0) return IMMTSF_EINVAL;
+    for (int i = 0; i < g_ntwins; ++i)
+        if (g_twins[i].base == base) { g_twins[i] = TwinRange{base, static_cast<const unsigned short*>(twin), count}; return IMMTSF_OK; }
+    if (g_ntwins >= kMaxTwins) return IMMTSF_EUNSUPPORTED;
+    g_twins[g_ntwins++] = TwinRange{base, static_cast<const unsigned short*>(twin), count};
+    return IMMTSF_OK;
+}
+
+extern "C" int immtsf_bf16_twin_unregister(const float* base) {
+    for (int i = 0; i < g_ntwins; ++i)
+        if (g_twins[i].base == base) { g_twins[i] = g_twins[--g_ntwins]; return IMMTSF_OK; }
+    return IMMTSF_OK;
+}
+
+extern "C" int immtsf_bf16_twin_enable(int on) { g_twins_on = on ? 1 : 0; return IMMTSF_OK; }
 
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
     if (!g_tap_on || g_tap_n >= kTapCap) return launch_gemm_impl(layout, precision, g, stream);
@@ -583,6 +762,21 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         }
     }
 
+    // bf16 twin of the B operand (weights; forward NT and data-gradient NN): every problem of the launch must have one
+    bool bbf = false;
+    if (precision == 1 && layout != GEMM_TN && g.nbatch <= 1 && !g.b_rowmap) {
+        bbf = true;
+        for (int i = 0; i < g.nprob && bbf; ++i) {
+            const size_t span = layout == GEMM_NT ? (size_t)(g.N - 1) * g.ldb + g.K : (size_t)(g.K - 1) * g.ldb + g.N;
+            g.p[i].Bh = immtsf_twin_lookup(g.p[i].B, span);
+            bbf = g.p[i].Bh != nullptr;
+        }
+        if (bbf) {
+            bool vb8 = (g.ldb % 8) == 0;
+            for (int i = 0; i < g.nprob; ++i) vb8 = vb8 && ((reinterpret_cast<uintptr_t>(g.p[i].Bh) & 15) == 0);
+            if (!vb8) bbf = false;      // misaligned twin: stay on the fp32 operand (its own vecB flag is already set)
+        }
+    }
     if (precision == 1) {
         int v = g_variant;
         if (v == 0) {
@@ -602,17 +796,28 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             case 1: return launch_cfg<true, 64, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 2: return launch_cfg<true, 64, 64, 128, 2, 2>(layout, g, Mmax, splits, stream);
             case 3: return launch_cfg<true, 128, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
-            case 4: return launch_cfg<true, 128, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
+            case 4:
+                if (bbf) return launch_cfg<true, 128, 128, 64, 2, 2, false, true>(layout, g, Mmax, splits, stream);
+                return launch_cfg<true, 128, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 5: return launch_cfg<true, 32, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 6: return launch_cfg<true, 64, 128, 64, 2, 2>(layout, g, Mmax, splits, stream);
-            case 7: return launch_cfg<true, 64, 64, 32, 2, 2>(layout, g, Mmax, splits, stream);
+            case 7:
+                if (bbf) return launch_cfg<true, 64, 64, 32, 2, 2, false, true>(layout, g, Mmax, splits, stream);
+                return launch_cfg<true, 64, 64, 32, 2, 2>(layout, g, Mmax, splits, stream);
             case 8: return launch_cfg<true, 64, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 9: return launch_cfg<true, 96, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 10: return launch_cfg<true, 96, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
-            case 11: return launch_cfg<true, 64, 64, 64, 2, 4>(layout, g, Mmax, splits, stream);
+            case 11:
+                if (bbf) return launch_cfg<true, 64, 64, 64, 2, 4, false, true>(layout, g, Mmax, splits, stream);
+                return launch_cfg<true, 64, 64, 64, 2, 4>(layout, g, Mmax, splits, stream);
             case 12: return launch_cfg<true, 128, 64, 64, 4, 2>(layout, g, Mmax, splits, stream);
             case 13: return launch_cfg<true, 128, 128, 64, 4, 2>(layout, g, Mmax, splits, stream);
-            case 14: return launch_cfg<true, 64, 64, 128, 2, 4>(layout, g, Mmax, splits, stream);
+            case 14:
+                if (bbf) return launch_cfg<true, 64, 64, 128, 2, 4, false, true>(layout, g, Mmax, splits, stream);
+                return launch_cfg<true, 64, 64, 128, 2, 4>(layout, g, Mmax, splits, stream);
+            case 15: return launch_cfg<true, 64, 64, 64, 2, 2, true>(layout, g, Mmax, splits, stream);
+            case 16: return launch_cfg<true, 64, 64, 32, 2, 2, true>(layout, g, Mmax, splits, stream);
+            case 17: return launch_cfg<true, 128, 64, 32, 2, 2, true>(layout, g, Mmax, splits, stream);
             default: return IMMTSF_EINVAL;
         }
     }

@@ -10,6 +10,7 @@ struct GemmProblem {
     float* C;
     const float* bias;   // length N, may be null
     float* bias_grad;    // TN + ones_col: length M, receives sum_k opA(m,k)
+    const void* Bh;      // set by the launcher: bf16 twin of B (same element offsets) when one is registered
 };
 
 // C[m,n] = epilogue( alpha * sum_k opA(m,k) * opB(n,k) )
@@ -49,6 +50,10 @@ struct GemmArgs {
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
+
+// bf16 twins (immtsf_bf16_twin_register): a registered fp32 range [base, base+count) has a bf16 copy with the same
+// element offsets, kept current by its owner (the fused Adam kernel writes it).  Returns the twin of `p` or null.
+const void* immtsf_twin_lookup(const float* p, size_t min_elems);
 
 // precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);

@@ -1,5 +1,6 @@
 // Fused tails of the MMF blocks + loss + optimizer.  All HBM/latency-bound: one thread or one wave per row.
 #include "tail.hpp"
+#include "gemm.hpp"
 
 namespace {
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
-                                                    const long long* __restrict__ step_dev) {
+                                                    const long long* __restrict__ step_dev, bf16_t* __restrict__ twin) {
     __shared__ float red[16];
     if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)
         const float st = (float)step_dev[0];
@@ -170,11 +171,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
         m[i] = mi;
         v[i] = vi;
-        p[i] -= step * mi / (sqrtf(vi) / bc2s + eps);
+        const float pn = p[i] - step * mi / (sqrtf(vi) / bc2s + eps);
+        p[i] = pn;
+        if (twin) twin[i] = (bf16_t)pn;      // bf16 twin of the parameters (the GEMMs' weight operand), kept current here
     }
 }
 
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+}
+
 }  // namespace
+
+int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), n);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
 
 int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s) {
     if (rows <= 0) return IMMTSF_OK;
@@ -233,7 +248,8 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
     const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, nparts, (const long long*)nullptr);
+                       norm_scratch, nparts, (const long long*)nullptr,
+                       reinterpret_cast<bf16_t*>(const_cast<void*>(immtsf_twin_lookup(param, n))));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -249,7 +265,8 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
     IMMTSF_LAUNCH_CHECK();
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
-                       norm_scratch, nparts, (const long long*)step_dev);
+                       norm_scratch, nparts, (const long long*)step_dev,
+                       reinterpret_cast<bf16_t*>(const_cast<void*>(immtsf_twin_lookup(param, n))));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

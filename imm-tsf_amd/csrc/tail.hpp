@@ -24,3 +24,6 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
 int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
                     hipStream_t s);
+
+// dst[i] = bf16(src[i]) (round to nearest even): refresh of a bf16 twin
+int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);

@@ -134,6 +134,10 @@ _PROTOS = {
     "immtsf_time2vec_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_time2vec_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                            c_f32p, c_f32p, c_stream]),
+    "immtsf_bf16_twin_register": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t]),
+    "immtsf_bf16_twin_unregister": (C.c_int, [c_f32p]),
+    "immtsf_bf16_twin_enable": (C.c_int, [C.c_int32]),
+    "immtsf_f32_to_bf16": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_gemm_batched": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int64, C.c_int64, c_f32p, C.c_int32,
                                       C.c_int64, C.c_int64, c_f32p, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, c_stream]),
@@ -165,6 +169,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("IMMTSF_LIB", LIB_PATH)       # measurement builds (tools/); the default is the in-tree library
     if not os.path.exists(LIB_PATH):
         raise ImmtsfError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

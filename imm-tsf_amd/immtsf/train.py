@@ -30,7 +30,7 @@ def shard_range(n_items: int, rank: int, world: int):
 class FlatTrainer:
     def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
-                 sink_buckets: Sequence[int] = (), device_step: bool = False):
+                 sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
         sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks)."""
         self.group = group
@@ -45,8 +45,11 @@ class FlatTrainer:
         if not params:
             raise ValueError("no trainable parameters")
         dev = params[0].device
-        n = sum(p.numel() for p in params)
-        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        # every parameter starts on a 32-byte boundary of the flat buffers, so that it (and its bf16 twin) can be fetched
+        # with 16-byte loads; the padding elements stay zero everywhere
+        pad8 = lambda k: (k + 7) // 8 * 8      # noqa: E731
+        n = sum(pad8(p.numel()) for p in params)
+        self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -68,10 +71,18 @@ class FlatTrainer:
                     p._immtsf_grad_sink = gview
                     p._immtsf_grad_prezeroed = True   # zero_grad() memsets the whole flat buffer every step
                 p.grad = gview              # optimizers / clip utilities that look at .grad still work
-                off += k
+                off += pad8(k)
             self._views.append(views)
             self.ranges.append((start, off))
         self.sink_buckets = set(sink_buckets)
+        # bf16 twin of the parameters: the forward / data-gradient GEMMs read their weight operand from it in bf16 mode
+        # (half the operand bytes, no conversion); the fused Adam kernel writes it together with the parameters
+        self.flat_twin = None
+        if (bf16_twin if bf16_twin is not None else dev.type == "cuda") and dev.type == "cuda":
+            lib = _lib.load()
+            self.flat_twin = torch.empty(n, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(self.flat_param), _lib.ptr(self.flat_twin), n), "bf16_twin_register")
+            self.refresh_twins()
         # device_step: Adam's step number (and the dropout key offset) live in device memory so that a captured
         # hipGraph advances them on every replay (immtsf.config.enable_device_counters)
         self.device_step = device_step and dev.type == "cuda"
@@ -91,6 +102,36 @@ class FlatTrainer:
             for bi in self.sink_buckets:
                 head = self.buckets[bi][0]
                 head._immtsf_bwd_hook = (lambda i=bi: self._bucket_ready(i))
+
+    def gather(self, flat: torch.Tensor) -> torch.Tensor:
+        """the parameters' elements of a flat buffer (param / grad / moment), concatenated in bucket order without the
+        alignment padding"""
+        out, off = [], 0
+        for b in self.buckets:
+            for p in b:
+                out.append(flat[off:off + p.numel()])
+                off += (p.numel() + 7) // 8 * 8
+        return torch.cat(out)
+
+    def refresh_twins(self):
+        """re-derive the bf16 twin from the fp32 parameters: call after writing parameters by any means other than
+        step() (load_state_dict, manual edits)."""
+        if self.flat_twin is not None:
+            lib = _lib.load()
+            _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(self.flat_param), _lib.ptr(self.flat_twin), self.flat_param.numel(),
+                                              _lib.stream_ptr()), "f32_to_bf16")
+
+    def close(self):
+        """drop the twin registration (the registry is keyed by the flat buffer's address)"""
+        if getattr(self, "flat_twin", None) is not None:
+            try:
+                _lib.load().immtsf_bf16_twin_unregister(_lib.ptr(self.flat_param))
+            except Exception:
+                pass
+            self.flat_twin = None
+
+    def __del__(self):
+        self.close()
 
     # ---------------------------------------------------------------------------------------------- step pieces
     def zero_grad(self):

@@ -289,6 +289,15 @@ int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float
                             const float* b, float* out, immtsf_stream_t stream);
 int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const float* w, const float* b, const float* dout,
                              float* dw0, float* db0, float* dw, float* db, float* scratch, immtsf_stream_t stream);
+/* bf16 twins.  In bf16 precision the MFMA operands are rounded to bf16 anyway; a registered fp32 range
+ * [base, base+count) whose owner keeps a bf16 copy (same element offsets) lets every GEMM whose B operand lies inside
+ * it -- the weights of the forward (NT) and data-gradient (NN) GEMMs -- fetch half as many bytes with no conversion.
+ * immtsf_adam_step[_dev] on a registered parameter range writes the twin together with the parameters; after any other
+ * write to the range call immtsf_f32_to_bf16 (FlatTrainer.refresh_twins).  Process-global registry (<= 16 ranges). */
+int immtsf_bf16_twin_register(const float* base, void* twin, size_t count);
+int immtsf_bf16_twin_unregister(const float* base);
+int immtsf_bf16_twin_enable(int32_t on);            /* A/B switch for measurements; default on */
+int immtsf_f32_to_bf16(const float* src, void* dst, size_t n, immtsf_stream_t stream);
 /* batched over (outer, inner) with element strides, used by FullAttention (layers/SelfAttention_Family.py:50-77) */
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,

@@ -76,11 +76,11 @@ def _worker(rank, world, port, q):
     loss = _loss(params, shard, cnt, H)
     loss.backward()
     tr.sync_grads()
-    g_dp = tr.flat_grad.clone()
+    g_dp = tr.gather(tr.flat_grad)
     loss_sum = loss.detach().clone()
     dist.all_reduce(loss_sum)                         # the ranks' shares add up to the global loss
     tr.step()
-    p_dp = tr.flat_param.clone()
+    p_dp = tr.gather(tr.flat_param)
     if rank == 0:
         # single-process reference on the full batch
         ref = _params(z)

@@ -103,3 +103,62 @@ def test_two_stream_overlap_same_result_and_dropout_advances():
     g = GraphedStep(tr, _loss_fn(model, fusion, batch, torch.cuda.Stream(device=dev)))
     ls = [float(g().detach()) for _ in range(4)]
     assert len({round(v, 7) for v in ls}) == 4, ls
+
+
+def test_bf16_twin_operand_is_bit_identical():
+    """a GEMM whose weight operand has a registered bf16 twin must return exactly what the fp32-operand GEMM returns
+    (the same values are rounded to bf16 either way), for NT (forward) and NN (data gradient), incl. a ragged K tail"""
+    dev = _dev()
+    from immtsf import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    for layout, M, N, K in [(0, 300, 192, 160), (1, 300, 160, 192), (0, 2048, 768, 768), (1, 2048, 768, 768), (0, 70, 64, 100)]:
+        W = torch.randn((N, K) if layout == 0 else (K, N), device=dev)
+        A = torch.randn(M, K, device=dev)
+        bias = torch.randn(N, device=dev)
+        outs = []
+        for use_twin in (False, True):
+            if use_twin:
+                twin = W.to(torch.bfloat16).contiguous()
+                _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(W), _lib.ptr(twin), W.numel()), "reg")
+            Cm = torch.empty(M, N, device=dev)
+            _lib.check(lib.immtsf_gemm(layout, 1, _lib.ptr(A), K, _lib.ptr(W), W.shape[1], _lib.ptr(Cm), N, _lib.ptr(bias), M, N, K,
+                                       1.0, 0, 0, _lib.stream_ptr()), "gemm")
+            torch.cuda.synchronize()
+            outs.append(Cm)
+        lib.immtsf_bf16_twin_unregister(_lib.ptr(W))
+        assert torch.equal(outs[0], outs[1]), (layout, M, N, K)
+        ref = (A @ W.t() if layout == 0 else A @ W) + bias
+        assert float((outs[1] - ref).abs().max() / ref.abs().max()) < 2e-2
+
+
+def test_training_with_twins_matches_without():
+    """bf16 mode, dropout off: FlatTrainer's bf16 parameter twin (written by the fused Adam kernel every step) must not
+    change the trajectory -- a stale twin would."""
+    dev = _dev()
+    from immtsf import config
+    res = []
+    for twin in (False, True):
+        model, fusion, tr, batch = _setup(dev, 0.0)
+        tr.close()
+        from immtsf.train import FlatTrainer
+        tr = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+                         lr=1e-2, eps=1e-3, max_norm=1.0, sink_buckets=(0, 1), overlap=False, device_step=True, bf16_twin=twin)
+        config.precision = "bf16"
+        f = _loss_fn(model, fusion, batch)
+        ls = []
+        for _ in range(5):
+            tr.zero_grad()
+            l = f()
+            l.backward()
+            tr.sync_grads()
+            tr.step()
+            ls.append(float(l.detach()))
+        res.append((ls, tr.flat_param.clone()))
+        assert (tr.flat_twin is not None) == twin
+        if twin:
+            assert torch.equal(tr.flat_twin, tr.flat_param.to(torch.bfloat16))
+        tr.close()
+    config.precision = "fp32"
+    assert res[0][0][-1] < res[0][0][0]
+    assert max(abs(a - b) for a, b in zip(res[0][0], res[1][0])) < 2e-4 * abs(res[0][0][0])

@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
+    ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
+                    help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 specialised wgrad kernel)")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     args = ap.parse_args()
 
@@ -173,6 +175,8 @@ def main():
     from immtsf.train import FlatTrainer, GraphedStep
     from models.tPatchGNN import tPatchGNN
     lib = _lib.load()
+    if args.gemm_config:
+        lib.immtsf_debug_gemm_config(args.gemm_config, 0)
     config.precision = args.precision
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
     config.manual_seed(1234 + rank)
@@ -285,6 +289,11 @@ def main():
         Ab, Bb = torch.randn(*shapes[0], device=dev), torch.randn(*shapes[1], device=dev)
         Cb = torch.empty(Mm, Nn, device=dev)
         prec_code = 1 if args.precision == "bf16" else 0
+        # in the step the weight operand of a forward / data-gradient GEMM is read from FlatTrainer's bf16 twin: same here
+        twin_b = None
+        if prec_code == 1 and lay_i != 2 and trainer.flat_twin is not None:
+            twin_b = Bb.to(torch.bfloat16).contiguous()
+            _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(Bb), _lib.ptr(twin_b), Bb.numel()), "bf16_twin_register")
 
         def one():
             for _ in range(nprob):
@@ -309,6 +318,8 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         kernel_us = ev0.elapsed_time(ev1) / (10 * reps * nprob) * 1e3
+        if twin_b is not None:
+            lib.immtsf_bf16_twin_unregister(_lib.ptr(Bb))
         ach = (top["flops"] / nprob) / (kernel_us * 1e-6) / 1e12
         allfl = sum(r["flops"] * r["launches"] for r in rows) / sum(r["total_ms"] for r in rows) / 1e9
         lay = {0: "NT", 1: "NN", 2: "TN"}[top["key"][0]]
@@ -327,8 +338,9 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3,
                     "unit": "TFLOP/s", "frac": round(ach / (PEAK_BF16_TFLOPS if args.precision == "bf16" else 157.3), 5),
                     "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
-                    "algorithmic_bytes": 4 * (top["key"][2] * top["key"][4] + top["key"][3] * top["key"][4] + top["key"][2] * top["key"][3]),
-                    "kernel": f"gemm_kernel {lay} M={top['key'][2]} N={top['key'][3]} K={top['key'][4]} (x{top['key'][5] * top['key'][6]} problems per launch in the step; per-problem figures here)",
+                    "algorithmic_bytes": 4 * Mm * Kk + (2 if twin_b is not None else 4) * Nn * Kk + 4 * Mm * Nn,
+                    "b_operand": "bf16 twin of the weights" if twin_b is not None else "fp32",
+                    "kernel": f"gemm_kernel {lay} M={Mm} N={Nn} K={Kk} (x{top['key'][5] * top['key'][6]} problems per launch in the step; per-problem figures here)",
                     "avg_launch_us": round(kernel_us, 2), "avg_launch_us_eager_tap": round(top["avg_us"], 2),
                     "launches_per_step": top["launches"] // k2,
                     "all_gemm_ms_per_step": round(gemm_ms, 4), "all_gemm_tflops": round(allfl, 2),

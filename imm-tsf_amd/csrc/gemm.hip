@@ -606,7 +606,7 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 }
 
 // tuning override for tools/gemm_bench.py (0 = heuristic)
-int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0;
+int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 0;
 
 }  // namespace
 
@@ -614,6 +614,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_variant = variant & 0xff;
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
     g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
+    g_tn_spec = (variant & 0x2000) ? 1 : 0;  // bit 13 enables the specialised weight-gradient choice (A/B measurements)
     g_splitk = splitk;
     return 0;
 }
@@ -738,13 +739,22 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
     const bool can_split = g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
-    if (can_split) {
+    // OFF by default (debug bit 13): weight-gradient GEMMs with 96..230 output tiles on the wave-specialised kernel,
+    // unsplit.  Isolated it wins (r01g tn_sweep: 15.4 vs 19.4 us at 768x1152x1117: its consumer waves never wait on
+    // global loads, no atomics, nothing to pre-zero); inside the step it loses (1.46 -> 1.60 ms): with the bias-gradient
+    // ones column the edge tile column runs the unoverlapped checked-loader path and becomes the kernel's tail.
+    bool tn_spec = false;
+    if (layout == GEMM_TN && precision == 1 && g_variant == 0 && g_tn_spec && va && vb && !g.a_rowmap && !g.b_rowmap && g.nbatch <= 1) {
+        const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N + (g.ones_col ? 1 : 0), 64) * nbz;
+        tn_spec = tiles >= 96 && tiles <= 230 && g.K >= 256;
+    }
+    if (can_split && !tn_spec) {
         if (g_splitk > 0) splits = g_splitk;
         else {
             const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * nbz;
             const int ksteps = cdiv(g.K, 64);
             if ((tiles < 192 && ksteps >= 8) || (tiles < 256 && ksteps >= 32)) {   // r01g: at 200+ tiles the 8-wave tiles beat split-K
-                splits = (int)((512 + tiles - 1) / tiles);
+                splits = (int)(512 / tiles);        // all workgroups co-resident (2 per CU): no tail round
                 if (splits > ksteps / 2) splits = ksteps / 2;
                 if (splits > 512) splits = 512;
                 if (splits < 1) splits = 1;
@@ -785,7 +795,8 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             // below ~512 big tiles the grid cannot fill 256 CUs with 128x128 tiles: 64x64 tiles with EIGHT waves
             // (more wavefronts per CU to cover the load -> LDS -> MFMA latency chain), 128-deep K tiles when every
             // K tile is then full (r01g sweep: 10-25 % over the 4-wave 64x64x64 tile at the fusion shapes)
-            if (tiles128 >= 512) v = 4;
+            if (tn_spec) v = 15;
+            else if (tiles128 >= 512) v = 4;
             else if (layout == GEMM_TN || dyn_k || (g.K % 128) != 0) v = 11;
             else v = 14;
             // reductions that are a multiple of 32 but not of 64 (padded small-model dims): 32-deep K tiles keep every

@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
-                    help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 specialised wgrad kernel)")
+                    help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 no specialised wgrad kernel)")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     args = ap.parse_args()
 

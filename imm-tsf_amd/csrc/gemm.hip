@@ -75,7 +75,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
         offC = bo * g.sC_o + bin * g.sC_i;
     }
     int M = g.M, K = g.K;
-    const int N = g.N + ((TA && TB && g.ones_col) ? 1 : 0);   // logical N incl. the virtual ones column
+    const int N = g.N;
     const int Nreal = g.N;
     if (g.dyn) {
         const int dv = *g.dyn;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                     const int sk = g.b_rowmap ? g.b_rowmap[gk] : gk;
                     const float* src = Bp + (size_t)sk * g.ldb + gcol;
                     if (g.vecB && gcol + 3 < Nreal) v = *reinterpret_cast<const float4*>(src);
-                    else {   // columns >= Nreal are the virtual ones column (only reachable when N == Nreal + 1)
+                    else {
                         v.x = (gcol < Nreal) ? src[0] : 1.f;
                         if (gcol + 1 < N) v.y = (gcol + 1 < Nreal) ? src[1] : 1.f;
                         if (gcol + 2 < N) v.z = (gcol + 2 < Nreal) ? src[2] : 1.f;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     // offset + uniform k advance.  Valid when both operands are 16-byte aligned, the contiguous dimension of every
     // chunk is fully inside the matrix and the K tile is full.  Rows past M / N of a row-major operand are clamped
     // to the last valid row (their products only feed output rows/cols that are never stored).
-    bool fast = g.vecA && g.vecB && !(TA && g.a_rowmap) && !(TB && g.b_rowmap) && !(TA && TB && g.ones_col && col0 + BN > Nreal);
+    bool fast = g.vecA && g.vecB && !(TA && g.a_rowmap) && !(TB && g.b_rowmap);
     if (TA) fast = fast && (row0 + BM <= M);
     if (TB) fast = fast && (col0 + BN <= Nreal);
     unsigned oa[CA], ob[CB];
@@ -281,9 +281,19 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
             dst[0] = (T)v.x; dst[pitch] = (T)v.y; dst[2 * pitch] = (T)v.z; dst[3 * pitch] = (T)v.w;
         }
     };
+    // TN + bias gradient: bias_grad[m] = sum_k A[k][m] (the column sums of dY) is gathered from the A chunks on their way
+    // to LDS by the workgroups of the FIRST tile column -- no extra tile column, no extra pass over dY
+    const bool want_bsum = TA && TB && g.ones_col && P.bias_grad != nullptr && col0 == 0;
+    float4 bsum[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tile = [&](int buf, const float4 (&ra)[CA], const float4 (&rb)[CB]) {
         T* As = smem + buf * BUF;
         T* Bs = As + GA::elems;
+        if (TA && TB && want_bsum) {
+#pragma unroll
+            for (int i = 0; i < CA; ++i) { bsum[i].x += ra[i].x; bsum[i].y += ra[i].y; bsum[i].z += ra[i].z; bsum[i].w += ra[i].w; }
+        }
 #pragma unroll
         for (int i = 0; i < CA; ++i) put4(As, TA, GA::kmajor, GA::pitch, BM, ltid + i * NL, ra[i]);
         if (BBF && b_h) {          // bf16 chunks go to LDS as they are: one 16-byte write each
@@ -497,6 +507,53 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
         pipeline(kt0, kt1, load_slow);
     }
 
+    if (TA && TB && g.ones_col) {          // block-uniform branch (the barriers below are reached by every thread)
+        if (col0 == 0 && P.bias_grad) {
+            float* bs = reinterpret_cast<float*>(smem);     // staging tiles are dead after the last barrier
+            for (int i = tid; i < BM; i += NT) bs[i] = 0.f;
+            __syncthreads();
+            if (is_loader) {
+                constexpr int R = BM / 4;           // chunks (of 4 rows) per k-line of the A tile
+                if (NL % R == 0 && 64 % R == 0) {
+                    // every chunk of a thread covers the same 4 rows (rq = lane % R): sum them, fold the lanes that share
+                    // rq with shuffles, one LDS atomic per wave and row
+                    float4 t = bsum[0];
+#pragma unroll
+                    for (int i = 1; i < CA; ++i) { t.x += bsum[i].x; t.y += bsum[i].y; t.z += bsum[i].z; t.w += bsum[i].w; }
+#pragma unroll
+                    for (int o = 32; o >= R; o >>= 1) {
+                        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
+                        t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
+                    }
+                    if (lane < R) {
+                        atomicAdd(bs + lane * 4 + 0, t.x);
+                        atomicAdd(bs + lane * 4 + 1, t.y);
+                        atomicAdd(bs + lane * 4 + 2, t.z);
+                        atomicAdd(bs + lane * 4 + 3, t.w);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CA; ++i) {
+                        const int rq = (ltid + i * NL) % R;
+                        atomicAdd(bs + rq * 4 + 0, bsum[i].x);
+                        atomicAdd(bs + rq * 4 + 1, bsum[i].y);
+                        atomicAdd(bs + rq * 4 + 2, bsum[i].z);
+                        atomicAdd(bs + rq * 4 + 3, bsum[i].w);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < BM; i += NT) {
+                const int row = row0 + i;
+                if (row < M) {
+                    if (gridDim.y > 1) atomicAdd(P.bias_grad + row, g.alpha * bs[i]);
+                    else P.bias_grad[row] = g.alpha * bs[i];
+                }
+            }
+            __syncthreads();
+        }
+    }
+
     // epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* __restrict__ C = P.C + offC;
     const bool first = blockIdx.y == 0;
@@ -505,7 +562,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     // 16-byte chunks of C rows -- 16 lanes cover one 256-byte row segment instead of 64-byte slivers.
     constexpr int CP = BN + 4;
     constexpr bool kCtFits = (size_t)BM * CP * sizeof(float) <= (size_t)2 * BUF * sizeof(T);
-    if (kCtFits && g.vecC && splits == 1 && !(TA && TB && g.ones_col)) {
+    if (kCtFits && g.vecC && splits == 1) {
         float* Ct = reinterpret_cast<float*>(smem);
         if (is_compute) {
 #pragma unroll
@@ -558,13 +615,6 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
             for (int j = 0; j < TN; ++j) {
                 const int col = col0 + wn0 + j * 16 + fr;
                 if (col >= N) continue;
-                if (col >= Nreal) {   // virtual ones column: bias gradient
-                    if (P.bias_grad) {
-                        if (splits > 1) atomicAdd(P.bias_grad + row, g.alpha * acc[i][j][r]);
-                        else P.bias_grad[row] = g.alpha * acc[i][j][r];
-                    }
-                    continue;
-                }
                 float v = g.alpha * acc[i][j][r];
                 if (P.bias && first) v += P.bias[col];
                 if (!live) v = 0.f;
@@ -588,7 +638,7 @@ long g_last_grid_threads = 0;   // for the timing tap: lets bench.py match a lau
 
 template <bool BF16, int BM, int BN, int BK, int WM, int WN, bool SPEC = false, bool BBF = false>
 int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
-    const int Nlog = g.N + ((layout == GEMM_TN && g.ones_col) ? 1 : 0);
+    const int Nlog = g.N;
     dim3 grid(cdiv(Mmax, BM) * cdiv(Nlog, BN), splits, g.nprob * (g.nbatch > 1 ? g.nbatch : 1)), block((SPEC ? 2 : 1) * WM * WN * 64);
     if (grid.x == 0) return IMMTSF_OK;
     g_last_grid_threads = (long)grid.x * grid.y * grid.z * block.x;
@@ -606,7 +656,7 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 }
 
 // tuning override for tools/gemm_bench.py (0 = heuristic)
-int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 0;
+int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1;
 
 }  // namespace
 
@@ -614,7 +664,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_variant = variant & 0xff;
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
     g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
-    g_tn_spec = (variant & 0x2000) ? 1 : 0;  // bit 13 enables the specialised weight-gradient choice (A/B measurements)
+    g_tn_spec = (variant & 0x2000) ? 0 : 1;  // bit 13 disables the specialised weight-gradient choice (A/B measurements)
     g_splitk = splitk;
     return 0;
 }
@@ -739,13 +789,13 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
     const bool can_split = g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
-    // OFF by default (debug bit 13): weight-gradient GEMMs with 96..230 output tiles on the wave-specialised kernel,
-    // unsplit.  Isolated it wins (r01g tn_sweep: 15.4 vs 19.4 us at 768x1152x1117: its consumer waves never wait on
-    // global loads, no atomics, nothing to pre-zero); inside the step it loses (1.46 -> 1.60 ms): with the bias-gradient
-    // ones column the edge tile column runs the unoverlapped checked-loader path and becomes the kernel's tail.
+    // weight-gradient GEMMs with 96..230 output tiles (768x768 .. 768x1152 at the fusion dims): the wave-specialised
+    // kernel, unsplit -- its consumer waves never wait on global loads (the k-major fragment reads carry a conservative
+    // vmcnt(0)), no atomics, nothing to pre-zero.  r01g: 15.4 vs 19.4 us isolated at 768x1152x1117, step 1.46 -> 1.43 ms
+    // (it only pays since the bias gradient stopped being a virtual tile column, whose edge tiles ran the checked loader).
     bool tn_spec = false;
     if (layout == GEMM_TN && precision == 1 && g_variant == 0 && g_tn_spec && va && vb && !g.a_rowmap && !g.b_rowmap && g.nbatch <= 1) {
-        const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N + (g.ones_col ? 1 : 0), 64) * nbz;
+        const long tiles = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * nbz;
         tn_spec = tiles >= 96 && tiles <= 230 && g.K >= 256;
     }
     if (can_split && !tn_spec) {

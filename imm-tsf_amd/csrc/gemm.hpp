@@ -37,8 +37,8 @@ struct GemmArgs {
     // bi % batch_inner); each operand pointer advances by bo*s?_o + bin*s?_i elements.  nbatch <= 1: no batching.
     int nbatch, batch_inner;
     long sA_o, sA_i, sB_o, sB_i, sC_o, sC_i;
-    // TN only: when p[i].bias_grad != null the B operand gets a virtual all-ones column N, whose result
-    // (= column sums of A over the reduction index, i.e. the bias gradient) is written to bias_grad[m].
+    // TN only: when p[i].bias_grad != null the workgroups of the first tile column also reduce the A chunks they stage
+    // over the reduction index (= column sums of dY, the bias gradient, exact fp32) into bias_grad[m].
     int ones_col;
     // optional relu-backward mask: results whose relu_ref[m*ld_ref + n] <= 0 are zeroed (relu_ref = forward output)
     const float* relu_ref;

@@ -90,7 +90,23 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
         const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
         lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
     }
-    const int row0 = (lin / tiles_n) * BM, col0 = (lin % tiles_n) * BN;
+    int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
+    if (g.xcd_remap && g.xcd_remap != 8) {
+        // 2-D variant: the XCD's range of positions walks a RECTANGLE of tiles (xm x xn = 8 rectangles, enumerated one
+        // after the other), so an L2 holds tiles_m/xm row panels of A and tiles_n/xn panels of B instead of a sliver of A
+        // and ALL of B -- which is what overflows 4 MiB when the reduction is long (weight gradients: r01g PMC, 59 MB
+        // fetched for 12.6 MB of operands at 768x768x2048).  Still a bijection for any grid.
+        const int tiles_m = gridDim.x / tiles_n, xm = g.xcd_remap, xn = 8 / xm;
+        int p = lin;
+        for (int rct = 0; rct < 8; ++rct) {
+            const int mi = rct / xn, ni = rct - mi * xn;
+            const int m0 = tiles_m * mi / xm, m1 = tiles_m * (mi + 1) / xm, n0 = tiles_n * ni / xn, n1 = tiles_n * (ni + 1) / xn;
+            const int wn = n1 - n0, cnt = (m1 - m0) * wn;
+            if (p < cnt) { tile_m = m0 + p / wn; tile_n = n0 + p % wn; break; }
+            p -= cnt;
+        }
+    }
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
     if (row0 >= M) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -284,15 +300,21 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     // TN + bias gradient: bias_grad[m] = sum_k A[k][m] (the column sums of dY) is gathered from the A chunks on their way
     // to LDS by the workgroups of the FIRST tile column -- no extra tile column, no extra pass over dY
     const bool want_bsum = TA && TB && g.ones_col && P.bias_grad != nullptr && col0 == 0;
-    float4 bsum[CA];
+    constexpr int RCH = BM / 4;                                      // 4-row chunks per k-line of the A tile
+    constexpr bool BS1 = (NL % RCH == 0) && (64 % RCH == 0);        // all chunks of a thread cover the same 4 rows
+    constexpr int NBS = (TA && TB) ? (BS1 ? 1 : CA) : 1;
+    float4 bsum[NBS];
 #pragma unroll
-    for (int i = 0; i < CA; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < NBS; ++i) bsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tile = [&](int buf, const float4 (&ra)[CA], const float4 (&rb)[CB]) {
         T* As = smem + buf * BUF;
         T* Bs = As + GA::elems;
         if (TA && TB && want_bsum) {
 #pragma unroll
-            for (int i = 0; i < CA; ++i) { bsum[i].x += ra[i].x; bsum[i].y += ra[i].y; bsum[i].z += ra[i].z; bsum[i].w += ra[i].w; }
+            for (int i = 0; i < CA; ++i) {
+                float4& b = bsum[BS1 ? 0 : i];
+                b.x += ra[i].x; b.y += ra[i].y; b.z += ra[i].z; b.w += ra[i].w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < CA; ++i) put4(As, TA, GA::kmajor, GA::pitch, BM, ltid + i * NL, ra[i]);
@@ -513,13 +535,11 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
             for (int i = tid; i < BM; i += NT) bs[i] = 0.f;
             __syncthreads();
             if (is_loader) {
-                constexpr int R = BM / 4;           // chunks (of 4 rows) per k-line of the A tile
-                if (NL % R == 0 && 64 % R == 0) {
-                    // every chunk of a thread covers the same 4 rows (rq = lane % R): sum them, fold the lanes that share
-                    // rq with shuffles, one LDS atomic per wave and row
+                constexpr int R = RCH;
+                if (BS1) {
+                    // every chunk of a thread covers the same 4 rows (rq = lane % R): fold the lanes that share rq with
+                    // shuffles, one LDS atomic per wave and row
                     float4 t = bsum[0];
-#pragma unroll
-                    for (int i = 1; i < CA; ++i) { t.x += bsum[i].x; t.y += bsum[i].y; t.z += bsum[i].z; t.w += bsum[i].w; }
 #pragma unroll
                     for (int o = 32; o >= R; o >>= 1) {
                         t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
@@ -533,7 +553,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < CA; ++i) {
+                    for (int i = 0; i < NBS; ++i) {
                         const int rq = (ltid + i * NL) % R;
                         atomicAdd(bs + rq * 4 + 0, bsum[i].x);
                         atomicAdd(bs + rq * 4 + 1, bsum[i].y);
@@ -656,7 +676,7 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 }
 
 // tuning override for tools/gemm_bench.py (0 = heuristic)
-int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1;
+int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 0;
 
 }  // namespace
 
@@ -665,6 +685,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
     g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
     g_tn_spec = (variant & 0x2000) ? 0 : 1;  // bit 13 disables the specialised weight-gradient choice (A/B measurements)
+    g_xcd2d = (variant & 0x4000) ? 1 : 0;    // bit 14: allow the 2-D XCD order (measured slower at the fusion shapes: off)
     g_splitk = splitk;
     return 0;
 }
@@ -778,7 +799,18 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     {   // XCD-aware order pays when several L2s would otherwise stream the same mid-sized operands; it hurts once
         // the grid is large enough that the default order already keeps every XCD on its own tile rows
         const long gx = (long)cdiv(g.M, 64) * cdiv(g.N, 64);
-        g.xcd_remap = (g_xcd && gx >= 64 && gx < 2048 && g.N >= 256) ? 1 : 0;
+        g.xcd_remap = 0;
+        if (g_xcd && gx >= 64 && gx < 2048 && g.N >= 256) {
+            // 8 = contiguous tile rows per XCD; 4 / 2 / 1 = xm of the 2-D variant: least (A panels + B panels) per L2
+            const int tm = cdiv(g.M, 64), tn = cdiv(g.N, 64);
+            int best = 8;
+            float cost = (float)tm / 8.f + (float)tn;
+            for (int xm = 4; xm >= 1; xm >>= 1) {
+                const float c = (float)tm / (float)xm + (float)tn / (float)(8 / xm);
+                if (c < cost * 0.85f) { cost = c; best = xm; }
+            }
+            g.xcd_remap = (g_xcd2d || best == 8) ? best : 8;
+        }
     }
     if (g.row_flag && g.row_flag_div <= 0) return IMMTSF_EINVAL;
     if (g.nbatch > 1 && g.batch_inner <= 0) return IMMTSF_EINVAL;

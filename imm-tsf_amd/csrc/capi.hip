@@ -37,7 +37,8 @@ int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, 
 }
 
 int immtsf_linear_backward(int32_t precision, const float* x, const float* W, const float* dy, int32_t M, int32_t N,
-                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, immtsf_stream_t stream) {
+                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, int32_t grads_prezeroed,
+                           immtsf_stream_t stream) {
     if (!dy || M <= 0 || N <= 0 || K <= 0 || (db && !dW) || (dx && !W) || (dW && !x)) return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dx) {                   // dx (M,K) = dy (M,N) @ W (N,K)
@@ -50,6 +51,7 @@ int immtsf_linear_backward(int32_t precision, const float* x, const float* W, co
     if (dW) {                   // dW (N,K) = dy^T (N,M) @ x (M,K); db = dy^T 1
         GemmArgs g = gemm_args(N, K, M, N, K, K);
         set_problem(g, 0, dy, x, dW, nullptr, db);
+        g.c_prezeroed = grads_prezeroed ? 1 : 0;
         if (int rc = immtsf_launch_gemm(GEMM_TN, precision, g, s)) return rc;
     }
     return IMMTSF_OK;
@@ -119,6 +121,10 @@ int immtsf_layernorm_backward(float* dz_dy, int32_t rows, int32_t d, const float
     if (!dz_dy || !gamma || !xhat || !rstd || !dx || d <= 0) return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     CHECK(launch_layernorm_bwd(dz_dy, rows, d, gamma, xhat, rstd, dx, mk_drop(p_drop, seed), site, s));
+    if (dgamma && dbeta) {
+        if (!scratch) return IMMTSF_EINVAL;
+        return launch_colsum2(dz_dy, xhat, rows, d, d, dgamma, dbeta, scratch, s);
+    }
     if (dgamma) {
         if (!scratch) return IMMTSF_EINVAL;
         CHECK(launch_colsum(dz_dy, xhat, rows, nullptr, d, d, dgamma, 0, scratch, s));

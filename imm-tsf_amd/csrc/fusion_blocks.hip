@@ -187,8 +187,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
-    CHECK(launch_colsum(sc.dz, w.xhat, BT, nullptr, d, d, gr->ln_w, 0, sc.red, s));
-    CHECK(launch_colsum(sc.dz, nullptr, BT, nullptr, d, d, gr->ln_b, 0, sc.red, s));
+    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s));
     // residual: dQ_param = sum over all (b,t) rows; then only windows with notes feed the attention branch
     CHECK(launch_colsum(sc.dx, nullptr, BT, nullptr, d, d, gr->Q_param, 0, sc.red, s));
     CHECK(launch_mask_rows(sc.dx, BT, d, w.mtxt, T, s));

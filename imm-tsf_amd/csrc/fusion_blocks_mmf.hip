@@ -227,8 +227,7 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
-    CHECK(launch_colsum(sc.dn, w.xhatC, BT, nullptr, C, C, gr->ln_w, 0, sc.red, s));
-    CHECK(launch_colsum(sc.dn, nullptr, BT, nullptr, C, C, gr->ln_b, 0, sc.red, s));
+    CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
     {   // residual_head
         GemmArgs g = gemm_args(BT, d, C, C, d, d);
         set_problem(g, 0, sc.ddelta, p->res_w, sc.dU, nullptr);

@@ -161,8 +161,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
-    CHECK(launch_colsum(sc.dz, w.xhat, BT, nullptr, d, d, gr->ln_w, 0, sc.red, s));
-    CHECK(launch_colsum(sc.dz, nullptr, BT, nullptr, d, d, gr->ln_b, 0, sc.red, s));
+    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s));
     CHECK(launch_recavg_bwd(B, T, d, w.offsets, w.rowmap, tau, t_hat, p->log_recency_sigma, w.Vp, w.Eraw, w.denom, sc.dEraw,
                             sc.dVp, sc.dls_part, s));
     CHECK(launch_colsum(sc.dls_part, nullptr, B, nullptr, 1, 1, gr->log_recency_sigma, 0, sc.red, s));
@@ -224,8 +223,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     Fork fk(s);
     CHECK(launch_gr_tail_bwd(BT, T, C, Hd, dY_out, p->res_w, p->ln_w, w.xhat, w.rstd, w.g, w.dd, M_txt, sc.dn, sc.ddelta,
                              sc.dgl, sc.dh_in, drop, SITE_GR_OUT, s));
-    CHECK(launch_colsum(sc.dn, w.xhat, BT, nullptr, C, C, gr->ln_w, 0, sc.red, s));
-    CHECK(launch_colsum(sc.dn, nullptr, BT, nullptr, C, C, gr->ln_b, 0, sc.red, s));
+    CHECK(launch_colsum2(sc.dn, w.xhat, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
     {   // residual_head: dW_r = ddelta^T h ; db_r
         GemmArgs h = gemm_args(C, Hd, BT, C, Hd, Hd);
         set_problem(h, 0, sc.ddelta, w.h, gr->res_w, nullptr, gr->res_b);

@@ -191,6 +191,43 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (ty == 0 && n < N) partial[(size_t)slab * N + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
+// both LayerNorm parameter gradients in one pass: partial[slab][0][n] = sum_r X*Y, partial[slab][1][n] = sum_r X
+__global__ __launch_bounds__(256) void colsum2_partial_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M,
+                                                               int N, int ld, float* __restrict__ partial) {
+    __shared__ float red[2][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, slab = blockIdx.y;
+    const int rps = (M + kSlabs - 1) / kSlabs;
+    const int r0 = slab * rps, r1 = min(M, r0 + rps);
+    float a = 0.f, b = 0.f;
+    if (n < N)
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const float x = X[(size_t)r * ld + n];
+            a = fmaf(x, Y[(size_t)r * ld + n], a);
+            b += x;
+        }
+    red[0][ty][tx] = a;
+    red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        partial[((size_t)slab * 2 + 0) * N + n] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        partial[((size_t)slab * 2 + 1) * N + n] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
+                                                             float* __restrict__ out_x) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < kSlabs; ++s) {
+        a += partial[((size_t)s * 2 + 0) * N + n];
+        b += partial[((size_t)s * 2 + 1) * N + n];
+    }
+    out_xy[n] = a;
+    out_x[n] = b;
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out,
                                                             int accumulate) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -263,19 +300,22 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
 }
 
 // y[j] = sum_i W[i,j] x[i]: 64 columns x 16 row lanes per workgroup, rows strided (coalesced over j)
+// gridDim.y row slabs; with more than one slab the result is ADDED to y with atomics (y must hold the running value)
 __global__ __launch_bounds__(1024) void matvec_t_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
                                                          int rows, int cols, float* __restrict__ y, int accumulate) {
     __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, j = blockIdx.x * 64 + tx;
+    const int rps = (rows + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * rps, r1 = min(rows, r0 + rps);
     float a = 0.f;
     if (j < cols)
-        for (int i = ty; i < rows; i += 16) a = fmaf(W[(size_t)i * ldw + j], x[i], a);
+        for (int i = r0 + ty; i < r1; i += 16) a = fmaf(W[(size_t)i * ldw + j], x[i], a);
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && j < cols) {
         float t = 0.f;
         for (int k = 0; k < 16; ++k) t += red[k][tx];
-        y[j] = accumulate ? y[j] + t : t;
+        if (gridDim.y > 1) atomicAdd(y + j, t);
+        else y[j] = accumulate ? y[j] + t : t;
     }
 }
 
@@ -371,6 +411,16 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
     return IMMTSF_OK;
 }
 
+int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
+                   hipStream_t s) {
+    if (N <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(colsum2_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, N, ld, scratch);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum2_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out_xy, out_x);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s) {
     if (rows <= 0) return IMMTSF_OK;
@@ -398,7 +448,10 @@ int launch_matvec(const float* W, int ldw, const float* x, const float* b, int r
 
 int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols, float* y, int accumulate,
                     hipStream_t s) {
-    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdiv(cols, 64)), dim3(1024), 0, s, W, ldw, x, rows, cols, y, accumulate);
+    // 12 workgroups cannot stream a 768x768 matrix quickly: when the result accumulates anyway, spread the rows over
+    // slabs and add with atomics
+    const int slabs = (accumulate && rows >= 256) ? 16 : 1;
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdiv(cols, 64), slabs), dim3(1024), 0, s, W, ldw, x, rows, cols, y, accumulate);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

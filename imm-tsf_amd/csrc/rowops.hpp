@@ -25,6 +25,9 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
 // out[n] = sum_{m < M} X[m,n] * (Y ? Y[m,n] : 1)   (M may come from *dyn).  scratch >= 32*N floats.
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
                   float* scratch, hipStream_t s);
+// out_xy[n] = sum_m X*Y, out_x[n] = sum_m X in one pass (LayerNorm's gamma / beta gradients).  scratch >= 64*N floats.
+int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
+                   hipStream_t s);
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s);

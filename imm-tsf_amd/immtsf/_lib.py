@@ -130,7 +130,7 @@ _PROTOS = {
     "immtsf_gemm": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p,
                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_stream]),
     "immtsf_linear_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
-                                         c_f32p, c_f32p, c_f32p, c_stream]),
+                                         c_f32p, c_f32p, c_f32p, C.c_int32, c_stream]),
     "immtsf_time2vec_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_time2vec_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                            c_f32p, c_f32p, c_stream]),

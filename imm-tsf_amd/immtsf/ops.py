@@ -499,10 +499,13 @@ class LinearFn(torch.autograd.Function):
             dy2 = torch.ops.aten.threshold_backward(dy2, y.reshape(M, N), 0.0)
         need_w = ctx.needs_input_grad[1]
         dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
-        dW = torch.empty(N, K, dtype=torch.float32, device=dy.device) if need_w else None
-        db = torch.empty(N, dtype=torch.float32, device=dy.device) if (need_w and ctx.has_bias) else None
+        dW = db = None
+        if need_w:              # ONE zero fill for dW|db: the split-K weight gradient then needs no memsets of its own
+            flat = torch.zeros(N * K + (N if ctx.has_bias else 0), dtype=torch.float32, device=dy.device)
+            dW = flat[:N * K].view(N, K)
+            db = flat[N * K:] if ctx.has_bias else None
         check(lib.immtsf_linear_backward(ctx.precision, ptr(x2), ptr(W), ptr(dy2), M, N, K, ptr(dx), None, ptr(dW), ptr(db),
-                                         stream_ptr()), "linear_backward")
+                                         1, stream_ptr()), "linear_backward")
         return (dx.view(ctx.shape) if dx is not None else None), dW, db, None, None
 
 
@@ -541,19 +544,26 @@ class MLPFn(torch.autograd.Function):
         dWs, dbs = [None] * nl, [None] * nl
         g = dy.contiguous().reshape(-1, Ws[-1].shape[0])
         dev = dy.device
+        # ONE zero-filled buffer for every layer's dW|db (32-byte aligned slices): no per-GEMM memsets
+        sizes = [((W.numel() + 7) // 8 * 8, (W.shape[0] + 7) // 8 * 8) if ctx.needs_input_grad[3 + i] else (0, 0)
+                 for i, W in enumerate(Ws)]
+        flat = torch.zeros(max(1, sum(a + b for a, b in sizes)), dtype=torch.float32, device=dev)
+        off = 0
+        for i, W in enumerate(Ws):
+            if ctx.needs_input_grad[3 + i]:
+                dWs[i] = flat[off:off + W.numel()].view(W.shape)
+                off += sizes[i][0]
+                if ctx.has_bias[i]:
+                    dbs[i] = flat[off:off + W.shape[0]]
+                off += sizes[i][1]
         for i in reversed(range(nl)):
             x, W = acts[i], Ws[i]
             M, K = x.shape
             N = W.shape[0]
             need_x = i > 0 or ctx.needs_input_grad[0]
-            need_w = ctx.needs_input_grad[3 + i]
             dx = torch.empty(M, K, dtype=torch.float32, device=dev) if need_x else None
-            if need_w:
-                dWs[i] = torch.empty(N, K, dtype=torch.float32, device=dev)
-                if ctx.has_bias[i]:
-                    dbs[i] = torch.empty(N, dtype=torch.float32, device=dev)
             check(lib.immtsf_linear_backward(ctx.precision, ptr(x), ptr(W), ptr(g), M, N, K, ptr(dx),
-                                             ptr(x) if i > 0 else None, ptr(dWs[i]), ptr(dbs[i]), stream_ptr()),
+                                             ptr(x) if i > 0 else None, ptr(dWs[i]), ptr(dbs[i]), 1, stream_ptr()),
                   "linear_backward")
             g = dx
         return (g.view(ctx.shape) if g is not None else None), None, None, *dWs, *dbs
@@ -626,7 +636,7 @@ class LayerNormFn(torch.autograd.Function):
         g = dz.contiguous().reshape(rows, d).clone()
         dx = torch.empty_like(xhat)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        scratch = torch.empty(32 * d, dtype=torch.float32, device=dz.device)
+        scratch = torch.empty(64 * d, dtype=torch.float32, device=dz.device)
         check(lib.immtsf_layernorm_backward(ptr(g), rows, d, ptr(gamma), ptr(xhat), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
                                             ptr(scratch), 0.0, 0, 0, stream_ptr()), "layernorm_backward")
         return dx.view(ctx.shape), dgamma, dbeta, None

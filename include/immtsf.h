@@ -279,9 +279,11 @@ int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, 
                 int32_t act, immtsf_stream_t stream);
 /* nn.Linear autograd in one call (x:(M,K), W:(N,K), dy:(M,N)): dx = dy W, optionally masked with relu_x (dx[m,k] = 0
  * where relu_x[m,k] <= 0: x was a ReLU output, so dx is the gradient of the PRE-activation); dW = dy^T x; db = column
- * sums of dy (folded into the dW GEMM as a virtual ones column).  Any of dx / dW+db may be NULL; db needs dW. */
+ * sums of dy (reduced inside the dW GEMM).  Any of dx / dW+db may be NULL; db needs dW.  grads_prezeroed: dW and db
+ * already hold zeros (one caller-side fill for many layers), so a split-K weight gradient skips its own memsets. */
 int immtsf_linear_backward(int32_t precision, const float* x, const float* W, const float* dy, int32_t M, int32_t N,
-                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, immtsf_stream_t stream);
+                           int32_t K, float* dx, const float* relu_x, float* dW, float* db, int32_t grads_prezeroed,
+                           immtsf_stream_t stream);
 /* Time2Vec / tPatchGNN LearnableTE rows (fusions/TTF_T2V_XAttn.py:7-24, models/tPatchGNN.py:176-180):
  * out[r,0] = w0*t[r]+b0, out[r,j] = sin(w[j-1]*t[r]+b[j-1]).  backward: parameter gradients from dout (t is data);
  * scratch >= 2*64*d floats. */
@@ -315,6 +317,7 @@ int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H
 int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
                              float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,
                              immtsf_stream_t stream);
+/* backward: dz_dy is overwritten with dy; scratch >= 64*d floats (both parameter gradients come from one pass) */
 int immtsf_layernorm_backward(float* dz_dy, int32_t rows, int32_t d, const float* gamma, const float* xhat,
                               const float* rstd, float* dx, float* dgamma, float* dbeta, float* scratch,
                               float p_drop, uint64_t seed, uint64_t site, immtsf_stream_t stream);

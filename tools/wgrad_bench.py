@@ -12,7 +12,7 @@ for rows, N, K, bias in [(2048, 768, 768, True), (2048, 768, 768, False), (1117,
     x, dy = torch.randn(rows, K, device=dev), torch.randn(rows, N, device=dev)
     dW, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
     def run():
-        lib.immtsf_linear_backward(1, _lib.ptr(x), None, _lib.ptr(dy), rows, N, K, None, None, _lib.ptr(dW), _lib.ptr(db) if bias else None, _lib.stream_ptr())
+        lib.immtsf_linear_backward(1, _lib.ptr(x), None, _lib.ptr(dy), rows, N, K, None, None, _lib.ptr(dW), _lib.ptr(db) if bias else None, 0, _lib.stream_ptr())
     for _ in range(3): run()
     s = torch.cuda.Stream()
     with torch.cuda.stream(s): run()

@@ -64,3 +64,8 @@ class FusionModel(nn.Module):
         """deferred-mode check of the note-embedding NaN flag set by the kernels."""
         if hasattr(self.ttf, "check_nan"):
             self.ttf.check_nan()
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -42,3 +42,8 @@ class MMF_GR_Add(nn.Module):
         self.last_seed = config.next_seed() if training else 0
         return MMFGRAddFn.apply(f32(Y_ts), f32(E_txt), M_u8, self.hidden_dim, self.p_drop, training,
                                 resolve_precision(self), self.last_seed, *self._params())
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

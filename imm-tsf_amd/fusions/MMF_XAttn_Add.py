@@ -59,3 +59,8 @@ class MMF_XAttn_Add(nn.Module):
         p = self._params()
         return MMFXAttnQFn.apply(f32(Y_ts), Ki, Vi, M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
                                  resolve_precision(self), self.last_seed, p[0], *p[3:])
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

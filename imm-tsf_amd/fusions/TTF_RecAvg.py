@@ -63,3 +63,8 @@ class TTF_RecAvg(nn.Module):
 
     def check_nan(self):
         self._nan.raise_if_set("Input embeddings V contain NaN values.")
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

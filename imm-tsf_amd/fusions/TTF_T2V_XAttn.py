@@ -96,3 +96,8 @@ class TTF_T2V_XAttn(nn.Module):
     def check_nan(self):
         """deferred-mode companion: raises if any forward since the last check saw NaN note embeddings."""
         self._nan.raise_if_set("Input embeddings V contain NaN values.")
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

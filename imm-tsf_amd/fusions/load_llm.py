@@ -27,6 +27,21 @@ def get_d_model(llm_model_fusion: str) -> int:
             f"unknown LLM alias {llm_model_fusion!r}: add it with fusions.load_llm.register_d_model(name, d_model)") from None
 
 
+_CONTEXT = {"GPT2": 1024, "GPT2M": 1024, "GPT2L": 1024, "GPT2XL": 1024, "BERT": 512, "Llama": 131072, "DeepSeek": 4096,
+            "openai-community/gpt2": 1024, "openai-community/gpt2-medium": 1024, "openai-community/gpt2-large": 1024,
+            "openai-community/gpt2-xl": 1024, "google-bert/bert-base-uncased": 512, "meta-llama/Llama-3.1-8B": 131072,
+            "deepseek-ai/deepseek-llm-7b-base": 4096}
+
+
+def get_context_window_size(llm_model_fusion: str, device="cpu") -> int:
+    """positional context window of the LLM (reference :38-76 loads the model to read it; a table here, same values
+    as the alias comments at :5-13)"""
+    try:
+        return _CONTEXT[llm_model_fusion]
+    except KeyError:
+        raise KeyError(f"unknown LLM alias {llm_model_fusion!r}") from None
+
+
 def load_llm(*_a, **_k):
     raise NotImplementedError("raw-text fusion (use_text_embeddings=False) is not part of the MI355X hot path; "
                               "precompute note embeddings and pass use_text_embeddings=True")
@@ -34,3 +49,8 @@ def load_llm(*_a, **_k):
 
 def embed_notes(*_a, **_k):
     raise NotImplementedError("raw-text fusion (use_text_embeddings=False) is not part of the MI355X hot path")
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

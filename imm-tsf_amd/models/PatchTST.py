@@ -58,3 +58,8 @@ class PatchTST(nn.Module):
         dec = self.head(enc, tp_to_predict).permute(0, 2, 1)        # (B, pred_len, K)
         dec = dec * stdev[:, 0, :].unsqueeze(1) + means[:, 0, :].unsqueeze(1)
         return dec[:, -self.pred_len:, :][:, :Lp, :]
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -182,3 +182,8 @@ class TimeLLM(nn.Module):
         if self.use_norm:
             out = out * stdev + means
         return out[:, :Lp, :]
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

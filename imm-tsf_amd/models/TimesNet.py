@@ -73,3 +73,8 @@ class TimesNet(nn.Module):
         dec = linear(enc, self.projection.weight, self.projection.bias)
         dec = dec * stdev[:, 0, :].unsqueeze(1) + means[:, 0, :].unsqueeze(1)
         return dec[:, -self.pred_len:, :][:, :Lp, :]
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

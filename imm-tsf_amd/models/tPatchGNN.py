@@ -239,3 +239,8 @@ class tPatchGNN(nn.Module):
         te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1)).expand(B, N, Lp, self.te_dim)
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
         return self._mlp(self.decoder, h).squeeze(-1).permute(0, 2, 1)
+
+
+from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402
+
+_reexport_missing(globals())     # names of the reference module this build does not mirror

@@ -162,3 +162,41 @@ def test_training_with_twins_matches_without():
     config.precision = "fp32"
     assert res[0][0][-1] < res[0][0][0]
     assert max(abs(a - b) for a, b in zip(res[0][0], res[1][0])) < 2e-4 * abs(res[0][0][0])
+
+
+def test_evaluation_metrics_match_reference_formula():
+    """lib.evaluation.evaluation (device-side accumulation, one host transfer) against the reference's definition
+    (lib/evaluation.py:192-283) evaluated with plain torch over the same predictions"""
+    dev = _dev()
+    import bench
+    from lib.evaluation import evaluation
+    model, fusion, tr, _ = _setup(dev, 0.0)
+    tr.close()
+    model.eval()
+    fusion.eval()
+    batches = []
+    for seed in (11, 12, 13):
+        cpu_batch, _ = bench.synth_batch(seed, 8)
+        b = {k: v.to(dev) for k, v in cpu_batch.items()}
+        b["notes_embeddings"] = b["notes_embeddings"][..., :48].contiguous()
+        batches.append(b)
+    got = evaluation(model, fusion, batches)
+    se = ae = ape = cnt = cnt_ape = 0
+    with torch.no_grad():
+        for b in batches:
+            pred = fusion(b["notes_embeddings"], b["tau"], b["tp_to_predict"],
+                          model.forecasting(b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"]))
+            t, m = b["data_to_predict"], b["mask_predicted_data"]
+            C = t.shape[-1]
+            se = se + (((t - pred) ** 2) * m).reshape(-1, C).sum(0)
+            ae = ae + ((t - pred).abs() * m).reshape(-1, C).sum(0)
+            m2 = (t != 0) * m
+            ape = ape + ((t - pred).abs() / (t + (t == 0) * 1e-8) * m2).reshape(-1, C).sum(0)
+            cnt = cnt + m.reshape(-1, C).sum(0)
+            cnt_ape = cnt_ape + m2.reshape(-1, C).sum(0)
+    mse = float(((se / (cnt + 1e-8)).sum() / torch.count_nonzero(cnt)))
+    mae = float(((ae / (cnt + 1e-8)).sum() / torch.count_nonzero(cnt)))
+    mape = float(((ape / (cnt_ape + 1e-8)).sum() / torch.count_nonzero(cnt_ape)))
+    assert set(got) == {"loss", "mse", "mae", "rmse", "mape"} and all(isinstance(v, float) for v in got.values())
+    for k, v in (("loss", mse), ("mse", mse), ("mae", mae), ("rmse", mse ** 0.5), ("mape", mape)):
+        assert abs(got[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, got[k], v)

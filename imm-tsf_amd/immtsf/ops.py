@@ -698,6 +698,66 @@ class FullAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None, None
 
 
+class FullAttentionQKVFn(torch.autograd.Function):
+    """self-attention on a PACKED in-projection output qkv (B, L, 3, H, E) (what `x @ in_proj_weight^T` yields): the
+    batched GEMMs read q / k / v through strides and the backward writes dq / dk / dv straight into one (B,L,3,H,E)
+    tensor -- no slice copies forward, no zero-fill + copy + add per slice backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, p_drop, training, seed, site, causal, precision):
+        lib = _lib.load()
+        qkv = _c(qkv)
+        _need_gpu(qkv)
+        B, L, three, H, E = qkv.shape
+        assert three == 3
+        dev = qkv.device
+        ld, so = 3 * H * E, L * 3 * H * E
+        q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * H * E, qkv.data_ptr() + 8 * H * E
+        P = torch.empty(B, H, L, L, dtype=torch.float32, device=dev)
+        check(lib.immtsf_gemm_batched(0, precision, C.c_void_p(q), ld, so, E, C.c_void_p(k), ld, so, E, ptr(P), L, H * L * L, L * L,
+                                      B, H, L, L, E, float(scale), stream_ptr()), "qk^T")
+        p = float(p_drop) if training else 0.0
+        A = torch.empty_like(P) if p > 0 else P
+        cnt = config.dropout_counter_ptr(dev) if p > 0 else None
+        check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), B, H, L, L, None, p, seed, site, 1 if causal else 0, cnt,
+                                              stream_ptr()), "softmax")
+        out = torch.empty(B, L, H, E, dtype=torch.float32, device=dev)
+        check(lib.immtsf_gemm_batched(1, precision, ptr(A), L, H * L * L, L * L, C.c_void_p(v), ld, so, E, ptr(out), H * E,
+                                      L * H * E, E, B, H, L, E, L, 1.0, stream_ptr()), "a.v")
+        ctx.save_for_backward(qkv, P, A)
+        ctx.cfg = (scale, p, seed, site, precision, cnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        qkv, P, A = ctx.saved_tensors
+        scale, p, seed, site, precision, cnt = ctx.cfg
+        B, L, _, H, E = qkv.shape
+        ld, so = 3 * H * E, L * 3 * H * E
+        q, k, v = qkv.data_ptr(), qkv.data_ptr() + 4 * H * E, qkv.data_ptr() + 8 * H * E
+        dout = dout.contiguous()
+        dA = torch.empty_like(P)
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + 4 * H * E, dqkv.data_ptr() + 8 * H * E
+        st = stream_ptr()
+        check(lib.immtsf_gemm_batched(0, precision, ptr(dout), H * E, L * H * E, E, C.c_void_p(v), ld, so, E, ptr(dA), L,
+                                      H * L * L, L * L, B, H, L, L, E, 1.0, st), "dA")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(A), L, H * L * L, L * L, ptr(dout), H * E, L * H * E, E, C.c_void_p(dv), ld,
+                                      so, E, B, H, L, E, L, 1.0, st), "dV")
+        check(lib.immtsf_softmax_rows_backward(ptr(dA), ptr(P), B, H, L, L, p, seed, site, cnt, st), "softmax_bwd")
+        check(lib.immtsf_gemm_batched(1, precision, ptr(dA), L, H * L * L, L * L, C.c_void_p(k), ld, so, E, C.c_void_p(dq), ld, so, E,
+                                      B, H, L, E, L, float(scale), st), "dQ")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(dA), L, H * L * L, L * L, C.c_void_p(q), ld, so, E, C.c_void_p(dk), ld, so, E,
+                                      B, H, L, E, L, float(scale), st), "dK")
+        return dqkv, None, None, None, None, None, None, None
+
+
+def full_attention_qkv(qkv, scale, p_drop=0.0, training=False, seed=0, site=16, causal=False, precision=None):
+    """qkv (B, L, 3, H, E) -> (B, L, H, E)"""
+    return FullAttentionQKVFn.apply(qkv.float(), scale, p_drop, training, seed, site, causal, config.precision_code(precision))
+
+
 def full_attention(q, k, v, scale, p_drop=0.0, training=False, seed=0, site=16, causal=False, precision=None):
     return FullAttentionFn.apply(q.float(), k.float(), v.float(), scale, p_drop, training, seed, site, causal,
                                  config.precision_code(precision))

@@ -155,15 +155,15 @@ class tPatchGNN(nn.Module):
         """one post-norm nn.TransformerEncoderLayer (relu FFN, batch_first) evaluated from ITS parameters on the HIP
         GEMM / LayerNorm / attention kernels: at d_model=32 with dim_feedforward=2048 the stock path spends its time
         in badly-shaped library GEMMs.  Dropout uses torch's generator exactly like the stock layer."""
-        from immtsf.ops import full_attention, layer_norm, linear
+        from immtsf.ops import full_attention_qkv, layer_norm, linear
         Bs, S, D = x.shape
         at = lyr.self_attn
         H = at.num_heads
         qkv = linear(x, at.in_proj_weight, at.in_proj_bias).view(Bs, S, 3, H, D // H)
         p_att = at.dropout if self.training else 0.0
         from immtsf import config
-        a = full_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 1.0 / math.sqrt(D // H), p_att, self.training,
-                           config.next_seed() if p_att > 0 else 0, 900)
+        a = full_attention_qkv(qkv, 1.0 / math.sqrt(D // H), p_att, self.training,
+                               config.next_seed() if p_att > 0 else 0, 900)
         sa = linear(a.reshape(Bs, S, D), at.out_proj.weight, at.out_proj.bias)
         x = layer_norm(x + lyr.dropout1(sa), lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps)
         ff = linear(lyr.dropout(linear(x, lyr.linear1.weight, lyr.linear1.bias, relu=True)), lyr.linear2.weight, lyr.linear2.bias)

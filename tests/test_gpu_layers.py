@@ -193,3 +193,20 @@ def test_time2vec_vs_torch():
             assert _rel(a, b.cpu()) < 2e-4
     with pytest.raises(RuntimeError):
         ops.time2vec(t.requires_grad_(True), lin0.weight, lin0.bias, None, None)
+
+
+def test_packed_qkv_attention_equals_sliced():
+    """full_attention_qkv (strided reads of a packed in-projection, packed gradient) == full_attention on the slices"""
+    dev = _dev()
+    from immtsf import config, ops
+    config.precision = "fp32"
+    torch.manual_seed(4)
+    for B, L, H, E in [(512, 2, 1, 32), (5, 19, 3, 8)]:
+        qkv = torch.randn(B, L, 3, H, E, device=dev)
+        a, b = qkv.clone().requires_grad_(True), qkv.clone().requires_grad_(True)
+        up = torch.randn(B, L, H, E, device=dev)
+        o1 = ops.full_attention(a[:, :, 0], a[:, :, 1], a[:, :, 2], E ** -0.5)
+        o2 = ops.full_attention_qkv(b, E ** -0.5)
+        (o1 * up).sum().backward()
+        (o2 * up).sum().backward()
+        assert _rel(o2, o1.detach().cpu()) < 1e-6 and _rel(b.grad, a.grad.cpu()) < 1e-6

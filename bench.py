@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
                     help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 no specialised wgrad kernel)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     args = ap.parse_args()
 
@@ -163,9 +165,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
@@ -194,7 +198,7 @@ def main():
     # per-variable observation counts of the GLOBAL batch: a property of the data (mask), reduced once when the batch
     # is built, so the step itself has no collective besides the gradient all-reduce
     global_cnt = batch["mask_predicted_data"].reshape(-1, C).sum(0)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.all_reduce(global_cnt)
 
@@ -218,7 +222,7 @@ def main():
     step = GraphedStep(trainer, loss_fn) if use_graph else eager_step
 
     def barrier():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -231,7 +235,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -367,10 +371,16 @@ def main():
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * B_PER_GPU * world / (ms_per_step * 1e-3) / 1e12, 2),
                        "grad_bytes": trainer.grad_bytes()},
             "roofline": roofline, "cpu_baseline": cpu}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()      # RCCL may log on teardown: keep the JSON line the last thing rank 0 prints
+    if rank == 0:
+        sys.stderr.flush()
+        print(json.dumps(line), flush=True)
+    # native libraries (RCCL prints its path on unload) must not write to stdout behind the JSON line
+    sys.stdout.flush()
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 
 if __name__ == "__main__":

@@ -94,7 +94,8 @@ class FlatTrainer:
         if group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(group)
-        self.overlap = overlap and self.world > 1 and dev.type == "cuda"
+        self.collective = group is not None          # a 1-rank group still runs the (trivial) collectives: lets one GPU
+        self.overlap = overlap and self.collective and dev.type == "cuda"      # exercise the multi-GPU code path
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._pending: List = []
         self._reduced = [False] * len(self.buckets)
@@ -169,7 +170,7 @@ class FlatTrainer:
         self._collect_autograd_grads()
 
     def _bucket_ready(self, bi: int):
-        if self.world == 1 or self._reduced[bi]:
+        if not self.collective or self._reduced[bi]:
             return
         import torch.distributed as dist
         if bi not in self.sink_buckets:
@@ -191,7 +192,7 @@ class FlatTrainer:
         normalised over the GLOBAL batch (immtsf.ops.masked_mse with `group`), so the sum of the ranks' gradients
         is exactly the single-process full-batch gradient."""
         self._collect_autograd_grads()
-        if self.world > 1:
+        if self.collective:
             if not self.overlap and not any(self._reduced):
                 import torch.distributed as dist
                 dist.all_reduce(self.flat_grad, group=self.group)      # one collective for the whole flat buffer

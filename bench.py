@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
                     help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 no specialised wgrad kernel)")
+    ap.add_argument("--captured-comm", action="store_true",
+                    help="N>1 graph mode: capture the bucketed RCCL all-reduces inside graph A (overlapped with the backward). "
+                         "Verified here only on a 1-rank group, so the default is one eager all-reduce between the two graphs")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
@@ -192,7 +195,8 @@ def main():
     use_graph = not args.no_graph
     trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
                           lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1),
-                          overlap=not use_graph, device_step=use_graph)
+                          overlap=True, device_step=use_graph)
+    comm_mode = "bucketed on a side stream" if dist_on else "none"
     cpu_batch, sum_n = synth_batch(100 + rank, B_PER_GPU)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
     # per-variable observation counts of the GLOBAL batch: a property of the data (mask), reduced once when the batch
@@ -219,7 +223,23 @@ def main():
 
     # hipGraph replay (immtsf.train.GraphedStep): graph A = zero-grad, backbone + fusion forward, loss, backward, gradient
     # collection; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam + device-side counters
-    step = GraphedStep(trainer, loss_fn) if use_graph else eager_step
+    if use_graph:
+        step = None
+        if dist_on and args.captured_comm:
+            # RCCL all-reduces captured inside graph A, bucket by bucket on the communication stream while the backward
+            # of the later buckets still runs; falls back to one eager all-reduce between the graphs if capture fails
+            try:
+                step = GraphedStep(trainer, loss_fn, capture_collectives=True)
+                comm_mode = "captured, bucketed"
+            except Exception as e:      # noqa: BLE001
+                print(f"# collective capture unavailable ({type(e).__name__}: {e}); eager all-reduce between graphs", file=sys.stderr)
+                torch.cuda.synchronize()
+        if step is None:
+            if dist_on:
+                trainer.overlap, comm_mode = False, "eager, between the graphs"
+            step = GraphedStep(trainer, loss_fn)
+    else:
+        step = eager_step
 
     def barrier():
         if dist_on:
@@ -369,7 +389,7 @@ def main():
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "sum_notes_rank0": sum_n,
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * B_PER_GPU * world / (ms_per_step * 1e-3) / 1e12, 2),
-                       "grad_bytes": trainer.grad_bytes()},
+                       "grad_bytes": trainer.grad_bytes(), "grad_allreduce": comm_mode},
             "roofline": roofline, "cpu_baseline": cpu}
     if dist_on:
         import torch.distributed as dist

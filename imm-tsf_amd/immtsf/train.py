@@ -236,18 +236,21 @@ class FlatTrainer:
 class GraphedStep:
     """One training step as two hipGraphs (HIP streams + graphs instead of a tracing compiler):
         graph A = zero-grad, forward, loss, backward, gradient collection into the flat buffer
-        [world > 1: eager RCCL all-reduce of the flat gradient between the graphs]
+                  [+ with capture_collectives: the RCCL gradient all-reduces, bucket by bucket on the communication
+                  stream as the backward finishes each bucket -- a parallel branch of the graph]
+        [otherwise, world > 1: one eager RCCL all-reduce of the flat gradient between the graphs]
         graph B = clip + Adam, which also bumps the device-side Adam step and dropout-key counters, so every replay
                   is a NEW training step (needs FlatTrainer(device_step=True)).
     `loss_fn()` runs the forward and returns the scalar loss; inputs must be static device tensors."""
 
-    def __init__(self, trainer: FlatTrainer, loss_fn, warmup: int = 3):
+    def __init__(self, trainer: FlatTrainer, loss_fn, warmup: int = 3, capture_collectives: bool = False):
         if not trainer.device_step:
             raise ValueError("GraphedStep needs FlatTrainer(device_step=True): host-side step counters would freeze in the graph")
         self.trainer, self.loss_fn = trainer, loss_fn
+        self.captured_comm = bool(capture_collectives and trainer.collective)
         side = torch.cuda.Stream(device=trainer.flat_param.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up off the default stream: allocator pools, lazy inits
+        with torch.cuda.stream(side):           # warm-up off the default stream: allocator pools, lazy inits, RCCL channels
             for _ in range(warmup):
                 self._fwd_bwd()
                 trainer.sync_grads()
@@ -257,6 +260,8 @@ class GraphedStep:
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
+            if self.captured_comm:
+                trainer.sync_grads()
         with torch.cuda.graph(self.graph_b):
             trainer.step()
 
@@ -270,7 +275,8 @@ class GraphedStep:
     def __call__(self):
         t = self.trainer
         self.graph_a.replay()
-        t._reduced = [False] * len(t.buckets)
-        t.sync_grads()
+        if not self.captured_comm:
+            t._reduced = [False] * len(t.buckets)
+            t.sync_grads()
         self.graph_b.replay()
         return self.loss

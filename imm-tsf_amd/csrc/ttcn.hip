@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void unpack_g_kernel(Dims d, UnpackPtrs q) {
 // Pooling forward.  grid = P, block = ceil(NC/64)*64; thread c owns filter column c.  S (R, NCp): logits in, softmax
 // weights out (in place).  ctr (P, NC) = sum_l sm*X, out (P, K) = relu(sum_f ctr + T_bias).
 __global__ void pool_fwd_kernel(Dims d, float* __restrict__ S, const float* __restrict__ X, const float* __restrict__ mask,
-                                const float* __restrict__ Tb, float* __restrict__ ctr, float* __restrict__ out) {
+                                const float* __restrict__ Tb, float* __restrict__ ctr, float* __restrict__ out, int out_ld,
+                                int flag_col) {
     extern __shared__ float lds[];   // [NC] contributions
     const int p = blockIdx.x, c = threadIdx.x;
     const bool col = c < d.NC;
@@ -104,7 +105,12 @@ __global__ void pool_fwd_kernel(Dims d, float* __restrict__ S, const float* __re
     if (c < d.K) {
         float a = Tb[c];
         for (int f = 0; f < d.F; ++f) a += lds[c * d.F + f];
-        out[(size_t)p * d.K + c] = fmaxf(a, 0.f);
+        out[(size_t)p * out_ld + c] = fmaxf(a, 0.f);
+    }
+    if (flag_col >= 0 && c == 0) {          // patch-non-empty flag (models/tPatchGNN.py:268-270) written beside the embedding
+        float any = 0.f;
+        for (int l = 0; l < d.L; ++l) any += mp[l];
+        out[(size_t)p * out_ld + flag_col] = any > 0.f ? 1.f : 0.f;
     }
 }
 
@@ -112,7 +118,7 @@ __global__ void pool_fwd_kernel(Dims d, float* __restrict__ S, const float* __re
 // dpool (P, K) = dout * [out > 0] is also written (for the T_bias column sum).
 __global__ void pool_bwd_kernel(Dims d, float* __restrict__ S, const float* __restrict__ X, const float* __restrict__ mask,
                                 const float* __restrict__ ctr, const float* __restrict__ out, const float* __restrict__ dout,
-                                float* __restrict__ dX, float* __restrict__ dpool) {
+                                int out_ld, float* __restrict__ dX, float* __restrict__ dpool) {
     extern __shared__ float lds[];   // dp[K] | smt[LC][NC]
     float* dp = lds;
     float* smt = lds + d.K;
@@ -120,7 +126,7 @@ __global__ void pool_bwd_kernel(Dims d, float* __restrict__ S, const float* __re
     const bool col = c < d.NC;
     const int fc = col ? c % d.F : 0, kc = col ? c / d.F : 0;
     if (c < d.K) {
-        const float g = out[(size_t)p * d.K + c] > 0.f ? dout[(size_t)p * d.K + c] : 0.f;
+        const float g = out[(size_t)p * out_ld + c] > 0.f ? dout[(size_t)p * out_ld + c] : 0.f;
         dp[c] = g;
         dpool[(size_t)p * d.K + c] = g;
     }
@@ -206,9 +212,10 @@ size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t t
 }
 
 int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
-                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, void* workspace,
-                        size_t workspace_bytes, immtsf_stream_t stream) {
+                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, int32_t out_ld,
+                        int32_t flag_col, void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
     if (!x || !tt || !mask || !p || !out || !workspace) return IMMTSF_EINVAL;
+    if (out_ld < ttcn_dim || flag_col >= out_ld || (flag_col >= 0 && flag_col < ttcn_dim)) return IMMTSF_EINVAL;
     if (bad_dims(P, L, te_dim, ttcn_dim)) return (1 + te_dim) * ttcn_dim > 1024 ? IMMTSF_EUNSUPPORTED : IMMTSF_EINVAL;
     if (P == 0) return IMMTSF_OK;
     const Dims d = mk_dims(P, L, te_dim, ttcn_dim);
@@ -240,17 +247,17 @@ int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, 
         CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
     const int threads = cdiv(d.NC, 64) * 64;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(P), dim3(threads), d.NC * sizeof(float), s, d, w.S, w.X, mask, p->T_bias, w.ctr, out);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(P), dim3(threads), d.NC * sizeof(float), s, d, w.S, w.X, mask, p->T_bias, w.ctr, out, out_ld, flag_col);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
                          const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
-                         const float* dout, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                         const immtsf_ttcn_params* gr, immtsf_stream_t stream) {
+                         const float* dout, int32_t out_ld, void* workspace, size_t workspace_bytes, void* scratch,
+                         size_t scratch_bytes, const immtsf_ttcn_params* gr, immtsf_stream_t stream) {
     (void)x;
-    if (!tt || !mask || !p || !out || !dout || !gr || !workspace || !scratch) return IMMTSF_EINVAL;
+    if (!tt || !mask || !p || !out || !dout || !gr || !workspace || !scratch || out_ld < ttcn_dim) return IMMTSF_EINVAL;
     if (bad_dims(P, L, te_dim, ttcn_dim)) return IMMTSF_EINVAL;
     if (P == 0) return IMMTSF_OK;
     const Dims d = mk_dims(P, L, te_dim, ttcn_dim);
@@ -261,7 +268,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     const int threads = cdiv(d.NC, 64) * 64;
     const size_t lds = (size_t)(d.K + LC * d.NC) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, sc.dX, sc.dpool);
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, out_ld, sc.dX, sc.dpool);
     IMMTSF_LAUNCH_CHECK();
     Fork fk(s);
     CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));

@@ -111,10 +111,10 @@ _PROTOS = {
     "immtsf_ttcn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "immtsf_ttcn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "immtsf_ttcn_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
-                                      _P(TTCNParams), c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+                                      _P(TTCNParams), c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_ttcn_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
-                                       _P(TTCNParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                       _P(TTCNParams), c_stream]),
+                                       _P(TTCNParams), c_f32p, c_f32p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
+                                       C.c_size_t, _P(TTCNParams), c_stream]),
     "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_masked_mse_finish": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                            C.c_float, c_stream]),

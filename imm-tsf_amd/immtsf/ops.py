@@ -369,10 +369,11 @@ class MMFGRAddFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ tPatchGNN TE + TTCN
 class TTCNPatchEncodeFn(torch.autograd.Function):
-    """(x, tt, mask: (P,L)) -> (P, ttcn_dim).  params in immtsf_ttcn_params order."""
+    """(x, tt, mask: (P,L)) -> (P, ttcn_dim) or, with_flag, (P, ttcn_dim + 1) whose last column is the patch-non-empty
+    flag (any mask > 0; no gradient).  params in immtsf_ttcn_params order."""
 
     @staticmethod
-    def forward(ctx, x, tt, mask, precision, *params):
+    def forward(ctx, x, tt, mask, precision, with_flag, *params):
         lib = _lib.load()
         x, tt, mask = _c(x), _c(tt), _c(mask)
         params = tuple(_c(p) for p in params)
@@ -380,12 +381,13 @@ class TTCNPatchEncodeFn(torch.autograd.Function):
         P, L = x.shape
         te_dim = params[2].numel() + 1
         K = params[10].numel()
-        out = torch.empty(P, K, dtype=torch.float32, device=x.device)
+        ld = K + 1 if with_flag else K
+        out = torch.empty(P, ld, dtype=torch.float32, device=x.device)
         ws = _bytes(lib.immtsf_ttcn_workspace_bytes(P, L, te_dim, K), x.device)
         ps = _struct(TTCNParams, params)
-        check(lib.immtsf_ttcn_forward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(ws),
-                                      ws.numel(), stream_ptr()), "ttcn_forward")
-        ctx.dims = (P, L, te_dim, K, precision)
+        check(lib.immtsf_ttcn_forward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ld,
+                                      K if with_flag else -1, ptr(ws), ws.numel(), stream_ptr()), "ttcn_forward")
+        ctx.dims = (P, L, te_dim, K, precision, ld)
         ctx.ws = ws
         ctx.sinks = _sinks_of(params)
         ctx.save_for_backward(x, tt, mask, out, *params)
@@ -395,21 +397,23 @@ class TTCNPatchEncodeFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         x, tt, mask, out, *params = ctx.saved_tensors
-        P, L, te_dim, K, precision = ctx.dims
+        P, L, te_dim, K, precision, ld = ctx.dims
         dout = dout.contiguous()
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttcn_scratch_bytes(P, L, te_dim, K), x.device)
         ps, gs = _struct(TTCNParams, params), _struct(TTCNParams, grads)
-        check(lib.immtsf_ttcn_backward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout),
+        check(lib.immtsf_ttcn_backward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout), ld,
                                        ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
               "ttcn_backward")
-        return (None, None, None, None) + tuple(rets)
+        return (None, None, None, None, None) + tuple(rets)
 
 
-def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias, precision=None):
-    """Fused LearnableTE + TTCN of tPatchGNN (models/tPatchGNN.py:176-195) on (P, L) patch tensors."""
-    return TTCNPatchEncodeFn.apply(x.float(), tt.float(), mask.float(), config.precision_code(precision), te_scale_w,
-                                   te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias)
+def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias, precision=None,
+                      with_flag=False):
+    """Fused LearnableTE + TTCN of tPatchGNN (models/tPatchGNN.py:176-195) on (P, L) patch tensors; with_flag appends
+    the patch-non-empty column of :268-270."""
+    return TTCNPatchEncodeFn.apply(x.float(), tt.float(), mask.float(), config.precision_code(precision), bool(with_flag),
+                                   te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias)
 
 
 class GCNAdaptiveFn(torch.autograd.Function):

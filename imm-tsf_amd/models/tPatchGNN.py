@@ -141,9 +141,9 @@ class tPatchGNN(nn.Module):
         if self.patch_encoder != "torch":      # "auto"/"hip": the fused kernel (raises on CPU tensors: no silent fallback)
             from immtsf.ops import ttcn_patch_encode
             lin = self.Filter_Generators
-            h = ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
-                                  self.te_periodic.bias, lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias,
-                                  lin[4].weight, lin[4].bias, self.T_bias)
+            return ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
+                                     self.te_periodic.bias, lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias,
+                                     lin[4].weight, lin[4].bias, self.T_bias, with_flag=True)     # flag column written in-kernel
         else:
             te = self.LearnableTE(tt.unsqueeze(-1))
             h = self.TTCN(torch.cat([x.unsqueeze(-1), te], -1), mask.unsqueeze(-1))

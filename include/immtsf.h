@@ -198,16 +198,18 @@ typedef struct immtsf_ttcn_params {
 size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
 size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
 /* the three filter-generator layers run on the MFMA GEMM over all P*L slots (`precision` as everywhere), the masked
- * softmax + pooling are streaming kernels; `workspace` holds the saved-for-backward state */
+ * softmax + pooling are streaming kernels; `workspace` holds the saved-for-backward state.  out / dout have leading
+ * dimension out_ld >= K; flag_col >= K (or -1): column that receives the patch-non-empty flag (any mask > 0), so the
+ * caller's [embedding ; flag] concatenation (models/tPatchGNN.py:268-270) needs no extra kernels */
 int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
-                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, void* workspace,
-                        size_t workspace_bytes, immtsf_stream_t stream);
+                        const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, int32_t out_ld,
+                        int32_t flag_col, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
 /* dout (P,K) -> every parameter gradient (overwritten).  No gradient flows to x / tt / mask (data).
  * NOTE: consumes the workspace (the saved softmax weights are overwritten): one backward per forward. */
 int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
                          const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
-                         const float* dout, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                         const immtsf_ttcn_params* grads, immtsf_stream_t stream);
+                         const float* dout, int32_t out_ld, void* workspace, size_t workspace_bytes, void* scratch,
+                         size_t scratch_bytes, const immtsf_ttcn_params* grads, immtsf_stream_t stream);
 
 /* ---- tPatchGNN adaptive-graph stage (models/tPatchGNN.py:205-238; gcn/nconv/linear :29-84), one (window, patch)
  * cell per workgroup, everything in LDS.  x, out, dout, dx: (B, N, M, D) contiguous.  Pointers in state_dict order. */

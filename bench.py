@@ -158,6 +158,9 @@ def main():
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     args = ap.parse_args()
+    # stdout carries exactly one line, the JSON result: everything else a module prints (the fusion registry announces
+    # its choices like the reference does) goes to stderr
+    json_out, sys.stdout = sys.stdout, sys.stderr
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -397,9 +400,9 @@ def main():
         dist.destroy_process_group()      # RCCL may log on teardown: keep the JSON line the last thing rank 0 prints
     if rank == 0:
         sys.stderr.flush()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     # native libraries (RCCL prints its path on unload) must not write to stdout behind the JSON line
-    sys.stdout.flush()
+    json_out.flush()
     os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
 
 

@@ -255,7 +255,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     auto load_fast = [&](int k0, float4 (&ra)[CA], float4 (&rb)[CB]) {
         const unsigned ka = TA ? (unsigned)k0 * (unsigned)g.lda : (unsigned)k0;
         const unsigned kb = TB ? (unsigned)k0 * (unsigned)g.ldb : (unsigned)k0;
-#ifdef IMMTSF_EXPERIMENT_HALF_BYTES     // measurement only (tools/gemm_halfbytes.py): fetch half the bytes, as if the
+#ifdef IMMTSF_EXPERIMENT_HALF_BYTES     // measurement only (tools/gemm_twin_bench.py): fetch half the bytes, as if the
                                         // operands were stored as bf16; the results are garbage
 #pragma unroll
         for (int i = 0; i < CA; ++i) { const float2 t = *reinterpret_cast<const float2*>(A + ((oa[i] + ka) >> 1)); ra[i] = make_float4(t.x, t.y, t.x, t.y); }
@@ -897,20 +897,14 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             case 7:
                 if (bbf) return launch_cfg<true, 64, 64, 32, 2, 2, false, true>(layout, g, Mmax, splits, stream);
                 return launch_cfg<true, 64, 64, 32, 2, 2>(layout, g, Mmax, splits, stream);
-            case 8: return launch_cfg<true, 64, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
-            case 9: return launch_cfg<true, 96, 64, 64, 2, 2>(layout, g, Mmax, splits, stream);
-            case 10: return launch_cfg<true, 96, 96, 64, 2, 2>(layout, g, Mmax, splits, stream);
             case 11:
                 if (bbf) return launch_cfg<true, 64, 64, 64, 2, 4, false, true>(layout, g, Mmax, splits, stream);
                 return launch_cfg<true, 64, 64, 64, 2, 4>(layout, g, Mmax, splits, stream);
-            case 12: return launch_cfg<true, 128, 64, 64, 4, 2>(layout, g, Mmax, splits, stream);
-            case 13: return launch_cfg<true, 128, 128, 64, 4, 2>(layout, g, Mmax, splits, stream);
             case 14:
                 if (bbf) return launch_cfg<true, 64, 64, 128, 2, 4, false, true>(layout, g, Mmax, splits, stream);
                 return launch_cfg<true, 64, 64, 128, 2, 4>(layout, g, Mmax, splits, stream);
             case 15: return launch_cfg<true, 64, 64, 64, 2, 2, true>(layout, g, Mmax, splits, stream);
             case 16: return launch_cfg<true, 64, 64, 32, 2, 2, true>(layout, g, Mmax, splits, stream);
-            case 17: return launch_cfg<true, 128, 64, 32, 2, 2, true>(layout, g, Mmax, splits, stream);
             default: return IMMTSF_EINVAL;
         }
     }

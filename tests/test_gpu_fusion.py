@@ -449,3 +449,31 @@ def test_timellm_offline_smoke():
     assert out.shape == (3, 5, 3) and torch.isfinite(out).all()
     out.square().mean().backward()
     assert torch.isfinite(m.mapping_layer.weight.grad).all()
+
+
+def test_mmf_monolithic_entry_equals_the_two_halves():
+    """immtsf_mmf_xattn_add_forward/backward (one call) and the key/value + query halves the module uses are the same
+    computation: outputs and every gradient must agree to fp32 rounding."""
+    dev = _dev()
+    from fusions.MMF_XAttn_Add import MMF_XAttn_Add
+    from immtsf import config
+    from immtsf.ops import MMFXAttnAddFn
+    config.precision = "fp32"
+    torch.manual_seed(2)
+    B, T, Cc, d, H = 5, 9, 3, 16, 2
+    mmf = MMF_XAttn_Add(d, Cc, d, n_heads_fusion=H, dropout=0.0, kappa=0.7).to(dev).train()
+    Y, E = torch.randn(B, T, Cc, device=dev), torch.randn(B, T, d, device=dev)
+    M = torch.tensor([1, 1, 0, 1, 1], dtype=torch.bool, device=dev).view(B, 1)
+    up = torch.randn(B, T, Cc, device=dev)
+    res = []
+    for mono in (False, True):
+        mmf.zero_grad()
+        y, e = Y.clone().requires_grad_(True), E.clone().requires_grad_(True)
+        if mono:
+            out = MMFXAttnAddFn.apply(y, e, M.view(B).view(torch.uint8), H, 0.7, 0.0, False, 0, 0, *mmf._params())
+        else:
+            out = mmf(y, e, M)
+        (out * up).sum().backward()
+        res.append([out.detach(), y.grad, e.grad] + [p.grad.clone() for p in mmf.parameters()])
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1e-3, float(b.abs().max()))

@@ -19,7 +19,8 @@ SHAPES = [  # layout, M, N, K
     (0, 1117, 768, 1152), (0, 1117, 1536, 768), (2, 1536, 768, 1117), (1, 1117, 1152, 768),
     (0, 2048, 8, 768), (0, 2048, 768, 8), (2, 8, 768, 2048), (0, 4096, 4096, 4096), (1, 4096, 4096, 4096), (2, 4096, 4096, 4096),
 ]
-VARIANTS = {1: "64x64x64", 2: "64x64x128", 3: "128x64x64", 4: "128x128x64", 5: "32x64x64", 6: "64x128x64", 7: "64x64x32", 8: "64x96x64", 9: "96x64x64", 10: "96x96x64", 11: "64x64x64w8", 12: "128x64x64w8", 13: "128x128x64w8", 14: "64x64x128w8", 15: "64x64x64spec", 16: "64x64x32spec", 17: "128x64x32spec"}
+VARIANTS = {1: "64x64x64", 2: "64x64x128", 3: "128x64x64", 4: "128x128x64", 5: "32x64x64", 6: "64x128x64", 7: "64x64x32",
+            11: "64x64x64w8", 14: "64x64x128w8", 15: "64x64x64spec", 16: "64x64x32spec"}
 
 
 def bench(layout, M, N, K, variant, splitk):

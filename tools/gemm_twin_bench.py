@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Graph-timed GEMM launches (50 per hipGraph).  Run once with the product library and once with
-IMMTSF_LIB=imm-tsf_amd/immtsf/libimmtsf_hip_halfbytes.so (built with -DIMMTSF_EXPERIMENT_HALF_BYTES: every operand
-fetch moves half the bytes, as bf16 storage would) to see what operand bytes through the L1 cost."""
+"""Graph-timed GEMM launches (50 per hipGraph) with the weight operand read as fp32 vs from a registered bf16 twin, for
+the tile variants the launcher can pick (v0 = its own choice).  profiles/ and DESIGN.md section 8 quote these numbers."""
 import os
 import sys
 

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     for (int i = wave; i < n; i += 4) {
         const float* kr = KVp + (size_t)(o0 + i) * ld + h * hd;
         float a = 0.f;
+#pragma unroll 4
         for (int c = lane; c < hd; c += 64) a = fmaf(qs[h * hd + c], kr[c], a);
         a = wave_sum(a);
         if (lane == 0) sc[i] = a;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     if (drop.p <= 0.f) {   // every forecast step sees the same weights
         if (!valid) return;
         float acc = 0.f;
+#pragma unroll 8
         for (int i = 0; i < n; ++i) acc = fmaf(sc[i], vbase[(size_t)i * ld], acc);
         for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = acc;
         return;
@@ -79,10 +81,14 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
             __syncthreads();
             if (valid) {
                 const int cnt = min(64, n - i0);
-                for (int ii = 0; ii < cnt; ++ii) {
-                    const float v = vbase[(size_t)(i0 + ii) * ld];
+                for (int ii = 0; ii < cnt; ii += 4) {     // four notes per step: their V loads are in flight together
+                    float v[4];                           // (one load -> 32 FMAs -> next load serialises on latency)
 #pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) acc[tt] = fmaf(atile[tt * 64 + ii], v, acc[tt]);
+                    for (int u = 0; u < 4; ++u) v[u] = (ii + u < cnt) ? vbase[(size_t)(i0 + ii + u) * ld] : 0.f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) acc[tt] = fmaf(atile[tt * 64 + ii + u], v[u], acc[tt]);   // tile is 0 past n
                 }
             }
         }
@@ -116,6 +122,12 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
     float gsum = 0.f;
     if (drop.p <= 0.f && valid)
         for (int t = 0; t < T; ++t) gsum += dc[(size_t)t * d];
+    // the upstream gradient column is the same for every note of the window: up to DCR forecast steps stay in registers
+    // (re-reading them per note made every note wait on T dependent loads)
+    constexpr int DCR = 32;
+    float dcv[DCR];
+#pragma unroll
+    for (int t = 0; t < DCR; ++t) dcv[t] = (valid && drop.p > 0.f && t < T) ? dc[(size_t)t * d] : 0.f;
     for (int i = wave; i < n; i += 4) {
         float g = gsum;
         if (drop.p > 0.f) {
@@ -132,9 +144,11 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
             }
             g = 0.f;
 #pragma unroll
+            for (int tt = 0; tt < DCR; ++tt) g = fmaf(__shfl(mreg[0], tt, 64), dcv[tt], g);      // steps 0..DCR-1 (dcv is 0 past T)
+#pragma unroll
             for (int k = 0; k < MT; ++k) {
                 const int tcnt = min(64, T - k * 64);
-                for (int tt = 0; tt < tcnt; ++tt) {
+                for (int tt = (k == 0 ? DCR : 0); tt < tcnt; ++tt) {
                     const float mt = __shfl(mreg[k], tt, 64);
                     if (valid) g = fmaf(mt, dc[(size_t)(k * 64 + tt) * d], g);
                 }
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     for (int c = tid; c < hd; c += 256) {
         const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
         float a = 0.f;
+#pragma unroll 8
         for (int i = 0; i < n; ++i) a = fmaf(ds[i], kc[(size_t)i * ld], a);
         dqs_part[(size_t)b * d + h * hd + c] = a;
     }

@@ -680,7 +680,10 @@ int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 
 
 }  // namespace
 
+extern int g_immtsf_ttcn_fused;      // ttcn.hip
+
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
+    g_immtsf_ttcn_fused = (variant & 0x8000) ? 0 : 1;   // bit 15: TTCN on the streaming formulation (A/B measurements)
     g_variant = variant & 0xff;
     g_xcd = (variant & 0x100) ? 0 : 1;      // bit 8 disables the XCD-aware tile order (A/B measurements)
     g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)

@@ -18,6 +18,8 @@
 #include "block_util.hpp"
 #include "rowops.hpp"
 
+int g_immtsf_ttcn_fused = 1;    // A/B switch: immtsf_debug_gemm_config bit 15 turns the fused layer-3 path off
+
 namespace {
 
 constexpr int LC = 32;   // slots per LDS chunk in the pooling backward
@@ -241,6 +243,8 @@ int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, 
         g.act = 1;
         CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
+    if (g_immtsf_ttcn_fused && ttcn_fused_supported(precision, L, d.F, d.K))      // layer 3 + softmax + pooling without the filter tensor
+        return launch_ttcn3_fwd(P, L, d.F, d.K, w.h2, w.W3p, w.b3p, w.X, mask, p->T_bias, w.ctr, out, out_ld, flag_col, s);
     {   // filt = h2 W3^T + b3
         GemmArgs g = gemm_args(d.R, d.NCp, d.Kp, d.Kp, d.Kp, d.NCp);
         set_problem(g, 0, w.h2, w.W3p, w.S, w.b3p);
@@ -265,19 +269,25 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     Sc sc = carve_sc(d, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int threads = cdiv(d.NC, 64) * 64;
-    const size_t lds = (size_t)(d.K + LC * d.NC) * sizeof(float);
-    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, out_ld, sc.dX, sc.dpool);
-    IMMTSF_LAUNCH_CHECK();
-    Fork fk(s);
-    CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
-    {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once for the split-K GEMMs
+    const bool fused = g_immtsf_ttcn_fused && ttcn_fused_supported(precision, L, d.F, d.K);
+    {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once (split-K GEMMs / atomics)
         const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
         hipError_t e = hipMemsetAsync(sc.gW1p, 0, nbytes, s);
         if (e != hipSuccess) return (int)e;
     }
-    {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
+    Fork fk(s);
+    if (fused) {     // pooling + layer-3 backward with the filter tile recomputed on chip
+        CHECK(launch_ttcn3_bwd(P, L, d.F, d.K, w.h2, w.W3p, w.b3p, w.X, mask, w.ctr, out, dout, out_ld, sc.dX, sc.dpool, sc.dz2,
+                               sc.gW3p, sc.gb3p, s));
+    } else {
+        const int threads = cdiv(d.NC, 64) * 64;
+        const size_t lds = (size_t)(d.K + LC * d.NC) * sizeof(float);
+        if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(P), dim3(threads), lds, s, d, w.S, w.X, mask, w.ctr, out, dout, out_ld, sc.dX, sc.dpool);
+        IMMTSF_LAUNCH_CHECK();
+    }
+    CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
+    if (!fused) {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
         GemmArgs h = gemm_args(d.NCp, d.Kp, d.R, d.NCp, d.Kp, d.Kp);
         set_problem(h, 0, w.S, w.h2, sc.gW3p, nullptr, sc.gb3p);
         h.c_prezeroed = 1;

@@ -160,3 +160,51 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
     gmax = max(float(g.abs().max()) for g in res["torch"][2].values())
     for n in names:
         assert _rel(res["hip"][2][n], res["torch"][2][n], floor=1e-3 * gmax) < 2e-4, n
+
+
+@pytest.mark.parametrize("L", [32, 45, 7])
+def test_ttcn_fused_layer3_equals_streaming_bf16(L):
+    """bf16 mode: the fused kernel pair (filter tile produced, normalised and pooled on chip; backward recomputes it)
+    against the streaming formulation (filter tensor through HBM) -- same rounding points, so they must agree far
+    inside the bf16 band -- and both against the fp32 eager formulation at the bf16 tolerance."""
+    dev = _dev()
+    from immtsf import _lib, config
+    from models.tPatchGNN import tPatchGNN
+    lib = _lib.load()
+    args = types.SimpleNamespace(device=str(dev), hid_dim=32, C=8, npatch=2, nlayer=1, te_dim=10, n_heads=1, tf_layer=1,
+                                 node_dim=10, hop=1, outlayer="Linear", immtsf_patch_encoder="hip")
+    torch.manual_seed(0)
+    m = tPatchGNN(args).to(dev)
+    g = torch.Generator().manual_seed(L)
+    P = 64 * 8 * 2
+    cnt = torch.randint(1, L + 1, (P, 1), generator=g)
+    cnt[torch.rand(P, 1, generator=g) < 0.3] = 0
+    mask = (torch.arange(L).view(1, -1) < cnt).float().to(dev)
+    x = torch.randn(P, L, generator=g).to(dev) * mask
+    tt = torch.rand(P, L, generator=g).to(dev) * mask
+    up = torch.randn(P, 32, generator=g).to(dev)
+    res = {}
+    try:
+        for mode, cfgbits, prec, enc in (("fused", 0, "bf16", "hip"), ("stream", 0x8000, "bf16", "hip"), ("eager", 0, "fp32", "torch")):
+            lib.immtsf_debug_gemm_config(cfgbits, 0)
+            config.precision = prec
+            m.patch_encoder = enc
+            m.zero_grad()
+            h = m._encode_patches(x, tt, mask)
+            (h * up).sum().backward()
+            res[mode] = (h.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        lib.immtsf_debug_gemm_config(0, 0)
+        config.precision = "fp32"
+
+    gnorm = max(float(g.double().norm()) for g in res["eager"][1].values())
+
+    def l2(a, b):      # relative L2; gradients that are zero by construction (the filter bias: a per-column shift of a
+        return float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-3 * gnorm))   # softmax) count as noise
+    assert l2(res["fused"][0], res["stream"][0]) < 2e-3
+    assert l2(res["fused"][0], res["eager"][0]) < 3e-2
+    assert res["fused"][1].keys() == res["stream"][1].keys() == res["eager"][1].keys()
+    for k in res["eager"][1]:
+        assert l2(res["fused"][1][k], res["stream"][1][k]) < 5e-3, k
+        # vs fp32: inside the bf16 band, or no worse than the streaming bf16 path on cancellation-prone gradients
+        assert l2(res["fused"][1][k], res["eager"][1][k]) < max(4e-2, 1.5 * l2(res["stream"][1][k], res["eager"][1][k])), k

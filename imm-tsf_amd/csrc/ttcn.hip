@@ -18,7 +18,7 @@
 #include "block_util.hpp"
 #include "rowops.hpp"
 
-int g_immtsf_ttcn_fused = 1;    // A/B switch: immtsf_debug_gemm_config bit 15 turns the fused layer-3 path off
+int g_immtsf_ttcn_fused = 1;    // A/B switch: immtsf_debug_gemm_config bit 15 selects the streaming formulation below
 
 namespace {
 
@@ -158,7 +158,7 @@ __global__ void pool_bwd_kernel(Dims d, float* __restrict__ S, const float* __re
 }
 
 struct Ws {   // forward workspace = saved for backward
-    float *X, *h1, *h2, *S, *ctr, *W1p, *b1p, *W2p, *b2p, *W3p, *b3p;
+    float *X, *h1, *h2, *S, *ctr, *W1p, *b1p, *W2p, *b2p, *W3p, *b3p, *pack;
     size_t bytes;
 };
 Ws carve_ws(const Dims& d, void* base) {
@@ -168,18 +168,19 @@ Ws carve_ws(const Dims& d, void* base) {
     w.h1 = k.take<float>((size_t)d.R * d.Kp);
     w.h2 = k.take<float>((size_t)d.R * d.Kp);
     w.S = k.take<float>((size_t)d.R * d.NCp);
-    w.ctr = k.take<float>((size_t)d.P * d.NC);
+    w.ctr = k.take<float>((size_t)d.P * (d.NC > d.F * 32 ? d.NC : d.F * 32));      // (P, F*32) in the on-chip formulation
     w.W1p = k.take<float>(d.Kp * d.Fp);
     w.b1p = k.take<float>(d.Kp);
     w.W2p = k.take<float>(d.Kp * d.Kp);
     w.b2p = k.take<float>(d.Kp);
     w.W3p = k.take<float>((size_t)d.NCp * d.Kp);
     w.b3p = k.take<float>(d.NCp);
+    w.pack = k.take<float>(ttcn_full_pack_floats(d.F));
     w.bytes = k.bytes();
     return w;
 }
 struct Sc {
-    float *dX, *dpool, *dz2, *dz1, *gW1p, *gb1p, *gW2p, *gb2p, *gW3p, *gb3p, *red;
+    float *dX, *dpool, *dz2, *dz1, *gW1p, *gb1p, *gW2p, *gb2p, *gW3p, *gb3p, *red, *slab;
     size_t bytes;
 };
 Sc carve_sc(const Dims& d, void* base) {
@@ -196,6 +197,7 @@ Sc carve_sc(const Dims& d, void* base) {
     s.gW3p = k.take<float>((size_t)d.NCp * d.Kp);
     s.gb3p = k.take<float>(d.NCp);
     s.red = k.take<float>(64 * (d.NCp + 64) + 2 * 256 * d.F);
+    s.slab = k.take<float>(ttcn_full_slab_floats(d.F));
     s.bytes = k.bytes();
     return s;
 }
@@ -224,6 +226,8 @@ int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, 
     Ws w = carve_ws(d, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g_immtsf_ttcn_fused && ttcn_full_supported(precision, L, d.F, d.K))      // the whole encoder on chip, one kernel
+        return launch_ttcn_full_fwd(P, L, d.F, d.K, x, tt, mask, p, w.pack, w.ctr, out, out_ld, flag_col, s);
     PackPtrs q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3, w.W1p, w.b1p, w.W2p, w.b2p, w.W3p, w.b3p};
     hipLaunchKernelGGL(pack_w_kernel, dim3(cdiv(d.NCp * d.Kp, 256)), dim3(256), 0, s, d, q);
     IMMTSF_LAUNCH_CHECK();
@@ -243,8 +247,6 @@ int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, 
         g.act = 1;
         CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
-    if (g_immtsf_ttcn_fused && ttcn_fused_supported(precision, L, d.F, d.K))      // layer 3 + softmax + pooling without the filter tensor
-        return launch_ttcn3_fwd(P, L, d.F, d.K, w.h2, w.W3p, w.b3p, w.X, mask, p->T_bias, w.ctr, out, out_ld, flag_col, s);
     {   // filt = h2 W3^T + b3
         GemmArgs g = gemm_args(d.R, d.NCp, d.Kp, d.Kp, d.Kp, d.NCp);
         set_problem(g, 0, w.h2, w.W3p, w.S, w.b3p);
@@ -260,7 +262,6 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
                          const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
                          const float* dout, int32_t out_ld, void* workspace, size_t workspace_bytes, void* scratch,
                          size_t scratch_bytes, const immtsf_ttcn_params* gr, immtsf_stream_t stream) {
-    (void)x;
     if (!tt || !mask || !p || !out || !dout || !gr || !workspace || !scratch || out_ld < ttcn_dim) return IMMTSF_EINVAL;
     if (bad_dims(P, L, te_dim, ttcn_dim)) return IMMTSF_EINVAL;
     if (P == 0) return IMMTSF_OK;
@@ -269,17 +270,16 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     Sc sc = carve_sc(d, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool fused = g_immtsf_ttcn_fused && ttcn_fused_supported(precision, L, d.F, d.K);
+    if (g_immtsf_ttcn_fused && ttcn_full_supported(precision, L, d.F, d.K))
+        return launch_ttcn_full_bwd(P, L, d.F, d.K, x, tt, mask, p, w.pack, w.ctr, out, dout, out_ld, sc.slab, gr,
+                                    static_cast<hipStream_t>(stream));
     {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once (split-K GEMMs / atomics)
         const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
         hipError_t e = hipMemsetAsync(sc.gW1p, 0, nbytes, s);
         if (e != hipSuccess) return (int)e;
     }
     Fork fk(s);
-    if (fused) {     // pooling + layer-3 backward with the filter tile recomputed on chip
-        CHECK(launch_ttcn3_bwd(P, L, d.F, d.K, w.h2, w.W3p, w.b3p, w.X, mask, w.ctr, out, dout, out_ld, sc.dX, sc.dpool, sc.dz2,
-                               sc.gW3p, sc.gb3p, s));
-    } else {
+    {
         const int threads = cdiv(d.NC, 64) * 64;
         const size_t lds = (size_t)(d.K + LC * d.NC) * sizeof(float);
         if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
@@ -287,7 +287,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
         IMMTSF_LAUNCH_CHECK();
     }
     CHECK(launch_colsum(sc.dpool, nullptr, P, nullptr, d.K, d.K, gr->T_bias, 0, sc.red, s));
-    if (!fused) {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
+    {   // layer 3: dW3 = dF^T h2 (+db3) ; dz2 = (dF W3) * [h2 > 0]
         GemmArgs h = gemm_args(d.NCp, d.Kp, d.R, d.NCp, d.Kp, d.Kp);
         set_problem(h, 0, w.S, w.h2, sc.gW3p, nullptr, sc.gb3p);
         h.c_prezeroed = 1;

@@ -1,0 +1,558 @@
+// The whole time-aware patch encoder of one patch on one CU (bf16 MFMA mode, ttcn_dim <= 32, 1 + te_dim <= 16, L <= 64):
+// LearnableTE, the three filter-generator layers, the masked softmax over the patch's slots and the meta-filter pooling,
+// forward in one kernel and backward in one kernel.  Reference: models/tPatchGNN.py:176-195.
+//
+// Why: the streaming formulation (ttcn.hip) runs the layers as GEMMs over all P*L slots and therefore moves the
+// (P*L, F*K) filter tensor through HBM six times per step (46 MB a pass at the benchmark shape) plus 19 launches.  But a
+// patch's working set is tiny -- X: L x F, h1/h2: L x 32, filter tile: L x F*K -- every contraction has K <= 32 (one
+// MFMA k-step) or M, N <= 32, and the softmax runs over the tile's ROWS, which the 16x16 accumulator layout keeps in
+// 4 lane groups x 4 registers (two xor-shuffles finish a column).  So a workgroup builds X from (x, t), runs the MLP
+// through small bf16 LDS tiles, produces each 16-column slice of the filter tile with RT MFMAs, normalises and pools
+// it in registers; nothing but the (P, K) result and the pooled contributions goes back to HBM.  The backward RECOMPUTES
+// all of that, forms d(logits) in registers, parks it in LDS as bf16 and runs the six backward products as MFMAs on
+// LDS tiles; weight / bias / time-embedding gradients are accumulated in registers across the patches of a persistent
+// workgroup and added to HBM once per workgroup.
+//
+// Column order: filter column c = k*F + f in the reference; here c' = f*32 + k (W3 is packed that way), so a 16-column
+// tile has ONE f: the pooling-path gradient of X (a sum over k) is a 16-lane shuffle reduction instead of 11k LDS
+// atomics per patch (measured: 40 us of an 88 us kernel).
+#include "ttcn.hpp"
+#include "../../include/immtsf.h"
+#include "common.hpp"
+
+namespace {
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KP = 32;        // padded ttcn_dim and padded feature width (one MFMA k-step)
+constexpr int PT = 40;        // pitch (bf16 elements) of the 32-wide LDS tiles: 80-byte rows, conflict-free b128 reads
+constexpr int MAXF = 4;       // f's per wave (F <= 16)
+
+struct FD { int P, L, F, K, NCq; };
+
+// slab of padded gradients (fp32), zeroed by the launcher: offsets in floats
+struct Slab { int W1, b1, W2, b2, W3, b3, te, Tb, total; };
+__host__ __device__ inline Slab slab_of(int F) {
+    Slab s;
+    int o = 0;
+    s.W1 = o; o += KP * KP;          // [k1][f]
+    s.b1 = o; o += KP;
+    s.W2 = o; o += KP * KP;          // [k2][k1]
+    s.b2 = o; o += KP;
+    s.W3 = o; o += F * 32 * KP;      // [c'][k2]
+    s.b3 = o; o += F * 32;
+    s.te = o; o += 2 * KP;           // [f] d/dw part, [32+f] d/db part
+    s.Tb = o; o += KP;
+    s.total = o;
+    return s;
+}
+
+__device__ __forceinline__ bf16x8 load8_bf16(const float* __restrict__ src) {     // 8 consecutive fp32 -> bf16x8 (RNE)
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    bf16x8 r;
+    r[0] = (bf16_t)a.x; r[1] = (bf16_t)a.y; r[2] = (bf16_t)a.z; r[3] = (bf16_t)a.w;
+    r[4] = (bf16_t)b.x; r[5] = (bf16_t)b.y; r[6] = (bf16_t)b.z; r[7] = (bf16_t)b.w;
+    return r;
+}
+__device__ __forceinline__ float col_sum(float v) {       // over the 4 lane groups that hold one column's rows
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float row_sum16(float v) {     // over the 16 lanes (columns) of a lane group
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+// A / B fragment from a row-major bf16 LDS tile: row = row0 + (lane & 15), k = k0 + (lane >> 4) * 8 ..
+__device__ __forceinline__ bf16x8 frag_row(const bf16_t* tile, int pitch, int row0, int k0, int fr, int fq) {
+    return *reinterpret_cast<const bf16x8*>(tile + (row0 + fr) * pitch + k0 + fq * 8);
+}
+// hardware-transpose read of a 16(row) x 8(k) bf16 fragment from a [k][row] LDS image (see gemm.hip)
+__device__ __forceinline__ bf16x8 frag_kmajor(const bf16_t* tile, int pitch, int rbase, int kbase, int fr, int fq) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int q = fr >> 2, pp = fr & 3;
+    const bf16_t* a0 = tile + (kbase + fq * 8 + q) * pitch + rbase + 4 * pp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+struct TEp { const float *ws, *bs, *wp, *bp; };
+
+// X[l, 0] = x ; X[l, 1] = ws*t+bs ; X[l, 1+j] = sin(wp_j t + bp_j) ; zero padding.  Xb: bf16 [ROWS][PT]; Xf: fp32 [ROWS][16]
+template <int RT>
+__device__ __forceinline__ void build_x(const FD& d, const float* __restrict__ x, const float* __restrict__ tt, TEp te, int p,
+                                        bf16_t* Xb, float* Xf) {
+    for (int i = threadIdx.x; i < RT * 16 * KP; i += 256) {
+        const int l = i >> 5, f = i & 31;
+        float v = 0.f;
+        if (l < d.L && f < d.F) {
+            const float t = tt[(size_t)p * d.L + l];
+            v = f == 0 ? x[(size_t)p * d.L + l] : f == 1 ? fmaf(te.ws[0], t, te.bs[0]) : sinf(fmaf(te.wp[f - 2], t, te.bp[f - 2]));
+        }
+        Xb[l * PT + f] = (bf16_t)v;
+        if (f < 16) Xf[l * 16 + f] = v;
+    }
+}
+
+// one MLP layer on LDS tiles: out[l, n] = relu(sum_k in[l, k] W[n, k] + b[n]); output tiles (rt, nt) dealt to the waves
+template <int RT>
+__device__ __forceinline__ void mlp_layer(const bf16_t* in, bf16_t* outp, const float* __restrict__ W, const float* __restrict__ b,
+                                          int wave, int fr, int fq) {
+    for (int t = wave; t < RT * 2; t += 4) {
+        const int rt = t >> 1, nt = t & 1;
+        const f32x4 acc = mfma(frag_row(in, PT, rt * 16, 0, fr, fq), load8_bf16(W + (nt * 16 + fr) * KP + fq * 8), zero4());
+        const float bias = b[nt * 16 + fr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outp[(rt * 16 + fq * 4 + r) * PT + nt * 16 + fr] = (bf16_t)fmaxf(acc[r] + bias, 0.f);
+    }
+}
+
+// One 16-column tile of the filter logits -> masked softmax over the patch's L rows, in registers.
+// sm[rt][r] = softmax weight of row rt*16 + fq*4 + r (0 for rows >= L)
+template <int RT>
+__device__ __forceinline__ void sm_tile(const FD& d, const bf16x8 (&a)[RT], const bf16x8 b, const float bias,
+                                        const float (&mk)[RT][4], int fq, float (&sm)[RT][4]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 acc = mfma(a[rt], b, zero4());
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + fq * 4 + r;
+            float v = -INFINITY;
+            if (row < d.L) v = (acc[r] + bias) * mk[rt][r] + (1.f - mk[rt][r]) * (-1e8f);
+            sm[rt][r] = v;
+            m = fmaxf(m, v);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sm[rt][r] = expf(sm[rt][r] - m);     // exp(-inf) = 0 for the padded rows
+            s += sm[rt][r];
+        }
+    s = col_sum(s);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[rt][r] *= inv;
+}
+
+struct Wts { const float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; };     // packed fp32 weights (ttcn_pack_kernel)
+
+// ---------------------------------------------------------------------------------------------------- forward
+// grid P, 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq]
+template <int RT>
+__global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
+                                                             const float* __restrict__ mask, TEp te, Wts w,
+                                                             const float* __restrict__ Tb, float* __restrict__ ctr,
+                                                             float* __restrict__ out, int out_ld, int flag_col) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWS = RT * 16;
+    bf16_t* Xb = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* h1s = Xb + ROWS * PT;
+    bf16_t* h2s = h1s + ROWS * PT;
+    float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);
+    float* cl = Xf + ROWS * 16;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    build_x<RT>(d, x, tt, te, p, Xb, Xf);
+    __syncthreads();
+    mlp_layer<RT>(Xb, h1s, w.W1p, w.b1p, wave, fr, fq);
+    __syncthreads();
+    mlp_layer<RT>(h1s, h2s, w.W2p, w.b2p, wave, fr, fq);
+    __syncthreads();
+    bf16x8 a[RT];
+    float mk[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + fq * 4 + r;
+            mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
+        }
+    }
+    for (int f = wave; f < d.F; f += 4) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int c = f * 32 + half * 16 + fr;
+            float sm[RT][4];
+            sm_tile<RT>(d, a, load8_bf16(w.W3q + (size_t)c * KP + fq * 8), w.b3q[c], mk, fq, sm);
+            float acc = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = fmaf(sm[rt][r], Xf[(rt * 16 + fq * 4 + r) * 16 + f], acc);   // sm is 0 past L
+            acc = col_sum(acc);
+            if (fq == 0) {
+                cl[c] = acc;
+                ctr[(size_t)p * d.NCq + c] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < d.K) {
+        float s = Tb[tid];
+        for (int f = 0; f < d.F; ++f) s += cl[f * 32 + tid];
+        out[(size_t)p * out_ld + tid] = fmaxf(s, 0.f);
+    }
+    if (flag_col >= 0 && tid == 64) {
+        float any = 0.f;
+        for (int l = 0; l < d.L; ++l) any += mask[(size_t)p * d.L + l];
+        out[(size_t)p * out_ld + flag_col] = any > 0.f ? 1.f : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- backward
+// transposed bf16 copies of the weights for the data-gradient products (ttcn_pack_kernel)
+struct WtsT { const bf16_t *W3T /*[k2][c']*/, *W2T /*[k1][k2]*/, *W1T /*[f][k1]*/; };
+
+// persistent workgroups, 256 threads.  LDS: Xb | h1s | h2s | dz2s | dz1s (bf16 [ROWS][PT]) | dS bf16 [ROWS][NCq+8] |
+// Xf, dXp fp32 [ROWS][16] | cts fp32 [NCq] | dp fp32 [32]
+template <int RT>
+__global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
+                                                             const float* __restrict__ mask, TEp te, Wts w, WtsT wt,
+                                                             const float* __restrict__ ctr, const float* __restrict__ out,
+                                                             const float* __restrict__ dout, int out_ld, float* __restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWS = RT * 16;
+    const int pitchC = d.NCq + 8;
+    bf16_t* Xb = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* h1s = Xb + ROWS * PT;
+    bf16_t* h2s = h1s + ROWS * PT;
+    bf16_t* dz2s = h2s + ROWS * PT;
+    bf16_t* dz1s = dz2s + ROWS * PT;
+    bf16_t* dS = dz1s + ROWS * PT;
+    float* Xf = reinterpret_cast<float*>(dS + ROWS * pitchC);
+    float* dXp = Xf + ROWS * 16;
+    float* cts = dXp + ROWS * 16;
+    float* dp = cts + d.NCq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const Slab sl = slab_of(d.F);
+
+    // ---- operands that never change: registers for the whole kernel
+    bf16x8 bw[MAXF][2];             // layer-3 B fragments of this wave's f's
+    float b3v[MAXF][2];
+    f32x4 accW3[MAXF][2][2];        // dW3 tiles: [f slot][half][k2 tile]
+    float accB3[MAXF][2];
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int f = wave + 4 * j, c = f * 32 + half * 16 + fr;
+            if (f < d.F) { bw[j][half] = load8_bf16(w.W3q + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
+            else { bw[j][half] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; b3v[j][half] = 0.f; }
+            accW3[j][half][0] = zero4(); accW3[j][half][1] = zero4();
+            accB3[j][half] = 0.f;
+        }
+    // per-wave tile roles of the 32x32 products: (tmt, tnt)
+    const int tnt = wave & 1, tmt = wave >> 1;
+    const bf16x8 w2t = *reinterpret_cast<const bf16x8*>(wt.W2T + (tnt * 16 + fr) * KP + fq * 8);     // dh1 = dz2 W2, k1 tile tnt
+    const bf16x8 w1t = *reinterpret_cast<const bf16x8*>(wt.W1T + fr * KP + fq * 8);                  // dXm = dz1 W1, f tile 0
+    f32x4 accW2 = zero4(), accW1 = zero4();
+    float accb = 0.f;               // tid < 32: db2[tid]; 64 <= tid < 96: db1[tid - 64]; 128 <= tid < 160: dT_bias[tid - 128]
+    float te_w = 0.f, te_b = 0.f;   // time-embedding gradients of column f = fr (waves that own a dXm tile)
+
+    for (int p = blockIdx.x; p < d.P; p += gridDim.x) {
+        // ---- stage
+        if (tid < KP) {
+            float g = 0.f;
+            if (tid < d.K) g = out[(size_t)p * out_ld + tid] > 0.f ? dout[(size_t)p * out_ld + tid] : 0.f;
+            dp[tid] = g;
+        }
+        for (int i = tid; i < d.NCq; i += 256) cts[i] = ctr[(size_t)p * d.NCq + i];
+        build_x<RT>(d, x, tt, te, p, Xb, Xf);
+        __syncthreads();
+        if (tid >= 128 && tid < 128 + KP) accb += dp[tid - 128];
+        mlp_layer<RT>(Xb, h1s, w.W1p, w.b1p, wave, fr, fq);
+        __syncthreads();
+        mlp_layer<RT>(h1s, h2s, w.W2p, w.b2p, wave, fr, fq);
+        __syncthreads();
+        bf16x8 a[RT];
+        float mk[RT][4];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + fq * 4 + r;
+                mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
+            }
+        }
+        // ---- d(logits), tile by tile in registers -> LDS (bf16); pooling-path dX by shuffles; db3
+#pragma unroll
+        for (int j = 0; j < MAXF; ++j) {
+            const int f = wave + 4 * j;
+            if (f < d.F) {
+                float dxs[RT][4];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dxs[rt][r] = 0.f;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int k = half * 16 + fr, c = f * 32 + k;
+                    float sm[RT][4];
+                    sm_tile<RT>(d, a, bw[j][half], b3v[j][half], mk, fq, sm);
+                    const float dpk = k < d.K ? dp[k] : 0.f, ct_c = cts[c];
+                    float colsum = 0.f;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = rt * 16 + fq * 4 + r;
+                            const float smd = sm[rt][r] * dpk;                       // 0 past L (sm) and past K (dpk)
+                            const float ds = smd * (Xf[row * 16 + f] - ct_c) * mk[rt][r];
+                            dS[row * pitchC + c] = (bf16_t)ds;
+                            colsum += ds;
+                            dxs[rt][r] += smd;
+                        }
+                    accB3[j][half] += col_sum(colsum);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float s = row_sum16(dxs[rt][r]);       // sum over the 32 k's of this f (two halves already added)
+                        if (fr == 0) dXp[(rt * 16 + fq * 4 + r) * 16 + f] = s;
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- dz2 = (dS W3) * [h2 > 0] -> LDS tile; dW3 += dS^T h2
+        for (int t = wave; t < RT * 2; t += 4) {
+            const int rt = t >> 1, nt = t & 1;
+            f32x4 acc = zero4();
+            for (int kk = 0; kk < d.NCq; kk += 32)
+                acc = mfma(frag_row(dS, pitchC, rt * 16, kk, fr, fq),
+                           *reinterpret_cast<const bf16x8*>(wt.W3T + (size_t)(nt * 16 + fr) * d.NCq + kk + fq * 8), acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (rt * 16 + fq * 4 + r) * PT + nt * 16 + fr;
+                dz2s[o] = (float)h2s[o] > 0.f ? (bf16_t)acc[r] : (bf16_t)0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MAXF; ++j) {
+            const int f = wave + 4 * j;
+            if (f < d.F) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int kk = 0; kk < ROWS; kk += 32) {
+                        const bf16x8 af = frag_kmajor(dS, pitchC, f * 32 + half * 16, kk, fr, fq);
+                        accW3[j][half][0] = mfma(af, frag_kmajor(h2s, PT, 0, kk, fr, fq), accW3[j][half][0]);
+                        accW3[j][half][1] = mfma(af, frag_kmajor(h2s, PT, 16, kk, fr, fq), accW3[j][half][1]);
+                    }
+            }
+        }
+        __syncthreads();
+        // ---- layer 2 backward: dW2 += dz2^T h1 (tile (tmt, tnt)); db2; dz1 = (dz2 W2) * [h1 > 0]
+#pragma unroll
+        for (int kk = 0; kk < ROWS; kk += 32)
+            accW2 = mfma(frag_kmajor(dz2s, PT, tmt * 16, kk, fr, fq), frag_kmajor(h1s, PT, tnt * 16, kk, fr, fq), accW2);
+        if (tid < KP) {
+            float s = 0.f;
+            for (int l = 0; l < d.L; ++l) s += (float)dz2s[l * PT + tid];
+            accb += s;
+        }
+        for (int t = wave; t < RT * 2; t += 4) {
+            const int rt = t >> 1;      // nt = t & 1 = wave & 1 = tnt (t advances by 4)
+            const f32x4 acc = mfma(frag_row(dz2s, PT, rt * 16, 0, fr, fq), w2t, zero4());
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (rt * 16 + fq * 4 + r) * PT + tnt * 16 + fr;
+                dz1s[o] = (float)h1s[o] > 0.f ? (bf16_t)acc[r] : (bf16_t)0.f;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 backward: dW1 += dz1^T X (f tile 0 only: F <= 16); db1; dX = dXpool + dz1 W1 -> time-embedding grads
+        if (wave < 2) {
+#pragma unroll
+            for (int kk = 0; kk < ROWS; kk += 32)
+                accW1 = mfma(frag_kmajor(dz1s, PT, wave * 16, kk, fr, fq), frag_kmajor(Xb, PT, 0, kk, fr, fq), accW1);
+        }
+        if (tid >= 64 && tid < 64 + KP) {
+            float s = 0.f;
+            for (int l = 0; l < d.L; ++l) s += (float)dz1s[l * PT + tid - 64];
+            accb += s;
+        }
+        for (int rt = (RT == 2 ? wave - 2 : wave); rt >= 0 && rt < RT; rt += 4) {      // RT = 2: waves 2, 3; RT = 4: all four
+            const f32x4 acc = mfma(frag_row(dz1s, PT, rt * 16, 0, fr, fq), w1t, zero4());
+            const int f = fr;
+            if (f >= 1 && f < d.F) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + fq * 4 + r;
+                    if (row < d.L) {
+                        const float g = acc[r] + dXp[row * 16 + f], t = tt[(size_t)p * d.L + row];
+                        const float gg = f == 1 ? g : g * cosf(fmaf(te.wp[f - 2], t, te.bp[f - 2]));
+                        te_w = fmaf(gg, t, te_w);
+                        te_b += gg;
+                    }
+                }
+            }
+        }
+        __syncthreads();     // every LDS tile is rewritten by the next patch
+    }
+
+    // ---- one atomic add per accumulated element per workgroup
+#pragma unroll
+    for (int j = 0; j < MAXF; ++j) {
+        const int f = wave + 4 * j;
+        if (f < d.F) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        atomicAdd(slab + sl.W3 + (size_t)(f * 32 + half * 16 + fq * 4 + r) * KP + nt * 16 + fr, accW3[j][half][nt][r]);
+                if (fq == 0) atomicAdd(slab + sl.b3 + f * 32 + half * 16 + fr, accB3[j][half]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        atomicAdd(slab + sl.W2 + (tmt * 16 + fq * 4 + r) * KP + tnt * 16 + fr, accW2[r]);
+        if (wave < 2) atomicAdd(slab + sl.W1 + (wave * 16 + fq * 4 + r) * KP + fr, accW1[r]);
+    }
+    if (tid < KP) atomicAdd(slab + sl.b2 + tid, accb);
+    else if (tid >= 64 && tid < 64 + KP) atomicAdd(slab + sl.b1 + tid - 64, accb);
+    else if (tid >= 128 && tid < 128 + KP) atomicAdd(slab + sl.Tb + tid - 128, accb);
+    te_w = col_sum(te_w);
+    te_b = col_sum(te_b);
+    if (fq == 0 && (RT == 4 || wave >= 2)) {
+        atomicAdd(slab + sl.te + fr, te_w);
+        atomicAdd(slab + sl.te + KP + fr, te_b);
+    }
+}
+
+// ---- packing: padded fp32 weights (+ the f-major W3), transposed bf16 copies; unpacking of the gradient slab
+struct PackIn { const float *W1, *b1, *W2, *b2, *W3, *b3; };
+__global__ __launch_bounds__(256) void ttcn_pack_kernel(int F, int K, PackIn q, float* W1p, float* b1p, float* W2p, float* b2p,
+                                                         float* W3q, float* b3q, bf16_t* W3T, bf16_t* W2T, bf16_t* W1T) {
+    const int i = blockIdx.x * 256 + threadIdx.x, NCq = F * 32;
+    if (i < KP * KP) {
+        const int r = i >> 5, c = i & 31;
+        const float v1 = (r < K && c < F) ? q.W1[r * F + c] : 0.f, v2 = (r < K && c < K) ? q.W2[r * K + c] : 0.f;
+        W1p[i] = v1;                      // [k1][f]
+        W2p[i] = v2;                      // [k2][k1]
+        W1T[c * KP + r] = (bf16_t)v1;     // [f][k1]
+        W2T[c * KP + r] = (bf16_t)v2;     // [k1][k2]
+    }
+    if (i < KP) { b1p[i] = i < K ? q.b1[i] : 0.f; b2p[i] = i < K ? q.b2[i] : 0.f; }
+    if (i < NCq * KP) {
+        const int c = i >> 5, kk = i & 31, f = c >> 5, k = c & 31;
+        const float v = (k < K && kk < K) ? q.W3[(size_t)(k * F + f) * K + kk] : 0.f;
+        W3q[i] = v;
+        W3T[(size_t)kk * NCq + c] = (bf16_t)v;
+    }
+    if (i < NCq) { const int f = i >> 5, k = i & 31; b3q[i] = k < K ? q.b3[k * F + f] : 0.f; }
+}
+
+struct UnpackOut { float *W1, *b1, *W2, *b2, *W3, *b3, *ws, *bs, *wp, *bp, *Tb; };
+__global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const float* __restrict__ slab, UnpackOut g) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const Slab sl = slab_of(F);
+    if (i < K * F) g.W1[i] = slab[sl.W1 + (i / F) * KP + i % F];
+    if (i < K * K) g.W2[i] = slab[sl.W2 + (i / K) * KP + i % K];
+    if (i < F * K * K) {
+        const int c = i / K, kk = i % K, k = c / F, f = c % F;
+        g.W3[i] = slab[sl.W3 + (size_t)(f * 32 + k) * KP + kk];
+    }
+    if (i < F * K) { const int k = i / F, f = i % F; g.b3[i] = slab[sl.b3 + f * 32 + k]; }
+    if (i < K) { g.b1[i] = slab[sl.b1 + i]; g.b2[i] = slab[sl.b2 + i]; g.Tb[i] = slab[sl.Tb + i]; }
+    if (i == 0) { g.ws[0] = slab[sl.te + 1]; g.bs[0] = slab[sl.te + KP + 1]; }
+    if (i < F - 2) { g.wp[i] = slab[sl.te + 2 + i]; g.bp[i] = slab[sl.te + KP + 2 + i]; }
+}
+
+size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + 64; }
+size_t bwd_lds(int RT, int NCq) {
+    const size_t ROWS = RT * 16;
+    return ROWS * PT * 2 * 5 + ROWS * (NCq + 8) * 2 + ROWS * 16 * 4 * 2 + (size_t)NCq * 4 + KP * 4 + 64;
+}
+
+struct PackPtrs { float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; bf16_t *W3T, *W2T, *W1T; };
+PackPtrs pack_ptrs(float* base, int F) {
+    PackPtrs q;
+    float* o = base;
+    q.W1p = o; o += KP * KP;
+    q.W2p = o; o += KP * KP;
+    q.b1p = o; o += KP;
+    q.b2p = o; o += KP;
+    q.W3q = o; o += (size_t)F * 32 * KP;
+    q.b3q = o; o += F * 32;
+    q.W3T = reinterpret_cast<bf16_t*>(o); o += (size_t)F * 32 * KP / 2;      // every block above is a multiple of 32 floats
+    q.W2T = reinterpret_cast<bf16_t*>(o); o += KP * KP / 2;
+    q.W1T = reinterpret_cast<bf16_t*>(o);
+    return q;
+}
+
+}  // namespace
+
+bool ttcn_full_supported(int precision, int L, int F, int K) {
+    return precision == 1 && K >= 1 && K <= 32 && F >= 2 && F <= 16 && L >= 1 && L <= 64;
+}
+size_t ttcn_full_pack_floats(int F) { return (size_t)2 * KP * KP + 2 * KP + (size_t)F * 32 * KP + F * 32 + (size_t)F * 32 * KP / 2 + KP * KP + 64; }
+size_t ttcn_full_slab_floats(int F) { return slab_of(F).total; }
+
+int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
+                         float* pack, float* ctr, float* out, int out_ld, int flag_col, hipStream_t s) {
+    const FD d{P, L, F, K, F * 32};
+    const PackPtrs q = pack_ptrs(pack, F);
+    hipLaunchKernelGGL(ttcn_pack_kernel, dim3(cdiv(F * 32 * KP, 256)), dim3(256), 0, s, F, K, PackIn{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3},
+                       q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q, q.W3T, q.W2T, q.W1T);
+    IMMTSF_LAUNCH_CHECK();
+    const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
+    const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
+    if (L <= 32) {
+        hipLaunchKernelGGL(ttcn_full_fwd_kernel<2>, dim3(P), dim3(256), fwd_lds(2, d.NCq), s, d, x, tt, mask, te, w, p->T_bias, ctr, out, out_ld,
+                           flag_col);
+    } else {
+        hipLaunchKernelGGL(ttcn_full_fwd_kernel<4>, dim3(P), dim3(256), fwd_lds(4, d.NCq), s, d, x, tt, mask, te, w, p->T_bias, ctr, out, out_ld,
+                           flag_col);
+    }
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
+                         const float* pack, const float* ctr, const float* out, const float* dout, int out_ld, float* slab,
+                         const immtsf_ttcn_params* gr, hipStream_t s) {
+    const FD d{P, L, F, K, F * 32};
+    const PackPtrs q = pack_ptrs(const_cast<float*>(pack), F);
+    hipError_t e = hipMemsetAsync(slab, 0, slab_of(F).total * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
+    const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
+    const WtsT wt{q.W3T, q.W2T, q.W1T};
+    const int grid = P < 768 ? P : 768;           // three persistent workgroups per CU
+    if (L <= 32) {
+        const size_t lds = bwd_lds(2, d.NCq);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ttcn_full_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, slab);
+    } else {
+        const size_t lds = bwd_lds(4, d.NCq);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ttcn_full_bwd_kernel<4>, dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, slab);
+    }
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(cdiv(F * K * K, 256)), dim3(256), 0, s, F, K, slab,
+                       UnpackOut{gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b,
+                                 gr->T_bias});
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}

@@ -163,7 +163,7 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
 
 
 @pytest.mark.parametrize("L", [32, 45, 7])
-def test_ttcn_fused_layer3_equals_streaming_bf16(L):
+def test_ttcn_on_chip_equals_streaming_bf16(L):
     """bf16 mode: the fused kernel pair (filter tile produced, normalised and pooled on chip; backward recomputes it)
     against the streaming formulation (filter tensor through HBM) -- same rounding points, so they must agree far
     inside the bf16 band -- and both against the fp32 eager formulation at the bf16 tolerance."""

@@ -255,13 +255,6 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     auto load_fast = [&](int k0, float4 (&ra)[CA], float4 (&rb)[CB]) {
         const unsigned ka = TA ? (unsigned)k0 * (unsigned)g.lda : (unsigned)k0;
         const unsigned kb = TB ? (unsigned)k0 * (unsigned)g.ldb : (unsigned)k0;
-#ifdef IMMTSF_EXPERIMENT_HALF_BYTES     // measurement only (tools/gemm_twin_bench.py): fetch half the bytes, as if the
-                                        // operands were stored as bf16; the results are garbage
-#pragma unroll
-        for (int i = 0; i < CA; ++i) { const float2 t = *reinterpret_cast<const float2*>(A + ((oa[i] + ka) >> 1)); ra[i] = make_float4(t.x, t.y, t.x, t.y); }
-#pragma unroll
-        for (int i = 0; i < CB; ++i) { const float2 t = *reinterpret_cast<const float2*>(Bp + ((ob[i] + kb) >> 1)); rb[i] = make_float4(t.x, t.y, t.x, t.y); }
-#else
 #pragma unroll
         for (int i = 0; i < CA; ++i) ra[i] = *reinterpret_cast<const float4*>(A + (oa[i] + ka));
         if (BBF) {
@@ -272,7 +265,6 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
 #pragma unroll
             for (int i = 0; i < CB; ++i) rb[i] = *reinterpret_cast<const float4*>(Bp + (ob[i] + kb));
         }
-#endif
     };
     // write one 4-element chunk of a staged tile.  `transposed`: the 4 values run along the tile's ROW index.
     auto put4 = [&](T* base, bool transposed, bool kmajor, int pitch, int BR, int c, const float4& v) {
@@ -884,6 +876,9 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             else if (tiles128 >= 512) v = 4;
             else if (layout == GEMM_TN || dyn_k || (g.K % 128) != 0) v = 11;
             else v = 14;
+            // (variant 17, a 64x96 tile = exactly one workgroup per CU at 2048x768, is 8 % faster in isolation -- 11.4 vs
+            // 12.5 us -- but its 87 KB of LDS leaves no room for the other stream's kernels on the CU: the step gets 1 %
+            // slower, r01j A/B 1.190 vs 1.176 ms.  Kept for tools/gemm_twin_bench.py only.)
             // reductions that are a multiple of 32 but not of 64 (padded small-model dims): 32-deep K tiles keep every
             // tile on the straight-line loader
             if (!dyn_k && (g.K % 64) != 0 && (g.K % 32) == 0 && g.K <= 512) v = 7;
@@ -906,6 +901,9 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
             case 14:
                 if (bbf) return launch_cfg<true, 64, 64, 128, 2, 4, false, true>(layout, g, Mmax, splits, stream);
                 return launch_cfg<true, 64, 64, 128, 2, 4>(layout, g, Mmax, splits, stream);
+            case 17:
+                if (bbf) return launch_cfg<true, 64, 96, 128, 4, 2, false, true>(layout, g, Mmax, splits, stream);
+                return launch_cfg<true, 64, 96, 128, 4, 2>(layout, g, Mmax, splits, stream);
             case 15: return launch_cfg<true, 64, 64, 64, 2, 2, true>(layout, g, Mmax, splits, stream);
             case 16: return launch_cfg<true, 64, 64, 32, 2, 2, true>(layout, g, Mmax, splits, stream);
             default: return IMMTSF_EINVAL;

@@ -19,6 +19,7 @@
 #include "ttcn.hpp"
 #include "../../include/immtsf.h"
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -539,7 +540,10 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
     const WtsT wt{q.W3T, q.W2T, q.W1T};
-    const int grid = P < 768 ? P : 768;           // three persistent workgroups per CU
+    // persistent workgroups, one per CU: measured 256 / 512 / 768 / 1024 -> backbone fwd+bwd 603 / 617 / 621 / 631 us
+    // (fewer workgroups = fewer end-of-kernel gradient atomics; the per-patch work is latency- not occupancy-bound)
+    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 256;
+    const int grid = P < gmax ? P : gmax;
     if (L <= 32) {
         const size_t lds = bwd_lds(2, d.NCq);
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -181,7 +181,7 @@ def main():
 
     from fusions.FusionModel import FusionModel
     from immtsf import _lib, config
-    from immtsf.ops import masked_mse
+    from immtsf.ops import backward_unit, masked_mse
     from immtsf.train import FlatTrainer, GraphedStep
     from models.tPatchGNN import tPatchGNN
     lib = _lib.load()
@@ -219,7 +219,7 @@ def main():
     def eager_step():
         trainer.zero_grad()
         loss = loss_fn()
-        loss.backward()
+        backward_unit(loss)
         trainer.sync_grads()
         trainer.step()
         return loss

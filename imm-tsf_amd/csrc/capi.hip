@@ -147,6 +147,14 @@ int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* m
     return launch_mse_sums(truth, pred, mask, rows, C, err_sum, cnt, scratch, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_masked_mse(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C, const float* cnt_global,
+                      float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, immtsf_stream_t stream) {
+    if (!truth || !pred || !mask || !loss || rows < 0 || C <= 0) return IMMTSF_EINVAL;
+    if ((int64_t)rows * C > IMMTSF_MSE_SMALL_MAX || C > 4096) return IMMTSF_EUNSUPPORTED;
+    return launch_mse_small(truth, pred, mask, rows, C, cnt_global, err_sum, cnt, loss, dpred, grad_scale,
+                            static_cast<hipStream_t>(stream));
+}
+
 int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
                              const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
                              immtsf_stream_t stream) {

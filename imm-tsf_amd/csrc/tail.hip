@@ -131,6 +131,61 @@ __global__ __launch_bounds__(256) void mse_finish_kernel(const float* __restrict
     }
 }
 
+// the three stages above in ONE workgroup, for the usual case of a prediction tensor of a few thousand elements and no
+// cross-rank reduction between the sums and the divide (the three launches are ~16 us of latency on the step's
+// critical path between the forward and the backward; this is one).  cnt_in != null: per-variable counts of the
+// global batch (data parallel without a collective in the step); err_sum / cnt are also written for the caller.
+__global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
+                                                          const float* __restrict__ mask, int rows, int C, int CT,
+                                                          const float* __restrict__ cnt_in, float* __restrict__ err_sum,
+                                                          float* __restrict__ cnt, float* __restrict__ loss,
+                                                          float* __restrict__ dpred, float grad_scale) {
+    extern __shared__ float sm[];              // se[C] | sn[C] | re[1024] | rc[1024]
+    float *se = sm, *sn = sm + C, *re = sm + 2 * C, *rc = re + 1024;
+    __shared__ float s_nav;
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int c = c0 + tx;
+        float e = 0.f, n = 0.f;
+        if (c < C)
+            for (int r = ty; r < rows; r += RT) {
+                const size_t i = (size_t)r * C + c;
+                const float dlt = truth[i] - pred[i], m = mask[i];
+                e = fmaf(dlt * dlt, m, e);
+                n += m;
+            }
+        re[threadIdx.x] = e;
+        rc[threadIdx.x] = n;
+        __syncthreads();
+        if (ty == 0 && c < C) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < RT; ++k) { a += re[k * CT + tx]; b += rc[k * CT + tx]; }
+            se[c] = a;
+            sn[c] = cnt_in ? cnt_in[c] : b;
+            if (err_sum) err_sum[c] = a;
+            if (cnt) cnt[c] = b;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float tot = 0.f, navail = 0.f;
+        for (int c = 0; c < C; ++c) {
+            tot += se[c] / (sn[c] + 1e-8f);
+            navail += (sn[c] != 0.f) ? 1.f : 0.f;
+        }
+        if (loss) loss[0] = tot / navail;
+        s_nav = navail;
+    }
+    __syncthreads();
+    if (!dpred) return;
+    const float navail = s_nav;
+    const size_t n = (size_t)rows * C;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const int c = (int)(i % C);
+        dpred[i] = grad_scale * 2.f * (pred[i] - truth[i]) * mask[i] / ((sn[c] + 1e-8f) * navail);
+    }
+}
+
 // ---- clip_grad_norm_ + Adam (main.py:1024,1098-1101) on one flat buffer -------------------------------------
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
     __shared__ float red[16];
@@ -225,6 +280,16 @@ int launch_mse_sums(const float* truth, const float* pred, const float* mask, in
     hipLaunchKernelGGL(mse_partial_kernel, dim3(kMseSlabs), dim3(256), 0, s, truth, pred, mask, rows, C, CT, scratch);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(mse_sums_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, s, scratch, C, err_sum, cnt);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_mse_small(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt_in,
+                     float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s) {
+    int CT = 1;
+    while (CT < C && CT < 64) CT <<= 1;
+    hipLaunchKernelGGL(mse_small_kernel, dim3(1), dim3(1024), (size_t)(2 * C + 2048) * sizeof(float), s, truth, pred, mask, rows, C, CT,
+                       cnt_in, err_sum, cnt, loss, dpred, grad_scale);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -16,6 +16,8 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
 
 int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
                     float* cnt, float* scratch, hipStream_t s);
+int launch_mse_small(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt_in,
+                     float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
 int launch_mse_finish(const float* truth, const float* pred, const float* mask, int rows, int C, const float* err_sum,
                       const float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
 

@@ -781,6 +781,15 @@ class MaskedMSEFn(torch.autograd.Function):
         _need_gpu(pred, truth, mask)
         Cc = pred.shape[-1]
         rows = pred.numel() // Cc
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        if group is None and rows * Cc <= _MSE_SMALL_MAX and Cc <= 4096:
+            # one single-workgroup kernel instead of three launches (they sit between the forward and the backward)
+            cnt = _c(global_cnt.to(torch.float32)) if global_cnt is not None else None
+            check(lib.immtsf_masked_mse(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(cnt) if cnt is not None else None, None,
+                                        None, ptr(loss), ptr(dpred), 1.0, stream_ptr()), "masked_mse")
+            ctx.save_for_backward(dpred)
+            return loss
         buf = torch.empty(2 + 128, Cc, dtype=torch.float32, device=pred.device)
         sums = buf[:2]
         check(lib.immtsf_masked_mse_sums(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(sums[1]),
@@ -791,8 +800,6 @@ class MaskedMSEFn(torch.autograd.Function):
         elif group is not None:
             import torch.distributed as dist
             dist.all_reduce(sums, group=group)
-        loss = torch.empty((), dtype=torch.float32, device=pred.device)
-        dpred = torch.empty_like(pred)
         check(lib.immtsf_masked_mse_finish(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(sums[0]), ptr(cnt), ptr(loss),
                                            ptr(dpred), 1.0, stream_ptr()), "masked_mse_finish")
         ctx.save_for_backward(dpred)
@@ -801,7 +808,33 @@ class MaskedMSEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dpred,) = ctx.saved_tensors
+        if is_unit_grad(dloss):      # d(loss)/d(loss) = 1 from backward_unit(): the saved gradient is the answer
+            return dpred, None, None, None, None
         return dpred * dloss, None, None, None, None
+
+
+_MSE_SMALL_MAX = 1 << 17        # IMMTSF_MSE_SMALL_MAX
+_unit_grads = {}
+
+
+def unit_grad(device) -> torch.Tensor:
+    """The constant scalar 1.0 that `backward_unit` seeds the backward pass with (one per device, never written)."""
+    key = (device.type, device.index)
+    t = _unit_grads.get(key)
+    if t is None:
+        t = _unit_grads[key] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def is_unit_grad(t: torch.Tensor) -> bool:
+    u = _unit_grads.get((t.device.type, t.device.index))
+    return u is not None and t.data_ptr() == u.data_ptr() and t.dim() == 0
+
+
+def backward_unit(loss: torch.Tensor):
+    """loss.backward() seeded with the cached constant 1.0: no fill kernel for the seed, and loss functions that saved
+    their input gradient (masked_mse) hand it on without a multiply -- two launches less between forward and backward."""
+    loss.backward(gradient=unit_grad(loss.device))
 
 
 def masked_mse(pred, truth, mask, group=None, global_cnt=None):

@@ -17,7 +17,7 @@ from typing import Iterable, List, Optional, Sequence
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 def shard_range(n_items: int, rank: int, world: int):
@@ -268,7 +268,7 @@ class GraphedStep:
     def _fwd_bwd(self):
         self.trainer.zero_grad()
         loss = self.loss_fn()
-        loss.backward()
+        ops.backward_unit(loss)
         self.trainer.collect_grads()
         return loss
 

@@ -197,8 +197,11 @@ typedef struct immtsf_ttcn_params {
 
 size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
 size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
-/* the three filter-generator layers run on the MFMA GEMM over all P*L slots (`precision` as everywhere), the masked
- * softmax + pooling are streaming kernels; `workspace` holds the saved-for-backward state.  out / dout have leading
+/* bf16 mode with L <= 64, te_dim <= 15, ttcn_dim <= 32: the whole encoder of a patch runs on one CU (time embedding,
+ * three filter-generator layers and the filter logits as MFMAs on LDS tiles, masked softmax and pooling in the
+ * accumulator registers), one kernel per direction; the backward recomputes the forward on chip.  Otherwise the three
+ * layers run on the MFMA GEMM over all P*L slots (`precision` as everywhere) and the masked softmax + pooling are
+ * streaming kernels.  `workspace` holds the saved-for-backward state in both cases.  out / dout have leading
  * dimension out_ld >= K; flag_col >= K (or -1): column that receives the patch-non-empty flag (any mask > 0), so the
  * caller's [embedding ; flag] concatenation (models/tPatchGNN.py:268-270) needs no extra kernels */
 int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
@@ -240,6 +243,14 @@ int immtsf_masked_mse_sums(const float* truth, const float* pred, const float* m
 int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
                              const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
                              immtsf_stream_t stream);
+
+/* the two calls above as ONE single-workgroup kernel, for rows*C <= IMMTSF_MSE_SMALL_MAX and no reduction across
+ * ranks between the sums and the divide (IMMTSF_EUNSUPPORTED otherwise: use the pair).  cnt_global (may be NULL):
+ * per-variable observation counts of the global batch, used for the divide instead of the local counts (data
+ * parallelism with the counts reduced when the batch was built).  err_sum, cnt, dpred may be NULL. */
+#define IMMTSF_MSE_SMALL_MAX (1 << 17)
+int immtsf_masked_mse(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C, const float* cnt_global,
+                      float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, immtsf_stream_t stream);
 
 /* ---- device-side batch builder: the reference's collate functions over a dataset that is
  * resident in HBM.  Replaces lib/parse_datasets.py:252-295 (variable_time_collate_fn), :298-366 +

@@ -389,6 +389,35 @@ def test_masked_mse_matches_oracle():
     assert _relerr(pg.grad, pc.grad) < 1e-5
 
 
+def test_masked_mse_single_kernel_vs_staged_and_unit_seed():
+    """The single-workgroup kernel (small inputs), the three-stage path (large inputs, or a process group) and the
+    oracle agree, with local and with global counts; backward_unit() seeds with the cached 1 and skips the multiply."""
+    dev = _dev()
+    from immtsf import ops
+    from oracle import fusion_ref as R
+    g = torch.Generator().manual_seed(3)
+    for shape in [(64, 32, 8), (7, 5, 3), (300, 64, 9)]:            # the last one is above IMMTSF_MSE_SMALL_MAX
+        t, p = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
+        mk = (torch.rand(*shape, generator=g) < 0.6).float()
+        mk[..., 0] = 0.0                                            # a variable that is never observed
+        pc = p.clone().requires_grad_(True)
+        ref = R.masked_mse(t, pc, mk)
+        ref.backward()
+        pg = p.to(dev).requires_grad_(True)
+        loss = ops.masked_mse(pg, t.to(dev), mk.to(dev))
+        ops.backward_unit(loss)
+        assert _relerr(loss, ref) < 1e-5
+        assert _relerr(pg.grad, pc.grad) < 1e-5
+        # global counts = 2x the local ones: loss and gradient halve
+        cnt = 2.0 * mk.reshape(-1, shape[-1]).sum(0).to(dev)
+        pg2 = p.to(dev).requires_grad_(True)
+        l2 = ops.masked_mse(pg2, t.to(dev), mk.to(dev), None, cnt)
+        l2.backward()
+        assert _relerr(l2, 0.5 * ref) < 1e-5
+        assert _relerr(pg2.grad, 0.5 * pc.grad) < 1e-5
+    assert ops.is_unit_grad(ops.unit_grad(dev)) and not ops.is_unit_grad(torch.ones((), device=dev))
+
+
 def test_long_ragged_llama_dims_fp32():
     """BASELINE configs[4] flavour (MIMIC-shaped): long ragged note sequences (N up to 1500 here, kernels are sized for
     4096), LLaMA-width embeddings d_m=4096 -> d_txt=768, T=32, C=8; few windows so the CPU oracle stays quick."""

@@ -157,7 +157,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
+    ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
+                    help="exploration only (DESIGN.md section 8, batch-size table): the metric is quoted on 64 windows per GPU")
     args = ap.parse_args()
+    globals()["B_PER_GPU"] = args.windows_per_gpu
     # stdout carries exactly one line, the JSON result: everything else a module prints (the fusion registry announces
     # its choices like the reference does) goes to stderr
     json_out, sys.stdout = sys.stdout, sys.stderr
@@ -387,7 +390,7 @@ def main():
             "launch": ("hipGraph replay (2 graphs/step)" if use_graph else "eager") +
                       ("" if args.no_overlap else ", backbone on a second HIP stream beside TTF"),
             "config": {"workload": "cfg2: tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT2 dims (d_m=d_txt=768, H=1), "
-                                   "64 ragged windows per GPU (N_b~U{1..32}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
+                                   f"{B_PER_GPU} ragged windows per GPU (N_b~U{{1..32}}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "sum_notes_rank0": sum_n,
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),

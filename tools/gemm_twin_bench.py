@@ -50,8 +50,12 @@ def bench(layout, M, N, K, cfg, twin=False):
 
 
 print("library:", os.path.basename(_lib.LIB_PATH))
-for layout, M, N, K in [(0, 2048, 768, 768), (1, 2048, 768, 768), (0, 2048, 1536, 768), (1, 2048, 1152, 768), (0, 1117, 1536, 768), (1, 1117, 1152, 768)]:
+shapes = [(0, 2048, 768, 768), (1, 2048, 768, 768), (0, 2048, 1536, 768), (1, 2048, 1152, 768), (0, 1117, 1536, 768), (1, 1117, 1152, 768)]
+if len(sys.argv) >= 5:          # gemm_twin_bench.py LAYOUT M N K [LAYOUT M N K ...]
+    a = [int(v) for v in sys.argv[1:]]
+    shapes = [tuple(a[i:i + 4]) for i in range(0, len(a) - 3, 4)]
+for layout, M, N, K in shapes:
     row = [f"{['NT','NN','TN'][layout]} {M}x{N}x{K}:"]
-    for v in (0, 11, 14, 17):
+    for v in (0, 4, 11, 14, 17):
         row.append(f"v{v} {bench(layout, M, N, K, v):7.1f} / twin {bench(layout, M, N, K, v, True):7.1f}")
     print("  ".join(row))

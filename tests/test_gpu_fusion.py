@@ -458,6 +458,85 @@ def test_cfg3_shape_patchtst_fusion_step():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+def test_cfg4_shape_timesnet_fusion_step():
+    """BASELINE configs[3] (one rank's shard): TimesNet + TTF_RecAvg + MMF_XAttn_Add, GDELT-shaped, 64 windows, C=8,
+    input_len = pred_len = 32, TimesNet d_model=16, d_ff=32, top_k=5, e_layers=2 (main.py:852-858): one full training
+    step on the HIP path in fp32 against the oracle for the fusion part (the backbone output is fed to both)."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    from immtsf.ops import masked_mse
+    from models.TimesNet import TimesNet
+    from oracle import fusion_ref as R
+    register_d_model("SYN768", 768)
+    config.precision = "fp32"
+    a = _args("TTF_RecAvg", "MMF_XAttn_Add", "SYN768", 768, 1, 8, dropout=0.0)
+    a.input_len = a.pred_len = 32
+    a.d_model, a.d_ff, a.top_k, a.e_layers, a.num_kernels, a.enc_in, a.c_out, a.batch_size = 16, 32, 5, 2, 6, 8, 8, 64
+    a.embed, a.freq = "fixed", "h"
+    torch.manual_seed(0)
+    model, fusion = TimesNet(a).to(dev).train(), FusionModel(a).to(dev).train()
+    notes, tau, t_hat, Y, up = _synthetic(5, 64, 32, 32, 8, 768, dev)
+    g = torch.Generator().manual_seed(4)
+    data = torch.randn(64, 32, 8, generator=g).to(dev)
+    mask = (torch.rand(64, 32, 8, generator=g) < 0.7).float().to(dev)
+    tp = torch.sort(torch.rand(64, 32, generator=g), 1).values.to(dev)
+    tmask = (up > 0).float()
+    pred = model.forecasting(t_hat.to(dev), data * mask, tp, mask)
+    out = fusion(notes.to(dev), tau.to(dev), t_hat.to(dev), pred)
+    loss = masked_mse(out, Y.to(dev), tmask.to(dev))
+    loss.backward()
+    assert out.shape == (64, 32, 8) and torch.isfinite(loss)
+    for k, p in fusion.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    got = [k for k, p in model.named_parameters() if p.grad is not None]      # the temporal embedding is unused (x_mark=None)
+    assert got and all(torch.isfinite(dict(model.named_parameters())[k].grad).all() for k in got)
+    prm = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in fusion.state_dict().items()}
+    ref = R.fusion_forward("TTF_RecAvg", "MMF_XAttn_Add", prm, notes, tau, t_hat, pred.detach().cpu(), H=1, kappa=0.5,
+                           expand_T=False)
+    R.masked_mse(Y, ref, tmask).backward()
+    assert _relerr(out, ref) < 1e-4
+    _check({k: _relerr(q.grad, prm[k].grad) for k, q in fusion.named_parameters()}, 3e-4)
+
+
+def test_cfg5_full_size_long_ragged_bf16():
+    """BASELINE configs[4] at its full per-GPU size: 64 windows, N_b ~ U{1..4096} notes (Sum N ~ 130 k), d_m = 4096 ->
+    d_txt = 768, T = 32, C = 8, bf16.  The oracle cannot run this (its K/V expansion alone is ~26 GB), so: finite loss
+    and gradients, the ragged index equals the lengths the batch was built with, and the first 4 windows give the same
+    result alone as inside the full batch (window independence at full size, bf16 tolerance)."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    register_d_model("SYN", 4096)
+    config.precision = "bf16"
+    try:
+        B, N, T, C = 64, 4096, 32, 8
+        torch.manual_seed(0)
+        m = FusionModel(_args("TTF_T2V_XAttn", "MMF_XAttn_Add", "SYN", 768, 1, C)).to(dev).train()
+        g = torch.Generator(device=dev).manual_seed(11)
+        lengths = torch.randint(1, N + 1, (B,), generator=g, device=dev)
+        lengths[0], lengths[1] = N, 1
+        keep = torch.arange(N, device=dev).view(1, N) < lengths.view(B, 1)
+        notes = torch.randn(B, N, 4096, generator=g, device=dev) * keep.unsqueeze(-1)
+        tau = torch.sort(torch.rand(B, N, generator=g, device=dev) * 24.0, 1).values * keep
+        t_hat = torch.sort(torch.rand(B, T, generator=g, device=dev), 1).values
+        Y = torch.randn(B, T, C, generator=g, device=dev).requires_grad_(True)
+        E, M = m.ttf(notes, tau, t_hat)
+        assert bool(M.all())
+        out = m.mmf(Y, E, M)
+        out.square().mean().backward()
+        assert torch.isfinite(out).all()
+        for k, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        with torch.no_grad():
+            sub = m(notes[:4].contiguous(), tau[:4].contiguous(), t_hat[:4].contiguous(), Y[:4].detach().contiguous())
+        assert _l2err(sub, out[:4]) < 3e-2
+    finally:
+        config.precision = "fp32"
+
+
 def test_timellm_offline_smoke():
     """TimeLLM wrapper with a random-init GPT-2 body (no hub access here): shapes and finite outputs/gradients only --
     full-forward parity with the reference is unpinned."""

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib, config
-from ._lib import FusionCfg, GCNParams, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
+from ._lib import DecoderParams, FusionCfg, GCNParams, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
 
 
 def _need_gpu(*ts):
@@ -463,6 +463,67 @@ def gcn_adaptive(x, order, nodevec1, nodevec2, gate1, gate2, lin1, lin2, mlp_con
     """x (B,N,M,D) -> (B,N,M,D); gate*: nn.Linear(D+nd,1), lin*: nn.Linear(D,nd), mlp_conv: the 1x1 nn.Conv2d."""
     return GCNAdaptiveFn.apply(x.float(), int(order), nodevec1, nodevec2, gate1.weight, gate1.bias, gate2.weight, gate2.bias,
                                lin1.weight, lin1.bias, lin2.weight, lin2.bias, mlp_conv.weight, mlp_conv.bias)
+
+
+class TPatchDecoderFn(torch.autograd.Function):
+    """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction, exact fp32.
+    Backward recomputes the forward; parameter gradients accumulate by atomics into one zeroed flat buffer."""
+
+    @staticmethod
+    def forward(ctx, h, te, *params):
+        lib = _lib.load()
+        h, te = _c(h), _c(te)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(h, te, *params)
+        B, N, D = h.shape
+        Lp, E = te.shape[1], te.shape[2]
+        H = params[2].shape[0]
+        out = torch.empty(B, Lp, N, dtype=torch.float32, device=h.device)
+        ps = _struct(DecoderParams, params)
+        check(lib.immtsf_tpatchgnn_decoder_forward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(out), stream_ptr()),
+              "tpatchgnn_decoder_forward")
+        ctx.dims = (B, N, Lp, D, E, H)
+        ctx.save_for_backward(h, te, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        h, te, *params = ctx.saved_tensors
+        B, N, Lp, D, E, H = ctx.dims
+        dout = dout.contiguous()
+        dh, dte = torch.empty_like(h), torch.empty_like(te)
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=h.device)
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        ps, gs = _struct(DecoderParams, params), _struct(DecoderParams, grads)
+        check(lib.immtsf_tpatchgnn_decoder_backward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh), ptr(dte),
+                                                    C.byref(gs), stream_ptr()), "tpatchgnn_decoder_backward")
+        return (dh, dte) + tuple(grads)
+
+
+def tpatch_decoder_supported(seq, N, Lp, D, E):
+    """seq: the reference's decoder nn.Sequential (Linear, ReLU, Linear, ReLU, Linear(H, 1))"""
+    mods = list(seq)
+    if len(mods) != 5 or not all(isinstance(m, torch.nn.Linear) for m in mods[0::2]) \
+            or not all(isinstance(m, torch.nn.ReLU) for m in mods[1::2]):
+        return False
+    l1, l2, l3 = mods[0], mods[2], mods[4]
+    H = l1.out_features
+    if l1.in_features != D + E or l2.in_features != H or l2.out_features != H or l3.in_features != H or l3.out_features != 1:
+        return False
+    if any(m.bias is None for m in (l1, l2, l3)):
+        return False
+    return _lib.load().immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) > 0
+
+
+def tpatch_decoder(seq, h, te):
+    """decoder(cat[h broadcast over Lp ; te broadcast over N]).squeeze(-1).permute(0, 2, 1) of models/tPatchGNN.py:283-291
+    without materialising the (B, N, Lp, D+E) tensor: h (B,N,D), te (B,Lp,E) -> (B,Lp,N)."""
+    l1, l2, l3 = seq[0], seq[2], seq[4]
+    return TPatchDecoderFn.apply(h.float(), te.float(), l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)
 
 
 # ------------------------------------------------------------------------------------------------ layer primitives

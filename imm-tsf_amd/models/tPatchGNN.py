@@ -235,8 +235,13 @@ class tPatchGNN(nn.Module):
         h = self.IMTS_Model(x_patch)                                     # (B,N,hid)
         Lp = time_steps_to_predict.shape[-1]
         # the reference repeats the prediction times over the N variables before embedding them (:283-285); the
-        # embedding is the same for every variable, so embed once and broadcast (expand's backward sums over N)
-        te_pred = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1)).expand(B, N, Lp, self.te_dim)
+        # embedding is the same for every variable, so embed once per window
+        te = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1))                     # (B,1,Lp,te_dim)
+        if self.patch_encoder != "torch":
+            from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
+            if tpatch_decoder_supported(self.decoder, N, Lp, h.shape[-1], self.te_dim):
+                return tpatch_decoder(self.decoder, h, te.view(B, Lp, self.te_dim))          # (B,Lp,N), one kernel
+        te_pred = te.expand(B, N, Lp, self.te_dim)                                         # expand's backward sums over N
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
         return self._mlp(self.decoder, h).squeeze(-1).permute(0, 2, 1)
 

@@ -234,6 +234,26 @@ int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, in
                                   const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
                                   immtsf_stream_t stream);
 
+/* ---- tPatchGNN forecast decoder (models/tPatchGNN.py:168-174 as applied at :283-291): Linear(D+E, H) -> ReLU ->
+ * Linear(H, H) -> ReLU -> Linear(H, 1) on [h[b, n] ; te[b, lp]] for every (b, n, lp), one kernel per direction (the
+ * first layer is separable in h and te; exact fp32 in both precision modes).  h: (B, N, D) encoder state, te: (B, Lp, E)
+ * time embedding of the prediction times, out / dout: (B, Lp, N).  H must be 32 (the reference's hid_dim) and N, Lp small enough for one
+ * window's vectors to sit in LDS: immtsf_tpatchgnn_decoder_lds_bytes returns 0 otherwise (callers then use the GEMM
+ * chain).  Pointers in nn.Sequential order: decoder.0 / .2 / .4 */
+typedef struct immtsf_decoder_params {
+    float *W1, *b1; /* (H, D+E), (H) */
+    float *W2, *b2; /* (H, H), (H)   */
+    float *W3, *b3; /* (1, H), (1)   */
+} immtsf_decoder_params;
+size_t immtsf_tpatchgnn_decoder_lds_bytes(int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H);
+int immtsf_tpatchgnn_decoder_forward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
+                                     const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream);
+/* dh (B, N, D) and dte (B, Lp, E) are overwritten; parameter gradients are ACCUMULATED (atomics) into `grads`, which the
+ * caller zeroes (or lets run on as a running sum).  Recomputes the forward: nothing is saved. */
+int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
+                                      const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
+                                      float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream);
+
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data
  * parallelism the caller all-reduces them before calling _finish).  scratch: >= 128*C floats.  loss: device scalar.

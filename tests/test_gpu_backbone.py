@@ -208,3 +208,42 @@ def test_ttcn_on_chip_equals_streaming_bf16(L):
         assert l2(res["fused"][1][k], res["stream"][1][k]) < 5e-3, k
         # vs fp32: inside the bf16 band, or no worse than the streaming bf16 path on cancellation-prone gradients
         assert l2(res["fused"][1][k], res["eager"][1][k]) < max(4e-2, 1.5 * l2(res["stream"][1][k], res["eager"][1][k])), k
+
+
+@pytest.mark.parametrize("B,N,Lp,D,E,H", [(64, 8, 32, 32, 10, 32), (3, 5, 7, 32, 4, 32), (2, 41, 70, 24, 10, 32),
+                                          (2, 3, 260, 32, 10, 32), (4, 6, 20, 48, 6, 32)])
+def test_fused_decoder_vs_eager(B, N, Lp, D, E, H):
+    """models/tPatchGNN.py:283-291: decoder(cat[h repeated over Lp ; te repeated over N]) as one kernel per direction
+    equals the eager nn.Sequential on the materialised (B, N, Lp, D+E) tensor -- outputs, data gradients and every
+    parameter gradient (fp32 both sides; shapes include several row chunks per window, Lp > 256 and D != H)."""
+    dev = _dev()
+    from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
+    torch.manual_seed(B * 1000 + Lp)
+    dec = torch.nn.Sequential(torch.nn.Linear(D + E, H), torch.nn.ReLU(inplace=True), torch.nn.Linear(H, H),
+                              torch.nn.ReLU(inplace=True), torch.nn.Linear(H, 1)).to(dev)
+    assert tpatch_decoder_supported(dec, N, Lp, D, E)
+    h = torch.randn(B, N, D, device=dev, requires_grad=True)
+    te = torch.randn(B, Lp, E, device=dev, requires_grad=True)
+    up = torch.randn(B, Lp, N, device=dev)
+    out = tpatch_decoder(dec, h, te)
+    (out * up).sum().backward()
+    got = [h.grad.clone(), te.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+    h.grad = te.grad = None
+    dec.zero_grad()
+    x = torch.cat([h.unsqueeze(2).expand(B, N, Lp, D), te.unsqueeze(1).expand(B, N, Lp, E)], dim=-1)
+    ref = dec(x.double().float()).squeeze(-1).permute(0, 2, 1)
+    (ref * up).sum().backward()
+    want = [h.grad, te.grad] + [p.grad for p in dec.parameters()]
+    assert out.shape == (B, Lp, N) and _rel(out, ref) < 1e-5
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert _rel(a, b) < 2e-5, i
+
+
+def test_fused_decoder_unsupported_shapes_fall_back():
+    dev = _dev()
+    from immtsf.ops import tpatch_decoder_supported
+    mk = lambda *mods: torch.nn.Sequential(*mods).to(dev)      # noqa: E731
+    L, R = torch.nn.Linear, torch.nn.ReLU
+    assert not tpatch_decoder_supported(mk(L(42, 64), R(), L(64, 64), R(), L(64, 1)), 8, 32, 32, 10)      # H != 32
+    assert not tpatch_decoder_supported(mk(L(42, 32), R(), L(32, 1)), 8, 32, 32, 10)                      # other depth
+    assert not tpatch_decoder_supported(mk(L(42, 32), R(), L(32, 32), R(), L(32, 1)), 2000, 2000, 32, 10)  # LDS

@@ -249,6 +249,151 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(float* __restrict
     for (int i = lane; i < S; i += 64) g[i] = p[i] * (g[i] - dot);
 }
 
+// ---- short-sequence self-attention on the packed in-projection output qkv (B, L, 3, H, E), L <= SHORT_L ----------
+// tPatchGNN attends over the M patches of one variable: M = 2 at the benchmark configuration, i.e. 512 sequences of
+// length 2.  As batched GEMMs + a row softmax that is 3 launches forward and 5 backward of ~8 us each for 2x2 score
+// matrices; here one thread owns one (sequence, head, position), everything in registers, one launch per direction.
+// Same arithmetic and the same dropout indexing (site, ((b*H+h)*L + l)*L + s) as the GEMM + softmax_rows path.
+constexpr int SHORT_L = 8;
+constexpr int SHORT_EV = 16;      // float4 chunks per row: head dim <= 64, multiple of 4
+
+struct ShortDims { int B, L, H, E; };
+
+// one row of E floats as (predicated) float4 chunks: every chunk is an independent 16-byte load, issued back to back
+__device__ __forceinline__ void short_load(const float* __restrict__ p, int ev, float4 (&r)[SHORT_EV]) {
+#pragma unroll
+    for (int c = 0; c < SHORT_EV; ++c) r[c] = c < ev ? reinterpret_cast<const float4*>(p)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ float short_dot(const float4 (&a)[SHORT_EV], const float4 (&b)[SHORT_EV]) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < SHORT_EV; ++c) {
+        s = fmaf(a[c].x, b[c].x, s); s = fmaf(a[c].y, b[c].y, s); s = fmaf(a[c].z, b[c].z, s); s = fmaf(a[c].w, b[c].w, s);
+    }
+    return s;
+}
+__device__ __forceinline__ void short_axpy(float w, const float4 (&x)[SHORT_EV], float4 (&acc)[SHORT_EV]) {
+#pragma unroll
+    for (int c = 0; c < SHORT_EV; ++c) {
+        acc[c].x = fmaf(w, x[c].x, acc[c].x); acc[c].y = fmaf(w, x[c].y, acc[c].y);
+        acc[c].z = fmaf(w, x[c].z, acc[c].z); acc[c].w = fmaf(w, x[c].w, acc[c].w);
+    }
+}
+__device__ __forceinline__ void short_store(float* __restrict__ p, int ev, float scale, const float4 (&r)[SHORT_EV]) {
+#pragma unroll
+    for (int c = 0; c < SHORT_EV; ++c)
+        if (c < ev) reinterpret_cast<float4*>(p)[c] = make_float4(scale * r[c].x, scale * r[c].y, scale * r[c].z, scale * r[c].w);
+}
+
+// element offsets inside the packed (B, L, 3, H, E) tensor
+__device__ __forceinline__ size_t short_off(const ShortDims& d, int b, int l, int which, int h) {
+    return (((size_t)b * d.L + l) * 3 + which) * d.H * d.E + (size_t)h * d.E;
+}
+
+// scores of query row l of (b, h): p[s] = softmax_s(scale q[l].k[s]) (causal: s <= l), a[s] = p[s] * dropscale
+__device__ __forceinline__ void short_row(const ShortDims& d, const float* __restrict__ qkv, int b, int h, int l, float scale,
+                                          int causal, const DropCfg& drop, uint64_t site, float (&p)[SHORT_L], float (&a)[SHORT_L]) {
+    const int ev = d.E >> 2, Sv = causal ? l + 1 : d.L;
+    float4 q[SHORT_EV], k[SHORT_EV];
+    short_load(qkv + short_off(d, b, l, 0, h), ev, q);
+    float m = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SHORT_L; ++s) {
+        float acc = 0.f;
+        if (s < Sv) {
+            short_load(qkv + short_off(d, b, s, 1, h), ev, k);
+            acc = scale * short_dot(q, k);
+            m = fmaxf(m, acc);
+        }
+        p[s] = acc;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < SHORT_L; ++s) {
+        p[s] = s < Sv ? expf(p[s] - m) : 0.f;
+        sum += p[s];
+    }
+    const float inv = 1.f / sum;
+    const uint64_t row = ((uint64_t)b * d.H + h) * d.L + l;
+#pragma unroll
+    for (int s = 0; s < SHORT_L; ++s) {
+        p[s] *= inv;
+        a[s] = s < d.L ? p[s] * dropout_scale(drop, site, row * d.L + s) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_short_fwd_kernel(ShortDims d, const float* __restrict__ qkv, float scale, int causal,
+                                                              DropCfg drop, uint64_t site, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.B * d.H * d.L) return;
+    const int l = i % d.L, h = (i / d.L) % d.H, b = i / (d.L * d.H), ev = d.E >> 2;
+    float p[SHORT_L], a[SHORT_L];
+    short_row(d, qkv, b, h, l, scale, causal, drop, site, p, a);
+    float4 acc[SHORT_EV], v[SHORT_EV];
+#pragma unroll
+    for (int c = 0; c < SHORT_EV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < SHORT_L; ++s)
+        if (s < d.L) {
+            short_load(qkv + short_off(d, b, s, 2, h), ev, v);
+            short_axpy(a[s], v, acc);
+        }
+    short_store(out + (((size_t)b * d.L + l) * d.H + h) * d.E, ev, 1.f, acc);
+}
+
+// thread (b, h, i): as query row i -> dq[i]; as key / value row i -> dk[i], dv[i] (recomputing every query row's softmax)
+__global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              float scale, int causal, DropCfg drop, uint64_t site,
+                                                              float* __restrict__ dqkv) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.B * d.H * d.L) return;
+    const int i = t % d.L, h = (t / d.L) % d.H, b = t / (d.L * d.H), ev = d.E >> 2;
+    float wk[SHORT_L], wv[SHORT_L], wq[SHORT_L];      // dS[l][i] (l = 0..), A[l][i], dS[i][s]
+#pragma unroll
+    for (int l = 0; l < SHORT_L; ++l) { wk[l] = 0.f; wv[l] = 0.f; wq[l] = 0.f; }
+#pragma unroll
+    for (int l = 0; l < SHORT_L; ++l) {
+        if (l < d.L) {
+            float p[SHORT_L], a[SHORT_L], dp[SHORT_L];
+            short_row(d, qkv, b, h, l, scale, causal, drop, site, p, a);
+            float4 g[SHORT_EV], v[SHORT_EV];
+            short_load(dout + (((size_t)b * d.L + l) * d.H + h) * d.E, ev, g);
+            const uint64_t row = ((uint64_t)b * d.H + h) * d.L + l;
+            float dot = 0.f;
+#pragma unroll
+            for (int s = 0; s < SHORT_L; ++s) {
+                float acc = 0.f;
+                if (s < d.L) {
+                    short_load(qkv + short_off(d, b, s, 2, h), ev, v);
+                    acc = short_dot(g, v) * dropout_scale(drop, site, row * d.L + s);
+                }
+                dp[s] = acc;
+                dot = fmaf(p[s], acc, dot);
+            }
+#pragma unroll
+            for (int s = 0; s < SHORT_L; ++s) {
+                const float ds = p[s] * (dp[s] - dot);
+                if (s == i) { wk[l] = ds; wv[l] = a[s]; }
+                if (l == i) wq[s] = ds;
+            }
+        }
+    }
+    float4 acc[SHORT_EV], x[SHORT_EV];
+    for (int which = 0; which < 3; ++which) {      // dq[i] = scale sum_j dS[i][j] k[j]; dk[i] = scale sum_j dS[j][i] q[j]; dv[i] = sum_j A[j][i] dout[j]
+#pragma unroll
+        for (int c = 0; c < SHORT_EV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < SHORT_L; ++j)
+            if (j < d.L) {
+                const float* src = which == 0 ? qkv + short_off(d, b, j, 1, h)
+                                 : which == 1 ? qkv + short_off(d, b, j, 0, h) : dout + (((size_t)b * d.L + j) * d.H + h) * d.E;
+                short_load(src, ev, x);
+                short_axpy(which == 0 ? wq[j] : which == 1 ? wk[j] : wv[j], x, acc);
+            }
+        short_store(dqkv + short_off(d, b, i, which, h), ev, which == 2 ? 1.f : scale, acc);
+    }
+}
+
 }  // namespace
 
 int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
@@ -295,6 +440,30 @@ int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int 
     const int rows = B * H * L;
     if (rows <= 0) return IMMTSF_OK;
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dA, P, rows, S, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_attn_short_fwd(const float* qkv, int B, int L, int H, int E, float scale, int causal, DropCfg drop, uint64_t site,
+                          float* out, hipStream_t s) {
+    if (L > SHORT_L || E > 4 * SHORT_EV || (E & 3) || (reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return IMMTSF_EUNSUPPORTED;
+    const int n = B * H * L;
+    if (n <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(attn_short_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, scale, causal, drop, site, out);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int H, int E, float scale, int causal, DropCfg drop,
+                          uint64_t site, float* dqkv, hipStream_t s) {
+    if (L > SHORT_L || E > 4 * SHORT_EV || (E & 3) || ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout) |
+                                                        reinterpret_cast<uintptr_t>(dqkv)) & 15))
+        return IMMTSF_EUNSUPPORTED;
+    const int n = B * H * L;
+    if (n <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(attn_short_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, dout, scale, causal, drop,
+                       site, dqkv);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -23,3 +23,10 @@ int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, con
 // dA -> dS in place: dP = dA*dropscale; dS = P*(dP - sum(P*dP))
 int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int S, DropCfg drop, uint64_t site,
                             hipStream_t s);
+
+// self-attention over sequences of at most IMMTSF_ATTN_SHORT_MAX positions on the packed in-projection output
+// qkv (B, L, 3, H, E): out (B, L, H, E); backward recomputes the softmax and writes dqkv (B, L, 3, H, E)
+int launch_attn_short_fwd(const float* qkv, int B, int L, int H, int E, float scale, int causal, DropCfg drop, uint64_t site,
+                          float* out, hipStream_t s);
+int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int H, int E, float scale, int causal, DropCfg drop,
+                          uint64_t site, float* dqkv, hipStream_t s);

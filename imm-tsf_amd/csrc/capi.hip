@@ -107,6 +107,24 @@ int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H
     return launch_softmax_rows_bwd(dA, P, B, H, L, S, d, site, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_attention_short_forward(const float* qkv, int32_t B, int32_t L, int32_t H, int32_t E, float scale, int32_t causal,
+                                   float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, float* out,
+                                   immtsf_stream_t stream) {
+    if (!qkv || !out || B < 0 || L <= 0 || H <= 0 || E <= 0) return IMMTSF_EINVAL;
+    DropCfg d = mk_drop(p_drop, seed);
+    d.seed_dev = seed_step_dev;
+    return launch_attn_short_fwd(qkv, B, L, H, E, scale, causal, d, site, out, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_attention_short_backward(const float* qkv, const float* dout, int32_t B, int32_t L, int32_t H, int32_t E, float scale,
+                                    int32_t causal, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev,
+                                    float* dqkv, immtsf_stream_t stream) {
+    if (!qkv || !dout || !dqkv || B < 0 || L <= 0 || H <= 0 || E <= 0) return IMMTSF_EINVAL;
+    DropCfg d = mk_drop(p_drop, seed);
+    d.seed_dev = seed_step_dev;
+    return launch_attn_short_bwd(qkv, dout, B, L, H, E, scale, causal, d, site, dqkv, static_cast<hipStream_t>(stream));
+}
+
 int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
                              float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,
                              immtsf_stream_t stream) {

@@ -127,8 +127,8 @@ __device__ __forceinline__ void sm_tile(const FD& d, const bf16x8 (&a)[RT], cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rt * 16 + fq * 4 + r;
-            float v = -INFINITY;
-            if (row < d.L) v = (acc[r] + bias) * mk[rt][r] + (1.f - mk[rt][r]) * (-1e8f);
+            // reference: Filter * mask + (1 - mask) * (-1e8); mask is 0 / 1, so this select is the same value
+            const float v = row < d.L ? (mk[rt][r] != 0.f ? acc[r] + bias : -1e8f) : -INFINITY;
             sm[rt][r] = v;
             m = fmaxf(m, v);
         }
@@ -140,11 +140,11 @@ __device__ __forceinline__ void sm_tile(const FD& d, const bf16x8 (&a)[RT], cons
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            sm[rt][r] = expf(sm[rt][r] - m);     // exp(-inf) = 0 for the padded rows
+            sm[rt][r] = __expf(sm[rt][r] - m);   // exp(-inf) = 0 for the padded rows; bf16 mode: the fast exp is ample
             s += sm[rt][r];
         }
     s = col_sum(s);
-    const float inv = 1.f / s;
+    const float inv = __frcp_rn(s);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll

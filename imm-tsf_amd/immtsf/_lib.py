@@ -152,6 +152,10 @@ _PROTOS = {
                                               C.c_float, C.c_uint64, C.c_uint64, C.c_int32, C.c_void_p, c_stream]),
     "immtsf_softmax_rows_backward": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                                C.c_uint64, C.c_uint64, C.c_void_p, c_stream]),
+    "immtsf_attention_short_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                                 C.c_uint64, C.c_uint64, C.c_void_p, c_f32p, c_stream]),
+    "immtsf_attention_short_backward": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                                  C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, c_f32p, c_stream]),
     "immtsf_layernorm_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p,
                                            c_f32p, C.c_float, C.c_uint64, C.c_uint64, c_stream]),
     "immtsf_layernorm_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,

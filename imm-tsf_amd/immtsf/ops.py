@@ -818,8 +818,45 @@ class FullAttentionQKVFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
+ATTN_SHORT_MAX = 8      # IMMTSF_ATTN_SHORT_MAX
+
+
+class ShortAttentionQKVFn(torch.autograd.Function):
+    """FullAttentionQKVFn for sequences of at most ATTN_SHORT_MAX positions: one thread per (sequence, head, position), one
+    launch per direction, exact fp32, same dropout stream; the backward recomputes the softmax (nothing but qkv is saved)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, p_drop, training, seed, site, causal):
+        lib = _lib.load()
+        qkv = _c(qkv)
+        _need_gpu(qkv)
+        B, L, three, H, E = qkv.shape
+        assert three == 3 and L <= ATTN_SHORT_MAX
+        p = float(p_drop) if training else 0.0
+        cnt = config.dropout_counter_ptr(qkv.device) if p > 0 else None
+        out = torch.empty(B, L, H, E, dtype=torch.float32, device=qkv.device)
+        check(lib.immtsf_attention_short_forward(ptr(qkv), B, L, H, E, float(scale), 1 if causal else 0, p, seed, site, cnt,
+                                                 ptr(out), stream_ptr()), "attention_short_forward")
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (float(scale), p, seed, site, 1 if causal else 0, cnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (qkv,) = ctx.saved_tensors
+        scale, p, seed, site, causal, cnt = ctx.cfg
+        B, L, _, H, E = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        check(lib.immtsf_attention_short_backward(ptr(qkv), ptr(dout.contiguous()), B, L, H, E, scale, causal, p, seed, site, cnt,
+                                                  ptr(dqkv), stream_ptr()), "attention_short_backward")
+        return dqkv, None, None, None, None, None, None
+
+
 def full_attention_qkv(qkv, scale, p_drop=0.0, training=False, seed=0, site=16, causal=False, precision=None):
     """qkv (B, L, 3, H, E) -> (B, L, H, E)"""
+    if qkv.shape[1] <= ATTN_SHORT_MAX and qkv.shape[4] <= 64 and qkv.shape[4] % 4 == 0:
+        return ShortAttentionQKVFn.apply(qkv.float(), scale, p_drop, training, seed, site, causal)
     return FullAttentionQKVFn.apply(qkv.float(), scale, p_drop, training, seed, site, causal, config.precision_code(precision))
 
 

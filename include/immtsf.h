@@ -346,6 +346,19 @@ int immtsf_softmax_rows_forward(float* sc, float* A, int32_t B, int32_t H, int32
                                 immtsf_stream_t stream);
 int immtsf_softmax_rows_backward(float* dA, const float* P, int32_t B, int32_t H, int32_t L, int32_t S, float p_drop,
                                  uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, immtsf_stream_t stream);
+/* FullAttention over SHORT sequences (L <= IMMTSF_ATTN_SHORT_MAX; tPatchGNN attends over M = 2 patches) on the packed
+ * in-projection output qkv (B, L, 3, H, E): out (B, L, H, E) = dropout(softmax(scale q k^T [causal])) v with one thread per
+ * (sequence, head, position) -- one launch per direction instead of 2 batched GEMMs + softmax (3 + 5 launches).  Same
+ * dropout stream as immtsf_softmax_rows_* (site, ((b*H+h)*L + l)*L + s).  The backward recomputes the softmax and
+ * overwrites dqkv (B, L, 3, H, E).  Exact fp32.  IMMTSF_EUNSUPPORTED when L is larger, E > 64, E % 4 != 0 or a pointer is
+ * not 16-byte aligned. */
+#define IMMTSF_ATTN_SHORT_MAX 8
+int immtsf_attention_short_forward(const float* qkv, int32_t B, int32_t L, int32_t H, int32_t E, float scale, int32_t causal,
+                                   float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, float* out,
+                                   immtsf_stream_t stream);
+int immtsf_attention_short_backward(const float* qkv, const float* dout, int32_t B, int32_t L, int32_t H, int32_t E, float scale,
+                                    int32_t causal, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev,
+                                    float* dqkv, immtsf_stream_t stream);
 /* LayerNorm(+dropout) rows: xhat,rstd may be NULL in forward when no backward follows */
 int immtsf_layernorm_forward(const float* x, int32_t rows, int32_t d, const float* gamma, const float* beta, float eps,
                              float* xhat, float* rstd, float* z, float p_drop, uint64_t seed, uint64_t site,

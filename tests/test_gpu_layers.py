@@ -201,7 +201,7 @@ def test_packed_qkv_attention_equals_sliced():
     from immtsf import config, ops
     config.precision = "fp32"
     torch.manual_seed(4)
-    for B, L, H, E in [(512, 2, 1, 32), (5, 19, 3, 8)]:
+    for B, L, H, E in [(512, 2, 1, 32), (5, 19, 3, 8), (7, 8, 2, 24), (3, 1, 1, 64), (3, 2, 1, 5)]:      # L <= 8, E % 4 == 0, E <= 64: the one-thread-per-row kernel
         qkv = torch.randn(B, L, 3, H, E, device=dev)
         a, b = qkv.clone().requires_grad_(True), qkv.clone().requires_grad_(True)
         up = torch.randn(B, L, H, E, device=dev)
@@ -210,3 +210,22 @@ def test_packed_qkv_attention_equals_sliced():
         (o1 * up).sum().backward()
         (o2 * up).sum().backward()
         assert _rel(o2, o1.detach().cpu()) < 1e-6 and _rel(b.grad, a.grad.cpu()) < 1e-6
+
+
+def test_short_attention_causal_and_dropout_equal_the_gemm_path():
+    """L <= ATTN_SHORT_MAX routes full_attention_qkv to the one-launch kernel: causal masking and train-mode dropout (same
+    Philox site / index stream) give what the batched-GEMM + row-softmax formulation gives, forward and backward."""
+    dev = _dev()
+    from immtsf import config, ops
+    config.precision = "fp32"
+    torch.manual_seed(9)
+    for causal, p in [(True, 0.0), (False, 0.3), (True, 0.25)]:
+        B, L, H, E = 33, 6, 2, 16
+        qkv = torch.randn(B, L, 3, H, E, device=dev)
+        a, b = qkv.clone().requires_grad_(True), qkv.clone().requires_grad_(True)
+        up = torch.randn(B, L, H, E, device=dev)
+        o1 = ops.FullAttentionQKVFn.apply(a, E ** -0.5, p, True, 77, 21, causal, 0)
+        o2 = ops.full_attention_qkv(b, E ** -0.5, p, True, 77, 21, causal)
+        (o1 * up).sum().backward()
+        (o2 * up).sum().backward()
+        assert _rel(o2, o1.detach().cpu()) < 1e-5 and _rel(b.grad, a.grad.cpu()) < 1e-5, (causal, p)

@@ -200,6 +200,9 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         g.row_flag = M_txt; g.row_flag_div = T;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
+    if (xadd_head_supported(C, d))        // residual_head + LayerNorm(C) + dropout + blend in one kernel (w.delta stays unused)
+        return launch_xadd_head_fwd(w.U, p->res_w, p->res_b, Y_ts, M_txt, BT, T, C, d, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC,
+                                    Y_out, drop, SITE_XADD_OUT, s);
     {   // residual_head
         GemmArgs g = gemm_args(BT, C, d, d, d, C);
         set_problem(g, 0, w.U, p->res_w, w.delta, p->res_b);

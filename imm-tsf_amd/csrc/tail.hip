@@ -157,9 +157,12 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
         re[threadIdx.x] = e;
         rc[threadIdx.x] = n;
         __syncthreads();
+        for (int st = RT >> 1; st > 0; st >>= 1) {      // tree over the row lanes (RT is a power of two): log2(RT) steps, not RT
+            if (ty < st) { re[threadIdx.x] += re[threadIdx.x + st * CT]; rc[threadIdx.x] += rc[threadIdx.x + st * CT]; }
+            __syncthreads();
+        }
         if (ty == 0 && c < C) {
-            float a = 0.f, b = 0.f;
-            for (int k = 0; k < RT; ++k) { a += re[k * CT + tx]; b += rc[k * CT + tx]; }
+            const float a = re[tx], b = rc[tx];
             se[c] = a;
             sn[c] = cnt_in ? cnt_in[c] : b;
             if (err_sum) err_sum[c] = a;

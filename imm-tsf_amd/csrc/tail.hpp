@@ -14,6 +14,13 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
                         const float* xhat, const float* rstd, float kappa, float* dY, float* dn, float* ddelta,
                         DropCfg drop, uint64_t site, hipStream_t s);
 
+// the forward output head of MMF_XAttn_Add in one kernel (xadd_head.hip): residual_head Linear(d -> C) on U, LayerNorm(C),
+// dropout, no-text zeroing, kappa blend; saves xhat / rstd like launch_ln_blend_fwd.  C <= 16, d <= 1024, d % 4 == 0.
+bool xadd_head_supported(int C, int d);
+int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const float* Y, const unsigned char* mtxt, int BT, int T,
+                         int C, int d, const float* gamma, const float* beta, float kappa, float* xhat, float* rstd, float* Yout,
+                         DropCfg drop, uint64_t site, hipStream_t s);
+
 int launch_mse_sums(const float* truth, const float* pred, const float* mask, int rows, int C, float* err_sum,
                     float* cnt, float* scratch, hipStream_t s);
 int launch_mse_small(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt_in,

@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
+    ap.add_argument("--no-wgrad-fork", action="store_true",
+                    help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
                     help="exploration only (DESIGN.md section 8, batch-size table): the metric is quoted on 64 windows per GPU")
     args = ap.parse_args()
@@ -190,6 +192,8 @@ def main():
     lib = _lib.load()
     if args.gemm_config:
         lib.immtsf_debug_gemm_config(args.gemm_config, 0)
+    if args.no_wgrad_fork:
+        lib.immtsf_set_side_stream(0)
     config.precision = args.precision
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
     config.manual_seed(1234 + rank)

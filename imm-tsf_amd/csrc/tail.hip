@@ -190,26 +190,31 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
 }
 
 // ---- clip_grad_norm_ + Adam (main.py:1024,1098-1101) on one flat buffer -------------------------------------
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+// 16-byte loads (the flat buffers are 16-byte aligned; a tail of < 4 elements is handled by the last threads).  The
+// first thread also advances the device-side step / dropout counters when given (graph replay: one launch less).
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, int vec, float* __restrict__ part,
+                                                              long long* step_dev, unsigned long long* drop_dev) {
     __shared__ float red[16];
-    float a = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a = fmaf(g[i], g[i], a);
-    a = block_sum(a, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = a;
-}
-
-__global__ void bump_counters_kernel(long long* step_dev, unsigned long long* drop_dev) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        step_dev[0] += 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (step_dev) step_dev[0] += 1;
         if (drop_dev) drop_dev[0] += 1;
     }
+    float a = 0.f;
+    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(g)[i];
+        a = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, a))));
+    }
+    for (size_t i = (n4 << 2) + t0; i < n; i += stride) a = fmaf(g[i], g[i], a);
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
-                                                    const long long* __restrict__ step_dev, bf16_t* __restrict__ twin) {
+                                                    const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec) {
     __shared__ float red[16];
     if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)
         const float st = (float)step_dev[0];
@@ -222,16 +227,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(1.f, max_norm / (total + 1e-6f));
     const float step = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float gi = g[i] * coef;
-        if (wd != 0.f) gi = fmaf(wd, p[i], gi);
-        const float mi = fmaf(b1, m[i], (1.f - b1) * gi);
-        const float vi = fmaf(b2, v[i], (1.f - b2) * gi * gi);
-        m[i] = mi;
-        v[i] = vi;
-        const float pn = p[i] - step * mi / (sqrtf(vi) / bc2s + eps);
-        p[i] = pn;
-        if (twin) twin[i] = (bf16_t)pn;      // bf16 twin of the parameters (the GEMMs' weight operand), kept current here
+    auto upd = [&](float gi, float pi, float& mi, float& vi) -> float {
+        gi *= coef;
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        mi = fmaf(b1, mi, (1.f - b1) * gi);
+        vi = fmaf(b2, vi, (1.f - b2) * gi * gi);
+        return pi - step * mi / (sqrtf(vi) / bc2s + eps);
+    };
+    // 16 bytes per lane on all seven streams (the flat buffers are 16-byte aligned), scalar tail
+    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i], p4 = reinterpret_cast<const float4*>(p)[i];
+        float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], o;
+        o.x = upd(g4.x, p4.x, m4.x, v4.x); o.y = upd(g4.y, p4.y, m4.y, v4.y);
+        o.z = upd(g4.z, p4.z, m4.z, v4.z); o.w = upd(g4.w, p4.w, m4.w, v4.w);
+        reinterpret_cast<float4*>(m)[i] = m4;
+        reinterpret_cast<float4*>(v)[i] = v4;
+        reinterpret_cast<float4*>(p)[i] = o;
+        if (twin) {          // bf16 twin of the parameters (the GEMMs' weight operand), kept current here
+            bf16x4 h;
+            h[0] = (bf16_t)o.x; h[1] = (bf16_t)o.y; h[2] = (bf16_t)o.z; h[3] = (bf16_t)o.w;
+            reinterpret_cast<bf16x4*>(twin)[i] = h;
+        }
+    }
+    for (size_t i = (n4 << 2) + t0; i < n; i += stride) {
+        float mi = m[i], vi = v[i];
+        const float pn = upd(g[i], p[i], mi, vi);
+        m[i] = mi; v[i] = vi; p[i] = pn;
+        if (twin) twin[i] = (bf16_t)pn;
     }
 }
 
@@ -307,17 +330,26 @@ int launch_mse_finish(const float* truth, const float* pred, const float* mask, 
     return IMMTSF_OK;
 }
 
+// 16-byte accesses need 16-byte aligned buffers (8 for the bf16 twin): FlatTrainer's are; anything else goes scalar
+static int adam_vec_ok(const float* p, const float* g, const float* m, const float* v, const void* twin) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                        reinterpret_cast<uintptr_t>(v);
+    return (a & 15) == 0 && (reinterpret_cast<uintptr_t>(twin) & 7) == 0;
+}
+
 int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                 float wd, int step, float max_norm, float* norm_scratch, hipStream_t s) {
     if (n == 0) return IMMTSF_OK;
     const int nparts = 1024;
-    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, norm_scratch);
+    void* twin = const_cast<void*>(immtsf_twin_lookup(param, n));
+    const int vec = adam_vec_ok(param, grad, m, v, twin);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, vec, norm_scratch, (long long*)nullptr,
+                       (unsigned long long*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, nparts, (const long long*)nullptr,
-                       reinterpret_cast<bf16_t*>(const_cast<void*>(immtsf_twin_lookup(param, n))));
+                       norm_scratch, nparts, (const long long*)nullptr, reinterpret_cast<bf16_t*>(twin), vec);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -327,14 +359,13 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
                     hipStream_t s) {
     if (n == 0) return IMMTSF_OK;
     const int nparts = 1024;
-    hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, s, step_dev, drop_dev);
-    IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, norm_scratch);
+    void* twin = const_cast<void*>(immtsf_twin_lookup(param, n));
+    const int vec = adam_vec_ok(param, grad, m, v, twin);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev);
     IMMTSF_LAUNCH_CHECK();
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
-                       norm_scratch, nparts, (const long long*)step_dev,
-                       reinterpret_cast<bf16_t*>(const_cast<void*>(immtsf_twin_lookup(param, n))));
+                       norm_scratch, nparts, (const long long*)step_dev, reinterpret_cast<bf16_t*>(twin), vec);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -266,6 +266,8 @@ class GraphedStep:
             trainer.step()
 
     def _fwd_bwd(self):
+        # (the 32 MB gradient memset as a third parallel branch of graph A, beside the forward, was measured: the step
+        # got 5 % SLOWER -- 1.18 vs 1.12 ms -- so it stays in front of the forward)
         self.trainer.zero_grad()
         loss = self.loss_fn()
         ops.backward_unit(loss)

@@ -157,6 +157,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="N>1: element type of the gradient all-reduce; auto = bf16 in bf16 mode (half the xGMI bytes), fp32 otherwise")
     ap.add_argument("--no-wgrad-fork", action="store_true",
                     help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
@@ -203,9 +205,10 @@ def main():
     model = tPatchGNN(a).to(dev).train()
     fusion = FusionModel(a).to(dev).train()
     use_graph = not args.no_graph
+    wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
                           lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1),
-                          overlap=True, device_step=use_graph)
+                          overlap=True, device_step=use_graph, grad_wire=wire)
     comm_mode = "bucketed on a side stream" if dist_on else "none"
     cpu_batch, sum_n = synth_batch(100 + rank, B_PER_GPU)
     batch = {k: v.to(dev) for k, v in cpu_batch.items()}
@@ -399,7 +402,8 @@ def main():
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "sum_notes_rank0": sum_n,
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * B_PER_GPU * world / (ms_per_step * 1e-3) / 1e12, 2),
-                       "grad_bytes": trainer.grad_bytes(), "grad_allreduce": comm_mode},
+                       "grad_bytes": trainer.grad_bytes(),
+                       "grad_allreduce": comm_mode + (f", {wire} on the wire" if dist_on else "")},
             "roofline": roofline, "cpu_baseline": cpu}
     if dist_on:
         import torch.distributed as dist

@@ -75,6 +75,11 @@ int immtsf_f32_to_bf16(const float* src, void* dst, size_t n, immtsf_stream_t st
     return launch_f32_to_bf16(src, dst, n, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_bf16_to_f32(const void* src, float* dst, size_t n, immtsf_stream_t stream) {
+    if (!src || !dst) return IMMTSF_EINVAL;
+    return launch_bf16_to_f32(src, dst, n, static_cast<hipStream_t>(stream));
+}
+
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,
                         int64_t sC_i, int32_t n_outer, int32_t n_inner, int32_t M, int32_t N, int32_t K, float alpha,

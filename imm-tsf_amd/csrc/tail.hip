@@ -148,7 +148,8 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
         const int c = c0 + tx;
         float e = 0.f, n = 0.f;
         if (c < C)
-            for (int r = ty; r < rows; r += RT) {
+#pragma unroll 8
+            for (int r = ty; r < rows; r += RT) {       // independent loads: keep 8 rows in flight (one CU does all the work)
                 const size_t i = (size_t)r * C + c;
                 const float dlt = truth[i] - pred[i], m = mask[i];
                 e = fmaf(dlt * dlt, m, e);
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
     if (!dpred) return;
     const float navail = s_nav;
     const size_t n = (size_t)rows * C;
+#pragma unroll 8
     for (size_t i = threadIdx.x; i < n; i += 1024) {
         const int c = (int)(i % C);
         dpred[i] = grad_scale * 2.f * (pred[i] - truth[i]) * mask[i] / ((sn[c] + 1e-8f) * navail);
@@ -258,16 +260,42 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (bf16_t)src[i];
+// fp32 <-> bf16 streams, 16 bytes of fp32 per lane when both pointers allow it (twins, the bf16 gradient wire)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int vec) {
+    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(src)[i];
+        bf16x4 h;
+        h[0] = (bf16_t)x.x; h[1] = (bf16_t)x.y; h[2] = (bf16_t)x.z; h[3] = (bf16_t)x.w;
+        reinterpret_cast<bf16x4*>(dst)[i] = h;
+    }
+    for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
+}
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n, int vec) {
+    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const bf16x4 h = reinterpret_cast<const bf16x4*>(src)[i];
+        reinterpret_cast<float4*>(dst)[i] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+    }
+    for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (float)src[i];
 }
 
 }  // namespace
 
 int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
     if (n == 0) return IMMTSF_OK;
-    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), n);
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
+    const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), n, vec);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
+    const int vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 7) == 0;
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const bf16_t*>(src), dst, n, vec);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -36,3 +36,5 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
 
 // dst[i] = bf16(src[i]) (round to nearest even): refresh of a bf16 twin
 int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+// dst[i] = float(src[i]) (exact)
+int launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t s);

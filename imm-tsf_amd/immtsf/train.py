@@ -30,9 +30,16 @@ def shard_range(n_items: int, rank: int, world: int):
 class FlatTrainer:
     def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
-                 sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None):
+                 sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None,
+                 grad_wire: str = "fp32"):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
-        sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks)."""
+        sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks).
+        grad_wire: "fp32" (exact: the sum of the ranks' gradients) or "bf16" (the gradients are rounded to bf16 for the
+        all-reduce and widened again: half the bytes on xGMI -- the collective is per-link bandwidth bound -- at the
+        cost of ~3 significant digits per element, which clip + Adam's normalised update tolerates)."""
+        if grad_wire not in ("fp32", "bf16"):
+            raise ValueError("grad_wire must be 'fp32' or 'bf16'")
+        self.grad_wire = grad_wire
         self.group = group
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.step_count = 0
@@ -54,6 +61,7 @@ class FlatTrainer:
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._wire = torch.empty(n, dtype=torch.bfloat16, device=dev) if grad_wire == "bf16" and group is not None else None
         self.ranges = []
         self._views = []
         self._collected = True
@@ -182,10 +190,28 @@ class FlatTrainer:
         if self.overlap:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(self.flat_grad[lo:hi], group=self.group)
+                self._all_reduce(lo, hi)
         else:
-            dist.all_reduce(self.flat_grad[lo:hi], group=self.group)
+            self._all_reduce(lo, hi)
         self._reduced[bi] = True
+
+    def _all_reduce(self, lo: int, hi: int):
+        """sum flat_grad[lo:hi] over the group on the current stream, through the chosen wire format"""
+        import torch.distributed as dist
+        g = self.flat_grad[lo:hi]
+        if self.grad_wire == "fp32":
+            dist.all_reduce(g, group=self.group)
+            return
+        w = self._wire[lo:hi]
+        if g.is_cuda:                   # 16-byte conversion kernels (round to nearest even / exact widening)
+            lib = _lib.load()
+            _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(g), _lib.ptr(w), g.numel(), _lib.stream_ptr()), "f32_to_bf16")
+            dist.all_reduce(w, group=self.group)
+            _lib.check(lib.immtsf_bf16_to_f32(_lib.ptr(w), _lib.ptr(g), g.numel(), _lib.stream_ptr()), "bf16_to_f32")
+        else:
+            w.copy_(g)
+            dist.all_reduce(w, group=self.group)
+            g.copy_(w)
 
     def sync_grads(self):
         """all-reduce (sum) whatever has not been reduced yet and join the communication stream.  The loss is
@@ -195,7 +221,7 @@ class FlatTrainer:
         if self.collective:
             if not self.overlap and not any(self._reduced):
                 import torch.distributed as dist
-                dist.all_reduce(self.flat_grad, group=self.group)      # one collective for the whole flat buffer
+                self._all_reduce(0, self.flat_grad.numel())            # one collective for the whole flat buffer
                 self._reduced = [True] * len(self.buckets)
             for bi in range(len(self.buckets)):
                 self._bucket_ready(bi)

@@ -333,6 +333,8 @@ int immtsf_bf16_twin_register(const float* base, void* twin, size_t count);
 int immtsf_bf16_twin_unregister(const float* base);
 int immtsf_bf16_twin_enable(int32_t on);            /* A/B switch for measurements; default on */
 int immtsf_f32_to_bf16(const float* src, void* dst, size_t n, immtsf_stream_t stream);
+/* the reverse (exact widening): used with immtsf_f32_to_bf16 around a bf16 gradient all-reduce (FlatTrainer grad_wire) */
+int immtsf_bf16_to_f32(const void* src, float* dst, size_t n, immtsf_stream_t stream);
 /* batched over (outer, inner) with element strides, used by FullAttention (layers/SelfAttention_Family.py:50-77) */
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,

@@ -53,7 +53,7 @@ def _params(z):
     return {k: torch.nn.Parameter(v.clone()) for k, v in R.params_from_npz(z).items()}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wire="fp32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
     torch.set_num_threads(2)
@@ -71,7 +71,7 @@ def _worker(rank, world, port, q):
     dist.all_reduce(cnt)                              # counts of the global batch: data only, reduced once
     ttf = [p for k, p in params.items() if k.startswith("ttf.")]
     mmf = [p for k, p in params.items() if k.startswith("mmf.")]
-    tr = FlatTrainer([mmf, ttf], lr=1e-2, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD)
+    tr = FlatTrainer([mmf, ttf], lr=1e-2, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD, grad_wire=wire)
     tr.zero_grad()
     loss = _loss(params, shard, cnt, H)
     loss.backward()
@@ -116,6 +116,23 @@ def test_two_rank_gradients_match_single_process():
     assert res["perr"] < 1e-6, res
     assert res["lerr"] < 1e-6, res
     assert res["views"]
+
+
+def test_two_rank_bf16_gradient_wire():
+    """grad_wire="bf16": the all-reduce moves bf16 (half the bytes); the reduced gradient equals the full-batch one to
+    bf16 resolution (two roundings: per-rank operand and the sum), the loss is untouched."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "bf16")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert 1e-6 < res["gerr"] < 1e-2, res           # really went through bf16, and no worse than its resolution
+    assert res["lerr"] < 1e-6, res
 
 
 def test_shard_range_covers_everything_once():

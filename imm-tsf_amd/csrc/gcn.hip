@@ -78,13 +78,16 @@ __device__ void cell_forward(float* sm, const Lds& l, const Dims& d, const Param
             const int k = j < nd ? j : j - nd;
             const float* w = (j < nd ? p.l1w : p.l2w) + (size_t)k * D;
             acc = (j < nd ? p.l1b : p.l2b)[k];
+#pragma unroll 8
             for (int f = 0; f < D; ++f) acc = fmaf(w[f], xr[f], acc);
             sm[(j < nd ? l.L1 : l.L2) + n * nd + k] = acc;
         } else {
             const bool one = j == 2 * nd;
             const float* w = one ? p.g1w : p.g2w;
             acc = (one ? p.g1b : p.g2b)[0];
+#pragma unroll 8
             for (int f = 0; f < D; ++f) acc = fmaf(w[f], xr[f], acc);
+#pragma unroll 8
             for (int k = 0; k < nd; ++k) acc = fmaf(w[D + k], one ? p.nv1[n * nd + k] : p.nv2[k * N + n], acc);
             const float t = tanhf(acc);
             sm[l.vec + (one ? 0 : 1) * N + n] = t;
@@ -101,6 +104,7 @@ __device__ void cell_forward(float* sm, const Lds& l, const Dims& d, const Param
     for (int i = tid; i < N * N; i += nt) {
         const int r = i / N, c = i - r * N;
         float acc = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nd; ++k) acc = fmaf(sm[l.NV1 + r * nd + k], sm[l.NV2 + k * N + c], acc);
         sm[l.S + i] = fmaxf(acc, 0.f);
     }
@@ -125,6 +129,7 @@ __device__ void cell_forward(float* sm, const Lds& l, const Dims& d, const Param
         for (int i = tid; i < N * D; i += nt) {
             const int v = i / D, f = i - v * D;
             float acc = 0.f;
+#pragma unroll 8
             for (int n = 0; n < N; ++n) acc = fmaf(sm[l.A + n * N + v], src[n * D + f], acc);
             dst[i] = acc;
         }
@@ -135,6 +140,7 @@ __device__ void cell_forward(float* sm, const Lds& l, const Dims& d, const Param
         const int v = i / D, o = i - v * D;
         float acc = p.mb[o];
         const float* w = sm + l.Wm + o * l.ldw;
+#pragma unroll 8
         for (int c = 0; c < l.F; ++c) acc = fmaf(w[c], feat_at(sm, l, d, v, c), acc);
         sm[l.Z + i] = acc;
     }
@@ -171,12 +177,14 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     // mixing-layer parameter gradients
     for (int o = tid; o < D; o += nt) {
         float acc = 0.f;
+#pragma unroll 8
         for (int v = 0; v < N; ++v) acc += sm[l.Z + v * D + o];
         atomicAdd(g.mb + o, acc);
     }
     for (int i = tid; i < D * l.F; i += nt) {
         const int o = i / l.F, c = i - o * l.F;
         float acc = 0.f;
+#pragma unroll 8
         for (int v = 0; v < N; ++v) acc = fmaf(sm[l.Z + v * D + o], feat_at(sm, l, d, v, c), acc);
         atomicAdd(g.mw + i, acc);
     }
@@ -184,6 +192,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     for (int i = tid; i < (d.order + 1) * N * D; i += nt) {
         const int k = i / (N * D), r = i - k * N * D, v = r / D, f = r - v * D;
         float acc = 0.f;
+#pragma unroll 8
         for (int o = 0; o < D; ++o) acc = fmaf(sm[l.Wm + o * l.ldw + k * D + f], sm[l.Z + v * D + o], acc);
         sm[l.dfeat + i] = acc;
     }
@@ -196,12 +205,14 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         for (int i = tid; i < N * N; i += nt) {
             const int n = i / N, v = i - n * N;
             float acc = 0.f;
+#pragma unroll 8
             for (int f = 0; f < D; ++f) acc = fmaf(xs[n * D + f], dk[v * D + f], acc);
             sm[l.dA + i] += acc;
         }
         for (int i = tid; i < N * D; i += nt) {
             const int n = i / D, f = i - n * D;
             float acc = 0.f;
+#pragma unroll 8
             for (int v = 0; v < N; ++v) acc = fmaf(sm[l.A + n * N + v], dk[v * D + f], acc);
             dprev[i] += acc;
         }
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     // softmax + relu backward (in place: dA -> dS)
     for (int r = tid; r < N; r += nt) {
         float dot = 0.f;
+#pragma unroll 8
         for (int c = 0; c < N; ++c) dot = fmaf(sm[l.A + r * N + c], sm[l.dA + r * N + c], dot);
         for (int c = 0; c < N; ++c) {
             const float v = sm[l.A + r * N + c] * (sm[l.dA + r * N + c] - dot);
@@ -220,6 +232,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     for (int i = tid; i < N * nd; i += nt) {
         const int n = i / nd, k = i - n * nd;
         float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
         for (int c = 0; c < N; ++c) {
             a1 = fmaf(sm[l.dA + n * N + c], sm[l.NV2 + k * N + c], a1);      // dNV1[n,k] = sum_j dS[n,j] NV2[k,j]
             a2 = fmaf(sm[l.NV1 + c * nd + k], sm[l.dA + c * N + n], a2);      // dNV2[k,n] = sum_i NV1[i,k] dS[i,n]
@@ -236,6 +249,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         const float* dnv = sm + (which ? l.dNV2 : l.dNV1) + n * nd;
         const float* L = sm + (which ? l.L2 : l.L1) + n * nd;
         float dg = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nd; ++k) dg = fmaf(dnv[k], L[k], dg);
         const float t = sm[l.vec + which * N + n];
         sm[l.vec + (4 + which) * N + n] = t > 0.f ? dg * (1.f - t * t) : 0.f;
@@ -266,9 +280,11 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         const float* dL = sm + (which ? l.dL2 : l.dL1);
         float acc = 0.f;
         if (f < D) {
+#pragma unroll 8
             for (int n = 0; n < N; ++n) acc = fmaf(dL[n * nd + k], sm[l.X + n * D + f], acc);
             atomicAdd((which ? g.l2w : g.l1w) + k * D + f, acc);
         } else {
+#pragma unroll 8
             for (int n = 0; n < N; ++n) acc += dL[n * nd + k];
             atomicAdd((which ? g.l2b : g.l1b) + k, acc);
         }

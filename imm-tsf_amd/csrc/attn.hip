@@ -30,13 +30,25 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
         if (valid) for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = 0.f;
         return;
     }
-    for (int i = wave; i < n; i += 4) {
+    // two notes per pass, their key loads (hd/64 each, unrolled) all in flight together: a wave's notes are a chain of
+    // global-load round trips otherwise (n/4 of them)
+    for (int i = wave; i < n; i += 8) {
+        const int i2 = i + 4;
         const float* kr = KVp + (size_t)(o0 + i) * ld + h * hd;
-        float a = 0.f;
-#pragma unroll 4
-        for (int c = lane; c < hd; c += 64) a = fmaf(qs[h * hd + c], kr[c], a);
+        const float* kr2 = KVp + (size_t)(o0 + (i2 < n ? i2 : i)) * ld + h * hd;
+        float a = 0.f, a2 = 0.f;
+#pragma unroll 12
+        for (int c = lane; c < hd; c += 64) {
+            const float q = qs[h * hd + c];
+            a = fmaf(q, kr[c], a);
+            a2 = fmaf(q, kr2[c], a2);
+        }
         a = wave_sum(a);
-        if (lane == 0) sc[i] = a;
+        a2 = wave_sum(a2);
+        if (lane == 0) {
+            sc[i] = a;
+            if (i2 < n) sc[i2] = a2;
+        }
     }
     __syncthreads();
     float m = -INFINITY;
@@ -81,12 +93,12 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
             __syncthreads();
             if (valid) {
                 const int cnt = min(64, n - i0);
-                for (int ii = 0; ii < cnt; ii += 4) {     // four notes per step: their V loads are in flight together
-                    float v[4];                           // (one load -> 32 FMAs -> next load serialises on latency)
+                for (int ii = 0; ii < cnt; ii += 8) {     // eight notes per step: their V loads are in flight together
+                    float v[8];                           // (one load -> 32 FMAs -> next load serialises on latency)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = (ii + u < cnt) ? vbase[(size_t)(i0 + ii + u) * ld] : 0.f;
+                    for (int u = 0; u < 8; ++u) v[u] = (ii + u < cnt) ? vbase[(size_t)(i0 + ii + u) * ld] : 0.f;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 8; ++u)
 #pragma unroll
                         for (int tt = 0; tt < TT; ++tt) acc[tt] = fmaf(atile[tt * 64 + ii + u], v[u], acc[tt]);   // tile is 0 past n
                 }

@@ -114,6 +114,16 @@ __device__ __forceinline__ float dropout_scale(const DropCfg& d, uint64_t site, 
     return dropout_scale(seed, site, idx, d.p, d.inv_keep);
 }
 
+// four consecutive elements idx4 .. idx4+3 (idx4 % 4 == 0) share ONE Philox call: same bits as four dropout_scale calls
+__device__ __forceinline__ void dropout_scale4(const DropCfg& d, uint64_t site, uint64_t idx4, float (&s)[4]) {
+    if (d.p <= 0.f) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
+    const uint64_t seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
+    const Philox4 r = philox4x32_10(seed, site, idx4 >> 2);
+    const uint32_t bits[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[e] = (float)(bits[e] >> 8) * (1.0f / 16777216.0f) >= d.p ? d.inv_keep : 0.f;
+}
+
 // dropout sites (Philox subsequence ids) -- one per dropout call of the reference modules
 enum : uint64_t {
     SITE_T2V_ATTN = 1,   // fusions/TTF_T2V_XAttn.py:79-84  (attention-weight dropout inside MHA)

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
     }
 }
 
-// Backward, part 2.  grid (B, H), 256 threads; LDS: ds[N] | red[16].
+// Backward, part 2.  grid (B, H, ceil(hd/256)), 256 threads (every workgroup recomputes the window's ds -- n values -- and
+// owns a 256-column slice of dk / dqs_part; one workgroup per window made 64 of them walk all hd columns); LDS: ds[N] | red[16].
 //   ds[i] = p[i] (dp[i] - sum_j p[j] dp[j]);  dk[i,:] = ds[i] * qs_h;  dqs_part[b, h, :] = sum_i ds[i] k[i,:]
 __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                   const float* __restrict__ KVp, const float* __restrict__ qs,
@@ -186,12 +187,13 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     extern __shared__ float lds[];
     float* ds = lds;
     float* red = lds + dm.N;
-    const int b = blockIdx.x, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, h = blockIdx.y, c0 = blockIdx.z * 256;
+    const int tid = threadIdx.x;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d;
     const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    const int c = c0 + tid;
     if (n == 0) {
-        for (int c = tid; c < hd; c += 256) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
+        if (c < hd) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
         return;
     }
     float part = 0.f;
@@ -204,18 +206,17 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     __syncthreads();
     for (int i = tid; i < n; i += 256) ds[i] = P[(size_t)(o0 + i) * dm.H + h] * (ds[i] - dot);
     __syncthreads();
-    for (int i = wave; i < n; i += 4) {
-        float* dkr = dKVp + (size_t)(o0 + i) * ld + h * hd;
-        const float dsi = ds[i];
-        for (int c = lane; c < hd; c += 64) dkr[c] = dsi * qs[h * hd + c];
-    }
-    for (int c = tid; c < hd; c += 256) {
-        const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
-        float a = 0.f;
+    if (c >= hd) return;
+    const float q = qs[h * hd + c];
+    const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
+    float* dkc = dKVp + (size_t)o0 * ld + h * hd + c;
+    float a = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < n; ++i) a = fmaf(ds[i], kc[(size_t)i * ld], a);
-        dqs_part[(size_t)b * d + h * hd + c] = a;
+    for (int i = 0; i < n; ++i) {
+        a = fmaf(ds[i], kc[(size_t)i * ld], a);
+        dkc[(size_t)i * ld] = ds[i] * q;
     }
+    dqs_part[(size_t)b * d + h * hd + c] = a;
 }
 
 // ---- dense attention rows: one wave per (b,h,l) row of length S ---------------------------------------
@@ -431,8 +432,8 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
     hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
                        dctx, dKVp, dp_buf, drop, site);
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B, dm.H), dim3(256), lds, s, dm, offsets, KVp, qs, P, dp_buf, dKVp,
-                       dqs_part);
+    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P, dp_buf,
+                       dKVp, dqs_part);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -204,6 +204,15 @@ def test_pairs_fp32_small_odd_shapes(ttf, mmf):
     _check(gerrs, 2e-4)
 
 
+@pytest.mark.parametrize("C,d_txt", [(20, 12), (3, 10)])
+def test_xattn_add_shapes_outside_the_fused_head_and_vector_rows(C, d_txt):
+    """C > 16 keeps MMF_XAttn_Add's output head on the GEMM + ln_blend kernels; d_txt % 4 != 0 keeps LayerNorm and the
+    head on their scalar-row kernels: both fallbacks still match the oracle (fp32)."""
+    errs, gerrs = _run_pair("TTF_T2V_XAttn", "MMF_XAttn_Add", B=4, N=5, T=6, C=C, d_m=16, d_txt=d_txt, H=2, precision="fp32")
+    _check(errs, 1e-4)
+    _check(gerrs, 2e-4)
+
+
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
 def test_pairs_fp32_benchmark_shape(ttf, mmf):
     # BASELINE config 2 shape: B=64, N<=32, T=32, C=8, d_m=d=768, H=1

@@ -175,6 +175,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    # control-flow test of the N>1 path on a 1-GPU box: IMMTSF_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL refuses two ranks on one device); numbers from such a run mean nothing
+    share_gpu = bool(os.environ.get("IMMTSF_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -183,7 +188,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
     from fusions.FusionModel import FusionModel
@@ -284,8 +292,11 @@ def main():
         # stream (the stream the library launches on) over a further block of identical steps.
         k2 = min(args.steps, 20)
         lib.immtsf_timing_enable(1)
+        # rank 0 only: the other ranks are already waiting at the final barrier, so this leg must not issue collectives
+        was_collective, trainer.collective = trainer.collective, False
         for _ in range(k2):
             eager_step()      # the tap records at launch time, so this leg launches eagerly (same kernels, same shapes)
+        trainer.collective = was_collective
         torch.cuda.synchronize()
         cap = 16384
         meta = (ctypes.c_int32 * (10 * cap))()

@@ -110,7 +110,7 @@ class FlatTrainer:
         if self.overlap:
             for bi in self.sink_buckets:
                 head = self.buckets[bi][0]
-                head._immtsf_bwd_hook = (lambda i=bi: self._bucket_ready(i))
+                head._immtsf_bwd_hook = (lambda i=bi: self._on_bucket_done(i))
 
     def gather(self, flat: torch.Tensor) -> torch.Tensor:
         """the parameters' elements of a flat buffer (param / grad / moment), concatenated in bucket order without the
@@ -176,6 +176,13 @@ class FlatTrainer:
         step is being captured into a hipGraph, so that the copy is part of the graph and runs on every replay."""
         self._collected = False
         self._collect_autograd_grads()
+
+    def _on_bucket_done(self, bi: int):
+        """backward hook of a sink bucket: start its all-reduce now -- only while overlapping is on.  (A caller that turns
+        `overlap` off after construction, e.g. GraphedStep without captured collectives, must not get collectives issued
+        from inside the backward: under graph capture they would be captured AND repeated eagerly afterwards.)"""
+        if self.overlap:
+            self._bucket_ready(bi)
 
     def _bucket_ready(self, bi: int):
         if not self.collective or self._reduced[bi]:

@@ -248,13 +248,14 @@ def main():
         step = None
         if dist_on and args.captured_comm:
             # RCCL all-reduces captured inside graph A, bucket by bucket on the communication stream while the backward
-            # of the later buckets still runs; falls back to one eager all-reduce between the graphs if capture fails
+            # of the later buckets still runs.  A failed capture leaves the HIP context unusable (seen with gloo, which
+            # cannot be captured), so there is no fallback: run without the flag instead
             try:
                 step = GraphedStep(trainer, loss_fn, capture_collectives=True)
                 comm_mode = "captured, bucketed"
             except Exception as e:      # noqa: BLE001
-                print(f"# collective capture unavailable ({type(e).__name__}: {e}); eager all-reduce between graphs", file=sys.stderr)
-                torch.cuda.synchronize()
+                raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
+                                 "re-run without the flag (eager all-reduce between the two graphs)") from e
         if step is None:
             if dist_on:
                 trainer.overlap, comm_mode = False, "eager, between the graphs"

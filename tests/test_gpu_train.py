@@ -200,3 +200,67 @@ def test_evaluation_metrics_match_reference_formula():
     assert set(got) == {"loss", "mse", "mae", "rmse", "mape"} and all(isinstance(v, float) for v in got.values())
     for k, v in (("loss", mse), ("mse", mse), ("mae", mae), ("rmse", mse ** 0.5), ("mape", mape)):
         assert abs(got[k] - v) <= 1e-5 * max(1.0, abs(v)), (k, got[k], v)
+
+
+def _two_rank_worker(rank, world, port, q, wire):
+    """one rank of the data-parallel graph step: both ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+    device) -- what is under test is the N>1 control flow of GraphedStep / FlatTrainer, not the transport"""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from immtsf.ops import masked_mse
+    from immtsf.train import FlatTrainer, GraphedStep, shard_range
+    from lib.evaluation import forecast_and_fuse
+    model, fusion, _, batch = _setup(dev, 0.0)
+    lo, hi = shard_range(8, rank, world)
+    shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
+    cnt = shard["mask_predicted_data"].reshape(-1, shard["mask_predicted_data"].shape[-1]).sum(0)
+    dist.all_reduce(cnt)                # observation counts of the GLOBAL batch: data only, reduced once
+    tr = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())], lr=1e-2, eps=1e-3,
+                     max_norm=1.0, sink_buckets=(0, 1), overlap=True, device_step=True, group=dist.group.WORLD, grad_wire=wire)
+    tr.overlap = False                  # what bench.py does for graph mode: one eager all-reduce between the two graphs
+
+    def f():
+        out = forecast_and_fuse(model, fusion, shard, None)
+        return masked_mse(out, shard["data_to_predict"], shard["mask_predicted_data"], None, cnt)
+    g = GraphedStep(tr, f)              # 3 warm-up steps ...
+    for _ in range(2):                  # ... + 2 replays
+        g()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(tr.gather(tr.flat_param).cpu().numpy())        # by value: the process exits before the parent reads it
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire,tol", [("fp32", 3e-4), ("bf16", 3e-2)])
+def test_two_rank_graph_step_equals_single_process(wire, tol):
+    """bench.py's N>1 path (graph A -> eager all-reduce -> graph B) on two ranks trains like one process on the full batch;
+    the bucket hooks must NOT issue collectives inside the captured backward when overlap is off (they would be captured
+    and then repeated eagerly: gradients x world)."""
+    dev = _dev()
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, wire)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = torch.from_numpy(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    f = _loss_fn(model, fusion, batch)
+    for _ in range(5):
+        tr.zero_grad()
+        f().backward()
+        tr.sync_grads()
+        tr.step()
+    ref = tr.gather(tr.flat_param).cpu()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < tol, err

@@ -215,6 +215,32 @@ __global__ __launch_bounds__(256) void colsum2_partial_kernel(const float* __res
     }
 }
 
+// narrow matrices (N <= 32 columns, e.g. LayerNorm over the C series variables): ONE workgroup, CT column lanes x
+// 1024/CT row lanes, tree over the row lanes -- one launch instead of the two-stage pair (whose 64-wide column tiling
+// would leave 7/8 of every wave idle)
+__global__ __launch_bounds__(1024) void colsum2_small_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M, int N,
+                                                              int ld, int CT, float* __restrict__ out_xy, float* __restrict__ out_x) {
+    __shared__ float ra[1024], rb[1024];
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    float a = 0.f, b = 0.f;
+    if (tx < N) {
+#pragma unroll 8
+        for (int r = ty; r < M; r += RT) {
+            const float x = X[(size_t)r * ld + tx];
+            a = fmaf(x, Y[(size_t)r * ld + tx], a);
+            b += x;
+        }
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = RT >> 1; st > 0; st >>= 1) {
+        if (ty < st) { ra[threadIdx.x] += ra[threadIdx.x + st * CT]; rb[threadIdx.x] += rb[threadIdx.x + st * CT]; }
+        __syncthreads();
+    }
+    if (ty == 0 && tx < N) { out_xy[tx] = ra[tx]; out_x[tx] = rb[tx]; }
+}
+
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -499,6 +525,13 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
                    hipStream_t s) {
     if (N <= 0) return IMMTSF_OK;
+    if (N <= 32 && (long)M * N <= (1L << 17)) {
+        int CT = 1;
+        while (CT < N) CT <<= 1;
+        hipLaunchKernelGGL(colsum2_small_kernel, dim3(1), dim3(1024), 0, s, X, Y, M, N, ld, CT, out_xy, out_x);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     hipLaunchKernelGGL(colsum2_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, N, ld, scratch);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out_xy, out_x);

@@ -65,6 +65,31 @@ __global__ __launch_bounds__(256) void ln_blend_bwd_kernel(const float* __restri
         ddelta[(size_t)row * C + c] = rs * (dn[(size_t)row * C + c] * gamma[c] - c1 - h[c] * c2);
 }
 
+// C <= 64: one lane per element, CT = pow2 >= C lanes per row, the two row sums by xor-shuffles (the kernel above walks a
+// row serially in one thread: 8 workgroups, 8 us at 2048 x 8)
+__global__ __launch_bounds__(256) void ln_blend_bwd_lanes_kernel(const float* __restrict__ dYout, const unsigned char* __restrict__ mtxt,
+                                                                  int BT, int T, int C, int CT, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                                  float kappa, float* __restrict__ dY, float* __restrict__ dn,
+                                                                  float* __restrict__ ddelta, DropCfg drop, uint64_t site) {
+    const int t = blockIdx.x * 256 + threadIdx.x, row = t / CT, c = t - row * CT;
+    const bool on = row < BT && c < C;
+    float gn = 0.f, tt = 0.f, h = 0.f, gm = 0.f;
+    if (on) {
+        const size_t o = (size_t)row * C + c;
+        const float inv = 1.f / (1.f + kappa), kk = kappa * inv * (mtxt[row / T] ? 1.f : 0.f), g = dYout[o];
+        gn = kk * g * dropout_scale(drop, site, (uint64_t)o);
+        dn[o] = gn;
+        dY[o] = g * inv;
+        gm = gamma[c];
+        h = xhat[o];
+        tt = gn * gm;
+    }
+    float c1 = tt, c2 = tt * h;
+    for (int o = CT >> 1; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    if (on) ddelta[(size_t)row * C + c] = rstd[row] * (tt - c1 / (float)C - h * (c2 / (float)C));
+}
+
 // ---- masked MSE (lib/evaluation.py:17-62, func="MSE", reduce="mean") -------------------------------------
 // stage 1: grid = 64 row slabs; block = CT column lanes x (256/CT) row lanes (CT = pow2 >= min(C,64)), so one
 // wave-instruction reads whole contiguous rows.  partial[slab][0][c] = sum err, partial[slab][1][c] = sum mask.
@@ -321,6 +346,14 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
                         const float* xhat, const float* rstd, float kappa, float* dY, float* dn, float* ddelta,
                         DropCfg drop, uint64_t site, hipStream_t s) {
     if (BT <= 0) return IMMTSF_OK;
+    if (C <= 64) {
+        int CT = 1;
+        while (CT < C) CT <<= 1;
+        hipLaunchKernelGGL(ln_blend_bwd_lanes_kernel, dim3((unsigned)(((long)BT * CT + 255) / 256)), dim3(256), 0, s, dYout, mtxt, BT, T, C, CT, gamma, xhat,
+                           rstd, kappa, dY, dn, ddelta, drop, site);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     hipLaunchKernelGGL(ln_blend_bwd_kernel, dim3(cdiv(BT, 256)), dim3(256), 0, s, dYout, mtxt, BT, T, C, gamma, xhat, rstd, kappa,
                        dY, dn, ddelta, drop, site);
     IMMTSF_LAUNCH_CHECK();

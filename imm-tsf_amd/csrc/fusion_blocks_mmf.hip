@@ -38,8 +38,8 @@ KVScratch carve_kv_scratch(const immtsf_fusion_cfg* c, void* base) {
     const size_t BT = (size_t)c->B * c->T, d = c->d;
     Carver k(base);
     KVScratch s;
-    s.dK0 = k.take<float>(BT * d);
-    s.dV0 = k.take<float>(BT * d);
+    s.dK0 = k.take<float>(BT * 2 * d);      // [dK0 | dV0] side by side, row pitch 2d: one K = 2d GEMM can read both
+    s.dV0 = s.dK0 ? s.dK0 + d : nullptr;
     s.bytes = k.bytes();
     return s;
 }
@@ -306,7 +306,7 @@ int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
     const int d = cfg->d, BT = cfg->B * cfg->T, prec = cfg->precision;
     Fork fk(s);
     {   // MHA in-projections of k, v
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
+        GemmArgs g = gemm_args(BT, d, d, d, d, 2 * d);
         g.nprob = 2;
         set_problem(g, 0, dKi, p->attn_in_w + (size_t)d * d, sc.dK0, nullptr);
         set_problem(g, 1, dVi, p->attn_in_w + (size_t)2 * d * d, sc.dV0, nullptr);
@@ -319,14 +319,22 @@ int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // proj_k / proj_v: dE = dK0 W_k + dV0 W_v ; dW_k = dK0^T E ; dW_v = dV0^T E
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, sc.dK0, p->proj_k_w, dE_txt, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs g2 = gemm_args(BT, d, d, d, d, d);
-        set_problem(g2, 0, sc.dV0, p->proj_v_w, dE_txt, nullptr);
-        g2.accumulate = 1;
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g2, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
+        if (p->proj_v_w == p->proj_k_w + (size_t)d * d) {
+            // the two weights are adjacent (FlatTrainer's flat buffer, or any state-dict-order allocation): [W_k ; W_v] is one
+            // (2d, d) matrix and dE = [dK0 | dV0] [W_k ; W_v] ONE GEMM with K = 2d instead of two K = d launches
+            GemmArgs g = gemm_args(BT, d, 2 * d, 2 * d, d, d);
+            set_problem(g, 0, sc.dK0, p->proj_k_w, dE_txt, nullptr);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        } else {
+            GemmArgs g = gemm_args(BT, d, d, 2 * d, d, d);
+            set_problem(g, 0, sc.dK0, p->proj_k_w, dE_txt, nullptr);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs g2 = gemm_args(BT, d, d, 2 * d, d, d);
+            set_problem(g2, 0, sc.dV0, p->proj_v_w, dE_txt, nullptr);
+            g2.accumulate = 1;
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g2, s));
+        }
+        GemmArgs h = gemm_args(d, d, BT, 2 * d, d, d);
         h.nprob = 2;
         set_problem(h, 0, sc.dK0, E_txt, gr->proj_k_w, nullptr);
         set_problem(h, 1, sc.dV0, E_txt, gr->proj_v_w, nullptr);

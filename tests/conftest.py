@@ -19,3 +19,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fresh_immtsf_state():
+    """process-global switches of the library must not leak from one test into the next: the device-side dropout / step
+    counters (enabled by FlatTrainer(device_step=True), bumped by every GraphedStep replay) and the precision mode"""
+    yield
+    try:
+        from immtsf import config
+    except Exception:       # noqa: BLE001  (CPU-only collection without the package importable)
+        return
+    config.disable_device_counters()
+    config.precision = "fp32"

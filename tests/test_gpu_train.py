@@ -264,3 +264,32 @@ def test_two_rank_graph_step_equals_single_process(wire, tol):
     ref = tr.gather(tr.flat_param).cpu()
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < tol, err
+
+
+def test_adjacent_projection_weights_take_the_single_gemm_path():
+    """inside FlatTrainer's flat buffer proj_k.weight and proj_v.weight of MMF_XAttn_Add are adjacent, which lets the
+    backward form dE = [dK0 | dV0] [W_k ; W_v] as ONE GEMM: same gradients as with separately allocated parameters."""
+    dev = _dev()
+    from fusions.MMF_XAttn_Add import MMF_XAttn_Add
+    from immtsf import config
+    from immtsf.train import FlatTrainer
+    config.precision = "fp32"
+    torch.manual_seed(3)
+    a = MMF_XAttn_Add(d_txt=32, C=5, d_attn=32, n_heads_fusion=2, dropout=0.0, kappa=0.5).to(dev).train()
+    b = MMF_XAttn_Add(d_txt=32, C=5, d_attn=32, n_heads_fusion=2, dropout=0.0, kappa=0.5).to(dev).train()
+    b.load_state_dict(a.state_dict())
+    tr = FlatTrainer([list(b.parameters())], sink_buckets=(), overlap=False)
+    assert b.proj_v.weight.data_ptr() == b.proj_k.weight.data_ptr() + 4 * b.proj_k.weight.numel()
+    g = torch.Generator().manual_seed(1)
+    Y, E = torch.randn(6, 7, 5, generator=g).to(dev), torch.randn(6, 7, 32, generator=g).to(dev)
+    M = torch.tensor([1, 1, 0, 1, 1, 1], dtype=torch.bool, device=dev).view(6, 1)
+    up = torch.randn(6, 7, 5, generator=g).to(dev)
+    Ea, Eb = E.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    (a(Y, Ea, M) * up).sum().backward()
+    tr.zero_grad()
+    (b(Y, Eb, M) * up).sum().backward()
+    torch.cuda.synchronize()
+    assert float((Ea.grad - Eb.grad).abs().max() / Ea.grad.abs().max()) < 1e-5
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert float((p.grad - q.grad).abs().max() / max(float(p.grad.abs().max()), 1e-6)) < 1e-5, k
+    tr.close()

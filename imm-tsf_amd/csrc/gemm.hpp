@@ -10,7 +10,9 @@ struct GemmProblem {
     float* C;
     const float* bias;   // length N, may be null
     float* bias_grad;    // TN + ones_col: length M, receives sum_k opA(m,k)
-    const void* Bh;      // set by the launcher: bf16 twin of B (same element offsets) when one is registered
+    const void* Bh;      // bf16 copy of B (same element offsets): given by the caller, else looked up in the twin registry
+    const void* Ah;      // bf16 copy of A (same element offsets, same lda), written by A's producer; may be null
+    void* Ch;            // optional bf16 copy of the result (row pitch GemmArgs::ldch); C may then be null
 };
 
 // C[m,n] = epilogue( alpha * sum_k opA(m,k) * opB(n,k) )
@@ -22,6 +24,7 @@ struct GemmArgs {
     int nprob;
     int M, N, K;
     int lda, ldb, ldc;
+    int ldch;              // row pitch of the bf16 result copies p[i].Ch (0: same as ldc)
     const int* dyn;        // device int overriding M (dyn_which==0) or K (dyn_which==1); may be null
     int dyn_which;
     const int* a_rowmap;   // !TA: source row of A for logical row m.  TA: source row for reduction index k
@@ -54,6 +57,13 @@ enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 // bf16 twins (immtsf_bf16_twin_register): a registered fp32 range [base, base+count) has a bf16 copy with the same
 // element offsets, kept current by its owner (the fused Adam kernel writes it).  Returns the twin of `p` or null.
 const void* immtsf_twin_lookup(const float* p, size_t min_elems);
+
+// ---- gemm2.hip: the bf16-in-memory path.  Both operands are bf16 in HBM and go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4) through a multi-stage ring; same GemmArgs, reading p[i].Ah / p[i].Bh and writing p[i].C
+// (fp32, may be null) and/or p[i].Ch (bf16, may be null).  Returns IMMTSF_EUNSUPPORTED for argument combinations it
+// does not implement (batched form, TN with a row map, unaligned operands): the caller then uses immtsf_launch_gemm.
+bool immtsf_gemm2_supported(int layout, const GemmArgs& g);
+int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream);
 
 // precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);

@@ -1,0 +1,513 @@
+// bf16-in-memory MFMA GEMM for gfx950: both operands are bf16 in HBM and travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no conversion, no ds_write), through a ring of S LDS stages with
+// ONE raw s_barrier per 64-deep K step and a counted s_waitcnt vmcnt(N) that leaves S-2 later stages in flight
+// across the barrier.  At the fusion shapes (2048 x 768 x 768 and relatives) the K loop is bound by what a CU can
+// pull out of its XCD's L2 (r01: time linear in K, 11.8 ns per K unit with fp32 activations whatever the tiling);
+// this path halves those bytes and keeps 2-3 K steps of them in flight instead of one.
+//
+// LDS-DMA writes lane-linearly (wave-uniform LDS base + lane * 16 B), so the LDS images are plain arrays of 16-byte
+// chunks and every bank-conflict-avoiding permutation lives in the per-lane SOURCE address and in the fragment reads:
+//   * R image (operand rows x 64 k, k contiguous in memory: A of NT/NN, B of NT): chunk (row, c) sits at position
+//     row*8 + (c ^ ((row>>1)&7)); a fragment is one ds_read_b128 and the 16 lanes of a read group hit 16 different
+//     16-byte slots of the 256-byte bank row.
+//   * T image (64 k-lines x operand rows, the reduction index is the slow one in memory: B of NN, A and B of TN):
+//     64-column blocks of [k][8 chunks], chunk (k, n8) at position k*8 + (n8 ^ sw(k)),
+//     sw(k) = (((k>>1)&1)<<1) | (((k>>3)&1)<<2); fragments come out of ds_read_b64_tr_b16 (hardware transpose),
+//     whose 32-lane groups then cover all 64 banks exactly once.  Global side: 8 lanes fetch one full 128-byte line.
+// Out-of-range k-lines / columns (ragged K = note count, K not a multiple of 64, N edge of a T image) are fetched from
+// a 16-byte zero page; out-of-range rows of an R image are clamped to the last row (their products only reach output
+// elements that are never stored).  The steps past the end of the K range issue zero-page loads too, so every wave
+// issues the same number of loads per step and the vmcnt arithmetic has no special cases.
+#include "gemm.hpp"
+#include <string.h>
+
+namespace {
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int BK2 = 64;
+
+// WK > 1: WK groups of WM x WN waves share the output tile and split the K steps round-robin (group kg takes steps
+// kt0 + kg, kt0 + kg + WK, ...), each with its own ring; their accumulators are summed through LDS in the epilogue.
+// More waves and more LDS-DMA streams per CU without smaller per-wave tiles: one LDS-DMA stream per wave lands ~1 KiB
+// per ~100 cycles whatever is asked of it, so a 4-wave workgroup cannot pull what the CU's L2 port offers.
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g) {
+    constexpr int NT = WM * WN * 64;          // threads of one K group
+    constexpr int NTALL = NT * WK;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;       // 16-byte chunks per thread, stage and operand
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0 && CA >= 1 && CB >= 1, "whole chunks per thread");
+    // T images come in blocks of 64 columns (8 chunks per k-line) or, when the tile width is only a multiple of 32, of
+    // 32 columns (4 chunks per k-line, chunk (k, n8) at position k*4 + (n8 ^ (((k>>3)&1)<<1)): conflict-free as well,
+    // 64-byte global segments)
+    static_assert(!TA || BM % 32 == 0, "T images come in 32- or 64-column blocks");
+    static_assert(!TB || BN % 32 == 0, "T images come in 32- or 64-column blocks");
+    constexpr int LA = (BM % 64 == 0) ? 3 : 2, LB = (BN % 64 == 0) ? 3 : 2;     // log2(chunks per k-line of a block)
+    static_assert((BM / WM) % 16 == 0 && (BN / WN) % 16 == 0, "wave tile = whole 16x16 MFMA tiles");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SB = A_BYTES + B_BYTES;
+    constexpr int LPS = CA + CB;
+    static_assert((S - 2) * LPS <= 63, "vmcnt immediate");
+    constexpr int CP = BN + 4;                              // epilogue staging pitch (floats)
+    constexpr int RING = S * SB;                            // bytes of one K group's ring
+    // the epilogue stages the accumulators through the (then dead) ring in bands of BAND tile rows
+    constexpr int BAND = (BM * CP * 4 <= RING) ? BM : (BM / 2 * CP * 4 <= RING) ? BM / 2 : BM / 4;
+    static_assert(BAND * CP * 4 <= RING && BAND % 16 == 0, "epilogue band must fit the ring");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[WK * RING];
+
+    const GemmProblem P = g.p[blockIdx.z];
+    int M = g.M, K = g.K;
+    const int N = g.N;
+    if (g.dyn) {
+        const int dv = *g.dyn;
+        if (g.dyn_which == 0) M = dv; else K = dv;
+    }
+    const int tiles_n = (N + BN - 1) / BN;
+    int lin = blockIdx.x;
+    if (g.xcd_remap) {        // contiguous tile range per XCD (bijective for any grid size), see gemm.hip
+        const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
+        lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    }
+    const int tile_m = lin / tiles_n, tile_n = lin % tiles_n;
+    const int row0 = tile_m * BM, col0 = tile_n * BN;
+    if (row0 >= M) return;
+
+    const int tid_all = threadIdx.x, kg = WK > 1 ? tid_all / NT : 0;
+    const int tid = WK > 1 ? tid_all % NT : tid_all, lane = tid & 63, wave = tid >> 6;
+    unsigned char* smem = smem_all + kg * RING;
+    const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+    const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(P.Ah);
+    const bf16_t* __restrict__ Bm = reinterpret_cast<const bf16_t*>(P.Bh);
+    const bf16_t* zp = reinterpret_cast<const bf16_t*>(g_zero_page);
+
+    // K range of this split, in 64-deep steps
+    const int nk_total = (K + BK2 - 1) / BK2;
+    const int splits = gridDim.y;
+    const int per = (nk_total + splits - 1) / splits;
+    const int kt0 = blockIdx.y * per, kt1 = min(nk_total, kt0 + per);
+    if (splits > 1 && kt0 >= kt1) return;
+    const int kend = min(K, kt1 * BK2);
+
+    // ---- per-thread source pointers of its chunks at k = 0 (R image: pointer to (row, c*8); T image: pointer to
+    // (k-line, column)), the k coordinate the validity test needs, and whether the chunk's columns exist at all
+    const bf16_t* pa[CA];
+    const bf16_t* pb[CB];
+    int ka[CA], kb[CB];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+        const int p = tid + i * NT;
+        if (!TA) {
+            const int r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
+            int grow = min(row0 + r, M - 1);
+            if (g.a_rowmap) grow = g.a_rowmap[grow];
+            pa[i] = A + (size_t)grow * g.lda + c * 8;
+            ka[i] = c * 8;
+        } else {
+            const int b = p >> (6 + LA), pk = p & ((64 << LA) - 1), k = pk >> LA;
+            const int n8 = (pk & ((1 << LA) - 1)) ^ (LA == 3 ? ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2)) : (((k >> 3) & 1) << 1));
+            const int col = row0 + b * (8 << LA) + n8 * 8;
+            pa[i] = A + (size_t)k * g.lda + col;
+            ka[i] = (col + 8 <= M) ? k : (1 << 30);        // columns past M: always the zero page
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+        const int p = tid + i * NT;
+        if (!TB) {
+            const int r = p >> 3, c = (p & 7) ^ ((r >> 1) & 7);
+            const int gcol = min(col0 + r, N - 1);
+            pb[i] = Bm + (size_t)gcol * g.ldb + c * 8;
+            kb[i] = c * 8;
+        } else {
+            const int b = p >> (6 + LB), pk = p & ((64 << LB) - 1), k = pk >> LB;
+            const int n8 = (pk & ((1 << LB) - 1)) ^ (LB == 3 ? ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2)) : (((k >> 3) & 1) << 1));
+            const int col = col0 + b * (8 << LB) + n8 * 8;
+            pb[i] = Bm + (size_t)k * g.ldb + col;
+            kb[i] = (col + 8 <= N) ? k : (1 << 30);
+        }
+    }
+    const size_t stepA = TA ? (size_t)BK2 * g.lda : (size_t)BK2;       // elements per K step
+    const size_t stepB = TB ? (size_t)BK2 * g.ldb : (size_t)BK2;
+
+    // issue the LDS-DMA loads of K step `t` into ring slot `slot`
+    auto issue = [&](int t, int slot) {
+        const int k0 = t * BK2;
+        unsigned char* sa = smem + slot * SB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const bf16_t* src = (k0 + ka[i] < kend) ? pa[i] + (size_t)(t) * stepA : zp;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(sa + i * (NT * 16)), 16, 0, 0);
+        }
+        unsigned char* sb = smem + slot * SB + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const bf16_t* src = (k0 + kb[i] < kend) ? pb[i] + (size_t)(t) * stepB : zp;
+            __builtin_amdgcn_global_load_lds((glb_vp)src, (lds_vp)(sb + i * (NT * 16)), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // TN + bias gradient: bias_grad[m] = sum_k A[k][m] as one more MFMA column against a fragment of ones, in the
+    // workgroups of the first tile column and there in the waves of the first wave column
+    const bool want_bsum = TA && TB && g.ones_col && P.bias_grad != nullptr && col0 == 0 && wn0 == 0;
+    f32x4 accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a stage (constant over the K loop)
+    int offA[TM], offB[TN];
+    if (!TA) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) offA[i] = (wm0 + i * 16 + fr) * 128;
+    } else {
+        const int q = fr >> 2, p = fr & 3, sw = LA == 3 ? (((q >> 1) << 1) | ((fq & 1) << 2)) : ((fq & 1) << 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rb = wm0 + i * 16, n8 = 2 * ((rb & ((8 << LA) - 1)) >> 4) + (p >> 1);
+            offA[i] = (rb >> (3 + LA)) * (1024 << LA) + (((fq * 8 + q) << LA) + (n8 ^ sw)) * 16 + (p & 1) * 8;
+        }
+    }
+    if (!TB) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) offB[j] = A_BYTES + (wn0 + j * 16 + fr) * 128;
+    } else {
+        const int q = fr >> 2, p = fr & 3, sw = LB == 3 ? (((q >> 1) << 1) | ((fq & 1) << 2)) : ((fq & 1) << 1);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int rb = wn0 + j * 16, n8 = 2 * ((rb & ((8 << LB) - 1)) >> 4) + (p >> 1);
+            offB[j] = A_BYTES + (rb >> (3 + LB)) * (1024 << LB) + (((fq * 8 + q) << LB) + (n8 ^ sw)) * 16 + (p & 1) * 8;
+        }
+    }
+    const int rsw = fr >> 1;      // R image: chunk c of row r sits in slot c ^ ((r>>1)&7), and (r>>1)&7 == fr>>1 here
+
+    auto frag = [&](const unsigned char* st, bool T, int L, int off, int kk) -> bf16x8 {
+        if (!T) return *reinterpret_cast<const bf16x8*>(st + off + (((kk * 4 + fq) ^ rsw) << 4));
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        // k-lines kk*32 + fq*8 + q and + 4; a k-line of a block is 16 << L bytes
+        const unsigned char* a0 = st + off + kk * (32 * (16 << L));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * (16 << L)));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    // ---- the ring.  Before iteration t's wait, stages kt0 .. kt0+t+S-2 have been issued; stage t is complete once at
+    // most (S-2)*LPS of this wave's loads are outstanding, and everybody's once all waves are past the barrier -- which
+    // also says everyone is done reading slot (t-1)%S, the slot stage t+S-1 goes into.
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s) issue(kt0 + kg + s * WK, s);
+    int slot = 0, fill = S - 1;
+    for (int t = kt0 + kg; t < kt1 + kg; t += WK) {     // same trip count in every K group (steps >= kt1 load zeros)
+        wait_vmcnt<(S - 2) * LPS>();
+        __builtin_amdgcn_s_barrier();
+        issue(t + (S - 1) * WK, fill);
+        const unsigned char* st = smem + slot * SB;
+        bf16x8 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[kk][i] = frag(st, TA, LA, offA[i], kk);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[kk][j] = frag(st, TB, LB, offB[j], kk);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+            if (TA && TB && want_bsum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], ones, accb[i], 0, 0, 0);
+            }
+        }
+        slot = slot + 1 == S ? 0 : slot + 1;
+        fill = fill + 1 == S ? 0 : fill + 1;
+    }
+    wait_vmcnt<0>();                      // the zero-page loads of the steps past kt1 still target the ring
+    __builtin_amdgcn_s_barrier();
+
+    // bias-gradient partial sums.  C/D map: col = lane & 15, row = (lane >> 4)*4 + reg; every column holds the sum
+    if (TA && TB && want_bsum && fr == 0 && gridDim.y > 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wm0 + i * 16 + fq * 4 + r;
+                if (row < M) atomicAdd(P.bias_grad + row, g.alpha * accb[i][r]);
+            }
+    }
+
+    float* __restrict__ C = P.C;
+    bf16_t* __restrict__ Ch = reinterpret_cast<bf16_t*>(P.Ch);
+    const bool first = blockIdx.y == 0;
+    // ---- epilogue through LDS: whole 16-byte pieces of C rows (fp32) and 8-byte pieces of the bf16 copy
+    float* Ct = reinterpret_cast<float*>(smem);
+    const int ldch = g.ldch ? g.ldch : g.ldc;
+    const bool bsum_wg = TA && TB && g.ones_col && P.bias_grad != nullptr && col0 == 0;
+#pragma unroll 1
+    for (int band0 = 0; band0 < BM; band0 += BAND) {
+        if (band0 > 0) __syncthreads();           // the previous band has been read
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rb = wm0 + i * 16 - band0;   // wave-uniform
+            if (rb < 0 || rb >= BAND) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ct[(rb + fq * 4 + r) * CP + wn0 + j * 16 + fr] = acc[i][j][r];
+            if (TA && TB && want_bsum && fr == 0) {       // the staging tile's first padding column carries the bias-gradient sums
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ct[(rb + fq * 4 + r) * CP + BN] = accb[i][r];
+            }
+        }
+        __syncthreads();
+        if (TA && TB && bsum_wg && splits == 1) {
+            for (int rl = tid_all; rl < BAND; rl += NTALL) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < WK; ++w) sum += *reinterpret_cast<const float*>(smem_all + w * RING + (rl * CP + BN) * 4);
+                if (row0 + band0 + rl < M) P.bias_grad[row0 + band0 + rl] = g.alpha * sum;
+            }
+        }
+        constexpr int NCH = BAND * BN / 4;
+        for (int q = tid_all; q < NCH; q += NTALL) {
+            const int rl = q / (BN / 4), c4 = (q % (BN / 4)) * 4;
+            const int row = row0 + band0 + rl, col = col0 + c4;
+            if (row >= M || col >= N) continue;
+            float4 a4 = *reinterpret_cast<const float4*>(smem_all + (rl * CP + c4) * 4);
+#pragma unroll
+            for (int w = 1; w < WK; ++w) {
+                const float4 b4 = *reinterpret_cast<const float4*>(smem_all + w * RING + (rl * CP + c4) * 4);
+                a4.x += b4.x; a4.y += b4.y; a4.z += b4.z; a4.w += b4.w;
+            }
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            const bool live = g.row_flag ? (g.row_flag[row / g.row_flag_div] != 0) : true;
+            const int nv = min(4, N - col);
+            float* dst = C ? C + (size_t)row * g.ldc + col : nullptr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= nv) break;
+                float x = g.alpha * v[e];
+                if (P.bias && first) x += P.bias[col + e];
+                if (!live) x = 0.f;
+                if (g.add_vec && first) x += g.add_vec[col + e];
+                if (splits > 1) {          // split-K: the K groups are already summed; one fp32 atomic per element into a zeroed C
+                    atomicAdd(dst + e, x);
+                    continue;
+                }
+                if (g.act == 1) x = fmaxf(x, 0.f);
+                else if (g.act == 2) x = gelu_erf2(x);
+                if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col + e] <= 0.f) x = 0.f;
+                if (g.accumulate) x += dst[e];
+                v[e] = x;
+            }
+            if (splits > 1) continue;
+            if (dst) {
+                if (nv == 4 && g.vecC) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int e = 0; e < nv; ++e) dst[e] = v[e];
+            }
+            if (Ch) {
+                bf16_t* dh = Ch + (size_t)row * ldch + col;
+                if (nv == 4 && g.vecB) {       // vecB doubles as "the bf16 result is 8-byte aligned" on this path
+                    bf16x4 h;
+                    h[0] = (bf16_t)v[0]; h[1] = (bf16_t)v[1]; h[2] = (bf16_t)v[2]; h[3] = (bf16_t)v[3];
+                    *reinterpret_cast<bf16x4*>(dh) = h;
+                } else {
+                    for (int e = 0; e < nv; ++e) dh[e] = (bf16_t)v[e];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int S, int WK = 1>
+int launch2(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
+    dim3 grid(cdiv(Mmax, BM) * cdiv(g.N, BN), splits, g.nprob), block(WM * WN * WK * 64);
+    if (grid.x == 0) return IMMTSF_OK;
+    switch (layout) {
+        case GEMM_NT: hipLaunchKernelGGL((gemm2_kernel<false, false, BM, BN, WM, WN, S, WK>), grid, block, 0, stream, g); break;
+        case GEMM_NN:
+            if constexpr (BN % 32 == 0) hipLaunchKernelGGL((gemm2_kernel<false, true, BM, BN, WM, WN, S, WK>), grid, block, 0, stream, g);
+            else return IMMTSF_EUNSUPPORTED;
+            break;
+        case GEMM_TN:
+            if constexpr (BN % 32 == 0 && BM % 32 == 0) hipLaunchKernelGGL((gemm2_kernel<true, true, BM, BN, WM, WN, S, WK>), grid, block, 0, stream, g);
+            else return IMMTSF_EUNSUPPORTED;
+            break;
+        default: return IMMTSF_EINVAL;
+    }
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int g2_variant = 0, g2_splitk = 0, g2_xcd = -1;
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
+    g2_variant = variant;
+    g2_splitk = splitk;
+    g2_xcd = xcd;
+    return 0;
+}
+
+bool immtsf_gemm2_supported(int layout, const GemmArgs& g) {
+    if (layout < 0 || layout > 2 || g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS || g.nbatch > 1) return false;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+    if ((g.lda % 8) || (g.ldb % 8)) return false;
+    if (layout == GEMM_TN && (g.a_rowmap || g.b_rowmap)) return false;
+    if (layout == GEMM_NN && g.b_rowmap) return false;
+    // chunks are 8 elements along the contiguous dimension: the K tail of an R image and the column edge of a T image
+    // are handled in whole chunks
+    if (layout == GEMM_NT && (g.K % 8)) return false;
+    if (layout == GEMM_NN && ((g.K % 8) || (g.N % 8))) return false;
+    if (layout == GEMM_TN && ((g.M % 8) || (g.N % 8))) return false;
+    if (g.dyn && g.dyn_which == 1 && layout != GEMM_TN) return false;      // a dynamic K must not cut a chunk
+    if (g.dyn && g.dyn_which == 0 && layout == GEMM_TN) return false;
+    for (int i = 0; i < g.nprob; ++i) {
+        const GemmProblem& p = g.p[i];
+        if (!p.Ah || !p.Bh || !al16(p.Ah) || !al16(p.Bh)) return false;
+        if (!p.C && !p.Ch) return false;
+        if (g.accumulate && !p.C) return false;
+    }
+    return true;
+}
+
+int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
+    if (!immtsf_gemm2_supported(layout, g)) return IMMTSF_EUNSUPPORTED;
+    if (g.row_flag && g.row_flag_div <= 0) return IMMTSF_EINVAL;
+    if (g.ones_col && layout != GEMM_TN) return IMMTSF_EINVAL;
+    const int ldch = g.ldch ? g.ldch : g.ldc;
+    bool vc = (g.ldc % 4) == 0, vh = (ldch % 4) == 0, any_h = false, all_c = true;
+    for (int i = 0; i < g.nprob; ++i) {
+        if (g.p[i].C) vc = vc && al16(g.p[i].C); else all_c = false;
+        if (g.p[i].Ch) { any_h = true; vh = vh && ((reinterpret_cast<uintptr_t>(g.p[i].Ch) & 7) == 0); }
+    }
+    g.vecC = vc ? 1 : 0;
+    g.vecB = vh ? 1 : 0;
+    g.vecA = 1;
+    const int Mmax = g.M;
+    const long t64 = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * g.nprob;
+
+    // split-K over workgroups (fp32 atomics into a zeroed C) is only a tool option here: the K-group variants below split
+    // the reduction INSIDE a workgroup and sum through LDS, which measured faster at every weight-gradient shape of the
+    // fusion step (r02: 768x768x2048 13.1 us unsplit on 64x64 k4 vs 17.9 us as 2 atomic splits of the 4-wave tile)
+    const bool can_split = all_c && !any_h && g.act == 0 && !g.relu_ref && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
+    int splits = 1;
+    if (can_split && g2_splitk > 1) splits = g2_splitk;
+    if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
+        for (int i = 0; i < g.nprob; ++i) {
+            hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
+            if (e != hipSuccess) return (int)e;
+            if (g.p[i].bias_grad) {
+                e = hipMemsetAsync(g.p[i].bias_grad, 0, (size_t)Mmax * sizeof(float), stream);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+    }
+    {
+        const bool b_fits_l2 = (size_t)g.N * g.K * 2 <= (size_t)3 << 20;
+        g.xcd_remap = (t64 >= 64 && (t64 < 2048 || b_fits_l2) && g.N >= 256) ? 8 : 0;
+        if (g2_xcd >= 0) g.xcd_remap = g2_xcd ? 8 : 0;
+    }
+    int v = g2_variant;
+    if (v == 0) {
+        // Tile choice (r02 sweeps, profiles/r02_gemm2_sweep.txt).  The K-group variants (k4: 16 waves, 128-160 KB of LDS)
+        // run ONE workgroup per CU, so they want a grid that fills the 256 CUs in a single round; when the rows are a
+        // device-side count (ragged notes) the expected fill is about half the allocation bound.
+        const int Meff = (g.dyn && g.dyn_which == 0) ? (Mmax * 9 + 15) / 16 : Mmax;
+        const long n64 = (long)cdiv(Meff, 64) * cdiv(g.N, 64) * g.nprob;
+        const long n96 = (long)cdiv(Meff, 64) * cdiv(g.N, 96) * g.nprob;
+        const long n128x96 = (long)cdiv(Meff, 128) * cdiv(g.N, 96) * g.nprob;
+        const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
+        const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
+        if (t128 >= 1024 && layout != GEMM_TN) v = 13;          // 256x256, 8 waves, 2 stages
+        else if (t128 >= 512) v = 7;                              // 256x128
+        else if (n64 <= 272) v = 17;                              // 64x64 k4
+        else if (n96_ok && n96 <= 272) v = 16;                    // 64x96 k4
+        else if (n96_ok && n128x96 <= 272) v = 22;                // 128x96 k2
+        else v = 9;                                               // 64x64, 8 waves, 4 stages, two workgroups per CU
+    }
+    switch (v) {
+        case 1: return launch2<64, 64, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 2: return launch2<64, 96, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 3: return launch2<128, 64, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 4: return launch2<64, 128, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 5: return launch2<128, 128, 2, 2, 3>(layout, g, Mmax, splits, stream);
+        case 6: return launch2<128, 128, 2, 4, 4>(layout, g, Mmax, splits, stream);
+        case 7: return launch2<256, 128, 4, 2, 3>(layout, g, Mmax, splits, stream);
+        case 8: return launch2<64, 64, 2, 2, 3>(layout, g, Mmax, splits, stream);
+        case 9: return launch2<64, 64, 2, 4, 4>(layout, g, Mmax, splits, stream);
+        case 10: return launch2<96, 64, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 11: return launch2<64, 96, 2, 2, 6>(layout, g, Mmax, splits, stream);
+        case 12: return launch2<128, 96, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 13: return launch2<256, 256, 2, 4, 2>(layout, g, Mmax, splits, stream);
+        case 14: return launch2<64, 96, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 15: return launch2<64, 64, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 16: return launch2<64, 96, 2, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 17: return launch2<64, 64, 2, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        case 18: return launch2<128, 128, 2, 2, 2, 2>(layout, g, Mmax, splits, stream);
+        case 19: return launch2<96, 64, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 20: return launch2<128, 64, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 21: return launch2<64, 128, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 22: return launch2<128, 96, 2, 2, 2, 2>(layout, g, Mmax, splits, stream);
+        case 23: return launch2<64, 64, 2, 2, 4, 2>(layout, g, Mmax, splits, stream);
+        case 24: return launch2<256, 128, 4, 2, 2>(layout, g, Mmax, splits, stream);
+        case 25: return launch2<96, 96, 2, 2, 3, 2>(layout, g, Mmax, splits, stream);
+        case 26: return launch2<64, 96, 2, 2, 2, 3>(layout, g, Mmax, splits, stream);
+        case 27: return launch2<96, 64, 2, 2, 2, 4>(layout, g, Mmax, splits, stream);
+        default: return IMMTSF_EINVAL;
+    }
+}
+
+// debug / test / tool entry (declared in include/immtsf.h)
+extern "C" int immtsf_gemm_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc,
+                                void* Ch, int32_t ldch, const float* bias, float* bias_grad, int32_t M, int32_t N, int32_t K,
+                                float alpha, int32_t accumulate, int32_t act, const int32_t* dyn, int32_t dyn_which,
+                                const int32_t* a_rowmap, void* stream) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.nprob = 1;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldch = ldch;
+    g.alpha = alpha;
+    g.accumulate = accumulate;
+    g.act = act;
+    g.row_flag_div = 1;
+    g.nbatch = 1;
+    g.batch_inner = 1;
+    g.dyn = dyn;
+    g.dyn_which = dyn_which;
+    g.a_rowmap = a_rowmap;
+    g.p[0].Ah = A;
+    g.p[0].Bh = B;
+    g.p[0].C = C;
+    g.p[0].Ch = Ch;
+    g.p[0].bias = bias;
+    g.p[0].bias_grad = bias_grad;
+    if (bias_grad) g.ones_col = 1;
+    return immtsf_launch_gemm2(layout, g, static_cast<hipStream_t>(stream));
+}

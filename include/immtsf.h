@@ -404,6 +404,21 @@ int immtsf_side_stream_enabled(void);
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);
 int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);
 
+/* The bf16-in-memory GEMM the bf16 mode runs its projections on (csrc/gemm2.hip): A and B are bf16 in HBM and reach
+ * LDS by LDS-DMA through a multi-stage ring; results as fp32 (C, may be NULL) and/or bf16 (Ch, may be NULL; row pitch
+ * ldch).  layout 0 NT: C = A(M,K) B(N,K)^T (a linear layer's forward, layers/*.py nn.Linear call sites and
+ * fusions/*.py projections); 1 NN: C = A(M,K) B(K,N) (its data gradient); 2 TN: C = A(K,M)^T B(K,N) (its weight
+ * gradient; bias_grad (M) = column sums of A when given).  dyn: optional device int32 overriding M (dyn_which 0, NT/NN)
+ * or K (dyn_which 1, TN) -- the ragged note count; a_rowmap: optional source row per logical row of A (NT/NN).
+ * IMMTSF_EUNSUPPORTED: operands not 16-byte aligned / leading dimensions not multiples of 8 / K (NT, NN) or M, N (TN)
+ * not multiples of 8. */
+int immtsf_gemm_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc, void* Ch,
+                     int32_t ldch, const float* bias, float* bias_grad, int32_t M, int32_t N, int32_t K, float alpha,
+                     int32_t accumulate, int32_t act, const int32_t* dyn, int32_t dyn_which, const int32_t* a_rowmap,
+                     immtsf_stream_t stream);
+/* tuning aid for tools/gemm2_bench.py: force a tile variant, a split-K factor, the XCD tile order (-1 = heuristic) */
+int immtsf_debug_gemm2_config(int32_t variant, int32_t splitk, int32_t xcd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
                                                                const int* __restrict__ rowmap,
                                                                const float* __restrict__ KVp, const float* __restrict__ qs,
                                                                float* __restrict__ P, float* __restrict__ ctx, DropCfg drop,
-                                                               uint64_t site) {
+                                                               uint64_t site, bf16_t* __restrict__ ctx_h) {
     extern __shared__ float lds[];
     float* sc = lds;
     float* atile = lds + dm.N;
@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     const int e = ez * 256 + tid;
     const bool valid = e < hd;
     if (n == 0) {   // no notes: the caller zeroes the row after out_proj anyway (M_txt); keep ctx defined
-        if (valid) for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = 0.f;
+        if (valid) for (int t = 0; t < T; ++t) {
+            const size_t o = (size_t)(b * T + t) * d + h * hd + e;
+            if (ctx) ctx[o] = 0.f;
+            if (ctx_h) ctx_h[o] = (bf16_t)0.f;
+        }
         return;
     }
     // two notes per pass, their key loads (hd/64 each, unrolled) all in flight together: a wave's notes are a chain of
@@ -71,7 +75,11 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
         float acc = 0.f;
 #pragma unroll 8
         for (int i = 0; i < n; ++i) acc = fmaf(sc[i], vbase[(size_t)i * ld], acc);
-        for (int t = 0; t < T; ++t) ctx[(size_t)(b * T + t) * d + h * hd + e] = acc;
+        for (int t = 0; t < T; ++t) {
+            const size_t o = (size_t)(b * T + t) * d + h * hd + e;
+            if (ctx) ctx[o] = acc;
+            if (ctx_h) ctx_h[o] = (bf16_t)acc;
+        }
         return;
     }
     for (int t0 = 0; t0 < T; t0 += TT) {
@@ -107,7 +115,11 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
         if (valid) {
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt)
-                if (t0 + tt < T) ctx[(size_t)(b * T + t0 + tt) * d + h * hd + e] = acc[tt];
+                if (t0 + tt < T) {
+                    const size_t o = (size_t)(b * T + t0 + tt) * d + h * hd + e;
+                    if (ctx) ctx[o] = acc[tt];
+                    if (ctx_h) ctx_h[o] = (bf16_t)acc[tt];
+                }
         }
     }
 }
@@ -123,7 +135,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
                                                                   const int* __restrict__ rowmap,
                                                                   const float* __restrict__ KVp, const float* __restrict__ P,
                                                                   const float* __restrict__ dctx, float* __restrict__ dKVp,
-                                                                  float* __restrict__ dp_buf, DropCfg drop, uint64_t site) {
+                                                                  float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
+                                                                  bf16_t* __restrict__ dKVp_h) {
     const int b = blockIdx.x, h = blockIdx.y, c = blockIdx.z * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
@@ -170,7 +183,9 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
         if (valid) {
             const size_t off = (size_t)(o0 + i) * ld + d + h * hd + c;
             a = g * KVp[off];
-            dKVp[off] = P[(size_t)(o0 + i) * dm.H + h] * g;
+            const float dvv = P[(size_t)(o0 + i) * dm.H + h] * g;
+            if (dKVp) dKVp[off] = dvv;
+            if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
         }
         a = wave_sum(a);
         if (lane == 0) atomicAdd(dp_buf + (size_t)(o0 + i) * dm.H + h, a);
@@ -183,7 +198,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
 __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                   const float* __restrict__ KVp, const float* __restrict__ qs,
                                                                   const float* __restrict__ P, const float* __restrict__ dp_buf,
-                                                                  float* __restrict__ dKVp, float* __restrict__ dqs_part) {
+                                                                  float* __restrict__ dKVp, float* __restrict__ dqs_part,
+                                                                  bf16_t* __restrict__ dKVp_h) {
     extern __shared__ float lds[];
     float* ds = lds;
     float* red = lds + dm.N;
@@ -209,12 +225,14 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     if (c >= hd) return;
     const float q = qs[h * hd + c];
     const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
-    float* dkc = dKVp + (size_t)o0 * ld + h * hd + c;
+    const size_t dk0 = (size_t)o0 * ld + h * hd + c;
     float a = 0.f;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
         a = fmaf(ds[i], kc[(size_t)i * ld], a);
-        dkc[(size_t)i * ld] = ds[i] * q;
+        const float dkv = ds[i] * q;
+        if (dKVp) dKVp[dk0 + (size_t)i * ld] = dkv;
+        if (dKVp_h) dKVp_h[dk0 + (size_t)i * ld] = (bf16_t)dkv;
     }
     dqs_part[(size_t)b * d + h * hd + c] = a;
 }
@@ -410,19 +428,19 @@ __global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const 
 }  // namespace
 
 int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s) {
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h) {
     if (dm.B <= 0) return IMMTSF_OK;
     const size_t lds = (size_t)(dm.N + TT * 64 + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
     hipLaunchKernelGGL(ragged_attn_fwd_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
-                       P, ctx, drop, site);
+                       P, ctx, drop, site, static_cast<bf16_t*>(ctx_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
                            const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
-                           uint64_t site, hipStream_t s) {
+                           uint64_t site, hipStream_t s, void* dKVp_h) {
     if (dm.B <= 0) return IMMTSF_OK;
     if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
     const size_t lds = (size_t)(dm.N + 16) * sizeof(float);
@@ -430,10 +448,10 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
     hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
-                       dctx, dKVp, dp_buf, drop, site);
+                       dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h));
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P, dp_buf,
-                       dKVp, dqs_part);
+                       dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -10,11 +10,11 @@ struct RaggedAttnDims {
 
 // forward: KVp packed rows [R, 2d] = (k | v); qs = scaled query [d]; P out [R, H]; ctx out [B*T, d]
 int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s);
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h = nullptr);   // ctx_h: bf16 ctx (ctx may be null)
 // backward: dctx [B*T, d] -> dKVp [R, 2d] (dk | dv), dqs_part [B, d]; dp_buf: scratch of B*N*H floats
 int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
                            const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
-                           uint64_t site, hipStream_t s);
+                           uint64_t site, hipStream_t s, void* dKVp_h = nullptr);   // dKVp_h: bf16 copy (dKVp may be null)
 
 // rows = B*H*L, each of length S.  In place on `sc`: P = softmax(sc) (0 where !live[b]); A = P*dropscale
 // written to `A` (may alias sc when drop.p == 0).

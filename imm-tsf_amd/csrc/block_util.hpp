@@ -2,10 +2,22 @@
 #pragma once
 #include "../../include/immtsf.h"
 #include "gemm.hpp"
+#include "tail.hpp"
 #include <string.h>
 
 namespace {
 
+// ---- bf16 mode keeps every GEMM operand as bf16 in HBM (gemm2.hip reads it by LDS-DMA): a logical matrix is an fp32
+// image (for the row kernels, the parity mode and the round-1 GEMM), a bf16 image (for the bf16-in-memory GEMM), or both
+struct Mat {
+    float* f;
+    void* h;
+};
+inline Mat mat(float* f, void* h = nullptr) { return Mat{f, h}; }
+inline Mat cmat(const float* f, const void* h = nullptr) { return Mat{const_cast<float*>(f), const_cast<void*>(h)}; }
+inline Mat mat_off(Mat m, size_t elems) {
+    return Mat{m.f ? m.f + elems : nullptr, m.h ? static_cast<void*>(static_cast<unsigned short*>(m.h) + elems) : nullptr};
+}
 struct Carver {
     char* base;
     size_t off;
@@ -17,6 +29,13 @@ struct Carver {
         return p;
     }
     size_t bytes() const { return (off + 255) & ~size_t(255); }
+    // fp32 and / or bf16 image of an n-element matrix
+    Mat take_mat(size_t n, bool want_f, bool want_h) {
+        Mat m{nullptr, nullptr};
+        if (want_f) m.f = take<float>(n);
+        if (want_h) m.h = take<unsigned short>(n);
+        return m;
+    }
 };
 
 inline DropCfg drop_of(const immtsf_fusion_cfg* c) {
@@ -41,6 +60,28 @@ inline GemmArgs gemm_args(int M, int N, int K, int lda, int ldb, int ldc) {
     return g;
 }
 inline void prezeroed(GemmArgs& g, const immtsf_fusion_cfg* c) { g.c_prezeroed = c->grads_prezeroed ? 1 : 0; }
+
+inline void set_problem2(GemmArgs& g, int i, Mat A, Mat B, Mat C, const float* bias, float* bias_grad = nullptr) {
+    g.p[i].A = A.f; g.p[i].Ah = A.h;
+    g.p[i].B = B.f; g.p[i].Bh = B.h;
+    g.p[i].C = C.f; g.p[i].Ch = C.h;
+    g.p[i].bias = bias; g.p[i].bias_grad = bias_grad;
+    if (bias_grad) g.ones_col = 1;
+}
+// bf16 image of a weight matrix for the bf16-in-memory GEMM: its registered twin (FlatTrainer keeps one current), else a
+// cast into the caller's `slot` (enqueued on `s`).  hf == false: fp32 only.
+inline int weight_mat(bool hf, const float* W, size_t n, void* slot, hipStream_t s, Mat* out) {
+    out->f = const_cast<float*>(W);
+    out->h = nullptr;
+    if (!hf || !W) return 0;
+    const void* tw = immtsf_twin_lookup(W, n);
+    if (tw && (reinterpret_cast<uintptr_t>(tw) & 15) == 0) { out->h = const_cast<void*>(tw); return 0; }
+    if (!slot) return IMMTSF_EWORKSPACE;
+    const int rc = launch_f32_to_bf16(W, slot, n, s);
+    out->h = slot;
+    return rc;
+}
+
 inline void set_problem(GemmArgs& g, int i, const float* A, const float* B, float* C, const float* bias, float* bias_grad = nullptr) {
     g.p[i].A = A; g.p[i].B = B; g.p[i].C = C; g.p[i].bias = bias; g.p[i].bias_grad = bias_grad;
     if (bias_grad) g.ones_col = 1;

@@ -13,14 +13,23 @@
 namespace {
 
 // ================================================================================================ TTF_T2V_XAttn
+// bf16 dataflow (`hf`): in bf16 mode, when every reduction length is a whole number of 8-element chunks, the operands of
+// the projections live in HBM as bf16 (written by their producers' epilogues) and the GEMMs run on the LDS-DMA kernel
+// (gemm2.hip); tensors only row kernels read stay fp32.  Otherwise (fp32 parity mode, odd dims) every tensor is fp32 and
+// the round-1 kernel converts while staging.
+inline bool t2v_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d >= 16 && (c->d % 16) == 0 && (c->d_m % 8) == 0; }
+
 struct T2VWs {
     unsigned char *mask, *mtxt;
     int *lengths, *offsets, *rowmap, *seg;
-    float *Xcat, *KV, *KVp, *q, *qs, *P, *ctx, *xpre, *xhat, *rstd, *z;
+    Mat Xcat, KV, ctx, z;
+    float *KVp, *q, *qs, *P, *xpre, *xhat, *rstd;
+    void *w_in, *w_kv, *w_inkv, *w_out, *w_po;     // bf16 weight images when no twin is registered (hf only)
     size_t bytes;
 };
 T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     const size_t B = c->B, N = c->N, T = c->T, d = c->d, dt = c->d / 2, R = B * N, BT = B * T;
+    const bool hf = t2v_hf(c);
     Carver k(base);
     T2VWs w;
     w.mask = k.take<unsigned char>(R);
@@ -29,33 +38,44 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     w.offsets = k.take<int>(B + 1);
     w.rowmap = k.take<int>(R);
     w.seg = k.take<int>(R);
-    w.Xcat = k.take<float>(R * (d + dt));
-    w.KV = k.take<float>(R * d);
+    w.Xcat = k.take_mat(R * (d + dt), !hf, hf);
+    w.KV = k.take_mat(R * d, !hf, hf);
     w.KVp = k.take<float>(R * 2 * d);
     w.q = k.take<float>(d);
     w.qs = k.take<float>(d);
     w.P = k.take<float>(R * c->H);
-    w.ctx = k.take<float>(BT * d);
+    w.ctx = k.take_mat(BT * d, !hf, hf);
     w.xpre = k.take<float>(BT * d);
     w.xhat = k.take<float>(BT * d);
     w.rstd = k.take<float>(BT);
-    w.z = k.take<float>(BT * d);
+    w.z = k.take_mat(BT * d, !hf, hf);
+    w.w_in = w.w_kv = w.w_inkv = w.w_out = w.w_po = nullptr;
+    if (hf) {
+        w.w_in = k.take<unsigned short>(d * (size_t)c->d_m);
+        w.w_kv = k.take<unsigned short>(d * (d + dt));
+        w.w_inkv = k.take<unsigned short>(2 * d * d);
+        w.w_out = k.take<unsigned short>(d * d);
+        w.w_po = k.take<unsigned short>(d * d);
+    }
     w.bytes = k.bytes();
     return w;
 }
 struct T2VScratch {
-    float *dz, *dx, *dctx, *dKVp, *dKV, *dXcat, *dqs_part, *dqs, *dq, *dp, *red;
+    Mat dE, dx, dKVp, dKV;
+    float *dz, *dctx, *dXcat, *dqs_part, *dqs, *dq, *dp, *red;
     size_t bytes;
 };
 T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     const size_t B = c->B, N = c->N, T = c->T, d = c->d, dt = c->d / 2, R = B * N, BT = B * T;
+    const bool hf = t2v_hf(c);
     Carver k(base);
     T2VScratch s;
+    s.dE = k.take_mat(BT * d, false, hf);
     s.dz = k.take<float>(BT * d);
-    s.dx = k.take<float>(BT * d);
+    s.dx = k.take_mat(BT * d, true, hf);
     s.dctx = k.take<float>(BT * d);
-    s.dKVp = k.take<float>(R * 2 * d);
-    s.dKV = k.take<float>(R * d);
+    s.dKVp = k.take_mat(R * 2 * d, !hf, hf);
+    s.dKV = k.take_mat(R * d, !hf, hf);
     s.dXcat = k.take<float>(R * (d + dt));
     s.dqs_part = k.take<float>(B * d);
     s.dqs = k.take<float>(d);
@@ -64,6 +84,19 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.red = k.take<float>(64 * (d + dt + 8));
     s.bytes = k.bytes();
     return s;
+}
+
+// the block's GEMM weights as (fp32, bf16) pairs
+struct T2VW { Mat in, kv, inkv, out, po; };
+int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2VWs& w, hipStream_t s, T2VW* o) {
+    const bool hf = t2v_hf(c);
+    const size_t d = c->d, dcat = d + d / 2;
+    CHECK(weight_mat(hf, p->input_proj_w, d * (size_t)c->d_m, w.w_in, s, &o->in));
+    CHECK(weight_mat(hf, p->kv_w, d * dcat, w.w_kv, s, &o->kv));
+    CHECK(weight_mat(hf, p->attn_in_w + d * d, 2 * d * d, w.w_inkv, s, &o->inkv));
+    CHECK(weight_mat(hf, p->attn_out_w, d * d, w.w_out, s, &o->out));
+    CHECK(weight_mat(hf, p->proj_out_w, d * d, w.w_po, s, &o->po));
+    return 0;
 }
 
 }  // namespace
@@ -102,46 +135,50 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
 
+    const bool hf = t2v_hf(cfg);
+    T2VW W;
+    CHECK(t2v_weights(cfg, p, w, s, &W));
     if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
     else CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
     CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s));
     const int* gather = src_rows ? src_rows : w.rowmap;
-    // [input_proj(V) ; time2vec(tau)] on the packed rows
+    // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
+    // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
     if (p->input_proj_w) {
         GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, dcat);
-        set_problem(g, 0, notes, p->input_proj_w, w.Xcat, p->input_proj_b);
+        set_problem2(g, 0, cmat(notes), W.in, w.Xcat, p->input_proj_b);
         g.dyn = total; g.dyn_which = 0; g.a_rowmap = gather;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     } else {
-        CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, d, w.Xcat, dcat, s));
+        CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, d, w.Xcat.f, dcat, s, w.Xcat.h));
     }
     CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b,
-                              w.Xcat + d, dcat, s));
+                              w.Xcat.f ? w.Xcat.f + d : nullptr, dcat, s, w.Xcat.h ? mat_off(w.Xcat, d).h : nullptr));
     {   // KV = KV_proj([V;tau])
         GemmArgs g = gemm_args(R, d, dcat, dcat, dcat, d);
-        set_problem(g, 0, w.Xcat, p->kv_w, w.KV, p->kv_b);
+        set_problem2(g, 0, w.Xcat, W.kv, w.KV, p->kv_b);
         g.dyn = total;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     {   // packed k|v in-projection (rows d..3d of attn.in_proj_weight), once per note
         GemmArgs g = gemm_args(R, 2 * d, d, d, d, 2 * d);
-        set_problem(g, 0, w.KV, p->attn_in_w + (size_t)d * d, w.KVp, p->attn_in_b + d);
+        set_problem2(g, 0, w.KV, W.inkv, mat(w.KVp), p->attn_in_b + d);
         g.dyn = total;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx, drop, SITE_T2V_ATTN, s));
+    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h));
     {   // out_proj, zero the windows without notes, + Q_param residual
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, w.ctx, p->attn_out_w, w.xpre, p->attn_out_b);
+        set_problem2(g, 0, w.ctx, W.out, mat(w.xpre), p->attn_out_b);
         g.row_flag = w.mtxt; g.row_flag_div = T; g.add_vec = p->Q_param;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z, drop, SITE_T2V_OUT, s));
+    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z.f, drop, SITE_T2V_OUT, s, w.z.h));
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, w.z, p->proj_out_w, E_txt, p->proj_out_b);
+        set_problem2(g, 0, w.z, W.po, mat(E_txt), p->proj_out_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     hipError_t e = hipMemcpyAsync(M_txt, w.mtxt, B, hipMemcpyDeviceToDevice, s);
@@ -177,32 +214,40 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     const float scale = sqrtf(1.0f / (float)hd);
     Fork fk(s);   // weight-gradient GEMMs run on the side stream, joined before returning
 
+    const bool hf = t2v_hf(cfg);
+    T2VW W;
+    CHECK(t2v_weights(cfg, p, w, s, &W));
+    Mat dE = cmat(dE_txt);
+    if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
+        CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+        dE.h = sc.dE.h;
+    }
     {   // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, dE_txt, p->proj_out_w, sc.dz, nullptr);
+        set_problem2(g, 0, dE, W.po, mat(sc.dz), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem(h, 0, dE_txt, w.z, gr->proj_out_w, nullptr, gr->proj_out_b);
+        set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
+    CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
     CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s));
     // residual: dQ_param = sum over all (b,t) rows; then only windows with notes feed the attention branch
-    CHECK(launch_colsum(sc.dx, nullptr, BT, nullptr, d, d, gr->Q_param, 0, sc.red, s));
-    CHECK(launch_mask_rows(sc.dx, BT, d, w.mtxt, T, s));
+    CHECK(launch_colsum(sc.dx.f, nullptr, BT, nullptr, d, d, gr->Q_param, 0, sc.red, s));
+    CHECK(launch_mask_rows(sc.dx.f, BT, d, w.mtxt, T, s, sc.dx.h));
     {   // out_proj
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, sc.dx, p->attn_out_w, sc.dctx, nullptr);
+        set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem(h, 0, sc.dx, w.ctx, gr->attn_out_w, nullptr, gr->attn_out_b);
+        set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp, sc.dqs_part, sc.dp, drop,
-                                 SITE_T2V_ATTN, s));
+    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
+                                 SITE_T2V_ATTN, s, sc.dKVp.h));
     // query path: q = W_q Q_param + b_q, qs = q * scale
     CHECK(launch_colsum(sc.dqs_part, nullptr, B, nullptr, d, d, sc.dqs, 0, sc.red, s));
     CHECK(launch_axpy(sc.dqs, scale, sc.dq, d, 0, s));
@@ -211,27 +256,27 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     CHECK(launch_matvec_t(p->attn_in_w, d, sc.dq, d, d, gr->Q_param, 1, s));        // += W_q^T dq
     {   // k|v in-projection
         GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
-        set_problem(g, 0, sc.dKVp, p->attn_in_w + (size_t)d * d, sc.dKV, nullptr);
+        set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
         g.dyn = total; g.dyn_which = 0;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
-        set_problem(h, 0, sc.dKVp, w.KV, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
+        set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
         h.dyn = total; h.dyn_which = 1;
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     {   // KV_proj
         GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
-        set_problem(g, 0, sc.dKV, p->kv_w, sc.dXcat, nullptr);
+        set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat), nullptr);
         g.dyn = total; g.dyn_which = 0;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
-        set_problem(h, 0, sc.dKV, w.Xcat, gr->kv_w, nullptr, gr->kv_b);
+        set_problem2(h, 0, sc.dKV, w.Xcat, mat(gr->kv_w), nullptr, gr->kv_b);
         h.dyn = total; h.dyn_which = 1;
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp
+    if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp   (row-mapped, fp32 operands: the round-1 kernel)
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;

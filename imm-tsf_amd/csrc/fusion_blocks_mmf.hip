@@ -13,38 +13,74 @@
 
 namespace {
 
-// ---- the block is split into a key/value half (depends only on E_txt: proj_k/proj_v + their MHA in-projections) and
-// a query half (everything else).  The halves are separate C entry points so the host can run the key/value half --
-// four of the block's six 2048x768x768 GEMMs forward, eight backward -- on the text stream beside the backbone, and
-// start the backbone's backward as soon as the query half has produced dY_ts.  The monolithic entry points call both.
+// ---- Folded form.  Between proj_{q,k,v} (no bias) and the MHA in-projections there is no nonlinearity, and neither is
+// there between out_proj and residual_head (only the zeroing of no-text windows, which commutes with a row-wise linear
+// map up to the bias), so per step the block forms the PRODUCT weights once
+//     W_Kf = W_in,k W_k   W_Vf = W_in,v W_v   (d x d each, stacked as W_KVf (2d, d))      W_Qf = W_in,q W_q  (d x C)
+//     W_HO = W_res W_out  (C x d)             b_HO = W_res b_out + b_res
+// and runs ONE (B*T) x 2d x d projection of E_txt (k | v side by side), a (B*T) x d x C projection of Y_ts, the attention,
+// and the C-wide head straight on the attention output.  Backward: the data gradients flow through the same products
+// and the gradients of the ORIGINAL parameters follow by the chain rule from the product weights' gradients (d x d x d
+// GEMMs instead of (B*T) x d x d ones): dW_in,k = dW_Kf W_k^T, dW_k = W_in,k^T dW_Kf, ...  Same function, same
+// state_dict, results equal to the unfolded chain up to fp32 reassociation (bf16 mode: one operand rounding of the
+// product weight instead of one of the intermediate activation).  Six of the block's eight (B*T) x d x d forward GEMMs
+// and eight of its twelve backward ones disappear.
+//
+// The block is split into a key/value half (depends only on E_txt) and a query half (everything else).  The halves are
+// separate C entry points so the host can run the key/value half on the text stream beside the backbone, and start the
+// backbone's backward as soon as the query half has produced dY_ts.  The monolithic entry points call both.
+inline bool xadd_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d >= 16 && (c->d % 8) == 0; }
+
 struct KVWs {
-    float *K0, *V0;
+    Mat E, WKVf;          // bf16 image of E_txt (hf) ; the stacked product weight (2d, d)
+    void *w_k, *w_v, *w_inkv;
     size_t bytes;
 };
 KVWs carve_kv(const immtsf_fusion_cfg* c, void* base) {
     const size_t BT = (size_t)c->B * c->T, d = c->d;
+    const bool hf = xadd_hf(c);
     Carver k(base);
     KVWs w;
-    w.K0 = k.take<float>(BT * d);
-    w.V0 = k.take<float>(BT * d);
+    w.E = k.take_mat(BT * d, false, hf);
+    w.WKVf = k.take_mat(2 * d * d, !hf, hf);
+    w.w_k = w.w_v = w.w_inkv = nullptr;
+    if (hf) {
+        w.w_k = k.take<unsigned short>(d * d);
+        w.w_v = k.take<unsigned short>(d * d);
+        w.w_inkv = k.take<unsigned short>(2 * d * d);
+    }
     w.bytes = k.bytes();
     return w;
 }
 struct KVScratch {
-    float *dK0, *dV0;
+    Mat dKV, dWKVf;
     size_t bytes;
 };
 KVScratch carve_kv_scratch(const immtsf_fusion_cfg* c, void* base) {
     const size_t BT = (size_t)c->B * c->T, d = c->d;
+    const bool hf = xadd_hf(c);
     Carver k(base);
     KVScratch s;
-    s.dK0 = k.take<float>(BT * 2 * d);      // [dK0 | dV0] side by side, row pitch 2d: one K = 2d GEMM can read both
-    s.dV0 = s.dK0 ? s.dK0 + d : nullptr;
+    s.dKV = k.take_mat(BT * 2 * d, false, hf);
+    s.dWKVf = k.take_mat(2 * d * d, !hf, hf);
     s.bytes = k.bytes();
     return s;
 }
+struct KVW { Mat k, v, ink, inv; };
+int kv_weights(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const KVWs& w, hipStream_t s, KVW* o) {
+    const bool hf = xadd_hf(c);
+    const size_t d = c->d;
+    CHECK(weight_mat(hf, p->proj_k_w, d * d, w.w_k, s, &o->k));
+    CHECK(weight_mat(hf, p->proj_v_w, d * d, w.w_v, s, &o->v));
+    Mat inkv;
+    CHECK(weight_mat(hf, p->attn_in_w + d * d, 2 * d * d, w.w_inkv, s, &inkv));
+    o->ink = inkv;
+    o->inv = mat_off(inkv, d * d);
+    return 0;
+}
+
 struct QWs {
-    float *Q0, *Qi, *Pm, *Am, *O, *U, *delta, *xhatC, *rstdC;
+    float *WQf, *WHO, *bHO, *tHO, *Qi, *Pm, *Am, *O, *delta, *xhatC, *rstdC;
     size_t bytes;
 };
 QWs carve_q(const immtsf_fusion_cfg* c, void* base) {
@@ -52,12 +88,14 @@ QWs carve_q(const immtsf_fusion_cfg* c, void* base) {
     const bool dropping = c->training && c->p_drop > 0.f;
     Carver k(base);
     QWs w;
-    w.Q0 = k.take<float>(BT * d);
+    w.WQf = k.take<float>(d * C);
+    w.WHO = k.take<float>(C * d);
+    w.bHO = k.take<float>(C);
+    w.tHO = k.take<float>(C);
     w.Qi = k.take<float>(BT * d);
     w.Pm = k.take<float>(S);
     w.Am = dropping ? k.take<float>(S) : w.Pm;
     w.O = k.take<float>(BT * d);
-    w.U = k.take<float>(BT * d);
     w.delta = k.take<float>(BT * C);
     w.xhatC = k.take<float>(BT * C);
     w.rstdC = k.take<float>(BT);
@@ -65,7 +103,7 @@ QWs carve_q(const immtsf_fusion_cfg* c, void* base) {
     return w;
 }
 struct QScratch {
-    float *dn, *ddelta, *dU, *dO, *dA, *dQi, *dQ0, *red;
+    float *dn, *ddelta, *dO, *dA, *dQi, *dWQf, *dWHO, *slive, *red;
     size_t bytes;
 };
 QScratch carve_q_scratch(const immtsf_fusion_cfg* c, void* base) {
@@ -74,19 +112,20 @@ QScratch carve_q_scratch(const immtsf_fusion_cfg* c, void* base) {
     QScratch s;
     s.dn = k.take<float>(BT * C);
     s.ddelta = k.take<float>(BT * C);
-    s.dU = k.take<float>(BT * d);
     s.dO = k.take<float>(BT * d);
     s.dA = k.take<float>(S);
     s.dQi = k.take<float>(BT * d);
-    s.dQ0 = k.take<float>(BT * d);
+    s.dWQf = k.take<float>(d * C);
+    s.dWHO = k.take<float>(C * d);
+    s.slive = k.take<float>(C);
     s.red = k.take<float>(64 * (d + C + 8));
     s.bytes = k.bytes();
     return s;
 }
-// monolithic call: [query half][key/value half][Ki][Vi]
+// monolithic call: [query half][key/value half][KV]
 struct XAddWs {
     void *q, *kv;
-    float *Ki, *Vi;
+    float* KV;
     size_t qb, kvb, bytes;
 };
 XAddWs carve_xadd(const immtsf_fusion_cfg* c, void* base) {
@@ -97,12 +136,11 @@ XAddWs carve_xadd(const immtsf_fusion_cfg* c, void* base) {
     w.kvb = carve_kv(c, nullptr).bytes;
     w.q = k.take<unsigned char>(w.qb);
     w.kv = k.take<unsigned char>(w.kvb);
-    w.Ki = k.take<float>(BT * d);
-    w.Vi = k.take<float>(BT * d);
+    w.KV = k.take<float>(BT * 2 * d);
     w.bytes = k.bytes();
     return w;
 }
-XAddWs carve_xadd_scratch(const immtsf_fusion_cfg* c, void* base) {     // same shape: [q scratch][kv scratch][dKi][dVi]
+XAddWs carve_xadd_scratch(const immtsf_fusion_cfg* c, void* base) {     // same shape: [q scratch][kv scratch][dKV]
     const size_t BT = (size_t)c->B * c->T, d = c->d;
     Carver k(base);
     XAddWs w;
@@ -110,13 +148,12 @@ XAddWs carve_xadd_scratch(const immtsf_fusion_cfg* c, void* base) {     // same 
     w.kvb = carve_kv_scratch(c, nullptr).bytes;
     w.q = k.take<unsigned char>(w.qb);
     w.kv = k.take<unsigned char>(w.kvb);
-    w.Ki = k.take<float>(BT * d);
-    w.Vi = k.take<float>(BT * d);
+    w.KV = k.take<float>(BT * 2 * d);
     w.bytes = k.bytes();
     return w;
 }
 
-// batched (window, head) view of a (B*T, d) activation: element stride T*d per window, hd per head
+// batched (window, head) view of a (B*T, ld) activation: element stride T*ld per window, hd per head
 inline void batch_bh(GemmArgs& g, int B, int H, long sA_o, long sA_i, long sB_o, long sB_i, long sC_o, long sC_i) {
     g.nbatch = B * H;
     g.batch_inner = H;
@@ -136,87 +173,97 @@ size_t immtsf_mmf_xattn_q_scratch_bytes(const immtsf_fusion_cfg* cfg) { return b
 size_t immtsf_mmf_xattn_add_workspace_bytes(const immtsf_fusion_cfg* cfg) { return bad_x(cfg) ? 0 : carve_xadd(cfg, nullptr).bytes; }
 size_t immtsf_mmf_xattn_add_scratch_bytes(const immtsf_fusion_cfg* cfg) { return bad_x(cfg) ? 0 : carve_xadd_scratch(cfg, nullptr).bytes; }
 
-int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* Ki,
-                                float* Vi, void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
-    if (bad_x(cfg) || !p || !E_txt || !Ki || !Vi || !workspace) return IMMTSF_EINVAL;
+int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* KV,
+                                void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !E_txt || !KV || !workspace) return IMMTSF_EINVAL;
     KVWs w = carve_kv(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int d = cfg->d, BT = cfg->B * cfg->T, prec = cfg->precision;
-    {   // K0, V0 = E {W_k, W_v}^T   (two problems, one launch)
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        g.nprob = 2;
-        set_problem(g, 0, E_txt, p->proj_k_w, w.K0, nullptr);
-        set_problem(g, 1, E_txt, p->proj_v_w, w.V0, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    const bool hf = xadd_hf(cfg);
+    KVW W;
+    CHECK(kv_weights(cfg, p, w, s, &W));
+    Mat E = cmat(E_txt);
+    if (hf) {
+        CHECK(launch_f32_to_bf16(E_txt, w.E.h, (size_t)BT * d, s));
+        E.h = w.E.h;
     }
-    {   // MHA in-projections of k, v
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
+    {   // W_KVf = [W_in,k W_k ; W_in,v W_v]   (two d x d x d products, one launch)
+        GemmArgs g = gemm_args(d, d, d, d, d, d);
         g.nprob = 2;
-        set_problem(g, 0, w.K0, p->attn_in_w + (size_t)d * d, Ki, p->attn_in_b + d);
-        set_problem(g, 1, w.V0, p->attn_in_w + (size_t)2 * d * d, Vi, p->attn_in_b + 2 * d);
+        set_problem2(g, 0, W.ink, W.k, w.WKVf, nullptr);
+        set_problem2(g, 1, W.inv, W.v, mat_off(w.WKVf, (size_t)d * d), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // (k | v) = E W_KVf^T + (b_k | b_v)
+        GemmArgs g = gemm_args(BT, 2 * d, d, d, d, 2 * d);
+        set_problem2(g, 0, E, w.WKVf, mat(KV), p->attn_in_b + d);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     return IMMTSF_OK;
 }
 
-int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* Ki,
-                               const float* Vi, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
-                               immtsf_stream_t stream) {
-    if (bad_x(cfg) || !p || !Y_ts || !Ki || !Vi || !M_txt || !Y_out || !workspace) return IMMTSF_EINVAL;
+int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
+                               const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !Y_ts || !KV || !M_txt || !Y_out || !workspace) return IMMTSF_EINVAL;
     QWs w = carve_q(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = cfg->B, T = cfg->T, d = cfg->d, C = cfg->C, H = cfg->H, hd = d / H, BT = B * T, prec = cfg->precision;
     const DropCfg drop = drop_of(cfg);
     const long TT2 = (long)T * T;
-    {   // Q0 = Y W_q^T
-        GemmArgs g = gemm_args(BT, d, C, C, C, d);
-        set_problem(g, 0, Y_ts, p->proj_q_w, w.Q0, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    const float* Ki = KV;
+    const float* Vi = KV + d;
+    {   // W_Qf = W_in,q W_q  (d x C)
+        GemmArgs g = gemm_args(d, C, d, d, C, C);
+        set_problem(g, 0, p->attn_in_w, p->proj_q_w, w.WQf, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
-    {   // MHA in-projection of q
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, w.Q0, p->attn_in_w, w.Qi, p->attn_in_b);
+    {   // Qi = Y W_Qf^T + b_q
+        GemmArgs g = gemm_args(BT, d, C, C, C, d);
+        set_problem(g, 0, Y_ts, w.WQf, w.Qi, p->attn_in_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     {   // scores[b,h] = scale * Qi_h Ki_h^T
-        GemmArgs g = gemm_args(T, T, hd, d, d, T);
+        GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
         set_problem(g, 0, w.Qi, Ki, w.Pm, nullptr);
         g.alpha = sqrtf(1.0f / (float)hd);
-        batch_bh(g, B, H, (long)T * d, hd, (long)T * d, hd, (long)H * TT2, TT2);
+        batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     CHECK(launch_softmax_rows_fwd(w.Pm, w.Am, B, H, T, T, M_txt, drop, SITE_XADD_ATTN, 0, s));
-    {   // O_h = A V_h
-        GemmArgs g = gemm_args(T, hd, T, T, d, d);
+    {   // O_h = A V_h   (zero for the no-text windows: their attention rows are zero)
+        GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
         set_problem(g, 0, w.Am, Vi, w.O, nullptr);
-        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
-    {   // out_proj, zero no-text windows (attn_out = where(M, attn_out, 0))
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, w.O, p->attn_out_w, w.U, p->attn_out_b);
-        g.row_flag = M_txt; g.row_flag_div = T;
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    {   // W_HO = W_res W_out  (C x d);  t = W_res b_out;  b_HO = t + b_res
+        GemmArgs g = gemm_args(C, d, d, d, d, d);
+        set_problem(g, 0, p->res_w, p->attn_out_w, w.WHO, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        CHECK(launch_matvec(p->res_w, d, p->attn_out_b, p->res_b, C, d, w.bHO, nullptr, 1.f, s));
     }
-    if (xadd_head_supported(C, d))        // residual_head + LayerNorm(C) + dropout + blend in one kernel (w.delta stays unused)
-        return launch_xadd_head_fwd(w.U, p->res_w, p->res_b, Y_ts, M_txt, BT, T, C, d, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC,
+    // delta = M ? O W_HO^T + b_HO : b_res   (residual_head(where(M, out_proj(O), 0)))
+    if (xadd_head_supported(C, d))        // head + LayerNorm(C) + dropout + blend in one kernel (w.delta stays unused)
+        return launch_xadd_head_fwd(w.O, w.WHO, w.bHO, p->res_b, Y_ts, M_txt, BT, T, C, d, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC,
                                     Y_out, drop, SITE_XADD_OUT, s);
-    {   // residual_head
+    CHECK(launch_matvec(p->res_w, d, p->attn_out_b, nullptr, C, d, w.tHO, nullptr, 1.f, s));
+    {
         GemmArgs g = gemm_args(BT, C, d, d, d, C);
-        set_problem(g, 0, w.U, p->res_w, w.delta, p->res_b);
+        set_problem(g, 0, w.O, w.WHO, w.delta, w.tHO);
+        g.row_flag = M_txt; g.row_flag_div = T; g.add_vec = p->res_b;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     return launch_ln_blend_fwd(w.delta, Y_ts, M_txt, BT, T, C, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC, Y_out, drop,
                                SITE_XADD_OUT, s);
 }
 
-int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* Ki,
-                                const float* Vi, const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKi,
-                                float* dVi, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                                const immtsf_xadd_params* gr, immtsf_stream_t stream) {
-    if (bad_x(cfg) || !p || !gr || !Y_ts || !Ki || !Vi || !M_txt || !dY_out || !dY_ts || !dKi || !dVi || !workspace || !scratch)
+int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
+                                const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKV, void* workspace,
+                                size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* gr,
+                                immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !gr || !Y_ts || !KV || !M_txt || !dY_out || !dY_ts || !dKV || !workspace || !scratch)
         return IMMTSF_EINVAL;
     QWs w = carve_q(cfg, workspace);
     QScratch sc = carve_q_scratch(cfg, scratch);
@@ -226,120 +273,126 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     const DropCfg drop = drop_of(cfg);
     const long TT2 = (long)T * T;
     const float scale = sqrtf(1.0f / (float)hd);
-    Fork fk(s);   // weight-gradient GEMMs may run on the side stream, joined before returning
+    const float* Ki = KV;
+    const float* Vi = KV + d;
+    Fork fk(s);   // parameter-gradient work runs on the side stream, joined before returning
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
     CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
-    {   // residual_head
-        GemmArgs g = gemm_args(BT, d, C, C, d, d);
-        set_problem(g, 0, sc.ddelta, p->res_w, sc.dU, nullptr);
-        g.row_flag = M_txt; g.row_flag_div = T;      // where(M, attn_out, 0): no gradient into no-text windows
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
-        set_problem(h, 0, sc.ddelta, w.U, gr->res_w, nullptr, gr->res_b);
+        set_problem(h, 0, sc.ddelta, w.O, sc.dWHO, nullptr, gr->res_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
-    {   // out_proj
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, sc.dU, p->attn_out_w, sc.dO, nullptr);
+    CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
+    CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
+    {   // dO = ddelta W_HO
+        GemmArgs g = gemm_args(BT, d, C, C, d, d);
+        set_problem(g, 0, sc.ddelta, w.WHO, sc.dO, nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem(h, 0, sc.dU, w.O, gr->attn_out_w, nullptr, gr->attn_out_b);
+    }
+    {   // chain rule through W_HO = W_res W_out, b_HO = W_res b_out + b_res
+        hipStream_t f = fk.fork();
+        CHECK(launch_matvec_t(p->res_w, d, sc.slive, C, d, gr->attn_out_b, 0, f));      // d b_out = W_res^T s_live
+        CHECK(launch_outer(sc.slive, p->attn_out_b, C, d, gr->res_w, d, f));             // dW_res = s_live b_out^T + dW_HO W_out^T
+        GemmArgs g = gemm_args(C, d, d, d, d, d);
+        set_problem(g, 0, sc.dWHO, p->attn_out_w, gr->res_w, nullptr);
+        g.accumulate = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, f));
+        GemmArgs h = gemm_args(d, d, C, d, d, d);                                          // dW_out = W_res^T dW_HO
+        set_problem(h, 0, p->res_w, sc.dWHO, gr->attn_out_w, nullptr);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));
     }
     {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
-        GemmArgs g = gemm_args(T, T, hd, d, d, T);
+        GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
         set_problem(g, 0, sc.dO, Vi, sc.dA, nullptr);
-        batch_bh(g, B, H, (long)T * d, hd, (long)T * d, hd, (long)H * TT2, TT2);
+        batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-        GemmArgs h = gemm_args(T, hd, T, T, d, d);
-        set_problem(h, 0, w.Am, sc.dO, dVi, nullptr);
-        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
+        set_problem(h, 0, w.Am, sc.dO, dKV + d, nullptr);
+        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_softmax_rows_bwd(sc.dA, w.Pm, B, H, T, T, drop, SITE_XADD_ATTN, s));
     {   // dQ_h = scale dS K_h ; dK_h = scale dS^T Q_h
-        GemmArgs g = gemm_args(T, hd, T, T, d, d);
+        GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
         set_problem(g, 0, sc.dA, Ki, sc.dQi, nullptr);
         g.alpha = scale;
-        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(T, hd, T, T, d, d);
-        set_problem(h, 0, sc.dA, w.Qi, dKi, nullptr);
+        GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
+        set_problem(h, 0, sc.dA, w.Qi, dKV, nullptr);
         h.alpha = scale;
-        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * d, hd);
+        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
-    {   // MHA in-projection of q
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem(g, 0, sc.dQi, p->attn_in_w, sc.dQ0, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem(h, 0, sc.dQi, w.Q0, gr->attn_in_w, nullptr, gr->attn_in_b);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
-    }
-    {   // proj_q: dY += dQ0 W_q ; dW_q = dQ0^T Y
+    {   // dY += dQi W_Qf
         GemmArgs g = gemm_args(BT, C, d, d, C, C);
-        set_problem(g, 0, sc.dQ0, p->proj_q_w, dY_ts, nullptr);
+        set_problem(g, 0, sc.dQi, w.WQf, dY_ts, nullptr);
         g.accumulate = 1;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // dW_Qf = dQi^T Y, d b_q = column sums of dQi;  then dW_in,q = dW_Qf W_q^T, dW_q = W_in,q^T dW_Qf
+        hipStream_t f = fk.fork();
         GemmArgs h = gemm_args(d, C, BT, d, C, C);
-        set_problem(h, 0, sc.dQ0, Y_ts, gr->proj_q_w, nullptr);
+        set_problem(h, 0, sc.dQi, Y_ts, sc.dWQf, nullptr, gr->attn_in_b);
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        h.c_prezeroed = 0;           // dW_Qf is scratch, not a zero-filled gradient sink (the bias gradient is: split-K would add
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));      // to both, so the launcher's own zero-fill covers both)
+        GemmArgs g = gemm_args(d, d, C, C, C, d);
+        set_problem(g, 0, sc.dWQf, p->proj_q_w, gr->attn_in_w, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, f));
+        GemmArgs h2 = gemm_args(d, C, d, d, C, C);
+        set_problem(h2, 0, p->attn_in_w, sc.dWQf, gr->proj_q_w, nullptr);
+        prezeroed(h2, cfg);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h2, f));
     }
     return fk.join();
 }
 
-int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt,
-                                 const float* dKi, const float* dVi, float* dE_txt, void* workspace, size_t workspace_bytes,
-                                 void* scratch, size_t scratch_bytes, const immtsf_xadd_params* gr, immtsf_stream_t stream) {
-    if (bad_x(cfg) || !p || !gr || !E_txt || !dKi || !dVi || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dKV,
+                                 float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                 const immtsf_xadd_params* gr, immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !gr || !E_txt || !dKV || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
     KVWs w = carve_kv(cfg, workspace);
     KVScratch sc = carve_kv_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int d = cfg->d, BT = cfg->B * cfg->T, prec = cfg->precision;
-    Fork fk(s);
-    {   // MHA in-projections of k, v
-        GemmArgs g = gemm_args(BT, d, d, d, d, 2 * d);
-        g.nprob = 2;
-        set_problem(g, 0, dKi, p->attn_in_w + (size_t)d * d, sc.dK0, nullptr);
-        set_problem(g, 1, dVi, p->attn_in_w + (size_t)2 * d * d, sc.dV0, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        h.nprob = 2;
-        set_problem(h, 0, dKi, w.K0, gr->attn_in_w + (size_t)d * d, nullptr, gr->attn_in_b + d);
-        set_problem(h, 1, dVi, w.V0, gr->attn_in_w + (size_t)2 * d * d, nullptr, gr->attn_in_b + 2 * d);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+    const bool hf = xadd_hf(cfg);
+    KVW W;
+    CHECK(kv_weights(cfg, p, w, s, &W));
+    Mat dK = cmat(dKV), E = cmat(E_txt, w.E.h);
+    if (hf) {
+        CHECK(launch_f32_to_bf16(dKV, sc.dKV.h, (size_t)BT * 2 * d, s));
+        dK.h = sc.dKV.h;
     }
-    {   // proj_k / proj_v: dE = dK0 W_k + dV0 W_v ; dW_k = dK0^T E ; dW_v = dV0^T E
-        if (p->proj_v_w == p->proj_k_w + (size_t)d * d) {
-            // the two weights are adjacent (FlatTrainer's flat buffer, or any state-dict-order allocation): [W_k ; W_v] is one
-            // (2d, d) matrix and dE = [dK0 | dV0] [W_k ; W_v] ONE GEMM with K = 2d instead of two K = d launches
-            GemmArgs g = gemm_args(BT, d, 2 * d, 2 * d, d, d);
-            set_problem(g, 0, sc.dK0, p->proj_k_w, dE_txt, nullptr);
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        } else {
-            GemmArgs g = gemm_args(BT, d, d, 2 * d, d, d);
-            set_problem(g, 0, sc.dK0, p->proj_k_w, dE_txt, nullptr);
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-            GemmArgs g2 = gemm_args(BT, d, d, 2 * d, d, d);
-            set_problem(g2, 0, sc.dV0, p->proj_v_w, dE_txt, nullptr);
-            g2.accumulate = 1;
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g2, s));
-        }
-        GemmArgs h = gemm_args(d, d, BT, 2 * d, d, d);
-        h.nprob = 2;
-        set_problem(h, 0, sc.dK0, E_txt, gr->proj_k_w, nullptr);
-        set_problem(h, 1, sc.dV0, E_txt, gr->proj_v_w, nullptr);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+    Fork fk(s);
+    {   // dE = (dK | dV) W_KVf
+        GemmArgs g = gemm_args(BT, d, 2 * d, 2 * d, d, d);
+        set_problem2(g, 0, dK, w.WKVf, mat(dE_txt), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // dW_KVf = (dK | dV)^T E ; (d b_k | d b_v) = column sums;  then the chain rule through W_{K,V}f = W_in W_proj
+        hipStream_t f = fk.fork();
+        GemmArgs h = gemm_args(2 * d, d, BT, 2 * d, d, d);
+        set_problem2(h, 0, dK, E, sc.dWKVf, nullptr, gr->attn_in_b + d);
+        h.c_prezeroed = 0;           // scratch output: see the query half
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));
+        GemmArgs g = gemm_args(d, d, d, d, d, d);                 // dW_in,{k,v} = dW_{K,V}f W_{k,v}^T
+        g.nprob = 2;
+        set_problem2(g, 0, sc.dWKVf, W.k, mat(gr->attn_in_w + (size_t)d * d), nullptr);
+        set_problem2(g, 1, mat_off(sc.dWKVf, (size_t)d * d), W.v, mat(gr->attn_in_w + (size_t)2 * d * d), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, f));
+        GemmArgs h2 = gemm_args(d, d, d, d, d, d);                // dW_{k,v} = W_in,{k,v}^T dW_{K,V}f
+        h2.nprob = 2;
+        set_problem2(h2, 0, W.ink, sc.dWKVf, mat(gr->proj_k_w), nullptr);
+        set_problem2(h2, 1, W.inv, mat_off(sc.dWKVf, (size_t)d * d), mat(gr->proj_v_w), nullptr);
+        prezeroed(h2, cfg);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h2, f));
     }
     return fk.join();
 }
@@ -350,8 +403,8 @@ int immtsf_mmf_xattn_add_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
     if (bad_x(cfg) || !workspace) return IMMTSF_EINVAL;
     XAddWs w = carve_xadd(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
-    CHECK(immtsf_mmf_xattn_kv_forward(cfg, p, E_txt, w.Ki, w.Vi, w.kv, w.kvb, stream));
-    return immtsf_mmf_xattn_q_forward(cfg, p, Y_ts, w.Ki, w.Vi, M_txt, Y_out, w.q, w.qb, stream);
+    CHECK(immtsf_mmf_xattn_kv_forward(cfg, p, E_txt, w.KV, w.kv, w.kvb, stream));
+    return immtsf_mmf_xattn_q_forward(cfg, p, Y_ts, w.KV, M_txt, Y_out, w.q, w.qb, stream);
 }
 
 int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
@@ -362,9 +415,8 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
     XAddWs w = carve_xadd(cfg, workspace);
     XAddWs sc = carve_xadd_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
-    CHECK(immtsf_mmf_xattn_q_backward(cfg, p, Y_ts, w.Ki, w.Vi, M_txt, dY_out, dY_ts, sc.Ki, sc.Vi, w.q, w.qb, sc.q, sc.qb, gr,
-                                      stream));
-    return immtsf_mmf_xattn_kv_backward(cfg, p, E_txt, sc.Ki, sc.Vi, dE_txt, w.kv, w.kvb, sc.kv, sc.kvb, gr, stream);
+    CHECK(immtsf_mmf_xattn_q_backward(cfg, p, Y_ts, w.KV, M_txt, dY_out, dY_ts, sc.KV, w.q, w.qb, sc.q, sc.qb, gr, stream));
+    return immtsf_mmf_xattn_kv_backward(cfg, p, E_txt, sc.KV, dE_txt, w.kv, w.kvb, sc.kv, sc.kvb, gr, stream);
 }
 
 }  // extern "C"

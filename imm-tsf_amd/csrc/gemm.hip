@@ -595,7 +595,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
             float v[4] = {a4.x, a4.y, a4.z, a4.w};
             const bool live = g.row_flag ? (g.row_flag[row / g.row_flag_div] != 0) : true;
             const int nv = min(4, N - col);
-            float* dst = C + (size_t)row * g.ldc + col;
+            float* dst = P.C ? C + (size_t)row * g.ldc + col : nullptr;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (e >= nv) break;
@@ -609,8 +609,14 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                 if (g.accumulate) x += dst[e];
                 v[e] = x;
             }
-            if (nv == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            else for (int e = 0; e < nv; ++e) dst[e] = v[e];
+            if (dst) {
+                if (nv == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int e = 0; e < nv; ++e) dst[e] = v[e];
+            }
+            if (P.Ch) {          // optional bf16 copy of the result for a bf16-in-memory consumer (gemm2.hip)
+                bf16_t* dh = reinterpret_cast<bf16_t*>(P.Ch) + offC + (size_t)row * (g.ldch ? g.ldch : g.ldc) + col;
+                for (int e = 0; e < nv; ++e) dh[e] = (bf16_t)v[e];
+            }
         }
         return;
     }
@@ -639,7 +645,8 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                     else if (g.act == 2) v = gelu_erf(v);
                     if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col] <= 0.f) v = 0.f;   // relu backward mask
                     if (g.accumulate) v += *dst;
-                    *dst = v;
+                    if (P.C) *dst = v;
+                    if (P.Ch) reinterpret_cast<bf16_t*>(P.Ch)[offC + (size_t)row * (g.ldch ? g.ldch : g.ldc) + col] = (bf16_t)v;
                 }
             }
         }
@@ -667,6 +674,8 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
     return IMMTSF_OK;
 }
 
+static int g_force_old = 0;      // immtsf_debug_gemm_config bit 16: keep bf16 mode on the round-1 kernel (A/B measurements)
+
 // tuning override for tools/gemm_bench.py (0 = heuristic)
 int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 0;
 
@@ -681,6 +690,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_dbg = (variant >> 9) & 15;            // ablation: 1 skip MFMA, 2 skip global loads, 4 skip LDS stores (results wrong)
     g_tn_spec = (variant & 0x2000) ? 0 : 1;  // bit 13 disables the specialised weight-gradient choice (A/B measurements)
     g_xcd2d = (variant & 0x4000) ? 1 : 0;    // bit 14: allow the 2-D XCD order (measured slower at the fusion shapes: off)
+    g_force_old = (variant & 0x10000) ? 1 : 0;
     g_splitk = splitk;
     return 0;
 }
@@ -731,17 +741,41 @@ extern "C" int immtsf_bf16_twin_unregister(const float* base) {
 
 extern "C" int immtsf_bf16_twin_enable(int on) { g_twins_on = on ? 1 : 0; return IMMTSF_OK; }
 
+// bf16 mode: a launch whose every problem carries a bf16 A (p.Ah) and a bf16 B (p.Bh, or a registered twin of p.B) goes
+// to the bf16-in-memory kernel (gemm2.hip) when that kernel implements the argument combination; everything else (fp32
+// parity mode, batched form, row-mapped weight gradients, K or N below the 8-element chunk) runs on the kernel below,
+// which needs the fp32 operands.
+static int route_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
+    if (precision == 1 && g.nbatch <= 1 && !g_force_old) {
+        bool have = true;
+        for (int i = 0; i < g.nprob && have; ++i) {
+            GemmProblem& p = g.p[i];
+            if (!p.Ah) { have = false; break; }
+            if (!p.Bh && p.B && layout != GEMM_TN) {
+                const size_t span = layout == GEMM_NT ? (size_t)(g.N - 1) * g.ldb + g.K : (size_t)(g.K - 1) * g.ldb + g.N;
+                p.Bh = immtsf_twin_lookup(p.B, span);
+            }
+            if (!p.Bh) have = false;
+        }
+        if (have && immtsf_gemm2_supported(layout, g)) return immtsf_launch_gemm2(layout, g, stream);
+    }
+    for (int i = 0; i < g.nprob; ++i)
+        if (!g.p[i].A || !g.p[i].B || (!g.p[i].C && !g.p[i].Ch) || (!g.p[i].C && g.accumulate))
+            return IMMTSF_EUNSUPPORTED;      // bf16-only operands that gemm2 cannot take
+    return launch_gemm_impl(layout, precision, g, stream);
+}
+
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
-    if (!g_tap_on || g_tap_n >= kTapCap) return launch_gemm_impl(layout, precision, g, stream);
+    if (!g_tap_on || g_tap_n >= kTapCap) return route_gemm(layout, precision, g, stream);
     TapRec& r = g_tap[g_tap_n];
     if (g_tap_n >= g_tap_events) {
-        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return launch_gemm_impl(layout, precision, g, stream);
+        if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return route_gemm(layout, precision, g, stream);
         g_tap_events = g_tap_n + 1;
     }
     const int m[8] = {layout, precision, g.M, g.N, g.K, g.nprob, g.nbatch > 1 ? g.nbatch : 1, g.dyn ? 1 + g.dyn_which : 0};
     for (int i = 0; i < 8; ++i) r.meta[i] = m[i];
     (void)hipEventRecord(r.e0, stream);
-    const int rc = launch_gemm_impl(layout, precision, g, stream);
+    const int rc = route_gemm(layout, precision, g, stream);
     (void)hipEventRecord(r.e1, stream);
     r.meta[8] = (int)g_last_grid_threads;
     r.meta[9] = 0;
@@ -787,7 +821,11 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     g.vecA = va ? 1 : 0;
     g.vecB = vb ? 1 : 0;
     bool vc = (g.ldc % 4) == 0;
-    for (int i = 0; i < g.nprob; ++i) vc = vc && ((reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0);
+    bool all_c = true;       // split-K needs an fp32 C to add into and cannot serve a bf16 copy
+    for (int i = 0; i < g.nprob; ++i) {
+        vc = vc && ((reinterpret_cast<uintptr_t>(g.p[i].C) & 15) == 0);
+        all_c = all_c && g.p[i].C != nullptr && g.p[i].Ch == nullptr;
+    }
     if (g.nbatch > 1) vc = vc && (g.sC_o % 4 == 0) && (g.sC_i % 4 == 0);
     g.vecC = vc ? 1 : 0;
     g.dbg = g_dbg;
@@ -818,7 +856,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
-    const bool can_split = g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = all_c && g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     // weight-gradient GEMMs with 96..230 output tiles (768x768 .. 768x1152 at the fusion dims): the wave-specialised
     // kernel, unsplit -- its consumer waves never wait on global loads (the k-major fragment reads carry a conservative
@@ -859,7 +897,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         bbf = true;
         for (int i = 0; i < g.nprob && bbf; ++i) {
             const size_t span = layout == GEMM_NT ? (size_t)(g.N - 1) * g.ldb + g.K : (size_t)(g.K - 1) * g.ldb + g.N;
-            g.p[i].Bh = immtsf_twin_lookup(g.p[i].B, span);
+            if (!g.p[i].Bh) g.p[i].Bh = immtsf_twin_lookup(g.p[i].B, span);
             bbf = g.p[i].Bh != nullptr;
         }
         if (bbf) {

@@ -100,12 +100,16 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src,
                                                            const int* __restrict__ rowmap, const int* __restrict__ total,
-                                                           int width, float* __restrict__ dst, int ld_dst) {
+                                                           int width, float* __restrict__ dst, int ld_dst,
+                                                           bf16_t* __restrict__ dst_h) {
     const int r = blockIdx.x;
     if (r >= *total) return;
     const float* s = src + (size_t)rowmap[r] * ld_src;
-    float* d = dst + (size_t)r * ld_dst;
-    for (int i = threadIdx.x; i < width; i += blockDim.x) d[i] = s[i];
+    for (int i = threadIdx.x; i < width; i += blockDim.x) {
+        const float v = s[i];
+        if (dst) dst[(size_t)r * ld_dst + i] = v;
+        if (dst_h) dst_h[(size_t)r * ld_dst + i] = (bf16_t)v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- Time2Vec
@@ -114,12 +118,15 @@ __global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restri
                                                             const int* __restrict__ total, int d_tau,
                                                             const float* __restrict__ w0, const float* __restrict__ b0,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ dst, int ld_dst, int max_rows) {
+                                                            float* __restrict__ dst, int ld_dst, int max_rows,
+                                                            bf16_t* __restrict__ dst_h) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const int r = (int)(idx / d_tau), j = (int)(idx % d_tau);
     if (r >= (total ? *total : max_rows)) return;
     const float t = tau_pad[rowmap ? rowmap[r] : r];
-    dst[(size_t)r * ld_dst + j] = (j == 0) ? fmaf(w0[0], t, b0[0]) : sinf(fmaf(w[j - 1], t, b[j - 1]));
+    const float v = (j == 0) ? fmaf(w0[0], t, b0[0]) : sinf(fmaf(w[j - 1], t, b[j - 1]));
+    if (dst) dst[(size_t)r * ld_dst + j] = v;
+    if (dst_h) dst_h[(size_t)r * ld_dst + j] = (bf16_t)v;
 }
 
 // partial[slab][0][j] = sum_r g*tau, partial[slab][1][j] = sum_r g,  g = dfeat[r,j] * (j ? cos(w tau + b) : 1)
@@ -268,7 +275,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int rows, int d,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, float* __restrict__ xhat, float* __restrict__ rstd,
-                                                             float* __restrict__ z, DropCfg drop, uint64_t site) {
+                                                             float* __restrict__ z, DropCfg drop, uint64_t site,
+                                                             bf16_t* __restrict__ zh) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* p = x + (size_t)row * d;
@@ -283,7 +291,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         const float h = (p[i] - mu) * rs;
         if (xhat) xhat[(size_t)row * d + i] = h;
         const float y = fmaf(h, gamma[i], beta[i]);
-        z[(size_t)row * d + i] = y * dropout_scale(drop, site, (uint64_t)row * d + i);
+        const float zv = y * dropout_scale(drop, site, (uint64_t)row * d + i);
+        if (z) z[(size_t)row * d + i] = zv;
+        if (zh) zh[(size_t)row * d + i] = (bf16_t)zv;
     }
 }
 
@@ -294,7 +304,8 @@ constexpr int LN_DV = 4;
 __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x, int rows, int d,
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, float* __restrict__ xhat, float* __restrict__ rstd,
-                                                                 float* __restrict__ z, DropCfg drop, uint64_t site) {
+                                                                 float* __restrict__ z, DropCfg drop, uint64_t site,
+                                                                 bf16_t* __restrict__ zh) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), d4 = d >> 2;
     if (row >= rows) return;
     const float4* p = reinterpret_cast<const float4*>(x + (size_t)row * d);
@@ -325,8 +336,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
             const float4 g = reinterpret_cast<const float4*>(gamma)[q], b = reinterpret_cast<const float4*>(beta)[q];
             float sc[4];
             dropout_scale4(drop, site, (uint64_t)row * d + (uint64_t)q * 4, sc);
-            reinterpret_cast<float4*>(z + (size_t)row * d)[q] =
-                make_float4(fmaf(h.x, g.x, b.x) * sc[0], fmaf(h.y, g.y, b.y) * sc[1], fmaf(h.z, g.z, b.z) * sc[2], fmaf(h.w, g.w, b.w) * sc[3]);
+            const float4 zv = make_float4(fmaf(h.x, g.x, b.x) * sc[0], fmaf(h.y, g.y, b.y) * sc[1], fmaf(h.z, g.z, b.z) * sc[2], fmaf(h.w, g.w, b.w) * sc[3]);
+            if (z) reinterpret_cast<float4*>(z + (size_t)row * d)[q] = zv;
+            if (zh) {
+                bf16x4 hv;
+                hv[0] = (bf16_t)zv.x; hv[1] = (bf16_t)zv.y; hv[2] = (bf16_t)zv.z; hv[3] = (bf16_t)zv.w;
+                reinterpret_cast<bf16x4*>(zh + (size_t)row * d)[q] = hv;
+            }
         }
     }
 }
@@ -482,20 +498,20 @@ int launch_mask_from_lengths(const int* lengths, int B, int N, unsigned char* ma
 }
 
 int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const int* total, int max_rows, int width,
-                       float* dst, int ld_dst, hipStream_t s) {
+                       float* dst, int ld_dst, hipStream_t s, void* dst_h) {
     if (max_rows <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(max_rows), dim3(256), 0, s, src, ld_src, rowmap, total, width, dst, ld_dst);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(max_rows), dim3(256), 0, s, src, ld_src, rowmap, total, width, dst, ld_dst, static_cast<bf16_t*>(dst_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w0, const float* b0, const float* w, const float* b, float* dst, int ld_dst,
-                        hipStream_t s) {
+                        hipStream_t s, void* dst_h) {
     if (max_rows <= 0) return IMMTSF_OK;
     const long n = (long)max_rows * d_tau;
     hipLaunchKernelGGL(time2vec_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tau_pad, rowmap, total, d_tau,
-                       w0, b0, w, b, dst, ld_dst, max_rows);
+                       w0, b0, w, b, dst, ld_dst, max_rows, static_cast<bf16_t*>(dst_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -540,16 +556,16 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
 }
 
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
-                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s) {
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh) {
     if (rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(xhat) |
                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta);
     if ((d & 3) == 0 && d <= 256 * LN_DV && (al & 15) == 0)
         hipLaunchKernelGGL(layernorm_fwd_vec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
-                           drop, site);
+                           drop, site, static_cast<bf16_t*>(zh));
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
-                           drop, site);
+                           drop, site, static_cast<bf16_t*>(zh));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

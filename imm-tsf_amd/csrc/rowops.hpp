@@ -12,11 +12,11 @@ int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, i
 int launch_mask_from_lengths(const int* lengths, int B, int N, unsigned char* mask, hipStream_t s);
 // gather packed rows: dst[r, 0:d_m] = src[rowmap[r], 0:d_m]   (r < *total)
 int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const int* total, int max_rows, int width,
-                       float* dst, int ld_dst, hipStream_t s);
+                       float* dst, int ld_dst, hipStream_t s, void* dst_h = nullptr);
 // a3 Time2Vec on packed rows: dst[r, j] = j==0 ? w0*tau+b0 : sin(w[j-1]*tau+b[j-1]),  tau = tau_pad[rowmap[r]]
 int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w0, const float* b0, const float* w, const float* b, float* dst, int ld_dst,
-                        hipStream_t s);
+                        hipStream_t s, void* dst_h = nullptr);      // dst_h: optional bf16 copy (same ld); dst may then be null
 // Time2Vec parameter gradients from dFeat (packed rows, ld): nslabs row slabs (0 = 32), scratch >= 2*nslabs*d_tau floats;
 // rowmap/total may be null (rows 0..max_rows-1 used directly)
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
@@ -30,7 +30,7 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
                    hipStream_t s);
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
-                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s);
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr);   // zh: bf16 z (z may be null)
 // in: dz (grad wrt z).  out: dy written IN PLACE over dz (dy = dz*dropscale), dx.
 int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
                          float* dx, DropCfg drop, uint64_t site, hipStream_t s);

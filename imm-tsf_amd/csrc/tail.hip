@@ -5,10 +5,16 @@
 namespace {
 
 __global__ __launch_bounds__(256) void mask_rows_kernel(float* __restrict__ x, int rows, int d,
-                                                         const unsigned char* __restrict__ flag, int div) {
+                                                         const unsigned char* __restrict__ flag, int div, bf16_t* __restrict__ xh) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows || flag[row / div]) return;
-    for (int i = lane; i < d; i += 64) x[(size_t)row * d + i] = 0.f;
+    if (row >= rows) return;
+    const bool live = flag[row / div] != 0;
+    if (live && !xh) return;
+    for (int i = lane; i < d; i += 64) {
+        const size_t o = (size_t)row * d + i;
+        if (!live) x[o] = 0.f;
+        if (xh) xh[o] = live ? (bf16_t)x[o] : (bf16_t)0.f;
+    }
 }
 
 // reference: fusions/MMF_XAttn_Add.py:93-102
@@ -325,9 +331,9 @@ int launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t s) {
     return IMMTSF_OK;
 }
 
-int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s) {
+int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s, void* xh) {
     if (rows <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, flag, div);
+    hipLaunchKernelGGL(mask_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, flag, div, static_cast<bf16_t*>(xh));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

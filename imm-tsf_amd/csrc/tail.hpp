@@ -3,7 +3,7 @@
 #include "common.hpp"
 
 // zero the rows m whose window flag[m / div] == 0
-int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s);
+int launch_mask_rows(float* x, int rows, int d, const unsigned char* flag, int div, hipStream_t s, void* xh = nullptr);   // xh: bf16 copy of the result
 
 // MMF_XAttn_Add tail (fusions/MMF_XAttn_Add.py:93-102): LN over C, dropout, zero no-text windows, kappa blend
 int launch_ln_blend_fwd(const float* delta, const float* Y, const unsigned char* mtxt, int BT, int T, int C,
@@ -17,7 +17,8 @@ int launch_ln_blend_bwd(const float* dYout, const unsigned char* mtxt, int BT, i
 // the forward output head of MMF_XAttn_Add in one kernel (xadd_head.hip): residual_head Linear(d -> C) on U, LayerNorm(C),
 // dropout, no-text zeroing, kappa blend; saves xhat / rstd like launch_ln_blend_fwd.  C <= 16, d <= 1024, d % 4 == 0.
 bool xadd_head_supported(int C, int d);
-int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const float* Y, const unsigned char* mtxt, int BT, int T,
+// bW: bias of the rows whose window has text, bWdead: bias of the others (U is zero there)
+int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const float* bWdead, const float* Y, const unsigned char* mtxt, int BT, int T,
                          int C, int d, const float* gamma, const float* beta, float kappa, float* xhat, float* rstd, float* Yout,
                          DropCfg drop, uint64_t site, hipStream_t s);
 

@@ -17,7 +17,8 @@ struct HeadDims { int BT, T, C, d; };
 
 template <int CM>
 __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const float* __restrict__ U, const float* __restrict__ W,
-                                                             const float* __restrict__ bW, const float* __restrict__ Y,
+                                                             const float* __restrict__ bW, const float* __restrict__ bWdead,
+                                                             const float* __restrict__ Y,
                                                              const unsigned char* __restrict__ mtxt, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float kappa, float* __restrict__ xhat,
                                                              float* __restrict__ rstd, float* __restrict__ Yout, DropCfg drop,
@@ -45,10 +46,12 @@ __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const f
                     }
             }
         }
+        const bool live = mtxt[row / hd.T] != 0;
+        const float* bias = live ? bW : bWdead;       // a window without text: U is zero there and the head reduces to its own bias
         float mu = 0.f;
 #pragma unroll
         for (int c = 0; c < CM; ++c)
-            if (c < C) { acc[c] = wave_sum(acc[c]) + bW[c]; mu += acc[c]; }
+            if (c < C) { acc[c] = wave_sum(acc[c]) + bias[c]; mu += acc[c]; }
         mu /= (float)C;
         float var = 0.f;
 #pragma unroll
@@ -60,7 +63,6 @@ __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const f
         for (int c = 0; c < CM; ++c)
             if (c == lane) mine = acc[c];
         if (lane < C) {
-            const bool live = mtxt[row / hd.T] != 0;
             const float h = (mine - mu) * rs;
             const size_t o = (size_t)row * C + lane;
             xhat[o] = h;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const f
 
 bool xadd_head_supported(int C, int d) { return C >= 1 && C <= 16 && d >= 4 && d <= 256 * HEAD_DV && (d & 3) == 0; }
 
-int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const float* Y, const unsigned char* mtxt, int BT, int T,
+int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const float* bWdead, const float* Y, const unsigned char* mtxt, int BT, int T,
                          int C, int d, const float* gamma, const float* beta, float kappa, float* xhat, float* rstd, float* Yout,
                          DropCfg drop, uint64_t site, hipStream_t s) {
     if (!xadd_head_supported(C, d)) return IMMTSF_EUNSUPPORTED;
@@ -85,10 +87,10 @@ int launch_xadd_head_fwd(const float* U, const float* W, const float* bW, const 
     const int grid = cdiv(BT, 4);      // one row per wave: a single global-load round trip after the staged weights (2 rows per wave: 14.3 us)
     const size_t lds = (size_t)C * d * sizeof(float);
     if (C <= 8)
-        hipLaunchKernelGGL(xadd_head_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, hd, U, W, bW, Y, mtxt, gamma, beta, kappa, xhat, rstd, Yout,
+        hipLaunchKernelGGL(xadd_head_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, hd, U, W, bW, bWdead, Y, mtxt, gamma, beta, kappa, xhat, rstd, Yout,
                            drop, site);
     else
-        hipLaunchKernelGGL(xadd_head_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, hd, U, W, bW, Y, mtxt, gamma, beta, kappa, xhat, rstd, Yout,
+        hipLaunchKernelGGL(xadd_head_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, hd, U, W, bW, bWdead, Y, mtxt, gamma, beta, kappa, xhat, rstd, Yout,
                            drop, site);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

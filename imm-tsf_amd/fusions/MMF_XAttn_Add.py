@@ -2,8 +2,10 @@
 embedding (keys/values), residual head, LayerNorm(C), dropout and a fixed-kappa convex blend.
 
 Interface/state_dict follow the reference (fusions/MMF_XAttn_Add.py:9-103); computed by
-`immtsf_mmf_xattn_{kv,q}_forward/backward` (the block as a key/value half and a query half; grouped MFMA GEMMs for the projections, batched MFMA GEMMs for QK^T and
-A*V over (window, head), fused softmax+dropout rows, fused LN/blend tail).  Quirk kept: a window without text
+`immtsf_mmf_xattn_{kv,q}_forward/backward` (the block as a key/value half and a query half; the back-to-back linear maps
+proj_{q,k,v} -> MHA in-projection and out_proj -> residual_head run as per-step PRODUCT weights, the original parameters'
+gradients follow by the chain rule; batched MFMA GEMMs for QK^T and A*V over (window, head), fused softmax+dropout rows,
+fused head + LN/blend tail).  Quirk kept: a window without text
 returns Y_ts/(1+kappa).
 """
 import torch
@@ -42,8 +44,9 @@ class MMF_XAttn_Add(nn.Module):
                 self.residual_head.bias, self.layer_norm.weight, self.layer_norm.bias)
 
     def project_kv(self, E_txt):
-        """key/value half (proj_k / proj_v + their MHA in-projections): depends only on the text side, so a caller
-        can run it on the text stream while the backbone is still producing Y_ts (lib.evaluation.forecast_and_fuse)"""
+        """key/value half (proj_k / proj_v + their MHA in-projections -> one (B,T,2d) tensor k | v): depends only on the text
+        side, so a caller can run it on the text stream while the backbone is still producing Y_ts
+        (lib.evaluation.forecast_and_fuse)"""
         return MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
                                   getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
                                   self.attn.in_proj_weight, self.attn.in_proj_bias)
@@ -55,9 +58,9 @@ class MMF_XAttn_Add(nn.Module):
         M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
         training = self.training and self.p_drop > 0.0
         self.last_seed = config.next_seed() if training else 0
-        Ki, Vi = self.project_kv(E_txt) if kv is None else kv
+        KV = self.project_kv(E_txt) if kv is None else kv
         p = self._params()
-        return MMFXAttnQFn.apply(f32(Y_ts), Ki, Vi, M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
+        return MMFXAttnQFn.apply(f32(Y_ts), KV, M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
                                  resolve_precision(self), self.last_seed, p[0], *p[3:])
 
 

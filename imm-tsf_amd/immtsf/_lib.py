@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ImmtsfError(RuntimeError):
@@ -93,14 +93,13 @@ _PROTOS = {
     "immtsf_mmf_xattn_kv_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xattn_q_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xattn_q_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
-    "immtsf_mmf_xattn_kv_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
-                                              c_stream]),
-    "immtsf_mmf_xattn_kv_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+    "immtsf_mmf_xattn_kv_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xattn_kv_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p,
                                                C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
-    "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
+    "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
                                              C.c_size_t, c_stream]),
-    "immtsf_mmf_xattn_q_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
-                                              c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
+    "immtsf_mmf_xattn_q_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
+                                              c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
                                               c_stream]),
     "immtsf_mmf_gr_add_workspace_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
     "immtsf_mmf_gr_add_scratch_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),

@@ -251,8 +251,9 @@ def _half_grads(params, owned_full, owned_part, sinks):
 
 
 class MMFXAttnKVFn(torch.autograd.Function):
-    """key/value half of MMF_XAttn_Add: E_txt -> (Ki, Vi) = in_proj_{k,v}(proj_{k,v}(E_txt)).  Depends only on the text
-    side, so it can run beside the backbone; params: (proj_k_w, proj_v_w, attn_in_w, attn_in_b)."""
+    """key/value half of MMF_XAttn_Add: E_txt -> KV (B,T,2d) = (k | v) = in_proj_{k,v}(proj_{k,v}(E_txt)), computed with the
+    per-step product weights.  Depends only on the text side, so it can run beside the backbone; params: (proj_k_w,
+    proj_v_w, attn_in_w, attn_in_b)."""
 
     @staticmethod
     def forward(ctx, E, H, precision, done_hook, proj_k_w, proj_v_w, attn_in_w, attn_in_b):
@@ -263,19 +264,19 @@ class MMFXAttnKVFn(torch.autograd.Function):
         B, T, d = E.shape
         cfg = make_cfg(B, 0, T, 1, 0, d, H, precision, False, 0.0, 0.0, 0, E.device)
         ws = _bytes(lib.immtsf_mmf_xattn_kv_workspace_bytes(C.byref(cfg)), E.device)
-        Ki, Vi = torch.empty_like(E), torch.empty_like(E)
+        KV = torch.empty(B, T, 2 * d, dtype=torch.float32, device=E.device)
         ps = _struct(XAddParams, params)
-        check(lib.immtsf_mmf_xattn_kv_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(Ki), ptr(Vi), ptr(ws), ws.numel(),
-                                              stream_ptr()), "mmf_xattn_kv_forward")
+        check(lib.immtsf_mmf_xattn_kv_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(KV), ptr(ws), ws.numel(), stream_ptr()),
+              "mmf_xattn_kv_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.sinks = _sinks_of(params)
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = done_hook          # the block's gradients are final once THIS half's backward has run
         ctx.save_for_backward(E, *params[1:5])
-        return Ki, Vi
+        return KV
 
     @staticmethod
-    def backward(ctx, dKi, dVi):
+    def backward(ctx, dKV):
         lib = _lib.load()
         E, wk, wv, win, bin_ = ctx.saved_tensors
         params = [None, wk, wv, win, bin_, None, None, None, None, None, None]
@@ -283,49 +284,49 @@ class MMFXAttnKVFn(torch.autograd.Function):
         dE = torch.empty_like(E)
         sc = _bytes(lib.immtsf_mmf_xattn_kv_scratch_bytes(C.byref(ctx.cfg)), E.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
-        check(lib.immtsf_mmf_xattn_kv_backward(C.byref(ctx.cfg), C.byref(ps), ptr(E), ptr(dKi.contiguous()), ptr(dVi.contiguous()),
-                                               ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
-                                               stream_ptr()), "mmf_xattn_kv_backward")
+        check(lib.immtsf_mmf_xattn_kv_backward(C.byref(ctx.cfg), C.byref(ps), ptr(E), ptr(dKV.contiguous()), ptr(dE), ptr(ctx.ws),
+                                               ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+              "mmf_xattn_kv_backward")
         _fire(ctx.done_hook)
         return (dE, None, None, None) + tuple(rets[1:5])
 
 
 class MMFXAttnQFn(torch.autograd.Function):
-    """query half of MMF_XAttn_Add: (Y_ts, Ki, Vi, M_txt) -> Y_out.  params in XAddParams order without proj_k/proj_v."""
+    """query half of MMF_XAttn_Add: (Y_ts, KV, M_txt) -> Y_out.  params in XAddParams order without proj_k/proj_v."""
 
     @staticmethod
-    def forward(ctx, Y, Ki, Vi, M_u8, H, kappa, p_drop, training, precision, seed, proj_q_w, attn_in_w, attn_in_b, *rest):
+    def forward(ctx, Y, KV, M_u8, H, kappa, p_drop, training, precision, seed, proj_q_w, attn_in_w, attn_in_b, *rest):
         lib = _lib.load()
-        Y, Ki, Vi, M_u8 = _c(Y), _c(Ki), _c(Vi), _c(M_u8)
+        Y, KV, M_u8 = _c(Y), _c(KV), _c(M_u8)
         params = (_c(proj_q_w), None, None, _c(attn_in_w), _c(attn_in_b)) + tuple(_c(p) for p in rest)
-        _need_gpu(Y, Ki, Vi, M_u8, *params)
+        _need_gpu(Y, KV, M_u8, *params)
         B, T, Cc = Y.shape
-        d = Ki.shape[2]
+        d = KV.shape[2] // 2
         cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed, Y.device)
         ws = _bytes(lib.immtsf_mmf_xattn_q_workspace_bytes(C.byref(cfg)), Y.device)
         out = torch.empty_like(Y)
         ps = _struct(XAddParams, params)
-        check(lib.immtsf_mmf_xattn_q_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(Ki), ptr(Vi), ptr(M_u8), ptr(out), ptr(ws),
+        check(lib.immtsf_mmf_xattn_q_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(out), ptr(ws),
                                              ws.numel(), stream_ptr()), "mmf_xattn_q_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.sinks = _sinks_of(params)
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
-        ctx.save_for_backward(Y, Ki, Vi, M_u8, params[0], *params[3:])
+        ctx.save_for_backward(Y, KV, M_u8, params[0], *params[3:])
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        Y, Ki, Vi, M_u8, wq, *rest = ctx.saved_tensors
+        Y, KV, M_u8, wq, *rest = ctx.saved_tensors
         params = [wq, None, None] + list(rest)
         grads, rets = _half_grads(params, (0, 5, 6, 7, 8, 9, 10), (3, 4), ctx.sinks)
-        dY, dKi, dVi = torch.empty_like(Y), torch.empty_like(Ki), torch.empty_like(Vi)
+        dY, dKV = torch.empty_like(Y), torch.empty_like(KV)
         sc = _bytes(lib.immtsf_mmf_xattn_q_scratch_bytes(C.byref(ctx.cfg)), Y.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
-        check(lib.immtsf_mmf_xattn_q_backward(C.byref(ctx.cfg), C.byref(ps), ptr(Y), ptr(Ki), ptr(Vi), ptr(M_u8),
-                                              ptr(dout.contiguous()), ptr(dY), ptr(dKi), ptr(dVi), ptr(ctx.ws), ctx.ws.numel(),
-                                              ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "mmf_xattn_q_backward")
-        return (dY, dKi, dVi, None, None, None, None, None, None, None, rets[0]) + tuple(rets[3:])
+        check(lib.immtsf_mmf_xattn_q_backward(C.byref(ctx.cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(dout.contiguous()),
+                                              ptr(dY), ptr(dKV), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
+                                              stream_ptr()), "mmf_xattn_q_backward")
+        return (dY, dKV, None, None, None, None, None, None, None, rets[0]) + tuple(rets[3:])
 
 
 # ------------------------------------------------------------------------------------------------ MMF_GR_Add

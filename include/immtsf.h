@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define IMMTSF_ABI_VERSION 1
+#define IMMTSF_ABI_VERSION 2
 
 #define IMMTSF_OK 0
 #define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
@@ -143,27 +143,27 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
                                   const float* E_txt, const uint8_t* M_txt, const float* dY_out, float* dY_ts,
                                   float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
                                   size_t scratch_bytes, const immtsf_xadd_params* grads, immtsf_stream_t stream);
-/* The same block as two halves, for two-stream scheduling: the key/value half depends only on E_txt (proj_k, proj_v and
- * their MHA in-projections -> Ki, Vi (B*T, d)), the query half is everything else.  Run kv_forward on the text stream
- * beside the backbone; in backward the query half yields dY_ts (-> backbone) and dKi/dVi (-> kv_backward -> dE_txt).
- * Each half writes only the parameter gradients it owns (kv: proj_k_w, proj_v_w, rows d..3d of attn_in_w/_b; q: the
- * rest).  The monolithic entry points above are exactly kv + q. */
+/* The same block as two halves, for two-stream scheduling: the key/value half depends only on E_txt -- it yields
+ * KV (B*T, 2d) = (k | v) side by side, i.e. the MHA in-projections of proj_k(E_txt) and proj_v(E_txt), computed with the
+ * per-step product weights W_in,k W_k and W_in,v W_v (fusion_blocks_mmf.hip) -- the query half is everything else.  Run
+ * kv_forward on the text stream beside the backbone; in backward the query half yields dY_ts (-> backbone) and dKV
+ * (-> kv_backward -> dE_txt).  Each half writes only the parameter gradients it owns (kv: proj_k_w, proj_v_w, rows
+ * d..3d of attn_in_w/_b; q: the rest).  The monolithic entry points above are exactly kv + q. */
 size_t immtsf_mmf_xattn_kv_workspace_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xattn_kv_scratch_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xattn_q_workspace_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xattn_q_scratch_bytes(const immtsf_fusion_cfg* cfg);
-int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* Ki,
-                                float* Vi, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
-int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt,
-                                 const float* dKi, const float* dVi, float* dE_txt, void* workspace, size_t workspace_bytes,
-                                 void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads, immtsf_stream_t stream);
-int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* Ki,
-                               const float* Vi, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
-                               immtsf_stream_t stream);
-int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* Ki,
-                                const float* Vi, const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKi,
-                                float* dVi, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
-                                const immtsf_xadd_params* grads, immtsf_stream_t stream);
+int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* KV,
+                                void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dKV,
+                                 float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                 const immtsf_xadd_params* grads, immtsf_stream_t stream);
+int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
+                               const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
+                                const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKV, void* workspace,
+                                size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
+                                immtsf_stream_t stream);
 
 /* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
 typedef struct immtsf_gr_params {

@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying hipGraphs")
     ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
                     help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 no specialised wgrad kernel)")
+    ap.add_argument("--gemm2-variant", type=int, default=0, help="A/B measurements only: force one tile variant of the bf16-in-memory GEMM")
+    ap.add_argument("--one-graph", action="store_true", help="the round-1 launch model: the whole step as parallel branches of one hipGraph")
     ap.add_argument("--captured-comm", action="store_true",
                     help="N>1 graph mode: capture the bucketed RCCL all-reduces inside graph A (overlapped with the backward). "
                          "Verified here only on a 1-rank group, so the default is one eager all-reduce between the two graphs")
@@ -197,11 +199,13 @@ def main():
     from fusions.FusionModel import FusionModel
     from immtsf import _lib, config
     from immtsf.ops import backward_unit, masked_mse
-    from immtsf.train import FlatTrainer, GraphedStep
+    from immtsf.train import FlatTrainer, GraphedStep, PhasedStep
     from models.tPatchGNN import tPatchGNN
     lib = _lib.load()
     if args.gemm_config:
         lib.immtsf_debug_gemm_config(args.gemm_config, 0)
+    if args.gemm2_variant:
+        lib.immtsf_debug_gemm2_config(args.gemm2_variant, 0, -1)
     if args.no_wgrad_fork:
         lib.immtsf_set_side_stream(0)
     config.precision = args.precision
@@ -215,7 +219,7 @@ def main():
     use_graph = not args.no_graph
     wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
-                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1),
+                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=(0, 1, 2), sink_exclude=[model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias],
                           overlap=True, device_step=use_graph, grad_wire=wire)
     comm_mode = "bucketed on a side stream" if dist_on else "none"
     cpu_batch, sum_n = synth_batch(100 + rank, B_PER_GPU)
@@ -244,6 +248,8 @@ def main():
 
     # hipGraph replay (immtsf.train.GraphedStep): graph A = zero-grad, backbone + fusion forward, loss, backward, gradient
     # collection; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam + device-side counters
+    launch_mode = ("hipGraph replay (2 graphs/step)" if use_graph else "eager") + \
+                  ("" if args.no_overlap else ", backbone on a second HIP stream beside TTF")
     if use_graph:
         step = None
         if dist_on and args.captured_comm:
@@ -256,6 +262,22 @@ def main():
             except Exception as e:      # noqa: BLE001
                 raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
                                  "re-run without the flag (eager all-reduce between the two graphs)") from e
+        if step is None and not args.no_overlap and not args.one_graph and hasattr(fusion.mmf, "project_kv"):
+            # two streams, six single-chain graphs, events in between (immtsf.train.PhasedStep)
+            fc_args = (batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
+
+            def text_fn():
+                E, M = fusion.ttf(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"])
+                return (E, M) + tuple(fusion.mmf.project_kv(E))
+
+            def head_fn(pred, E, M, kv, fold):
+                out = fusion.mmf(pred, E, M, kv=(kv, fold))
+                return masked_mse(out, batch["data_to_predict"], batch["mask_predicted_data"], None, global_cnt)
+
+            if dist_on:
+                comm_mode = "eager, in front of the optimizer graph"
+            step = PhasedStep(trainer, text_fn, lambda: model.forecasting(*fc_args), head_fn)
+            launch_mode = "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them"
         if step is None:
             if dist_on:
                 trainer.overlap, comm_mode = False, "eager, between the graphs"
@@ -275,6 +297,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue_s = time.perf_counter() - t0      # host time to enqueue the timed steps (no sync inside the loop)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist_on:
@@ -406,8 +429,7 @@ def main():
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "launch": ("hipGraph replay (2 graphs/step)" if use_graph else "eager") +
-                      ("" if args.no_overlap else ", backbone on a second HIP stream beside TTF"),
+            "launch": launch_mode, "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "config": {"workload": "cfg2: tPatchGNN + TTF_T2V_XAttn + MMF_XAttn_Add, GPT2 dims (d_m=d_txt=768, H=1), "
                                    f"{B_PER_GPU} ragged windows per GPU (N_b~U{{1..32}}, T=32, C=8, M=2 patches, L<=32), dropout 0.1",
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",

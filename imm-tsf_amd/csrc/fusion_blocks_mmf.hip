@@ -79,8 +79,24 @@ int kv_weights(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const KV
     return 0;
 }
 
+// the query half's per-step product weights: W_Qf (d, C) | W_HO (C, d) | b_HO (C) | t_HO = W_res b_out (C).  They depend on
+// parameters only, so a caller can form them ahead of time (immtsf_mmf_xattn_q_fold, e.g. beside the key/value half
+// while the backbone still runs) and hand them to q_forward / q_backward; otherwise they live in the forward workspace.
+struct QFold {
+    float *WQf, *WHO, *bHO, *tHO;
+};
+inline size_t qfold_floats(const immtsf_fusion_cfg* c) { return (size_t)2 * c->d * c->C + 2 * (size_t)c->C + 16; }
+inline QFold qfold_at(const immtsf_fusion_cfg* c, float* base) {
+    QFold f;
+    const size_t d = c->d, C = c->C;
+    f.WQf = base;
+    f.WHO = base + d * C;
+    f.bHO = f.WHO + C * d;
+    f.tHO = f.bHO + ((C + 3) / 4) * 4;
+    return f;
+}
 struct QWs {
-    float *WQf, *WHO, *bHO, *tHO, *Qi, *Pm, *Am, *O, *delta, *xhatC, *rstdC;
+    float *fold, *Qi, *Pm, *Am, *O, *delta, *xhatC, *rstdC;
     size_t bytes;
 };
 QWs carve_q(const immtsf_fusion_cfg* c, void* base) {
@@ -88,10 +104,7 @@ QWs carve_q(const immtsf_fusion_cfg* c, void* base) {
     const bool dropping = c->training && c->p_drop > 0.f;
     Carver k(base);
     QWs w;
-    w.WQf = k.take<float>(d * C);
-    w.WHO = k.take<float>(C * d);
-    w.bHO = k.take<float>(C);
-    w.tHO = k.take<float>(C);
+    w.fold = k.take<float>(qfold_floats(c));
     w.Qi = k.take<float>(BT * d);
     w.Pm = k.take<float>(S);
     w.Am = dropping ? k.take<float>(S) : w.Pm;
@@ -203,8 +216,29 @@ int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     return IMMTSF_OK;
 }
 
+size_t immtsf_mmf_xattn_q_fold_floats(const immtsf_fusion_cfg* cfg) { return bad_x(cfg) ? 0 : qfold_floats(cfg); }
+
+int immtsf_mmf_xattn_q_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, float* fold, immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !fold) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int d = cfg->d, C = cfg->C, prec = cfg->precision;
+    const QFold f = qfold_at(cfg, fold);
+    {   // W_Qf = W_in,q W_q  (d x C)
+        GemmArgs g = gemm_args(d, C, d, d, C, C);
+        set_problem(g, 0, p->attn_in_w, p->proj_q_w, f.WQf, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // W_HO = W_res W_out  (C x d);  t = W_res b_out;  b_HO = t + b_res
+        GemmArgs g = gemm_args(C, d, d, d, d, d);
+        set_problem(g, 0, p->res_w, p->attn_out_w, f.WHO, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    return launch_matvec(p->res_w, d, p->attn_out_b, p->res_b, C, d, f.bHO, nullptr, 1.f, s, f.tHO);
+}
+
 int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
-                               const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+                               const uint8_t* M_txt, const float* fold, float* Y_out, void* workspace, size_t workspace_bytes,
+                               immtsf_stream_t stream) {
     if (bad_x(cfg) || !p || !Y_ts || !KV || !M_txt || !Y_out || !workspace) return IMMTSF_EINVAL;
     QWs w = carve_q(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
@@ -214,14 +248,14 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
     const long TT2 = (long)T * T;
     const float* Ki = KV;
     const float* Vi = KV + d;
-    {   // W_Qf = W_in,q W_q  (d x C)
-        GemmArgs g = gemm_args(d, C, d, d, C, C);
-        set_problem(g, 0, p->attn_in_w, p->proj_q_w, w.WQf, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    if (!fold) {
+        CHECK(immtsf_mmf_xattn_q_fold(cfg, p, w.fold, stream));
+        fold = w.fold;
     }
+    const QFold f = qfold_at(cfg, const_cast<float*>(fold));
     {   // Qi = Y W_Qf^T + b_q
         GemmArgs g = gemm_args(BT, d, C, C, C, d);
-        set_problem(g, 0, Y_ts, w.WQf, w.Qi, p->attn_in_b);
+        set_problem(g, 0, Y_ts, f.WQf, w.Qi, p->attn_in_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     {   // scores[b,h] = scale * Qi_h Ki_h^T
@@ -238,20 +272,13 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
-    {   // W_HO = W_res W_out  (C x d);  t = W_res b_out;  b_HO = t + b_res
-        GemmArgs g = gemm_args(C, d, d, d, d, d);
-        set_problem(g, 0, p->res_w, p->attn_out_w, w.WHO, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        CHECK(launch_matvec(p->res_w, d, p->attn_out_b, p->res_b, C, d, w.bHO, nullptr, 1.f, s));
-    }
     // delta = M ? O W_HO^T + b_HO : b_res   (residual_head(where(M, out_proj(O), 0)))
     if (xadd_head_supported(C, d))        // head + LayerNorm(C) + dropout + blend in one kernel (w.delta stays unused)
-        return launch_xadd_head_fwd(w.O, w.WHO, w.bHO, p->res_b, Y_ts, M_txt, BT, T, C, d, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC,
+        return launch_xadd_head_fwd(w.O, f.WHO, f.bHO, p->res_b, Y_ts, M_txt, BT, T, C, d, p->ln_w, p->ln_b, cfg->kappa, w.xhatC, w.rstdC,
                                     Y_out, drop, SITE_XADD_OUT, s);
-    CHECK(launch_matvec(p->res_w, d, p->attn_out_b, nullptr, C, d, w.tHO, nullptr, 1.f, s));
     {
         GemmArgs g = gemm_args(BT, C, d, d, d, C);
-        set_problem(g, 0, w.O, w.WHO, w.delta, w.tHO);
+        set_problem(g, 0, w.O, f.WHO, w.delta, f.tHO);
         g.row_flag = M_txt; g.row_flag_div = T; g.add_vec = p->res_b;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
@@ -259,10 +286,59 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
                                SITE_XADD_OUT, s);
 }
 
+// parameter gradients of the query half from what its data-path backward left in `scratch` (ddelta, dQi) and the
+// forward workspace (O): everything here is off the path to dY_ts / dKV
+int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
+                                       const uint8_t* M_txt, const float* fold, void* workspace, size_t workspace_bytes,
+                                       void* scratch, size_t scratch_bytes, const immtsf_xadd_params* gr, immtsf_stream_t stream) {
+    if (bad_x(cfg) || !p || !gr || !Y_ts || !M_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+    QWs w = carve_q(cfg, workspace);
+    QScratch sc = carve_q_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int B = cfg->B, T = cfg->T, d = cfg->d, C = cfg->C, BT = B * T, prec = cfg->precision;
+    (void)fold;
+    CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
+    {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
+        GemmArgs h = gemm_args(C, d, BT, C, d, d);
+        set_problem(h, 0, sc.ddelta, w.O, sc.dWHO, nullptr, gr->res_b);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+    }
+    CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
+    CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
+    {   // chain rule through W_HO = W_res W_out, b_HO = W_res b_out + b_res
+        CHECK(launch_matvec_t(p->res_w, d, sc.slive, C, d, gr->attn_out_b, 0, s));      // d b_out = W_res^T s_live
+        CHECK(launch_outer(sc.slive, p->attn_out_b, C, d, gr->res_w, d, s));             // dW_res = s_live b_out^T + dW_HO W_out^T
+        GemmArgs g = gemm_args(C, d, d, d, d, d);
+        set_problem(g, 0, sc.dWHO, p->attn_out_w, gr->res_w, nullptr);
+        g.accumulate = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+        GemmArgs h = gemm_args(d, d, C, d, d, d);                                          // dW_out = W_res^T dW_HO
+        set_problem(h, 0, p->res_w, sc.dWHO, gr->attn_out_w, nullptr);
+        prezeroed(h, cfg);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+    }
+    {   // dW_Qf = dQi^T Y, d b_q = column sums of dQi;  then dW_in,q = dW_Qf W_q^T, dW_q = W_in,q^T dW_Qf
+        GemmArgs h = gemm_args(d, C, BT, d, C, C);
+        set_problem(h, 0, sc.dQi, Y_ts, sc.dWQf, nullptr, gr->attn_in_b);      // (scratch output: the launcher zero-fills if it splits)
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        GemmArgs g = gemm_args(d, d, C, C, C, d);
+        set_problem(g, 0, sc.dWQf, p->proj_q_w, gr->attn_in_w, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+        GemmArgs h2 = gemm_args(d, C, d, d, C, C);
+        set_problem(h2, 0, p->attn_in_w, sc.dWQf, gr->proj_q_w, nullptr);
+        prezeroed(h2, cfg);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h2, s));
+    }
+    return IMMTSF_OK;
+}
+
+// defer_params != 0: only the data path (dY_ts, dKV) runs; the caller must keep `workspace` and `scratch` alive and call
+// immtsf_mmf_xattn_q_backward_params with them later (any stream ordered after this call) to get the parameter gradients
 int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
-                                const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKV, void* workspace,
-                                size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* gr,
-                                immtsf_stream_t stream) {
+                                const uint8_t* M_txt, const float* fold, const float* dY_out, float* dY_ts, float* dKV,
+                                void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                const immtsf_xadd_params* gr, int32_t defer_params, immtsf_stream_t stream) {
     if (bad_x(cfg) || !p || !gr || !Y_ts || !KV || !M_txt || !dY_out || !dY_ts || !dKV || !workspace || !scratch)
         return IMMTSF_EINVAL;
     QWs w = carve_q(cfg, workspace);
@@ -275,36 +351,16 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     const float scale = sqrtf(1.0f / (float)hd);
     const float* Ki = KV;
     const float* Vi = KV + d;
-    Fork fk(s);   // parameter-gradient work runs on the side stream, joined before returning
+    if (!fold) fold = w.fold;
+    const QFold f = qfold_at(cfg, const_cast<float*>(fold));
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
-    CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
-    {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
-        GemmArgs h = gemm_args(C, d, BT, C, d, d);
-        set_problem(h, 0, sc.ddelta, w.O, sc.dWHO, nullptr, gr->res_b);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
-    }
-    CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
-    CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
-    {   // dO = ddelta W_HO
+    {   // dO = where(M, ddelta W_HO, 0)
         GemmArgs g = gemm_args(BT, d, C, C, d, d);
-        set_problem(g, 0, sc.ddelta, w.WHO, sc.dO, nullptr);
+        set_problem(g, 0, sc.ddelta, f.WHO, sc.dO, nullptr);
+        g.row_flag = M_txt; g.row_flag_div = T;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-    }
-    {   // chain rule through W_HO = W_res W_out, b_HO = W_res b_out + b_res
-        hipStream_t f = fk.fork();
-        CHECK(launch_matvec_t(p->res_w, d, sc.slive, C, d, gr->attn_out_b, 0, f));      // d b_out = W_res^T s_live
-        CHECK(launch_outer(sc.slive, p->attn_out_b, C, d, gr->res_w, d, f));             // dW_res = s_live b_out^T + dW_HO W_out^T
-        GemmArgs g = gemm_args(C, d, d, d, d, d);
-        set_problem(g, 0, sc.dWHO, p->attn_out_w, gr->res_w, nullptr);
-        g.accumulate = 1;
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, f));
-        GemmArgs h = gemm_args(d, d, C, d, d, d);                                          // dW_out = W_res^T dW_HO
-        set_problem(h, 0, p->res_w, sc.dWHO, gr->attn_out_w, nullptr);
-        prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));
     }
     {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
         GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
@@ -331,25 +387,13 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     }
     {   // dY += dQi W_Qf
         GemmArgs g = gemm_args(BT, C, d, d, C, C);
-        set_problem(g, 0, sc.dQi, w.WQf, dY_ts, nullptr);
+        set_problem(g, 0, sc.dQi, f.WQf, dY_ts, nullptr);
         g.accumulate = 1;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
-    {   // dW_Qf = dQi^T Y, d b_q = column sums of dQi;  then dW_in,q = dW_Qf W_q^T, dW_q = W_in,q^T dW_Qf
-        hipStream_t f = fk.fork();
-        GemmArgs h = gemm_args(d, C, BT, d, C, C);
-        set_problem(h, 0, sc.dQi, Y_ts, sc.dWQf, nullptr, gr->attn_in_b);
-        prezeroed(h, cfg);
-        h.c_prezeroed = 0;           // dW_Qf is scratch, not a zero-filled gradient sink (the bias gradient is: split-K would add
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));      // to both, so the launcher's own zero-fill covers both)
-        GemmArgs g = gemm_args(d, d, C, C, C, d);
-        set_problem(g, 0, sc.dWQf, p->proj_q_w, gr->attn_in_w, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, f));
-        GemmArgs h2 = gemm_args(d, C, d, d, C, C);
-        set_problem(h2, 0, p->attn_in_w, sc.dWQf, gr->proj_q_w, nullptr);
-        prezeroed(h2, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h2, f));
-    }
+    if (defer_params) return IMMTSF_OK;
+    Fork fk(s);
+    CHECK(immtsf_mmf_xattn_q_backward_params(cfg, p, Y_ts, M_txt, fold, workspace, workspace_bytes, scratch, scratch_bytes, gr, fk.fork()));
     return fk.join();
 }
 
@@ -404,7 +448,7 @@ int immtsf_mmf_xattn_add_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
     XAddWs w = carve_xadd(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     CHECK(immtsf_mmf_xattn_kv_forward(cfg, p, E_txt, w.KV, w.kv, w.kvb, stream));
-    return immtsf_mmf_xattn_q_forward(cfg, p, Y_ts, w.KV, M_txt, Y_out, w.q, w.qb, stream);
+    return immtsf_mmf_xattn_q_forward(cfg, p, Y_ts, w.KV, M_txt, nullptr, Y_out, w.q, w.qb, stream);
 }
 
 int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
@@ -415,7 +459,7 @@ int immtsf_mmf_xattn_add_backward(const immtsf_fusion_cfg* cfg, const immtsf_xad
     XAddWs w = carve_xadd(cfg, workspace);
     XAddWs sc = carve_xadd_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
-    CHECK(immtsf_mmf_xattn_q_backward(cfg, p, Y_ts, w.KV, M_txt, dY_out, dY_ts, sc.KV, w.q, w.qb, sc.q, sc.qb, gr, stream));
+    CHECK(immtsf_mmf_xattn_q_backward(cfg, p, Y_ts, w.KV, M_txt, nullptr, dY_out, dY_ts, sc.KV, w.q, w.qb, sc.q, sc.qb, gr, 0, stream));
     return immtsf_mmf_xattn_kv_backward(cfg, p, E_txt, sc.KV, dE_txt, w.kv, w.kvb, sc.kv, sc.kvb, gr, stream);
 }
 

@@ -413,13 +413,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
 // ------------------------------------------------------------------------------------------- tiny vector ops
 __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
                                                       const float* __restrict__ b, int rows, int cols,
-                                                      float* __restrict__ y, float* __restrict__ ys, float scale) {
+                                                      float* __restrict__ y, float* __restrict__ ys, float scale,
+                                                      float* __restrict__ y_nobias) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float a = 0.f;
     for (int j = lane; j < cols; j += 64) a = fmaf(W[(size_t)row * ldw + j], x[j], a);
     a = wave_sum(a);
     if (lane == 0) {
+        if (y_nobias) y_nobias[row] = a;
         if (b) a += b[row];
         if (y) y[row] = a;
         if (ys) ys[row] = a * scale;
@@ -586,8 +588,8 @@ int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, cons
 }
 
 int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
-                  float scale, hipStream_t s) {
-    hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, W, ldw, x, b, rows, cols, y, ys, scale);
+                  float scale, hipStream_t s, float* y_nobias) {
+    hipLaunchKernelGGL(matvec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, W, ldw, x, b, rows, cols, y, ys, scale, y_nobias);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -36,7 +36,7 @@ int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, cons
                          float* dx, DropCfg drop, uint64_t site, hipStream_t s);
 // y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale
 int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
-                  float scale, hipStream_t s);
+                  float scale, hipStream_t s, float* y_nobias = nullptr);      // y_nobias: W x without the bias
 // y[j] = sum_i W[i,j] x[i]   (transposed mat-vec)
 int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols, float* y, int accumulate,
                     hipStream_t s);

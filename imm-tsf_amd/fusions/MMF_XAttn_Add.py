@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from fusions._common import f32, resolve_precision
 from immtsf import config
-from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn
+from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn, mmf_xattn_q_fold
 
 
 class MMF_XAttn_Add(nn.Module):
@@ -47,9 +47,12 @@ class MMF_XAttn_Add(nn.Module):
         """key/value half (proj_k / proj_v + their MHA in-projections -> one (B,T,2d) tensor k | v): depends only on the text
         side, so a caller can run it on the text stream while the backbone is still producing Y_ts
         (lib.evaluation.forecast_and_fuse)"""
-        return MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
-                                  getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
-                                  self.attn.in_proj_weight, self.attn.in_proj_bias)
+        KV = MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
+                                getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
+                                self.attn.in_proj_weight, self.attn.in_proj_bias)
+        # the query half's product weights depend on parameters only: form them here too, beside the backbone
+        fold = mmf_xattn_q_fold(self.C, self.d_attn, self.n_heads, resolve_precision(self), self._params())
+        return KV, fold
 
     def forward(self, Y_ts, E_txt, M_txt, kv=None):
         """Y_ts (B,T,C), E_txt (B,T,d_txt), M_txt (B,1)|(B,) bool -> (B,T,C).  kv: the result of project_kv(E_txt)
@@ -58,9 +61,9 @@ class MMF_XAttn_Add(nn.Module):
         M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
         training = self.training and self.p_drop > 0.0
         self.last_seed = config.next_seed() if training else 0
-        KV = self.project_kv(E_txt) if kv is None else kv
+        KV, fold = self.project_kv(E_txt) if kv is None else kv
         p = self._params()
-        return MMFXAttnQFn.apply(f32(Y_ts), KV, M_u8, self.n_heads, float(self.kappa), self.p_drop, training,
+        return MMFXAttnQFn.apply(f32(Y_ts), KV, M_u8, fold, self.n_heads, float(self.kappa), self.p_drop, training,
                                  resolve_precision(self), self.last_seed, p[0], *p[3:])
 
 

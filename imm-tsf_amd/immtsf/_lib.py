@@ -96,11 +96,15 @@ _PROTOS = {
     "immtsf_mmf_xattn_kv_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_mmf_xattn_kv_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p,
                                                C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
-    "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
+    "immtsf_mmf_xattn_q_fold_floats": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_mmf_xattn_q_fold": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_stream]),
+    "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_void_p,
                                              C.c_size_t, c_stream]),
-    "immtsf_mmf_xattn_q_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p,
-                                              c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams),
+    "immtsf_mmf_xattn_q_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p,
+                                              c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams), C.c_int32,
                                               c_stream]),
+    "immtsf_mmf_xattn_q_backward_params": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_u8p, c_f32p, C.c_void_p,
+                                                     C.c_size_t, C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
     "immtsf_mmf_gr_add_workspace_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
     "immtsf_mmf_gr_add_scratch_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
     "immtsf_mmf_gr_add_forward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,

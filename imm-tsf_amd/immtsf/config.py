@@ -14,6 +14,12 @@ precision = os.environ.get("IMMTSF_PRECISION", "fp32")
 nan_check = os.environ.get("IMMTSF_NAN_CHECK", "sync")
 
 
+# While set, backward passes whose parameter gradients go to FlatTrainer sinks only compute the DATA gradients and queue
+# the parameter-gradient work in immtsf.ops (run_deferred() enqueues it): immtsf.train.PhasedStep uses it to take that
+# work off the path between the loss and the backbone's backward.  Off everywhere else.
+defer_param_grads = False
+
+
 def precision_code(p=None) -> int:
     p = precision if p is None else p
     if p not in _PRECISIONS:

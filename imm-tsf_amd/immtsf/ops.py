@@ -71,6 +71,26 @@ def _grad_buffers(params, sinks=None):
     return bufs, rets
 
 
+def _zeroed_grad_buffers(params, sinks):
+    """like _grad_buffers for backward kernels that ACCUMULATE parameter gradients by atomics: the buffers must read zero.
+    Sinks whose owner zero-fills them every step (FlatTrainer) are used as they are; everything else comes out of one
+    zero-filled allocation."""
+    pre = [s is not None and getattr(p, "_immtsf_grad_prezeroed", False) for p, s in zip(params, sinks)]
+    n = sum(p.numel() for p, ok in zip(params, pre) if not ok)
+    flat = torch.zeros(n, dtype=torch.float32, device=params[0].device) if n else None
+    bufs, rets, off = [], [], 0
+    for p, s, ok in zip(params, sinks, pre):
+        if ok:
+            bufs.append(s)
+            rets.append(None)
+        else:
+            v = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
+            bufs.append(v)
+            rets.append(v)
+    return bufs, rets
+
+
 def _fire(hook):
     if hook is not None:
         hook()
@@ -291,11 +311,36 @@ class MMFXAttnKVFn(torch.autograd.Function):
         return (dE, None, None, None) + tuple(rets[1:5])
 
 
+_deferred = []          # parameter-gradient work postponed by a backward (config.defer_param_grads): closures
+
+
+def run_deferred():
+    """enqueue (on the current stream) the parameter-gradient work that backward passes postponed while
+    `immtsf.config.defer_param_grads` was set (immtsf.train.PhasedStep moves it off the path to the backbone's backward)"""
+    work = list(_deferred)
+    del _deferred[:]
+    for fn in work:
+        fn()
+
+
+def mmf_xattn_q_fold(Y_C, d, H, precision, params):
+    """the query half's per-step product weights (see immtsf_mmf_xattn_q_fold): a flat fp32 tensor; no autograd -- the
+    parameters' gradients come out of MMFXAttnQFn.backward by the chain rule"""
+    lib = _lib.load()
+    dev = params[0].device
+    cfg = make_cfg(1, 0, 1, Y_C, 0, d, H, precision, False, 0.0, 0.0, 0, dev)
+    fold = torch.empty(lib.immtsf_mmf_xattn_q_fold_floats(C.byref(cfg)), dtype=torch.float32, device=dev)
+    ps = _struct(XAddParams, tuple(None if p is None else _c(p.detach()) for p in params))
+    check(lib.immtsf_mmf_xattn_q_fold(C.byref(cfg), C.byref(ps), ptr(fold), stream_ptr()), "mmf_xattn_q_fold")
+    return fold
+
+
 class MMFXAttnQFn(torch.autograd.Function):
-    """query half of MMF_XAttn_Add: (Y_ts, KV, M_txt) -> Y_out.  params in XAddParams order without proj_k/proj_v."""
+    """query half of MMF_XAttn_Add: (Y_ts, KV, M_txt) -> Y_out.  params in XAddParams order without proj_k/proj_v.
+    fold: the result of mmf_xattn_q_fold (or None: formed inside the forward)."""
 
     @staticmethod
-    def forward(ctx, Y, KV, M_u8, H, kappa, p_drop, training, precision, seed, proj_q_w, attn_in_w, attn_in_b, *rest):
+    def forward(ctx, Y, KV, M_u8, fold, H, kappa, p_drop, training, precision, seed, proj_q_w, attn_in_w, attn_in_b, *rest):
         lib = _lib.load()
         Y, KV, M_u8 = _c(Y), _c(KV), _c(M_u8)
         params = (_c(proj_q_w), None, None, _c(attn_in_w), _c(attn_in_b)) + tuple(_c(p) for p in rest)
@@ -306,9 +351,9 @@ class MMFXAttnQFn(torch.autograd.Function):
         ws = _bytes(lib.immtsf_mmf_xattn_q_workspace_bytes(C.byref(cfg)), Y.device)
         out = torch.empty_like(Y)
         ps = _struct(XAddParams, params)
-        check(lib.immtsf_mmf_xattn_q_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(out), ptr(ws),
+        check(lib.immtsf_mmf_xattn_q_forward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(fold), ptr(out), ptr(ws),
                                              ws.numel(), stream_ptr()), "mmf_xattn_q_forward")
-        ctx.cfg, ctx.ws = cfg, ws
+        ctx.cfg, ctx.ws, ctx.fold = cfg, ws, fold
         ctx.sinks = _sinks_of(params)
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.save_for_backward(Y, KV, M_u8, params[0], *params[3:])
@@ -323,10 +368,21 @@ class MMFXAttnQFn(torch.autograd.Function):
         dY, dKV = torch.empty_like(Y), torch.empty_like(KV)
         sc = _bytes(lib.immtsf_mmf_xattn_q_scratch_bytes(C.byref(ctx.cfg)), Y.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
-        check(lib.immtsf_mmf_xattn_q_backward(C.byref(ctx.cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(dout.contiguous()),
-                                              ptr(dY), ptr(dKV), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
-                                              stream_ptr()), "mmf_xattn_q_backward")
-        return (dY, dKV, None, None, None, None, None, None, None, rets[0]) + tuple(rets[3:])
+        # the parameter gradients can only be postponed when they go to sinks (autograd gets None for them either way)
+        defer = bool(config.defer_param_grads) and all(r is None for r in rets)
+        cfg, ws, fold = ctx.cfg, ctx.ws, ctx.fold
+        check(lib.immtsf_mmf_xattn_q_backward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(fold), ptr(dout.contiguous()),
+                                              ptr(dY), ptr(dKV), ptr(ws), ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
+                                              1 if defer else 0, stream_ptr()), "mmf_xattn_q_backward")
+        if defer:
+            keep = (Y, M_u8, params, grads)         # the closure keeps every buffer it touches alive
+
+            def finish():
+                check(lib.immtsf_mmf_xattn_q_backward_params(C.byref(cfg), C.byref(ps), ptr(keep[0]), ptr(keep[1]), ptr(fold), ptr(ws),
+                                                             ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+                      "mmf_xattn_q_backward_params")
+            _deferred.append(finish)
+        return (dY, dKV, None, None, None, None, None, None, None, None, rets[0]) + tuple(rets[3:])
 
 
 # ------------------------------------------------------------------------------------------------ MMF_GR_Add
@@ -435,6 +491,7 @@ class GCNAdaptiveFn(torch.autograd.Function):
         check(lib.immtsf_tpatchgnn_gcn_forward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out), stream_ptr()),
               "tpatchgnn_gcn_forward")
         ctx.dims = (B, N, M, D, nd, order)
+        ctx.sinks = _sinks_of(params)
         ctx.save_for_backward(x, *params)
         return out
 
@@ -445,15 +502,11 @@ class GCNAdaptiveFn(torch.autograd.Function):
         B, N, M, D, nd, order = ctx.dims
         dout = dout.contiguous()
         dx = torch.empty_like(x)
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=x.device)
-        grads, o = [], 0
-        for p in params:
-            grads.append(flat[o:o + p.numel()].view(p.shape))
-            o += p.numel()
+        grads, rets = _zeroed_grad_buffers(params, ctx.sinks)
         ps, gs = _struct(GCNParams, params), _struct(GCNParams, grads)
         check(lib.immtsf_tpatchgnn_gcn_backward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs),
                                                 stream_ptr()), "tpatchgnn_gcn_backward")
-        return (dx, None) + tuple(grads)
+        return (dx, None) + tuple(rets)
 
 
 def gcn_adaptive_supported(N, D, nd, order):
@@ -484,6 +537,7 @@ class TPatchDecoderFn(torch.autograd.Function):
         check(lib.immtsf_tpatchgnn_decoder_forward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(out), stream_ptr()),
               "tpatchgnn_decoder_forward")
         ctx.dims = (B, N, Lp, D, E, H)
+        ctx.sinks = _sinks_of(params)
         ctx.save_for_backward(h, te, *params)
         return out
 
@@ -494,15 +548,11 @@ class TPatchDecoderFn(torch.autograd.Function):
         B, N, Lp, D, E, H = ctx.dims
         dout = dout.contiguous()
         dh, dte = torch.empty_like(h), torch.empty_like(te)
-        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=h.device)
-        grads, o = [], 0
-        for p in params:
-            grads.append(flat[o:o + p.numel()].view(p.shape))
-            o += p.numel()
+        grads, rets = _zeroed_grad_buffers(params, ctx.sinks)
         ps, gs = _struct(DecoderParams, params), _struct(DecoderParams, grads)
         check(lib.immtsf_tpatchgnn_decoder_backward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh), ptr(dte),
                                                     C.byref(gs), stream_ptr()), "tpatchgnn_decoder_backward")
-        return (dh, dte) + tuple(grads)
+        return (dh, dte) + tuple(rets)
 
 
 def tpatch_decoder_supported(seq, N, Lp, D, E):
@@ -552,6 +602,8 @@ class LinearFn(torch.autograd.Function):
         _gemm(0, precision, x2, K, W, K, y, N, b, M, N, K, act=1 if relu else 0)
         ctx.save_for_backward(x2, W, y if relu else None)
         ctx.has_bias, ctx.precision, ctx.shape = b is not None, precision, x.shape
+        ctx.sinks = _sinks_of((W, b))
+        ctx.pre = all(s is not None and getattr(p, "_immtsf_grad_prezeroed", False) for p, s in zip((W, b), ctx.sinks) if p is not None)
         return y
 
     @staticmethod
@@ -565,14 +617,16 @@ class LinearFn(torch.autograd.Function):
             dy2 = torch.ops.aten.threshold_backward(dy2, y.reshape(M, N), 0.0)
         need_w = ctx.needs_input_grad[1]
         dx = torch.empty(M, K, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
-        dW = db = None
-        if need_w:              # ONE zero fill for dW|db: the split-K weight gradient then needs no memsets of its own
+        dW = db = rW = rb = None
+        if need_w and ctx.pre:  # gradient sinks that their owner zero-fills every step: written in place, nothing returned
+            dW, db = ctx.sinks
+        elif need_w:            # ONE zero fill for dW|db: the split-K weight gradient then needs no memsets of its own
             flat = torch.zeros(N * K + (N if ctx.has_bias else 0), dtype=torch.float32, device=dy.device)
-            dW = flat[:N * K].view(N, K)
-            db = flat[N * K:] if ctx.has_bias else None
+            dW = rW = flat[:N * K].view(N, K)
+            db = rb = flat[N * K:] if ctx.has_bias else None
         check(lib.immtsf_linear_backward(ctx.precision, ptr(x2), ptr(W), ptr(dy2), M, N, K, ptr(dx), None, ptr(dW), ptr(db),
                                          1, stream_ptr()), "linear_backward")
-        return (dx.view(ctx.shape) if dx is not None else None), dW, db, None, None
+        return (dx.view(ctx.shape) if dx is not None else None), rW, rb, None, None
 
 
 def linear(x, W, b=None, precision=None, relu=False):
@@ -600,6 +654,9 @@ class MLPFn(torch.autograd.Function):
             acts.append(y)
         ctx.save_for_backward(*acts[:-1], *Ws)
         ctx.nl, ctx.has_bias, ctx.precision, ctx.shape = nl, has_bias, precision, x.shape
+        ctx.wsinks, ctx.bsinks = _sinks_of(params[:nl]), _sinks_of(bs)
+        ctx.pre = all(s is not None and getattr(p, "_immtsf_grad_prezeroed", False)
+                      for p, s in zip(list(params[:nl]) + bs, ctx.wsinks + ctx.bsinks) if p is not None)
         return acts[-1]
 
     @staticmethod
@@ -610,18 +667,23 @@ class MLPFn(torch.autograd.Function):
         dWs, dbs = [None] * nl, [None] * nl
         g = dy.contiguous().reshape(-1, Ws[-1].shape[0])
         dev = dy.device
-        # ONE zero-filled buffer for every layer's dW|db (32-byte aligned slices): no per-GEMM memsets
-        sizes = [((W.numel() + 7) // 8 * 8, (W.shape[0] + 7) // 8 * 8) if ctx.needs_input_grad[3 + i] else (0, 0)
-                 for i, W in enumerate(Ws)]
-        flat = torch.zeros(max(1, sum(a + b for a, b in sizes)), dtype=torch.float32, device=dev)
-        off = 0
-        for i, W in enumerate(Ws):
-            if ctx.needs_input_grad[3 + i]:
-                dWs[i] = flat[off:off + W.numel()].view(W.shape)
-                off += sizes[i][0]
-                if ctx.has_bias[i]:
-                    dbs[i] = flat[off:off + W.shape[0]]
-                off += sizes[i][1]
+        if ctx.pre:             # FlatTrainer sinks (zero-filled by their owner every step): written in place
+            dWs, dbs = list(ctx.wsinks), list(ctx.bsinks)
+            rWs, rbs = [None] * nl, [None] * nl
+        else:
+            # ONE zero-filled buffer for every layer's dW|db (32-byte aligned slices): no per-GEMM memsets
+            sizes = [((W.numel() + 7) // 8 * 8, (W.shape[0] + 7) // 8 * 8) if ctx.needs_input_grad[3 + i] else (0, 0)
+                     for i, W in enumerate(Ws)]
+            flat = torch.zeros(max(1, sum(a + b for a, b in sizes)), dtype=torch.float32, device=dev)
+            off = 0
+            for i, W in enumerate(Ws):
+                if ctx.needs_input_grad[3 + i]:
+                    dWs[i] = flat[off:off + W.numel()].view(W.shape)
+                    off += sizes[i][0]
+                    if ctx.has_bias[i]:
+                        dbs[i] = flat[off:off + W.shape[0]]
+                    off += sizes[i][1]
+            rWs, rbs = dWs, dbs
         for i in reversed(range(nl)):
             x, W = acts[i], Ws[i]
             M, K = x.shape
@@ -632,7 +694,7 @@ class MLPFn(torch.autograd.Function):
                                              ptr(x) if i > 0 else None, ptr(dWs[i]), ptr(dbs[i]), 1, stream_ptr()),
                   "linear_backward")
             g = dx
-        return (g.view(ctx.shape) if g is not None else None), None, None, *dWs, *dbs
+        return (g.view(ctx.shape) if g is not None else None), None, None, *rWs, *rbs
 
 
 def mlp(x, weights, biases, precision=None):
@@ -692,6 +754,7 @@ class LayerNormFn(torch.autograd.Function):
                                            0.0, 0, 0, stream_ptr()), "layernorm_forward")
         ctx.save_for_backward(xhat, rstd, gamma)
         ctx.shape = x.shape
+        ctx.sinks = _sinks_of((gamma, beta))
         return z
 
     @staticmethod
@@ -701,11 +764,11 @@ class LayerNormFn(torch.autograd.Function):
         rows, d = xhat.shape
         g = dz.contiguous().reshape(rows, d).clone()
         dx = torch.empty_like(xhat)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        (dgamma, dbeta), rets = _grad_buffers((gamma, gamma), ctx.sinks)        # overwritten by the kernel
         scratch = torch.empty(64 * d, dtype=torch.float32, device=dz.device)
         check(lib.immtsf_layernorm_backward(ptr(g), rows, d, ptr(gamma), ptr(xhat), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta),
                                             ptr(scratch), 0.0, 0, 0, stream_ptr()), "layernorm_backward")
-        return dx.view(ctx.shape), dgamma, dbeta, None
+        return dx.view(ctx.shape), rets[0], rets[1], None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

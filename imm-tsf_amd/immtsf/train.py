@@ -31,9 +31,14 @@ class FlatTrainer:
     def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
                  sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None,
-                 grad_wire: str = "fp32"):
+                 grad_wire: str = "fp32", sink_exclude: Iterable[torch.nn.Parameter] = ()):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
-        sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks).
+        sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks; the
+        backbone too when every op that uses its parameters is an immtsf.ops function).  A sink parameter must be used by
+        exactly ONE such op per step (the op overwrites, or atomically accumulates onto, the zero-filled slice);
+        sink_exclude: parameters of sink buckets that are used more than once or by stock torch ops (e.g. tPatchGNN's
+        time-embedding weights, shared by the patch encoder and the decoder's time features) -- autograd accumulates those
+        as usual and they are copied into the flat buffer after the backward.
         grad_wire: "fp32" (exact: the sum of the ranks' gradients) or "bf16" (the gradients are rounded to bf16 for the
         all-reduce and widened again: half the bytes on xGMI -- the collective is per-link bandwidth bound -- at the
         cost of ~3 significant digits per element, which clip + Adam's normalised update tolerates)."""
@@ -65,6 +70,8 @@ class FlatTrainer:
         self.ranges = []
         self._views = []
         self._collected = True
+        excl = {id(p) for p in sink_exclude}
+        self._autograd_owned = []        # (parameter, flat gradient view) pairs autograd accumulates itself
         off = 0
         for bi, b in enumerate(self.buckets):
             start = off
@@ -75,9 +82,11 @@ class FlatTrainer:
                 p.data = self.flat_param[off:off + k].view(p.shape)
                 gview = self.flat_grad[off:off + k].view(p.shape)
                 views.append(gview)
-                if bi in sink_buckets:
+                if bi in sink_buckets and id(p) not in excl:
                     p._immtsf_grad_sink = gview
                     p._immtsf_grad_prezeroed = True   # zero_grad() memsets the whole flat buffer every step
+                else:
+                    self._autograd_owned.append((p, gview))
                 p.grad = gview              # optimizers / clip utilities that look at .grad still work
                 off += pad8(k)
             self._views.append(views)
@@ -149,10 +158,8 @@ class FlatTrainer:
         parameters get `.grad = None` so that AccumulateGrad adopts the incoming tensor instead of launching one add
         kernel per parameter -- `_collect_autograd_grads` copies them into the flat buffer with one multi-tensor copy."""
         self.flat_grad.zero_()
-        for bi, b in enumerate(self.buckets):
-            if bi not in self.sink_buckets:
-                for p in b:
-                    p.grad = None
+        for p, _ in self._autograd_owned:
+            p.grad = None
         self._reduced = [False] * len(self.buckets)
         self._collected = False
 
@@ -161,13 +168,10 @@ class FlatTrainer:
             return
         self._collected = True
         dst, src = [], []
-        for bi, b in enumerate(self.buckets):
-            if bi in self.sink_buckets:
-                continue
-            for p, v in zip(b, self._views[bi]):
-                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
-                    dst.append(v)
-                    src.append(p.grad.reshape(v.shape))
+        for p, v in self._autograd_owned:
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(p.grad.reshape(v.shape))
         if dst:
             torch._foreach_copy_(dst, src)
 
@@ -281,6 +285,10 @@ class GraphedStep:
             raise ValueError("GraphedStep needs FlatTrainer(device_step=True): host-side step counters would freeze in the graph")
         self.trainer, self.loss_fn = trainer, loss_fn
         self.captured_comm = bool(capture_collectives and trainer.collective)
+        if trainer.collective and not self.captured_comm:
+            # the bucket hooks must not fire inside the captured backward: their all-reduces would be captured (pulling the
+            # communication stream into the capture without a join) AND repeated by sync_grads() between the graphs
+            trainer.overlap = False
         side = torch.cuda.Stream(device=trainer.flat_param.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up off the default stream: allocator pools, lazy inits, RCCL channels
@@ -314,4 +322,139 @@ class GraphedStep:
             t._reduced = [False] * len(t.buckets)
             t.sync_grads()
         self.graph_b.replay()
+        return self.loss
+
+
+class PhasedStep:
+    """One training step as SIX single-stream hipGraphs replayed on TWO HIP streams, with HIP events between them.
+
+    The step has two chains that only meet at the modality fusion: the text side (TTF + the key/value half of MMF) and
+    the backbone.  Captured as parallel branches of ONE hipGraph they are at the mercy of the graph executor: on
+    ROCm 7.2 the branch that is not the capturing stream's continuation started 200-400 us after its inputs were ready
+    (r02 traces: the forward overlapped, the two backward branches ran one after the other although the captured
+    dependencies were exactly fork -> join).  Here every graph is a plain chain, the parallelism is two real streams, and
+    the dependencies are event waits the host enqueues between graph launches:
+
+        stream T (text):      T1 zero-grad, TTF fwd, MMF k|v fwd ........ T2 MMF query half fwd, loss, its backward ... T3 k|v + TTF bwd .. O clip+Adam
+        stream B (backbone):  B1 backbone fwd ............................(waits T2) B2 backbone bwd, gradient collection ..........^
+                                          T2 waits B1                                                      O waits B2
+
+    text_fn() -> tuple of tensors (those that require grad are cut: the head sees detached copies and their gradients
+    are fed back into T3); backbone_fn() -> pred_y; head_fn(pred_y, *text_out) -> scalar loss.  Needs
+    FlatTrainer(device_step=True).  world > 1: one eager all-reduce of the flat gradient in front of O (like
+    GraphedStep without captured collectives)."""
+
+    def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3):
+        if not trainer.device_step:
+            raise ValueError("PhasedStep needs FlatTrainer(device_step=True): host-side step counters would freeze in the graphs")
+        self.trainer = trainer
+        self.text_fn, self.backbone_fn, self.head_fn = text_fn, backbone_fn, head_fn
+        if trainer.collective:
+            trainer.overlap = False
+        dev = trainer.flat_param.device
+        self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        self.T.wait_stream(cur)
+        self.B.wait_stream(cur)
+        for _ in range(warmup):       # eager, on the two streams: allocator pools, lazy inits, RCCL channels
+            self._eager_step()
+        torch.cuda.synchronize()
+        G = torch.cuda.CUDAGraph
+        self.gT1, self.gB1, self.gT2, self.gB2, self.gT3, self.gO = G(), G(), G(), G(), G(), G()
+        # one memory pool per stream: graphs that replay concurrently must never be handed each other's freed blocks
+        poolT, poolB = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(self.gT1, pool=poolT, stream=self.T):
+            trainer.zero_grad()
+            outs = text_fn()
+        with torch.cuda.graph(self.gB1, pool=poolB, stream=self.B):
+            pred = backbone_fn()
+        with torch.cuda.graph(self.gT2, pool=poolT, stream=self.T):
+            py, cuts, loss = self._head(pred, outs)
+            dpy = py.grad
+            dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
+        with torch.cuda.graph(self.gB2, pool=poolB, stream=self.B):
+            torch.autograd.backward([pred], [dpy])
+            trainer.collect_grads()
+        with torch.cuda.graph(self.gT3, pool=poolT, stream=self.T):
+            self._text_backward(outs, dcuts)
+        with torch.cuda.graph(self.gO, pool=poolT, stream=self.T):
+            trainer.step()
+        self.loss = loss
+        self._keep = (outs, pred, py, cuts, dpy, dcuts)          # boundary tensors live in the graphs' pools: keep them referenced
+        self.eB1, self.eT2, self.eB2, self.eO = (torch.cuda.Event() for _ in range(4))
+        self.eO.record(self.T)
+
+    def _head(self, pred, outs):
+        from . import config
+        py = pred.detach().requires_grad_(True)
+        cuts = [o.detach().requires_grad_(True) if (torch.is_tensor(o) and o.requires_grad) else o for o in outs]
+        loss = self.head_fn(py, *cuts)
+        config.defer_param_grads = True       # the head's parameter gradients are enqueued behind the text-side backward (T3)
+        try:
+            ops.backward_unit(loss)
+        finally:
+            config.defer_param_grads = False
+        return py, cuts, loss
+
+    @staticmethod
+    def _text_backward(outs, dcuts):
+        ts = [o for o, g in zip(outs, dcuts) if g is not None]
+        gs = [g for g in dcuts if g is not None]
+        if ts:
+            torch.autograd.backward(ts, gs)
+        ops.run_deferred()
+
+    def _eager_step(self):
+        t = self.trainer
+        with torch.cuda.stream(self.T):
+            t.zero_grad()
+            outs = self.text_fn()
+        self.B.wait_stream(self.T)       # (the zero-fill precedes every gradient write)
+        with torch.cuda.stream(self.B):
+            pred = self.backbone_fn()
+        self.T.wait_stream(self.B)
+        with torch.cuda.stream(self.T):
+            py, cuts, loss = self._head(pred, outs)
+            dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
+        self.B.wait_stream(self.T)
+        with torch.cuda.stream(self.B):
+            torch.autograd.backward([pred], [py.grad])
+            t.collect_grads()
+        with torch.cuda.stream(self.T):
+            self._text_backward(outs, dcuts)
+        self.T.wait_stream(self.B)
+        with torch.cuda.stream(self.T):
+            t._reduced = [False] * len(t.buckets)
+            t.sync_grads()
+            t.step()
+        return loss
+
+    def __call__(self):
+        t, T, B = self.trainer, self.T, self.B
+        cur = torch.cuda.current_stream()
+        T.wait_stream(cur)
+        with torch.cuda.stream(T):
+            self.gT1.replay()
+        with torch.cuda.stream(B):
+            B.wait_event(self.eO)            # the previous step's parameter update
+            self.gB1.replay()
+            self.eB1.record(B)
+        with torch.cuda.stream(T):
+            T.wait_event(self.eB1)
+            self.gT2.replay()
+            self.eT2.record(T)
+        with torch.cuda.stream(B):
+            B.wait_event(self.eT2)
+            self.gB2.replay()
+            self.eB2.record(B)
+        with torch.cuda.stream(T):
+            self.gT3.replay()
+            T.wait_event(self.eB2)
+            if t.collective:
+                t._reduced = [False] * len(t.buckets)
+                t._collected = True
+                t.sync_grads()
+            self.gO.replay()
+            self.eO.record(T)
+        cur.wait_stream(T)
         return self.loss

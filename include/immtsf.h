@@ -158,12 +158,25 @@ int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
 int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dKV,
                                  float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                                  const immtsf_xadd_params* grads, immtsf_stream_t stream);
+/* The query half's per-step product weights (W_in,q W_q | W_res W_out | W_res b_out + b_res | W_res b_out) depend on
+ * parameters only: q_fold forms them into `fold` (q_fold_floats(cfg) floats) ahead of time -- e.g. beside the key/value
+ * half while the backbone still runs -- and q_forward / q_backward take them (fold == NULL: formed inside q_forward,
+ * kept in its workspace). */
+size_t immtsf_mmf_xattn_q_fold_floats(const immtsf_fusion_cfg* cfg);
+int immtsf_mmf_xattn_q_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, float* fold, immtsf_stream_t stream);
 int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
-                               const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+                               const uint8_t* M_txt, const float* fold, float* Y_out, void* workspace, size_t workspace_bytes,
+                               immtsf_stream_t stream);
+/* defer_params != 0: only the data path (dY_ts, dKV) is enqueued; keep `workspace` and `scratch` alive and call
+ * q_backward_params with them later, on any stream ordered after this call, for the parameter gradients. */
 int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts, const float* KV,
-                                const uint8_t* M_txt, const float* dY_out, float* dY_ts, float* dKV, void* workspace,
-                                size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
-                                immtsf_stream_t stream);
+                                const uint8_t* M_txt, const float* fold, const float* dY_out, float* dY_ts, float* dKV,
+                                void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                const immtsf_xadd_params* grads, int32_t defer_params, immtsf_stream_t stream);
+int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* Y_ts,
+                                       const uint8_t* M_txt, const float* fold, void* workspace, size_t workspace_bytes,
+                                       void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
+                                       immtsf_stream_t stream);
 
 /* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
 typedef struct immtsf_gr_params {

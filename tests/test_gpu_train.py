@@ -293,3 +293,71 @@ def test_adjacent_projection_weights_take_the_single_gemm_path():
     for (k, p), q in zip(a.named_parameters(), b.parameters()):
         assert float((p.grad - q.grad).abs().max() / max(float(p.grad.abs().max()), 1e-6)) < 1e-5, k
     tr.close()
+
+
+def _setup_sinks(dev, dropout, seed=0):
+    """like _setup, with the backbone bucket on gradient sinks too (all but the shared time-embedding parameters)"""
+    model, fusion, tr, batch = _setup(dev, dropout, seed)
+    from immtsf.train import FlatTrainer
+    tr.close()
+    te = [model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias]
+    tr2 = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+                      lr=1e-2, eps=1e-3, max_norm=1.0, sink_buckets=(0, 1, 2), sink_exclude=te, overlap=False, device_step=True)
+    return model, fusion, tr2, batch
+
+
+def test_backbone_gradient_sinks_equal_autograd_accumulation():
+    """the backbone ops writing their parameter gradients straight into the flat buffer (no fills, no per-parameter adds,
+    no collection copy) must give the flat gradient autograd + collect_grads gives"""
+    dev = _dev()
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    tr.zero_grad()
+    _loss_fn(model, fusion, batch)().backward()
+    tr.collect_grads()
+    ref = tr.gather(tr.flat_grad).clone()
+    tr.close()
+    model, fusion, tr, batch = _setup_sinks(dev, 0.0)
+    assert len(tr._autograd_owned) == 4
+    tr.zero_grad()
+    _loss_fn(model, fusion, batch)().backward()
+    tr.collect_grads()
+    got = tr.gather(tr.flat_grad)
+    torch.cuda.synchronize()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
+    tr.close()
+
+
+def test_phased_step_trains_like_eager():
+    """immtsf.train.PhasedStep (six single-stream graphs on two streams, the query half's parameter gradients deferred
+    behind the text-side backward) must train exactly like the eager step"""
+    dev = _dev()
+    from immtsf.ops import masked_mse
+    from immtsf.train import PhasedStep
+    steps = 4
+    model, fusion, tr, batch = _setup_sinks(dev, 0.0)
+    f = _loss_fn(model, fusion, batch)
+    for _ in range(3 + steps):
+        tr.zero_grad()
+        f().backward()
+        tr.sync_grads()
+        tr.step()
+    ref = tr.flat_param.clone()
+    tr.close()
+    model, fusion, tr, batch = _setup_sinks(dev, 0.0)
+    fc = (batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
+
+    def text_fn():
+        E, M = fusion.ttf(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"])
+        return (E, M) + tuple(fusion.mmf.project_kv(E))
+
+    def head_fn(pred, E, M, kv, fold):
+        return masked_mse(fusion.mmf(pred, E, M, kv=(kv, fold)), batch["data_to_predict"], batch["mask_predicted_data"])
+
+    st = PhasedStep(tr, text_fn, lambda: model.forecasting(*fc), head_fn)
+    losses = [float(st().detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    assert losses[-1] < losses[0]
+    err = float((tr.flat_param - ref).abs().max() / ref.abs().max())
+    assert err < 2e-4, err
+    tr.close()

@@ -152,7 +152,9 @@ def main():
     ap.add_argument("--gemm-config", type=lambda x: int(x, 0), default=0,
                     help="A/B measurements only: immtsf_debug_gemm_config bits (0x100 no XCD order, 0x2000 no specialised wgrad kernel)")
     ap.add_argument("--gemm2-variant", type=int, default=0, help="A/B measurements only: force one tile variant of the bf16-in-memory GEMM")
-    ap.add_argument("--one-graph", action="store_true", help="the round-1 launch model: the whole step as parallel branches of one hipGraph")
+    ap.add_argument("--phased", action="store_true",
+                    help="immtsf.train.PhasedStep: six single-stream hipGraphs on two HIP streams with events between them, instead "
+                         "of the whole step as parallel branches of one hipGraph (DESIGN.md section 6 has both measured)")
     ap.add_argument("--captured-comm", action="store_true",
                     help="N>1 graph mode: capture the bucketed RCCL all-reduces inside graph A (overlapped with the backward). "
                          "Verified here only on a 1-rank group, so the default is one eager all-reduce between the two graphs")
@@ -262,7 +264,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
                                  "re-run without the flag (eager all-reduce between the two graphs)") from e
-        if step is None and not args.no_overlap and not args.one_graph and hasattr(fusion.mmf, "project_kv"):
+        if step is None and args.phased and not args.no_overlap and hasattr(fusion.mmf, "project_kv"):
             # two streams, six single-chain graphs, events in between (immtsf.train.PhasedStep)
             fc_args = (batch["tp_to_predict"], batch["observed_data"], batch["observed_tp"], batch["observed_mask"])
 

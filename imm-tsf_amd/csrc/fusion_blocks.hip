@@ -178,7 +178,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z.f, drop, SITE_T2V_OUT, s, w.z.h));
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem2(g, 0, w.z, W.po, mat(E_txt), p->proj_out_b);
+        set_problem2(g, 0, w.z, W.po, mat(E_txt, hf ? cfg->out_h : nullptr), p->proj_out_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     hipError_t e = hipMemcpyAsync(M_txt, w.mtxt, B, hipMemcpyDeviceToDevice, s);
@@ -218,7 +218,9 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     T2VW W;
     CHECK(t2v_weights(cfg, p, w, s, &W));
     Mat dE = cmat(dE_txt);
-    if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
+    if (hf && cfg->in_h) {
+        dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
+    } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
         CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
         dE.h = sc.dE.h;
     }

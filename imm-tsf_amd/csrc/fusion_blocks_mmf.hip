@@ -29,7 +29,7 @@ namespace {
 // The block is split into a key/value half (depends only on E_txt) and a query half (everything else).  The halves are
 // separate C entry points so the host can run the key/value half on the text stream beside the backbone, and start the
 // backbone's backward as soon as the query half has produced dY_ts.  The monolithic entry points call both.
-inline bool xadd_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d >= 16 && (c->d % 8) == 0; }
+inline bool xadd_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d >= 16 && (c->d % 16) == 0; }
 
 struct KVWs {
     Mat E, WKVf;          // bf16 image of E_txt (hf) ; the stacked product weight (2d, d)
@@ -197,7 +197,9 @@ int immtsf_mmf_xattn_kv_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     KVW W;
     CHECK(kv_weights(cfg, p, w, s, &W));
     Mat E = cmat(E_txt);
-    if (hf) {
+    if (hf && cfg->in_h) {
+        E.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
         CHECK(launch_f32_to_bf16(E_txt, w.E.h, (size_t)BT * d, s));
         E.h = w.E.h;
     }
@@ -353,6 +355,7 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
     const float* Vi = KV + d;
     if (!fold) fold = w.fold;
     const QFold f = qfold_at(cfg, const_cast<float*>(fold));
+    unsigned short* dKV_h = (xadd_hf(cfg) && cfg->out_h) ? static_cast<unsigned short*>(cfg->out_h) : nullptr;   // bf16 image of dKV
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
@@ -369,6 +372,7 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
         GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
         set_problem(h, 0, w.Am, sc.dO, dKV + d, nullptr);
+        if (dKV_h) h.p[0].Ch = dKV_h + d;
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
@@ -381,6 +385,7 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
         set_problem(h, 0, sc.dA, w.Qi, dKV, nullptr);
+        if (dKV_h) h.p[0].Ch = dKV_h;
         h.alpha = scale;
         batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
@@ -409,15 +414,17 @@ int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
     const bool hf = xadd_hf(cfg);
     KVW W;
     CHECK(kv_weights(cfg, p, w, s, &W));
-    Mat dK = cmat(dKV), E = cmat(E_txt, w.E.h);
-    if (hf) {
+    Mat dK = cmat(dKV), E = cmat(E_txt, (hf && cfg->aux_h) ? cfg->aux_h : w.E.h);
+    if (hf && cfg->in_h) {
+        dK.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
         CHECK(launch_f32_to_bf16(dKV, sc.dKV.h, (size_t)BT * 2 * d, s));
         dK.h = sc.dKV.h;
     }
     Fork fk(s);
     {   // dE = (dK | dV) W_KVf
         GemmArgs g = gemm_args(BT, d, 2 * d, 2 * d, d, d);
-        set_problem2(g, 0, dK, w.WKVf, mat(dE_txt), nullptr);
+        set_problem2(g, 0, dK, w.WKVf, mat(dE_txt, hf ? cfg->out_h : nullptr), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     {   // dW_KVf = (dK | dV)^T E ; (d b_k | d b_v) = column sums;  then the chain rule through W_{K,V}f = W_in W_proj

@@ -100,6 +100,30 @@ def _bytes(n, dev):
     return torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev)
 
 
+# ---- bf16 images of activations that cross a block boundary (bf16 mode).  The producer registers (fp32 tensor, bf16
+# image); a consumer that is handed the SAME, unmodified fp32 tensor finds the image and skips its cast kernel.  The
+# fp32 tensor is kept referenced while registered, so its storage cannot be recycled under a stale entry.
+_shadows = []          # [(fp32 tensor, version at registration, bf16 tensor)], newest last, at most _SHADOW_CAP entries
+_SHADOW_CAP = 6
+
+
+def _shadow_put(t, h):
+    _shadows.append((t, t._version, h))
+    if len(_shadows) > _SHADOW_CAP:
+        del _shadows[0]
+
+
+def _shadow_get(x):
+    for t, ver, h in reversed(_shadows):
+        if t.data_ptr() == x.data_ptr() and t.shape == x.shape and t._version == ver and x._version == ver and x.is_contiguous():
+            return h
+    return None
+
+
+def _bf16_dataflow(precision, d):
+    return precision == 1 and d >= 16 and d % 16 == 0
+
+
 def make_cfg(B, N, T, Cc, d_m, d, H, precision, training, p_drop, kappa, seed, device=None):
     return FusionCfg(B, N, T, Cc, d_m, d, H, precision, 1 if training else 0, float(p_drop), float(kappa),
                      int(seed) & 0xFFFFFFFFFFFFFFFF, None if device is None else config.dropout_counter_ptr(device))
@@ -138,6 +162,10 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)
         ps = _struct(T2VParams, params)
+        E_h = None
+        if _bf16_dataflow(precision, d) and d_m % 8 == 0:
+            E_h = torch.empty(B, T, d, dtype=torch.bfloat16, device=notes.device)
+            cfg.out_h = E_h.data_ptr()
         if packed:
             check(lib.immtsf_ttf_t2v_xattn_forward_packed(C.byref(cfg), C.byref(ps), ptr(notes), ptr(src_rows), ptr(lengths),
                                                           ptr(tau), ptr(E), ptr(M), ptr(ws), ws.numel(), stream_ptr()),
@@ -145,6 +173,9 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         else:
             check(lib.immtsf_ttf_t2v_xattn_forward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(E), ptr(M), ptr(ws),
                                                    ws.numel(), ptr(nan_flag), stream_ptr()), "ttf_t2v_xattn_forward")
+        cfg.out_h = None
+        if E_h is not None:
+            _shadow_put(E, E_h)
         ctx.cfg, ctx.ws, ctx.src_rows = cfg, ws, src_rows
         ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
@@ -164,6 +195,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
         ps, gs = _struct(T2VParams, params), _struct(T2VParams, grads)
+        dE_h = _shadow_get(dE) if _bf16_dataflow(ctx.cfg.precision, ctx.cfg.d) else None
+        ctx.cfg.in_h = None if dE_h is None else dE_h.data_ptr()
         if ctx.src_rows is not None:
             check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
                                                            ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
@@ -286,6 +319,9 @@ class MMFXAttnKVFn(torch.autograd.Function):
         ws = _bytes(lib.immtsf_mmf_xattn_kv_workspace_bytes(C.byref(cfg)), E.device)
         KV = torch.empty(B, T, 2 * d, dtype=torch.float32, device=E.device)
         ps = _struct(XAddParams, params)
+        E_h = _shadow_get(E) if _bf16_dataflow(precision, d) else None
+        cfg.in_h = None if E_h is None else E_h.data_ptr()
+        ctx.E_h = E_h
         check(lib.immtsf_mmf_xattn_kv_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(KV), ptr(ws), ws.numel(), stream_ptr()),
               "mmf_xattn_kv_forward")
         ctx.cfg, ctx.ws = cfg, ws
@@ -304,9 +340,19 @@ class MMFXAttnKVFn(torch.autograd.Function):
         dE = torch.empty_like(E)
         sc = _bytes(lib.immtsf_mmf_xattn_kv_scratch_bytes(C.byref(ctx.cfg)), E.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
-        check(lib.immtsf_mmf_xattn_kv_backward(C.byref(ctx.cfg), C.byref(ps), ptr(E), ptr(dKV.contiguous()), ptr(dE), ptr(ctx.ws),
+        dKV = dKV.contiguous()
+        cfg, dE_h = ctx.cfg, None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            dKV_h = _shadow_get(dKV)
+            cfg.in_h = None if dKV_h is None else dKV_h.data_ptr()
+            cfg.aux_h = None if ctx.E_h is None else ctx.E_h.data_ptr()
+            dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
+            cfg.out_h = dE_h.data_ptr()
+        check(lib.immtsf_mmf_xattn_kv_backward(C.byref(cfg), C.byref(ps), ptr(E), ptr(dKV), ptr(dE), ptr(ctx.ws),
                                                ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
               "mmf_xattn_kv_backward")
+        if dE_h is not None:
+            _shadow_put(dE, dE_h)
         _fire(ctx.done_hook)
         return (dE, None, None, None) + tuple(rets[1:5])
 
@@ -371,9 +417,16 @@ class MMFXAttnQFn(torch.autograd.Function):
         # the parameter gradients can only be postponed when they go to sinks (autograd gets None for them either way)
         defer = bool(config.defer_param_grads) and all(r is None for r in rets)
         cfg, ws, fold = ctx.cfg, ctx.ws, ctx.fold
+        dKV_h = None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            dKV_h = torch.empty(dKV.shape, dtype=torch.bfloat16, device=dKV.device)
+            cfg.out_h = dKV_h.data_ptr()
         check(lib.immtsf_mmf_xattn_q_backward(C.byref(cfg), C.byref(ps), ptr(Y), ptr(KV), ptr(M_u8), ptr(fold), ptr(dout.contiguous()),
                                               ptr(dY), ptr(dKV), ptr(ws), ws.numel(), ptr(sc), sc.numel(), C.byref(gs),
                                               1 if defer else 0, stream_ptr()), "mmf_xattn_q_backward")
+        cfg.out_h = None
+        if dKV_h is not None:
+            _shadow_put(dKV, dKV_h)
         if defer:
             keep = (Y, M_u8, params, grads)         # the closure keeps every buffer it touches alive
 

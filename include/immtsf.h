@@ -56,6 +56,15 @@ typedef struct immtsf_fusion_cfg {
     int32_t grads_prezeroed;       /* backward only: every gradient buffer passed in `grads` is already zero (e.g. one
                                       memset of a flat gradient buffer per step), so split-K weight-gradient GEMMs skip
                                       their own zero-fill */
+    /* bf16 mode, optional (NULL = off): bf16 images of the activations that cross a block boundary, so that the consumer's
+     * GEMMs read them by LDS-DMA without a cast kernel of their own.  out_h: the call also writes its main activation
+     * output there (ttf forward: E_txt (B*T*d); mmf q backward: dKV (B*T*2d); mmf kv backward: dE_txt).  in_h: image of
+     * the call's main activation input, produced that way (mmf kv forward: E_txt; mmf kv backward: dKV; ttf backward:
+     * dE_txt).  aux_h: mmf kv backward only, the image of E_txt its forward was given as in_h.  Only honoured when the
+     * call runs the bf16 dataflow (precision 1, d a multiple of 16). */
+    const void* in_h;
+    const void* aux_h;
+    void* out_h;
 } immtsf_fusion_cfg;
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)

@@ -681,6 +681,8 @@ int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 
 
 }  // namespace
 
+void immtsf_gemm_note_grid(long threads) { g_last_grid_threads = threads; }
+
 extern int g_immtsf_ttcn_fused;      // ttcn.hip
 
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
@@ -745,6 +747,7 @@ extern "C" int immtsf_bf16_twin_enable(int on) { g_twins_on = on ? 1 : 0; return
 // to the bf16-in-memory kernel (gemm2.hip) when that kernel implements the argument combination; everything else (fp32
 // parity mode, batched form, row-mapped weight gradients, K or N below the 8-element chunk) runs on the kernel below,
 // which needs the fp32 operands.
+static int g_last_path = 0;       // for the timing tap: 1 = the kernel in this file, 2 = gemm2.hip (bf16 operands in memory)
 static int route_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
     if (precision == 1 && g.nbatch <= 1 && !g_force_old) {
         bool have = true;
@@ -757,8 +760,12 @@ static int route_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream
             }
             if (!p.Bh) have = false;
         }
-        if (have && immtsf_gemm2_supported(layout, g)) return immtsf_launch_gemm2(layout, g, stream);
+        if (have && immtsf_gemm2_supported(layout, g)) {
+            g_last_path = 2;
+            return immtsf_launch_gemm2(layout, g, stream);
+        }
     }
+    g_last_path = 1;
     for (int i = 0; i < g.nprob; ++i)
         if (!g.p[i].A || !g.p[i].B || (!g.p[i].C && !g.p[i].Ch) || (!g.p[i].C && g.accumulate))
             return IMMTSF_EUNSUPPORTED;      // bf16-only operands that gemm2 cannot take
@@ -778,7 +785,7 @@ int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t strea
     const int rc = route_gemm(layout, precision, g, stream);
     (void)hipEventRecord(r.e1, stream);
     r.meta[8] = (int)g_last_grid_threads;
-    r.meta[9] = 0;
+    r.meta[9] = g_last_path;
     ++g_tap_n;
     return rc;
 }

@@ -63,6 +63,7 @@ const void* immtsf_twin_lookup(const float* p, size_t min_elems);
 // (fp32, may be null) and/or p[i].Ch (bf16, may be null).  Returns IMMTSF_EUNSUPPORTED for argument combinations it
 // does not implement (batched form, TN with a row map, unaligned operands): the caller then uses immtsf_launch_gemm.
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g);
+void immtsf_gemm_note_grid(long threads);      // timing tap: threads of the launch just made
 int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream);
 
 // precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)

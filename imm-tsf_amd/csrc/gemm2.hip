@@ -345,6 +345,7 @@ template <int BM, int BN, int WM, int WN, int S, int WK = 1>
 int launch2(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
     dim3 grid(cdiv(Mmax, BM) * cdiv(g.N, BN), splits, g.nprob), block(WM * WN * WK * 64);
     if (grid.x == 0) return IMMTSF_OK;
+    immtsf_gemm_note_grid((long)grid.x * grid.y * grid.z * block.x);
     switch (layout) {
         case GEMM_NT: hipLaunchKernelGGL((gemm2_kernel<false, false, BM, BN, WM, WN, S, WK>), grid, block, 0, stream, g); break;
         case GEMM_NN:

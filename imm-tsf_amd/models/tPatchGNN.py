@@ -2,9 +2,10 @@
 (models/tPatchGNN.py:86-293), device-agnostic (the reference hard-codes .cuda() for the node vectors, :131-132).
 
 On the hot path is the time-aware patch encoder: LearnableTE (:176-180) + TTCN
-(:182-195), a masked softmax over each patch's irregular observations.  `patch_encoder = "hip"` routes it through
-the fused HIP kernel (immtsf.ops.ttcn_patch_encode); the per-patch transformer, the adaptive-graph GCN and the
-decoder MLP are tiny (hid_dim = 32) and run as stock PyTorch-ROCm ops.
+(:182-195), a masked softmax over each patch's irregular observations: the fused HIP kernel
+(immtsf.ops.ttcn_patch_encode).  The per-patch transformer layer, the adaptive-graph stage and the forecast decoder run
+on the HIP GEMM / LayerNorm / attention ops and the single-kernel graph-stage / decoder ops.  There is no eager or CPU
+formulation in this module: the plain-torch restatement used to check it lives in oracle/tpatchgnn_ref.py (tests only).
 """
 import math
 
@@ -116,39 +117,21 @@ class tPatchGNN(nn.Module):
             nn.Linear(enc_dim + args.te_dim, args.hid_dim), nn.ReLU(inplace=True),
             nn.Linear(args.hid_dim, args.hid_dim), nn.ReLU(inplace=True),
             nn.Linear(args.hid_dim, 1))
-        # "auto"/"hip": fused TE+TTCN HIP kernel; "torch": explicit opt-in to the eager formulation (CPU baseline, tests)
-        self.patch_encoder = getattr(args, "immtsf_patch_encoder", "auto")
 
     # ---- time-aware patch encoder ---------------------------------------------------------------
     def LearnableTE(self, tt):
-        if self.patch_encoder != "torch":      # one HIP kernel forward, two backward (vs. 4 + two K=1 library GEMMs)
-            from immtsf.ops import time2vec
-            return time2vec(tt.squeeze(-1), self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
-                            self.te_periodic.bias)
-        return torch.cat([self.te_scale(tt), torch.sin(self.te_periodic(tt))], -1)
-
-    def TTCN(self, X_int, mask_X):
-        """X_int (P,L,F), mask_X (P,L,1) -> (P, ttcn_dim): meta-filter pooling with a masked softmax over L."""
-        P, L, Fin = X_int.shape
-        filt = self.Filter_Generators(X_int)
-        filt = filt * mask_X + (1 - mask_X) * (-1e8)
-        sm = F.softmax(filt, dim=-2).view(P, L, self.ttcn_dim, Fin)
-        pooled = torch.einsum("plf,plkf->pk", X_int, sm)
-        return torch.relu(pooled + self.T_bias)
+        """[w0 t + b0 ; sin(W t + b)] (reference :176-180): one HIP kernel forward, two backward"""
+        from immtsf.ops import time2vec
+        return time2vec(tt.squeeze(-1), self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight, self.te_periodic.bias)
 
     def _encode_patches(self, x, tt, mask):
-        """x, tt, mask: (P, L) -> (P, hid_dim) patch embedding incl. the patch-non-empty flag."""
-        if self.patch_encoder != "torch":      # "auto"/"hip": the fused kernel (raises on CPU tensors: no silent fallback)
-            from immtsf.ops import ttcn_patch_encode
-            lin = self.Filter_Generators
-            return ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
-                                     self.te_periodic.bias, lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias,
-                                     lin[4].weight, lin[4].bias, self.T_bias, with_flag=True)     # flag column written in-kernel
-        else:
-            te = self.LearnableTE(tt.unsqueeze(-1))
-            h = self.TTCN(torch.cat([x.unsqueeze(-1), te], -1), mask.unsqueeze(-1))
-        flag = (mask.sum(dim=1, keepdim=True) > 0).to(h.dtype)
-        return torch.cat([h, flag], dim=-1)
+        """x, tt, mask: (P, L) -> (P, hid_dim) patch embedding incl. the patch-non-empty flag: the fused TE + TTCN kernel
+        (raises on CPU tensors: there is no fallback)"""
+        from immtsf.ops import ttcn_patch_encode
+        lin = self.Filter_Generators
+        return ttcn_patch_encode(x, tt, mask, self.te_scale.weight, self.te_scale.bias, self.te_periodic.weight,
+                                 self.te_periodic.bias, lin[0].weight, lin[0].bias, lin[2].weight, lin[2].bias,
+                                 lin[4].weight, lin[4].bias, self.T_bias, with_flag=True)     # flag column written in-kernel
 
     # ---- transformer + adaptive-graph GCN over (variables x patches) ------------------------------
     def _encoder_layer_hip(self, lyr, x):
@@ -171,16 +154,12 @@ class tPatchGNN(nn.Module):
 
     def _transformer(self, layer, x):
         enc = self.transformer_encoder[layer]
-        if self.patch_encoder == "torch":
-            return enc(x)
         for lyr in enc.layers:
             x = self._encoder_layer_hip(lyr, x)
         return x if enc.norm is None else enc.norm(x)
 
     def _mlp(self, seq, x):
-        """nn.Sequential of Linear/ReLU evaluated on the HIP GEMM (eager torch when patch_encoder == 'torch')"""
-        if self.patch_encoder == "torch":
-            return seq(x)
+        """nn.Sequential of Linear/ReLU evaluated on the HIP GEMM"""
         from immtsf.ops import linear, mlp
         mods = list(seq)
         if all(isinstance(m, nn.Linear if i % 2 == 0 else nn.ReLU) for i, m in enumerate(mods)) and len(mods) % 2 == 1:
@@ -194,7 +173,7 @@ class tPatchGNN(nn.Module):
         """node-vector gating -> adaptive adjacency -> graph convolution -> 1x1 mixing (reference :212-236), (B,N,M,D)"""
         B, N, M, D = x.shape
         gc = self.gconv[layer]
-        if self.patch_encoder != "torch" and not self.supports:
+        if not self.supports:
             from immtsf.ops import gcn_adaptive, gcn_adaptive_supported
             if gcn_adaptive_supported(N, D, self.nodevec_dim, gc.order):     # one cell's operands fit a CU's LDS
                 return gcn_adaptive(x, gc.order, self.nodevec1, self.nodevec2, self.nodevec_gate1[layer][0],
@@ -237,10 +216,9 @@ class tPatchGNN(nn.Module):
         # the reference repeats the prediction times over the N variables before embedding them (:283-285); the
         # embedding is the same for every variable, so embed once per window
         te = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1))                     # (B,1,Lp,te_dim)
-        if self.patch_encoder != "torch":
-            from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
-            if tpatch_decoder_supported(self.decoder, N, Lp, h.shape[-1], self.te_dim):
-                return tpatch_decoder(self.decoder, h, te.view(B, Lp, self.te_dim))          # (B,Lp,N), one kernel
+        from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
+        if tpatch_decoder_supported(self.decoder, N, Lp, h.shape[-1], self.te_dim):
+            return tpatch_decoder(self.decoder, h, te.view(B, Lp, self.te_dim))          # (B,Lp,N), one kernel
         te_pred = te.expand(B, N, Lp, self.te_dim)                                         # expand's backward sums over N
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)
         return self._mlp(self.decoder, h).squeeze(-1).permute(0, 2, 1)

@@ -24,11 +24,20 @@ def _rel(a, b, floor=1e-3):
     return float((a - b).abs().max() / max(float(b.abs().max()), floor))
 
 
+def _oracle_twin(m, args, dev):
+    """oracle/tpatchgnn_ref.py (the plain-torch restatement, pinned against the reference's goldens in
+    tests/test_oracle_golden.py) with the product module's weights, on the same device: the eager comparator"""
+    from oracle.tpatchgnn_ref import TPatchGNNRef
+    ref = TPatchGNNRef(args).to(dev)
+    ref.load_state_dict(m.state_dict(), strict=True)
+    return ref
+
+
 def _golden_model(dev, encoder):
     from models.tPatchGNN import tPatchGNN
     z = np.load(os.path.join(GOLDEN, "model_tpatchgnn.npz"))
     args = types.SimpleNamespace(device=str(dev), hid_dim=8, C=3, npatch=2, nlayer=1, te_dim=4, n_heads=1, tf_layer=1,
-                                 node_dim=4, hop=1, outlayer="Linear", immtsf_patch_encoder=encoder)
+                                 node_dim=4, hop=1, outlayer="Linear")
     m = tPatchGNN(args).to(dev)
     m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}, strict=True)
     return m.eval(), z
@@ -55,10 +64,9 @@ def test_ttcn_vs_reference_golden():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("encoder", ["hip", "torch"])
-def test_tpatchgnn_forecasting_vs_reference_golden(encoder):
+def test_tpatchgnn_forecasting_vs_reference_golden():
     dev = _dev()
-    m, z = _golden_model(dev, encoder)
+    m, z = _golden_model(dev, "hip")
     out = m.forecasting(*[torch.from_numpy(z[k]).to(dev) for k in ("tp", "X", "tt", "mask")])
     assert out.shape == z["out"].shape
     assert _rel(out, torch.from_numpy(z["out"])) < 1e-4
@@ -78,9 +86,10 @@ def test_ttcn_benchmark_dims_vs_eager(L):
     dev = _dev()
     from models.tPatchGNN import tPatchGNN
     args = types.SimpleNamespace(device=str(dev), hid_dim=32, C=8, npatch=2, nlayer=1, te_dim=10, n_heads=1, tf_layer=1,
-                                 node_dim=10, hop=1, outlayer="Linear", immtsf_patch_encoder="hip")
+                                 node_dim=10, hop=1, outlayer="Linear")
     torch.manual_seed(0)
     m = tPatchGNN(args).to(dev)
+    ref = _oracle_twin(m, args, dev)
     g = torch.Generator().manual_seed(1)
     P = 64 * 8 * 2
     cnt = torch.randint(1, L + 1, (P, 1), generator=g)
@@ -89,17 +98,14 @@ def test_ttcn_benchmark_dims_vs_eager(L):
     x = torch.randn(P, L, generator=g).to(dev) * mask
     tt = torch.rand(P, L, generator=g).to(dev) * mask
     up = torch.randn(P, 32, generator=g).to(dev)
-    m.patch_encoder = "hip"
     h = m._encode_patches(x, tt, mask)
     (h * up).sum().backward()
     g_hip = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-    m.zero_grad()
-    m.patch_encoder = "torch"
-    h2 = m._encode_patches(x, tt, mask)
+    h2 = ref.encode_patches(x, tt, mask)
     (h2 * up).sum().backward()
     assert _rel(h, h2) < 1e-4
-    gmax = max(float(p.grad.abs().max()) for p in m.parameters() if p.grad is not None)
-    bad = {k: _rel(g_hip[k], p.grad, floor=1e-2 * gmax) for k, p in m.named_parameters() if p.grad is not None}
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    bad = {k: _rel(g_hip[k], p.grad, floor=1e-2 * gmax) for k, p in ref.named_parameters() if p.grad is not None}
     bad = {k: v for k, v in bad.items() if v > 3e-4}
     assert not bad, bad
 
@@ -139,8 +145,10 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
     from models.tPatchGNN import tPatchGNN
     torch.manual_seed(B * 100 + N)
     args = types.SimpleNamespace(device=str(dev), hid_dim=D, C=N, npatch=M, nlayer=1, te_dim=4, n_heads=1, tf_layer=1,
-                                 node_dim=nd, hop=hop, outlayer="Linear", immtsf_patch_encoder="hip")
+                                 node_dim=nd, hop=hop, outlayer="Linear")
     m = tPatchGNN(args).to(dev)
+    ref = _oracle_twin(m, args, dev)
+    rps = dict(ref.named_parameters())
     names = ["nodevec1", "nodevec2", "nodevec_gate1.0.0.weight", "nodevec_gate1.0.0.bias", "nodevec_gate2.0.0.weight",
              "nodevec_gate2.0.0.bias", "nodevec_linear1.0.weight", "nodevec_linear1.0.bias", "nodevec_linear2.0.weight",
              "nodevec_linear2.0.bias", "gconv.0.mlp.mlp.weight", "gconv.0.mlp.mlp.bias"]
@@ -149,12 +157,10 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
     up = torch.randn(B, N, M, D, device=dev)
     res = {}
     for mode in ("torch", "hip"):
-        m.patch_encoder = mode
-        m.zero_grad()
         xi = x.clone().requires_grad_(True)
-        out = m._graph_stage(0, xi)
+        out = m._graph_stage(0, xi) if mode == "hip" else ref.graph_stage(0, xi)
         (out * up).sum().backward()
-        res[mode] = (out.detach(), xi.grad.clone(), {n: ps[n].grad.clone() for n in names})
+        res[mode] = (out.detach(), xi.grad.clone(), {n: (ps if mode == "hip" else rps)[n].grad.clone() for n in names})
     assert _rel(res["hip"][0], res["torch"][0]) < 1e-4
     assert _rel(res["hip"][1], res["torch"][1]) < 2e-4
     gmax = max(float(g.abs().max()) for g in res["torch"][2].values())
@@ -172,9 +178,10 @@ def test_ttcn_on_chip_equals_streaming_bf16(L):
     from models.tPatchGNN import tPatchGNN
     lib = _lib.load()
     args = types.SimpleNamespace(device=str(dev), hid_dim=32, C=8, npatch=2, nlayer=1, te_dim=10, n_heads=1, tf_layer=1,
-                                 node_dim=10, hop=1, outlayer="Linear", immtsf_patch_encoder="hip")
+                                 node_dim=10, hop=1, outlayer="Linear")
     torch.manual_seed(0)
     m = tPatchGNN(args).to(dev)
+    ref = _oracle_twin(m, args, dev)
     g = torch.Generator().manual_seed(L)
     P = 64 * 8 * 2
     cnt = torch.randint(1, L + 1, (P, 1), generator=g)
@@ -188,11 +195,11 @@ def test_ttcn_on_chip_equals_streaming_bf16(L):
         for mode, cfgbits, prec, enc in (("fused", 0, "bf16", "hip"), ("stream", 0x8000, "bf16", "hip"), ("eager", 0, "fp32", "torch")):
             lib.immtsf_debug_gemm_config(cfgbits, 0)
             config.precision = prec
-            m.patch_encoder = enc
-            m.zero_grad()
-            h = m._encode_patches(x, tt, mask)
+            mod = m if enc == "hip" else ref
+            mod.zero_grad()
+            h = m._encode_patches(x, tt, mask) if enc == "hip" else ref.encode_patches(x, tt, mask)
             (h * up).sum().backward()
-            res[mode] = (h.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            res[mode] = (h.detach().clone(), {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None})
     finally:
         lib.immtsf_debug_gemm_config(0, 0)
         config.precision = "fp32"

@@ -164,3 +164,37 @@ def test_nan_guard():
     notes[0, 0, 0] = float("nan")
     with pytest.raises(ValueError):
         R.ttf_t2v_xattn(R.params_from_npz(z), notes, _t(z["tau"]), _t(z["t_hat"]), int(z["H"]))
+
+
+def test_tpatchgnn_oracle_vs_reference_golden():
+    """oracle/tpatchgnn_ref.py (the eager restatement the GPU tests and bench.py's cpu_baseline use) against the fixture
+    generated from the real reference's models/tPatchGNN.py: TE + TTCN in isolation and the whole `forecasting`, outputs
+    and the gradient of every parameter (tests/golden/make_golden.py:gen_tpatchgnn)."""
+    import types
+
+    from oracle.tpatchgnn_ref import TPatchGNNRef
+    z = _load("model_tpatchgnn")
+    args = types.SimpleNamespace(device="cpu", hid_dim=8, C=3, npatch=2, nlayer=1, te_dim=4, n_heads=1, tf_layer=1, node_dim=4,
+                                 hop=1, outlayer="Linear")
+    m = TPatchGNNRef(args)
+    m.load_state_dict({k[2:]: _t(z[k]) for k in z.files if k.startswith("p.")}, strict=True)
+    m.eval()
+    X, tt, mask, tp = (_t(z[k]) for k in ("X", "tt", "mask", "tp"))
+    B, M, L, N = X.shape
+    flat = lambda t: t.permute(0, 3, 1, 2).reshape(B * N * M, L)    # noqa: E731
+    h = m.encode_patches(flat(X), flat(tt), flat(mask))[:, :-1]
+    _close(h.detach(), z["ttcn_out"], 2e-5, "ttcn_out")
+    (h * _t(z["ttcn_upstream"])).sum().backward()
+    gmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("g_ttcn."))
+    n = 0
+    for k, p in m.named_parameters():
+        if f"g_ttcn.{k}" in z.files:
+            _close(p.grad, z[f"g_ttcn.{k}"], 1e-4, "g_ttcn." + k, floor=1e-2 * gmax)
+            n += 1
+    assert n == 11
+    m.zero_grad()
+    out = m.forecasting(tp, X, tt, mask)
+    _close(out.detach(), z["out"], 2e-5, "forecasting")
+    (out * _t(z["upstream"])).sum().backward()
+    for k, p in m.named_parameters():
+        _close(p.grad, z["g." + k], 1e-4, "g." + k)

@@ -378,39 +378,52 @@ def gemm_roofline(w, lib, args, k2=20):
                   f"path={'gemm2' if k[9] == 2 else 'gemm'} launches/step={r['launches']/k2:5.1f} avg_us={r['avg_us']:7.1f} "
                   f"us/step={r['total_ms']*1e3/k2:7.1f} TF={r['flops']/(r['avg_us']*1e-6)/1e12:7.2f}", file=sys.stderr)
     gemm_ms = sum(r["total_ms"] for r in rows) / k2
-    top = rows[0]
-    lay_i, Mm, Nn, Kk, nprob, path = top["key"][0], top["M"], top["N"], top["K"], top["key"][5], top["key"][9]
     bf16 = args.precision == "bf16"
-    shapes = {0: ((Mm, Kk), (Nn, Kk)), 1: ((Mm, Kk), (Kk, Nn)), 2: ((Kk, Mm), (Kk, Nn))}[lay_i]
-    Ab, Bb = torch.randn(*shapes[0], device=dev), torch.randn(*shapes[1], device=dev)
-    Cb = torch.empty(Mm, Nn, device=dev)
-    twin_b = None
-    if path == 2:       # bf16 operands in memory (LDS-DMA kernel): both operand images are bf16, the result fp32
-        Ah, Bh = Ab.bfloat16(), Bb.bfloat16()
 
-        def one():
-            for _ in range(nprob):
-                _lib.check(lib.immtsf_gemm_bf16(lay_i, _lib.ptr(Ah), Ah.shape[1], _lib.ptr(Bh), Bh.shape[1], _lib.ptr(Cb), Nn, None, Nn,
-                                                None, None, Mm, Nn, Kk, 1.0, 0, 0, None, 0, None, _lib.stream_ptr()), "gemm_bf16")
-        alg_bytes = 2 * Mm * Kk + 2 * Nn * Kk + 4 * Mm * Nn
-        operands = "A, B bf16 in HBM (LDS-DMA), C fp32"
-        kname = "gemm2_kernel"
-    else:
+    def retime(r):
+        """(launcher closure, algorithmic bytes, operand description, kernel name) of one tap row"""
+        lay_i, Mm, Nn, Kk, nprob, nbatch, path = r["key"][0], r["M"], r["N"], r["K"], r["key"][5], max(r["key"][6], 1), r["key"][9]
+        shapes = {0: ((Mm, Kk), (Nn, Kk)), 1: ((Mm, Kk), (Kk, Nn)), 2: ((Kk, Mm), (Kk, Nn))}[lay_i]
+        Ab, Bb = torch.randn(*shapes[0], device=dev), torch.randn(*shapes[1], device=dev)
+        Cb = torch.empty(Mm, Nn, device=dev)
+        reps = nprob * nbatch          # the batched / grouped problems of one launch are re-timed as that many plain launches
+        if path == 2:       # bf16 operands in memory (LDS-DMA kernel): both operand images are bf16, the result fp32
+            Ah, Bh = Ab.bfloat16(), Bb.bfloat16()
+
+            def one():
+                for _ in range(min(reps, 8)):
+                    _lib.check(lib.immtsf_gemm_bf16(lay_i, _lib.ptr(Ah), Ah.shape[1], _lib.ptr(Bh), Bh.shape[1], _lib.ptr(Cb), Nn, None, Nn,
+                                                    None, None, Mm, Nn, Kk, 1.0, 0, 0, None, 0, None, _lib.stream_ptr()), "gemm_bf16")
+            return one, min(reps, 8), 2 * Mm * Kk + 2 * Nn * Kk + 4 * Mm * Nn, "A, B bf16 in HBM (LDS-DMA), C fp32", "gemm2_kernel", None
+        twin = None
         # in the step the weight operand of a forward / data-gradient GEMM is read from FlatTrainer's bf16 twin: same here
-        if bf16 and lay_i != 2 and w.trainer.flat_twin is not None:
-            twin_b = Bb.to(torch.bfloat16).contiguous()
-            _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(Bb), _lib.ptr(twin_b), Bb.numel()), "bf16_twin_register")
+        if bf16 and lay_i != 2 and nbatch == 1 and w.trainer.flat_twin is not None:
+            twin = Bb.to(torch.bfloat16).contiguous()
+            _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(Bb), _lib.ptr(twin), Bb.numel()), "bf16_twin_register")
 
         def one():
-            for _ in range(nprob):
+            for _ in range(min(reps, 8)):
                 _lib.check(lib.immtsf_gemm(lay_i, 1 if bf16 else 0, _lib.ptr(Ab), Ab.shape[1], _lib.ptr(Bb), Bb.shape[1], _lib.ptr(Cb),
                                            Nn, None, Mm, Nn, Kk, 1.0, 0, 0, _lib.stream_ptr()), "gemm")
-        alg_bytes = 4 * Mm * Kk + (2 if twin_b is not None else 4) * Nn * Kk + 4 * Mm * Nn
-        operands = "A fp32, B " + ("bf16 twin of the weights" if twin_b is not None else "fp32") + ", C fp32"
-        kname = "gemm_kernel"
-    kernel_us = graph_kernel_us(one) / nprob
-    if twin_b is not None:
-        lib.immtsf_bf16_twin_unregister(_lib.ptr(Bb))
+        return (one, min(reps, 8), 4 * Mm * Kk + (2 if twin is not None else 4) * Nn * Kk + 4 * Mm * Nn,
+                "A fp32, B " + ("bf16 twin of the weights" if twin is not None else "fp32") + ", C fp32", "gemm_kernel", (Bb, twin))
+
+    # the eager tap's durations include launch latency, which ranks tiny batched launches far too high: the candidates (the
+    # five largest tap totals) are re-timed inside a hipGraph and ranked by kernel time x launches per step
+    best = None
+    for r in rows[:5]:
+        if r["flops"] <= 0:
+            continue
+        one, n_in, alg_bytes, operands, kname, tw = retime(r)
+        us = graph_kernel_us(one, reps=20, replays=5) / n_in
+        if tw is not None and tw[1] is not None:
+            lib.immtsf_bf16_twin_unregister(_lib.ptr(tw[0]))
+        per_launch = us * r["key"][5] * max(r["key"][6], 1)
+        tot = per_launch * r["launches"] / k2
+        if best is None or tot > best[0]:
+            best = (tot, r, us, alg_bytes, operands, kname)
+    _, top, kernel_us, alg_bytes, operands, kname = best
+    lay_i, Mm, Nn, Kk, nprob, path = top["key"][0], top["M"], top["N"], top["K"], top["key"][5], top["key"][9]
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
     ach = (top["flops"] / nprob / max(top["key"][6], 1)) / (kernel_us * 1e-6) / 1e12
     allfl = sum(r["flops"] * r["launches"] for r in rows) / sum(r["total_ms"] for r in rows) / 1e9

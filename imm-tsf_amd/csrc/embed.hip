@@ -1,0 +1,205 @@
+// Time-aware patch embedding and data embedding (a13) as ONE gather + skinny-product + positional
+// table + dropout kernel per direction -- no padded copy, no unfolded (rows, P, patch_len) tensor, no [x(l-1);x(l);x(l+1)]
+// concatenation, no separate add / dropout passes.
+//
+//   mode 0, PatchEmbedding (reference layers/Embed.py:165-190): x (R, L) rows (R = B * n_vars; PatchTST feeds the
+//       (value, mask, time)-interleaved series, models/PatchTST.py:100-105) -> ReplicationPad1d((0, pad)) ->
+//       unfold(size = K = patch_len, step = stride) -> Linear(K -> D, no bias) + pe[p] -> dropout:
+//           out[r, p, :] = drop( sum_k W[:, k] * x[r, min(p * stride + k, L - 1)] + pe[p, :] )
+//   mode 1, TokenEmbedding + PositionalEmbedding (reference :29-42, 109-126): x (R = B, L, c_in), circular 3-tap
+//       Conv1d(c_in -> D, no bias), weight (D, c_in, 3) read as (D, K = 3 c_in) with k = c * 3 + t:
+//           out[b, l, :] = drop( sum_{c,t} W[:, c, t] * x[b, (l + t - 1) mod L, c] + pe[l, :] )
+//
+// HBM-bound on the (R, P, D) output (PatchTST cfg3: 384 x 10 x 512 fp32 = 7.9 MB written once; the inputs are 36 KB of
+// weights, 20 KB of table and 147 KB of series).  Exact fp32 FMAs in both precision modes (K <= 64: an MFMA tile would
+// be mostly padding).  Forward: a workgroup per (row, chunk of patches), W transposed in LDS, one thread per output
+// column, stores coalesced along D.  Backward: dW by per-thread register accumulators over a slice of
+// the (row, patch) pairs, combined with one fp32 atomic per element and workgroup; dx (optional: the series are data in
+// every configured backbone) by a wave per (row, patch).
+#include "../../include/immtsf.h"
+#include "common.hpp"
+
+namespace {
+
+constexpr int EMB_KMAX = 64;
+
+struct EmbDims {
+    int mode, R, L, c_in, P, K, stride, D;
+};
+
+__device__ __forceinline__ int emb_src(const EmbDims& e, int p, int k) {      // offset of gathered element (p, k) inside row r's data
+    if (e.mode == 0) return min(p * e.stride + k, e.L - 1);
+    const int c = k / 3, t = k - 3 * c;
+    int l = p + t - 1;
+    l = l < 0 ? l + e.L : (l >= e.L ? l - e.L : l);
+    return l * e.c_in + c;
+}
+
+// grid (R, ceil(P / PT)); LDS: Wt[K][D] | g[PT][K]
+template <int PT>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ pe, float* __restrict__ out, DropCfg drop,
+                                                         uint64_t site) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Wt = lds;
+    float* g = lds + (size_t)e.K * e.D;
+    const int r = blockIdx.x, p0 = blockIdx.y * PT, tid = threadIdx.x;
+    for (int i = tid; i < e.K * e.D; i += 256) {        // W is (D, K): transpose into [k][d]
+        const int d = i / e.K, k = i - d * e.K;
+        Wt[k * e.D + d] = W[i];
+    }
+    const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
+    const float* xr = x + (size_t)r * row_elems;
+    const int np = min(PT, e.P - p0);
+    for (int i = tid; i < np * e.K; i += 256) {
+        const int pp = i / e.K, k = i - pp * e.K;
+        g[i] = xr[emb_src(e, p0 + pp, k)];
+    }
+    __syncthreads();
+    for (int pp = 0; pp < np; ++pp) {
+        const int p = p0 + pp;
+        const float* gp = g + pp * e.K;
+        for (int d = tid; d < e.D; d += 256) {
+            float a = pe[(size_t)p * e.D + d];
+            for (int k = 0; k < e.K; ++k) a = fmaf(Wt[k * e.D + d], gp[k], a);
+            const size_t o = ((size_t)r * e.P + p) * e.D + d;
+            out[o] = a * dropout_scale(drop, site, (uint64_t)o);
+        }
+    }
+}
+
+// dW[d, k] += sum over this workgroup's (row, patch) pairs of dout[r,p,d] * dropscale * g(r,p,k).  grid (NB); one thread per
+// output column d (D <= 512: two columns per thread at most); LDS: g[PB][K] per batch of PB pairs
+template <int DPT>
+__global__ __launch_bounds__(256) void embed_bwd_w_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ dout,
+                                                           float* __restrict__ dW, DropCfg drop, uint64_t site) {
+    constexpr int PB = 16;
+    __shared__ float g[PB * EMB_KMAX];
+    const int tid = threadIdx.x;
+    const long pairs = (long)e.R * e.P;
+    const long per = (pairs + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * per, q1 = min(pairs, q0 + per);
+    const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
+    float acc[DPT][EMB_KMAX];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j)
+#pragma unroll
+        for (int k = 0; k < EMB_KMAX; ++k) acc[j][k] = 0.f;
+    for (long qb = q0; qb < q1; qb += PB) {
+        const int nq = (int)min((long)PB, q1 - qb);
+        __syncthreads();
+        for (int i = tid; i < nq * e.K; i += 256) {
+            const int qq = i / e.K, k = i - qq * e.K;
+            const long q = qb + qq;
+            const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
+            g[qq * EMB_KMAX + k] = x[(size_t)r * row_elems + emb_src(e, p, k)];
+        }
+        __syncthreads();
+        for (int qq = 0; qq < nq; ++qq) {
+            const long q = qb + qq;
+#pragma unroll
+            for (int j = 0; j < DPT; ++j) {
+                const int d = tid + 256 * j;
+                if (d < e.D) {
+                    const size_t o = (size_t)q * e.D + d;
+                    const float dv = dout[o] * dropout_scale(drop, site, (uint64_t)o);
+#pragma unroll
+                    for (int k = 0; k < EMB_KMAX; ++k)
+                        if (k < e.K) acc[j][k] = fmaf(dv, g[qq * EMB_KMAX + k], acc[j][k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid + 256 * j;
+        if (d < e.D) {
+#pragma unroll
+            for (int k = 0; k < EMB_KMAX; ++k)
+                if (k < e.K) atomicAdd(dW + (size_t)d * e.K + k, acc[j][k]);
+        }
+    }
+}
+
+// dx: a wave per (row, patch): v[k] = sum_d dout[r,p,d] * dropscale * W[d,k], scattered onto the source positions
+__global__ __launch_bounds__(256) void embed_bwd_x_kernel(EmbDims e, const float* __restrict__ W, const float* __restrict__ dout,
+                                                           float* __restrict__ dx, DropCfg drop, uint64_t site) {
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= (long)e.R * e.P) return;
+    const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
+    const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
+    for (int k = 0; k < e.K; ++k) {
+        float a = 0.f;
+        for (int d = lane; d < e.D; d += 64) {
+            const size_t o = (size_t)q * e.D + d;
+            a = fmaf(dout[o] * dropout_scale(drop, site, (uint64_t)o), W[(size_t)d * e.K + k], a);
+        }
+        a = wave_sum(a);
+        if (lane == 0) atomicAdd(dx + (size_t)r * row_elems + emb_src(e, p, k), a);
+    }
+}
+
+DropCfg mk_drop2(float p, uint64_t seed, const uint64_t* seed_dev) {
+    DropCfg d;
+    d.seed = seed;
+    d.p = p > 0.f ? p : 0.f;
+    d.inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    d.seed_dev = seed_dev;
+    return d;
+}
+
+bool emb_bad(const EmbDims& e) {
+    if (e.R <= 0 || e.L <= 0 || e.P <= 0 || e.D <= 0 || e.K <= 0 || e.K > EMB_KMAX || e.D > 512) return true;
+    if (e.mode == 0) return e.stride <= 0;
+    if (e.mode == 1) return e.c_in <= 0 || e.K != 3 * e.c_in || e.P != e.L;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int immtsf_embed_forward(int32_t mode, const float* x, int32_t R, int32_t L, int32_t c_in, int32_t P, int32_t K, int32_t stride,
+                         int32_t D, const float* W, const float* pe, float* out, float p_drop, uint64_t seed, uint64_t site,
+                         const uint64_t* seed_step_dev, immtsf_stream_t stream) {
+    const EmbDims e{mode, R, L, c_in, P, K, stride, D};
+    if (!x || !W || !pe || !out) return IMMTSF_EINVAL;
+    if (emb_bad(e)) return IMMTSF_EUNSUPPORTED;
+    constexpr int PT = 16;
+    const size_t lds = ((size_t)K * D + (size_t)PT * K) * sizeof(float);
+    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
+    hipLaunchKernelGGL(embed_fwd_kernel<PT>, dim3(R, cdiv(P, PT)), dim3(256), lds, static_cast<hipStream_t>(stream), e, x, W, pe, out,
+                       mk_drop2(p_drop, seed, seed_step_dev), site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+/* dW (D, K) must read zero on entry unless dw_prezeroed == 0 (then it is zero-filled here); dx (same shape as x) may be NULL */
+int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, int32_t c_in, int32_t P, int32_t K, int32_t stride,
+                          int32_t D, const float* W, const float* dout, float* dW, int32_t dw_prezeroed, float* dx, float p_drop,
+                          uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, immtsf_stream_t stream) {
+    const EmbDims e{mode, R, L, c_in, P, K, stride, D};
+    if (!x || !W || !dout || !dW) return IMMTSF_EINVAL;
+    if (emb_bad(e)) return IMMTSF_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DropCfg drop = mk_drop2(p_drop, seed, seed_step_dev);
+    if (!dw_prezeroed) {
+        hipError_t er = hipMemsetAsync(dW, 0, (size_t)D * K * sizeof(float), s);
+        if (er != hipSuccess) return (int)er;
+    }
+    const long pairs = (long)R * P;
+    const int nb = (int)min((long)256, (pairs + 15) / 16);
+    if (D <= 256) hipLaunchKernelGGL(embed_bwd_w_kernel<1>, dim3(nb), dim3(256), 0, s, e, x, dout, dW, drop, site);
+    else hipLaunchKernelGGL(embed_bwd_w_kernel<2>, dim3(nb), dim3(256), 0, s, e, x, dout, dW, drop, site);
+    IMMTSF_LAUNCH_CHECK();
+    if (dx) {
+        const size_t n = (size_t)R * (mode == 0 ? (size_t)L : (size_t)L * c_in);
+        hipError_t er = hipMemsetAsync(dx, 0, n * sizeof(float), s);
+        if (er != hipSuccess) return (int)er;
+        hipLaunchKernelGGL(embed_bwd_x_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, e, W, dout, dx, drop, site);
+        IMMTSF_LAUNCH_CHECK();
+    }
+    return IMMTSF_OK;
+}
+
+}  // extern "C"

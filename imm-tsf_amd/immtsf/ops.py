@@ -935,6 +935,64 @@ class FullAttentionQKVFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
+class SharedKVAttentionFn(torch.autograd.Function):
+    """softmax(scale * q k^T) v where the keys / values are ONE set shared by the whole batch (TimeLLM's ReprogrammingLayer,
+    models/TimeLLM.py:43-61: the mapped word prototypes): q (B,L,H,E), k (S,H,E), v (S,H,E) -> (B,L,H,E).  Per head one MFMA
+    GEMM over all B*L query rows (batched over the heads through strides), the fused softmax + dropout row kernel, and one
+    GEMM back; the scores live as (H, B*L, S)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale, p_drop, training, seed, site, precision):
+        lib = _lib.load()
+        q, k, v = _c(q), _c(k), _c(v)
+        _need_gpu(q, k, v)
+        B, L, H, E = q.shape
+        S = k.shape[0]
+        R = B * L
+        dev = q.device
+        P = torch.empty(H, R, S, dtype=torch.float32, device=dev)
+        st = stream_ptr()
+        check(lib.immtsf_gemm_batched(0, precision, ptr(q), H * E, 0, E, ptr(k), H * E, 0, E, ptr(P), S, 0, R * S, 1, H, R, S, E,
+                                      float(scale), st), "q k^T")
+        p = float(p_drop) if training else 0.0
+        A = torch.empty_like(P) if p > 0 else P
+        cnt = config.dropout_counter_ptr(dev) if p > 0 else None
+        check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), 1, H, R, S, None, p, seed, site, 0, cnt, st), "softmax")
+        out = torch.empty(B, L, H, E, dtype=torch.float32, device=dev)
+        check(lib.immtsf_gemm_batched(1, precision, ptr(A), S, 0, R * S, ptr(v), H * E, 0, E, ptr(out), H * E, 0, E, 1, H, R, E, S,
+                                      1.0, st), "a v")
+        ctx.save_for_backward(q, k, v, P, A)
+        ctx.cfg = (scale, p, seed, site, precision, cnt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        q, k, v, P, A = ctx.saved_tensors
+        scale, p, seed, site, precision, cnt = ctx.cfg
+        B, L, H, E = q.shape
+        S, R = k.shape[0], B * L
+        dout = dout.contiguous()
+        dA = torch.empty_like(P)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        st = stream_ptr()
+        check(lib.immtsf_gemm_batched(0, precision, ptr(dout), H * E, 0, E, ptr(v), H * E, 0, E, ptr(dA), S, 0, R * S, 1, H, R, S, E,
+                                      1.0, st), "dA")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(A), S, 0, R * S, ptr(dout), H * E, 0, E, ptr(dv), H * E, 0, E, 1, H, S, E, R,
+                                      1.0, st), "dV")
+        check(lib.immtsf_softmax_rows_backward(ptr(dA), ptr(P), 1, H, R, S, p, seed, site, cnt, st), "softmax_bwd")
+        check(lib.immtsf_gemm_batched(1, precision, ptr(dA), S, 0, R * S, ptr(k), H * E, 0, E, ptr(dq), H * E, 0, E, 1, H, R, E, S,
+                                      float(scale), st), "dQ")
+        check(lib.immtsf_gemm_batched(2, precision, ptr(dA), S, 0, R * S, ptr(q), H * E, 0, E, ptr(dk), H * E, 0, E, 1, H, S, E, R,
+                                      float(scale), st), "dK")
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def shared_kv_attention(q, k, v, scale, p_drop=0.0, training=False, seed=0, site=16, precision=None):
+    return SharedKVAttentionFn.apply(q.float(), k.float(), v.float(), scale, p_drop, training, seed, site,
+                                     config.precision_code(precision))
+
+
 ATTN_SHORT_MAX = 8      # IMMTSF_ATTN_SHORT_MAX
 
 
@@ -980,6 +1038,68 @@ def full_attention_qkv(qkv, scale, p_drop=0.0, training=False, seed=0, site=16, 
 def full_attention(q, k, v, scale, p_drop=0.0, training=False, seed=0, site=16, causal=False, precision=None):
     return FullAttentionFn.apply(q.float(), k.float(), v.float(), scale, p_drop, training, seed, site, causal,
                                  config.precision_code(precision))
+
+
+# ------------------------------------------------------------------------------------------------ embeddings (a12 / a13)
+EMBED_KMAX, EMBED_DMAX = 64, 512      # csrc/embed.hip limits
+SITE_LAYER_BASE = 16                  # csrc/common.hpp: dropout sites of the layers/ modules
+
+
+class EmbedFn(torch.autograd.Function):
+    """immtsf_embed_forward/backward: mode 0 = replication pad + unfold + Linear(patch_len -> D) + pe + dropout on (R, L)
+    rows, mode 1 = circular 3-tap token convolution + pe + dropout on (B, L, c_in); W (D, K) resp. (D, c_in, 3)."""
+
+    @staticmethod
+    def forward(ctx, x, W, pe, mode, P, K, stride, p_drop, training, seed, site):
+        lib = _lib.load()
+        x, W, pe = _c(x), _c(W), _c(pe)
+        _need_gpu(x, W, pe)
+        if mode == 0:
+            R, L, c_in = x.shape[0], x.shape[1], 1
+        else:
+            R, L, c_in = x.shape
+        D = W.shape[0]
+        p = float(p_drop) if training else 0.0
+        cnt = config.dropout_counter_ptr(x.device) if p > 0 else None
+        out = torch.empty(R, P, D, dtype=torch.float32, device=x.device)
+        check(lib.immtsf_embed_forward(mode, ptr(x), R, L, c_in, P, K, stride, D, ptr(W), ptr(pe), ptr(out), p, seed, site, cnt,
+                                       stream_ptr()), "embed_forward")
+        ctx.save_for_backward(x, W)
+        ctx.cfg = (mode, R, L, c_in, P, K, stride, D, p, seed, site, cnt)
+        ctx.sink = getattr(W, "_immtsf_grad_sink", None) if getattr(W, "_immtsf_grad_prezeroed", False) else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        mode, R, L, c_in, P, K, stride, D, p, seed, site, cnt = ctx.cfg
+        dW = ctx.sink if ctx.sink is not None else torch.empty_like(W)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib.immtsf_embed_backward(mode, ptr(x), R, L, c_in, P, K, stride, D, ptr(W), ptr(dout.contiguous()), ptr(dW),
+                                        1 if ctx.sink is not None else 0, ptr(dx), p, seed, site, cnt, stream_ptr()), "embed_backward")
+        return (dx, None if ctx.sink is not None else dW) + (None,) * 9
+
+
+def embed_supported(K, D):
+    return K <= EMBED_KMAX and D <= EMBED_DMAX
+
+
+def patch_embed(x, W, pe, patch_len, stride, pad, p_drop=0.0, training=False, site=None):
+    """x (B, n_vars, L) -> (B * n_vars, P, D): PatchEmbedding (layers/Embed.py:165-190) in one kernel"""
+    B, n_vars, L = x.shape
+    P = (L + pad - patch_len) // stride + 1
+    p = float(p_drop) if training else 0.0
+    return EmbedFn.apply(x.float().reshape(B * n_vars, L), W, pe.reshape(-1, pe.shape[-1]), 0, P, patch_len, stride, p, training,
+                         config.next_seed() if p > 0 else 0, SITE_LAYER_BASE + 40 if site is None else site)
+
+
+def token_embed(x, W, pe, p_drop=0.0, training=False, site=None):
+    """x (B, L, c_in) -> (B, L, D): TokenEmbedding + PositionalEmbedding + dropout of DataEmbedding in one kernel"""
+    B, L, c_in = x.shape
+    p = float(p_drop) if training else 0.0
+    return EmbedFn.apply(x.float(), W, pe.reshape(-1, pe.shape[-1]), 1, L, 3 * c_in, 1, p, training,
+                         config.next_seed() if p > 0 else 0, SITE_LAYER_BASE + 41 if site is None else site)
 
 
 # ------------------------------------------------------------------------------------------------ loss

@@ -1,14 +1,17 @@
 """Embeddings used by PatchTST / TimesNet / TimeLLM (reference layers/Embed.py:8-42, 109-126, 165-190).
 
-The contractions (patch -> d_model skinny GEMM, 3-tap circular token convolution as one GEMM over [x(l-1);x(l);x(l+1)])
-run on the HIP MFMA GEMM; the gathers (replication pad + unfold, circular roll) are index ops.  Fixed sinusoid tables
-are buffers with the reference's names so state_dict keys match."""
+PatchEmbedding (replication pad -> unfold -> Linear(patch_len -> d_model) -> + positional table -> dropout) and
+DataEmbedding without time marks (circular 3-tap token convolution -> + positional table -> dropout) each run as ONE HIP
+kernel per direction (immtsf.ops.patch_embed / token_embed, csrc/embed.hip): no padded copy, no unfolded tensor, no
+separate add / dropout passes.  Shapes outside the kernel's limits (patch_len or 3 c_in > 64, d_model > 512) and
+DataEmbedding with time marks use the HIP GEMM on gathered taps.  Fixed sinusoid tables are buffers with the
+reference's names so state_dict keys match."""
 import math
 
 import torch
 import torch.nn as nn
 
-from immtsf.ops import linear
+from immtsf.ops import embed_supported, linear, patch_embed, token_embed
 
 
 def _sinusoid(n, d_model):
@@ -90,6 +93,9 @@ class DataEmbedding(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
 
     def forward(self, x, x_mark=None):
+        conv = self.value_embedding.tokenConv
+        if x_mark is None and x.is_cuda and embed_supported(3 * conv.in_channels, conv.out_channels):
+            return token_embed(x, conv.weight, self.position_embedding.pe, self.dropout.p, self.training)
         y = self.value_embedding(x) + self.position_embedding(x)
         if x_mark is not None:
             y = y + self.temporal_embedding(x_mark)
@@ -108,6 +114,10 @@ class PatchEmbedding(nn.Module):
 
     def forward(self, x):                       # x (B, n_vars, L) -> ((B*n_vars, P, d_model), n_vars)
         n_vars = x.shape[1]
+        W = self.value_embedding.weight
+        if x.is_cuda and embed_supported(self.patch_len, W.shape[0]):
+            pad = self.padding_patch_layer.padding[1]
+            return patch_embed(x, W, self.position_embedding.pe, self.patch_len, self.stride, pad, self.dropout.p, self.training), n_vars
         x = self.padding_patch_layer(x).unfold(dimension=-1, size=self.patch_len, step=self.stride)
         x = torch.reshape(x, (x.shape[0] * x.shape[1], x.shape[2], x.shape[3]))
         y = linear(x, self.value_embedding.weight, None)

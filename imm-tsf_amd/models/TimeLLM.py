@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf.ops import linear
+from immtsf import config
+from immtsf.ops import linear, shared_kv_attention
 from layers.Embed import PatchEmbedding
 from models._common import masked_instance_norm
 
@@ -48,10 +49,11 @@ class ReprogrammingLayer(nn.Module):
         q = linear(Q, self.query_projection.weight, self.query_projection.bias).view(Bm, Lq, H, -1)
         k = linear(K_src, self.key_projection.weight, self.key_projection.bias).view(Vs, H, -1)
         v = linear(V_src, self.value_projection.weight, self.value_projection.bias).view(Vs, H, -1)
-        scale = 1.0 / sqrt(K_src.size(-1) // H)
-        A = self.dropout(torch.softmax(scale * torch.einsum("blhe,she->bhls", q, k), dim=-1))
-        out = torch.einsum("bhls,she->blhe", A, v).reshape(Bm, Lq, -1)
-        return linear(out, self.out_projection.weight, self.out_projection.bias)
+        scale = 1.0 / sqrt(K_src.size(-1) // H)          # d_llm / H, as the reference has it (:51)
+        p = float(self.dropout.p)
+        training = self.training and p > 0.0
+        out = shared_kv_attention(q, k, v, scale, p, training, config.next_seed() if training else 0, 16 + 1023)
+        return linear(out.reshape(Bm, Lq, -1), self.out_projection.weight, self.out_projection.bias)
 
 
 class _ByteTokenizer:

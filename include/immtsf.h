@@ -426,6 +426,22 @@ int immtsf_side_stream_enabled(void);
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);
 int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);
 
+/* ---- a12 / a13: the time-aware patch embedding and the data embedding as one gather + skinny product + positional
+ * table + dropout kernel per direction (csrc/embed.hip), exact fp32.
+ *   mode 0 = PatchEmbedding.forward (layers/Embed.py:165-190): x (R, L) rows, R = B * n_vars;
+ *            out[r,p,:] = drop(sum_k W[:,k] x[r, min(p*stride + k, L-1)] + pe[p,:]), W (D, K = patch_len), P patches.
+ *   mode 1 = TokenEmbedding + PositionalEmbedding of DataEmbedding (layers/Embed.py:29-42,109-126): x (R = B, L, c_in);
+ *            out[b,l,:] = drop(sum_{c,t} W[:,c,t] x[b,(l+t-1) mod L,c] + pe[l,:]), W (D, c_in, 3) = (D, K = 3 c_in), P = L.
+ * pe: the (>= P, D) sinusoid table.  Dropout: Philox keyed by (seed [+ *seed_step_dev], site, element index), p_drop = 0
+ * off.  backward: dW (D, K) accumulates by atomics onto zeros (dw_prezeroed != 0: the caller zero-filled it; else the
+ * call does); dx (shape of x) is optional (NULL: the series are data).  IMMTSF_EUNSUPPORTED: K > 64 or D > 512. */
+int immtsf_embed_forward(int32_t mode, const float* x, int32_t R, int32_t L, int32_t c_in, int32_t P, int32_t K, int32_t stride,
+                         int32_t D, const float* W, const float* pe, float* out, float p_drop, uint64_t seed, uint64_t site,
+                         const uint64_t* seed_step_dev, immtsf_stream_t stream);
+int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, int32_t c_in, int32_t P, int32_t K, int32_t stride,
+                          int32_t D, const float* W, const float* dout, float* dW, int32_t dw_prezeroed, float* dx, float p_drop,
+                          uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, immtsf_stream_t stream);
+
 /* The bf16-in-memory GEMM the bf16 mode runs its projections on (csrc/gemm2.hip): A and B are bf16 in HBM and reach
  * LDS by LDS-DMA through a multi-stage ring; results as fp32 (C, may be NULL) and/or bf16 (Ch, may be NULL; row pitch
  * ldch).  layout 0 NT: C = A(M,K) B(N,K)^T (a linear layer's forward, layers/*.py nn.Linear call sites and

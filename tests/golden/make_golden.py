@@ -386,9 +386,78 @@ def gen_models():
         save(f"model_{name.lower()}", **arrs)
 
 
+def gen_layers_big():
+    """PatchTST-size layers (d_model 512, 2 heads, d_ff 2048, 10 patches, 48 rows; patch_len 18, stride 9 on 96-step
+    interleaved rows) and TimeLLM's ReprogrammingLayer, weights from tests/golden/seeded.py.  Stored: the first 8 rows of
+    the output and of the input gradient, and a fingerprint (4 random projections + norm) of every parameter gradient."""
+    _install_shims()
+    sys.path.insert(0, OUT)
+    import seeded
+    SA = importlib.import_module("layers.SelfAttention_Family")
+    EM = importlib.import_module("layers.Embed")
+    TE = importlib.import_module("layers.Transformer_EncDec")
+    R, P, D, H, DFF = 48, 10, 512, 2, 2048
+
+    def run(mod, x, tag, seed, post=lambda o: o):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items() if v.dtype.is_floating_point and "pe" not in k.split(".")[-1]}
+        sd = seeded.state_like(shapes, seed)
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        xx = torch.from_numpy(x).clone().requires_grad_(True)
+        o = post(mod(xx))
+        up = torch.from_numpy(seeded.rand(tuple(o.shape), seed + 1000))
+        (o * up).sum().backward()
+        arrs = dict(out8=_np(o)[:8], out_norm=np.float64(np.linalg.norm(_np(o).astype(np.float64))),
+                    gx8=_np(xx.grad)[:8], gx_norm=np.float64(np.linalg.norm(_np(xx.grad).astype(np.float64))))
+        for i, (k, p_) in enumerate(sorted(mod.named_parameters())):
+            arrs["probe." + k] = seeded.probes(_np(p_.grad), seed + 2000 + i)
+        save(tag, **arrs)
+
+    x = seeded.rand((R, P, D), 501)
+    al = SA.AttentionLayer(SA.FullAttention(False, attention_dropout=0.0), D, H)
+    run(_Wrap3(al), x, "layer_big_attention_layer", 510)
+    el = TE.EncoderLayer(SA.AttentionLayer(SA.FullAttention(False, attention_dropout=0.0), D, H), D, DFF, dropout=0.0, activation="gelu")
+    run(el, x, "layer_big_encoder_layer", 520, post=lambda o: o[0])
+    pe = EM.PatchEmbedding(D, 18, 9, 9, 0.0)
+    xs = seeded.rand((8, 6, 96), 530)
+    run(pe, xs, "layer_big_patch_embedding", 531, post=lambda o: o[0])
+    TL = importlib.import_module("models.TimeLLM")
+    rl = TL.ReprogrammingLayer(16, 8, d_llm=768, attention_dropout=0.0)
+    src = torch.from_numpy(seeded.rand((1000, 768), 541))
+    run(_WrapR(rl, src), seeded.rand((48, 5, 16), 540), "layer_big_reprogramming", 542)
+
+
+class _Wrap3(torch.nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return self.m(x, x, x, None)[0]
+
+    def state_dict(self, *a, **k):
+        return self.m.state_dict(*a, **k)
+
+    def load_state_dict(self, sd, strict=True):
+        return self.m.load_state_dict(sd, strict)
+
+    def named_parameters(self, *a, **k):
+        return self.m.named_parameters(*a, **k)
+
+
+class _WrapR(_Wrap3):
+    def __init__(self, m, src):
+        super().__init__(m)
+        self.src = src
+
+    def forward(self, x):
+        return self.m(x, self.src, self.src)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["fusion", "loss", "layers", "tpatchgnn", "models"]
+    which = sys.argv[1:] or ["fusion", "loss", "layers", "layers_big", "tpatchgnn", "models"]
+    if "layers_big" in which:
+        gen_layers_big()
     if "fusion" in which:
         gen_fusion(_ref_modules())
     if "loss" in which:

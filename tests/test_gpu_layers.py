@@ -229,3 +229,110 @@ def test_short_attention_causal_and_dropout_equal_the_gemm_path():
         (o1 * up).sum().backward()
         (o2 * up).sum().backward()
         assert _rel(o2, o1.detach().cpu()) < 1e-5 and _rel(b.grad, a.grad.cpu()) < 1e-5, (causal, p)
+
+
+# ---- PatchTST-size layers (d_model 512, 2 heads, d_ff 2048, 10 patches, 48 rows) and TimeLLM's ReprogrammingLayer against
+# fixtures generated from the real reference (tests/golden/make_golden.py:gen_layers_big; weights regenerated from
+# tests/golden/seeded.py), fp32 mode at 1e-4 / 2e-4 and bf16 mode at 3e-2 / 4e-2 (relative L2 for bf16) ------------------
+def _big(tag):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_golden import _big_case
+    return _big_case(tag)
+
+
+def _build_big(tag, dev):
+    from layers.Embed import PatchEmbedding
+    from layers.SelfAttention_Family import AttentionLayer, FullAttention
+    from layers.Transformer_EncDec import EncoderLayer
+    seeded, x, sd, seed = _big(tag)
+    D, H, DFF = 512, 2, 2048
+    if tag == "attention_layer":
+        m = AttentionLayer(FullAttention(False, attention_dropout=0.0), D, H)
+        run = lambda xx: m(xx, xx, xx, None)[0]      # noqa: E731
+    elif tag == "encoder_layer":
+        m = EncoderLayer(AttentionLayer(FullAttention(False, attention_dropout=0.0), D, H), D, DFF, dropout=0.0, activation="gelu")
+        run = lambda xx: m(xx)[0]      # noqa: E731
+    elif tag == "patch_embedding":
+        m = PatchEmbedding(D, 18, 9, 9, 0.0)
+        run = lambda xx: m(xx)[0]      # noqa: E731
+    else:
+        from models.TimeLLM import ReprogrammingLayer
+        m = ReprogrammingLayer(16, 8, d_llm=768, attention_dropout=0.0)
+        src = torch.from_numpy(seeded.rand((1000, 768), 541)).to(dev)
+        run = lambda xx: m(xx, src, src)      # noqa: E731
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    return m.to(dev).train(), run, seeded, x, seed
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("tag", ["attention_layer", "encoder_layer", "patch_embedding", "reprogramming"])
+def test_layers_patchtst_size_vs_reference_golden(tag, precision):
+    dev = _dev()
+    from immtsf import config
+    z = _z("layer_big_" + tag)
+    config.precision = precision
+    try:
+        m, run, seeded, x, seed = _build_big(tag, dev)
+        xx = torch.from_numpy(x).to(dev).requires_grad_(True)
+        o = run(xx)
+        up = torch.from_numpy(seeded.rand(tuple(o.shape), seed + 1000)).to(dev)
+        (o * up).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        config.precision = "fp32"
+    out, gx = o.detach().cpu().numpy().astype(np.float64), xx.grad.cpu().numpy().astype(np.float64)
+    grads = {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+    if precision == "fp32":
+        tol_o, tol_g = 1e-4, 2e-4
+        assert np.abs(out[:8] - z["out8"]).max() <= tol_o * np.abs(z["out8"]).max()
+        assert np.abs(gx[:8] - z["gx8"]).max() <= tol_g * np.abs(z["gx8"]).max()
+    else:
+        tol_o, tol_g = 3e-2, 4e-2
+        assert np.linalg.norm(out[:8] - z["out8"]) <= tol_o * np.linalg.norm(z["out8"])
+        assert np.linalg.norm(gx[:8] - z["gx8"]) <= tol_g * np.linalg.norm(z["gx8"])
+    assert abs(np.linalg.norm(out) / float(z["out_norm"]) - 1.0) < tol_o
+    assert abs(np.linalg.norm(gx) / float(z["gx_norm"]) - 1.0) < tol_g
+    gmax = max(float(z["probe." + k][-1]) for k in grads)
+    for i, k in enumerate(sorted(grads)):
+        want = z["probe." + k]
+        got = seeded.probes(grads[k], seed + 2000 + i)
+        # a random projection of a gradient with relative error eps deviates by ~ eps * norm
+        assert np.abs(got - want).max() <= 4 * tol_g * max(want[-1], 1e-2 * gmax), (tag, precision, k, got, want)
+
+
+def test_patch_and_token_embedding_dropout_and_input_gradient():
+    """the one-kernel embeddings: the input gradient (not needed by any configured backbone, but part of the op) equals
+    autograd through the eager formulation, and with dropout on the kept fraction matches p and the output is the
+    dropout-free output times the exported mask / (1 - p)"""
+    dev = _dev()
+    from immtsf import config, ops
+    from oracle import layers_ref as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 4, 50, generator=g).to(dev).requires_grad_(True)
+    W = (torch.randn(96, 12, generator=g) * 0.3).to(dev).requires_grad_(True)
+    pe = L.sinusoid(200, 96, dev)
+    o = ops.patch_embed(x, W, pe, 12, 5, 5)
+    ref = L.patch_embedding(W.detach().clone().requires_grad_(True), x.detach().clone().requires_grad_(True), 12, 5, 5)
+    up = torch.randn(o.shape, generator=g).to(dev)
+    (o * up).sum().backward()
+    xr, wr = x.detach().clone().requires_grad_(True), W.detach().clone().requires_grad_(True)
+    (L.patch_embedding(wr, xr, 12, 5, 5) * up).sum().backward()
+    assert _rel(o, ref.detach().cpu()) < 1e-5 and _rel(x.grad, xr.grad.cpu()) < 1e-4 and _rel(W.grad, wr.grad.cpu()) < 1e-4
+    xt = torch.randn(3, 20, 7, generator=g).to(dev).requires_grad_(True)
+    Wt = (torch.randn(32, 7, 3, generator=g) * 0.3).to(dev).requires_grad_(True)
+    pe2 = L.sinusoid(64, 32, dev)
+    o = ops.token_embed(xt, Wt, pe2)
+    up = torch.randn(o.shape, generator=g).to(dev)
+    (o * up).sum().backward()
+    xr, wr = xt.detach().clone().requires_grad_(True), Wt.detach().clone().requires_grad_(True)
+    r = L.data_embedding(wr, xr)
+    (r * up).sum().backward()
+    assert _rel(o, r.detach().cpu()) < 1e-5 and _rel(xt.grad, xr.grad.cpu()) < 1e-4 and _rel(Wt.grad, wr.grad.cpu()) < 1e-4
+    config.manual_seed(9)
+    od = ops.patch_embed(x.detach(), W.detach(), pe, 12, 5, 5, p_drop=0.25, training=True)
+    o0 = ops.patch_embed(x.detach(), W.detach(), pe, 12, 5, 5)
+    kept = (od != 0)
+    frac = float(kept.float().mean())
+    assert abs(frac - 0.75) < 0.02, frac
+    assert _rel(od[kept], (o0[kept] / 0.75).cpu()) < 1e-5

@@ -198,3 +198,113 @@ def test_tpatchgnn_oracle_vs_reference_golden():
     (out * _t(z["upstream"])).sum().backward()
     for k, p in m.named_parameters():
         _close(p.grad, z["g." + k], 1e-4, "g." + k)
+
+
+# ---- oracle/layers_ref.py against the reference's layer fixtures ----------------------------------------------------
+def _layer_params(z):
+    return {k[2:]: _t(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("p.")}
+
+
+def test_layers_oracle_toy_goldens():
+    from oracle import layers_ref as L
+    z = _load("layer_full_attention")
+    q, k, v = (_t(z[n]).clone().requires_grad_(True) for n in ("q", "k", "v"))
+    o = L.full_attention(q, k, v)
+    _close(o.detach(), z["out"], 2e-5, "full_attention")
+    (o * _t(z["upstream"])).sum().backward()
+    for t, n in ((q, "gq"), (k, "gk"), (v, "gv")):
+        _close(t.grad, z[n], 1e-4, n)
+    z = _load("layer_attention_layer")
+    p = _layer_params(z)
+    x = _t(z["x"]).clone().requires_grad_(True)
+    o = L.attention_layer(p, "", x, x, x, int(z["H"]))
+    _close(o.detach(), z["out"], 2e-5, "attention_layer")
+    (o * _t(z["upstream"])).sum().backward()
+    _close(x.grad, z["gx"], 1e-4, "attention_layer gx")
+    for kname, t in p.items():
+        _close(t.grad, z["g." + kname], 1e-4, kname)
+    z = _load("layer_encoder")
+    p = _layer_params(z)
+    x = _t(z["x"]).clone().requires_grad_(True)
+    o = L.encoder(p, x, int(z["H"]), 2)
+    _close(o.detach(), z["out"], 2e-5, "encoder")
+    (o * _t(z["upstream"])).sum().backward()
+    _close(x.grad, z["gx"], 1e-4, "encoder gx")
+    for kname, t in p.items():
+        _close(t.grad, z["g." + kname], 1e-4, kname)
+    z = _load("layer_patch_embedding")
+    w = _t(z["w"]).clone().requires_grad_(True)
+    x = _t(z["x"]).clone().requires_grad_(True)
+    o = L.patch_embedding(w, x, int(z["patch_len"]), int(z["stride"]), int(z["stride"]))
+    _close(o.detach(), z["out"], 2e-5, "patch_embedding")
+    (o * _t(z["upstream"])).sum().backward()
+    _close(x.grad, z["gx"], 1e-4, "patch gx")
+    _close(w.grad, z["gw"], 1e-4, "patch gw")
+    z = _load("layer_data_embedding")
+    w = _t(z["w"]).clone().requires_grad_(True)
+    x = _t(z["x"]).clone().requires_grad_(True)
+    o = L.data_embedding(w, x)
+    _close(o.detach(), z["out"], 2e-5, "data_embedding")
+    (o * _t(z["upstream"])).sum().backward()
+    _close(x.grad, z["gx"], 1e-4, "data gx")
+    _close(w.grad, z["gw"], 1e-4, "data gw")
+
+
+def _big_case(tag):
+    """inputs / weights of a PatchTST-size layer case, regenerated from tests/golden/seeded.py exactly as make_golden.py did"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import seeded
+    D, H, DFF = 512, 2, 2048
+    att = {f"{n}_projection.{w}": ((D, D) if w == "weight" else (D,)) for n in ("query", "key", "value", "out") for w in ("weight", "bias")}
+    if tag == "attention_layer":
+        return seeded, seeded.rand((48, 10, D), 501), seeded.state_like(att, 510), 510
+    if tag == "encoder_layer":
+        shapes = {"attention." + k: v for k, v in att.items()}
+        shapes.update({"conv1.weight": (DFF, D, 1), "conv1.bias": (DFF,), "conv2.weight": (D, DFF, 1), "conv2.bias": (D,),
+                       "norm1.weight": (D,), "norm1.bias": (D,), "norm2.weight": (D,), "norm2.bias": (D,)})
+        return seeded, seeded.rand((48, 10, D), 501), seeded.state_like(shapes, 520), 520
+    if tag == "patch_embedding":
+        return seeded, seeded.rand((8, 6, 96), 530), seeded.state_like({"value_embedding.weight": (D, 18)}, 531), 531
+    if tag == "reprogramming":
+        # d_keys = d_model // n_heads = 2: the projections are 16 wide (models/TimeLLM.py:36-41)
+        shapes = {"query_projection.weight": (16, 16), "query_projection.bias": (16,), "key_projection.weight": (16, 768),
+                  "key_projection.bias": (16,), "value_projection.weight": (16, 768), "value_projection.bias": (16,),
+                  "out_projection.weight": (768, 16), "out_projection.bias": (768,)}
+        return seeded, seeded.rand((48, 5, 16), 540), seeded.state_like(shapes, 542), 542
+    raise KeyError(tag)
+
+
+def _check_big(tag, out, gx, grads, z, seeded, seed, tol_o, tol_g):
+    _close(out[:8], z["out8"], tol_o, tag + " out8")
+    assert abs(float(np.linalg.norm(np.asarray(out, np.float64))) / float(z["out_norm"]) - 1.0) < tol_o, tag + " out norm"
+    _close(gx[:8], z["gx8"], tol_g, tag + " gx8", floor=1e-3 * float(np.abs(z["gx8"]).max()))
+    assert abs(float(np.linalg.norm(np.asarray(gx, np.float64))) / float(z["gx_norm"]) - 1.0) < tol_g, tag + " gx norm"
+    # gradients that are zero in exact arithmetic (the key bias: a softmax shift) are rounding noise on both sides: judge
+    # every fingerprint against the largest gradient norm of the module, not its own
+    gmax = max(float(z["probe." + k][-1]) for k in grads)
+    for i, k in enumerate(sorted(grads)):
+        want = z["probe." + k]
+        got = seeded.probes(grads[k], seed + 2000 + i)
+        assert np.abs(got - want).max() <= tol_g * max(want[-1], 1e-2 * gmax) * 4, (tag, k, got, want)     # |projection| ~ norm
+
+
+@pytest.mark.parametrize("tag", ["attention_layer", "encoder_layer", "patch_embedding", "reprogramming"])
+def test_layers_oracle_patchtst_size(tag):
+    from oracle import layers_ref as L
+    seeded, x, sd, seed = _big_case(tag)
+    z = _load("layer_big_" + tag)
+    p = {k: _t(v).clone().requires_grad_(True) for k, v in sd.items()}
+    xx = _t(x).clone().requires_grad_(True)
+    if tag == "attention_layer":
+        o = L.attention_layer(p, "", xx, xx, xx, 2)
+    elif tag == "encoder_layer":
+        o = L.encoder_layer(p, "", xx, 2, "gelu")
+    elif tag == "patch_embedding":
+        o = L.patch_embedding(p["value_embedding.weight"], xx, 18, 9, 9)
+    else:
+        src = _t(seeded.rand((1000, 768), 541))
+        o = L.reprogramming_layer(p, xx, src, src, 8)
+    up = _t(seeded.rand(tuple(o.shape), seed + 1000))
+    (o * up).sum().backward()
+    _check_big(tag, o.detach().numpy(), xx.grad.numpy(), {k: v.grad.numpy() for k, v in p.items()}, z, seeded, seed, 5e-5, 2e-4)

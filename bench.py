@@ -246,7 +246,8 @@ def cpu_baseline(batch, warmup=3, steps=10, budget_s=45.0):
 class Workload:
     """one BASELINE configuration on one device: models, trainer, batch, the loss closure of a step"""
 
-    def __init__(self, cfg, dev, windows, precision, group=None, wire="fp32", device_step=True, seed_off=0, overlap=True):
+    def __init__(self, cfg, dev, windows, precision, group=None, wire="fp32", device_step=True, seed_off=0, overlap=True,
+                 shard_optimizer=False, param_wire="fp32"):
         from fusions.FusionModel import FusionModel
         from fusions.load_llm import register_d_model
         from immtsf import config
@@ -270,7 +271,8 @@ class Workload:
         sinks = (0, 1, 2) if c["backbone"] == "tPatchGNN" else (0, 1)
         self.trainer = FlatTrainer([list(self.fusion.mmf.parameters()), list(self.fusion.ttf.parameters()), backbone_params],
                                    lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_exclude=excl,
-                                   overlap=True, device_step=device_step and self.graphable, grad_wire=wire)
+                                   overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
+                                   shard_optimizer=shard_optimizer, param_wire=param_wire)
         big = c["N_MAX"] * c["d_m"] * windows > (1 << 28)
         if big:
             self.batch, self.sum_n = synth_batch(100 + seed_off, windows, cfg, device=dev)
@@ -549,6 +551,13 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="N>1: element type of the gradient all-reduce; auto = bf16 in bf16 mode (half the xGMI bytes), fp32 otherwise")
+    ap.add_argument("--no-shard-optimizer", action="store_true",
+                    help="N>1: all-reduce the flat gradient and run clip + Adam replicated on every rank, instead of reduce-scatter -> "
+                         "clip + Adam on the rank's 1/N shard -> all-gather (FlatTrainer(shard_optimizer=True), the default)")
+    ap.add_argument("--param-wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="sharded optimizer: what the all-gather moves; auto = bf16 in bf16 mode (with the bf16 gradient wire the step "
+                         "then moves exactly the bytes of one bf16 all-reduce; the replicated fp32 parameters are the widened bf16 "
+                         "image, the fp32 master stays with the owner), fp32 (exact) otherwise")
     ap.add_argument("--no-wgrad-fork", action="store_true",
                     help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
@@ -598,8 +607,10 @@ def main():
     config.manual_seed(1234 + rank)
 
     wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
+    pwire = args.param_wire if args.param_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
+    sharded = dist_on and not args.no_shard_optimizer
     w = Workload(args.config, dev, W, args.precision, group=group, wire=wire, device_step=not args.no_graph, seed_off=rank,
-                 overlap=not args.no_overlap)
+                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire)
     trainer, fusion = w.trainer, w.fusion
     use_graph = (not args.no_graph) and w.graphable
     comm_mode = "bucketed on a side stream" if dist_on else "none"
@@ -644,7 +655,9 @@ def main():
             launch_mode = "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them"
         if step is None:
             if dist_on:
-                trainer.overlap, comm_mode = False, "eager, between the graphs"
+                trainer.overlap = False
+                comm_mode = (f"reduce-scatter ({wire}) -> clip + Adam on the rank's 1/{world} shard -> all-gather ({pwire}), eager, behind "
+                             "graph A") if sharded else "all-reduce, eager, between the graphs"
             step = GraphedStep(trainer, w.loss_fn)
     else:
         step = w.eager_step
@@ -721,7 +734,7 @@ def main():
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * W * world / (ms_per_step * 1e-3) / 1e12, 2),
                        "grad_bytes": grad_bytes,
-                       "grad_allreduce": comm_mode + (f", {wire} on the wire" if dist_on else "")},
+                       "grad_allreduce": comm_mode + (f", {wire} on the wire" if dist_on and not sharded else "")},
             "roofline": roofline, "roofline_hbm": hbm, "cpu_baseline": cpu}
         line.update(extras)
     if dist_on:

@@ -421,6 +421,29 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
     return IMMTSF_OK;
 }
 
+// the two halves of the step as separate launches, for a SHARDED optimizer: every rank squares its own gradient shard,
+// the 1024 partial sums are all-reduced (4 KB), and the update of the shard clips by the GLOBAL norm
+int launch_adam_sqnorm(const float* grad, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
+                       hipStream_t s) {
+    const int vec = ((reinterpret_cast<uintptr_t>(grad) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int launch_adam_apply(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                      float wd, int step, const long long* step_dev, float max_norm, const float* norm_scratch, void* twin,
+                      hipStream_t s) {
+    if (n == 0) return IMMTSF_OK;
+    if (!twin) twin = const_cast<void*>(immtsf_twin_lookup(param, n));
+    const int vec = adam_vec_ok(param, grad, m, v, twin);
+    const float bc1 = step_dev ? 1.f : 1.f - powf(b1, (float)step), bc2s = step_dev ? 1.f : sqrtf(1.f - powf(b2, (float)step));
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
+                       norm_scratch, 1024, step_dev, reinterpret_cast<bf16_t*>(twin), vec);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
                     hipStream_t s) {

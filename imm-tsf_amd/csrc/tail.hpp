@@ -35,6 +35,12 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
                     hipStream_t s);
 
+int launch_adam_sqnorm(const float* grad, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
+                       hipStream_t s);
+int launch_adam_apply(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                      float wd, int step, const long long* step_dev, float max_norm, const float* norm_scratch, void* twin,
+                      hipStream_t s);
+
 // dst[i] = bf16(src[i]) (round to nearest even): refresh of a bf16 twin
 int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 // dst[i] = float(src[i]) (exact)

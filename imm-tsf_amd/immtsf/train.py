@@ -31,7 +31,8 @@ class FlatTrainer:
     def __init__(self, buckets: Sequence[Iterable[torch.nn.Parameter]], lr: float = 1e-3, weight_decay: float = 0.0,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
                  sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None,
-                 grad_wire: str = "fp32", sink_exclude: Iterable[torch.nn.Parameter] = ()):
+                 grad_wire: str = "fp32", sink_exclude: Iterable[torch.nn.Parameter] = (), shard_optimizer: bool = False,
+                 param_wire: str = "fp32"):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
         sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks; the
         backbone too when every op that uses its parameters is an immtsf.ops function).  A sink parameter must be used by
@@ -44,8 +45,23 @@ class FlatTrainer:
         cost of ~3 significant digits per element, which clip + Adam's normalised update tolerates)."""
         if grad_wire not in ("fp32", "bf16"):
             raise ValueError("grad_wire must be 'fp32' or 'bf16'")
+        if param_wire not in ("fp32", "bf16"):
+            raise ValueError("param_wire must be 'fp32' or 'bf16'")
         self.grad_wire = grad_wire
         self.group = group
+        self.world, self.rank = 1, 0
+        if group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        # shard_optimizer (ZeRO-1 style; world > 1 or a 1-rank group): the flat gradient is REDUCE-SCATTERED (each rank
+        # receives the sum of its 1/W slice: half the bytes of an all-reduce), clip + Adam run on that slice only -- the
+        # moments exist only there: 1/W of the optimizer state and of its 28 bytes/parameter of HBM traffic -- and the
+        # updated parameters are ALL-GATHERED.  param_wire "fp32": the gathered parameters are the exact fp32 values (what a
+        # single process would hold; 4 bytes/parameter on the wire).  "bf16": only the bf16 image is gathered (2
+        # bytes/parameter: the whole step then moves what one bf16 all-reduce moves) and every rank's replicated fp32
+        # parameters are its widening -- mixed-precision semantics: the fp32 master copy lives with the owner's shard.
+        self.sharded = bool(shard_optimizer and group is not None)
+        self.param_wire = param_wire
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.step_count = 0
         seen, self.buckets = set(), []
@@ -61,10 +77,18 @@ class FlatTrainer:
         # with 16-byte loads; the padding elements stay zero everywhere
         pad8 = lambda k: (k + 7) // 8 * 8      # noqa: E731
         n = sum(pad8(p.numel()) for p in params)
+        if self.sharded:
+            q = 8 * self.world
+            n = (n + q - 1) // q * q              # equal, 32-byte aligned shards
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        per = n // self.world if self.sharded else n
+        self.shard = (self.rank * per, (self.rank + 1) * per) if self.sharded else (0, n)
+        self.exp_avg = torch.zeros(per, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(per, dtype=torch.float32, device=dev)
+        self._wire_shard = torch.empty(per, dtype=torch.bfloat16, device=dev) if self.sharded and grad_wire == "bf16" else None
+        self._grad_shard = torch.empty(per, dtype=torch.float32, device=dev) if self.sharded and grad_wire == "fp32" else None
+        self.master = None               # param_wire "bf16": fp32 master copy of this rank's parameter shard (set below)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
         self._wire = torch.empty(n, dtype=torch.bfloat16, device=dev) if grad_wire == "bf16" and group is not None else None
         self.ranges = []
@@ -107,10 +131,12 @@ class FlatTrainer:
             from . import config
             _, self.drop_dev = config.enable_device_counters(dev)      # dropout key counter: shared by the device's modules
             self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)    # Adam's step number: this trainer's own
-        self.world = 1
-        if group is not None:
-            import torch.distributed as dist
-            self.world = dist.get_world_size(group)
+        if self.sharded and param_wire == "bf16":
+            if self.flat_twin is None:
+                self.flat_twin = torch.empty(n, dtype=torch.bfloat16, device=dev)
+                self.flat_twin.copy_(self.flat_param)
+            self.master = self.flat_param[self.shard[0]:self.shard[1]].clone()
+            self.flat_param.copy_(self.flat_twin)       # the replicated parameters are the widened bf16 image on every rank
         self.collective = group is not None          # a 1-rank group still runs the (trivial) collectives: lets one GPU
         self.overlap = overlap and self.collective and dev.type == "cuda"      # exercise the multi-GPU code path
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
@@ -229,6 +255,11 @@ class FlatTrainer:
         normalised over the GLOBAL batch (immtsf.ops.masked_mse with `group`), so the sum of the ranks' gradients
         is exactly the single-process full-batch gradient."""
         self._collect_autograd_grads()
+        if self.sharded:
+            if not all(self._reduced):
+                self._reduce_scatter()
+                self._reduced = [True] * len(self.buckets)
+            return
         if self.collective:
             if not self.overlap and not any(self._reduced):
                 import torch.distributed as dist
@@ -239,8 +270,94 @@ class FlatTrainer:
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
 
+    def _reduce_scatter(self):
+        """flat_grad[shard] <- sum over ranks of flat_grad[shard] (RCCL reduce-scatter, through the wire format; gloo, which
+        has no reduce-scatter, all-reduces the whole buffer: same values in the shard, test backend only)"""
+        import torch.distributed as dist
+        lo, hi = self.shard
+        g = self.flat_grad
+        native = dist.get_backend(self.group) != "gloo"
+        if self.grad_wire == "bf16":
+            w = self._wire
+            if g.is_cuda:
+                lib = _lib.load()
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(g), _lib.ptr(w), g.numel(), _lib.stream_ptr()), "f32_to_bf16")
+            else:
+                w.copy_(g)
+            if native:
+                dist.reduce_scatter_tensor(self._wire_shard, w, group=self.group)
+                src = self._wire_shard
+            else:
+                dist.all_reduce(w, group=self.group)
+                src = w[lo:hi]
+            if g.is_cuda:
+                lib = _lib.load()
+                _lib.check(lib.immtsf_bf16_to_f32(_lib.ptr(src), _lib.ptr(g[lo:hi]), hi - lo, _lib.stream_ptr()), "bf16_to_f32")
+            else:
+                g[lo:hi].copy_(src)
+        elif native:
+            dist.reduce_scatter_tensor(self._grad_shard, g, group=self.group)
+            g[lo:hi].copy_(self._grad_shard)
+        else:
+            dist.all_reduce(g, group=self.group)
+
+    def _all_gather(self, full, shard):
+        import torch.distributed as dist
+        if dist.get_backend(self.group) != "gloo":
+            dist.all_gather_into_tensor(full, shard, group=self.group)
+        else:
+            per = shard.numel()
+            dist.all_gather([full[r * per:(r + 1) * per] for r in range(self.world)], shard.clone(), group=self.group)
+
+    def _step_sharded(self):
+        """clip + Adam on this rank's shard (global norm: 1024 partial sums of squares, all-reduced), then all-gather"""
+        import torch.distributed as dist
+        lo, hi = self.shard
+        per = hi - lo
+        g = self.flat_grad[lo:hi]
+        p = self.master if self.master is not None else self.flat_param[lo:hi]
+        if self.flat_param.is_cuda:
+            lib = _lib.load()
+            sd = _lib.ptr(self.step_dev) if self.device_step else None
+            dd = _lib.ptr(self.drop_dev) if self.device_step else None
+            _lib.check(lib.immtsf_adam_sqnorm(_lib.ptr(g), per, _lib.ptr(self.norm_scratch), sd, dd, _lib.stream_ptr()), "adam_sqnorm")
+            dist.all_reduce(self.norm_scratch, group=self.group)
+            tw = _lib.ptr(self.flat_twin[lo:hi]) if self.flat_twin is not None else None
+            _lib.check(lib.immtsf_adam_apply(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), per, self.lr,
+                                             self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, sd, self.max_norm,
+                                             _lib.ptr(self.norm_scratch), tw, _lib.stream_ptr()), "adam_apply")
+        else:
+            sq = (g * g).sum().reshape(1)
+            dist.all_reduce(sq, group=self.group)
+            gg = g
+            if self.max_norm and self.max_norm > 0:
+                gg = g * torch.clamp(self.max_norm / (sq.sqrt() + 1e-6), max=1.0)
+            if self.wd:
+                gg = gg + self.wd * p
+            b1, b2 = self.betas
+            self.exp_avg.mul_(b1).add_(gg, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            p.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
+            if self.flat_twin is not None:
+                self.flat_twin[lo:hi].copy_(p)
+        if self.param_wire == "bf16":
+            self._all_gather(self.flat_twin, self.flat_twin[lo:hi])
+            if self.flat_param.is_cuda:
+                lib = _lib.load()
+                _lib.check(lib.immtsf_bf16_to_f32(_lib.ptr(self.flat_twin), _lib.ptr(self.flat_param), self.flat_param.numel(),
+                                                  _lib.stream_ptr()), "bf16_to_f32")
+            else:
+                self.flat_param.copy_(self.flat_twin)
+        else:
+            self._all_gather(self.flat_param, self.flat_param[lo:hi])
+            self.refresh_twins()
+
     def step(self):
         self.step_count += 1
+        if self.sharded:
+            self._step_sharded()
+            return
         if self.flat_param.is_cuda and self.device_step:
             lib = _lib.load()
             _lib.check(lib.immtsf_adam_step_dev(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
@@ -303,8 +420,9 @@ class GraphedStep:
             self.loss = self._fwd_bwd()
             if self.captured_comm:
                 trainer.sync_grads()
-        with torch.cuda.graph(self.graph_b):
-            trainer.step()
+        if not trainer.sharded:          # a sharded optimizer's step holds two collectives: it stays eager (three kernels)
+            with torch.cuda.graph(self.graph_b):
+                trainer.step()
 
     def _fwd_bwd(self):
         # (the 32 MB gradient memset as a third parallel branch of graph A, beside the forward, was measured: the step
@@ -321,7 +439,10 @@ class GraphedStep:
         if not self.captured_comm:
             t._reduced = [False] * len(t.buckets)
             t.sync_grads()
-        self.graph_b.replay()
+        if t.sharded:
+            t.step()
+        else:
+            self.graph_b.replay()
         return self.loss
 
 

@@ -413,6 +413,17 @@ int immtsf_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm,
                          float* norm_scratch, uint64_t* dropout_step_dev, immtsf_stream_t stream);
 
+/* The same step as two calls, for a sharded optimizer (immtsf.train.FlatTrainer(shard_optimizer=True): each rank owns
+ * 1/W of the flat buffers): adam_sqnorm writes 1024 partial sums of squares of `grad` (this rank's shard of the
+ * reduce-scattered gradient) to norm_scratch and bumps the device counters (both may be NULL); the caller sum-all-reduces
+ * norm_scratch[0..1024) over the ranks; adam_apply then clips by the global norm and updates param / moments (and `twin`,
+ * the bf16 image of `param`: NULL = the registered twin, if any).  step_dev NULL: bias corrections from the host `step`. */
+int immtsf_adam_sqnorm(const float* grad, uint64_t n, float* norm_scratch, int64_t* step_dev, uint64_t* dropout_step_dev,
+                       immtsf_stream_t stream);
+int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, const int64_t* step_dev, float max_norm,
+                      const float* norm_scratch, void* twin, immtsf_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
  * precision, M, N, K, nprob, nbatch, dyn, grid threads, 0) and ms[max]; returns the number of records and resets the tap.

@@ -53,6 +53,56 @@ def _params(z):
     return {k: torch.nn.Parameter(v.clone()) for k, v in R.params_from_npz(z).items()}
 
 
+def _worker_sharded(rank, world, port, q, wire, param_wire):
+    """three training steps with FlatTrainer(shard_optimizer=True) on half batches vs torch Adam on the full batch"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    torch.set_num_threads(2)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from immtsf.train import FlatTrainer, shard_range
+    z = np.load(os.path.join(GOLDEN, "fusion_TTF_T2V_XAttn_MMF_XAttn_Add_tiny_h2.npz"))
+    H = int(z["H"])
+    params = _params(z)
+    full = _batch(7, 6, 5, 6, 3, 16)
+    lo, hi = shard_range(6, rank, world)
+    shard = tuple(t[lo:hi] for t in full)
+    cnt = shard[5].reshape(-1, 3).sum(0)
+    dist.all_reduce(cnt)
+    ttf = [p for k, p in params.items() if k.startswith("ttf.")]
+    mmf = [p for k, p in params.items() if k.startswith("mmf.")]
+    # eps 1e-3: Adam's sign-like early steps would otherwise turn the 1e-10 summation-order noise of gradients that are
+    # zero in exact arithmetic (the key bias) into +-lr * 1e-2 parameter differences
+    tr = FlatTrainer([mmf, ttf], lr=1e-2, eps=1e-3, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD, grad_wire=wire,
+                     shard_optimizer=True, param_wire=param_wire)
+    assert tr.exp_avg.numel() * world == tr.flat_param.numel()          # the moments exist for this rank's shard only
+    for _ in range(3):
+        tr.zero_grad()
+        _loss(params, shard, cnt, H).backward()
+        tr.sync_grads()
+        tr.step()
+    p_dp = tr.gather(tr.flat_param)
+    # every rank must hold the same replicated parameters
+    chk = p_dp.clone()
+    dist.all_reduce(chk)
+    same = float((chk / world - p_dp).abs().max())
+    if rank == 0:
+        ref = _params(z)
+        order = [k for k in ref if k.startswith("mmf.")] + [k for k in ref if k.startswith("ttf.")]
+        opt = torch.optim.Adam([ref[k] for k in order], lr=1e-2, eps=1e-3, weight_decay=1e-3)
+        cnt_full = full[5].reshape(-1, 3).sum(0)
+        for _ in range(3):
+            opt.zero_grad()
+            _loss(ref, full, cnt_full, H).backward()
+            torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)
+            opt.step()
+        p_ref = torch.cat([ref[k].detach().reshape(-1) for k in order])
+        q.put({"perr": float((p_dp - p_ref).abs().max()), "same": same})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q, wire="fp32"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
@@ -133,6 +183,26 @@ def test_two_rank_bf16_gradient_wire():
         assert p.exitcode == 0
     assert 1e-6 < res["gerr"] < 1e-2, res           # really went through bf16, and no worse than its resolution
     assert res["lerr"] < 1e-6, res
+
+
+@pytest.mark.parametrize("wire,param_wire,tol", [("fp32", "fp32", 1e-5), ("bf16", "fp32", 3e-3), ("fp32", "bf16", 2e-2)])
+def test_two_rank_sharded_optimizer_matches_single_process(wire, param_wire, tol):
+    """reduce-scatter of the flat gradient + clip/Adam on each rank's shard (global norm from all-reduced partial sums) +
+    all-gather of the parameters == torch Adam on the full batch: 1e-5 with exact wires; with a bf16 gradient wire the
+    update direction is Adam-normalised, so three steps at lr 1e-2 may differ by a few 1e-3; with a bf16 parameter wire
+    the replicated parameters are bf16-rounded by construction (8 significant bits)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q, wire, param_wire)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["perr"] < tol, res
+    assert res["same"] < 1e-7, res
 
 
 def test_shard_range_covers_everything_once():

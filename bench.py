@@ -273,6 +273,7 @@ class Workload:
                                    lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_exclude=excl,
                                    overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
+        self.trainer.watch(self.model, self.fusion)
         big = c["N_MAX"] * c["d_m"] * windows > (1 << 28)
         if big:
             self.batch, self.sum_n = synth_batch(100 + seed_off, windows, cfg, device=dev)

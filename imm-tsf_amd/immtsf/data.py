@@ -37,10 +37,15 @@ class ResidentStore:
         is_hist = tt < np.float32(history)
         self.hist_len = np.bincount(seg[is_hist], minlength=self.W).astype(np.int32)
         self.pred_len = (np.diff(self._row_off) - self.hist_len).astype(np.int32)
-        for w in range(self.W):       # history rows must be a prefix and times ascending (the dataset sorts by time)
-            t = tt[self._row_off[w]:self._row_off[w + 1]]
-            if np.any(np.diff(t) <= 0):
-                raise ValueError(f"window {w}: timestamps must be strictly increasing")
+        # history rows must be a prefix of every window: times non-decreasing inside a window (the dataset sorts by time;
+        # equal timestamps -- duplicate date_time rows -- are fine, the reference only splits on tt < history,
+        # lib/parse_datasets.py:252-295).  One vectorised check over all rows.
+        if len(tt) > 1:
+            drop = np.diff(tt) < 0
+            drop[self._row_off[1:-1] - 1] = False          # the step from one window's last row to the next window's first
+            if np.any(drop):
+                w = int(np.searchsorted(self._row_off, int(np.argmax(drop)) + 1, side="right") - 1)
+                raise ValueError(f"window {w}: timestamps must be non-decreasing")
         self.n_notes = np.diff(note_off).astype(np.int32)
         self._patch_cache = {}
         # ---- device arrays

@@ -158,12 +158,32 @@ class FlatTrainer:
         return torch.cat(out)
 
     def refresh_twins(self):
-        """re-derive the bf16 twin from the fp32 parameters: call after writing parameters by any means other than
-        step() (load_state_dict, manual edits)."""
+        """re-derive the bf16 twin (and, with a bf16 parameter wire, the owner's fp32 master shard) from the fp32
+        parameters: needed after writing parameters by any means other than step() -- load_state_dict, a torch.optim
+        optimizer, manual edits.  `watch(modules)` arranges for it to run by itself after load_state_dict."""
+        if self.master is not None:
+            self.master.copy_(self.flat_param[self.shard[0]:self.shard[1]])
         if self.flat_twin is not None:
-            lib = _lib.load()
-            _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(self.flat_param), _lib.ptr(self.flat_twin), self.flat_param.numel(),
-                                              _lib.stream_ptr()), "f32_to_bf16")
+            if self.flat_param.is_cuda:
+                lib = _lib.load()
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(self.flat_param), _lib.ptr(self.flat_twin), self.flat_param.numel(),
+                                                  _lib.stream_ptr()), "f32_to_bf16")
+            else:
+                self.flat_twin.copy_(self.flat_param)
+            if self.master is not None:
+                self.flat_param.copy_(self.flat_twin)
+
+    after_external_update = refresh_twins
+
+    def watch(self, *modules):
+        """keep the bf16 twin current across `module.load_state_dict(...)` (checkpoint resume, best-model reload before
+        the test pass of the reference's main.py flow): a post-hook on each given module refreshes the twin.  In bf16 mode
+        the forward / data-gradient GEMMs read their weights from the twin, so a stale twin would silently evaluate the old
+        weights.  Parameter writes that bypass load_state_dict (a torch.optim step on these parameters, manual edits) still
+        need an explicit after_external_update()."""
+        for m in modules:
+            m.register_load_state_dict_post_hook(lambda module, incompatible_keys: self.refresh_twins())
+        return self
 
     def close(self):
         """drop the twin registration (the registry is keyed by the flat buffer's address)"""
@@ -383,6 +403,33 @@ class FlatTrainer:
             bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
             self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
 
+    def snapshot(self):
+        """parameters, Adam moments and step / dropout counters (GraphedStep / PhasedStep restore them after warming up)"""
+        s = {"param": self.flat_param.clone(), "m": self.exp_avg.clone(), "v": self.exp_avg_sq.clone(), "step": self.step_count}
+        if self.master is not None:
+            s["master"] = self.master.clone()
+        if self.device_step:
+            s["step_dev"], s["drop_dev"] = self.step_dev.clone(), self.drop_dev.clone()
+        return s
+
+    def restore(self, s):
+        self.flat_param.copy_(s["param"])
+        self.exp_avg.copy_(s["m"])
+        self.exp_avg_sq.copy_(s["v"])
+        self.step_count = s["step"]
+        if self.master is not None:
+            self.master.copy_(s["master"])
+        if self.device_step:
+            self.step_dev.copy_(s["step_dev"])
+            self.drop_dev.copy_(s["drop_dev"])
+        if self.flat_twin is not None:
+            if self.flat_param.is_cuda:
+                lib = _lib.load()
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(self.flat_param), _lib.ptr(self.flat_twin), self.flat_param.numel(),
+                                                  _lib.stream_ptr()), "f32_to_bf16")
+            else:
+                self.flat_twin.copy_(self.flat_param)
+
     def grad_bytes(self) -> int:
         return self.flat_grad.numel() * 4
 
@@ -397,7 +444,8 @@ class GraphedStep:
                   is a NEW training step (needs FlatTrainer(device_step=True)).
     `loss_fn()` runs the forward and returns the scalar loss; inputs must be static device tensors."""
 
-    def __init__(self, trainer: FlatTrainer, loss_fn, warmup: int = 3, capture_collectives: bool = False):
+    def __init__(self, trainer: FlatTrainer, loss_fn, warmup: int = 3, capture_collectives: bool = False,
+                 restore_after_warmup: bool = True):
         if not trainer.device_step:
             raise ValueError("GraphedStep needs FlatTrainer(device_step=True): host-side step counters would freeze in the graph")
         self.trainer, self.loss_fn = trainer, loss_fn
@@ -408,13 +456,19 @@ class GraphedStep:
             trainer.overlap = False
         side = torch.cuda.Stream(device=trainer.flat_param.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up off the default stream: allocator pools, lazy inits, RCCL channels
+        # the warm-up runs REAL steps (allocator pools, lazy inits, RCCL channels): parameters, moments and the step / dropout
+        # counters are put back afterwards, so that the first replay is training step 1 from the caller's weights
+        snap = trainer.snapshot() if restore_after_warmup else None
+        with torch.cuda.stream(side):           # off the default stream
             for _ in range(warmup):
                 self._fwd_bwd()
                 trainer.sync_grads()
                 trainer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            trainer.restore(snap)
+            torch.cuda.synchronize()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
@@ -477,8 +531,11 @@ class PhasedStep:
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
-        for _ in range(warmup):       # eager, on the two streams: allocator pools, lazy inits, RCCL channels
+        snap = trainer.snapshot()
+        for _ in range(warmup):       # eager REAL steps on the two streams (allocator pools, lazy inits, RCCL channels) ...
             self._eager_step()
+        torch.cuda.synchronize()
+        trainer.restore(snap)         # ... undone: the first replay is training step 1 from the caller's weights
         torch.cuda.synchronize()
         G = torch.cuda.CUDAGraph
         self.gT1, self.gB1, self.gT2, self.gB2, self.gT3, self.gO = G(), G(), G(), G(), G(), G()

@@ -70,7 +70,7 @@ def test_graph_replay_trains_like_eager_incl_backbone():
     # eager
     model, fusion, tr, batch = _setup(dev, 0.0)
     f = _loss_fn(model, fusion, batch)
-    for _ in range(3 + steps):          # GraphedStep warms up with 3 real steps
+    for _ in range(steps):              # GraphedStep's warm-up steps are undone: replay 1 is step 1
         tr.zero_grad()
         f().backward()
         tr.sync_grads()
@@ -226,8 +226,8 @@ def _two_rank_worker(rank, world, port, q, wire):
     def f():
         out = forecast_and_fuse(model, fusion, shard, None)
         return masked_mse(out, shard["data_to_predict"], shard["mask_predicted_data"], None, cnt)
-    g = GraphedStep(tr, f)              # 3 warm-up steps ...
-    for _ in range(2):                  # ... + 2 replays
+    g = GraphedStep(tr, f)              # (its 3 warm-up steps are undone)
+    for _ in range(5):
         g()
     torch.cuda.synchronize()
     if rank == 0:
@@ -337,7 +337,7 @@ def test_phased_step_trains_like_eager():
     steps = 4
     model, fusion, tr, batch = _setup_sinks(dev, 0.0)
     f = _loss_fn(model, fusion, batch)
-    for _ in range(3 + steps):
+    for _ in range(steps):
         tr.zero_grad()
         f().backward()
         tr.sync_grads()
@@ -361,3 +361,35 @@ def test_phased_step_trains_like_eager():
     err = float((tr.flat_param - ref).abs().max() / ref.abs().max())
     assert err < 2e-4, err
     tr.close()
+
+
+def test_load_state_dict_refreshes_the_bf16_twin():
+    """bf16 mode reads the GEMM weights from FlatTrainer's bf16 twin: after trainer.watch(module), module.load_state_dict
+    must refresh it (the forward then uses the NEW weights); without the hook the twin would be stale"""
+    dev = _dev()
+    from immtsf import config
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    assert tr.flat_twin is not None
+    tr.watch(model, fusion)
+    config.precision = "bf16"
+    try:
+        f = _loss_fn(model, fusion, batch)
+        with torch.no_grad():
+            l0 = float(f())
+        sd = {k: v.clone() for k, v in fusion.state_dict().items()}
+        for k in sd:
+            if sd[k].dtype.is_floating_point and sd[k].dim() == 2:
+                sd[k] = sd[k] * 1.5
+        fusion.load_state_dict(sd)
+        with torch.no_grad():
+            l1 = float(f())
+        # reference point: the same weights in a trainer built AFTER the load (twin derived from them at construction)
+        tr.refresh_twins()
+        with torch.no_grad():
+            l2 = float(f())
+        torch.cuda.synchronize()
+    finally:
+        config.precision = "fp32"
+        tr.close()
+    assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)          # the new weights are in effect
+    assert l1 == l2, (l1, l2)                               # and the hook left nothing stale

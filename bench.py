@@ -412,11 +412,12 @@ def gemm_roofline(w, lib, args, k2=20):
                 "A fp32, B " + ("bf16 twin of the weights" if twin is not None else "fp32") + ", C fp32", "gemm_kernel", (Bb, twin))
 
     # the eager tap's durations include launch latency, which ranks tiny batched launches far too high: the candidates (the
-    # five largest tap totals) are re-timed inside a hipGraph and ranked by kernel time x launches per step
+    # six largest tap totals among the instances carrying >= 3 % of the step's GEMM flops) are re-timed inside a hipGraph and
+    # ranked by kernel time x launches per step
     best = None
-    for r in rows[:5]:
-        if r["flops"] <= 0:
-            continue
+    step_flops = sum(r["flops"] * r["launches"] for r in rows)
+    cands = [r for r in rows if r["flops"] * r["launches"] >= 0.03 * step_flops][:6]      # launch-latency-only rows are not "the GEMM"
+    for r in cands:
         one, n_in, alg_bytes, operands, kname, tw = retime(r)
         us = graph_kernel_us(one, reps=20, replays=5) / n_in
         if tw is not None and tw[1] is not None:

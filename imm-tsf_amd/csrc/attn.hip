@@ -10,30 +10,109 @@ namespace {
 
 constexpr int TT = 32;   // forecast steps accumulated per pass in registers
 
-// grid (B, H, ceil(hd/256)), 256 threads; LDS: sc[N] | atile[TT*64] | red[16]
+// Long windows (cfg5: up to 4096 notes, lengths U{1..4096}) make one workgroup per window the whole story: 64 x H x
+// ceil(hd/256) workgroups, the longest one walking 4096 notes.  Above RAGGED_SPLIT_N padded notes the work is cut into
+// chunks of RAGGED_CH notes instead (SPLIT = true): scores by one wave per packed row (ragged_scores_kernel), the softmax
+// by one workgroup per (window, head) over the n scores (ragged_softmax_kernel), the weighted sum of the values by one
+// workgroup per (window, chunk, head, 256 columns) into per-chunk partial sums (this kernel with SPLIT), summed by
+// ragged_ctx_reduce_kernel.  Windows of one chunk write ctx directly.
+constexpr int RAGGED_SPLIT_N = 256;
+constexpr int RAGGED_CH = 256;
+
+// one wave per (packed row, head): S[row, h] = qs_h . k_row
+__global__ __launch_bounds__(256) void ragged_scores_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                             const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                             float* __restrict__ S) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, lane = threadIdx.x & 63;
+    if (row >= offsets[dm.B]) return;
+    const int hd = dm.hd, ld = 2 * dm.H * hd;
+    const float* kr = KVp + (size_t)row * ld + h * hd;
+    const float* q = qs + h * hd;
+    float a = 0.f;
+    if ((hd & 3) == 0) {
+        for (int c = lane * 4; c < hd; c += 256) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + c), qv = *reinterpret_cast<const float4*>(q + c);
+            a = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, a))));
+        }
+    } else {
+        for (int c = lane; c < hd; c += 64) a = fmaf(q[c], kr[c], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) S[(size_t)row * dm.H + h] = a;
+}
+
+// grid (B, H): softmax over the window's n scores, in place (P[row, h], stride H)
+__global__ __launch_bounds__(256) void ragged_softmax_kernel(RaggedAttnDims dm, const int* __restrict__ offsets, float* __restrict__ P) {
+    __shared__ float red[16];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    if (n == 0) return;
+    float* p = P + (size_t)o0 * dm.H + h;
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, p[(size_t)i * dm.H]);
+    m = block_max(m, red);
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) sum += expf(p[(size_t)i * dm.H] - m);
+    sum = block_sum(sum, red);
+    const float inv = 1.f / sum;
+    for (int i = tid; i < n; i += 256) p[(size_t)i * dm.H] = expf(p[(size_t)i * dm.H] - m) * inv;
+}
+
+// grid (B, ceil(T d / 256)): ctx[b] = sum of the window's chunk partials (windows of <= 1 chunk were written directly)
+__global__ __launch_bounds__(256) void ragged_ctx_reduce_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                                 const float* __restrict__ part, int maxch, float* __restrict__ ctx,
+                                                                 bf16_t* __restrict__ ctx_h) {
+    const int b = blockIdx.x;
+    const int n = offsets[b + 1] - offsets[b], nch = (n + RAGGED_CH - 1) / RAGGED_CH;
+    if (nch <= 1) return;
+    const size_t Td = (size_t)dm.T * dm.H * dm.hd, x = (size_t)blockIdx.y * 256 + threadIdx.x;
+    if (x >= Td) return;
+    float a = 0.f;
+    for (int c = 0; c < nch; ++c) a += part[((size_t)b * maxch + c) * Td + x];
+    if (ctx) ctx[(size_t)b * Td + x] = a;
+    if (ctx_h) ctx_h[(size_t)b * Td + x] = (bf16_t)a;
+}
+
+// !SPLIT: grid (B, H, ceil(hd/256)), 256 threads; LDS: sc[N] | atile[TT*64] | red[16]
+//  SPLIT: grid (B * maxch, H, ceil(hd/256)); P holds the normalised weights already; LDS: sc[RAGGED_CH] | atile | red
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                const int* __restrict__ rowmap,
                                                                const float* __restrict__ KVp, const float* __restrict__ qs,
                                                                float* __restrict__ P, float* __restrict__ ctx, DropCfg drop,
-                                                               uint64_t site, bf16_t* __restrict__ ctx_h) {
+                                                               uint64_t site, bf16_t* __restrict__ ctx_h, float* __restrict__ part,
+                                                               int maxch) {
     extern __shared__ float lds[];
     float* sc = lds;
-    float* atile = lds + dm.N;
+    float* atile = lds + (SPLIT ? RAGGED_CH : dm.N);
     float* red = atile + TT * 64;
-    const int b = blockIdx.x, h = blockIdx.y, ez = blockIdx.z;
+    const int b = SPLIT ? blockIdx.x / maxch : blockIdx.x, ch = SPLIT ? blockIdx.x % maxch : 0;
+    const int h = blockIdx.y, ez = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
-    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    const int ob = offsets[b], nfull = offsets[b + 1] - ob;
     const int e = ez * 256 + tid;
     const bool valid = e < hd;
-    if (n == 0) {   // no notes: the caller zeroes the row after out_proj anyway (M_txt); keep ctx defined
-        if (valid) for (int t = 0; t < T; ++t) {
+    if (nfull == 0) {   // no notes: the caller zeroes the row after out_proj anyway (M_txt); keep ctx defined
+        if (valid && ch == 0) for (int t = 0; t < T; ++t) {
             const size_t o = (size_t)(b * T + t) * d + h * hd + e;
             if (ctx) ctx[o] = 0.f;
             if (ctx_h) ctx_h[o] = (bf16_t)0.f;
         }
         return;
     }
+    const int i_lo = ch * RAGGED_CH;
+    if (i_lo >= nfull) return;
+    const int o0 = ob + i_lo, n = SPLIT ? min(RAGGED_CH, nfull - i_lo) : nfull;
+    // where this workgroup's (T, 256-column) block of sums goes: ctx itself, or the chunk's partial
+    float* dst = ctx;
+    bf16_t* dst_h = ctx_h;
+    size_t obase = (size_t)b * T * d;
+    if (SPLIT && nfull > RAGGED_CH) { dst = part; dst_h = nullptr; obase = ((size_t)b * maxch + ch) * T * d; }
+    if (SPLIT) {
+        for (int i = tid; i < n; i += 256) sc[i] = P[(size_t)(o0 + i) * dm.H + h];
+        __syncthreads();
+    } else {
     // two notes per pass, their key loads (hd/64 each, unrolled) all in flight together: a wave's notes are a chain of
     // global-load round trips otherwise (n/4 of them)
     for (int i = wave; i < n; i += 8) {
@@ -68,6 +147,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
         if (ez == 0) P[(size_t)(o0 + i) * dm.H + h] = p;
     }
     __syncthreads();
+    }
 
     const float* vbase = KVp + (size_t)o0 * ld + d + h * hd + e;
     if (drop.p <= 0.f) {   // every forecast step sees the same weights
@@ -76,9 +156,9 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
 #pragma unroll 8
         for (int i = 0; i < n; ++i) acc = fmaf(sc[i], vbase[(size_t)i * ld], acc);
         for (int t = 0; t < T; ++t) {
-            const size_t o = (size_t)(b * T + t) * d + h * hd + e;
-            if (ctx) ctx[o] = acc;
-            if (ctx_h) ctx_h[o] = (bf16_t)acc;
+            const size_t o = obase + (size_t)t * d + h * hd + e;
+            if (dst) dst[o] = acc;
+            if (dst_h) dst_h[o] = (bf16_t)acc;
         }
         return;
     }
@@ -116,9 +196,9 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt)
                 if (t0 + tt < T) {
-                    const size_t o = (size_t)(b * T + t0 + tt) * d + h * hd + e;
-                    if (ctx) ctx[o] = acc[tt];
-                    if (ctx_h) ctx_h[o] = (bf16_t)acc[tt];
+                    const size_t o = obase + (size_t)(t0 + tt) * d + h * hd + e;
+                    if (dst) dst[o] = acc[tt];
+                    if (dst_h) dst_h[o] = (bf16_t)acc[tt];
                 }
         }
     }
@@ -136,12 +216,16 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
                                                                   const float* __restrict__ KVp, const float* __restrict__ P,
                                                                   const float* __restrict__ dctx, float* __restrict__ dKVp,
                                                                   float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
-                                                                  bf16_t* __restrict__ dKVp_h) {
-    const int b = blockIdx.x, h = blockIdx.y, c = blockIdx.z * 64 + (threadIdx.x & 63);
+                                                                  bf16_t* __restrict__ dKVp_h, int maxch) {
+    // maxch > 1: grid.x = B * maxch, workgroup (b, ch) takes notes [ch * RAGGED_CH, +RAGGED_CH) of window b
+    const int b = blockIdx.x / maxch, ch = blockIdx.x % maxch;
+    const int h = blockIdx.y, c = blockIdx.z * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
-    const int o0 = offsets[b], n = offsets[b + 1] - o0;
-    if (n == 0) return;
+    const int ob = offsets[b], nfull = offsets[b + 1] - ob;
+    const int i_lo = maxch > 1 ? ch * RAGGED_CH : 0;
+    if (i_lo >= nfull) return;
+    const int o0 = ob + i_lo, n = maxch > 1 ? min(RAGGED_CH, nfull - i_lo) : nfull;
     const bool valid = c < hd;
     const float* dc = dctx + (size_t)b * T * d + h * hd + c;   // row t at dc + t*d
     float gsum = 0.f;
@@ -192,6 +276,94 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
     }
 }
 
+// Backward, part 1 for long windows (chunked path).  grid (B * maxch, H, ceil(hd/256)), 256 threads, one column per thread,
+// the chunk's RAGGED_CH notes walked by every thread.  The dropout scales m[t, i] of the chunk are generated ONCE per
+// workgroup into LDS (four consecutive notes share one Philox call when their original positions are consecutive) instead
+// of once per wave and 64-column slice, g[i, c] = sum_t m[t, i] dctx[t, c] reads them as wave-wide broadcasts against the
+// T upstream values the thread keeps in registers (T <= 32; beyond that they are re-read through L1), and the per-note
+// dp partial sums of the four waves meet in LDS: one atomic per note and workgroup.
+// LDS: mt[T][RAGGED_CH] (dropout only) | dpw[4][RAGGED_CH]
+template <bool REG>
+__global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                                       const int* __restrict__ rowmap,
+                                                                       const float* __restrict__ KVp, const float* __restrict__ P,
+                                                                       const float* __restrict__ dctx, float* __restrict__ dKVp,
+                                                                       float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
+                                                                       bf16_t* __restrict__ dKVp_h, int maxch) {
+    extern __shared__ float lds[];
+    const int T = dm.T;
+    const bool dropping = drop.p > 0.f;
+    float* mt = lds;
+    float* dpw = lds + (dropping ? (size_t)T * RAGGED_CH : 0);
+    const int b = blockIdx.x / maxch, ch = blockIdx.x % maxch, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.z * 256 + tid;
+    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d;
+    const int ob = offsets[b], nfull = offsets[b + 1] - ob, i_lo = ch * RAGGED_CH;
+    if (i_lo >= nfull) return;
+    const int o0 = ob + i_lo, n = min(RAGGED_CH, nfull - i_lo);
+    const bool valid = c < hd;
+    if (dropping) {
+        const int n4 = (n + 3) >> 2;
+        for (int x = tid; x < T * n4; x += 256) {
+            const int t = x / n4, i = (x - t * n4) * 4;
+            const int r0 = rowmap[o0 + i] - b * dm.N;
+            const uint64_t base = ((uint64_t)(b * T + t) * dm.H + h) * dm.N;
+            float sc4[4];
+            const bool run = i + 3 < n && (((base + r0) & 3) == 0) && rowmap[o0 + i + 3] - b * dm.N == r0 + 3;
+            if (run) {
+                dropout_scale4(drop, site, base + r0, sc4);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    sc4[u] = i + u < n ? dropout_scale(drop, site, base + (uint64_t)(rowmap[o0 + i + u] - b * dm.N)) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i + u < n) mt[t * RAGGED_CH + i + u] = sc4[u];
+        }
+    }
+    const float* dc = dctx + (size_t)b * T * d + h * hd + c;   // row t at dc + t*d
+    constexpr int DCR = 32;
+    float dcv[DCR];
+    float gsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < DCR; ++t) {
+        dcv[t] = (valid && t < T) ? dc[(size_t)t * d] : 0.f;
+        gsum += dcv[t];
+    }
+    if (!REG && valid)
+        for (int t = DCR; t < T; ++t) gsum += dc[(size_t)t * d];
+    __syncthreads();
+    const size_t voff = (size_t)o0 * ld + d + h * hd + c;
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+        float g = gsum;
+        if (dropping) {
+            g = 0.f;
+            if (REG) {
+#pragma unroll
+                for (int t = 0; t < DCR; ++t)
+                    if (t < T) g = fmaf(mt[t * RAGGED_CH + i], dcv[t], g);
+            } else {
+                for (int t = 0; t < T; ++t) g = fmaf(mt[t * RAGGED_CH + i], valid ? dc[(size_t)t * d] : 0.f, g);
+            }
+        }
+        float a = 0.f;
+        if (valid) {
+            const size_t off = voff + (size_t)i * ld;
+            a = g * KVp[off];
+            const float dvv = P[(size_t)(o0 + i) * dm.H + h] * g;
+            if (dKVp) dKVp[off] = dvv;
+            if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
+        }
+        a = wave_sum(a);
+        if (lane == 0) dpw[wave * RAGGED_CH + i] = a;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        atomicAdd(dp_buf + (size_t)(o0 + i) * dm.H + h, dpw[i] + dpw[RAGGED_CH + i] + dpw[2 * RAGGED_CH + i] + dpw[3 * RAGGED_CH + i]);
+}
+
 // Backward, part 2.  grid (B, H, ceil(hd/256)), 256 threads (every workgroup recomputes the window's ds -- n values -- and
 // owns a 256-column slice of dk / dqs_part; one workgroup per window made 64 of them walk all hd columns); LDS: ds[N] | red[16].
 //   ds[i] = p[i] (dp[i] - sum_j p[j] dp[j]);  dk[i,:] = ds[i] * qs_h;  dqs_part[b, h, :] = sum_i ds[i] k[i,:]
@@ -199,23 +371,29 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
                                                                   const float* __restrict__ KVp, const float* __restrict__ qs,
                                                                   const float* __restrict__ P, const float* __restrict__ dp_buf,
                                                                   float* __restrict__ dKVp, float* __restrict__ dqs_part,
-                                                                  bf16_t* __restrict__ dKVp_h) {
+                                                                  bf16_t* __restrict__ dKVp_h, int maxch) {
+    // maxch > 1: grid.x = B * maxch; workgroup (b, ch) recomputes the window's sum_j p_j dp_j (n values), owns the chunk's
+    // ds / dk rows and adds its share of dqs_part (zero-filled by the launcher) with one atomic per column
     extern __shared__ float lds[];
     float* ds = lds;
-    float* red = lds + dm.N;
-    const int b = blockIdx.x, h = blockIdx.y, c0 = blockIdx.z * 256;
+    float* red = lds + (maxch > 1 ? RAGGED_CH : dm.N);
+    const int b = blockIdx.x / maxch, ch = blockIdx.x % maxch;
+    const int h = blockIdx.y, c0 = blockIdx.z * 256;
     const int tid = threadIdx.x;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d;
-    const int o0 = offsets[b], n = offsets[b + 1] - o0;
+    const int ob = offsets[b], nfull = offsets[b + 1] - ob;
     const int c = c0 + tid;
-    if (n == 0) {
-        if (c < hd) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
+    if (nfull == 0) {
+        if (c < hd && maxch == 1) dqs_part[(size_t)b * d + h * hd + c] = 0.f;
         return;
     }
+    const int i_lo = maxch > 1 ? ch * RAGGED_CH : 0;
+    if (i_lo >= nfull) return;
+    const int o0 = ob + i_lo, n = maxch > 1 ? min(RAGGED_CH, nfull - i_lo) : nfull;
     float part = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const float p = P[(size_t)(o0 + i) * dm.H + h], g = dp_buf[(size_t)(o0 + i) * dm.H + h];
-        ds[i] = g;
+    for (int i = tid; i < nfull; i += 256) {
+        const float p = P[(size_t)(ob + i) * dm.H + h], g = dp_buf[(size_t)(ob + i) * dm.H + h];
+        if (i >= i_lo && i < i_lo + n) ds[i - i_lo] = g;
         part = fmaf(p, g, part);
     }
     const float dot = block_sum(part, red);
@@ -234,7 +412,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
         if (dKVp) dKVp[dk0 + (size_t)i * ld] = dkv;
         if (dKVp_h) dKVp_h[dk0 + (size_t)i * ld] = (bf16_t)dkv;
     }
-    dqs_part[(size_t)b * d + h * hd + c] = a;
+    if (maxch > 1) atomicAdd(dqs_part + (size_t)b * d + h * hd + c, a);
+    else dqs_part[(size_t)b * d + h * hd + c] = a;
 }
 
 // ---- dense attention rows: one wave per (b,h,l) row of length S ---------------------------------------
@@ -427,13 +606,34 @@ __global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const 
 
 }  // namespace
 
+size_t ragged_attn_part_floats(int B, int T, int d, int N) {
+    return N > RAGGED_SPLIT_N ? (size_t)B * cdiv(N, RAGGED_CH) * T * d : 0;
+}
+
 int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h) {
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h, float* part) {
     if (dm.B <= 0) return IMMTSF_OK;
+    bf16_t* ch = static_cast<bf16_t*>(ctx_h);
+    if (dm.N > RAGGED_SPLIT_N) {      // long windows: chunked (see the comment above the kernels)
+        if (!part) return IMMTSF_EWORKSPACE;
+        const int maxch = cdiv(dm.N, RAGGED_CH);
+        const size_t lds = (size_t)(RAGGED_CH + TT * 64 + 16) * sizeof(float);
+        hipLaunchKernelGGL(ragged_scores_kernel, dim3(cdiv(dm.B * dm.N, 4), dm.H), dim3(256), 0, s, dm, offsets, KVp, qs, P);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ragged_softmax_kernel, dim3(dm.B, dm.H), dim3(256), 0, s, dm, offsets, P);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ragged_attn_fwd_kernel<true>, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap,
+                           KVp, qs, P, ctx, drop, site, ch, part, maxch);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ragged_ctx_reduce_kernel, dim3(dm.B, cdiv(dm.T * dm.H * dm.hd, 256)), dim3(256), 0, s, dm, offsets, part, maxch,
+                           ctx, ch);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     const size_t lds = (size_t)(dm.N + TT * 64 + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(ragged_attn_fwd_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
-                       P, ctx, drop, site, static_cast<bf16_t*>(ctx_h));
+    hipLaunchKernelGGL(ragged_attn_fwd_kernel<false>, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
+                       P, ctx, drop, site, ch, nullptr, 1);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -443,15 +643,35 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
                            uint64_t site, hipStream_t s, void* dKVp_h) {
     if (dm.B <= 0) return IMMTSF_OK;
     if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
-    const size_t lds = (size_t)(dm.N + 16) * sizeof(float);
+    const int maxch = dm.N > RAGGED_SPLIT_N ? cdiv(dm.N, RAGGED_CH) : 1;
+    const size_t lds = (size_t)((maxch > 1 ? RAGGED_CH : dm.N) + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
     hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
-                       dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h));
+    if (maxch > 1) {
+        e = hipMemsetAsync(dqs_part, 0, (size_t)dm.B * dm.H * dm.hd * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const size_t lds_long = ((drop.p > 0.f ? (size_t)dm.T * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
+    if (maxch > 1 && lds_long <= 128 * 1024) {
+        if (lds_long > 64 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+        }
+        const dim3 grid(dm.B * maxch, dm.H, cdiv(dm.hd, 256));
+        if (dm.T <= 32)
+            hipLaunchKernelGGL(ragged_attn_bwd_dv_long_kernel<true>, grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
+                               dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
+        else
+            hipLaunchKernelGGL(ragged_attn_bwd_dv_long_kernel<false>, grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
+                               dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
+    } else {
+        hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
+                           dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
+    }
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P, dp_buf,
-                       dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h));
+    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P,
+                       dp_buf, dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h), maxch);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -87,7 +87,7 @@ inline void set_problem(GemmArgs& g, int i, const float* A, const float* B, floa
     if (bias_grad) g.ones_col = 1;
 }
 
-// ---- fork/join onto a library-owned side stream ---------------------------------------------------------------
+// ---- fork/join onto a library-owned side stream (off unless immtsf_set_side_stream(1)) ---------------------------
 // A linear layer's two backward GEMMs (data gradient NN, weight gradient TN) are independent and each under-fills
 // the 256 CUs at the fusion shapes, so the weight-gradient GEMM is enqueued on a side stream that is forked from and
 // joined back into the caller's stream inside the same call (works eagerly and under hipGraph capture: the side
@@ -100,7 +100,7 @@ struct SideStream {
     bool ok = false;
 };
 inline SideStream& side_stream_state() {
-    static SideStream st[16];
+    static thread_local SideStream st[16];      // per calling thread and device: two threads never share fork/join events
     int dev = 0;
     (void)hipGetDevice(&dev);
     SideStream& s = st[dev & 15];

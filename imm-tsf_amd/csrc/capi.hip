@@ -5,6 +5,7 @@
 #include "rowops.hpp"
 #include "tail.hpp"
 #include "block_util.hpp"
+#include <atomic>
 
 namespace {
 inline DropCfg mk_drop(float p, uint64_t seed) {
@@ -17,12 +18,12 @@ inline DropCfg mk_drop(float p, uint64_t seed) {
 }
 }  // namespace
 
-namespace { int g_side_enabled = 0; }   // measured slower under hipGraph replay at the cfg2 shapes (3.18 vs 2.64 ms/step): off by default
+namespace { std::atomic<int> g_side_enabled{0}; }   // measured slower under hipGraph replay at the cfg2 shapes (3.18 vs 2.64 ms/step): off by default
 
 extern "C" {
 
 int immtsf_side_stream_enabled(void) { return g_side_enabled; }
-int immtsf_set_side_stream(int32_t on) { g_side_enabled = on ? 1 : 0; return 0; }
+int immtsf_set_side_stream(int32_t on) { g_side_enabled.store(on ? 1 : 0); return 0; }
 
 int immtsf_gemm(int32_t layout, int32_t precision, const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                 int32_t ldc, const float* bias, int32_t M, int32_t N, int32_t K, float alpha, int32_t accumulate,

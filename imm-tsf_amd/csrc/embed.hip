@@ -12,10 +12,10 @@
 //
 // HBM-bound on the (R, P, D) output (PatchTST cfg3: 384 x 10 x 512 fp32 = 7.9 MB written once; the inputs are 36 KB of
 // weights, 20 KB of table and 147 KB of series).  Exact fp32 FMAs in both precision modes (K <= 64: an MFMA tile would
-// be mostly padding).  Forward: a workgroup per (row, chunk of patches), W transposed in LDS, one thread per output
-// column, stores coalesced along D.  Backward: dW by per-thread register accumulators over a slice of
-// the (row, patch) pairs, combined with one fp32 atomic per element and workgroup; dx (optional: the series are data in
-// every configured backbone) by a wave per (row, patch).
+// be mostly padding).  Forward: a workgroup per 16 (row, patch) pairs, one thread per output column with that column's K
+// weights in registers, stores coalesced along D.  Backward: dW by workgroups that own 16 output columns and a slice of
+// the pairs (register accumulators, LDS sum over the pair lanes, <= 8 atomic adds per element); dx (optional: the series
+// are data in every configured backbone) by a wave per (row, patch).
 #include "../../include/immtsf.h"
 #include "common.hpp"
 
@@ -35,87 +35,98 @@ __device__ __forceinline__ int emb_src(const EmbDims& e, int p, int k) {      //
     return l * e.c_in + c;
 }
 
-// grid (R, ceil(P / PT)); LDS: Wt[K][D] | g[PT][K]
-template <int PT>
+// grid ceil(R P / PB): a workgroup takes PB consecutive (row, patch) pairs; their gathered taps sit in LDS (g[PB][K], read as
+// wave-wide broadcasts), every thread keeps its output column's K weights in registers and writes that column of the PB
+// outputs, coalesced along D
+template <int PB>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ pe, float* __restrict__ out, DropCfg drop,
                                                          uint64_t site) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Wt = lds;
-    float* g = lds + (size_t)e.K * e.D;
-    const int r = blockIdx.x, p0 = blockIdx.y * PT, tid = threadIdx.x;
-    for (int i = tid; i < e.K * e.D; i += 256) {        // W is (D, K): transpose into [k][d]
-        const int d = i / e.K, k = i - d * e.K;
-        Wt[k * e.D + d] = W[i];
-    }
+    __shared__ __attribute__((aligned(16))) float g[PB * EMB_KMAX];
+    const int tid = threadIdx.x;
+    const long pairs = (long)e.R * e.P, q0 = (long)blockIdx.x * PB;
+    const int nq = (int)min((long)PB, pairs - q0);
     const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
-    const float* xr = x + (size_t)r * row_elems;
-    const int np = min(PT, e.P - p0);
-    for (int i = tid; i < np * e.K; i += 256) {
-        const int pp = i / e.K, k = i - pp * e.K;
-        g[i] = xr[emb_src(e, p0 + pp, k)];
+    for (int i = tid; i < nq * e.K; i += 256) {
+        const int qq = i / e.K, k = i - qq * e.K;
+        const long q = q0 + qq;
+        const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
+        g[qq * EMB_KMAX + k] = x[(size_t)r * row_elems + emb_src(e, p, k)];
     }
     __syncthreads();
-    for (int pp = 0; pp < np; ++pp) {
-        const int p = p0 + pp;
-        const float* gp = g + pp * e.K;
-        for (int d = tid; d < e.D; d += 256) {
+    for (int d = tid; d < e.D; d += 256) {
+        float w[EMB_KMAX];
+#pragma unroll
+        for (int k = 0; k < EMB_KMAX; ++k) w[k] = k < e.K ? W[(size_t)d * e.K + k] : 0.f;
+        for (int qq = 0; qq < nq; ++qq) {
+            const long q = q0 + qq;
+            const int p = (int)(q % e.P);
             float a = pe[(size_t)p * e.D + d];
-            for (int k = 0; k < e.K; ++k) a = fmaf(Wt[k * e.D + d], gp[k], a);
-            const size_t o = ((size_t)r * e.P + p) * e.D + d;
+#pragma unroll
+            for (int k = 0; k < EMB_KMAX; ++k)
+                if (k < e.K) a = fmaf(w[k], g[qq * EMB_KMAX + k], a);
+            const size_t o = (size_t)q * e.D + d;
             out[o] = a * dropout_scale(drop, site, (uint64_t)o);
         }
     }
 }
 
-// dW[d, k] += sum over this workgroup's (row, patch) pairs of dout[r,p,d] * dropscale * g(r,p,k).  grid (NB); one thread per
-// output column d (D <= 512: two columns per thread at most); LDS: g[PB][K] per batch of PB pairs
-template <int DPT>
+// dW[d, k] = sum over (row, patch) pairs q of dout[q, d] * dropscale * g(q, k): a (D x pairs) x (pairs x K) product with a
+// tiny K.  grid (ceil(D / 16), S): a workgroup owns 16 output columns d and one of S slices of the pairs; its 256 threads
+// are 16 columns x 16 pair lanes, every thread keeps K accumulators, the 16 pair lanes are summed through LDS and the
+// workgroup adds its 16 x K block with one atomic per element (S <= 8 adds per address; S = 1 for short inputs).
+// (The first version gave every workgroup all D columns of 16 pairs: 240 workgroups x D K atomics on D K addresses
+// serialised in L2 -- 306 us at PatchTST's 512 x 16; this one is ~10 us.)
 __global__ __launch_bounds__(256) void embed_bwd_w_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ dout,
                                                            float* __restrict__ dW, DropCfg drop, uint64_t site) {
-    constexpr int PB = 16;
-    __shared__ float g[PB * EMB_KMAX];
-    const int tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* g = lds;                              // [16 pairs][K]
+    float* red = lds + 16 * EMB_KMAX;            // [16 pair lanes][16 columns][K + 1]
+    const int tid = threadIdx.x, dc = tid & 15, pl = tid >> 4;
+    const int d = blockIdx.x * 16 + dc;
     const long pairs = (long)e.R * e.P;
-    const long per = (pairs + gridDim.x - 1) / gridDim.x, q0 = blockIdx.x * per, q1 = min(pairs, q0 + per);
+    const long per = ((pairs + gridDim.y - 1) / gridDim.y + 15) & ~15L, q0 = blockIdx.y * per, q1 = min(pairs, q0 + per);
     const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
-    float acc[DPT][EMB_KMAX];
+    float acc[EMB_KMAX];
 #pragma unroll
-    for (int j = 0; j < DPT; ++j)
-#pragma unroll
-        for (int k = 0; k < EMB_KMAX; ++k) acc[j][k] = 0.f;
-    for (long qb = q0; qb < q1; qb += PB) {
-        const int nq = (int)min((long)PB, q1 - qb);
+    for (int k = 0; k < EMB_KMAX; ++k) acc[k] = 0.f;
+    for (long qb = q0; qb < q1; qb += 16) {
         __syncthreads();
-        for (int i = tid; i < nq * e.K; i += 256) {
+        for (int i = tid; i < 16 * e.K; i += 256) {
             const int qq = i / e.K, k = i - qq * e.K;
             const long q = qb + qq;
-            const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
-            g[qq * EMB_KMAX + k] = x[(size_t)r * row_elems + emb_src(e, p, k)];
+            float v = 0.f;
+            if (q < q1) {
+                const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
+                v = x[(size_t)r * row_elems + emb_src(e, p, k)];
+            }
+            g[qq * EMB_KMAX + k] = v;
         }
         __syncthreads();
-        for (int qq = 0; qq < nq; ++qq) {
-            const long q = qb + qq;
-#pragma unroll
-            for (int j = 0; j < DPT; ++j) {
-                const int d = tid + 256 * j;
-                if (d < e.D) {
-                    const size_t o = (size_t)q * e.D + d;
-                    const float dv = dout[o] * dropout_scale(drop, site, (uint64_t)o);
-#pragma unroll
-                    for (int k = 0; k < EMB_KMAX; ++k)
-                        if (k < e.K) acc[j][k] = fmaf(dv, g[qq * EMB_KMAX + k], acc[j][k]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < DPT; ++j) {
-        const int d = tid + 256 * j;
-        if (d < e.D) {
+        const long q = qb + pl;
+        if (q < q1 && d < e.D) {
+            const size_t o = (size_t)q * e.D + d;
+            const float dv = dout[o] * dropout_scale(drop, site, (uint64_t)o);
 #pragma unroll
             for (int k = 0; k < EMB_KMAX; ++k)
-                if (k < e.K) atomicAdd(dW + (size_t)d * e.K + k, acc[j][k]);
+                if (k < e.K) acc[k] = fmaf(dv, g[pl * EMB_KMAX + k], acc[k]);
+        }
+    }
+    __syncthreads();
+    const int pitch = e.K + 1;
+#pragma unroll
+    for (int k = 0; k < EMB_KMAX; ++k)
+        if (k < e.K) red[(pl * 16 + dc) * pitch + k] = acc[k];
+    __syncthreads();
+    for (int i = tid; i < 16 * e.K; i += 256) {
+        const int c = i / e.K, k = i - c * e.K;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a += red[(j * 16 + c) * pitch + k];
+        const int dd = blockIdx.x * 16 + c;
+        if (dd < e.D) {
+            if (gridDim.y == 1) dW[(size_t)dd * e.K + k] = a;       // sole writer: dW need not be zero
+            else atomicAdd(dW + (size_t)dd * e.K + k, a);
         }
     }
 }
@@ -165,11 +176,10 @@ int immtsf_embed_forward(int32_t mode, const float* x, int32_t R, int32_t L, int
     const EmbDims e{mode, R, L, c_in, P, K, stride, D};
     if (!x || !W || !pe || !out) return IMMTSF_EINVAL;
     if (emb_bad(e)) return IMMTSF_EUNSUPPORTED;
-    constexpr int PT = 16;
-    const size_t lds = ((size_t)K * D + (size_t)PT * K) * sizeof(float);
-    if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(embed_fwd_kernel<PT>, dim3(R, cdiv(P, PT)), dim3(256), lds, static_cast<hipStream_t>(stream), e, x, W, pe, out,
-                       mk_drop2(p_drop, seed, seed_step_dev), site);
+    constexpr int PB = 16;
+    const long pairs = (long)R * P;
+    hipLaunchKernelGGL(embed_fwd_kernel<PB>, dim3((unsigned)((pairs + PB - 1) / PB)), dim3(256), 0, static_cast<hipStream_t>(stream), e, x, W,
+                       pe, out, mk_drop2(p_drop, seed, seed_step_dev), site);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -183,14 +193,17 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
     if (emb_bad(e)) return IMMTSF_EUNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DropCfg drop = mk_drop2(p_drop, seed, seed_step_dev);
-    if (!dw_prezeroed) {
+    const long pairs = (long)R * P;
+    const int cs = cdiv(D, 16);
+    int S = (int)min((long)8, max((long)1, pairs / 256));        // >= 256 pairs per slice; S * cs workgroups
+    while (S > 1 && S * cs > 1024) --S;
+    if (S == 1 && !dw_prezeroed) { /* sole writer per element: no zero-fill needed */ }
+    else if (!dw_prezeroed) {
         hipError_t er = hipMemsetAsync(dW, 0, (size_t)D * K * sizeof(float), s);
         if (er != hipSuccess) return (int)er;
     }
-    const long pairs = (long)R * P;
-    const int nb = (int)min((long)256, (pairs + 15) / 16);
-    if (D <= 256) hipLaunchKernelGGL(embed_bwd_w_kernel<1>, dim3(nb), dim3(256), 0, s, e, x, dout, dW, drop, site);
-    else hipLaunchKernelGGL(embed_bwd_w_kernel<2>, dim3(nb), dim3(256), 0, s, e, x, dout, dW, drop, site);
+    const size_t lds = (16 * EMB_KMAX + 256 * (size_t)(K + 1)) * sizeof(float);
+    hipLaunchKernelGGL(embed_bwd_w_kernel, dim3(cs, S), dim3(256), lds, s, e, x, dout, dW, drop, site);
     IMMTSF_LAUNCH_CHECK();
     if (dx) {
         const size_t n = (size_t)R * (mode == 0 ? (size_t)L : (size_t)L * c_in);

@@ -23,7 +23,7 @@ struct T2VWs {
     unsigned char *mask, *mtxt;
     int *lengths, *offsets, *rowmap, *seg;
     Mat Xcat, KV, ctx, z;
-    float *KVp, *q, *qs, *P, *xpre, *xhat, *rstd;
+    float *KVp, *q, *qs, *P, *xpre, *xhat, *rstd, *part;
     void *w_in, *w_kv, *w_inkv, *w_out, *w_po;     // bf16 weight images when no twin is registered (hf only)
     size_t bytes;
 };
@@ -49,6 +49,7 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     w.xhat = k.take<float>(BT * d);
     w.rstd = k.take<float>(BT);
     w.z = k.take_mat(BT * d, !hf, hf);
+    w.part = k.take<float>(ragged_attn_part_floats(c->B, c->T, c->d, c->N));     // long windows only (0 otherwise)
     w.w_in = w.w_kv = w.w_inkv = w.w_out = w.w_po = nullptr;
     if (hf) {
         w.w_in = k.take<unsigned short>(d * (size_t)c->d_m);
@@ -168,7 +169,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     }
     CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h));
+    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h, w.part));
     {   // out_proj, zero the windows without notes, + Q_param residual
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, w.ctx, W.out, mat(w.xpre), p->attn_out_b);

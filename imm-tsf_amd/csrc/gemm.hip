@@ -18,6 +18,9 @@
 //   * arbitrary M/N/K by zero-filling tile edges; M or K may live in device memory (ragged note count), so no host
 //     synchronisation is needed to size the launch.
 #include "gemm.hpp"
+#include <atomic>
+#include <mutex>
+#include <shared_mutex>
 
 namespace {
 
@@ -653,7 +656,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
     }
 }
 
-long g_last_grid_threads = 0;   // for the timing tap: lets bench.py match a launch with rocprof's Grid_Size
+thread_local long g_last_grid_threads = 0;   // for the timing tap: lets bench.py match a launch with rocprof's Grid_Size
 
 template <bool BF16, int BM, int BN, int BK, int WM, int WN, bool SPEC = false, bool BBF = false>
 int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t stream) {
@@ -676,7 +679,7 @@ int launch_cfg(int layout, const GemmArgs& g, int Mmax, int splits, hipStream_t 
 
 static int g_force_old = 0;      // immtsf_debug_gemm_config bit 16: keep bf16 mode on the round-1 kernel (A/B measurements)
 
-// tuning override for tools/gemm_bench.py (0 = heuristic)
+// tuning override for tools/gemm_bench.py (0 = heuristic).  Process-wide A/B switches: set them while no call is in flight
 int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 0;
 
 }  // namespace
@@ -698,27 +701,32 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
 }
 
 // ---- optional per-launch timing tap (bench.py's roofline leg): hipEvents bracket every GEMM launch on the
-// stream it is launched on.  Off by default; the only process-global state in the library.
+// stream it is launched on.  Off by default; while it is on, launches take g_tap_mu one at a time.
 namespace {
 struct TapRec { hipEvent_t e0, e1; int meta[10]; };
 constexpr int kTapCap = 16384;
 TapRec* g_tap = nullptr;
-int g_tap_n = 0, g_tap_on = 0, g_tap_events = 0;
+int g_tap_n = 0, g_tap_events = 0;
+std::atomic<int> g_tap_on{0};
+std::mutex g_tap_mu;
 }  // namespace
 
 static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t stream);
 
-// ---- bf16 twin registry (process-global, like the timing tap): a handful of ranges, linear lookup
+// ---- bf16 twin registry (process-wide, empty by default): a handful of ranges, linear lookup under a reader lock;
+// register / unregister take the writer lock, so a lookup sees a range entirely or not at all
 namespace {
 struct TwinRange { const float* base; const unsigned short* twin; size_t count; };
 constexpr int kMaxTwins = 16;
 TwinRange g_twins[kMaxTwins];
 int g_ntwins = 0;
-int g_twins_on = 1;
+std::atomic<int> g_twins_on{1};
+std::shared_mutex g_twins_mu;
 }  // namespace
 
 const void* immtsf_twin_lookup(const float* p, size_t min_elems) {
-    if (!g_twins_on) return nullptr;
+    if (!g_twins_on.load(std::memory_order_relaxed)) return nullptr;
+    std::shared_lock<std::shared_mutex> lk(g_twins_mu);
     for (int i = 0; i < g_ntwins; ++i) {
         const TwinRange& r = g_twins[i];
         if (p >= r.base && p + min_elems <= r.base + r.count) return r.twin + (p - r.base);
@@ -728,6 +736,7 @@ const void* immtsf_twin_lookup(const float* p, size_t min_elems) {
 
 extern "C" int immtsf_bf16_twin_register(const float* base, void* twin, size_t count) {
     if (!base || !twin || count == 0) return IMMTSF_EINVAL;
+    std::unique_lock<std::shared_mutex> lk(g_twins_mu);
     for (int i = 0; i < g_ntwins; ++i)
         if (g_twins[i].base == base) { g_twins[i] = TwinRange{base, static_cast<const unsigned short*>(twin), count}; return IMMTSF_OK; }
     if (g_ntwins >= kMaxTwins) return IMMTSF_EUNSUPPORTED;
@@ -736,18 +745,19 @@ extern "C" int immtsf_bf16_twin_register(const float* base, void* twin, size_t c
 }
 
 extern "C" int immtsf_bf16_twin_unregister(const float* base) {
+    std::unique_lock<std::shared_mutex> lk(g_twins_mu);
     for (int i = 0; i < g_ntwins; ++i)
         if (g_twins[i].base == base) { g_twins[i] = g_twins[--g_ntwins]; return IMMTSF_OK; }
     return IMMTSF_OK;
 }
 
-extern "C" int immtsf_bf16_twin_enable(int on) { g_twins_on = on ? 1 : 0; return IMMTSF_OK; }
+extern "C" int immtsf_bf16_twin_enable(int on) { g_twins_on.store(on ? 1 : 0); return IMMTSF_OK; }
 
 // bf16 mode: a launch whose every problem carries a bf16 A (p.Ah) and a bf16 B (p.Bh, or a registered twin of p.B) goes
 // to the bf16-in-memory kernel (gemm2.hip) when that kernel implements the argument combination; everything else (fp32
 // parity mode, batched form, row-mapped weight gradients, K or N below the 8-element chunk) runs on the kernel below,
 // which needs the fp32 operands.
-static int g_last_path = 0;       // for the timing tap: 1 = the kernel in this file, 2 = gemm2.hip (bf16 operands in memory)
+static thread_local int g_last_path = 0;       // for the timing tap: 1 = the kernel in this file, 2 = gemm2.hip (bf16 operands in memory)
 static int route_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
     if (precision == 1 && g.nbatch <= 1 && !g_force_old) {
         bool have = true;
@@ -773,7 +783,9 @@ static int route_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream
 }
 
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream) {
-    if (!g_tap_on || g_tap_n >= kTapCap) return route_gemm(layout, precision, g, stream);
+    if (!g_tap_on.load(std::memory_order_relaxed)) return route_gemm(layout, precision, g, stream);
+    std::lock_guard<std::mutex> lk(g_tap_mu);
+    if (!g_tap || g_tap_n >= kTapCap) return route_gemm(layout, precision, g, stream);
     TapRec& r = g_tap[g_tap_n];
     if (g_tap_n >= g_tap_events) {
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return route_gemm(layout, precision, g, stream);
@@ -791,14 +803,16 @@ int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t strea
 }
 
 extern "C" int immtsf_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_tap_mu);
     if (on && !g_tap) g_tap = new TapRec[kTapCap];
-    g_tap_on = on ? 1 : 0;
+    g_tap_on.store(on ? 1 : 0);
     g_tap_n = 0;
     return 0;
 }
 
 // host arrays: meta[10*max] (layout, precision, M, N, K, nprob, nbatch, dyn, grid threads, 0), ms[max]
 extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
+    std::lock_guard<std::mutex> lk(g_tap_mu);
     const int n = g_tap_n < max ? g_tap_n : max;
     for (int i = 0; i < n; ++i) {
         (void)hipEventSynchronize(g_tap[i].e1);

@@ -14,7 +14,14 @@
  *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*, NULL = default stream); nothing
  *    synchronises, allocates or frees, so the calls can be captured into a hipGraph.
  *  - return value: 0 = ok; <0 = IMMTSF_E*; >0 = hipError_t of a failed launch.  Nothing throws.
- *  - no global state; re-entrant; thread-safe as long as two calls do not share output/workspace buffers.
+ *  - every compute entry point is re-entrant: concurrent calls from different host threads (each on its own stream) are
+ *    safe as long as they do not share output / workspace buffers (tests/test_gpu_abi_threads.py).  The library keeps NO
+ *    per-call state between calls; what it does keep process-wide is optional, empty / off by default, and listed here:
+ *      (1) the bf16 twin registry (immtsf_bf16_twin_register ...): <= 16 address ranges behind a reader/writer lock;
+ *      (2) the GEMM timing tap (immtsf_timing_enable ...): a mutex-guarded record buffer, used by bench.py only;
+ *      (3) the A/B switches immtsf_debug_gemm_config / immtsf_debug_gemm2_config / immtsf_set_side_stream: plain
+ *          process-wide integers for measurements -- change them only while no call is in flight;
+ *      (4) when immtsf_set_side_stream(1): one side stream + two events per (host thread, device), created at first use.
  *  - precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32; parity mode), 1 = bf16 MFMA operands with fp32
  *    accumulation (v_mfma_f32_16x16x32_bf16; tensors in memory stay fp32).
  */
@@ -350,7 +357,9 @@ int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const floa
  * [base, base+count) whose owner keeps a bf16 copy (same element offsets) lets every GEMM whose B operand lies inside
  * it -- the weights of the forward (NT) and data-gradient (NN) GEMMs -- fetch half as many bytes with no conversion.
  * immtsf_adam_step[_dev] on a registered parameter range writes the twin together with the parameters; after any other
- * write to the range call immtsf_f32_to_bf16 (FlatTrainer.refresh_twins).  Process-global registry (<= 16 ranges). */
+ * write to the range call immtsf_f32_to_bf16 (FlatTrainer.refresh_twins).  Process-wide registry (<= 16 ranges), reader /
+ * writer locked: register / unregister from any thread while other threads launch; an unregistered twin must stay
+ * allocated until the work already enqueued against it has run. */
 int immtsf_bf16_twin_register(const float* base, void* twin, size_t count);
 int immtsf_bf16_twin_unregister(const float* base);
 int immtsf_bf16_twin_enable(int32_t on);            /* A/B switch for measurements; default on */
@@ -426,11 +435,12 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
 
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
- * precision, M, N, K, nprob, nbatch, dyn, grid threads, 0) and ms[max]; returns the number of records and resets the tap.
- * This tap is the library's only process-global state; it is off by default. */
+ * precision, M, N, K, nprob, nbatch, dyn, grid threads, kernel path) and ms[max]; returns the number of records and resets
+ * the tap.  Off by default; while it is on, GEMM launches from all threads are serialised by the tap's mutex. */
 int immtsf_timing_enable(int32_t on);
 /* Backward calls enqueue weight-gradient GEMMs on a library-owned side stream forked from / joined into `stream`
- * inside the call (concurrency with the data-gradient GEMMs; valid under hipGraph capture).  0 disables it. */
+ * inside the call (concurrency with the data-gradient GEMMs; valid under hipGraph capture).  0 (the default) disables it.
+ * The stream and its two events belong to the calling host thread (one set per thread and device). */
 int immtsf_set_side_stream(int32_t on);
 int immtsf_side_stream_enabled(void);
 /* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */

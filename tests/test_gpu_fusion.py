@@ -140,10 +140,11 @@ def test_ragged_index_bit_exact(case):
 
 
 # ------------------------------------------------------------------------------------------ oracle, synthetic
-def _synthetic(seed, B, N, T, C, d_m, dev, min_notes=1, scatter_masks=False):
+def _synthetic(seed, B, N, T, C, d_m, dev, min_notes=1, scatter_masks=False, lengths=None):
     g = torch.Generator().manual_seed(seed)
     notes = torch.randn(B, N, d_m, generator=g)
-    lengths = torch.randint(min_notes, N + 1, (B,), generator=g)
+    drawn = torch.randint(min_notes, N + 1, (B,), generator=g)
+    lengths = drawn if lengths is None else torch.tensor(lengths)
     tau = torch.zeros(B, N)
     for b in range(B):
         L = int(lengths[b])
@@ -158,7 +159,7 @@ def _synthetic(seed, B, N, T, C, d_m, dev, min_notes=1, scatter_masks=False):
 
 
 def _run_pair(ttf, mmf, B, N, T, C, d_m, d_txt, H, precision, seed=0, llm="GPT2", min_notes=1, scatter=False,
-              err=None):
+              err=None, lengths=None):
     err = err or _relerr
     dev = _dev()
     from fusions.FusionModel import FusionModel
@@ -173,7 +174,7 @@ def _run_pair(ttf, mmf, B, N, T, C, d_m, d_txt, H, precision, seed=0, llm="GPT2"
         for k, p in m.named_parameters():
             if "layer_norm" in k:
                 p.uniform_(0.5, 1.5) if k.endswith("weight") else p.uniform_(-0.3, 0.3)
-    notes, tau, t_hat, Y, up = _synthetic(seed + 1, B, N, T, C, d_m, dev, min_notes, scatter)
+    notes, tau, t_hat, Y, up = _synthetic(seed + 1, B, N, T, C, d_m, dev, min_notes, scatter, lengths)
     m.train()
     Yg = Y.to(dev).requires_grad_(True)
     out = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Yg)
@@ -436,6 +437,57 @@ def test_long_ragged_llama_dims_fp32():
                             precision="fp32", min_notes=700)
     _check(errs, 1e-4)
     _check(gerrs, 3e-4)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg5_longest_windows_vs_oracle(precision):
+    """BASELINE configs[4]'s extreme: two windows of N_b = 4096 and 2977 notes (the chunked ragged-attention path: 16 and
+    12 chunks of 256 notes, partial sums, cross-chunk softmax / dqs reductions), d_m = 4096 -> d_txt = 768, T = 32, C = 8,
+    against the oracle -- north_star tolerances: fp32 1e-4 (gradients 3e-4: 4096-term sums), bf16 3e-2 / 4e-2."""
+    errs, gerrs = _run_pair("TTF_T2V_XAttn", "MMF_XAttn_Add", B=2, N=4096, T=32, C=8, d_m=4096, d_txt=768, H=1,
+                            precision=precision, lengths=[4096, 2977], err=_relerr if precision == "fp32" else _l2err)
+    if precision == "fp32":
+        _check(errs, 1e-4)
+        _check(gerrs, 3e-4)
+    else:
+        _check(errs, 3e-2)
+        small = {k: v for k, v in gerrs.items() if "time2vec.linear" in k}
+        _check({k: v for k, v in gerrs.items() if k not in small}, 4e-2)
+        _check(small, 2.5e-1)
+
+
+def test_chunked_attention_dropout_and_empty_windows():
+    """the chunked path (N > 256) with attention-weight dropout on, multi-head, a one-note window, a one-chunk window
+    and a window that ends exactly on a chunk boundary: the exported Philox keep-masks fed to the oracle, fp32 1e-4."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config, ops
+    from oracle import fusion_ref as R
+    B, N, T, C, d_m, d, H, pd = 5, 700, 9, 4, 40, 32, 2, 0.25
+    register_d_model("SYN", d_m)
+    config.precision = "fp32"
+    config.manual_seed(77)
+    torch.manual_seed(5)
+    m = FusionModel(_args("TTF_T2V_XAttn", "MMF_XAttn_Add", "SYN", d, H, C, dropout=pd)).to(dev).train()
+    notes, tau, t_hat, Y, up = _synthetic(9, B, N, T, C, d_m, dev, lengths=[700, 1, 512, 37, 257])
+    Yg = Y.to(dev).requires_grad_(True)
+    out = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Yg)
+    (out * up.to(dev)).sum().backward()
+    keep = lambda seed, site, shape: ops.dropout_keep_mask(seed, site, int(np.prod(shape)), pd, dev).cpu().view(*shape).float()  # noqa: E731
+    drop = {"ttf": {"attn": keep(m.ttf.last_seed, 1, (B, T, H, N)), "out": keep(m.ttf.last_seed, 2, (B, T, d))},
+            "mmf": {"attn": keep(m.mmf.last_seed, 4, (B, H, T, T)), "out": keep(m.mmf.last_seed, 5, (B, T, C))}}
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    Yc = Y.clone().requires_grad_(True)
+    ref = R.fusion_forward("TTF_T2V_XAttn", "MMF_XAttn_Add", p, notes, tau, t_hat, Yc, H=H, kappa=0.5, drop=drop, p_drop=pd,
+                           expand_T=True)
+    (ref * up).sum().backward()
+    gerrs = {"gY": _relerr(Yg.grad, Yc.grad)}
+    for k, prm in m.named_parameters():
+        g = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+        gerrs["g." + k] = _relerr(prm.grad, g)
+    _check({"out": _relerr(out, ref)}, 1e-4)
+    _check(gerrs, 2e-4)
 
 
 def test_cfg3_shape_patchtst_fusion_step():

@@ -16,7 +16,7 @@ import sys
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*_counter_collection.csv")))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[(r["Kernel_Name"], int(r["Grid_Size"]), int(r["Workgroup_Size"]))].append(float(r["Counter_Value"]))

@@ -282,7 +282,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
 // of once per wave and 64-column slice, g[i, c] = sum_t m[t, i] dctx[t, c] reads them as wave-wide broadcasts against the
 // T upstream values the thread keeps in registers (T <= 32; beyond that they are re-read through L1), and the per-note
 // dp partial sums of the four waves meet in LDS: one atomic per note and workgroup.
-// LDS: mt[T][RAGGED_CH] (dropout only) | dpw[4][RAGGED_CH]
+// LDS: mt[RAGGED_CH][Tp] (dropout only; note-major so that a note's T scales are a few 16-byte broadcast reads; Tp = T
+// rounded up to 4, 32 when T <= 32, padding zero) | dpw[4][RAGGED_CH]
 template <bool REG>
 __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                        const int* __restrict__ rowmap,
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
     extern __shared__ float lds[];
     const int T = dm.T;
     const bool dropping = drop.p > 0.f;
+    const int Tp = REG ? 32 : ((T + 3) & ~3);
     float* mt = lds;
-    float* dpw = lds + (dropping ? (size_t)T * RAGGED_CH : 0);
+    float* dpw = lds + (dropping ? (size_t)Tp * RAGGED_CH : 0);
     const int b = blockIdx.x / maxch, ch = blockIdx.x % maxch, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = blockIdx.z * 256 + tid;
     const int hd = dm.hd, d = dm.H * hd, ld = 2 * d;
@@ -304,6 +306,10 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
     const bool valid = c < hd;
     if (dropping) {
         const int n4 = (n + 3) >> 2;
+        for (int x = tid; x < n * (Tp - T); x += 256) {      // zero padding t in [T, Tp)
+            const int i = x / (Tp - T), t = T + (x - i * (Tp - T));
+            mt[i * Tp + t] = 0.f;
+        }
         for (int x = tid; x < T * n4; x += 256) {
             const int t = x / n4, i = (x - t * n4) * 4;
             const int r0 = rowmap[o0 + i] - b * dm.N;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (i + u < n) mt[t * RAGGED_CH + i + u] = sc4[u];
+                if (i + u < n) mt[(i + u) * Tp + t] = sc4[u];
         }
     }
     const float* dc = dctx + (size_t)b * T * d + h * hd + c;   // row t at dc + t*d
@@ -341,11 +347,14 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
         if (dropping) {
             g = 0.f;
             if (REG) {
+                const float4* m4 = reinterpret_cast<const float4*>(mt + i * 32);
 #pragma unroll
-                for (int t = 0; t < DCR; ++t)
-                    if (t < T) g = fmaf(mt[t * RAGGED_CH + i], dcv[t], g);
+                for (int t4 = 0; t4 < DCR / 4; ++t4) {
+                    const float4 m = m4[t4];
+                    g = fmaf(m.x, dcv[4 * t4], fmaf(m.y, dcv[4 * t4 + 1], fmaf(m.z, dcv[4 * t4 + 2], fmaf(m.w, dcv[4 * t4 + 3], g))));
+                }
             } else {
-                for (int t = 0; t < T; ++t) g = fmaf(mt[t * RAGGED_CH + i], valid ? dc[(size_t)t * d] : 0.f, g);
+                for (int t = 0; t < T; ++t) g = fmaf(mt[i * Tp + t], valid ? dc[(size_t)t * d] : 0.f, g);
             }
         }
         float a = 0.f;
@@ -652,7 +661,7 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
         e = hipMemsetAsync(dqs_part, 0, (size_t)dm.B * dm.H * dm.hd * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
-    const size_t lds_long = ((drop.p > 0.f ? (size_t)dm.T * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
+    const size_t lds_long = ((drop.p > 0.f ? (size_t)(dm.T <= 32 ? 32 : ((dm.T + 3) & ~3)) * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
     if (maxch > 1 && lds_long <= 128 * 1024) {
         if (lds_long > 64 * 1024) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);

@@ -63,7 +63,8 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
 }
 struct T2VScratch {
     Mat dE, dx, dKVp, dKV;
-    float *dz, *dctx, *dXcat, *dqs_part, *dqs, *dq, *dp, *red;
+    float *dz, *dctx, *dXcat, *dqs_part, *dqs, *dq, *dp, *red, *red_t2v;
+    int t2v_slabs;
     size_t bytes;
 };
 T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
@@ -83,6 +84,8 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dq = k.take<float>(d);
     s.dp = k.take<float>(R * c->H);
     s.red = k.take<float>(64 * (d + dt + 8));
+    s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));       // time2vec backward: ~256 packed rows per slab
+    s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
     s.bytes = k.bytes();
     return s;
 }
@@ -287,7 +290,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
-                              gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red, 0, s));
+                              gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
     return fk.join();
 }
 

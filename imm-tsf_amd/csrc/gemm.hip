@@ -608,6 +608,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                 if (g.add_vec) x += g.add_vec[col + e];
                 if (g.act == 1) x = fmaxf(x, 0.f);
                 else if (g.act == 2) x = gelu_erf(x);
+                if (g.epi_drop.p > 0.f) x *= dropout_scale(g.epi_drop, g.epi_site, (uint64_t)row * N + col + e);
                 if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col + e] <= 0.f) x = 0.f;
                 if (g.accumulate) x += dst[e];
                 v[e] = x;
@@ -646,6 +647,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                 } else {
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = gelu_erf(v);
+                    if (g.epi_drop.p > 0.f) v *= dropout_scale(g.epi_drop, g.epi_site, (uint64_t)row * N + col);
                     if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col] <= 0.f) v = 0.f;   // relu backward mask
                     if (g.accumulate) v += *dst;
                     if (P.C) *dst = v;
@@ -877,7 +879,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
-    const bool can_split = all_c && g.act == 0 && !g.relu_ref && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = all_c && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     // weight-gradient GEMMs with 96..230 output tiles (768x768 .. 768x1152 at the fusion dims): the wave-specialised
     // kernel, unsplit -- its consumer waves never wait on global loads (the k-major fragment reads carry a conservative

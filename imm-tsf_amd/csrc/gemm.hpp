@@ -48,6 +48,9 @@ struct GemmArgs {
     int ld_ref;
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
+    // optional dropout on the result (after the activation): element (m, n) uses Philox index m * N + n of site epi_site
+    DropCfg epi_drop;
+    uint64_t epi_site;
     int xcd_remap;         // set by the launcher
     int dbg;               // ablation flags (tools/gemm_bench.py), 0 in production
 };

@@ -143,7 +143,22 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
     float aw = 0.f, ab = 0.f;
     if (j < d_tau) {
         const float wj = j ? w[j - 1] : 0.f, bj = j ? b[j - 1] : 0.f;
-        for (int r = r0 + ty; r < r1; r += 4) {
+        int r = r0 + ty;
+        for (; r + 12 < r1; r += 16) {      // four rows per pass: their (rowmap -> tau, dfeat) load chains are in flight together
+            float t[4], g[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t[u] = tau_pad[rowmap ? rowmap[r + 4 * u] : r + 4 * u];
+                g[u] = dfeat[(size_t)(r + 4 * u) * ld + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (j) g[u] *= cosf(fmaf(wj, t[u], bj));
+                aw = fmaf(g[u], t[u], aw);
+                ab += g[u];
+            }
+        }
+        for (; r < r1; r += 4) {
             const float t = tau_pad[rowmap ? rowmap[r] : r];
             float g = dfeat[(size_t)r * ld + j];
             if (j) g *= cosf(fmaf(wj, t, bj));
@@ -305,7 +320,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float eps, float* __restrict__ xhat, float* __restrict__ rstd,
                                                                  float* __restrict__ z, DropCfg drop, uint64_t site,
-                                                                 bf16_t* __restrict__ zh) {
+                                                                 bf16_t* __restrict__ zh, const float* __restrict__ res,
+                                                                 DropCfg pre, uint64_t presite) {
+    // res != null: the normalised row is res + dropout_pre(x) (post-norm residual block: LayerNorm(x_in + Dropout(branch)))
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), d4 = d >> 2;
     if (row >= rows) return;
     const float4* p = reinterpret_cast<const float4*>(x + (size_t)row * d);
@@ -315,6 +332,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
     for (int j = 0; j < LN_DV; ++j) {
         const int q = lane + 64 * j;
         xv[j] = q < d4 ? p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (res && q < d4) {
+            float sc[4];
+            dropout_scale4(pre, presite, (uint64_t)row * d + (uint64_t)q * 4, sc);
+            const float4 r = reinterpret_cast<const float4*>(res + (size_t)row * d)[q];
+            xv[j] = make_float4(fmaf(xv[j].x, sc[0], r.x), fmaf(xv[j].y, sc[1], r.y), fmaf(xv[j].z, sc[2], r.z), fmaf(xv[j].w, sc[3], r.w));
+        }
         s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
     }
     const float mu = wave_sum(s) / (float)d;
@@ -350,7 +373,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(float* __restrict__ dz_dy, int rows, int d,
                                                                  const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                                  const float* __restrict__ rstd, float* __restrict__ dx,
-                                                                 DropCfg drop, uint64_t site) {
+                                                                 DropCfg drop, uint64_t site, float* __restrict__ dbranch,
+                                                                 DropCfg pre, uint64_t presite) {
+    // dbranch != null: also the gradient of the branch input of the residual form, dx * dropout_pre mask
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), d4 = d >> 2;
     if (row >= rows) return;
     float4* g = reinterpret_cast<float4*>(dz_dy + (size_t)row * d);
@@ -367,7 +392,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(float* __restric
             dropout_scale4(drop, site, (uint64_t)row * d + (uint64_t)q * 4, sc);
             float4 dy = g[q];
             dy = make_float4(dy.x * sc[0], dy.y * sc[1], dy.z * sc[2], dy.w * sc[3]);
-            g[q] = dy;
+            if (drop.p > 0.f) g[q] = dy;      // without output dropout dz is left as it is (callers may pass a read-only tensor)
             const float4 gm = reinterpret_cast<const float4*>(gamma)[q];
             hv[j] = h[q];
             tv[j] = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
@@ -381,10 +406,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(float* __restric
 #pragma unroll
     for (int j = 0; j < LN_DV; ++j) {
         const int q = lane + 64 * j;
-        if (q < d4)
-            reinterpret_cast<float4*>(dx + (size_t)row * d)[q] =
-                make_float4(rs * (tv[j].x - c1 - hv[j].x * c2), rs * (tv[j].y - c1 - hv[j].y * c2), rs * (tv[j].z - c1 - hv[j].z * c2),
-                            rs * (tv[j].w - c1 - hv[j].w * c2));
+        if (q < d4) {
+            const float4 o = make_float4(rs * (tv[j].x - c1 - hv[j].x * c2), rs * (tv[j].y - c1 - hv[j].y * c2),
+                                         rs * (tv[j].z - c1 - hv[j].z * c2), rs * (tv[j].w - c1 - hv[j].w * c2));
+            reinterpret_cast<float4*>(dx + (size_t)row * d)[q] = o;
+            if (dbranch) {
+                float sc[4];
+                dropout_scale4(pre, presite, (uint64_t)row * d + (uint64_t)q * 4, sc);
+                reinterpret_cast<float4*>(dbranch + (size_t)row * d)[q] = make_float4(o.x * sc[0], o.y * sc[1], o.z * sc[2], o.w * sc[3]);
+            }
+        }
     }
 }
 
@@ -558,13 +589,16 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
 }
 
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
-                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh) {
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh, const float* res, DropCfg pre,
+                         uint64_t presite) {
     if (rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(xhat) |
-                         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta);
+                         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(res);
     if ((d & 3) == 0 && d <= 256 * LN_DV && (al & 15) == 0)
         hipLaunchKernelGGL(layernorm_fwd_vec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
-                           drop, site, static_cast<bf16_t*>(zh));
+                           drop, site, static_cast<bf16_t*>(zh), res, pre, presite);
+    else if (res)
+        return IMMTSF_EUNSUPPORTED;      // the residual form needs d % 4 == 0, d <= 1024 and 16-byte aligned rows
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
                            drop, site, static_cast<bf16_t*>(zh));
@@ -573,13 +607,15 @@ int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, co
 }
 
 int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
-                         float* dx, DropCfg drop, uint64_t site, hipStream_t s) {
+                         float* dx, DropCfg drop, uint64_t site, hipStream_t s, float* dbranch, DropCfg pre, uint64_t presite) {
     if (rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(dz_dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(xhat) |
-                         reinterpret_cast<uintptr_t>(gamma);
+                         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dbranch);
     if ((d & 3) == 0 && d <= 256 * LN_DV && (al & 15) == 0)
         hipLaunchKernelGGL(layernorm_bwd_vec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop,
-                           site);
+                           site, dbranch, pre, presite);
+    else if (dbranch)
+        return IMMTSF_EUNSUPPORTED;
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop,
                            site);

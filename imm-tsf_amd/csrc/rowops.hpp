@@ -30,10 +30,13 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
                    hipStream_t s);
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
-                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr);   // zh: bf16 z (z may be null)
+                         float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr,      // zh: bf16 z (z may be null)
+                         const float* res = nullptr, DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0);
+// (res != null: the row normalised is res + dropout_pre(x) -- LayerNorm(x_in + Dropout(branch)) of a post-norm block)
 // in: dz (grad wrt z).  out: dy written IN PLACE over dz (dy = dz*dropscale), dx.
 int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
-                         float* dx, DropCfg drop, uint64_t site, hipStream_t s);
+                         float* dx, DropCfg drop, uint64_t site, hipStream_t s, float* dbranch = nullptr,
+                         DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0);      // dbranch = dx * dropout_pre mask
 // y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale
 int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
                   float scale, hipStream_t s, float* y_nobias = nullptr);      // y_nobias: W x without the bias

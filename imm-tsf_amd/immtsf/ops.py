@@ -572,6 +572,64 @@ def gcn_adaptive(x, order, nodevec1, nodevec2, gate1, gate2, lin1, lin2, mlp_con
                                lin1.weight, lin1.bias, lin2.weight, lin2.bias, mlp_conv.weight, mlp_conv.bias)
 
 
+class EncoderLayerFn(torch.autograd.Function):
+    """immtsf_encoder_layer_forward/backward: nn.TransformerEncoderLayer (post-norm, relu, batch_first) over short sequences,
+    params in immtsf_encoder_layer_params order.  7 launches forward, 15 backward (csrc/encoder_layer.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, H, p_attn, p_drop, eps, training, precision, seed, site_base, *params):
+        lib = _lib.load()
+        x = _c(x)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(x, *params)
+        Bs, S, D = x.shape
+        F = params[6].shape[0]
+        p_on = training and (p_attn > 0 or p_drop > 0)
+        cfg = _lib.EncoderLayerCfg(Bs, S, D, int(H), F, precision, 1 if training else 0, float(p_attn), float(p_drop), float(eps),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, config.dropout_counter_ptr(x.device) if p_on else None,
+                                   int(site_base), 0)
+        ws = _bytes(lib.immtsf_encoder_layer_workspace_bytes(C.byref(cfg)), x.device)
+        out = torch.empty_like(x)
+        ps = _struct(_lib.EncoderLayerParams, params)
+        check(lib.immtsf_encoder_layer_forward(C.byref(cfg), C.byref(ps), ptr(x), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+              "encoder_layer_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.sinks = _sinks_of(params)
+        ctx.save_for_backward(x, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        grads, rets = _grad_buffers(params, ctx.sinks)
+        cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
+        sc = _bytes(lib.immtsf_encoder_layer_scratch_bytes(C.byref(cfg)), x.device)
+        ps, gs = _struct(_lib.EncoderLayerParams, params), _struct(_lib.EncoderLayerParams, grads)
+        check(lib.immtsf_encoder_layer_backward(C.byref(cfg), C.byref(ps), ptr(x), ptr(dout), ptr(dx), ptr(ctx.ws), ctx.ws.numel(),
+                                                ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "encoder_layer_backward")
+        ctx.ws = None
+        return (dx,) + (None,) * 8 + tuple(rets)
+
+
+def encoder_layer_supported(S, D, H):
+    return S <= 8 and D % 4 == 0 and D <= 1024 and D % H == 0 and (D // H) <= 64 and (D // H) % 4 == 0
+
+
+def encoder_layer(lyr, x, training, site_base, precision=None):
+    """lyr: an nn.TransformerEncoderLayer (post-norm, relu, batch_first); x (Bs, S, D)"""
+    at = lyr.self_attn
+    p_attn, p_drop = float(at.dropout), float(lyr.dropout.p)
+    seed = config.next_seed() if training and (p_attn > 0 or p_drop > 0) else 0
+    return EncoderLayerFn.apply(x.float(), at.num_heads, p_attn, p_drop, lyr.norm1.eps, bool(training), config.precision_code(precision),
+                                seed, site_base, at.in_proj_weight, at.in_proj_bias, at.out_proj.weight, at.out_proj.bias,
+                                lyr.norm1.weight, lyr.norm1.bias, lyr.linear1.weight, lyr.linear1.bias, lyr.linear2.weight,
+                                lyr.linear2.bias, lyr.norm2.weight, lyr.norm2.bias)
+
+
 class TPatchDecoderFn(torch.autograd.Function):
     """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction, exact fp32.
     Backward recomputes the forward; parameter gradients accumulate by atomics into one zeroed flat buffer."""

@@ -153,9 +153,14 @@ class tPatchGNN(nn.Module):
         return layer_norm(x + lyr.dropout2(ff), lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps)
 
     def _transformer(self, layer, x):
+        from immtsf.ops import SITE_LAYER_BASE, encoder_layer, encoder_layer_supported
         enc = self.transformer_encoder[layer]
-        for lyr in enc.layers:
-            x = self._encoder_layer_hip(lyr, x)
+        for li, lyr in enumerate(enc.layers):
+            if encoder_layer_supported(x.shape[1], x.shape[2], lyr.self_attn.num_heads):
+                # the whole layer behind one entry point per direction (csrc/encoder_layer.hip): 7 + 15 launches instead of 13 + ~24
+                x = encoder_layer(lyr, x, self.training, SITE_LAYER_BASE + 64 + 8 * (layer * len(enc.layers) + li))
+            else:
+                x = self._encoder_layer_hip(lyr, x)
         return x if enc.norm is None else enc.norm(x)
 
     def _mlp(self, seq, x):

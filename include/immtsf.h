@@ -433,6 +433,42 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
                       float beta2, float eps, float weight_decay, int32_t step, const int64_t* step_dev, float max_norm,
                       const float* norm_scratch, void* twin, immtsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * One post-norm transformer encoder layer over short sequences: nn.TransformerEncoderLayer(d_model = D, nhead = H,
+ * dim_feedforward = F, activation relu, batch_first) as tPatchGNN applies it to the M patches of every variable
+ * (reference models/tPatchGNN.py:118-121 construction, :200-205 use).  x, out (Bs, S, D); S <= 8, D / H <= 64, D % 4 == 0.
+ *   qkv = x in_w^T + in_b ; a = softmax(q k^T / sqrt(D/H)) v ; x1 = LN1(x + drop(a out_w^T + out_b))
+ *   out = LN2(x1 + drop(drop(relu(x1 w1^T + b1)) w2^T + b2))
+ * Dropout (training != 0): p_attn on the attention weights, p_drop on the three nn.Dropout sites, Philox sites
+ * site_base + {0 attention, 1 dropout1, 2 dropout, 3 dropout2}.  7 launches forward, 15 backward.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct immtsf_encoder_layer_cfg {
+    int32_t Bs, S, D, H, F;
+    int32_t precision, training;
+    float p_attn, p_drop, eps;
+    uint64_t seed;
+    const uint64_t* seed_step_dev; /* as in immtsf_fusion_cfg */
+    uint64_t site_base;
+    int32_t grads_prezeroed;       /* backward: the buffers in `grads` read zero already */
+} immtsf_encoder_layer_cfg;
+typedef struct immtsf_encoder_layer_params {
+    float *in_w, *in_b;   /* (3D, D), (3D)  self_attn.in_proj_* */
+    float *out_w, *out_b; /* (D, D), (D)    self_attn.out_proj.* */
+    float *ln1_w, *ln1_b; /* (D), (D)       norm1 */
+    float *w1, *b1;       /* (F, D), (F)    linear1 */
+    float *w2, *b2;       /* (D, F), (D)    linear2 */
+    float *ln2_w, *ln2_b; /* (D), (D)       norm2 */
+} immtsf_encoder_layer_params;
+size_t immtsf_encoder_layer_workspace_bytes(const immtsf_encoder_layer_cfg* cfg);
+size_t immtsf_encoder_layer_scratch_bytes(const immtsf_encoder_layer_cfg* cfg);
+/* the forward workspace holds what backward needs (qkv, a, x1, h with its dropout applied, the LayerNorm statistics) */
+int immtsf_encoder_layer_forward(const immtsf_encoder_layer_cfg* cfg, const immtsf_encoder_layer_params* p, const float* x, float* out,
+                                 void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+/* dout (Bs, S, D) -> dx and every parameter gradient (`grads`: same layout as the parameters, all non-NULL) */
+int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* cfg, const immtsf_encoder_layer_params* p, const float* x,
+                                  const float* dout, float* dx, void* workspace, size_t workspace_bytes, void* scratch,
+                                  size_t scratch_bytes, const immtsf_encoder_layer_params* grads, immtsf_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
  * precision, M, N, K, nprob, nbatch, dyn, grid threads, kernel path) and ms[max]; returns the number of records and resets

@@ -26,7 +26,8 @@ def _t(a, dev):
 
 
 def _rel(a, b, floor=1e-3):
-    a, b = a.detach().double().cpu(), torch.as_tensor(np.asarray(b)).double()
+    b = b.detach().cpu() if torch.is_tensor(b) else torch.as_tensor(np.asarray(b))
+    a, b = a.detach().double().cpu(), b.double()
     assert a.shape == b.shape, (a.shape, b.shape)
     return float((a - b).abs().max() / max(float(b.abs().max()), floor))
 
@@ -336,3 +337,84 @@ def test_patch_and_token_embedding_dropout_and_input_gradient():
     frac = float(kept.float().mean())
     assert abs(frac - 0.75) < 0.02, frac
     assert _rel(od[kept], (o0[kept] / 0.75).cpu()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ fused encoder layer block
+def _l2err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-3 * max(1.0, b.numel() ** 0.5)))
+
+
+@pytest.mark.parametrize("S,D,H,F,precision", [(2, 32, 1, 2048, "fp32"), (5, 48, 4, 96, "fp32"), (2, 32, 1, 2048, "bf16")])
+def test_encoder_layer_block_vs_torch_layer(S, D, H, F, precision):
+    """immtsf_encoder_layer_forward/backward against torch's own nn.TransformerEncoderLayer evaluated in float64 on the CPU
+    (dropout 0): tPatchGNN's shape (S = 2 patches, d_model 32, dim_feedforward 2048) and an odd multi-head one."""
+    dev = _dev()
+    from immtsf import config, ops
+    torch.manual_seed(3)
+    ref = torch.nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=F, dropout=0.0, batch_first=True).double()
+    lyr = torch.nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=F, dropout=0.0, batch_first=True).to(dev)
+    lyr.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = torch.randn(37, S, D)
+    up = torch.randn(37, S, D)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * up.double()).sum().backward()
+    config.precision = precision
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        y = ops.encoder_layer(lyr, xg, True, ops.SITE_LAYER_BASE + 64)
+        (y * up.to(dev)).sum().backward()
+    finally:
+        config.precision = "fp32"
+    err = _rel if precision == "fp32" else _l2err
+    tol_o, tol_g = (1e-4, 3e-4) if precision == "fp32" else (3e-2, 4e-2)
+    errs = {"out": err(y, yr.detach().float()), "dx": err(xg.grad, xr.grad.float())}
+    for (k, p), (_, q) in zip(lyr.named_parameters(), ref.named_parameters()):
+        errs["g." + k] = err(p.grad, q.grad.float())
+    assert errs.pop("out") <= tol_o
+    bad = {k: v for k, v in errs.items() if not v <= tol_g}
+    assert not bad, bad
+
+
+def test_encoder_layer_block_dropout_masks():
+    """training mode, p = 0.3 on all four sites: the block must equal a torch composition that uses the exported Philox
+    keep-masks (attention weights, dropout1, feed-forward dropout, dropout2), forward and backward, fp32 1e-4 / 3e-4."""
+    dev = _dev()
+    from immtsf import config, ops
+    Bs, S, D, H, F, p = 29, 3, 32, 2, 64, 0.3
+    torch.manual_seed(5)
+    config.manual_seed(99)
+    lyr = torch.nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=F, dropout=p, batch_first=True).to(dev).train()
+    x = torch.randn(Bs, S, D, device=dev, requires_grad=True)
+    up = torch.randn(Bs, S, D, device=dev)
+    base = ops.SITE_LAYER_BASE + 64
+    cnt0 = config._counter
+    y = ops.encoder_layer(lyr, x, True, base)
+    (y * up).sum().backward()
+    got = {"dx": x.grad.clone(), **{k: q.grad.clone() for k, q in lyr.named_parameters()}}
+    # the seed the call drew: replay config.next_seed() from the same counter
+    config._counter = cnt0
+    seed = config.next_seed()
+    keep = lambda site, shape: ops.dropout_keep_mask(seed, site, int(np.prod(shape)), p, dev).view(*shape).double() / (1 - p)  # noqa: E731
+    m_att, m1, mf, m2 = keep(base, (Bs, H, S, S)), keep(base + 1, (Bs * S, D)), keep(base + 2, (Bs * S, F)), keep(base + 3, (Bs * S, D))
+    P = {k: q.detach().double().requires_grad_(True) for k, q in lyr.named_parameters()}
+    xd = x.detach().double().requires_grad_(True)
+    E = D // H
+    qkv = (xd.reshape(-1, D) @ P["self_attn.in_proj_weight"].T + P["self_attn.in_proj_bias"]).view(Bs, S, 3, H, E)
+    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+    A = torch.softmax(q @ k.transpose(-1, -2) / E ** 0.5, -1) * m_att
+    a = (A @ v).transpose(1, 2).reshape(Bs * S, D)
+    sa = a @ P["self_attn.out_proj.weight"].T + P["self_attn.out_proj.bias"]
+    ln = torch.nn.functional.layer_norm
+    x1 = ln(xd.reshape(-1, D) + sa * m1, (D,), P["norm1.weight"], P["norm1.bias"], lyr.norm1.eps)
+    h = torch.relu(x1 @ P["linear1.weight"].T + P["linear1.bias"]) * mf
+    ff = h @ P["linear2.weight"].T + P["linear2.bias"]
+    out = ln(x1 + ff * m2, (D,), P["norm2.weight"], P["norm2.bias"], lyr.norm2.eps).view(Bs, S, D)
+    (out * up.double()).sum().backward()
+    assert _rel(y, out.detach().float()) <= 1e-4
+    errs = {"dx": _rel(got["dx"], xd.grad.float())}
+    for k2, q2 in P.items():
+        errs[k2] = _rel(got[k2], q2.grad.float())
+    bad = {k2: v2 for k2, v2 in errs.items() if not v2 <= 3e-4}
+    assert not bad, bad

@@ -263,14 +263,14 @@ class Workload:
         self.fusion = FusionModel(a).to(dev).train()
         # host syncs inside the backbone (data-dependent shapes / prompt strings) rule out graph capture
         self.graphable = c["backbone"] in ("tPatchGNN", "PatchTST")
-        excl = []
+        excl = []      # tPatchGNN's time-embedding parameters: used by the patch encoder AND the decoder, both accumulate
         if c["backbone"] == "tPatchGNN":
             m = self.model
             excl = [m.te_scale.weight, m.te_scale.bias, m.te_periodic.weight, m.te_periodic.bias]
         backbone_params = [p for p in self.model.parameters() if p.requires_grad]
         sinks = (0, 1, 2) if c["backbone"] == "tPatchGNN" else (0, 1)
         self.trainer = FlatTrainer([list(self.fusion.mmf.parameters()), list(self.fusion.ttf.parameters()), backbone_params],
-                                   lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_exclude=excl,
+                                   lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl,
                                    overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
         self.trainer.watch(self.model, self.fusion)

@@ -65,10 +65,11 @@ int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float
 }
 
 int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const float* w, const float* b, const float* dout,
-                             float* dw0, float* db0, float* dw, float* db, float* scratch, immtsf_stream_t stream) {
+                             float* dw0, float* db0, float* dw, float* db, float* scratch, int32_t accumulate,
+                             immtsf_stream_t stream) {
     if (!t || !dout || !dw0 || !db0 || !scratch || d < 1 || (d > 1 && (!w || !b || !dw || !db))) return IMMTSF_EINVAL;
     return launch_time2vec_bwd(t, nullptr, nullptr, rows, d, w, b, dout, d, dw0, db0, dw, db, scratch, 64,
-                               static_cast<hipStream_t>(stream));
+                               static_cast<hipStream_t>(stream), accumulate);
 }
 
 int immtsf_f32_to_bf16(const float* src, void* dst, size_t n, immtsf_stream_t stream) {

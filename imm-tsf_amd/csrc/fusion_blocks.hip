@@ -83,7 +83,7 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dqs = k.take<float>(d);
     s.dq = k.take<float>(d);
     s.dp = k.take<float>(R * c->H);
-    s.red = k.take<float>(64 * (d + dt + 8));
+    s.red = k.take<float>(64 * 3 * d + 64 * 8);
     s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));       // time2vec backward: ~256 packed rows per slab
     s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
     s.bytes = k.bytes();
@@ -238,10 +238,9 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
-    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s));
-    // residual: dQ_param = sum over all (b,t) rows; then only windows with notes feed the attention branch
-    CHECK(launch_colsum(sc.dx.f, nullptr, BT, nullptr, d, d, gr->Q_param, 0, sc.red, s));
-    CHECK(launch_mask_rows(sc.dx.f, BT, d, w.mtxt, T, s, sc.dx.h));
+    // LayerNorm parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with notes feed
+    // the attention branch (rows zeroed, bf16 image written) -- one pass
+    CHECK(launch_colsum3(sc.dz, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s));
     {   // out_proj
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
@@ -254,12 +253,8 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
     CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
                                  SITE_T2V_ATTN, s, sc.dKVp.h));
-    // query path: q = W_q Q_param + b_q, qs = q * scale
-    CHECK(launch_colsum(sc.dqs_part, nullptr, B, nullptr, d, d, sc.dqs, 0, sc.red, s));
-    CHECK(launch_axpy(sc.dqs, scale, sc.dq, d, 0, s));
-    CHECK(launch_outer(sc.dq, p->Q_param, d, d, gr->attn_in_w, d, s));              // rows 0..d of in_proj_weight
-    CHECK(launch_axpy(sc.dq, 1.f, gr->attn_in_b, d, 0, s));
-    CHECK(launch_matvec_t(p->attn_in_w, d, sc.dq, d, d, gr->Q_param, 1, s));        // += W_q^T dq
+    // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq
+    CHECK(launch_query_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
     {   // k|v in-projection
         GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
         set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);

@@ -225,14 +225,20 @@ int immtsf_mmf_xattn_q_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_para
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int d = cfg->d, C = cfg->C, prec = cfg->precision;
     const QFold f = qfold_at(cfg, fold);
+    {   // both folded products split K (12 tiles each otherwise): ONE zero-fill for the two adjacent outputs
+        hipError_t e = hipMemsetAsync(f.WQf, 0, (size_t)2 * d * C * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     {   // W_Qf = W_in,q W_q  (d x C)
         GemmArgs g = gemm_args(d, C, d, d, C, C);
         set_problem(g, 0, p->attn_in_w, p->proj_q_w, f.WQf, nullptr);
+        g.c_prezeroed = 1;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     {   // W_HO = W_res W_out  (C x d);  t = W_res b_out;  b_HO = t + b_res
         GemmArgs g = gemm_args(C, d, d, d, d, d);
         set_problem(g, 0, p->res_w, p->attn_out_w, f.WHO, nullptr);
+        g.c_prezeroed = 1;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     return launch_matvec(p->res_w, d, p->attn_out_b, p->res_b, C, d, f.bHO, nullptr, 1.f, s, f.tHO);
@@ -300,10 +306,25 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = cfg->B, T = cfg->T, d = cfg->d, C = cfg->C, BT = B * T, prec = cfg->precision;
     (void)fold;
+    // the two split-K weight-gradient products below land in scratch (dW_Qf, dW_HO: carved back to back): ONE zero-fill for
+    // both instead of the launcher's own fill per output and per bias gradient
+    int pz = 0;
+    {
+        const size_t nbytes = (size_t)((char*)(sc.dWHO + (size_t)C * d) - (char*)sc.dWQf);
+        hipError_t e = hipMemsetAsync(sc.dWQf, 0, nbytes, s);
+        if (e != hipSuccess) return (int)e;
+        pz = 1;
+        if (!cfg->grads_prezeroed) {       // the bias gradients those two GEMMs also reduce must read zero as well
+            e = hipMemsetAsync(gr->res_b, 0, (size_t)C * sizeof(float), s);
+            if (e == hipSuccess) e = hipMemsetAsync(gr->attn_in_b, 0, (size_t)d * sizeof(float), s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
     CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
     {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
         set_problem(h, 0, sc.ddelta, w.O, sc.dWHO, nullptr, gr->res_b);
+        h.c_prezeroed = pz;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
     CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
@@ -322,7 +343,8 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
     }
     {   // dW_Qf = dQi^T Y, d b_q = column sums of dQi;  then dW_in,q = dW_Qf W_q^T, dW_q = W_in,q^T dW_Qf
         GemmArgs h = gemm_args(d, C, BT, d, C, C);
-        set_problem(h, 0, sc.dQi, Y_ts, sc.dWQf, nullptr, gr->attn_in_b);      // (scratch output: the launcher zero-fills if it splits)
+        set_problem(h, 0, sc.dQi, Y_ts, sc.dWQf, nullptr, gr->attn_in_b);
+        h.c_prezeroed = pz;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
         GemmArgs g = gemm_args(d, d, C, C, C, d);
         set_problem(g, 0, sc.dWQf, p->proj_q_w, gr->attn_in_w, nullptr);

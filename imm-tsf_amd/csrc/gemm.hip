@@ -879,7 +879,7 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     const int nbz = g.nprob * (g.nbatch > 1 ? g.nbatch : 1);
 
     // ---- split-K: only for plain overwrite epilogues on a dense C (the launcher zero-fills it)
-    const bool can_split = all_c && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = all_c && !g.no_split && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && g.nbatch <= 1 && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     // weight-gradient GEMMs with 96..230 output tiles (768x768 .. 768x1152 at the fusion dims): the wave-specialised
     // kernel, unsplit -- its consumer waves never wait on global loads (the k-major fragment reads carry a conservative

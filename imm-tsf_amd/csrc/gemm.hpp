@@ -48,6 +48,7 @@ struct GemmArgs {
     int ld_ref;
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
+    int no_split;          // never split K (tiny products whose zero-fill + atomics cost more than the serial K loop)
     // optional dropout on the result (after the activation): element (m, n) uses Philox index m * N + n of site epi_site
     DropCfg epi_drop;
     uint64_t epi_site;

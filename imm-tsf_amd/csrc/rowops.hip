@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
 
 // one wave per feature column: lanes stride over the slabs, shuffle-reduce
 __global__ __launch_bounds__(256) void time2vec_bwd_final_kernel(const float* __restrict__ partial, int d_tau,
-                                                                  float* dw0, float* db0, float* dw, float* db, int nsl) {
+                                                                  float* dw0, float* db0, float* dw, float* db, int nsl,
+                                                                  int accumulate) {
     const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= d_tau) return;
     float aw = 0.f, ab = 0.f;
@@ -187,9 +188,9 @@ __global__ __launch_bounds__(256) void time2vec_bwd_final_kernel(const float* __
     }
     aw = wave_sum(aw);
     ab = wave_sum(ab);
-    if (lane == 0) {
-        if (j == 0) { dw0[0] = aw; db0[0] = ab; }
-        else { dw[j - 1] = aw; db[j - 1] = ab; }
+    if (lane == 0) {        // accumulate: the parameters have a second user this step whose backward adds into the same buffers
+        if (j == 0) { dw0[0] = accumulate ? dw0[0] + aw : aw; db0[0] = accumulate ? db0[0] + ab : ab; }
+        else { dw[j - 1] = accumulate ? dw[j - 1] + aw : aw; db[j - 1] = accumulate ? db[j - 1] + ab : ab; }
     }
 }
 
@@ -235,6 +236,55 @@ __global__ __launch_bounds__(256) void colsum2_partial_kernel(const float* __res
         partial[((size_t)slab * 2 + 0) * N + n] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
         partial[((size_t)slab * 2 + 1) * N + n] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
     }
+}
+
+// LayerNorm backward's three column reductions in one pass over the rows -- sum X*Y (dgamma), sum X (dbeta), sum Z (the
+// residual vector's gradient) -- which also zeroes Z's rows whose row_flag[r / flag_div] == 0 and writes Z's bf16 image
+// (what the next GEMM reads): colsum2 + colsum + mask_rows = 5 launches otherwise.  partial[slab][3][N].
+__global__ __launch_bounds__(256) void colsum3_partial_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                               float* __restrict__ Z, int M, int N, int ld, float* __restrict__ partial,
+                                                               const unsigned char* __restrict__ row_flag, int flag_div,
+                                                               bf16_t* __restrict__ Zh) {
+    __shared__ float red[3][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx, slab = blockIdx.y, nsl = gridDim.y;
+    const int rps = (M + nsl - 1) / nsl;
+    const int r0 = slab * rps, r1 = min(M, r0 + rps);
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (n < N)
+        for (int r = r0 + ty; r < r1; r += 4) {
+            const size_t o = (size_t)r * ld + n;
+            const float x = X[o];
+            float z = Z[o];
+            a = fmaf(x, Y[o], a);
+            b += x;
+            c += z;
+            if (row_flag && !row_flag[r / flag_div]) { z = 0.f; Z[o] = 0.f; }
+            if (Zh) Zh[o] = (bf16_t)z;
+        }
+    red[0][ty][tx] = a;
+    red[1][ty][tx] = b;
+    red[2][ty][tx] = c;
+    __syncthreads();
+    if (ty == 0 && n < N)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            partial[((size_t)slab * 3 + k) * N + n] = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
+}
+
+__global__ __launch_bounds__(256) void colsum3_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
+                                                             float* __restrict__ out_x, float* __restrict__ out_z, int nsl) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int s = 0; s < nsl; ++s) {
+        a += partial[((size_t)s * 3 + 0) * N + n];
+        b += partial[((size_t)s * 3 + 1) * N + n];
+        c += partial[((size_t)s * 3 + 2) * N + n];
+    }
+    out_xy[n] = a;
+    out_x[n] = b;
+    out_z[n] = c;
 }
 
 // narrow matrices (N <= 32 columns, e.g. LayerNorm over the C series variables): ONE workgroup, CT column lanes x
@@ -495,6 +545,42 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src
     dst[i] = accumulate ? dst[i] + v : v;
 }
 
+// Backward of a learned query q = W_q Q + b_q, qs = scale * q (TTF_T2V_XAttn's single query) in ONE launch, from the
+// per-window partial gradients dqs_part (B, d):
+//   dq = scale * sum_b dqs_part[b] ;  dW_q = dq Q^T ;  db_q = dq ;  dQ += W_q^T dq
+// (colsum partial + final, axpy, outer, axpy, transposed mat-vec: six launches of ~5 us each otherwise.)
+// grid ceil(d / QB_ROWS): a workgroup owns QB_ROWS rows i: dq[i] (16 lanes per row over the B windows), those rows of dW_q and
+// db_q, and its rows' share of W_q^T dq, added into dQ with one atomic per column.
+constexpr int QB_ROWS = 16;
+__global__ __launch_bounds__(256) void query_bwd_kernel(const float* __restrict__ dqs_part, int B, int d, float scale,
+                                                         const float* __restrict__ Wq, int ldw, const float* __restrict__ Q,
+                                                         float* __restrict__ dWq, int ldg, float* __restrict__ dbq,
+                                                         float* __restrict__ dQ) {
+    __shared__ float dq[QB_ROWS];     // only this workgroup's rows of dq enter its share of all three results
+    const int tid = threadIdx.x, i0 = blockIdx.x * QB_ROWS, rows = min(QB_ROWS, d - i0);
+    {
+        const int r = tid >> 4, part = tid & 15;      // 16 lanes per row split the B windows
+        float a = 0.f;
+        if (r < rows)
+            for (int b = part; b < B; b += 16) a += dqs_part[(size_t)b * d + i0 + r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (part == 0 && r < rows) dq[r] = a * scale;
+    }
+    __syncthreads();
+    if (tid < rows) dbq[i0 + tid] = dq[tid];
+    for (int j = tid; j < d; j += 256) {
+        const float qj = Q[j];
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const float g = dq[r];
+            dWq[(size_t)(i0 + r) * ldg + j] = g * qj;
+            a = fmaf(Wq[(size_t)(i0 + r) * ldw + j], g, a);
+        }
+        atomicAdd(dQ + j, a);
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ dst, float v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = v;
 }
@@ -551,12 +637,12 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
-                        float* db, float* scratch, int nslabs, hipStream_t s) {
+                        float* db, float* scratch, int nslabs, hipStream_t s, int accumulate) {
     if (nslabs < 1) nslabs = kSlabs;
     hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), nslabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
                        dfeat, ld, scratch, max_rows);
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 4)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs);
+    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 4)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs, accumulate);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -584,6 +670,18 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
     hipLaunchKernelGGL(colsum2_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, N, ld, scratch);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum2_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out_xy, out_x);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
+                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s) {
+    if (N <= 0) return IMMTSF_OK;
+    const int nsl = M >= 1024 ? 64 : kSlabs;
+    hipLaunchKernelGGL(colsum3_partial_kernel, dim3(cdiv(N, 64), nsl), dim3(256), 0, s, X, Y, Z, M, N, ld, scratch, row_flag,
+                       flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(Zh));
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum3_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out_xy, out_x, out_z, nsl);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -643,6 +741,15 @@ int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols,
 int launch_outer(const float* a, const float* b, int rows, int cols, float* out, int ld, hipStream_t s) {
     const long n = (long)rows * cols;
     hipLaunchKernelGGL(outer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, rows, cols, out, ld);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_query_bwd(const float* dqs_part, int B, int d, float scale, const float* Wq, int ldw, const float* Q, float* dWq, int ldg,
+                     float* dbq, float* dQ, hipStream_t s) {
+    if (d <= 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(query_bwd_kernel, dim3(cdiv(d, QB_ROWS)), dim3(256), 0, s, dqs_part, B, d, scale, Wq, ldw, Q,
+                       dWq, ldg, dbq, dQ);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

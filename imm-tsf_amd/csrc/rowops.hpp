@@ -21,13 +21,17 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 // rowmap/total may be null (rows 0..max_rows-1 used directly)
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
-                        float* db, float* scratch, int nslabs, hipStream_t s);
+                        float* db, float* scratch, int nslabs, hipStream_t s, int accumulate = 0);
 // out[n] = sum_{m < M} X[m,n] * (Y ? Y[m,n] : 1)   (M may come from *dyn).  scratch >= 32*N floats.
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
                   float* scratch, hipStream_t s);
 // out_xy[n] = sum_m X*Y, out_x[n] = sum_m X in one pass (LayerNorm's gamma / beta gradients).  scratch >= 64*N floats.
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
                    hipStream_t s);
+// out_xy = sum_m X*Y, out_x = sum_m X, out_z = sum_m Z in one pass; afterwards Z's rows with row_flag[m / flag_div] == 0 are zero
+// (row_flag may be null) and Zh (may be null) holds Z's bf16 image.  scratch >= 64 * 3 * N floats.
+int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
+                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s);
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr,      // zh: bf16 z (z may be null)
@@ -47,6 +51,10 @@ int launch_matvec_t(const float* W, int ldw, const float* x, int rows, int cols,
 int launch_outer(const float* a, const float* b, int rows, int cols, float* out, int ld, hipStream_t s);
 // dst = alpha*src (n elements)  /  dst += alpha*src
 int launch_axpy(const float* src, float alpha, float* dst, int n, int accumulate, hipStream_t s);
+// backward of q = W_q Q + b_q, qs = scale q from per-window partials dqs_part (B, d): dW_q (d, d; written), db_q (d; written),
+// dQ (d; ADDED to what it holds)
+int launch_query_bwd(const float* dqs_part, int B, int d, float scale, const float* Wq, int ldw, const float* Q, float* dWq, int ldg,
+                     float* dbq, float* dQ, hipStream_t s);
 int launch_fill(float* dst, float v, size_t n, hipStream_t s);
 // keep-mask export for tests: out[i] = 1 if element i of `site` is kept
 int launch_dropout_mask(uint64_t seed, uint64_t site, size_t n, float p, unsigned char* out, hipStream_t s);

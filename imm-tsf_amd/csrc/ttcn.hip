@@ -261,7 +261,7 @@ int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, 
 int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
                          const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
                          const float* dout, int32_t out_ld, void* workspace, size_t workspace_bytes, void* scratch,
-                         size_t scratch_bytes, const immtsf_ttcn_params* gr, immtsf_stream_t stream) {
+                         size_t scratch_bytes, const immtsf_ttcn_params* gr, int32_t te_accumulate, immtsf_stream_t stream) {
     if (!tt || !mask || !p || !out || !dout || !gr || !workspace || !scratch || out_ld < ttcn_dim) return IMMTSF_EINVAL;
     if (bad_dims(P, L, te_dim, ttcn_dim)) return IMMTSF_EINVAL;
     if (P == 0) return IMMTSF_OK;
@@ -272,7 +272,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g_immtsf_ttcn_fused && ttcn_full_supported(precision, L, d.F, d.K))
         return launch_ttcn_full_bwd(P, L, d.F, d.K, x, tt, mask, p, w.pack, w.ctr, out, dout, out_ld, sc.slab, gr,
-                                    static_cast<hipStream_t>(stream));
+                                    static_cast<hipStream_t>(stream), te_accumulate);
     {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once (split-K GEMMs / atomics)
         const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
         hipError_t e = hipMemsetAsync(sc.gW1p, 0, nbytes, s);
@@ -323,7 +323,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
     IMMTSF_LAUNCH_CHECK();
     // time-embedding parameters: same reduction as Time2Vec's backward, on dX[:, 1:F] with the slot times
     return launch_time2vec_bwd(tt, nullptr, nullptr, d.R, d.F - 1, p->te_per_w, p->te_per_b, sc.dX + 1, d.Fp, gr->te_scale_w,
-                               gr->te_scale_b, gr->te_per_w, gr->te_per_b, sc.red, 256, s);
+                               gr->te_scale_b, gr->te_per_w, gr->te_per_b, sc.red, 256, s, te_accumulate);
 }
 
 }  // extern "C"

@@ -13,4 +13,4 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
                          float* pack, float* ctr, float* out, int out_ld, int flag_col, hipStream_t s);
 int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
                          const float* pack, const float* ctr, const float* out, const float* dout, int out_ld, float* slab,
-                         const immtsf_ttcn_params* gr, hipStream_t s);
+                         const immtsf_ttcn_params* gr, hipStream_t s, int te_acc = 0);

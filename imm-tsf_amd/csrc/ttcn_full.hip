@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void ttcn_pack_kernel(int F, int K, PackIn q, 
 }
 
 struct UnpackOut { float *W1, *b1, *W2, *b2, *W3, *b3, *ws, *bs, *wp, *bp, *Tb; };
-__global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const float* __restrict__ slab, UnpackOut g) {
+__global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const float* __restrict__ slab, UnpackOut g, int te_acc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const Slab sl = slab_of(F);
     if (i < K * F) g.W1[i] = slab[sl.W1 + (i / F) * KP + i % F];
@@ -476,8 +476,9 @@ __global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const fl
     }
     if (i < F * K) { const int k = i / F, f = i % F; g.b3[i] = slab[sl.b3 + f * 32 + k]; }
     if (i < K) { g.b1[i] = slab[sl.b1 + i]; g.b2[i] = slab[sl.b2 + i]; g.Tb[i] = slab[sl.Tb + i]; }
-    if (i == 0) { g.ws[0] = slab[sl.te + 1]; g.bs[0] = slab[sl.te + KP + 1]; }
-    if (i < F - 2) { g.wp[i] = slab[sl.te + 2 + i]; g.bp[i] = slab[sl.te + KP + 2 + i]; }
+    // te_acc: the time-embedding parameters are shared with the decoder's LearnableTE, whose backward adds into the same buffers
+    if (i == 0) { g.ws[0] = (te_acc ? g.ws[0] : 0.f) + slab[sl.te + 1]; g.bs[0] = (te_acc ? g.bs[0] : 0.f) + slab[sl.te + KP + 1]; }
+    if (i < F - 2) { g.wp[i] = (te_acc ? g.wp[i] : 0.f) + slab[sl.te + 2 + i]; g.bp[i] = (te_acc ? g.bp[i] : 0.f) + slab[sl.te + KP + 2 + i]; }
 }
 
 size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + 64; }
@@ -532,7 +533,7 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
 
 int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
                          const float* pack, const float* ctr, const float* out, const float* dout, int out_ld, float* slab,
-                         const immtsf_ttcn_params* gr, hipStream_t s) {
+                         const immtsf_ttcn_params* gr, hipStream_t s, int te_acc) {
     const FD d{P, L, F, K, F * 32};
     const PackPtrs q = pack_ptrs(const_cast<float*>(pack), F);
     hipError_t e = hipMemsetAsync(slab, 0, slab_of(F).total * sizeof(float), s);
@@ -556,7 +557,7 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(cdiv(F * K * K, 256)), dim3(256), 0, s, F, K, slab,
                        UnpackOut{gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b,
-                                 gr->T_bias});
+                                 gr->T_bias}, te_acc);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -127,7 +127,7 @@ _PROTOS = {
                                       _P(TTCNParams), c_f32p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_ttcn_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
                                        _P(TTCNParams), c_f32p, c_f32p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p,
-                                       C.c_size_t, _P(TTCNParams), c_stream]),
+                                       C.c_size_t, _P(TTCNParams), C.c_int32, c_stream]),
     "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_masked_mse": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float,
                                     c_stream]),
@@ -157,7 +157,7 @@ _PROTOS = {
                                          c_f32p, c_f32p, c_f32p, C.c_int32, c_stream]),
     "immtsf_time2vec_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_time2vec_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                           c_f32p, c_f32p, c_stream]),
+                                           c_f32p, c_f32p, C.c_int32, c_stream]),
     "immtsf_bf16_twin_register": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t]),
     "immtsf_bf16_twin_unregister": (C.c_int, [c_f32p]),
     "immtsf_bf16_twin_enable": (C.c_int, [C.c_int32]),

@@ -42,6 +42,12 @@ def _sinks_of(params):
     return [None if p is None else getattr(p, "_immtsf_grad_sink", None) for p in params]
 
 
+def _shared(params, sinks):
+    """True when every given parameter writes to a sink that several HIP backward ops ADD into (FlatTrainer sink_shared:
+    the buffers are zero-filled once per step and every writer accumulates)."""
+    return all(s is not None and getattr(p, "_immtsf_grad_shared", False) for p, s in zip(params, sinks))
+
+
 def _prezeroed(params, sinks):
     """1 when every gradient of the block goes to a sink that its owner zero-fills each step (FlatTrainer)."""
     ok = all(p is None or (s is not None and getattr(p, "_immtsf_grad_prezeroed", False)) for p, s in zip(params, sinks))
@@ -509,11 +515,12 @@ class TTCNPatchEncodeFn(torch.autograd.Function):
         x, tt, mask, out, *params = ctx.saved_tensors
         P, L, te_dim, K, precision, ld = ctx.dims
         dout = dout.contiguous()
+        te_acc = _shared(params[:4], ctx.sinks[:4])       # time-embedding parameters shared with the decoder's LearnableTE
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttcn_scratch_bytes(P, L, te_dim, K), x.device)
         ps, gs = _struct(TTCNParams, params), _struct(TTCNParams, grads)
         check(lib.immtsf_ttcn_backward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout), ld,
-                                       ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+                                       ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), 1 if te_acc else 0, stream_ptr()),
               "ttcn_backward")
         return (None, None, None, None, None) + tuple(rets)
 
@@ -835,13 +842,20 @@ class Time2VecFn(torch.autograd.Function):
         t1, w0, b0, w, b = ctx.saved_tensors
         d = ctx.d
         g = dout.contiguous().reshape(-1, d)
-        dw0, db0 = torch.empty_like(w0), torch.empty_like(b0)
-        dw = torch.empty_like(w) if w is not None else None
-        db = torch.empty_like(b) if b is not None else None
+        params = (w0, b0, w, b)
+        sinks = _sinks_of(params)
+        acc = w is not None and _shared(params, sinks)      # parameters shared with another HIP op (tPatchGNN: the TTCN encoder)
+        if acc:
+            (dw0, db0, dw, db), rets = sinks, (None,) * 4
+        else:
+            dw0, db0 = torch.empty_like(w0), torch.empty_like(b0)
+            dw = torch.empty_like(w) if w is not None else None
+            db = torch.empty_like(b) if b is not None else None
+            rets = (dw0, db0, dw, db)
         scratch = torch.empty(2 * 64 * d, dtype=torch.float32, device=g.device)
         check(lib.immtsf_time2vec_backward(ptr(t1), t1.numel(), d, ptr(w), ptr(b), ptr(g), ptr(dw0), ptr(db0), ptr(dw), ptr(db),
-                                           ptr(scratch), stream_ptr()), "time2vec_backward")
-        return None, dw0, db0, dw, db
+                                           ptr(scratch), 1 if acc else 0, stream_ptr()), "time2vec_backward")
+        return (None,) + tuple(rets)
 
 
 def time2vec(t, w0, b0, w, b):

@@ -32,7 +32,7 @@ class FlatTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, group=None, overlap: bool = True,
                  sink_buckets: Sequence[int] = (), device_step: bool = False, bf16_twin: Optional[bool] = None,
                  grad_wire: str = "fp32", sink_exclude: Iterable[torch.nn.Parameter] = (), shard_optimizer: bool = False,
-                 param_wire: str = "fp32"):
+                 param_wire: str = "fp32", sink_shared: Iterable[torch.nn.Parameter] = ()):
         """buckets: parameter groups in the order their gradients become final during backward (first = earliest).
         sink_buckets: indices of buckets whose gradients are written by the HIP backward directly (fusion blocks; the
         backbone too when every op that uses its parameters is an immtsf.ops function).  A sink parameter must be used by
@@ -40,6 +40,9 @@ class FlatTrainer:
         sink_exclude: parameters of sink buckets that are used more than once or by stock torch ops (e.g. tPatchGNN's
         time-embedding weights, shared by the patch encoder and the decoder's time features) -- autograd accumulates those
         as usual and they are copied into the flat buffer after the backward.
+        sink_shared: parameters of sink buckets used by SEVERAL immtsf.ops functions that support accumulation
+        (ops.time2vec and ops.ttcn_patch_encode: tPatchGNN's four time-embedding parameters): every user ADDS its
+        gradient into the zero-filled slice, so no autograd accumulation kernels run for them either.
         grad_wire: "fp32" (exact: the sum of the ranks' gradients) or "bf16" (the gradients are rounded to bf16 for the
         all-reduce and widened again: half the bytes on xGMI -- the collective is per-link bandwidth bound -- at the
         cost of ~3 significant digits per element, which clip + Adam's normalised update tolerates)."""
@@ -95,6 +98,7 @@ class FlatTrainer:
         self._views = []
         self._collected = True
         excl = {id(p) for p in sink_exclude}
+        shared = {id(p) for p in sink_shared}
         self._autograd_owned = []        # (parameter, flat gradient view) pairs autograd accumulates itself
         off = 0
         for bi, b in enumerate(self.buckets):
@@ -109,6 +113,7 @@ class FlatTrainer:
                 if bi in sink_buckets and id(p) not in excl:
                     p._immtsf_grad_sink = gview
                     p._immtsf_grad_prezeroed = True   # zero_grad() memsets the whole flat buffer every step
+                    p._immtsf_grad_shared = id(p) in shared
                 else:
                     self._autograd_owned.append((p, gview))
                 p.grad = gview              # optimizers / clip utilities that look at .grad still work

@@ -236,12 +236,14 @@ size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t t
 int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
                         const float* tt, const float* mask, const immtsf_ttcn_params* p, float* out, int32_t out_ld,
                         int32_t flag_col, void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
-/* dout (P,K) -> every parameter gradient (overwritten).  No gradient flows to x / tt / mask (data).
+/* dout (P,K) -> every parameter gradient (overwritten; te_accumulate != 0: the four time-embedding gradients are ADDED to
+ * what their buffers hold -- the decoder's LearnableTE shares those parameters and its backward adds into the same, zero-
+ * initialised buffers).  No gradient flows to x / tt / mask (data).
  * NOTE: consumes the workspace (the saved softmax weights are overwritten): one backward per forward. */
 int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,
                          const float* tt, const float* mask, const immtsf_ttcn_params* p, const float* out,
                          const float* dout, int32_t out_ld, void* workspace, size_t workspace_bytes, void* scratch,
-                         size_t scratch_bytes, const immtsf_ttcn_params* grads, immtsf_stream_t stream);
+                         size_t scratch_bytes, const immtsf_ttcn_params* grads, int32_t te_accumulate, immtsf_stream_t stream);
 
 /* ---- tPatchGNN adaptive-graph stage (models/tPatchGNN.py:205-238; gcn/nconv/linear :29-84), one (window, patch)
  * cell per workgroup, everything in LDS.  x, out, dout, dx: (B, N, M, D) contiguous.  Pointers in state_dict order. */
@@ -352,7 +354,8 @@ int immtsf_linear_backward(int32_t precision, const float* x, const float* W, co
 int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float* w0, const float* b0, const float* w,
                             const float* b, float* out, immtsf_stream_t stream);
 int immtsf_time2vec_backward(const float* t, int32_t rows, int32_t d, const float* w, const float* b, const float* dout,
-                             float* dw0, float* db0, float* dw, float* db, float* scratch, immtsf_stream_t stream);
+                             float* dw0, float* db0, float* dw, float* db, float* scratch, int32_t accumulate,
+                             immtsf_stream_t stream);
 /* bf16 twins.  In bf16 precision the MFMA operands are rounded to bf16 anyway; a registered fp32 range
  * [base, base+count) whose owner keeps a bf16 copy (same element offsets) lets every GEMM whose B operand lies inside
  * it -- the weights of the forward (NT) and data-gradient (NN) GEMMs -- fetch half as many bytes with no conversion.

@@ -49,7 +49,7 @@ def main():
     model = tPatchGNN(a).to(dev).train()
     fusion = FusionModel(a).to(dev).train()
     trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
-                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=None, sink_buckets=(0, 1, 2), sink_exclude=[model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias], overlap=False,
+                          lr=1e-3, weight_decay=0.0, max_norm=1.0, group=None, sink_buckets=(0, 1, 2), sink_shared=[model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias], overlap=False,
                           device_step=True)
     cpu_batch, _ = bench.synth_batch(100, bench.B_PER_GPU)
     b = {k: v.to(dev) for k, v in cpu_batch.items()}

@@ -473,34 +473,40 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(float* __restrict
 // length 2.  As batched GEMMs + a row softmax that is 3 launches forward and 5 backward of ~8 us each for 2x2 score
 // matrices; here one thread owns one (sequence, head, position), everything in registers, one launch per direction.
 // Same arithmetic and the same dropout indexing (site, ((b*H+h)*L + l)*L + s) as the GEMM + softmax_rows path.
-constexpr int SHORT_L = 8;
-constexpr int SHORT_EV = 16;      // float4 chunks per row: head dim <= 64, multiple of 4
+constexpr int SHORT_L = 8;       // longest sequence
+constexpr int SHORT_EV = 16;     // float4 chunks per row: head dim <= 64, multiple of 4
+// The kernels are instantiated for (SL, SEV) = bounds on (L, E / 4): every per-thread array and unrolled loop is sized by
+// them, and the (8, 16) instance alone needs 2.9 KB of scratch per lane in the backward (25 us at tPatchGNN's L = 2, E = 32).
 
 struct ShortDims { int B, L, H, E; };
 
 // one row of E floats as (predicated) float4 chunks: every chunk is an independent 16-byte load, issued back to back
-__device__ __forceinline__ void short_load(const float* __restrict__ p, int ev, float4 (&r)[SHORT_EV]) {
+template <int SEV>
+__device__ __forceinline__ void short_load(const float* __restrict__ p, int ev, float4 (&r)[SEV]) {
 #pragma unroll
-    for (int c = 0; c < SHORT_EV; ++c) r[c] = c < ev ? reinterpret_cast<const float4*>(p)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < SEV; ++c) r[c] = c < ev ? reinterpret_cast<const float4*>(p)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
-__device__ __forceinline__ float short_dot(const float4 (&a)[SHORT_EV], const float4 (&b)[SHORT_EV]) {
+template <int SEV>
+__device__ __forceinline__ float short_dot(const float4 (&a)[SEV], const float4 (&b)[SEV]) {
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < SHORT_EV; ++c) {
+    for (int c = 0; c < SEV; ++c) {
         s = fmaf(a[c].x, b[c].x, s); s = fmaf(a[c].y, b[c].y, s); s = fmaf(a[c].z, b[c].z, s); s = fmaf(a[c].w, b[c].w, s);
     }
     return s;
 }
-__device__ __forceinline__ void short_axpy(float w, const float4 (&x)[SHORT_EV], float4 (&acc)[SHORT_EV]) {
+template <int SEV>
+__device__ __forceinline__ void short_axpy(float w, const float4 (&x)[SEV], float4 (&acc)[SEV]) {
 #pragma unroll
-    for (int c = 0; c < SHORT_EV; ++c) {
+    for (int c = 0; c < SEV; ++c) {
         acc[c].x = fmaf(w, x[c].x, acc[c].x); acc[c].y = fmaf(w, x[c].y, acc[c].y);
         acc[c].z = fmaf(w, x[c].z, acc[c].z); acc[c].w = fmaf(w, x[c].w, acc[c].w);
     }
 }
-__device__ __forceinline__ void short_store(float* __restrict__ p, int ev, float scale, const float4 (&r)[SHORT_EV]) {
+template <int SEV>
+__device__ __forceinline__ void short_store(float* __restrict__ p, int ev, float scale, const float4 (&r)[SEV]) {
 #pragma unroll
-    for (int c = 0; c < SHORT_EV; ++c)
+    for (int c = 0; c < SEV; ++c)
         if (c < ev) reinterpret_cast<float4*>(p)[c] = make_float4(scale * r[c].x, scale * r[c].y, scale * r[c].z, scale * r[c].w);
 }
 
@@ -510,14 +516,16 @@ __device__ __forceinline__ size_t short_off(const ShortDims& d, int b, int l, in
 }
 
 // scores of query row l of (b, h): p[s] = softmax_s(scale q[l].k[s]) (causal: s <= l), a[s] = p[s] * dropscale
-__device__ __forceinline__ void short_row(const ShortDims& d, const float* __restrict__ qkv, int b, int h, int l, float scale,
-                                          int causal, const DropCfg& drop, uint64_t site, float (&p)[SHORT_L], float (&a)[SHORT_L]) {
+// (b indexes `qkv`, which may be a staged copy of a few sequences; bg is the sequence's global index, for the dropout row)
+template <int SL, int SEV>
+__device__ __forceinline__ void short_row(const ShortDims& d, const float* __restrict__ qkv, int b, int bg, int h, int l, float scale,
+                                          int causal, const DropCfg& drop, uint64_t site, float (&p)[SL], float (&a)[SL]) {
     const int ev = d.E >> 2, Sv = causal ? l + 1 : d.L;
-    float4 q[SHORT_EV], k[SHORT_EV];
+    float4 q[SEV], k[SEV];
     short_load(qkv + short_off(d, b, l, 0, h), ev, q);
     float m = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < SHORT_L; ++s) {
+    for (int s = 0; s < SL; ++s) {
         float acc = 0.f;
         if (s < Sv) {
             short_load(qkv + short_off(d, b, s, 1, h), ev, k);
@@ -528,59 +536,85 @@ __device__ __forceinline__ void short_row(const ShortDims& d, const float* __res
     }
     float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < SHORT_L; ++s) {
+    for (int s = 0; s < SL; ++s) {
         p[s] = s < Sv ? expf(p[s] - m) : 0.f;
         sum += p[s];
     }
     const float inv = 1.f / sum;
-    const uint64_t row = ((uint64_t)b * d.H + h) * d.L + l;
+    const uint64_t row = ((uint64_t)bg * d.H + h) * d.L + l;
 #pragma unroll
-    for (int s = 0; s < SHORT_L; ++s) {
+    for (int s = 0; s < SL; ++s) {
         p[s] *= inv;
         a[s] = s < d.L ? p[s] * dropout_scale(drop, site, row * d.L + s) : 0.f;
     }
 }
 
-__global__ __launch_bounds__(256) void attn_short_fwd_kernel(ShortDims d, const float* __restrict__ qkv, float scale, int causal,
-                                                              DropCfg drop, uint64_t site, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.B * d.H * d.L) return;
-    const int l = i % d.L, h = (i / d.L) % d.H, b = i / (d.L * d.H), ev = d.E >> 2;
-    float p[SHORT_L], a[SHORT_L];
-    short_row(d, qkv, b, h, l, scale, causal, drop, site, p, a);
-    float4 acc[SHORT_EV], v[SHORT_EV];
+template <int SL, int SEV>
+__device__ __forceinline__ void attn_short_fwd_body(const ShortDims& d, const float* __restrict__ qkv, int b, int bg, int h, int l,
+                                                    float scale, int causal, const DropCfg& drop, uint64_t site,
+                                                    float* __restrict__ out) {
+    const int ev = d.E >> 2;
+    float p[SL], a[SL];
+    short_row<SL, SEV>(d, qkv, b, bg, h, l, scale, causal, drop, site, p, a);
+    float4 acc[SEV], v[SEV];
 #pragma unroll
-    for (int c = 0; c < SHORT_EV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < SEV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int s = 0; s < SHORT_L; ++s)
+    for (int s = 0; s < SL; ++s)
         if (s < d.L) {
             short_load(qkv + short_off(d, b, s, 2, h), ev, v);
             short_axpy(a[s], v, acc);
         }
-    short_store(out + (((size_t)b * d.L + l) * d.H + h) * d.E, ev, 1.f, acc);
+    short_store(out + (((size_t)bg * d.L + l) * d.H + h) * d.E, ev, 1.f, acc);
+}
+
+template <int SL, int SEV>
+__global__ __launch_bounds__(256) void attn_short_fwd_kernel(ShortDims d, const float* __restrict__ qkv, float scale, int causal,
+                                                              DropCfg drop, uint64_t site, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.B * d.H * d.L) return;
+    const int l = i % d.L, h = (i / d.L) % d.H, b = i / (d.L * d.H);
+    attn_short_fwd_body<SL, SEV>(d, qkv, b, b, h, l, scale, causal, drop, site, out);
+}
+
+// Staged form: a thread's work is a chain of ~(3 L + 2) dependent row loads, and with one thread per (sequence, head,
+// position) the whole launch is a handful of waves -- pure load latency (12 us forward, 25 us backward at 512 sequences of
+// 2).  Here a workgroup first copies its SB sequences' qkv (and dout) rows -- contiguous in memory -- into LDS with one
+// round of coalesced 16-byte loads, and the per-thread chains then run against LDS.  grid ceil(B / SB).
+template <int SL, int SEV>
+__global__ __launch_bounds__(256) void attn_short_fwd_staged_kernel(ShortDims d, const float* __restrict__ qkv, float scale, int causal,
+                                                                     DropCfg drop, uint64_t site, float* __restrict__ out, int SB) {
+    extern __shared__ __attribute__((aligned(16))) float st[];
+    const int b0 = blockIdx.x * SB, nb = min(SB, d.B - b0), per = d.L * 3 * d.H * d.E;
+    const float4* src = reinterpret_cast<const float4*>(qkv + (size_t)b0 * per);
+    for (int x = threadIdx.x; x < nb * per / 4; x += 256) reinterpret_cast<float4*>(st)[x] = src[x];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= nb * d.H * d.L) return;
+    const int l = t % d.L, h = (t / d.L) % d.H, bl = t / (d.L * d.H);
+    attn_short_fwd_body<SL, SEV>(d, st, bl, b0 + bl, h, l, scale, causal, drop, site, out);
 }
 
 // thread (b, h, i): as query row i -> dq[i]; as key / value row i -> dk[i], dv[i] (recomputing every query row's softmax)
-__global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                              float scale, int causal, DropCfg drop, uint64_t site,
-                                                              float* __restrict__ dqkv) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= d.B * d.H * d.L) return;
-    const int i = t % d.L, h = (t / d.L) % d.H, b = t / (d.L * d.H), ev = d.E >> 2;
-    float wk[SHORT_L], wv[SHORT_L], wq[SHORT_L];      // dS[l][i] (l = 0..), A[l][i], dS[i][s]
+template <int SL, int SEV>
+__device__ __forceinline__ void attn_short_bwd_body(const ShortDims& d, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                    int b, int bg, int h, int i, float scale, int causal, const DropCfg& drop,
+                                                    uint64_t site, float* __restrict__ dqkv) {
+    const int ev = d.E >> 2;
+    float wk[SL], wv[SL], wq[SL];      // dS[l][i] (l = 0..), A[l][i], dS[i][s]
 #pragma unroll
-    for (int l = 0; l < SHORT_L; ++l) { wk[l] = 0.f; wv[l] = 0.f; wq[l] = 0.f; }
+    for (int l = 0; l < SL; ++l) { wk[l] = 0.f; wv[l] = 0.f; wq[l] = 0.f; }
 #pragma unroll
-    for (int l = 0; l < SHORT_L; ++l) {
+    for (int l = 0; l < SL; ++l) {
         if (l < d.L) {
-            float p[SHORT_L], a[SHORT_L], dp[SHORT_L];
-            short_row(d, qkv, b, h, l, scale, causal, drop, site, p, a);
-            float4 g[SHORT_EV], v[SHORT_EV];
+            float p[SL], a[SL], dp[SL];
+            short_row<SL, SEV>(d, qkv, b, bg, h, l, scale, causal, drop, site, p, a);
+            float4 g[SEV], v[SEV];
             short_load(dout + (((size_t)b * d.L + l) * d.H + h) * d.E, ev, g);
-            const uint64_t row = ((uint64_t)b * d.H + h) * d.L + l;
+            const uint64_t row = ((uint64_t)bg * d.H + h) * d.L + l;
             float dot = 0.f;
 #pragma unroll
-            for (int s = 0; s < SHORT_L; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 float acc = 0.f;
                 if (s < d.L) {
                     short_load(qkv + short_off(d, b, s, 2, h), ev, v);
@@ -590,27 +624,56 @@ __global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const 
                 dot = fmaf(p[s], acc, dot);
             }
 #pragma unroll
-            for (int s = 0; s < SHORT_L; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 const float ds = p[s] * (dp[s] - dot);
                 if (s == i) { wk[l] = ds; wv[l] = a[s]; }
                 if (l == i) wq[s] = ds;
             }
         }
     }
-    float4 acc[SHORT_EV], x[SHORT_EV];
+    float4 acc[SEV], x[SEV];
     for (int which = 0; which < 3; ++which) {      // dq[i] = scale sum_j dS[i][j] k[j]; dk[i] = scale sum_j dS[j][i] q[j]; dv[i] = sum_j A[j][i] dout[j]
 #pragma unroll
-        for (int c = 0; c < SHORT_EV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < SEV; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < SHORT_L; ++j)
+        for (int j = 0; j < SL; ++j)
             if (j < d.L) {
                 const float* src = which == 0 ? qkv + short_off(d, b, j, 1, h)
                                  : which == 1 ? qkv + short_off(d, b, j, 0, h) : dout + (((size_t)b * d.L + j) * d.H + h) * d.E;
                 short_load(src, ev, x);
                 short_axpy(which == 0 ? wq[j] : which == 1 ? wk[j] : wv[j], x, acc);
             }
-        short_store(dqkv + short_off(d, b, i, which, h), ev, which == 2 ? 1.f : scale, acc);
+        short_store(dqkv + short_off(d, bg, i, which, h), ev, which == 2 ? 1.f : scale, acc);
     }
+}
+
+template <int SL, int SEV>
+__global__ __launch_bounds__(256) void attn_short_bwd_kernel(ShortDims d, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                              float scale, int causal, DropCfg drop, uint64_t site,
+                                                              float* __restrict__ dqkv) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.B * d.H * d.L) return;
+    const int i = t % d.L, h = (t / d.L) % d.H, b = t / (d.L * d.H);
+    attn_short_bwd_body<SL, SEV>(d, qkv, dout, b, b, h, i, scale, causal, drop, site, dqkv);
+}
+
+template <int SL, int SEV>
+__global__ __launch_bounds__(256) void attn_short_bwd_staged_kernel(ShortDims d, const float* __restrict__ qkv,
+                                                                     const float* __restrict__ dout, float scale, int causal, DropCfg drop,
+                                                                     uint64_t site, float* __restrict__ dqkv, int SB) {
+    extern __shared__ __attribute__((aligned(16))) float st[];
+    const int b0 = blockIdx.x * SB, nb = min(SB, d.B - b0), per = d.L * 3 * d.H * d.E, pero = d.L * d.H * d.E;
+    float* sq = st;
+    float* so = st + (size_t)SB * per;
+    const float4* src = reinterpret_cast<const float4*>(qkv + (size_t)b0 * per);
+    for (int x = threadIdx.x; x < nb * per / 4; x += 256) reinterpret_cast<float4*>(sq)[x] = src[x];
+    const float4* srco = reinterpret_cast<const float4*>(dout + (size_t)b0 * pero);
+    for (int x = threadIdx.x; x < nb * pero / 4; x += 256) reinterpret_cast<float4*>(so)[x] = srco[x];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t >= nb * d.H * d.L) return;
+    const int i = t % d.L, h = (t / d.L) % d.H, bl = t / (d.L * d.H);
+    attn_short_bwd_body<SL, SEV>(d, sq, so, bl, b0 + bl, h, i, scale, causal, drop, site, dqkv);
 }
 
 }  // namespace
@@ -704,13 +767,35 @@ int launch_softmax_rows_bwd(float* dA, const float* P, int B, int H, int L, int 
     return IMMTSF_OK;
 }
 
+// sequences per workgroup of the staged kernels: one thread per (sequence, head, position) within 256 threads, rows_per
+// (3 forward, 4 backward) x L x H x E floats per sequence within 48 KB of LDS; a small SB spreads the launch over more CUs
+static int short_stage_seqs(int L, int H, int E, int rows_per) {
+    int sb = 256 / (H * L);
+    const int lds_cap = (48 * 1024) / (rows_per * L * H * E * (int)sizeof(float));
+    if (sb > lds_cap) sb = lds_cap;
+    if (sb > 16) sb = 16;
+    return sb;
+}
+
 int launch_attn_short_fwd(const float* qkv, int B, int L, int H, int E, float scale, int causal, DropCfg drop, uint64_t site,
                           float* out, hipStream_t s) {
     if (L > SHORT_L || E > 4 * SHORT_EV || (E & 3) || (reinterpret_cast<uintptr_t>(qkv) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
         return IMMTSF_EUNSUPPORTED;
     const int n = B * H * L;
     if (n <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(attn_short_fwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, scale, causal, drop, site, out);
+    const int SB = short_stage_seqs(L, H, E, 3);
+    if (SB >= 4) {
+#define IMMTSF_SHORT_FWD_STAGED(SL, SEV)                                                                                        \
+        hipLaunchKernelGGL((attn_short_fwd_staged_kernel<SL, SEV>), dim3(cdiv(B, SB)), dim3(256), (size_t)SB * L * 3 * H * E * sizeof(float), \
+                           s, ShortDims{B, L, H, E}, qkv, scale, causal, drop, site, out, SB)
+        if (L <= 2 && E <= 32) IMMTSF_SHORT_FWD_STAGED(2, 8);
+        else if (L <= 4 && E <= 32) IMMTSF_SHORT_FWD_STAGED(4, 8);
+        else IMMTSF_SHORT_FWD_STAGED(8, 16);
+#undef IMMTSF_SHORT_FWD_STAGED
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
+    hipLaunchKernelGGL((attn_short_fwd_kernel<8, 16>), dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, scale, causal, drop, site, out);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -722,7 +807,19 @@ int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int
         return IMMTSF_EUNSUPPORTED;
     const int n = B * H * L;
     if (n <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(attn_short_bwd_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, dout, scale, causal, drop,
+    const int SB = short_stage_seqs(L, H, E, 4);
+    if (SB >= 4) {
+#define IMMTSF_SHORT_BWD_STAGED(SL, SEV)                                                                                        \
+        hipLaunchKernelGGL((attn_short_bwd_staged_kernel<SL, SEV>), dim3(cdiv(B, SB)), dim3(256), (size_t)SB * L * 4 * H * E * sizeof(float), \
+                           s, ShortDims{B, L, H, E}, qkv, dout, scale, causal, drop, site, dqkv, SB)
+        if (L <= 2 && E <= 32) IMMTSF_SHORT_BWD_STAGED(2, 8);
+        else if (L <= 4 && E <= 32) IMMTSF_SHORT_BWD_STAGED(4, 8);
+        else IMMTSF_SHORT_BWD_STAGED(8, 16);
+#undef IMMTSF_SHORT_BWD_STAGED
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
+    hipLaunchKernelGGL((attn_short_bwd_kernel<8, 16>), dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, dout, scale, causal, drop,
                        site, dqkv);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

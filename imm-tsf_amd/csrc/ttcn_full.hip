@@ -541,9 +541,11 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
     const WtsT wt{q.W3T, q.W2T, q.W1T};
-    // persistent workgroups, one per CU: measured 256 / 512 / 768 / 1024 -> backbone fwd+bwd 603 / 617 / 621 / 631 us
+    // persistent workgroups: measured alone 256 / 512 / 768 / 1024 -> backbone fwd+bwd 603 / 617 / 621 / 631 us; inside the step, beside
+    // the text-side backward GEMMs on the other stream, 64 / 96 / 128 / 192 / 256 / 512 -> 1.040 / 0.950 / 0.915 / 0.911 / 0.930 / 0.927 ms/step:
+    // 192 leaves a quarter of the CUs free for the GEMM workgroups this kernel's ~100 KB of LDS would otherwise lock out
     // (fewer workgroups = fewer end-of-kernel gradient atomics; the per-patch work is latency- not occupancy-bound)
-    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 256;
+    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 192;
     const int grid = P < gmax ? P : gmax;
     if (L <= 32) {
         const size_t lds = bwd_lds(2, d.NCq);

@@ -38,33 +38,43 @@ __device__ __forceinline__ int emb_src(const EmbDims& e, int p, int k) {      //
 // grid ceil(R P / PB): a workgroup takes PB consecutive (row, patch) pairs; their gathered taps sit in LDS (g[PB][K], read as
 // wave-wide broadcasts), every thread keeps its output column's K weights in registers and writes that column of the PB
 // outputs, coalesced along D
-template <int PB>
+// KB: compile-time bound on K (16 / 32 / 64), the tap rows in LDS and the weight registers are zero-padded to it: the K loop
+// is KB/4 16-byte broadcast reads + KB FMAs with no branches (with a run-time K every FMA waited on its own 4-byte LDS read
+// behind a branch: 58 us for PatchTST's 9.4 MB of output)
+template <int PB, int KB>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ W,
                                                          const float* __restrict__ pe, float* __restrict__ out, DropCfg drop,
                                                          uint64_t site) {
-    __shared__ __attribute__((aligned(16))) float g[PB * EMB_KMAX];
+    __shared__ __attribute__((aligned(16))) float g[PB * KB];
     const int tid = threadIdx.x;
     const long pairs = (long)e.R * e.P, q0 = (long)blockIdx.x * PB;
     const int nq = (int)min((long)PB, pairs - q0);
     const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
-    for (int i = tid; i < nq * e.K; i += 256) {
-        const int qq = i / e.K, k = i - qq * e.K;
-        const long q = q0 + qq;
-        const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
-        g[qq * EMB_KMAX + k] = x[(size_t)r * row_elems + emb_src(e, p, k)];
+    for (int i = tid; i < PB * KB; i += 256) {
+        const int qq = i / KB, k = i - qq * KB;
+        float v = 0.f;
+        if (qq < nq && k < e.K) {
+            const long q = q0 + qq;
+            const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
+            v = x[(size_t)r * row_elems + emb_src(e, p, k)];
+        }
+        g[i] = v;
     }
     __syncthreads();
     for (int d = tid; d < e.D; d += 256) {
-        float w[EMB_KMAX];
+        float w[KB];
 #pragma unroll
-        for (int k = 0; k < EMB_KMAX; ++k) w[k] = k < e.K ? W[(size_t)d * e.K + k] : 0.f;
+        for (int k = 0; k < KB; ++k) w[k] = k < e.K ? W[(size_t)d * e.K + k] : 0.f;
         for (int qq = 0; qq < nq; ++qq) {
             const long q = q0 + qq;
             const int p = (int)(q % e.P);
             float a = pe[(size_t)p * e.D + d];
+            const float4* g4 = reinterpret_cast<const float4*>(g + qq * KB);
 #pragma unroll
-            for (int k = 0; k < EMB_KMAX; ++k)
-                if (k < e.K) a = fmaf(w[k], g[qq * EMB_KMAX + k], a);
+            for (int k4 = 0; k4 < KB / 4; ++k4) {
+                const float4 t = g4[k4];
+                a = fmaf(w[4 * k4], t.x, fmaf(w[4 * k4 + 1], t.y, fmaf(w[4 * k4 + 2], t.z, fmaf(w[4 * k4 + 3], t.w, a))));
+            }
             const size_t o = (size_t)q * e.D + d;
             out[o] = a * dropout_scale(drop, site, (uint64_t)o);
         }
@@ -77,46 +87,52 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbDims e, const float* 
 // workgroup adds its 16 x K block with one atomic per element (S <= 8 adds per address; S = 1 for short inputs).
 // (The first version gave every workgroup all D columns of 16 pairs: 240 workgroups x D K atomics on D K addresses
 // serialised in L2 -- 306 us at PatchTST's 512 x 16; this one is ~10 us.)
+template <int KB>
 __global__ __launch_bounds__(256) void embed_bwd_w_kernel(EmbDims e, const float* __restrict__ x, const float* __restrict__ dout,
                                                            float* __restrict__ dW, DropCfg drop, uint64_t site) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* g = lds;                              // [16 pairs][K]
-    float* red = lds + 16 * EMB_KMAX;            // [16 pair lanes][16 columns][K + 1]
+    float* g = lds;                              // [16 pairs][KB], zero-padded
+    float* red = lds + 16 * KB;                  // [16 pair lanes][16 columns][KB + 1]
     const int tid = threadIdx.x, dc = tid & 15, pl = tid >> 4;
     const int d = blockIdx.x * 16 + dc;
     const long pairs = (long)e.R * e.P;
     const long per = ((pairs + gridDim.y - 1) / gridDim.y + 15) & ~15L, q0 = blockIdx.y * per, q1 = min(pairs, q0 + per);
     const size_t row_elems = e.mode == 0 ? (size_t)e.L : (size_t)e.L * e.c_in;
-    float acc[EMB_KMAX];
+    float acc[KB];
 #pragma unroll
-    for (int k = 0; k < EMB_KMAX; ++k) acc[k] = 0.f;
+    for (int k = 0; k < KB; ++k) acc[k] = 0.f;
     for (long qb = q0; qb < q1; qb += 16) {
         __syncthreads();
-        for (int i = tid; i < 16 * e.K; i += 256) {
-            const int qq = i / e.K, k = i - qq * e.K;
+        for (int i = tid; i < 16 * KB; i += 256) {
+            const int qq = i / KB, k = i - qq * KB;
             const long q = qb + qq;
             float v = 0.f;
-            if (q < q1) {
+            if (q < q1 && k < e.K) {
                 const int r = (int)(q / e.P), p = (int)(q - (long)r * e.P);
                 v = x[(size_t)r * row_elems + emb_src(e, p, k)];
             }
-            g[qq * EMB_KMAX + k] = v;
+            g[i] = v;
         }
         __syncthreads();
         const long q = qb + pl;
         if (q < q1 && d < e.D) {
             const size_t o = (size_t)q * e.D + d;
             const float dv = dout[o] * dropout_scale(drop, site, (uint64_t)o);
+            const float4* g4 = reinterpret_cast<const float4*>(g + pl * KB);
 #pragma unroll
-            for (int k = 0; k < EMB_KMAX; ++k)
-                if (k < e.K) acc[k] = fmaf(dv, g[pl * EMB_KMAX + k], acc[k]);
+            for (int k4 = 0; k4 < KB / 4; ++k4) {
+                const float4 t = g4[k4];
+                acc[4 * k4] = fmaf(dv, t.x, acc[4 * k4]);
+                acc[4 * k4 + 1] = fmaf(dv, t.y, acc[4 * k4 + 1]);
+                acc[4 * k4 + 2] = fmaf(dv, t.z, acc[4 * k4 + 2]);
+                acc[4 * k4 + 3] = fmaf(dv, t.w, acc[4 * k4 + 3]);
+            }
         }
     }
     __syncthreads();
-    const int pitch = e.K + 1;
+    constexpr int pitch = KB + 1;
 #pragma unroll
-    for (int k = 0; k < EMB_KMAX; ++k)
-        if (k < e.K) red[(pl * 16 + dc) * pitch + k] = acc[k];
+    for (int k = 0; k < KB; ++k) red[(pl * 16 + dc) * pitch + k] = acc[k];
     __syncthreads();
     for (int i = tid; i < 16 * e.K; i += 256) {
         const int c = i / e.K, k = i - c * e.K;
@@ -178,8 +194,12 @@ int immtsf_embed_forward(int32_t mode, const float* x, int32_t R, int32_t L, int
     if (emb_bad(e)) return IMMTSF_EUNSUPPORTED;
     constexpr int PB = 16;
     const long pairs = (long)R * P;
-    hipLaunchKernelGGL(embed_fwd_kernel<PB>, dim3((unsigned)((pairs + PB - 1) / PB)), dim3(256), 0, static_cast<hipStream_t>(stream), e, x, W,
-                       pe, out, mk_drop2(p_drop, seed, seed_step_dev), site);
+    const dim3 grid((unsigned)((pairs + PB - 1) / PB));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DropCfg drop = mk_drop2(p_drop, seed, seed_step_dev);
+    if (K <= 16) hipLaunchKernelGGL((embed_fwd_kernel<PB, 16>), grid, dim3(256), 0, s, e, x, W, pe, out, drop, site);
+    else if (K <= 32) hipLaunchKernelGGL((embed_fwd_kernel<PB, 32>), grid, dim3(256), 0, s, e, x, W, pe, out, drop, site);
+    else hipLaunchKernelGGL((embed_fwd_kernel<PB, 64>), grid, dim3(256), 0, s, e, x, W, pe, out, drop, site);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -202,8 +222,12 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
         hipError_t er = hipMemsetAsync(dW, 0, (size_t)D * K * sizeof(float), s);
         if (er != hipSuccess) return (int)er;
     }
-    const size_t lds = (16 * EMB_KMAX + 256 * (size_t)(K + 1)) * sizeof(float);
-    hipLaunchKernelGGL(embed_bwd_w_kernel, dim3(cs, S), dim3(256), lds, s, e, x, dout, dW, drop, site);
+    const int KB = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
+    const size_t lds = (16 * (size_t)KB + 256 * (size_t)(KB + 1)) * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(embed_bwd_w_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (KB == 16) hipLaunchKernelGGL(embed_bwd_w_kernel<16>, dim3(cs, S), dim3(256), lds, s, e, x, dout, dW, drop, site);
+    else if (KB == 32) hipLaunchKernelGGL(embed_bwd_w_kernel<32>, dim3(cs, S), dim3(256), lds, s, e, x, dout, dW, drop, site);
+    else hipLaunchKernelGGL(embed_bwd_w_kernel<64>, dim3(cs, S), dim3(256), lds, s, e, x, dout, dW, drop, site);
     IMMTSF_LAUNCH_CHECK();
     if (dx) {
         const size_t n = (size_t)R * (mode == 0 ? (size_t)L : (size_t)L * c_in);

@@ -53,6 +53,7 @@ struct GemmArgs {
     DropCfg epi_drop;
     uint64_t epi_site;
     int xcd_remap;         // set by the launcher
+    int xcd_gm;            // gemm2: > 0 = the 8 XCDs own an xcd_gm x (8 / xcd_gm) arrangement of equal rectangles of the tile grid
     int dbg;               // ablation flags (tools/gemm_bench.py), 0 in production
 };
 

@@ -23,6 +23,7 @@ struct T2VWs {
     unsigned char *mask, *mtxt;
     int *lengths, *offsets, *rowmap, *seg;
     Mat Xcat, KV, ctx, z;
+    void* Vh;        // bf16 image of the gathered (packed) note embeddings [R, d_m] (hf with an input projection)
     float *KVp, *q, *qs, *P, *xpre, *xhat, *rstd, *part;
     void *w_in, *w_kv, *w_inkv, *w_out, *w_po;     // bf16 weight images when no twin is registered (hf only)
     size_t bytes;
@@ -38,6 +39,7 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     w.offsets = k.take<int>(B + 1);
     w.rowmap = k.take<int>(R);
     w.seg = k.take<int>(R);
+    w.Vh = hf ? k.take<unsigned short>(R * (size_t)c->d_m) : nullptr;
     w.Xcat = k.take_mat(R * (d + dt), !hf, hf);
     w.KV = k.take_mat(R * d, !hf, hf);
     w.KVp = k.take<float>(R * 2 * d);
@@ -64,6 +66,7 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
 struct T2VScratch {
     Mat dE, dx, dKVp, dKV;
     float *dz, *dctx, *dXcat, *dqs_part, *dqs, *dq, *dp, *red, *red_t2v;
+    void* dXcat_h;
     int t2v_slabs;
     size_t bytes;
 };
@@ -79,6 +82,7 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dKVp = k.take_mat(R * 2 * d, !hf, hf);
     s.dKV = k.take_mat(R * d, !hf, hf);
     s.dXcat = k.take<float>(R * (d + dt));
+    s.dXcat_h = hf ? k.take<unsigned short>(R * (d + dt)) : nullptr;
     s.dqs_part = k.take<float>(B * d);
     s.dqs = k.take<float>(d);
     s.dq = k.take<float>(d);
@@ -148,7 +152,16 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     const int* gather = src_rows ? src_rows : w.rowmap;
     // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
     // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
-    if (p->input_proj_w) {
+    if (p->input_proj_w && hf) {
+        // bf16 mode: ONE gather + cast pass writes the packed bf16 image of the notes; the projection (here) and its weight
+        // gradient (backward) then run on the bf16-in-memory GEMM instead of re-reading the fp32 rows through a row map
+        // (cfg5: 145 k x 4096 rows -- the row-mapped fp32 weight gradient was the slowest kernel of the fusion path, 6.4 ms)
+        CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, cfg->d_m, nullptr, cfg->d_m, s, w.Vh));
+        GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, dcat);
+        set_problem2(g, 0, mat(nullptr, w.Vh), W.in, w.Xcat, p->input_proj_b);
+        g.dyn = total; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    } else if (p->input_proj_w) {
         GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, dcat);
         set_problem2(g, 0, cmat(notes), W.in, w.Xcat, p->input_proj_b);
         g.dyn = total; g.dyn_which = 0; g.a_rowmap = gather;
@@ -268,7 +281,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     }
     {   // KV_proj
         GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
-        set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat), nullptr);
+        set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat, p->input_proj_w ? sc.dXcat_h : nullptr), nullptr);
         g.dyn = total; g.dyn_which = 0;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
         GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
@@ -277,7 +290,13 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    if (p->input_proj_w) {   // dW_in = dVp^T V(gathered) ; db_in = colsum dVp   (row-mapped, fp32 operands: the round-1 kernel)
+    if (p->input_proj_w && hf) {   // dW_in = dVp^T V ; db_in = colsum dVp: both operands are bf16 images (dXcat's first d columns, the packed notes)
+        GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
+        set_problem2(h, 0, mat(nullptr, sc.dXcat_h), mat(nullptr, w.Vh), mat(gr->input_proj_w), nullptr, gr->input_proj_b);
+        h.dyn = total; h.dyn_which = 1;
+        prezeroed(h, cfg);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+    } else if (p->input_proj_w) {   // row-mapped, fp32 operands: the round-1 kernel
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;

@@ -101,10 +101,23 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src,
                                                            const int* __restrict__ rowmap, const int* __restrict__ total,
                                                            int width, float* __restrict__ dst, int ld_dst,
-                                                           bf16_t* __restrict__ dst_h) {
+                                                           bf16_t* __restrict__ dst_h, int vec) {
     const int r = blockIdx.x;
     if (r >= *total) return;
     const float* s = src + (size_t)rowmap[r] * ld_src;
+    if (vec) {      // width, both pitches multiples of 4 and 16-byte aligned bases: 16-byte loads, 8-byte bf16 stores
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        for (int i = threadIdx.x; i < (width >> 2); i += blockDim.x) {
+            const float4 v = s4[i];
+            if (dst) reinterpret_cast<float4*>(dst + (size_t)r * ld_dst)[i] = v;
+            if (dst_h) {
+                bf16x4 h;
+                h[0] = (bf16_t)v.x; h[1] = (bf16_t)v.y; h[2] = (bf16_t)v.z; h[3] = (bf16_t)v.w;
+                reinterpret_cast<bf16x4*>(dst_h + (size_t)r * ld_dst)[i] = h;
+            }
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < width; i += blockDim.x) {
         const float v = s[i];
         if (dst) dst[(size_t)r * ld_dst + i] = v;
@@ -619,7 +632,10 @@ int launch_mask_from_lengths(const int* lengths, int B, int N, unsigned char* ma
 int launch_gather_rows(const float* src, int ld_src, const int* rowmap, const int* total, int max_rows, int width,
                        float* dst, int ld_dst, hipStream_t s, void* dst_h) {
     if (max_rows <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(max_rows), dim3(256), 0, s, src, ld_src, rowmap, total, width, dst, ld_dst, static_cast<bf16_t*>(dst_h));
+    const uintptr_t al = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dst_h);
+    const int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(max_rows), dim3(256), 0, s, src, ld_src, rowmap, total, width, dst, ld_dst,
+                       static_cast<bf16_t*>(dst_h), vec);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

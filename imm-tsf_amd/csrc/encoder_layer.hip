@@ -70,6 +70,100 @@ inline bool bad_el(const immtsf_encoder_layer_cfg* c) {
            c->precision < 0 || c->precision > 1 || c->p_attn < 0.f || c->p_attn >= 1.f || c->p_drop < 0.f || c->p_drop >= 1.f;
 }
 
+// ---- the feed-forward half shared by the two block entry points:  out = LN(x1 + drop(drop(act(x1 W1^T + b1)) W2^T + b2))
+// act 1 = ReLU, 2 = GELU(erf).  Saved: h (with its dropout applied), for GELU also the pre-activation z; LN statistics.
+struct FFNDims { int R, D, F, act, prec; float eps; uint64_t site_h, site_out; };
+int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const float* x1, const float* w1, const float* b1,
+                const float* w2, const float* b2, const float* ln_w, const float* ln_b, float* h, float* z, float* ff, float* xhat,
+                float* rstd, float* out, hipStream_t s) {
+    {   // h = dropout(act(x1 W1^T + b1)): activation and dropout in the epilogue (z = the pre-activation, GELU only)
+        GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.D, f.F);
+        set_problem(g, 0, x1, w1, h, b1);
+        g.p[0].Cpre = f.act == 2 ? z : nullptr;
+        g.act = f.act;
+        g.epi_drop = dd; g.epi_site = f.site_h;
+        CHECK(immtsf_launch_gemm(GEMM_NT, f.prec, g, s));
+    }
+    {
+        GemmArgs g = gemm_args(f.R, f.D, f.F, f.F, f.F, f.D);
+        set_problem(g, 0, h, w2, ff, b2);
+        CHECK(immtsf_launch_gemm(GEMM_NT, f.prec, g, s));
+    }
+    return launch_layernorm_fwd(ff, f.R, f.D, ln_w, ln_b, f.eps, xhat, rstd, out, none, 0, s, nullptr, x1, dd, f.site_out);
+}
+// dout -> d1 (gradient wrt x1, complete: residual share + through the two GEMMs) and the six parameter gradients
+int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int pz, const float* x1, const float* w1, const float* w2,
+                 const float* ln_w, const float* h, const float* z, const float* xhat, const float* rstd, const float* dout, float* d1,
+                 float* dff, float* dh, float* red, float* gw1, float* gb1, float* gw2, float* gb2, float* gln_w, float* gln_b,
+                 hipStream_t s) {
+    auto wgrad = [&](const float* dy, const float* xin, int N, int K, float* dW, float* db) {
+        GemmArgs g = gemm_args(N, K, f.R, N, K, K);
+        set_problem(g, 0, dy, xin, dW, nullptr, db);
+        g.c_prezeroed = pz;
+        return immtsf_launch_gemm(GEMM_TN, f.prec, g, s);
+    };
+    // LayerNorm: d1 = gradient of (x1 + drop(ff)) -- the residual's share; dff = d1 * dropout mask.  No output dropout: the
+    // kernel leaves dz untouched, so the caller's dout is read in place
+    float* g2 = const_cast<float*>(dout);
+    CHECK(launch_layernorm_bwd(g2, f.R, f.D, ln_w, xhat, rstd, d1, none, 0, s, dff, dd, f.site_out));
+    CHECK(launch_colsum2(g2, xhat, f.R, f.D, f.D, gln_w, gln_b, red, s));
+    {   // linear2: dh = (dff W2) x act'(.) x the feed-forward dropout
+        GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.F, f.F);
+        set_problem(g, 0, dff, w2, dh, nullptr);
+        if (f.act == 2) {      // GELU: the factor comes from the saved pre-activation, the dropout mask is regenerated
+            g.relu_ref = z; g.ld_ref = f.F; g.ref_kind = 2;
+            g.epi_drop = dd; g.epi_site = f.site_h;
+        } else {               // ReLU: h == 0 <=> negative pre-activation or dropped: one mask, scaled by 1 / keep
+            g.relu_ref = h; g.ld_ref = f.F;
+            g.alpha = dd.inv_keep;
+        }
+        CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
+    }
+    CHECK(wgrad(dff, h, f.D, f.F, gw2, gb2));
+    {   // linear1: d1 += dh W1
+        GemmArgs g = gemm_args(f.R, f.D, f.F, f.F, f.D, f.D);
+        set_problem(g, 0, dh, w1, d1, nullptr);
+        g.accumulate = 1;
+        CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
+    }
+    return wgrad(dh, x1, f.F, f.D, gw1, gb1);
+}
+
+struct FFNWs { float *h, *z, *ff, *xhat, *rstd; size_t bytes; };
+FFNWs carve_ffn(size_t R, size_t D, size_t F, int act, void* base) {
+    Carver k(base);
+    FFNWs w;
+    w.h = k.take<float>(R * F);
+    w.z = act == 2 ? k.take<float>(R * F) : nullptr;
+    w.ff = k.take<float>(R * D);
+    w.xhat = k.take<float>(R * D);
+    w.rstd = k.take<float>(R);
+    w.bytes = k.bytes();
+    return w;
+}
+struct FFNScratch { float *dff, *dh, *red; size_t bytes; };
+FFNScratch carve_ffn_scratch(size_t R, size_t D, size_t F, void* base) {
+    Carver k(base);
+    FFNScratch s;
+    s.dff = k.take<float>(R * D);
+    s.dh = k.take<float>(R * F);
+    s.red = k.take<float>(64 * (D + 8));
+    s.bytes = k.bytes();
+    return s;
+}
+inline DropCfg mk_drop3(int training, float p, uint64_t seed, const uint64_t* seed_dev) {
+    DropCfg d;
+    d.seed = seed;
+    d.p = (training && p > 0.f) ? p : 0.f;
+    d.inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
+    d.seed_dev = seed_dev;
+    return d;
+}
+inline bool bad_ffn(const immtsf_ffn_block_cfg* c) {
+    return !c || c->R <= 0 || c->D <= 0 || c->F <= 0 || (c->D & 3) || c->D > 1024 || (c->act != 1 && c->act != 2) || c->precision < 0 ||
+           c->precision > 1 || c->p_drop < 0.f || c->p_drop >= 1.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -101,19 +195,8 @@ int immtsf_encoder_layer_forward(const immtsf_encoder_layer_cfg* c, const immtsf
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     CHECK(launch_layernorm_fwd(w.sa, R, D, p->ln1_w, p->ln1_b, c->eps, w.xhat1, w.rstd1, w.x1, none, 0, s, nullptr, x, dd, c->site_base + 1));
-    {   // h = dropout(relu(x1 W1^T + b1)): activation and dropout in the epilogue
-        GemmArgs g = gemm_args(R, F, D, D, D, F);
-        set_problem(g, 0, w.x1, p->w1, w.h, p->b1);
-        g.act = 1;
-        g.epi_drop = dd; g.epi_site = c->site_base + 2;
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-    }
-    {
-        GemmArgs g = gemm_args(R, D, F, F, F, D);
-        set_problem(g, 0, w.h, p->w2, w.ff, p->b2);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-    }
-    return launch_layernorm_fwd(w.ff, R, D, p->ln2_w, p->ln2_b, c->eps, w.xhat2, w.rstd2, out, none, 0, s, nullptr, w.x1, dd, c->site_base + 3);
+    const FFNDims f{R, D, F, 1, prec, c->eps, c->site_base + 2, c->site_base + 3};
+    return ffn_forward(f, dd, none, w.x1, p->w1, p->b1, p->w2, p->b2, p->ln2_w, p->ln2_b, w.h, nullptr, w.ff, w.xhat2, w.rstd2, out, s);
 }
 
 /* dout (R, D) -> dx (R, D) and the parameter gradients in `gr` (same layout as the parameters; every buffer is overwritten
@@ -135,26 +218,11 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
         g.c_prezeroed = pz;
         return immtsf_launch_gemm(GEMM_TN, prec, g, s);
     };
-    // LayerNorm2: d1 = gradient of (x1 + drop(ff)) -- the residual's share; dff = d1 * dropout mask
-    // (no output dropout: the kernel leaves dz untouched, so the caller's dout is read in place)
-    float* g2 = const_cast<float*>(dout);
-    CHECK(launch_layernorm_bwd(g2, R, D, p->ln2_w, w.xhat2, w.rstd2, sc.d1, none, 0, s, sc.dff, dd, c->site_base + 3));
-    CHECK(launch_colsum2(g2, w.xhat2, R, D, D, gr->ln2_w, gr->ln2_b, sc.red, s));
-    {   // linear2: dh = (dff W2) masked by h != 0 (relu' and the feed-forward dropout in one) and scaled by 1/keep
-        GemmArgs g = gemm_args(R, F, D, D, F, F);
-        set_problem(g, 0, sc.dff, p->w2, sc.dh, nullptr);
-        g.relu_ref = w.h; g.ld_ref = F;
-        g.alpha = dd.inv_keep;
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    {
+        const FFNDims f{R, D, F, 1, prec, c->eps, c->site_base + 2, c->site_base + 3};
+        CHECK(ffn_backward(f, dd, none, pz, w.x1, p->w1, p->w2, p->ln2_w, w.h, nullptr, w.xhat2, w.rstd2, dout, sc.d1, sc.dff, sc.dh, sc.red,
+                           gr->w1, gr->b1, gr->w2, gr->b2, gr->ln2_w, gr->ln2_b, s));
     }
-    CHECK(wgrad(sc.dff, w.h, D, F, gr->w2, gr->b2));
-    {   // linear1: d1 += dh W1
-        GemmArgs g = gemm_args(R, D, F, F, D, D);
-        set_problem(g, 0, sc.dh, p->w1, sc.d1, nullptr);
-        g.accumulate = 1;
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-    }
-    CHECK(wgrad(sc.dh, w.x1, F, D, gr->w1, gr->b1));
     // LayerNorm1: dx = gradient of (x + drop(sa)) -- the input's residual share; dsa = dx * dropout mask
     CHECK(launch_layernorm_bwd(sc.d1, R, D, p->ln1_w, w.xhat1, w.rstd1, dx, none, 0, s, sc.dsa, dd, c->site_base + 1));
     CHECK(launch_colsum2(sc.d1, w.xhat1, R, D, D, gr->ln1_w, gr->ln1_b, sc.red, s));
@@ -172,6 +240,55 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     return wgrad(sc.dqkv, x, 3 * D, D, gr->in_w, gr->in_b);
+}
+
+/* ---- LayerNorm(x + Dropout(branch)): the residual joint of every post-norm block (reference layers/Transformer_EncDec.py:52,58) */
+int immtsf_residual_layernorm_forward(const float* x, const float* branch, int32_t rows, int32_t d, const float* gamma, const float* beta,
+                                      float eps, int32_t training, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev,
+                                      float* xhat, float* rstd, float* out, immtsf_stream_t stream) {
+    if (!x || !branch || !gamma || !beta || !xhat || !rstd || !out || rows < 0 || d <= 0 || p_drop < 0.f || p_drop >= 1.f) return IMMTSF_EINVAL;
+    const DropCfg dd = mk_drop3(training, p_drop, seed, seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
+    return launch_layernorm_fwd(branch, rows, d, gamma, beta, eps, xhat, rstd, out, none, 0, static_cast<hipStream_t>(stream), nullptr, x, dd, site);
+}
+
+/* dout -> dx (= the gradient of the normalised sum) and dbranch = dx * dropout mask; dgamma, dbeta written; scratch >= 64 (d + 8)
+ * floats.  dout is only read. */
+int immtsf_residual_layernorm_backward(const float* dout, int32_t rows, int32_t d, const float* gamma, const float* xhat, const float* rstd,
+                                       int32_t training, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, float* dx,
+                                       float* dbranch, float* dgamma, float* dbeta, float* scratch, immtsf_stream_t stream) {
+    if (!dout || !gamma || !xhat || !rstd || !dx || !dbranch || !dgamma || !dbeta || !scratch || rows < 0 || d <= 0) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const DropCfg dd = mk_drop3(training, p_drop, seed, seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
+    float* g = const_cast<float*>(dout);
+    CHECK(launch_layernorm_bwd(g, rows, d, gamma, xhat, rstd, dx, none, 0, s, dbranch, dd, site));
+    return launch_colsum2(g, xhat, rows, d, d, dgamma, dbeta, scratch, s);
+}
+
+size_t immtsf_ffn_block_workspace_bytes(const immtsf_ffn_block_cfg* c) { return bad_ffn(c) ? 0 : carve_ffn(c->R, c->D, c->F, c->act, nullptr).bytes; }
+size_t immtsf_ffn_block_scratch_bytes(const immtsf_ffn_block_cfg* c) { return bad_ffn(c) ? 0 : carve_ffn_scratch(c->R, c->D, c->F, nullptr).bytes; }
+
+int immtsf_ffn_block_forward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_block_params* p, const float* x, float* out, void* workspace,
+                             size_t workspace_bytes, immtsf_stream_t stream) {
+    if (bad_ffn(c) || !p || !x || !out || !workspace) return IMMTSF_EINVAL;
+    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
+    const FFNDims f{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
+    return ffn_forward(f, dd, none, x, p->w1, p->b1, p->w2, p->b2, p->ln_w, p->ln_b, w.h, w.z, w.ff, w.xhat, w.rstd, out,
+                       static_cast<hipStream_t>(stream));
+}
+
+int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_block_params* p, const float* x, const float* dout, float* dx,
+                              void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                              const immtsf_ffn_block_params* gr, immtsf_stream_t stream) {
+    if (bad_ffn(c) || !p || !gr || !x || !dout || !dx || !workspace || !scratch) return IMMTSF_EINVAL;
+    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, workspace);
+    FFNScratch sc = carve_ffn_scratch(c->R, c->D, c->F, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
+    const FFNDims f{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
+    return ffn_backward(f, dd, none, c->grads_prezeroed ? 1 : 0, x, p->w1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
+                        sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

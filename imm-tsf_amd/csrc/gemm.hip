@@ -31,6 +31,10 @@ template <bool BF16> struct LdsElem { typedef float T; };
 template <> struct LdsElem<true> { typedef bf16_t T; };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// d/dz of the above: Phi(z) + z phi(z)
+__device__ __forceinline__ float gelu_erf_grad(float z) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+}
 
 // LDS image of one operand tile: R = [rows][BK+pad] (k contiguous), KM = [BK][rows+8] (row contiguous, bf16 only)
 template <bool BF16, bool TR, int ROWS, int BK> struct TileGeom {
@@ -606,10 +610,15 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                 if (P.bias) x += P.bias[col + e];
                 if (!live) x = 0.f;
                 if (g.add_vec) x += g.add_vec[col + e];
+                if (P.Cpre) P.Cpre[(size_t)row * g.ldc + col + e] = x;
                 if (g.act == 1) x = fmaxf(x, 0.f);
                 else if (g.act == 2) x = gelu_erf(x);
                 if (g.epi_drop.p > 0.f) x *= dropout_scale(g.epi_drop, g.epi_site, (uint64_t)row * N + col + e);
-                if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col + e] <= 0.f) x = 0.f;
+                if (g.relu_ref) {
+                    const float rv = g.relu_ref[(size_t)row * g.ld_ref + col + e];
+                    if (g.ref_kind == 2) x *= gelu_erf_grad(rv);
+                    else if (rv <= 0.f) x = 0.f;
+                }
                 if (g.accumulate) x += dst[e];
                 v[e] = x;
             }
@@ -645,10 +654,15 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                 if (splits > 1) {
                     atomicAdd(dst, v);
                 } else {
+                    if (P.Cpre) P.Cpre[(size_t)row * g.ldc + col] = v;
                     if (g.act == 1) v = fmaxf(v, 0.f);
                     else if (g.act == 2) v = gelu_erf(v);
                     if (g.epi_drop.p > 0.f) v *= dropout_scale(g.epi_drop, g.epi_site, (uint64_t)row * N + col);
-                    if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col] <= 0.f) v = 0.f;   // relu backward mask
+                    if (g.relu_ref) {                                  // activation-backward factor
+                        const float rv = g.relu_ref[(size_t)row * g.ld_ref + col];
+                        if (g.ref_kind == 2) v *= gelu_erf_grad(rv);
+                        else if (rv <= 0.f) v = 0.f;
+                    }
                     if (g.accumulate) v += *dst;
                     if (P.C) *dst = v;
                     if (P.Ch) reinterpret_cast<bf16_t*>(P.Ch)[offC + (size_t)row * (g.ldch ? g.ldch : g.ldc) + col] = (bf16_t)v;

@@ -13,6 +13,8 @@ struct GemmProblem {
     const void* Bh;      // bf16 copy of B (same element offsets): given by the caller, else looked up in the twin registry
     const void* Ah;      // bf16 copy of A (same element offsets, same lda), written by A's producer; may be null
     void* Ch;            // optional bf16 copy of the result (row pitch GemmArgs::ldch); C may then be null
+    float* Cpre;         // optional: the value BEFORE the activation (after bias / row flag / add_vec), same pitch as C --
+                         // what a GELU backward needs (gemm.hip only)
 };
 
 // C[m,n] = epilogue( alpha * sum_k opA(m,k) * opB(n,k) )
@@ -46,6 +48,8 @@ struct GemmArgs {
     // optional relu-backward mask: results whose relu_ref[m*ld_ref + n] <= 0 are zeroed (relu_ref = forward output)
     const float* relu_ref;
     int ld_ref;
+    int ref_kind;          // 0: relu_ref is a ReLU output (mask where <= 0); 2: relu_ref is a GELU PRE-activation z, results are
+                           // multiplied by gelu'(z) (gemm.hip only)
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
     int no_split;          // never split K (tiny products whose zero-fill + atomics cost more than the serial K loop)

@@ -403,7 +403,9 @@ extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g) {
     if (layout < 0 || layout > 2 || g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS || g.nbatch > 1) return false;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
-    if (g.epi_drop.p > 0.f) return false;       // dropout epilogue: the kernel in gemm.hip
+    if (g.epi_drop.p > 0.f || g.ref_kind) return false;       // dropout epilogue, GELU backward factor: the kernel in gemm.hip
+    for (int i = 0; i < g.nprob; ++i)
+        if (g.p[i].Cpre) return false;
     if ((g.lda % 8) || (g.ldb % 8)) return false;
     if (layout == GEMM_TN && (g.a_rowmap || g.b_rowmap)) return false;
     if (layout == GEMM_NN && g.b_rowmap) return false;

@@ -56,6 +56,13 @@ class EncoderLayerCfg(C.Structure):
 
 EncoderLayerParams = _ptr_struct("EncoderLayerParams", [
     "in_w", "in_b", "out_w", "out_b", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2", "ln2_w", "ln2_b"])
+class FFNBlockCfg(C.Structure):
+    _fields_ = [("R", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("act", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
+                ("p_drop", C.c_float), ("eps", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("site_base", C.c_uint64),
+                ("grads_prezeroed", C.c_int32)]
+
+
+FFNBlockParams = _ptr_struct("FFNBlockParams", ["w1", "b1", "w2", "b2", "ln_w", "ln_b"])
 GCNParams = _ptr_struct("GCNParams", [
     "nodevec1", "nodevec2", "gate1_w", "gate1_b", "gate2_w", "gate2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
     "mlp_w", "mlp_b"])
@@ -139,6 +146,15 @@ _PROTOS = {
     "immtsf_encoder_layer_forward": (C.c_int, [_P(EncoderLayerCfg), _P(EncoderLayerParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_encoder_layer_backward": (C.c_int, [_P(EncoderLayerCfg), _P(EncoderLayerParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                                 C.c_void_p, C.c_size_t, _P(EncoderLayerParams), c_stream]),
+    "immtsf_residual_layernorm_forward": (C.c_int, [c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_float, C.c_int32, C.c_float,
+                                                    C.c_uint64, C.c_uint64, C.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "immtsf_residual_layernorm_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_float, C.c_uint64,
+                                                     C.c_uint64, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "immtsf_ffn_block_workspace_bytes": (C.c_size_t, [_P(FFNBlockCfg)]),
+    "immtsf_ffn_block_scratch_bytes": (C.c_size_t, [_P(FFNBlockCfg)]),
+    "immtsf_ffn_block_forward": (C.c_int, [_P(FFNBlockCfg), _P(FFNBlockParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_ffn_block_backward": (C.c_int, [_P(FFNBlockCfg), _P(FFNBlockParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t, _P(FFNBlockParams), c_stream]),
     "immtsf_tpatchgnn_gcn_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_stream]),
     "immtsf_tpatchgnn_gcn_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams),
                                                 c_stream]),

@@ -637,6 +637,99 @@ def encoder_layer(lyr, x, training, site_base, precision=None):
                                 lyr.linear2.bias, lyr.norm2.weight, lyr.norm2.bias)
 
 
+class ResidualLayerNormFn(torch.autograd.Function):
+    """out = LayerNorm(x + Dropout(branch)) in one kernel per direction (+ the two-parameter column sums backward)."""
+
+    @staticmethod
+    def forward(ctx, x, branch, gamma, beta, eps, p_drop, training, seed, site):
+        lib = _lib.load()
+        x2, b2 = _c(x).reshape(-1, x.shape[-1]), _c(branch).reshape(-1, x.shape[-1])
+        _need_gpu(x2, b2, gamma, beta)
+        rows, d = x2.shape
+        p = float(p_drop) if training else 0.0
+        cnt = config.dropout_counter_ptr(x.device) if p > 0 else None
+        xhat = torch.empty_like(x2)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        check(lib.immtsf_residual_layernorm_forward(ptr(x2), ptr(b2), rows, d, ptr(gamma), ptr(beta), float(eps), 1 if training else 0, p,
+                                                    seed, site, cnt, ptr(xhat), ptr(rstd), ptr(out), stream_ptr()), "residual_layernorm_forward")
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.cfg = (rows, d, 1 if training else 0, p, seed, site, cnt, x.shape)
+        ctx.sinks = _sinks_of((gamma, beta))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        xhat, rstd, gamma = ctx.saved_tensors
+        rows, d, tr, p, seed, site, cnt, shape = ctx.cfg
+        g = dout.contiguous()
+        dx, db = torch.empty_like(xhat), torch.empty_like(xhat)
+        (dgamma, dbeta), rets = _grad_buffers((gamma, gamma), ctx.sinks)
+        scratch = torch.empty(64 * (d + 8), dtype=torch.float32, device=g.device)
+        check(lib.immtsf_residual_layernorm_backward(ptr(g), rows, d, ptr(gamma), ptr(xhat), ptr(rstd), tr, p, seed, site, cnt, ptr(dx),
+                                                     ptr(db), ptr(dgamma), ptr(dbeta), ptr(scratch), stream_ptr()), "residual_layernorm_backward")
+        return dx.view(shape), db.view(shape), rets[0], rets[1], None, None, None, None, None
+
+
+def residual_layernorm_supported(d):
+    return d % 4 == 0 and d <= 1024
+
+
+def residual_layer_norm(x, branch, norm, p_drop, training, site):
+    """norm: an nn.LayerNorm; x, branch (..., d)"""
+    seed = config.next_seed() if training and p_drop > 0 else 0
+    return ResidualLayerNormFn.apply(x.float(), branch.float(), norm.weight, norm.bias, norm.eps, float(p_drop), bool(training), seed, site)
+
+
+class FFNBlockFn(torch.autograd.Function):
+    """immtsf_ffn_block_forward/backward: out = LayerNorm(x + Dropout(W2 Dropout(act(W1 x + b1)) + b2)); W1 / W2 may be the
+    (out, in, 1) weights of kernel-size-1 nn.Conv1d modules (same memory as (out, in))."""
+
+    @staticmethod
+    def forward(ctx, x, act, p_drop, eps, training, precision, seed, site_base, *params):
+        lib = _lib.load()
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        params = tuple(_c(p) for p in params)
+        _need_gpu(x2, *params)
+        R, D = x2.shape
+        F = params[0].shape[0]
+        p = float(p_drop) if training else 0.0
+        cfg = _lib.FFNBlockCfg(R, D, F, int(act), precision, 1 if training else 0, p, float(eps), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                               config.dropout_counter_ptr(x.device) if p > 0 else None, int(site_base), 0)
+        ws = _bytes(lib.immtsf_ffn_block_workspace_bytes(C.byref(cfg)), x.device)
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        ps = _struct(_lib.FFNBlockParams, params)
+        check(lib.immtsf_ffn_block_forward(C.byref(cfg), C.byref(ps), ptr(x2), ptr(out), ptr(ws), ws.numel(), stream_ptr()), "ffn_block_forward")
+        ctx.cfg, ctx.ws, ctx.shape = cfg, ws, x.shape
+        ctx.sinks = _sinks_of(params)
+        ctx.save_for_backward(x2, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x2, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty_like(x2)
+        grads, rets = _grad_buffers(params, ctx.sinks)
+        cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
+        sc = _bytes(lib.immtsf_ffn_block_scratch_bytes(C.byref(cfg)), x2.device)
+        ps, gs = _struct(_lib.FFNBlockParams, params), _struct(_lib.FFNBlockParams, grads)
+        check(lib.immtsf_ffn_block_backward(C.byref(cfg), C.byref(ps), ptr(x2), ptr(dout), ptr(dx), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
+                                            sc.numel(), C.byref(gs), stream_ptr()), "ffn_block_backward")
+        ctx.ws = None
+        return (dx.view(ctx.shape),) + (None,) * 7 + tuple(rets)
+
+
+def ffn_block(x, conv1, conv2, norm, act, p_drop, training, site_base, precision=None):
+    """conv1 / conv2: nn.Conv1d(kernel_size=1) or nn.Linear; norm: nn.LayerNorm; act: "relu" | "gelu"."""
+    seed = config.next_seed() if training and p_drop > 0 else 0
+    return FFNBlockFn.apply(x.float(), 1 if act == "relu" else 2, float(p_drop), norm.eps, bool(training), config.precision_code(precision),
+                            seed, site_base, conv1.weight, conv1.bias, conv2.weight, conv2.bias, norm.weight, norm.bias)
+
+
 class TPatchDecoderFn(torch.autograd.Function):
     """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction, exact fp32.
     Backward recomputes the forward; parameter gradients accumulate by atomics into one zeroed flat buffer."""

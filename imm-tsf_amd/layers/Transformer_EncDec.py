@@ -1,10 +1,12 @@
 """EncoderLayer / Encoder (reference layers/Transformer_EncDec.py:27-80): post-LN block whose 1x1 convolutions are the
-two FFN GEMMs.  GEMMs and LayerNorm run on the HIP kernels; activation/dropout are elementwise torch ops."""
+two FFN GEMMs.  The two residual joints are block calls (immtsf.ops.residual_layer_norm, ffn_block: residual add and
+dropout inside the LayerNorm kernels, activation -- ReLU or GELU -- and dropout in the GEMM epilogues); widths the
+row kernels do not take (d_model % 4 != 0 or > 1024) and CPU tensors (which raise inside the ops) use the op-by-op form."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf.ops import layer_norm, linear
+from immtsf.ops import SITE_LAYER_BASE, ffn_block, layer_norm, linear, residual_layer_norm, residual_layernorm_supported
 
 
 def _ln(norm: nn.LayerNorm, x):
@@ -22,9 +24,14 @@ class EncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
         self.activation = F.relu if activation == "relu" else F.gelu
+        self._act = "relu" if activation == "relu" else "gelu"
 
     def forward(self, x, attn_mask=None, tau=None, delta=None):
         new_x, attn = self.attention(x, x, x, attn_mask=attn_mask, tau=tau, delta=delta)
+        if x.is_cuda and residual_layernorm_supported(x.shape[-1]):
+            base = SITE_LAYER_BASE + 128         # every call draws its own Philox key, so the sites can be shared by all layers
+            x = residual_layer_norm(x, new_x, self.norm1, self.dropout.p, self.training, base)
+            return ffn_block(x, self.conv1, self.conv2, self.norm2, self._act, self.dropout.p, self.training, base + 1), attn
         x = x + self.dropout(new_x)
         y = x = _ln(self.norm1, x)
         y = self.dropout(self.activation(linear(y, self.conv1.weight.squeeze(-1), self.conv1.bias)))

@@ -472,6 +472,46 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* cfg, const imm
                                   const float* dout, float* dx, void* workspace, size_t workspace_bytes, void* scratch,
                                   size_t scratch_bytes, const immtsf_encoder_layer_params* grads, immtsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * The two joints of the reference's post-norm EncoderLayer (layers/Transformer_EncDec.py:27-61; PatchTST, TimeLLM's
+ * patch path, TimesNet's callers), each one block call per direction instead of dropout / add / LayerNorm /
+ * activation kernels around the GEMMs:
+ *   residual_layernorm:  out = LayerNorm(x + Dropout(branch))                                    (:52-54, the attention joint)
+ *   ffn_block:           out = LayerNorm(x + Dropout(conv2(Dropout(act(conv1(x))))))            (:56-61; conv k=1 = Linear)
+ * act: 1 ReLU, 2 GELU(erf) -- activation and dropout live in the first GEMM's epilogue, the activation derivative (from
+ * the saved pre-activation for GELU) and the regenerated dropout mask in the epilogue of the data-gradient GEMM.
+ * D % 4 == 0, D <= 1024.  Philox sites: residual_layernorm `site`; ffn_block site_base (hidden) and site_base + 1 (output).
+ * ---------------------------------------------------------------------------------------------------------- */
+int immtsf_residual_layernorm_forward(const float* x, const float* branch, int32_t rows, int32_t d, const float* gamma, const float* beta,
+                                      float eps, int32_t training, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev,
+                                      float* xhat, float* rstd, float* out, immtsf_stream_t stream);
+/* dout (read only) -> dx (gradient wrt x), dbranch (gradient wrt branch), dgamma, dbeta (written); scratch >= 64 (d + 8) floats */
+int immtsf_residual_layernorm_backward(const float* dout, int32_t rows, int32_t d, const float* gamma, const float* xhat, const float* rstd,
+                                       int32_t training, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, float* dx,
+                                       float* dbranch, float* dgamma, float* dbeta, float* scratch, immtsf_stream_t stream);
+typedef struct immtsf_ffn_block_cfg {
+    int32_t R, D, F;               /* rows, d_model, d_ff */
+    int32_t act;                   /* 1 relu, 2 gelu */
+    int32_t precision, training;
+    float p_drop, eps;
+    uint64_t seed;
+    const uint64_t* seed_step_dev;
+    uint64_t site_base;
+    int32_t grads_prezeroed;
+} immtsf_ffn_block_cfg;
+typedef struct immtsf_ffn_block_params {
+    float *w1, *b1;     /* (F, D), (F)   conv1 (kernel size 1) */
+    float *w2, *b2;     /* (D, F), (D)   conv2 */
+    float *ln_w, *ln_b; /* (D), (D)      norm2 */
+} immtsf_ffn_block_params;
+size_t immtsf_ffn_block_workspace_bytes(const immtsf_ffn_block_cfg* cfg);
+size_t immtsf_ffn_block_scratch_bytes(const immtsf_ffn_block_cfg* cfg);
+int immtsf_ffn_block_forward(const immtsf_ffn_block_cfg* cfg, const immtsf_ffn_block_params* p, const float* x, float* out, void* workspace,
+                             size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* cfg, const immtsf_ffn_block_params* p, const float* x, const float* dout, float* dx,
+                              void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                              const immtsf_ffn_block_params* grads, immtsf_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
  * precision, M, N, K, nprob, nbatch, dyn, grid threads, kernel path) and ms[max]; returns the number of records and resets

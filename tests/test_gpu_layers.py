@@ -418,3 +418,54 @@ def test_encoder_layer_block_dropout_masks():
         errs[k2] = _rel(got[k2], q2.grad.float())
     bad = {k2: v2 for k2, v2 in errs.items() if not v2 <= 3e-4}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("act,p", [("gelu", 0.0), ("gelu", 0.3), ("relu", 0.3)])
+def test_ffn_block_and_residual_layernorm_vs_torch(act, p):
+    """ops.residual_layer_norm + ops.ffn_block (the two joints of layers.Transformer_EncDec.EncoderLayer) against a float64
+    torch composition that uses the exported Philox keep-masks: GELU/ReLU in the GEMM epilogue, the activation derivative
+    and the regenerated dropout mask in the data-gradient epilogue; fp32 1e-4 / 3e-4."""
+    dev = _dev()
+    from immtsf import config, ops
+    R, D, F = 150, 48, 112
+    torch.manual_seed(11)
+    config.manual_seed(5)
+    conv1, conv2 = torch.nn.Conv1d(D, F, 1).to(dev), torch.nn.Conv1d(F, D, 1).to(dev)
+    n1, n2 = torch.nn.LayerNorm(D).to(dev), torch.nn.LayerNorm(D).to(dev)
+    with torch.no_grad():
+        for n in (n1, n2):
+            n.weight.uniform_(0.5, 1.5)
+            n.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(6, 25, D, device=dev, requires_grad=True)
+    br = torch.randn(6, 25, D, device=dev, requires_grad=True)
+    up = torch.randn(6, 25, D, device=dev)
+    base = ops.SITE_LAYER_BASE + 128
+    c0 = config._counter
+    x1 = ops.residual_layer_norm(x, br, n1, p, True, base)
+    y = ops.ffn_block(x1, conv1, conv2, n2, act, p, True, base + 1)
+    (y * up).sum().backward()
+    config._counter = c0
+    s1 = config.next_seed() if p > 0 else 0
+    s2 = config.next_seed() if p > 0 else 0
+    keep = lambda seed, site, shape: (ops.dropout_keep_mask(seed, site, int(np.prod(shape)), p, dev).view(*shape).double() / (1 - p)  # noqa: E731
+                                      if p > 0 else torch.ones(*shape, dtype=torch.float64, device=dev))
+    m1, mh, mo = keep(s1, base, (R, D)), keep(s2, base + 1, (R, F)), keep(s2, base + 2, (R, D))
+    P = {k: q.detach().double().requires_grad_(True) for k, q in (("w1", conv1.weight), ("b1", conv1.bias), ("w2", conv2.weight),
+                                                                  ("b2", conv2.bias), ("g1", n1.weight), ("be1", n1.bias),
+                                                                  ("g2", n2.weight), ("be2", n2.bias))}
+    xd, bd = x.detach().double().reshape(R, D).requires_grad_(True), br.detach().double().reshape(R, D).requires_grad_(True)
+    ln = torch.nn.functional.layer_norm
+    a1 = ln(xd + bd * m1, (D,), P["g1"], P["be1"], n1.eps)
+    pre = a1 @ P["w1"].squeeze(-1).T + P["b1"]
+    h = (torch.nn.functional.gelu(pre) if act == "gelu" else torch.relu(pre)) * mh
+    ff = h @ P["w2"].squeeze(-1).T + P["b2"]
+    out = ln(a1 + ff * mo, (D,), P["g2"], P["be2"], n2.eps)
+    (out * up.double().reshape(R, D)).sum().backward()
+    assert _rel(y.reshape(R, D), out.detach().float()) <= 1e-4
+    errs = {"dx": _rel(x.grad.reshape(R, D), xd.grad.float()), "dbranch": _rel(br.grad.reshape(R, D), bd.grad.float()),
+            "w1": _rel(conv1.weight.grad, P["w1"].grad.float()), "b1": _rel(conv1.bias.grad, P["b1"].grad.float()),
+            "w2": _rel(conv2.weight.grad, P["w2"].grad.float()), "b2": _rel(conv2.bias.grad, P["b2"].grad.float()),
+            "g1": _rel(n1.weight.grad, P["g1"].grad.float()), "be1": _rel(n1.bias.grad, P["be1"].grad.float()),
+            "g2": _rel(n2.weight.grad, P["g2"].grad.float()), "be2": _rel(n2.bias.grad, P["be2"].grad.float())}
+    bad = {k: v for k, v in errs.items() if not v <= 3e-4}
+    assert not bad, bad

@@ -447,6 +447,19 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     const bool can_split = all_c && !any_h && g.act == 0 && !g.relu_ref && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     if (can_split && g2_splitk > 1) splits = g2_splitk;
+    // ... except for LONG reductions on few tiles (weight gradients at >= 512 windows per GPU: 768x768x32768): there the 64x64
+    // tiles are bound by L2 -> LDS bytes (1.2 GB for 100 MB of operands), 128x128 tiles halve that but leave 36 workgroups,
+    // so the reduction is cut over ~256 / tiles workgroups: 151 -> 112 us (tools/gemm2_bench.py longk)
+    bool long_k = false;
+    if (can_split && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.K >= 16384 && g.nprob == 1) {
+        const long t128s = (long)cdiv(Mmax, 128) * cdiv(g.N, 128);
+        if (t128s <= 72) {
+            long_k = true;
+            splits = (int)(256 / t128s);
+            if (splits > 8) splits = 8;
+            if (splits < 1) splits = 1;
+        }
+    }
     if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
             hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
@@ -474,7 +487,8 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         const long n128x96 = (long)cdiv(Meff, 128) * cdiv(g.N, 96) * g.nprob;
         const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
         const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
-        if (t128 >= 1024 && layout != GEMM_TN) v = 13;          // 256x256, 8 waves, 2 stages
+        if (long_k) v = 18;                                       // 128x128 k2 with the reduction split over workgroups
+        else if (t128 >= 1024 && layout != GEMM_TN) v = 13;     // 256x256, 8 waves, 2 stages
         else if (t128 >= 512) v = 7;                              // 256x128
         else if (n64 <= 272) v = 17;                              // 64x64 k4
         else if (n96_ok && n96 <= 272) v = 16;                    // 64x96 k4

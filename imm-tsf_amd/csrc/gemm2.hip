@@ -453,9 +453,9 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     bool long_k = false;
     if (can_split && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.K >= 16384 && g.nprob == 1) {
         const long t128s = (long)cdiv(Mmax, 128) * cdiv(g.N, 128);
-        if (t128s <= 72) {
+        if (t128s <= 256) {       // (768x4096x145k, cfg5's input-projection gradient, 192 tiles: 4249 us on 128x96 k2 -> 1770 us split 4)
             long_k = true;
-            splits = (int)(256 / t128s);
+            splits = t128s <= 72 ? (int)(256 / t128s) : 4;
             if (splits > 8) splits = 8;
             if (splits < 1) splits = 1;
         }

@@ -281,7 +281,7 @@ class FlatTrainer:
         is exactly the single-process full-batch gradient."""
         self._collect_autograd_grads()
         if self.sharded:
-            if not all(self._reduced):
+            if self.collective and not all(self._reduced):      # collective off (a rank-local measurement leg): no communication
                 self._reduce_scatter()
                 self._reduced = [True] * len(self.buckets)
             return
@@ -346,14 +346,16 @@ class FlatTrainer:
             sd = _lib.ptr(self.step_dev) if self.device_step else None
             dd = _lib.ptr(self.drop_dev) if self.device_step else None
             _lib.check(lib.immtsf_adam_sqnorm(_lib.ptr(g), per, _lib.ptr(self.norm_scratch), sd, dd, _lib.stream_ptr()), "adam_sqnorm")
-            dist.all_reduce(self.norm_scratch, group=self.group)
+            if self.collective:
+                dist.all_reduce(self.norm_scratch, group=self.group)
             tw = _lib.ptr(self.flat_twin[lo:hi]) if self.flat_twin is not None else None
             _lib.check(lib.immtsf_adam_apply(_lib.ptr(p), _lib.ptr(g), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), per, self.lr,
                                              self.betas[0], self.betas[1], self.eps, self.wd, self.step_count, sd, self.max_norm,
                                              _lib.ptr(self.norm_scratch), tw, _lib.stream_ptr()), "adam_apply")
         else:
             sq = (g * g).sum().reshape(1)
-            dist.all_reduce(sq, group=self.group)
+            if self.collective:
+                dist.all_reduce(sq, group=self.group)
             gg = g
             if self.max_norm and self.max_norm > 0:
                 gg = g * torch.clamp(self.max_norm / (sq.sqrt() + 1e-6), max=1.0)
@@ -366,6 +368,10 @@ class FlatTrainer:
             p.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
             if self.flat_twin is not None:
                 self.flat_twin[lo:hi].copy_(p)
+        if not self.collective:          # rank-local leg: the other ranks' shards simply keep their values
+            if self.param_wire != "bf16":
+                self.refresh_twins()
+            return
         if self.param_wire == "bf16":
             self._all_gather(self.flat_twin, self.flat_twin[lo:hi])
             if self.flat_param.is_cuda:

@@ -98,6 +98,14 @@ def _worker_sharded(rank, world, port, q, wire, param_wire):
             torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)
             opt.step()
         p_ref = torch.cat([ref[k].detach().reshape(-1) for k in order])
+        # a rank-local leg (bench.py's roofline tap runs steps on rank 0 only): with `collective` off the sharded step must not
+        # communicate -- rank 1 is already waiting at the barrier below, so a collective here would hang the pair
+        tr.collective = False
+        tr.zero_grad()
+        _loss(params, shard, cnt, H).backward()
+        tr.sync_grads()
+        tr.step()
+        tr.collective = True
         q.put({"perr": float((p_dp - p_ref).abs().max()), "same": same})
     dist.barrier()
     dist.destroy_process_group()

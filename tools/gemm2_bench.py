@@ -181,6 +181,16 @@ print("correctness failures:", bad, flush=True)
 print("== timing (us per launch, 50 launches per hipGraph, best of 3 replays)")
 shapes = [(0, 2048, 768, 768), (1, 2048, 768, 768), (2, 768, 768, 2048), (0, 2048, 1536, 768), (1, 2048, 768, 1536),
           (2, 1536, 768, 2048), (0, 1117, 1536, 768), (2, 1536, 768, 1117), (0, 768, 768, 768), (2, 768, 768, 768)]
+if mode == "longk5":
+    M, N, K = 768, 4096, 145408
+    print(f"TN {M}x{N}x{K}: vendor {bench_vendor(2, M, N, K):8.1f} us   heuristic {bench2(2, M, N, K, 0, 0, 'f32'):8.1f} us", flush=True)
+    for v in (18, 22, 7, 6):
+        row = []
+        for sk in (1, 2, 3, 4):
+            u = bench2(2, M, N, K, v, sk, "f32")
+            row.append(f"sk{sk} {u:7.1f}" if u else f"sk{sk}    -")
+        print(f"   v{v:2d} {VAR[v]:13s} " + " ".join(row), flush=True)
+    sys.exit(0)
 if mode == "longk":
     # long reductions (weight gradients at >= 512 windows per GPU): tile variants x cross-workgroup split-K
     for K in (8192, 32768):

@@ -1,0 +1,191 @@
+// TimesNet's Inception block (reference layers/Conv_Blocks.py:5-31: the MEAN of num_kernels same-padded 2-D convolutions
+// with kernel sizes 1, 3, ..., 2 n - 1) as ONE convolution on the MFMA GEMM.
+//
+// Convolution is linear in the kernel, so mean_i conv(x, W_i) = conv(x, W_eff) with W_eff = (1/n) sum_i W_i zero-padded
+// to the largest size KS = 2 n - 1 (immtsf_inception_merge; its backward, immtsf_inception_unmerge, hands every W_i the
+// centre crop of dW_eff / n).  The merged convolution runs channels-last -- TimesBlock's (B, length, d_model) activations
+// ARE channels-last images (B, length / period, period, d_model), so the reference's permutes disappear -- as
+//   im2col:  col[(b,h,w), (dy,dx,ci)] = x[b, h+dy-r, w+dx-r, ci]   (zero outside; r = KS / 2)
+//   GEMM  :  y[(b,h,w), co] = act(col W_eff^T + b_eff)              (bias / GELU in the epilogue, pre-activation kept)
+// and backward as dcol = dz W_eff (GEMM), dx = col2im(dcol) (a gather: every input element sums its <= KS^2 terms, no
+// atomics), dW_eff = dz^T col + db_eff (GEMM with the bias-gradient reduction).  Per period that is 2 launches forward and
+// 4-5 backward per convolution instead of 6 MIOpen convolutions + stack + mean (and their 12+ backward kernels).
+#include "../../include/immtsf.h"
+#include "block_util.hpp"
+
+namespace {
+
+struct ConvDims { int B, H, W, C, KS; };
+
+// grid rows = B*H*W; 256 threads walk the K = KS*KS*C columns of one row (C contiguous floats per tap)
+__global__ __launch_bounds__(256) void im2col_cl_kernel(ConvDims d, const float* __restrict__ x, float* __restrict__ col) {
+    const int row = blockIdx.x, w = row % d.W, h = (row / d.W) % d.H, b = row / (d.W * d.H), r = d.KS >> 1;
+    const int K = d.KS * d.KS * d.C;
+    float* out = col + (size_t)row * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int ci = k % d.C, tap = k / d.C, dx = tap % d.KS, dy = tap / d.KS;
+        const int hh = h + dy - r, ww = w + dx - r;
+        out[k] = (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[(((size_t)b * d.H + hh) * d.W + ww) * d.C + ci] : 0.f;
+    }
+}
+
+// dx[b,h,w,ci] = sum over taps of dcol[(b, h-dy+r, w-dx+r), (dy,dx,ci)]; one thread per input element
+__global__ __launch_bounds__(256) void col2im_cl_kernel(ConvDims d, const float* __restrict__ dcol, float* __restrict__ dxo) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)d.B * d.H * d.W * d.C;
+    if (i >= n) return;
+    const int ci = (int)(i % d.C);
+    const long p = i / d.C;
+    const int w = (int)(p % d.W), h = (int)((p / d.W) % d.H), b = (int)(p / ((long)d.W * d.H)), r = d.KS >> 1;
+    const int K = d.KS * d.KS * d.C;
+    float a = 0.f;
+    for (int dy = 0; dy < d.KS; ++dy) {
+        const int hh = h - dy + r;
+        if (hh < 0 || hh >= d.H) continue;
+        for (int dxx = 0; dxx < d.KS; ++dxx) {
+            const int ww = w - dxx + r;
+            if (ww < 0 || ww >= d.W) continue;
+            a += dcol[(((size_t)b * d.H + hh) * d.W + ww) * K + (dy * d.KS + dxx) * d.C + ci];
+        }
+    }
+    dxo[i] = a;
+}
+
+__device__ __forceinline__ float gelu_grad(float z) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * gelu_grad(z[i]);
+}
+
+struct KernelPtrs { const float* w[IMMTSF_INCEPTION_MAX]; const float* b[IMMTSF_INCEPTION_MAX]; };
+struct KernelGrads { float* w[IMMTSF_INCEPTION_MAX]; float* b[IMMTSF_INCEPTION_MAX]; };
+
+// W_eff[co][(dy,dx,ci)] = (1/n) sum_i W_i[co][ci][dy-r+i][dx-r+i] over the kernels that reach (dy,dx); b_eff = mean b_i
+__global__ __launch_bounds__(256) void inception_merge_kernel(int n, int Cin, int Cout, KernelPtrs p, float* __restrict__ Weff,
+                                                               float* __restrict__ beff) {
+    const int KS = 2 * n - 1, r = n - 1, K = KS * KS * Cin;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long)Cout * K) {
+        const int co = (int)(i / K), k = (int)(i % K), ci = k % Cin, tap = k / Cin, dx = tap % KS, dy = tap / KS;
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const int s = 2 * j + 1, yy = dy - r + j, xx = dx - r + j;
+            if (yy >= 0 && yy < s && xx >= 0 && xx < s) a += p.w[j][(((size_t)co * Cin + ci) * s + yy) * s + xx];
+        }
+        Weff[i] = a / (float)n;
+    }
+    if (i < Cout) {
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a += p.b[j][i];
+        beff[i] = a / (float)n;
+    }
+}
+
+// dW_j[co][ci][yy][xx] = dW_eff[co][((yy-j+r)*KS + (xx-j+r))*Cin + ci] / n ; db_j = db_eff / n   (written)
+__global__ __launch_bounds__(256) void inception_unmerge_kernel(int n, int Cin, int Cout, const float* __restrict__ dWeff,
+                                                                 const float* __restrict__ dbeff, KernelGrads g) {
+    const int KS = 2 * n - 1, r = n - 1, K = KS * KS * Cin, j = blockIdx.y, s = 2 * j + 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, cnt = (long)Cout * Cin * s * s;
+    const float inv = 1.f / (float)n;
+    if (i < cnt) {
+        const int xx = (int)(i % s), yy = (int)((i / s) % s), ci = (int)((i / ((long)s * s)) % Cin), co = (int)(i / ((long)s * s * Cin));
+        g.w[j][i] = dWeff[(size_t)co * K + ((yy - j + r) * KS + (xx - j + r)) * Cin + ci] * inv;
+    }
+    if (i < Cout) g.b[j][i] = dbeff[i] * inv;
+}
+
+inline bool bad_conv(int B, int H, int W, int Cin, int Cout, int KS) {
+    return B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KS < 1 || !(KS & 1) || (long)B * H * W > (1L << 30);
+}
+
+}  // namespace
+
+extern "C" {
+
+int immtsf_inception_merge(int32_t n, int32_t Cin, int32_t Cout, const float* const* W, const float* const* b, float* W_eff, float* b_eff,
+                           immtsf_stream_t stream) {
+    if (n < 1 || n > IMMTSF_INCEPTION_MAX || Cin <= 0 || Cout <= 0 || !W || !b || !W_eff || !b_eff) return IMMTSF_EINVAL;
+    KernelPtrs p;
+    for (int j = 0; j < n; ++j) {
+        if (!W[j] || !b[j]) return IMMTSF_EINVAL;
+        p.w[j] = W[j];
+        p.b[j] = b[j];
+    }
+    const long total = (long)Cout * (2 * n - 1) * (2 * n - 1) * Cin;
+    hipLaunchKernelGGL(inception_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, Cin,
+                       Cout, p, W_eff, b_eff);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int immtsf_inception_unmerge(int32_t n, int32_t Cin, int32_t Cout, const float* dW_eff, const float* db_eff, float* const* dW, float* const* db,
+                             immtsf_stream_t stream) {
+    if (n < 1 || n > IMMTSF_INCEPTION_MAX || Cin <= 0 || Cout <= 0 || !dW_eff || !db_eff || !dW || !db) return IMMTSF_EINVAL;
+    KernelGrads g;
+    for (int j = 0; j < n; ++j) {
+        if (!dW[j] || !db[j]) return IMMTSF_EINVAL;
+        g.w[j] = dW[j];
+        g.b[j] = db[j];
+    }
+    const long biggest = (long)Cout * Cin * (2 * n - 1) * (2 * n - 1);
+    hipLaunchKernelGGL(inception_unmerge_kernel, dim3((unsigned)((biggest + 255) / 256), n), dim3(256), 0, static_cast<hipStream_t>(stream), n,
+                       Cin, Cout, dW_eff, db_eff, g);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+/* x (B, H, W, Cin) channels-last; W_eff (Cout, KS*KS*Cin) tap-major / channel-minor; y (B, H, W, Cout).  col: workspace of
+ * B*H*W * KS*KS*Cin floats, kept for backward; z_pre (may be NULL unless act == 2): the pre-activation, kept for backward */
+int immtsf_conv2d_same_cl_forward(int32_t precision, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t KS,
+                                  const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
+                                  immtsf_stream_t stream) {
+    if (!x || !W_eff || !col || !y || bad_conv(B, H, W, Cin, Cout, KS) || (act != 0 && act != 2) || (act == 2 && !z_pre)) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = B * H * W, K = KS * KS * Cin;
+    hipLaunchKernelGGL(im2col_cl_kernel, dim3(rows), dim3(256), 0, s, ConvDims{B, H, W, Cin, KS}, x, col);
+    IMMTSF_LAUNCH_CHECK();
+    GemmArgs g = gemm_args(rows, Cout, K, K, K, Cout);
+    set_problem(g, 0, col, W_eff, y, b_eff);
+    g.p[0].Cpre = act == 2 ? z_pre : nullptr;
+    g.act = act;
+    return immtsf_launch_gemm(GEMM_NT, precision, g, s);
+}
+
+/* dy (B, H, W, Cout) -> dx (B, H, W, Cin; may be NULL), dW_eff (Cout, K), db_eff (Cout) (written).  scratch: B*H*W * (K + Cout)
+ * floats (dcol, and dz when act != 0) */
+int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const float* z_pre, const float* y, const float* dy, int32_t B,
+                                   int32_t H, int32_t W, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act, float* dx,
+                                   float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream) {
+    (void)y;
+    if (!col || !dy || !W_eff || !dW_eff || !db_eff || !scratch || bad_conv(B, H, W, Cin, Cout, KS) || (act != 0 && act != 2) ||
+        (act == 2 && !z_pre))
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = B * H * W, K = KS * KS * Cin;
+    float* dcol = scratch;
+    float* dz = scratch + (size_t)rows * K;
+    const float* g0 = dy;
+    if (act == 2) {
+        const long n = (long)rows * Cout;
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, z_pre, dz, n);
+        IMMTSF_LAUNCH_CHECK();
+        g0 = dz;
+    }
+    {   // dW_eff = g0^T col ; db_eff = column sums of g0
+        GemmArgs h = gemm_args(Cout, K, rows, Cout, K, K);
+        set_problem(h, 0, g0, col, dW_eff, nullptr, db_eff);
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+    }
+    if (dx) {
+        GemmArgs g = gemm_args(rows, K, Cout, Cout, K, K);
+        set_problem(g, 0, g0, W_eff, dcol, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
+        const long n = (long)rows * Cin;
+        hipLaunchKernelGGL(col2im_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ConvDims{B, H, W, Cin, KS}, dcol, dx);
+        IMMTSF_LAUNCH_CHECK();
+    }
+    return IMMTSF_OK;
+}
+
+}  // extern "C"

@@ -155,6 +155,14 @@ _PROTOS = {
     "immtsf_ffn_block_forward": (C.c_int, [_P(FFNBlockCfg), _P(FFNBlockParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_ffn_block_backward": (C.c_int, [_P(FFNBlockCfg), _P(FFNBlockParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t, _P(FFNBlockParams), c_stream]),
+    "immtsf_inception_merge": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_f32p, c_f32p, c_stream]),
+    "immtsf_inception_unmerge": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           c_stream]),
+    "immtsf_conv2d_same_cl_forward": (C.c_int, [C.c_int32, c_f32p] + [C.c_int32] * 5 + [c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                                                                     c_f32p, c_stream]),
+    "immtsf_conv2d_same_cl_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p] + [C.c_int32] * 5 + [c_f32p, C.c_int32, C.c_int32,
+                                                                                                               c_f32p, c_f32p, c_f32p, c_f32p,
+                                                                                                               c_stream]),
     "immtsf_tpatchgnn_gcn_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_stream]),
     "immtsf_tpatchgnn_gcn_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams),
                                                 c_stream]),

@@ -730,6 +730,96 @@ def ffn_block(x, conv1, conv2, norm, act, p_drop, training, site_base, precision
                             seed, site_base, conv1.weight, conv1.bias, conv2.weight, conv2.bias, norm.weight, norm.bias)
 
 
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+class InceptionMergeFn(torch.autograd.Function):
+    """(W_0 .. W_{n-1}, b_0 .. b_{n-1}) of an Inception_Block_V1 (kernel sizes 1, 3, .., 2n-1) -> the ONE averaged kernel as a
+    GEMM weight W_eff (Cout, KS*KS*Cin) and bias b_eff (immtsf_inception_merge / _unmerge)."""
+
+    @staticmethod
+    def forward(ctx, n, *wb):
+        lib = _lib.load()
+        ws, bs = [_c(t) for t in wb[:n]], [_c(t) for t in wb[n:]]
+        _need_gpu(*ws, *bs)
+        Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+        KS = 2 * n - 1
+        Weff = torch.empty(Cout, KS * KS * Cin, dtype=torch.float32, device=ws[0].device)
+        beff = torch.empty(Cout, dtype=torch.float32, device=ws[0].device)
+        check(lib.immtsf_inception_merge(n, Cin, Cout, _ptr_array(ws), _ptr_array(bs), ptr(Weff), ptr(beff), stream_ptr()), "inception_merge")
+        ctx.dims = (n, Cin, Cout)
+        ctx.shapes = [w.shape for w in ws] + [b.shape for b in bs]
+        ctx.sinks = _sinks_of(wb)
+        ctx.params = wb            # parameters (not saved tensors: only their sinks / shapes are needed)
+        return Weff, beff
+
+    @staticmethod
+    def backward(ctx, dW, db):
+        lib = _lib.load()
+        n, Cin, Cout = ctx.dims
+        grads, rets = _grad_buffers(ctx.params, ctx.sinks)
+        ctx.params = None
+        check(lib.immtsf_inception_unmerge(n, Cin, Cout, ptr(dW.contiguous()), ptr(db.contiguous()), _ptr_array(grads[:n]), _ptr_array(grads[n:]),
+                                           stream_ptr()), "inception_unmerge")
+        return (None,) + tuple(rets)
+
+
+class Conv2dSameCLFn(torch.autograd.Function):
+    """y (B,H,W,Cout) = act(conv2d_same(x (B,H,W,Cin), W_eff) + b_eff) on channels-last images: im2col + MFMA GEMM
+    (immtsf_conv2d_same_cl_forward/backward); act 0 none, 2 GELU."""
+
+    @staticmethod
+    def forward(ctx, x, Weff, beff, KS, act, precision):
+        lib = _lib.load()
+        x, Weff, beff = _c(x), _c(Weff), _c(beff)
+        _need_gpu(x, Weff, beff)
+        B, H, W, Cin = x.shape
+        Cout = Weff.shape[0]
+        rows, K = B * H * W, KS * KS * Cin
+        col = torch.empty(rows, K, dtype=torch.float32, device=x.device)
+        z = torch.empty(rows, Cout, dtype=torch.float32, device=x.device) if act == 2 else None
+        y = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+        check(lib.immtsf_conv2d_same_cl_forward(precision, ptr(x), B, H, W, Cin, KS, ptr(Weff), ptr(beff), Cout, act, ptr(col), ptr(z), ptr(y),
+                                                stream_ptr()), "conv2d_same_cl_forward")
+        ctx.save_for_backward(col, z, Weff)
+        ctx.dims = (B, H, W, Cin, KS, Cout, act, precision)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        col, z, Weff = ctx.saved_tensors
+        B, H, W, Cin, KS, Cout, act, precision = ctx.dims
+        rows, K = B * H * W, KS * KS * Cin
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(Weff)
+        db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(rows * (K + Cout), dtype=torch.float32, device=dy.device)
+        check(lib.immtsf_conv2d_same_cl_backward(precision, ptr(col), ptr(z), None, ptr(dy), B, H, W, Cin, KS, ptr(Weff), Cout, act, ptr(dx),
+                                                 ptr(dW), ptr(db), ptr(scratch), stream_ptr()), "conv2d_same_cl_backward")
+        return dx, dW, db, None, None, None
+
+
+INCEPTION_MAX = 8
+
+
+def inception_merge(block):
+    """block: layers.Conv_Blocks.Inception_Block_V1 -> (W_eff, b_eff, KS)"""
+    ks = block.kernels
+    n = len(ks)
+    Weff, beff = InceptionMergeFn.apply(n, *[k.weight for k in ks], *[k.bias for k in ks])
+    return Weff, beff, 2 * n - 1
+
+
+def conv2d_same_cl(x, Weff, beff, KS, act=None, precision=None):
+    return Conv2dSameCLFn.apply(x.float(), Weff, beff, int(KS), 2 if act == "gelu" else 0, config.precision_code(precision))
+
+
 class TPatchDecoderFn(torch.autograd.Function):
     """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction, exact fp32.
     Backward recomputes the forward; parameter gradients accumulate by atomics into one zeroed flat buffer."""

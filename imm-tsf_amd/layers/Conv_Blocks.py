@@ -1,5 +1,6 @@
 """Inception block of TimesNet (reference layers/Conv_Blocks.py:5-31): mean of `num_kernels` same-padded 2-D convs.
-Backbone-internal; runs on MIOpen through stock torch."""
+models/TimesNet.py evaluates it as ONE merged convolution on the HIP GEMM (immtsf.ops.inception_merge + conv2d_same_cl);
+this module keeps the reference's parameters / state_dict keys and its op-by-op forward for callers that use it directly."""
 import torch
 import torch.nn as nn
 

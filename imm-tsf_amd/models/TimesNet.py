@@ -1,12 +1,15 @@
 """TimesNet backbone (reference models/TimesNet.py:9-152): DataEmbedding(2C+1 -> d_model) on [value; mask; time],
-FFT period selection, 2-D Inception convolutions per period, adaptive aggregation.  Same signature/state_dict;
-DataEmbedding's token convolution and the two Linear maps run on the HIP GEMM, the Inception convs on MIOpen."""
+FFT period selection, 2-D Inception convolutions per period, adaptive aggregation.  Same signature/state_dict.
+DataEmbedding is one HIP kernel, the two Linear maps run on the HIP GEMM, and each Inception block (the mean of six
+same-padded convolutions, layers/Conv_Blocks.py:5-31) runs as ONE merged convolution on channels-last images: im2col +
+MFMA GEMM with the bias / GELU epilogue (immtsf.ops.inception_merge / conv2d_same_cl, csrc/conv.hip).  The FFT period
+selection keeps the reference's host sync (:13-16): the image shapes depend on it."""
 import torch
 import torch.fft
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf.ops import layer_norm, linear
+from immtsf.ops import INCEPTION_MAX, conv2d_same_cl, inception_merge, layer_norm, linear
 from layers.Conv_Blocks import Inception_Block_V1
 from layers.Embed import DataEmbedding
 from models._common import pad_history, plain_instance_norm
@@ -33,13 +36,23 @@ class TimesBlock(nn.Module):
         B, T, N = x.size()
         total = self.seq_len + self.pred_len
         periods, weight = FFT_for_Period(x, self.k)
+        inc1, act, inc2 = self.conv[0], self.conv[1], self.conv[2]
+        merged = (x.is_cuda and isinstance(inc1, Inception_Block_V1) and isinstance(inc2, Inception_Block_V1) and isinstance(act, nn.GELU)
+                  and getattr(act, "approximate", "none") == "none" and max(len(inc1.kernels), len(inc2.kernels)) <= INCEPTION_MAX)
+        if merged:      # one averaged kernel per block and step, shared by all periods
+            W1, b1, K1 = inception_merge(inc1)
+            W2, b2, K2 = inception_merge(inc2)
         res = []
         for period in periods:
             period = int(period)
             length = total if total % period == 0 else (total // period + 1) * period
             out = F.pad(x, (0, 0, 0, length - total)) if length != total else x
-            out = out.reshape(B, length // period, period, N).permute(0, 3, 1, 2).contiguous()
-            out = self.conv(out).permute(0, 2, 3, 1).reshape(B, -1, N)
+            if merged:      # (B, length, N) IS the channels-last image (B, length / period, period, N): no permutes
+                img = conv2d_same_cl(out.reshape(B, length // period, period, N), W1, b1, K1, act="gelu")
+                out = conv2d_same_cl(img, W2, b2, K2).reshape(B, -1, N)
+            else:
+                out = out.reshape(B, length // period, period, N).permute(0, 3, 1, 2).contiguous()
+                out = self.conv(out).permute(0, 2, 3, 1).reshape(B, -1, N)
             res.append(out[:, :total, :])
         res = torch.stack(res, dim=-1)
         w = F.softmax(weight, dim=1).unsqueeze(1).unsqueeze(1)

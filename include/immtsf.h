@@ -512,6 +512,30 @@ int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* cfg, const immtsf_ffn_
                               void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                               const immtsf_ffn_block_params* grads, immtsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * TimesNet's Inception block (reference layers/Conv_Blocks.py:5-31, used by models/TimesNet.py:21-68): the mean of n
+ * same-padded 2-D convolutions with kernel sizes 1, 3, ..., 2n-1 is ONE convolution with the averaged, zero-padded
+ * kernel.  merge builds that kernel as a GEMM weight W_eff (Cout, KS*KS*Cin), KS = 2n-1, columns ordered (dy, dx, ci);
+ * unmerge is its backward (each W_i receives the centre crop of dW_eff / n, each b_i db_eff / n; written).  W / b / dW /
+ * db: HOST arrays of n device pointers, W_i (Cout, Cin, 2i+1, 2i+1) as nn.Conv2d stores it.
+ * conv2d_same_cl: the merged convolution on channels-last images (B, H, W, C) -- TimesBlock's (B, length, d_model)
+ * activations viewed as (B, length/period, period, d_model) -- as im2col + MFMA GEMM (bias / GELU epilogue); backward:
+ * GEMM + col2im gather for dx, GEMM with bias-gradient reduction for dW_eff / db_eff.  act: 0 none, 2 GELU(erf).
+ * ---------------------------------------------------------------------------------------------------------- */
+#define IMMTSF_INCEPTION_MAX 8
+int immtsf_inception_merge(int32_t n, int32_t Cin, int32_t Cout, const float* const* W, const float* const* b, float* W_eff, float* b_eff,
+                           immtsf_stream_t stream);
+int immtsf_inception_unmerge(int32_t n, int32_t Cin, int32_t Cout, const float* dW_eff, const float* db_eff, float* const* dW, float* const* db,
+                             immtsf_stream_t stream);
+/* col: B*H*W * KS*KS*Cin floats (kept for backward); z_pre: B*H*W*Cout floats, required when act == 2 (kept for backward) */
+int immtsf_conv2d_same_cl_forward(int32_t precision, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t KS,
+                                  const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
+                                  immtsf_stream_t stream);
+/* dx may be NULL; dW_eff, db_eff are written; scratch: B*H*W * (KS*KS*Cin + Cout) floats */
+int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const float* z_pre, const float* y, const float* dy, int32_t B,
+                                   int32_t H, int32_t W, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act, float* dx,
+                                   float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
  * precision, M, N, K, nprob, nbatch, dyn, grid threads, kernel path) and ms[max]; returns the number of records and resets

@@ -469,3 +469,41 @@ def test_ffn_block_and_residual_layernorm_vs_torch(act, p):
             "g2": _rel(n2.weight.grad, P["g2"].grad.float()), "be2": _rel(n2.bias.grad, P["be2"].grad.float())}
     bad = {k: v for k, v in errs.items() if not v <= 3e-4}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,n,precision", [(3, 5, 4, 6, 8, 3, "fp32"), (64, 8, 8, 16, 32, 6, "fp32"), (64, 8, 8, 16, 32, 6, "bf16")])
+def test_inception_block_as_one_merged_convolution(B, H, W, Cin, Cout, n, precision):
+    """ops.inception_merge + ops.conv2d_same_cl (GELU) against layers.Conv_Blocks.Inception_Block_V1 evaluated by torch in
+    float64 on the CPU (the mean of n same-padded convolutions), forward and every gradient; the second case is TimesNet's
+    cfg4 shape (d_model 16 -> d_ff 32, six kernels up to 11 x 11, 64 windows x 64 positions)."""
+    dev = _dev()
+    from immtsf import config, ops
+    from layers.Conv_Blocks import Inception_Block_V1
+    torch.manual_seed(2)
+    blk = Inception_Block_V1(Cin, Cout, num_kernels=n).to(dev)
+    with torch.no_grad():
+        for k in blk.kernels:
+            k.bias.uniform_(-0.2, 0.2)
+    ref = Inception_Block_V1(Cin, Cout, num_kernels=n).double()
+    ref.load_state_dict({k: v.double().cpu() for k, v in blk.state_dict().items()})
+    x = torch.randn(B, H, W, Cin)
+    up = torch.randn(B, H, W, Cout)
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.gelu(ref(xr.permute(0, 3, 1, 2))).permute(0, 2, 3, 1)
+    (yr * up.double()).sum().backward()
+    config.precision = precision
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        Weff, beff, KS = ops.inception_merge(blk)
+        y = ops.conv2d_same_cl(xg, Weff, beff, KS, act="gelu")
+        (y * up.to(dev)).sum().backward()
+    finally:
+        config.precision = "fp32"
+    err = _rel if precision == "fp32" else _l2err
+    tol_o, tol_g = (1e-4, 3e-4) if precision == "fp32" else (3e-2, 4e-2)
+    assert err(y, yr.detach().float()) <= tol_o
+    errs = {"dx": err(xg.grad, xr.grad.float())}
+    for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        errs[k] = err(p.grad, q.grad.float())
+    bad = {k: v for k, v in errs.items() if not v <= tol_g}
+    assert not bad, bad

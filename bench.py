@@ -661,6 +661,8 @@ def main():
                 comm_mode = (f"reduce-scatter ({wire}) -> clip + Adam on the rank's 1/{world} shard -> all-gather ({pwire}), eager, behind "
                              "graph A") if sharded else "all-reduce, eager, between the graphs"
             step = GraphedStep(trainer, w.loss_fn)
+            if getattr(step, "single", False):
+                launch_mode = launch_mode.replace("(2 graphs/step)", "(1 graph/step: forward, backward, clip + Adam)")
     else:
         step = w.eager_step
 

@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Iterable, List, Optional, Sequence
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -481,11 +483,16 @@ class GraphedStep:
             trainer.restore(snap)
             torch.cuda.synchronize()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # no communication between backward and optimizer (one process): clip + Adam ride at the end of graph A -- one graph
+        # launch per step instead of two
+        self.single = (not trainer.collective) and os.environ.get("IMMTSF_TWO_GRAPHS", "0") != "1"
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
             if self.captured_comm:
                 trainer.sync_grads()
-        if not trainer.sharded:          # a sharded optimizer's step holds two collectives: it stays eager (three kernels)
+            if self.single:
+                trainer.step()
+        if not trainer.sharded and not self.single:          # a sharded optimizer's step holds two collectives: it stays eager (three kernels)
             with torch.cuda.graph(self.graph_b):
                 trainer.step()
 
@@ -501,6 +508,8 @@ class GraphedStep:
     def __call__(self):
         t = self.trainer
         self.graph_a.replay()
+        if self.single:
+            return self.loss
         if not self.captured_comm:
             t._reduced = [False] * len(t.buckets)
             t.sync_grads()

@@ -326,6 +326,41 @@ __global__ __launch_bounds__(1024) void colsum2_small_kernel(const float* __rest
     if (ty == 0 && tx < N) { out_xy[tx] = ra[tx]; out_x[tx] = rb[tx]; }
 }
 
+// the same for N % 4 == 0 with 16-byte row chunks: N / 4 column lanes x (1024 / (N/4)) row lanes -- a quarter of the loads
+// per thread in flight as float4s (M = 1024, N = 32: 8 rows per thread instead of 32; 17 -> ~6 us)
+__global__ __launch_bounds__(1024) void colsum2_small_vec_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M, int N,
+                                                                  int ld, int CT, float* __restrict__ out_xy, float* __restrict__ out_x) {
+    __shared__ float4 ra[1024], rb[1024];
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (tx * 4 < N) {
+#pragma unroll 8
+        for (int r = ty; r < M; r += RT) {
+            const float4 x = *reinterpret_cast<const float4*>(X + (size_t)r * ld + tx * 4);
+            const float4 y = *reinterpret_cast<const float4*>(Y + (size_t)r * ld + tx * 4);
+            a.x = fmaf(x.x, y.x, a.x); a.y = fmaf(x.y, y.y, a.y); a.z = fmaf(x.z, y.z, a.z); a.w = fmaf(x.w, y.w, a.w);
+            b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w;
+        }
+    }
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = b;
+    __syncthreads();
+    for (int st = RT >> 1; st > 0; st >>= 1) {
+        if (ty < st) {
+            const float4 p = ra[threadIdx.x + st * CT], q = rb[threadIdx.x + st * CT];
+            float4& u = ra[threadIdx.x];
+            float4& v = rb[threadIdx.x];
+            u.x += p.x; u.y += p.y; u.z += p.z; u.w += p.w;
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && tx * 4 < N) {
+        *reinterpret_cast<float4*>(out_xy + tx * 4) = ra[tx];
+        *reinterpret_cast<float4*>(out_x + tx * 4) = rb[tx];
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -679,7 +714,15 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
     if (N <= 32 && (long)M * N <= (1L << 17)) {
         int CT = 1;
         while (CT < N) CT <<= 1;
-        hipLaunchKernelGGL(colsum2_small_kernel, dim3(1), dim3(1024), 0, s, X, Y, M, N, ld, CT, out_xy, out_x);
+        const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(out_xy) |
+                             reinterpret_cast<uintptr_t>(out_x);
+        if ((N & 3) == 0 && (ld & 3) == 0 && (al & 15) == 0 && M >= 256) {
+            int CV = 1;
+            while (CV < N / 4) CV <<= 1;
+            hipLaunchKernelGGL(colsum2_small_vec_kernel, dim3(1), dim3(1024), 0, s, X, Y, M, N, ld, CV, out_xy, out_x);
+        } else {
+            hipLaunchKernelGGL(colsum2_small_kernel, dim3(1), dim3(1024), 0, s, X, Y, M, N, ld, CT, out_xy, out_x);
+        }
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }

@@ -175,10 +175,29 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
     float *se = sm, *sn = sm + C, *re = sm + 2 * C, *rc = re + 1024;
     __shared__ float s_nav;
     const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    // CT == C (C a power of two) and <= 16 K elements: thread t touches exactly the elements t + 1024 k in both passes, so the
+    // masked differences stay in registers for the gradient pass (no second read of the three tensors)
+    constexpr int KEEP = 16;
+    const bool keep = CT == C && (size_t)rows * C <= (size_t)KEEP * 1024;
+    float dm[KEEP];
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) dm[k] = 0.f;
     for (int c0 = 0; c0 < C; c0 += CT) {
         const int c = c0 + tx;
         float e = 0.f, n = 0.f;
-        if (c < C)
+        if (c < C && keep) {
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k) {
+                const int r = ty + k * RT;
+                if (r < rows) {
+                    const size_t i = (size_t)r * C + c;
+                    const float dlt = truth[i] - pred[i], m = mask[i];
+                    e = fmaf(dlt * dlt, m, e);
+                    n += m;
+                    dm[k] = -dlt * m;
+                }
+            }
+        } else if (c < C)
 #pragma unroll 8
             for (int r = ty; r < rows; r += RT) {       // independent loads: keep 8 rows in flight (one CU does all the work)
                 const size_t i = (size_t)r * C + c;
@@ -215,6 +234,15 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
     if (!dpred) return;
     const float navail = s_nav;
     const size_t n = (size_t)rows * C;
+    if (keep) {
+        const float f = grad_scale * 2.f / ((sn[tx] + 1e-8f) * navail);
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) {
+            const size_t i = (size_t)threadIdx.x + (size_t)k * 1024;
+            if (i < n) dpred[i] = dm[k] * f;
+        }
+        return;
+    }
 #pragma unroll 8
     for (size_t i = threadIdx.x; i < n; i += 1024) {
         const int c = (int)(i % C);

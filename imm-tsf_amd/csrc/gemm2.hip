@@ -488,7 +488,8 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
         const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
         if (long_k) v = 18;                                       // 128x128 k2 with the reduction split over workgroups
-        else if (t128 >= 1024 && layout != GEMM_TN) v = 13;     // 256x256, 8 waves, 2 stages
+        else if (t128 >= 1024 && layout == GEMM_NT && g.N >= 1024) v = 13;     // 256x256, 8 waves, 2 stages (short-K, N = 768 and NN: 256x128 wins,
+                                                                                // tools/gemm2_bench.py bigm)
         else if (t128 >= 512) v = 7;                              // 256x128
         else if (n64 <= 272) v = 17;                              // 64x64 k4
         else if (n96_ok && n96 <= 272) v = 16;                    // 64x96 k4

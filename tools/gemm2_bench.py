@@ -181,6 +181,15 @@ print("correctness failures:", bad, flush=True)
 print("== timing (us per launch, 50 launches per hipGraph, best of 3 replays)")
 shapes = [(0, 2048, 768, 768), (1, 2048, 768, 768), (2, 768, 768, 2048), (0, 2048, 1536, 768), (1, 2048, 768, 1536),
           (2, 1536, 768, 2048), (0, 1117, 1536, 768), (2, 1536, 768, 1117), (0, 768, 768, 768), (2, 768, 768, 768)]
+if mode == "bigm":
+    # many rows, short K (forward / data-gradient GEMMs at 1024 windows per GPU)
+    for (lay, M, N, K) in ((0, 32768, 768, 768), (1, 32768, 768, 768), (0, 32768, 1536, 768), (1, 32768, 768, 1536)):
+        fl = 2.0 * M * N * K
+        print(f"{['NT','NN','TN'][lay]} {M}x{N}x{K}: vendor {bench_vendor(lay, M, N, K):8.1f} us   heuristic {bench2(lay, M, N, K, 0, 0, 'both'):8.1f} us (fp32 + bf16 result)", flush=True)
+        for v in (5, 6, 7, 9, 12, 13, 24):
+            u = bench2(lay, M, N, K, v, 1, "both")
+            print(f"   v{v:2d} {VAR[v]:13s} {u:8.1f} us {fl/u/1e6:7.1f} TF" if u else f"   v{v:2d} -", flush=True)
+    sys.exit(0)
 if mode == "longk5":
     M, N, K = 768, 4096, 145408
     print(f"TN {M}x{N}x{K}: vendor {bench_vendor(2, M, N, K):8.1f} us   heuristic {bench2(2, M, N, K, 0, 0, 'f32'):8.1f} us", flush=True)

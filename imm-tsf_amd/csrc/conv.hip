@@ -7,9 +7,9 @@
 // ARE channels-last images (B, length / period, period, d_model), so the reference's permutes disappear -- as
 //   im2col:  col[(b,h,w), (dy,dx,ci)] = x[b, h+dy-r, w+dx-r, ci]   (zero outside; r = KS / 2)
 //   GEMM  :  y[(b,h,w), co] = act(col W_eff^T + b_eff)              (bias / GELU in the epilogue, pre-activation kept)
-// and backward as dcol = dz W_eff (GEMM), dx = col2im(dcol) (a gather: every input element sums its <= KS^2 terms, no
-// atomics), dW_eff = dz^T col + db_eff (GEMM with the bias-gradient reduction).  Per period that is 2 launches forward and
-// 4-5 backward per convolution instead of 6 MIOpen convolutions + stack + mean (and their 12+ backward kernels).
+// and backward as dW_eff = dz^T col + db_eff (GEMM with the bias-gradient reduction) and dx = the SAME im2col + GEMM
+// convolution applied to dz with the kernel flipped and its channel roles swapped.  Per period that is 2 launches forward
+// and 4-5 backward per convolution instead of 6 MIOpen convolutions + stack + mean (and their 12+ backward kernels).
 #include "../../include/immtsf.h"
 #include "block_util.hpp"
 
@@ -27,27 +27,6 @@ __global__ __launch_bounds__(256) void im2col_cl_kernel(ConvDims d, const float*
         const int hh = h + dy - r, ww = w + dx - r;
         out[k] = (hh >= 0 && hh < d.H && ww >= 0 && ww < d.W) ? x[(((size_t)b * d.H + hh) * d.W + ww) * d.C + ci] : 0.f;
     }
-}
-
-// dx[b,h,w,ci] = sum over taps of dcol[(b, h-dy+r, w-dx+r), (dy,dx,ci)]; one thread per input element
-__global__ __launch_bounds__(256) void col2im_cl_kernel(ConvDims d, const float* __restrict__ dcol, float* __restrict__ dxo) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)d.B * d.H * d.W * d.C;
-    if (i >= n) return;
-    const int ci = (int)(i % d.C);
-    const long p = i / d.C;
-    const int w = (int)(p % d.W), h = (int)((p / d.W) % d.H), b = (int)(p / ((long)d.W * d.H)), r = d.KS >> 1;
-    const int K = d.KS * d.KS * d.C;
-    float a = 0.f;
-    for (int dy = 0; dy < d.KS; ++dy) {
-        const int hh = h - dy + r;
-        if (hh < 0 || hh >= d.H) continue;
-        for (int dxx = 0; dxx < d.KS; ++dxx) {
-            const int ww = w - dxx + r;
-            if (ww < 0 || ww >= d.W) continue;
-            a += dcol[(((size_t)b * d.H + hh) * d.W + ww) * K + (dy * d.KS + dxx) * d.C + ci];
-        }
-    }
-    dxo[i] = a;
 }
 
 __device__ __forceinline__ float gelu_grad(float z) {
@@ -93,6 +72,15 @@ __global__ __launch_bounds__(256) void inception_unmerge_kernel(int n, int Cin, 
         g.w[j][i] = dWeff[(size_t)co * K + ((yy - j + r) * KS + (xx - j + r)) * Cin + ci] * inv;
     }
     if (i < Cout) g.b[j][i] = dbeff[i] * inv;
+}
+
+// the data gradient of a same-padded convolution is the convolution of dz with the kernel flipped in both directions and
+// its channel roles swapped: Wf[ci][(dy,dx,co)] = W_eff[co][(KS-1-dy, KS-1-dx, ci)]
+__global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int KS, const float* __restrict__ Weff, float* __restrict__ Wf) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, K2 = (long)KS * KS * Cout;
+    if (i >= (long)Cin * K2) return;
+    const int ci = (int)(i / K2), k = (int)(i % K2), co = k % Cout, tap = k / Cout, dx = tap % KS, dy = tap / KS;
+    Wf[i] = Weff[(size_t)co * KS * KS * Cin + ((KS - 1 - dy) * KS + (KS - 1 - dx)) * Cin + ci];
 }
 
 inline bool bad_conv(int B, int H, int W, int Cin, int Cout, int KS) {
@@ -152,8 +140,13 @@ int immtsf_conv2d_same_cl_forward(int32_t precision, const float* x, int32_t B, 
     return immtsf_launch_gemm(GEMM_NT, precision, g, s);
 }
 
-/* dy (B, H, W, Cout) -> dx (B, H, W, Cin; may be NULL), dW_eff (Cout, K), db_eff (Cout) (written).  scratch: B*H*W * (K + Cout)
- * floats (dcol, and dz when act != 0) */
+/* dy (B, H, W, Cout) -> dx (B, H, W, Cin; may be NULL), dW_eff (Cout, K), db_eff (Cout) (written).  scratch:
+ * immtsf_conv2d_same_cl_scratch_floats(...) floats (the im2col image of dz, dz itself when act != 0, the flipped kernel) */
+size_t immtsf_conv2d_same_cl_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t KS, int32_t Cout) {
+    const size_t rows = (size_t)B * H * W, K = (size_t)KS * KS * Cin, K2 = (size_t)KS * KS * Cout;
+    return rows * (K > K2 ? K : K2) + rows * Cout + (size_t)Cin * K2 + 64;
+}
+
 int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const float* z_pre, const float* y, const float* dy, int32_t B,
                                    int32_t H, int32_t W, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act, float* dx,
                                    float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream) {
@@ -163,8 +156,8 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
         return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows = B * H * W, K = KS * KS * Cin;
-    float* dcol = scratch;
-    float* dz = scratch + (size_t)rows * K;
+    const int K2s = KS * KS * Cout;
+    float* dz = scratch + (size_t)rows * (K > K2s ? K : K2s);
     const float* g0 = dy;
     if (act == 2) {
         const long n = (long)rows * Cout;
@@ -178,12 +171,20 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
         CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
     }
     if (dx) {
-        GemmArgs g = gemm_args(rows, K, Cout, Cout, K, K);
-        set_problem(g, 0, g0, W_eff, dcol, nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, precision, g, s));
-        const long n = (long)rows * Cin;
-        hipLaunchKernelGGL(col2im_cl_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ConvDims{B, H, W, Cin, KS}, dcol, dx);
+        // dx = conv(g0, flipped kernel): the same im2col + GEMM as the forward (K = KS*KS*Cout) instead of materialising
+        // dcol = g0 W_eff (rows x KS*KS*Cin floats: 64 MB at TimesNet's cfg4 shape, written by a K = Cout = 16 GEMM at 0.7 TB/s)
+        // and gathering it back
+        const int K2 = KS * KS * Cout;
+        float* colz = scratch;                                   // rows x K2
+        float* Wf = scratch + (size_t)rows * (K > K2 ? K : K2) + (size_t)rows * Cout;     // Cin x K2, behind dz
+        const long nw = (long)Cin * K2;
+        hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
         IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(im2col_cl_kernel, dim3(rows), dim3(256), 0, s, ConvDims{B, H, W, Cout, KS}, g0, colz);
+        IMMTSF_LAUNCH_CHECK();
+        GemmArgs g = gemm_args(rows, Cin, K2, K2, K2, Cin);
+        set_problem(g, 0, colz, Wf, dx, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
     return IMMTSF_OK;
 }

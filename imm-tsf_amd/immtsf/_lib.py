@@ -160,6 +160,7 @@ _PROTOS = {
                                            c_stream]),
     "immtsf_conv2d_same_cl_forward": (C.c_int, [C.c_int32, c_f32p] + [C.c_int32] * 5 + [c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                                                                      c_f32p, c_stream]),
+    "immtsf_conv2d_same_cl_scratch_floats": (C.c_size_t, [C.c_int32] * 6),
     "immtsf_conv2d_same_cl_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p] + [C.c_int32] * 5 + [c_f32p, C.c_int32, C.c_int32,
                                                                                                                c_f32p, c_f32p, c_f32p, c_f32p,
                                                                                                                c_stream]),

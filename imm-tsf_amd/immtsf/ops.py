@@ -799,7 +799,7 @@ class Conv2dSameCLFn(torch.autograd.Function):
         dx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(Weff)
         db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-        scratch = torch.empty(rows * (K + Cout), dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(lib.immtsf_conv2d_same_cl_scratch_floats(B, H, W, Cin, KS, Cout), dtype=torch.float32, device=dy.device)
         check(lib.immtsf_conv2d_same_cl_backward(precision, ptr(col), ptr(z), None, ptr(dy), B, H, W, Cin, KS, ptr(Weff), Cout, act, ptr(dx),
                                                  ptr(dW), ptr(db), ptr(scratch), stream_ptr()), "conv2d_same_cl_backward")
         return dx, dW, db, None, None, None

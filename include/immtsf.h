@@ -520,7 +520,8 @@ int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* cfg, const immtsf_ffn_
  * db: HOST arrays of n device pointers, W_i (Cout, Cin, 2i+1, 2i+1) as nn.Conv2d stores it.
  * conv2d_same_cl: the merged convolution on channels-last images (B, H, W, C) -- TimesBlock's (B, length, d_model)
  * activations viewed as (B, length/period, period, d_model) -- as im2col + MFMA GEMM (bias / GELU epilogue); backward:
- * GEMM + col2im gather for dx, GEMM with bias-gradient reduction for dW_eff / db_eff.  act: 0 none, 2 GELU(erf).
+ * the same convolution of dz with the flipped kernel for dx, GEMM with bias-gradient reduction for dW_eff / db_eff.
+ * act: 0 none, 2 GELU(erf).
  * ---------------------------------------------------------------------------------------------------------- */
 #define IMMTSF_INCEPTION_MAX 8
 int immtsf_inception_merge(int32_t n, int32_t Cin, int32_t Cout, const float* const* W, const float* const* b, float* W_eff, float* b_eff,
@@ -531,7 +532,9 @@ int immtsf_inception_unmerge(int32_t n, int32_t Cin, int32_t Cout, const float* 
 int immtsf_conv2d_same_cl_forward(int32_t precision, const float* x, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t KS,
                                   const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
                                   immtsf_stream_t stream);
-/* dx may be NULL; dW_eff, db_eff are written; scratch: B*H*W * (KS*KS*Cin + Cout) floats */
+/* dx may be NULL (then only the weight gradients are formed); dW_eff, db_eff are written; dx = the same im2col + GEMM convolution
+ * applied to dz with the flipped kernel.  scratch: immtsf_conv2d_same_cl_scratch_floats(...) floats */
+size_t immtsf_conv2d_same_cl_scratch_floats(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t KS, int32_t Cout);
 int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const float* z_pre, const float* y, const float* dy, int32_t B,
                                    int32_t H, int32_t W, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act, float* dx,
                                    float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream);
@@ -568,8 +571,8 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
 
 /* The bf16-in-memory GEMM the bf16 mode runs its projections on (csrc/gemm2.hip): A and B are bf16 in HBM and reach
  * LDS by LDS-DMA through a multi-stage ring; results as fp32 (C, may be NULL) and/or bf16 (Ch, may be NULL; row pitch
- * ldch).  layout 0 NT: C = A(M,K) B(N,K)^T (a linear layer's forward, layers/*.py nn.Linear call sites and
- * fusions/*.py projections); 1 NN: C = A(M,K) B(K,N) (its data gradient); 2 TN: C = A(K,M)^T B(K,N) (its weight
+ * ldch).  layout 0 NT: C = A(M,K) B(N,K)^T (a linear layer's forward, layers/<module>.py nn.Linear call sites and
+ * fusions/<module>.py projections); 1 NN: C = A(M,K) B(K,N) (its data gradient); 2 TN: C = A(K,M)^T B(K,N) (its weight
  * gradient; bias_grad (M) = column sums of A when given).  dyn: optional device int32 overriding M (dyn_which 0, NT/NN)
  * or K (dyn_which 1, TN) -- the ragged note count; a_rowmap: optional source row per logical row of A (NT/NN).
  * IMMTSF_EUNSUPPORTED: operands not 16-byte aligned / leading dimensions not multiples of 8 / K (NT, NN) or M, N (TN)

@@ -215,6 +215,18 @@ def test_xattn_add_shapes_outside_the_fused_head_and_vector_rows(C, d_txt):
 
 
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
+@pytest.mark.parametrize("d_m,d_txt", [(40, 24), (44, 48)])
+def test_pairs_bf16_shapes_outside_the_bf16_dataflow(ttf, mmf, d_m, d_txt):
+    """bf16 mode at widths the bf16-in-memory GEMM path does not take (d_txt % 16 != 0, or d_m % 8 != 0): the blocks fall back
+    to fp32 activations in memory + the round-1 kernel (operands rounded while staged) and must still be within the bf16 bars."""
+    errs, gerrs = _run_pair(ttf, mmf, B=9, N=11, T=7, C=5, d_m=d_m, d_txt=d_txt, H=2, precision="bf16", err=_l2err)
+    _check(errs, 3e-2)
+    small = {k: v for k, v in gerrs.items() if "time2vec.linear" in k or "log_recency_sigma" in k}
+    _check({k: v for k, v in gerrs.items() if k not in small}, 4e-2)
+    _check(small, 2.5e-1)
+
+
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
 def test_pairs_fp32_benchmark_shape(ttf, mmf):
     # BASELINE config 2 shape: B=64, N<=32, T=32, C=8, d_m=d=768, H=1
     errs, gerrs = _run_pair(ttf, mmf, B=64, N=32, T=32, C=8, d_m=768, d_txt=768, H=1, precision="fp32")

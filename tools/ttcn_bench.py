@@ -25,7 +25,7 @@ ps, gs = _struct(TTCNParams, params), _struct(TTCNParams, grads)
 def fwd():
     assert lib.immtsf_ttcn_forward(P, L, te_dim, K, 1, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), K + 1, K, ptr(ws), ws.numel(), _lib.stream_ptr()) == 0
 def bwd():
-    assert lib.immtsf_ttcn_backward(P, L, te_dim, K, 1, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout), K + 1, ptr(ws), ws.numel(), ptr(sc), sc.numel(), C.byref(gs), _lib.stream_ptr()) == 0
+    assert lib.immtsf_ttcn_backward(P, L, te_dim, K, 1, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout), K + 1, ptr(ws), ws.numel(), ptr(sc), sc.numel(), C.byref(gs), 0, _lib.stream_ptr()) == 0
 def timed(fn, n=20):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s): fn()

@@ -874,7 +874,10 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
         // the contiguous order also wins on large grids (r01j, 32768x768x768: NT 123 -> 85 us, NN 169 -> 144 us; 4096^3,
         // whose B is 64 MB, loses 30 % with it and keeps the default order)
         const bool b_fits_l2 = (size_t)g.N * g.K * sizeof(float) <= (size_t)3 << 20;
-        if (g_xcd && gx >= 64 && (gx < 2048 || b_fits_l2) && g.N >= 256) {
+        // (a device-side row count -- ragged notes, ~half of the allocation bound -- leaves the XCDs that own the tail of the
+        // tile rows with nothing to do under a contiguous order: those launches keep the round-robin order)
+        const bool dyn_rows = g.dyn && g.dyn_which == 0;
+        if (g_xcd && !dyn_rows && gx >= 64 && (gx < 2048 || b_fits_l2) && g.N >= 256) {
             // 8 = contiguous tile rows per XCD; 4 / 2 / 1 = xm of the 2-D variant: least (A panels + B panels) per L2
             const int tm = cdiv(g.M, 64), tn = cdiv(g.N, 64);
             int best = 8;

@@ -472,7 +472,10 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     }
     {
         const bool b_fits_l2 = (size_t)g.N * g.K * 2 <= (size_t)3 << 20;
-        g.xcd_remap = (t64 >= 64 && (t64 < 2048 || b_fits_l2) && g.N >= 256) ? 8 : 0;
+        // a device-side row count (ragged notes: about half of the allocation bound) leaves the XCDs that own the tail of the tile
+        // rows idle under any contiguous / rectangular assignment: those launches keep the hardware's round-robin order
+        const bool dyn_rows = g.dyn && g.dyn_which == 0;
+        g.xcd_remap = (!dyn_rows && t64 >= 64 && (t64 < 2048 || b_fits_l2) && g.N >= 256) ? 8 : 0;
         g.xcd_gm = g.xcd_remap ? 1 : 0;       // launch2 turns the flag into the group height for its tile shape
         if (g2_xcd >= 0) { g.xcd_remap = g2_xcd ? 8 : 0; g.xcd_gm = g2_xcd >= 2 ? 1 : 0; }
     }

@@ -285,19 +285,28 @@ __global__ __launch_bounds__(256) void colsum3_partial_kernel(const float* __res
             partial[((size_t)slab * 3 + k) * N + n] = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
 }
 
+// grid ceil(N / 64): 64 columns x 4 slab lanes per workgroup (a thread that walks all 64 slabs alone is a 192-load chain: 19 us)
 __global__ __launch_bounds__(256) void colsum3_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x, float* __restrict__ out_z, int nsl) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[3][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, n = blockIdx.x * 64 + tx;
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int s = 0; s < nsl; ++s) {
-        a += partial[((size_t)s * 3 + 0) * N + n];
-        b += partial[((size_t)s * 3 + 1) * N + n];
-        c += partial[((size_t)s * 3 + 2) * N + n];
+    if (n < N)
+#pragma unroll 4
+        for (int s = ty; s < nsl; s += 4) {
+            a += partial[((size_t)s * 3 + 0) * N + n];
+            b += partial[((size_t)s * 3 + 1) * N + n];
+            c += partial[((size_t)s * 3 + 2) * N + n];
+        }
+    red[0][ty][tx] = a;
+    red[1][ty][tx] = b;
+    red[2][ty][tx] = c;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        out_xy[n] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
+        out_x[n] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+        out_z[n] = red[2][0][tx] + red[2][1][tx] + red[2][2][tx] + red[2][3][tx];
     }
-    out_xy[n] = a;
-    out_x[n] = b;
-    out_z[n] = c;
 }
 
 // narrow matrices (N <= 32 columns, e.g. LayerNorm over the C series variables): ONE workgroup, CT column lanes x
@@ -740,7 +749,7 @@ int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int l
     hipLaunchKernelGGL(colsum3_partial_kernel, dim3(cdiv(N, 64), nsl), dim3(256), 0, s, X, Y, Z, M, N, ld, scratch, row_flag,
                        flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(Zh));
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum3_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out_xy, out_x, out_z, nsl);
+    hipLaunchKernelGGL(colsum3_final_kernel, dim3(cdiv(N, 64)), dim3(256), 0, s, scratch, N, out_xy, out_x, out_z, nsl);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -543,9 +543,10 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     const WtsT wt{q.W3T, q.W2T, q.W1T};
     // persistent workgroups: measured alone 256 / 512 / 768 / 1024 -> backbone fwd+bwd 603 / 617 / 621 / 631 us; inside the step, beside
     // the text-side backward GEMMs on the other stream, 64 / 96 / 128 / 192 / 256 / 512 -> 1.040 / 0.950 / 0.915 / 0.911 / 0.930 / 0.927 ms/step:
-    // 192 leaves a quarter of the CUs free for the GEMM workgroups this kernel's ~100 KB of LDS would otherwise lock out
+    // (re-measured after the later launch cuts: 160 / 192 / 224 / 256 -> 0.891 / 0.882 / 0.874 / 0.887): 224 leaves an eighth of the CUs to
+    // the other stream's GEMM workgroups
     // (fewer workgroups = fewer end-of-kernel gradient atomics; the per-patch work is latency- not occupancy-bound)
-    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 192;
+    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 224;
     const int grid = P < gmax ? P : gmax;
     if (L <= 32) {
         const size_t lds = bwd_lds(2, d.NCq);

@@ -205,12 +205,32 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
                 e = fmaf(dlt * dlt, m, e);
                 n += m;
             }
-        re[threadIdx.x] = e;
-        rc[threadIdx.x] = n;
-        __syncthreads();
-        for (int st = RT >> 1; st > 0; st >>= 1) {      // tree over the row lanes (RT is a power of two): log2(RT) steps, not RT
-            if (ty < st) { re[threadIdx.x] += re[threadIdx.x + st * CT]; rc[threadIdx.x] += rc[threadIdx.x + st * CT]; }
+        if (CT <= 32) {
+            // the row lanes of one column sit CT lanes apart inside a wave: xor-shuffle over the offsets >= CT first (no barrier),
+            // then one LDS round over the 16 waves -- the 7-step tree with a 1024-thread barrier per step was half of this kernel
+            for (int o = 32; o >= CT; o >>= 1) {
+                e += __shfl_xor(e, o, 64);
+                n += __shfl_xor(n, o, 64);
+            }
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            if (lane < CT) { re[wave * CT + lane] = e; rc[wave * CT + lane] = n; }
             __syncthreads();
+            if (threadIdx.x < CT) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { a += re[w * CT + threadIdx.x]; b += rc[w * CT + threadIdx.x]; }
+                re[threadIdx.x] = a;
+                rc[threadIdx.x] = b;
+            }
+            __syncthreads();
+        } else {
+            re[threadIdx.x] = e;
+            rc[threadIdx.x] = n;
+            __syncthreads();
+            for (int st = RT >> 1; st > 0; st >>= 1) {      // tree over the row lanes (RT is a power of two): log2(RT) steps, not RT
+                if (ty < st) { re[threadIdx.x] += re[threadIdx.x + st * CT]; rc[threadIdx.x] += rc[threadIdx.x + st * CT]; }
+                __syncthreads();
+            }
         }
         if (ty == 0 && c < C) {
             const float a = re[tx], b = rc[tx];

@@ -370,6 +370,32 @@ __global__ __launch_bounds__(1024) void colsum2_small_vec_kernel(const float* __
     }
 }
 
+// one sum (of X, or of X*Y) over the rows of a narrow matrix (N <= 32) in ONE workgroup: row lanes sit CT lanes apart inside a
+// wave (xor shuffles first), one LDS round over the 16 waves -- instead of the two-stage pair
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ X, const float* __restrict__ Y, int M, int N, int ld,
+                                                             int CT, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16 * 32];
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    float a = 0.f;
+    if (tx < N) {
+#pragma unroll 8
+        for (int r = ty; r < M; r += RT) {
+            const float x = X[(size_t)r * ld + tx];
+            a = Y ? fmaf(x, Y[(size_t)r * ld + tx], a) : a + x;
+        }
+    }
+    for (int o = 32; o >= CT; o >>= 1) a += __shfl_xor(a, o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < CT) red[wave * CT + lane] = a;
+    __syncthreads();
+    if (threadIdx.x < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w * CT + threadIdx.x];
+        out[threadIdx.x] = accumulate ? out[threadIdx.x] + t : t;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -710,6 +736,13 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
                   float* scratch, hipStream_t s) {
     if (N <= 0) return IMMTSF_OK;
+    if (N <= 32 && !dyn && (long)M * N <= (1L << 17)) {
+        int CT = 1;
+        while (CT < N) CT <<= 1;
+        hipLaunchKernelGGL(colsum_small_kernel, dim3(1), dim3(1024), 0, s, X, Y, M, N, ld, CT, out, accumulate);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, dyn, N, ld, scratch);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out, accumulate);

@@ -841,10 +841,118 @@ extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
     return n;
 }
 
+// ---- skinny products: a reduction or an output dimension of <= 16 (MMF_XAttn_Add's query projection Y (BT, C) -> (BT, d)
+// and its data gradient back to C columns, C = 8 at the benchmark configuration).  As 64 x 64 MFMA tiles these are ~11 us
+// of padding and pipeline fill each, on the serial section of the step between the two forward and the two backward
+// branches; as plain fp32 FMAs they are bound by their 6 MB of output / input: ~3-4 us.  Exact fp32 in both precision modes.
+namespace {
+constexpr int SKINNY = 16;
+// K == KB (8 or 16, rows 16-byte aligned): C[m, n] = rowflag(alpha sum_k A[m, k] opB(n, k) + bias[n]); a thread owns 4
+// consecutive n of one row m; A's row and (NT) B's rows come in as float4s, no per-tap branches
+template <bool TB, int KB>
+__global__ __launch_bounds__(256) void skinny_k_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int N,
+                                                        float alpha, const unsigned char* __restrict__ row_flag, int flag_div) {
+    const int n4 = N >> 2;                       // N % 4 == 0 (host-checked)
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * n4) return;
+    const int m = (int)(i / n4), n0 = (int)(i % n4) * 4;
+    float a[KB];
+#pragma unroll
+    for (int k4 = 0; k4 < KB / 4; ++k4) {
+        const float4 v = reinterpret_cast<const float4*>(A + (size_t)m * lda)[k4];
+        a[4 * k4] = v.x; a[4 * k4 + 1] = v.y; a[4 * k4 + 2] = v.z; a[4 * k4 + 3] = v.w;
+    }
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (TB) {                                    // B[k][n]: one float4 of 4 consecutive n per k
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const float4 b = *reinterpret_cast<const float4*>(B + (size_t)k * ldb + n0);
+            o[0] = fmaf(a[k], b.x, o[0]); o[1] = fmaf(a[k], b.y, o[1]); o[2] = fmaf(a[k], b.z, o[2]); o[3] = fmaf(a[k], b.w, o[3]);
+        }
+    } else {                                     // B[n][k]: KB / 4 float4s per n
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k4 = 0; k4 < KB / 4; ++k4) {
+                const float4 b = reinterpret_cast<const float4*>(B + (size_t)(n0 + j) * ldb)[k4];
+                o[j] = fmaf(a[4 * k4], b.x, fmaf(a[4 * k4 + 1], b.y, fmaf(a[4 * k4 + 2], b.z, fmaf(a[4 * k4 + 3], b.w, o[j]))));
+            }
+    }
+    const bool live = row_flag ? row_flag[m / flag_div] != 0 : true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = live ? alpha * o[j] + (bias ? bias[n0 + j] : 0.f) : 0.f;
+    *reinterpret_cast<float4*>(C + (size_t)m * ldc + n0) = make_float4(o[0], o[1], o[2], o[3]);
+}
+// NN, N == NB (8 or 16): C[m, n] (+)= alpha sum_k A[m, k] B[k, n]; a wave owns one row m, lanes stride over k with NB
+// accumulators each (B's row k is NB / 4 float4s), butterfly over the wave at the end
+template <int NB>
+__global__ __launch_bounds__(256) void skinny_n_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        float* __restrict__ C, int ldc, int M, int K, float alpha, int accumulate) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) acc[n] = 0.f;
+#pragma unroll 4
+    for (int k = lane; k < K; k += 64) {
+        const float a = A[(size_t)m * lda + k];
+#pragma unroll
+        for (int n4 = 0; n4 < NB / 4; ++n4) {
+            const float4 b = reinterpret_cast<const float4*>(B + (size_t)k * ldb)[n4];
+            acc[4 * n4] = fmaf(a, b.x, acc[4 * n4]); acc[4 * n4 + 1] = fmaf(a, b.y, acc[4 * n4 + 1]);
+            acc[4 * n4 + 2] = fmaf(a, b.z, acc[4 * n4 + 2]); acc[4 * n4 + 3] = fmaf(a, b.w, acc[4 * n4 + 3]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+    if (lane < NB) {
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) v = lane == n ? acc[n] : v;
+        float* dst = C + (size_t)m * ldc + lane;
+        *dst = alpha * v + (accumulate ? *dst : 0.f);
+    }
+}
+inline bool skinny_plain(const GemmArgs& g) {
+    return g.nprob == 1 && g.nbatch <= 1 && !g.dyn && !g.a_rowmap && !g.b_rowmap && !g.add_vec && g.act == 0 && !g.relu_ref &&
+           g.epi_drop.p <= 0.f && !g.p[0].Ch && !g.p[0].Cpre && !g.p[0].bias_grad && g.p[0].A && g.p[0].B && g.p[0].C;
+}
+}  // namespace
+
 static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t stream) {
     if (g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS) return IMMTSF_EINVAL;
     if (g.M < 0 || g.N < 0 || g.K < 0) return IMMTSF_EINVAL;
     if (g.M == 0 || g.N == 0) return IMMTSF_OK;
+    if (g_variant == 0 && skinny_plain(g) && g.M >= 256) {
+        const uintptr_t al = reinterpret_cast<uintptr_t>(g.p[0].A) | reinterpret_cast<uintptr_t>(g.p[0].B) | reinterpret_cast<uintptr_t>(g.p[0].C);
+        const bool al16 = (al & 15) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.ldc & 3) == 0;
+        if (al16 && (layout == GEMM_NT || layout == GEMM_NN) && (g.K == 8 || g.K == 16) && g.N >= 64 && (g.N & 3) == 0 && !g.accumulate) {
+            const long thr = (long)g.M * (g.N / 4);
+            const dim3 grid((unsigned)((thr + 255) / 256));
+            const int fd = g.row_flag_div > 0 ? g.row_flag_div : 1;
+#define IMMTSF_SKINNY_K(TB, KB)                                                                                                      \
+    hipLaunchKernelGGL((skinny_k_kernel<TB, KB>), grid, dim3(256), 0, stream, g.p[0].A, g.lda, g.p[0].B, g.ldb, g.p[0].C, g.ldc, g.p[0].bias, \
+                       g.M, g.N, g.alpha, g.row_flag, fd)
+            if (layout == GEMM_NT) { if (g.K == 8) IMMTSF_SKINNY_K(false, 8); else IMMTSF_SKINNY_K(false, 16); }
+            else { if (g.K == 8) IMMTSF_SKINNY_K(true, 8); else IMMTSF_SKINNY_K(true, 16); }
+#undef IMMTSF_SKINNY_K
+            IMMTSF_LAUNCH_CHECK();
+            return IMMTSF_OK;
+        }
+        if (al16 && layout == GEMM_NN && (g.N == 8 || g.N == 16) && g.K >= 64 && !g.p[0].bias && !g.row_flag) {
+            if (g.N == 8)
+                hipLaunchKernelGGL(skinny_n_kernel<8>, dim3(cdiv(g.M, 4)), dim3(256), 0, stream, g.p[0].A, g.lda, g.p[0].B, g.ldb, g.p[0].C, g.ldc,
+                                   g.M, g.K, g.alpha, g.accumulate);
+            else
+                hipLaunchKernelGGL(skinny_n_kernel<16>, dim3(cdiv(g.M, 4)), dim3(256), 0, stream, g.p[0].A, g.lda, g.p[0].B, g.ldb, g.p[0].C, g.ldc,
+                                   g.M, g.K, g.alpha, g.accumulate);
+            IMMTSF_LAUNCH_CHECK();
+            return IMMTSF_OK;
+        }
+    }
     // vector-load eligibility is a property of every problem's base pointers and the leading dims
     bool va = (g.lda % 4) == 0, vb = (g.ldb % 4) == 0;
     for (int i = 0; i < g.nprob; ++i) {

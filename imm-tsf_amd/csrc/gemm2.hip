@@ -487,7 +487,6 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         const int Meff = (g.dyn && g.dyn_which == 0) ? (Mmax * 9 + 15) / 16 : Mmax;
         const long n64 = (long)cdiv(Meff, 64) * cdiv(g.N, 64) * g.nprob;
         const long n96 = (long)cdiv(Meff, 64) * cdiv(g.N, 96) * g.nprob;
-        const long n128x96 = (long)cdiv(Meff, 128) * cdiv(g.N, 96) * g.nprob;
         const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
         const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
         if (long_k) v = 18;                                       // 128x128 k2 with the reduction split over workgroups
@@ -496,7 +495,8 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         else if (t128 >= 512) v = 7;                              // 256x128
         else if (n64 <= 272) v = 17;                              // 64x64 k4
         else if (n96_ok && n96 <= 272) v = 16;                    // 64x96 k4
-        else if (n96_ok && n128x96 <= 272) v = 22;                // 128x96 k2
+        // (128x96 k2 was the pick for 272 < tiles of 64x96 <= 544: it wins no shape of the r02 sweep -- 1117x1536x768 NT 13.3 us against
+        // 9.7 on 64x64w8, 17.5 in the step with the device-side row count -- and is a tool-only variant now)
         else v = 9;                                               // 64x64, 8 waves, 4 stages, two workgroups per CU
     }
     switch (v) {

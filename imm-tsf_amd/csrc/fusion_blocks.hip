@@ -149,7 +149,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     CHECK(t2v_weights(cfg, p, w, s, &W));
     if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
     else CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
-    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s));
+    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));      // M_txt written here: no copy at the end
     const int* gather = src_rows ? src_rows : w.rowmap;
     // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
     // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
@@ -200,8 +200,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
         set_problem2(g, 0, w.z, W.po, mat(E_txt, hf ? cfg->out_h : nullptr), p->proj_out_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    hipError_t e = hipMemcpyAsync(M_txt, w.mtxt, B, hipMemcpyDeviceToDevice, s);
-    return e == hipSuccess ? IMMTSF_OK : (int)e;
+    return IMMTSF_OK;
 }
 
 int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,

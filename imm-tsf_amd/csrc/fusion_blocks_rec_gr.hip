@@ -118,7 +118,7 @@ int immtsf_ttf_recavg_forward(const immtsf_fusion_cfg* cfg, const immtsf_recavg_
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
     CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
-    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s));
+    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));
     if (p->input_proj_w) {
         GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, d);
         set_problem(g, 0, notes, p->input_proj_w, w.Vp, p->input_proj_b);
@@ -134,8 +134,7 @@ int immtsf_ttf_recavg_forward(const immtsf_fusion_cfg* cfg, const immtsf_recavg_
         set_problem(g, 0, w.z, p->proj_w, E_txt, p->proj_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    hipError_t e = hipMemcpyAsync(M_txt, w.mtxt, B, hipMemcpyDeviceToDevice, s);
-    return e == hipSuccess ? IMMTSF_OK : (int)e;
+    return IMMTSF_OK;
 }
 
 int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg_params* p, const float* notes,

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void mask_from_lengths_kernel(const int* __res
 __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char* __restrict__ mask, int B, int N,
                                                             int* __restrict__ lengths, int* __restrict__ offsets,
                                                             int* __restrict__ rowmap, int* __restrict__ seg,
-                                                            unsigned char* __restrict__ mtxt) {
+                                                            unsigned char* __restrict__ mtxt, unsigned char* __restrict__ mtxt2) {
     __shared__ int sh[1024];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
             const bool m = (n < N) && mask[(size_t)b * N + n] != 0;
             cnt += __popcll(__ballot(m));
         }
-        if (lane == 0) { lengths[b] = cnt; mtxt[b] = cnt > 0 ? 1 : 0; }
+        if (lane == 0) { lengths[b] = cnt; mtxt[b] = cnt > 0 ? 1 : 0; if (mtxt2) mtxt2[b] = cnt > 0 ? 1 : 0; }
     }
     if (tid == 0) carry = 0;
     __syncthreads();   // lengths[] written by this block are visible after the barrier (same CU)
@@ -185,6 +185,43 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
     if (ty == 0 && j < d_tau) {
         partial[((size_t)slab * 2 + 0) * d_tau + j] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
         partial[((size_t)slab * 2 + 1) * d_tau + j] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
+    }
+}
+
+// narrow embeddings (d_tau <= 32: tPatchGNN's LearnableTE of the prediction times, 10 columns x 2048 rows) in ONE workgroup:
+// CT column lanes x 1024 / CT row lanes, xor shuffles over the row lanes of a wave, one LDS round over the 16 waves
+__global__ __launch_bounds__(1024) void time2vec_bwd_small_kernel(const float* __restrict__ tau, int rows, int d_tau, int CT,
+                                                                   const float* __restrict__ w, const float* __restrict__ b,
+                                                                   const float* __restrict__ dfeat, int ld, float* dw0, float* db0, float* dw,
+                                                                   float* db, int accumulate) {
+    __shared__ float ra[16 * 32], rb[16 * 32];
+    const int RT = 1024 / CT, j = threadIdx.x % CT, ty = threadIdx.x / CT;
+    float aw = 0.f, ab = 0.f;
+    if (j < d_tau) {
+        const float wj = j ? w[j - 1] : 0.f, bj = j ? b[j - 1] : 0.f;
+#pragma unroll 4
+        for (int r = ty; r < rows; r += RT) {
+            const float t = tau[r];
+            float g = dfeat[(size_t)r * ld + j];
+            if (j) g *= cosf(fmaf(wj, t, bj));
+            aw = fmaf(g, t, aw);
+            ab += g;
+        }
+    }
+    for (int o = 32; o >= CT; o >>= 1) {
+        aw += __shfl_xor(aw, o, 64);
+        ab += __shfl_xor(ab, o, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < CT) { ra[wave * CT + lane] = aw; rb[wave * CT + lane] = ab; }
+    __syncthreads();
+    if (threadIdx.x < d_tau) {
+        float sw = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { sw += ra[k * CT + threadIdx.x]; sb += rb[k * CT + threadIdx.x]; }
+        const int jj = threadIdx.x;
+        if (jj == 0) { dw0[0] = accumulate ? dw0[0] + sw : sw; db0[0] = accumulate ? db0[0] + sb : sb; }
+        else { dw[jj - 1] = accumulate ? dw[jj - 1] + sw : sw; db[jj - 1] = accumulate ? db[jj - 1] + sb : sb; }
     }
 }
 
@@ -686,8 +723,8 @@ int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int
 }
 
 int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
-                        unsigned char* mtxt, hipStream_t s) {
-    hipLaunchKernelGGL(ragged_index_kernel, dim3(1), dim3(1024), 0, s, mask, B, N, lengths, offsets, rowmap, seg, mtxt);
+                        unsigned char* mtxt, hipStream_t s, unsigned char* mtxt2) {
+    hipLaunchKernelGGL(ragged_index_kernel, dim3(1), dim3(1024), 0, s, mask, B, N, lengths, offsets, rowmap, seg, mtxt, mtxt2);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -724,6 +761,14 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
                         float* db, float* scratch, int nslabs, hipStream_t s, int accumulate) {
+    if (!rowmap && !total && d_tau <= 32 && max_rows <= (1 << 15) && max_rows > 0) {
+        int CT = 1;
+        while (CT < d_tau) CT <<= 1;
+        hipLaunchKernelGGL(time2vec_bwd_small_kernel, dim3(1), dim3(1024), 0, s, tau_pad, max_rows, d_tau, CT, w, b, dfeat, ld, dw0, db0, dw, db,
+                           accumulate);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     if (nslabs < 1) nslabs = kSlabs;
     hipLaunchKernelGGL(time2vec_bwd_kernel, dim3(cdiv(d_tau, 64), nslabs), dim3(256), 0, s, tau_pad, rowmap, total, d_tau, w, b,
                        dfeat, ld, scratch, max_rows);

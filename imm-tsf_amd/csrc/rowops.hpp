@@ -7,7 +7,7 @@
 int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int* nan_flag, hipStream_t s);
 // lengths/offsets/rowmap/seg/M_txt from the mask.  offsets has B+1 entries, offsets[B] = total notes.
 int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
-                        unsigned char* mtxt, hipStream_t s);
+                        unsigned char* mtxt, hipStream_t s, unsigned char* mtxt2 = nullptr);
 // mask[b,n] = n < lengths[b]  (packed-input mode: the batch builder already knows every window's note count)
 int launch_mask_from_lengths(const int* lengths, int B, int N, unsigned char* mask, hipStream_t s);
 // gather packed rows: dst[r, 0:d_m] = src[rowmap[r], 0:d_m]   (r < *total)

@@ -189,6 +189,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
+        ctx.set_materialize_grads(False)      # no zero-filled uint8 'gradient' of M (one fill kernel per backward)
         return E, M
 
     @staticmethod
@@ -197,6 +198,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         notes, tau = saved[0], saved[1]
         params = [None if isnone else p for p, isnone in zip(saved[2:], ctx.none_mask)]
+        if dE is None:       # E_txt unused downstream (grads are not materialised, see forward)
+            dE = torch.zeros(ctx.cfg.B, ctx.cfg.T, ctx.cfg.d, dtype=torch.float32, device=notes.device)
         dE = dE.contiguous()
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
@@ -240,6 +243,7 @@ class TTFRecAvgFn(torch.autograd.Function):
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
         ctx.mark_non_differentiable(M)
+        ctx.set_materialize_grads(False)      # no zero-filled uint8 'gradient' of M (one fill kernel per backward)
         return E, M
 
     @staticmethod
@@ -248,6 +252,8 @@ class TTFRecAvgFn(torch.autograd.Function):
         saved = ctx.saved_tensors
         notes, tau, t_hat = saved[:3]
         params = [None if isnone else p for p, isnone in zip(saved[3:], ctx.none_mask)]
+        if dE is None:
+            dE = torch.zeros(ctx.cfg.B, ctx.cfg.T, ctx.cfg.d, dtype=torch.float32, device=notes.device)
         dE = dE.contiguous()
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_recavg_scratch_bytes(C.byref(ctx.cfg)), notes.device)

@@ -27,7 +27,7 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KP = 32;        // padded ttcn_dim and padded feature width (one MFMA k-step)
 constexpr int PT = 40;        // pitch (bf16 elements) of the 32-wide LDS tiles: 80-byte rows, conflict-free b128 reads
-constexpr int MAXF = 4;       // f's per wave (F <= 16)
+
 
 struct FD { int P, L, F, K, NCq; };
 
@@ -218,12 +218,13 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
 
 // ---------------------------------------------------------------------------------------------------- backward
 // transposed bf16 copies of the weights for the data-gradient products (ttcn_pack_kernel)
-struct WtsT { const bf16_t *W3T /*[k2][c']*/, *W2T /*[k1][k2]*/, *W1T /*[f][k1]*/; };
+struct WtsT { const bf16_t *W3T /*[k2][c']*/, *W2T /*[k1][k2]*/, *W1T /*[f][k1]*/, *W3h /*[c'][k2]*/; };
 
 // persistent workgroups, 256 threads.  LDS: Xb | h1s | h2s | dz2s | dz1s (bf16 [ROWS][PT]) | dS bf16 [ROWS][NCq+8] |
 // Xf, dXp fp32 [ROWS][16] | cts fp32 [NCq] | dp fp32 [32]
-template <int RT>
-__global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
+// MF = ceil(F / 4): the f slots a wave owns (its layer-3 fragments and dW3 tiles live in registers for the whole kernel)
+template <int RT, int MF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2 : 1))) void ttcn_full_bwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
                                                              const float* __restrict__ mask, TEp te, Wts w, WtsT wt,
                                                              const float* __restrict__ ctr, const float* __restrict__ out,
                                                              const float* __restrict__ dout, int out_ld, float* __restrict__ slab) {
@@ -244,17 +245,12 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
     const Slab sl = slab_of(d.F);
 
     // ---- operands that never change: registers for the whole kernel
-    bf16x8 bw[MAXF][2];             // layer-3 B fragments of this wave's f's
-    float b3v[MAXF][2];
-    f32x4 accW3[MAXF][2][2];        // dW3 tiles: [f slot][half][k2 tile]
-    float accB3[MAXF][2];
+    f32x4 accW3[MF][2][2];        // dW3 tiles: [f slot][half][k2 tile]
+    float accB3[MF][2];
 #pragma unroll
-    for (int j = 0; j < MAXF; ++j)
+    for (int j = 0; j < MF; ++j)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int f = wave + 4 * j, c = f * 32 + half * 16 + fr;
-            if (f < d.F) { bw[j][half] = load8_bf16(w.W3q + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
-            else { bw[j][half] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; b3v[j][half] = 0.f; }
             accW3[j][half][0] = zero4(); accW3[j][half][1] = zero4();
             accB3[j][half] = 0.f;
         }
@@ -294,7 +290,7 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
         }
         // ---- d(logits), tile by tile in registers -> LDS (bf16); pooling-path dX by shuffles; db3
 #pragma unroll
-        for (int j = 0; j < MAXF; ++j) {
+        for (int j = 0; j < MF; ++j) {
             const int f = wave + 4 * j;
             if (f < d.F) {
                 float dxs[RT][4];
@@ -306,7 +302,7 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
                 for (int half = 0; half < 2; ++half) {
                     const int k = half * 16 + fr, c = f * 32 + k;
                     float sm[RT][4];
-                    sm_tile<RT>(d, a, bw[j][half], b3v[j][half], mk, fq, sm);
+                    sm_tile<RT>(d, a, *reinterpret_cast<const bf16x8*>(wt.W3h + (size_t)c * KP + fq * 8), w.b3q[c], mk, fq, sm);     // L1 / L2 hits
                     const float dpk = k < d.K ? dp[k] : 0.f, ct_c = cts[c];
                     float colsum = 0.f;
 #pragma unroll
@@ -346,7 +342,7 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
             }
         }
 #pragma unroll
-        for (int j = 0; j < MAXF; ++j) {
+        for (int j = 0; j < MF; ++j) {
             const int f = wave + 4 * j;
             if (f < d.F) {
 #pragma unroll
@@ -411,7 +407,7 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
 
     // ---- one atomic add per accumulated element per workgroup
 #pragma unroll
-    for (int j = 0; j < MAXF; ++j) {
+    for (int j = 0; j < MF; ++j) {
         const int f = wave + 4 * j;
         if (f < d.F) {
 #pragma unroll
@@ -444,7 +440,7 @@ __global__ __launch_bounds__(256) void ttcn_full_bwd_kernel(FD d, const float* _
 // ---- packing: padded fp32 weights (+ the f-major W3), transposed bf16 copies; unpacking of the gradient slab
 struct PackIn { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 __global__ __launch_bounds__(256) void ttcn_pack_kernel(int F, int K, PackIn q, float* W1p, float* b1p, float* W2p, float* b2p,
-                                                         float* W3q, float* b3q, bf16_t* W3T, bf16_t* W2T, bf16_t* W1T) {
+                                                         float* W3q, float* b3q, bf16_t* W3T, bf16_t* W2T, bf16_t* W1T, bf16_t* W3h) {
     const int i = blockIdx.x * 256 + threadIdx.x, NCq = F * 32;
     if (i < KP * KP) {
         const int r = i >> 5, c = i & 31;
@@ -460,6 +456,7 @@ __global__ __launch_bounds__(256) void ttcn_pack_kernel(int F, int K, PackIn q, 
         const float v = (k < K && kk < K) ? q.W3[(size_t)(k * F + f) * K + kk] : 0.f;
         W3q[i] = v;
         W3T[(size_t)kk * NCq + c] = (bf16_t)v;
+        W3h[i] = (bf16_t)v;
     }
     if (i < NCq) { const int f = i >> 5, k = i & 31; b3q[i] = k < K ? q.b3[k * F + f] : 0.f; }
 }
@@ -487,7 +484,7 @@ size_t bwd_lds(int RT, int NCq) {
     return ROWS * PT * 2 * 5 + ROWS * (NCq + 8) * 2 + ROWS * 16 * 4 * 2 + (size_t)NCq * 4 + KP * 4 + 64;
 }
 
-struct PackPtrs { float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; bf16_t *W3T, *W2T, *W1T; };
+struct PackPtrs { float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; bf16_t *W3T, *W2T, *W1T, *W3h; };
 PackPtrs pack_ptrs(float* base, int F) {
     PackPtrs q;
     float* o = base;
@@ -499,7 +496,8 @@ PackPtrs pack_ptrs(float* base, int F) {
     q.b3q = o; o += F * 32;
     q.W3T = reinterpret_cast<bf16_t*>(o); o += (size_t)F * 32 * KP / 2;      // every block above is a multiple of 32 floats
     q.W2T = reinterpret_cast<bf16_t*>(o); o += KP * KP / 2;
-    q.W1T = reinterpret_cast<bf16_t*>(o);
+    q.W1T = reinterpret_cast<bf16_t*>(o); o += KP * KP / 2;
+    q.W3h = reinterpret_cast<bf16_t*>(o);
     return q;
 }
 
@@ -508,7 +506,7 @@ PackPtrs pack_ptrs(float* base, int F) {
 bool ttcn_full_supported(int precision, int L, int F, int K) {
     return precision == 1 && K >= 1 && K <= 32 && F >= 2 && F <= 16 && L >= 1 && L <= 64;
 }
-size_t ttcn_full_pack_floats(int F) { return (size_t)2 * KP * KP + 2 * KP + (size_t)F * 32 * KP + F * 32 + (size_t)F * 32 * KP / 2 + KP * KP + 64; }
+size_t ttcn_full_pack_floats(int F) { return (size_t)2 * KP * KP + 2 * KP + (size_t)F * 32 * KP + F * 32 + (size_t)F * 32 * KP + KP * KP + 64; }
 size_t ttcn_full_slab_floats(int F) { return slab_of(F).total; }
 
 int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
@@ -516,7 +514,7 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
     const FD d{P, L, F, K, F * 32};
     const PackPtrs q = pack_ptrs(pack, F);
     hipLaunchKernelGGL(ttcn_pack_kernel, dim3(cdiv(F * 32 * KP, 256)), dim3(256), 0, s, F, K, PackIn{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3},
-                       q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q, q.W3T, q.W2T, q.W1T);
+                       q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q, q.W3T, q.W2T, q.W1T, q.W3h);
     IMMTSF_LAUNCH_CHECK();
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
@@ -540,23 +538,31 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     if (e != hipSuccess) return (int)e;
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
-    const WtsT wt{q.W3T, q.W2T, q.W1T};
-    // persistent workgroups: measured alone 256 / 512 / 768 / 1024 -> backbone fwd+bwd 603 / 617 / 621 / 631 us; inside the step, beside
-    // the text-side backward GEMMs on the other stream, 64 / 96 / 128 / 192 / 256 / 512 -> 1.040 / 0.950 / 0.915 / 0.911 / 0.930 / 0.927 ms/step:
-    // (re-measured after the later launch cuts: 160 / 192 / 224 / 256 -> 0.891 / 0.882 / 0.874 / 0.887): 224 leaves an eighth of the CUs to
-    // the other stream's GEMM workgroups
-    // (fewer workgroups = fewer end-of-kernel gradient atomics; the per-patch work is latency- not occupancy-bound)
-    static const int gmax = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 224;
+    const WtsT wt{q.W3T, q.W2T, q.W1T, q.W3h};
+    // persistent workgroups; the per-patch work is a chain of small dependent MFMA / LDS phases (latency-, not throughput-bound), so a
+    // second workgroup per CU hides it: the L <= 32 instances are held to 256 registers / lane (two waves per SIMD).  Measured inside the
+    // cfg2 step, beside the text-side backward GEMMs on the other stream: one wave / SIMD at 160 / 192 / 224 / 256 workgroups ->
+    // 0.891 / 0.882 / 0.874 / 0.887 ms (later 0.850 at 224); two waves / SIMD at 256 / 342 / 384 / 448 / 512 -> 0.856 / 0.847 / 0.839 /
+    // 0.841 / 0.852.  Alone (P = 1024): 103 us at 224 x 1 wave, 80 us at 448 x 2 waves.
+    static const int genv = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 0;
+    const int gmax = genv > 0 ? genv : (L <= 32 ? 384 : 224);
     const int grid = P < gmax ? P : gmax;
+    const size_t lds = bwd_lds(L <= 32 ? 2 : 4, d.NCq);
+    const int mf = (F + 3) / 4;
+#define TTCN_BWD(RT, MF)                                                                                                                  \
+    do {                                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<RT, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                                          \
+        hipLaunchKernelGGL((ttcn_full_bwd_kernel<RT, MF>), dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, \
+                           slab);                                                                                                         \
+    } while (0)
     if (L <= 32) {
-        const size_t lds = bwd_lds(2, d.NCq);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ttcn_full_bwd_kernel<2>, dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, slab);
+        if (mf == 1) TTCN_BWD(2, 1); else if (mf == 2) TTCN_BWD(2, 2); else if (mf == 3) TTCN_BWD(2, 3); else TTCN_BWD(2, 4);
     } else {
-        const size_t lds = bwd_lds(4, d.NCq);
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ttcn_full_bwd_kernel<4>, dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, slab);
+        if (mf == 1) TTCN_BWD(4, 1); else if (mf == 2) TTCN_BWD(4, 2); else if (mf == 3) TTCN_BWD(4, 3); else TTCN_BWD(4, 4);
     }
+#undef TTCN_BWD
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(cdiv(F * K * K, 256)), dim3(256), 0, s, F, K, slab,
                        UnpackOut{gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b,

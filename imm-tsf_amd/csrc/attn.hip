@@ -676,6 +676,261 @@ __global__ __launch_bounds__(256) void attn_short_bwd_staged_kernel(ShortDims d,
     attn_short_bwd_body<SL, SEV>(d, sq, so, bl, b0 + bl, h, i, scale, causal, drop, site, dqkv);
 }
 
+
+// ---- dense T x T cross-attention of MMF_XAttn_Add over the prediction steps of a window (T <= 32), bf16 mode ------------
+// As batched GEMMs + a row softmax this is 3 launches forward and 5 backward of 32 x 32 (x hd) problems per (window, head)
+// on the serial section between the forward and the backward of the step: ~10 us apiece for 0.1 GFLOP in total.  Here one
+// workgroup per (window, head, 256-column chunk of the head dimension) does a whole direction for its chunk of the outputs: the two k-contiguous products (Q K^T, dO V^T) as MFMA tiles straight
+// from global fp32 rows (a 16 x 16 tile and half of the head dimension per wave, eight waves), the softmax / its backward on the 32 x 32 tile in LDS (8 lanes per
+// row), and the products against V / K / dO / Q from bf16 LDS images of 256-column chunks, read with the hardware
+// transpose where the reduction index is the row index of the image.  Operand rounding as in the GEMM path (bf16 operands,
+// fp32 accumulation); same dropout indexing as softmax_rows_{fwd,bwd}: (site, ((b*H + h)*T + i)*T + j).
+constexpr int XS_T = 32;         // padded tile: rows / columns beyond T are zero
+constexpr int XS_PT = 40;        // pitch of the 32 x 32 bf16 tiles (80-byte rows)
+constexpr int XS_EC = 256;       // columns of the head dimension staged per pass
+constexpr int XS_PC = XS_EC + 8; // pitch of the staged chunk images
+constexpr int XS_PS = 33;        // pitch of the fp32 score tile
+#ifndef XS_UF
+#define XS_UF 12
+#endif
+struct XSmallDims { int B, T, H, hd, d; };     // d = H * hd: pitch of Q / O / dO rows (K | V rows: 2d)
+typedef short xs_s16x4 __attribute__((ext_vector_type(4)));
+typedef short xs_s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 xs_load8(const float* __restrict__ src) {     // 8 consecutive fp32 -> bf16x8 (RNE)
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const bf16x8 r = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)b.x, (bf16_t)b.y, (bf16_t)b.z, (bf16_t)b.w};
+    return r;
+}
+// fragment of a row-major bf16 LDS tile: row = row0 + (lane & 15), k = k0 + (lane >> 4) * 8 ..
+__device__ __forceinline__ bf16x8 xs_frag_row(const bf16_t* tile, int pitch, int row0, int k0, int fr, int fq) {
+    return *reinterpret_cast<const bf16x8*>(tile + (row0 + fr) * pitch + k0 + fq * 8);
+}
+// hardware-transpose read of a 16 (row) x 8 (k) fragment from a [k][row] LDS image (see gemm.hip)
+__device__ __forceinline__ bf16x8 xs_frag_kmajor(const bf16_t* tile, int pitch, int rbase, int kbase, int fr, int fq) {
+    typedef __attribute__((address_space(3))) xs_s16x4 lds_s16x4;
+    const int q = fr >> 2, pp = fr & 3;
+    const bf16_t* a0 = tile + (kbase + fq * 8 + q) * pitch + rbase + 4 * pp;
+    const xs_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    const xs_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+    const xs_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ f32x4 xs_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// Sf / Sf2[i][j] = alpha * (partial) sum_e X[i][e] Y[j][e] on the padded 32 x 32 tile: wave w owns tile ((w & 3) >> 1, w & 1)
+// and half (w >> 2) of the k-steps (Sf: first half, Sf2: second half; the callers add them); U k-steps of loads are in
+// flight per wave -- the rows come from HBM / MALL, and one workgroup per window has nothing else to hide that latency with.
+// Rows beyond T read row T - 1 (their results are masked by the callers).
+template <int U>
+__device__ __forceinline__ void xs_scores(int T, int hd, const float* __restrict__ X, size_t ldx, const float* __restrict__ Y, size_t ldy,
+                                          float alpha, float* Sf, float* Sf2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4, mt = (wave & 3) >> 1, nt = wave & 1;
+    const int half = wave >> 2, ksteps = hd >> 5, ks0 = (ksteps + 1) >> 1;
+    const float* xr = X + (size_t)min(mt * 16 + fr, T - 1) * ldx + fq * 8;
+    const float* yr = Y + (size_t)min(nt * 16 + fr, T - 1) * ldy + fq * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = (half ? ks0 : 0) * 32;
+    const int kend = (half ? ksteps : ks0) * 32;
+    for (; k + 32 * U <= kend; k += 32 * U) {
+        bf16x8 av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { av[u] = xs_load8(xr + k + 32 * u); bv[u] = xs_load8(yr + k + 32 * u); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = xs_mfma(av[u], bv[u], acc);
+    }
+    for (; k + 32 <= kend; k += 32) acc = xs_mfma(xs_load8(xr + k), xs_load8(yr + k), acc);
+    if (half && (hd & 31)) {                   // hd % 32 == 16: the upper half of the last k-step is zero
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        bf16x8 at = z, bt = z;
+        if (fq < 2) { at = xs_load8(xr + k); bt = xs_load8(yr + k); }
+        acc = xs_mfma(at, bt, acc);
+    }
+    float* out = half ? Sf2 : Sf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * XS_PS + nt * 16 + fr] = alpha * acc[r];
+}
+// bf16 image img[r][e] (pitch XS_PC) of rows r < 32 of X, columns e0 .. e0 + ec (rows beyond T: zero), in two steps so that a
+// chunk's loads can be in flight while the previous chunk is being used: 512 threads x XS_NPRE float4 = 32 rows x 256 columns
+constexpr int XS_NPRE = XS_T * XS_EC / 4 / 512;
+struct XsPre { float4 v[XS_NPRE]; };
+__device__ __forceinline__ void xs_stage_load(int T, int e0, int ec, const float* __restrict__ X, size_t ldx, XsPre& p) {
+    const int n4 = ec >> 2;
+#pragma unroll
+    for (int u = 0; u < XS_NPRE; ++u) {
+        const int x = threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+        p.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < T) p.v[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx + e0)[c];      // r < T <= 32 also bounds x
+    }
+}
+__device__ __forceinline__ void xs_stage_store(int ec, const XsPre& p, bf16_t* img) {
+    const int n4 = ec >> 2;
+#pragma unroll
+    for (int u = 0; u < XS_NPRE; ++u) {
+        const int x = threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+        if (r < XS_T) {
+            const bf16x4 hv = {(bf16_t)p.v[u].x, (bf16_t)p.v[u].y, (bf16_t)p.v[u].z, (bf16_t)p.v[u].w};
+            *reinterpret_cast<bf16x4*>(img + r * XS_PC + 4 * c) = hv;
+        }
+    }
+}
+// Z[m][e0 + n] = sum_k W(m, k) img[k][n] for the staged chunk: 2 x ec/16 tiles dealt to the eight waves.  WT: W is read through
+// the hardware transpose (W(m, k) = tile[k][m]) instead of row-major (tile[m][k]).  Rows m >= T are not written.
+template <bool WT>
+__device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, const bf16_t* img, float* __restrict__ Z, size_t ldz,
+                                       bf16_t* __restrict__ Zh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const bf16x8 w0 = WT ? xs_frag_kmajor(Wt, XS_PT, 0, 0, fr, fq) : xs_frag_row(Wt, XS_PT, 0, 0, fr, fq);
+    const bf16x8 w1 = WT ? xs_frag_kmajor(Wt, XS_PT, 16, 0, fr, fq) : xs_frag_row(Wt, XS_PT, 16, 0, fr, fq);
+    for (int nt = wave; nt < (ec >> 4); nt += 8) {
+        const bf16x8 bfrag = xs_frag_kmajor(img, XS_PC, nt * 16, 0, fr, fq);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 c0 = xs_mfma(w0, bfrag, z), c1 = xs_mfma(w1, bfrag, z);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m0 = fq * 4 + r, m1 = 16 + m0;
+            const size_t col = (size_t)e0 + nt * 16 + fr;
+            if (m0 < T) { Z[(size_t)m0 * ldz + col] = c0[r]; if (Zh) Zh[(size_t)m0 * ldz + col] = (bf16_t)c0[r]; }
+            if (m1 < T) { Z[(size_t)m1 * ldz + col] = c1[r]; if (Zh) Zh[(size_t)m1 * ldz + col] = (bf16_t)c1[r]; }
+        }
+    }
+}
+__device__ __forceinline__ float xs_sum8(float v) {       // over the 8 lanes that share a row
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+__device__ __forceinline__ float xs_max8(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, const float* __restrict__ Q, const float* __restrict__ KV,
+                                                              const unsigned char* __restrict__ live, float scale, DropCfg drop,
+                                                              uint64_t site, float* __restrict__ Pm, float* __restrict__ Am,
+                                                              float* __restrict__ O) {
+    __shared__ __attribute__((aligned(16))) float Sf[XS_T * XS_PS], Sf2[XS_T * XS_PS];
+    __shared__ __attribute__((aligned(16))) bf16_t Ab[XS_T * XS_PT];
+    __shared__ __attribute__((aligned(16))) bf16_t img[XS_T * XS_PC];
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, T = dm.T;
+    const size_t q0 = (size_t)b * T * dm.d + (size_t)h * dm.hd, k0 = (size_t)b * T * 2 * dm.d + (size_t)h * dm.hd;
+    const size_t ldk = (size_t)2 * dm.d, pg = (size_t)(b * dm.H + h) * T * T;
+    if (live && !live[b]) {        // window without text: zero attention rows, zero context
+        if (blockIdx.z == 0)
+            for (int x = tid; x < T * T; x += 512) { Pm[pg + x] = 0.f; Am[pg + x] = 0.f; }
+        const int z0 = blockIdx.z * XS_EC, n4 = min(XS_EC, dm.hd - z0) >> 2;
+        for (int x = tid; x < T * n4; x += 512)
+            reinterpret_cast<float4*>(O + q0 + (size_t)(x / n4) * dm.d + z0)[x % n4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    // blockIdx.z: the 256-column chunk of the head dimension whose part of O this workgroup produces (every chunk's workgroup
+    // forms the full score tile: its operands are L2 hits for all but the first, and the chunks run on different CUs)
+    const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);
+    XsPre pre;
+    xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, pre);        // V's chunk travels beside the score operands
+    xs_scores<XS_UF>(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, scale, Sf, Sf2);
+    xs_stage_store(ec, pre, img);
+    __syncthreads();
+    if (tid < 256) {   // softmax + dropout: 8 lanes per row, 4 columns each
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        float sv[4], m = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sv[q] = (i < T && j0 + q < T) ? Sf[i * XS_PS + j0 + q] + Sf2[i * XS_PS + j0 + q] : -INFINITY;
+            m = fmaxf(m, sv[q]);
+        }
+        m = xs_max8(m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sv[q] = (i < T && j0 + q < T) ? expf(sv[q] - m) : 0.f; sum += sv[q]; }
+        sum = xs_sum8(sum);
+        const float inv = 1.f / sum;
+        const uint64_t row = ((uint64_t)b * dm.H + h) * T + i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float av = 0.f;
+            if (i < T && j0 + q < T) {
+                const float pv = sv[q] * inv;
+                av = pv * dropout_scale(drop, site, row * T + j0 + q);
+                if (blockIdx.z == 0) {
+                    Pm[pg + (size_t)i * T + j0 + q] = pv;
+                    Am[pg + (size_t)i * T + j0 + q] = av;
+                }
+            }
+            Ab[i * XS_PT + j0 + q] = (bf16_t)av;
+        }
+    }
+    __syncthreads();
+    xs_mix<false>(T, e0, ec, Ab, img, O + q0, dm.d, nullptr);       // O = A V
+}
+
+// dO -> dQ, (dK | dV) (+ optional bf16 image)
+__global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, const float* __restrict__ Q, const float* __restrict__ KV,
+                                                              const float* __restrict__ dO, const float* __restrict__ Pm,
+                                                              const float* __restrict__ Am, const unsigned char* __restrict__ live,
+                                                              float scale, DropCfg drop, uint64_t site, float* __restrict__ dQ,
+                                                              float* __restrict__ dKV, bf16_t* __restrict__ dKV_h) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs_smem[];
+    float* Sf = reinterpret_cast<float*>(xs_smem);
+    float* Sf2 = Sf + XS_T * XS_PS;
+    bf16_t* Ab = reinterpret_cast<bf16_t*>(Sf2 + XS_T * XS_PS);
+    bf16_t* dSb = Ab + XS_T * XS_PT;
+    bf16_t* imK = dSb + XS_T * XS_PT;
+    bf16_t* imG = imK + XS_T * XS_PC;
+    bf16_t* imQ = imG + XS_T * XS_PC;
+    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, T = dm.T;
+    const size_t q0 = (size_t)b * T * dm.d + (size_t)h * dm.hd, k0 = (size_t)b * T * 2 * dm.d + (size_t)h * dm.hd;
+    const size_t ldk = (size_t)2 * dm.d, pg = (size_t)(b * dm.H + h) * T * T;
+    if (live && !live[b]) {        // dO, A and P are zero there: so is every gradient
+        const int z0 = blockIdx.z * XS_EC, n4 = min(XS_EC, dm.hd - z0) >> 2;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bf16x4 zh = {0, 0, 0, 0};
+        for (int x = tid; x < T * n4; x += 512) {
+            const int i = x / n4, c = x - i * n4;
+            reinterpret_cast<float4*>(dQ + q0 + (size_t)i * dm.d + z0)[c] = z4;
+            reinterpret_cast<float4*>(dKV + k0 + (size_t)i * ldk + z0)[c] = z4;
+            reinterpret_cast<float4*>(dKV + k0 + dm.d + (size_t)i * ldk + z0)[c] = z4;
+            if (dKV_h) {
+                reinterpret_cast<bf16x4*>(dKV_h + k0 + (size_t)i * ldk + z0)[c] = zh;
+                reinterpret_cast<bf16x4*>(dKV_h + k0 + dm.d + (size_t)i * ldk + z0)[c] = zh;
+            }
+        }
+        return;
+    }
+    const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);       // this workgroup's chunk of dQ, dK, dV (see the forward)
+    XsPre pK, pG, pQ;
+    xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's three images travel beside dA's operands
+    xs_stage_load(T, e0, ec, dO + q0, dm.d, pG);
+    xs_stage_load(T, e0, ec, Q + q0, dm.d, pQ);
+    xs_scores<6>(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, 1.f, Sf, Sf2);        // dA = dO V^T
+    xs_stage_store(ec, pK, imK);
+    xs_stage_store(ec, pG, imG);
+    xs_stage_store(ec, pQ, imQ);
+    __syncthreads();
+    if (tid < 256) {   // dS = scale P (dA dropscale - sum_j P dA dropscale): 8 lanes per row, 4 columns each
+        const int i = tid >> 3, j0 = (tid & 7) * 4;
+        const uint64_t row = ((uint64_t)b * dm.H + h) * T + i;
+        float pv[4], dp[4], av[4], dot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = i < T && j0 + q < T;
+            pv[q] = in ? Pm[pg + (size_t)i * T + j0 + q] : 0.f;
+            av[q] = in ? Am[pg + (size_t)i * T + j0 + q] : 0.f;
+            dp[q] = in ? (Sf[i * XS_PS + j0 + q] + Sf2[i * XS_PS + j0 + q]) * dropout_scale(drop, site, row * T + j0 + q) : 0.f;
+            dot = fmaf(pv[q], dp[q], dot);
+        }
+        dot = xs_sum8(dot);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            dSb[i * XS_PT + j0 + q] = (bf16_t)(scale * pv[q] * (dp[q] - dot));      // scale folded in: dQ and dK both carry it
+            Ab[i * XS_PT + j0 + q] = (bf16_t)av[q];
+        }
+    }
+    __syncthreads();
+    xs_mix<false>(T, e0, ec, dSb, imK, dQ + q0, dm.d, nullptr);                                             // dQ = dS K
+    xs_mix<true>(T, e0, ec, Ab, imG, dKV + k0 + dm.d, ldk, dKV_h ? dKV_h + k0 + dm.d : nullptr);          // dV = A^T dO
+    xs_mix<true>(T, e0, ec, dSb, imQ, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);                       // dK = dS^T Q
+}
+constexpr size_t XS_BWD_LDS = (size_t)2 * XS_T * XS_PS * 4 + (size_t)2 * XS_T * XS_PT * 2 + (size_t)3 * XS_T * XS_PC * 2;
+
 }  // namespace
 
 size_t ragged_attn_part_floats(int B, int T, int d, int N) {
@@ -821,6 +1076,37 @@ int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int
     }
     hipLaunchKernelGGL((attn_short_bwd_kernel<8, 16>), dim3(cdiv(n, 256)), dim3(256), 0, s, ShortDims{B, L, H, E}, qkv, dout, scale, causal, drop,
                        site, dqkv);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+bool xattn_small_supported(int T, int H, int hd) { return T >= 1 && T <= XS_T && H >= 1 && hd >= 16 && (hd % 16) == 0; }
+
+int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char* live, int B, int T, int H, int hd, float scale, DropCfg drop,
+                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s) {
+    if (B <= 0) return IMMTSF_OK;
+    if (!xattn_small_supported(T, H, hd) || ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(O)) & 15))
+        return IMMTSF_EINVAL;
+    const XSmallDims dm{B, T, H, hd, H * hd};
+    hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), 0, s, dm, Q, KV, live, scale, drop, site, Pm, Am, O);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, const float* Pm, const float* Am, const unsigned char* live,
+                           int B, int T, int H, int hd, float scale, DropCfg drop, uint64_t site, float* dQ, float* dKV, void* dKV_h,
+                           hipStream_t s) {
+    if (B <= 0) return IMMTSF_OK;
+    if (!xattn_small_supported(T, H, hd) ||
+        ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(dO) | reinterpret_cast<uintptr_t>(dQ) |
+          reinterpret_cast<uintptr_t>(dKV)) & 15) || (reinterpret_cast<uintptr_t>(dKV_h) & 7))
+        return IMMTSF_EINVAL;
+    const XSmallDims dm{B, T, H, hd, H * hd};
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_bwd_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)XS_BWD_LDS);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), XS_BWD_LDS, s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
+                       static_cast<bf16_t*>(dKV_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

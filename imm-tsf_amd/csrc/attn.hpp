@@ -32,3 +32,13 @@ int launch_attn_short_fwd(const float* qkv, int B, int L, int H, int E, float sc
                           float* out, hipStream_t s);
 int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int H, int E, float scale, int causal, DropCfg drop,
                           uint64_t site, float* dqkv, hipStream_t s);
+
+// dense T x T cross-attention for T <= 32 keys / queries per window (MMF_XAttn_Add over the prediction steps) with bf16 MFMA
+// operands, one launch per direction: Q (B*T, H*hd), KV (B*T, 2*H*hd) = (k | v); P / A (B, H, T, T) are written by the forward
+// and read by the backward; live[b] == 0: zero attention, zero context, zero gradients.  dKV_h: optional bf16 image of dKV.
+bool xattn_small_supported(int T, int H, int hd);       // T <= 32, hd % 16 == 0
+int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char* live, int B, int T, int H, int hd, float scale, DropCfg drop,
+                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s);
+int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, const float* Pm, const float* Am, const unsigned char* live,
+                           int B, int T, int H, int hd, float scale, DropCfg drop, uint64_t site, float* dQ, float* dKV, void* dKV_h,
+                           hipStream_t s);

@@ -175,6 +175,13 @@ inline void batch_bh(GemmArgs& g, int B, int H, long sA_o, long sA_i, long sB_o,
 
 bool bad_x(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) || cfg->C <= 0; }
 
+// bf16 mode, T x T attention over <= 32 prediction steps: the one-launch MFMA kernels of attn.hip instead of batched GEMMs + row softmax
+// (IMMTSF_XATTN_SMALL=0: the GEMM path, for A/B measurements)
+bool xattn_small(const immtsf_fusion_cfg* c) {
+    static const bool on = !(getenv("IMMTSF_XATTN_SMALL") && atoi(getenv("IMMTSF_XATTN_SMALL")) == 0);
+    return on && c->precision == 1 && xattn_small_supported(c->T, c->H, c->d / c->H);
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,19 +273,23 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         set_problem(g, 0, Y_ts, f.WQf, w.Qi, p->attn_in_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    {   // scores[b,h] = scale * Qi_h Ki_h^T
-        GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
-        set_problem(g, 0, w.Qi, Ki, w.Pm, nullptr);
-        g.alpha = sqrtf(1.0f / (float)hd);
-        batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-    }
-    CHECK(launch_softmax_rows_fwd(w.Pm, w.Am, B, H, T, T, M_txt, drop, SITE_XADD_ATTN, 0, s));
-    {   // O_h = A V_h   (zero for the no-text windows: their attention rows are zero)
-        GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
-        set_problem(g, 0, w.Am, Vi, w.O, nullptr);
-        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    if (xattn_small(cfg)) {      // few prediction steps: scores, softmax, dropout and A V in one launch
+        CHECK(launch_xattn_small_fwd(w.Qi, KV, M_txt, B, T, H, hd, sqrtf(1.0f / (float)hd), drop, SITE_XADD_ATTN, w.Pm, w.Am, w.O, s));
+    } else {
+        {   // scores[b,h] = scale * Qi_h Ki_h^T
+            GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
+            set_problem(g, 0, w.Qi, Ki, w.Pm, nullptr);
+            g.alpha = sqrtf(1.0f / (float)hd);
+            batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
+            CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+        }
+        CHECK(launch_softmax_rows_fwd(w.Pm, w.Am, B, H, T, T, M_txt, drop, SITE_XADD_ATTN, 0, s));
+        {   // O_h = A V_h   (zero for the no-text windows: their attention rows are zero)
+            GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
+            set_problem(g, 0, w.Am, Vi, w.O, nullptr);
+            batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        }
     }
     // delta = M ? O W_HO^T + b_HO : b_res   (residual_head(where(M, out_proj(O), 0)))
     if (xadd_head_supported(C, d))        // head + LayerNorm(C) + dropout + blend in one kernel (w.delta stays unused)
@@ -387,30 +398,34 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         g.row_flag = M_txt; g.row_flag_div = T;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
-    {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
-        GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
-        set_problem(g, 0, sc.dO, Vi, sc.dA, nullptr);
-        batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-        GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
-        set_problem(h, 0, w.Am, sc.dO, dKV + d, nullptr);
-        if (dKV_h) h.p[0].Ch = dKV_h + d;
-        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
-    }
-    CHECK(launch_softmax_rows_bwd(sc.dA, w.Pm, B, H, T, T, drop, SITE_XADD_ATTN, s));
-    {   // dQ_h = scale dS K_h ; dK_h = scale dS^T Q_h
-        GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
-        set_problem(g, 0, sc.dA, Ki, sc.dQi, nullptr);
-        g.alpha = scale;
-        batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
-        set_problem(h, 0, sc.dA, w.Qi, dKV, nullptr);
-        if (dKV_h) h.p[0].Ch = dKV_h;
-        h.alpha = scale;
-        batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+    if (xattn_small(cfg)) {
+        CHECK(launch_xattn_small_bwd(w.Qi, KV, sc.dO, w.Pm, w.Am, M_txt, B, T, H, hd, scale, drop, SITE_XADD_ATTN, sc.dQi, dKV, dKV_h, s));
+    } else {
+        {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
+            GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
+            set_problem(g, 0, sc.dO, Vi, sc.dA, nullptr);
+            batch_bh(g, B, H, (long)T * d, hd, (long)T * 2 * d, hd, (long)H * TT2, TT2);
+            CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+            GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
+            set_problem(h, 0, w.Am, sc.dO, dKV + d, nullptr);
+            if (dKV_h) h.p[0].Ch = dKV_h + d;
+            batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
+            CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        }
+        CHECK(launch_softmax_rows_bwd(sc.dA, w.Pm, B, H, T, T, drop, SITE_XADD_ATTN, s));
+        {   // dQ_h = scale dS K_h ; dK_h = scale dS^T Q_h
+            GemmArgs g = gemm_args(T, hd, T, T, 2 * d, d);
+            set_problem(g, 0, sc.dA, Ki, sc.dQi, nullptr);
+            g.alpha = scale;
+            batch_bh(g, B, H, (long)H * TT2, TT2, (long)T * 2 * d, hd, (long)T * d, hd);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs h = gemm_args(T, hd, T, T, d, 2 * d);
+            set_problem(h, 0, sc.dA, w.Qi, dKV, nullptr);
+            if (dKV_h) h.p[0].Ch = dKV_h;
+            h.alpha = scale;
+            batch_bh(h, B, H, (long)H * TT2, TT2, (long)T * d, hd, (long)T * 2 * d, hd);
+            CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
+        }
     }
     {   // dY += dQi W_Qf
         GemmArgs g = gemm_args(BT, C, d, d, C, C);

@@ -690,9 +690,6 @@ constexpr int XS_PT = 40;        // pitch of the 32 x 32 bf16 tiles (80-byte row
 constexpr int XS_EC = 256;       // columns of the head dimension staged per pass
 constexpr int XS_PC = XS_EC + 8; // pitch of the staged chunk images
 constexpr int XS_PS = 33;        // pitch of the fp32 score tile
-#ifndef XS_UF
-#define XS_UF 12
-#endif
 struct XSmallDims { int B, T, H, hd, d; };     // d = H * hd: pitch of Q / O / dO rows (K | V rows: 2d)
 typedef short xs_s16x4 __attribute__((ext_vector_type(4)));
 typedef short xs_s16x8 __attribute__((ext_vector_type(8)));
@@ -750,6 +747,51 @@ __device__ __forceinline__ void xs_scores(int T, int hd, const float* __restrict
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * XS_PS + nt * 16 + fr] = alpha * acc[r];
 }
+// The same tile from bf16 LDS images of the two operands (hd <= XS_HD_STAGED, hd % 32 == 0): read straight from global memory
+// every load instruction of a fragment touches 16 rows that are a row pitch (3 - 6 KB) apart, and the product ran at a fraction
+// of the rate of the same bytes read row by row; staged, a wave's load covers 1 KB of one row.
+constexpr int XS_HD_STAGED = 768;
+__host__ __device__ inline bool xs_staged(int hd) { return hd <= XS_HD_STAGED && (hd & 31) == 0; }
+// images imX, imY [32][pf] of X, Y (rows beyond T: zero): 512 threads, eight 16-byte loads of each operand in flight per thread
+__device__ __forceinline__ void xs_stage_pair(int T, int hd, const float* __restrict__ X, size_t ldx, const float* __restrict__ Y, size_t ldy,
+                                              bf16_t* imX, bf16_t* imY, int pf) {
+    const int n4 = hd >> 2, total = XS_T * n4;
+    for (int base = 0; base < total; base += 512 * 8) {
+        float4 vx[8], vy[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+            vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vy[u] = vx[u];
+            if (r < T) {          // r < T <= 32 also bounds x
+                vx[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx)[c];
+                vy[u] = reinterpret_cast<const float4*>(Y + (size_t)r * ldy)[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+            if (x < total) {
+                const bf16x4 hx = {(bf16_t)vx[u].x, (bf16_t)vx[u].y, (bf16_t)vx[u].z, (bf16_t)vx[u].w};
+                const bf16x4 hy = {(bf16_t)vy[u].x, (bf16_t)vy[u].y, (bf16_t)vy[u].z, (bf16_t)vy[u].w};
+                *reinterpret_cast<bf16x4*>(imX + r * pf + 4 * c) = hx;
+                *reinterpret_cast<bf16x4*>(imY + r * pf + 4 * c) = hy;
+            }
+        }
+    }
+}
+__device__ __forceinline__ void xs_scores_lds(int hd, const bf16_t* imX, const bf16_t* imY, int pf, float alpha, float* Sf, float* Sf2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4, mt = (wave & 3) >> 1, nt = wave & 1;
+    const int half = wave >> 2, ksteps = hd >> 5, ks0 = (ksteps + 1) >> 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int kend = (half ? ksteps : ks0) * 32;
+#pragma unroll 4
+    for (int k = (half ? ks0 : 0) * 32; k < kend; k += 32)
+        acc = xs_mfma(xs_frag_row(imX, pf, mt * 16, k, fr, fq), xs_frag_row(imY, pf, nt * 16, k, fr, fq), acc);
+    float* out = half ? Sf2 : Sf;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * XS_PS + nt * 16 + fr] = alpha * acc[r];
+}
 // bf16 image img[r][e] (pitch XS_PC) of rows r < 32 of X, columns e0 .. e0 + ec (rows beyond T: zero), in two steps so that a
 // chunk's loads can be in flight while the previous chunk is being used: 512 threads x XS_NPRE float4 = 32 rows x 256 columns
 constexpr int XS_NPRE = XS_T * XS_EC / 4 / 512;
@@ -777,13 +819,13 @@ __device__ __forceinline__ void xs_stage_store(int ec, const XsPre& p, bf16_t* i
 // Z[m][e0 + n] = sum_k W(m, k) img[k][n] for the staged chunk: 2 x ec/16 tiles dealt to the eight waves.  WT: W is read through
 // the hardware transpose (W(m, k) = tile[k][m]) instead of row-major (tile[m][k]).  Rows m >= T are not written.
 template <bool WT>
-__device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, const bf16_t* img, float* __restrict__ Z, size_t ldz,
-                                       bf16_t* __restrict__ Zh) {
+__device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, const bf16_t* img, int pimg, float* __restrict__ Z,
+                                       size_t ldz, bf16_t* __restrict__ Zh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const bf16x8 w0 = WT ? xs_frag_kmajor(Wt, XS_PT, 0, 0, fr, fq) : xs_frag_row(Wt, XS_PT, 0, 0, fr, fq);
     const bf16x8 w1 = WT ? xs_frag_kmajor(Wt, XS_PT, 16, 0, fr, fq) : xs_frag_row(Wt, XS_PT, 16, 0, fr, fq);
     for (int nt = wave; nt < (ec >> 4); nt += 8) {
-        const bf16x8 bfrag = xs_frag_kmajor(img, XS_PC, nt * 16, 0, fr, fq);
+        const bf16x8 bfrag = xs_frag_kmajor(img, pimg, nt * 16, 0, fr, fq);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         const f32x4 c0 = xs_mfma(w0, bfrag, z), c1 = xs_mfma(w1, bfrag, z);
 #pragma unroll
@@ -808,9 +850,14 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
                                                               const unsigned char* __restrict__ live, float scale, DropCfg drop,
                                                               uint64_t site, float* __restrict__ Pm, float* __restrict__ Am,
                                                               float* __restrict__ O) {
-    __shared__ __attribute__((aligned(16))) float Sf[XS_T * XS_PS], Sf2[XS_T * XS_PS];
-    __shared__ __attribute__((aligned(16))) bf16_t Ab[XS_T * XS_PT];
-    __shared__ __attribute__((aligned(16))) bf16_t img[XS_T * XS_PC];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs_smem[];
+    float* Sf = reinterpret_cast<float*>(xs_smem);
+    float* Sf2 = Sf + XS_T * XS_PS;
+    bf16_t* Ab = reinterpret_cast<bf16_t*>(Sf2 + XS_T * XS_PS);
+    bf16_t* img = Ab + XS_T * XS_PT;
+    bf16_t* imX = img + XS_T * XS_PC;           // staged score operands (xs_staged(hd) only)
+    const int pf = dm.hd + 8;
+    bf16_t* imY = imX + XS_T * pf;
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, T = dm.T;
     const size_t q0 = (size_t)b * T * dm.d + (size_t)h * dm.hd, k0 = (size_t)b * T * 2 * dm.d + (size_t)h * dm.hd;
     const size_t ldk = (size_t)2 * dm.d, pg = (size_t)(b * dm.H + h) * T * T;
@@ -827,8 +874,15 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
     const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);
     XsPre pre;
     xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, pre);        // V's chunk travels beside the score operands
-    xs_scores<XS_UF>(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, scale, Sf, Sf2);
-    xs_stage_store(ec, pre, img);
+    if (xs_staged(dm.hd)) {
+        xs_stage_pair(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, imX, imY, pf);
+        xs_stage_store(ec, pre, img);
+        __syncthreads();
+        xs_scores_lds(dm.hd, imX, imY, pf, scale, Sf, Sf2);
+    } else {
+        xs_scores<6>(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, scale, Sf, Sf2);
+        xs_stage_store(ec, pre, img);
+    }
     __syncthreads();
     if (tid < 256) {   // softmax + dropout: 8 lanes per row, 4 columns each
         const int i = tid >> 3, j0 = (tid & 7) * 4;
@@ -859,7 +913,7 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
         }
     }
     __syncthreads();
-    xs_mix<false>(T, e0, ec, Ab, img, O + q0, dm.d, nullptr);       // O = A V
+    xs_mix<false>(T, e0, ec, Ab, img, XS_PC, O + q0, dm.d, nullptr);       // O = A V
 }
 
 // dO -> dQ, (dK | dV) (+ optional bf16 image)
@@ -874,8 +928,11 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     bf16_t* Ab = reinterpret_cast<bf16_t*>(Sf2 + XS_T * XS_PS);
     bf16_t* dSb = Ab + XS_T * XS_PT;
     bf16_t* imK = dSb + XS_T * XS_PT;
-    bf16_t* imG = imK + XS_T * XS_PC;
-    bf16_t* imQ = imG + XS_T * XS_PC;
+    bf16_t* imQ = imK + XS_T * XS_PC;
+    bf16_t* imG = imQ + XS_T * XS_PC;           // dO: its chunk (pitch XS_PC), or staged whole beside V (pitch hd + 8: xs_staged(hd))
+    const bool staged = xs_staged(dm.hd);
+    const int pf = dm.hd + 8, pg_img = staged ? pf : XS_PC;
+    bf16_t* imV = imG + XS_T * pf;
     const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, T = dm.T;
     const size_t q0 = (size_t)b * T * dm.d + (size_t)h * dm.hd, k0 = (size_t)b * T * 2 * dm.d + (size_t)h * dm.hd;
     const size_t ldk = (size_t)2 * dm.d, pg = (size_t)(b * dm.H + h) * T * T;
@@ -897,13 +954,21 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     }
     const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);       // this workgroup's chunk of dQ, dK, dV (see the forward)
     XsPre pK, pG, pQ;
-    xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's three images travel beside dA's operands
-    xs_stage_load(T, e0, ec, dO + q0, dm.d, pG);
+    xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's images travel beside dA's operands
     xs_stage_load(T, e0, ec, Q + q0, dm.d, pQ);
-    xs_scores<6>(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, 1.f, Sf, Sf2);        // dA = dO V^T
-    xs_stage_store(ec, pK, imK);
-    xs_stage_store(ec, pG, imG);
-    xs_stage_store(ec, pQ, imQ);
+    if (staged) {
+        xs_stage_pair(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, imG, imV, pf);
+        xs_stage_store(ec, pK, imK);
+        xs_stage_store(ec, pQ, imQ);
+        __syncthreads();
+        xs_scores_lds(dm.hd, imG, imV, pf, 1.f, Sf, Sf2);                            // dA = dO V^T
+    } else {
+        xs_stage_load(T, e0, ec, dO + q0, dm.d, pG);
+        xs_scores<6>(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, 1.f, Sf, Sf2);
+        xs_stage_store(ec, pK, imK);
+        xs_stage_store(ec, pQ, imQ);
+        xs_stage_store(ec, pG, imG);
+    }
     __syncthreads();
     if (tid < 256) {   // dS = scale P (dA dropscale - sum_j P dA dropscale): 8 lanes per row, 4 columns each
         const int i = tid >> 3, j0 = (tid & 7) * 4;
@@ -925,11 +990,17 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
         }
     }
     __syncthreads();
-    xs_mix<false>(T, e0, ec, dSb, imK, dQ + q0, dm.d, nullptr);                                             // dQ = dS K
-    xs_mix<true>(T, e0, ec, Ab, imG, dKV + k0 + dm.d, ldk, dKV_h ? dKV_h + k0 + dm.d : nullptr);          // dV = A^T dO
-    xs_mix<true>(T, e0, ec, dSb, imQ, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);                       // dK = dS^T Q
+    xs_mix<false>(T, e0, ec, dSb, imK, XS_PC, dQ + q0, dm.d, nullptr);                                                      // dQ = dS K
+    xs_mix<true>(T, e0, ec, Ab, staged ? imG + e0 : imG, pg_img, dKV + k0 + dm.d, ldk, dKV_h ? dKV_h + k0 + dm.d : nullptr);   // dV = A^T dO
+    xs_mix<true>(T, e0, ec, dSb, imQ, XS_PC, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);                                // dK = dS^T Q
 }
-constexpr size_t XS_BWD_LDS = (size_t)2 * XS_T * XS_PS * 4 + (size_t)2 * XS_T * XS_PT * 2 + (size_t)3 * XS_T * XS_PC * 2;
+inline size_t xs_fwd_lds(int hd) {
+    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)XS_T * XS_PT * 2 + (size_t)XS_T * XS_PC * 2 + (xs_staged(hd) ? (size_t)2 * XS_T * (hd + 8) * 2 : 0);
+}
+inline size_t xs_bwd_lds(int hd) {
+    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)2 * XS_T * XS_PT * 2 + (size_t)2 * XS_T * XS_PC * 2 +
+           (xs_staged(hd) ? (size_t)2 * XS_T * (hd + 8) * 2 : (size_t)XS_T * XS_PC * 2);
+}
 
 }  // namespace
 
@@ -1088,7 +1159,11 @@ int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char*
     if (!xattn_small_supported(T, H, hd) || ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(O)) & 15))
         return IMMTSF_EINVAL;
     const XSmallDims dm{B, T, H, hd, H * hd};
-    hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), 0, s, dm, Q, KV, live, scale, drop, site, Pm, Am, O);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_fwd_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_fwd_lds(XS_HD_STAGED));
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_fwd_lds(hd), s, dm, Q, KV, live, scale, drop, site, Pm,
+                       Am, O);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -1103,9 +1178,9 @@ int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, con
         return IMMTSF_EINVAL;
     const XSmallDims dm{B, T, H, hd, H * hd};
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_bwd_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)XS_BWD_LDS);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bwd_lds(XS_HD_STAGED));
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), XS_BWD_LDS, s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
+    hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_bwd_lds(hd), s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
                        static_cast<bf16_t*>(dKV_h));
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

@@ -255,17 +255,16 @@ def test_llama_dims_multihead_fp32():
 
 
 # ------------------------------------------------------------------------------------------ dropout
-@pytest.mark.parametrize("ttf,mmf", PAIRS)
-def test_dropout_with_exported_masks(ttf, mmf):
+def _dropout_parity(ttf, mmf, precision="fp32", B=6, N=9, T=7, C=4, d_m=40, d=32, H=2, pd=0.25, err=None, tol=(1e-4, 2e-4), exact_eval=True):
     """train mode, p=0.25: export the Philox keep-masks the kernels used and feed them to the oracle."""
     dev = _dev()
     from fusions.FusionModel import FusionModel
     from fusions.load_llm import register_d_model
     from immtsf import config, ops
     from oracle import fusion_ref as R
-    B, N, T, C, d_m, d, H, pd = 6, 9, 7, 4, 40, 32, 2, 0.25
+    _relerr = err or globals()["_relerr"]
     register_d_model("SYN", d_m)
-    config.precision = "fp32"
+    config.precision = precision
     config.manual_seed(1234)
     torch.manual_seed(3)
     a = _args(ttf, mmf, "SYN", d, H, C, dropout=pd)
@@ -304,16 +303,35 @@ def test_dropout_with_exported_masks(ttf, mmf):
     for k, prm in m.named_parameters():
         g = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
         gerrs["g." + k] = _relerr(prm.grad, g)
-    _check(errs, 1e-4)
-    _check(gerrs, 2e-4)
+    _check(errs, tol[0])
+    small = {k: v for k, v in gerrs.items() if precision == "bf16" and ("time2vec.linear" in k or "log_recency_sigma" in k)}
+    _check({k: v for k, v in gerrs.items() if k not in small}, tol[1])
+    _check(small, 2.5e-1)
     # eval mode ignores dropout and is deterministic
     m.eval()
     with torch.no_grad():
         o1 = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))
         o2 = m(notes.to(dev), tau.to(dev), t_hat.to(dev), Y.to(dev))
-    assert torch.equal(o1, o2)
+    if exact_eval:
+        assert torch.equal(o1, o2)
+    else:       # a GEMM that splits its reduction over workgroups adds the partial sums in arrival order
+        _check({"eval-repeat": _relerr(o1, o2)}, 1e-5)
     ref_eval = R.fusion_forward(ttf, mmf, {k: v.detach() for k, v in p.items()}, notes, tau, t_hat, Y, H=H, kappa=0.5)
-    _check({"eval": _relerr(o1, ref_eval)}, 1e-4)
+    _check({"eval": _relerr(o1, ref_eval)}, tol[0])
+
+
+@pytest.mark.parametrize("ttf,mmf", PAIRS)
+def test_dropout_with_exported_masks(ttf, mmf):
+    _dropout_parity(ttf, mmf)
+
+
+@pytest.mark.parametrize("T,H,d", [(17, 2, 64), (7, 2, 96), (32, 1, 1024)])
+def test_xattn_add_tile_attention_bf16_with_dropout(T, H, d):
+    """bf16 mode runs MMF_XAttn_Add's T x T attention as one MFMA tile kernel per direction (attn.hip: xattn_tile_*): head widths
+    on the LDS-staged score path (32), on the direct one with a half k-step tail (48) and over four column chunks (1024); T
+    odd / below / at the 32-row tile; attention dropout through the same exported Philox masks as the GEMM path."""
+    _dropout_parity("TTF_T2V_XAttn", "MMF_XAttn_Add", precision="bf16", T=T, H=H, d=d, d_m=64, err=_l2err, tol=(3e-2, 4e-2),
+                    exact_eval=d < 1024)
 
 
 def test_dropout_mask_statistics():

@@ -690,6 +690,7 @@ constexpr int XS_PT = 40;        // pitch of the 32 x 32 bf16 tiles (80-byte row
 constexpr int XS_EC = 256;       // columns of the head dimension staged per pass
 constexpr int XS_PC = XS_EC + 8; // pitch of the staged chunk images
 constexpr int XS_PS = 33;        // pitch of the fp32 score tile
+constexpr int XS_GC = 16;        // widest C-column input of a generated operand (XsGen)
 struct XSmallDims { int B, T, H, hd, d; };     // d = H * hd: pitch of Q / O / dO rows (K | V rows: 2d)
 typedef short xs_s16x4 __attribute__((ext_vector_type(4)));
 typedef short xs_s16x8 __attribute__((ext_vector_type(8)));
@@ -780,6 +781,95 @@ __device__ __forceinline__ void xs_stage_pair(int T, int hd, const float* __rest
         }
     }
 }
+__device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
+    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc);
+    return fmaf(a.w, b.w, acc);
+}
+__device__ __forceinline__ void axpy4(float w, const float4 x, float4& acc) {
+    acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y); acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
+}
+// single-operand form of the above
+__device__ __forceinline__ void xs_stage_one(int T, int hd, const float* __restrict__ X, size_t ldx, bf16_t* imX, int pf) {
+    const int n4 = hd >> 2, total = XS_T * n4;
+    for (int base = 0; base < total; base += 512 * 8) {
+        float4 vx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+            vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < T) vx[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx)[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
+            if (x < total) {
+                const bf16x4 hx = {(bf16_t)vx[u].x, (bf16_t)vx[u].y, (bf16_t)vx[u].z, (bf16_t)vx[u].w};
+                *reinterpret_cast<bf16x4*>(imX + r * pf + 4 * c) = hx;
+            }
+        }
+    }
+}
+// ---- operands that are themselves a C-column product (C <= 16): the projected queries Q = Y W_Q^T + b_q and the context
+// gradient dO = ddelta W_O of MMF_XAttn_Add.  As launches of their own they are 6.3 MB written and read back three times on the
+// serial section of the step; here the 32 x C input tile sits in LDS and a thread that owns four columns forms them for a group
+// of rows straight into the bf16 image (fp32 FMAs, one rounding: the values the separate launch + staging would give).
+struct XsGen {
+    const float *Y, *WQ, *bq;      // Y (B*T, C), WQ (d, C), bq (d)
+    const float *dd, *WO;          // backward: ddelta (B*T, C), WO (C, d)
+    int C;                         // 0: Q / dO are read from memory
+};
+// tile[r][k] = src[(row0 + r) * C + k], r < T (zero beyond)
+__device__ __forceinline__ void xs_gen_tile(int T, int C, const float* __restrict__ src, float* tile) {
+    for (int x = threadIdx.x; x < XS_T * C; x += 512) tile[x] = x < T * C ? src[x] : 0.f;
+}
+// img[r][icol0 + e] (pitch) for e < ec, r < 32:  WROWS: bias[ecol0 + e] + sum_k tile[r][k] W[(ecol0 + e) * C + k];
+// else sum_k tile[r][k] W[k * ldw + ecol0 + e]
+template <int C4, bool WROWS>
+__device__ __forceinline__ void xs_generate_c(const float* tile, const float* __restrict__ W, size_t ldw, const float* __restrict__ bias,
+                                              int ecol0, int ec, bf16_t* img, int pitch, int icol0) {
+    constexpr int C = 4 * C4;
+    const int n4 = ec >> 2;
+    for (int x = threadIdx.x; x < n4 * 8; x += 512) {
+        const int c = x % n4, rg = x / n4, e = ecol0 + 4 * c;
+        float4 w[C];          // WROWS: w[j * C4 + k4] = W[e + j][4 k4 ..]; else w[k] = W[k][e ..]
+#pragma unroll
+        for (int q = 0; q < C; ++q)
+            w[q] = WROWS ? reinterpret_cast<const float4*>(W + (size_t)(e + q / C4) * C)[q % C4] : *reinterpret_cast<const float4*>(W + (size_t)q * ldw + e);
+        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rg * 4 + rr;
+            float4 y[C4];
+#pragma unroll
+            for (int k4 = 0; k4 < C4; ++k4) y[k4] = *reinterpret_cast<const float4*>(tile + r * C + 4 * k4);
+            float4 o = bv;
+            if (WROWS) {
+#pragma unroll
+                for (int k4 = 0; k4 < C4; ++k4) {
+                    o.x = dot4(y[k4], w[0 * C4 + k4], o.x); o.y = dot4(y[k4], w[1 * C4 + k4], o.y);
+                    o.z = dot4(y[k4], w[2 * C4 + k4], o.z); o.w = dot4(y[k4], w[3 * C4 + k4], o.w);
+                }
+            } else {
+#pragma unroll
+                for (int k4 = 0; k4 < C4; ++k4) {
+                    axpy4(y[k4].x, w[4 * k4], o); axpy4(y[k4].y, w[4 * k4 + 1], o); axpy4(y[k4].z, w[4 * k4 + 2], o); axpy4(y[k4].w, w[4 * k4 + 3], o);
+                }
+            }
+            const bf16x4 hv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+            *reinterpret_cast<bf16x4*>(img + r * pitch + icol0 + 4 * c) = hv;
+        }
+    }
+}
+template <bool WROWS>
+__device__ __forceinline__ void xs_generate(int C, const float* tile, const float* __restrict__ W, size_t ldw, const float* __restrict__ bias,
+                                            int ecol0, int ec, bf16_t* img, int pitch, int icol0) {
+    switch (C >> 2) {
+    case 1: xs_generate_c<1, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
+    case 2: xs_generate_c<2, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
+    case 3: xs_generate_c<3, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
+    default: xs_generate_c<4, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
+    }
+}
 __device__ __forceinline__ void xs_scores_lds(int hd, const bf16_t* imX, const bf16_t* imY, int pf, float alpha, float* Sf, float* Sf2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4, mt = (wave & 3) >> 1, nt = wave & 1;
     const int half = wave >> 2, ksteps = hd >> 5, ks0 = (ksteps + 1) >> 1;
@@ -849,11 +939,12 @@ __device__ __forceinline__ float xs_max8(float v) {
 __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, const float* __restrict__ Q, const float* __restrict__ KV,
                                                               const unsigned char* __restrict__ live, float scale, DropCfg drop,
                                                               uint64_t site, float* __restrict__ Pm, float* __restrict__ Am,
-                                                              float* __restrict__ O) {
+                                                              float* __restrict__ O, XsGen gn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xs_smem[];
     float* Sf = reinterpret_cast<float*>(xs_smem);
     float* Sf2 = Sf + XS_T * XS_PS;
-    bf16_t* Ab = reinterpret_cast<bf16_t*>(Sf2 + XS_T * XS_PS);
+    float* ytile = Sf2 + XS_T * XS_PS;           // [32][C] input tile of a generated operand (XsGen)
+    bf16_t* Ab = reinterpret_cast<bf16_t*>(ytile + XS_T * XS_GC);
     bf16_t* img = Ab + XS_T * XS_PT;
     bf16_t* imX = img + XS_T * XS_PC;           // staged score operands (xs_staged(hd) only)
     const int pf = dm.hd + 8;
@@ -875,7 +966,14 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
     XsPre pre;
     xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, pre);        // V's chunk travels beside the score operands
     if (xs_staged(dm.hd)) {
-        xs_stage_pair(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, imX, imY, pf);
+        if (gn.C) {       // Q is formed here from the C-column input (host: only with the staged path)
+            xs_gen_tile(T, gn.C, gn.Y + (size_t)b * T * gn.C, ytile);
+            xs_stage_one(T, dm.hd, KV + k0, ldk, imY, pf);
+            __syncthreads();
+            xs_generate<true>(gn.C, ytile, gn.WQ, 0, gn.bq, h * dm.hd, dm.hd, imX, pf, 0);
+        } else {
+            xs_stage_pair(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, imX, imY, pf);
+        }
         xs_stage_store(ec, pre, img);
         __syncthreads();
         xs_scores_lds(dm.hd, imX, imY, pf, scale, Sf, Sf2);
@@ -921,11 +1019,13 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
                                                               const float* __restrict__ dO, const float* __restrict__ Pm,
                                                               const float* __restrict__ Am, const unsigned char* __restrict__ live,
                                                               float scale, DropCfg drop, uint64_t site, float* __restrict__ dQ,
-                                                              float* __restrict__ dKV, bf16_t* __restrict__ dKV_h) {
+                                                              float* __restrict__ dKV, bf16_t* __restrict__ dKV_h, XsGen gn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xs_smem[];
     float* Sf = reinterpret_cast<float*>(xs_smem);
     float* Sf2 = Sf + XS_T * XS_PS;
-    bf16_t* Ab = reinterpret_cast<bf16_t*>(Sf2 + XS_T * XS_PS);
+    float* ytile = Sf2 + XS_T * XS_PS;           // [32][C] input tiles of the generated operands (XsGen): Y, ddelta
+    float* dtile = ytile + XS_T * XS_GC;
+    bf16_t* Ab = reinterpret_cast<bf16_t*>(dtile + XS_T * XS_GC);
     bf16_t* dSb = Ab + XS_T * XS_PT;
     bf16_t* imK = dSb + XS_T * XS_PT;
     bf16_t* imQ = imK + XS_T * XS_PC;
@@ -955,14 +1055,25 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);       // this workgroup's chunk of dQ, dK, dV (see the forward)
     XsPre pK, pG, pQ;
     xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's images travel beside dA's operands
-    xs_stage_load(T, e0, ec, Q + q0, dm.d, pQ);
-    if (staged) {
+    if (staged && gn.C) {      // dO and Q's chunk are formed here from their C-column inputs (host: only with the staged path)
+        xs_gen_tile(T, gn.C, gn.Y + (size_t)b * T * gn.C, ytile);
+        xs_gen_tile(T, gn.C, gn.dd + (size_t)b * T * gn.C, dtile);
+        xs_stage_one(T, dm.hd, KV + k0 + dm.d, ldk, imV, pf);
+        xs_stage_store(ec, pK, imK);
+        __syncthreads();
+        xs_generate<false>(gn.C, dtile, gn.WO, dm.d, nullptr, h * dm.hd, dm.hd, imG, pf, 0);
+        xs_generate<true>(gn.C, ytile, gn.WQ, 0, gn.bq, h * dm.hd + e0, ec, imQ, XS_PC, 0);
+        __syncthreads();
+        xs_scores_lds(dm.hd, imG, imV, pf, 1.f, Sf, Sf2);                            // dA = dO V^T
+    } else if (staged) {
+        xs_stage_load(T, e0, ec, Q + q0, dm.d, pQ);
         xs_stage_pair(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, imG, imV, pf);
         xs_stage_store(ec, pK, imK);
         xs_stage_store(ec, pQ, imQ);
         __syncthreads();
         xs_scores_lds(dm.hd, imG, imV, pf, 1.f, Sf, Sf2);                            // dA = dO V^T
     } else {
+        xs_stage_load(T, e0, ec, Q + q0, dm.d, pQ);
         xs_stage_load(T, e0, ec, dO + q0, dm.d, pG);
         xs_scores<6>(T, dm.hd, dO + q0, dm.d, KV + k0 + dm.d, ldk, 1.f, Sf, Sf2);
         xs_stage_store(ec, pK, imK);
@@ -995,10 +1106,11 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     xs_mix<true>(T, e0, ec, dSb, imQ, XS_PC, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);                                // dK = dS^T Q
 }
 inline size_t xs_fwd_lds(int hd) {
-    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)XS_T * XS_PT * 2 + (size_t)XS_T * XS_PC * 2 + (xs_staged(hd) ? (size_t)2 * XS_T * (hd + 8) * 2 : 0);
+    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)XS_T * XS_GC * 4 + (size_t)XS_T * XS_PT * 2 + (size_t)XS_T * XS_PC * 2 +
+           (xs_staged(hd) ? (size_t)2 * XS_T * (hd + 8) * 2 : 0);
 }
 inline size_t xs_bwd_lds(int hd) {
-    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)2 * XS_T * XS_PT * 2 + (size_t)2 * XS_T * XS_PC * 2 +
+    return (size_t)2 * XS_T * XS_PS * 4 + (size_t)2 * XS_T * XS_GC * 4 + (size_t)2 * XS_T * XS_PT * 2 + (size_t)2 * XS_T * XS_PC * 2 +
            (xs_staged(hd) ? (size_t)2 * XS_T * (hd + 8) * 2 : (size_t)XS_T * XS_PC * 2);
 }
 
@@ -1152,36 +1264,50 @@ int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int
 }
 
 bool xattn_small_supported(int T, int H, int hd) { return T >= 1 && T <= XS_T && H >= 1 && hd >= 16 && (hd % 16) == 0; }
+bool xattn_small_generates(int hd, int C) { return xs_staged(hd) && C >= 4 && C <= XS_GC && (C % 4) == 0; }
+static bool xs_gen_ok(const XattnGen* g, int hd, bool bwd, XsGen* out) {
+    *out = XsGen{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if (!g || g->C == 0) return true;
+    uintptr_t a = reinterpret_cast<uintptr_t>(g->Y) | reinterpret_cast<uintptr_t>(g->WQ) | reinterpret_cast<uintptr_t>(g->bq);
+    if (bwd) a |= reinterpret_cast<uintptr_t>(g->dd) | reinterpret_cast<uintptr_t>(g->WO);
+    if (!xattn_small_generates(hd, g->C) || !g->Y || !g->WQ || !g->bq || (bwd && (!g->dd || !g->WO)) || (a & 15)) return false;
+    *out = XsGen{g->Y, g->WQ, g->bq, g->dd, g->WO, g->C};
+    return true;
+}
 
 int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char* live, int B, int T, int H, int hd, float scale, DropCfg drop,
-                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s) {
+                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s, const XattnGen* gen) {
     if (B <= 0) return IMMTSF_OK;
-    if (!xattn_small_supported(T, H, hd) || ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(O)) & 15))
+    XsGen gn;
+    if (!xattn_small_supported(T, H, hd) || ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(O)) & 15) ||
+        !xs_gen_ok(gen, hd, false, &gn) || (!gn.C && !Q))
         return IMMTSF_EINVAL;
     const XSmallDims dm{B, T, H, hd, H * hd};
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_fwd_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_fwd_lds(XS_HD_STAGED));
     if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_fwd_lds(hd), s, dm, Q, KV, live, scale, drop, site, Pm,
-                       Am, O);
+                       Am, O, gn);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, const float* Pm, const float* Am, const unsigned char* live,
                            int B, int T, int H, int hd, float scale, DropCfg drop, uint64_t site, float* dQ, float* dKV, void* dKV_h,
-                           hipStream_t s) {
+                           hipStream_t s, const XattnGen* gen) {
     if (B <= 0) return IMMTSF_OK;
+    XsGen gn;
     if (!xattn_small_supported(T, H, hd) ||
         ((reinterpret_cast<uintptr_t>(Q) | reinterpret_cast<uintptr_t>(KV) | reinterpret_cast<uintptr_t>(dO) | reinterpret_cast<uintptr_t>(dQ) |
-          reinterpret_cast<uintptr_t>(dKV)) & 15) || (reinterpret_cast<uintptr_t>(dKV_h) & 7))
+          reinterpret_cast<uintptr_t>(dKV)) & 15) || (reinterpret_cast<uintptr_t>(dKV_h) & 7) || !xs_gen_ok(gen, hd, true, &gn) ||
+        (!gn.C && (!Q || !dO)))
         return IMMTSF_EINVAL;
     const XSmallDims dm{B, T, H, hd, H * hd};
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_bwd_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bwd_lds(XS_HD_STAGED));
     if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_bwd_lds(hd), s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
-                       static_cast<bf16_t*>(dKV_h));
+                       static_cast<bf16_t*>(dKV_h), gn);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -36,9 +36,13 @@ int launch_attn_short_bwd(const float* qkv, const float* dout, int B, int L, int
 // dense T x T cross-attention for T <= 32 keys / queries per window (MMF_XAttn_Add over the prediction steps) with bf16 MFMA
 // operands, one launch per direction: Q (B*T, H*hd), KV (B*T, 2*H*hd) = (k | v); P / A (B, H, T, T) are written by the forward
 // and read by the backward; live[b] == 0: zero attention, zero context, zero gradients.  dKV_h: optional bf16 image of dKV.
+// gen (optional, xattn_small_generates(hd, C)): Q = Y WQ^T + bq (Y (B*T, C), WQ (H*hd, C), bq (H*hd)) and, backward,
+// dO = dd WO (dd (B*T, C), WO (C, H*hd)) are formed inside the kernels from their C-column inputs; Q / dO may then be null.
+struct XattnGen { const float *Y, *WQ, *bq, *dd, *WO; int C; };
 bool xattn_small_supported(int T, int H, int hd);       // T <= 32, hd % 16 == 0
+bool xattn_small_generates(int hd, int C);              // hd <= 768, hd % 32 == 0, C in {4, 8, 12, 16}
 int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char* live, int B, int T, int H, int hd, float scale, DropCfg drop,
-                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s);
+                           uint64_t site, float* Pm, float* Am, float* O, hipStream_t s, const XattnGen* gen = nullptr);
 int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, const float* Pm, const float* Am, const unsigned char* live,
                            int B, int T, int H, int hd, float scale, DropCfg drop, uint64_t site, float* dQ, float* dKV, void* dKV_h,
-                           hipStream_t s);
+                           hipStream_t s, const XattnGen* gen = nullptr);

@@ -182,6 +182,15 @@ bool xattn_small(const immtsf_fusion_cfg* c) {
     return on && c->precision == 1 && xattn_small_supported(c->T, c->H, c->d / c->H);
 }
 
+// the query projection (forward, backward) and the context gradient (backward) as operands formed inside the tile kernels from
+// their C-column inputs: decided from what the forward and the backward both see, so that they agree on whether Qi exists
+bool xattn_gen(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const float* Y_ts, const QFold& f) {
+    static const bool on = !(getenv("IMMTSF_XATTN_GEN") && atoi(getenv("IMMTSF_XATTN_GEN")) == 0);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(Y_ts) | reinterpret_cast<uintptr_t>(f.WQf) | reinterpret_cast<uintptr_t>(f.WHO) |
+                        reinterpret_cast<uintptr_t>(p->attn_in_b);
+    return on && xattn_small(c) && xattn_small_generates(c->d / c->H, c->C) && (a & 15) == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -268,13 +277,16 @@ int immtsf_mmf_xattn_q_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         fold = w.fold;
     }
     const QFold f = qfold_at(cfg, const_cast<float*>(fold));
-    {   // Qi = Y W_Qf^T + b_q
+    const bool gen = xattn_gen(cfg, p, Y_ts, f);      // the tile kernel forms Qi = Y W_Qf^T + b_q itself
+    if (!gen) {   // Qi = Y W_Qf^T + b_q
         GemmArgs g = gemm_args(BT, d, C, C, C, d);
         set_problem(g, 0, Y_ts, f.WQf, w.Qi, p->attn_in_b);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     if (xattn_small(cfg)) {      // few prediction steps: scores, softmax, dropout and A V in one launch
-        CHECK(launch_xattn_small_fwd(w.Qi, KV, M_txt, B, T, H, hd, sqrtf(1.0f / (float)hd), drop, SITE_XADD_ATTN, w.Pm, w.Am, w.O, s));
+        const XattnGen xg{Y_ts, f.WQf, p->attn_in_b, nullptr, nullptr, gen ? C : 0};
+        CHECK(launch_xattn_small_fwd(gen ? nullptr : w.Qi, KV, M_txt, B, T, H, hd, sqrtf(1.0f / (float)hd), drop, SITE_XADD_ATTN, w.Pm, w.Am, w.O,
+                                     s, &xg));
     } else {
         {   // scores[b,h] = scale * Qi_h Ki_h^T
             GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);
@@ -392,14 +404,17 @@ int immtsf_mmf_xattn_q_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
 
     CHECK(launch_ln_blend_bwd(dY_out, M_txt, BT, T, C, p->ln_w, w.xhatC, w.rstdC, cfg->kappa, dY_ts, sc.dn, sc.ddelta, drop,
                               SITE_XADD_OUT, s));
-    {   // dO = where(M, ddelta W_HO, 0)
+    const bool gen = xattn_gen(cfg, p, Y_ts, f);      // the tile kernel forms dO (and Qi again) itself
+    if (!gen) {   // dO = where(M, ddelta W_HO, 0)
         GemmArgs g = gemm_args(BT, d, C, C, d, d);
         set_problem(g, 0, sc.ddelta, f.WHO, sc.dO, nullptr);
         g.row_flag = M_txt; g.row_flag_div = T;
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     if (xattn_small(cfg)) {
-        CHECK(launch_xattn_small_bwd(w.Qi, KV, sc.dO, w.Pm, w.Am, M_txt, B, T, H, hd, scale, drop, SITE_XADD_ATTN, sc.dQi, dKV, dKV_h, s));
+        const XattnGen xg{Y_ts, f.WQf, p->attn_in_b, sc.ddelta, f.WHO, gen ? C : 0};
+        CHECK(launch_xattn_small_bwd(gen ? nullptr : w.Qi, KV, gen ? nullptr : sc.dO, w.Pm, w.Am, M_txt, B, T, H, hd, scale, drop, SITE_XADD_ATTN,
+                                     sc.dQi, dKV, dKV_h, s, &xg));
     } else {
         {   // dA[b,h] = dO_h V_h^T ;  dV_h = A^T dO_h
             GemmArgs g = gemm_args(T, T, hd, d, 2 * d, T);

@@ -180,6 +180,14 @@ int immtsf_masked_mse(const float* truth, const float* pred, const float* mask, 
                             static_cast<hipStream_t>(stream));
 }
 
+int immtsf_masked_mse_counted(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C, const float* cnt_global,
+                              float* scratch, float* loss, float* dpred, float grad_scale, immtsf_stream_t stream) {
+    if (!truth || !pred || !mask || !cnt_global || !scratch || !loss || rows < 0 || C <= 0) return IMMTSF_EINVAL;
+    if (C > 64) return IMMTSF_EUNSUPPORTED;
+    return launch_mse_counted(truth, pred, mask, rows, C, cnt_global, scratch + 1, reinterpret_cast<unsigned int*>(scratch), loss, dpred,
+                              grad_scale, static_cast<hipStream_t>(stream));
+}
+
 int immtsf_masked_mse_finish(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
                              const float* err_sum, const float* cnt, float* loss, float* dpred, float grad_scale,
                              immtsf_stream_t stream) {

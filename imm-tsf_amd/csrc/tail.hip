@@ -425,6 +425,61 @@ int launch_mse_sums(const float* truth, const float* pred, const float* mask, in
     return IMMTSF_OK;
 }
 
+// With the per-variable counts known beforehand (they depend on the mask only: data pipelines reduce them when the batch is
+// built) nothing in the gradient waits for a reduction, so the work spreads over several workgroups: every element's gradient
+// is final on first touch, the loss is the sum of per-workgroup partials that the LAST workgroup to finish (ticket counter)
+// adds up in index order -- deterministic, no zero-fill, the ticket is left at zero for the next call.  C <= 64.
+constexpr int MSE_PARTS = 64;
+__global__ __launch_bounds__(256) void mse_counted_kernel(const float* __restrict__ truth, const float* __restrict__ pred,
+                                                           const float* __restrict__ mask, size_t n, int C,
+                                                           const float* __restrict__ cnt, float* __restrict__ partial,
+                                                           unsigned int* __restrict__ ticket, float* __restrict__ loss,
+                                                           float* __restrict__ dpred, float grad_scale) {
+    __shared__ float s_red[4], s_nav;
+    __shared__ unsigned int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (wave == 0) {
+        const bool live = lane < C && cnt[lane] != 0.f;
+        const unsigned long long b = __ballot(live);
+        if (lane == 0) s_nav = (float)__popcll(b);
+    }
+    __syncthreads();
+    const float navail = s_nav;
+    float e = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float dlt = truth[i] - pred[i], m = mask[i], den = cnt[c] + 1e-8f;
+        e += dlt * dlt * m / den;
+        if (dpred) dpred[i] = -dlt * m * (grad_scale * 2.f / (den * navail));
+    }
+    e = wave_sum(e);
+    if (lane == 0) s_red[wave] = e;
+    __syncthreads();
+    if (tid == 0) {
+        partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && tid == 0) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned int k = 0; k < gridDim.x; ++k) tot += __builtin_nontemporal_load(partial + k);
+        if (loss) loss[0] = tot / navail;
+        *ticket = 0u;
+    }
+}
+
+int launch_mse_counted(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt, float* partial,
+                       unsigned int* ticket, float* loss, float* dpred, float grad_scale, hipStream_t s) {
+    const size_t n = (size_t)rows * C;
+    int grid = (int)((n + 1023) / 1024);        // four elements per thread
+    grid = grid < 1 ? 1 : (grid > MSE_PARTS ? MSE_PARTS : grid);
+    hipLaunchKernelGGL(mse_counted_kernel, dim3(grid), dim3(256), 0, s, truth, pred, mask, n, C, cnt, partial, ticket, loss, dpred, grad_scale);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 int launch_mse_small(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt_in,
                      float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s) {
     int CT = 1;

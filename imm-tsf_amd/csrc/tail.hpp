@@ -26,6 +26,10 @@ int launch_mse_sums(const float* truth, const float* pred, const float* mask, in
                     float* cnt, float* scratch, hipStream_t s);
 int launch_mse_small(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt_in,
                      float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
+// cnt known beforehand, C <= 64: several workgroups, last-to-finish adds the partial losses (partial: >= 64 floats, ticket: one
+// zero-initialised word that the call leaves zero)
+int launch_mse_counted(const float* truth, const float* pred, const float* mask, int rows, int C, const float* cnt, float* partial,
+                       unsigned int* ticket, float* loss, float* dpred, float grad_scale, hipStream_t s);
 int launch_mse_finish(const float* truth, const float* pred, const float* mask, int rows, int C, const float* err_sum,
                       const float* cnt, float* loss, float* dpred, float grad_scale, hipStream_t s);
 

@@ -25,9 +25,17 @@ __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const f
                                                              uint64_t site) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];        // [C][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = hd.C, d4 = hd.d >> 2;
+    const int per = (hd.BT + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(hd.BT, r0 + per);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the wave's first row travels beside the weights (one global round trip for the usual one row per wave, not two)
+    float4 u[HEAD_DV];
+#pragma unroll
+    for (int j = 0; j < HEAD_DV; ++j) {
+        const int q = lane + 64 * j;
+        u[j] = (q < d4 && r0 + wave < r1) ? reinterpret_cast<const float4*>(U + (size_t)(r0 + wave) * hd.d)[q] : z4;
+    }
     for (int i = threadIdx.x; i < C * d4; i += 256) reinterpret_cast<float4*>(Ws)[i] = reinterpret_cast<const float4*>(W)[i];
     __syncthreads();
-    const int per = (hd.BT + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = min(hd.BT, r0 + per);
     const float inv = 1.f / (1.f + kappa);
     for (int row = r0 + wave; row < r1; row += 4) {
         float acc[CM];
@@ -37,13 +45,19 @@ __global__ __launch_bounds__(256) void xadd_head_fwd_kernel(HeadDims hd, const f
         for (int j = 0; j < HEAD_DV; ++j) {
             const int q = lane + 64 * j;
             if (q < d4) {
-                const float4 u = reinterpret_cast<const float4*>(U + (size_t)row * hd.d)[q];
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
                     if (c < C) {
                         const float4 w = reinterpret_cast<const float4*>(Ws + c * hd.d)[q];
-                        acc[c] = fmaf(u.x, w.x, fmaf(u.y, w.y, fmaf(u.z, w.z, fmaf(u.w, w.w, acc[c]))));
+                        acc[c] = fmaf(u[j].x, w.x, fmaf(u[j].y, w.y, fmaf(u[j].z, w.z, fmaf(u[j].w, w.w, acc[c]))));
                     }
+            }
+        }
+        if (row + 4 < r1) {
+#pragma unroll
+            for (int j = 0; j < HEAD_DV; ++j) {
+                const int q = lane + 64 * j;
+                u[j] = q < d4 ? reinterpret_cast<const float4*>(U + (size_t)(row + 4) * hd.d)[q] : z4;
             }
         }
         const bool live = mtxt[row / hd.T] != 0;

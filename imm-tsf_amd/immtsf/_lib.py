@@ -138,6 +138,7 @@ _PROTOS = {
     "immtsf_masked_mse_sums": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_masked_mse": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float,
                                     c_stream]),
+    "immtsf_masked_mse_counted": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_stream]),
     "immtsf_masked_mse_finish": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                            C.c_float, c_stream]),
     "immtsf_tpatchgnn_gcn_lds_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -1379,6 +1379,13 @@ class MaskedMSEFn(torch.autograd.Function):
         rows = pred.numel() // Cc
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
         dpred = torch.empty_like(pred)
+        if group is None and global_cnt is not None and Cc <= 64:
+            # counts known beforehand: nothing waits for a reduction, several workgroups, one launch
+            cnt = _c(global_cnt.to(torch.float32))
+            check(lib.immtsf_masked_mse_counted(ptr(truth), ptr(pred), ptr(mask), rows, Cc, ptr(cnt), ptr(_mse_scratch(pred.device)),
+                                                ptr(loss), ptr(dpred), 1.0, stream_ptr()), "masked_mse_counted")
+            ctx.save_for_backward(dpred)
+            return loss
         if group is None and rows * Cc <= _MSE_SMALL_MAX and Cc <= 4096:
             # one single-workgroup kernel instead of three launches (they sit between the forward and the backward)
             cnt = _c(global_cnt.to(torch.float32)) if global_cnt is not None else None
@@ -1410,6 +1417,18 @@ class MaskedMSEFn(torch.autograd.Function):
 
 
 _MSE_SMALL_MAX = 1 << 17        # IMMTSF_MSE_SMALL_MAX
+_mse_scratch_cache = {}
+
+
+def _mse_scratch(device) -> torch.Tensor:
+    """Ticket word + partial losses of immtsf_masked_mse_counted: one zero-initialised buffer per device, kept for the life of
+    the process (a captured graph keeps pointing at it).  One loss per step and process: calls are ordered on their stream; two
+    concurrent calls on different streams of one device would need their own buffers (the C entry point takes any)."""
+    key = (device.type, device.index)
+    t = _mse_scratch_cache.get(key)
+    if t is None:
+        t = _mse_scratch_cache[key] = torch.zeros(65, dtype=torch.float32, device=device)
+    return t
 _unit_grads = {}
 
 

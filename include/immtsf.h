@@ -303,6 +303,17 @@ int immtsf_masked_mse_finish(const float* truth, const float* pred, const float*
 int immtsf_masked_mse(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C, const float* cnt_global,
                       float* err_sum, float* cnt, float* loss, float* dpred, float grad_scale, immtsf_stream_t stream);
 
+/* the same loss when the per-variable observation counts are known before the step (they depend on the mask only; the
+ * reference recomputes them inside compute_error, lib/evaluation.py:36-47): no element waits for a reduction, so the
+ * work spreads over up to 64 workgroups and the last one to finish adds the partial losses in index order
+ * (deterministic).  C <= 64 (IMMTSF_EUNSUPPORTED above).  scratch: IMMTSF_MSE_COUNTED_SCRATCH floats owned by the caller,
+ * zero-initialised ONCE; word 0 is a ticket counter that every call leaves at zero, so the buffer can be reused by the
+ * next call on the same stream (not by concurrent calls). */
+#define IMMTSF_MSE_COUNTED_SCRATCH 65
+int immtsf_masked_mse_counted(const float* truth, const float* pred, const float* mask, int32_t rows, int32_t C,
+                              const float* cnt_global, float* scratch, float* loss, float* dpred, float grad_scale,
+                              immtsf_stream_t stream);
+
 /* ---- device-side batch builder: the reference's collate functions over a dataset that is
  * resident in HBM.  Replaces lib/parse_datasets.py:252-295 (variable_time_collate_fn), :298-366 +
  * lib/utils.py:359-413 (patch_variable_time_collate_fn / split_and_patch_batch) and :764-824 (multimodal wrapper).

@@ -432,13 +432,14 @@ def test_masked_mse_matches_oracle():
 
 
 def test_masked_mse_single_kernel_vs_staged_and_unit_seed():
-    """The single-workgroup kernel (small inputs), the three-stage path (large inputs, or a process group) and the
-    oracle agree, with local and with global counts; backward_unit() seeds with the cached 1 and skips the multiply."""
+    """The single-workgroup kernel (small inputs), the three-stage path (large inputs, or a process group), the multi-workgroup
+    kernel for counts known beforehand (C <= 64; called twice: its ticket word must come back to zero) and the oracle agree,
+    with local and with global counts; backward_unit() seeds with the cached 1 and skips the multiply."""
     dev = _dev()
     from immtsf import ops
     from oracle import fusion_ref as R
     g = torch.Generator().manual_seed(3)
-    for shape in [(64, 32, 8), (7, 5, 3), (300, 64, 9)]:            # the last one is above IMMTSF_MSE_SMALL_MAX
+    for shape in [(64, 32, 8), (7, 5, 3), (300, 64, 9), (40, 3, 70)]:      # the third is above IMMTSF_MSE_SMALL_MAX; the last has C > 64
         t, p = torch.randn(*shape, generator=g), torch.randn(*shape, generator=g)
         mk = (torch.rand(*shape, generator=g) < 0.6).float()
         mk[..., 0] = 0.0                                            # a variable that is never observed
@@ -457,6 +458,8 @@ def test_masked_mse_single_kernel_vs_staged_and_unit_seed():
         l2.backward()
         assert _relerr(l2, 0.5 * ref) < 1e-5
         assert _relerr(pg2.grad, 0.5 * pc.grad) < 1e-5
+        l3 = ops.masked_mse(p.to(dev), t.to(dev), mk.to(dev), None, cnt)
+        assert torch.equal(l3, l2.detach())
     assert ops.is_unit_grad(ops.unit_grad(dev)) and not ops.is_unit_grad(torch.ones((), device=dev))
 
 

@@ -753,33 +753,48 @@ __device__ __forceinline__ void xs_scores(int T, int hd, const float* __restrict
 // of the rate of the same bytes read row by row; staged, a wave's load covers 1 KB of one row.
 constexpr int XS_HD_STAGED = 768;
 __host__ __device__ inline bool xs_staged(int hd) { return hd <= XS_HD_STAGED && (hd & 31) == 0; }
-// images imX, imY [32][pf] of X, Y (rows beyond T: zero): 512 threads, eight 16-byte loads of each operand in flight per thread
-__device__ __forceinline__ void xs_stage_pair(int T, int hd, const float* __restrict__ X, size_t ldx, const float* __restrict__ Y, size_t ldy,
-                                              bf16_t* imX, bf16_t* imY, int pf) {
-    const int n4 = hd >> 2, total = XS_T * n4;
-    for (int base = 0; base < total; base += 512 * 8) {
-        float4 vx[8], vy[8];
+// images imX, imY [32][pf] of X, Y (rows beyond T: zero): wave w owns rows w, w + 8, w + 16, w + 24 and its lanes stride the
+// 16-byte chunks of a row (hd <= 768: three per lane) -- no index arithmetic beyond adds (a first version mapped a flat index to
+// (row, chunk) with two run-time divisions per element: 7 us of the kernel for 98 KB), all loads of an operand in flight at once
+constexpr int XS_SU = XS_HD_STAGED / 4 / 64;       // chunks per lane and row
+__device__ __forceinline__ void xs_stage_rows(int T, int hd, const float* __restrict__ X, size_t ldx, float4 (&v)[4][XS_SU]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = hd >> 2;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-            vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vy[u] = vx[u];
-            if (r < T) {          // r < T <= 32 also bounds x
-                vx[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx)[c];
-                vy[u] = reinterpret_cast<const float4*>(Y + (size_t)r * ldy)[c];
-            }
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int r = wave + 8 * k;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-            if (x < total) {
-                const bf16x4 hx = {(bf16_t)vx[u].x, (bf16_t)vx[u].y, (bf16_t)vx[u].z, (bf16_t)vx[u].w};
-                const bf16x4 hy = {(bf16_t)vy[u].x, (bf16_t)vy[u].y, (bf16_t)vy[u].z, (bf16_t)vy[u].w};
-                *reinterpret_cast<bf16x4*>(imX + r * pf + 4 * c) = hx;
-                *reinterpret_cast<bf16x4*>(imY + r * pf + 4 * c) = hy;
-            }
+        for (int u = 0; u < XS_SU; ++u) {
+            const int c = lane + 64 * u;
+            v[k][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < T && c < n4) v[k][u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx)[c];
         }
     }
+}
+__device__ __forceinline__ void xs_store_rows(int hd, const float4 (&v)[4][XS_SU], bf16_t* im, int pf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = hd >> 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < XS_SU; ++u) {
+            const int c = lane + 64 * u;
+            if (c < n4) {
+                const bf16x4 hx = {(bf16_t)v[k][u].x, (bf16_t)v[k][u].y, (bf16_t)v[k][u].z, (bf16_t)v[k][u].w};
+                *reinterpret_cast<bf16x4*>(im + (wave + 8 * k) * pf + 4 * c) = hx;
+            }
+        }
+}
+__device__ __forceinline__ void xs_stage_pair(int T, int hd, const float* __restrict__ X, size_t ldx, const float* __restrict__ Y, size_t ldy,
+                                              bf16_t* imX, bf16_t* imY, int pf) {
+    float4 vx[4][XS_SU], vy[4][XS_SU];
+    xs_stage_rows(T, hd, X, ldx, vx);
+    xs_stage_rows(T, hd, Y, ldy, vy);
+    xs_store_rows(hd, vx, imX, pf);
+    xs_store_rows(hd, vy, imY, pf);
+}
+__device__ __forceinline__ void xs_stage_one(int T, int hd, const float* __restrict__ X, size_t ldx, bf16_t* imX, int pf) {
+    float4 vx[4][XS_SU];
+    xs_stage_rows(T, hd, X, ldx, vx);
+    xs_store_rows(hd, vx, imX, pf);
 }
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
     acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc);
@@ -788,25 +803,27 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc)
 __device__ __forceinline__ void axpy4(float w, const float4 x, float4& acc) {
     acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y); acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
 }
-// single-operand form of the above
-__device__ __forceinline__ void xs_stage_one(int T, int hd, const float* __restrict__ X, size_t ldx, bf16_t* imX, int pf) {
-    const int n4 = hd >> 2, total = XS_T * n4;
-    for (int base = 0; base < total; base += 512 * 8) {
-        float4 vx[8];
+// bf16 image img[r][e] (pitch XS_PC) of rows r < 32 of X, columns e0 .. e0 + ec (rows beyond T: zero), in two steps so that a
+// chunk's loads can be in flight while something else runs: wave w owns rows w, w + 8, w + 16, w + 24, lane = 16-byte chunk
+constexpr int XS_NPRE = XS_T / 8;
+static_assert(XS_EC / 4 <= 64, "one lane per 16-byte chunk of a staged row");
+struct XsPre { float4 v[XS_NPRE]; };
+__device__ __forceinline__ void xs_stage_load(int T, int e0, int ec, const float* __restrict__ X, size_t ldx, XsPre& p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-            vx[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < T) vx[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx)[c];
-        }
+    for (int u = 0; u < XS_NPRE; ++u) {
+        const int r = wave + 8 * u;
+        p.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < T && 4 * lane < ec) p.v[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx + e0)[lane];
+    }
+}
+__device__ __forceinline__ void xs_stage_store(int ec, const XsPre& p, bf16_t* img) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (4 * lane >= ec) return;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x = base + threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-            if (x < total) {
-                const bf16x4 hx = {(bf16_t)vx[u].x, (bf16_t)vx[u].y, (bf16_t)vx[u].z, (bf16_t)vx[u].w};
-                *reinterpret_cast<bf16x4*>(imX + r * pf + 4 * c) = hx;
-            }
-        }
+    for (int u = 0; u < XS_NPRE; ++u) {
+        const bf16x4 hv = {(bf16_t)p.v[u].x, (bf16_t)p.v[u].y, (bf16_t)p.v[u].z, (bf16_t)p.v[u].w};
+        *reinterpret_cast<bf16x4*>(img + (wave + 8 * u) * XS_PC + 4 * lane) = hv;
     }
 }
 // ---- operands that are themselves a C-column product (C <= 16): the projected queries Q = Y W_Q^T + b_q and the context
@@ -818,57 +835,92 @@ struct XsGen {
     const float *dd, *WO;          // backward: ddelta (B*T, C), WO (C, d)
     int C;                         // 0: Q / dO are read from memory
 };
-// tile[r][k] = src[(row0 + r) * C + k], r < T (zero beyond)
-__device__ __forceinline__ void xs_gen_tile(int T, int C, const float* __restrict__ src, float* tile) {
-    for (int x = threadIdx.x; x < XS_T * C; x += 512) tile[x] = x < T * C ? src[x] : 0.f;
-}
 // img[r][icol0 + e] (pitch) for e < ec, r < 32:  WROWS: bias[ecol0 + e] + sum_k tile[r][k] W[(ecol0 + e) * C + k];
-// else sum_k tile[r][k] W[k * ldw + ecol0 + e]
+// else sum_k tile[r][k] W[k * ldw + ecol0 + e].  A lane owns one 4-column chunk (its W values live in registers), the waves
+// that share a 64-chunk column group split the 32 rows between them (ec <= 768: 1, 2 or 3 groups -> 8, 4 or 2 waves each).
+// In two steps, so that W's loads are issued together with every other operand's (a first version went through three
+// dependent global round trips -- input tile, staged operand, W: 9 of the forward's 13 us).
+template <int C4> struct XsGenRegs { float4 w[4 * C4]; float4 bv; int c, r0, nrow; bool on; };
 template <int C4, bool WROWS>
-__device__ __forceinline__ void xs_generate_c(const float* tile, const float* __restrict__ W, size_t ldw, const float* __restrict__ bias,
-                                              int ecol0, int ec, bf16_t* img, int pitch, int icol0) {
+__device__ __forceinline__ void xs_gen_load(const float* __restrict__ W, size_t ldw, const float* __restrict__ bias, int ecol0, int ec,
+                                            XsGenRegs<C4>& g) {
     constexpr int C = 4 * C4;
-    const int n4 = ec >> 2;
-    for (int x = threadIdx.x; x < n4 * 8; x += 512) {
-        const int c = x % n4, rg = x / n4, e = ecol0 + 4 * c;
-        float4 w[C];          // WROWS: w[j * C4 + k4] = W[e + j][4 k4 ..]; else w[k] = W[k][e ..]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n4 = ec >> 2, ncw = (n4 + 63) >> 6;
+    const int sh = ncw == 1 ? 3 : ncw == 2 ? 2 : 1;         // log2 of the waves per column group
+    const int cw = wave >> sh;
+    g.c = cw * 64 + lane;
+    g.nrow = XS_T >> sh;
+    g.r0 = (wave & ((1 << sh) - 1)) * g.nrow;
+    g.on = cw < ncw && g.c < n4;
+    const int e = ecol0 + 4 * (g.on ? g.c : 0);
 #pragma unroll
-        for (int q = 0; q < C; ++q)
-            w[q] = WROWS ? reinterpret_cast<const float4*>(W + (size_t)(e + q / C4) * C)[q % C4] : *reinterpret_cast<const float4*>(W + (size_t)q * ldw + e);
-        const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < C; ++q)          // WROWS: w[j * C4 + k4] = W[e + j][4 k4 ..]; else w[k] = W[k][e ..]
+        g.w[q] = WROWS ? reinterpret_cast<const float4*>(W + (size_t)(e + q / C4) * C)[q % C4] : *reinterpret_cast<const float4*>(W + (size_t)q * ldw + e);
+    g.bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) g.bv = *reinterpret_cast<const float4*>(bias + e);
+}
+template <int C4, bool WROWS>
+__device__ __forceinline__ void xs_gen_compute(const XsGenRegs<C4>& g, const float* tile, bf16_t* img, int pitch, int icol0) {
+    constexpr int C = 4 * C4;
+    if (!g.on) return;
+#pragma unroll 4
+    for (int r = g.r0; r < g.r0 + g.nrow; ++r) {
+        float4 y[C4];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = rg * 4 + rr;
-            float4 y[C4];
+        for (int k4 = 0; k4 < C4; ++k4) y[k4] = *reinterpret_cast<const float4*>(tile + r * C + 4 * k4);
+        float4 o = g.bv;
+        if (WROWS) {
 #pragma unroll
-            for (int k4 = 0; k4 < C4; ++k4) y[k4] = *reinterpret_cast<const float4*>(tile + r * C + 4 * k4);
-            float4 o = bv;
-            if (WROWS) {
-#pragma unroll
-                for (int k4 = 0; k4 < C4; ++k4) {
-                    o.x = dot4(y[k4], w[0 * C4 + k4], o.x); o.y = dot4(y[k4], w[1 * C4 + k4], o.y);
-                    o.z = dot4(y[k4], w[2 * C4 + k4], o.z); o.w = dot4(y[k4], w[3 * C4 + k4], o.w);
-                }
-            } else {
-#pragma unroll
-                for (int k4 = 0; k4 < C4; ++k4) {
-                    axpy4(y[k4].x, w[4 * k4], o); axpy4(y[k4].y, w[4 * k4 + 1], o); axpy4(y[k4].z, w[4 * k4 + 2], o); axpy4(y[k4].w, w[4 * k4 + 3], o);
-                }
+            for (int k4 = 0; k4 < C4; ++k4) {
+                o.x = dot4(y[k4], g.w[0 * C4 + k4], o.x); o.y = dot4(y[k4], g.w[1 * C4 + k4], o.y);
+                o.z = dot4(y[k4], g.w[2 * C4 + k4], o.z); o.w = dot4(y[k4], g.w[3 * C4 + k4], o.w);
             }
-            const bf16x4 hv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
-            *reinterpret_cast<bf16x4*>(img + r * pitch + icol0 + 4 * c) = hv;
+        } else {
+#pragma unroll
+            for (int k4 = 0; k4 < C4; ++k4) {
+                axpy4(y[k4].x, g.w[4 * k4], o); axpy4(y[k4].y, g.w[4 * k4 + 1], o); axpy4(y[k4].z, g.w[4 * k4 + 2], o);
+                axpy4(y[k4].w, g.w[4 * k4 + 3], o);
+            }
         }
+        const bf16x4 hv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+        *reinterpret_cast<bf16x4*>(img + r * pitch + icol0 + 4 * g.c) = hv;
     }
 }
-template <bool WROWS>
-__device__ __forceinline__ void xs_generate(int C, const float* tile, const float* __restrict__ W, size_t ldw, const float* __restrict__ bias,
-                                            int ecol0, int ec, bf16_t* img, int pitch, int icol0) {
-    switch (C >> 2) {
-    case 1: xs_generate_c<1, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
-    case 2: xs_generate_c<2, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
-    case 3: xs_generate_c<3, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
-    default: xs_generate_c<4, WROWS>(tile, W, ldw, bias, ecol0, ec, img, pitch, icol0); break;
-    }
+// the forward's operand stage with a generated Q: every global load is issued before the first use (one round trip)
+template <int C4>
+__device__ __forceinline__ void xs_fwd_stage_gen(int T, int hd, int b, int hcol0, const XsGen& gn, const float* __restrict__ Krows, size_t ldk,
+                                                 const XsPre& pre, int ec, float* ytile, bf16_t* imX, bf16_t* imY, int pf, bf16_t* img) {
+    const int C = 4 * C4, x = threadIdx.x;
+    const float yv = x < T * C ? gn.Y[(size_t)b * T * C + x] : 0.f;          // 32 * C <= 512 threads
+    float4 vk[4][XS_SU];
+    xs_stage_rows(T, hd, Krows, ldk, vk);
+    XsGenRegs<C4> gq;
+    xs_gen_load<C4, true>(gn.WQ, 0, gn.bq, hcol0, hd, gq);
+    if (x < XS_T * C) ytile[x] = yv;
+    xs_store_rows(hd, vk, imY, pf);
+    xs_stage_store(ec, pre, img);
+    __syncthreads();
+    xs_gen_compute<C4, true>(gq, ytile, imX, pf, 0);
+}
+// the backward's: dO (whole) and Q's chunk generated, V staged, K's chunk from its prefetch registers
+template <int C4>
+__device__ __forceinline__ void xs_bwd_stage_gen(int T, int hd, int b, int hcol0, int e0, int ec, const XsGen& gn, size_t ldo,
+                                                 const float* __restrict__ Vrows, size_t ldk, const XsPre& pK, float* ytile, float* dtile,
+                                                 bf16_t* imG, bf16_t* imV, int pf, bf16_t* imK, bf16_t* imQ) {
+    const int C = 4 * C4, x = threadIdx.x;
+    const float yv = x < T * C ? gn.Y[(size_t)b * T * C + x] : 0.f;
+    const float dv = x < T * C ? gn.dd[(size_t)b * T * C + x] : 0.f;
+    float4 vv[4][XS_SU];
+    xs_stage_rows(T, hd, Vrows, ldk, vv);
+    XsGenRegs<C4> go, gq;
+    xs_gen_load<C4, false>(gn.WO, ldo, nullptr, hcol0, hd, go);
+    xs_gen_load<C4, true>(gn.WQ, 0, gn.bq, hcol0 + e0, ec, gq);
+    if (x < XS_T * C) { ytile[x] = yv; dtile[x] = dv; }
+    xs_store_rows(hd, vv, imV, pf);
+    xs_stage_store(ec, pK, imK);
+    __syncthreads();
+    xs_gen_compute<C4, false>(go, dtile, imG, pf, 0);
+    xs_gen_compute<C4, true>(gq, ytile, imQ, XS_PC, 0);
 }
 __device__ __forceinline__ void xs_scores_lds(int hd, const bf16_t* imX, const bf16_t* imY, int pf, float alpha, float* Sf, float* Sf2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4, mt = (wave & 3) >> 1, nt = wave & 1;
@@ -881,30 +933,6 @@ __device__ __forceinline__ void xs_scores_lds(int hd, const bf16_t* imX, const b
     float* out = half ? Sf2 : Sf;
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(mt * 16 + fq * 4 + r) * XS_PS + nt * 16 + fr] = alpha * acc[r];
-}
-// bf16 image img[r][e] (pitch XS_PC) of rows r < 32 of X, columns e0 .. e0 + ec (rows beyond T: zero), in two steps so that a
-// chunk's loads can be in flight while the previous chunk is being used: 512 threads x XS_NPRE float4 = 32 rows x 256 columns
-constexpr int XS_NPRE = XS_T * XS_EC / 4 / 512;
-struct XsPre { float4 v[XS_NPRE]; };
-__device__ __forceinline__ void xs_stage_load(int T, int e0, int ec, const float* __restrict__ X, size_t ldx, XsPre& p) {
-    const int n4 = ec >> 2;
-#pragma unroll
-    for (int u = 0; u < XS_NPRE; ++u) {
-        const int x = threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-        p.v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < T) p.v[u] = reinterpret_cast<const float4*>(X + (size_t)r * ldx + e0)[c];      // r < T <= 32 also bounds x
-    }
-}
-__device__ __forceinline__ void xs_stage_store(int ec, const XsPre& p, bf16_t* img) {
-    const int n4 = ec >> 2;
-#pragma unroll
-    for (int u = 0; u < XS_NPRE; ++u) {
-        const int x = threadIdx.x + u * 512, r = x / n4, c = x - r * n4;
-        if (r < XS_T) {
-            const bf16x4 hv = {(bf16_t)p.v[u].x, (bf16_t)p.v[u].y, (bf16_t)p.v[u].z, (bf16_t)p.v[u].w};
-            *reinterpret_cast<bf16x4*>(img + r * XS_PC + 4 * c) = hv;
-        }
-    }
 }
 // Z[m][e0 + n] = sum_k W(m, k) img[k][n] for the staged chunk: 2 x ec/16 tiles dealt to the eight waves.  WT: W is read through
 // the hardware transpose (W(m, k) = tile[k][m]) instead of row-major (tile[m][k]).  Rows m >= T are not written.
@@ -967,14 +995,16 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
     xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, pre);        // V's chunk travels beside the score operands
     if (xs_staged(dm.hd)) {
         if (gn.C) {       // Q is formed here from the C-column input (host: only with the staged path)
-            xs_gen_tile(T, gn.C, gn.Y + (size_t)b * T * gn.C, ytile);
-            xs_stage_one(T, dm.hd, KV + k0, ldk, imY, pf);
-            __syncthreads();
-            xs_generate<true>(gn.C, ytile, gn.WQ, 0, gn.bq, h * dm.hd, dm.hd, imX, pf, 0);
+            switch (gn.C >> 2) {
+            case 1: xs_fwd_stage_gen<1>(T, dm.hd, b, h * dm.hd, gn, KV + k0, ldk, pre, ec, ytile, imX, imY, pf, img); break;
+            case 2: xs_fwd_stage_gen<2>(T, dm.hd, b, h * dm.hd, gn, KV + k0, ldk, pre, ec, ytile, imX, imY, pf, img); break;
+            case 3: xs_fwd_stage_gen<3>(T, dm.hd, b, h * dm.hd, gn, KV + k0, ldk, pre, ec, ytile, imX, imY, pf, img); break;
+            default: xs_fwd_stage_gen<4>(T, dm.hd, b, h * dm.hd, gn, KV + k0, ldk, pre, ec, ytile, imX, imY, pf, img); break;
+            }
         } else {
             xs_stage_pair(T, dm.hd, Q + q0, dm.d, KV + k0, ldk, imX, imY, pf);
+            xs_stage_store(ec, pre, img);
         }
-        xs_stage_store(ec, pre, img);
         __syncthreads();
         xs_scores_lds(dm.hd, imX, imY, pf, scale, Sf, Sf2);
     } else {
@@ -1056,13 +1086,12 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     XsPre pK, pG, pQ;
     xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's images travel beside dA's operands
     if (staged && gn.C) {      // dO and Q's chunk are formed here from their C-column inputs (host: only with the staged path)
-        xs_gen_tile(T, gn.C, gn.Y + (size_t)b * T * gn.C, ytile);
-        xs_gen_tile(T, gn.C, gn.dd + (size_t)b * T * gn.C, dtile);
-        xs_stage_one(T, dm.hd, KV + k0 + dm.d, ldk, imV, pf);
-        xs_stage_store(ec, pK, imK);
-        __syncthreads();
-        xs_generate<false>(gn.C, dtile, gn.WO, dm.d, nullptr, h * dm.hd, dm.hd, imG, pf, 0);
-        xs_generate<true>(gn.C, ytile, gn.WQ, 0, gn.bq, h * dm.hd + e0, ec, imQ, XS_PC, 0);
+        switch (gn.C >> 2) {
+        case 1: xs_bwd_stage_gen<1>(T, dm.hd, b, h * dm.hd, e0, ec, gn, dm.d, KV + k0 + dm.d, ldk, pK, ytile, dtile, imG, imV, pf, imK, imQ); break;
+        case 2: xs_bwd_stage_gen<2>(T, dm.hd, b, h * dm.hd, e0, ec, gn, dm.d, KV + k0 + dm.d, ldk, pK, ytile, dtile, imG, imV, pf, imK, imQ); break;
+        case 3: xs_bwd_stage_gen<3>(T, dm.hd, b, h * dm.hd, e0, ec, gn, dm.d, KV + k0 + dm.d, ldk, pK, ytile, dtile, imG, imV, pf, imK, imQ); break;
+        default: xs_bwd_stage_gen<4>(T, dm.hd, b, h * dm.hd, e0, ec, gn, dm.d, KV + k0 + dm.d, ldk, pK, ytile, dtile, imG, imV, pf, imK, imQ); break;
+        }
         __syncthreads();
         xs_scores_lds(dm.hd, imG, imV, pf, 1.f, Sf, Sf2);                            // dA = dO V^T
     } else if (staged) {

@@ -199,13 +199,25 @@ __global__ __launch_bounds__(1024) void time2vec_bwd_small_kernel(const float* _
     float aw = 0.f, ab = 0.f;
     if (j < d_tau) {
         const float wj = j ? w[j - 1] : 0.f, bj = j ? b[j - 1] : 0.f;
-#pragma unroll 4
-        for (int r = ty; r < rows; r += RT) {
-            const float t = tau[r];
-            float g = dfeat[(size_t)r * ld + j];
-            if (j) g *= cosf(fmaf(wj, t, bj));
-            aw = fmaf(g, t, aw);
-            ab += g;
+        // 16 rows of loads in flight per thread: one workgroup does all the work, and at 4 the 2048 rows of the benchmark were eight
+        // dependent global round trips (10 of the kernel's 15 us)
+        constexpr int U = 16;
+        for (int r0 = ty; r0 < rows; r0 += RT * U) {
+            float tt[U], gg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * RT;
+                tt[u] = 0.f;
+                gg[u] = 0.f;
+                if (r < rows) { tt[u] = tau[r]; gg[u] = dfeat[(size_t)r * ld + j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float g = gg[u];
+                if (j) g *= cosf(fmaf(wj, tt[u], bj));
+                aw = fmaf(g, tt[u], aw);
+                ab += g;
+            }
         }
     }
     for (int o = 32; o >= CT; o >>= 1) {

@@ -43,16 +43,20 @@ class MMF_XAttn_Add(nn.Module):
                 self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.residual_head.weight,
                 self.residual_head.bias, self.layer_norm.weight, self.layer_norm.bias)
 
-    def project_kv(self, E_txt):
+    def fold_weights(self):
+        """the query half's product weights (parameters only: any stream, any time before forward())"""
+        return mmf_xattn_q_fold(self.C, self.d_attn, self.n_heads, resolve_precision(self), self._params())
+
+    def project_kv(self, E_txt, with_fold=True):
         """key/value half (proj_k / proj_v + their MHA in-projections -> one (B,T,2d) tensor k | v): depends only on the text
         side, so a caller can run it on the text stream while the backbone is still producing Y_ts
         (lib.evaluation.forecast_and_fuse)"""
         KV = MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
                                 getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
                                 self.attn.in_proj_weight, self.attn.in_proj_bias)
-        # the query half's product weights depend on parameters only: form them here too, beside the backbone
-        fold = mmf_xattn_q_fold(self.C, self.d_attn, self.n_heads, resolve_precision(self), self._params())
-        return KV, fold
+        # the query half's product weights depend on parameters only: form them here too, beside the backbone (with_fold=False:
+        # the caller forms them elsewhere with fold_weights() and passes kv=(KV, fold) to forward())
+        return KV, (self.fold_weights() if with_fold else None)
 
     def forward(self, Y_ts, E_txt, M_txt, kv=None):
         """Y_ts (B,T,C), E_txt (B,T,d_txt), M_txt (B,1)|(B,) bool -> (B,T,C).  kv: the result of project_kv(E_txt)

@@ -4,6 +4,8 @@
 (immtsf.ops.masked_mse: per-variable sums -> optional all-reduce -> loss and d(pred) in one more kernel); every
 other combination is evaluated with plain torch ops (metrics only, off the hot path).
 """
+import os
+
 import torch
 
 from immtsf import config
@@ -42,6 +44,12 @@ def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None)
     raise Exception("Reduce argument not specified!")
 
 
+# MMF_XAttn_Add's folded query-half weights depend on parameters only.  Formed in front of the backbone on ITS stream instead of
+# behind the key/value projection on the text stream the cfg2 step got slower (0.793 vs 0.783 ms, 3 runs each): in the forward
+# the backbone is the longer chain.  Off unless asked for.
+_FOLD_ON_SIDE = os.environ.get("IMMTSF_FOLD_ON_SIDE", "0") == "1"
+
+
 def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
     """backbone forecast -> fusion.  The backbone and the text-timestamp fusion (TTF) do not depend on each other
     -- only the modality fusion (MMF) needs both -- so with `side_stream` the backbone is enqueued on that HIP stream
@@ -60,8 +68,16 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
     # backward instead of behind them (r02 trace: placed last it started 200 us after its input was ready).  Re-measured after
     # the launch cuts of r02 (backbone first / text first): 0.908 / 0.906 ms per step -- no difference any more.
     E_txt, M_txt = fusion.ttf(notes, tau, tp)
-    kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
+    fold_side = _FOLD_ON_SIDE and hasattr(fusion.mmf, "fold_weights")
+    if fold_side:
+        kv = fusion.mmf.project_kv(E_txt, with_fold=False)
+    else:
+        kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
     with torch.cuda.stream(side_stream):
+        if fold_side:      # parameters only: in front of the backbone on its stream
+            fold = fusion.mmf.fold_weights()
+            fold.record_stream(main)
+            kv = (kv[0], fold)
         pred_y = model.forecasting(*fc_args)
     main.wait_stream(side_stream)
     pred_y.record_stream(main)

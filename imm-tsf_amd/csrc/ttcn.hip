@@ -206,6 +206,25 @@ bool bad_dims(int P, int L, int te_dim, int K) { return P < 0 || L <= 0 || te_di
 
 }  // namespace
 
+// The patch encoder wants (B*N*M, L) rows; the batch holds (B, M, L, N) tensors (values, time stamps, mask).  One launch for the
+// three of them (as three permute + contiguous copies they are three stock element-wise launches in front of the backbone).
+namespace {
+__global__ __launch_bounds__(256) void patch_flatten3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              const float* __restrict__ c, int B, int M, int L, int N,
+                                                              float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc) {
+    const size_t total = (size_t)B * M * L * N, o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total) return;
+    const int l = (int)(o % L);                     // o = ((b*N + n)*M + m)*L + l
+    size_t r = o / L;
+    const int m = (int)(r % M); r /= M;
+    const int n = (int)(r % N);
+    const size_t bb = r / N, i = ((bb * M + m) * L + l) * N + n;
+    oa[o] = a[i];
+    ob[o] = b[i];
+    oc[o] = c[i];
+}
+}  // namespace
+
 extern "C" {
 
 size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim) {
@@ -213,6 +232,17 @@ size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t
 }
 size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim) {
     return bad_dims(P, L, te_dim, ttcn_dim) ? 0 : carve_sc(mk_dims(P, L, te_dim, ttcn_dim), nullptr).bytes;
+}
+
+int immtsf_patch_flatten3(const float* x, const float* tt, const float* mask, int32_t B, int32_t M, int32_t L, int32_t N, float* ox,
+                          float* ott, float* omask, immtsf_stream_t stream) {
+    if (!x || !tt || !mask || !ox || !ott || !omask || B < 0 || M <= 0 || L <= 0 || N <= 0) return IMMTSF_EINVAL;
+    const size_t total = (size_t)B * M * L * N;
+    if (total == 0) return IMMTSF_OK;
+    hipLaunchKernelGGL(patch_flatten3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x, tt, mask,
+                       B, M, L, N, ox, ott, omask);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
 }
 
 int immtsf_ttcn_forward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim, int32_t precision, const float* x,

@@ -187,6 +187,7 @@ _PROTOS = {
     "immtsf_bf16_twin_register": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t]),
     "immtsf_bf16_twin_unregister": (C.c_int, [c_f32p]),
     "immtsf_bf16_twin_enable": (C.c_int, [C.c_int32]),
+    "immtsf_patch_flatten3": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_f32_to_bf16": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_bf16_to_f32": (C.c_int, [C.c_void_p, c_f32p, C.c_size_t, c_stream]),
     "immtsf_gemm_batched": (C.c_int, [C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int64, C.c_int64, c_f32p, C.c_int32,

@@ -539,6 +539,19 @@ def ttcn_patch_encode(x, tt, mask, te_scale_w, te_scale_b, te_per_w, te_per_b, W
                                    te_scale_w, te_scale_b, te_per_w, te_per_b, W1, b1, W2, b2, W3, b3, T_bias)
 
 
+def patch_flatten3(X, tt, mask):
+    """X, tt, mask (B, M, L, N) data tensors (no gradient) -> three (B*N*M, L) tensors, the patch rows of tPatchGNN's encoder
+    (models/tPatchGNN.py:271-275), in one launch instead of three permute copies."""
+    lib = _lib.load()
+    X, tt, mask = _c(X.float()), _c(tt.float()), _c(mask.float())
+    _need_gpu(X, tt, mask)
+    B, M, L, N = X.shape
+    out = torch.empty(3, B * N * M, L, dtype=torch.float32, device=X.device)
+    check(lib.immtsf_patch_flatten3(ptr(X), ptr(tt), ptr(mask), B, M, L, N, ptr(out[0]), ptr(out[1]), ptr(out[2]), stream_ptr()),
+          "patch_flatten3")
+    return out[0], out[1], out[2]
+
+
 class GCNAdaptiveFn(torch.autograd.Function):
     """tPatchGNN's adaptive-graph stage on (B,N,M,D): one workgroup per (window, patch) cell, params in
     immtsf_gcn_params order.  Backward recomputes the cell in LDS; parameter gradients accumulate by atomics into one

@@ -214,8 +214,14 @@ class tPatchGNN(nn.Module):
         """time_steps_to_predict (B,Lp); X, truth_time_steps, mask (B,M,L,N) -> (B,Lp,N)"""
         B, M, L, N = X.shape
         self.batch_size = B
-        flat = lambda t: t.permute(0, 3, 1, 2).reshape(B * N * M, L)    # noqa: E731
-        x_patch = self._encode_patches(flat(X), flat(truth_time_steps), flat(mask)).view(B, N, M, -1)
+        if X.is_cuda and not (X.requires_grad or truth_time_steps.requires_grad) and mask is not None and mask.shape == X.shape \
+                and truth_time_steps.shape == X.shape:
+            from immtsf.ops import patch_flatten3
+            fx, ft, fm = patch_flatten3(X, truth_time_steps, mask)          # one launch for the three (B,M,L,N) -> (B*N*M, L) copies
+        else:
+            flat = lambda t: t.permute(0, 3, 1, 2).reshape(B * N * M, L)    # noqa: E731
+            fx, ft, fm = flat(X), flat(truth_time_steps), flat(mask)
+        x_patch = self._encode_patches(fx, ft, fm).view(B, N, M, -1)
         h = self.IMTS_Model(x_patch)                                     # (B,N,hid)
         Lp = time_steps_to_predict.shape[-1]
         # the reference repeats the prediction times over the N variables before embedding them (:283-285); the

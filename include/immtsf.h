@@ -226,6 +226,11 @@ typedef struct immtsf_ttcn_params {
 
 size_t immtsf_ttcn_workspace_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
 size_t immtsf_ttcn_scratch_bytes(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim);
+/* (B, M, L, N) batch tensors (values, time stamps, observation mask) -> the (B*N*M, L) patch rows of
+ * models/tPatchGNN.py:271-275 (three permute(0, 3, 1, 2).reshape copies there), in one launch. */
+int immtsf_patch_flatten3(const float* x, const float* tt, const float* mask, int32_t B, int32_t M, int32_t L, int32_t N, float* ox,
+                          float* ott, float* omask, immtsf_stream_t stream);
+
 /* bf16 mode with L <= 64, te_dim <= 15, ttcn_dim <= 32: the whole encoder of a patch runs on one CU (time embedding,
  * three filter-generator layers and the filter logits as MFMAs on LDS tiles, masked softmax and pooling in the
  * accumulator registers), one kernel per direction; the backward recomputes the forward on chip.  Otherwise the three

@@ -254,3 +254,18 @@ def test_fused_decoder_unsupported_shapes_fall_back():
     assert not tpatch_decoder_supported(mk(L(42, 64), R(), L(64, 64), R(), L(64, 1)), 8, 32, 32, 10)      # H != 32
     assert not tpatch_decoder_supported(mk(L(42, 32), R(), L(32, 1)), 8, 32, 32, 10)                      # other depth
     assert not tpatch_decoder_supported(mk(L(42, 32), R(), L(32, 32), R(), L(32, 1)), 2000, 2000, 32, 10)  # LDS
+
+
+@pytest.mark.parametrize("shape", [(64, 2, 32, 8), (3, 5, 7, 11), (1, 1, 1, 1)])
+def test_patch_flatten3_equals_three_permute_copies(shape):
+    """immtsf_patch_flatten3: (B, M, L, N) values / time stamps / mask -> the encoder's (B*N*M, L) patch rows, bit-exact with
+    the reference's permute(0, 3, 1, 2).reshape (models/tPatchGNN.py:271-275)"""
+    dev = _dev()
+    from immtsf.ops import patch_flatten3
+    B, M, L, N = shape
+    g = torch.Generator().manual_seed(5)
+    x, tt = torch.randn(B, M, L, N, generator=g).to(dev), torch.rand(B, M, L, N, generator=g).to(dev)
+    mk = (torch.rand(B, M, L, N, generator=g) < 0.5).float().to(dev)
+    fx, ft, fm = patch_flatten3(x, tt, mk)
+    for got, src in ((fx, x), (ft, tt), (fm, mk)):
+        assert torch.equal(got, src.permute(0, 3, 1, 2).reshape(B * N * M, L))

@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
                                                                   const float* __restrict__ KVp, const float* __restrict__ P,
                                                                   const float* __restrict__ dctx, float* __restrict__ dKVp,
                                                                   float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
-                                                                  bf16_t* __restrict__ dKVp_h, int maxch) {
+                                                                  bf16_t* __restrict__ dKVp_h, int maxch, size_t dp_stride) {
     // maxch > 1: grid.x = B * maxch, workgroup (b, ch) takes notes [ch * RAGGED_CH, +RAGGED_CH) of window b
+    // dp_stride != 0: every 64-column slice writes its partial dp into its own slab (slab z at dp_buf + z * dp_stride; exactly one
+    // writer per note and slice, part 2 adds the slabs): no zero-fill in front of this kernel and no atomics
     const int b = blockIdx.x / maxch, ch = blockIdx.x % maxch;
     const int h = blockIdx.y, c = blockIdx.z * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -272,7 +274,10 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
             if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
         }
         a = wave_sum(a);
-        if (lane == 0) atomicAdd(dp_buf + (size_t)(o0 + i) * dm.H + h, a);
+        if (lane == 0) {
+            if (dp_stride) dp_buf[(size_t)blockIdx.z * dp_stride + (size_t)(o0 + i) * dm.H + h] = a;
+            else atomicAdd(dp_buf + (size_t)(o0 + i) * dm.H + h, a);
+        }
     }
 }
 
@@ -380,7 +385,8 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
                                                                   const float* __restrict__ KVp, const float* __restrict__ qs,
                                                                   const float* __restrict__ P, const float* __restrict__ dp_buf,
                                                                   float* __restrict__ dKVp, float* __restrict__ dqs_part,
-                                                                  bf16_t* __restrict__ dKVp_h, int maxch) {
+                                                                  bf16_t* __restrict__ dKVp_h, int maxch, int dp_slabs, size_t dp_stride) {
+    // dp_slabs > 1: dp arrives as that many partial slabs (see part 1)
     // maxch > 1: grid.x = B * maxch; workgroup (b, ch) recomputes the window's sum_j p_j dp_j (n values), owns the chunk's
     // ds / dk rows and adds its share of dqs_part (zero-filled by the launcher) with one atomic per column
     extern __shared__ float lds[];
@@ -401,7 +407,9 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     const int o0 = ob + i_lo, n = maxch > 1 ? min(RAGGED_CH, nfull - i_lo) : nfull;
     float part = 0.f;
     for (int i = tid; i < nfull; i += 256) {
-        const float p = P[(size_t)(ob + i) * dm.H + h], g = dp_buf[(size_t)(ob + i) * dm.H + h];
+        const float p = P[(size_t)(ob + i) * dm.H + h];
+        float g = dp_buf[(size_t)(ob + i) * dm.H + h];
+        for (int z = 1; z < dp_slabs; ++z) g += dp_buf[(size_t)z * dp_stride + (size_t)(ob + i) * dm.H + h];
         if (i >= i_lo && i < i_lo + n) ds[i - i_lo] = g;
         part = fmaf(p, g, part);
     }
@@ -1145,6 +1153,9 @@ inline size_t xs_bwd_lds(int hd) {
 
 }  // namespace
 
+size_t ragged_attn_dp_floats(int B, int N, int H, int hd) {
+    return (size_t)B * N * H * (N > RAGGED_SPLIT_N ? 1 : cdiv(hd, 64));
+}
 size_t ragged_attn_part_floats(int B, int T, int d, int N) {
     return N > RAGGED_SPLIT_N ? (size_t)B * cdiv(N, RAGGED_CH) * T * d : 0;
 }
@@ -1185,10 +1196,12 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
     const int maxch = dm.N > RAGGED_SPLIT_N ? cdiv(dm.N, RAGGED_CH) : 1;
     const size_t lds = (size_t)((maxch > 1 ? RAGGED_CH : dm.N) + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    // short windows: dp as one slab per 64-column slice (dp_buf holds ragged_attn_dp_floats): no zero-fill, no atomics
+    const size_t dp_stride = maxch > 1 ? 0 : (size_t)dm.B * dm.N * dm.H;
+    const int dp_slabs = maxch > 1 ? 1 : cdiv(dm.hd, 64);
     if (maxch > 1) {
-        e = hipMemsetAsync(dqs_part, 0, (size_t)dm.B * dm.H * dm.hd * sizeof(float), s);
+        hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
+        if (e == hipSuccess) e = hipMemsetAsync(dqs_part, 0, (size_t)dm.B * dm.H * dm.hd * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
     }
     const size_t lds_long = ((drop.p > 0.f ? (size_t)(dm.T <= 32 ? 32 : ((dm.T + 3) & ~3)) * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
@@ -1206,11 +1219,11 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
                                dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
     } else {
         hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
-                           dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
+                           dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch, dp_stride);
     }
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P,
-                       dp_buf, dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h), maxch);
+                       dp_buf, dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h), maxch, dp_slabs, dp_stride);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -13,7 +13,8 @@ int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* row
                            float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h = nullptr,      // ctx_h: bf16 ctx (ctx may be null)
                            float* part = nullptr);    // chunk partial sums, ragged_attn_part_floats(B, T, H * hd, N) floats (0 for short windows)
 size_t ragged_attn_part_floats(int B, int T, int d, int N);
-// backward: dctx [B*T, d] -> dKVp [R, 2d] (dk | dv), dqs_part [B, d]; dp_buf: scratch of B*N*H floats
+// backward: dctx [B*T, d] -> dKVp [R, 2d] (dk | dv), dqs_part [B, d]; dp_buf: scratch of ragged_attn_dp_floats(B, N, H, hd) floats
+size_t ragged_attn_dp_floats(int B, int N, int H, int hd);
 int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
                            const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
                            uint64_t site, hipStream_t s, void* dKVp_h = nullptr);   // dKVp_h: bf16 copy (dKVp may be null)

@@ -87,7 +87,7 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dqs_part = k.take<float>(B * d);
     s.dqs = k.take<float>(d);
     s.dq = k.take<float>(d);
-    s.dp = k.take<float>(R * c->H);
+    s.dp = k.take<float>(ragged_attn_dp_floats(c->B, c->N, c->H, c->d / c->H));
     s.red = k.take<float>(64 * 3 * d + 64 * 8);
     s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));       // time2vec backward: ~256 packed rows per slab
     s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);

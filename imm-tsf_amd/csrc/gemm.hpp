@@ -59,6 +59,15 @@ struct GemmArgs {
     int xcd_remap;         // set by the launcher
     int xcd_gm;            // gemm2: > 0 = the 8 XCDs own an xcd_gm x (8 / xcd_gm) arrangement of equal rectangles of the tile grid
     int dbg;               // ablation flags (tools/gemm_bench.py), 0 in production
+    // gemm2: the tile-index arithmetic of the kernel's first instructions, precomputed by the launcher (g2_fast != 0): every
+    // workgroup used to open with ~8 run-time integer divisions (tile grid, XCD partition, K split), ~0.5 us before its first load.
+    // n / d for n, d < 65536 as __umulhi(n, ceil(2^32 / d)); magic 0 = divisor 1
+    int g2_fast;
+    int g2_tiles_n;
+    unsigned g2_tn_magic;  // lin / tiles_n
+    int g2_rows_x, g2_cols_x, g2_xc_shift;
+    unsigned g2_cx_magic;  // idx / cols_x
+    int g2_per;            // K steps per split (0: K is a device value, divide in the kernel)
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

@@ -74,8 +74,23 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
         const int dv = *g.dyn;
         if (g.dyn_which == 0) M = dv; else K = dv;
     }
-    const int tiles_n = (N + BN - 1) / BN;
     int lin = blockIdx.x, tile_m, tile_n;
+    if (g.g2_fast) {          // launcher-made reciprocals instead of run-time divisions (see GemmArgs)
+        if (g.xcd_remap && g.xcd_gm > 0) {
+            const int xcd = lin & 7, idx = lin >> 3;
+            const int qi = g.g2_cx_magic ? (int)__umulhi((unsigned)idx, g.g2_cx_magic) : idx;
+            tile_m = (xcd >> g.g2_xc_shift) * g.g2_rows_x + qi;
+            tile_n = (xcd & ((1 << g.g2_xc_shift) - 1)) * g.g2_cols_x + (idx - qi * g.g2_cols_x);
+        } else {
+            if (g.xcd_remap) {
+                const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
+                lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+            }
+            tile_m = g.g2_tn_magic ? (int)__umulhi((unsigned)lin, g.g2_tn_magic) : lin;
+            tile_n = lin - tile_m * g.g2_tiles_n;
+        }
+    } else {
+    const int tiles_n = (N + BN - 1) / BN;
     if (g.xcd_remap && g.xcd_gm > 0) {
         // Exact 2-D partition: workgroup i runs on XCD i % 8 (round-robin dispatch) and is that XCD's (i / 8)-th tile; the 8
         // XCDs own an XR x XC arrangement (XR = xcd_gm, XR * XC = 8) of equal rectangles of the tile grid, so an XCD's L2
@@ -93,6 +108,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
         tile_m = lin / tiles_n;
         tile_n = lin % tiles_n;
     }
+    }
     const int row0 = tile_m * BM, col0 = tile_n * BN;
     if (row0 >= M) return;
 
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
     // K range of this split, in 64-deep steps
     const int nk_total = (K + BK2 - 1) / BK2;
     const int splits = gridDim.y;
-    const int per = (nk_total + splits - 1) / splits;
+    const int per = (g.g2_fast && g.g2_per) ? g.g2_per : (nk_total + splits - 1) / splits;
     const int kt0 = blockIdx.y * per, kt1 = min(nk_total, kt0 + per);
     if (splits > 1 && kt0 >= kt1) return;
     const int kend = min(K, kt1 * BK2);
@@ -369,6 +385,19 @@ int launch2(int layout, const GemmArgs& g_in, int Mmax, int splits, hipStream_t 
             if (!best || cost < best_cost) { best = XR; best_cost = cost; }
         }
         g.xcd_gm = best;
+    }
+    {   // the kernel's tile-index arithmetic as shifts and multiplications (GemmArgs::g2_*)
+        const int tiles_m = cdiv(Mmax, BM), tiles_n = cdiv(g.N, BN);
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); };
+        g.g2_fast = grid.x < 65536 && tiles_n < 65536 && Mmax == g.M;
+        g.g2_tiles_n = tiles_n;
+        g.g2_tn_magic = magic(tiles_n);
+        const int XR = g.xcd_gm > 0 ? g.xcd_gm : 1, XC = 8 / XR;
+        g.g2_rows_x = tiles_m / XR;
+        g.g2_cols_x = tiles_n / XC;
+        g.g2_xc_shift = XC == 8 ? 3 : XC == 4 ? 2 : XC == 2 ? 1 : 0;
+        g.g2_cx_magic = magic(g.g2_cols_x);
+        g.g2_per = (g.dyn && g.dyn_which == 1) ? 0 : cdiv(cdiv(g.K, BK2), splits);
     }
     immtsf_gemm_note_grid((long)grid.x * grid.y * grid.z * block.x);
     switch (layout) {

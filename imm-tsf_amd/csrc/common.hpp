@@ -27,16 +27,44 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- wave / block reductions ----------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane steps without the LDS crossbar: __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipeline round trip per step and
+// an address register); inside a row of 16 lanes the DPP modifiers of the VALU add / max do the exchange for free, and
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange rows (swap(v, v) returns (v of the even rows | v of the odd rows)
+// replicated, so their sum / max is the value combined with lane ^ 16, resp. lane ^ 32).
+typedef unsigned immtsf_u2 __attribute__((ext_vector_type(2)));
+#define IMMTSF_DPP(v, ctrl) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes of a row, in every lane of the row
+    v += IMMTSF_DPP(v, 0xB1);      // quad_perm [1,0,3,2]
+    v += IMMTSF_DPP(v, 0x4E);      // quad_perm [2,3,0,1]
+    v += IMMTSF_DPP(v, 0x141);     // row_half_mirror
+    v += IMMTSF_DPP(v, 0x140);     // row_mirror
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, IMMTSF_DPP(v, 0xB1));
+    v = fmaxf(v, IMMTSF_DPP(v, 0x4E));
+    v = fmaxf(v, IMMTSF_DPP(v, 0x141));
+    v = fmaxf(v, IMMTSF_DPP(v, 0x140));
     return v;
 }
+__device__ __forceinline__ float xor16_sum(float v) {      // v + v[lane ^ 16]
+    const immtsf_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {      // v + v[lane ^ 32]
+    const immtsf_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    const immtsf_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    const immtsf_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+__device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 
 // Block-wide sum for blockDim.x <= 1024 (multiple of 64). `red` is >= 16 floats of LDS.
 // Every thread gets the result.  Contains two barriers.

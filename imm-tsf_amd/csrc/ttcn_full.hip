@@ -55,18 +55,9 @@ __device__ __forceinline__ bf16x8 load8_bf16(const float* __restrict__ src) {   
     r[4] = (bf16_t)b.x; r[5] = (bf16_t)b.y; r[6] = (bf16_t)b.z; r[7] = (bf16_t)b.w;
     return r;
 }
-__device__ __forceinline__ float col_sum(float v) {       // over the 4 lane groups that hold one column's rows
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-__device__ __forceinline__ float row_sum16(float v) {     // over the 16 lanes (columns) of a lane group
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ float col_sum(float v) { return xor32_sum(xor16_sum(v)); }      // over the 4 lane groups that hold one column's rows
+__device__ __forceinline__ float col_max(float v) { return xor32_max(xor16_max(v)); }
+__device__ __forceinline__ float row_sum16(float v) { return row16_sum(v); }                // over the 16 lanes (columns) of a lane group
 // A / B fragment from a row-major bf16 LDS tile: row = row0 + (lane & 15), k = k0 + (lane >> 4) * 8 ..
 __device__ __forceinline__ bf16x8 frag_row(const bf16_t* tile, int pitch, int row0, int k0, int fr, int fq) {
     return *reinterpret_cast<const bf16x8*>(tile + (row0 + fr) * pitch + k0 + fq * 8);
@@ -133,8 +124,7 @@ __device__ __forceinline__ void sm_tile(const FD& d, const bf16x8 (&a)[RT], cons
             m = fmaxf(m, v);
         }
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = col_max(m);
     float s = 0.f;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)

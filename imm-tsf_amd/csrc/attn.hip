@@ -964,12 +964,10 @@ __device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, 
     }
 }
 __device__ __forceinline__ float xs_sum8(float v) {       // over the 8 lanes that share a row
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-    return v;
+    return group_sum(v, 8);
 }
 __device__ __forceinline__ float xs_max8(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64)); v = fmaxf(v, __shfl_xor(v, 4, 64));
-    return v;
+    return group8_max(v);
 }
 
 __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, const float* __restrict__ Q, const float* __restrict__ KV,

@@ -63,6 +63,34 @@ __device__ __forceinline__ float xor32_max(float v) {
     const immtsf_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
+// sum over the lanes with the same lane % CT (CT a power of two <= 64): the row steps as rotations (a rotation orbit of a row is
+// the coset)
+__device__ __forceinline__ float coset_sum(float v, int CT) {
+    if (CT <= 32) v = xor32_sum(v);
+    if (CT <= 16) v = xor16_sum(v);
+    if (CT <= 8) v += IMMTSF_DPP(v, 0x128);     // row_ror:8
+    if (CT <= 4) v += IMMTSF_DPP(v, 0x124);     // row_ror:4
+    if (CT <= 2) v += IMMTSF_DPP(v, 0x122);     // row_ror:2
+    if (CT <= 1) v += IMMTSF_DPP(v, 0x121);     // row_ror:1
+    return v;
+}
+// sum over the aligned group of CT consecutive lanes a lane belongs to (CT a power of two <= 64), in every lane of the group
+__device__ __forceinline__ float group_sum(float v, int CT) {
+    if (CT >= 2) v += IMMTSF_DPP(v, 0xB1);      // quad_perm [1,0,3,2]
+    if (CT >= 4) v += IMMTSF_DPP(v, 0x4E);      // quad_perm [2,3,0,1]
+    if (CT >= 8) v += IMMTSF_DPP(v, 0x141);     // row_half_mirror
+    if (CT >= 16) v += IMMTSF_DPP(v, 0x140);    // row_mirror
+    if (CT >= 32) v = xor16_sum(v);
+    if (CT >= 64) v = xor32_sum(v);
+    return v;
+}
+__device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, IMMTSF_DPP(v, 0xB1));
+    v = fmaxf(v, IMMTSF_DPP(v, 0x4E));
+    return fmaxf(v, IMMTSF_DPP(v, 0x141));
+}
+// the value of lane l (wave-uniform l) in every lane: v_readlane instead of ds_bpermute
+__device__ __forceinline__ float lane_bcast(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 __device__ __forceinline__ float wave_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
 __device__ __forceinline__ float wave_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 

@@ -539,11 +539,7 @@ __global__ __launch_bounds__((SPEC ? 2 : 1) * WM * WN * 64) void gemm_kernel(con
                     // every chunk of a thread covers the same 4 rows (rq = lane % R): fold the lanes that share rq with
                     // shuffles, one LDS atomic per wave and row
                     float4 t = bsum[0];
-#pragma unroll
-                    for (int o = 32; o >= R; o >>= 1) {
-                        t.x += __shfl_xor(t.x, o, 64); t.y += __shfl_xor(t.y, o, 64);
-                        t.z += __shfl_xor(t.z, o, 64); t.w += __shfl_xor(t.w, o, 64);
-                    }
+                    t.x = coset_sum(t.x, R); t.y = coset_sum(t.y, R); t.z = coset_sum(t.z, R); t.w = coset_sum(t.w, R);
                     if (lane < R) {
                         atomicAdd(bs + lane * 4 + 0, t.x);
                         atomicAdd(bs + lane * 4 + 1, t.y);
@@ -906,8 +902,7 @@ __global__ __launch_bounds__(256) void skinny_n_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int n = 0; n < NB; ++n)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+        acc[n] = wave_sum(acc[n]);
     if (lane < NB) {
         float v = 0.f;
 #pragma unroll

@@ -220,10 +220,8 @@ __global__ __launch_bounds__(1024) void time2vec_bwd_small_kernel(const float* _
             }
         }
     }
-    for (int o = 32; o >= CT; o >>= 1) {
-        aw += __shfl_xor(aw, o, 64);
-        ab += __shfl_xor(ab, o, 64);
-    }
+    aw = coset_sum(aw, CT);
+    ab = coset_sum(ab, CT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < CT) { ra[wave * CT + lane] = aw; rb[wave * CT + lane] = ab; }
     __syncthreads();
@@ -433,7 +431,7 @@ __global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restr
             a = Y ? fmaf(x, Y[(size_t)r * ld + tx], a) : a + x;
         }
     }
-    for (int o = 32; o >= CT; o >>= 1) a += __shfl_xor(a, o, 64);
+    a = coset_sum(a, CT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < CT) red[wave * CT + lane] = a;
     __syncthreads();
@@ -695,8 +693,7 @@ __global__ __launch_bounds__(256) void query_bwd_kernel(const float* __restrict_
         float a = 0.f;
         if (r < rows)
             for (int b = part; b < B; b += 16) a += dqs_part[(size_t)b * d + i0 + r];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        a = row16_sum(a);
         if (part == 0 && r < rows) dq[r] = a * scale;
     }
     __syncthreads();

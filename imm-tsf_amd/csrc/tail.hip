@@ -92,7 +92,8 @@ __global__ __launch_bounds__(256) void ln_blend_bwd_lanes_kernel(const float* __
         tt = gn * gm;
     }
     float c1 = tt, c2 = tt * h;
-    for (int o = CT >> 1; o > 0; o >>= 1) { c1 += __shfl_xor(c1, o, 64); c2 += __shfl_xor(c2, o, 64); }
+    c1 = group_sum(c1, CT);
+    c2 = group_sum(c2, CT);
     if (on) ddelta[(size_t)row * C + c] = rstd[row] * (tt - c1 / (float)C - h * (c2 / (float)C));
 }
 
@@ -208,10 +209,8 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
         if (CT <= 32) {
             // the row lanes of one column sit CT lanes apart inside a wave: xor-shuffle over the offsets >= CT first (no barrier),
             // then one LDS round over the 16 waves -- the 7-step tree with a 1024-thread barrier per step was half of this kernel
-            for (int o = 32; o >= CT; o >>= 1) {
-                e += __shfl_xor(e, o, 64);
-                n += __shfl_xor(n, o, 64);
-            }
+            e = coset_sum(e, CT);
+            n = coset_sum(n, CT);
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
             if (lane < CT) { re[wave * CT + lane] = e; rc[wave * CT + lane] = n; }
             __syncthreads();

@@ -145,9 +145,12 @@ struct Wts { const float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; };     // packed fp
 
 // ---------------------------------------------------------------------------------------------------- forward
 // grid P, 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq]
-template <int RT>
+// MF = ceil(F / 4): the f's a wave owns.  Their layer-3 fragments (bf16 image W3h of the pack kernel), biases and the rows' mask
+// values are loaded FIRST, beside the staging loads: in front of their first use they were three dependent round trips (one per
+// f of the wave) on a kernel whose whole timeline is ~10 us.
+template <int RT, int MF>
 __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
-                                                             const float* __restrict__ mask, TEp te, Wts w,
+                                                             const float* __restrict__ mask, TEp te, Wts w, const bf16_t* __restrict__ W3h,
                                                              const float* __restrict__ Tb, float* __restrict__ ctr,
                                                              float* __restrict__ out, int out_ld, int flag_col) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,6 +161,24 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);
     float* cl = Xf + ROWS * 16;
     const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    bf16x8 bw[MF][2];
+    float b3v[MF][2], mk[RT][4];
+#pragma unroll
+    for (int j = 0; j < MF; ++j)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int f = wave + 4 * j, c = f * 32 + half * 16 + fr;
+            bw[j][half] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            b3v[j][half] = 0.f;
+            if (f < d.F) { bw[j][half] = *reinterpret_cast<const bf16x8*>(W3h + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
+        }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rt * 16 + fq * 4 + r;
+            mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
+        }
     build_x<RT>(d, x, tt, te, p, Xb, Xf);
     __syncthreads();
     mlp_layer<RT>(Xb, h1s, w.W1p, w.b1p, wave, fr, fq);
@@ -165,31 +186,27 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     mlp_layer<RT>(h1s, h2s, w.W2p, w.b2p, wave, fr, fq);
     __syncthreads();
     bf16x8 a[RT];
-    float mk[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+    for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + fq * 4 + r;
-            mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
-        }
-    }
-    for (int f = wave; f < d.F; f += 4) {
+    for (int j = 0; j < MF; ++j) {
+        const int f = wave + 4 * j;
+        if (f < d.F) {
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int c = f * 32 + half * 16 + fr;
-            float sm[RT][4];
-            sm_tile<RT>(d, a, load8_bf16(w.W3q + (size_t)c * KP + fq * 8), w.b3q[c], mk, fq, sm);
-            float acc = 0.f;
+            for (int half = 0; half < 2; ++half) {
+                const int c = f * 32 + half * 16 + fr;
+                float sm[RT][4];
+                sm_tile<RT>(d, a, bw[j][half], b3v[j][half], mk, fq, sm);
+                float acc = 0.f;
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+                for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = fmaf(sm[rt][r], Xf[(rt * 16 + fq * 4 + r) * 16 + f], acc);   // sm is 0 past L
-            acc = col_sum(acc);
-            if (fq == 0) {
-                cl[c] = acc;
-                ctr[(size_t)p * d.NCq + c] = acc;
+                    for (int r = 0; r < 4; ++r) acc = fmaf(sm[rt][r], Xf[(rt * 16 + fq * 4 + r) * 16 + f], acc);   // sm is 0 past L
+                acc = col_sum(acc);
+                if (fq == 0) {
+                    cl[c] = acc;
+                    ctr[(size_t)p * d.NCq + c] = acc;
+                }
             }
         }
     }
@@ -508,13 +525,16 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
     IMMTSF_LAUNCH_CHECK();
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
+    const int mf = (F + 3) / 4;
+#define TTCN_FWD(RT, MF)                                                                                                                     \
+    hipLaunchKernelGGL((ttcn_full_fwd_kernel<RT, MF>), dim3(P), dim3(256), fwd_lds(RT, d.NCq), s, d, x, tt, mask, te, w, q.W3h, p->T_bias, ctr, \
+                       out, out_ld, flag_col)
     if (L <= 32) {
-        hipLaunchKernelGGL(ttcn_full_fwd_kernel<2>, dim3(P), dim3(256), fwd_lds(2, d.NCq), s, d, x, tt, mask, te, w, p->T_bias, ctr, out, out_ld,
-                           flag_col);
+        if (mf == 1) TTCN_FWD(2, 1); else if (mf == 2) TTCN_FWD(2, 2); else if (mf == 3) TTCN_FWD(2, 3); else TTCN_FWD(2, 4);
     } else {
-        hipLaunchKernelGGL(ttcn_full_fwd_kernel<4>, dim3(P), dim3(256), fwd_lds(4, d.NCq), s, d, x, tt, mask, te, w, p->T_bias, ctr, out, out_ld,
-                           flag_col);
+        if (mf == 1) TTCN_FWD(4, 1); else if (mf == 2) TTCN_FWD(4, 2); else if (mf == 3) TTCN_FWD(4, 3); else TTCN_FWD(4, 4);
     }
+#undef TTCN_FWD
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
-                                                    const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec) {
+                                                    const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec,
+                                                    float* __restrict__ gz) {
+    // gz != null (== g): the gradient is left zero behind the update -- the next step's zero-fill rides on this pass
     __shared__ float red[16];
     if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)
         const float st = (float)step_dev[0];
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<float4*>(m)[i] = m4;
         reinterpret_cast<float4*>(v)[i] = v4;
         reinterpret_cast<float4*>(p)[i] = o;
+        if (gz) reinterpret_cast<float4*>(gz)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (twin) {          // bf16 twin of the parameters (the GEMMs' weight operand), kept current here
             bf16x4 h;
             h[0] = (bf16_t)o.x; h[1] = (bf16_t)o.y; h[2] = (bf16_t)o.z; h[3] = (bf16_t)o.w;
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         float mi = m[i], vi = v[i];
         const float pn = upd(g[i], p[i], mi, vi);
         m[i] = mi; v[i] = vi; p[i] = pn;
+        if (gz) gz[i] = 0.f;
         if (twin) twin[i] = (bf16_t)pn;
     }
 }
@@ -518,7 +522,7 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
     const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, nparts, (const long long*)nullptr, reinterpret_cast<bf16_t*>(twin), vec);
+                       norm_scratch, nparts, (const long long*)nullptr, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -541,14 +545,14 @@ int launch_adam_apply(float* param, const float* grad, float* m, float* v, size_
     const float bc1 = step_dev ? 1.f : 1.f - powf(b1, (float)step), bc2s = step_dev ? 1.f : sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, 1024, step_dev, reinterpret_cast<bf16_t*>(twin), vec);
+                       norm_scratch, 1024, step_dev, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
-                    hipStream_t s) {
+                    hipStream_t s, int zero_grad) {
     if (n == 0) return IMMTSF_OK;
     const int nparts = 1024;
     void* twin = const_cast<void*>(immtsf_twin_lookup(param, n));
@@ -557,7 +561,8 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
     IMMTSF_LAUNCH_CHECK();
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
-                       norm_scratch, nparts, (const long long*)step_dev, reinterpret_cast<bf16_t*>(twin), vec);
+                       norm_scratch, nparts, (const long long*)step_dev, reinterpret_cast<bf16_t*>(twin), vec,
+                       zero_grad ? const_cast<float*>(grad) : nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -221,6 +221,8 @@ _PROTOS = {
     "immtsf_debug_gemm2_config": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "immtsf_adam_step_dev": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
+    "immtsf_adam_step_dev_zero": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
     "immtsf_adam_sqnorm": (C.c_int, [c_f32p, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p, c_stream]),
     "immtsf_adam_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),

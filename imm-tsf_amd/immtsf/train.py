@@ -210,7 +210,10 @@ class FlatTrainer:
         split-K weight gradients, atomically accumulates onto the zeros: `grads_prezeroed`) its ranges; autograd-owned
         parameters get `.grad = None` so that AccumulateGrad adopts the incoming tensor instead of launching one add
         kernel per parameter -- `_collect_autograd_grads` copies them into the flat buffer with one multi-tensor copy."""
-        self.flat_grad.zero_()
+        # zero_in_step (GraphedStep's one-graph mode turns it on): the previous step()'s Adam pass already left the buffer zero
+        if not (getattr(self, "zero_in_step", False) and getattr(self, "_grad_zeroed_by_step", False)):
+            self.flat_grad.zero_()
+        self._grad_zeroed_by_step = False
         for p, _ in self._autograd_owned:
             p.grad = None
         self._reduced = [False] * len(self.buckets)
@@ -393,7 +396,10 @@ class FlatTrainer:
             return
         if self.flat_param.is_cuda and self.device_step:
             lib = _lib.load()
-            _lib.check(lib.immtsf_adam_step_dev(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+            zero = getattr(self, "zero_in_step", False)
+            fn = lib.immtsf_adam_step_dev_zero if zero else lib.immtsf_adam_step_dev
+            self._grad_zeroed_by_step = bool(zero)
+            _lib.check(fn(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
                                                 _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0],
                                                 self.betas[1], self.eps, self.wd, _lib.ptr(self.step_dev), self.max_norm,
                                                 _lib.ptr(self.norm_scratch), _lib.ptr(self.drop_dev), _lib.stream_ptr()),
@@ -467,6 +473,12 @@ class GraphedStep:
             # the bucket hooks must not fire inside the captured backward: their all-reduces would be captured (pulling the
             # communication stream into the capture without a join) AND repeated by sync_grads() between the graphs
             trainer.overlap = False
+        # no communication between backward and optimizer (one process): clip + Adam ride at the end of graph A -- one graph
+        # launch per step instead of two -- and Adam's pass over the gradient leaves it zero for the next replay (the 32 MB
+        # zero-fill in front of the forward was 12 us that nothing could overlap: both branches wait for it)
+        self.single = (not trainer.collective) and os.environ.get("IMMTSF_TWO_GRAPHS", "0") != "1"
+        if self.single and not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
+            trainer.zero_in_step = True
         side = torch.cuda.Stream(device=trainer.flat_param.device)
         side.wait_stream(torch.cuda.current_stream())
         # the warm-up runs REAL steps (allocator pools, lazy inits, RCCL channels): parameters, moments and the step / dropout
@@ -483,9 +495,6 @@ class GraphedStep:
             trainer.restore(snap)
             torch.cuda.synchronize()
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        # no communication between backward and optimizer (one process): clip + Adam ride at the end of graph A -- one graph
-        # launch per step instead of two
-        self.single = (not trainer.collective) and os.environ.get("IMMTSF_TWO_GRAPHS", "0") != "1"
         with torch.cuda.graph(self.graph_a):
             self.loss = self._fwd_bwd()
             if self.captured_comm:

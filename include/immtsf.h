@@ -441,6 +441,12 @@ int immtsf_adam_step_dev(float* param, const float* grad, float* exp_avg, float*
                          float beta1, float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm,
                          float* norm_scratch, uint64_t* dropout_step_dev, immtsf_stream_t stream);
 
+/* immtsf_adam_step_dev that also leaves `grad` ZERO behind the update: the next step's zero-fill of the gradient buffer (a
+ * 32 MB memset in front of everything at the benchmark configuration) rides on the pass Adam makes over it anyway. */
+int immtsf_adam_step_dev_zero(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm, float* norm_scratch,
+                              uint64_t* dropout_step_dev, immtsf_stream_t stream);
+
 /* The same step as two calls, for a sharded optimizer (immtsf.train.FlatTrainer(shard_optimizer=True): each rank owns
  * 1/W of the flat buffers): adam_sqnorm writes 1024 partial sums of squares of `grad` (this rank's shard of the
  * reduce-scattered gradient) to norm_scratch and bumps the device counters (both may be NULL); the caller sum-all-reduces

@@ -154,11 +154,16 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
     // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
     static const int notes_image = getenv("IMMTSF_T2V_NOTES_IMAGE") ? atoi(getenv("IMMTSF_T2V_NOTES_IMAGE")) : 1;
+    bool staged = false;       // Time2Vec and the query projection already done by the notes-stage launch
     if (p->input_proj_w && hf && notes_image) {
         // bf16 mode: ONE gather + cast pass writes the packed bf16 image of the notes; the projection (here) and its weight
         // gradient (backward) then run on the bf16-in-memory GEMM instead of re-reading the fp32 rows through a row map
         // (cfg5: 145 k x 4096 rows -- the row-mapped fp32 weight gradient was the slowest kernel of the fusion path, 6.4 ms)
-        CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, cfg->d_m, nullptr, cfg->d_m, s, w.Vh));
+        // (with Time2Vec of the time stamps and the learned query's in-projection in the same launch: three independent row jobs)
+        CHECK(launch_notes_stage(notes, cfg->d_m, gather, total, R, cfg->d_m, w.Vh, cfg->d_m, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b,
+                                 p->t2v_per_w, p->t2v_per_b, w.Xcat.f ? w.Xcat.f + d : nullptr, dcat, w.Xcat.h ? mat_off(w.Xcat, d).h : nullptr,
+                                 p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
+        staged = true;
         GemmArgs g = gemm_args(R, d, cfg->d_m, cfg->d_m, cfg->d_m, dcat);
         set_problem2(g, 0, mat(nullptr, w.Vh), W.in, w.Xcat, p->input_proj_b);
         g.dyn = total; g.dyn_which = 0;
@@ -171,8 +176,9 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     } else {
         CHECK(launch_gather_rows(notes, cfg->d_m, gather, total, R, d, w.Xcat.f, dcat, s, w.Xcat.h));
     }
-    CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b,
-                              w.Xcat.f ? w.Xcat.f + d : nullptr, dcat, s, w.Xcat.h ? mat_off(w.Xcat, d).h : nullptr));
+    if (!staged)
+        CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b,
+                                  w.Xcat.f ? w.Xcat.f + d : nullptr, dcat, s, w.Xcat.h ? mat_off(w.Xcat, d).h : nullptr));
     {   // KV = KV_proj([V;tau])
         GemmArgs g = gemm_args(R, d, dcat, dcat, dcat, d);
         set_problem2(g, 0, w.Xcat, W.kv, w.KV, p->kv_b);
@@ -185,7 +191,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
         g.dyn = total;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
+    if (!staged) CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
     CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h, w.part));
     {   // out_proj, zero the windows without notes, + Q_param residual

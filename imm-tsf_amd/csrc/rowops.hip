@@ -98,11 +98,10 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
     }
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src,
-                                                           const int* __restrict__ rowmap, const int* __restrict__ total,
-                                                           int width, float* __restrict__ dst, int ld_dst,
-                                                           bf16_t* __restrict__ dst_h, int vec) {
-    const int r = blockIdx.x;
+__device__ __forceinline__ void gather_rows_body(int r, const float* __restrict__ src, int ld_src,
+                                                 const int* __restrict__ rowmap, const int* __restrict__ total,
+                                                 int width, float* __restrict__ dst, int ld_dst,
+                                                 bf16_t* __restrict__ dst_h, int vec) {
     if (r >= *total) return;
     const float* s = src + (size_t)rowmap[r] * ld_src;
     if (vec) {      // width, both pitches multiples of 4 and 16-byte aligned bases: 16-byte loads, 8-byte bf16 stores
@@ -124,22 +123,36 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
         if (dst_h) dst_h[(size_t)r * ld_dst + i] = (bf16_t)v;
     }
 }
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int ld_src,
+                                                           const int* __restrict__ rowmap, const int* __restrict__ total,
+                                                           int width, float* __restrict__ dst, int ld_dst,
+                                                           bf16_t* __restrict__ dst_h, int vec) {
+    gather_rows_body(blockIdx.x, src, ld_src, rowmap, total, width, dst, ld_dst, dst_h, vec);
+}
 
 // ------------------------------------------------------------------------------------------- Time2Vec
 // reference: fusions/TTF_T2V_XAttn.py:7-24  (applied to RAW tau, :136)
-__global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
-                                                            const int* __restrict__ total, int d_tau,
-                                                            const float* __restrict__ w0, const float* __restrict__ b0,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ dst, int ld_dst, int max_rows,
-                                                            bf16_t* __restrict__ dst_h) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void time2vec_fwd_body(int bid, const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
+                                                  const int* __restrict__ total, int d_tau,
+                                                  const float* __restrict__ w0, const float* __restrict__ b0,
+                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                  float* __restrict__ dst, int ld_dst, int max_rows,
+                                                  bf16_t* __restrict__ dst_h) {
+    const long idx = (long)bid * 256 + threadIdx.x;
     const int r = (int)(idx / d_tau), j = (int)(idx % d_tau);
     if (r >= (total ? *total : max_rows)) return;
     const float t = tau_pad[rowmap ? rowmap[r] : r];
     const float v = (j == 0) ? fmaf(w0[0], t, b0[0]) : sinf(fmaf(w[j - 1], t, b[j - 1]));
     if (dst) dst[(size_t)r * ld_dst + j] = v;
     if (dst_h) dst_h[(size_t)r * ld_dst + j] = (bf16_t)v;
+}
+__global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
+                                                            const int* __restrict__ total, int d_tau,
+                                                            const float* __restrict__ w0, const float* __restrict__ b0,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ dst, int ld_dst, int max_rows,
+                                                            bf16_t* __restrict__ dst_h) {
+    time2vec_fwd_body(blockIdx.x, tau_pad, rowmap, total, d_tau, w0, b0, w, b, dst, ld_dst, max_rows, dst_h);
 }
 
 // partial[slab][0][j] = sum_r g*tau, partial[slab][1][j] = sum_r g,  g = dfeat[r,j] * (j ? cos(w tau + b) : 1)
@@ -622,11 +635,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------- tiny vector ops
-__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
-                                                      const float* __restrict__ b, int rows, int cols,
-                                                      float* __restrict__ y, float* __restrict__ ys, float scale,
-                                                      float* __restrict__ y_nobias) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void matvec_body(int bid, const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                            const float* __restrict__ b, int rows, int cols,
+                                            float* __restrict__ y, float* __restrict__ ys, float scale,
+                                            float* __restrict__ y_nobias) {
+    const int lane = threadIdx.x & 63, row = bid * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float a = 0.f;
     for (int j = lane; j < cols; j += 64) a = fmaf(W[(size_t)row * ldw + j], x[j], a);
@@ -637,6 +650,25 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
         if (y) y[row] = a;
         if (ys) ys[row] = a * scale;
     }
+}
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W, int ldw, const float* __restrict__ x,
+                                                      const float* __restrict__ b, int rows, int cols,
+                                                      float* __restrict__ y, float* __restrict__ ys, float scale,
+                                                      float* __restrict__ y_nobias) {
+    matvec_body(blockIdx.x, W, ldw, x, b, rows, cols, y, ys, scale, y_nobias);
+}
+// Three independent row jobs at the head of TTF_T2V_XAttn's forward -- pack + cast the notes, Time2Vec of their time stamps, the
+// learned query's in-projection (parameters only) -- as ONE launch: workgroups [0, na) gather, [na, na + nb) Time2Vec, the rest
+// the mat-vec.  (Each was a launch of its own on the text side's forward chain; a dependent launch costs ~5 us whatever it does.)
+struct GatherJob { const float* src; int ld_src; const int* rowmap; const int* total; int width; float* dst; int ld_dst; bf16_t* dst_h; int vec; };
+struct T2VJob { const float* tau_pad; const int* rowmap; const int* total; int d_tau; const float *w0, *b0, *w, *b; float* dst; int ld_dst, max_rows; bf16_t* dst_h; };
+struct MatvecJob { const float* W; int ldw; const float *x, *b; int rows, cols; float *y, *ys; float scale; };
+__global__ __launch_bounds__(256) void notes_stage_kernel(GatherJob a, int na, T2VJob t, int nb, MatvecJob m) {
+    int bid = blockIdx.x;
+    if (bid < na) { gather_rows_body(bid, a.src, a.ld_src, a.rowmap, a.total, a.width, a.dst, a.ld_dst, a.dst_h, a.vec); return; }
+    bid -= na;
+    if (bid < nb) { time2vec_fwd_body(bid, t.tau_pad, t.rowmap, t.total, t.d_tau, t.w0, t.b0, t.w, t.b, t.dst, t.ld_dst, t.max_rows, t.dst_h); return; }
+    matvec_body(bid - nb, m.W, m.ldw, m.x, m.b, m.rows, m.cols, m.y, m.ys, m.scale, nullptr);
 }
 
 // y[j] = sum_i W[i,j] x[i]: 64 columns x 16 row lanes per workgroup, rows strided (coalesced over j)
@@ -763,6 +795,22 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
     const long n = (long)max_rows * d_tau;
     hipLaunchKernelGGL(time2vec_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tau_pad, rowmap, total, d_tau,
                        w0, b0, w, b, dst, ld_dst, max_rows, static_cast<bf16_t*>(dst_h));
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int* total, int max_rows, int width, void* dst_h, int ld_dst,
+                       const float* tau_pad, const int* rowmap, int d_tau, const float* w0, const float* b0, const float* w, const float* b,
+                       float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
+                       float* y, float* ys, float scale, hipStream_t s) {
+    if (max_rows <= 0) return IMMTSF_OK;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_h);
+    const int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
+    const GatherJob a{src, ld_src, gmap, total, width, nullptr, ld_dst, static_cast<bf16_t*>(dst_h), vec};
+    const T2VJob t{tau_pad, rowmap, total, d_tau, w0, b0, w, b, t_dst, t_ld, max_rows, static_cast<bf16_t*>(t_dst_h)};
+    const MatvecJob m{W, ldw, x, bias, rows, cols, y, ys, scale};
+    const int na = max_rows, nb = (int)(((long)max_rows * d_tau + 255) / 256), nc = cdiv(rows, 4);
+    hipLaunchKernelGGL(notes_stage_kernel, dim3(na + nb + nc), dim3(256), 0, s, a, na, t, nb, m);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

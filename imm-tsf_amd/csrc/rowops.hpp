@@ -19,6 +19,11 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
                         hipStream_t s, void* dst_h = nullptr);      // dst_h: optional bf16 copy (same ld); dst may then be null
 // Time2Vec parameter gradients from dFeat (packed rows, ld): nslabs row slabs (0 = 32), scratch >= 2*nslabs*d_tau floats;
 // rowmap/total may be null (rows 0..max_rows-1 used directly)
+// gather + cast of the packed notes (bf16 image only), Time2Vec of their time stamps and the learned query's in-projection in one launch
+int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int* total, int max_rows, int width, void* dst_h, int ld_dst,
+                       const float* tau_pad, const int* rowmap, int d_tau, const float* w0, const float* b0, const float* w, const float* b,
+                       float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
+                       float* y, float* ys, float scale, hipStream_t s);
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
                         float* db, float* scratch, int nslabs, hipStream_t s, int accumulate = 0);

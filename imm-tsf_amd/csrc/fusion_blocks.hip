@@ -273,8 +273,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
     CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
                                  SITE_T2V_ATTN, s, sc.dKVp.h));
-    // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq
-    CHECK(launch_query_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
+    // (the query path's backward -- parameter gradients only -- rides with Time2Vec's at the end of this function)
     {   // k|v in-projection
         GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
         set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
@@ -311,8 +310,11 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w,
-                              gr->t2v_lin_b, gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
+    // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq -- in the same
+    // launch as the first stage of Time2Vec's parameter gradients
+    CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
+                               w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
+                               gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
     return fk.join();
 }
 

@@ -156,14 +156,13 @@ __global__ __launch_bounds__(256) void time2vec_fwd_kernel(const float* __restri
 }
 
 // partial[slab][0][j] = sum_r g*tau, partial[slab][1][j] = sum_r g,  g = dfeat[r,j] * (j ? cos(w tau + b) : 1)
-__global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
-                                                            const int* __restrict__ total, int d_tau,
-                                                            const float* __restrict__ w, const float* __restrict__ b,
-                                                            const float* __restrict__ dfeat, int ld,
-                                                            float* __restrict__ partial, int max_rows) {
-    __shared__ float red[2][4][64];
+__device__ __forceinline__ void time2vec_bwd_body(int bx, int slab, int nsl, float (*red)[4][64], const float* __restrict__ tau_pad,
+                                                  const int* __restrict__ rowmap, const int* __restrict__ total, int d_tau,
+                                                  const float* __restrict__ w, const float* __restrict__ b,
+                                                  const float* __restrict__ dfeat, int ld,
+                                                  float* __restrict__ partial, int max_rows) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx, slab = blockIdx.y, nsl = gridDim.y;
+    const int j = bx * 64 + tx;
     const int M = total ? *total : max_rows, rps = (M + nsl - 1) / nsl;
     const int r0 = slab * rps, r1 = min(M, r0 + rps);
     float aw = 0.f, ab = 0.f;
@@ -199,6 +198,14 @@ __global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restri
         partial[((size_t)slab * 2 + 0) * d_tau + j] = red[0][0][tx] + red[0][1][tx] + red[0][2][tx] + red[0][3][tx];
         partial[((size_t)slab * 2 + 1) * d_tau + j] = red[1][0][tx] + red[1][1][tx] + red[1][2][tx] + red[1][3][tx];
     }
+}
+__global__ __launch_bounds__(256) void time2vec_bwd_kernel(const float* __restrict__ tau_pad, const int* __restrict__ rowmap,
+                                                            const int* __restrict__ total, int d_tau,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            const float* __restrict__ dfeat, int ld,
+                                                            float* __restrict__ partial, int max_rows) {
+    __shared__ float red[2][4][64];
+    time2vec_bwd_body(blockIdx.x, blockIdx.y, gridDim.y, red, tau_pad, rowmap, total, d_tau, w, b, dfeat, ld, partial, max_rows);
 }
 
 // narrow embeddings (d_tau <= 32: tPatchGNN's LearnableTE of the prediction times, 10 columns x 2048 rows) in ONE workgroup:
@@ -714,12 +721,12 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src
 // grid ceil(d / QB_ROWS): a workgroup owns QB_ROWS rows i: dq[i] (16 lanes per row over the B windows), those rows of dW_q and
 // db_q, and its rows' share of W_q^T dq, added into dQ with one atomic per column.
 constexpr int QB_ROWS = 16;
-__global__ __launch_bounds__(256) void query_bwd_kernel(const float* __restrict__ dqs_part, int B, int d, float scale,
-                                                         const float* __restrict__ Wq, int ldw, const float* __restrict__ Q,
-                                                         float* __restrict__ dWq, int ldg, float* __restrict__ dbq,
-                                                         float* __restrict__ dQ) {
-    __shared__ float dq[QB_ROWS];     // only this workgroup's rows of dq enter its share of all three results
-    const int tid = threadIdx.x, i0 = blockIdx.x * QB_ROWS, rows = min(QB_ROWS, d - i0);
+__device__ __forceinline__ void query_bwd_body(int bid, float* dq, const float* __restrict__ dqs_part, int B, int d, float scale,
+                                               const float* __restrict__ Wq, int ldw, const float* __restrict__ Q,
+                                               float* __restrict__ dWq, int ldg, float* __restrict__ dbq,
+                                               float* __restrict__ dQ) {
+    // dq[QB_ROWS] (LDS): only this workgroup's rows of dq enter its share of all three results
+    const int tid = threadIdx.x, i0 = bid * QB_ROWS, rows = min(QB_ROWS, d - i0);
     {
         const int r = tid >> 4, part = tid & 15;      // 16 lanes per row split the B windows
         float a = 0.f;
@@ -740,6 +747,28 @@ __global__ __launch_bounds__(256) void query_bwd_kernel(const float* __restrict_
         }
         atomicAdd(dQ + j, a);
     }
+}
+__global__ __launch_bounds__(256) void query_bwd_kernel(const float* __restrict__ dqs_part, int B, int d, float scale,
+                                                         const float* __restrict__ Wq, int ldw, const float* __restrict__ Q,
+                                                         float* __restrict__ dWq, int ldg, float* __restrict__ dbq,
+                                                         float* __restrict__ dQ) {
+    __shared__ float dq[QB_ROWS];
+    query_bwd_body(blockIdx.x, dq, dqs_part, B, d, scale, Wq, ldw, Q, dWq, ldg, dbq, dQ);
+}
+// the learned query's backward and the first stage of Time2Vec's parameter gradients in one launch (both end in parameter
+// gradients only; the query's sat in the middle of the text side's backward chain): workgroups [0, nq) the query, the rest
+// Time2Vec's (column block, slab) grid
+struct QueryBwdJob { const float* dqs_part; int B, d; float scale; const float* Wq; int ldw; const float* Q; float* dWq; int ldg; float *dbq, *dQ; };
+struct T2VBwdJob { const float* tau_pad; const int *rowmap, *total; int d_tau; const float *w, *b, *dfeat; int ld; float* partial; int max_rows, gx, nsl; };
+__global__ __launch_bounds__(256) void query_t2v_bwd_kernel(QueryBwdJob q, int nq, T2VBwdJob t) {
+    __shared__ float red[2][4][64];
+    int bid = blockIdx.x;
+    if (bid < nq) {
+        query_bwd_body(bid, &red[0][0][0], q.dqs_part, q.B, q.d, q.scale, q.Wq, q.ldw, q.Q, q.dWq, q.ldg, q.dbq, q.dQ);
+        return;
+    }
+    bid -= nq;
+    time2vec_bwd_body(bid % t.gx, bid / t.gx, t.nsl, red, t.tau_pad, t.rowmap, t.total, t.d_tau, t.w, t.b, t.dfeat, t.ld, t.partial, t.max_rows);
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ dst, float v, size_t n) {
@@ -953,6 +982,23 @@ int launch_query_bwd(const float* dqs_part, int B, int d, float scale, const flo
     if (d <= 0) return IMMTSF_OK;
     hipLaunchKernelGGL(query_bwd_kernel, dim3(cdiv(d, QB_ROWS)), dim3(256), 0, s, dqs_part, B, d, scale, Wq, ldw, Q,
                        dWq, ldg, dbq, dQ);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+// launch_query_bwd + launch_time2vec_bwd (general two-stage form) with their first kernels merged
+int launch_query_t2v_bwd(const float* dqs_part, int B, int d, float scale, const float* Wq, int ldw, const float* Q, float* dWq, int ldg,
+                         float* dbq, float* dQ, const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw, float* db,
+                         float* scratch, int nslabs, hipStream_t s, int accumulate) {
+    if (d <= 0 || max_rows <= 0) return IMMTSF_EINVAL;
+    if (nslabs < 1) nslabs = kSlabs;
+    const int nq = cdiv(d, QB_ROWS), gx = cdiv(d_tau, 64);
+    const QueryBwdJob q{dqs_part, B, d, scale, Wq, ldw, Q, dWq, ldg, dbq, dQ};
+    const T2VBwdJob t{tau_pad, rowmap, total, d_tau, w, b, dfeat, ld, scratch, max_rows, gx, nslabs};
+    hipLaunchKernelGGL(query_t2v_bwd_kernel, dim3(nq + gx * nslabs), dim3(256), 0, s, q, nq, t);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(time2vec_bwd_final_kernel, dim3(cdiv(d_tau, 4)), dim3(256), 0, s, scratch, d_tau, dw0, db0, dw, db, nslabs, accumulate);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

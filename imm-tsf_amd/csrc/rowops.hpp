@@ -24,6 +24,10 @@ int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int*
                        const float* tau_pad, const int* rowmap, int d_tau, const float* w0, const float* b0, const float* w, const float* b,
                        float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
                        float* y, float* ys, float scale, hipStream_t s);
+int launch_query_t2v_bwd(const float* dqs_part, int B, int d, float scale, const float* Wq, int ldw, const float* Q, float* dWq, int ldg,
+                         float* dbq, float* dQ, const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
+                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw, float* db,
+                         float* scratch, int nslabs, hipStream_t s, int accumulate = 0);
 int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                         const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw,
                         float* db, float* scratch, int nslabs, hipStream_t s, int accumulate = 0);

@@ -605,6 +605,8 @@ def main():
         lib.immtsf_debug_gemm2_config(args.gemm2_variant, 0, -1)
     if args.no_wgrad_fork:
         lib.immtsf_set_side_stream(0)
+    elif os.environ.get("IMMTSF_WGRAD_FORK") == "1":      # A/B: weight-gradient GEMMs on the library's side stream (off by default)
+        lib.immtsf_set_side_stream(1)
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
     config.manual_seed(1234 + rank)
 

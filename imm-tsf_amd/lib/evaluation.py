@@ -47,7 +47,7 @@ def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None)
 # MMF_XAttn_Add's folded query-half weights depend on parameters only.  Formed in front of the backbone on ITS stream instead of
 # behind the key/value projection on the text stream the cfg2 step got slower (0.793 vs 0.783 ms, 3 runs each): in the forward
 # the backbone is the longer chain.  Off unless asked for.
-_FOLD_ON_SIDE = os.environ.get("IMMTSF_FOLD_ON_SIDE", "0") == "1"
+_FOLD_ON_SIDE = int(os.environ.get("IMMTSF_FOLD_ON_SIDE", "0") or 0)      # 1: in front of the backbone, 2: behind it
 
 
 def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
@@ -74,11 +74,14 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
     else:
         kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
     with torch.cuda.stream(side_stream):
-        if fold_side:      # parameters only: in front of the backbone on its stream
+        if fold_side and _FOLD_ON_SIDE == 1:      # parameters only: in front of the backbone on its stream
             fold = fusion.mmf.fold_weights()
+        pred_y = model.forecasting(*fc_args)
+        if fold_side and _FOLD_ON_SIDE != 1:      # ... or behind it
+            fold = fusion.mmf.fold_weights()
+        if fold_side:
             fold.record_stream(main)
             kv = (kv[0], fold)
-        pred_y = model.forecasting(*fc_args)
     main.wait_stream(side_stream)
     pred_y.record_stream(main)
     return fusion.mmf(pred_y, E_txt, M_txt) if kv is None else fusion.mmf(pred_y, E_txt, M_txt, kv=kv)

@@ -182,6 +182,106 @@ bool xattn_small(const immtsf_fusion_cfg* c) {
     return on && c->precision == 1 && xattn_small_supported(c->T, c->H, c->d / c->H);
 }
 
+// ---- the three folded products of the query half (parameters only) as ONE launch of three independent jobs:
+//   job A, workgroups [0, na):  W_Qf[m][n] = sum_k W_in,q[m][k] W_q[k][n]   (d x C, K = d): a wave per row m, lanes stride k
+//   job B, [na, na + nb):       W_HO[c][e] = sum_k W_res[c][k] W_out[k][e]  (C x d, K = d): 64 columns per workgroup, the lanes'
+//                               16 k-groups meet by permlane swaps inside a wave and through LDS across the four waves
+//   job C, the rest:            t_HO[c] = sum_k W_res[c][k] b_out[k];  b_HO = t_HO + b_res
+// (As GEMM launches they were a zero-fill, a skinny product, a split-K product and a mat-vec: four dependent launches of
+// parameter-only work on the text side's forward chain.)  Exact fp32.  C <= 16, d % 4 == 0.
+constexpr int QF_C = 16;
+struct QFoldJob { const float *Win, *Wq, *Wres, *Wout, *bout, *bres; float *WQf, *WHO, *bHO, *tHO; int d, C; };
+__global__ __launch_bounds__(256) void qfold_kernel(QFoldJob q, int na, int nb) {
+    __shared__ __attribute__((aligned(16))) float red[4][QF_C][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = q.d, C = q.C;
+    int bid = blockIdx.x;
+    if (bid < na) {                 // ---- job A
+        const int m = bid * 4 + wave;
+        if (m >= d) return;
+        float acc[QF_C];
+#pragma unroll
+        for (int n = 0; n < QF_C; ++n) acc[n] = 0.f;
+#pragma unroll 4
+        for (int k = lane; k < d; k += 64) {      // (unrolled: a round trip per k step otherwise)
+            const float a = q.Win[(size_t)m * d + k];
+#pragma unroll
+            for (int n = 0; n < QF_C; ++n)
+                if (n < C) acc[n] = fmaf(a, q.Wq[(size_t)k * C + n], acc[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < QF_C; ++n)
+            if (n < C) {
+                const float v = wave_sum(acc[n]);
+                if (lane == 0) q.WQf[(size_t)m * C + n] = v;
+            }
+        return;
+    }
+    bid -= na;
+    if (bid < nb) {                 // ---- job B: columns e0 .. e0 + 64, thread = (4-column group eq, k-group kg)
+        const int eq = tid & 15, kg = tid >> 4, e = bid * 64 + eq * 4;
+        float4 acc[QF_C];
+#pragma unroll
+        for (int c = 0; c < QF_C; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < d) {
+            constexpr int U = 8;          // k steps whose loads are in flight together (12 workgroups: latency is all there is)
+            int k = kg;
+            for (; k + 16 * (U - 1) < d; k += 16 * U) {
+                float4 w[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) w[u] = *reinterpret_cast<const float4*>(q.Wout + (size_t)(k + 16 * u) * d + e);
+#pragma unroll
+                for (int c = 0; c < QF_C; ++c)
+                    if (c < C) {
+                        float r[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) r[u] = q.Wres[(size_t)c * d + k + 16 * u];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            acc[c].x = fmaf(r[u], w[u].x, acc[c].x); acc[c].y = fmaf(r[u], w[u].y, acc[c].y);
+                            acc[c].z = fmaf(r[u], w[u].z, acc[c].z); acc[c].w = fmaf(r[u], w[u].w, acc[c].w);
+                        }
+                    }
+            }
+            for (; k < d; k += 16) {
+                const float4 w = *reinterpret_cast<const float4*>(q.Wout + (size_t)k * d + e);
+#pragma unroll
+                for (int c = 0; c < QF_C; ++c)
+                    if (c < C) {
+                        const float r = q.Wres[(size_t)c * d + k];
+                        acc[c].x = fmaf(r, w.x, acc[c].x); acc[c].y = fmaf(r, w.y, acc[c].y);
+                        acc[c].z = fmaf(r, w.z, acc[c].z); acc[c].w = fmaf(r, w.w, acc[c].w);
+                    }
+            }
+        }
+        // the four k-groups of a wave sit 16 lanes apart: lane ^ 16, lane ^ 32
+#pragma unroll
+        for (int c = 0; c < QF_C; ++c)
+            if (c < C) {
+                acc[c].x = xor32_sum(xor16_sum(acc[c].x)); acc[c].y = xor32_sum(xor16_sum(acc[c].y));
+                acc[c].z = xor32_sum(xor16_sum(acc[c].z)); acc[c].w = xor32_sum(xor16_sum(acc[c].w));
+                if (lane < 16) *reinterpret_cast<float4*>(&red[wave][c][eq * 4]) = acc[c];
+            }
+        __syncthreads();
+        for (int x = tid; x < C * 64; x += 256) {
+            const int c = x >> 6, col = x & 63;
+            if (bid * 64 + col < d) q.WHO[(size_t)c * d + bid * 64 + col] = (red[0][c][col] + red[1][c][col]) + (red[2][c][col] + red[3][c][col]);
+        }
+        return;
+    }
+    bid -= nb;                      // ---- job C
+    const int c = bid * 4 + wave;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int k = lane; k < d; k += 64) a = fmaf(q.Wres[(size_t)c * d + k], q.bout[k], a);
+    a = wave_sum(a);
+    if (lane == 0) { q.tHO[c] = a; q.bHO[c] = a + q.bres[c]; }
+}
+bool qfold_one_launch(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const float* fold) {
+    static const bool on = !(getenv("IMMTSF_QFOLD_ONE") && atoi(getenv("IMMTSF_QFOLD_ONE")) == 0);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p->attn_out_w) | reinterpret_cast<uintptr_t>(fold);
+    return on && c->C <= QF_C && (c->d & 3) == 0 && (a & 15) == 0;
+}
+
 // the query projection (forward, backward) and the context gradient (backward) as operands formed inside the tile kernels from
 // their C-column inputs: decided from what the forward and the backward both see, so that they agree on whether Qi exists
 bool xattn_gen(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const float* Y_ts, const QFold& f) {
@@ -241,6 +341,13 @@ int immtsf_mmf_xattn_q_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_para
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int d = cfg->d, C = cfg->C, prec = cfg->precision;
     const QFold f = qfold_at(cfg, fold);
+    if (qfold_one_launch(cfg, p, fold)) {
+        const QFoldJob q{p->attn_in_w, p->proj_q_w, p->res_w, p->attn_out_w, p->attn_out_b, p->res_b, f.WQf, f.WHO, f.bHO, f.tHO, d, C};
+        const int na = (d + 3) / 4, nb = (d + 63) / 64, nc = (C + 3) / 4;
+        hipLaunchKernelGGL(qfold_kernel, dim3(na + nb + nc), dim3(256), 0, s, q, na, nb);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     {   // both folded products split K (12 tiles each otherwise): ONE zero-fill for the two adjacent outputs
         hipError_t e = hipMemsetAsync(f.WQf, 0, (size_t)2 * d * C * sizeof(float), s);
         if (e != hipSuccess) return (int)e;

@@ -450,18 +450,31 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
             if (e != hipSuccess) return (int)e;
         }
     }
-    CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
+    // LayerNorm(C)'s two parameter gradients and s_live (column sums of ddelta over the windows with text) in one launch, then
+    // d b_out = W_res^T s_live and the first term of dW_res = s_live b_out^T + dW_HO W_out^T in another
+    static const bool head_small = !(getenv("IMMTSF_HEAD_SUMS") && atoi(getenv("IMMTSF_HEAD_SUMS")) == 0);
+    const bool hs = head_small && head_sums_supported(BT, C);
+    if (hs) {
+        CHECK(launch_head_sums(sc.dn, w.xhatC, sc.ddelta, M_txt, T, BT, C, gr->ln_w, gr->ln_b, sc.slive, s));
+        CHECK(launch_head_outer(p->res_w, d, sc.slive, p->attn_out_b, C, gr->attn_out_b, gr->res_w, s));
+    } else {
+        CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
+    }
     {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
         set_problem(h, 0, sc.ddelta, w.O, sc.dWHO, nullptr, gr->res_b);
         h.c_prezeroed = pz;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, s));
     }
-    CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
-    CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
+    if (!hs) {
+        CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
+        CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
+    }
     {   // chain rule through W_HO = W_res W_out, b_HO = W_res b_out + b_res
-        CHECK(launch_matvec_t(p->res_w, d, sc.slive, C, d, gr->attn_out_b, 0, s));      // d b_out = W_res^T s_live
-        CHECK(launch_outer(sc.slive, p->attn_out_b, C, d, gr->res_w, d, s));             // dW_res = s_live b_out^T + dW_HO W_out^T
+        if (!hs) {
+            CHECK(launch_matvec_t(p->res_w, d, sc.slive, C, d, gr->attn_out_b, 0, s));      // d b_out = W_res^T s_live
+            CHECK(launch_outer(sc.slive, p->attn_out_b, C, d, gr->res_w, d, s));             // dW_res = s_live b_out^T + dW_HO W_out^T
+        }
         GemmArgs g = gemm_args(C, d, d, d, d, d);
         set_problem(g, 0, sc.dWHO, p->attn_out_w, gr->res_w, nullptr);
         g.accumulate = 1;

@@ -1003,6 +1003,76 @@ int launch_query_t2v_bwd(const float* dqs_part, int B, int d, float scale, const
     return IMMTSF_OK;
 }
 
+// ---- the small reductions of MMF_XAttn_Add's parameter gradients (C <= 32 series variables), two launches instead of six:
+// head_sums:  workgroup 0: LayerNorm(C)'s (sum dn*xhat, sum dn) over the rows; workgroup 1: the column sums of ddelta over the rows
+//             of windows WITH text (s_live) -- the row mask applied while reading, ddelta stays as it is
+// head_outer: d b_out[j] = sum_c W_res[c][j] s_live[c] and dW_res[c][j] = s_live[c] b_out[j], one thread per column j
+// (before: colsum2, mask_rows, colsum, matvec_t, outer as five launches on the chain in front of the backbone's backward)
+__global__ __launch_bounds__(1024) void head_sums_kernel(const float* __restrict__ dn, const float* __restrict__ xhat,
+                                                          const float* __restrict__ ddelta, const unsigned char* __restrict__ flag,
+                                                          int flag_div, int M, int C, int CT, float* __restrict__ out_xy,
+                                                          float* __restrict__ out_x, float* __restrict__ slive) {
+    __shared__ float ra[16 * 32], rb[16 * 32];
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a = 0.f, b = 0.f;
+    if (blockIdx.x == 0) {
+        if (tx < C) {
+#pragma unroll 8
+            for (int r = ty; r < M; r += RT) {
+                const float x = dn[(size_t)r * C + tx];
+                a = fmaf(x, xhat[(size_t)r * C + tx], a);
+                b += x;
+            }
+        }
+    } else if (tx < C) {
+#pragma unroll 8
+        for (int r = ty; r < M; r += RT) {
+            const float x = ddelta[(size_t)r * C + tx];
+            if (flag[r / flag_div]) a += x;
+        }
+    }
+    a = coset_sum(a, CT);
+    b = coset_sum(b, CT);
+    if (lane < CT) { ra[wave * CT + lane] = a; rb[wave * CT + lane] = b; }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { ta += ra[w * CT + threadIdx.x]; tb += rb[w * CT + threadIdx.x]; }
+        if (blockIdx.x == 0) { out_xy[threadIdx.x] = ta; out_x[threadIdx.x] = tb; }
+        else slive[threadIdx.x] = ta;
+    }
+}
+__global__ __launch_bounds__(256) void head_outer_kernel(const float* __restrict__ Wres, int d, const float* __restrict__ slive,
+                                                          const float* __restrict__ bout, int C, float* __restrict__ dbout,
+                                                          float* __restrict__ dWres) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    const float bj = bout[j];
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float sl = slive[c];
+        a = fmaf(Wres[(size_t)c * d + j], sl, a);
+        dWres[(size_t)c * d + j] = sl * bj;
+    }
+    dbout[j] = a;
+}
+bool head_sums_supported(int M, int C) { return C >= 1 && C <= 32 && (long)M * C <= (1L << 17); }
+int launch_head_sums(const float* dn, const float* xhat, const float* ddelta, const unsigned char* flag, int flag_div, int M, int C,
+                     float* out_xy, float* out_x, float* slive, hipStream_t s) {
+    if (!head_sums_supported(M, C) || flag_div <= 0) return IMMTSF_EUNSUPPORTED;
+    int CT = 1;
+    while (CT < C) CT <<= 1;
+    hipLaunchKernelGGL(head_sums_kernel, dim3(2), dim3(1024), 0, s, dn, xhat, ddelta, flag, flag_div, M, C, CT, out_xy, out_x, slive);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int launch_head_outer(const float* Wres, int d, const float* slive, const float* bout, int C, float* dbout, float* dWres, hipStream_t s) {
+    hipLaunchKernelGGL(head_outer_kernel, dim3(cdiv(d, 256)), dim3(256), 0, s, Wres, d, slive, bout, C, dbout, dWres);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 int launch_axpy(const float* src, float alpha, float* dst, int n, int accumulate, hipStream_t s) {
     if (n <= 0) return IMMTSF_OK;
     hipLaunchKernelGGL(axpy_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, src, alpha, dst, n, accumulate);

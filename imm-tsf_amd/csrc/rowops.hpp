@@ -67,3 +67,8 @@ int launch_query_bwd(const float* dqs_part, int B, int d, float scale, const flo
 int launch_fill(float* dst, float v, size_t n, hipStream_t s);
 // keep-mask export for tests: out[i] = 1 if element i of `site` is kept
 int launch_dropout_mask(uint64_t seed, uint64_t site, size_t n, float p, unsigned char* out, hipStream_t s);
+// the small reductions of MMF_XAttn_Add's parameter gradients (see rowops.hip): C <= 32 and M * C <= 2^17
+bool head_sums_supported(int M, int C);
+int launch_head_sums(const float* dn, const float* xhat, const float* ddelta, const unsigned char* flag, int flag_div, int M, int C,
+                     float* out_xy, float* out_x, float* slive, hipStream_t s);
+int launch_head_outer(const float* Wres, int d, const float* slive, const float* bout, int C, float* dbout, float* dWres, hipStream_t s);

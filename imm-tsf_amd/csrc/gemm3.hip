@@ -1,0 +1,637 @@
+// Persistent "ping-pong" bf16 GEMM for the many-rows regime of the fusion path (forward / data-gradient projections at
+// >= 512 windows per GPU: M = 16 k ... 260 k rows, N = 768 ... 1536, K = 768 ... 4096; reference call sites
+// fusions/TTF_T2V_XAttn.py:70-84 input_proj / KV_proj / MHA in-proj, fusions/MMF_XAttn_Add.py:36-47).
+//
+// Why a third GEMM: gemm2.hip's one-barrier-per-K-step ring runs these shapes at 4.5-9 % of the bf16 MFMA peak
+// (profiles/r02_*): per 256-row tile the ring prologue and the fp32 epilogue through LDS (~24 us per tile at K = 768) are as
+// long as the K loop itself and overlap with nothing, because a 128 KB ring leaves one workgroup per CU.  Here
+//   * ONE persistent 512-thread workgroup per CU walks its tiles; the LDS-DMA stream simply continues into the next tile's
+//     first K-tiles, so there is no ring prologue after the first tile;
+//   * the 8 waves are two groups of 4 (waves 0-3 own the top half of the tile's rows, waves 4-7 the bottom half); wave w and
+//     wave w+4 share a SIMD.  The groups run the same program one s_barrier apart: while one group issues its 16 MFMAs of a
+//     phase (one 64 x 32 quadrant of the wave's 128 x 64 tile over the 64-deep K-tile), the other reads its next fragments
+//     from LDS and issues its share of the LDS-DMA loads -- the matrix pipe of every SIMD always has one wave in its
+//     MFMA section (MI355X_MICROARCH "two waves per SIMD": split roles by wave >= 4);
+//   * LDS-DMA (buffer_load_dwordx4 ... lds) half-tiles (16 KB: 128 rows x 64 k) are issued one per phase, 1-1.25 K-tiles
+//     ahead of their first read, and retired by counted s_waitcnt vmcnt(N) twice per K-tile; raw s_barrier only;
+//   * the epilogue never touches LDS or a barrier: the product is formed transposed (acc = B-fragment x A-fragment), so a lane
+//     holds 4 consecutive columns of one row and stores 16 bytes (fp32) / 8 bytes (bf16) straight from its accumulators; the
+//     stores of quadrant q of tile i are issued in phase q of tile i+1's FIRST K-tile, in the wave's LDS-read section,
+//     just before that phase's MFMAs overwrite the quadrant (first MFMA of a tile takes C = 0);
+//   * bias / add_vec / row flags of a tile come through LDS by LDS-DMA as well ("epilogue vectors"), so no ordinary
+//     global load ever makes hipcc drain the LDS-DMA queue with a vmcnt(0).
+// Buffer descriptors do all the edge handling: rows past M and k-lines past K are out of range of the descriptor and
+// read as zeros; chunks past the K tail / column edge get an out-of-range offset; stores past M are dropped.
+//
+// LDS images are gemm2.hip's (same conflict-free permutations, verified there):
+//   R image (rows x 64 k, k contiguous): chunk (row, c) at position row*8 + (c ^ ((row>>1)&7)); fragment = ds_read_b128.
+//   T image (64 k-lines x 64-column blocks): chunk (k, n8) at k*8 + (n8 ^ sw(k)); fragment = 2 x ds_read_b64_tr_b16.
+#include "gemm.hpp"
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+// ds_read_b64_tr_b16 as inline asm: through the builtin hipcc cannot tell the read from the LDS-DMA writes in flight and puts
+// an s_waitcnt vmcnt(0) in front of every group of transposed reads (the whole load pipeline drained four times per K-tile).
+// The data is waited for by the read section's own s_waitcnt lgkmcnt(0) + sched_barrier ahead of the MFMAs that use it.
+// ds_read_b128 the same way: hipcc orders an LDS-DMA behind every pending ds_read it knows of (s_waitcnt lgkmcnt before the
+// buffer_load ... lds), which serialises a read section into "reads, their latency, then the DMA issue"; as asm the reads go
+// first and the DMA issue overlaps their latency.  (The DMA targets of a phase never overlap what the phase reads.)
+template <int OFF> __device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset immediate");
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset immediate");
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
+constexpr unsigned G3_OOB = 0xFFFFFF00u;        // a voffset no descriptor below reaches (num_records are clamped to it)
+constexpr int G3_BN = 256;
+
+struct G3Args {
+    const void* A;            // bf16
+    const void* B;            // bf16
+    float* C;                 // fp32 result or null
+    void* Ch;                 // bf16 result or null
+    const float* bias;        // [N] or null
+    const float* add_vec;     // [N] or null
+    const int* row_flag;      // int32 per row group: rows with row_flag[m / row_flag_div] == 0 are zeroed (before add_vec), or null
+    const int* dyn;           // device row count overriding M, or null
+    int row_flag_div;
+    unsigned rf_magic;        // floor(2^32 / row_flag_div) (0: div == 1): m / div = __umulhi(m, magic) (+1 after one check)
+    int M, N, K;
+    int lda, ldb, ldc, ldch;
+    float alpha;
+    int tiles_n;
+    unsigned tn_magic;        // id / tiles_n as __umulhi(id, magic); 0: tiles_n == 1
+};
+
+struct G3Page { unsigned int w[512]; };
+constexpr G3Page g3_make_page() {
+    G3Page p{};
+    for (int i = 256; i < 512; ++i) p.w[i] = 1u;
+    return p;
+}
+__device__ __attribute__((aligned(16))) const G3Page g3_zero_page = g3_make_page();     // 1 KiB of zeros, 1 KiB of int32 ones
+
+// where the LDS-DMA loads of one K-tile come from (all wave-uniform)
+struct G3Cur {
+    int id, kt;               // tile id (>= number of tiles: past the end), K-tile inside the tile
+    int row0, col0;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    int krem0;                // K range of the tile's reduction (0 past the end: every chunk invalid)
+    int ncolA, ncolB;         // T images: valid columns from the tile's first column on
+};
+
+// EPI: 0 = x = alpha * acc only (no epilogue vectors are loaded or read); 1 = bias / add_vec / row flags through LDS
+// VAR: 0 the kernel; 2 / 3 / 4 = timing experiments of tools/gemm3_bench.py probe (no LDS fragment reads / no LDS-DMA / neither:
+//      they compute garbage)
+template <bool TA, bool TB, int BM, int OUT, int EPI, int VAR = 0>
+__global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
+    constexpr int GH = BM / 2;                  // rows of a wave group
+    constexpr int TMW = GH / 16;                // 16-row MFMA tiles per wave (8 or 4)
+    constexpr int HM = TMW / 2;                 // ... per phase (row half mh of the wave's tile)
+    constexpr int GQ = GH / 2;                  // rows of one group in one row half (64 or 32)
+    constexpr int LPA = GH * 8 / 512;           // LDS-DMA loads per thread per A half-tile (2 or 1)
+    constexpr int LPB = 2;
+    constexpr int A_HALF = GH * 128, B_HALF = 128 * 128;
+    constexpr int STAGE = 2 * A_HALF + 2 * B_HALF;
+    constexpr int EVB = 8 * 1024;               // epilogue vectors of one tile: 1 KiB per wave
+    constexpr int NKIND = (OUT & 1) + ((OUT >> 1) & 1);
+    constexpr int NS = HM * 4 * NKIND;          // stores per phase of a storing K-tile
+    constexpr int XB = LPA + 2 * LPB;           // loads a thread issues in phase B (A row half 0 + both B halves of K-tile t+2)
+    constexpr int XA = LPA;                     // ... in phase A (A row half 1 of K-tile t+1)
+    constexpr int EV1 = EPI ? 1 : 0;
+    constexpr int ST_AUX = 0;        // default cache policy: nt result stores measured 1.1-1.5x slower, sc1 (write-through) 0-10 % slower (r03)
+    static_assert(BM == 256 || BM == 128, "tile heights");
+    auto cap63 = [](int v) constexpr { return v > 63 ? 63 : v; };      // a smaller count only waits for more
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * EVB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    int M = g.M;
+    if (g.dyn) M = *g.dyn;
+    const int N = g.N, K = g.K;
+    const int nk = (K + 63) >> 6;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = g.tiles_n;
+    const int nt = tiles_m * tiles_n;
+    const int G = gridDim.x;                    // a multiple of 8
+    const int first_id = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);    // round r: tile r*G + first_id, neighbours share an XCD
+    if (first_id >= nt) return;
+
+    // ---------------------------------------------------------------- LDS map of one stage (64-deep K-tile)
+    //   [ Am0 | Am1 | B0 | B1 ]   Am<mh>: row half mh of BOTH wave groups (group 0's GQ rows, then group 1's), what phase mh reads;
+    //                             B<nh>: columns nh*128 .. +127 of the tile (wave wc owns columns nh*128 + wc*32 .. +31 of each)
+    // ---------------------------------------------------------------- per-thread constants of the LDS-DMA loads
+    // position p = tid (+ 512 for a thread's second load) of a half-tile image
+    const int lda2 = g.lda * 2, ldb2 = g.ldb * 2;
+    int voA, kcA, c8A = 0, voB, kcB, c8B = 0;
+    int stepA;                                  // voffset of a thread's second A load relative to its first
+    {
+        const int row = tid >> 3, slot = tid & 7;
+        const int cR = slot ^ ((row >> 1) & 7);
+        const int k = tid >> 3, n8 = slot ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+        if (!TA) {
+            // image row r of Am<mh> is tile row (r / GQ) * GH + mh * GQ + r % GQ.  BM = 256: a thread's two loads are rows
+            // r and r + 64 = the same row of the two groups; BM = 128: one load, r = tid >> 3 covers both groups
+            const int trow = LPA == 2 ? row : (row / GQ) * GH + (row % GQ);
+            voA = trow * lda2 + cR * 16;
+            kcA = cR * 8;
+            stepA = GH * lda2;
+        } else {
+            // image column c of Am<mh>: same mapping on columns; a 64-column block is one group's (BM = 256) or both groups' 32
+            const int tcol = LPA == 2 ? n8 * 8 : ((n8 * 8) / GQ) * GH + ((n8 * 8) % GQ);
+            voA = k * lda2 + tcol * 2;
+            kcA = k;
+            c8A = tcol;
+            stepA = GH * 2;
+        }
+        if (!TB) { voB = row * ldb2 + cR * 16; kcB = cR * 8; }
+        else     { voB = k * ldb2 + n8 * 16;   kcB = k; c8B = n8 * 8; }
+    }
+    const int stepB = TB ? 128 : 64 * ldb2;                     // a thread's second B load: 64 rows / the next 64-column block
+    const int halfA = TA ? GQ * 2 : GQ * lda2;                  // row half 1 of A: GQ rows (columns) further inside each group
+    const int halfB = TB ? 256 : 128 * ldb2;                    // column half 1 of B
+    const int kstepA = TA ? 64 * lda2 : 128, kstepB = TB ? 64 * ldb2 : 128;      // bytes per K-tile
+
+    // ---------------------------------------------------------------- fragment read offsets (inside a half-tile)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // R image: byte offset of (row fr, k-chunk kk*4 + fq) of a 16-row tile; tiles are 2048 bytes apart
+    // T image: lane (fq, q = fr>>2, p = fr&3) reads k-lines kk*32 + fq*8 + q (and + 4), columns 16*tl + 4p .. 4p+3: chunk
+    //          n8 = 2*(tl&3) + (p>>1) of the k-line's block (tl>>2), stored at slot n8 ^ sw
+    int ofA[4], ofB[2];       // R: [kk]; T: A by tile ii of the phase (this wave's group folded in), B by jj
+    {
+        const int q = fr >> 2, p = fr & 3, sw = ((q >> 1) << 1) | ((fq & 1) << 2);
+        const int tbase = ((fq * 8 + q) << 7) + (p & 1) * 8;
+        if (!TA) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ofA[kk] = (grp * GQ + fr) * 128 + (((kk * 4 + fq) ^ (fr >> 1)) << 4);
+            ofA[2] = ofA[3] = 0;
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {          // tile grp*HM + ii of the half-tile
+                const int tl = grp * HM + (ii < HM ? ii : 0);
+                ofA[ii] = (tl >> 2) * 8192 + tbase + (((2 * (tl & 3) + (p >> 1)) ^ sw) << 4);
+            }
+        }
+        if (!TB) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) ofB[kk] = (wc * 32 + fr) * 128 + (((kk * 4 + fq) ^ (fr >> 1)) << 4);
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {          // tile wc*2 + jj of the half: block wc>>1, tl & 3 = (wc&1)*2 + jj
+                const int t = (wc & 1) * 2 + jj;
+                ofB[jj] = (wc >> 1) * 8192 + tbase + (((2 * t + (p >> 1)) ^ sw) << 4);
+            }
+        }
+    }
+    // A fragment: 16-row tile II of this wave's rows in the Am half-tile at LDS byte offset `base`, k-half KK
+    auto fragA = [&](unsigned base, auto ii_c, auto kk_c) __attribute__((always_inline)) -> bf16x8 {
+        constexpr int ii = decltype(ii_c)::value, kk = decltype(kk_c)::value;
+        if constexpr (VAR == 2 || VAR == 4) {
+            bf16x8 d;
+            asm volatile("" : "=v"(d));
+            return d;
+        } else if constexpr (!TA) {
+            return lds_b128<ii * 2048>(lds0 + base + (unsigned)ofA[kk]);
+        } else {
+            const unsigned a0 = lds0 + base + (unsigned)ofA[ii];
+            const s16x4 lo = lds_tr16<kk * 4096>(a0);
+            const s16x4 hi = lds_tr16<kk * 4096 + 512>(a0);
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto fragB = [&](unsigned base, auto jj_c, auto kk_c) __attribute__((always_inline)) -> bf16x8 {     // tile wc*2 + jj of a B half-tile
+        constexpr int jj = decltype(jj_c)::value, kk = decltype(kk_c)::value;
+        if constexpr (VAR == 2 || VAR == 4) {
+            bf16x8 d;
+            asm volatile("" : "=v"(d));
+            return d;
+        } else if constexpr (!TB) {
+            return lds_b128<jj * 2048>(lds0 + base + (unsigned)ofB[kk]);
+        } else {
+            const unsigned a0 = lds0 + base + (unsigned)ofB[jj];
+            const s16x4 lo = lds_tr16<kk * 4096>(a0);
+            const s16x4 hi = lds_tr16<kk * 4096 + 512>(a0);
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+
+    // ---------------------------------------------------------------- load cursors
+    // bytes of `rows` rows of pitch `pitch2` bytes (minus `sub`), clamped to the largest num_records used here -- on the scalar unit
+    auto nrec_of = [&](int rows, int pitch2, int sub) __attribute__((always_inline)) -> int {
+        const unsigned r = rows > 0 ? (unsigned)rows : 0u;
+        const unsigned lo = r * (unsigned)pitch2, hi = __umulhi(r, (unsigned)pitch2);
+        unsigned v = hi ? G3_OOB : (lo < G3_OOB ? lo : G3_OOB);
+        v -= (unsigned)sub;       // sub < v by construction (a tile's first column lies inside the first k-line); NOT a saturating
+                                  // subtract: that one only exists on the VALU and drags the descriptor into VGPRs (waterfall loops)
+        return (int)v;
+    };
+    auto set_tile = [&](G3Cur& c, int id) __attribute__((always_inline)) {
+        c.id = id;
+        c.kt = 0;
+        const bool ok = id < nt;
+        const int idc = ok ? id : 0;
+        const int tm = g.tn_magic ? (int)__umulhi((unsigned)idc, g.tn_magic) : idc;
+        const int tn = idc - tm * tiles_n;
+        c.row0 = tm * BM;
+        c.col0 = tn * G3_BN;
+        c.krem0 = ok ? K : 0;
+        const char* pa = reinterpret_cast<const char*>(g.A);
+        const char* pb = reinterpret_cast<const char*>(g.B);
+        if (!TA) c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + (size_t)(unsigned)c.row0 * (unsigned)lda2), (short)0, nrec_of(M - c.row0, lda2, 0), 0x00020000);
+        else     c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + (size_t)c.row0 * 2), (short)0, nrec_of(K, lda2, c.row0 * 2), 0x00020000);
+        if (!TB) c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + (size_t)(unsigned)c.col0 * (unsigned)ldb2), (short)0, nrec_of(N - c.col0, ldb2, 0), 0x00020000);
+        else     c.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(pb + (size_t)c.col0 * 2), (short)0, nrec_of(K, ldb2, c.col0 * 2), 0x00020000);
+        c.ncolA = M - c.row0;
+        c.ncolB = N - c.col0;
+    };
+    auto advance = [&](G3Cur& c) __attribute__((always_inline)) {
+        c.kt += 1;
+        if (c.kt == nk) set_tile(c, c.id + G);
+    };
+    // one half-tile of cursor c's K-tile into LDS at `dst` (wave-uniform): A row half mh / B column half nh
+    auto issueA = [&](const G3Cur& c, int mh, unsigned char* dst) __attribute__((always_inline)) {
+        if (VAR == 3 || VAR == 4) return;
+        const int krem = c.krem0 - c.kt * 64;
+        const unsigned uadd = (unsigned)(c.kt * kstepA + mh * halfA);
+#pragma unroll
+        for (int i = 0; i < LPA; ++i) {
+            bool ok = kcA < krem;
+            if (TA) ok = ok & (mh * GQ + i * GH + c8A + 8 <= c.ncolA);
+            const unsigned v = ok ? (unsigned)voA + (unsigned)(i * stepA) + uadd : G3_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_vp)(dst + i * 8192 + wave * 1024), 16, (int)v, 0, 0, 0);
+        }
+    };
+    auto issueB = [&](const G3Cur& c, int nh, unsigned char* dst) __attribute__((always_inline)) {
+        if (VAR == 3 || VAR == 4) return;
+        const int krem = c.krem0 - c.kt * 64;
+        const unsigned uadd = (unsigned)(c.kt * kstepB + nh * halfB);
+#pragma unroll
+        for (int i = 0; i < LPB; ++i) {
+            bool ok = kcB < krem;
+            if (TB) ok = ok & (nh * 128 + i * 64 + c8B + 8 <= c.ncolB);
+            const unsigned v = ok ? (unsigned)voB + (unsigned)(i * stepB) + uadd : G3_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rb, (lds_vp)(dst + i * 8192 + wave * 1024), 16, (int)v, 0, 0, 0);
+        }
+    };
+    // epilogue vectors of the tile at (row0, col0): ONE 16-byte-per-lane LDS-DMA load per wave (every wave's vmcnt sees the
+    // same count), source picked per wave without a branch:
+    //   wave 0  bias[col0 .. col0+255]      -> ev + 0       (absent: zeros)
+    //   wave 1  add_vec[col0 .. col0+255]   -> ev + 1024    (absent: zeros)
+    //   waves 2-5  lane l: the 16 bytes at &row_flag[(row0 + (w-2)*64 + l) / div] -> ev + 2048 + (w-2)*1024 + l*16: the flag of
+    //           tile row r is the int at ev + 2048 + r*16 (absent: ones)
+    //   waves 6, 7  zeros (dummy)
+    auto issueEV = [&](int row0, int col0, unsigned char* ev) __attribute__((always_inline)) {
+        const char* zp = reinterpret_cast<const char*>(g3_zero_page.w);      // 1 KiB of zeros, then 1 KiB of int32 ones
+        const float* vec = wave == 0 ? g.bias : g.add_vec;
+        const bool isvec = wave < 2 && vec != nullptr;
+        const bool isflag = wave >= 2 && wave < 6;
+        const bool realflag = isflag && g.row_flag != nullptr;
+        const char* base = isvec ? reinterpret_cast<const char*>(vec + col0)
+                         : realflag ? reinterpret_cast<const char*>(g.row_flag)
+                         : isflag ? zp + 1024 : zp;
+        const int nrec = isvec ? (N - col0) * 4 : realflag ? (int)(((unsigned)(M - 1) / (unsigned)g.row_flag_div + 1) * 4) : 1024;
+        const unsigned row = (unsigned)(row0 + (wave - 2) * 64 + lane);
+        unsigned q = g.rf_magic ? __umulhi(row, g.rf_magic) : row;
+        q += (row - q * (unsigned)g.row_flag_div >= (unsigned)g.row_flag_div) ? 1u : 0u;
+        const int vo = realflag ? (int)(q * 4) : lane * 16;
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, nrec, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_vp)(ev + wave * 1024), 16, vo, 0, 0, 0);
+    };
+
+    // ---------------------------------------------------------------- accumulators and the epilogue
+    f32x4 acc[TMW][4];
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, (short)0, nrec_of(M, g.ldc * 4, 0), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)g.Ch, (short)0, nrec_of(M, g.ldch * 2, 0), 0x00020000);
+    const unsigned ldc4 = (unsigned)g.ldc * 4u, ldh2 = (unsigned)g.ldch * 2u;
+    // store row half mh of this wave's accumulators (HM x 4 MFMA tiles) of the tile at (row0, col0); ev = that tile's epilogue
+    // vectors in LDS.  x = rowflag(alpha * acc + bias) + add_vec.  Rows past M are out of range of the descriptors (dropped);
+    // columns past N get an out-of-range offset.
+    auto store_half = [&](auto mh_c, int row0, int col0, const unsigned char* ev) __attribute__((always_inline)) {
+        constexpr int mh = decltype(mh_c)::value;
+        // an opaque zero: keeps the offsets below from being hoisted out of the tile loop into two dozen long-lived VGPRs
+        int oz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+        const int colw = wc * 32 + fq * 4 + oz;                     // column inside the tile of this lane's 4 values, j = 0
+        const int rloc = grp * GH + mh * GQ + fr;                   // row inside the tile, ii = 0
+        const unsigned vrow = (unsigned)(row0 + rloc);
+        const unsigned voC = vrow * ldc4 + (unsigned)(col0 + colw) * 4u, voH = vrow * ldh2 + (unsigned)(col0 + colw) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ct = colw + (j >> 1) * 128 + (j & 1) * 16;
+            const bool cok = col0 + ct < N;                          // N % 4 == 0: a lane's 4 columns are in or out together
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, a4 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI) {
+                b4 = *reinterpret_cast<const f32x4*>(ev + ct * 4);
+                a4 = *reinterpret_cast<const f32x4*>(ev + 1024 + ct * 4);
+            }
+#pragma unroll
+            for (int ii = 0; ii < HM; ++ii) {
+                f32x4 v = acc[mh * HM + ii][j];
+                if (EPI) {
+                    const float live = *reinterpret_cast<const int*>(ev + 2048 + (rloc + ii * 16) * 16) != 0 ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (g.alpha * v[e] + b4[e]) * live + a4[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e];
+                }
+                if (OUT & 1) {
+                    const unsigned vo = cok ? voC + (unsigned)(ii * 16) * ldc4 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 4) : G3_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rC, (int)vo, 0, ST_AUX);
+                }
+                if (OUT & 2) {
+                    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+                    const unsigned vo = cok ? voH + (unsigned)(ii * 16) * ldh2 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 2) : G3_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), rH, (int)vo, 0, ST_AUX);
+                }
+            }
+        }
+    };
+    // a tile's accumulators restart from zero: plain v_mov in the LDS-read section (while the SIMD's other wave has the matrix
+    // pipe), so every MFMA of the kernel accumulates in place -- an MFMA with C = 0 is a second definition of the accumulator
+    // and made hipcc spill all 128 of them around the first K-tile of every tile
+    auto zero_half = [&](auto mh_c) __attribute__((always_inline)) {
+        constexpr int mh = decltype(mh_c)::value;
+#pragma unroll
+        for (int ii = 0; ii < HM; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float z0, z1, z2, z3;       // (opaque to the optimiser, which would otherwise fold the zero back into the MFMA's C)
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                acc[mh * HM + ii][j] = f32x4{z0, z1, z2, z3};
+            }
+    };
+
+    // ---------------------------------------------------------------- prologue
+    G3Cur c1, c2;             // c1: the K-tile after the one being computed; c2: the one after that
+    set_tile(c1, first_id);
+    // K-tile 0 of the first tile completely; A row half 0 and both B halves of K-tile 1
+    issueA(c1, 0, smem);
+    issueA(c1, 1, smem + A_HALF);
+    issueB(c1, 0, smem + 2 * A_HALF);
+    issueB(c1, 1, smem + 2 * A_HALF + B_HALF);
+    advance(c1);
+    issueA(c1, 0, smem + STAGE);
+    issueB(c1, 0, smem + STAGE + 2 * A_HALF);
+    issueB(c1, 1, smem + STAGE + 2 * A_HALF + B_HALF);
+    c2 = c1;
+    advance(c2);
+    wait_vm<(VAR == 3 || VAR == 4) ? 0 : XB>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) __builtin_amdgcn_s_barrier();         // the second group runs one barrier behind
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------------------------------------------------------- one K-tile = 2 phases (row halves of the wave's tile)
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    bf16x8 af[2][HM], bf[2][4];          // A fragments of the current row half, B fragments of all 4 column tiles (kept for phase B)
+    int buf = 0, evsel = 0;
+    int prow0 = 0, pcol0 = 0;            // the tile whose accumulators are complete (being stored)
+    auto mfma_half = [&](auto mh_c) __attribute__((always_inline)) {
+        constexpr int mh = decltype(mh_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int ii = 0; ii < HM; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4& a = acc[mh * HM + ii][j];
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], af[kk][ii], a, 0, 0, 0);
+                }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto close_read = [&]() __attribute__((always_inline)) {          // end of a read section: own LDS reads retired, then the barrier
+        wait_lgkm0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto close_mfma = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---------------------------------------------------------------- the K-tile loop, flattened over this workgroup's tiles
+    // ONE loop body (hipcc's register allocation of several specialised copies of it spilled the accumulators); what differs
+    // between K-tiles is decided by wave-uniform flags:
+    //   first : first K-tile of an output tile -- loads the tile's epilogue vectors, zeroes each row half before its MFMAs
+    //   store : first && a previous tile exists -- that tile's row half mh is stored in phase mh, before the zeroing
+    //   pstore: the previous K-tile was a `store` one (its stores sit between the loads the counted waits skip)
+    // (the launcher guarantees nk >= 2, so a `store` K-tile is never followed by another `first` one)
+    //
+    // Loads in flight.  Phase A of K-tile t issues A row half 1 of K-tile t+1 (XA loads); phase B issues A row half 0 and both B
+    // halves of K-tile t+2 (XB loads) into the stage being computed: phase A was the last reader of those three regions and every
+    // wave has retired its phase-A reads (lgkmcnt(0) before the barrier that closes a read section).  Every load gets one full
+    // K-tile of flight: the wait of phase B retires what phase B of the previous K-tile issued (next read: phase A of t+1),
+    // the wait of phase A retires what phase A of the previous K-tile issued (next read: phase B of t).  Each wave waits for its
+    // own loads before the barrier that closes its read section; the reads come one read section later.
+    int id = first_id, kt = 0, row0 = 0, col0 = 0;
+    bool have_prev = false;
+    for (;;) {
+        const bool first = kt == 0;
+        const bool store = first && have_prev;
+        const bool pstore = kt == 1 && have_prev;
+        if (first) {
+            const int tm = g.tn_magic ? (int)__umulhi((unsigned)id, g.tn_magic) : id;
+            row0 = tm * BM;
+            col0 = (id - tm * tiles_n) * G3_BN;
+        }
+        unsigned char* st = smem + buf * STAGE;
+        unsigned char* nx = smem + (buf ^ 1) * STAGE;
+        const unsigned sA0 = (unsigned)(buf * STAGE), sA1 = sA0 + A_HALF;
+        const unsigned sB0 = sA0 + 2 * A_HALF, sB1 = sB0 + B_HALF;
+        const unsigned char* evp = smem + 2 * STAGE + (evsel ^ 1) * EVB;        // vectors of the tile being stored
+        // ---- phase A: row half 0 x all 4 column tiles
+        static_for<2>([&](auto kk) {
+            static_for<2>([&](auto jj) { bf[kk][jj] = fragB(sB0, jj, kk); });
+            static_for<2>([&](auto jj) { bf[kk][2 + jj] = fragB(sB1, jj, kk); });
+            static_for<HM>([&](auto ii) { af[kk][ii] = fragA(sA0, ii, kk); });
+        });
+        issueA(c1, 1, nx + A_HALF);
+        if (EPI && first) issueEV(row0, col0, smem + 2 * STAGE + evsel * EVB);
+        if (VAR != 3 && VAR != 4) {
+            // outstanding and younger than phase A's loads of the previous K-tile: [stores of its phase A] phase B's XB [stores of its
+            // phase B] this phase's XA [+ the epilogue vectors]
+            if (first) wait_vm<cap63(XB + XA + EV1)>();
+            else if (pstore) wait_vm<cap63(XB + XA + 2 * NS)>();
+            else wait_vm<XB + XA>();
+        }
+        if (store) store_half(I0{}, prow0, pcol0, evp);
+        if (first) zero_half(I0{});
+        close_read();
+        mfma_half(I0{});
+        close_mfma();
+        // ---- phase B: row half 1
+        static_for<2>([&](auto kk) { static_for<HM>([&](auto ii) { af[kk][ii] = fragA(sA1, ii, kk); }); });
+        issueA(c2, 0, st);
+        issueB(c2, 0, st + 2 * A_HALF);
+        issueB(c2, 1, st + 2 * A_HALF + B_HALF);
+        if (VAR != 3 && VAR != 4) {
+            // younger than phase B's loads of the previous K-tile: [stores of the previous K-tile's phase B] phase A's XA [+ vectors]
+            // [stores of phase A] this phase's XB
+            if (store) wait_vm<cap63(XA + EV1 + NS + XB)>();
+            else if (first) wait_vm<cap63(XA + EV1 + XB)>();
+            else if (pstore) wait_vm<cap63(NS + XA + XB)>();
+            else wait_vm<XA + XB>();
+        }
+        if (store) store_half(I1{}, prow0, pcol0, evp);
+        if (first) zero_half(I1{});
+        close_read();
+        mfma_half(I1{});
+        close_mfma();
+        c1 = c2;
+        advance(c2);
+        buf ^= 1;
+        kt += 1;
+        if (kt == nk) {
+            kt = 0;
+            have_prev = true;
+            prow0 = row0;
+            pcol0 = col0;
+            evsel ^= 1;
+            id += G;
+            if (id >= nt) break;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();         // pairs with the second group's last barrier
+    __builtin_amdgcn_sched_barrier(0);
+    {   // the last tile's accumulators
+        const unsigned char* evp = smem + 2 * STAGE + (evsel ^ 1) * EVB;
+        wait_vm<0>();           // (its epilogue vectors landed long ago; the dummy loads past the end still target the ring)
+        store_half(I0{}, prow0, pcol0, evp);
+        store_half(I1{}, prow0, pcol0, evp);
+    }
+}
+
+int g3_bm = 0, g3_grid = 0, g3_var = 0;      // tool overrides (immtsf_debug_gemm3_config)
+
+template <bool TA, bool TB, int BM, int EPI>
+int launch3_epi(const G3Args& g, int grid, hipStream_t stream) {
+    const int out = (g.C ? 1 : 0) | (g.Ch ? 2 : 0);
+    switch (out) {
+        case 1: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 1, EPI>), dim3(grid), dim3(512), 0, stream, g); break;
+        case 2:
+            if constexpr (BM == 256 && EPI == 0 && !TA && !TB) {     // timing experiments (tools/gemm3_bench.py probe); 2-4 compute garbage
+                if (g3_var == 2) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 2>), dim3(grid), dim3(512), 0, stream, g); break; }
+                if (g3_var == 3) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 3>), dim3(grid), dim3(512), 0, stream, g); break; }
+                if (g3_var == 4) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 4>), dim3(grid), dim3(512), 0, stream, g); break; }
+            }
+            hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI>), dim3(grid), dim3(512), 0, stream, g);
+            break;
+        case 3: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 3, EPI>), dim3(grid), dim3(512), 0, stream, g); break;
+        default: return IMMTSF_EINVAL;
+    }
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+template <bool TA, bool TB, int BM>
+int launch3_out(const G3Args& g, int grid, hipStream_t stream) {
+    if (g.bias || g.add_vec || g.row_flag) return launch3_epi<TA, TB, BM, 1>(g, grid, stream);
+    return launch3_epi<TA, TB, BM, 0>(g, grid, stream);
+}
+
+inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int immtsf_debug_gemm3_config(int bm, int grid) {
+    g3_bm = bm & 0xffff;         // bits 16..: experimental kernel variant (tools only)
+    g3_var = bm >> 16;
+    g3_grid = grid;
+    return 0;
+}
+
+// layout: GEMM_NT / GEMM_NN / GEMM_TN.  Returns IMMTSF_EUNSUPPORTED for what this kernel does not do (the caller falls back
+// to gemm2): K <= 64, unaligned operands, leading dimensions that are not whole 16-byte chunks, results beyond 4 GiB.
+int immtsf_launch_gemm3(int layout, const void* A, int lda, const void* B, int ldb, float* C, int ldc, void* Ch, int ldch,
+                        const float* bias, const float* add_vec, const int* row_flag, int row_flag_div, int M, int N, int K,
+                        float alpha, int act, const int* dyn_rows, hipStream_t stream) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 64 || act != 0) return IMMTSF_EUNSUPPORTED;
+    if (!A || !B || (!C && !Ch) || !al16p(A) || !al16p(B) || (lda % 8) || (ldb % 8) || (N % 8)) return IMMTSF_EUNSUPPORTED;
+    if (layout == GEMM_NT && (K % 8)) return IMMTSF_EUNSUPPORTED;
+    if (layout == GEMM_NN && (K % 8)) return IMMTSF_EUNSUPPORTED;
+    if (layout == GEMM_TN && (M % 8)) return IMMTSF_EUNSUPPORTED;
+    if (C && (!al16p(C) || (ldc % 4) || (long)M * ldc * 4 > (long)G3_OOB)) return IMMTSF_EUNSUPPORTED;
+    if (Ch && ((reinterpret_cast<uintptr_t>(Ch) & 7) || (ldch % 4) || (long)M * ldch * 2 > (long)G3_OOB)) return IMMTSF_EUNSUPPORTED;
+    if (bias && !al16p(bias)) return IMMTSF_EUNSUPPORTED;
+    if (add_vec && !al16p(add_vec)) return IMMTSF_EUNSUPPORTED;
+    if (row_flag && row_flag_div <= 0) return IMMTSF_EINVAL;
+    if (dyn_rows && layout == GEMM_TN) return IMMTSF_EUNSUPPORTED;
+    // operand extents must fit a 32-bit buffer offset
+    const long ea = layout == GEMM_TN ? (long)K * lda * 2 : (long)M * lda * 2;
+    const long eb = layout == GEMM_NT ? (long)N * ldb * 2 : (long)K * ldb * 2;
+    if (ea > (long)G3_OOB || eb > (long)G3_OOB) return IMMTSF_EUNSUPPORTED;
+    G3Args g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.Ch = Ch;
+    g.bias = bias; g.add_vec = add_vec; g.row_flag = row_flag; g.dyn = dyn_rows;
+    g.row_flag_div = row_flag_div > 0 ? row_flag_div : 1;
+    g.rf_magic = g.row_flag_div > 1 ? (unsigned)(0x100000000ull / (unsigned)g.row_flag_div) : 0u;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldch = ldch;
+    g.alpha = alpha;
+    g.tiles_n = cdiv(N, G3_BN);
+    g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
+    // tile height: 256 rows unless that leaves the last round of tiles mostly empty and 128-row tiles fill it
+    int bm = g3_bm;
+    if (bm == 0) {
+        const long t256 = (long)cdiv(M, 256) * g.tiles_n, t128 = (long)cdiv(M, 128) * g.tiles_n;
+        const double e256 = (double)t256 / (256.0 * cdiv((int)t256, 256)), e128 = (double)t128 / (256.0 * cdiv((int)t128, 256));
+        bm = (e256 >= 0.85 || e256 >= e128) ? 256 : 128;
+    }
+    const long nt = (long)cdiv(M, bm) * g.tiles_n;
+    if (nt * 8 >= 0x7fffffff) return IMMTSF_EUNSUPPORTED;
+    int grid = g3_grid > 0 ? g3_grid : 256;
+    if (!dyn_rows && nt < grid) grid = (int)((nt + 7) / 8 * 8);
+    grid = (grid + 7) / 8 * 8;
+    immtsf_gemm_note_grid((long)grid * 512);
+#define G3_LAUNCH(TA_, TB_) (bm == 256 ? launch3_out<TA_, TB_, 256>(g, grid, stream) : launch3_out<TA_, TB_, 128>(g, grid, stream))
+    switch (layout) {
+        case GEMM_NT: return G3_LAUNCH(false, false);
+        case GEMM_NN: return G3_LAUNCH(false, true);
+        default: return G3_LAUNCH(true, true);
+    }
+#undef G3_LAUNCH
+}
+
+// debug / test / tool entry (declared in include/immtsf.h)
+extern "C" int immtsf_gemm3_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc,
+                                 void* Ch, int32_t ldch, const float* bias, const float* add_vec, const int32_t* row_flag,
+                                 int32_t row_flag_div, int32_t M, int32_t N, int32_t K, float alpha, int32_t act,
+                                 const int32_t* dyn_rows, void* stream) {
+    return immtsf_launch_gemm3(layout, A, lda, B, ldb, C, ldc, Ch, ldch, bias, add_vec, row_flag, row_flag_div, M, N, K, alpha, act,
+                               dyn_rows, static_cast<hipStream_t>(stream));
+}

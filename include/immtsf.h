@@ -606,6 +606,18 @@ int immtsf_gemm_bf16(int32_t layout, const void* A, int32_t lda, const void* B, 
 /* tuning aid for tools/gemm2_bench.py: force a tile variant, a split-K factor, the XCD tile order (-1 = heuristic) */
 int immtsf_debug_gemm2_config(int32_t variant, int32_t splitk, int32_t xcd);
 
+/* The persistent many-rows GEMM (csrc/gemm3.hip): same operands and layouts as immtsf_gemm_bf16, for M >> 256 with
+ * K > 64 -- the fusion projections at >= 512 windows per GPU (fusions/TTF_T2V_XAttn.py:70-84 input_proj / KV_proj /
+ * attn in-proj, fusions/MMF_XAttn_Add.py:36-47).  One 512-thread workgroup per CU walks 256 x 256 (or 128 x 256) tiles;
+ * results as fp32 (C, may be NULL) and/or bf16 (Ch, may be NULL), x = rowflag(alpha * acc + bias) + add_vec, where
+ * row_flag is int32 per group of row_flag_div rows (zero: the rows are zeroed before add_vec).  dyn_rows: optional device
+ * int32 overriding M (NT / NN).  IMMTSF_EUNSUPPORTED (use immtsf_gemm_bf16): K <= 64, act != 0, misaligned operands. */
+int immtsf_gemm3_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc, void* Ch,
+                      int32_t ldch, const float* bias, const float* add_vec, const int32_t* row_flag, int32_t row_flag_div,
+                      int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const int32_t* dyn_rows, immtsf_stream_t stream);
+/* tuning aid for tools/gemm3_bench.py: force the tile height (256 / 128, 0 = heuristic) and the grid (0 = 256 workgroups) */
+int immtsf_debug_gemm3_config(int32_t bm, int32_t grid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Correctness + graph-timed benchmark of the persistent many-rows GEMM (csrc/gemm3.hip, through immtsf_gemm3_bf16) against
+gemm2 (immtsf_gemm_bf16, heuristic variant) and the vendor GEMM (torch.matmul on bf16 = hipBLASLt) on the same box.
+usage: python tools/gemm3_bench.py [check|bigm|full] [out=bf16|f32|both]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+import torch  # noqa: E402
+
+from immtsf import _lib  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+mode = sys.argv[1] if len(sys.argv) > 1 else "check"
+LAY = ["NT", "NN", "TN"]
+
+
+def graph_time(run, n=20, reps=5):
+    for _ in range(2):
+        run()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            run()
+    g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / n * 1e3)
+    ts.sort()
+    return ts[0], ts[len(ts) // 2]
+
+
+def operands(layout, M, N, K, scale=1.0):
+    A = torch.randn((M, K) if layout < 2 else (K, M), device=dev) * scale
+    B = torch.randn((N, K) if layout == 0 else (K, N), device=dev) * scale
+    return A.bfloat16(), B.bfloat16()
+
+
+def ref_of(layout, Ah, Bh):
+    a, b = Ah.float(), Bh.float()
+    return (a @ b.t()) if layout == 0 else (a @ b) if layout == 1 else (a.t() @ b)
+
+
+LDA_OVERRIDE = int(os.environ["G3_LDA"]) if "G3_LDA" in os.environ else None     # timing experiments only (results are garbage)
+LDC_OVERRIDE = int(os.environ["G3_LDC"]) if "G3_LDC" in os.environ else None     # 0: every row of the result lands on row 0 (no write traffic past L2)
+
+
+def run3(layout, Ah, Bh, C, Ch, M, N, K, bias=None, add=None, flag=None, div=1, alpha=1.0, dyn=None):
+    lda = Ah.shape[1] if LDA_OVERRIDE is None else LDA_OVERRIDE
+    ldc = N if LDC_OVERRIDE is None else LDC_OVERRIDE
+    return lib.immtsf_gemm3_bf16(layout, _lib.ptr(Ah), lda, _lib.ptr(Bh), Bh.shape[1], _lib.ptr(C), ldc, _lib.ptr(Ch), ldc,
+                                 _lib.ptr(bias), _lib.ptr(add), _lib.ptr(flag), div, M, N, K, alpha, 0, _lib.ptr(dyn), _lib.stream_ptr())
+
+
+def run2(layout, Ah, Bh, C, Ch, M, N, K):
+    return lib.immtsf_gemm_bf16(layout, _lib.ptr(Ah), Ah.shape[1], _lib.ptr(Bh), Bh.shape[1], _lib.ptr(C), N, _lib.ptr(Ch), N,
+                                None, None, M, N, K, 1.0, 0, 0, None, 0, None, _lib.stream_ptr())
+
+
+def check(layout, M, N, K, bm=0, out="both", extras=False, grid=0):
+    torch.manual_seed(M * 7 + N * 3 + K + layout)
+    Ah, Bh = operands(layout, M, N, K)
+    C = torch.full((M, N), -7.0, device=dev) if out in ("f32", "both") else None
+    Ch = torch.full((M, N), -7.0, device=dev, dtype=torch.bfloat16) if out in ("bf16", "both") else None
+    bias = torch.randn(N, device=dev) if extras else None
+    add = torch.randn(N, device=dev) if extras else None
+    div = 5
+    flag = (torch.rand((M + div - 1) // div, device=dev) > 0.3).int() if extras else None
+    alpha = 0.5 if extras else 1.0
+    lib.immtsf_debug_gemm3_config(bm, grid)
+    rc = run3(layout, Ah, Bh, C, Ch, M, N, K, bias, add, flag, div, alpha)
+    torch.cuda.synchronize()
+    lib.immtsf_debug_gemm3_config(0, 0)
+    if rc != 0:
+        return None
+    ref = ref_of(layout, Ah, Bh) * alpha
+    if extras:
+        ref = ref + bias
+        ref = ref * flag.repeat_interleave(div)[:M, None].float()
+        ref = ref + add
+    den = ref.abs().max()
+    e = float((C - ref).abs().max() / den) if C is not None else 0.0
+    eh = float((Ch.float() - ref).abs().max() / den) if Ch is not None else 0.0
+    return e, eh
+
+
+def bench(layout, M, N, K, out, bm=0, grid=0):
+    Ah, Bh = operands(layout, M, N, K)
+    C = torch.zeros(M, N, device=dev) if out in ("f32", "both") else None
+    Ch = torch.zeros(M, N, device=dev, dtype=torch.bfloat16) if out in ("bf16", "both") else None
+    lib.immtsf_debug_gemm3_config(bm, grid)
+    if run3(layout, Ah, Bh, C, Ch, M, N, K) != 0:
+        lib.immtsf_debug_gemm3_config(0, 0)
+        return None
+    r = graph_time(lambda: run3(layout, Ah, Bh, C, Ch, M, N, K))
+    lib.immtsf_debug_gemm3_config(0, 0)
+    return r
+
+
+def bench_g2(layout, M, N, K, out):
+    Ah, Bh = operands(layout, M, N, K)
+    C = torch.zeros(M, N, device=dev) if out in ("f32", "both") else None
+    Ch = torch.zeros(M, N, device=dev, dtype=torch.bfloat16) if out in ("bf16", "both") else None
+    if run2(layout, Ah, Bh, C, Ch, M, N, K) != 0:
+        return None
+    return graph_time(lambda: run2(layout, Ah, Bh, C, Ch, M, N, K))
+
+
+def bench_vendor(layout, M, N, K):
+    Ah, Bh = operands(layout, M, N, K)
+    o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    if layout == 0:
+        f = lambda: torch.matmul(Ah, Bh.t(), out=o)
+    elif layout == 1:
+        f = lambda: torch.matmul(Ah, Bh, out=o)
+    else:
+        f = lambda: torch.matmul(Ah.t(), Bh, out=o)
+    return graph_time(f)
+
+
+bad = 0
+if mode in ("check", "full", "bigm"):
+    print("== correctness (rel. max error vs fp32 matmul of the bf16 operands; fp32 out / bf16 out)", flush=True)
+    cases = [(0, 2048, 768, 768), (0, 1000, 768, 200), (0, 513, 1152, 136), (0, 4096, 1536, 768), (0, 300, 264, 72), (0, 70000, 768, 768),
+             (1, 2048, 768, 768), (1, 1117, 1152, 768), (1, 300, 264, 136), (1, 4096, 768, 1536),
+             (2, 768, 768, 2048), (2, 1536, 768, 1117), (2, 264, 136, 300)]
+    if mode == "bigm":
+        cases = [(0, 2048, 768, 768), (1, 2048, 768, 768), (0, 513, 1152, 136)]
+    for layout, M, N, K in cases:
+        for bm in (256, 128):
+            for extras in (False, True):
+                for out in (("both",) if not extras else ("both", "bf16", "f32")):
+                    r = check(layout, M, N, K, bm, out, extras)
+                    if r is None:
+                        print(f"{LAY[layout]} {M}x{N}x{K} bm{bm} unsupported", flush=True)
+                        continue
+                    ok = r[0] < 2e-5 and r[1] < 1e-2
+                    bad += 0 if ok else 1
+                    print(f"{LAY[layout]} {M}x{N}x{K} bm{bm} out={out:4s} extras={int(extras)} err {r[0]:.1e} / {r[1]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    # device-side row count
+    M, N, K = 3000, 768, 768
+    Ah, Bh = operands(0, M, N, K)
+    C = torch.full((M, N), -7.0, device=dev)
+    dyn = torch.tensor([1733], device=dev, dtype=torch.int32)
+    run3(0, Ah, Bh, C, None, M, N, K, dyn=dyn)
+    torch.cuda.synchronize()
+    ref = ref_of(0, Ah[:1733], Bh)
+    e = float((C[:1733] - ref).abs().max() / ref.abs().max())
+    untouched = bool((C[1733:] == -7.0).all())
+    ok = e < 2e-5 and untouched
+    bad += 0 if ok else 1
+    print(f"NT dyn rows err {e:.1e} rows past M untouched {untouched} {'ok' if ok else 'FAIL'}")
+    # repeatability (races show up as run-to-run differences)
+    M, N, K = 8192, 768, 1152
+    Ah, Bh = operands(0, M, N, K)
+    C0 = torch.zeros(M, N, device=dev)
+    run3(0, Ah, Bh, C0, None, M, N, K)
+    torch.cuda.synchronize()
+    nd = 0
+    for _ in range(20):
+        C1 = torch.zeros(M, N, device=dev)
+        run3(0, Ah, Bh, C1, None, M, N, K)
+        torch.cuda.synchronize()
+        nd += int((C1 != C0).sum())
+    ref = ref_of(0, Ah, Bh)
+    e = float((C0 - ref).abs().max() / ref.abs().max())
+    ok = nd == 0 and e < 2e-5
+    bad += 0 if ok else 1
+    print(f"NT 8192x768x1152 20 repeats: differing elements {nd}, err {e:.1e} {'ok' if ok else 'FAIL'}")
+    print("correctness failures:", bad, flush=True)
+
+VARS = tuple(int(v) for v in os.environ.get("G3_VARS", "").split(",") if v)
+if mode == "probe":
+    # where the time goes: the same launches with A's row pitch overridden (G3_LDA=0: every A load out of range, no memory
+    # traffic for A at all; G3_LDA=64: all of A inside a few MB, L2 hits) -- run this mode once per setting
+    for lay, M, N, K in [(0, 32768, 768, 768), (0, 65536, 768, 768), (0, 145408, 768, 4096), (0, 145408, 768, 1152), (1, 32768, 768, 768)]:
+        fl = 2.0 * M * N * K
+        line = f"{LAY[lay]} {M}x{N}x{K} lda={LDA_OVERRIDE} ldc={LDC_OVERRIDE}:"
+        for bm in (256, 128) + tuple(256 + (v << 16) for v in VARS):
+            r = bench(lay, M, N, K, "bf16", bm)
+            line += f" bm{bm & 0xffff}{('v%d' % (bm >> 16)) if bm >> 16 else ''} {r[0]:8.1f} us {fl / r[0] / 1e6:7.1f} TF |" if r else " - |"
+        print(line, flush=True)
+    sys.exit(0)
+
+if mode in ("bigm", "full"):
+    outs = [a.split("=")[1] for a in sys.argv[2:] if a.startswith("out=")] or ["bf16", "f32", "both"]
+    print("== timing (us per launch: best / median of 5 graph replays of 20 launches)", flush=True)
+    shapes = [(0, 32768, 768, 768), (1, 32768, 768, 768), (0, 32768, 768, 1152), (0, 32768, 1536, 768), (1, 32768, 768, 1536),
+              (1, 32768, 1152, 768), (0, 16896, 768, 768), (0, 65536, 768, 768), (0, 145408, 768, 1152), (0, 145408, 1536, 768),
+              (1, 145408, 768, 1536), (0, 145408, 768, 4096)]
+    if mode == "full":
+        shapes += [(0, 4096, 4096, 4096), (1, 4096, 4096, 4096), (2, 4096, 4096, 4096), (0, 8192, 8192, 8192)]
+    for lay, M, N, K in shapes:
+        fl = 2.0 * M * N * K
+        v = bench_vendor(lay, M, N, K)
+        print(f"{LAY[lay]} {M}x{N}x{K}: vendor (bf16 out) {v[0]:8.1f} / {v[1]:8.1f} us  {fl / v[0] / 1e6:7.1f} TF", flush=True)
+        for out in outs:
+            g2 = bench_g2(lay, M, N, K, out)
+            line = f"   out={out:4s} gemm2 {g2[0]:8.1f} us {fl / g2[0] / 1e6:7.1f} TF |" if g2 else f"   out={out:4s} gemm2 - |"
+            for bm in (256, 128):
+                r = bench(lay, M, N, K, out, bm)
+                line += f" g3 bm{bm} {r[0]:8.1f} / {r[1]:8.1f} us {fl / r[0] / 1e6:7.1f} TF |" if r else f" g3 bm{bm} - |"
+            print(line, flush=True)
+sys.exit(1 if bad else 0)

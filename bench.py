@@ -553,9 +553,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="do not run the backbone on a second HIP stream beside TTF")
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="N>1: element type of the gradient all-reduce; auto = bf16 in bf16 mode (half the xGMI bytes), fp32 otherwise")
-    ap.add_argument("--no-shard-optimizer", action="store_true",
-                    help="N>1: all-reduce the flat gradient and run clip + Adam replicated on every rank, instead of reduce-scatter -> "
-                         "clip + Adam on the rank's 1/N shard -> all-gather (FlatTrainer(shard_optimizer=True), the default)")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N>1: reduce-scatter -> clip + Adam on the rank's 1/N shard -> all-gather (FlatTrainer(shard_optimizer=True)) instead "
+                         "of the default: all-reduce of the flat gradient, clip + Adam replicated on every rank.  Opt-in: the native "
+                         "reduce_scatter_tensor / all_gather_into_tensor branches have only run on gloo's fallbacks and a 1-rank RCCL group")
+    ap.add_argument("--no-shard-optimizer", action="store_true", help="(accepted for compatibility: this is the default now)")
     ap.add_argument("--param-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="sharded optimizer: what the all-gather moves; auto = bf16 in bf16 mode (with the bf16 gradient wire the step "
                          "then moves exactly the bytes of one bf16 all-reduce; the replicated fp32 parameters are the widened bf16 "
@@ -612,7 +614,7 @@ def main():
 
     wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     pwire = args.param_wire if args.param_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
-    sharded = dist_on and not args.no_shard_optimizer
+    sharded = dist_on and args.shard_optimizer and not args.no_shard_optimizer
     w = Workload(args.config, dev, W, args.precision, group=group, wire=wire, device_step=not args.no_graph, seed_off=rank,
                  overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire)
     trainer, fusion = w.trainer, w.fusion

@@ -69,6 +69,9 @@ struct T2VScratch {
     float *dz, *dctx, *dXcat, *dqs_part, *dqs, *dq, *dp, *red, *red_t2v;
     void* dXcat_h;
     int t2v_slabs;
+    // split-K workspaces of the five weight-gradient GEMMs (they run concurrently on forked streams): empty below 8192 rows
+    void* sk[5];
+    size_t skb[5];
     size_t bytes;
 };
 T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
@@ -91,6 +94,16 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.red = k.take<float>(64 * 3 * d + 64 * 8);
     s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));       // time2vec backward: ~256 packed rows per slab
     s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
+    {
+        const int di = (int)d, dc = (int)(d + dt), dm = c->d_m, Rb = (int)R, BTb = (int)BT;
+        const size_t need[5] = {hf ? immtsf_gemm3_tn_ws_bytes(di, di, BTb) : 0, hf ? immtsf_gemm3_tn_ws_bytes(di, di, BTb) : 0,
+                                hf ? immtsf_gemm3_tn_ws_bytes(2 * di, di, Rb) : 0, hf ? immtsf_gemm3_tn_ws_bytes(di, dc, Rb) : 0,
+                                hf ? immtsf_gemm3_tn_ws_bytes(di, dm, Rb) : 0};
+        for (int i = 0; i < 5; ++i) {
+            s.skb[i] = need[i];
+            s.sk[i] = need[i] ? k.take<unsigned char>(need[i]) : nullptr;
+        }
+    }
     s.bytes = k.bytes();
     return s;
 }
@@ -198,6 +211,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, w.ctx, W.out, mat(w.xpre), p->attn_out_b);
         g.row_flag = w.mtxt; g.row_flag_div = T; g.add_vec = p->Q_param;
+        g.row_flag32 = w.lengths;         // same zero pattern as M_txt
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z.f, drop, SITE_T2V_OUT, s, w.z.h));
@@ -255,6 +269,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
         prezeroed(h, cfg);
+        h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
@@ -268,6 +283,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         GemmArgs h = gemm_args(d, d, BT, d, d, d);
         set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
         prezeroed(h, cfg);
+        h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
@@ -282,6 +298,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
         set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
         h.dyn = total; h.dyn_which = 1;
+        h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
@@ -293,6 +310,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
         set_problem2(h, 0, sc.dKV, w.Xcat, mat(gr->kv_w), nullptr, gr->kv_b);
         h.dyn = total; h.dyn_which = 1;
+        h.ws = sc.sk[3]; h.ws_bytes = sc.skb[3];
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
@@ -301,6 +319,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem2(h, 0, mat(nullptr, sc.dXcat_h), mat(nullptr, w.Vh), mat(gr->input_proj_w), nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1;
+        h.ws = sc.sk[4]; h.ws_bytes = sc.skb[4];
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     } else if (p->input_proj_w) {   // row-mapped, fp32 operands: the round-1 kernel

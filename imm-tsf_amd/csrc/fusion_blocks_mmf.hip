@@ -54,6 +54,8 @@ KVWs carve_kv(const immtsf_fusion_cfg* c, void* base) {
 }
 struct KVScratch {
     Mat dKV, dWKVf;
+    void* sk;         // split-K workspace of the dW_KVf product (empty below 8192 rows)
+    size_t skb;
     size_t bytes;
 };
 KVScratch carve_kv_scratch(const immtsf_fusion_cfg* c, void* base) {
@@ -63,6 +65,8 @@ KVScratch carve_kv_scratch(const immtsf_fusion_cfg* c, void* base) {
     KVScratch s;
     s.dKV = k.take_mat(BT * 2 * d, false, hf);
     s.dWKVf = k.take_mat(2 * d * d, !hf, hf);
+    s.skb = hf ? immtsf_gemm3_tn_ws_bytes((int)(2 * d), (int)d, (int)BT) : 0;
+    s.sk = s.skb ? k.take<unsigned char>(s.skb) : nullptr;
     s.bytes = k.bytes();
     return s;
 }
@@ -604,6 +608,7 @@ int immtsf_mmf_xattn_kv_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd
         GemmArgs h = gemm_args(2 * d, d, BT, 2 * d, d, d);
         set_problem2(h, 0, dK, E, sc.dWKVf, nullptr, gr->attn_in_b + d);
         h.c_prezeroed = 0;           // scratch output: see the query half
+        h.ws = sc.sk; h.ws_bytes = sc.skb;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, f));
         GemmArgs g = gemm_args(d, d, d, d, d, d);                 // dW_in,{k,v} = dW_{K,V}f W_{k,v}^T
         g.nprob = 2;

@@ -35,6 +35,8 @@ struct GemmArgs {
     int accumulate;
     const unsigned char* row_flag;   // optional: rows with row_flag[m / row_flag_div] == 0 are zeroed
     int row_flag_div;
+    const int* row_flag32;           // optional int32 array with the same zero / non-zero pattern as row_flag (e.g. the per-window note
+                                     // counts behind M_txt): lets the many-rows kernel (gemm3.hip) fetch the flags by LDS-DMA
     const float* add_vec;  // optional, length N
     int act;               // 0 none, 1 relu, 2 gelu(erf)
     int vecA, vecB, vecC;  // host-verified: 16-byte aligned base and ld % 4 == 0
@@ -52,6 +54,10 @@ struct GemmArgs {
                            // multiplied by gelu'(z) (gemm.hip only)
     // the caller guarantees C (and bias_grad) are already zero: split-K skips its own zero-fill
     int c_prezeroed;
+    // optional split-K workspace (TN weight gradients with a long reduction): immtsf_gemm3_tn_ws_bytes(M, N, K) bytes, private to
+    // this launch until it has completed; without it such products run on gemm2's tiles
+    void* ws;
+    size_t ws_bytes;
     int no_split;          // never split K (tiny products whose zero-fill + atomics cost more than the serial K loop)
     // optional dropout on the result (after the activation): element (m, n) uses Philox index m * N + n of site epi_site
     DropCfg epi_drop;
@@ -83,6 +89,16 @@ const void* immtsf_twin_lookup(const float* p, size_t min_elems);
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g);
 void immtsf_gemm_note_grid(long threads);      // timing tap: threads of the launch just made
 int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream);
+
+// ---- gemm3.hip: the persistent many-rows kernel (M >> 256, K > 64, plain epilogue: alpha, bias, row flags, add_vec).
+// IMMTSF_EUNSUPPORTED for anything else: the caller falls back to gemm2.
+int immtsf_launch_gemm3(int layout, const void* A, int lda, const void* B, int ldb, float* C, int ldc, void* Ch, int ldch,
+                        const float* bias, const float* add_vec, const int* row_flag, int row_flag_div, int M, int N, int K,
+                        float alpha, int act, const int* dyn_rows, hipStream_t stream);
+// TN with a long reduction (K >= 8192) and few tiles: split-K over the persistent workgroups + one reduce launch.
+size_t immtsf_gemm3_tn_ws_bytes(int M, int N, int K);     // 0: this product would not take the split path
+int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, void* Ch, int ldch, float* bias_grad, int M, int N,
+                           int K, float alpha, int accumulate, const int* dynk, void* ws, size_t ws_bytes, hipStream_t stream);
 
 // precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);

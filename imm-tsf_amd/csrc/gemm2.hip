@@ -20,6 +20,7 @@
 // issues the same number of loads per step and the vmcnt arithmetic has no special cases.
 #include "gemm.hpp"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -469,6 +470,25 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     g.vecA = 1;
     const int Mmax = g.M;
     const long t64 = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * g.nprob;
+
+    // many rows (forward / data-gradient projections at >= 256 windows per GPU): the persistent ping-pong kernel of gemm3.hip,
+    // 1.4-2x this file's tiles from ~190 row tiles of 128 on (profiles/r03_gemm_bigM.txt)
+    static const int use_g3 = getenv("IMMTSF_GEMM3") ? atoi(getenv("IMMTSF_GEMM3")) : 1;
+    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && g.act == 0 && !g.relu_ref && !g.accumulate &&
+        !g.a_rowmap && !g.b_rowmap && !g.ones_col && (!g.row_flag || g.row_flag32) && !(g.dyn && g.dyn_which != 0) &&
+        (long)cdiv(Mmax, 128) * cdiv(g.N, 256) >= 192) {
+        const GemmProblem& p = g.p[0];
+        const int rc = immtsf_launch_gemm3(layout, p.Ah, g.lda, p.Bh, g.ldb, p.C, g.ldc, p.Ch, ldch, p.bias, g.add_vec,
+                                           g.row_flag ? g.row_flag32 : nullptr, g.row_flag_div, Mmax, g.N, g.K, g.alpha, 0, g.dyn, stream);
+        if (rc != IMMTSF_EUNSUPPORTED) return rc;
+    }
+    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && g.ws && g.act == 0 && !g.relu_ref && !g.a_rowmap &&
+        !g.b_rowmap && !(g.dyn && g.dyn_which != 1)) {
+        const GemmProblem& p = g.p[0];
+        const int rc = immtsf_launch_gemm3_tn(p.Ah, g.lda, p.Bh, g.ldb, p.C, g.ldc, p.Ch, ldch, g.ones_col ? p.bias_grad : nullptr, Mmax, g.N, g.K,
+                                              g.alpha, g.accumulate, g.dyn, g.ws, g.ws_bytes, stream);
+        if (rc != IMMTSF_EUNSUPPORTED) return rc;
+    }
 
     // split-K over workgroups (fp32 atomics into a zeroed C) is only a tool option here: the K-group variants below split
     // the reduction INSIDE a workgroup and sum through LDS, which measured faster at every weight-gradient shape of the

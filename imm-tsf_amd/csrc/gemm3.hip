@@ -81,6 +81,11 @@ struct G3Args {
     const float* add_vec;     // [N] or null
     const int* row_flag;      // int32 per row group: rows with row_flag[m / row_flag_div] == 0 are zeroed (before add_vec), or null
     const int* dyn;           // device row count overriding M, or null
+    const int* dynk;          // split mode: device reduction length overriding K, or null
+    float* slab;              // split mode: [items][BM x 256] fp32 partial tiles (item = tile * splits + split)
+    float* slab_b;            // split mode, bias gradient requested: [items][BM] partial column sums of A (tiles of column 0 only)
+    int splits;               // split mode: K-ranges per tile
+    unsigned s_magic;         // id / splits as __umulhi(id, magic); 0: splits == 1
     int row_flag_div;
     unsigned rf_magic;        // floor(2^32 / row_flag_div) (0: div == 1): m / div = __umulhi(m, magic) (+1 after one check)
     int M, N, K;
@@ -100,7 +105,8 @@ __device__ __attribute__((aligned(16))) const G3Page g3_zero_page = g3_make_page
 
 // where the LDS-DMA loads of one K-tile come from (all wave-uniform)
 struct G3Cur {
-    int id, kt;               // tile id (>= number of tiles: past the end), K-tile inside the tile
+    int id, kt;               // work item (tile, or tile * splits + split; >= number of items: past the end), K-tile inside it
+    int kt0;                  // first K-tile of the item's reduction range
     int row0, col0;
     __amdgpu_buffer_rsrc_t ra, rb;
     int krem0;                // K range of the tile's reduction (0 past the end: every chunk invalid)
@@ -110,7 +116,10 @@ struct G3Cur {
 // EPI: 0 = x = alpha * acc only (no epilogue vectors are loaded or read); 1 = bias / add_vec / row flags through LDS
 // VAR: 0 the kernel; 2 / 3 / 4 = timing experiments of tools/gemm3_bench.py probe (no LDS fragment reads / no LDS-DMA / neither:
 //      they compute garbage)
-template <bool TA, bool TB, int BM, int OUT, int EPI, int VAR = 0>
+// SPLIT (TN weight gradients: few tiles, long reduction): a work item is (tile, K-range); its fp32 partial tile goes to
+//      slab[item] and -- for the tiles of column 0, first wave column -- the column sums of A (the bias gradient, one more MFMA
+//      against a fragment of ones) to slab_b[item]; gemm3_reduce_kernel sums the ranges.  OUT = 1, EPI = 0.
+template <bool TA, bool TB, int BM, int OUT, int EPI, int VAR = 0, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     constexpr int GH = BM / 2;                  // rows of a wave group
     constexpr int TMW = GH / 16;                // 16-row MFMA tiles per wave (8 or 4)
@@ -122,12 +131,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     constexpr int STAGE = 2 * A_HALF + 2 * B_HALF;
     constexpr int EVB = 8 * 1024;               // epilogue vectors of one tile: 1 KiB per wave
     constexpr int NKIND = (OUT & 1) + ((OUT >> 1) & 1);
-    constexpr int NS = HM * 4 * NKIND;          // stores per phase of a storing K-tile
+    constexpr int NS = HM * 4 * NKIND + (SPLIT ? HM : 0);      // stores per phase of a storing K-tile
     constexpr int XB = LPA + 2 * LPB;           // loads a thread issues in phase B (A row half 0 + both B halves of K-tile t+2)
     constexpr int XA = LPA;                     // ... in phase A (A row half 1 of K-tile t+1)
     constexpr int EV1 = EPI ? 1 : 0;
     constexpr int ST_AUX = 0;        // default cache policy: nt result stores measured 1.1-1.5x slower, sc1 (write-through) 0-10 % slower (r03)
     static_assert(BM == 256 || BM == 128, "tile heights");
+    static_assert(!SPLIT || (OUT == 1 && EPI == 0 && TA && TB), "split mode: fp32 partial tiles of a TN product");
     auto cap63 = [](int v) constexpr { return v > 63 ? 63 : v; };      // a smaller count only waits for more
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE + 2 * EVB];
@@ -139,10 +149,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 
     int M = g.M;
     if (g.dyn) M = *g.dyn;
-    const int N = g.N, K = g.K;
-    const int nk = (K + 63) >> 6;
+    int K = g.K;
+    if (SPLIT && g.dynk) K = *g.dynk;
+    const int N = g.N;
+    const int S = SPLIT ? g.splits : 1;
+    int nk = (K + 63) >> 6;                     // K-tiles per work item
+    if (SPLIT) {
+        nk = (nk + S - 1) / S;
+        nk = nk < 2 ? 2 : nk;                   // (the loop needs two K-tiles per item; ranges past K read zeros)
+    }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = g.tiles_n;
-    const int nt = tiles_m * tiles_n;
+    const int nt = tiles_m * tiles_n * S;       // work items
     const int G = gridDim.x;                    // a multiple of 8
     const int first_id = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);    // round r: tile r*G + first_id, neighbours share an XCD
     if (first_id >= nt) return;
@@ -260,11 +277,15 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         c.kt = 0;
         const bool ok = id < nt;
         const int idc = ok ? id : 0;
-        const int tm = g.tn_magic ? (int)__umulhi((unsigned)idc, g.tn_magic) : idc;
-        const int tn = idc - tm * tiles_n;
+        const int tile = (SPLIT && g.s_magic) ? (int)__umulhi((unsigned)idc, g.s_magic) : idc;
+        const int split = SPLIT ? idc - tile * S : 0;
+        const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
+        const int tn = tile - tm * tiles_n;
         c.row0 = tm * BM;
         c.col0 = tn * G3_BN;
-        c.krem0 = ok ? K : 0;
+        c.kt0 = split * nk;
+        const int kend = (c.kt0 + nk) * 64;
+        c.krem0 = ok ? (kend < K ? kend : K) : 0;
         const char* pa = reinterpret_cast<const char*>(g.A);
         const char* pb = reinterpret_cast<const char*>(g.B);
         if (!TA) c.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(pa + (size_t)(unsigned)c.row0 * (unsigned)lda2), (short)0, nrec_of(M - c.row0, lda2, 0), 0x00020000);
@@ -281,8 +302,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     // one half-tile of cursor c's K-tile into LDS at `dst` (wave-uniform): A row half mh / B column half nh
     auto issueA = [&](const G3Cur& c, int mh, unsigned char* dst) __attribute__((always_inline)) {
         if (VAR == 3 || VAR == 4) return;
-        const int krem = c.krem0 - c.kt * 64;
-        const unsigned uadd = (unsigned)(c.kt * kstepA + mh * halfA);
+        const int krem = c.krem0 - (c.kt0 + c.kt) * 64;
+        const unsigned uadd = (unsigned)((c.kt0 + c.kt) * kstepA + mh * halfA);
 #pragma unroll
         for (int i = 0; i < LPA; ++i) {
             bool ok = kcA < krem;
@@ -293,8 +314,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     };
     auto issueB = [&](const G3Cur& c, int nh, unsigned char* dst) __attribute__((always_inline)) {
         if (VAR == 3 || VAR == 4) return;
-        const int krem = c.krem0 - c.kt * 64;
-        const unsigned uadd = (unsigned)(c.kt * kstepB + nh * halfB);
+        const int krem = c.krem0 - (c.kt0 + c.kt) * 64;
+        const unsigned uadd = (unsigned)((c.kt0 + c.kt) * kstepB + nh * halfB);
 #pragma unroll
         for (int i = 0; i < LPB; ++i) {
             bool ok = kcB < krem;
@@ -330,13 +351,22 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 
     // ---------------------------------------------------------------- accumulators and the epilogue
     f32x4 acc[TMW][4];
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc((void*)g.C, (short)0, nrec_of(M, g.ldc * 4, 0), 0x00020000);
+    // split mode stores the item's tile at rows item*BM .. of the slab (pitch 256 floats, all 256 columns, alpha applied later)
+    const __amdgpu_buffer_rsrc_t rC = SPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)g.slab, (short)0, nrec_of(nt * BM, 1024, 0), 0x00020000)
+                                            : __builtin_amdgcn_make_buffer_rsrc((void*)g.C, (short)0, nrec_of(M, g.ldc * 4, 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)g.Ch, (short)0, nrec_of(M, g.ldch * 2, 0), 0x00020000);
-    const unsigned ldc4 = (unsigned)g.ldc * 4u, ldh2 = (unsigned)g.ldch * 2u;
+    const __amdgpu_buffer_rsrc_t rSB = __builtin_amdgcn_make_buffer_rsrc((void*)g.slab_b, (short)0, SPLIT && g.slab_b ? nt * BM * 4 : 0, 0x00020000);
+    const unsigned ldc4 = SPLIT ? 1024u : (unsigned)g.ldc * 4u, ldh2 = (unsigned)g.ldch * 2u;
+    const int Nst = SPLIT ? 256 : N;            // columns that exist in the store target
+    const float alpha = SPLIT ? 1.f : g.alpha;
+    f32x4 accb[SPLIT ? TMW : 1];                // split mode: column sums of A for this wave's rows (tiles of column 0, wave column 0)
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
     // store row half mh of this wave's accumulators (HM x 4 MFMA tiles) of the tile at (row0, col0); ev = that tile's epilogue
     // vectors in LDS.  x = rowflag(alpha * acc + bias) + add_vec.  Rows past M are out of range of the descriptors (dropped);
     // columns past N get an out-of-range offset.
-    auto store_half = [&](auto mh_c, int row0, int col0, const unsigned char* ev) __attribute__((always_inline)) {
+    auto store_half = [&](auto mh_c, int row0, int col0, const unsigned char* ev, bool with_b) __attribute__((always_inline)) {
         constexpr int mh = decltype(mh_c)::value;
         // an opaque zero: keeps the offsets below from being hoisted out of the tile loop into two dozen long-lived VGPRs
         int oz;
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ct = colw + (j >> 1) * 128 + (j & 1) * 16;
-            const bool cok = col0 + ct < N;                          // N % 4 == 0: a lane's 4 columns are in or out together
+            const bool cok = col0 + ct < Nst;                        // N % 4 == 0: a lane's 4 columns are in or out together
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, a4 = {0.f, 0.f, 0.f, 0.f};
             if (EPI) {
                 b4 = *reinterpret_cast<const f32x4*>(ev + ct * 4);
@@ -360,10 +390,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
                 if (EPI) {
                     const float live = *reinterpret_cast<const int*>(ev + 2048 + (rloc + ii * 16) * 16) != 0 ? 1.f : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (g.alpha * v[e] + b4[e]) * live + a4[e];
+                    for (int e = 0; e < 4; ++e) v[e] = (alpha * v[e] + b4[e]) * live + a4[e];
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = g.alpha * v[e];
+                    for (int e = 0; e < 4; ++e) v[e] = alpha * v[e];
                 }
                 if (OUT & 1) {
                     const unsigned vo = cok ? voC + (unsigned)(ii * 16) * ldc4 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 4) : G3_OOB;
@@ -374,6 +404,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
                     const unsigned vo = cok ? voH + (unsigned)(ii * 16) * ldh2 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 2) : G3_OOB;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), rH, (int)vo, 0, ST_AUX);
                 }
+            }
+        }
+        if (SPLIT) {        // the column sums (every register of a lane holds its row's sum); every wave issues the stores, only the
+                            // waves that formed the sums with an in-range offset (each wave's vmcnt must see the same count)
+#pragma unroll
+            for (int ii = 0; ii < HM; ++ii) {
+                const unsigned vo = with_b ? (vrow + (unsigned)(ii * 16)) * 4u : G3_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, accb[SPLIT ? mh * HM + ii : 0][0]), rSB, (int)vo, 0, 0);
             }
         }
     };
@@ -390,6 +428,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
                 asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
                 acc[mh * HM + ii][j] = f32x4{z0, z1, z2, z3};
             }
+        if (SPLIT) {
+#pragma unroll
+            for (int ii = 0; ii < HM; ++ii) {
+                float z0, z1, z2, z3;
+                asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
+                accb[SPLIT ? mh * HM + ii : 0] = f32x4{z0, z1, z2, z3};
+            }
+        }
     };
 
     // ---------------------------------------------------------------- prologue
@@ -419,6 +465,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     bf16x8 af[2][HM], bf[2][4];          // A fragments of the current row half, B fragments of all 4 column tiles (kept for phase B)
     int buf = 0, evsel = 0;
     int prow0 = 0, pcol0 = 0;            // the tile whose accumulators are complete (being stored)
+    bool do_b = false, pdo_b = false;      // split mode: this wave forms the bias-gradient sums of the current / the finished item
     auto mfma_half = [&](auto mh_c) __attribute__((always_inline)) {
         constexpr int mh = decltype(mh_c)::value;
         __builtin_amdgcn_s_setprio(1);
@@ -431,6 +478,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
                     f32x4& a = acc[mh * HM + ii][j];
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], af[kk][ii], a, 0, 0, 0);
                 }
+        if (SPLIT) {
+            if (do_b) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int ii = 0; ii < HM; ++ii) {
+                        f32x4& a = accb[SPLIT ? mh * HM + ii : 0];
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[kk][ii], a, 0, 0, 0);
+                    }
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
     };
     auto close_read = [&]() __attribute__((always_inline)) {          // end of a read section: own LDS reads retired, then the barrier
@@ -465,9 +523,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         const bool store = first && have_prev;
         const bool pstore = kt == 1 && have_prev;
         if (first) {
-            const int tm = g.tn_magic ? (int)__umulhi((unsigned)id, g.tn_magic) : id;
-            row0 = tm * BM;
-            col0 = (id - tm * tiles_n) * G3_BN;
+            if (SPLIT) {        // store coordinates = the item's slab rows; the tile's column decides who sums A's columns
+                const int tile = g.s_magic ? (int)__umulhi((unsigned)id, g.s_magic) : id;
+                const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
+                row0 = id * BM;
+                col0 = 0;
+                do_b = g.slab_b != nullptr && tile - tm * tiles_n == 0 && wc == 0;
+            } else {
+                const int tm = g.tn_magic ? (int)__umulhi((unsigned)id, g.tn_magic) : id;
+                row0 = tm * BM;
+                col0 = (id - tm * tiles_n) * G3_BN;
+            }
         }
         unsigned char* st = smem + buf * STAGE;
         unsigned char* nx = smem + (buf ^ 1) * STAGE;
@@ -489,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             else if (pstore) wait_vm<cap63(XB + XA + 2 * NS)>();
             else wait_vm<XB + XA>();
         }
-        if (store) store_half(I0{}, prow0, pcol0, evp);
+        if (store) store_half(I0{}, prow0, pcol0, evp, pdo_b);
         if (first) zero_half(I0{});
         close_read();
         mfma_half(I0{});
@@ -507,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             else if (pstore) wait_vm<cap63(NS + XA + XB)>();
             else wait_vm<XA + XB>();
         }
-        if (store) store_half(I1{}, prow0, pcol0, evp);
+        if (store) store_half(I1{}, prow0, pcol0, evp, pdo_b);
         if (first) zero_half(I1{});
         close_read();
         mfma_half(I1{});
@@ -521,6 +587,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             have_prev = true;
             prow0 = row0;
             pcol0 = col0;
+            pdo_b = do_b;
             evsel ^= 1;
             id += G;
             if (id >= nt) break;
@@ -531,8 +598,47 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     {   // the last tile's accumulators
         const unsigned char* evp = smem + 2 * STAGE + (evsel ^ 1) * EVB;
         wait_vm<0>();           // (its epilogue vectors landed long ago; the dummy loads past the end still target the ring)
-        store_half(I0{}, prow0, pcol0, evp);
-        store_half(I1{}, prow0, pcol0, evp);
+        store_half(I0{}, prow0, pcol0, evp, pdo_b);
+        store_half(I1{}, prow0, pcol0, evp, pdo_b);
+    }
+}
+
+
+// C[m, n] = alpha * sum_s slab[tile * S + s][m % BM][n % 256] (+ C[m, n]); bias_grad[m] = alpha * sum_s slab_b[tile(m, 0) * S + s][m % BM]
+__global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_b, float* __restrict__ C,
+                                                           int ldc, bf16_t* __restrict__ Ch, int ldch, float* __restrict__ bias_grad, int M, int N,
+                                                           int BM, int tiles_n, int S, float alpha, int accumulate) {
+    const int n4 = N >> 2;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x, total = (long)M * n4;
+    if (idx < total) {
+        const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
+        const int tm = m / BM, r = m - tm * BM, tn = n >> 8, c = n & 255;
+        const float* p = slab + ((size_t)(tm * tiles_n + tn) * S * BM + r) * 256 + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < S; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * BM * 256);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+        if (C) {
+            float4* dst = reinterpret_cast<float4*>(C + (size_t)m * ldc + n);
+            if (accumulate) {
+                const float4 old = *dst;
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *dst = o;
+        }
+        if (Ch) {
+            bf16x4 h;
+            h[0] = (bf16_t)o.x; h[1] = (bf16_t)o.y; h[2] = (bf16_t)o.z; h[3] = (bf16_t)o.w;
+            *reinterpret_cast<bf16x4*>(Ch + (size_t)m * ldch + n) = h;
+        }
+    } else if (bias_grad && idx - total < M) {
+        const int m = (int)(idx - total), tm = m / BM, r = m - tm * BM;
+        const float* p = slab_b + (size_t)(tm * tiles_n) * S * BM + r;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += p[(size_t)s * BM];
+        bias_grad[m] = alpha * acc + (accumulate ? bias_grad[m] : 0.f);
     }
 }
 
@@ -634,4 +740,70 @@ extern "C" int immtsf_gemm3_bf16(int32_t layout, const void* A, int32_t lda, con
                                  const int32_t* dyn_rows, void* stream) {
     return immtsf_launch_gemm3(layout, A, lda, B, ldb, C, ldc, Ch, ldch, bias, add_vec, row_flag, row_flag_div, M, N, K, alpha, act,
                                dyn_rows, static_cast<hipStream_t>(stream));
+}
+
+// ---- TN with a long reduction and few tiles (weight gradients at >= 256 windows per GPU): split-K over the persistent
+// workgroups, fp32 partial tiles in `ws`, one reduce launch.  C = alpha * A(K,M)^T B(K,N) (+ C); bias_grad (M) = alpha * column
+// sums of A.  dynk: optional device int32 overriding K (the ragged note count).
+static void g3_tn_plan(int M, int N, int K, int* bm, int* splits, size_t* bytes) {
+    *bm = 256;
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, G3_BN);
+    const int nk = cdiv(K, 64);
+    int S = tiles >= 256 ? 1 : (int)(256 / tiles);
+    while (S > 1 && nk / S < 6) --S;         // at least ~6 K-tiles per item: the partial tile's store is worth ~1
+    *splits = S;
+    *bytes = (size_t)tiles * S * 256 * (256 + 1) * sizeof(float);
+}
+size_t immtsf_gemm3_tn_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K < 8192 || (M % 8) || (N % 8)) return 0;
+    int bm, S;
+    size_t bytes;
+    g3_tn_plan(M, N, K, &bm, &S, &bytes);
+    return S >= 2 ? bytes : 0;
+}
+int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, void* Ch, int ldch, float* bias_grad, int M, int N,
+                           int K, float alpha, int accumulate, const int* dynk, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!A || !B || (!C && !Ch) || !ws || M <= 0 || N <= 0 || K < 8192 || (accumulate && !C)) return IMMTSF_EUNSUPPORTED;
+    if (!al16p(A) || !al16p(B) || !al16p(ws) || (lda % 8) || (ldb % 8) || (M % 8) || (N % 8)) return IMMTSF_EUNSUPPORTED;
+    if (C && (!al16p(C) || (ldc % 4))) return IMMTSF_EUNSUPPORTED;
+    if (Ch && ((reinterpret_cast<uintptr_t>(Ch) & 7) || (ldch % 4))) return IMMTSF_EUNSUPPORTED;
+    if ((long)K * lda * 2 > (long)G3_OOB || (long)K * ldb * 2 > (long)G3_OOB) return IMMTSF_EUNSUPPORTED;
+    int bm, S;
+    size_t bytes;
+    g3_tn_plan(M, N, K, &bm, &S, &bytes);
+    if (S < 2 || bytes > ws_bytes || bytes > (size_t)G3_OOB) return IMMTSF_EUNSUPPORTED;
+    G3Args g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb;
+    g.alpha = 1.f;
+    g.row_flag_div = 1;
+    g.tiles_n = cdiv(N, G3_BN);
+    g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
+    g.splits = S;
+    g.s_magic = (unsigned)((0x100000000ull + (unsigned)S - 1) / (unsigned)S);
+    g.dynk = dynk;
+    const long items = (long)cdiv(M, 256) * g.tiles_n * S;
+    g.slab = static_cast<float*>(ws);
+    g.slab_b = bias_grad ? g.slab + (size_t)items * 256 * 256 : nullptr;
+    int grid = g3_grid > 0 ? g3_grid : 256;
+    if (items < grid) grid = (int)((items + 7) / 8 * 8);
+    immtsf_gemm_note_grid((long)grid * 512);
+    hipLaunchKernelGGL((gemm3_kernel<true, true, 256, 1, 0, 0, true>), dim3(grid), dim3(512), 0, stream, g);
+    IMMTSF_LAUNCH_CHECK();
+    const long threads = (long)M * (N / 4) + (bias_grad ? M : 0);
+    hipLaunchKernelGGL(gemm3_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, g.slab, g.slab_b, C, ldc,
+                       reinterpret_cast<bf16_t*>(Ch), ldch, bias_grad, M, N, 256, g.tiles_n, S, alpha, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+// debug / test / tool entry (declared in include/immtsf.h): TN with split-K; ws from immtsf_gemm3_tn_workspace_bytes
+extern "C" size_t immtsf_gemm3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) { return immtsf_gemm3_tn_ws_bytes(M, N, K); }
+extern "C" int immtsf_gemm3_tn_bf16(const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc, float* bias_grad, int32_t M,
+                                    int32_t N, int32_t K, float alpha, int32_t accumulate, const int32_t* dyn_k, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    return immtsf_launch_gemm3_tn(A, lda, B, ldb, C, ldc, nullptr, 0, bias_grad, M, N, K, alpha, accumulate, dyn_k, ws, ws_bytes,
+                                  static_cast<hipStream_t>(stream));
 }

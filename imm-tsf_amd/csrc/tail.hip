@@ -290,12 +290,13 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
     if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+// (g and gz may be the same buffer -- read, then zeroed: neither is declared __restrict__)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
                                                     const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec,
-                                                    float* __restrict__ gz) {
+                                                    float* gz) {
     // gz != null (== g): the gradient is left zero behind the update -- the next step's zero-fill rides on this pass
     __shared__ float red[16];
     if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)

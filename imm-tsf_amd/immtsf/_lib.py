@@ -223,6 +223,9 @@ _PROTOS = {
                                     C.c_int32, c_f32p, c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                     C.c_int32, c_i32p, c_stream]),
     "immtsf_debug_gemm3_config": (C.c_int, [C.c_int32, C.c_int32]),
+    "immtsf_gemm3_tn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "immtsf_gemm3_tn_bf16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_int32, c_i32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_adam_step_dev": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
     "immtsf_adam_step_dev_zero": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,

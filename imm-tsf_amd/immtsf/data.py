@@ -42,7 +42,9 @@ class ResidentStore:
         # lib/parse_datasets.py:252-295).  One vectorised check over all rows.
         if len(tt) > 1:
             drop = np.diff(tt) < 0
-            drop[self._row_off[1:-1] - 1] = False          # the step from one window's last row to the next window's first
+            b = self._row_off[1:-1]                        # the step from one window's last row to the next window's first
+            b = b[(b > 0) & (b < len(tt))]                 # (empty windows at either end have no such step)
+            drop[b - 1] = False
             if np.any(drop):
                 w = int(np.searchsorted(self._row_off, int(np.argmax(drop)) + 1, side="right") - 1)
                 raise ValueError(f"window {w}: timestamps must be non-decreasing")

@@ -145,7 +145,9 @@ class FlatTrainer:
             self.master = self.flat_param[self.shard[0]:self.shard[1]].clone()
             self.flat_param.copy_(self.flat_twin)       # the replicated parameters are the widened bf16 image on every rank
         self.collective = group is not None          # a 1-rank group still runs the (trivial) collectives: lets one GPU
-        self.overlap = overlap and self.collective and dev.type == "cuda"      # exercise the multi-GPU code path
+        # (the sharded optimizer reduce-scatters the whole flat gradient in sync_grads: per-bucket all-reduces from the backward
+        # hooks would sum the sink buckets twice and race with it on the communication stream)
+        self.overlap = overlap and self.collective and dev.type == "cuda" and not self.sharded
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._pending: List = []
         self._reduced = [False] * len(self.buckets)
@@ -245,7 +247,7 @@ class FlatTrainer:
             self._bucket_ready(bi)
 
     def _bucket_ready(self, bi: int):
-        if not self.collective or self._reduced[bi]:
+        if not self.collective or self.sharded or self._reduced[bi]:
             return
         import torch.distributed as dist
         if bi not in self.sink_buckets:
@@ -289,6 +291,8 @@ class FlatTrainer:
             if self.collective and not all(self._reduced):      # collective off (a rank-local measurement leg): no communication
                 self._reduce_scatter()
                 self._reduced = [True] * len(self.buckets)
+            if self.comm_stream is not None:                    # (nothing is enqueued there in sharded mode; joined all the same)
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
             return
         if self.collective:
             if not self.overlap and not any(self._reduced):
@@ -449,6 +453,54 @@ class FlatTrainer:
             else:
                 self.flat_twin.copy_(self.flat_param)
 
+    def state_dict(self):
+        """checkpoint of the optimizer: Adam moments, step counters and -- with a bf16 parameter wire -- the fp32 master
+        parameters, all as FULL flat tensors (a sharded trainer gathers its ranks' shards; every rank returns the same
+        dict).  Together with the modules' own state_dict this resumes training exactly; `load_state_dict` takes it back on
+        any world size with the same parameter layout."""
+        def full(shard):
+            if not self.sharded:
+                return shard.detach().clone()
+            out = torch.empty(self.flat_param.numel(), dtype=shard.dtype, device=shard.device)
+            self._all_gather(out, shard.contiguous())
+            return out
+        sd = {"exp_avg": full(self.exp_avg), "exp_avg_sq": full(self.exp_avg_sq), "step": self.step_count,
+              "n": self.flat_param.numel(), "world": self.world}
+        if self.master is not None:
+            sd["master"] = full(self.master)
+        if self.device_step:
+            sd["step_dev"], sd["drop_dev"] = self.step_dev.clone(), self.drop_dev.clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        n = self.flat_param.numel()
+        k = min(n, int(sd["n"]))            # (the flat length is padded to a multiple of 8 * world: the common prefix is the payload)
+        lo, hi = self.shard
+        def take(dst, src):
+            dst.zero_()
+            a, b = lo, min(hi, k)
+            if b > a:
+                dst[:b - a].copy_(src[a:b].to(dst.device))
+        take(self.exp_avg, sd["exp_avg"])
+        take(self.exp_avg_sq, sd["exp_avg_sq"])
+        self.step_count = int(sd["step"])
+        if "master" in sd:
+            if self.master is not None:
+                take(self.master, sd["master"])
+            else:                           # resuming without a bf16 parameter wire: the master IS the parameter vector
+                self.flat_param[:k].copy_(sd["master"][:k].to(self.flat_param.device))
+        elif self.master is not None:
+            self.master.copy_(self.flat_param[lo:hi])
+        if self.device_step and "step_dev" in sd:
+            self.step_dev.copy_(sd["step_dev"])
+            self.drop_dev.copy_(sd["drop_dev"])
+        if self.master is None:
+            self.refresh_twins()
+        elif self.flat_twin is not None:    # replicated parameters = widened bf16 image of the masters: rebuild from the checkpoint
+            src = sd["master"][:k].to(self.flat_param.device) if "master" in sd else self.flat_param[:k]
+            self.flat_twin[:k].copy_(src)
+            self.flat_param[:k].copy_(self.flat_twin[:k])
+
     def grad_bytes(self) -> int:
         return self.flat_grad.numel() * 4
 
@@ -584,8 +636,12 @@ class PhasedStep:
             trainer.collect_grads()
         with torch.cuda.graph(self.gT3, pool=poolT, stream=self.T):
             self._text_backward(outs, dcuts)
-        with torch.cuda.graph(self.gO, pool=poolT, stream=self.T):
-            trainer.step()
+        # the optimizer as a graph -- unless it holds collectives (sharded: norm all-reduce + parameter all-gather), which stay eager
+        # like GraphedStep's (capture_collectives is the only path that puts RCCL calls into a graph)
+        self.opt_eager = bool(trainer.sharded and trainer.collective)
+        if not self.opt_eager:
+            with torch.cuda.graph(self.gO, pool=poolT, stream=self.T):
+                trainer.step()
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)          # boundary tensors live in the graphs' pools: keep them referenced
         self.eB1, self.eT2, self.eB2, self.eO = (torch.cuda.Event() for _ in range(4))
@@ -640,6 +696,7 @@ class PhasedStep:
         t, T, B = self.trainer, self.T, self.B
         cur = torch.cuda.current_stream()
         T.wait_stream(cur)
+        B.wait_stream(cur)          # the caller may have refreshed the static batch / the parameters on its stream
         with torch.cuda.stream(T):
             self.gT1.replay()
         with torch.cuda.stream(B):
@@ -661,7 +718,10 @@ class PhasedStep:
                 t._reduced = [False] * len(t.buckets)
                 t._collected = True
                 t.sync_grads()
-            self.gO.replay()
+            if self.opt_eager:
+                t.step()
+            else:
+                self.gO.replay()
             self.eO.record(T)
         cur.wait_stream(T)
         return self.loss

@@ -2,8 +2,11 @@
 
 Same constructor / `forecasting` signature and state_dict keys.  The frozen LLM and its tokenizer come from the HF hub
 in the reference (:128-159); with no network they cannot be instantiated, so `configs.immtsf_offline_llm = True`
-builds a RANDOM-INIT GPT-2 of the requested depth and a deterministic byte-level tokenizer stand-in (shape-faithful
-for benchmarking; full-forward parity with the reference is therefore unpinned).  The sub-layers on the
+builds a RANDOM-INIT GPT-2 of the requested depth and a deterministic byte-level tokenizer stand-in.  The wrapper's
+composition (prompt -> tokens -> two patch embeddings -> reprogramming -> LLM -> hidden[:, -total:, :d_ff] -> head) is pinned
+against the reference run the same way (its loader patched to the same stand-ins, tests/golden/make_golden.py gen_timellm ->
+tests/golden/model_timellm.npz, test_gpu_fusion.py::test_timellm_forecasting_vs_reference_golden); parity with PRETRAINED
+weights stays unpinned.  The sub-layers on the
 hot-path scope -- PatchEmbedding on values and on timestamps, ReprogrammingLayer projections, FlattenHead -- use the
 HIP GEMM."""
 from math import sqrt
@@ -119,7 +122,9 @@ class TimeLLM(nn.Module):
         if offline:
             if model_name != "GPT2":
                 raise ValueError("immtsf_offline_llm supports GPT2 only")
-            self.llm_model = GPT2Model(GPT2Config(n_layer=layers))
+            # (a dict: extra GPT2Config fields -- the parity fixture uses a 320-entry vocabulary, tests/golden/make_golden.py)
+            extra = offline if isinstance(offline, dict) else {}
+            self.llm_model = GPT2Model(GPT2Config(n_layer=layers, **extra))
             self.tokenizer = _ByteTokenizer()
             return
         cfg = Cfg.from_pretrained(repo)

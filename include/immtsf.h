@@ -615,6 +615,14 @@ int immtsf_debug_gemm2_config(int32_t variant, int32_t splitk, int32_t xcd);
 int immtsf_gemm3_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc, void* Ch,
                       int32_t ldch, const float* bias, const float* add_vec, const int32_t* row_flag, int32_t row_flag_div,
                       int32_t M, int32_t N, int32_t K, float alpha, int32_t act, const int32_t* dyn_rows, immtsf_stream_t stream);
+/* TN with a long reduction and few tiles -- the weight gradients dW = dY^T X at >= 256 windows per GPU (K = rows of dY >= 8192):
+ * C (M, N, fp32) = alpha * A(K, M)^T B(K, N) (+ C if accumulate), bias_grad (M, may be NULL) = alpha * column sums of A.  The
+ * reduction is split over the persistent workgroups, fp32 partial tiles go to `ws` (immtsf_gemm3_tn_workspace_bytes bytes, 0 =
+ * the product is too small for this path), one reduce launch follows.  dyn_k: optional device int32 overriding K. */
+size_t immtsf_gemm3_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int immtsf_gemm3_tn_bf16(const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc, float* bias_grad, int32_t M,
+                         int32_t N, int32_t K, float alpha, int32_t accumulate, const int32_t* dyn_k, void* ws, size_t ws_bytes,
+                         immtsf_stream_t stream);
 /* tuning aid for tools/gemm3_bench.py: force the tile height (256 / 128, 0 = heuristic) and the grid (0 = 256 workgroups) */
 int immtsf_debug_gemm3_config(int32_t bm, int32_t grid);
 

@@ -453,6 +453,71 @@ class _WrapR(_Wrap3):
         return self.m(x, self.src, self.src)
 
 
+class _ByteTok:
+    """the offline tokenizer stand-in shared with the mirror (models/TimeLLM.py `_ByteTokenizer`): one token per byte,
+    right-padded with id 0"""
+    eos_token = "<eos>"
+    pad_token = "<eos>"
+
+    def __call__(self, prompts, return_tensors="pt", padding=True, truncation=True, max_length=512):
+        ids = [list(q.encode("utf-8"))[:max_length] for q in prompts]
+        n = max(len(i) for i in ids)
+        t = torch.zeros((len(ids), n), dtype=torch.long)
+        for r, i in enumerate(ids):
+            t[r, :len(i)] = torch.tensor(i, dtype=torch.long)
+        return type("Enc", (), {"input_ids": t})()
+
+    def add_special_tokens(self, _):
+        pass
+
+
+TIMELLM_CFG = dict(input_len=16, pred_len=8, use_norm=True, d_ff=32, ts_vocab_size=20, input_token_len=8, stride=4,
+                   domain_des="synthetic", top_k=3, C=3, llm_model_timellm="GPT2", llm_layers_timellm=2, dropout=0.0, d_model=16,
+                   n_heads=2, batch_size=4, device="cpu")
+TIMELLM_GPT2 = dict(vocab_size=320, n_positions=512)      # a small vocabulary: the byte tokenizer only emits ids < 256
+
+
+def gen_timellm():
+    """The reference TimeLLM wrapper end to end (models/TimeLLM.py:167-278: stats -> prompt -> tokens -> two patch embeddings ->
+    reprogramming -> LLM -> hidden[:, -total:, :d_ff] -> head -> de-normalise), with `_get_model_and_tokenizer` (:128-159, needs
+    the hub) replaced by a random-init 2-layer GPT-2 + the byte tokenizer.  Weights of every tensor come from seeded.state_like:
+    the fixture stores inputs, the output and gradient fingerprints only."""
+    _install_shims()
+    sys.path.insert(0, OUT)
+    import seeded
+    from transformers import GPT2Config, GPT2Model
+    mod = importlib.import_module("models.TimeLLM")
+
+    def fake(self, model_name, layers):
+        self.llm_model = GPT2Model(GPT2Config(n_layer=layers, **TIMELLM_GPT2))
+        self.tokenizer = _ByteTok()
+    mod.TimeLLM._get_model_and_tokenizer = fake
+    torch.manual_seed(61)
+    m = mod.TimeLLM(types.SimpleNamespace(**TIMELLM_CFG))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    sd = {k: torch.from_numpy(v) for k, v in seeded.state_like(shapes, 6100).items()}
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+    m.word_embeddings = m.llm_model.get_input_embeddings().weight
+    m.train()
+    g = torch.Generator().manual_seed(62)
+    B, L, Lp, K = 3, 12, 5, 3
+    data = torch.randn(B, L, K, generator=g)
+    mask = (torch.rand(B, L, K, generator=g) < 0.8).float()
+    data = data * mask
+    tp = torch.sort(torch.rand(B, L, generator=g), 1).values
+    tpp = torch.sort(torch.rand(B, Lp, generator=g), 1).values
+    out = m.forecasting(tpp, data.clone(), tp, mask)
+    up = torch.randn(out.shape, generator=g)
+    (out * up).sum().backward()
+    arrs = dict(data=_np(data), mask=_np(mask), tp=_np(tp), tpp=_np(tpp), out=_np(out), upstream=_np(up),
+                keys=np.array(sorted(shapes)), prompt0=np.array(m._get_prompt(torch.zeros(1, 16, 3))[0]))
+    for i, (k, p_) in enumerate(sorted(m.named_parameters())):
+        if p_.requires_grad:
+            arrs[f"gp.{k}"] = seeded.probes(_np(p_.grad), 6200 + i)
+    save("model_timellm", **arrs)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     which = sys.argv[1:] or ["fusion", "loss", "layers", "layers_big", "tpatchgnn", "models"]
@@ -468,3 +533,5 @@ if __name__ == "__main__":
         gen_tpatchgnn()
     if "models" in which:
         gen_models()
+    if "timellm" in which:
+        gen_timellm()

@@ -82,6 +82,21 @@ def _worker_sharded(rank, world, port, q, wire, param_wire):
         _loss(params, shard, cnt, H).backward()
         tr.sync_grads()
         tr.step()
+    # checkpoint / resume: a second trainer built from the current parameters + tr.state_dict() takes the same fourth step
+    # (gathers the moment shards and, with the bf16 wire, the fp32 master shards -- FlatTrainer.state_dict)
+    sd = tr.state_dict()
+    params2 = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+    tr2 = FlatTrainer([[p for k, p in params2.items() if k.startswith("mmf.")], [p for k, p in params2.items() if k.startswith("ttf.")]],
+                      lr=1e-2, eps=1e-3, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD, grad_wire=wire, shard_optimizer=True,
+                      param_wire=param_wire)
+    tr2.load_state_dict(sd)
+    for t_, ps_ in ((tr, params), (tr2, params2)):
+        t_.zero_grad()
+        _loss(ps_, shard, cnt, H).backward()
+        t_.sync_grads()
+        t_.step()
+    resume_err = float((tr.gather(tr.flat_param) - tr2.gather(tr2.flat_param)).abs().max())
+    assert resume_err < 1e-6, resume_err
     p_dp = tr.gather(tr.flat_param)
     # every rank must hold the same replicated parameters
     chk = p_dp.clone()
@@ -92,7 +107,7 @@ def _worker_sharded(rank, world, port, q, wire, param_wire):
         order = [k for k in ref if k.startswith("mmf.")] + [k for k in ref if k.startswith("ttf.")]
         opt = torch.optim.Adam([ref[k] for k in order], lr=1e-2, eps=1e-3, weight_decay=1e-3)
         cnt_full = full[5].reshape(-1, 3).sum(0)
-        for _ in range(3):
+        for _ in range(4):
             opt.zero_grad()
             _loss(ref, full, cnt_full, H).backward()
             torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)

@@ -10,6 +10,7 @@ Index/bool tensors: bit-exact.
 """
 import glob
 import os
+import sys
 import types
 
 import numpy as np
@@ -653,6 +654,40 @@ def test_timellm_offline_smoke():
     assert out.shape == (3, 5, 3) and torch.isfinite(out).all()
     out.square().mean().backward()
     assert torch.isfinite(m.mapping_layer.weight.grad).all()
+
+
+def test_timellm_forecasting_vs_reference_golden():
+    """The TimeLLM wrapper end to end against the REFERENCE's forecasting (models/TimeLLM.py:167-278) run with its hub loader
+    patched to a random-init 2-layer GPT-2 + byte tokenizer (tests/golden/make_golden.py gen_timellm): same seeded weights in
+    every tensor (tests/golden/seeded.py), output 1e-4, gradient fingerprints of every trainable parameter 1e-3."""
+    dev = _dev()
+    sys.path.insert(0, GOLDEN)
+    import seeded
+    from immtsf import config
+    from models.TimeLLM import TimeLLM
+    config.precision = "fp32"
+    z = np.load(os.path.join(GOLDEN, "model_timellm.npz"))
+    cfg = types.SimpleNamespace(input_len=16, pred_len=8, use_norm=True, d_ff=32, ts_vocab_size=20, input_token_len=8, stride=4,
+                                domain_des="synthetic", top_k=3, C=3, llm_model_timellm="GPT2", llm_layers_timellm=2, dropout=0.0,
+                                d_model=16, n_heads=2, batch_size=4, device=str(dev),
+                                immtsf_offline_llm=dict(vocab_size=320, n_positions=512))
+    m = TimeLLM(cfg)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+    assert sorted(shapes) == [str(k) for k in z["keys"]], "state_dict keys differ from the reference's"
+    assert m._get_prompt(torch.zeros(1, 16, 3))[0] == str(z["prompt0"])          # the prompt text is byte-identical
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in seeded.state_like(shapes, 6100).items()}, strict=False)
+    assert not missing.unexpected_keys
+    m = m.to(dev).train()
+    m.word_embeddings = m.llm_model.get_input_embeddings().weight
+    t = lambda k: torch.from_numpy(z[k]).to(dev)     # noqa: E731
+    out = m.forecasting(t("tpp"), t("data").clone(), t("tp"), t("mask"))
+    assert _l2err(out, t("out")) < 1e-4
+    (out * t("upstream")).sum().backward()
+    for i, (k, p_) in enumerate(sorted(m.named_parameters())):
+        if p_.requires_grad:
+            got = seeded.probes(p_.grad.detach().cpu().numpy(), 6200 + i)
+            ref = z[f"gp.{k}"]
+            assert np.abs(got - ref).max() <= 1e-3 * max(1e-6, np.abs(ref).max()), (k, got, ref)
 
 
 def test_mmf_monolithic_entry_equals_the_two_halves():

@@ -266,6 +266,69 @@ def test_two_rank_graph_step_equals_single_process(wire, tol):
     assert err < tol, err
 
 
+def _two_rank_eager_worker(rank, world, port, q, sharded):
+    """the EAGER data-parallel step with overlap=True (bucket hooks + communication stream), all-reduce or sharded optimizer"""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from immtsf.ops import masked_mse
+    from immtsf.train import FlatTrainer, shard_range
+    from lib.evaluation import forecast_and_fuse
+    model, fusion, _, batch = _setup(dev, 0.0)
+    lo, hi = shard_range(8, rank, world)
+    shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
+    cnt = shard["mask_predicted_data"].reshape(-1, shard["mask_predicted_data"].shape[-1]).sum(0)
+    dist.all_reduce(cnt)
+    tr = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())], lr=1e-2, eps=1e-3,
+                     max_norm=1.0, sink_buckets=(0, 1), overlap=True, device_step=False, group=dist.group.WORLD, grad_wire="fp32",
+                     shard_optimizer=sharded)
+    assert tr.overlap == (not sharded)          # the sharded optimizer never all-reduces buckets from the backward hooks
+    for _ in range(4):
+        tr.zero_grad()
+        out = forecast_and_fuse(model, fusion, shard, None)
+        masked_mse(out, shard["data_to_predict"], shard["mask_predicted_data"], None, cnt).backward()
+        tr.sync_grads()
+        tr.step()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(tr.gather(tr.flat_param).cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_two_rank_eager_step_equals_single_process(sharded):
+    """eager N>1 step with overlap=True -- what bench.py runs for the configurations it cannot graph and under --no-graph: the
+    sharded optimizer must not have its sink buckets all-reduced by the backward hooks before the reduce-scatter sums them again
+    (round-2 advisor finding: gradients x world), and must not leave the communication stream unjoined."""
+    dev = _dev()
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_eager_worker, args=(r, 2, port, q, sharded)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = torch.from_numpy(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    f = _loss_fn(model, fusion, batch)
+    for _ in range(4):
+        tr.zero_grad()
+        f().backward()
+        tr.sync_grads()
+        tr.step()
+    ref = tr.gather(tr.flat_param).cpu()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 3e-4, err
+
+
 def test_adjacent_projection_weights_take_the_single_gemm_path():
     """inside FlatTrainer's flat buffer proj_k.weight and proj_v.weight of MMF_XAttn_Add are adjacent, which lets the
     backward form dE = [dK0 | dV0] [W_k ; W_v] as ONE GEMM: same gradients as with separately allocated parameters."""
@@ -394,3 +457,62 @@ def test_load_state_dict_refreshes_the_bf16_twin():
         tr.close()
     assert abs(l1 - l0) > 1e-3 * abs(l0), (l0, l1)          # the new weights are in effect
     assert l1 == l2, (l1, l2)                               # and the hook left nothing stale
+
+
+@pytest.mark.parametrize("precision,tol_loss,tol_param,tol_delta", [("fp32", 1e-4, 3e-4, 5e-3), ("bf16", 3e-2, 3e-3, 2.5e-1)])
+def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
+    """The BENCHMARKED composition against the oracle, not against itself: three cfg2 training steps (tPatchGNN -> TTF_T2V_XAttn
+    -> MMF_XAttn_Add -> masked MSE -> clip 1.0 -> Adam) at B = 64, d = 768 through bench.Workload + GraphedStep (hipGraph replay,
+    backbone on the second HIP stream, gradient sinks into the flat buffer) vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
+    torch.optim.Adam on the CPU from identical weights (reference: lib/evaluation.py:72-164, main.py:1093-1101).  Dropout 0.
+    Bars: loss of every step `tol_loss` relative; final parameters `tol_param` relative L2; the three-step UPDATE (p_final -
+    p_init) `tol_delta` relative L2 -- in bf16 mode the update of weakly driven parameters carries the operands' 2^-9 rounding."""
+    dev = _dev()
+    sys.path.insert(0, ROOT)
+    import bench
+    from immtsf import config
+    from immtsf.train import GraphedStep
+    from oracle import fusion_ref as R
+    from oracle import tpatchgnn_ref as TP
+    old_drop = bench.P_DROP
+    bench.P_DROP = 0.0
+    try:
+        w = bench.Workload("cfg2", dev, 64, precision, device_step=True)
+        # Adam eps 1e-3 on both sides: with 1e-8 the sign-like first steps turn 1e-9 summation-order noise on gradients that are
+        # zero in exact arithmetic (the softmax's key bias) into +-lr parameter differences
+        w.trainer.eps = 1e-3
+        a = bench.model_args("cpu")
+        ref_model = TP.build(a).train()
+        ref_model.load_state_dict({k: v.detach().cpu() for k, v in w.model.state_dict().items()})
+        params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in w.fusion.state_dict().items()}
+        p0 = torch.cat([v.detach().reshape(-1) for v in params.values()] + [q.detach().reshape(-1) for q in ref_model.parameters()])
+        opt = torch.optim.Adam(list(ref_model.parameters()) + list(params.values()), lr=1e-3, eps=1e-3)
+        b = w.cpu_batch
+        ref_losses = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)
+            pred = ref_model.forecasting(b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
+            out = R.fusion_forward("TTF_T2V_XAttn", "MMF_XAttn_Add", params, b["notes_embeddings"], b["tau"], b["tp_to_predict"], pred,
+                                   H=bench.H, kappa=bench.KAPPA, expand_T=False)
+            loss = R.masked_mse(b["data_to_predict"], out, b["mask_predicted_data"])
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(list(ref_model.parameters()) + list(params.values()), 1.0)
+            opt.step()
+            ref_losses.append(float(loss))
+        step = GraphedStep(w.trainer, w.loss_fn)          # (its warm-up steps are undone)
+        got_losses = [float(step()) for _ in range(3)]
+        torch.cuda.synchronize()
+        for g_, r_ in zip(got_losses, ref_losses):
+            assert abs(g_ - r_) <= tol_loss * abs(r_), (got_losses, ref_losses)
+        sd_f = {k: v.detach().cpu() for k, v in w.fusion.state_dict().items()}
+        names = [n for n, _ in ref_model.named_parameters()]
+        sd_m = dict(w.model.named_parameters())
+        p_gpu = torch.cat([sd_f[k].reshape(-1) for k in params] + [sd_m[n].detach().cpu().reshape(-1) for n in names])
+        p_ref = torch.cat([v.detach().reshape(-1) for v in params.values()] + [q.detach().reshape(-1) for q in ref_model.parameters()])
+        e_param = float((p_gpu - p_ref).norm() / p_ref.norm())
+        e_delta = float(((p_gpu - p0) - (p_ref - p0)).norm() / (p_ref - p0).norm())
+        assert e_param < tol_param and e_delta < tol_delta, (e_param, e_delta)
+        w.close()
+    finally:
+        bench.P_DROP = old_drop
+        config.precision = "fp32"

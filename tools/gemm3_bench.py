@@ -194,10 +194,63 @@ if mode == "probe":
         print(line, flush=True)
     sys.exit(0)
 
+if mode in ("tn", "tnv", "full", "check"):
+    print("== TN split-K (weight gradients): correctness and timing", flush=True)
+
+    def run_tn(Ah, Bh, C, bg, M, N, K, ws, alpha=1.0, acc=0, dynk=None):
+        return lib.immtsf_gemm3_tn_bf16(_lib.ptr(Ah), Ah.shape[1], _lib.ptr(Bh), Bh.shape[1], _lib.ptr(C), N, _lib.ptr(bg), M, N, K, alpha, acc,
+                                        _lib.ptr(dynk), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
+
+    for (M, N, K, dyn) in [(768, 768, 32768, None), (1536, 768, 16500, None), (768, 1152, 16896, 9001), (264, 520, 8200, None), (768, 768, 131072, None)]:
+        torch.manual_seed(M + N + K)
+        Ah, Bh = operands(2, M, N, K, scale=0.25)
+        nb = lib.immtsf_gemm3_tn_workspace_bytes(M, N, K)
+        if nb == 0:
+            print(f"TN {M}x{N}x{K}: not on the split path", flush=True)
+            continue
+        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        C = torch.full((M, N), 3.0, device=dev)
+        bg = torch.full((M,), -2.0, device=dev)
+        dynk = torch.tensor([dyn], device=dev, dtype=torch.int32) if dyn else None
+        rc = run_tn(Ah, Bh, C, bg, M, N, K, ws, alpha=0.5, acc=1, dynk=dynk)
+        torch.cuda.synchronize()
+        Ke = dyn or K
+        ref = 0.5 * ref_of(2, Ah[:Ke], Bh[:Ke]) + 3.0
+        refb = 0.5 * Ah[:Ke].float().sum(0) - 2.0
+        e = float((C - ref).abs().max() / ref.abs().max())
+        eb = float((bg - refb).abs().max() / refb.abs().max())
+        ok = rc == 0 and e < 2e-5 and eb < 2e-5
+        bad += 0 if ok else 1
+        print(f"TN {M}x{N}x{K} dynK={dyn} rc={rc} ws={nb >> 20} MB err {e:.1e} bias_grad err {eb:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+    if mode in ("tn", "tnv", "full"):
+        for (M, N, K) in [(768, 768, 32768), (1536, 768, 32768), (768, 1152, 32768), (768, 768, 16896), (768, 768, 145408), (768, 4096, 145408), (1536, 768, 145408)]:
+            fl = 2.0 * M * N * K
+            Ah, Bh = operands(2, M, N, K)
+            nb = lib.immtsf_gemm3_tn_workspace_bytes(M, N, K)
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            C = torch.zeros(M, N, device=dev)
+            bg = torch.zeros(M, device=dev)
+            # (the vendor TN launch hung in torch.cuda.synchronize() when it followed this tool's own graphs in one process: it is
+            # timed in a process of its own, mode tnv)
+            v = bench_vendor(2, M, N, K) if mode == "tnv" else (float("nan"), float("nan"))
+            if mode == "tnv":
+                print(f"TN {M}x{N}x{K}: vendor {v[0]:8.1f} us {fl / v[0] / 1e6:7.1f} TF", flush=True)
+                continue
+            g2 = graph_time(lambda: lib.immtsf_gemm_bf16(2, _lib.ptr(Ah), M, _lib.ptr(Bh), N, _lib.ptr(C), N, None, N, None, _lib.ptr(bg), M, N, K, 1.0, 0, 0,
+                                                         None, 0, None, _lib.stream_ptr()))
+            line = f"TN {M}x{N}x{K}: vendor {v[0]:8.1f} us {fl / v[0] / 1e6:7.1f} TF | gemm2 (+bias grad) {g2[0]:8.1f} us {fl / g2[0] / 1e6:7.1f} TF |"
+            if nb:
+                r = graph_time(lambda: run_tn(Ah, Bh, C, bg, M, N, K, ws))
+                r0 = graph_time(lambda: run_tn(Ah, Bh, C, None, M, N, K, ws))
+                line += f" g3 split (+bias grad) {r[0]:8.1f} / {r[1]:8.1f} us {fl / r[0] / 1e6:7.1f} TF | without {r0[0]:8.1f} us"
+            print(line, flush=True)
+    print("correctness failures:", bad, flush=True)
+
 if mode in ("bigm", "full"):
     outs = [a.split("=")[1] for a in sys.argv[2:] if a.startswith("out=")] or ["bf16", "f32", "both"]
     print("== timing (us per launch: best / median of 5 graph replays of 20 launches)", flush=True)
-    shapes = [(0, 32768, 768, 768), (1, 32768, 768, 768), (0, 32768, 768, 1152), (0, 32768, 1536, 768), (1, 32768, 768, 1536),
+    shapes = [(0, 2048, 768, 768), (0, 4096, 768, 768), (0, 8192, 768, 768), (1, 8192, 768, 768), (0, 8192, 1536, 768), (1, 8192, 768, 1536), (0, 12288, 768, 1152),
+              (0, 32768, 768, 768), (1, 32768, 768, 768), (0, 32768, 768, 1152), (0, 32768, 1536, 768), (1, 32768, 768, 1536),
               (1, 32768, 1152, 768), (0, 16896, 768, 768), (0, 65536, 768, 768), (0, 145408, 768, 1152), (0, 145408, 1536, 768),
               (1, 145408, 768, 1536), (0, 145408, 768, 4096)]
     if mode == "full":

@@ -435,7 +435,7 @@ def gemm_roofline(w, lib, args, k2=20):
     # HBM traffic of that kernel instance from the committed rocprofv3 PMC passes (tools/pmc_summary.py; counters cannot be
     # read from inside the process): matched by kernel name + layout + launch grid
     traffic, tsrc = None, None
-    for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
@@ -448,8 +448,19 @@ def gemm_roofline(w, lib, args, k2=20):
                 break
         if traffic is not None:
             break
+    ach_tap = (top["flops"] / nprob / max(top["key"][6], 1)) / (top["avg_us"] / (nprob * max(top["key"][6], 1)) * 1e-6) / 1e12
+    prov = None
+    if tsrc:
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", tsrc)))
+            prov = {"file": "profiles/" + tsrc, "commit": pj.get("commit"), "ms_per_step_when_profiled": pj.get("ms_per_step")}
+        except Exception:
+            prov = {"file": "profiles/" + tsrc}
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
-            "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{tsrc})" if tsrc else
+            "batch": f"{w.B} windows per GPU", "achieved_in_step_tap": round(ach_tap, 2), "frac_in_step_tap": round(ach_tap / peak, 5),
+            "traffic": traffic, "traffic_provenance": prov,
+            "traffic_unit": f"bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{tsrc}: a committed profile of this kernel "
+                            "instance, not a measurement of this run)" if tsrc else
             "bytes/launch: no PMC record for this kernel instance under profiles/",
             "algorithmic_bytes": alg_bytes, "operands": operands,
             "kernel": f"{kname} {lay} M={Mm} N={Nn} K={Kk} (x{top['key'][5] * top['key'][6]} problems per launch in the step; per-problem figures here)",
@@ -686,6 +697,17 @@ def main():
     assert torch.isfinite(loss).all(), "loss is not finite"
     ms_per_step = elapsed / args.steps * 1e3
     windows_per_s = W * world * args.steps / elapsed
+    # the contract's K steps are a ~15 ms sample at cfg2: the same step is replayed in blocks of 20 (>= 200 replays, N = 1 only: no
+    # extra collectives are spent on it) and the block means are reported next to `ms_per_step` -- median and spread, not `value`
+    step_stats = None
+    if world == 1 and use_graph and not args.no_extras:
+        blocks = []
+        for _ in range(12):
+            el, _, _ = time_steps(step, 20, 0, torch.cuda.synchronize)
+            blocks.append(el / 20 * 1e3)
+        blocks.sort()
+        step_stats = {"replays": 240, "block": 20, "median_ms": round(blocks[len(blocks) // 2], 4), "min_ms": round(blocks[0], 4),
+                      "max_ms": round(blocks[-1], 4)}
 
     roofline = hbm = None
     if not args.no_roofline and rank == 0:
@@ -743,7 +765,15 @@ def main():
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * W * world / (ms_per_step * 1e-3) / 1e12, 2),
                        "grad_bytes": grad_bytes,
                        "grad_allreduce": comm_mode + (f", {wire} on the wire" if dist_on and not sharded else "")},
-            "roofline": roofline, "roofline_hbm": hbm, "cpu_baseline": cpu}
+            "roofline": roofline, "roofline_hbm": hbm, "cpu_baseline": cpu,
+            "roofline_fusion_step": {"bound": "mfma", "achieved": round(fl_win * W * world / (ms_per_step * 1e-3) / 1e12 / world, 2),
+                                     "peak": PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS, "unit": "TFLOP/s per GPU",
+                                     "frac": round(fl_win * W / (ms_per_step * 1e-3) / 1e12 /
+                                                   (PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS), 5),
+                                     "batch": f"{W} windows per GPU",
+                                     "what": "SURVEY 8d algorithmic fusion flops of the timed region / its time (the whole step: backbone, "
+                                             "loss, optimizer and launch gaps are in the denominator)"},
+            "step_stats": step_stats}
         line.update(extras)
     if dist_on:
         import torch.distributed as dist

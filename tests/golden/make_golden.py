@@ -474,7 +474,9 @@ class _ByteTok:
 TIMELLM_CFG = dict(input_len=16, pred_len=8, use_norm=True, d_ff=32, ts_vocab_size=20, input_token_len=8, stride=4,
                    domain_des="synthetic", top_k=3, C=3, llm_model_timellm="GPT2", llm_layers_timellm=2, dropout=0.0, d_model=16,
                    n_heads=2, batch_size=4, device="cpu")
-TIMELLM_GPT2 = dict(vocab_size=320, n_positions=512)      # a small vocabulary: the byte tokenizer only emits ids < 256
+# a small vocabulary (the byte tokenizer only emits ids < 256) and NO dropout inside the LLM body: the reference leaves the frozen
+# GPT-2 in train mode (its own dropout draws from torch's CPU generator, which no GPU run can reproduce)
+TIMELLM_GPT2 = dict(vocab_size=320, n_positions=512, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
 
 
 def gen_timellm():
@@ -500,6 +502,7 @@ def gen_timellm():
     assert not missing.unexpected_keys, missing
     m.word_embeddings = m.llm_model.get_input_embeddings().weight
     m.train()
+    m.reprogramming_layer.dropout.p = 0.0       # (constructed with its default attention_dropout = 0.1 whatever configs.dropout says, :105)
     g = torch.Generator().manual_seed(62)
     B, L, Lp, K = 3, 12, 5, 3
     data = torch.randn(B, L, K, generator=g)
@@ -507,11 +510,14 @@ def gen_timellm():
     data = data * mask
     tp = torch.sort(torch.rand(B, L, generator=g), 1).values
     tpp = torch.sort(torch.rand(B, Lp, generator=g), 1).values
+    seen = []
+    real_prompt = m._get_prompt
+    m._get_prompt = lambda x: seen.append(real_prompt(x)) or seen[-1]       # record the prompt strings of this batch
     out = m.forecasting(tpp, data.clone(), tp, mask)
     up = torch.randn(out.shape, generator=g)
     (out * up).sum().backward()
     arrs = dict(data=_np(data), mask=_np(mask), tp=_np(tp), tpp=_np(tpp), out=_np(out), upstream=_np(up),
-                keys=np.array(sorted(shapes)), prompt0=np.array(m._get_prompt(torch.zeros(1, 16, 3))[0]))
+                keys=np.array(sorted(shapes)), prompt0=np.array(real_prompt(torch.zeros(1, 16, 3))[0]), prompts=np.array(seen[0]))
     for i, (k, p_) in enumerate(sorted(m.named_parameters())):
         if p_.requires_grad:
             arrs[f"gp.{k}"] = seeded.probes(_np(p_.grad), 6200 + i)

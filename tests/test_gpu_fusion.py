@@ -670,7 +670,7 @@ def test_timellm_forecasting_vs_reference_golden():
     cfg = types.SimpleNamespace(input_len=16, pred_len=8, use_norm=True, d_ff=32, ts_vocab_size=20, input_token_len=8, stride=4,
                                 domain_des="synthetic", top_k=3, C=3, llm_model_timellm="GPT2", llm_layers_timellm=2, dropout=0.0,
                                 d_model=16, n_heads=2, batch_size=4, device=str(dev),
-                                immtsf_offline_llm=dict(vocab_size=320, n_positions=512))
+                                immtsf_offline_llm=dict(vocab_size=320, n_positions=512, resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0))
     m = TimeLLM(cfg)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.dtype.is_floating_point}
     assert sorted(shapes) == [str(k) for k in z["keys"]], "state_dict keys differ from the reference's"
@@ -679,15 +679,36 @@ def test_timellm_forecasting_vs_reference_golden():
     assert not missing.unexpected_keys
     m = m.to(dev).train()
     m.word_embeddings = m.llm_model.get_input_embeddings().weight
+    m.reprogramming_layer.dropout.p = 0.0            # as the fixture: the layer's own default 0.1 is the only dropout left in the path
     t = lambda k: torch.from_numpy(z[k]).to(dev)     # noqa: E731
+    # The prompt spells the batch statistics with all float digits (reference :167-194), so a 1-ulp difference between the CPU's and
+    # the GPU's normalisation changes the token string.  The statistics are compared as NUMBERS (same text skeleton, values to 1e-5);
+    # downstream both sides then consume the reference's recorded strings, so the comparison pins the composition, not the last digit.
+    import re
+    ref_prompts = [str(q) for q in z["prompts"]]
+    seen = []
+    real_prompt = m._get_prompt
+    m._get_prompt = lambda x: seen.append(real_prompt(x)) or ref_prompts
     out = m.forecasting(t("tpp"), t("data").clone(), t("tp"), t("mask"))
+    num, lags = r"-?\d+\.\d+(?:e-?\d+)?", r"Top lags \[([\d, ]+)\]"
+    for mine, ref in zip(seen[0], ref_prompts):
+        # (the circular autocorrelation is symmetric, corr[k] == corr[L - k], so torch.topk's order inside such a pair is a tie
+        # the CPU and the GPU break differently: the lag lists are compared as classes {k, L - k})
+        skel = lambda q: re.sub(lags, "Top lags [*]", re.sub(num, "#", q))       # noqa: E731
+        assert skel(mine) == skel(ref), (mine, ref)
+        a, b = [float(v) for v in re.findall(num, mine)], [float(v) for v in re.findall(num, ref)]
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6), (mine, ref)
+        cls = lambda q: sorted(min(int(v), 16 - int(v)) for v in re.search(lags, q).group(1).split(","))      # noqa: E731
+        assert cls(mine) == cls(ref), (mine, ref)
     assert _l2err(out, t("out")) < 1e-4
     (out * t("upstream")).sum().backward()
     for i, (k, p_) in enumerate(sorted(m.named_parameters())):
         if p_.requires_grad:
             got = seeded.probes(p_.grad.detach().cpu().numpy(), 6200 + i)
             ref = z[f"gp.{k}"]
-            assert np.abs(got - ref).max() <= 1e-3 * max(1e-6, np.abs(ref).max()), (k, got, ref)
+            # (floor: the key projection's bias gradient is zero in exact arithmetic -- softmax is shift invariant -- and ~1e-9 noise
+            # on both sides)
+            assert np.abs(got - ref).max() <= 1e-3 * max(1e-4, np.abs(ref).max()), (k, got, ref)
 
 
 def test_mmf_monolithic_entry_equals_the_two_halves():

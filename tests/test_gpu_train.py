@@ -476,6 +476,7 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
     from oracle import tpatchgnn_ref as TP
     old_drop = bench.P_DROP
     bench.P_DROP = 0.0
+    config.nan_check = "deferred"       # no host syncs inside the captured step (what bench.py sets)
     try:
         w = bench.Workload("cfg2", dev, 64, precision, device_step=True)
         # Adam eps 1e-3 on both sides: with 1e-8 the sign-like first steps turn 1e-9 summation-order noise on gradients that are
@@ -483,6 +484,16 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
         w.trainer.eps = 1e-3
         a = bench.model_args("cpu")
         ref_model = TP.build(a).train()
+
+        def no_dropout(model):          # the stock transformer layer of the backbone is built with torch's default dropout 0.1
+            for mm in model.modules():
+                if isinstance(mm, torch.nn.Dropout):
+                    mm.p = 0.0
+            for lyr in model.transformer_encoder:
+                for l_ in lyr.layers:
+                    l_.self_attn.dropout = 0.0
+        no_dropout(w.model)
+        no_dropout(ref_model)
         ref_model.load_state_dict({k: v.detach().cpu() for k, v in w.model.state_dict().items()})
         params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in w.fusion.state_dict().items()}
         p0 = torch.cat([v.detach().reshape(-1) for v in params.values()] + [q.detach().reshape(-1) for q in ref_model.parameters()])
@@ -511,7 +522,16 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
         p_ref = torch.cat([v.detach().reshape(-1) for v in params.values()] + [q.detach().reshape(-1) for q in ref_model.parameters()])
         e_param = float((p_gpu - p_ref).norm() / p_ref.norm())
         e_delta = float(((p_gpu - p0) - (p_ref - p0)).norm() / (p_ref - p0).norm())
-        assert e_param < tol_param and e_delta < tol_delta, (e_param, e_delta)
+        # per-tensor update errors, worst first (diagnostics of a failure)
+        worst, off = [], 0
+        for k, v in list(params.items()) + [(n, q) for n, q in ref_model.named_parameters()]:
+            n_ = v.numel()
+            d_ref = (p_ref - p0)[off:off + n_]
+            d_gpu = (p_gpu - p0)[off:off + n_]
+            worst.append((float((d_gpu - d_ref).norm() / (p_ref - p0).norm()), float((d_gpu - d_ref).norm() / max(float(d_ref.norm()), 1e-12)), k))
+            off += n_
+        worst.sort(reverse=True)
+        assert e_param < tol_param and e_delta < tol_delta, (e_param, e_delta, worst[:6])
         w.close()
     finally:
         bench.P_DROP = old_drop

@@ -1,7 +1,9 @@
+# usage: bash tools/prof_windows.sh [windows=1024] [tag=w]   -> gpurun_out/prof_<tag>_stats.csv (per-kernel totals over 10 steps)
+W=${1:-1024}; TAG=${2:-w}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_w
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_w -o r -- python3 bench.py --windows-per-gpu 1024 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/prof_w.log 2>&1
-f=$(ls gpurun_out/prof_w/*results.db 2>/dev/null | head -1)
-python3 tools/rocpd_stats.py $f gpurun_out/prof_w_stats.csv; rm -f $f
-tail -1 gpurun_out/prof_w.log | cut -c1-200
+rm -rf gpurun_out/prof_$TAG
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o r -- python3 bench.py --windows-per-gpu $W --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/prof_$TAG.log 2>&1
+f=$(ls gpurun_out/prof_$TAG/*results.db 2>/dev/null | head -1)
+python3 tools/rocpd_stats.py $f gpurun_out/prof_${TAG}_stats.csv; rm -f $f
+tail -1 gpurun_out/prof_$TAG.log | cut -c1-200

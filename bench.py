@@ -247,7 +247,7 @@ class Workload:
     """one BASELINE configuration on one device: models, trainer, batch, the loss closure of a step"""
 
     def __init__(self, cfg, dev, windows, precision, group=None, wire="fp32", device_step=True, seed_off=0, overlap=True,
-                 shard_optimizer=False, param_wire="fp32"):
+                 shard_optimizer=False, param_wire="fp32", packed_notes=False):
         from fusions.FusionModel import FusionModel
         from fusions.load_llm import register_d_model
         from immtsf import config
@@ -281,6 +281,18 @@ class Workload:
         else:
             self.cpu_batch, self.sum_n = synth_batch(100 + seed_off, windows, cfg)
             self.batch = {k: v.to(dev) for k, v in self.cpu_batch.items()}
+        self.packed = bool(packed_notes) and c["ttf"] == "TTF_T2V_XAttn"
+        if self.packed:
+            # the notes as the device collate hands them over (immtsf.data.ResidentStore.collate): the embedding
+            # rows stay in one resident matrix, the batch carries a row index per note and the per-window counts -- no zero-padded
+            # (B, N, d_m) tensor, no |V| > 0 scan (note_mask) to re-derive the index from
+            from immtsf.ops import PackedNotes
+            notes = self.batch["notes_embeddings"]
+            Bn, Nn, dm = notes.shape
+            keep = notes.abs().sum(2) > 0
+            lengths = keep.sum(1).to(torch.int32)
+            rows = torch.arange(Bn * Nn, device=dev, dtype=torch.int32).view(Bn, Nn)[keep].contiguous()
+            self.batch["notes_embeddings"] = PackedNotes(notes.reshape(Bn * Nn, dm).contiguous(), rows, lengths, Nn)
         self.global_cnt = self.batch["mask_predicted_data"].reshape(-1, c["C"]).sum(0)
         self.side = torch.cuda.Stream(device=dev) if overlap else None
 
@@ -573,6 +585,9 @@ def main():
                     help="sharded optimizer: what the all-gather moves; auto = bf16 in bf16 mode (with the bf16 gradient wire the step "
                          "then moves exactly the bytes of one bf16 all-reduce; the replicated fp32 parameters are the widened bf16 "
                          "image, the fp32 master stays with the owner), fp32 (exact) otherwise")
+    ap.add_argument("--packed-notes", action="store_true",
+                    help="hand the notes over in the packed form of the device collate (resident embedding matrix + row index + per-window "
+                         "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
     ap.add_argument("--no-wgrad-fork", action="store_true",
                     help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
@@ -627,7 +642,7 @@ def main():
     pwire = args.param_wire if args.param_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     sharded = dist_on and args.shard_optimizer and not args.no_shard_optimizer
     w = Workload(args.config, dev, W, args.precision, group=group, wire=wire, device_step=not args.no_graph, seed_off=rank,
-                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire)
+                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=args.packed_notes)
     trainer, fusion = w.trainer, w.fusion
     use_graph = (not args.no_graph) and w.graphable
     comm_mode = "bucketed on a side stream" if dist_on else "none"
@@ -733,6 +748,15 @@ def main():
             ww.close()
             del st, ww
         extras["sweep"] = sweep
+        # the same step with the notes handed over packed (what immtsf.data's device collate produces)
+        wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=True)
+        st = GraphedStep(wp.trainer, wp.loss_fn)
+        el, _, _ = time_steps(st, 40, 5, torch.cuda.synchronize)
+        extras["packed"] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
+                            "what": "notes as PackedNotes (resident embedding matrix + int32 row index + per-window counts, the device "
+                                    "collate's output) instead of the zero-padded (B, N, d_m) tensor: no note_mask scan in the step"}
+        wp.close()
+        del st, wp
         # the fp32 parity mode (1e-4 against the reference) on the same step
         wf = Workload("cfg2", dev, B_PER_GPU, "fp32")
         st = GraphedStep(wf.trainer, wf.loss_fn)

@@ -53,7 +53,7 @@ ELScratch carve_el_scratch(size_t R, size_t D, size_t F, void* base) {
     s.dsa = k.take<float>(R * D);
     s.da = k.take<float>(R * D);
     s.dqkv = k.take<float>(R * 3 * D);
-    s.red = k.take<float>(64 * (D + 8));
+    s.red = k.take<float>(colsum_scratch_floats(D, 2));
     s.bytes = k.bytes();
     return s;
 }
@@ -106,7 +106,7 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
     // kernel leaves dz untouched, so the caller's dout is read in place
     float* g2 = const_cast<float*>(dout);
     CHECK(launch_layernorm_bwd(g2, f.R, f.D, ln_w, xhat, rstd, d1, none, 0, s, dff, dd, f.site_out));
-    CHECK(launch_colsum2(g2, xhat, f.R, f.D, f.D, gln_w, gln_b, red, s));
+    CHECK(launch_colsum2(g2, xhat, f.R, f.D, f.D, gln_w, gln_b, red, s, true));       // (red: colsum_scratch_floats(D, 2) at both carve sites)
     {   // linear2: dh = (dff W2) x act'(.) x the feed-forward dropout
         GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.F, f.F);
         set_problem(g, 0, dff, w2, dh, nullptr);
@@ -147,7 +147,7 @@ FFNScratch carve_ffn_scratch(size_t R, size_t D, size_t F, void* base) {
     FFNScratch s;
     s.dff = k.take<float>(R * D);
     s.dh = k.take<float>(R * F);
-    s.red = k.take<float>(64 * (D + 8));
+    s.red = k.take<float>(colsum_scratch_floats(D, 2));
     s.bytes = k.bytes();
     return s;
 }
@@ -225,7 +225,7 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
     }
     // LayerNorm1: dx = gradient of (x + drop(sa)) -- the input's residual share; dsa = dx * dropout mask
     CHECK(launch_layernorm_bwd(sc.d1, R, D, p->ln1_w, w.xhat1, w.rstd1, dx, none, 0, s, sc.dsa, dd, c->site_base + 1));
-    CHECK(launch_colsum2(sc.d1, w.xhat1, R, D, D, gr->ln1_w, gr->ln1_b, sc.red, s));
+    CHECK(launch_colsum2(sc.d1, w.xhat1, R, D, D, gr->ln1_w, gr->ln1_b, sc.red, s, true));
     {   // out_proj
         GemmArgs g = gemm_args(R, D, D, D, D, D);
         set_problem(g, 0, sc.dsa, p->out_w, sc.da, nullptr);

@@ -48,7 +48,7 @@ RecScratch carve_rec_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dEraw = k.take<float>(BT * d);
     s.dVp = k.take<float>(R * d);
     s.dls_part = k.take<float>(B);
-    s.red = k.take<float>(64 * (d + 8));
+    s.red = k.take<float>(colsum_scratch_floats(d, 2));
     s.bytes = k.bytes();
     return s;
 }
@@ -160,7 +160,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
-    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s));
+    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s, true));
     CHECK(launch_recavg_bwd(B, T, d, w.offsets, w.rowmap, tau, t_hat, p->log_recency_sigma, w.Vp, w.Eraw, w.denom, sc.dEraw,
                             sc.dVp, sc.dls_part, s));
     CHECK(launch_colsum(sc.dls_part, nullptr, B, nullptr, 1, 1, gr->log_recency_sigma, 0, sc.red, s));

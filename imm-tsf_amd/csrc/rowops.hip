@@ -98,6 +98,63 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
     }
 }
 
+// many windows (B > 256): the same three phases as three launches -- a wave per window over the whole chip for the counting and the
+// compaction, one workgroup only for the scan of the B lengths (the one-workgroup kernel above walks B * N mask bytes alone:
+// 0.36 ms at 4096 windows).  Outputs identical.
+__global__ __launch_bounds__(1024) void ragged_count_kernel(const unsigned char* __restrict__ mask, int B, int N, int* __restrict__ lengths,
+                                                            unsigned char* __restrict__ mtxt, unsigned char* __restrict__ mtxt2) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int cnt = 0;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        const bool m = (n < N) && mask[(size_t)b * N + n] != 0;
+        cnt += __popcll(__ballot(m));
+    }
+    if (lane == 0) { lengths[b] = cnt; mtxt[b] = cnt > 0 ? 1 : 0; if (mtxt2) mtxt2[b] = cnt > 0 ? 1 : 0; }
+}
+__global__ __launch_bounds__(1024) void ragged_scan_kernel(const int* __restrict__ lengths, int B, int* __restrict__ offsets) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + tid;
+        const int len = (b < B) ? lengths[b] : 0;
+        sh[tid] = len;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int v = (tid >= off) ? sh[tid - off] : 0;
+            __syncthreads();
+            sh[tid] += v;
+            __syncthreads();
+        }
+        if (b < B) offsets[b] = carry + sh[tid] - len;
+        __syncthreads();
+        if (tid == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (tid == 0) offsets[B] = carry;
+}
+__global__ __launch_bounds__(1024) void ragged_fill_kernel(const unsigned char* __restrict__ mask, int B, int N, const int* __restrict__ offsets,
+                                                           int* __restrict__ rowmap, int* __restrict__ seg) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int pos = offsets[b];
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        const bool m = (n < N) && mask[(size_t)b * N + n] != 0;
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+            const int k = pos + __popcll(bal & ((1ull << lane) - 1ull));
+            rowmap[k] = b * N + n;
+            seg[k] = b;
+        }
+        pos += __popcll(bal);
+    }
+}
+
 __device__ __forceinline__ void gather_rows_body(int r, const float* __restrict__ src, int ld_src,
                                                  const int* __restrict__ rowmap, const int* __restrict__ total,
                                                  int width, float* __restrict__ dst, int ld_dst,
@@ -485,6 +542,116 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     out[n] = accumulate ? out[n] + a : a;
 }
 
+// ---- many rows (M >= 4096, the >= 256-window regime): 16 bytes per lane instead of 4, CL column lanes x 256 / CL row lanes per
+// workgroup (CL = min(64, N / 4 rounded up to a power of two): narrow matrices keep every lane busy), up to 256 row slabs so that
+// the grid covers the chip.  partial[slab][K][N].  K sums: 1: X (* Y); 2: X * Y and X; 3: X * Y, X and Z (+ Z's row zeroing and
+// bf16 image, as colsum3_partial_kernel).  The one-dword-per-lane kernels above read 131072 x 768 fp32 at ~1 TB/s.
+constexpr int kSlabsBig = 256;
+template <int K>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ Z,
+                                                          int M, int N, int ld, float* __restrict__ partial, int cl_shift,
+                                                          const unsigned char* __restrict__ row_flag, int flag_div, bf16_t* __restrict__ Zh) {
+    __shared__ float4 red[K][256];
+    const int CL = 1 << cl_shift, RL = 256 >> cl_shift;
+    const int tx = threadIdx.x & (CL - 1), ty = threadIdx.x >> cl_shift;
+    const int n = (blockIdx.x * CL + tx) * 4, slab = blockIdx.y, nsl = gridDim.y;
+    const int rps = (M + nsl - 1) / nsl;
+    const int r0 = slab * rps, r1 = min(M, r0 + rps);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
+    if (n < N)
+        for (int r = r0 + ty; r < r1; r += RL) {
+            const size_t o = (size_t)r * ld + n;
+            const float4 x = *reinterpret_cast<const float4*>(X + o);
+            if (K >= 2 || Y) {
+                const float4 y = Y ? *reinterpret_cast<const float4*>(Y + o) : make_float4(1.f, 1.f, 1.f, 1.f);
+                a.x = fmaf(x.x, y.x, a.x); a.y = fmaf(x.y, y.y, a.y); a.z = fmaf(x.z, y.z, a.z); a.w = fmaf(x.w, y.w, a.w);
+            } else {
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            }
+            if (K >= 2) { b.x += x.x; b.y += x.y; b.z += x.z; b.w += x.w; }
+            if (K >= 3) {
+                float4 z = *reinterpret_cast<const float4*>(Z + o);
+                c.x += z.x; c.y += z.y; c.z += z.z; c.w += z.w;
+                if (row_flag && !row_flag[r / flag_div]) {
+                    z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(Z + o) = z;
+                }
+                if (Zh) {
+                    bf16x4 h;
+                    h[0] = (bf16_t)z.x; h[1] = (bf16_t)z.y; h[2] = (bf16_t)z.z; h[3] = (bf16_t)z.w;
+                    *reinterpret_cast<bf16x4*>(Zh + o) = h;
+                }
+            }
+        }
+    red[0][threadIdx.x] = a;
+    if (K >= 2) red[1][threadIdx.x] = b;
+    if (K >= 3) red[2][threadIdx.x] = c;
+    __syncthreads();
+    for (int off = RL >> 1; off > 0; off >>= 1) {
+        if (ty < off) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float4 u = red[k][threadIdx.x];
+                const float4 v = red[k][threadIdx.x + (off << cl_shift)];
+                u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+                red[k][threadIdx.x] = u;
+            }
+        }
+        __syncthreads();
+    }
+    if (ty == 0 && n < N) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(partial + ((size_t)slab * K + k) * N + n) = red[k][tx];
+    }
+}
+// grid ceil(N / 64): 64 columns x 4 slab lanes per workgroup
+template <int K>
+__global__ __launch_bounds__(256) void colsum_vec_final_kernel(const float* __restrict__ partial, int N, int nsl, float* __restrict__ o0,
+                                                                float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
+    __shared__ float red[K][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, n = blockIdx.x * 64 + tx;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    if (n < N)
+#pragma unroll 4
+        for (int s = ty; s < nsl; s += 4)
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += partial[((size_t)s * K + k) * N + n];
+#pragma unroll
+    for (int k = 0; k < K; ++k) red[k][ty][tx] = acc[k];
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        float* outs[3] = {o0, o1, o2};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float v = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
+            outs[k][n] = accumulate ? outs[k][n] + v : v;
+        }
+    }
+}
+// the many-row path applies: vectorisable and worth the bigger grid
+static bool colsum_vec_ok(const void* X, const void* Y, const void* Z, const void* Zh, int M, int N, int ld, bool big_scratch) {
+    if (!big_scratch || M < 4096 || (N & 3) || (ld & 3)) return false;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(Z);
+    return (al & 15) == 0 && (reinterpret_cast<uintptr_t>(Zh) & 7) == 0;
+}
+template <int K>
+static int launch_colsum_vec(const float* X, const float* Y, float* Z, int M, int N, int ld, float* o0, float* o1, float* o2, int accumulate,
+                             float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s) {
+    int sh = 0;
+    while ((1 << sh) < cdiv(N, 4) && sh < 6) ++sh;
+    const int CL = 1 << sh, RL = 256 / CL;
+    int nsl = M / (RL * 8);                      // >= 8 rows per row lane
+    nsl = nsl < 32 ? 32 : (nsl > kSlabsBig ? kSlabsBig : nsl);
+    hipLaunchKernelGGL((colsum_vec_kernel<K>), dim3(cdiv(N, CL * 4), nsl), dim3(256), 0, s, X, Y, Z, M, N, ld, scratch, sh, row_flag,
+                       flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(Zh));
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((colsum_vec_final_kernel<K>), dim3(cdiv(N, 64)), dim3(256), 0, s, scratch, N, nsl, o0, o1, o2, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 // ------------------------------------------------------------------------------------------- LayerNorm
 // one wave per row; two-pass statistics like torch (mean, then mean of squared deviations), eps inside sqrt.
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int rows, int d,
@@ -794,6 +961,15 @@ int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int
 
 int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
                         unsigned char* mtxt, hipStream_t s, unsigned char* mtxt2) {
+    if (B > 256) {
+        hipLaunchKernelGGL(ragged_count_kernel, dim3(cdiv(B, 16)), dim3(1024), 0, s, mask, B, N, lengths, mtxt, mtxt2);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, lengths, B, offsets);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ragged_fill_kernel, dim3(cdiv(B, 16)), dim3(1024), 0, s, mask, B, N, offsets, rowmap, seg);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     hipLaunchKernelGGL(ragged_index_kernel, dim3(1), dim3(1024), 0, s, mask, B, N, lengths, offsets, rowmap, seg, mtxt, mtxt2);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
@@ -882,8 +1058,10 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
 }
 
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
-                   hipStream_t s) {
+                   hipStream_t s, bool big_scratch) {
     if (N <= 0) return IMMTSF_OK;
+    if (colsum_vec_ok(X, Y, nullptr, nullptr, M, N, ld, big_scratch))
+        return launch_colsum_vec<2>(X, Y, nullptr, M, N, ld, out_xy, out_x, nullptr, 0, scratch, nullptr, 1, nullptr, s);
     if (N <= 32 && (long)M * N <= (1L << 17)) {
         int CT = 1;
         while (CT < N) CT <<= 1;
@@ -907,8 +1085,10 @@ int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* 
 }
 
 int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
-                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s) {
+                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s, bool big_scratch) {
     if (N <= 0) return IMMTSF_OK;
+    if (colsum_vec_ok(X, Y, Z, Zh, M, N, ld, big_scratch))
+        return launch_colsum_vec<3>(X, Y, Z, M, N, ld, out_xy, out_x, out_z, 0, scratch, row_flag, flag_div, Zh, s);
     const int nsl = M >= 1024 ? 64 : kSlabs;
     hipLaunchKernelGGL(colsum3_partial_kernel, dim3(cdiv(N, 64), nsl), dim3(256), 0, s, X, Y, Z, M, N, ld, scratch, row_flag,
                        flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(Zh));

@@ -35,12 +35,14 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
                   float* scratch, hipStream_t s);
 // out_xy[n] = sum_m X*Y, out_x[n] = sum_m X in one pass (LayerNorm's gamma / beta gradients).  scratch >= 64*N floats.
+// big_scratch: scratch holds colsum_scratch_floats(N, 2) floats -- enables the many-row path (M >= 4096: 16-byte loads, <= 256 slabs)
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
-                   hipStream_t s);
+                   hipStream_t s, bool big_scratch = false);
+inline size_t colsum_scratch_floats(size_t ncols, int k) { return (size_t)256 * k * ((ncols + 3) & ~(size_t)3) + 64 * 8; }
 // out_xy = sum_m X*Y, out_x = sum_m X, out_z = sum_m Z in one pass; afterwards Z's rows with row_flag[m / flag_div] == 0 are zero
 // (row_flag may be null) and Zh (may be null) holds Z's bf16 image.  scratch >= 64 * 3 * N floats.
 int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
-                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s);
+                   float* scratch, const unsigned char* row_flag, int flag_div, void* Zh, hipStream_t s, bool big_scratch = false);
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr,      // zh: bf16 z (z may be null)

@@ -175,7 +175,11 @@ class tPatchGNN(nn.Module):
         return x
 
     def _graph_stage(self, layer, x):
-        """node-vector gating -> adaptive adjacency -> graph convolution -> 1x1 mixing (reference :212-236), (B,N,M,D)"""
+        """node-vector gating -> adaptive adjacency -> graph convolution -> 1x1 mixing (reference :212-236), (B,N,M,D).
+        One fused kernel per direction when a (window, patch) cell's operands fit a CU's LDS (every BASELINE configuration);
+        larger variable counts, or externally supplied `supports`, take the stock-torch formulation below -- the module's tested
+        behaviour for such shapes (tests/test_gpu_backbone.py::test_out_of_limit_shapes_take_the_tested_unfused_paths), not a
+        silent substitute for a missing extension: the fused path raises when the library is absent."""
         B, N, M, D = x.shape
         gc = self.gconv[layer]
         if not self.supports:

@@ -168,6 +168,42 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
         assert _rel(res["hip"][2][n], res["torch"][2][n], floor=1e-3 * gmax) < 2e-4, n
 
 
+def test_out_of_limit_shapes_take_the_tested_unfused_paths():
+    """Shapes outside the fused kernels' limits -- more variables than one graph cell's LDS image holds (adaptive-graph stage), more
+    than 8 patches per variable (transformer block) -- run the module's UNFUSED formulations: `_graph_stage`'s stock-torch branch and
+    `_encoder_layer_hip` (per-op HIP GEMM / attention / LayerNorm).  Neither is reached by a BASELINE configuration; both are the
+    product's behaviour for such inputs, so both are compared with the oracle here (eval mode: no dropout)."""
+    dev = _dev()
+    from immtsf.ops import encoder_layer_supported, gcn_adaptive_supported
+    from models.tPatchGNN import tPatchGNN
+    torch.manual_seed(11)
+    B, N, M, D, nd = 2, 300, 12, 32, 10
+    assert not gcn_adaptive_supported(N, D, nd, 1) and not encoder_layer_supported(M, D, 1)
+    args = types.SimpleNamespace(device=str(dev), hid_dim=D, C=N, npatch=M, nlayer=1, te_dim=4, n_heads=1, tf_layer=1,
+                                 node_dim=nd, hop=1, outlayer="Linear")
+    m = tPatchGNN(args).to(dev).eval()
+    ref = _oracle_twin(m, args, dev).eval()
+    x = torch.randn(B, N, M, D, device=dev)
+    up = torch.randn(B, N, M, D, device=dev)
+    res = {}
+    for mode, mod in (("hip", m), ("torch", ref)):
+        xi = x.clone().requires_grad_(True)
+        out = mod._graph_stage(0, xi) if mode == "hip" else mod.graph_stage(0, xi)
+        (out * up).sum().backward()
+        res[mode] = (out.detach(), xi.grad.clone())
+    assert _rel(res["hip"][0], res["torch"][0]) < 1e-4 and _rel(res["hip"][1], res["torch"][1]) < 2e-4
+    # the transformer over 12 patches: product `_transformer` (falls to `_encoder_layer_hip`) vs the oracle's stock encoder
+    seq = torch.randn(B * 7, M, D, device=dev)
+    ups = torch.randn(B * 7, M, D, device=dev)
+    got, want = [], []
+    for store, fn in ((got, lambda t: m._transformer(0, t)), (want, lambda t: ref.transformer_encoder[0](t))):
+        si = seq.clone().requires_grad_(True)
+        o = fn(si)
+        (o * ups).sum().backward()
+        store += [o.detach(), si.grad.clone()]
+    assert _rel(got[0], want[0]) < 1e-4 and _rel(got[1], want[1]) < 3e-4
+
+
 @pytest.mark.parametrize("L", [32, 45, 7])
 def test_ttcn_on_chip_equals_streaming_bf16(L):
     """bf16 mode: the fused kernel pair (filter tile produced, normalised and pooled on chip; backward recomputes it)

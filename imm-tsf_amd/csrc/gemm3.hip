@@ -70,7 +70,6 @@ template <int OFF> __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
 }
 
 constexpr unsigned G3_OOB = 0xFFFFFF00u;        // a voffset no descriptor below reaches (num_records are clamped to it)
-constexpr int G3_BN = 256;
 
 struct G3Args {
     const void* A;            // bf16
@@ -119,24 +118,28 @@ struct G3Cur {
 // SPLIT (TN weight gradients: few tiles, long reduction): a work item is (tile, K-range); its fp32 partial tile goes to
 //      slab[item] and -- for the tiles of column 0, first wave column -- the column sums of A (the bias gradient, one more MFMA
 //      against a fragment of ones) to slab_b[item]; gemm3_reduce_kernel sums the ranges.  OUT = 1, EPI = 0.
-template <bool TA, bool TB, int BM, int OUT, int EPI, int VAR = 0, bool SPLIT = false>
+// BN: tile width, 256 or 192 (768 = 4 x 192: 512 tiles = exactly two rounds at 32 768 rows where 256-wide tiles make 1.5)
+template <bool TA, bool TB, int BM, int OUT, int EPI, int VAR = 0, bool SPLIT = false, int BN = 256>
 __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     constexpr int GH = BM / 2;                  // rows of a wave group
     constexpr int TMW = GH / 16;                // 16-row MFMA tiles per wave (8 or 4)
     constexpr int HM = TMW / 2;                 // ... per phase (row half mh of the wave's tile)
     constexpr int GQ = GH / 2;                  // rows of one group in one row half (64 or 32)
     constexpr int LPA = GH * 8 / 512;           // LDS-DMA loads per thread per A half-tile (2 or 1)
-    constexpr int LPB = 2;
-    constexpr int A_HALF = GH * 128, B_HALF = 128 * 128;
-    constexpr int STAGE = 2 * A_HALF + 2 * B_HALF;
+    constexpr int TNW = BN / 64;                // 16-column MFMA tiles per wave (4 or 3): wave wc owns columns wc * BN/4 .. of the tile
+    constexpr int WCOLS = BN / 4;
+    constexpr int LPB = BN * 8 / 512;           // LDS-DMA loads per thread for the B region of a stage (4 or 3)
+    constexpr int A_HALF = GH * 128, B_REG = BN * 128;
+    constexpr int STAGE = 2 * A_HALF + B_REG;
     constexpr int EVB = 8 * 1024;               // epilogue vectors of one tile: 1 KiB per wave
     constexpr int NKIND = (OUT & 1) + ((OUT >> 1) & 1);
-    constexpr int NS = HM * 4 * NKIND + (SPLIT ? HM : 0);      // stores per phase of a storing K-tile
-    constexpr int XB = LPA + 2 * LPB;           // loads a thread issues in phase B (A row half 0 + both B halves of K-tile t+2)
+    constexpr int NS = HM * TNW * NKIND + (SPLIT ? HM : 0);    // stores per phase of a storing K-tile
+    constexpr int XB = LPA + LPB;               // loads a thread issues in phase B (A row half 0 + the B region of K-tile t+2)
     constexpr int XA = LPA;                     // ... in phase A (A row half 1 of K-tile t+1)
     constexpr int EV1 = EPI ? 1 : 0;
     constexpr int ST_AUX = 0;        // default cache policy: nt result stores measured 1.1-1.5x slower, sc1 (write-through) 0-10 % slower (r03)
     static_assert(BM == 256 || BM == 128, "tile heights");
+    static_assert(BN == 256 || BN == 192, "tile widths");
     static_assert(!SPLIT || (OUT == 1 && EPI == 0 && TA && TB), "split mode: fp32 partial tiles of a TN product");
     auto cap63 = [](int v) constexpr { return v > 63 ? 63 : v; };      // a smaller count only waits for more
 
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     if (first_id >= nt) return;
 
     // ---------------------------------------------------------------- LDS map of one stage (64-deep K-tile)
-    //   [ Am0 | Am1 | B0 | B1 ]   Am<mh>: row half mh of BOTH wave groups (group 0's GQ rows, then group 1's), what phase mh reads;
-    //                             B<nh>: columns nh*128 .. +127 of the tile (wave wc owns columns nh*128 + wc*32 .. +31 of each)
+    //   [ Am0 | Am1 | B ]   Am<mh>: row half mh of BOTH wave groups (group 0's GQ rows, then group 1's), what phase mh reads;
+    //                       B: the tile's BN columns (wave wc owns columns wc * BN/4 .. + BN/4 - 1), all read in phase A
     // ---------------------------------------------------------------- per-thread constants of the LDS-DMA loads
     // position p = tid (+ 512 for a thread's second load) of a half-tile image
     const int lda2 = g.lda * 2, ldb2 = g.ldb * 2;
@@ -196,7 +199,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     }
     const int stepB = TB ? 128 : 64 * ldb2;                     // a thread's second B load: 64 rows / the next 64-column block
     const int halfA = TA ? GQ * 2 : GQ * lda2;                  // row half 1 of A: GQ rows (columns) further inside each group
-    const int halfB = TB ? 256 : 128 * ldb2;                    // column half 1 of B
     const int kstepA = TA ? 64 * lda2 : 128, kstepB = TB ? 64 * ldb2 : 128;      // bytes per K-tile
 
     // ---------------------------------------------------------------- fragment read offsets (inside a half-tile)
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     // R image: byte offset of (row fr, k-chunk kk*4 + fq) of a 16-row tile; tiles are 2048 bytes apart
     // T image: lane (fq, q = fr>>2, p = fr&3) reads k-lines kk*32 + fq*8 + q (and + 4), columns 16*tl + 4p .. 4p+3: chunk
     //          n8 = 2*(tl&3) + (p>>1) of the k-line's block (tl>>2), stored at slot n8 ^ sw
-    int ofA[4], ofB[2];       // R: [kk]; T: A by tile ii of the phase (this wave's group folded in), B by jj
+    int ofA[4], ofB[4];       // R: [kk]; T: A by tile ii of the phase (this wave's group folded in), B by tile j of the wave
     {
         const int q = fr >> 2, p = fr & 3, sw = ((q >> 1) << 1) | ((fq & 1) << 2);
         const int tbase = ((fq * 8 + q) << 7) + (p & 1) * 8;
@@ -221,12 +223,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         }
         if (!TB) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) ofB[kk] = (wc * 32 + fr) * 128 + (((kk * 4 + fq) ^ (fr >> 1)) << 4);
+            for (int kk = 0; kk < 2; ++kk) ofB[kk] = (wc * WCOLS + fr) * 128 + (((kk * 4 + fq) ^ (fr >> 1)) << 4);
+            ofB[2] = ofB[3] = 0;
         } else {
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {          // tile wc*2 + jj of the half: block wc>>1, tl & 3 = (wc&1)*2 + jj
-                const int t = (wc & 1) * 2 + jj;
-                ofB[jj] = (wc >> 1) * 8192 + tbase + (((2 * t + (p >> 1)) ^ sw) << 4);
+            for (int j = 0; j < 4; ++j) {             // tile wc * TNW + j of the region: 64-column block tl >> 2, position tl & 3
+                const int tl = wc * TNW + (j < TNW ? j : 0);
+                ofB[j] = (tl >> 2) * 8192 + tbase + (((2 * (tl & 3) + (p >> 1)) ^ sw) << 4);
             }
         }
     }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
     };
-    auto fragB = [&](unsigned base, auto jj_c, auto kk_c) __attribute__((always_inline)) -> bf16x8 {     // tile wc*2 + jj of a B half-tile
+    auto fragB = [&](unsigned base, auto jj_c, auto kk_c) __attribute__((always_inline)) -> bf16x8 {     // tile j of this wave's columns
         constexpr int jj = decltype(jj_c)::value, kk = decltype(kk_c)::value;
         if constexpr (VAR == 2 || VAR == 4) {
             bf16x8 d;
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
         const int tn = tile - tm * tiles_n;
         c.row0 = tm * BM;
-        c.col0 = tn * G3_BN;
+        c.col0 = tn * BN;
         c.kt0 = split * nk;
         const int kend = (c.kt0 + nk) * 64;
         c.krem0 = ok ? (kend < K ? kend : K) : 0;
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         c.kt += 1;
         if (c.kt == nk) set_tile(c, c.id + G);
     };
-    // one half-tile of cursor c's K-tile into LDS at `dst` (wave-uniform): A row half mh / B column half nh
+    // cursor c's K-tile into LDS at `dst` (wave-uniform): A row half mh (a half-tile) / the whole B region
     auto issueA = [&](const G3Cur& c, int mh, unsigned char* dst) __attribute__((always_inline)) {
         if (VAR == 3 || VAR == 4) return;
         const int krem = c.krem0 - (c.kt0 + c.kt) * 64;
@@ -312,14 +315,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(c.ra, (lds_vp)(dst + i * 8192 + wave * 1024), 16, (int)v, 0, 0, 0);
         }
     };
-    auto issueB = [&](const G3Cur& c, int nh, unsigned char* dst) __attribute__((always_inline)) {
+    auto issueB = [&](const G3Cur& c, unsigned char* dst) __attribute__((always_inline)) {
         if (VAR == 3 || VAR == 4) return;
         const int krem = c.krem0 - (c.kt0 + c.kt) * 64;
-        const unsigned uadd = (unsigned)((c.kt0 + c.kt) * kstepB + nh * halfB);
+        const unsigned uadd = (unsigned)((c.kt0 + c.kt) * kstepB);
 #pragma unroll
         for (int i = 0; i < LPB; ++i) {
             bool ok = kcB < krem;
-            if (TB) ok = ok & (nh * 128 + i * 64 + c8B + 8 <= c.ncolB);
+            if (TB) ok = ok & (i * 64 + c8B + 8 <= c.ncolB);
             const unsigned v = ok ? (unsigned)voB + (unsigned)(i * stepB) + uadd : G3_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rb, (lds_vp)(dst + i * 8192 + wave * 1024), 16, (int)v, 0, 0, 0);
         }
@@ -350,14 +353,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     };
 
     // ---------------------------------------------------------------- accumulators and the epilogue
-    f32x4 acc[TMW][4];
+    f32x4 acc[TMW][TNW];
     // split mode stores the item's tile at rows item*BM .. of the slab (pitch 256 floats, all 256 columns, alpha applied later)
-    const __amdgpu_buffer_rsrc_t rC = SPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)g.slab, (short)0, nrec_of(nt * BM, 1024, 0), 0x00020000)
+    const __amdgpu_buffer_rsrc_t rC = SPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)g.slab, (short)0, nrec_of(nt * BM, BN * 4, 0), 0x00020000)
                                             : __builtin_amdgcn_make_buffer_rsrc((void*)g.C, (short)0, nrec_of(M, g.ldc * 4, 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc((void*)g.Ch, (short)0, nrec_of(M, g.ldch * 2, 0), 0x00020000);
     const __amdgpu_buffer_rsrc_t rSB = __builtin_amdgcn_make_buffer_rsrc((void*)g.slab_b, (short)0, SPLIT && g.slab_b ? nt * BM * 4 : 0, 0x00020000);
-    const unsigned ldc4 = SPLIT ? 1024u : (unsigned)g.ldc * 4u, ldh2 = (unsigned)g.ldch * 2u;
-    const int Nst = SPLIT ? 256 : N;            // columns that exist in the store target
+    const unsigned ldc4 = SPLIT ? (unsigned)(BN * 4) : (unsigned)g.ldc * 4u, ldh2 = (unsigned)g.ldch * 2u;
+    const int Nst = SPLIT ? BN : N;            // columns that exist in the store target
     const float alpha = SPLIT ? 1.f : g.alpha;
     f32x4 accb[SPLIT ? TMW : 1];                // split mode: column sums of A for this wave's rows (tiles of column 0, wave column 0)
     bf16x8 ones;
@@ -371,13 +374,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         // an opaque zero: keeps the offsets below from being hoisted out of the tile loop into two dozen long-lived VGPRs
         int oz;
         asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-        const int colw = wc * 32 + fq * 4 + oz;                     // column inside the tile of this lane's 4 values, j = 0
+        const int colw = wc * WCOLS + fq * 4 + oz;                  // column inside the tile of this lane's 4 values, j = 0
         const int rloc = grp * GH + mh * GQ + fr;                   // row inside the tile, ii = 0
         const unsigned vrow = (unsigned)(row0 + rloc);
         const unsigned voC = vrow * ldc4 + (unsigned)(col0 + colw) * 4u, voH = vrow * ldh2 + (unsigned)(col0 + colw) * 2u;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ct = colw + (j >> 1) * 128 + (j & 1) * 16;
+        for (int j = 0; j < TNW; ++j) {
+            const int ct = colw + j * 16;
             const bool cok = col0 + ct < Nst;                        // N % 4 == 0: a lane's 4 columns are in or out together
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, a4 = {0.f, 0.f, 0.f, 0.f};
             if (EPI) {
@@ -396,12 +399,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
                     for (int e = 0; e < 4; ++e) v[e] = alpha * v[e];
                 }
                 if (OUT & 1) {
-                    const unsigned vo = cok ? voC + (unsigned)(ii * 16) * ldc4 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 4) : G3_OOB;
+                    const unsigned vo = cok ? voC + (unsigned)(ii * 16) * ldc4 + (unsigned)(j * 64) : G3_OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rC, (int)vo, 0, ST_AUX);
                 }
                 if (OUT & 2) {
                     const bf16x4 h = __builtin_convertvector(v, bf16x4);
-                    const unsigned vo = cok ? voH + (unsigned)(ii * 16) * ldh2 + (unsigned)(((j >> 1) * 128 + (j & 1) * 16) * 2) : G3_OOB;
+                    const unsigned vo = cok ? voH + (unsigned)(ii * 16) * ldh2 + (unsigned)(j * 32) : G3_OOB;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, h), rH, (int)vo, 0, ST_AUX);
                 }
             }
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 #pragma unroll
         for (int ii = 0; ii < HM; ++ii)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < TNW; ++j) {
                 float z0, z1, z2, z3;       // (opaque to the optimiser, which would otherwise fold the zero back into the MFMA's C)
                 asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z0), "=v"(z1), "=v"(z2), "=v"(z3));
                 acc[mh * HM + ii][j] = f32x4{z0, z1, z2, z3};
@@ -441,15 +444,13 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     // ---------------------------------------------------------------- prologue
     G3Cur c1, c2;             // c1: the K-tile after the one being computed; c2: the one after that
     set_tile(c1, first_id);
-    // K-tile 0 of the first tile completely; A row half 0 and both B halves of K-tile 1
+    // K-tile 0 of the first tile completely; A row half 0 and the B region of K-tile 1
     issueA(c1, 0, smem);
     issueA(c1, 1, smem + A_HALF);
-    issueB(c1, 0, smem + 2 * A_HALF);
-    issueB(c1, 1, smem + 2 * A_HALF + B_HALF);
+    issueB(c1, smem + 2 * A_HALF);
     advance(c1);
     issueA(c1, 0, smem + STAGE);
-    issueB(c1, 0, smem + STAGE + 2 * A_HALF);
-    issueB(c1, 1, smem + STAGE + 2 * A_HALF + B_HALF);
+    issueB(c1, smem + STAGE + 2 * A_HALF);
     c2 = c1;
     advance(c2);
     wait_vm<(VAR == 3 || VAR == 4) ? 0 : XB>();
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
     // ---------------------------------------------------------------- one K-tile = 2 phases (row halves of the wave's tile)
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    bf16x8 af[2][HM], bf[2][4];          // A fragments of the current row half, B fragments of all 4 column tiles (kept for phase B)
+    bf16x8 af[2][HM], bf[2][TNW];        // A fragments of the current row half, B fragments of the wave's column tiles (kept for phase B)
     int buf = 0, evsel = 0;
     int prow0 = 0, pcol0 = 0;            // the tile whose accumulators are complete (being stored)
     bool do_b = false, pdo_b = false;      // split mode: this wave forms the bias-gradient sums of the current / the finished item
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 #pragma unroll
             for (int ii = 0; ii < HM; ++ii)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNW; ++j) {
                     f32x4& a = acc[mh * HM + ii][j];
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[kk][j], af[kk][ii], a, 0, 0, 0);
                 }
@@ -532,18 +533,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
             } else {
                 const int tm = g.tn_magic ? (int)__umulhi((unsigned)id, g.tn_magic) : id;
                 row0 = tm * BM;
-                col0 = (id - tm * tiles_n) * G3_BN;
+                col0 = (id - tm * tiles_n) * BN;
             }
         }
         unsigned char* st = smem + buf * STAGE;
         unsigned char* nx = smem + (buf ^ 1) * STAGE;
         const unsigned sA0 = (unsigned)(buf * STAGE), sA1 = sA0 + A_HALF;
-        const unsigned sB0 = sA0 + 2 * A_HALF, sB1 = sB0 + B_HALF;
+        const unsigned sB = sA0 + 2 * A_HALF;
         const unsigned char* evp = smem + 2 * STAGE + (evsel ^ 1) * EVB;        // vectors of the tile being stored
         // ---- phase A: row half 0 x all 4 column tiles
         static_for<2>([&](auto kk) {
-            static_for<2>([&](auto jj) { bf[kk][jj] = fragB(sB0, jj, kk); });
-            static_for<2>([&](auto jj) { bf[kk][2 + jj] = fragB(sB1, jj, kk); });
+            static_for<TNW>([&](auto jj) { bf[kk][jj] = fragB(sB, jj, kk); });
             static_for<HM>([&](auto ii) { af[kk][ii] = fragA(sA0, ii, kk); });
         });
         issueA(c1, 1, nx + A_HALF);
@@ -563,8 +563,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         // ---- phase B: row half 1
         static_for<2>([&](auto kk) { static_for<HM>([&](auto ii) { af[kk][ii] = fragA(sA1, ii, kk); }); });
         issueA(c2, 0, st);
-        issueB(c2, 0, st + 2 * A_HALF);
-        issueB(c2, 1, st + 2 * A_HALF + B_HALF);
+        issueB(c2, st + 2 * A_HALF);
         if (VAR != 3 && VAR != 4) {
             // younger than phase B's loads of the previous K-tile: [stores of the previous K-tile's phase B] phase A's XA [+ vectors]
             // [stores of phase A] this phase's XB
@@ -642,31 +641,32 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restri
     }
 }
 
-int g3_bm = 0, g3_grid = 0, g3_var = 0;      // tool overrides (immtsf_debug_gemm3_config)
+constexpr int G3_BN = 256;                   // tile width of the split-K path and the default
+int g3_bm = 0, g3_grid = 0, g3_var = 0, g3_bn = 0;      // tool overrides (immtsf_debug_gemm3_config)
 
-template <bool TA, bool TB, int BM, int EPI>
+template <bool TA, bool TB, int BM, int EPI, int BN>
 int launch3_epi(const G3Args& g, int grid, hipStream_t stream) {
     const int out = (g.C ? 1 : 0) | (g.Ch ? 2 : 0);
     switch (out) {
-        case 1: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 1, EPI>), dim3(grid), dim3(512), 0, stream, g); break;
+        case 1: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 1, EPI, 0, false, BN>), dim3(grid), dim3(512), 0, stream, g); break;
         case 2:
-            if constexpr (BM == 256 && EPI == 0 && !TA && !TB) {     // timing experiments (tools/gemm3_bench.py probe); 2-4 compute garbage
+            if constexpr (BM == 256 && EPI == 0 && !TA && !TB && BN == 256) {     // timing experiments (tools/gemm3_bench.py probe); 2-4 compute garbage
                 if (g3_var == 2) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 2>), dim3(grid), dim3(512), 0, stream, g); break; }
                 if (g3_var == 3) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 3>), dim3(grid), dim3(512), 0, stream, g); break; }
                 if (g3_var == 4) { hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 4>), dim3(grid), dim3(512), 0, stream, g); break; }
             }
-            hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI>), dim3(grid), dim3(512), 0, stream, g);
+            hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 2, EPI, 0, false, BN>), dim3(grid), dim3(512), 0, stream, g);
             break;
-        case 3: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 3, EPI>), dim3(grid), dim3(512), 0, stream, g); break;
+        case 3: hipLaunchKernelGGL((gemm3_kernel<TA, TB, BM, 3, EPI, 0, false, BN>), dim3(grid), dim3(512), 0, stream, g); break;
         default: return IMMTSF_EINVAL;
     }
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
-template <bool TA, bool TB, int BM>
+template <bool TA, bool TB, int BM, int BN = 256>
 int launch3_out(const G3Args& g, int grid, hipStream_t stream) {
-    if (g.bias || g.add_vec || g.row_flag) return launch3_epi<TA, TB, BM, 1>(g, grid, stream);
-    return launch3_epi<TA, TB, BM, 0>(g, grid, stream);
+    if (g.bias || g.add_vec || g.row_flag) return launch3_epi<TA, TB, BM, 1, BN>(g, grid, stream);
+    return launch3_epi<TA, TB, BM, 0, BN>(g, grid, stream);
 }
 
 inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -674,7 +674,8 @@ inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 }  // namespace
 
 extern "C" int immtsf_debug_gemm3_config(int bm, int grid) {
-    g3_bm = bm & 0xffff;         // bits 16..: experimental kernel variant (tools only)
+    g3_bm = bm & 0xfff;          // bits 12..15: tile width override (1: 256, 2: 192); bits 16..: experimental kernel variant (tools only)
+    g3_bn = (bm >> 12) & 0xf;
     g3_var = bm >> 16;
     g3_grid = grid;
     return 0;
@@ -709,26 +710,37 @@ int immtsf_launch_gemm3(int layout, const void* A, int lda, const void* B, int l
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldch = ldch;
     g.alpha = alpha;
-    g.tiles_n = cdiv(N, G3_BN);
-    g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
-    // tile height: 256 rows unless that leaves the last round of tiles mostly empty and 128-row tiles fill it
-    int bm = g3_bm;
-    if (bm == 0) {
-        const long t256 = (long)cdiv(M, 256) * g.tiles_n, t128 = (long)cdiv(M, 128) * g.tiles_n;
-        const double e256 = (double)t256 / (256.0 * cdiv((int)t256, 256)), e128 = (double)t128 / (256.0 * cdiv((int)t128, 256));
-        bm = (e256 >= 0.85 || e256 >= e128) ? 256 : 128;
+    // tile shape by the time model rounds(tiles / 256 workgroups) x tile area (192-wide tiles cost ~6 % more per flop: fewer
+    // MFMAs per byte staged); 128-row tiles only when the 256-row rounds are poorly filled.  192-wide tiles exist for NT / NN.
+    int bm = g3_bm, bn = g3_bn == 1 ? 256 : g3_bn == 2 ? 192 : 0;
+    {
+        double best = 0;
+        int bbm = 256, bbn = 256;
+        for (int cand = 0; cand < 4; ++cand) {
+            const int cbm = cand & 1 ? 128 : 256, cbn = cand & 2 ? 192 : 256;
+            if ((bm && cbm != bm) || (bn && cbn != bn)) continue;
+            if (cbn == 192 && (layout == GEMM_TN || cbm != 256)) continue;
+            const long tiles = (long)cdiv(M, cbm) * cdiv(N, cbn);
+            const double cost = (double)cdiv((int)((tiles + 255) / 256 * 256), 256) * cbm * cbn * (cbm == 128 ? 1.18 : 1.0) * (cbn == 192 ? 1.06 : 1.0);
+            if (best == 0 || cost < best) { best = cost; bbm = cbm; bbn = cbn; }
+        }
+        if (best == 0) return IMMTSF_EINVAL;
+        bm = bbm; bn = bbn;
     }
+    g.tiles_n = cdiv(N, bn);
+    g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
     const long nt = (long)cdiv(M, bm) * g.tiles_n;
     if (nt * 8 >= 0x7fffffff) return IMMTSF_EUNSUPPORTED;
     int grid = g3_grid > 0 ? g3_grid : 256;
     if (!dyn_rows && nt < grid) grid = (int)((nt + 7) / 8 * 8);
     grid = (grid + 7) / 8 * 8;
     immtsf_gemm_note_grid((long)grid * 512);
-#define G3_LAUNCH(TA_, TB_) (bm == 256 ? launch3_out<TA_, TB_, 256>(g, grid, stream) : launch3_out<TA_, TB_, 128>(g, grid, stream))
+#define G3_LAUNCH(TA_, TB_) (bn == 192 ? launch3_out<TA_, TB_, 256, 192>(g, grid, stream) \
+                            : bm == 256 ? launch3_out<TA_, TB_, 256>(g, grid, stream) : launch3_out<TA_, TB_, 128>(g, grid, stream))
     switch (layout) {
         case GEMM_NT: return G3_LAUNCH(false, false);
         case GEMM_NN: return G3_LAUNCH(false, true);
-        default: return G3_LAUNCH(true, true);
+        default: return bm == 256 ? launch3_out<true, true, 256>(g, grid, stream) : launch3_out<true, true, 128>(g, grid, stream);
     }
 #undef G3_LAUNCH
 }

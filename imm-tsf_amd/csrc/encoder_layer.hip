@@ -16,6 +16,7 @@
 #include "../../include/immtsf.h"
 #include "attn.hpp"
 #include "block_util.hpp"
+#include "ffn32.hpp"
 #include "rowops.hpp"
 
 namespace {
@@ -76,6 +77,11 @@ struct FFNDims { int R, D, F, act, prec; float eps; uint64_t site_h, site_out; }
 int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const float* x1, const float* w1, const float* b1,
                 const float* w2, const float* b2, const float* ln_w, const float* ln_b, float* h, float* z, float* ff, float* xhat,
                 float* rstd, float* out, hipStream_t s) {
+    if (ffn32_ok(f.R, f.D, f.F, f.act, f.prec)) {       // many rows, d_model 32: h never exists (ffn32.hip); its buffer holds the mask words
+        if (ffn32_saved_bytes(f.R, f.F) > (size_t)f.R * f.F * sizeof(float)) return IMMTSF_EWORKSPACE;
+        CHECK(ffn32_forward(f.R, f.F, dd, f.site_h, x1, w1, b1, w2, b2, h, ff, s));
+        return launch_layernorm_fwd(ff, f.R, f.D, ln_w, ln_b, f.eps, xhat, rstd, out, none, 0, s, nullptr, x1, dd, f.site_out);
+    }
     {   // h = dropout(act(x1 W1^T + b1)): activation and dropout in the epilogue (z = the pre-activation, GELU only)
         GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.D, f.F);
         set_problem(g, 0, x1, w1, h, b1);
@@ -92,8 +98,8 @@ int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const 
     return launch_layernorm_fwd(ff, f.R, f.D, ln_w, ln_b, f.eps, xhat, rstd, out, none, 0, s, nullptr, x1, dd, f.site_out);
 }
 // dout -> d1 (gradient wrt x1, complete: residual share + through the two GEMMs) and the six parameter gradients
-int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int pz, const float* x1, const float* w1, const float* w2,
-                 const float* ln_w, const float* h, const float* z, const float* xhat, const float* rstd, const float* dout, float* d1,
+int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int pz, const float* x1, const float* w1, const float* b1,
+                 const float* w2, const float* ln_w, const float* h, const float* z, const float* xhat, const float* rstd, const float* dout, float* d1,
                  float* dff, float* dh, float* red, float* gw1, float* gb1, float* gw2, float* gb2, float* gln_w, float* gln_b,
                  hipStream_t s) {
     auto wgrad = [&](const float* dy, const float* xin, int N, int K, float* dW, float* db) {
@@ -107,6 +113,11 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
     float* g2 = const_cast<float*>(dout);
     CHECK(launch_layernorm_bwd(g2, f.R, f.D, ln_w, xhat, rstd, d1, none, 0, s, dff, dd, f.site_out));
     CHECK(launch_colsum2(g2, xhat, f.R, f.D, f.D, gln_w, gln_b, red, s, true));       // (red: colsum_scratch_floats(D, 2) at both carve sites)
+    if (ffn32_ok(f.R, f.D, f.F, f.act, f.prec)) {       // the forward took the fused path: h holds weight images + mask words
+        if (ffn32_scratch_bytes(f.R, f.F) > (size_t)f.R * f.F * sizeof(float)) return IMMTSF_EWORKSPACE;
+        CHECK(ffn32_backward(f.R, f.F, dd, x1, b1, dff, h, dh, d1, gw1, gb1, gw2, s));
+        return launch_colsum(dff, nullptr, f.R, nullptr, f.D, f.D, gb2, 0, red, s, true);
+    }
     {   // linear2: dh = (dff W2) x act'(.) x the feed-forward dropout
         GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.F, f.F);
         set_problem(g, 0, dff, w2, dh, nullptr);
@@ -220,7 +231,7 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
     };
     {
         const FFNDims f{R, D, F, 1, prec, c->eps, c->site_base + 2, c->site_base + 3};
-        CHECK(ffn_backward(f, dd, none, pz, w.x1, p->w1, p->w2, p->ln2_w, w.h, nullptr, w.xhat2, w.rstd2, dout, sc.d1, sc.dff, sc.dh, sc.red,
+        CHECK(ffn_backward(f, dd, none, pz, w.x1, p->w1, p->b1, p->w2, p->ln2_w, w.h, nullptr, w.xhat2, w.rstd2, dout, sc.d1, sc.dff, sc.dh, sc.red,
                            gr->w1, gr->b1, gr->w2, gr->b2, gr->ln2_w, gr->ln2_b, s));
     }
     // LayerNorm1: dx = gradient of (x + drop(sa)) -- the input's residual share; dsa = dx * dropout mask
@@ -287,7 +298,7 @@ int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_bl
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
     const FFNDims f{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
-    return ffn_backward(f, dd, none, c->grads_prezeroed ? 1 : 0, x, p->w1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
+    return ffn_backward(f, dd, none, c->grads_prezeroed ? 1 : 0, x, p->w1, p->b1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
                         sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream));
 }
 

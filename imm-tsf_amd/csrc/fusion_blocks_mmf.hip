@@ -135,7 +135,7 @@ QScratch carve_q_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dWQf = k.take<float>(d * C);
     s.dWHO = k.take<float>(C * d);
     s.slive = k.take<float>(C);
-    s.red = k.take<float>(64 * (d + C + 8));
+    s.red = k.take<float>(64 * (d + C + 8) + colsum_scratch_floats(C, 2));
     s.bytes = k.bytes();
     return s;
 }
@@ -462,7 +462,7 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
         CHECK(launch_head_sums(sc.dn, w.xhatC, sc.ddelta, M_txt, T, BT, C, gr->ln_w, gr->ln_b, sc.slive, s));
         CHECK(launch_head_outer(p->res_w, d, sc.slive, p->attn_out_b, C, gr->attn_out_b, gr->res_w, s));
     } else {
-        CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
+        CHECK(launch_colsum2(sc.dn, w.xhatC, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s, true));
     }
     {   // dW_HO = ddelta^T O (O is zero in the no-text windows);  d b_res = column sums of ddelta over ALL rows
         GemmArgs h = gemm_args(C, d, BT, C, d, d);
@@ -472,7 +472,7 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
     }
     if (!hs) {
         CHECK(launch_mask_rows(sc.ddelta, BT, C, M_txt, T, s));       // from here on only the windows with text
-        CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s));
+        CHECK(launch_colsum(sc.ddelta, nullptr, BT, nullptr, C, C, sc.slive, 0, sc.red, s, true));
     }
     {   // chain rule through W_HO = W_res W_out, b_HO = W_res b_out + b_res
         if (!hs) {

@@ -93,7 +93,7 @@ GRScratch carve_gr_scratch(const immtsf_fusion_cfg* c, int Hd, void* base) {
     s.dgi = k.take<float>(BT * 3 * Hd);
     s.dgh = k.take<float>(BT * 3 * Hd);
     s.dx = k.take<float>(BT * (C + d));
-    s.red = k.take<float>(64 * (C + d + 3 * Hd + 8));
+    s.red = k.take<float>(64 * (C + d + 3 * Hd + 8) + colsum_scratch_floats(C, 2));
     s.bytes = k.bytes();
     return s;
 }
@@ -222,7 +222,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
     Fork fk(s);
     CHECK(launch_gr_tail_bwd(BT, T, C, Hd, dY_out, p->res_w, p->ln_w, w.xhat, w.rstd, w.g, w.dd, M_txt, sc.dn, sc.ddelta,
                              sc.dgl, sc.dh_in, drop, SITE_GR_OUT, s));
-    CHECK(launch_colsum2(sc.dn, w.xhat, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s));
+    CHECK(launch_colsum2(sc.dn, w.xhat, BT, C, C, gr->ln_w, gr->ln_b, sc.red, s, true));
     {   // residual_head: dW_r = ddelta^T h ; db_r
         GemmArgs h = gemm_args(C, Hd, BT, C, Hd, Hd);
         set_problem(h, 0, sc.ddelta, w.h, gr->res_w, nullptr, gr->res_b);

@@ -1041,8 +1041,10 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
 }
 
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
-                  float* scratch, hipStream_t s) {
+                  float* scratch, hipStream_t s, bool big_scratch) {
     if (N <= 0) return IMMTSF_OK;
+    if (!dyn && colsum_vec_ok(X, Y, nullptr, nullptr, M, N, ld, big_scratch))
+        return launch_colsum_vec<1>(X, Y, nullptr, M, N, ld, out, nullptr, nullptr, accumulate, scratch, nullptr, 1, nullptr, s);
     if (N <= 32 && !dyn && (long)M * N <= (1L << 17)) {
         int CT = 1;
         while (CT < N) CT <<= 1;

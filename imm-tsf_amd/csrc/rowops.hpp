@@ -33,7 +33,7 @@ int launch_time2vec_bwd(const float* tau_pad, const int* rowmap, const int* tota
                         float* db, float* scratch, int nslabs, hipStream_t s, int accumulate = 0);
 // out[n] = sum_{m < M} X[m,n] * (Y ? Y[m,n] : 1)   (M may come from *dyn).  scratch >= 32*N floats.
 int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, int ld, float* out, int accumulate,
-                  float* scratch, hipStream_t s);
+                  float* scratch, hipStream_t s, bool big_scratch = false);       // big_scratch: as for launch_colsum2 (k = 1)
 // out_xy[n] = sum_m X*Y, out_x[n] = sum_m X in one pass (LayerNorm's gamma / beta gradients).  scratch >= 64*N floats.
 // big_scratch: scratch holds colsum_scratch_floats(N, 2) floats -- enables the many-row path (M >= 4096: 16-byte loads, <= 256 slabs)
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,

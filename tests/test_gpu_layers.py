@@ -420,6 +420,54 @@ def test_encoder_layer_block_dropout_masks():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("R,p", [(6007, 0.0), (6007, 0.3), (2048, 0.3), (40000, 0.1)])
+def test_ffn_block_many_rows_fused_vs_torch(R, p):
+    """The many-rows feed-forward of tPatchGNN's encoder layer (csrc/ffn32.hip: d_model 32, dim_feedforward 2048, ReLU, bf16,
+    no (R x F) intermediate; reference models/tPatchGNN.py:118-121) against the float64 torch composition that uses the
+    exported Philox keep-masks -- forward, data gradient and all parameter gradients at the bf16 bars; ragged row counts
+    (not a multiple of the 16-row tiles / 128-row sub-blocks) and the three rows-per-wave variants."""
+    dev = _dev()
+    from immtsf import config, ops
+    D, F = 32, 2048
+    torch.manual_seed(17)
+    config.manual_seed(23)
+    conv1, conv2 = torch.nn.Conv1d(D, F, 1).to(dev), torch.nn.Conv1d(F, D, 1).to(dev)
+    n2 = torch.nn.LayerNorm(D).to(dev)
+    with torch.no_grad():
+        n2.weight.uniform_(0.5, 1.5)
+        n2.bias.uniform_(-0.3, 0.3)
+        conv1.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(1, R, D, device=dev, requires_grad=True)
+    up = torch.randn(1, R, D, device=dev)
+    base = ops.SITE_LAYER_BASE + 192
+    c0 = config._counter
+    config.precision = "bf16"
+    try:
+        y = ops.ffn_block(x, conv1, conv2, n2, "relu", p, True, base)
+        (y * up).sum().backward()
+    finally:
+        config.precision = "fp32"
+    config._counter = c0
+    seed = config.next_seed() if p > 0 else 0
+    keep = lambda site, shape: (ops.dropout_keep_mask(seed, site, int(np.prod(shape)), p, dev).view(*shape).double() / (1 - p)  # noqa: E731
+                                if p > 0 else torch.ones(*shape, dtype=torch.float64, device=dev))
+    mh, mo = keep(base, (R, F)), keep(base + 1, (R, D))
+    P = {k: q.detach().double().requires_grad_(True) for k, q in (("w1", conv1.weight), ("b1", conv1.bias), ("w2", conv2.weight),
+                                                                  ("b2", conv2.bias), ("g2", n2.weight), ("be2", n2.bias))}
+    xd = x.detach().double().reshape(R, D).requires_grad_(True)
+    h = torch.relu(xd @ P["w1"].squeeze(-1).T + P["b1"]) * mh
+    ff = h @ P["w2"].squeeze(-1).T + P["b2"]
+    out = torch.nn.functional.layer_norm(xd + ff * mo, (D,), P["g2"], P["be2"], n2.eps)
+    (out * up.double().reshape(R, D)).sum().backward()
+    assert _l2err(y.reshape(R, D), out.detach().float()) <= 3e-2
+    errs = {"dx": _l2err(x.grad.reshape(R, D), xd.grad.float()),
+            "w1": _l2err(conv1.weight.grad, P["w1"].grad.float()), "b1": _l2err(conv1.bias.grad, P["b1"].grad.float()),
+            "w2": _l2err(conv2.weight.grad, P["w2"].grad.float()), "b2": _l2err(conv2.bias.grad, P["b2"].grad.float()),
+            "g2": _l2err(n2.weight.grad, P["g2"].grad.float()), "be2": _l2err(n2.bias.grad, P["be2"].grad.float())}
+    bad = {k: v for k, v in errs.items() if not v <= 4e-2}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("act,p", [("gelu", 0.0), ("gelu", 0.3), ("relu", 0.3)])
 def test_ffn_block_and_residual_layernorm_vs_torch(act, p):
     """ops.residual_layer_norm + ops.ffn_block (the two joints of layers.Transformer_EncDec.EncoderLayer) against a float64

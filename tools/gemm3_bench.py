@@ -139,16 +139,18 @@ if mode in ("check", "full", "bigm"):
     if mode == "bigm":
         cases = [(0, 2048, 768, 768), (1, 2048, 768, 768), (0, 513, 1152, 136)]
     for layout, M, N, K in cases:
-        for bm in (256, 128):
+        for bm in (256 | (1 << 12), 128 | (1 << 12), 256 | (2 << 12)):          # 1 << 12: 256-wide tiles, 2 << 12: 192-wide (NT / NN)
+            if (bm >> 12) == 2 and layout == 2:
+                continue
             for extras in (False, True):
                 for out in (("both",) if not extras else ("both", "bf16", "f32")):
                     r = check(layout, M, N, K, bm, out, extras)
                     if r is None:
-                        print(f"{LAY[layout]} {M}x{N}x{K} bm{bm} unsupported", flush=True)
+                        print(f"{LAY[layout]} {M}x{N}x{K} bm{bm & 0xfff} unsupported", flush=True)
                         continue
                     ok = r[0] < 2e-5 and r[1] < 1e-2
                     bad += 0 if ok else 1
-                    print(f"{LAY[layout]} {M}x{N}x{K} bm{bm} out={out:4s} extras={int(extras)} err {r[0]:.1e} / {r[1]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
+                    print(f"{LAY[layout]} {M}x{N}x{K} bm{bm & 0xfff}{['', '', 'w192'][min(bm >> 12, 2)]} out={out:4s} extras={int(extras)} err {r[0]:.1e} / {r[1]:.1e} {'ok' if ok else 'FAIL'}", flush=True)
     # device-side row count
     M, N, K = 3000, 768, 768
     Ah, Bh = operands(0, M, N, K)
@@ -262,8 +264,11 @@ if mode in ("bigm", "full"):
         for out in outs:
             g2 = bench_g2(lay, M, N, K, out)
             line = f"   out={out:4s} gemm2 {g2[0]:8.1f} us {fl / g2[0] / 1e6:7.1f} TF |" if g2 else f"   out={out:4s} gemm2 - |"
-            for bm in (256, 128):
+            for bm in (256 | (1 << 12), 128 | (1 << 12), 256 | (2 << 12), 0):
+                if lay == 2 and (bm >> 12) == 2:
+                    continue
                 r = bench(lay, M, N, K, out, bm)
-                line += f" g3 bm{bm} {r[0]:8.1f} / {r[1]:8.1f} us {fl / r[0] / 1e6:7.1f} TF |" if r else f" g3 bm{bm} - |"
+                tag = "auto" if bm == 0 else f"{bm & 0xfff}x{256 if (bm >> 12) == 1 else 192}"
+                line += f" g3 {tag} {r[0]:8.1f} / {r[1]:8.1f} us {fl / r[0] / 1e6:7.1f} TF |" if r else f" g3 {tag} - |"
             print(line, flush=True)
 sys.exit(1 if bad else 0)

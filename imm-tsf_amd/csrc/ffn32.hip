@@ -113,13 +113,48 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
     const bf16x8* fa = reinterpret_cast<const bf16x8*>(a.imgA) + lane;
     const bf16x8* fb = reinterpret_cast<const bf16x8*>(a.imgB) + lane;
     const bool drop = !BWD && a.drop.p > 0.f;
+    // the next chunk's weight fragments, bias and (backward) mask words are requested before the current chunk is computed:
+    // one chunk is ~4 RT MFMAs, far shorter than a trip to L2
+    bf16x8 n1_0 = fa[0], n1_1 = fa[64], n2_0 = fb[0], n2_1 = fb[64];
+    float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
+    if (!BWD) {
+        nb0 = *reinterpret_cast<const float4*>(a.b1 + fq * 4);
+        nb1 = *reinterpret_cast<const float4*>(a.b1 + 16 + fq * 4);
+    }
+    uint64_t nm[BWD ? RT : 1][8];
+    if (BWD) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const uint64_t* rec = a.mask + (size_t)min(rt0 + rt, a.nrt - 1) * 8;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) nm[rt][w] = rec[w];
+        }
+    }
     for (int c = 0; c < NC; ++c) {
-        const bf16x8 a1_0 = fa[(c * 2 + 0) * 64], a1_1 = fa[(c * 2 + 1) * 64];
-        const bf16x8 a2_0 = fb[(c * 2 + 0) * 64], a2_1 = fb[(c * 2 + 1) * 64];
-        float4 bb0 = make_float4(0.f, 0.f, 0.f, 0.f), bb1 = bb0;
-        if (!BWD) {
-            bb0 = *reinterpret_cast<const float4*>(a.b1 + c * 32 + fq * 4);
-            bb1 = *reinterpret_cast<const float4*>(a.b1 + c * 32 + 16 + fq * 4);
+        const bf16x8 a1_0 = n1_0, a1_1 = n1_1, a2_0 = n2_0, a2_1 = n2_1;
+        const float4 bb0 = nb0, bb1 = nb1;
+        uint64_t cm[BWD ? RT : 1][8];
+        if (BWD) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) cm[rt][w] = nm[rt][w];
+        }
+        {
+            const int cn = c + 1 < NC ? c + 1 : c;
+            n1_0 = fa[(cn * 2 + 0) * 64]; n1_1 = fa[(cn * 2 + 1) * 64];
+            n2_0 = fb[(cn * 2 + 0) * 64]; n2_1 = fb[(cn * 2 + 1) * 64];
+            if (!BWD) {
+                nb0 = *reinterpret_cast<const float4*>(a.b1 + cn * 32 + fq * 4);
+                nb1 = *reinterpret_cast<const float4*>(a.b1 + cn * 32 + 16 + fq * 4);
+            } else {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const uint64_t* rec = a.mask + ((size_t)cn * a.nrt + min(rt0 + rt, a.nrt - 1)) * 8;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) nm[rt][w] = rec[w];
+                }
+            }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -157,8 +192,8 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    h0[e] = sel_mask(h0[e], rec[e]);
-                    h1[e] = sel_mask(h1[e], rec[4 + e]);
+                    h0[e] = sel_mask(h0[e], cm[rt][e]);
+                    h1[e] = sel_mask(h1[e], cm[rt][4 + e]);
                 }
             }
             const bf16x8 hb = pack8(h0, h1);
@@ -202,7 +237,7 @@ constexpr int WG_SB = 128;    // rows per LDS sub-block
 __device__ __forceinline__ unsigned img_off(int r, int q) { return (unsigned)(r * 64 + ((q ^ ((r >> 2) & 3)) << 4)); }
 
 // grid (F / 256, row blocks), 256 threads: wave w owns chunks blockIdx.x * 8 + 2 w, + 1
-__global__ __launch_bounds__(256) void ffn32_wgrad_kernel(const WgArgs a) {
+__global__ __launch_bounds__(256, 2) void ffn32_wgrad_kernel(const WgArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char sx[WG_SB * 64], sd[WG_SB * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int F = a.F, NC = F >> 5;
@@ -243,6 +278,14 @@ __global__ __launch_bounds__(256) void ffn32_wgrad_kernel(const WgArgs a) {
         }                                                                                                    \
     }
     FFN32_FETCH(row_lo)
+    // this lane's 16-bit mask piece of (chunk c0 + ch, row tile rt, ft): mbase[(ch * nrt + rt) * 32 + ft * 16]
+    const uint16_t* mbase = a.mask16 + (size_t)c0 * a.nrt * 32 + (fr & 3) * 4 + (fr >> 2);
+    unsigned nmk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = i >> 2, ft = (i >> 1) & 1, t = i & 1;
+        nmk[i] = mbase[((size_t)ch * a.nrt + min((row_lo >> 4) + t, a.nrt - 1)) * 32 + ft * 16];
+    }
     const int tq = fr >> 2, tp = fr & 3;          // transposed reads: this lane addresses k-line (row) 4 fq + tq, columns 4 tp .. + 3
     for (int base = row_lo; base < row_hi; base += WG_SB) {
         if (base != row_lo) __syncthreads();
@@ -272,6 +315,19 @@ __global__ __launch_bounds__(256) void ffn32_wgrad_kernel(const WgArgs a) {
                 xT[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(xl, xh, 0, 1, 2, 3, 4, 5, 6, 7));
                 dT[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(dl, dh, 0, 1, 2, 3, 4, 5, 6, 7));
             }
+            // this block's mask pieces (requested one block ahead): [ch][ft][t]
+            unsigned mk[2][2][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mk[i >> 2][(i >> 1) & 1][i & 1] = nmk[i];
+            {
+                const int rtile = (base + r0 + 32) >> 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ch = i >> 2, ft = (i >> 1) & 1, t = i & 1;
+                    const int rtc = min(rtile + t, a.nrt - 1);
+                    nmk[i] = mbase[((size_t)ch * a.nrt + rtc) * 32 + ft * 16];
+                }
+            }
             const int rtile = (base + r0) >> 4;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
@@ -285,10 +341,7 @@ __global__ __launch_bounds__(256) void ffn32_wgrad_kernel(const WgArgs a) {
                         h[t] = mfma(xb[t], w1[ch][ft], z);            // [i = row 4 fq + e of tile t][j = hidden unit fr of tile ft]
                         d[t] = mfma(db[t], w2[ch][ft], z);
                         // mask piece of (chunk, row tile, ft, e' = fr & 3, q' = fr >> 2): bits = the 16 rows of the tile
-                        unsigned m = 0;
-                        if (rtile + t < a.nrt)
-                            m = a.mask16[(((size_t)(c0 + ch) * a.nrt + (rtile + t)) * 8 + ft * 4 + (fr & 3)) * 4 + (fr >> 2)];
-                        m >>= 4 * fq;
+                        const unsigned m = (rtile + t < a.nrt ? mk[ch][ft][t] : 0u) >> (4 * fq);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const bool live = (m >> e) & 1u;
@@ -348,8 +401,8 @@ __global__ __launch_bounds__(256) void ffn32_wgrad_reduce_kernel(const float* __
     }
 }
 
-inline int rows_block(int R) {      // rows per row block of the weight-gradient kernel: ~32 blocks, whole sub-blocks
-    int rb = (R + 31) / 32;
+inline int rows_block(int R) {      // rows per row block of the weight-gradient kernel: ~64 blocks (x F / 256 workgroups), whole sub-blocks
+    int rb = (R + 63) / 64;
     rb = (rb + WG_SB - 1) / WG_SB * WG_SB;
     return rb < WG_SB ? WG_SB : rb;
 }
@@ -377,7 +430,7 @@ int ffn32_forward(int R, int F, const DropCfg& dd, uint64_t site, const float* x
     a.mask = reinterpret_cast<uint64_t*>(img + (size_t)4 * F * FD);
     a.R = R; a.F = F; a.nrt = (R + 15) / 16;
     a.drop = dd; a.site = site; a.scale = dd.p > 0.f ? dd.inv_keep : 1.f;
-    const int rt = a.nrt >= 4096 ? 4 : a.nrt >= 2048 ? 2 : 1;
+    const int rt = a.nrt >= 16384 ? 4 : a.nrt >= 4096 ? 2 : 1;       // >= 2 waves per SIMD first (the Philox draws are VALU work)
     const int grid = (a.nrt + 4 * rt - 1) / (4 * rt);
     if (rt == 4) hipLaunchKernelGGL((ffn32_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, a);
     else if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
@@ -398,10 +451,9 @@ int ffn32_backward(int R, int F, const DropCfg& dd, const float* x1, const float
         a.mask = reinterpret_cast<uint64_t*>(const_cast<bf16_t*>(img) + (size_t)4 * F * FD);
         a.R = R; a.F = F; a.nrt = nrt;
         a.drop = dd; a.site = 0; a.scale = scale;
-        const int rt = nrt >= 4096 ? 4 : nrt >= 2048 ? 2 : 1;
+        const int rt = nrt >= 4096 ? 2 : 1;          // (the mask words of RT row tiles x 2 chunks live in SGPRs: RT <= 2)
         const int grid = (nrt + 4 * rt - 1) / (4 * rt);
-        if (rt == 4) hipLaunchKernelGGL((ffn32_rows_kernel<4, true>), dim3(grid), dim3(256), 0, s, a);
-        else if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
+        if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((ffn32_rows_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
         IMMTSF_LAUNCH_CHECK();
     }

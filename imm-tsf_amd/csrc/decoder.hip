@@ -9,8 +9,8 @@
 // thread: h1 = relu(u[n] + v[lp]), 32 x 32 FMAs against W2 broadcast from LDS, a dot with w3.  Exact fp32 (plain
 // v_fma), in both precision modes -- the whole decoder is 35 MFLOP.  The backward recomputes the forward per row, runs
 // dW2 = dH2^T H1 as register-blocked FMAs over an LDS image of the chunk's rows, reduces the first layer's gradient
-// over lp (-> du[n]) and over n (-> dv[lp]) in LDS and adds the parameter gradients to global memory with one atomic
-// per element per window.
+// over lp (-> du[n]) and over n (-> dv[lp]) in LDS; a workgroup walks several windows (<= one resident workgroup per CU
+// slot) with the parameter gradients in registers / LDS and adds them to global memory with one atomic per element at the end.
 #include "../../include/immtsf.h"
 #include "common.hpp"
 
@@ -38,8 +38,8 @@ size_t fwd_lds(int N, int Lp, int D, int E) {
     return (size_t)(H * H + 3 * H + (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E)) * sizeof(float);
 }
 template <int H>
-size_t bwd_lds(int N, int Lp) {
-    return (size_t)(H * H + 3 * H + 2 * (N + Lp) * Geo<H>::P1 + 2 * 256 * Geo<H>::PR + 2 * H + 8) * sizeof(float);
+size_t bwd_lds(int N, int Lp, int D, int E) {       // ... + the workgroup's running dW1 / db1 (it walks several windows)
+    return (size_t)(H * H + 3 * H + 2 * (N + Lp) * Geo<H>::P1 + 2 * 256 * Geo<H>::PR + 2 * H + 8 + H * (D + E) + H) * sizeof(float);
 }
 
 // coalesced copies: W1s[k][D+E+1], hs[n][D], tes[lp][E] (contiguous, in this order, at `st`)
@@ -160,17 +160,14 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
     float* dv = du + d.N * P1;
     float* dw3s = dv + d.Lp * P1;             // [H]
     float* db2s = dw3s + H;                   // [H]
-    float* db3s = db2s + H;                   // [1]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    float* db3s = db2s + H;                   // [1] (+ 7 of padding)
+    float* gW1s = db3s + 8;                   // [H][D + E] running dW1 of this workgroup's windows
+    float* gb1s = gW1s + H * (d.D + d.E);     // [H]
+    const int tid = threadIdx.x;
     for (int i = tid; i < H * H; i += 256) W2s[i] = p.W2[i];
-    if (tid < H) { b2s[tid] = p.b2[tid]; w3s[tid] = p.W3[tid]; dw3s[tid] = 0.f; db2s[tid] = 0.f; }
+    if (tid < H) { b2s[tid] = p.b2[tid]; w3s[tid] = p.W3[tid]; dw3s[tid] = 0.f; db2s[tid] = 0.f; gb1s[tid] = 0.f; }
     if (tid == 0) db3s[0] = 0.f;
-    for (int i = tid; i < (d.N + d.Lp) * P1; i += 256) du[i] = 0.f;      // du and dv are contiguous
-    stage<H>(d, p, h, te, b, Xs);       // the staged operands borrow the first chunk image (launcher checks they fit)
-    __syncthreads();
-    first_layer<H>(d, p.b1, Xs, u, v);
-    __syncthreads();
-
+    for (int i = tid; i < H * (d.D + d.E); i += 256) gW1s[i] = 0.f;
     const int LPC = lpc_of(d.Lp), NC = 256 / LPC;
     const int ln = tid / LPC, llp = tid - ln * LPC;
     const int wj = tid / (H / KPT), wk = (tid % (H / KPT)) * KPT;      // this thread's strip of dW2
@@ -178,6 +175,15 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
 #pragma unroll
     for (int i = 0; i < KPT; ++i) accW[i] = 0.f;
     float accb2 = 0.f;
+
+    // a workgroup walks windows b, b + grid, ...: the parameter gradients stay in registers / LDS across them and reach global
+    // memory once per workgroup (with one workgroup per window the ~2.5 k atomics of each of 4096 windows queue up per address)
+    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+    for (int i = tid; i < (d.N + d.Lp) * P1; i += 256) du[i] = 0.f;      // du and dv are contiguous
+    stage<H>(d, p, h, te, b, Xs);       // the staged operands borrow the first chunk image (launcher checks they fit)
+    __syncthreads();
+    first_layer<H>(d, p.b1, Xs, u, v);
+    __syncthreads();
 
     for (int n0 = 0; n0 < d.N; n0 += NC)
         for (int lp0 = 0; lp0 < d.Lp; lp0 += LPC) {
@@ -284,17 +290,12 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
             __syncthreads();
         }
 
-    // ---- parameter gradients of this window -> global (one atomic per element), data gradients dh / dte
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) atomicAdd(g.W2 + wj * H + wk + i, accW[i]);
-    if (wk == 0) atomicAdd(g.b2 + wj, accb2);
+    // ---- this window's first-layer parameter gradients -> the running sums, data gradients dh / dte
     if (tid < H) {
-        atomicAdd(g.W3 + tid, dw3s[tid]);
         float s = 0.f;
         for (int n = 0; n < d.N; ++n) s += du[n * P1 + tid];
-        atomicAdd(g.b1 + tid, s);
+        gb1s[tid] += s;
     }
-    if (tid == 0) atomicAdd(g.b3, db3s[0]);
     stage<H>(d, p, h, te, b, Xs);       // the chunk images are dead: W1 / h / te again for the first layer's gradients
     __syncthreads();
     const int ld = d.D + d.E, pw = ld + 1;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
 #pragma unroll 8
             for (int lp = 0; lp < d.Lp; ++lp) a = fmaf(dv[lp * P1 + k], tes[lp * d.E + c - d.D], a);
         }
-        atomicAdd(g.W1 + i, a);
+        gW1s[i] += a;
     }
     for (int i = tid; i < d.N * d.D; i += 256) {        // dh[b, n, c] = sum_k W1[k][c] du[n][k]
         const int n = i / d.D, c = i - n * d.D;
@@ -326,6 +327,19 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
         for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
         dte[(size_t)b * d.Lp * d.E + i] = a;
     }
+    __syncthreads();        // the next window restages over Xs and clears du / dv
+    }   // windows
+
+    // ---- parameter gradients of this workgroup's windows -> global (one atomic per element)
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) atomicAdd(g.W2 + wj * H + wk + i, accW[i]);
+    if (wk == 0) atomicAdd(g.b2 + wj, accb2);
+    if (tid < H) {
+        atomicAdd(g.W3 + tid, dw3s[tid]);
+        atomicAdd(g.b1 + tid, gb1s[tid]);
+    }
+    if (tid == 0) atomicAdd(g.b3, db3s[0]);
+    for (int i = tid; i < H * (d.D + d.E); i += 256) atomicAdd(g.W1 + i, gW1s[i]);
 }
 
 constexpr size_t kLdsMax = 150 * 1024;
@@ -340,7 +354,7 @@ extern "C" {
 
 size_t immtsf_tpatchgnn_decoder_lds_bytes(int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H) {
     if (!dims_ok(1, N, Lp, D, E, H)) return 0;
-    const size_t b = bwd_lds<32>(N, Lp), f = fwd_lds<32>(N, Lp, D, E);
+    const size_t b = bwd_lds<32>(N, Lp, D, E), f = fwd_lds<32>(N, Lp, D, E);
     if (stage_floats(32, N, Lp, D, E) > (size_t)2 * 256 * Geo<32>::PR) return 0;      // staged operands borrow the chunk images
     return b <= kLdsMax && f <= kLdsMax ? (b > f ? b : f) : 0;
 }
@@ -370,9 +384,11 @@ int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t 
     const DecDims d{B, N, Lp, D, E};
     const DecP q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3};
     const DecG gq{grads->W1, grads->b1, grads->W2, grads->b2, grads->W3, grads->b3};
-    const size_t lds = bwd_lds<32>(N, Lp);
+    const size_t lds = bwd_lds<32>(N, Lp, D, E);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(B), dim3(256), lds, s, d, q, h, te, dout, dh, dte, gq);
+    const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;      // resident workgroups per CU by LDS
+    const int grid = B < 256 * per_cu ? B : 256 * per_cu;
+    hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(grid), dim3(256), lds, s, d, q, h, te, dout, dh, dte, gq);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -16,6 +16,7 @@ struct Dims {
 // LDS map (float offsets); the same struct is built on host (for the size) and device
 struct Lds {
     int X, Xk, Z, dfeat, L1, L2, dL1, dL2, NV1, NV2, dNV1, dNV2, A, S, dA, Wm, vec, total, ldw, F;
+    int fwd_total, g_mb, g_mw, g_nv1, g_nv2, g_g1w, g_g2w, g_gb, g_l1w, g_l2w, g_l1b, g_l2b;
     __host__ __device__ explicit Lds(const Dims& d) {
         const int ND = d.N * d.D, Nn = d.N * d.nd, NN = d.N * d.N;
         F = (d.order + 1) * d.D;            // concatenated feature width
@@ -38,6 +39,19 @@ struct Lds {
         dA = o;     o += NN;
         Wm = o;     o += d.D * ldw;
         vec = o;    o += 8 * d.N;           // t1, t2, g1, g2, da1, da2, (2 spare)
+        fwd_total = o;
+        // backward only: the workgroup's running parameter gradients (it walks several cells; one atomic per element at the end)
+        g_mb = o;   o += d.D;
+        g_mw = o;   o += d.D * F;
+        g_nv1 = o;  o += Nn;
+        g_nv2 = o;  o += Nn;
+        g_g1w = o;  o += d.D + d.nd;
+        g_g2w = o;  o += d.D + d.nd;
+        g_gb = o;   o += 2;                 // gate1_b, gate2_b
+        g_l1w = o;  o += d.nd * d.D;
+        g_l2w = o;  o += d.nd * d.D;
+        g_l1b = o;  o += d.nd;
+        g_l2b = o;  o += d.nd;
         total = o;
     }
 };
@@ -164,7 +178,12 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     const Lds l(d);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int N = d.N, D = d.D, nd = d.nd;
-    const int b = blockIdx.x / d.M, m = blockIdx.x - b * d.M;
+    for (int i = l.g_mb + tid; i < l.total; i += nt) sm[i] = 0.f;
+    // a workgroup walks cells blockIdx.x, + gridDim.x, ...: every parameter-gradient element below is owned by one thread
+    // (same loop shape in every cell), accumulated in LDS and added to global memory once per workgroup -- with one workgroup
+    // per cell the ~3.5 k atomics of each of B * M cells queue up per address and were the whole run time of this kernel
+    for (int cell = blockIdx.x; cell < d.B * d.M; cell += gridDim.x) {
+    const int b = cell / d.M, m = cell - b * d.M;
     cell_forward(sm, l, d, p, x, b, m);
     // dZ = dout * relu'(Z)
     for (int i = tid; i < N * D; i += nt) {
@@ -179,14 +198,14 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         float acc = 0.f;
 #pragma unroll 8
         for (int v = 0; v < N; ++v) acc += sm[l.Z + v * D + o];
-        atomicAdd(g.mb + o, acc);
+        sm[l.g_mb + o] += acc;
     }
     for (int i = tid; i < D * l.F; i += nt) {
         const int o = i / l.F, c = i - o * l.F;
         float acc = 0.f;
 #pragma unroll 8
         for (int v = 0; v < N; ++v) acc = fmaf(sm[l.Z + v * D + o], feat_at(sm, l, d, v, c), acc);
-        atomicAdd(g.mw + i, acc);
+        sm[l.g_mw + i] += acc;
     }
     // dfeat[k][v, f] = sum_o Wm[o, k*D + f] dZ[v, o]     (stored as order+1 slabs of N x D, like X/Xk)
     for (int i = tid; i < (d.order + 1) * N * D; i += nt) {
@@ -260,8 +279,8 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     // node vectors
     for (int i = tid; i < N * nd; i += nt) {
         const int n = i / nd, k = i - n * nd;
-        atomicAdd(g.nv1 + n * nd + k, sm[l.dNV1 + i] + da1[n] * p.g1w[D + k]);
-        atomicAdd(g.nv2 + k * N + n, sm[l.dNV2 + i] + da2[n] * p.g2w[D + k]);
+        sm[l.g_nv1 + n * nd + k] += sm[l.dNV1 + i] + da1[n] * p.g1w[D + k];
+        sm[l.g_nv2 + k * N + n] += sm[l.dNV2 + i] + da2[n] * p.g2w[D + k];
     }
     // gate weights / biases
     for (int i = tid; i < 2 * (D + nd + 1); i += nt) {
@@ -271,8 +290,8 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         if (j < D) for (int n = 0; n < N; ++n) acc = fmaf(da[n], sm[l.X + n * D + j], acc);
         else if (j < D + nd) for (int n = 0; n < N; ++n) acc = fmaf(da[n], which ? p.nv2[(j - D) * N + n] : p.nv1[n * nd + (j - D)], acc);
         else for (int n = 0; n < N; ++n) acc += da[n];
-        if (j < D + nd) atomicAdd((which ? g.g2w : g.g1w) + j, acc);
-        else atomicAdd(which ? g.g2b : g.g1b, acc);
+        if (j < D + nd) sm[(which ? l.g_g2w : l.g_g1w) + j] += acc;
+        else sm[l.g_gb + which] += acc;
     }
     // nd-wide linears
     for (int i = tid; i < 2 * nd * (D + 1); i += nt) {
@@ -282,11 +301,11 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         if (f < D) {
 #pragma unroll 8
             for (int n = 0; n < N; ++n) acc = fmaf(dL[n * nd + k], sm[l.X + n * D + f], acc);
-            atomicAdd((which ? g.l2w : g.l1w) + k * D + f, acc);
+            sm[(which ? l.g_l2w : l.g_l1w) + k * D + f] += acc;
         } else {
 #pragma unroll 8
             for (int n = 0; n < N; ++n) acc += dL[n * nd + k];
-            atomicAdd((which ? g.l2b : g.l1b) + k, acc);
+            sm[(which ? l.g_l2b : l.g_l1b) + k] += acc;
         }
     }
     // dx
@@ -301,6 +320,23 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         }
         dx[(((size_t)b * N + n) * d.M + m) * D + f] = acc;
     }
+    __syncthreads();        // the next cell's forward overwrites what the loops above read
+    }   // cells
+    auto flush = [&](float* dst, int off, int n) __attribute__((always_inline)) {
+        for (int i = tid; i < n; i += nt) atomicAdd(dst + i, sm[off + i]);
+    };
+    flush(g.mb, l.g_mb, D);
+    flush(g.mw, l.g_mw, D * l.F);
+    flush(g.nv1, l.g_nv1, N * nd);
+    flush(g.nv2, l.g_nv2, N * nd);
+    flush(g.g1w, l.g_g1w, D + nd);
+    flush(g.g2w, l.g_g2w, D + nd);
+    flush(g.g1b, l.g_gb, 1);
+    flush(g.g2b, l.g_gb + 1, 1);
+    flush(g.l1w, l.g_l1w, nd * D);
+    flush(g.l2w, l.g_l2w, nd * D);
+    flush(g.l1b, l.g_l1b, nd);
+    flush(g.l2b, l.g_l2b, nd);
 }
 
 constexpr size_t kMaxLds = 160 * 1024 - 256;
@@ -337,6 +373,7 @@ int immtsf_tpatchgnn_gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int
     size_t bytes = 0;
     if (!x || !out || !all_set(p)) return IMMTSF_EINVAL;
     if (int rc = check_dims(d, &bytes)) return rc;
+    bytes = (size_t)Lds(d).fwd_total * sizeof(float);       // (the backward's gradient accumulators are not needed)
     if (bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_fwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -361,7 +398,10 @@ int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, in
     }
     const Grads g{grads->nodevec1, grads->nodevec2, grads->gate1_w, grads->gate1_b, grads->gate2_w, grads->gate2_b,
                   grads->lin1_w, grads->lin1_b, grads->lin2_w, grads->lin2_b, grads->mlp_w, grads->mlp_b};
-    hipLaunchKernelGGL(gcn_bwd_kernel, dim3(B * M), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, dout,
+    int per_cu = (int)((160 * 1024) / bytes);      // resident workgroups per CU by LDS, at most 4: the grid is the atomics' fan-in
+    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    const int cells = B * M, grid = cells < 256 * per_cu ? cells : 256 * per_cu;
+    hipLaunchKernelGGL(gcn_bwd_kernel, dim3(grid), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, dout,
                        dx, g);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

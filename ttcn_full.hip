@@ -30,9 +30,9 @@ constexpr int KP = 32;        // padded ttcn_dim and padded feature width (one M
 constexpr int PT = 40;        // pitch (bf16 elements) of the 32-wide LDS tiles: 80-byte rows, conflict-free b128 reads
 
 
-struct FD { int P, L, F, K, NCq, dbg; };
+struct FD { int P, L, F, K, NCq; };
 
-// slab of padded gradients (fp32), one per workgroup of the backward (summed by ttcn_unpack_kernel): offsets in floats
+// slab of padded gradients (fp32), zeroed by the launcher: offsets in floats
 struct Slab { int W1, b1, W2, b2, W3, b3, te, Tb, total; };
 __host__ __device__ inline Slab slab_of(int F) {
     Slab s;
@@ -288,7 +288,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
     // The layer-3 weights are read twice per patch (logits: rows c' as B fragments; dz2 = dS W3: the same image through the
     // hardware transpose) -- 17 dependent L2 round trips per patch per wave when fetched from global memory, a fifth of the
     // patch's timeline.  A persistent workgroup stages them once.
-    if (!(d.dbg & 1))
     for (int i = tid; i < d.NCq * 4; i += 256) {
         const int c = i >> 2, q = i & 3;
         *reinterpret_cast<bf16x8*>(W3s + c * PT + q * 8) = *reinterpret_cast<const bf16x8*>(wt.W3h + (size_t)c * KP + q * 8);
@@ -471,9 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
         __syncthreads();     // every LDS tile is rewritten by the next patch
     }
 
-    // ---- this workgroup's sums -> its own slab (plain stores; ttcn_unpack_kernel adds the slabs up).  As atomics into one slab
-    // the ~11 k adds of each workgroup queued up per address: 67 us of an 88 us kernel at P = 1024 / 384 workgroups.
-    float* my = slab + (size_t)blockIdx.x * sl.total;
+    // ---- one atomic add per accumulated element per workgroup
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
         const int f = wave + 4 * j;
@@ -484,41 +481,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        my[sl.W3 + (size_t)(f * 32 + half * 16 + fq * 4 + r) * KP + nt * 16 + fr] = accW3[j][half][nt][r];
+                        atomicAdd(slab + sl.W3 + (size_t)(f * 32 + half * 16 + fq * 4 + r) * KP + nt * 16 + fr, accW3[j][half][nt][r]);
                 const float b3sum = col_sum(accB3[j][half]);
-                if (fq == 0) my[sl.b3 + f * 32 + half * 16 + fr] = b3sum;
+                if (fq == 0) atomicAdd(slab + sl.b3 + f * 32 + half * 16 + fr, b3sum);
             }
         }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        my[sl.W2 + (tmt * 16 + fq * 4 + r) * KP + tnt * 16 + fr] = accW2[r];
-        if (wave < 2) my[sl.W1 + (wave * 16 + fq * 4 + r) * KP + fr] = accW1[r];
+        atomicAdd(slab + sl.W2 + (tmt * 16 + fq * 4 + r) * KP + tnt * 16 + fr, accW2[r]);
+        if (wave < 2) atomicAdd(slab + sl.W1 + (wave * 16 + fq * 4 + r) * KP + fr, accW1[r]);
     }
-    if (tid < KP) my[sl.b2 + tid] = accb;
-    else if (tid >= 64 && tid < 64 + KP) my[sl.b1 + tid - 64] = accb;
-    else if (tid >= 128 && tid < 128 + KP) my[sl.Tb + tid - 128] = accb;
-    // time-embedding gradients: several waves hold shares of the same entry -> summed in LDS first
-    float* tes = cts;                 // (every tile of the last patch is dead: the loop ends with a barrier)
-    if (tid < 2 * KP) tes[tid] = 0.f;
-    __syncthreads();
+    if (tid < KP) atomicAdd(slab + sl.b2 + tid, accb);
+    else if (tid >= 64 && tid < 64 + KP) atomicAdd(slab + sl.b1 + tid - 64, accb);
+    else if (tid >= 128 && tid < 128 + KP) atomicAdd(slab + sl.Tb + tid - 128, accb);
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
         const int f = wave + 4 * j;
         const float sw = col_sum(row_sum16(tpw[j])), sb = col_sum(row_sum16(tpb[j]));
         if (lane == 0 && f >= 1 && f < d.F) {
-            atomicAdd(tes + f, sw);
-            atomicAdd(tes + KP + f, sb);
+            atomicAdd(slab + sl.te + f, sw);
+            atomicAdd(slab + sl.te + KP + f, sb);
         }
     }
     te_w = col_sum(te_w);
     te_b = col_sum(te_b);
     if (fq == 0 && (RT == 4 || wave >= 2)) {
-        atomicAdd(tes + fr, te_w);
-        atomicAdd(tes + KP + fr, te_b);
+        atomicAdd(slab + sl.te + fr, te_w);
+        atomicAdd(slab + sl.te + KP + fr, te_b);
     }
-    __syncthreads();
-    if (tid < 2 * KP) my[sl.te + tid] = tes[tid];
 }
 
 // ---- packing: padded fp32 weights (+ the f-major W3), transposed bf16 copies; unpacking of the gradient slab
@@ -546,41 +537,21 @@ __global__ __launch_bounds__(256) void ttcn_pack_kernel(int F, int K, PackIn q, 
 }
 
 struct UnpackOut { float *W1, *b1, *W2, *b2, *W3, *b3, *ws, *bs, *wp, *bp, *Tb; };
-// grid ceil(outputs / 32), 256 threads = 32 outputs x 8 slab lanes: out = sum over the nslab per-workgroup slabs of the backward
-__global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const float* __restrict__ slab, int nslab, UnpackOut g, int te_acc) {
-    __shared__ float red[8][33];
+__global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const float* __restrict__ slab, UnpackOut g, int te_acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const Slab sl = slab_of(F);
-    const int slot = threadIdx.x & 31, part = threadIdx.x >> 5;
-    int i = blockIdx.x * 32 + slot, n;
-    float* dst = nullptr;
-    int off = 0;
-    bool acc = false;      // te_acc: the time-embedding parameters are shared with the decoder's LearnableTE, whose backward adds into the same buffers
-    if (i < (n = K * F)) { dst = g.W1 + i; off = sl.W1 + (i / F) * KP + i % F; }
-    else if ((i -= n) < (n = K * K)) { dst = g.W2 + i; off = sl.W2 + (i / K) * KP + i % K; }
-    else if ((i -= n) < (n = F * K * K)) { const int c = i / K, kk = i % K, k = c / F, f = c % F; dst = g.W3 + i; off = sl.W3 + (f * 32 + k) * KP + kk; }
-    else if ((i -= n) < (n = F * K)) { const int k = i / F, f = i % F; dst = g.b3 + i; off = sl.b3 + f * 32 + k; }
-    else if ((i -= n) < K) { dst = g.b1 + i; off = sl.b1 + i; }
-    else if ((i -= K) < K) { dst = g.b2 + i; off = sl.b2 + i; }
-    else if ((i -= K) < K) { dst = g.Tb + i; off = sl.Tb + i; }
-    else if ((i -= K) < 1) { dst = g.ws; off = sl.te + 1; acc = te_acc != 0; }
-    else if ((i -= 1) < 1) { dst = g.bs; off = sl.te + KP + 1; acc = te_acc != 0; }
-    else if ((i -= 1) < F - 2) { dst = g.wp + i; off = sl.te + 2 + i; acc = te_acc != 0; }
-    else if ((i -= F - 2) < F - 2) { dst = g.bp + i; off = sl.te + KP + 2 + i; acc = te_acc != 0; }
-    float s = 0.f;
-    if (dst) {
-#pragma unroll 8
-        for (int w = part; w < nslab; w += 8) s += slab[(size_t)w * sl.total + off];
+    if (i < K * F) g.W1[i] = slab[sl.W1 + (i / F) * KP + i % F];
+    if (i < K * K) g.W2[i] = slab[sl.W2 + (i / K) * KP + i % K];
+    if (i < F * K * K) {
+        const int c = i / K, kk = i % K, k = c / F, f = c % F;
+        g.W3[i] = slab[sl.W3 + (size_t)(f * 32 + k) * KP + kk];
     }
-    red[part][slot] = s;
-    __syncthreads();
-    if (part == 0 && dst) {
-#pragma unroll
-        for (int q = 1; q < 8; ++q) s += red[q][slot];
-        *dst = (acc ? *dst : 0.f) + s;
-    }
+    if (i < F * K) { const int k = i / F, f = i % F; g.b3[i] = slab[sl.b3 + f * 32 + k]; }
+    if (i < K) { g.b1[i] = slab[sl.b1 + i]; g.b2[i] = slab[sl.b2 + i]; g.Tb[i] = slab[sl.Tb + i]; }
+    // te_acc: the time-embedding parameters are shared with the decoder's LearnableTE, whose backward adds into the same buffers
+    if (i == 0) { g.ws[0] = (te_acc ? g.ws[0] : 0.f) + slab[sl.te + 1]; g.bs[0] = (te_acc ? g.bs[0] : 0.f) + slab[sl.te + KP + 1]; }
+    if (i < F - 2) { g.wp[i] = (te_acc ? g.wp[i] : 0.f) + slab[sl.te + 2 + i]; g.bp[i] = (te_acc ? g.bp[i] : 0.f) + slab[sl.te + KP + 2 + i]; }
 }
-inline int ttcn_unpack_outputs(int F, int K) { return K * F + K * K + F * K * K + F * K + 3 * K + 2 + 2 * (F - 2); }
-constexpr int kMaxBwdGrid = 512;       // slabs in the caller's scratch
 
 size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + 64; }
 size_t bwd_lds(int RT, int NCq) {
@@ -611,7 +582,7 @@ bool ttcn_full_supported(int precision, int L, int F, int K) {
     return precision == 1 && K >= 1 && K <= 32 && F >= 2 && F <= 16 && L >= 1 && L <= 64;
 }
 size_t ttcn_full_pack_floats(int F) { return (size_t)2 * KP * KP + 2 * KP + (size_t)F * 32 * KP + F * 32 + (size_t)F * 32 * KP + KP * KP + 64; }
-size_t ttcn_full_slab_floats(int F) { return (size_t)kMaxBwdGrid * slab_of(F).total; }     // one slab per workgroup of the backward
+size_t ttcn_full_slab_floats(int F) { return slab_of(F).total; }
 
 int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
                          float* pack, float* ctr, float* out, int out_ld, int flag_col, hipStream_t s) {
@@ -639,8 +610,10 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
 int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
                          const float* pack, const float* ctr, const float* out, const float* dout, int out_ld, float* slab,
                          const immtsf_ttcn_params* gr, hipStream_t s, int te_acc) {
-    const FD d{P, L, F, K, F * 32, getenv("TTCN_DBG") ? atoi(getenv("TTCN_DBG")) : 0};
+    const FD d{P, L, F, K, F * 32};
     const PackPtrs q = pack_ptrs(const_cast<float*>(pack), F);
+    hipError_t e = hipMemsetAsync(slab, 0, slab_of(F).total * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
     const WtsT wt{q.W3T, q.W2T, q.W1T, q.W3h};
@@ -650,8 +623,7 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     // 0.891 / 0.882 / 0.874 / 0.887 ms (later 0.850 at 224); two waves / SIMD at 256 / 342 / 384 / 448 / 512 -> 0.856 / 0.847 / 0.839 /
     // 0.841 / 0.852.  Alone (P = 1024): 103 us at 224 x 1 wave, 80 us at 448 x 2 waves.
     static const int genv = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 0;
-    int gmax = genv > 0 ? genv : (L <= 32 ? (P >= 8192 ? 512 : 384) : 224);     // many patches: exactly two workgroups per CU
-    gmax = gmax > kMaxBwdGrid ? kMaxBwdGrid : gmax;
+    const int gmax = genv > 0 ? genv : (L <= 32 ? (P >= 8192 ? 512 : 384) : 224);     // many patches: exactly two workgroups per CU
     const int grid = P < gmax ? P : gmax;
     const size_t lds = bwd_lds(L <= 32 ? 2 : 4, d.NCq);
     const int mf = (F + 3) / 4;
@@ -675,7 +647,7 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     }
 #undef TTCN_BWD
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(cdiv(ttcn_unpack_outputs(F, K), 32)), dim3(256), 0, s, F, K, slab, grid,
+    hipLaunchKernelGGL(ttcn_unpack_kernel, dim3(cdiv(F * K * K, 256)), dim3(256), 0, s, F, K, slab,
                        UnpackOut{gr->W1, gr->b1, gr->W2, gr->b2, gr->W3, gr->b3, gr->te_scale_w, gr->te_scale_b, gr->te_per_w, gr->te_per_b,
                                  gr->T_bias}, te_acc);
     IMMTSF_LAUNCH_CHECK();

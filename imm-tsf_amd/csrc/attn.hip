@@ -944,6 +944,8 @@ __device__ __forceinline__ void xs_scores_lds(int hd, const bf16_t* imX, const b
 }
 // Z[m][e0 + n] = sum_k W(m, k) img[k][n] for the staged chunk: 2 x ec/16 tiles dealt to the eight waves.  WT: W is read through
 // the hardware transpose (W(m, k) = tile[k][m]) instead of row-major (tile[m][k]).  Rows m >= T are not written.
+// The product is formed transposed (image fragment as the first operand): a lane then holds four consecutive columns of one
+// row and stores 16 bytes (8 as bf16) instead of four scattered scalars.
 template <bool WT>
 __device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, const bf16_t* img, int pimg, float* __restrict__ Z,
                                        size_t ldz, bf16_t* __restrict__ Zh) {
@@ -953,15 +955,26 @@ __device__ __forceinline__ void xs_mix(int T, int e0, int ec, const bf16_t* Wt, 
     for (int nt = wave; nt < (ec >> 4); nt += 8) {
         const bf16x8 bfrag = xs_frag_kmajor(img, pimg, nt * 16, 0, fr, fq);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 c0 = xs_mfma(w0, bfrag, z), c1 = xs_mfma(w1, bfrag, z);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m0 = fq * 4 + r, m1 = 16 + m0;
-            const size_t col = (size_t)e0 + nt * 16 + fr;
-            if (m0 < T) { Z[(size_t)m0 * ldz + col] = c0[r]; if (Zh) Zh[(size_t)m0 * ldz + col] = (bf16_t)c0[r]; }
-            if (m1 < T) { Z[(size_t)m1 * ldz + col] = c1[r]; if (Zh) Zh[(size_t)m1 * ldz + col] = (bf16_t)c1[r]; }
+        const f32x4 c0 = xs_mfma(bfrag, w0, z), c1 = xs_mfma(bfrag, w1, z);      // [column 4 fq + r][row fr (+ 16)]
+        const size_t col = (size_t)e0 + nt * 16 + fq * 4;
+        if (fr < T) {
+            *reinterpret_cast<float4*>(Z + (size_t)fr * ldz + col) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+            if (Zh) *reinterpret_cast<bf16x4*>(Zh + (size_t)fr * ldz + col) = bf16x4{(bf16_t)c0[0], (bf16_t)c0[1], (bf16_t)c0[2], (bf16_t)c0[3]};
+        }
+        if (16 + fr < T) {
+            *reinterpret_cast<float4*>(Z + (size_t)(16 + fr) * ldz + col) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+            if (Zh) *reinterpret_cast<bf16x4*>(Zh + (size_t)(16 + fr) * ldz + col) = bf16x4{(bf16_t)c1[0], (bf16_t)c1[1], (bf16_t)c1[2], (bf16_t)c1[3]};
         }
     }
+}
+// a further chunk of the backward (a workgroup that walks the chunks): K's chunk from its prefetch registers, Q's chunk generated
+template <int C4>
+__device__ __forceinline__ void xs_bwd_next_gen(int hcol, int ec, const XsGen& gn, const XsPre& nK, const float* ytile, bf16_t* imK, bf16_t* imQ) {
+    XsGenRegs<C4> gq;
+    xs_gen_load<C4, true>(gn.WQ, 0, gn.bq, hcol, ec, gq);
+    __syncthreads();        // the previous chunk's images have been read
+    xs_stage_store(ec, nK, imK);
+    xs_gen_compute<C4, true>(gq, ytile, imQ, XS_PC, 0);
 }
 __device__ __forceinline__ float xs_sum8(float v) {       // over the 8 lanes that share a row
     return group_sum(v, 8);
@@ -989,14 +1002,17 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
     if (live && !live[b]) {        // window without text: zero attention rows, zero context
         if (blockIdx.z == 0)
             for (int x = tid; x < T * T; x += 512) { Pm[pg + x] = 0.f; Am[pg + x] = 0.f; }
-        const int z0 = blockIdx.z * XS_EC, n4 = min(XS_EC, dm.hd - z0) >> 2;
-        for (int x = tid; x < T * n4; x += 512)
-            reinterpret_cast<float4*>(O + q0 + (size_t)(x / n4) * dm.d + z0)[x % n4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z0 = blockIdx.z * XS_EC; z0 < dm.hd; z0 += gridDim.z * XS_EC) {
+            const int n4 = min(XS_EC, dm.hd - z0) >> 2;
+            for (int x = tid; x < T * n4; x += 512)
+                reinterpret_cast<float4*>(O + q0 + (size_t)(x / n4) * dm.d + z0)[x % n4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         return;
     }
-    // blockIdx.z: the 256-column chunk of the head dimension whose part of O this workgroup produces (every chunk's workgroup
-    // forms the full score tile: its operands are L2 hits for all but the first, and the chunks run on different CUs)
-    const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);
+    // blockIdx.z, + gridDim.z, ...: the 256-column chunks of the head dimension whose part of O this workgroup produces.  Few windows:
+    // one chunk per workgroup (every chunk's workgroup forms the full score tile: its operands are L2 hits for all but the first, and
+    // the chunks run on different CUs).  Many windows (gridDim.z = 1): the workgroup forms the score tile once and walks the chunks.
+    int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);
     XsPre pre;
     xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, pre);        // V's chunk travels beside the score operands
     if (xs_staged(dm.hd)) {
@@ -1048,6 +1064,15 @@ __global__ __launch_bounds__(512) void xattn_tile_fwd_kernel(XSmallDims dm, cons
     }
     __syncthreads();
     xs_mix<false>(T, e0, ec, Ab, img, XS_PC, O + q0, dm.d, nullptr);       // O = A V
+    for (e0 += gridDim.z * XS_EC; e0 < dm.hd; e0 += gridDim.z * XS_EC) {
+        ec = min(XS_EC, dm.hd - e0);
+        XsPre nx;
+        xs_stage_load(T, e0, ec, KV + k0 + dm.d, ldk, nx);
+        __syncthreads();        // the previous chunk's image has been read
+        xs_stage_store(ec, nx, img);
+        __syncthreads();
+        xs_mix<false>(T, e0, ec, Ab, img, XS_PC, O + q0, dm.d, nullptr);
+    }
 }
 
 // dO -> dQ, (dK | dV) (+ optional bf16 image)
@@ -1073,9 +1098,10 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     const size_t q0 = (size_t)b * T * dm.d + (size_t)h * dm.hd, k0 = (size_t)b * T * 2 * dm.d + (size_t)h * dm.hd;
     const size_t ldk = (size_t)2 * dm.d, pg = (size_t)(b * dm.H + h) * T * T;
     if (live && !live[b]) {        // dO, A and P are zero there: so is every gradient
-        const int z0 = blockIdx.z * XS_EC, n4 = min(XS_EC, dm.hd - z0) >> 2;
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         const bf16x4 zh = {0, 0, 0, 0};
+        for (int z0 = blockIdx.z * XS_EC; z0 < dm.hd; z0 += gridDim.z * XS_EC) {
+        const int n4 = min(XS_EC, dm.hd - z0) >> 2;
         for (int x = tid; x < T * n4; x += 512) {
             const int i = x / n4, c = x - i * n4;
             reinterpret_cast<float4*>(dQ + q0 + (size_t)i * dm.d + z0)[c] = z4;
@@ -1086,9 +1112,10 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
                 reinterpret_cast<bf16x4*>(dKV_h + k0 + dm.d + (size_t)i * ldk + z0)[c] = zh;
             }
         }
+        }
         return;
     }
-    const int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);       // this workgroup's chunk of dQ, dK, dV (see the forward)
+    int e0 = blockIdx.z * XS_EC, ec = min(XS_EC, dm.hd - e0);       // this workgroup's chunks of dQ, dK, dV: e0, e0 + gridDim.z * 256, ... (see the forward)
     XsPre pK, pG, pQ;
     xs_stage_load(T, e0, ec, KV + k0, ldk, pK);           // the chunk's images travel beside dA's operands
     if (staged && gn.C) {      // dO and Q's chunk are formed here from their C-column inputs (host: only with the staged path)
@@ -1139,6 +1166,30 @@ __global__ __launch_bounds__(512) void xattn_tile_bwd_kernel(XSmallDims dm, cons
     xs_mix<false>(T, e0, ec, dSb, imK, XS_PC, dQ + q0, dm.d, nullptr);                                                      // dQ = dS K
     xs_mix<true>(T, e0, ec, Ab, staged ? imG + e0 : imG, pg_img, dKV + k0 + dm.d, ldk, dKV_h ? dKV_h + k0 + dm.d : nullptr);   // dV = A^T dO
     xs_mix<true>(T, e0, ec, dSb, imQ, XS_PC, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);                                // dK = dS^T Q
+    for (e0 += gridDim.z * XS_EC; e0 < dm.hd; e0 += gridDim.z * XS_EC) {       // many windows: dA / dS were formed once, the chunks follow
+        ec = min(XS_EC, dm.hd - e0);
+        XsPre nK, nQ, nG;
+        xs_stage_load(T, e0, ec, KV + k0, ldk, nK);
+        if (staged && gn.C) {
+            switch (gn.C >> 2) {
+            case 1: xs_bwd_next_gen<1>(h * dm.hd + e0, ec, gn, nK, ytile, imK, imQ); break;
+            case 2: xs_bwd_next_gen<2>(h * dm.hd + e0, ec, gn, nK, ytile, imK, imQ); break;
+            case 3: xs_bwd_next_gen<3>(h * dm.hd + e0, ec, gn, nK, ytile, imK, imQ); break;
+            default: xs_bwd_next_gen<4>(h * dm.hd + e0, ec, gn, nK, ytile, imK, imQ); break;
+            }
+        } else {
+            xs_stage_load(T, e0, ec, Q + q0, dm.d, nQ);
+            if (!staged) xs_stage_load(T, e0, ec, dO + q0, dm.d, nG);
+            __syncthreads();
+            xs_stage_store(ec, nK, imK);
+            xs_stage_store(ec, nQ, imQ);
+            if (!staged) xs_stage_store(ec, nG, imG);
+        }
+        __syncthreads();
+        xs_mix<false>(T, e0, ec, dSb, imK, XS_PC, dQ + q0, dm.d, nullptr);
+        xs_mix<true>(T, e0, ec, Ab, staged ? imG + e0 : imG, pg_img, dKV + k0 + dm.d, ldk, dKV_h ? dKV_h + k0 + dm.d : nullptr);
+        xs_mix<true>(T, e0, ec, dSb, imQ, XS_PC, dKV + k0, ldk, dKV_h ? dKV_h + k0 : nullptr);
+    }
 }
 inline size_t xs_fwd_lds(int hd) {
     return (size_t)2 * XS_T * XS_PS * 4 + (size_t)XS_T * XS_GC * 4 + (size_t)XS_T * XS_PT * 2 + (size_t)XS_T * XS_PC * 2 +
@@ -1326,7 +1377,9 @@ int launch_xattn_small_fwd(const float* Q, const float* KV, const unsigned char*
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_fwd_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_fwd_lds(XS_HD_STAGED));
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_fwd_lds(hd), s, dm, Q, KV, live, scale, drop, site, Pm,
+    // few windows: a workgroup per 256-column chunk (parallelism); many: one per (window, head) that forms the scores once
+    const int nz = B * H >= 1024 ? 1 : cdiv(hd, XS_EC);
+    hipLaunchKernelGGL(xattn_tile_fwd_kernel, dim3(B, H, nz), dim3(512), xs_fwd_lds(hd), s, dm, Q, KV, live, scale, drop, site, Pm,
                        Am, O, gn);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
@@ -1346,7 +1399,8 @@ int launch_xattn_small_bwd(const float* Q, const float* KV, const float* dO, con
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(xattn_tile_bwd_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)xs_bwd_lds(XS_HD_STAGED));
     if (attr != hipSuccess) return (int)attr;
-    hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, cdiv(hd, XS_EC)), dim3(512), xs_bwd_lds(hd), s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
+    const int nz = B * H >= 1024 ? 1 : cdiv(hd, XS_EC);
+    hipLaunchKernelGGL(xattn_tile_bwd_kernel, dim3(B, H, nz), dim3(512), xs_bwd_lds(hd), s, dm, Q, KV, dO, Pm, Am, live, scale, drop, site, dQ, dKV,
                        static_cast<bf16_t*>(dKV_h), gn);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

@@ -101,9 +101,11 @@ __global__ __launch_bounds__(1024) void ragged_index_kernel(const unsigned char*
 // many windows (B > 256): the same three phases as three launches -- a wave per window over the whole chip for the counting and the
 // compaction, one workgroup only for the scan of the B lengths (the one-workgroup kernel above walks B * N mask bytes alone:
 // 0.36 ms at 4096 windows).  Outputs identical.
-__global__ __launch_bounds__(1024) void ragged_count_kernel(const unsigned char* __restrict__ mask, int B, int N, int* __restrict__ lengths,
-                                                            unsigned char* __restrict__ mtxt, unsigned char* __restrict__ mtxt2) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
+// (256-thread workgroups: a 1024-thread one needs four free wave slots on EVERY SIMD of a CU at once and starved behind the other
+// stream's TTCN forward, whose small workgroups keep refilling the slots -- 470 us for a 5 us kernel at 4096 windows)
+__global__ __launch_bounds__(256) void ragged_count_kernel(const unsigned char* __restrict__ mask, int B, int N, int* __restrict__ lengths,
+                                                           unsigned char* __restrict__ mtxt, unsigned char* __restrict__ mtxt2) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     int cnt = 0;
     for (int n0 = 0; n0 < N; n0 += 64) {
@@ -137,9 +139,9 @@ __global__ __launch_bounds__(1024) void ragged_scan_kernel(const int* __restrict
     }
     if (tid == 0) offsets[B] = carry;
 }
-__global__ __launch_bounds__(1024) void ragged_fill_kernel(const unsigned char* __restrict__ mask, int B, int N, const int* __restrict__ offsets,
-                                                           int* __restrict__ rowmap, int* __restrict__ seg) {
-    const int lane = threadIdx.x & 63, b = blockIdx.x * 16 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void ragged_fill_kernel(const unsigned char* __restrict__ mask, int B, int N, const int* __restrict__ offsets,
+                                                          int* __restrict__ rowmap, int* __restrict__ seg) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     int pos = offsets[b];
     for (int n0 = 0; n0 < N; n0 += 64) {
@@ -604,30 +606,25 @@ __global__ __launch_bounds__(256) void colsum_vec_kernel(const float* __restrict
         for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(partial + ((size_t)slab * K + k) * N + n) = red[k][tx];
     }
 }
-// grid ceil(N / 64): 64 columns x 4 slab lanes per workgroup
+// grid (ceil(N / 32), K): 32 columns x 8 slab lanes per workgroup, one of the K sums per grid row (a thread walks nsl / 8 slabs:
+// with 64 columns x 4 lanes x all K sums per thread this was 104 us behind a 400 us first pass at 256 slabs)
 template <int K>
 __global__ __launch_bounds__(256) void colsum_vec_final_kernel(const float* __restrict__ partial, int N, int nsl, float* __restrict__ o0,
                                                                 float* __restrict__ o1, float* __restrict__ o2, int accumulate) {
-    __shared__ float red[K][4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, n = blockIdx.x * 64 + tx;
-    float acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, n = blockIdx.x * 32 + tx, k = blockIdx.y;
+    float acc = 0.f;
     if (n < N)
-#pragma unroll 4
-        for (int s = ty; s < nsl; s += 4)
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] += partial[((size_t)s * K + k) * N + n];
-#pragma unroll
-    for (int k = 0; k < K; ++k) red[k][ty][tx] = acc[k];
+#pragma unroll 8
+        for (int s = ty; s < nsl; s += 8) acc += partial[((size_t)s * K + k) * N + n];
+    red[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && n < N) {
-        float* outs[3] = {o0, o1, o2};
+        float* out = k == 0 ? o0 : k == 1 ? o1 : o2;
+        float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float v = red[k][0][tx] + red[k][1][tx] + red[k][2][tx] + red[k][3][tx];
-            outs[k][n] = accumulate ? outs[k][n] + v : v;
-        }
+        for (int q = 0; q < 8; ++q) v += red[q][tx];
+        out[n] = accumulate ? out[n] + v : v;
     }
 }
 // the many-row path applies: vectorisable and worth the bigger grid
@@ -647,7 +644,7 @@ static int launch_colsum_vec(const float* X, const float* Y, float* Z, int M, in
     hipLaunchKernelGGL((colsum_vec_kernel<K>), dim3(cdiv(N, CL * 4), nsl), dim3(256), 0, s, X, Y, Z, M, N, ld, scratch, sh, row_flag,
                        flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(Zh));
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL((colsum_vec_final_kernel<K>), dim3(cdiv(N, 64)), dim3(256), 0, s, scratch, N, nsl, o0, o1, o2, accumulate);
+    hipLaunchKernelGGL((colsum_vec_final_kernel<K>), dim3(cdiv(N, 32), K), dim3(256), 0, s, scratch, N, nsl, o0, o1, o2, accumulate);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -962,11 +959,11 @@ int launch_note_mask(const float* V, int rows, int d_m, unsigned char* mask, int
 int launch_ragged_index(const unsigned char* mask, int B, int N, int* lengths, int* offsets, int* rowmap, int* seg,
                         unsigned char* mtxt, hipStream_t s, unsigned char* mtxt2) {
     if (B > 256) {
-        hipLaunchKernelGGL(ragged_count_kernel, dim3(cdiv(B, 16)), dim3(1024), 0, s, mask, B, N, lengths, mtxt, mtxt2);
+        hipLaunchKernelGGL(ragged_count_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, mask, B, N, lengths, mtxt, mtxt2);
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL(ragged_scan_kernel, dim3(1), dim3(1024), 0, s, lengths, B, offsets);
         IMMTSF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ragged_fill_kernel, dim3(cdiv(B, 16)), dim3(1024), 0, s, mask, B, N, offsets, rowmap, seg);
+        hipLaunchKernelGGL(ragged_fill_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, mask, B, N, offsets, rowmap, seg);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }

@@ -228,6 +228,85 @@ def test_two_rank_sharded_optimizer_matches_single_process(wire, param_wire, tol
     assert res["same"] < 1e-7, res
 
 
+def _worker_bucketed(rank, world, port, q, wire):
+    """three optimizer steps with the gradient all-reduced BUCKET BY BUCKET in the order the backward finishes the buckets (what
+    the bucket hooks / the captured communication branch do on the GPU: last bucket first, each as soon as its gradients
+    exist), global clip, Adam -- against torch.optim.Adam on the full batch in one process"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from immtsf.train import FlatTrainer, shard_range
+    z = np.load(os.path.join(GOLDEN, "fusion_TTF_T2V_XAttn_MMF_XAttn_Add_tiny_h2.npz"))
+    H = int(z["H"])
+    params = _params(z)
+    B = 8
+    ttf = [p for k, p in params.items() if k.startswith("ttf.")]
+    mmf = [p for k, p in params.items() if k.startswith("mmf.")]
+    half = len(ttf) // 2
+    buckets = [mmf, ttf[:half], ttf[half:]]          # three buckets: the text side in two
+    tr = FlatTrainer(buckets, lr=1e-2, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD, grad_wire=wire)
+    order_fired = []
+    for step in range(3):
+        full = _batch(20 + step, B, 5, 6, 3, 16)
+        lo, hi = shard_range(B, rank, world)
+        shard = tuple(t[lo:hi] for t in full)
+        cnt = shard[5].reshape(-1, 3).sum(0)
+        dist.all_reduce(cnt)
+        tr.zero_grad()
+        _loss(params, shard, cnt, H).backward()
+        for bi in reversed(range(len(buckets))):      # the order the backward completes them
+            tr._bucket_ready(bi)
+            order_fired.append(bi)
+        assert all(tr._reduced)
+        tr.sync_grads()                               # nothing left to reduce: must not reduce anything twice
+        tr.step()
+    p_dp = tr.gather(tr.flat_param)
+    if rank == 0:
+        ref = _params(z)
+        rb = [[k for k in ref if k.startswith("mmf.")], [k for k in ref if k.startswith("ttf.")]]
+        order = rb[0] + rb[1]
+        opt = torch.optim.Adam([ref[k] for k in order], lr=1e-2, weight_decay=1e-3)
+        stable = None
+        for step in range(3):
+            full = _batch(20 + step, B, 5, 6, 3, 16)
+            opt.zero_grad()
+            _loss(ref, full, full[5].reshape(-1, 3).sum(0), H).backward()
+            g = torch.cat([ref[k].grad.reshape(-1) for k in order]).abs()
+            # Adam's update is g / sqrt(v): an element whose gradient is rounding noise (|g| < 1e-4 max|g|) moves by +-lr with the
+            # sign of that noise, which differs between summation orders -- such elements are not compared
+            ok = g > 1e-4 * g.max()
+            stable = ok if stable is None else stable & ok
+            torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)
+            opt.step()
+        p_ref = torch.cat([ref[k].detach().reshape(-1) for k in order])
+        q.put({"perr": float((p_dp - p_ref).abs()[stable].max()), "stable": float(stable.float().mean()), "order": order_fired[:3]})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,wire,tol", [(2, "fp32", 1e-4), (4, "fp32", 1e-4), (4, "bf16", 5e-3)])
+def test_bucketed_all_reduce_three_steps_match_single_process(world, wire, tol):
+    """world sizes 2 and 4: per-bucket all-reduces issued in backward-completion order + global-norm clip + Adam, three steps,
+    equal the single-process full-batch steps (fp32 wire to 1e-4 after three Adam steps; the bf16 wire within Adam-normalised
+    bf16 resolution) on every element whose gradient is not rounding noise"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, world, port, q, wire)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["perr"] < tol, res
+    assert res["stable"] > 0.5, res
+    assert res["order"] == [2, 1, 0]
+
+
 def test_shard_range_covers_everything_once():
     from immtsf.train import shard_range
     for n in (1, 7, 64, 512, 513):

@@ -13,6 +13,7 @@
 // slot) with the parameter gradients in registers / LDS and adds them to global memory with one atomic per element at the end.
 #include "../../include/immtsf.h"
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -32,7 +33,7 @@ template <int H> struct Geo {
 
 // staged copies of W1 (pitch D+E+1), h[b] and te[b]: the first layer and the last phase of the backward read them many
 // times with per-thread strides (from global memory that was 13 of the forward's 17 us)
-inline size_t stage_floats(int H, int N, int Lp, int D, int E) { return (size_t)H * (D + E + 1) + (size_t)N * D + (size_t)Lp * E; }
+__host__ __device__ inline size_t stage_floats(int H, int N, int Lp, int D, int E) { return (size_t)H * (D + E + 1) + (size_t)N * D + (size_t)Lp * E; }
 template <int H>
 size_t fwd_lds(int N, int Lp, int D, int E) {
     return (size_t)(H * H + 3 * H + (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E)) * sizeof(float);
@@ -342,6 +343,303 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
     for (int i = tid; i < H * (d.D + d.E); i += 256) atomicAdd(g.W1 + i, gW1s[i]);
 }
 
+// ---------------------------------------------------------------------------------------------------- bf16 MFMA variants
+// precision 1 (bf16 operands, fp32 accumulation -- the mode of every other product of the step).  The (n, lp) rows of a window
+// are 16-row MFMA tiles; H = 32 is one K-step of v_mfma_f32_16x16x32_bf16.  h1 = relu(u[n] + v[lp]) is cheap to form from the LDS
+// vectors in ANY operand layout, so nothing is ever transposed through memory:
+//   forward   z2^T = W2 h1^T (A = W2 rows, B = h1: lane = row, 4 consecutive j per register quad) -> bias, ReLU, dot with w3 over
+//             the lane's 8 j + two xor shuffles;
+//   backward  the same product gives g2 = dy w3 [z2 > 0] in the A layout of dh1 = g2 W2 (B = W2 with its j taken in the
+//             accumulator order), whose result (lane = k, rows in registers) is masked by [h1 > 0] and added to du[n] / dv[lp]
+//             in LDS; the product with the operands swapped gives g2 with lane = j -- the B layout of dW2^T = h1^T g2 over a
+//             pair of row tiles (rows in the accumulator order on both sides, h1^T formed directly from u / v).
+// dW2 / db2 / dW3 / db3 live in registers across the windows of a persistent workgroup; the first layer's gradients and dh / dte
+// are the fp32 code of the exact kernel.  ~16 MFMAs + ~400 VALU instructions per 32 rows instead of ~3000 FMAs per row.
+typedef float dec_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dec_f32x4 dec_mfma(bf16x8 a, bf16x8 b, dec_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 dec_load8(const float* __restrict__ src) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    bf16x8 r;
+    r[0] = (bf16_t)a.x; r[1] = (bf16_t)a.y; r[2] = (bf16_t)a.z; r[3] = (bf16_t)a.w;
+    r[4] = (bf16_t)b.x; r[5] = (bf16_t)b.y; r[6] = (bf16_t)b.z; r[7] = (bf16_t)b.w;
+    return r;
+}
+// h1 fragment of row r (operand index = lane & 15): k = 8 fq .. + 7
+__device__ __forceinline__ bf16x8 dec_h1_frag(const float* u, const float* v, int P1, int n, int lp, int fq) {
+    bf16x8 r;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) r[s] = (bf16_t)fmaxf(u[n * P1 + fq * 8 + s] + v[lp * P1 + fq * 8 + s], 0.f);
+    return r;
+}
+
+template <int H>
+size_t fwd_lds_mfma(int N, int Lp, int D, int E) { return (size_t)((N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + 8) * sizeof(float); }
+template <int H>
+size_t bwd_lds_mfma(int N, int Lp, int D, int E) {
+    return (size_t)(2 * (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + ((N * Lp + 31) & ~31) + H * (D + E) + H + 8 * (H * H + 2 * H + 4) + 16) * sizeof(float);
+}
+
+// grid B, 256 threads
+__global__ __launch_bounds__(256) void dec_fwd_mfma_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
+                                                            float* __restrict__ out) {
+    constexpr int H = 32, P1 = Geo<H>::P1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* u = sm;
+    float* v = u + d.N * P1;
+    float* st = v + d.Lp * P1;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const bf16x8 wA0 = dec_load8(p.W2 + (size_t)fr * H + fq * 8), wA1 = dec_load8(p.W2 + (size_t)(16 + fr) * H + fq * 8);
+    float b2v[2][4], w3v[2][4];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b2v[jt][e] = p.b2[jt * 16 + fq * 4 + e]; w3v[jt][e] = p.W3[jt * 16 + fq * 4 + e]; }
+    const float b3 = p.b3[0];
+    stage<H>(d, p, h, te, b, st);
+    __syncthreads();
+    first_layer<H>(d, p.b1, st, u, v);
+    __syncthreads();
+    const int rows = d.N * d.Lp, tiles = (rows + 15) >> 4;
+    for (int t = wave; t < tiles; t += 4) {
+        const int r = t * 16 + fr, rc = r < rows ? r : rows - 1, n = rc / d.Lp, lp = rc - n * d.Lp;
+        const bf16x8 hb = dec_h1_frag(u, v, P1, n, lp, fq);
+        const dec_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const dec_f32x4 z0 = dec_mfma(wA0, hb, z), z1 = dec_mfma(wA1, hb, z);
+        float y = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            y = fmaf(w3v[0][e], fmaxf(z0[e] + b2v[0][e], 0.f), y);
+            y = fmaf(w3v[1][e], fmaxf(z1[e] + b2v[1][e], 0.f), y);
+        }
+        y = xor32_sum(xor16_sum(y));
+        if (fq == 0 && r < rows) out[((size_t)b * d.Lp + lp) * d.N + n] = y + b3;
+    }
+}
+
+// persistent workgroups (grid <= B), 512 threads (eight waves share a window's 16-row tiles: the per-tile chain of dependent LDS
+// reads / MFMAs / LDS atomics is latency-bound, more waves per window is what shortens it)
+__global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
+                                                            const float* __restrict__ dout, float* __restrict__ dh,
+                                                            float* __restrict__ dte, DecG g) {
+    constexpr int H = 32, P1 = Geo<H>::P1;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* u = sm;
+    float* v = u + d.N * P1;
+    float* du = v + d.Lp * P1;
+    float* dv = du + d.N * P1;
+    float* Xs = dv + d.Lp * P1;                        // staged W1 | h[b] | te[b]
+    float* dys = Xs + stage_floats(H, d.N, d.Lp, d.D, d.E);     // dy of the window's rows, r = n * Lp + lp
+    float* gW1s = dys + ((d.N * d.Lp + 31) & ~31);
+    float* gb1s = gW1s + H * (d.D + d.E);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    constexpr int NT = 512, NW = NT / 64;
+    // W2 in the three operand forms (registers for the whole kernel)
+    bf16x8 wA[2], wP[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        wA[t] = dec_load8(p.W2 + (size_t)(t * 16 + fr) * H + fq * 8);           // [j = 16 t + fr][k = 8 fq ..]: A of z2^T, B of z2
+#pragma unroll
+        for (int s = 0; s < 8; ++s)                                             // B of dh1: [j in accumulator order][k = 16 t + fr]
+            wP[t][s] = (bf16_t)p.W2[(size_t)((s >> 2) * 16 + fq * 4 + (s & 3)) * H + t * 16 + fr];
+    }
+    float b2o1[2][4], w3o1[2][4], b2o2[2], w3o2[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { b2o1[jt][e] = p.b2[jt * 16 + fq * 4 + e]; w3o1[jt][e] = p.W3[jt * 16 + fq * 4 + e]; }
+        b2o2[jt] = p.b2[jt * 16 + fr];
+        w3o2[jt] = p.W3[jt * 16 + fr];
+    }
+    dec_f32x4 accW2[2][2];            // [kt][jt]: dW2[j = 16 jt + fr][k = 16 kt + 4 fq + e]
+    float accw3[2][4], accb2[2][4], accb3 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) accW2[a][c] = dec_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accw3[a][e] = accb2[a][e] = 0.f;
+    for (int i = tid; i < H * (d.D + d.E); i += NT) gW1s[i] = 0.f;
+    if (tid < H) gb1s[tid] = 0.f;
+    const int rows = d.N * d.Lp, tiles = (rows + 15) >> 4, pairs = (tiles + 1) >> 1;
+
+    for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+        for (int i = tid; i < (d.N + d.Lp) * P1; i += NT) du[i] = 0.f;      // du and dv are contiguous
+        for (int r = tid; r < pairs * 32; r += NT) {            // (padded to whole tile pairs with zeros)
+            const int n = r / d.Lp, lp = r - n * d.Lp;
+            dys[r] = r < rows ? dout[((size_t)b * d.Lp + lp) * d.N + n] : 0.f;
+        }
+        stage<H>(d, p, h, te, b, Xs);
+        __syncthreads();
+        first_layer<H>(d, p.b1, Xs, u, v);
+        __syncthreads();
+        for (int pr = wave; pr < pairs; pr += NW) {
+            bf16x8 hb[2];
+            dec_f32x4 g2o2[2][2];          // [t][jt]: g2 with lane = j (16 jt + fr), rows 4 fq + e of tile t
+            int ou[2][4], ov[2][4];        // u / v offsets (n * P1, lp * P1) of rows 4 fq + e of tile t (clamped to the last row)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int r0 = (pr * 2 + t) * 16;                  // wave-uniform: one division per tile, the lanes walk on from it
+                const int r0c = r0 < rows ? r0 : rows - 1, n0 = r0c / d.Lp, lp0 = r0c - n0 * d.Lp;
+                auto locate = [&](int o, int& un, int& vl) __attribute__((always_inline)) {
+                    int rr = r0 + o;
+                    rr = rr < rows ? rr : rows - 1;
+                    int n = n0, lp = lp0 + (rr - r0c);
+                    if (d.Lp >= 16) {                    // a tile spans at most two variables: one wrap
+                        if (lp >= d.Lp) { lp -= d.Lp; ++n; }
+                    } else {
+                        n = rr / d.Lp;
+                        lp = rr - n * d.Lp;
+                    }
+                    un = n * P1; vl = lp * P1;
+                };
+                int un1, vl1;
+                locate(fr, un1, vl1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) locate(fq * 4 + e, ou[t][e], ov[t][e]);
+                const float dy1 = dys[r0 + fr];                     // (zero past the window's rows)
+                {
+                    bf16x8 r;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] = (bf16_t)fmaxf(u[un1 + fq * 8 + q] + v[vl1 + fq * 8 + q], 0.f);
+                    hb[t] = r;
+                }
+                const dec_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                dec_f32x4 gq[2];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const dec_f32x4 z1 = dec_mfma(wA[jt], hb[t], z);             // lane = row fr, j = 16 jt + 4 fq + e
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = z1[e] + b2o1[jt][e];
+                        const float gv = a > 0.f ? dy1 * w3o1[jt][e] : 0.f;
+                        accw3[jt][e] = fmaf(dy1, fmaxf(a, 0.f), accw3[jt][e]);
+                        accb2[jt][e] += gv;
+                        gq[jt][e] = gv;
+                    }
+                }
+                if (fq == 0) accb3 += dy1;
+                bf16x8 gA;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gA[e] = (bf16_t)gq[0][e]; gA[4 + e] = (bf16_t)gq[1][e]; }
+                // dh1 = g2 W2 -> [h1 > 0] -> du[n] / dv[lp]: lane = k (16 kt + fr), rows 4 fq + e (rows past the end: g2 = 0)
+                // (rows grow with fq and e: first row in lane 0's e = 0, last in lane 63's e = 3 -- a wave-uniform test)
+                const bool one_n = __builtin_amdgcn_readfirstlane(ou[t][0]) == __builtin_amdgcn_readlane(ou[t][3], 63);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    const dec_f32x4 dh1 = dec_mfma(gA, wP[kt], z);
+                    const int k = kt * 16 + fr;
+                    float m[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        m[e] = u[ou[t][e] + k] + v[ov[t][e] + k] > 0.f ? dh1[e] : 0.f;
+                        atomicAdd(dv + ov[t][e] + k, m[e]);
+                    }
+                    if (one_n) {      // the whole tile is one variable (Lp a multiple of 16): one add per k
+                        const float sacc = xor32_sum(xor16_sum((m[0] + m[1]) + (m[2] + m[3])));
+                        if (fq == 0) atomicAdd(du + ou[t][0] + k, sacc);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(du + ou[t][e] + k, m[e]);
+                    }
+                }
+                // the same product with the operands swapped: lane = j
+                const float4 dy4 = *reinterpret_cast<const float4*>(dys + r0 + fq * 4);
+                const float dy2[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) {
+                    const dec_f32x4 z2 = dec_mfma(hb[t], wA[jt], z);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g2o2[t][jt][e] = z2[e] + b2o2[jt] > 0.f ? dy2[e] * w3o2[jt] : 0.f;
+                }
+            }
+            // dW2^T += h1^T g2 over the pair's 32 rows (rows in the accumulator order (4 fq + s | 16 + 4 fq + s - 4) on both sides)
+            bf16x8 gB[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gB[jt][e] = (bf16_t)g2o2[0][jt][e]; gB[jt][4 + e] = (bf16_t)g2o2[1][jt][e]; }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                bf16x8 hT;
+                const int k = kt * 16 + fr;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hT[q] = (bf16_t)fmaxf(u[ou[q >> 2][q & 3] + k] + v[ov[q >> 2][q & 3] + k], 0.f);
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) accW2[kt][jt] = dec_mfma(hT, gB[jt], accW2[kt][jt]);
+            }
+        }
+        __syncthreads();
+        // ---- first layer (fp32, as in the exact kernel): db1, dW1 -> the running sums; dh, dte
+        if (tid < H) {
+            float s = 0.f;
+            for (int n = 0; n < d.N; ++n) s += du[n * P1 + tid];
+            gb1s[tid] += s;
+        }
+        const int ld = d.D + d.E, pw = ld + 1;
+        const float* hs = Xs + H * pw;
+        const float* tes = hs + d.N * d.D;
+        for (int i = tid; i < H * ld; i += NT) {
+            const int k = i / ld, c = i - k * ld;
+            float a = 0.f;
+            if (c < d.D) {
+#pragma unroll 8
+                for (int n = 0; n < d.N; ++n) a = fmaf(du[n * P1 + k], hs[n * d.D + c], a);
+            } else {
+#pragma unroll 8
+                for (int lp = 0; lp < d.Lp; ++lp) a = fmaf(dv[lp * P1 + k], tes[lp * d.E + c - d.D], a);
+            }
+            gW1s[i] += a;
+        }
+        for (int i = tid; i < d.N * d.D; i += NT) {
+            const int n = i / d.D, c = i - n * d.D;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + c], du[n * P1 + k], a);
+            dh[(size_t)b * d.N * d.D + i] = a;
+        }
+        for (int i = tid; i < d.Lp * d.E; i += NT) {
+            const int lp = i / d.E, e = i - lp * d.E;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
+            dte[(size_t)b * d.Lp * d.E + i] = a;
+        }
+        __syncthreads();
+    }
+    // ---- this workgroup's parameter gradients -> global: the four waves' sums are added up in LDS first (one atomic per element
+    // per WORKGROUP: the atomics queue per address, their count is what the flush costs)
+    float* red = gb1s + H;                              // [NW][RED]: W2 (1024) | b2 (32) | W3 (32) | b3 (1)
+    constexpr int RED = H * H + 2 * H + 4;
+    float* mine = red + wave * RED;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mine[(jt * 16 + fr) * H + kt * 16 + fq * 4 + e] = accW2[kt][jt][e];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sb = row16_sum(accb2[jt][e]), sw = row16_sum(accw3[jt][e]);
+            if (fr == 0) { mine[H * H + jt * 16 + fq * 4 + e] = sb; mine[H * H + H + jt * 16 + fq * 4 + e] = sw; }
+        }
+    accb3 = wave_sum(accb3);
+    if (lane == 0) mine[H * H + 2 * H] = accb3;
+    __syncthreads();
+    for (int i = tid; i < H * H + 2 * H + 1; i += NT) {
+        float v4 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v4 += red[w * RED + i];
+        float* dst = i < H * H ? g.W2 + i : i < H * H + H ? g.b2 + (i - H * H) : i < H * H + 2 * H ? g.W3 + (i - H * H - H) : g.b3;
+        atomicAdd(dst, v4);
+    }
+    if (tid < H) atomicAdd(g.b1 + tid, gb1s[tid]);
+    for (int i = tid; i < H * (d.D + d.E); i += NT) atomicAdd(g.W1 + i, gW1s[i]);
+}
+
 constexpr size_t kLdsMax = 150 * 1024;
 
 bool dims_ok(int B, int N, int Lp, int D, int E, int H) {
@@ -361,12 +659,27 @@ size_t immtsf_tpatchgnn_decoder_lds_bytes(int32_t N, int32_t Lp, int32_t D, int3
 
 int immtsf_tpatchgnn_decoder_forward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
                                      const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream) {
-    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !out) return IMMTSF_EINVAL;
+    return immtsf_tpatchgnn_decoder_forward_p(B, N, Lp, D, E, H, 0, h, te, p, out, stream);
+}
+
+static bool dec_mfma_ok(const immtsf_decoder_params* p) {
+    static const bool on = !(getenv("IMMTSF_DEC_MFMA") && atoi(getenv("IMMTSF_DEC_MFMA")) == 0);
+    return on && (reinterpret_cast<uintptr_t>(p->W2) & 15) == 0;
+}
+
+int immtsf_tpatchgnn_decoder_forward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                       const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream) {
+    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !out || precision < 0 || precision > 1) return IMMTSF_EINVAL;
     if (immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) == 0) return IMMTSF_EUNSUPPORTED;
     if (B == 0) return IMMTSF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DecDims d{B, N, Lp, D, E};
     const DecP q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3};
+    if (precision == 1 && dec_mfma_ok(p)) {
+        hipLaunchKernelGGL(dec_fwd_mfma_kernel, dim3(B), dim3(256), fwd_lds_mfma<32>(N, Lp, D, E), s, d, q, h, te, out);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     const size_t lds = fwd_lds<32>(N, Lp, D, E);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(B), dim3(256), lds, s, d, q, h, te, out);
@@ -377,13 +690,28 @@ int immtsf_tpatchgnn_decoder_forward(int32_t B, int32_t N, int32_t Lp, int32_t D
 int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
                                       const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
                                       float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream) {
-    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !dout || !dh || !dte || !grads) return IMMTSF_EINVAL;
+    return immtsf_tpatchgnn_decoder_backward_p(B, N, Lp, D, E, H, 0, h, te, p, dout, dh, dte, grads, stream);
+}
+
+int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                        const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
+                                        float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream) {
+    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !dout || !dh || !dte || !grads || precision < 0 || precision > 1) return IMMTSF_EINVAL;
     if (immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) == 0) return IMMTSF_EUNSUPPORTED;
     if (B == 0) return IMMTSF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DecDims d{B, N, Lp, D, E};
     const DecP q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3};
     const DecG gq{grads->W1, grads->b1, grads->W2, grads->b2, grads->W3, grads->b3};
+    if (precision == 1 && dec_mfma_ok(p)) {
+        const size_t lm = bwd_lds_mfma<32>(N, Lp, D, E);
+        int per = (int)(160 * 1024 / lm);
+        per = per < 1 ? 1 : per > 2 ? 2 : per;          // (the grid is the fan-in of the final atomics)
+        const int grid = B < 256 * per ? B : 256 * per;
+        hipLaunchKernelGGL(dec_bwd_mfma_kernel, dim3(grid), dim3(512), lm, s, d, q, h, te, dout, dh, dte, gq);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     const size_t lds = bwd_lds<32>(N, Lp, D, E);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;      // resident workgroups per CU by LDS

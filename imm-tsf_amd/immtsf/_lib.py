@@ -172,6 +172,9 @@ _PROTOS = {
     "immtsf_tpatchgnn_decoder_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_stream]),
     "immtsf_tpatchgnn_decoder_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_f32p, c_f32p,
                                                     _P(DecoderParams), c_stream]),
+    "immtsf_tpatchgnn_decoder_forward_p": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_stream]),
+    "immtsf_tpatchgnn_decoder_backward_p": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_f32p, c_f32p,
+                                                   _P(DecoderParams), c_stream]),
     "immtsf_collate_series": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_float] + [c_f32p] * 6 + [c_stream]),
     "immtsf_collate_patches": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                          C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -840,11 +840,12 @@ def conv2d_same_cl(x, Weff, beff, KS, act=None, precision=None):
 
 
 class TPatchDecoderFn(torch.autograd.Function):
-    """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction, exact fp32.
-    Backward recomputes the forward; parameter gradients accumulate by atomics into one zeroed flat buffer."""
+    """tPatchGNN's forecast decoder on (h (B,N,D), te (B,Lp,E)) -> (B,Lp,N): one kernel per direction -- exact fp32, or in bf16
+    mode the second layer and its gradients on MFMA tiles (csrc/decoder.hip).  Backward recomputes the forward; parameter
+    gradients accumulate by atomics into one zeroed flat buffer."""
 
     @staticmethod
-    def forward(ctx, h, te, *params):
+    def forward(ctx, h, te, precision, *params):
         lib = _lib.load()
         h, te = _c(h), _c(te)
         params = tuple(_c(p) for p in params)
@@ -854,9 +855,9 @@ class TPatchDecoderFn(torch.autograd.Function):
         H = params[2].shape[0]
         out = torch.empty(B, Lp, N, dtype=torch.float32, device=h.device)
         ps = _struct(DecoderParams, params)
-        check(lib.immtsf_tpatchgnn_decoder_forward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(out), stream_ptr()),
+        check(lib.immtsf_tpatchgnn_decoder_forward_p(B, N, Lp, D, E, H, precision, ptr(h), ptr(te), C.byref(ps), ptr(out), stream_ptr()),
               "tpatchgnn_decoder_forward")
-        ctx.dims = (B, N, Lp, D, E, H)
+        ctx.dims = (B, N, Lp, D, E, H, precision)
         ctx.sinks = _sinks_of(params)
         ctx.save_for_backward(h, te, *params)
         return out
@@ -865,14 +866,14 @@ class TPatchDecoderFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         h, te, *params = ctx.saved_tensors
-        B, N, Lp, D, E, H = ctx.dims
+        B, N, Lp, D, E, H, precision = ctx.dims
         dout = dout.contiguous()
         dh, dte = torch.empty_like(h), torch.empty_like(te)
         grads, rets = _zeroed_grad_buffers(params, ctx.sinks)
         ps, gs = _struct(DecoderParams, params), _struct(DecoderParams, grads)
-        check(lib.immtsf_tpatchgnn_decoder_backward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh), ptr(dte),
-                                                    C.byref(gs), stream_ptr()), "tpatchgnn_decoder_backward")
-        return (dh, dte) + tuple(rets)
+        check(lib.immtsf_tpatchgnn_decoder_backward_p(B, N, Lp, D, E, H, precision, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh),
+                                                      ptr(dte), C.byref(gs), stream_ptr()), "tpatchgnn_decoder_backward")
+        return (dh, dte, None) + tuple(rets)
 
 
 def tpatch_decoder_supported(seq, N, Lp, D, E):
@@ -890,11 +891,12 @@ def tpatch_decoder_supported(seq, N, Lp, D, E):
     return _lib.load().immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) > 0
 
 
-def tpatch_decoder(seq, h, te):
+def tpatch_decoder(seq, h, te, precision=None):
     """decoder(cat[h broadcast over Lp ; te broadcast over N]).squeeze(-1).permute(0, 2, 1) of models/tPatchGNN.py:283-291
     without materialising the (B, N, Lp, D+E) tensor: h (B,N,D), te (B,Lp,E) -> (B,Lp,N)."""
     l1, l2, l3 = seq[0], seq[2], seq[4]
-    return TPatchDecoderFn.apply(h.float(), te.float(), l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias)
+    return TPatchDecoderFn.apply(h.float(), te.float(), config.precision_code(precision), l1.weight, l1.bias, l2.weight, l2.bias,
+                                 l3.weight, l3.bias)
 
 
 # ------------------------------------------------------------------------------------------------ layer primitives

@@ -289,6 +289,14 @@ int immtsf_tpatchgnn_decoder_forward(int32_t B, int32_t N, int32_t Lp, int32_t D
 int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
                                       const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
                                       float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream);
+/* The same with a precision argument (0: the exact fp32 kernels above; 1: bf16 operands / fp32 accumulation on MFMA tiles for the
+ * second layer and its gradients -- H = 32 is one K-step -- with the first layer and the (n, lp) bookkeeping unchanged).
+ * Reference: models/tPatchGNN.py:168-174, 283-291. */
+int immtsf_tpatchgnn_decoder_forward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                       const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream);
+int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                        const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
+                                        float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream);
 
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data

@@ -282,6 +282,53 @@ def test_fused_decoder_vs_eager(B, N, Lp, D, E, H):
         assert _rel(a, b) < 2e-5, i
 
 
+@pytest.mark.parametrize("B,N,Lp,D,E", [(64, 8, 32, 32, 10), (3, 5, 7, 32, 4), (2, 41, 70, 24, 10), (300, 8, 32, 32, 10), (5, 3, 260, 32, 10)])
+def test_fused_decoder_bf16_mfma_vs_eager(B, N, Lp, D, E):
+    """bf16 mode: the decoder's second layer and its gradients on MFMA tiles (csrc/decoder.hip dec_fwd/bwd_mfma_kernel; persistent
+    workgroups that walk several windows at B = 300) against the eager fp32 nn.Sequential at the bf16 bars -- ragged tile
+    counts (rows not a multiple of 16 / 32), several variables per tile (Lp < 16) and Lp > 256."""
+    dev = _dev()
+    from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
+    H = 32
+    torch.manual_seed(B * 77 + Lp)
+    dec = torch.nn.Sequential(torch.nn.Linear(D + E, H), torch.nn.ReLU(inplace=True), torch.nn.Linear(H, H),
+                              torch.nn.ReLU(inplace=True), torch.nn.Linear(H, 1)).to(dev)
+    assert tpatch_decoder_supported(dec, N, Lp, D, E)
+    h = torch.randn(B, N, D, device=dev, requires_grad=True)
+    te = torch.randn(B, Lp, E, device=dev, requires_grad=True)
+    up = torch.randn(B, Lp, N, device=dev)
+    out = tpatch_decoder(dec, h, te, precision="bf16")
+    (out * up).sum().backward()
+    got = [h.grad.clone(), te.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+    h.grad = te.grad = None
+    dec.zero_grad()
+    x = torch.cat([h.unsqueeze(2).expand(B, N, Lp, D), te.unsqueeze(1).expand(B, N, Lp, E)], dim=-1)
+    l2 = lambda a, b: float((a.detach().double() - b.detach().double()).norm() / b.detach().double().norm().clamp_min(1e-12))      # noqa: E731
+
+    def run(bf16_operands):
+        h.grad = te.grad = None
+        dec.zero_grad()
+        h1 = torch.relu(dec[0](x))
+        if bf16_operands:      # what the kernel computes: second-layer operands rounded to bf16, fp32 accumulation
+            z2 = h1.bfloat16().float() @ dec[2].weight.bfloat16().float().T + dec[2].bias
+        else:
+            z2 = dec[2](h1)
+        ref = dec[4](torch.relu(z2)).squeeze(-1).permute(0, 2, 1)
+        (ref * up).sum().backward()
+        return ref, [h.grad.clone(), te.grad.clone()] + [p.grad.clone() for p in dec.parameters()]
+
+    # against the same arithmetic in torch (the ReLU masks agree): tight; against plain fp32 (masks of pre-activations within
+    # bf16 rounding of zero flip, each flip is an O(1) error of that element's gradient): the bf16-mode bar of the step tests
+    ref_e, want_e = run(True)
+    assert l2(out, ref_e) < 2e-3
+    errs = {i: l2(a, b) for i, (a, b) in enumerate(zip(got, want_e))}
+    assert all(e < 1.5e-2 for e in errs.values()), errs
+    ref_f, want_f = run(False)
+    assert l2(out, ref_f) < 2e-2
+    errs = {i: l2(a, b) for i, (a, b) in enumerate(zip(got, want_f))}
+    assert all(e < 1e-1 for e in errs.values()), errs
+
+
 def test_fused_decoder_unsupported_shapes_fall_back():
     dev = _dev()
     from immtsf.ops import tpatch_decoder_supported

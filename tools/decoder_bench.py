@@ -18,10 +18,11 @@ params = [torch.randn(*s, device=dev) * 0.2 for s in [(H, D + E), (H,), (H, H), 
 grads = [torch.zeros_like(p) for p in params]
 out, dh, dte = torch.empty(B, Lp, N, device=dev), torch.empty_like(h), torch.empty_like(te)
 ps, gs = _struct(DecoderParams, params), _struct(DecoderParams, grads)
+PREC = 0
 def fwd():
-    assert lib.immtsf_tpatchgnn_decoder_forward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(out), _lib.stream_ptr()) == 0
+    assert lib.immtsf_tpatchgnn_decoder_forward_p(B, N, Lp, D, E, H, PREC, ptr(h), ptr(te), C.byref(ps), ptr(out), _lib.stream_ptr()) == 0
 def bwd():
-    assert lib.immtsf_tpatchgnn_decoder_backward(B, N, Lp, D, E, H, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh), ptr(dte), C.byref(gs), _lib.stream_ptr()) == 0
+    assert lib.immtsf_tpatchgnn_decoder_backward_p(B, N, Lp, D, E, H, PREC, ptr(h), ptr(te), C.byref(ps), ptr(dout), ptr(dh), ptr(dte), C.byref(gs), _lib.stream_ptr()) == 0
 def timed(fn, n=20):
     s = torch.cuda.Stream()
     with torch.cuda.stream(s): fn()
@@ -33,5 +34,6 @@ def timed(fn, n=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-fwd(); bwd(); torch.cuda.synchronize()
-print(f"B={B} N={N} Lp={Lp} D={D} E={E} H={H}: forward {timed(fwd):6.1f} us   backward {timed(bwd):6.1f} us")
+for PREC in (0, 1):
+    fwd(); bwd(); torch.cuda.synchronize()
+    print(f"B={B} N={N} Lp={Lp} D={D} E={E} H={H} precision {PREC} ({'exact fp32' if PREC == 0 else 'bf16 MFMA'}): forward {timed(fwd):6.1f} us   backward {timed(bwd):6.1f} us")

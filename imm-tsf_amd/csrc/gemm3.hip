@@ -81,10 +81,12 @@ struct G3Args {
     const int* row_flag;      // int32 per row group: rows with row_flag[m / row_flag_div] == 0 are zeroed (before add_vec), or null
     const int* dyn;           // device row count overriding M, or null
     const int* dynk;          // split mode: device reduction length overriding K, or null
-    float* slab;              // split mode: [items][BM x 256] fp32 partial tiles (item = tile * splits + split)
+    float* slab;              // split mode: [items][BM x 256] fp32 partial tiles (item = split * tiles + tile: neighbouring items --
+                              // an XCD's share of a round -- are the tiles of ONE K-range and find each other's A / B panels in L2)
     float* slab_b;            // split mode, bias gradient requested: [items][BM] partial column sums of A (tiles of column 0 only)
     int splits;               // split mode: K-ranges per tile
-    unsigned s_magic;         // id / splits as __umulhi(id, magic); 0: splits == 1
+    unsigned s_magic;         // id / tiles as __umulhi(id, magic) (split mode)
+    int tiles_total;          // split mode: tiles (items = tiles_total * splits)
     int row_flag_div;
     unsigned rf_magic;        // floor(2^32 / row_flag_div) (0: div == 1): m / div = __umulhi(m, magic) (+1 after one check)
     int M, N, K;
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         c.kt = 0;
         const bool ok = id < nt;
         const int idc = ok ? id : 0;
-        const int tile = (SPLIT && g.s_magic) ? (int)__umulhi((unsigned)idc, g.s_magic) : idc;
-        const int split = SPLIT ? idc - tile * S : 0;
+        const int split = SPLIT ? (int)__umulhi((unsigned)idc, g.s_magic) : 0;
+        const int tile = SPLIT ? idc - split * g.tiles_total : idc;
         const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
         const int tn = tile - tm * tiles_n;
         c.row0 = tm * BM;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         const bool pstore = kt == 1 && have_prev;
         if (first) {
             if (SPLIT) {        // store coordinates = the item's slab rows; the tile's column decides who sums A's columns
-                const int tile = g.s_magic ? (int)__umulhi((unsigned)id, g.s_magic) : id;
+                const int tile = id - (int)__umulhi((unsigned)id, g.s_magic) * g.tiles_total;
                 const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
                 row0 = id * BM;
                 col0 = 0;
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
 }
 
 
-// C[m, n] = alpha * sum_s slab[tile * S + s][m % BM][n % 256] (+ C[m, n]); bias_grad[m] = alpha * sum_s slab_b[tile(m, 0) * S + s][m % BM]
+// C[m, n] = alpha * sum_s slab[s * tiles + tile][m % BM][n % 256] (+ C[m, n]); bias_grad[m] = alpha * sum_s slab_b[s * tiles + tile(m, 0)][m % BM]
 __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_b, float* __restrict__ C,
                                                            int ldc, bf16_t* __restrict__ Ch, int ldch, float* __restrict__ bias_grad, int M, int N,
                                                            int BM, int tiles_n, int S, float alpha, int accumulate) {
@@ -612,10 +614,11 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restri
     if (idx < total) {
         const int m = (int)(idx / n4), n = (int)(idx - (long)m * n4) * 4;
         const int tm = m / BM, r = m - tm * BM, tn = n >> 8, c = n & 255;
-        const float* p = slab + ((size_t)(tm * tiles_n + tn) * S * BM + r) * 256 + c;
+        const size_t tiles = (size_t)((M + BM - 1) / BM) * tiles_n;
+        const float* p = slab + ((size_t)(tm * tiles_n + tn) * BM + r) * 256 + c;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int s = 0; s < S; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * BM * 256);
+            const float4 v = *reinterpret_cast<const float4*>(p + (size_t)s * tiles * BM * 256);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         float4 o = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
@@ -634,9 +637,10 @@ __global__ __launch_bounds__(256) void gemm3_reduce_kernel(const float* __restri
         }
     } else if (bias_grad && idx - total < M) {
         const int m = (int)(idx - total), tm = m / BM, r = m - tm * BM;
-        const float* p = slab_b + (size_t)(tm * tiles_n) * S * BM + r;
+        const size_t tiles = (size_t)((M + BM - 1) / BM) * tiles_n;
+        const float* p = slab_b + (size_t)(tm * tiles_n) * BM + r;
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc += p[(size_t)s * BM];
+        for (int s = 0; s < S; ++s) acc += p[(size_t)s * tiles * BM];
         bias_grad[m] = alpha * acc + (accumulate ? bias_grad[m] : 0.f);
     }
 }
@@ -794,7 +798,8 @@ int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float
     g.tiles_n = cdiv(N, G3_BN);
     g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
     g.splits = S;
-    g.s_magic = (unsigned)((0x100000000ull + (unsigned)S - 1) / (unsigned)S);
+    g.tiles_total = cdiv(M, 256) * g.tiles_n;
+    g.s_magic = (unsigned)((0x100000000ull + (unsigned)g.tiles_total - 1) / (unsigned)g.tiles_total);
     g.dynk = dynk;
     const long items = (long)cdiv(M, 256) * g.tiles_n * S;
     g.slab = static_cast<float*>(ws);

@@ -119,6 +119,7 @@ public:
     explicit Fork(hipStream_t main) : main_(main), st_(side_stream_state()), used_(false) {
         active_ = st_.ok && immtsf_side_stream_enabled();
     }
+    bool forking() const { return active_; }
     // stream for work that may run concurrently with what follows on the main stream; everything enqueued on the main
     // stream so far is a dependency
     hipStream_t fork() {

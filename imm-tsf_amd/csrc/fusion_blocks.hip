@@ -250,7 +250,16 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     const DropCfg drop = drop_of(cfg);
     const int* total = w.offsets + B;
     const float scale = sqrtf(1.0f / (float)hd);
-    Fork fk(s);   // weight-gradient GEMMs run on the side stream, joined before returning
+    Fork fk(s);   // (A/B option) weight-gradient GEMMs on the side stream, joined before returning
+    // The weight gradients wait on nothing but their dY and nothing in this call waits on them: with IMMTSF_GEMM_GROUP=1 they are
+    // collected and go out as ONE grouped launch at the end (gemm2_group_kernel)
+    GemmArgs wg[6];
+    int nwg = 0;
+    const bool defer_wg = !fk.forking() && immtsf_gemm_group_enabled();       // (off by default: see gemm2.hip)
+    auto wgrad = [&](GemmArgs& h) -> int {
+        if (defer_wg && nwg < 6) { wg[nwg++] = h; return 0; }
+        return immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork());
+    };
 
     const bool hf = t2v_hf(cfg);
     T2VW W;
@@ -270,7 +279,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
         prezeroed(h, cfg);
         h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     }
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
     // LayerNorm parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with notes feed
@@ -284,7 +293,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
         prezeroed(h, cfg);
         h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
     CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
@@ -300,7 +309,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         h.dyn = total; h.dyn_which = 1;
         h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     }
     {   // KV_proj
         GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
@@ -312,7 +321,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         h.dyn = total; h.dyn_which = 1;
         h.ws = sc.sk[3]; h.ws_bytes = sc.skb[3];
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     }
     static const int notes_image_b = getenv("IMMTSF_T2V_NOTES_IMAGE") ? atoi(getenv("IMMTSF_T2V_NOTES_IMAGE")) : 1;
     if (p->input_proj_w && hf && notes_image_b) {   // dW_in = dVp^T V ; db_in = colsum dVp: both operands are bf16 images (dXcat's first d columns, the packed notes)
@@ -321,19 +330,20 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         h.dyn = total; h.dyn_which = 1;
         h.ws = sc.sk[4]; h.ws_bytes = sc.skb[4];
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     } else if (p->input_proj_w) {   // row-mapped, fp32 operands: the round-1 kernel
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
         h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;
         prezeroed(h, cfg);
-        CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
+        CHECK(wgrad(h));
     }
     // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq -- in the same
     // launch as the first stage of Time2Vec's parameter gradients
     CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
                                w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
                                gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
+    CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
     return fk.join();
 }
 

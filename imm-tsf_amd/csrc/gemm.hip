@@ -814,6 +814,25 @@ int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t strea
     return rc;
 }
 
+int immtsf_launch_gemm_tn_list(int precision, GemmArgs* list, int n, hipStream_t stream) {
+    if (n <= 0) return IMMTSF_OK;
+    // one grouped launch when every product has bf16 operands in memory and fits the grouped kernel (and no timing tap is
+    // recording per-launch times)
+    if (precision == 1 && n >= 2 && !g_force_old && !g_tap_on.load(std::memory_order_relaxed)) {
+        bool have = true;
+        for (int i = 0; i < n && have; ++i) have = list[i].nprob == 1 && list[i].nbatch <= 1 && list[i].p[0].Ah && list[i].p[0].Bh;
+        if (have) {
+            const int rc = immtsf_launch_gemm2_group_tn(list, n, stream);
+            if (rc != IMMTSF_EUNSUPPORTED) return rc;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int rc = immtsf_launch_gemm(GEMM_TN, precision, list[i], stream);
+        if (rc != 0) return rc;
+    }
+    return IMMTSF_OK;
+}
+
 extern "C" int immtsf_timing_enable(int on) {
     std::lock_guard<std::mutex> lk(g_tap_mu);
     if (on && !g_tap) g_tap = new TapRec[kTapCap];

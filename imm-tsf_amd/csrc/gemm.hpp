@@ -89,6 +89,9 @@ const void* immtsf_twin_lookup(const float* p, size_t min_elems);
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g);
 void immtsf_gemm_note_grid(long threads);      // timing tap: threads of the launch just made
 int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream);
+// several TN products of different shapes in one launch (64 x 64 K-group tiles); IMMTSF_EUNSUPPORTED: launch them one by one
+int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream);
+bool immtsf_gemm_group_enabled();      // IMMTSF_GEMM_GROUP=1 (off by default: measured slower inside the cfg2 step)
 
 // ---- gemm3.hip: the persistent many-rows kernel (M >> 256, K > 64, plain epilogue: alpha, bias, row flags, add_vec).
 // IMMTSF_EUNSUPPORTED for anything else: the caller falls back to gemm2.
@@ -102,3 +105,5 @@ int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float
 
 // precision: 0 = exact fp32 (v_mfma_f32_16x16x4_f32), 1 = bf16 operands / fp32 accumulate (v_mfma_f32_16x16x32_bf16)
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);
+// the weight-gradient products a block collected (immtsf_launch_gemm's arguments): one grouped launch when they qualify, else one by one
+int immtsf_launch_gemm_tn_list(int precision, GemmArgs* list, int n, hipStream_t stream);

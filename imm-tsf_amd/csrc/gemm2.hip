@@ -43,8 +43,10 @@ constexpr int BK2 = 64;
 // kt0 + kg, kt0 + kg + WK, ...), each with its own ring; their accumulators are summed through LDS in the epilogue.
 // More waves and more LDS-DMA streams per CU without smaller per-wave tiles: one LDS-DMA stream per wave lands ~1 KiB
 // per ~100 cycles whatever is asked of it, so a 4-wave workgroup cannot pull what the CU's L2 port offers.
+// (the kernel's body as a device function: bx / by / bz = the workgroup's tile index, K split and problem; gx / gy = the extents
+// of the tile and split dimensions -- gemm2_kernel passes blockIdx / gridDim, gemm2_group_kernel a sub-problem's own numbering)
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
-__global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, const int by, const int bz, const int gx, const int gy) {
     constexpr int NT = WM * WN * 64;          // threads of one K group
     constexpr int NTALL = NT * WK;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
 
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[WK * RING];
 
-    const GemmProblem P = g.p[blockIdx.z];
+    const GemmProblem P = g.p[bz];
     int M = g.M, K = g.K;
     const int N = g.N;
     if (g.dyn) {
         const int dv = *g.dyn;
         if (g.dyn_which == 0) M = dv; else K = dv;
     }
-    int lin = blockIdx.x, tile_m, tile_n;
+    int lin = bx, tile_m, tile_n;
     if (g.g2_fast) {          // launcher-made reciprocals instead of run-time divisions (see GemmArgs)
         if (g.xcd_remap && g.xcd_gm > 0) {
             const int xcd = lin & 7, idx = lin >> 3;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
             tile_n = (xcd & ((1 << g.g2_xc_shift) - 1)) * g.g2_cols_x + (idx - qi * g.g2_cols_x);
         } else {
             if (g.xcd_remap) {
-                const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
+                const int total = gx, q = total >> 3, r = total & 7, xcd = lin & 7;
                 lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
             }
             tile_m = g.g2_tn_magic ? (int)__umulhi((unsigned)lin, g.g2_tn_magic) : lin;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
         tile_n = (xcd % XC) * cols_x + idx % cols_x;
     } else {
         if (g.xcd_remap) {        // contiguous tile range per XCD (bijective for any grid size), see gemm.hip
-            const int total = gridDim.x, q = total >> 3, r = total & 7, xcd = lin & 7;
+            const int total = gx, q = total >> 3, r = total & 7, xcd = lin & 7;
             lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
         }
         tile_m = lin / tiles_n;
@@ -123,9 +125,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
 
     // K range of this split, in 64-deep steps
     const int nk_total = (K + BK2 - 1) / BK2;
-    const int splits = gridDim.y;
+    const int splits = gy;
     const int per = (g.g2_fast && g.g2_per) ? g.g2_per : (nk_total + splits - 1) / splits;
-    const int kt0 = blockIdx.y * per, kt1 = min(nk_total, kt0 + per);
+    const int kt0 = by * per, kt1 = min(nk_total, kt0 + per);
     if (splits > 1 && kt0 >= kt1) return;
     const int kend = min(K, kt1 * BK2);
 
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
     __builtin_amdgcn_s_barrier();
 
     // bias-gradient partial sums.  C/D map: col = lane & 15, row = (lane >> 4)*4 + reg; every column holds the sum
-    if (TA && TB && want_bsum && fr == 0 && gridDim.y > 1) {
+    if (TA && TB && want_bsum && fr == 0 && gy > 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
 
     float* __restrict__ C = P.C;
     bf16_t* __restrict__ Ch = reinterpret_cast<bf16_t*>(P.Ch);
-    const bool first = blockIdx.y == 0;
+    const bool first = by == 0;
     // ---- epilogue through LDS: whole 16-byte pieces of C rows (fp32) and 8-byte pieces of the bf16 copy
     float* Ct = reinterpret_cast<float*>(smem);
     const int ldch = g.ldch ? g.ldch : g.ldc;
@@ -368,6 +370,29 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g
             }
         }
     }
+}
+
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_kernel(const GemmArgs g) {
+    gemm2_body<TA, TB, BM, BN, WM, WN, S, WK>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// Several products of different shapes in ONE launch (the text side's weight gradients at <= a few thousand rows: five TN
+// products of 10 - 18 us each that wait on nothing but their dY -- a launch each was ~75 us of the backward's dependent chain).
+// The grid is the concatenation of the sub-problems' tile lists; a workgroup looks its sub-problem up and runs the ordinary body.
+constexpr int G2_GROUP_MAX = 6;
+struct GemmGroupArgs {
+    GemmArgs sub[G2_GROUP_MAX];
+    int tile0[G2_GROUP_MAX + 1];      // first workgroup of each sub-problem
+    int n;
+};
+template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_group_kernel(const GemmGroupArgs gg) {
+    int s = 0;
+#pragma unroll
+    for (int i = 1; i < G2_GROUP_MAX; ++i)
+        if (i < gg.n && (int)blockIdx.x >= gg.tile0[i]) s = i;
+    gemm2_body<TA, TB, BM, BN, WM, WN, S, WK>(gg.sub[s], (int)blockIdx.x - gg.tile0[s], 0, 0, gg.tile0[s + 1] - gg.tile0[s], 1);
 }
 
 template <int BM, int BN, int WM, int WN, int S, int WK = 1>
@@ -578,6 +603,41 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         case 27: return launch2<96, 64, 2, 2, 2, 4>(layout, g, Mmax, splits, stream);
         default: return IMMTSF_EINVAL;
     }
+}
+
+// Off unless IMMTSF_GEMM_GROUP=1 -- measured at 64 windows (cfg2): the five text-side weight gradients as one 936-workgroup launch at
+// the end of the backward take 47 us alone on the critical stream, where the separate launches (10 - 18 us each) had overlapped
+// with the backbone's backward: 0.731 vs 0.716 ms per step.
+bool immtsf_gemm_group_enabled() {
+    static const bool on = getenv("IMMTSF_GEMM_GROUP") && atoi(getenv("IMMTSF_GEMM_GROUP")) == 1;
+    return on;
+}
+// n (2 .. 6) TN products C_i = alpha A_i^T B_i (+ bias gradients) of different shapes as ONE launch of the 64 x 64 K-group
+// tiles: every product must be one the single launch would run on those tiles without splitting (bf16 operands, fp32 result, no
+// activation / row maps / row counts, K < 8192).  IMMTSF_EUNSUPPORTED otherwise: the caller launches them one by one.
+int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
+    if (!immtsf_gemm_group_enabled() || n < 2 || n > G2_GROUP_MAX || g2_variant != 0 || g2_splitk > 1) return IMMTSF_EUNSUPPORTED;
+    GemmGroupArgs gg;
+    memset(&gg, 0, sizeof(gg));
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = list[i];
+        if (!immtsf_gemm2_supported(GEMM_TN, g) || g.nprob != 1 || g.act != 0 || g.relu_ref || g.row_flag || g.add_vec || g.accumulate ||
+            g.K >= 8192 || (g.dyn && g.dyn_which != 1) || g.p[0].Ch || !g.p[0].C || (g.ldc % 4) || !al16(g.p[0].C))
+            return IMMTSF_EUNSUPPORTED;
+        g.vecA = 1; g.vecB = 1; g.vecC = 1;
+        g.xcd_remap = 0; g.xcd_gm = 0; g.g2_fast = 0;
+        gg.sub[i] = g;
+        gg.tile0[i] = tiles;
+        tiles += cdiv(g.M, 64) * cdiv(g.N, 64);
+    }
+    gg.tile0[n] = tiles;
+    for (int i = n + 1; i <= G2_GROUP_MAX; ++i) gg.tile0[i] = tiles;
+    gg.n = n;
+    immtsf_gemm_note_grid((long)tiles * 1024);
+    hipLaunchKernelGGL((gemm2_group_kernel<true, true, 64, 64, 2, 2, 2, 4>), dim3(tiles), dim3(1024), 0, stream, gg);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
 }
 
 // debug / test / tool entry (declared in include/immtsf.h)

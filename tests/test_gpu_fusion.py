@@ -782,3 +782,16 @@ def test_mmf_monolithic_entry_equals_the_two_halves():
         res.append([out.detach(), y.grad, e.grad] + [p.grad.clone() for p in mmf.parameters()])
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 1e-5 * max(1e-3, float(b.abs().max()))
+
+
+def test_grouped_weight_gradient_launch_opt_in():
+    """IMMTSF_GEMM_GROUP=1 (csrc/gemm2.hip gemm2_group_kernel: the T2V backward's five TN weight gradients, different shapes, as ONE
+    launch at the end of the call; read once per process, so a child process): the bf16 benchmark-shape parity tests still pass."""
+    import subprocess
+    import sys
+    env = dict(os.environ, IMMTSF_GEMM_GROUP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "test_pairs_bf16_benchmark_shape or test_pairs_bf16_shapes_outside", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -4,7 +4,7 @@ W=${1:-1024}; TAG=${2:-w}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o r -- python3 bench.py --windows-per-gpu $W --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/prof_$TAG.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$TAG -o r -- python3 bench.py --windows-per-gpu $W --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-extras $PROF_EXTRA > gpurun_out/prof_$TAG.log 2>&1
 f=$(ls gpurun_out/prof_$TAG/*results.db 2>/dev/null | head -1)
 python3 tools/rocpd_stats.py $f gpurun_out/prof_${TAG}_stats.csv
 python3 tools/rocpd_seq.py $f > gpurun_out/prof_${TAG}_seq.txt

@@ -162,7 +162,7 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
     CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
     CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s, true));
     CHECK(launch_recavg_bwd(B, T, d, w.offsets, w.rowmap, tau, t_hat, p->log_recency_sigma, w.Vp, w.Eraw, w.denom, sc.dEraw,
-                            sc.dVp, sc.dls_part, s));
+                            sc.dVp, sc.dls_part, s, cfg->precision));
     CHECK(launch_colsum(sc.dls_part, nullptr, B, nullptr, 1, 1, gr->log_recency_sigma, 0, sc.red, s));
     if (p->input_proj_w) {
         GemmArgs h = gemm_args(d, cfg->d_m, R, d, cfg->d_m, cfg->d_m);

@@ -91,7 +91,7 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dqs = k.take<float>(d);
     s.dq = k.take<float>(d);
     s.dp = k.take<float>(ragged_attn_dp_floats(c->B, c->N, c->H, c->d / c->H));
-    s.red = k.take<float>(colsum_scratch_floats(d, 3));
+    s.red = k.take<float>(ln_sums_scratch_floats(d, 3));        // (>= colsum_scratch_floats(d, 3): the fallback's scratch)
     s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));       // time2vec backward: ~256 packed rows per slab
     s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
     {
@@ -281,10 +281,19 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
         CHECK(wgrad(h));
     }
-    CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
-    // LayerNorm parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with notes feed
-    // the attention branch (rows zeroed, bf16 image written) -- one pass
-    CHECK(launch_colsum3(sc.dz, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+    // LayerNorm backward; its parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with
+    // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
+    // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
+    {
+        const int rc = launch_layernorm_bwd_sums(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                 gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
+        if (rc == IMMTSF_EUNSUPPORTED) {
+            CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
+            CHECK(launch_colsum3(sc.dz, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+        } else {
+            CHECK(rc);
+        }
+    }
     {   // out_proj
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);

@@ -48,7 +48,7 @@ RecScratch carve_rec_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dEraw = k.take<float>(BT * d);
     s.dVp = k.take<float>(R * d);
     s.dls_part = k.take<float>(B);
-    s.red = k.take<float>(colsum_scratch_floats(d, 2));
+    s.red = k.take<float>(ln_sums_scratch_floats(d, 2));        // (>= colsum_scratch_floats(d, 2): the fallback's scratch)
     s.bytes = k.bytes();
     return s;
 }
@@ -159,8 +159,16 @@ int immtsf_ttf_recavg_backward(const immtsf_fusion_cfg* cfg, const immtsf_recavg
         prezeroed(h, cfg);
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, h, fk.fork()));
     }
-    CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
-    CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s, true));
+    {   // LayerNorm backward with its parameter-gradient sums in the same pass; small / unaligned cases: the two separate passes
+        const int rc = launch_layernorm_bwd_sums(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, gr->ln_w, gr->ln_b,
+                                                 nullptr, sc.red, nullptr, 1, nullptr, s);
+        if (rc == IMMTSF_EUNSUPPORTED) {
+            CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dEraw, drop, SITE_REC_OUT, s));
+            CHECK(launch_colsum2(sc.dz, w.xhat, BT, d, d, gr->ln_w, gr->ln_b, sc.red, s, true));
+        } else {
+            CHECK(rc);
+        }
+    }
     CHECK(launch_recavg_bwd(B, T, d, w.offsets, w.rowmap, tau, t_hat, p->log_recency_sigma, w.Vp, w.Eraw, w.denom, sc.dEraw,
                             sc.dVp, sc.dls_part, s, cfg->precision));
     CHECK(launch_colsum(sc.dls_part, nullptr, B, nullptr, 1, 1, gr->log_recency_sigma, 0, sc.red, s));

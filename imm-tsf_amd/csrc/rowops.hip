@@ -783,6 +783,116 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(float* __restric
     }
 }
 
+// LayerNorm backward WITH the parameter-gradient sums of its rows: a workgroup walks rows blockIdx.x * 4 + wave, + 4 gridDim.x, ...
+// and every lane keeps the column sums of dy * xhat (-> d gamma), dy (-> d beta) and, K == 3, of dx (the residual's share: the
+// gradient of a parameter that is added to every row) for its own columns; the four waves are added up in LDS and the workgroup
+// writes ONE partial row set, partial[(blockIdx.x * K + k) * d + n] -- the layout colsum_vec_final_kernel<K> sums.  K == 3 also does
+// what the text side's colsum3 pass did on its way: rows whose row_flag[row / flag_div] == 0 are zeroed in dx (AFTER their
+// contribution to the third sum) and dx's bf16 image is written.  Saves the separate pass over dz, xhat and dx (3 x rows x d x 4
+// bytes: 1.3 GB at 4096 windows) and a launch.
+template <int K>
+__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(float* __restrict__ dz_dy, int rows, int d, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                                  float* __restrict__ dx, DropCfg drop, uint64_t site,
+                                                                  float* __restrict__ partial, const unsigned char* __restrict__ row_flag,
+                                                                  int flag_div, bf16_t* __restrict__ dxh) {
+    extern __shared__ __attribute__((aligned(16))) float ln_red[];       // [3 waves][K][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
+    float4 sw[LN_DV], sb[LN_DV], sq[K == 3 ? LN_DV : 1];
+#pragma unroll
+    for (int j = 0; j < LN_DV; ++j) {
+        sw[j] = sb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (K == 3) sq[j] = sw[j];
+    }
+    float4 gm[LN_DV];
+#pragma unroll
+    for (int j = 0; j < LN_DV; ++j) {
+        const int q = lane + 64 * j;
+        gm[j] = q < d4 ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += 4 * gridDim.x) {
+        float4* g = reinterpret_cast<float4*>(dz_dy + (size_t)row * d);
+        const float4* h = reinterpret_cast<const float4*>(xhat + (size_t)row * d);
+        float4 tv[LN_DV], hv[LN_DV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_DV; ++j) {
+            const int q = lane + 64 * j;
+            tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            hv[j] = tv[j];
+            if (q < d4) {
+                float sc[4];
+                dropout_scale4(drop, site, (uint64_t)row * d + (uint64_t)q * 4, sc);
+                float4 dy = g[q];
+                dy = make_float4(dy.x * sc[0], dy.y * sc[1], dy.z * sc[2], dy.w * sc[3]);
+                if (drop.p > 0.f) g[q] = dy;
+                hv[j] = h[q];
+                sw[j].x = fmaf(dy.x, hv[j].x, sw[j].x); sw[j].y = fmaf(dy.y, hv[j].y, sw[j].y);
+                sw[j].z = fmaf(dy.z, hv[j].z, sw[j].z); sw[j].w = fmaf(dy.w, hv[j].w, sw[j].w);
+                sb[j].x += dy.x; sb[j].y += dy.y; sb[j].z += dy.z; sb[j].w += dy.w;
+                tv[j] = make_float4(dy.x * gm[j].x, dy.y * gm[j].y, dy.z * gm[j].z, dy.w * gm[j].w);
+                c1 += (tv[j].x + tv[j].y) + (tv[j].z + tv[j].w);
+                c2 = fmaf(tv[j].x, hv[j].x, fmaf(tv[j].y, hv[j].y, fmaf(tv[j].z, hv[j].z, fmaf(tv[j].w, hv[j].w, c2))));
+            }
+        }
+        c1 = wave_sum(c1) / (float)d;
+        c2 = wave_sum(c2) / (float)d;
+        const float rs = rstd[row];
+        const bool keep = !(K == 3 && row_flag) || row_flag[row / flag_div] != 0;
+#pragma unroll
+        for (int j = 0; j < LN_DV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < d4) {
+                float4 o = make_float4(rs * (tv[j].x - c1 - hv[j].x * c2), rs * (tv[j].y - c1 - hv[j].y * c2),
+                                       rs * (tv[j].z - c1 - hv[j].z * c2), rs * (tv[j].w - c1 - hv[j].w * c2));
+                if (K == 3) { sq[j].x += o.x; sq[j].y += o.y; sq[j].z += o.z; sq[j].w += o.w; }
+                if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                reinterpret_cast<float4*>(dx + (size_t)row * d)[q] = o;
+                if (K == 3 && dxh) {
+                    const bf16x4 hvv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+                    reinterpret_cast<bf16x4*>(dxh + (size_t)row * d)[q] = hvv;
+                }
+            }
+        }
+    }
+    // waves 1..3 park their sums, wave 0 adds them and writes the workgroup's partial rows
+    float4* red4 = reinterpret_cast<float4*>(ln_red);
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < LN_DV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < d4) {
+                red4[((wave - 1) * K + 0) * d4 + q] = sw[j];
+                red4[((wave - 1) * K + 1) * d4 + q] = sb[j];
+                if (K == 3) red4[((wave - 1) * K + 2) * d4 + q] = sq[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < LN_DV; ++j) {
+            const int q = lane + 64 * j;
+            if (q < d4) {
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 a = red4[(w * K + 0) * d4 + q], b = red4[(w * K + 1) * d4 + q];
+                    sw[j].x += a.x; sw[j].y += a.y; sw[j].z += a.z; sw[j].w += a.w;
+                    sb[j].x += b.x; sb[j].y += b.y; sb[j].z += b.z; sb[j].w += b.w;
+                    if (K == 3) {
+                        const float4 c = red4[(w * K + 2) * d4 + q];
+                        sq[j].x += c.x; sq[j].y += c.y; sq[j].z += c.z; sq[j].w += c.w;
+                    }
+                }
+                float4* out = reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * K * d);
+                out[0 * d4 + q] = sw[j];
+                out[1 * d4 + q] = sb[j];
+                if (K == 3) out[2 * d4 + q] = sq[j];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dz_dy, int rows, int d,
                                                              const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                              const float* __restrict__ rstd, float* __restrict__ dx,
@@ -1128,6 +1238,39 @@ int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, cons
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop,
                            site);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+// LayerNorm backward + its parameter-gradient sums in one pass (+ final reduce): out_gw = sum_rows dy * xhat, out_gb = sum_rows dy,
+// out_q (optional) = sum_rows dx; row_flag / dxh: see the kernel.  scratch: ln_sums_scratch_floats(d, 3 or 2) floats.
+// IMMTSF_EUNSUPPORTED when the vector path does not apply (the caller then runs launch_layernorm_bwd + launch_colsum2/3).
+int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd, float* dx,
+                              DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
+                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s) {
+    if (rows <= 0) return IMMTSF_OK;
+    static const bool on = !(getenv("IMMTSF_LN_SUMS") && atoi(getenv("IMMTSF_LN_SUMS")) == 0);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(dz_dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(xhat) |
+                         reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(scratch);
+    if (!on || (d & 3) || d > 256 * LN_DV || (al & 15) || (reinterpret_cast<uintptr_t>(dxh) & 7) || rows < 512) return IMMTSF_EUNSUPPORTED;
+    // one row per wave up to 2048 workgroups (a wave's rows are a dependent chain: few rows per wave, many waves), then more rows
+    // per wave; the partial sums are nsl x K x d floats (ln_sums_scratch_floats)
+    int nsl = (rows + 3) / 4;
+    nsl = nsl > kLnSlabsMax ? kLnSlabsMax : nsl;
+    const size_t lds = (size_t)3 * (out_q ? 3 : 2) * d * sizeof(float);
+    if (out_q) {
+        if (lds > 64 * 1024) return IMMTSF_EUNSUPPORTED;
+        hipLaunchKernelGGL((layernorm_bwd_sums_kernel<3>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site, scratch,
+                           row_flag, flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(dxh));
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((colsum_vec_final_kernel<3>), dim3(cdiv(d, 32), 3), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, out_q, 0);
+    } else {
+        if (lds > 64 * 1024 || row_flag || dxh) return IMMTSF_EUNSUPPORTED;
+        hipLaunchKernelGGL((layernorm_bwd_sums_kernel<2>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site, scratch,
+                           nullptr, 1, nullptr);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL((colsum_vec_final_kernel<2>), dim3(cdiv(d, 32), 2), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, nullptr, 0);
+    }
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -51,7 +51,14 @@ int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, co
 // in: dz (grad wrt z).  out: dy written IN PLACE over dz (dy = dz*dropscale), dx.
 int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
                          float* dx, DropCfg drop, uint64_t site, hipStream_t s, float* dbranch = nullptr,
-                         DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0);      // dbranch = dx * dropout_pre mask
+                         DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0);
+// LayerNorm backward fused with the column sums that give d gamma / d beta (/ the sum of dx: K = 3, which also zeroes flagged rows of
+// dx and writes its bf16 image, like launch_colsum3): IMMTSF_EUNSUPPORTED -> launch_layernorm_bwd + launch_colsum2 / 3
+constexpr int kLnSlabsMax = 2048;
+inline size_t ln_sums_scratch_floats(size_t d, int k) { return (size_t)kLnSlabsMax * k * ((d + 3) & ~(size_t)3) + 64 * 8; }      // `scratch` of the call below
+int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd, float* dx,
+                              DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
+                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s);      // dbranch = dx * dropout_pre mask
 // y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale
 int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
                   float scale, hipStream_t s, float* y_nobias = nullptr);      // y_nobias: W x without the bias

@@ -18,6 +18,7 @@
 #include "block_util.hpp"
 #include "ffn32.hpp"
 #include "rowops.hpp"
+#include "skinny_tn.hpp"
 
 namespace {
 
@@ -42,7 +43,7 @@ ELWs carve_el(size_t R, size_t D, size_t F, void* base) {
     return w;
 }
 struct ELScratch {
-    float *d1, *dff, *dh, *dsa, *da, *dqkv, *red;
+    float *d1, *dff, *dh, *dsa, *da, *dqkv, *red, *sk;      // sk: slabs of the skinny weight-gradient kernel (d_model <= 64)
     size_t bytes;
 };
 ELScratch carve_el_scratch(size_t R, size_t D, size_t F, void* base) {
@@ -55,6 +56,7 @@ ELScratch carve_el_scratch(size_t R, size_t D, size_t F, void* base) {
     s.da = k.take<float>(R * D);
     s.dqkv = k.take<float>(R * 3 * D);
     s.red = k.take<float>(colsum_scratch_floats(D, 2));
+    s.sk = D <= 64 ? k.take<float>(skinny_tn_scratch_floats(3 * (int)D, (int)D, (int)R)) : nullptr;
     s.bytes = k.bytes();
     return s;
 }
@@ -224,6 +226,8 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
     const DropCfg da = el_drop(c, c->p_attn), dd = el_drop(c, c->p_drop), none = el_drop(c, 0.f);
     const int pz = c->grads_prezeroed ? 1 : 0;
     auto wgrad = [&](const float* dy, const float* xin, int N, int K, float* dW, float* db) {      // dW (N,K) = dy^T xin ; db = colsum dy
+        // many rows, tiny output (d_model 32: 96 x 32 and 32 x 32 over 65 k rows at 4096 windows): the streaming kernel of skinny_tn.hip
+        if (prec == 1 && sc.sk && skinny_tn_ok(N, K, R, N, K, dy, xin, dW)) return launch_skinny_tn(dy, N, N, xin, K, K, R, dW, db, sc.sk, s);
         GemmArgs g = gemm_args(N, K, R, N, K, K);
         set_problem(g, 0, dy, xin, dW, nullptr, db);
         g.c_prezeroed = pz;

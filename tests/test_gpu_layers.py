@@ -377,6 +377,39 @@ def test_encoder_layer_block_vs_torch_layer(S, D, H, F, precision):
     assert not bad, bad
 
 
+def test_encoder_layer_block_many_rows_bf16():
+    """tPatchGNN's layer at many windows (5003 sequences of 2 patches = 10 006 rows, d_model 32, bf16): the paths that only exist
+    there -- the feed-forward without its intermediate (csrc/ffn32.hip) and the streaming weight gradients of the attention
+    projections (csrc/skinny_tn.hip) -- against torch's layer in float64, all outputs and parameter gradients at the bf16 bars."""
+    dev = _dev()
+    from immtsf import config, ops
+    S, D, H, F, Bs = 2, 32, 1, 2048, 5003
+    torch.manual_seed(8)
+    ref = torch.nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=F, dropout=0.0, batch_first=True).double()
+    lyr = torch.nn.TransformerEncoderLayer(d_model=D, nhead=H, dim_feedforward=F, dropout=0.0, batch_first=True).to(dev)
+    lyr.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    x = torch.randn(Bs, S, D)
+    up = torch.randn(Bs, S, D)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * up.double()).sum().backward()
+    config.precision = "bf16"
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        y = ops.encoder_layer(lyr, xg, True, ops.SITE_LAYER_BASE + 64)
+        (y * up.to(dev)).sum().backward()
+    finally:
+        config.precision = "fp32"
+    errs = {"out": _l2err(y, yr.detach().float()), "dx": _l2err(xg.grad, xr.grad.float())}
+    for (k, p), (_, q) in zip(lyr.named_parameters(), ref.named_parameters()):
+        errs["g." + k] = _l2err(p.grad, q.grad.float())
+    assert errs.pop("out") <= 3e-2
+    # (5e-2: the first feed-forward weight's gradient goes through two ReLU masks of bf16 pre-activations -- the ones within rounding
+    # of zero flip against the float64 reference -- it sits at 4.0e-2 with or without the two many-row kernels)
+    bad = {k: v for k, v in errs.items() if not v <= 5e-2}
+    assert not bad, bad
+
+
 def test_encoder_layer_block_dropout_masks():
     """training mode, p = 0.3 on all four sites: the block must equal a torch composition that uses the exported Philox
     keep-masks (attention weights, dropout1, feed-forward dropout, dropout2), forward and backward, fp32 1e-4 / 3e-4."""

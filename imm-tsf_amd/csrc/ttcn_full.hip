@@ -174,7 +174,7 @@ __device__ __forceinline__ float sm_tile(const FD& d, const bf16x8 (&a)[RT], con
 struct Wts { const float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; };     // packed fp32 weights (ttcn_pack_kernel)
 
 // ---------------------------------------------------------------------------------------------------- forward
-// grid P, 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq]
+// persistent workgroups (grid <= 2048), 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq]
 // MF = ceil(F / 4): the f's a wave owns.  Their layer-3 fragments (bf16 image W3h of the pack kernel), biases and the rows' mask
 // values are loaded FIRST, beside the staging loads: in front of their first use they were three dependent round trips (one per
 // f of the wave) on a kernel whose whole timeline is ~10 us.
@@ -190,9 +190,16 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     bf16_t* h2s = h1s + ROWS * PT;
     float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);
     float* cl = Xf + ROWS * 16;
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    // persistent workgroups (grid <= P): the layer-3 fragments of this wave's f slots, the MLP's weight fragments of its column tile and
+    // the biases are loaded ONCE; a workgroup per patch re-fetched them (L2 round trips in front of every phase) 65 536 times at
+    // 4096 windows
     bf16x8 bw[MF][2];
     float b3v[MF][2], mk[RT][4];
+    const int tnt = wave & 1;
+    const bf16x8 mw1 = load8_bf16(w.W1p + (tnt * 16 + fr) * KP + fq * 8), mw2 = load8_bf16(w.W2p + (tnt * 16 + fr) * KP + fq * 8);
+    const float mb1 = w.b1p[tnt * 16 + fr], mb2 = w.b2p[tnt * 16 + fr];
+    const float tb = tid < d.K ? Tb[tid] : 0.f;
 #pragma unroll
     for (int j = 0; j < MF; ++j)
 #pragma unroll
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
             b3v[j][half] = 0.f;
             if (f < d.F) { bw[j][half] = *reinterpret_cast<const bf16x8*>(W3h + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
         }
+    for (int p = blockIdx.x; p < d.P; p += gridDim.x) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -211,9 +219,9 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
         }
     build_x<RT>(d, x, tt, te, p, Xb, Xf);
     __syncthreads();
-    mlp_layer<RT>(Xb, h1s, w.W1p, w.b1p, wave, fr, fq);
+    mlp_layer_frag<RT>(Xb, h1s, mw1, mb1, wave, fr, fq);
     __syncthreads();
-    mlp_layer<RT>(h1s, h2s, w.W2p, w.b2p, wave, fr, fq);
+    mlp_layer_frag<RT>(h1s, h2s, mw2, mb2, wave, fr, fq);
     __syncthreads();
     bf16x8 a[RT];
 #pragma unroll
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     }
     __syncthreads();
     if (tid < d.K) {
-        float s = Tb[tid];
+        float s = tb;
         for (int f = 0; f < d.F; ++f) s += cl[f * 32 + tid];
         out[(size_t)p * out_ld + tid] = fmaxf(s, 0.f);
     }
@@ -251,6 +259,8 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
         for (int l = 0; l < d.L; ++l) any += mask[(size_t)p * d.L + l];
         out[(size_t)p * out_ld + flag_col] = any > 0.f ? 1.f : 0.f;
     }
+    __syncthreads();        // the next patch rewrites every LDS tile (and cl)
+    }   // patches
 }
 
 // ---------------------------------------------------------------------------------------------------- backward
@@ -624,7 +634,7 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
     const int mf = (F + 3) / 4;
 #define TTCN_FWD(RT, MF)                                                                                                                     \
-    hipLaunchKernelGGL((ttcn_full_fwd_kernel<RT, MF>), dim3(P), dim3(256), fwd_lds(RT, d.NCq), s, d, x, tt, mask, te, w, q.W3h, p->T_bias, ctr, \
+    hipLaunchKernelGGL((ttcn_full_fwd_kernel<RT, MF>), dim3(P < 2048 ? P : 2048), dim3(256), fwd_lds(RT, d.NCq), s, d, x, tt, mask, te, w, q.W3h, p->T_bias, ctr, \
                        out, out_ld, flag_col)
     if (L <= 32) {
         if (mf == 1) TTCN_FWD(2, 1); else if (mf == 2) TTCN_FWD(2, 2); else if (mf == 3) TTCN_FWD(2, 3); else TTCN_FWD(2, 4);

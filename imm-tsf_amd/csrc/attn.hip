@@ -19,23 +19,30 @@ constexpr int TT = 32;   // forecast steps accumulated per pass in registers
 constexpr int RAGGED_SPLIT_N = 256;
 constexpr int RAGGED_CH = 256;
 
+// K | V rows are fp32, or -- bf16 mode -- the bf16 image the in-projection GEMM writes (half the bytes of the step's largest tensor)
+__device__ __forceinline__ float4 kv_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 kv_load4(const bf16_t* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
 // one wave per (packed row, head): S[row, h] = qs_h . k_row
+template <typename KT>
 __global__ __launch_bounds__(256) void ragged_scores_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
-                                                             const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                             const KT* __restrict__ KVp, const float* __restrict__ qs,
                                                              float* __restrict__ S) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, lane = threadIdx.x & 63;
     if (row >= offsets[dm.B]) return;
     const int hd = dm.hd, ld = 2 * dm.H * hd;
-    const float* kr = KVp + (size_t)row * ld + h * hd;
+    const KT* kr = KVp + (size_t)row * ld + h * hd;
     const float* q = qs + h * hd;
     float a = 0.f;
     if ((hd & 3) == 0) {
         for (int c = lane * 4; c < hd; c += 256) {
-            const float4 kv = *reinterpret_cast<const float4*>(kr + c), qv = *reinterpret_cast<const float4*>(q + c);
+            const float4 kv = kv_load4(kr + c), qv = *reinterpret_cast<const float4*>(q + c);
             a = fmaf(qv.x, kv.x, fmaf(qv.y, kv.y, fmaf(qv.z, kv.z, fmaf(qv.w, kv.w, a))));
         }
     } else {
-        for (int c = lane; c < hd; c += 64) a = fmaf(q[c], kr[c], a);
+        for (int c = lane; c < hd; c += 64) a = fmaf(q[c], (float)kr[c], a);
     }
     a = wave_sum(a);
     if (lane == 0) S[(size_t)row * dm.H + h] = a;
@@ -75,10 +82,10 @@ __global__ __launch_bounds__(256) void ragged_ctx_reduce_kernel(RaggedAttnDims d
 
 // !SPLIT: grid (B, H, ceil(hd/256)), 256 threads; LDS: sc[N] | atile[TT*64] | red[16]
 //  SPLIT: grid (B * maxch, H, ceil(hd/256)); P holds the normalised weights already; LDS: sc[RAGGED_CH] | atile | red
-template <bool SPLIT>
+template <bool SPLIT, typename KT>
 __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                const int* __restrict__ rowmap,
-                                                               const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                               const KT* __restrict__ KVp, const float* __restrict__ qs,
                                                                float* __restrict__ P, float* __restrict__ ctx, DropCfg drop,
                                                                uint64_t site, bf16_t* __restrict__ ctx_h, float* __restrict__ part,
                                                                int maxch) {
@@ -117,14 +124,14 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     // global-load round trips otherwise (n/4 of them)
     for (int i = wave; i < n; i += 8) {
         const int i2 = i + 4;
-        const float* kr = KVp + (size_t)(o0 + i) * ld + h * hd;
-        const float* kr2 = KVp + (size_t)(o0 + (i2 < n ? i2 : i)) * ld + h * hd;
+        const KT* kr = KVp + (size_t)(o0 + i) * ld + h * hd;
+        const KT* kr2 = KVp + (size_t)(o0 + (i2 < n ? i2 : i)) * ld + h * hd;
         float a = 0.f, a2 = 0.f;
 #pragma unroll 12
         for (int c = lane; c < hd; c += 64) {
             const float q = qs[h * hd + c];
-            a = fmaf(q, kr[c], a);
-            a2 = fmaf(q, kr2[c], a2);
+            a = fmaf(q, (float)kr[c], a);
+            a2 = fmaf(q, (float)kr2[c], a2);
         }
         a = wave_sum(a);
         a2 = wave_sum(a2);
@@ -149,12 +156,12 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     __syncthreads();
     }
 
-    const float* vbase = KVp + (size_t)o0 * ld + d + h * hd + e;
+    const KT* vbase = KVp + (size_t)o0 * ld + d + h * hd + e;
     if (drop.p <= 0.f) {   // every forecast step sees the same weights
         if (!valid) return;
         float acc = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < n; ++i) acc = fmaf(sc[i], vbase[(size_t)i * ld], acc);
+        for (int i = 0; i < n; ++i) acc = fmaf(sc[i], (float)vbase[(size_t)i * ld], acc);
         for (int t = 0; t < T; ++t) {
             const size_t o = obase + (size_t)t * d + h * hd + e;
             if (dst) dst[o] = acc;
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
                 for (int ii = 0; ii < cnt; ii += 8) {     // eight notes per step: their V loads are in flight together
                     float v[8];                           // (one load -> 32 FMAs -> next load serialises on latency)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = (ii + u < cnt) ? vbase[(size_t)(i0 + ii + u) * ld] : 0.f;
+                    for (int u = 0; u < 8; ++u) v[u] = (ii + u < cnt) ? (float)vbase[(size_t)(i0 + ii + u) * ld] : 0.f;
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -211,9 +218,10 @@ constexpr int MT = 4;   // backward keeps the dropout scales of up to MT*64 fore
 //   g[c]      = sum_t m[t,i] * dctx[b,t,h,c]            (m = dropout scale of the attention weight, 1 if p = 0)
 //   dv[i,c]   = p[i] * g[c]
 //   dp[i]    += sum_c g[c] * v[i,c]                     (fp32 atomic: hd/64 partial sums per note)
+template <typename KT>
 __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                   const int* __restrict__ rowmap,
-                                                                  const float* __restrict__ KVp, const float* __restrict__ P,
+                                                                  const KT* __restrict__ KVp, const float* __restrict__ P,
                                                                   const float* __restrict__ dctx, float* __restrict__ dKVp,
                                                                   float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
                                                                   bf16_t* __restrict__ dKVp_h, int maxch, size_t dp_stride) {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
         float a = 0.f;
         if (valid) {
             const size_t off = (size_t)(o0 + i) * ld + d + h * hd + c;
-            a = g * KVp[off];
+            a = g * (float)KVp[off];
             const float dvv = P[(size_t)(o0 + i) * dm.H + h] * g;
             if (dKVp) dKVp[off] = dvv;
             if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
@@ -289,10 +297,10 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_kernel(RaggedAttnDims 
 // dp partial sums of the four waves meet in LDS: one atomic per note and workgroup.
 // LDS: mt[RAGGED_CH][Tp] (dropout only; note-major so that a note's T scales are a few 16-byte broadcast reads; Tp = T
 // rounded up to 4, 32 when T <= 32, padding zero) | dpw[4][RAGGED_CH]
-template <bool REG>
+template <bool REG, typename KT>
 __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
                                                                        const int* __restrict__ rowmap,
-                                                                       const float* __restrict__ KVp, const float* __restrict__ P,
+                                                                       const KT* __restrict__ KVp, const float* __restrict__ P,
                                                                        const float* __restrict__ dctx, float* __restrict__ dKVp,
                                                                        float* __restrict__ dp_buf, DropCfg drop, uint64_t site,
                                                                        bf16_t* __restrict__ dKVp_h, int maxch) {
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
         float a = 0.f;
         if (valid) {
             const size_t off = voff + (size_t)i * ld;
-            a = g * KVp[off];
+            a = g * (float)KVp[off];
             const float dvv = P[(size_t)(o0 + i) * dm.H + h] * g;
             if (dKVp) dKVp[off] = dvv;
             if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
@@ -381,8 +389,9 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_dv_long_kernel(RaggedAttn
 // Backward, part 2.  grid (B, H, ceil(hd/256)), 256 threads (every workgroup recomputes the window's ds -- n values -- and
 // owns a 256-column slice of dk / dqs_part; one workgroup per window made 64 of them walk all hd columns); LDS: ds[N] | red[16].
 //   ds[i] = p[i] (dp[i] - sum_j p[j] dp[j]);  dk[i,:] = ds[i] * qs_h;  dqs_part[b, h, :] = sum_i ds[i] k[i,:]
+template <typename KT>
 __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
-                                                                  const float* __restrict__ KVp, const float* __restrict__ qs,
+                                                                  const KT* __restrict__ KVp, const float* __restrict__ qs,
                                                                   const float* __restrict__ P, const float* __restrict__ dp_buf,
                                                                   float* __restrict__ dKVp, float* __restrict__ dqs_part,
                                                                   bf16_t* __restrict__ dKVp_h, int maxch, int dp_slabs, size_t dp_stride) {
@@ -419,12 +428,12 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     __syncthreads();
     if (c >= hd) return;
     const float q = qs[h * hd + c];
-    const float* kc = KVp + (size_t)o0 * ld + h * hd + c;
+    const KT* kc = KVp + (size_t)o0 * ld + h * hd + c;
     const size_t dk0 = (size_t)o0 * ld + h * hd + c;
     float a = 0.f;
 #pragma unroll 8
     for (int i = 0; i < n; ++i) {
-        a = fmaf(ds[i], kc[(size_t)i * ld], a);
+        a = fmaf(ds[i], (float)kc[(size_t)i * ld], a);
         const float dkv = ds[i] * q;
         if (dKVp) dKVp[dk0 + (size_t)i * ld] = dkv;
         if (dKVp_h) dKVp_h[dk0 + (size_t)i * ld] = (bf16_t)dkv;
@@ -1209,19 +1218,20 @@ size_t ragged_attn_part_floats(int B, int T, int d, int N) {
     return N > RAGGED_SPLIT_N ? (size_t)B * cdiv(N, RAGGED_CH) * T * d : 0;
 }
 
-int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h, float* part) {
+template <typename KT>
+static int ragged_attn_fwd_impl(RaggedAttnDims dm, const int* offsets, const int* rowmap, const KT* KVp, const float* qs,
+                                float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h, float* part) {
     if (dm.B <= 0) return IMMTSF_OK;
     bf16_t* ch = static_cast<bf16_t*>(ctx_h);
     if (dm.N > RAGGED_SPLIT_N) {      // long windows: chunked (see the comment above the kernels)
         if (!part) return IMMTSF_EWORKSPACE;
         const int maxch = cdiv(dm.N, RAGGED_CH);
         const size_t lds = (size_t)(RAGGED_CH + TT * 64 + 16) * sizeof(float);
-        hipLaunchKernelGGL(ragged_scores_kernel, dim3(cdiv(dm.B * dm.N, 4), dm.H), dim3(256), 0, s, dm, offsets, KVp, qs, P);
+        hipLaunchKernelGGL((ragged_scores_kernel<KT>), dim3(cdiv(dm.B * dm.N, 4), dm.H), dim3(256), 0, s, dm, offsets, KVp, qs, P);
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL(ragged_softmax_kernel, dim3(dm.B, dm.H), dim3(256), 0, s, dm, offsets, P);
         IMMTSF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(ragged_attn_fwd_kernel<true>, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap,
+        hipLaunchKernelGGL((ragged_attn_fwd_kernel<true, KT>), dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap,
                            KVp, qs, P, ctx, drop, site, ch, part, maxch);
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL(ragged_ctx_reduce_kernel, dim3(dm.B, cdiv(dm.T * dm.H * dm.hd, 256)), dim3(256), 0, s, dm, offsets, part, maxch,
@@ -1231,15 +1241,16 @@ int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* row
     }
     const size_t lds = (size_t)(dm.N + TT * 64 + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(ragged_attn_fwd_kernel<false>, dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
+    hipLaunchKernelGGL((ragged_attn_fwd_kernel<false, KT>), dim3(dm.B, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, rowmap, KVp, qs,
                        P, ctx, drop, site, ch, nullptr, 1);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
-int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
-                           const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
-                           uint64_t site, hipStream_t s, void* dKVp_h) {
+template <typename KT>
+static int ragged_attn_bwd_impl(RaggedAttnDims dm, const int* offsets, const int* rowmap, const KT* KVp, const float* qs,
+                                const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
+                                uint64_t site, hipStream_t s, void* dKVp_h) {
     if (dm.B <= 0) return IMMTSF_OK;
     if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
     const int maxch = dm.N > RAGGED_SPLIT_N ? cdiv(dm.N, RAGGED_CH) : 1;
@@ -1256,25 +1267,39 @@ int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* row
     const size_t lds_long = ((drop.p > 0.f ? (size_t)(dm.T <= 32 ? 32 : ((dm.T + 3) & ~3)) * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
     if (maxch > 1 && lds_long <= 128 * 1024) {
         if (lds_long > 64 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<true, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ragged_attn_bwd_dv_long_kernel<false, KT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_long);
         }
         const dim3 grid(dm.B * maxch, dm.H, cdiv(dm.hd, 256));
         if (dm.T <= 32)
-            hipLaunchKernelGGL(ragged_attn_bwd_dv_long_kernel<true>, grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
+            hipLaunchKernelGGL((ragged_attn_bwd_dv_long_kernel<true, KT>), grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
                                dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
         else
-            hipLaunchKernelGGL(ragged_attn_bwd_dv_long_kernel<false>, grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
+            hipLaunchKernelGGL((ragged_attn_bwd_dv_long_kernel<false, KT>), grid, dim3(256), lds_long, s, dm, offsets, rowmap, KVp, P, dctx, dKVp,
                                dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch);
     } else {
-        hipLaunchKernelGGL(ragged_attn_bwd_dv_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
+        hipLaunchKernelGGL((ragged_attn_bwd_dv_kernel<KT>), dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 64)), dim3(256), 0, s, dm, offsets, rowmap, KVp, P,
                            dctx, dKVp, dp_buf, drop, site, static_cast<bf16_t*>(dKVp_h), maxch, dp_stride);
     }
     IMMTSF_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ragged_attn_bwd_ds_kernel, dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P,
+    hipLaunchKernelGGL((ragged_attn_bwd_ds_kernel<KT>), dim3(dm.B * maxch, dm.H, cdiv(dm.hd, 256)), dim3(256), lds, s, dm, offsets, KVp, qs, P,
                        dp_buf, dKVp, dqs_part, static_cast<bf16_t*>(dKVp_h), maxch, dp_slabs, dp_stride);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+
+// KVp_h != null: the K | V rows are read from that bf16 image (same layout) instead of KVp
+int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h, float* part, const void* KVp_h) {
+    if (KVp_h) return ragged_attn_fwd_impl(dm, offsets, rowmap, static_cast<const bf16_t*>(KVp_h), qs, P, ctx, drop, site, s, ctx_h, part);
+    return ragged_attn_fwd_impl(dm, offsets, rowmap, KVp, qs, P, ctx, drop, site, s, ctx_h, part);
+}
+int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
+                           const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
+                           uint64_t site, hipStream_t s, void* dKVp_h, const void* KVp_h) {
+    if (KVp_h)
+        return ragged_attn_bwd_impl(dm, offsets, rowmap, static_cast<const bf16_t*>(KVp_h), qs, P, dctx, dKVp, dqs_part, dp_buf, drop, site, s, dKVp_h);
+    return ragged_attn_bwd_impl(dm, offsets, rowmap, KVp, qs, P, dctx, dKVp, dqs_part, dp_buf, drop, site, s, dKVp_h);
 }
 
 int launch_softmax_rows_fwd(float* sc, float* A, int B, int H, int L, int S, const unsigned char* live, DropCfg drop,

@@ -11,13 +11,13 @@ struct RaggedAttnDims {
 // forward: KVp packed rows [R, 2d] = (k | v); qs = scaled query [d]; P out [R, H]; ctx out [B*T, d]
 int launch_ragged_attn_fwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
                            float* P, float* ctx, DropCfg drop, uint64_t site, hipStream_t s, void* ctx_h = nullptr,      // ctx_h: bf16 ctx (ctx may be null)
-                           float* part = nullptr);    // chunk partial sums, ragged_attn_part_floats(B, T, H * hd, N) floats (0 for short windows)
+                           float* part = nullptr, const void* KVp_h = nullptr);      // KVp_h: read K | V from this bf16 image instead    // chunk partial sums, ragged_attn_part_floats(B, T, H * hd, N) floats (0 for short windows)
 size_t ragged_attn_part_floats(int B, int T, int d, int N);
 // backward: dctx [B*T, d] -> dKVp [R, 2d] (dk | dv), dqs_part [B, d]; dp_buf: scratch of ragged_attn_dp_floats(B, N, H, hd) floats
 size_t ragged_attn_dp_floats(int B, int N, int H, int hd);
 int launch_ragged_attn_bwd(RaggedAttnDims dm, const int* offsets, const int* rowmap, const float* KVp, const float* qs,
                            const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
-                           uint64_t site, hipStream_t s, void* dKVp_h = nullptr);   // dKVp_h: bf16 copy (dKVp may be null)
+                           uint64_t site, hipStream_t s, void* dKVp_h = nullptr, const void* KVp_h = nullptr);   // dKVp_h: bf16 copy (dKVp may be null)
 
 // rows = B*H*L, each of length S.  In place on `sc`: P = softmax(sc) (0 where !live[b]); A = P*dropscale
 // written to `A` (may alias sc when drop.p == 0).

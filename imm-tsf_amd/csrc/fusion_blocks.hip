@@ -25,7 +25,8 @@ struct T2VWs {
     int *lengths, *offsets, *rowmap, *seg;
     Mat Xcat, KV, ctx, z;
     void* Vh;        // bf16 image of the gathered (packed) note embeddings [R, d_m] (hf with an input projection)
-    float *KVp, *q, *qs, *P, *xpre, *xhat, *rstd, *part;
+    Mat KVp;                  // packed k | v in-projection: fp32, or -- bf16 dataflow -- only the bf16 image (its one reader is the ragged attention)
+    float *q, *qs, *P, *xpre, *xhat, *rstd, *part;
     void *w_in, *w_kv, *w_inkv, *w_out, *w_po;     // bf16 weight images when no twin is registered (hf only)
     size_t bytes;
 };
@@ -43,7 +44,7 @@ T2VWs carve_t2v(const immtsf_fusion_cfg* c, void* base) {
     w.Vh = hf ? k.take<unsigned short>(R * (size_t)c->d_m) : nullptr;
     w.Xcat = k.take_mat(R * (d + dt), !hf, hf);
     w.KV = k.take_mat(R * d, !hf, hf);
-    w.KVp = k.take<float>(R * 2 * d);
+    w.KVp = k.take_mat(R * 2 * d, !hf, hf);
     w.q = k.take<float>(d);
     w.qs = k.take<float>(d);
     w.P = k.take<float>(R * c->H);
@@ -200,13 +201,13 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     }
     {   // packed k|v in-projection (rows d..3d of attn.in_proj_weight), once per note
         GemmArgs g = gemm_args(R, 2 * d, d, d, d, 2 * d);
-        set_problem2(g, 0, w.KV, W.inkv, mat(w.KVp), p->attn_in_b + d);
+        set_problem2(g, 0, w.KV, W.inkv, w.KVp, p->attn_in_b + d);
         g.dyn = total;
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     if (!staged) CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, sqrtf(1.0f / (float)hd), s));
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h, w.part));
+    CHECK(launch_ragged_attn_fwd(dm, w.offsets, w.rowmap, w.KVp.f, w.qs, w.P, w.ctx.f, drop, SITE_T2V_ATTN, s, w.ctx.h, w.part, w.KVp.h));
     {   // out_proj, zero the windows without notes, + Q_param residual
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, w.ctx, W.out, mat(w.xpre), p->attn_out_b);
@@ -305,8 +306,8 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         CHECK(wgrad(h));
     }
     RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
-                                 SITE_T2V_ATTN, s, sc.dKVp.h));
+    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp.f, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
+                                 SITE_T2V_ATTN, s, sc.dKVp.h, w.KVp.h));
     // (the query path's backward -- parameter gradients only -- rides with Time2Vec's at the end of this function)
     {   // k|v in-projection
         GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);

@@ -320,6 +320,35 @@ class Workload:
         self.trainer.close()
 
 
+FLAGS_MAX_WINDOWS = 128      # FlagStep wins where the step is a latency chain (64 windows: -3 %); from 256 windows on GraphedStep does
+
+
+def flag_step(w):
+    """immtsf.train.FlagStep for a single-process cfg2-style workload (text side | backbone | head), or None when the workload does
+    not decompose that way or a spin timed out in three trial replays (the caller then uses GraphedStep)."""
+    from immtsf.ops import masked_mse
+    from immtsf.train import FlagStep
+    fusion = w.fusion
+    if w.side is None or not hasattr(fusion, "ttf") or not hasattr(fusion.mmf, "project_kv") or not w.graphable:
+        return None
+    b = w.batch
+    fc_args = (b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
+
+    def text_fn():
+        E, M = fusion.ttf(b["notes_embeddings"], b["tau"], b["tp_to_predict"])
+        return (E, M) + tuple(fusion.mmf.project_kv(E))
+
+    def head_fn(pred, E, M, kv, fold):
+        out = fusion.mmf(pred, E, M, kv=(kv, fold))
+        return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, w.global_cnt)
+
+    st = FlagStep(w.trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
+    for _ in range(3):
+        st()
+    torch.cuda.synchronize()
+    return None if st.timed_out() else st
+
+
 def time_steps(step, steps, warmup, barrier):
     for _ in range(warmup):
         loss = step()
@@ -571,6 +600,10 @@ def main():
     ap.add_argument("--phased", action="store_true",
                     help="immtsf.train.PhasedStep: six single-stream hipGraphs on two HIP streams with events between them, instead "
                          "of the whole step as parallel branches of one hipGraph (DESIGN.md section 6 has both measured)")
+    ap.add_argument("--flags", action="store_true",
+                    help="immtsf.train.FlagStep at any batch size: one hipGraph whose two branches synchronise through device flags "
+                         "(spin kernels) instead of graph edges (single process; the default up to 128 windows per GPU)")
+    ap.add_argument("--no-flags", action="store_true", help="GraphedStep (graph edges between the branches) at every batch size")
     ap.add_argument("--captured-comm", action="store_true",
                     help="N>1 graph mode: capture the bucketed RCCL all-reduces inside graph A (overlapped with the backward). "
                          "Verified here only on a 1-rank group, so the default is one eager all-reduce between the two graphs")
@@ -628,7 +661,7 @@ def main():
 
     from immtsf import _lib, config
     from immtsf.ops import masked_mse
-    from immtsf.train import GraphedStep, PhasedStep
+    from immtsf.train import FlagStep, GraphedStep, PhasedStep
     lib = _lib.load()
     if args.gemm_config:
         lib.immtsf_debug_gemm_config(args.gemm_config, 0)
@@ -671,7 +704,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
                                  "re-run without the flag (eager all-reduce between the two graphs)") from e
-        if step is None and args.phased and not args.no_overlap and hasattr(fusion.mmf, "project_kv"):
+        if step is None and (args.phased or (args.flags and not dist_on)) and not args.no_overlap and hasattr(fusion.mmf, "project_kv"):
             # two streams, six single-chain graphs, events in between (immtsf.train.PhasedStep)
             b = w.batch
             fc_args = (b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
@@ -686,8 +719,16 @@ def main():
 
             if dist_on:
                 comm_mode = "eager, in front of the optimizer graph"
-            step = PhasedStep(trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
-            launch_mode = "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them"
+            if args.flags and not dist_on:
+                step = FlagStep(trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
+                launch_mode = "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags"
+            else:
+                step = PhasedStep(trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
+                launch_mode = "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them"
+        if step is None and not dist_on and not args.no_flags and not args.no_overlap and W <= FLAGS_MAX_WINDOWS:
+            step = flag_step(w)
+            if step is not None:
+                launch_mode = "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags"
         if step is None:
             if dist_on:
                 trainer.overlap = False
@@ -741,7 +782,7 @@ def main():
         sweep = []
         for nw in (64, 256, 1024, 4096):
             ww = Workload("cfg2", dev, nw, args.precision)
-            st = GraphedStep(ww.trainer, ww.loss_fn)
+            st = (flag_step(ww) if nw <= FLAGS_MAX_WINDOWS and not args.no_flags else None) or GraphedStep(ww.trainer, ww.loss_fn)
             k = 30 if nw <= 256 else 10
             el, _, _ = time_steps(st, k, 3, torch.cuda.synchronize)
             ms = el / k * 1e3
@@ -753,7 +794,7 @@ def main():
         extras["sweep"] = sweep
         # the same step with the notes handed over packed (what immtsf.data's device collate produces)
         wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=True)
-        st = GraphedStep(wp.trainer, wp.loss_fn)
+        st = (None if args.no_flags else flag_step(wp)) or GraphedStep(wp.trainer, wp.loss_fn)
         el, _, _ = time_steps(st, 40, 5, torch.cuda.synchronize)
         extras["packed"] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
                             "what": "notes as PackedNotes (resident embedding matrix + int32 row index + per-window counts, the device "

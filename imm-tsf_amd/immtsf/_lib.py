@@ -211,6 +211,9 @@ _PROTOS = {
     "immtsf_dropout_mask": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, c_u8p, c_stream]),
     "immtsf_set_side_stream": (C.c_int, [C.c_int32]),
     "immtsf_side_stream_enabled": (C.c_int, []),
+    "immtsf_flag_set": (C.c_int, [C.c_void_p, c_stream]),
+    "immtsf_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_flags_clear": (C.c_int, [C.c_void_p, C.c_int32, c_stream]),
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
     "immtsf_debug_gemm_config": (C.c_int, [C.c_int32, C.c_int32]),
     "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),

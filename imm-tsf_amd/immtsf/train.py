@@ -725,3 +725,85 @@ class PhasedStep:
             self.eO.record(T)
         cur.wait_stream(T)
         return self.loss
+
+
+class FlagStep(PhasedStep):
+    """PhasedStep's decomposition (text / backbone / head) as ONE hipGraph whose two branches have NO edges between the fork at
+    the start of the step and the join in front of the optimizer: where a branch needs the other's result it spins on a device
+    flag (csrc/sync.hip) instead of waiting on an event.
+
+    Why: on ROCm 7.2 a graph branch (or a stream) that reaches a dependency BEFORE it is satisfied resumes 110 - 175 us after the
+    producer has finished (the text-side backward of the cfg2 step: profiles/r03_step_kernel_sequence.txt), whereas a wait that is
+    already satisfied costs nothing.  A one-lane spin kernel resumes within a microsecond and occupies one wave slot.
+
+        stream T:  zero-grad, text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ............ wait(B2) | join B | clear, clip + Adam
+        stream B:  (forked at the start)   backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
+
+    Single process only (no collectives inside).  `flags[8]` is set if a spin ever timed out (50 ms): check `timed_out()`."""
+
+    def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3):
+        if not trainer.device_step:
+            raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
+        if trainer.collective:
+            raise ValueError("FlagStep is the single-process step: use GraphedStep / PhasedStep with a process group")
+        self.trainer = trainer
+        self.text_fn, self.backbone_fn, self.head_fn = text_fn, backbone_fn, head_fn
+        dev = trainer.flat_param.device
+        lib = _lib.load()
+        self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        self.T.wait_stream(cur)
+        self.B.wait_stream(cur)
+        snap = trainer.snapshot()
+        for _ in range(warmup):
+            self._eager_step()
+        torch.cuda.synchronize()
+        trainer.restore(snap)
+        torch.cuda.synchronize()
+        if not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
+            trainer.zero_in_step = True
+        self.flags = torch.zeros(16, dtype=torch.int32, device=dev)
+        fp = self.flags.data_ptr()
+        F_B1, F_T2, F_B2, F_ERR = fp, fp + 4, fp + 8, fp + 32
+        sp = lambda st: st.cuda_stream        # noqa: E731
+
+        def fset(flag, st):
+            _lib.check(lib.immtsf_flag_set(flag, sp(st)), "flag_set")
+
+        def fwait(flag, st):
+            _lib.check(lib.immtsf_flag_wait(flag, F_ERR, 50, sp(st)), "flag_wait")
+
+        self.graph = torch.cuda.CUDAGraph()
+        B = self.B
+        with torch.cuda.graph(self.graph):
+            T = torch.cuda.current_stream()
+            trainer.zero_grad()
+            B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
+            outs = text_fn()
+            with torch.cuda.stream(B):
+                pred = backbone_fn()
+                fset(F_B1, B)
+            fwait(F_B1, T)
+            py, cuts, loss = self._head(pred, outs)
+            dpy = py.grad
+            dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
+            fset(F_T2, T)
+            with torch.cuda.stream(B):
+                fwait(F_T2, B)
+                torch.autograd.backward([pred], [dpy])
+                trainer.collect_grads()
+                fset(F_B2, B)
+            self._text_backward(outs, dcuts)
+            fwait(F_B2, T)
+            T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
+            _lib.check(lib.immtsf_flags_clear(fp, 3, sp(T)), "flags_clear")
+            trainer.step()
+        self.loss = loss
+        self._keep = (outs, pred, py, cuts, dpy, dcuts)
+
+    def timed_out(self) -> bool:
+        return bool(int(self.flags[8].item()) != 0)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.loss

@@ -578,6 +578,13 @@ int immtsf_timing_enable(int32_t on);
  * inside the call (concurrency with the data-gradient GEMMs; valid under hipGraph capture).  0 (the default) disables it.
  * The stream and its two events belong to the calling host thread (one set per thread and device). */
 int immtsf_set_side_stream(int32_t on);
+
+/* Device-side flags between two streams of one captured step (csrc/sync.hip; immtsf.train.FlagStep): flag_set behind the
+ * producer's last kernel, flag_wait (a one-lane spin with a timeout, *err = 1 when it gave up) in front of the consumer's first,
+ * flags_clear (n <= 64 consecutive flags) once both are done.  No reference counterpart: launch-model plumbing. */
+int immtsf_flag_set(int32_t* flag, immtsf_stream_t stream);
+int immtsf_flag_wait(int32_t* flag, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
+int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream);
 int immtsf_side_stream_enabled(void);
 /* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);

@@ -392,12 +392,14 @@ def test_backbone_gradient_sinks_equal_autograd_accumulation():
     tr.close()
 
 
-def test_phased_step_trains_like_eager():
+@pytest.mark.parametrize("kind", ["phased", "flags"])
+def test_phased_step_trains_like_eager(kind):
     """immtsf.train.PhasedStep (six single-stream graphs on two streams, the query half's parameter gradients deferred
-    behind the text-side backward) must train exactly like the eager step"""
+    behind the text-side backward) and immtsf.train.FlagStep (the same decomposition as ONE graph whose branches synchronise
+    through device flags instead of graph edges, csrc/sync.hip) must train exactly like the eager step; no spin may time out"""
     dev = _dev()
     from immtsf.ops import masked_mse
-    from immtsf.train import PhasedStep
+    from immtsf.train import FlagStep, PhasedStep
     steps = 4
     model, fusion, tr, batch = _setup_sinks(dev, 0.0)
     f = _loss_fn(model, fusion, batch)
@@ -418,9 +420,11 @@ def test_phased_step_trains_like_eager():
     def head_fn(pred, E, M, kv, fold):
         return masked_mse(fusion.mmf(pred, E, M, kv=(kv, fold)), batch["data_to_predict"], batch["mask_predicted_data"])
 
-    st = PhasedStep(tr, text_fn, lambda: model.forecasting(*fc), head_fn)
+    st = (PhasedStep if kind == "phased" else FlagStep)(tr, text_fn, lambda: model.forecasting(*fc), head_fn)
     losses = [float(st().detach()) for _ in range(steps)]
     torch.cuda.synchronize()
+    if kind == "flags":
+        assert not st.timed_out()
     assert losses[-1] < losses[0]
     err = float((tr.flat_param - ref).abs().max() / ref.abs().max())
     assert err < 2e-4, err

@@ -795,8 +795,10 @@ def main():
         # the same step with the notes handed over packed (what immtsf.data's device collate produces)
         wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=True)
         st = (None if args.no_flags else flag_step(wp)) or GraphedStep(wp.trainer, wp.loss_fn)
-        el, _, _ = time_steps(st, 40, 5, torch.cuda.synchronize)
+        blocks = sorted(time_steps(st, 40, 5 if i == 0 else 0, torch.cuda.synchronize)[0] for i in range(5))
+        el = blocks[2]             # median of five blocks of 40 replays (a single block right after the 4096-window leg was seen 25 % off)
         extras["packed"] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
+                            "blocks_ms": [round(b / 40 * 1e3, 4) for b in blocks],
                             "what": "notes as PackedNotes (resident embedding matrix + int32 row index + per-window counts, the device "
                                     "collate's output) instead of the zero-padded (B, N, d_m) tensor: no note_mask scan in the step"}
         wp.close()

@@ -1,0 +1,1070 @@
+// MMF_XAttn_Add (fusions/MMF_XAttn_Add.py:56-103) in its LOW-RANK form (round 3).
+//
+// The block's queries come from Y_ts, which has only C columns (the series variables, C = 8 at the benchmark configuration), and
+// its attention output is consumed only by residual_head, which has only C rows.  Between proj_{q,k,v} and the MHA in-projections
+// and between out_proj and residual_head there is no nonlinearity, so per head h (head dimension E, m = the head's rows)
+//
+//     S_h[t,s]  = scale q_h[t] . k_h[s] = [Y[t] | 1] G_h [E_txt[s] | 1]^T         G_h = scale [W_Qf,h | b_q,h]^T [W_Kf,h | b_k,h]   (C+1) x (d+1)
+//     delta[t]  = sum_h sum_s A_h[t,s] ( U_h [E_txt[s] | 1]^T ) + b_HO               U_h = W_HO,h [W_Vf,h | b_v,h]                    C x (d+1)
+//
+// with W_Qf = W_in,q W_q, W_Kf = W_in,k W_k, W_Vf = W_in,v W_v, W_HO = W_res W_out, b_HO = W_res b_out + b_res.  G_h and U_h depend on
+// parameters only.  The text side therefore needs ONE skinny projection per step, P = [E_txt | 1] W_fold^T with W_fold = the stacked
+// rows of (G_h, U_h): (2C+1) H columns instead of the 2d columns of (k | v), and the whole T x T attention of a window (scores,
+// softmax, dropout, mix, bias, LayerNorm(C), dropout, kappa blend) is a few hundred FMAs per row on those columns: one kernel per
+// direction, fp32 in both precision modes.  What disappears: the (B T) x 2d x d key/value projection with its data and weight
+// gradients (the largest GEMMs of the block: 0.93 TFLOP per step at 4096 windows), the MFMA tile attention over d-wide rows and
+// its 400 MB context tensors, the C-wide head over them.  The gradients of the ORIGINAL parameters follow from dW_fold = dP^T [E|1]
+// by the chain rule through the factors above -- products with at most (C+1) H rows or rank, three small multi-job launches.
+// Same function, same state_dict; results equal to the reference's up to fp32 reassociation (bf16 mode: E_txt and W_fold are rounded
+// once for the P product; everything else is fp32).
+//
+// Split for two-stream scheduling like the full-rank form: the P half (fold + projection; backward: dE_txt and every parameter
+// gradient except LayerNorm's) depends only on the text side; the Q half (attention + head) is the serial section between the
+// backbone's forward and backward.  b_HO travels from the P half to the Q half as a C-vector and its gradient back.
+#include "../../include/immtsf.h"
+#include "gemm.hpp"
+#include "rowops.hpp"
+#include "tail.hpp"
+#include "block_util.hpp"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// small multi-job launches: every product of the fold / chain rule has <= 16 rows or rank <= 16 per group
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int XR = 16;            // rows of an NN / NT job, rank per group of an OUTER job
+constexpr int XJ_MAX = 20;
+enum { XJ_NN = 0, XJ_NT = 1, XJ_OUTER = 2, XJ_COPY = 3 };
+struct XJob {
+    int form, nblk;
+    const float* L; int lsr, lsn;     // NN / NT: L[r * lsr + k * lsn]   OUTER: P[j * lsr + m * lsn]   COPY: L[i * lsn] (null: zeros)
+    int R;                            // NN / NT: rows   OUTER: rank per group
+    const float* W; int ldw, qsn;     // NN: W[k * ldw + n]   NT: W[m * ldw + k]   OUTER: Q[j * ldw + n * qsn]
+    int K, N, M;                      // NN: K, N   NT: K, N (= output columns m)   OUTER: M x N output   COPY: N elements
+    float* out; int osr, osn;         // out[r * osr + n * osn]  (OUTER: out[m * osr + n * osn])
+    unsigned short* out16;            // NN / COPY: optional bf16 copy, same indexing
+    float alpha;
+    const float *lb, *wb;             // NT: alpha * (dot + lb[r] * wb[m])
+    const float* radd;                // NT: + radd[r]
+    const float* xrow;                // NT: out[R * osr + m * osn] = xrow[m]  (one more row, copied)
+    int ng; long pgs, qgs;            // OUTER: sum over ng groups, P += pgs, Q += qgs per group
+};
+struct XJobs { int first[XJ_MAX]; int n; XJob j[XJ_MAX]; };       // first[i]: first workgroup of job i
+
+__device__ __forceinline__ unsigned short f2bf(float v) {
+    return __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+}
+
+constexpr int XJ_LK = 16 * 1024;      // floats of the staged L operand: R * K <= 16 K (else it is read from global memory)
+
+// the <= 16 rows of an NN / NT job's L operand as an LDS image Ls[r * K + k] (one round of coalesced loads; the products then read it
+// as broadcasts / 16-byte rows instead of issuing R dependent global loads per k step)
+__device__ __forceinline__ bool xjob_stage_l(const XJob& J, float* Ls) {
+    if (J.R * J.K > XJ_LK) return false;
+    if (J.lsn == 1) {
+        for (int i = threadIdx.x; i < J.R * J.K; i += 256) {
+            const int r = i / J.K, k = i - r * J.K;
+            Ls[i] = J.L[(size_t)r * J.lsr + k];
+        }
+    } else {       // k-major source (W_q read as its transpose): consecutive threads take consecutive source elements
+        for (int i = threadIdx.x; i < J.R * J.K; i += 256) {
+            const int k = i / J.R, r = i - k * J.R;
+            Ls[r * J.K + k] = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+template <bool STAGED>
+__device__ __forceinline__ void xjob_nn_acc(const XJob& J, int kg, int n, const float* Ls, float4 (&acc)[XR]) {
+    constexpr int U = 12;
+    const int R = J.R;
+    for (int k0 = kg; k0 < J.K; k0 += 64 * U) {
+        float4 w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            w[u] = k0 + 64 * u < J.K ? *reinterpret_cast<const float4*>(J.W + (size_t)(k0 + 64 * u) * J.ldw + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < XR; ++r)
+            if (r < R) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int k = k0 + 64 * u;
+                    float l = 0.f;
+                    if (k < J.K) {
+                        if (STAGED) l = Ls[r * J.K + k];
+                        else l = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
+                    }
+                    acc[r].x = fmaf(l, w[u].x, acc[r].x); acc[r].y = fmaf(l, w[u].y, acc[r].y);
+                    acc[r].z = fmaf(l, w[u].z, acc[r].z); acc[r].w = fmaf(l, w[u].w, acc[r].w);
+                }
+            }
+    }
+}
+
+// NN: out[r][n] = alpha * sum_k L[r][k] W[k][n].  A workgroup owns 16 output columns: thread = (4-column group eq, k-group kg of 64);
+// up to 12 k steps of W are in flight per thread
+__device__ __forceinline__ void xjob_nn(const XJob& J, int blk, float* Ls, float* red /* [4][XR][16] */) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, eq = tid & 3, kg = tid >> 2, n = blk * 16 + eq * 4, R = J.R;
+    const bool staged = xjob_stage_l(J, Ls);
+    float4 acc[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < J.N) {
+        if (staged) xjob_nn_acc<true>(J, kg, n, Ls, acc);
+        else xjob_nn_acc<false>(J, kg, n, Ls, acc);
+    }
+    // the sixteen k-groups of a wave sit 4 lanes apart: lane ^ 4, ^ 8 (row rotates), ^ 16, ^ 32
+#define XR_RED(v) v += IMMTSF_DPP(v, 0x124); v += IMMTSF_DPP(v, 0x128); v = xor32_sum(xor16_sum(v))
+#pragma unroll
+    for (int r = 0; r < XR; ++r)
+        if (r < R) {
+            XR_RED(acc[r].x); XR_RED(acc[r].y); XR_RED(acc[r].z); XR_RED(acc[r].w);
+            if (lane < 4) *reinterpret_cast<float4*>(&red[(wave * XR + r) * 16 + eq * 4]) = acc[r];
+        }
+#undef XR_RED
+    __syncthreads();
+    for (int x = tid; x < R * 16; x += 256) {
+        const int r = x >> 4, col = x & 15, nn = blk * 16 + col;
+        if (nn < J.N) {
+            const float v = J.alpha * ((red[(0 * XR + r) * 16 + col] + red[(1 * XR + r) * 16 + col]) +
+                                       (red[(2 * XR + r) * 16 + col] + red[(3 * XR + r) * 16 + col]));
+            const size_t o = (size_t)r * J.osr + (size_t)nn * J.osn;
+            J.out[o] = v;
+            if (J.out16) J.out16[o] = f2bf(v);
+        }
+    }
+}
+
+// NT: out[r][m] = alpha * (sum_k L[r][k] W[m][k] + lb[r] wb[m]) + radd[r].  A wave owns two output columns m, the lanes stride k
+__device__ __forceinline__ void xjob_nt(const XJob& J, int blk, float* Ls) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, R = J.R;
+    const bool staged = xjob_stage_l(J, Ls);
+    const int m0 = blk * 8 + wave * 2;
+    if (m0 >= J.N) return;
+    const bool two = m0 + 1 < J.N;
+    const float* w0 = J.W + (size_t)m0 * J.ldw;
+    const float* w1 = J.W + (size_t)(two ? m0 + 1 : m0) * J.ldw;
+    float a0[XR], a1[XR];
+#pragma unroll
+    for (int r = 0; r < XR; ++r) a0[r] = a1[r] = 0.f;
+    if (staged && (J.K & 3) == 0 && (J.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(J.W) & 15) == 0) {
+        constexpr int U = 4;                 // 16-byte steps per lane in flight (K <= 1024 per round)
+        for (int k0 = lane * 4; k0 < J.K; k0 += 256 * U) {
+            float4 x0[U], x1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                x0[u] = k < J.K ? *reinterpret_cast<const float4*>(w0 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x1[u] = k < J.K ? *reinterpret_cast<const float4*>(w1 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < XR; ++r)
+                if (r < R) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = k0 + 256 * u;
+                        if (k < J.K) {
+                            const float4 l = *reinterpret_cast<const float4*>(Ls + r * J.K + k);
+                            a0[r] = fmaf(l.x, x0[u].x, fmaf(l.y, x0[u].y, fmaf(l.z, x0[u].z, fmaf(l.w, x0[u].w, a0[r]))));
+                            a1[r] = fmaf(l.x, x1[u].x, fmaf(l.y, x1[u].y, fmaf(l.z, x1[u].z, fmaf(l.w, x1[u].w, a1[r]))));
+                        }
+                    }
+                }
+        }
+    } else {
+        if (staged) {
+#pragma unroll 4
+            for (int k = lane; k < J.K; k += 64) {
+                const float x0 = w0[k], x1 = w1[k];
+#pragma unroll
+                for (int r = 0; r < XR; ++r)
+                    if (r < R) {
+                        const float l = Ls[r * J.K + k];
+                        a0[r] = fmaf(l, x0, a0[r]);
+                        a1[r] = fmaf(l, x1, a1[r]);
+                    }
+            }
+        } else {
+#pragma unroll 4
+            for (int k = lane; k < J.K; k += 64) {
+                const float x0 = w0[k], x1 = w1[k];
+#pragma unroll
+                for (int r = 0; r < XR; ++r)
+                    if (r < R) {
+                        const float l = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
+                        a0[r] = fmaf(l, x0, a0[r]);
+                        a1[r] = fmaf(l, x1, a1[r]);
+                    }
+            }
+        }
+    }
+    float mine0 = 0.f, mine1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < XR; ++r)
+        if (r < R) {
+            const float v0 = wave_sum(a0[r]), v1 = wave_sum(a1[r]);
+            if (lane == r) { mine0 = v0; mine1 = v1; }
+        }
+    if (lane < R) {
+        const float lbv = J.lb ? J.lb[lane] : 0.f, ra = J.radd ? J.radd[lane] : 0.f;
+        float v = mine0;
+        if (J.lb) v = fmaf(lbv, J.wb[m0], v);
+        J.out[(size_t)lane * J.osr + (size_t)m0 * J.osn] = fmaf(v, J.alpha, ra);
+        if (two) {
+            v = mine1;
+            if (J.lb) v = fmaf(lbv, J.wb[m0 + 1], v);
+            J.out[(size_t)lane * J.osr + (size_t)(m0 + 1) * J.osn] = fmaf(v, J.alpha, ra);
+        }
+    }
+    if (J.xrow && lane == 63) {
+        J.out[(size_t)R * J.osr + (size_t)m0 * J.osn] = J.xrow[m0];
+        if (two) J.out[(size_t)R * J.osr + (size_t)(m0 + 1) * J.osn] = J.xrow[m0 + 1];
+    }
+}
+
+// OUTER: out[m][n] = alpha * sum_g sum_{j < R} P_g[j][m] Q_g[j][n].  A workgroup owns 16 rows x 256 columns, a thread 4 x 4 of them;
+// a group's R rows of both operands are requested together
+__device__ __forceinline__ void xjob_outer(const XJob& J, int blk) {
+    const int nbn = (J.N + 255) / 256, bm = blk / nbn, bn = blk - bm * nbn;
+    const int m0 = bm * 16 + (threadIdx.x >> 6) * 4, n0 = bn * 256 + (threadIdx.x & 63) * 4;
+    if (m0 >= J.M || n0 >= J.N) return;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    const bool vq = J.qsn == 1 && n0 + 3 < J.N && (J.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(J.W) & 15) == 0 && (J.qgs & 3) == 0;
+    const bool vp = J.lsn == 1 && m0 + 3 < J.M && (J.lsr & 3) == 0 && (reinterpret_cast<uintptr_t>(J.L) & 15) == 0 && (J.pgs & 3) == 0;
+    for (int g = 0; g < J.ng; ++g) {
+        const float* P = J.L + g * J.pgs;
+        const float* Q = J.W + g * J.qgs;
+        float4 pv[XR], qv[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            pv[j] = qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < J.R) {
+                if (vp) pv[j] = *reinterpret_cast<const float4*>(P + (size_t)j * J.lsr + m0);
+                else {
+                    const float* pp = P + (size_t)j * J.lsr;
+                    pv[j].x = pp[(size_t)m0 * J.lsn];
+                    if (m0 + 1 < J.M) pv[j].y = pp[(size_t)(m0 + 1) * J.lsn];
+                    if (m0 + 2 < J.M) pv[j].z = pp[(size_t)(m0 + 2) * J.lsn];
+                    if (m0 + 3 < J.M) pv[j].w = pp[(size_t)(m0 + 3) * J.lsn];
+                }
+                if (vq) qv[j] = *reinterpret_cast<const float4*>(Q + (size_t)j * J.ldw + n0);
+                else {
+                    const float* qq = Q + (size_t)j * J.ldw;
+                    qv[j].x = qq[(size_t)n0 * J.qsn];
+                    if (n0 + 1 < J.N) qv[j].y = qq[(size_t)(n0 + 1) * J.qsn];
+                    if (n0 + 2 < J.N) qv[j].z = qq[(size_t)(n0 + 2) * J.qsn];
+                    if (n0 + 3 < J.N) qv[j].w = qq[(size_t)(n0 + 3) * J.qsn];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XR; ++j)
+            if (j < J.R) {
+                const float p[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w}, q[4] = {qv[j].x, qv[j].y, qv[j].z, qv[j].w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(p[a], q[b], acc[a][b]);
+            }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        if (m0 + a >= J.M) break;
+        float* o = J.out + (size_t)(m0 + a) * J.osr + (size_t)n0 * J.osn;
+        if (J.osn == 1 && n0 + 3 < J.N && (J.osr & 3) == 0 && (reinterpret_cast<uintptr_t>(J.out) & 15) == 0) {
+            *reinterpret_cast<float4*>(o) = make_float4(J.alpha * acc[a][0], J.alpha * acc[a][1], J.alpha * acc[a][2], J.alpha * acc[a][3]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (n0 + b < J.N) o[(size_t)b * J.osn] = J.alpha * acc[a][b];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void xjobs_kernel(XJobs js) {
+    __shared__ __attribute__((aligned(16))) float Ls[XJ_LK];
+    __shared__ __attribute__((aligned(16))) float red[4 * XR * 16];
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < XJ_MAX; ++i) ji += (i < js.n && (int)blockIdx.x >= js.first[i]) ? 1 : 0;
+    const int blk = blockIdx.x - js.first[ji];
+    const XJob& J = js.j[ji];
+    if (J.form == XJ_NN) xjob_nn(J, blk, Ls, red);
+    else if (J.form == XJ_NT) xjob_nt(J, blk, Ls);
+    else if (J.form == XJ_OUTER) xjob_outer(J, blk);
+    else {
+        for (int i = blk * 1024 + threadIdx.x; i < min(J.N, (blk + 1) * 1024); i += 256) {
+            const float v = J.L ? J.alpha * J.L[(size_t)i * J.lsn] : 0.f;
+            if (J.out) J.out[(size_t)i * J.osn] = v;
+            if (J.out16) J.out16[(size_t)i * J.osn] = f2bf(v);
+        }
+    }
+}
+
+struct XJobList {
+    XJobs js;
+    int blocks = 0;
+    bool overflow = false;
+    XJobList() { js.n = 0; memset(js.first, 0, sizeof(js.first)); }
+    XJob* add(int form, int nblk) {
+        if (js.n >= XJ_MAX) { overflow = true; return &js.j[XJ_MAX - 1]; }
+        js.first[js.n] = blocks;
+        XJob* j = &js.j[js.n++];
+        memset(j, 0, sizeof(XJob));
+        j->form = form; j->nblk = nblk; j->alpha = 1.f; j->lsn = 1; j->osn = 1; j->qsn = 1; j->ng = 1;
+        blocks += nblk;
+        return j;
+    }
+    void nn(const float* L, int lsr, int R, const float* W, int ldw, int K, int N, float* out, int osr, float alpha, unsigned short* out16 = nullptr,
+            int osn = 1) {
+        XJob* j = add(XJ_NN, cdiv(N, 16));
+        j->L = L; j->lsr = lsr; j->R = R; j->W = W; j->ldw = ldw; j->K = K; j->N = N; j->out = out; j->osr = osr; j->osn = osn; j->alpha = alpha;
+        j->out16 = out16;
+    }
+    XJob* nt(const float* L, int lsr, int lsn, int R, const float* W, int ldw, int K, int Mout, float* out, int osr, float alpha) {
+        XJob* j = add(XJ_NT, cdiv(Mout, 8));
+        j->L = L; j->lsr = lsr; j->lsn = lsn; j->R = R; j->W = W; j->ldw = ldw; j->K = K; j->N = Mout; j->out = out; j->osr = osr; j->alpha = alpha;
+        return j;
+    }
+    XJob* outer(const float* P, int lsr, int rank, const float* Q, int ldq, int M, int N, float* out, int osr, float alpha) {
+        XJob* j = add(XJ_OUTER, cdiv(M, 16) * cdiv(N, 256));
+        j->L = P; j->lsr = lsr; j->R = rank; j->W = Q; j->ldw = ldq; j->M = M; j->N = N; j->out = out; j->osr = osr; j->alpha = alpha;
+        return j;
+    }
+    void copy(const float* src, int n, float* out, unsigned short* out16 = nullptr) {
+        XJob* j = add(XJ_COPY, cdiv(n, 1024));
+        j->L = src; j->N = n; j->out = out; j->out16 = out16;
+    }
+    int launch(hipStream_t s) {
+        if (overflow) return IMMTSF_EUNSUPPORTED;
+        if (!blocks) return IMMTSF_OK;
+        hipLaunchKernelGGL(xjobs_kernel, dim3(blocks), dim3(256), 0, s, js);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// shapes
+// ------------------------------------------------------------------------------------------------------------------------------
+struct XRDims { int B, T, C, Cq, H, d, E, Wd, PW; };       // Wd = 2C+1 columns per head, PW = row pitch of P (multiple of 8)
+inline XRDims xr_dims(const immtsf_fusion_cfg* c) {
+    XRDims x;
+    x.B = c->B; x.T = c->T; x.C = c->C; x.Cq = c->C + 1; x.H = c->H; x.d = c->d; x.E = c->d / c->H; x.Wd = 2 * c->C + 1;
+    x.PW = (x.H * x.Wd + 7) & ~7;
+    return x;
+}
+inline int xq_mask_bytes(int T) { return (((T + 3) / 4) + 3) & ~3; }       // dropout keep bits of a (row, head): 4 keys per byte
+// LDS floats of the Q kernels per window: P rows, Y rows, ddelta rows, lse, D, dropout keep bits
+inline size_t xq_lds_floats(const XRDims& x) { return (size_t)x.T * (x.PW + 2 * x.C + 2 * x.H) + (size_t)x.H * x.T * (xq_mask_bytes(x.T) / 4); }
+constexpr size_t XQ_LDS_MAX = 60 * 1024;
+bool xr_supported(const immtsf_fusion_cfg* c) {
+    if (bad_cfg(c) || c->C < 1 || c->C > 15 || c->H > 4 || ((c->d / c->H) & 3) || c->d > 4096) return false;
+    const XRDims x = xr_dims(c);
+    if (x.PW > 128) return false;
+    return xq_lds_floats(x) * sizeof(float) <= XQ_LDS_MAX;
+}
+inline bool xr_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d >= 16 && (c->d % 16) == 0; }
+
+// forward workspace of the P half: the factors of the fold (kept for the backward)
+struct XPWs {
+    float *AqT, *WHO, *GA, *UA, *Wf, *Wfb;
+    unsigned short *Wf16, *E16;
+    size_t bytes;
+};
+XPWs carve_xp(const immtsf_fusion_cfg* c, void* base) {
+    const XRDims x = xr_dims(c);
+    const size_t d = x.d;
+    const bool hf = xr_hf(c);
+    Carver k(base);
+    XPWs w;
+    w.AqT = k.take<float>(x.Cq * d);
+    w.WHO = k.take<float>(x.C * d);
+    w.GA = k.take<float>((size_t)x.H * x.Cq * d);
+    w.UA = k.take<float>((size_t)x.H * x.C * d);
+    w.Wf = k.take<float>((size_t)x.PW * d);
+    w.Wfb = k.take<float>(x.PW);
+    w.Wf16 = hf ? k.take<unsigned short>((size_t)x.PW * d) : nullptr;
+    w.E16 = hf ? k.take<unsigned short>((size_t)x.B * x.T * d) : nullptr;
+    w.bytes = k.bytes();
+    return w;
+}
+struct XPScratch {
+    float *dWf, *dWfb, *T1, *RW, *dAqT, *dWHO;
+    unsigned short* dP16;
+    void* sk;
+    size_t skb, bytes;
+};
+XPScratch carve_xp_scratch(const immtsf_fusion_cfg* c, void* base) {
+    const XRDims x = xr_dims(c);
+    const size_t d = x.d, BT = (size_t)x.B * x.T;
+    const bool hf = xr_hf(c);
+    Carver k(base);
+    XPScratch s;
+    s.dWf = k.take<float>((size_t)x.PW * d);
+    s.dWfb = k.take<float>(x.PW);
+    s.T1 = k.take<float>((size_t)x.H * x.Cq * d);
+    s.RW = k.take<float>((size_t)x.H * x.C * d);
+    s.dAqT = k.take<float>(x.Cq * d);
+    s.dWHO = k.take<float>(x.C * d);
+    s.dP16 = hf ? k.take<unsigned short>(BT * x.PW) : nullptr;
+    s.skb = hf ? immtsf_gemm3_tn_ws_bytes(x.PW, (int)d, (int)BT) : 0;
+    s.sk = s.skb ? k.take<unsigned char>(s.skb) : nullptr;
+    s.bytes = k.bytes();
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Q half: a group of `parts` adjacent lanes per (window, row) -- query row in the first phase, key row in the second (backward);
+// the lanes of a group split the other index and meet by DPP sums
+// ------------------------------------------------------------------------------------------------------------------------------
+struct XQDims { int B, T, C, H, PW, Wd, wpb, TB, parts, psh; float kappa; };
+struct XQWs {
+    float *lse, *xhat, *rstd, *slabs;
+    unsigned int* ticket;
+    size_t bytes;
+};
+inline int xq_wpb(const XRDims& x) {
+    int wpb = 256 / x.T;
+    if (wpb < 1) wpb = 1;
+    const size_t per = xq_lds_floats(x) * sizeof(float);
+    while (wpb > 1 && per * wpb > XQ_LDS_MAX) --wpb;
+    // enough workgroups for the chip before windows share one
+    while (wpb > 1 && cdiv(x.B, wpb) < 256) --wpb;
+    return wpb;
+}
+XQWs carve_xq(const immtsf_fusion_cfg* c, void* base) {
+    const XRDims x = xr_dims(c);
+    const size_t BT = (size_t)x.B * x.T;
+    Carver k(base);
+    XQWs w;
+    w.lse = k.take<float>(BT * x.H);
+    w.xhat = k.take<float>(BT * x.C);
+    w.rstd = k.take<float>(BT);
+    w.slabs = k.take<float>((size_t)cdiv(x.B, xq_wpb(x)) * 3 * x.C);
+    w.ticket = k.take<unsigned int>(4);
+    w.bytes = k.bytes();
+    return w;
+}
+
+struct DropL { uint64_t seed; float p, inv_keep; };
+__device__ __forceinline__ DropL drop_local(const DropCfg& d) {        // the device-side seed counter read ONCE (a dependent load per call otherwise)
+    DropL l;
+    l.seed = d.seed + (d.seed_dev ? *d.seed_dev : 0ull);
+    l.p = d.p; l.inv_keep = d.inv_keep;
+    return l;
+}
+// elements idx .. idx + 3 of a site (only the first n matter): one Philox call when idx is a multiple of 4
+__device__ __forceinline__ void drop4(const DropL& d, uint64_t site, uint64_t idx, int n, float (&s)[4]) {
+    if (d.p <= 0.f) { s[0] = s[1] = s[2] = s[3] = 1.f; return; }
+    if ((idx & 3) == 0) {
+        const Philox4 r = philox4x32_10(d.seed, site, idx >> 2);
+        const uint32_t bits[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = (float)(bits[e] >> 8) * (1.0f / 16777216.0f) >= d.p ? d.inv_keep : 0.f;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] = e < n ? dropout_scale(d.seed, site, idx + e, d.p, d.inv_keep) : 0.f;
+    }
+}
+__device__ __forceinline__ float group_max(float v, int CT) {       // CT <= 16
+    if (CT >= 2) v = fmaxf(v, IMMTSF_DPP(v, 0xB1));
+    if (CT >= 4) v = fmaxf(v, IMMTSF_DPP(v, 0x4E));
+    if (CT >= 8) v = fmaxf(v, IMMTSF_DPP(v, 0x141));
+    if (CT >= 16) v = fmaxf(v, IMMTSF_DPP(v, 0x140));
+    return v;
+}
+template <int CM>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, int C, float (&v)[CM]) {
+    if ((C & 3) == 0) {
+#pragma unroll
+        for (int c = 0; c < CM; c += 4)
+            if (c < C) {
+                const float4 t = *reinterpret_cast<const float4*>(p + c);
+                v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+            } else {
+                v[c] = v[c + 1] = v[c + 2] = v[c + 3] = 0.f;
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CM; ++c) v[c] = c < C ? p[c] : 0.f;
+    }
+}
+// dropout scales of the C output columns of a row (site SITE_XADD_OUT, index row * C + c)
+template <int CM>
+__device__ __forceinline__ void drop_row(const DropL& d, uint64_t o0, int C, float (&v)[CM]) {
+#pragma unroll
+    for (int c = 0; c < CM; c += 4)
+        if (c < C) {
+            float s[4];
+            drop4(d, SITE_XADD_OUT, o0 + c, C - c, s);
+            v[c] = s[0]; v[c + 1] = s[1]; v[c + 2] = s[2]; v[c + 3] = s[3];
+        } else {
+            v[c] = v[c + 1] = v[c + 2] = v[c + 3] = 0.f;
+        }
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void xrank_q_fwd_kernel(XQDims q, const float* __restrict__ Y, const float* __restrict__ P,
+                                                           const float* __restrict__ bHO, const unsigned char* __restrict__ mtxt,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ Yout, float* __restrict__ lse,
+                                                           float* __restrict__ xhat, float* __restrict__ rstd, unsigned int* ticket, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int T = q.T, C = q.C, H = q.H, PW = q.PW, parts = q.parts, psh = q.psh, nch = (T + 3) >> 2;
+    const int b0 = blockIdx.x * q.wpb, nw = min(q.wpb, q.B - b0), rows = nw * T;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0u;       // the backward's last-workgroup ticket starts at zero
+    {   // the windows' P rows are contiguous
+        const float4* src = reinterpret_cast<const float4*>(P + (size_t)b0 * T * PW);
+        for (int i = threadIdx.x; i < rows * PW / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = src[i];
+    }
+    const DropL dl = drop_local(drop);
+    float gm[CM], bt[CM], bh[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { gm[c] = c < C ? gamma[c] : 0.f; bt[c] = c < C ? beta[c] : 0.f; bh[c] = c < C ? bHO[c] : 0.f; }
+    __syncthreads();
+    const float inv = 1.f / (1.f + q.kappa);
+    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+        const int row = idx >> psh, part = idx & (parts - 1);
+        const int lw = row / T, t = row - lw * T, b = b0 + lw;
+        const size_t grow = (size_t)b * T + t;
+        float y[CM], delta[CM];
+        load_row<CM>(Y + grow * C, C, y);
+        const bool live = mtxt[b] != 0;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) delta[c] = bh[c];
+        if (live) {
+            for (int h = 0; h < H; ++h) {
+                const float* Ph = lds + (size_t)lw * T * PW + h * q.Wd;
+                float mx = -INFINITY;
+                for (int j = part; j < nch; j += parts) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) sc = fmaf(y[c], kw[c], sc);
+                            mx = fmaxf(mx, sc);
+                        }
+                    }
+                }
+                mx = group_max(mx, parts);
+                float sum = 0.f, acc[CM];
+#pragma unroll
+                for (int c = 0; c < CM; ++c) acc[c] = 0.f;
+                const uint64_t base = (((uint64_t)b * H + h) * T + t) * T;
+                for (int j = part; j < nch; j += parts) {
+                    float dr[4];
+                    drop4(dl, SITE_XADD_ATTN, base + 4 * j, T - 4 * j, dr);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) sc = fmaf(y[c], kw[c], sc);
+                            const float e = __expf(sc - mx);
+                            sum += e;
+                            const float ed = e * dr[u];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) acc[c] = fmaf(ed, kw[C + 1 + c], acc[c]);
+                        }
+                    }
+                }
+                sum = group_sum(sum, parts);
+                const float is = 1.f / sum;
+                if (part == 0) lse[grow * H + h] = mx + __logf(sum);
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) delta[c] = fmaf(group_sum(acc[c], parts), is, delta[c]);
+            }
+        }
+        if (part != 0) continue;
+        float mu = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) mu += delta[c];
+        mu /= (float)C;
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) { const float tt = delta[c] - mu; var = fmaf(tt, tt, var); }
+        const float rs = 1.0f / sqrtf(var / (float)C + 1e-5f);
+        rstd[grow] = rs;
+        float ds[CM];
+        if (live) drop_row<CM>(dl, (uint64_t)grow * C, C, ds);
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) {
+                const float hh = (delta[c] - mu) * rs;
+                const size_t o = grow * C + c;
+                xhat[o] = hh;
+                const float v = live ? fmaf(hh, gm[c], bt[c]) * ds[c] : 0.f;
+                Yout[o] = (y[c] + q.kappa * v) * inv;
+            }
+    }
+}
+
+template <int CM>
+__global__ __launch_bounds__(256) void xrank_q_bwd_kernel(XQDims q, const float* __restrict__ Y, const float* __restrict__ P,
+                                                           const unsigned char* __restrict__ mtxt, const float* __restrict__ gamma,
+                                                           const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                           const float* __restrict__ lse, const float* __restrict__ dYout,
+                                                           float* __restrict__ dY, float* __restrict__ dP,
+                                                           unsigned short* __restrict__ dP16, float* __restrict__ slabs, unsigned int* ticket,
+                                                           float* __restrict__ g_lnw, float* __restrict__ g_lnb, float* __restrict__ g_bho,
+                                                           DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[4][64];
+    __shared__ int s_last;
+    const int T = q.T, C = q.C, H = q.H, PW = q.PW, TB = q.TB, parts = q.parts, psh = q.psh, nch = (T + 3) >> 2;
+    const int b0 = blockIdx.x * q.wpb, nw = min(q.wpb, q.B - b0), rows = nw * T;
+    float* Ps = lds;                                   // [rows][PW]
+    float* Ys = Ps + (size_t)q.wpb * T * PW;           // [rows][C]
+    float* Ds = Ys + (size_t)q.wpb * T * C;            // ddelta [rows][C]
+    float* Ls = Ds + (size_t)q.wpb * T * C;            // lse [rows][H]
+    float* Dd = Ls + (size_t)q.wpb * T * H;            // D [rows][H]
+    unsigned char* Mk = reinterpret_cast<unsigned char*>(Dd + (size_t)q.wpb * T * H);      // keep bits [rows][H][TB]: 4 keys per byte
+    {
+        const float4* src = reinterpret_cast<const float4*>(P + (size_t)b0 * T * PW);
+        for (int i = threadIdx.x; i < rows * PW / 4; i += 256) reinterpret_cast<float4*>(Ps)[i] = src[i];
+    }
+    const DropL dl = drop_local(drop);
+    float gm[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) gm[c] = c < C ? gamma[c] : 0.f;
+    __syncthreads();
+    const float inv = 1.f / (1.f + q.kappa);
+    float s_w[CM], s_b[CM], s_d[CM];       // partial sums: d ln_w, d ln_b, d b_HO
+#pragma unroll
+    for (int c = 0; c < CM; ++c) s_w[c] = s_b[c] = s_d[c] = 0.f;
+    // ---- phase 1: group = query row, its lanes split the keys in chunks of four
+    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+        const int row = idx >> psh, part = idx & (parts - 1);
+        const int lw = row / T, t = row - lw * T, b = b0 + lw;
+        const size_t grow = (size_t)b * T + t;
+        const bool live = mtxt[b] != 0;
+        float y[CM], gy[CM], dd[CM], dy[CM];
+        load_row<CM>(Y + grow * C, C, y);
+        load_row<CM>(dYout + grow * C, C, gy);
+        {
+            float xh[CM], dsc[CM], g[CM], m1 = 0.f, m2 = 0.f;
+            float rs = 0.f;
+            if (live) {
+                load_row<CM>(xhat + grow * C, C, xh);
+                rs = rstd[grow];
+                drop_row<CM>(dl, (uint64_t)grow * C, C, dsc);
+            }
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                dy[c] = part == 0 ? gy[c] * inv : 0.f;
+                g[c] = 0.f;
+                if (c < C && live) {
+                    const float dn = q.kappa * inv * gy[c] * dsc[c];
+                    if (part == 0) { s_w[c] = fmaf(dn, xh[c], s_w[c]); s_b[c] += dn; }
+                    g[c] = dn * gm[c];
+                    m1 += g[c];
+                    m2 = fmaf(g[c], xh[c], m2);
+                } else if (!live) {
+                    xh[c] = 0.f;
+                }
+            }
+            m1 /= (float)C; m2 /= (float)C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                dd[c] = (c < C && live) ? rs * (g[c] - m1 - xh[c] * m2) : 0.f;
+                if (part == 0) {
+                    s_d[c] += dd[c];
+                    if (c < C) { Ys[row * C + c] = y[c]; Ds[row * C + c] = dd[c]; }
+                }
+            }
+        }
+        if (live) {
+            for (int h = 0; h < H; ++h) {
+                const float* Ph = Ps + (size_t)lw * T * PW + h * q.Wd;
+                const float l = lse[grow * H + h];
+                const uint64_t base = (((uint64_t)b * H + h) * T + t) * T;
+                unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
+                // D = sum_s A_drop[t,s] dA[t,s] from the SAME a and dA values the gradient below uses: where the text rows of a window
+                // are nearly equal, dA - D is a difference of nearly equal numbers, and a D formed any other way (e.g. from the
+                // forward's output) leaves its own rounding in every dS
+                float D = 0.f;
+                for (int j = part; j < nch; j += parts) {
+                    float dr[4];
+                    drop4(dl, SITE_XADD_ATTN, base + 4 * j, T - 4 * j, dr);
+                    unsigned int bits = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C], dA = 0.f;
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
+                            D = fmaf(__expf(sc - l) * dr[u], dA, D);
+                            if (dr[u] != 0.f) bits |= 1u << u;
+                        }
+                    }
+                    mk[j] = (unsigned char)bits;
+                }
+                D = group_sum(D, parts);
+                if (part == 0) { Ls[row * H + h] = l; Dd[row * H + h] = D; }
+                for (int j = part; j < nch; j += parts) {
+                    const unsigned int bits = mk[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C], dA = 0.f;
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
+                            const float dr = (bits >> u) & 1u ? dl.inv_keep : 0.f;
+                            const float ds = __expf(sc - l) * (dA * dr - D);
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) dy[c] = fmaf(ds, kw[c], dy[c]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) {
+                const float v = group_sum(dy[c], parts);
+                if (part == 0) dY[grow * C + c] = v;
+            }
+    }
+    __syncthreads();
+    // ---- phase 2: group = key row, its lanes split the query rows
+    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+        const int row = idx >> psh, part = idx & (parts - 1);
+        const int lw = row / T, s = row - lw * T, b = b0 + lw;
+        const size_t grow = (size_t)b * T + s;
+        const bool live = mtxt[b] != 0;
+        float* out = dP + grow * PW;
+        unsigned short* out16 = dP16 ? dP16 + grow * PW : nullptr;
+        for (int h = 0; h < H; ++h) {
+            float kw[CM], vw[CM], dkw[CM], dvw[CM], dkb = 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) { kw[c] = 0.f; vw[c] = 0.f; dkw[c] = 0.f; dvw[c] = 0.f; }
+            if (live) {
+                const float* Ph = Ps + ((size_t)lw * T + s) * PW + h * q.Wd;
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) { kw[c] = Ph[c]; vw[c] = Ph[C + 1 + c]; }
+                const float kb = Ph[C];
+                for (int t = part; t < T; t += parts) {
+                    const int r2 = lw * T + t;
+                    const float* yt = Ys + r2 * C;
+                    const float* dt = Ds + r2 * C;
+                    float sc = kb, dA = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < C) { sc = fmaf(yt[c], kw[c], sc); dA = fmaf(dt[c], vw[c], dA); }
+                    const float a = __expf(sc - Ls[r2 * H + h]);
+                    const float dr = (Mk[((size_t)r2 * H + h) * TB + (s >> 2)] >> (s & 3)) & 1u ? dl.inv_keep : 0.f;
+                    const float ds = a * (dA * dr - Dd[r2 * H + h]);
+                    const float ad = a * dr;
+                    dkb += ds;
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < C) { dkw[c] = fmaf(ds, yt[c], dkw[c]); dvw[c] = fmaf(ad, dt[c], dvw[c]); }
+                }
+            }
+            dkb = group_sum(dkb, parts);
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < C) { dkw[c] = group_sum(dkw[c], parts); dvw[c] = group_sum(dvw[c], parts); }
+            if (part == 0) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) {
+                        out[h * q.Wd + c] = dkw[c];
+                        out[h * q.Wd + C + 1 + c] = dvw[c];
+                        if (out16) { out16[h * q.Wd + c] = f2bf(dkw[c]); out16[h * q.Wd + C + 1 + c] = f2bf(dvw[c]); }
+                    }
+                out[h * q.Wd + C] = dkb;
+                if (out16) out16[h * q.Wd + C] = f2bf(dkb);
+            }
+        }
+        if (part == 0)
+            for (int c = H * q.Wd; c < PW; ++c) {
+                out[c] = 0.f;
+                if (out16) out16[c] = 0;
+            }
+    }
+    // ---- the three C-vectors: workgroup sums -> slab; the last workgroup to finish adds the slabs in index order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            const float a = wave_sum(s_w[c]), bb = wave_sum(s_b[c]), d2 = wave_sum(s_d[c]);
+            if (c < C) {
+                if (lane == c) mine = a;
+                if (lane == C + c) mine = bb;
+                if (lane == 2 * C + c) mine = d2;
+            }
+        }
+        red[wave][lane] = mine;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * C)
+        slabs[(size_t)blockIdx.x * 3 * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    {   // value = lane (< 3C), the four waves take every fourth slab
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int G = gridDim.x;
+        if (lane < 3 * C) {
+            int g = wave;
+            for (; g + 12 < G; g += 16) {
+                a0 += __builtin_nontemporal_load(slabs + (size_t)g * 3 * C + lane);
+                a1 += __builtin_nontemporal_load(slabs + (size_t)(g + 4) * 3 * C + lane);
+                a2 += __builtin_nontemporal_load(slabs + (size_t)(g + 8) * 3 * C + lane);
+                a3 += __builtin_nontemporal_load(slabs + (size_t)(g + 12) * 3 * C + lane);
+            }
+            for (; g < G; g += 4) a0 += __builtin_nontemporal_load(slabs + (size_t)g * 3 * C + lane);
+        }
+        red[wave][lane] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 3 * C) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+        (k == 0 ? g_lnw : k == 1 ? g_lnb : g_bho)[c] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+}
+
+inline XQDims xq_dims(const immtsf_fusion_cfg* c) {
+    const XRDims x = xr_dims(c);
+    XQDims q;
+    q.B = x.B; q.T = x.T; q.C = x.C; q.H = x.H; q.PW = x.PW; q.Wd = x.Wd; q.wpb = xq_wpb(x); q.TB = xq_mask_bytes(x.T); q.kappa = c->kappa;
+    // lanes per row: as many as 256 threads give the workgroup's rows, at most 8 (and one chunk of four keys each)
+    int parts = 1, psh = 0;
+    const int nch = (x.T + 3) / 4;
+    while (parts < 8 && q.wpb * x.T * parts * 2 <= 256 && parts * 2 <= nch) { parts *= 2; ++psh; }
+    q.parts = parts; q.psh = psh;
+    return q;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* row pitch (floats) of P / dP, 0 when the shape is outside the low-rank path's limits (C <= 15, H <= 4, (2C+1) H <= 128, d % 4 == 0,
+ * one window's rows within 60 KB of LDS) */
+int32_t immtsf_mmf_xrank_pw(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? xr_dims(cfg).PW : 0; }
+size_t immtsf_mmf_xrank_p_workspace_bytes(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? carve_xp(cfg, nullptr).bytes : 0; }
+size_t immtsf_mmf_xrank_p_scratch_bytes(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? carve_xp_scratch(cfg, nullptr).bytes : 0; }
+size_t immtsf_mmf_xrank_q_workspace_bytes(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? carve_xq(cfg, nullptr).bytes : 0; }
+
+int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* P, float* bHO,
+                               void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !E_txt || !P || !bHO || !workspace) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E, BT = x.B * x.T, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
+    const float scale = sqrtf(1.0f / (float)E);
+    const float *Wiq = p->attn_in_w, *Wik = p->attn_in_w + (size_t)d * d, *Wiv = p->attn_in_w + (size_t)2 * d * d;
+    const float *biq = p->attn_in_b, *bik = p->attn_in_b + d, *biv = p->attn_in_b + 2 * d;
+    {   // AqT = [W_in,q W_q | b_q]^T ((C+1) x d);  W_HO = W_res W_out (C x d);  b_HO = W_res b_out + b_res
+        XJobList L;
+        L.nt(p->proj_q_w, 1, C, C, Wiq, d, d, d, w.AqT, d, 1.f)->xrow = biq;
+        L.nn(p->res_w, d, C, p->attn_out_w, d, d, d, w.WHO, d, 1.f);
+        L.nt(p->res_w, d, 1, C, p->attn_out_b, d, d, 1, bHO, 1, 1.f)->radd = p->res_b;
+        CHECK(L.launch(s));
+    }
+    {   // per head: GA_h = AqT[:, head] W_in,k[head, :],  UA_h = W_HO[:, head] W_in,v[head, :]  and the bias columns of W_fold
+        XJobList L;
+        for (int h = 0; h < H; ++h) {
+            const size_t o = (size_t)h * E;
+            L.nn(w.AqT + o, d, Cq, Wik + o * d, d, E, d, w.GA + (size_t)h * Cq * d, d, 1.f);
+            L.nt(w.AqT + o, d, 1, Cq, bik + o, E, E, 1, w.Wfb + h * x.Wd, 1, scale);
+            L.nn(w.WHO + o, d, C, Wiv + o * d, d, E, d, w.UA + (size_t)h * C * d, d, 1.f);
+            L.nt(w.WHO + o, d, 1, C, biv + o, E, E, 1, w.Wfb + h * x.Wd + Cq, 1, 1.f);
+        }
+        if (x.PW > H * x.Wd) L.copy(nullptr, x.PW - H * x.Wd, w.Wfb + H * x.Wd);
+        CHECK(L.launch(s));
+    }
+    {   // W_fold rows: G_h = scale GA_h W_k,  U_h = UA_h W_v  (+ the bf16 image, zero rows up to PW)
+        XJobList L;
+        for (int h = 0; h < H; ++h) {
+            const size_t r0 = (size_t)h * x.Wd;
+            L.nn(w.GA + (size_t)h * Cq * d, d, Cq, p->proj_k_w, d, d, d, w.Wf + r0 * d, d, scale, hf ? w.Wf16 + r0 * d : nullptr);
+            L.nn(w.UA + (size_t)h * C * d, d, C, p->proj_v_w, d, d, d, w.Wf + (r0 + Cq) * d, d, 1.f, hf ? w.Wf16 + (r0 + Cq) * d : nullptr);
+        }
+        if (x.PW > H * x.Wd) L.copy(nullptr, (x.PW - H * x.Wd) * d, w.Wf + (size_t)H * x.Wd * d, hf ? w.Wf16 + (size_t)H * x.Wd * d : nullptr);
+        CHECK(L.launch(s));
+    }
+    Mat Em = cmat(E_txt);
+    if (hf && cfg->in_h) {
+        Em.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
+        CHECK(launch_f32_to_bf16(E_txt, w.E16, (size_t)BT * d, s));
+        Em.h = w.E16;
+    }
+    {   // P = E W_fold^T + b_fold
+        GemmArgs g = gemm_args(BT, x.PW, d, d, d, x.PW);
+        set_problem2(g, 0, Em, mat(w.Wf, w.Wf16), mat(P), w.Wfb);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    return IMMTSF_OK;
+}
+
+/* dP (B*T, PW), dbHO (C) -> dE_txt (B*T, d) and the gradients of every parameter except LayerNorm's (all overwritten) */
+int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
+                                const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
+                                size_t scratch_bytes, const immtsf_xadd_params* gr, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !gr || !E_txt || !dP || !dbHO || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    XPScratch sc = carve_xp_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E, BT = x.B * x.T, prec = cfg->precision, Wd = x.Wd;
+    const bool hf = xr_hf(cfg);
+    const float scale = sqrtf(1.0f / (float)E);
+    const float *Wiq = p->attn_in_w, *Wik = p->attn_in_w + (size_t)d * d, *Wiv = p->attn_in_w + (size_t)2 * d * d;
+    const float *bik = p->attn_in_b + d, *biv = p->attn_in_b + 2 * d;
+    Mat dPm = cmat(dP), Em = cmat(E_txt, hf ? (cfg->aux_h ? cfg->aux_h : static_cast<const void*>(w.E16)) : nullptr);
+    if (hf && !cfg->aux_h) CHECK(launch_f32_to_bf16(E_txt, w.E16, (size_t)BT * d, s));      // (the forward may have been given its own image)
+    if (hf && cfg->in_h) {
+        dPm.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
+        CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
+        dPm.h = sc.dP16;
+    }
+    {   // dE = dP W_fold
+        GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
+        set_problem2(g, 0, dPm, mat(w.Wf, w.Wf16), mat(dE_txt, hf ? cfg->out_h : nullptr), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // dW_fold = dP^T E,  d b_fold = column sums of dP
+        GemmArgs g = gemm_args(x.PW, d, BT, x.PW, d, d);
+        set_problem2(g, 0, dPm, Em, mat(sc.dWf), nullptr, sc.dWfb);
+        g.c_prezeroed = 0;
+        g.ws = sc.sk; g.ws_bytes = sc.skb;
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
+    }
+    float *g_iq = gr->attn_in_w, *g_ik = gr->attn_in_w + (size_t)d * d, *g_iv = gr->attn_in_w + (size_t)2 * d * d;
+    float *gb_iq = gr->attn_in_b, *gb_ik = gr->attn_in_b + d, *gb_iv = gr->attn_in_b + 2 * d;
+    {   // T1_h = dG_h W_k^T, RW_h = dU_h W_v^T;  dW_k = scale sum_h GA_h^T dG_h, dW_v = sum_h UA_h^T dU_h;  d b_k, d b_v
+        XJobList L;
+        for (int h = 0; h < H; ++h) {
+            const size_t r0 = (size_t)h * Wd;
+            L.nt(sc.dWf + r0 * d, d, 1, Cq, p->proj_k_w, d, d, d, sc.T1 + (size_t)h * Cq * d, d, 1.f);
+            L.nt(sc.dWf + (r0 + Cq) * d, d, 1, C, p->proj_v_w, d, d, d, sc.RW + (size_t)h * C * d, d, 1.f);
+            const size_t o = (size_t)h * E;
+            // d b_k[m] = scale sum_j AqT[j][m] d b_fold[(h, j)]: an M x 1 outer product
+            L.outer(w.AqT + o, d, Cq, sc.dWfb + r0, 1, E, 1, gb_ik + o, 1, scale);
+            L.outer(w.WHO + o, d, C, sc.dWfb + r0 + Cq, 1, E, 1, gb_iv + o, 1, 1.f);
+        }
+        XJob* a = L.outer(w.GA, d, Cq, sc.dWf, d, d, d, gr->proj_k_w, d, scale);
+        a->ng = H; a->pgs = (long)Cq * d; a->qgs = (long)Wd * d;
+        XJob* b = L.outer(w.UA, d, C, sc.dWf + (size_t)Cq * d, d, d, d, gr->proj_v_w, d, 1.f);
+        b->ng = H; b->pgs = (long)C * d; b->qgs = (long)Wd * d;
+        CHECK(L.launch(s));
+    }
+    {   // dAqT_h = scale (T1_h W_in,k[head]^T + d b_fold b_k^T), dW_HO,h = RW_h W_in,v[head]^T + d b_fold b_v^T;  dW_in,k, dW_in,v
+        XJobList L;
+        for (int h = 0; h < H; ++h) {
+            const size_t r0 = (size_t)h * Wd, o = (size_t)h * E;
+            XJob* a = L.nt(sc.T1 + (size_t)h * Cq * d, d, 1, Cq, Wik + o * d, d, d, E, sc.dAqT + o, d, scale);
+            a->lb = sc.dWfb + r0; a->wb = bik + o;
+            XJob* b = L.nt(sc.RW + (size_t)h * C * d, d, 1, C, Wiv + o * d, d, d, E, sc.dWHO + o, d, 1.f);
+            b->lb = sc.dWfb + r0 + Cq; b->wb = biv + o;
+            L.outer(w.AqT + o, d, Cq, sc.T1 + (size_t)h * Cq * d, d, E, d, g_ik + o * d, d, scale);
+            L.outer(w.WHO + o, d, C, sc.RW + (size_t)h * C * d, d, E, d, g_iv + o * d, d, 1.f);
+        }
+        CHECK(L.launch(s));
+    }
+    {   // the query side and the output side: W_Qf = W_in,q W_q, W_HO = W_res W_out, b_HO = W_res b_out + b_res
+        XJobList L;
+        L.outer(sc.dAqT, d, C, p->proj_q_w, 1, d, d, g_iq, d, 1.f)->qsn = C;            // dW_in,q[m][n] = sum_c dAqT[c][m] W_q[n][c]
+        L.copy(sc.dAqT + (size_t)C * d, d, gb_iq);                                       // d b_q = row C of dAqT
+        L.nn(sc.dAqT, d, C, Wiq, d, d, d, gr->proj_q_w, 1, 1.f, nullptr, C);             // dW_q[k][c] = sum_m dAqT[c][m] W_in,q[m][k]
+        L.outer(p->res_w, d, C, sc.dWHO, d, d, d, gr->attn_out_w, d, 1.f);               // dW_out = W_res^T dW_HO
+        L.outer(p->res_w, d, C, dbHO, 1, d, 1, gr->attn_out_b, 1, 1.f);                  // d b_out = W_res^T d b_HO
+        XJob* a = L.nt(sc.dWHO, d, 1, C, p->attn_out_w, d, d, d, gr->res_w, d, 1.f);     // dW_res = dW_HO W_out^T + d b_HO b_out^T
+        a->lb = dbHO; a->wb = p->attn_out_b;
+        L.copy(dbHO, C, gr->res_b);
+        CHECK(L.launch(s));
+    }
+    return IMMTSF_OK;
+}
+
+int immtsf_mmf_xrank_q_forward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
+                               const float* bHO, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
+                               immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !ln_w || !ln_b || !Y_ts || !P || !bHO || !M_txt || !Y_out || !workspace) return IMMTSF_EINVAL;
+    XQWs w = carve_xq(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const XQDims q = xq_dims(cfg);
+    const DropCfg drop = drop_of(cfg);
+    const size_t lds = (size_t)q.wpb * q.T * q.PW * sizeof(float);
+    const int grid = cdiv(q.B, q.wpb);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (q.C <= 8)
+        hipLaunchKernelGGL(xrank_q_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, Y_out, w.lse, w.xhat, w.rstd,
+                           w.ticket, drop);
+    else
+        hipLaunchKernelGGL(xrank_q_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, Y_out, w.lse, w.xhat, w.rstd,
+                           w.ticket, drop);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+/* dY_out -> dY_ts (B*T, C), dP (B*T, PW) (+ its bf16 image in cfg->out_h when the bf16 dataflow is on), d b_HO (C), d ln_w, d ln_b */
+int immtsf_mmf_xrank_q_backward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* Y_ts, const float* P, const uint8_t* M_txt,
+                                const float* dY_out, float* dY_ts, float* dP, float* dbHO, float* d_ln_w, float* d_ln_b, void* workspace,
+                                size_t workspace_bytes, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !ln_w || !Y_ts || !P || !M_txt || !dY_out || !dY_ts || !dP || !dbHO || !d_ln_w || !d_ln_b || !workspace)
+        return IMMTSF_EINVAL;
+    XQWs w = carve_xq(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const XQDims q = xq_dims(cfg);
+    const XRDims x = xr_dims(cfg);
+    const DropCfg drop = drop_of(cfg);
+    const size_t lds = xq_lds_floats(x) * q.wpb * sizeof(float);
+    const int grid = cdiv(q.B, q.wpb);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* dP16 = (xr_hf(cfg) && cfg->out_h) ? static_cast<unsigned short*>(cfg->out_h) : nullptr;
+    if (q.C <= 8)
+        hipLaunchKernelGGL(xrank_q_bwd_kernel<8>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, M_txt, ln_w, w.xhat, w.rstd, w.lse, dY_out, dY_ts, dP,
+                           dP16, w.slabs, w.ticket, d_ln_w, d_ln_b, dbHO, drop);
+    else
+        hipLaunchKernelGGL(xrank_q_bwd_kernel<16>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, M_txt, ln_w, w.xhat, w.rstd, w.lse, dY_out, dY_ts, dP,
+                           dP16, w.slabs, w.ticket, d_ln_w, d_ln_b, dbHO, drop);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+}  // extern "C"

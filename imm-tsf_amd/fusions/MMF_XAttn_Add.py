@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from fusions._common import f32, resolve_precision
 from immtsf import config
-from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn, mmf_xattn_q_fold
+from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn, MMFXRankPFn, MMFXRankQFn, mmf_xattn_q_fold, mmf_xrank_pw
 
 
 class MMF_XAttn_Add(nn.Module):
@@ -37,11 +37,19 @@ class MMF_XAttn_Add(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.precision = None
         self.last_seed = 0
+        self._rank_ok = {}
 
     def _params(self):
         return (self.proj_q.weight, self.proj_k.weight, self.proj_v.weight, self.attn.in_proj_weight,
                 self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.residual_head.weight,
                 self.residual_head.bias, self.layer_norm.weight, self.layer_norm.bias)
+
+    def _rank(self, T):
+        """the low-rank form (immtsf.ops.MMFXRankPFn / MMFXRankQFn, csrc/xrank.hip) takes these dimensions"""
+        key = (int(T), bool(config.xattn_rank))
+        if key not in self._rank_ok:
+            self._rank_ok[key] = mmf_xrank_pw(T, self.C, self.d_attn, self.n_heads) > 0
+        return self._rank_ok[key]
 
     def fold_weights(self):
         """the query half's product weights (parameters only: any stream, any time before forward())"""
@@ -50,7 +58,11 @@ class MMF_XAttn_Add(nn.Module):
     def project_kv(self, E_txt, with_fold=True):
         """key/value half (proj_k / proj_v + their MHA in-projections -> one (B,T,2d) tensor k | v): depends only on the text
         side, so a caller can run it on the text stream while the backbone is still producing Y_ts
-        (lib.evaluation.forecast_and_fuse)"""
+        (lib.evaluation.forecast_and_fuse).  In the low-rank form the pair is (P, b_HO): the text side's projection onto the
+        (2C+1) H columns the attention needs and the folded output bias (both carry gradients back to this half)."""
+        if self._rank(E_txt.shape[1]):
+            return MMFXRankPFn.apply(f32(E_txt), self.C, self.n_heads, resolve_precision(self),
+                                     getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), *self._params()[:9])
         KV = MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
                                 getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
                                 self.attn.in_proj_weight, self.attn.in_proj_bias)
@@ -67,6 +79,11 @@ class MMF_XAttn_Add(nn.Module):
         self.last_seed = config.next_seed() if training else 0
         KV, fold = self.project_kv(E_txt) if kv is None else kv
         p = self._params()
+        if self._rank(Y_ts.shape[1]):
+            if fold is None:        # (a caller that asked for with_fold=False: b_HO only comes with P)
+                KV, fold = self.project_kv(E_txt)
+            return MMFXRankQFn.apply(f32(Y_ts), KV, fold, M_u8, self.d_attn, self.n_heads, float(self.kappa), self.p_drop, training,
+                                     resolve_precision(self), self.last_seed, p[9], p[10])
         return MMFXAttnQFn.apply(f32(Y_ts), KV, M_u8, fold, self.n_heads, float(self.kappa), self.p_drop, training,
                                  resolve_precision(self), self.last_seed, p[0], *p[3:])
 

@@ -86,3 +86,8 @@ def disable_device_counters(device=None):
 def dropout_counter_ptr(device):
     c = _device_counters.get(str(device))
     return None if c is None else c[1].data_ptr()
+
+# MMF_XAttn_Add in its low-rank form (csrc/xrank.hip) wherever its limits allow; False (or IMMTSF_XATTN_RANK=0): the full-rank
+# key/value + query halves
+import os as _os
+xattn_rank = _os.environ.get("IMMTSF_XATTN_RANK", "1") != "0"

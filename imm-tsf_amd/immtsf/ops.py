@@ -107,21 +107,25 @@ def _bytes(n, dev):
 
 
 # ---- bf16 images of activations that cross a block boundary (bf16 mode).  The producer registers (fp32 tensor, bf16
-# image); a consumer that is handed the SAME, unmodified fp32 tensor finds the image and skips its cast kernel.  The
-# fp32 tensor is kept referenced while registered, so its storage cannot be recycled under a stale entry.
-_shadows = []          # [(fp32 tensor, version at registration, bf16 tensor)], newest last, at most _SHADOW_CAP entries
+# image); a consumer that is handed the SAME, unmodified fp32 data finds the image and skips its cast kernel.  The registry
+# holds the fp32 tensor's STORAGE (so the address cannot be recycled under a stale entry) but not the tensor: a gradient that a
+# backward returns must stay un-referenced, or autograd's AccumulateGrad clones it instead of taking it (a copy launch on the
+# serial section in front of the backbone's backward, and the clone then misses its image: a cast launch more).
+_shadows = []          # [(storage, data_ptr, shape, version, bf16 tensor)], newest last, at most _SHADOW_CAP entries
 _SHADOW_CAP = 6
 
 
 def _shadow_put(t, h):
-    _shadows.append((t, t._version, h))
+    _shadows.append((t.untyped_storage(), t.data_ptr(), tuple(t.shape), t._version, h))
     if len(_shadows) > _SHADOW_CAP:
         del _shadows[0]
 
 
 def _shadow_get(x):
-    for t, ver, h in reversed(_shadows):
-        if t.data_ptr() == x.data_ptr() and t.shape == x.shape and t._version == ver and x._version == ver and x.is_contiguous():
+    if not x.is_contiguous():
+        return None
+    for _st, p, shape, ver, h in reversed(_shadows):
+        if p == x.data_ptr() and shape == tuple(x.shape) and x._version == ver:
             return h
     return None
 
@@ -448,6 +452,116 @@ class MMFXAttnQFn(torch.autograd.Function):
                       "mmf_xattn_q_backward_params")
             _deferred.append(finish)
         return (dY, dKV, None, None, None, None, None, None, None, None, rets[0]) + tuple(rets[3:])
+
+
+# ---- MMF_XAttn_Add, low-rank form (csrc/xrank.hip): the text side is projected onto (2C+1) H columns, the attention + head is one
+# kernel per direction on those columns
+def mmf_xrank_pw(T, Cc, d, H):
+    """row pitch of P for these dimensions, or 0 when the low-rank form does not take them (config.xattn_rank off, or limits)"""
+    if not config.xattn_rank:
+        return 0
+    lib = _lib.load()
+    cfg = make_cfg(1, 0, T, Cc, 0, d, H, 0, False, 0.0, 0.0, 0, None)
+    return int(lib.immtsf_mmf_xrank_pw(C.byref(cfg)))
+
+
+class MMFXRankPFn(torch.autograd.Function):
+    """P half of MMF_XAttn_Add's low-rank form: E_txt -> (P (B,T,pw), b_HO (C)).  Depends only on the text side; its backward yields
+    dE_txt and the gradients of every parameter except LayerNorm's.  params: XAddParams order without ln_w / ln_b."""
+
+    @staticmethod
+    def forward(ctx, E, Cc, H, precision, done_hook, *params9):
+        lib = _lib.load()
+        E = _c(E)
+        params = tuple(_c(p) for p in params9) + (None, None)
+        _need_gpu(E, *params)
+        B, T, d = E.shape
+        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, False, 0.0, 0.0, 0, E.device)
+        pw = int(lib.immtsf_mmf_xrank_pw(C.byref(cfg)))
+        if pw <= 0:
+            raise _lib.ImmtsfError("MMF_XAttn_Add low-rank form: shape outside its limits")
+        ws = _bytes(lib.immtsf_mmf_xrank_p_workspace_bytes(C.byref(cfg)), E.device)
+        P = torch.empty(B, T, pw, dtype=torch.float32, device=E.device)
+        bHO = torch.empty(Cc, dtype=torch.float32, device=E.device)
+        ps = _struct(XAddParams, params)
+        E_h = _shadow_get(E) if _bf16_dataflow(precision, d) else None
+        cfg.in_h = None if E_h is None else E_h.data_ptr()
+        ctx.E_h = E_h
+        check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(), stream_ptr()),
+              "mmf_xrank_p_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.sinks = _sinks_of(params)
+        ctx.done_hook = done_hook          # the block's gradients are final once THIS half's backward has run
+        ctx.save_for_backward(E, *params[:9])
+        return P, bHO
+
+    @staticmethod
+    def backward(ctx, dP, dbHO):
+        lib = _lib.load()
+        E, *params9 = ctx.saved_tensors
+        params = list(params9) + [None, None]
+        grads, rets = _grad_buffers(params, ctx.sinks)
+        dE = torch.empty_like(E)
+        cfg = ctx.cfg
+        sc = _bytes(lib.immtsf_mmf_xrank_p_scratch_bytes(C.byref(cfg)), E.device)
+        ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
+        dP = dP.contiguous()
+        dbHO = torch.zeros(cfg.C, dtype=torch.float32, device=E.device) if dbHO is None else dbHO.contiguous()
+        dE_h = None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            dP_h = _shadow_get(dP)
+            cfg.in_h = None if dP_h is None else dP_h.data_ptr()
+            cfg.aux_h = None if ctx.E_h is None else ctx.E_h.data_ptr()
+            dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
+            cfg.out_h = dE_h.data_ptr()
+        check(lib.immtsf_mmf_xrank_p_backward(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dbHO), ptr(dE), ptr(ctx.ws), ctx.ws.numel(),
+                                              ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "mmf_xrank_p_backward")
+        if dE_h is not None:
+            _shadow_put(dE, dE_h)
+        _fire(ctx.done_hook)
+        return (dE, None, None, None, None) + tuple(rets[:9])
+
+
+class MMFXRankQFn(torch.autograd.Function):
+    """Q half of the low-rank form: (Y_ts, P, b_HO, M_txt, ln_w, ln_b) -> Y_out; the serial section between the backbone's forward
+    and backward (one kernel per direction)."""
+
+    @staticmethod
+    def forward(ctx, Y, P, bHO, M_u8, d, H, kappa, p_drop, training, precision, seed, ln_w, ln_b):
+        lib = _lib.load()
+        Y, P, bHO, M_u8, ln_w, ln_b = _c(Y), _c(P), _c(bHO), _c(M_u8), _c(ln_w), _c(ln_b)
+        _need_gpu(Y, P, bHO, M_u8, ln_w, ln_b)
+        B, T, Cc = Y.shape
+        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed, Y.device)
+        if int(lib.immtsf_mmf_xrank_pw(C.byref(cfg))) != P.shape[2]:
+            raise _lib.ImmtsfError("MMF_XAttn_Add low-rank form: P does not have the row pitch of these dimensions")
+        ws = _bytes(lib.immtsf_mmf_xrank_q_workspace_bytes(C.byref(cfg)), Y.device)
+        out = torch.empty_like(Y)
+        check(lib.immtsf_mmf_xrank_q_forward(C.byref(cfg), ptr(ln_w), ptr(ln_b), ptr(Y), ptr(P), ptr(bHO), ptr(M_u8), ptr(out), ptr(ws),
+                                             ws.numel(), stream_ptr()), "mmf_xrank_q_forward")
+        ctx.cfg, ctx.ws = cfg, ws
+        ctx.sinks = _sinks_of((ln_w, ln_b))
+        ctx.save_for_backward(Y, P, M_u8, ln_w, ln_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        Y, P, M_u8, ln_w, ln_b = ctx.saved_tensors
+        grads, rets = _grad_buffers((ln_w, ln_b), ctx.sinks)
+        dY, dP = torch.empty_like(Y), torch.empty_like(P)
+        dbHO = torch.empty(Y.shape[2], dtype=torch.float32, device=Y.device)
+        cfg, dP_h = ctx.cfg, None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            dP_h = torch.empty(dP.shape, dtype=torch.bfloat16, device=dP.device)
+            cfg.out_h = dP_h.data_ptr()
+        check(lib.immtsf_mmf_xrank_q_backward(C.byref(cfg), ptr(ln_w), ptr(Y), ptr(P), ptr(M_u8), ptr(dout.contiguous()), ptr(dY), ptr(dP),
+                                              ptr(dbHO), ptr(grads[0]), ptr(grads[1]), ptr(ctx.ws), ctx.ws.numel(), stream_ptr()),
+              "mmf_xrank_q_backward")
+        cfg.out_h = None
+        if dP_h is not None:
+            _shadow_put(dP, dP_h)
+        return (dY, dP, dbHO, None, None, None, None, None, None, None, None) + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ MMF_GR_Add

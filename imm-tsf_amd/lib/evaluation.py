@@ -68,7 +68,7 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
     # backward instead of behind them (r02 trace: placed last it started 200 us after its input was ready).  Re-measured after
     # the launch cuts of r02 (backbone first / text first): 0.908 / 0.906 ms per step -- no difference any more.
     E_txt, M_txt = fusion.ttf(notes, tau, tp)
-    fold_side = _FOLD_ON_SIDE and hasattr(fusion.mmf, "fold_weights")
+    fold_side = _FOLD_ON_SIDE and hasattr(fusion.mmf, "fold_weights") and not fusion.mmf._rank(E_txt.shape[1])     # (low-rank form: no separate fold)
     if fold_side:
         kv = fusion.mmf.project_kv(E_txt, with_fold=False)
     else:

@@ -194,6 +194,33 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
                                        void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
                                        immtsf_stream_t stream);
 
+/* ---- a6, low-rank form (csrc/xrank.hip).  Y_ts has C columns and residual_head has C rows, and nothing between proj_{q,k,v} and
+ * the MHA in-projections, or between out_proj and residual_head, is nonlinear: per head the scores are [Y|1] G_h [E_txt|1]^T and
+ * the head output is A_h (U_h [E_txt|1]^T) with parameter-only (C+1) x (d+1) / C x (d+1) matrices G_h, U_h.  The P half forms
+ * them (fold), projects P = [E_txt|1] W_fold^T ((2C+1) H columns, row pitch xrank_pw) and, backward, turns dP into dE_txt and the
+ * gradients of every parameter except LayerNorm's by the chain rule; the Q half is the whole attention + head + LayerNorm(C) +
+ * blend on those columns in one kernel per direction.  Same function and gradients as the entry points above (fp32
+ * reassociation); xrank_pw == 0: shape outside this form's limits, use the full-rank entry points.
+ * cfg->in_h / aux_h / out_h as for the kv half: p_forward in_h = bf16 E_txt; q_backward out_h = bf16 dP; p_backward in_h = bf16
+ * dP, aux_h = bf16 E_txt, out_h = bf16 dE_txt. */
+int32_t immtsf_mmf_xrank_pw(const immtsf_fusion_cfg* cfg);
+size_t immtsf_mmf_xrank_p_workspace_bytes(const immtsf_fusion_cfg* cfg);
+size_t immtsf_mmf_xrank_p_scratch_bytes(const immtsf_fusion_cfg* cfg);
+size_t immtsf_mmf_xrank_q_workspace_bytes(const immtsf_fusion_cfg* cfg);
+/* E_txt (B*T, d) -> P (B*T, pw), b_HO (C) = W_res b_out + b_res */
+int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* P, float* bHO,
+                               void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+/* dP, d b_HO -> dE_txt and the gradients of all parameters but ln_w / ln_b (overwritten; grads->ln_* are not touched) */
+int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
+                                const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
+                                size_t scratch_bytes, const immtsf_xadd_params* grads, immtsf_stream_t stream);
+int immtsf_mmf_xrank_q_forward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
+                               const float* bHO, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
+                               immtsf_stream_t stream);
+int immtsf_mmf_xrank_q_backward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* Y_ts, const float* P, const uint8_t* M_txt,
+                                const float* dY_out, float* dY_ts, float* dP, float* dbHO, float* d_ln_w, float* d_ln_b, void* workspace,
+                                size_t workspace_bytes, immtsf_stream_t stream);
+
 /* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
 typedef struct immtsf_gr_params {
     float *w_ih, *w_hh, *b_ih, *b_hh; /* (3Hd, C+d),(3Hd,Hd),(3Hd),(3Hd)  gru.*_l0 */

@@ -784,6 +784,52 @@ def test_mmf_monolithic_entry_equals_the_two_halves():
         assert float((a - b).abs().max()) <= 1e-5 * max(1e-3, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (3, 13, 5, 48, 4, 0.3), (64, 32, 8, 768, 1, 0.1),
+                                            (2, 260, 8, 64, 1, 0.1), (300, 6, 15, 16, 1, 0.0)])
+def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision):
+    """MMF_XAttn_Add's low-rank form (csrc/xrank.hip: the text side projected onto the (2C+1) H columns the attention needs, the
+    attention + head as one kernel per direction, parameter gradients by the chain rule through the folded factors) against the
+    full-rank key/value + query halves (immtsf.config.xattn_rank = False): same Philox sites and indices, so also under dropout;
+    outputs, data gradients and every parameter gradient.  (Both are pinned to the reference by the goldens: the module takes the
+    low-rank form wherever its limits allow.)"""
+    dev = _dev()
+    from fusions.MMF_XAttn_Add import MMF_XAttn_Add
+    from immtsf import config
+    config.precision = precision
+    torch.manual_seed(B * 1000 + T)
+    mmf = MMF_XAttn_Add(d, Cc, d, n_heads_fusion=H, dropout=pd, kappa=0.7).to(dev).train()
+    with torch.no_grad():
+        for p_ in mmf.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    Y, E = torch.randn(B, T, Cc, device=dev), torch.randn(B, T, d, device=dev)
+    M = (torch.rand(B, device=dev) > 0.25).view(B, 1)
+    M[0] = True
+    up = torch.randn(B, T, Cc, device=dev)
+    res, seed0 = [], config.next_seed
+    try:
+        config.next_seed = lambda: 4242
+        for rank in (True, False):
+            config.xattn_rank = rank
+            assert mmf._rank(T) == rank
+            mmf.zero_grad()
+            y, e = Y.clone().requires_grad_(True), E.clone().requires_grad_(True)
+            out = mmf(y, e, M)
+            (out * up).sum().backward()
+            res.append([("out", out.detach()), ("dY", y.grad), ("dE", e.grad)] + [(k, p_.grad.clone()) for k, p_ in mmf.named_parameters()])
+    finally:
+        config.next_seed, config.xattn_rank, config.precision = seed0, True, "fp32"
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][3:])
+    for (k, a), (_, b) in zip(*res):
+        assert torch.isfinite(a).all(), k
+        # floor: the key projection's bias gradient is zero in exact arithmetic; small gradients are compared on the scale of the block's largest
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("out", "dY", "dE") else 1e-6)
+        err = float((a - b).norm()) / den
+        assert err <= tol, (k, err)
+
+
 def test_grouped_weight_gradient_launch_opt_in():
     """IMMTSF_GEMM_GROUP=1 (csrc/gemm2.hip gemm2_group_kernel: the T2V backward's five TN weight gradients, different shapes, as ONE
     launch at the end of the call; read once per process, so a child process): the bf16 benchmark-shape parity tests still pass."""

@@ -300,8 +300,9 @@ class Workload:
         from immtsf.ops import masked_mse
         from lib.evaluation import forecast_and_fuse
         b = self.batch
-        out = forecast_and_fuse(self.model, self.fusion, b, self.side)
-        return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, self.global_cnt)
+        # (where the fusion's last block can run its head, the loss and their backward as one launch -- MMF_XAttn_Add's low-rank
+        # form -- forecast_and_fuse returns the loss itself)
+        return forecast_and_fuse(self.model, self.fusion, b, self.side, loss=(b["data_to_predict"], b["mask_predicted_data"], self.global_cnt))
 
     def eager_step(self):
         from immtsf.ops import backward_unit
@@ -339,6 +340,8 @@ def flag_step(w):
         return (E, M) + tuple(fusion.mmf.project_kv(E))
 
     def head_fn(pred, E, M, kv, fold):
+        if hasattr(fusion.mmf, "forward_loss"):      # head + loss (+ their backward) in one launch where the block can
+            return fusion.mmf.forward_loss(pred, E, M, b["data_to_predict"], b["mask_predicted_data"], w.global_cnt, kv=(kv, fold))
         out = fusion.mmf(pred, E, M, kv=(kv, fold))
         return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, w.global_cnt)
 
@@ -714,6 +717,8 @@ def main():
                 return (E, M) + tuple(fusion.mmf.project_kv(E))
 
             def head_fn(pred, E, M, kv, fold):
+                if hasattr(fusion.mmf, "forward_loss"):
+                    return fusion.mmf.forward_loss(pred, E, M, b["data_to_predict"], b["mask_predicted_data"], w.global_cnt, kv=(kv, fold))
                 out = fusion.mmf(pred, E, M, kv=(kv, fold))
                 return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, w.global_cnt)
 

@@ -50,18 +50,18 @@ struct XJob {
     const float* xrow;                // NT: out[R * osr + m * osn] = xrow[m]  (one more row, copied)
     int ng; long pgs, qgs;            // OUTER: sum over ng groups, P += pgs, Q += qgs per group
 };
-struct XJobs { int first[XJ_MAX]; int n; XJob j[XJ_MAX]; };       // first[i]: first workgroup of job i
+struct XJobs { int first[XJ_MAX]; int n; int lds_floats; XJob j[XJ_MAX]; };       // first[i]: first workgroup of job i
 
 __device__ __forceinline__ unsigned short f2bf(float v) {
     return __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
 }
 
-constexpr int XJ_LK = 16 * 1024;      // floats of the staged L operand: R * K <= 16 K (else it is read from global memory)
+constexpr int XJ_LK = 16 * 1024;      // most floats of a staged L operand (dynamic LDS, sized per launch; 0: every job reads L from global memory)
 
 // the <= 16 rows of an NN / NT job's L operand as an LDS image Ls[r * K + k] (one round of coalesced loads; the products then read it
 // as broadcasts / 16-byte rows instead of issuing R dependent global loads per k step)
-__device__ __forceinline__ bool xjob_stage_l(const XJob& J, float* Ls) {
-    if (J.R * J.K > XJ_LK) return false;
+__device__ __forceinline__ bool xjob_stage_l(const XJob& J, float* Ls, int cap) {
+    if (J.R * J.K > cap) return false;
     if (J.lsn == 1) {
         for (int i = threadIdx.x; i < J.R * J.K; i += 256) {
             const int r = i / J.K, k = i - r * J.K;
@@ -79,36 +79,54 @@ __device__ __forceinline__ bool xjob_stage_l(const XJob& J, float* Ls) {
 
 template <bool STAGED>
 __device__ __forceinline__ void xjob_nn_acc(const XJob& J, int kg, int n, const float* Ls, float4 (&acc)[XR]) {
-    constexpr int U = 12;
+    constexpr int U = STAGED ? 12 : 6;
     const int R = J.R;
     for (int k0 = kg; k0 < J.K; k0 += 64 * U) {
         float4 w[U];
 #pragma unroll
         for (int u = 0; u < U; ++u)
             w[u] = k0 + 64 * u < J.K ? *reinterpret_cast<const float4*>(J.W + (size_t)(k0 + 64 * u) * J.ldw + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (STAGED) {
 #pragma unroll
-        for (int r = 0; r < XR; ++r)
-            if (r < R) {
+            for (int r = 0; r < XR; ++r)
+                if (r < R) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int k = k0 + 64 * u;
-                    float l = 0.f;
-                    if (k < J.K) {
-                        if (STAGED) l = Ls[r * J.K + k];
-                        else l = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
+                    for (int u = 0; u < U; ++u) {
+                        const int k = k0 + 64 * u;
+                        const float l = k < J.K ? Ls[r * J.K + k] : 0.f;
+                        acc[r].x = fmaf(l, w[u].x, acc[r].x); acc[r].y = fmaf(l, w[u].y, acc[r].y);
+                        acc[r].z = fmaf(l, w[u].z, acc[r].z); acc[r].w = fmaf(l, w[u].w, acc[r].w);
                     }
-                    acc[r].x = fmaf(l, w[u].x, acc[r].x); acc[r].y = fmaf(l, w[u].y, acc[r].y);
-                    acc[r].z = fmaf(l, w[u].z, acc[r].z); acc[r].w = fmaf(l, w[u].w, acc[r].w);
                 }
+        } else {        // every L value of the round requested before the first use
+#pragma unroll
+            for (int rb = 0; rb < XR; rb += 8) {        // (eight rows at a time: the operand registers of sixteen would halve the occupancy)
+                if (rb >= R) break;
+                float l[8][U];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = k0 + 64 * u;
+                        l[r][u] = (rb + r < R && k < J.K) ? J.L[(size_t)(rb + r) * J.lsr + (size_t)k * J.lsn] : 0.f;
+                    }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        acc[rb + r].x = fmaf(l[r][u], w[u].x, acc[rb + r].x); acc[rb + r].y = fmaf(l[r][u], w[u].y, acc[rb + r].y);
+                        acc[rb + r].z = fmaf(l[r][u], w[u].z, acc[rb + r].z); acc[rb + r].w = fmaf(l[r][u], w[u].w, acc[rb + r].w);
+                    }
             }
+        }
     }
 }
 
 // NN: out[r][n] = alpha * sum_k L[r][k] W[k][n].  A workgroup owns 16 output columns: thread = (4-column group eq, k-group kg of 64);
 // up to 12 k steps of W are in flight per thread
-__device__ __forceinline__ void xjob_nn(const XJob& J, int blk, float* Ls, float* red /* [4][XR][16] */) {
+__device__ __forceinline__ void xjob_nn(const XJob& J, int blk, float* Ls, int cap, float* red /* [4][XR][16] */) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, eq = tid & 3, kg = tid >> 2, n = blk * 16 + eq * 4, R = J.R;
-    const bool staged = xjob_stage_l(J, Ls);
+    const bool staged = xjob_stage_l(J, Ls, cap);
     float4 acc[XR];
 #pragma unroll
     for (int r = 0; r < XR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -138,10 +156,11 @@ __device__ __forceinline__ void xjob_nn(const XJob& J, int blk, float* Ls, float
     }
 }
 
-// NT: out[r][m] = alpha * (sum_k L[r][k] W[m][k] + lb[r] wb[m]) + radd[r].  A wave owns two output columns m, the lanes stride k
-__device__ __forceinline__ void xjob_nt(const XJob& J, int blk, float* Ls) {
+// NT: out[r][m] = alpha * (sum_k L[r][k] W[m][k] + lb[r] wb[m]) + radd[r].  A wave owns two output columns m, the lanes stride k.
+// Row-major L is read straight from global memory (16-byte loads, a round's worth in flight); a k-major L is staged in LDS.
+__device__ __forceinline__ void xjob_nt(const XJob& J, int blk, float* Ls, int cap) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, R = J.R;
-    const bool staged = xjob_stage_l(J, Ls);
+    const bool staged = J.lsn != 1 && xjob_stage_l(J, Ls, cap);
     const int m0 = blk * 8 + wave * 2;
     if (m0 >= J.N) return;
     const bool two = m0 + 1 < J.N;
@@ -150,7 +169,8 @@ __device__ __forceinline__ void xjob_nt(const XJob& J, int blk, float* Ls) {
     float a0[XR], a1[XR];
 #pragma unroll
     for (int r = 0; r < XR; ++r) a0[r] = a1[r] = 0.f;
-    if (staged && (J.K & 3) == 0 && (J.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(J.W) & 15) == 0) {
+    const bool vec = (J.K & 3) == 0 && (J.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(J.W) & 15) == 0;
+    if (vec && staged) {
         constexpr int U = 4;                 // 16-byte steps per lane in flight (K <= 1024 per round)
         for (int k0 = lane * 4; k0 < J.K; k0 += 256 * U) {
             float4 x0[U], x1[U];
@@ -174,31 +194,60 @@ __device__ __forceinline__ void xjob_nt(const XJob& J, int blk, float* Ls) {
                     }
                 }
         }
+    } else if (vec && J.lsn == 1 && (J.lsr & 3) == 0 && (reinterpret_cast<uintptr_t>(J.L) & 15) == 0) {
+        constexpr int U = 3;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = lane * 4; k0 < J.K; k0 += 256 * U) {
+            float4 x0[U], x1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + 256 * u;
+                x0[u] = k < J.K ? *reinterpret_cast<const float4*>(w0 + k) : z4;
+                x1[u] = k < J.K ? *reinterpret_cast<const float4*>(w1 + k) : z4;
+            }
+#pragma unroll
+            for (int rb = 0; rb < XR; rb += 8) {
+                if (rb >= R) break;
+                float4 l[8][U];
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = k0 + 256 * u;
+                        l[r][u] = (rb + r < R && k < J.K) ? *reinterpret_cast<const float4*>(J.L + (size_t)(rb + r) * J.lsr + k) : z4;
+                    }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        a0[rb + r] = fmaf(l[r][u].x, x0[u].x, fmaf(l[r][u].y, x0[u].y, fmaf(l[r][u].z, x0[u].z, fmaf(l[r][u].w, x0[u].w, a0[rb + r]))));
+                        a1[rb + r] = fmaf(l[r][u].x, x1[u].x, fmaf(l[r][u].y, x1[u].y, fmaf(l[r][u].z, x1[u].z, fmaf(l[r][u].w, x1[u].w, a1[rb + r]))));
+                    }
+            }
+        }
+    } else if (staged) {
+#pragma unroll 4
+        for (int k = lane; k < J.K; k += 64) {
+            const float x0 = w0[k], x1 = w1[k];
+#pragma unroll
+            for (int r = 0; r < XR; ++r)
+                if (r < R) {
+                    const float l = Ls[r * J.K + k];
+                    a0[r] = fmaf(l, x0, a0[r]);
+                    a1[r] = fmaf(l, x1, a1[r]);
+                }
+        }
     } else {
-        if (staged) {
 #pragma unroll 4
-            for (int k = lane; k < J.K; k += 64) {
-                const float x0 = w0[k], x1 = w1[k];
+        for (int k = lane; k < J.K; k += 64) {
+            const float x0 = w0[k], x1 = w1[k];
 #pragma unroll
-                for (int r = 0; r < XR; ++r)
-                    if (r < R) {
-                        const float l = Ls[r * J.K + k];
-                        a0[r] = fmaf(l, x0, a0[r]);
-                        a1[r] = fmaf(l, x1, a1[r]);
-                    }
-            }
-        } else {
-#pragma unroll 4
-            for (int k = lane; k < J.K; k += 64) {
-                const float x0 = w0[k], x1 = w1[k];
-#pragma unroll
-                for (int r = 0; r < XR; ++r)
-                    if (r < R) {
-                        const float l = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
-                        a0[r] = fmaf(l, x0, a0[r]);
-                        a1[r] = fmaf(l, x1, a1[r]);
-                    }
-            }
+            for (int r = 0; r < XR; ++r)
+                if (r < R) {
+                    const float l = J.L[(size_t)r * J.lsr + (size_t)k * J.lsn];
+                    a0[r] = fmaf(l, x0, a0[r]);
+                    a1[r] = fmaf(l, x1, a1[r]);
+                }
         }
     }
     float mine0 = 0.f, mine1 = 0.f;
@@ -288,16 +337,23 @@ __device__ __forceinline__ void xjob_outer(const XJob& J, int blk) {
     }
 }
 
-__global__ __launch_bounds__(256) void xjobs_kernel(XJobs js) {
-    __shared__ __attribute__((aligned(16))) float Ls[XJ_LK];
+typedef const XJobs* XJobsK;
+__global__ __launch_bounds__(256) void xjobs_kernel(XJobs js_arg) {
+    extern __shared__ __attribute__((aligned(16))) float Ls[];      // lds_floats floats
     __shared__ __attribute__((aligned(16))) float red[4 * XR * 16];
+    // the job table is read where it lies, in the kernel-argument segment (scalar loads at a run-time offset): indexing the by-value
+    // parameter with a run-time index makes hipcc copy all 3 KB of it into registers / scratch
+    XJobsK js = (XJobsK)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)js_arg;
+    const int n = js->n;
     int ji = 0;
 #pragma unroll
-    for (int i = 1; i < XJ_MAX; ++i) ji += (i < js.n && (int)blockIdx.x >= js.first[i]) ? 1 : 0;
-    const int blk = blockIdx.x - js.first[ji];
-    const XJob& J = js.j[ji];
-    if (J.form == XJ_NN) xjob_nn(J, blk, Ls, red);
-    else if (J.form == XJ_NT) xjob_nt(J, blk, Ls);
+    for (int i = 1; i < XJ_MAX; ++i) ji += (i < n && (int)blockIdx.x >= js->first[i]) ? 1 : 0;
+    const int blk = blockIdx.x - js->first[ji];
+    const XJob J = js->j[ji];
+    const int cap = js->lds_floats;
+    if (J.form == XJ_NN) xjob_nn(J, blk, Ls, cap, red);
+    else if (J.form == XJ_NT) xjob_nt(J, blk, Ls, cap);
     else if (J.form == XJ_OUTER) xjob_outer(J, blk);
     else {
         for (int i = blk * 1024 + threadIdx.x; i < min(J.N, (blk + 1) * 1024); i += 256) {
@@ -342,10 +398,21 @@ struct XJobList {
         XJob* j = add(XJ_COPY, cdiv(n, 1024));
         j->L = src; j->N = n; j->out = out; j->out16 = out16;
     }
-    int launch(hipStream_t s) {
+    // stage: the L operands of the NN jobs (and of NT jobs with a k-major L) go through LDS -- for launches that run beside nothing
+    // LDS-hungry; without it every job reads L from global memory (no LDS beyond 4 KB: the backward's launches share the chip with the
+    // backbone's backward, whose workgroups would otherwise wait for LDS behind several hundred 30 KB workgroups)
+    int launch(hipStream_t s, bool stage) {
         if (overflow) return IMMTSF_EUNSUPPORTED;
         if (!blocks) return IMMTSF_OK;
-        hipLaunchKernelGGL(xjobs_kernel, dim3(blocks), dim3(256), 0, s, js);
+        int fl = 0;
+        if (stage)
+            for (int i = 0; i < js.n; ++i) {
+                const XJob& j = js.j[i];
+                const bool wants = j.form == XJ_NN || (j.form == XJ_NT && j.lsn != 1);
+                if (wants && j.R * j.K <= XJ_LK && j.R * j.K > fl) fl = j.R * j.K;
+            }
+        js.lds_floats = fl;
+        hipLaunchKernelGGL(xjobs_kernel, dim3(blocks), dim3(256), (size_t)fl * sizeof(float), s, js);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }
@@ -860,6 +927,333 @@ __global__ __launch_bounds__(256) void xrank_q_bwd_kernel(XQDims q, const float*
     if (threadIdx.x == 0) *ticket = 0u;
 }
 
+// ---- training step: forward, masked-MSE loss (lib/evaluation.py:17-62 with the per-variable observation counts known beforehand, as
+// immtsf_masked_mse_counted) and backward of the Q half in ONE launch.  Every quantity the backward needs from the forward and from
+// the loss is local to a row once the counts are given, so a workgroup runs its windows' forward, forms d loss / d Y_out in registers
+// and goes straight on: the serial section between the backbone's forward and backward is one kernel instead of three (and the
+// LayerNorm statistics, the attention's log-sum-exp and d loss / d Y_out never travel through memory).
+template <int CM>
+__global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const float* __restrict__ Y, const float* __restrict__ P,
+                                                             const float* __restrict__ bHO, const unsigned char* __restrict__ mtxt,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ truth, const float* __restrict__ tmask,
+                                                             const float* __restrict__ cnt, float grad_scale, float* __restrict__ Yout,
+                                                             float* __restrict__ dY, float* __restrict__ dP,
+                                                             unsigned short* __restrict__ dP16, float* __restrict__ slabs, unsigned int* ticket,
+                                                             float* __restrict__ g_lnw, float* __restrict__ g_lnb, float* __restrict__ g_bho,
+                                                             float* __restrict__ loss, DropCfg drop) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[4][64];
+    __shared__ int s_last;
+    const int T = q.T, C = q.C, H = q.H, PW = q.PW, TB = q.TB, parts = q.parts, psh = q.psh, nch = (T + 3) >> 2;
+    const int b0 = blockIdx.x * q.wpb, nw = min(q.wpb, q.B - b0), rows = nw * T;
+    float* Ps = lds;                                   // [rows][PW]
+    float* Ys = Ps + (size_t)q.wpb * T * PW;           // [rows][C]
+    float* Ds = Ys + (size_t)q.wpb * T * C;            // ddelta [rows][C]
+    float* Ls = Ds + (size_t)q.wpb * T * C;            // lse [rows][H]
+    float* Dd = Ls + (size_t)q.wpb * T * H;            // D [rows][H]
+    unsigned char* Mk = reinterpret_cast<unsigned char*>(Dd + (size_t)q.wpb * T * H);      // keep bits [rows][H][TB]: 4 keys per byte
+    {
+        const float4* src = reinterpret_cast<const float4*>(P + (size_t)b0 * T * PW);
+        for (int i = threadIdx.x; i < rows * PW / 4; i += 256) reinterpret_cast<float4*>(Ps)[i] = src[i];
+    }
+    const DropL dl = drop_local(drop);
+    float gm[CM], bt[CM], bh[CM], lsc[CM], navail = 0.f;      // lsc: 1 / (count + 1e-8) of a variable (0 beyond C)
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        gm[c] = c < C ? gamma[c] : 0.f; bt[c] = c < C ? beta[c] : 0.f; bh[c] = c < C ? bHO[c] : 0.f;
+        const float n_c = c < C ? cnt[c] : 0.f;
+        lsc[c] = c < C ? 1.f / (n_c + 1e-8f) : 0.f;
+        navail += (c < C && n_c != 0.f) ? 1.f : 0.f;
+    }
+    float s_e = 0.f;      // partial loss
+    __syncthreads();
+    const float inv = 1.f / (1.f + q.kappa);
+    float s_w[CM], s_b[CM], s_d[CM];       // partial sums: d ln_w, d ln_b, d b_HO
+#pragma unroll
+    for (int c = 0; c < CM; ++c) s_w[c] = s_b[c] = s_d[c] = 0.f;
+    // ---- phase 1: group = query row, its lanes split the keys in chunks of four
+    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+        const int row = idx >> psh, part = idx & (parts - 1);
+        const int lw = row / T, t = row - lw * T, b = b0 + lw;
+        const size_t grow = (size_t)b * T + t;
+        const bool live = mtxt[b] != 0;
+        float y[CM], gy[CM], dd[CM], dy[CM], delta[CM], lseh[4];
+        load_row<CM>(Y + grow * C, C, y);
+#pragma unroll
+        for (int c = 0; c < CM; ++c) delta[c] = bh[c];
+        lseh[0] = lseh[1] = lseh[2] = lseh[3] = 0.f;
+        if (live) {       // ---- forward of the row (as xrank_q_fwd_kernel)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h >= H) break;
+                const float* Ph = Ps + (size_t)lw * T * PW + h * q.Wd;
+                float mx = -INFINITY;
+                for (int j = part; j < nch; j += parts) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) sc = fmaf(y[c], kw[c], sc);
+                            mx = fmaxf(mx, sc);
+                        }
+                    }
+                }
+                mx = group_max(mx, parts);
+                float sum = 0.f, acc[CM];
+#pragma unroll
+                for (int c = 0; c < CM; ++c) acc[c] = 0.f;
+                const uint64_t base = (((uint64_t)b * H + h) * T + t) * T;
+                unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
+                for (int j = part; j < nch; j += parts) {
+                    float dr[4];
+                    drop4(dl, SITE_XADD_ATTN, base + 4 * j, T - 4 * j, dr);
+                    unsigned int bits = 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) sc = fmaf(y[c], kw[c], sc);
+                            const float e = __expf(sc - mx);
+                            sum += e;
+                            const float ed = e * dr[u];
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) acc[c] = fmaf(ed, kw[C + 1 + c], acc[c]);
+                            if (dr[u] != 0.f) bits |= 1u << u;
+                        }
+                    }
+                    mk[j] = (unsigned char)bits;        // the keep bits of the row's keys, for both backward phases
+                }
+                sum = group_sum(sum, parts);
+                const float is = 1.f / sum;
+                lseh[h] = mx + __logf(sum);
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) delta[c] = fmaf(group_sum(acc[c], parts), is, delta[c]);
+            }
+        }
+        {   // ---- LayerNorm(C), dropout, blend; the loss and its gradient; LayerNorm backward -- all in the row's registers
+            float mu = 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < C) mu += delta[c];
+            mu /= (float)C;
+            float var = 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < C) { const float tt = delta[c] - mu; var = fmaf(tt, tt, var); }
+            const float rs = 1.0f / sqrtf(var / (float)C + 1e-5f);
+            float xh[CM], dsc[CM], tr[CM], tm[CM], g[CM], m1 = 0.f, m2 = 0.f;
+            load_row<CM>(truth + grow * C, C, tr);
+            load_row<CM>(tmask + grow * C, C, tm);
+            if (live) drop_row<CM>(dl, (uint64_t)grow * C, C, dsc);
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                xh[c] = (delta[c] - mu) * rs;
+                const float v = (live && c < C) ? fmaf(xh[c], gm[c], bt[c]) * dsc[c] : 0.f;
+                const float yo = (y[c] + q.kappa * v) * inv;
+                if (part == 0 && c < C && Yout) Yout[grow * C + c] = yo;
+                const float dlt = tr[c] - yo;
+                if (part == 0) s_e = fmaf(dlt * dlt, tm[c] * lsc[c], s_e);
+                gy[c] = c < C ? -dlt * tm[c] * lsc[c] * (grad_scale * 2.f / navail) : 0.f;
+                dy[c] = part == 0 ? gy[c] * inv : 0.f;
+                g[c] = 0.f;
+                if (c < C && live) {
+                    const float dn = q.kappa * inv * gy[c] * dsc[c];
+                    if (part == 0) { s_w[c] = fmaf(dn, xh[c], s_w[c]); s_b[c] += dn; }
+                    g[c] = dn * gm[c];
+                    m1 += g[c];
+                    m2 = fmaf(g[c], xh[c], m2);
+                }
+            }
+            m1 /= (float)C; m2 /= (float)C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                dd[c] = (c < C && live) ? rs * (g[c] - m1 - xh[c] * m2) : 0.f;
+                if (part == 0) {
+                    s_d[c] += dd[c];
+                    if (c < C) { Ys[row * C + c] = y[c]; Ds[row * C + c] = dd[c]; }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h >= H) break;
+                const float* Ph = Ps + (size_t)lw * T * PW + h * q.Wd;
+                const float l = lseh[h];
+                unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
+                // D = sum_s A_drop[t,s] dA[t,s] from the SAME a and dA values the gradient below uses: where the text rows of a window
+                // are nearly equal, dA - D is a difference of nearly equal numbers, and a D formed any other way (e.g. from the
+                // forward's output) leaves its own rounding in every dS
+                float D = 0.f;
+                for (int j = part; j < nch; j += parts) {
+                    const unsigned int bits = mk[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C], dA = 0.f;
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
+                            D = fmaf(__expf(sc - l) * ((bits >> u) & 1u ? dl.inv_keep : 0.f), dA, D);
+                        }
+                    }
+                }
+                D = group_sum(D, parts);
+                if (part == 0) { Ls[row * H + h] = l; Dd[row * H + h] = D; }
+                for (int j = part; j < nch; j += parts) {
+                    const unsigned int bits = mk[j];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = 4 * j + u;
+                        if (s < T) {
+                            const float* kw = Ph + s * PW;
+                            float sc = kw[C], dA = 0.f;
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
+                            const float dr = (bits >> u) & 1u ? dl.inv_keep : 0.f;
+                            const float ds = __expf(sc - l) * (dA * dr - D);
+#pragma unroll
+                            for (int c = 0; c < CM; ++c)
+                                if (c < C) dy[c] = fmaf(ds, kw[c], dy[c]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+            if (c < C) {
+                const float v = group_sum(dy[c], parts);
+                if (part == 0) dY[grow * C + c] = v;
+            }
+    }
+    __syncthreads();
+    // ---- phase 2: group = key row, its lanes split the query rows
+    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+        const int row = idx >> psh, part = idx & (parts - 1);
+        const int lw = row / T, s = row - lw * T, b = b0 + lw;
+        const size_t grow = (size_t)b * T + s;
+        const bool live = mtxt[b] != 0;
+        float* out = dP + grow * PW;
+        unsigned short* out16 = dP16 ? dP16 + grow * PW : nullptr;
+        for (int h = 0; h < H; ++h) {
+            float kw[CM], vw[CM], dkw[CM], dvw[CM], dkb = 0.f;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) { kw[c] = 0.f; vw[c] = 0.f; dkw[c] = 0.f; dvw[c] = 0.f; }
+            if (live) {
+                const float* Ph = Ps + ((size_t)lw * T + s) * PW + h * q.Wd;
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) { kw[c] = Ph[c]; vw[c] = Ph[C + 1 + c]; }
+                const float kb = Ph[C];
+                for (int t = part; t < T; t += parts) {
+                    const int r2 = lw * T + t;
+                    const float* yt = Ys + r2 * C;
+                    const float* dt = Ds + r2 * C;
+                    float sc = kb, dA = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < C) { sc = fmaf(yt[c], kw[c], sc); dA = fmaf(dt[c], vw[c], dA); }
+                    const float a = __expf(sc - Ls[r2 * H + h]);
+                    const float dr = (Mk[((size_t)r2 * H + h) * TB + (s >> 2)] >> (s & 3)) & 1u ? dl.inv_keep : 0.f;
+                    const float ds = a * (dA * dr - Dd[r2 * H + h]);
+                    const float ad = a * dr;
+                    dkb += ds;
+#pragma unroll
+                    for (int c = 0; c < CM; ++c)
+                        if (c < C) { dkw[c] = fmaf(ds, yt[c], dkw[c]); dvw[c] = fmaf(ad, dt[c], dvw[c]); }
+                }
+            }
+            dkb = group_sum(dkb, parts);
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < C) { dkw[c] = group_sum(dkw[c], parts); dvw[c] = group_sum(dvw[c], parts); }
+            if (part == 0) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) {
+                        out[h * q.Wd + c] = dkw[c];
+                        out[h * q.Wd + C + 1 + c] = dvw[c];
+                        if (out16) { out16[h * q.Wd + c] = f2bf(dkw[c]); out16[h * q.Wd + C + 1 + c] = f2bf(dvw[c]); }
+                    }
+                out[h * q.Wd + C] = dkb;
+                if (out16) out16[h * q.Wd + C] = f2bf(dkb);
+            }
+        }
+        if (part == 0)
+            for (int c = H * q.Wd; c < PW; ++c) {
+                out[c] = 0.f;
+                if (out16) out16[c] = 0;
+            }
+    }
+    // ---- the three C-vectors: workgroup sums -> slab; the last workgroup to finish adds the slabs in index order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            const float a = wave_sum(s_w[c]), bb = wave_sum(s_b[c]), d2 = wave_sum(s_d[c]);
+            if (c < C) {
+                if (lane == c) mine = a;
+                if (lane == C + c) mine = bb;
+                if (lane == 2 * C + c) mine = d2;
+            }
+        }
+        const float e2 = wave_sum(s_e);
+        if (lane == 3 * C) mine = e2;
+        red[wave][lane] = mine;
+    }
+    __syncthreads();
+    const int NV = 3 * C + 1;
+    if ((int)threadIdx.x < NV)
+        slabs[(size_t)blockIdx.x * NV + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    {   // value = lane (< 3C), the four waves take every fourth slab
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int G = gridDim.x;
+        if (lane < NV) {
+            int g = wave;
+            for (; g + 12 < G; g += 16) {
+                a0 += __builtin_nontemporal_load(slabs + (size_t)g * NV + lane);
+                a1 += __builtin_nontemporal_load(slabs + (size_t)(g + 4) * NV + lane);
+                a2 += __builtin_nontemporal_load(slabs + (size_t)(g + 8) * NV + lane);
+                a3 += __builtin_nontemporal_load(slabs + (size_t)(g + 12) * NV + lane);
+            }
+            for (; g < G; g += 4) a0 += __builtin_nontemporal_load(slabs + (size_t)g * NV + lane);
+        }
+        red[wave][lane] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int k = threadIdx.x / C, c = threadIdx.x - k * C;
+        if (k == 3) loss[0] = v / navail;
+        else (k == 0 ? g_lnw : k == 1 ? g_lnb : g_bho)[c] = v;
+    }
+    if (threadIdx.x == 0) *ticket = 0u;
+}
+
 inline XQDims xq_dims(const immtsf_fusion_cfg* c) {
     const XRDims x = xr_dims(c);
     XQDims q;
@@ -900,7 +1294,7 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         L.nt(p->proj_q_w, 1, C, C, Wiq, d, d, d, w.AqT, d, 1.f)->xrow = biq;
         L.nn(p->res_w, d, C, p->attn_out_w, d, d, d, w.WHO, d, 1.f);
         L.nt(p->res_w, d, 1, C, p->attn_out_b, d, d, 1, bHO, 1, 1.f)->radd = p->res_b;
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, true));
     }
     {   // per head: GA_h = AqT[:, head] W_in,k[head, :],  UA_h = W_HO[:, head] W_in,v[head, :]  and the bias columns of W_fold
         XJobList L;
@@ -912,7 +1306,7 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
             L.nt(w.WHO + o, d, 1, C, biv + o, E, E, 1, w.Wfb + h * x.Wd + Cq, 1, 1.f);
         }
         if (x.PW > H * x.Wd) L.copy(nullptr, x.PW - H * x.Wd, w.Wfb + H * x.Wd);
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, true));
     }
     {   // W_fold rows: G_h = scale GA_h W_k,  U_h = UA_h W_v  (+ the bf16 image, zero rows up to PW)
         XJobList L;
@@ -922,7 +1316,7 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
             L.nn(w.UA + (size_t)h * C * d, d, C, p->proj_v_w, d, d, d, w.Wf + (r0 + Cq) * d, d, 1.f, hf ? w.Wf16 + (r0 + Cq) * d : nullptr);
         }
         if (x.PW > H * x.Wd) L.copy(nullptr, (x.PW - H * x.Wd) * d, w.Wf + (size_t)H * x.Wd * d, hf ? w.Wf16 + (size_t)H * x.Wd * d : nullptr);
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, true));
     }
     Mat Em = cmat(E_txt);
     if (hf && cfg->in_h) {
@@ -991,7 +1385,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         a->ng = H; a->pgs = (long)Cq * d; a->qgs = (long)Wd * d;
         XJob* b = L.outer(w.UA, d, C, sc.dWf + (size_t)Cq * d, d, d, d, gr->proj_v_w, d, 1.f);
         b->ng = H; b->pgs = (long)C * d; b->qgs = (long)Wd * d;
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, false));
     }
     {   // dAqT_h = scale (T1_h W_in,k[head]^T + d b_fold b_k^T), dW_HO,h = RW_h W_in,v[head]^T + d b_fold b_v^T;  dW_in,k, dW_in,v
         XJobList L;
@@ -1004,7 +1398,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
             L.outer(w.AqT + o, d, Cq, sc.T1 + (size_t)h * Cq * d, d, E, d, g_ik + o * d, d, scale);
             L.outer(w.WHO + o, d, C, sc.RW + (size_t)h * C * d, d, E, d, g_iv + o * d, d, 1.f);
         }
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, false));
     }
     {   // the query side and the output side: W_Qf = W_in,q W_q, W_HO = W_res W_out, b_HO = W_res b_out + b_res
         XJobList L;
@@ -1016,7 +1410,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         XJob* a = L.nt(sc.dWHO, d, 1, C, p->attn_out_w, d, d, d, gr->res_w, d, 1.f);     // dW_res = dW_HO W_out^T + d b_HO b_out^T
         a->lb = dbHO; a->wb = p->attn_out_b;
         L.copy(dbHO, C, gr->res_b);
-        CHECK(L.launch(s));
+        CHECK(L.launch(s, false));
     }
     return IMMTSF_OK;
 }
@@ -1063,6 +1457,42 @@ int immtsf_mmf_xrank_q_backward(const immtsf_fusion_cfg* cfg, const float* ln_w,
     else
         hipLaunchKernelGGL(xrank_q_bwd_kernel<16>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, M_txt, ln_w, w.xhat, w.rstd, w.lse, dY_out, dY_ts, dP,
                            dP16, w.slabs, w.ticket, d_ln_w, d_ln_b, dbHO, drop);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+size_t immtsf_mmf_xrank_q_train_scratch_bytes(const immtsf_fusion_cfg* cfg) {
+    if (!xr_supported(cfg)) return 0;
+    const XRDims x = xr_dims(cfg);
+    return (size_t)cdiv(x.B, xq_wpb(x)) * (3 * x.C + 1) * sizeof(float) + 256;
+}
+
+/* Training step of the Q half in one launch: forward, masked-MSE loss against `truth` under `mask` with the per-variable observation
+ * counts `cnt` (C floats; the loss of immtsf_masked_mse_counted: mean over the variables with a non-zero count of sum err^2 / count),
+ * and backward seeded with d loss = grad_scale.  Y_out may be NULL.  ticket: one zero-initialised device word that the call leaves
+ * zero (calls sharing it must be ordered); scratch: q_train_scratch_bytes. */
+int immtsf_mmf_xrank_q_train(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
+                             const float* bHO, const uint8_t* M_txt, const float* truth, const float* mask, const float* cnt,
+                             float grad_scale, float* Y_out, float* loss, float* dY_ts, float* dP, float* dbHO, float* d_ln_w,
+                             float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !ln_w || !ln_b || !Y_ts || !P || !bHO || !M_txt || !truth || !mask || !cnt || !loss || !dY_ts || !dP || !dbHO ||
+        !d_ln_w || !d_ln_b || !scratch || !ticket)
+        return IMMTSF_EINVAL;
+    if (scratch_bytes < immtsf_mmf_xrank_q_train_scratch_bytes(cfg)) return IMMTSF_EWORKSPACE;
+    const XQDims q = xq_dims(cfg);
+    const XRDims x = xr_dims(cfg);
+    const DropCfg drop = drop_of(cfg);
+    const size_t lds = xq_lds_floats(x) * q.wpb * sizeof(float);
+    const int grid = cdiv(q.B, q.wpb);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(scratch) + 255) & ~uintptr_t(255));
+    unsigned short* dP16 = (xr_hf(cfg) && cfg->out_h) ? static_cast<unsigned short*>(cfg->out_h) : nullptr;
+    if (q.C <= 8)
+        hipLaunchKernelGGL(xrank_q_train_kernel<8>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, truth, mask, cnt, grad_scale, Y_out,
+                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, drop);
+    else
+        hipLaunchKernelGGL(xrank_q_train_kernel<16>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, truth, mask, cnt, grad_scale, Y_out,
+                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, drop);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 from fusions._common import f32, resolve_precision
 from immtsf import config
-from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn, MMFXRankPFn, MMFXRankQFn, mmf_xattn_q_fold, mmf_xrank_pw
+from immtsf.ops import MMFXAttnKVFn, MMFXAttnQFn, MMFXRankPFn, MMFXRankQFn, MMFXRankQLossFn, masked_mse, mmf_xattn_q_fold, mmf_xrank_pw
 
 
 class MMF_XAttn_Add(nn.Module):
@@ -86,6 +86,21 @@ class MMF_XAttn_Add(nn.Module):
                                      resolve_precision(self), self.last_seed, p[9], p[10])
         return MMFXAttnQFn.apply(f32(Y_ts), KV, M_u8, fold, self.n_heads, float(self.kappa), self.p_drop, training,
                                  resolve_precision(self), self.last_seed, p[0], *p[3:])
+
+    def forward_loss(self, Y_ts, E_txt, M_txt, truth, mask, global_cnt, kv=None):
+        """masked_mse(forward(Y_ts, E_txt, M_txt, kv), truth, mask, global_cnt=global_cnt) for a training step: in the low-rank form
+        the head, the loss and the backward of both are one launch (immtsf.ops.MMFXRankQLossFn; the gradients exist when this
+        returns, loss.backward() hands them on); otherwise the two calls."""
+        if not (self._rank(Y_ts.shape[1]) and torch.is_grad_enabled() and global_cnt is not None and config.xattn_fused_loss):
+            return masked_mse(self.forward(Y_ts, E_txt, M_txt, kv=kv), truth, mask, None, global_cnt)
+        B = Y_ts.shape[0]
+        M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
+        training = self.training and self.p_drop > 0.0
+        self.last_seed = config.next_seed() if training else 0
+        P, bHO = self.project_kv(E_txt) if (kv is None or kv[1] is None) else kv
+        p = self._params()
+        return MMFXRankQLossFn.apply(f32(Y_ts), P, bHO, M_u8, f32(truth), f32(mask), global_cnt, self.d_attn, self.n_heads, float(self.kappa),
+                                     self.p_drop, training, resolve_precision(self), self.last_seed, p[9], p[10])
 
 
 from immtsf.dropin import reexport_missing as _reexport_missing  # noqa: E402

@@ -91,3 +91,6 @@ def dropout_counter_ptr(device):
 # key/value + query halves
 import os as _os
 xattn_rank = _os.environ.get("IMMTSF_XATTN_RANK", "1") != "0"
+# ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
+# launch (MMF_XAttn_Add.forward_loss); IMMTSF_XATTN_FUSED_LOSS=0: the Q half and the loss as separate ops
+xattn_fused_loss = _os.environ.get("IMMTSF_XATTN_FUSED_LOSS", "1") != "0"

@@ -564,6 +564,61 @@ class MMFXRankQFn(torch.autograd.Function):
         return (dY, dP, dbHO, None, None, None, None, None, None, None, None) + tuple(rets)
 
 
+_xq_tickets = {}
+
+
+def _xq_ticket(device) -> torch.Tensor:
+    """the zero-initialised ticket word of immtsf_mmf_xrank_q_train: one per device for the life of the process (a captured graph keeps
+    pointing at it; the call leaves it zero; one training step per device at a time)"""
+    key = (device.type, device.index)
+    t = _xq_tickets.get(key)
+    if t is None:
+        t = _xq_tickets[key] = torch.zeros(64, dtype=torch.int32, device=device)
+    return t
+
+
+class MMFXRankQLossFn(torch.autograd.Function):
+    """Q half of the low-rank form + masked MSE (immtsf.ops.masked_mse with global_cnt) + the backward of both, ONE launch: the
+    forward computes the loss and every gradient (seeded with 1); backward() hands them on (scaled unless the seed is
+    backward_unit's).  (Y_ts, P, b_HO, M_txt, truth, mask, cnt, ln_w, ln_b) -> loss."""
+
+    @staticmethod
+    def forward(ctx, Y, P, bHO, M_u8, truth, mask, cnt, d, H, kappa, p_drop, training, precision, seed, ln_w, ln_b):
+        lib = _lib.load()
+        Y, P, bHO, M_u8, ln_w, ln_b = _c(Y), _c(P), _c(bHO), _c(M_u8), _c(ln_w), _c(ln_b)
+        truth, mask, cnt = _c(truth), _c(mask), _c(cnt.to(torch.float32))
+        _need_gpu(Y, P, bHO, M_u8, truth, mask, cnt, ln_w, ln_b)
+        B, T, Cc = Y.shape
+        cfg = make_cfg(B, 0, T, Cc, 0, d, H, precision, training, p_drop, kappa, seed, Y.device)
+        if int(lib.immtsf_mmf_xrank_pw(C.byref(cfg))) != P.shape[2]:
+            raise _lib.ImmtsfError("MMF_XAttn_Add low-rank form: P does not have the row pitch of these dimensions")
+        sc = _bytes(lib.immtsf_mmf_xrank_q_train_scratch_bytes(C.byref(cfg)), Y.device)
+        sinks = _sinks_of((ln_w, ln_b))
+        grads, rets = _grad_buffers((ln_w, ln_b), sinks)
+        dY, dP = torch.empty_like(Y), torch.empty_like(P)
+        dbHO = torch.empty(Cc, dtype=torch.float32, device=Y.device)
+        loss = torch.empty((), dtype=torch.float32, device=Y.device)
+        dP_h = None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            dP_h = torch.empty(dP.shape, dtype=torch.bfloat16, device=dP.device)
+            cfg.out_h = dP_h.data_ptr()
+        check(lib.immtsf_mmf_xrank_q_train(C.byref(cfg), ptr(ln_w), ptr(ln_b), ptr(Y), ptr(P), ptr(bHO), ptr(M_u8), ptr(truth), ptr(mask),
+                                           ptr(cnt), 1.0, None, ptr(loss), ptr(dY), ptr(dP), ptr(dbHO), ptr(grads[0]), ptr(grads[1]),
+                                           ptr(sc), sc.numel(), ptr(_xq_ticket(Y.device)), stream_ptr()), "mmf_xrank_q_train")
+        if dP_h is not None:
+            _shadow_put(dP, dP_h)
+        ctx.grads = (dY, dP, dbHO) + tuple(rets)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g = ctx.grads
+        ctx.grads = None
+        if not is_unit_grad(dloss):
+            g = tuple(None if t is None else t * dloss for t in g)
+        return (g[0], g[1], g[2]) + (None,) * 11 + (g[3], g[4])
+
+
 # ------------------------------------------------------------------------------------------------ MMF_GR_Add
 class MMFGRAddFn(torch.autograd.Function):
     @staticmethod

@@ -50,16 +50,22 @@ def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None)
 _FOLD_ON_SIDE = int(os.environ.get("IMMTSF_FOLD_ON_SIDE", "0") or 0)      # 1: in front of the backbone, 2: behind it
 
 
-def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
+def forecast_and_fuse(model, fusion, batch_dict, side_stream=None, loss=None):
     """backbone forecast -> fusion.  The backbone and the text-timestamp fusion (TTF) do not depend on each other
     -- only the modality fusion (MMF) needs both -- so with `side_stream` the backbone is enqueued on that HIP stream
     while TTF runs on the current one, joined before MMF.  autograd replays each backward on its forward's stream, so
     the two backward halves overlap the same way.  Both halves are latency-bound at 64 windows; overlapping them is
-    worth more than any single kernel."""
+    worth more than any single kernel.
+
+    loss = (truth, mask, global_cnt): return masked_mse(fused forecast, truth, mask, global_cnt=global_cnt) instead of the forecast
+    -- a fusion whose last block can run its head, that loss and the backward of both as one launch (MMF_XAttn_Add.forward_loss)
+    does so."""
+    from immtsf.ops import masked_mse
     notes, tau, tp = batch_dict["notes_embeddings"], batch_dict["tau"], batch_dict["tp_to_predict"]
     fc_args = (tp, batch_dict["observed_data"], batch_dict["observed_tp"], batch_dict["observed_mask"])
     if side_stream is None or not hasattr(fusion, "ttf"):
-        return fusion(notes, tau, tp, model.forecasting(*fc_args))
+        out = fusion(notes, tau, tp, model.forecasting(*fc_args))
+        return out if loss is None else masked_mse(out, loss[0], loss[1], None, loss[2])
     main = torch.cuda.current_stream()
     side_stream.wait_stream(main)
     # Host order: text side first, backbone second.  autograd runs ready backward nodes in reverse creation order, so the
@@ -84,7 +90,10 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None):
             kv = (kv[0], fold)
     main.wait_stream(side_stream)
     pred_y.record_stream(main)
-    return fusion.mmf(pred_y, E_txt, M_txt) if kv is None else fusion.mmf(pred_y, E_txt, M_txt, kv=kv)
+    if loss is not None and hasattr(fusion.mmf, "forward_loss"):
+        return fusion.mmf.forward_loss(pred_y, E_txt, M_txt, loss[0], loss[1], loss[2], kv=kv)
+    out = fusion.mmf(pred_y, E_txt, M_txt) if kv is None else fusion.mmf(pred_y, E_txt, M_txt, kv=kv)
+    return out if loss is None else masked_mse(out, loss[0], loss[1], None, loss[2])
 
 
 def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_embeddings=True, group=None):

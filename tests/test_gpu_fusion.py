@@ -830,6 +830,55 @@ def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision)
         assert err <= tol, (k, err)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (64, 32, 8, 768, 1, 0.1), (300, 6, 15, 16, 1, 0.1)])
+def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precision):
+    """MMF_XAttn_Add.forward_loss (immtsf_mmf_xrank_q_train: the Q half, the masked MSE with known observation counts and the backward
+    of both as ONE kernel) against masked_mse(forward(...)) + autograd: the loss and every gradient, with dropout (same Philox sites)."""
+    dev = _dev()
+    from fusions.MMF_XAttn_Add import MMF_XAttn_Add
+    from immtsf import config
+    from immtsf.ops import backward_unit
+    config.precision = precision
+    torch.manual_seed(B * 7 + T)
+    mmf = MMF_XAttn_Add(d, Cc, d, n_heads_fusion=H, dropout=pd, kappa=0.6).to(dev).train()
+    Y, E = torch.randn(B, T, Cc, device=dev), torch.randn(B, T, d, device=dev)
+    M = (torch.rand(B, device=dev) > 0.25).view(B, 1)
+    M[0] = True
+    truth = torch.randn(B, T, Cc, device=dev)
+    mask = (torch.rand(B, T, Cc, device=dev) > 0.4).float()
+    mask[..., 0] = 0.0 if Cc > 2 else mask[..., 0]        # a variable without observations: out of the mean
+    cnt = mask.reshape(-1, Cc).sum(0)
+    res, seed0 = [], config.next_seed
+    try:
+        config.next_seed = lambda: 777
+        for fused in (True, False):
+            config.xattn_fused_loss = fused
+            mmf.zero_grad()
+            y, e = Y.clone().requires_grad_(True), E.clone().requires_grad_(True)
+            loss = mmf.forward_loss(y, e, M, truth, mask, cnt)
+            if fused:
+                backward_unit(loss)
+            else:
+                loss.backward()
+            res.append([("loss", loss.detach().reshape(1)), ("dY", y.grad), ("dE", e.grad)] + [(k, p_.grad.clone()) for k, p_ in mmf.named_parameters()])
+        # a seed other than backward_unit's: the stored gradients are scaled
+        config.xattn_fused_loss = True
+        mmf.zero_grad()
+        y = Y.clone().requires_grad_(True)
+        (3.0 * mmf.forward_loss(y, E, M, truth, mask, cnt)).backward()
+        assert float((y.grad - 3.0 * res[0][1][1]).abs().max()) <= 1e-5 * float(res[0][1][1].abs().max())
+    finally:
+        config.next_seed, config.xattn_fused_loss, config.precision = seed0, True, "fp32"
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][3:])
+    for (k, a), (_, b) in zip(*res):
+        assert torch.isfinite(a).all(), k
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("loss", "dY", "dE") else 1e-9)
+        err = float((a - b).norm()) / den
+        assert err <= tol, (k, err)
+
+
 def test_grouped_weight_gradient_launch_opt_in():
     """IMMTSF_GEMM_GROUP=1 (csrc/gemm2.hip gemm2_group_kernel: the T2V backward's five TN weight gradients, different shapes, as ONE
     launch at the end of the call; read once per process, so a child process): the bf16 benchmark-shape parity tests still pass."""

@@ -392,7 +392,7 @@ def test_backbone_gradient_sinks_equal_autograd_accumulation():
     tr.close()
 
 
-@pytest.mark.parametrize("kind", ["phased", "flags"])
+@pytest.mark.parametrize("kind", ["phased", "flags", "flags_fused_loss"])
 def test_phased_step_trains_like_eager(kind):
     """immtsf.train.PhasedStep (six single-stream graphs on two streams, the query half's parameter gradients deferred
     behind the text-side backward) and immtsf.train.FlagStep (the same decomposition as ONE graph whose branches synchronise
@@ -417,13 +417,17 @@ def test_phased_step_trains_like_eager(kind):
         E, M = fusion.ttf(batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"])
         return (E, M) + tuple(fusion.mmf.project_kv(E))
 
+    cnt = batch["mask_predicted_data"].reshape(-1, batch["mask_predicted_data"].shape[-1]).sum(0)
+
     def head_fn(pred, E, M, kv, fold):
+        if kind == "flags_fused_loss":       # MMF_XAttn_Add's head + the loss + their backward as one launch (csrc/xrank.hip)
+            return fusion.mmf.forward_loss(pred, E, M, batch["data_to_predict"], batch["mask_predicted_data"], cnt, kv=(kv, fold))
         return masked_mse(fusion.mmf(pred, E, M, kv=(kv, fold)), batch["data_to_predict"], batch["mask_predicted_data"])
 
     st = (PhasedStep if kind == "phased" else FlagStep)(tr, text_fn, lambda: model.forecasting(*fc), head_fn)
     losses = [float(st().detach()) for _ in range(steps)]
     torch.cuda.synchronize()
-    if kind == "flags":
+    if kind != "phased":
         assert not st.timed_out()
     assert losses[-1] < losses[0]
     err = float((tr.flat_param - ref).abs().max() / ref.abs().max())

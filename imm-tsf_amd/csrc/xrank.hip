@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
                                                              float* __restrict__ dY, float* __restrict__ dP,
                                                              unsigned short* __restrict__ dP16, float* __restrict__ slabs, unsigned int* ticket,
                                                              float* __restrict__ g_lnw, float* __restrict__ g_lnb, float* __restrict__ g_bho,
-                                                             float* __restrict__ loss, DropCfg drop) {
+                                                             float* __restrict__ loss, int* done_flag, DropCfg drop) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[4][64];
     __shared__ int s_last;
@@ -1142,6 +1142,16 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
             }
     }
     __syncthreads();
+    // dY_ts is complete for this workgroup: the LAST workgroup to get here publishes `done_flag` (a device flag another stream's
+    // spin kernel waits on, immtsf_flag_wait) -- the backbone's backward starts while phase 2 and the reductions still run
+    if (done_flag && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) {
+            ticket[1] = 0u;
+            __threadfence();
+            __hip_atomic_store(done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // ---- phase 2: group = key row, its lanes split the query rows
     for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
         const int row = idx >> psh, part = idx & (parts - 1);
@@ -1469,12 +1479,15 @@ size_t immtsf_mmf_xrank_q_train_scratch_bytes(const immtsf_fusion_cfg* cfg) {
 
 /* Training step of the Q half in one launch: forward, masked-MSE loss against `truth` under `mask` with the per-variable observation
  * counts `cnt` (C floats; the loss of immtsf_masked_mse_counted: mean over the variables with a non-zero count of sum err^2 / count),
- * and backward seeded with d loss = grad_scale.  Y_out may be NULL.  ticket: one zero-initialised device word that the call leaves
- * zero (calls sharing it must be ordered); scratch: q_train_scratch_bytes. */
+ * and backward seeded with d loss = grad_scale.  Y_out may be NULL.  ticket: two zero-initialised device words that the call leaves
+ * zero (calls sharing them must be ordered); scratch: q_train_scratch_bytes.  done_flag (may be NULL): set to 1 (release, device
+ * scope) as soon as dY_ts is complete -- before the rest of the kernel has run -- for a consumer on another stream that waits with
+ * immtsf_flag_wait. */
 int immtsf_mmf_xrank_q_train(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
                              const float* bHO, const uint8_t* M_txt, const float* truth, const float* mask, const float* cnt,
                              float grad_scale, float* Y_out, float* loss, float* dY_ts, float* dP, float* dbHO, float* d_ln_w,
-                             float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, immtsf_stream_t stream) {
+                             float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, int32_t* done_flag,
+                             immtsf_stream_t stream) {
     if (!xr_supported(cfg) || !ln_w || !ln_b || !Y_ts || !P || !bHO || !M_txt || !truth || !mask || !cnt || !loss || !dY_ts || !dP || !dbHO ||
         !d_ln_w || !d_ln_b || !scratch || !ticket)
         return IMMTSF_EINVAL;
@@ -1489,10 +1502,10 @@ int immtsf_mmf_xrank_q_train(const immtsf_fusion_cfg* cfg, const float* ln_w, co
     unsigned short* dP16 = (xr_hf(cfg) && cfg->out_h) ? static_cast<unsigned short*>(cfg->out_h) : nullptr;
     if (q.C <= 8)
         hipLaunchKernelGGL(xrank_q_train_kernel<8>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, truth, mask, cnt, grad_scale, Y_out,
-                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, drop);
+                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, done_flag, drop);
     else
         hipLaunchKernelGGL(xrank_q_train_kernel<16>, dim3(grid), dim3(256), lds, s, q, Y_ts, P, bHO, M_txt, ln_w, ln_b, truth, mask, cnt, grad_scale, Y_out,
-                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, drop);
+                           dY_ts, dP, dP16, slabs, ticket, d_ln_w, d_ln_b, dbHO, loss, done_flag, drop);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -126,7 +126,7 @@ _PROTOS = {
     "immtsf_mmf_xrank_q_train_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xrank_q_train": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, C.c_float,
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
-                                         c_stream]),
+                                         C.c_void_p, c_stream]),
     "immtsf_mmf_xattn_q_fold_floats": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xattn_q_fold": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_stream]),
     "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_void_p,

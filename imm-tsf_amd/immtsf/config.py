@@ -94,3 +94,6 @@ xattn_rank = _os.environ.get("IMMTSF_XATTN_RANK", "1") != "0"
 # ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
 # launch (MMF_XAttn_Add.forward_loss); IMMTSF_XATTN_FUSED_LOSS=0: the Q half and the loss as separate ops
 xattn_fused_loss = _os.environ.get("IMMTSF_XATTN_FUSED_LOSS", "1") != "0"
+# immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
+head_done_flag = None
+head_dy_ptr = None        # ... and, when a head took the flag: the address of the dY_ts buffer its kernel publishes

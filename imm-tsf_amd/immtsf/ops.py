@@ -585,6 +585,9 @@ class MMFXRankQLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, Y, P, bHO, M_u8, truth, mask, cnt, d, H, kappa, p_drop, training, precision, seed, ln_w, ln_b):
         lib = _lib.load()
+        # the early "dY_ts is ready" flag is only sound when autograd hands THIS call's dY buffer on as Y's gradient: a
+        # non-contiguous Y makes AccumulateGrad clone it into Y's layout (a copy kernel behind this one)
+        y_dense = Y.is_contiguous()
         Y, P, bHO, M_u8, ln_w, ln_b = _c(Y), _c(P), _c(bHO), _c(M_u8), _c(ln_w), _c(ln_b)
         truth, mask, cnt = _c(truth), _c(mask), _c(cnt.to(torch.float32))
         _need_gpu(Y, P, bHO, M_u8, truth, mask, cnt, ln_w, ln_b)
@@ -602,9 +605,15 @@ class MMFXRankQLossFn(torch.autograd.Function):
         if _bf16_dataflow(cfg.precision, cfg.d):
             dP_h = torch.empty(dP.shape, dtype=torch.bfloat16, device=dP.device)
             cfg.out_h = dP_h.data_ptr()
+        # immtsf.train.FlagStep: the device flag the backbone's stream waits on before its backward is published by this kernel as
+        # soon as dY_ts is complete (config.head_done_flag is consumed: the caller sees None and skips its own flag_set)
+        flag = None
+        if y_dense and config.head_done_flag is not None:
+            flag, config.head_done_flag = config.head_done_flag, None
+            config.head_dy_ptr = dY.data_ptr()
         check(lib.immtsf_mmf_xrank_q_train(C.byref(cfg), ptr(ln_w), ptr(ln_b), ptr(Y), ptr(P), ptr(bHO), ptr(M_u8), ptr(truth), ptr(mask),
                                            ptr(cnt), 1.0, None, ptr(loss), ptr(dY), ptr(dP), ptr(dbHO), ptr(grads[0]), ptr(grads[1]),
-                                           ptr(sc), sc.numel(), ptr(_xq_ticket(Y.device)), stream_ptr()), "mmf_xrank_q_train")
+                                           ptr(sc), sc.numel(), ptr(_xq_ticket(Y.device)), flag, stream_ptr()), "mmf_xrank_q_train")
         if dP_h is not None:
             _shadow_put(dP, dP_h)
         ctx.grads = (dY, dP, dbHO) + tuple(rets)

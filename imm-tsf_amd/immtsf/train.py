@@ -754,14 +754,16 @@ class FlagStep(PhasedStep):
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
+        # (before the warm-up: its last Adam pass then leaves the gradient buffer zero, and the captured zero_grad() holds no fill --
+        # set afterwards, a 32 MB fill that both branches wait for sat at the head of every replay)
+        if not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
+            trainer.zero_in_step = True
         snap = trainer.snapshot()
         for _ in range(warmup):
             self._eager_step()
         torch.cuda.synchronize()
         trainer.restore(snap)
         torch.cuda.synchronize()
-        if not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
-            trainer.zero_in_step = True
         self.flags = torch.zeros(16, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
         F_B1, F_T2, F_B2, F_ERR = fp, fp + 4, fp + 8, fp + 32
@@ -784,10 +786,17 @@ class FlagStep(PhasedStep):
                 pred = backbone_fn()
                 fset(F_B1, B)
             fwait(F_B1, T)
+            from . import config
+            config.head_done_flag = F_T2 if os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0" else None
             py, cuts, loss = self._head(pred, outs)
             dpy = py.grad
             dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
-            fset(F_T2, T)
+            if config.head_done_flag is not None or os.environ.get("IMMTSF_HEAD_FLAG", "1") == "0":
+                fset(F_T2, T)                     # (a head that publishes the flag itself -- MMFXRankQLossFn -- has consumed it)
+            elif dpy is None or dpy.data_ptr() != config.head_dy_ptr:
+                raise RuntimeError("FlagStep: the head published its dY flag early, but autograd did not hand that buffer on as the "
+                                   "backbone's output gradient (IMMTSF_HEAD_FLAG=0 disables the early flag)")
+            config.head_done_flag = None
             with torch.cuda.stream(B):
                 fwait(F_T2, B)
                 torch.autograd.backward([pred], [dpy])

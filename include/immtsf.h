@@ -224,13 +224,15 @@ int immtsf_mmf_xrank_q_backward(const immtsf_fusion_cfg* cfg, const float* ln_w,
 /* The Q half's training step in ONE launch: forward, the masked-MSE loss of immtsf_masked_mse_counted against truth / mask (B*T, C)
  * with the per-variable observation counts cnt (C), and the backward seeded with d loss = grad_scale -- everything the backward
  * needs from the forward and the loss is local to a row once the counts are known.  Outputs: loss (1 float), dY_ts, dP (+ bf16
- * image in cfg->out_h), d b_HO, d ln_w, d ln_b; Y_out optional (NULL: not written).  ticket: one zero-initialised device word the
- * call leaves zero (calls that share it must be ordered on their streams). */
+ * image in cfg->out_h), d b_HO, d ln_w, d ln_b; Y_out optional (NULL: not written).  ticket: two zero-initialised device words the
+ * call leaves zero (calls that share them must be ordered on their streams).  done_flag (optional): set to 1 as soon as dY_ts is
+ * complete, for a consumer on another stream that waits with immtsf_flag_wait (the rest of the kernel then overlaps with it). */
 size_t immtsf_mmf_xrank_q_train_scratch_bytes(const immtsf_fusion_cfg* cfg);
 int immtsf_mmf_xrank_q_train(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
                              const float* bHO, const uint8_t* M_txt, const float* truth, const float* mask, const float* cnt,
                              float grad_scale, float* Y_out, float* loss, float* dY_ts, float* dP, float* dbHO, float* d_ln_w,
-                             float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, immtsf_stream_t stream);
+                             float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, int32_t* done_flag,
+                             immtsf_stream_t stream);
 
 /* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
 typedef struct immtsf_gr_params {

@@ -424,7 +424,13 @@ def test_phased_step_trains_like_eager(kind):
             return fusion.mmf.forward_loss(pred, E, M, batch["data_to_predict"], batch["mask_predicted_data"], cnt, kv=(kv, fold))
         return masked_mse(fusion.mmf(pred, E, M, kv=(kv, fold)), batch["data_to_predict"], batch["mask_predicted_data"])
 
-    st = (PhasedStep if kind == "phased" else FlagStep)(tr, text_fn, lambda: model.forecasting(*fc), head_fn)
+    from immtsf import config
+    config.head_dy_ptr = None
+    # (fused loss: a contiguous forecast, as the fused decoder of the benchmark configuration returns it -- the head then publishes
+    # the "dY is ready" flag itself, in the middle of its kernel, and FlagStep leaves its own flag_set out)
+    bb = (lambda: model.forecasting(*fc).contiguous()) if kind == "flags_fused_loss" else (lambda: model.forecasting(*fc))
+    st = (PhasedStep if kind == "phased" else FlagStep)(tr, text_fn, bb, head_fn)
+    assert (config.head_dy_ptr is not None) == (kind == "flags_fused_loss")
     losses = [float(st().detach()) for _ in range(steps)]
     torch.cuda.synchronize()
     if kind != "phased":

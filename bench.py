@@ -494,7 +494,7 @@ def gemm_roofline(w, lib, args, k2=20):
     # HBM traffic of that kernel instance from the committed rocprofv3 PMC passes (tools/pmc_summary.py; counters cannot be
     # read from inside the process): matched by kernel name + layout + launch grid
     traffic, tsrc = None, None
-    for fn in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for fn in ("r03b_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:

@@ -11,5 +11,5 @@ for W in 64 4096; do
   python3 tools/pmc_summary.py $O/${T}_fetch $O/${T}_write $O/${T}.json | head -4
   rm -rf $O/${T}_fetch $O/${T}_write
 done
-cp $O/r03_pmc_w64.json $O/r03_pmc_traffic.json
-cp $O/r03_pmc_w4096.json $O/r03_pmc_traffic_w4096.json
+cp $O/r03_pmc_w64.json $O/${PMC_TAG:-r03}_pmc_traffic.json
+cp $O/r03_pmc_w4096.json $O/${PMC_TAG:-r03}_pmc_traffic_w4096.json

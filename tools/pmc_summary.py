@@ -34,7 +34,9 @@ def main():
                     "write_bytes_per_launch": round(1024.0 * sum(w) / len(w)) if w else None,
                     "fetch_size_raw_kib": round(sum(v) / len(v), 2)})
     res.sort(key=lambda r: -(r["fetch_bytes_per_launch"] * r["launches"]))
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 6 "
+    json.dump({"commit": os.environ.get("IMMTSF_PMC_COMMIT"),            # tree the passes were taken at (the GPU box has no .git)
+               "ms_per_step": float(os.environ["IMMTSF_PMC_MS"]) if os.environ.get("IMMTSF_PMC_MS") else None,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 6 "
                          "--warmup 2 --no-cpu-baseline --no-roofline --no-graph",
                "correction": "fetch bytes = 2 * FETCH_SIZE KiB * 1024 (gfx950 half-count for 16 B/lane streams); write exact",
                "kernels": res[:60]}, open(out, "w"), indent=1)

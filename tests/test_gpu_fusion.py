@@ -786,7 +786,7 @@ def test_mmf_monolithic_entry_equals_the_two_halves():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (3, 13, 5, 48, 4, 0.3), (64, 32, 8, 768, 1, 0.1),
-                                            (2, 260, 8, 64, 1, 0.1), (300, 6, 15, 16, 1, 0.0)])
+                                            (2, 260, 8, 64, 1, 0.1), (300, 6, 15, 16, 1, 0.0), (1, 1, 1, 4, 1, 0.0), (2, 3, 15, 16, 4, 0.25)])
 def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision):
     """MMF_XAttn_Add's low-rank form (csrc/xrank.hip: the text side projected onto the (2C+1) H columns the attention needs, the
     attention + head as one kernel per direction, parameter gradients by the chain rule through the folded factors) against the
@@ -806,6 +806,8 @@ def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision)
     Y, E = torch.randn(B, T, Cc, device=dev), torch.randn(B, T, d, device=dev)
     M = (torch.rand(B, device=dev) > 0.25).view(B, 1)
     M[0] = True
+    if B == 2 and T == 3:
+        M[:] = False          # no window has text: the block degenerates to Y / (1 + kappa), every parameter gradient is zero
     up = torch.randn(B, T, Cc, device=dev)
     res, seed0 = [], config.next_seed
     try:
@@ -825,7 +827,7 @@ def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision)
     for (k, a), (_, b) in zip(*res):
         assert torch.isfinite(a).all(), k
         # floor: the key projection's bias gradient is zero in exact arithmetic; small gradients are compared on the scale of the block's largest
-        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("out", "dY", "dE") else 1e-6)
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("out", "dY", "dE") else 1e-6) + 1e-30
         err = float((a - b).norm()) / den
         assert err <= tol, (k, err)
 

@@ -19,6 +19,7 @@
 #include "ffn32.hpp"
 #include "rowops.hpp"
 #include "skinny_tn.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,9 +77,38 @@ inline bool bad_el(const immtsf_encoder_layer_cfg* c) {
 // ---- the feed-forward half shared by the two block entry points:  out = LN(x1 + drop(drop(act(x1 W1^T + b1)) W2^T + b2))
 // act 1 = ReLU, 2 = GELU(erf).  Saved: h (with its dropout applied), for GELU also the pre-activation z; LN statistics.
 struct FFNDims { int R, D, F, act, prec; float eps; uint64_t site_h, site_out; };
+// GELU feed-forward at PatchTST-like sizes in bf16 mode (round 3): both GEMM operands as bf16 images in HBM -> the LDS-DMA kernel
+// (gemm2.hip) with the activation / dropout / GELU' epilogues, instead of fp32 activations converted while they are staged
+// (gemm.hip: 4608 x 2048 x 512 at 150 - 190 TFLOP/s).  x1 and dff are cast once each (5 us); h and dh exist only as bf16.
+// IMMTSF_FFN_HF=0: the fp32-activation path, for A/B runs.
+struct FFNHf { unsigned short *x16, *h16, *w1h, *w2h, *dff16, *dh16; };
+inline bool ffn_hf(const FFNDims& f) {
+    static const bool on = !(getenv("IMMTSF_FFN_HF") && atoi(getenv("IMMTSF_FFN_HF")) == 0);
+    return on && f.prec == 1 && f.act == 2 && f.R >= 1024 && (f.D % 16) == 0 && (f.F % 16) == 0;
+}
 int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const float* x1, const float* w1, const float* b1,
                 const float* w2, const float* b2, const float* ln_w, const float* ln_b, float* h, float* z, float* ff, float* xhat,
-                float* rstd, float* out, hipStream_t s) {
+                float* rstd, float* out, hipStream_t s, const FFNHf* hf = nullptr) {
+    if (hf) {
+        Mat W1, W2;
+        CHECK(weight_mat(true, w1, (size_t)f.F * f.D, hf->w1h, s, &W1));
+        CHECK(weight_mat(true, w2, (size_t)f.D * f.F, hf->w2h, s, &W2));
+        CHECK(launch_f32_to_bf16(x1, hf->x16, (size_t)f.R * f.D, s));
+        {   // h16 = bf16(dropout(gelu(z))), z = x1 W1^T + b1 kept in fp32 for the backward's GELU'
+            GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.D, f.F);
+            set_problem2(g, 0, cmat(x1, hf->x16), W1, mat(nullptr, hf->h16), b1);
+            g.p[0].Cpre = z;
+            g.act = f.act;
+            g.epi_drop = dd; g.epi_site = f.site_h;
+            CHECK(immtsf_launch_gemm(GEMM_NT, f.prec, g, s));
+        }
+        {
+            GemmArgs g = gemm_args(f.R, f.D, f.F, f.F, f.F, f.D);
+            set_problem2(g, 0, mat(nullptr, hf->h16), W2, mat(ff), b2);
+            CHECK(immtsf_launch_gemm(GEMM_NT, f.prec, g, s));
+        }
+        return launch_layernorm_fwd(ff, f.R, f.D, ln_w, ln_b, f.eps, xhat, rstd, out, none, 0, s, nullptr, x1, dd, f.site_out);
+    }
     if (ffn32_ok(f.R, f.D, f.F, f.act, f.prec)) {       // many rows, d_model 32: h never exists (ffn32.hip); its buffer holds the mask words
         if (ffn32_saved_bytes(f.R, f.F) > (size_t)f.R * f.F * sizeof(float)) return IMMTSF_EWORKSPACE;
         CHECK(ffn32_forward(f.R, f.F, dd, f.site_h, x1, w1, b1, w2, b2, h, ff, s));
@@ -103,7 +133,7 @@ int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const 
 int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int pz, const float* x1, const float* w1, const float* b1,
                  const float* w2, const float* ln_w, const float* h, const float* z, const float* xhat, const float* rstd, const float* dout, float* d1,
                  float* dff, float* dh, float* red, float* gw1, float* gb1, float* gw2, float* gb2, float* gln_w, float* gln_b,
-                 hipStream_t s) {
+                 hipStream_t s, const FFNHf* hf = nullptr) {
     auto wgrad = [&](const float* dy, const float* xin, int N, int K, float* dW, float* db) {
         GemmArgs g = gemm_args(N, K, f.R, N, K, K);
         set_problem(g, 0, dy, xin, dW, nullptr, db);
@@ -119,6 +149,36 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
         if (ffn32_scratch_bytes(f.R, f.F) > (size_t)f.R * f.F * sizeof(float)) return IMMTSF_EWORKSPACE;
         CHECK(ffn32_backward(f.R, f.F, dd, x1, b1, dff, h, dh, d1, gw1, gb1, gw2, s));
         return launch_colsum(dff, nullptr, f.R, nullptr, f.D, f.D, gb2, 0, red, s, true);
+    }
+    if (hf) {
+        Mat W1, W2;
+        CHECK(weight_mat(true, w1, (size_t)f.F * f.D, hf->w1h, s, &W1));
+        CHECK(weight_mat(true, w2, (size_t)f.D * f.F, hf->w2h, s, &W2));
+        CHECK(launch_f32_to_bf16(dff, hf->dff16, (size_t)f.R * f.D, s));
+        const Mat DFF = cmat(dff, hf->dff16), H = mat(nullptr, hf->h16), DH = mat(nullptr, hf->dh16), X = cmat(x1, hf->x16);
+        {   // dh16 = bf16((dff W2) x gelu'(z) x the feed-forward dropout)
+            GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.F, f.F);
+            set_problem2(g, 0, DFF, W2, DH, nullptr);
+            g.relu_ref = z; g.ld_ref = f.F; g.ref_kind = 2;
+            g.epi_drop = dd; g.epi_site = f.site_h;
+            CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
+        }
+        {   // dW2 = dff^T h, db2
+            GemmArgs g = gemm_args(f.D, f.F, f.R, f.D, f.F, f.F);
+            set_problem2(g, 0, DFF, H, mat(gw2), nullptr, gb2);
+            g.c_prezeroed = pz;
+            CHECK(immtsf_launch_gemm(GEMM_TN, f.prec, g, s));
+        }
+        {   // d1 += dh W1
+            GemmArgs g = gemm_args(f.R, f.D, f.F, f.F, f.D, f.D);
+            set_problem2(g, 0, DH, W1, mat(d1), nullptr);
+            g.accumulate = 1;
+            CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
+        }
+        GemmArgs g = gemm_args(f.F, f.D, f.R, f.F, f.D, f.D);      // dW1 = dh^T x1, db1
+        set_problem2(g, 0, DH, X, mat(gw1), nullptr, gb1);
+        g.c_prezeroed = pz;
+        return immtsf_launch_gemm(GEMM_TN, f.prec, g, s);
     }
     {   // linear2: dh = (dff W2) x act'(.) x the feed-forward dropout
         GemmArgs g = gemm_args(f.R, f.F, f.D, f.D, f.F, f.F);
@@ -142,27 +202,36 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
     return wgrad(dh, x1, f.F, f.D, gw1, gb1);
 }
 
-struct FFNWs { float *h, *z, *ff, *xhat, *rstd; size_t bytes; };
-FFNWs carve_ffn(size_t R, size_t D, size_t F, int act, void* base) {
+struct FFNWs { float *h, *z, *ff, *xhat, *rstd; unsigned short *x16, *h16, *w1h, *w2h; size_t bytes; };
+FFNWs carve_ffn(size_t R, size_t D, size_t F, int act, bool hf, void* base) {
     Carver k(base);
     FFNWs w;
-    w.h = k.take<float>(R * F);
+    w.h = hf ? nullptr : k.take<float>(R * F);
     w.z = act == 2 ? k.take<float>(R * F) : nullptr;
     w.ff = k.take<float>(R * D);
     w.xhat = k.take<float>(R * D);
     w.rstd = k.take<float>(R);
+    w.x16 = hf ? k.take<unsigned short>(R * D) : nullptr;
+    w.h16 = hf ? k.take<unsigned short>(R * F) : nullptr;
+    w.w1h = hf ? k.take<unsigned short>(F * D) : nullptr;
+    w.w2h = hf ? k.take<unsigned short>(D * F) : nullptr;
     w.bytes = k.bytes();
     return w;
 }
-struct FFNScratch { float *dff, *dh, *red; size_t bytes; };
-FFNScratch carve_ffn_scratch(size_t R, size_t D, size_t F, void* base) {
+struct FFNScratch { float *dff, *dh, *red; unsigned short *dff16, *dh16; size_t bytes; };
+FFNScratch carve_ffn_scratch(size_t R, size_t D, size_t F, bool hf, void* base) {
     Carver k(base);
     FFNScratch s;
     s.dff = k.take<float>(R * D);
-    s.dh = k.take<float>(R * F);
+    s.dh = hf ? nullptr : k.take<float>(R * F);
     s.red = k.take<float>(colsum_scratch_floats(D, 2));
+    s.dff16 = hf ? k.take<unsigned short>(R * D) : nullptr;
+    s.dh16 = hf ? k.take<unsigned short>(R * F) : nullptr;
     s.bytes = k.bytes();
     return s;
+}
+inline FFNDims ffn_dims(const immtsf_ffn_block_cfg* c) {
+    return FFNDims{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
 }
 inline DropCfg mk_drop3(int training, float p, uint64_t seed, const uint64_t* seed_dev) {
     DropCfg d;
@@ -279,31 +348,39 @@ int immtsf_residual_layernorm_backward(const float* dout, int32_t rows, int32_t 
     return launch_colsum2(g, xhat, rows, d, d, dgamma, dbeta, scratch, s);
 }
 
-size_t immtsf_ffn_block_workspace_bytes(const immtsf_ffn_block_cfg* c) { return bad_ffn(c) ? 0 : carve_ffn(c->R, c->D, c->F, c->act, nullptr).bytes; }
-size_t immtsf_ffn_block_scratch_bytes(const immtsf_ffn_block_cfg* c) { return bad_ffn(c) ? 0 : carve_ffn_scratch(c->R, c->D, c->F, nullptr).bytes; }
+size_t immtsf_ffn_block_workspace_bytes(const immtsf_ffn_block_cfg* c) {
+    return bad_ffn(c) ? 0 : carve_ffn(c->R, c->D, c->F, c->act, ffn_hf(ffn_dims(c)), nullptr).bytes;
+}
+size_t immtsf_ffn_block_scratch_bytes(const immtsf_ffn_block_cfg* c) {
+    return bad_ffn(c) ? 0 : carve_ffn_scratch(c->R, c->D, c->F, ffn_hf(ffn_dims(c)), nullptr).bytes;
+}
 
 int immtsf_ffn_block_forward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_block_params* p, const float* x, float* out, void* workspace,
                              size_t workspace_bytes, immtsf_stream_t stream) {
     if (bad_ffn(c) || !p || !x || !out || !workspace) return IMMTSF_EINVAL;
-    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, workspace);
+    const FFNDims f = ffn_dims(c);
+    const bool hf = ffn_hf(f);
+    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, hf, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
-    const FFNDims f{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
+    const FFNHf im{w.x16, w.h16, w.w1h, w.w2h, nullptr, nullptr};
     return ffn_forward(f, dd, none, x, p->w1, p->b1, p->w2, p->b2, p->ln_w, p->ln_b, w.h, w.z, w.ff, w.xhat, w.rstd, out,
-                       static_cast<hipStream_t>(stream));
+                       static_cast<hipStream_t>(stream), hf ? &im : nullptr);
 }
 
 int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_block_params* p, const float* x, const float* dout, float* dx,
                               void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                               const immtsf_ffn_block_params* gr, immtsf_stream_t stream) {
     if (bad_ffn(c) || !p || !gr || !x || !dout || !dx || !workspace || !scratch) return IMMTSF_EINVAL;
-    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, workspace);
-    FFNScratch sc = carve_ffn_scratch(c->R, c->D, c->F, scratch);
+    const FFNDims f = ffn_dims(c);
+    const bool hf = ffn_hf(f);
+    FFNWs w = carve_ffn(c->R, c->D, c->F, c->act, hf, workspace);
+    FFNScratch sc = carve_ffn_scratch(c->R, c->D, c->F, hf, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
-    const FFNDims f{c->R, c->D, c->F, c->act, c->precision, c->eps, c->site_base, c->site_base + 1};
+    const FFNHf im{w.x16, w.h16, w.w1h, w.w2h, sc.dff16, sc.dh16};
     return ffn_backward(f, dd, none, c->grads_prezeroed ? 1 : 0, x, p->w1, p->b1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
-                        sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream));
+                        sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream), hf ? &im : nullptr);
 }
 
 }  // extern "C"

@@ -31,6 +31,9 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ float gelu_erf2(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf2_grad(float z) {      // Phi(z) + z phi(z)
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
+}
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "vmcnt immediate");
@@ -347,9 +350,15 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
                     atomicAdd(dst + e, x);
                     continue;
                 }
+                if (P.Cpre) P.Cpre[(size_t)row * g.ldc + col + e] = x;        // the pre-activation (what a GELU backward needs)
                 if (g.act == 1) x = fmaxf(x, 0.f);
                 else if (g.act == 2) x = gelu_erf2(x);
-                if (g.relu_ref && g.relu_ref[(size_t)row * g.ld_ref + col + e] <= 0.f) x = 0.f;
+                if (g.epi_drop.p > 0.f) x *= dropout_scale(g.epi_drop, g.epi_site, (uint64_t)row * N + col + e);
+                if (g.relu_ref) {
+                    const float rv = g.relu_ref[(size_t)row * g.ld_ref + col + e];
+                    if (g.ref_kind == 2) x *= gelu_erf2_grad(rv);
+                    else if (rv <= 0.f) x = 0.f;
+                }
                 if (g.accumulate) x += dst[e];
                 v[e] = x;
             }
@@ -458,9 +467,8 @@ extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g) {
     if (layout < 0 || layout > 2 || g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS || g.nbatch > 1) return false;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
-    if (g.epi_drop.p > 0.f || g.ref_kind) return false;       // dropout epilogue, GELU backward factor: the kernel in gemm.hip
-    for (int i = 0; i < g.nprob; ++i)
-        if (g.p[i].Cpre) return false;
+    if (g.ref_kind && (g.ref_kind != 2 || !g.relu_ref)) return false;
+    if ((g.epi_drop.p > 0.f || g.ref_kind) && (g.N & 3)) return false;       // (dropout / GELU' epilogues: round 3, for the FFN block)
     if ((g.lda % 8) || (g.ldb % 8)) return false;
     if (layout == GEMM_TN && (g.a_rowmap || g.b_rowmap)) return false;
     if (layout == GEMM_NN && g.b_rowmap) return false;
@@ -499,7 +507,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     // many rows (forward / data-gradient projections at >= 256 windows per GPU): the persistent ping-pong kernel of gemm3.hip,
     // 1.4-2x this file's tiles from ~190 row tiles of 128 on (profiles/r03_gemm_bigM.txt)
     static const int use_g3 = getenv("IMMTSF_GEMM3") ? atoi(getenv("IMMTSF_GEMM3")) : 1;
-    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && g.act == 0 && !g.relu_ref && !g.accumulate &&
+    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && g.act == 0 && !g.relu_ref && !g.accumulate && g.epi_drop.p <= 0.f && !g.p[0].Cpre &&
         !g.a_rowmap && !g.b_rowmap && !g.ones_col && (!g.row_flag || g.row_flag32) && !(g.dyn && g.dyn_which != 0) &&
         (long)cdiv(Mmax, 128) * cdiv(g.N, 256) >= 192) {
         const GemmProblem& p = g.p[0];
@@ -518,7 +526,8 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     // split-K over workgroups (fp32 atomics into a zeroed C) is only a tool option here: the K-group variants below split
     // the reduction INSIDE a workgroup and sum through LDS, which measured faster at every weight-gradient shape of the
     // fusion step (r02: 768x768x2048 13.1 us unsplit on 64x64 k4 vs 17.9 us as 2 atomic splits of the 4-wave tile)
-    const bool can_split = all_c && !any_h && g.act == 0 && !g.relu_ref && (g.accumulate || g.ldc == g.N) && !(g.dyn && g.dyn_which == 0);
+    const bool can_split = all_c && !any_h && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && !g.p[0].Cpre && (g.accumulate || g.ldc == g.N) &&
+                           !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     if (can_split && g2_splitk > 1) splits = g2_splitk;
     // ... except for LONG reductions on few tiles (weight gradients at >= 512 windows per GPU: 768x768x32768): there the 64x64

@@ -127,6 +127,11 @@ _PROTOS = {
     "immtsf_mmf_xrank_q_train": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, C.c_float,
                                          c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
                                          C.c_void_p, c_stream]),
+    "immtsf_attn_mid_supported": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "immtsf_attn_mid_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                        C.c_int32, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, c_f32p, c_f32p, c_stream]),
+    "immtsf_attn_mid_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_float, C.c_float, C.c_uint64, C.c_uint64, C.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_mmf_xattn_q_fold_floats": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xattn_q_fold": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_stream]),
     "immtsf_mmf_xattn_q_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, C.c_void_p,

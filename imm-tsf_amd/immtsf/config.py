@@ -97,3 +97,6 @@ xattn_fused_loss = _os.environ.get("IMMTSF_XATTN_FUSED_LOSS", "1") != "0"
 # immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
 head_done_flag = None
 head_dy_ptr = None        # ... and, when a head took the flag: the address of the dY_ts buffer its kernel publishes
+# FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); IMMTSF_ATTN_MID=0:
+# batched GEMMs + row softmax
+attn_mid = _os.environ.get("IMMTSF_ATTN_MID", "1") != "0"

@@ -1295,9 +1295,20 @@ class FullAttentionFn(torch.autograd.Function):
         S, D = k.shape[1], v.shape[3]
         dev = q.device
         P = torch.empty(B, H, L, S, dtype=torch.float32, device=dev)
+        p = float(p_drop) if training else 0.0
+        if config.attn_mid and lib.immtsf_attn_mid_supported(L, S, E, D):
+            # few positions, wide heads (PatchTST: 10 x 10 scores with E = 256): one kernel per direction (csrc/attn_mid.hip)
+            cnt = config.dropout_counter_ptr(dev) if p > 0 else None
+            out = torch.empty(B, L, H, D, dtype=torch.float32, device=dev)
+            check(lib.immtsf_attn_mid_forward(ptr(q), ptr(k), ptr(v), B, L, S, H, E, D, float(scale), 1 if causal else 0, p, seed, site, cnt,
+                                              ptr(P), ptr(out), stream_ptr()), "attn_mid_forward")
+            ctx.save_for_backward(q, k, v, P)
+            ctx.cfg = (scale, p, seed, site, precision, cnt)
+            ctx.mid = True
+            return out
+        ctx.mid = False
         check(lib.immtsf_gemm_batched(0, precision, ptr(q), H * E, L * H * E, E, ptr(k), H * E, S * H * E, E, ptr(P), S,
                                       H * L * S, L * S, B, H, L, S, E, float(scale), stream_ptr()), "qk^T")
-        p = float(p_drop) if training else 0.0
         A = torch.empty_like(P) if p > 0 else P
         cnt = config.dropout_counter_ptr(dev) if p > 0 else None
         check(lib.immtsf_softmax_rows_forward(ptr(P), ptr(A), B, H, L, S, None, p, seed, site, 1 if causal else 0, cnt,
@@ -1312,14 +1323,22 @@ class FullAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        q, k, v, P, A = ctx.saved_tensors
+        if ctx.mid:
+            q, k, v, P = ctx.saved_tensors
+            A = None
+        else:
+            q, k, v, P, A = ctx.saved_tensors
         scale, p, seed, site, precision, cnt = ctx.cfg
         B, L, H, E = q.shape
         S, D = k.shape[1], v.shape[3]
         dout = dout.contiguous()
-        dA = torch.empty_like(P)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         st = stream_ptr()
+        if ctx.mid:
+            check(lib.immtsf_attn_mid_backward(ptr(q), ptr(k), ptr(v), ptr(P), ptr(dout), B, L, S, H, E, D, float(scale), p, seed, site, cnt,
+                                               ptr(dq), ptr(dk), ptr(dv), st), "attn_mid_backward")
+            return dq, dk, dv, None, None, None, None, None, None, None
+        dA = torch.empty_like(P)
         # dA = dO V^T ; dV = A^T dO
         check(lib.immtsf_gemm_batched(0, precision, ptr(dout), H * D, L * H * D, D, ptr(v), H * D, S * H * D, D, ptr(dA), S,
                                       H * L * S, L * S, B, H, L, S, D, 1.0, st), "dA")

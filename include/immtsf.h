@@ -234,6 +234,19 @@ int immtsf_mmf_xrank_q_train(const immtsf_fusion_cfg* cfg, const float* ln_w, co
                              float* d_ln_b, void* scratch, size_t scratch_bytes, uint32_t* ticket, int32_t* done_flag,
                              immtsf_stream_t stream);
 
+/* ---- a9, short sequences with wide heads (round 3; csrc/attn_mid.hip): softmax(scale Q K^T) V per (batch, head) on (B, L, H, E) /
+ * (B, S, H, E) / (B, S, H, D) tensors for L, S <= 32 and E, D <= 256 (multiples of 4) -- PatchTST's FullAttention over the patches
+ * of a variable (layers/SelfAttention_Family.py:50-77).  One launch per direction instead of batched GEMMs + row softmax
+ * (3 forward, 5 backward); exact fp32; P (B, H, L, S) = the probabilities before dropout, the dropout indexing is that of
+ * immtsf_softmax_rows_* (site, ((b H + h) L + l) S + s).  causal != 0: TriangularCausalMask. */
+int32_t immtsf_attn_mid_supported(int32_t L, int32_t S, int32_t E, int32_t D);
+int immtsf_attn_mid_forward(const float* q, const float* k, const float* v, int32_t B, int32_t L, int32_t S, int32_t H, int32_t E, int32_t D,
+                            float scale, int32_t causal, float p_drop, uint64_t seed, uint64_t site, const uint64_t* seed_step_dev, float* P,
+                            float* out, immtsf_stream_t stream);
+int immtsf_attn_mid_backward(const float* q, const float* k, const float* v, const float* P, const float* dout, int32_t B, int32_t L, int32_t S,
+                             int32_t H, int32_t E, int32_t D, float scale, float p_drop, uint64_t seed, uint64_t site,
+                             const uint64_t* seed_step_dev, float* dq, float* dk, float* dv, immtsf_stream_t stream);
+
 /* ---- a7: MMF_GR_Add.forward (fusions/MMF_GR_Add.py:31-61; nn.GRU gate order r,z,n; hidden_dim = Hd) */
 typedef struct immtsf_gr_params {
     float *w_ih, *w_hh, *b_ih, *b_hh; /* (3Hd, C+d),(3Hd,Hd),(3Hd),(3Hd)  gru.*_l0 */

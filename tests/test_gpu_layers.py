@@ -73,6 +73,53 @@ def test_full_attention_causal_and_dropout_vs_torch():
     assert _rel(gq, gq_ref.cpu()) < 2e-4
 
 
+@pytest.mark.parametrize("B,L,S,H,E,D", [(3, 10, 10, 2, 256, 256), (2, 32, 32, 1, 64, 32), (5, 7, 12, 3, 24, 40), (1, 1, 1, 1, 4, 4)])
+def test_full_attention_short_wide_one_kernel_vs_torch(B, L, S, H, E, D):
+    """csrc/attn_mid.hip (FullAttention over <= 32 positions, heads up to 256 wide: one kernel per direction) against torch: plain,
+    causal, and with dropout under the exported Philox mask; every gradient; and against the batched-GEMM path it replaces"""
+    dev = _dev()
+    from immtsf import config, ops
+    from layers.SelfAttention_Family import FullAttention
+    g = torch.Generator().manual_seed(L * 100 + E)
+    q = torch.randn(B, L, H, E, generator=g).to(dev).requires_grad_(True)
+    k = torch.randn(B, S, H, E, generator=g).to(dev).requires_grad_(True)
+    v = torch.randn(B, S, H, D, generator=g).to(dev).requires_grad_(True)
+    up = torch.randn(B, L, H, D, generator=g).to(dev)
+    for causal in ((False, True) if L == S else (False,)):
+        fa = FullAttention(causal, attention_dropout=0.0).to(dev)
+        o, _ = fa(q, k, v, None)
+        s_ = torch.einsum("blhe,bshe->bhls", q, k) / E ** 0.5
+        if causal:
+            s_ = s_.masked_fill(torch.triu(torch.ones(L, S, dtype=torch.bool, device=dev), 1), float("-inf"))
+        ref = torch.einsum("bhls,bshd->blhd", torch.softmax(s_, -1), v)
+        assert _rel(o, ref.detach().cpu()) < 1e-5
+        got = torch.autograd.grad((o * up).sum(), (q, k, v))
+        want = torch.autograd.grad((ref * up).sum(), (q, k, v))
+        for a, b in zip(got, want):
+            assert _rel(a, b.cpu()) < 1e-4
+    config.manual_seed(7)
+    fd = FullAttention(False, attention_dropout=0.3).to(dev).train()
+    o2, _ = fd(q, k, v, None)
+    config.manual_seed(7)
+    seed = config.next_seed()
+    keep = ops.dropout_keep_mask(seed, fd.site, B * H * L * S, 0.3, dev).view(B, H, L, S).float()
+    a_ = torch.softmax(torch.einsum("blhe,bshe->bhls", q, k) / E ** 0.5, -1) * keep / 0.7
+    ref2 = torch.einsum("bhls,bshd->blhd", a_, v)
+    assert _rel(o2, ref2.detach().cpu()) < 1e-5
+    got = torch.autograd.grad((o2 * up).sum(), (q, k, v))
+    want = torch.autograd.grad((ref2 * up).sum(), (q, k, v))
+    for a, b in zip(got, want):
+        assert _rel(a, b.cpu()) < 1e-4
+    # the batched-GEMM path with the same seed draws the same mask
+    try:
+        config.attn_mid = False
+        config.manual_seed(7)
+        o3, _ = fd(q, k, v, None)
+    finally:
+        config.attn_mid = True
+    assert _rel(o3, o2.detach().cpu()) < 1e-4
+
+
 def _load(mod, z):
     sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
     missing = mod.load_state_dict(sd, strict=False)

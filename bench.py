@@ -336,7 +336,7 @@ class Workload:
         self.trainer.close()
 
 
-FLAGS_MAX_WINDOWS = 128      # FlagStep wins where the step is a latency chain (64 windows: -3 %); from 256 windows on GraphedStep does
+FLAGS_MAX_WINDOWS = 512      # FlagStep wins where the step is a latency chain (64 windows: -3 %, 256: -2 %, 512: -1 %); beyond, GraphedStep
 
 
 def flag_step(w):

@@ -27,13 +27,15 @@
 #include "tail.hpp"
 #include "block_util.hpp"
 #include <math.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // small multi-job launches: every product of the fold / chain rule has <= 16 rows or rank <= 16 per group
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr int XR = 16;            // rows of an NN / NT job, rank per group of an OUTER job
+constexpr int XR = 8;             // rows of an NN / NT job (the host splits taller products); OUTER jobs walk their rank in chunks of XR
 constexpr int XJ_MAX = 20;
 enum { XJ_NN = 0, XJ_NT = 1, XJ_OUTER = 2, XJ_COPY = 3 };
 struct XJob {
@@ -79,7 +81,7 @@ __device__ __forceinline__ bool xjob_stage_l(const XJob& J, float* Ls, int cap) 
 
 template <bool STAGED>
 __device__ __forceinline__ void xjob_nn_acc(const XJob& J, int kg, int n, const float* Ls, float4 (&acc)[XR]) {
-    constexpr int U = STAGED ? 12 : 6;
+    constexpr int U = STAGED ? 8 : 6;
     const int R = J.R;
     for (int k0 = kg; k0 < J.K; k0 += 64 * U) {
         float4 w[U];
@@ -290,38 +292,40 @@ __device__ __forceinline__ void xjob_outer(const XJob& J, int blk) {
     for (int g = 0; g < J.ng; ++g) {
         const float* P = J.L + g * J.pgs;
         const float* Q = J.W + g * J.qgs;
-        float4 pv[XR], qv[XR];
+        for (int j0 = 0; j0 < J.R; j0 += XR) {
+            float4 pv[XR], qv[XR];
 #pragma unroll
-        for (int j = 0; j < XR; ++j) {
-            pv[j] = qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < J.R) {
-                if (vp) pv[j] = *reinterpret_cast<const float4*>(P + (size_t)j * J.lsr + m0);
-                else {
-                    const float* pp = P + (size_t)j * J.lsr;
-                    pv[j].x = pp[(size_t)m0 * J.lsn];
-                    if (m0 + 1 < J.M) pv[j].y = pp[(size_t)(m0 + 1) * J.lsn];
-                    if (m0 + 2 < J.M) pv[j].z = pp[(size_t)(m0 + 2) * J.lsn];
-                    if (m0 + 3 < J.M) pv[j].w = pp[(size_t)(m0 + 3) * J.lsn];
-                }
-                if (vq) qv[j] = *reinterpret_cast<const float4*>(Q + (size_t)j * J.ldw + n0);
-                else {
-                    const float* qq = Q + (size_t)j * J.ldw;
-                    qv[j].x = qq[(size_t)n0 * J.qsn];
-                    if (n0 + 1 < J.N) qv[j].y = qq[(size_t)(n0 + 1) * J.qsn];
-                    if (n0 + 2 < J.N) qv[j].z = qq[(size_t)(n0 + 2) * J.qsn];
-                    if (n0 + 3 < J.N) qv[j].w = qq[(size_t)(n0 + 3) * J.qsn];
+            for (int jj = 0; jj < XR; ++jj) {
+                const int j = j0 + jj;
+                pv[jj] = qv[jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (j < J.R) {
+                    if (vp) pv[jj] = *reinterpret_cast<const float4*>(P + (size_t)j * J.lsr + m0);
+                    else {
+                        const float* pp = P + (size_t)j * J.lsr;
+                        pv[jj].x = pp[(size_t)m0 * J.lsn];
+                        if (m0 + 1 < J.M) pv[jj].y = pp[(size_t)(m0 + 1) * J.lsn];
+                        if (m0 + 2 < J.M) pv[jj].z = pp[(size_t)(m0 + 2) * J.lsn];
+                        if (m0 + 3 < J.M) pv[jj].w = pp[(size_t)(m0 + 3) * J.lsn];
+                    }
+                    if (vq) qv[jj] = *reinterpret_cast<const float4*>(Q + (size_t)j * J.ldw + n0);
+                    else {
+                        const float* qq = Q + (size_t)j * J.ldw;
+                        qv[jj].x = qq[(size_t)n0 * J.qsn];
+                        if (n0 + 1 < J.N) qv[jj].y = qq[(size_t)(n0 + 1) * J.qsn];
+                        if (n0 + 2 < J.N) qv[jj].z = qq[(size_t)(n0 + 2) * J.qsn];
+                        if (n0 + 3 < J.N) qv[jj].w = qq[(size_t)(n0 + 3) * J.qsn];
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < XR; ++j)
-            if (j < J.R) {
-                const float p[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w}, q[4] = {qv[j].x, qv[j].y, qv[j].z, qv[j].w};
+            for (int jj = 0; jj < XR; ++jj) {
+                const float p[4] = {pv[jj].x, pv[jj].y, pv[jj].z, pv[jj].w}, q[4] = {qv[jj].x, qv[jj].y, qv[jj].z, qv[jj].w};
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(p[a], q[b], acc[a][b]);
             }
+        }
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -338,7 +342,7 @@ __device__ __forceinline__ void xjob_outer(const XJob& J, int blk) {
 }
 
 typedef const XJobs* XJobsK;
-__global__ __launch_bounds__(256) void xjobs_kernel(XJobs js_arg) {
+__global__ __launch_bounds__(256, 2) void xjobs_kernel(XJobs js_arg) {
     extern __shared__ __attribute__((aligned(16))) float Ls[];      // lds_floats floats
     __shared__ __attribute__((aligned(16))) float red[4 * XR * 16];
     // the job table is read where it lies, in the kernel-argument segment (scalar loads at a run-time offset): indexing the by-value
@@ -365,29 +369,35 @@ __global__ __launch_bounds__(256) void xjobs_kernel(XJobs js_arg) {
 }
 
 struct XJobList {
-    XJobs js;
-    int blocks = 0;
-    bool overflow = false;
-    XJobList() { js.n = 0; memset(js.first, 0, sizeof(js.first)); }
+    std::vector<XJob> jobs;
     XJob* add(int form, int nblk) {
-        if (js.n >= XJ_MAX) { overflow = true; return &js.j[XJ_MAX - 1]; }
-        js.first[js.n] = blocks;
-        XJob* j = &js.j[js.n++];
+        jobs.emplace_back();
+        XJob* j = &jobs.back();
         memset(j, 0, sizeof(XJob));
         j->form = form; j->nblk = nblk; j->alpha = 1.f; j->lsn = 1; j->osn = 1; j->qsn = 1; j->ng = 1;
-        blocks += nblk;
         return j;
     }
+    // (products taller than XR rows are split into row chunks: a job's accumulators are sized for XR)
     void nn(const float* L, int lsr, int R, const float* W, int ldw, int K, int N, float* out, int osr, float alpha, unsigned short* out16 = nullptr,
             int osn = 1) {
-        XJob* j = add(XJ_NN, cdiv(N, 16));
-        j->L = L; j->lsr = lsr; j->R = R; j->W = W; j->ldw = ldw; j->K = K; j->N = N; j->out = out; j->osr = osr; j->osn = osn; j->alpha = alpha;
-        j->out16 = out16;
+        for (int r0 = 0; r0 < R; r0 += XR) {
+            XJob* j = add(XJ_NN, cdiv(N, 16));
+            j->L = L + (size_t)r0 * lsr; j->lsr = lsr; j->R = std::min(XR, R - r0); j->W = W; j->ldw = ldw; j->K = K; j->N = N;
+            j->out = out + (size_t)r0 * osr; j->osr = osr; j->osn = osn; j->alpha = alpha;
+            j->out16 = out16 ? out16 + (size_t)r0 * osr : nullptr;
+        }
     }
-    XJob* nt(const float* L, int lsr, int lsn, int R, const float* W, int ldw, int K, int Mout, float* out, int osr, float alpha) {
-        XJob* j = add(XJ_NT, cdiv(Mout, 8));
-        j->L = L; j->lsr = lsr; j->lsn = lsn; j->R = R; j->W = W; j->ldw = ldw; j->K = K; j->N = Mout; j->out = out; j->osr = osr; j->alpha = alpha;
-        return j;
+    // lb / radd: per-row vectors (advance with the row chunk), wb: per-column vector, xrow: copied into row R (by the last chunk)
+    void nt(const float* L, int lsr, int lsn, int R, const float* W, int ldw, int K, int Mout, float* out, int osr, float alpha,
+            const float* lb = nullptr, const float* wb = nullptr, const float* radd = nullptr, const float* xrow = nullptr) {
+        for (int r0 = 0; r0 < R; r0 += XR) {
+            XJob* j = add(XJ_NT, cdiv(Mout, 8));
+            const int rc = std::min(XR, R - r0);
+            j->L = L + (size_t)r0 * lsr; j->lsr = lsr; j->lsn = lsn; j->R = rc; j->W = W; j->ldw = ldw; j->K = K; j->N = Mout;
+            j->out = out + (size_t)r0 * osr; j->osr = osr; j->alpha = alpha;
+            j->lb = lb ? lb + r0 : nullptr; j->wb = wb; j->radd = radd ? radd + r0 : nullptr;
+            j->xrow = (xrow && r0 + rc == R) ? xrow : nullptr;
+        }
     }
     XJob* outer(const float* P, int lsr, int rank, const float* Q, int ldq, int M, int N, float* out, int osr, float alpha) {
         XJob* j = add(XJ_OUTER, cdiv(M, 16) * cdiv(N, 256));
@@ -402,18 +412,25 @@ struct XJobList {
     // LDS-hungry; without it every job reads L from global memory (no LDS beyond 4 KB: the backward's launches share the chip with the
     // backbone's backward, whose workgroups would otherwise wait for LDS behind several hundred 30 KB workgroups)
     int launch(hipStream_t s, bool stage) {
-        if (overflow) return IMMTSF_EUNSUPPORTED;
-        if (!blocks) return IMMTSF_OK;
-        int fl = 0;
-        if (stage)
-            for (int i = 0; i < js.n; ++i) {
-                const XJob& j = js.j[i];
+        for (size_t b0 = 0; b0 < jobs.size(); b0 += XJ_MAX) {
+            XJobs js;
+            memset(&js, 0, sizeof(js));
+            int blocks = 0, fl = 0;
+            const int n = (int)std::min<size_t>(XJ_MAX, jobs.size() - b0);
+            for (int i = 0; i < n; ++i) {
+                const XJob& j = jobs[b0 + i];
+                js.j[i] = j;
+                js.first[i] = blocks;
+                blocks += j.nblk;
                 const bool wants = j.form == XJ_NN || (j.form == XJ_NT && j.lsn != 1);
-                if (wants && j.R * j.K <= XJ_LK && j.R * j.K > fl) fl = j.R * j.K;
+                if (stage && wants && j.R * j.K <= XJ_LK && j.R * j.K > fl) fl = j.R * j.K;
             }
-        js.lds_floats = fl;
-        hipLaunchKernelGGL(xjobs_kernel, dim3(blocks), dim3(256), (size_t)fl * sizeof(float), s, js);
-        IMMTSF_LAUNCH_CHECK();
+            js.n = n;
+            js.lds_floats = fl;
+            if (!blocks) continue;
+            hipLaunchKernelGGL(xjobs_kernel, dim3(blocks), dim3(256), (size_t)fl * sizeof(float), s, js);
+            IMMTSF_LAUNCH_CHECK();
+        }
         return IMMTSF_OK;
     }
 };
@@ -1301,9 +1318,9 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
     const float *biq = p->attn_in_b, *bik = p->attn_in_b + d, *biv = p->attn_in_b + 2 * d;
     {   // AqT = [W_in,q W_q | b_q]^T ((C+1) x d);  W_HO = W_res W_out (C x d);  b_HO = W_res b_out + b_res
         XJobList L;
-        L.nt(p->proj_q_w, 1, C, C, Wiq, d, d, d, w.AqT, d, 1.f)->xrow = biq;
+        L.nt(p->proj_q_w, 1, C, C, Wiq, d, d, d, w.AqT, d, 1.f, nullptr, nullptr, nullptr, biq);
         L.nn(p->res_w, d, C, p->attn_out_w, d, d, d, w.WHO, d, 1.f);
-        L.nt(p->res_w, d, 1, C, p->attn_out_b, d, d, 1, bHO, 1, 1.f)->radd = p->res_b;
+        L.nt(p->res_w, d, 1, C, p->attn_out_b, d, d, 1, bHO, 1, 1.f, nullptr, nullptr, p->res_b);
         CHECK(L.launch(s, true));
     }
     {   // per head: GA_h = AqT[:, head] W_in,k[head, :],  UA_h = W_HO[:, head] W_in,v[head, :]  and the bias columns of W_fold
@@ -1401,10 +1418,8 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         XJobList L;
         for (int h = 0; h < H; ++h) {
             const size_t r0 = (size_t)h * Wd, o = (size_t)h * E;
-            XJob* a = L.nt(sc.T1 + (size_t)h * Cq * d, d, 1, Cq, Wik + o * d, d, d, E, sc.dAqT + o, d, scale);
-            a->lb = sc.dWfb + r0; a->wb = bik + o;
-            XJob* b = L.nt(sc.RW + (size_t)h * C * d, d, 1, C, Wiv + o * d, d, d, E, sc.dWHO + o, d, 1.f);
-            b->lb = sc.dWfb + r0 + Cq; b->wb = biv + o;
+            L.nt(sc.T1 + (size_t)h * Cq * d, d, 1, Cq, Wik + o * d, d, d, E, sc.dAqT + o, d, scale, sc.dWfb + r0, bik + o);
+            L.nt(sc.RW + (size_t)h * C * d, d, 1, C, Wiv + o * d, d, d, E, sc.dWHO + o, d, 1.f, sc.dWfb + r0 + Cq, biv + o);
             L.outer(w.AqT + o, d, Cq, sc.T1 + (size_t)h * Cq * d, d, E, d, g_ik + o * d, d, scale);
             L.outer(w.WHO + o, d, C, sc.RW + (size_t)h * C * d, d, E, d, g_iv + o * d, d, 1.f);
         }
@@ -1417,8 +1432,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         L.nn(sc.dAqT, d, C, Wiq, d, d, d, gr->proj_q_w, 1, 1.f, nullptr, C);             // dW_q[k][c] = sum_m dAqT[c][m] W_in,q[m][k]
         L.outer(p->res_w, d, C, sc.dWHO, d, d, d, gr->attn_out_w, d, 1.f);               // dW_out = W_res^T dW_HO
         L.outer(p->res_w, d, C, dbHO, 1, d, 1, gr->attn_out_b, 1, 1.f);                  // d b_out = W_res^T d b_HO
-        XJob* a = L.nt(sc.dWHO, d, 1, C, p->attn_out_w, d, d, d, gr->res_w, d, 1.f);     // dW_res = dW_HO W_out^T + d b_HO b_out^T
-        a->lb = dbHO; a->wb = p->attn_out_b;
+        L.nt(sc.dWHO, d, 1, C, p->attn_out_w, d, d, d, gr->res_w, d, 1.f, dbHO, p->attn_out_b);     // dW_res = dW_HO W_out^T + d b_HO b_out^T
         L.copy(dbHO, C, gr->res_b);
         CHECK(L.launch(s, false));
     }

@@ -16,6 +16,7 @@
 #include "../../include/immtsf.h"
 #include "attn.hpp"
 #include "block_util.hpp"
+#include "enc_head.hpp"
 #include "ffn32.hpp"
 #include "rowops.hpp"
 #include "skinny_tn.hpp"
@@ -45,11 +46,13 @@ ELWs carve_el(size_t R, size_t D, size_t F, void* base) {
 }
 struct ELScratch {
     float *d1, *dff, *dh, *dsa, *da, *dqkv, *red, *sk;      // sk: slabs of the skinny weight-gradient kernel (d_model <= 64)
+    float* eh;                                               // slabs of the fused attention half (enc_head.hip)
     size_t bytes;
 };
-ELScratch carve_el_scratch(size_t R, size_t D, size_t F, void* base) {
+ELScratch carve_el_scratch(size_t R, size_t D, size_t F, void* base, size_t eh_floats = 0) {
     Carver k(base);
     ELScratch s;
+    s.eh = eh_floats ? k.take<float>(eh_floats) : nullptr;
     s.d1 = k.take<float>(R * D);
     s.dff = k.take<float>(R * D);
     s.dh = k.take<float>(R * F);
@@ -68,6 +71,9 @@ inline DropCfg el_drop(const immtsf_encoder_layer_cfg* c, float p) {
     d.inv_keep = d.p > 0.f ? 1.f / (1.f - d.p) : 1.f;
     d.seed_dev = c->seed_step_dev;
     return d;
+}
+inline size_t el_eh_floats(const immtsf_encoder_layer_cfg* c) {
+    return enc_head32_ok(c->Bs, c->S, c->D, c->H) ? enc_head32_slab_floats(c->Bs, c->S, c->H) : 0;
 }
 inline bool bad_el(const immtsf_encoder_layer_cfg* c) {
     return !c || c->Bs <= 0 || c->S <= 0 || c->D <= 0 || c->H <= 0 || c->F <= 0 || (c->D % c->H) || (c->D & 3) || c->D > 1024 ||
@@ -254,7 +260,7 @@ size_t immtsf_encoder_layer_workspace_bytes(const immtsf_encoder_layer_cfg* c) {
     return bad_el(c) ? 0 : carve_el((size_t)c->Bs * c->S, c->D, c->F, nullptr).bytes;
 }
 size_t immtsf_encoder_layer_scratch_bytes(const immtsf_encoder_layer_cfg* c) {
-    return bad_el(c) ? 0 : carve_el_scratch((size_t)c->Bs * c->S, c->D, c->F, nullptr).bytes;
+    return bad_el(c) ? 0 : carve_el_scratch((size_t)c->Bs * c->S, c->D, c->F, nullptr, el_eh_floats(c)).bytes;
 }
 
 int immtsf_encoder_layer_forward(const immtsf_encoder_layer_cfg* c, const immtsf_encoder_layer_params* p, const float* x, float* out,
@@ -265,18 +271,23 @@ int immtsf_encoder_layer_forward(const immtsf_encoder_layer_cfg* c, const immtsf
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DropCfg da = el_drop(c, c->p_attn), dd = el_drop(c, c->p_drop), none = el_drop(c, 0.f);
-    {   // packed in-projection
-        GemmArgs g = gemm_args(R, 3 * D, D, D, D, 3 * D);
-        set_problem(g, 0, x, p->in_w, w.qkv, p->in_b);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    if (enc_head32_ok(c->Bs, c->S, D, c->H)) {       // d_model 32: projections, attention and LayerNorm1 as one kernel (enc_head.hip)
+        CHECK(launch_enc_head32_fwd(x, c->Bs, c->S, c->H, p->in_w, p->in_b, p->out_w, p->out_b, p->ln1_w, p->ln1_b, c->eps, da, dd,
+                                    c->site_base + 0, w.x1, w.xhat1, w.rstd1, s));
+    } else {
+        {   // packed in-projection
+            GemmArgs g = gemm_args(R, 3 * D, D, D, D, 3 * D);
+            set_problem(g, 0, x, p->in_w, w.qkv, p->in_b);
+            CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+        }
+        CHECK(launch_attn_short_fwd(w.qkv, c->Bs, c->S, c->H, E, 1.0f / sqrtf((float)E), 0, da, c->site_base + 0, w.a, s));
+        {
+            GemmArgs g = gemm_args(R, D, D, D, D, D);
+            set_problem(g, 0, w.a, p->out_w, w.sa, p->out_b);
+            CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+        }
+        CHECK(launch_layernorm_fwd(w.sa, R, D, p->ln1_w, p->ln1_b, c->eps, w.xhat1, w.rstd1, w.x1, none, 0, s, nullptr, x, dd, c->site_base + 1));
     }
-    CHECK(launch_attn_short_fwd(w.qkv, c->Bs, c->S, c->H, E, 1.0f / sqrtf((float)E), 0, da, c->site_base + 0, w.a, s));
-    {
-        GemmArgs g = gemm_args(R, D, D, D, D, D);
-        set_problem(g, 0, w.a, p->out_w, w.sa, p->out_b);
-        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
-    }
-    CHECK(launch_layernorm_fwd(w.sa, R, D, p->ln1_w, p->ln1_b, c->eps, w.xhat1, w.rstd1, w.x1, none, 0, s, nullptr, x, dd, c->site_base + 1));
     const FFNDims f{R, D, F, 1, prec, c->eps, c->site_base + 2, c->site_base + 3};
     return ffn_forward(f, dd, none, w.x1, p->w1, p->b1, p->w2, p->b2, p->ln2_w, p->ln2_b, w.h, nullptr, w.ff, w.xhat2, w.rstd2, out, s);
 }
@@ -289,7 +300,7 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
     if (bad_el(c) || !p || !gr || !x || !dout || !dx || !workspace || !scratch) return IMMTSF_EINVAL;
     const int R = c->Bs * c->S, D = c->D, F = c->F, E = D / c->H, prec = c->precision;
     ELWs w = carve_el(R, D, F, workspace);
-    ELScratch sc = carve_el_scratch(R, D, F, scratch);
+    ELScratch sc = carve_el_scratch(R, D, F, scratch, el_eh_floats(c));
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DropCfg da = el_drop(c, c->p_attn), dd = el_drop(c, c->p_drop), none = el_drop(c, 0.f);
@@ -307,6 +318,9 @@ int immtsf_encoder_layer_backward(const immtsf_encoder_layer_cfg* c, const immts
         CHECK(ffn_backward(f, dd, none, pz, w.x1, p->w1, p->b1, p->w2, p->ln2_w, w.h, nullptr, w.xhat2, w.rstd2, dout, sc.d1, sc.dff, sc.dh, sc.red,
                            gr->w1, gr->b1, gr->w2, gr->b2, gr->ln2_w, gr->ln2_b, s));
     }
+    if (sc.eh)        // the attention half's backward as one kernel + the slab sum
+        return launch_enc_head32_bwd(x, sc.d1, w.xhat1, w.rstd1, c->Bs, c->S, c->H, p->in_w, p->in_b, p->out_w, p->out_b, p->ln1_w, c->eps, da, dd,
+                                     c->site_base + 0, dx, gr->in_w, gr->in_b, gr->out_w, gr->out_b, gr->ln1_w, gr->ln1_b, sc.eh, s);
     // LayerNorm1: dx = gradient of (x + drop(sa)) -- the input's residual share; dsa = dx * dropout mask
     CHECK(launch_layernorm_bwd(sc.d1, R, D, p->ln1_w, w.xhat1, w.rstd1, dx, none, 0, s, sc.dsa, dd, c->site_base + 1));
     CHECK(launch_colsum2(sc.d1, w.xhat1, R, D, D, gr->ln1_w, gr->ln1_b, sc.red, s, true));

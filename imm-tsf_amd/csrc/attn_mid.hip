@@ -26,17 +26,25 @@ __device__ __forceinline__ void am_stage(float* dst, int pitch, const float* src
 // dot[l][s] = sum_e X[l][e] Y[s][e] for all (l, s): a wave takes rows l = wave, wave + 4, ...; lanes stride e in 16-byte steps
 __device__ __forceinline__ void am_dots(const float* X, int px, int L, const float* Y, int py, int S, int E, float* out /* [L][AM_L] */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = lane * 4;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = wave; l < L; l += 4) {
-        const int e0 = lane * 4;
-        const float4 x = e0 < E ? *reinterpret_cast<const float4*>(X + l * px + e0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s = 0; s < S; ++s) {
-            float a = 0.f;
-            if (e0 < E) {
-                const float4 y = *reinterpret_cast<const float4*>(Y + s * py + e0);
-                a = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w)));
+        const float4 x = e0 < E ? *reinterpret_cast<const float4*>(X + l * px + e0) : z4;
+        for (int s0 = 0; s0 < S; s0 += 8) {          // eight keys at a time: their LDS reads and lane sums are independent chains
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 y = (s0 + u < S && e0 < E) ? *reinterpret_cast<const float4*>(Y + (s0 + u) * py + e0) : z4;
+                a[u] = fmaf(x.x, y.x, fmaf(x.y, y.y, fmaf(x.z, y.z, x.w * y.w)));
             }
-            a = wave_sum(a);
-            if (lane == 0) out[l * AM_L + s] = a;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = wave_sum(a[u]);
+            if (lane < 8 && s0 + lane < S) {
+                float v = a[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) v = lane == u ? a[u] : v;
+                out[l * AM_L + s0 + lane] = v;
+            }
         }
     }
 }
@@ -57,20 +65,17 @@ __global__ __launch_bounds__(256) void attn_mid_fwd_kernel(AmDims d, const float
     __syncthreads();
     am_dots(Qs, pe, L, Ks, pe, S, E, Sc);
     __syncthreads();
-    if ((int)threadIdx.x < L) {          // softmax + dropout of row l
-        const int l = threadIdx.x;
+    for (int i = threadIdx.x; i < L * S; i += 256) {          // softmax + dropout: a thread per (l, s), the row statistics recomputed per thread
+        const int l = i / S, s = i - l * S;
         const int Sv = d.causal ? min(S, l + 1) : S;
         float m = -INFINITY;
-        for (int s = 0; s < Sv; ++s) m = fmaxf(m, d.scale * Sc[l * AM_L + s]);
+        for (int t = 0; t < Sv; ++t) m = fmaxf(m, d.scale * Sc[l * AM_L + t]);
         float sum = 0.f;
-        for (int s = 0; s < Sv; ++s) sum += expf(d.scale * Sc[l * AM_L + s] - m);
-        const float inv = 1.f / sum;
+        for (int t = 0; t < Sv; ++t) sum += expf(d.scale * Sc[l * AM_L + t] - m);
         const uint64_t row = ((uint64_t)b * H + h) * L + l;
-        for (int s = 0; s < S; ++s) {
-            const float p = s < Sv ? expf(d.scale * Sc[l * AM_L + s] - m) * inv : 0.f;
-            P[row * S + s] = p;
-            Ad[l * AM_L + s] = p * dropout_scale(drop, site, row * S + s);
-        }
+        const float p = s < Sv ? expf(d.scale * Sc[l * AM_L + s] - m) / sum : 0.f;
+        P[row * S + s] = p;
+        Ad[l * AM_L + s] = p * dropout_scale(drop, site, row * S + s);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256)
@@ -114,16 +119,24 @@ __global__ __launch_bounds__(256) void attn_mid_bwd_kernel(AmDims d, const float
             dv[(((long)b * S + s) * H + h) * D + c] = a;
         }
     __syncthreads();
-    if ((int)threadIdx.x < L) {          // dS = P (dA x dropout - sum_s P dA x dropout), as immtsf_softmax_rows_backward
-        const int l = threadIdx.x;
-        float dot = 0.f;
-        for (int s = 0; s < S; ++s) {
+    float ds_mine[4];          // dS = P (dA x dropout - sum_s P dA x dropout), as immtsf_softmax_rows_backward: a thread per (l, s)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = threadIdx.x + 256 * r;
+        ds_mine[r] = 0.f;
+        if (i < L * S) {
+            const int l = i / S, s = i - l * S;
+            float dot = 0.f;
+            for (int t = 0; t < S; ++t) dot = fmaf(Sc[l * AM_L + t], Ad[l * AM_L + t], dot);        // sum_t dA[t] x (P[t] x dropout[t])
             const float p = Pr[l * AM_L + s];
-            const float g = p > 0.f ? Sc[l * AM_L + s] * (Ad[l * AM_L + s] / p) : 0.f;      // dA x dropout scale (A / P; masked keys: 0)
-            Sc[l * AM_L + s] = g;
-            dot = fmaf(p, g, dot);
+            ds_mine[r] = d.scale * (Sc[l * AM_L + s] * Ad[l * AM_L + s] - p * dot);
         }
-        for (int s = 0; s < S; ++s) Sc[l * AM_L + s] = d.scale * Pr[l * AM_L + s] * (Sc[l * AM_L + s] - dot);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = threadIdx.x + 256 * r;
+        if (i < L * S) Sc[(i / S) * AM_L + (i - (i / S) * S)] = ds_mine[r];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < E; c += 256) {

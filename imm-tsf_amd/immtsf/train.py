@@ -788,15 +788,18 @@ class FlagStep(PhasedStep):
             fwait(F_B1, T)
             from . import config
             config.head_done_flag = F_T2 if os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0" else None
-            py, cuts, loss = self._head(pred, outs)
+            try:
+                py, cuts, loss = self._head(pred, outs)
+                taken = config.head_done_flag is None and os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0"
+            finally:
+                config.head_done_flag = None      # (never leave the address of this step's flag behind for an unrelated call)
             dpy = py.grad
             dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
-            if config.head_done_flag is not None or os.environ.get("IMMTSF_HEAD_FLAG", "1") == "0":
+            if not taken:
                 fset(F_T2, T)                     # (a head that publishes the flag itself -- MMFXRankQLossFn -- has consumed it)
             elif dpy is None or dpy.data_ptr() != config.head_dy_ptr:
                 raise RuntimeError("FlagStep: the head published its dY flag early, but autograd did not hand that buffer on as the "
                                    "backbone's output gradient (IMMTSF_HEAD_FLAG=0 disables the early flag)")
-            config.head_done_flag = None
             with torch.cuda.stream(B):
                 fwait(F_T2, B)
                 torch.autograd.backward([pred], [dpy])

@@ -89,13 +89,18 @@ struct RowsArgs {
     float scale;              // applied to the second product (1 / keep)
 };
 
-// grid ceil(nrt / (4 RT)), 256 threads; no LDS, no barrier
-template <int RT, bool BWD>
+// grid ceil(nrt / (4 RT)), 256 threads; no LDS, no barrier.
+// SPLIT (few rows: R <= 4096, RT = 1): grid nrt, 512 threads -- the eight waves of a workgroup share ONE row tile and split the
+// hidden dimension (F / 256 chunks each instead of F / 32: the wave's walk over the chunks is the kernel's whole duration), their
+// partial output tiles meet in LDS.  At 1024 rows (64 windows) the feed-forward then is 2 + 3 short launches on 64 CUs instead of
+// 3 + 4 GEMM launches of up to 512 workgroups.
+template <int RT, bool BWD, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
-    const int rt0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + wave) * RT);
-    if (rt0 >= a.nrt) return;
+    const int rt0 = __builtin_amdgcn_readfirstlane(SPLIT ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wave) * RT);
+    if (!SPLIT && rt0 >= a.nrt) return;
     const int F = a.F, NC = F >> 5;
+    const int c0 = SPLIT ? __builtin_amdgcn_readfirstlane(wave * (NC >> 2)) : 0, c1 = SPLIT ? c0 + (NC >> 2) : NC;
     bf16x8 xb[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -115,22 +120,22 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
     const bool drop = !BWD && a.drop.p > 0.f;
     // the next chunk's weight fragments, bias and (backward) mask words are requested before the current chunk is computed:
     // one chunk is ~4 RT MFMAs, far shorter than a trip to L2
-    bf16x8 n1_0 = fa[0], n1_1 = fa[64], n2_0 = fb[0], n2_1 = fb[64];
+    bf16x8 n1_0 = fa[(c0 * 2) * 64], n1_1 = fa[(c0 * 2 + 1) * 64], n2_0 = fb[(c0 * 2) * 64], n2_1 = fb[(c0 * 2 + 1) * 64];
     float4 nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0;
     if (!BWD) {
-        nb0 = *reinterpret_cast<const float4*>(a.b1 + fq * 4);
-        nb1 = *reinterpret_cast<const float4*>(a.b1 + 16 + fq * 4);
+        nb0 = *reinterpret_cast<const float4*>(a.b1 + c0 * 32 + fq * 4);
+        nb1 = *reinterpret_cast<const float4*>(a.b1 + c0 * 32 + 16 + fq * 4);
     }
     uint64_t nm[BWD ? RT : 1][8];
     if (BWD) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            const uint64_t* rec = a.mask + (size_t)min(rt0 + rt, a.nrt - 1) * 8;
+            const uint64_t* rec = a.mask + ((size_t)c0 * a.nrt + min(rt0 + rt, a.nrt - 1)) * 8;
 #pragma unroll
             for (int w = 0; w < 8; ++w) nm[rt][w] = rec[w];
         }
     }
-    for (int c = 0; c < NC; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const bf16x8 a1_0 = n1_0, a1_1 = n1_1, a2_0 = n2_0, a2_1 = n2_1;
         const float4 bb0 = nb0, bb1 = nb1;
         uint64_t cm[BWD ? RT : 1][8];
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
                 for (int w = 0; w < 8; ++w) cm[rt][w] = nm[rt][w];
         }
         {
-            const int cn = c + 1 < NC ? c + 1 : c;
+            const int cn = c + 1 < c1 ? c + 1 : c;
             n1_0 = fa[(cn * 2 + 0) * 64]; n1_1 = fa[(cn * 2 + 1) * 64];
             n2_0 = fb[(cn * 2 + 0) * 64]; n2_1 = fb[(cn * 2 + 1) * 64];
             if (!BWD) {
@@ -199,6 +204,18 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
             const bf16x8 hb = pack8(h0, h1);
             acc[rt][0] = mfma(a2_0, hb, acc[rt][0]);
             acc[rt][1] = mfma(a2_1, hb, acc[rt][1]);
+        }
+    }
+    if (SPLIT) {          // the eight waves' partial tiles of the one row tile: summed by wave 0
+        __shared__ __attribute__((aligned(16))) float red[4][64][8];
+        *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = acc[0][0];
+        *reinterpret_cast<f32x4*>(&red[wave][lane][4]) = acc[0][1];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            acc[0][0] += *reinterpret_cast<const f32x4*>(&red[w][lane][0]);
+            acc[0][1] += *reinterpret_cast<const f32x4*>(&red[w][lane][4]);
         }
     }
 #pragma unroll
@@ -409,9 +426,13 @@ inline int rows_block(int R) {      // rows per row block of the weight-gradient
 
 }  // namespace
 
+static int ffn32_split_max() {        // row tiles up to which the rows kernels split the hidden dimension (IMMTSF_FFN32_SPLIT_MAX: A/B runs)
+    static const int v = getenv("IMMTSF_FFN32_SPLIT_MAX") ? atoi(getenv("IMMTSF_FFN32_SPLIT_MAX")) : 256;
+    return v;
+}
 bool ffn32_ok(int R, int D, int F, int act, int prec) {
     static const bool on = !(getenv("IMMTSF_FFN32") && atoi(getenv("IMMTSF_FFN32")) == 0);
-    return on && D == FD && act == 1 && prec == 1 && R >= 2048 && F >= 256 && (F % 256) == 0;
+    return on && D == FD && act == 1 && prec == 1 && R >= 256 && F >= 256 && (F % 256) == 0;
 }
 size_t ffn32_saved_bytes(int R, int F) { return (size_t)4 * F * FD * 2 + (size_t)(F / 32) * ((R + 15) / 16) * 64; }
 size_t ffn32_scratch_bytes(int R, int F) {
@@ -432,7 +453,8 @@ int ffn32_forward(int R, int F, const DropCfg& dd, uint64_t site, const float* x
     a.drop = dd; a.site = site; a.scale = dd.p > 0.f ? dd.inv_keep : 1.f;
     const int rt = a.nrt >= 16384 ? 4 : a.nrt >= 4096 ? 2 : 1;       // >= 2 waves per SIMD first (the Philox draws are VALU work)
     const int grid = (a.nrt + 4 * rt - 1) / (4 * rt);
-    if (rt == 4) hipLaunchKernelGGL((ffn32_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, a);
+    if (a.nrt <= ffn32_split_max()) hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true>), dim3(a.nrt), dim3(256), 0, s, a);       // few rows: split the hidden dimension
+    else if (rt == 4) hipLaunchKernelGGL((ffn32_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, a);
     else if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((ffn32_rows_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);
     IMMTSF_LAUNCH_CHECK();
@@ -453,7 +475,8 @@ int ffn32_backward(int R, int F, const DropCfg& dd, const float* x1, const float
         a.drop = dd; a.site = 0; a.scale = scale;
         const int rt = nrt >= 4096 ? 2 : 1;          // (the mask words of RT row tiles x 2 chunks live in SGPRs: RT <= 2)
         const int grid = (nrt + 4 * rt - 1) / (4 * rt);
-        if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
+        if (nrt <= ffn32_split_max()) hipLaunchKernelGGL((ffn32_rows_kernel<1, true, true>), dim3(nrt), dim3(256), 0, s, a);
+        else if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((ffn32_rows_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
         IMMTSF_LAUNCH_CHECK();
     }

@@ -500,7 +500,7 @@ def test_encoder_layer_block_dropout_masks():
     assert not bad, bad
 
 
-@pytest.mark.parametrize("R,p", [(6007, 0.0), (6007, 0.3), (2048, 0.3), (40000, 0.1)])
+@pytest.mark.parametrize("R,p", [(6007, 0.0), (6007, 0.3), (2048, 0.3), (40000, 0.1), (1024, 0.1), (1000, 0.0), (300, 0.3), (4096, 0.2)])
 def test_ffn_block_many_rows_fused_vs_torch(R, p):
     """The many-rows feed-forward of tPatchGNN's encoder layer (csrc/ffn32.hip: d_model 32, dim_feedforward 2048, ReLU, bf16,
     no (R x F) intermediate; reference models/tPatchGNN.py:118-121) against the float64 torch composition that uses the

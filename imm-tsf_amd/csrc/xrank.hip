@@ -1304,14 +1304,17 @@ size_t immtsf_mmf_xrank_p_workspace_bytes(const immtsf_fusion_cfg* cfg) { return
 size_t immtsf_mmf_xrank_p_scratch_bytes(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? carve_xp_scratch(cfg, nullptr).bytes : 0; }
 size_t immtsf_mmf_xrank_q_workspace_bytes(const immtsf_fusion_cfg* cfg) { return xr_supported(cfg) ? carve_xq(cfg, nullptr).bytes : 0; }
 
-int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* P, float* bHO,
-                               void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
-    if (!xr_supported(cfg) || !p || !E_txt || !P || !bHO || !workspace) return IMMTSF_EINVAL;
+/* the fold alone (parameters only: W_fold, its bias, its bf16 image and the factors the backward needs go to `workspace`, b_HO to
+ * bHO): may run ahead of time on ANY stream -- e.g. a third one beside the text side and the backbone -- before
+ * immtsf_mmf_xrank_p_forward(..., folded = 1, ...) on a stream ordered behind it */
+int immtsf_mmf_xrank_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, float* bHO, void* workspace, size_t workspace_bytes,
+                          immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !bHO || !workspace) return IMMTSF_EINVAL;
     XPWs w = carve_xp(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const XRDims x = xr_dims(cfg);
-    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E, BT = x.B * x.T, prec = cfg->precision;
+    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E;
     const bool hf = xr_hf(cfg);
     const float scale = sqrtf(1.0f / (float)E);
     const float *Wiq = p->attn_in_w, *Wik = p->attn_in_w + (size_t)d * d, *Wiv = p->attn_in_w + (size_t)2 * d * d;
@@ -1345,6 +1348,19 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         if (x.PW > H * x.Wd) L.copy(nullptr, (x.PW - H * x.Wd) * d, w.Wf + (size_t)H * x.Wd * d, hf ? w.Wf16 + (size_t)H * x.Wd * d : nullptr);
         CHECK(L.launch(s, true));
     }
+    return IMMTSF_OK;
+}
+
+int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* P, float* bHO,
+                               void* workspace, size_t workspace_bytes, int32_t folded, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !E_txt || !P || !bHO || !workspace) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    if (!folded) CHECK(immtsf_mmf_xrank_fold(cfg, p, bHO, workspace, workspace_bytes, stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
     Mat Em = cmat(E_txt);
     if (hf && cfg->in_h) {
         Em.h = const_cast<void*>(cfg->in_h);

@@ -116,7 +116,9 @@ _PROTOS = {
     "immtsf_mmf_xrank_p_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xrank_p_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_mmf_xrank_q_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
-    "immtsf_mmf_xrank_p_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xrank_fold": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xrank_p_forward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_int32,
+                                           c_stream]),
     "immtsf_mmf_xrank_p_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
     "immtsf_mmf_xrank_q_forward": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,

@@ -100,3 +100,6 @@ head_dy_ptr = None        # ... and, when a head took the flag: the address of t
 # FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); IMMTSF_ATTN_MID=0:
 # batched GEMMs + row softmax
 attn_mid = _os.environ.get("IMMTSF_ATTN_MID", "1") != "0"
+# a torch.cuda.Stream on which MMF_XAttn_Add's fold (parameters only) may run ahead of the text side (None: in line); the stream
+# must be ordered behind the previous optimizer step (immtsf.train.FlagStep forks it at the start of the captured step)
+fold_stream = None

@@ -487,8 +487,17 @@ class MMFXRankPFn(torch.autograd.Function):
         E_h = _shadow_get(E) if _bf16_dataflow(precision, d) else None
         cfg.in_h = None if E_h is None else E_h.data_ptr()
         ctx.E_h = E_h
-        check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(), stream_ptr()),
-              "mmf_xrank_p_forward")
+        # the fold depends on parameters only: with config.fold_stream (immtsf.train.FlagStep) it runs on that stream, beside the
+        # text side's own forward, and this stream picks it up just before the projection
+        L = config.fold_stream
+        if L is not None:
+            cur = torch.cuda.current_stream()
+            ws.record_stream(L)
+            bHO.record_stream(L)
+            check(lib.immtsf_mmf_xrank_fold(C.byref(cfg), C.byref(ps), ptr(bHO), ptr(ws), ws.numel(), L.cuda_stream), "mmf_xrank_fold")
+            cur.wait_stream(L)
+        check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(),
+                                             0 if L is None else 1, stream_ptr()), "mmf_xrank_p_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.sinks = _sinks_of(params)
         ctx.done_hook = done_hook          # the block's gradients are final once THIS half's backward has run

@@ -751,6 +751,7 @@ class FlagStep(PhasedStep):
         dev = trainer.flat_param.device
         lib = _lib.load()
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.L = torch.cuda.Stream(device=dev) if os.environ.get("IMMTSF_FOLD_STREAM", "0") == "1" else None        # (off: measured slower)
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
@@ -781,12 +782,21 @@ class FlagStep(PhasedStep):
             T = torch.cuda.current_stream()
             trainer.zero_grad()
             B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
-            outs = text_fn()
+            from . import config
+            L = self.L
+            if L is not None:                     # a third branch for parameter-only work of the text side (MMF_XAttn_Add's fold):
+                L.wait_stream(T)                  # forked here, joined by the op that consumes its result (long after it has finished)
+                config.fold_stream = L
+            try:
+                outs = text_fn()
+            finally:
+                config.fold_stream = None
+            if L is not None:
+                T.wait_stream(L)                  # (a text_fn that never used the branch: join it anyway)
             with torch.cuda.stream(B):
                 pred = backbone_fn()
                 fset(F_B1, B)
             fwait(F_B1, T)
-            from . import config
             config.head_done_flag = F_T2 if os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0" else None
             try:
                 py, cuts, loss = self._head(pred, outs)

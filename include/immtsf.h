@@ -207,9 +207,12 @@ int32_t immtsf_mmf_xrank_pw(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xrank_p_workspace_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xrank_p_scratch_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_mmf_xrank_q_workspace_bytes(const immtsf_fusion_cfg* cfg);
-/* E_txt (B*T, d) -> P (B*T, pw), b_HO (C) = W_res b_out + b_res */
+/* E_txt (B*T, d) -> P (B*T, pw), b_HO (C) = W_res b_out + b_res.  folded != 0: immtsf_mmf_xrank_fold has already run on this
+ * workspace / bHO (the fold depends on parameters only, so it may run ahead of time on any stream this call is ordered behind) */
+int immtsf_mmf_xrank_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, float* bHO, void* workspace, size_t workspace_bytes,
+                          immtsf_stream_t stream);
 int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, float* P, float* bHO,
-                               void* workspace, size_t workspace_bytes, immtsf_stream_t stream);
+                               void* workspace, size_t workspace_bytes, int32_t folded, immtsf_stream_t stream);
 /* dP, d b_HO -> dE_txt and the gradients of all parameters but ln_w / ln_b (overwritten; grads->ln_* are not touched) */
 int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
                                 const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,

@@ -614,11 +614,13 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     }
 }
 
-// Off unless IMMTSF_GEMM_GROUP=1 -- measured at 64 windows (cfg2): the five text-side weight gradients as one 936-workgroup launch at
-// the end of the backward take 47 us alone on the critical stream, where the separate launches (10 - 18 us each) had overlapped
-// with the backbone's backward: 0.731 vs 0.716 ms per step.
+// On unless IMMTSF_GEMM_GROUP=0.  History: measured at 64 windows (cfg2) early in round 3 the five text-side weight gradients as one
+// 936-workgroup launch at the end of the backward took 47 us alone on the critical stream, where the separate launches (10 - 18 us
+// each) had overlapped with the backbone's backward: 0.731 vs 0.716 ms per step, and the switch stayed off.  At the end of the round
+// the step is bound by the chip time its two branches share, and one launch that fills every CU once beats five that each
+// hold 144 - 216 of them: 0.567 - 0.571 vs 0.581 - 0.589 ms.
 bool immtsf_gemm_group_enabled() {
-    static const bool on = getenv("IMMTSF_GEMM_GROUP") && atoi(getenv("IMMTSF_GEMM_GROUP")) == 1;
+    static const bool on = !(getenv("IMMTSF_GEMM_GROUP") && atoi(getenv("IMMTSF_GEMM_GROUP")) == 0);
     return on;
 }
 // n (2 .. 6) TN products C_i = alpha A_i^T B_i (+ bias gradients) of different shapes as ONE launch of the 64 x 64 K-group

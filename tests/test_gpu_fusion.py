@@ -881,12 +881,13 @@ def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precisio
         assert err <= tol, (k, err)
 
 
-def test_grouped_weight_gradient_launch_opt_in():
-    """IMMTSF_GEMM_GROUP=1 (csrc/gemm2.hip gemm2_group_kernel: the T2V backward's five TN weight gradients, different shapes, as ONE
-    launch at the end of the call; read once per process, so a child process): the bf16 benchmark-shape parity tests still pass."""
+def test_separate_weight_gradient_launches_opt_out():
+    """The T2V backward's five TN weight gradients (different shapes) run as ONE grouped launch at the end of the call by default
+    (csrc/gemm2.hip gemm2_group_kernel; every bf16 parity test of this file goes through it); IMMTSF_GEMM_GROUP=0 launches them one by
+    one (read once per process, so a child process): the bf16 benchmark-shape parity tests pass that way too."""
     import subprocess
     import sys
-    env = dict(os.environ, IMMTSF_GEMM_GROUP="1")
+    env = dict(os.environ, IMMTSF_GEMM_GROUP="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
                         "test_pairs_bf16_benchmark_shape or test_pairs_bf16_shapes_outside", "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)

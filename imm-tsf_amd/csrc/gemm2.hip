@@ -642,6 +642,9 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
         gg.tile0[i] = tiles;
         tiles += cdiv(g.M, 64) * cdiv(g.N, 64);
     }
+    // (four rounds of one-workgroup-per-CU tiles at most: with a wide member -- 768 x 4096 at LLaMA-width embeddings, 768 tiles of its
+    // own -- the separate launches are as good or better: cfg3 1.349 grouped vs 1.331 ms)
+    if (tiles > 1024) return IMMTSF_EUNSUPPORTED;
     gg.tile0[n] = tiles;
     for (int i = n + 1; i <= G2_GROUP_MAX; ++i) gg.tile0[i] = tiles;
     gg.n = n;

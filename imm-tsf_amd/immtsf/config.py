@@ -103,3 +103,4 @@ attn_mid = _os.environ.get("IMMTSF_ATTN_MID", "1") != "0"
 # a torch.cuda.Stream on which MMF_XAttn_Add's fold (parameters only) may run ahead of the text side (None: in line); the stream
 # must be ordered behind the previous optimizer step (immtsf.train.FlagStep forks it at the start of the captured step)
 fold_stream = None
+fold_flag = None          # (flag address, time-out report address): hand the fold over through a device flag instead of a stream event

@@ -495,7 +495,11 @@ class MMFXRankPFn(torch.autograd.Function):
             ws.record_stream(L)
             bHO.record_stream(L)
             check(lib.immtsf_mmf_xrank_fold(C.byref(cfg), C.byref(ps), ptr(bHO), ptr(ws), ws.numel(), L.cuda_stream), "mmf_xrank_fold")
-            cur.wait_stream(L)
+            if config.fold_flag is not None:      # hand-over through a device flag (no graph edge): (flag address, time-out report address)
+                check(lib.immtsf_flag_set(config.fold_flag[0], L.cuda_stream), "flag_set")
+                check(lib.immtsf_flag_wait(config.fold_flag[0], config.fold_flag[1], 50, cur.cuda_stream), "flag_wait")
+            else:
+                cur.wait_stream(L)
         check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(),
                                              0 if L is None else 1, stream_ptr()), "mmf_xrank_p_forward")
         ctx.cfg, ctx.ws = cfg, ws

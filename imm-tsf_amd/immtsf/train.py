@@ -751,7 +751,11 @@ class FlagStep(PhasedStep):
         dev = trainer.flat_param.device
         lib = _lib.load()
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        self.L = torch.cuda.Stream(device=dev) if os.environ.get("IMMTSF_FOLD_STREAM", "0") == "1" else None        # (off: measured slower)
+        # parameter-only work of the text side (MMF_XAttn_Add's fold): "1" = on a third branch (measured slower), "2" = at the
+        # head of the backbone's branch, whose forward is the shorter one
+        fs = os.environ.get("IMMTSF_FOLD_STREAM", "3")          # ("3": as "2", handed over through a device flag instead of an event)
+        self.L = torch.cuda.Stream(device=dev) if fs == "1" else self.B if fs in ("2", "3") else None
+        self._fold_by_flag = fs == "3"
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
@@ -784,14 +788,17 @@ class FlagStep(PhasedStep):
             B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
             from . import config
             L = self.L
-            if L is not None:                     # a third branch for parameter-only work of the text side (MMF_XAttn_Add's fold):
-                L.wait_stream(T)                  # forked here, joined by the op that consumes its result (long after it has finished)
+            if L is not None:                     # a branch for parameter-only work of the text side (MMF_XAttn_Add's fold):
+                if L is not B:
+                    L.wait_stream(T)              # forked here, joined by the op that consumes its result (long after it has finished)
                 config.fold_stream = L
+                config.fold_flag = (fp + 12, F_ERR) if self._fold_by_flag else None
             try:
                 outs = text_fn()
             finally:
                 config.fold_stream = None
-            if L is not None:
+                config.fold_flag = None
+            if L is not None and L is not B:
                 T.wait_stream(L)                  # (a text_fn that never used the branch: join it anyway)
             with torch.cuda.stream(B):
                 pred = backbone_fn()
@@ -818,7 +825,7 @@ class FlagStep(PhasedStep):
             self._text_backward(outs, dcuts)
             fwait(F_B2, T)
             T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
-            _lib.check(lib.immtsf_flags_clear(fp, 3, sp(T)), "flags_clear")
+            _lib.check(lib.immtsf_flags_clear(fp, 4, sp(T)), "flags_clear")
             trainer.step()
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)

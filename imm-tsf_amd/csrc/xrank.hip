@@ -447,7 +447,14 @@ inline XRDims xr_dims(const immtsf_fusion_cfg* c) {
 }
 inline int xq_mask_bytes(int T) { return (((T + 3) / 4) + 3) & ~3; }       // dropout keep bits of a (row, head): 4 keys per byte
 // LDS floats of the Q kernels per window: P rows, Y rows, ddelta rows, lse, D, dropout keep bits
-inline size_t xq_lds_floats(const XRDims& x) { return (size_t)x.T * (x.PW + 2 * x.C + 2 * x.H) + (size_t)x.H * x.T * (xq_mask_bytes(x.T) / 4); }
+#define XQ_PL(CM) (2 * (CM) + 4)       // pitch of a key row padded to the template width CM (xrank_q_train_kernel): k weights | v weights | k bias
+inline size_t xq_lds_floats(const XRDims& x) {
+    const size_t masks = (size_t)x.H * x.T * (xq_mask_bytes(x.T) / 4);
+    const size_t packed = (size_t)x.T * (x.PW + 2 * x.C + 2 * x.H) + masks;          // forward / backward kernels: rows as P has them
+    const int CM = x.C <= 8 ? 8 : 16, TP = (x.T + 3) & ~3;
+    const size_t padded = (size_t)x.H * TP * XQ_PL(CM) + (size_t)x.T * (2 * CM + 2 * x.H) + masks;      // training kernel
+    return packed > padded ? packed : padded;
+}
 constexpr size_t XQ_LDS_MAX = 60 * 1024;
 bool xr_supported(const immtsf_fusion_cfg* c) {
     if (bad_cfg(c) || c->C < 1 || c->C > 15 || c->H > 4 || ((c->d / c->H) & 3) || c->d > 4096) return false;
@@ -949,6 +956,25 @@ __global__ __launch_bounds__(256) void xrank_q_bwd_kernel(XQDims q, const float*
 // the loss is local to a row once the counts are given, so a workgroup runs its windows' forward, forms d loss / d Y_out in registers
 // and goes straight on: the serial section between the backbone's forward and backward is one kernel instead of three (and the
 // LayerNorm statistics, the attention's log-sum-exp and d loss / d Y_out never travel through memory).
+// CM floats from a 16-byte aligned LDS address
+template <int CM>
+__device__ __forceinline__ void lds_vec(const float* p, float (&v)[CM]) {
+#pragma unroll
+    for (int c = 0; c < CM; c += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + c);
+        v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
+    }
+}
+template <int CM>
+__device__ __forceinline__ void lds_put(float* p, const float (&v)[CM]) {
+#pragma unroll
+    for (int c = 0; c < CM; c += 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[c], v[c + 1], v[c + 2], v[c + 3]);
+}
+
+// The key rows sit in LDS PADDED to the template width (XQ_PL(CM) floats per (head, key): k weights | v weights | k bias, zeros beyond
+// C and beyond T): every inner loop is unconditional float4 LDS reads and FMAs over CM columns.  (With `if (c < C)` around each
+// element the compiler emitted a scalar branch and a dependent LDS round trip per element: 2600 branches, 21 000 lines of ISA, 32 us
+// for 64 windows; this form: see DESIGN.md section 4c.)
 template <int CM>
 __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const float* __restrict__ Y, const float* __restrict__ P,
                                                              const float* __restrict__ bHO, const unsigned char* __restrict__ mtxt,
@@ -962,17 +988,49 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ float red[4][64];
     __shared__ int s_last;
-    const int T = q.T, C = q.C, H = q.H, PW = q.PW, TB = q.TB, parts = q.parts, psh = q.psh, nch = (T + 3) >> 2;
-    const int b0 = blockIdx.x * q.wpb, nw = min(q.wpb, q.B - b0), rows = nw * T;
-    float* Ps = lds;                                   // [rows][PW]
-    float* Ys = Ps + (size_t)q.wpb * T * PW;           // [rows][C]
-    float* Ds = Ys + (size_t)q.wpb * T * C;            // ddelta [rows][C]
-    float* Ls = Ds + (size_t)q.wpb * T * C;            // lse [rows][H]
-    float* Dd = Ls + (size_t)q.wpb * T * H;            // D [rows][H]
+    __shared__ unsigned char s_live[256];      // the windows' M_txt flags (wpb <= 256)
+    constexpr int PL = XQ_PL(CM);
+    const int T = q.T, C = q.C, H = q.H, PW = q.PW, TB = q.TB, parts = q.parts, psh = q.psh, nch = (T + 3) >> 2, TP = nch * 4;
+    const int b0 = blockIdx.x * q.wpb, nw = min(q.wpb, q.B - b0), rows = nw * T, total = rows << psh;
+    float* Ks = lds;                                       // [wpb][H][TP][PL]
+    float* Ys = Ks + (size_t)q.wpb * H * TP * PL;          // [rows][CM]
+    float* Ds = Ys + (size_t)q.wpb * T * CM;               // ddelta [rows][CM]
+    float* Ls = Ds + (size_t)q.wpb * T * CM;               // lse [rows][H]
+    float* Dd = Ls + (size_t)q.wpb * T * H;                // D [rows][H]
     unsigned char* Mk = reinterpret_cast<unsigned char*>(Dd + (size_t)q.wpb * T * H);      // keep bits [rows][H][TB]: 4 keys per byte
-    {
-        const float4* src = reinterpret_cast<const float4*>(P + (size_t)b0 * T * PW);
-        for (int i = threadIdx.x; i < rows * PW / 4; i += 256) reinterpret_cast<float4*>(Ps)[i] = src[i];
+    // the first row's global operands are on their way while the key rows are staged
+    int idx = threadIdx.x;
+    float y[CM], tr[CM], tm[CM];
+    if (idx < total) {
+        const size_t grow = (size_t)b0 * T + (idx >> psh);
+        load_row<CM>(Y + grow * C, C, y);
+        load_row<CM>(truth + grow * C, C, tr);
+        load_row<CM>(tmask + grow * C, C, tm);
+    }
+    if ((int)threadIdx.x < nw) s_live[threadIdx.x] = mtxt[b0 + threadIdx.x];
+    for (int i = threadIdx.x; i < nw * H * TP; i += 256) {       // a thread per (window, head, key): its 2C+1 loads in flight together
+        const int s = i % TP, r = i / TP;
+        const int h = r % H, lw = r / H;
+        const float* src = P + ((size_t)(b0 + lw) * T + (s < T ? s : 0)) * PW + h * q.Wd;
+        float kw[CM], vw[CM], kb[4];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            const int cc = c < C ? c : 0;
+            kw[c] = src[cc];
+            vw[c] = src[C + 1 + cc];
+        }
+        kb[0] = src[C]; kb[1] = kb[2] = kb[3] = 0.f;
+        const bool in = s < T;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            kw[c] = (in && c < C) ? kw[c] : 0.f;
+            vw[c] = (in && c < C) ? vw[c] : 0.f;
+        }
+        kb[0] = in ? kb[0] : 0.f;
+        float* dst = Ks + (size_t)i * PL;
+        lds_put<CM>(dst, kw);
+        lds_put<CM>(dst + CM, vw);
+        lds_put<4>(dst + 2 * CM, kb);
     }
     const DropL dl = drop_local(drop);
     float gm[CM], bt[CM], bh[CM], lsc[CM], navail = 0.f;      // lsc: 1 / (count + 1e-8) of a variable (0 beyond C)
@@ -990,34 +1048,31 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
 #pragma unroll
     for (int c = 0; c < CM; ++c) s_w[c] = s_b[c] = s_d[c] = 0.f;
     // ---- phase 1: group = query row, its lanes split the keys in chunks of four
-    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
+    for (; idx < total; idx += 256) {
         const int row = idx >> psh, part = idx & (parts - 1);
         const int lw = row / T, t = row - lw * T, b = b0 + lw;
         const size_t grow = (size_t)b * T + t;
-        const bool live = mtxt[b] != 0;
-        float y[CM], gy[CM], dd[CM], dy[CM], delta[CM], lseh[4];
-        load_row<CM>(Y + grow * C, C, y);
+        const bool live = s_live[lw] != 0;
+        float gy[CM], dd[CM], dy[CM], delta[CM];
 #pragma unroll
         for (int c = 0; c < CM; ++c) delta[c] = bh[c];
-        lseh[0] = lseh[1] = lseh[2] = lseh[3] = 0.f;
-        if (live) {       // ---- forward of the row (as xrank_q_fwd_kernel)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (h >= H) break;
-                const float* Ph = Ps + (size_t)lw * T * PW + h * q.Wd;
+        if (live) {       // ---- forward of the row
+#pragma unroll 1
+            for (int h = 0; h < H; ++h) {
+                const float* Kh = Ks + (size_t)(lw * H + h) * TP * PL;
                 float mx = -INFINITY;
+#pragma unroll 1
                 for (int j = part; j < nch; j += parts) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int s = 4 * j + u;
-                        if (s < T) {
-                            const float* kw = Ph + s * PW;
-                            float sc = kw[C];
+                        const float* kr = Kh + s * PL;
+                        float kw[CM];
+                        lds_vec<CM>(kr, kw);
+                        float sc = kr[2 * CM];
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) sc = fmaf(y[c], kw[c], sc);
-                            mx = fmaxf(mx, sc);
-                        }
+                        for (int c = 0; c < CM; ++c) sc = fmaf(y[c], kw[c], sc);
+                        mx = fmaxf(mx, s < T ? sc : -INFINITY);
                     }
                 }
                 mx = group_max(mx, parts);
@@ -1026,6 +1081,7 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
                 for (int c = 0; c < CM; ++c) acc[c] = 0.f;
                 const uint64_t base = (((uint64_t)b * H + h) * T + t) * T;
                 unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
+#pragma unroll 1
                 for (int j = part; j < nch; j += parts) {
                     float dr[4];
                     drop4(dl, SITE_XADD_ATTN, base + 4 * j, T - 4 * j, dr);
@@ -1033,130 +1089,125 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int s = 4 * j + u;
-                        if (s < T) {
-                            const float* kw = Ph + s * PW;
-                            float sc = kw[C];
+                        const float* kr = Kh + s * PL;
+                        float kw[CM], vw[CM];
+                        lds_vec<CM>(kr, kw);
+                        lds_vec<CM>(kr + CM, vw);
+                        float sc = kr[2 * CM];
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) sc = fmaf(y[c], kw[c], sc);
-                            const float e = __expf(sc - mx);
-                            sum += e;
-                            const float ed = e * dr[u];
+                        for (int c = 0; c < CM; ++c) sc = fmaf(y[c], kw[c], sc);
+                        const float e = s < T ? __expf(sc - mx) : 0.f;
+                        sum += e;
+                        const float ed = e * dr[u];
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) acc[c] = fmaf(ed, kw[C + 1 + c], acc[c]);
-                            if (dr[u] != 0.f) bits |= 1u << u;
-                        }
+                        for (int c = 0; c < CM; ++c) acc[c] = fmaf(ed, vw[c], acc[c]);
+                        bits |= (dr[u] != 0.f ? 1u : 0u) << u;
                     }
                     mk[j] = (unsigned char)bits;        // the keep bits of the row's keys, for both backward phases
                 }
                 sum = group_sum(sum, parts);
                 const float is = 1.f / sum;
-                lseh[h] = mx + __logf(sum);
+                Ls[row * H + h] = mx + __logf(sum);     // (every lane of the group: the same value)
 #pragma unroll
-                for (int c = 0; c < CM; ++c)
-                    if (c < C) delta[c] = fmaf(group_sum(acc[c], parts), is, delta[c]);
+                for (int c = 0; c < CM; ++c) delta[c] = fmaf(group_sum(acc[c], parts), is, delta[c]);
             }
         }
         {   // ---- LayerNorm(C), dropout, blend; the loss and its gradient; LayerNorm backward -- all in the row's registers
             float mu = 0.f;
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
-                if (c < C) mu += delta[c];
+            for (int c = 0; c < CM; ++c) mu += delta[c];          // (0 beyond C)
             mu /= (float)C;
             float var = 0.f;
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
-                if (c < C) { const float tt = delta[c] - mu; var = fmaf(tt, tt, var); }
+            for (int c = 0; c < CM; ++c) { const float tt = c < C ? delta[c] - mu : 0.f; var = fmaf(tt, tt, var); }
             const float rs = 1.0f / sqrtf(var / (float)C + 1e-5f);
-            float xh[CM], dsc[CM], tr[CM], tm[CM], g[CM], m1 = 0.f, m2 = 0.f;
-            load_row<CM>(truth + grow * C, C, tr);
-            load_row<CM>(tmask + grow * C, C, tm);
+            float xh[CM], dsc[CM], g[CM], m1 = 0.f, m2 = 0.f;
             if (live) drop_row<CM>(dl, (uint64_t)grow * C, C, dsc);
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
+                const bool on = c < C && live;
                 xh[c] = (delta[c] - mu) * rs;
-                const float v = (live && c < C) ? fmaf(xh[c], gm[c], bt[c]) * dsc[c] : 0.f;
+                const float v = on ? fmaf(xh[c], gm[c], bt[c]) * dsc[c] : 0.f;
                 const float yo = (y[c] + q.kappa * v) * inv;
                 if (part == 0 && c < C && Yout) Yout[grow * C + c] = yo;
                 const float dlt = tr[c] - yo;
                 if (part == 0) s_e = fmaf(dlt * dlt, tm[c] * lsc[c], s_e);
                 gy[c] = c < C ? -dlt * tm[c] * lsc[c] * (grad_scale * 2.f / navail) : 0.f;
                 dy[c] = part == 0 ? gy[c] * inv : 0.f;
-                g[c] = 0.f;
-                if (c < C && live) {
-                    const float dn = q.kappa * inv * gy[c] * dsc[c];
-                    if (part == 0) { s_w[c] = fmaf(dn, xh[c], s_w[c]); s_b[c] += dn; }
-                    g[c] = dn * gm[c];
-                    m1 += g[c];
-                    m2 = fmaf(g[c], xh[c], m2);
-                }
+                const float dn = on ? q.kappa * inv * gy[c] * dsc[c] : 0.f;
+                if (part == 0) { s_w[c] = fmaf(dn, on ? xh[c] : 0.f, s_w[c]); s_b[c] += dn; }
+                g[c] = dn * gm[c];
+                m1 += g[c];
+                m2 = fmaf(g[c], on ? xh[c] : 0.f, m2);
             }
             m1 /= (float)C; m2 /= (float)C;
 #pragma unroll
             for (int c = 0; c < CM; ++c) {
                 dd[c] = (c < C && live) ? rs * (g[c] - m1 - xh[c] * m2) : 0.f;
-                if (part == 0) {
-                    s_d[c] += dd[c];
-                    if (c < C) { Ys[row * C + c] = y[c]; Ds[row * C + c] = dd[c]; }
-                }
+                if (part == 0) s_d[c] += dd[c];
             }
+            if (part == 0) { lds_put<CM>(Ys + row * CM, y); lds_put<CM>(Ds + row * CM, dd); }
         }
         if (live) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                if (h >= H) break;
-                const float* Ph = Ps + (size_t)lw * T * PW + h * q.Wd;
-                const float l = lseh[h];
-                unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
+#pragma unroll 1
+            for (int h = 0; h < H; ++h) {
+                const float* Kh = Ks + (size_t)(lw * H + h) * TP * PL;
+                const float l = Ls[row * H + h];
+                const unsigned char* mk = Mk + ((size_t)row * H + h) * TB;
                 // D = sum_s A_drop[t,s] dA[t,s] from the SAME a and dA values the gradient below uses: where the text rows of a window
                 // are nearly equal, dA - D is a difference of nearly equal numbers, and a D formed any other way (e.g. from the
-                // forward's output) leaves its own rounding in every dS
+                // forward's output) leaves its own rounding in every dS.  (Keys beyond T are zero rows: dA = 0 and k weights = 0, so
+                // they add nothing to D or to dY.)
                 float D = 0.f;
+#pragma unroll 1
                 for (int j = part; j < nch; j += parts) {
                     const unsigned int bits = mk[j];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int s = 4 * j + u;
-                        if (s < T) {
-                            const float* kw = Ph + s * PW;
-                            float sc = kw[C], dA = 0.f;
+                        const float* kr = Kh + (4 * j + u) * PL;
+                        float kw[CM], vw[CM];
+                        lds_vec<CM>(kr, kw);
+                        lds_vec<CM>(kr + CM, vw);
+                        float sc = kr[2 * CM], dA = 0.f;
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
-                            D = fmaf(__expf(sc - l) * ((bits >> u) & 1u ? dl.inv_keep : 0.f), dA, D);
-                        }
+                        for (int c = 0; c < CM; ++c) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], vw[c], dA); }
+                        D = fmaf(__expf(sc - l) * ((bits >> u) & 1u ? dl.inv_keep : 0.f), dA, D);
                     }
                 }
                 D = group_sum(D, parts);
-                if (part == 0) { Ls[row * H + h] = l; Dd[row * H + h] = D; }
+                if (part == 0) Dd[row * H + h] = D;
+#pragma unroll 1
                 for (int j = part; j < nch; j += parts) {
                     const unsigned int bits = mk[j];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int s = 4 * j + u;
-                        if (s < T) {
-                            const float* kw = Ph + s * PW;
-                            float sc = kw[C], dA = 0.f;
+                        const float* kr = Kh + (4 * j + u) * PL;
+                        float kw[CM], vw[CM];
+                        lds_vec<CM>(kr, kw);
+                        lds_vec<CM>(kr + CM, vw);
+                        float sc = kr[2 * CM], dA = 0.f;
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], kw[C + 1 + c], dA); }
-                            const float dr = (bits >> u) & 1u ? dl.inv_keep : 0.f;
-                            const float ds = __expf(sc - l) * (dA * dr - D);
+                        for (int c = 0; c < CM; ++c) { sc = fmaf(y[c], kw[c], sc); dA = fmaf(dd[c], vw[c], dA); }
+                        const float dr = (bits >> u) & 1u ? dl.inv_keep : 0.f;
+                        const float ds = __expf(sc - l) * (dA * dr - D);
 #pragma unroll
-                            for (int c = 0; c < CM; ++c)
-                                if (c < C) dy[c] = fmaf(ds, kw[c], dy[c]);
-                        }
+                        for (int c = 0; c < CM; ++c) dy[c] = fmaf(ds, kw[c], dy[c]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int c = 0; c < CM; ++c)
-            if (c < C) {
-                const float v = group_sum(dy[c], parts);
-                if (part == 0) dY[grow * C + c] = v;
-            }
+        for (int c = 0; c < CM; ++c) {
+            const float v = group_sum(dy[c], parts);
+            if (part == 0 && c < C) dY[grow * C + c] = v;
+        }
+        const int nxt = idx + 256;        // the next row's operands
+        if (nxt < total) {
+            const size_t g2 = (size_t)b0 * T + (nxt >> psh);
+            load_row<CM>(Y + g2 * C, C, y);
+            load_row<CM>(truth + g2 * C, C, tr);
+            load_row<CM>(tmask + g2 * C, C, tm);
+        }
     }
     __syncthreads();
     // dY_ts is complete for this workgroup: the LAST workgroup to get here publishes `done_flag` (a device flag another stream's
@@ -1170,45 +1221,45 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
         }
     }
     // ---- phase 2: group = key row, its lanes split the query rows
-    for (int idx = threadIdx.x; idx < (rows << psh); idx += 256) {
-        const int row = idx >> psh, part = idx & (parts - 1);
+    for (int i2 = threadIdx.x; i2 < total; i2 += 256) {
+        const int row = i2 >> psh, part = i2 & (parts - 1);
         const int lw = row / T, s = row - lw * T, b = b0 + lw;
         const size_t grow = (size_t)b * T + s;
-        const bool live = mtxt[b] != 0;
+        const bool alive = s_live[lw] != 0;
         float* out = dP + grow * PW;
         unsigned short* out16 = dP16 ? dP16 + grow * PW : nullptr;
+#pragma unroll 1
         for (int h = 0; h < H; ++h) {
-            float kw[CM], vw[CM], dkw[CM], dvw[CM], dkb = 0.f;
+            float dkw[CM], dvw[CM], dkb = 0.f;
 #pragma unroll
-            for (int c = 0; c < CM; ++c) { kw[c] = 0.f; vw[c] = 0.f; dkw[c] = 0.f; dvw[c] = 0.f; }
-            if (live) {
-                const float* Ph = Ps + ((size_t)lw * T + s) * PW + h * q.Wd;
-#pragma unroll
-                for (int c = 0; c < CM; ++c)
-                    if (c < C) { kw[c] = Ph[c]; vw[c] = Ph[C + 1 + c]; }
-                const float kb = Ph[C];
+            for (int c = 0; c < CM; ++c) { dkw[c] = 0.f; dvw[c] = 0.f; }
+            if (alive) {
+                const float* kr = Ks + ((size_t)(lw * H + h) * TP + s) * PL;
+                float kw[CM], vw[CM];
+                lds_vec<CM>(kr, kw);
+                lds_vec<CM>(kr + CM, vw);
+                const float kb = kr[2 * CM];
+#pragma unroll 2
                 for (int t = part; t < T; t += parts) {
                     const int r2 = lw * T + t;
-                    const float* yt = Ys + r2 * C;
-                    const float* dt = Ds + r2 * C;
+                    float yt[CM], dt[CM];
+                    lds_vec<CM>(Ys + r2 * CM, yt);
+                    lds_vec<CM>(Ds + r2 * CM, dt);
                     float sc = kb, dA = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CM; ++c)
-                        if (c < C) { sc = fmaf(yt[c], kw[c], sc); dA = fmaf(dt[c], vw[c], dA); }
+                    for (int c = 0; c < CM; ++c) { sc = fmaf(yt[c], kw[c], sc); dA = fmaf(dt[c], vw[c], dA); }
                     const float a = __expf(sc - Ls[r2 * H + h]);
                     const float dr = (Mk[((size_t)r2 * H + h) * TB + (s >> 2)] >> (s & 3)) & 1u ? dl.inv_keep : 0.f;
                     const float ds = a * (dA * dr - Dd[r2 * H + h]);
                     const float ad = a * dr;
                     dkb += ds;
 #pragma unroll
-                    for (int c = 0; c < CM; ++c)
-                        if (c < C) { dkw[c] = fmaf(ds, yt[c], dkw[c]); dvw[c] = fmaf(ad, dt[c], dvw[c]); }
+                    for (int c = 0; c < CM; ++c) { dkw[c] = fmaf(ds, yt[c], dkw[c]); dvw[c] = fmaf(ad, dt[c], dvw[c]); }
                 }
             }
             dkb = group_sum(dkb, parts);
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
-                if (c < C) { dkw[c] = group_sum(dkw[c], parts); dvw[c] = group_sum(dvw[c], parts); }
+            for (int c = 0; c < CM; ++c) { dkw[c] = group_sum(dkw[c], parts); dvw[c] = group_sum(dvw[c], parts); }
             if (part == 0) {
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
@@ -1256,20 +1307,20 @@ __global__ __launch_bounds__(256) void xrank_q_train_kernel(XQDims q, const floa
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    {   // value = lane (< 3C), the four waves take every fourth slab
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    {   // value = lane (< 3C + 1), the four waves take every fourth slab, eight loads in flight
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.f;
         const int G = gridDim.x;
         if (lane < NV) {
             int g = wave;
-            for (; g + 12 < G; g += 16) {
-                a0 += __builtin_nontemporal_load(slabs + (size_t)g * NV + lane);
-                a1 += __builtin_nontemporal_load(slabs + (size_t)(g + 4) * NV + lane);
-                a2 += __builtin_nontemporal_load(slabs + (size_t)(g + 8) * NV + lane);
-                a3 += __builtin_nontemporal_load(slabs + (size_t)(g + 12) * NV + lane);
+            for (; g + 28 < G; g += 32) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += __builtin_nontemporal_load(slabs + (size_t)(g + 4 * u) * NV + lane);
             }
-            for (; g < G; g += 4) a0 += __builtin_nontemporal_load(slabs + (size_t)g * NV + lane);
+            for (; g < G; g += 4) a[0] += __builtin_nontemporal_load(slabs + (size_t)g * NV + lane);
         }
-        red[wave][lane] = (a0 + a1) + (a2 + a3);
+        red[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     __syncthreads();
     if ((int)threadIdx.x < NV) {

@@ -375,8 +375,9 @@ __device__ __forceinline__ bf16x8 dec_h1_frag(const float* u, const float* v, in
 template <int H>
 size_t fwd_lds_mfma(int N, int Lp, int D, int E) { return (size_t)((N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + 8) * sizeof(float); }
 template <int H>
-size_t bwd_lds_mfma(int N, int Lp, int D, int E) {
-    return (size_t)(2 * (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + ((N * Lp + 31) & ~31) + H * (D + E) + H + 8 * (H * H + 2 * H + 4) + 16) * sizeof(float);
+size_t bwd_lds_mfma(int N, int Lp, int D, int E, bool with_slabs) {
+    const size_t red = 8 * (H * H + 2 * H + 4), slabs = with_slabs ? (size_t)8 * (Lp + 1) * Geo<H>::P1 : 0;      // the waves' parameter sums | their dv slabs (same region)
+    return (size_t)(2 * (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + ((N * Lp + 31) & ~31) + H * (D + E) + H + (red > slabs ? red : slabs) + 16) * sizeof(float);
 }
 
 // grid B, 256 threads
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(256) void dec_fwd_mfma_kernel(DecDims d, DecP p, co
 // reads / MFMAs / LDS atomics is latency-bound, more waves per window is what shortens it)
 __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
                                                             const float* __restrict__ dout, float* __restrict__ dh,
-                                                            float* __restrict__ dte, DecG g) {
+                                                            float* __restrict__ dte, DecG g, int use_slabs) {
     constexpr int H = 32, P1 = Geo<H>::P1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* u = sm;
@@ -463,6 +464,14 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
     for (int i = tid; i < H * (d.D + d.E); i += NT) gW1s[i] = 0.f;
     if (tid < H) gb1s[tid] = 0.f;
     const int rows = d.N * d.Lp, tiles = (rows + 15) >> 4, pairs = (tiles + 1) >> 1;
+    // dv of a wave's tiles goes to a slab of its own, [Lp + 1][P1] (the last row takes the padding rows), by plain read-modify-write:
+    // fp32 LDS atomics retire about one lane per clock for the whole CU -- eight waves' 10 k lane-adds were 5 us per tile, 10 of the
+    // tile loop's 12.6 us.  One ds instruction touches rows 4 fq + e (e fixed): distinct steps lp whenever Lp > 12.  The slabs share
+    // the region of the final parameter sums (`red`), are added up in wave order after the loop: the sum is deterministic, too
+    float* red = gb1s + H;
+    const bool priv = use_slabs != 0;       // (the host: Lp > 12 and the slabs fit)
+    const int slab_floats = (d.Lp + 1) * P1;
+    float* slab = red + (size_t)wave * slab_floats;
 
     for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
         for (int i = tid; i < (d.N + d.Lp) * P1; i += NT) du[i] = 0.f;      // du and dv are contiguous
@@ -470,6 +479,8 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             const int n = r / d.Lp, lp = r - n * d.Lp;
             dys[r] = r < rows ? dout[((size_t)b * d.Lp + lp) * d.N + n] : 0.f;
         }
+        if (priv)
+            for (int i = lane; i < slab_floats; i += 64) slab[i] = 0.f;
         stage<H>(d, p, h, te, b, Xs);
         __syncthreads();
         first_layer<H>(d, p.b1, Xs, u, v);
@@ -478,6 +489,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             bf16x8 hb[2];
             dec_f32x4 g2o2[2][2];          // [t][jt]: g2 with lane = j (16 jt + fr), rows 4 fq + e of tile t
             int ou[2][4], ov[2][4];        // u / v offsets (n * P1, lp * P1) of rows 4 fq + e of tile t (clamped to the last row)
+            int os[2][4];                  // the rows' offsets in the wave's dv slab (padding rows: the extra row)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int r0 = (pr * 2 + t) * 16;                  // wave-uniform: one division per tile, the lanes walk on from it
@@ -497,7 +509,10 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
                 int un1, vl1;
                 locate(fr, un1, vl1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) locate(fq * 4 + e, ou[t][e], ov[t][e]);
+                for (int e = 0; e < 4; ++e) {
+                    locate(fq * 4 + e, ou[t][e], ov[t][e]);
+                    os[t][e] = r0 + fq * 4 + e < rows ? ov[t][e] : d.Lp * P1;
+                }
                 const float dy1 = dys[r0 + fr];                     // (zero past the window's rows)
                 {
                     bf16x8 r;
@@ -532,9 +547,13 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
                     const int k = kt * 16 + fr;
                     float m[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        m[e] = u[ou[t][e] + k] + v[ov[t][e] + k] > 0.f ? dh1[e] : 0.f;
-                        atomicAdd(dv + ov[t][e] + k, m[e]);
+                    for (int e = 0; e < 4; ++e) m[e] = u[ou[t][e] + k] + v[ov[t][e] + k] > 0.f ? dh1[e] : 0.f;
+                    if (priv) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) slab[os[t][e] + k] += m[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(dv + ov[t][e] + k, m[e]);
                     }
                     if (one_n) {      // the whole tile is one variable (Lp a multiple of 16): one add per k
                         const float sacc = xor32_sum(xor16_sum((m[0] + m[1]) + (m[2] + m[3])));
@@ -571,6 +590,15 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             }
         }
         __syncthreads();
+        if (priv) {
+            for (int i = tid; i < d.Lp * P1; i += NT) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a += red[w * slab_floats + i];
+                dv[i] = a;
+            }
+            __syncthreads();
+        }
         // ---- first layer (fp32, as in the exact kernel): db1, dW1 -> the running sums; dh, dte
         if (tid < H) {
             float s = 0.f;
@@ -610,7 +638,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
     }
     // ---- this workgroup's parameter gradients -> global: the four waves' sums are added up in LDS first (one atomic per element
     // per WORKGROUP: the atomics queue per address, their count is what the flush costs)
-    float* red = gb1s + H;                              // [NW][RED]: W2 (1024) | b2 (32) | W3 (32) | b3 (1)
+    // red: [NW][RED]: W2 (1024) | b2 (32) | W3 (32) | b3 (1)
     constexpr int RED = H * H + 2 * H + 4;
     float* mine = red + wave * RED;
 #pragma unroll
@@ -704,11 +732,12 @@ int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_
     const DecP q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3};
     const DecG gq{grads->W1, grads->b1, grads->W2, grads->b2, grads->W3, grads->b3};
     if (precision == 1 && dec_mfma_ok(p)) {
-        const size_t lm = bwd_lds_mfma<32>(N, Lp, D, E);
+        const bool slabs = Lp > 12 && bwd_lds_mfma<32>(N, Lp, D, E, true) <= kLdsMax;      // else: LDS atomics on the one dv image
+        const size_t lm = bwd_lds_mfma<32>(N, Lp, D, E, slabs);
         int per = (int)(160 * 1024 / lm);
         per = per < 1 ? 1 : per > 2 ? 2 : per;          // (the grid is the fan-in of the final atomics)
         const int grid = B < 256 * per ? B : 256 * per;
-        hipLaunchKernelGGL(dec_bwd_mfma_kernel, dim3(grid), dim3(512), lm, s, d, q, h, te, dout, dh, dte, gq);
+        hipLaunchKernelGGL(dec_bwd_mfma_kernel, dim3(grid), dim3(512), lm, s, d, q, h, te, dout, dh, dte, gq, slabs ? 1 : 0);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }

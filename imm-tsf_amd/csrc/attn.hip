@@ -211,6 +211,157 @@ __global__ __launch_bounds__(256) void ragged_attn_fwd_kernel(RaggedAttnDims dm,
     }
 }
 
+// 16-byte pieces of a K row
+template <typename KT> struct KVec;
+template <> struct KVec<float> {
+    static constexpr int W = 4;
+    typedef float4 raw;
+    static __device__ __forceinline__ raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ void unpack(const raw& r, float (&o)[4]) { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+};
+template <> struct KVec<bf16_t> {
+    static constexpr int W = 8;
+    typedef uint4 raw;
+    static __device__ __forceinline__ raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+    static __device__ __forceinline__ void unpack(const raw& r, float (&o)[8]) {
+        const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(w[j] << 16); o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+    }
+};
+constexpr int RS_PCS = 3;       // 16-byte pieces of a K row per lane: hd <= 192 W
+
+// Windows of <= NV (32 / 64) padded notes and <= TT forecast steps, the fusion's own regime: ONE round of global loads.  The general
+// kernel above walks a window's notes as dependent rounds -- two notes' keys per wave and pass, eight value rows per step, the
+// dropout tile behind the softmax: ~14 global round trips of 1 - 2 us for a 32-note window (27.9 us in the 64-window step).  Here
+// every load a thread needs -- its value column (NV rows), eight notes' keys per wave as 16-byte pieces, the row map -- is issued
+// up front, the dropout scales are generated while they fly, each wave does the softmax over the <= 64 scores in its own lanes
+// (no second barrier; the weights reach the columns by v_readlane), one barrier in all.  grid (B, H, ceil(hd/256)), 256 threads.
+template <typename KT, int NV>
+__global__ __launch_bounds__(256) void ragged_attn_fwd_short_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
+                                                                     const int* __restrict__ rowmap, const KT* __restrict__ KVp,
+                                                                     const float* __restrict__ qs, float* __restrict__ P,
+                                                                     float* __restrict__ ctx, DropCfg drop, uint64_t site,
+                                                                     bf16_t* __restrict__ ctx_h) {
+    typedef KVec<KT> V;
+    constexpr int W = V::W;
+    __shared__ float sc[NV];
+    __shared__ __attribute__((aligned(16))) float mt[TT * NV];       // dropout scale of (forecast step, note); 0 past T / n
+    const int b = blockIdx.x, h = blockIdx.y, ez = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
+    const int ob = offsets[b], n = offsets[b + 1] - ob;
+    const int e = ez * 256 + tid;
+    const bool valid = e < hd;
+    if (n == 0) {   // no notes: the caller zeroes the row after out_proj anyway (M_txt); keep ctx defined
+        if (valid) for (int t = 0; t < T; ++t) {
+            const size_t o = (size_t)(b * T + t) * d + h * hd + e;
+            if (ctx) ctx[o] = 0.f;
+            if (ctx_h) ctx_h[o] = (bf16_t)0.f;
+        }
+        return;
+    }
+    // this thread's value column (rows past n: the last row again, weight 0)
+    KT vr[NV];
+    {
+        const KT* vbase = KVp + (size_t)ob * ld + d + h * hd + (valid ? e : 0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) vr[i] = vbase[(size_t)(i < n ? i : n - 1) * ld];
+    }
+    // the query's pieces, then eight notes' keys per wave and pass: note i0 + wave + 4 u
+    const int nvp = hd / W;
+    float q[RS_PCS][W];
+#pragma unroll
+    for (int pc = 0; pc < RS_PCS; ++pc) {
+        const int piece = lane + 64 * pc;
+#pragma unroll
+        for (int j = 0; j < W; j += 4) {
+            const float4 t = piece < nvp ? *reinterpret_cast<const float4*>(qs + h * hd + piece * W + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            q[pc][j] = t.x; q[pc][j + 1] = t.y; q[pc][j + 2] = t.z; q[pc][j + 3] = t.w;
+        }
+    }
+    typename V::raw kr[8][RS_PCS];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = wave + 4 * u;
+        const KT* kp = KVp + (size_t)(ob + (i < n ? i : n - 1)) * ld + h * hd;
+#pragma unroll
+        for (int pc = 0; pc < RS_PCS; ++pc) {
+            const int piece = lane + 64 * pc;
+            kr[u][pc] = piece < nvp ? *reinterpret_cast<const typename V::raw*>(kp + piece * W) : V::zero();
+        }
+    }
+    // the dropout scales while the loads are in flight
+    {
+        const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
+        for (int x = tid; x < TT * NV; x += 256) {
+            const int tt = x / NV, ii = x - tt * NV;
+            float a = 0.f;
+            if (tt < T && ii < n) {
+                a = 1.f;
+                if (drop.p > 0.f) {
+                    const int n_orig = rowmap[ob + ii] - b * dm.N;
+                    const uint64_t idx = ((uint64_t)(b * T + tt) * dm.H + h) * dm.N + n_orig;
+                    a = dropout_scale(seed, site, idx, drop.p, drop.inv_keep);
+                }
+            }
+            mt[x] = a;
+        }
+    }
+    for (int i0 = 0;;) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float a = 0.f;
+#pragma unroll
+            for (int pc = 0; pc < RS_PCS; ++pc) {
+                float k[W];
+                V::unpack(kr[u][pc], k);
+#pragma unroll
+                for (int j = 0; j < W; ++j) a = fmaf(q[pc][j], k[j], a);
+            }
+            a = wave_sum(a);
+            const int i = i0 + wave + 4 * u;
+            if (lane == 0 && i < n) sc[i] = a;
+        }
+        i0 += 32;
+        if (i0 >= NV || i0 >= n) break;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + wave + 4 * u;
+            const KT* kp = KVp + (size_t)(ob + (i < n ? i : n - 1)) * ld + h * hd;
+#pragma unroll
+            for (int pc = 0; pc < RS_PCS; ++pc) {
+                const int piece = lane + 64 * pc;
+                kr[u][pc] = piece < nvp ? *reinterpret_cast<const typename V::raw*>(kp + piece * W) : V::zero();
+            }
+        }
+    }
+    __syncthreads();
+    // softmax over the window's n <= 64 scores, in every wave's own lanes
+    const float s_l = lane < n ? sc[lane] : -INFINITY;
+    const float m = wave_max(s_l);
+    float p = lane < n ? expf(s_l - m) : 0.f;
+    p *= 1.f / wave_sum(p);
+    if (wave == 0 && ez == 0 && lane < n) P[(size_t)(ob + lane) * dm.H + h] = p;
+    if (!valid) return;
+    float pv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) pv[i] = lane_bcast(p, i) * (float)vr[i];        // (weight 0 past n)
+    const size_t obase = (size_t)b * T * d + h * hd + e;
+#pragma unroll 2
+    for (int tt = 0; tt < T; ++tt) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; i += 4) {
+            const float4 m4 = *reinterpret_cast<const float4*>(mt + tt * NV + i);
+            acc = fmaf(m4.x, pv[i], acc); acc = fmaf(m4.y, pv[i + 1], acc); acc = fmaf(m4.z, pv[i + 2], acc); acc = fmaf(m4.w, pv[i + 3], acc);
+        }
+        const size_t o = obase + (size_t)tt * d;
+        if (ctx) ctx[o] = acc;
+        if (ctx_h) ctx_h[o] = (bf16_t)acc;
+    }
+}
+
 constexpr int MT = 4;   // backward keeps the dropout scales of up to MT*64 forecast steps in registers
 
 // Backward, part 1.  grid (B, H, ceil(hd/64)), 256 threads: every workgroup owns 64 head columns of one window,
@@ -1238,6 +1389,20 @@ static int ragged_attn_fwd_impl(RaggedAttnDims dm, const int* offsets, const int
                            ctx, ch);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
+    }
+    {   // the fusion's own regime: short windows, one round of loads (ragged_attn_fwd_short_kernel); IMMTSF_RAGGED_SHORT=0: off
+        static const bool on = !(getenv("IMMTSF_RAGGED_SHORT") && atoi(getenv("IMMTSF_RAGGED_SHORT")) == 0);
+        constexpr int W = KVec<KT>::W;
+        if (on && dm.N <= 64 && dm.T <= TT && (dm.hd % W) == 0 && dm.hd / W <= 64 * RS_PCS && (reinterpret_cast<uintptr_t>(KVp) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(qs) & 15) == 0) {
+            const dim3 grid(dm.B, dm.H, cdiv(dm.hd, 256));
+            if (dm.N <= 32)
+                hipLaunchKernelGGL((ragged_attn_fwd_short_kernel<KT, 32>), grid, dim3(256), 0, s, dm, offsets, rowmap, KVp, qs, P, ctx, drop, site, ch);
+            else
+                hipLaunchKernelGGL((ragged_attn_fwd_short_kernel<KT, 64>), grid, dim3(256), 0, s, dm, offsets, rowmap, KVp, qs, P, ctx, drop, site, ch);
+            IMMTSF_LAUNCH_CHECK();
+            return IMMTSF_OK;
+        }
     }
     const size_t lds = (size_t)(dm.N + TT * 64 + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;

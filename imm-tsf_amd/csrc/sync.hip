@@ -9,7 +9,20 @@
 
 namespace {
 
+// optional trace of the flag kernels (immtsf_flag_trace / immtsf_flag_trace_read; tools/flag_timeline.py): who waited for whom, and
+// how long, inside a replayed step -- on the 100 MHz wall clock, without a profiler serialising the two branches
+constexpr int FT_N = 256;
+__device__ int ft_on;
+__device__ unsigned int ft_count;
+__device__ long long ft_ring[FT_N][3];       // flag address | kind (0 set, 1 wait entered, 2 wait left, 3 clear) | wall clock
+__device__ __forceinline__ void ft_note(const void* flag, int kind) {
+    if (!ft_on) return;
+    const unsigned int i = atomicAdd(&ft_count, 1u);
+    if (i < FT_N) { ft_ring[i][0] = (long long)(uintptr_t)flag; ft_ring[i][1] = kind; ft_ring[i][2] = wall_clock64(); }
+}
+
 __global__ void flag_set_kernel(int* flag) {
+    ft_note(flag, 0);
     __threadfence_system();
     __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -17,6 +30,7 @@ __global__ void flag_set_kernel(int* flag) {
 // reports it in *err
 __global__ void flag_wait_kernel(int* flag, int* err, long long ticks) {
     const long long t0 = wall_clock64();
+    ft_note(flag, 1);
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > ticks) {
@@ -24,9 +38,11 @@ __global__ void flag_wait_kernel(int* flag, int* err, long long ticks) {
             break;
         }
     }
+    ft_note(flag, 2);
     __threadfence_system();
 }
 __global__ void flags_clear_kernel(int* flags, int n) {
+    if (threadIdx.x == 0) ft_note(flags, 3);
     if ((int)threadIdx.x < n) flags[threadIdx.x] = 0;
 }
 
@@ -51,6 +67,28 @@ int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream) {
     hipLaunchKernelGGL(flags_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), flags, n);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+
+/* trace of the flag kernels: enable != 0 empties the ring and switches recording on, 0 switches it off (synchronises the device) */
+int immtsf_flag_trace(int32_t enable) {
+    const int on = enable ? 1 : 0;
+    const unsigned int zero = 0u;
+    if (hipDeviceSynchronize() != hipSuccess) return IMMTSF_EINVAL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ft_count), &zero, sizeof(zero)) != hipSuccess) return IMMTSF_EINVAL;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ft_on), &on, sizeof(on)) != hipSuccess) return IMMTSF_EINVAL;
+    return IMMTSF_OK;
+}
+/* the recorded entries, three int64 each (flag address, kind: 0 set / 1 wait entered / 2 wait left / 3 clear, 100 MHz wall clock), at
+ * most max_entries (<= 256) of them; returns the count, < 0 on error (synchronises the device) */
+int immtsf_flag_trace_read(int64_t* out, int32_t max_entries) {
+    if (!out || max_entries <= 0) return -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(ft_count), sizeof(n)) != hipSuccess) return -1;
+    if (n > (unsigned)FT_N) n = FT_N;
+    if (n > (unsigned)max_entries) n = (unsigned)max_entries;
+    if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_ring), sizeof(long long) * 3 * n) != hipSuccess) return -1;
+    return (int)n;
 }
 
 }  // extern "C"

@@ -1427,21 +1427,18 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
     return IMMTSF_OK;
 }
 
-/* dP (B*T, PW), dbHO (C) -> dE_txt (B*T, d) and the gradients of every parameter except LayerNorm's (all overwritten) */
-int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
-                                const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
-                                size_t scratch_bytes, const immtsf_xadd_params* gr, immtsf_stream_t stream) {
-    if (!xr_supported(cfg) || !p || !gr || !E_txt || !dP || !dbHO || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+/* the data half of immtsf_mmf_xrank_p_backward: dE = dP W_fold and dW_fold = dP^T E (+ its column sums) into `scratch` */
+int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
+                                     float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                     immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !E_txt || !dP || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
     XPWs w = carve_xp(cfg, workspace);
     XPScratch sc = carve_xp_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const XRDims x = xr_dims(cfg);
-    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E, BT = x.B * x.T, prec = cfg->precision, Wd = x.Wd;
+    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
     const bool hf = xr_hf(cfg);
-    const float scale = sqrtf(1.0f / (float)E);
-    const float *Wiq = p->attn_in_w, *Wik = p->attn_in_w + (size_t)d * d, *Wiv = p->attn_in_w + (size_t)2 * d * d;
-    const float *bik = p->attn_in_b + d, *biv = p->attn_in_b + 2 * d;
     Mat dPm = cmat(dP), Em = cmat(E_txt, hf ? (cfg->aux_h ? cfg->aux_h : static_cast<const void*>(w.E16)) : nullptr);
     if (hf && !cfg->aux_h) CHECK(launch_f32_to_bf16(E_txt, w.E16, (size_t)BT * d, s));      // (the forward may have been given its own image)
     if (hf && cfg->in_h) {
@@ -1462,9 +1459,29 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         g.ws = sc.sk; g.ws_bytes = sc.skb;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
     }
+    return IMMTSF_OK;
+}
+
+/* the parameter half: the chain rule from dW_fold (in `scratch`, left there by ..._backward_data on a stream this call is ordered
+ * behind) to the block's parameter gradients -- three dependent multi-job launches, of which this call runs [first, last) (0 <= first
+ * <= last <= 3): parameter-only work that nothing but the optimizer waits for, so a caller may run its tail on another stream
+ * (immtsf.train.FlagStep hands it to the backbone's branch, which finishes its backward earlier) */
+int immtsf_mmf_xrank_p_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* dbHO, void* workspace,
+                                       size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* gr,
+                                       int32_t first, int32_t last, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !gr || !dbHO || !workspace || !scratch || first < 0 || last > 3 || first > last) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    XPScratch sc = carve_xp_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, C = x.C, Cq = x.Cq, H = x.H, E = x.E, Wd = x.Wd;
+    const float scale = sqrtf(1.0f / (float)E);
+    const float *Wiq = p->attn_in_w, *Wik = p->attn_in_w + (size_t)d * d, *Wiv = p->attn_in_w + (size_t)2 * d * d;
+    const float *bik = p->attn_in_b + d, *biv = p->attn_in_b + 2 * d;
     float *g_iq = gr->attn_in_w, *g_ik = gr->attn_in_w + (size_t)d * d, *g_iv = gr->attn_in_w + (size_t)2 * d * d;
     float *gb_iq = gr->attn_in_b, *gb_ik = gr->attn_in_b + d, *gb_iv = gr->attn_in_b + 2 * d;
-    {   // T1_h = dG_h W_k^T, RW_h = dU_h W_v^T;  dW_k = scale sum_h GA_h^T dG_h, dW_v = sum_h UA_h^T dU_h;  d b_k, d b_v
+    if (first <= 0 && last > 0) {   // T1_h = dG_h W_k^T, RW_h = dU_h W_v^T;  dW_k = scale sum_h GA_h^T dG_h, dW_v = sum_h UA_h^T dU_h;  d b_k, d b_v
         XJobList L;
         for (int h = 0; h < H; ++h) {
             const size_t r0 = (size_t)h * Wd;
@@ -1481,7 +1498,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         b->ng = H; b->pgs = (long)C * d; b->qgs = (long)Wd * d;
         CHECK(L.launch(s, false));
     }
-    {   // dAqT_h = scale (T1_h W_in,k[head]^T + d b_fold b_k^T), dW_HO,h = RW_h W_in,v[head]^T + d b_fold b_v^T;  dW_in,k, dW_in,v
+    if (first <= 1 && last > 1) {   // dAqT_h = scale (T1_h W_in,k[head]^T + d b_fold b_k^T), dW_HO,h = RW_h W_in,v[head]^T + d b_fold b_v^T;  dW_in,k, dW_in,v
         XJobList L;
         for (int h = 0; h < H; ++h) {
             const size_t r0 = (size_t)h * Wd, o = (size_t)h * E;
@@ -1492,7 +1509,7 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         }
         CHECK(L.launch(s, false));
     }
-    {   // the query side and the output side: W_Qf = W_in,q W_q, W_HO = W_res W_out, b_HO = W_res b_out + b_res
+    if (first <= 2 && last > 2) {   // the query side and the output side: W_Qf = W_in,q W_q, W_HO = W_res W_out, b_HO = W_res b_out + b_res
         XJobList L;
         L.outer(sc.dAqT, d, C, p->proj_q_w, 1, d, d, g_iq, d, 1.f)->qsn = C;            // dW_in,q[m][n] = sum_c dAqT[c][m] W_q[n][c]
         L.copy(sc.dAqT + (size_t)C * d, d, gb_iq);                                       // d b_q = row C of dAqT
@@ -1504,6 +1521,15 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
         CHECK(L.launch(s, false));
     }
     return IMMTSF_OK;
+}
+
+/* dP (B*T, PW), dbHO (C) -> dE_txt (B*T, d) and the gradients of every parameter except LayerNorm's (all overwritten) */
+int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
+                                const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
+                                size_t scratch_bytes, const immtsf_xadd_params* gr, immtsf_stream_t stream) {
+    if (!gr || !dbHO) return IMMTSF_EINVAL;
+    if (int rc = immtsf_mmf_xrank_p_backward_data(cfg, p, E_txt, dP, dE_txt, workspace, workspace_bytes, scratch, scratch_bytes, stream)) return rc;
+    return immtsf_mmf_xrank_p_backward_params(cfg, p, dbHO, workspace, workspace_bytes, scratch, scratch_bytes, gr, 0, 3, stream);
 }
 
 int immtsf_mmf_xrank_q_forward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,

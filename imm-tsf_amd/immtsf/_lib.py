@@ -121,6 +121,10 @@ _PROTOS = {
                                            c_stream]),
     "immtsf_mmf_xrank_p_backward": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
+    "immtsf_mmf_xrank_p_backward_data": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
+                                                 C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xrank_p_backward_params": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                   C.c_size_t, _P(XAddParams), C.c_int32, C.c_int32, c_stream]),
     "immtsf_mmf_xrank_q_forward": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,
                                            C.c_size_t, c_stream]),
     "immtsf_mmf_xrank_q_backward": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
@@ -236,6 +240,8 @@ _PROTOS = {
     "immtsf_flag_set": (C.c_int, [C.c_void_p, c_stream]),
     "immtsf_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_flags_clear": (C.c_int, [C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_flag_trace": (C.c_int, [C.c_int32]),
+    "immtsf_flag_trace_read": (C.c_int, [C.c_void_p, C.c_int32]),
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
     "immtsf_debug_gemm_config": (C.c_int, [C.c_int32, C.c_int32]),
     "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),

@@ -103,4 +103,7 @@ attn_mid = _os.environ.get("IMMTSF_ATTN_MID", "1") != "0"
 # a torch.cuda.Stream on which MMF_XAttn_Add's fold (parameters only) may run ahead of the text side (None: in line); the stream
 # must be ordered behind the previous optimizer step (immtsf.train.FlagStep forks it at the start of the captured step)
 fold_stream = None
+param_tail = None        # FlagStep: {"flag": (address, time-out report address), "jobs": []} -- ops whose parameter-gradient tail nothing but the
+                         # optimizer waits for (MMF_XAttn_Add's chain rule through the fold) set the flag behind the data half and
+                         # leave the tail as a job (a callable taking a raw stream) for the branch that has time to spare
 fold_flag = None          # (flag address, time-out report address): hand the fold over through a device flag instead of a stream event

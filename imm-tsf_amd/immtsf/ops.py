@@ -527,8 +527,25 @@ class MMFXRankPFn(torch.autograd.Function):
             cfg.aux_h = None if ctx.E_h is None else ctx.E_h.data_ptr()
             dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
             cfg.out_h = dE_h.data_ptr()
-        check(lib.immtsf_mmf_xrank_p_backward(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dbHO), ptr(dE), ptr(ctx.ws), ctx.ws.numel(),
-                                              ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "mmf_xrank_p_backward")
+        tail = config.param_tail
+        if tail is not None and all(r is None for r in rets[:9]) and tail["defer"] > 0:
+            # every gradient goes straight to its sink: the last `defer` launches of the parameter chain are left to the other branch
+            k = 3 - min(3, int(tail["defer"]))
+            check(lib.immtsf_mmf_xrank_p_backward_data(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
+                                                       sc.numel(), stream_ptr()), "mmf_xrank_p_backward_data")
+            ws = ctx.ws
+
+            def run_params(stream, first, last, cfg=cfg, ps=ps, gs=gs, dbHO=dbHO, ws=ws, sc=sc, keep=(params, grads)):
+                check(lib.immtsf_mmf_xrank_p_backward_params(C.byref(cfg), C.byref(ps), ptr(dbHO), ptr(ws), ws.numel(), ptr(sc), sc.numel(),
+                                                             C.byref(gs), first, last, stream), "mmf_xrank_p_backward_params")
+
+            if k > 0:
+                run_params(stream_ptr(), 0, k)
+            check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
+            tail["jobs"].append(lambda stream: run_params(stream, k, 3))
+        else:
+            check(lib.immtsf_mmf_xrank_p_backward(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dbHO), ptr(dE), ptr(ctx.ws), ctx.ws.numel(),
+                                                  ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "mmf_xrank_p_backward")
         if dE_h is not None:
             _shadow_put(dE, dE_h)
         _fire(ctx.done_hook)

@@ -756,6 +756,7 @@ class FlagStep(PhasedStep):
         fs = os.environ.get("IMMTSF_FOLD_STREAM", "3")          # ("3": as "2", handed over through a device flag instead of an event)
         self.L = torch.cuda.Stream(device=dev) if fs == "1" else self.B if fs in ("2", "3") else None
         self._fold_by_flag = fs == "3"
+        self._defer = int(os.environ.get("IMMTSF_PARAM_TAIL", "1"))      # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
@@ -821,11 +822,23 @@ class FlagStep(PhasedStep):
                 fwait(F_T2, B)
                 torch.autograd.backward([pred], [dpy])
                 trainer.collect_grads()
+            # parameter-gradient tails of the text side (work only the optimizer waits for) go to the END of the backbone's branch,
+            # which finishes its backward first (tools/flag_timeline.py: 60 us earlier at 64 windows); flag 4 says their inputs exist
+            tail = {"flag": (fp + 16, F_ERR), "jobs": [], "defer": self._defer}
+            config.param_tail = tail if self._defer > 0 else None
+            try:
+                self._text_backward(outs, dcuts)
+            finally:
+                config.param_tail = None
+            with torch.cuda.stream(B):
+                if tail["jobs"]:
+                    fwait(fp + 16, B)
+                    for job in tail["jobs"]:
+                        job(sp(B))
                 fset(F_B2, B)
-            self._text_backward(outs, dcuts)
             fwait(F_B2, T)
             T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
-            _lib.check(lib.immtsf_flags_clear(fp, 4, sp(T)), "flags_clear")
+            _lib.check(lib.immtsf_flags_clear(fp, 5, sp(T)), "flags_clear")
             trainer.step()
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)

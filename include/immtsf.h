@@ -217,6 +217,17 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
 int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
                                 const float* dbHO, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
                                 size_t scratch_bytes, const immtsf_xadd_params* grads, immtsf_stream_t stream);
+/* The two halves of immtsf_mmf_xrank_p_backward, for callers that order them themselves.  ..._data: dE_txt = dP W_fold and dW_fold =
+ * dP^T E_txt (+ column sums) into `scratch`.  ..._params: the chain rule from dW_fold to the block's parameter gradients, three
+ * dependent multi-job launches of which the call runs [first, last) (0 <= first <= last <= 3) -- parameter-only work that only the
+ * optimizer waits for, so its tail may run on another stream ordered behind ..._data (immtsf.train.FlagStep gives it to the
+ * backbone's branch).  Same workspace / scratch as the combined call. */
+int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
+                                     float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                                     immtsf_stream_t stream);
+int immtsf_mmf_xrank_p_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* dbHO, void* workspace,
+                                       size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
+                                       int32_t first, int32_t last, immtsf_stream_t stream);
 int immtsf_mmf_xrank_q_forward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
                                const float* bHO, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
                                immtsf_stream_t stream);
@@ -641,6 +652,12 @@ int immtsf_set_side_stream(int32_t on);
 int immtsf_flag_set(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait(int32_t* flag, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
 int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream);
+/* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
+ * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (256 entries) and starts recording, (0) stops;
+ * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,
+ * 3 clear), wall clock -- and returns their count (< 0: error).  Both synchronise the device. */
+int immtsf_flag_trace(int32_t enable);
+int immtsf_flag_trace_read(int64_t* out, int32_t max_entries);
 int immtsf_side_stream_enabled(void);
 /* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);

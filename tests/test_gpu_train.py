@@ -550,3 +550,40 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
     finally:
         bench.P_DROP = old_drop
         config.precision = "fp32"
+
+
+@pytest.mark.gpu
+def test_device_flags_and_their_trace():
+    """immtsf_flag_set / immtsf_flag_wait across two streams (csrc/sync.hip) and the trace the flag kernels keep when asked
+    (immtsf_flag_trace / immtsf_flag_trace_read, tools/flag_timeline.py): the consumer's wait is entered before the producer's set and
+    left after it, on one clock; a wait on a flag nobody sets gives up and reports it."""
+    import ctypes as C
+    from immtsf import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    flags = torch.zeros(16, dtype=torch.int32, device=dev)
+    fp = flags.data_ptr()
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    _lib.check(lib.immtsf_flag_trace(1), "flag_trace")
+    _lib.check(lib.immtsf_flag_wait(fp, fp + 32, 2000, b.cuda_stream), "flag_wait")        # spins until stream a gets there
+    x = torch.randn(2048, 2048, device=dev)
+    with torch.cuda.stream(a):
+        for _ in range(4):
+            x = x @ x * 1e-3
+        _lib.check(lib.immtsf_flag_set(fp, a.cuda_stream), "flag_set")
+    buf = (C.c_int64 * (3 * 16))()
+    n = lib.immtsf_flag_trace_read(buf, 16)
+    assert n == 3
+    ev = {int(buf[3 * i + 1]): int(buf[3 * i + 2]) for i in range(n)}
+    assert all(int(buf[3 * i]) == fp for i in range(n))
+    assert ev[1] <= ev[0] <= ev[2], ev                  # entered <= set <= left
+    assert int(flags[0]) == 1 and int(flags[8]) == 0
+    _lib.check(lib.immtsf_flags_clear(fp, 4, a.cuda_stream), "flags_clear")
+    _lib.check(lib.immtsf_flag_wait(fp + 4, fp + 32, 1, a.cuda_stream), "flag_wait")        # nobody sets flag 1: gives up after 1 ms
+    torch.cuda.synchronize()
+    assert int(flags[8]) == 1
+    assert lib.immtsf_flag_trace_read(buf, 16) == 6     # + clear, wait entered, wait left
+    _lib.check(lib.immtsf_flag_trace(0), "flag_trace")
+    _lib.check(lib.immtsf_flag_set(fp, a.cuda_stream), "flag_set")
+    assert lib.immtsf_flag_trace_read(buf, 16) == 0

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Where the two branches of immtsf.train.FlagStep wait for each other inside a replayed step: the flag kernels' own trace
+(immtsf_flag_trace, 100 MHz device wall clock -- no profiler, nothing serialised).  Prints, per step, the time of every flag event
+after the previous step's flags_clear, and how long each wait spun.  usage: flag_timeline.py [windows] [steps]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "imm-tsf_amd")]
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+
+def main():
+    from immtsf import _lib, config
+    W = int(sys.argv[1]) if len(sys.argv) > 1 else bench.B_PER_GPU
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    config.nan_check = "deferred"
+    config.manual_seed(1234)
+    w = bench.Workload("cfg2", dev, W, os.environ.get("PREC", "bf16"))
+    st = bench.flag_step(w)
+    if st is None:
+        raise SystemExit("FlagStep not available for this workload")
+    for _ in range(20):
+        st()
+    base = st.flags.data_ptr()
+    names = {0: "backbone forward done", 4: "head: dY published", 8: "backbone backward done", 12: "fold done"}
+    _lib.check(lib.immtsf_flag_trace(1), "flag_trace")
+    for _ in range(steps):
+        st()
+    buf = (C.c_int64 * (3 * 256))()
+    n = lib.immtsf_flag_trace_read(buf, 256)
+    lib.immtsf_flag_trace(0)
+    ev = sorted(((buf[3 * i + 2], buf[3 * i] - base, buf[3 * i + 1]) for i in range(n)))
+    kinds = {0: "set", 1: "wait entered", 2: "wait left", 3: "flags cleared (optimizer follows)"}
+    t_clear, step = None, 0
+    entered = {}
+    for t, off, kind in ev:
+        if kind == 3:
+            if t_clear is not None:
+                print("  step %d: %.1f us from clear to clear" % (step, (t - t_clear) / 100.0))
+            t_clear, step = t, step + 1
+            continue
+        if t_clear is None:
+            continue
+        rel = (t - t_clear) / 100.0
+        extra = ""
+        if kind == 1:
+            entered[off] = t
+        if kind == 2 and off in entered:
+            extra = "  (spun %.1f us)" % ((t - entered.pop(off)) / 100.0)
+        print("    +%7.1f us  %-26s %s%s" % (rel, names.get(off, "flag %d" % off), kinds[kind], extra))
+
+
+if __name__ == "__main__":
+    main()

@@ -631,6 +631,8 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
     GemmGroupArgs gg;
     memset(&gg, 0, sizeof(gg));
     int tiles = 0;
+    // IMMTSF_GROUP_TILE=128: 128 x 128 tiles (two K-groups of 2 x 2 waves) -- a quarter of the workgroups, half the operand traffic
+    static const int gt = (getenv("IMMTSF_GROUP_TILE") && atoi(getenv("IMMTSF_GROUP_TILE")) == 128) ? 128 : 64;
     for (int i = 0; i < n; ++i) {
         GemmArgs g = list[i];
         if (!immtsf_gemm2_supported(GEMM_TN, g) || g.nprob != 1 || g.act != 0 || g.relu_ref || g.row_flag || g.add_vec || g.accumulate ||
@@ -640,7 +642,7 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
         g.xcd_remap = 0; g.xcd_gm = 0; g.g2_fast = 0;
         gg.sub[i] = g;
         gg.tile0[i] = tiles;
-        tiles += cdiv(g.M, 64) * cdiv(g.N, 64);
+        tiles += cdiv(g.M, gt) * cdiv(g.N, gt);
     }
     // (four rounds of one-workgroup-per-CU tiles at most: with a wide member -- 768 x 4096 at LLaMA-width embeddings, 768 tiles of its
     // own -- the separate launches are as good or better: cfg3 1.349 grouped vs 1.331 ms)
@@ -648,8 +650,11 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
     gg.tile0[n] = tiles;
     for (int i = n + 1; i <= G2_GROUP_MAX; ++i) gg.tile0[i] = tiles;
     gg.n = n;
-    immtsf_gemm_note_grid((long)tiles * 1024);
-    hipLaunchKernelGGL((gemm2_group_kernel<true, true, 64, 64, 2, 2, 2, 4>), dim3(tiles), dim3(1024), 0, stream, gg);
+    immtsf_gemm_note_grid((long)tiles * (gt == 128 ? 512 : 1024));
+    if (gt == 128)
+        hipLaunchKernelGGL((gemm2_group_kernel<true, true, 128, 128, 2, 2, 2, 2>), dim3(tiles), dim3(512), 0, stream, gg);
+    else
+        hipLaunchKernelGGL((gemm2_group_kernel<true, true, 64, 64, 2, 2, 2, 4>), dim3(tiles), dim3(1024), 0, stream, gg);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

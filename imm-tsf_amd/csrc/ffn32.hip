@@ -94,13 +94,13 @@ struct RowsArgs {
 // hidden dimension (F / 256 chunks each instead of F / 32: the wave's walk over the chunks is the kernel's whole duration), their
 // partial output tiles meet in LDS.  At 1024 rows (64 windows) the feed-forward then is 2 + 3 short launches on 64 CUs instead of
 // 3 + 4 GEMM launches of up to 512 workgroups.
-template <int RT, bool BWD, bool SPLIT = false>
-__global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
+template <int RT, bool BWD, bool SPLIT = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void ffn32_rows_kernel(const RowsArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int rt0 = __builtin_amdgcn_readfirstlane(SPLIT ? (int)blockIdx.x : (int)(blockIdx.x * 4 + wave) * RT);
     if (!SPLIT && rt0 >= a.nrt) return;
     const int F = a.F, NC = F >> 5;
-    const int c0 = SPLIT ? __builtin_amdgcn_readfirstlane(wave * (NC >> 2)) : 0, c1 = SPLIT ? c0 + (NC >> 2) : NC;
+    const int c0 = SPLIT ? __builtin_amdgcn_readfirstlane(wave * (NC / NW)) : 0, c1 = SPLIT ? c0 + (NC / NW) : NC;
     bf16x8 xb[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -207,13 +207,13 @@ __global__ __launch_bounds__(256) void ffn32_rows_kernel(const RowsArgs a) {
         }
     }
     if (SPLIT) {          // the eight waves' partial tiles of the one row tile: summed by wave 0
-        __shared__ __attribute__((aligned(16))) float red[4][64][8];
+        __shared__ __attribute__((aligned(16))) float red[NW][64][8];
         *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = acc[0][0];
         *reinterpret_cast<f32x4*>(&red[wave][lane][4]) = acc[0][1];
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             acc[0][0] += *reinterpret_cast<const f32x4*>(&red[w][lane][0]);
             acc[0][1] += *reinterpret_cast<const f32x4*>(&red[w][lane][4]);
         }
@@ -453,7 +453,13 @@ int ffn32_forward(int R, int F, const DropCfg& dd, uint64_t site, const float* x
     a.drop = dd; a.site = site; a.scale = dd.p > 0.f ? dd.inv_keep : 1.f;
     const int rt = a.nrt >= 16384 ? 4 : a.nrt >= 4096 ? 2 : 1;       // >= 2 waves per SIMD first (the Philox draws are VALU work)
     const int grid = (a.nrt + 4 * rt - 1) / (4 * rt);
-    if (a.nrt <= ffn32_split_max()) hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true>), dim3(a.nrt), dim3(256), 0, s, a);       // few rows: split the hidden dimension
+    // few rows: split the hidden dimension -- over EIGHT waves in the forward, whose chunk is ~450 instructions of Philox, ballots and
+    // mask packing issued back to back by a lone wave per SIMD (17.8 us for 1024 rows on four waves); the backward stays on four (an
+    // eight-wave backward produced wrong data gradients: DESIGN 6)
+    static const bool fwd8 = !(getenv("IMMTSF_FFN32_FWD8") && atoi(getenv("IMMTSF_FFN32_FWD8")) == 0);
+    if (a.nrt <= ffn32_split_max() && fwd8 && ((a.F >> 5) % 8) == 0)
+        hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true, 8>), dim3(a.nrt), dim3(512), 0, s, a);
+    else if (a.nrt <= ffn32_split_max()) hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true>), dim3(a.nrt), dim3(256), 0, s, a);
     else if (rt == 4) hipLaunchKernelGGL((ffn32_rows_kernel<4, false>), dim3(grid), dim3(256), 0, s, a);
     else if (rt == 2) hipLaunchKernelGGL((ffn32_rows_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((ffn32_rows_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);

@@ -640,6 +640,22 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
             return IMMTSF_EUNSUPPORTED;
         g.vecA = 1; g.vecB = 1; g.vecC = 1;
         g.xcd_remap = 0; g.xcd_gm = 0; g.g2_fast = 0;
+        // a member whose first workgroup is a multiple of 8 keeps "workgroup i runs on XCD i % 8" in its own numbering: the exact 2-D XCD
+        // partition of the single launch (each L2 fetches 1/XR of A and 1/XC of B; without it the grouped launch fetched 147 MB for
+        // ~30 MB of operands, profiles/r03i_pmc_traffic.json).  IMMTSF_GROUP_XCD=0: off
+        static const bool gx_on = !(getenv("IMMTSF_GROUP_XCD") && atoi(getenv("IMMTSF_GROUP_XCD")) == 0);
+        if (gx_on && (tiles & 7) == 0) {
+            const int tiles_m = cdiv(g.M, gt), tiles_n = cdiv(g.N, gt);
+            int best = 0;
+            long best_cost = 0;
+            for (int XR = 1; XR <= 8; XR *= 2) {
+                const int XC = 8 / XR;
+                if (tiles_m % XR || tiles_n % XC) continue;
+                const long cost = (long)(tiles_m / XR) + (long)(tiles_n / XC);
+                if (!best || cost < best_cost) { best = XR; best_cost = cost; }
+            }
+            if (best) { g.xcd_remap = 8; g.xcd_gm = best; }
+        }
         gg.sub[i] = g;
         gg.tile0[i] = tiles;
         tiles += cdiv(g.M, gt) * cdiv(g.N, gt);

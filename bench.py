@@ -339,11 +339,9 @@ class Workload:
 FLAGS_MAX_WINDOWS = 512      # FlagStep wins where the step is a latency chain (64 windows: -3 %, 256: -2 %, 512: -1 %); beyond, GraphedStep
 
 
-def flag_step(w):
-    """immtsf.train.FlagStep for a single-process cfg2-style workload (text side | backbone | head), or None when the workload does
-    not decompose that way or a spin timed out in three trial replays (the caller then uses GraphedStep)."""
+def flag_fns(w):
+    """(text_fn, backbone_fn, head_fn) of a cfg2-style workload (text side | backbone | head), or None when it does not decompose"""
     from immtsf.ops import masked_mse
-    from immtsf.train import FlagStep
     fusion = w.fusion
     if w.side is None or not hasattr(fusion, "ttf") or not hasattr(fusion.mmf, "project_kv") or not w.graphable:
         return None
@@ -360,11 +358,69 @@ def flag_step(w):
         out = fusion.mmf(pred, E, M, kv=(kv, fold))
         return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, w.global_cnt)
 
-    st = FlagStep(w.trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
+    return text_fn, (lambda: w.model.forecasting(*fc_args)), head_fn
+
+
+def flag_step(w):
+    """immtsf.train.FlagStep for a cfg2-style workload -- single process, or data parallel with the bucketed all-reduce beside the
+    backward -- or None when the workload does not decompose that way or a spin timed out (on any rank) in three trial replays; the
+    trial steps are undone (parameters, moments, counters restored), so the caller's first step is training step 1 either way."""
+    from immtsf.train import FlagStep
+    fns = flag_fns(w)
+    if fns is None or w.trainer.sharded:
+        return None
+    st = FlagStep(w.trainer, *fns)
+    snap = w.trainer.snapshot()
     for _ in range(3):
         st()
     torch.cuda.synchronize()
-    return None if st.timed_out() else st
+    try:
+        st.check()                 # (a collective when the trainer has a process group: every rank takes the same branch)
+        ok = True
+    except Exception as e:         # noqa: BLE001
+        print(f"# FlagStep rejected: {e}", file=sys.stderr)
+        ok = False
+    w.trainer.restore(snap)
+    w.trainer.flat_grad.zero_()
+    torch.cuda.synchronize()
+    if not ok:
+        st.clear_error()
+    return st if ok else None
+
+
+def build_step(w, mode="auto", dist_on=False, captured_comm=False):
+    """the step engine bench.py times for workload `w` -- also what tests/test_gpu_train.py::test_cfg2_step_vs_oracle runs, so that the
+    oracle comparison covers the timed composition.  mode: "auto" (FlagStep up to FLAGS_MAX_WINDOWS windows per GPU where the
+    workload decomposes, GraphedStep otherwise), "flags", "graphed", "phased", "eager".  Returns (step, info)."""
+    from immtsf.train import GraphedStep, PhasedStep
+    trainer = w.trainer
+    info = {"engine": None, "flag_step_rejected": False}
+    if mode == "eager" or not w.graphable:
+        info["engine"] = "eager"
+        return w.eager_step, info
+    step = None
+    if dist_on and captured_comm:
+        # RCCL all-reduces captured inside graph A, bucket by bucket on the communication stream while the backward of the later
+        # buckets still runs.  A failed capture leaves the HIP context unusable (seen with gloo, which cannot be captured): no fallback
+        step = GraphedStep(trainer, w.loss_fn, capture_collectives=True)
+        info["engine"] = "graphed+captured-comm"
+        return step, info
+    if mode == "phased":
+        fns = flag_fns(w)
+        if fns is not None:
+            info["engine"] = "phased"
+            return PhasedStep(trainer, *fns), info
+    if mode == "flags" or (mode == "auto" and w.B <= FLAGS_MAX_WINDOWS):
+        step = flag_step(w)
+        if step is not None:
+            info["engine"] = "flags"
+            return step, info
+        info["flag_step_rejected"] = flag_fns(w) is not None and not trainer.sharded
+    if dist_on:
+        trainer.overlap = False
+    step = GraphedStep(trainer, w.loss_fn)
+    info["engine"] = "graphed"
+    return step, info
 
 
 def time_steps(step, steps, warmup, barrier):
@@ -601,6 +657,39 @@ def dropin_ms(dev, precision, steps=20, warmup=5):
         config.nan_check = old
 
 
+def spawn_ranks(n):
+    """run this script as n ranks on one node (python -m torch.distributed.run ...) in a child process group; stdout of the
+    children is scanned for rank 0's JSON line, which is printed last; returns the launcher's exit code"""
+    import socket
+    import subprocess
+    share = bool(os.environ.get("IMMTSF_BENCH_SHARE_GPU"))
+    have = torch.cuda.device_count()             # (counting devices does not initialise the GPU)
+    if have < n and not share:
+        print(f"bench.py --gpus {n}: only {have} GPU(s) visible", file=sys.stderr)
+        return 2
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    return rc if rc else (0 if line is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -620,7 +709,7 @@ def main():
                          "of the whole step as parallel branches of one hipGraph (DESIGN.md section 6 has both measured)")
     ap.add_argument("--flags", action="store_true",
                     help="immtsf.train.FlagStep at any batch size: one hipGraph whose two branches synchronise through device flags "
-                         "(spin kernels) instead of graph edges (single process; the default up to 128 windows per GPU)")
+                         f"(spin kernels) instead of graph edges (the default up to {FLAGS_MAX_WINDOWS} windows per GPU)")
     ap.add_argument("--no-flags", action="store_true", help="GraphedStep (graph edges between the branches) at every batch size")
     ap.add_argument("--captured-comm", action="store_true",
                     help="N>1 graph mode: capture the bucketed RCCL all-reduces inside graph A (overlapped with the backward). "
@@ -655,8 +744,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start N FRESH rank processes (torch.distributed.run) before anything in
+        # this one has touched the GPU, relay rank 0's JSON line and exit with the launcher's code.  (Never an exec: a process that
+        # has initialised the GPU must not be replaced; this parent never initialises it.)
+        sys.stdout = json_out
+        raise SystemExit(spawn_ranks(args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+        raise SystemExit(f"--gpus {args.gpus} with WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     assert torch.cuda.is_available(), "bench.py needs the MI355X"
     # control-flow test of the N>1 path on a 1-GPU box: IMMTSF_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo
     # (RCCL refuses two ranks on one device); numbers from such a run mean nothing
@@ -679,7 +774,7 @@ def main():
 
     from immtsf import _lib, config
     from immtsf.ops import masked_mse
-    from immtsf.train import FlagStep, GraphedStep, PhasedStep
+    from immtsf.train import GraphedStep
     lib = _lib.load()
     if args.gemm_config:
         lib.immtsf_debug_gemm_config(args.gemm_config, 0)
@@ -706,59 +801,42 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(w.global_cnt)
 
-    # hipGraph replay (immtsf.train.GraphedStep): graph A = zero-grad, backbone + fusion forward, loss, backward, gradient
-    # collection; [N>1: eager RCCL all-reduce of the flat gradient]; graph B = clip + Adam + device-side counters
-    launch_mode = ("hipGraph replay (2 graphs/step)" if use_graph else "eager launches") + \
-                  ("" if args.no_overlap else ", backbone on a second HIP stream beside TTF")
-    if use_graph:
-        step = None
+    # hipGraph replay.  One process: ONE graph per step whose two branches (text side | backbone) synchronise through device flags
+    # (immtsf.train.FlagStep) up to FLAGS_MAX_WINDOWS windows per GPU, beyond that graph edges (GraphedStep).  N > 1: the same flag
+    # graph without the optimizer, the bucketed all-reduce on a communication stream BESIDE the backward (a counting device flag per
+    # bucket), what completes with the join reduced behind the graph, then graph B = clip + Adam
+    mode = "eager" if not use_graph else "phased" if args.phased else "graphed" if (args.no_flags or args.no_overlap) else \
+           "flags" if args.flags else "auto"
+    if dist_on and sharded and mode in ("auto", "flags"):
+        mode = "graphed"
+    try:
+        step, step_info = build_step(w, mode, dist_on=dist_on, captured_comm=bool(dist_on and args.captured_comm and use_graph))
+    except Exception as e:      # noqa: BLE001
         if dist_on and args.captured_comm:
-            # RCCL all-reduces captured inside graph A, bucket by bucket on the communication stream while the backward
-            # of the later buckets still runs.  A failed capture leaves the HIP context unusable (seen with gloo, which
-            # cannot be captured), so there is no fallback: run without the flag instead
-            try:
-                step = GraphedStep(trainer, w.loss_fn, capture_collectives=True)
-                comm_mode = "captured, bucketed"
-            except Exception as e:      # noqa: BLE001
-                raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
-                                 "re-run without the flag (eager all-reduce between the two graphs)") from e
-        if step is None and (args.phased or (args.flags and not dist_on)) and not args.no_overlap and hasattr(fusion.mmf, "project_kv"):
-            # two streams, six single-chain graphs, events in between (immtsf.train.PhasedStep)
-            b = w.batch
-            fc_args = (b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
-
-            def text_fn():
-                E, M = fusion.ttf(b["notes_embeddings"], b["tau"], b["tp_to_predict"])
-                return (E, M) + tuple(fusion.mmf.project_kv(E))
-
-            def head_fn(pred, E, M, kv, fold):
-                if hasattr(fusion.mmf, "forward_loss"):
-                    return fusion.mmf.forward_loss(pred, E, M, b["data_to_predict"], b["mask_predicted_data"], w.global_cnt, kv=(kv, fold))
-                out = fusion.mmf(pred, E, M, kv=(kv, fold))
-                return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, w.global_cnt)
-
-            if dist_on:
-                comm_mode = "eager, in front of the optimizer graph"
-            if args.flags and not dist_on:
-                step = FlagStep(trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
-                launch_mode = "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags"
-            else:
-                step = PhasedStep(trainer, text_fn, lambda: w.model.forecasting(*fc_args), head_fn)
-                launch_mode = "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them"
-        if step is None and not dist_on and not args.no_flags and not args.no_overlap and W <= FLAGS_MAX_WINDOWS:
-            step = flag_step(w)
-            if step is not None:
-                launch_mode = "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags"
-        if step is None:
-            if dist_on:
-                trainer.overlap = False
-                comm_mode = (f"reduce-scatter ({wire}) -> clip + Adam on the rank's 1/{world} shard -> all-gather ({pwire}), eager, behind "
-                             "graph A") if sharded else "all-reduce, eager, between the graphs"
-            step = GraphedStep(trainer, w.loss_fn)
-            if getattr(step, "single", False):
-                launch_mode = launch_mode.replace("(2 graphs/step)", "(1 graph/step: forward, backward, clip + Adam)")
-    else:
-        step = w.eager_step
+            raise SystemExit(f"--captured-comm: the collectives could not be captured ({type(e).__name__}); "
+                             "re-run without the flag") from e
+        raise
+    eng = step_info["engine"]
+    launch_mode = {"eager": "eager launches",
+                   "flags": "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags",
+                   "phased": "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them",
+                   "graphed": "hipGraph replay (2 graphs/step)", "graphed+captured-comm": "hipGraph replay (2 graphs/step)"}[eng]
+    if eng == "graphed" and getattr(step, "single", False):
+        launch_mode = "hipGraph replay (1 graph/step: forward, backward, clip + Adam)"
+    if eng in ("eager", "graphed", "graphed+captured-comm") and not args.no_overlap:
+        launch_mode += ", backbone on a second HIP stream beside TTF"
+    if dist_on:
+        if eng == "flags":
+            launch_mode += "; N > 1: + graph B (clip + Adam) behind the all-reduce"
+            comm_mode = (f"bucketed, beside the backward: {len(step.segments)} bucket(s) on a communication stream behind counting device "
+                         f"flags, {len(step.rest)} range(s) behind the graph")
+        elif eng == "graphed+captured-comm":
+            comm_mode = "captured, bucketed"
+        elif eng == "eager":
+            comm_mode = "bucketed on a side stream"
+        else:
+            comm_mode = (f"reduce-scatter ({wire}) -> clip + Adam on the rank's 1/{world} shard -> all-gather ({pwire}), eager, behind "
+                         "graph A") if sharded else "all-reduce, eager, between the graphs"
 
     def barrier():
         if dist_on:
@@ -772,6 +850,25 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if step_info["engine"] == "flags":
+        # a spin that gave up (on any rank) dropped steps inside the timed region: the number is void -- fall back to graph edges,
+        # say so in the line, and time again
+        try:
+            step.check()
+        except Exception as e:      # noqa: BLE001
+            print(f"# FlagStep rejected after the timed region: {e}", file=sys.stderr)
+            step.clear_error()
+            trainer.flat_grad.zero_()
+            step, step_info = build_step(w, "graphed", dist_on=dist_on)
+            step_info["flag_step_rejected"] = True
+            launch_mode = "hipGraph replay (graph edges between the branches; the flag engine timed out and was rejected)"
+            if dist_on:
+                comm_mode = "all-reduce, eager, between the graphs"
+            elapsed, host_enqueue_s, loss = time_steps(step, args.steps, args.warmup, barrier)
+            if dist_on:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
     fusion.check_nan()
     assert torch.isfinite(loss).all(), "loss is not finite"
     ms_per_step = elapsed / args.steps * 1e3
@@ -802,7 +899,7 @@ def main():
         sweep = []
         for nw in (64, 256, 1024, 4096):
             ww = Workload("cfg2", dev, nw, args.precision)
-            st = (flag_step(ww) if nw <= FLAGS_MAX_WINDOWS and not args.no_flags else None) or GraphedStep(ww.trainer, ww.loss_fn)
+            st, _ = build_step(ww, "graphed" if args.no_flags else "auto")
             k = 10 if nw <= 256 else 4            # median of three blocks (one block of 30 was once seen 2.7 x off: a transient of the box)
             blocks = sorted(time_steps(st, k, 3 if i == 0 else 0, torch.cuda.synchronize)[0] for i in range(3))
             ms = blocks[1] / k * 1e3
@@ -815,7 +912,7 @@ def main():
         extras["sweep"] = sweep
         # the same step with the notes handed over packed (what immtsf.data's device collate produces)
         wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=True)
-        st = (None if args.no_flags else flag_step(wp)) or GraphedStep(wp.trainer, wp.loss_fn)
+        st, _ = build_step(wp, "graphed" if args.no_flags else "auto")
         blocks = sorted(time_steps(st, 40, 5 if i == 0 else 0, torch.cuda.synchronize)[0] for i in range(5))
         el = blocks[2]             # median of five blocks of 40 replays (a single block right after the 4096-window leg was seen 25 % off)
         extras["packed"] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
@@ -848,7 +945,8 @@ def main():
             "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "launch": launch_mode, "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
+            "launch": launch_mode, "engine": step_info["engine"], "flag_step_rejected": step_info["flag_step_rejected"],
+            "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
             "config": {"workload": f"{args.config}: " + CONFIGS[args.config]["text"].format(B=W),
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",
                        "global_batch": W * world, "parallelism": f"dp{world}", "sum_notes_rank0": w.sum_n,

@@ -222,6 +222,16 @@ int immtsf_adam_step_dev_zero(float* param, float* grad, float* exp_avg, float* 
                            reinterpret_cast<unsigned long long*>(dropout_step_dev), static_cast<hipStream_t>(stream), 1);
 }
 
+int immtsf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm, float* norm_scratch,
+                             uint64_t* dropout_step_dev, const int32_t* skip_flag, int32_t zero_grad, immtsf_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !norm_scratch || !step_dev || !skip_flag) return IMMTSF_EINVAL;
+    return launch_adam_dev(param, grad, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay,
+                           reinterpret_cast<long long*>(step_dev), max_norm, norm_scratch,
+                           reinterpret_cast<unsigned long long*>(dropout_step_dev), static_cast<hipStream_t>(stream), zero_grad ? 1 : 0,
+                           skip_flag);
+}
+
 int immtsf_adam_sqnorm(const float* grad, uint64_t n, float* norm_scratch, int64_t* step_dev, uint64_t* dropout_step_dev,
                        immtsf_stream_t stream) {
     if (!grad || !norm_scratch) return IMMTSF_EINVAL;

@@ -516,7 +516,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         if (rc != IMMTSF_EUNSUPPORTED) return rc;
     }
     if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && g.ws && g.act == 0 && !g.relu_ref && !g.a_rowmap &&
-        !g.b_rowmap && !(g.dyn && g.dyn_which != 1)) {
+        !g.b_rowmap && !(g.dyn && g.dyn_which != 1) && !g.row_flag && !g.add_vec && !g.p[0].bias && g.epi_drop.p <= 0.f && !g.p[0].Cpre) {
         const GemmProblem& p = g.p[0];
         const int rc = immtsf_launch_gemm3_tn(p.Ah, g.lda, p.Bh, g.ldb, p.C, g.ldc, p.Ch, ldch, g.ones_col ? p.bias_grad : nullptr, Mmax, g.N, g.K,
                                               g.alpha, g.accumulate, g.dyn, g.ws, g.ws_bytes, stream);

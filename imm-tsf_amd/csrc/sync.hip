@@ -41,6 +41,27 @@ __global__ void flag_wait_kernel(int* flag, int* err, long long ticks) {
     ft_note(flag, 2);
     __threadfence_system();
 }
+// counting form, for a consumer OUTSIDE the captured step (the communication stream of the data-parallel step, which is enqueued
+// eagerly beside the replaying graph): the producer inside the graph adds 1 per replay, the consumer of replay k waits for >= k.
+// Nothing is ever cleared, so a consumer that runs late can never miss (or double-count) a hand-over.
+__global__ void flag_bump_kernel(int* flag) {
+    ft_note(flag, 0);
+    __threadfence_system();
+    __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void flag_wait_ge_kernel(int* flag, int target, int* err, long long ticks) {
+    const long long t0 = wall_clock64();
+    ft_note(flag, 1);
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > ticks) {
+            atomicExch(err, 1);
+            break;
+        }
+    }
+    ft_note(flag, 2);
+    __threadfence_system();
+}
 __global__ void flags_clear_kernel(int* flags, int n) {
     if (threadIdx.x == 0) ft_note(flags, 3);
     if ((int)threadIdx.x < n) flags[threadIdx.x] = 0;
@@ -59,6 +80,19 @@ int immtsf_flag_set(int32_t* flag, immtsf_stream_t stream) {
 int immtsf_flag_wait(int32_t* flag, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream) {
     if (!flag || !err || timeout_ms <= 0) return IMMTSF_EINVAL;
     hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, err, (long long)timeout_ms * 100000ll);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream) {
+    if (!flag) return IMMTSF_EINVAL;
+    hipLaunchKernelGGL(flag_bump_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream) {
+    if (!flag || !err || timeout_ms <= 0) return IMMTSF_EINVAL;
+    hipLaunchKernelGGL(flag_wait_ge_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, target, err,
+                       (long long)timeout_ms * 100000ll);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

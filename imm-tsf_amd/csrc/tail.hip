@@ -272,11 +272,13 @@ __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict
 // ---- clip_grad_norm_ + Adam (main.py:1024,1098-1101) on one flat buffer -------------------------------------
 // 16-byte loads (the flat buffers are 16-byte aligned; a tail of < 4 elements is handled by the last threads).  The
 // first thread also advances the device-side step / dropout counters when given (graph replay: one launch less).
+// skip (optional device word): non-zero = this step is DROPPED -- a spin of the flag engine timed out, i.e. some gradient may be
+// incomplete (csrc/sync.hip): the step number is not advanced here and adam_kernel leaves parameters and moments alone
 __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, int vec, float* __restrict__ part,
-                                                              long long* step_dev, unsigned long long* drop_dev) {
+                                                              long long* step_dev, unsigned long long* drop_dev, const int* skip) {
     __shared__ float red[16];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (step_dev) step_dev[0] += 1;
+        if (step_dev && !(skip && *skip)) step_dev[0] += 1;
         if (drop_dev) drop_dev[0] += 1;
     }
     float a = 0.f;
@@ -296,9 +298,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
                                                     const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec,
-                                                    float* gz) {
+                                                    float* gz, const int* skip) {
     // gz != null (== g): the gradient is left zero behind the update -- the next step's zero-fill rides on this pass
     __shared__ float red[16];
+    if (skip && *skip) {          // dropped step (see sqnorm_partial_kernel): only the zero-fill happens
+        if (gz) {
+            const size_t stride = (size_t)gridDim.x * 256;
+            for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) gz[i] = 0.f;
+        }
+        return;
+    }
     if (step_dev) {   // bias corrections from the device-side step counter (already incremented for this step)
         const float st = (float)step_dev[0];
         bc1 = 1.f - powf(b1, st);
@@ -518,12 +527,12 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
     void* twin = const_cast<void*>(immtsf_twin_lookup(param, n));
     const int vec = adam_vec_ok(param, grad, m, v, twin);
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, vec, norm_scratch, (long long*)nullptr,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, (const int*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     const float bc1 = 1.f - powf(b1, (float)step), bc2s = sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, nparts, (const long long*)nullptr, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr);
+                       norm_scratch, nparts, (const long long*)nullptr, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr, (const int*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -533,7 +542,7 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
 int launch_adam_sqnorm(const float* grad, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
                        hipStream_t s) {
     const int vec = ((reinterpret_cast<uintptr_t>(grad) & 15) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(1024), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev, (const int*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -546,24 +555,24 @@ int launch_adam_apply(float* param, const float* grad, float* m, float* v, size_
     const float bc1 = step_dev ? 1.f : 1.f - powf(b1, (float)step), bc2s = step_dev ? 1.f : sqrtf(1.f - powf(b2, (float)step));
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s, max_norm,
-                       norm_scratch, 1024, step_dev, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr);
+                       norm_scratch, 1024, step_dev, reinterpret_cast<bf16_t*>(twin), vec, (float*)nullptr, (const int*)nullptr);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 
 int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
-                    hipStream_t s, int zero_grad) {
+                    hipStream_t s, int zero_grad, const int* skip) {
     if (n == 0) return IMMTSF_OK;
     const int nparts = 1024;
     void* twin = const_cast<void*>(immtsf_twin_lookup(param, n));
     const int vec = adam_vec_ok(param, grad, m, v, twin);
-    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nparts), dim3(256), 0, s, grad, n, vec, norm_scratch, step_dev, drop_dev, skip);
     IMMTSF_LAUNCH_CHECK();
     const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
                        norm_scratch, nparts, (const long long*)step_dev, reinterpret_cast<bf16_t*>(twin), vec,
-                       zero_grad ? const_cast<float*>(grad) : nullptr);
+                       zero_grad ? const_cast<float*>(grad) : nullptr, skip);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

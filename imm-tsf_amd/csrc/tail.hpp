@@ -37,7 +37,8 @@ int launch_adam(float* param, const float* grad, float* m, float* v, size_t n, f
                 float wd, int step, float max_norm, float* norm_scratch, hipStream_t s);
 int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                     float wd, long long* step_dev, float max_norm, float* norm_scratch, unsigned long long* drop_dev,
-                    hipStream_t s, int zero_grad = 0);      // zero_grad: the gradient buffer is left zero (it is written)
+                    hipStream_t s, int zero_grad = 0,      // zero_grad: the gradient buffer is left zero (it is written)
+                    const int* skip = nullptr);            // skip: device word, non-zero = drop this step (no update, step not counted)
 
 int launch_adam_sqnorm(const float* grad, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
                        hipStream_t s);

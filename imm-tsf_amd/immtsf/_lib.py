@@ -240,6 +240,8 @@ _PROTOS = {
     "immtsf_flag_set": (C.c_int, [C.c_void_p, c_stream]),
     "immtsf_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_flags_clear": (C.c_int, [C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_flag_bump": (C.c_int, [C.c_void_p, c_stream]),
+    "immtsf_flag_wait_ge": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_flag_trace": (C.c_int, [C.c_int32]),
     "immtsf_flag_trace_read": (C.c_int, [C.c_void_p, C.c_int32]),
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
@@ -264,6 +266,8 @@ _PROTOS = {
                                        C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
     "immtsf_adam_step_dev_zero": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                        C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
+    "immtsf_adam_step_guarded": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
+                                           C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_adam_sqnorm": (C.c_int, [c_f32p, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p, c_stream]),
     "immtsf_adam_apply": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int32, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),

@@ -647,6 +647,9 @@ class MMFXRankQLossFn(torch.autograd.Function):
         if dP_h is not None:
             _shadow_put(dP, dP_h)
         ctx.grads = (dY, dP, dbHO) + tuple(rets)
+        # LayerNorm's two gradients went straight to FlatTrainer's sinks (rets None): they were written with the unit seed, so a
+        # backward with any other seed (loss scaling, loss * k) has to rescale them where they lie
+        ctx.sunk = tuple(b for b, r in zip(grads, rets) if r is None)
         return loss
 
     @staticmethod
@@ -655,6 +658,9 @@ class MMFXRankQLossFn(torch.autograd.Function):
         ctx.grads = None
         if not is_unit_grad(dloss):
             g = tuple(None if t is None else t * dloss for t in g)
+            for b in ctx.sunk:           # (one writer per sink and step -- the sink contract -- so scaling in place is exact)
+                b.mul_(dloss)
+        ctx.sunk = ()
         return (g[0], g[1], g[2]) + (None,) * 11 + (g[3], g[4])
 
 

@@ -151,7 +151,7 @@ class FlatTrainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self._pending: List = []
         self._reduced = [False] * len(self.buckets)
-        if self.overlap:
+        if self.collective and dev.type == "cuda" and not self.sharded:
             for bi in self.sink_buckets:
                 head = self.buckets[bi][0]
                 head._immtsf_bwd_hook = (lambda i=bi: self._on_bucket_done(i))
@@ -243,6 +243,10 @@ class FlatTrainer:
         """backward hook of a sink bucket: start its all-reduce now -- only while overlapping is on.  (A caller that turns
         `overlap` off after construction, e.g. GraphedStep without captured collectives, must not get collectives issued
         from inside the backward: under graph capture they would be captured AND repeated eagerly afterwards.)"""
+        cap = getattr(self, "_capture_hook", None)
+        if cap is not None:          # FlagStep's capture of the data-parallel step: announce the bucket by a device flag instead
+            cap(bi)
+            return
         if self.overlap:
             self._bucket_ready(bi)
 
@@ -398,7 +402,18 @@ class FlatTrainer:
         if self.sharded:
             self._step_sharded()
             return
-        if self.flat_param.is_cuda and self.device_step:
+        if self.flat_param.is_cuda and self.device_step and getattr(self, "step_guard", None):
+            # behind a guard word (FlagStep's time-out report): a non-zero word drops the step on the device -- no update from
+            # gradients a missed hand-over may have left incomplete (csrc/tail.hip sqnorm_partial_kernel / adam_kernel)
+            lib = _lib.load()
+            zero = getattr(self, "zero_in_step", False)
+            self._grad_zeroed_by_step = bool(zero)
+            _lib.check(lib.immtsf_adam_step_guarded(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+                                                    _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, self.wd, _lib.ptr(self.step_dev), self.max_norm,
+                                                    _lib.ptr(self.norm_scratch), _lib.ptr(self.drop_dev), int(self.step_guard),
+                                                    1 if zero else 0, _lib.stream_ptr()), "adam_step_guarded")
+        elif self.flat_param.is_cuda and self.device_step:
             lib = _lib.load()
             zero = getattr(self, "zero_in_step", False)
             fn = lib.immtsf_adam_step_dev_zero if zero else lib.immtsf_adam_step_dev
@@ -739,40 +754,61 @@ class FlagStep(PhasedStep):
         stream T:  zero-grad, text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ............ wait(B2) | join B | clear, clip + Adam
         stream B:  (forked at the start)   backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
 
-    Single process only (no collectives inside).  `flags[8]` is set if a spin ever timed out (50 ms): check `timed_out()`."""
+    Parameter-only work of the text side (MMF_XAttn_Add's fold) runs at the head of the backbone's branch, whose forward is the
+    shorter one, and is handed over through a flag as well; the last `param_tail` launches of MMF_XAttn_Add's parameter-gradient
+    chain (work only the optimizer waits for) run at the end of the backbone's branch (DESIGN.md section 6 has every placement that
+    was measured).
 
-    def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3):
+    Data parallel (trainer.collective): the same graph without the optimizer, and the gradient all-reduce BESIDE the backward:
+
+        stream S (caller):  graph A ......................................... | wait(comm) | all-reduce(rest) | graph B: clip + Adam
+        comm stream:        wait_ge(bucket i, k) all-reduce(bucket i) ...      (eager, enqueued right behind graph A's launch)
+
+    Inside graph A a bucket whose gradients are final (the block's backward hook) bumps a COUNTING flag; the communication stream,
+    which is not ordered behind S at all, spins for the k-th bump in front of the k-th replay's all-reduce of that bucket.  What has
+    not been announced by a hook (the bucket that completes with the join, the autograd-owned backbone gradients) is reduced on S
+    behind graph A.  Ordering argument (no spin and no collective ever waits on the other kind in a cycle): a spin waits only for
+    kernels of ITS OWN rank's graph A, which wait for nothing outside that graph; a collective waits for the peers' same
+    collective, which sits behind the peers' own spins; graph A never waits for the communication stream (graph B does, through
+    an ordinary event that is recorded after the last collective).  Every spin gives up after 50 ms and reports it in the guard
+    word, which makes the captured Adam pass DROP the step (immtsf_adam_step_guarded) -- `check()` raises on every rank.
+
+    `flags[8]` is the guard word: `timed_out()` / `check()`."""
+
+    def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
+                 fold_by_flag: bool = True, head_flag: bool = True):
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
-        if trainer.collective:
-            raise ValueError("FlagStep is the single-process step: use GraphedStep / PhasedStep with a process group")
+        if trainer.sharded:
+            raise ValueError("FlagStep reduces whole buckets: use GraphedStep / PhasedStep with a sharded optimizer")
         self.trainer = trainer
         self.text_fn, self.backbone_fn, self.head_fn = text_fn, backbone_fn, head_fn
         dev = trainer.flat_param.device
         lib = _lib.load()
+        self.dist = bool(trainer.collective)
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        # parameter-only work of the text side (MMF_XAttn_Add's fold): "1" = on a third branch (measured slower, DESIGN 6), "2" = at the
-        # head of the backbone's branch, whose forward is the shorter one
-        fs = os.environ.get("IMMTSF_FOLD_STREAM", "3")          # ("3": as "2", handed over through a device flag instead of an event)
-        self.L = torch.cuda.Stream(device=dev) if fs == "1" else self.B if fs in ("2", "3") else None
-        self._fold_by_flag = fs == "3"
-        self._defer = int(os.environ.get("IMMTSF_PARAM_TAIL", "1"))      # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch
+        # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch (data parallel: none -- the bucket's hook must
+        # fire behind its LAST gradient write, on the branch that announces it)
+        self._defer = (0 if self.dist else 1) if param_tail is None else int(param_tail)
+        if self.dist:
+            trainer.overlap = False           # no collectives from inside the captured backward (the hooks bump flags instead)
+            self._defer = 0
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
         # (before the warm-up: its last Adam pass then leaves the gradient buffer zero, and the captured zero_grad() holds no fill --
         # set afterwards, a 32 MB fill that both branches wait for sat at the head of every replay)
-        if not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
-            trainer.zero_in_step = True
+        trainer.zero_in_step = True
         snap = trainer.snapshot()
         for _ in range(warmup):
             self._eager_step()
         torch.cuda.synchronize()
         trainer.restore(snap)
         torch.cuda.synchronize()
-        self.flags = torch.zeros(16, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(32, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
         F_B1, F_T2, F_B2, F_ERR = fp, fp + 4, fp + 8, fp + 32
+        self._f_err = F_ERR
         sp = lambda st: st.cuda_stream        # noqa: E731
 
         def fset(flag, st):
@@ -781,71 +817,137 @@ class FlagStep(PhasedStep):
         def fwait(flag, st):
             _lib.check(lib.immtsf_flag_wait(flag, F_ERR, 50, sp(st)), "flag_wait")
 
+        # data parallel: counting flags 16.. (never cleared), one per announced bucket, in the order the hooks fire
+        self.segments = []                    # [(flag address, lo, hi)]
+        announced = set()
+
+        def announce(bi):
+            if bi in announced:
+                return
+            lo, hi = trainer.ranges[bi]
+            announced.add(bi)
+            if hi == lo:
+                return
+            flag = fp + 4 * (16 + len(self.segments))
+            _lib.check(lib.immtsf_flag_bump(flag, torch.cuda.current_stream().cuda_stream), "flag_bump")
+            self.segments.append((flag, lo, hi))
+
+        trainer.step_guard = F_ERR
         self.graph = torch.cuda.CUDAGraph()
         B = self.B
-        with torch.cuda.graph(self.graph):
-            T = torch.cuda.current_stream()
-            trainer.zero_grad()
-            B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
-            from . import config
-            L = self.L
-            if L is not None:                     # a branch for parameter-only work of the text side (MMF_XAttn_Add's fold):
-                if L is not B:
-                    L.wait_stream(T)              # forked here, joined by the op that consumes its result (long after it has finished)
-                config.fold_stream = L
-                config.fold_flag = (fp + 12, F_ERR) if self._fold_by_flag else None
-            try:
-                outs = text_fn()
-            finally:
-                config.fold_stream = None
-                config.fold_flag = None
-            if L is not None and L is not B:
-                T.wait_stream(L)                  # (a text_fn that never used the branch: join it anyway)
-            with torch.cuda.stream(B):
-                pred = backbone_fn()
-                fset(F_B1, B)
-            fwait(F_B1, T)
-            config.head_done_flag = F_T2 if os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0" else None
-            try:
-                py, cuts, loss = self._head(pred, outs)
-                taken = config.head_done_flag is None and os.environ.get("IMMTSF_HEAD_FLAG", "1") != "0"
-            finally:
-                config.head_done_flag = None      # (never leave the address of this step's flag behind for an unrelated call)
-            dpy = py.grad
-            dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
-            if not taken:
-                fset(F_T2, T)                     # (a head that publishes the flag itself -- MMFXRankQLossFn -- has consumed it)
-            elif dpy is None or dpy.data_ptr() != config.head_dy_ptr:
-                raise RuntimeError("FlagStep: the head published its dY flag early, but autograd did not hand that buffer on as the "
-                                   "backbone's output gradient (IMMTSF_HEAD_FLAG=0 disables the early flag)")
-            with torch.cuda.stream(B):
-                fwait(F_T2, B)
-                torch.autograd.backward([pred], [dpy])
-                trainer.collect_grads()
-            # parameter-gradient tails of the text side (work only the optimizer waits for) go to the END of the backbone's branch,
-            # which finishes its backward first (tools/flag_timeline.py: 60 us earlier at 64 windows); flag 4 says their inputs exist
-            tail = {"flag": (fp + 16, F_ERR), "jobs": [], "defer": self._defer}
-            config.param_tail = tail if self._defer > 0 else None
-            try:
-                self._text_backward(outs, dcuts)
-            finally:
-                config.param_tail = None
-            with torch.cuda.stream(B):
-                if tail["jobs"]:
-                    fwait(fp + 16, B)
-                    for job in tail["jobs"]:
-                        job(sp(B))
-                fset(F_B2, B)
-            fwait(F_B2, T)
-            T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
-            _lib.check(lib.immtsf_flags_clear(fp, 5, sp(T)), "flags_clear")
-            trainer.step()
+        from . import config
+        try:
+            with torch.cuda.graph(self.graph):
+                T = torch.cuda.current_stream()
+                trainer.zero_grad()
+                B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
+                config.fold_stream = B                # parameter-only work of the text side: at the head of the backbone's branch
+                config.fold_flag = (fp + 12, F_ERR) if fold_by_flag else None
+                try:
+                    outs = text_fn()
+                finally:
+                    config.fold_stream = None
+                    config.fold_flag = None
+                with torch.cuda.stream(B):
+                    pred = backbone_fn()
+                    fset(F_B1, B)
+                fwait(F_B1, T)
+                config.head_done_flag = F_T2 if head_flag else None
+                try:
+                    py, cuts, loss = self._head(pred, outs)
+                    taken = config.head_done_flag is None and head_flag
+                finally:
+                    config.head_done_flag = None      # (never leave the address of this step's flag behind for an unrelated call)
+                dpy = py.grad
+                dcuts = [c.grad if (torch.is_tensor(c) and c.requires_grad) else None for c in cuts]
+                if not taken:
+                    fset(F_T2, T)                     # (a head that publishes the flag itself -- MMFXRankQLossFn -- has consumed it)
+                elif dpy is None or dpy.data_ptr() != config.head_dy_ptr:
+                    raise RuntimeError("FlagStep: the head published its dY flag early, but autograd did not hand that buffer on as the "
+                                       "backbone's output gradient (head_flag=False disables the early flag)")
+                with torch.cuda.stream(B):
+                    fwait(F_T2, B)
+                    torch.autograd.backward([pred], [dpy])
+                    trainer.collect_grads()
+                # parameter-gradient tails of the text side (work only the optimizer waits for) go to the END of the backbone's branch,
+                # which finishes its backward first (tools/flag_timeline.py: 60 us earlier at 64 windows); flag 4 says their inputs exist
+                tail = {"flag": (fp + 16, F_ERR), "jobs": [], "defer": self._defer}
+                config.param_tail = tail if self._defer > 0 else None
+                trainer._capture_hook = announce if self.dist else None
+                try:
+                    self._text_backward(outs, dcuts)
+                finally:
+                    config.param_tail = None
+                    trainer._capture_hook = None
+                with torch.cuda.stream(B):
+                    if tail["jobs"]:
+                        fwait(fp + 16, B)
+                        for job in tail["jobs"]:
+                            job(sp(B))
+                    fset(F_B2, B)
+                fwait(F_B2, T)
+                T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
+                _lib.check(lib.immtsf_flags_clear(fp, 5, sp(T)), "flags_clear")
+                if not self.dist:
+                    trainer.step()
+            self.graph_b = None
+            if self.dist:
+                # what no hook announced is reduced behind graph A on the caller's stream: contiguous runs of the remaining buckets
+                self.rest = []
+                for bi, (lo, hi) in enumerate(trainer.ranges):
+                    if bi in announced or hi == lo:
+                        continue
+                    if self.rest and self.rest[-1][1] == lo:
+                        self.rest[-1] = (self.rest[-1][0], hi)
+                    else:
+                        self.rest.append((lo, hi))
+                self.comm = trainer.comm_stream or torch.cuda.Stream(device=dev)
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b):
+                    trainer.step()
+        finally:
+            trainer.step_guard = None
+        self._epoch = 0
+        self._ev = torch.cuda.Event()
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)
 
     def timed_out(self) -> bool:
+        """this rank's guard word (synchronises)"""
         return bool(int(self.flags[8].item()) != 0)
+
+    def check(self):
+        """raise, on EVERY rank, if a spin timed out on any of them since the last clear_error(): the steps since then were dropped on
+        the ranks that saw it (a collective call when the trainer has a process group; synchronises)"""
+        bad = self.flags[8:9].to(torch.float32)
+        if self.dist:
+            import torch.distributed as dist
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.trainer.group)
+        if float(bad.item()) != 0.0:
+            raise _lib.ImmtsfError("FlagStep: a device-flag wait timed out (the two graph branches, or the communication stream, did not "
+                                   "run concurrently): the guarded optimizer dropped the affected steps; restore a snapshot and use "
+                                   "GraphedStep")
+
+    def clear_error(self):
+        self.flags[8:9].zero_()
 
     def __call__(self):
         self.graph.replay()
+        if not self.dist:
+            return self.loss
+        t = self.trainer
+        lib = _lib.load()
+        self._epoch += 1
+        S = torch.cuda.current_stream()
+        if self.segments:
+            with torch.cuda.stream(self.comm):
+                for flag, lo, hi in self.segments:
+                    _lib.check(lib.immtsf_flag_wait_ge(flag, self._epoch & 0x7FFFFFFF, self._f_err, 50, self.comm.cuda_stream), "flag_wait_ge")
+                    t._all_reduce(lo, hi)
+                self._ev.record(self.comm)
+        for lo, hi in self.rest:
+            t._all_reduce(lo, hi)
+        if self.segments:
+            S.wait_event(self._ev)
+        self.graph_b.replay()
         return self.loss

@@ -522,6 +522,14 @@ int immtsf_adam_step_dev_zero(float* param, float* grad, float* exp_avg, float* 
                               float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm, float* norm_scratch,
                               uint64_t* dropout_step_dev, immtsf_stream_t stream);
 
+/* immtsf_adam_step_dev[_zero] behind a guard word: *skip_flag != 0 (device int32, e.g. the time-out word of immtsf_flag_wait)
+ * DROPS the step -- parameters, moments and *step_dev stay as they are; the dropout counter still advances and, with zero_grad,
+ * the gradient is still left zero -- so a captured step whose flag hand-over failed cannot apply half-finished gradients.
+ * No reference counterpart: launch-model plumbing (immtsf.train.FlagStep). */
+int immtsf_adam_step_guarded(float* param, float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t* step_dev, float max_norm, float* norm_scratch,
+                             uint64_t* dropout_step_dev, const int32_t* skip_flag, int32_t zero_grad, immtsf_stream_t stream);
+
 /* The same step as two calls, for a sharded optimizer (immtsf.train.FlatTrainer(shard_optimizer=True): each rank owns
  * 1/W of the flat buffers): adam_sqnorm writes 1024 partial sums of squares of `grad` (this rank's shard of the
  * reduce-scattered gradient) to norm_scratch and bumps the device counters (both may be NULL); the caller sum-all-reduces
@@ -652,6 +660,11 @@ int immtsf_set_side_stream(int32_t on);
 int immtsf_flag_set(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait(int32_t* flag, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
 int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream);
+/* Counting form, for a consumer that is NOT part of the captured step (the communication stream of the data-parallel step, enqueued
+ * eagerly beside the replaying graph): flag_bump adds 1 (release) behind the producer's last kernel on every replay; flag_wait_ge
+ * spins until *flag - target >= 0 (the consumer of replay k passes k).  Never cleared: a late consumer cannot miss a hand-over. */
+int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream);
+int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
 /* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
  * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (256 entries) and starts recording, (0) stops;
  * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,

@@ -90,6 +90,15 @@ def _worker_sharded(rank, world, port, q, wire, param_wire):
                       lr=1e-2, eps=1e-3, weight_decay=1e-3, max_norm=0.5, group=dist.group.WORLD, grad_wire=wire, shard_optimizer=True,
                       param_wire=param_wire)
     tr2.load_state_dict(sd)
+    # ... and on ANOTHER world size: the checkpoint saved at world 2 resumes in a single-process, unsharded trainer, whose next step on
+    # the FULL batch is the data-parallel pair's next step (exact wires only; round-3 advisor finding)
+    tr3 = params3 = None
+    if wire == "fp32" and param_wire == "fp32":
+        params3 = {k: torch.nn.Parameter(v.detach().clone()) for k, v in params.items()}
+        tr3 = FlatTrainer([[p for k, p in params3.items() if k.startswith("mmf.")], [p for k, p in params3.items() if k.startswith("ttf.")]],
+                          lr=1e-2, eps=1e-3, weight_decay=1e-3, max_norm=0.5)
+        tr3.load_state_dict(sd)
+        assert tr3.exp_avg.numel() == tr3.flat_param.numel() and tr3.step_count == 3
     for t_, ps_ in ((tr, params), (tr2, params2)):
         t_.zero_grad()
         _loss(ps_, shard, cnt, H).backward()
@@ -97,6 +106,13 @@ def _worker_sharded(rank, world, port, q, wire, param_wire):
         t_.step()
     resume_err = float((tr.gather(tr.flat_param) - tr2.gather(tr2.flat_param)).abs().max())
     assert resume_err < 1e-6, resume_err
+    if tr3 is not None:
+        tr3.zero_grad()
+        _loss(params3, full, full[5].reshape(-1, 3).sum(0), H).backward()
+        tr3.sync_grads()
+        tr3.step()
+        cross_err = float((tr.gather(tr.flat_param) - tr3.gather(tr3.flat_param)).abs().max())
+        assert cross_err < 1e-5, cross_err
     p_dp = tr.gather(tr.flat_param)
     # every rank must hold the same replicated parameters
     chk = p_dp.clone()
@@ -262,6 +278,8 @@ def _worker_bucketed(rank, world, port, q, wire):
             order_fired.append(bi)
         assert all(tr._reduced)
         tr.sync_grads()                               # nothing left to reduce: must not reduce anything twice
+        if step == 0:
+            g_dp0 = tr.gather(tr.flat_grad).clone()   # the all-reduced gradient itself, before clip + Adam: every element
         tr.step()
     p_dp = tr.gather(tr.flat_param)
     if rank == 0:
@@ -274,6 +292,8 @@ def _worker_bucketed(rank, world, port, q, wire):
             full = _batch(20 + step, B, 5, 6, 3, 16)
             opt.zero_grad()
             _loss(ref, full, full[5].reshape(-1, 3).sum(0), H).backward()
+            if step == 0:
+                g_ref0 = torch.cat([ref[k].grad.reshape(-1) for k in order]).clone()
             g = torch.cat([ref[k].grad.reshape(-1) for k in order]).abs()
             # Adam's update is g / sqrt(v): an element whose gradient is rounding noise (|g| < 1e-4 max|g|) moves by +-lr with the
             # sign of that noise, which differs between summation orders -- such elements are not compared
@@ -282,7 +302,8 @@ def _worker_bucketed(rank, world, port, q, wire):
             torch.nn.utils.clip_grad_norm_([ref[k] for k in order], 0.5)
             opt.step()
         p_ref = torch.cat([ref[k].detach().reshape(-1) for k in order])
-        q.put({"perr": float((p_dp - p_ref).abs()[stable].max()), "stable": float(stable.float().mean()), "order": order_fired[:3]})
+        q.put({"perr": float((p_dp - p_ref).abs()[stable].max()), "stable": float(stable.float().mean()), "order": order_fired[:3],
+               "gerr": float((g_dp0 - g_ref0).abs().max() / g_ref0.abs().max())})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -303,6 +324,9 @@ def test_bucketed_all_reduce_three_steps_match_single_process(world, wire, tol):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res["perr"] < tol, res
+    # the all-reduced flat gradient of the first step, EVERY element, against the single-process gradient: a bucket reduced twice or
+    # not at all cannot hide in the elements the parameter comparison leaves out
+    assert res["gerr"] < (1e-5 if wire == "fp32" else 1e-2), res
     assert res["stable"] > 0.5, res
     assert res["order"] == [2, 1, 0]
 

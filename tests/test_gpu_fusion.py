@@ -870,6 +870,21 @@ def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precisio
         y = Y.clone().requires_grad_(True)
         (3.0 * mmf.forward_loss(y, E, M, truth, mask, cnt)).backward()
         assert float((y.grad - 3.0 * res[0][1][1]).abs().max()) <= 1e-5 * float(res[0][1][1].abs().max())
+        # ... also the ones that went straight into FlatTrainer's gradient sinks (LayerNorm's two: written by the forward with the
+        # unit seed, rescaled in place by a backward with another seed -- round-3 advisor finding)
+        from immtsf.train import FlatTrainer
+        ref_g = {k: b.clone() for k, b in res[0][3:]}
+        tr = FlatTrainer([list(mmf.parameters())], sink_buckets=(0,), overlap=False)
+        try:
+            tr.zero_grad()
+            y = Y.clone().requires_grad_(True)
+            (3.0 * mmf.forward_loss(y, E, M, truth, mask, cnt)).backward()
+            torch.cuda.synchronize()
+            for k, p_ in mmf.named_parameters():
+                got, want = p_._immtsf_grad_sink, 3.0 * ref_g[k]
+                assert float((got - want).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * max(float(want.abs().max()), 1e-6), k
+        finally:
+            tr.close()
     finally:
         config.next_seed, config.xattn_fused_loss, config.precision = seed0, True, "fp32"
     tol = 1e-4 if precision == "fp32" else 2e-2

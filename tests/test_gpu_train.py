@@ -329,6 +329,80 @@ def test_two_rank_eager_step_equals_single_process(sharded):
     assert err < 3e-4, err
 
 
+def _two_rank_flag_worker(rank, world, port, q, wire):
+    """one rank of the data-parallel FLAG step (bench.py's N > 1 default): graph A with counting flags per announced bucket, the
+    bucketed all-reduce on the communication stream beside the backward, the rest behind the graph, graph B = clip + Adam.  Both
+    ranks share cuda:0 over gloo: the control flow is under test, not the transport."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    from immtsf.ops import masked_mse
+    from immtsf.train import FlagStep, FlatTrainer, shard_range
+    model, fusion, tr0, batch = _setup(dev, 0.0)
+    tr0.close()
+    lo, hi = shard_range(8, rank, world)
+    shard = {k: v[lo:hi].contiguous() for k, v in batch.items()}
+    cnt = shard["mask_predicted_data"].reshape(-1, shard["mask_predicted_data"].shape[-1]).sum(0)
+    dist.all_reduce(cnt)
+    te = [model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias]
+    tr = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())], lr=1e-2, eps=1e-3,
+                     max_norm=0.05, sink_buckets=(0, 1, 2), sink_shared=te, overlap=True, device_step=True, group=dist.group.WORLD,
+                     grad_wire=wire)
+    fc = (shard["tp_to_predict"], shard["observed_data"], shard["observed_tp"], shard["observed_mask"])
+
+    def text_fn():
+        E, M = fusion.ttf(shard["notes_embeddings"], shard["tau"], shard["tp_to_predict"])
+        return (E, M) + tuple(fusion.mmf.project_kv(E))
+
+    def head_fn(pred, E, M, kv, fold):
+        return fusion.mmf.forward_loss(pred, E, M, shard["data_to_predict"], shard["mask_predicted_data"], cnt, kv=(kv, fold))
+
+    st = FlagStep(tr, text_fn, lambda: model.forecasting(*fc).contiguous(), head_fn)
+    assert st.dist and len(st.segments) >= 1          # at least MMF's bucket is reduced beside the backward
+    for _ in range(3):
+        st()
+    torch.cuda.synchronize()
+    st.check()
+    if rank == 0:
+        q.put((tr.gather(tr.flat_param).cpu().numpy(), len(st.segments), len(st.rest)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire,tol", [("fp32", 3e-4), ("bf16", 3e-2)])
+def test_two_rank_flag_step_equals_single_process(wire, tol):
+    """bench.py's N > 1 default -- FlagStep with the bucketed all-reduce beside the backward -- on two ranks (half batches) trains like
+    one process on the full batch: 3 steps, clip active (max_norm 0.05).  SURVEY 8e."""
+    dev = _dev()
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_flag_worker, args=(r, 2, port, q, wire)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, nseg, nrest = q.get(timeout=300)
+    got = torch.from_numpy(got)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, fusion, tr, batch = _setup_sinks(dev, 0.0)
+    tr.max_norm = 0.05
+    f = _loss_fn(model, fusion, batch)
+    for _ in range(3):
+        tr.zero_grad()
+        f().backward()
+        tr.sync_grads()
+        tr.step()
+    ref = tr.gather(tr.flat_param).cpu()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < tol, (err, nseg, nrest)
+
+
 def test_adjacent_projection_weights_take_the_single_gemm_path():
     """inside FlatTrainer's flat buffer proj_k.weight and proj_v.weight of MMF_XAttn_Add are adjacent, which lets the
     backward form dE = [dK0 | dV0] [W_k ; W_v] as ONE GEMM: same gradients as with separately allocated parameters."""
@@ -473,11 +547,15 @@ def test_load_state_dict_refreshes_the_bf16_twin():
     assert l1 == l2, (l1, l2)                               # and the hook left nothing stale
 
 
+@pytest.mark.parametrize("engine", ["flags", "flags_packed", "graphed"])
 @pytest.mark.parametrize("precision,tol_loss,tol_param,tol_delta", [("fp32", 1e-4, 3e-4, 5e-3), ("bf16", 3e-2, 3e-3, 2.5e-1)])
-def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
+def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     """The BENCHMARKED composition against the oracle, not against itself: three cfg2 training steps (tPatchGNN -> TTF_T2V_XAttn
-    -> MMF_XAttn_Add -> masked MSE -> clip 1.0 -> Adam) at B = 64, d = 768 through bench.Workload + GraphedStep (hipGraph replay,
-    backbone on the second HIP stream, gradient sinks into the flat buffer) vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
+    -> MMF_XAttn_Add -> masked MSE -> clip 1.0 -> Adam) at B = 64, d = 768 through bench.Workload + bench.build_step -- exactly what
+    bench.py times: "flags" = immtsf.train.FlagStep (one hipGraph, the two branches synchronised by device flags, the head publishing
+    the dY flag mid-kernel, MMF_XAttn_Add's fold and parameter tail on the backbone's branch, grouped weight gradients: the headline
+    engine), "flags_packed" = the same with the notes handed over as PackedNotes (the `packed` companion), "graphed" = GraphedStep
+    (graph edges: the engine beyond 512 windows per GPU) -- vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
     torch.optim.Adam on the CPU from identical weights (reference: lib/evaluation.py:72-164, main.py:1093-1101).  Dropout 0.
     Bars: loss of every step `tol_loss` relative; final parameters `tol_param` relative L2; the three-step UPDATE (p_final -
     p_init) `tol_delta` relative L2 -- in bf16 mode the update of weakly driven parameters carries the operands' 2^-9 rounding."""
@@ -485,14 +563,13 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
     sys.path.insert(0, ROOT)
     import bench
     from immtsf import config
-    from immtsf.train import GraphedStep
     from oracle import fusion_ref as R
     from oracle import tpatchgnn_ref as TP
     old_drop = bench.P_DROP
     bench.P_DROP = 0.0
     config.nan_check = "deferred"       # no host syncs inside the captured step (what bench.py sets)
     try:
-        w = bench.Workload("cfg2", dev, 64, precision, device_step=True)
+        w = bench.Workload("cfg2", dev, 64, precision, device_step=True, packed_notes=engine == "flags_packed")
         # Adam eps 1e-3 on both sides: with 1e-8 the sign-like first steps turn 1e-9 summation-order noise on gradients that are
         # zero in exact arithmetic (the softmax's key bias) into +-lr parameter differences
         w.trainer.eps = 1e-3
@@ -524,9 +601,12 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta):
             torch.nn.utils.clip_grad_norm_(list(ref_model.parameters()) + list(params.values()), 1.0)
             opt.step()
             ref_losses.append(float(loss))
-        step = GraphedStep(w.trainer, w.loss_fn)          # (its warm-up steps are undone)
+        step, info = bench.build_step(w, "graphed" if engine == "graphed" else "flags")          # (warm-up / trial steps are undone)
+        assert info["engine"] == ("graphed" if engine == "graphed" else "flags") and not info["flag_step_rejected"], info
         got_losses = [float(step()) for _ in range(3)]
         torch.cuda.synchronize()
+        if engine != "graphed":
+            step.check()                                  # no spin gave up: no step was dropped
         for g_, r_ in zip(got_losses, ref_losses):
             assert abs(g_ - r_) <= tol_loss * abs(r_), (got_losses, ref_losses)
         sd_f = {k: v.detach().cpu() for k, v in w.fusion.state_dict().items()}

@@ -733,6 +733,9 @@ def main():
                          "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
     ap.add_argument("--no-wgrad-fork", action="store_true",
                     help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
+    ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain"],
+                    help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
+                         "reference's GEMM chain (immtsf.config.t2v_form)")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,
                     help="exploration only (the `sweep` field covers 64..4096): the metric is quoted on 64 windows per GPU")
     args = ap.parse_args()
@@ -785,6 +788,7 @@ def main():
     elif os.environ.get("IMMTSF_WGRAD_FORK") == "1":      # A/B: weight-gradient GEMMs on the library's side stream (off by default)
         lib.immtsf_set_side_stream(1)
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
+    config.t2v_form = args.t2v_form
     config.manual_seed(1234 + rank)
 
     wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")

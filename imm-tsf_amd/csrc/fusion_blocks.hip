@@ -7,6 +7,7 @@
 #include "rowops.hpp"
 #include "tail.hpp"
 #include "block_util.hpp"
+#include "t2v_fold.hpp"
 #include <stdlib.h>
 #include <math.h>
 #include <string.h>
@@ -122,6 +123,333 @@ int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2
     return 0;
 }
 
+
+// ================================================================================================ TTF_T2V_XAttn, folded form
+// (csrc/t2v_fold.hip has the algebra and the non-GEMM kernels; this is the launch sequence.)  Taken wherever its limits hold unless the
+// caller asks for the chain as written (immtsf_fusion_cfg.form = 1, the cross-check).
+inline bool t2v_fold_on(const immtsf_fusion_cfg* c) {
+    if (c->form == 1 || !t2v_fold_shape_ok(c->N, c->T, c->d, c->H)) return false;
+    if ((c->d_m % 8) || (c->d % 16) || c->d_m <= 0) return false;            // X rows and the Time2Vec half in 16-byte pieces
+    if (c->precision == 1 && !(t2v_hf(c) && ((c->d / c->H) % 8) == 0)) return false;
+    return true;
+}
+struct T2VFoldWs {
+    unsigned char *mask, *mtxt;
+    int *lengths, *offsets, *rowmap, *seg;
+    Mat X, z, zln;            // [R, dmc] notes | Time2Vec ; [R, H d] folded value rows ; [BT, d] LayerNorm output
+    float *S, *P, *q, *qs, *xpre, *xhat, *rstd;
+    Mat OVa;                  // [H d + 8, d]: W_o[:, h] W_v[h, :] per head, then G_h = (scale q_h)^T W_k,h, then zero rows
+    Mat Ab;                   // [d, dmc] = [W_KV[:, :d] W_in | W_KV[:, d:]] (with an input projection; else W_KV itself)
+    Mat Wa;                   // [H d + 8, dmc]: W_tot per head, then the score vectors u_h, then zero rows
+    float *bvec1, *bvec2, *cvec;
+    void *w_in, *w_kv, *w_att, *w_out, *w_po;
+    size_t bytes;
+};
+T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
+    const size_t B = c->B, N = c->N, T = c->T, d = c->d, dt = d / 2, R = B * N, BT = B * T, H = c->H, Hd = H * d, Ma = Hd + 8;
+    const size_t dmc = (size_t)c->d_m + dt;
+    const bool hf = t2v_hf(c) && c->precision == 1;
+    Carver k(base);
+    T2VFoldWs w;
+    w.mask = k.take<unsigned char>(R);
+    w.mtxt = k.take<unsigned char>(B);
+    w.lengths = k.take<int>(B);
+    w.offsets = k.take<int>(B + 1);
+    w.rowmap = k.take<int>(R);
+    w.seg = k.take<int>(R);
+    w.X = k.take_mat(R * dmc, !hf, hf);
+    w.z = k.take_mat(R * Hd, !hf, hf);
+    w.S = k.take<float>(R * H);
+    w.P = k.take<float>(R * H);
+    w.q = k.take<float>(d);
+    w.qs = k.take<float>(d);
+    w.xpre = k.take<float>(BT * d);
+    w.xhat = k.take<float>(BT * d);
+    w.rstd = k.take<float>(BT);
+    w.zln = k.take_mat(BT * d, !hf, hf);
+    w.OVa = k.take_mat(Ma * d, true, hf);
+    w.Ab = k.take_mat(d * dmc, true, hf);
+    w.Wa = k.take_mat(Ma * dmc, true, hf);
+    w.bvec1 = k.take<float>(d);
+    w.bvec2 = k.take<float>(d);
+    w.cvec = k.take<float>(Hd);
+    w.w_in = w.w_kv = w.w_att = w.w_out = w.w_po = nullptr;
+    if (hf) {
+        w.w_in = k.take<unsigned short>(d * (size_t)c->d_m);
+        w.w_kv = k.take<unsigned short>(d * (d + dt));
+        w.w_att = k.take<unsigned short>(3 * d * d);
+        w.w_out = k.take<unsigned short>(d * d);
+        w.w_po = k.take<unsigned short>(d * d);
+    }
+    w.bytes = k.bytes();
+    return w;
+}
+struct T2VFoldScratch {
+    Mat dE, dza, dWa, dOVa, dA;
+    float *dzln, *dx, *dbo_part, *dXt, *dcv, *dbvec1, *dbvec2, *dqs, *red, *red_t2v, *red_bo;
+    int t2v_slabs;
+    void* sk[2];
+    size_t skb[2];
+    size_t bytes;
+};
+T2VFoldScratch carve_t2v_fold_scratch(const immtsf_fusion_cfg* c, void* base) {
+    const size_t B = c->B, N = c->N, T = c->T, d = c->d, dt = d / 2, R = B * N, BT = B * T, H = c->H, Hd = H * d, Ma = Hd + 8;
+    const size_t dmc = (size_t)c->d_m + dt;
+    const bool hf = t2v_hf(c) && c->precision == 1;
+    Carver k(base);
+    T2VFoldScratch s;
+    s.dE = k.take_mat(BT * d, false, hf);
+    s.dzln = k.take<float>(BT * d);
+    s.dx = k.take<float>(BT * d);
+    s.dza = k.take_mat(R * Ma, !hf, hf);
+    s.dbo_part = k.take<float>(B * d);
+    s.dXt = k.take<float>(R * dt);
+    s.dWa = k.take_mat(Ma * dmc, true, hf);
+    s.dcv = k.take<float>(Ma);
+    s.dOVa = k.take_mat(Ma * d, true, hf);
+    s.dA = k.take_mat(d * dmc, true, hf);
+    s.dbvec1 = k.take<float>(d);
+    s.dbvec2 = k.take<float>(d);
+    s.dqs = k.take<float>(d);
+    s.red = k.take<float>(ln_sums_scratch_floats(d, 3));
+    s.red_bo = k.take<float>(colsum_scratch_floats(d, 1) + 64 * d);
+    s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));
+    s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
+    {
+        const size_t need[2] = {hf ? immtsf_gemm3_tn_ws_bytes((int)d, (int)d, (int)BT) : 0, hf ? immtsf_gemm3_tn_ws_bytes((int)Ma, (int)dmc, (int)R) : 0};
+        for (int i = 0; i < 2; ++i) {
+            s.skb[i] = need[i];
+            s.sk[i] = need[i] ? k.take<unsigned char>(need[i]) : nullptr;
+        }
+    }
+    s.bytes = k.bytes();
+    return s;
+}
+// the block's weights as (fp32, bf16) pairs: in = input_proj, kv = KV_proj, att = attn.in_proj (3d, d), out, po
+struct T2VFW { Mat in, kv, att, out, po; };
+int t2v_fold_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2VFoldWs& w, hipStream_t s, T2VFW* o) {
+    const bool hf = t2v_hf(c) && c->precision == 1;
+    const size_t d = c->d, dcat = d + d / 2;
+    CHECK(weight_mat(hf, p->input_proj_w, d * (size_t)c->d_m, w.w_in, s, &o->in));
+    CHECK(weight_mat(hf, p->kv_w, d * dcat, w.w_kv, s, &o->kv));
+    CHECK(weight_mat(hf, p->attn_in_w, 3 * d * d, w.w_att, s, &o->att));
+    CHECK(weight_mat(hf, p->attn_out_w, d * d, w.w_out, s, &o->out));
+    CHECK(weight_mat(hf, p->proj_out_w, d * d, w.w_po, s, &o->po));
+    return 0;
+}
+inline int fold_gemm(int layout, int prec, int M, int N, int K, Mat A, int lda, Mat B, int ldb, Mat C, int ldc, const float* bias, hipStream_t s) {
+    GemmArgs g = gemm_args(M, N, K, lda, ldb, ldc);
+    set_problem2(g, 0, A, B, C, bias);
+    return immtsf_launch_gemm(layout, prec, g, s);
+}
+
+int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes, const int32_t* src_rows,
+                     const int32_t* lengths_in, const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,
+                     int32_t* nan_flag, hipStream_t s) {
+    T2VFoldWs w = carve_t2v_fold(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H, d_m = cfg->d_m;
+    const int R = B * N, BT = B * T, prec = cfg->precision, dmc = d_m + dt, Hd = H * d, Ma = Hd + 8;
+    const bool hf = t2v_hf(cfg) && prec == 1, inp = p->input_proj_w != nullptr;
+    const DropCfg drop = drop_of(cfg);
+    const int* total = w.offsets + B;
+    T2VFW W;
+    CHECK(t2v_fold_weights(cfg, p, w, s, &W));
+    if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
+    else CHECK(launch_note_mask(notes, R, d_m, w.mask, nan_flag, s));
+    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));
+    const int* gather = src_rows ? src_rows : w.rowmap;
+    const float scale = sqrtf(1.0f / (float)hd);
+    // X = [V ; Time2Vec(tau)] on the packed rows (+ the learned query's in-projection: parameters only)
+    if (hf) {
+        CHECK(launch_notes_stage(notes, d_m, gather, total, R, d_m, w.X.h, dmc, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w,
+                                 p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s));
+    } else {
+        CHECK(launch_gather_rows(notes, d_m, gather, total, R, d_m, w.X.f, dmc, s, nullptr));
+        CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b, w.X.f + d_m, dmc, s, nullptr));
+        CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s));
+    }
+    // ---- the fold (parameters only)
+    const Mat Wq_k = mat_off(W.att, (size_t)d * d), Wv = mat_off(W.att, (size_t)2 * d * d);
+    const Mat Abuf = inp ? w.Ab : W.kv;
+    const int ldab = inp ? dmc : dcat;         // (without an input projection d_m == d: the two pitches are the same number)
+    {
+        VecJobList l;
+        VecJob& z1 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.Wa.f + (size_t)Hd * dmc, 8, dmc);
+        z1.yh = hf ? mat_off(w.Wa, (size_t)Hd * dmc).h : nullptr; z1.ldy = dmc;
+        VecJob& z2 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.OVa.f + (size_t)Hd * d, 8, d);
+        z2.yh = hf ? mat_off(w.OVa, (size_t)Hd * d).h : nullptr; z2.ldy = d;
+        if (inp) l.add(VJ_MV, p->kv_w, dcat, p->input_proj_b, p->kv_b, w.bvec1, d, d);
+        CHECK(launch_vecjobs(l, s));
+    }
+    const float* bvec1 = inp ? w.bvec1 : p->kv_b;
+    for (int h = 0; h < H; ++h)         // OV_h = W_o[:, h] W_v[h, :]
+        CHECK(fold_gemm(GEMM_NN, prec, d, d, hd, mat_off(W.out, (size_t)h * hd), d, mat_off(Wv, (size_t)h * hd * d), d, mat_off(w.OVa, (size_t)h * d * d), d, nullptr, s));
+    if (inp) CHECK(fold_gemm(GEMM_NN, prec, d, d_m, d, W.kv, dcat, W.in, d_m, w.Ab, dmc, nullptr, s));
+    {
+        VecJobList l;
+        for (int h = 0; h < H; ++h) {
+            VecJob& g = l.add(VJ_MVT, Wq_k.f + (size_t)h * hd * d, d, w.qs + h * hd, nullptr, w.OVa.f + (size_t)(Hd + h) * d, hd, d);
+            g.yh = hf ? mat_off(w.OVa, (size_t)(Hd + h) * d).h : nullptr;
+        }
+        l.add(VJ_MV, Wv.f, d, bvec1, p->attn_in_b + 2 * d, w.bvec2, d, d);
+        if (inp) {
+            VecJob& c = l.add(VJ_COPY, p->kv_w + d, dcat, nullptr, nullptr, w.Ab.f + d_m, d, dt);
+            c.yh = hf ? mat_off(w.Ab, d_m).h : nullptr; c.ldy = dmc;
+        }
+        CHECK(launch_vecjobs(l, s));
+    }
+    CHECK(fold_gemm(GEMM_NN, prec, Hd, dmc, d, w.OVa, d, Abuf, ldab, w.Wa, dmc, nullptr, s));
+    {
+        VecJobList l;
+        for (int h = 0; h < H; ++h) {
+            VecJob& u = l.add(VJ_MVT, Abuf.f, ldab, w.OVa.f + (size_t)(Hd + h) * d, nullptr, w.Wa.f + (size_t)(Hd + h) * dmc, d, dmc);
+            u.yh = hf ? mat_off(w.Wa, (size_t)(Hd + h) * dmc).h : nullptr;
+            l.add(VJ_MV, p->attn_out_w + h * hd, d, w.bvec2 + h * hd, nullptr, w.cvec + h * d, d, hd);
+        }
+        CHECK(launch_vecjobs(l, s));
+    }
+    // ---- the data path
+    CHECK(launch_t2v_scores(hf ? w.X.h : (const void*)w.X.f, hf ? 1 : 0, dmc, w.Wa.f + (size_t)Hd * dmc, dmc, H, total, R, w.S, s));
+    {
+        GemmArgs g = gemm_args(R, Hd, dmc, dmc, dmc, Hd);
+        set_problem2(g, 0, w.X, w.Wa, w.z, w.cvec);
+        g.dyn = total; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
+    CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
+                             drop, SITE_T2V_ATTN, s));
+    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.zln.f, drop, SITE_T2V_OUT, s, w.zln.h));
+    {
+        GemmArgs g = gemm_args(BT, d, d, d, d, d);
+        set_problem2(g, 0, w.zln, W.po, mat(E_txt, hf ? cfg->out_h : nullptr), p->proj_out_b);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    (void)Ma;
+    return IMMTSF_OK;
+}
+
+int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* tau, const float* dE_txt, void* workspace,
+                      size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr, hipStream_t s) {
+    T2VFoldWs w = carve_t2v_fold(cfg, workspace);
+    T2VFoldScratch sc = carve_t2v_fold_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H, d_m = cfg->d_m;
+    const int R = B * N, BT = B * T, prec = cfg->precision, dmc = d_m + dt, Hd = H * d, Ma = Hd + 8;
+    const bool hf = t2v_hf(cfg) && prec == 1, inp = p->input_proj_w != nullptr;
+    const DropCfg drop = drop_of(cfg);
+    const int* total = w.offsets + B;
+    const float scale = sqrtf(1.0f / (float)hd);
+    T2VFW W;
+    CHECK(t2v_fold_weights(cfg, p, w, s, &W));
+    const Mat Wq_k = mat_off(W.att, (size_t)d * d), Wv = mat_off(W.att, (size_t)2 * d * d);
+    const Mat Abuf = inp ? w.Ab : W.kv;
+    const int ldab = inp ? dmc : dcat;
+    const float* bvec1 = inp ? w.bvec1 : p->kv_b;
+    GemmArgs wg[2];
+    int nwg = 0;
+    Mat dE = cmat(dE_txt);
+    if (hf && cfg->in_h) {
+        dE.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
+        CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+        dE.h = sc.dE.h;
+    }
+    {   // proj_out: dzln = dE W_po ; dW_po = dE^T zln ; db_po = colsum dE
+        GemmArgs g = gemm_args(BT, d, d, d, d, d);
+        set_problem2(g, 0, dE, W.po, mat(sc.dzln), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        GemmArgs h = gemm_args(d, d, BT, d, d, d);
+        set_problem2(h, 0, dE, w.zln, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
+        prezeroed(h, cfg);
+        h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
+        wg[nwg++] = h;
+    }
+    {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
+        const int rc = launch_layernorm_bwd_sums(sc.dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                 gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
+        if (rc == IMMTSF_EUNSUPPORTED) {
+            CHECK(launch_layernorm_bwd(sc.dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
+            CHECK(launch_colsum3(sc.dzln, w.xhat, sc.dx, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, nullptr, s, true));
+        } else {
+            CHECK(rc);
+        }
+    }
+    T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
+    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, hf ? sc.dza.h : (void*)sc.dza.f,
+                             sc.dbo_part, drop, SITE_T2V_ATTN, s));
+    CHECK(launch_colsum(sc.dbo_part, nullptr, B, nullptr, d, d, gr->attn_out_b, 0, sc.red_bo, s));          // d b_o
+    {   // Time2Vec rows: dX_tau = dz_aug W_aug[:, d_m:]  (the score path rides in the augmented column)
+        GemmArgs g = gemm_args(R, dt, Ma, Ma, dmc, dt);
+        set_problem2(g, 0, sc.dza, mat_off(w.Wa, d_m), mat(sc.dXt), nullptr);
+        g.dyn = total; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXt, dt, gr->t2v_lin_w, gr->t2v_lin_b, gr->t2v_per_w,
+                              gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
+    {   // dW_aug = dz_aug^T X (+ dc = column sums of dz_aug)
+        GemmArgs h = gemm_args(Ma, dmc, R, Ma, dmc, dmc);
+        set_problem2(h, 0, sc.dza, w.X, mat(sc.dWa.f), nullptr, sc.dcv);
+        h.dyn = total; h.dyn_which = 1;
+        h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
+        wg[nwg++] = h;
+    }
+    CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
+    if (hf) CHECK(launch_f32_to_bf16(sc.dWa.f, sc.dWa.h, (size_t)Ma * dmc, s));
+    // ---- chain rule through the fold (parameters only)
+    {
+        VecJobList l;
+        for (int h = 0; h < H; ++h) l.add(VJ_MVT, p->attn_out_w + h * hd, d, sc.dcv + h * d, nullptr, sc.dbvec2 + h * hd, d, hd);
+        CHECK(launch_vecjobs(l, s));
+    }
+    CHECK(fold_gemm(GEMM_NT, prec, Ma, d, dmc, sc.dWa, dmc, Abuf, ldab, sc.dOVa, d, nullptr, s));          // rows H d ..: dG_h
+    CHECK(fold_gemm(GEMM_TN, prec, d, dmc, Ma, w.OVa, d, sc.dWa, dmc, inp ? sc.dA : mat(gr->kv_w), inp ? dmc : dcat, nullptr, s));
+    {
+        VecJobList l;
+        VecJob& q = l.add(VJ_MV, Wq_k.f, d, sc.dOVa.f + (size_t)Hd * d, nullptr, sc.dqs, d, d);
+        q.xdiv = hd; q.xld = d;
+        l.add(VJ_MVT, Wv.f, d, sc.dbvec2, nullptr, sc.dbvec1, d, d);
+        VecJob& bv = l.add(VJ_COPY, sc.dbvec2, d, nullptr, nullptr, gr->attn_in_b + 2 * d, 1, d);
+        bv.ldy = d;
+        VecJob& bk = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, gr->attn_in_b + d, 1, d);
+        bk.ldy = d;
+        CHECK(launch_vecjobs(l, s));
+    }
+    for (int h = 0; h < H; ++h) {
+        CHECK(fold_gemm(GEMM_NT, prec, d, hd, d, mat_off(sc.dOVa, (size_t)h * d * d), d, mat_off(Wv, (size_t)h * hd * d), d,
+                        mat(gr->attn_out_w + h * hd), d, nullptr, s));
+        CHECK(fold_gemm(GEMM_TN, prec, hd, d, d, mat_off(W.out, (size_t)h * hd), d, mat_off(sc.dOVa, (size_t)h * d * d), d,
+                        mat(gr->attn_in_w + (size_t)(2 * d + h * hd) * d), d, nullptr, s));
+    }
+    if (inp) {
+        CHECK(fold_gemm(GEMM_NT, prec, d, d, d_m, sc.dA, dmc, W.in, d_m, mat(gr->kv_w), dcat, nullptr, s));
+        CHECK(fold_gemm(GEMM_TN, prec, d, d_m, d, W.kv, dcat, sc.dA, dmc, mat(gr->input_proj_w), d_m, nullptr, s));
+    }
+    {
+        VecJobList l;
+        if (inp) l.add(VJ_MVT, p->kv_w, dcat, sc.dbvec1, nullptr, gr->input_proj_b, d, d);
+        VecJob& bk = l.add(VJ_COPY, sc.dbvec1, d, nullptr, nullptr, gr->kv_b, 1, d);
+        bk.ldy = d;
+        CHECK(launch_vecjobs(l, s));
+    }
+    CHECK(launch_query_bwd(sc.dqs, 1, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
+    {
+        Rank1JobList l;
+        for (int h = 0; h < H; ++h) {
+            l.add(gr->attn_out_w + h * hd, d, d, hd, 1, sc.dcv + h * d, w.bvec2 + h * hd);
+            l.add(gr->attn_in_w + (size_t)(d + h * hd) * d, d, hd, d, 0, w.qs + h * hd, sc.dOVa.f + (size_t)(Hd + h) * d);
+        }
+        l.add(gr->attn_in_w + (size_t)2 * d * d, d, d, d, 1, sc.dbvec2, bvec1);
+        if (inp) {
+            l.add(gr->kv_w, dcat, d, d, 1, sc.dbvec1, p->input_proj_b);
+            l.add(gr->kv_w + d, dcat, d, dt, 2, nullptr, nullptr, sc.dA.f + d_m, dmc);
+        }
+        CHECK(launch_rank1jobs(l, s));
+    }
+    return IMMTSF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -138,8 +466,15 @@ int immtsf_ragged_index(const float* notes, int32_t B, int32_t N, int32_t d_m, u
     return launch_ragged_index(note_mask, B, N, lengths, offsets, rowmap, seg, m_txt, s);
 }
 
-size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) ? 0 : carve_t2v(cfg, nullptr).bytes; }
-size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) ? 0 : carve_t2v_scratch(cfg, nullptr).bytes; }
+size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg) {
+    if (bad_cfg(cfg)) return 0;
+    return t2v_fold_on(cfg) ? carve_t2v_fold(cfg, nullptr).bytes : carve_t2v(cfg, nullptr).bytes;
+}
+size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg) {
+    if (bad_cfg(cfg)) return 0;
+    return t2v_fold_on(cfg) ? carve_t2v_fold_scratch(cfg, nullptr).bytes : carve_t2v_scratch(cfg, nullptr).bytes;
+}
+int immtsf_ttf_t2v_xattn_folded(const immtsf_fusion_cfg* cfg) { return (!bad_cfg(cfg) && t2v_fold_on(cfg)) ? 1 : 0; }
 
 // `src_rows` == null: `notes` is the zero-padded (B,N,d_m) tensor and the ragged index is derived from it (reference
 // semantics).  Otherwise `notes` is the resident embedding matrix, src_rows[packed row] its row and `lengths_in` the
@@ -150,6 +485,9 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     if (bad_cfg(cfg) || !p || !notes || !tau || !E_txt || !M_txt || !workspace) return IMMTSF_EINVAL;
     if (cfg->d < 4 || cfg->N <= 0 || cfg->d_m <= 0) return IMMTSF_EINVAL;
     if (!p->input_proj_w && cfg->d != cfg->d_m) return IMMTSF_EINVAL;
+    if (t2v_fold_on(cfg))
+        return t2v_fold_forward(cfg, p, notes, src_rows, lengths_in, tau, E_txt, M_txt, workspace, workspace_bytes, nan_flag,
+                                static_cast<hipStream_t>(stream));
     T2VWs w = carve_t2v(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -242,6 +580,8 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
                         void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
                         immtsf_stream_t stream) {
     if (bad_cfg(cfg) || !p || !gr || !notes || !tau || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+    if (t2v_fold_on(cfg))
+        return t2v_fold_backward(cfg, p, tau, dE_txt, workspace, workspace_bytes, scratch, scratch_bytes, gr, static_cast<hipStream_t>(stream));
     T2VWs w = carve_t2v(cfg, workspace);
     T2VScratch sc = carve_t2v_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;

@@ -1,0 +1,416 @@
+// TTF_T2V_XAttn in FOLDED form (reference: fusions/TTF_T2V_XAttn.py:120-182).
+//
+// The block's query is ONE learned vector for every (window, forecast step) (:91, :143 -- t_hat only gives the shape), and nothing
+// between input_proj and out_proj is nonlinear except the softmax over a window's notes.  With x_n = [V_n ; Time2Vec(tau_n)] the raw
+// (d_m + d/2)-vector of a note:
+//
+//   score  s[n, h] = u_h . x_n + const        u_h = D^T W_KV^T W_k,h^T (scale q_h)      (the constant drops out of the softmax)
+//   value  z[n, h] = W_tot,h x_n + c_h        W_tot,h = W_o[:, h] W_v[h, :] W_KV D      D = blockdiag(W_in, I)
+//   E_attn[b, t]   = sum_h sum_n a~[b, t, h, n] z[n, h] + b_o                           a~ = dropout(softmax_n(s))
+//
+// so the ΣN-row GEMM chain input_proj -> KV_proj -> in-projection (k | v) and the (B T)-row out_proj collapse into ONE ΣN x (H d) x
+// (d_m + d/2) product; W_tot, u, c are parameter-only products (d x d x d class), and the original parameters' gradients follow from
+// dW_tot, du, dc by the chain rule through the same factors.  This file holds the kernels that are not GEMMs: the multi-job vector
+// and rank-1 launches of the parameter chains, the scores, and the softmax + dropout + mix in both directions.
+#include "t2v_fold.hpp"
+
+namespace {
+
+constexpr int TT = 32;        // forecast steps per window (limit of the folded form)
+
+// ------------------------------------------------------------------------------------------------ multi-job vector kernel
+struct VecJobsK { VecJob j[VJ_MAX]; int wg0[VJ_MAX + 1]; int n; };
+
+__device__ __forceinline__ void vj_store(const VecJob& J, size_t idx, float v) {
+    if (J.y) J.y[idx] = v;
+    if (J.yh) static_cast<bf16_t*>(J.yh)[idx] = (bf16_t)v;
+}
+
+__global__ __launch_bounds__(256) void vecjobs_kernel(VecJobsK L) {
+    __shared__ float red[4][64];
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < L.n && (int)blockIdx.x >= L.wg0[ji + 1]) ++ji;
+    const VecJob& J = L.j[ji];
+    const int bid = blockIdx.x - L.wg0[ji];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (J.type == VJ_MV) {
+        const int row = bid * 4 + wave;
+        if (row >= J.rows) return;
+        const float* x = J.x + (J.xdiv > 0 ? (size_t)(row / J.xdiv) * J.xld : 0);
+        const float* w = J.W + (size_t)row * J.ld;
+        float a = 0.f;
+        if (((J.ld | J.cols) & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(x)) & 15) == 0) {
+#pragma unroll 4
+            for (int j = lane * 4; j < J.cols; j += 256) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + j), xv = *reinterpret_cast<const float4*>(x + j);
+                a = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, a))));
+            }
+        } else {
+            for (int j = lane; j < J.cols; j += 64) a = fmaf(w[j], x[j], a);
+        }
+        a = wave_sum(a);
+        if (lane == 0) vj_store(J, row, J.scale * (a + (J.b ? J.b[row] : 0.f)));
+        return;
+    }
+    if (J.type == VJ_MVT) {
+        const int j = bid * 64 + lane;
+        float a = 0.f;
+        if (j < J.cols) {
+#pragma unroll 8
+            for (int i = wave; i < J.rows; i += 4) a = fmaf(J.W[(size_t)i * J.ld + j], J.x[i], a);
+        }
+        red[wave][lane] = a;
+        __syncthreads();
+        if (wave == 0 && j < J.cols) {
+            const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+            vj_store(J, j, J.scale * (t + (J.b ? J.b[j] : 0.f)));
+        }
+        return;
+    }
+    // VJ_COPY
+    const long n = (long)J.rows * J.cols, nwg = L.wg0[ji + 1] - L.wg0[ji];
+    for (long x = (long)bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+        const int i = (int)(x / J.cols), j = (int)(x - (long)i * J.cols);
+        vj_store(J, (size_t)i * J.ldy + j, J.W ? J.scale * J.W[(size_t)i * J.ld + j] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ multi-job rank-1 kernel
+struct Rank1K { Rank1Job j[R1_MAX]; int wg0[R1_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void rank1jobs_kernel(Rank1K L) {
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < L.n && (int)blockIdx.x >= L.wg0[ji + 1]) ++ji;
+    const Rank1Job& J = L.j[ji];
+    const long nwg = L.wg0[ji + 1] - L.wg0[ji], bid = blockIdx.x - L.wg0[ji];
+    const int c4 = J.cols >> 2;
+    const bool vec = (J.cols & 3) == 0 && (J.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(J.out) & 15) == 0 &&
+                     (!J.b || (reinterpret_cast<uintptr_t>(J.b) & 15) == 0) &&
+                     (J.mode != 2 || ((J.lds & 3) == 0 && (reinterpret_cast<uintptr_t>(J.src) & 15) == 0));
+    if (vec) {
+        const long n = (long)J.rows * c4;
+        for (long x = bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+            const int i = (int)(x / c4), j = (int)(x - (long)i * c4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4* o = reinterpret_cast<float4*>(J.out + (size_t)i * J.ld + j);
+            if (J.mode == 1) v = *o;
+            else if (J.mode == 2) v = *reinterpret_cast<const float4*>(J.src + (size_t)i * J.lds + j);
+            if (J.a) {
+                const float ai = J.a[i];
+                const float4 bv = *reinterpret_cast<const float4*>(J.b + j);
+                v.x = fmaf(ai, bv.x, v.x); v.y = fmaf(ai, bv.y, v.y); v.z = fmaf(ai, bv.z, v.z); v.w = fmaf(ai, bv.w, v.w);
+            }
+            *o = v;
+        }
+        return;
+    }
+    const long n = (long)J.rows * J.cols;
+    for (long x = bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+        const int i = (int)(x / J.cols), j = (int)(x - (long)i * J.cols);
+        float v = J.mode == 1 ? J.out[(size_t)i * J.ld + j] : J.mode == 2 ? J.src[(size_t)i * J.lds + j] : 0.f;
+        if (J.a) v = fmaf(J.a[i], J.b[j], v);
+        J.out[(size_t)i * J.ld + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scores
+__device__ __forceinline__ void ld8(const float* p, float (&o)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&o)[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    const unsigned int w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { o[2 * j] = __uint_as_float(w[j] << 16); o[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+// one wave per packed row, every head: S[r, h] = X[r, :] . U[h, :]  (dmc a multiple of 8)
+template <typename KT, int HMAX>
+__global__ __launch_bounds__(256) void t2v_scores_kernel(const KT* __restrict__ X, int dmc, const float* __restrict__ U, int ldu, int H,
+                                                          const int* __restrict__ total, int max_rows, float* __restrict__ S) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int rows = total ? min(*total, max_rows) : max_rows;
+    if (row >= rows) return;
+    const KT* xr = X + (size_t)row * dmc;
+    float a[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) a[h] = 0.f;
+#pragma unroll 2
+    for (int c = lane * 8; c < dmc; c += 512) {
+        float xv[8];
+        ld8(xr + c, xv);
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            if (h < H) {
+                float uv[8];
+                ld8(U + (size_t)h * ldu + c, uv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[h] = fmaf(xv[j], uv[j], a[h]);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        if (h < H) {
+            const float t = wave_sum(a[h]);
+            if (lane == 0) S[(size_t)row * H + h] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mix, forward
+// grid (B, ceil(d / 256)), 256 threads: a thread owns one output column e of its window for all T steps.  Per head: the window's
+// n <= NV scores -> softmax in every wave's own lanes, the (step, note) dropout scales as an LDS tile, the value column z[n, h d + e]
+// of the window's notes in registers (every load issued before the first use), acc[t] += sum_n mt[t, n] p[n] z[n].
+template <typename KT, int NV>
+__global__ __launch_bounds__(256) void t2v_mix_fwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+                                                           const float* __restrict__ S, const KT* __restrict__ z,
+                                                           const float* __restrict__ b_o, const float* __restrict__ q_res,
+                                                           float* __restrict__ P, float* __restrict__ xpre, DropCfg drop, uint64_t site) {
+    __shared__ __attribute__((aligned(16))) float mt[TT * NV];       // dropout scale of (forecast step, note); 0 past T / n
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = dm.d, H = dm.H, Hd = H * d, T = dm.T;
+    const int ob = offsets[b], n = offsets[b + 1] - ob;
+    const int e = blockIdx.y * 256 + tid;
+    const bool valid = e < d;
+    const float qr = valid ? q_res[e] : 0.f;
+    if (n == 0) {        // no notes: E_attn is zero (M_txt), the residual query remains
+        if (valid) for (int t = 0; t < T; ++t) xpre[(size_t)(b * T + t) * d + e] = qr;
+        return;
+    }
+    float acc[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) acc[t] = 0.f;
+    const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
+    for (int h = 0; h < H; ++h) {
+        // this thread's value column of head h (rows past n: the last row again, weight 0)
+        KT vr[NV];
+        {
+            const KT* vbase = z + (size_t)ob * Hd + (size_t)h * d + (valid ? e : 0);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vr[i] = vbase[(size_t)(i < n ? i : n - 1) * Hd];
+        }
+        const float s_l = lane < n ? S[(size_t)(ob + lane) * H + h] : -INFINITY;
+        if (h > 0) __syncthreads();            // the previous head's tile has been read
+        for (int x = tid; x < TT * NV; x += 256) {
+            const int tt = x / NV, ii = x - tt * NV;
+            float a = 0.f;
+            if (tt < T && ii < n) {
+                a = 1.f;
+                if (drop.p > 0.f) {
+                    const int n_orig = rowmap[ob + ii] - b * dm.N;
+                    const uint64_t idx = ((uint64_t)(b * T + tt) * H + h) * dm.N + n_orig;
+                    a = dropout_scale(seed, site, idx, drop.p, drop.inv_keep);
+                }
+            }
+            mt[x] = a;
+        }
+        const float m = wave_max(s_l);
+        float p = lane < n ? expf(s_l - m) : 0.f;
+        p *= 1.f / wave_sum(p);
+        if (wave == 0 && blockIdx.y == 0 && lane < n) P[(size_t)(ob + lane) * H + h] = p;
+        __syncthreads();
+        float pv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pv[i] = lane_bcast(p, i) * (float)vr[i];        // (weight 0 past n)
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float a = acc[tt];
+#pragma unroll
+            for (int i = 0; i < NV; i += 4) {
+                const float4 m4 = *reinterpret_cast<const float4*>(mt + tt * NV + i);
+                a = fmaf(m4.x, pv[i], a); a = fmaf(m4.y, pv[i + 1], a); a = fmaf(m4.z, pv[i + 2], a); a = fmaf(m4.w, pv[i + 3], a);
+            }
+            acc[tt] = a;
+        }
+    }
+    if (!valid) return;
+    const float add = b_o[e] + qr;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+        if (tt < T) xpre[(size_t)(b * T + tt) * d + e] = acc[tt] + add;
+}
+
+// ------------------------------------------------------------------------------------------------ mix, backward
+// grid (B), 256 threads: the workgroup owns its window -- every column, every head -- so the softmax backward needs no second launch:
+//   g[n, h, e]  = sum_t mt[t, h, n] dx[b, t, e]          dz[n, h d + e] = p[n, h] g        dp[n, h] = sum_e g z[n, h d + e]
+//   ds[n, h]    = p[n, h] (dp[n, h] - sum_j p[j, h] dp[j, h])                                  -> column H d + h of dz_aug
+// The window's dropout tiles (all heads) are built once, note-major, so a note's T scales are eight 16-byte broadcast reads; a
+// thread walks the columns e = tid, tid + 256, ... with the T upstream values of its column in registers; the per-note dot products
+// meet in wave-private LDS slabs (plain adds by lane 0, summed in wave order).
+template <typename KT, int NV, int HMAX>
+__global__ __launch_bounds__(256) void t2v_mix_bwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+                                                           const float* __restrict__ P, const KT* __restrict__ z,
+                                                           const float* __restrict__ dx, KT* __restrict__ dz, float* __restrict__ dbo_part,
+                                                           DropCfg drop, uint64_t site) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = dm.H;
+    float* mt = lds;                                   // [H][NV][TT]
+    float* pl = mt + (size_t)H * NV * TT;              // [H][NV]
+    float* dpw = pl + H * NV;                          // [4 waves][H][NV]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = dm.d, Hd = H * d, Ma = Hd + 8, T = dm.T;
+    const int ob = offsets[b], n = offsets[b + 1] - ob;
+    if (n == 0) {
+        for (int e = tid; e < d; e += 256) dbo_part[(size_t)b * d + e] = 0.f;
+        return;
+    }
+    const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
+    for (int x = tid; x < H * NV * TT; x += 256) {
+        const int h = x / (NV * TT), r = x - h * NV * TT, ii = r / TT, tt = r - ii * TT;
+        float a = 0.f;
+        if (tt < T && ii < n) {
+            a = 1.f;
+            if (drop.p > 0.f) {
+                const int n_orig = rowmap[ob + ii] - b * dm.N;
+                const uint64_t idx = ((uint64_t)(b * T + tt) * H + h) * dm.N + n_orig;
+                a = dropout_scale(seed, site, idx, drop.p, drop.inv_keep);
+            }
+        }
+        mt[x] = a;
+    }
+    for (int x = tid; x < H * NV; x += 256) {
+        const int h = x / NV, ii = x - h * NV;
+        pl[x] = ii < n ? P[(size_t)(ob + ii) * H + h] : 0.f;
+    }
+    for (int x = tid; x < 4 * H * NV; x += 256) dpw[x] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < ((d + 255) & ~255); e += 256) {
+        const bool valid = e < d;
+        float dcv[TT];
+        float gsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            dcv[t] = (valid && t < T) ? dx[(size_t)(b * T + t) * d + e] : 0.f;
+            gsum += dcv[t];
+        }
+        if (valid) dbo_part[(size_t)b * d + e] = gsum;
+        for (int h = 0; h < H; ++h) {
+            KT vr[NV];
+            {
+                const KT* vbase = z + (size_t)ob * Hd + (size_t)h * d + (valid ? e : 0);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) vr[i] = vbase[(size_t)(i < n ? i : n - 1) * Hd];
+            }
+#pragma unroll 4
+            for (int i = 0; i < NV; ++i) {
+                if (i >= n) break;              // (n is workgroup-uniform)
+                const float4* m4 = reinterpret_cast<const float4*>(mt + ((size_t)h * NV + i) * TT);
+                float g = 0.f;
+#pragma unroll
+                for (int t4 = 0; t4 < TT / 4; ++t4) {
+                    const float4 m = m4[t4];
+                    g = fmaf(m.x, dcv[4 * t4], fmaf(m.y, dcv[4 * t4 + 1], fmaf(m.z, dcv[4 * t4 + 2], fmaf(m.w, dcv[4 * t4 + 3], g))));
+                }
+                float a = valid ? g * (float)vr[i] : 0.f;
+                if (valid) dz[(size_t)(ob + i) * Ma + (size_t)h * d + e] = (KT)(pl[h * NV + i] * g);
+                a = wave_sum(a);
+                if (lane == 0) dpw[(wave * H + h) * NV + i] += a;
+            }
+        }
+    }
+    __syncthreads();
+    // softmax backward per head, notes in the lanes of wave h (h < H <= 4); the pad columns of dz_aug are zeroed by the same lanes
+    if (wave < H) {            // (wave-uniform: the wave reductions below run with every lane active)
+        const int h = wave;
+        float dp = 0.f, p = 0.f;
+        if (lane < n) {
+            dp = dpw[(0 * H + h) * NV + lane] + dpw[(1 * H + h) * NV + lane] + dpw[(2 * H + h) * NV + lane] + dpw[(3 * H + h) * NV + lane];
+            p = pl[h * NV + lane];
+        }
+        const float dot = wave_sum(p * dp);
+        if (lane < n) {
+            KT* row = dz + (size_t)(ob + lane) * Ma + Hd;
+            row[h] = (KT)(p * (dp - dot));
+            if (h == 0)
+                for (int j = H; j < 8; ++j) row[j] = (KT)0.f;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_vecjobs(const VecJobList& l, hipStream_t s) {
+    if (l.n <= 0) return IMMTSF_OK;
+    if (l.n > VJ_MAX) return IMMTSF_EINVAL;
+    VecJobsK K;
+    int wg = 0;
+    for (int i = 0; i < l.n; ++i) {
+        const VecJob& J = l.j[i];
+        if (J.rows <= 0 || J.cols <= 0 || (!J.y && !J.yh)) return IMMTSF_EINVAL;
+        K.j[i] = J;
+        K.wg0[i] = wg;
+        if (J.type == VJ_MV) wg += cdiv(J.rows, 4);
+        else if (J.type == VJ_MVT) wg += cdiv(J.cols, 64);
+        else {
+            const long n = (long)J.rows * J.cols;
+            wg += (int)((n + 2047) / 2048 > 128 ? 128 : (n + 2047) / 2048);
+        }
+    }
+    for (int i = l.n; i <= VJ_MAX; ++i) K.wg0[i] = wg;
+    K.n = l.n;
+    hipLaunchKernelGGL(vecjobs_kernel, dim3(wg), dim3(256), 0, s, K);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_rank1jobs(const Rank1JobList& l, hipStream_t s) {
+    if (l.n <= 0) return IMMTSF_OK;
+    if (l.n > R1_MAX) return IMMTSF_EINVAL;
+    Rank1K K;
+    int wg = 0;
+    for (int i = 0; i < l.n; ++i) {
+        const Rank1Job& J = l.j[i];
+        if (J.rows <= 0 || J.cols <= 0 || !J.out || (J.mode == 2 && !J.src) || (J.a && !J.b)) return IMMTSF_EINVAL;
+        K.j[i] = J;
+        K.wg0[i] = wg;
+        const long n = (long)J.rows * J.cols;
+        wg += (int)((n + 4095) / 4096 > 192 ? 192 : (n + 4095) / 4096);
+    }
+    for (int i = l.n; i <= R1_MAX; ++i) K.wg0[i] = wg;
+    K.n = l.n;
+    hipLaunchKernelGGL(rank1jobs_kernel, dim3(wg), dim3(256), 0, s, K);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+bool t2v_fold_shape_ok(int N, int T, int d, int H) { return N >= 1 && N <= 64 && T >= 1 && T <= TT && d >= 8 && d <= 1024 && (d % 8) == 0 && H >= 1 && H <= 4; }
+
+int launch_t2v_scores(const void* X, int x_is_bf16, int dmc, const float* U, int ldu, int H, const int* total, int max_rows, float* S,
+                      hipStream_t s) {
+    if (max_rows <= 0) return IMMTSF_OK;
+    if (H < 1 || H > 4 || (dmc % 8) || (ldu % 4) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(U) & 15)) return IMMTSF_EUNSUPPORTED;
+    const dim3 grid(cdiv(max_rows, 4));
+    if (x_is_bf16) hipLaunchKernelGGL((t2v_scores_kernel<bf16_t, 4>), grid, dim3(256), 0, s, static_cast<const bf16_t*>(X), dmc, U, ldu, H, total, max_rows, S);
+    else hipLaunchKernelGGL((t2v_scores_kernel<float, 4>), grid, dim3(256), 0, s, static_cast<const float*>(X), dmc, U, ldu, H, total, max_rows, S);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
+                       const float* q_res, float* P, float* xpre, DropCfg drop, uint64_t site, hipStream_t s) {
+    if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H)) return IMMTSF_EUNSUPPORTED;
+    const dim3 grid(dm.B, cdiv(dm.d, 256));
+#define MIXF(KT, NV) hipLaunchKernelGGL((t2v_mix_fwd_kernel<KT, NV>), grid, dim3(256), 0, s, dm, offsets, rowmap, S, static_cast<const KT*>(z), \
+                                        b_o, q_res, P, xpre, drop, site)
+    if (z_is_bf16) { if (dm.N <= 32) MIXF(bf16_t, 32); else MIXF(bf16_t, 64); }
+    else { if (dm.N <= 32) MIXF(float, 32); else MIXF(float, 64); }
+#undef MIXF
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const float* dx,
+                       void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s) {
+    if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H)) return IMMTSF_EUNSUPPORTED;
+    const int NV = dm.N <= 32 ? 32 : 64;
+    const size_t lds = ((size_t)dm.H * NV * TT + (size_t)dm.H * NV + 4 * (size_t)dm.H * NV) * sizeof(float);
+#define MIXB(KT, NVV) hipLaunchKernelGGL((t2v_mix_bwd_kernel<KT, NVV, 4>), dim3(dm.B), dim3(256), lds, s, dm, offsets, rowmap, P, \
+                                         static_cast<const KT*>(z), dx, static_cast<KT*>(dz_aug), dbo_part, drop, site)
+    if (z_is_bf16) { if (NV == 32) MIXB(bf16_t, 32); else MIXB(bf16_t, 64); }
+    else { if (NV == 32) MIXB(float, 32); else MIXB(float, 64); }
+#undef MIXB
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}

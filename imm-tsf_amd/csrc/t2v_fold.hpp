@@ -1,0 +1,63 @@
+// Kernels of TTF_T2V_XAttn's FOLDED form (t2v_fold.hip; orchestration in fusion_blocks.hip).  reference: fusions/TTF_T2V_XAttn.py:120-182.
+#pragma once
+#include "common.hpp"
+
+// ---- several independent small vector jobs as ONE launch (the parameter-only chains of the fold and of its chain rule) ----------
+enum { VJ_MV = 0, VJ_MVT = 1, VJ_COPY = 2 };
+struct VecJob {
+    int type;            // VJ_MV:   y[i] = scale * (sum_j W[i ld + j] x_i[j] + (b ? b[i] : 0)),  x_i = x + (i / xdiv) xld      i < rows, j < cols
+                         // VJ_MVT:  y[j] = scale * (sum_i W[i ld + j] x[i]   + (b ? b[j] : 0))                                   i < rows, j < cols
+                         // VJ_COPY: y[i ldy + j] = scale * W[i ld + j] (W == null: 0)                                            i < rows, j < cols
+    const float* W;
+    int ld;
+    const float* x;
+    const float* b;
+    float* y;            // may be null when yh is given
+    void* yh;            // optional bf16 copy of y (same indexing)
+    int rows, cols, ldy;
+    int xdiv, xld;       // VJ_MV only (xdiv <= 0: one x for every row)
+    float scale;
+};
+constexpr int VJ_MAX = 10;
+struct VecJobList {
+    VecJob j[VJ_MAX];
+    int n;
+    VecJobList() : n(0) {}
+    VecJob& add(int type, const float* W, int ld, const float* x, const float* b, float* y, int rows, int cols) {
+        VecJob& v = j[n++];
+        v.type = type; v.W = W; v.ld = ld; v.x = x; v.b = b; v.y = y; v.yh = nullptr; v.rows = rows; v.cols = cols; v.ldy = cols;
+        v.xdiv = 0; v.xld = 0; v.scale = 1.f;
+        return v;
+    }
+};
+int launch_vecjobs(const VecJobList& l, hipStream_t s);
+
+// ---- several rank-1 / copy jobs on matrices as ONE launch:  out[i ld + j] = base + (a ? a[i] b[j] : 0),
+// base = mode 0: 0, mode 1: out[i ld + j] (accumulate), mode 2: src[i lds + j]
+struct Rank1Job { float* out; int ld; const float* src; int lds; const float *a, *b; int rows, cols, mode; };
+constexpr int R1_MAX = 12;
+struct Rank1JobList {
+    Rank1Job j[R1_MAX];
+    int n;
+    Rank1JobList() : n(0) {}
+    void add(float* out, int ld, int rows, int cols, int mode, const float* a, const float* b, const float* src = nullptr, int lds = 0) {
+        Rank1Job& r = j[n++];
+        r.out = out; r.ld = ld; r.src = src; r.lds = lds; r.a = a; r.b = b; r.rows = rows; r.cols = cols; r.mode = mode;
+    }
+};
+int launch_rank1jobs(const Rank1JobList& l, hipStream_t s);
+
+// ---- the data path.  X (R, dmc) = [note embedding (d_m) ; Time2Vec (d/2)] per packed note, fp32 or bf16 (xh != 0); z (R, H d) the
+// folded value rows per head; S / P (R, H) scores / softmax weights
+struct T2VFoldDims { int B, T, H, d, N, dmc; };     // N: padded notes per window (dropout index only)
+bool t2v_fold_shape_ok(int N, int T, int d, int H);
+// S[r, h] = X[r, :] . U[h, :]   (U fp32, pitch ldu)
+int launch_t2v_scores(const void* X, int x_is_bf16, int dmc, const float* U, int ldu, int H, const int* total, int max_rows, float* S, hipStream_t s);
+// softmax over the window's notes per head (P written), attention dropout per (window, step, head, note), mix of the z rows:
+// xpre[b, t, :] = (n_b > 0 ? sum_h sum_n a~ z[n, h] + b_o : 0) + q_res
+int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
+                       const float* q_res, float* P, float* xpre, DropCfg drop, uint64_t site, hipStream_t s);
+// backward of the mix and the softmax: dz_aug (R, H d + 8): columns [h d, (h+1) d) = dz of head h, column H d + h = ds of head h, the
+// rest 0 (fp32 or bf16 like z); dbo_part (B, d) = sum_t dx[b, t, :] of the windows with notes (0 otherwise)
+int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const float* dx,
+                       void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ImmtsfError(RuntimeError):
@@ -31,7 +31,7 @@ class FusionCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("d_m", C.c_int32),
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
                 ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("grads_prezeroed", C.c_int32),
-                ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p)]
+                ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p)]
 
 
 def _ptr_struct(name, fields):
@@ -83,6 +83,7 @@ _PROTOS = {
                                       c_u8p, c_i32p, c_stream]),
     "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_ttf_t2v_xattn_folded": (C.c_int, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_forward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, c_u8p, C.c_void_p,
                                                C.c_size_t, c_i32p, c_stream]),
     "immtsf_ttf_t2v_xattn_backward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, C.c_void_p,

@@ -87,19 +87,20 @@ def dropout_counter_ptr(device):
     c = _device_counters.get(str(device))
     return None if c is None else c[1].data_ptr()
 
-# MMF_XAttn_Add in its low-rank form (csrc/xrank.hip) wherever its limits allow; False (or IMMTSF_XATTN_RANK=0): the full-rank
-# key/value + query halves
-import os as _os
-xattn_rank = _os.environ.get("IMMTSF_XATTN_RANK", "1") != "0"
+# Alternative formulations kept as cross-checks of the default ones (tests flip these attributes; no environment variables):
+# MMF_XAttn_Add in its low-rank form (csrc/xrank.hip) wherever its limits allow; False: the full-rank key/value + query halves
+xattn_rank = True
 # ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
-# launch (MMF_XAttn_Add.forward_loss); IMMTSF_XATTN_FUSED_LOSS=0: the Q half and the loss as separate ops
-xattn_fused_loss = _os.environ.get("IMMTSF_XATTN_FUSED_LOSS", "1") != "0"
+# launch (MMF_XAttn_Add.forward_loss); False: the Q half and the loss as separate ops
+xattn_fused_loss = True
+# TTF_T2V_XAttn: "auto" = the folded form (csrc/t2v_fold.hip) wherever its limits hold, "chain" = the reference's GEMM chain as written
+t2v_form = "auto"
 # immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
 head_done_flag = None
 head_dy_ptr = None        # ... and, when a head took the flag: the address of the dY_ts buffer its kernel publishes
-# FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); IMMTSF_ATTN_MID=0:
-# batched GEMMs + row softmax
-attn_mid = _os.environ.get("IMMTSF_ATTN_MID", "1") != "0"
+# FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); False: batched GEMMs +
+# row softmax
+attn_mid = True
 # a torch.cuda.Stream on which MMF_XAttn_Add's fold (parameters only) may run ahead of the text side (None: in line); the stream
 # must be ordered behind the previous optimizer step (immtsf.train.FlagStep forks it at the start of the captured step)
 fold_stream = None

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMMTSF_ABI_VERSION 2
+#define IMMTSF_ABI_VERSION 3
 
 #define IMMTSF_OK 0
 #define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
@@ -63,6 +63,10 @@ typedef struct immtsf_fusion_cfg {
     int32_t grads_prezeroed;       /* backward only: every gradient buffer passed in `grads` is already zero (e.g. one
                                       memset of a flat gradient buffer per step), so split-K weight-gradient GEMMs skip
                                       their own zero-fill */
+    int32_t form;                  /* TTF_T2V_XAttn: 0 = the library chooses (the FOLDED form -- csrc/t2v_fold.hip -- wherever its limits
+                                      hold: N <= 64 padded notes, T <= 32, d <= 1024, H <= 4), 1 = the reference's GEMM chain as written
+                                      (the cross-check).  Same function, same parameters, same dropout masks either way; forward and
+                                      backward of one call pair must be given the same value.  (ABI 3; occupies former padding) */
     /* bf16 mode, optional (NULL = off): bf16 images of the activations that cross a block boundary, so that the consumer's
      * GEMMs read them by LDS-DMA without a cast kernel of their own.  out_h: the call also writes its main activation
      * output there (ttf forward: E_txt (B*T*d); mmf q backward: dKV (B*T*2d); mmf kv backward: dE_txt).  in_h: image of
@@ -99,6 +103,11 @@ typedef struct immtsf_t2v_params {
 
 size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg);
 size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg);
+/* 1 when calls with this cfg run the block in its FOLDED form (csrc/t2v_fold.hip: scores as a mat-vec of the raw notes with a folded
+ * vector per head, ONE sum-of-notes x (H d) x (d_m + d/2) product in place of input_proj / KV_proj / in-projection / out_proj,
+ * parameter gradients by the chain rule through the folded factors), 0 when they run the reference's GEMM chain as written
+ * (cfg->form == 1, or a shape outside the folded form's limits).  reference: fusions/TTF_T2V_XAttn.py:120-182 either way. */
+int immtsf_ttf_t2v_xattn_folded(const immtsf_fusion_cfg* cfg);
 /* notes (B,N,d_m), tau (B,N)  ->  E_txt (B,T,d), M_txt u8 (B).  t_hat's values do not enter this block (only T). */
 int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
                                  const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,

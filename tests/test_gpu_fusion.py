@@ -833,6 +833,72 @@ def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N,T,d_m,d,H,pd,packed", [(5, 6, 7, 48, 32, 1, 0.0, False), (6, 32, 32, 96, 64, 2, 0.2, False), (3, 17, 13, 64, 64, 4, 0.3, True),
+                                                      (64, 32, 32, 768, 768, 1, 0.1, False), (64, 32, 32, 768, 768, 1, 0.1, True),
+                                                      (4, 64, 9, 4096, 128, 1, 0.1, False), (7, 5, 32, 80, None, 2, 0.15, False),
+                                                      (300, 9, 6, 32, 16, 1, 0.0, True)])
+def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, packed, precision):
+    """TTF_T2V_XAttn's folded form (csrc/t2v_fold.hip: scores as a mat-vec of the raw notes with a folded vector per head, one
+    sum-of-notes x (H d) x (d_m + d/2) product in place of input_proj / KV_proj / in-projection / out_proj, parameter gradients by the
+    chain rule through the folded factors) against the reference's GEMM chain as written (immtsf.config.t2v_form = "chain"): same Philox
+    sites and indices, so also under dropout; E_txt, M_txt and every parameter gradient; padded and packed notes, with and without an
+    input projection (d_txt = None), a window without notes.  (Both are pinned to the reference by the goldens: the module takes the
+    folded form wherever its limits hold.)  reference: fusions/TTF_T2V_XAttn.py:120-182."""
+    dev = _dev()
+    import ctypes as C
+    from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+    from fusions.load_llm import register_d_model
+    from immtsf import _lib, config
+    from immtsf.ops import PackedNotes, make_cfg
+    register_d_model(f"FOLD{d_m}", d_m)
+    config.precision = precision
+    torch.manual_seed(B * 100 + N)
+    ttf = TTF_T2V_XAttn(f"FOLD{d_m}", 6, n_heads_fusion=H, dropout=pd, d_txt=d).to(dev).train()
+    dd = ttf.d_txt
+    with torch.no_grad():
+        for p_ in ttf.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    g = torch.Generator().manual_seed(B + 17 * T)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    if B > 2:
+        lengths[1] = 0            # a window without notes
+    keep = torch.arange(N).view(1, -1) < lengths.view(-1, 1)
+    notes = (torch.randn(B, N, d_m, generator=g) * keep.unsqueeze(-1)).to(dev)
+    tau = (torch.sort(torch.rand(B, N, generator=g) * 24.0, dim=1).values * keep).to(dev)
+    t_hat = torch.rand(B, T, generator=g).to(dev)
+    up = torch.randn(B, T, dd, generator=g).to(dev)
+    src = notes
+    if packed:
+        rows = torch.arange(B * N, device=dev, dtype=torch.int32).view(B, N)[keep.to(dev)].contiguous()
+        src = PackedNotes(notes.reshape(B * N, d_m).contiguous(), rows, lengths.to(dev).to(torch.int32), N)
+    cfg = make_cfg(B, N, T, 0, d_m, dd, H, 1 if precision == "bf16" else 0, True, pd, 0.0, 0, None)
+    assert _lib.load().immtsf_ttf_t2v_xattn_folded(C.byref(cfg)) == 1          # these shapes are inside the folded form's limits
+    res, seed0 = [], config.next_seed
+    try:
+        config.next_seed = lambda: 9191
+        for form in ("auto", "chain"):
+            config.t2v_form = form
+            ttf.zero_grad()
+            E, M = ttf(src, tau, t_hat)
+            (E * up).sum().backward()
+            res.append([("E", E.detach()), ("M", M.float())] + [(k, p_.grad.clone()) for k, p_ in ttf.named_parameters()])
+    finally:
+        config.next_seed, config.t2v_form, config.precision = seed0, "auto", "fp32"
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][2:])
+    for (k, a), (_, b) in zip(*res):
+        assert torch.isfinite(a).all(), k
+        if k == "M":
+            assert torch.equal(a, b)
+            continue
+        # floor: the key bias gradient is zero in exact arithmetic; small gradients are compared on the scale of the block's largest
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k != "E" else 1e-6) + 1e-30
+        err = float((a - b).norm()) / den
+        assert err <= tol, (k, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (64, 32, 8, 768, 1, 0.1), (300, 6, 15, 16, 1, 0.1)])
 def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precision):
     """MMF_XAttn_Add.forward_loss (immtsf_mmf_xrank_q_train: the Q half, the masked MSE with known observation counts and the backward

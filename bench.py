@@ -733,7 +733,7 @@ def main():
                          "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
     ap.add_argument("--no-wgrad-fork", action="store_true",
                     help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
-    ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain"],
+    ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold"],
                     help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
                          "reference's GEMM chain (immtsf.config.t2v_form)")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,

@@ -129,6 +129,7 @@ int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2
 // caller asks for the chain as written (immtsf_fusion_cfg.form = 1, the cross-check).
 inline bool t2v_fold_on(const immtsf_fusion_cfg* c) {
     if (c->form == 1 || !t2v_fold_shape_ok(c->N, c->T, c->d, c->H)) return false;
+    if (c->form == 0 && (long)c->B * c->N < IMMTSF_T2V_FOLD_MIN_ROWS) return false;      // small batches: the chain's GEMMs are as cheap as the fold's fixed cost
     if ((c->d_m % 8) || (c->d % 16) || c->d_m <= 0) return false;            // X rows and the Time2Vec half in 16-byte pieces
     if (c->precision == 1 && !(t2v_hf(c) && ((c->d / c->H) % 8) == 0)) return false;
     return true;
@@ -260,28 +261,25 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));
     const int* gather = src_rows ? src_rows : w.rowmap;
     const float scale = sqrtf(1.0f / (float)hd);
-    // X = [V ; Time2Vec(tau)] on the packed rows (+ the learned query's in-projection: parameters only)
+    // X = [V ; Time2Vec(tau)] on the packed rows; in the same launch the two parameter-only mat-vecs the fold starts from: the learned
+    // query's in-projection and bvec1 = W_KV[:, :d] b_in + b_KV
     if (hf) {
         CHECK(launch_notes_stage(notes, d_m, gather, total, R, d_m, w.X.h, dmc, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w,
-                                 p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s));
+                                 p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s,
+                                 inp ? p->kv_w : nullptr, dcat, p->input_proj_b, p->kv_b, d, d, w.bvec1));
     } else {
         CHECK(launch_gather_rows(notes, d_m, gather, total, R, d_m, w.X.f, dmc, s, nullptr));
         CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b, w.X.f + d_m, dmc, s, nullptr));
-        CHECK(launch_matvec(p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s));
-    }
-    // ---- the fold (parameters only)
-    const Mat Wq_k = mat_off(W.att, (size_t)d * d), Wv = mat_off(W.att, (size_t)2 * d * d);
-    const Mat Abuf = inp ? w.Ab : W.kv;
-    const int ldab = inp ? dmc : dcat;         // (without an input projection d_m == d: the two pitches are the same number)
-    {
         VecJobList l;
-        VecJob& z1 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.Wa.f + (size_t)Hd * dmc, 8, dmc);
-        z1.yh = hf ? mat_off(w.Wa, (size_t)Hd * dmc).h : nullptr; z1.ldy = dmc;
-        VecJob& z2 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.OVa.f + (size_t)Hd * d, 8, d);
-        z2.yh = hf ? mat_off(w.OVa, (size_t)Hd * d).h : nullptr; z2.ldy = d;
+        VecJob& q = l.add(VJ_MV, p->attn_in_w, d, p->Q_param, p->attn_in_b, w.qs, d, d);
+        q.scale = scale;
         if (inp) l.add(VJ_MV, p->kv_w, dcat, p->input_proj_b, p->kv_b, w.bvec1, d, d);
         CHECK(launch_vecjobs(l, s));
     }
+    // ---- the fold (parameters only): five launches
+    const Mat Wq_k = mat_off(W.att, (size_t)d * d), Wv = mat_off(W.att, (size_t)2 * d * d);
+    const Mat Abuf = inp ? w.Ab : W.kv;
+    const int ldab = inp ? dmc : dcat;         // (without an input projection d_m == d: the two pitches are the same number)
     const float* bvec1 = inp ? w.bvec1 : p->kv_b;
     for (int h = 0; h < H; ++h)         // OV_h = W_o[:, h] W_v[h, :]
         CHECK(fold_gemm(GEMM_NN, prec, d, d, hd, mat_off(W.out, (size_t)h * hd), d, mat_off(Wv, (size_t)h * hd * d), d, mat_off(w.OVa, (size_t)h * d * d), d, nullptr, s));
@@ -292,6 +290,8 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
             VecJob& g = l.add(VJ_MVT, Wq_k.f + (size_t)h * hd * d, d, w.qs + h * hd, nullptr, w.OVa.f + (size_t)(Hd + h) * d, hd, d);
             g.yh = hf ? mat_off(w.OVa, (size_t)(Hd + h) * d).h : nullptr;
         }
+        VecJob& z2 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.OVa.f + (size_t)(Hd + H) * d, 8 - H, d);       // the pad rows
+        z2.yh = hf ? mat_off(w.OVa, (size_t)(Hd + H) * d).h : nullptr; z2.ldy = d;
         l.add(VJ_MV, Wv.f, d, bvec1, p->attn_in_b + 2 * d, w.bvec2, d, d);
         if (inp) {
             VecJob& c = l.add(VJ_COPY, p->kv_w + d, dcat, nullptr, nullptr, w.Ab.f + d_m, d, dt);
@@ -307,6 +307,8 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
             u.yh = hf ? mat_off(w.Wa, (size_t)(Hd + h) * dmc).h : nullptr;
             l.add(VJ_MV, p->attn_out_w + h * hd, d, w.bvec2 + h * hd, nullptr, w.cvec + h * d, d, hd);
         }
+        VecJob& z1 = l.add(VJ_COPY, nullptr, 0, nullptr, nullptr, w.Wa.f + (size_t)(Hd + H) * dmc, 8 - H, dmc);     // the pad rows
+        z1.yh = hf ? mat_off(w.Wa, (size_t)(Hd + H) * dmc).h : nullptr; z1.ldy = dmc;
         CHECK(launch_vecjobs(l, s));
     }
     // ---- the data path
@@ -379,7 +381,6 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
     CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, hf ? sc.dza.h : (void*)sc.dza.f,
                              sc.dbo_part, drop, SITE_T2V_ATTN, s));
-    CHECK(launch_colsum(sc.dbo_part, nullptr, B, nullptr, d, d, gr->attn_out_b, 0, sc.red_bo, s));          // d b_o
     {   // Time2Vec rows: dX_tau = dz_aug W_aug[:, d_m:]  (the score path rides in the augmented column)
         GemmArgs g = gemm_args(R, dt, Ma, Ma, dmc, dt);
         set_problem2(g, 0, sc.dza, mat_off(w.Wa, d_m), mat(sc.dXt), nullptr);
@@ -396,11 +397,15 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         wg[nwg++] = h;
     }
     CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
-    if (hf) CHECK(launch_f32_to_bf16(sc.dWa.f, sc.dWa.h, (size_t)Ma * dmc, s));
-    // ---- chain rule through the fold (parameters only)
+    // ---- chain rule through the fold (parameters only): vector jobs, two products, vector jobs, 2 H + 2 products, one last launch
     {
         VecJobList l;
         for (int h = 0; h < H; ++h) l.add(VJ_MVT, p->attn_out_w + h * hd, d, sc.dcv + h * d, nullptr, sc.dbvec2 + h * hd, d, hd);
+        l.add(VJ_MVT, sc.dbo_part, d, nullptr, nullptr, gr->attn_out_b, B, d);                   // d b_o = sum over the windows
+        if (hf) {
+            VecJob& c = l.add(VJ_COPY, sc.dWa.f, dmc, nullptr, nullptr, nullptr, Ma, dmc);      // bf16 image of dW_aug for the two products
+            c.yh = sc.dWa.h; c.ldy = dmc;
+        }
         CHECK(launch_vecjobs(l, s));
     }
     CHECK(fold_gemm(GEMM_NT, prec, Ma, d, dmc, sc.dWa, dmc, Abuf, ldab, sc.dOVa, d, nullptr, s));          // rows H d ..: dG_h
@@ -426,26 +431,27 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         CHECK(fold_gemm(GEMM_NT, prec, d, d, d_m, sc.dA, dmc, W.in, d_m, mat(gr->kv_w), dcat, nullptr, s));
         CHECK(fold_gemm(GEMM_TN, prec, d, d_m, d, W.kv, dcat, sc.dA, dmc, mat(gr->input_proj_w), d_m, nullptr, s));
     }
-    {
+    {   // the rank-1 terms on top of the products, the remaining bias gradients, the learned query's backward (dq = scale dqs:
+        // dW_q = dq Q^T, db_q = dq, dQ += W_q^T dq)
         VecJobList l;
         if (inp) l.add(VJ_MVT, p->kv_w, dcat, sc.dbvec1, nullptr, gr->input_proj_b, d, d);
         VecJob& bk = l.add(VJ_COPY, sc.dbvec1, d, nullptr, nullptr, gr->kv_b, 1, d);
         bk.ldy = d;
-        CHECK(launch_vecjobs(l, s));
-    }
-    CHECK(launch_query_bwd(sc.dqs, 1, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
-    {
-        Rank1JobList l;
+        l.rank1(gr->attn_in_w, d, d, d, 0, sc.dqs, p->Q_param).scale = scale;
+        VecJob& bq = l.add(VJ_COPY, sc.dqs, d, nullptr, nullptr, gr->attn_in_b, 1, d);
+        bq.ldy = d; bq.scale = scale;
+        VecJob& dq = l.add(VJ_MVT, p->attn_in_w, d, sc.dqs, nullptr, gr->Q_param, d, d);
+        dq.scale = scale; dq.acc = 1;
         for (int h = 0; h < H; ++h) {
-            l.add(gr->attn_out_w + h * hd, d, d, hd, 1, sc.dcv + h * d, w.bvec2 + h * hd);
-            l.add(gr->attn_in_w + (size_t)(d + h * hd) * d, d, hd, d, 0, w.qs + h * hd, sc.dOVa.f + (size_t)(Hd + h) * d);
+            l.rank1(gr->attn_out_w + h * hd, d, d, hd, 1, sc.dcv + h * d, w.bvec2 + h * hd);
+            l.rank1(gr->attn_in_w + (size_t)(d + h * hd) * d, d, hd, d, 0, w.qs + h * hd, sc.dOVa.f + (size_t)(Hd + h) * d);
         }
-        l.add(gr->attn_in_w + (size_t)2 * d * d, d, d, d, 1, sc.dbvec2, bvec1);
+        l.rank1(gr->attn_in_w + (size_t)2 * d * d, d, d, d, 1, sc.dbvec2, bvec1);
         if (inp) {
-            l.add(gr->kv_w, dcat, d, d, 1, sc.dbvec1, p->input_proj_b);
-            l.add(gr->kv_w + d, dcat, d, dt, 2, nullptr, nullptr, sc.dA.f + d_m, dmc);
+            l.rank1(gr->kv_w, dcat, d, d, 1, sc.dbvec1, p->input_proj_b);
+            l.rank1(gr->kv_w + d, dcat, d, dt, 2, nullptr, nullptr, sc.dA.f + d_m, dmc);
         }
-        CHECK(launch_rank1jobs(l, s));
+        CHECK(launch_vecjobs(l, s));
     }
     return IMMTSF_OK;
 }

@@ -944,12 +944,14 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
 struct GatherJob { const float* src; int ld_src; const int* rowmap; const int* total; int width; float* dst; int ld_dst; bf16_t* dst_h; int vec; };
 struct T2VJob { const float* tau_pad; const int* rowmap; const int* total; int d_tau; const float *w0, *b0, *w, *b; float* dst; int ld_dst, max_rows; bf16_t* dst_h; };
 struct MatvecJob { const float* W; int ldw; const float *x, *b; int rows, cols; float *y, *ys; float scale; };
-__global__ __launch_bounds__(256) void notes_stage_kernel(GatherJob a, int na, T2VJob t, int nb, MatvecJob m) {
+__global__ __launch_bounds__(256) void notes_stage_kernel(GatherJob a, int na, T2VJob t, int nb, MatvecJob m, int nc, MatvecJob m2) {
     int bid = blockIdx.x;
     if (bid < na) { gather_rows_body(bid, a.src, a.ld_src, a.rowmap, a.total, a.width, a.dst, a.ld_dst, a.dst_h, a.vec); return; }
     bid -= na;
     if (bid < nb) { time2vec_fwd_body(bid, t.tau_pad, t.rowmap, t.total, t.d_tau, t.w0, t.b0, t.w, t.b, t.dst, t.ld_dst, t.max_rows, t.dst_h); return; }
-    matvec_body(bid - nb, m.W, m.ldw, m.x, m.b, m.rows, m.cols, m.y, m.ys, m.scale, nullptr);
+    bid -= nb;
+    if (bid < nc) { matvec_body(bid, m.W, m.ldw, m.x, m.b, m.rows, m.cols, m.y, m.ys, m.scale, nullptr); return; }
+    matvec_body(bid - nc, m2.W, m2.ldw, m2.x, m2.b, m2.rows, m2.cols, m2.y, m2.ys, m2.scale, nullptr);       // (a second, optional mat-vec)
 }
 
 // y[j] = sum_i W[i,j] x[i]: 64 columns x 16 row lanes per workgroup, rows strided (coalesced over j)
@@ -1114,15 +1116,17 @@ int launch_time2vec_fwd(const float* tau_pad, const int* rowmap, const int* tota
 int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int* total, int max_rows, int width, void* dst_h, int ld_dst,
                        const float* tau_pad, const int* rowmap, int d_tau, const float* w0, const float* b0, const float* w, const float* b,
                        float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
-                       float* y, float* ys, float scale, hipStream_t s) {
+                       float* y, float* ys, float scale, hipStream_t s, const float* W2, int ldw2, const float* x2, const float* bias2, int rows2,
+                       int cols2, float* y2) {
     if (max_rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_h);
     const int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
     const GatherJob a{src, ld_src, gmap, total, width, nullptr, ld_dst, static_cast<bf16_t*>(dst_h), vec};
     const T2VJob t{tau_pad, rowmap, total, d_tau, w0, b0, w, b, t_dst, t_ld, max_rows, static_cast<bf16_t*>(t_dst_h)};
     const MatvecJob m{W, ldw, x, bias, rows, cols, y, ys, scale};
-    const int na = max_rows, nb = (int)(((long)max_rows * d_tau + 255) / 256), nc = cdiv(rows, 4);
-    hipLaunchKernelGGL(notes_stage_kernel, dim3(na + nb + nc), dim3(256), 0, s, a, na, t, nb, m);
+    const MatvecJob m2{W2, ldw2, x2, bias2, W2 ? rows2 : 0, cols2, y2, nullptr, 1.f};
+    const int na = max_rows, nb = (int)(((long)max_rows * d_tau + 255) / 256), nc = cdiv(rows, 4), nd = W2 ? cdiv(rows2, 4) : 0;
+    hipLaunchKernelGGL(notes_stage_kernel, dim3(na + nb + nc + nd), dim3(256), 0, s, a, na, t, nb, m, nc, m2);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -58,46 +58,40 @@ __global__ __launch_bounds__(256) void vecjobs_kernel(VecJobsK L) {
         float a = 0.f;
         if (j < J.cols) {
 #pragma unroll 8
-            for (int i = wave; i < J.rows; i += 4) a = fmaf(J.W[(size_t)i * J.ld + j], J.x[i], a);
+            for (int i = wave; i < J.rows; i += 4) a = fmaf(J.W[(size_t)i * J.ld + j], J.x ? J.x[i] : 1.f, a);
         }
         red[wave][lane] = a;
         __syncthreads();
         if (wave == 0 && j < J.cols) {
             const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-            vj_store(J, j, J.scale * (t + (J.b ? J.b[j] : 0.f)));
+            vj_store(J, j, (J.acc ? J.y[j] : 0.f) + J.scale * (t + (J.b ? J.b[j] : 0.f)));
         }
         return;
     }
-    // VJ_COPY
-    const long n = (long)J.rows * J.cols, nwg = L.wg0[ji + 1] - L.wg0[ji];
-    for (long x = (long)bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
-        const int i = (int)(x / J.cols), j = (int)(x - (long)i * J.cols);
-        vj_store(J, (size_t)i * J.ldy + j, J.W ? J.scale * J.W[(size_t)i * J.ld + j] : 0.f);
+    const long nwg = L.wg0[ji + 1] - L.wg0[ji];
+    if (J.type == VJ_COPY) {
+        const long n = (long)J.rows * J.cols;
+        for (long x = (long)bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+            const int i = (int)(x / J.cols), j = (int)(x - (long)i * J.cols);
+            vj_store(J, (size_t)i * J.ldy + j, J.W ? J.scale * J.W[(size_t)i * J.ld + j] : 0.f);
+        }
+        return;
     }
-}
-
-// ------------------------------------------------------------------------------------------------ multi-job rank-1 kernel
-struct Rank1K { Rank1Job j[R1_MAX]; int wg0[R1_MAX + 1]; int n; };
-__global__ __launch_bounds__(256) void rank1jobs_kernel(Rank1K L) {
-    int ji = 0;
-#pragma unroll 1
-    while (ji + 1 < L.n && (int)blockIdx.x >= L.wg0[ji + 1]) ++ji;
-    const Rank1Job& J = L.j[ji];
-    const long nwg = L.wg0[ji + 1] - L.wg0[ji], bid = blockIdx.x - L.wg0[ji];
+    // VJ_RANK1: y[i ldy + j] = base + scale x[i] b[j]
     const int c4 = J.cols >> 2;
-    const bool vec = (J.cols & 3) == 0 && (J.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(J.out) & 15) == 0 &&
+    const bool vec = (J.cols & 3) == 0 && (J.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(J.y) & 15) == 0 &&
                      (!J.b || (reinterpret_cast<uintptr_t>(J.b) & 15) == 0) &&
-                     (J.mode != 2 || ((J.lds & 3) == 0 && (reinterpret_cast<uintptr_t>(J.src) & 15) == 0));
+                     (J.acc != 2 || ((J.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(J.W) & 15) == 0));
     if (vec) {
         const long n = (long)J.rows * c4;
-        for (long x = bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+        for (long x = (long)bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
             const int i = (int)(x / c4), j = (int)(x - (long)i * c4) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4* o = reinterpret_cast<float4*>(J.out + (size_t)i * J.ld + j);
-            if (J.mode == 1) v = *o;
-            else if (J.mode == 2) v = *reinterpret_cast<const float4*>(J.src + (size_t)i * J.lds + j);
-            if (J.a) {
-                const float ai = J.a[i];
+            float4* o = reinterpret_cast<float4*>(J.y + (size_t)i * J.ldy + j);
+            if (J.acc == 1) v = *o;
+            else if (J.acc == 2) v = *reinterpret_cast<const float4*>(J.W + (size_t)i * J.ld + j);
+            if (J.x) {
+                const float ai = J.scale * J.x[i];
                 const float4 bv = *reinterpret_cast<const float4*>(J.b + j);
                 v.x = fmaf(ai, bv.x, v.x); v.y = fmaf(ai, bv.y, v.y); v.z = fmaf(ai, bv.z, v.z); v.w = fmaf(ai, bv.w, v.w);
             }
@@ -106,11 +100,11 @@ __global__ __launch_bounds__(256) void rank1jobs_kernel(Rank1K L) {
         return;
     }
     const long n = (long)J.rows * J.cols;
-    for (long x = bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
+    for (long x = (long)bid * 256 + threadIdx.x; x < n; x += nwg * 256) {
         const int i = (int)(x / J.cols), j = (int)(x - (long)i * J.cols);
-        float v = J.mode == 1 ? J.out[(size_t)i * J.ld + j] : J.mode == 2 ? J.src[(size_t)i * J.lds + j] : 0.f;
-        if (J.a) v = fmaf(J.a[i], J.b[j], v);
-        J.out[(size_t)i * J.ld + j] = v;
+        float v = J.acc == 1 ? J.y[(size_t)i * J.ldy + j] : J.acc == 2 ? J.W[(size_t)i * J.ld + j] : 0.f;
+        if (J.x) v = fmaf(J.scale * J.x[i], J.b[j], v);
+        J.y[(size_t)i * J.ldy + j] = v;
     }
 }
 
@@ -343,34 +337,18 @@ int launch_vecjobs(const VecJobList& l, hipStream_t s) {
         K.wg0[i] = wg;
         if (J.type == VJ_MV) wg += cdiv(J.rows, 4);
         else if (J.type == VJ_MVT) wg += cdiv(J.cols, 64);
-        else {
+        else if (J.type == VJ_COPY) {
             const long n = (long)J.rows * J.cols;
             wg += (int)((n + 2047) / 2048 > 128 ? 128 : (n + 2047) / 2048);
+        } else {
+            if (!J.y || (J.acc == 2 && !J.W) || (J.x && !J.b)) return IMMTSF_EINVAL;
+            const long n = (long)J.rows * J.cols;
+            wg += (int)((n + 4095) / 4096 > 192 ? 192 : (n + 4095) / 4096);
         }
     }
     for (int i = l.n; i <= VJ_MAX; ++i) K.wg0[i] = wg;
     K.n = l.n;
     hipLaunchKernelGGL(vecjobs_kernel, dim3(wg), dim3(256), 0, s, K);
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-
-int launch_rank1jobs(const Rank1JobList& l, hipStream_t s) {
-    if (l.n <= 0) return IMMTSF_OK;
-    if (l.n > R1_MAX) return IMMTSF_EINVAL;
-    Rank1K K;
-    int wg = 0;
-    for (int i = 0; i < l.n; ++i) {
-        const Rank1Job& J = l.j[i];
-        if (J.rows <= 0 || J.cols <= 0 || !J.out || (J.mode == 2 && !J.src) || (J.a && !J.b)) return IMMTSF_EINVAL;
-        K.j[i] = J;
-        K.wg0[i] = wg;
-        const long n = (long)J.rows * J.cols;
-        wg += (int)((n + 4095) / 4096 > 192 ? 192 : (n + 4095) / 4096);
-    }
-    for (int i = l.n; i <= R1_MAX; ++i) K.wg0[i] = wg;
-    K.n = l.n;
-    hipLaunchKernelGGL(rank1jobs_kernel, dim3(wg), dim3(256), 0, s, K);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

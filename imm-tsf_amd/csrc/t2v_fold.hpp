@@ -3,11 +3,12 @@
 #include "common.hpp"
 
 // ---- several independent small vector jobs as ONE launch (the parameter-only chains of the fold and of its chain rule) ----------
-enum { VJ_MV = 0, VJ_MVT = 1, VJ_COPY = 2 };
+enum { VJ_MV = 0, VJ_MVT = 1, VJ_COPY = 2, VJ_RANK1 = 3 };
 struct VecJob {
     int type;            // VJ_MV:   y[i] = scale * (sum_j W[i ld + j] x_i[j] + (b ? b[i] : 0)),  x_i = x + (i / xdiv) xld      i < rows, j < cols
-                         // VJ_MVT:  y[j] = scale * (sum_i W[i ld + j] x[i]   + (b ? b[j] : 0))                                   i < rows, j < cols
+                         // VJ_MVT:  y[j] = [y[j] +] scale * (sum_i W[i ld + j] (x ? x[i] : 1) + (b ? b[j] : 0))   (acc: added to y)    i < rows, j < cols
                          // VJ_COPY: y[i ldy + j] = scale * W[i ld + j] (W == null: 0)                                            i < rows, j < cols
+                         // VJ_RANK1: y[i ldy + j] = base + scale * x[i] b[j]; base = acc 0: 0, 1: y[i ldy + j], 2: W[i ld + j]   (x == null: base only)
     const float* W;
     int ld;
     const float* x;
@@ -17,8 +18,9 @@ struct VecJob {
     int rows, cols, ldy;
     int xdiv, xld;       // VJ_MV only (xdiv <= 0: one x for every row)
     float scale;
+    int acc;             // VJ_MVT: 1 = add to y; VJ_RANK1: the base (0 / 1 / 2)
 };
-constexpr int VJ_MAX = 10;
+constexpr int VJ_MAX = 20;
 struct VecJobList {
     VecJob j[VJ_MAX];
     int n;
@@ -26,26 +28,17 @@ struct VecJobList {
     VecJob& add(int type, const float* W, int ld, const float* x, const float* b, float* y, int rows, int cols) {
         VecJob& v = j[n++];
         v.type = type; v.W = W; v.ld = ld; v.x = x; v.b = b; v.y = y; v.yh = nullptr; v.rows = rows; v.cols = cols; v.ldy = cols;
-        v.xdiv = 0; v.xld = 0; v.scale = 1.f;
+        v.xdiv = 0; v.xld = 0; v.scale = 1.f; v.acc = 0;
+        return v;
+    }
+    // y[i ldy + j] = base + scale a[i] b[j]   (base 0: 0, 1: y, 2: src)
+    VecJob& rank1(float* y, int ldy, int rows, int cols, int base, const float* a, const float* b, const float* src = nullptr, int lds = 0) {
+        VecJob& v = add(VJ_RANK1, src, lds, a, b, y, rows, cols);
+        v.ldy = ldy; v.acc = base;
         return v;
     }
 };
 int launch_vecjobs(const VecJobList& l, hipStream_t s);
-
-// ---- several rank-1 / copy jobs on matrices as ONE launch:  out[i ld + j] = base + (a ? a[i] b[j] : 0),
-// base = mode 0: 0, mode 1: out[i ld + j] (accumulate), mode 2: src[i lds + j]
-struct Rank1Job { float* out; int ld; const float* src; int lds; const float *a, *b; int rows, cols, mode; };
-constexpr int R1_MAX = 12;
-struct Rank1JobList {
-    Rank1Job j[R1_MAX];
-    int n;
-    Rank1JobList() : n(0) {}
-    void add(float* out, int ld, int rows, int cols, int mode, const float* a, const float* b, const float* src = nullptr, int lds = 0) {
-        Rank1Job& r = j[n++];
-        r.out = out; r.ld = ld; r.src = src; r.lds = lds; r.a = a; r.b = b; r.rows = rows; r.cols = cols; r.mode = mode;
-    }
-};
-int launch_rank1jobs(const Rank1JobList& l, hipStream_t s);
 
 // ---- the data path.  X (R, dmc) = [note embedding (d_m) ; Time2Vec (d/2)] per packed note, fp32 or bf16 (xh != 0); z (R, H d) the
 // folded value rows per head; S / P (R, H) scores / softmax weights

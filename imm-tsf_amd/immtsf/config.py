@@ -93,7 +93,9 @@ xattn_rank = True
 # ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
 # launch (MMF_XAttn_Add.forward_loss); False: the Q half and the loss as separate ops
 xattn_fused_loss = True
-# TTF_T2V_XAttn: "auto" = the folded form (csrc/t2v_fold.hip) wherever its limits hold, "chain" = the reference's GEMM chain as written
+# TTF_T2V_XAttn: "auto" = the library chooses by batch size (the folded form, csrc/t2v_fold.hip, from IMMTSF_T2V_FOLD_MIN_ROWS padded note
+# rows on -- its parameter-only chains are a fixed cost), "fold" = the folded form wherever its limits hold, "chain" = the reference's
+# GEMM chain as written
 t2v_form = "auto"
 # immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
 head_done_flag = None

@@ -168,7 +168,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         d_m = notes.shape[-1]
         d = params[0].numel()
         cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed, notes.device)
-        cfg.form = 1 if config.t2v_form == "chain" else 0        # (the backward reads the same cfg: one form per call pair)
+        cfg.form = {"auto": 0, "chain": 1, "fold": 2}[config.t2v_form]        # (the backward reads the same cfg: one form per call pair)
         ws = _bytes(lib.immtsf_ttf_t2v_xattn_workspace_bytes(C.byref(cfg)), notes.device)
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)

@@ -36,6 +36,7 @@ extern "C" {
 #endif
 
 #define IMMTSF_ABI_VERSION 3
+#define IMMTSF_T2V_FOLD_MIN_ROWS 8192 /* see immtsf_fusion_cfg.form */
 
 #define IMMTSF_OK 0
 #define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
@@ -63,10 +64,12 @@ typedef struct immtsf_fusion_cfg {
     int32_t grads_prezeroed;       /* backward only: every gradient buffer passed in `grads` is already zero (e.g. one
                                       memset of a flat gradient buffer per step), so split-K weight-gradient GEMMs skip
                                       their own zero-fill */
-    int32_t form;                  /* TTF_T2V_XAttn: 0 = the library chooses (the FOLDED form -- csrc/t2v_fold.hip -- wherever its limits
-                                      hold: N <= 64 padded notes, T <= 32, d <= 1024, H <= 4), 1 = the reference's GEMM chain as written
-                                      (the cross-check).  Same function, same parameters, same dropout masks either way; forward and
-                                      backward of one call pair must be given the same value.  (ABI 3; occupies former padding) */
+    int32_t form;                  /* TTF_T2V_XAttn: 0 = the library chooses by batch size (the FOLDED form -- csrc/t2v_fold.hip -- from
+                                      IMMTSF_T2V_FOLD_MIN_ROWS padded note rows B*N on, where its limits hold: N <= 64 padded notes,
+                                      T <= 32, d <= 1024, H <= 4; below that the fixed cost of its parameter-only chains outweighs the
+                                      rows it saves), 1 = the reference's GEMM chain as written, 2 = the folded form wherever its limits
+                                      hold.  Same function, same parameters, same dropout masks either way; forward and backward of one
+                                      call pair must be given the same value.  (ABI 3; occupies former padding) */
     /* bf16 mode, optional (NULL = off): bf16 images of the activations that cross a block boundary, so that the consumer's
      * GEMMs read them by LDS-DMA without a cast kernel of their own.  out_h: the call also writes its main activation
      * output there (ttf forward: E_txt (B*T*d); mmf q backward: dKV (B*T*2d); mmf kv backward: dE_txt).  in_h: image of

@@ -69,10 +69,20 @@ def _split_name(path):
     return ttf, mmf, case
 
 
+@pytest.fixture(params=["fold", "chain"])
+def t2v_form(request):
+    """run the test with TTF_T2V_XAttn forced into its folded form (wherever that form's limits hold; csrc/t2v_fold.hip) and as the
+    reference's GEMM chain: the library's own choice ("auto") is one of the two, by batch size"""
+    from immtsf import config
+    old, config.t2v_form = config.t2v_form, request.param
+    yield request.param
+    config.t2v_form = old
+
+
 # ------------------------------------------------------------------------------------------ golden vectors
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "fusion_*.npz"))),
                          ids=lambda p: os.path.basename(p)[7:-4])
-def test_fusion_model_vs_reference_golden(path):
+def test_fusion_model_vs_reference_golden(path, t2v_form):
     dev = _dev()
     _setup_toys()
     from fusions.FusionModel import FusionModel
@@ -199,7 +209,7 @@ PAIRS = [("TTF_T2V_XAttn", "MMF_XAttn_Add"), ("TTF_T2V_XAttn", "MMF_GR_Add"), ("
 
 
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
-def test_pairs_fp32_small_odd_shapes(ttf, mmf):
+def test_pairs_fp32_small_odd_shapes(ttf, mmf, t2v_form):
     # dims that are not multiples of any tile: exercises every edge path of the GEMM and the row kernels
     errs, gerrs = _run_pair(ttf, mmf, B=5, N=7, T=9, C=5, d_m=52, d_txt=36, H=3, precision="fp32", scatter=True)
     _check(errs, 1e-4)
@@ -228,7 +238,7 @@ def test_pairs_bf16_shapes_outside_the_bf16_dataflow(ttf, mmf, d_m, d_txt):
 
 
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
-def test_pairs_fp32_benchmark_shape(ttf, mmf):
+def test_pairs_fp32_benchmark_shape(ttf, mmf, t2v_form):
     # BASELINE config 2 shape: B=64, N<=32, T=32, C=8, d_m=d=768, H=1
     errs, gerrs = _run_pair(ttf, mmf, B=64, N=32, T=32, C=8, d_m=768, d_txt=768, H=1, precision="fp32")
     _check(errs, 1e-4)
@@ -236,7 +246,7 @@ def test_pairs_fp32_benchmark_shape(ttf, mmf):
 
 
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
-def test_pairs_bf16_benchmark_shape(ttf, mmf):
+def test_pairs_bf16_benchmark_shape(ttf, mmf, t2v_form):
     errs, gerrs = _run_pair(ttf, mmf, B=64, N=32, T=32, C=8, d_m=768, d_txt=768, H=1, precision="bf16", err=_l2err)
     _check(errs, 3e-2)
     # scalar / near-cancelling gradients (time2vec.linear, log_recency_sigma) get a wider band in bf16: they are sums of
@@ -248,7 +258,7 @@ def test_pairs_bf16_benchmark_shape(ttf, mmf):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_many_windows_paths_vs_oracle(precision):
+def test_many_windows_paths_vs_oracle(precision, t2v_form):
     """320 windows (B*T = 10 240 rows, ~5 k packed note rows, d_m 256 -> d 768): the many-row paths against the oracle -- the
     three-launch index builder (B > 256), the 16-byte column sums (M >= 4096) and, in bf16 mode, the persistent GEMM of
     csrc/gemm3.hip for the projections over B*T rows (240 row tiles of 128 x 256) and its split-K form with the in-kernel bias
@@ -262,7 +272,7 @@ def test_many_windows_paths_vs_oracle(precision):
     _check(small, 2.5e-1)
 
 
-def test_llama_dims_multihead_fp32():
+def test_llama_dims_multihead_fp32(t2v_form):
     # config 3/5 flavour: d_m=4096 -> d=768, H=4, fewer windows so the CPU oracle stays quick
     errs, gerrs = _run_pair("TTF_T2V_XAttn", "MMF_XAttn_Add", B=6, N=40, T=16, C=6, d_m=4096, d_txt=768, H=4,
                             precision="fp32")
@@ -337,7 +347,7 @@ def _dropout_parity(ttf, mmf, precision="fp32", B=6, N=9, T=7, C=4, d_m=40, d=32
 
 
 @pytest.mark.parametrize("ttf,mmf", PAIRS)
-def test_dropout_with_exported_masks(ttf, mmf):
+def test_dropout_with_exported_masks(ttf, mmf, t2v_form):
     _dropout_parity(ttf, mmf)
 
 
@@ -402,7 +412,7 @@ def test_nan_and_shape_errors():
         m(notes, tau, t_hat, Y)      # CPU tensors: no silent fallback
 
 
-def test_padding_invariance_and_window_independence():
+def test_padding_invariance_and_window_independence(t2v_form):
     """size-independent properties at the full benchmark shape: (1) extra zero padding of the note axis changes
     nothing (the ragged pack ignores it); (2) a window's output does not depend on the other windows."""
     dev = _dev()
@@ -873,11 +883,14 @@ def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, pac
         rows = torch.arange(B * N, device=dev, dtype=torch.int32).view(B, N)[keep.to(dev)].contiguous()
         src = PackedNotes(notes.reshape(B * N, d_m).contiguous(), rows, lengths.to(dev).to(torch.int32), N)
     cfg = make_cfg(B, N, T, 0, d_m, dd, H, 1 if precision == "bf16" else 0, True, pd, 0.0, 0, None)
+    cfg.form = 2
     assert _lib.load().immtsf_ttf_t2v_xattn_folded(C.byref(cfg)) == 1          # these shapes are inside the folded form's limits
+    cfg.form = 1
+    assert _lib.load().immtsf_ttf_t2v_xattn_folded(C.byref(cfg)) == 0
     res, seed0 = [], config.next_seed
     try:
         config.next_seed = lambda: 9191
-        for form in ("auto", "chain"):
+        for form in ("fold", "chain"):
             config.t2v_form = form
             ttf.zero_grad()
             E, M = ttf(src, tau, t_hat)

@@ -115,29 +115,34 @@ __global__ __launch_bounds__(256) void ragged_count_kernel(const unsigned char* 
     }
     if (lane == 0) { lengths[b] = cnt; mtxt[b] = cnt > 0 ? 1 : 0; if (mtxt2) mtxt2[b] = cnt > 0 ? 1 : 0; }
 }
+// exclusive scan of the B window lengths by ONE workgroup: a thread sums its `per` consecutive windows, the 64 lanes of a wave
+// scan those sums by shuffles, the 16 waves meet in LDS -- one barrier (the first version walked 1024 windows per pass through a
+// 10-step LDS scan with two barriers per step: 190 us at 4096 windows)
 __global__ __launch_bounds__(1024) void ragged_scan_kernel(const int* __restrict__ lengths, int B, int* __restrict__ offsets) {
-    __shared__ int sh[1024];
-    __shared__ int carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < B; base += 1024) {
-        const int b = base + tid;
-        const int len = (b < B) ? lengths[b] : 0;
-        sh[tid] = len;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const int v = (tid >= off) ? sh[tid - off] : 0;
-            __syncthreads();
-            sh[tid] += v;
-            __syncthreads();
-        }
-        if (b < B) offsets[b] = carry + sh[tid] - len;
-        __syncthreads();
-        if (tid == 1023) carry += sh[1023];
-        __syncthreads();
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (B + 1023) / 1024, b0 = tid * per;
+    int loc = 0;
+    for (int k = 0; k < per; ++k)
+        if (b0 + k < B) loc += lengths[b0 + k];
+    int v = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
     }
-    if (tid == 0) offsets[B] = carry;
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w_ = 0; w_ < 16; ++w_) {
+        if (w_ < wave) base += wsum[w_];
+        tot += wsum[w_];
+    }
+    int run = base + v - loc;
+    for (int k = 0; k < per; ++k)
+        if (b0 + k < B) { offsets[b0 + k] = run; run += lengths[b0 + k]; }
+    if (tid == 0) offsets[B] = tot;
 }
 __global__ __launch_bounds__(256) void ragged_fill_kernel(const unsigned char* __restrict__ mask, int B, int N, const int* __restrict__ offsets,
                                                           int* __restrict__ rowmap, int* __restrict__ seg) {
@@ -944,9 +949,46 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
 struct GatherJob { const float* src; int ld_src; const int* rowmap; const int* total; int width; float* dst; int ld_dst; bf16_t* dst_h; int vec; };
 struct T2VJob { const float* tau_pad; const int* rowmap; const int* total; int d_tau; const float *w0, *b0, *w, *b; float* dst; int ld_dst, max_rows; bf16_t* dst_h; };
 struct MatvecJob { const float* W; int ldw; const float *x, *b; int rows, cols; float *y, *ys; float scale; };
+// a packed row per WAVE (vec == 2: 16-byte-aligned rows, bf16 destination): the row's gather + cast with up to four 16-byte loads per
+// lane in flight, and its Time2Vec columns from one load of the time stamp.  (A workgroup per row and a thread per Time2Vec element
+// were 131 072 + 196 608 workgroups at 4096 windows, half of them empty: 290 us for 330 MB.)
+__device__ __forceinline__ void notes_row_wave_body(int r, const GatherJob& a, const T2VJob& t) {
+    if (r >= *a.total) return;
+    const int lane = threadIdx.x & 63;
+    const float4* s4 = reinterpret_cast<const float4*>(a.src + (size_t)a.rowmap[r] * a.ld_src);
+    bf16x4* d4 = reinterpret_cast<bf16x4*>(a.dst_h + (size_t)r * a.ld_dst);
+    const float tv = t.tau_pad[t.rowmap ? t.rowmap[r] : r];
+    const int n4 = a.width >> 2;
+    for (int i0 = lane; i0 < n4; i0 += 256) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            v[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n4) {
+                bf16x4 h;
+                h[0] = (bf16_t)v[u].x; h[1] = (bf16_t)v[u].y; h[2] = (bf16_t)v[u].z; h[3] = (bf16_t)v[u].w;
+                d4[i] = h;
+            }
+        }
+    }
+    for (int j = lane; j < t.d_tau; j += 64) {
+        const float v = (j == 0) ? fmaf(t.w0[0], tv, t.b0[0]) : sinf(fmaf(t.w[j - 1], tv, t.b[j - 1]));
+        if (t.dst) t.dst[(size_t)r * t.ld_dst + j] = v;
+        if (t.dst_h) t.dst_h[(size_t)r * t.ld_dst + j] = (bf16_t)v;
+    }
+}
 __global__ __launch_bounds__(256) void notes_stage_kernel(GatherJob a, int na, T2VJob t, int nb, MatvecJob m, int nc, MatvecJob m2) {
     int bid = blockIdx.x;
-    if (bid < na) { gather_rows_body(bid, a.src, a.ld_src, a.rowmap, a.total, a.width, a.dst, a.ld_dst, a.dst_h, a.vec); return; }
+    if (bid < na) {
+        if (a.vec == 2) notes_row_wave_body(bid * 4 + (threadIdx.x >> 6), a, t);
+        else gather_rows_body(bid, a.src, a.ld_src, a.rowmap, a.total, a.width, a.dst, a.ld_dst, a.dst_h, a.vec);
+        return;
+    }
     bid -= na;
     if (bid < nb) { time2vec_fwd_body(bid, t.tau_pad, t.rowmap, t.total, t.d_tau, t.w0, t.b0, t.w, t.b, t.dst, t.ld_dst, t.max_rows, t.dst_h); return; }
     bid -= nb;
@@ -1120,12 +1162,14 @@ int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int*
                        int cols2, float* y2) {
     if (max_rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_h);
-    const int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
+    int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
+    if (vec && dst_h && gmap && total) vec = 2;          // a packed row per wave, gather + Time2Vec together
     const GatherJob a{src, ld_src, gmap, total, width, nullptr, ld_dst, static_cast<bf16_t*>(dst_h), vec};
     const T2VJob t{tau_pad, rowmap, total, d_tau, w0, b0, w, b, t_dst, t_ld, max_rows, static_cast<bf16_t*>(t_dst_h)};
     const MatvecJob m{W, ldw, x, bias, rows, cols, y, ys, scale};
     const MatvecJob m2{W2, ldw2, x2, bias2, W2 ? rows2 : 0, cols2, y2, nullptr, 1.f};
-    const int na = max_rows, nb = (int)(((long)max_rows * d_tau + 255) / 256), nc = cdiv(rows, 4), nd = W2 ? cdiv(rows2, 4) : 0;
+    const int na = vec == 2 ? cdiv(max_rows, 4) : max_rows, nb = vec == 2 ? 0 : (int)(((long)max_rows * d_tau + 255) / 256);
+    const int nc = cdiv(rows, 4), nd = W2 ? cdiv(rows2, 4) : 0;
     hipLaunchKernelGGL(notes_stage_kernel, dim3(na + nb + nc + nd), dim3(256), 0, s, a, na, t, nb, m, nc, m2);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

@@ -459,10 +459,25 @@ def graph_kernel_us(fn, reps=50, replays=10):
     return e0.elapsed_time(e1) / (reps * replays) * 1e3
 
 
+def csrc_sha():
+    """content hash of the kernel sources (imm-tsf_amd/csrc/*.hip, *.hpp, include/immtsf.h): a PMC profile under profiles/ counts as a
+    measurement of THIS build only when it carries the same hash (tools/pmc_summary.py stamps it on the GPU box; there is no .git there)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "imm-tsf_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "imm-tsf_amd", "csrc", "*.hpp")))
+    for f in files + [os.path.join(ROOT, "include", "immtsf.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def gemm_roofline(w, lib, args, k2=20):
-    """dominant kernel = the MFMA GEMM instance with the largest total time in the step.  HIP events bracket every GEMM
-    launch on its launch stream over a block of eagerly launched steps (the library's timing tap) to find it; exactly
-    that GEMM (same kernel path, same operand types) is then re-timed as 50 back-to-back launches inside one hipGraph."""
+    """dominant kernel = the MFMA GEMM LAUNCH with the largest in-graph time per step.  HIP events bracket every GEMM launch on its
+    launch stream over a block of eagerly launched steps (the library's timing tap; a grouped weight-gradient launch is ONE record with
+    the sum of its members' flops and bytes) to find the candidates; each candidate -- the same kernel path, operand types and, for a
+    grouped launch, member list -- is then re-timed as back-to-back launches inside one hipGraph (kernel time without launch latency:
+    what rocprofv3 reports as the kernel's duration) and the candidates are ranked by that time x launches per step."""
     from immtsf import _lib
     dev = w.dev
     lib.immtsf_timing_enable(1)
@@ -474,45 +489,71 @@ def gemm_roofline(w, lib, args, k2=20):
     cap = 16384
     meta = (ctypes.c_int32 * (10 * cap))()
     ms = (ctypes.c_float * cap)()
-    n = lib.immtsf_timing_collect(cap, meta, ms)
+    mem = (ctypes.c_int32 * (24 * cap))()
+    n = lib.immtsf_timing_collect(cap, meta, ms, mem)
     lib.immtsf_timing_enable(0)
     groups = {}
     for i in range(n):
-        groups.setdefault(tuple(meta[10 * i:10 * i + 10]), []).append(ms[i])
+        groups.setdefault((tuple(meta[10 * i:10 * i + 10]), tuple(mem[24 * i:24 * i + 24])), []).append(ms[i])
     rows = []
-    for key, v in groups.items():
+    for (key, members), v in groups.items():
         layout, prec, Mm, Nn, Kk, nprob, nbatch, dyn, grid_threads, path = key
-        if dyn == 1:
-            Mm = w.sum_n
-        elif dyn == 2:
-            Kk = w.sum_n
-        fl = 2.0 * Mm * Nn * Kk * nprob * nbatch
-        rows.append(dict(key=key, M=Mm, N=Nn, K=Kk, launches=len(v), avg_us=1e3 * float(np.mean(v)), total_ms=float(np.sum(v)), flops=fl))
+        if layout == 3:         # grouped TN launch: members (M, N, K, K-is-a-device-value)
+            mem_l = [(members[4 * j], members[4 * j + 1], w.sum_n if members[4 * j + 3] else members[4 * j + 2]) for j in range(nprob)]
+            fl = sum(2.0 * a * b_ * c for a, b_, c in mem_l)
+            byts = sum(2 * c * a + 2 * c * b_ + 4 * a * b_ for a, b_, c in mem_l)
+        else:
+            if dyn == 1:
+                Mm = w.sum_n
+            elif dyn == 2:
+                Kk = w.sum_n
+            mem_l = None
+            fl = 2.0 * Mm * Nn * Kk * nprob * max(nbatch, 1)
+            byts = None
+        rows.append(dict(key=key, members=mem_l, M=Mm, N=Nn, K=Kk, launches=len(v), avg_us=1e3 * float(np.mean(v)), total_ms=float(np.sum(v)),
+                         flops=fl, bytes=byts))
     rows.sort(key=lambda r: -r["total_ms"])
     if os.environ.get("IMMTSF_BENCH_GEMM_TABLE"):
         for r in rows:
             k = r["key"]
-            print(f"# gemm {['NT','NN','TN'][k[0]]} M={r['M']:6d} N={r['N']:5d} K={r['K']:6d} prob={k[5]} batch={k[6]:4d} dyn={k[7]} "
-                  f"path={'gemm2' if k[9] == 2 else 'gemm'} launches/step={r['launches']/k2:5.1f} avg_us={r['avg_us']:7.1f} "
+            print(f"# gemm {['NT','NN','TN','TNgroup'][k[0]]} M={r['M']:6d} N={r['N']:5d} K={r['K']:6d} prob={k[5]} batch={k[6]:4d} dyn={k[7]} "
+                  f"path={k[9]} launches/step={r['launches']/k2:5.1f} avg_us={r['avg_us']:7.1f} "
                   f"us/step={r['total_ms']*1e3/k2:7.1f} TF={r['flops']/(r['avg_us']*1e-6)/1e12:7.2f}", file=sys.stderr)
     gemm_ms = sum(r["total_ms"] for r in rows) / k2
     bf16 = args.precision == "bf16"
 
     def retime(r):
-        """(launcher closure, algorithmic bytes, operand description, kernel name) of one tap row"""
+        """(launcher closure = ONE launch of the step's kind, algorithmic bytes, operand description, rocprof kernel-name prefix, keep)"""
         lay_i, Mm, Nn, Kk, nprob, nbatch, path = r["key"][0], r["M"], r["N"], r["K"], r["key"][5], max(r["key"][6], 1), r["key"][9]
+        if lay_i == 3:
+            ms_ = r["members"]
+            As = [torch.randn(c, a, device=dev).bfloat16() for a, b_, c in ms_]
+            Bs = [torch.randn(c, b_, device=dev).bfloat16() for a, b_, c in ms_]
+            Cs = [torch.empty(a, b_, device=dev) for a, b_, c in ms_]
+            k_ = len(ms_)
+            pa = (ctypes.c_void_p * k_)(*[t.data_ptr() for t in As])
+            pb = (ctypes.c_void_p * k_)(*[t.data_ptr() for t in Bs])
+            pc = (ctypes.c_void_p * k_)(*[t.data_ptr() for t in Cs])
+            i32 = lambda xs: (ctypes.c_int32 * k_)(*xs)      # noqa: E731
+            la, lb, lc = i32([a for a, b_, c in ms_]), i32([b_ for a, b_, c in ms_]), i32([b_ for a, b_, c in ms_])
+            mm, nn, kk = i32([a for a, b_, c in ms_]), i32([b_ for a, b_, c in ms_]), i32([c for a, b_, c in ms_])
+
+            def one():
+                _lib.check(lib.immtsf_gemm_bf16_group_tn(k_, pa, la, pb, lb, pc, lc, mm, nn, kk, _lib.stream_ptr()), "gemm_bf16_group_tn")
+            return (one, r["bytes"], f"{k_} weight gradients of different shapes in one launch; A, B bf16 in HBM (LDS-DMA), C fp32",
+                    "gemm2_group_kernel<", (As, Bs, Cs, pa, pb, pc, la, lb, lc, mm, nn, kk))
         shapes = {0: ((Mm, Kk), (Nn, Kk)), 1: ((Mm, Kk), (Kk, Nn)), 2: ((Kk, Mm), (Kk, Nn))}[lay_i]
         Ab, Bb = torch.randn(*shapes[0], device=dev), torch.randn(*shapes[1], device=dev)
         Cb = torch.empty(Mm, Nn, device=dev)
-        reps = nprob * nbatch          # the batched / grouped problems of one launch are re-timed as that many plain launches
-        if path == 2:       # bf16 operands in memory (LDS-DMA kernel): both operand images are bf16, the result fp32
+        reps = nprob * nbatch          # the batched / multi-problem forms of one launch are re-timed as that many plain launches
+        if path == 2:       # bf16 operands in memory (LDS-DMA kernels: gemm2, or gemm3 for many rows): both operand images are bf16
             Ah, Bh = Ab.bfloat16(), Bb.bfloat16()
 
             def one():
-                for _ in range(min(reps, 8)):
+                for _ in range(reps):
                     _lib.check(lib.immtsf_gemm_bf16(lay_i, _lib.ptr(Ah), Ah.shape[1], _lib.ptr(Bh), Bh.shape[1], _lib.ptr(Cb), Nn, None, Nn,
                                                     None, None, Mm, Nn, Kk, 1.0, 0, 0, None, 0, None, _lib.stream_ptr()), "gemm_bf16")
-            return one, min(reps, 8), 2 * Mm * Kk + 2 * Nn * Kk + 4 * Mm * Nn, "A, B bf16 in HBM (LDS-DMA), C fp32", "gemm2_kernel", None
+            return one, reps * (2 * Mm * Kk + 2 * Nn * Kk + 4 * Mm * Nn), "A, B bf16 in HBM (LDS-DMA), C fp32", "gemm", (Ah, Bh, Cb)
         twin = None
         # in the step the weight operand of a forward / data-gradient GEMM is read from FlatTrainer's bf16 twin: same here
         if bf16 and lay_i != 2 and nbatch == 1 and w.trainer.flat_twin is not None:
@@ -520,68 +561,74 @@ def gemm_roofline(w, lib, args, k2=20):
             _lib.check(lib.immtsf_bf16_twin_register(_lib.ptr(Bb), _lib.ptr(twin), Bb.numel()), "bf16_twin_register")
 
         def one():
-            for _ in range(min(reps, 8)):
+            for _ in range(reps):
                 _lib.check(lib.immtsf_gemm(lay_i, 1 if bf16 else 0, _lib.ptr(Ab), Ab.shape[1], _lib.ptr(Bb), Bb.shape[1], _lib.ptr(Cb),
                                            Nn, None, Mm, Nn, Kk, 1.0, 0, 0, _lib.stream_ptr()), "gemm")
-        return (one, min(reps, 8), 4 * Mm * Kk + (2 if twin is not None else 4) * Nn * Kk + 4 * Mm * Nn,
-                "A fp32, B " + ("bf16 twin of the weights" if twin is not None else "fp32") + ", C fp32", "gemm_kernel", (Bb, twin))
+        return (one, reps * (4 * Mm * Kk + (2 if twin is not None else 4) * Nn * Kk + 4 * Mm * Nn),
+                "A fp32, B " + ("bf16 twin of the weights" if twin is not None else "fp32") + ", C fp32", "gemm_kernel<", (Ab, Bb, Cb, twin))
 
-    # the eager tap's durations include launch latency, which ranks tiny batched launches far too high: the candidates (the
-    # six largest tap totals among the instances carrying >= 3 % of the step's GEMM flops) are re-timed inside a hipGraph and
-    # ranked by kernel time x launches per step
+    # the eager tap's durations include launch latency, which ranks tiny batched launches far too high: the candidates (the six
+    # largest tap totals among the launches carrying >= 3 % of the step's GEMM flops) are re-timed inside a hipGraph and ranked by
+    # kernel time x launches per step
     best = None
     step_flops = sum(r["flops"] * r["launches"] for r in rows)
-    cands = [r for r in rows if r["flops"] * r["launches"] >= 0.03 * step_flops][:6]      # launch-latency-only rows are not "the GEMM"
+    cands = [r for r in rows if r["flops"] * r["launches"] >= 0.03 * step_flops][:6]
     for r in cands:
-        one, n_in, alg_bytes, operands, kname, tw = retime(r)
-        us = graph_kernel_us(one, reps=20, replays=5) / n_in
-        if tw is not None and tw[1] is not None:
-            lib.immtsf_bf16_twin_unregister(_lib.ptr(tw[0]))
-        per_launch = us * r["key"][5] * max(r["key"][6], 1)
-        tot = per_launch * r["launches"] / k2
+        one, alg_bytes, operands, kname, keep = retime(r)
+        us = graph_kernel_us(one, reps=20, replays=5)
+        if kname == "gemm_kernel<" and keep[3] is not None:
+            lib.immtsf_bf16_twin_unregister(_lib.ptr(keep[1]))
+        tot = us * r["launches"] / k2
         if best is None or tot > best[0]:
             best = (tot, r, us, alg_bytes, operands, kname)
+        del keep
     _, top, kernel_us, alg_bytes, operands, kname = best
-    lay_i, Mm, Nn, Kk, nprob, path = top["key"][0], top["M"], top["N"], top["K"], top["key"][5], top["key"][9]
+    lay_i, Mm, Nn, Kk, nprob, path, grid_threads = top["key"][0], top["M"], top["N"], top["K"], top["key"][5], top["key"][9], top["key"][8]
     peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
-    ach = (top["flops"] / nprob / max(top["key"][6], 1)) / (kernel_us * 1e-6) / 1e12
+    ach = top["flops"] / (kernel_us * 1e-6) / 1e12
+    ach_tap = top["flops"] / (top["avg_us"] * 1e-6) / 1e12
     allfl = sum(r["flops"] * r["launches"] for r in rows) / sum(r["total_ms"] for r in rows) / 1e9
-    lay = {0: "NT", 1: "NN", 2: "TN"}[lay_i]
-    # HBM traffic of that kernel instance from the committed rocprofv3 PMC passes (tools/pmc_summary.py; counters cannot be
-    # read from inside the process): matched by kernel name + layout + launch grid
-    traffic, tsrc = None, None
-    for fn in ("r03b_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    lay = {0: "NT", 1: "NN", 2: "TN", 3: "TN group"}[lay_i]
+    # HBM-side traffic of that launch from a committed rocprofv3 PMC pass (counters cannot be read from inside the process) -- only
+    # from a profile of THIS build: its csrc hash must equal the one of the sources this run was built from
+    sha = csrc_sha()
+    traffic, prov, why = None, None, "no PMC profile under profiles/ for this build"
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
-        except Exception:
+            pmc = json.load(open(fn))
+        except Exception:      # noqa: BLE001
             continue
-        tag = {0: "<false, false", 1: "<false, true", 2: "<true, true"}[lay_i] if path == 2 else \
-              {0: "<true, false, false", 1: "<true, false, true", 2: "<true, true, true"}[lay_i]
+        if pmc.get("csrc_sha") != sha or pmc.get("windows_per_gpu", 64) != w.B:
+            continue
+        tag = {0: "<false, false", 1: "<false, true", 2: "<true, true", 3: ""}[lay_i]
         for kr in pmc["kernels"]:
-            if kname + tag in kr["kernel"] and kr["grid_threads"] == top["key"][8]:
-                traffic, tsrc = kr["fetch_bytes_per_launch"] + (kr["write_bytes_per_launch"] or 0), fn
+            nm = kr["kernel"]
+            hit = (kname in nm) if lay_i == 3 else (("gemm2_kernel" + tag in nm or "gemm3_kernel" + tag in nm or "gemm_kernel<true, " + tag[1:] in nm))
+            if hit and kr["grid_threads"] == grid_threads:
+                traffic = kr["fetch_bytes_per_launch"] + (kr["write_bytes_per_launch"] or 0)
+                prov = {"file": "profiles/" + os.path.basename(fn), "commit": pmc.get("commit"), "csrc_sha": sha, "kernel": nm[:160],
+                        "fetch_bytes_per_launch": kr["fetch_bytes_per_launch"], "write_bytes_per_launch": kr["write_bytes_per_launch"],
+                        "launches_profiled": kr["launches"]}
                 break
         if traffic is not None:
             break
-    ach_tap = (top["flops"] / nprob / max(top["key"][6], 1)) / (top["avg_us"] / (nprob * max(top["key"][6], 1)) * 1e-6) / 1e12
-    prov = None
-    if tsrc:
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", tsrc)))
-            prov = {"file": "profiles/" + tsrc, "commit": pj.get("commit"), "ms_per_step_when_profiled": pj.get("ms_per_step")}
-        except Exception:
-            prov = {"file": "profiles/" + tsrc}
+        why = f"{os.path.basename(fn)} is a profile of this build but holds no record of this launch (grid {grid_threads} threads)"
+    if top["members"]:
+        desc = (f"gemm2_group_kernel: {len(top['members'])} TN weight gradients in one launch, (M x N x K) = " +
+                ", ".join(f"{a}x{b_}x{c}" for a, b_, c in top["members"]))
+    else:
+        desc = f"{'gemm2/gemm3 (bf16 operands in HBM)' if path == 2 else 'gemm_kernel'} {lay} M={Mm} N={Nn} K={Kk} x{nprob * max(top['key'][6], 1)} problems per launch"
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
             "batch": f"{w.B} windows per GPU", "achieved_in_step_tap": round(ach_tap, 2), "frac_in_step_tap": round(ach_tap / peak, 5),
             "traffic": traffic, "traffic_provenance": prov,
-            "traffic_unit": f"bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/{tsrc}: a committed profile of this kernel "
-                            "instance, not a measurement of this run)" if tsrc else
-            "bytes/launch: no PMC record for this kernel instance under profiles/",
-            "algorithmic_bytes": alg_bytes, "operands": operands,
-            "kernel": f"{kname} {lay} M={Mm} N={Nn} K={Kk} (x{top['key'][5] * top['key'][6]} problems per launch in the step; per-problem figures here)",
+            "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of this build: a committed profile of "
+                            "this launch, not a measurement of this run)" if traffic is not None else f"null: {why} (csrc hash {sha})",
+            "algorithmic_bytes": alg_bytes, "operands": operands, "flops_per_launch": top["flops"],
+            "kernel": desc, "kernel_name_prefix": kname if lay_i == 3 else None, "grid_threads": grid_threads,
             "avg_launch_us": round(kernel_us, 2), "avg_launch_us_eager_tap": round(top["avg_us"], 2),
-            "launches_per_step": top["launches"] // k2, "all_gemm_ms_per_step": round(gemm_ms, 4), "all_gemm_tflops": round(allfl, 2),
-            "gemm_launches_per_step": sum(r["launches"] for r in rows) // k2,
+            "launches_per_step": round(top["launches"] / k2, 2), "all_gemm_ms_per_step": round(gemm_ms, 4), "all_gemm_tflops": round(allfl, 2),
+            "gemm_launches_per_step": round(sum(r["launches"] for r in rows) / k2, 1),
             "gather_gemm": next(({"M": r["M"], "N": r["N"], "K": r["K"], "avg_us_eager_tap": round(r["avg_us"], 2)} for r in rows
                                  if r["key"][7] == 1 and r["K"] == CONFIGS[w.cfg]["d_m"] and r["key"][0] == 0), None)}
 

@@ -715,7 +715,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
 // ---- optional per-launch timing tap (bench.py's roofline leg): hipEvents bracket every GEMM launch on the
 // stream it is launched on.  Off by default; while it is on, launches take g_tap_mu one at a time.
 namespace {
-struct TapRec { hipEvent_t e0, e1; int meta[10]; };
+struct TapRec { hipEvent_t e0, e1; int meta[10]; int members[24]; };      // members: (M, N, K, dyn) of up to 6 products of a grouped launch
 constexpr int kTapCap = 16384;
 TapRec* g_tap = nullptr;
 int g_tap_n = 0, g_tap_events = 0;
@@ -818,12 +818,41 @@ int immtsf_launch_gemm_tn_list(int precision, GemmArgs* list, int n, hipStream_t
     if (n <= 0) return IMMTSF_OK;
     // one grouped launch when every product has bf16 operands in memory and fits the grouped kernel (and no timing tap is
     // recording per-launch times)
-    if (precision == 1 && n >= 2 && !g_force_old && !g_tap_on.load(std::memory_order_relaxed)) {
+    if (precision == 1 && n >= 2 && !g_force_old) {
         bool have = true;
         for (int i = 0; i < n && have; ++i) have = list[i].nprob == 1 && list[i].nbatch <= 1 && list[i].p[0].Ah && list[i].p[0].Bh;
-        if (have) {
+        if (have && !g_tap_on.load(std::memory_order_relaxed)) {
             const int rc = immtsf_launch_gemm2_group_tn(list, n, stream);
             if (rc != IMMTSF_EUNSUPPORTED) return rc;
+        } else if (have) {
+            // the timing tap records the grouped launch as ONE record (layout code 3, path 3, nprob = members; their shapes in the
+            // record's member table), so that bench.py ranks and re-times the launch that runs in the step
+            std::lock_guard<std::mutex> lk(g_tap_mu);
+            if (g_tap && g_tap_n < kTapCap && n <= 6) {
+                TapRec& r = g_tap[g_tap_n];
+                bool ev = true;
+                if (g_tap_n >= g_tap_events) {
+                    ev = hipEventCreate(&r.e0) == hipSuccess && hipEventCreate(&r.e1) == hipSuccess;
+                    if (ev) g_tap_events = g_tap_n + 1;
+                }
+                if (ev) {
+                    (void)hipEventRecord(r.e0, stream);
+                    const int rc = immtsf_launch_gemm2_group_tn(list, n, stream);
+                    if (rc != IMMTSF_EUNSUPPORTED) {
+                        (void)hipEventRecord(r.e1, stream);
+                        const int m[10] = {3, precision, list[0].M, list[0].N, list[0].K, n, 1, 0, (int)g_last_grid_threads, 3};
+                        for (int i = 0; i < 10; ++i) r.meta[i] = m[i];
+                        for (int i = 0; i < 6; ++i) {
+                            r.members[4 * i] = i < n ? list[i].M : 0;
+                            r.members[4 * i + 1] = i < n ? list[i].N : 0;
+                            r.members[4 * i + 2] = i < n ? list[i].K : 0;
+                            r.members[4 * i + 3] = i < n && list[i].dyn ? 1 : 0;
+                        }
+                        ++g_tap_n;
+                        return rc;
+                    }
+                }
+            }
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -841,8 +870,8 @@ extern "C" int immtsf_timing_enable(int on) {
     return 0;
 }
 
-// host arrays: meta[10*max] (layout, precision, M, N, K, nprob, nbatch, dyn, grid threads, 0), ms[max]
-extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
+// host arrays: meta[10*max] (layout, precision, M, N, K, nprob, nbatch, dyn, grid threads, path), ms[max], members[24*max] (optional)
+extern "C" int immtsf_timing_collect(int max, int* meta, float* ms, int* members) {
     std::lock_guard<std::mutex> lk(g_tap_mu);
     const int n = g_tap_n < max ? g_tap_n : max;
     for (int i = 0; i < n; ++i) {
@@ -851,6 +880,8 @@ extern "C" int immtsf_timing_collect(int max, int* meta, float* ms) {
         (void)hipEventElapsedTime(&t, g_tap[i].e0, g_tap[i].e1);
         ms[i] = t;
         for (int k = 0; k < 10; ++k) meta[10 * i + k] = g_tap[i].meta[k];
+        if (members)
+            for (int k = 0; k < 24; ++k) members[24 * i + k] = g_tap[i].meta[0] == 3 ? g_tap[i].members[k] : 0;
     }
     g_tap_n = 0;
     return n;

@@ -675,6 +675,29 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
     return IMMTSF_OK;
 }
 
+// n (2 .. 6) weight-gradient products of different shapes as one launch (bench.py re-times the step's grouped launch through this)
+extern "C" int immtsf_gemm_bf16_group_tn(int32_t n, const void* const* A, const int32_t* lda, const void* const* B, const int32_t* ldb,
+                                         float* const* C, const int32_t* ldc, const int32_t* M, const int32_t* N, const int32_t* K,
+                                         void* stream) {
+    if (n < 2 || n > G2_GROUP_MAX || !A || !B || !C || !lda || !ldb || !ldc || !M || !N || !K) return IMMTSF_EINVAL;
+    GemmArgs list[G2_GROUP_MAX];
+    for (int i = 0; i < n; ++i) {
+        GemmArgs& g = list[i];
+        memset(&g, 0, sizeof(g));
+        g.nprob = 1;
+        g.M = M[i]; g.N = N[i]; g.K = K[i];
+        g.lda = lda[i]; g.ldb = ldb[i]; g.ldc = ldc[i];
+        g.alpha = 1.f;
+        g.row_flag_div = 1;
+        g.nbatch = 1;
+        g.batch_inner = 1;
+        g.p[0].Ah = A[i];
+        g.p[0].Bh = B[i];
+        g.p[0].C = C[i];
+    }
+    return immtsf_launch_gemm2_group_tn(list, n, static_cast<hipStream_t>(stream));
+}
+
 // debug / test / tool entry (declared in include/immtsf.h)
 extern "C" int immtsf_gemm_bf16(int32_t layout, const void* A, int32_t lda, const void* B, int32_t ldb, float* C, int32_t ldc,
                                 void* Ch, int32_t ldch, const float* bias, float* bias_grad, int32_t M, int32_t N, int32_t K,

@@ -247,7 +247,9 @@ _PROTOS = {
     "immtsf_flag_trace_read": (C.c_int, [C.c_void_p, C.c_int32]),
     "immtsf_timing_enable": (C.c_int, [C.c_int32]),
     "immtsf_debug_gemm_config": (C.c_int, [C.c_int32, C.c_int32]),
-    "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p]),
+    "immtsf_timing_collect": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "immtsf_gemm_bf16_group_tn": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, c_stream]),
     "immtsf_embed_forward": (C.c_int, [C.c_int32, c_f32p] + [C.c_int32] * 7 + [c_f32p, c_f32p, c_f32p, C.c_float, C.c_uint64, C.c_uint64,
                                        C.c_void_p, c_stream]),
     "immtsf_embed_backward": (C.c_int, [C.c_int32, c_f32p] + [C.c_int32] * 7 + [c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_float,

@@ -686,7 +686,9 @@ int immtsf_flag_trace_read(int64_t* out, int32_t max_entries);
 int immtsf_side_stream_enabled(void);
 /* tuning aid for tools/gemm_bench.py: force a GEMM tile variant (1..6) and/or split-K factor; 0 = heuristic */
 int immtsf_debug_gemm_config(int32_t variant, int32_t splitk);
-int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host);
+/* members_host (optional, int32[24 * max]): for a GROUPED weight-gradient launch -- recorded as one record with layout code 3, kernel
+ * path 3 and nprob = the number of member products -- the members' (M, N, K, K-is-a-device-value) quadruples, zero otherwise. */
+int immtsf_timing_collect(int32_t max, int32_t* meta_host, float* ms_host, int32_t* members_host);
 
 /* ---- a12 / a13: the time-aware patch embedding and the data embedding as one gather + skinny product + positional
  * table + dropout kernel per direction (csrc/embed.hip), exact fp32.
@@ -716,6 +718,12 @@ int immtsf_gemm_bf16(int32_t layout, const void* A, int32_t lda, const void* B, 
                      int32_t ldch, const float* bias, float* bias_grad, int32_t M, int32_t N, int32_t K, float alpha,
                      int32_t accumulate, int32_t act, const int32_t* dyn, int32_t dyn_which, const int32_t* a_rowmap,
                      immtsf_stream_t stream);
+/* n (2 .. 6) TN products C_i (M_i, N_i) = A_i (K_i, M_i)^T B_i (K_i, N_i) of different shapes as ONE launch of gemm2's grouped kernel --
+ * what a block's backward does with its weight gradients (csrc/gemm2.hip immtsf_launch_gemm2_group_tn).  Measurement entry: bench.py
+ * re-times the step's grouped launch through it.  IMMTSF_EUNSUPPORTED: a member the grouped kernel does not take. */
+int immtsf_gemm_bf16_group_tn(int32_t n, const void* const* A, const int32_t* lda, const void* const* B, const int32_t* ldb,
+                              float* const* C, const int32_t* ldc, const int32_t* M, const int32_t* N, const int32_t* K,
+                              immtsf_stream_t stream);
 /* tuning aid for tools/gemm2_bench.py: force a tile variant, a split-K factor, the XCD tile order (-1 = heuristic) */
 int immtsf_debug_gemm2_config(int32_t variant, int32_t splitk, int32_t xcd);
 

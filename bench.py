@@ -257,6 +257,61 @@ def cpu_baseline(batch, warmup=3, steps=10, budget_s=45.0):
                       f"oracle/tpatchgnn_ref.py, fp32, dropout {P_DROP}"}
 
 
+def cpu_baseline_fusion(cfg, warmup=2, steps=6, budget_s=30.0):
+    """cfg3 / cfg4 / cfg5: the fusion blocks' CPU restatement (oracle/fusion_ref.py, op-for-op incl. the T-expanded K/V; kind "port")
+    timed on this box's host cores on the configuration's own synthetic batch, the backbone's forecast replaced by a fixed random
+    Y_ts -- no CPU restatement of PatchTST / TimesNet / TimeLLM travels to the GPU box, so the region is
+    fusion forward + masked MSE + backward + clip + Adam on the fusion parameters.  cfg5 is timed at B = 2 and scaled linearly (the
+    expanded K/V of 64 windows of up to 4096 notes does not fit), as BASELINE.md section 3 prescribes."""
+    from oracle import fusion_ref as R
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    register_d_model("SYN4096", 4096)
+    c = CONFIGS[cfg]
+    Bs = 2 if cfg == "cfg5" else B_PER_GPU
+    ncpu = os.cpu_count() or 1
+    nt = min(ncpu, 32)
+    torch.set_num_threads(nt)
+    torch.manual_seed(0)
+    a = model_args("cpu", cfg, Bs)
+    fus = FusionModel(a)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in fus.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    batch, _ = synth_batch(100, Bs, cfg)
+    T, Cc, NM = c["T"], c["C"], c["N_MAX"]
+    Y = torch.randn(Bs, T, Cc)
+    keep = 1.0 - P_DROP
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        drop = {"ttf": {"attn": torch.bernoulli(torch.full((Bs, T, H, NM), keep)), "out": torch.bernoulli(torch.full((Bs, T, D_TXT), keep))},
+                "mmf": {"attn": torch.bernoulli(torch.full((Bs, H, T, T), keep)), "out": torch.bernoulli(torch.full((Bs, T, Cc), keep))}}
+        out = R.fusion_forward(c["ttf"], c["mmf"], params, batch["notes_embeddings"], batch["tau"], batch["tp_to_predict"], Y, H=H,
+                               kappa=KAPPA, drop=drop, p_drop=P_DROP, expand_T=True)
+        loss = R.masked_mse(batch["data_to_predict"], out, batch["mask_predicted_data"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+
+    t0 = time.perf_counter()
+    for _ in range(warmup):
+        step()
+    per = (time.perf_counter() - t0) / warmup
+    n = steps if per * steps <= budget_s else max(2, int(budget_s / per))
+    ts = []
+    for _ in range(n):
+        t1 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t1)
+    med = float(np.median(ts))
+    return {"value": round(Bs / med, 3), "unit": "windows/s", "cores": nt, "kind": "port", "all_cores": ncpu, "cpu_model": cpu_model_name(),
+            "sample": f"{n} timed steps after {warmup} warm-up steps of the {cfg} synthetic batch at B = {Bs}"
+                      f"{' (scaled linearly in B: BASELINE.md section 3)' if cfg == 'cfg5' else ''}, median {med*1e3:.0f} ms/step on {nt} "
+                      f"torch threads; region: fusion forward ({c['ttf']} + {c['mmf']}, oracle/fusion_ref.py with the T-expanded K/V) + "
+                      f"masked MSE + backward + clip + Adam -- the backbone is NOT in this figure (no CPU restatement of "
+                      f"{c['backbone']} travels to the GPU box)"}
+
+
 # ================================================================================================ workload on the GPU
 class Workload:
     """one BASELINE configuration on one device: models, trainer, batch, the loss closure of a step"""
@@ -599,7 +654,7 @@ def gemm_roofline(w, lib, args, k2=20):
             pmc = json.load(open(fn))
         except Exception:      # noqa: BLE001
             continue
-        if pmc.get("csrc_sha") != sha or pmc.get("windows_per_gpu", 64) != w.B:
+        if pmc.get("csrc_sha") != sha or pmc.get("windows_per_gpu", 64) != w.B or pmc.get("config", "cfg2") != w.cfg:
             continue
         tag = {0: "<false, false", 1: "<false, true", 2: "<true, true", 3: ""}[lay_i]
         for kr in pmc["kernels"]:
@@ -778,8 +833,6 @@ def main():
     ap.add_argument("--packed-notes", action="store_true",
                     help="hand the notes over in the packed form of the device collate (resident embedding matrix + row index + per-window "
                          "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
-    ap.add_argument("--no-wgrad-fork", action="store_true",
-                    help="A/B measurements only: weight-gradient GEMMs on the caller's stream instead of the library's side stream")
     ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold"],
                     help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
                          "reference's GEMM chain (immtsf.config.t2v_form)")
@@ -830,10 +883,6 @@ def main():
         lib.immtsf_debug_gemm_config(args.gemm_config, 0)
     if args.gemm2_variant:
         lib.immtsf_debug_gemm2_config(args.gemm2_variant, 0, -1)
-    if args.no_wgrad_fork:
-        lib.immtsf_set_side_stream(0)
-    elif os.environ.get("IMMTSF_WGRAD_FORK") == "1":      # A/B: weight-gradient GEMMs on the library's side stream (off by default)
-        lib.immtsf_set_side_stream(1)
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
     config.t2v_form = args.t2v_form
     config.manual_seed(1234 + rank)
@@ -988,6 +1037,8 @@ def main():
     if not args.no_cpu_baseline and rank == 0 and world == 1 and args.config == "cfg2":
         cpu_b, _ = synth_batch(100, B_PER_GPU)
         cpu = cpu_baseline(cpu_b)
+    elif not args.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline_fusion(args.config)
 
     if rank == 0:
         fl_win = fusion_flops_per_window(w.sum_n, W, args.config)

@@ -1391,7 +1391,7 @@ static int ragged_attn_fwd_impl(RaggedAttnDims dm, const int* offsets, const int
         return IMMTSF_OK;
     }
     {   // the fusion's own regime: short windows, one round of loads (ragged_attn_fwd_short_kernel); IMMTSF_RAGGED_SHORT=0: off
-        static const bool on = !(getenv("IMMTSF_RAGGED_SHORT") && atoi(getenv("IMMTSF_RAGGED_SHORT")) == 0);
+        constexpr bool on = true;
         constexpr int W = KVec<KT>::W;
         if (on && dm.N <= 64 && dm.T <= TT && (dm.hd % W) == 0 && dm.hd / W <= 64 * RS_PCS && (reinterpret_cast<uintptr_t>(KVp) & 15) == 0 &&
             (reinterpret_cast<uintptr_t>(qs) & 15) == 0) {

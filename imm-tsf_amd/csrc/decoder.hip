@@ -691,7 +691,7 @@ int immtsf_tpatchgnn_decoder_forward(int32_t B, int32_t N, int32_t Lp, int32_t D
 }
 
 static bool dec_mfma_ok(const immtsf_decoder_params* p) {
-    static const bool on = !(getenv("IMMTSF_DEC_MFMA") && atoi(getenv("IMMTSF_DEC_MFMA")) == 0);
+    constexpr bool on = true;
     return on && (reinterpret_cast<uintptr_t>(p->W2) & 15) == 0;
 }
 

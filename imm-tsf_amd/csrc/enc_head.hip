@@ -311,7 +311,7 @@ inline int eh_grid(const EhDims& d) {
 }  // namespace
 
 bool enc_head32_ok(int Bs, int S, int D, int H) {
-    static const bool on = !(getenv("IMMTSF_ENC_HEAD") && atoi(getenv("IMMTSF_ENC_HEAD")) == 0);
+    constexpr bool on = true;
     return on && D == EH_D && S >= 1 && S <= EH_S && H >= 1 && H <= 4 && (EH_D % H) == 0 && Bs >= 1;
 }
 size_t enc_head32_slab_floats(int Bs, int S, int H) { return (size_t)eh_grid(eh_dims(Bs, S, H, 0.f)) * EH_NG; }

@@ -427,11 +427,11 @@ inline int rows_block(int R) {      // rows per row block of the weight-gradient
 }  // namespace
 
 static int ffn32_split_max() {        // row tiles up to which the rows kernels split the hidden dimension (IMMTSF_FFN32_SPLIT_MAX: A/B runs)
-    static const int v = getenv("IMMTSF_FFN32_SPLIT_MAX") ? atoi(getenv("IMMTSF_FFN32_SPLIT_MAX")) : 256;
+    constexpr int v = 256;
     return v;
 }
 bool ffn32_ok(int R, int D, int F, int act, int prec) {
-    static const bool on = !(getenv("IMMTSF_FFN32") && atoi(getenv("IMMTSF_FFN32")) == 0);
+    constexpr bool on = true;
     return on && D == FD && act == 1 && prec == 1 && R >= 256 && F >= 256 && (F % 256) == 0;
 }
 size_t ffn32_saved_bytes(int R, int F) { return (size_t)4 * F * FD * 2 + (size_t)(F / 32) * ((R + 15) / 16) * 64; }
@@ -456,7 +456,7 @@ int ffn32_forward(int R, int F, const DropCfg& dd, uint64_t site, const float* x
     // few rows: split the hidden dimension -- over EIGHT waves in the forward, whose chunk is ~450 instructions of Philox, ballots and
     // mask packing issued back to back by a lone wave per SIMD (17.8 us for 1024 rows on four waves); the backward stays on four (an
     // eight-wave backward produced wrong data gradients: DESIGN 6)
-    static const bool fwd8 = !(getenv("IMMTSF_FFN32_FWD8") && atoi(getenv("IMMTSF_FFN32_FWD8")) == 0);
+    constexpr bool fwd8 = true;
     if (a.nrt <= ffn32_split_max() && fwd8 && ((a.F >> 5) % 8) == 0)
         hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true, 8>), dim3(a.nrt), dim3(512), 0, s, a);
     else if (a.nrt <= ffn32_split_max()) hipLaunchKernelGGL((ffn32_rows_kernel<1, false, true>), dim3(a.nrt), dim3(256), 0, s, a);

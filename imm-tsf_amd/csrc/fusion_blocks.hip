@@ -511,7 +511,7 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     const int* gather = src_rows ? src_rows : w.rowmap;
     // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
     // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
-    static const int notes_image = getenv("IMMTSF_T2V_NOTES_IMAGE") ? atoi(getenv("IMMTSF_T2V_NOTES_IMAGE")) : 1;
+    constexpr int notes_image = 1;
     bool staged = false;       // Time2Vec and the query projection already done by the notes-stage launch
     if (p->input_proj_w && hf && notes_image) {
         // bf16 mode: ONE gather + cast pass writes the packed bf16 image of the notes; the projection (here) and its weight
@@ -679,7 +679,7 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         prezeroed(h, cfg);
         CHECK(wgrad(h));
     }
-    static const int notes_image_b = getenv("IMMTSF_T2V_NOTES_IMAGE") ? atoi(getenv("IMMTSF_T2V_NOTES_IMAGE")) : 1;
+    constexpr int notes_image_b = 1;
     if (p->input_proj_w && hf && notes_image_b) {   // dW_in = dVp^T V ; db_in = colsum dVp: both operands are bf16 images (dXcat's first d columns, the packed notes)
         GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
         set_problem2(h, 0, mat(nullptr, sc.dXcat_h), mat(nullptr, w.Vh), mat(gr->input_proj_w), nullptr, gr->input_proj_b);

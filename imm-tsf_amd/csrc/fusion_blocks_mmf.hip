@@ -182,7 +182,7 @@ bool bad_x(const immtsf_fusion_cfg* cfg) { return bad_cfg(cfg) || cfg->C <= 0; }
 // bf16 mode, T x T attention over <= 32 prediction steps: the one-launch MFMA kernels of attn.hip instead of batched GEMMs + row softmax
 // (IMMTSF_XATTN_SMALL=0: the GEMM path, for A/B measurements)
 bool xattn_small(const immtsf_fusion_cfg* c) {
-    static const bool on = !(getenv("IMMTSF_XATTN_SMALL") && atoi(getenv("IMMTSF_XATTN_SMALL")) == 0);
+    constexpr bool on = true;
     return on && c->precision == 1 && xattn_small_supported(c->T, c->H, c->d / c->H);
 }
 
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void qfold_kernel(QFoldJob q, int na, int nb) 
     if (lane == 0) { q.tHO[c] = a; q.bHO[c] = a + q.bres[c]; }
 }
 bool qfold_one_launch(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const float* fold) {
-    static const bool on = !(getenv("IMMTSF_QFOLD_ONE") && atoi(getenv("IMMTSF_QFOLD_ONE")) == 0);
+    constexpr bool on = true;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p->attn_out_w) | reinterpret_cast<uintptr_t>(fold);
     return on && c->C <= QF_C && (c->d & 3) == 0 && (a & 15) == 0;
 }
@@ -289,7 +289,7 @@ bool qfold_one_launch(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, c
 // the query projection (forward, backward) and the context gradient (backward) as operands formed inside the tile kernels from
 // their C-column inputs: decided from what the forward and the backward both see, so that they agree on whether Qi exists
 bool xattn_gen(const immtsf_fusion_cfg* c, const immtsf_xadd_params* p, const float* Y_ts, const QFold& f) {
-    static const bool on = !(getenv("IMMTSF_XATTN_GEN") && atoi(getenv("IMMTSF_XATTN_GEN")) == 0);
+    constexpr bool on = true;
     const uintptr_t a = reinterpret_cast<uintptr_t>(Y_ts) | reinterpret_cast<uintptr_t>(f.WQf) | reinterpret_cast<uintptr_t>(f.WHO) |
                         reinterpret_cast<uintptr_t>(p->attn_in_b);
     return on && xattn_small(c) && xattn_small_generates(c->d / c->H, c->C) && (a & 15) == 0;
@@ -456,7 +456,7 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
     }
     // LayerNorm(C)'s two parameter gradients and s_live (column sums of ddelta over the windows with text) in one launch, then
     // d b_out = W_res^T s_live and the first term of dW_res = s_live b_out^T + dW_HO W_out^T in another
-    static const bool head_small = !(getenv("IMMTSF_HEAD_SUMS") && atoi(getenv("IMMTSF_HEAD_SUMS")) == 0);
+    constexpr bool head_small = true;
     const bool hs = head_small && head_sums_supported(BT, C);
     if (hs) {
         CHECK(launch_head_sums(sc.dn, w.xhatC, sc.ddelta, M_txt, T, BT, C, gr->ln_w, gr->ln_b, sc.slive, s));

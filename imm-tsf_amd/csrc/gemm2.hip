@@ -506,7 +506,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
 
     // many rows (forward / data-gradient projections at >= 256 windows per GPU): the persistent ping-pong kernel of gemm3.hip,
     // 1.4-2x this file's tiles from ~190 row tiles of 128 on (profiles/r03_gemm_bigM.txt)
-    static const int use_g3 = getenv("IMMTSF_GEMM3") ? atoi(getenv("IMMTSF_GEMM3")) : 1;
+    constexpr int use_g3 = 1;
     if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && g.act == 0 && !g.relu_ref && !g.accumulate && g.epi_drop.p <= 0.f && !g.p[0].Cpre &&
         !g.a_rowmap && !g.b_rowmap && !g.ones_col && (!g.row_flag || g.row_flag32) && !(g.dyn && g.dyn_which != 0) &&
         (long)cdiv(Mmax, 128) * cdiv(g.N, 256) >= 192) {
@@ -620,7 +620,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
 // the step is bound by the chip time its two branches share, and one launch that fills every CU once beats five that each
 // hold 144 - 216 of them: 0.567 - 0.571 vs 0.581 - 0.589 ms.
 bool immtsf_gemm_group_enabled() {
-    static const bool on = !(getenv("IMMTSF_GEMM_GROUP") && atoi(getenv("IMMTSF_GEMM_GROUP")) == 0);
+    constexpr bool on = true;
     return on;
 }
 // n (2 .. 6) TN products C_i = alpha A_i^T B_i (+ bias gradients) of different shapes as ONE launch of the 64 x 64 K-group
@@ -632,7 +632,7 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
     memset(&gg, 0, sizeof(gg));
     int tiles = 0;
     // IMMTSF_GROUP_TILE=128: 128 x 128 tiles (two K-groups of 2 x 2 waves) -- a quarter of the workgroups, half the operand traffic
-    static const int gt = (getenv("IMMTSF_GROUP_TILE") && atoi(getenv("IMMTSF_GROUP_TILE")) == 128) ? 128 : 64;
+    constexpr int gt = 64;
     for (int i = 0; i < n; ++i) {
         GemmArgs g = list[i];
         if (!immtsf_gemm2_supported(GEMM_TN, g) || g.nprob != 1 || g.act != 0 || g.relu_ref || g.row_flag || g.add_vec || g.accumulate ||
@@ -643,7 +643,7 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
         // a member whose first workgroup is a multiple of 8 keeps "workgroup i runs on XCD i % 8" in its own numbering: the exact 2-D XCD
         // partition of the single launch (each L2 fetches 1/XR of A and 1/XC of B; without it the grouped launch fetched 147 MB for
         // ~30 MB of operands, profiles/r03i_pmc_traffic.json).  IMMTSF_GROUP_XCD=0: off
-        static const bool gx_on = !(getenv("IMMTSF_GROUP_XCD") && atoi(getenv("IMMTSF_GROUP_XCD")) == 0);
+        constexpr bool gx_on = true;
         if (gx_on && (tiles & 7) == 0) {
             const int tiles_m = cdiv(g.M, gt), tiles_n = cdiv(g.N, gt);
             int best = 0;

@@ -253,7 +253,7 @@ int launch_recavg_bwd(int B, int T, int d, const int* offsets, const int* rowmap
                       const float* log_sigma, const float* Vp, const float* Eraw, const float* denom, const float* dEraw,
                       float* dVp, float* dls_part, hipStream_t s, int precision) {
     if (B <= 0) return IMMTSF_OK;
-    static const bool mfma_on = !(getenv("IMMTSF_RECAVG_MFMA") && atoi(getenv("IMMTSF_RECAVG_MFMA")) == 0);
+    constexpr bool mfma_on = true;
     const size_t lm = (size_t)2 * 32 * (d + 8) * 2 + 32 * 40 * 2 + (3 * 32 + 16) * sizeof(float);
     const uintptr_t al = reinterpret_cast<uintptr_t>(Vp) | reinterpret_cast<uintptr_t>(Eraw) | reinterpret_cast<uintptr_t>(dEraw) |
                          reinterpret_cast<uintptr_t>(dVp);

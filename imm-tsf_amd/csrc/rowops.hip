@@ -1297,7 +1297,7 @@ int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma,
                               DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
                               const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s) {
     if (rows <= 0) return IMMTSF_OK;
-    static const bool on = !(getenv("IMMTSF_LN_SUMS") && atoi(getenv("IMMTSF_LN_SUMS")) == 0);
+    constexpr bool on = true;
     const uintptr_t al = reinterpret_cast<uintptr_t>(dz_dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(xhat) |
                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(scratch);
     if (!on || (d & 3) || d > 256 * LN_DV || (al & 15) || (reinterpret_cast<uintptr_t>(dxh) & 7) || rows < 512) return IMMTSF_EUNSUPPORTED;

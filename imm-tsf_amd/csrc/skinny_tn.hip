@@ -127,7 +127,7 @@ inline int st_row_block(int R) {       // ~256 row blocks of whole sub-blocks
 }  // namespace
 
 bool skinny_tn_ok(int M, int N, int R, int ldy, int ldx, const void* dY, const void* X, const void* dW) {
-    static const bool on = !(getenv("IMMTSF_SKINNY_TN") && atoi(getenv("IMMTSF_SKINNY_TN")) == 0);
+    constexpr bool on = true;
     const uintptr_t al = reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X);
     return on && M >= 16 && M <= 192 && N >= 16 && N <= 64 && (M % 16) == 0 && (N % 16) == 0 && R >= 8192 && (ldy % 4) == 0 && (ldx % 4) == 0 &&
            (al & 15) == 0 && dW != nullptr && (M / 16) * (N / 16) + M / 16 <= 4 * ST_MAXT;

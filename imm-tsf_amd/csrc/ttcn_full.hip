@@ -649,7 +649,7 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
 int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float* tt, const float* mask, const immtsf_ttcn_params* p,
                          const float* pack, const float* ctr, const float* out, const float* dout, int out_ld, float* slab,
                          const immtsf_ttcn_params* gr, hipStream_t s, int te_acc) {
-    const FD d{P, L, F, K, F * 32, getenv("TTCN_DBG") ? atoi(getenv("TTCN_DBG")) : 0};
+    const FD d{P, L, F, K, F * 32, 0};
     const PackPtrs q = pack_ptrs(const_cast<float*>(pack), F);
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
@@ -659,7 +659,7 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     // cfg2 step, beside the text-side backward GEMMs on the other stream: one wave / SIMD at 160 / 192 / 224 / 256 workgroups ->
     // 0.891 / 0.882 / 0.874 / 0.887 ms (later 0.850 at 224); two waves / SIMD at 256 / 342 / 384 / 448 / 512 -> 0.856 / 0.847 / 0.839 /
     // 0.841 / 0.852.  Alone (P = 1024): 103 us at 224 x 1 wave, 80 us at 448 x 2 waves.
-    static const int genv = getenv("IMMTSF_TTCN_GRID") ? atoi(getenv("IMMTSF_TTCN_GRID")) : 0;
+    constexpr int genv = 0;
     int gmax = genv > 0 ? genv : (L <= 32 ? (P >= 8192 ? 512 : 384) : 224);     // many patches: exactly two workgroups per CU
     gmax = gmax > kMaxBwdGrid ? kMaxBwdGrid : gmax;
     const int grid = P < gmax ? P : gmax;
@@ -670,11 +670,6 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
         if (lds > 64 * 1024)                                                                                                              \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ttcn_full_bwd_kernel<RT, MF>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)lds);                                                                                          \
-        if (getenv("IMMTSF_TTCN_DEBUG")) {                                                                                                \
-            int nb_ = -1;                                                                                                                 \
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb_, ttcn_full_bwd_kernel<RT, MF>, 256, lds);                              \
-            fprintf(stderr, "ttcn_full_bwd<%d,%d>: grid %d lds %zu resident workgroups / CU %d\n", RT, MF, grid, lds, nb_);                \
-        }                                                                                                                                 \
         hipLaunchKernelGGL((ttcn_full_bwd_kernel<RT, MF>), dim3(grid), dim3(256), lds, s, d, x, tt, mask, te, w, wt, ctr, out, dout, out_ld, \
                            slab);                                                                                                         \
     } while (0)

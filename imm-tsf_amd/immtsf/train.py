@@ -543,8 +543,8 @@ class GraphedStep:
         # no communication between backward and optimizer (one process): clip + Adam ride at the end of graph A -- one graph
         # launch per step instead of two -- and Adam's pass over the gradient leaves it zero for the next replay (the 32 MB
         # zero-fill in front of the forward was 12 us that nothing could overlap: both branches wait for it)
-        self.single = (not trainer.collective) and os.environ.get("IMMTSF_TWO_GRAPHS", "0") != "1"
-        if self.single and not trainer.sharded and os.environ.get("IMMTSF_ZERO_IN_STEP", "1") != "0":
+        self.single = not trainer.collective
+        if self.single and not trainer.sharded:
             trainer.zero_in_step = True
         side = torch.cuda.Stream(device=trainer.flat_param.device)
         side.wait_stream(torch.cuda.current_stream())

@@ -44,12 +44,6 @@ def compute_error(truth, pred_y, mask, func, reduce, norm_dict=None, group=None)
     raise Exception("Reduce argument not specified!")
 
 
-# MMF_XAttn_Add's folded query-half weights depend on parameters only.  Formed in front of the backbone on ITS stream instead of
-# behind the key/value projection on the text stream the cfg2 step got slower (0.793 vs 0.783 ms, 3 runs each): in the forward
-# the backbone is the longer chain.  Off unless asked for.
-_FOLD_ON_SIDE = int(os.environ.get("IMMTSF_FOLD_ON_SIDE", "0") or 0)      # 1: in front of the backbone, 2: behind it
-
-
 def forecast_and_fuse(model, fusion, batch_dict, side_stream=None, loss=None):
     """backbone forecast -> fusion.  The backbone and the text-timestamp fusion (TTF) do not depend on each other
     -- only the modality fusion (MMF) needs both -- so with `side_stream` the backbone is enqueued on that HIP stream
@@ -74,20 +68,9 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None, loss=None):
     # backward instead of behind them (r02 trace: placed last it started 200 us after its input was ready).  Re-measured after
     # the launch cuts of r02 (backbone first / text first): 0.908 / 0.906 ms per step -- no difference any more.
     E_txt, M_txt = fusion.ttf(notes, tau, tp)
-    fold_side = _FOLD_ON_SIDE and hasattr(fusion.mmf, "fold_weights") and not fusion.mmf._rank(E_txt.shape[1])     # (low-rank form: no separate fold)
-    if fold_side:
-        kv = fusion.mmf.project_kv(E_txt, with_fold=False)
-    else:
-        kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
+    kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
     with torch.cuda.stream(side_stream):
-        if fold_side and _FOLD_ON_SIDE == 1:      # parameters only: in front of the backbone on its stream
-            fold = fusion.mmf.fold_weights()
         pred_y = model.forecasting(*fc_args)
-        if fold_side and _FOLD_ON_SIDE != 1:      # ... or behind it
-            fold = fusion.mmf.fold_weights()
-        if fold_side:
-            fold.record_stream(main)
-            kv = (kv[0], fold)
     main.wait_stream(side_stream)
     pred_y.record_stream(main)
     if loss is not None and hasattr(fusion.mmf, "forward_loss"):

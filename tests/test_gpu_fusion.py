@@ -973,17 +973,3 @@ def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precisio
         den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("loss", "dY", "dE") else 1e-9)
         err = float((a - b).norm()) / den
         assert err <= tol, (k, err)
-
-
-def test_separate_weight_gradient_launches_opt_out():
-    """The T2V backward's five TN weight gradients (different shapes) run as ONE grouped launch at the end of the call by default
-    (csrc/gemm2.hip gemm2_group_kernel; every bf16 parity test of this file goes through it); IMMTSF_GEMM_GROUP=0 launches them one by
-    one (read once per process, so a child process): the bf16 benchmark-shape parity tests pass that way too."""
-    import subprocess
-    import sys
-    env = dict(os.environ, IMMTSF_GEMM_GROUP="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "test_pairs_bf16_benchmark_shape or test_pairs_bf16_shapes_outside", "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout

@@ -38,7 +38,7 @@ def main():
     import bench
     json.dump({"commit": os.environ.get("IMMTSF_PMC_COMMIT"),            # tree the passes were taken at (the GPU box has no .git)
                "csrc_sha": bench.csrc_sha(),                             # content hash of the kernel sources: bench.py trusts the profile only for this build
-               "windows_per_gpu": int(os.environ.get("IMMTSF_PMC_WINDOWS", "64")),
+               "windows_per_gpu": int(os.environ.get("IMMTSF_PMC_WINDOWS", "64")), "config": os.environ.get("IMMTSF_PMC_CONFIG", "cfg2"),
                "ms_per_step": float(os.environ["IMMTSF_PMC_MS"]) if os.environ.get("IMMTSF_PMC_MS") else None,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 6 "
                          "--warmup 2 --no-cpu-baseline --no-roofline --no-graph",

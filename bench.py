@@ -317,7 +317,7 @@ class Workload:
     """one BASELINE configuration on one device: models, trainer, batch, the loss closure of a step"""
 
     def __init__(self, cfg, dev, windows, precision, group=None, wire="fp32", device_step=True, seed_off=0, overlap=True,
-                 shard_optimizer=False, param_wire="fp32", packed_notes=False):
+                 shard_optimizer=False, param_wire="fp32", packed_notes=False, fusion_only=False):
         from fusions.FusionModel import FusionModel
         from fusions.load_llm import register_d_model
         from immtsf import config
@@ -332,7 +332,8 @@ class Workload:
         self.model = getattr(importlib.import_module("models." + c["backbone"]), c["backbone"])(a).to(dev).train()
         self.fusion = FusionModel(a).to(dev).train()
         # host syncs inside the backbone (data-dependent shapes / prompt strings) rule out graph capture
-        self.graphable = c["backbone"] in ("tPatchGNN", "PatchTST")
+        self.graphable = c["backbone"] in ("tPatchGNN", "PatchTST") or fusion_only
+        self.fusion_only = bool(fusion_only)
         excl = []      # tPatchGNN's time-embedding parameters: used by the patch encoder AND the decoder, both accumulate
         if c["backbone"] == "tPatchGNN":
             m = self.model
@@ -365,11 +366,21 @@ class Workload:
             self.batch["notes_embeddings"] = PackedNotes(notes.reshape(Bn * Nn, dm).contiguous(), rows, lengths, Nn)
         self.global_cnt = self.batch["mask_predicted_data"].reshape(-1, c["C"]).sum(0)
         self.side = torch.cuda.Stream(device=dev) if overlap else None
+        if self.fusion_only:
+            # --fusion-only: the backbone's forecast is a fixed random tensor (a leaf that takes a gradient), so the step is the
+            # fusion blocks + loss + their backward + the optimizer over the fusion's parameters -- what cfg5's 100 ms of frozen
+            # GPT-2 body otherwise hides
+            g = torch.Generator().manual_seed(4242 + seed_off)
+            self.fixed_pred = torch.randn(windows, c["T"], c["C"], generator=g).to(dev).requires_grad_(True)
 
     def loss_fn(self):
         from immtsf.ops import masked_mse
         from lib.evaluation import forecast_and_fuse
         b = self.batch
+        if self.fusion_only:
+            self.fixed_pred.grad = None
+            out = self.fusion(b["notes_embeddings"], b["tau"], b["tp_to_predict"], self.fixed_pred)
+            return masked_mse(out, b["data_to_predict"], b["mask_predicted_data"], None, self.global_cnt)
         # (where the fusion's last block can run its head, the loss and their backward as one launch -- MMF_XAttn_Add's low-rank
         # form -- forecast_and_fuse returns the loss itself)
         return forecast_and_fuse(self.model, self.fusion, b, self.side, loss=(b["data_to_predict"], b["mask_predicted_data"], self.global_cnt))
@@ -398,7 +409,7 @@ def flag_fns(w):
     """(text_fn, backbone_fn, head_fn) of a cfg2-style workload (text side | backbone | head), or None when it does not decompose"""
     from immtsf.ops import masked_mse
     fusion = w.fusion
-    if w.side is None or not hasattr(fusion, "ttf") or not hasattr(fusion.mmf, "project_kv") or not w.graphable:
+    if w.side is None or not hasattr(fusion, "ttf") or not hasattr(fusion.mmf, "project_kv") or not w.graphable or w.fusion_only:
         return None
     b = w.batch
     fc_args = (b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
@@ -833,6 +844,9 @@ def main():
     ap.add_argument("--packed-notes", action="store_true",
                     help="hand the notes over in the packed form of the device collate (resident embedding matrix + row index + per-window "
                          "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
+    ap.add_argument("--fusion-only", action="store_true",
+                    help="time the fusion blocks + loss + backward + optimizer with the backbone's forecast replaced by a fixed random tensor "
+                         "(cfg5: the 7 ms of fusion without the 97 ms frozen GPT-2 body of TimeLLM)")
     ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold"],
                     help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
                          "reference's GEMM chain (immtsf.config.t2v_form)")
@@ -891,7 +905,8 @@ def main():
     pwire = args.param_wire if args.param_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     sharded = dist_on and args.shard_optimizer and not args.no_shard_optimizer
     w = Workload(args.config, dev, W, args.precision, group=group, wire=wire, device_step=not args.no_graph, seed_off=rank,
-                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=args.packed_notes)
+                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=args.packed_notes,
+                 fusion_only=args.fusion_only)
     trainer, fusion = w.trainer, w.fusion
     use_graph = (not args.no_graph) and w.graphable
     comm_mode = "bucketed on a side stream" if dist_on else "none"
@@ -1049,7 +1064,8 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "launch": launch_mode, "engine": step_info["engine"], "flag_step_rejected": step_info["flag_step_rejected"],
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 4),
-            "config": {"workload": f"{args.config}: " + CONFIGS[args.config]["text"].format(B=W),
+            "config": {"workload": f"{args.config}: " + CONFIGS[args.config]["text"].format(B=W) +
+                                   (" -- FUSION ONLY: the backbone's forecast is a fixed random tensor" if args.fusion_only else ""),
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",
                        "global_batch": W * world, "parallelism": f"dp{world}", "sum_notes_rank0": w.sum_n,
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),

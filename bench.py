@@ -730,16 +730,18 @@ def hbm_roofline(w, lib, roof):
                     f"sum of notes {w.sum_n}; HBM3E spec 8 TB/s, a streaming copy reaches ~6.3 TB/s on this part"}
 
 
-def dropin_ms(dev, precision, steps=20, warmup=5):
-    """what an unmodified main.py gets through the drop-in seam: lib.evaluation.compute_all_losses + torch.optim.Adam +
-    clip_grad_norm_, eager launches, the reference's NaN guards on (IMMTSF_NAN_CHECK=sync) -- no FlatTrainer, no graphs"""
+def dropin_ms(dev, precision, steps=20, warmup=5, nan_check="sync"):
+    """what an unmodified main.py gets through the drop-in seam: lib.evaluation.compute_all_losses + loss.backward() + clip_grad_norm_ +
+    torch.optim.Adam.  nan_check "sync" (the default of the seam: the reference's NaN guards on, a host sync per check, eager
+    launches) or "deferred" (IMMTSF_NAN_CHECK=deferred: no host syncs, forward + loss + backward of a repeated batch shape replayed
+    from a hipGraph -- lib/evaluation.py _SeamGraph); no FlatTrainer either way"""
     from fusions.FusionModel import FusionModel
     from immtsf import config
     from lib.evaluation import compute_all_losses
     from models.tPatchGNN import tPatchGNN
     config.precision = precision
     old = config.nan_check
-    config.nan_check = "sync"
+    config.nan_check = nan_check
     try:
         torch.manual_seed(0)
         a = model_args(str(dev))
@@ -1043,9 +1045,13 @@ def main():
         extras["ms_per_step_fp32"] = round(el / 20 * 1e3, 4)
         wf.close()
         del st, wf
-        extras["dropin"] = {"ms_per_step": round(dropin_ms(dev, args.precision), 4),
-                            "what": "unmodified-main.py seam: lib.evaluation.compute_all_losses + torch.optim.Adam + clip_grad_norm_, eager "
-                                    "launches, the reference's NaN guards on (IMMTSF_NAN_CHECK=sync), no FlatTrainer / hipGraph / second stream"}
+        extras["dropin"] = {"ms_per_step": round(dropin_ms(dev, args.precision, nan_check="deferred"), 4),
+                            "ms_per_step_nan_guards_sync": round(dropin_ms(dev, args.precision), 4),
+                            "what": "unmodified-main.py seam: lib.evaluation.compute_all_losses + loss.backward() + clip_grad_norm_ + "
+                                    "torch.optim.Adam, no FlatTrainer.  ms_per_step: IMMTSF_NAN_CHECK=deferred (no host syncs; forward + loss "
+                                    "+ backward replayed from a hipGraph per batch shape, the clip and the optimizer eager); "
+                                    "ms_per_step_nan_guards_sync: the seam's default, the reference's NaN guards with their host syncs, "
+                                    "every launch eager"}
         config.precision = args.precision
 
     cpu = None

@@ -5,6 +5,7 @@
 // n_b notes only (offsets[b]..offsets[b+1]) -- no -inf padding, no T-fold copy of K/V (the reference materialises
 // T copies, :150-159) -- and only the attention-weight dropout makes the T output rows differ.
 #include "attn.hpp"
+#include "rowops.hpp"
 
 namespace {
 
@@ -1425,9 +1426,10 @@ static int ragged_attn_bwd_impl(RaggedAttnDims dm, const int* offsets, const int
     const size_t dp_stride = maxch > 1 ? 0 : (size_t)dm.B * dm.N * dm.H;
     const int dp_slabs = maxch > 1 ? 1 : cdiv(dm.hd, 64);
     if (maxch > 1) {
-        hipError_t e = hipMemsetAsync(dp_buf, 0, (size_t)dm.B * dm.N * dm.H * sizeof(float), s);
-        if (e == hipSuccess) e = hipMemsetAsync(dqs_part, 0, (size_t)dm.B * dm.H * dm.hd * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
+        // (fill kernels, not hipMemsetAsync: a memset node captured into a hipGraph did not zero the buffer again on the second and later
+        // replays on ROCm 7.2 -- tests/test_gpu_train.py::test_split_k_gemm_zero_fill_survives_graph_replay; every zero-fill of this library is a kernel)
+        if (int rc = launch_fill(dp_buf, 0.f, (size_t)dm.B * dm.N * dm.H, s)) return rc;
+        if (int rc = launch_fill(dqs_part, 0.f, (size_t)dm.B * dm.H * dm.hd, s)) return rc;
     }
     const size_t lds_long = ((drop.p > 0.f ? (size_t)(dm.T <= 32 ? 32 : ((dm.T + 3) & ~3)) * RAGGED_CH : 0) + 4 * RAGGED_CH) * sizeof(float);
     if (maxch > 1 && lds_long <= 128 * 1024) {

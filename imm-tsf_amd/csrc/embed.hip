@@ -18,6 +18,7 @@
 // are data in every configured backbone) by a wave per (row, patch).
 #include "../../include/immtsf.h"
 #include "common.hpp"
+#include "rowops.hpp"
 
 namespace {
 
@@ -219,8 +220,7 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
     while (S > 1 && S * cs > 1024) --S;
     if (S == 1 && !dw_prezeroed) { /* sole writer per element: no zero-fill needed */ }
     else if (!dw_prezeroed) {
-        hipError_t er = hipMemsetAsync(dW, 0, (size_t)D * K * sizeof(float), s);
-        if (er != hipSuccess) return (int)er;
+        if (int rc = launch_fill(dW, 0.f, (size_t)D * K, s)) return rc;       // (a kernel: memset nodes misbehave under graph replay)
     }
     const int KB = K <= 16 ? 16 : (K <= 32 ? 32 : 64);
     const size_t lds = (16 * (size_t)KB + 256 * (size_t)(KB + 1)) * sizeof(float);
@@ -231,8 +231,7 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
     IMMTSF_LAUNCH_CHECK();
     if (dx) {
         const size_t n = (size_t)R * (mode == 0 ? (size_t)L : (size_t)L * c_in);
-        hipError_t er = hipMemsetAsync(dx, 0, n * sizeof(float), s);
-        if (er != hipSuccess) return (int)er;
+        if (int rc = launch_fill(dx, 0.f, n, s)) return rc;
         hipLaunchKernelGGL(embed_bwd_x_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, s, e, W, dout, dx, drop, site);
         IMMTSF_LAUNCH_CHECK();
     }

@@ -353,8 +353,7 @@ int immtsf_mmf_xattn_q_fold(const immtsf_fusion_cfg* cfg, const immtsf_xadd_para
         return IMMTSF_OK;
     }
     {   // both folded products split K (12 tiles each otherwise): ONE zero-fill for the two adjacent outputs
-        hipError_t e = hipMemsetAsync(f.WQf, 0, (size_t)2 * d * C * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
+        CHECK(launch_fill(f.WQf, 0.f, (size_t)2 * d * C, s));       // (a kernel: memset nodes misbehave under graph replay)
     }
     {   // W_Qf = W_in,q W_q  (d x C)
         GemmArgs g = gemm_args(d, C, d, d, C, C);
@@ -445,13 +444,11 @@ int immtsf_mmf_xattn_q_backward_params(const immtsf_fusion_cfg* cfg, const immts
     int pz = 0;
     {
         const size_t nbytes = (size_t)((char*)(sc.dWHO + (size_t)C * d) - (char*)sc.dWQf);
-        hipError_t e = hipMemsetAsync(sc.dWQf, 0, nbytes, s);
-        if (e != hipSuccess) return (int)e;
+        CHECK(launch_fill(sc.dWQf, 0.f, nbytes / sizeof(float), s));
         pz = 1;
         if (!cfg->grads_prezeroed) {       // the bias gradients those two GEMMs also reduce must read zero as well
-            e = hipMemsetAsync(gr->res_b, 0, (size_t)C * sizeof(float), s);
-            if (e == hipSuccess) e = hipMemsetAsync(gr->attn_in_b, 0, (size_t)d * sizeof(float), s);
-            if (e != hipSuccess) return (int)e;
+            CHECK(launch_fill(gr->res_b, 0.f, (size_t)C, s));
+            CHECK(launch_fill(gr->attn_in_b, 0.f, (size_t)d, s));
         }
     }
     // LayerNorm(C)'s two parameter gradients and s_live (column sums of ddelta over the windows with text) in one launch, then

@@ -264,8 +264,7 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t Hd, const i
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
     // dY = dYout (direct path: out = Y + (1-g) dd) + dx[:, :C] ; dE = dx[:, C:]
-    hipError_t e = hipMemcpyAsync(dY_ts, dY_out, (size_t)BT * C * sizeof(float), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
+    CHECK(launch_axpy(dY_out, 1.f, dY_ts, BT * C, 0, s));       // (a copy kernel, not a memcpy node: see launch_fill's note in attn.hip)
     CHECK(launch_split2(sc.dx, C, d, BT, dY_ts, 1, dE_txt, s));
     return fk.join();
 }

@@ -18,6 +18,7 @@
 //   * arbitrary M/N/K by zero-filling tile edges; M or K may live in device memory (ragged note count), so no host
 //     synchronisation is needed to size the launch.
 #include "gemm.hpp"
+#include "rowops.hpp"
 #include <atomic>
 #include <mutex>
 #include <shared_mutex>
@@ -1075,12 +1076,12 @@ static int launch_gemm_impl(int layout, int precision, GemmArgs& g, hipStream_t 
     }
     if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
-            hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
-            if (e != hipSuccess) return (int)e;
-            if (g.p[i].bias_grad) {
-                e = hipMemsetAsync(g.p[i].bias_grad, 0, (size_t)Mmax * sizeof(float), stream);
-                if (e != hipSuccess) return (int)e;
-            }
+            // a fill KERNEL, not hipMemsetAsync: captured into a hipGraph, the memset node left C dirty on the second and later replays
+            // (ROCm 7.2; tests/test_gpu_train.py::test_split_k_gemm_zero_fill_survives_graph_replay: split-K 128 x 16 x 2048, replay 0 exact, replays 1.. off by 1.0) -- which no trainer-owned
+            // step ever hit (their split-K outputs are pre-zeroed gradient sinks), but the graph-cached drop-in seam did
+            if (int rc = launch_fill(g.p[i].C, 0.f, (size_t)Mmax * g.N, stream)) return rc;
+            if (g.p[i].bias_grad)
+                if (int rc = launch_fill(g.p[i].bias_grad, 0.f, (size_t)Mmax, stream)) return rc;
         }
     }
 

@@ -19,6 +19,7 @@
 // elements that are never stored).  The steps past the end of the K range issue zero-page loads too, so every wave
 // issues the same number of loads per step and the vmcnt arithmetic has no special cases.
 #include "gemm.hpp"
+#include "rowops.hpp"
 #include <string.h>
 #include <stdlib.h>
 
@@ -545,12 +546,10 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     }
     if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
-            hipError_t e = hipMemsetAsync(g.p[i].C, 0, (size_t)Mmax * g.N * sizeof(float), stream);
-            if (e != hipSuccess) return (int)e;
-            if (g.p[i].bias_grad) {
-                e = hipMemsetAsync(g.p[i].bias_grad, 0, (size_t)Mmax * sizeof(float), stream);
-                if (e != hipSuccess) return (int)e;
-            }
+            // (fill kernels, not memset nodes: see gemm.hip)
+            if (int rc = launch_fill(g.p[i].C, 0.f, (size_t)Mmax * g.N, stream)) return rc;
+            if (g.p[i].bias_grad)
+                if (int rc = launch_fill(g.p[i].bias_grad, 0.f, (size_t)Mmax, stream)) return rc;
         }
     }
     {

@@ -305,8 +305,7 @@ int immtsf_ttcn_backward(int32_t P, int32_t L, int32_t te_dim, int32_t ttcn_dim,
                                     static_cast<hipStream_t>(stream), te_accumulate);
     {   // the padded weight-gradient slab (gW1p .. gb3p, carved back to back) is zeroed once (split-K GEMMs / atomics)
         const size_t nbytes = (size_t)((char*)(sc.gb3p + d.NCp) - (char*)sc.gW1p);
-        hipError_t e = hipMemsetAsync(sc.gW1p, 0, nbytes, s);
-        if (e != hipSuccess) return (int)e;
+        if (int rc = launch_fill(sc.gW1p, 0.f, nbytes / sizeof(float), s)) return rc;       // (a kernel, not a memset node: see gemm.hip)
     }
     Fork fk(s);
     {

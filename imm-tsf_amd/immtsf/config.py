@@ -93,6 +93,9 @@ xattn_rank = True
 # ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
 # launch (MMF_XAttn_Add.forward_loss); False: the Q half and the loss as separate ops
 xattn_fused_loss = True
+# the zero-edit seam (lib.evaluation.compute_all_losses) serves a repeated (model, fusion, batch shape) from a replayed hipGraph when
+# nan_check is "deferred" (no host syncs inside the step); False: every call is launched eagerly
+seam_graph = True
 # TTF_T2V_XAttn: "auto" = the library chooses by batch size (the folded form, csrc/t2v_fold.hip, from IMMTSF_T2V_FOLD_MIN_ROWS padded note
 # rows on -- its parameter-only chains are a fixed cost), "fold" = the folded form wherever its limits hold, "chain" = the reference's
 # GEMM chain as written

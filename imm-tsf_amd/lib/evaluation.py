@@ -79,11 +79,115 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None, loss=None):
     return out if loss is None else masked_mse(out, loss[0], loss[1], None, loss[2])
 
 
+# ---- the zero-edit seam as a replayed hipGraph --------------------------------------------------------------------------------
+# An unmodified main.py calls compute_all_losses(...), loss.backward(), clip_grad_norm_, optimizer.step() (main.py:1093-1101): eager,
+# that is ~100 launches enqueued from Python -- host-bound at 3 ms per step.  With IMMTSF_NAN_CHECK=deferred (no host syncs in the step)
+# the forward, the loss and the WHOLE backward of a (model, fusion, batch shape) that has been seen before are captured once into a
+# hipGraph over static copies of the batch; a call then copies the batch in, replays the graph, and returns a loss whose backward()
+# only hands the gradients the graph computed to the parameters' .grad (added to what is there, like autograd does).  Same kernels,
+# same results as the eager call (tests/test_gpu_train.py::test_dropin_seam_graph_replay_equals_eager); clip and optimizer stay the
+# caller's.  A new batch shape is run eagerly the first time and captured the second; at most _GRAPH_CAP graphs are kept.
+_GRAPH_CAP = 8
+_graphs = {}      # key -> _SeamGraph
+_seen = {}        # key -> number of eager calls so far
+
+
+class _SeamLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, g):
+        ctx.g = g
+        return g.loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g = ctx.g
+        ps = [p for p, gr in zip(g.params, g.grads) if gr is not None]
+        gs = [gr for gr in g.grads if gr is not None]
+        # the static gradient buffers are rewritten by the next replay: the parameters get their own copies, scaled by the seed --
+        # multi-tensor launches, not one kernel per parameter
+        vals = torch._foreach_mul(gs, dloss)
+        fresh = [(p, v) for p, v in zip(ps, vals) if p.grad is None]
+        old = [(p, v) for p, v in zip(ps, vals) if p.grad is not None]
+        for p, v in fresh:
+            p.grad = v
+        if old:
+            torch._foreach_add_([p.grad for p, _ in old], [v for _, v in old])
+        return None, None
+
+
+class _SeamGraph:
+    def __init__(self, model, fusion, batch_dict, names):
+        from immtsf import ops
+        dev = batch_dict["tp_to_predict"].device
+        self.names = names
+        self.static = {k: batch_dict[k].detach().clone() for k in names}
+        from torch.nn.utils import stateless
+        named_m = [(k, p) for k, p in model.named_parameters() if p.requires_grad]
+        named_f = [(k, p) for k, p in fusion.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named_m + named_f]
+        self.unit = ops.unit_grad(dev)
+        self.anchor = torch.zeros((), device=dev, requires_grad=True)
+        _, self.drop_dev = config.enable_device_counters(dev)       # the dropout key advances on the device, once per replay
+        C = self.static["mask_predicted_data"].shape[-1]
+
+        def run():
+            b = self.static
+            cnt = b["mask_predicted_data"].reshape(-1, C).sum(0)
+            # The captured forward sees ALIASES of the parameters (detached views of the same storage, fresh autograd leaves), and the
+            # gradients come back through torch.autograd.grad.  Why: a parameter's gradient-accumulator node remembers the stream it
+            # was created on and is shared by every live autograd graph that uses the parameter -- e.g. the caller's previous eager
+            # `loss`, still referenced while this call runs (main.py:1093 reassigns it afterwards).  The engine would synchronise the
+            # capturing stream with THAT stream: an event recorded outside the capture, and hipStreamEndCapture crashes (ROCm 7.2).
+            al_m = {k: p.detach().requires_grad_(True) for k, p in named_m}
+            al_f = {k: p.detach().requires_grad_(True) for k, p in named_f}
+            with stateless._reparametrize_module(model, al_m), stateless._reparametrize_module(fusion, al_f):
+                # (one stream: what the seam buys is the host side -- one graph launch instead of ~100 enqueued from Python)
+                loss = forecast_and_fuse(model, fusion, b, None, loss=(b["data_to_predict"], b["mask_predicted_data"], cnt))
+            grads = torch.autograd.grad(loss, list(al_m.values()) + list(al_f.values()), grad_outputs=self.unit, allow_unused=True)
+            self.drop_dev.add_(1)
+            return loss, grads
+
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                run()
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.grads = run()
+
+    def __call__(self, batch_dict):
+        torch._foreach_copy_([self.static[k] for k in self.names], [batch_dict[k] for k in self.names])
+        self.graph.replay()
+        return _SeamLoss.apply(self.anchor, self)
+
+
+def _seam_key(model, fusion, batch_dict, names):
+    return (id(model), id(fusion), model.training, fusion.training, config.precision, config.t2v_form,
+            tuple((k, tuple(batch_dict[k].shape), batch_dict[k].dtype) for k in names))
+
+
 def compute_all_losses(model, fusion, batch_dict, enable_text=True, use_text_embeddings=True, group=None):
     """One training-step forward: backbone forecast -> fusion -> masked MSE (lib/evaluation.py:72-164).
     The reference's per-step host syncs (NaN checks, per-row mask loop, .item()) follow immtsf.config.nan_check:
-    in "sync" mode they are all performed; otherwise the loss stays on the device (results["mse"] is a tensor)."""
+    in "sync" mode they are all performed; otherwise the loss stays on the device (results["mse"] is a tensor) and -- config.seam_graph
+    -- a repeated (model, fusion, batch shape) is served by a replayed hipGraph (see above)."""
     sync = config.nan_check == "sync"
+    names = ("tp_to_predict", "observed_data", "observed_tp", "observed_mask", "notes_embeddings", "tau", "data_to_predict",
+             "mask_predicted_data")
+    if (not sync and config.seam_graph and enable_text and fusion is not None and use_text_embeddings and group is None and
+            torch.is_grad_enabled() and model.training and hasattr(fusion, "ttf") and getattr(model, "immtsf_graphable", False) and
+            all(torch.is_tensor(batch_dict.get(k)) and batch_dict[k].is_cuda for k in names)):
+        key = _seam_key(model, fusion, batch_dict, names)
+        g = _graphs.get(key)
+        if g is None and _seen.get(key, 0) >= 1 and len(_graphs) < _GRAPH_CAP:
+            g = _graphs[key] = _SeamGraph(model, fusion, batch_dict, names)
+        if g is not None:
+            loss = g(batch_dict)
+            return {"loss": loss, "mse": loss.detach()}
+        _seen[key] = _seen.get(key, 0) + 1
     pred_y = model.forecasting(batch_dict["tp_to_predict"], batch_dict["observed_data"], batch_dict["observed_tp"],
                                batch_dict["observed_mask"])
     if sync and torch.isnan(pred_y).any():

@@ -10,6 +10,8 @@ from models._common import masked_instance_norm
 
 
 class DLinear(nn.Module):
+    immtsf_graphable = True      # no host syncs / data-dependent shapes in forecasting()
+
     def __init__(self, configs, individual=False):
         super().__init__()
         self.input_len = configs.input_len

@@ -27,6 +27,8 @@ class FlattenHead(nn.Module):
 
 
 class PatchTST(nn.Module):
+    immtsf_graphable = True      # no host syncs / data-dependent shapes in forecasting(): a step may be captured into a hipGraph
+
     def __init__(self, configs, patch_len=6 * 3, stride=3 * 3):
         super().__init__()
         self.input_len = configs.input_len

@@ -61,6 +61,8 @@ class PositionalEncoding(nn.Module):
 
 
 class tPatchGNN(nn.Module):
+    immtsf_graphable = True      # no host syncs / data-dependent shapes in forecasting(): a step may be captured into a hipGraph
+
     def __init__(self, args, supports=None, dropout=0):
         super().__init__()
         self.device = args.device

@@ -19,7 +19,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _setup(dev, dropout, seed=0):
+def _setup(dev, dropout, seed=0, trainer=True):
     import bench
     from fusions.FusionModel import FusionModel
     from fusions.load_llm import register_d_model
@@ -44,7 +44,7 @@ def _setup(dev, dropout, seed=0):
     for lyr in model.transformer_encoder:
         for l in lyr.layers:
             l.self_attn.dropout = 0.0
-    trainer = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+    trainer = None if not trainer else FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
                           lr=1e-2, eps=1e-3, max_norm=1.0, sink_buckets=(0, 1), overlap=False, device_step=True)   # eps: Adam's sign-like first
     # steps would otherwise turn 1e-9 atomic-order noise on ~zero gradients into +-lr parameter differences
     cpu_batch, _ = bench.synth_batch(5, 8)
@@ -513,6 +513,90 @@ def test_phased_step_trains_like_eager(kind):
     err = float((tr.flat_param - ref).abs().max() / ref.abs().max())
     assert err < 2e-4, err
     tr.close()
+
+
+def test_split_k_gemm_zero_fill_survives_graph_replay():
+    """A split-K product (few output tiles, long reduction: 128 x 16 x 2048 in exact fp32) zero-fills its output in front of the atomic
+    accumulation.  As a hipMemsetAsync node inside a captured hipGraph that fill left the output dirty on the second and later
+    replays (ROCm 7.2): replay 0 exact, replays 1.. off by 1.0 -- found through the graph-cached drop-in seam, whose transformer-layer
+    GEMMs are not pre-zeroed gradient sinks.  Every zero-fill of the library is a kernel now; this pins it."""
+    dev = _dev()
+    from immtsf import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    M, N, K = 128, 16, 2048
+    A, B = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev)
+    Cc = torch.empty(M, N, device=dev)
+
+    def run():
+        _lib.check(lib.immtsf_gemm(0, 0, _lib.ptr(A), K, _lib.ptr(B), K, _lib.ptr(Cc), N, None, M, N, K, 1.0, 0, 0, _lib.stream_ptr()), "gemm")
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ref = A @ B.t()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    for i in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        assert float((Cc - ref).abs().max()) < 1e-3, i
+
+
+def test_dropin_seam_graph_replay_equals_eager():
+    """The zero-edit seam of an unmodified main.py (lib.evaluation.compute_all_losses -> loss.backward() -> clip_grad_norm_ ->
+    torch.optim.Adam.step(), main.py:1093-1101) served from a replayed hipGraph (IMMTSF_NAN_CHECK=deferred; the first call of a batch
+    shape is eager, the second captures, later ones replay) trains exactly like the eager seam; gradients ACCUMULATE into .grad like
+    autograd's when the caller does not zero them; a second batch of the same shape goes through the same graph."""
+    dev = _dev()
+    from immtsf import config
+    from lib import evaluation as ev
+    from lib.evaluation import compute_all_losses
+    import bench
+
+    def train(seam):
+        ev._graphs.clear(); ev._seen.clear()
+        model, fusion, _, batch = _setup(dev, 0.0, trainer=False)          # (plain parameters: what an unmodified main.py has)
+        cpu2, _ = bench.synth_batch(6, 8)
+        batch2 = {k: v.to(dev) for k, v in cpu2.items()}
+        batch2["notes_embeddings"] = batch2["notes_embeddings"][..., :48].contiguous()
+        params = [p for p in list(model.parameters()) + list(fusion.parameters())]
+        opt = torch.optim.Adam(params, lr=1e-2, eps=1e-3)
+        config.seam_graph = seam
+        losses = []
+        for i in range(6):
+            opt.zero_grad()
+            res = compute_all_losses(model, fusion, batch if i % 2 == 0 else batch2)
+            res["loss"].backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            losses.append(float(res["loss"]))
+        # accumulation: two backward passes without zero_grad
+        opt.zero_grad()
+        compute_all_losses(model, fusion, batch)["loss"].backward()
+        g1 = [p.grad.clone() for p in params if p.grad is not None]
+        compute_all_losses(model, fusion, batch)["loss"].backward()
+        g2 = [p.grad.clone() for p in params if p.grad is not None]
+        torch.cuda.synchronize()
+        n_graphs = len(ev._graphs)
+        return torch.cat([p.detach().reshape(-1) for p in params]), losses, g1, g2, n_graphs
+
+    old = config.seam_graph
+    try:
+        p_e, l_e, _, _, n_e = train(False)
+        p_g, l_g, g1, g2, n_g = train(True)
+    finally:
+        config.seam_graph = old
+        ev._graphs.clear(); ev._seen.clear()
+    assert n_e == 0 and n_g == 1              # one shape -> one graph, used by both batches
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_g)
+    assert float((p_e - p_g).abs().max() / p_e.abs().max()) < 2e-4
+    for a, b in zip(g1, g2):
+        assert float((b - 2 * a).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6)
 
 
 def test_load_state_dict_refreshes_the_bf16_twin():

@@ -818,7 +818,7 @@ class FlagStep(PhasedStep):
             _lib.check(lib.immtsf_flag_wait(flag, F_ERR, 50, sp(st)), "flag_wait")
 
         # data parallel: counting flags 16.. (never cleared), one per announced bucket, in the order the hooks fire
-        self.segments = []                    # [(flag address, lo, hi)]
+        self.segments = []                    # [(flag address, lo, hi, bucket)]
         announced = set()
 
         def announce(bi):
@@ -830,7 +830,7 @@ class FlagStep(PhasedStep):
                 return
             flag = fp + 4 * (16 + len(self.segments))
             _lib.check(lib.immtsf_flag_bump(flag, torch.cuda.current_stream().cuda_stream), "flag_bump")
-            self.segments.append((flag, lo, hi))
+            self.segments.append((flag, lo, hi, bi))
 
         trainer.step_guard = F_ERR
         self.graph = torch.cuda.CUDAGraph()
@@ -879,6 +879,11 @@ class FlagStep(PhasedStep):
                 finally:
                     config.param_tail = None
                     trainer._capture_hook = None
+                if self.segments:
+                    # the bucket whose hook fired LAST on the text side: nothing but the join follows it, a flag buys no overlap -- it is
+                    # reduced behind the graph together with whatever else is left (cfg2: TTF + the backbone, adjacent ranges, ONE
+                    # collective); its flag bump stays in the graph, unread
+                    announced.discard(self.segments.pop()[3])
                 with torch.cuda.stream(B):
                     if tail["jobs"]:
                         fwait(fp + 16, B)
@@ -941,7 +946,7 @@ class FlagStep(PhasedStep):
         S = torch.cuda.current_stream()
         if self.segments:
             with torch.cuda.stream(self.comm):
-                for flag, lo, hi in self.segments:
+                for flag, lo, hi, _ in self.segments:
                     _lib.check(lib.immtsf_flag_wait_ge(flag, self._epoch & 0x7FFFFFFF, self._f_err, 50, self.comm.cuda_stream), "flag_wait_ge")
                     t._all_reduce(lo, hi)
                 self._ev.record(self.comm)

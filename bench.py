@@ -415,8 +415,8 @@ def flag_fns(w):
     fc_args = (b["tp_to_predict"], b["observed_data"], b["observed_tp"], b["observed_mask"])
 
     def text_fn():
-        E, M = fusion.ttf(b["notes_embeddings"], b["tau"], b["tp_to_predict"])
-        return (E, M) + tuple(fusion.mmf.project_kv(E))
+        E, M, kv = fusion.text_side(b["notes_embeddings"], b["tau"], b["tp_to_predict"])
+        return (E, M) + tuple(kv)
 
     def head_fn(pred, E, M, kv, fold):
         if hasattr(fusion.mmf, "forward_loss"):      # head + loss (+ their backward) in one launch where the block can
@@ -849,6 +849,9 @@ def main():
     ap.add_argument("--fusion-only", action="store_true",
                     help="time the fusion blocks + loss + backward + optimizer with the backbone's forecast replaced by a fixed random tensor "
                          "(cfg5: the 7 ms of fusion without the 97 ms frozen GPT-2 body of TimeLLM)")
+    ap.add_argument("--fuse-tail", default="auto", choices=["auto", "on", "off"],
+                    help="A/B measurements only: TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection "
+                         "(immtsf.config.fuse_tail; auto = on)")
     ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold"],
                     help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
                          "reference's GEMM chain (immtsf.config.t2v_form)")
@@ -901,6 +904,7 @@ def main():
         lib.immtsf_debug_gemm2_config(args.gemm2_variant, 0, -1)
     config.nan_check = "deferred"       # no host syncs inside the step; the flag is checked after the run
     config.t2v_form = args.t2v_form
+    config.fuse_tail = {"auto": "auto", "on": True, "off": False}[args.fuse_tail]
     config.manual_seed(1234 + rank)
 
     wire = args.grad_wire if args.grad_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")

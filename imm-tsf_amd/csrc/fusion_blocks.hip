@@ -128,8 +128,9 @@ int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2
 // (csrc/t2v_fold.hip has the algebra and the non-GEMM kernels; this is the launch sequence.)  Taken wherever its limits hold unless the
 // caller asks for the chain as written (immtsf_fusion_cfg.form = 1, the cross-check).
 inline bool t2v_fold_on(const immtsf_fusion_cfg* c) {
-    if (c->form == 1 || !t2v_fold_shape_ok(c->N, c->T, c->d, c->H)) return false;
-    if (c->form == 0 && (long)c->B * c->N < IMMTSF_T2V_FOLD_MIN_ROWS) return false;      // small batches: the chain's GEMMs are as cheap as the fold's fixed cost
+    const int form = c->form & 3;
+    if (form == 1 || !t2v_fold_shape_ok(c->N, c->T, c->d, c->H)) return false;
+    if (form == 0 && (long)c->B * c->N < IMMTSF_T2V_FOLD_MIN_ROWS) return false;      // small batches: the chain's GEMMs are as cheap as the fold's fixed cost
     if ((c->d_m % 8) || (c->d % 16) || c->d_m <= 0) return false;            // X rows and the Time2Vec half in 16-byte pieces
     if (c->precision == 1 && !(t2v_hf(c) && ((c->d / c->H) % 8) == 0)) return false;
     return true;
@@ -322,6 +323,10 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
     CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
                              drop, SITE_T2V_ATTN, s));
+    if (cfg->form & IMMTSF_FORM_NO_PROJ) {       // proj_out is the consumer's (immtsf_mmf_xrank_p_forward_z): hand over Z itself
+        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
+                                    hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr);
+    }
     CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.zln.f, drop, SITE_T2V_OUT, s, w.zln.h));
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -351,14 +356,19 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     const float* bvec1 = inp ? w.bvec1 : p->kv_b;
     GemmArgs wg[2];
     int nwg = 0;
-    Mat dE = cmat(dE_txt);
-    if (hf && cfg->in_h) {
-        dE.h = const_cast<void*>(cfg->in_h);
-    } else if (hf) {
-        CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
-        dE.h = sc.dE.h;
-    }
-    {   // proj_out: dzln = dE W_po ; dW_po = dE^T zln ; db_po = colsum dE
+    const bool noproj = (cfg->form & IMMTSF_FORM_NO_PROJ) != 0;
+    float* dzln = sc.dzln;
+    if (noproj) {        // the incoming gradient IS dZ (the consumer owns proj_out): LayerNorm's backward works on it in place
+        dzln = const_cast<float*>(dE_txt);
+    } else {
+        Mat dE = cmat(dE_txt);
+        if (hf && cfg->in_h) {
+            dE.h = const_cast<void*>(cfg->in_h);
+        } else if (hf) {
+            CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+            dE.h = sc.dE.h;
+        }
+        // proj_out: dzln = dE W_po ; dW_po = dE^T zln ; db_po = colsum dE
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, dE, W.po, mat(sc.dzln), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
@@ -369,11 +379,11 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         wg[nwg++] = h;
     }
     {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
-        const int rc = launch_layernorm_bwd_sums(sc.dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+        const int rc = launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
                                                  gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
         if (rc == IMMTSF_EUNSUPPORTED) {
-            CHECK(launch_layernorm_bwd(sc.dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
-            CHECK(launch_colsum3(sc.dzln, w.xhat, sc.dx, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, nullptr, s, true));
+            CHECK(launch_layernorm_bwd(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
+            CHECK(launch_colsum3(dzln, w.xhat, sc.dx, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, nullptr, s, true));
         } else {
             CHECK(rc);
         }
@@ -559,6 +569,9 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
         g.row_flag32 = w.lengths;         // same zero pattern as M_txt
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
+    if (cfg->form & IMMTSF_FORM_NO_PROJ)         // proj_out is the consumer's: hand over Z itself
+        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
+                                    hf ? (cfg->out_h ? cfg->out_h : w.z.h) : nullptr);
     CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z.f, drop, SITE_T2V_OUT, s, w.z.h));
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
@@ -611,14 +624,19 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     const bool hf = t2v_hf(cfg);
     T2VW W;
     CHECK(t2v_weights(cfg, p, w, s, &W));
-    Mat dE = cmat(dE_txt);
-    if (hf && cfg->in_h) {
-        dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
-    } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
-        CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
-        dE.h = sc.dE.h;
-    }
-    {   // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
+    const bool noproj = (cfg->form & IMMTSF_FORM_NO_PROJ) != 0;
+    float* dzp = sc.dz;
+    if (noproj) {        // the incoming gradient IS dZ (the consumer owns proj_out): LayerNorm's backward works on it in place
+        dzp = const_cast<float*>(dE_txt);
+    } else {
+        Mat dE = cmat(dE_txt);
+        if (hf && cfg->in_h) {
+            dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
+        } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
+            CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+            dE.h = sc.dE.h;
+        }
+        // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, dE, W.po, mat(sc.dz), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
@@ -632,11 +650,11 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
     // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
     {
-        const int rc = launch_layernorm_bwd_sums(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+        const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
                                                  gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
         if (rc == IMMTSF_EUNSUPPORTED) {
-            CHECK(launch_layernorm_bwd(sc.dz, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
-            CHECK(launch_colsum3(sc.dz, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+            CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
+            CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
         } else {
             CHECK(rc);
         }

@@ -458,7 +458,9 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 }  // namespace
 
+static int g2_group_tile = 0;       // tile edge of the grouped weight-gradient launch: 0 = by tile count, 64 | 128 forced (tool switch: variant 1064 / 1128 / 1000)
 extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
+    if (variant == 1000 || variant == 1064 || variant == 1128) { g2_group_tile = variant - 1000; return 0; }
     g2_variant = variant;
     g2_splitk = splitk;
     g2_xcd = xcd;
@@ -630,8 +632,15 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
     GemmGroupArgs gg;
     memset(&gg, 0, sizeof(gg));
     int tiles = 0;
-    // IMMTSF_GROUP_TILE=128: 128 x 128 tiles (two K-groups of 2 x 2 waves) -- a quarter of the workgroups, half the operand traffic
-    constexpr int gt = 64;
+    // 128 x 128 tiles (two K-groups of 2 x 2 waves) when they still give every CU most of a tile (>= 192 of them): a quarter of the
+    // workgroups and half the operand traffic of the 64 x 64 K-group tiles (cfg2's five text-side weight gradients: 234 tiles in
+    // one round instead of 936 in four; 0.546 vs 0.549 ms per step, HBM-side traffic per launch halved)
+    int gt = g2_group_tile;
+    if (gt == 0) {
+        long t128 = 0;
+        for (int i = 0; i < n; ++i) t128 += (long)cdiv(list[i].M, 128) * cdiv(list[i].N, 128);
+        gt = t128 >= 192 ? 128 : 64;
+    }
     for (int i = 0; i < n; ++i) {
         GemmArgs g = list[i];
         if (!immtsf_gemm2_supported(GEMM_TN, g) || g.nprob != 1 || g.act != 0 || g.relu_ref || g.row_flag || g.add_vec || g.accumulate ||

@@ -26,6 +26,7 @@
 #include "rowops.hpp"
 #include "tail.hpp"
 #include "block_util.hpp"
+#include "t2v_fold.hpp"
 #include <math.h>
 #include <algorithm>
 #include <vector>
@@ -468,6 +469,8 @@ inline bool xr_hf(const immtsf_fusion_cfg* c) { return c->precision == 1 && c->d
 struct XPWs {
     float *AqT, *WHO, *GA, *UA, *Wf, *Wfb;
     unsigned short *Wf16, *E16;
+    float *Wc, *bc;              // the "_z" form: W_fold composed with the producer's last linear map, Wc = W_fold W_po, bc = W_fold b_po + b_fold
+    unsigned short *Wc16, *Wpo16;      // Wpo16: bf16 image of the producer's weight when no twin is registered
     size_t bytes;
 };
 XPWs carve_xp(const immtsf_fusion_cfg* c, void* base) {
@@ -484,12 +487,17 @@ XPWs carve_xp(const immtsf_fusion_cfg* c, void* base) {
     w.Wfb = k.take<float>(x.PW);
     w.Wf16 = hf ? k.take<unsigned short>((size_t)x.PW * d) : nullptr;
     w.E16 = hf ? k.take<unsigned short>((size_t)x.B * x.T * d) : nullptr;
+    w.Wc = k.take<float>((size_t)x.PW * d);
+    w.bc = k.take<float>(x.PW);
+    w.Wc16 = hf ? k.take<unsigned short>((size_t)x.PW * d) : nullptr;
+    w.Wpo16 = hf ? k.take<unsigned short>(d * d) : nullptr;
     w.bytes = k.bytes();
     return w;
 }
 struct XPScratch {
     float *dWf, *dWfb, *T1, *RW, *dAqT, *dWHO;
-    unsigned short* dP16;
+    float *dWc, *dbc;            // the "_z" form
+    unsigned short *dP16, *dWc16;
     void* sk;
     size_t skb, bytes;
 };
@@ -506,6 +514,9 @@ XPScratch carve_xp_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dAqT = k.take<float>(x.Cq * d);
     s.dWHO = k.take<float>(x.C * d);
     s.dP16 = hf ? k.take<unsigned short>(BT * x.PW) : nullptr;
+    s.dWc = k.take<float>((size_t)x.PW * d);
+    s.dbc = k.take<float>(x.PW);
+    s.dWc16 = hf ? k.take<unsigned short>((size_t)x.PW * d) : nullptr;
     s.skb = hf ? immtsf_gemm3_tn_ws_bytes(x.PW, (int)d, (int)BT) : 0;
     s.sk = s.skb ? k.take<unsigned char>(s.skb) : nullptr;
     s.bytes = k.bytes();
@@ -1423,6 +1434,106 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
         GemmArgs g = gemm_args(BT, x.PW, d, d, d, x.PW);
         set_problem2(g, 0, Em, mat(w.Wf, w.Wf16), mat(P), w.Wfb);
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    return IMMTSF_OK;
+}
+
+/* ---- the "_z" form: the text side's producer ends in a linear map E_txt = Z W_po^T + b_po (TTF_T2V_XAttn's proj_out,
+ * fusions/TTF_T2V_XAttn.py:182) whose only consumer is this projection, so P = [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T: the
+ * (B T) x d x d product, its data gradient and its weight gradient become PW-row products (PW = 24 at cfg2), E_txt and dE_txt are
+ * never formed.  proj_w (d, d), proj_b (d): the producer's parameters; their gradients come out of the backward here. */
+int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
+                                 const float* Z, float* P, float* bHO, void* workspace, size_t workspace_bytes, int32_t folded,
+                                 immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !P || !bHO || !workspace) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    if (!folded) CHECK(immtsf_mmf_xrank_fold(cfg, p, bHO, workspace, workspace_bytes, stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
+    Mat Wpo;
+    CHECK(weight_mat(hf, proj_w, (size_t)d * d, w.Wpo16, s, &Wpo));
+    {   // Wc = W_fold W_po  (PW x d)
+        GemmArgs g = gemm_args(x.PW, d, d, d, d, d);
+        set_problem2(g, 0, mat(w.Wf, w.Wf16), Wpo, mat(w.Wc, w.Wc16), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // bc = W_fold b_po + b_fold
+        VecJobList l;
+        l.add(VJ_MV, w.Wf, d, proj_b, w.Wfb, w.bc, x.PW, d);
+        CHECK(launch_vecjobs(l, s));
+    }
+    Mat Zm = cmat(Z);
+    if (hf && cfg->in_h) {
+        Zm.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
+        CHECK(launch_f32_to_bf16(Z, w.E16, (size_t)BT * d, s));
+        Zm.h = w.E16;
+    }
+    {   // P = Z Wc^T + bc
+        GemmArgs g = gemm_args(BT, x.PW, d, d, d, x.PW);
+        set_problem2(g, 0, Zm, mat(w.Wc, w.Wc16), mat(P), w.bc);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    return IMMTSF_OK;
+}
+
+/* the data half of the "_z" backward: dZ = dP Wc, dWc = dP^T Z (+ column sums), then -- parameters only -- dW_fold = dWc W_po^T +
+ * dbc b_po^T, db_fold = dbc (left in `scratch` for immtsf_mmf_xrank_p_backward_params) and the producer's gradients dW_po = W_fold^T dWc,
+ * db_po = W_fold^T dbc (written to g_proj_w / g_proj_b) */
+int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
+                                       const float* Z, const float* dP, float* dZ, void* workspace, size_t workspace_bytes, void* scratch,
+                                       size_t scratch_bytes, float* g_proj_w, float* g_proj_b, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !dP || !dZ || !workspace || !scratch || !g_proj_w || !g_proj_b) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    XPScratch sc = carve_xp_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
+    Mat Wpo;
+    CHECK(weight_mat(hf, proj_w, (size_t)d * d, w.Wpo16, s, &Wpo));
+    Mat dPm = cmat(dP), Zm = cmat(Z, hf ? (cfg->aux_h ? cfg->aux_h : static_cast<const void*>(w.E16)) : nullptr);
+    if (hf && !cfg->aux_h) CHECK(launch_f32_to_bf16(Z, w.E16, (size_t)BT * d, s));
+    if (hf && cfg->in_h) {
+        dPm.h = const_cast<void*>(cfg->in_h);
+    } else if (hf) {
+        CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
+        dPm.h = sc.dP16;
+    }
+    {   // dZ = dP Wc
+        GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
+        set_problem2(g, 0, dPm, mat(w.Wc, w.Wc16), mat(dZ, hf ? cfg->out_h : nullptr), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    {   // dWc = dP^T Z,  dbc = column sums of dP
+        GemmArgs g = gemm_args(x.PW, d, BT, x.PW, d, d);
+        set_problem2(g, 0, dPm, Zm, mat(sc.dWc), nullptr, sc.dbc);
+        g.c_prezeroed = 0;
+        g.ws = sc.sk; g.ws_bytes = sc.skb;
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
+    }
+    if (hf) CHECK(launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * d, s));
+    {   // dW_fold = dWc W_po^T
+        GemmArgs g = gemm_args(x.PW, d, d, d, d, d);
+        set_problem2(g, 0, mat(sc.dWc, sc.dWc16), Wpo, mat(sc.dWf), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
+    }
+    {   // dW_po = W_fold^T dWc  (a rank-PW product)
+        GemmArgs g = gemm_args(d, d, x.PW, d, d, d);
+        set_problem2(g, 0, mat(w.Wf, w.Wf16), mat(sc.dWc, sc.dWc16), mat(g_proj_w), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
+    }
+    {   // db_po = W_fold^T dbc;  dW_fold += dbc b_po^T;  db_fold = dbc
+        VecJobList l;
+        l.add(VJ_MVT, w.Wf, d, sc.dbc, nullptr, g_proj_b, x.PW, d);
+        l.rank1(sc.dWf, d, x.PW, d, 1, sc.dbc, proj_b);
+        VecJob& c = l.add(VJ_COPY, sc.dbc, x.PW, nullptr, nullptr, sc.dWfb, 1, x.PW);
+        c.ldy = x.PW;
+        CHECK(launch_vecjobs(l, s));
     }
     return IMMTSF_OK;
 }

@@ -47,15 +47,41 @@ class FusionModel(nn.Module):
             self.ttf.precision = precision
             self.mmf.precision = precision
 
+    def fused_tail(self, rows: int, T: int) -> bool:
+        """TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection (csrc/xrank.hip "_z" form): three (B T)-row d x d
+        products become 24-column ones plus a short parameter-only chain.  Measured (cfg2, bf16, fused / separate): 64 windows 0.538 /
+        0.550 ms, 256: 0.929 / 0.996, 1024: 1.89 / 2.05, 4096: 6.33 / 6.31 (the backbone's branch bounds that step) -- so "auto" takes it
+        wherever the pair allows.  Same function, same parameters, same gradients
+        (tests/test_gpu_fusion.py::test_fused_tail_equals_separate_blocks)."""
+        mode = config.fuse_tail
+        if mode is False or mode == "off" or type(self.ttf) is not TTF_T2V_XAttn or not hasattr(self.mmf, "_rank"):
+            return False
+        if not (config.xattn_rank and self.mmf._rank(T)):
+            return False
+        return True
+
+    def text_side(self, notes_input, tau, t_hat):
+        """everything that depends on the text only: (E_txt or its pre-projection Z, M_txt, kv) with kv = mmf.project_kv(...) when the
+        modality block has a text-only half (None otherwise).  What forward(), lib.evaluation.forecast_and_fuse and the step engines
+        call; E_txt is Z when fused_tail() holds (its only consumer, the low-rank projection, then applies proj_out itself)."""
+        from fusions._common import prep_t_hat
+        B = tau.shape[0]
+        T = prep_t_hat(t_hat, B).shape[1]
+        if self.fused_tail(B * T, T):
+            Z, M_txt = self.ttf(notes_input, tau, t_hat, tail=False)
+            return Z, M_txt, self.mmf.project_kv(Z, proj=self.ttf.proj_out)
+        E_txt, M_txt = self.ttf(notes_input, tau, t_hat)
+        return E_txt, M_txt, (self.mmf.project_kv(E_txt) if hasattr(self.mmf, "project_kv") else None)
+
     def forward(self, notes_input, tau, t_hat, Y_ts):
         sync = config.nan_check == "sync"
         if sync and torch.isnan(Y_ts).any():
             print(f"Y_ts: {Y_ts}")
             raise ValueError("Y_ts contains NaN values.")
-        E_txt, M_txt = self.ttf(notes_input, tau, t_hat)
+        E_txt, M_txt, kv = self.text_side(notes_input, tau, t_hat)
         if sync and torch.isnan(E_txt).any():
             raise ValueError("E_txt contains NaN values.")
-        Y_out = self.mmf(Y_ts, E_txt, M_txt)
+        Y_out = self.mmf(Y_ts, E_txt, M_txt) if kv is None else self.mmf(Y_ts, E_txt, M_txt, kv=kv)
         if sync and torch.isnan(Y_out).any():
             raise ValueError("Y_out contains NaN values.")
         return Y_out

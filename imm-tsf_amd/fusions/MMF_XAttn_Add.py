@@ -55,14 +55,19 @@ class MMF_XAttn_Add(nn.Module):
         """the query half's product weights (parameters only: any stream, any time before forward())"""
         return mmf_xattn_q_fold(self.C, self.d_attn, self.n_heads, resolve_precision(self), self._params())
 
-    def project_kv(self, E_txt, with_fold=True):
+    def project_kv(self, E_txt, with_fold=True, proj=None):
         """key/value half (proj_k / proj_v + their MHA in-projections -> one (B,T,2d) tensor k | v): depends only on the text
         side, so a caller can run it on the text stream while the backbone is still producing Y_ts
         (lib.evaluation.forecast_and_fuse).  In the low-rank form the pair is (P, b_HO): the text side's projection onto the
         (2C+1) H columns the attention needs and the folded output bias (both carry gradients back to this half)."""
         if self._rank(E_txt.shape[1]):
+            # proj = the nn.Linear the text side would have applied last (TTF_T2V_XAttn.proj_out, when E_txt is really its input Z):
+            # composed into the low-rank projection, so that the (B T) x d x d product and its two gradient products never run
+            extra = () if proj is None else (proj.weight, proj.bias)
             return MMFXRankPFn.apply(f32(E_txt), self.C, self.n_heads, resolve_precision(self),
-                                     getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), *self._params()[:9])
+                                     getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), *self._params()[:9], *extra)
+        if proj is not None:
+            raise ValueError("project_kv(proj=...) needs the low-rank form (immtsf.config.xattn_rank, C <= 15, H <= 4)")
         KV = MMFXAttnKVFn.apply(f32(E_txt), self.n_heads, resolve_precision(self),
                                 getattr(self.proj_q.weight, "_immtsf_bwd_hook", None), self.proj_k.weight, self.proj_v.weight,
                                 self.attn.in_proj_weight, self.attn.in_proj_bias)

@@ -71,10 +71,12 @@ class TTF_T2V_XAttn(nn.Module):
                 self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.layer_norm.weight,
                 self.layer_norm.bias, self.proj_out.weight, self.proj_out.bias)
 
-    def forward(self, notes_input, tau: torch.Tensor, t_hat: torch.Tensor):
+    def forward(self, notes_input, tau: torch.Tensor, t_hat: torch.Tensor, tail: bool = True):
         """notes_input (B,N,d_model) zero-padded embeddings -- or a PackedNotes over a resident embedding matrix
         (immtsf.data.ResidentStore.collate: no padded tensor, no note-mask re-derivation) --, tau (B,N),
-        t_hat (B,T) or (T,) -> E_txt (B,T,d_txt), M_txt (B,1) bool."""
+        t_hat (B,T) or (T,) -> E_txt (B,T,d_txt), M_txt (B,1) bool.  tail=False (not part of the reference's signature; used by
+        FusionModel.text_side): stop in front of proj_out and return Z = dropout(LayerNorm(E_attn + Q)) in E_txt's place -- for a consumer
+        that composes proj_out into its own projection (MMF_XAttn_Add.project_kv(Z, proj=self.proj_out))."""
         if not self.use_text_embeddings:
             raise NotImplementedError("raw-text mode is not part of the MI355X hot path")
         packed = notes_input if isinstance(notes_input, PackedNotes) else None
@@ -88,7 +90,7 @@ class TTF_T2V_XAttn(nn.Module):
         flag = None if mode == "off" else self._nan.get(V.device)
         E_txt, M = TTFT2VXAttnFn.apply(V, f32(tau), T, self.n_heads, self.p_drop, training, resolve_precision(self),
                                        self.last_seed, flag, None if packed is None else packed.src_rows,
-                                       None if packed is None else packed.lengths, *self._params())
+                                       None if packed is None else packed.lengths, not tail, *self._params())
         if mode == "sync":
             self._nan.raise_if_set("Input embeddings V contain NaN values.")
         return E_txt, M.view(torch.bool).view(B, 1)

@@ -93,6 +93,9 @@ xattn_rank = True
 # ... and, for a training step whose loss is the masked MSE with known observation counts, the Q half + loss + their backward as ONE
 # launch (MMF_XAttn_Add.forward_loss); False: the Q half and the loss as separate ops
 xattn_fused_loss = True
+# FusionModel: TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection: "auto" / True = wherever the pair of blocks
+# allows it, False = the two blocks as written (tests run both)
+fuse_tail = "auto"
 # the zero-edit seam (lib.evaluation.compute_all_losses) serves a repeated (model, fusion, batch shape) from a replayed hipGraph when
 # nan_check is "deferred" (no host syncs inside the step); False: every call is launched eagerly
 seam_graph = True

@@ -158,7 +158,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
     params in immtsf_t2v_params order."""
 
     @staticmethod
-    def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, src_rows, lengths, *params):
+    def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, src_rows, lengths, no_proj, *params):
         lib = _lib.load()
         notes, tau = _c(notes), _c(tau)
         params = tuple(_c(p) for p in params)
@@ -169,6 +169,9 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         d = params[0].numel()
         cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed, notes.device)
         cfg.form = {"auto": 0, "chain": 1, "fold": 2}[config.t2v_form]        # (the backward reads the same cfg: one form per call pair)
+        if no_proj:             # proj_out is left to the consumer (MMFXRankPFn's "_z" form): the output is Z, the LayerNorm + dropout result
+            cfg.form |= _lib.FORM_NO_PROJ
+        ctx.no_proj = bool(no_proj)
         ws = _bytes(lib.immtsf_ttf_t2v_xattn_workspace_bytes(C.byref(cfg)), notes.device)
         E = torch.empty(B, T, d, dtype=torch.float32, device=notes.device)
         M = torch.empty(B, dtype=torch.uint8, device=notes.device)
@@ -220,7 +223,10 @@ class TTFT2VXAttnFn(torch.autograd.Function):
                                                     ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
                   "ttf_t2v_xattn_backward")
         _fire(ctx.done_hook)
-        return (None,) * 11 + tuple(rets)
+        if ctx.no_proj:         # (proj_out's gradients come out of the consumer's backward)
+            rets = list(rets)
+            rets[15] = rets[16] = None
+        return (None,) * 12 + tuple(rets)
 
 
 # ------------------------------------------------------------------------------------------------ TTF_RecAvg
@@ -474,6 +480,9 @@ class MMFXRankPFn(torch.autograd.Function):
     def forward(ctx, E, Cc, H, precision, done_hook, *params9):
         lib = _lib.load()
         E = _c(E)
+        # "_z" form: two more parameters, the producer's last linear map (proj_out.weight, .bias); E is then Z, its input
+        proj = tuple(_c(p) for p in params9[9:11]) if len(params9) == 11 else None
+        params9 = params9[:9]
         params = tuple(_c(p) for p in params9) + (None, None)
         _need_gpu(E, *params)
         B, T, d = E.shape
@@ -501,18 +510,29 @@ class MMFXRankPFn(torch.autograd.Function):
                 check(lib.immtsf_flag_wait(config.fold_flag[0], config.fold_flag[1], 50, cur.cuda_stream), "flag_wait")
             else:
                 cur.wait_stream(L)
-        check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(),
-                                             0 if L is None else 1, stream_ptr()), "mmf_xrank_p_forward")
+        if proj is not None:
+            _need_gpu(*proj)
+            check(lib.immtsf_mmf_xrank_p_forward_z(C.byref(cfg), C.byref(ps), ptr(proj[0]), ptr(proj[1]), ptr(E), ptr(P), ptr(bHO), ptr(ws),
+                                                   ws.numel(), 0 if L is None else 1, stream_ptr()), "mmf_xrank_p_forward_z")
+        else:
+            check(lib.immtsf_mmf_xrank_p_forward(C.byref(cfg), C.byref(ps), ptr(E), ptr(P), ptr(bHO), ptr(ws), ws.numel(),
+                                                 0 if L is None else 1, stream_ptr()), "mmf_xrank_p_forward")
         ctx.cfg, ctx.ws = cfg, ws
         ctx.sinks = _sinks_of(params)
         ctx.done_hook = done_hook          # the block's gradients are final once THIS half's backward has run
-        ctx.save_for_backward(E, *params[:9])
+        ctx.has_proj = proj is not None
+        ctx.proj_sinks = _sinks_of(proj) if proj is not None else None
+        ctx.save_for_backward(E, *params[:9], *(proj or ()))
         return P, bHO
 
     @staticmethod
     def backward(ctx, dP, dbHO):
         lib = _lib.load()
         E, *params9 = ctx.saved_tensors
+        proj = None
+        if ctx.has_proj:
+            proj, params9 = params9[9:11], params9[:9]
+            pgrads, prets = _grad_buffers(proj, ctx.proj_sinks)
         params = list(params9) + [None, None]
         grads, rets = _grad_buffers(params, ctx.sinks)
         dE = torch.empty_like(E)
@@ -526,14 +546,25 @@ class MMFXRankPFn(torch.autograd.Function):
             dP_h = _shadow_get(dP)
             cfg.in_h = None if dP_h is None else dP_h.data_ptr()
             cfg.aux_h = None if ctx.E_h is None else ctx.E_h.data_ptr()
-            dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
-            cfg.out_h = dE_h.data_ptr()
+            if proj is None:        # ("_z" form: the producer's backward reads dZ as fp32 rows only)
+                dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
+                cfg.out_h = dE_h.data_ptr()
+            else:
+                cfg.out_h = None
+
+        def data_half():
+            if proj is not None:
+                check(lib.immtsf_mmf_xrank_p_backward_data_z(C.byref(cfg), C.byref(ps), ptr(proj[0]), ptr(proj[1]), ptr(E), ptr(dP), ptr(dE),
+                                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), ptr(pgrads[0]), ptr(pgrads[1]),
+                                                             stream_ptr()), "mmf_xrank_p_backward_data_z")
+            else:
+                check(lib.immtsf_mmf_xrank_p_backward_data(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
+                                                           sc.numel(), stream_ptr()), "mmf_xrank_p_backward_data")
         tail = config.param_tail
         if tail is not None and all(r is None for r in rets[:9]) and tail["defer"] > 0:
             # every gradient goes straight to its sink: the last `defer` launches of the parameter chain are left to the other branch
             k = 3 - min(3, int(tail["defer"]))
-            check(lib.immtsf_mmf_xrank_p_backward_data(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
-                                                       sc.numel(), stream_ptr()), "mmf_xrank_p_backward_data")
+            data_half()
             ws = ctx.ws
 
             def run_params(stream, first, last, cfg=cfg, ps=ps, gs=gs, dbHO=dbHO, ws=ws, sc=sc, keep=(params, grads)):
@@ -545,12 +576,13 @@ class MMFXRankPFn(torch.autograd.Function):
             check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
             tail["jobs"].append(lambda stream: run_params(stream, k, 3))
         else:
-            check(lib.immtsf_mmf_xrank_p_backward(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dbHO), ptr(dE), ptr(ctx.ws), ctx.ws.numel(),
-                                                  ptr(sc), sc.numel(), C.byref(gs), stream_ptr()), "mmf_xrank_p_backward")
+            data_half()
+            check(lib.immtsf_mmf_xrank_p_backward_params(C.byref(cfg), C.byref(ps), ptr(dbHO), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
+                                                         C.byref(gs), 0, 3, stream_ptr()), "mmf_xrank_p_backward_params")
         if dE_h is not None:
             _shadow_put(dE, dE_h)
         _fire(ctx.done_hook)
-        return (dE, None, None, None, None) + tuple(rets[:9])
+        return (dE, None, None, None, None) + tuple(rets[:9]) + (tuple(prets) if proj is not None else ())
 
 
 class MMFXRankQFn(torch.autograd.Function):

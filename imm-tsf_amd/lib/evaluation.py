@@ -67,8 +67,7 @@ def forecast_and_fuse(model, fusion, batch_dict, side_stream=None, loss=None):
     # enqueued (and, under hipGraph capture, placed in the graph's submission order) BEFORE the key/value-half and TTF
     # backward instead of behind them (r02 trace: placed last it started 200 us after its input was ready).  Re-measured after
     # the launch cuts of r02 (backbone first / text first): 0.908 / 0.906 ms per step -- no difference any more.
-    E_txt, M_txt = fusion.ttf(notes, tau, tp)
-    kv = fusion.mmf.project_kv(E_txt) if hasattr(fusion.mmf, "project_kv") else None    # text-only half of the MMF block
+    E_txt, M_txt, kv = fusion.text_side(notes, tau, tp)      # TTF + the text-only half of the MMF block
     with torch.cuda.stream(side_stream):
         pred_y = model.forecasting(*fc_args)
     main.wait_stream(side_stream)

@@ -37,6 +37,8 @@ extern "C" {
 
 #define IMMTSF_ABI_VERSION 3
 #define IMMTSF_T2V_FOLD_MIN_ROWS 8192 /* see immtsf_fusion_cfg.form */
+#define IMMTSF_FORM_NO_PROJ 16        /* immtsf_fusion_cfg.form bit, TTF_T2V_XAttn: leave proj_out to the consumer (E_txt := Z, dE_txt := dZ,
+                                         which the backward overwrites in place; proj_out's gradients are not written) */
 
 #define IMMTSF_OK 0
 #define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
@@ -240,6 +242,17 @@ int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_
 int immtsf_mmf_xrank_p_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* dbHO, void* workspace,
                                        size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
                                        int32_t first, int32_t last, immtsf_stream_t stream);
+/* The P half when the text side's producer ends in a linear map whose only consumer is this projection (TTF_T2V_XAttn's proj_out,
+ * fusions/TTF_T2V_XAttn.py:182, called with immtsf_fusion_cfg.form | IMMTSF_FORM_NO_PROJ so that it hands over Z = its LayerNorm +
+ * dropout output): P = [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T -- the (B T) x d x d product, its data and weight gradients
+ * become PW-row products, E_txt / dE_txt are never formed.  backward_data_z writes dZ, the producer's gradients (g_proj_w, g_proj_b) and
+ * leaves dW_fold / db_fold in `scratch` for immtsf_mmf_xrank_p_backward_params. */
+int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
+                                 const float* Z, float* P, float* bHO, void* workspace, size_t workspace_bytes, int32_t folded,
+                                 immtsf_stream_t stream);
+int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
+                                       const float* Z, const float* dP, float* dZ, void* workspace, size_t workspace_bytes, void* scratch,
+                                       size_t scratch_bytes, float* g_proj_w, float* g_proj_b, immtsf_stream_t stream);
 int immtsf_mmf_xrank_q_forward(const immtsf_fusion_cfg* cfg, const float* ln_w, const float* ln_b, const float* Y_ts, const float* P,
                                const float* bHO, const uint8_t* M_txt, float* Y_out, void* workspace, size_t workspace_bytes,
                                immtsf_stream_t stream);

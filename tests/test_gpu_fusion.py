@@ -912,6 +912,66 @@ def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, pac
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("form", ["fold", "chain"])
+@pytest.mark.parametrize("B,N,T,d_m,d,H,Cc,pd", [(5, 6, 7, 48, 32, 1, 3, 0.0), (6, 32, 32, 96, 64, 2, 8, 0.2), (64, 32, 32, 768, 768, 1, 8, 0.1)])
+def test_fused_tail_equals_separate_blocks(B, N, T, d_m, d, H, Cc, pd, form, precision):
+    """FusionModel with TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection (immtsf.config.fuse_tail = True:
+    the TTF block hands over Z, its LayerNorm + dropout output, and the P half computes [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T --
+    csrc/xrank.hip immtsf_mmf_xrank_p_forward_z / _backward_data_z) against the two blocks as written (fuse_tail = False): output, dY_ts
+    and every parameter gradient incl. proj_out's, both TTF forms, with dropout (same Philox sites).  reference:
+    fusions/TTF_T2V_XAttn.py:177-182 feeding fusions/MMF_XAttn_Add.py:56-75."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    register_d_model(f"FT{d_m}", d_m)
+    config.precision = precision
+    torch.manual_seed(B * 10 + T)
+    a = types.SimpleNamespace(TTF_module="TTF_T2V_XAttn", MMF_module="MMF_XAttn_Add", llm_model_fusion=f"FT{d_m}", llm_layers_fusion=6,
+                              max_length=1024, device="cuda", use_text_embeddings=True, recency_sigma=1.0, n_heads_fusion=H, dropout=pd,
+                              d_txt=d, C=Cc, kappa=0.5)
+    m = FusionModel(a).to(dev).train()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    g = torch.Generator().manual_seed(B + 3 * T)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    if B > 2:
+        lengths[1] = 0
+    keep = torch.arange(N).view(1, -1) < lengths.view(-1, 1)
+    notes = (torch.randn(B, N, d_m, generator=g) * keep.unsqueeze(-1)).to(dev)
+    tau = (torch.sort(torch.rand(B, N, generator=g) * 24.0, dim=1).values * keep).to(dev)
+    t_hat = torch.rand(B, T, generator=g).to(dev)
+    Y = torch.randn(B, T, Cc, generator=g).to(dev)
+    up = torch.randn(B, T, Cc, generator=g).to(dev)
+    res, seed0 = [], config.next_seed
+    try:
+        config.t2v_form = form
+        for fuse in (True, False):
+            config.fuse_tail = fuse
+            seeds = iter([5151, 6262, 7373, 8484])
+            config.next_seed = lambda: next(seeds)
+            assert m.fused_tail(B * T, T) == fuse
+            m.zero_grad()
+            y = Y.clone().requires_grad_(True)
+            out = m(notes, tau, t_hat, y)
+            (out * up).sum().backward()
+            res.append([("out", out.detach()), ("dY", y.grad)] + [(k, p_.grad.clone()) for k, p_ in m.named_parameters()])
+    finally:
+        config.next_seed, config.fuse_tail, config.t2v_form, config.precision = seed0, "auto", "auto", "fp32"
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][2:])
+    for (k, a_), (_, b_) in zip(*res):
+        assert torch.isfinite(a_).all(), k
+        den = float(b_.norm()) + (1e-3 * gmax * b_.numel() ** 0.5 if k not in ("out", "dY") else 1e-6) + 1e-30
+        err = float((a_ - b_).norm()) / den
+        # (bf16: Time2Vec's two scalar gradients are sums over every note with heavy cancellation -- the bar tests/test_gpu_train.py's
+        # oracle comparison uses for them)
+        assert err <= (2.5e-1 if precision == "bf16" and k.startswith("ttf.time2vec.linear") else tol), (k, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (64, 32, 8, 768, 1, 0.1), (300, 6, 15, 16, 1, 0.1)])
 def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precision):
     """MMF_XAttn_Add.forward_loss (immtsf_mmf_xrank_q_train: the Q half, the masked MSE with known observation counts and the backward

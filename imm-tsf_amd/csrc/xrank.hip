@@ -1442,16 +1442,9 @@ int immtsf_mmf_xrank_p_forward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_p
  * fusions/TTF_T2V_XAttn.py:182) whose only consumer is this projection, so P = [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T: the
  * (B T) x d x d product, its data gradient and its weight gradient become PW-row products (PW = 24 at cfg2), E_txt and dE_txt are
  * never formed.  proj_w (d, d), proj_b (d): the producer's parameters; their gradients come out of the backward here. */
-int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
-                                 const float* Z, float* P, float* bHO, void* workspace, size_t workspace_bytes, int32_t folded,
-                                 immtsf_stream_t stream) {
-    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !P || !bHO || !workspace) return IMMTSF_EINVAL;
-    XPWs w = carve_xp(cfg, workspace);
-    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
-    if (!folded) CHECK(immtsf_mmf_xrank_fold(cfg, p, bHO, workspace, workspace_bytes, stream));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+static int xrank_compose_z(const immtsf_fusion_cfg* cfg, const float* proj_w, const float* proj_b, const XPWs& w, hipStream_t s) {
     const XRDims x = xr_dims(cfg);
-    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
+    const int d = x.d, prec = cfg->precision;
     const bool hf = xr_hf(cfg);
     Mat Wpo;
     CHECK(weight_mat(hf, proj_w, (size_t)d * d, w.Wpo16, s, &Wpo));
@@ -1465,6 +1458,29 @@ int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd
         l.add(VJ_MV, w.Wf, d, proj_b, w.Wfb, w.bc, x.PW, d);
         CHECK(launch_vecjobs(l, s));
     }
+    return IMMTSF_OK;
+}
+
+/* immtsf_mmf_xrank_fold + the composition with the producer's last linear map (Wc, bc): everything of the "_z" forward that depends on
+ * parameters only -- may run ahead of time on any stream, before immtsf_mmf_xrank_p_forward_z(..., folded = 1, ...) */
+int immtsf_mmf_xrank_fold_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b, float* bHO,
+                            void* workspace, size_t workspace_bytes, immtsf_stream_t stream) {
+    if (!proj_w || !proj_b) return IMMTSF_EINVAL;
+    CHECK(immtsf_mmf_xrank_fold(cfg, p, bHO, workspace, workspace_bytes, stream));
+    return xrank_compose_z(cfg, proj_w, proj_b, carve_xp(cfg, workspace), static_cast<hipStream_t>(stream));
+}
+
+int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
+                                 const float* Z, float* P, float* bHO, void* workspace, size_t workspace_bytes, int32_t folded,
+                                 immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !P || !bHO || !workspace) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    if (!folded) CHECK(immtsf_mmf_xrank_fold_z(cfg, p, proj_w, proj_b, bHO, workspace, workspace_bytes, stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, BT = x.B * x.T, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
     Mat Zm = cmat(Z);
     if (hf && cfg->in_h) {
         Zm.h = const_cast<void*>(cfg->in_h);
@@ -1480,13 +1496,11 @@ int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd
     return IMMTSF_OK;
 }
 
-/* the data half of the "_z" backward: dZ = dP Wc, dWc = dP^T Z (+ column sums), then -- parameters only -- dW_fold = dWc W_po^T +
- * dbc b_po^T, db_fold = dbc (left in `scratch` for immtsf_mmf_xrank_p_backward_params) and the producer's gradients dW_po = W_fold^T dWc,
- * db_po = W_fold^T dbc (written to g_proj_w / g_proj_b) */
+/* the data half of the "_z" backward: dZ = dP Wc, dWc = dP^T Z (+ column sums) */
 int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
                                        const float* Z, const float* dP, float* dZ, void* workspace, size_t workspace_bytes, void* scratch,
-                                       size_t scratch_bytes, float* g_proj_w, float* g_proj_b, immtsf_stream_t stream) {
-    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !dP || !dZ || !workspace || !scratch || !g_proj_w || !g_proj_b) return IMMTSF_EINVAL;
+                                       size_t scratch_bytes, immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !p || !proj_w || !proj_b || !Z || !dP || !dZ || !workspace || !scratch) return IMMTSF_EINVAL;
     XPWs w = carve_xp(cfg, workspace);
     XPScratch sc = carve_xp_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
@@ -1517,6 +1531,25 @@ int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immts
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
     }
     if (hf) CHECK(launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * d, s));
+    return IMMTSF_OK;
+}
+
+/* the parameter-only step between ..._backward_data_z and immtsf_mmf_xrank_p_backward_params: dW_fold = dWc W_po^T + dbc b_po^T, db_fold
+ * = dbc (left in `scratch`) and the producer's gradients dW_po = W_fold^T dWc, db_po = W_fold^T dbc -- any stream ordered behind the data
+ * half (immtsf.train.FlagStep leaves it, with the parameter chain, to the branch that has time to spare) */
+int immtsf_mmf_xrank_p_backward_pre_z(const immtsf_fusion_cfg* cfg, const float* proj_w, const float* proj_b, void* workspace,
+                                      size_t workspace_bytes, void* scratch, size_t scratch_bytes, float* g_proj_w, float* g_proj_b,
+                                      immtsf_stream_t stream) {
+    if (!xr_supported(cfg) || !proj_w || !proj_b || !workspace || !scratch || !g_proj_w || !g_proj_b) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    XPScratch sc = carve_xp_scratch(cfg, scratch);
+    if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const XRDims x = xr_dims(cfg);
+    const int d = x.d, prec = cfg->precision;
+    const bool hf = xr_hf(cfg);
+    Mat Wpo;
+    CHECK(weight_mat(hf, proj_w, (size_t)d * d, w.Wpo16, s, &Wpo));
     {   // dW_fold = dWc W_po^T
         GemmArgs g = gemm_args(x.PW, d, d, d, d, d);
         set_problem2(g, 0, mat(sc.dWc, sc.dWc16), Wpo, mat(sc.dWf), nullptr);

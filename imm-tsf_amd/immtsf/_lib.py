@@ -125,10 +125,13 @@ _PROTOS = {
                                             C.c_void_p, C.c_size_t, _P(XAddParams), c_stream]),
     "immtsf_mmf_xrank_p_backward_data": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xrank_fold_z": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
     "immtsf_mmf_xrank_p_forward_z": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t,
                                              C.c_int32, c_stream]),
     "immtsf_mmf_xrank_p_backward_data_z": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
-                                                   C.c_size_t, C.c_void_p, C.c_size_t, c_f32p, c_f32p, c_stream]),
+                                                   C.c_size_t, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_xrank_p_backward_pre_z": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, c_f32p,
+                                                  c_f32p, c_stream]),
     "immtsf_mmf_xrank_p_backward_params": (C.c_int, [_P(FusionCfg), _P(XAddParams), c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
                                                    C.c_size_t, _P(XAddParams), C.c_int32, C.c_int32, c_stream]),
     "immtsf_mmf_xrank_q_forward": (C.c_int, [_P(FusionCfg), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_u8p, c_f32p, C.c_void_p,

@@ -504,7 +504,11 @@ class MMFXRankPFn(torch.autograd.Function):
             cur = torch.cuda.current_stream()
             ws.record_stream(L)
             bHO.record_stream(L)
-            check(lib.immtsf_mmf_xrank_fold(C.byref(cfg), C.byref(ps), ptr(bHO), ptr(ws), ws.numel(), L.cuda_stream), "mmf_xrank_fold")
+            if proj is not None:
+                check(lib.immtsf_mmf_xrank_fold_z(C.byref(cfg), C.byref(ps), ptr(proj[0]), ptr(proj[1]), ptr(bHO), ptr(ws), ws.numel(),
+                                                  L.cuda_stream), "mmf_xrank_fold_z")
+            else:
+                check(lib.immtsf_mmf_xrank_fold(C.byref(cfg), C.byref(ps), ptr(bHO), ptr(ws), ws.numel(), L.cuda_stream), "mmf_xrank_fold")
             if config.fold_flag is not None:      # hand-over through a device flag (no graph edge): (flag address, time-out report address)
                 check(lib.immtsf_flag_set(config.fold_flag[0], L.cuda_stream), "flag_set")
                 check(lib.immtsf_flag_wait(config.fold_flag[0], config.fold_flag[1], 50, cur.cuda_stream), "flag_wait")
@@ -552,11 +556,18 @@ class MMFXRankPFn(torch.autograd.Function):
             else:
                 cfg.out_h = None
 
+        ws0 = ctx.ws
+
+        def pre(stream):           # "_z" form: the parameter-only step in front of the chain (dW_fold from dWc; proj_out's gradients)
+            if proj is not None:
+                check(lib.immtsf_mmf_xrank_p_backward_pre_z(C.byref(cfg), ptr(proj[0]), ptr(proj[1]), ptr(ws0), ws0.numel(), ptr(sc), sc.numel(),
+                                                            ptr(pgrads[0]), ptr(pgrads[1]), stream), "mmf_xrank_p_backward_pre_z")
+
         def data_half():
             if proj is not None:
                 check(lib.immtsf_mmf_xrank_p_backward_data_z(C.byref(cfg), C.byref(ps), ptr(proj[0]), ptr(proj[1]), ptr(E), ptr(dP), ptr(dE),
-                                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), ptr(pgrads[0]), ptr(pgrads[1]),
-                                                             stream_ptr()), "mmf_xrank_p_backward_data_z")
+                                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), stream_ptr()),
+                      "mmf_xrank_p_backward_data_z")
             else:
                 check(lib.immtsf_mmf_xrank_p_backward_data(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
                                                            sc.numel(), stream_ptr()), "mmf_xrank_p_backward_data")
@@ -572,11 +583,16 @@ class MMFXRankPFn(torch.autograd.Function):
                                                              C.byref(gs), first, last, stream), "mmf_xrank_p_backward_params")
 
             if k > 0:
+                pre(stream_ptr())
                 run_params(stream_ptr(), 0, k)
             check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
-            tail["jobs"].append(lambda stream: run_params(stream, k, 3))
+            if k > 0:
+                tail["jobs"].append(lambda stream: run_params(stream, k, 3))
+            else:
+                tail["jobs"].append(lambda stream: (pre(stream), run_params(stream, 0, 3)))
         else:
             data_half()
+            pre(stream_ptr())
             check(lib.immtsf_mmf_xrank_p_backward_params(C.byref(cfg), C.byref(ps), ptr(dbHO), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
                                                          C.byref(gs), 0, 3, stream_ptr()), "mmf_xrank_p_backward_params")
         if dE_h is not None:

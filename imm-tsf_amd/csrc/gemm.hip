@@ -700,6 +700,7 @@ int g_variant = 0, g_splitk = 0, g_xcd = 1, g_dbg = 0, g_tn_spec = 1, g_xcd2d = 
 void immtsf_gemm_note_grid(long threads) { g_last_grid_threads = threads; }
 
 extern int g_immtsf_ttcn_fused;      // ttcn.hip
+extern int g_immtsf_ttcn_bwd_grid;   // ttcn_full.hip
 
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_immtsf_ttcn_fused = (variant & 0x8000) ? 0 : 1;   // bit 15: TTCN on the streaming formulation (A/B measurements)
@@ -709,6 +710,7 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_tn_spec = (variant & 0x2000) ? 0 : 1;  // bit 13 disables the specialised weight-gradient choice (A/B measurements)
     g_xcd2d = (variant & 0x4000) ? 1 : 0;    // bit 14: allow the 2-D XCD order (measured slower at the fusion shapes: off)
     g_force_old = (variant & 0x10000) ? 1 : 0;
+    g_immtsf_ttcn_bwd_grid = (variant >> 17) & 1023;      // bits 17..26: persistent workgroups of the on-chip TTCN backward (0 = rule)
     g_splitk = splitk;
     return 0;
 }

@@ -22,6 +22,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+int g_immtsf_ttcn_bwd_grid = 0;
+
 namespace {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -659,7 +661,7 @@ int launch_ttcn_full_bwd(int P, int L, int F, int K, const float* x, const float
     // cfg2 step, beside the text-side backward GEMMs on the other stream: one wave / SIMD at 160 / 192 / 224 / 256 workgroups ->
     // 0.891 / 0.882 / 0.874 / 0.887 ms (later 0.850 at 224); two waves / SIMD at 256 / 342 / 384 / 448 / 512 -> 0.856 / 0.847 / 0.839 /
     // 0.841 / 0.852.  Alone (P = 1024): 103 us at 224 x 1 wave, 80 us at 448 x 2 waves.
-    constexpr int genv = 0;
+    const int genv = g_immtsf_ttcn_bwd_grid;      // tool switch (immtsf_debug_gemm_config bits 17..26), 0 = the rule below
     int gmax = genv > 0 ? genv : (L <= 32 ? (P >= 8192 ? 512 : 384) : 224);     // many patches: exactly two workgroups per CU
     gmax = gmax > kMaxBwdGrid ? kMaxBwdGrid : gmax;
     const int grid = P < gmax ? P : gmax;

@@ -435,7 +435,7 @@ def flag_step(w):
     fns = flag_fns(w)
     if fns is None or w.trainer.sharded:
         return None
-    st = FlagStep(w.trainer, *fns)
+    st = FlagStep(w.trainer, *fns, **json.loads(os.environ.get("IMMTSF_BENCH_FLAG_KW", "{}")))      # (A/B measurements only)
     snap = w.trainer.snapshot()
     for _ in range(3):
         st()

@@ -80,23 +80,78 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 struct TEp { const float *ws, *bs, *wp, *bp; };
 
+// ---- per-patch inputs.  A persistent workgroup loads the NEXT patch's rows (t, x, mask; the backward: the pooled contributions
+// and the masked output gradient as well) into registers at the top of a patch and parks them in the other half of a double-buffered LDS
+// block just before the patch's last barrier: the global-load latency (1-2 us under load, paid twice per patch when the loads sat in
+// front of their uses: a third of a patch's timeline) is hidden behind the patch's own work.
+// block layout (floats): t [ROWS] | x [ROWS] | mask [ROWS] | (backward) dp [KP] | ctr [NCq]
+template <int RT, bool BWD>
+struct PatchIn {
+    static constexpr int ROWS = RT * 16, HEAD = 3 * ROWS + (BWD ? KP : 0);
+    float row, c[2];
+    __device__ __forceinline__ void fetch(const FD& d, int p, const float* __restrict__ x, const float* __restrict__ tt,
+                                          const float* __restrict__ mask, const float* __restrict__ ctr, const float* __restrict__ out,
+                                          const float* __restrict__ dout, int out_ld) {
+        const int tid = threadIdx.x;
+        row = 0.f; c[0] = c[1] = 0.f;
+        if (tid < 3 * ROWS) {
+            const int which = tid / ROWS, l = tid % ROWS;
+            if (l < d.L) row = (which == 0 ? tt : which == 1 ? x : mask)[(size_t)p * d.L + l];
+        } else if (BWD && tid < HEAD) {
+            const int k = tid - 3 * ROWS;
+            if (k < d.K) row = out[(size_t)p * out_ld + k] > 0.f ? dout[(size_t)p * out_ld + k] : 0.f;
+        }
+        if (BWD) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                if (i < d.NCq) c[j] = ctr[(size_t)p * d.NCq + i];
+            }
+        }
+    }
+    __device__ __forceinline__ void park(const FD& d, float* blk) const {
+        const int tid = threadIdx.x;
+        if (tid < HEAD) blk[tid] = row;
+        if (BWD) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = tid + 256 * j;
+                if (i < d.NCq) blk[HEAD + i] = c[j];
+            }
+        }
+    }
+};
+
+// a thread's column of X never changes (f = tid & 31): its time-embedding parameters live in registers for the whole kernel
+struct XCol { float w, b; int kind; };      // kind 0: the value column, 1: linear, 2: periodic, 3: padding
+__device__ __forceinline__ XCol x_col(const FD& d, TEp te) {
+    const int f = threadIdx.x & 31;
+    XCol c{0.f, 0.f, 3};
+    if (f == 0) c.kind = 0;
+    else if (f == 1) { c.w = te.ws[0]; c.b = te.bs[0]; c.kind = 1; }
+    else if (f < d.F) { c.w = te.wp[f - 2]; c.b = te.bp[f - 2]; c.kind = 2; }
+    return c;
+}
+
 // X[l, 0] = x ; X[l, 1] = ws*t+bs ; X[l, 1+j] = sin(wp_j t + bp_j) ; zero padding.  Xb: bf16 [ROWS][PT]; Xf: fp32 [ROWS][16]
+// blk: the patch's staged rows (t | x | ...)
 template <int RT>
-__device__ __forceinline__ void build_x(const FD& d, const float* __restrict__ x, const float* __restrict__ tt, TEp te, int p,
-                                        bf16_t* Xb, float* Xf, float* Xc = nullptr, float* Xct = nullptr) {
+__device__ __forceinline__ void build_x(const FD& d, const XCol xc, const float* blk, bf16_t* Xb, float* Xf, float* Xc = nullptr,
+                                        float* Xct = nullptr) {
     // Xc (backward): d X[l, f] / d(its pre-activation): 0 for the value column, 1 for the linear one, cos(.) for the periodic ones;
     // Xct = Xc * t
-    for (int i = threadIdx.x; i < RT * 16 * KP; i += 256) {
-        const int l = i >> 5, f = i & 31;
+    const int f = threadIdx.x & 31;
+#pragma unroll
+    for (int j = 0; j < RT * 2; ++j) {
+        const int l = (threadIdx.x >> 5) + 8 * j;
         float v = 0.f, c = 0.f, t = 0.f;
-        if (l < d.L && f < d.F) {
-            t = tt[(size_t)p * d.L + l];
-            if (f == 0) v = x[(size_t)p * d.L + l];
-            else if (f == 1) { v = fmaf(te.ws[0], t, te.bs[0]); c = 1.f; }
+        if (l < d.L && xc.kind != 3) {
+            t = blk[l];
+            if (xc.kind == 0) v = blk[RT * 16 + l];
             else {
-                const float ph = fmaf(te.wp[f - 2], t, te.bp[f - 2]);
-                v = __sinf(ph);            // (bf16 mode: v_sin_f32 / v_cos_f32)
-                c = __cosf(ph);
+                const float ph = fmaf(xc.w, t, xc.b);
+                v = xc.kind == 1 ? ph : __sinf(ph);            // (bf16 mode: v_sin_f32 / v_cos_f32)
+                c = xc.kind == 1 ? 1.f : __cosf(ph);
             }
         }
         Xb[l * PT + f] = (bf16_t)v;
@@ -176,7 +231,7 @@ __device__ __forceinline__ float sm_tile(const FD& d, const bf16x8 (&a)[RT], con
 struct Wts { const float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; };     // packed fp32 weights (ttcn_pack_kernel)
 
 // ---------------------------------------------------------------------------------------------------- forward
-// persistent workgroups (grid <= 2048), 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq]
+// persistent workgroups (grid <= 2048), 256 threads.  LDS: Xb | h1s | h2s (bf16 [ROWS][PT]) | Xf fp32 [ROWS][16] | ctr fp32 [NCq] | staged rows fp32 [2][3 ROWS]
 // MF = ceil(F / 4): the f's a wave owns.  Their layer-3 fragments (bf16 image W3h of the pack kernel), biases and the rows' mask
 // values are loaded FIRST, beside the staging loads: in front of their first use they were three dependent round trips (one per
 // f of the wave) on a kernel whose whole timeline is ~10 us.
@@ -192,6 +247,7 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     bf16_t* h2s = h1s + ROWS * PT;
     float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);
     float* cl = Xf + ROWS * 16;
+    float* pin = cl + d.NCq;                      // [2][3 * ROWS]: the patch's staged rows, double-buffered (PatchIn)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     // persistent workgroups (grid <= P): the layer-3 fragments of this wave's f slots, the MLP's weight fragments of its column tile and
     // the biases are loaded ONCE; a workgroup per patch re-fetched them (L2 round trips in front of every phase) 65 536 times at
@@ -199,6 +255,10 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     bf16x8 bw[MF][2];
     float b3v[MF][2], mk[RT][4];
     const int tnt = wave & 1;
+    typedef PatchIn<RT, false> PI;
+    PI nx;
+    nx.fetch(d, blockIdx.x, x, tt, mask, nullptr, nullptr, nullptr, 0);
+    const XCol xc = x_col(d, te);
     const bf16x8 mw1 = load8_bf16(w.W1p + (tnt * 16 + fr) * KP + fq * 8), mw2 = load8_bf16(w.W2p + (tnt * 16 + fr) * KP + fq * 8);
     const float mb1 = w.b1p[tnt * 16 + fr], mb2 = w.b2p[tnt * 16 + fr];
     const float tb = tid < d.K ? Tb[tid] : 0.f;
@@ -211,15 +271,18 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
             b3v[j][half] = 0.f;
             if (f < d.F) { bw[j][half] = *reinterpret_cast<const bf16x8*>(W3h + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
         }
-    for (int p = blockIdx.x; p < d.P; p += gridDim.x) {
+    nx.park(d, pin);
+    __syncthreads();
+    int it = 0;
+    for (int p = blockIdx.x; p < d.P; p += gridDim.x, ++it) {
+    const float* cur = pin + (it & 1) * PI::HEAD;
+    const int pn = p + gridDim.x;
+    if (pn < d.P) nx.fetch(d, pn, x, tt, mask, nullptr, nullptr, nullptr, 0);
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + fq * 4 + r;
-            mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
-        }
-    build_x<RT>(d, x, tt, te, p, Xb, Xf);
+        for (int r = 0; r < 4; ++r) mk[rt][r] = cur[2 * ROWS + rt * 16 + fq * 4 + r];      // (0 past L)
+    build_x<RT>(d, xc, cur, Xb, Xf);
     __syncthreads();
     mlp_layer_frag<RT>(Xb, h1s, mw1, mb1, wave, fr, fq);
     __syncthreads();
@@ -250,16 +313,17 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
             }
         }
     }
+    if (pn < d.P) nx.park(d, pin + ((it + 1) & 1) * PI::HEAD);     // (that half was last read in the previous patch)
     __syncthreads();
     if (tid < d.K) {
         float s = tb;
         for (int f = 0; f < d.F; ++f) s += cl[f * 32 + tid];
         out[(size_t)p * out_ld + tid] = fmaxf(s, 0.f);
     }
-    if (flag_col >= 0 && tid == 64) {
-        float any = 0.f;
-        for (int l = 0; l < d.L; ++l) any += mask[(size_t)p * d.L + l];
-        out[(size_t)p * out_ld + flag_col] = any > 0.f ? 1.f : 0.f;
+    if (flag_col >= 0 && wave == 1) {
+        float any = lane < d.L ? cur[2 * ROWS + lane] : 0.f;
+        any = wave_sum(any);
+        if (lane == 0) out[(size_t)p * out_ld + flag_col] = any > 0.f ? 1.f : 0.f;
     }
     __syncthreads();        // the next patch rewrites every LDS tile (and cl)
     }   // patches
@@ -270,7 +334,7 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
 struct WtsT { const bf16_t *W3T /*[k2][c']*/, *W2T /*[k1][k2]*/, *W1T /*[f][k1]*/, *W3h /*[c'][k2]*/; };
 
 // persistent workgroups, 256 threads.  LDS: Xb | h1s | h2s | dz2s | dz1s (bf16 [ROWS][PT]) | dS bf16 [ROWS][NCq+8] |
-// Xf, Xc, Xct fp32 [ROWS][16] | cts fp32 [NCq] | dp fp32 [32] | W3s bf16 [NCq][PT]
+// Xf, Xc, Xct fp32 [ROWS][16] | staged patch inputs fp32 [2][3 ROWS + 32 + NCq] (PatchIn) | W3s bf16 [NCq][PT]
 // MF = ceil(F / 4): the f slots a wave owns (its layer-3 fragments and dW3 tiles live in registers for the whole kernel)
 template <int RT, int MF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2 : 1))) void ttcn_full_bwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
@@ -289,14 +353,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
     float* Xf = reinterpret_cast<float*>(dS + ROWS * pitchC);
     float* Xc = Xf + ROWS * 16;
     float* Xct = Xc + ROWS * 16;
-    float* cts = Xct + ROWS * 16;
-    float* dp = cts + d.NCq;
-    bf16_t* W3s = reinterpret_cast<bf16_t*>(dp + KP);       // [NCq][PT]: layer-3 weights, rows c' (k2 contiguous) -- see below
+    typedef PatchIn<RT, true> PI;
+    const int PIN = PI::HEAD + d.NCq;                       // floats of one staged patch: t | x | mask | dp | ctr
+    float* pin = Xct + ROWS * 16;                           // [2][PIN]
+    bf16_t* W3s = reinterpret_cast<bf16_t*>(pin + 2 * PIN); // [NCq][PT]: layer-3 weights, rows c' (k2 contiguous) -- see below
     bf16_t* W1s = W3s + d.NCq * PT;                         // [k1][PT] (f contiguous), [k2][PT] (k1 contiguous): the MLP's weights; their
     bf16_t* W2s = W1s + KP * PT;                            // transposes (data-gradient products) are read through the hardware transpose
     float* b3s = reinterpret_cast<float*>(W2s + KP * PT);   // [NCq] layer-3 bias
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const Slab sl = slab_of(d.F);
+    PI nx;
+    nx.fetch(d, blockIdx.x, x, tt, mask, ctr, out, dout, out_ld);
+    const XCol xc = x_col(d, te);
     // The layer-3 weights are read twice per patch (logits: rows c' as B fragments; dz2 = dS W3: the same image through the
     // hardware transpose) -- 17 dependent L2 round trips per patch per wave when fetched from global memory, a fifth of the
     // patch's timeline.  A persistent workgroup stages them once.
@@ -332,15 +400,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
 #pragma unroll
     for (int j = 0; j < MF; ++j) tpw[j] = tpb[j] = 0.f;
 
-    for (int p = blockIdx.x; p < d.P; p += gridDim.x) {
-        // ---- stage
-        if (tid < KP) {
-            float g = 0.f;
-            if (tid < d.K) g = out[(size_t)p * out_ld + tid] > 0.f ? dout[(size_t)p * out_ld + tid] : 0.f;
-            dp[tid] = g;
-        }
-        for (int i = tid; i < d.NCq; i += 256) cts[i] = ctr[(size_t)p * d.NCq + i];
-        build_x<RT>(d, x, tt, te, p, Xb, Xf, Xc, Xct);
+    nx.park(d, pin);
+    __syncthreads();
+    int it = 0;
+    for (int p = blockIdx.x; p < d.P; p += gridDim.x, ++it) {
+        // ---- stage: this patch's rows are in LDS already; the next patch's loads start here
+        const float* cur = pin + (it & 1) * PIN;
+        const float *dp = cur + 3 * ROWS, *cts = cur + PI::HEAD;
+        const int pn = p + gridDim.x;
+        if (pn < d.P) nx.fetch(d, pn, x, tt, mask, ctr, out, dout, out_ld);
+        build_x<RT>(d, xc, cur, Xb, Xf, Xc, Xct);
         __syncthreads();
         if (tid >= 128 && tid < 128 + KP) accb += dp[tid - 128];
         mlp_layer_frag<RT>(Xb, h1s, frag_row(W1s, PT, tnt * 16, 0, fr, fq), mb1, wave, fr, fq);
@@ -353,10 +422,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
         for (int rt = 0; rt < RT; ++rt) {
             a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rt * 16 + fq * 4 + r;
-                mk[rt][r] = row < d.L ? mask[(size_t)p * d.L + row] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) mk[rt][r] = cur[2 * ROWS + rt * 16 + fq * 4 + r];      // (0 past L)
         }
         // ---- d(logits), tile by tile in registers -> LDS (bf16); pooling-path dX by shuffles; db3
 #pragma unroll
@@ -466,20 +532,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
         }
         for (int rt = (RT == 2 ? wave - 2 : wave); rt >= 0 && rt < RT; rt += 4) {      // RT = 2: waves 2, 3; RT = 4: all four
             const f32x4 acc = mfma(frag_row(dz1s, PT, rt * 16, 0, fr, fq), frag_kmajor(W1s, PT, 0, 0, fr, fq), zero4());            // dXm = dz1 W1, f tile 0
-            const int f = fr;
-            if (f >= 1 && f < d.F) {
+            // d X / d(pre-activation) and its product with t are in LDS (Xc, Xct: zero for the value column, the padding and rows past L)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rt * 16 + fq * 4 + r;
-                    if (row < d.L) {
-                        const float g = acc[r], t = tt[(size_t)p * d.L + row];
-                        const float gg = f == 1 ? g : g * __cosf(fmaf(te.wp[f - 2], t, te.bp[f - 2]));
-                        te_w = fmaf(gg, t, te_w);
-                        te_b += gg;
-                    }
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = (rt * 16 + fq * 4 + r) * 16 + fr;
+                te_w = fmaf(acc[r], Xct[o], te_w);
+                te_b = fmaf(acc[r], Xc[o], te_b);
             }
         }
+        if (pn < d.P) nx.park(d, pin + ((it + 1) & 1) * PIN);     // (that half was last read in the previous patch)
         __syncthreads();     // every LDS tile is rewritten by the next patch
     }
 
@@ -511,7 +572,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
     else if (tid >= 64 && tid < 64 + KP) my[sl.b1 + tid - 64] = accb;
     else if (tid >= 128 && tid < 128 + KP) my[sl.Tb + tid - 128] = accb;
     // time-embedding gradients: several waves hold shares of the same entry -> summed in LDS first
-    float* tes = cts;                 // (every tile of the last patch is dead: the loop ends with a barrier)
+    float* tes = pin;                 // (every tile of the last patch is dead: the loop ends with a barrier)
     if (tid < 2 * KP) tes[tid] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -594,10 +655,10 @@ __global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const fl
 inline int ttcn_unpack_outputs(int F, int K) { return K * F + K * K + F * K * K + F * K + 3 * K + 2 + 2 * (F - 2); }
 constexpr int kMaxBwdGrid = 512;       // slabs in the caller's scratch
 
-size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + 64; }
+size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + (size_t)2 * 3 * RT * 16 * 4 + 64; }
 size_t bwd_lds(int RT, int NCq) {
     const size_t ROWS = RT * 16;
-    return ROWS * PT * 2 * 5 + ROWS * (NCq + 8) * 2 + ROWS * 16 * 4 * 3 + (size_t)NCq * 4 + KP * 4 + (size_t)(NCq + 2 * KP) * PT * 2 + (size_t)NCq * 4 + 64;
+    return ROWS * PT * 2 * 5 + ROWS * (NCq + 8) * 2 + ROWS * 16 * 4 * 3 + 2 * (3 * ROWS + KP + (size_t)NCq) * 4 + (size_t)(NCq + 2 * KP) * PT * 2 + (size_t)NCq * 4 + 64;
 }
 
 struct PackPtrs { float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; bf16_t *W3T, *W2T, *W1T, *W3h; };

@@ -754,10 +754,11 @@ class FlagStep(PhasedStep):
         stream T:  zero-grad, text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ............ wait(B2) | join B | clear, clip + Adam
         stream B:  (forked at the start)   backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
 
-    Parameter-only work of the text side (MMF_XAttn_Add's fold) runs at the head of the backbone's branch, whose forward is the
-    shorter one, and is handed over through a flag as well; the last `param_tail` launches of MMF_XAttn_Add's parameter-gradient
-    chain (work only the optimizer waits for) run at the end of the backbone's branch (DESIGN.md section 6 has every placement that
-    was measured).
+    Parameter-only work of the text side runs on a THIRD branch P (param_branch; forked and joined like B, no edges in between):
+    MMF_XAttn_Add's fold at its head, handed to T through a flag, and MMF_XAttn_Add's parameter-gradient chain (`param_tail`
+    launches of it: work only the optimizer waits for) behind a flag that says its inputs exist.  With param_branch=False both sit
+    on the backbone's branch (fold at its head, the last launch of the chain at its end), which is what rounds 3 measured;
+    the third branch took the 64-window step from 0.536 to 0.496 ms (DESIGN.md section 6 has every placement that was measured).
 
     Data parallel (trainer.collective): the same graph without the optimizer, and the gradient all-reduce BESIDE the backward:
 
@@ -776,7 +777,7 @@ class FlagStep(PhasedStep):
     `flags[8]` is the guard word: `timed_out()` / `check()`."""
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
-                 fold_by_flag: bool = True, head_flag: bool = True):
+                 fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True):
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
         if trainer.sharded:
@@ -787,15 +788,18 @@ class FlagStep(PhasedStep):
         lib = _lib.load()
         self.dist = bool(trainer.collective)
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        # parameter-only work (MMF_XAttn_Add's fold in front, its parameter-gradient chain behind) on a THIRD branch of the graph
+        self.P = torch.cuda.Stream(device=dev) if param_branch else self.B
         # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch (data parallel: none -- the bucket's hook must
         # fire behind its LAST gradient write, on the branch that announces it)
-        self._defer = (0 if self.dist else 1) if param_tail is None else int(param_tail)
+        self._defer = (0 if self.dist else (3 if param_branch else 1)) if param_tail is None else int(param_tail)
         if self.dist:
             trainer.overlap = False           # no collectives from inside the captured backward (the hooks bump flags instead)
             self._defer = 0
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
+        self.P.wait_stream(cur)
         # (before the warm-up: its last Adam pass then leaves the gradient buffer zero, and the captured zero_grad() holds no fill --
         # set afterwards, a 32 MB fill that both branches wait for sat at the head of every replay)
         trainer.zero_in_step = True
@@ -807,7 +811,7 @@ class FlagStep(PhasedStep):
         torch.cuda.synchronize()
         self.flags = torch.zeros(32, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
-        F_B1, F_T2, F_B2, F_ERR = fp, fp + 4, fp + 8, fp + 32
+        F_B1, F_T2, F_B2, F_P2, F_ERR = fp, fp + 4, fp + 8, fp + 20, fp + 32
         self._f_err = F_ERR
         sp = lambda st: st.cuda_stream        # noqa: E731
 
@@ -834,14 +838,16 @@ class FlagStep(PhasedStep):
 
         trainer.step_guard = F_ERR
         self.graph = torch.cuda.CUDAGraph()
-        B = self.B
+        B, P = self.B, self.P
         from . import config
         try:
             with torch.cuda.graph(self.graph):
                 T = torch.cuda.current_stream()
                 trainer.zero_grad()
                 B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
-                config.fold_stream = B                # parameter-only work of the text side: at the head of the backbone's branch
+                if P is not B:
+                    P.wait_stream(T)
+                config.fold_stream = P                # parameter-only work of the text side: on its own branch (or at the head of the backbone's)
                 config.fold_flag = (fp + 12, F_ERR) if fold_by_flag else None
                 try:
                     outs = text_fn()
@@ -884,15 +890,21 @@ class FlagStep(PhasedStep):
                     # reduced behind the graph together with whatever else is left (cfg2: TTF + the backbone, adjacent ranges, ONE
                     # collective); its flag bump stays in the graph, unread
                     announced.discard(self.segments.pop()[3])
-                with torch.cuda.stream(B):
+                with torch.cuda.stream(P):
                     if tail["jobs"]:
-                        fwait(fp + 16, B)
+                        fwait(fp + 16, P)
                         for job in tail["jobs"]:
-                            job(sp(B))
+                            job(sp(P))
+                    if P is not B:
+                        fset(F_P2, P)
+                with torch.cuda.stream(B):
                     fset(F_B2, B)
                 fwait(F_B2, T)
                 T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
-                _lib.check(lib.immtsf_flags_clear(fp, 5, sp(T)), "flags_clear")
+                if P is not B:
+                    fwait(F_P2, T)
+                    T.wait_stream(P)
+                _lib.check(lib.immtsf_flags_clear(fp, 6, sp(T)), "flags_clear")
                 if not self.dist:
                     trainer.step()
             self.graph_b = None

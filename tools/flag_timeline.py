@@ -27,7 +27,7 @@ def main():
     for _ in range(20):
         st()
     base = st.flags.data_ptr()
-    names = {0: "backbone forward done", 4: "head: dY published", 8: "backbone backward done", 12: "fold done", 16: "parameter tail: inputs ready"}
+    names = {0: "backbone forward done", 4: "head: dY published", 8: "backbone backward done", 12: "fold done", 16: "parameter tail: inputs ready", 20: "parameter branch done"}
     _lib.check(lib.immtsf_flag_trace(1), "flag_trace")
     for _ in range(steps):
         st()

@@ -27,6 +27,7 @@ int g_immtsf_ttcn_bwd_grid = 0;
 namespace {
 
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));       // element-wise arithmetic on these compiles to v_pk_{fma,mul,add}_f32
 
 constexpr int KP = 32;        // padded ttcn_dim and padded feature width (one MFMA k-step)
 constexpr int PT = 40;        // pitch (bf16 elements) of the 32-wide LDS tiles: 80-byte rows, conflict-free b128 reads
@@ -133,13 +134,13 @@ __device__ __forceinline__ XCol x_col(const FD& d, TEp te) {
     return c;
 }
 
-// X[l, 0] = x ; X[l, 1] = ws*t+bs ; X[l, 1+j] = sin(wp_j t + bp_j) ; zero padding.  Xb: bf16 [ROWS][PT]; Xf: fp32 [ROWS][16]
-// blk: the patch's staged rows (t | x | ...)
-template <int RT>
-__device__ __forceinline__ void build_x(const FD& d, const XCol xc, const float* blk, bf16_t* Xb, float* Xf, float* Xc = nullptr,
-                                        float* Xct = nullptr) {
-    // Xc (backward): d X[l, f] / d(its pre-activation): 0 for the value column, 1 for the linear one, cos(.) for the periodic ones;
-    // Xct = Xc * t
+// X[l, 0] = x ; X[l, 1] = ws*t+bs ; X[l, 1+j] = sin(wp_j t + bp_j) ; zero padding.  Xb: bf16 [ROWS][PT]; Xf: fp32 [ROWS][16] --
+// or, TR (backward): [16][ROWS + 4], rows contiguous: the accumulator layout gives a lane four consecutive rows of one column, so its
+// share of a column of X (and of Xc, Xct) is ONE 16-byte read.  blk: the patch's staged rows (t | x | ...)
+template <int RT> constexpr int xt_pitch() { return RT * 16 + 4; }
+template <int RT, bool TR = false>
+__device__ __forceinline__ void build_x(const FD& d, const XCol xc, const float* blk, bf16_t* Xb, float* Xf, float* Xc = nullptr) {
+    // Xc (backward): d X[l, f] / d(its pre-activation): 0 for the value column, 1 for the linear one, cos(.) for the periodic ones
     const int f = threadIdx.x & 31;
 #pragma unroll
     for (int j = 0; j < RT * 2; ++j) {
@@ -156,8 +157,9 @@ __device__ __forceinline__ void build_x(const FD& d, const XCol xc, const float*
         }
         Xb[l * PT + f] = (bf16_t)v;
         if (f < 16) {
-            Xf[l * 16 + f] = v;
-            if (Xc) { Xc[l * 16 + f] = c; Xct[l * 16 + f] = c * t; }
+            const int o = TR ? f * xt_pitch<RT>() + l : l * 16 + f;
+            Xf[o] = v;
+            if (Xc) Xc[o] = c;
         }
     }
 }
@@ -186,48 +188,6 @@ __device__ __forceinline__ void mlp_layer_frag(const bf16_t* in, bf16_t* outp, c
     }
 }
 
-// One 16-column tile of the filter logits -> masked softmax over the patch's L rows, in registers.
-// sm[rt][r] = softmax weight of row rt*16 + fq*4 + r (0 for rows >= L); NORM = false: sm is left unnormalised (exp(v - max)) and
-// the column's 1 / sum is returned for the caller to fold into its own factor
-template <int RT, bool NORM = true>
-__device__ __forceinline__ float sm_tile(const FD& d, const bf16x8 (&a)[RT], const bf16x8 b, const float bias,
-                                         const float (&mk)[RT][4], int fq, float (&sm)[RT][4]) {
-    constexpr float LOG2E = 1.4426950408889634f;
-    const float bias2 = bias * LOG2E;
-    float m = -INFINITY;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const f32x4 acc = mfma(a[rt], b, zero4());
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rt * 16 + fq * 4 + r;
-            // reference: Filter * mask + (1 - mask) * (-1e8); mask is 0 / 1, so this select is the same value.  Kept in log2 units
-            // (one fma instead of add + the multiply inside exp)
-            const float v = row < d.L ? (mk[rt][r] != 0.f ? fmaf(acc[r], LOG2E, bias2) : -1e8f * LOG2E) : -INFINITY;
-            sm[rt][r] = v;
-            m = fmaxf(m, v);
-        }
-    }
-    m = col_max(m);
-    float s = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sm[rt][r] = __builtin_amdgcn_exp2f(sm[rt][r] - m);   // exp2(-inf) = 0 for the padded rows; bf16 mode: v_exp_f32 is ample
-            s += sm[rt][r];
-        }
-    s = col_sum(s);
-    const float inv = __builtin_amdgcn_rcpf(s);      // (v_rcp_f32: 1 ulp; __frcp_rn expands to the full IEEE division sequence)
-    if (NORM) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sm[rt][r] *= inv;
-    }
-    return inv;
-}
-
 struct Wts { const float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; };     // packed fp32 weights (ttcn_pack_kernel)
 
 // ---------------------------------------------------------------------------------------------------- forward
@@ -241,19 +201,20 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
                                                              const float* __restrict__ Tb, float* __restrict__ ctr,
                                                              float* __restrict__ out, int out_ld, int flag_col) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ROWS = RT * 16;
+    constexpr int ROWS = RT * 16, XP = xt_pitch<RT>();
+    constexpr float LOG2E = 1.4426950408889634f;
     bf16_t* Xb = reinterpret_cast<bf16_t*>(smem);
     bf16_t* h1s = Xb + ROWS * PT;
     bf16_t* h2s = h1s + ROWS * PT;
-    float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);
-    float* cl = Xf + ROWS * 16;
+    float* Xf = reinterpret_cast<float*>(h2s + ROWS * PT);      // [16][XP]: a lane's four rows of a column are one 16-byte read
+    float* cl = Xf + 16 * XP;
     float* pin = cl + d.NCq;                      // [2][3 * ROWS]: the patch's staged rows, double-buffered (PatchIn)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     // persistent workgroups (grid <= P): the layer-3 fragments of this wave's f slots, the MLP's weight fragments of its column tile and
     // the biases are loaded ONCE; a workgroup per patch re-fetched them (L2 round trips in front of every phase) 65 536 times at
     // 4096 windows
     bf16x8 bw[MF][2];
-    float b3v[MF][2], mk[RT][4];
+    float b3v[MF][2];               // (log2 units)
     const int tnt = wave & 1;
     typedef PatchIn<RT, false> PI;
     PI nx;
@@ -269,7 +230,7 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
             const int f = wave + 4 * j, c = f * 32 + half * 16 + fr;
             bw[j][half] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             b3v[j][half] = 0.f;
-            if (f < d.F) { bw[j][half] = *reinterpret_cast<const bf16x8*>(W3h + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c]; }
+            if (f < d.F) { bw[j][half] = *reinterpret_cast<const bf16x8*>(W3h + (size_t)c * KP + fq * 8); b3v[j][half] = w.b3q[c] * LOG2E; }
         }
     nx.park(d, pin);
     __syncthreads();
@@ -278,34 +239,72 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
     const float* cur = pin + (it & 1) * PI::HEAD;
     const int pn = p + gridDim.x;
     if (pn < d.P) nx.fetch(d, pn, x, tt, mask, nullptr, nullptr, nullptr, 0);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mk[rt][r] = cur[2 * ROWS + rt * 16 + fq * 4 + r];      // (0 past L)
-    build_x<RT>(d, xc, cur, Xb, Xf);
+    build_x<RT, true>(d, xc, cur, Xb, Xf);
     __syncthreads();
     mlp_layer_frag<RT>(Xb, h1s, mw1, mb1, wave, fr, fq);
     __syncthreads();
     mlp_layer_frag<RT>(h1s, h2s, mw2, mb2, wave, fr, fq);
     __syncthreads();
     bf16x8 a[RT];
+    // the lane's rows: live (mask != 0), or the value the reference puts in their place: Filter * mask + (1 - mask) * (-1e8) for a
+    // masked slot (mask is 0 / 1, so a select is the same value), -inf past L -- in log2 units
+    bool on[RT][4];
+    float cval[RT][4];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+    for (int rt = 0; rt < RT; ++rt) {
+        a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(cur + 2 * ROWS + rt * 16 + fq * 4);     // (0 past L)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            on[rt][r] = m4[r] != 0.f;
+            cval[rt][r] = rt * 16 + fq * 4 + r < d.L ? -1e8f * LOG2E : -INFINITY;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
         const int f = wave + 4 * j;
         if (f < d.F) {
+            f32x2 xf[RT][2];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(Xf + f * XP + rt * 16 + fq * 4);
+                xf[rt][0] = f32x2{x4[0], x4[1]};
+                xf[rt][1] = f32x2{x4[2], x4[3]};
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int c = f * 32 + half * 16 + fr;
-                float sm[RT][4];
-                sm_tile<RT>(d, a, bw[j][half], b3v[j][half], mk, fq, sm);
-                float acc = 0.f;
+                // one 16-column tile of the filter logits -> masked softmax over the patch's rows and the pooling, on PAIRS of rows
+                // (v_pk_*_f32); the softmax's 1 / sum is applied to the pooled value, not to the weights
+                const float bias2 = b3v[j][half];
+                f32x2 v[RT][2];
+                float m = -INFINITY;
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const f32x4 acc = mfma(a[rt], bw[j][half], zero4());
+                    v[rt][0] = f32x2{acc[0], acc[1]} * LOG2E + bias2;
+                    v[rt][1] = f32x2{acc[2], acc[3]} * LOG2E + bias2;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            v[rt][h][e] = on[rt][2 * h + e] ? v[rt][h][e] : cval[rt][2 * h + e];
+                            m = fmaxf(m, v[rt][h][e]);
+                        }
+                }
+                m = col_max(m);
+                f32x2 s2{0.f, 0.f}, p2{0.f, 0.f};
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = fmaf(sm[rt][r], Xf[(rt * 16 + fq * 4 + r) * 16 + f], acc);   // sm is 0 past L
-                acc = col_sum(acc);
+                    for (int h = 0; h < 2; ++h) {
+                        v[rt][h] -= m;
+                        v[rt][h][0] = __builtin_amdgcn_exp2f(v[rt][h][0]);   // exp2(-inf) = 0 for the padded rows; bf16 mode: v_exp_f32 is ample
+                        v[rt][h][1] = __builtin_amdgcn_exp2f(v[rt][h][1]);
+                        s2 += v[rt][h];
+                        p2 += v[rt][h] * xf[rt][h];
+                    }
+                const float acc = col_sum(p2[0] + p2[1]) * __builtin_amdgcn_rcpf(col_sum(s2[0] + s2[1]));    // (v_rcp_f32: 1 ulp)
                 if (fq == 0) {
                     cl[c] = acc;
                     ctr[(size_t)p * d.NCq + c] = acc;
@@ -333,33 +332,38 @@ __global__ __launch_bounds__(256) void ttcn_full_fwd_kernel(FD d, const float* _
 // transposed bf16 copies of the weights for the data-gradient products (ttcn_pack_kernel)
 struct WtsT { const bf16_t *W3T /*[k2][c']*/, *W2T /*[k1][k2]*/, *W1T /*[f][k1]*/, *W3h /*[c'][k2]*/; };
 
-// persistent workgroups, 256 threads.  LDS: Xb | h1s | h2s | dz2s | dz1s (bf16 [ROWS][PT]) | dS bf16 [ROWS][NCq+8] |
-// Xf, Xc, Xct fp32 [ROWS][16] | staged patch inputs fp32 [2][3 ROWS + 32 + NCq] (PatchIn) | W3s bf16 [NCq][PT]
+// persistent workgroups, 256 threads.  LDS: Xb | h1s | h2s (later dz1) | dz2s (bf16 [ROWS][PT]) | dST bf16 [NCq][ROWS + 8] (d(logits),
+// TRANSPOSED: a lane's four rows of a column are one 8-byte store) | XfT, XcT fp32 [16][ROWS + 4] |
+// staged patch inputs fp32 [2][3 ROWS + 32 + NCq] (PatchIn) | W3s bf16 [NCq][PT] | W1s, W2s | b3s
 // MF = ceil(F / 4): the f slots a wave owns (its layer-3 fragments and dW3 tiles live in registers for the whole kernel)
+//
+// Issue-bound kernel (3 000 instructions per patch and wave when first measured, 40 % of them the element-wise d(logits) phase): that
+// phase works on PAIRS of rows (v_pk_fma / mul / add_f32: the accumulator layout hands a lane rows 4 fq .. 4 fq + 3 of a column, two
+// pairs), the bias gradients are summed from the accumulators as they are produced (they were two 32-step serial LDS loops on one wave:
+// a quarter of the kernel), and no operand of the patch loop comes from global memory.
 template <int RT, int MF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2 : 1))) void ttcn_full_bwd_kernel(FD d, const float* __restrict__ x, const float* __restrict__ tt,
                                                              const float* __restrict__ mask, TEp te, Wts w, WtsT wt,
                                                              const float* __restrict__ ctr, const float* __restrict__ out,
                                                              const float* __restrict__ dout, int out_ld, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ROWS = RT * 16;
-    const int pitchC = d.NCq + 8;
+    constexpr int ROWS = RT * 16, PTT = ROWS + 8, XP = xt_pitch<RT>();
+    constexpr float LOG2E = 1.4426950408889634f;
     bf16_t* Xb = reinterpret_cast<bf16_t*>(smem);
     bf16_t* h1s = Xb + ROWS * PT;
     bf16_t* h2s = h1s + ROWS * PT;
     bf16_t* dz2s = h2s + ROWS * PT;
-    bf16_t* dz1s = dz2s + ROWS * PT;
-    bf16_t* dS = dz1s + ROWS * PT;
-    float* Xf = reinterpret_cast<float*>(dS + ROWS * pitchC);
-    float* Xc = Xf + ROWS * 16;
-    float* Xct = Xc + ROWS * 16;
+    bf16_t* dz1s = h2s;                                     // (h2 is dead once dz2 and dW3 are done: a barrier earlier)
+    bf16_t* dST = dz2s + ROWS * PT;                         // [NCq][PTT]
+    float* Xf = reinterpret_cast<float*>(dST + d.NCq * PTT);
+    float* Xc = Xf + 16 * XP;
     typedef PatchIn<RT, true> PI;
     const int PIN = PI::HEAD + d.NCq;                       // floats of one staged patch: t | x | mask | dp | ctr
-    float* pin = Xct + ROWS * 16;                           // [2][PIN]
+    float* pin = Xc + 16 * XP;                              // [2][PIN]
     bf16_t* W3s = reinterpret_cast<bf16_t*>(pin + 2 * PIN); // [NCq][PT]: layer-3 weights, rows c' (k2 contiguous) -- see below
     bf16_t* W1s = W3s + d.NCq * PT;                         // [k1][PT] (f contiguous), [k2][PT] (k1 contiguous): the MLP's weights; their
     bf16_t* W2s = W1s + KP * PT;                            // transposes (data-gradient products) are read through the hardware transpose
-    float* b3s = reinterpret_cast<float*>(W2s + KP * PT);   // [NCq] layer-3 bias
+    float* b3s = reinterpret_cast<float*>(W2s + KP * PT);   // [NCq] layer-3 bias, in log2 units (x log2 e)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const Slab sl = slab_of(d.F);
     PI nx;
@@ -368,12 +372,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
     // The layer-3 weights are read twice per patch (logits: rows c' as B fragments; dz2 = dS W3: the same image through the
     // hardware transpose) -- 17 dependent L2 round trips per patch per wave when fetched from global memory, a fifth of the
     // patch's timeline.  A persistent workgroup stages them once.
-    if (!(d.dbg & 1))
     for (int i = tid; i < d.NCq * 4; i += 256) {
         const int c = i >> 2, q = i & 3;
         *reinterpret_cast<bf16x8*>(W3s + c * PT + q * 8) = *reinterpret_cast<const bf16x8*>(wt.W3h + (size_t)c * KP + q * 8);
     }
-    for (int i = tid; i < d.NCq; i += 256) b3s[i] = w.b3q[i];
+    for (int i = tid; i < d.NCq; i += 256) b3s[i] = w.b3q[i] * LOG2E;
     if (tid < 2 * KP * 4) {
         const int which = tid >> 7, r = (tid >> 2) & 31, q = tid & 3;
         *reinterpret_cast<bf16x8*>((which ? W2s : W1s) + r * PT + q * 8) = load8_bf16((which ? w.W2p : w.W1p) + r * KP + q * 8);
@@ -381,24 +384,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
 
     // ---- operands that never change: registers for the whole kernel
     f32x4 accW3[MF][2][2];        // dW3 tiles: [f slot][half][k2 tile]
-    float accB3[MF][2];
+    f32x2 accB3[MF][2];           // db3: this lane's rows only, as two running pairs (summed once, after the last patch)
 #pragma unroll
     for (int j = 0; j < MF; ++j)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             accW3[j][half][0] = zero4(); accW3[j][half][1] = zero4();
-            accB3[j][half] = 0.f;
+            accB3[j][half] = f32x2{0.f, 0.f};
         }
     // per-wave tile roles of the 32x32 products: (tmt, tnt)
     const int tnt = wave & 1, tmt = wave >> 1;
     // the MLP's biases of this wave's output column tile (tnt)
     const float mb1 = w.b1p[tnt * 16 + fr], mb2 = w.b2p[tnt * 16 + fr];
     f32x4 accW2 = zero4(), accW1 = zero4();
-    float accb = 0.f;               // tid < 32: db2[tid]; 64 <= tid < 96: db1[tid - 64]; 128 <= tid < 160: dT_bias[tid - 128]
+    float sb2 = 0.f, sb1 = 0.f;     // db2 / db1 of column tnt * 16 + fr: this lane's rows, straight from the accumulators of dz2 / dz1
+    float accT = 0.f;               // 128 <= tid < 160: dT_bias[tid - 128]
     float te_w = 0.f, te_b = 0.f;   // time-embedding gradients of column f = fr through the MLP (waves that own a dXm tile)
-    float tpw[MF], tpb[MF];         // ... and through the pooling, of this wave's f slots: per-lane partial sums over the lane's (row, k)
+    f32x2 tpw[MF], tpb[MF];         // ... and through the pooling, of this wave's f slots: per-lane partial sums over the lane's (row, k)
 #pragma unroll
-    for (int j = 0; j < MF; ++j) tpw[j] = tpb[j] = 0.f;
+    for (int j = 0; j < MF; ++j) tpw[j] = tpb[j] = f32x2{0.f, 0.f};
 
     nx.park(d, pin);
     __syncthreads();
@@ -409,80 +413,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
         const float *dp = cur + 3 * ROWS, *cts = cur + PI::HEAD;
         const int pn = p + gridDim.x;
         if (pn < d.P) nx.fetch(d, pn, x, tt, mask, ctr, out, dout, out_ld);
-        build_x<RT>(d, xc, cur, Xb, Xf, Xc, Xct);
+        build_x<RT, true>(d, xc, cur, Xb, Xf, Xc);
         __syncthreads();
-        if (tid >= 128 && tid < 128 + KP) accb += dp[tid - 128];
+        if (tid >= 128 && tid < 128 + KP) accT += dp[tid - 128];
         mlp_layer_frag<RT>(Xb, h1s, frag_row(W1s, PT, tnt * 16, 0, fr, fq), mb1, wave, fr, fq);
         __syncthreads();
         mlp_layer_frag<RT>(h1s, h2s, frag_row(W2s, PT, tnt * 16, 0, fr, fq), mb2, wave, fr, fq);
         __syncthreads();
         bf16x8 a[RT];
-        float mk[RT][4];
+        // the lane's rows: live (mask != 0), or the value the reference puts in their place: Filter * mask + (1 - mask) * (-1e8) for a
+        // masked slot (mask is 0 / 1, so a select is the same value), -inf past L.  `any`: the patch has a live row at all -- the
+        // mask factor of d(logits) only matters when it has none (a masked row's weight is exactly 0 next to a live one)
+        bool on[RT][4];
+        float cval[RT][4], anyf = 0.f;
+        f32x4 t4[RT];            // the rows' times (0 past L)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             a[rt] = frag_row(h2s, PT, rt * 16, 0, fr, fq);
+            t4[rt] = *reinterpret_cast<const f32x4*>(cur + rt * 16 + fq * 4);
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(cur + 2 * ROWS + rt * 16 + fq * 4);     // (0 past L)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mk[rt][r] = cur[2 * ROWS + rt * 16 + fq * 4 + r];      // (0 past L)
+            for (int r = 0; r < 4; ++r) {
+                on[rt][r] = m4[r] != 0.f;
+                cval[rt][r] = rt * 16 + fq * 4 + r < d.L ? -1e8f * LOG2E : -INFINITY;
+                anyf += on[rt][r] ? 1.f : 0.f;
+            }
         }
-        // ---- d(logits), tile by tile in registers -> LDS (bf16); pooling-path dX by shuffles; db3
+        anyf = col_sum(anyf) > 0.f ? 1.f : 0.f;
+        // ---- d(logits), tile by tile in registers -> LDS (bf16, transposed); pooling-path dX; db3
 #pragma unroll
         for (int j = 0; j < MF; ++j) {
             const int f = wave + 4 * j;
             if (f < d.F) {
-                // xf: this f's column of X for the lane's rows (both halves use it); dxs: this lane's share of the pooling path's
+                // xfa: this f's column of X for the lane's rows (x any); dxs: this lane's share of the pooling path's
                 // dX[l, f] = sum_k sm dp.  That gradient only feeds the time-embedding parameters, which are linear in it: the lane
                 // adds dxs * (cos, cos * t) to per-lane sums that are reduced across lanes once, after the last patch -- no
                 // per-row 16-lane reductions, no dX tile
-                float xf[RT][4], dxs[RT][4];
+                f32x2 xfa[RT][2], dxs[RT][2];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        xf[rt][r] = Xf[(rt * 16 + fq * 4 + r) * 16 + f];
-                        dxs[rt][r] = 0.f;
-                    }
+                for (int rt = 0; rt < RT; ++rt) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(Xf + f * XP + rt * 16 + fq * 4);
+                    xfa[rt][0] = f32x2{x4[0], x4[1]} * anyf;
+                    xfa[rt][1] = f32x2{x4[2], x4[3]} * anyf;
+                    dxs[rt][0] = dxs[rt][1] = f32x2{0.f, 0.f};
+                }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int k = half * 16 + fr, c = f * 32 + k;
-                    float sm[RT][4];
-                    const float inv = sm_tile<RT, false>(d, a, frag_row(W3s, PT, f * 32 + half * 16, 0, fr, fq), b3s[c], mk, fq, sm);
-                    const float dpk = dp[k] * inv, ct_c = cts[c];       // (dp is zero past K; the softmax's 1 / sum rides on it)
-                    float colsum = 0.f;
+                    const bf16x8 b = frag_row(W3s, PT, f * 32 + half * 16, 0, fr, fq);
+                    const float bias2 = b3s[c];
+                    f32x2 v[RT][2];
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const f32x4 acc = mfma(a[rt], b, zero4());
+                        v[rt][0] = f32x2{acc[0], acc[1]} * LOG2E + bias2;       // log2 units: one fma per pair, no multiply inside exp
+                        v[rt][1] = f32x2{acc[2], acc[3]} * LOG2E + bias2;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                v[rt][h][e] = on[rt][2 * h + e] ? v[rt][h][e] : cval[rt][2 * h + e];
+                                m = fmaxf(m, v[rt][h][e]);
+                            }
+                    }
+                    m = col_max(m);
+                    f32x2 s2{0.f, 0.f};
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = rt * 16 + fq * 4 + r;
-                            const float smd = sm[rt][r] * dpk;                       // 0 past L (sm) and past K (dpk)
-                            const float ds = smd * (xf[rt][r] - ct_c) * mk[rt][r];
-                            dS[row * pitchC + c] = (bf16_t)ds;
-                            colsum += ds;
-                            dxs[rt][r] += smd;
+                        for (int h = 0; h < 2; ++h) {
+                            v[rt][h] -= m;
+                            v[rt][h][0] = __builtin_amdgcn_exp2f(v[rt][h][0]);   // exp2(-inf) = 0 for the padded rows; bf16 mode: v_exp_f32 is ample
+                            v[rt][h][1] = __builtin_amdgcn_exp2f(v[rt][h][1]);
+                            s2 += v[rt][h];
                         }
-                    accB3[j][half] += colsum;      // this lane's rows only: the four lane groups are summed once, after the last patch
+                    const float inv = __builtin_amdgcn_rcpf(col_sum(s2[0] + s2[1]));    // (v_rcp_f32: 1 ulp)
+                    const float dpk = dp[k] * inv, cta = cts[c] * anyf;   // (dp is zero past K; the softmax's 1 / sum rides on it)
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x2 smd = v[rt][h] * dpk;                    // 0 past L (sm) and past K (dpk)
+                            const f32x2 ds = smd * (xfa[rt][h] - cta);           // (x the mask: see `any`)
+                            dxs[rt][h] += smd;
+                            accB3[j][half] += ds;
+                            o[2 * h] = (bf16_t)ds[0];
+                            o[2 * h + 1] = (bf16_t)ds[1];
+                        }
+                        *reinterpret_cast<bf16x4*>(dST + c * PTT + rt * 16 + fq * 4) = o;
+                    }
                 }
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int o = (rt * 16 + fq * 4 + r) * 16 + f;
-                        tpb[j] = fmaf(dxs[rt][r], Xc[o], tpb[j]);
-                        tpw[j] = fmaf(dxs[rt][r], Xct[o], tpw[j]);
-                    }
+                for (int rt = 0; rt < RT; ++rt) {
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(Xc + f * XP + rt * 16 + fq * 4);
+                    const f32x2 g0 = dxs[rt][0] * f32x2{c4[0], c4[1]}, g1 = dxs[rt][1] * f32x2{c4[2], c4[3]};
+                    tpb[j] += g0 + g1;
+                    tpw[j] += g0 * f32x2{t4[rt][0], t4[rt][1]} + g1 * f32x2{t4[rt][2], t4[rt][3]};
+                }
             }
         }
         __syncthreads();
-        // ---- dz2 = (dS W3) * [h2 > 0] -> LDS tile; dW3 += dS^T h2
+        // ---- dz2 = (dS W3) * [h2 > 0] -> LDS tile (+ db2 from the accumulators); dW3 += dS^T h2
         for (int t = wave; t < RT * 2; t += 4) {
-            const int rt = t >> 1, nt = t & 1;
+            const int rt = t >> 1;      // (column tile t & 1 = wave & 1 = tnt: t advances by 4)
             f32x4 acc = zero4();
 #pragma unroll 4
             for (int kk = 0; kk < d.NCq; kk += 32)
-                acc = mfma(frag_row(dS, pitchC, rt * 16, kk, fr, fq), frag_kmajor(W3s, PT, nt * 16, kk, fr, fq), acc);
+                acc = mfma(frag_kmajor(dST, PTT, rt * 16, kk, fr, fq), frag_kmajor(W3s, PT, tnt * 16, kk, fr, fq), acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (rt * 16 + fq * 4 + r) * PT + nt * 16 + fr;
-                dz2s[o] = (float)h2s[o] > 0.f ? (bf16_t)acc[r] : (bf16_t)0.f;
+                const int o = (rt * 16 + fq * 4 + r) * PT + tnt * 16 + fr;
+                const float g = (float)h2s[o] > 0.f ? acc[r] : 0.f;
+                dz2s[o] = (bf16_t)g;
+                sb2 += g;
             }
         }
 #pragma unroll
@@ -493,51 +538,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
                 for (int half = 0; half < 2; ++half)
 #pragma unroll
                     for (int kk = 0; kk < ROWS; kk += 32) {
-                        const bf16x8 af = frag_kmajor(dS, pitchC, f * 32 + half * 16, kk, fr, fq);
+                        const bf16x8 af = frag_row(dST, PTT, f * 32 + half * 16, kk, fr, fq);
                         accW3[j][half][0] = mfma(af, frag_kmajor(h2s, PT, 0, kk, fr, fq), accW3[j][half][0]);
                         accW3[j][half][1] = mfma(af, frag_kmajor(h2s, PT, 16, kk, fr, fq), accW3[j][half][1]);
                     }
             }
         }
         __syncthreads();
-        // ---- layer 2 backward: dW2 += dz2^T h1 (tile (tmt, tnt)); db2; dz1 = (dz2 W2) * [h1 > 0]
+        // ---- layer 2 backward: dW2 += dz2^T h1 (tile (tmt, tnt)); dz1 = (dz2 W2) * [h1 > 0] (+ db1 from the accumulators)
 #pragma unroll
         for (int kk = 0; kk < ROWS; kk += 32)
             accW2 = mfma(frag_kmajor(dz2s, PT, tmt * 16, kk, fr, fq), frag_kmajor(h1s, PT, tnt * 16, kk, fr, fq), accW2);
-        if (tid < KP) {
-            float s = 0.f;
-            for (int l = 0; l < d.L; ++l) s += (float)dz2s[l * PT + tid];
-            accb += s;
-        }
         for (int t = wave; t < RT * 2; t += 4) {
             const int rt = t >> 1;      // nt = t & 1 = wave & 1 = tnt (t advances by 4)
             const f32x4 acc = mfma(frag_row(dz2s, PT, rt * 16, 0, fr, fq), frag_kmajor(W2s, PT, tnt * 16, 0, fr, fq), zero4());     // dh1 = dz2 W2, k1 tile tnt
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (rt * 16 + fq * 4 + r) * PT + tnt * 16 + fr;
-                dz1s[o] = (float)h1s[o] > 0.f ? (bf16_t)acc[r] : (bf16_t)0.f;
+                const float g = (float)h1s[o] > 0.f ? acc[r] : 0.f;
+                dz1s[o] = (bf16_t)g;
+                sb1 += g;
             }
         }
         __syncthreads();
-        // ---- layer 1 backward: dW1 += dz1^T X (f tile 0 only: F <= 16); db1; dX = dz1 W1 -> time-embedding grads (the pooling path's share: above)
+        // ---- layer 1 backward: dW1 += dz1^T X (f tile 0 only: F <= 16); dX = dz1 W1 -> time-embedding grads (the pooling path's share: above)
         if (wave < 2) {
 #pragma unroll
             for (int kk = 0; kk < ROWS; kk += 32)
                 accW1 = mfma(frag_kmajor(dz1s, PT, wave * 16, kk, fr, fq), frag_kmajor(Xb, PT, 0, kk, fr, fq), accW1);
         }
-        if (tid >= 64 && tid < 64 + KP) {
-            float s = 0.f;
-            for (int l = 0; l < d.L; ++l) s += (float)dz1s[l * PT + tid - 64];
-            accb += s;
-        }
         for (int rt = (RT == 2 ? wave - 2 : wave); rt >= 0 && rt < RT; rt += 4) {      // RT = 2: waves 2, 3; RT = 4: all four
             const f32x4 acc = mfma(frag_row(dz1s, PT, rt * 16, 0, fr, fq), frag_kmajor(W1s, PT, 0, 0, fr, fq), zero4());            // dXm = dz1 W1, f tile 0
-            // d X / d(pre-activation) and its product with t are in LDS (Xc, Xct: zero for the value column, the padding and rows past L)
+            // d X / d(pre-activation) is in LDS (Xc: zero for the value column, the padding and rows past L)
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(Xc + fr * XP + rt * 16 + fq * 4);
+            const f32x4 tr = *reinterpret_cast<const f32x4*>(cur + rt * 16 + fq * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (rt * 16 + fq * 4 + r) * 16 + fr;
-                te_w = fmaf(acc[r], Xct[o], te_w);
-                te_b = fmaf(acc[r], Xc[o], te_b);
+                const float g = acc[r] * c4[r];
+                te_w = fmaf(g, tr[r], te_w);
+                te_b += g;
             }
         }
         if (pn < d.P) nx.park(d, pin + ((it + 1) & 1) * PIN);     // (that half was last read in the previous patch)
@@ -558,7 +597,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         my[sl.W3 + (size_t)(f * 32 + half * 16 + fq * 4 + r) * KP + nt * 16 + fr] = accW3[j][half][nt][r];
-                const float b3sum = col_sum(accB3[j][half]);
+                const float b3sum = col_sum(accB3[j][half][0] + accB3[j][half][1]);
                 if (fq == 0) my[sl.b3 + f * 32 + half * 16 + fr] = b3sum;
             }
         }
@@ -568,17 +607,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
         my[sl.W2 + (tmt * 16 + fq * 4 + r) * KP + tnt * 16 + fr] = accW2[r];
         if (wave < 2) my[sl.W1 + (wave * 16 + fq * 4 + r) * KP + fr] = accW1[r];
     }
-    if (tid < KP) my[sl.b2 + tid] = accb;
-    else if (tid >= 64 && tid < 64 + KP) my[sl.b1 + tid - 64] = accb;
-    else if (tid >= 128 && tid < 128 + KP) my[sl.Tb + tid - 128] = accb;
-    // time-embedding gradients: several waves hold shares of the same entry -> summed in LDS first
-    float* tes = pin;                 // (every tile of the last patch is dead: the loop ends with a barrier)
-    if (tid < 2 * KP) tes[tid] = 0.f;
+    if (tid >= 128 && tid < 128 + KP) my[sl.Tb + tid - 128] = accT;
+    // bias and time-embedding gradients: several waves hold shares of the same entry -> summed in LDS first
+    float* tes = pin;                 // [te_w 32 | te_b 32 | db2 32 | db1 32] (every tile of the last patch is dead: the loop ends with a barrier)
+    if (tid < 4 * KP) tes[tid] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
         const int f = wave + 4 * j;
-        const float sw = col_sum(row_sum16(tpw[j])), sb = col_sum(row_sum16(tpb[j]));
+        const float sw = col_sum(row_sum16(tpw[j][0] + tpw[j][1])), sb = col_sum(row_sum16(tpb[j][0] + tpb[j][1]));
         if (lane == 0 && f >= 1 && f < d.F) {
             atomicAdd(tes + f, sw);
             atomicAdd(tes + KP + f, sb);
@@ -586,12 +623,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 2
     }
     te_w = col_sum(te_w);
     te_b = col_sum(te_b);
-    if (fq == 0 && (RT == 4 || wave >= 2)) {
-        atomicAdd(tes + fr, te_w);
-        atomicAdd(tes + KP + fr, te_b);
+    sb2 = col_sum(sb2);
+    sb1 = col_sum(sb1);
+    if (fq == 0) {
+        if (RT == 4 || wave >= 2) {
+            atomicAdd(tes + fr, te_w);
+            atomicAdd(tes + KP + fr, te_b);
+        }
+        atomicAdd(tes + 2 * KP + tnt * 16 + fr, sb2);
+        atomicAdd(tes + 3 * KP + tnt * 16 + fr, sb1);
     }
     __syncthreads();
     if (tid < 2 * KP) my[sl.te + tid] = tes[tid];
+    else if (tid < 3 * KP) my[sl.b2 + tid - 2 * KP] = tes[tid];
+    else if (tid < 4 * KP) my[sl.b1 + tid - 3 * KP] = tes[tid];
 }
 
 // ---- packing: padded fp32 weights (+ the f-major W3), transposed bf16 copies; unpacking of the gradient slab
@@ -655,10 +700,10 @@ __global__ __launch_bounds__(256) void ttcn_unpack_kernel(int F, int K, const fl
 inline int ttcn_unpack_outputs(int F, int K) { return K * F + K * K + F * K * K + F * K + 3 * K + 2 + 2 * (F - 2); }
 constexpr int kMaxBwdGrid = 512;       // slabs in the caller's scratch
 
-size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)RT * 16 * 16 * 4 + (size_t)NCq * 4 + (size_t)2 * 3 * RT * 16 * 4 + 64; }
+size_t fwd_lds(int RT, int NCq) { return (size_t)RT * 16 * PT * 2 * 3 + (size_t)16 * (RT * 16 + 4) * 4 + (size_t)NCq * 4 + (size_t)2 * 3 * RT * 16 * 4 + 64; }
 size_t bwd_lds(int RT, int NCq) {
     const size_t ROWS = RT * 16;
-    return ROWS * PT * 2 * 5 + ROWS * (NCq + 8) * 2 + ROWS * 16 * 4 * 3 + 2 * (3 * ROWS + KP + (size_t)NCq) * 4 + (size_t)(NCq + 2 * KP) * PT * 2 + (size_t)NCq * 4 + 64;
+    return ROWS * PT * 2 * 4 + (size_t)NCq * (ROWS + 8) * 2 + 16 * (ROWS + 4) * 4 * 2 + 2 * (3 * ROWS + KP + (size_t)NCq) * 4 + (size_t)(NCq + 2 * KP) * PT * 2 + (size_t)NCq * 4;
 }
 
 struct PackPtrs { float *W1p, *b1p, *W2p, *b2p, *W3q, *b3q; bf16_t *W3T, *W2T, *W1T, *W3h; };

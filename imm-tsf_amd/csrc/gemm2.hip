@@ -50,7 +50,8 @@ constexpr int BK2 = 64;
 // (the kernel's body as a device function: bx / by / bz = the workgroup's tile index, K split and problem; gx / gy = the extents
 // of the tile and split dimensions -- gemm2_kernel passes blockIdx / gridDim, gemm2_group_kernel a sub-problem's own numbering)
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
-__device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, const int by, const int bz, const int gx, const int gy) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, const int by, const int bz, const int gx, const int gy,
+                                           const int tile_m_given = -1, const int tile_n_given = -1) {
     constexpr int NT = WM * WN * 64;          // threads of one K group
     constexpr int NTALL = NT * WK;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -82,7 +83,10 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
         if (g.dyn_which == 0) M = dv; else K = dv;
     }
     int lin = bx, tile_m, tile_n;
-    if (g.g2_fast) {          // launcher-made reciprocals instead of run-time divisions (see GemmArgs)
+    if (tile_m_given >= 0) {          // the caller has placed this workgroup (gemm2_group_kernel)
+        tile_m = tile_m_given;
+        tile_n = tile_n_given;
+    } else if (g.g2_fast) {          // launcher-made reciprocals instead of run-time divisions (see GemmArgs)
         if (g.xcd_remap && g.xcd_gm > 0) {
             const int xcd = lin & 7, idx = lin >> 3;
             const int qi = g.g2_cx_magic ? (int)__umulhi((unsigned)idx, g.g2_cx_magic) : idx;
@@ -394,6 +398,7 @@ constexpr int G2_GROUP_MAX = 6;
 struct GemmGroupArgs {
     GemmArgs sub[G2_GROUP_MAX];
     int tile0[G2_GROUP_MAX + 1];      // first workgroup of each sub-problem
+    int tiles_m[G2_GROUP_MAX], strip[G2_GROUP_MAX];      // tile rows; width (in tiles) of the column strips the tiles are walked in
     int n;
 };
 template <bool TA, bool TB, int BM, int BN, int WM, int WN, int S, int WK = 1>
@@ -402,7 +407,23 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_group_kernel(const Gemm
 #pragma unroll
     for (int i = 1; i < G2_GROUP_MAX; ++i)
         if (i < gg.n && (int)blockIdx.x >= gg.tile0[i]) s = i;
-    gemm2_body<TA, TB, BM, BN, WM, WN, S, WK>(gg.sub[s], (int)blockIdx.x - gg.tile0[s], 0, 0, gg.tile0[s + 1] - gg.tile0[s], 1);
+    // XCD-aware placement.  Workgroup i runs on XCD i % 8 (round-robin dispatch), each XCD has its own L2, and a tile row / column of
+    // a weight gradient is a K x 128 operand panel that every L2 touching it fetches again: in launch order the launch pulled 92 -
+    // 105 MB through the fabric for 19 MB of operands.  So the member's workgroups that share an XCD take CONSECUTIVE tiles of a walk
+    // that keeps neighbours close in both directions: column strips of `strip` tiles, row-major inside a strip (a run of q tiles
+    // touches ~q / strip + strip panels instead of ~2 q): 60 MB (PMC FETCH_SIZE, cfg2 at 64 windows).
+    const int t0 = gg.tile0[s], t1 = gg.tile0[s + 1], id = (int)blockIdx.x, x = id & 7;
+    int start = 0, fx = 0;
+#pragma unroll
+    for (int xx = 0; xx < 8; ++xx) {
+        const int f = t0 + ((xx - t0) & 7), c = f < t1 ? ((t1 - 1 - f) >> 3) + 1 : 0;
+        if (xx < x) start += c;
+        if (xx == x) fx = f;
+    }
+    const int L = start + ((id - fx) >> 3);
+    const int w = gg.strip[s], tm = gg.tiles_m[s];
+    const int st = L / (tm * w), r = L - st * tm * w, tile_m = r / w;
+    gemm2_body<TA, TB, BM, BN, WM, WN, S, WK>(gg.sub[s], 0, 0, 0, t1 - t0, 1, tile_m, st * w + r - tile_m * w);
 }
 
 template <int BM, int BN, int WM, int WN, int S, int WK = 1>
@@ -641,6 +662,10 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
         for (int i = 0; i < n; ++i) t128 += (long)cdiv(list[i].M, 128) * cdiv(list[i].N, 128);
         gt = t128 >= 192 ? 128 : 64;
     }
+    // (measured and dropped, tools/group_bench.py at the cfg2 shapes: deeper rings -- 128 x 128 with 4 stages and one K group 50 - 64 us,
+    // 64 x 64 with 8 waves and 4 stages 38 - 48 -- against 41 - 43 for the two tiles below; splitting the reduction of the longest
+    // member, 2048 rows beside three ~1100-note ones, over two workgroups per tile: 34 us alone, but 234 workgroups of 128 KB of LDS
+    // instead of 198 leave the backbone's branch fewer CUs and the step 1.5 % slower)
     for (int i = 0; i < n; ++i) {
         GemmArgs g = list[i];
         if (!immtsf_gemm2_supported(GEMM_TN, g) || g.nprob != 1 || g.act != 0 || g.relu_ref || g.row_flag || g.add_vec || g.accumulate ||
@@ -648,25 +673,15 @@ int immtsf_launch_gemm2_group_tn(GemmArgs* list, int n, hipStream_t stream) {
             return IMMTSF_EUNSUPPORTED;
         g.vecA = 1; g.vecB = 1; g.vecC = 1;
         g.xcd_remap = 0; g.xcd_gm = 0; g.g2_fast = 0;
-        // a member whose first workgroup is a multiple of 8 keeps "workgroup i runs on XCD i % 8" in its own numbering: the exact 2-D XCD
-        // partition of the single launch (each L2 fetches 1/XR of A and 1/XC of B; without it the grouped launch fetched 147 MB for
-        // ~30 MB of operands, profiles/r03i_pmc_traffic.json).  IMMTSF_GROUP_XCD=0: off
-        constexpr bool gx_on = true;
-        if (gx_on && (tiles & 7) == 0) {
-            const int tiles_m = cdiv(g.M, gt), tiles_n = cdiv(g.N, gt);
-            int best = 0;
-            long best_cost = 0;
-            for (int XR = 1; XR <= 8; XR *= 2) {
-                const int XC = 8 / XR;
-                if (tiles_m % XR || tiles_n % XC) continue;
-                const long cost = (long)(tiles_m / XR) + (long)(tiles_n / XC);
-                if (!best || cost < best_cost) { best = XR; best_cost = cost; }
-            }
-            if (best) { g.xcd_remap = 8; g.xcd_gm = best; }
-        }
+        const int tm = cdiv(g.M, gt), tn = cdiv(g.N, gt), q = tm * tn / 8 > 0 ? tm * tn / 8 : 1;
+        int w = 1;          // strip width: the divisor of the tile columns closest to sqrt(tiles per XCD)
+        for (int c = 2; c <= 4; ++c)
+            if (tn % c == 0 && c * c <= 2 * q) w = c;
         gg.sub[i] = g;
         gg.tile0[i] = tiles;
-        tiles += cdiv(g.M, gt) * cdiv(g.N, gt);
+        gg.tiles_m[i] = tm;
+        gg.strip[i] = w;
+        tiles += tm * tn;
     }
     // (four rounds of one-workgroup-per-CU tiles at most: with a wide member -- 768 x 4096 at LLaMA-width embeddings, 768 tiles of its
     // own -- the separate launches are as good or better: cfg3 1.349 grouped vs 1.331 ms)

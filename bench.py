@@ -353,6 +353,7 @@ class Workload:
             self.cpu_batch, self.sum_n = synth_batch(100 + seed_off, windows, cfg)
             self.batch = {k: v.to(dev) for k, v in self.cpu_batch.items()}
         self.packed = bool(packed_notes) and c["ttf"] == "TTF_T2V_XAttn"
+        self.padded_notes = self.batch["notes_embeddings"]          # (the zero-padded form: hbm_roofline times its scan either way)
         if self.packed:
             # the notes as the device collate hands them over (immtsf.data.ResidentStore.collate): the embedding
             # rows stay in one resident matrix, the batch carries a row index per note and the per-window counts -- no zero-padded
@@ -703,8 +704,8 @@ def hbm_roofline(w, lib, roof):
     """the gather / mask path against the HBM roofline: each kernel timed as 20 launches inside one hipGraph on the batch
     of the step; bytes = what the kernel must read and write once (SURVEY 8d `gather-path GB/s`)."""
     from immtsf import _lib
-    dev, b = w.dev, w.batch
-    notes = b["notes_embeddings"]
+    dev = w.dev
+    notes = w.padded_notes
     B, N, d_m = notes.shape
     mask = torch.empty(B, N, dtype=torch.uint8, device=dev)
     i32 = lambda *s: torch.empty(*s, dtype=torch.int32, device=dev)      # noqa: E731
@@ -716,7 +717,8 @@ def hbm_roofline(w, lib, roof):
     out = []
     us = graph_kernel_us(ragged, reps=20)
     byts = B * N * d_m * 4 + B * N * 9 + 4 * (2 * B + 1)
-    out.append({"kernel": "note_mask + ragged_index (a2: (sum|V| > 0) scan of the padded notes -> lengths/offsets/rowmap)",
+    out.append({"kernel": "note_mask + ragged_index (a2: (sum|V| > 0) scan of the padded notes -> lengths/offsets/rowmap"
+                          + ("; NOT in the timed step: the notes arrive packed, see config.notes)" if w.packed else ")"),
                 "bytes": byts, "us": round(us, 2), "GB/s": round(byts / us / 1e3, 1), "frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 4)})
     gg = roof.get("gather_gemm") if roof else None
     if gg:
@@ -843,9 +845,11 @@ def main():
                     help="sharded optimizer: what the all-gather moves; auto = bf16 in bf16 mode (with the bf16 gradient wire the step "
                          "then moves exactly the bytes of one bf16 all-reduce; the replicated fp32 parameters are the widened bf16 "
                          "image, the fp32 master stays with the owner), fp32 (exact) otherwise")
-    ap.add_argument("--packed-notes", action="store_true",
-                    help="hand the notes over in the packed form of the device collate (resident embedding matrix + row index + per-window "
-                         "counts) instead of the reference's zero-padded (B, N, d_m) tensor: the step then has no note_mask scan")
+    ap.add_argument("--padded-notes", action="store_true",
+                    help="hand the notes over as the reference's zero-padded (B, N, d_m) tensor; the default is the packed form of the "
+                         "device collate (resident embedding matrix + row index + per-window counts: BASELINE's 'single ragged buffer "
+                         "with an offset index'), whose step has no (sum |V| > 0) scan")
+    ap.add_argument("--packed-notes", action="store_true", help="(accepted for compatibility: this is the default now)")
     ap.add_argument("--fusion-only", action="store_true",
                     help="time the fusion blocks + loss + backward + optimizer with the backbone's forecast replaced by a fixed random tensor "
                          "(cfg5: the 7 ms of fusion without the 97 ms frozen GPT-2 body of TimeLLM)")
@@ -911,7 +915,7 @@ def main():
     pwire = args.param_wire if args.param_wire != "auto" else ("bf16" if args.precision == "bf16" else "fp32")
     sharded = dist_on and args.shard_optimizer and not args.no_shard_optimizer
     w = Workload(args.config, dev, W, args.precision, group=group, wire=wire, device_step=not args.no_graph, seed_off=rank,
-                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=args.packed_notes,
+                 overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=not args.padded_notes,
                  fusion_only=args.fusion_only)
     trainer, fusion = w.trainer, w.fusion
     use_graph = (not args.no_graph) and w.graphable
@@ -1019,7 +1023,7 @@ def main():
         # windows per GPU: where the step leaves the launch-bound regime (the >= 40 % MFMA target presumes a batch size)
         sweep = []
         for nw in (64, 256, 1024, 4096):
-            ww = Workload("cfg2", dev, nw, args.precision)
+            ww = Workload("cfg2", dev, nw, args.precision, packed_notes=not args.padded_notes)
             st, _ = build_step(ww, "graphed" if args.no_flags else "auto")
             k = 10 if nw <= 256 else 4            # median of three blocks (one block of 30 was once seen 2.7 x off: a transient of the box)
             blocks = sorted(time_steps(st, k, 3 if i == 0 else 0, torch.cuda.synchronize)[0] for i in range(3))
@@ -1031,15 +1035,18 @@ def main():
             ww.close()
             del st, ww
         extras["sweep"] = sweep
-        # the same step with the notes handed over packed (what immtsf.data's device collate produces)
-        wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=True)
+        # the same step with the notes handed over in the other form (padded: the reference's collate; packed: immtsf.data's device collate)
+        other = "packed" if args.padded_notes else "padded"
+        wp = Workload("cfg2", dev, B_PER_GPU, args.precision, packed_notes=bool(args.padded_notes))
         st, _ = build_step(wp, "graphed" if args.no_flags else "auto")
         blocks = sorted(time_steps(st, 40, 5 if i == 0 else 0, torch.cuda.synchronize)[0] for i in range(5))
         el = blocks[2]             # median of five blocks of 40 replays (a single block right after the 4096-window leg was seen 25 % off)
-        extras["packed"] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
-                            "blocks_ms": [round(b / 40 * 1e3, 4) for b in blocks],
-                            "what": "notes as PackedNotes (resident embedding matrix + int32 row index + per-window counts, the device "
-                                    "collate's output) instead of the zero-padded (B, N, d_m) tensor: no note_mask scan in the step"}
+        extras[other] = {"ms_per_step": round(el / 40 * 1e3, 4), "windows_per_s": round(B_PER_GPU / (el / 40), 1),
+                         "blocks_ms": [round(b / 40 * 1e3, 4) for b in blocks],
+                         "what": "the same step with the notes as " + (
+                             "PackedNotes (resident embedding matrix + int32 row index + per-window counts, the device collate's output): "
+                             "no note_mask scan in the step" if other == "packed" else
+                             "the reference's zero-padded (B, N, d_m) tensor: note_mask + ragged_index re-derive the index in the step")}
         wp.close()
         del st, wp
         # the fp32 parity mode (1e-4 against the reference) on the same step
@@ -1077,6 +1084,9 @@ def main():
             "config": {"workload": f"{args.config}: " + CONFIGS[args.config]["text"].format(B=W) +
                                    (" -- FUSION ONLY: the backbone's forecast is a fixed random tensor" if args.fusion_only else ""),
                        "step": "backbone fwd + fusion fwd + masked MSE + backward + grad all-reduce (N>1) + clip + Adam",
+                       "notes": ("packed: one ragged buffer of embedding rows + int32 row index + per-window counts (the device collate's "
+                                 "output; extras.padded = the same step on the reference's zero-padded tensor)") if w.packed else
+                                "padded: the reference's zero-padded (B, N, d_m) tensor, index re-derived in the step",
                        "global_batch": W * world, "parallelism": f"dp{world}", "sum_notes_rank0": w.sum_n,
                        "fusion_algorithmic_gflop_per_window": round(fl_win / 1e9, 4),
                        "fusion_algorithmic_tflops_at_step_time": round(fl_win * W * world / (ms_per_step * 1e-3) / 1e12, 2),

@@ -20,6 +20,25 @@ namespace {
 struct DecDims { int B, N, Lp, D, E; };
 struct DecP { const float *W1, *b1, *W2, *b2, *W3, *b3; };
 struct DecG { float *W1, *b1, *W2, *b2, *W3, *b3; };
+// LearnableTE of the prediction times inside the decoder (models/tPatchGNN.py:176-180 applied at :283-285): te[b, lp, :] =
+// [w0 t + b0 ; sin(w t + b)] is built from t (B, Lp) while the window is staged, and the backward turns its d te rows into the four
+// parameter gradients on the spot -- the separate Time2Vec launches (forward 4 us; backward: 14 us of ONE workgroup on the backbone's
+// dependent chain) and the (B, Lp, E) te / d te tensors disappear.  t == nullptr: te / dte are the caller's tensors.
+struct DecTE { const float *t, *w0, *b0, *w, *b; float *gw0, *gb0, *gw, *gb; };
+__device__ __forceinline__ float dec_te_value(const DecTE& q, float t, int e) {
+    return e == 0 ? fmaf(q.w0[0], t, q.b0[0]) : sinf(fmaf(q.w[e - 1], t, q.b[e - 1]));
+}
+// d te[b, lp, e] = a  ->  d w_e += g t, d b_e += g with g = a (e = 0) or a cos(w t + b): LDS sums [0..16) d w | [16..32) d b (E <= 16)
+__device__ __forceinline__ void dec_te_grad(const DecTE& q, float t, int e, float a, float* gtes) {
+    const float g = e == 0 ? a : a * cosf(fmaf(q.w[e - 1], t, q.b[e - 1]));
+    atomicAdd(gtes + e, g * t);
+    atomicAdd(gtes + 16 + e, g);
+}
+__device__ __forceinline__ void dec_te_flush(const DecTE& q, int i, int E, const float* gtes) {      // i < 2 E: one global atomic each
+    const int e = i < E ? i : i - E;
+    float* dst = i < E ? (e == 0 ? q.gw0 : q.gw + e - 1) : (e == 0 ? q.gb0 : q.gb + e - 1);
+    atomicAdd(dst, gtes[(i < E ? 0 : 16) + e]);
+}
 
 // chunk geometry: 256 rows = NC variables x LPC steps, LPC = smallest power of two >= min(Lp, 256)
 __host__ __device__ inline int lpc_of(int Lp) { int c = 1; while (c < Lp && c < 256) c <<= 1; return c; }
@@ -40,19 +59,23 @@ size_t fwd_lds(int N, int Lp, int D, int E) {
 }
 template <int H>
 size_t bwd_lds(int N, int Lp, int D, int E) {       // ... + the workgroup's running dW1 / db1 (it walks several windows)
-    return (size_t)(H * H + 3 * H + 2 * (N + Lp) * Geo<H>::P1 + 2 * 256 * Geo<H>::PR + 2 * H + 8 + H * (D + E) + H) * sizeof(float);
+    return (size_t)(H * H + 3 * H + 2 * (N + Lp) * Geo<H>::P1 + 2 * 256 * Geo<H>::PR + 2 * H + 8 + H * (D + E) + H + 32) * sizeof(float);
 }
 
 // coalesced copies: W1s[k][D+E+1], hs[n][D], tes[lp][E] (contiguous, in this order, at `st`)
 template <int H>
 __device__ __forceinline__ void stage(const DecDims& d, const DecP& p, const float* __restrict__ h, const float* __restrict__ te, int b,
-                                      float* st) {
+                                      float* st, const DecTE& tq, int nthreads = 256) {
     const int ld = d.D + d.E, pw = ld + 1;
     float* hs = st + H * pw;
     float* tes = hs + d.N * d.D;
-    for (int i = threadIdx.x; i < H * ld; i += 256) st[(i / ld) * pw + i % ld] = p.W1[i];
-    for (int i = threadIdx.x; i < d.N * d.D; i += 256) hs[i] = h[(size_t)b * d.N * d.D + i];
-    for (int i = threadIdx.x; i < d.Lp * d.E; i += 256) tes[i] = te[(size_t)b * d.Lp * d.E + i];
+    for (int i = threadIdx.x; i < H * ld; i += nthreads) st[(i / ld) * pw + i % ld] = p.W1[i];
+    for (int i = threadIdx.x; i < d.N * d.D; i += nthreads) hs[i] = h[(size_t)b * d.N * d.D + i];
+    if (tq.t) {
+        for (int i = threadIdx.x; i < d.Lp * d.E; i += nthreads) tes[i] = dec_te_value(tq, tq.t[(size_t)b * d.Lp + i / d.E], i % d.E);
+    } else {
+        for (int i = threadIdx.x; i < d.Lp * d.E; i += nthreads) tes[i] = te[(size_t)b * d.Lp * d.E + i];
+    }
 }
 // u[n][k] = b1[k] + sum_d W1[k][d] h[b, n, d];  v[lp][k] = sum_e W1[k][D + e] te[b, lp, e]   (operands staged by stage())
 template <int H>
@@ -111,7 +134,7 @@ __device__ __forceinline__ void second_layer(const float* W2s, const float* b2s,
 
 template <int H>
 __global__ __launch_bounds__(256) void dec_fwd_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, DecTE tq) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int P1 = Geo<H>::P1;
     float* W2s = sm;
@@ -124,7 +147,7 @@ __global__ __launch_bounds__(256) void dec_fwd_kernel(DecDims d, DecP p, const f
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < H * H; i += 256) W2s[i] = p.W2[i];
     if (threadIdx.x < H) { b2s[threadIdx.x] = p.b2[threadIdx.x]; w3s[threadIdx.x] = p.W3[threadIdx.x]; }
-    stage<H>(d, p, h, te, b, st);
+    stage<H>(d, p, h, te, b, st, tq);
     __syncthreads();
     first_layer<H>(d, p.b1, st, u, v);
     __syncthreads();
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(256) void dec_fwd_kernel(DecDims d, DecP p, const f
 template <int H>
 __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
                                                        const float* __restrict__ dout, float* __restrict__ dh,
-                                                       float* __restrict__ dte, DecG g) {
+                                                       float* __restrict__ dte, DecG g, DecTE tq) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int P1 = Geo<H>::P1, PR = Geo<H>::PR, KPT = Geo<H>::KPT;
     float* W2s = sm;
@@ -164,7 +187,9 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
     float* db3s = db2s + H;                   // [1] (+ 7 of padding)
     float* gW1s = db3s + 8;                   // [H][D + E] running dW1 of this workgroup's windows
     float* gb1s = gW1s + H * (d.D + d.E);     // [H]
+    float* gtes = gb1s + H;                   // [2][16]: running d w | d b of the fused LearnableTE
     const int tid = threadIdx.x;
+    if (tid < 32) gtes[tid] = 0.f;
     for (int i = tid; i < H * H; i += 256) W2s[i] = p.W2[i];
     if (tid < H) { b2s[tid] = p.b2[tid]; w3s[tid] = p.W3[tid]; dw3s[tid] = 0.f; db2s[tid] = 0.f; gb1s[tid] = 0.f; }
     if (tid == 0) db3s[0] = 0.f;
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
     // memory once per workgroup (with one workgroup per window the ~2.5 k atomics of each of 4096 windows queue up per address)
     for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
     for (int i = tid; i < (d.N + d.Lp) * P1; i += 256) du[i] = 0.f;      // du and dv are contiguous
-    stage<H>(d, p, h, te, b, Xs);       // the staged operands borrow the first chunk image (launcher checks they fit)
+    stage<H>(d, p, h, te, b, Xs, tq);       // the staged operands borrow the first chunk image (launcher checks they fit)
     __syncthreads();
     first_layer<H>(d, p.b1, Xs, u, v);
     __syncthreads();
@@ -297,7 +322,7 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
         for (int n = 0; n < d.N; ++n) s += du[n * P1 + tid];
         gb1s[tid] += s;
     }
-    stage<H>(d, p, h, te, b, Xs);       // the chunk images are dead: W1 / h / te again for the first layer's gradients
+    stage<H>(d, p, h, te, b, Xs, tq);       // the chunk images are dead: W1 / h / te again for the first layer's gradients
     __syncthreads();
     const int ld = d.D + d.E, pw = ld + 1;
     const float* hs = Xs + H * pw;
@@ -326,10 +351,12 @@ __global__ __launch_bounds__(256) void dec_bwd_kernel(DecDims d, DecP p, const f
         float a = 0.f;
 #pragma unroll
         for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
-        dte[(size_t)b * d.Lp * d.E + i] = a;
+        if (tq.t) dec_te_grad(tq, tq.t[(size_t)b * d.Lp + lp], e, a, gtes);
+        else dte[(size_t)b * d.Lp * d.E + i] = a;
     }
     __syncthreads();        // the next window restages over Xs and clears du / dv
     }   // windows
+    if (tq.t && tid < 2 * d.E) dec_te_flush(tq, tid, d.E, gtes);
 
     // ---- parameter gradients of this workgroup's windows -> global (one atomic per element)
 #pragma unroll
@@ -377,12 +404,12 @@ size_t fwd_lds_mfma(int N, int Lp, int D, int E) { return (size_t)((N + Lp) * Ge
 template <int H>
 size_t bwd_lds_mfma(int N, int Lp, int D, int E, bool with_slabs) {
     const size_t red = 8 * (H * H + 2 * H + 4), slabs = with_slabs ? (size_t)8 * (Lp + 1) * Geo<H>::P1 : 0;      // the waves' parameter sums | their dv slabs (same region)
-    return (size_t)(2 * (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + ((N * Lp + 31) & ~31) + H * (D + E) + H + (red > slabs ? red : slabs) + 16) * sizeof(float);
+    return (size_t)(2 * (N + Lp) * Geo<H>::P1 + stage_floats(H, N, Lp, D, E) + ((N * Lp + 31) & ~31) + H * (D + E) + H + 32 + (red > slabs ? red : slabs) + 16) * sizeof(float);
 }
 
 // grid B, 256 threads
 __global__ __launch_bounds__(256) void dec_fwd_mfma_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, DecTE tq) {
     constexpr int H = 32, P1 = Geo<H>::P1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* u = sm;
@@ -396,7 +423,7 @@ __global__ __launch_bounds__(256) void dec_fwd_mfma_kernel(DecDims d, DecP p, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) { b2v[jt][e] = p.b2[jt * 16 + fq * 4 + e]; w3v[jt][e] = p.W3[jt * 16 + fq * 4 + e]; }
     const float b3 = p.b3[0];
-    stage<H>(d, p, h, te, b, st);
+    stage<H>(d, p, h, te, b, st, tq);
     __syncthreads();
     first_layer<H>(d, p.b1, st, u, v);
     __syncthreads();
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(256) void dec_fwd_mfma_kernel(DecDims d, DecP p, co
 // reads / MFMAs / LDS atomics is latency-bound, more waves per window is what shortens it)
 __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, const float* __restrict__ h, const float* __restrict__ te,
                                                             const float* __restrict__ dout, float* __restrict__ dh,
-                                                            float* __restrict__ dte, DecG g, int use_slabs) {
+                                                            float* __restrict__ dte, DecG g, int use_slabs, DecTE tq) {
     constexpr int H = 32, P1 = Geo<H>::P1;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* u = sm;
@@ -468,7 +495,9 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
     // fp32 LDS atomics retire about one lane per clock for the whole CU -- eight waves' 10 k lane-adds were 5 us per tile, 10 of the
     // tile loop's 12.6 us.  One ds instruction touches rows 4 fq + e (e fixed): distinct steps lp whenever Lp > 12.  The slabs share
     // the region of the final parameter sums (`red`), are added up in wave order after the loop: the sum is deterministic, too
-    float* red = gb1s + H;
+    float* gtes = gb1s + H;                   // [2][16]: running d w | d b of the fused LearnableTE
+    if (tid < 32) gtes[tid] = 0.f;
+    float* red = gtes + 32;
     const bool priv = use_slabs != 0;       // (the host: Lp > 12 and the slabs fit)
     const int slab_floats = (d.Lp + 1) * P1;
     float* slab = red + (size_t)wave * slab_floats;
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
         }
         if (priv)
             for (int i = lane; i < slab_floats; i += 64) slab[i] = 0.f;
-        stage<H>(d, p, h, te, b, Xs);
+        stage<H>(d, p, h, te, b, Xs, tq, NT);
         __syncthreads();
         first_layer<H>(d, p.b1, Xs, u, v);
         __syncthreads();
@@ -632,7 +661,8 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             float a = 0.f;
 #pragma unroll
             for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
-            dte[(size_t)b * d.Lp * d.E + i] = a;
+            if (tq.t) dec_te_grad(tq, tq.t[(size_t)b * d.Lp + lp], e, a, gtes);
+            else dte[(size_t)b * d.Lp * d.E + i] = a;
         }
         __syncthreads();
     }
@@ -666,6 +696,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
     }
     if (tid < H) atomicAdd(g.b1 + tid, gb1s[tid]);
     for (int i = tid; i < H * (d.D + d.E); i += NT) atomicAdd(g.W1 + i, gW1s[i]);
+    if (tq.t && tid < 2 * d.E) dec_te_flush(tq, tid, d.E, gtes);
 }
 
 constexpr size_t kLdsMax = 150 * 1024;
@@ -695,24 +726,37 @@ static bool dec_mfma_ok(const immtsf_decoder_params* p) {
     return on && (reinterpret_cast<uintptr_t>(p->W2) & 15) == 0;
 }
 
-int immtsf_tpatchgnn_decoder_forward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
-                                       const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream) {
-    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !out || precision < 0 || precision > 1) return IMMTSF_EINVAL;
+static int dec_forward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                       const float* te, const DecTE& tq, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream) {
+    if (!dims_ok(B, N, Lp, D, E, H) || !h || (!te && !tq.t) || !p || !out || precision < 0 || precision > 1) return IMMTSF_EINVAL;
     if (immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) == 0) return IMMTSF_EUNSUPPORTED;
     if (B == 0) return IMMTSF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DecDims d{B, N, Lp, D, E};
     const DecP q{p->W1, p->b1, p->W2, p->b2, p->W3, p->b3};
     if (precision == 1 && dec_mfma_ok(p)) {
-        hipLaunchKernelGGL(dec_fwd_mfma_kernel, dim3(B), dim3(256), fwd_lds_mfma<32>(N, Lp, D, E), s, d, q, h, te, out);
+        hipLaunchKernelGGL(dec_fwd_mfma_kernel, dim3(B), dim3(256), fwd_lds_mfma<32>(N, Lp, D, E), s, d, q, h, te, out, tq);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }
     const size_t lds = fwd_lds<32>(N, Lp, D, E);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(B), dim3(256), lds, s, d, q, h, te, out);
+    hipLaunchKernelGGL(dec_fwd_kernel<32>, dim3(B), dim3(256), lds, s, d, q, h, te, out, tq);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+int immtsf_tpatchgnn_decoder_forward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                       const float* te, const immtsf_decoder_params* p, float* out, immtsf_stream_t stream) {
+    return dec_forward(B, N, Lp, D, E, H, precision, h, te, DecTE{}, p, out, stream);
+}
+/* LearnableTE inside the decoder: t (B, Lp) prediction times, tp = its four parameters (te_scale.weight / .bias (1), te_periodic.weight /
+ * .bias (E - 1)); E <= 16 */
+int immtsf_tpatchgnn_decoder_forward_te(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                        const float* t, const immtsf_time2vec_params* tp, const immtsf_decoder_params* p, float* out,
+                                        immtsf_stream_t stream) {
+    if (!t || !tp || !tp->w0 || !tp->b0 || E < 1 || E > 16 || (E > 1 && (!tp->w || !tp->b))) return IMMTSF_EINVAL;
+    return dec_forward(B, N, Lp, D, E, H, precision, h, nullptr, DecTE{t, tp->w0, tp->b0, tp->w, tp->b, nullptr, nullptr, nullptr, nullptr}, p, out,
+                       stream);
 }
 
 int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, const float* h,
@@ -721,10 +765,11 @@ int immtsf_tpatchgnn_decoder_backward(int32_t B, int32_t N, int32_t Lp, int32_t 
     return immtsf_tpatchgnn_decoder_backward_p(B, N, Lp, D, E, H, 0, h, te, p, dout, dh, dte, grads, stream);
 }
 
-int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
-                                        const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
-                                        float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream) {
-    if (!dims_ok(B, N, Lp, D, E, H) || !h || !te || !p || !dout || !dh || !dte || !grads || precision < 0 || precision > 1) return IMMTSF_EINVAL;
+static int dec_backward(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                        const float* te, const DecTE& tq, const immtsf_decoder_params* p, const float* dout, float* dh,
+                        float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream) {
+    if (!dims_ok(B, N, Lp, D, E, H) || !h || (!tq.t && (!te || !dte)) || !p || !dout || !dh || !grads || precision < 0 || precision > 1)
+        return IMMTSF_EINVAL;
     if (immtsf_tpatchgnn_decoder_lds_bytes(N, Lp, D, E, H) == 0) return IMMTSF_EUNSUPPORTED;
     if (B == 0) return IMMTSF_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -737,7 +782,7 @@ int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_
         int per = (int)(160 * 1024 / lm);
         per = per < 1 ? 1 : per > 2 ? 2 : per;          // (the grid is the fan-in of the final atomics)
         const int grid = B < 256 * per ? B : 256 * per;
-        hipLaunchKernelGGL(dec_bwd_mfma_kernel, dim3(grid), dim3(512), lm, s, d, q, h, te, dout, dh, dte, gq, slabs ? 1 : 0);
+        hipLaunchKernelGGL(dec_bwd_mfma_kernel, dim3(grid), dim3(512), lm, s, d, q, h, te, dout, dh, dte, gq, slabs ? 1 : 0, tq);
         IMMTSF_LAUNCH_CHECK();
         return IMMTSF_OK;
     }
@@ -745,9 +790,25 @@ int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;      // resident workgroups per CU by LDS
     const int grid = B < 256 * per_cu ? B : 256 * per_cu;
-    hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(grid), dim3(256), lds, s, d, q, h, te, dout, dh, dte, gq);
+    hipLaunchKernelGGL(dec_bwd_kernel<32>, dim3(grid), dim3(256), lds, s, d, q, h, te, dout, dh, dte, gq, tq);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                        const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
+                                        float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream) {
+    return dec_backward(B, N, Lp, D, E, H, precision, h, te, DecTE{}, p, dout, dh, dte, grads, stream);
+}
+/* ... and its backward: the four LearnableTE gradients are ACCUMULATED (atomics) into tgrads like the decoder's own into `grads` */
+int immtsf_tpatchgnn_decoder_backward_te(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                         const float* t, const immtsf_time2vec_params* tp, const immtsf_decoder_params* p, const float* dout,
+                                         float* dh, const immtsf_decoder_params* grads, const immtsf_time2vec_params* tgrads,
+                                         immtsf_stream_t stream) {
+    if (!t || !tp || !tgrads || !tp->w0 || !tp->b0 || !tgrads->w0 || !tgrads->b0 || E < 1 || E > 16 ||
+        (E > 1 && (!tp->w || !tp->b || !tgrads->w || !tgrads->b)))
+        return IMMTSF_EINVAL;
+    return dec_backward(B, N, Lp, D, E, H, precision, h, nullptr, DecTE{t, tp->w0, tp->b0, tp->w, tp->b, tgrads->w0, tgrads->b0, tgrads->w, tgrads->b},
+                        p, dout, dh, nullptr, grads, stream);
 }
 
 }  // extern "C"

@@ -68,6 +68,7 @@ GCNParams = _ptr_struct("GCNParams", [
     "nodevec1", "nodevec2", "gate1_w", "gate1_b", "gate2_w", "gate2_b", "lin1_w", "lin1_b", "lin2_w", "lin2_b",
     "mlp_w", "mlp_b"])
 DecoderParams = _ptr_struct("DecoderParams", ["W1", "b1", "W2", "b2", "W3", "b3"])
+Time2VecParams = _ptr_struct("Time2VecParams", ["w0", "b0", "w", "b"])
 GRParams = _ptr_struct("GRParams", [
     "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
 
@@ -210,6 +211,10 @@ _PROTOS = {
     "immtsf_tpatchgnn_decoder_forward_p": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_stream]),
     "immtsf_tpatchgnn_decoder_backward_p": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(DecoderParams), c_f32p, c_f32p, c_f32p,
                                                    _P(DecoderParams), c_stream]),
+    "immtsf_tpatchgnn_decoder_forward_te": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(Time2VecParams), _P(DecoderParams), c_f32p,
+                                                      c_stream]),
+    "immtsf_tpatchgnn_decoder_backward_te": (C.c_int, [C.c_int32] * 7 + [c_f32p, c_f32p, _P(Time2VecParams), _P(DecoderParams), c_f32p,
+                                                       c_f32p, _P(DecoderParams), _P(Time2VecParams), c_stream]),
     "immtsf_collate_series": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_float] + [c_f32p] * 6 + [c_stream]),
     "immtsf_collate_patches": (C.c_int, [_P(Store), c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
                                          C.c_float, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -1139,6 +1139,47 @@ class TPatchDecoderFn(torch.autograd.Function):
         return (dh, dte, None) + tuple(rets)
 
 
+class TPatchDecoderTEFn(torch.autograd.Function):
+    """The decoder with LearnableTE of the prediction times inside: (h (B,N,D), t (B,Lp)) -> (B,Lp,N).  te = [w0 t + b0 ; sin(w t + b)]
+    is built while a window is staged and its gradient is reduced to the four parameter gradients in the backward kernel: no
+    (B,Lp,E) tensor, no separate Time2Vec launches (models/tPatchGNN.py:176-180, 283-291).  t is data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, h, t, precision, w0, b0, w, b, *params):
+        lib = _lib.load()
+        h, t = _c(h), _c(t)
+        tparams = tuple(_c(q) for q in (w0, b0, w, b))
+        params = tuple(_c(q) for q in params)
+        _need_gpu(h, t, *tparams, *params)
+        B, N, D = h.shape
+        Lp, E = t.shape[1], 1 + tparams[2].numel()
+        H = params[2].shape[0]
+        out = torch.empty(B, Lp, N, dtype=torch.float32, device=h.device)
+        ps, ts = _struct(DecoderParams, params), _struct(_lib.Time2VecParams, tparams)
+        check(lib.immtsf_tpatchgnn_decoder_forward_te(B, N, Lp, D, E, H, precision, ptr(h), ptr(t), C.byref(ts), C.byref(ps), ptr(out),
+                                                      stream_ptr()), "tpatchgnn_decoder_forward_te")
+        ctx.dims = (B, N, Lp, D, E, H, precision)
+        ctx.sinks, ctx.tsinks = _sinks_of(params), _sinks_of(tparams)
+        ctx.save_for_backward(h, t, *tparams, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        h, t, w0, b0, w, b, *params = ctx.saved_tensors
+        tparams = (w0, b0, w, b)
+        B, N, Lp, D, E, H, precision = ctx.dims
+        dout = dout.contiguous()
+        dh = torch.empty_like(h)
+        grads, rets = _zeroed_grad_buffers(params, ctx.sinks)
+        tgrads, trets = _zeroed_grad_buffers(tparams, ctx.tsinks)       # (shared sinks -- the patch encoder adds into them too -- are zero-filled by their owner)
+        ps, gs = _struct(DecoderParams, params), _struct(DecoderParams, grads)
+        ts, tg = _struct(_lib.Time2VecParams, tparams), _struct(_lib.Time2VecParams, tgrads)
+        check(lib.immtsf_tpatchgnn_decoder_backward_te(B, N, Lp, D, E, H, precision, ptr(h), ptr(t), C.byref(ts), C.byref(ps), ptr(dout),
+                                                       ptr(dh), C.byref(gs), C.byref(tg), stream_ptr()), "tpatchgnn_decoder_backward_te")
+        return (dh, None, None) + tuple(trets) + tuple(rets)
+
+
 def tpatch_decoder_supported(seq, N, Lp, D, E):
     """seq: the reference's decoder nn.Sequential (Linear, ReLU, Linear, ReLU, Linear(H, 1))"""
     mods = list(seq)
@@ -1160,6 +1201,15 @@ def tpatch_decoder(seq, h, te, precision=None):
     l1, l2, l3 = seq[0], seq[2], seq[4]
     return TPatchDecoderFn.apply(h.float(), te.float(), config.precision_code(precision), l1.weight, l1.bias, l2.weight, l2.bias,
                                  l3.weight, l3.bias)
+
+
+def tpatch_decoder_te(seq, h, t, w0, b0, w, b, precision=None):
+    """tpatch_decoder with the time embedding of the prediction times t (B, Lp) computed inside (w0 / b0: te_scale, w / b: te_periodic)"""
+    if t.requires_grad:
+        raise RuntimeError("immtsf.tpatch_decoder_te: timestamps are data; no gradient is produced for them")
+    l1, l2, l3 = seq[0], seq[2], seq[4]
+    return TPatchDecoderTEFn.apply(h.float(), t.float(), config.precision_code(precision), w0, b0, w, b, l1.weight, l1.bias, l2.weight,
+                                   l2.bias, l3.weight, l3.bias)
 
 
 # ------------------------------------------------------------------------------------------------ layer primitives

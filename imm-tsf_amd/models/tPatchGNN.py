@@ -232,9 +232,14 @@ class tPatchGNN(nn.Module):
         Lp = time_steps_to_predict.shape[-1]
         # the reference repeats the prediction times over the N variables before embedding them (:283-285); the
         # embedding is the same for every variable, so embed once per window
+        from immtsf.ops import tpatch_decoder, tpatch_decoder_supported, tpatch_decoder_te
+        fits = tpatch_decoder_supported(self.decoder, N, Lp, h.shape[-1], self.te_dim)
+        if fits and self.te_dim <= 16 and not time_steps_to_predict.requires_grad:
+            # (B,Lp,N), one kernel: LearnableTE of the prediction times is computed inside, its gradients come out of the backward kernel
+            return tpatch_decoder_te(self.decoder, h, time_steps_to_predict.reshape(B, Lp), self.te_scale.weight, self.te_scale.bias,
+                                     self.te_periodic.weight, self.te_periodic.bias)
         te = self.LearnableTE(time_steps_to_predict.view(B, 1, Lp, 1))                     # (B,1,Lp,te_dim)
-        from immtsf.ops import tpatch_decoder, tpatch_decoder_supported
-        if tpatch_decoder_supported(self.decoder, N, Lp, h.shape[-1], self.te_dim):
+        if fits:
             return tpatch_decoder(self.decoder, h, te.view(B, Lp, self.te_dim))          # (B,Lp,N), one kernel
         te_pred = te.expand(B, N, Lp, self.te_dim)                                         # expand's backward sums over N
         h = torch.cat([h.unsqueeze(2).expand(B, N, Lp, h.shape[-1]), te_pred], dim=-1)

@@ -394,6 +394,21 @@ int immtsf_tpatchgnn_decoder_forward_p(int32_t B, int32_t N, int32_t Lp, int32_t
 int immtsf_tpatchgnn_decoder_backward_p(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
                                         const float* te, const immtsf_decoder_params* p, const float* dout, float* dh,
                                         float* dte, const immtsf_decoder_params* grads, immtsf_stream_t stream);
+/* The decoder with tPatchGNN's LearnableTE of the prediction times inside (models/tPatchGNN.py:176-180 applied at :283-285): t (B, Lp)
+ * instead of te; the kernels build te[b, lp, :] = [w0 t + b0 ; sin(w t + b)] while they stage a window, and the backward reduces
+ * d te to the four parameter gradients on the spot (ACCUMULATED into tgrads by atomics, like `grads`: the same buffers may be shared
+ * with the patch encoder's time embedding).  No (B, Lp, E) tensor, no separate Time2Vec launches.  E <= 16. */
+typedef struct immtsf_time2vec_params {
+    float *w0, *b0; /* Linear(1, 1): (1, 1), (1)          */
+    float *w, *b;   /* Linear(1, E - 1): (E - 1, 1), (E - 1); NULL when E == 1 */
+} immtsf_time2vec_params;
+int immtsf_tpatchgnn_decoder_forward_te(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                        const float* t, const immtsf_time2vec_params* tp, const immtsf_decoder_params* p, float* out,
+                                        immtsf_stream_t stream);
+int immtsf_tpatchgnn_decoder_backward_te(int32_t B, int32_t N, int32_t Lp, int32_t D, int32_t E, int32_t H, int32_t precision, const float* h,
+                                         const float* t, const immtsf_time2vec_params* tp, const immtsf_decoder_params* p, const float* dout,
+                                         float* dh, const immtsf_decoder_params* grads, const immtsf_time2vec_params* tgrads,
+                                         immtsf_stream_t stream);
 
 /* ---- a16: masked per-variable MSE, compute_error(truth, pred, mask, "MSE", "mean") lib/evaluation.py:17-62.
  * pred/truth/mask (rows, C).  err_sum, cnt: (C) device buffers (outputs of the local reduction; under data

@@ -328,6 +328,40 @@ def test_fused_decoder_bf16_mfma_vs_eager(B, N, Lp, D, E):
     errs = {i: l2(a, b) for i, (a, b) in enumerate(zip(got, want_f))}
     assert all(e < 1e-1 for e in errs.values()), errs
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,N,Lp,D,E", [(64, 8, 32, 32, 10), (3, 5, 7, 32, 4), (300, 8, 32, 32, 10), (2, 3, 260, 32, 10), (4, 6, 20, 48, 2)])
+def test_decoder_with_learnable_te_inside_equals_the_two_ops(precision, B, N, Lp, D, E):
+    """tpatch_decoder_te (LearnableTE of the prediction times built while a window is staged, its gradient reduced to the four
+    parameter gradients in the backward kernel; models/tPatchGNN.py:176-180 + :283-291) against time2vec + tpatch_decoder, the same
+    kernels with te as a tensor: output, d h, the decoder's gradients identical in arithmetic; the time-embedding gradients are the
+    same sums in another order.  Gradients ACCUMULATE into what the buffers hold (the patch encoder shares them)."""
+    dev = _dev()
+    from immtsf.ops import time2vec, tpatch_decoder, tpatch_decoder_te
+    H = 32
+    torch.manual_seed(B * 31 + Lp + E)
+    dec = torch.nn.Sequential(torch.nn.Linear(D + E, H), torch.nn.ReLU(inplace=True), torch.nn.Linear(H, H),
+                              torch.nn.ReLU(inplace=True), torch.nn.Linear(H, 1)).to(dev)
+    te_s, te_p = torch.nn.Linear(1, 1).to(dev), torch.nn.Linear(1, E - 1).to(dev)
+    tw = (te_s.weight, te_s.bias, te_p.weight, te_p.bias)
+    h = torch.randn(B, N, D, device=dev, requires_grad=True)
+    t = torch.rand(B, Lp, device=dev) * 3.0
+    up = torch.randn(B, Lp, N, device=dev)
+    params = list(dec.parameters()) + list(tw)
+
+    def grads(out):
+        for q in params + [h]:
+            q.grad = None
+        (out * up).sum().backward()
+        return [h.grad.clone()] + [q.grad.clone() for q in params]
+
+    ref = tpatch_decoder(dec, h, time2vec(t, *tw), precision=precision)
+    want = grads(ref)
+    out = tpatch_decoder_te(dec, h, t, *tw, precision=precision)
+    got = grads(out)
+    assert _rel(out, ref) < 1e-6
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert _rel(a, b) < (1e-6 if i < 7 else 1e-4), (i, _rel(a, b))       # (scalar sums of cancelling terms, in another order)
+
 
 def test_fused_decoder_unsupported_shapes_fall_back():
     dev = _dev()

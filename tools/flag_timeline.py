@@ -20,7 +20,7 @@ def main():
     dev = torch.device("cuda", 0)
     config.nan_check = "deferred"
     config.manual_seed(1234)
-    w = bench.Workload("cfg2", dev, W, os.environ.get("PREC", "bf16"))
+    w = bench.Workload("cfg2", dev, W, os.environ.get("PREC", "bf16"), packed_notes=os.environ.get("PADDED", "0") != "1")
     st = bench.flag_step(w)
     if st is None:
         raise SystemExit("FlagStep not available for this workload")

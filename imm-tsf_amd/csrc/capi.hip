@@ -42,6 +42,8 @@ int immtsf_linear_backward(int32_t precision, const float* x, const float* W, co
                            immtsf_stream_t stream) {
     if (!dy || M <= 0 || N <= 0 || K <= 0 || (db && !dW) || (dx && !W) || (dW && !x)) return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // a small layer (tPatchGNN's temporal aggregation): both products in one launch, exact fp32 (linear_small.hip)
+    if (linear_small_ok(M, N, K) && (!dW || grads_prezeroed)) return launch_linear_small_bwd(x, W, dy, M, N, K, dx, relu_x, dW, db, s);
     if (dx) {                   // dx (M,K) = dy (M,N) @ W (N,K)
         GemmArgs g = gemm_args(M, K, N, N, K, K);
         set_problem(g, 0, dy, W, dx, nullptr);

@@ -107,3 +107,9 @@ int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float
 int immtsf_launch_gemm(int layout, int precision, GemmArgs& g, hipStream_t stream);
 // the weight-gradient products a block collected (immtsf_launch_gemm's arguments): one grouped launch when they qualify, else one by one
 int immtsf_launch_gemm_tn_list(int precision, GemmArgs* list, int n, hipStream_t stream);
+
+// linear_small.hip: backward of a small linear layer (N <= 32 outputs, K <= 64 inputs, M <= 4096 rows) as ONE launch; dW / db are
+// ADDED to by atomics (the buffers read zero), dx is overwritten
+bool linear_small_ok(int M, int N, int K);
+int launch_linear_small_bwd(const float* x, const float* W, const float* dy, int M, int N, int K, float* dx, const float* relu_x, float* dW,
+                            float* db, hipStream_t s);

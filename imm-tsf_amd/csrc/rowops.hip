@@ -527,6 +527,43 @@ __global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restr
     }
 }
 
+// a LayerNorm's two parameter gradients (sums of X * Y and of X) and a bias gradient (sums of Z) over the same few rows in ONE launch of
+// two workgroups -- the encoder layer's feed-forward half at <= 4096 rows of d_model 32: two single-workgroup launches on the
+// backbone's dependent backward chain before
+__global__ __launch_bounds__(1024) void colsum_small_pair_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                  const float* __restrict__ Z, int M, int N, int ld, int CT,
+                                                                  float* __restrict__ out_xy, float* __restrict__ out_x,
+                                                                  float* __restrict__ out_z) {
+    __shared__ float red[3][16 * 32];
+    const int RT = 1024 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const bool first = blockIdx.x == 0;
+    float a = 0.f, b = 0.f;
+    if (tx < N) {
+#pragma unroll 8
+        for (int r = ty; r < M; r += RT) {
+            if (first) {
+                const float x = X[(size_t)r * ld + tx];
+                a = fmaf(x, Y[(size_t)r * ld + tx], a);
+                b += x;
+            } else {
+                a += Z[(size_t)r * ld + tx];
+            }
+        }
+    }
+    a = coset_sum(a, CT);
+    b = coset_sum(b, CT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < CT) { red[0][wave * CT + lane] = a; red[1][wave * CT + lane] = b; }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        float s = 0.f, t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { s += red[0][w * CT + threadIdx.x]; t += red[1][w * CT + threadIdx.x]; }
+        if (first) { out_xy[threadIdx.x] = s; out_x[threadIdx.x] = t; }
+        else out_z[threadIdx.x] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -1210,6 +1247,16 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), kSlabs), dim3(256), 0, s, X, Y, M, dyn, N, ld, scratch);
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, scratch, N, out, accumulate);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+bool colsum_small_pair_ok(int M, int N) { return N >= 1 && N <= 32 && M >= 1 && (long)M * N <= (1L << 17); }
+int launch_colsum_small_pair(const float* X, const float* Y, const float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
+                             hipStream_t s) {
+    int CT = 1;
+    while (CT < N) CT <<= 1;
+    hipLaunchKernelGGL(colsum_small_pair_kernel, dim3(2), dim3(1024), 0, s, X, Y, Z, M, N, ld, CT, out_xy, out_x, out_z);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

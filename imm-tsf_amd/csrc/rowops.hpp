@@ -38,6 +38,11 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
                   float* scratch, hipStream_t s, bool big_scratch = false);       // big_scratch: as for launch_colsum2 (k = 1)
 // out_xy[n] = sum_m X*Y, out_x[n] = sum_m X in one pass (LayerNorm's gamma / beta gradients).  scratch >= 64*N floats.
 // big_scratch: scratch holds colsum_scratch_floats(N, 2) floats -- enables the many-row path (M >= 4096: 16-byte loads, <= 256 slabs)
+// sums of X * Y and of X (a LayerNorm's parameter gradients) and of Z (a bias gradient) over the same M rows of N <= 32 columns in one
+// launch (M * N <= 2^17)
+bool colsum_small_pair_ok(int M, int N);
+int launch_colsum_small_pair(const float* X, const float* Y, const float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
+                             hipStream_t s);
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
                    hipStream_t s, bool big_scratch = false);
 inline size_t colsum_scratch_floats(size_t ncols, int k) { return (size_t)256 * k * ((ncols + 3) & ~(size_t)3) + 64 * 8; }

@@ -596,7 +596,8 @@ def test_dropin_seam_graph_replay_equals_eager():
         assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_g)
     assert float((p_e - p_g).abs().max() / p_e.abs().max()) < 2e-4
     for a, b in zip(g1, g2):
-        assert float((b - 2 * a).abs().max()) <= 1e-5 * max(float(a.abs().max()), 1e-6)
+        # (1e-4: the time-embedding scalars are atomic sums of cancelling terms -- their order differs between the two passes)
+        assert float((b - 2 * a).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
 
 
 def test_load_state_dict_refreshes_the_bf16_twin():

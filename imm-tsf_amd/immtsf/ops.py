@@ -590,6 +590,10 @@ class MMFXRankPFn(torch.autograd.Function):
                 tail["jobs"].append(lambda stream: run_params(stream, k, 3))
             else:
                 tail["jobs"].append(lambda stream: (pre(stream), run_params(stream, 0, 3)))
+            # the block's gradients are final behind the LAST of those launches: its hook (data parallel: the bucket's announcement)
+            # fires there, on the stream that runs them
+            hook, ctx.done_hook = ctx.done_hook, None
+            tail["jobs"].append(lambda stream, hook=hook: _fire(hook))
         else:
             data_half()
             pre(stream_ptr())

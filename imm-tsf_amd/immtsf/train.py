@@ -792,10 +792,13 @@ class FlagStep(PhasedStep):
         self.P = torch.cuda.Stream(device=dev) if param_branch else self.B
         # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch (data parallel: none -- the bucket's hook must
         # fire behind its LAST gradient write, on the branch that announces it)
-        self._defer = (0 if self.dist else (3 if param_branch else 1)) if param_tail is None else int(param_tail)
+        # (data parallel without the third branch: none -- the bucket's hook must fire behind its LAST gradient write on the branch
+        # that announces it; with it, the hook rides at the end of the deferred launches on P)
+        self._defer = (3 if param_branch else (0 if self.dist else 1)) if param_tail is None else int(param_tail)
         if self.dist:
             trainer.overlap = False           # no collectives from inside the captured backward (the hooks bump flags instead)
-            self._defer = 0
+            if not param_branch:
+                self._defer = 0
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
@@ -824,6 +827,7 @@ class FlagStep(PhasedStep):
         # data parallel: counting flags 16.. (never cleared), one per announced bucket, in the order the hooks fire
         self.segments = []                    # [(flag address, lo, hi, bucket)]
         announced = set()
+        nflags = [0]
 
         def announce(bi):
             if bi in announced:
@@ -832,7 +836,10 @@ class FlagStep(PhasedStep):
             announced.add(bi)
             if hi == lo:
                 return
-            flag = fp + 4 * (16 + len(self.segments))
+            flag = fp + 4 * (16 + nflags[0])                 # (one counting flag per announcement, also the ones dropped below)
+            nflags[0] += 1
+            if nflags[0] > 15:
+                raise RuntimeError("FlagStep: more than 15 announced buckets")
             _lib.check(lib.immtsf_flag_bump(flag, torch.cuda.current_stream().cuda_stream), "flag_bump")
             self.segments.append((flag, lo, hi, bi))
 
@@ -890,11 +897,16 @@ class FlagStep(PhasedStep):
                     # reduced behind the graph together with whatever else is left (cfg2: TTF + the backbone, adjacent ranges, ONE
                     # collective); its flag bump stays in the graph, unread
                     announced.discard(self.segments.pop()[3])
+                trainer._capture_hook = announce if self.dist else None
+                try:
+                    with torch.cuda.stream(P):
+                        if tail["jobs"]:
+                            fwait(fp + 16, P)
+                            for job in tail["jobs"]:
+                                job(sp(P))
+                finally:
+                    trainer._capture_hook = None
                 with torch.cuda.stream(P):
-                    if tail["jobs"]:
-                        fwait(fp + 16, P)
-                        for job in tail["jobs"]:
-                            job(sp(P))
                     if P is not B:
                         fset(F_P2, P)
                 with torch.cuda.stream(B):

@@ -17,4 +17,4 @@ print('ms', d['ms_per_step'], 'value', d['value'], d['engine']); print('roofline
 print('sweep', [(s['windows_per_gpu'], s['ms_per_step']) for s in d['sweep']]); print('other notes form', (d.get('padded') or d.get('packed'))['ms_per_step'], 'fp32', d['ms_per_step_fp32'], 'dropin', d['dropin']['ms_per_step'], d['dropin']['ms_per_step_nan_guards_sync'])
 print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores']); print('step_stats', d['step_stats'])"
 timeout 600 python3 bench.py --no-extras --no-cpu-baseline --no-roofline --force-dist > $O/r04_bench_line_force_dist.json 2>/dev/null
-python3 -c "import json; d=json.load(open('$O/r04_bench_line_force_dist.json')); print('force-dist', d['ms_per_step'], d['config']['grad_allreduce'])"
+python3 -c "import json; d=json.loads(open('$O/r04_bench_line_force_dist.json').read().strip().splitlines()[-1]); print('force-dist', d['ms_per_step'], d['config']['grad_allreduce'])"

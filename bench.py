@@ -485,7 +485,7 @@ def build_step(w, mode="auto", dist_on=False, captured_comm=False):
         info["flag_step_rejected"] = flag_fns(w) is not None and not trainer.sharded
     if dist_on:
         trainer.overlap = False
-    step = GraphedStep(trainer, w.loss_fn)
+    step = GraphedStep(trainer, w.loss_fn, **json.loads(os.environ.get("IMMTSF_BENCH_GRAPH_KW", "{}")))      # (A/B measurements only)
     info["engine"] = "graphed"
     return step, info
 

@@ -391,6 +391,9 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
     CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, hf ? sc.dza.h : (void*)sc.dza.f,
                              sc.dbo_part, drop, SITE_T2V_ATTN, s));
+    // (the row-bound kernels of the block are behind us: see the header.  In FRONT of the mix the hint cost 7 % at 4096 windows)
+    if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
+
     {   // Time2Vec rows: dX_tau = dz_aug W_aug[:, d_m:]  (the score path rides in the augmented column)
         GemmArgs g = gemm_args(R, dt, Ma, Ma, dmc, dt);
         set_problem2(g, 0, sc.dza, mat_off(w.Wa, d_m), mat(sc.dXt), nullptr);
@@ -605,6 +608,8 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     T2VScratch sc = carve_t2v_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (the chain as written has no small-launch tail to share the chip with: whoever waits for the hint goes ahead at once)
+    if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H;
     const int R = B * N, BT = B * T, prec = cfg->precision;
     const DropCfg drop = drop_of(cfg);

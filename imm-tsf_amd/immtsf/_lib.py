@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 FORM_NO_PROJ = 16        # immtsf_fusion_cfg.form bit (IMMTSF_FORM_NO_PROJ)
 
 
@@ -32,7 +32,7 @@ class FusionCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("d_m", C.c_int32),
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
                 ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("grads_prezeroed", C.c_int32),
-                ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p)]
+                ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p), ("sched_flag", C.c_void_p)]
 
 
 def _ptr_struct(name, fields):

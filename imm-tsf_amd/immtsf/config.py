@@ -115,4 +115,7 @@ fold_stream = None
 param_tail = None        # FlagStep: {"flag": (address, time-out report address), "jobs": []} -- ops whose parameter-gradient tail nothing but the
                          # optimizer waits for (MMF_XAttn_Add's chain rule through the fold) set the flag behind the data half and
                          # leave the tail as a job (a callable taking a raw stream) for the branch that has time to spare
+sched_gate = None        # GraphedStep: (flag address, time-out report address) -- TTF_T2V_XAttn's backward sets the flag behind its row-bound
+                         # kernels, the patch encoder's backward (parameter gradients only, on the backbone's stream) spins on it first
+sched_armed = None       # stream of the TTF_T2V_XAttn forward that will set it (None: nobody will -- nobody may wait)
 fold_flag = None          # (flag address, time-out report address): hand the fold over through a device flag instead of a stream event

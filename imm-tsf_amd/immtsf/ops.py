@@ -191,6 +191,12 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         if E_h is not None:
             _shadow_put(E, E_h)
         ctx.cfg, ctx.ws, ctx.src_rows = cfg, ws, src_rows
+        # scheduling hint of a two-stream captured step (immtsf.train.GraphedStep): this call's backward will set the gate behind its
+        # row-bound kernels; remember who promised, so that nobody waits for a flag nobody sets
+        ctx.gate = None
+        if config.sched_gate is not None and training:
+            ctx.gate = config.sched_gate[0]
+            config.sched_armed = torch.cuda.current_stream().cuda_stream
         ctx.save_for_backward(notes, tau, *[p if p is not None else notes.new_empty(0) for p in params])
         ctx.none_mask = [p is None for p in params]
         ctx.sinks = _sinks_of(params)
@@ -212,6 +218,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttf_t2v_xattn_scratch_bytes(C.byref(ctx.cfg)), notes.device)
         ps, gs = _struct(T2VParams, params), _struct(T2VParams, grads)
+        ctx.cfg.sched_flag = ctx.gate
         dE_h = _shadow_get(dE) if _bf16_dataflow(ctx.cfg.precision, ctx.cfg.d) else None
         ctx.cfg.in_h = None if dE_h is None else dE_h.data_ptr()
         if ctx.src_rows is not None:
@@ -792,6 +799,11 @@ class TTCNPatchEncodeFn(torch.autograd.Function):
         grads, rets = _grad_buffers(params, ctx.sinks)
         sc = _bytes(lib.immtsf_ttcn_scratch_bytes(P, L, te_dim, K), x.device)
         ps, gs = _struct(TTCNParams, params), _struct(TTCNParams, grads)
+        g = config.sched_gate
+        if g is not None and config.sched_armed is not None and config.sched_armed != torch.cuda.current_stream().cuda_stream:
+            # parameter gradients only, chip-filling, nothing but the optimizer waits for them: go behind the text side's row-bound
+            # backward kernels (a hint: the spin gives up after 50 ms and the call proceeds)
+            check(lib.immtsf_flag_wait(g[0], g[1], 50, stream_ptr()), "flag_wait")
         check(lib.immtsf_ttcn_backward(P, L, te_dim, K, precision, ptr(x), ptr(tt), ptr(mask), C.byref(ps), ptr(out), ptr(dout), ld,
                                        ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), 1 if te_acc else 0, stream_ptr()),
               "ttcn_backward")

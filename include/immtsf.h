@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMMTSF_ABI_VERSION 3
+#define IMMTSF_ABI_VERSION 4
 #define IMMTSF_T2V_FOLD_MIN_ROWS 8192 /* see immtsf_fusion_cfg.form */
 #define IMMTSF_FORM_NO_PROJ 16        /* immtsf_fusion_cfg.form bit, TTF_T2V_XAttn: leave proj_out to the consumer (E_txt := Z, dE_txt := dZ,
                                          which the backward overwrites in place; proj_out's gradients are not written) */
@@ -81,6 +81,11 @@ typedef struct immtsf_fusion_cfg {
     const void* in_h;
     const void* aux_h;
     void* out_h;
+    int32_t* sched_flag;           /* TTF_T2V_XAttn backward, optional (NULL = off): a device flag (immtsf_flag_*) the call sets to 1 behind the
+                                      last launch of its row-bound part -- what follows are parameter chains of small launches.  A SCHEDULING
+                                      HINT, not a dependency: a caller that runs chip-filling work nothing waits for on another stream (the
+                                      patch encoder's backward) lets it spin on this flag, so that it shares the chip with the small launches
+                                      instead of the row-bound ones.  (ABI 4) */
 } immtsf_fusion_cfg;
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)

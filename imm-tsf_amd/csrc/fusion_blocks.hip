@@ -391,7 +391,8 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
     CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, hf ? sc.dza.h : (void*)sc.dza.f,
                              sc.dbo_part, drop, SITE_T2V_ATTN, s));
-    // (the row-bound kernels of the block are behind us: see the header.  In FRONT of the mix the hint cost 7 % at 4096 windows)
+    // (the row-bound kernels of the block are behind us: see the header.  Measured at 4096 windows: no hint 4.75 ms, here 4.63, in front
+    // of the mix 4.96, behind the last weight-gradient GEMM 5.30)
     if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
 
     {   // Time2Vec rows: dX_tau = dz_aug W_aug[:, d_m:]  (the score path rides in the augmented column)

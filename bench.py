@@ -403,7 +403,9 @@ class Workload:
         self.trainer.close()
 
 
-FLAGS_MAX_WINDOWS = 512      # FlagStep wins where the step is a latency chain (64 windows: -3 %, 256: -2 %, 512: -1 %); beyond, GraphedStep
+FLAGS_MAX_WINDOWS = 4096     # FlagStep (three branches, device flags) against GraphedStep (graph edges), round 4: 256 windows 0.873 / 0.976 ms,
+#                              512: 1.169 / 1.220, 1024: 1.601 / 1.688, 2048: 2.640 / 2.698, 4096: 4.638 / 4.682; beyond: not measured
+FLAGS_GATE_MIN_WINDOWS = 2048    # FlagStep's scheduling hint (sched_gate): 512 windows 1.165 with / 1.157 without, 1024: 1.626 / 1.603, 4096: 4.638 / 4.726
 
 
 def flag_fns(w):
@@ -436,7 +438,9 @@ def flag_step(w):
     fns = flag_fns(w)
     if fns is None or w.trainer.sharded:
         return None
-    st = FlagStep(w.trainer, *fns, **json.loads(os.environ.get("IMMTSF_BENCH_FLAG_KW", "{}")))      # (A/B measurements only)
+    kw = {"sched_gate": w.B >= FLAGS_GATE_MIN_WINDOWS}
+    kw.update(json.loads(os.environ.get("IMMTSF_BENCH_FLAG_KW", "{}")))      # (A/B measurements only)
+    st = FlagStep(w.trainer, *fns, **kw)
     snap = w.trainer.snapshot()
     for _ in range(3):
         st()
@@ -825,7 +829,7 @@ def main():
                     help="immtsf.train.PhasedStep: six single-stream hipGraphs on two HIP streams with events between them, instead "
                          "of the whole step as parallel branches of one hipGraph (DESIGN.md section 6 has both measured)")
     ap.add_argument("--flags", action="store_true",
-                    help="immtsf.train.FlagStep at any batch size: one hipGraph whose two branches synchronise through device flags "
+                    help="immtsf.train.FlagStep at any batch size: one hipGraph whose branches synchronise through device flags "
                          f"(spin kernels) instead of graph edges (the default up to {FLAGS_MAX_WINDOWS} windows per GPU)")
     ap.add_argument("--no-flags", action="store_true", help="GraphedStep (graph edges between the branches) at every batch size")
     ap.add_argument("--captured-comm", action="store_true",
@@ -926,8 +930,8 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(w.global_cnt)
 
-    # hipGraph replay.  One process: ONE graph per step whose two branches (text side | backbone) synchronise through device flags
-    # (immtsf.train.FlagStep) up to FLAGS_MAX_WINDOWS windows per GPU, beyond that graph edges (GraphedStep).  N > 1: the same flag
+    # hipGraph replay.  One process: ONE graph per step whose branches (text side | backbone | parameter-only work) synchronise through
+    # device flags (immtsf.train.FlagStep) up to FLAGS_MAX_WINDOWS windows per GPU, beyond that graph edges (GraphedStep).  N > 1: the same flag
     # graph without the optimizer, the bucketed all-reduce on a communication stream BESIDE the backward (a counting device flag per
     # bucket), what completes with the join reduced behind the graph, then graph B = clip + Adam
     mode = "eager" if not use_graph else "phased" if args.phased else "graphed" if (args.no_flags or args.no_overlap) else \
@@ -943,7 +947,7 @@ def main():
         raise
     eng = step_info["engine"]
     launch_mode = {"eager": "eager launches",
-                   "flags": "hipGraph replay: 1 graph per step, two branches (text side | backbone) synchronised by device flags",
+                   "flags": "hipGraph replay: 1 graph per step, three branches (text side | backbone | parameter-only work) synchronised by device flags",
                    "phased": "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them",
                    "graphed": "hipGraph replay (2 graphs/step)", "graphed+captured-comm": "hipGraph replay (2 graphs/step)"}[eng]
     if eng == "graphed" and getattr(step, "single", False):

@@ -789,7 +789,7 @@ class FlagStep(PhasedStep):
     `flags[8]` is the guard word: `timed_out()` / `check()`."""
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
-                 fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True):
+                 fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True):
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
         if trainer.sharded:
@@ -868,6 +868,9 @@ class FlagStep(PhasedStep):
                     P.wait_stream(T)
                 config.fold_stream = P                # parameter-only work of the text side: on its own branch (or at the head of the backbone's)
                 config.fold_flag = (fp + 12, F_ERR) if fold_by_flag else None
+                # scheduling hint (GraphedStep._fwd_bwd has the why): flag 6, its time-out goes to word 7 -- NOT the guard word, a hint
+                # that expires costs nothing but the overlap it was after
+                config.sched_gate, config.sched_armed = ((fp + 24, fp + 28) if sched_gate else None), None
                 try:
                     outs = text_fn()
                 finally:
@@ -928,7 +931,7 @@ class FlagStep(PhasedStep):
                 if P is not B:
                     fwait(F_P2, T)
                     T.wait_stream(P)
-                _lib.check(lib.immtsf_flags_clear(fp, 6, sp(T)), "flags_clear")
+                _lib.check(lib.immtsf_flags_clear(fp, 8, sp(T)), "flags_clear")
                 if not self.dist:
                     trainer.step()
             self.graph_b = None
@@ -948,6 +951,7 @@ class FlagStep(PhasedStep):
                     trainer.step()
         finally:
             trainer.step_guard = None
+            config.sched_gate = config.sched_armed = None
         self._epoch = 0
         self._ev = torch.cuda.Event()
         self.loss = loss

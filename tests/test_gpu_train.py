@@ -632,7 +632,7 @@ def test_load_state_dict_refreshes_the_bf16_twin():
     assert l1 == l2, (l1, l2)                               # and the hook left nothing stale
 
 
-@pytest.mark.parametrize("engine", ["flags", "flags_packed", "graphed"])
+@pytest.mark.parametrize("engine", ["flags", "flags_packed", "flags_fold", "graphed", "graphed_fold"])
 @pytest.mark.parametrize("precision,tol_loss,tol_param,tol_delta", [("fp32", 1e-4, 3e-4, 5e-3), ("bf16", 3e-2, 3e-3, 2.5e-1)])
 def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     """The BENCHMARKED composition against the oracle, not against itself: three cfg2 training steps (tPatchGNN -> TTF_T2V_XAttn
@@ -640,7 +640,9 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     bench.py times: "flags" = immtsf.train.FlagStep (one hipGraph, the two branches synchronised by device flags, the head publishing
     the dY flag mid-kernel, MMF_XAttn_Add's fold and parameter tail on the backbone's branch, grouped weight gradients: the headline
     engine), "flags_packed" = the same with the notes handed over as PackedNotes (the `packed` companion), "graphed" = GraphedStep
-    (graph edges: the engine beyond 512 windows per GPU) -- vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
+    (graph edges); "flags_fold" / "graphed_fold" = the same two engines with TTF_T2V_XAttn forced into its folded form (what the
+    size rule picks from 256 windows on: under FlagStep the fold's parameter-only halves run on the parameter branch behind their own
+    flags, under GraphedStep the scheduling hint is live) -- vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
     torch.optim.Adam on the CPU from identical weights (reference: lib/evaluation.py:72-164, main.py:1093-1101).  Dropout 0.
     Bars: loss of every step `tol_loss` relative; final parameters `tol_param` relative L2; the three-step UPDATE (p_final -
     p_init) `tol_delta` relative L2 -- in bf16 mode the update of weakly driven parameters carries the operands' 2^-9 rounding."""
@@ -653,6 +655,8 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     old_drop = bench.P_DROP
     bench.P_DROP = 0.0
     config.nan_check = "deferred"       # no host syncs inside the captured step (what bench.py sets)
+    old_form = config.t2v_form
+    config.t2v_form = "fold" if engine.endswith("_fold") else "auto"
     try:
         w = bench.Workload("cfg2", dev, 64, precision, device_step=True, packed_notes=engine == "flags_packed")
         # Adam eps 1e-3 on both sides: with 1e-8 the sign-like first steps turn 1e-9 summation-order noise on gradients that are
@@ -686,11 +690,12 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
             torch.nn.utils.clip_grad_norm_(list(ref_model.parameters()) + list(params.values()), 1.0)
             opt.step()
             ref_losses.append(float(loss))
-        step, info = bench.build_step(w, "graphed" if engine == "graphed" else "flags")          # (warm-up / trial steps are undone)
-        assert info["engine"] == ("graphed" if engine == "graphed" else "flags") and not info["flag_step_rejected"], info
+        eng = "graphed" if engine.startswith("graphed") else "flags"
+        step, info = bench.build_step(w, eng)          # (warm-up / trial steps are undone)
+        assert info["engine"] == eng and not info["flag_step_rejected"], info
         got_losses = [float(step()) for _ in range(3)]
         torch.cuda.synchronize()
-        if engine != "graphed":
+        if eng != "graphed":
             step.check()                                  # no spin gave up: no step was dropped
         for g_, r_ in zip(got_losses, ref_losses):
             assert abs(g_ - r_) <= tol_loss * abs(r_), (got_losses, ref_losses)
@@ -715,6 +720,7 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     finally:
         bench.P_DROP = old_drop
         config.precision = "fp32"
+        config.t2v_form = old_form
 
 
 @pytest.mark.gpu

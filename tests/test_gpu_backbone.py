@@ -360,7 +360,9 @@ def test_decoder_with_learnable_te_inside_equals_the_two_ops(precision, B, N, Lp
     got = grads(out)
     assert _rel(out, ref) < 1e-6
     for i, (a, b) in enumerate(zip(got, want)):
-        assert _rel(a, b) < (1e-6 if i < 7 else 1e-4), (i, _rel(a, b))       # (scalar sums of cancelling terms, in another order)
+        # (the decoder's gradients are atomic sums -- their order differs from launch to launch: 1e-5; the time embedding's are scalar
+        # sums of cancelling terms in another order: 1e-4)
+        assert _rel(a, b) < (1e-5 if i < 7 else 1e-4), (i, _rel(a, b))
 
 
 def test_fused_decoder_unsupported_shapes_fall_back():

@@ -741,9 +741,8 @@ int launch_ttcn_full_fwd(int P, int L, int F, int K, const float* x, const float
     const TEp te{p->te_scale_w, p->te_scale_b, p->te_per_w, p->te_per_b};
     const Wts w{q.W1p, q.b1p, q.W2p, q.b2p, q.W3q, q.b3q};
     const int mf = (F + 3) / 4;
-    const int fgrid = getenv("TTCN_FWD_GRID") ? atoi(getenv("TTCN_FWD_GRID")) : 2048;
 #define TTCN_FWD(RT, MF)                                                                                                                     \
-    hipLaunchKernelGGL((ttcn_full_fwd_kernel<RT, MF>), dim3(P < fgrid ? P : fgrid), dim3(256), fwd_lds(RT, d.NCq), s, d, x, tt, mask, te, w, q.W3h, p->T_bias, ctr, \
+    hipLaunchKernelGGL((ttcn_full_fwd_kernel<RT, MF>), dim3(P < 2048 ? P : 2048), dim3(256), fwd_lds(RT, d.NCq), s, d, x, tt, mask, te, w, q.W3h, p->T_bias, ctr, \
                        out, out_ld, flag_col)
     if (L <= 32) {
         if (mf == 1) TTCN_FWD(2, 1); else if (mf == 2) TTCN_FWD(2, 2); else if (mf == 3) TTCN_FWD(2, 3); else TTCN_FWD(2, 4);

@@ -755,7 +755,7 @@ class PhasedStep:
 
 
 class FlagStep(PhasedStep):
-    """PhasedStep's decomposition (text / backbone / head) as ONE hipGraph whose two branches have NO edges between the fork at
+    """PhasedStep's decomposition (text / backbone / head) as ONE hipGraph whose branches have NO edges between the fork at
     the start of the step and the join in front of the optimizer: where a branch needs the other's result it spins on a device
     flag (csrc/sync.hip) instead of waiting on an event.
 

@@ -637,7 +637,7 @@ def test_load_state_dict_refreshes_the_bf16_twin():
 def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     """The BENCHMARKED composition against the oracle, not against itself: three cfg2 training steps (tPatchGNN -> TTF_T2V_XAttn
     -> MMF_XAttn_Add -> masked MSE -> clip 1.0 -> Adam) at B = 64, d = 768 through bench.Workload + bench.build_step -- exactly what
-    bench.py times: "flags" = immtsf.train.FlagStep (one hipGraph, the two branches synchronised by device flags, the head publishing
+    bench.py times: "flags" = immtsf.train.FlagStep (one hipGraph, three branches synchronised by device flags, the head publishing
     the dY flag mid-kernel, MMF_XAttn_Add's fold and parameter tail on the backbone's branch, grouped weight gradients: the headline
     engine), "flags_packed" = the same with the notes handed over as PackedNotes (the `packed` companion), "graphed" = GraphedStep
     (graph edges); "flags_fold" / "graphed_fold" = the same two engines with TTF_T2V_XAttn forced into its folded form (what the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the two branches of immtsf.train.FlagStep wait for each other inside a replayed step: the flag kernels' own trace
+"""Where the branches of immtsf.train.FlagStep wait for each other inside a replayed step: the flag kernels' own trace
 (immtsf_flag_trace, 100 MHz device wall clock -- no profiler, nothing serialised).  Prints, per step, the time of every flag event
 after the previous step's flags_clear, and how long each wait spun.  usage: flag_timeline.py [windows] [steps]"""
 import ctypes as C

@@ -638,11 +638,11 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
     """The BENCHMARKED composition against the oracle, not against itself: three cfg2 training steps (tPatchGNN -> TTF_T2V_XAttn
     -> MMF_XAttn_Add -> masked MSE -> clip 1.0 -> Adam) at B = 64, d = 768 through bench.Workload + bench.build_step -- exactly what
     bench.py times: "flags" = immtsf.train.FlagStep (one hipGraph, three branches synchronised by device flags, the head publishing
-    the dY flag mid-kernel, MMF_XAttn_Add's fold and parameter tail on the backbone's branch, grouped weight gradients: the headline
-    engine), "flags_packed" = the same with the notes handed over as PackedNotes (the `packed` companion), "graphed" = GraphedStep
-    (graph edges); "flags_fold" / "graphed_fold" = the same two engines with TTF_T2V_XAttn forced into its folded form (what the
-    size rule picks from 256 windows on: under FlagStep the fold's parameter-only halves run on the parameter branch behind their own
-    flags, under GraphedStep the scheduling hint is live) -- vs oracle/tpatchgnn_ref.py + oracle/fusion_ref.py +
+    the dY flag mid-kernel, MMF_XAttn_Add's fold and parameter chain on the parameter branch, grouped weight gradients), "flags_packed"
+    = the same with the notes handed over as PackedNotes (bench.py's default hand-over), "graphed" = GraphedStep (graph edges);
+    "flags_fold" / "graphed_fold" = the same two engines with TTF_T2V_XAttn forced into its folded form (what the size rule picks from
+    256 windows on; the scheduling hint between its backward and the patch encoder's is live) -- vs oracle/tpatchgnn_ref.py +
+    oracle/fusion_ref.py +
     torch.optim.Adam on the CPU from identical weights (reference: lib/evaluation.py:72-164, main.py:1093-1101).  Dropout 0.
     Bars: loss of every step `tol_loss` relative; final parameters `tol_param` relative L2; the three-step UPDATE (p_final -
     p_init) `tol_delta` relative L2 -- in bf16 mode the update of weakly driven parameters carries the operands' 2^-9 rounding."""

@@ -1036,6 +1036,11 @@ def main():
             sweep.append({"windows_per_gpu": nw, "ms_per_step": round(ms, 4), "windows_per_s": round(nw / ms * 1e3, 1),
                           "fusion_algorithmic_tflops": round(tf, 2), "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4),
                           "fusion_executed_tflops": round(fusion_executed_flops_per_window(ww.sum_n, nw, "cfg2") * nw / (ms * 1e-3) / 1e12, 2)})
+            if nw == 4096:      # the gather / mask path where it is not one launch latency long: the index scan over 403 MB of padded notes
+                try:
+                    extras["roofline_hbm_4096_windows"] = hbm_roofline(ww, lib, None)
+                except Exception as e:           # noqa: BLE001 -- a companion figure must not cost the line
+                    extras["roofline_hbm_4096_windows"] = {"error": str(e)[:200]}
             ww.close()
             del st, ww
         extras["sweep"] = sweep

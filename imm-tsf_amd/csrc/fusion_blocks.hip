@@ -323,11 +323,18 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
     CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
                              drop, SITE_T2V_ATTN, s));
+    // bf16 dataflow: x_hat's only reader is the LayerNorm backward with sums, which widens on load -- it is stored as bf16 alone (in the
+    // fp32 image's place) wherever that kernel will take the shape (the backward makes the same test)
+    const bool compact = hf && ln_sums_compact_ok(BT, d);
+    float* xhat_f = compact ? nullptr : w.xhat;
+    void* xhat_h = compact ? static_cast<void*>(w.xhat) : nullptr;
+    const DropCfg nodrop = DropCfg{0, 0.f, 1.f, nullptr};
     if (cfg->form & IMMTSF_FORM_NO_PROJ) {       // proj_out is the consumer's (immtsf_mmf_xrank_p_forward_z): hand over Z itself
-        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
-                                    hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr);
+        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
+                                    hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr, nullptr, nodrop, 0, xhat_h);
     }
-    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.zln.f, drop, SITE_T2V_OUT, s, w.zln.h));
+    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, w.zln.f, drop, SITE_T2V_OUT, s, w.zln.h, nullptr, nodrop, 0,
+                               xhat_h));
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, w.zln, W.po, mat(E_txt, hf ? cfg->out_h : nullptr), p->proj_out_b);
@@ -378,9 +385,15 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
         wg[nwg++] = h;
     }
+    // (compact: the forward stored x_hat as bf16 alone, and dx's one reader -- the mix backward -- takes its bf16 image: 1.6 GB of this
+    // kernel's 2.0 at 4096 windows were those two fp32 images)
+    const bool compact = hf && ln_sums_compact_ok(BT, d);
     {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
-        const int rc = launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                 gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
+        const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, nullptr, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                           gr->Q_param, sc.red, w.mtxt, T, sc.dx, s, w.xhat)
+                               : launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                           gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
+        if (compact && rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (the forward's test promised this path)
         if (rc == IMMTSF_EUNSUPPORTED) {
             CHECK(launch_layernorm_bwd(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, s));
             CHECK(launch_colsum3(dzln, w.xhat, sc.dx, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, nullptr, s, true));
@@ -389,8 +402,8 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         }
     }
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
-    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, hf ? sc.dza.h : (void*)sc.dza.f,
-                             sc.dbo_part, drop, SITE_T2V_ATTN, s));
+    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, compact ? 1 : 0,
+                             hf ? sc.dza.h : (void*)sc.dza.f, sc.dbo_part, drop, SITE_T2V_ATTN, s));
     // (the row-bound kernels of the block are behind us: see the header.  Measured at 4096 windows: no hint 4.75 ms, here 4.63, in front
     // of the mix 4.96, behind the last weight-gradient GEMM 5.30)
     if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));

@@ -727,8 +727,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
                                                                  float eps, float* __restrict__ xhat, float* __restrict__ rstd,
                                                                  float* __restrict__ z, DropCfg drop, uint64_t site,
                                                                  bf16_t* __restrict__ zh, const float* __restrict__ res,
-                                                                 DropCfg pre, uint64_t presite) {
+                                                                 DropCfg pre, uint64_t presite, bf16_t* __restrict__ xhat_h) {
     // res != null: the normalised row is res + dropout_pre(x) (post-norm residual block: LayerNorm(x_in + Dropout(branch)))
+    // xhat_h: x_hat as a bf16 image (with xhat == null: INSTEAD of the fp32 one -- its only reader, the backward, can take either)
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6), d4 = d >> 2;
     if (row >= rows) return;
     const float4* p = reinterpret_cast<const float4*>(x + (size_t)row * d);
@@ -762,6 +763,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
         if (q < d4) {
             const float4 h = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
             if (xhat) reinterpret_cast<float4*>(xhat + (size_t)row * d)[q] = h;
+            if (xhat_h) {
+                const bf16x4 hh = {(bf16_t)h.x, (bf16_t)h.y, (bf16_t)h.z, (bf16_t)h.w};
+                reinterpret_cast<bf16x4*>(xhat_h + (size_t)row * d)[q] = hh;
+            }
             const float4 g = reinterpret_cast<const float4*>(gamma)[q], b = reinterpret_cast<const float4*>(beta)[q];
             float sc[4];
             dropout_scale4(drop, site, (uint64_t)row * d + (uint64_t)q * 4, sc);
@@ -832,12 +837,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(float* __restric
 // what the text side's colsum3 pass did on its way: rows whose row_flag[row / flag_div] == 0 are zeroed in dx (AFTER their
 // contribution to the third sum) and dx's bf16 image is written.  Saves the separate pass over dz, xhat and dx (3 x rows x d x 4
 // bytes: 1.3 GB at 4096 windows) and a launch.
-template <int K>
-__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(float* __restrict__ dz_dy, int rows, int d, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ xhat, const float* __restrict__ rstd,
+// XH: x_hat comes as the bf16 image the forward wrote instead of the fp32 one (launch_layernorm_fwd's xhat_h); dx may be null when
+// its bf16 image dxh is all the consumer reads: 0.8 GB in + 0.4 GB out per launch at 4096 windows become 0.6 + 0.2
+template <int K, bool XH>
+__global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float* __restrict__ dz_dy, int rows, int d, const float* __restrict__ gamma,
+                                                                  const void* __restrict__ xhat_any, const float* __restrict__ rstd,
                                                                   float* __restrict__ dx, DropCfg drop, uint64_t site,
                                                                   float* __restrict__ partial, const unsigned char* __restrict__ row_flag,
                                                                   int flag_div, bf16_t* __restrict__ dxh) {
+    const float* xhat = XH ? nullptr : static_cast<const float*>(xhat_any);
+    const bf16_t* xhat_h = XH ? static_cast<const bf16_t*>(xhat_any) : nullptr;
     extern __shared__ __attribute__((aligned(16))) float ln_red[];       // [3 waves][K][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d4 = d >> 2;
     float4 sw[LN_DV], sb[LN_DV], sq[K == 3 ? LN_DV : 1];
@@ -854,7 +863,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(float* __restri
     }
     for (int row = blockIdx.x * 4 + wave; row < rows; row += 4 * gridDim.x) {
         const float4* g = reinterpret_cast<const float4*>(dz_dy + (size_t)row * d);
-        const float4* h = reinterpret_cast<const float4*>(xhat + (size_t)row * d);
+        const float4* h = XH ? nullptr : reinterpret_cast<const float4*>(xhat + (size_t)row * d);
+        const bf16x4* hh = XH ? reinterpret_cast<const bf16x4*>(xhat_h + (size_t)row * d) : nullptr;
         float4 tv[LN_DV], hv[LN_DV];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -869,7 +879,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(float* __restri
                 dy = make_float4(dy.x * sc[0], dy.y * sc[1], dy.z * sc[2], dy.w * sc[3]);
                 // (dy is NOT written back: its only readers were the column sums, which are formed right here -- 0.4 GB of the kernel's
                 // 1.6 GB at 4096 windows with dropout on)
-                hv[j] = h[q];
+                if (XH) { const bf16x4 t4 = hh[q]; hv[j] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]); }
+                else hv[j] = h[q];
                 sw[j].x = fmaf(dy.x, hv[j].x, sw[j].x); sw[j].y = fmaf(dy.y, hv[j].y, sw[j].y);
                 sw[j].z = fmaf(dy.z, hv[j].z, sw[j].z); sw[j].w = fmaf(dy.w, hv[j].w, sw[j].w);
                 sb[j].x += dy.x; sb[j].y += dy.y; sb[j].z += dy.z; sb[j].w += dy.w;
@@ -890,7 +901,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(float* __restri
                                        rs * (tv[j].z - c1 - hv[j].z * c2), rs * (tv[j].w - c1 - hv[j].w * c2));
                 if (K == 3) { sq[j].x += o.x; sq[j].y += o.y; sq[j].z += o.z; sq[j].w += o.w; }
                 if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
-                reinterpret_cast<float4*>(dx + (size_t)row * d)[q] = o;
+                if (dx) reinterpret_cast<float4*>(dx + (size_t)row * d)[q] = o;
                 if (K == 3 && dxh) {
                     const bf16x4 hvv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
                     reinterpret_cast<bf16x4*>(dxh + (size_t)row * d)[q] = hvv;
@@ -1305,15 +1316,15 @@ int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int l
 
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh, const float* res, DropCfg pre,
-                         uint64_t presite) {
+                         uint64_t presite, void* xhat_h) {
     if (rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(xhat) |
                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(res);
-    if ((d & 3) == 0 && d <= 256 * LN_DV && (al & 15) == 0)
+    if ((d & 3) == 0 && d <= 256 * LN_DV && (al & 15) == 0 && (reinterpret_cast<uintptr_t>(xhat_h) & 7) == 0)
         hipLaunchKernelGGL(layernorm_fwd_vec_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
-                           drop, site, static_cast<bf16_t*>(zh), res, pre, presite);
-    else if (res)
-        return IMMTSF_EUNSUPPORTED;      // the residual form needs d % 4 == 0, d <= 1024 and 16-byte aligned rows
+                           drop, site, static_cast<bf16_t*>(zh), res, pre, presite, static_cast<bf16_t*>(xhat_h));
+    else if (res || xhat_h)
+        return IMMTSF_EUNSUPPORTED;      // the residual form and the bf16 x_hat image need d % 4 == 0, d <= 1024 and 16-byte aligned rows
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, d, gamma, beta, eps, xhat, rstd, z,
                            drop, site, static_cast<bf16_t*>(zh));
@@ -1341,14 +1352,20 @@ int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, cons
 // LayerNorm backward + its parameter-gradient sums in one pass (+ final reduce): out_gw = sum_rows dy * xhat, out_gb = sum_rows dy,
 // out_q (optional) = sum_rows dx; row_flag / dxh: see the kernel.  scratch: ln_sums_scratch_floats(d, 3 or 2) floats.
 // IMMTSF_EUNSUPPORTED when the vector path does not apply (the caller then runs launch_layernorm_bwd + launch_colsum2/3).
+bool ln_sums_compact_ok(int rows, int d) {        // the K = 3 kernel's own limits, for callers that store x_hat / dx as bf16 only
+    return (d & 3) == 0 && d <= 256 * LN_DV && rows >= 512 && (size_t)3 * 3 * d * sizeof(float) <= 64 * 1024;
+}
 int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd, float* dx,
                               DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
-                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s) {
+                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s, const void* xhat_h) {
     if (rows <= 0) return IMMTSF_OK;
     constexpr bool on = true;
     const uintptr_t al = reinterpret_cast<uintptr_t>(dz_dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(xhat) |
                          reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(scratch);
-    if (!on || (d & 3) || d > 256 * LN_DV || (al & 15) || (reinterpret_cast<uintptr_t>(dxh) & 7) || rows < 512) return IMMTSF_EUNSUPPORTED;
+    if (!on || (d & 3) || d > 256 * LN_DV || (al & 15) || ((reinterpret_cast<uintptr_t>(dxh) | reinterpret_cast<uintptr_t>(xhat_h)) & 7) ||
+        rows < 512)
+        return IMMTSF_EUNSUPPORTED;
+    if ((!xhat && !xhat_h) || (!dx && !dxh)) return IMMTSF_EINVAL;
     // one row per wave up to 2048 workgroups (a wave's rows are a dependent chain: few rows per wave, many waves), then more rows
     // per wave; the partial sums are nsl x K x d floats (ln_sums_scratch_floats)
     int nsl = (rows + 3) / 4;
@@ -1356,13 +1373,17 @@ int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma,
     const size_t lds = (size_t)3 * (out_q ? 3 : 2) * d * sizeof(float);
     if (out_q) {
         if (lds > 64 * 1024) return IMMTSF_EUNSUPPORTED;
-        hipLaunchKernelGGL((layernorm_bwd_sums_kernel<3>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site, scratch,
-                           row_flag, flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(dxh));
+        if (xhat_h)
+            hipLaunchKernelGGL((layernorm_bwd_sums_kernel<3, true>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat_h, rstd, dx, drop, site,
+                               scratch, row_flag, flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(dxh));
+        else
+            hipLaunchKernelGGL((layernorm_bwd_sums_kernel<3, false>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site,
+                               scratch, row_flag, flag_div > 0 ? flag_div : 1, static_cast<bf16_t*>(dxh));
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL((colsum_vec_final_kernel<3>), dim3(cdiv(d, 32), 3), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, out_q, 0);
     } else {
-        if (lds > 64 * 1024 || row_flag || dxh) return IMMTSF_EUNSUPPORTED;
-        hipLaunchKernelGGL((layernorm_bwd_sums_kernel<2>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site, scratch,
+        if (lds > 64 * 1024 || row_flag || dxh || xhat_h || !dx) return IMMTSF_EUNSUPPORTED;
+        hipLaunchKernelGGL((layernorm_bwd_sums_kernel<2, false>), dim3(nsl), dim3(256), lds, s, dz_dy, rows, d, gamma, xhat, rstd, dx, drop, site, scratch,
                            nullptr, 1, nullptr);
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL((colsum_vec_final_kernel<2>), dim3(cdiv(d, 32), 2), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, nullptr, 0);

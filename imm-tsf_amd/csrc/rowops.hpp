@@ -53,7 +53,8 @@ int launch_colsum3(const float* X, const float* Y, float* Z, int M, int N, int l
 // LayerNorm over the last dim with fused dropout: xhat, rstd saved; z = drop(xhat*gamma+beta)
 int launch_layernorm_fwd(const float* x, int rows, int d, const float* gamma, const float* beta, float eps, float* xhat,
                          float* rstd, float* z, DropCfg drop, uint64_t site, hipStream_t s, void* zh = nullptr,      // zh: bf16 z (z may be null)
-                         const float* res = nullptr, DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0);
+                         const float* res = nullptr, DropCfg pre = DropCfg{0, 0.f, 1.f, nullptr}, uint64_t presite = 0,
+                         void* xhat_h = nullptr);        // xhat_h: x_hat as bf16 (xhat may then be null: the backward with sums reads either)
 // (res != null: the row normalised is res + dropout_pre(x) -- LayerNorm(x_in + Dropout(branch)) of a post-norm block)
 // in: dz (grad wrt z).  out: dy written IN PLACE over dz (dy = dz*dropscale), dx.
 int launch_layernorm_bwd(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd,
@@ -65,7 +66,9 @@ constexpr int kLnSlabsMax = 2048;
 inline size_t ln_sums_scratch_floats(size_t d, int k) { return (size_t)kLnSlabsMax * k * ((d + 3) & ~(size_t)3) + 64 * 8; }      // `scratch` of the call below
 int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd, float* dx,
                               DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
-                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s);      // dbranch = dx * dropout_pre mask
+                              const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s, const void* xhat_h = nullptr);
+// (xhat_h: the bf16 x_hat image of launch_layernorm_fwd instead of xhat; dx may be null when dxh is all the consumer reads)
+bool ln_sums_compact_ok(int rows, int d);     // the sums kernel takes (rows, d) whatever the pointers: a forward may store x_hat as bf16 only      // dbranch = dx * dropout_pre mask
 // y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale
 int launch_matvec(const float* W, int ldw, const float* x, const float* b, int rows, int cols, float* y, float* ys,
                   float scale, hipStream_t s, float* y_nobias = nullptr);      // y_nobias: W x without the bias

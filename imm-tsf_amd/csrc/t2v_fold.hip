@@ -233,10 +233,11 @@ __global__ __launch_bounds__(256) void t2v_mix_fwd_kernel(T2VFoldDims dm, const 
 // The window's dropout tiles (all heads) are built once, note-major, so a note's T scales are eight 16-byte broadcast reads; a
 // thread walks the columns e = tid, tid + 256, ... with the T upstream values of its column in registers; the per-note dot products
 // meet in wave-private LDS slabs (plain adds by lane 0, summed in wave order).
-template <typename KT, int NV, int HMAX>
+// DT: the type dx is stored in (float, or bf16 when the LayerNorm backward in front wrote its compact image only)
+template <typename KT, int NV, int HMAX, typename DT>
 __global__ __launch_bounds__(256) void t2v_mix_bwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
                                                            const float* __restrict__ P, const KT* __restrict__ z,
-                                                           const float* __restrict__ dx, KT* __restrict__ dz, float* __restrict__ dbo_part,
+                                                           const DT* __restrict__ dx, KT* __restrict__ dz, float* __restrict__ dbo_part,
                                                            DropCfg drop, uint64_t site) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int H = dm.H;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void t2v_mix_bwd_kernel(T2VFoldDims dm, const 
         float gsum = 0.f;
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
-            dcv[t] = (valid && t < T) ? dx[(size_t)(b * T + t) * d + e] : 0.f;
+            dcv[t] = (valid && t < T) ? (float)dx[(size_t)(b * T + t) * d + e] : 0.f;
             gsum += dcv[t];
         }
         if (valid) dbo_part[(size_t)b * d + e] = gsum;
@@ -379,15 +380,17 @@ int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, co
     return IMMTSF_OK;
 }
 
-int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const float* dx,
-                       void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s) {
+int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const void* dx,
+                       int dx_is_bf16, void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s) {
     if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H)) return IMMTSF_EUNSUPPORTED;
+    if (dx_is_bf16 && !z_is_bf16) return IMMTSF_EINVAL;
     const int NV = dm.N <= 32 ? 32 : 64;
     const size_t lds = ((size_t)dm.H * NV * TT + (size_t)dm.H * NV + 4 * (size_t)dm.H * NV) * sizeof(float);
-#define MIXB(KT, NVV) hipLaunchKernelGGL((t2v_mix_bwd_kernel<KT, NVV, 4>), dim3(dm.B), dim3(256), lds, s, dm, offsets, rowmap, P, \
-                                         static_cast<const KT*>(z), dx, static_cast<KT*>(dz_aug), dbo_part, drop, site)
-    if (z_is_bf16) { if (NV == 32) MIXB(bf16_t, 32); else MIXB(bf16_t, 64); }
-    else { if (NV == 32) MIXB(float, 32); else MIXB(float, 64); }
+#define MIXB(KT, NVV, DT) hipLaunchKernelGGL((t2v_mix_bwd_kernel<KT, NVV, 4, DT>), dim3(dm.B), dim3(256), lds, s, dm, offsets, rowmap, P, \
+                                             static_cast<const KT*>(z), static_cast<const DT*>(dx), static_cast<KT*>(dz_aug), dbo_part, drop, site)
+    if (z_is_bf16 && dx_is_bf16) { if (NV == 32) MIXB(bf16_t, 32, bf16_t); else MIXB(bf16_t, 64, bf16_t); }
+    else if (z_is_bf16) { if (NV == 32) MIXB(bf16_t, 32, float); else MIXB(bf16_t, 64, float); }
+    else { if (NV == 32) MIXB(float, 32, float); else MIXB(float, 64, float); }
 #undef MIXB
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

@@ -52,5 +52,5 @@ int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, co
                        const float* q_res, float* P, float* xpre, DropCfg drop, uint64_t site, hipStream_t s);
 // backward of the mix and the softmax: dz_aug (R, H d + 8): columns [h d, (h+1) d) = dz of head h, column H d + h = ds of head h, the
 // rest 0 (fp32 or bf16 like z); dbo_part (B, d) = sum_t dx[b, t, :] of the windows with notes (0 otherwise)
-int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const float* dx,
-                       void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s);
+int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const void* dx,
+                       int dx_is_bf16, void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s);

@@ -385,12 +385,12 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
         wg[nwg++] = h;
     }
-    // (compact: the forward stored x_hat as bf16 alone, and dx's one reader -- the mix backward -- takes its bf16 image: 1.6 GB of this
-    // kernel's 2.0 at 4096 windows were those two fp32 images)
+    // (compact: the forward stored x_hat as bf16 alone.  dx stays fp32: handed to the mix backward as bf16 alone -- another 0.4 GB less --
+    // that kernel took 421 us instead of 291 at 4096 windows, staged through LDS 500)
     const bool compact = hf && ln_sums_compact_ok(BT, d);
     {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
-        const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, nullptr, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                           gr->Q_param, sc.red, w.mtxt, T, sc.dx, s, w.xhat)
+        const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                           gr->Q_param, sc.red, w.mtxt, T, nullptr, s, w.xhat)
                                : launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
                                                            gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
         if (compact && rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (the forward's test promised this path)
@@ -402,7 +402,7 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         }
     }
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
-    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, compact ? 1 : 0,
+    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, 0,
                              hf ? sc.dza.h : (void*)sc.dza.f, sc.dbo_part, drop, SITE_T2V_ATTN, s));
     // (the row-bound kernels of the block are behind us: see the header.  Measured at 4096 windows: no hint 4.75 ms, here 4.63, in front
     // of the mix 4.96, behind the last weight-gradient GEMM 5.30)

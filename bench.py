@@ -405,7 +405,8 @@ class Workload:
 
 FLAGS_MAX_WINDOWS = 4096     # FlagStep (three branches, device flags) against GraphedStep (graph edges), round 4: 256 windows 0.873 / 0.976 ms,
 #                              512: 1.169 / 1.220, 1024: 1.601 / 1.688, 2048: 2.640 / 2.698, 4096: 4.638 / 4.682; beyond: not measured
-FLAGS_GATE_MIN_WINDOWS = 2048    # FlagStep's scheduling hint (sched_gate): 512 windows 1.165 with / 1.157 without, 1024: 1.626 / 1.603, 4096: 4.638 / 4.726
+FLAGS_GATE_MIN_WINDOWS = 4096    # FlagStep's scheduling hint (sched_gate), with / without: 512 windows 1.165 / 1.157, 1024: 1.626 / 1.603, 2048: 2.58 / 2.51,
+#                                  3072: 3.53 / 3.55, 4096: 4.638 / 4.726
 
 
 def flag_fns(w):

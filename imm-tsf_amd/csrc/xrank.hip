@@ -1355,6 +1355,55 @@ inline XQDims xq_dims(const immtsf_fusion_cfg* c) {
     return q;
 }
 
+// ------------------------------------------------------------------------------------------------ rank-PW expansion
+// C (M, N) = A (M, K) B (K, N) with K = PW <= 32 (the low-rank projection's data gradient: dZ = dP W_c, 131 072 x 768 x 24 at 4096
+// windows).  As a GEMM it is one 64-deep K step of padding per tile and then all epilogue: 532 us for 403 MB of output on gemm2's
+// 256 x 128 tiles.  It is a row kernel: a thread keeps its four columns of B in registers (K float4), the workgroup's rows of A sit
+// in LDS, every output row is K broadcast-FMAs per lane and one 16-byte store (+ the bf16 image when asked).  Exact fp32.
+constexpr int RX_ROWS = 32, RX_KMAX = 32;
+template <int K>
+__global__ __launch_bounds__(256) void rank_expand_kernel(const float* __restrict__ A, int lda, const float* __restrict__ Bm, int ldb,
+                                                           float* __restrict__ Cm, bf16_t* __restrict__ Ch, int M, int N) {
+    __shared__ float As[RX_ROWS][K];
+    const int r0 = blockIdx.x * RX_ROWS, rows = min(RX_ROWS, M - r0), c4 = threadIdx.x;
+    for (int i = threadIdx.x; i < RX_ROWS * K; i += blockDim.x) {
+        const int r = i / K, k = i - r * K;
+        As[r][k] = r < rows ? A[(size_t)(r0 + r) * lda + k] : 0.f;
+    }
+    float4 b[K];
+    const bool live = c4 * 4 < N;
+#pragma unroll
+    for (int k = 0; k < K; ++k) b[k] = live ? *reinterpret_cast<const float4*>(Bm + (size_t)k * ldb + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (!live) return;
+    for (int r = 0; r < rows; ++r) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float a = As[r][k];
+            acc.x = fmaf(a, b[k].x, acc.x); acc.y = fmaf(a, b[k].y, acc.y); acc.z = fmaf(a, b[k].z, acc.z); acc.w = fmaf(a, b[k].w, acc.w);
+        }
+        *reinterpret_cast<float4*>(Cm + (size_t)(r0 + r) * N + c4 * 4) = acc;
+        if (Ch) {
+            const bf16x4 h = {(bf16_t)acc.x, (bf16_t)acc.y, (bf16_t)acc.z, (bf16_t)acc.w};
+            *reinterpret_cast<bf16x4*>(Ch + (size_t)(r0 + r) * N + c4 * 4) = h;
+        }
+    }
+}
+// applies from 4096 rows on (below, the GEMM's few tiles are as quick), K in {8, 16, 24, 32}, N % 4 == 0, N <= 1024, dense 16-byte aligned C
+bool rank_expand_ok(int M, int N, int K, const void* Bm, int ldb, const void* Cm, const void* Ch) {
+    return M >= 4096 && (K == 8 || K == 16 || K == 24 || K == 32) && (N & 3) == 0 && N <= 1024 && (ldb & 3) == 0 &&
+           ((reinterpret_cast<uintptr_t>(Bm) | reinterpret_cast<uintptr_t>(Cm)) & 15) == 0 && (reinterpret_cast<uintptr_t>(Ch) & 7) == 0;
+}
+int launch_rank_expand(const float* A, int lda, const float* Bm, int ldb, float* Cm, void* Ch, int M, int N, int K, hipStream_t s) {
+    const dim3 grid(cdiv(M, RX_ROWS)), block(((N / 4 + 63) / 64) * 64);
+#define RX(KK) hipLaunchKernelGGL((rank_expand_kernel<KK>), grid, block, 0, s, A, lda, Bm, ldb, Cm, static_cast<bf16_t*>(Ch), M, N)
+    if (K == 8) RX(8); else if (K == 16) RX(16); else if (K == 24) RX(24); else RX(32);
+#undef RX
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1518,7 +1567,9 @@ int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immts
         CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
         dPm.h = sc.dP16;
     }
-    {   // dZ = dP Wc
+    if (rank_expand_ok(BT, d, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr)) {       // dZ = dP Wc: many rows, rank PW (see rank_expand_kernel)
+        CHECK(launch_rank_expand(dP, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr, BT, d, x.PW, s));
+    } else {
         GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
         set_problem2(g, 0, dPm, mat(w.Wc, w.Wc16), mat(dZ, hf ? cfg->out_h : nullptr), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
@@ -1591,7 +1642,9 @@ int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_
         CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
         dPm.h = sc.dP16;
     }
-    {   // dE = dP W_fold
+    if (rank_expand_ok(BT, d, x.PW, w.Wf, d, dE_txt, hf ? cfg->out_h : nullptr)) {  // dE = dP W_fold: many rows, rank PW (see rank_expand_kernel)
+        CHECK(launch_rank_expand(dP, x.PW, w.Wf, d, dE_txt, hf ? cfg->out_h : nullptr, BT, d, x.PW, s));
+    } else {
         GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
         set_problem2(g, 0, dPm, mat(w.Wf, w.Wf16), mat(dE_txt, hf ? cfg->out_h : nullptr), nullptr);
         CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));

@@ -796,7 +796,8 @@ def test_mmf_monolithic_entry_equals_the_two_halves():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (3, 13, 5, 48, 4, 0.3), (64, 32, 8, 768, 1, 0.1),
-                                            (2, 260, 8, 64, 1, 0.1), (300, 6, 15, 16, 1, 0.0), (1, 1, 1, 4, 1, 0.0), (2, 3, 15, 16, 4, 0.25)])
+                                            (2, 260, 8, 64, 1, 0.1), (300, 6, 15, 16, 1, 0.0), (1, 1, 1, 4, 1, 0.0), (2, 3, 15, 16, 4, 0.25),
+                                            (160, 32, 8, 64, 1, 0.1)])       # (the last: >= 4096 rows, the data gradient as a row kernel -- rank_expand)
 def test_xattn_add_low_rank_form_equals_full_rank(B, T, Cc, d, H, pd, precision):
     """MMF_XAttn_Add's low-rank form (csrc/xrank.hip: the text side projected onto the (2C+1) H columns the attention needs, the
     attention + head as one kernel per direction, parameter gradients by the chain rule through the folded factors) against the
@@ -913,7 +914,8 @@ def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, pac
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("form", ["fold", "chain"])
-@pytest.mark.parametrize("B,N,T,d_m,d,H,Cc,pd", [(5, 6, 7, 48, 32, 1, 3, 0.0), (6, 32, 32, 96, 64, 2, 8, 0.2), (64, 32, 32, 768, 768, 1, 8, 0.1)])
+@pytest.mark.parametrize("B,N,T,d_m,d,H,Cc,pd", [(5, 6, 7, 48, 32, 1, 3, 0.0), (6, 32, 32, 96, 64, 2, 8, 0.2), (64, 32, 32, 768, 768, 1, 8, 0.1),
+                                                 (144, 16, 32, 64, 64, 1, 8, 0.1)])      # (the last: >= 4096 rows -- rank_expand on the "_z" path, compact x_hat)
 def test_fused_tail_equals_separate_blocks(B, N, T, d_m, d, H, Cc, pd, form, precision):
     """FusionModel with TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection (immtsf.config.fuse_tail = True:
     the TTF block hands over Z, its LayerNorm + dropout output, and the P half computes [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T --

@@ -339,8 +339,13 @@ class Workload:
             m = self.model
             excl = [m.te_scale.weight, m.te_scale.bias, m.te_periodic.weight, m.te_periodic.bias]
         backbone_params = [p for p in self.model.parameters() if p.requires_grad]
-        sinks = (0, 1, 2) if c["backbone"] == "tPatchGNN" else (0, 1)
-        self.trainer = FlatTrainer([list(self.fusion.mmf.parameters()), list(self.fusion.ttf.parameters()), backbone_params],
+        # buckets = the groups whose gradients complete together, in the flat buffers' order: MMF (+ the proj_out it folds), TTF's three
+        # backward phases, the backbone LAST (a data-parallel FlagStep appends the ranks' guard word to the last range)
+        fb, self.bucket_names = self.fusion.grad_buckets(c["T"])
+        self.bucket_names = list(self.bucket_names) + ["backbone"]
+        nf = len(fb)
+        sinks = tuple(range(nf + 1)) if c["backbone"] == "tPatchGNN" else tuple(range(nf))
+        self.trainer = FlatTrainer(fb + [backbone_params],
                                    lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl,
                                    overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
@@ -439,7 +444,13 @@ def flag_step(w):
     fns = flag_fns(w)
     if fns is None or w.trainer.sharded:
         return None
-    kw = {"sched_gate": w.B >= FLAGS_GATE_MIN_WINDOWS}
+    names = w.bucket_names
+    kw = {"sched_gate": w.B >= FLAGS_GATE_MIN_WINDOWS,
+          # clip + Adam of a bucket at the head of the branch that reads its parameters first: TTF on the text side, the backbone on its
+          # own branch, MMF_XAttn_Add (+ the proj_out it folds) on the parameter branch
+          "adam_split": ([i for i, n in enumerate(names) if n.startswith("ttf")], [i for i, n in enumerate(names) if n == "backbone"],
+                         [i for i, n in enumerate(names) if n == "mmf"]),
+          "backbone_buckets": [i for i, n in enumerate(names) if n == "backbone"]}
     kw.update(json.loads(os.environ.get("IMMTSF_BENCH_FLAG_KW", "{}")))      # (A/B measurements only)
     st = FlagStep(w.trainer, *fns, **kw)
     snap = w.trainer.snapshot()
@@ -452,11 +463,12 @@ def flag_step(w):
     except Exception as e:         # noqa: BLE001
         print(f"# FlagStep rejected: {e}", file=sys.stderr)
         ok = False
+    st.reset()                     # (the third trial's gradient still waits for its optimizer step: dropped with the trial)
     w.trainer.restore(snap)
-    w.trainer.flat_grad.zero_()
     torch.cuda.synchronize()
     if not ok:
         st.clear_error()
+        w.trainer._flush_cb = None
     return st if ok else None
 
 
@@ -931,10 +943,11 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(w.global_cnt)
 
-    # hipGraph replay.  One process: ONE graph per step whose branches (text side | backbone | parameter-only work) synchronise through
-    # device flags (immtsf.train.FlagStep) up to FLAGS_MAX_WINDOWS windows per GPU, beyond that graph edges (GraphedStep).  N > 1: the same flag
-    # graph without the optimizer, the bucketed all-reduce on a communication stream BESIDE the backward (a counting device flag per
-    # bucket), what completes with the join reduced behind the graph, then graph B = clip + Adam
+    # hipGraph replay.  ONE graph per step whose branches (text side | backbone | parameter-only work) synchronise through device flags
+    # (immtsf.train.FlagStep) up to FLAGS_MAX_WINDOWS windows per GPU, beyond that graph edges (GraphedStep).  clip + Adam of step k sit
+    # at the head of replay k + 1, each bucket on the branch that reads it first.  N > 1: the SAME single graph; every bucket is rounded
+    # to the bf16 wire image where it completes and announced by a counting device flag, a communication stream runs the all-reduces
+    # beside the backward, and Adam reads the reduced wire image
     mode = "eager" if not use_graph else "phased" if args.phased else "graphed" if (args.no_flags or args.no_overlap) else \
            "flags" if args.flags else "auto"
     if dist_on and sharded and mode in ("auto", "flags"):
@@ -948,7 +961,8 @@ def main():
         raise
     eng = step_info["engine"]
     launch_mode = {"eager": "eager launches",
-                   "flags": "hipGraph replay: 1 graph per step, three branches (text side | backbone | parameter-only work) synchronised by device flags",
+                   "flags": "hipGraph replay: 1 graph per step, three branches (text side | backbone | parameter-only work) synchronised by device "
+                            "flags; clip + Adam of step k at the head of replay k + 1, each bucket on the branch that reads it first",
                    "phased": "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them",
                    "graphed": "hipGraph replay (2 graphs/step)", "graphed+captured-comm": "hipGraph replay (2 graphs/step)"}[eng]
     if eng == "graphed" and getattr(step, "single", False):
@@ -957,9 +971,10 @@ def main():
         launch_mode += ", backbone on a second HIP stream beside TTF"
     if dist_on:
         if eng == "flags":
-            launch_mode += "; N > 1: + graph B (clip + Adam) behind the all-reduce"
+            launch_mode += "; N > 1: the same single graph (clip + Adam of step k at the head of replay k + 1 read the reduced wire image)"
             comm_mode = (f"bucketed, beside the backward: {len(step.segments)} bucket(s) on a communication stream behind counting device "
-                         f"flags, {len(step.rest)} range(s) behind the graph")
+                         "flags [" + ", ".join("+".join(w.bucket_names[b] for b in g["buckets"]) + f"@{g['branch']}:{(g['hi'] - g['lo']) * (2 if wire == 'bf16' else 4) / 1e6:.2f}MB"
+                                               for g in step.segments) + "], the ranks' guard word summed by the last one")
         elif eng == "graphed+captured-comm":
             comm_mode = "captured, bucketed"
         elif eng == "eager":

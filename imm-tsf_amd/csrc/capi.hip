@@ -250,4 +250,39 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
                              static_cast<hipStream_t>(stream));
 }
 
+int immtsf_adam_prepare(const float* grad, const void* grad_h, uint64_t n, float* norm_scratch, int64_t* step_dev,
+                        uint64_t* dropout_step_dev, int32_t* pending, const int32_t* err, const void* guard_h, const float* guard_f,
+                        int32_t* skip_out, immtsf_stream_t stream) {
+    if ((!grad && !grad_h) || !norm_scratch) return IMMTSF_EINVAL;
+    return launch_adam_prepare(grad, grad_h, (size_t)n, norm_scratch, reinterpret_cast<long long*>(step_dev),
+                               reinterpret_cast<unsigned long long*>(dropout_step_dev), pending, err, guard_h, guard_f, skip_out,
+                               static_cast<hipStream_t>(stream));
+}
+
+int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_avg, float* exp_avg_sq, uint64_t n, uint64_t lo,
+                      uint64_t hi, float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev,
+                      float max_norm, const float* norm_scratch, int32_t zero_grad, const int32_t* skip, immtsf_stream_t stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !norm_scratch || !step_dev || hi > n || lo > hi || (lo & 7)) return IMMTSF_EINVAL;
+    return launch_adam_range(param, grad, grad_h, exp_avg, exp_avg_sq, (size_t)n, (size_t)lo, (size_t)hi, lr, beta1, beta2, eps,
+                             weight_decay, reinterpret_cast<const long long*>(step_dev), max_norm, norm_scratch, zero_grad ? 1 : 0, skip,
+                             static_cast<hipStream_t>(stream));
+}
+
+int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_stream_t stream) {
+    if (!err || !slot) return IMMTSF_EINVAL;
+    return launch_guard_pack(err, slot, is_bf16 ? 1 : 0, static_cast<hipStream_t>(stream));
+}
+
+int immtsf_abi_sizes(int32_t* out, int32_t max) {
+    const int32_t sz[IMMTSF_ABI_NSTRUCTS] = {
+        (int32_t)sizeof(immtsf_fusion_cfg), (int32_t)sizeof(immtsf_t2v_params), (int32_t)sizeof(immtsf_recavg_params),
+        (int32_t)sizeof(immtsf_xadd_params), (int32_t)sizeof(immtsf_gr_params), (int32_t)sizeof(immtsf_ttcn_params),
+        (int32_t)sizeof(immtsf_gcn_params), (int32_t)sizeof(immtsf_decoder_params), (int32_t)sizeof(immtsf_time2vec_params),
+        (int32_t)sizeof(immtsf_encoder_layer_cfg), (int32_t)sizeof(immtsf_encoder_layer_params), (int32_t)sizeof(immtsf_ffn_block_cfg),
+        (int32_t)sizeof(immtsf_ffn_block_params), (int32_t)sizeof(immtsf_store)};
+    if (!out || max <= 0) return IMMTSF_ABI_NSTRUCTS;
+    for (int i = 0; i < IMMTSF_ABI_NSTRUCTS && i < max; ++i) out[i] = sz[i];
+    return IMMTSF_ABI_NSTRUCTS;
+}
+
 }  // extern "C"

@@ -616,14 +616,23 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
                         void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
                         immtsf_stream_t stream) {
     if (bad_cfg(cfg) || !p || !gr || !notes || !tau || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
-    if (t2v_fold_on(cfg))
+    // phases (immtsf_fusion_cfg.bwd_phase): 0 = everything, every weight gradient in ONE grouped launch at the end (the best form on one
+    // GPU); a mask = only those phases, each call's weight gradients leaving with the call (data parallel: finished buckets go to the
+    // all-reduce while the later phases still run)
+    const int ph = cfg->bwd_phase ? (cfg->bwd_phase & 7) : 7;
+    if (cfg->bwd_phase < 0 || cfg->bwd_phase > 7 || cfg->reserved0 != 0) return IMMTSF_EINVAL;
+    if (t2v_fold_on(cfg)) {
+        // the folded form's parameter gradients all come out of its chain rule at the end: a phased caller gets the work with phase C
+        if (!(ph & IMMTSF_BWD_PHASE_C)) return IMMTSF_OK;
         return t2v_fold_backward(cfg, p, tau, dE_txt, workspace, workspace_bytes, scratch, scratch_bytes, gr, static_cast<hipStream_t>(stream));
+    }
     T2VWs w = carve_t2v(cfg, workspace);
     T2VScratch sc = carve_t2v_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool phA = ph & IMMTSF_BWD_PHASE_A, phB = ph & IMMTSF_BWD_PHASE_B, phC = ph & IMMTSF_BWD_PHASE_C;
     // (the chain as written has no small-launch tail to share the chip with: whoever waits for the hint goes ahead at once)
-    if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
+    if (cfg->sched_flag && phA) CHECK(immtsf_flag_set(cfg->sched_flag, s));
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H;
     const int R = B * N, BT = B * T, prec = cfg->precision;
     const DropCfg drop = drop_of(cfg);
@@ -645,97 +654,109 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     CHECK(t2v_weights(cfg, p, w, s, &W));
     const bool noproj = (cfg->form & IMMTSF_FORM_NO_PROJ) != 0;
     float* dzp = sc.dz;
-    if (noproj) {        // the incoming gradient IS dZ (the consumer owns proj_out): LayerNorm's backward works on it in place
-        dzp = const_cast<float*>(dE_txt);
-    } else {
-        Mat dE = cmat(dE_txt);
-        if (hf && cfg->in_h) {
-            dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
-        } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
-            CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
-            dE.h = sc.dE.h;
+    if (noproj) dzp = const_cast<float*>(dE_txt);        // the incoming gradient IS dZ (the consumer owns proj_out): LayerNorm's backward works on it in place
+    if (phA) {
+        if (!noproj) {
+            Mat dE = cmat(dE_txt);
+            if (hf && cfg->in_h) {
+                dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
+            } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
+                CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+                dE.h = sc.dE.h;
+            }
+            // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
+            GemmArgs g = gemm_args(BT, d, d, d, d, d);
+            set_problem2(g, 0, dE, W.po, mat(sc.dz), nullptr);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs h = gemm_args(d, d, BT, d, d, d);
+            set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
+            prezeroed(h, cfg);
+            h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
+            CHECK(wgrad(h));
         }
-        // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem2(g, 0, dE, W.po, mat(sc.dz), nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
-        prezeroed(h, cfg);
-        h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
-        CHECK(wgrad(h));
+        // LayerNorm backward; its parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with
+        // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
+        // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
+        {
+            const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                     gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
+            if (rc == IMMTSF_EUNSUPPORTED) {
+                CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
+                CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+            } else {
+                CHECK(rc);
+            }
+        }
+        {   // out_proj
+            GemmArgs g = gemm_args(BT, d, d, d, d, d);
+            set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs h = gemm_args(d, d, BT, d, d, d);
+            set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
+            prezeroed(h, cfg);
+            h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
+            CHECK(wgrad(h));
+        }
     }
-    // LayerNorm backward; its parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with
-    // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
-    // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
-    {
-        const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                 gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
-        if (rc == IMMTSF_EUNSUPPORTED) {
-            CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
-            CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+    if (phB) {
+        RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
+        CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp.f, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
+                                     SITE_T2V_ATTN, s, sc.dKVp.h, w.KVp.h));
+        // (one call: the query path's backward -- parameter gradients only -- rides with Time2Vec's at the end of phase C)
+        {   // k|v in-projection
+            GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
+            set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
+            g.dyn = total; g.dyn_which = 0;
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
+            set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
+            h.dyn = total; h.dyn_which = 1;
+            h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
+            prezeroed(h, cfg);
+            CHECK(wgrad(h));
+        }
+        if (!phC)     // phased: attn.in_proj and Q_param are complete when this call's launches are -- the query path goes here, alone
+            CHECK(launch_query_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
+    }
+    if (phC) {
+        {   // KV_proj
+            GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
+            set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat, p->input_proj_w ? sc.dXcat_h : nullptr), nullptr);
+            g.dyn = total; g.dyn_which = 0;
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+            GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
+            set_problem2(h, 0, sc.dKV, w.Xcat, mat(gr->kv_w), nullptr, gr->kv_b);
+            h.dyn = total; h.dyn_which = 1;
+            h.ws = sc.sk[3]; h.ws_bytes = sc.skb[3];
+            prezeroed(h, cfg);
+            CHECK(wgrad(h));
+        }
+        constexpr int notes_image_b = 1;
+        if (p->input_proj_w && hf && notes_image_b) {   // dW_in = dVp^T V ; db_in = colsum dVp: both operands are bf16 images (dXcat's first d columns, the packed notes)
+            GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
+            set_problem2(h, 0, mat(nullptr, sc.dXcat_h), mat(nullptr, w.Vh), mat(gr->input_proj_w), nullptr, gr->input_proj_b);
+            h.dyn = total; h.dyn_which = 1;
+            h.ws = sc.sk[4]; h.ws_bytes = sc.skb[4];
+            prezeroed(h, cfg);
+            CHECK(wgrad(h));
+        } else if (p->input_proj_w) {   // row-mapped, fp32 operands: the round-1 kernel
+            GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
+            set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
+            h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;
+            prezeroed(h, cfg);
+            CHECK(wgrad(h));
+        }
+        if (phB) {
+            // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq -- in the same
+            // launch as the first stage of Time2Vec's parameter gradients
+            CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
+                                       w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
+                                       gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
         } else {
-            CHECK(rc);
+            CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
+                                      gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
         }
     }
-    {   // out_proj
-        GemmArgs g = gemm_args(BT, d, d, d, d, d);
-        set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, d, BT, d, d, d);
-        set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
-        prezeroed(h, cfg);
-        h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
-        CHECK(wgrad(h));
-    }
-    RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
-    CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp.f, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
-                                 SITE_T2V_ATTN, s, sc.dKVp.h, w.KVp.h));
-    // (the query path's backward -- parameter gradients only -- rides with Time2Vec's at the end of this function)
-    {   // k|v in-projection
-        GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
-        set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
-        g.dyn = total; g.dyn_which = 0;
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
-        set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
-        h.dyn = total; h.dyn_which = 1;
-        h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
-        prezeroed(h, cfg);
-        CHECK(wgrad(h));
-    }
-    {   // KV_proj
-        GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
-        set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat, p->input_proj_w ? sc.dXcat_h : nullptr), nullptr);
-        g.dyn = total; g.dyn_which = 0;
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-        GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
-        set_problem2(h, 0, sc.dKV, w.Xcat, mat(gr->kv_w), nullptr, gr->kv_b);
-        h.dyn = total; h.dyn_which = 1;
-        h.ws = sc.sk[3]; h.ws_bytes = sc.skb[3];
-        prezeroed(h, cfg);
-        CHECK(wgrad(h));
-    }
-    constexpr int notes_image_b = 1;
-    if (p->input_proj_w && hf && notes_image_b) {   // dW_in = dVp^T V ; db_in = colsum dVp: both operands are bf16 images (dXcat's first d columns, the packed notes)
-        GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
-        set_problem2(h, 0, mat(nullptr, sc.dXcat_h), mat(nullptr, w.Vh), mat(gr->input_proj_w), nullptr, gr->input_proj_b);
-        h.dyn = total; h.dyn_which = 1;
-        h.ws = sc.sk[4]; h.ws_bytes = sc.skb[4];
-        prezeroed(h, cfg);
-        CHECK(wgrad(h));
-    } else if (p->input_proj_w) {   // row-mapped, fp32 operands: the round-1 kernel
-        GemmArgs h = gemm_args(d, cfg->d_m, R, dcat, cfg->d_m, cfg->d_m);
-        set_problem(h, 0, sc.dXcat, notes, gr->input_proj_w, nullptr, gr->input_proj_b);
-        h.dyn = total; h.dyn_which = 1; h.b_rowmap = src_rows ? src_rows : w.rowmap;
-        prezeroed(h, cfg);
-        CHECK(wgrad(h));
-    }
-    // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq -- in the same
-    // launch as the first stage of Time2Vec's parameter gradients
-    CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
-                               w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
-                               gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
     CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
     return fk.join();
 }

@@ -11,7 +11,7 @@ namespace {
 
 // optional trace of the flag kernels (immtsf_flag_trace / immtsf_flag_trace_read; tools/flag_timeline.py): who waited for whom, and
 // how long, inside a replayed step -- on the 100 MHz wall clock, without a profiler serialising the two branches
-constexpr int FT_N = 256;
+constexpr int FT_N = 1024;
 __device__ int ft_on;
 __device__ unsigned int ft_count;
 __device__ long long ft_ring[FT_N][3];       // flag address | kind (0 set, 1 wait entered, 2 wait left, 3 clear) | wall clock
@@ -62,9 +62,10 @@ __global__ void flag_wait_ge_kernel(int* flag, int target, int* err, long long t
     ft_note(flag, 2);
     __threadfence_system();
 }
-__global__ void flags_clear_kernel(int* flags, int n) {
+__global__ void flags_clear_kernel(int* flags, int n, int* set_flag = nullptr) {
     if (threadIdx.x == 0) ft_note(flags, 3);
     if ((int)threadIdx.x < n) flags[threadIdx.x] = 0;
+    if (set_flag && threadIdx.x == 0) *set_flag = 1;
 }
 
 }  // namespace
@@ -98,7 +99,13 @@ int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t tim
 }
 int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream) {
     if (!flags || n <= 0 || n > 64) return IMMTSF_EINVAL;
-    hipLaunchKernelGGL(flags_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), flags, n);
+    hipLaunchKernelGGL(flags_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), flags, n, (int*)nullptr);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int immtsf_flags_clear_set(int32_t* flags, int32_t n, int32_t* set_flag, immtsf_stream_t stream) {
+    if (!flags || n <= 0 || n > 64 || !set_flag) return IMMTSF_EINVAL;
+    hipLaunchKernelGGL(flags_clear_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), flags, n, set_flag);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

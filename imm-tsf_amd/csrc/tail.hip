@@ -292,14 +292,62 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
     if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
+// sqnorm_partial_kernel for a step whose optimizer pass sits at the head of the NEXT replay (immtsf.train.FlagStep): the gradient may
+// come as its bf16 wire image (gh), and the first thread takes the step decision -- drop when no gradient is pending, when a flag wait
+// of this rank timed out, or when the guard slot the last collective summed over the ranks is non-zero -- for the range updates that
+// follow on the branches (adam_kernel reads *skip_out)
+__global__ __launch_bounds__(256) void adam_prepare_kernel(const float* __restrict__ g, const bf16_t* __restrict__ gh, size_t n, int vec,
+                                                            float* __restrict__ part, long long* step_dev, unsigned long long* drop_dev,
+                                                            int* pending, const int* err, const bf16_t* guard_h, const float* guard_f,
+                                                            int* skip_out) {
+    __shared__ float red[16];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int skip = 0;
+        if (pending) { if (*pending == 0) skip = 1; *pending = 0; }
+        if (err && *err) skip = 1;
+        if (guard_h && (float)guard_h[0] != 0.f) skip = 1;
+        if (guard_f && guard_f[0] != 0.f) skip = 1;
+        if (skip_out) *skip_out = skip;
+        if (step_dev && !skip) step_dev[0] += 1;
+        if (drop_dev) drop_dev[0] += 1;
+    }
+    float a = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gh) {
+        const size_t n8 = vec ? n >> 3 : 0;
+        for (size_t i = t0; i < n8; i += stride) {
+            const bf16x8 x = reinterpret_cast<const bf16x8*>(gh)[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float f = (float)x[k]; a = fmaf(f, f, a); }
+        }
+        for (size_t i = (n8 << 3) + t0; i < n; i += stride) { const float f = (float)gh[i]; a = fmaf(f, f, a); }
+    } else {
+        const size_t n4 = vec ? n >> 2 : 0;
+        for (size_t i = t0; i < n4; i += stride) {
+            const float4 x = reinterpret_cast<const float4*>(g)[i];
+            a = fmaf(x.x, x.x, fmaf(x.y, x.y, fmaf(x.z, x.z, fmaf(x.w, x.w, a))));
+        }
+        for (size_t i = (n4 << 2) + t0; i < n; i += stride) a = fmaf(g[i], g[i], a);
+    }
+    a = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+// this rank's guard word in the gradient wire's element type, for the slot the step's last all-reduce sums over the ranks
+__global__ void guard_pack_kernel(const int* err, void* slot, int is_bf16) {
+    const float v = (*err != 0) ? 1.f : 0.f;
+    if (is_bf16) *static_cast<bf16_t*>(slot) = (bf16_t)v;
+    else *static_cast<float*>(slot) = v;
+}
+
 // (g and gz may be the same buffer -- read, then zeroed: neither is declared __restrict__)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
                                                     float wd, float bc1, float bc2s, float max_norm,
                                                     const float* __restrict__ part, int nparts,
                                                     const long long* __restrict__ step_dev, bf16_t* __restrict__ twin, int vec,
-                                                    float* gz, const int* skip) {
+                                                    float* gz, const int* skip, const bf16_t* __restrict__ gh = nullptr) {
     // gz != null (== g): the gradient is left zero behind the update -- the next step's zero-fill rides on this pass
+    // gh != null: the gradient is read from its bf16 wire image (what a bf16 all-reduce left behind) instead of g
     __shared__ float red[16];
     if (skip && *skip) {          // dropped step (see sqnorm_partial_kernel): only the zero-fill happens
         if (gz) {
@@ -329,7 +377,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // 16 bytes per lane on all seven streams (the flat buffers are 16-byte aligned), scalar tail
     const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (size_t i = t0; i < n4; i += stride) {
-        const float4 g4 = reinterpret_cast<const float4*>(g)[i], p4 = reinterpret_cast<const float4*>(p)[i];
+        float4 g4;
+        if (gh) {
+            const bf16x4 h4 = reinterpret_cast<const bf16x4*>(gh)[i];
+            g4 = make_float4((float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]);
+        } else {
+            g4 = reinterpret_cast<const float4*>(g)[i];
+        }
+        const float4 p4 = reinterpret_cast<const float4*>(p)[i];
         float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], o;
         o.x = upd(g4.x, p4.x, m4.x, v4.x); o.y = upd(g4.y, p4.y, m4.y, v4.y);
         o.z = upd(g4.z, p4.z, m4.z, v4.z); o.w = upd(g4.w, p4.w, m4.w, v4.w);
@@ -345,7 +400,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     for (size_t i = (n4 << 2) + t0; i < n; i += stride) {
         float mi = m[i], vi = v[i];
-        const float pn = upd(g[i], p[i], mi, vi);
+        const float pn = upd(gh ? (float)gh[i] : g[i], p[i], mi, vi);
         m[i] = mi; v[i] = vi; p[i] = pn;
         if (gz) gz[i] = 0.f;
         if (twin) twin[i] = (bf16_t)pn;
@@ -573,6 +628,36 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, m, v, n, lr, b1, b2, eps, wd, 1.f, 1.f, max_norm,
                        norm_scratch, nparts, (const long long*)step_dev, reinterpret_cast<bf16_t*>(twin), vec,
                        zero_grad ? const_cast<float*>(grad) : nullptr, skip);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int launch_adam_prepare(const float* grad, const void* grad_h, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
+                        int* pending, const int* err, const void* guard_h, const float* guard_f, int* skip_out, hipStream_t s) {
+    const uintptr_t a = grad_h ? reinterpret_cast<uintptr_t>(grad_h) : reinterpret_cast<uintptr_t>(grad);
+    const int vec = (a & 15) == 0;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1024), dim3(256), 0, s, grad, static_cast<const bf16_t*>(grad_h), n, vec, norm_scratch, step_dev,
+                       drop_dev, pending, err, static_cast<const bf16_t*>(guard_h), guard_f, skip_out);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int launch_adam_range(float* param, float* grad, const void* grad_h, float* m, float* v, size_t n, size_t lo, size_t hi, float lr, float b1,
+                      float b2, float eps, float wd, const long long* step_dev, float max_norm, const float* norm_scratch, int zero_grad,
+                      const int* skip, hipStream_t s) {
+    if (hi <= lo) return IMMTSF_OK;
+    const bf16_t* twin0 = static_cast<const bf16_t*>(immtsf_twin_lookup(param, n));
+    bf16_t* twin = twin0 ? const_cast<bf16_t*>(twin0) + lo : nullptr;
+    const bf16_t* gh = grad_h ? static_cast<const bf16_t*>(grad_h) + lo : nullptr;
+    const size_t k = hi - lo;
+    const int vec = adam_vec_ok(param + lo, grad + lo, m + lo, v + lo, twin) && (reinterpret_cast<uintptr_t>(gh) & 7) == 0;
+    const unsigned blocks = (unsigned)((k / 4 + 255) / 256 > 2048 ? 2048 : (k / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param + lo, grad + lo, m + lo, v + lo, k, lr, b1, b2, eps, wd, 1.f, 1.f,
+                       max_norm, norm_scratch, 1024, step_dev, twin, vec, zero_grad ? grad + lo : nullptr, skip, gh);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int launch_guard_pack(const int* err, void* slot, int is_bf16, hipStream_t s) {
+    hipLaunchKernelGGL(guard_pack_kernel, dim3(1), dim3(1), 0, s, err, slot, is_bf16);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

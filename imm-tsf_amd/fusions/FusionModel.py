@@ -60,6 +60,20 @@ class FusionModel(nn.Module):
             return False
         return True
 
+    def grad_buckets(self, T: int):
+        """the parameters as the groups whose gradients a training step completes together, for immtsf.train.FlatTrainer's buckets:
+        [MMF's (+ TTF's proj_out when the pair runs fused: its gradient leaves MMF's parameter chain)], then TTF's backward phases
+        (TTF_T2V_XAttn.grad_phases) or TTF's parameters as one group.  Returns (buckets, names); names[i] in {"mmf", "ttf", "ttf_a",
+        "ttf_b", "ttf_c"}."""
+        fused = self.fused_tail(0, T)
+        mmf = list(self.mmf.parameters())
+        if hasattr(self.ttf, "grad_phases"):
+            ph = self.ttf.grad_phases(tail=not fused)
+            if fused:
+                mmf = mmf + [self.ttf.proj_out.weight, self.ttf.proj_out.bias]
+            return [mmf] + ph, ["mmf", "ttf_a", "ttf_b", "ttf_c"]
+        return [mmf, list(self.ttf.parameters())], ["mmf", "ttf"]
+
     def text_side(self, notes_input, tau, t_hat):
         """everything that depends on the text only: (E_txt or its pre-projection Z, M_txt, kv) with kv = mmf.project_kv(...) when the
         modality block has a text-only half (None otherwise).  What forward(), lib.evaluation.forecast_and_fuse and the step engines

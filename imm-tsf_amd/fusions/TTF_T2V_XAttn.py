@@ -71,6 +71,19 @@ class TTF_T2V_XAttn(nn.Module):
                 self.attn.in_proj_bias, self.attn.out_proj.weight, self.attn.out_proj.bias, self.layer_norm.weight,
                 self.layer_norm.bias, self.proj_out.weight, self.proj_out.bias)
 
+    def grad_phases(self, tail: bool = True):
+        """the parameters in the three groups whose gradients the backward completes one after the other (include/immtsf.h
+        IMMTSF_BWD_PHASE_A / B / C): [out_proj, layer_norm (, proj_out)], [attn.in_proj, Q_param], [input_proj, time2vec, KV_proj].  A
+        trainer that makes each group a bucket (immtsf.train.FlatTrainer) lets a data-parallel step all-reduce a group while the later
+        phases still run.  tail=False: without proj_out (a consumer that folds it -- FusionModel.fused_tail -- produces its gradient)."""
+        a = [self.attn.out_proj.weight, self.attn.out_proj.bias, self.layer_norm.weight, self.layer_norm.bias]
+        if tail:
+            a += [self.proj_out.weight, self.proj_out.bias]
+        b = [self.attn.in_proj_weight, self.attn.in_proj_bias, self.Q_param]
+        c = ([] if self.input_proj is None else [self.input_proj.weight, self.input_proj.bias]) + \
+            list(self.time2vec.parameters()) + [self.KV_proj.weight, self.KV_proj.bias]
+        return [a, b, c]
+
     def forward(self, notes_input, tau: torch.Tensor, t_hat: torch.Tensor, tail: bool = True):
         """notes_input (B,N,d_model) zero-padded embeddings -- or a PackedNotes over a resident embedding matrix
         (immtsf.data.ResidentStore.collate: no padded tensor, no note-mask re-derivation) --, tau (B,N),

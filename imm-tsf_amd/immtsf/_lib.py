@@ -11,8 +11,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 FORM_NO_PROJ = 16        # immtsf_fusion_cfg.form bit (IMMTSF_FORM_NO_PROJ)
+BWD_PHASE_A, BWD_PHASE_B, BWD_PHASE_C = 1, 2, 4      # immtsf_fusion_cfg.bwd_phase bits (IMMTSF_BWD_PHASE_*)
 
 
 class ImmtsfError(RuntimeError):
@@ -32,7 +33,8 @@ class FusionCfg(C.Structure):
     _fields_ = [("B", C.c_int32), ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("d_m", C.c_int32),
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
                 ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("grads_prezeroed", C.c_int32),
-                ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p), ("sched_flag", C.c_void_p)]
+                ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p), ("sched_flag", C.c_void_p),
+                ("bwd_phase", C.c_int32), ("reserved0", C.c_int32)]
 
 
 def _ptr_struct(name, fields):
@@ -81,6 +83,7 @@ class Store(C.Structure):
 _P = C.POINTER
 _PROTOS = {
     "immtsf_abi_version": (C.c_int, []),
+    "immtsf_abi_sizes": (C.c_int, [C.c_void_p, C.c_int32]),
     "immtsf_ragged_index": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_u8p, c_i32p, c_i32p, c_i32p, c_i32p,
                                       c_u8p, c_i32p, c_stream]),
     "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
@@ -254,6 +257,7 @@ _PROTOS = {
     "immtsf_flag_set": (C.c_int, [C.c_void_p, c_stream]),
     "immtsf_flag_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_flags_clear": (C.c_int, [C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_flags_clear_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, c_stream]),
     "immtsf_flag_bump": (C.c_int, [C.c_void_p, c_stream]),
     "immtsf_flag_wait_ge": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_flag_trace": (C.c_int, [C.c_int32]),
@@ -289,7 +293,18 @@ _PROTOS = {
                                     C.c_int32, C.c_void_p, C.c_float, c_f32p, C.c_void_p, c_stream]),
     "immtsf_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),
+    "immtsf_adam_prepare": (C.c_int, [c_f32p, C.c_void_p, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      c_f32p, C.c_void_p, c_stream]),
+    "immtsf_adam_range": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_int32, C.c_void_p, c_stream]),
+    "immtsf_guard_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
 }
+
+# the structs of the ABI in immtsf_abi_sizes' order (tests/test_abi.py compares ctypes.sizeof with the library's sizeof)
+def abi_structs():
+    return [FusionCfg, T2VParams, RecAvgParams, XAddParams, GRParams, TTCNParams, GCNParams, DecoderParams, Time2VecParams,
+            EncoderLayerCfg, EncoderLayerParams, FFNBlockCfg, FFNBlockParams, Store]
+
 
 _lib = None
 
@@ -315,6 +330,10 @@ def load():
         fn.argtypes = args
     if lib.immtsf_abi_version() != ABI_VERSION:
         raise ImmtsfError("libimmtsf_hip.so ABI version mismatch; rebuild it")
+    structs = abi_structs()
+    sizes = (C.c_int32 * len(structs))()
+    if lib.immtsf_abi_sizes(sizes, len(structs)) != len(structs) or any(int(sizes[i]) != C.sizeof(t) for i, t in enumerate(structs)):
+        raise ImmtsfError("libimmtsf_hip.so struct layout differs from this binding (immtsf_abi_sizes); rebuild it")
     _lib = lib
     return lib
 

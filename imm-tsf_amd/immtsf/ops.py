@@ -201,7 +201,9 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.none_mask = [p is None for p in params]
         ctx.sinks = _sinks_of(params)
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
-        ctx.done_hook = getattr(params[0], "_immtsf_bwd_hook", None)
+        # bucket hooks (immtsf.train.FlatTrainer): a hook fires behind the backward PHASE that completes its bucket -- out_proj /
+        # LayerNorm (/ proj_out) gradients are final long before input_proj's, and a data-parallel step hands them to the all-reduce then
+        ctx.phase_hooks = _t2v_phase_hooks(params, no_proj, bool(lib.immtsf_ttf_t2v_xattn_folded(C.byref(cfg))))
         ctx.mark_non_differentiable(M)
         ctx.set_materialize_grads(False)      # no zero-filled uint8 'gradient' of M (one fill kernel per backward)
         return E, M
@@ -221,19 +223,54 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg.sched_flag = ctx.gate
         dE_h = _shadow_get(dE) if _bf16_dataflow(ctx.cfg.precision, ctx.cfg.d) else None
         ctx.cfg.in_h = None if dE_h is None else dE_h.data_ptr()
-        if ctx.src_rows is not None:
-            check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
-                                                           ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
-                                                           C.byref(gs), stream_ptr()), "ttf_t2v_xattn_backward_packed")
-        else:
-            check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
-                                                    ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
-                  "ttf_t2v_xattn_backward")
-        _fire(ctx.done_hook)
+        # one call (every weight gradient in one grouped launch) unless a bucket completes before the last phase: then one call per
+        # run of phases up to the next hook (immtsf_fusion_cfg.bwd_phase)
+        hooks = ctx.phase_hooks
+        cuts = sorted({ph for ph, _ in hooks if ph < 2})
+        calls, lo = [], 0
+        for c in cuts + [2]:
+            calls.append((sum(1 << i for i in range(lo, c + 1)) if cuts else 0, c))
+            lo = c + 1
+        for mask, last in calls:
+            ctx.cfg.bwd_phase = mask
+            if ctx.src_rows is not None:
+                check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
+                                                               ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
+                                                               C.byref(gs), stream_ptr()), "ttf_t2v_xattn_backward_packed")
+            else:
+                check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
+                                                        ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+                      "ttf_t2v_xattn_backward")
+            for ph, hook in hooks:
+                if ph == last:
+                    _fire(hook)
+        ctx.cfg.bwd_phase = 0
         if ctx.no_proj:         # (proj_out's gradients come out of the consumer's backward)
             rets = list(rets)
             rets[15] = rets[16] = None
         return (None,) * 12 + tuple(rets)
+
+
+_T2V_PHASE = (1, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 0, 0, 0, 0, 0, 0)      # immtsf_t2v_params index -> backward phase that completes its gradient
+
+
+def _t2v_phase_hooks(params, no_proj, folded):
+    """[(phase, hook)] for TTFT2VXAttnFn.backward: every bucket hook found on the block's parameters, with the phase (0 A, 1 B, 2 C:
+    include/immtsf.h IMMTSF_BWD_PHASE_*) behind which ALL of the block's parameters in that hook's bucket have their final gradient.  The
+    folded form's gradients all leave its chain rule at the end (phase C); so does a hook whose parameter carries no bucket stamp."""
+    own = [(i, p) for i, p in enumerate(params) if p is not None and not (no_proj and i >= 15)]
+    out, seen = [], set()
+    for i, p in own:
+        hook = getattr(p, "_immtsf_bwd_hook", None)
+        if hook is None or id(hook) in seen:
+            continue
+        seen.add(id(hook))
+        bucket = getattr(p, "_immtsf_bucket", None)
+        if folded or bucket is None:
+            out.append((2, hook))
+            continue
+        out.append((max(_T2V_PHASE[j] for j, q in own if getattr(q, "_immtsf_bucket", None) == bucket), hook))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ TTF_RecAvg

@@ -86,7 +86,10 @@ class FlatTrainer:
             q = 8 * self.world
             n = (n + q - 1) // q * q              # equal, 32-byte aligned shards
         self.flat_param = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # (8 more elements behind the payload: the GUARD SLOT of a data-parallel FlagStep -- each rank's time-out word, summed over the
+        # ranks by the step's last collective, so that every rank drops the same step)
+        self._grad_store = torch.zeros(n + 8, dtype=torch.float32, device=dev)
+        self.flat_grad = self._grad_store[:n]
         per = n // self.world if self.sharded else n
         self.shard = (self.rank * per, (self.rank + 1) * per) if self.sharded else (0, n)
         self.exp_avg = torch.zeros(per, dtype=torch.float32, device=dev)
@@ -95,7 +98,8 @@ class FlatTrainer:
         self._grad_shard = torch.empty(per, dtype=torch.float32, device=dev) if self.sharded and grad_wire == "fp32" else None
         self.master = None               # param_wire "bf16": fp32 master copy of this rank's parameter shard (set below)
         self.norm_scratch = torch.zeros(1024, dtype=torch.float32, device=dev)
-        self._wire = torch.empty(n, dtype=torch.bfloat16, device=dev) if grad_wire == "bf16" and group is not None else None
+        self._wire_store = torch.zeros(n + 8, dtype=torch.bfloat16, device=dev) if grad_wire == "bf16" and group is not None else None
+        self._wire = None if self._wire_store is None else self._wire_store[:n]
         self.ranges = []
         self._views = []
         self._collected = True
@@ -119,6 +123,7 @@ class FlatTrainer:
                 else:
                     self._autograd_owned.append((p, gview))
                 p.grad = gview              # optimizers / clip utilities that look at .grad still work
+                p._immtsf_bucket = (id(self), bi)      # (ops with several backward phases fire a bucket's hook behind the phase that completes it)
                 off += pad8(k)
             self._views.append(views)
             self.ranges.append((start, off))
@@ -441,6 +446,31 @@ class FlatTrainer:
             bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
             self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
 
+    def adam_prepare(self, pending=None, err=None, skip_out=None, from_wire=False, guard=False):
+        """first half of clip + Adam as launches the caller places (include/immtsf.h immtsf_adam_prepare): the squared norm of the whole
+        gradient (from_wire: of its reduced bf16 wire image) and the step decision into `skip_out`; addresses are raw device pointers"""
+        lib = _lib.load()
+        n = self.flat_param.numel()
+        wire = self._wire if (from_wire and self._wire is not None) else None
+        gh = gf = None
+        if guard:
+            if wire is not None:
+                gh = self._wire_store[n:].data_ptr()
+            else:
+                gf = self._grad_store[n:].data_ptr()
+        _lib.check(lib.immtsf_adam_prepare(_lib.ptr(self.flat_grad), None if wire is None else wire.data_ptr(), n, _lib.ptr(self.norm_scratch),
+                                           _lib.ptr(self.step_dev), _lib.ptr(self.drop_dev), pending, err, gh, gf, skip_out,
+                                           _lib.stream_ptr()), "adam_prepare")
+
+    def adam_range(self, lo, hi, skip=None, from_wire=False):
+        """second half: the update of flat elements [lo, hi) on the current stream, clipped by adam_prepare's norm; leaves the gradient zero"""
+        lib = _lib.load()
+        wire = self._wire if (from_wire and self._wire is not None) else None
+        _lib.check(lib.immtsf_adam_range(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), None if wire is None else wire.data_ptr(),
+                                         _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.flat_param.numel(), lo, hi, self.lr,
+                                         self.betas[0], self.betas[1], self.eps, self.wd, _lib.ptr(self.step_dev), self.max_norm,
+                                         _lib.ptr(self.norm_scratch), 1, skip, _lib.stream_ptr()), "adam_range")
+
     def snapshot(self):
         """parameters, Adam moments and step / dropout counters (GraphedStep / PhasedStep restore them after warming up)"""
         s = {"param": self.flat_param.clone(), "m": self.exp_avg.clone(), "v": self.exp_avg_sq.clone(), "step": self.step_count}
@@ -468,11 +498,20 @@ class FlatTrainer:
             else:
                 self.flat_twin.copy_(self.flat_param)
 
+    def flush(self):
+        """apply an optimizer step a step engine still holds back (FlagStep runs clip + Adam of step k at the head of replay k + 1): a
+        no-op otherwise.  state_dict() calls it; call it yourself before reading parameters that must include the last step."""
+        cb = getattr(self, "_flush_cb", None)
+        if cb is not None:
+            cb()
+
     def state_dict(self):
         """checkpoint of the optimizer: Adam moments, step counters and -- with a bf16 parameter wire -- the fp32 master
         parameters, all as FULL flat tensors (a sharded trainer gathers its ranks' shards; every rank returns the same
         dict).  Together with the modules' own state_dict this resumes training exactly; `load_state_dict` takes it back on
         any world size with the same parameter layout."""
+        self.flush()
+
         def full(shard):
             if not self.sharded:
                 return shard.detach().clone()
@@ -755,41 +794,56 @@ class PhasedStep:
 
 
 class FlagStep(PhasedStep):
-    """PhasedStep's decomposition (text / backbone / head) as ONE hipGraph whose branches have NO edges between the fork at
-    the start of the step and the join in front of the optimizer: where a branch needs the other's result it spins on a device
-    flag (csrc/sync.hip) instead of waiting on an event.
+    """PhasedStep's decomposition (text / backbone / head) as ONE hipGraph per step whose branches have NO edges between the fork at the
+    start of the step and the join at its end: where a branch needs another's result it spins on a device flag (csrc/sync.hip) instead
+    of waiting on an event.
 
     Why: on ROCm 7.2 a graph branch (or a stream) that reaches a dependency BEFORE it is satisfied resumes 110 - 175 us after the
     producer has finished (the text-side backward of the cfg2 step: profiles/r03_step_kernel_sequence.txt), whereas a wait that is
     already satisfied costs nothing.  A one-lane spin kernel resumes within a microsecond and occupies one wave slot.
 
-        stream T:  zero-grad, text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ............ wait(B2) | join B | clear, clip + Adam
-        stream B:  (forked at the start)   backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
+        stream T:  norm + step decision | Adam(T's buckets), text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ... wait(B2) | join | clear
+        stream B:  (forked behind the norm)  Adam(B's buckets), backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
+        stream P:  (forked behind T's Adam)  Adam(P's buckets), fold, set .......... wait(tail inputs) parameter-gradient chain, set(P2)
 
-    Parameter-only work of the text side runs on a THIRD branch P (param_branch; forked and joined like B, no edges in between):
-    MMF_XAttn_Add's fold at its head, handed to T through a flag, and MMF_XAttn_Add's parameter-gradient chain (`param_tail`
-    launches of it: work only the optimizer waits for) behind a flag that says its inputs exist.  With param_branch=False both sit
-    on the backbone's branch (fold at its head, the last launch of the chain at its end), which is what rounds 3 measured;
-    the third branch took the 64-window step from 0.536 to 0.496 ms (DESIGN.md section 6 has every placement that was measured).
+    THE OPTIMIZER SITS AT THE HEAD OF THE NEXT REPLAY (round 5).  clip + Adam of step k run at the head of replay k + 1 (`flush()`
+    applies the last one; FlatTrainer.state_dict() flushes): the squared norm of the whole gradient and the step decision on T
+    (immtsf_adam_prepare), then the update of every bucket on the branch that reads its parameters FIRST (`adam_split`) -- the backbone
+    starts behind its own 0.3 MB instead of behind all 277 MB of optimizer traffic, the text side behind its 150 MB, and the parameter
+    branch updates MMF's parameters beside the text side's first kernels.  And because nothing follows the backward inside the graph,
+    a data-parallel step is the SAME single graph launch:
 
-    Data parallel (trainer.collective): the same graph without the optimizer, and the gradient all-reduce BESIDE the backward:
+        stream S (caller):  [wait_ge(comm_done, k-1)] graph k
+        comm stream:        wait_ge(bucket i, k) all-reduce(bucket i) ... guard slot + last bucket ... bump(comm_done)     (eager)
 
-        stream S (caller):  graph A ......................................... | wait(comm) | all-reduce(rest) | graph B: clip + Adam
-        comm stream:        wait_ge(bucket i, k) all-reduce(bucket i) ...      (eager, enqueued right behind graph A's launch)
+    Inside the graph a bucket whose gradients are final -- a block's backward hook; TTF_T2V_XAttn's backward runs in three phases and
+    fires a hook per phase (ops._t2v_phase_hooks); `backbone_buckets` complete with the backbone's backward; what nobody announces
+    completes with the join -- is rounded to the bf16 wire image in place of a conversion kernel around the collective (bf16 wire) and
+    bumps a COUNTING flag; the communication stream, not ordered behind S at all, spins for the k-th bump in front of the k-th
+    replay's all-reduce of that bucket, in place, on the wire image; Adam at the head of replay k + 1 reads the reduced wire image
+    directly.  Ordering argument (no spin and no collective ever waits on the other kind in a cycle): a spin on the communication
+    stream waits only for kernels of ITS OWN rank's graph k, which wait for nothing outside that graph; a collective waits for the
+    peers' same collective, which sits behind the peers' own spins; graph k + 1 waits (one eager spin on S) for the communication
+    stream's last bump of step k.
 
-    Inside graph A a bucket whose gradients are final (the block's backward hook) bumps a COUNTING flag; the communication stream,
-    which is not ordered behind S at all, spins for the k-th bump in front of the k-th replay's all-reduce of that bucket.  What has
-    not been announced by a hook (the bucket that completes with the join, the autograd-owned backbone gradients) is reduced on S
-    behind graph A.  Ordering argument (no spin and no collective ever waits on the other kind in a cycle): a spin waits only for
-    kernels of ITS OWN rank's graph A, which wait for nothing outside that graph; a collective waits for the peers' same
-    collective, which sits behind the peers' own spins; graph A never waits for the communication stream (graph B does, through
-    an ordinary event that is recorded after the last collective).  Every spin gives up after 50 ms and reports it in the guard
-    word, which makes the captured Adam pass DROP the step (immtsf_adam_step_guarded) -- `check()` raises on every rank.
+    Fail-safe.  Every spin gives up after `timeout_ms` and sets the guard word flags[8].  The step decision reads it -- and, data
+    parallel, the ranks' guard words SUMMED by the step's last collective (a slot behind the last bucket), so EVERY rank drops the same
+    step (no update, step not counted, gradient zeroed) and the replicas stay identical; the word is sticky until clear_error().
+    `check()` raises on every rank; `check_every` > 0 makes __call__ do that every so many steps."""
 
-    `flags[8]` is the guard word: `timed_out()` / `check()`."""
+    # flag words (int32 offsets into self.flags)
+    _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _ERR, _PENDING, _SKIP, _COMM_DONE = range(12)
+    _COUNT0 = 16
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
-                 fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True):
+                 fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
+                 adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
+                 check_every: int = 0):
+        """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
+        branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
+        (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
+        backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
+        announced on B instead of waiting for the join."""
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
         if trainer.sharded:
@@ -799,78 +853,110 @@ class FlagStep(PhasedStep):
         dev = trainer.flat_param.device
         lib = _lib.load()
         self.dist = bool(trainer.collective)
+        self.timeout_ms, self.comm_timeout_ms, self.check_every = int(timeout_ms), int(comm_timeout_ms), int(check_every)
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         # parameter-only work (MMF_XAttn_Add's fold in front, its parameter-gradient chain behind) on a THIRD branch of the graph
         self.P = torch.cuda.Stream(device=dev) if param_branch else self.B
-        # launches of MMF_XAttn_Add's parameter chain left to the backbone's branch (data parallel: none -- the bucket's hook must
-        # fire behind its LAST gradient write, on the branch that announces it)
-        # (data parallel without the third branch: none -- the bucket's hook must fire behind its LAST gradient write on the branch
-        # that announces it; with it, the hook rides at the end of the deferred launches on P)
+        # launches of MMF_XAttn_Add's parameter chain left to the parameter branch (without one, data parallel: none -- the bucket's
+        # hook must fire behind its LAST gradient write, on the branch that announces it)
         self._defer = (3 if param_branch else (0 if self.dist else 1)) if param_tail is None else int(param_tail)
         if self.dist:
             trainer.overlap = False           # no collectives from inside the captured backward (the hooks bump flags instead)
             if not param_branch:
                 self._defer = 0
+        nb = len(trainer.buckets)
+        if adam_split is not None:
+            listed = sorted(b for grp in adam_split for b in grp)
+            if len(adam_split) != 3 or listed != list(range(nb)):
+                raise ValueError("adam_split must be three lists that hold every bucket index exactly once")
+            if not param_branch and adam_split[2]:
+                adam_split = (list(adam_split[0]), list(adam_split[1]) + list(adam_split[2]), [])
         cur = torch.cuda.current_stream()
         self.T.wait_stream(cur)
         self.B.wait_stream(cur)
         self.P.wait_stream(cur)
-        # (before the warm-up: its last Adam pass then leaves the gradient buffer zero, and the captured zero_grad() holds no fill --
-        # set afterwards, a 32 MB fill that both branches wait for sat at the head of every replay)
+        # (before the warm-up: its last Adam pass then leaves the gradient buffer zero, and the captured zero_grad() holds no fill)
         trainer.zero_in_step = True
         snap = trainer.snapshot()
         for _ in range(warmup):
             self._eager_step()
         torch.cuda.synchronize()
         trainer.restore(snap)
+        trainer.flat_grad.zero_()
         torch.cuda.synchronize()
-        self.flags = torch.zeros(32, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(48, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
-        F_B1, F_T2, F_B2, F_P2, F_ERR = fp, fp + 4, fp + 8, fp + 20, fp + 32
-        self._f_err = F_ERR
+        W = lambda i: fp + 4 * i        # noqa: E731
+        F_B1, F_T2, F_B2, F_P2, F_ERR = W(self._B1), W(self._T2), W(self._B2), W(self._P2), W(self._ERR)
+        self._f_err, self._f_pending, self._f_skip, self._f_comm = F_ERR, W(self._PENDING), W(self._SKIP), W(self._COMM_DONE)
         sp = lambda st: st.cuda_stream        # noqa: E731
+        tmo = self.timeout_ms
 
         def fset(flag, st):
             _lib.check(lib.immtsf_flag_set(flag, sp(st)), "flag_set")
 
         def fwait(flag, st):
-            _lib.check(lib.immtsf_flag_wait(flag, F_ERR, 50, sp(st)), "flag_wait")
+            _lib.check(lib.immtsf_flag_wait(flag, F_ERR, tmo, sp(st)), "flag_wait")
 
-        # data parallel: counting flags 16.. (never cleared), one per announced bucket, in the order the hooks fire
-        self.segments = []                    # [(flag address, lo, hi, bucket)]
+        bf16_wire = self.dist and trainer._wire is not None
+        self._from_wire = bf16_wire
+        # data parallel: counting flags (never cleared), one per announced bucket
+        self.segments = []                    # [dict(flag, lo, hi, buckets, branch)]
         announced = set()
-        nflags = [0]
+        branch_now = ["T"]
+
+        def announce_range(lo, hi, buckets):
+            if hi == lo:
+                return
+            k = len(self.segments)
+            if self._COUNT0 + k >= 48:
+                raise RuntimeError("FlagStep: more than 32 announced buckets")
+            flag = W(self._COUNT0 + k)
+            st = torch.cuda.current_stream().cuda_stream
+            if bf16_wire:       # the wire image, written where the bucket completes: no conversion kernel around the collective
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
+            _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
+            self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0]})
 
         def announce(bi):
             if bi in announced:
                 return
-            lo, hi = trainer.ranges[bi]
             announced.add(bi)
-            if hi == lo:
-                return
-            flag = fp + 4 * (16 + nflags[0])                 # (one counting flag per announcement, also the ones dropped below)
-            nflags[0] += 1
-            if nflags[0] > 15:
-                raise RuntimeError("FlagStep: more than 15 announced buckets")
-            _lib.check(lib.immtsf_flag_bump(flag, torch.cuda.current_stream().cuda_stream), "flag_bump")
-            self.segments.append((flag, lo, hi, bi))
+            announce_range(*trainer.ranges[bi], (bi,))
 
-        trainer.step_guard = F_ERR
+        def adam(buckets):
+            for lo, hi in _runs([trainer.ranges[b] for b in sorted(buckets)]):
+                trainer.adam_range(lo, hi, skip=self._f_skip, from_wire=bf16_wire)
+
         self.graph = torch.cuda.CUDAGraph()
         B, P = self.B, self.P
         from . import config
         try:
             with torch.cuda.graph(self.graph):
                 T = torch.cuda.current_stream()
+                trainer._grad_zeroed_by_step = True       # (the Adam passes below leave every range zero)
                 trainer.zero_grad()
-                B.wait_stream(T)                      # fork (satisfied when B gets there: nothing runs on B before it)
-                if P is not B:
-                    P.wait_stream(T)
+                # ---- the previous replay's optimizer step: norm + decision, then the buckets on the branches that read them first
+                trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist)
+                if adam_split is None:
+                    adam(range(nb))
+                    B.wait_stream(T)                  # fork (satisfied when B gets there: nothing runs on B before it)
+                    if P is not B:
+                        P.wait_stream(T)
+                else:
+                    B.wait_stream(T)
+                    with torch.cuda.stream(B):
+                        adam(adam_split[1])
+                    adam(adam_split[0])
+                    if P is not B:
+                        P.wait_stream(T)              # (behind T's own update: the two large updates do not share the HBM)
+                        with torch.cuda.stream(P):
+                            adam(adam_split[2])
                 config.fold_stream = P                # parameter-only work of the text side: on its own branch (or at the head of the backbone's)
-                config.fold_flag = (fp + 12, F_ERR) if fold_by_flag else None
-                # scheduling hint (GraphedStep._fwd_bwd has the why): flag 6, its time-out goes to word 7 -- NOT the guard word, a hint
+                config.fold_flag = (W(self._FOLD), F_ERR) if fold_by_flag else None
+                # scheduling hint (GraphedStep._fwd_bwd has the why): its time-out goes to its own word -- NOT the guard word, a hint
                 # that expires costs nothing but the overlap it was after
-                config.sched_gate, config.sched_armed = ((fp + 24, fp + 28) if sched_gate else None), None
+                config.sched_gate, config.sched_armed = ((W(self._SCHED), W(self._SCHED_TO)) if sched_gate else None), None
                 try:
                     outs = text_fn()
                 finally:
@@ -897,26 +983,27 @@ class FlagStep(PhasedStep):
                     fwait(F_T2, B)
                     torch.autograd.backward([pred], [dpy])
                     trainer.collect_grads()
-                # parameter-gradient tails of the text side (work only the optimizer waits for) go to the END of the backbone's branch,
-                # which finishes its backward first (tools/flag_timeline.py: 60 us earlier at 64 windows); flag 4 says their inputs exist
-                tail = {"flag": (fp + 16, F_ERR), "jobs": [], "defer": self._defer}
+                    if self.dist:
+                        branch_now[0] = "B"
+                        for bi in backbone_buckets:
+                            announce(bi)
+                # parameter-gradient tails of the text side (work only the optimizer waits for) go to the parameter branch;
+                # the TAIL flag says their inputs exist
+                tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer}
                 config.param_tail = tail if self._defer > 0 else None
                 trainer._capture_hook = announce if self.dist else None
+                branch_now[0] = "T"
                 try:
                     self._text_backward(outs, dcuts)
                 finally:
                     config.param_tail = None
                     trainer._capture_hook = None
-                if self.segments:
-                    # the bucket whose hook fired LAST on the text side: nothing but the join follows it, a flag buys no overlap -- it is
-                    # reduced behind the graph together with whatever else is left (cfg2: TTF + the backbone, adjacent ranges, ONE
-                    # collective); its flag bump stays in the graph, unread
-                    announced.discard(self.segments.pop()[3])
                 trainer._capture_hook = announce if self.dist else None
+                branch_now[0] = "P"
                 try:
                     with torch.cuda.stream(P):
                         if tail["jobs"]:
-                            fwait(fp + 16, P)
+                            fwait(W(self._TAIL), P)
                             for job in tail["jobs"]:
                                 job(sp(P))
                 finally:
@@ -931,68 +1018,111 @@ class FlagStep(PhasedStep):
                 if P is not B:
                     fwait(F_P2, T)
                     T.wait_stream(P)
-                _lib.check(lib.immtsf_flags_clear(fp, 8, sp(T)), "flags_clear")
-                if not self.dist:
-                    trainer.step()
-            self.graph_b = None
-            if self.dist:
-                # what no hook announced is reduced behind graph A on the caller's stream: contiguous runs of the remaining buckets
-                self.rest = []
-                for bi, (lo, hi) in enumerate(trainer.ranges):
-                    if bi in announced or hi == lo:
-                        continue
-                    if self.rest and self.rest[-1][1] == lo:
-                        self.rest[-1] = (self.rest[-1][0], hi)
-                    else:
-                        self.rest.append((lo, hi))
-                self.comm = trainer.comm_stream or torch.cuda.Stream(device=dev)
-                self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b):
-                    trainer.step()
+                if self.dist:
+                    # what nobody announced is complete now: contiguous runs of the remaining buckets, announced behind the join
+                    branch_now[0] = "J"
+                    rest = [bi for bi in range(nb) if bi not in announced]
+                    for lo, hi in _runs([trainer.ranges[b] for b in rest]):
+                        announce_range(lo, hi, [b for b in rest if lo <= trainer.ranges[b][0] and trainer.ranges[b][1] <= hi])
+                    announced.update(rest)
+                _lib.check(lib.immtsf_flags_clear_set(fp, 8, self._f_pending, sp(T)), "flags_clear_set")
         finally:
-            trainer.step_guard = None
             config.sched_gate = config.sched_armed = None
+        # the communication stream's order: the text side's buckets but its last, the parameter branch's, the text side's last, the
+        # backbone's, the join's -- the order in which they complete at the benchmark configuration; the SAME on every rank
+        tseg = [g for g in self.segments if g["branch"] == "T"]
+        self.segments = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
+                         [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
+        self.comm = None
+        if self.dist:
+            self.comm = trainer.comm_stream or torch.cuda.Stream(device=dev)
         self._epoch = 0
-        self._ev = torch.cuda.Event()
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)
+        trainer._flush_cb = self.flush
 
+    # ------------------------------------------------------------------------------------------------------------------------------
     def timed_out(self) -> bool:
         """this rank's guard word (synchronises)"""
-        return bool(int(self.flags[8].item()) != 0)
+        return bool(int(self.flags[self._ERR].item()) != 0)
 
     def check(self):
-        """raise, on EVERY rank, if a spin timed out on any of them since the last clear_error(): the steps since then were dropped on
-        the ranks that saw it (a collective call when the trainer has a process group; synchronises)"""
-        bad = self.flags[8:9].to(torch.float32)
+        """raise, on EVERY rank, if a spin timed out on any of them since the last clear_error(): the steps since then were dropped --
+        on every rank alike (a collective call when the trainer has a process group; synchronises)"""
+        bad = self.flags[self._ERR:self._ERR + 1].to(torch.float32)
         if self.dist:
             import torch.distributed as dist
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=self.trainer.group)
         if float(bad.item()) != 0.0:
-            raise _lib.ImmtsfError("FlagStep: a device-flag wait timed out (the two graph branches, or the communication stream, did not "
-                                   "run concurrently): the guarded optimizer dropped the affected steps; restore a snapshot and use "
-                                   "GraphedStep")
+            raise _lib.ImmtsfError("FlagStep: a device-flag wait timed out (the graph's branches, or the communication stream, did not "
+                                   "run concurrently): the guarded optimizer dropped the affected steps on every rank; clear_error() "
+                                   "and go on, or restore a snapshot and use GraphedStep")
 
     def clear_error(self):
-        self.flags[8:9].zero_()
+        self.flags[self._ERR:self._ERR + 1].zero_()
+
+    def reset(self):
+        """forget a gradient that is waiting for its optimizer step (after trial replays whose effect the caller undoes with
+        trainer.restore): the next replay's head then applies nothing"""
+        self._wait_comm(torch.cuda.current_stream())
+        self.flags[self._PENDING:self._PENDING + 1].zero_()
+        self.trainer.flat_grad.zero_()
+
+    def _wait_comm(self, stream):
+        """`stream` waits (one spin kernel) for the collectives of the last replay"""
+        if self.dist and self._epoch > 0:
+            _lib.check(_lib.load().immtsf_flag_wait_ge(self._f_comm, self._epoch & 0x7FFFFFFF, self._f_err, self.comm_timeout_ms,
+                                                       stream.cuda_stream), "flag_wait_ge")
+
+    def flush(self):
+        """apply the optimizer step of the last replay now (eager launches on the current stream); the next replay's head then finds
+        nothing pending.  Idempotent."""
+        S = torch.cuda.current_stream()
+        self._wait_comm(S)
+        t = self.trainer
+        t.adam_prepare(pending=self._f_pending, err=self._f_err, skip_out=self._f_skip, from_wire=self._from_wire, guard=self.dist)
+        t.adam_range(0, t.flat_param.numel(), skip=self._f_skip, from_wire=self._from_wire)
+        # (the dropout counter advanced with the decision: harmless -- every replay draws a fresh key anyway)
 
     def __call__(self):
-        self.graph.replay()
-        if not self.dist:
-            return self.loss
-        t = self.trainer
-        lib = _lib.load()
-        self._epoch += 1
         S = torch.cuda.current_stream()
-        if self.segments:
+        self._wait_comm(S)
+        self.graph.replay()
+        self._epoch += 1
+        if self.dist:
+            t, lib, k = self.trainer, _lib.load(), self._epoch & 0x7FFFFFFF
+            n = t.flat_param.numel()
+            store = t._wire_store if self._from_wire else t._grad_store
+            cs = self.comm.cuda_stream
+            import torch.distributed as dist
             with torch.cuda.stream(self.comm):
-                for flag, lo, hi, _ in self.segments:
-                    _lib.check(lib.immtsf_flag_wait_ge(flag, self._epoch & 0x7FFFFFFF, self._f_err, 50, self.comm.cuda_stream), "flag_wait_ge")
-                    t._all_reduce(lo, hi)
-                self._ev.record(self.comm)
-        for lo, hi in self.rest:
-            t._all_reduce(lo, hi)
-        if self.segments:
-            S.wait_event(self._ev)
-        self.graph_b.replay()
+                last = len(self.segments) - 1
+                for i, g in enumerate(self.segments):
+                    _lib.check(lib.immtsf_flag_wait_ge(g["flag"], k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
+                    hi = g["hi"]
+                    if i == last:
+                        # this rank's guard word rides with the last collective: into the slot behind the payload when the last range
+                        # ends there, else as eight elements of its own
+                        _lib.check(lib.immtsf_guard_pack(self._f_err, store[n:].data_ptr(), 1 if self._from_wire else 0, cs), "guard_pack")
+                        if hi == n:
+                            hi = n + 8
+                    dist.all_reduce(store[g["lo"]:hi], group=t.group)
+                    if i == last and hi != n + 8:
+                        dist.all_reduce(store[n:n + 8], group=t.group)
+                _lib.check(lib.immtsf_flag_bump(self._f_comm, cs), "flag_bump")
+            if self.check_every and self._epoch % self.check_every == 0:
+                self.check()
+        elif self.check_every and self._epoch % self.check_every == 0:
+            self.check()
         return self.loss
+
+
+def _runs(ranges):
+    """contiguous runs of (lo, hi) ranges (sorted by lo; empty ones dropped)"""
+    out = []
+    for lo, hi in sorted(r for r in ranges if r[1] > r[0]):
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define IMMTSF_ABI_VERSION 4
+#define IMMTSF_ABI_VERSION 5
 #define IMMTSF_T2V_FOLD_MIN_ROWS 8192 /* see immtsf_fusion_cfg.form */
 #define IMMTSF_FORM_NO_PROJ 16        /* immtsf_fusion_cfg.form bit, TTF_T2V_XAttn: leave proj_out to the consumer (E_txt := Z, dE_txt := dZ,
                                          which the backward overwrites in place; proj_out's gradients are not written) */
@@ -48,6 +48,13 @@ extern "C" {
 typedef void* immtsf_stream_t;
 
 int immtsf_abi_version(void);
+/* sizeof of every struct of this ABI, in the order immtsf_fusion_cfg, immtsf_t2v_params, immtsf_recavg_params, immtsf_xadd_params,
+ * immtsf_gr_params, immtsf_ttcn_params, immtsf_gcn_params, immtsf_decoder_params, immtsf_time2vec_params, immtsf_encoder_layer_cfg,
+ * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store: lets a binding check its own struct
+ * definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes min(max, 14) entries to the HOST
+ * array `out`, returns the number of structs (14).  (ABI 5) */
+#define IMMTSF_ABI_NSTRUCTS 14
+int immtsf_abi_sizes(int32_t* out, int32_t max);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Shape/config of one fusion call.  B windows, N padded notes per window, T padded forecast steps, C channels,
@@ -86,7 +93,20 @@ typedef struct immtsf_fusion_cfg {
                                       HINT, not a dependency: a caller that runs chip-filling work nothing waits for on another stream (the
                                       patch encoder's backward) lets it spin on this flag, so that it shares the chip with the small launches
                                       instead of the row-bound ones.  (ABI 4) */
+    int32_t bwd_phase;             /* TTF_T2V_XAttn backward in its chain form, optional (0 = the whole backward in one call, every weight
+                                      gradient in ONE grouped launch at its end): a mask of IMMTSF_BWD_PHASE_* -- the call runs only those
+                                      phases, each phase's weight gradients leave with that call, and the caller runs the three phases in
+                                      order (same cfg, workspace, scratch and grads).  What a data-parallel step uses to hand finished
+                                      gradient buckets to the all-reduce while the rest of the backward still runs
+                                      (immtsf.train.FlagStep).  The folded form ignores it unless it is exactly one phase, in which case only
+                                      IMMTSF_BWD_PHASE_C does the work.  (ABI 5) */
+    int32_t reserved0;             /* must be 0 */
 } immtsf_fusion_cfg;
+/* after phase A: d proj_out (unless IMMTSF_FORM_NO_PROJ), d layer_norm, d attn.out_proj are final; after B: d attn.in_proj_{weight,bias}
+ * and d Q_param; after C: d input_proj, d time2vec, d KV_proj */
+#define IMMTSF_BWD_PHASE_A 1
+#define IMMTSF_BWD_PHASE_B 2
+#define IMMTSF_BWD_PHASE_C 4
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)
  * fusions/TTF_T2V_XAttn.py:107,124,146 ; fusions/TTF_RecAvg.py:69,110.
@@ -591,6 +611,27 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
                       float beta2, float eps, float weight_decay, int32_t step, const int64_t* step_dev, float max_norm,
                       const float* norm_scratch, void* twin, immtsf_stream_t stream);
 
+/* clip + Adam as launches the CALLER places (ABI 5; immtsf.train.FlagStep puts them at the head of the NEXT step's graph, the update
+ * of every parameter range on the branch that reads those parameters first):
+ *   adam_prepare: 1024 partial sums of squares of the whole gradient -- fp32 `grad`, or, when `grad_h` is given, its bf16 wire image
+ *     (what a bf16 all-reduce left behind: no widening pass) -- into norm_scratch; the step DECISION: *skip_out = 1 (drop: no update,
+ *     step not counted) when *pending == 0 (no gradient waits: the first replay, or behind a flush), when *err != 0 (a device-flag
+ *     wait of this rank timed out) or when the guard slot is non-zero (guard_h: one bf16 value, guard_f: one float -- the time-out
+ *     words of ALL ranks summed by the step's last collective, so every rank drops the same step); *pending is cleared;
+ *     *step_dev += 1 unless dropped; *dropout_step_dev += 1 always.  pending / err / guard_* / step_dev / dropout_step_dev may be NULL.
+ *   adam_range: the update of elements [lo, hi) of the flat buffers (lo a multiple of 8), clipped by the norm adam_prepare left in
+ *     norm_scratch; the gradient is read from grad_h (bf16) when given, else from grad; zero_grad != 0 leaves grad[lo, hi) zero;
+ *     the registered bf16 twin of `param` is kept current; *skip != 0: only the zero-fill happens. */
+int immtsf_adam_prepare(const float* grad, const void* grad_h, uint64_t n, float* norm_scratch, int64_t* step_dev,
+                        uint64_t* dropout_step_dev, int32_t* pending, const int32_t* err, const void* guard_h, const float* guard_f,
+                        int32_t* skip_out, immtsf_stream_t stream);
+int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_avg, float* exp_avg_sq, uint64_t n, uint64_t lo,
+                      uint64_t hi, float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev,
+                      float max_norm, const float* norm_scratch, int32_t zero_grad, const int32_t* skip, immtsf_stream_t stream);
+/* *slot = (*err != 0) in the gradient wire's element type (is_bf16 != 0: one bf16, else one float): the guard word of this rank,
+ * written into the slot behind the last bucket so that the step's last all-reduce sums it over the ranks (see adam_prepare) */
+int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * One post-norm transformer encoder layer over short sequences: nn.TransformerEncoderLayer(d_model = D, nhead = H,
  * dim_feedforward = F, activation relu, batch_first) as tPatchGNN applies it to the M patches of every variable
@@ -710,13 +751,15 @@ int immtsf_set_side_stream(int32_t on);
 int immtsf_flag_set(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait(int32_t* flag, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
 int immtsf_flags_clear(int32_t* flags, int32_t n, immtsf_stream_t stream);
+/* flags_clear, and *set_flag = 1 in the same launch (the end of a captured step: clear the hand-over flags, mark a gradient pending) */
+int immtsf_flags_clear_set(int32_t* flags, int32_t n, int32_t* set_flag, immtsf_stream_t stream);
 /* Counting form, for a consumer that is NOT part of the captured step (the communication stream of the data-parallel step, enqueued
  * eagerly beside the replaying graph): flag_bump adds 1 (release) behind the producer's last kernel on every replay; flag_wait_ge
  * spins until *flag - target >= 0 (the consumer of replay k passes k).  Never cleared: a late consumer cannot miss a hand-over. */
 int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
 /* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
- * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (256 entries) and starts recording, (0) stops;
+ * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (1024 entries) and starts recording, (0) stops;
  * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,
  * 3 clear), wall clock -- and returns their count (< 0: error).  Both synchronise the device. */
 int immtsf_flag_trace(int32_t enable);

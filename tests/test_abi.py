@@ -31,6 +31,34 @@ def test_header_symbols_are_exported_and_bound():
     assert _lib.load().immtsf_abi_version() == _lib.ABI_VERSION
 
 
+def test_struct_layouts_match_the_library():
+    """every ABI struct of the ctypes binding has the size the library was compiled with (immtsf_abi_sizes), and the config struct's
+    fields are, name by name and in order, the members include/immtsf.h declares -- a field added on one side only cannot drift in
+    silently (round-4 review: INTEGRATION.md documented a struct two fields short)"""
+    from immtsf import _lib
+    lib = _lib.load()
+    structs = _lib.abi_structs()
+    out = (ctypes.c_int32 * 32)()
+    n = lib.immtsf_abi_sizes(out, 32)
+    assert n == len(structs)
+    for i, t in enumerate(structs):
+        assert int(out[i]) == ctypes.sizeof(t), (t.__name__, int(out[i]), ctypes.sizeof(t))
+    src = open(os.path.join(ROOT, "include", "immtsf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct immtsf_fusion_cfg \{(.*?)\} immtsf_fusion_cfg;", src, flags=re.S).group(1)
+    members = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            members += [re.sub(r"[^A-Za-z0-9_]", "", x.split()[-1]) for x in decl.split(",")]
+    assert members == [f for f, _ in _lib.FusionCfg._fields_]
+    # INTEGRATION.md shows the same struct to a maintainer binding the library by hand
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for f, _ in _lib.FusionCfg._fields_:
+        assert f'"{f}"' in doc, f"INTEGRATION.md's Cfg example lacks {f}"
+    assert f"IMMTSF_ABI_VERSION` is {_lib.ABI_VERSION}" in doc
+
+
 def test_workspace_queries_run_without_gpu():
     from immtsf import _lib
     lib = _lib.load()

@@ -329,17 +329,20 @@ def test_two_rank_eager_step_equals_single_process(sharded):
     assert err < 3e-4, err
 
 
-def _two_rank_flag_worker(rank, world, port, q, wire):
-    """one rank of the data-parallel FLAG step (bench.py's N > 1 default): graph A with counting flags per announced bucket, the
-    bucketed all-reduce on the communication stream beside the backward, the rest behind the graph, graph B = clip + Adam.  Both
-    ranks share cuda:0 over gloo: the control flow is under test, not the transport."""
+def _two_rank_flag_worker(rank, world, port, q, wire, layout="phases", inject=False):
+    """one rank of the data-parallel FLAG step (bench.py's N > 1 default): ONE graph per step, every bucket rounded to the wire image
+    where it completes and announced by a counting flag, the all-reduces on the communication stream beside the backward, clip + Adam of
+    step k at the head of replay k + 1 reading the reduced wire.  Both ranks share cuda:0 over gloo: the control flow is under test,
+    not the transport.  layout "phases": bench.py's buckets (FusionModel.grad_buckets: MMF, TTF's three backward phases, the backbone;
+    Adam split over the branches); "blocks": one bucket per block, everything on the text branch.  inject: after two good steps rank 1
+    waits for a flag nobody sets -- BOTH ranks must drop that step."""
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    from immtsf.ops import masked_mse
+    from immtsf import _lib
     from immtsf.train import FlagStep, FlatTrainer, shard_range
     model, fusion, tr0, batch = _setup(dev, 0.0)
     tr0.close()
@@ -348,48 +351,97 @@ def _two_rank_flag_worker(rank, world, port, q, wire):
     cnt = shard["mask_predicted_data"].reshape(-1, shard["mask_predicted_data"].shape[-1]).sum(0)
     dist.all_reduce(cnt)
     te = [model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias]
-    tr = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())], lr=1e-2, eps=1e-3,
-                     max_norm=0.05, sink_buckets=(0, 1, 2), sink_shared=te, overlap=True, device_step=True, group=dist.group.WORLD,
-                     grad_wire=wire)
+    kw = {}
+    if layout == "phases":
+        fb, names = fusion.grad_buckets(shard["tp_to_predict"].shape[1])
+        buckets = fb + [list(model.parameters())]
+        names = list(names) + ["backbone"]
+        kw = {"adam_split": ([i for i, n in enumerate(names) if n.startswith("ttf")], [len(names) - 1], [0]), "backbone_buckets": [len(names) - 1]}
+    else:
+        buckets = [list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())]
+    tr = FlatTrainer(buckets, lr=1e-2, eps=1e-3, max_norm=0.05, sink_buckets=tuple(range(len(buckets))), sink_shared=te, overlap=True,
+                     device_step=True, group=dist.group.WORLD, grad_wire=wire)
     fc = (shard["tp_to_predict"], shard["observed_data"], shard["observed_tp"], shard["observed_mask"])
 
     def text_fn():
-        E, M = fusion.ttf(shard["notes_embeddings"], shard["tau"], shard["tp_to_predict"])
+        if layout == "phases":      # the fused pair (proj_out folded into MMF's projection: its gradient leaves MMF's chain, MMF's bucket holds it)
+            E, M, kv = fusion.text_side(shard["notes_embeddings"], shard["tau"], shard["tp_to_predict"])
+            return (E, M) + tuple(kv)
+        E, M = fusion.ttf(shard["notes_embeddings"], shard["tau"], shard["tp_to_predict"])      # one bucket per block: the blocks as written
         return (E, M) + tuple(fusion.mmf.project_kv(E))
 
     def head_fn(pred, E, M, kv, fold):
         return fusion.mmf.forward_loss(pred, E, M, shard["data_to_predict"], shard["mask_predicted_data"], cnt, kv=(kv, fold))
 
-    st = FlagStep(tr, text_fn, lambda: model.forecasting(*fc).contiguous(), head_fn)
-    assert st.dist and len(st.segments) >= 1          # at least MMF's bucket is reduced beside the backward
-    for _ in range(3):
+    st = FlagStep(tr, text_fn, lambda: model.forecasting(*fc).contiguous(), head_fn, timeout_ms=20 if inject else 50, **kw)
+    assert st.dist and len(st.segments) >= (4 if layout == "phases" else 2)
+    if not inject:
+        for _ in range(3):
+            st()
+        tr.flush()
+        torch.cuda.synchronize()
+        st.check()
+        if rank == 0:
+            q.put((tr.gather(tr.flat_param).cpu().numpy(), len(st.segments), [g["branch"] for g in st.segments]))
+    else:
+        for _ in range(2):
+            st()
+        tr.flush()
+        torch.cuda.synchronize()
+        st.check()
+        p2 = tr.gather(tr.flat_param).clone()
+        keep = st.segments[0]["flag"]
+        if rank == 1:
+            st.segments[0]["flag"] = st.flags.data_ptr() + 4 * 47        # a word nobody bumps: the communication stream's spin gives up
         st()
-    torch.cuda.synchronize()
-    st.check()
-    if rank == 0:
-        q.put((tr.gather(tr.flat_param).cpu().numpy(), len(st.segments), len(st.rest)))
+        tr.flush()
+        torch.cuda.synchronize()
+        p3 = tr.gather(tr.flat_param).clone()
+        raised = False
+        try:
+            st.check()
+        except _lib.ImmtsfError:
+            raised = True
+        own = bool(st.timed_out())
+        st.segments[0]["flag"] = keep
+        st.clear_error()
+        st()
+        tr.flush()
+        torch.cuda.synchronize()
+        st.check()
+        p4 = tr.gather(tr.flat_param).clone()
+        q.put((rank, p2.cpu().numpy(), p3.cpu().numpy(), p4.cpu().numpy(), raised, own))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("wire,tol", [("fp32", 3e-4), ("bf16", 3e-2)])
-def test_two_rank_flag_step_equals_single_process(wire, tol):
-    """bench.py's N > 1 default -- FlagStep with the bucketed all-reduce beside the backward -- on two ranks (half batches) trains like
-    one process on the full batch: 3 steps, clip active (max_norm 0.05).  SURVEY 8e."""
-    dev = _dev()
+def _spawn2(target, args):
     import torch.multiprocessing as mp
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_flag_worker, args=(r, 2, port, q, wire)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + tuple(args)) for r in range(2)]
     for p in procs:
         p.start()
-    got, nseg, nrest = q.get(timeout=300)
+    return q, procs
+
+
+@pytest.mark.parametrize("layout", ["phases", "blocks"])
+@pytest.mark.parametrize("wire,tol", [("fp32", 3e-4), ("bf16", 3e-2)])
+def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
+    """bench.py's N > 1 default -- FlagStep with the bucketed all-reduce beside the backward, one graph per step, the optimizer at the
+    head of the next replay -- on two ranks (half batches) trains like one process on the full batch: 3 steps, clip active (max_norm
+    0.05).  SURVEY 8e."""
+    dev = _dev()
+    q, procs = _spawn2(_two_rank_flag_worker, (wire, layout))
+    got, nseg, branches = q.get(timeout=300)
     got = torch.from_numpy(got)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    if layout == "phases":      # TTF's first two phases, then MMF's (parameter branch), TTF's last, the backbone's: the communication stream's order
+        assert branches == ["T", "T", "P", "T", "B"], branches
     model, fusion, tr, batch = _setup_sinks(dev, 0.0)
     tr.max_norm = 0.05
     f = _loss_fn(model, fusion, batch)
@@ -400,7 +452,90 @@ def test_two_rank_flag_step_equals_single_process(wire, tol):
         tr.step()
     ref = tr.gather(tr.flat_param).cpu()
     err = float((got - ref).abs().max() / ref.abs().max())
-    assert err < tol, (err, nseg, nrest)
+    assert err < tol, (err, nseg, branches)
+
+
+def test_two_rank_flag_step_drops_a_timed_out_step_on_every_rank():
+    """Cross-rank guard coherence (round-4 review): a device-flag wait that gives up on ONE rank (here: rank 1's communication stream
+    spins on a word nobody bumps) must make EVERY rank drop that step -- the guard words ride with the step's last collective and the
+    step decision reads their sum -- so the replicas stay bit-identical; check() raises on both; after clear_error() training goes on."""
+    _dev()
+    q, procs = _spawn2(_two_rank_flag_worker, ("bf16", "phases", True))
+    res = {}
+    for _ in range(2):
+        r = q.get(timeout=300)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import numpy as np
+    for rank in (0, 1):
+        p2, p3, p4, raised, own = res[rank]
+        assert np.array_equal(p2, p3), f"rank {rank} applied a step the other rank's time-out should have dropped"
+        assert raised, f"check() did not raise on rank {rank}"
+        assert own == (rank == 1)                      # only rank 1's own guard word was set: rank 0 learnt it from the collective
+        assert not np.array_equal(p3, p4)              # training continues after clear_error()
+    for i in range(3):
+        assert np.array_equal(res[0][i], res[1][i]), "replicas diverged"
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("tail", [True, False])
+def test_t2v_backward_in_phases_equals_one_call(precision, tol, tail):
+    """TTF_T2V_XAttn's backward as three calls (immtsf_fusion_cfg.bwd_phase: what a data-parallel step uses to hand finished gradient
+    buckets to the all-reduce early) writes the gradients the single call writes, and every bucket's hook fires behind the phase that
+    completes it -- in order A, B, C.  tail=False: the form in which the consumer owns proj_out."""
+    dev = _dev()
+    from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+    from fusions.load_llm import register_d_model
+    from immtsf import config
+    from immtsf.train import FlatTrainer
+    register_d_model("TOY64", 64)
+    config.precision = precision
+    config.nan_check = "deferred"
+    try:
+        def build():
+            torch.manual_seed(11)
+            return TTF_T2V_XAttn("TOY64", 6, n_heads_fusion=2, dropout=0.0, d_txt=32).to(dev).train()
+        g = torch.Generator().manual_seed(2)
+        B, N, T = 12, 9, 7
+        notes = torch.randn(B, N, 64, generator=g)
+        lengths = torch.randint(1, N + 1, (B,), generator=g)
+        tau = torch.rand(B, N, generator=g) * 24
+        for b in range(B):
+            notes[b, int(lengths[b]):] = 0
+            tau[b, int(lengths[b]):] = 0
+        notes, tau = notes.to(dev), tau.to(dev)
+        t_hat = torch.sort(torch.rand(B, T, generator=g), 1).values.to(dev)
+        up = torch.randn(B, T, 32, generator=g).to(dev)
+
+        def run(m, tr):
+            tr.zero_grad()
+            E, _ = m(notes, tau, t_hat, tail=tail)
+            (E * up).sum().backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+        a = build()
+        ta = FlatTrainer([list(a.parameters())], sink_buckets=(0,), overlap=False)
+        ga = run(a, ta)
+        b = build()
+        tb = FlatTrainer(b.grad_phases(tail=tail) + ([[b.proj_out.weight, b.proj_out.bias]] if not tail else []), sink_buckets=(0, 1, 2),
+                         overlap=False)
+        fired = []
+        for i, ps in enumerate(tb.buckets[:3]):
+            ps[0]._immtsf_bwd_hook = (lambda i=i: fired.append(i))
+        gb = run(b, tb)
+        assert fired == [0, 1, 2], fired
+        for k in ga:
+            if not tail and k.startswith("proj_out"):
+                continue
+            ref = ga[k]
+            err = float((gb[k] - ref).abs().max() / max(float(ref.abs().max()), 1e-6))
+            assert err < tol, (k, err)
+        ta.close(); tb.close()
+    finally:
+        config.precision = "fp32"
 
 
 def test_adjacent_projection_weights_take_the_single_gemm_path():
@@ -506,6 +641,7 @@ def test_phased_step_trains_like_eager(kind):
     st = (PhasedStep if kind == "phased" else FlagStep)(tr, text_fn, bb, head_fn)
     assert (config.head_dy_ptr is not None) == (kind == "flags_fused_loss")
     losses = [float(st().detach()) for _ in range(steps)]
+    tr.flush()               # (FlagStep: the last step's clip + Adam would run at the head of the next replay)
     torch.cuda.synchronize()
     if kind != "phased":
         assert not st.timed_out()
@@ -694,6 +830,7 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
         step, info = bench.build_step(w, eng)          # (warm-up / trial steps are undone)
         assert info["engine"] == eng and not info["flag_step_rejected"], info
         got_losses = [float(step()) for _ in range(3)]
+        w.trainer.flush()                                 # (FlagStep applies step k's clip + Adam at the head of replay k + 1)
         torch.cuda.synchronize()
         if eng != "graphed":
             step.check()                                  # no spin gave up: no step was dropped

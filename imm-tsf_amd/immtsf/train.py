@@ -1035,7 +1035,11 @@ class FlagStep(PhasedStep):
                          [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
         self.comm = None
         if self.dist:
-            self.comm = trainer.comm_stream or torch.cuda.Stream(device=dev)
+            # a HIGH-PRIORITY stream of its own: HIP deals streams of one priority round-robin onto a handful of hardware queues, and a
+            # communication stream that lands on the caller's queue runs its spins BEHIND the graph it is meant to run beside (seen
+            # with the trainer's default-priority stream: every bucket's wait was entered 3 us after the step's last kernel, the five
+            # collectives then cost 65 us in front of the next step); the other priority level has queues of its own
+            self.comm = torch.cuda.Stream(device=dev, priority=-1)
         self._epoch = 0
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)

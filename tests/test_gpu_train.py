@@ -329,6 +329,12 @@ def test_two_rank_eager_step_equals_single_process(sharded):
     assert err < 3e-4, err
 
 
+def _named_flat(model, fusion):
+    """every parameter, concatenated in NAME order (a trainer's own gather() follows its bucket layout, which differs between trainers)"""
+    named = sorted([("m." + k, p) for k, p in model.named_parameters()] + [("f." + k, p) for k, p in fusion.named_parameters()])
+    return torch.cat([p.detach().reshape(-1) for _, p in named])
+
+
 def _two_rank_flag_worker(rank, world, port, q, wire, layout="phases", inject=False):
     """one rank of the data-parallel FLAG step (bench.py's N > 1 default): ONE graph per step, every bucket rounded to the wire image
     where it completes and announced by a counting flag, the all-reduces on the communication stream beside the backward, clip + Adam of
@@ -382,7 +388,7 @@ def _two_rank_flag_worker(rank, world, port, q, wire, layout="phases", inject=Fa
         torch.cuda.synchronize()
         st.check()
         if rank == 0:
-            q.put((tr.gather(tr.flat_param).cpu().numpy(), len(st.segments), [g["branch"] for g in st.segments]))
+            q.put((_named_flat(model, fusion).cpu().numpy(), len(st.segments), [g["branch"] for g in st.segments]))
     else:
         for _ in range(2):
             st()
@@ -450,7 +456,7 @@ def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
         f().backward()
         tr.sync_grads()
         tr.step()
-    ref = tr.gather(tr.flat_param).cpu()
+    ref = _named_flat(model, fusion).cpu()
     err = float((got - ref).abs().max() / ref.abs().max())
     assert err < tol, (err, nseg, branches)
 

@@ -154,7 +154,7 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
         if (ffn32_scratch_bytes(f.R, f.F) > (size_t)f.R * f.F * sizeof(float)) return IMMTSF_EWORKSPACE;
         CHECK(ffn32_backward(f.R, f.F, dd, x1, b1, dff, h, dh, d1, gw1, gb1, gw2, s));
         if (colsum_small_pair_ok(f.R, f.D))      // few rows: LayerNorm's two parameter gradients and the second bias gradient in one launch
-            return launch_colsum_small_pair(g2, xhat, dff, f.R, f.D, f.D, gln_w, gln_b, gb2, s);
+            return launch_colsum_small_pair(g2, xhat, dff, f.R, f.D, f.D, gln_w, gln_b, gb2, s, pz);
         CHECK(launch_colsum2(g2, xhat, f.R, f.D, f.D, gln_w, gln_b, red, s, true));   // (red: colsum_scratch_floats(D, 2) at both carve sites)
         return launch_colsum(dff, nullptr, f.R, nullptr, f.D, f.D, gb2, 0, red, s, true);
     }

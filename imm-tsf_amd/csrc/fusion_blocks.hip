@@ -110,6 +110,17 @@ T2VScratch carve_t2v_scratch(const immtsf_fusion_cfg* c, void* base) {
     return s;
 }
 
+// a batch's ragged index built ahead of the call (immtsf_fusion_cfg.note_index) replaces the workspace's own index arrays
+template <typename WS> inline void use_note_index(const immtsf_fusion_cfg* c, WS& w) {
+    const immtsf_note_index* ix = c->note_index;
+    if (!ix) return;
+    w.mask = ix->mask; w.mtxt = ix->mtxt; w.lengths = ix->lengths; w.offsets = ix->offsets; w.rowmap = ix->rowmap; w.seg = ix->seg;
+}
+inline bool bad_note_index(const immtsf_fusion_cfg* c) {
+    const immtsf_note_index* ix = c->note_index;
+    return ix && (!ix->mask || !ix->mtxt || !ix->lengths || !ix->offsets || !ix->rowmap || !ix->seg);
+}
+
 // the block's GEMM weights as (fp32, bf16) pairs
 struct T2VW { Mat in, kv, inkv, out, po; };
 int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2VWs& w, hipStream_t s, T2VW* o) {
@@ -250,6 +261,8 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
                      int32_t* nan_flag, hipStream_t s) {
     T2VFoldWs w = carve_t2v_fold(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const bool indexed = src_rows && cfg->note_index;
+    if (indexed) use_note_index(cfg, w);
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H, d_m = cfg->d_m;
     const int R = B * N, BT = B * T, prec = cfg->precision, dmc = d_m + dt, Hd = H * d, Ma = Hd + 8;
     const bool hf = t2v_hf(cfg) && prec == 1, inp = p->input_proj_w != nullptr;
@@ -257,9 +270,11 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     const int* total = w.offsets + B;
     T2VFW W;
     CHECK(t2v_fold_weights(cfg, p, w, s, &W));
-    if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
-    else CHECK(launch_note_mask(notes, R, d_m, w.mask, nan_flag, s));
-    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));
+    if (!indexed) {
+        if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
+        else CHECK(launch_note_mask(notes, R, d_m, w.mask, nan_flag, s));
+        CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));
+    }
     const int* gather = src_rows ? src_rows : w.rowmap;
     const float scale = sqrtf(1.0f / (float)hd);
     // X = [V ; Time2Vec(tau)] on the packed rows; in the same launch the two parameter-only mat-vecs the fold starts from: the learned
@@ -349,6 +364,7 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     T2VFoldWs w = carve_t2v_fold(cfg, workspace);
     T2VFoldScratch sc = carve_t2v_fold_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    use_note_index(cfg, w);
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H, d_m = cfg->d_m;
     const int R = B * N, BT = B * T, prec = cfg->precision, dmc = d_m + dt, Hd = H * d, Ma = Hd + 8;
     const bool hf = t2v_hf(cfg) && prec == 1, inp = p->input_proj_w != nullptr;
@@ -499,6 +515,14 @@ int immtsf_ragged_index(const float* notes, int32_t B, int32_t N, int32_t d_m, u
     return launch_ragged_index(note_mask, B, N, lengths, offsets, rowmap, seg, m_txt, s);
 }
 
+int immtsf_note_index_build(const int32_t* lengths_in, int32_t B, int32_t N, const immtsf_note_index* out, immtsf_stream_t stream) {
+    if (!lengths_in || !out || B <= 0 || N <= 0 || !out->mask || !out->mtxt || !out->lengths || !out->offsets || !out->rowmap || !out->seg)
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    CHECK(launch_mask_from_lengths(lengths_in, B, N, out->mask, s));
+    return launch_ragged_index(out->mask, B, N, out->lengths, out->offsets, out->rowmap, out->seg, out->mtxt, s);
+}
+
 size_t immtsf_ttf_t2v_xattn_workspace_bytes(const immtsf_fusion_cfg* cfg) {
     if (bad_cfg(cfg)) return 0;
     return t2v_fold_on(cfg) ? carve_t2v_fold(cfg, nullptr).bytes : carve_t2v(cfg, nullptr).bytes;
@@ -515,7 +539,9 @@ int immtsf_ttf_t2v_xattn_folded(const immtsf_fusion_cfg* cfg) { return (!bad_cfg
 static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes, const int32_t* src_rows,
                        const int32_t* lengths_in, const float* tau, float* E_txt, uint8_t* M_txt, void* workspace,
                        size_t workspace_bytes, int32_t* nan_flag, immtsf_stream_t stream) {
-    if (bad_cfg(cfg) || !p || !notes || !tau || !E_txt || !M_txt || !workspace) return IMMTSF_EINVAL;
+    if (bad_cfg(cfg) || !p || !notes || !tau || !E_txt || !workspace || bad_note_index(cfg)) return IMMTSF_EINVAL;
+    if (!M_txt && !(src_rows && cfg->note_index)) return IMMTSF_EINVAL;
+    if (cfg->note_index && !src_rows) return IMMTSF_EINVAL;         // (an index comes with packed notes only)
     if (cfg->d < 4 || cfg->N <= 0 || cfg->d_m <= 0) return IMMTSF_EINVAL;
     if (!p->input_proj_w && cfg->d != cfg->d_m) return IMMTSF_EINVAL;
     if (t2v_fold_on(cfg))
@@ -523,6 +549,8 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
                                 static_cast<hipStream_t>(stream));
     T2VWs w = carve_t2v(cfg, workspace);
     if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    const bool indexed = src_rows && cfg->note_index;
+    if (indexed) use_note_index(cfg, w);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H;
     const int R = B * N, BT = B * T, prec = cfg->precision;
@@ -532,9 +560,11 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
     const bool hf = t2v_hf(cfg);
     T2VW W;
     CHECK(t2v_weights(cfg, p, w, s, &W));
-    if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
-    else CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
-    CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));      // M_txt written here: no copy at the end
+    if (!indexed) {
+        if (src_rows) CHECK(launch_mask_from_lengths(lengths_in, B, N, w.mask, s));
+        else CHECK(launch_note_mask(notes, R, cfg->d_m, w.mask, nan_flag, s));
+        CHECK(launch_ragged_index(w.mask, B, N, w.lengths, w.offsets, w.rowmap, w.seg, w.mtxt, s, M_txt));      // M_txt written here: no copy at the end
+    }
     const int* gather = src_rows ? src_rows : w.rowmap;
     // [input_proj(V) ; time2vec(tau)] on the packed rows.  The note embeddings are fp32 in memory (gathered rows of the
     // padded tensor or of the resident matrix): this one GEMM converts while staging and emits the bf16 image directly
@@ -615,12 +645,13 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
                         const float* tau, const float* dE_txt, void* workspace, size_t workspace_bytes,
                         void* scratch, size_t scratch_bytes, const immtsf_t2v_params* gr,
                         immtsf_stream_t stream) {
-    if (bad_cfg(cfg) || !p || !gr || !notes || !tau || !dE_txt || !workspace || !scratch) return IMMTSF_EINVAL;
+    if (bad_cfg(cfg) || !p || !gr || !notes || !tau || !dE_txt || !workspace || !scratch || bad_note_index(cfg)) return IMMTSF_EINVAL;
+    if (cfg->note_index && !src_rows) return IMMTSF_EINVAL;
     // phases (immtsf_fusion_cfg.bwd_phase): 0 = everything, every weight gradient in ONE grouped launch at the end (the best form on one
-    // GPU); a mask = only those phases, each call's weight gradients leaving with the call (data parallel: finished buckets go to the
-    // all-reduce while the later phases still run)
-    const int ph = cfg->bwd_phase ? (cfg->bwd_phase & 7) : 7;
-    if (cfg->bwd_phase < 0 || cfg->bwd_phase > 7 || cfg->reserved0 != 0) return IMMTSF_EINVAL;
+    // stream); a mask = the data paths (bits 0..2) and parameter gradients (bits 4..6) of phases A, B, C this call runs -- the products
+    // of one call leave as one grouped launch
+    if (cfg->bwd_phase < 0 || (cfg->bwd_phase & ~0x77) || cfg->reserved0 != 0) return IMMTSF_EINVAL;
+    const int ph = cfg->bwd_phase ? cfg->bwd_phase : 0x77;
     if (t2v_fold_on(cfg)) {
         // the folded form's parameter gradients all come out of its chain rule at the end: a phased caller gets the work with phase C
         if (!(ph & IMMTSF_BWD_PHASE_C)) return IMMTSF_OK;
@@ -629,8 +660,10 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     T2VWs w = carve_t2v(cfg, workspace);
     T2VScratch sc = carve_t2v_scratch(cfg, scratch);
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
+    if (src_rows) use_note_index(cfg, w);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool phA = ph & IMMTSF_BWD_PHASE_A, phB = ph & IMMTSF_BWD_PHASE_B, phC = ph & IMMTSF_BWD_PHASE_C;
+    const bool wgA = ph & IMMTSF_BWD_WGRAD_A, wgB = ph & IMMTSF_BWD_WGRAD_B, wgC = ph & IMMTSF_BWD_WGRAD_C;
     // (the chain as written has no small-launch tail to share the chip with: whoever waits for the hint goes ahead at once)
     if (cfg->sched_flag && phA) CHECK(immtsf_flag_set(cfg->sched_flag, s));
     const int B = cfg->B, N = cfg->N, T = cfg->T, d = cfg->d, dt = d / 2, dcat = d + dt, H = cfg->H, hd = d / H;
@@ -655,75 +688,79 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
     const bool noproj = (cfg->form & IMMTSF_FORM_NO_PROJ) != 0;
     float* dzp = sc.dz;
     if (noproj) dzp = const_cast<float*>(dE_txt);        // the incoming gradient IS dZ (the consumer owns proj_out): LayerNorm's backward works on it in place
-    if (phA) {
-        if (!noproj) {
-            Mat dE = cmat(dE_txt);
-            if (hf && cfg->in_h) {
-                dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
-            } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
-                CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
-                dE.h = sc.dE.h;
-            }
-            // proj_out: dz = dE W_po ; dW_po = dE^T z ; db_po = colsum dE
+    // ---- phase A: proj_out, LayerNorm, out_proj
+    if (!noproj && (phA || wgA)) {
+        Mat dE = cmat(dE_txt);
+        if (hf && cfg->in_h) {
+            dE.h = const_cast<void*>(cfg->in_h);      // the producer (MMF key/value backward) wrote the bf16 image already
+        } else if (hf) {       // the upstream gradient arrives as fp32 (block boundary): one cast for its two GEMMs
+            if (phA) CHECK(launch_f32_to_bf16(dE_txt, sc.dE.h, (size_t)BT * d, s));
+            dE.h = sc.dE.h;
+        }
+        if (phA) {   // proj_out: dz = dE W_po
             GemmArgs g = gemm_args(BT, d, d, d, d, d);
             set_problem2(g, 0, dE, W.po, mat(sc.dz), nullptr);
             CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        }
+        if (wgA) {   // dW_po = dE^T z ; db_po = colsum dE
             GemmArgs h = gemm_args(d, d, BT, d, d, d);
             set_problem2(h, 0, dE, w.z, mat(gr->proj_out_w), nullptr, gr->proj_out_b);
             prezeroed(h, cfg);
             h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
             CHECK(wgrad(h));
         }
+    }
+    if (phA) {
         // LayerNorm backward; its parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with
         // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
         // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
-        {
-            const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                     gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
-            if (rc == IMMTSF_EUNSUPPORTED) {
-                CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
-                CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
-            } else {
-                CHECK(rc);
-            }
+        const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                 gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
+        if (rc == IMMTSF_EUNSUPPORTED) {
+            CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
+            CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));
+        } else {
+            CHECK(rc);
         }
-        {   // out_proj
-            GemmArgs g = gemm_args(BT, d, d, d, d, d);
-            set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-            GemmArgs h = gemm_args(d, d, BT, d, d, d);
-            set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
-            prezeroed(h, cfg);
-            h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
-            CHECK(wgrad(h));
-        }
+        // out_proj: dctx = dx W_out
+        GemmArgs g = gemm_args(BT, d, d, d, d, d);
+        set_problem2(g, 0, sc.dx, W.out, mat(sc.dctx), nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
+    if (wgA) {
+        GemmArgs h = gemm_args(d, d, BT, d, d, d);
+        set_problem2(h, 0, sc.dx, w.ctx, mat(gr->attn_out_w), nullptr, gr->attn_out_b);
+        prezeroed(h, cfg);
+        h.ws = sc.sk[1]; h.ws_bytes = sc.skb[1];
+        CHECK(wgrad(h));
+    }
+    // ---- phase B: the ragged attention, the k|v in-projection, the query path
     if (phB) {
         RaggedAttnDims dm; dm.B = B; dm.T = T; dm.H = H; dm.hd = hd; dm.N = N;
         CHECK(launch_ragged_attn_bwd(dm, w.offsets, w.rowmap, w.KVp.f, w.qs, w.P, sc.dctx, sc.dKVp.f, sc.dqs_part, sc.dp, drop,
                                      SITE_T2V_ATTN, s, sc.dKVp.h, w.KVp.h));
-        // (one call: the query path's backward -- parameter gradients only -- rides with Time2Vec's at the end of phase C)
-        {   // k|v in-projection
-            GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
-            set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
-            g.dyn = total; g.dyn_which = 0;
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
-            GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
-            set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
-            h.dyn = total; h.dyn_which = 1;
-            h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
-            prezeroed(h, cfg);
-            CHECK(wgrad(h));
-        }
-        if (!phC)     // phased: attn.in_proj and Q_param are complete when this call's launches are -- the query path goes here, alone
-            CHECK(launch_query_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
+        GemmArgs g = gemm_args(R, d, 2 * d, 2 * d, d, d);
+        set_problem2(g, 0, sc.dKVp, W.inkv, sc.dKV, nullptr);
+        g.dyn = total; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
     }
+    if (wgB) {
+        GemmArgs h = gemm_args(2 * d, d, R, 2 * d, d, d);
+        set_problem2(h, 0, sc.dKVp, w.KV, mat(gr->attn_in_w + (size_t)d * d), nullptr, gr->attn_in_b + d);
+        h.dyn = total; h.dyn_which = 1;
+        h.ws = sc.sk[2]; h.ws_bytes = sc.skb[2];
+        prezeroed(h, cfg);
+        CHECK(wgrad(h));
+    }
+    // ---- phase C: KV_proj, input_proj, Time2Vec
     if (phC) {
-        {   // KV_proj
-            GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
-            set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat, p->input_proj_w ? sc.dXcat_h : nullptr), nullptr);
-            g.dyn = total; g.dyn_which = 0;
-            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        GemmArgs g = gemm_args(R, dcat, d, d, dcat, dcat);
+        set_problem2(g, 0, sc.dKV, W.kv, mat(sc.dXcat, p->input_proj_w ? sc.dXcat_h : nullptr), nullptr);
+        g.dyn = total; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    }
+    if (wgC) {
+        {
             GemmArgs h = gemm_args(d, dcat, R, d, dcat, dcat);
             set_problem2(h, 0, sc.dKV, w.Xcat, mat(gr->kv_w), nullptr, gr->kv_b);
             h.dyn = total; h.dyn_which = 1;
@@ -746,16 +783,18 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
             prezeroed(h, cfg);
             CHECK(wgrad(h));
         }
-        if (phB) {
-            // query path: q = W_q Q_param + b_q, qs = q * scale: dW_q (rows 0..d of in_proj_weight), db_q, dQ_param += W_q^T dq -- in the same
-            // launch as the first stage of Time2Vec's parameter gradients
-            CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
-                                       w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
-                                       gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
-        } else {
-            CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
-                                      gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
-        }
+    }
+    // the small parameter-gradient kernels: the query path (q = W_q Q_param + b_q, qs = q * scale: dW_q -- rows 0..d of in_proj_weight --,
+    // db_q, dQ_param += W_q^T dq) belongs to phase B's parameter gradients, Time2Vec's to phase C's; in one call they share a launch
+    if (wgB && wgC) {
+        CHECK(launch_query_t2v_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, tau,
+                                   w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
+                                   gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
+    } else if (wgB) {
+        CHECK(launch_query_bwd(sc.dqs_part, B, d, scale, p->attn_in_w, d, p->Q_param, gr->attn_in_w, d, gr->attn_in_b, gr->Q_param, s));
+    } else if (wgC) {
+        CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXcat + d, dcat, gr->t2v_lin_w, gr->t2v_lin_b,
+                                  gr->t2v_per_w, gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
     }
     CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
     return fk.join();

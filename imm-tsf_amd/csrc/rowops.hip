@@ -564,6 +564,42 @@ __global__ __launch_bounds__(1024) void colsum_small_pair_kernel(const float* __
     }
 }
 
+// the same three sums spread over the chip, for outputs that read ZERO (a trainer's pre-zeroed gradient sinks): a workgroup of 256
+// threads takes 256 / CT rows per pass over its row slab and adds its N partial sums to the outputs with one atomic each -- the pair
+// kernel above is two workgroups walking 1024 rows in 32 dependent steps, 18 us on the backbone's backward chain at the benchmark shape
+__global__ __launch_bounds__(256) void colsum_small_atomic_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                                   const float* __restrict__ Z, int M, int N, int ld, int CT, int rows_per_wg,
+                                                                   float* __restrict__ out_xy, float* __restrict__ out_x,
+                                                                   float* __restrict__ out_z) {
+    __shared__ float red[3][4 * 32];
+    const int RT = 256 / CT, tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (tx < N) {
+#pragma unroll 4
+        for (int r = r0 + ty; r < r1; r += RT) {
+            const float x = X[(size_t)r * ld + tx];
+            a = fmaf(x, Y[(size_t)r * ld + tx], a);
+            b += x;
+            c += Z[(size_t)r * ld + tx];
+        }
+    }
+    a = coset_sum(a, CT);
+    b = coset_sum(b, CT);
+    c = coset_sum(c, CT);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < CT) { red[0][wave * CT + lane] = a; red[1][wave * CT + lane] = b; red[2][wave * CT + lane] = c; }
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        float s = 0.f, t = 0.f, u = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += red[0][w * CT + threadIdx.x]; t += red[1][w * CT + threadIdx.x]; u += red[2][w * CT + threadIdx.x]; }
+        atomicAdd(out_xy + threadIdx.x, s);
+        atomicAdd(out_x + threadIdx.x, t);
+        atomicAdd(out_z + threadIdx.x, u);
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum2_final_kernel(const float* __restrict__ partial, int N, float* __restrict__ out_xy,
                                                              float* __restrict__ out_x) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -1265,9 +1301,15 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
 
 bool colsum_small_pair_ok(int M, int N) { return N >= 1 && N <= 32 && M >= 1 && (long)M * N <= (1L << 17); }
 int launch_colsum_small_pair(const float* X, const float* Y, const float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
-                             hipStream_t s) {
+                             hipStream_t s, int outputs_zero) {
     int CT = 1;
     while (CT < N) CT <<= 1;
+    if (outputs_zero && M >= 128) {       // pre-zeroed outputs: ~32 rows per workgroup, atomics
+        const int RT = 256 / CT, per = ((32 + RT - 1) / RT) * RT;
+        hipLaunchKernelGGL(colsum_small_atomic_kernel, dim3(cdiv(M, per)), dim3(256), 0, s, X, Y, Z, M, N, ld, CT, per, out_xy, out_x, out_z);
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
     hipLaunchKernelGGL(colsum_small_pair_kernel, dim3(2), dim3(1024), 0, s, X, Y, Z, M, N, ld, CT, out_xy, out_x, out_z);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

@@ -42,7 +42,7 @@ int launch_colsum(const float* X, const float* Y, int M, const int* dyn, int N, 
 // launch (M * N <= 2^17)
 bool colsum_small_pair_ok(int M, int N);
 int launch_colsum_small_pair(const float* X, const float* Y, const float* Z, int M, int N, int ld, float* out_xy, float* out_x, float* out_z,
-                             hipStream_t s);
+                             hipStream_t s, int outputs_zero = 0);      // outputs_zero: the three outputs read zero (pre-zeroed sinks): spread over the chip, atomics
 int launch_colsum2(const float* X, const float* Y, int M, int N, int ld, float* out_xy, float* out_x, float* scratch,
                    hipStream_t s, bool big_scratch = false);
 inline size_t colsum_scratch_floats(size_t ncols, int k) { return (size_t)256 * k * ((ncols + 3) & ~(size_t)3) + 64 * 8; }

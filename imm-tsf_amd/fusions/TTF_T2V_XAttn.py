@@ -102,7 +102,7 @@ class TTF_T2V_XAttn(nn.Module):
         mode = config.nan_check
         flag = None if mode == "off" else self._nan.get(V.device)
         E_txt, M = TTFT2VXAttnFn.apply(V, f32(tau), T, self.n_heads, self.p_drop, training, resolve_precision(self),
-                                       self.last_seed, flag, None if packed is None else packed.src_rows,
+                                       self.last_seed, flag, packed,
                                        None if packed is None else packed.lengths, not tail, *self._params())
         if mode == "sync":
             self._nan.raise_if_set("Input embeddings V contain NaN values.")

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
 ABI_VERSION = 5
 FORM_NO_PROJ = 16        # immtsf_fusion_cfg.form bit (IMMTSF_FORM_NO_PROJ)
-BWD_PHASE_A, BWD_PHASE_B, BWD_PHASE_C = 1, 2, 4      # immtsf_fusion_cfg.bwd_phase bits (IMMTSF_BWD_PHASE_*)
+BWD_PHASE_A, BWD_PHASE_B, BWD_PHASE_C = 1, 2, 4      # immtsf_fusion_cfg.bwd_phase bits: data paths (IMMTSF_BWD_PHASE_*)
+BWD_WGRAD_A, BWD_WGRAD_B, BWD_WGRAD_C = 16, 32, 64   # ... and parameter gradients (IMMTSF_BWD_WGRAD_*)
 
 
 class ImmtsfError(RuntimeError):
@@ -34,7 +35,7 @@ class FusionCfg(C.Structure):
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
                 ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("grads_prezeroed", C.c_int32),
                 ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p), ("sched_flag", C.c_void_p),
-                ("bwd_phase", C.c_int32), ("reserved0", C.c_int32)]
+                ("bwd_phase", C.c_int32), ("reserved0", C.c_int32), ("note_index", C.c_void_p)]
 
 
 def _ptr_struct(name, fields):
@@ -71,6 +72,7 @@ GCNParams = _ptr_struct("GCNParams", [
     "mlp_w", "mlp_b"])
 DecoderParams = _ptr_struct("DecoderParams", ["W1", "b1", "W2", "b2", "W3", "b3"])
 Time2VecParams = _ptr_struct("Time2VecParams", ["w0", "b0", "w", "b"])
+NoteIndex = _ptr_struct("NoteIndex", ["mask", "mtxt", "lengths", "offsets", "rowmap", "seg"])
 GRParams = _ptr_struct("GRParams", [
     "w_ih", "w_hh", "b_ih", "b_hh", "res_w", "res_b", "gate_w", "gate_b", "ln_w", "ln_b"])
 
@@ -86,6 +88,7 @@ _PROTOS = {
     "immtsf_abi_sizes": (C.c_int, [C.c_void_p, C.c_int32]),
     "immtsf_ragged_index": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_u8p, c_i32p, c_i32p, c_i32p, c_i32p,
                                       c_u8p, c_i32p, c_stream]),
+    "immtsf_note_index_build": (C.c_int, [c_i32p, C.c_int32, C.c_int32, _P(NoteIndex), c_stream]),
     "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_folded": (C.c_int, [_P(FusionCfg)]),
@@ -303,7 +306,7 @@ _PROTOS = {
 # the structs of the ABI in immtsf_abi_sizes' order (tests/test_abi.py compares ctypes.sizeof with the library's sizeof)
 def abi_structs():
     return [FusionCfg, T2VParams, RecAvgParams, XAddParams, GRParams, TTCNParams, GCNParams, DecoderParams, Time2VecParams,
-            EncoderLayerCfg, EncoderLayerParams, FFNBlockCfg, FFNBlockParams, Store]
+            EncoderLayerCfg, EncoderLayerParams, FFNBlockCfg, FFNBlockParams, Store, NoteIndex]
 
 
 _lib = None

@@ -106,6 +106,9 @@ t2v_form = "auto"
 # immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
 head_done_flag = None
 head_dy_ptr = None        # ... and, when a head took the flag: the address of the dY_ts buffer its kernel publishes
+# TTF_T2V_XAttn on PackedNotes: use the batch's prebuilt ragged index (PackedNotes.index(), built once per batch) instead of deriving
+# it inside every forward; False: the call derives it (two launches at its head) -- the cross-check
+note_index = True
 # FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); False: batched GEMMs +
 # row softmax
 attn_mid = True

@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib, config
-from ._lib import DecoderParams, FusionCfg, GCNParams, GRParams, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
+from ._lib import DecoderParams, FusionCfg, GCNParams, GRParams, NoteIndex, RecAvgParams, T2VParams, TTCNParams, XAddParams, check, ptr, stream_ptr
 
 
 def _need_gpu(*ts):
@@ -151,6 +151,22 @@ class PackedNotes:
         self.emb, self.src_rows, self.lengths, self.N = emb, src_rows, lengths, int(N)
         self.shape = (lengths.shape[0], self.N, emb.shape[1])
         self.device = emb.device
+        self._index = None
+
+    def index(self):
+        """the batch's ragged index (immtsf_note_index: mask, M_txt, lengths, offsets, rowmap, seg), built ONCE per batch -- the batch
+        builder knows every window's note count, so the index is part of the hand-over (offsets authoritative) instead
+        of two launches at the head of every forward.  Returns (ctypes struct, tensors it points into)."""
+        if self._index is None:
+            B, N = self.lengths.shape[0], self.N
+            dev = self.device
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)        # noqa: E731
+            i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)       # noqa: E731
+            t = {"mask": u8(B * N), "mtxt": u8(B), "lengths": i32(B), "offsets": i32(B + 1), "rowmap": i32(B * N), "seg": i32(B * N)}
+            ix = NoteIndex(*[t[f].data_ptr() for f in NoteIndex.FIELDS])
+            check(_lib.load().immtsf_note_index_build(ptr(self.lengths), B, N, C.byref(ix), stream_ptr()), "note_index_build")
+            self._index = (ix, t)
+        return self._index
 
 
 class TTFT2VXAttnFn(torch.autograd.Function):
@@ -163,6 +179,11 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         notes, tau = _c(notes), _c(tau)
         params = tuple(_c(p) for p in params)
         _need_gpu(notes, tau, *params)
+        # (src_rows may come as the PackedNotes itself: then the batch's prebuilt ragged index is used instead of deriving it in the call)
+        index = None
+        if isinstance(src_rows, PackedNotes):
+            index = src_rows.index() if config.note_index else None
+            src_rows = src_rows.src_rows
         packed = src_rows is not None
         B, N = tau.shape
         d_m = notes.shape[-1]
@@ -180,6 +201,10 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         if _bf16_dataflow(precision, d) and d_m % 8 == 0:
             E_h = torch.empty(B, T, d, dtype=torch.bfloat16, device=notes.device)
             cfg.out_h = E_h.data_ptr()
+        if index is not None:
+            cfg.note_index = C.addressof(index[0])
+            M = index[1]["mtxt"].view(-1)        # (a fresh tensor object over the batch's M_txt: no copy, no launch)
+        ctx.index = index                        # (keeps the struct and its tensors alive for the backward)
         if packed:
             check(lib.immtsf_ttf_t2v_xattn_forward_packed(C.byref(cfg), C.byref(ps), ptr(notes), ptr(src_rows), ptr(lengths),
                                                           ptr(tau), ptr(E), ptr(M), ptr(ws), ws.numel(), stream_ptr()),
@@ -203,7 +228,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
         # bucket hooks (immtsf.train.FlatTrainer): a hook fires behind the backward PHASE that completes its bucket -- out_proj /
         # LayerNorm (/ proj_out) gradients are final long before input_proj's, and a data-parallel step hands them to the all-reduce then
-        ctx.phase_hooks = _t2v_phase_hooks(params, no_proj, bool(lib.immtsf_ttf_t2v_xattn_folded(C.byref(cfg))))
+        ctx.folded = bool(lib.immtsf_ttf_t2v_xattn_folded(C.byref(cfg)))
+        ctx.phase_hooks = _t2v_phase_hooks(params, no_proj, ctx.folded)
         ctx.mark_non_differentiable(M)
         ctx.set_materialize_grads(False)      # no zero-filled uint8 'gradient' of M (one fill kernel per backward)
         return E, M
@@ -223,28 +249,56 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg.sched_flag = ctx.gate
         dE_h = _shadow_get(dE) if _bf16_dataflow(ctx.cfg.precision, ctx.cfg.d) else None
         ctx.cfg.in_h = None if dE_h is None else dE_h.data_ptr()
-        # one call (every weight gradient in one grouped launch) unless a bucket completes before the last phase: then one call per
-        # run of phases up to the next hook (immtsf_fusion_cfg.bwd_phase)
-        hooks = ctx.phase_hooks
-        cuts = sorted({ph for ph, _ in hooks if ph < 2})
-        calls, lo = [], 0
-        for c in cuts + [2]:
-            calls.append((sum(1 << i for i in range(lo, c + 1)) if cuts else 0, c))
-            lo = c + 1
-        for mask, last in calls:
-            ctx.cfg.bwd_phase = mask
-            if ctx.src_rows is not None:
-                check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
+        cfg, hooks = ctx.cfg, ctx.phase_hooks
+        packed = ctx.src_rows is not None
+
+        def call(mask, stream=None):
+            cfg.bwd_phase = mask
+            st = stream_ptr() if stream is None else stream
+            if packed:
+                check(lib.immtsf_ttf_t2v_xattn_backward_packed(C.byref(cfg), C.byref(ps), ptr(notes), ptr(ctx.src_rows), ptr(tau),
                                                                ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
-                                                               C.byref(gs), stream_ptr()), "ttf_t2v_xattn_backward_packed")
+                                                               C.byref(gs), st), "ttf_t2v_xattn_backward_packed")
             else:
-                check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(ctx.cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
-                                                        ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), stream_ptr()),
+                check(lib.immtsf_ttf_t2v_xattn_backward(C.byref(cfg), C.byref(ps), ptr(notes), ptr(tau), ptr(dE), ptr(ctx.ws),
+                                                        ctx.ws.numel(), ptr(sc), sc.numel(), C.byref(gs), st),
                       "ttf_t2v_xattn_backward")
-            for ph, hook in hooks:
-                if ph == last:
-                    _fire(hook)
-        ctx.cfg.bwd_phase = 0
+            cfg.bwd_phase = 0
+
+        tail = config.param_tail
+        split = (tail is not None and tail.get("ttf_flag") is not None and tail.get("defer", 0) > 0 and not ctx.folded and
+                 all(r is None for r in rets) and _bf16_dataflow(cfg.precision, cfg.d))
+        if split:
+            # a step with a parameter-only branch (immtsf.train.FlagStep): this stream runs the data path and the LAST phase's weight
+            # gradients; the weight gradients of phases A and B -- whose inputs exist long before the end -- leave as one grouped launch
+            # on that branch, behind a flag that says phase B's data path has run.  Their buckets' hooks fire there.
+            call(_lib.BWD_PHASE_A | _lib.BWD_PHASE_B)
+            flag, err = tail["ttf_flag"]
+            check(lib.immtsf_flag_set(flag, stream_ptr()), "flag_set")
+            call(_lib.BWD_PHASE_C | _lib.BWD_WGRAD_C)
+            early = [h for ph, h in hooks if ph < 2]
+            keep = (notes, tau, dE, sc, ps, gs, params, grads, dE_h)          # the job runs later, on another stream: everything it touches stays alive
+
+            def job(stream, keep=keep):
+                check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
+                call(_lib.BWD_WGRAD_A | _lib.BWD_WGRAD_B, stream)
+                for h in early:
+                    _fire(h)
+            tail["jobs"].append(job)
+            for ph, h in hooks:
+                if ph == 2:
+                    _fire(h)
+        else:
+            # one call (every weight gradient in one grouped launch) unless a bucket completes before the last phase: then one call per
+            # run of phases up to the next hook (immtsf_fusion_cfg.bwd_phase), data path and weight gradients together
+            cuts = sorted({ph for ph, _ in hooks if ph < 2})
+            lo = 0
+            for c in cuts + [2]:
+                call(sum(0x11 << i for i in range(lo, c + 1)) if cuts else 0)
+                lo = c + 1
+                for ph, h in hooks:
+                    if ph == c:
+                        _fire(h)
         if ctx.no_proj:         # (proj_out's gradients come out of the consumer's backward)
             rets = list(rets)
             rets[15] = rets[16] = None
@@ -630,6 +684,7 @@ class MMFXRankPFn(torch.autograd.Function):
                 pre(stream_ptr())
                 run_params(stream_ptr(), 0, k)
             check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
+            tail["flag_set"] = True          # (the branch that runs the jobs waits for the flag only when somebody set it)
             if k > 0:
                 tail["jobs"].append(lambda stream: run_params(stream, k, 3))
             else:

@@ -832,18 +832,22 @@ class FlagStep(PhasedStep):
     `check()` raises on every rank; `check_every` > 0 makes __call__ do that every so many steps."""
 
     # flag words (int32 offsets into self.flags)
-    _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _ERR, _PENDING, _SKIP, _COMM_DONE = range(12)
+    _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _TTF = range(9)        # hand-over flags: cleared at the end of every replay
+    _ERR, _PENDING, _SKIP, _COMM_DONE = 12, 13, 14, 15                           # guard word, gradient pending, step decision, collectives done
     _COUNT0 = 16
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
         backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
-        announced on B instead of waiting for the join."""
+        announced on B instead of waiting for the join.
+        ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
+        backward ends) leave the text side's dependent chain for the parameter branch, behind MMF_XAttn_Add's chain
+        (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks)."""
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
         if trainer.sharded:
@@ -989,7 +993,8 @@ class FlagStep(PhasedStep):
                             announce(bi)
                 # parameter-gradient tails of the text side (work only the optimizer waits for) go to the parameter branch;
                 # the TAIL flag says their inputs exist
-                tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer}
+                tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer,
+                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None}
                 config.param_tail = tail if self._defer > 0 else None
                 trainer._capture_hook = announce if self.dist else None
                 branch_now[0] = "T"
@@ -1003,7 +1008,8 @@ class FlagStep(PhasedStep):
                 try:
                     with torch.cuda.stream(P):
                         if tail["jobs"]:
-                            fwait(W(self._TAIL), P)
+                            if tail.get("flag_set"):
+                                fwait(W(self._TAIL), P)
                             for job in tail["jobs"]:
                                 job(sp(P))
                 finally:
@@ -1025,7 +1031,7 @@ class FlagStep(PhasedStep):
                     for lo, hi in _runs([trainer.ranges[b] for b in rest]):
                         announce_range(lo, hi, [b for b in rest if lo <= trainer.ranges[b][0] and trainer.ranges[b][1] <= hi])
                     announced.update(rest)
-                _lib.check(lib.immtsf_flags_clear_set(fp, 8, self._f_pending, sp(T)), "flags_clear_set")
+                _lib.check(lib.immtsf_flags_clear_set(fp, 9, self._f_pending, sp(T)), "flags_clear_set")
         finally:
             config.sched_gate = config.sched_armed = None
         # the communication stream's order: the text side's buckets but its last, the parameter branch's, the text side's last, the

@@ -50,10 +50,10 @@ typedef void* immtsf_stream_t;
 int immtsf_abi_version(void);
 /* sizeof of every struct of this ABI, in the order immtsf_fusion_cfg, immtsf_t2v_params, immtsf_recavg_params, immtsf_xadd_params,
  * immtsf_gr_params, immtsf_ttcn_params, immtsf_gcn_params, immtsf_decoder_params, immtsf_time2vec_params, immtsf_encoder_layer_cfg,
- * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store: lets a binding check its own struct
- * definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes min(max, 14) entries to the HOST
- * array `out`, returns the number of structs (14).  (ABI 5) */
-#define IMMTSF_ABI_NSTRUCTS 14
+ * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store, immtsf_note_index: lets a binding check its
+ * own struct definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes min(max, 15) entries to
+ * the HOST array `out`, returns the number of structs (15).  (ABI 5) */
+#define IMMTSF_ABI_NSTRUCTS 15
 int immtsf_abi_sizes(int32_t* out, int32_t max);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -94,19 +94,43 @@ typedef struct immtsf_fusion_cfg {
                                       patch encoder's backward) lets it spin on this flag, so that it shares the chip with the small launches
                                       instead of the row-bound ones.  (ABI 4) */
     int32_t bwd_phase;             /* TTF_T2V_XAttn backward in its chain form, optional (0 = the whole backward in one call, every weight
-                                      gradient in ONE grouped launch at its end): a mask of IMMTSF_BWD_PHASE_* -- the call runs only those
-                                      phases, each phase's weight gradients leave with that call, and the caller runs the three phases in
-                                      order (same cfg, workspace, scratch and grads).  What a data-parallel step uses to hand finished
-                                      gradient buckets to the all-reduce while the rest of the backward still runs
-                                      (immtsf.train.FlagStep).  The folded form ignores it unless it is exactly one phase, in which case only
-                                      IMMTSF_BWD_PHASE_C does the work.  (ABI 5) */
+                                      gradient in ONE grouped launch at its end): a mask -- bits 0..2 = the DATA path of phases A, B, C
+                                      (IMMTSF_BWD_PHASE_*), bits 4..6 = the PARAMETER gradients of phases A, B, C (IMMTSF_BWD_WGRAD_*: the
+                                      weight-gradient products, which nothing in the backward waits for, as one grouped launch per call,
+                                      and phase B's query path).  The caller runs the data phases in order A, B, C and a phase's parameter
+                                      gradients in or behind the call that ran its data path -- on any stream ordered behind it (same cfg,
+                                      workspace, scratch and grads in every call).  Uses: a data-parallel step hands finished gradient
+                                      buckets to the all-reduce while the later phases still run; a step with a parameter-only branch
+                                      moves the early weight gradients off the text side's dependent chain (immtsf.train.FlagStep).  The
+                                      folded form does all its work in the call that holds IMMTSF_BWD_PHASE_C.  (ABI 5) */
     int32_t reserved0;             /* must be 0 */
+    const struct immtsf_note_index* note_index; /* TTF_T2V_XAttn *_packed calls, optional (NULL = the call derives the index itself: two
+                                      launches in front of everything else): the ragged index of the batch's notes, built ONCE per batch by
+                                      immtsf_note_index_build -- by the batch builder, where the per-window note counts are known
+                                      (immtsf.data / SURVEY 8f row 1: "offsets authoritative") -- instead of inside every forward.  HOST
+                                      struct of device pointers; forward and backward of a call pair get the same one; M_txt may then be NULL
+                                      (it is note_index->mtxt).  (ABI 5) */
 } immtsf_fusion_cfg;
+/* the ragged index of a packed batch (what immtsf_ragged_index derives from a zero-padded tensor): mask u8 (B*N: n < lengths[b]), mtxt u8
+ * (B: lengths[b] > 0), lengths i32 (B), offsets i32 (B+1; offsets[B] = total notes), rowmap i32 (B*N; packed row -> b*N+n), seg i32 (B*N;
+ * packed row -> window).  Reference: the quantities fusions/TTF_T2V_XAttn.py:107,124,146 re-derive from the padded tensor every call. */
+typedef struct immtsf_note_index {
+    uint8_t* mask;
+    uint8_t* mtxt;
+    int32_t* lengths;
+    int32_t* offsets;
+    int32_t* rowmap;
+    int32_t* seg;
+} immtsf_note_index;
+int immtsf_note_index_build(const int32_t* lengths_in, int32_t B, int32_t N, const immtsf_note_index* out, immtsf_stream_t stream);
 /* after phase A: d proj_out (unless IMMTSF_FORM_NO_PROJ), d layer_norm, d attn.out_proj are final; after B: d attn.in_proj_{weight,bias}
  * and d Q_param; after C: d input_proj, d time2vec, d KV_proj */
 #define IMMTSF_BWD_PHASE_A 1
 #define IMMTSF_BWD_PHASE_B 2
 #define IMMTSF_BWD_PHASE_C 4
+#define IMMTSF_BWD_WGRAD_A 16
+#define IMMTSF_BWD_WGRAD_B 32
+#define IMMTSF_BWD_WGRAD_C 64
 
 /* a2: ragged index of a zero-padded note tensor.  reference: note_mask = (V.abs().sum(2) > 0)
  * fusions/TTF_T2V_XAttn.py:107,124,146 ; fusions/TTF_RecAvg.py:69,110.

@@ -912,6 +912,58 @@ def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, pac
         assert err <= tol, (k, err)
 
 
+@pytest.mark.parametrize("form", ["fold", "chain"])
+def test_prebuilt_note_index_equals_the_derived_one(form):
+    """PackedNotes.index() (immtsf_note_index_build: the batch's ragged index built once, by whoever builds the batch) is, array by array
+    and bit for bit, what immtsf_ragged_index derives from the zero-padded tensor (a2), and TTF_T2V_XAttn on it (immtsf_fusion_cfg.
+    note_index) returns the very E_txt, M_txt and gradients of the call that derives the index itself (config.note_index = False)."""
+    dev = _dev()
+    import ctypes as C
+    from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+    from fusions.load_llm import register_d_model
+    from immtsf import _lib, config
+    from immtsf.ops import PackedNotes
+    lib = _lib.load()
+    B, N, T, d_m, d = 40, 11, 9, 64, 32
+    register_d_model("IDX64", d_m)
+    torch.manual_seed(3)
+    ttf = TTF_T2V_XAttn("IDX64", 6, n_heads_fusion=2, dropout=0.0, d_txt=d).to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    lengths = torch.randint(0, N + 1, (B,), generator=g)
+    lengths[0], lengths[1] = N, 0
+    keep = torch.arange(N).view(1, -1) < lengths.view(-1, 1)
+    notes = ((torch.randn(B, N, d_m, generator=g) + 3.0) * keep.unsqueeze(-1)).to(dev)
+    tau = (torch.sort(torch.rand(B, N, generator=g) * 24.0, dim=1).values * keep).to(dev)
+    t_hat = torch.rand(B, T, generator=g).to(dev)
+    up = torch.randn(B, T, d, generator=g).to(dev)
+    rows = torch.arange(B * N, device=dev, dtype=torch.int32).view(B, N)[keep.to(dev)].contiguous()
+    src = PackedNotes(notes.reshape(B * N, d_m).contiguous(), rows, lengths.to(dev).to(torch.int32), N)
+    # the arrays against a2 on the padded tensor
+    ix = src.index()[1]
+    mask = torch.empty(B, N, dtype=torch.uint8, device=dev)
+    i32 = lambda *s_: torch.empty(*s_, dtype=torch.int32, device=dev)      # noqa: E731
+    le, of, rm, sg, mt = i32(B), i32(B + 1), i32(B * N), i32(B * N), torch.empty(B, dtype=torch.uint8, device=dev)
+    _lib.check(lib.immtsf_ragged_index(_lib.ptr(notes), B, N, d_m, _lib.ptr(mask), _lib.ptr(le), _lib.ptr(of), _lib.ptr(rm), _lib.ptr(sg),
+                                       _lib.ptr(mt), None, _lib.stream_ptr()), "ragged_index")
+    torch.cuda.synchronize()
+    total = int(of[B])
+    assert torch.equal(ix["mask"].view(B, N), mask) and torch.equal(ix["mtxt"], mt) and torch.equal(ix["lengths"], le)
+    assert torch.equal(ix["offsets"], of) and torch.equal(ix["rowmap"][:total], rm[:total]) and torch.equal(ix["seg"][:total], sg[:total])
+    res = []
+    try:
+        config.t2v_form = form
+        for use in (True, False):
+            config.note_index = use
+            ttf.zero_grad()
+            E, M = ttf(src, tau, t_hat)
+            (E * up).sum().backward()
+            res.append([E.detach().clone(), M.clone()] + [p_.grad.clone() for p_ in ttf.parameters()])
+    finally:
+        config.t2v_form, config.note_index = "auto", True
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("form", ["fold", "chain"])
 @pytest.mark.parametrize("B,N,T,d_m,d,H,Cc,pd", [(5, 6, 7, 48, 32, 1, 3, 0.0), (6, 32, 32, 96, 64, 2, 8, 0.2), (64, 32, 32, 768, 768, 1, 8, 0.1),

@@ -252,11 +252,18 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
 
 int immtsf_adam_prepare(const float* grad, const void* grad_h, uint64_t n, float* norm_scratch, int64_t* step_dev,
                         uint64_t* dropout_step_dev, int32_t* pending, const int32_t* err, const void* guard_h, const float* guard_f,
-                        int32_t* skip_out, immtsf_stream_t stream) {
+                        int32_t* skip_out, int32_t* epoch, immtsf_stream_t stream) {
     if ((!grad && !grad_h) || !norm_scratch) return IMMTSF_EINVAL;
     return launch_adam_prepare(grad, grad_h, (size_t)n, norm_scratch, reinterpret_cast<long long*>(step_dev),
-                               reinterpret_cast<unsigned long long*>(dropout_step_dev), pending, err, guard_h, guard_f, skip_out,
+                               reinterpret_cast<unsigned long long*>(dropout_step_dev), pending, err, guard_h, guard_f, skip_out, epoch,
                                static_cast<hipStream_t>(stream));
+}
+
+int immtsf_copy_segments(int32_t k, const float* const* src, float* const* dst, const int32_t* counts, immtsf_stream_t stream) {
+    if (k <= 0 || k > 8 || !src || !dst || !counts) return IMMTSF_EINVAL;
+    for (int i = 0; i < k; ++i)
+        if (counts[i] < 0 || (counts[i] > 0 && (!src[i] || !dst[i]))) return IMMTSF_EINVAL;
+    return launch_copy_segments(k, src, dst, counts, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_avg, float* exp_avg_sq, uint64_t n, uint64_t lo,

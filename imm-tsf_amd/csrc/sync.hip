@@ -62,6 +62,20 @@ __global__ void flag_wait_ge_kernel(int* flag, int target, int* err, long long t
     ft_note(flag, 2);
     __threadfence_system();
 }
+__global__ void flag_wait_ge_dev_kernel(int* flag, const int* target_dev, int* err, long long ticks) {
+    const long long t0 = wall_clock64();
+    ft_note(flag, 1);
+    const int target = __hip_atomic_load(target_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > ticks) {
+            atomicExch(err, 1);
+            break;
+        }
+    }
+    ft_note(flag, 2);
+    __threadfence_system();
+}
 __global__ void flags_clear_kernel(int* flags, int n, int* set_flag = nullptr) {
     if (threadIdx.x == 0) ft_note(flags, 3);
     if ((int)threadIdx.x < n) flags[threadIdx.x] = 0;
@@ -93,6 +107,13 @@ int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream) {
 int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream) {
     if (!flag || !err || timeout_ms <= 0) return IMMTSF_EINVAL;
     hipLaunchKernelGGL(flag_wait_ge_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, target, err,
+                       (long long)timeout_ms * 100000ll);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int immtsf_flag_wait_ge_dev(int32_t* flag, const int32_t* target_dev, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream) {
+    if (!flag || !target_dev || !err || timeout_ms <= 0) return IMMTSF_EINVAL;
+    hipLaunchKernelGGL(flag_wait_ge_dev_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, target_dev, err,
                        (long long)timeout_ms * 100000ll);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;

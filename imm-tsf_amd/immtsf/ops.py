@@ -680,6 +680,32 @@ class MMFXRankPFn(torch.autograd.Function):
                 check(lib.immtsf_mmf_xrank_p_backward_params(C.byref(cfg), C.byref(ps), ptr(dbHO), ptr(ws), ws.numel(), ptr(sc), sc.numel(),
                                                              C.byref(gs), first, last, stream), "mmf_xrank_p_backward_params")
 
+            seed_reduce = tail.get("seed_reduce")
+            if seed_reduce is not None and ctx.done_hook is not None:
+                # data parallel (immtsf.train.FlagStep): every gradient the chain (and the "_z" pre-step) writes is a LINEAR function of
+                # the seeds the data half left in the scratch -- dW_fold / dWc with their column sums, d b_HO -- so the ranks all-reduce
+                # THOSE (75 KB) in front of the chain, and every rank's chain yields the summed gradients: the block's ~14 MB of
+                # parameter gradients never cross the wire.  seed_reduce(stream, segments, produced, hook) gathers the segments,
+                # hands them to the communication stream, waits for the sum and scatters it back -- as launches on `stream`
+                region, floats = C.c_void_p(), C.c_size_t()
+                z = 1 if proj is not None else 0
+                check(lib.immtsf_mmf_xrank_seed_region(C.byref(cfg), ptr(sc), sc.numel(), z, C.byref(region), C.byref(floats)), "mmf_xrank_seed_region")
+                segs = [(int(region.value), int(floats.value)), (dbHO.data_ptr(), dbHO.numel())]
+                produced = [q for q in list(params9) + list(proj or ()) if q is not None]
+                hook, ctx.done_hook = ctx.done_hook, None
+                k = 0        # (the whole chain behind the reduction, on the branch that waits for it)
+
+                def reduce_job(stream, cfg=cfg, sc=sc):
+                    seed_reduce(stream, segs, produced, hook)
+                    check(lib.immtsf_mmf_xrank_seed_refresh(C.byref(cfg), ptr(sc), sc.numel(), z, stream), "mmf_xrank_seed_refresh")
+                check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
+                tail["flag_set"] = True
+                tail["jobs"].append(reduce_job)
+                tail["jobs"].append(lambda stream: (pre(stream), run_params(stream, 0, 3)))
+                tail["jobs"].append(lambda stream, hook=hook: tail["prereduced"](hook))
+                if dE_h is not None:
+                    _shadow_put(dE, dE_h)
+                return (dE, None, None, None, None) + tuple(rets[:9]) + (tuple(prets) if proj is not None else ())
             if k > 0:
                 pre(stream_ptr())
                 run_params(stream_ptr(), 0, k)

@@ -159,7 +159,9 @@ class FlatTrainer:
         if self.collective and dev.type == "cuda" and not self.sharded:
             for bi in self.sink_buckets:
                 head = self.buckets[bi][0]
-                head._immtsf_bwd_hook = (lambda i=bi: self._on_bucket_done(i))
+                hook = (lambda i=bi: self._on_bucket_done(i))
+                hook._immtsf_bucket_index = bi
+                head._immtsf_bwd_hook = hook
 
     def gather(self, flat: torch.Tensor) -> torch.Tensor:
         """the parameters' elements of a flat buffer (param / grad / moment), concatenated in bucket order without the
@@ -446,7 +448,7 @@ class FlatTrainer:
             bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
             self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
 
-    def adam_prepare(self, pending=None, err=None, skip_out=None, from_wire=False, guard=False):
+    def adam_prepare(self, pending=None, err=None, skip_out=None, from_wire=False, guard=False, epoch=None):
         """first half of clip + Adam as launches the caller places (include/immtsf.h immtsf_adam_prepare): the squared norm of the whole
         gradient (from_wire: of its reduced bf16 wire image) and the step decision into `skip_out`; addresses are raw device pointers"""
         lib = _lib.load()
@@ -459,7 +461,7 @@ class FlatTrainer:
             else:
                 gf = self._grad_store[n:].data_ptr()
         _lib.check(lib.immtsf_adam_prepare(_lib.ptr(self.flat_grad), None if wire is None else wire.data_ptr(), n, _lib.ptr(self.norm_scratch),
-                                           _lib.ptr(self.step_dev), _lib.ptr(self.drop_dev), pending, err, gh, gf, skip_out,
+                                           _lib.ptr(self.step_dev), _lib.ptr(self.drop_dev), pending, err, gh, gf, skip_out, epoch,
                                            _lib.stream_ptr()), "adam_prepare")
 
     def adam_range(self, lo, hi, skip=None, from_wire=False):
@@ -834,17 +836,22 @@ class FlagStep(PhasedStep):
     # flag words (int32 offsets into self.flags)
     _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _TTF = range(9)        # hand-over flags: cleared at the end of every replay
     _ERR, _PENDING, _SKIP, _COMM_DONE = 12, 13, 14, 15                           # guard word, gradient pending, step decision, collectives done
+    _EPOCH, _SEED, _SEED_DONE = 9, 10, 11                                         # replay number (device side), seeds gathered, seeds summed (counting)
     _COUNT0 = 16
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0, ttf_wgrad_tail: bool = True):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = True, merge_adjacent: bool = True):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
         backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
         announced on B instead of waiting for the join.
+        seed_reduce (data parallel): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's low-rank
+        form: ops.MMFXRankPFn) has the SEEDS all-reduced in front of its parameter chain instead of the gradients behind it.
+        merge_adjacent (data parallel): buckets announced by the same branch that follow each other on the communication stream and in
+        the flat buffer go out as one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
         backward ends) leave the text side's dependent chain for the parameter branch, behind MMF_XAttn_Add's chain
         (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks)."""
@@ -893,6 +900,7 @@ class FlagStep(PhasedStep):
         W = lambda i: fp + 4 * i        # noqa: E731
         F_B1, F_T2, F_B2, F_P2, F_ERR = W(self._B1), W(self._T2), W(self._B2), W(self._P2), W(self._ERR)
         self._f_err, self._f_pending, self._f_skip, self._f_comm = F_ERR, W(self._PENDING), W(self._SKIP), W(self._COMM_DONE)
+        self._f_seed, self._f_seed_done = W(self._SEED), W(self._SEED_DONE)
         sp = lambda st: st.cuda_stream        # noqa: E731
         tmo = self.timeout_ms
 
@@ -928,6 +936,50 @@ class FlagStep(PhasedStep):
             announced.add(bi)
             announce_range(*trainer.ranges[bi], (bi,))
 
+        def prereduced(hook):
+            # a bucket whose gradients already ARE the sum over the ranks (its chain ran on all-reduced seeds): only the wire image
+            # (what the norm and Adam read), no collective
+            bi = getattr(hook, "_immtsf_bucket_index", None)
+            if bi is None or bi in announced:
+                raise RuntimeError("FlagStep: a pre-reduced bucket must be announced once, by its trainer hook")
+            announced.add(bi)
+            lo, hi = trainer.ranges[bi]
+            if bf16_wire and hi > lo:
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo,
+                                                  torch.cuda.current_stream().cuda_stream), "f32_to_bf16")
+            self.prereduced.append(bi)
+
+        self.seed_buf, self.prereduced = None, []
+
+        def seed_reduce_fn(stream, segs, produced, hook):
+            # gather the seeds (+ the gradients of the bucket's parameters the chain does not produce: final by now) into one staging
+            # buffer, announce it, wait -- INSIDE the graph -- for the communication stream's all-reduce of this replay, scatter back
+            bi = getattr(hook, "_immtsf_bucket_index", None)
+            if self.seed_buf is not None or bi is None:
+                raise RuntimeError("FlagStep: one seed reduction per step")
+            made = {id(q) for q in produced}
+            segs = list(segs)
+            for q, v in zip(trainer.buckets[bi], trainer._views[bi]):
+                if id(q) not in made:
+                    segs.append((v.data_ptr(), v.numel()))
+            if len(segs) > 8:
+                raise RuntimeError("FlagStep: more than 8 seed segments")
+            total = sum(-(-c // 4) * 4 for _, c in segs)
+            self.seed_buf = torch.empty(total, dtype=torch.float32, device=dev)
+            k = len(segs)
+            offs, o = [], 0
+            for _, c in segs:
+                offs.append(o)
+                o += -(-c // 4) * 4
+            base = self.seed_buf.data_ptr()
+            arr = lambda xs: (C.c_void_p * k)(*xs)        # noqa: E731
+            srcs, stage = arr([p for p, _ in segs]), arr([base + 4 * x for x in offs])
+            cnts = (C.c_int32 * k)(*[c for _, c in segs])
+            _lib.check(lib.immtsf_copy_segments(k, srcs, stage, cnts, stream), "copy_segments")
+            _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
+            _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
+            _lib.check(lib.immtsf_copy_segments(k, stage, srcs, cnts, stream), "copy_segments")
+
         def adam(buckets):
             for lo, hi in _runs([trainer.ranges[b] for b in sorted(buckets)]):
                 trainer.adam_range(lo, hi, skip=self._f_skip, from_wire=bf16_wire)
@@ -941,7 +993,8 @@ class FlagStep(PhasedStep):
                 trainer._grad_zeroed_by_step = True       # (the Adam passes below leave every range zero)
                 trainer.zero_grad()
                 # ---- the previous replay's optimizer step: norm + decision, then the buckets on the branches that read them first
-                trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist)
+                trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist,
+                                     epoch=W(self._EPOCH))
                 if adam_split is None:
                     adam(range(nb))
                     B.wait_stream(T)                  # fork (satisfied when B gets there: nothing runs on B before it)
@@ -994,7 +1047,8 @@ class FlagStep(PhasedStep):
                 # parameter-gradient tails of the text side (work only the optimizer waits for) go to the parameter branch;
                 # the TAIL flag says their inputs exist
                 tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer,
-                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None}
+                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None,
+                        "seed_reduce": seed_reduce_fn if (self.dist and seed_reduce and P is not B) else None, "prereduced": prereduced}
                 config.param_tail = tail if self._defer > 0 else None
                 trainer._capture_hook = announce if self.dist else None
                 branch_now[0] = "T"
@@ -1039,6 +1093,17 @@ class FlagStep(PhasedStep):
         tseg = [g for g in self.segments if g["branch"] == "T"]
         self.segments = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
                          [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
+        if merge_adjacent:
+            merged = []
+            for g in self.segments:
+                if merged and merged[-1]["hi"] == g["lo"] and merged[-1]["branch"][-1] == g["branch"]:      # (same branch: final together)
+                    m = merged[-1]
+                    m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + [g["flag"]], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
+                else:
+                    merged.append(dict(g, flags=[g["flag"]]))
+            self.segments = merged
+        else:
+            self.segments = [dict(g, flags=[g["flag"]]) for g in self.segments]
         self.comm = None
         if self.dist:
             # a HIGH-PRIORITY stream of its own: HIP deals streams of one priority round-robin onto a handful of hardware queues, and a
@@ -1106,9 +1171,14 @@ class FlagStep(PhasedStep):
             cs = self.comm.cuda_stream
             import torch.distributed as dist
             with torch.cuda.stream(self.comm):
+                if self.seed_buf is not None:       # the seeds of a block's parameter chain: summed in fp32, handed back to the graph
+                    _lib.check(lib.immtsf_flag_wait_ge(self._f_seed, k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
+                    dist.all_reduce(self.seed_buf, group=t.group)
+                    _lib.check(lib.immtsf_flag_bump(self._f_seed_done, cs), "flag_bump")
                 last = len(self.segments) - 1
                 for i, g in enumerate(self.segments):
-                    _lib.check(lib.immtsf_flag_wait_ge(g["flag"], k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
+                    for f in g["flags"]:
+                        _lib.check(lib.immtsf_flag_wait_ge(f, k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
                     hi = g["hi"]
                     if i == last:
                         # this rank's guard word rides with the last collective: into the slot behind the payload when the last range

@@ -960,8 +960,9 @@ def test_prebuilt_note_index_equals_the_derived_one(form):
             res.append([E.detach().clone(), M.clone()] + [p_.grad.clone() for p_ in ttf.parameters()])
     finally:
         config.t2v_form, config.note_index = "auto", True
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2:], res[1][2:]):          # (split-K weight gradients accumulate by atomics: equal up to their order)
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6)
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])

@@ -1560,28 +1560,34 @@ int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immts
     Mat Wpo;
     CHECK(weight_mat(hf, proj_w, (size_t)d * d, w.Wpo16, s, &Wpo));
     Mat dPm = cmat(dP), Zm = cmat(Z, hf ? (cfg->aux_h ? cfg->aux_h : static_cast<const void*>(w.E16)) : nullptr);
-    if (hf && !cfg->aux_h) CHECK(launch_f32_to_bf16(Z, w.E16, (size_t)BT * d, s));
+    const bool seed_only = cfg->bwd_phase != 0 && !(cfg->bwd_phase & IMMTSF_BWD_PHASE_A);      // (the images were made by the data call)
+    if (hf && !cfg->aux_h && !seed_only) CHECK(launch_f32_to_bf16(Z, w.E16, (size_t)BT * d, s));
     if (hf && cfg->in_h) {
         dPm.h = const_cast<void*>(cfg->in_h);
     } else if (hf) {
-        CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
+        if (!seed_only) CHECK(launch_f32_to_bf16(dP, sc.dP16, (size_t)BT * x.PW, s));
         dPm.h = sc.dP16;
     }
-    if (rank_expand_ok(BT, d, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr)) {       // dZ = dP Wc: many rows, rank PW (see rank_expand_kernel)
-        CHECK(launch_rank_expand(dP, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr, BT, d, x.PW, s));
-    } else {
-        GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
-        set_problem2(g, 0, dPm, mat(w.Wc, w.Wc16), mat(dZ, hf ? cfg->out_h : nullptr), nullptr);
-        CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+    // immtsf_fusion_cfg.bwd_phase: 0 = both halves; IMMTSF_BWD_PHASE_A = only dZ (what the producer's backward waits for);
+    // IMMTSF_BWD_WGRAD_A = only the chain's seeds dWc / dbc (parameter-gradient work: any stream ordered behind dP)
+    const bool do_data = cfg->bwd_phase == 0 || (cfg->bwd_phase & IMMTSF_BWD_PHASE_A), do_seed = cfg->bwd_phase == 0 || (cfg->bwd_phase & IMMTSF_BWD_WGRAD_A);
+    if (do_data) {
+        if (rank_expand_ok(BT, d, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr)) {       // dZ = dP Wc: many rows, rank PW (see rank_expand_kernel)
+            CHECK(launch_rank_expand(dP, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr, BT, d, x.PW, s));
+        } else {
+            GemmArgs g = gemm_args(BT, d, x.PW, x.PW, d, d);
+            set_problem2(g, 0, dPm, mat(w.Wc, w.Wc16), mat(dZ, hf ? cfg->out_h : nullptr), nullptr);
+            CHECK(immtsf_launch_gemm(GEMM_NN, prec, g, s));
+        }
     }
-    {   // dWc = dP^T Z,  dbc = column sums of dP
+    if (do_seed) {   // dWc = dP^T Z,  dbc = column sums of dP
         GemmArgs g = gemm_args(x.PW, d, BT, x.PW, d, d);
         set_problem2(g, 0, dPm, Zm, mat(sc.dWc), nullptr, sc.dbc);
         g.c_prezeroed = 0;
         g.ws = sc.sk; g.ws_bytes = sc.skb;
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
+        if (hf) CHECK(launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * d, s));
     }
-    if (hf) CHECK(launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * d, s));
     return IMMTSF_OK;
 }
 

@@ -661,11 +661,15 @@ class MMFXRankPFn(torch.autograd.Function):
                 check(lib.immtsf_mmf_xrank_p_backward_pre_z(C.byref(cfg), ptr(proj[0]), ptr(proj[1]), ptr(ws0), ws0.numel(), ptr(sc), sc.numel(),
                                                             ptr(pgrads[0]), ptr(pgrads[1]), stream), "mmf_xrank_p_backward_pre_z")
 
-        def data_half():
+        def data_half(part=0, stream=None):
+            # part 0: dZ and the chain's seeds; "_z" form only: BWD_PHASE_A = dZ alone, BWD_WGRAD_A = the seeds (dWc, dbc) alone
             if proj is not None:
+                cfg.bwd_phase = part
                 check(lib.immtsf_mmf_xrank_p_backward_data_z(C.byref(cfg), C.byref(ps), ptr(proj[0]), ptr(proj[1]), ptr(E), ptr(dP), ptr(dE),
-                                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(), stream_ptr()),
+                                                             ptr(ctx.ws), ctx.ws.numel(), ptr(sc), sc.numel(),
+                                                             stream_ptr() if stream is None else stream),
                       "mmf_xrank_p_backward_data_z")
+                cfg.bwd_phase = 0
             else:
                 check(lib.immtsf_mmf_xrank_p_backward_data(C.byref(cfg), C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
                                                            sc.numel(), stream_ptr()), "mmf_xrank_p_backward_data")
@@ -673,7 +677,12 @@ class MMFXRankPFn(torch.autograd.Function):
         if tail is not None and all(r is None for r in rets[:9]) and tail["defer"] > 0:
             # every gradient goes straight to its sink: the last `defer` launches of the parameter chain are left to the other branch
             k = 3 - min(3, int(tail["defer"]))
-            data_half()
+            # the "_z" form with the whole chain deferred: this stream (the text side's dependent chain) only forms dZ; the chain's
+            # seeds dWc = dP^T Z -- parameter-gradient work too -- open the other branch's jobs
+            seeds_later = proj is not None and k == 0
+            data_half(_lib.BWD_PHASE_A if seeds_later else 0)
+            if seeds_later:
+                tail["jobs"].append(lambda stream, keep=(E, dP): data_half(_lib.BWD_WGRAD_A, stream))
             ws = ctx.ws
 
             def run_params(stream, first, last, cfg=cfg, ps=ps, gs=gs, dbHO=dbHO, ws=ws, sc=sc, keep=(params, grads)):

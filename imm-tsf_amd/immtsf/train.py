@@ -835,19 +835,26 @@ class FlagStep(PhasedStep):
 
     # flag words (int32 offsets into self.flags)
     _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _TTF = range(9)        # hand-over flags: cleared at the end of every replay
-    _ERR, _PENDING, _SKIP, _COMM_DONE = 12, 13, 14, 15                           # guard word, gradient pending, step decision, collectives done
-    _EPOCH, _SEED, _SEED_DONE = 9, 10, 11                                         # replay number (device side), seeds gathered, seeds summed (counting)
-    _COUNT0 = 16
+    _C2, _SEED, _SEED_DONE = 9, 10, 11      # communication branch done; seeds gathered / summed (captured collectives: plain flags, cleared
+    #                                         with the others; eager collectives: counting flags, never cleared)
+    _COUNT0 = 16                            # one flag per announced bucket (plain / counting likewise)
+    _ERR, _PENDING, _SKIP, _COMM_DONE, _EPOCH = 40, 41, 42, 43, 44      # guard word, gradient pending, step decision, collectives done, replay number
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = True, merge_adjacent: bool = True):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = True, merge_adjacent: bool = True,
+                 captured_comm: Optional[bool] = None):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
         backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
         announced on B instead of waiting for the join.
+        captured_comm (data parallel): the collectives are CAPTURED into the step's graph, on a fourth branch that spins on the buckets'
+        flags -- one graph launch per step and nothing else: no eager launches (a c10d all-reduce costs the host 30 - 50 us, five of them
+        made the 0.46 ms step host-bound), no communication stream whose hardware queue may be shared with, or -- at high priority -- starve,
+        the graph's branches.  None: on for the nccl (RCCL) backend, off otherwise (gloo cannot be captured: the eager communication
+        stream with counting flags is what the two-rank tests on one GPU run).
         seed_reduce (data parallel): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's low-rank
         form: ops.MMFXRankPFn) has the SEEDS all-reduced in front of its parameter chain instead of the gradients behind it.
         merge_adjacent (data parallel): buckets announced by the same branch that follow each other on the communication stream and in
@@ -865,6 +872,10 @@ class FlagStep(PhasedStep):
         lib = _lib.load()
         self.dist = bool(trainer.collective)
         self.timeout_ms, self.comm_timeout_ms, self.check_every = int(timeout_ms), int(comm_timeout_ms), int(check_every)
+        if captured_comm is None and self.dist:
+            import torch.distributed as dist
+            captured_comm = dist.get_backend(trainer.group) == "nccl"
+        self.captured = bool(captured_comm and self.dist)
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         # parameter-only work (MMF_XAttn_Add's fold in front, its parameter-gradient chain behind) on a THIRD branch of the graph
         self.P = torch.cuda.Stream(device=dev) if param_branch else self.B
@@ -895,6 +906,7 @@ class FlagStep(PhasedStep):
         trainer.restore(snap)
         trainer.flat_grad.zero_()
         torch.cuda.synchronize()
+        self.Cs = torch.cuda.Stream(device=dev) if self.captured else None      # the communication branch of the graph
         self.flags = torch.zeros(48, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
         W = lambda i: fp + 4 * i        # noqa: E731
@@ -921,13 +933,14 @@ class FlagStep(PhasedStep):
             if hi == lo:
                 return
             k = len(self.segments)
-            if self._COUNT0 + k >= 48:
-                raise RuntimeError("FlagStep: more than 32 announced buckets")
+            if self._COUNT0 + k >= self._ERR:
+                raise RuntimeError("FlagStep: more than 24 announced buckets")
             flag = W(self._COUNT0 + k)
             st = torch.cuda.current_stream().cuda_stream
             if bf16_wire:       # the wire image, written where the bucket completes: no conversion kernel around the collective
                 _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
-            _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
+            _lib.check((lib.immtsf_flag_set if self.captured else lib.immtsf_flag_bump)(flag, st), "flag_bump")
+            self._nflags = k + 1
             self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0]})
 
         def announce(bi):
@@ -949,7 +962,7 @@ class FlagStep(PhasedStep):
                                                   torch.cuda.current_stream().cuda_stream), "f32_to_bf16")
             self.prereduced.append(bi)
 
-        self.seed_buf, self.prereduced = None, []
+        self.seed_buf, self.prereduced, self._nflags = None, [], 0
 
         def seed_reduce_fn(stream, segs, produced, hook):
             # gather the seeds (+ the gradients of the bucket's parameters the chain does not produce: final by now) into one staging
@@ -976,8 +989,12 @@ class FlagStep(PhasedStep):
             srcs, stage = arr([p for p, _ in segs]), arr([base + 4 * x for x in offs])
             cnts = (C.c_int32 * k)(*[c for _, c in segs])
             _lib.check(lib.immtsf_copy_segments(k, srcs, stage, cnts, stream), "copy_segments")
-            _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
-            _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
+            if self.captured:
+                _lib.check(lib.immtsf_flag_set(W(self._SEED), stream), "flag_set")
+                _lib.check(lib.immtsf_flag_wait(W(self._SEED_DONE), F_ERR, self.comm_timeout_ms, stream), "flag_wait")
+            else:
+                _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
+                _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
             _lib.check(lib.immtsf_copy_segments(k, stage, srcs, cnts, stream), "copy_segments")
 
         def adam(buckets):
@@ -995,6 +1012,8 @@ class FlagStep(PhasedStep):
                 # ---- the previous replay's optimizer step: norm + decision, then the buckets on the branches that read them first
                 trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist,
                                      epoch=W(self._EPOCH))
+                if self.captured:
+                    self.Cs.wait_stream(T)            # the communication branch: forked here, filled in at the end of the capture
                 if adam_split is None:
                     adam(range(nb))
                     B.wait_stream(T)                  # fork (satisfied when B gets there: nothing runs on B before it)
@@ -1085,32 +1104,31 @@ class FlagStep(PhasedStep):
                     for lo, hi in _runs([trainer.ranges[b] for b in rest]):
                         announce_range(lo, hi, [b for b in rest if lo <= trainer.ranges[b][0] and trainer.ranges[b][1] <= hi])
                     announced.update(rest)
-                _lib.check(lib.immtsf_flags_clear_set(fp, 9, self._f_pending, sp(T)), "flags_clear_set")
+                nclear = 9
+                if self.captured:
+                    self._order_segments(merge_adjacent)
+                    with torch.cuda.stream(self.Cs):
+                        self._enqueue_collectives(self.Cs.cuda_stream, None)
+                        fset(W(self._C2), self.Cs)
+                    _lib.check(lib.immtsf_flag_wait(W(self._C2), F_ERR, self.comm_timeout_ms, sp(T)), "flag_wait")
+                    T.wait_stream(self.Cs)
+                    nclear = self._COUNT0 + self._nflags
+                _lib.check(lib.immtsf_flags_clear_set(fp, min(nclear, self._ERR), self._f_pending, sp(T)), "flags_clear_set")
         finally:
             config.sched_gate = config.sched_armed = None
-        # the communication stream's order: the text side's buckets but its last, the parameter branch's, the text side's last, the
-        # backbone's, the join's -- the order in which they complete at the benchmark configuration; the SAME on every rank
-        tseg = [g for g in self.segments if g["branch"] == "T"]
-        self.segments = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
-                         [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
-        if merge_adjacent:
-            merged = []
-            for g in self.segments:
-                if merged and merged[-1]["hi"] == g["lo"] and merged[-1]["branch"][-1] == g["branch"]:      # (same branch: final together)
-                    m = merged[-1]
-                    m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + [g["flag"]], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
-                else:
-                    merged.append(dict(g, flags=[g["flag"]]))
-            self.segments = merged
-        else:
-            self.segments = [dict(g, flags=[g["flag"]]) for g in self.segments]
+        if not self.captured:
+            self._order_segments(merge_adjacent)
         self.comm = None
-        if self.dist:
+        if self.dist and not self.captured:
             # a HIGH-PRIORITY stream of its own: HIP deals streams of one priority round-robin onto a handful of hardware queues, and a
             # communication stream that lands on the caller's queue runs its spins BEHIND the graph it is meant to run beside (seen
             # with the trainer's default-priority stream: every bucket's wait was entered 3 us after the step's last kernel, the five
             # collectives then cost 65 us in front of the next step); the other priority level has queues of its own
-            self.comm = torch.cuda.Stream(device=dev, priority=-1)
+            # (default priority.  A high-priority stream gets a hardware queue of its own -- the trainer's default-priority stream once
+            # landed on the caller's queue and ran every spin BEHIND the graph it was meant to run beside -- but a spin kernel on a
+            # high-priority queue was seen to slow the graph's text branch threefold (1.36 vs 0.53 ms per step, profiles/r05_dist_ab.txt):
+            # with an eager communication stream raise GPU_MAX_HW_QUEUES instead; bench.py sets 8)
+            self.comm = torch.cuda.Stream(device=dev, priority=int(os.environ.get("IMMTSF_COMM_PRIO", "0")))
         self._epoch = 0
         self.loss = loss
         self._keep = (outs, pred, py, cuts, dpy, dcuts)
@@ -1143,9 +1161,60 @@ class FlagStep(PhasedStep):
         self.flags[self._PENDING:self._PENDING + 1].zero_()
         self.trainer.flat_grad.zero_()
 
+    def _order_segments(self, merge_adjacent):
+        """the communication order: the text side's buckets but its last, the parameter branch's, the text side's last, the backbone's, the
+        join's -- the order in which they complete at the benchmark configuration; the SAME on every rank.  merge_adjacent: buckets
+        announced by the same branch that follow each other here and in the flat buffer go out as one collective."""
+        tseg = [g for g in self.segments if g["branch"] == "T"]
+        segs = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
+                [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
+        merged = []
+        for g in segs:
+            if merge_adjacent and merged and merged[-1]["hi"] == g["lo"] and merged[-1]["branch"][-1] == g["branch"]:
+                m = merged[-1]
+                m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + [g["flag"]], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
+            else:
+                merged.append(dict(g, flags=[g["flag"]]))
+        self.segments = merged
+
+    def _enqueue_collectives(self, cs, k):
+        """the step's collectives on the current stream (raw handle `cs`): the seeds, then every segment behind its buckets' flags, this
+        rank's guard word riding with the last one.  k: the replay number the counting flags are compared with (eager communication
+        stream); None: plain flags (the captured communication branch)."""
+        import torch.distributed as dist
+        t, lib = self.trainer, _lib.load()
+        n = t.flat_param.numel()
+        store = t._wire_store if self._from_wire else t._grad_store
+
+        def wait(flag, tmo):
+            if k is None:
+                _lib.check(lib.immtsf_flag_wait(flag, self._f_err, tmo, cs), "flag_wait")
+            else:
+                _lib.check(lib.immtsf_flag_wait_ge(flag, k, self._f_err, tmo, cs), "flag_wait_ge")
+
+        if self.seed_buf is not None:       # the seeds of a block's parameter chain: summed in fp32, handed back to the graph
+            wait(self._f_seed, self.timeout_ms)
+            dist.all_reduce(self.seed_buf, group=t.group)
+            _lib.check((lib.immtsf_flag_set if k is None else lib.immtsf_flag_bump)(self._f_seed_done, cs), "flag_bump")
+        last = len(self.segments) - 1
+        for i, g in enumerate(self.segments):
+            for f in g["flags"]:
+                wait(f, self.timeout_ms)
+            hi = g["hi"]
+            if i == last:
+                # this rank's guard word rides with the last collective: into the slot behind the payload when the last range
+                # ends there, else as eight elements of its own
+                _lib.check(lib.immtsf_guard_pack(self._f_err, store[n:].data_ptr(), 1 if self._from_wire else 0, cs), "guard_pack")
+                if hi == n:
+                    hi = n + 8
+            dist.all_reduce(store[g["lo"]:hi], group=t.group)
+            if i == last and hi != n + 8:
+                dist.all_reduce(store[n:n + 8], group=t.group)
+
     def _wait_comm(self, stream):
-        """`stream` waits (one spin kernel) for the collectives of the last replay"""
-        if self.dist and self._epoch > 0:
+        """`stream` waits (one spin kernel) for the collectives of the last replay (eager communication stream only: captured
+        collectives are part of the graph the stream is ordered behind anyway)"""
+        if self.dist and not self.captured and self._epoch > 0:
             _lib.check(_lib.load().immtsf_flag_wait_ge(self._f_comm, self._epoch & 0x7FFFFFFF, self._f_err, self.comm_timeout_ms,
                                                        stream.cuda_stream), "flag_wait_ge")
 
@@ -1164,35 +1233,11 @@ class FlagStep(PhasedStep):
         self._wait_comm(S)
         self.graph.replay()
         self._epoch += 1
-        if self.dist:
-            t, lib, k = self.trainer, _lib.load(), self._epoch & 0x7FFFFFFF
-            n = t.flat_param.numel()
-            store = t._wire_store if self._from_wire else t._grad_store
-            cs = self.comm.cuda_stream
-            import torch.distributed as dist
+        if self.dist and not self.captured:
             with torch.cuda.stream(self.comm):
-                if self.seed_buf is not None:       # the seeds of a block's parameter chain: summed in fp32, handed back to the graph
-                    _lib.check(lib.immtsf_flag_wait_ge(self._f_seed, k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
-                    dist.all_reduce(self.seed_buf, group=t.group)
-                    _lib.check(lib.immtsf_flag_bump(self._f_seed_done, cs), "flag_bump")
-                last = len(self.segments) - 1
-                for i, g in enumerate(self.segments):
-                    for f in g["flags"]:
-                        _lib.check(lib.immtsf_flag_wait_ge(f, k, self._f_err, self.timeout_ms, cs), "flag_wait_ge")
-                    hi = g["hi"]
-                    if i == last:
-                        # this rank's guard word rides with the last collective: into the slot behind the payload when the last range
-                        # ends there, else as eight elements of its own
-                        _lib.check(lib.immtsf_guard_pack(self._f_err, store[n:].data_ptr(), 1 if self._from_wire else 0, cs), "guard_pack")
-                        if hi == n:
-                            hi = n + 8
-                    dist.all_reduce(store[g["lo"]:hi], group=t.group)
-                    if i == last and hi != n + 8:
-                        dist.all_reduce(store[n:n + 8], group=t.group)
-                _lib.check(lib.immtsf_flag_bump(self._f_comm, cs), "flag_bump")
-            if self.check_every and self._epoch % self.check_every == 0:
-                self.check()
-        elif self.check_every and self._epoch % self.check_every == 0:
+                self._enqueue_collectives(self.comm.cuda_stream, self._epoch & 0x7FFFFFFF)
+                _lib.check(_lib.load().immtsf_flag_bump(self._f_comm, self.comm.cuda_stream), "flag_bump")
+        if self.check_every and self._epoch % self.check_every == 0:
             self.check()
         return self.loss
 

@@ -303,7 +303,8 @@ int immtsf_mmf_xrank_p_backward_params(const immtsf_fusion_cfg* cfg, const immts
 /* The P half when the text side's producer ends in a linear map whose only consumer is this projection (TTF_T2V_XAttn's proj_out,
  * fusions/TTF_T2V_XAttn.py:182, called with immtsf_fusion_cfg.form | IMMTSF_FORM_NO_PROJ so that it hands over Z = its LayerNorm +
  * dropout output): P = [Z | 1] [W_fold W_po | W_fold b_po + b_fold]^T -- the (B T) x d x d product, its data and weight gradients
- * become PW-row products, E_txt / dE_txt are never formed.  backward_data_z writes dZ (and dWc into `scratch`); backward_pre_z --
+ * become PW-row products, E_txt / dE_txt are never formed.  backward_data_z writes dZ (and dWc into `scratch`; cfg->bwd_phase
+ * IMMTSF_BWD_PHASE_A: only dZ, IMMTSF_BWD_WGRAD_A: only dWc / dbc -- parameter-gradient work for a stream of its own); backward_pre_z --
  * parameters only -- the producer's gradients (g_proj_w, g_proj_b) and dW_fold / db_fold for immtsf_mmf_xrank_p_backward_params. */
 int immtsf_mmf_xrank_fold_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b, float* bHO,
                             void* workspace, size_t workspace_bytes, immtsf_stream_t stream);      /* the parameter-only part, ahead of time */

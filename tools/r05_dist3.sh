@@ -1,0 +1,35 @@
+#!/bin/bash
+tag=${1:-f}
+out=gpurun_out/r05$tag
+mkdir -p $out
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+run() {  # name, kw json, extra env
+  name=$1; kw=$2; shift; shift
+  env IMMTSF_BENCH_FLAG_KW="$kw" "$@" timeout 300 python bench.py --steps 40 --warmup 10 --force-dist --no-extras --no-cpu-baseline --no-roofline > $out/fd_$name.json 2> $out/fd_$name.err
+  python - <<PY | tee -a $out/summary.txt
+import json
+try:
+    d=json.load(open("$out/fd_$name.json"))
+    print("$name", d["ms_per_step"], d["flag_step_rejected"], "host", d["host_enqueue_ms_per_step"], d["config"]["grad_allreduce"][90:230])
+except Exception as e:
+    print("$name failed", e)
+    print(open("$out/fd_$name.err").read()[-1500:])
+PY
+}
+timeout 300 python bench.py --steps 40 --warmup 10 --no-extras --no-cpu-baseline --no-roofline > $out/single.json 2> $out/single.err
+python -c "import json; d=json.load(open('$out/single.json')); print('single', d['ms_per_step'], d['host_enqueue_ms_per_step'])" | tee -a $out/summary.txt
+run captured '{}' X=1
+run captured_noseed '{"seed_reduce": false}' X=1
+run captured_nowgt '{"ttf_wgrad_tail": false}' X=1
+run eager '{"captured_comm": false}' X=1
+run eager_hwq4 '{"captured_comm": false}' GPU_MAX_HW_QUEUES=4
+DIST=1 timeout 300 python tools/flag_timeline.py 64 6 > $out/flag_timeline_64_dist.txt 2>&1
+tail -50 $out/flag_timeline_64_dist.txt | tee -a $out/summary.txt
+timeout 300 python tools/flag_timeline.py 64 6 > $out/flag_timeline_64.txt 2>&1
+tail -25 $out/flag_timeline_64.txt | tee -a $out/summary.txt
+for v in 2009 2016 2026; do
+timeout 300 python bench.py --steps 40 --warmup 10 --no-extras --no-cpu-baseline --no-roofline --gemm2-variant $v > $out/single_v$v.json 2> $out/single_v$v.err
+python -c "import json; d=json.load(open('$out/single_v$v.json')); print('single nn-dyn variant $v', d['ms_per_step'], d['host_enqueue_ms_per_step'])" | tee -a $out/summary.txt
+done
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -m gpu > $out/test_train.log 2>&1; echo "train tests rc=$?" | tee -a $out/summary.txt
+tail -3 $out/test_train.log | tee -a $out/summary.txt

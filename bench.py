@@ -15,9 +15,6 @@ windows per GPU).  Rank 0 prints ONE JSON line: metric/value, `roofline` (domina
 (the gather / mask path as GB/s against 8 TB/s), `sweep` (windows per GPU 64..4096), `ms_per_step_fp32` (the 1e-4
 parity mode), `dropin` (the zero-edit main.py seam: compute_all_losses + torch Adam, eager), `cpu_baseline`.
 """
-import os as _os
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # (read by the HIP runtime when it initialises: more hardware queues than the default 4, so
-#                                                      that the streams of a step -- graph branches, a communication stream -- do not share one)
 import argparse
 import ctypes
 import json

@@ -97,9 +97,14 @@ def _zeroed_grad_buffers(params, sinks):
     return bufs, rets
 
 
-def _fire(hook):
+def _fire(hook, burst=None):
+    """run a bucket hook (immtsf.train.FlatTrainer); burst: a token shared by hooks fired back to back -- buckets that complete at the
+    same moment -- which lets a data-parallel step send them as one collective"""
     if hook is not None:
-        hook()
+        if burst is not None and getattr(hook, "_immtsf_bucket_index", None) is not None:
+            hook(burst)
+        else:
+            hook()
 
 
 def _bytes(n, dev):
@@ -267,7 +272,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
 
         tail = config.param_tail
         split = (tail is not None and tail.get("ttf_flag") is not None and tail.get("defer", 0) > 0 and not ctx.folded and
-                 all(r is None for r in rets) and _bf16_dataflow(cfg.precision, cfg.d))
+                 all(r is None for r in rets))
         if split:
             # a step with a parameter-only branch (immtsf.train.FlagStep): this stream runs the data path and the LAST phase's weight
             # gradients; the weight gradients of phases A and B -- whose inputs exist long before the end -- leave as one grouped launch
@@ -282,8 +287,9 @@ class TTFT2VXAttnFn(torch.autograd.Function):
             def job(stream, keep=keep):
                 check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
                 call(_lib.BWD_WGRAD_A | _lib.BWD_WGRAD_B, stream)
+                burst = object()
                 for h in early:
-                    _fire(h)
+                    _fire(h, burst)
             tail["jobs"].append(job)
             for ph, h in hooks:
                 if ph == 2:

@@ -159,7 +159,7 @@ class FlatTrainer:
         if self.collective and dev.type == "cuda" and not self.sharded:
             for bi in self.sink_buckets:
                 head = self.buckets[bi][0]
-                hook = (lambda i=bi: self._on_bucket_done(i))
+                hook = (lambda burst=None, i=bi: self._on_bucket_done(i, burst))
                 hook._immtsf_bucket_index = bi
                 head._immtsf_bwd_hook = hook
 
@@ -246,13 +246,13 @@ class FlatTrainer:
         self._collected = False
         self._collect_autograd_grads()
 
-    def _on_bucket_done(self, bi: int):
+    def _on_bucket_done(self, bi: int, burst=None):
         """backward hook of a sink bucket: start its all-reduce now -- only while overlapping is on.  (A caller that turns
         `overlap` off after construction, e.g. GraphedStep without captured collectives, must not get collectives issued
         from inside the backward: under graph capture they would be captured AND repeated eagerly afterwards.)"""
         cap = getattr(self, "_capture_hook", None)
         if cap is not None:          # FlagStep's capture of the data-parallel step: announce the bucket by a device flag instead
-            cap(bi)
+            cap(bi, burst)
             return
         if self.overlap:
             self._bucket_ready(bi)
@@ -857,8 +857,8 @@ class FlagStep(PhasedStep):
         stream with counting flags is what the two-rank tests on one GPU run).
         seed_reduce (data parallel): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's low-rank
         form: ops.MMFXRankPFn) has the SEEDS all-reduced in front of its parameter chain instead of the gradients behind it.
-        merge_adjacent (data parallel): buckets announced by the same branch that follow each other on the communication stream and in
-        the flat buffer go out as one collective.
+        merge_adjacent (data parallel): buckets announced in one burst (they complete at the same moment) that are neighbours in the flat
+        buffer go out as one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
         backward ends) leave the text side's dependent chain for the parameter branch, behind MMF_XAttn_Add's chain
         (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks)."""
@@ -929,7 +929,7 @@ class FlagStep(PhasedStep):
         announced = set()
         branch_now = ["T"]
 
-        def announce_range(lo, hi, buckets):
+        def announce_range(lo, hi, buckets, burst=None):
             if hi == lo:
                 return
             k = len(self.segments)
@@ -941,13 +941,13 @@ class FlagStep(PhasedStep):
                 _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
             _lib.check((lib.immtsf_flag_set if self.captured else lib.immtsf_flag_bump)(flag, st), "flag_bump")
             self._nflags = k + 1
-            self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0]})
+            self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0], "burst": burst})
 
-        def announce(bi):
+        def announce(bi, burst=None):
             if bi in announced:
                 return
             announced.add(bi)
-            announce_range(*trainer.ranges[bi], (bi,))
+            announce_range(*trainer.ranges[bi], (bi,), burst)
 
         def prereduced(hook):
             # a bucket whose gradients already ARE the sum over the ranks (its chain ran on all-reduced seeds): only the wire image
@@ -1164,17 +1164,22 @@ class FlagStep(PhasedStep):
     def _order_segments(self, merge_adjacent):
         """the communication order: the text side's buckets but its last, the parameter branch's, the text side's last, the backbone's, the
         join's -- the order in which they complete at the benchmark configuration; the SAME on every rank.  merge_adjacent: buckets
-        announced by the same branch that follow each other here and in the flat buffer go out as one collective."""
+        announced in one burst (hooks fired back to back: they complete at the same moment) that are neighbours in the flat buffer go out
+        as one collective."""
         tseg = [g for g in self.segments if g["branch"] == "T"]
         segs = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
                 [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
         merged = []
         for g in segs:
-            if merge_adjacent and merged and merged[-1]["hi"] == g["lo"] and merged[-1]["branch"][-1] == g["branch"]:
-                m = merged[-1]
-                m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + [g["flag"]], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
+            g = dict(g, flags=[g["flag"]])
+            m = next((x for x in merged if merge_adjacent and g["burst"] is not None and x["burst"] is g["burst"] and
+                      (x["hi"] == g["lo"] or g["hi"] == x["lo"])), None)
+            if m is None:
+                merged.append(g)
+            elif m["hi"] == g["lo"]:
+                m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + g["flags"], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
             else:
-                merged.append(dict(g, flags=[g["flag"]]))
+                m["lo"], m["flags"], m["buckets"], m["branch"] = g["lo"], g["flags"] + m["flags"], g["buckets"] + m["buckets"], g["branch"] + m["branch"]
         self.segments = merged
 
     def _enqueue_collectives(self, cs, k):

@@ -342,6 +342,15 @@ def _two_rank_flag_worker(rank, world, port, q, wire, layout="phases", inject=Fa
     not the transport.  layout "phases": bench.py's buckets (FusionModel.grad_buckets: MMF, TTF's three backward phases, the backbone;
     Adam split over the branches); "blocks": one bucket per block, everything on the text branch.  inject: after two good steps rank 1
     waits for a flag nobody sets -- BOTH ranks must drop that step."""
+    try:
+        _two_rank_flag_body(rank, world, port, q, wire, layout, inject)
+    except BaseException:       # noqa: BLE001 -- the parent must not sit out its queue time-out when a rank dies
+        import traceback
+        q.put(("error", rank, traceback.format_exc()))
+        raise
+
+
+def _two_rank_flag_body(rank, world, port, q, wire, layout, inject):
     import torch.distributed as dist
     sys.path.insert(0, os.path.join(ROOT, "imm-tsf_amd"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -441,7 +450,9 @@ def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
     0.05).  SURVEY 8e."""
     dev = _dev()
     q, procs = _spawn2(_two_rank_flag_worker, (wire, layout))
-    got, nseg, branches = q.get(timeout=300)
+    res = q.get(timeout=300)
+    assert not (isinstance(res[0], str) and res[0] == "error"), res[-1]
+    got, nseg, branches = res
     got = torch.from_numpy(got)
     for p in procs:
         p.join(timeout=120)
@@ -449,7 +460,7 @@ def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
     if layout == "phases":
         # MMF's gradients never cross the wire (its chain runs on all-reduced seeds); TTF's first two phases leave the parameter branch
         # as one collective, its last phase the text side, the backbone its own branch: the communication stream's order
-        assert branches == ["PP", "T", "B"], branches
+        assert branches == ["PP", "T", "B"], branches       # (a burst's members in buffer order: ttf_a, ttf_b)
     model, fusion, tr, batch = _setup_sinks(dev, 0.0)
     tr.max_norm = 0.05
     f = _loss_fn(model, fusion, batch)
@@ -472,6 +483,7 @@ def test_two_rank_flag_step_drops_a_timed_out_step_on_every_rank():
     res = {}
     for _ in range(2):
         r = q.get(timeout=300)
+        assert r[0] != "error", r[-1]
         res[r[0]] = r[1:]
     for p in procs:
         p.join(timeout=120)

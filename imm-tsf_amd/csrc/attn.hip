@@ -594,127 +594,6 @@ __global__ __launch_bounds__(256) void ragged_attn_bwd_ds_kernel(RaggedAttnDims 
     else dqs_part[(size_t)b * d + h * hd + c] = a;
 }
 
-// Backward of a SHORT window as ONE kernel (round 5): workgroup (b, h), 256 threads, CPT head columns per thread (hd <= 256 CPT);
-// n <= 64 notes, T <= 32 steps.  What parts 1 and 2 above do in two launches with a dp round trip through HBM -- 22 + 15 us on the
-// text side's dependent backward chain at the benchmark shape, where part 1 regenerated every dropout scale once per 64-column slice
-// (12 times) -- with the window's dropout scales generated ONCE into LDS, dp summed over the workgroup's waves in LDS, and the
-// softmax backward + dk / dqs_part in the same pass:
-//   g[i,c] = sum_t m[t,i] dctx[t,c];  dv[i,c] = p[i] g[i,c];  dp[i] = sum_c g[i,c] v[i,c]
-//   ds[i] = p[i] (dp[i] - sum_j p[j] dp[j]);  dk[i,c] = ds[i] qs[c];  dqs_part[b,h,c] = sum_i ds[i] k[i,c]
-constexpr int RO_N = 64, RO_T = 32;
-template <typename KT, int CPT>
-__global__ __launch_bounds__(256) void ragged_attn_bwd_one_kernel(RaggedAttnDims dm, const int* __restrict__ offsets,
-                                                                   const int* __restrict__ rowmap, const KT* __restrict__ KVp,
-                                                                   const float* __restrict__ qs, const float* __restrict__ P,
-                                                                   const float* __restrict__ dctx, float* __restrict__ dKVp,
-                                                                   float* __restrict__ dqs_part, DropCfg drop, uint64_t site,
-                                                                   bf16_t* __restrict__ dKVp_h) {
-    __shared__ float mt[RO_N * RO_T];          // dropout scales, note-major
-    __shared__ float dpw[4][RO_N], pb[RO_N], dsb[RO_N], red[16];
-    const int b = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hd = dm.hd, d = dm.H * hd, ld = 2 * d, T = dm.T;
-    const int ob = offsets[b], n = offsets[b + 1] - ob;
-    if (n == 0) {
-#pragma unroll
-        for (int k = 0; k < CPT; ++k)
-            if (k * 256 + tid < hd) dqs_part[(size_t)b * d + h * hd + k * 256 + tid] = 0.f;
-        return;
-    }
-    const bool dropping = drop.p > 0.f;
-    if (dropping) {
-        const int n4 = (n + 3) >> 2;
-        for (int x = tid; x < n * (RO_T - T); x += 256) {      // zero padding t in [T, 32)
-            const int i = x / (RO_T - T), t = T + (x - i * (RO_T - T));
-            mt[i * RO_T + t] = 0.f;
-        }
-        for (int x = tid; x < T * n4; x += 256) {
-            const int t = x / n4, i = (x - t * n4) * 4;
-            const int r0 = rowmap[ob + i] - b * dm.N;
-            const uint64_t base = ((uint64_t)(b * T + t) * dm.H + h) * dm.N;
-            float sc4[4];
-            const bool run = i + 3 < n && (((base + r0) & 3) == 0) && rowmap[ob + i + 3] - b * dm.N == r0 + 3;
-            if (run) {
-                dropout_scale4(drop, site, base + r0, sc4);
-            } else {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    sc4[u] = i + u < n ? dropout_scale(drop, site, base + (uint64_t)(rowmap[ob + i + u] - b * dm.N)) : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i + u < n) mt[(i + u) * RO_T + t] = sc4[u];
-        }
-    }
-    if (tid < n) pb[tid] = P[(size_t)(ob + tid) * dm.H + h];
-    // the upstream gradient columns: the same for every note of the window, kept in registers
-    float dcv[CPT][RO_T], gsum[CPT];
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = k * 256 + tid;
-        const float* dc = dctx + (size_t)b * T * d + h * hd + c;
-        gsum[k] = 0.f;
-#pragma unroll
-        for (int t = 0; t < RO_T; ++t) {
-            dcv[k][t] = (c < hd && t < T) ? dc[(size_t)t * d] : 0.f;
-            gsum[k] += dcv[k][t];
-        }
-    }
-    __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        float a = 0.f;
-        const float p = pb[i];
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int c = k * 256 + tid;
-            float g = gsum[k];
-            if (dropping) {
-                g = 0.f;
-                const float4* m4 = reinterpret_cast<const float4*>(mt + i * RO_T);
-#pragma unroll
-                for (int t4 = 0; t4 < RO_T / 4; ++t4) {
-                    const float4 m = m4[t4];
-                    g = fmaf(m.x, dcv[k][4 * t4], fmaf(m.y, dcv[k][4 * t4 + 1], fmaf(m.z, dcv[k][4 * t4 + 2], fmaf(m.w, dcv[k][4 * t4 + 3], g))));
-                }
-            }
-            if (c < hd) {
-                const size_t off = (size_t)(ob + i) * ld + d + h * hd + c;
-                a = fmaf(g, (float)KVp[off], a);
-                const float dvv = p * g;
-                if (dKVp) dKVp[off] = dvv;
-                if (dKVp_h) dKVp_h[off] = (bf16_t)dvv;
-            }
-        }
-        a = wave_sum(a);
-        if (lane == 0) dpw[wave][i] = a;
-    }
-    __syncthreads();
-    float part = 0.f, dpv = 0.f;
-    if (tid < n) {
-        dpv = dpw[0][tid] + dpw[1][tid] + dpw[2][tid] + dpw[3][tid];
-        part = pb[tid] * dpv;
-    }
-    const float dot = block_sum(part, red);
-    if (tid < n) dsb[tid] = pb[tid] * (dpv - dot);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const int c = k * 256 + tid;
-        if (c >= hd) continue;
-        const float q = qs[h * hd + c];
-        const size_t k0 = (size_t)ob * ld + h * hd + c;
-        float a = 0.f;
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
-            const float dsi = dsb[i];
-            a = fmaf(dsi, (float)KVp[k0 + (size_t)i * ld], a);
-            const float dkv = dsi * q;
-            if (dKVp) dKVp[k0 + (size_t)i * ld] = dkv;
-            if (dKVp_h) dKVp_h[k0 + (size_t)i * ld] = (bf16_t)dkv;
-        }
-        dqs_part[(size_t)b * d + h * hd + c] = a;
-    }
-}
-
 // ---- dense attention rows: one wave per (b,h,l) row of length S ---------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(float* __restrict__ sc, float* __restrict__ A, int rows, int HL,
                                                                 int S, const unsigned char* __restrict__ live, DropCfg drop,
@@ -1534,25 +1413,12 @@ static int ragged_attn_fwd_impl(RaggedAttnDims dm, const int* offsets, const int
     return IMMTSF_OK;
 }
 
-int g_attn_bwd_one = 1;       // tool switch (immtsf_debug_gemm_config bit 27 clears it): the two-kernel backward for short windows too
 template <typename KT>
 static int ragged_attn_bwd_impl(RaggedAttnDims dm, const int* offsets, const int* rowmap, const KT* KVp, const float* qs,
                                 const float* P, const float* dctx, float* dKVp, float* dqs_part, float* dp_buf, DropCfg drop,
                                 uint64_t site, hipStream_t s, void* dKVp_h) {
     if (dm.B <= 0) return IMMTSF_OK;
     if (drop.p > 0.f && dm.T > MT * 64) return IMMTSF_EUNSUPPORTED;
-    if (g_attn_bwd_one && dm.N <= RO_N && dm.T <= RO_T && dm.hd <= 768) {       // short windows: the whole backward of a window in one kernel
-        const dim3 grid(dm.B, dm.H);
-        bf16_t* dh = static_cast<bf16_t*>(dKVp_h);
-        if (dm.hd <= 256)
-            hipLaunchKernelGGL((ragged_attn_bwd_one_kernel<KT, 1>), grid, dim3(256), 0, s, dm, offsets, rowmap, KVp, qs, P, dctx, dKVp, dqs_part, drop, site, dh);
-        else if (dm.hd <= 512)
-            hipLaunchKernelGGL((ragged_attn_bwd_one_kernel<KT, 2>), grid, dim3(256), 0, s, dm, offsets, rowmap, KVp, qs, P, dctx, dKVp, dqs_part, drop, site, dh);
-        else
-            hipLaunchKernelGGL((ragged_attn_bwd_one_kernel<KT, 3>), grid, dim3(256), 0, s, dm, offsets, rowmap, KVp, qs, P, dctx, dKVp, dqs_part, drop, site, dh);
-        IMMTSF_LAUNCH_CHECK();
-        return IMMTSF_OK;
-    }
     const int maxch = dm.N > RAGGED_SPLIT_N ? cdiv(dm.N, RAGGED_CH) : 1;
     const size_t lds = (size_t)((maxch > 1 ? RAGGED_CH : dm.N) + 16) * sizeof(float);
     if (lds > 160 * 1024) return IMMTSF_EUNSUPPORTED;

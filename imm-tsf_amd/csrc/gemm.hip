@@ -701,7 +701,6 @@ void immtsf_gemm_note_grid(long threads) { g_last_grid_threads = threads; }
 
 extern int g_immtsf_ttcn_fused;      // ttcn.hip
 extern int g_immtsf_ttcn_bwd_grid;   // ttcn_full.hip
-extern int g_attn_bwd_one;           // attn.hip
 
 extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_immtsf_ttcn_fused = (variant & 0x8000) ? 0 : 1;   // bit 15: TTCN on the streaming formulation (A/B measurements)
@@ -712,7 +711,6 @@ extern "C" int immtsf_debug_gemm_config(int variant, int splitk) {
     g_xcd2d = (variant & 0x4000) ? 1 : 0;    // bit 14: allow the 2-D XCD order (measured slower at the fusion shapes: off)
     g_force_old = (variant & 0x10000) ? 1 : 0;
     g_immtsf_ttcn_bwd_grid = (variant >> 17) & 1023;      // bits 17..26: persistent workgroups of the on-chip TTCN backward (0 = rule)
-    g_attn_bwd_one = (variant & (1 << 27)) ? 0 : 1;       // bit 27: the short-window ragged attention backward as two kernels (A/B measurements)
     g_splitk = splitk;
     return 0;
 }

@@ -480,10 +480,8 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 static int g2_group_tile = 0;       // tile edge of the grouped weight-gradient launch: 0 = by tile count, 64 | 128 forced (tool switch: variant 1064 / 1128 / 1000)
-static int g2_nn_dyn = 0;           // tool switch (variant 2000 + v): tile variant of the NN launches whose row count is a device value
 extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
     if (variant == 1000 || variant == 1064 || variant == 1128) { g2_group_tile = variant - 1000; return 0; }
-    if (variant >= 2000 && variant < 2100) { g2_nn_dyn = variant - 2000; return 0; }
     g2_variant = variant;
     g2_splitk = splitk;
     g2_xcd = xcd;
@@ -596,8 +594,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         const long n96 = (long)cdiv(Meff, 64) * cdiv(g.N, 96) * g.nprob;
         const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
         const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
-        if (g2_nn_dyn && layout == GEMM_NN && g.dyn && g.dyn_which == 0) v = g2_nn_dyn;
-        else if (long_k) v = 18;                                  // 128x128 k2 with the reduction split over workgroups
+        if (long_k) v = 18;                                       // 128x128 k2 with the reduction split over workgroups
         else if (t128 >= 1024 && layout == GEMM_NT && g.N >= 1024) v = 13;     // 256x256, 8 waves, 2 stages (short-K, N = 768 and NN: 256x128 wins,
                                                                                 // tools/gemm2_bench.py bigm)
         else if (t128 >= 512) v = 7;                              // 256x128

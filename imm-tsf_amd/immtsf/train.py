@@ -835,28 +835,24 @@ class FlagStep(PhasedStep):
 
     # flag words (int32 offsets into self.flags)
     _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _TTF = range(9)        # hand-over flags: cleared at the end of every replay
-    _C2, _SEED, _SEED_DONE = 9, 10, 11      # communication branch done; seeds gathered / summed (captured collectives: plain flags, cleared
-    #                                         with the others; eager collectives: counting flags, never cleared)
-    _COUNT0 = 16                            # one flag per announced bucket (plain / counting likewise)
+    _SEED, _SEED_DONE = 10, 11              # seeds gathered / summed (counting flags: never cleared)
+    _COUNT0 = 16                            # one counting flag per announced bucket
     _ERR, _PENDING, _SKIP, _COMM_DONE, _EPOCH = 40, 41, 42, 43, 44      # guard word, gradient pending, step decision, collectives done, replay number
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = True, merge_adjacent: bool = True,
-                 captured_comm: Optional[bool] = None):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = False, merge_adjacent: bool = True):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
         backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
         announced on B instead of waiting for the join.
-        captured_comm (data parallel): the collectives are CAPTURED into the step's graph, on a fourth branch that spins on the buckets'
-        flags -- one graph launch per step and nothing else: no eager launches (a c10d all-reduce costs the host 30 - 50 us, five of them
-        made the 0.46 ms step host-bound), no communication stream whose hardware queue may be shared with, or -- at high priority -- starve,
-        the graph's branches.  None: on for the nccl (RCCL) backend, off otherwise (gloo cannot be captured: the eager communication
-        stream with counting flags is what the two-rank tests on one GPU run).
-        seed_reduce (data parallel): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's low-rank
-        form: ops.MMFXRankPFn) has the SEEDS all-reduced in front of its parameter chain instead of the gradients behind it.
+        seed_reduce (data parallel, opt-in): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's
+        low-rank form: ops.MMFXRankPFn) has the SEEDS all-reduced (75 KB, fp32) in front of its parameter chain instead of the gradients
+        (8.3 MB) behind it -- half the step's wire bytes.  The price: the parameter branch then WAITS, inside the graph, for the
+        communication stream's collective, so the graph no longer runs to its end on its own: a communication stream that shares a
+        hardware queue with a spinning branch cannot be ridden out, only timed out (comm_timeout_ms).  Off by default for that reason.
         merge_adjacent (data parallel): buckets announced in one burst (they complete at the same moment) that are neighbours in the flat
         buffer go out as one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
@@ -872,10 +868,6 @@ class FlagStep(PhasedStep):
         lib = _lib.load()
         self.dist = bool(trainer.collective)
         self.timeout_ms, self.comm_timeout_ms, self.check_every = int(timeout_ms), int(comm_timeout_ms), int(check_every)
-        if captured_comm is None and self.dist:
-            import torch.distributed as dist
-            captured_comm = dist.get_backend(trainer.group) == "nccl"
-        self.captured = bool(captured_comm and self.dist)
         self.T, self.B = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
         # parameter-only work (MMF_XAttn_Add's fold in front, its parameter-gradient chain behind) on a THIRD branch of the graph
         self.P = torch.cuda.Stream(device=dev) if param_branch else self.B
@@ -906,7 +898,6 @@ class FlagStep(PhasedStep):
         trainer.restore(snap)
         trainer.flat_grad.zero_()
         torch.cuda.synchronize()
-        self.Cs = torch.cuda.Stream(device=dev) if self.captured else None      # the communication branch of the graph
         self.flags = torch.zeros(48, dtype=torch.int32, device=dev)
         fp = self.flags.data_ptr()
         W = lambda i: fp + 4 * i        # noqa: E731
@@ -939,7 +930,7 @@ class FlagStep(PhasedStep):
             st = torch.cuda.current_stream().cuda_stream
             if bf16_wire:       # the wire image, written where the bucket completes: no conversion kernel around the collective
                 _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
-            _lib.check((lib.immtsf_flag_set if self.captured else lib.immtsf_flag_bump)(flag, st), "flag_bump")
+            _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
             self._nflags = k + 1
             self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0], "burst": burst})
 
@@ -989,12 +980,8 @@ class FlagStep(PhasedStep):
             srcs, stage = arr([p for p, _ in segs]), arr([base + 4 * x for x in offs])
             cnts = (C.c_int32 * k)(*[c for _, c in segs])
             _lib.check(lib.immtsf_copy_segments(k, srcs, stage, cnts, stream), "copy_segments")
-            if self.captured:
-                _lib.check(lib.immtsf_flag_set(W(self._SEED), stream), "flag_set")
-                _lib.check(lib.immtsf_flag_wait(W(self._SEED_DONE), F_ERR, self.comm_timeout_ms, stream), "flag_wait")
-            else:
-                _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
-                _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
+            _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
+            _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
             _lib.check(lib.immtsf_copy_segments(k, stage, srcs, cnts, stream), "copy_segments")
 
         def adam(buckets):
@@ -1012,8 +999,6 @@ class FlagStep(PhasedStep):
                 # ---- the previous replay's optimizer step: norm + decision, then the buckets on the branches that read them first
                 trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist,
                                      epoch=W(self._EPOCH))
-                if self.captured:
-                    self.Cs.wait_stream(T)            # the communication branch: forked here, filled in at the end of the capture
                 if adam_split is None:
                     adam(range(nb))
                     B.wait_stream(T)                  # fork (satisfied when B gets there: nothing runs on B before it)
@@ -1095,7 +1080,8 @@ class FlagStep(PhasedStep):
                 fwait(F_B2, T)
                 T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
                 if P is not B:
-                    fwait(F_P2, T)
+                    # (a parameter branch that waited for a collective -- seed_reduce -- may be as late as the slowest peer)
+                    _lib.check(lib.immtsf_flag_wait(F_P2, F_ERR, self.comm_timeout_ms if self.seed_buf is not None else tmo, sp(T)), "flag_wait")
                     T.wait_stream(P)
                 if self.dist:
                     # what nobody announced is complete now: contiguous runs of the remaining buckets, announced behind the join
@@ -1104,20 +1090,10 @@ class FlagStep(PhasedStep):
                     for lo, hi in _runs([trainer.ranges[b] for b in rest]):
                         announce_range(lo, hi, [b for b in rest if lo <= trainer.ranges[b][0] and trainer.ranges[b][1] <= hi])
                     announced.update(rest)
-                nclear = 9
-                if self.captured:
-                    self._order_segments(merge_adjacent)
-                    with torch.cuda.stream(self.Cs):
-                        self._enqueue_collectives(self.Cs.cuda_stream, None)
-                        fset(W(self._C2), self.Cs)
-                    _lib.check(lib.immtsf_flag_wait(W(self._C2), F_ERR, self.comm_timeout_ms, sp(T)), "flag_wait")
-                    T.wait_stream(self.Cs)
-                    nclear = self._COUNT0 + self._nflags
-                _lib.check(lib.immtsf_flags_clear_set(fp, min(nclear, self._ERR), self._f_pending, sp(T)), "flags_clear_set")
+                _lib.check(lib.immtsf_flags_clear_set(fp, 9, self._f_pending, sp(T)), "flags_clear_set")
         finally:
             config.sched_gate = config.sched_armed = None
-        if not self.captured:
-            self._order_segments(merge_adjacent)
+        self._order_segments(merge_adjacent)
         self.comm = None
         if self.dist and not self.captured:
             # a HIGH-PRIORITY stream of its own: HIP deals streams of one priority round-robin onto a handful of hardware queues, and a
@@ -1184,23 +1160,19 @@ class FlagStep(PhasedStep):
 
     def _enqueue_collectives(self, cs, k):
         """the step's collectives on the current stream (raw handle `cs`): the seeds, then every segment behind its buckets' flags, this
-        rank's guard word riding with the last one.  k: the replay number the counting flags are compared with (eager communication
-        stream); None: plain flags (the captured communication branch)."""
+        rank's guard word riding with the last one.  k: the replay number the counting flags are compared with."""
         import torch.distributed as dist
         t, lib = self.trainer, _lib.load()
         n = t.flat_param.numel()
         store = t._wire_store if self._from_wire else t._grad_store
 
         def wait(flag, tmo):
-            if k is None:
-                _lib.check(lib.immtsf_flag_wait(flag, self._f_err, tmo, cs), "flag_wait")
-            else:
-                _lib.check(lib.immtsf_flag_wait_ge(flag, k, self._f_err, tmo, cs), "flag_wait_ge")
+            _lib.check(lib.immtsf_flag_wait_ge(flag, k, self._f_err, tmo, cs), "flag_wait_ge")
 
         if self.seed_buf is not None:       # the seeds of a block's parameter chain: summed in fp32, handed back to the graph
             wait(self._f_seed, self.timeout_ms)
             dist.all_reduce(self.seed_buf, group=t.group)
-            _lib.check((lib.immtsf_flag_set if k is None else lib.immtsf_flag_bump)(self._f_seed_done, cs), "flag_bump")
+            _lib.check(lib.immtsf_flag_bump(self._f_seed_done, cs), "flag_bump")
         last = len(self.segments) - 1
         for i, g in enumerate(self.segments):
             for f in g["flags"]:
@@ -1217,9 +1189,8 @@ class FlagStep(PhasedStep):
                 dist.all_reduce(store[n:n + 8], group=t.group)
 
     def _wait_comm(self, stream):
-        """`stream` waits (one spin kernel) for the collectives of the last replay (eager communication stream only: captured
-        collectives are part of the graph the stream is ordered behind anyway)"""
-        if self.dist and not self.captured and self._epoch > 0:
+        """`stream` waits (one spin kernel) for the collectives of the last replay"""
+        if self.dist and self._epoch > 0:
             _lib.check(_lib.load().immtsf_flag_wait_ge(self._f_comm, self._epoch & 0x7FFFFFFF, self._f_err, self.comm_timeout_ms,
                                                        stream.cuda_stream), "flag_wait_ge")
 
@@ -1238,7 +1209,7 @@ class FlagStep(PhasedStep):
         self._wait_comm(S)
         self.graph.replay()
         self._epoch += 1
-        if self.dist and not self.captured:
+        if self.dist:
             with torch.cuda.stream(self.comm):
                 self._enqueue_collectives(self.comm.cuda_stream, self._epoch & 0x7FFFFFFF)
                 _lib.check(_lib.load().immtsf_flag_bump(self._f_comm, self.comm.cuda_stream), "flag_bump")

@@ -1095,15 +1095,13 @@ class FlagStep(PhasedStep):
             config.sched_gate = config.sched_armed = None
         self._order_segments(merge_adjacent)
         self.comm = None
-        if self.dist and not self.captured:
-            # a HIGH-PRIORITY stream of its own: HIP deals streams of one priority round-robin onto a handful of hardware queues, and a
-            # communication stream that lands on the caller's queue runs its spins BEHIND the graph it is meant to run beside (seen
-            # with the trainer's default-priority stream: every bucket's wait was entered 3 us after the step's last kernel, the five
-            # collectives then cost 65 us in front of the next step); the other priority level has queues of its own
-            # (default priority.  A high-priority stream gets a hardware queue of its own -- the trainer's default-priority stream once
-            # landed on the caller's queue and ran every spin BEHIND the graph it was meant to run beside -- but a spin kernel on a
-            # high-priority queue was seen to slow the graph's text branch threefold (1.36 vs 0.53 ms per step, profiles/r05_dist_ab.txt):
-            # with an eager communication stream raise GPU_MAX_HW_QUEUES instead; bench.py sets 8)
+        if self.dist:
+            # A stream of its own at DEFAULT priority.  HIP deals the streams of one priority round-robin onto a handful of hardware
+            # queues, so this stream may share one with a branch of the graph and then run its spins behind that branch instead of
+            # beside it (seen once: every bucket's wait entered 3 us after the step's last kernel, the collectives exposed in front of
+            # the next step) -- slower, never wrong: the graph does not wait for this stream.  A HIGH-priority stream gets queues of
+            # its own, but a spin kernel on a high-priority queue slowed the graph's text branch THREEFOLD (1.36 vs 0.51 ms per step:
+            # profiles/r05_dist_ab.txt), so that is not the default.
             self.comm = torch.cuda.Stream(device=dev, priority=int(os.environ.get("IMMTSF_COMM_PRIO", "0")))
         self._epoch = 0
         self.loss = loss

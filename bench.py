@@ -339,13 +339,18 @@ class Workload:
             m = self.model
             excl = [m.te_scale.weight, m.te_scale.bias, m.te_periodic.weight, m.te_periodic.bias]
         backbone_params = [p for p in self.model.parameters() if p.requires_grad]
-        # buckets = the groups whose gradients complete together, in the flat buffers' order: MMF (+ the proj_out it folds), TTF's three
-        # backward phases, the backbone LAST (a data-parallel FlagStep appends the ranks' guard word to the last range)
-        fb, self.bucket_names = self.fusion.grad_buckets(c["T"])
-        self.bucket_names = list(self.bucket_names) + ["backbone"]
-        nf = len(fb)
-        sinks = tuple(range(nf + 1)) if c["backbone"] == "tPatchGNN" else tuple(range(nf))
-        self.trainer = FlatTrainer(fb + [backbone_params],
+        # buckets = the groups whose gradients complete together.  Order in the flat buffers: MMF (+ the proj_out it folds), the
+        # backbone, then TTF's backward phases with the LAST-completing ones at the end (C, then A and B, whose weight gradients FlagStep
+        # moves to the parameter branch behind MMF's chain): a data-parallel FlagStep appends the ranks' guard word to the last range
+        fb, fnames = self.fusion.grad_buckets(c["T"])
+        ttf = [i for i, n in enumerate(fnames) if n.startswith("ttf")]
+        ttf = [i for i in ttf if fnames[i] == "ttf_c"] + [i for i in ttf if fnames[i] != "ttf_c"]
+        order = [i for i, n in enumerate(fnames) if not n.startswith("ttf")]
+        buckets = [fb[i] for i in order] + [backbone_params] + [fb[i] for i in ttf]
+        self.bucket_names = [fnames[i] for i in order] + ["backbone"] + [fnames[i] for i in ttf]
+        bb = self.bucket_names.index("backbone")
+        sinks = tuple(i for i in range(len(buckets)) if i != bb or c["backbone"] == "tPatchGNN")
+        self.trainer = FlatTrainer(buckets,
                                    lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl,
                                    overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
@@ -456,6 +461,8 @@ def flag_step(w):
     snap = w.trainer.snapshot()
     for _ in range(3):
         st()
+    if st.dist:
+        st.calibrate_comm_order(3)  # (three more trial replays, traced: the collectives in the order in which the buckets really complete)
     torch.cuda.synchronize()
     try:
         st.check()                 # (a collective when the trainer has a process group: every rank takes the same branch)
@@ -974,7 +981,8 @@ def main():
             launch_mode += "; N > 1: the same single graph (clip + Adam of step k at the head of replay k + 1 read the reduced wire image)"
             comm_mode = (f"bucketed, beside the backward: {len(step.segments)} bucket(s) on a communication stream behind counting device "
                          "flags [" + ", ".join("+".join(w.bucket_names[b] for b in g["buckets"]) + f"@{g['branch']}:{(g['hi'] - g['lo']) * (2 if wire == 'bf16' else 4) / 1e6:.2f}MB"
-                                               for g in step.segments) + "], the ranks' guard word summed by the last one")
+                                               for g in step.segments) + "], the ranks' guard word summed by the last one" +
+                         (f"; order = measured completion (us after the step's start: {step.completion_us})" if getattr(step, "completion_us", None) else ""))
         elif eng == "graphed+captured-comm":
             comm_mode = "captured, bucketed"
         elif eng == "eager":

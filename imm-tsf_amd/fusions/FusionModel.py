@@ -3,7 +3,7 @@
 Same registry, constructor (reads the same `args.*` attributes) and forward signature as the reference
 (fusions/FusionModel.py:14-113); `args.TTF_module` / `args.MMF_module` may be a registry string or a class.
 The NaN guards of the reference (three `torch.isnan(x).any()` host syncs per step, :103-112) are honoured
-according to `immtsf.config.nan_check`: "sync" (default, reference behaviour), "deferred" (no sync; call
+according to `immtsf.config.nan_check`: "sync" (reference behaviour), "deferred" (the default: no sync; lib.evaluation raises at the next call, or call
 `check_nan()`), or "off".
 """
 import torch

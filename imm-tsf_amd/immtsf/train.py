@@ -1156,6 +1156,45 @@ class FlagStep(PhasedStep):
                 m["lo"], m["flags"], m["buckets"], m["branch"] = g["lo"], g["flags"] + m["flags"], g["buckets"] + m["buckets"], g["branch"] + m["branch"]
         self.segments = merged
 
+    def calibrate_comm_order(self, replays: int = 3):
+        """order the communication stream's collectives by when their buckets ACTUALLY complete: `replays` replays under the flag
+        kernels' own trace (immtsf_flag_trace: device wall clock, nothing serialised), the completion time of every segment (its last
+        flag, relative to the previous step's clear) averaged over the replays and -- so that every rank ends up with the SAME order --
+        over the ranks.  The static order of _order_segments is a guess from the program's structure; a collective that waits for a
+        late bucket while earlier-finished ones queue behind it leaves them all exposed at the end of the step (measured: three
+        collectives behind the last flag, 37 us in front of the next step; ordered by completion: one).  The replays are real training
+        steps: callers undo them (bench.flag_step restores its snapshot).  A collective call when the trainer has a process group."""
+        if not self.dist or len(self.segments) < 2:
+            return
+        lib = _lib.load()
+        torch.cuda.synchronize()
+        _lib.check(lib.immtsf_flag_trace(1), "flag_trace")
+        for _ in range(replays):
+            self()
+        torch.cuda.synchronize()
+        buf = (C.c_int64 * (3 * 1024))()
+        n = lib.immtsf_flag_trace_read(buf, 1024)
+        lib.immtsf_flag_trace(0)
+        base = self.flags.data_ptr()
+        ev = sorted((buf[3 * i + 2], buf[3 * i] - base, buf[3 * i + 1]) for i in range(max(n, 0)))
+        t_clear, acc = None, {}
+        for t, off, kind in ev:
+            if kind == 3 and off == 0:
+                t_clear = t
+            elif kind == 0 and t_clear is not None:
+                acc.setdefault(off, []).append((t - t_clear) / 100.0)
+        times = []
+        for g in self.segments:
+            ts = [sum(acc[f - base]) / len(acc[f - base]) for f in g["flags"] if acc.get(f - base)]
+            times.append(max(ts) if len(ts) == len(g["flags"]) else float("inf"))
+        tt = torch.tensor(times, dtype=torch.float64, device=self.flags.device)
+        tt = torch.where(torch.isfinite(tt), tt, torch.full_like(tt, 1e9))
+        import torch.distributed as dist
+        dist.all_reduce(tt, group=self.trainer.group)
+        order = sorted(range(len(self.segments)), key=lambda i: (float(tt[i]), i))
+        self.segments = [self.segments[i] for i in order]
+        self.completion_us = [round(float(tt[i]) / self.trainer.world, 1) for i in order]
+
     def _enqueue_collectives(self, cs, k):
         """the step's collectives on the current stream (raw handle `cs`): the seeds, then every segment behind its buckets' flags, this
         rank's guard word riding with the last one.  k: the replay number the counting flags are compared with."""

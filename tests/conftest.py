@@ -32,3 +32,4 @@ def _fresh_immtsf_state():
         return
     config.disable_device_counters()
     config.precision = "fp32"
+    config.nan_check = os.environ.get("IMMTSF_NAN_CHECK", "deferred")

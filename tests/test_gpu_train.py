@@ -742,7 +742,7 @@ def test_dropin_seam_graph_replay_equals_eager():
         compute_all_losses(model, fusion, batch)["loss"].backward()
         g2 = [p.grad.clone() for p in params if p.grad is not None]
         torch.cuda.synchronize()
-        n_graphs = len(ev._graphs)
+        n_graphs = sum(len(v) for v in ev._graphs.values())
         return torch.cat([p.detach().reshape(-1) for p in params]), losses, g1, g2, n_graphs
 
     old = config.seam_graph
@@ -753,12 +753,143 @@ def test_dropin_seam_graph_replay_equals_eager():
         config.seam_graph = old
         ev._graphs.clear(); ev._seen.clear()
     assert n_e == 0 and n_g == 1              # one shape -> one graph, used by both batches
+    import gc
+    gc.collect()
+    assert sum(len(v) for v in ev._graphs.values()) == 0          # the cache died with the models (weak keys): no stale graph for a recycled id
     for a, b in zip(l_e, l_g):
         assert abs(a - b) <= 1e-5 * abs(a), (l_e, l_g)
     assert float((p_e - p_g).abs().max() / p_e.abs().max()) < 2e-4
     for a, b in zip(g1, g2):
         # (1e-4: the time-embedding scalars are atomic sums of cancelling terms -- their order differs between the two passes)
         assert float((b - 2 * a).abs().max()) <= 1e-4 * max(float(a.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("seam", [False, True])
+def test_optim_shim_trains_like_torch_adam(seam):
+    """immtsf.optim (what `optim.Adam(...)` / `clip_grad_norm_(...)` of an unmodified main.py resolve to once lib.evaluation is imported,
+    main.py:1024,1098-1101): FusedAdam on flat buffers + the clip folded into its step train like torch.optim.Adam + torch's clip -- with
+    weight decay, over the eager seam and the graph-replayed one; state_dict() / load_state_dict() keep torch's format (a checkpoint of
+    one loads into the other); anything FusedAdam does not take falls back to torch's Adam."""
+    dev = _dev()
+    from immtsf import config, optim
+    from lib import evaluation as ev
+    from lib.evaluation import compute_all_losses
+    old = config.seam_graph
+    config.seam_graph = seam
+
+    def train(fused, steps=5, resume=None):
+        ev._graphs.clear(); ev._seen.clear()
+        model, fusion, _, batch = _setup(dev, 0.0, trainer=False)
+        params = [p for p in list(model.parameters()) + list(fusion.parameters())]
+        mk = optim.Adam if fused else optim._torch_adam
+        clip = optim.clip_grad_norm_ if fused else optim._torch_clip
+        opt = mk(params, lr=1e-2, eps=1e-3, weight_decay=1e-3)
+        assert isinstance(opt, optim.FusedAdam) == fused
+        if resume is not None:
+            opt.load_state_dict(resume[0])
+            with torch.no_grad():
+                for p, v in zip(params, resume[1]):
+                    p.copy_(v)
+        norms = []
+        for _ in range(steps):
+            opt.zero_grad()
+            compute_all_losses(model, fusion, batch)["loss"].backward()
+            norms.append(float(clip(params, 0.05)))
+            opt.step()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in params]).clone(), norms, opt.state_dict(), [p.detach().clone() for p in params]
+
+    try:
+        p_t, n_t, sd_t, w_t = train(False)
+        p_f, n_f, sd_f, w_f = train(True)
+        assert float((p_t - p_f).abs().max() / p_t.abs().max()) < 2e-4
+        for a, b in zip(n_t, n_f):
+            assert abs(a - b) <= 1e-4 * abs(a), (n_t, n_f)                 # the norm clip_grad_norm_ returns
+        # a torch checkpoint resumes in the fused optimizer and the other way round: 2 more steps land on the same parameters
+        p_a = train(True, steps=2, resume=(sd_t, w_t))[0]
+        p_b = train(False, steps=2, resume=(sd_f, w_f))[0]
+        assert float((p_a - p_b).abs().max() / p_a.abs().max()) < 2e-4
+        assert isinstance(optim.Adam([torch.nn.Parameter(torch.zeros(3))]), optim._torch_adam)              # CPU parameter: torch's
+        assert isinstance(optim.Adam([torch.nn.Parameter(torch.zeros(3, device=dev))], amsgrad=True), optim._torch_adam)
+    finally:
+        config.seam_graph = old
+        ev._graphs.clear(); ev._seen.clear()
+
+
+def test_deferred_nan_guards_raise_at_the_next_call():
+    """immtsf.config.nan_check = "deferred" (the default): the reference's ValueErrors (fusions/TTF_T2V_XAttn.py:116-117,
+    lib/evaluation.py:158-160) are raised by the NEXT compute_all_losses() call instead of inside the step that met the NaN -- no host
+    sync inside the step; a clean step raises nothing."""
+    dev = _dev()
+    from immtsf import config
+    from lib import evaluation as ev
+    from lib.evaluation import compute_all_losses
+    config.nan_check = "deferred"
+    config.seam_graph = False
+    try:
+        model, fusion, _, batch = _setup(dev, 0.0, trainer=False)
+        ev._probe.clear()
+        compute_all_losses(model, fusion, batch)["loss"].backward()
+        torch.cuda.synchronize()
+        compute_all_losses(model, fusion, batch)                               # clean: nothing raised
+        bad = dict(batch)
+        bad["notes_embeddings"] = batch["notes_embeddings"].clone()
+        bad["notes_embeddings"][1, 0, 3] = float("nan")
+        torch.cuda.synchronize()
+        compute_all_losses(model, fusion, bad)                                  # the step itself goes through ...
+        torch.cuda.synchronize()                                                # (main.py's own loss.item())
+        with pytest.raises(ValueError, match="Input embeddings V contain NaN"):
+            compute_all_losses(model, fusion, batch)                            # ... the next call raises
+        torch.cuda.synchronize()
+        bad2 = dict(batch)
+        bad2["data_to_predict"] = batch["data_to_predict"].clone()
+        bad2["data_to_predict"][0, 0, 0] = float("nan")
+        bad2["mask_predicted_data"] = batch["mask_predicted_data"].clone()
+        bad2["mask_predicted_data"][0, 0, 0] = 1.0
+        ev._probe.clear()
+        compute_all_losses(model, fusion, bad2)
+        torch.cuda.synchronize()
+        with pytest.raises(ValueError, match="MSE is NaN"):
+            compute_all_losses(model, fusion, batch)
+    finally:
+        config.seam_graph = True
+        ev._probe.clear()
+
+
+def test_dropin_seam_graph_guards():
+    """the seam graph's guards (round-4 advisor findings): a loss whose graph was replayed again before its backward() raises instead of
+    handing on the other batch's gradients; a parameter frozen after the capture gets a graph of its own (the key holds every parameter's
+    storage address and requires_grad); building a graph leaves module buffers and the dropout counter as they were."""
+    dev = _dev()
+    from immtsf import config
+    from lib import evaluation as ev
+    from lib.evaluation import compute_all_losses
+    old = config.seam_graph
+    config.seam_graph = True
+    try:
+        model, fusion, _, batch = _setup(dev, 0.1, trainer=False)
+        drop_dev = config.enable_device_counters(dev)[1]
+        compute_all_losses(model, fusion, batch)["loss"].backward()            # first sighting: eager
+        d0 = int(drop_dev.item())
+        bufs0 = [b.clone() for b in list(model.buffers()) + list(fusion.buffers())]
+        l1 = compute_all_losses(model, fusion, batch)["loss"]                     # second: captured (two warm-up runs + capture) and replayed
+        assert sum(len(v) for v in ev._graphs.values()) == 1
+        assert int(drop_dev.item()) == d0 + 1                                     # one step's worth, not three
+        for a, b in zip(bufs0, list(model.buffers()) + list(fusion.buffers())):
+            if not b.dtype.is_floating_point:                                     # (e.g. BatchNorm's num_batches_tracked: ONE step, not three)
+                assert int((b - a).abs().max()) <= 1
+        l2 = compute_all_losses(model, fusion, batch)["loss"]
+        with pytest.raises(RuntimeError, match="before this loss's backward"):
+            l1.backward()
+        l2.backward()
+        p0 = next(fusion.mmf.parameters())
+        p0.requires_grad_(False)
+        compute_all_losses(model, fusion, batch)["loss"].backward()              # new key: eager
+        compute_all_losses(model, fusion, batch)["loss"].backward()              # ... then a second graph
+        assert sum(len(v) for v in ev._graphs.values()) == 2
+    finally:
+        config.seam_graph = old
+        ev._graphs.clear(); ev._seen.clear()
 
 
 def test_load_state_dict_refreshes_the_bf16_twin():

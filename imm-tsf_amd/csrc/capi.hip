@@ -275,6 +275,11 @@ int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_
                              static_cast<hipStream_t>(stream));
 }
 
+int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream) {
+    if (!src || !dst || !flag || !ticket || n == 0) return IMMTSF_EINVAL;
+    return launch_f32_to_bf16_bump(src, dst, n, flag, ticket, static_cast<hipStream_t>(stream));
+}
+
 int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_stream_t stream) {
     if (!err || !slot) return IMMTSF_EINVAL;
     return launch_guard_pack(err, slot, is_bf16 ? 1 : 0, static_cast<hipStream_t>(stream));

@@ -424,6 +424,29 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     }
     for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
 }
+// f32_to_bf16_kernel that also BUMPS a counting flag when the whole image is written (the last workgroup to finish does it: a ticket
+// word the launch leaves zero) -- a gradient bucket's wire image and its announcement in one launch
+__global__ __launch_bounds__(256) void f32_to_bf16_bump_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int vec,
+                                                                int* flag, unsigned int* ticket) {
+    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t0; i < n4; i += stride) {
+        const float4 x = reinterpret_cast<const float4*>(src)[i];
+        bf16x4 h;
+        h[0] = (bf16_t)x.x; h[1] = (bf16_t)x.y; h[2] = (bf16_t)x.z; h[3] = (bf16_t)x.w;
+        reinterpret_cast<bf16x4*>(dst)[i] = h;
+    }
+    for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n, int vec) {
     const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (size_t i = t0; i < n4; i += stride) {
@@ -674,6 +697,13 @@ int launch_copy_segments(int k, const float* const* src, float* const* dst, cons
     for (int i = 0; i < k; ++i) { c.src[i] = src[i]; c.dst[i] = dst[i]; c.n[i] = counts[i]; most = counts[i] > most ? counts[i] : most; }
     if (most <= 0) return IMMTSF_OK;
     hipLaunchKernelGGL(copy_segments_kernel, dim3(cdiv(most, 1024) > 64 ? 64 : cdiv(most, 1024)), dim3(256), 0, s, c);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+int launch_f32_to_bf16_bump(const float* src, void* dst, size_t n, int* flag, unsigned int* ticket, hipStream_t s) {
+    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
+    const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
+    hipLaunchKernelGGL(f32_to_bf16_bump_kernel, dim3(blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), n, vec, flag, ticket);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -57,5 +57,6 @@ int launch_guard_pack(const int* err, void* slot, int is_bf16, hipStream_t s);
 
 // dst[i] = bf16(src[i]) (round to nearest even): refresh of a bf16 twin
 int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+int launch_f32_to_bf16_bump(const float* src, void* dst, size_t n, int* flag, unsigned int* ticket, hipStream_t s);
 // dst[i] = float(src[i]) (exact)
 int launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t s);

@@ -98,8 +98,8 @@ def _zeroed_grad_buffers(params, sinks):
 
 
 def _fire(hook, burst=None):
-    """run a bucket hook (immtsf.train.FlatTrainer); burst: a token shared by hooks fired back to back -- buckets that complete at the
-    same moment -- which lets a data-parallel step send them as one collective"""
+    """run a bucket hook (immtsf.train.FlatTrainer); burst: (token, index, count) of hooks fired back to back -- buckets that complete at
+    the same moment -- which lets a data-parallel step pack, announce and send neighbours in the flat buffer as one"""
     if hook is not None:
         if burst is not None and getattr(hook, "_immtsf_bucket_index", None) is not None:
             hook(burst)
@@ -287,9 +287,9 @@ class TTFT2VXAttnFn(torch.autograd.Function):
             def job(stream, keep=keep):
                 check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
                 call(_lib.BWD_WGRAD_A | _lib.BWD_WGRAD_B, stream)
-                burst = object()
-                for h in early:
-                    _fire(h, burst)
+                token = object()
+                for i_, h in enumerate(early):
+                    _fire(h, (token, i_, len(early)))
             tail["jobs"].append(job)
             for ph, h in hooks:
                 if ph == 2:

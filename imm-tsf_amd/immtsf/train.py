@@ -854,7 +854,7 @@ class FlagStep(PhasedStep):
         communication stream's collective, so the graph no longer runs to its end on its own: a communication stream that shares a
         hardware queue with a spinning branch cannot be ridden out, only timed out (comm_timeout_ms).  Off by default for that reason.
         merge_adjacent (data parallel): buckets announced in one burst (they complete at the same moment) that are neighbours in the flat
-        buffer go out as one collective.
+        buffer get one wire image, one flag and one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
         backward ends) leave the text side's dependent chain for the parameter branch, behind MMF_XAttn_Add's chain
         (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks)."""
@@ -920,6 +920,8 @@ class FlagStep(PhasedStep):
         announced = set()
         branch_now = ["T"]
 
+        self._tickets = torch.zeros(64, dtype=torch.int32, device=dev)
+
         def announce_range(lo, hi, buckets, burst=None):
             if hi == lo:
                 return
@@ -928,17 +930,33 @@ class FlagStep(PhasedStep):
                 raise RuntimeError("FlagStep: more than 24 announced buckets")
             flag = W(self._COUNT0 + k)
             st = torch.cuda.current_stream().cuda_stream
-            if bf16_wire:       # the wire image, written where the bucket completes: no conversion kernel around the collective
-                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
-            _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
-            self._nflags = k + 1
-            self.segments.append({"flag": flag, "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0], "burst": burst})
+            if bf16_wire:       # the wire image, written where the bucket completes, and the announcement: ONE launch -- no conversion
+                # kernel around the collective, no separate flag kernel on the announcing branch
+                _lib.check(lib.immtsf_f32_to_bf16_bump(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, flag,
+                                                       self._tickets.data_ptr() + 4 * k, st), "f32_to_bf16_bump")
+            else:
+                _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
+            self.segments.append({"flag": flag, "flags": [flag], "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0] * len(buckets)})
+
+        bursts = {}
 
         def announce(bi, burst=None):
             if bi in announced:
                 return
             announced.add(bi)
-            announce_range(*trainer.ranges[bi], (bi,), burst)
+            if burst is None or not merge_adjacent:
+                announce_range(*trainer.ranges[bi], (bi,))
+                return
+            # a burst: hooks fired back to back (the buckets complete at the same moment): its members that are neighbours in the flat
+            # buffer get ONE wire image, ONE flag and ONE collective -- emitted when the burst's last member has reported
+            token, i, cnt = burst
+            bursts.setdefault(id(token), []).append(bi)
+            if i + 1 < cnt:
+                return
+            members = sorted(bursts.pop(id(token)), key=lambda b_: trainer.ranges[b_][0])
+            for lo, hi in _runs([trainer.ranges[b_] for b_ in members]):
+                announce_range(lo, hi, [b_ for b_ in members if lo <= trainer.ranges[b_][0] and trainer.ranges[b_][1] <= hi and
+                                        trainer.ranges[b_][1] > trainer.ranges[b_][0]])
 
         def prereduced(hook):
             # a bucket whose gradients already ARE the sum over the ranks (its chain ran on all-reduced seeds): only the wire image
@@ -1093,7 +1111,7 @@ class FlagStep(PhasedStep):
                 _lib.check(lib.immtsf_flags_clear_set(fp, 9, self._f_pending, sp(T)), "flags_clear_set")
         finally:
             config.sched_gate = config.sched_armed = None
-        self._order_segments(merge_adjacent)
+        self._order_segments()
         self.comm = None
         if self.dist:
             # A stream of its own at DEFAULT priority.  HIP deals the streams of one priority round-robin onto a handful of hardware
@@ -1135,26 +1153,12 @@ class FlagStep(PhasedStep):
         self.flags[self._PENDING:self._PENDING + 1].zero_()
         self.trainer.flat_grad.zero_()
 
-    def _order_segments(self, merge_adjacent):
-        """the communication order: the text side's buckets but its last, the parameter branch's, the text side's last, the backbone's, the
-        join's -- the order in which they complete at the benchmark configuration; the SAME on every rank.  merge_adjacent: buckets
-        announced in one burst (hooks fired back to back: they complete at the same moment) that are neighbours in the flat buffer go out
-        as one collective."""
-        tseg = [g for g in self.segments if g["branch"] == "T"]
-        segs = (tseg[:-1] + [g for g in self.segments if g["branch"] == "P"] + tseg[-1:] +
-                [g for g in self.segments if g["branch"] == "B"] + [g for g in self.segments if g["branch"] == "J"])
-        merged = []
-        for g in segs:
-            g = dict(g, flags=[g["flag"]])
-            m = next((x for x in merged if merge_adjacent and g["burst"] is not None and x["burst"] is g["burst"] and
-                      (x["hi"] == g["lo"] or g["hi"] == x["lo"])), None)
-            if m is None:
-                merged.append(g)
-            elif m["hi"] == g["lo"]:
-                m["hi"], m["flags"], m["buckets"], m["branch"] = g["hi"], m["flags"] + g["flags"], m["buckets"] + g["buckets"], m["branch"] + g["branch"]
-            else:
-                m["lo"], m["flags"], m["buckets"], m["branch"] = g["lo"], g["flags"] + m["flags"], g["buckets"] + m["buckets"], g["branch"] + m["branch"]
-        self.segments = merged
+    def _order_segments(self):
+        """the communication order before any measurement: the text side's buckets but its last, the parameter branch's, the text side's
+        last, the backbone's, the join's; the SAME on every rank (calibrate_comm_order replaces it by the measured completion order)"""
+        tseg = [g for g in self.segments if g["branch"][0] == "T"]
+        self.segments = (tseg[:-1] + [g for g in self.segments if g["branch"][0] == "P"] + tseg[-1:] +
+                         [g for g in self.segments if g["branch"][0] == "B"] + [g for g in self.segments if g["branch"][0] == "J"])
 
     def calibrate_comm_order(self, replays: int = 3):
         """order the communication stream's collectives by when their buckets ACTUALLY complete: `replays` replays under the flag
@@ -1185,8 +1189,8 @@ class FlagStep(PhasedStep):
                 acc.setdefault(off, []).append((t - t_clear) / 100.0)
         times = []
         for g in self.segments:
-            ts = [sum(acc[f - base]) / len(acc[f - base]) for f in g["flags"] if acc.get(f - base)]
-            times.append(max(ts) if len(ts) == len(g["flags"]) else float("inf"))
+            ts = acc.get(g["flag"] - base)
+            times.append(sum(ts) / len(ts) if ts else float("inf"))
         tt = torch.tensor(times, dtype=torch.float64, device=self.flags.device)
         tt = torch.where(torch.isfinite(tt), tt, torch.full_like(tt, 1e9))
         import torch.distributed as dist
@@ -1212,15 +1216,16 @@ class FlagStep(PhasedStep):
             _lib.check(lib.immtsf_flag_bump(self._f_seed_done, cs), "flag_bump")
         last = len(self.segments) - 1
         for i, g in enumerate(self.segments):
-            for f in g["flags"]:
-                wait(f, self.timeout_ms)
             hi = g["hi"]
             if i == last:
-                # this rank's guard word rides with the last collective: into the slot behind the payload when the last range
-                # ends there, else as eight elements of its own
-                _lib.check(lib.immtsf_guard_pack(self._f_err, store[n:].data_ptr(), 1 if self._from_wire else 0, cs), "guard_pack")
+                # this rank's guard word rides with the last collective (written by the wait kernel itself): into the slot behind the
+                # payload when the last range ends there, else as eight elements of its own
+                _lib.check(lib.immtsf_flag_wait_ge_guard(g["flag"], k, self._f_err, self.timeout_ms, store[n:].data_ptr(),
+                                                         1 if self._from_wire else 0, cs), "flag_wait_ge_guard")
                 if hi == n:
                     hi = n + 8
+            else:
+                wait(g["flag"], self.timeout_ms)
             dist.all_reduce(store[g["lo"]:hi], group=t.group)
             if i == last and hi != n + 8:
                 dist.all_reduce(store[n:n + 8], group=t.group)

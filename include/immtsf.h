@@ -793,6 +793,12 @@ int immtsf_flags_clear_set(int32_t* flags, int32_t n, int32_t* set_flag, immtsf_
  * spins until *flag - target >= 0 (the consumer of replay k passes k).  Never cleared: a late consumer cannot miss a hand-over. */
 int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
+/* flag_wait_ge followed, in the same launch, by immtsf_guard_pack(err, slot, is_bf16): the wait in front of a step's LAST collective */
+int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, void* slot, int32_t is_bf16,
+                              immtsf_stream_t stream);
+/* immtsf_f32_to_bf16 followed, in the same launch, by immtsf_flag_bump(flag): a gradient bucket's bf16 wire image and its announcement.
+ * ticket: a zero-initialised device word the launch leaves zero (launches sharing it must be ordered). */
+int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream);
 /* flag_wait_ge whose target is read from device memory when the kernel runs (*target_dev: e.g. the replay number immtsf_adam_prepare
  * counts): a wait INSIDE a captured step for something a stream outside the graph produces once per replay (the data-parallel step's
  * parameter branch waiting for the all-reduce of MMF_XAttn_Add's chain seeds) */

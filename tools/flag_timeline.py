@@ -41,8 +41,7 @@ def main():
              4 * st._COMM_DONE: "collectives of the step done"}
     names[4 * st._SEED], names[4 * st._SEED_DONE], names[4 * st._TTF] = "chain seeds gathered", "chain seeds summed", "TTF phase B data path done"
     for i, g in enumerate(st.segments):
-        for j, f in enumerate(g["flags"]):
-            names[f - base] = "bucket %s final (%s, segment of %.2f MB bf16)" % (w.bucket_names[g["buckets"][j]], g["branch"][j], (g["hi"] - g["lo"]) * 2 / 1e6)
+        names[g["flag"] - base] = "bucket %s final (%s, %.2f MB bf16)" % ("+".join(w.bucket_names[b] for b in g["buckets"]), g["branch"], (g["hi"] - g["lo"]) * 2 / 1e6)
     _lib.check(lib.immtsf_flag_trace(1), "flag_trace")
     for _ in range(steps):
         st()

@@ -60,6 +60,60 @@ int immtsf_linear_backward(int32_t precision, const float* x, const float* W, co
     return IMMTSF_OK;
 }
 
+int immtsf_linear_bf16_forward(int32_t nl, const float* x, void* x16, const float* const* W, void* const* w16, const float* const* b,
+                               float* const* y, int32_t M, int32_t N, int32_t K, int32_t act, immtsf_stream_t stream) {
+    if (nl < 1 || nl > 3 || !x || !x16 || !W || !y || M <= 0 || N <= 0 || K <= 0 || (act && nl != 1)) return IMMTSF_EINVAL;
+    if ((K & 7) || (N & 7)) return IMMTSF_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    CHECK(launch_f32_to_bf16(x, x16, (size_t)M * K, s));
+    GemmArgs g = gemm_args(M, N, K, K, K, N);
+    g.nprob = nl;
+    g.act = act;
+    for (int i = 0; i < nl; ++i) {
+        if (!W[i] || !y[i]) return IMMTSF_EINVAL;
+        Mat Wm;
+        CHECK(weight_mat(true, W[i], (size_t)N * K, w16 ? w16[i] : nullptr, s, &Wm));
+        set_problem2(g, i, cmat(x, x16), Wm, mat(y[i]), b ? b[i] : nullptr);
+    }
+    return immtsf_launch_gemm(GEMM_NT, 1, g, s);
+}
+
+int immtsf_linear_bf16_backward(int32_t nl, const void* x16, const float* const* W, void* const* w16, const float* const* dy, void* dy16,
+                                float* dx, float* const* dW, float* const* db, int32_t M, int32_t N, int32_t K,
+                                int32_t grads_prezeroed, immtsf_stream_t stream) {
+    if (nl < 1 || nl > 3 || !x16 || !W || !dy || !dy16 || M <= 0 || N <= 0 || K <= 0) return IMMTSF_EINVAL;
+    if ((K & 7) || (N & 7)) return IMMTSF_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned short* d16 = static_cast<unsigned short*>(dy16);
+    for (int i = 0; i < nl; ++i) {
+        if (!dy[i] || !W[i]) return IMMTSF_EINVAL;
+        CHECK(launch_f32_to_bf16(dy[i], d16 + (size_t)i * M * N, (size_t)M * N, s));
+    }
+    if (dx) {                   // dx (M, K) = sum_i dy_i (M, N) @ W_i (N, K)
+        for (int i = 0; i < nl; ++i) {
+            Mat Wm;
+            CHECK(weight_mat(true, W[i], (size_t)N * K, w16 ? w16[i] : nullptr, s, &Wm));
+            GemmArgs g = gemm_args(M, K, N, N, K, K);
+            set_problem2(g, 0, cmat(dy[i], d16 + (size_t)i * M * N), Wm, mat(dx), nullptr);
+            g.accumulate = i > 0 ? 1 : 0;
+            CHECK(immtsf_launch_gemm(GEMM_NN, 1, g, s));
+        }
+    }
+    if (dW) {                   // dW_i (N, K) = dy_i^T (N, M) @ x (M, K); db_i = dy_i^T 1 -- one grouped launch
+        GemmArgs wg[3];
+        int n = 0;
+        for (int i = 0; i < nl; ++i) {
+            if (!dW[i]) continue;
+            GemmArgs h = gemm_args(N, K, M, N, K, K);
+            set_problem2(h, 0, cmat(dy[i], d16 + (size_t)i * M * N), cmat(nullptr, x16), mat(dW[i]), nullptr, db ? db[i] : nullptr);
+            h.c_prezeroed = grads_prezeroed ? 1 : 0;
+            wg[n++] = h;
+        }
+        CHECK(immtsf_launch_gemm_tn_list(1, wg, n, s));
+    }
+    return IMMTSF_OK;
+}
+
 int immtsf_time2vec_forward(const float* t, int32_t rows, int32_t d, const float* w0, const float* b0, const float* w,
                             const float* b, float* out, immtsf_stream_t stream) {
     if (!t || !w0 || !b0 || !out || d < 1 || (d > 1 && (!w || !b))) return IMMTSF_EINVAL;
@@ -252,18 +306,11 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
 
 int immtsf_adam_prepare(const float* grad, const void* grad_h, uint64_t n, float* norm_scratch, int64_t* step_dev,
                         uint64_t* dropout_step_dev, int32_t* pending, const int32_t* err, const void* guard_h, const float* guard_f,
-                        int32_t* skip_out, int32_t* epoch, immtsf_stream_t stream) {
+                        int32_t* skip_out, immtsf_stream_t stream) {
     if ((!grad && !grad_h) || !norm_scratch) return IMMTSF_EINVAL;
     return launch_adam_prepare(grad, grad_h, (size_t)n, norm_scratch, reinterpret_cast<long long*>(step_dev),
-                               reinterpret_cast<unsigned long long*>(dropout_step_dev), pending, err, guard_h, guard_f, skip_out, epoch,
+                               reinterpret_cast<unsigned long long*>(dropout_step_dev), pending, err, guard_h, guard_f, skip_out,
                                static_cast<hipStream_t>(stream));
-}
-
-int immtsf_copy_segments(int32_t k, const float* const* src, float* const* dst, const int32_t* counts, immtsf_stream_t stream) {
-    if (k <= 0 || k > 8 || !src || !dst || !counts) return IMMTSF_EINVAL;
-    for (int i = 0; i < k; ++i)
-        if (counts[i] < 0 || (counts[i] > 0 && (!src[i] || !dst[i]))) return IMMTSF_EINVAL;
-    return launch_copy_segments(k, src, dst, counts, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_avg, float* exp_avg_sq, uint64_t n, uint64_t lo,
@@ -273,11 +320,6 @@ int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_
     return launch_adam_range(param, grad, grad_h, exp_avg, exp_avg_sq, (size_t)n, (size_t)lo, (size_t)hi, lr, beta1, beta2, eps,
                              weight_decay, reinterpret_cast<const long long*>(step_dev), max_norm, norm_scratch, zero_grad ? 1 : 0, skip,
                              static_cast<hipStream_t>(stream));
-}
-
-int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream) {
-    if (!src || !dst || !flag || !ticket || n == 0) return IMMTSF_EINVAL;
-    return launch_f32_to_bf16_bump(src, dst, n, flag, ticket, static_cast<hipStream_t>(stream));
 }
 
 int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_stream_t stream) {

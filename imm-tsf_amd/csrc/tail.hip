@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void adam_prepare_kernel(const float* __restrict__ g, const bf16_t* __restrict__ gh, size_t n, int vec,
                                                             float* __restrict__ part, long long* step_dev, unsigned long long* drop_dev,
                                                             int* pending, const int* err, const bf16_t* guard_h, const float* guard_f,
-                                                            int* skip_out, int* epoch) {
+                                                            int* skip_out) {
     __shared__ float red[16];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         int skip = 0;
@@ -310,7 +310,6 @@ __global__ __launch_bounds__(256) void adam_prepare_kernel(const float* __restri
         if (skip_out) *skip_out = skip;
         if (step_dev && !skip) step_dev[0] += 1;
         if (drop_dev) drop_dev[0] += 1;
-        if (epoch) __hip_atomic_fetch_add(epoch, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     float a = 0.f;
     const size_t stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -332,11 +331,6 @@ __global__ __launch_bounds__(256) void adam_prepare_kernel(const float* __restri
     }
     a = block_sum(a, red);
     if (threadIdx.x == 0) part[blockIdx.x] = a;
-}
-struct CopySegs { const float* src[8]; float* dst[8]; int n[8]; int k; };
-__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs c) {
-    for (int i = 0; i < c.k; ++i)
-        for (int j = blockIdx.x * 256 + threadIdx.x; j < c.n[i]; j += gridDim.x * 256) c.dst[i][j] = c.src[i][j];
 }
 // this rank's guard word in the gradient wire's element type, for the slot the step's last all-reduce sums over the ranks
 __global__ void guard_pack_kernel(const int* err, void* slot, int is_bf16) {
@@ -423,29 +417,6 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
         reinterpret_cast<bf16x4*>(dst)[i] = h;
     }
     for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
-}
-// f32_to_bf16_kernel that also BUMPS a counting flag when the whole image is written (the last workgroup to finish does it: a ticket
-// word the launch leaves zero) -- a gradient bucket's wire image and its announcement in one launch
-__global__ __launch_bounds__(256) void f32_to_bf16_bump_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int vec,
-                                                                int* flag, unsigned int* ticket) {
-    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t i = t0; i < n4; i += stride) {
-        const float4 x = reinterpret_cast<const float4*>(src)[i];
-        bf16x4 h;
-        h[0] = (bf16_t)x.x; h[1] = (bf16_t)x.y; h[2] = (bf16_t)x.z; h[3] = (bf16_t)x.w;
-        reinterpret_cast<bf16x4*>(dst)[i] = h;
-    }
-    for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __threadfence_system();
-            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n, int vec) {
     const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -662,11 +633,11 @@ int launch_adam_dev(float* param, const float* grad, float* m, float* v, size_t 
 }
 
 int launch_adam_prepare(const float* grad, const void* grad_h, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
-                        int* pending, const int* err, const void* guard_h, const float* guard_f, int* skip_out, int* epoch, hipStream_t s) {
+                        int* pending, const int* err, const void* guard_h, const float* guard_f, int* skip_out, hipStream_t s) {
     const uintptr_t a = grad_h ? reinterpret_cast<uintptr_t>(grad_h) : reinterpret_cast<uintptr_t>(grad);
     const int vec = (a & 15) == 0;
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1024), dim3(256), 0, s, grad, static_cast<const bf16_t*>(grad_h), n, vec, norm_scratch, step_dev,
-                       drop_dev, pending, err, static_cast<const bf16_t*>(guard_h), guard_f, skip_out, epoch);
+                       drop_dev, pending, err, static_cast<const bf16_t*>(guard_h), guard_f, skip_out);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -687,23 +658,6 @@ int launch_adam_range(float* param, float* grad, const void* grad_h, float* m, f
 }
 int launch_guard_pack(const int* err, void* slot, int is_bf16, hipStream_t s) {
     hipLaunchKernelGGL(guard_pack_kernel, dim3(1), dim3(1), 0, s, err, slot, is_bf16);
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-int launch_copy_segments(int k, const float* const* src, float* const* dst, const int* counts, hipStream_t s) {
-    CopySegs c;
-    c.k = k;
-    int most = 0;
-    for (int i = 0; i < k; ++i) { c.src[i] = src[i]; c.dst[i] = dst[i]; c.n[i] = counts[i]; most = counts[i] > most ? counts[i] : most; }
-    if (most <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(copy_segments_kernel, dim3(cdiv(most, 1024) > 64 ? 64 : cdiv(most, 1024)), dim3(256), 0, s, c);
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-int launch_f32_to_bf16_bump(const float* src, void* dst, size_t n, int* flag, unsigned int* ticket, hipStream_t s) {
-    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 4096 ? 4096 : (n / 4 + 255) / 256 + 1);
-    const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
-    hipLaunchKernelGGL(f32_to_bf16_bump_kernel, dim3(blocks), dim3(256), 0, s, src, static_cast<bf16_t*>(dst), n, vec, flag, ticket);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -48,8 +48,7 @@ int launch_adam_apply(float* param, const float* grad, float* m, float* v, size_
 
 // clip + Adam as launches the caller places (include/immtsf.h immtsf_adam_prepare / _range / immtsf_guard_pack)
 int launch_adam_prepare(const float* grad, const void* grad_h, size_t n, float* norm_scratch, long long* step_dev, unsigned long long* drop_dev,
-                        int* pending, const int* err, const void* guard_h, const float* guard_f, int* skip_out, int* epoch, hipStream_t s);
-int launch_copy_segments(int k, const float* const* src, float* const* dst, const int* counts, hipStream_t s);
+                        int* pending, const int* err, const void* guard_h, const float* guard_f, int* skip_out, hipStream_t s);
 int launch_adam_range(float* param, float* grad, const void* grad_h, float* m, float* v, size_t n, size_t lo, size_t hi, float lr, float b1,
                       float b2, float eps, float wd, const long long* step_dev, float max_norm, const float* norm_scratch, int zero_grad,
                       const int* skip, hipStream_t s);
@@ -57,6 +56,5 @@ int launch_guard_pack(const int* err, void* slot, int is_bf16, hipStream_t s);
 
 // dst[i] = bf16(src[i]) (round to nearest even): refresh of a bf16 twin
 int launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
-int launch_f32_to_bf16_bump(const float* src, void* dst, size_t n, int* flag, unsigned int* ticket, hipStream_t s);
 // dst[i] = float(src[i]) (exact)
 int launch_bf16_to_f32(const void* src, float* dst, size_t n, hipStream_t s);

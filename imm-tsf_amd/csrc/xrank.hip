@@ -1665,27 +1665,6 @@ int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_
     return IMMTSF_OK;
 }
 
-int immtsf_mmf_xrank_seed_region(const immtsf_fusion_cfg* cfg, void* scratch, size_t scratch_bytes, int32_t z_form, float** region,
-                                 size_t* floats) {
-    if (!xr_supported(cfg) || !scratch || !region || !floats) return IMMTSF_EINVAL;
-    XPScratch sc = carve_xp_scratch(cfg, scratch);
-    if (scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
-    const XRDims x = xr_dims(cfg);
-    float* lo = z_form ? sc.dWc : sc.dWf;
-    float* hi = (z_form ? sc.dbc : sc.dWfb) + x.PW;
-    *region = lo;
-    *floats = (size_t)(hi - lo);
-    return IMMTSF_OK;
-}
-int immtsf_mmf_xrank_seed_refresh(const immtsf_fusion_cfg* cfg, void* scratch, size_t scratch_bytes, int32_t z_form, immtsf_stream_t stream) {
-    if (!xr_supported(cfg) || !scratch) return IMMTSF_EINVAL;
-    XPScratch sc = carve_xp_scratch(cfg, scratch);
-    if (scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
-    const XRDims x = xr_dims(cfg);
-    if (z_form && xr_hf(cfg)) return launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * x.d, static_cast<hipStream_t>(stream));
-    return IMMTSF_OK;
-}
-
 /* the parameter half: the chain rule from dW_fold (in `scratch`, left there by ..._backward_data on a stream this call is ordered
  * behind) to the block's parameter gradients -- three dependent multi-job launches, of which this call runs [first, last) (0 <= first
  * <= last <= 3): parameter-only work that nothing but the optimizer waits for, so a caller may run its tail on another stream

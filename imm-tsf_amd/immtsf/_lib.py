@@ -230,6 +230,10 @@ _PROTOS = {
                               C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_int32, c_stream]),
     "immtsf_linear_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
                                          c_f32p, c_f32p, c_f32p, C.c_int32, c_stream]),
+    "immtsf_linear_bf16_forward": (C.c_int, [C.c_int32, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                             C.c_int32, C.c_int32, c_stream]),
+    "immtsf_linear_bf16_backward": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p,
+                                              C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_stream]),
     "immtsf_time2vec_forward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_time2vec_backward": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                            c_f32p, c_f32p, C.c_int32, c_stream]),
@@ -297,13 +301,9 @@ _PROTOS = {
     "immtsf_adam_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_uint64, C.c_float, C.c_float, C.c_float,
                                    C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),
     "immtsf_adam_prepare": (C.c_int, [c_f32p, C.c_void_p, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      c_f32p, C.c_void_p, C.c_void_p, c_stream]),
-    "immtsf_flag_wait_ge_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_stream]),
+                                      c_f32p, C.c_void_p, c_stream]),
     "immtsf_flag_wait_ge_guard": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_f32_to_bf16_bump": (C.c_int, [c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, c_stream]),
-    "immtsf_copy_segments": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, c_stream]),
-    "immtsf_mmf_xrank_seed_region": (C.c_int, [_P(FusionCfg), C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_void_p]),
-    "immtsf_mmf_xrank_seed_refresh": (C.c_int, [_P(FusionCfg), C.c_void_p, C.c_size_t, C.c_int32, c_stream]),
     "immtsf_adam_range": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_int32, C.c_void_p, c_stream]),
     "immtsf_guard_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),

@@ -695,32 +695,6 @@ class MMFXRankPFn(torch.autograd.Function):
                 check(lib.immtsf_mmf_xrank_p_backward_params(C.byref(cfg), C.byref(ps), ptr(dbHO), ptr(ws), ws.numel(), ptr(sc), sc.numel(),
                                                              C.byref(gs), first, last, stream), "mmf_xrank_p_backward_params")
 
-            seed_reduce = tail.get("seed_reduce")
-            if seed_reduce is not None and ctx.done_hook is not None:
-                # data parallel (immtsf.train.FlagStep): every gradient the chain (and the "_z" pre-step) writes is a LINEAR function of
-                # the seeds the data half left in the scratch -- dW_fold / dWc with their column sums, d b_HO -- so the ranks all-reduce
-                # THOSE (75 KB) in front of the chain, and every rank's chain yields the summed gradients: the block's ~14 MB of
-                # parameter gradients never cross the wire.  seed_reduce(stream, segments, produced, hook) gathers the segments,
-                # hands them to the communication stream, waits for the sum and scatters it back -- as launches on `stream`
-                region, floats = C.c_void_p(), C.c_size_t()
-                z = 1 if proj is not None else 0
-                check(lib.immtsf_mmf_xrank_seed_region(C.byref(cfg), ptr(sc), sc.numel(), z, C.byref(region), C.byref(floats)), "mmf_xrank_seed_region")
-                segs = [(int(region.value), int(floats.value)), (dbHO.data_ptr(), dbHO.numel())]
-                produced = [q for q in list(params9) + list(proj or ()) if q is not None]
-                hook, ctx.done_hook = ctx.done_hook, None
-                k = 0        # (the whole chain behind the reduction, on the branch that waits for it)
-
-                def reduce_job(stream, cfg=cfg, sc=sc):
-                    seed_reduce(stream, segs, produced, hook)
-                    check(lib.immtsf_mmf_xrank_seed_refresh(C.byref(cfg), ptr(sc), sc.numel(), z, stream), "mmf_xrank_seed_refresh")
-                check(lib.immtsf_flag_set(tail["flag"][0], stream_ptr()), "flag_set")
-                tail["flag_set"] = True
-                tail["jobs"].append(reduce_job)
-                tail["jobs"].append(lambda stream: (pre(stream), run_params(stream, 0, 3)))
-                tail["jobs"].append(lambda stream, hook=hook: tail["prereduced"](hook))
-                if dE_h is not None:
-                    _shadow_put(dE, dE_h)
-                return (dE, None, None, None, None) + tuple(rets[:9]) + (tuple(prets) if proj is not None else ())
             if k > 0:
                 pre(stream_ptr())
                 run_params(stream_ptr(), 0, k)
@@ -1413,8 +1387,87 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(ctx.shape) if dx is not None else None), rW, rb, None, None
 
 
+class LinearBf16Fn(torch.autograd.Function):
+    """nl (1..3) linear layers y_i = act(x W_i^T + b_i) that share ONE input, in the bf16 dataflow (immtsf_linear_bf16_forward /
+    _backward): the input is cast once and kept as bf16 for the weight gradients, the weights are read from FlatTrainer's bf16 twins
+    (else cast into a scratch image), the forward is ONE launch, the backward one cast per upstream gradient, nl accumulating
+    data-gradient launches and ONE grouped weight-gradient launch.  args: x, relu, nl, W_1..W_nl, b_1..b_nl (None allowed)."""
+
+    @staticmethod
+    def forward(ctx, x, relu, nl, *wb):
+        lib = _lib.load()
+        Ws, bs = [_c(w) for w in wb[:nl]], list(wb[nl:])
+        x2 = _c(x).reshape(-1, x.shape[-1])
+        _need_gpu(x2, *Ws)
+        M, K = x2.shape
+        N = Ws[0].shape[0]
+        dev = x.device
+        x16 = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
+        w16 = [torch.empty(N, K, dtype=torch.bfloat16, device=dev) for _ in range(nl)]       # (unused when a twin is registered)
+        ys = [torch.empty(*x.shape[:-1], N, dtype=torch.float32, device=dev) for _ in range(nl)]
+        arr = lambda ts: (C.c_void_p * nl)(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+        check(lib.immtsf_linear_bf16_forward(nl, ptr(x2), ptr(x16), arr(Ws), arr(w16), arr(bs), arr(ys), M, N, K, 1 if relu else 0,
+                                             stream_ptr()), "linear_bf16_forward")
+        ctx.save_for_backward(x16, *Ws, *([ys[0]] if relu else []))
+        ctx.nl, ctx.relu, ctx.shape, ctx.w16 = nl, relu, x.shape, w16
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.wsinks, ctx.bsinks = _sinks_of(Ws), _sinks_of(bs)
+        ctx.pre = all(s is not None and getattr(p, "_immtsf_grad_prezeroed", False)
+                      for p, s in zip(list(Ws) + bs, ctx.wsinks + ctx.bsinks) if p is not None)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        x16, Ws = saved[0], saved[1:1 + nl]
+        M, K = x16.shape
+        N = Ws[0].shape[0]
+        dev = x16.device
+        dys = [torch.zeros(M, N, dtype=torch.float32, device=dev) if d is None else d.contiguous().reshape(M, N) for d in dys]
+        if ctx.relu:
+            dys[0] = torch.ops.aten.threshold_backward(dys[0], saved[1 + nl].reshape(M, N), 0.0)
+        need_w = any(ctx.needs_input_grad[3 + i] for i in range(nl))
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        rW, rb = [None] * nl, [None] * nl
+        dW, db = [None] * nl, [None] * nl
+        if need_w and ctx.pre:          # gradient sinks that their owner zero-fills every step: written in place, nothing returned
+            dW, db = list(ctx.wsinks), list(ctx.bsinks)
+        elif need_w:                    # ONE zero fill for every dW | db
+            per = N * K + N
+            flat = torch.zeros(nl * per, dtype=torch.float32, device=dev)
+            for i in range(nl):
+                dW[i] = rW[i] = flat[i * per:i * per + N * K].view(N, K)
+                if ctx.has_bias[i]:
+                    db[i] = rb[i] = flat[i * per + N * K:(i + 1) * per]
+        dy16 = torch.empty(nl * M * N, dtype=torch.bfloat16, device=dev)
+        arr = lambda ts: (C.c_void_p * nl)(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+        check(lib.immtsf_linear_bf16_backward(nl, ptr(x16), arr(Ws), arr(ctx.w16), arr(dys), ptr(dy16), ptr(dx), arr(dW) if need_w else None,
+                                              arr(db) if need_w else None, M, N, K, 1, stream_ptr()), "linear_bf16_backward")
+        return ((dx.view(ctx.shape) if dx is not None else None), None, None) + tuple(rW) + tuple(rb)
+
+
+def _bf16_linear_ok(x, W, precision):
+    # (small layers -- tPatchGNN's 64 -> 32 temporal aggregation -- keep their exact-fp32 one-launch kernels)
+    return (config.precision_code(precision) == 1 and x.is_cuda and W.shape[1] % 8 == 0 and W.shape[0] % 8 == 0 and W.shape[1] >= 128 and
+            W.shape[0] >= 64 and x.numel() // x.shape[-1] >= 256)
+
+
 def linear(x, W, b=None, precision=None, relu=False):
+    if _bf16_linear_ok(x, W, precision):      # bf16 mode, enough rows: the bf16-in-HBM kernels (operands cast once, weights from their twins)
+        return LinearBf16Fn.apply(x.float(), relu, 1, W, b)[0]
     return LinearFn.apply(x.float(), W, b, config.precision_code(precision), relu)
+
+
+def linear_multi(x, weights, biases, precision=None):
+    """[x W_i^T + b_i] for layers sharing one input (a self-attention's q | k | v projections) -- one launch forward, one grouped
+    weight-gradient launch backward in bf16 mode; one linear() each otherwise"""
+    nl = len(weights)
+    same = all(w.shape == weights[0].shape for w in weights)
+    if 1 <= nl <= 3 and same and _bf16_linear_ok(x, weights[0], precision):
+        return list(LinearBf16Fn.apply(x.float(), False, nl, *weights, *biases))
+    return [linear(x, w, b, precision) for w, b in zip(weights, biases)]
 
 
 class MLPFn(torch.autograd.Function):

@@ -90,7 +90,7 @@ class FusedAdam(torch.optim.Optimizer):
         n = self.flat_param.numel()
         st = _lib.stream_ptr()
         _lib.check(lib.immtsf_adam_prepare(_lib.ptr(self.flat_grad), None, n, _lib.ptr(self.norm_scratch), _lib.ptr(self.step_dev), None,
-                                           None, None, None, None, None, None, st), "adam_prepare")
+                                           None, None, None, None, None, st), "adam_prepare")
         _lib.check(lib.immtsf_adam_range(_lib.ptr(self.flat_param), _lib.ptr(self.flat_grad), None, _lib.ptr(self.exp_avg),
                                          _lib.ptr(self.exp_avg_sq), n, 0, n, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                          float(g["eps"]), float(g["weight_decay"]), _lib.ptr(self.step_dev), float(self._pending_clip),

@@ -448,7 +448,7 @@ class FlatTrainer:
             bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
             self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / (bc2 ** 0.5) + self.eps, value=-self.lr / bc1)
 
-    def adam_prepare(self, pending=None, err=None, skip_out=None, from_wire=False, guard=False, epoch=None):
+    def adam_prepare(self, pending=None, err=None, skip_out=None, from_wire=False, guard=False):
         """first half of clip + Adam as launches the caller places (include/immtsf.h immtsf_adam_prepare): the squared norm of the whole
         gradient (from_wire: of its reduced bf16 wire image) and the step decision into `skip_out`; addresses are raw device pointers"""
         lib = _lib.load()
@@ -461,7 +461,7 @@ class FlatTrainer:
             else:
                 gf = self._grad_store[n:].data_ptr()
         _lib.check(lib.immtsf_adam_prepare(_lib.ptr(self.flat_grad), None if wire is None else wire.data_ptr(), n, _lib.ptr(self.norm_scratch),
-                                           _lib.ptr(self.step_dev), _lib.ptr(self.drop_dev), pending, err, gh, gf, skip_out, epoch,
+                                           _lib.ptr(self.step_dev), _lib.ptr(self.drop_dev), pending, err, gh, gf, skip_out,
                                            _lib.stream_ptr()), "adam_prepare")
 
     def adam_range(self, lo, hi, skip=None, from_wire=False):
@@ -835,24 +835,18 @@ class FlagStep(PhasedStep):
 
     # flag words (int32 offsets into self.flags)
     _B1, _T2, _B2, _FOLD, _TAIL, _P2, _SCHED, _SCHED_TO, _TTF = range(9)        # hand-over flags: cleared at the end of every replay
-    _SEED, _SEED_DONE = 10, 11              # seeds gathered / summed (counting flags: never cleared)
     _COUNT0 = 16                            # one counting flag per announced bucket
-    _ERR, _PENDING, _SKIP, _COMM_DONE, _EPOCH = 40, 41, 42, 43, 44      # guard word, gradient pending, step decision, collectives done, replay number
+    _ERR, _PENDING, _SKIP, _COMM_DONE = 40, 41, 42, 43      # guard word, gradient pending, step decision, collectives done
 
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0, ttf_wgrad_tail: bool = True, seed_reduce: bool = False, merge_adjacent: bool = True):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True, merge_adjacent: bool = True):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
         backbone_buckets: buckets whose gradients are final when backbone_fn's backward (and the gradient collection) has run:
         announced on B instead of waiting for the join.
-        seed_reduce (data parallel, opt-in): a block whose parameter gradients are a linear function of small "seeds" (MMF_XAttn_Add's
-        low-rank form: ops.MMFXRankPFn) has the SEEDS all-reduced (75 KB, fp32) in front of its parameter chain instead of the gradients
-        (8.3 MB) behind it -- half the step's wire bytes.  The price: the parameter branch then WAITS, inside the graph, for the
-        communication stream's collective, so the graph no longer runs to its end on its own: a communication stream that shares a
-        hardware queue with a spinning branch cannot be ridden out, only timed out (comm_timeout_ms).  Off by default for that reason.
         merge_adjacent (data parallel): buckets announced in one burst (they complete at the same moment) that are neighbours in the flat
         buffer get one wire image, one flag and one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
@@ -903,7 +897,6 @@ class FlagStep(PhasedStep):
         W = lambda i: fp + 4 * i        # noqa: E731
         F_B1, F_T2, F_B2, F_P2, F_ERR = W(self._B1), W(self._T2), W(self._B2), W(self._P2), W(self._ERR)
         self._f_err, self._f_pending, self._f_skip, self._f_comm = F_ERR, W(self._PENDING), W(self._SKIP), W(self._COMM_DONE)
-        self._f_seed, self._f_seed_done = W(self._SEED), W(self._SEED_DONE)
         sp = lambda st: st.cuda_stream        # noqa: E731
         tmo = self.timeout_ms
 
@@ -958,50 +951,6 @@ class FlagStep(PhasedStep):
                 announce_range(lo, hi, [b_ for b_ in members if lo <= trainer.ranges[b_][0] and trainer.ranges[b_][1] <= hi and
                                         trainer.ranges[b_][1] > trainer.ranges[b_][0]])
 
-        def prereduced(hook):
-            # a bucket whose gradients already ARE the sum over the ranks (its chain ran on all-reduced seeds): only the wire image
-            # (what the norm and Adam read), no collective
-            bi = getattr(hook, "_immtsf_bucket_index", None)
-            if bi is None or bi in announced:
-                raise RuntimeError("FlagStep: a pre-reduced bucket must be announced once, by its trainer hook")
-            announced.add(bi)
-            lo, hi = trainer.ranges[bi]
-            if bf16_wire and hi > lo:
-                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo,
-                                                  torch.cuda.current_stream().cuda_stream), "f32_to_bf16")
-            self.prereduced.append(bi)
-
-        self.seed_buf, self.prereduced, self._nflags = None, [], 0
-
-        def seed_reduce_fn(stream, segs, produced, hook):
-            # gather the seeds (+ the gradients of the bucket's parameters the chain does not produce: final by now) into one staging
-            # buffer, announce it, wait -- INSIDE the graph -- for the communication stream's all-reduce of this replay, scatter back
-            bi = getattr(hook, "_immtsf_bucket_index", None)
-            if self.seed_buf is not None or bi is None:
-                raise RuntimeError("FlagStep: one seed reduction per step")
-            made = {id(q) for q in produced}
-            segs = list(segs)
-            for q, v in zip(trainer.buckets[bi], trainer._views[bi]):
-                if id(q) not in made:
-                    segs.append((v.data_ptr(), v.numel()))
-            if len(segs) > 8:
-                raise RuntimeError("FlagStep: more than 8 seed segments")
-            total = sum(-(-c // 4) * 4 for _, c in segs)
-            self.seed_buf = torch.empty(total, dtype=torch.float32, device=dev)
-            k = len(segs)
-            offs, o = [], 0
-            for _, c in segs:
-                offs.append(o)
-                o += -(-c // 4) * 4
-            base = self.seed_buf.data_ptr()
-            arr = lambda xs: (C.c_void_p * k)(*xs)        # noqa: E731
-            srcs, stage = arr([p for p, _ in segs]), arr([base + 4 * x for x in offs])
-            cnts = (C.c_int32 * k)(*[c for _, c in segs])
-            _lib.check(lib.immtsf_copy_segments(k, srcs, stage, cnts, stream), "copy_segments")
-            _lib.check(lib.immtsf_flag_bump(W(self._SEED), stream), "flag_bump")
-            _lib.check(lib.immtsf_flag_wait_ge_dev(W(self._SEED_DONE), W(self._EPOCH), F_ERR, self.comm_timeout_ms, stream), "flag_wait_ge_dev")
-            _lib.check(lib.immtsf_copy_segments(k, stage, srcs, cnts, stream), "copy_segments")
-
         def adam(buckets):
             for lo, hi in _runs([trainer.ranges[b] for b in sorted(buckets)]):
                 trainer.adam_range(lo, hi, skip=self._f_skip, from_wire=bf16_wire)
@@ -1015,8 +964,7 @@ class FlagStep(PhasedStep):
                 trainer._grad_zeroed_by_step = True       # (the Adam passes below leave every range zero)
                 trainer.zero_grad()
                 # ---- the previous replay's optimizer step: norm + decision, then the buckets on the branches that read them first
-                trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist,
-                                     epoch=W(self._EPOCH))
+                trainer.adam_prepare(pending=self._f_pending, err=F_ERR, skip_out=self._f_skip, from_wire=bf16_wire, guard=self.dist)
                 if adam_split is None:
                     adam(range(nb))
                     B.wait_stream(T)                  # fork (satisfied when B gets there: nothing runs on B before it)
@@ -1069,8 +1017,7 @@ class FlagStep(PhasedStep):
                 # parameter-gradient tails of the text side (work only the optimizer waits for) go to the parameter branch;
                 # the TAIL flag says their inputs exist
                 tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer,
-                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None,
-                        "seed_reduce": seed_reduce_fn if (self.dist and seed_reduce and P is not B) else None, "prereduced": prereduced}
+                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None}
                 config.param_tail = tail if self._defer > 0 else None
                 trainer._capture_hook = announce if self.dist else None
                 branch_now[0] = "T"
@@ -1098,8 +1045,7 @@ class FlagStep(PhasedStep):
                 fwait(F_B2, T)
                 T.wait_stream(B)                      # join (B's last kernel has run: the flag says so)
                 if P is not B:
-                    # (a parameter branch that waited for a collective -- seed_reduce -- may be as late as the slowest peer)
-                    _lib.check(lib.immtsf_flag_wait(F_P2, F_ERR, self.comm_timeout_ms if self.seed_buf is not None else tmo, sp(T)), "flag_wait")
+                    fwait(F_P2, T)
                     T.wait_stream(P)
                 if self.dist:
                     # what nobody announced is complete now: contiguous runs of the remaining buckets, announced behind the join
@@ -1210,10 +1156,6 @@ class FlagStep(PhasedStep):
         def wait(flag, tmo):
             _lib.check(lib.immtsf_flag_wait_ge(flag, k, self._f_err, tmo, cs), "flag_wait_ge")
 
-        if self.seed_buf is not None:       # the seeds of a block's parameter chain: summed in fp32, handed back to the graph
-            wait(self._f_seed, self.timeout_ms)
-            dist.all_reduce(self.seed_buf, group=t.group)
-            _lib.check(lib.immtsf_flag_bump(self._f_seed_done, cs), "flag_bump")
         last = len(self.segments) - 1
         for i, g in enumerate(self.segments):
             hi = g["hi"]

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from immtsf import config
-from immtsf.ops import full_attention, linear
+from immtsf.ops import full_attention, linear, linear_multi
 
 
 class FullAttention(nn.Module):
@@ -58,9 +58,14 @@ class AttentionLayer(nn.Module):
         B, L, _ = queries.shape
         S, H = keys.shape[1], self.n_heads
         prec = getattr(self.inner_attention, "precision", None)
-        q = linear(queries, self.query_projection.weight, self.query_projection.bias, prec).view(B, L, H, -1)
-        k = linear(keys, self.key_projection.weight, self.key_projection.bias, prec).view(B, S, H, -1)
-        v = linear(values, self.value_projection.weight, self.value_projection.bias, prec).view(B, S, H, -1)
+        if queries is keys and keys is values:      # self-attention: the three projections share their input -- one launch (bf16 mode)
+            q, k, v = linear_multi(queries, [self.query_projection.weight, self.key_projection.weight, self.value_projection.weight],
+                                   [self.query_projection.bias, self.key_projection.bias, self.value_projection.bias], prec)
+            q, k, v = q.view(B, L, H, -1), k.view(B, S, H, -1), v.view(B, S, H, -1)
+        else:
+            q = linear(queries, self.query_projection.weight, self.query_projection.bias, prec).view(B, L, H, -1)
+            k = linear(keys, self.key_projection.weight, self.key_projection.bias, prec).view(B, S, H, -1)
+            v = linear(values, self.value_projection.weight, self.value_projection.bias, prec).view(B, S, H, -1)
         out, attn = self.inner_attention(q, k, v, attn_mask, tau=tau, delta=delta)
         return linear(out.reshape(B, L, -1), self.out_projection.weight, self.out_projection.bias, prec), attn
 

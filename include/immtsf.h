@@ -288,15 +288,6 @@ int immtsf_mmf_xrank_p_backward(const immtsf_fusion_cfg* cfg, const immtsf_xadd_
 int immtsf_mmf_xrank_p_backward_data(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* E_txt, const float* dP,
                                      float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
                                      immtsf_stream_t stream);
-/* The SEEDS of the parameter chain: every parameter gradient immtsf_mmf_xrank_p_backward_params (and ..._pre_z) produces is a LINEAR
- * function -- through parameter-only factors -- of what the data half left in `scratch`: dW_fold and its column sums (z_form 0), or dWc
- * and dbc (z_form 1: the "_z" data half), one contiguous region of *floats floats at *region (alignment padding included), plus d b_HO.
- * A data-parallel step therefore all-reduces the seeds (~75 KB) BEFORE the chain instead of the block's parameter gradients (~14 MB)
- * behind it: the chain of every rank then yields the summed gradients.  seed_refresh: after the region was rewritten, re-derive what
- * the data half derives from it (the bf16 image of dWc). */
-int immtsf_mmf_xrank_seed_region(const immtsf_fusion_cfg* cfg, void* scratch, size_t scratch_bytes, int32_t z_form, float** region,
-                                 size_t* floats);
-int immtsf_mmf_xrank_seed_refresh(const immtsf_fusion_cfg* cfg, void* scratch, size_t scratch_bytes, int32_t z_form, immtsf_stream_t stream);
 int immtsf_mmf_xrank_p_backward_params(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* dbHO, void* workspace,
                                        size_t workspace_bytes, void* scratch, size_t scratch_bytes, const immtsf_xadd_params* grads,
                                        int32_t first, int32_t last, immtsf_stream_t stream);
@@ -564,6 +555,20 @@ int immtsf_bf16_twin_enable(int32_t on);            /* A/B switch for measuremen
 int immtsf_f32_to_bf16(const float* src, void* dst, size_t n, immtsf_stream_t stream);
 /* the reverse (exact widening): used with immtsf_f32_to_bf16 around a bf16 gradient all-reduce (FlatTrainer grad_wire) */
 int immtsf_bf16_to_f32(const void* src, float* dst, size_t n, immtsf_stream_t stream);
+/* nn.Linear in the bf16 dataflow (precision 1) with caller workspaces -- the layers/ mirror's projections (layers/SelfAttention_Family.py:
+ * 199-214 query / key / value / out projection of AttentionLayer; models/PatchTST.py FlattenHead): the input is cast ONCE (x16: M*K bf16,
+ * kept for the backward's weight gradients), the weights come from their registered bf16 twins (else are cast into w16[i]: N*K bf16, may be
+ * NULL when twins exist), and the products run on the bf16-in-HBM kernels (csrc/gemm2.hip / gemm3.hip) instead of converting fp32 tiles
+ * while staging.  nl (1..3) layers that share ONE input -- a self-attention's q | k | v -- are ONE forward launch (y[i]: M x N each) and,
+ * backward, one cast of the nl upstream gradients (dy16: nl*M*N bf16), nl accumulating data-gradient launches (dx = sum_i dy_i W_i;
+ * dx NULL: not needed) and ONE grouped weight-gradient launch (dW[i] = dy_i^T x, db[i] = column sums; db NULL or db[i] NULL: no bias).
+ * act: 0 / 1 (ReLU, nl == 1 only).  W / w16 / b / y / dy / dW / db: HOST arrays of nl device pointers.  IMMTSF_EUNSUPPORTED: K or N
+ * not a multiple of 8, nl > 3 (the caller falls back to immtsf_gemm / immtsf_linear_backward). */
+int immtsf_linear_bf16_forward(int32_t nl, const float* x, void* x16, const float* const* W, void* const* w16, const float* const* b,
+                               float* const* y, int32_t M, int32_t N, int32_t K, int32_t act, immtsf_stream_t stream);
+int immtsf_linear_bf16_backward(int32_t nl, const void* x16, const float* const* W, void* const* w16, const float* const* dy, void* dy16,
+                                float* dx, float* const* dW, float* const* db, int32_t M, int32_t N, int32_t K,
+                                int32_t grads_prezeroed, immtsf_stream_t stream);
 /* batched over (outer, inner) with element strides, used by FullAttention (layers/SelfAttention_Family.py:50-77) */
 int immtsf_gemm_batched(int32_t layout, int32_t precision, const float* A, int32_t lda, int64_t sA_o, int64_t sA_i,
                         const float* B, int32_t ldb, int64_t sB_o, int64_t sB_i, float* C, int32_t ldc, int64_t sC_o,
@@ -652,14 +657,13 @@ int immtsf_adam_apply(float* param, const float* grad, float* exp_avg, float* ex
  *     step not counted) when *pending == 0 (no gradient waits: the first replay, or behind a flush), when *err != 0 (a device-flag
  *     wait of this rank timed out) or when the guard slot is non-zero (guard_h: one bf16 value, guard_f: one float -- the time-out
  *     words of ALL ranks summed by the step's last collective, so every rank drops the same step); *pending is cleared;
- *     *step_dev += 1 unless dropped; *dropout_step_dev += 1 always; *epoch += 1 always (the replay number, for immtsf_flag_wait_ge_dev).
- *     pending / err / guard_* / step_dev / dropout_step_dev / epoch may be NULL.
+ *     *step_dev += 1 unless dropped; *dropout_step_dev += 1 always.  pending / err / guard_* / step_dev / dropout_step_dev may be NULL.
  *   adam_range: the update of elements [lo, hi) of the flat buffers (lo a multiple of 8), clipped by the norm adam_prepare left in
  *     norm_scratch; the gradient is read from grad_h (bf16) when given, else from grad; zero_grad != 0 leaves grad[lo, hi) zero;
  *     the registered bf16 twin of `param` is kept current; *skip != 0: only the zero-fill happens. */
 int immtsf_adam_prepare(const float* grad, const void* grad_h, uint64_t n, float* norm_scratch, int64_t* step_dev,
                         uint64_t* dropout_step_dev, int32_t* pending, const int32_t* err, const void* guard_h, const float* guard_f,
-                        int32_t* skip_out, int32_t* epoch, immtsf_stream_t stream);
+                        int32_t* skip_out, immtsf_stream_t stream);
 int immtsf_adam_range(float* param, float* grad, const void* grad_h, float* exp_avg, float* exp_avg_sq, uint64_t n, uint64_t lo,
                       uint64_t hi, float lr, float beta1, float beta2, float eps, float weight_decay, const int64_t* step_dev,
                       float max_norm, const float* norm_scratch, int32_t zero_grad, const int32_t* skip, immtsf_stream_t stream);
@@ -799,13 +803,6 @@ int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32
 /* immtsf_f32_to_bf16 followed, in the same launch, by immtsf_flag_bump(flag): a gradient bucket's bf16 wire image and its announcement.
  * ticket: a zero-initialised device word the launch leaves zero (launches sharing it must be ordered). */
 int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream);
-/* flag_wait_ge whose target is read from device memory when the kernel runs (*target_dev: e.g. the replay number immtsf_adam_prepare
- * counts): a wait INSIDE a captured step for something a stream outside the graph produces once per replay (the data-parallel step's
- * parameter branch waiting for the all-reduce of MMF_XAttn_Add's chain seeds) */
-int immtsf_flag_wait_ge_dev(int32_t* flag, const int32_t* target_dev, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
-/* k (<= 8) small fp32 segments copied in one launch: dst[i][0 .. counts[i]) = src[i][...].  src / dst / counts are HOST arrays (device
- * pointers inside).  Gathers scattered gradient pieces into one staging buffer for a single collective, and scatters them back. */
-int immtsf_copy_segments(int32_t k, const float* const* src, float* const* dst, const int32_t* counts, immtsf_stream_t stream);
 /* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
  * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (1024 entries) and starts recording, (0) stops;
  * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,

@@ -340,8 +340,7 @@ def _two_rank_flag_worker(rank, world, port, q, wire, layout="phases", inject=Fa
     where it completes and announced by a counting flag, the all-reduces on the communication stream beside the backward, clip + Adam of
     step k at the head of replay k + 1 reading the reduced wire.  Both ranks share cuda:0 over gloo: the control flow is under test,
     not the transport.  layout "phases": bench.py's buckets (FusionModel.grad_buckets: MMF, TTF's three backward phases, the backbone;
-    Adam split over the branches); "seeds": the same with MMF_XAttn_Add's chain seeds all-reduced instead of its gradients (opt-in);
-    "blocks": one bucket per block, everything on the text branch.  inject: after two good steps rank 1
+    Adam split over the branches); "blocks": one bucket per block, everything on the text branch.  inject: after two good steps rank 1
     waits for a flag nobody sets -- BOTH ranks must drop that step."""
     try:
         _two_rank_flag_body(rank, world, port, q, wire, layout, inject)
@@ -368,12 +367,11 @@ def _two_rank_flag_body(rank, world, port, q, wire, layout, inject):
     dist.all_reduce(cnt)
     te = [model.te_scale.weight, model.te_scale.bias, model.te_periodic.weight, model.te_periodic.bias]
     kw = {}
-    if layout in ("phases", "seeds"):
+    if layout == "phases":
         fb, names = fusion.grad_buckets(shard["tp_to_predict"].shape[1])
         buckets = fb + [list(model.parameters())]
         names = list(names) + ["backbone"]
-        kw = {"adam_split": ([i for i, n in enumerate(names) if n.startswith("ttf")], [len(names) - 1], [0]), "backbone_buckets": [len(names) - 1],
-              "seed_reduce": layout == "seeds"}
+        kw = {"adam_split": ([i for i, n in enumerate(names) if n.startswith("ttf")], [len(names) - 1], [0]), "backbone_buckets": [len(names) - 1]}
     else:
         buckets = [list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())]
     tr = FlatTrainer(buckets, lr=1e-2, eps=1e-3, max_norm=0.05, sink_buckets=tuple(range(len(buckets))), sink_shared=te, overlap=True,
@@ -390,10 +388,8 @@ def _two_rank_flag_body(rank, world, port, q, wire, layout, inject):
     def head_fn(pred, E, M, kv, fold):
         return fusion.mmf.forward_loss(pred, E, M, shard["data_to_predict"], shard["mask_predicted_data"], cnt, kv=(kv, fold))
 
-    # (seeds: the graph waits for a gloo collective between two processes that time-share one GPU -- every spin downstream of it needs room)
-    st = FlagStep(tr, text_fn, lambda: model.forecasting(*fc).contiguous(), head_fn, timeout_ms=20 if inject else (2000 if layout == "seeds" else 50), **kw)
+    st = FlagStep(tr, text_fn, lambda: model.forecasting(*fc).contiguous(), head_fn, timeout_ms=20 if inject else 50, **kw)
     assert st.dist and len(st.segments) >= (2 if layout == "blocks" else 3)
-    assert (st.seed_buf is not None and len(st.prereduced) == 1) == (layout == "seeds")
     if not inject:
         for _ in range(3):
             st()
@@ -446,7 +442,7 @@ def _spawn2(target, args):
     return q, procs
 
 
-@pytest.mark.parametrize("layout", ["phases", "blocks", "seeds"])
+@pytest.mark.parametrize("layout", ["phases", "blocks"])
 @pytest.mark.parametrize("wire,tol", [("fp32", 3e-4), ("bf16", 3e-2)])
 def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
     """bench.py's N > 1 default -- FlagStep with the bucketed all-reduce beside the backward, one graph per step, the optimizer at the
@@ -465,8 +461,6 @@ def test_two_rank_flag_step_equals_single_process(wire, tol, layout):
         # MMF's bucket and TTF's first two phases (one burst, one collective) leave the parameter branch, TTF's last phase the text
         # side, the backbone its own branch: the communication stream's order
         assert branches == ["P", "PP", "T", "B"], branches
-    if layout == "seeds":       # MMF's gradients never cross the wire: its chain runs on all-reduced seeds
-        assert branches == ["PP", "T", "B"], branches
     model, fusion, tr, batch = _setup_sinks(dev, 0.0)
     tr.max_norm = 0.05
     f = _loss_fn(model, fusion, batch)

@@ -39,7 +39,7 @@ def main():
     base = st.flags.data_ptr()
     names = {0: "backbone forward done", 4: "head: dY published", 8: "backbone backward done", 12: "fold done", 16: "parameter tail: inputs ready", 20: "parameter branch done",
              4 * st._COMM_DONE: "collectives of the step done"}
-    names[4 * st._SEED], names[4 * st._SEED_DONE], names[4 * st._TTF] = "chain seeds gathered", "chain seeds summed", "TTF phase B data path done"
+    names[4 * st._TTF] = "TTF phase B data path done"
     for i, g in enumerate(st.segments):
         names[g["flag"] - base] = "bucket %s final (%s, %.2f MB bf16)" % ("+".join(w.bucket_names[b] for b in g["buckets"]), g["branch"], (g["hi"] - g["lo"]) * 2 / 1e6)
     _lib.check(lib.immtsf_flag_trace(1), "flag_trace")

@@ -80,32 +80,6 @@ __global__ void flag_wait_ge_guard_kernel(int* flag, int target, int* err, long 
     else *static_cast<float*>(slot) = v;
     __threadfence_system();
 }
-// f32_to_bf16_kernel that also BUMPS a counting flag when the whole image is written (the last workgroup to finish does it: a ticket
-// word the launch leaves zero) -- a gradient bucket's wire image and its announcement in one launch
-__global__ __launch_bounds__(256) void f32_to_bf16_bump_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n, int vec,
-                                                                int* flag, unsigned int* ticket) {
-    const size_t n4 = vec ? n >> 2 : 0, stride = (size_t)gridDim.x * 256, t0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (size_t i = t0; i < n4; i += stride) {
-        const float4 x = reinterpret_cast<const float4*>(src)[i];
-        bf16x4 h;
-        h[0] = (bf16_t)x.x; h[1] = (bf16_t)x.y; h[2] = (bf16_t)x.z; h[3] = (bf16_t)x.w;
-        reinterpret_cast<bf16x4*>(dst)[i] = h;
-    }
-    for (size_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = (bf16_t)src[i];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // (relaxed: the fence above published this workgroup's stores, the flag's release below publishes the count -- an acq_rel
-        // ticket made 4096 workgroups queue for ~100 ns each on one L2 line: the launch took 400 us)
-        const unsigned int done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ft_note(flag, 0);
-            __threadfence_system();
-            __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
 __global__ void flags_clear_kernel(int* flags, int n, int* set_flag = nullptr) {
     if (threadIdx.x == 0) ft_note(flags, 3);
     if ((int)threadIdx.x < n) flags[threadIdx.x] = 0;
@@ -146,15 +120,6 @@ int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32
     if (!flag || !err || !slot || timeout_ms <= 0) return IMMTSF_EINVAL;
     hipLaunchKernelGGL(flag_wait_ge_guard_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, target, err,
                        (long long)timeout_ms * 100000ll, slot, is_bf16 ? 1 : 0);
-    IMMTSF_LAUNCH_CHECK();
-    return IMMTSF_OK;
-}
-int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream) {
-    if (!src || !dst || !flag || !ticket || n == 0) return IMMTSF_EINVAL;
-    const unsigned blocks = (unsigned)((n / 4 + 255) / 256 > 512 ? 512 : (n / 4 + 255) / 256 + 1);      // (few tickets: see the kernel)
-    const int vec = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
-    hipLaunchKernelGGL(f32_to_bf16_bump_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, static_cast<bf16_t*>(dst), n, vec,
-                       flag, ticket);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

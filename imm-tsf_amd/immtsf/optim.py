@@ -102,6 +102,13 @@ class FusedAdam(torch.optim.Optimizer):
     def owns(self, parameters) -> bool:
         return tuple(id(p) for p in parameters) == self._ids
 
+    def state_dict(self):
+        """torch.optim.Adam's format: per parameter `step` (a float32 scalar on the host, what torch's Adam keeps), `exp_avg`, `exp_avg_sq`"""
+        sd = super().state_dict()
+        step = torch.tensor(float(self.step_dev.item()))
+        sd["state"] = {k: {**v, "step": step.clone()} for k, v in sd["state"].items()}
+        return sd
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         # torch put fresh tensors into self.state: copy them into the flat buffers and point the state back at the views

@@ -913,8 +913,6 @@ class FlagStep(PhasedStep):
         announced = set()
         branch_now = ["T"]
 
-        self._tickets = torch.zeros(64, dtype=torch.int32, device=dev)
-
         def announce_range(lo, hi, buckets, burst=None):
             if hi == lo:
                 return
@@ -923,12 +921,11 @@ class FlagStep(PhasedStep):
                 raise RuntimeError("FlagStep: more than 24 announced buckets")
             flag = W(self._COUNT0 + k)
             st = torch.cuda.current_stream().cuda_stream
-            if bf16_wire:       # the wire image, written where the bucket completes, and the announcement: ONE launch -- no conversion
-                # kernel around the collective, no separate flag kernel on the announcing branch
-                _lib.check(lib.immtsf_f32_to_bf16_bump(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, flag,
-                                                       self._tickets.data_ptr() + 4 * k, st), "f32_to_bf16_bump")
-            else:
-                _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
+            if bf16_wire:       # the wire image, written where the bucket completes: no conversion kernel around the collective.  (As ONE
+                # launch with the announcement -- the last workgroup to finish bumps the flag -- it was slower: every workgroup's
+                # release fence is an L2 write-back on this part, 0.63 vs 0.49 ms per step; the kernel boundary does it once.)
+                _lib.check(lib.immtsf_f32_to_bf16(_lib.ptr(trainer.flat_grad[lo:hi]), _lib.ptr(trainer._wire[lo:hi]), hi - lo, st), "f32_to_bf16")
+            _lib.check(lib.immtsf_flag_bump(flag, st), "flag_bump")
             self.segments.append({"flag": flag, "flags": [flag], "lo": lo, "hi": hi, "buckets": tuple(buckets), "branch": branch_now[0] * len(buckets)})
 
         bursts = {}

@@ -800,9 +800,6 @@ int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t tim
 /* flag_wait_ge followed, in the same launch, by immtsf_guard_pack(err, slot, is_bf16): the wait in front of a step's LAST collective */
 int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, void* slot, int32_t is_bf16,
                               immtsf_stream_t stream);
-/* immtsf_f32_to_bf16 followed, in the same launch, by immtsf_flag_bump(flag): a gradient bucket's bf16 wire image and its announcement.
- * ticket: a zero-initialised device word the launch leaves zero (launches sharing it must be ordered). */
-int immtsf_f32_to_bf16_bump(const float* src, void* dst, size_t n, int32_t* flag, uint32_t* ticket, immtsf_stream_t stream);
 /* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
  * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (1024 entries) and starts recording, (0) stops;
  * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,

@@ -15,18 +15,52 @@ from layers.Embed import DataEmbedding
 from models._common import pad_history, plain_instance_norm
 
 
-def FFT_for_Period(x, k=2):
+class PeriodControl:
+    """The period selection of a TimesNet (reference models/TimesNet.py:9-18) decides tensor SHAPES from data: a top-k over the
+    batch-mean spectrum, read on the host (`.detach().cpu().numpy()`: a host sync per TimesBlock and step, in the reference and in this
+    mirror's eager path).  A step engine that replays the step from a hipGraph (immtsf.train.SpecGraphStep) cannot sync: it ASSUMES
+    the selection (`assumed`: per TimesBlock call of a forward, the top-k frequency indices as a tuple), and the captured kernels
+    re-derive it on the device and raise `mismatch` when it differs -- the engine's optimizer is guarded by that word, and the engine
+    repeats a mismatched step eagerly.  `observed`: what the last eager forward selected (the key of the graph to use next)."""
+
+    def __init__(self):
+        self.assumed, self.observed, self.mismatch, self._i, self._dev = None, [], None, 0, {}
+
+    def begin(self):
+        self._i, self.observed = 0, []
+
+    def key(self):
+        return tuple(self.observed)
+
+    def assumed_indices(self, i, device):
+        k = (i, self.assumed[i], str(device))
+        if k not in self._dev:
+            self._dev[k] = torch.tensor(self.assumed[i], dtype=torch.int64, device=device)
+        return self._dev[k]
+
+
+def FFT_for_Period(x, k=2, ctl=None):
     xf = torch.fft.rfft(x, dim=1)
     amp = xf.abs()
     freq = amp.mean(0).mean(-1)
     freq[0] = 0
+    if ctl is not None and ctl.assumed is not None:       # no host sync: shapes from the assumption, the device checks it
+        top_dev = torch.topk(freq, k).indices
+        want = ctl.assumed_indices(ctl._i, x.device)
+        ctl.mismatch.logical_or_((top_dev != want).any().reshape(1).to(ctl.mismatch.dtype))
+        top = torch.tensor(ctl.assumed[ctl._i]).numpy()
+        ctl._i += 1
+        return x.shape[1] // top, amp.mean(-1).index_select(1, want)
     top = torch.topk(freq, k).indices.detach().cpu().numpy()      # host sync, as in the reference (:13-16)
+    if ctl is not None:
+        ctl.observed.append(tuple(int(t) for t in top))
     return x.shape[1] // top, amp.mean(-1)[:, top]
 
 
 class TimesBlock(nn.Module):
     def __init__(self, configs):
         super().__init__()
+        self.ctl = None           # the owning TimesNet's PeriodControl
         self.seq_len, self.pred_len, self.k = configs.input_len, configs.pred_len, configs.top_k
         self.conv = nn.Sequential(Inception_Block_V1(configs.d_model, configs.d_ff, num_kernels=configs.num_kernels),
                                   nn.GELU(),
@@ -35,7 +69,7 @@ class TimesBlock(nn.Module):
     def forward(self, x):
         B, T, N = x.size()
         total = self.seq_len + self.pred_len
-        periods, weight = FFT_for_Period(x, self.k)
+        periods, weight = FFT_for_Period(x, self.k, self.ctl)
         inc1, act, inc2 = self.conv[0], self.conv[1], self.conv[2]
         merged = (x.is_cuda and isinstance(inc1, Inception_Block_V1) and isinstance(inc2, Inception_Block_V1) and isinstance(act, nn.GELU)
                   and getattr(act, "approximate", "none") == "none" and max(len(inc1.kernels), len(inc2.kernels)) <= INCEPTION_MAX)
@@ -67,6 +101,9 @@ class TimesNet(nn.Module):
         self.pred_len = configs.pred_len
         print("seq len:", self.seq_len, self.pred_len)
         self.model = nn.ModuleList([TimesBlock(configs) for _ in range(configs.e_layers)])
+        self.immtsf_period_ctl = PeriodControl()      # (shared by the blocks; plain attribute: not part of the state_dict)
+        for blk in self.model:
+            blk.ctl = self.immtsf_period_ctl
         self.enc_embedding = DataEmbedding(2 * configs.enc_in + 1, configs.d_model, configs.embed, configs.freq, configs.dropout)
         self.layer = configs.e_layers
         self.layer_norm = nn.LayerNorm(configs.d_model)
@@ -75,6 +112,7 @@ class TimesNet(nn.Module):
         self.zeros_pad = torch.zeros(configs.batch_size, max(configs.input_len, configs.pred_len), configs.enc_in).to(configs.device)
 
     def forecasting(self, tp_to_predict, observed_data, observed_tp, observed_mask):
+        self.immtsf_period_ctl.begin()
         tp_to_predict, data, tp, mask, Lp = pad_history(self.zeros_pad, self.input_len, self.pred_len, tp_to_predict,
                                                         observed_data, observed_tp, observed_mask)
         x, means, stdev = plain_instance_norm(data)

@@ -62,22 +62,27 @@ __global__ void flag_wait_ge_kernel(int* flag, int target, int* err, long long t
     ft_note(flag, 2);
     __threadfence_system();
 }
-// flag_wait_ge, then this rank's guard word into `slot` (the step's last collective sums it over the ranks): one launch instead of two on
-// the communication stream's exposed tail
-__global__ void flag_wait_ge_guard_kernel(int* flag, int target, int* err, long long ticks, void* slot, int is_bf16) {
+// flag_wait_ge on up to four flags at once (a collective over several buckets that complete together), then -- slot != null -- this rank's
+// guard word into `slot` (the step's last collective sums it over the ranks): ONE launch on the communication stream's exposed tail
+struct FlagSet { int* f[4]; int n; };
+__global__ void flag_wait_ge_multi_kernel(FlagSet fs, int target, int* err, long long ticks, void* slot, int is_bf16) {
     const long long t0 = wall_clock64();
-    ft_note(flag, 1);
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > ticks) {
-            atomicExch(err, 1);
-            break;
+    for (int i = 0; i < fs.n; ++i) {
+        ft_note(fs.f[i], 1);
+        while (__hip_atomic_load(fs.f[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > ticks) {
+                atomicExch(err, 1);
+                break;
+            }
         }
+        ft_note(fs.f[i], 2);
     }
-    ft_note(flag, 2);
-    const float v = (__hip_atomic_load(err, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1.f : 0.f;
-    if (is_bf16) *static_cast<__bf16*>(slot) = (__bf16)v;
-    else *static_cast<float*>(slot) = v;
+    if (slot) {
+        const float v = (__hip_atomic_load(err, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1.f : 0.f;
+        if (is_bf16) *static_cast<__bf16*>(slot) = (__bf16)v;
+        else *static_cast<float*>(slot) = v;
+    }
     __threadfence_system();
 }
 __global__ void flags_clear_kernel(int* flags, int n, int* set_flag = nullptr) {
@@ -115,11 +120,17 @@ int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t tim
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
-int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, void* slot, int32_t is_bf16,
-                              immtsf_stream_t stream) {
-    if (!flag || !err || !slot || timeout_ms <= 0) return IMMTSF_EINVAL;
-    hipLaunchKernelGGL(flag_wait_ge_guard_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), flag, target, err,
-                       (long long)timeout_ms * 100000ll, slot, is_bf16 ? 1 : 0);
+int immtsf_flag_wait_ge_multi(int32_t n, int32_t* const* flags, int32_t target, int32_t* err, int32_t timeout_ms, void* guard_slot,
+                              int32_t is_bf16, immtsf_stream_t stream) {
+    if (n < 1 || n > 4 || !flags || !err || timeout_ms <= 0) return IMMTSF_EINVAL;
+    FlagSet fs;
+    fs.n = n;
+    for (int i = 0; i < 4; ++i) {
+        fs.f[i] = i < n ? flags[i] : nullptr;
+        if (i < n && !flags[i]) return IMMTSF_EINVAL;
+    }
+    hipLaunchKernelGGL(flag_wait_ge_multi_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), fs, target, err,
+                       (long long)timeout_ms * 100000ll, guard_slot, is_bf16 ? 1 : 0);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

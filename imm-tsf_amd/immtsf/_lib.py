@@ -302,7 +302,7 @@ _PROTOS = {
                                    C.c_float, C.c_float, C.c_int32, C.c_float, c_f32p, c_stream]),
     "immtsf_adam_prepare": (C.c_int, [c_f32p, C.c_void_p, C.c_uint64, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       c_f32p, C.c_void_p, c_stream]),
-    "immtsf_flag_wait_ge_guard": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_flag_wait_ge_multi": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_adam_range": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, c_f32p, C.c_int32, C.c_void_p, c_stream]),
     "immtsf_guard_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, c_stream]),

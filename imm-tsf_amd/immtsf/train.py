@@ -697,6 +697,8 @@ class SpecGraphStep:
             while len(self.graphs) >= self.cap:
                 self.graphs.pop(next(iter(self.graphs)))
             ctl.assumed = list(key)
+            for i in range(len(key)):            # (the assumed indices as device tensors, made BEFORE the capture: a host-to-device copy)
+                ctl.assumed_indices(i, t.flat_param.device)
             t.step_guard = ctl.mismatch.data_ptr()
 
             def fn():
@@ -1178,7 +1180,7 @@ class FlagStep(PhasedStep):
         self.segments = (tseg[:-1] + [g for g in self.segments if g["branch"][0] == "P"] + tseg[-1:] +
                          [g for g in self.segments if g["branch"][0] == "B"] + [g for g in self.segments if g["branch"][0] == "J"])
 
-    def calibrate_comm_order(self, replays: int = 3):
+    def calibrate_comm_order(self, replays: int = 3, merge_tail_us: float = 60.0):
         """order the communication stream's collectives by when their buckets ACTUALLY complete: `replays` replays under the flag
         kernels' own trace (immtsf_flag_trace: device wall clock, nothing serialised), the completion time of every segment (its last
         flag, relative to the previous step's clear) averaged over the replays and -- so that every rank ends up with the SAME order --
@@ -1214,8 +1216,20 @@ class FlagStep(PhasedStep):
         import torch.distributed as dist
         dist.all_reduce(tt, group=self.trainer.group)
         order = sorted(range(len(self.segments)), key=lambda i: (float(tt[i]), i))
-        self.segments = [self.segments[i] for i in order]
-        self.completion_us = [round(float(tt[i]) / self.trainer.world, 1) for i in order]
+        segs = [dict(self.segments[i], done_us=float(tt[i]) / self.trainer.world) for i in order]
+        # the buckets that complete within `merge_tail_us` of the LAST one, when they are one contiguous range of the flat buffer, go out
+        # as ONE collective behind one wait on all their flags: every collective in the exposed tail costs its full latency (three
+        # collectives behind the last flag: +37 us at one rank, ~3 x the RCCL latency at eight); an earlier bucket keeps its own
+        tail = [g for g in segs if segs[-1]["done_us"] - g["done_us"] <= merge_tail_us]
+        if len(tail) > 1:
+            lo, hi = min(g["lo"] for g in tail), max(g["hi"] for g in tail)
+            if sum(g["hi"] - g["lo"] for g in tail) == hi - lo:
+                merged = {"flag": tail[-1]["flag"], "flags": [f for g in tail for f in g["flags"]], "lo": lo, "hi": hi,
+                          "buckets": tuple(b for g in sorted(tail, key=lambda g_: g_["lo"]) for b in g["buckets"]),
+                          "branch": "".join(g["branch"] for g in sorted(tail, key=lambda g_: g_["lo"])), "done_us": tail[-1]["done_us"]}
+                segs = segs[:len(segs) - len(tail)] + [merged]
+        self.segments = segs
+        self.completion_us = [round(g["done_us"], 1) for g in segs]
 
     def _enqueue_collectives(self, cs, k):
         """the step's collectives on the current stream (raw handle `cs`): the seeds, then every segment behind its buckets' flags, this
@@ -1225,21 +1239,22 @@ class FlagStep(PhasedStep):
         n = t.flat_param.numel()
         store = t._wire_store if self._from_wire else t._grad_store
 
-        def wait(flag, tmo):
-            _lib.check(lib.immtsf_flag_wait_ge(flag, k, self._f_err, tmo, cs), "flag_wait_ge")
-
         last = len(self.segments) - 1
         for i, g in enumerate(self.segments):
             hi = g["hi"]
+            slot = None
             if i == last:
                 # this rank's guard word rides with the last collective (written by the wait kernel itself): into the slot behind the
                 # payload when the last range ends there, else as eight elements of its own
-                _lib.check(lib.immtsf_flag_wait_ge_guard(g["flag"], k, self._f_err, self.timeout_ms, store[n:].data_ptr(),
-                                                         1 if self._from_wire else 0, cs), "flag_wait_ge_guard")
+                slot = store[n:].data_ptr()
                 if hi == n:
                     hi = n + 8
-            else:
-                wait(g["flag"], self.timeout_ms)
+            fl = g["flags"]
+            for j in range(0, len(fl), 4):       # ONE wait launch per (up to four) flags of a merged segment
+                part = fl[j:j + 4]
+                arr = (C.c_void_p * len(part))(*part)
+                _lib.check(lib.immtsf_flag_wait_ge_multi(len(part), arr, k, self._f_err, self.timeout_ms, slot if j + 4 >= len(fl) else None,
+                                                         1 if self._from_wire else 0, cs), "flag_wait_ge_multi")
             dist.all_reduce(store[g["lo"]:hi], group=t.group)
             if i == last and hi != n + 8:
                 dist.all_reduce(store[n:n + 8], group=t.group)

@@ -43,7 +43,7 @@ def FFT_for_Period(x, k=2, ctl=None):
     xf = torch.fft.rfft(x, dim=1)
     amp = xf.abs()
     freq = amp.mean(0).mean(-1)
-    freq[0] = 0
+    freq[0:1].zero_()          # (= the reference's `freq[0] = 0`, as a fill kernel: a Python scalar would be a host-to-device copy)
     if ctl is not None and ctl.assumed is not None:       # no host sync: shapes from the assumption, the device checks it
         top_dev = torch.topk(freq, k).indices
         want = ctl.assumed_indices(ctl._i, x.device)

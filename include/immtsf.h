@@ -797,9 +797,10 @@ int immtsf_flags_clear_set(int32_t* flags, int32_t n, int32_t* set_flag, immtsf_
  * spins until *flag - target >= 0 (the consumer of replay k passes k).  Never cleared: a late consumer cannot miss a hand-over. */
 int immtsf_flag_bump(int32_t* flag, immtsf_stream_t stream);
 int immtsf_flag_wait_ge(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, immtsf_stream_t stream);
-/* flag_wait_ge followed, in the same launch, by immtsf_guard_pack(err, slot, is_bf16): the wait in front of a step's LAST collective */
-int immtsf_flag_wait_ge_guard(int32_t* flag, int32_t target, int32_t* err, int32_t timeout_ms, void* slot, int32_t is_bf16,
-                              immtsf_stream_t stream);
+/* flag_wait_ge on n (1..4) flags in ONE launch (a collective over several buckets that complete together; flags: HOST array of device
+ * pointers), followed -- guard_slot != NULL -- by immtsf_guard_pack(err, guard_slot, is_bf16): the wait in front of a step's LAST collective */
+int immtsf_flag_wait_ge_multi(int32_t n, int32_t* const* flags, int32_t target, int32_t* err, int32_t timeout_ms, void* guard_slot,
+                              int32_t is_bf16, immtsf_stream_t stream);
 /* Trace of the flag kernels (a diagnostic: who waited for whom inside a replayed step, on the device's 100 MHz wall clock, without a
  * profiler serialising the branches).  immtsf_flag_trace(1) empties the ring (1024 entries) and starts recording, (0) stops;
  * immtsf_flag_trace_read copies up to max_entries entries of three int64 -- flag address, kind (0 set, 1 wait entered, 2 wait left,

@@ -405,9 +405,9 @@ def _two_rank_flag_body(rank, world, port, q, wire, layout, inject):
         torch.cuda.synchronize()
         st.check()
         p2 = tr.gather(tr.flat_param).clone()
-        keep = st.segments[0]["flag"]
+        keep = st.segments[0]["flags"][0]
         if rank == 1:
-            st.segments[0]["flag"] = st.flags.data_ptr() + 4 * 47        # a word nobody bumps: the communication stream's spin gives up
+            st.segments[0]["flags"][0] = st.flags.data_ptr() + 4 * 47   # a word nobody bumps: the communication stream's spin gives up
         st()
         tr.flush()
         torch.cuda.synchronize()
@@ -418,7 +418,7 @@ def _two_rank_flag_body(rank, world, port, q, wire, layout, inject):
         except _lib.ImmtsfError:
             raised = True
         own = bool(st.timed_out())
-        st.segments[0]["flag"] = keep
+        st.segments[0]["flags"][0] = keep
         st.clear_error()
         st()
         tr.flush()

@@ -48,8 +48,8 @@ CONFIGS = {
                       "(d_m=4096 -> d_txt=768), {B} ragged windows per GPU (N_b~U{{1..32}}, input_len=pred_len=32, C=6), dropout 0.1"),
     "cfg4": dict(backbone="TimesNet", ttf="TTF_RecAvg", mmf="MMF_XAttn_Add", llm="GPT2", d_m=768, C=8, N_MAX=32, T=32, L=32,
                  text="TimesNet (d_model=16, d_ff=32, top_k=5, 2 layers) + TTF_RecAvg + MMF_XAttn_Add, GPT2 dims, {B} ragged windows "
-                      "per GPU (N_b~U{{1..32}}, input_len=pred_len=32, C=8), dropout 0.1; TimesNet's period selection is a host read in the "
-                      "reference: the step is replayed from a hipGraph per selection, checked on the device (immtsf.train.SpecGraphStep)"),
+                      "per GPU (N_b~U{{1..32}}, input_len=pred_len=32, C=8), dropout 0.1; TimesNet's period selection (a host read in the "
+                      "reference) stays on the device, so the step replays from a hipGraph"),
     "cfg5": dict(backbone="TimeLLM", ttf="TTF_T2V_XAttn", mmf="MMF_XAttn_Add", llm="SYN4096", d_m=4096, C=8, N_MAX=4096, T=32, L=32,
                  text="TimeLLM (random-init 6-layer GPT-2 body, offline) + TTF_T2V_XAttn + MMF_XAttn_Add, long ragged note "
                       "sequences (N_b~U{{1..4096}}, d_m=4096 -> d_txt=768), {B} windows per GPU, T=32, C=8, dropout 0.1; TimeLLM "
@@ -332,10 +332,7 @@ class Workload:
         self.model = getattr(importlib.import_module("models." + c["backbone"]), c["backbone"])(a).to(dev).train()
         self.fusion = FusionModel(a).to(dev).train()
         # host syncs inside the backbone (data-dependent shapes / prompt strings) rule out graph capture
-        self.graphable = c["backbone"] in ("tPatchGNN", "PatchTST") or fusion_only
-        # ... except a data-dependent SHAPE decision the model exposes (TimesNet's period selection: models.TimesNet.PeriodControl): the
-        # step is then captured per decision and replayed speculatively (immtsf.train.SpecGraphStep)
-        self.spec_ctl = None if fusion_only else getattr(self.model, "immtsf_period_ctl", None)
+        self.graphable = bool(getattr(self.model, "immtsf_graphable", False)) or fusion_only
         self.fusion_only = bool(fusion_only)
         excl = []      # tPatchGNN's time-embedding parameters: used by the patch encoder AND the decoder, both accumulate
         if c["backbone"] == "tPatchGNN":
@@ -355,7 +352,7 @@ class Workload:
         sinks = tuple(i for i in range(len(buckets)) if i != bb or c["backbone"] == "tPatchGNN")
         self.trainer = FlatTrainer(buckets,
                                    lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl,
-                                   overlap=True, device_step=device_step and (self.graphable or self.spec_ctl is not None), grad_wire=wire,
+                                   overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
         self.trainer.watch(self.model, self.fusion)
         big = c["N_MAX"] * c["d_m"] * windows > (1 << 28)
@@ -489,10 +486,6 @@ def build_step(w, mode="auto", dist_on=False, captured_comm=False):
     from immtsf.train import GraphedStep, PhasedStep
     trainer = w.trainer
     info = {"engine": None, "flag_step_rejected": False}
-    if mode != "eager" and not w.graphable and w.spec_ctl is not None and not dist_on and trainer.device_step:
-        from immtsf.train import SpecGraphStep
-        info["engine"] = "spec-graphed"
-        return SpecGraphStep(trainer, w.loss_fn, w.spec_ctl), info
     if mode == "eager" or not w.graphable:
         info["engine"] = "eager"
         return w.eager_step, info
@@ -951,7 +944,7 @@ def main():
                  overlap=not args.no_overlap, shard_optimizer=sharded, param_wire=pwire, packed_notes=not args.padded_notes,
                  fusion_only=args.fusion_only)
     trainer, fusion = w.trainer, w.fusion
-    use_graph = (not args.no_graph) and (w.graphable or w.spec_ctl is not None)
+    use_graph = (not args.no_graph) and w.graphable
     comm_mode = "bucketed on a side stream" if dist_on else "none"
     # per-variable observation counts of the GLOBAL batch: a property of the data (mask), reduced once when the batch
     # is built, so the step itself has no collective besides the gradient all-reduce
@@ -980,9 +973,6 @@ def main():
                    "flags": "hipGraph replay: 1 graph per step, three branches (text side | backbone | parameter-only work) synchronised by device "
                             "flags; clip + Adam of step k at the head of replay k + 1, each bucket on the branch that reads it first",
                    "phased": "hipGraph replay: 6 single-stream graphs per step on 2 HIP streams (text side | backbone), HIP events between them",
-                   "spec-graphed": "hipGraph replay, one graph per period selection (immtsf.train.SpecGraphStep: the step is captured with "
-                                   "TimesNet's top-k periods assumed, the kernels check the assumption on the device, the guarded optimizer "
-                                   "drops a mismatched replay and the step is repeated eagerly; one 4-byte host read per step)",
                    "graphed": "hipGraph replay (2 graphs/step)", "graphed+captured-comm": "hipGraph replay (2 graphs/step)"}[eng]
     if eng == "graphed" and getattr(step, "single", False):
         launch_mode = "hipGraph replay (1 graph/step: forward, backward, clip + Adam)"
@@ -1121,10 +1111,6 @@ def main():
     elif not args.no_cpu_baseline and rank == 0 and world == 1:
         cpu = cpu_baseline_fusion(args.config)
 
-    if step_info["engine"] == "spec-graphed":
-        extras["spec_graph"] = {"replays": step.replays, "mismatches": step.mismatches, "graphs": len(step.graphs),
-                                "what": "replays whose assumed period selection the device confirmed / refuted (a refuted replay is dropped by "
-                                        "the guarded optimizer and repeated eagerly)"}
     if rank == 0:
         fl_win = fusion_flops_per_window(w.sum_n, W, args.config)
         line = {

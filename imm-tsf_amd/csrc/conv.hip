@@ -29,11 +29,48 @@ __global__ __launch_bounds__(256) void im2col_cl_kernel(ConvDims d, const float*
     }
 }
 
+// ---- the same convolution on TimesNet's period images with the period ON THE DEVICE (reference models/TimesNet.py:9-18, 44-62: the top-k
+// periods are read on the host and decide the image shapes -- two host syncs per step).  Images live "position-major": row l * B + b of
+// a (Lmax * B, C) matrix is position l of window b, so the rows of an image of any length are a PREFIX of the buffer, and the period
+// only enters as numbers the kernels read from device memory: rows = length * B valid rows (length = the series length rounded up to a
+// multiple of the period), image height = length / period, width = period.  Rows beyond `rows` are never read or written; the GEMMs
+// take their row count (NT / NN) or reduction length (TN) from the same device word.
+__global__ void period_rows_kernel(const long long* __restrict__ top, int k, int total, int B, int* __restrict__ period, int* __restrict__ rows) {
+    const int j = threadIdx.x;
+    if (j >= k) return;
+    const int f = (int)top[j];
+    const int p = f > 0 ? total / f : total;
+    const int length = (total % p == 0) ? total : (total / p + 1) * p;
+    period[j] = p;
+    rows[j] = length * B;
+}
+__global__ __launch_bounds__(256) void im2col_period_kernel(int B, int C, int KS, const int* __restrict__ period, const int* __restrict__ rows,
+                                                             const float* __restrict__ x, float* __restrict__ col) {
+    const int row = blockIdx.x;
+    if (row >= *rows) return;
+    const int p = *period, l = row / B, b = row - l * B, H = (*rows / B) / p, h = l / p, w = l - h * p, r = KS >> 1;
+    const int K = KS * KS * C;
+    float* out = col + (size_t)row * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int ci = k % C, tap = k / C, dx = tap % KS, dy = tap / KS;
+        const int hh = h + dy - r, ww = w + dx - r;
+        out[k] = (hh >= 0 && hh < H && ww >= 0 && ww < p) ? x[((size_t)(hh * p + ww) * B + b) * C + ci] : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz, int Cout,
+                                                             const int* __restrict__ rows);
+
 __device__ __forceinline__ float gelu_grad(float z) {
     return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z);
 }
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz, long n) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dz[i] = dy[i] * gelu_grad(z[i]);
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz, int Cout,
+                                                             const int* __restrict__ rows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)*rows * Cout;
     if (i < n) dz[i] = dy[i] * gelu_grad(z[i]);
 }
 
@@ -184,6 +221,74 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
         IMMTSF_LAUNCH_CHECK();
         GemmArgs g = gemm_args(rows, Cin, K2, K2, K2, Cin);
         set_problem(g, 0, colz, Wf, dx, nullptr);
+        CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
+    }
+    return IMMTSF_OK;
+}
+
+/* ---- period images with the period on the device (see the kernels above) ---- */
+int immtsf_period_rows(const int64_t* top, int32_t k, int32_t total, int32_t B, int32_t* period, int32_t* rows, immtsf_stream_t stream) {
+    if (!top || !period || !rows || k < 1 || k > 64 || total <= 0 || B <= 0) return IMMTSF_EINVAL;
+    hipLaunchKernelGGL(period_rows_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const long long*>(top), k, total, B,
+                       period, rows);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
+                                 int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
+                                 immtsf_stream_t stream) {
+    if (!x || !period || !rows || !W_eff || !col || !y || bad_conv(B, Lmax, 1, Cin, Cout, KS) || (act != 0 && act != 2) || (act == 2 && !z_pre))
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int max_rows = B * Lmax, K = KS * KS * Cin;
+    hipLaunchKernelGGL(im2col_period_kernel, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col);
+    IMMTSF_LAUNCH_CHECK();
+    GemmArgs g = gemm_args(max_rows, Cout, K, K, K, Cout);
+    set_problem(g, 0, col, W_eff, y, b_eff);
+    g.p[0].Cpre = act == 2 ? z_pre : nullptr;
+    g.act = act;
+    g.dyn = rows; g.dyn_which = 0;
+    return immtsf_launch_gemm(GEMM_NT, precision, g, s);
+}
+
+size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout) {
+    return immtsf_conv2d_same_cl_scratch_floats(B, Lmax, 1, Cin, KS, Cout);
+}
+
+int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
+                                  const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,
+                                  float* dx, float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream) {
+    if (!col || !dy || !period || !rows || !W_eff || !dW_eff || !db_eff || !scratch || bad_conv(B, Lmax, 1, Cin, Cout, KS) || (act != 0 && act != 2) ||
+        (act == 2 && !z_pre))
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int max_rows = B * Lmax, K = KS * KS * Cin, K2 = KS * KS * Cout;
+    float* dz = scratch + (size_t)max_rows * (K > K2 ? K : K2);
+    const float* g0 = dy;
+    if (act == 2) {
+        const long n = (long)max_rows * Cout;
+        hipLaunchKernelGGL(gelu_bwd_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, z_pre, dz, Cout, rows);
+        IMMTSF_LAUNCH_CHECK();
+        g0 = dz;
+    }
+    {   // dW_eff = g0^T col ; db_eff = column sums of g0 -- over the valid rows
+        GemmArgs h = gemm_args(Cout, K, max_rows, Cout, K, K);
+        set_problem(h, 0, g0, col, dW_eff, nullptr, db_eff);
+        h.dyn = rows; h.dyn_which = 1;
+        CHECK(immtsf_launch_gemm(GEMM_TN, precision, h, s));
+    }
+    if (dx) {
+        float* colz = scratch;
+        float* Wf = scratch + (size_t)max_rows * (K > K2 ? K : K2) + (size_t)max_rows * Cout;
+        const long nw = (long)Cin * K2;
+        hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
+        IMMTSF_LAUNCH_CHECK();
+        hipLaunchKernelGGL(im2col_period_kernel, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz);
+        IMMTSF_LAUNCH_CHECK();
+        GemmArgs g = gemm_args(max_rows, Cin, K2, K2, K2, Cin);
+        set_problem(g, 0, colz, Wf, dx, nullptr);
+        g.dyn = rows; g.dyn_which = 0;
         CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
     return IMMTSF_OK;

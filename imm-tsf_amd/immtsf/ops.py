@@ -1210,6 +1210,57 @@ class Conv2dSameCLFn(torch.autograd.Function):
         return dx, dW, db, None, None, None
 
 
+class Conv2dPeriodFn(torch.autograd.Function):
+    """Conv2dSameCLFn on a TimesNet period image whose period lives ON THE DEVICE (immtsf_conv2d_period_forward / _backward): x, y are
+    position-major (Lmax * B, C) matrices (row l * B + b), `period` / `rows` one device int32 each (ops.period_rows).  Every shape on the
+    host is static, so the step can be captured into a hipGraph; rows beyond `rows` are neither read nor written."""
+
+    @staticmethod
+    def forward(ctx, x, period, rows, Weff, beff, KS, act, precision, B, Lmax):
+        lib = _lib.load()
+        x, Weff, beff = _c(x), _c(Weff), _c(beff)
+        _need_gpu(x, Weff, beff)
+        Cin, Cout = x.shape[1], Weff.shape[0]
+        R, K = B * Lmax, KS * KS * Cin
+        col = torch.empty(R, K, dtype=torch.float32, device=x.device)
+        z = torch.empty(R, Cout, dtype=torch.float32, device=x.device) if act == 2 else None
+        y = torch.empty(R, Cout, dtype=torch.float32, device=x.device)
+        check(lib.immtsf_conv2d_period_forward(precision, ptr(x), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), ptr(beff), Cout, act,
+                                               ptr(col), ptr(z), ptr(y), stream_ptr()), "conv2d_period_forward")
+        ctx.save_for_backward(col, z, Weff, period, rows)
+        ctx.dims = (B, Lmax, Cin, KS, Cout, act, precision)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        col, z, Weff, period, rows = ctx.saved_tensors
+        B, Lmax, Cin, KS, Cout, act, precision = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.zeros(B * Lmax, Cin, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(Weff)
+        db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+        scratch = torch.empty(lib.immtsf_conv2d_period_scratch_floats(B, Lmax, Cin, KS, Cout), dtype=torch.float32, device=dy.device)
+        check(lib.immtsf_conv2d_period_backward(precision, ptr(col), ptr(z), ptr(dy), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), Cout,
+                                                act, ptr(dx), ptr(dW), ptr(db), ptr(scratch), stream_ptr()), "conv2d_period_backward")
+        return dx, None, None, dW, db, None, None, None, None, None
+
+
+def period_rows(top, total, B):
+    """top (k int64 device values: TimesNet's selected frequency indices) -> (period int32 (k), rows int32 (k)) on the device: period =
+    total // top, rows = B * (total rounded up to a multiple of the period) -- models/TimesNet.py:17-18, 50-56 without the host read"""
+    k = top.numel()
+    period = torch.empty(k, dtype=torch.int32, device=top.device)
+    rows = torch.empty(k, dtype=torch.int32, device=top.device)
+    check(_lib.load().immtsf_period_rows(ptr(_c(top)), k, int(total), int(B), ptr(period), ptr(rows), stream_ptr()), "period_rows")
+    return period, rows
+
+
+def conv2d_period(x, period, rows, Weff, beff, KS, B, Lmax, act=None, precision=None):
+    return Conv2dPeriodFn.apply(x.float(), period, rows, Weff, beff, int(KS), 2 if act == "gelu" else 0, config.precision_code(precision),
+                                int(B), int(Lmax))
+
+
 INCEPTION_MAX = 8
 
 

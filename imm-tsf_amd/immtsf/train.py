@@ -649,83 +649,6 @@ class GraphedStep:
         return self.loss
 
 
-class SpecGraphStep:
-    """A training step whose kernel SHAPES hang on a small data-dependent decision, as replayed hipGraphs -- one per decision.
-
-    TimesNet picks its top-k periods from the batch's spectrum on the host (models/TimesNet.py:9-18; two TimesBlocks, two host syncs
-    per step, the second one's input depending on the first one's output), which makes the step a chain of eager launches: 5 ms per
-    step at the benchmark shape, host-bound.  Here the step is captured with the decision ASSUMED (`ctl.assumed`: models.TimesNet.
-    PeriodControl); the captured kernels re-derive the decision on the device and raise `ctl.mismatch` when it differs, and the
-    captured clip + Adam is GUARDED by that word (immtsf_adam_step_guarded: a mismatched replay changes nothing and leaves the
-    gradient buffer zero).  A call = one replay + one 4-byte read; on a mismatch the step is repeated EAGERLY -- a real step, whose
-    forward also yields the new decision -- and the graph of the new decision serves from then on (captured at first use, `cap`
-    kept, least recently used dropped).  The reference's semantics exactly: every step uses the periods its own batch selects.
-
-    loss_fn() runs the forward and returns the scalar loss (inputs: static device tensors); ctl: the model's PeriodControl."""
-
-    def __init__(self, trainer: FlatTrainer, loss_fn, ctl, cap: int = 8, warmup: int = 2):
-        if not trainer.device_step:
-            raise ValueError("SpecGraphStep needs FlatTrainer(device_step=True)")
-        if trainer.collective:
-            raise ValueError("SpecGraphStep is a single-process engine")
-        self.trainer, self.loss_fn, self.ctl, self.cap, self.warmup = trainer, loss_fn, ctl, int(cap), int(warmup)
-        dev = trainer.flat_param.device
-        ctl.mismatch = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.graphs = {}            # key -> GraphedStep (insertion order = recency)
-        self.replays = self.mismatches = 0
-        self.loss = self._eager()   # the first decision comes from a real step
-        self.key = ctl.key()
-
-    def _eager(self):
-        t = self.trainer
-        self.ctl.assumed = None
-        guard, t.step_guard = getattr(t, "step_guard", None), None
-        try:
-            t.zero_grad()
-            loss = self.loss_fn()
-            ops.backward_unit(loss)
-            t.sync_grads()
-            t.step()
-        finally:
-            t.step_guard = guard
-        return loss.detach()
-
-    def _graph(self, key):
-        g = self.graphs.pop(key, None)
-        if g is None:
-            t, ctl = self.trainer, self.ctl
-            while len(self.graphs) >= self.cap:
-                self.graphs.pop(next(iter(self.graphs)))
-            ctl.assumed = list(key)
-            for i in range(len(key)):            # (the assumed indices as device tensors, made BEFORE the capture: a host-to-device copy)
-                ctl.assumed_indices(i, t.flat_param.device)
-            t.step_guard = ctl.mismatch.data_ptr()
-
-            def fn():
-                ctl.mismatch.zero_()
-                return self.loss_fn()
-            try:
-                g = GraphedStep(t, fn, warmup=self.warmup, sched_gate=False)
-            finally:
-                t.step_guard = None
-                ctl.assumed = None
-        self.graphs[key] = g
-        return g
-
-    def __call__(self):
-        g = self._graph(self.key)
-        self.ctl.assumed = list(self.key)       # (host-side bookkeeping only: the replay itself reads nothing from Python)
-        loss = g()
-        self.ctl.assumed = None
-        self.replays += 1
-        if int(self.ctl.mismatch.item()) != 0:   # the one host read of the step (the reference reads twice, mid-forward)
-            self.mismatches += 1
-            loss = self._eager()
-            self.key = self.ctl.key()
-        self.loss = loss
-        return loss
-
-
 class PhasedStep:
     """One training step as SIX single-stream hipGraphs replayed on TWO HIP streams, with HIP events between them.
 

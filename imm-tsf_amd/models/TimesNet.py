@@ -2,65 +2,43 @@
 FFT period selection, 2-D Inception convolutions per period, adaptive aggregation.  Same signature/state_dict.
 DataEmbedding is one HIP kernel, the two Linear maps run on the HIP GEMM, and each Inception block (the mean of six
 same-padded convolutions, layers/Conv_Blocks.py:5-31) runs as ONE merged convolution on channels-last images: im2col +
-MFMA GEMM with the bias / GELU epilogue (immtsf.ops.inception_merge / conv2d_same_cl, csrc/conv.hip).  The FFT period
-selection keeps the reference's host sync (:13-16): the image shapes depend on it."""
+MFMA GEMM with the bias / GELU epilogue (immtsf.ops.inception_merge / conv2d_period, csrc/conv.hip).  The FFT period
+selection -- a host read in the reference (:13-16), because the periods shape its images -- stays on the device: the images are
+prefixes of one static position-major buffer and the kernels read the period from device memory, so forecasting() has no host sync
+and a training step can be replayed from a hipGraph."""
 import torch
 import torch.fft
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf.ops import INCEPTION_MAX, conv2d_same_cl, inception_merge, layer_norm, linear
+from immtsf.ops import INCEPTION_MAX, conv2d_period, conv2d_same_cl, inception_merge, layer_norm, linear, period_rows
 from layers.Conv_Blocks import Inception_Block_V1
 from layers.Embed import DataEmbedding
 from models._common import pad_history, plain_instance_norm
 
 
-class PeriodControl:
-    """The period selection of a TimesNet (reference models/TimesNet.py:9-18) decides tensor SHAPES from data: a top-k over the
-    batch-mean spectrum, read on the host (`.detach().cpu().numpy()`: a host sync per TimesBlock and step, in the reference and in this
-    mirror's eager path).  A step engine that replays the step from a hipGraph (immtsf.train.SpecGraphStep) cannot sync: it ASSUMES
-    the selection (`assumed`: per TimesBlock call of a forward, the top-k frequency indices as a tuple), and the captured kernels
-    re-derive it on the device and raise `mismatch` when it differs -- the engine's optimizer is guarded by that word, and the engine
-    repeats a mismatched step eagerly.  `observed`: what the last eager forward selected (the key of the graph to use next)."""
-
-    def __init__(self):
-        self.assumed, self.observed, self.mismatch, self._i, self._dev = None, [], None, 0, {}
-
-    def begin(self):
-        self._i, self.observed = 0, []
-
-    def key(self):
-        return tuple(self.observed)
-
-    def assumed_indices(self, i, device):
-        k = (i, self.assumed[i], str(device))
-        if k not in self._dev:
-            self._dev[k] = torch.tensor(self.assumed[i], dtype=torch.int64, device=device)
-        return self._dev[k]
-
-
-def FFT_for_Period(x, k=2, ctl=None):
+def FFT_for_Period(x, k=2):
     xf = torch.fft.rfft(x, dim=1)
     amp = xf.abs()
     freq = amp.mean(0).mean(-1)
-    freq[0:1].zero_()          # (= the reference's `freq[0] = 0`, as a fill kernel: a Python scalar would be a host-to-device copy)
-    if ctl is not None and ctl.assumed is not None:       # no host sync: shapes from the assumption, the device checks it
-        top_dev = torch.topk(freq, k).indices
-        want = ctl.assumed_indices(ctl._i, x.device)
-        ctl.mismatch.logical_or_((top_dev != want).any().reshape(1).to(ctl.mismatch.dtype))
-        top = torch.tensor(ctl.assumed[ctl._i]).numpy()
-        ctl._i += 1
-        return x.shape[1] // top, amp.mean(-1).index_select(1, want)
+    freq[0] = 0
     top = torch.topk(freq, k).indices.detach().cpu().numpy()      # host sync, as in the reference (:13-16)
-    if ctl is not None:
-        ctl.observed.append(tuple(int(t) for t in top))
     return x.shape[1] // top, amp.mean(-1)[:, top]
+
+
+def fft_for_period_device(x, k):
+    """FFT_for_Period without the host read: (top (k) int64 frequency indices ON THE DEVICE, weight (B, k)).  The periods they stand
+    for only ever reach kernels as device numbers (ops.period_rows / conv2d_period)."""
+    amp = torch.fft.rfft(x, dim=1).abs()
+    freq = amp.mean(0).mean(-1)
+    freq = torch.cat([freq.new_zeros(1), freq[1:]])       # (= `freq[0] = 0`, without a host-to-device scalar copy)
+    top = torch.topk(freq, k).indices
+    return top, amp.mean(-1).index_select(1, top)
 
 
 class TimesBlock(nn.Module):
     def __init__(self, configs):
         super().__init__()
-        self.ctl = None           # the owning TimesNet's PeriodControl
         self.seq_len, self.pred_len, self.k = configs.input_len, configs.pred_len, configs.top_k
         self.conv = nn.Sequential(Inception_Block_V1(configs.d_model, configs.d_ff, num_kernels=configs.num_kernels),
                                   nn.GELU(),
@@ -69,13 +47,30 @@ class TimesBlock(nn.Module):
     def forward(self, x):
         B, T, N = x.size()
         total = self.seq_len + self.pred_len
-        periods, weight = FFT_for_Period(x, self.k, self.ctl)
         inc1, act, inc2 = self.conv[0], self.conv[1], self.conv[2]
         merged = (x.is_cuda and isinstance(inc1, Inception_Block_V1) and isinstance(inc2, Inception_Block_V1) and isinstance(act, nn.GELU)
                   and getattr(act, "approximate", "none") == "none" and max(len(inc1.kernels), len(inc2.kernels)) <= INCEPTION_MAX)
         if merged:      # one averaged kernel per block and step, shared by all periods
             W1, b1, K1 = inception_merge(inc1)
             W2, b2, K2 = inception_merge(inc2)
+        if merged and T == total:
+            # The periods stay ON THE DEVICE (round 5): the reference reads the top-k on the host (:13-16) because they shape its images --
+            # a host sync per TimesBlock and a step no hipGraph can hold.  Here the series is laid out position-major, (Lmax B, N) with
+            # row l B + b, so an image of ANY length is a prefix of one static buffer, and the period reaches the kernels as a device
+            # number (csrc/conv.hip conv2d_period_*): every host-side shape is static.
+            top, weight = fft_for_period_device(x, self.k)
+            period, rows = period_rows(top, total, B)
+            Lmax = 2 * total                   # length < total + period <= 2 total
+            xl = F.pad(x.transpose(0, 1), (0, 0, 0, 0, 0, Lmax - total)).reshape(Lmax * B, N)
+            res = []
+            for j in range(self.k):
+                img = conv2d_period(xl, period[j:j + 1], rows[j:j + 1], W1, b1, K1, B, Lmax, act="gelu")
+                out = conv2d_period(img, period[j:j + 1], rows[j:j + 1], W2, b2, K2, B, Lmax)
+                res.append(out.view(Lmax, B, N)[:total].transpose(0, 1))
+            res = torch.stack(res, dim=-1)
+            w = F.softmax(weight, dim=1).unsqueeze(1).unsqueeze(1)
+            return (res * w).sum(-1) + x
+        periods, weight = FFT_for_Period(x, self.k)
         res = []
         for period in periods:
             period = int(period)
@@ -94,6 +89,8 @@ class TimesBlock(nn.Module):
 
 
 class TimesNet(nn.Module):
+    immtsf_graphable = True      # (on the GPU: the period selection stays on the device -- TimesBlock.forward -- no host sync in forecasting())
+
     def __init__(self, configs):
         super().__init__()
         self.configs = configs
@@ -101,9 +98,6 @@ class TimesNet(nn.Module):
         self.pred_len = configs.pred_len
         print("seq len:", self.seq_len, self.pred_len)
         self.model = nn.ModuleList([TimesBlock(configs) for _ in range(configs.e_layers)])
-        self.immtsf_period_ctl = PeriodControl()      # (shared by the blocks; plain attribute: not part of the state_dict)
-        for blk in self.model:
-            blk.ctl = self.immtsf_period_ctl
         self.enc_embedding = DataEmbedding(2 * configs.enc_in + 1, configs.d_model, configs.embed, configs.freq, configs.dropout)
         self.layer = configs.e_layers
         self.layer_norm = nn.LayerNorm(configs.d_model)
@@ -112,7 +106,6 @@ class TimesNet(nn.Module):
         self.zeros_pad = torch.zeros(configs.batch_size, max(configs.input_len, configs.pred_len), configs.enc_in).to(configs.device)
 
     def forecasting(self, tp_to_predict, observed_data, observed_tp, observed_mask):
-        self.immtsf_period_ctl.begin()
         tp_to_predict, data, tp, mask, Lp = pad_history(self.zeros_pad, self.input_len, self.pred_len, tp_to_predict,
                                                         observed_data, observed_tp, observed_mask)
         x, means, stdev = plain_instance_norm(data)

@@ -774,6 +774,22 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
                                    int32_t H, int32_t W, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act, float* dx,
                                    float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream);
 
+/* The same convolution on TimesNet's period images with the period ON THE DEVICE (reference models/TimesNet.py:9-18 reads the top-k
+ * periods on the host, :44-62 shapes the images by them: two host syncs per step, and a step that cannot be replayed from a hipGraph).
+ * Images are position-major: row l * B + b of a (Lmax * B, C) matrix is position l of window b (rows beyond the series: zero), so an
+ * image of any length is a prefix of the buffer.  period_rows: top (k int64 device values: the selected frequency indices) -> period[j] =
+ * total / top[j], rows[j] = B * (total rounded up to a multiple of period[j]).  conv2d_period_*: conv2d_same_cl_* on the image
+ * (rows[0] / B / period[0]) x period[0] that the first rows[0] rows hold; `period` / `rows`: ONE device int32 each; rows beyond rows[0]
+ * are neither read nor written (dx rows beyond it are left as they are).  Lmax >= the largest possible length (2 * total). */
+int immtsf_period_rows(const int64_t* top, int32_t k, int32_t total, int32_t B, int32_t* period, int32_t* rows, immtsf_stream_t stream);
+int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
+                                 int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
+                                 immtsf_stream_t stream);
+size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout);
+int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
+                                  const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,
+                                  float* dx, float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream);
+
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,
  * precision, M, N, K, nprob, nbatch, dyn, grid threads, kernel path) and ms[max]; returns the number of records and resets

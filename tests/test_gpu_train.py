@@ -1011,54 +1011,49 @@ def test_cfg2_step_vs_oracle(precision, tol_loss, tol_param, tol_delta, engine):
         config.t2v_form = old_form
 
 
-def test_timesnet_spec_graph_step_trains_like_eager():
-    """immtsf.train.SpecGraphStep on the cfg4 composition (TimesNet + TTF_RecAvg + MMF_XAttn_Add): the step replayed from a hipGraph
-    captured with TimesNet's period selection ASSUMED (models/TimesNet.py:9-18 reads it on the host: two syncs per step) trains exactly
-    like the eager step -- also across a change of the batch that changes the selection: the device refutes the assumption, the guarded
-    optimizer drops that replay, the step is repeated eagerly and a second graph takes over."""
+def test_timesnet_graph_step_trains_like_eager():
+    """The cfg4 composition (TimesNet + TTF_RecAvg + MMF_XAttn_Add) replayed from a hipGraph -- possible because TimesNet's period
+    selection, a host read in the reference (models/TimesNet.py:9-18), stays on the device (models/TimesNet.py fft_for_period_device,
+    csrc/conv.hip conv2d_period_*) -- trains exactly like the eager step, also across a change of the batch that changes the selected
+    periods: the SAME graph serves, the new periods reach its kernels as device numbers."""
     dev = _dev()
     sys.path.insert(0, ROOT)
     import bench
     from immtsf import config
-    from immtsf.train import SpecGraphStep
+    from immtsf.train import GraphedStep
     config.nan_check = "deferred"
     old_drop = bench.P_DROP
     bench.P_DROP = 0.0
 
-    def run(spec):
+    def run(graph):
         w = bench.Workload("cfg4", dev, 16, "fp32", device_step=True)
         w.trainer.eps = 1e-3
         for mm in w.model.modules():
             if isinstance(mm, torch.nn.Dropout):
                 mm.p = 0.0
-        step = SpecGraphStep(w.trainer, w.loss_fn, w.spec_ctl) if spec else w.eager_step
-        if not spec:
-            w.eager_step()                     # (SpecGraphStep's constructor runs one real step)
+        step = GraphedStep(w.trainer, w.loss_fn) if graph else w.eager_step
         b = w.batch
-        keys = []
+        losses = []
         for i in range(8):
             if i == 4:                         # another signal: another spectrum, another top-k
                 L = b["observed_data"].shape[1]
                 t = torch.arange(L, device=dev, dtype=torch.float32).view(1, L, 1)
                 b["observed_data"].copy_(torch.sin(t * 2.3) * 3.0 + torch.cos(t * 0.37) + 0.01 * b["observed_data"])
-            step()
-            keys.append(w.spec_ctl.key() if not spec else step.key)
+            losses.append(float(step()))
         torch.cuda.synchronize()
         p = torch.cat([q.detach().reshape(-1) for q in list(w.model.parameters()) + list(w.fusion.parameters())]).clone()
-        stats = (step.replays, step.mismatches, len(step.graphs)) if spec else None
         w.close()
-        return p, keys, stats
+        return p, losses
 
     try:
-        p_e, k_e, _ = run(False)
-        p_s, k_s, stats = run(True)
+        p_e, l_e = run(False)
+        p_g, l_g = run(True)
     finally:
         bench.P_DROP = old_drop
         config.precision = "fp32"
-    assert k_e == k_s, (k_e, k_s)                      # the same period selections, step by step
-    assert len(set(k_e)) >= 2, k_e                     # ... and the batch change did change them
-    assert stats[1] >= 1 and stats[2] >= 2, stats      # at least one refuted replay, at least two graphs
-    err = float((p_e - p_s).abs().max() / p_e.abs().max())
+    for a, b_ in zip(l_e, l_g):
+        assert abs(a - b_) <= 1e-4 * abs(a), (l_e, l_g)
+    err = float((p_e - p_g).abs().max() / p_e.abs().max())
     assert err < 2e-4, err
 
 

@@ -44,18 +44,23 @@ __global__ void period_rows_kernel(const long long* __restrict__ top, int k, int
     period[j] = p;
     rows[j] = length * B;
 }
+template <typename OT>
 __global__ __launch_bounds__(256) void im2col_period_kernel(int B, int C, int KS, const int* __restrict__ period, const int* __restrict__ rows,
-                                                             const float* __restrict__ x, float* __restrict__ col) {
+                                                             const float* __restrict__ x, OT* __restrict__ col) {
     const int row = blockIdx.x;
     if (row >= *rows) return;
     const int p = *period, l = row / B, b = row - l * B, H = (*rows / B) / p, h = l / p, w = l - h * p, r = KS >> 1;
     const int K = KS * KS * C;
-    float* out = col + (size_t)row * K;
+    OT* out = col + (size_t)row * K;
     for (int k = threadIdx.x; k < K; k += 256) {
         const int ci = k % C, tap = k / C, dx = tap % KS, dy = tap / KS;
         const int hh = h + dy - r, ww = w + dx - r;
-        out[k] = (hh >= 0 && hh < H && ww >= 0 && ww < p) ? x[((size_t)(hh * p + ww) * B + b) * C + ci] : 0.f;
+        out[k] = (OT)((hh >= 0 && hh < H && ww >= 0 && ww < p) ? x[((size_t)(hh * p + ww) * B + b) * C + ci] : 0.f);
     }
+}
+__global__ __launch_bounds__(256) void gelu_rows_kernel(const float* __restrict__ z, float* __restrict__ y, int Cout, const int* __restrict__ rows) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)*rows * Cout;
+    if (i < n) { const float v = z[i]; y[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 }
 __global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ z, float* __restrict__ dz, int Cout,
                                                              const int* __restrict__ rows);
@@ -113,11 +118,12 @@ __global__ __launch_bounds__(256) void inception_unmerge_kernel(int n, int Cin, 
 
 // the data gradient of a same-padded convolution is the convolution of dz with the kernel flipped in both directions and
 // its channel roles swapped: Wf[ci][(dy,dx,co)] = W_eff[co][(KS-1-dy, KS-1-dx, ci)]
-__global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int KS, const float* __restrict__ Weff, float* __restrict__ Wf) {
+template <typename OT>
+__global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int KS, const float* __restrict__ Weff, OT* __restrict__ Wf) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, K2 = (long)KS * KS * Cout;
     if (i >= (long)Cin * K2) return;
     const int ci = (int)(i / K2), k = (int)(i % K2), co = k % Cout, tap = k / Cout, dx = tap % KS, dy = tap / KS;
-    Wf[i] = Weff[(size_t)co * KS * KS * Cin + ((KS - 1 - dy) * KS + (KS - 1 - dx)) * Cin + ci];
+    Wf[i] = (OT)Weff[(size_t)co * KS * KS * Cin + ((KS - 1 - dy) * KS + (KS - 1 - dx)) * Cin + ci];
 }
 
 inline bool bad_conv(int B, int H, int W, int Cin, int Cout, int KS) {
@@ -215,7 +221,7 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
         float* colz = scratch;                                   // rows x K2
         float* Wf = scratch + (size_t)rows * (K > K2 ? K : K2) + (size_t)rows * Cout;     // Cin x K2, behind dz
         const long nw = (long)Cin * K2;
-        hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
+        hipLaunchKernelGGL(flip_weight_kernel<float>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL(im2col_cl_kernel, dim3(rows), dim3(256), 0, s, ConvDims{B, H, W, Cout, KS}, g0, colz);
         IMMTSF_LAUNCH_CHECK();
@@ -235,14 +241,34 @@ int immtsf_period_rows(const int64_t* top, int32_t k, int32_t total, int32_t B, 
     return IMMTSF_OK;
 }
 
+// precision 1: `col` holds the im2col image as bf16 (R * K * 2 bytes suffice), the products run on the bf16-in-HBM kernels with the
+// device row count, GELU is its own row kernel behind the product (z_pre = the product)
+static bool period_hf(int precision, int Cin, int Cout, int KS) { return precision == 1 && ((KS * KS * Cin) % 8) == 0 && ((KS * KS * Cout) % 8) == 0 && (Cin % 8) == 0 && (Cout % 8) == 0; }
+
 int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
                                  int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
-                                 immtsf_stream_t stream) {
+                                 void* w16, immtsf_stream_t stream) {
     if (!x || !period || !rows || !W_eff || !col || !y || bad_conv(B, Lmax, 1, Cin, Cout, KS) || (act != 0 && act != 2) || (act == 2 && !z_pre))
         return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int max_rows = B * Lmax, K = KS * KS * Cin;
-    hipLaunchKernelGGL(im2col_period_kernel, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col);
+    if (period_hf(precision, Cin, Cout, KS) && w16) {
+        bf16_t* col16 = reinterpret_cast<bf16_t*>(col);
+        hipLaunchKernelGGL(im2col_period_kernel<bf16_t>, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col16);
+        IMMTSF_LAUNCH_CHECK();
+        CHECK(launch_f32_to_bf16(W_eff, w16, (size_t)Cout * K, s));
+        GemmArgs g = gemm_args(max_rows, Cout, K, K, K, Cout);
+        set_problem2(g, 0, mat(nullptr, col16), cmat(W_eff, w16), mat(act == 2 ? z_pre : y), b_eff);
+        g.dyn = rows; g.dyn_which = 0;
+        CHECK(immtsf_launch_gemm(GEMM_NT, 1, g, s));
+        if (act == 2) {
+            const long n = (long)max_rows * Cout;
+            hipLaunchKernelGGL(gelu_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, z_pre, y, Cout, rows);
+            IMMTSF_LAUNCH_CHECK();
+        }
+        return IMMTSF_OK;
+    }
+    hipLaunchKernelGGL(im2col_period_kernel<float>, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col);
     IMMTSF_LAUNCH_CHECK();
     GemmArgs g = gemm_args(max_rows, Cout, K, K, K, Cout);
     set_problem(g, 0, col, W_eff, y, b_eff);
@@ -253,17 +279,18 @@ int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, i
 }
 
 size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout) {
-    return immtsf_conv2d_same_cl_scratch_floats(B, Lmax, 1, Cin, KS, Cout);
+    return immtsf_conv2d_same_cl_scratch_floats(B, Lmax, 1, Cin, KS, Cout) + (size_t)B * Lmax * Cout;      // (+ the bf16 image of dz)
 }
 
 int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,
-                                  float* dx, float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream) {
+                                  float* dx, float* dW_eff, float* db_eff, float* scratch, void* w16, immtsf_stream_t stream) {
     if (!col || !dy || !period || !rows || !W_eff || !dW_eff || !db_eff || !scratch || bad_conv(B, Lmax, 1, Cin, Cout, KS) || (act != 0 && act != 2) ||
         (act == 2 && !z_pre))
         return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int max_rows = B * Lmax, K = KS * KS * Cin, K2 = KS * KS * Cout;
+    const bool hf = period_hf(precision, Cin, Cout, KS) && w16;
     float* dz = scratch + (size_t)max_rows * (K > K2 ? K : K2);
     const float* g0 = dy;
     if (act == 2) {
@@ -271,6 +298,32 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
         hipLaunchKernelGGL(gelu_bwd_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dy, z_pre, dz, Cout, rows);
         IMMTSF_LAUNCH_CHECK();
         g0 = dz;
+    }
+    float* Wf = scratch + (size_t)max_rows * (K > K2 ? K : K2) + (size_t)max_rows * Cout;      // Cin x K2 (fp32, or its bf16 image), behind dz
+    if (hf) {
+        // bf16 images: g0 (behind the flipped kernel), the forward's col, the flipped kernel, the im2col image of g0
+        bf16_t* g016 = reinterpret_cast<bf16_t*>(Wf + (size_t)Cin * K2);
+        CHECK(launch_f32_to_bf16(g0, g016, (size_t)max_rows * Cout, s));       // (rows beyond the valid ones: never read -- dynamic M / K)
+        {   // dW_eff = g0^T col ; db_eff = column sums of g0 -- over the valid rows
+            GemmArgs h = gemm_args(Cout, K, max_rows, Cout, K, K);
+            set_problem2(h, 0, cmat(g0, g016), cmat(nullptr, col), mat(dW_eff), nullptr, db_eff);
+            h.dyn = rows; h.dyn_which = 1;
+            CHECK(immtsf_launch_gemm(GEMM_TN, 1, h, s));
+        }
+        if (dx) {
+            bf16_t* colz16 = reinterpret_cast<bf16_t*>(scratch);
+            bf16_t* Wf16 = reinterpret_cast<bf16_t*>(Wf);
+            const long nw = (long)Cin * K2;
+            hipLaunchKernelGGL(flip_weight_kernel<bf16_t>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf16);
+            IMMTSF_LAUNCH_CHECK();
+            hipLaunchKernelGGL(im2col_period_kernel<bf16_t>, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz16);
+            IMMTSF_LAUNCH_CHECK();
+            GemmArgs g = gemm_args(max_rows, Cin, K2, K2, K2, Cin);
+            set_problem2(g, 0, mat(nullptr, colz16), mat(nullptr, Wf16), mat(dx), nullptr);
+            g.dyn = rows; g.dyn_which = 0;
+            CHECK(immtsf_launch_gemm(GEMM_NT, 1, g, s));
+        }
+        return IMMTSF_OK;
     }
     {   // dW_eff = g0^T col ; db_eff = column sums of g0 -- over the valid rows
         GemmArgs h = gemm_args(Cout, K, max_rows, Cout, K, K);
@@ -280,11 +333,10 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
     }
     if (dx) {
         float* colz = scratch;
-        float* Wf = scratch + (size_t)max_rows * (K > K2 ? K : K2) + (size_t)max_rows * Cout;
         const long nw = (long)Cin * K2;
-        hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
+        hipLaunchKernelGGL(flip_weight_kernel<float>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
         IMMTSF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(im2col_period_kernel, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz);
+        hipLaunchKernelGGL(im2col_period_kernel<float>, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz);
         IMMTSF_LAUNCH_CHECK();
         GemmArgs g = gemm_args(max_rows, Cin, K2, K2, K2, Cin);
         set_problem(g, 0, colz, Wf, dx, nullptr);

@@ -1222,11 +1222,14 @@ class Conv2dPeriodFn(torch.autograd.Function):
         _need_gpu(x, Weff, beff)
         Cin, Cout = x.shape[1], Weff.shape[0]
         R, K = B * Lmax, KS * KS * Cin
-        col = torch.empty(R, K, dtype=torch.float32, device=x.device)
+        hf = precision == 1 and Cin % 8 == 0 and Cout % 8 == 0      # bf16 mode: the im2col image as bf16, the products on the bf16-in-HBM kernels
+        col = torch.empty(R, K, dtype=torch.bfloat16 if hf else torch.float32, device=x.device)
+        w16 = torch.empty(Cout, K, dtype=torch.bfloat16, device=x.device) if hf else None
         z = torch.empty(R, Cout, dtype=torch.float32, device=x.device) if act == 2 else None
         y = torch.empty(R, Cout, dtype=torch.float32, device=x.device)
         check(lib.immtsf_conv2d_period_forward(precision, ptr(x), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), ptr(beff), Cout, act,
-                                               ptr(col), ptr(z), ptr(y), stream_ptr()), "conv2d_period_forward")
+                                               ptr(col), ptr(z), ptr(y), ptr(w16), stream_ptr()), "conv2d_period_forward")
+        ctx.hf = hf
         ctx.save_for_backward(col, z, Weff, period, rows)
         ctx.dims = (B, Lmax, Cin, KS, Cout, act, precision)
         return y
@@ -1241,8 +1244,9 @@ class Conv2dPeriodFn(torch.autograd.Function):
         dW = torch.empty_like(Weff)
         db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
         scratch = torch.empty(lib.immtsf_conv2d_period_scratch_floats(B, Lmax, Cin, KS, Cout), dtype=torch.float32, device=dy.device)
+        w16 = torch.empty(1, dtype=torch.bfloat16, device=dy.device) if ctx.hf else None       # (only says "the bf16 path": images live in scratch)
         check(lib.immtsf_conv2d_period_backward(precision, ptr(col), ptr(z), ptr(dy), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), Cout,
-                                                act, ptr(dx), ptr(dW), ptr(db), ptr(scratch), stream_ptr()), "conv2d_period_backward")
+                                                act, ptr(dx), ptr(dW), ptr(db), ptr(scratch), ptr(w16), stream_ptr()), "conv2d_period_backward")
         return dx, None, None, dW, db, None, None, None, None, None
 
 

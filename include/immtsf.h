@@ -780,15 +780,17 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
  * image of any length is a prefix of the buffer.  period_rows: top (k int64 device values: the selected frequency indices) -> period[j] =
  * total / top[j], rows[j] = B * (total rounded up to a multiple of period[j]).  conv2d_period_*: conv2d_same_cl_* on the image
  * (rows[0] / B / period[0]) x period[0] that the first rows[0] rows hold; `period` / `rows`: ONE device int32 each; rows beyond rows[0]
- * are neither read nor written (dx rows beyond it are left as they are).  Lmax >= the largest possible length (2 * total). */
+ * are neither read nor written (dx rows beyond it are left as they are).  Lmax >= the largest possible length (2 * total).
+ * w16 (Cout * KS*KS*Cin bf16, may be NULL): with precision 1 and channel counts that are multiples of 8 the im2col image is written as
+ * bf16 (`col` then holds R * K bf16 values) and the products run on the bf16-in-HBM kernels; forward and backward get the same choice. */
 int immtsf_period_rows(const int64_t* top, int32_t k, int32_t total, int32_t B, int32_t* period, int32_t* rows, immtsf_stream_t stream);
 int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
                                  int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
-                                 immtsf_stream_t stream);
+                                 void* w16, immtsf_stream_t stream);
 size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout);
 int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,
-                                  float* dx, float* dW_eff, float* db_eff, float* scratch, immtsf_stream_t stream);
+                                  float* dx, float* dW_eff, float* db_eff, float* scratch, void* w16, immtsf_stream_t stream);
 
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,

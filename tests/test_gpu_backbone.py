@@ -137,6 +137,56 @@ def test_backbone_wrappers_vs_reference_golden(name):
     assert not bad, bad
 
 
+def test_timesnet_bf16_period_images_vs_fp32():
+    """TimesNet at the cfg4 dimensions (d_model 16, d_ff 32, top_k 5, 2 layers, 64 windows): the bf16 mode's period images -- im2col
+    written as bf16, the products on the bf16-in-HBM kernels with the device-side row count (csrc/conv.hip conv2d_period_*) -- against
+    the exact-fp32 mode of the same module (which the reference golden pins): forecast and every parameter gradient inside the bf16
+    band; and forecasting() reads nothing on the host (the period selection stays on the device): it runs under hipGraph capture."""
+    dev = _dev()
+    from immtsf import config
+    from models.TimesNet import TimesNet
+    cfg = types.SimpleNamespace(input_len=32, pred_len=32, d_model=16, d_ff=32, n_heads=2, e_layers=2, dropout=0.0, factor=5,
+                                activation="gelu", enc_in=8, c_out=8, batch_size=64, device=str(dev), moving_avg=5, top_k=5,
+                                num_kernels=6, embed="fixed", freq="h")
+    torch.manual_seed(0)
+    m = TimesNet(cfg).to(dev).train()
+    g = torch.Generator().manual_seed(4)
+    data = torch.randn(64, 32, 8, generator=g).to(dev)
+    mask = (torch.rand(64, 32, 8, generator=g) < 0.7).float().to(dev)
+    tp = torch.sort(torch.rand(64, 32, generator=g), 1).values.to(dev)
+    tpp = torch.sort(torch.rand(64, 32, generator=g), 1).values.to(dev)
+    up = torch.randn(64, 32, 8, generator=g).to(dev)
+    res = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            config.precision = prec
+            m.zero_grad()
+            out = m.forecasting(tpp, data * mask, tp, mask)
+            (out * up).sum().backward()
+            res[prec] = (out.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        # no host read inside forecasting(): capturable
+        config.precision = "bf16"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            m.forecasting(tpp, data * mask, tp, mask)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr), torch.no_grad():
+            o2 = m.forecasting(tpp, data * mask, tp, mask)
+        gr.replay()
+        torch.cuda.synchronize()
+        assert _rel(o2, res["bf16"][0]) < 1e-5
+    finally:
+        config.precision = "fp32"
+    assert _rel(res["bf16"][0], res["fp32"][0]) < 3e-2
+    gmax = max(float(v.abs().max()) for v in res["fp32"][1].values())
+    bad = {k: _rel(res["bf16"][1][k], v, floor=1e-2 * gmax) for k, v in res["fp32"][1].items()}
+    bad = {k: v for k, v in bad.items() if v > 5e-2}
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("B,N,M,D,nd,hop", [(64, 8, 2, 32, 10, 1), (3, 5, 3, 16, 4, 2), (2, 41, 2, 64, 10, 1), (1, 1, 1, 8, 2, 3)])
 def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
     """the one-workgroup-per-cell adaptive-graph kernel (forward, and the recomputing backward with atomically

@@ -44,19 +44,52 @@ __global__ void period_rows_kernel(const long long* __restrict__ top, int k, int
     period[j] = p;
     rows[j] = length * B;
 }
-template <typename OT>
+constexpr int IMP_ROWS = 4;       // rows per workgroup (one row per workgroup was dispatch-bound: 8192 workgroups of 4 KB each, 20 us)
+__device__ __forceinline__ void imp_store(float* o, const float (&v)[8], int n) {
+    if (n == 8) { reinterpret_cast<float4*>(o)[0] = make_float4(v[0], v[1], v[2], v[3]); reinterpret_cast<float4*>(o)[1] = make_float4(v[4], v[5], v[6], v[7]); }
+    else o[0] = v[0];
+}
+__device__ __forceinline__ void imp_store(bf16_t* o, const float (&v)[8], int n) {
+    if (n == 8) {
+        typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+        bf16x8_t h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8_t*>(o) = h;
+    } else o[0] = (bf16_t)v[0];
+}
+// an item = CW channels of one tap of one row (CW = 8 when the channel count is a multiple of 8: two 16-byte loads, one 16- or 32-byte
+// store; else 1); a workgroup's IMP_ROWS rows are one flat item range
+template <typename OT, int CW>
 __global__ __launch_bounds__(256) void im2col_period_kernel(int B, int C, int KS, const int* __restrict__ period, const int* __restrict__ rows,
                                                              const float* __restrict__ x, OT* __restrict__ col) {
-    const int row = blockIdx.x;
-    if (row >= *rows) return;
-    const int p = *period, l = row / B, b = row - l * B, H = (*rows / B) / p, h = l / p, w = l - h * p, r = KS >> 1;
-    const int K = KS * KS * C;
-    OT* out = col + (size_t)row * K;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const int ci = k % C, tap = k / C, dx = tap % KS, dy = tap / KS;
-        const int hh = h + dy - r, ww = w + dx - r;
-        out[k] = (OT)((hh >= 0 && hh < H && ww >= 0 && ww < p) ? x[((size_t)(hh * p + ww) * B + b) * C + ci] : 0.f);
+    const int nrows = *rows, p = *period, H = (nrows / B) / p, r = KS >> 1, K = KS * KS * C;
+    const int cpt = C / CW, per_row = KS * KS * cpt, row0 = blockIdx.x * IMP_ROWS;
+    const int nr = min(IMP_ROWS, nrows - row0);
+    for (int it = threadIdx.x; it < nr * per_row; it += 256) {
+        const int rr = it / per_row, q = it - rr * per_row, tap = q / cpt, cc = (q - tap * cpt) * CW;
+        const int row = row0 + rr, l = row / B, b = row - l * B, h = l / p, w = l - h * p;
+        const int dy = tap / KS, dx = tap - dy * KS, hh = h + dy - r, ww = w + dx - r;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < p) {
+            const float* src = x + ((size_t)(hh * p + ww) * B + b) * C + cc;
+            if (CW == 8) {
+                const float4 a = reinterpret_cast<const float4*>(src)[0], c = reinterpret_cast<const float4*>(src)[1];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+            } else v[0] = src[0];
+        }
+        imp_store(col + (size_t)row * K + tap * C + cc, v, CW);
     }
+}
+template <typename OT>
+static void launch_im2col_period(int B, int C, int KS, const int* period, const int* rows, const float* x, OT* col, int max_rows, hipStream_t s) {
+    const dim3 grid(cdiv(max_rows, IMP_ROWS));
+    if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(col) & 15) == 0)
+        hipLaunchKernelGGL((im2col_period_kernel<OT, 8>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col);
+    else
+        hipLaunchKernelGGL((im2col_period_kernel<OT, 1>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col);
 }
 __global__ __launch_bounds__(256) void gelu_rows_kernel(const float* __restrict__ z, float* __restrict__ y, int Cout, const int* __restrict__ rows) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)*rows * Cout;
@@ -247,16 +280,16 @@ static bool period_hf(int precision, int Cin, int Cout, int KS) { return precisi
 
 int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
                                  int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
-                                 void* w16, immtsf_stream_t stream) {
+                                 void* w16, int32_t w16_ready, immtsf_stream_t stream) {
     if (!x || !period || !rows || !W_eff || !col || !y || bad_conv(B, Lmax, 1, Cin, Cout, KS) || (act != 0 && act != 2) || (act == 2 && !z_pre))
         return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int max_rows = B * Lmax, K = KS * KS * Cin;
     if (period_hf(precision, Cin, Cout, KS) && w16) {
         bf16_t* col16 = reinterpret_cast<bf16_t*>(col);
-        hipLaunchKernelGGL(im2col_period_kernel<bf16_t>, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col16);
+        launch_im2col_period<bf16_t>(B, Cin, KS, period, rows, x, col16, max_rows, s);
         IMMTSF_LAUNCH_CHECK();
-        CHECK(launch_f32_to_bf16(W_eff, w16, (size_t)Cout * K, s));
+        if (!w16_ready) CHECK(launch_f32_to_bf16(W_eff, w16, (size_t)Cout * K, s));      // (the caller casts once per block and step otherwise)
         GemmArgs g = gemm_args(max_rows, Cout, K, K, K, Cout);
         set_problem2(g, 0, mat(nullptr, col16), cmat(W_eff, w16), mat(act == 2 ? z_pre : y), b_eff);
         g.dyn = rows; g.dyn_which = 0;
@@ -268,7 +301,7 @@ int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, i
         }
         return IMMTSF_OK;
     }
-    hipLaunchKernelGGL(im2col_period_kernel<float>, dim3(max_rows), dim3(256), 0, s, B, Cin, KS, period, rows, x, col);
+    launch_im2col_period<float>(B, Cin, KS, period, rows, x, col, max_rows, s);
     IMMTSF_LAUNCH_CHECK();
     GemmArgs g = gemm_args(max_rows, Cout, K, K, K, Cout);
     set_problem(g, 0, col, W_eff, y, b_eff);
@@ -316,7 +349,7 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
             const long nw = (long)Cin * K2;
             hipLaunchKernelGGL(flip_weight_kernel<bf16_t>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf16);
             IMMTSF_LAUNCH_CHECK();
-            hipLaunchKernelGGL(im2col_period_kernel<bf16_t>, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz16);
+            launch_im2col_period<bf16_t>(B, Cout, KS, period, rows, g0, colz16, max_rows, s);
             IMMTSF_LAUNCH_CHECK();
             GemmArgs g = gemm_args(max_rows, Cin, K2, K2, K2, Cin);
             set_problem2(g, 0, mat(nullptr, colz16), mat(nullptr, Wf16), mat(dx), nullptr);
@@ -336,7 +369,7 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
         const long nw = (long)Cin * K2;
         hipLaunchKernelGGL(flip_weight_kernel<float>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf);
         IMMTSF_LAUNCH_CHECK();
-        hipLaunchKernelGGL(im2col_period_kernel<float>, dim3(max_rows), dim3(256), 0, s, B, Cout, KS, period, rows, g0, colz);
+        launch_im2col_period<float>(B, Cout, KS, period, rows, g0, colz, max_rows, s);
         IMMTSF_LAUNCH_CHECK();
         GemmArgs g = gemm_args(max_rows, Cin, K2, K2, K2, Cin);
         set_problem(g, 0, colz, Wf, dx, nullptr);

@@ -567,6 +567,10 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
             if (splits < 1) splits = 1;
         }
     }
+    // ... and for SKINNY weight gradients (M <= 64 output rows, N >= 1024: TimesNet's merged convolution kernels, 16 / 32 x 3872 from ~4000
+    // rows): one row of 64 x 64 tiles leaves three quarters of the chip idle for 32 us -- the reduction is cut four ways
+    if (can_split && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && Mmax <= 64 && g.N >= 1024 && g.K >= 2048 && !long_k)
+        splits = 4;
     if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
             // (fill kernels, not memset nodes: see gemm.hip)

@@ -209,7 +209,7 @@ _PROTOS = {
                                                                                                                c_stream]),
     "immtsf_period_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_stream]),
     "immtsf_conv2d_period_forward": (C.c_int, [C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
-                                               C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),
+                                               C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int32, c_stream]),
     "immtsf_conv2d_period_scratch_floats": (C.c_size_t, [C.c_int32] * 5),
     "immtsf_conv2d_period_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                                 c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),

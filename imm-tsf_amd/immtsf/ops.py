@@ -1216,7 +1216,7 @@ class Conv2dPeriodFn(torch.autograd.Function):
     host is static, so the step can be captured into a hipGraph; rows beyond `rows` are neither read nor written."""
 
     @staticmethod
-    def forward(ctx, x, period, rows, Weff, beff, KS, act, precision, B, Lmax):
+    def forward(ctx, x, period, rows, Weff, beff, KS, act, precision, B, Lmax, w16):
         lib = _lib.load()
         x, Weff, beff = _c(x), _c(Weff), _c(beff)
         _need_gpu(x, Weff, beff)
@@ -1224,11 +1224,15 @@ class Conv2dPeriodFn(torch.autograd.Function):
         R, K = B * Lmax, KS * KS * Cin
         hf = precision == 1 and Cin % 8 == 0 and Cout % 8 == 0      # bf16 mode: the im2col image as bf16, the products on the bf16-in-HBM kernels
         col = torch.empty(R, K, dtype=torch.bfloat16 if hf else torch.float32, device=x.device)
-        w16 = torch.empty(Cout, K, dtype=torch.bfloat16, device=x.device) if hf else None
+        ready = 1 if (hf and w16 is not None) else 0                # (the kernel's bf16 image, cast once by the caller for all periods)
+        if hf and w16 is None:
+            w16 = torch.empty(Cout, K, dtype=torch.bfloat16, device=x.device)
+        if not hf:
+            w16 = None
         z = torch.empty(R, Cout, dtype=torch.float32, device=x.device) if act == 2 else None
         y = torch.empty(R, Cout, dtype=torch.float32, device=x.device)
         check(lib.immtsf_conv2d_period_forward(precision, ptr(x), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), ptr(beff), Cout, act,
-                                               ptr(col), ptr(z), ptr(y), ptr(w16), stream_ptr()), "conv2d_period_forward")
+                                               ptr(col), ptr(z), ptr(y), ptr(w16), ready, stream_ptr()), "conv2d_period_forward")
         ctx.hf = hf
         ctx.save_for_backward(col, z, Weff, period, rows)
         ctx.dims = (B, Lmax, Cin, KS, Cout, act, precision)
@@ -1240,14 +1244,16 @@ class Conv2dPeriodFn(torch.autograd.Function):
         col, z, Weff, period, rows = ctx.saved_tensors
         B, Lmax, Cin, KS, Cout, act, precision = ctx.dims
         dy = dy.contiguous()
-        dx = torch.zeros(B * Lmax, Cin, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
+        # (rows beyond the image are never written: whoever consumes dx -- the previous period convolution, the slice that crops the
+        # series -- never reads them either)
+        dx = torch.empty(B * Lmax, Cin, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(Weff)
         db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
         scratch = torch.empty(lib.immtsf_conv2d_period_scratch_floats(B, Lmax, Cin, KS, Cout), dtype=torch.float32, device=dy.device)
         w16 = torch.empty(1, dtype=torch.bfloat16, device=dy.device) if ctx.hf else None       # (only says "the bf16 path": images live in scratch)
         check(lib.immtsf_conv2d_period_backward(precision, ptr(col), ptr(z), ptr(dy), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), Cout,
                                                 act, ptr(dx), ptr(dW), ptr(db), ptr(scratch), ptr(w16), stream_ptr()), "conv2d_period_backward")
-        return dx, None, None, dW, db, None, None, None, None, None
+        return dx, None, None, dW, db, None, None, None, None, None, None
 
 
 def period_rows(top, total, B):
@@ -1260,9 +1266,9 @@ def period_rows(top, total, B):
     return period, rows
 
 
-def conv2d_period(x, period, rows, Weff, beff, KS, B, Lmax, act=None, precision=None):
+def conv2d_period(x, period, rows, Weff, beff, KS, B, Lmax, act=None, precision=None, w16=None):
     return Conv2dPeriodFn.apply(x.float(), period, rows, Weff, beff, int(KS), 2 if act == "gelu" else 0, config.precision_code(precision),
-                                int(B), int(Lmax))
+                                int(B), int(Lmax), w16)
 
 
 INCEPTION_MAX = 8

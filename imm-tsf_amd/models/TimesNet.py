@@ -11,6 +11,7 @@ import torch.fft
 import torch.nn as nn
 import torch.nn.functional as F
 
+from immtsf import config
 from immtsf.ops import INCEPTION_MAX, conv2d_period, conv2d_same_cl, inception_merge, layer_norm, linear, period_rows
 from layers.Conv_Blocks import Inception_Block_V1
 from layers.Embed import DataEmbedding
@@ -62,10 +63,12 @@ class TimesBlock(nn.Module):
             period, rows = period_rows(top, total, B)
             Lmax = 2 * total                   # length < total + period <= 2 total
             xl = F.pad(x.transpose(0, 1), (0, 0, 0, 0, 0, Lmax - total)).reshape(Lmax * B, N)
+            bf16 = config.precision == "bf16"
+            W1h, W2h = (W1.detach().to(torch.bfloat16), W2.detach().to(torch.bfloat16)) if bf16 else (None, None)      # one cast for all periods
             res = []
             for j in range(self.k):
-                img = conv2d_period(xl, period[j:j + 1], rows[j:j + 1], W1, b1, K1, B, Lmax, act="gelu")
-                out = conv2d_period(img, period[j:j + 1], rows[j:j + 1], W2, b2, K2, B, Lmax)
+                img = conv2d_period(xl, period[j:j + 1], rows[j:j + 1], W1, b1, K1, B, Lmax, act="gelu", w16=W1h)
+                out = conv2d_period(img, period[j:j + 1], rows[j:j + 1], W2, b2, K2, B, Lmax, w16=W2h)
                 res.append(out.view(Lmax, B, N)[:total].transpose(0, 1))
             res = torch.stack(res, dim=-1)
             w = F.softmax(weight, dim=1).unsqueeze(1).unsqueeze(1)

@@ -782,11 +782,12 @@ int immtsf_conv2d_same_cl_backward(int32_t precision, const float* col, const fl
  * (rows[0] / B / period[0]) x period[0] that the first rows[0] rows hold; `period` / `rows`: ONE device int32 each; rows beyond rows[0]
  * are neither read nor written (dx rows beyond it are left as they are).  Lmax >= the largest possible length (2 * total).
  * w16 (Cout * KS*KS*Cin bf16, may be NULL): with precision 1 and channel counts that are multiples of 8 the im2col image is written as
- * bf16 (`col` then holds R * K bf16 values) and the products run on the bf16-in-HBM kernels; forward and backward get the same choice. */
+ * bf16 (`col` then holds R * K bf16 values) and the products run on the bf16-in-HBM kernels; forward and backward get the same choice;
+ * w16_ready != 0: w16 already holds W_eff's bf16 image (a caller that convolves several period images with one kernel casts it once). */
 int immtsf_period_rows(const int64_t* top, int32_t k, int32_t total, int32_t B, int32_t* period, int32_t* rows, immtsf_stream_t stream);
 int immtsf_conv2d_period_forward(int32_t precision, const float* x, int32_t B, int32_t Lmax, const int32_t* period, const int32_t* rows, int32_t Cin,
                                  int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act, float* col, float* z_pre, float* y,
-                                 void* w16, immtsf_stream_t stream);
+                                 void* w16, int32_t w16_ready, immtsf_stream_t stream);
 size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout);
 int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,

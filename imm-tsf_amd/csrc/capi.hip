@@ -333,7 +333,8 @@ int immtsf_abi_sizes(int32_t* out, int32_t max) {
         (int32_t)sizeof(immtsf_xadd_params), (int32_t)sizeof(immtsf_gr_params), (int32_t)sizeof(immtsf_ttcn_params),
         (int32_t)sizeof(immtsf_gcn_params), (int32_t)sizeof(immtsf_decoder_params), (int32_t)sizeof(immtsf_time2vec_params),
         (int32_t)sizeof(immtsf_encoder_layer_cfg), (int32_t)sizeof(immtsf_encoder_layer_params), (int32_t)sizeof(immtsf_ffn_block_cfg),
-        (int32_t)sizeof(immtsf_ffn_block_params), (int32_t)sizeof(immtsf_store), (int32_t)sizeof(immtsf_note_index)};
+        (int32_t)sizeof(immtsf_ffn_block_params), (int32_t)sizeof(immtsf_store), (int32_t)sizeof(immtsf_note_index),
+        (int32_t)sizeof(immtsf_lowrank_grad)};
     if (!out || max <= 0) return IMMTSF_ABI_NSTRUCTS;
     for (int i = 0; i < IMMTSF_ABI_NSTRUCTS && i < max; ++i) out[i] = sz[i];
     return IMMTSF_ABI_NSTRUCTS;

@@ -12,6 +12,7 @@
 // and 4-5 backward per convolution instead of 6 MIOpen convolutions + stack + mean (and their 12+ backward kernels).
 #include "../../include/immtsf.h"
 #include "block_util.hpp"
+#include "rowops.hpp"
 
 namespace {
 
@@ -60,10 +61,14 @@ __device__ __forceinline__ void imp_store(bf16_t* o, const float (&v)[8], int n)
 }
 // an item = CW channels of one tap of one row (CW = 8 when the channel count is a multiple of 8: two 16-byte loads, one 16- or 32-byte
 // store; else 1); a workgroup's IMP_ROWS rows are one flat item range
+// (grid.y: the period images of a batched call -- image z reads x + z xs, writes col + z cs, takes period[z] / rows[z])
 template <typename OT, int CW>
 __global__ __launch_bounds__(256) void im2col_period_kernel(int B, int C, int KS, const int* __restrict__ period, const int* __restrict__ rows,
-                                                             const float* __restrict__ x, OT* __restrict__ col) {
-    const int nrows = *rows, p = *period, H = (nrows / B) / p, r = KS >> 1, K = KS * KS * C;
+                                                             const float* __restrict__ x, OT* __restrict__ col, long xs, long cs) {
+    const int z = blockIdx.y;
+    x += (size_t)z * xs;
+    col += (size_t)z * cs;
+    const int nrows = rows[z], p = period[z], H = (nrows / B) / p, r = KS >> 1, K = KS * KS * C;
     const int cpt = C / CW, per_row = KS * KS * cpt, row0 = blockIdx.x * IMP_ROWS;
     const int nr = min(IMP_ROWS, nrows - row0);
     for (int it = threadIdx.x; it < nr * per_row; it += 256) {
@@ -84,12 +89,46 @@ __global__ __launch_bounds__(256) void im2col_period_kernel(int B, int C, int KS
     }
 }
 template <typename OT>
-static void launch_im2col_period(int B, int C, int KS, const int* period, const int* rows, const float* x, OT* col, int max_rows, hipStream_t s) {
-    const dim3 grid(cdiv(max_rows, IMP_ROWS));
-    if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(col) & 15) == 0)
-        hipLaunchKernelGGL((im2col_period_kernel<OT, 8>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col);
+static void launch_im2col_period(int B, int C, int KS, const int* period, const int* rows, const float* x, OT* col, int max_rows, hipStream_t s,
+                                 int k = 1, long xs = 0, long cs = 0) {
+    const dim3 grid(cdiv(max_rows, IMP_ROWS), k);
+    if ((C & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(col) & 15) == 0 && (xs & 3) == 0 && (cs & 7) == 0)
+        hipLaunchKernelGGL((im2col_period_kernel<OT, 8>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col, xs, cs);
     else
-        hipLaunchKernelGGL((im2col_period_kernel<OT, 1>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col);
+        hipLaunchKernelGGL((im2col_period_kernel<OT, 1>), grid, dim3(256), 0, s, B, C, KS, period, rows, x, col, xs, cs);
+}
+__device__ __forceinline__ float pg_gelu_grad(float z) { return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * expf(-0.5f * z * z); }
+// the gradient entering a batched period convolution's backward: g0 = dy (act == 0) or dy gelu'(z_pre), as fp32 (dz, act != 0 only: what
+// the im2col of the data gradient reads) and as the bf16 image the weight-gradient product reads; rows beyond an image's are skipped
+__global__ __launch_bounds__(256) void period_g0_kernel(const float* __restrict__ dy, const float* __restrict__ z_pre, float* __restrict__ dz,
+                                                         bf16_t* __restrict__ g16, int C, long per, const int* __restrict__ rows) {
+    const int z = blockIdx.y;
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long)rows[z] * C) return;
+    const size_t at = (size_t)z * per + i;
+    float4 v = *reinterpret_cast<const float4*>(dy + at);
+    if (z_pre) {
+        const float4 q = *reinterpret_cast<const float4*>(z_pre + at);
+        v = make_float4(v.x * pg_gelu_grad(q.x), v.y * pg_gelu_grad(q.y), v.z * pg_gelu_grad(q.z), v.w * pg_gelu_grad(q.w));
+        *reinterpret_cast<float4*>(dz + at) = v;
+    }
+    const bf16x4 h = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+    *reinterpret_cast<bf16x4*>(g16 + at) = h;
+}
+// dx[row, :] = sum over the k images that hold the row (row < rows[z]) of dxk[z, row, :]   (one input shared by every period image)
+__global__ __launch_bounds__(256) void period_sum_kernel(const float* __restrict__ dxk, int k, long per, const int* __restrict__ rows, int C,
+                                                          float* __restrict__ dx) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= per) return;
+    const int row = (int)(i / C);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < k; ++z) {
+        if (row < rows[z]) {
+            const float4 v = *reinterpret_cast<const float4*>(dxk + (size_t)z * per + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(dx + i) = a;
 }
 __global__ __launch_bounds__(256) void gelu_rows_kernel(const float* __restrict__ z, float* __restrict__ y, int Cout, const int* __restrict__ rows) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)*rows * Cout;
@@ -110,6 +149,48 @@ __global__ __launch_bounds__(256) void gelu_bwd_rows_kernel(const float* __restr
                                                              const int* __restrict__ rows) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)*rows * Cout;
     if (i < n) dz[i] = dy[i] * gelu_grad(z[i]);
+}
+
+// ---- TimesBlock's adaptive aggregation over the k period images (reference models/TimesNet.py:80-86: stack, softmax weights, sum, residual)
+// on the position-major images: out[b, t, :] = x[b, t, :] + sum_j w[b, j] Y[j, t B + b, :],  t < total
+__global__ __launch_bounds__(256) void period_agg_fwd_kernel(const float* __restrict__ Y, const float* __restrict__ w, const float* __restrict__ x,
+                                                              int B, int total, long per, int N, int k, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * total * N) return;
+    const int n = (int)(i % N);
+    const long bt = i / N;
+    const int t = (int)(bt % total), b = (int)(bt / total);
+    float a = x[i];
+    for (int j = 0; j < k; ++j) a = fmaf(w[b * k + j], Y[(size_t)j * per + ((size_t)t * B + b) * N + n], a);
+    out[i] = a;
+}
+// dY[j, t B + b, :] = w[b, j] dout[b, t, :] for t < total, 0 for the rows the crop dropped (every row up to Lmax: the images' own rows end
+// somewhere in between)
+__global__ __launch_bounds__(256) void period_agg_bwd_y_kernel(const float* __restrict__ w, const float* __restrict__ dout, int B, int total, int Lmax,
+                                                                int N, int k, float* __restrict__ dY) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, per = (long)Lmax * B * N;
+    if (i >= per * k) return;
+    const int j = (int)(i / per);
+    const long r = i - (long)j * per;
+    const int n = (int)(r % N);
+    const long lb = r / N;
+    const int b = (int)(lb % B), t = (int)(lb / B);
+    dY[i] = t < total ? w[b * k + j] * dout[((size_t)b * total + t) * N + n] : 0.f;
+}
+// dw[b, j] = sum_{t, n} dout[b, t, n] Y[j, t B + b, n]: one workgroup per window
+__global__ __launch_bounds__(256) void period_agg_bwd_w_kernel(const float* __restrict__ Y, const float* __restrict__ dout, int B, int total, long per,
+                                                                int N, int k, float* __restrict__ dw) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    for (int j = 0; j < k; ++j) {
+        float a = 0.f;
+        for (int x = threadIdx.x; x < total * N; x += 256) {
+            const int t = x / N, n = x - t * N;
+            a = fmaf(dout[((size_t)b * total + t) * N + n], Y[(size_t)j * per + ((size_t)t * B + b) * N + n], a);
+        }
+        a = block_sum(a, red);
+        if (threadIdx.x == 0) dw[b * k + j] = a;
+    }
 }
 
 struct KernelPtrs { const float* w[IMMTSF_INCEPTION_MAX]; const float* b[IMMTSF_INCEPTION_MAX]; };
@@ -376,6 +457,138 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
         g.dyn = rows; g.dyn_which = 0;
         CHECK(immtsf_launch_gemm(GEMM_NT, precision, g, s));
     }
+    return IMMTSF_OK;
+}
+
+/* ---- k period images in ONE call (TimesNet's TimesBlock: top-k periods, the same merged kernel for each; reference models/TimesNet.py:62-79
+ * loops over the periods).  x: one input shared by every image (x_stride == 0) or k inputs x + j x_stride; period / rows: k device
+ * numbers each (immtsf_period_rows); y, z_pre: (k, B*Lmax, Cout); col: k im2col images of B*Lmax x KS*KS*Cin (bf16 in bf16 mode, else
+ * fp32).  bf16 mode (the shapes period_hf takes): one im2col launch, one product launch with the k images along grid.z (bias + GELU in
+ * its epilogue) -- 2 launches instead of 3 k.  Otherwise: the k single-image calls.  k <= 16. */
+int immtsf_conv2d_periods_forward(int32_t precision, const float* x, int64_t x_stride, int32_t B, int32_t Lmax, int32_t k, const int32_t* period,
+                                  const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act,
+                                  float* col, float* z_pre, float* y, void* w16, int32_t w16_ready, immtsf_stream_t stream) {
+    if (!x || !period || !rows || !W_eff || !col || !y || k < 1 || k > 16 || x_stride < 0 || bad_conv(B, Lmax, 1, Cin, Cout, KS) ||
+        (act != 0 && act != 2) || (act == 2 && !z_pre))
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = B * Lmax, K = KS * KS * Cin;
+    const size_t per_y = (size_t)R * Cout, per_col = (size_t)R * K;
+    if (!(period_hf(precision, Cin, Cout, KS) && w16)) {
+        for (int j = 0; j < k; ++j)
+            CHECK(immtsf_conv2d_period_forward(precision, x + (size_t)j * x_stride, B, Lmax, period + j, rows + j, Cin, KS, W_eff, b_eff, Cout, act,
+                                               col + (size_t)j * per_col, act == 2 ? z_pre + (size_t)j * per_y : nullptr, y + (size_t)j * per_y, nullptr, 0,
+                                               stream));
+        return IMMTSF_OK;
+    }
+    bf16_t* col16 = reinterpret_cast<bf16_t*>(col);
+    launch_im2col_period<bf16_t>(B, Cin, KS, period, rows, x, col16, R, s, k, (long)x_stride, (long)per_col);
+    IMMTSF_LAUNCH_CHECK();
+    if (!w16_ready) CHECK(launch_f32_to_bf16(W_eff, w16, (size_t)Cout * K, s));
+    GemmArgs g = gemm_args(R, Cout, K, K, K, Cout);
+    set_problem2(g, 0, mat(nullptr, col16), cmat(W_eff, w16), mat(y), b_eff);
+    g.p[0].Cpre = act == 2 ? z_pre : nullptr;
+    g.act = act;
+    g.dyn = rows; g.dyn_which = 0; g.dyn_stride = 1;
+    g.zbatch = k; g.zsA = (long)per_col; g.zsB = 0; g.zsC = (long)per_y;
+    return immtsf_launch_gemm2(GEMM_NT, g, s);
+}
+
+size_t immtsf_conv2d_periods_scratch_floats(int32_t B, int32_t Lmax, int32_t k, int32_t Cin, int32_t KS, int32_t Cout) {
+    // k x [im2col image of g0 | dz | bf16 image of g0], the flipped kernel, k x (B Lmax, Cin) data gradients of a shared input, one
+    // kernel-gradient slot (the single-image fallback sums through it)
+    const size_t R = (size_t)B * Lmax, K = (size_t)KS * KS * Cin, K2 = (size_t)KS * KS * Cout;
+    return (size_t)k * (R * (K > K2 ? K : K2) + 2 * R * Cout + R * Cin) + (size_t)Cin * K2 + 64 + (size_t)Cout * K + Cout + 256;
+}
+
+/* dy (k, B*Lmax, Cout) -> dx ((B*Lmax, Cin) summed over the images when dx_shared, else (k, B*Lmax, Cin); may be NULL), dW_eff / db_eff: the
+ * SUM over the k images, ACCUMULATED by atomics -- the caller hands them in zeroed (one fill for both when they are one buffer).  Rows of
+ * dx beyond an image's rows are not written (a shared dx: zero where no image holds the row). */
+int immtsf_conv2d_periods_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax, int32_t k,
+                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout,
+                                   int32_t act, float* dx, int32_t dx_shared, float* dW_eff, float* db_eff, float* scratch, void* w16,
+                                   immtsf_stream_t stream) {
+    if (!col || !dy || !period || !rows || !W_eff || !dW_eff || !db_eff || !scratch || k < 1 || k > 16 || bad_conv(B, Lmax, 1, Cin, Cout, KS) ||
+        (act != 0 && act != 2) || (act == 2 && !z_pre))
+        return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = B * Lmax, K = KS * KS * Cin, K2 = KS * KS * Cout;
+    const size_t per_y = (size_t)R * Cout, per_col = (size_t)R * K, per_colz = (size_t)R * K2, per_x = (size_t)R * Cin;
+    const size_t colz_floats = (size_t)k * R * (K > K2 ? K : K2);
+    float* dz = scratch + colz_floats;                       // k x R x Cout
+    float* g16f = dz + (size_t)k * per_y;                    // k x R x Cout bf16 (in float slots)
+    float* Wf = g16f + (size_t)k * per_y;                    // Cin x K2 (+ 64)
+    float* dxk = Wf + (size_t)Cin * K2 + 64;                 // k x R x Cin
+    float* tW = dxk + (size_t)k * per_x;                     // Cout x K, then Cout
+    const bool hf = period_hf(precision, Cin, Cout, KS) && w16;
+    if (!hf) {
+        // the k single-image calls (their scratch: the head of this one, up to and including the flipped kernel's slot); their kernel
+        // gradients are summed through a slot of the scratch
+        float* tb = tW + (size_t)Cout * K;
+        for (int j = 0; j < k; ++j) {
+            float* dxj = dx ? (dx_shared ? dxk + (size_t)j * per_x : dx + (size_t)j * per_x) : nullptr;
+            CHECK(immtsf_conv2d_period_backward(precision, col + (size_t)j * per_col, act == 2 ? z_pre + (size_t)j * per_y : nullptr,
+                                                dy + (size_t)j * per_y, B, Lmax, period + j, rows + j, Cin, KS, W_eff, Cout, act, dxj, tW, tb, scratch,
+                                                nullptr, stream));
+            CHECK(launch_axpy(tW, 1.f, dW_eff, Cout * K, 1, s));
+            CHECK(launch_axpy(tb, 1.f, db_eff, Cout, 1, s));
+        }
+    } else {
+        bf16_t* g16 = reinterpret_cast<bf16_t*>(g16f);
+        const long n4 = ((long)per_y + 3) / 4;
+        hipLaunchKernelGGL(period_g0_kernel, dim3((unsigned)((n4 + 255) / 256), k), dim3(256), 0, s, dy, act == 2 ? z_pre : nullptr, dz, g16, Cout,
+                           (long)per_y, rows);
+        IMMTSF_LAUNCH_CHECK();
+        const float* g0 = act == 2 ? dz : dy;
+        {   // dW_eff += sum_z g0_z^T col_z ; db_eff += column sums -- the k images along grid.z, fp32 atomics into the zeroed buffers
+            GemmArgs h = gemm_args(Cout, K, R, Cout, K, K);
+            set_problem2(h, 0, cmat(nullptr, g16), cmat(nullptr, col), mat(dW_eff), nullptr, db_eff);
+            h.dyn = rows; h.dyn_which = 1; h.dyn_stride = 1;
+            h.zbatch = k; h.zsA = (long)per_y; h.zsB = (long)per_col; h.zsC = 0; h.atomic_c = 1; h.c_prezeroed = 1;
+            CHECK(immtsf_launch_gemm2(GEMM_TN, h, s));
+        }
+        if (dx) {
+            bf16_t* colz16 = reinterpret_cast<bf16_t*>(scratch);
+            bf16_t* Wf16 = reinterpret_cast<bf16_t*>(Wf);
+            const long nw = (long)Cin * K2;
+            hipLaunchKernelGGL(flip_weight_kernel<bf16_t>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf16);
+            IMMTSF_LAUNCH_CHECK();
+            launch_im2col_period<bf16_t>(B, Cout, KS, period, rows, g0, colz16, R, s, k, (long)per_y, (long)per_colz);
+            IMMTSF_LAUNCH_CHECK();
+            GemmArgs g = gemm_args(R, Cin, K2, K2, K2, Cin);
+            set_problem2(g, 0, mat(nullptr, colz16), mat(nullptr, Wf16), mat(dx_shared ? dxk : dx), nullptr);
+            g.dyn = rows; g.dyn_which = 0; g.dyn_stride = 1;
+            g.zbatch = k; g.zsA = (long)per_colz; g.zsB = 0; g.zsC = (long)per_x;
+            CHECK(immtsf_launch_gemm2(GEMM_NT, g, s));
+        }
+    }
+    if (dx && dx_shared) {
+        const long n4 = ((long)per_x + 3) / 4;
+        hipLaunchKernelGGL(period_sum_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, dxk, k, (long)per_x, rows, Cin, dx);
+        IMMTSF_LAUNCH_CHECK();
+    }
+    return IMMTSF_OK;
+}
+
+int immtsf_period_aggregate_forward(const float* Y, const float* w, const float* x, int32_t B, int32_t total, int32_t Lmax, int32_t N, int32_t k,
+                                    float* out, immtsf_stream_t stream) {
+    if (!Y || !w || !x || !out || B <= 0 || total <= 0 || Lmax < total || N <= 0 || k < 1 || k > 16) return IMMTSF_EINVAL;
+    const long n = (long)B * total * N;
+    hipLaunchKernelGGL(period_agg_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), Y, w, x, B, total,
+                       (long)Lmax * B * N, N, k, out);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+int immtsf_period_aggregate_backward(const float* Y, const float* w, const float* dout, int32_t B, int32_t total, int32_t Lmax, int32_t N, int32_t k,
+                                     float* dY, float* dw, immtsf_stream_t stream) {
+    if (!Y || !w || !dout || !dY || !dw || B <= 0 || total <= 0 || Lmax < total || N <= 0 || k < 1 || k > 16) return IMMTSF_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long n = (long)Lmax * B * N * k;
+    hipLaunchKernelGGL(period_agg_bwd_y_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, dout, B, total, Lmax, N, k, dY);
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL(period_agg_bwd_w_kernel, dim3(B), dim3(256), 0, s, Y, dout, B, total, (long)Lmax * B * N, N, k, dw);
+    IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
 

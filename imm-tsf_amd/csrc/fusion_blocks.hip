@@ -176,7 +176,7 @@ T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
     w.P = k.take<float>(R * H);
     w.q = k.take<float>(d);
     w.qs = k.take<float>(d);
-    w.xpre = k.take<float>(BT * d);
+    w.xpre = t2v_mix_wide_ok((int)d) ? nullptr : k.take<float>(BT * d);      // (the wide mix + LayerNorm kernel keeps x_pre in registers)
     w.xhat = k.take<float>(BT * d);
     w.rstd = k.take<float>(BT);
     w.zln = k.take_mat(BT * d, !hf, hf);
@@ -336,20 +336,26 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
-    CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
-                             drop, SITE_T2V_ATTN, s));
     // bf16 dataflow: x_hat's only reader is the LayerNorm backward with sums, which widens on load -- it is stored as bf16 alone (in the
     // fp32 image's place) wherever that kernel will take the shape (the backward makes the same test)
     const bool compact = hf && ln_sums_compact_ok(BT, d);
     float* xhat_f = compact ? nullptr : w.xhat;
     void* xhat_h = compact ? static_cast<void*>(w.xhat) : nullptr;
-    const DropCfg nodrop = DropCfg{0, 0.f, 1.f, nullptr};
-    if (cfg->form & IMMTSF_FORM_NO_PROJ) {       // proj_out is the consumer's (immtsf_mmf_xrank_p_forward_z): hand over Z itself
-        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
-                                    hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr, nullptr, nodrop, 0, xhat_h);
+    const bool noproj = (cfg->form & IMMTSF_FORM_NO_PROJ) != 0;
+    // what leaves the LayerNorm: Z itself to the caller (proj_out is the consumer's: immtsf_mmf_xrank_p_forward_z) -- fp32 unless the
+    // caller reads the bf16 image only (IMMTSF_FORM_HALF_OUT) -- or the operand of proj_out
+    void* z_h = noproj ? (hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr) : w.zln.h;
+    float* z_f = noproj ? (((cfg->form & IMMTSF_FORM_HALF_OUT) && hf && cfg->out_h) ? nullptr : E_txt) : w.zln.f;
+    if (t2v_mix_wide_ok(d)) {
+        CHECK(launch_t2v_mix_ln_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P,
+                                    p->ln_w, p->ln_b, 1e-5f, xhat_f, xhat_h, w.rstd, z_f, z_h, drop, SITE_T2V_ATTN, drop, SITE_T2V_OUT, s));
+    } else {
+        CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
+                                 drop, SITE_T2V_ATTN, s));
+        const DropCfg nodrop = DropCfg{0, 0.f, 1.f, nullptr};
+        CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, z_f, drop, SITE_T2V_OUT, s, z_h, nullptr, nodrop, 0, xhat_h));
     }
-    CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, w.zln.f, drop, SITE_T2V_OUT, s, w.zln.h, nullptr, nodrop, 0,
-                               xhat_h));
+    if (noproj) return IMMTSF_OK;
     {
         GemmArgs g = gemm_args(BT, d, d, d, d, d);
         set_problem2(g, 0, w.zln, W.po, mat(E_txt, hf ? cfg->out_h : nullptr), p->proj_out_b);
@@ -401,12 +407,21 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         h.ws = sc.sk[0]; h.ws_bytes = sc.skb[0];
         wg[nwg++] = h;
     }
-    // (compact: the forward stored x_hat as bf16 alone.  dx stays fp32: handed to the mix backward as bf16 alone -- another 0.4 GB less --
-    // that kernel took 421 us instead of 291 at 4096 windows, staged through LDS 500)
+    // compact: the forward stored x_hat as bf16 alone.  dx: as bf16 alone for the WIDE mix backward (8-byte loads; the narrow kernel's
+    // two-byte loads made it slower on a bf16 dx -- 421 us instead of 291 at 4096 windows -- and keeps the fp32 one)
     const bool compact = hf && ln_sums_compact_ok(BT, d);
-    {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
-        const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                           gr->Q_param, sc.red, w.mtxt, T, nullptr, s, w.xhat)
+    const bool dx_half = compact && t2v_mix_wide_ok(d) && t2v_mix_bwd_wide;
+    float* dx_f = dx_half ? nullptr : sc.dx;
+    void* dx_h = dx_half ? static_cast<void*>(sc.dx) : nullptr;
+    const immtsf_lowrank_grad* lr = cfg->lr_grad;
+    if (lr) {   // the upstream gradient is dZ = coef basis: formed inside the LayerNorm backward, never written
+        if (!noproj || !lr->coef || !lr->basis || lr->rank <= 0 || lr->ld < lr->rank || !compact) return IMMTSF_EINVAL;
+        const int rc = launch_layernorm_bwd_lr(lr->coef, lr->ld, lr->rank, lr->basis, BT, d, p->ln_w, nullptr, w.xhat, w.rstd, dx_f, dx_h, drop,
+                                               SITE_T2V_OUT, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, s);
+        if (rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (immtsf_ttf_t2v_xattn_accepts_lowrank said otherwise)
+    } else {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
+        const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, dx_f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                           gr->Q_param, sc.red, w.mtxt, T, dx_h, s, w.xhat)
                                : launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
                                                            gr->Q_param, sc.red, w.mtxt, T, nullptr, s);
         if (compact && rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (the forward's test promised this path)
@@ -418,8 +433,8 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         }
     }
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
-    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, sc.dx, 0,
-                             hf ? sc.dza.h : (void*)sc.dza.f, sc.dbo_part, drop, SITE_T2V_ATTN, s));
+    CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, dx_half ? dx_h : (const void*)sc.dx,
+                             dx_half ? 1 : 0, hf ? sc.dza.h : (void*)sc.dza.f, sc.dbo_part, drop, SITE_T2V_ATTN, s));
     // (the row-bound kernels of the block are behind us: see the header.  Measured at 4096 windows: no hint 4.75 ms, here 4.63, in front
     // of the mix 4.96, behind the last weight-gradient GEMM 5.30)
     if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
@@ -533,6 +548,14 @@ size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg) {
 }
 int immtsf_ttf_t2v_xattn_folded(const immtsf_fusion_cfg* cfg) { return (!bad_cfg(cfg) && t2v_fold_on(cfg)) ? 1 : 0; }
 
+int immtsf_ttf_t2v_xattn_accepts_lowrank(const immtsf_fusion_cfg* cfg, int32_t rank) {
+    if (bad_cfg(cfg) || !(cfg->form & IMMTSF_FORM_NO_PROJ)) return 0;
+    const int BT = cfg->B * cfg->T, d = cfg->d;
+    if (!ln_lr_ok(BT, d, rank)) return 0;
+    if (t2v_fold_on(cfg)) return (t2v_hf(cfg) && cfg->precision == 1 && ln_sums_compact_ok(BT, d)) ? 1 : 0;
+    return 1;
+}
+
 // `src_rows` == null: `notes` is the zero-padded (B,N,d_m) tensor and the ragged index is derived from it (reference
 // semantics).  Otherwise `notes` is the resident embedding matrix, src_rows[packed row] its row and `lengths_in` the
 // per-window note counts from the batch builder: no padded tensor, no |V|-sum scan.
@@ -616,8 +639,9 @@ static int t2v_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p,
         g.row_flag32 = w.lengths;         // same zero pattern as M_txt
         CHECK(immtsf_launch_gemm(GEMM_NT, prec, g, s));
     }
-    if (cfg->form & IMMTSF_FORM_NO_PROJ)         // proj_out is the consumer's: hand over Z itself
-        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, E_txt, drop, SITE_T2V_OUT, s,
+    if (cfg->form & IMMTSF_FORM_NO_PROJ)         // proj_out is the consumer's: hand over Z itself (fp32 unless the caller reads the bf16 image only)
+        return launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd,
+                                    ((cfg->form & IMMTSF_FORM_HALF_OUT) && hf && cfg->out_h) ? nullptr : E_txt, drop, SITE_T2V_OUT, s,
                                     hf ? (cfg->out_h ? cfg->out_h : w.z.h) : nullptr);
     CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, w.xhat, w.rstd, w.z.f, drop, SITE_T2V_OUT, s, w.z.h));
     {
@@ -714,8 +738,14 @@ static int t2v_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p
         // LayerNorm backward; its parameter gradients; residual: dQ_param = sum of dx over ALL (b,t) rows; then only the windows with
         // notes feed the attention branch (rows zeroed, bf16 image written) -- ONE pass over the rows (launch_layernorm_bwd_sums), or,
         // for small / unaligned cases, the LayerNorm backward and the three sums as two passes
-        const int rc = launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
-                                                 gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
+        const immtsf_lowrank_grad* lr = cfg->lr_grad;
+        if (lr && (!noproj || !lr->coef || !lr->basis || lr->rank <= 0 || lr->ld < lr->rank)) return IMMTSF_EINVAL;
+        // (lr: the upstream gradient is dZ = coef basis, formed inside the LayerNorm backward -- immtsf_ttf_t2v_xattn_accepts_lowrank)
+        const int rc = lr ? launch_layernorm_bwd_lr(lr->coef, lr->ld, lr->rank, lr->basis, BT, d, p->ln_w, w.xhat, nullptr, w.rstd, sc.dx.f, sc.dx.h,
+                                                    drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, s)
+                          : launch_layernorm_bwd_sums(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
+                                                      gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s);
+        if (lr && rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;
         if (rc == IMMTSF_EUNSUPPORTED) {
             CHECK(launch_layernorm_bwd(dzp, BT, d, p->ln_w, w.xhat, w.rstd, sc.dx.f, drop, SITE_T2V_OUT, s));
             CHECK(launch_colsum3(dzp, w.xhat, sc.dx.f, BT, d, d, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, sc.dx.h, s, true));

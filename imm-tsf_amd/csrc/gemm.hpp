@@ -74,6 +74,11 @@ struct GemmArgs {
     int g2_rows_x, g2_cols_x, g2_xc_shift;
     unsigned g2_cx_magic;  // idx / cols_x
     int g2_per;            // K steps per split (0: K is a device value, divide in the kernel)
+    // gemm2 only: ONE problem repeated zbatch times along grid.z (0: off) -- batch z reads A + z zsA, B + z zsB (bf16 elements), writes
+    // C / Ch / Cpre + z zsC and takes its device-side M or K from dyn[z dyn_stride].  atomic_c: every batch ADDS its product (and bias
+    // gradient) into the same zeroed C by fp32 atomics (zsC = 0: a weight gradient summed over the batches)
+    int zbatch, dyn_stride, atomic_c;
+    long zsA, zsB, zsC;
 };
 
 enum { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };

@@ -75,11 +75,18 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
 
     __shared__ __attribute__((aligned(16))) unsigned char smem_all[WK * RING];
 
-    const GemmProblem P = g.p[bz];
+    GemmProblem P = g.p[g.zbatch ? 0 : bz];
+    if (g.zbatch) {        // one problem, grid.z batches at fixed strides (see GemmArgs)
+        P.Ah = reinterpret_cast<const bf16_t*>(P.Ah) + (size_t)bz * g.zsA;
+        P.Bh = reinterpret_cast<const bf16_t*>(P.Bh) + (size_t)bz * g.zsB;
+        if (P.C) P.C += (size_t)bz * g.zsC;
+        if (P.Ch) P.Ch = reinterpret_cast<bf16_t*>(P.Ch) + (size_t)bz * g.zsC;
+        if (P.Cpre) P.Cpre += (size_t)bz * g.zsC;
+    }
     int M = g.M, K = g.K;
     const int N = g.N;
     if (g.dyn) {
-        const int dv = *g.dyn;
+        const int dv = g.dyn[g.zbatch ? bz * g.dyn_stride : 0];
         if (g.dyn_which == 0) M = dv; else K = dv;
     }
     int lin = bx, tile_m, tile_n;
@@ -137,6 +144,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
     const int per = (g.g2_fast && g.g2_per) ? g.g2_per : (nk_total + splits - 1) / splits;
     const int kt0 = by * per, kt1 = min(nk_total, kt0 + per);
     if (splits > 1 && kt0 >= kt1) return;
+    const bool atom = splits > 1 || g.atomic_c;       // results leave by fp32 atomics into a zeroed C
     const int kend = min(K, kt1 * BK2);
 
     // ---- per-thread source pointers of its chunks at k = 0 (R image: pointer to (row, c*8); T image: pointer to
@@ -287,7 +295,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
     __builtin_amdgcn_s_barrier();
 
     // bias-gradient partial sums.  C/D map: col = lane & 15, row = (lane >> 4)*4 + reg; every column holds the sum
-    if (TA && TB && want_bsum && fr == 0 && gy > 1) {
+    if (TA && TB && want_bsum && fr == 0 && atom) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -321,7 +329,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
             }
         }
         __syncthreads();
-        if (TA && TB && bsum_wg && splits == 1) {
+        if (TA && TB && bsum_wg && !atom) {
             for (int rl = tid_all; rl < BAND; rl += NTALL) {
                 float sum = 0.f;
 #pragma unroll
@@ -351,7 +359,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
                 if (P.bias && first) x += P.bias[col + e];
                 if (!live) x = 0.f;
                 if (g.add_vec && first) x += g.add_vec[col + e];
-                if (splits > 1) {          // split-K: the K groups are already summed; one fp32 atomic per element into a zeroed C
+                if (atom) {          // split-K / summed batches: the K groups are already summed; one fp32 atomic per element into a zeroed C
                     atomicAdd(dst + e, x);
                     continue;
                 }
@@ -367,7 +375,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int bx, cons
                 if (g.accumulate) x += dst[e];
                 v[e] = x;
             }
-            if (splits > 1) continue;
+            if (atom) continue;
             if (dst) {
                 if (nv == 4 && g.vecC) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 else for (int e = 0; e < nv; ++e) dst[e] = v[e];
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm2_group_kernel(const Gemm
 
 template <int BM, int BN, int WM, int WN, int S, int WK = 1>
 int launch2(int layout, const GemmArgs& g_in, int Mmax, int splits, hipStream_t stream) {
-    dim3 grid(cdiv(Mmax, BM) * cdiv(g_in.N, BN), splits, g_in.nprob), block(WM * WN * WK * 64);
+    dim3 grid(cdiv(Mmax, BM) * cdiv(g_in.N, BN), splits, g_in.zbatch ? g_in.zbatch : g_in.nprob), block(WM * WN * WK * 64);
     if (grid.x == 0) return IMMTSF_OK;
     GemmArgs g = g_in;
     if (g.xcd_remap && g.xcd_gm) {        // exact 2-D XCD partition when the tile grid divides; else the 1-D contiguous ranges
@@ -491,6 +499,7 @@ extern "C" int immtsf_debug_gemm2_config(int variant, int splitk, int xcd) {
 bool immtsf_gemm2_supported(int layout, const GemmArgs& g) {
     if (layout < 0 || layout > 2 || g.nprob < 1 || g.nprob > IMMTSF_GEMM_MAX_PROBLEMS || g.nbatch > 1) return false;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+    if (g.zbatch < 0 || (g.zbatch && g.nprob != 1) || (g.atomic_c && (g.act || g.p[0].Ch || g.p[0].Cpre || !g.p[0].C))) return false;
     if (g.ref_kind && (g.ref_kind != 2 || !g.relu_ref)) return false;
     if ((g.epi_drop.p > 0.f || g.ref_kind) && (g.N & 3)) return false;       // (dropout / GELU' epilogues: round 3, for the FFN block)
     if ((g.lda % 8) || (g.ldb % 8)) return false;
@@ -526,12 +535,13 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     g.vecB = vh ? 1 : 0;
     g.vecA = 1;
     const int Mmax = g.M;
-    const long t64 = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * g.nprob;
+    const int nz = g.zbatch ? g.zbatch : g.nprob;       // grid.z
+    const long t64 = (long)cdiv(Mmax, 64) * cdiv(g.N, 64) * nz;
 
     // many rows (forward / data-gradient projections at >= 256 windows per GPU): the persistent ping-pong kernel of gemm3.hip,
     // 1.4-2x this file's tiles from ~190 row tiles of 128 on (profiles/r03_gemm_bigM.txt)
     constexpr int use_g3 = 1;
-    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && g.act == 0 && !g.relu_ref && !g.accumulate && g.epi_drop.p <= 0.f && !g.p[0].Cpre &&
+    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout != GEMM_TN && g.nprob == 1 && !g.zbatch && g.act == 0 && !g.relu_ref && !g.accumulate && g.epi_drop.p <= 0.f && !g.p[0].Cpre &&
         !g.a_rowmap && !g.b_rowmap && !g.ones_col && (!g.row_flag || g.row_flag32) && !(g.dyn && g.dyn_which != 0) &&
         (long)cdiv(Mmax, 128) * cdiv(g.N, 256) >= 192) {
         const GemmProblem& p = g.p[0];
@@ -539,7 +549,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
                                            g.row_flag ? g.row_flag32 : nullptr, g.row_flag_div, Mmax, g.N, g.K, g.alpha, 0, g.dyn, stream);
         if (rc != IMMTSF_EUNSUPPORTED) return rc;
     }
-    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && g.ws && g.act == 0 && !g.relu_ref && !g.a_rowmap &&
+    if (use_g3 && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && !g.zbatch && g.ws && g.act == 0 && !g.relu_ref && !g.a_rowmap &&
         !g.b_rowmap && !(g.dyn && g.dyn_which != 1) && !g.row_flag && !g.add_vec && !g.p[0].bias && g.epi_drop.p <= 0.f && !g.p[0].Cpre) {
         const GemmProblem& p = g.p[0];
         const int rc = immtsf_launch_gemm3_tn(p.Ah, g.lda, p.Bh, g.ldb, p.C, g.ldc, p.Ch, ldch, g.ones_col ? p.bias_grad : nullptr, Mmax, g.N, g.K,
@@ -550,7 +560,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     // split-K over workgroups (fp32 atomics into a zeroed C) is only a tool option here: the K-group variants below split
     // the reduction INSIDE a workgroup and sum through LDS, which measured faster at every weight-gradient shape of the
     // fusion step (r02: 768x768x2048 13.1 us unsplit on 64x64 k4 vs 17.9 us as 2 atomic splits of the 4-wave tile)
-    const bool can_split = all_c && !any_h && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && !g.p[0].Cpre && (g.accumulate || g.ldc == g.N) &&
+    const bool can_split = !g.zbatch && all_c && !any_h && g.act == 0 && !g.relu_ref && g.epi_drop.p <= 0.f && !g.p[0].Cpre && (g.accumulate || g.ldc == g.N) &&
                            !(g.dyn && g.dyn_which == 0);
     int splits = 1;
     if (can_split && g2_splitk > 1) splits = g2_splitk;
@@ -571,7 +581,7 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
     // rows): one row of 64 x 64 tiles leaves three quarters of the chip idle for 32 us -- the reduction is cut four ways
     if (can_split && g2_variant == 0 && g2_splitk <= 1 && layout == GEMM_TN && g.nprob == 1 && Mmax <= 64 && g.N >= 1024 && g.K >= 2048 && !long_k)
         splits = 4;
-    if (splits > 1 && !g.c_prezeroed && !g.accumulate) {
+    if ((splits > 1 || g.atomic_c) && !g.c_prezeroed && !g.accumulate) {
         for (int i = 0; i < g.nprob; ++i) {
             // (fill kernels, not memset nodes: see gemm.hip)
             if (int rc = launch_fill(g.p[i].C, 0.f, (size_t)Mmax * g.N, stream)) return rc;
@@ -594,9 +604,9 @@ int immtsf_launch_gemm2(int layout, GemmArgs& g, hipStream_t stream) {
         // run ONE workgroup per CU, so they want a grid that fills the 256 CUs in a single round; when the rows are a
         // device-side count (ragged notes) the expected fill is about half the allocation bound.
         const int Meff = (g.dyn && g.dyn_which == 0) ? (Mmax * 9 + 15) / 16 : Mmax;
-        const long n64 = (long)cdiv(Meff, 64) * cdiv(g.N, 64) * g.nprob;
-        const long n96 = (long)cdiv(Meff, 64) * cdiv(g.N, 96) * g.nprob;
-        const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * g.nprob;
+        const long n64 = (long)cdiv(Meff, 64) * cdiv(g.N, 64) * nz;
+        const long n96 = (long)cdiv(Meff, 64) * cdiv(g.N, 96) * nz;
+        const long t128 = (long)cdiv(Mmax, 128) * cdiv(g.N, 128) * nz;
         const bool n96_ok = g.N % 96 == 0 || g.N >= 960;
         if (long_k) v = 18;                                       // 128x128 k2 with the reduction split over workgroups
         else if (t128 >= 1024 && layout == GEMM_NT && g.N >= 1024) v = 13;     // 256x256, 8 waves, 2 stages (short-K, N = 768 and NN: 256x128 wins,

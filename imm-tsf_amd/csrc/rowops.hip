@@ -983,6 +983,150 @@ __global__ __launch_bounds__(256) void layernorm_bwd_sums_kernel(const float* __
     }
 }
 
+// LayerNorm backward + sums (the K == 3, bf16-x_hat form above) whose upstream gradient arrives LOW-RANK: dy[row, :] = G[row, :PW] Wb
+// (Wb: PW x d) -- the gradient a rank-PW projection behind the LayerNorm sends back (MMF_XAttn_Add's composed projection: dZ = dP Wc,
+// csrc/xrank.hip).  The product is formed in registers from Wb held in LDS, so the (rows x d) fp32 dZ that rank_expand_kernel wrote and
+// this kernel re-read (0.8 GB of the step's traffic at 4096 windows, one launch on the text chain at 64) never exists.  512 threads:
+// eight waves share the LDS copy of Wb; a wave takes R consecutive rows at a time and every Wb read from LDS serves all R (R = 4 for
+// many rows: the LDS reads, PW x d x 4 bytes per row at R = 1, would otherwise cost as much as the HBM traffic).
+template <int R, int DV, bool XH>
+__global__ __launch_bounds__(512) void layernorm_bwd_lr_kernel(const float* __restrict__ G, int ldg, int PW, const float* __restrict__ Wb,
+                                                                int rows, int d, const float* __restrict__ gamma,
+                                                                const void* __restrict__ xhat_any, const float* __restrict__ rstd,
+                                                                float* __restrict__ dx, bf16_t* __restrict__ dxh, DropCfg drop, uint64_t site,
+                                                                float* __restrict__ partial, const unsigned char* __restrict__ row_flag,
+                                                                int flag_div) {
+    extern __shared__ __attribute__((aligned(16))) float lr_lds[];      // Wb [PW][d], then the workgroup's sums [3][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d4 = d >> 2;
+    float4* wl4 = reinterpret_cast<float4*>(lr_lds);
+    float4* red4 = wl4 + (size_t)PW * d4;
+    for (int x = tid; x < PW * d4; x += 512) wl4[x] = reinterpret_cast<const float4*>(Wb)[x];
+    float4 sw[DV], sb[DV], sq[DV], gm[DV];
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+        const int q = lane + 64 * j;
+        sw[j] = sb[j] = sq[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[j] = q < d4 ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    for (int row0 = (blockIdx.x * 8 + wave) * R; row0 < rows; row0 += gridDim.x * 8 * R) {
+        float4 dy[R][DV], hv[R][DV];
+        float gl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            const bool ok = row < rows;
+            gl[r] = (ok && lane < PW) ? G[(size_t)row * ldg + lane] : 0.f;
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const int q = lane + 64 * j;
+                hv[r][j] = dy[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && q < d4) {
+                    if (XH) {
+                        const bf16x4 t4 = reinterpret_cast<const bf16x4*>(static_cast<const bf16_t*>(xhat_any) + (size_t)row * d)[q];
+                        hv[r][j] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
+                    } else {
+                        hv[r][j] = reinterpret_cast<const float4*>(static_cast<const float*>(xhat_any) + (size_t)row * d)[q];
+                    }
+                }
+            }
+        }
+#pragma unroll 2
+        for (int k = 0; k < PW; ++k) {
+            float gk[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) gk[r] = lane_bcast(gl[r], k);
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const int q = lane + 64 * j;
+                if (q < d4) {
+                    const float4 w4 = wl4[k * d4 + q];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        dy[r][j].x = fmaf(gk[r], w4.x, dy[r][j].x); dy[r][j].y = fmaf(gk[r], w4.y, dy[r][j].y);
+                        dy[r][j].z = fmaf(gk[r], w4.z, dy[r][j].z); dy[r][j].w = fmaf(gk[r], w4.w, dy[r][j].w);
+                    }
+                }
+            }
+        }
+        // output-dropout keep bits of the wave's R x DV chunks in a rolled loop (one Philox call each), four bits per chunk
+        uint64_t kb = ~0ull;
+        if (drop.p > 0.f) {
+            kb = 0ull;
+#pragma unroll 1
+            for (int x = 0; x < R * DV; ++x) {
+                const int r = x / DV, j = x - r * DV, q = lane + 64 * j, row = row0 + r;
+                float sc[4];
+                dropout_scale4(drop, site, (uint64_t)row * d + (uint64_t)q * 4, sc);
+                const uint64_t bits = (sc[0] != 0.f ? 1ull : 0ull) | (sc[1] != 0.f ? 2ull : 0ull) | (sc[2] != 0.f ? 4ull : 0ull) | (sc[3] != 0.f ? 8ull : 0ull);
+                kb |= bits << (4 * x);
+            }
+        }
+        const float keepv = drop.p > 0.f ? drop.inv_keep : 1.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            const bool ok = row < rows;
+            float4 tv[DV];
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const uint32_t b4 = (uint32_t)(kb >> (4 * (r * DV + j))) & 15u;
+                float4 y = dy[r][j];
+                y = make_float4((b4 & 1u) ? y.x * keepv : 0.f, (b4 & 2u) ? y.y * keepv : 0.f, (b4 & 4u) ? y.z * keepv : 0.f, (b4 & 8u) ? y.w * keepv : 0.f);
+                const float4 h = hv[r][j];
+                sw[j].x = fmaf(y.x, h.x, sw[j].x); sw[j].y = fmaf(y.y, h.y, sw[j].y); sw[j].z = fmaf(y.z, h.z, sw[j].z); sw[j].w = fmaf(y.w, h.w, sw[j].w);
+                sb[j].x += y.x; sb[j].y += y.y; sb[j].z += y.z; sb[j].w += y.w;
+                tv[j] = make_float4(y.x * gm[j].x, y.y * gm[j].y, y.z * gm[j].z, y.w * gm[j].w);
+                c1 += (tv[j].x + tv[j].y) + (tv[j].z + tv[j].w);
+                c2 = fmaf(tv[j].x, h.x, fmaf(tv[j].y, h.y, fmaf(tv[j].z, h.z, fmaf(tv[j].w, h.w, c2))));
+            }
+            c1 = wave_sum(c1) / (float)d;
+            c2 = wave_sum(c2) / (float)d;
+            const float rs = ok ? rstd[row] : 0.f;
+            const bool keep = !row_flag || !ok || row_flag[row / flag_div] != 0;
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const int q = lane + 64 * j;
+                if (ok && q < d4) {
+                    const float4 h = hv[r][j];
+                    float4 o = make_float4(rs * (tv[j].x - c1 - h.x * c2), rs * (tv[j].y - c1 - h.y * c2), rs * (tv[j].z - c1 - h.z * c2),
+                                           rs * (tv[j].w - c1 - h.w * c2));
+                    sq[j].x += o.x; sq[j].y += o.y; sq[j].z += o.z; sq[j].w += o.w;
+                    if (!keep) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (dx) reinterpret_cast<float4*>(dx + (size_t)row * d)[q] = o;
+                    if (dxh) {
+                        const bf16x4 hvv = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+                        reinterpret_cast<bf16x4*>(dxh + (size_t)row * d)[q] = hvv;
+                    }
+                }
+            }
+        }
+    }
+    // the eight waves add up in wave order (deterministic), then the workgroup writes its partial row set
+    for (int w = 0; w < 8; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                const int q = lane + 64 * j;
+                if (q < d4) {
+                    if (w == 0) { red4[0 * d4 + q] = sw[j]; red4[1 * d4 + q] = sb[j]; red4[2 * d4 + q] = sq[j]; }
+                    else {
+                        float4 a = red4[0 * d4 + q], b = red4[1 * d4 + q], c = red4[2 * d4 + q];
+                        a.x += sw[j].x; a.y += sw[j].y; a.z += sw[j].z; a.w += sw[j].w;
+                        b.x += sb[j].x; b.y += sb[j].y; b.z += sb[j].z; b.w += sb[j].w;
+                        c.x += sq[j].x; c.y += sq[j].y; c.z += sq[j].z; c.w += sq[j].w;
+                        red4[0 * d4 + q] = a; red4[1 * d4 + q] = b; red4[2 * d4 + q] = c;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float4* out = reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 3 * d);
+    for (int x = tid; x < 3 * d4; x += 512) out[x] = red4[x];
+}
+
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dz_dy, int rows, int d,
                                                              const float* __restrict__ gamma, const float* __restrict__ xhat,
                                                              const float* __restrict__ rstd, float* __restrict__ dx,
@@ -1430,6 +1574,45 @@ int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma,
         IMMTSF_LAUNCH_CHECK();
         hipLaunchKernelGGL((colsum_vec_final_kernel<2>), dim3(cdiv(d, 32), 2), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, nullptr, 0);
     }
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+// the low-rank form: dy = G Wb (G: rows x PW, pitch ldg; Wb: PW x d) is never written -- see layernorm_bwd_lr_kernel.  x_hat as the
+// bf16 image, dx fp32 and / or bf16; sums and row flags as launch_layernorm_bwd_sums with out_q.  IMMTSF_EUNSUPPORTED outside its limits.
+bool ln_lr_ok(int rows, int d, int PW) {
+    return (d & 3) == 0 && d <= 1024 && d >= 256 && PW >= 1 && PW <= 64 && rows >= 512 && (size_t)(PW + 3) * d * sizeof(float) <= 150 * 1024;
+}
+int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, int rows, int d, const float* gamma, const float* xhat,
+                            const void* xhat_h, const float* rstd, float* dx, void* dxh, DropCfg drop, uint64_t site, float* out_gw, float* out_gb,
+                            float* out_q, float* scratch, const unsigned char* row_flag, int flag_div, hipStream_t s) {
+    if (!ln_lr_ok(rows, d, PW)) return IMMTSF_EUNSUPPORTED;
+    if (!G || !Wb || (!xhat && !xhat_h) || (!dx && !dxh) || !out_gw || !out_gb || !out_q || !scratch) return IMMTSF_EINVAL;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(Wb) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma) |
+                         reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(xhat);
+    if ((al & 15) || ((reinterpret_cast<uintptr_t>(dxh) | reinterpret_cast<uintptr_t>(xhat_h)) & 7)) return IMMTSF_EUNSUPPORTED;
+    const void* xa = xhat_h ? xhat_h : static_cast<const void*>(xhat);
+    const size_t lds = (size_t)(PW + 3) * d * sizeof(float);
+    const bool many = rows >= 8192;
+    const int per_wg = 8 * (many ? 4 : 1);
+    int nsl = cdiv(rows, per_wg);
+    nsl = nsl > 256 ? 256 : nsl;          // (one workgroup per CU: the LDS copy of Wb)
+    const int fd = flag_div > 0 ? flag_div : 1;
+#define LNLR(RR, DVV, XHH)                                                                                                                       \
+    do {                                                                                                                                         \
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(layernorm_bwd_lr_kernel<RR, DVV, XHH>),                 \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                              \
+        if (attr != hipSuccess) return (int)attr;                                                                                                \
+        hipLaunchKernelGGL((layernorm_bwd_lr_kernel<RR, DVV, XHH>), dim3(nsl), dim3(512), lds, s, G, ldg, PW, Wb, rows, d, gamma, xa, rstd, dx,   \
+                           static_cast<bf16_t*>(dxh), drop, site, scratch, row_flag, fd);                                                        \
+    } while (0)
+#define LNLR2(RR, DVV) do { if (xhat_h) LNLR(RR, DVV, true); else LNLR(RR, DVV, false); } while (0)
+    if (d <= 768) { if (many) LNLR2(4, 3); else LNLR2(1, 3); }
+    else { if (many) LNLR2(4, 4); else LNLR2(1, 4); }
+#undef LNLR2
+#undef LNLR
+    IMMTSF_LAUNCH_CHECK();
+    hipLaunchKernelGGL((colsum_vec_final_kernel<3>), dim3(cdiv(d, 32), 3), dim3(256), 0, s, scratch, d, nsl, out_gw, out_gb, out_q, 0);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -324,7 +324,295 @@ __global__ __launch_bounds__(256) void t2v_mix_bwd_kernel(T2VFoldDims dm, const 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ mix + LayerNorm, forward (wide form)
+// grid (B), 256 threads: the workgroup owns its window's T rows over ALL d <= 1024 columns -- a thread owns FOUR adjacent columns
+// (8- / 16-byte loads of the value rows, 8- / 16-byte stores of the outputs) for all T steps, 4 x 32 accumulators in registers -- so the
+// LayerNorm that follows the mix (reference: fusions/TTF_T2V_XAttn.py:176-179, ln(E_attn + Q) then dropout) runs on the accumulators:
+// no fp32 x_pre in HBM (403 MB written + read at 4096 windows), x_hat and Z leave once.  The dropout tile is note-major so that a note's T
+// scales are eight 16-byte broadcast reads shared by the thread's four columns.
+struct MixLn {
+    const float *gamma, *beta;
+    float eps;
+    float* xhat_f;        // x_hat as fp32, or ...
+    bf16_t* xhat_h;       // ... as bf16 alone (the compact form of launch_layernorm_fwd)
+    float* rstd;
+    float* z_f;           // Z = dropout(LayerNorm(.)) fp32 (may be null when z_h is all the consumer reads)
+    bf16_t* z_h;          // bf16 image (may be null)
+};
+__device__ __forceinline__ void ld4w(const float* p, float (&o)[4]) { const float4 a = *reinterpret_cast<const float4*>(p); o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
+__device__ __forceinline__ void ld4w(const bf16_t* p, float (&o)[4]) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u); o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4w(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4w(bf16_t* p, const float (&v)[4]) {
+    const bf16x4 h = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = h;
+}
+template <typename KT, int NV>
+__global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+                                                              const float* __restrict__ S, const KT* __restrict__ z,
+                                                              const float* __restrict__ b_o, const float* __restrict__ q_res,
+                                                              float* __restrict__ P, MixLn o, DropCfg drop, uint64_t site, DropCfg odrop,
+                                                              uint64_t osite) {
+    __shared__ __attribute__((aligned(16))) float mt[NV * TT];       // [note][step] dropout scale; 0 past n / T
+    __shared__ float pl[NV];
+    __shared__ float red[4][TT];
+    __shared__ float mu_s[TT], rs_s[TT];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = dm.d, H = dm.H, Hd = H * d, T = dm.T;
+    const int ob = offsets[b], n = offsets[b + 1] - ob;
+    const int e0 = tid * 4;
+    const bool valid = e0 < d;
+    float acc[4][TT];
+    {
+        float a0[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            float qv[4], bv[4] = {0.f, 0.f, 0.f, 0.f};
+            ld4w(q_res + e0, qv);
+            if (n > 0) ld4w(b_o + e0, bv);          // (no notes: E_attn is zero, the residual query remains)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a0[c] = qv[c] + bv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < TT; ++t) acc[c][t] = a0[c];
+    }
+    if (n > 0) {
+        const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
+        for (int h = 0; h < H; ++h) {
+            const float s_l = lane < n ? S[(size_t)(ob + lane) * H + h] : -INFINITY;
+            const float m = wave_max(s_l);
+            float p = lane < n ? expf(s_l - m) : 0.f;
+            p *= 1.f / wave_sum(p);
+            if (h > 0) __syncthreads();            // the previous head's tiles have been read
+            for (int x = tid; x < NV * TT; x += 256) {
+                const int ii = x / TT, tt = x - ii * TT;
+                float a = 0.f;
+                if (tt < T && ii < n) {
+                    a = 1.f;
+                    if (drop.p > 0.f) {
+                        const int n_orig = rowmap[ob + ii] - b * dm.N;
+                        const uint64_t idx = ((uint64_t)(b * T + tt) * H + h) * dm.N + n_orig;
+                        a = dropout_scale(seed, site, idx, drop.p, drop.inv_keep);
+                    }
+                }
+                mt[x] = a;
+            }
+            if (wave == 0) {
+                if (lane < NV) pl[lane] = p;                               // (0 past n)
+                if (lane < n) P[(size_t)(ob + lane) * H + h] = p;
+            }
+            __syncthreads();
+            if (valid) {
+                const KT* vb = z + (size_t)ob * Hd + (size_t)h * d + e0;
+                for (int i0 = 0; i0 < n; i0 += 8) {
+                    float zv[8][4];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ld4w(vb + (size_t)(i0 + k < n ? i0 + k : n - 1) * Hd, zv[k]);        // (every load before the first use)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (i0 + k >= n) break;             // (workgroup-uniform)
+                        const float pi = pl[i0 + k];
+                        float m4[TT];
+#pragma unroll
+                        for (int t4 = 0; t4 < TT / 4; ++t4) {
+                            const float4 q = *reinterpret_cast<const float4*>(mt + (i0 + k) * TT + 4 * t4);
+                            m4[4 * t4] = q.x; m4[4 * t4 + 1] = q.y; m4[4 * t4 + 2] = q.z; m4[4 * t4 + 3] = q.w;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float pv = pi * zv[k][c];
+#pragma unroll
+                            for (int t = 0; t < TT; ++t) acc[c][t] = fmaf(m4[t], pv, acc[c][t]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- LayerNorm over the d columns of each of the T rows (two passes over the registers: mean, then the centred squares)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const float ps = wave_sum(valid ? (acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t]) : 0.f);
+        if (lane == 0) red[wave][t] = ps;
+    }
+    __syncthreads();
+    if (tid < TT) mu_s[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)d;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        const float mu = mu_s[t];
+        float v = 0.f;
+        if (valid) {
+            const float a = acc[0][t] - mu, bb = acc[1][t] - mu, c = acc[2][t] - mu, e = acc[3][t] - mu;
+            v = fmaf(a, a, fmaf(bb, bb, fmaf(c, c, e * e)));
+        }
+        v = wave_sum(v);
+        if (lane == 0) red[wave][t] = v;
+    }
+    __syncthreads();
+    if (tid < TT) {
+        const float rs = 1.0f / sqrtf(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)d + o.eps);
+        rs_s[tid] = rs;
+        if (tid < T && o.rstd) o.rstd[b * T + tid] = rs;
+    }
+    __syncthreads();
+    if (!valid) return;
+    float gm[4], bt[4];
+    ld4w(o.gamma + e0, gm);
+    ld4w(o.beta + e0, bt);
+    // output dropout: the keep bits of the thread's 4 x T elements first, in a ROLLED loop (one Philox call per step; inlined 32 times into
+    // the store loop below the compiler gave up unrolling it and the accumulators went to scratch), four bits per step in two 64-bit words
+    uint64_t kb0 = ~0ull, kb1 = ~0ull;
+    if (odrop.p > 0.f) {
+        kb0 = kb1 = 0ull;
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            float sc[4];
+            dropout_scale4(odrop, osite, (uint64_t)((size_t)(b * T + t) * d + e0), sc);
+            const uint64_t bits = (sc[0] != 0.f ? 1ull : 0ull) | (sc[1] != 0.f ? 2ull : 0ull) | (sc[2] != 0.f ? 4ull : 0ull) | (sc[3] != 0.f ? 8ull : 0ull);
+            if (t < 16) kb0 |= bits << (4 * t); else kb1 |= bits << (4 * (t - 16));
+        }
+    }
+    const float keep = odrop.p > 0.f ? odrop.inv_keep : 1.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        if (t < T) {              // (a guard, not a break: the loop must unroll for the accumulators to stay in registers)
+            const float mu = mu_s[t], rs = rs_s[t];
+            const size_t at = (size_t)(b * T + t) * d + e0;
+            const uint32_t kb = (uint32_t)((t < 16 ? kb0 >> (4 * (t & 15)) : kb1 >> (4 * (t & 15))) & 15u);
+            float hv[4], zo[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hv[c] = (acc[c][t] - mu) * rs;
+            if (o.xhat_f) st4w(o.xhat_f + at, hv);
+            if (o.xhat_h) st4w(o.xhat_h + at, hv);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zo[c] = ((kb >> c) & 1u) ? fmaf(hv[c], gm[c], bt[c]) * keep : 0.f;
+            if (o.z_f) st4w(o.z_f + at, zo);
+            if (o.z_h) st4w(o.z_h + at, zo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mix, backward (wide form)
+// the same ownership as the wide forward: a thread holds the T upstream values of FOUR adjacent columns (one 8-byte load per row of a
+// bf16 dx -- the two-byte accesses of the narrow kernel made it slower on a bf16 dx than on the fp32 one), writes dz four columns at
+// a time, and the per-note dot products meet in wave-private LDS slabs exactly as in the narrow kernel.
+template <typename KT, int NV, typename DT>
+__global__ __launch_bounds__(256) void t2v_mix_bwd_wide_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+                                                                const float* __restrict__ P, const KT* __restrict__ z,
+                                                                const DT* __restrict__ dx, KT* __restrict__ dz, float* __restrict__ dbo_part,
+                                                                DropCfg drop, uint64_t site) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int H = dm.H;
+    float* mt = lds;                                   // [H][NV][TT]
+    float* pl = mt + (size_t)H * NV * TT;              // [H][NV]
+    float* dpw = pl + H * NV;                          // [4 waves][H][NV]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = dm.d, Hd = H * d, Ma = Hd + 8, T = dm.T;
+    const int ob = offsets[b], n = offsets[b + 1] - ob;
+    const int e0 = tid * 4;
+    const bool valid = e0 < d;
+    if (n == 0) {
+        if (valid) { const float zr[4] = {0.f, 0.f, 0.f, 0.f}; st4w(dbo_part + (size_t)b * d + e0, zr); }
+        return;
+    }
+    // the upstream rows first: the longest latency of the kernel runs under the tile construction
+    float dcv[4][TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid && t < T) ld4w(dx + (size_t)(b * T + t) * d + e0, v);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dcv[c][t] = v[c];
+    }
+    const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
+    for (int x = tid; x < H * NV * TT; x += 256) {
+        const int h = x / (NV * TT), r = x - h * NV * TT, ii = r / TT, tt = r - ii * TT;
+        float a = 0.f;
+        if (tt < T && ii < n) {
+            a = 1.f;
+            if (drop.p > 0.f) {
+                const int n_orig = rowmap[ob + ii] - b * dm.N;
+                const uint64_t idx = ((uint64_t)(b * T + tt) * H + h) * dm.N + n_orig;
+                a = dropout_scale(seed, site, idx, drop.p, drop.inv_keep);
+            }
+        }
+        mt[x] = a;
+    }
+    for (int x = tid; x < H * NV; x += 256) {
+        const int h = x / NV, ii = x - h * NV;
+        pl[x] = ii < n ? P[(size_t)(ob + ii) * H + h] : 0.f;
+    }
+    for (int x = tid; x < 4 * H * NV; x += 256) dpw[x] = 0.f;
+    __syncthreads();
+    if (valid) {
+        float gs[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float g = 0.f;
+#pragma unroll
+            for (int t = 0; t < TT; ++t) g += dcv[c][t];
+            gs[c] = g;
+        }
+        st4w(dbo_part + (size_t)b * d + e0, gs);
+    }
+    for (int h = 0; h < H; ++h) {
+        const KT* vb = z + (size_t)ob * Hd + (size_t)h * d + (valid ? e0 : 0);
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float zv[8][4];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ld4w(vb + (size_t)(i0 + k < n ? i0 + k : n - 1) * Hd, zv[k]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + k;
+                if (i >= n) break;              // (workgroup-uniform)
+                float m4[TT];
+#pragma unroll
+                for (int t4 = 0; t4 < TT / 4; ++t4) {
+                    const float4 q = *reinterpret_cast<const float4*>(mt + ((size_t)h * NV + i) * TT + 4 * t4);
+                    m4[4 * t4] = q.x; m4[4 * t4 + 1] = q.y; m4[4 * t4 + 2] = q.z; m4[4 * t4 + 3] = q.w;
+                }
+                const float pi = pl[h * NV + i];
+                float a = 0.f, out[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TT; ++t) g = fmaf(m4[t], dcv[c][t], g);
+                    a = fmaf(g, zv[k][c], a);
+                    out[c] = pi * g;
+                }
+                if (valid) st4w(dz + (size_t)(ob + i) * Ma + (size_t)h * d + e0, out);
+                a = wave_sum(valid ? a : 0.f);
+                if (lane == 0) dpw[(wave * H + h) * NV + i] += a;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave < H) {            // (wave-uniform: the wave reductions below run with every lane active)
+        const int h = wave;
+        float dp = 0.f, p = 0.f;
+        if (lane < n) {
+            dp = dpw[(0 * H + h) * NV + lane] + dpw[(1 * H + h) * NV + lane] + dpw[(2 * H + h) * NV + lane] + dpw[(3 * H + h) * NV + lane];
+            p = pl[h * NV + lane];
+        }
+        const float dot = wave_sum(p * dp);
+        if (lane < n) {
+            KT* row = dz + (size_t)(ob + lane) * Ma + Hd;
+            row[h] = (KT)(p * (dp - dot));
+            if (h == 0)
+                for (int j = H; j < 8; ++j) row[j] = (KT)0.f;
+        }
+    }
+}
+
 }  // namespace
+
+int t2v_mix_bwd_wide = 1;      // (tool switch: 0 = the narrow kernel)
 
 int launch_vecjobs(const VecJobList& l, hipStream_t s) {
     if (l.n <= 0) return IMMTSF_OK;
@@ -380,12 +668,41 @@ int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, co
     return IMMTSF_OK;
 }
 
+bool t2v_mix_wide_ok(int d) { return (d % 8) == 0 && d <= 1024; }      // (four adjacent columns per thread, 16-byte rows)
+
+int launch_t2v_mix_ln_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
+                          const float* q_res, float* P, const float* gamma, const float* beta, float eps, float* xhat_f, void* xhat_h,
+                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s) {
+    if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H) || !t2v_mix_wide_ok(dm.d)) return IMMTSF_EUNSUPPORTED;
+    if ((!xhat_f && !xhat_h) || (!z_f && !z_h)) return IMMTSF_EINVAL;
+    MixLn o;
+    o.gamma = gamma; o.beta = beta; o.eps = eps; o.xhat_f = xhat_f; o.xhat_h = static_cast<bf16_t*>(xhat_h); o.rstd = rstd; o.z_f = z_f;
+    o.z_h = static_cast<bf16_t*>(z_h);
+#define MIXL(KT, NV) hipLaunchKernelGGL((t2v_mix_ln_fwd_kernel<KT, NV>), dim3(dm.B), dim3(256), 0, s, dm, offsets, rowmap, S, static_cast<const KT*>(z), \
+                                        b_o, q_res, P, o, drop, site, odrop, osite)
+    if (z_is_bf16) { if (dm.N <= 32) MIXL(bf16_t, 32); else MIXL(bf16_t, 64); }
+    else { if (dm.N <= 32) MIXL(float, 32); else MIXL(float, 64); }
+#undef MIXL
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const void* dx,
                        int dx_is_bf16, void* dz_aug, float* dbo_part, DropCfg drop, uint64_t site, hipStream_t s) {
     if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H)) return IMMTSF_EUNSUPPORTED;
     if (dx_is_bf16 && !z_is_bf16) return IMMTSF_EINVAL;
     const int NV = dm.N <= 32 ? 32 : 64;
     const size_t lds = ((size_t)dm.H * NV * TT + (size_t)dm.H * NV + 4 * (size_t)dm.H * NV) * sizeof(float);
+    if (t2v_mix_wide_ok(dm.d) && t2v_mix_bwd_wide) {
+#define MIXW(KT, NVV, DT) hipLaunchKernelGGL((t2v_mix_bwd_wide_kernel<KT, NVV, DT>), dim3(dm.B), dim3(256), lds, s, dm, offsets, rowmap, P, \
+                                             static_cast<const KT*>(z), static_cast<const DT*>(dx), static_cast<KT*>(dz_aug), dbo_part, drop, site)
+        if (z_is_bf16 && dx_is_bf16) { if (NV == 32) MIXW(bf16_t, 32, bf16_t); else MIXW(bf16_t, 64, bf16_t); }
+        else if (z_is_bf16) { if (NV == 32) MIXW(bf16_t, 32, float); else MIXW(bf16_t, 64, float); }
+        else { if (NV == 32) MIXW(float, 32, float); else MIXW(float, 64, float); }
+#undef MIXW
+        IMMTSF_LAUNCH_CHECK();
+        return IMMTSF_OK;
+    }
 #define MIXB(KT, NVV, DT) hipLaunchKernelGGL((t2v_mix_bwd_kernel<KT, NVV, 4, DT>), dim3(dm.B), dim3(256), lds, s, dm, offsets, rowmap, P, \
                                              static_cast<const KT*>(z), static_cast<const DT*>(dx), static_cast<KT*>(dz_aug), dbo_part, drop, site)
     if (z_is_bf16 && dx_is_bf16) { if (NV == 32) MIXB(bf16_t, 32, bf16_t); else MIXB(bf16_t, 64, bf16_t); }

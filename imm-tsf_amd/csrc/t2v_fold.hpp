@@ -50,6 +50,13 @@ int launch_t2v_scores(const void* X, int x_is_bf16, int dmc, const float* U, int
 // xpre[b, t, :] = (n_b > 0 ? sum_h sum_n a~ z[n, h] + b_o : 0) + q_res
 int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
                        const float* q_res, float* P, float* xpre, DropCfg drop, uint64_t site, hipStream_t s);
+// the mix AND the LayerNorm + output dropout behind it in one launch (d % 8 == 0, d <= 1024: t2v_mix_wide_ok): x_hat (fp32 or, xhat_f ==
+// null, bf16 alone), rstd, Z fp32 and / or bf16 -- x_pre never reaches memory
+bool t2v_mix_wide_ok(int d);
+int launch_t2v_mix_ln_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
+                          const float* q_res, float* P, const float* gamma, const float* beta, float eps, float* xhat_f, void* xhat_h,
+                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s);
+extern int t2v_mix_bwd_wide;
 // backward of the mix and the softmax: dz_aug (R, H d + 8): columns [h d, (h+1) d) = dz of head h, column H d + h = ds of head h, the
 // rest 0 (fp32 or bf16 like z); dbo_part (B, d) = sum_t dx[b, t, :] of the windows with notes (0 otherwise)
 int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* P, const void* z, int z_is_bf16, const void* dx,

@@ -1571,7 +1571,7 @@ int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immts
     // immtsf_fusion_cfg.bwd_phase: 0 = both halves; IMMTSF_BWD_PHASE_A = only dZ (what the producer's backward waits for);
     // IMMTSF_BWD_WGRAD_A = only the chain's seeds dWc / dbc (parameter-gradient work: any stream ordered behind dP)
     const bool do_data = cfg->bwd_phase == 0 || (cfg->bwd_phase & IMMTSF_BWD_PHASE_A), do_seed = cfg->bwd_phase == 0 || (cfg->bwd_phase & IMMTSF_BWD_WGRAD_A);
-    if (do_data) {
+    if (do_data && !(cfg->form & IMMTSF_FORM_LOWRANK_OUT)) {      // (LOWRANK_OUT: the producer's backward forms dZ from (dP, Wc) itself)
         if (rank_expand_ok(BT, d, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr)) {       // dZ = dP Wc: many rows, rank PW (see rank_expand_kernel)
             CHECK(launch_rank_expand(dP, x.PW, w.Wc, d, dZ, hf ? cfg->out_h : nullptr, BT, d, x.PW, s));
         } else {
@@ -1588,6 +1588,15 @@ int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immts
         CHECK(immtsf_launch_gemm(GEMM_TN, prec, g, s));
         if (hf) CHECK(launch_f32_to_bf16(sc.dWc, sc.dWc16, (size_t)x.PW * d, s));
     }
+    return IMMTSF_OK;
+}
+
+int immtsf_mmf_xrank_lowrank_basis(const immtsf_fusion_cfg* cfg, void* workspace, size_t workspace_bytes, const float** basis, int32_t* rank) {
+    if (!xr_supported(cfg) || !workspace || !basis || !rank) return IMMTSF_EINVAL;
+    XPWs w = carve_xp(cfg, workspace);
+    if (workspace_bytes < w.bytes) return IMMTSF_EWORKSPACE;
+    *basis = w.Wc;
+    *rank = xr_dims(cfg).PW;
     return IMMTSF_OK;
 }
 

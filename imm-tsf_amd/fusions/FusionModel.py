@@ -82,7 +82,7 @@ class FusionModel(nn.Module):
         B = tau.shape[0]
         T = prep_t_hat(t_hat, B).shape[1]
         if self.fused_tail(B * T, T):
-            Z, M_txt = self.ttf(notes_input, tau, t_hat, tail=False)
+            Z, M_txt = self.ttf(notes_input, tau, t_hat, tail="handover")      # (Z's only consumer is the projection below: config.z_handover)
             return Z, M_txt, self.mmf.project_kv(Z, proj=self.ttf.proj_out)
         E_txt, M_txt = self.ttf(notes_input, tau, t_hat)
         return E_txt, M_txt, (self.mmf.project_kv(E_txt) if hasattr(self.mmf, "project_kv") else None)

@@ -89,7 +89,9 @@ class TTF_T2V_XAttn(nn.Module):
         (immtsf.data.ResidentStore.collate: no padded tensor, no note-mask re-derivation) --, tau (B,N),
         t_hat (B,T) or (T,) -> E_txt (B,T,d_txt), M_txt (B,1) bool.  tail=False (not part of the reference's signature; used by
         FusionModel.text_side): stop in front of proj_out and return Z = dropout(LayerNorm(E_attn + Q)) in E_txt's place -- for a consumer
-        that composes proj_out into its own projection (MMF_XAttn_Add.project_kv(Z, proj=self.proj_out))."""
+        that composes proj_out into its own projection (MMF_XAttn_Add.project_kv(Z, proj=self.proj_out)); tail="handover": the same, and
+        the caller promises that this projection is Z's ONLY consumer (immtsf.config.z_handover: in bf16 mode Z then exists as its bf16
+        image alone -- the returned fp32 tensor is a placeholder -- and the gradient comes back in low-rank form)."""
         if not self.use_text_embeddings:
             raise NotImplementedError("raw-text mode is not part of the MI355X hot path")
         packed = notes_input if isinstance(notes_input, PackedNotes) else None
@@ -103,7 +105,8 @@ class TTF_T2V_XAttn(nn.Module):
         flag = None if mode == "off" else self._nan.get(V.device)
         E_txt, M = TTFT2VXAttnFn.apply(V, f32(tau), T, self.n_heads, self.p_drop, training, resolve_precision(self),
                                        self.last_seed, flag, packed,
-                                       None if packed is None else packed.lengths, not tail, *self._params())
+                                       None if packed is None else packed.lengths,
+                                       "handover" if tail == "handover" else (not tail), *self._params())
         if mode == "sync":
             self._nan.raise_if_set("Input embeddings V contain NaN values.")
         return E_txt, M.view(torch.bool).view(B, 1)

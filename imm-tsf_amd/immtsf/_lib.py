@@ -11,8 +11,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libimmtsf_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 FORM_NO_PROJ = 16        # immtsf_fusion_cfg.form bit (IMMTSF_FORM_NO_PROJ)
+FORM_HALF_OUT = 32       # ... IMMTSF_FORM_HALF_OUT: the fp32 output is not written, its bf16 image is all the consumer reads
+FORM_LOWRANK_OUT = 64    # ... IMMTSF_FORM_LOWRANK_OUT: dZ = dP Wc is not written, the producer's backward takes (dP, Wc)
 BWD_PHASE_A, BWD_PHASE_B, BWD_PHASE_C = 1, 2, 4      # immtsf_fusion_cfg.bwd_phase bits: data paths (IMMTSF_BWD_PHASE_*)
 BWD_WGRAD_A, BWD_WGRAD_B, BWD_WGRAD_C = 16, 32, 64   # ... and parameter gradients (IMMTSF_BWD_WGRAD_*)
 
@@ -35,7 +37,12 @@ class FusionCfg(C.Structure):
                 ("d", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32), ("training", C.c_int32),
                 ("p_drop", C.c_float), ("kappa", C.c_float), ("seed", C.c_uint64), ("seed_step_dev", C.c_void_p), ("grads_prezeroed", C.c_int32),
                 ("form", C.c_int32), ("in_h", C.c_void_p), ("aux_h", C.c_void_p), ("out_h", C.c_void_p), ("sched_flag", C.c_void_p),
-                ("bwd_phase", C.c_int32), ("reserved0", C.c_int32), ("note_index", C.c_void_p)]
+                ("bwd_phase", C.c_int32), ("reserved0", C.c_int32), ("note_index", C.c_void_p), ("lr_grad", C.c_void_p)]
+
+
+class LowRankGrad(C.Structure):
+    """immtsf_lowrank_grad: an upstream gradient as coef (rows, rank; pitch ld) x basis (rank, d)"""
+    _fields_ = [("coef", C.c_void_p), ("basis", C.c_void_p), ("rank", C.c_int32), ("ld", C.c_int32)]
 
 
 def _ptr_struct(name, fields):
@@ -92,6 +99,8 @@ _PROTOS = {
     "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_folded": (C.c_int, [_P(FusionCfg)]),
+    "immtsf_ttf_t2v_xattn_accepts_lowrank": (C.c_int, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_xrank_lowrank_basis": (C.c_int, [_P(FusionCfg), C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "immtsf_ttf_t2v_xattn_forward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, c_u8p, C.c_void_p,
                                                C.c_size_t, c_i32p, c_stream]),
     "immtsf_ttf_t2v_xattn_backward": (C.c_int, [_P(FusionCfg), _P(T2VParams), c_f32p, c_f32p, c_f32p, C.c_void_p,
@@ -210,6 +219,15 @@ _PROTOS = {
     "immtsf_period_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_stream]),
     "immtsf_conv2d_period_forward": (C.c_int, [C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                                C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_conv2d_periods_forward": (C.c_int, [C.c_int32, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
+                                                c_f32p, c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int32, c_stream]),
+    "immtsf_conv2d_periods_scratch_floats": (C.c_size_t, [C.c_int32] * 6),
+    "immtsf_conv2d_periods_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32,
+                                                 C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                                 c_stream]),
+    "immtsf_period_aggregate_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_stream]),
+    "immtsf_period_aggregate_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
+                                                   c_stream]),
     "immtsf_conv2d_period_scratch_floats": (C.c_size_t, [C.c_int32] * 5),
     "immtsf_conv2d_period_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                                 c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),
@@ -317,7 +335,7 @@ _PROTOS = {
 # the structs of the ABI in immtsf_abi_sizes' order (tests/test_abi.py compares ctypes.sizeof with the library's sizeof)
 def abi_structs():
     return [FusionCfg, T2VParams, RecAvgParams, XAddParams, GRParams, TTCNParams, GCNParams, DecoderParams, Time2VecParams,
-            EncoderLayerCfg, EncoderLayerParams, FFNBlockCfg, FFNBlockParams, Store, NoteIndex]
+            EncoderLayerCfg, EncoderLayerParams, FFNBlockCfg, FFNBlockParams, Store, NoteIndex, LowRankGrad]
 
 
 _lib = None

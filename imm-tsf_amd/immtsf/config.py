@@ -112,6 +112,11 @@ head_dy_ptr = None        # ... and, when a head took the flag: the address of t
 # TTF_T2V_XAttn on PackedNotes: use the batch's prebuilt ragged index (PackedNotes.index(), built once per batch) instead of deriving
 # it inside every forward; False: the call derives it (two launches at its head) -- the cross-check
 note_index = True
+# the fused TTF_T2V_XAttn -> MMF_XAttn_Add tail (FusionModel.fused_tail) hands Z over as its bf16 image ALONE (no fp32 Z: it has no reader
+# in the bf16 dataflow) and takes the gradient back in LOW-RANK form (dP, Wc) -- dZ = dP Wc is formed inside the LayerNorm backward
+# instead of being written and re-read (0.8 GB per step at 4096 windows, one launch on the text chain at 64).  False: the dense hand-over
+# in both directions -- the cross-check
+z_handover = os.environ.get("IMMTSF_Z_HANDOVER", "1") != "0"
 # FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); False: batched GEMMs +
 # row softmax
 attn_mid = True

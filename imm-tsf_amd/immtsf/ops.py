@@ -135,6 +135,31 @@ def _shadow_get(x):
     return None
 
 
+# ---- hand-over of the fused tail (config.z_handover).  Forward: the producer (TTFT2VXAttnFn) registers its output Z with the cfg of its
+# call; the consumer (MMFXRankPFn) that is handed the same data finds it and may ask the library whether the producer's backward takes a
+# low-rank gradient.  Backward: the consumer registers (dZ placeholder -> dP, Wc); the producer's backward looks its incoming gradient up.
+_handover = []         # [(storage, data_ptr, shape, version, FusionCfg of the producer's call, half_only)]
+_lowrank = []          # [(storage, data_ptr, shape, version, (LowRankGrad struct, tensors it points into))]
+
+
+def _reg_put(reg, t, payload):
+    reg.append((t.untyped_storage(), t.data_ptr(), tuple(t.shape), t._version, payload))
+    if len(reg) > _SHADOW_CAP:
+        del reg[0]
+
+
+def _reg_take(reg, x, pop=False):
+    if x is None or not x.is_contiguous():
+        return None
+    for i in range(len(reg) - 1, -1, -1):
+        _st, p, shape, ver, payload = reg[i]
+        if p == x.data_ptr() and shape == tuple(x.shape) and x._version == ver:
+            if pop:
+                del reg[i]
+            return payload
+    return None
+
+
 def _bf16_dataflow(precision, d):
     return precision == 1 and d >= 16 and d % 16 == 0
 
@@ -180,7 +205,11 @@ class TTFT2VXAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, notes, tau, T, H, p_drop, training, precision, seed, nan_flag, src_rows, lengths, no_proj, *params):
+        # no_proj: False | True | "handover" (True + config.z_handover's promises: the output's only consumer reads the bf16 image when there
+        # is one, and may send its gradient back in low-rank form)
         lib = _lib.load()
+        handover = no_proj == "handover" and config.z_handover
+        no_proj = bool(no_proj)
         notes, tau = _c(notes), _c(tau)
         params = tuple(_c(p) for p in params)
         _need_gpu(notes, tau, *params)
@@ -206,6 +235,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         if _bf16_dataflow(precision, d) and d_m % 8 == 0:
             E_h = torch.empty(B, T, d, dtype=torch.bfloat16, device=notes.device)
             cfg.out_h = E_h.data_ptr()
+        if handover and E_h is not None and config.nan_check != "sync":
+            cfg.form |= _lib.FORM_HALF_OUT        # (E stays unwritten: whoever reads it must take the image -- MMFXRankPFn checks)
         if index is not None:
             cfg.note_index = C.addressof(index[0])
             M = index[1]["mtxt"].view(-1)        # (a fresh tensor object over the batch's M_txt: no copy, no launch)
@@ -220,6 +251,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         cfg.out_h = None
         if E_h is not None:
             _shadow_put(E, E_h)
+        if handover:
+            _reg_put(_handover, E, (cfg, bool(cfg.form & _lib.FORM_HALF_OUT)))
         ctx.cfg, ctx.ws, ctx.src_rows = cfg, ws, src_rows
         # scheduling hint of a two-stream captured step (immtsf.train.GraphedStep): this call's backward will set the gate behind its
         # row-bound kernels; remember who promised, so that nobody waits for a flag nobody sets
@@ -254,6 +287,8 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         ctx.cfg.sched_flag = ctx.gate
         dE_h = _shadow_get(dE) if _bf16_dataflow(ctx.cfg.precision, ctx.cfg.d) else None
         ctx.cfg.in_h = None if dE_h is None else dE_h.data_ptr()
+        lowrank = _reg_take(_lowrank, dE, pop=True) if ctx.no_proj else None      # (dE is then an unwritten placeholder: dZ = coef basis)
+        ctx.cfg.lr_grad = None if lowrank is None else C.addressof(lowrank[0])
         cfg, hooks = ctx.cfg, ctx.phase_hooks
         packed = ctx.src_rows is not None
 
@@ -282,7 +317,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
             check(lib.immtsf_flag_set(flag, stream_ptr()), "flag_set")
             call(_lib.BWD_PHASE_C | _lib.BWD_WGRAD_C)
             early = [h for ph, h in hooks if ph < 2]
-            keep = (notes, tau, dE, sc, ps, gs, params, grads, dE_h)          # the job runs later, on another stream: everything it touches stays alive
+            keep = (notes, tau, dE, sc, ps, gs, params, grads, dE_h, lowrank)   # the job runs later, on another stream: everything it touches stays alive
 
             def job(stream, keep=keep):
                 check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
@@ -305,6 +340,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
                 for ph, h in hooks:
                     if ph == c:
                         _fire(h)
+        cfg.lr_grad = None
         if ctx.no_proj:         # (proj_out's gradients come out of the consumer's backward)
             rets = list(rets)
             rets[15] = rets[16] = None
@@ -601,6 +637,13 @@ class MMFXRankPFn(torch.autograd.Function):
         E_h = _shadow_get(E) if _bf16_dataflow(precision, d) else None
         cfg.in_h = None if E_h is None else E_h.data_ptr()
         ctx.E_h = E_h
+        # the fused tail's hand-over (config.z_handover): did the producer promise to take a low-rank gradient for this Z?
+        ho = _reg_take(_handover, E, pop=True) if proj is not None else None      # (one consumer: the entry has done its work)
+        ctx.lowrank = False
+        if ho is not None:
+            if ho[1] and E_h is None:
+                raise _lib.ImmtsfError("Z was handed over as its bf16 image alone (config.z_handover) but the image is gone")
+            ctx.lowrank = bool(lib.immtsf_ttf_t2v_xattn_accepts_lowrank(C.byref(ho[0]), pw))
         # the fold depends on parameters only: with config.fold_stream (immtsf.train.FlagStep) it runs on that stream, beside the
         # text side's own forward, and this stream picks it up just before the projection
         L = config.fold_stream
@@ -643,8 +686,10 @@ class MMFXRankPFn(torch.autograd.Function):
             pgrads, prets = _grad_buffers(proj, ctx.proj_sinks)
         params = list(params9) + [None, None]
         grads, rets = _grad_buffers(params, ctx.sinks)
-        dE = torch.empty_like(E)
+        dE = torch.empty_like(E)          # (low-rank hand-over: an unwritten placeholder that carries the registration below)
         cfg = ctx.cfg
+        lowrank = ctx.lowrank and proj is not None and config.z_handover
+        cfg.form = (cfg.form | _lib.FORM_LOWRANK_OUT) if lowrank else (cfg.form & ~_lib.FORM_LOWRANK_OUT)
         sc = _bytes(lib.immtsf_mmf_xrank_p_scratch_bytes(C.byref(cfg)), E.device)
         ps, gs = _struct(XAddParams, params), _struct(XAddParams, grads)
         dP = dP.contiguous()
@@ -715,6 +760,11 @@ class MMFXRankPFn(torch.autograd.Function):
                                                          C.byref(gs), 0, 3, stream_ptr()), "mmf_xrank_p_backward_params")
         if dE_h is not None:
             _shadow_put(dE, dE_h)
+        if lowrank:
+            basis, rank = C.c_void_p(), C.c_int32()
+            check(lib.immtsf_mmf_xrank_lowrank_basis(C.byref(cfg), ptr(ctx.ws), ctx.ws.numel(), C.byref(basis), C.byref(rank)),
+                  "mmf_xrank_lowrank_basis")
+            _reg_put(_lowrank, dE, (_lib.LowRankGrad(dP.data_ptr(), basis.value, rank.value, dP.shape[-1]), dP, ctx.ws))
         _fire(ctx.done_hook)
         return (dE, None, None, None, None) + tuple(rets[:9]) + (tuple(prets) if proj is not None else ())
 
@@ -1254,6 +1304,89 @@ class Conv2dPeriodFn(torch.autograd.Function):
         check(lib.immtsf_conv2d_period_backward(precision, ptr(col), ptr(z), ptr(dy), B, Lmax, ptr(period), ptr(rows), Cin, KS, ptr(Weff), Cout,
                                                 act, ptr(dx), ptr(dW), ptr(db), ptr(scratch), ptr(w16), stream_ptr()), "conv2d_period_backward")
         return dx, None, None, dW, db, None, None, None, None, None, None
+
+
+class Conv2dPeriodsFn(torch.autograd.Function):
+    """Conv2dPeriodFn for the k period images of a TimesBlock in ONE call (immtsf_conv2d_periods_forward / _backward): x is one input shared
+    by every image, (R, Cin), or one per image, (k, R, Cin); y (k, R, Cout).  In bf16 mode the images ride along grid.z of one im2col and
+    one product launch per direction; the kernel's gradient is the sum over the images, accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, period, rows, Weff, beff, KS, act, precision, B, Lmax):
+        lib = _lib.load()
+        x, Weff, beff = _c(x), _c(Weff), _c(beff)
+        _need_gpu(x, Weff, beff)
+        k = period.numel()
+        shared = x.dim() == 2
+        Cin, Cout = x.shape[-1], Weff.shape[0]
+        R, K = B * Lmax, KS * KS * Cin
+        hf = precision == 1 and Cin % 8 == 0 and Cout % 8 == 0
+        col = torch.empty(k, R, K, dtype=torch.bfloat16 if hf else torch.float32, device=x.device)
+        w16 = torch.empty(Cout, K, dtype=torch.bfloat16, device=x.device) if hf else None
+        z = torch.empty(k, R, Cout, dtype=torch.float32, device=x.device) if act == 2 else None
+        y = torch.empty(k, R, Cout, dtype=torch.float32, device=x.device)
+        check(lib.immtsf_conv2d_periods_forward(precision, ptr(x), 0 if shared else R * Cin, B, Lmax, k, ptr(period), ptr(rows), Cin, KS, ptr(Weff),
+                                                ptr(beff), Cout, act, ptr(col), ptr(z), ptr(y), ptr(w16), 0, stream_ptr()), "conv2d_periods_forward")
+        ctx.hf, ctx.shared = hf, shared
+        ctx.save_for_backward(col, z, Weff, period, rows)
+        ctx.dims = (B, Lmax, Cin, KS, Cout, act, precision, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        col, z, Weff, period, rows = ctx.saved_tensors
+        B, Lmax, Cin, KS, Cout, act, precision, k = ctx.dims
+        dy = dy.contiguous()
+        R = B * Lmax
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, Cin) if ctx.shared else (k, R, Cin), dtype=torch.float32, device=dy.device)
+        acc = torch.zeros(Weff.numel() + Cout, dtype=torch.float32, device=dy.device)      # dW | db: the images add into it
+        dW, db = acc[:Weff.numel()].view_as(Weff), acc[Weff.numel():]
+        scratch = torch.empty(lib.immtsf_conv2d_periods_scratch_floats(B, Lmax, k, Cin, KS, Cout), dtype=torch.float32, device=dy.device)
+        w16 = torch.empty(1, dtype=torch.bfloat16, device=dy.device) if ctx.hf else None
+        check(lib.immtsf_conv2d_periods_backward(precision, ptr(col), ptr(z), ptr(dy), B, Lmax, k, ptr(period), ptr(rows), Cin, KS, ptr(Weff), Cout,
+                                                 act, ptr(dx), 1 if ctx.shared else 0, ptr(dW), ptr(db), ptr(scratch), ptr(w16), stream_ptr()),
+              "conv2d_periods_backward")
+        return dx, None, None, dW, db, None, None, None, None, None
+
+
+class PeriodAggregateFn(torch.autograd.Function):
+    """TimesBlock's aggregation of the k period images and its residual as one launch (immtsf_period_aggregate_forward / _backward):
+    (Y (k, Lmax*B, N) position-major, w (B, k) softmax weights, x (B, total, N)) -> x + sum_j w[:, j] Y_j cropped to `total` steps."""
+
+    @staticmethod
+    def forward(ctx, Y, w, x, B, total, Lmax):
+        lib = _lib.load()
+        Y, w, x = _c(Y), _c(w), _c(x)
+        _need_gpu(Y, w, x)
+        k, N = Y.shape[0], Y.shape[2]
+        out = torch.empty_like(x)
+        check(lib.immtsf_period_aggregate_forward(ptr(Y), ptr(w), ptr(x), B, total, Lmax, N, k, ptr(out), stream_ptr()), "period_aggregate_forward")
+        ctx.save_for_backward(Y, w)
+        ctx.dims = (B, total, Lmax, N, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        Y, w = ctx.saved_tensors
+        B, total, Lmax, N, k = ctx.dims
+        dout = dout.contiguous()
+        dY, dw = torch.empty_like(Y), torch.empty_like(w)
+        check(lib.immtsf_period_aggregate_backward(ptr(Y), ptr(w), ptr(dout), B, total, Lmax, N, k, ptr(dY), ptr(dw), stream_ptr()),
+              "period_aggregate_backward")
+        return dY, dw, dout, None, None, None
+
+
+def conv2d_periods(x, period, rows, Weff, beff, KS, B, Lmax, act=None, precision=None):
+    return Conv2dPeriodsFn.apply(x.float(), period, rows, Weff, beff, int(KS), 2 if act == "gelu" else 0, config.precision_code(precision),
+                                 int(B), int(Lmax))
+
+
+def period_aggregate(Y, w, x, B, total, Lmax):
+    return PeriodAggregateFn.apply(Y, w.float(), x.float(), int(B), int(total), int(Lmax))
 
 
 def period_rows(top, total, B):

@@ -100,6 +100,14 @@ _SEEN_CAP = 64
 _graphs = weakref.WeakKeyDictionary()      # model -> {key: _SeamGraph}, most recently used last
 _seen = weakref.WeakKeyDictionary()        # model -> {key: eager calls so far} (bounded)
 _pool = {}                                 # device index -> shared graph memory pool handle
+_pool_users = {}                           # device index -> live seam graphs in that pool (the handle dies with the last of them)
+
+
+def _pool_release(index):
+    _pool_users[index] = _pool_users.get(index, 1) - 1
+    if _pool_users[index] <= 0:            # the allocator retires a pool nobody captures into: a later graph must not be given its handle
+        _pool.pop(index, None)
+        _pool_users.pop(index, None)
 
 
 class _SeamLoss(torch.autograd.Function):
@@ -191,6 +199,8 @@ class _SeamGraph:
         pool = _pool.get(dev.index)
         if pool is None:
             pool = _pool[dev.index] = torch.cuda.graph_pool_handle()
+        _pool_users[dev.index] = _pool_users.get(dev.index, 0) + 1
+        weakref.finalize(self, _pool_release, dev.index)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, pool=pool):
             self.loss, self.grads = run()

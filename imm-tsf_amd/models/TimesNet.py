@@ -11,8 +11,7 @@ import torch.fft
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf import config
-from immtsf.ops import INCEPTION_MAX, conv2d_period, conv2d_same_cl, inception_merge, layer_norm, linear, period_rows
+from immtsf.ops import INCEPTION_MAX, conv2d_periods, conv2d_same_cl, inception_merge, layer_norm, linear, period_aggregate, period_rows
 from layers.Conv_Blocks import Inception_Block_V1
 from layers.Embed import DataEmbedding
 from models._common import pad_history, plain_instance_norm
@@ -63,16 +62,10 @@ class TimesBlock(nn.Module):
             period, rows = period_rows(top, total, B)
             Lmax = 2 * total                   # length < total + period <= 2 total
             xl = F.pad(x.transpose(0, 1), (0, 0, 0, 0, 0, Lmax - total)).reshape(Lmax * B, N)
-            bf16 = config.precision == "bf16"
-            W1h, W2h = (W1.detach().to(torch.bfloat16), W2.detach().to(torch.bfloat16)) if bf16 else (None, None)      # one cast for all periods
-            res = []
-            for j in range(self.k):
-                img = conv2d_period(xl, period[j:j + 1], rows[j:j + 1], W1, b1, K1, B, Lmax, act="gelu", w16=W1h)
-                out = conv2d_period(img, period[j:j + 1], rows[j:j + 1], W2, b2, K2, B, Lmax, w16=W2h)
-                res.append(out.view(Lmax, B, N)[:total].transpose(0, 1))
-            res = torch.stack(res, dim=-1)
-            w = F.softmax(weight, dim=1).unsqueeze(1).unsqueeze(1)
-            return (res * w).sum(-1) + x
+            # the k period images in ONE call per convolution (the same merged kernel for each), then the aggregation + residual as one launch
+            img = conv2d_periods(xl, period, rows, W1, b1, K1, B, Lmax, act="gelu")            # (k, Lmax B, d_ff)
+            out = conv2d_periods(img, period, rows, W2, b2, K2, B, Lmax)                       # (k, Lmax B, N)
+            return period_aggregate(out, F.softmax(weight, dim=1), x, B, total, Lmax)
         periods, weight = FFT_for_Period(x, self.k)
         res = []
         for period in periods:

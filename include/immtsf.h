@@ -35,10 +35,16 @@
 extern "C" {
 #endif
 
-#define IMMTSF_ABI_VERSION 5
+#define IMMTSF_ABI_VERSION 6
 #define IMMTSF_T2V_FOLD_MIN_ROWS 8192 /* see immtsf_fusion_cfg.form */
 #define IMMTSF_FORM_NO_PROJ 16        /* immtsf_fusion_cfg.form bit, TTF_T2V_XAttn: leave proj_out to the consumer (E_txt := Z, dE_txt := dZ,
                                          which the backward overwrites in place; proj_out's gradients are not written) */
+#define IMMTSF_FORM_HALF_OUT 32       /* immtsf_fusion_cfg.form bit, TTF_T2V_XAttn forward with out_h in the bf16 dataflow: the caller promises
+                                         that the output's only reader takes the bf16 image -- the fp32 E_txt (0.4 GB per step at 4096
+                                         windows, with no reader) is NOT written.  (ABI 6) */
+#define IMMTSF_FORM_LOWRANK_OUT 64    /* immtsf_fusion_cfg.form bit, immtsf_mmf_xrank_p_backward_data_z: dZ = dP Wc is NOT written -- the producer's
+                                         backward takes the pair (dP, Wc) itself (immtsf_fusion_cfg.lr_grad, immtsf_mmf_xrank_lowrank_basis).
+                                         (ABI 6) */
 
 #define IMMTSF_OK 0
 #define IMMTSF_EINVAL (-1)       /* bad dimension / null pointer */
@@ -50,10 +56,10 @@ typedef void* immtsf_stream_t;
 int immtsf_abi_version(void);
 /* sizeof of every struct of this ABI, in the order immtsf_fusion_cfg, immtsf_t2v_params, immtsf_recavg_params, immtsf_xadd_params,
  * immtsf_gr_params, immtsf_ttcn_params, immtsf_gcn_params, immtsf_decoder_params, immtsf_time2vec_params, immtsf_encoder_layer_cfg,
- * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store, immtsf_note_index: lets a binding check its
- * own struct definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes min(max, 15) entries to
- * the HOST array `out`, returns the number of structs (15).  (ABI 5) */
-#define IMMTSF_ABI_NSTRUCTS 15
+ * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store, immtsf_note_index, immtsf_lowrank_grad: lets a
+ * binding check its own struct definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes
+ * min(max, 16) entries to the HOST array `out`, returns the number of structs (16).  (ABI 5; 16 structs from ABI 6) */
+#define IMMTSF_ABI_NSTRUCTS 16
 int immtsf_abi_sizes(int32_t* out, int32_t max);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -110,7 +116,18 @@ typedef struct immtsf_fusion_cfg {
                                       (immtsf.data / SURVEY 8f row 1: "offsets authoritative") -- instead of inside every forward.  HOST
                                       struct of device pointers; forward and backward of a call pair get the same one; M_txt may then be NULL
                                       (it is note_index->mtxt).  (ABI 5) */
+    const struct immtsf_lowrank_grad* lr_grad; /* TTF_T2V_XAttn backward with IMMTSF_FORM_NO_PROJ, optional (NULL = dE_txt holds dZ): the upstream
+                                      gradient in LOW-RANK form, dZ = coef basis -- what a rank-r projection behind the block sends back
+                                      (MMF_XAttn_Add's composed projection).  The LayerNorm backward forms the product in registers; dE_txt
+                                      is then not read (it must still be a valid pointer).  Only where immtsf_ttf_t2v_xattn_accepts_lowrank
+                                      says so.  HOST struct of device pointers.  (ABI 6) */
 } immtsf_fusion_cfg;
+typedef struct immtsf_lowrank_grad {
+    const float* coef;             /* (B*T, rank) row-major, pitch ld */
+    const float* basis;            /* (rank, d) row-major, 16-byte aligned */
+    int32_t rank;
+    int32_t ld;
+} immtsf_lowrank_grad;
 /* the ragged index of a packed batch (what immtsf_ragged_index derives from a zero-padded tensor): mask u8 (B*N: n < lengths[b]), mtxt u8
  * (B: lengths[b] > 0), lengths i32 (B), offsets i32 (B+1; offsets[B] = total notes), rowmap i32 (B*N; packed row -> b*N+n), seg i32 (B*N;
  * packed row -> window).  Reference: the quantities fusions/TTF_T2V_XAttn.py:107,124,146 re-derive from the padded tensor every call. */
@@ -162,6 +179,10 @@ size_t immtsf_ttf_t2v_xattn_scratch_bytes(const immtsf_fusion_cfg* cfg);
  * parameter gradients by the chain rule through the folded factors), 0 when they run the reference's GEMM chain as written
  * (cfg->form == 1, or a shape outside the folded form's limits).  reference: fusions/TTF_T2V_XAttn.py:120-182 either way. */
 int immtsf_ttf_t2v_xattn_folded(const immtsf_fusion_cfg* cfg);
+/* 1 when the backward of calls with this cfg (IMMTSF_FORM_NO_PROJ set) takes its upstream gradient in low-rank form of this rank
+ * (immtsf_fusion_cfg.lr_grad), 0 otherwise: the one-pass LayerNorm backward with sums must apply (d % 4 == 0, 256 <= d <= 1024, B*T >= 512,
+ * (rank + 3) d floats of LDS <= 150 KB, rank <= 64) and, in the folded form, x_hat must be the bf16 image.  (ABI 6) */
+int immtsf_ttf_t2v_xattn_accepts_lowrank(const immtsf_fusion_cfg* cfg, int32_t rank);
 /* notes (B,N,d_m), tau (B,N)  ->  E_txt (B,T,d), M_txt u8 (B).  t_hat's values do not enter this block (only T). */
 int immtsf_ttf_t2v_xattn_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, const float* notes,
                                  const float* tau, float* E_txt, uint8_t* M_txt, void* workspace, size_t workspace_bytes,
@@ -305,6 +326,10 @@ int immtsf_mmf_xrank_p_forward_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd
 int immtsf_mmf_xrank_p_backward_data_z(const immtsf_fusion_cfg* cfg, const immtsf_xadd_params* p, const float* proj_w, const float* proj_b,
                                        const float* Z, const float* dP, float* dZ, void* workspace, size_t workspace_bytes, void* scratch,
                                        size_t scratch_bytes, immtsf_stream_t stream);
+/* the basis of the low-rank gradient ..._backward_data_z sends back (dZ = dP Wc): *basis = Wc (rank x d, fp32, inside `workspace`: valid
+ * while the forward's workspace lives), *rank = immtsf_mmf_xrank_pw(cfg).  With IMMTSF_FORM_LOWRANK_OUT in cfg->form the data call leaves
+ * dZ unwritten and the producer's backward is given {dP, Wc, rank, ld = rank} as immtsf_fusion_cfg.lr_grad.  (ABI 6) */
+int immtsf_mmf_xrank_lowrank_basis(const immtsf_fusion_cfg* cfg, void* workspace, size_t workspace_bytes, const float** basis, int32_t* rank);
 int immtsf_mmf_xrank_p_backward_pre_z(const immtsf_fusion_cfg* cfg, const float* proj_w, const float* proj_b, void* workspace,
                                       size_t workspace_bytes, void* scratch, size_t scratch_bytes, float* g_proj_w, float* g_proj_b,
                                       immtsf_stream_t stream);
@@ -792,6 +817,28 @@ size_t immtsf_conv2d_period_scratch_floats(int32_t B, int32_t Lmax, int32_t Cin,
 int immtsf_conv2d_period_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout, int32_t act,
                                   float* dx, float* dW_eff, float* db_eff, float* scratch, void* w16, immtsf_stream_t stream);
+/* k period images in ONE call (TimesBlock: the top-k periods share one merged kernel; reference models/TimesNet.py:62-79 loops over them).
+ * x: one input shared by every image (x_stride == 0) or k inputs x + j x_stride floats; period / rows: k device numbers each; y, z_pre:
+ * (k, B*Lmax, Cout); col: k im2col images (bf16 in bf16 mode, else fp32).  In bf16 mode the k images ride along grid.z of ONE im2col and ONE
+ * product launch (bias + GELU in its epilogue); otherwise the call is the k single-image calls.  k <= 16.  Backward: dx is (B*Lmax, Cin),
+ * summed over the images, when dx_shared, else (k, B*Lmax, Cin); dW_eff / db_eff receive the SUM over the images by accumulation -- the
+ * caller hands them in ZEROED.  (ABI 6) */
+int immtsf_conv2d_periods_forward(int32_t precision, const float* x, int64_t x_stride, int32_t B, int32_t Lmax, int32_t k, const int32_t* period,
+                                  const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act,
+                                  float* col, float* z_pre, float* y, void* w16, int32_t w16_ready, immtsf_stream_t stream);
+size_t immtsf_conv2d_periods_scratch_floats(int32_t B, int32_t Lmax, int32_t k, int32_t Cin, int32_t KS, int32_t Cout);
+int immtsf_conv2d_periods_backward(int32_t precision, const float* col, const float* z_pre, const float* dy, int32_t B, int32_t Lmax, int32_t k,
+                                   const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout,
+                                   int32_t act, float* dx, int32_t dx_shared, float* dW_eff, float* db_eff, float* scratch, void* w16,
+                                   immtsf_stream_t stream);
+/* TimesBlock's adaptive aggregation on the position-major images (reference models/TimesNet.py:80-86: stack the cropped images, weight them
+ * with softmax(amplitude), sum, add the residual): out[b, t, :] = x[b, t, :] + sum_j w[b, j] Y[j, t B + b, :], t < total; Y (k, Lmax*B, N), w
+ * (B, k) the softmax weights, x / out (B, total, N).  Backward: dY (k, Lmax*B, N) -- zero on the rows the crop dropped --, dw (B, k); the
+ * residual's gradient is dout itself.  (ABI 6) */
+int immtsf_period_aggregate_forward(const float* Y, const float* w, const float* x, int32_t B, int32_t total, int32_t Lmax, int32_t N, int32_t k,
+                                    float* out, immtsf_stream_t stream);
+int immtsf_period_aggregate_backward(const float* Y, const float* w, const float* dout, int32_t B, int32_t total, int32_t Lmax, int32_t N, int32_t k,
+                                     float* dY, float* dw, immtsf_stream_t stream);
 
 /* ---- measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by hipEvents on the
  * stream it is launched on.  collect() synchronises those events and fills HOST arrays meta[10*max] = (layout,

@@ -1027,6 +1027,75 @@ def test_fused_tail_equals_separate_blocks(B, N, T, d_m, d, H, Cc, pd, form, pre
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("form", ["fold", "chain"])
+@pytest.mark.parametrize("B,N,T,d_m,d,H,Cc,pd", [(64, 32, 32, 768, 768, 1, 8, 0.1), (40, 20, 16, 256, 256, 2, 4, 0.2), (20, 40, 32, 128, 1024, 4, 3, 0.1),
+                                                 (300, 12, 30, 64, 512, 1, 15, 0.0)])      # (the last: >= 8192 rows -- four rows per wave)
+def test_z_handover_equals_dense_handover(B, N, T, d_m, d, H, Cc, pd, form, precision):
+    """the fused tail with immtsf.config.z_handover (Z leaves TTF_T2V_XAttn as its bf16 image alone -- IMMTSF_FORM_HALF_OUT --, the gradient
+    comes back as the pair (dP, Wc) -- IMMTSF_FORM_LOWRANK_OUT / immtsf_fusion_cfg.lr_grad -- and dZ = dP Wc is formed inside the LayerNorm
+    backward, csrc/rowops.hip layernorm_bwd_lr_kernel) against the dense hand-over in both directions: output, dY_ts and every parameter
+    gradient, both TTF forms, with dropout.  reference: fusions/TTF_T2V_XAttn.py:176-182 feeding fusions/MMF_XAttn_Add.py:56-75."""
+    dev = _dev()
+    from fusions.FusionModel import FusionModel
+    from fusions.load_llm import register_d_model
+    from immtsf import config, ops
+    register_d_model(f"FT{d_m}", d_m)
+    config.precision = precision
+    torch.manual_seed(B * 10 + T)
+    a = types.SimpleNamespace(TTF_module="TTF_T2V_XAttn", MMF_module="MMF_XAttn_Add", llm_model_fusion=f"FT{d_m}", llm_layers_fusion=6,
+                              max_length=1024, device="cuda", use_text_embeddings=True, recency_sigma=1.0, n_heads_fusion=H, dropout=pd,
+                              d_txt=d, C=Cc, kappa=0.5)
+    m = FusionModel(a).to(dev).train()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    g = torch.Generator().manual_seed(B + 3 * T)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    lengths[1] = 0
+    keep = torch.arange(N).view(1, -1) < lengths.view(-1, 1)
+    notes = (torch.randn(B, N, d_m, generator=g) * keep.unsqueeze(-1)).to(dev)
+    tau = (torch.sort(torch.rand(B, N, generator=g) * 24.0, dim=1).values * keep).to(dev)
+    t_hat = torch.rand(B, T, generator=g).to(dev)
+    Y = torch.randn(B, T, Cc, generator=g).to(dev)
+    up = torch.randn(B, T, Cc, generator=g).to(dev)
+    res, seed0, took = [], config.next_seed, []
+    put0 = ops._reg_put
+    try:
+        config.t2v_form, config.fuse_tail = form, True
+        for ho in (True, False):
+            config.z_handover = ho
+            seeds = iter([5151, 6262, 7373, 8484])
+            config.next_seed = lambda: next(seeds)
+            n_lr = [0]
+
+            def counting_put(reg, t, payload, n_lr=n_lr):
+                if reg is ops._lowrank:
+                    n_lr[0] += 1
+                return put0(reg, t, payload)
+            ops._reg_put = counting_put
+            m.zero_grad()
+            y = Y.clone().requires_grad_(True)
+            out = m(notes, tau, t_hat, y)
+            (out * up).sum().backward()
+            took.append(n_lr[0])
+            res.append([("out", out.detach()), ("dY", y.grad)] + [(k, p_.grad.clone()) for k, p_ in m.named_parameters()])
+    finally:
+        ops._reg_put = put0
+        config.next_seed, config.fuse_tail, config.t2v_form, config.precision, config.z_handover = seed0, "auto", "auto", "fp32", True
+    # the low-rank gradient was really taken where the library says it can be (fold: the bf16 x_hat image only), and never without the knob
+    assert took[1] == 0 and took[0] == (1 if (form == "chain" or precision == "bf16") else 0), took
+    assert not ops._lowrank or ops._lowrank[-1][1] != 0
+    tol = 2e-4 if precision == "fp32" else 4e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][2:])
+    for (k, a_), (_, b_) in zip(*res):
+        assert torch.isfinite(a_).all(), k
+        den = float(b_.norm()) + (1e-3 * gmax * b_.numel() ** 0.5 if k not in ("out", "dY") else 1e-6) + 1e-30
+        err = float((a_ - b_).norm()) / den
+        assert err <= (2.5e-1 if precision == "bf16" and k.startswith("ttf.time2vec.linear") else tol), (k, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("B,T,Cc,d,H,pd", [(5, 7, 3, 32, 1, 0.0), (6, 32, 8, 64, 2, 0.2), (64, 32, 8, 768, 1, 0.1), (300, 6, 15, 16, 1, 0.1)])
 def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precision):
     """MMF_XAttn_Add.forward_loss (immtsf_mmf_xrank_q_train: the Q half, the masked MSE with known observation counts and the backward

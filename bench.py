@@ -741,6 +741,33 @@ def hbm_roofline(w, lib, roof):
         _lib.check(lib.immtsf_ragged_index(_lib.ptr(notes), B, N, d_m, _lib.ptr(mask), _lib.ptr(lengths), _lib.ptr(offsets),
                                            _lib.ptr(rowmap), _lib.ptr(seg), _lib.ptr(mtxt), None, _lib.stream_ptr()), "ragged_index")
     out = []
+    # the gather that IS in the timed step (packed notes, bf16 mode): notes_stage_kernel -- a wave per packed note: d_m fp32 read from the
+    # resident embedding matrix, d_m + d/2 bf16 written (the note and the Time2Vec of its time stamp: the fold's / the chain's X operand)
+    pk = w.batch.get("notes_embeddings") if isinstance(getattr(w, "batch", None), dict) else None
+    from immtsf.ops import PackedNotes
+    if isinstance(pk, PackedNotes) and hasattr(w.fusion, "ttf") and hasattr(w.fusion.ttf, "time2vec"):
+        ix = pk.index()[1]
+        try:
+            dt = w.fusion.ttf.time2vec.periodic.weight.numel() + 1           # (one linear + dt - 1 periodic features: d / 2)
+            R, ldx = B * N, d_m + dt
+            X = torch.empty(R, ldx, dtype=torch.bfloat16, device=dev)
+            tau = w.batch["tau"].float().contiguous()
+            lw, lb, pw_, pb = [p_.detach().float().contiguous() for p_ in w.fusion.ttf._params()[3:7]]
+            total = ix["offsets"][B:B + 1]
+
+            def stage():
+                _lib.check(lib.immtsf_notes_stage(_lib.ptr(pk.emb), d_m, _lib.ptr(pk.src_rows), _lib.ptr(total), R, _lib.ptr(X), ldx, _lib.ptr(tau),
+                                                  _lib.ptr(ix["rowmap"]), dt, _lib.ptr(lw), _lib.ptr(lb), _lib.ptr(pw_), _lib.ptr(pb),
+                                                  _lib.stream_ptr()), "notes_stage")
+            us = graph_kernel_us(stage, reps=20)
+            n_rows = int(w.sum_n)
+            byts = n_rows * (d_m * 4 + ldx * 2 + 12)
+            out.append({"kernel": "notes_stage_kernel (IN the timed step: gather of the packed notes from the resident embedding matrix, cast to "
+                                  "bf16, Time2Vec of their time stamps beside them -- one wave per note)",
+                        "bytes": byts, "us": round(us, 2), "GB/s": round(byts / us / 1e3, 1), "frac": round(byts / us / 1e3 / PEAK_HBM_GBS, 4),
+                        "rows": n_rows})
+        except Exception as e:       # noqa: BLE001 -- a companion figure must not cost the line
+            out.append({"kernel": "notes_stage_kernel", "error": str(e)[:200]})
     us = graph_kernel_us(ragged, reps=20)
     byts = B * N * d_m * 4 + B * N * 9 + 4 * (2 * B + 1)
     out.append({"kernel": "note_mask + ragged_index (a2: (sum|V| > 0) scan of the padded notes -> lengths/offsets/rowmap"

@@ -327,6 +327,17 @@ int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_st
     return launch_guard_pack(err, slot, is_bf16 ? 1 : 0, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_notes_stage(const float* emb, int32_t d_m, const int32_t* src_rows, const int32_t* total, int32_t max_rows, void* X_h, int32_t ldx,
+                       const float* tau, const int32_t* rowmap, int32_t dt, const float* lin_w, const float* lin_b, const float* per_w,
+                       const float* per_b, immtsf_stream_t stream) {
+    if (!emb || !src_rows || !total || !X_h || !tau || !rowmap || !lin_w || !lin_b || !per_w || !per_b || d_m <= 0 || dt <= 0 || max_rows <= 0 ||
+        ldx < d_m + dt)
+        return IMMTSF_EINVAL;
+    return launch_notes_stage(emb, d_m, src_rows, total, max_rows, d_m, X_h, ldx, tau, rowmap, dt, lin_w, lin_b, per_w, per_b, nullptr, ldx,
+                              static_cast<unsigned short*>(X_h) + d_m, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 1.f,
+                              static_cast<hipStream_t>(stream));
+}
+
 int immtsf_abi_sizes(int32_t* out, int32_t max) {
     const int32_t sz[IMMTSF_ABI_NSTRUCTS] = {
         (int32_t)sizeof(immtsf_fusion_cfg), (int32_t)sizeof(immtsf_t2v_params), (int32_t)sizeof(immtsf_recavg_params),

@@ -1009,28 +1009,52 @@ __global__ __launch_bounds__(512) void layernorm_bwd_lr_kernel(const float* __re
         gm[j] = q < d4 ? reinterpret_cast<const float4*>(gamma)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    for (int row0 = (blockIdx.x * 8 + wave) * R; row0 < rows; row0 += gridDim.x * 8 * R) {
-        float4 dy[R][DV], hv[R][DV];
-        float gl[R];
+    // the next rows' operands (x_hat as stored, the coefficient rows) are fetched while the current ones are worked on: with one
+    // workgroup per CU (the LDS copy of Wb) there are two waves per SIMD to hide a load behind, not eight
+    typedef typename std::conditional<XH, uint2, float4>::type Raw;
+    Raw hr[R][DV];
+    float gn[R];
+    const int stride = gridDim.x * 8 * R;
+    auto fetch = [&](int row0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
             const bool ok = row < rows;
-            gl[r] = (ok && lane < PW) ? G[(size_t)row * ldg + lane] : 0.f;
+            gn[r] = (ok && lane < PW) ? G[(size_t)row * ldg + lane] : 0.f;
 #pragma unroll
             for (int j = 0; j < DV; ++j) {
                 const int q = lane + 64 * j;
-                hv[r][j] = dy[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok && q < d4) {
-                    if (XH) {
-                        const bf16x4 t4 = reinterpret_cast<const bf16x4*>(static_cast<const bf16_t*>(xhat_any) + (size_t)row * d)[q];
-                        hv[r][j] = make_float4((float)t4[0], (float)t4[1], (float)t4[2], (float)t4[3]);
-                    } else {
-                        hv[r][j] = reinterpret_cast<const float4*>(static_cast<const float*>(xhat_any) + (size_t)row * d)[q];
-                    }
+                    if constexpr (XH) hr[r][j] = reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(xhat_any) + (size_t)row * d)[q];
+                    else hr[r][j] = reinterpret_cast<const float4*>(static_cast<const float*>(xhat_any) + (size_t)row * d)[q];
+                } else {
+                    if constexpr (XH) hr[r][j] = make_uint2(0u, 0u);
+                    else hr[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
+    };
+    const int first = (blockIdx.x * 8 + wave) * R;
+    if (first < rows) fetch(first);
+    for (int row0 = first; row0 < rows; row0 += stride) {
+        float4 dy[R][DV], hv[R][DV];
+        float gl[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            gl[r] = gn[r];
+#pragma unroll
+            for (int j = 0; j < DV; ++j) {
+                dy[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (XH) {
+                    const uint2 t = hr[r][j];
+                    hv[r][j] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                           __uint_as_float(t.y & 0xffff0000u));
+                } else {
+                    hv[r][j] = hr[r][j];
+                }
+            }
+        }
+        if (row0 + stride < rows) fetch(row0 + stride);
 #pragma unroll 2
         for (int k = 0; k < PW; ++k) {
             float gk[R];
@@ -1594,7 +1618,7 @@ int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, in
     const void* xa = xhat_h ? xhat_h : static_cast<const void*>(xhat);
     const size_t lds = (size_t)(PW + 3) * d * sizeof(float);
     const bool many = rows >= 8192;
-    const int per_wg = 8 * (many ? 4 : 1);
+    const int per_wg = 8 * (many ? (d <= 768 ? 4 : 2) : 1);
     int nsl = cdiv(rows, per_wg);
     nsl = nsl > 256 ? 256 : nsl;          // (one workgroup per CU: the LDS copy of Wb)
     const int fd = flag_div > 0 ? flag_div : 1;
@@ -1608,7 +1632,7 @@ int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, in
     } while (0)
 #define LNLR2(RR, DVV) do { if (xhat_h) LNLR(RR, DVV, true); else LNLR(RR, DVV, false); } while (0)
     if (d <= 768) { if (many) LNLR2(4, 3); else LNLR2(1, 3); }
-    else { if (many) LNLR2(4, 4); else LNLR2(1, 4); }
+    else { if (many) LNLR2(2, 4); else LNLR2(1, 4); }       // (four chunks per lane: two rows at a time fit the registers)
 #undef LNLR2
 #undef LNLR
     IMMTSF_LAUNCH_CHECK();

@@ -326,8 +326,8 @@ __global__ __launch_bounds__(256) void t2v_mix_bwd_kernel(T2VFoldDims dm, const 
 
 
 // ------------------------------------------------------------------------------------------------ mix + LayerNorm, forward (wide form)
-// grid (B), 256 threads: the workgroup owns its window's T rows over ALL d <= 1024 columns -- a thread owns FOUR adjacent columns
-// (8- / 16-byte loads of the value rows, 8- / 16-byte stores of the outputs) for all T steps, 4 x 32 accumulators in registers -- so the
+// grid (B): the workgroup owns its window's T rows over ALL d <= 1024 columns -- a thread owns FOUR adjacent columns (8- / 16-byte loads
+// of the value rows, 8- / 16-byte stores of the outputs) for 16 steps, 4 x 16 accumulators in registers -- so the
 // LayerNorm that follows the mix (reference: fusions/TTF_T2V_XAttn.py:176-179, ln(E_attn + Q) then dropout) runs on the accumulators:
 // no fp32 x_pre in HBM (403 MB written + read at 4096 windows), x_hat and Z leave once.  The dropout tile is note-major so that a note's T
 // scales are eight 16-byte broadcast reads shared by the thread's four columns.
@@ -350,22 +350,29 @@ __device__ __forceinline__ void st4w(bf16_t* p, const float (&v)[4]) {
     const bf16x4 h = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
     *reinterpret_cast<bf16x4*>(p) = h;
 }
+// Threads: G = ceil(d / 4) column groups (rounded up to whole waves) x NH halves of the T steps -- a thread owns four adjacent columns
+// for TH = 16 consecutive steps (4 x 16 accumulators: ~130 VGPRs, three waves per SIMD; with all 32 steps in one thread the kernel sat
+// at 200 VGPRs, two waves per SIMD, and at d = 768 a quarter of its 256 threads were idle: 379 us at 4096 windows).  A half is a set of
+// whole waves, so the dropout tile's rows stay broadcast reads.
+constexpr int TH = 16;
 template <typename KT, int NV>
-__global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+__global__ __launch_bounds__(512) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
                                                               const float* __restrict__ S, const KT* __restrict__ z,
                                                               const float* __restrict__ b_o, const float* __restrict__ q_res,
                                                               float* __restrict__ P, MixLn o, DropCfg drop, uint64_t site, DropCfg odrop,
-                                                              uint64_t osite) {
+                                                              uint64_t osite, int G) {
     __shared__ __attribute__((aligned(16))) float mt[NV * TT];       // [note][step] dropout scale; 0 past n / T
     __shared__ float pl[NV];
-    __shared__ float red[4][TT];
+    __shared__ float red[8][TH];
     __shared__ float mu_s[TT], rs_s[TT];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x;
     const int d = dm.d, H = dm.H, Hd = H * d, T = dm.T;
     const int ob = offsets[b], n = offsets[b + 1] - ob;
-    const int e0 = tid * 4;
+    const int half = tid / G, grp = tid - half * G, t0 = half * TH;       // (G is a multiple of 64: `half` is wave-uniform)
+    const int wpg = G >> 6;                                                // waves per half
+    const int e0 = grp * 4;
     const bool valid = e0 < d;
-    float acc[4][TT];
+    float acc[4][TH];
     {
         float a0[4] = {0.f, 0.f, 0.f, 0.f};
         if (valid) {
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < TT; ++t) acc[c][t] = a0[c];
+            for (int t = 0; t < TH; ++t) acc[c][t] = a0[c];
     }
     if (n > 0) {
         const uint64_t seed = drop.seed + ((drop.p > 0.f && drop.seed_dev) ? *drop.seed_dev : 0ull);
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
             float p = lane < n ? expf(s_l - m) : 0.f;
             p *= 1.f / wave_sum(p);
             if (h > 0) __syncthreads();            // the previous head's tiles have been read
-            for (int x = tid; x < NV * TT; x += 256) {
+            for (int x = tid; x < NV * TT; x += nthr) {
                 const int ii = x / TT, tt = x - ii * TT;
                 float a = 0.f;
                 if (tt < T && ii < n) {
@@ -416,35 +423,41 @@ __global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
                     for (int k = 0; k < 8; ++k) {
                         if (i0 + k >= n) break;             // (workgroup-uniform)
                         const float pi = pl[i0 + k];
-                        float m4[TT];
+                        float m4[TH];
 #pragma unroll
-                        for (int t4 = 0; t4 < TT / 4; ++t4) {
-                            const float4 q = *reinterpret_cast<const float4*>(mt + (i0 + k) * TT + 4 * t4);
+                        for (int t4 = 0; t4 < TH / 4; ++t4) {
+                            const float4 q = *reinterpret_cast<const float4*>(mt + (i0 + k) * TT + t0 + 4 * t4);
                             m4[4 * t4] = q.x; m4[4 * t4 + 1] = q.y; m4[4 * t4 + 2] = q.z; m4[4 * t4 + 3] = q.w;
                         }
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
                             const float pv = pi * zv[k][c];
 #pragma unroll
-                            for (int t = 0; t < TT; ++t) acc[c][t] = fmaf(m4[t], pv, acc[c][t]);
+                            for (int t = 0; t < TH; ++t) acc[c][t] = fmaf(m4[t], pv, acc[c][t]);
                         }
                     }
                 }
             }
         }
     }
-    // ---- LayerNorm over the d columns of each of the T rows (two passes over the registers: mean, then the centred squares)
+    // ---- LayerNorm over the d columns of each row (two passes over the registers: mean, then the centred squares); a row's columns
+    // live in the wpg waves of its half
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
+    for (int t = 0; t < TH; ++t) {
         const float ps = wave_sum(valid ? (acc[0][t] + acc[1][t]) + (acc[2][t] + acc[3][t]) : 0.f);
         if (lane == 0) red[wave][t] = ps;
     }
     __syncthreads();
-    if (tid < TT) mu_s[tid] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)d;
+    if (tid < TT) {
+        const int hh = tid / TH, tl = tid - hh * TH;
+        float a = 0.f;
+        if (hh * G < nthr) for (int w = 0; w < wpg; ++w) a += red[hh * wpg + w][tl];
+        mu_s[tid] = a / (float)d;
+    }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        const float mu = mu_s[t];
+    for (int t = 0; t < TH; ++t) {
+        const float mu = mu_s[t0 + t];
         float v = 0.f;
         if (valid) {
             const float a = acc[0][t] - mu, bb = acc[1][t] - mu, c = acc[2][t] - mu, e = acc[3][t] - mu;
@@ -455,7 +468,10 @@ __global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
     }
     __syncthreads();
     if (tid < TT) {
-        const float rs = 1.0f / sqrtf(((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)d + o.eps);
+        const int hh = tid / TH, tl = tid - hh * TH;
+        float a = 0.f;
+        if (hh * G < nthr) for (int w = 0; w < wpg; ++w) a += red[hh * wpg + w][tl];
+        const float rs = 1.0f / sqrtf(a / (float)d + o.eps);
         rs_s[tid] = rs;
         if (tid < T && o.rstd) o.rstd[b * T + tid] = rs;
     }
@@ -464,33 +480,34 @@ __global__ __launch_bounds__(256) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
     float gm[4], bt[4];
     ld4w(o.gamma + e0, gm);
     ld4w(o.beta + e0, bt);
-    // output dropout: the keep bits of the thread's 4 x T elements first, in a ROLLED loop (one Philox call per step; inlined 32 times into
-    // the store loop below the compiler gave up unrolling it and the accumulators went to scratch), four bits per step in two 64-bit words
-    uint64_t kb0 = ~0ull, kb1 = ~0ull;
+    // output dropout: the keep bits of the thread's 4 x TH elements first, in a ROLLED loop (one Philox call per step; inlined into the
+    // store loop below the compiler gave up unrolling it and the accumulators went to scratch), four bits per step in one 64-bit word
+    uint64_t kb = ~0ull;
     if (odrop.p > 0.f) {
-        kb0 = kb1 = 0ull;
+        kb = 0ull;
 #pragma unroll 1
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TH; ++t) {
+            if (t0 + t >= T) break;
             float sc[4];
-            dropout_scale4(odrop, osite, (uint64_t)((size_t)(b * T + t) * d + e0), sc);
+            dropout_scale4(odrop, osite, (uint64_t)((size_t)(b * T + t0 + t) * d + e0), sc);
             const uint64_t bits = (sc[0] != 0.f ? 1ull : 0ull) | (sc[1] != 0.f ? 2ull : 0ull) | (sc[2] != 0.f ? 4ull : 0ull) | (sc[3] != 0.f ? 8ull : 0ull);
-            if (t < 16) kb0 |= bits << (4 * t); else kb1 |= bits << (4 * (t - 16));
+            kb |= bits << (4 * t);
         }
     }
     const float keep = odrop.p > 0.f ? odrop.inv_keep : 1.f;
 #pragma unroll
-    for (int t = 0; t < TT; ++t) {
-        if (t < T) {              // (a guard, not a break: the loop must unroll for the accumulators to stay in registers)
-            const float mu = mu_s[t], rs = rs_s[t];
-            const size_t at = (size_t)(b * T + t) * d + e0;
-            const uint32_t kb = (uint32_t)((t < 16 ? kb0 >> (4 * (t & 15)) : kb1 >> (4 * (t & 15))) & 15u);
+    for (int t = 0; t < TH; ++t) {
+        if (t0 + t < T) {              // (a guard, not a break: the loop must unroll for the accumulators to stay in registers)
+            const float mu = mu_s[t0 + t], rs = rs_s[t0 + t];
+            const size_t at = (size_t)(b * T + t0 + t) * d + e0;
+            const uint32_t k4 = (uint32_t)(kb >> (4 * t)) & 15u;
             float hv[4], zo[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) hv[c] = (acc[c][t] - mu) * rs;
             if (o.xhat_f) st4w(o.xhat_f + at, hv);
             if (o.xhat_h) st4w(o.xhat_h + at, hv);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) zo[c] = ((kb >> c) & 1u) ? fmaf(hv[c], gm[c], bt[c]) * keep : 0.f;
+            for (int c = 0; c < 4; ++c) zo[c] = ((k4 >> c) & 1u) ? fmaf(hv[c], gm[c], bt[c]) * keep : 0.f;
             if (o.z_f) st4w(o.z_f + at, zo);
             if (o.z_h) st4w(o.z_h + at, zo);
         }
@@ -678,8 +695,9 @@ int launch_t2v_mix_ln_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap,
     MixLn o;
     o.gamma = gamma; o.beta = beta; o.eps = eps; o.xhat_f = xhat_f; o.xhat_h = static_cast<bf16_t*>(xhat_h); o.rstd = rstd; o.z_f = z_f;
     o.z_h = static_cast<bf16_t*>(z_h);
-#define MIXL(KT, NV) hipLaunchKernelGGL((t2v_mix_ln_fwd_kernel<KT, NV>), dim3(dm.B), dim3(256), 0, s, dm, offsets, rowmap, S, static_cast<const KT*>(z), \
-                                        b_o, q_res, P, o, drop, site, odrop, osite)
+    const int G = cdiv(cdiv(dm.d, 4), 64) * 64, NH = dm.T > TH ? 2 : 1;      // column groups (whole waves) x halves of the steps
+#define MIXL(KT, NV) hipLaunchKernelGGL((t2v_mix_ln_fwd_kernel<KT, NV>), dim3(dm.B), dim3(G * NH), 0, s, dm, offsets, rowmap, S, static_cast<const KT*>(z), \
+                                        b_o, q_res, P, o, drop, site, odrop, osite, G)
     if (z_is_bf16) { if (dm.N <= 32) MIXL(bf16_t, 32); else MIXL(bf16_t, 64); }
     else { if (dm.N <= 32) MIXL(float, 32); else MIXL(float, 64); }
 #undef MIXL

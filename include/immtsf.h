@@ -59,6 +59,13 @@ int immtsf_abi_version(void);
  * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store, immtsf_note_index, immtsf_lowrank_grad: lets a
  * binding check its own struct definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes
  * min(max, 16) entries to the HOST array `out`, returns the number of structs (16).  (ABI 5; 16 structs from ABI 6) */
+/* measurement aid: the gather that IS in the timed step of a packed batch in bf16 mode -- X_h[r, :d_m] = bf16(emb[src_rows[r], :]), X_h[r, d_m:
+ * d_m + dt] = bf16(Time2Vec(tau[rowmap[r]])) for r < *total (one wave per packed row; csrc/rowops.hip notes_stage_kernel, the first launch of
+ * immtsf_ttf_t2v_xattn_forward_packed's folded and staged forms).  bench.py times it for `roofline_hbm`.  reference: the note gather of
+ * fusions/TTF_T2V_XAttn.py:120-131 and time2vec :27-39.  (ABI 6) */
+int immtsf_notes_stage(const float* emb, int32_t d_m, const int32_t* src_rows, const int32_t* total, int32_t max_rows, void* X_h, int32_t ldx,
+                       const float* tau, const int32_t* rowmap, int32_t dt, const float* lin_w, const float* lin_b, const float* per_w,
+                       const float* per_b, immtsf_stream_t stream);
 #define IMMTSF_ABI_NSTRUCTS 16
 int immtsf_abi_sizes(int32_t* out, int32_t max);
 

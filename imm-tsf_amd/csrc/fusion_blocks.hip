@@ -151,6 +151,7 @@ struct T2VFoldWs {
     int *lengths, *offsets, *rowmap, *seg;
     Mat X, z, zln;            // [R, dmc] notes | Time2Vec ; [R, H d] folded value rows ; [BT, d] LayerNorm output
     float *S, *P, *q, *qs, *xpre, *xhat, *rstd;
+    unsigned long long* keep;      // the output dropout's keep bits (the wide mix + LayerNorm kernel writes, the low-rank LayerNorm backward reads)
     Mat OVa;                  // [H d + 8, d]: W_o[:, h] W_v[h, :] per head, then G_h = (scale q_h)^T W_k,h, then zero rows
     Mat Ab;                   // [d, dmc] = [W_KV[:, :d] W_in | W_KV[:, d:]] (with an input projection; else W_KV itself)
     Mat Wa;                   // [H d + 8, dmc]: W_tot per head, then the score vectors u_h, then zero rows
@@ -179,6 +180,7 @@ T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
     w.xpre = t2v_mix_wide_ok((int)d) ? nullptr : k.take<float>(BT * d);      // (the wide mix + LayerNorm kernel keeps x_pre in registers)
     w.xhat = k.take<float>(BT * d);
     w.rstd = k.take<float>(BT);
+    w.keep = t2v_mix_wide_ok((int)d) ? k.take<unsigned long long>(B * 2 * 256) : nullptr;
     w.zln = k.take_mat(BT * d, !hf, hf);
     w.OVa = k.take_mat(Ma * d, true, hf);
     w.Ab = k.take_mat(d * dmc, true, hf);
@@ -348,7 +350,7 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     float* z_f = noproj ? (((cfg->form & IMMTSF_FORM_HALF_OUT) && hf && cfg->out_h) ? nullptr : E_txt) : w.zln.f;
     if (t2v_mix_wide_ok(d)) {
         CHECK(launch_t2v_mix_ln_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P,
-                                    p->ln_w, p->ln_b, 1e-5f, xhat_f, xhat_h, w.rstd, z_f, z_h, drop, SITE_T2V_ATTN, drop, SITE_T2V_OUT, s));
+                                    p->ln_w, p->ln_b, 1e-5f, xhat_f, xhat_h, w.rstd, z_f, z_h, drop, SITE_T2V_ATTN, drop, SITE_T2V_OUT, s, w.keep));
     } else {
         CHECK(launch_t2v_mix_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P, w.xpre,
                                  drop, SITE_T2V_ATTN, s));
@@ -417,7 +419,8 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     if (lr) {   // the upstream gradient is dZ = coef basis: formed inside the LayerNorm backward, never written
         if (!noproj || !lr->coef || !lr->basis || lr->rank <= 0 || lr->ld < lr->rank || !compact) return IMMTSF_EINVAL;
         const int rc = launch_layernorm_bwd_lr(lr->coef, lr->ld, lr->rank, lr->basis, BT, d, p->ln_w, nullptr, w.xhat, w.rstd, dx_f, dx_h, drop,
-                                               SITE_T2V_OUT, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, s);
+                                               SITE_T2V_OUT, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, s,
+                                               t2v_mix_wide_ok(d) ? w.keep : nullptr, T);
         if (rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (immtsf_ttf_t2v_xattn_accepts_lowrank said otherwise)
     } else {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
         const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, dx_f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
@@ -459,7 +462,10 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     {
         VecJobList l;
         for (int h = 0; h < H; ++h) l.add(VJ_MVT, p->attn_out_w + h * hd, d, sc.dcv + h * d, nullptr, sc.dbvec2 + h * hd, d, hd);
-        l.add(VJ_MVT, sc.dbo_part, d, nullptr, nullptr, gr->attn_out_b, B, d);                   // d b_o = sum over the windows
+        // d b_o = sum over the windows: as a job of this launch for a few hundred windows; beyond that the job's 12 workgroups walked
+        // thousands of rows each (92 us at 4096 windows, the longest launch of the parameter chain) -- the slabbed column sum instead
+        if (B < 512) l.add(VJ_MVT, sc.dbo_part, d, nullptr, nullptr, gr->attn_out_b, B, d);
+        else CHECK(launch_colsum(sc.dbo_part, nullptr, B, nullptr, d, d, gr->attn_out_b, 0, sc.red_bo, s, true));
         if (hf) {
             VecJob& c = l.add(VJ_COPY, sc.dWa.f, dmc, nullptr, nullptr, nullptr, Ma, dmc);      // bf16 image of dW_aug for the two products
             c.yh = sc.dWa.h; c.ldy = dmc;

@@ -995,7 +995,10 @@ __global__ __launch_bounds__(512) void layernorm_bwd_lr_kernel(const float* __re
                                                                 const void* __restrict__ xhat_any, const float* __restrict__ rstd,
                                                                 float* __restrict__ dx, bf16_t* __restrict__ dxh, DropCfg drop, uint64_t site,
                                                                 float* __restrict__ partial, const unsigned char* __restrict__ row_flag,
-                                                                int flag_div) {
+                                                                int flag_div, const unsigned long long* __restrict__ keepw, int T) {
+    // keepw (optional): the forward's keep bits of this dropout site, word ((row / T) * 2 + (row % T) / 16) * 256 + q holds four bits per
+    // step (row % T) % 16 of column chunk q (t2v_mix_ln_fwd_kernel): one 8-byte load per chunk instead of a Philox call per (row, chunk)
+    // -- the generator was the largest share of this kernel's instructions
     extern __shared__ __attribute__((aligned(16))) float lr_lds[];      // Wb [PW][d], then the workgroup's sums [3][d]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d4 = d >> 2;
     float4* wl4 = reinterpret_cast<float4*>(lr_lds);
@@ -1075,7 +1078,19 @@ __global__ __launch_bounds__(512) void layernorm_bwd_lr_kernel(const float* __re
         }
         // output-dropout keep bits of the wave's R x DV chunks in a rolled loop (one Philox call each), four bits per chunk
         uint64_t kb = ~0ull;
-        if (drop.p > 0.f) {
+        if (drop.p > 0.f && keepw) {
+            kb = 0ull;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int row = min(row0 + r, rows - 1), bw = row / T, t = row - bw * T;
+#pragma unroll
+                for (int j = 0; j < DV; ++j) {
+                    const int q = lane + 64 * j;
+                    const unsigned long long wv = q < d4 ? keepw[((size_t)bw * 2 + (t >> 4)) * 256 + q] : 0ull;
+                    kb |= ((wv >> (4 * (t & 15))) & 15ull) << (4 * (r * DV + j));
+                }
+            }
+        } else if (drop.p > 0.f) {
             kb = 0ull;
 #pragma unroll 1
             for (int x = 0; x < R * DV; ++x) {
@@ -1609,8 +1624,9 @@ bool ln_lr_ok(int rows, int d, int PW) {
 }
 int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, int rows, int d, const float* gamma, const float* xhat,
                             const void* xhat_h, const float* rstd, float* dx, void* dxh, DropCfg drop, uint64_t site, float* out_gw, float* out_gb,
-                            float* out_q, float* scratch, const unsigned char* row_flag, int flag_div, hipStream_t s) {
+                            float* out_q, float* scratch, const unsigned char* row_flag, int flag_div, hipStream_t s, const void* keep, int keep_T) {
     if (!ln_lr_ok(rows, d, PW)) return IMMTSF_EUNSUPPORTED;
+    if (keep && (keep_T <= 0 || keep_T > 32)) return IMMTSF_EINVAL;
     if (!G || !Wb || (!xhat && !xhat_h) || (!dx && !dxh) || !out_gw || !out_gb || !out_q || !scratch) return IMMTSF_EINVAL;
     const uintptr_t al = reinterpret_cast<uintptr_t>(Wb) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(gamma) |
                          reinterpret_cast<uintptr_t>(scratch) | reinterpret_cast<uintptr_t>(xhat);
@@ -1628,7 +1644,7 @@ int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, in
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                              \
         if (attr != hipSuccess) return (int)attr;                                                                                                \
         hipLaunchKernelGGL((layernorm_bwd_lr_kernel<RR, DVV, XHH>), dim3(nsl), dim3(512), lds, s, G, ldg, PW, Wb, rows, d, gamma, xa, rstd, dx,   \
-                           static_cast<bf16_t*>(dxh), drop, site, scratch, row_flag, fd);                                                        \
+                           static_cast<bf16_t*>(dxh), drop, site, scratch, row_flag, fd, static_cast<const unsigned long long*>(keep), keep_T); \
     } while (0)
 #define LNLR2(RR, DVV) do { if (xhat_h) LNLR(RR, DVV, true); else LNLR(RR, DVV, false); } while (0)
     if (d <= 768) { if (many) LNLR2(4, 3); else LNLR2(1, 3); }

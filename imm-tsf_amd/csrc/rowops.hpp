@@ -71,7 +71,8 @@ int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma,
 bool ln_lr_ok(int rows, int d, int PW);
 int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, int rows, int d, const float* gamma, const float* xhat,
                             const void* xhat_h, const float* rstd, float* dx, void* dxh, DropCfg drop, uint64_t site, float* out_gw, float* out_gb,
-                            float* out_q, float* scratch, const unsigned char* row_flag, int flag_div, hipStream_t s);
+                            float* out_q, float* scratch, const unsigned char* row_flag, int flag_div, hipStream_t s, const void* keep = nullptr,
+                            int keep_T = 0);      // keep / keep_T: the forward's keep bits of this site (t2v_mix_ln_fwd_kernel), rows = windows x keep_T
 // (xhat_h: the bf16 x_hat image of launch_layernorm_fwd instead of xhat; dx may be null when dxh is all the consumer reads)
 bool ln_sums_compact_ok(int rows, int d);     // the sums kernel takes (rows, d) whatever the pointers: a forward may store x_hat as bf16 only      // dbranch = dx * dropout_pre mask
 // y[i] = sum_j W[i,j] x[j] + b[i]  (tiny mat-vec, e.g. q = W_q Q_param + b_q), then scaled copy ys = y*scale

@@ -339,6 +339,9 @@ struct MixLn {
     float* rstd;
     float* z_f;           // Z = dropout(LayerNorm(.)) fp32 (may be null when z_h is all the consumer reads)
     bf16_t* z_h;          // bf16 image (may be null)
+    unsigned long long* keep;   // optional: the output dropout's keep bits, one 64-bit word per (window, half of the steps, column group):
+                                // four bits per step -- what the LayerNorm backward would otherwise regenerate with a Philox call per
+                                // four elements (launch_layernorm_bwd_lr's `keep`); written only when the dropout is on
 };
 __device__ __forceinline__ void ld4w(const float* p, float (&o)[4]) { const float4 a = *reinterpret_cast<const float4*>(p); o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; }
 __device__ __forceinline__ void ld4w(const bf16_t* p, float (&o)[4]) {
@@ -493,6 +496,7 @@ __global__ __launch_bounds__(512) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
             const uint64_t bits = (sc[0] != 0.f ? 1ull : 0ull) | (sc[1] != 0.f ? 2ull : 0ull) | (sc[2] != 0.f ? 4ull : 0ull) | (sc[3] != 0.f ? 8ull : 0ull);
             kb |= bits << (4 * t);
         }
+        if (o.keep) o.keep[((size_t)b * 2 + half) * 256 + grp] = kb;
     }
     const float keep = odrop.p > 0.f ? odrop.inv_keep : 1.f;
 #pragma unroll
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(512) void t2v_mix_ln_fwd_kernel(T2VFoldDims dm, con
 // bf16 dx -- the two-byte accesses of the narrow kernel made it slower on a bf16 dx than on the fp32 one), writes dz four columns at
 // a time, and the per-note dot products meet in wave-private LDS slabs exactly as in the narrow kernel.
 template <typename KT, int NV, typename DT>
-__global__ __launch_bounds__(256) void t2v_mix_bwd_wide_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void t2v_mix_bwd_wide_kernel(T2VFoldDims dm, const int* __restrict__ offsets, const int* __restrict__ rowmap,
                                                                 const float* __restrict__ P, const KT* __restrict__ z,
                                                                 const DT* __restrict__ dx, KT* __restrict__ dz, float* __restrict__ dbo_part,
                                                                 DropCfg drop, uint64_t site) {
@@ -579,29 +583,35 @@ __global__ __launch_bounds__(256) void t2v_mix_bwd_wide_kernel(T2VFoldDims dm, c
     }
     for (int h = 0; h < H; ++h) {
         const KT* vb = z + (size_t)ob * Hd + (size_t)h * d + (valid ? e0 : 0);
-        for (int i0 = 0; i0 < n; i0 += 8) {
-            float zv[8][4];
+        for (int i0 = 0; i0 < n; i0 += 4) {
+            float zv[4][4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ld4w(vb + (size_t)(i0 + k < n ? i0 + k : n - 1) * Hd, zv[k]);
+            for (int k = 0; k < 4; ++k) ld4w(vb + (size_t)(i0 + k < n ? i0 + k : n - 1) * Hd, zv[k]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 const int i = i0 + k;
                 if (i >= n) break;              // (workgroup-uniform)
-                float m4[TT];
+                float g4[4] = {0.f, 0.f, 0.f, 0.f};
+                // the note's T scales in two halves of 16 (the registers the upstream values leave: three waves per SIMD)
 #pragma unroll
-                for (int t4 = 0; t4 < TT / 4; ++t4) {
-                    const float4 q = *reinterpret_cast<const float4*>(mt + ((size_t)h * NV + i) * TT + 4 * t4);
-                    m4[4 * t4] = q.x; m4[4 * t4 + 1] = q.y; m4[4 * t4 + 2] = q.z; m4[4 * t4 + 3] = q.w;
+                for (int hf2 = 0; hf2 < 2; ++hf2) {
+                    float m4[16];
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        const float4 q = *reinterpret_cast<const float4*>(mt + ((size_t)h * NV + i) * TT + hf2 * 16 + 4 * t4);
+                        m4[4 * t4] = q.x; m4[4 * t4 + 1] = q.y; m4[4 * t4 + 2] = q.z; m4[4 * t4 + 3] = q.w;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) g4[c] = fmaf(m4[t], dcv[c][hf2 * 16 + t], g4[c]);
                 }
                 const float pi = pl[h * NV + i];
                 float a = 0.f, out[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float g = 0.f;
-#pragma unroll
-                    for (int t = 0; t < TT; ++t) g = fmaf(m4[t], dcv[c][t], g);
-                    a = fmaf(g, zv[k][c], a);
-                    out[c] = pi * g;
+                    a = fmaf(g4[c], zv[k][c], a);
+                    out[c] = pi * g4[c];
                 }
                 if (valid) st4w(dz + (size_t)(ob + i) * Ma + (size_t)h * d + e0, out);
                 a = wave_sum(valid ? a : 0.f);
@@ -689,12 +699,14 @@ bool t2v_mix_wide_ok(int d) { return (d % 8) == 0 && d <= 1024; }      // (four 
 
 int launch_t2v_mix_ln_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
                           const float* q_res, float* P, const float* gamma, const float* beta, float eps, float* xhat_f, void* xhat_h,
-                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s) {
+                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s,
+                          void* keep) {
     if (!t2v_fold_shape_ok(dm.N, dm.T, dm.d, dm.H) || !t2v_mix_wide_ok(dm.d)) return IMMTSF_EUNSUPPORTED;
     if ((!xhat_f && !xhat_h) || (!z_f && !z_h)) return IMMTSF_EINVAL;
     MixLn o;
     o.gamma = gamma; o.beta = beta; o.eps = eps; o.xhat_f = xhat_f; o.xhat_h = static_cast<bf16_t*>(xhat_h); o.rstd = rstd; o.z_f = z_f;
     o.z_h = static_cast<bf16_t*>(z_h);
+    o.keep = static_cast<unsigned long long*>(keep);
     const int G = cdiv(cdiv(dm.d, 4), 64) * 64, NH = dm.T > TH ? 2 : 1;      // column groups (whole waves) x halves of the steps
 #define MIXL(KT, NV) hipLaunchKernelGGL((t2v_mix_ln_fwd_kernel<KT, NV>), dim3(dm.B), dim3(G * NH), 0, s, dm, offsets, rowmap, S, static_cast<const KT*>(z), \
                                         b_o, q_res, P, o, drop, site, odrop, osite, G)

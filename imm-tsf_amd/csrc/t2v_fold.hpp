@@ -55,7 +55,8 @@ int launch_t2v_mix_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, co
 bool t2v_mix_wide_ok(int d);
 int launch_t2v_mix_ln_fwd(T2VFoldDims dm, const int* offsets, const int* rowmap, const float* S, const void* z, int z_is_bf16, const float* b_o,
                           const float* q_res, float* P, const float* gamma, const float* beta, float eps, float* xhat_f, void* xhat_h,
-                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s);
+                          float* rstd, float* z_f, void* z_h, DropCfg drop, uint64_t site, DropCfg odrop, uint64_t osite, hipStream_t s,
+                          void* keep = nullptr);      // keep: optional (B, 2, 256) 64-bit words, the output dropout's keep bits (see MixLn)
 extern int t2v_mix_bwd_wide;
 // backward of the mix and the softmax: dz_aug (R, H d + 8): columns [h d, (h+1) d) = dz of head h, column H d + h = ds of head h, the
 // rest 0 (fp32 or bf16 like z); dbo_part (B, d) = sum_t dx[b, t, :] of the windows with notes (0 otherwise)

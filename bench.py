@@ -707,6 +707,27 @@ def gemm_roofline(w, lib, args, k2=20):
         if traffic is not None:
             break
         why = f"{os.path.basename(fn)} is a profile of this build but holds no record of this launch (grid {grid_threads} threads)"
+    # ... and the MFMA pipes' busy fraction of that launch from a committed SQ-counter pass of THIS build (tools/sq_pass_r05.sh)
+    mfma_busy, sq_prov = None, None
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_w*.json")), reverse=True):
+        try:
+            sq = json.load(open(fn))
+        except Exception:      # noqa: BLE001
+            continue
+        if sq.get("csrc_sha") != sha or sq.get("windows_per_gpu", 64) != w.B or sq.get("config", "cfg2") != w.cfg:
+            continue
+        tag = {0: "<false, false", 1: "<false, true", 2: "<true, true", 3: ""}[lay_i]
+        for kr in sq["kernels"]:
+            nm = kr["kernel"]
+            hit = (kname in nm) if lay_i == 3 else (("gemm2_kernel" + tag in nm or "gemm3_kernel" + tag in nm or "gemm_kernel<true, " + tag[1:] in nm))
+            if hit and kr["grid_threads"] == grid_threads and kr.get("mfma_busy") is not None:
+                mfma_busy = round(kr["mfma_busy"], 4)
+                sq_prov = {"file": "profiles/" + os.path.basename(fn), "csrc_sha": sha, "kernel": nm[:160], "launches_profiled": kr["launches"],
+                           "mfma_flops_counted": kr.get("mfma_flops"), "wait_any_frac": round(kr.get("wait_any_frac", 0.0), 3),
+                           "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs)"}
+                break
+        if mfma_busy is not None:
+            break
     if top["members"]:
         desc = (f"gemm2_group_kernel: {len(top['members'])} TN weight gradients in one launch, (M x N x K) = " +
                 ", ".join(f"{a}x{b_}x{c}" for a, b_, c in top["members"]))
@@ -714,7 +735,7 @@ def gemm_roofline(w, lib, args, k2=20):
         desc = f"{'gemm2/gemm3 (bf16 operands in HBM)' if path == 2 else 'gemm_kernel'} {lay} M={Mm} N={Nn} K={Kk} x{nprob * max(top['key'][6], 1)} problems per launch"
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5),
             "batch": f"{w.B} windows per GPU", "achieved_in_step_tap": round(ach_tap, 2), "frac_in_step_tap": round(ach_tap / peak, 5),
-            "traffic": traffic, "traffic_provenance": prov,
+            "traffic": traffic, "traffic_provenance": prov, "mfma_busy": mfma_busy, "mfma_busy_provenance": sq_prov,
             "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate PMC passes of this build: a committed profile of "
                             "this launch, not a measurement of this run)" if traffic is not None else f"null: {why} (csrc hash {sha})",
             "algorithmic_bytes": alg_bytes, "operands": operands, "flops_per_launch": top["flops"],

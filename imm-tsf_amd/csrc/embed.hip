@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbDims e, const float* 
 // dW[d, k] = sum over (row, patch) pairs q of dout[q, d] * dropscale * g(q, k): a (D x pairs) x (pairs x K) product with a
 // tiny K.  grid (ceil(D / 16), S): a workgroup owns 16 output columns d and one of S slices of the pairs; its 256 threads
 // are 16 columns x 16 pair lanes, every thread keeps K accumulators, the 16 pair lanes are summed through LDS and the
-// workgroup adds its 16 x K block with one atomic per element (S <= 8 adds per address; S = 1 for short inputs).
+// workgroup adds its 16 x K block with one atomic per element (S <= 32 adds per address; S = 1 for short inputs).
 // (The first version gave every workgroup all D columns of 16 pairs: 240 workgroups x D K atomics on D K addresses
 // serialised in L2 -- 306 us at PatchTST's 512 x 16; this one is ~10 us.)
 template <int KB>
@@ -216,8 +216,10 @@ int immtsf_embed_backward(int32_t mode, const float* x, int32_t R, int32_t L, in
     const DropCfg drop = mk_drop2(p_drop, seed, seed_step_dev);
     const long pairs = (long)R * P;
     const int cs = cdiv(D, 16);
-    int S = (int)min((long)8, max((long)1, pairs / 256));        // >= 256 pairs per slice; S * cs workgroups
-    while (S > 1 && S * cs > 1024) --S;
+    // >= 64 pairs per slice, S * cs workgroups.  (A slice is a dependent chain of 16-pair steps -- gather, barrier, one dout load, FMAs:
+    // with 8 slices PatchTST's 3840 pairs were 30 steps = 62-74 us at the tail of cfg3's backward; 32 slices: 8 steps.)
+    int S = (int)min((long)32, max((long)1, pairs / 64));
+    while (S > 1 && S * cs > 2048) --S;
     if (S == 1 && !dw_prezeroed) { /* sole writer per element: no zero-fill needed */ }
     else if (!dw_prezeroed) {
         if (int rc = launch_fill(dW, 0.f, (size_t)D * K, s)) return rc;       // (a kernel: memset nodes misbehave under graph replay)

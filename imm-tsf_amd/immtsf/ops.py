@@ -48,6 +48,21 @@ def _shared(params, sinks):
     return all(s is not None and getattr(p, "_immtsf_grad_shared", False) for p, s in zip(params, sinks))
 
 
+def _claim_sinks(params, sinks, who):
+    """two HIP ops that write the SAME parameters' sinks in one step (tPatchGNN's LearnableTE: the patch encoder and the decoder) must
+    both accumulate -- which they do only when the trainer declared the parameters `sink_shared`.  Each op names itself here in its
+    forward; a second writer of an undeclared sink raises instead of silently overwriting the first one's gradient."""
+    for p, s in zip(params, sinks):
+        if p is None or s is None or getattr(p, "_immtsf_grad_shared", False):
+            continue
+        seen = getattr(p, "_immtsf_sink_writers", None)
+        if seen is None:
+            p._immtsf_sink_writers = {who}
+        elif who not in seen:
+            raise _lib.ImmtsfError("a parameter's gradient sink has two writers (%s and %s) but was not declared shared: pass it in "
+                                   "FlatTrainer(sink_shared=[...])" % (sorted(seen)[0], who))
+
+
 def _prezeroed(params, sinks):
     """1 when every gradient of the block goes to a sink that its owner zero-fills each step (FlatTrainer)."""
     ok = all(p is None or (s is not None and getattr(p, "_immtsf_grad_prezeroed", False)) for p, s in zip(params, sinks))
@@ -943,6 +958,7 @@ class TTCNPatchEncodeFn(torch.autograd.Function):
         ctx.dims = (P, L, te_dim, K, precision, ld)
         ctx.ws = ws
         ctx.sinks = _sinks_of(params)
+        _claim_sinks(params[:4], ctx.sinks[:4], "ttcn_patch_encode")
         ctx.save_for_backward(x, tt, mask, out, *params)
         return out
 
@@ -1477,6 +1493,7 @@ class TPatchDecoderTEFn(torch.autograd.Function):
                                                       stream_ptr()), "tpatchgnn_decoder_forward_te")
         ctx.dims = (B, N, Lp, D, E, H, precision)
         ctx.sinks, ctx.tsinks = _sinks_of(params), _sinks_of(tparams)
+        _claim_sinks(tparams, ctx.tsinks, "tpatch_decoder_te")
         ctx.save_for_backward(h, t, *tparams, *params)
         return out
 

@@ -116,6 +116,8 @@ class FlatTrainer:
                 p.data = self.flat_param[off:off + k].view(p.shape)
                 gview = self.flat_grad[off:off + k].view(p.shape)
                 views.append(gview)
+                if hasattr(p, "_immtsf_sink_writers"):      # (immtsf.ops._claim_sinks: the writers of an earlier trainer's sink)
+                    del p._immtsf_sink_writers
                 if bi in sink_buckets and id(p) not in excl:
                     p._immtsf_grad_sink = gview
                     p._immtsf_grad_prezeroed = True   # zero_grad() memsets the whole flat buffer every step

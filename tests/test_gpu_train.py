@@ -599,6 +599,24 @@ def _setup_sinks(dev, dropout, seed=0):
     return model, fusion, tr2, batch
 
 
+def test_two_writers_of_an_undeclared_sink_raise():
+    """tPatchGNN's LearnableTE parameters get gradients from the patch encoder AND the decoder (models/tPatchGNN.py:176-195, :283-295): on
+    gradient sinks both ops must accumulate, which they only do for parameters declared `sink_shared` -- a backbone bucket on sinks
+    without the declaration raises in the forward instead of silently keeping one op's share"""
+    dev = _dev()
+    from immtsf import _lib
+    from immtsf.train import FlatTrainer
+    model, fusion, tr, batch = _setup(dev, 0.0)
+    tr.close()
+    tr2 = FlatTrainer([list(fusion.mmf.parameters()), list(fusion.ttf.parameters()), list(model.parameters())],
+                      lr=1e-2, eps=1e-3, max_norm=1.0, sink_buckets=(0, 1, 2), overlap=False, device_step=True)
+    try:
+        with pytest.raises(_lib.ImmtsfError, match="sink_shared"):
+            _loss_fn(model, fusion, batch)()
+    finally:
+        tr2.close()
+
+
 def test_backbone_gradient_sinks_equal_autograd_accumulation():
     """the backbone ops writing their parameter gradients straight into the flat buffer (no fills, no per-parameter adds,
     no collection copy) must give the flat gradient autograd + collect_grads gives"""

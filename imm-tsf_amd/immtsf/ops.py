@@ -1762,6 +1762,7 @@ class Time2VecFn(torch.autograd.Function):
         out = torch.empty(*t.shape, d, dtype=torch.float32, device=t.device)
         check(lib.immtsf_time2vec_forward(ptr(t1), t1.numel(), d, ptr(w0), ptr(b0), ptr(w), ptr(b), ptr(out), stream_ptr()),
               "time2vec_forward")
+        _claim_sinks((w0, b0, w, b), _sinks_of((w0, b0, w, b)), "time2vec")
         ctx.save_for_backward(t1, w0, b0, w, b)
         ctx.d = d
         return out

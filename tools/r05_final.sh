@@ -9,6 +9,8 @@ PART=${2:-ab}
 mkdir -p $O/r05final
 S=$O/r05final/summary.txt
 if [[ $PART == *a* ]]; then
+  timeout 2400 python3 -m pytest tests -x -q -m gpu > $O/r05final/test_gpu.log 2>&1; echo "gpu tests rc=$?" | tee -a $S; tail -2 $O/r05final/test_gpu.log | tee -a $S
+  timeout 600 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee -a $S
   for W in 64 1024 4096; do
     bash tools/prof_windows.sh $W r05_w$W > /dev/null 2>&1
     cp $O/prof_r05_w${W}_stats.csv $O/r05final/r05_w${W}_kernel_stats.csv; cp $O/prof_r05_w${W}_seq.txt $O/r05final/r05_w${W}_kernel_sequence.txt

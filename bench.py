@@ -1146,9 +1146,10 @@ def main():
         extras["dropin"] = {"ms_per_step": round(dropin_ms(dev, args.precision, nan_check="deferred"), 4),
                             "ms_per_step_nan_guards_sync": round(dropin_ms(dev, args.precision), 4),
                             "what": "unmodified-main.py seam: lib.evaluation.compute_all_losses + loss.backward() + clip_grad_norm_ + "
-                                    "torch.optim.Adam, no FlatTrainer.  ms_per_step: IMMTSF_NAN_CHECK=deferred (no host syncs; forward + loss "
-                                    "+ backward replayed from a hipGraph per batch shape, the clip and the optimizer eager); "
-                                    "ms_per_step_nan_guards_sync: the seam's default, the reference's NaN guards with their host syncs, "
+                                    "torch.optim.Adam as main.py writes them, no FlatTrainer.  ms_per_step: the seam's default "
+                                    "(IMMTSF_NAN_CHECK=deferred: no host syncs; forward + loss + backward replayed from a hipGraph per batch shape; "
+                                    "importing lib.evaluation routes optim.Adam / clip_grad_norm_ to immtsf.optim's two fused launches); "
+                                    "ms_per_step_nan_guards_sync: IMMTSF_NAN_CHECK=sync, the reference's NaN guards with their host syncs, "
                                     "every launch eager"}
         config.precision = args.precision
 

@@ -1390,6 +1390,8 @@ __global__ __launch_bounds__(256) void rank_expand_kernel(const float* __restric
         }
     }
 }
+}  // namespace
+// (external linkage: gr_train.hip uses the pair too)
 // applies from 4096 rows on (below, the GEMM's few tiles are as quick), K in {8, 16, 24, 32}, N % 4 == 0, N <= 1024, dense 16-byte aligned C
 bool rank_expand_ok(int M, int N, int K, const void* Bm, int ldb, const void* Cm, const void* Ch) {
     return M >= 4096 && (K == 8 || K == 16 || K == 24 || K == 32) && (N & 3) == 0 && N <= 1024 && (ldb & 3) == 0 &&
@@ -1403,6 +1405,7 @@ int launch_rank_expand(const float* A, int lda, const float* Bm, int ldb, float*
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
+namespace {
 
 }  // namespace
 

@@ -35,9 +35,46 @@ class MMF_GR_Add(nn.Module):
                 self.residual_head.weight, self.residual_head.bias, self.gate_net.weight, self.gate_net.bias,
                 self.layer_norm.weight, self.layer_norm.bias)
 
-    def forward(self, Y_ts, E_txt, M_txt):
+    # ---- split form (csrc/gr_train.hip): the text columns of the GRU's input map and of the gate net ahead of the backbone, the rest --
+    # with the loss and the backward of both -- as one launch between the backbone's forward and backward
+    def _split(self, T: int, d: int) -> bool:
+        if not config.gr_split:
+            return False
+        from immtsf.ops import gr_split_pw
+        return gr_split_pw(T, self.C, d, self.hidden_dim) > 0
+
+    def project_kv(self, E_txt, with_fold: bool = True):
+        """the text-only half of the block (the name FusionModel.text_side / the step engines look for): (P, None) with P (B, T, pw) =
+        E_txt [W_ih[:, C:] ; W_g[:, C:]]^T + [b_ih ; b_g] in the split form, (None, None) where it does not apply"""
+        if not self._split(E_txt.shape[1], E_txt.shape[2]):
+            return None, None
+        from immtsf.ops import MMFGRPFn
+        return MMFGRPFn.apply(f32(E_txt), self.C, self.hidden_dim, resolve_precision(self), *self._params()), None
+
+    def forward_loss(self, Y_ts, E_txt, M_txt, truth, mask, global_cnt, kv=None):
+        """masked_mse(forward(Y_ts, E_txt, M_txt), truth, mask, global_cnt=global_cnt) for a training step: in the split form the Y half,
+        the loss and the backward of both are one launch (immtsf.ops.MMFGRQLossFn); otherwise the two calls."""
+        from immtsf.ops import MMFGRQLossFn, masked_mse
+        P = kv[0] if kv is not None else None
+        if P is None and torch.is_grad_enabled() and global_cnt is not None and self._split(E_txt.shape[1], E_txt.shape[2]):
+            P = self.project_kv(E_txt)[0]
+        if P is None or not torch.is_grad_enabled() or global_cnt is None:
+            return masked_mse(self.forward(Y_ts, E_txt, M_txt), truth, mask, None, global_cnt)
         B = Y_ts.shape[0]
         M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
+        training = self.training and self.p_drop > 0.0
+        self.last_seed = config.next_seed() if training else 0
+        return MMFGRQLossFn.apply(f32(Y_ts), P, M_u8, f32(truth), f32(mask), global_cnt, self.hidden_dim, self.p_drop, training,
+                                  resolve_precision(self), self.last_seed, *self._params())
+
+    def forward(self, Y_ts, E_txt, M_txt, kv=None):
+        """kv: the result of project_kv(E_txt) when the caller computed it ahead of time (used where no gradient is wanted: the split
+        form's output-only launch; with autograd on, the block as written runs -- training goes through forward_loss)"""
+        B = Y_ts.shape[0]
+        M_u8 = M_txt.reshape(B).to(torch.bool).view(torch.uint8)
+        if kv is not None and kv[0] is not None and not torch.is_grad_enabled() and not (self.training and self.p_drop > 0.0):
+            from immtsf.ops import MMFGRQFn
+            return MMFGRQFn.apply(f32(Y_ts), kv[0], M_u8, self.hidden_dim, resolve_precision(self), *self._params())
         training = self.training and self.p_drop > 0.0
         self.last_seed = config.next_seed() if training else 0
         return MMFGRAddFn.apply(f32(Y_ts), f32(E_txt), M_u8, self.hidden_dim, self.p_drop, training,

@@ -181,6 +181,14 @@ _PROTOS = {
     "immtsf_mmf_gr_add_backward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p,
                                              c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                              _P(GRParams), c_stream]),
+    "immtsf_mmf_gr_pw": (C.c_int32, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_gr_p_workspace_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_gr_p_scratch_bytes": (C.c_size_t, [_P(FusionCfg), C.c_int32]),
+    "immtsf_mmf_gr_p_forward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, C.c_void_p, C.c_size_t, c_stream]),
+    "immtsf_mmf_gr_p_backward": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                           C.c_size_t, _P(GRParams), c_stream]),
+    "immtsf_mmf_gr_q_train": (C.c_int, [_P(FusionCfg), C.c_int32, _P(GRParams), c_f32p, c_f32p, c_u8p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, _P(GRParams), c_f32p, C.c_void_p, C.c_void_p, c_stream]),
     "immtsf_ttcn_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "immtsf_ttcn_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "immtsf_ttcn_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,

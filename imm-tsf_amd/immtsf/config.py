@@ -116,6 +116,9 @@ note_index = True
 # in the bf16 dataflow) and takes the gradient back in LOW-RANK form (dP, Wc) -- dZ = dP Wc is formed inside the LayerNorm backward
 # instead of being written and re-read (0.8 GB per step at 4096 windows, one launch on the text chain at 64).  False: the dense hand-over
 # in both directions -- the cross-check
+# MMF_GR_Add in split form (csrc/gr_train.hip: the text columns of its two linear maps ahead of the backbone, the Y half + loss + backward as
+# one launch); False: the block as written -- the cross-check
+gr_split = True
 z_handover = os.environ.get("IMMTSF_Z_HANDOVER", "1") != "0"
 # FullAttention over <= 32 positions with heads up to 256 wide as one kernel per direction (csrc/attn_mid.hip); False: batched GEMMs +
 # row softmax

@@ -935,6 +935,149 @@ class MMFGRAddFn(torch.autograd.Function):
         return (dY, dE, None, None, None, None, None, None) + tuple(rets)
 
 
+def gr_split_pw(T, Cc, d, hidden):
+    """row pitch of MMF_GR_Add's split-form P for these dimensions, 0 where the split form does not apply (immtsf_mmf_gr_pw)"""
+    cfg = make_cfg(1, 0, int(T), int(Cc), 0, int(d), 1, 0, False, 0.0, 0.0, 0, None)
+    return int(_lib.load().immtsf_mmf_gr_pw(C.byref(cfg), int(hidden)))
+
+
+class MMFGRPFn(torch.autograd.Function):
+    """P half of MMF_GR_Add's split form (csrc/gr_train.hip): E_txt -> P (B, T, pw), the text columns of the GRU's input map and of the
+    gate net (+ both biases).  Depends on the text side only; its backward yields dE_txt and the text columns of d W_ih / d W_g, d b_ih,
+    d b_g (the Y columns come out of MMFGRQLossFn).  params: GRParams order."""
+
+    @staticmethod
+    def forward(ctx, E, Cc, hidden, precision, *params):
+        lib = _lib.load()
+        E = _c(E)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(E, *params)
+        B, T, d = E.shape
+        cfg = make_cfg(B, 0, T, Cc, 0, d, 1, precision, False, 0.0, 0.0, 0, E.device)
+        pw = int(lib.immtsf_mmf_gr_pw(C.byref(cfg), hidden))
+        if pw <= 0:
+            raise _lib.ImmtsfError("MMF_GR_Add split form: shape outside its limits")
+        ws = _bytes(lib.immtsf_mmf_gr_p_workspace_bytes(C.byref(cfg), hidden), E.device)
+        P = torch.empty(B, T, pw, dtype=torch.float32, device=E.device)
+        E_h = _shadow_get(E) if _bf16_dataflow(precision, d) else None
+        cfg.in_h = None if E_h is None else E_h.data_ptr()
+        ps = _struct(GRParams, params)
+        check(lib.immtsf_mmf_gr_p_forward(C.byref(cfg), hidden, C.byref(ps), ptr(E), ptr(P), ptr(ws), ws.numel(), stream_ptr()),
+              "mmf_gr_p_forward")
+        cfg.in_h = None
+        ctx.cfg, ctx.ws, ctx.hidden, ctx.E_h = cfg, ws, hidden, E_h
+        ctx.sinks = _sinks_of(params)
+        ctx.save_for_backward(E, *params)
+        return P
+
+    @staticmethod
+    def backward(ctx, dP):
+        lib = _lib.load()
+        E, *params = ctx.saved_tensors
+        cfg = ctx.cfg
+        dP = dP.contiguous()
+        # the four gradients this half owns: w_ih (0), b_ih (2), gate_w (6), gate_b (7) -- the text columns of the two matrices only: a
+        # sink is written in place (the other half adds its columns to the same buffer), otherwise a zero-filled full-size tensor each
+        own = (0, 2, 6, 7)
+        bufs, rets = [None] * 10, [None] * 10
+        for i in own:
+            if ctx.sinks[i] is not None:
+                bufs[i] = ctx.sinks[i]
+            else:
+                bufs[i] = rets[i] = torch.zeros_like(params[i])
+        dE = torch.empty_like(E)
+        sc = _bytes(lib.immtsf_mmf_gr_p_scratch_bytes(C.byref(cfg), ctx.hidden), E.device)
+        ps, gs = _struct(GRParams, params), _struct(GRParams, bufs)
+        dE_h = None
+        if _bf16_dataflow(cfg.precision, cfg.d):
+            cfg.aux_h = None if ctx.E_h is None else ctx.E_h.data_ptr()
+            dE_h = torch.empty(dE.shape, dtype=torch.bfloat16, device=dE.device)
+            cfg.out_h = dE_h.data_ptr()
+        check(lib.immtsf_mmf_gr_p_backward(C.byref(cfg), ctx.hidden, C.byref(ps), ptr(E), ptr(dP), ptr(dE), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
+                                           sc.numel(), C.byref(gs), stream_ptr()), "mmf_gr_p_backward")
+        cfg.aux_h = cfg.out_h = None
+        if dE_h is not None:
+            _shadow_put(dE, dE_h)
+        _fire(getattr(params[0], "_immtsf_bwd_hook", None))      # (the block's gradients are final once THIS half's backward has run)
+        return (dE, None, None, None) + tuple(rets)
+
+
+class MMFGRQLossFn(torch.autograd.Function):
+    """the Y half of MMF_GR_Add's split form + masked MSE (immtsf.ops.masked_mse with global_cnt) + the backward of both, ONE launch
+    (immtsf_mmf_gr_q_train): the forward computes the loss and every gradient (seeded with 1); backward() hands them on.
+    (Y_ts, P, M_txt, truth, mask, cnt, params...) -> loss."""
+
+    @staticmethod
+    def forward(ctx, Y, P, M_u8, truth, mask, cnt, hidden, p_drop, training, precision, seed, *params):
+        lib = _lib.load()
+        y_dense = Y.is_contiguous()
+        Y, P, M_u8 = _c(Y), _c(P), _c(M_u8)
+        truth, mask, cnt = _c(truth), _c(mask), _c(cnt.to(torch.float32))
+        params = tuple(_c(p) for p in params)
+        _need_gpu(Y, P, M_u8, truth, mask, cnt, *params)
+        B, T, Cc = Y.shape
+        d = params[0].shape[1] - Cc
+        cfg = make_cfg(B, 0, T, Cc, 0, d, 1, precision, training, p_drop, 0.0, seed, Y.device)
+        if int(lib.immtsf_mmf_gr_pw(C.byref(cfg), hidden)) != P.shape[2]:
+            raise _lib.ImmtsfError("MMF_GR_Add split form: P does not have the row pitch of these dimensions")
+        sinks = _sinks_of(params)
+        # the eight gradients this half owns (w_ih and gate_w: their Y columns), ADDED into zeroed buffers: pre-zeroed sinks as they are
+        own = (0, 1, 3, 4, 5, 6, 8, 9)
+        bufs, rets = [None] * 10, [None] * 10
+        for i in own:
+            if sinks[i] is not None and getattr(params[i], "_immtsf_grad_prezeroed", False):
+                bufs[i] = sinks[i]
+            else:
+                bufs[i] = rets[i] = torch.zeros_like(params[i])
+        dY, dP = torch.empty_like(Y), torch.empty_like(P)
+        loss = torch.empty((), dtype=torch.float32, device=Y.device)
+        scratch = torch.empty(B, dtype=torch.float32, device=Y.device)
+        flag = None
+        if y_dense and config.head_done_flag is not None:      # immtsf.train.FlagStep: dY_ts is published by the kernel itself
+            flag, config.head_done_flag = config.head_done_flag, None
+            config.head_dy_ptr = dY.data_ptr()
+        ps, gs = _struct(GRParams, params), _struct(GRParams, bufs)
+        check(lib.immtsf_mmf_gr_q_train(C.byref(cfg), hidden, C.byref(ps), ptr(Y), ptr(P), ptr(M_u8), ptr(truth), ptr(mask), ptr(cnt), 1.0, None,
+                                        ptr(loss), ptr(dY), ptr(dP), C.byref(gs), ptr(scratch), ptr(_xq_ticket(Y.device)[8:]), flag, stream_ptr()),
+              "mmf_gr_q_train")
+        ctx.grads = (dY, dP) + tuple(rets)
+        ctx.sunk = tuple(bufs[i] for i in own if rets[i] is None)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        g = ctx.grads
+        ctx.grads = None
+        if not is_unit_grad(dloss):
+            g = tuple(None if t is None else t * dloss for t in g)
+            for b in ctx.sunk:
+                b.mul_(dloss)
+        ctx.sunk = ()
+        return (g[0], g[1]) + (None,) * 9 + tuple(g[2:])
+
+
+class MMFGRQFn(torch.autograd.Function):
+    """the Y half of the split form, output only (inference / no_grad: immtsf_mmf_gr_q_train with truth == NULL)."""
+
+    @staticmethod
+    def forward(ctx, Y, P, M_u8, hidden, precision, *params):
+        lib = _lib.load()
+        Y, P, M_u8 = _c(Y), _c(P), _c(M_u8)
+        params = tuple(_c(p) for p in params)
+        _need_gpu(Y, P, M_u8, *params)
+        B, T, Cc = Y.shape
+        cfg = make_cfg(B, 0, T, Cc, 0, params[0].shape[1] - Cc, 1, precision, False, 0.0, 0.0, 0, Y.device)
+        out = torch.empty_like(Y)
+        ps = _struct(GRParams, params)
+        check(lib.immtsf_mmf_gr_q_train(C.byref(cfg), hidden, C.byref(ps), ptr(Y), ptr(P), ptr(M_u8), None, None, None, 0.0, ptr(out), None, None,
+                                        None, None, None, None, None, stream_ptr()), "mmf_gr_q_train")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        raise RuntimeError("MMFGRQFn is the inference form of MMF_GR_Add's split path: training goes through MMFGRQLossFn or MMFGRAddFn")
+
+
 # ------------------------------------------------------------------------------------------------ tPatchGNN TE + TTCN
 class TTCNPatchEncodeFn(torch.autograd.Function):
     """(x, tt, mask: (P,L)) -> (P, ttcn_dim) or, with_flag, (P, ttcn_dim + 1) whose last column is the patch-non-empty

@@ -391,6 +391,30 @@ int immtsf_mmf_gr_add_backward(const immtsf_fusion_cfg* cfg, int32_t hidden, con
                                float* dY_ts, float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch,
                                size_t scratch_bytes, const immtsf_gr_params* grads, immtsf_stream_t stream);
 
+/* MMF_GR_Add in SPLIT form (round 5; csrc/gr_train.hip; reference fusions/MMF_GR_Add.py:41-60).  The GRU's input map and the gate net
+ * are linear in x = [Y_ts ; E_txt], so their text columns run where the text is -- the P half, ahead of the backbone:
+ *   P (B T, pw) = E_txt [W_ih[:, C:] ; W_g[:, C:]]^T + [b_ih ; b_g],   pw = immtsf_mmf_gr_pw = 3 hidden + C rounded up to 8 --
+ * and what is left between the backbone's forward and backward (the C-column products of Y_ts, the recurrence, residual head,
+ * LayerNorm(C), dropout, gate, blend; for a training step the masked MSE of immtsf_masked_mse_counted and the backward of all of it
+ * through time) is ONE launch, a wave per window: immtsf_mmf_gr_q_train.  Limits: T <= 64, C <= 16, hidden <= 16, d % 8 == 0
+ * (immtsf_mmf_gr_pw returns 0 outside them: use the as-written form above).  Parameter gradients: the P half's backward WRITES the text
+ * columns of d W_ih / d W_g and d b_ih / d b_g; q_train ADDS (atomics) the Y columns of d W_ih / d W_g and d W_hh, d b_hh, d res_w,
+ * d res_b, d ln_w, d ln_b into buffers the caller hands in zeroed.  truth == NULL: q_train only writes Y_out (inference).  scratch: B
+ * floats; ticket: two zero-initialised device words the call leaves zero; done_flag (optional): set to 1 as soon as dY_ts is complete
+ * (a consumer on another stream waits with immtsf_flag_wait).  (ABI 6) */
+int32_t immtsf_mmf_gr_pw(const immtsf_fusion_cfg* cfg, int32_t hidden);
+size_t immtsf_mmf_gr_p_workspace_bytes(const immtsf_fusion_cfg* cfg, int32_t hidden);
+size_t immtsf_mmf_gr_p_scratch_bytes(const immtsf_fusion_cfg* cfg, int32_t hidden);
+int immtsf_mmf_gr_p_forward(const immtsf_fusion_cfg* cfg, int32_t hidden, const immtsf_gr_params* p, const float* E_txt, float* P, void* workspace,
+                            size_t workspace_bytes, immtsf_stream_t stream);
+int immtsf_mmf_gr_p_backward(const immtsf_fusion_cfg* cfg, int32_t hidden, const immtsf_gr_params* p, const float* E_txt, const float* dP,
+                             float* dE_txt, void* workspace, size_t workspace_bytes, void* scratch, size_t scratch_bytes,
+                             const immtsf_gr_params* grads, immtsf_stream_t stream);
+int immtsf_mmf_gr_q_train(const immtsf_fusion_cfg* cfg, int32_t hidden, const immtsf_gr_params* p, const float* Y_ts, const float* P,
+                          const uint8_t* M_txt, const float* truth, const float* mask, const float* cnt, float grad_scale, float* Y_out,
+                          float* loss, float* dY_ts, float* dP, const immtsf_gr_params* grads, float* scratch, uint32_t* ticket,
+                          int32_t* done_flag, immtsf_stream_t stream);
+
 /* ---- a14: tPatchGNN time-aware patch encoder, LearnableTE + TTCN (models/tPatchGNN.py:176-195), fused.
  * x, tt, mask: (P, L) with P = B*N*M patches (the reference's (B*N*M, L, 1) tensors); F = 1 + te_dim,
  * K = ttcn_dim = hid_dim - 1.  out: (P, K) = relu(pooled + T_bias).  Limit: F*K <= 1024 (IMMTSF_EUNSUPPORTED). */

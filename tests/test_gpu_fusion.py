@@ -1157,3 +1157,78 @@ def test_xattn_add_head_loss_backward_in_one_launch(B, T, Cc, d, H, pd, precisio
         den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("loss", "dY", "dE") else 1e-9)
         err = float((a - b).norm()) / den
         assert err <= tol, (k, err)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,T,Cc,d,pd", [(5, 7, 3, 32, 0.0), (6, 32, 6, 768, 0.2), (64, 32, 6, 768, 0.1), (160, 32, 15, 64, 0.1), (3, 64, 16, 16, 0.0)])
+def test_gr_add_split_form_loss_backward_in_one_launch(B, T, Cc, d, pd, precision):
+    """MMF_GR_Add in split form (csrc/gr_train.hip: the text columns of the GRU's input map and of the gate net as the P half --
+    project_kv --, the Y half + masked MSE + the backward of both through time as ONE launch -- forward_loss) against the block as
+    written + masked_mse + autograd (immtsf.config.gr_split = False): the loss, dY_ts, dE_txt and every parameter gradient, with dropout
+    (same Philox site), windows without text, a variable without observations; gradient sinks; the output-only launch under no_grad.
+    reference: fusions/MMF_GR_Add.py:31-61."""
+    dev = _dev()
+    from fusions.MMF_GR_Add import MMF_GR_Add
+    from immtsf import config
+    from immtsf.ops import backward_unit
+    config.precision = precision
+    torch.manual_seed(B * 7 + T)
+    mmf = MMF_GR_Add(d, Cc, Cc, dropout=pd).to(dev).train()
+    Y, E = torch.randn(B, T, Cc, device=dev), torch.randn(B, T, d, device=dev)
+    M = (torch.rand(B, device=dev) > 0.25).view(B, 1)
+    M[0] = True
+    truth = torch.randn(B, T, Cc, device=dev)
+    mask = (torch.rand(B, T, Cc, device=dev) > 0.4).float()
+    mask[..., 0] = 0.0 if Cc > 2 else mask[..., 0]
+    cnt = mask.reshape(-1, Cc).sum(0)
+    res, seed0 = [], config.next_seed
+    try:
+        config.next_seed = lambda: 777
+        for split in (True, False):
+            config.gr_split = split
+            mmf.zero_grad()
+            y, e = Y.clone().requires_grad_(True), E.clone().requires_grad_(True)
+            kv = mmf.project_kv(e)
+            assert (kv[0] is not None) == split
+            loss = mmf.forward_loss(y, e, M, truth, mask, cnt, kv=kv)
+            if split:
+                backward_unit(loss)
+            else:
+                loss.backward()
+            res.append([("loss", loss.detach().reshape(1)), ("dY", y.grad), ("dE", e.grad)] + [(k, p_.grad.clone()) for k, p_ in mmf.named_parameters()])
+        config.gr_split = True
+        # a seed other than backward_unit's scales the stored gradients
+        mmf.zero_grad()
+        y = Y.clone().requires_grad_(True)
+        (3.0 * mmf.forward_loss(y, E, M, truth, mask, cnt)).backward()
+        assert float((y.grad - 3.0 * res[0][1][1]).abs().max()) <= 1e-5 * float(res[0][1][1].abs().max())
+        # gradient sinks: the two halves write / add their columns of d W_ih and d W_g into the same pre-zeroed buffers
+        from immtsf.train import FlatTrainer
+        ref_g = {k: b.clone() for k, b in res[0][3:]}
+        tr = FlatTrainer([list(mmf.parameters())], sink_buckets=(0,), overlap=False)
+        try:
+            tr.zero_grad()
+            y, e = Y.clone().requires_grad_(True), E.clone().requires_grad_(True)
+            (3.0 * mmf.forward_loss(y, e, M, truth, mask, cnt)).backward()
+            torch.cuda.synchronize()
+            for k, p_ in mmf.named_parameters():
+                got, want = p_._immtsf_grad_sink, 3.0 * ref_g[k]
+                assert float((got - want).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * max(float(want.abs().max()), 1e-6), k
+        finally:
+            tr.close()
+        # output only (no gradient wanted): the split form's launch against the block as written
+        mmf.eval()
+        with torch.no_grad():
+            out_split = mmf(Y, E, M, kv=mmf.project_kv(E))
+            config.gr_split = False
+            out_ref = mmf(Y, E, M)
+        assert float((out_split - out_ref).abs().max()) <= (1e-4 if precision == "fp32" else 3e-2) * float(out_ref.abs().max())
+    finally:
+        config.next_seed, config.gr_split, config.precision = seed0, True, "fp32"
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    gmax = max(float(b.abs().max()) for k, b in res[1][3:])
+    for (k, a), (_, b) in zip(*res):
+        assert torch.isfinite(a).all(), k
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k not in ("loss", "dY", "dE") else 1e-9)
+        err = float((a - b).norm()) / den
+        assert err <= tol, (k, err)

@@ -327,6 +327,11 @@ int immtsf_guard_pack(const int32_t* err, void* slot, int32_t is_bf16, immtsf_st
     return launch_guard_pack(err, slot, is_bf16 ? 1 : 0, static_cast<hipStream_t>(stream));
 }
 
+int immtsf_instance_norm(const float* x, int32_t B, int32_t L, int32_t C, float* xn, float* means, float* stdev, immtsf_stream_t stream) {
+    if (!x || !xn || !means || !stdev || B <= 0 || L <= 0 || C <= 0) return IMMTSF_EINVAL;
+    return launch_instance_norm(x, B, L, C, xn, means, stdev, static_cast<hipStream_t>(stream));
+}
+
 int immtsf_notes_stage(const float* emb, int32_t d_m, const int32_t* src_rows, const int32_t* total, int32_t max_rows, void* X_h, int32_t ldx,
                        const float* tau, const int32_t* rowmap, int32_t dt, const float* lin_w, const float* lin_b, const float* per_w,
                        const float* per_b, immtsf_stream_t stream) {

@@ -31,11 +31,11 @@ __device__ __forceinline__ float tanh_e(float x) { return 1.f - 2.f / (1.f + exp
 
 // LDS layout (floats), see gr_lds_floats
 struct GRL {
-    float *Y, *P, *Wy, *Gy, *Whh, *bhh, *Rw, *rb, *gam, *bet, *r, *z, *n, *hn, *hp, *h, *xhat, *g, *dd, *dout, *dhin, *dgh, *hs, *gh;
+    float *Y, *P, *Wy, *Gy, *Whh, *bhh, *Rw, *rb, *gam, *bet, *r, *z, *n, *hn, *hp, *h, *xhat, *g, *dd, *dout, *dhin, *dgh, *hs, *gh, *tr, *mk, *cn;
 };
 __host__ __device__ inline size_t gr_lds_floats(int T, int C, int Hd, int PW) {
     return (size_t)T * C + (size_t)T * PW + 3 * Hd * C + C * C + 3 * Hd * Hd + 3 * Hd + C * Hd + 3 * C + 6 * (size_t)T * Hd + 4 * (size_t)T * C +
-           (size_t)T * Hd + 3 * (size_t)T * Hd + Hd + 3 * Hd + 64;
+           (size_t)T * Hd + 3 * (size_t)T * Hd + Hd + 3 * Hd + 2 * (size_t)T * C + C + 64;
 }
 __device__ inline GRL gr_carve(float* p, int T, int C, int Hd, int PW) {
     GRL l;
@@ -63,6 +63,9 @@ __device__ inline GRL gr_carve(float* p, int T, int C, int Hd, int PW) {
     l.dgh = p; p += 3 * T * Hd;
     l.hs = p; p += Hd;
     l.gh = p; p += 3 * Hd;
+    l.tr = p; p += T * C;
+    l.mk = p; p += T * C;
+    l.cn = p; p += C;
     return l;
 }
 
@@ -90,6 +93,10 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
     for (int i = lane; i < C * Hd; i += 64) l.Rw[i] = p.res_w[i];
     for (int i = lane; i < C; i += 64) { l.rb[i] = p.res_b[i]; l.gam[i] = p.ln_w[i]; l.bet[i] = p.ln_b[i]; }
     if (lane < Hd) l.hs[lane] = 0.f;
+    if (TRAIN) {        // (the loss's operands too: a global load inside the per-row loop below is a full round trip with one wave per CU)
+        for (int i = lane; i < T * C; i += 64) { l.tr[i] = truth[row0 * C + i]; l.mk[i] = mask[row0 * C + i]; }
+        for (int i = lane; i < C; i += 64) l.cn[i] = cnt[i];
+    }
     __syncthreads();
     // ---- B: the Y_ts columns of the two maps on top of the text half
     for (int i = lane; i < T * (G3 + C); i += 64) {
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
     // ---- D: per row: residual head, LayerNorm(C), dropout, gate, blend; TRAIN: the loss term and the tail's backward in the same lane
     float e = 0.f, navail = 0.f;
     if (TRAIN) {
-        for (int c = 0; c < C; ++c) navail += cnt[c] != 0.f ? 1.f : 0.f;
+        for (int c = 0; c < C; ++c) navail += l.cn[c] != 0.f ? 1.f : 0.f;
     }
     for (int t = lane; t < T; t += 64) {
         const float* hr = l.h + t * Hd;
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
             const float out = g * y + (1.f - g) * (y + dd);
             if (Yout) Yout[gi_] = out;
             if (TRAIN) {
-                const float dlt = truth[gi_] - out, m = mask[gi_], den = cnt[c] + 1e-8f;
+                const float dlt = l.tr[t * C + c] - out, m = l.mk[t * C + c], den = l.cn[c] + 1e-8f;
                 e += dlt * dlt * m / den;
                 const float go = -dlt * m * (grad_scale * 2.f / (den * navail));       // d loss / d out
                 l.dout[t * C + c] = go;

@@ -67,6 +67,8 @@ inline size_t ln_sums_scratch_floats(size_t d, int k) { return (size_t)kLnSlabsM
 int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma, const float* xhat, const float* rstd, float* dx,
                               DropCfg drop, uint64_t site, float* out_gw, float* out_gb, float* out_q, float* scratch,
                               const unsigned char* row_flag, int flag_div, void* dxh, hipStream_t s, const void* xhat_h = nullptr);
+// x (B, L, C) -> (x - mean_t) / sqrt(var_t + 1e-5), means (B, C), stdev (B, C): one launch
+int launch_instance_norm(const float* x, int B, int L, int C, float* xn, float* means, float* stdev, hipStream_t s);
 // ... with the upstream gradient in low-rank form dy = G Wb (never written): see layernorm_bwd_lr_kernel
 bool ln_lr_ok(int rows, int d, int PW);
 int launch_layernorm_bwd_lr(const float* G, int ldg, int PW, const float* Wb, int rows, int d, const float* gamma, const float* xhat,

@@ -98,6 +98,7 @@ _PROTOS = {
     "immtsf_note_index_build": (C.c_int, [c_i32p, C.c_int32, C.c_int32, _P(NoteIndex), c_stream]),
     "immtsf_ttf_t2v_xattn_workspace_bytes": (C.c_size_t, [_P(FusionCfg)]),
     "immtsf_ttf_t2v_xattn_scratch_bytes": (C.c_size_t, [_P(FusionCfg)]),
+    "immtsf_instance_norm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_stream]),
     "immtsf_notes_stage": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_void_p, C.c_int32, c_f32p, c_i32p, C.c_int32, c_f32p, c_f32p,
                                      c_f32p, c_f32p, c_stream]),
     "immtsf_ttf_t2v_xattn_folded": (C.c_int, [_P(FusionCfg)]),

@@ -17,7 +17,18 @@ def pad_history(zeros_pad, input_len, pred_len, tp_to_predict, data, tp, mask):
 
 
 def plain_instance_norm(x):
-    """Non-stationary-Transformer normalisation over time (mean detached, biased variance)."""
+    """Non-stationary-Transformer normalisation over time (mean detached, biased variance).  On the GPU, for data (no gradient
+    wanted): one launch (immtsf_instance_norm) instead of the expression's six."""
+    if x.is_cuda and not x.requires_grad and x.dim() == 3 and x.dtype == torch.float32:
+        from immtsf import _lib
+        x = x.contiguous()
+        B, L, C = x.shape
+        xn = torch.empty_like(x)
+        means = torch.empty(B, 1, C, dtype=torch.float32, device=x.device)
+        stdev = torch.empty(B, 1, C, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().immtsf_instance_norm(_lib.ptr(x), B, L, C, _lib.ptr(xn), _lib.ptr(means), _lib.ptr(stdev), _lib.stream_ptr()),
+                   "instance_norm")
+        return xn, means, stdev
     means = x.mean(1, keepdim=True).detach()
     xc = x - means
     stdev = torch.sqrt(torch.var(xc, dim=1, keepdim=True, unbiased=False) + 1e-5)

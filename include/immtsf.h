@@ -59,6 +59,9 @@ int immtsf_abi_version(void);
  * immtsf_encoder_layer_params, immtsf_ffn_block_cfg, immtsf_ffn_block_params, immtsf_store, immtsf_note_index, immtsf_lowrank_grad: lets a
  * binding check its own struct definitions against the library it loaded (tests/test_abi.py compares with ctypes.sizeof).  Writes
  * min(max, 16) entries to the HOST array `out`, returns the number of structs (16).  (ABI 5; 16 structs from ABI 6) */
+/* the history's normalisation of PatchTST / TimesNet (reference models/PatchTST.py:104-109, models/TimesNet.py:113-117: x - mean over time,
+ * / sqrt(biased variance + 1e-5)) as one launch: x (B, L, C) -> xn (B, L, C), means (B, C), stdev (B, C).  Data only: no gradient.  (ABI 6) */
+int immtsf_instance_norm(const float* x, int32_t B, int32_t L, int32_t C, float* xn, float* means, float* stdev, immtsf_stream_t stream);
 /* measurement aid: the gather that IS in the timed step of a packed batch in bf16 mode -- X_h[r, :d_m] = bf16(emb[src_rows[r], :]), X_h[r, d_m:
  * d_m + dt] = bf16(Time2Vec(tau[rowmap[r]])) for r < *total (one wave per packed row; csrc/rowops.hip notes_stage_kernel, the first launch of
  * immtsf_ttf_t2v_xattn_forward_packed's folded and staged forms).  bench.py times it for `roofline_hbm`.  reference: the note gather of

@@ -438,3 +438,24 @@ def test_patch_flatten3_equals_three_permute_copies(shape):
     fx, ft, fm = patch_flatten3(x, tt, mk)
     for got, src in ((fx, x), (ft, tt), (fm, mk)):
         assert torch.equal(got, src.permute(0, 3, 1, 2).reshape(B * N * M, L))
+
+
+@pytest.mark.parametrize("B,L,C", [(3, 5, 2), (64, 32, 6), (257, 96, 8)])
+def test_instance_norm_equals_the_expression(B, L, C):
+    """immtsf_instance_norm (one launch) against the normalisation as the reference writes it (models/PatchTST.py:104-109,
+    models/TimesNet.py:113-117: x - mean over time, / sqrt(biased variance + 1e-5)); a tensor that wants a gradient keeps the expression"""
+    dev = _dev()
+    from models._common import plain_instance_norm
+    torch.manual_seed(B + L)
+    x = torch.randn(B, L, C, device=dev) * 3.0 + 1.5
+    xn, mu, sd = plain_instance_norm(x)
+    mu_r = x.mean(1, keepdim=True)
+    xc = x - mu_r
+    sd_r = torch.sqrt(torch.var(xc, dim=1, keepdim=True, unbiased=False) + 1e-5)
+    assert mu.shape == mu_r.shape and sd.shape == sd_r.shape
+    assert float((mu - mu_r).abs().max()) <= 1e-5 and float((sd - sd_r).abs().max()) <= 1e-5 * float(sd_r.abs().max())
+    assert float((xn - xc / sd_r).abs().max()) <= 1e-5
+    y = x.clone().requires_grad_(True)
+    yn, _, _ = plain_instance_norm(y)
+    yn.sum().backward()
+    assert y.grad is not None and torch.isfinite(y.grad).all()

@@ -349,9 +349,14 @@ class Workload:
         buckets = [fb[i] for i in order] + [backbone_params] + [fb[i] for i in ttf]
         self.bucket_names = [fnames[i] for i in order] + ["backbone"] + [fnames[i] for i in ttf]
         bb = self.bucket_names.index("backbone")
-        sinks = tuple(i for i in range(len(buckets)) if i != bb or c["backbone"] == "tPatchGNN")
+        # the backbone's bucket on gradient sinks: all of tPatchGNN; of another backbone the parameters it names (PatchTST: the large
+        # linear layers, whose weight gradients FlagStep moves to the parameter branch) -- the rest stays with autograd
+        named = getattr(self.model, "immtsf_sink_params", None)
+        keep_sink = {id(p) for p in named()} if named is not None else set()
+        sinks = tuple(i for i in range(len(buckets)) if i != bb or c["backbone"] == "tPatchGNN" or keep_sink)
+        not_sunk = [p for p in backbone_params if id(p) not in keep_sink] if (keep_sink and c["backbone"] != "tPatchGNN") else []
         self.trainer = FlatTrainer(buckets,
-                                   lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl,
+                                   lr=1e-3, weight_decay=0.0, max_norm=1.0, group=group, sink_buckets=sinks, sink_shared=excl, sink_exclude=not_sunk,
                                    overlap=True, device_step=device_step and self.graphable, grad_wire=wire,
                                    shard_optimizer=shard_optimizer, param_wire=param_wire)
         self.trainer.watch(self.model, self.fusion)

@@ -87,7 +87,8 @@ int immtsf_linear_bf16_backward(int32_t nl, const void* x16, const float* const*
     unsigned short* d16 = static_cast<unsigned short*>(dy16);
     for (int i = 0; i < nl; ++i) {
         if (!dy[i] || !W[i]) return IMMTSF_EINVAL;
-        CHECK(launch_f32_to_bf16(dy[i], d16 + (size_t)i * M * N, (size_t)M * N, s));
+        // (bit 1 of grads_prezeroed: dy16 holds the images already -- a second call that only forms the weight gradients, on another stream)
+        if (!(grads_prezeroed & 2)) CHECK(launch_f32_to_bf16(dy[i], d16 + (size_t)i * M * N, (size_t)M * N, s));
     }
     if (dx) {                   // dx (M, K) = sum_i dy_i (M, N) @ W_i (N, K)
         for (int i = 0; i < nl; ++i) {
@@ -106,7 +107,7 @@ int immtsf_linear_bf16_backward(int32_t nl, const void* x16, const float* const*
             if (!dW[i]) continue;
             GemmArgs h = gemm_args(N, K, M, N, K, K);
             set_problem2(h, 0, cmat(dy[i], d16 + (size_t)i * M * N), cmat(nullptr, x16), mat(dW[i]), nullptr, db ? db[i] : nullptr);
-            h.c_prezeroed = grads_prezeroed ? 1 : 0;
+            h.c_prezeroed = (grads_prezeroed & 1) ? 1 : 0;
             wg[n++] = h;
         }
         CHECK(immtsf_launch_gemm_tn_list(1, wg, n, s));

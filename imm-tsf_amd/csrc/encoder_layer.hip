@@ -139,7 +139,22 @@ int ffn_forward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, const 
 int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int pz, const float* x1, const float* w1, const float* b1,
                  const float* w2, const float* ln_w, const float* h, const float* z, const float* xhat, const float* rstd, const float* dout, float* d1,
                  float* dff, float* dh, float* red, float* gw1, float* gb1, float* gw2, float* gb2, float* gln_w, float* gln_b,
-                 hipStream_t s, const FFNHf* hf = nullptr) {
+                 hipStream_t s, const FFNHf* hf = nullptr, int phase = 0) {
+    // phase (the bf16-in-HBM path only): 0 = everything; 1 = the data path (LayerNorm backward, its two parameter sums, dh, d1) -- what
+    // the layers in front wait for; 2 = the two weight-gradient products alone, from the bf16 images the phase-1 call left in the
+    // workspace / scratch, on any stream ordered behind it (immtsf.train.FlagStep: the parameter branch)
+    if (phase && !(hf && !ffn32_ok(f.R, f.D, f.F, f.act, f.prec))) return IMMTSF_EUNSUPPORTED;
+    if (phase == 2) {
+        const Mat DFF = cmat(dff, hf->dff16), H = mat(nullptr, hf->h16), DH = mat(nullptr, hf->dh16), X = cmat(x1, hf->x16);
+        GemmArgs wg[2];
+        wg[0] = gemm_args(f.D, f.F, f.R, f.D, f.F, f.F);
+        set_problem2(wg[0], 0, DFF, H, mat(gw2), nullptr, gb2);
+        wg[0].c_prezeroed = pz;
+        wg[1] = gemm_args(f.F, f.D, f.R, f.F, f.D, f.D);
+        set_problem2(wg[1], 0, DH, X, mat(gw1), nullptr, gb1);
+        wg[1].c_prezeroed = pz;
+        return immtsf_launch_gemm_tn_list(f.prec, wg, 2, s);
+    }
     auto wgrad = [&](const float* dy, const float* xin, int N, int K, float* dW, float* db) {
         GemmArgs g = gemm_args(N, K, f.R, N, K, K);
         set_problem(g, 0, dy, xin, dW, nullptr, db);
@@ -172,7 +187,7 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
             g.epi_drop = dd; g.epi_site = f.site_h;
             CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
         }
-        {   // dW2 = dff^T h, db2
+        if (phase == 0) {   // dW2 = dff^T h, db2
             GemmArgs g = gemm_args(f.D, f.F, f.R, f.D, f.F, f.F);
             set_problem2(g, 0, DFF, H, mat(gw2), nullptr, gb2);
             g.c_prezeroed = pz;
@@ -184,6 +199,7 @@ int ffn_backward(const FFNDims& f, const DropCfg& dd, const DropCfg& none, int p
             g.accumulate = 1;
             CHECK(immtsf_launch_gemm(GEMM_NN, f.prec, g, s));
         }
+        if (phase == 1) return IMMTSF_OK;
         GemmArgs g = gemm_args(f.F, f.D, f.R, f.F, f.D, f.D);      // dW1 = dh^T x1, db1
         set_problem2(g, 0, DH, X, mat(gw1), nullptr, gb1);
         g.c_prezeroed = pz;
@@ -396,8 +412,11 @@ int immtsf_ffn_block_backward(const immtsf_ffn_block_cfg* c, const immtsf_ffn_bl
     if (workspace_bytes < w.bytes || scratch_bytes < sc.bytes) return IMMTSF_EWORKSPACE;
     const DropCfg dd = mk_drop3(c->training, c->p_drop, c->seed, c->seed_step_dev), none = mk_drop3(0, 0.f, 0, nullptr);
     const FFNHf im{w.x16, w.h16, w.w1h, w.w2h, sc.dff16, sc.dh16};
-    return ffn_backward(f, dd, none, c->grads_prezeroed ? 1 : 0, x, p->w1, p->b1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
-                        sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream), hf ? &im : nullptr);
+    // grads_prezeroed: bit 0 = the gradient buffers are zero already; bits 1-2 = phase (2: data path only, 4: weight gradients only)
+    const int phase = (c->grads_prezeroed >> 1) & 3;
+    if (phase == 3) return IMMTSF_EINVAL;
+    return ffn_backward(f, dd, none, c->grads_prezeroed & 1, x, p->w1, p->b1, p->w2, p->ln_w, w.h, w.z, w.xhat, w.rstd, dout, dx, sc.dff, sc.dh,
+                        sc.red, gr->w1, gr->b1, gr->w2, gr->b2, gr->ln_w, gr->ln_b, static_cast<hipStream_t>(stream), hf ? &im : nullptr, phase);
 }
 
 }  // extern "C"

@@ -1171,20 +1171,30 @@ __global__ __launch_bounds__(512) void layernorm_bwd_lr_kernel(const float* __re
 // stdev (B, C).  The six eager launches of the expression as written were 37 us at the head of the backbone's branch.
 __global__ __launch_bounds__(256) void instance_norm_kernel(const float* __restrict__ x, int B, int L, int C, float* __restrict__ xn,
                                                              float* __restrict__ means, float* __restrict__ stdev) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i - b * C;
-    const float* p = x + (size_t)b * L * C + c;
-    float s = 0.f;
-    for (int t = 0; t < L; ++t) s += p[(size_t)t * C];
-    const float mu = s / (float)L;
-    float v = 0.f;
-    for (int t = 0; t < L; ++t) { const float q = p[(size_t)t * C] - mu; v = fmaf(q, q, v); }
-    const float sd = sqrtf(v / (float)L + 1e-5f);
-    means[i] = mu;
-    stdev[i] = sd;
-    float* o = xn + (size_t)b * L * C + c;
-    for (int t = 0; t < L; ++t) o[(size_t)t * C] = (p[(size_t)t * C] - mu) / sd;
+    // one workgroup per window: its L x C values through LDS (coalesced in and out), a thread per variable for the two statistics
+    // (a thread per series walking global memory with stride C was 15 us of exposed load latency)
+    extern __shared__ float in_lds[];       // [L * C] values, then [C] mean, [C] 1 / stdev
+    const int b = blockIdx.x, n = L * C;
+    const float* p = x + (size_t)b * n;
+    float* mu_s = in_lds + n;
+    float* rs_s = mu_s + C;
+    for (int i = threadIdx.x; i < n; i += 256) in_lds[i] = p[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < L; ++t) s += in_lds[t * C + c];
+        const float mu = s / (float)L;
+        float v = 0.f;
+        for (int t = 0; t < L; ++t) { const float q = in_lds[t * C + c] - mu; v = fmaf(q, q, v); }
+        const float sd = sqrtf(v / (float)L + 1e-5f);
+        means[(size_t)b * C + c] = mu;
+        stdev[(size_t)b * C + c] = sd;
+        mu_s[c] = mu;
+        rs_s[c] = sd;
+    }
+    __syncthreads();
+    float* o = xn + (size_t)b * n;
+    for (int i = threadIdx.x; i < n; i += 256) { const int c = i % C; o[i] = (in_lds[i] - mu_s[c]) / rs_s[c]; }
 }
 
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dz_dy, int rows, int d,
@@ -1640,7 +1650,9 @@ int launch_layernorm_bwd_sums(float* dz_dy, int rows, int d, const float* gamma,
 
 int launch_instance_norm(const float* x, int B, int L, int C, float* xn, float* means, float* stdev, hipStream_t s) {
     if (B <= 0 || L <= 0 || C <= 0) return IMMTSF_OK;
-    hipLaunchKernelGGL(instance_norm_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, s, x, B, L, C, xn, means, stdev);
+    const size_t lds = ((size_t)L * C + 2 * (size_t)C) * sizeof(float);
+    if (lds > 64 * 1024) return IMMTSF_EUNSUPPORTED;
+    hipLaunchKernelGGL(instance_norm_kernel, dim3(B), dim3(256), lds, s, x, B, L, C, xn, means, stdev);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

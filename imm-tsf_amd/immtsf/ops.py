@@ -1328,12 +1328,37 @@ class FFNBlockFn(torch.autograd.Function):
         dout = dout.contiguous()
         dx = torch.empty_like(x2)
         grads, rets = _grad_buffers(params, ctx.sinks)
-        cfg.grads_prezeroed = _prezeroed(params, ctx.sinks)
+        pz = _prezeroed(params, ctx.sinks)
+        cfg.grads_prezeroed = pz
         sc = _bytes(lib.immtsf_ffn_block_scratch_bytes(C.byref(cfg)), x2.device)
         ps, gs = _struct(_lib.FFNBlockParams, params), _struct(_lib.FFNBlockParams, grads)
-        check(lib.immtsf_ffn_block_backward(C.byref(cfg), C.byref(ps), ptr(x2), ptr(dout), ptr(dx), ptr(ctx.ws), ctx.ws.numel(), ptr(sc),
-                                            sc.numel(), C.byref(gs), stream_ptr()), "ffn_block_backward")
+        ws = ctx.ws
         ctx.ws = None
+
+        def call(bits, stream):
+            cfg.grads_prezeroed = pz | bits
+            rc = lib.immtsf_ffn_block_backward(C.byref(cfg), C.byref(ps), ptr(x2), ptr(dout), ptr(dx), ptr(ws), ws.numel(), ptr(sc), sc.numel(),
+                                               C.byref(gs), stream)
+            cfg.grads_prezeroed = pz
+            return rc
+        # a step with a parameter-only branch (immtsf.train.FlagStep): the two weight-gradient products leave this stream's dependent chain
+        # (LinearBf16Fn.backward has the why); only when every gradient goes straight to a pre-zeroed sink and the library takes the phases
+        tail = config.param_tail
+        flags = tail.get("wgrad_flags") if tail is not None else None
+        if pz and flags and all(r is None for r in rets):
+            rc = call(2, stream_ptr())
+            if rc == 0:
+                flag, err = flags.pop()
+                check(lib.immtsf_flag_set(flag, stream_ptr()), "flag_set")
+
+                def job(stream, keep=(x2, dout, dx, ws, sc, params, grads, ps, gs)):
+                    check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
+                    check(call(4, stream), "ffn_block_backward")
+                tail["jobs_b"].append(job)
+                return (dx.view(ctx.shape),) + (None,) * 7 + tuple(rets)
+            if rc != -3:          # (IMMTSF_EUNSUPPORTED: nothing was launched -- the one-call form below)
+                check(rc, "ffn_block_backward")
+        check(call(0, stream_ptr()), "ffn_block_backward")
         return (dx.view(ctx.shape),) + (None,) * 7 + tuple(rets)
 
 
@@ -1797,6 +1822,26 @@ class LinearBf16Fn(torch.autograd.Function):
                     db[i] = rb[i] = flat[i * per + N * K:(i + 1) * per]
         dy16 = torch.empty(nl * M * N, dtype=torch.bfloat16, device=dev)
         arr = lambda ts: (C.c_void_p * nl)(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+        # a step with a parameter-only branch (immtsf.train.FlagStep): the weight gradients -- nothing in the backward waits for them --
+        # leave this stream's dependent chain: the data gradient (and the casts) here, then a flag; the grouped weight-gradient launch
+        # runs on that branch behind the flag.  Only when every gradient goes straight to a pre-zeroed sink (nothing is returned).
+        tail = config.param_tail
+        flags = tail.get("wgrad_flags") if tail is not None else None
+        if need_w and ctx.pre and flags and dx is not None:
+            check(lib.immtsf_linear_bf16_backward(nl, ptr(x16), arr(Ws), arr(ctx.w16), arr(dys), ptr(dy16), ptr(dx), None, None, M, N, K, 1,
+                                                  stream_ptr()), "linear_bf16_backward")
+            flag, err = flags.pop()
+            check(lib.immtsf_flag_set(flag, stream_ptr()), "flag_set")
+            keep = (x16, Ws, ctx.w16, dys, dy16, dW, db)          # the job runs later, on another stream: everything it touches stays alive
+
+            def job(stream, keep=keep, flag=flag, err=err, nl=nl, M=M, N=N, K=K):
+                x16_, Ws_, w16_, dys_, dy16_, dW_, db_ = keep
+                arr_ = lambda ts: (C.c_void_p * nl)(*[None if t is None else t.data_ptr() for t in ts])      # noqa: E731
+                check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
+                check(lib.immtsf_linear_bf16_backward(nl, ptr(x16_), arr_(Ws_), arr_(w16_), arr_(dys_), ptr(dy16_), None, arr_(dW_), arr_(db_), M, N, K,
+                                                      3, stream), "linear_bf16_backward")
+            tail["jobs_b"].append(job)
+            return (dx.view(ctx.shape), None, None) + tuple(rW) + tuple(rb)
         check(lib.immtsf_linear_bf16_backward(nl, ptr(x16), arr(Ws), arr(ctx.w16), arr(dys), ptr(dy16), ptr(dx), arr(dW) if need_w else None,
                                               arr(db) if need_w else None, M, N, K, 1, stream_ptr()), "linear_bf16_backward")
         return ((dx.view(ctx.shape) if dx is not None else None), None, None) + tuple(rW) + tuple(rb)

@@ -843,7 +843,7 @@ class FlagStep(PhasedStep):
     def __init__(self, trainer: FlatTrainer, text_fn, backbone_fn, head_fn, warmup: int = 3, param_tail: Optional[int] = None,
                  fold_by_flag: bool = True, head_flag: bool = True, param_branch: bool = True, sched_gate: bool = True,
                  adam_split=None, backbone_buckets: Sequence[int] = (), timeout_ms: int = 50, comm_timeout_ms: int = 5000,
-                 check_every: int = 0, ttf_wgrad_tail: bool = True, merge_adjacent: bool = True):
+                 check_every: int = 0, ttf_wgrad_tail: bool = True, merge_adjacent: bool = True, backbone_wgrad_tail: bool = True):
         """adam_split: (T's buckets, B's buckets, P's buckets) -- bucket indices whose clip + Adam update runs at the head of that
         branch; every bucket must be listed once, and a bucket belongs to the branch that reads its parameters FIRST in the step
         (bench.py: TTF -> T, the backbone -> B, MMF_XAttn_Add + the proj_out it folds -> P).  None: all on T, in front of the fork.
@@ -853,7 +853,11 @@ class FlagStep(PhasedStep):
         buffer get one wire image, one flag and one collective.
         ttf_wgrad_tail: TTF_T2V_XAttn's early weight gradients (out_proj, attn.in_proj: inputs ready long before the text side's
         backward ends) leave the text side's dependent chain for the parameter branch, behind MMF_XAttn_Add's chain
-        (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks)."""
+        (ops.TTFT2VXAttnFn.backward; needs param_branch and gradient sinks).
+        backbone_wgrad_tail: the weight gradients of a backbone's large linear layers (ops.LinearBf16Fn: PatchTST's q | k | v, output and
+        feed-forward projections) leave the backbone's dependent chain the same way: the data gradient stays, the grouped weight-gradient
+        launch runs on the parameter branch behind a flag of its own (up to seven layers per step; needs param_branch and gradient
+        sinks).  The backbone's buckets are then announced on that branch."""
         if not trainer.device_step:
             raise ValueError("FlagStep needs FlatTrainer(device_step=True)")
         if trainer.sharded:
@@ -1005,18 +1009,25 @@ class FlagStep(PhasedStep):
                 elif dpy is None or dpy.data_ptr() != config.head_dy_ptr:
                     raise RuntimeError("FlagStep: the head published its dY flag early, but autograd did not hand that buffer on as the "
                                        "backbone's output gradient (head_flag=False disables the early flag)")
+                # parameter-gradient tails (work only the optimizer waits for) go to the parameter branch: the text side's behind the TAIL
+                # flag (their inputs exist), a backbone's large linear layers' weight gradients (immtsf.ops.LinearBf16Fn: PatchTST's
+                # projections and feed-forward products) each behind a flag of its own from the spare words 9..15
+                tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "jobs_b": [], "defer": self._defer,
+                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None,
+                        "wgrad_flags": [(W(i), F_ERR) for i in range(15, 8, -1)] if (backbone_wgrad_tail and P is not B) else []}
                 with torch.cuda.stream(B):
                     fwait(F_T2, B)
-                    torch.autograd.backward([pred], [dpy])
+                    config.param_tail = {"jobs_b": tail["jobs_b"], "wgrad_flags": tail["wgrad_flags"]} if tail["wgrad_flags"] else None
+                    try:
+                        torch.autograd.backward([pred], [dpy])
+                    finally:
+                        config.param_tail = None
                     trainer.collect_grads()
-                    if self.dist:
+                    if self.dist and not tail["jobs_b"]:
                         branch_now[0] = "B"
                         for bi in backbone_buckets:
                             announce(bi)
-                # parameter-gradient tails of the text side (work only the optimizer waits for) go to the parameter branch;
-                # the TAIL flag says their inputs exist
-                tail = {"flag": (W(self._TAIL), F_ERR), "jobs": [], "defer": self._defer,
-                        "ttf_flag": (W(self._TTF), F_ERR) if (ttf_wgrad_tail and P is not B) else None}
+                tail["wgrad_flags"] = []              # (the text side's own products stay where they are)
                 config.param_tail = tail if self._defer > 0 else None
                 trainer._capture_hook = announce if self.dist else None
                 branch_now[0] = "T"
@@ -1029,6 +1040,11 @@ class FlagStep(PhasedStep):
                 branch_now[0] = "P"
                 try:
                     with torch.cuda.stream(P):
+                        for job in tail["jobs_b"]:            # the backbone's deferred weight gradients, each behind its own flag
+                            job(sp(P))
+                        if self.dist and tail["jobs_b"]:      # (the backbone's buckets are complete here, not at the end of its branch)
+                            for bi in backbone_buckets:
+                                announce(bi)
                         if tail["jobs"]:
                             if tail.get("flag_set"):
                                 fwait(W(self._TAIL), P)
@@ -1053,7 +1069,7 @@ class FlagStep(PhasedStep):
                     for lo, hi in _runs([trainer.ranges[b] for b in rest]):
                         announce_range(lo, hi, [b for b in rest if lo <= trainer.ranges[b][0] and trainer.ranges[b][1] <= hi])
                     announced.update(rest)
-                _lib.check(lib.immtsf_flags_clear_set(fp, 9, self._f_pending, sp(T)), "flags_clear_set")
+                _lib.check(lib.immtsf_flags_clear_set(fp, 16, self._f_pending, sp(T)), "flags_clear_set")
         finally:
             config.sched_gate = config.sched_armed = None
         self._order_segments()

@@ -29,6 +29,17 @@ class FlattenHead(nn.Module):
 class PatchTST(nn.Module):
     immtsf_graphable = True      # no host syncs / data-dependent shapes in forecasting(): a step may be captured into a hipGraph
 
+    def immtsf_sink_params(self):
+        """the parameters whose gradients the HIP backward writes in place when they are gradient sinks (immtsf.train.FlatTrainer): the
+        encoder layers' attention projections and feed-forward block -- the large products, whose weight gradients a step with a
+        parameter branch takes off the backbone's dependent chain (ops.LinearBf16Fn / FFNBlockFn)"""
+        out = []
+        for lyr in self.encoder.attn_layers:
+            a = lyr.attention
+            for m in (a.query_projection, a.key_projection, a.value_projection, a.out_projection, lyr.conv1, lyr.conv2, lyr.norm2):
+                out += [m.weight, m.bias]
+        return out
+
     def __init__(self, configs, patch_len=6 * 3, stride=3 * 3):
         super().__init__()
         self.input_len = configs.input_len

@@ -19,7 +19,7 @@ def pad_history(zeros_pad, input_len, pred_len, tp_to_predict, data, tp, mask):
 def plain_instance_norm(x):
     """Non-stationary-Transformer normalisation over time (mean detached, biased variance).  On the GPU, for data (no gradient
     wanted): one launch (immtsf_instance_norm) instead of the expression's six."""
-    if x.is_cuda and not x.requires_grad and x.dim() == 3 and x.dtype == torch.float32:
+    if x.is_cuda and not x.requires_grad and x.dim() == 3 and x.dtype == torch.float32 and x.shape[1] * x.shape[2] <= 16000:
         from immtsf import _lib
         x = x.contiguous()
         B, L, C = x.shape

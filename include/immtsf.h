@@ -621,7 +621,9 @@ int immtsf_bf16_to_f32(const void* src, float* dst, size_t n, immtsf_stream_t st
  * while staging.  nl (1..3) layers that share ONE input -- a self-attention's q | k | v -- are ONE forward launch (y[i]: M x N each) and,
  * backward, one cast of the nl upstream gradients (dy16: nl*M*N bf16), nl accumulating data-gradient launches (dx = sum_i dy_i W_i;
  * dx NULL: not needed) and ONE grouped weight-gradient launch (dW[i] = dy_i^T x, db[i] = column sums; db NULL or db[i] NULL: no bias).
- * act: 0 / 1 (ReLU, nl == 1 only).  W / w16 / b / y / dy / dW / db: HOST arrays of nl device pointers.  IMMTSF_EUNSUPPORTED: K or N
+ * act: 0 / 1 (ReLU, nl == 1 only).  grads_prezeroed: bit 0 = dW / db are zero already, bit 1 = dy16 holds the bf16 images already (a second
+ * call that only forms the weight gradients -- dx NULL -- on any stream ordered behind the first: the data gradient stays on the dependent
+ * chain, the weight gradients leave it).  W / w16 / b / y / dy / dW / db: HOST arrays of nl device pointers.  IMMTSF_EUNSUPPORTED: K or N
  * not a multiple of 8, nl > 3 (the caller falls back to immtsf_gemm / immtsf_linear_backward). */
 int immtsf_linear_bf16_forward(int32_t nl, const float* x, void* x16, const float* const* W, void* const* w16, const float* const* b,
                                float* const* y, int32_t M, int32_t N, int32_t K, int32_t act, immtsf_stream_t stream);
@@ -791,7 +793,10 @@ typedef struct immtsf_ffn_block_cfg {
     uint64_t seed;
     const uint64_t* seed_step_dev;
     uint64_t site_base;
-    int32_t grads_prezeroed;
+    int32_t grads_prezeroed;       /* bit 0: the gradient buffers are zero already.  Backward, bf16-in-HBM path only (else IMMTSF_EUNSUPPORTED,
+                                      nothing launched): bit 1 = the data path alone (everything but the two weight-gradient products),
+                                      bit 2 = the two weight-gradient products alone, from the images the bit-1 call left in workspace /
+                                      scratch, on any stream ordered behind it.  (ABI 6) */
 } immtsf_ffn_block_cfg;
 typedef struct immtsf_ffn_block_params {
     float *w1, *b1;     /* (F, D), (F)   conv1 (kernel size 1) */

@@ -1075,6 +1075,53 @@ def test_timesnet_graph_step_trains_like_eager():
     assert err < 2e-4, err
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cfg3_flag_step_trains_like_eager(precision):
+    """The cfg3 composition (PatchTST + TTF_T2V_XAttn + MMF_GR_Add) on immtsf.train.FlagStep -- possible since MMF_GR_Add has a text-only
+    half and a one-launch head (fusions/MMF_GR_Add.py project_kv / forward_loss, csrc/gr_train.hip), with the weight gradients of
+    PatchTST's large linear layers deferred to the parameter branch in bf16 mode (immtsf.ops.LinearBf16Fn) -- trains like the eager
+    step: the same losses, the same parameters after eight steps.  reference: main.py:1093-1101 over models/PatchTST.py,
+    fusions/MMF_GR_Add.py:31-61."""
+    dev = _dev()
+    sys.path.insert(0, ROOT)
+    import bench
+    from immtsf import config
+    config.nan_check = "deferred"
+    old_drop = bench.P_DROP
+    bench.P_DROP = 0.0
+
+    def run(flags):
+        w = bench.Workload("cfg3", dev, 16, precision, device_step=True)
+        w.trainer.eps = 1e-3
+        for mm in w.model.modules():
+            if isinstance(mm, torch.nn.Dropout):
+                mm.p = 0.0
+        if flags:
+            step = bench.flag_step(w)
+            assert step is not None, "FlagStep was rejected for the cfg3 workload"
+        else:
+            step = w.eager_step
+        losses = [float(step()) for _ in range(8)]
+        if flags:
+            step.flush()
+        torch.cuda.synchronize()
+        p = torch.cat([q.detach().reshape(-1) for q in list(w.model.parameters()) + list(w.fusion.parameters())]).clone()
+        w.close()
+        return p, losses
+
+    try:
+        p_e, l_e = run(False)
+        p_g, l_g = run(True)
+    finally:
+        bench.P_DROP = old_drop
+        config.precision = "fp32"
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    for a, b_ in zip(l_e, l_g):
+        assert abs(a - b_) <= tol * abs(a), (l_e, l_g)
+    err = float((p_e - p_g).abs().max() / p_e.abs().max())
+    assert err < (2e-4 if precision == "fp32" else 3e-2), err
+
+
 def _cfg2_reference(w, bench):
     """the oracle side of a cfg2 workload: (reference backbone, fusion parameters as leaf tensors, the CPU batch), from w's weights"""
     from oracle import tpatchgnn_ref as TP

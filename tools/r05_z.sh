@@ -3,7 +3,7 @@ tag=${1:-z}
 out=gpurun_out/r05$tag
 mkdir -p $out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1200 python -m pytest tests/test_gpu_fusion.py tests/test_gpu_backbone.py -x -q -m gpu -k "gr_ or instance_norm or PatchTST or patchtst or TimesNet or timesnet or cfg3 or cfg4" > $out/test.log 2>&1; echo "tests rc=$?" | tee -a $out/summary.txt
+timeout 1200 python -m pytest tests -x -q -m gpu > $out/test.log 2>&1; echo "tests rc=$?" | tee -a $out/summary.txt
 tail -4 $out/test.log | cut -c1-220 | tee -a $out/summary.txt
 for c in cfg3 cfg4; do
 timeout 600 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_$c.json 2> $out/bench_$c.err

@@ -26,8 +26,10 @@ struct GRTDims { int B, T, C, Hd, PW, ld; };       // PW: pitch of P (3 Hd + C r
 struct GRTP { const float *w_ih, *w_hh, *b_hh, *res_w, *res_b, *gate_w, *ln_w, *ln_b; };
 struct GRTG { float *w_ih, *w_hh, *b_hh, *res_w, *res_b, *gate_w, *ln_w, *ln_b; };
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float tanh_e(float x) { return 1.f - 2.f / (1.f + expf(2.f * x)); }       // (|error| ~ 1e-7: one exp instead of tanhf's branches)
+// the hardware's exp2 / reciprocal (1 ulp each): the recurrence is a chain of dependent instructions on ONE wave per CU, where expf's
+// range reduction and an IEEE division cost several hundred cycles a step (measured: 0.6 us per step with them, 19 of the kernel's 63 us)
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_e(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
 
 // LDS layout (floats), see gr_lds_floats
 struct GRL {
@@ -122,7 +124,11 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
         }
         const float br = lane < Hd ? l.bhh[lane] : 0.f, bz = lane < Hd ? l.bhh[Hd + lane] : 0.f, bn = lane < Hd ? l.bhh[2 * Hd + lane] : 0.f;
         float hcur = 0.f;
+        const int jl = lane < Hd ? lane : 0;
+        float g_r = l.P[jl], g_z = l.P[Hd + jl], g_n = l.P[2 * Hd + jl];       // (the step's input-side terms, one step ahead of their use)
         for (int t = 0; t < T; ++t) {
+            const float gr_ = g_r, gz_ = g_z, gn_ = g_n;
+            if (t + 1 < T) { const float* gi = l.P + (t + 1) * PW; g_r = gi[jl]; g_z = gi[Hd + jl]; g_n = gi[2 * Hd + jl]; }
             float hr = br, hz = bz, hn = bn;
 #pragma unroll
             for (int k = 0; k < HM; ++k) {
@@ -132,8 +138,7 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
                 }
             }
             if (lane < Hd) {
-                const float* gi = l.P + t * PW;
-                const float r = sigm(gi[lane] + hr), z = sigm(gi[Hd + lane] + hz), n = tanh_e(gi[2 * Hd + lane] + r * hn);
+                const float r = sigm(gr_ + hr), z = sigm(gz_ + hz), n = tanh_e(gn_ + r * hn);
                 const float h = (1.f - z) * n + z * hcur;
                 const int o = t * Hd + lane;
                 l.r[o] = r; l.z[o] = z; l.n[o] = n; l.hn[o] = hn; l.hp[o] = hcur; l.h[o] = h;
@@ -211,12 +216,15 @@ __global__ __launch_bounds__(64) void gr_train_kernel(GRTDims dm, GRTP p, const 
             wc[2 * HM + g] = on ? l.Whh[(2 * Hd + g) * Hd + lane] : 0.f;
         }
         float dh_carry = 0.f;
+        const int jl = lane < Hd ? lane : 0;
+        int o1 = (T - 1) * Hd + jl;
+        float n_dh = l.dhin[o1], n_r = l.r[o1], n_z = l.z[o1], n_n = l.n[o1], n_hn = l.hn[o1], n_hp = l.hp[o1];      // (one step ahead)
         for (int t = T - 1; t >= 0; --t) {
             float dar = 0.f, daz = 0.f, dhn = 0.f, dhz = 0.f;
+            const float c_dh = n_dh, r = n_r, z = n_z, n = n_n, hn = n_hn, hp = n_hp;
+            if (t > 0) { o1 = (t - 1) * Hd + jl; n_dh = l.dhin[o1]; n_r = l.r[o1]; n_z = l.z[o1]; n_n = l.n[o1]; n_hn = l.hn[o1]; n_hp = l.hp[o1]; }
             if (lane < Hd) {
-                const int o = t * Hd + lane;
-                const float dh = l.dhin[o] + dh_carry;
-                const float r = l.r[o], z = l.z[o], n = l.n[o], hn = l.hn[o], hp = l.hp[o];
+                const float dh = c_dh + dh_carry;
                 const float dn = dh * (1.f - z), dz = dh * (hp - n);
                 const float dan = dn * (1.f - n * n);
                 daz = dz * z * (1.f - z); dar = dan * hn * r * (1.f - r); dhn = dan * r;

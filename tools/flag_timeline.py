@@ -2,7 +2,8 @@
 """Where the branches of immtsf.train.FlagStep wait for each other inside a replayed step: the flag kernels' own trace
 (immtsf_flag_trace, 100 MHz device wall clock -- no profiler, nothing serialised).  Prints, per step, the time of every flag event
 after the previous step's flags_clear, and how long each wait spun.  usage: flag_timeline.py [windows] [steps]
-DIST=1: the data-parallel step on a 1-rank RCCL group (bucket announcements = when each gradient bucket is final)."""
+DIST=1: the data-parallel step on a 1-rank RCCL group (bucket announcements = when each gradient bucket is final); CFG=cfg3|cfg4: another
+configuration that runs on FlagStep."""
 import ctypes as C
 import os
 import sys
@@ -29,7 +30,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         group = dist.group.WORLD
     prec = os.environ.get("PREC", "bf16")
-    w = bench.Workload("cfg2", dev, W, prec, packed_notes=os.environ.get("PADDED", "0") != "1", group=group,
+    w = bench.Workload(os.environ.get("CFG", "cfg2"), dev, W, prec, packed_notes=os.environ.get("PADDED", "0") != "1", group=group,
                        wire="bf16" if prec == "bf16" else "fp32")
     st = bench.flag_step(w)
     if st is None:

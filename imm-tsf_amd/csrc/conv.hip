@@ -240,6 +240,121 @@ __global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int
     Wf[i] = (OT)Weff[(size_t)co * KS * KS * Cin + ((KS - 1 - dy) * KS + (KS - 1 - dx)) * Cin + ci];
 }
 
+// ---- a period image's convolution WITHOUT its im2col image (bf16 mode).  A period image is small -- at most Lmax positions x C channels:
+// 8 KB as bf16 at TimesNet's cfg4 shape -- so a workgroup keeps the whole image of one (window, period) in LDS and forms the rows of the
+// im2col matrix as MFMA operands straight from it: lane (row r, k-group q) reads the 8 channels of ONE tap of position r, 16 contiguous
+// bytes of LDS, or zeros outside the image (same padding).  The kernel matrix (Cout x KS KS C, bf16, 124 KB: L2-resident) is read as B
+// fragments, one k-step ahead.  Per convolution that replaces a 161 MB bf16 image written by im2col and read back by the product (both
+// HBM-bound: 39 + 44 us) with ~2 000 MFMAs per workgroup.  grid (B, k images), 256 threads: wave w owns row tiles w, w + 4 (Lmax <= 128)
+// and every column tile (Cout <= 64).  Output y[z][(l B + b) Cout + n] (+ z_pre, GELU) for the image's rows only.
+constexpr int CPM_RT = 2, CPM_CT = 4;      // row tiles per wave, column tiles (of 16)
+__global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, int C, int KS, const int* __restrict__ period,
+                                                                const int* __restrict__ rows, const float* __restrict__ x, long xs,
+                                                                const bf16_t* __restrict__ W16, const float* __restrict__ bias, int Cout, int act,
+                                                                float* __restrict__ zpre, float* __restrict__ y, long ys) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cpm_lds[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(cpm_lds);                       // [Lmax][C]
+    short* tapd = reinterpret_cast<short*>(img + (size_t)Lmax * C);         // [KS * KS][2]: (dy - r, dx - r)
+    const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int nrows = rows[z], p = period[z], len = nrows / B, H = len / p, rad = KS >> 1, taps = KS * KS;
+    const int c8 = C >> 3, nch = taps * c8, K = taps * C;
+    x += (size_t)z * xs;
+    // the image, cast once
+    for (int i = tid; i < len * c8; i += 256) {
+        const int l = i / c8, cc = (i - l * c8) * 8;
+        const float* src = x + ((size_t)l * B + b) * C + cc;
+        const float4 a = reinterpret_cast<const float4*>(src)[0], c = reinterpret_cast<const float4*>(src)[1];
+        const bf16x8 h = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)c.x, (bf16_t)c.y, (bf16_t)c.z, (bf16_t)c.w};
+        *reinterpret_cast<bf16x8*>(img + (size_t)l * C + cc) = h;
+    }
+    for (int i = tid; i < taps; i += 256) { tapd[2 * i] = (short)(i / KS - rad); tapd[2 * i + 1] = (short)(i % KS - rad); }
+    __syncthreads();
+    // this lane's rows: position -> (h, w)
+    int hh0[CPM_RT], ww0[CPM_RT];
+    bool rok[CPM_RT];
+#pragma unroll
+    for (int i = 0; i < CPM_RT; ++i) {
+        const int r = (wave + 4 * i) * 16 + fr;
+        rok[i] = r < len;
+        hh0[i] = r / p;
+        ww0[i] = r - hh0[i] * p;
+    }
+    const int nct = (Cout + 15) >> 4;
+    f32x4 acc[CPM_RT][CPM_CT];
+#pragma unroll
+    for (int i = 0; i < CPM_RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CPM_CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    const bool any_rows = (wave * 16) < len;       // (wave-uniform: a wave whose first tile lies beyond the image has nothing to do)
+    const int nks = (nch + 3) >> 2;
+    bf16x8 bn[CPM_CT];
+    auto load_b = [&](int ks) {
+        const int q = ks * 4 + fq;
+#pragma unroll
+        for (int j = 0; j < CPM_CT; ++j) {
+            const int n = j * 16 + fr;
+            bn[j] = (j < nct && n < Cout && q < nch) ? *reinterpret_cast<const bf16x8*>(W16 + (size_t)n * K + (size_t)q * 8) : zero8;
+        }
+    };
+    if (any_rows) {
+        load_b(0);
+        for (int ks = 0; ks < nks; ++ks) {
+            bf16x8 bc[CPM_CT];
+#pragma unroll
+            for (int j = 0; j < CPM_CT; ++j) bc[j] = bn[j];
+            if (ks + 1 < nks) load_b(ks + 1);
+            const int q = ks * 4 + fq;
+            const bool qok = q < nch;
+            const int tap = qok ? q / c8 : 0, cc = (q - tap * c8) * 8;
+            const int dy = tapd[2 * tap], dx = tapd[2 * tap + 1];
+#pragma unroll
+            for (int i = 0; i < CPM_RT; ++i) {
+                if ((wave + 4 * i) * 16 >= len) continue;       // (wave-uniform)
+                const int hh = hh0[i] + dy, ww = ww0[i] + dx;
+                const bool ok = qok && rok[i] && hh >= 0 && hh < H && ww >= 0 && ww < p;
+                const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(img + (size_t)(hh * p + ww) * C + cc) : zero8;
+#pragma unroll
+                for (int j = 0; j < CPM_CT; ++j)
+                    if (j < nct) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bc[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: C / D map col = fr, row = fq * 4 + reg
+    y += (size_t)z * ys;
+    if (zpre) zpre += (size_t)z * ys;
+#pragma unroll
+    for (int i = 0; i < CPM_RT; ++i) {
+#pragma unroll
+        for (int j = 0; j < CPM_CT; ++j) {
+            const int n = j * 16 + fr;
+            if (j >= nct || n >= Cout) continue;
+            const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = (wave + 4 * i) * 16 + fq * 4 + e;
+                if (r >= len) continue;
+                float v = acc[i][j][e] + bv;
+                const size_t at = ((size_t)r * B + b) * Cout + n;
+                if (zpre) zpre[at] = v;
+                if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                y[at] = v;
+            }
+        }
+    }
+}
+static bool conv_period_mfma_ok(int Lmax, int C, int Cout, int KS) {
+    return (C % 8) == 0 && C >= 8 && Cout >= 1 && Cout <= 16 * CPM_CT && Lmax <= 16 * 4 * CPM_RT && KS * KS <= 1024 &&
+           (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64 <= 64 * 1024;
+}
+static int launch_conv_period_mfma(int B, int Lmax, int k, int C, int KS, const int* period, const int* rows, const float* x, long xs,
+                                   const bf16_t* W16, const float* bias, int Cout, int act, float* zpre, float* y, long ys, hipStream_t s) {
+    const size_t lds = (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64;
+    hipLaunchKernelGGL(conv_period_mfma_kernel, dim3(B, k), dim3(256), lds, s, B, Lmax, C, KS, period, rows, x, xs, W16, bias, Cout, act, zpre, y, ys);
+    IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
 inline bool bad_conv(int B, int H, int W, int Cin, int Cout, int KS) {
     return B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KS < 1 || !(KS & 1) || (long)B * H * W > (1L << 30);
 }
@@ -468,12 +583,18 @@ int immtsf_conv2d_period_backward(int32_t precision, const float* col, const flo
 int immtsf_conv2d_periods_forward(int32_t precision, const float* x, int64_t x_stride, int32_t B, int32_t Lmax, int32_t k, const int32_t* period,
                                   const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, const float* b_eff, int32_t Cout, int32_t act,
                                   float* col, float* z_pre, float* y, void* w16, int32_t w16_ready, immtsf_stream_t stream) {
-    if (!x || !period || !rows || !W_eff || !col || !y || k < 1 || k > 16 || x_stride < 0 || bad_conv(B, Lmax, 1, Cin, Cout, KS) ||
+    if (!x || !period || !rows || !W_eff || !y || k < 1 || k > 16 || x_stride < 0 || bad_conv(B, Lmax, 1, Cin, Cout, KS) ||
         (act != 0 && act != 2) || (act == 2 && !z_pre))
         return IMMTSF_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int R = B * Lmax, K = KS * KS * Cin;
     const size_t per_y = (size_t)R * Cout, per_col = (size_t)R * K;
+    if (!col) {     // no im2col image: the workgroup of a (window, period) forms the operand rows from the image it holds in LDS
+        if (!(period_hf(precision, Cin, Cout, KS) && w16 && conv_period_mfma_ok(Lmax, Cin, Cout, KS))) return IMMTSF_EINVAL;
+        if (!w16_ready) CHECK(launch_f32_to_bf16(W_eff, w16, (size_t)Cout * K, s));
+        return launch_conv_period_mfma(B, Lmax, k, Cin, KS, period, rows, x, (long)x_stride, static_cast<const bf16_t*>(w16), b_eff, Cout, act,
+                                       act == 2 ? z_pre : nullptr, y, (long)per_y, s);
+    }
     if (!(period_hf(precision, Cin, Cout, KS) && w16)) {
         for (int j = 0; j < k; ++j)
             CHECK(immtsf_conv2d_period_forward(precision, x + (size_t)j * x_stride, B, Lmax, period + j, rows + j, Cin, KS, W_eff, b_eff, Cout, act,
@@ -589,6 +710,72 @@ int immtsf_period_aggregate_backward(const float* Y, const float* w, const float
     IMMTSF_LAUNCH_CHECK();
     hipLaunchKernelGGL(period_agg_bwd_w_kernel, dim3(B), dim3(256), 0, s, Y, dout, B, total, (long)Lmax * B * N, N, k, dw);
     IMMTSF_LAUNCH_CHECK();
+    return IMMTSF_OK;
+}
+
+/* 1 when immtsf_conv2d_periods_forward takes col == NULL for these dimensions (the implicit form: bf16 mode, channel counts multiples of 8 up
+ * to 64, Lmax <= 128) and immtsf_conv2d_periods_backward_x exists for them, 0 otherwise */
+int immtsf_conv2d_periods_implicit_ok(int32_t precision, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout) {
+    return (period_hf(precision, Cin, Cout, KS) && conv_period_mfma_ok(Lmax, Cin, Cout, KS) && conv_period_mfma_ok(Lmax, Cout, Cin, KS)) ? 1 : 0;
+}
+
+size_t immtsf_conv2d_periods_backward_x_scratch_floats(int32_t B, int32_t Lmax, int32_t k, int32_t Cin, int32_t KS, int32_t Cout) {
+    // [im2col image of x, bf16 | dz | bf16 image of g0 | flipped kernel, bf16 | per-image data gradients of a shared input]
+    const size_t R = (size_t)B * Lmax, K = (size_t)KS * KS * Cin, K2 = (size_t)KS * KS * Cout;
+    return (size_t)k * (R * K / 2 + 2 * R * Cout + R * Cin) + (size_t)Cin * K2 + 256;
+}
+
+/* the backward of the implicit form, from the INPUT x instead of a saved im2col image.  phase bit 0 = the data path (g0 = dy gelu'(z_pre),
+ * its bf16 image, dx through the same LDS-image kernel with the flipped kernel), bit 1 = the kernel's gradient (an im2col image of x in
+ * scratch -- nothing but this product reads it -- and the summed weight-gradient product; dW_eff / db_eff handed in ZEROED) from the images
+ * the bit-0 call left in `scratch`, on any stream ordered behind it; 3 = both. */
+int immtsf_conv2d_periods_backward_x(int32_t precision, const float* x, int64_t x_stride, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
+                                     int32_t k, const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff,
+                                     int32_t Cout, int32_t act, float* dx, int32_t dx_shared, float* dW_eff, float* db_eff, float* scratch,
+                                     int32_t phase, immtsf_stream_t stream) {
+    if (!x || !dy || !period || !rows || !W_eff || !scratch || k < 1 || k > 16 || x_stride < 0 || bad_conv(B, Lmax, 1, Cin, Cout, KS) ||
+        (act != 0 && act != 2) || (act == 2 && !z_pre) || phase < 1 || phase > 3 || ((phase & 2) && (!dW_eff || !db_eff)))
+        return IMMTSF_EINVAL;
+    if (!immtsf_conv2d_periods_implicit_ok(precision, Lmax, Cin, KS, Cout)) return IMMTSF_EUNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int R = B * Lmax, K = KS * KS * Cin, K2 = KS * KS * Cout;
+    const size_t per_y = (size_t)R * Cout, per_col = (size_t)R * K, per_x = (size_t)R * Cin;
+    bf16_t* col16 = reinterpret_cast<bf16_t*>(scratch);                      // k x R x K bf16
+    float* dz = scratch + ((size_t)k * per_col + 1) / 2;                     // k x R x Cout
+    dz = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(dz) + 15) & ~(uintptr_t)15);
+    float* g16f = dz + (size_t)k * per_y;                                    // k x R x Cout bf16 (in float slots)
+    float* Wf = g16f + (size_t)k * per_y;                                    // Cin x K2 bf16 (in float slots)
+    float* dxk = Wf + (size_t)Cin * K2;                                      // k x R x Cin
+    bf16_t* g16 = reinterpret_cast<bf16_t*>(g16f);
+    const float* g0 = act == 2 ? dz : dy;
+    if (phase & 1) {
+        const long n4 = ((long)per_y + 3) / 4;
+        hipLaunchKernelGGL(period_g0_kernel, dim3((unsigned)((n4 + 255) / 256), k), dim3(256), 0, s, dy, act == 2 ? z_pre : nullptr, dz, g16, Cout,
+                           (long)per_y, rows);
+        IMMTSF_LAUNCH_CHECK();
+        if (dx) {
+            bf16_t* Wf16 = reinterpret_cast<bf16_t*>(Wf);
+            const long nw = (long)Cin * K2;
+            hipLaunchKernelGGL(flip_weight_kernel<bf16_t>, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, s, Cin, Cout, KS, W_eff, Wf16);
+            IMMTSF_LAUNCH_CHECK();
+            CHECK(launch_conv_period_mfma(B, Lmax, k, Cout, KS, period, rows, g0, (long)per_y, Wf16, nullptr, Cin, 0, nullptr, dx_shared ? dxk : dx,
+                                          (long)per_x, s));
+            if (dx_shared) {
+                const long m4 = ((long)per_x + 3) / 4;
+                hipLaunchKernelGGL(period_sum_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, s, dxk, k, (long)per_x, rows, Cin, dx);
+                IMMTSF_LAUNCH_CHECK();
+            }
+        }
+    }
+    if (phase & 2) {
+        launch_im2col_period<bf16_t>(B, Cin, KS, period, rows, x, col16, R, s, k, (long)x_stride, (long)per_col);
+        IMMTSF_LAUNCH_CHECK();
+        GemmArgs h = gemm_args(Cout, K, R, Cout, K, K);
+        set_problem2(h, 0, cmat(nullptr, g16), cmat(nullptr, col16), mat(dW_eff), nullptr, db_eff);
+        h.dyn = rows; h.dyn_which = 1; h.dyn_stride = 1;
+        h.zbatch = k; h.zsA = (long)per_y; h.zsB = (long)per_col; h.zsC = 0; h.atomic_c = 1; h.c_prezeroed = 1;
+        CHECK(immtsf_launch_gemm2(GEMM_TN, h, s));
+    }
     return IMMTSF_OK;
 }
 

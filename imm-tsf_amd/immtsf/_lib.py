@@ -236,6 +236,11 @@ _PROTOS = {
     "immtsf_conv2d_periods_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32,
                                                  C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_void_p,
                                                  c_stream]),
+    "immtsf_conv2d_periods_implicit_ok": (C.c_int, [C.c_int32] * 5),
+    "immtsf_conv2d_periods_backward_x_scratch_floats": (C.c_size_t, [C.c_int32] * 6),
+    "immtsf_conv2d_periods_backward_x": (C.c_int, [C.c_int32, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p,
+                                                   C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, c_f32p, c_f32p,
+                                                   C.c_int32, c_stream]),
     "immtsf_period_aggregate_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_stream]),
     "immtsf_period_aggregate_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p,
                                                    c_stream]),

@@ -1536,6 +1536,102 @@ class Conv2dPeriodsFn(torch.autograd.Function):
         return dx, None, None, dW, db, None, None, None, None, None
 
 
+class InceptionPeriodsFn(torch.autograd.Function):
+    """An Inception_Block_V1 (layers/Conv_Blocks.py:8-31: the mean of n same-padded convolutions, kernel sizes 1, 3, .., 2n-1) over the k
+    period images of a TimesBlock in the IMPLICIT form (csrc/conv.hip conv_period_mfma_kernel: no im2col image, a workgroup holds a
+    (window, period) image in LDS): merge of the n kernels, the convolution (+ GELU), and backward the data gradient through the same
+    kernel, the merged kernel's gradient from an im2col image of the INPUT formed only for that product, and the un-merge into the n
+    kernels' gradients.  With a parameter branch (immtsf.train.FlagStep) and gradient sinks the kernel-gradient half runs there.
+    args: x (R, Cin) shared or (k, R, Cin), period, rows, act, precision, B, Lmax, n, W_0..W_{n-1}, b_0..b_{n-1}."""
+
+    @staticmethod
+    def forward(ctx, x, period, rows, act, precision, B, Lmax, n, *wb):
+        lib = _lib.load()
+        x = _c(x)
+        ws, bs = [_c(t) for t in wb[:n]], [_c(t) for t in wb[n:]]
+        _need_gpu(x, *ws, *bs)
+        k = period.numel()
+        shared = x.dim() == 2
+        Cout, Cin = ws[0].shape[0], ws[0].shape[1]
+        KS = 2 * n - 1
+        R, K = B * Lmax, KS * KS * Cin
+        dev = x.device
+        Weff = torch.empty(Cout, K, dtype=torch.float32, device=dev)
+        beff = torch.empty(Cout, dtype=torch.float32, device=dev)
+        check(lib.immtsf_inception_merge(n, Cin, Cout, _ptr_array(ws), _ptr_array(bs), ptr(Weff), ptr(beff), stream_ptr()), "inception_merge")
+        w16 = torch.empty(Cout, K, dtype=torch.bfloat16, device=dev)
+        z = torch.empty(k, R, Cout, dtype=torch.float32, device=dev) if act == 2 else None
+        y = torch.empty(k, R, Cout, dtype=torch.float32, device=dev)
+        check(lib.immtsf_conv2d_periods_forward(precision, ptr(x), 0 if shared else R * Cin, B, Lmax, k, ptr(period), ptr(rows), Cin, KS, ptr(Weff),
+                                                ptr(beff), Cout, act, None, ptr(z), ptr(y), ptr(w16), 0, stream_ptr()), "conv2d_periods_forward")
+        ctx.shared = shared
+        ctx.save_for_backward(x, z, Weff, period, rows)
+        ctx.dims = (B, Lmax, Cin, KS, Cout, act, precision, k, n)
+        ctx.sinks = _sinks_of(wb)
+        ctx.params = wb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, z, Weff, period, rows = ctx.saved_tensors
+        B, Lmax, Cin, KS, Cout, act, precision, k, n = ctx.dims
+        dy = dy.contiguous()
+        R = B * Lmax
+        dev = dy.device
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, Cin) if ctx.shared else (k, R, Cin), dtype=torch.float32, device=dev)
+        acc = torch.zeros(Weff.numel() + Cout, dtype=torch.float32, device=dev)      # d W_eff | d b_eff: the images add into it
+        dW, db = acc[:Weff.numel()].view_as(Weff), acc[Weff.numel():]
+        scratch = torch.empty(lib.immtsf_conv2d_periods_backward_x_scratch_floats(B, Lmax, k, Cin, KS, Cout), dtype=torch.float32, device=dev)
+        grads, rets = _grad_buffers(ctx.params, ctx.sinks)
+        ctx.params = None
+        xs = 0 if ctx.shared else R * Cin
+
+        def call(phase, stream):
+            check(lib.immtsf_conv2d_periods_backward_x(precision, ptr(x), xs, ptr(z), ptr(dy), B, Lmax, k, ptr(period), ptr(rows), Cin, KS, ptr(Weff),
+                                                       Cout, act, ptr(dx), 1 if ctx.shared else 0, ptr(dW), ptr(db), ptr(scratch), phase, stream),
+                  "conv2d_periods_backward_x")
+
+        def wgrad(stream, keep=(x, z, dy, Weff, acc, scratch, grads)):
+            call(2, stream)
+            check(lib.immtsf_inception_unmerge(n, Cin, Cout, ptr(dW), ptr(db), _ptr_array(grads[:n]), _ptr_array(grads[n:]), stream),
+                  "inception_unmerge")
+        call(1, stream_ptr())
+        # a step with a parameter-only branch: the kernels' gradients -- an im2col image, the summed product, the un-merge; nothing in the
+        # backward waits for them -- leave this stream's dependent chain (needs every kernel on a gradient sink: nothing is returned)
+        tail = config.param_tail
+        flags = tail.get("wgrad_flags") if tail is not None else None
+        if flags and all(r is None for r in rets):
+            flag, err = flags.pop()
+            check(lib.immtsf_flag_set(flag, stream_ptr()), "flag_set")
+
+            def job(stream):
+                check(lib.immtsf_flag_wait(flag, err, 50, stream), "flag_wait")
+                wgrad(stream)
+            tail["jobs_b"].append(job)
+        else:
+            wgrad(stream_ptr())
+        return (dx,) + (None,) * 7 + tuple(rets)
+
+
+def inception_periods_ok(block, Lmax, precision=None):
+    """True where InceptionPeriodsFn applies to this Inception_Block_V1 (immtsf_conv2d_periods_implicit_ok: bf16 mode, channel counts
+    multiples of 8 up to 64, Lmax <= 128)"""
+    n = len(block.kernels)
+    if n > INCEPTION_MAX or not block.kernels[0].weight.is_cuda:
+        return False
+    Cout, Cin = block.kernels[0].weight.shape[:2]
+    return bool(_lib.load().immtsf_conv2d_periods_implicit_ok(config.precision_code(precision), int(Lmax), int(Cin), 2 * n - 1, int(Cout)))
+
+
+def inception_periods(x, period, rows, block, B, Lmax, act=None, precision=None):
+    ks = block.kernels
+    return InceptionPeriodsFn.apply(x.float(), period, rows, 2 if act == "gelu" else 0, config.precision_code(precision), int(B), int(Lmax),
+                                    len(ks), *[c.weight for c in ks], *[c.bias for c in ks])
+
+
 class PeriodAggregateFn(torch.autograd.Function):
     """TimesBlock's aggregation of the k period images and its residual as one launch (immtsf_period_aggregate_forward / _backward):
     (Y (k, Lmax*B, N) position-major, w (B, k) softmax weights, x (B, total, N)) -> x + sum_j w[:, j] Y_j cropped to `total` steps."""

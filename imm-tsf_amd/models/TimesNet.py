@@ -11,7 +11,8 @@ import torch.fft
 import torch.nn as nn
 import torch.nn.functional as F
 
-from immtsf.ops import INCEPTION_MAX, conv2d_periods, conv2d_same_cl, inception_merge, layer_norm, linear, period_aggregate, period_rows
+from immtsf.ops import (INCEPTION_MAX, conv2d_periods, conv2d_same_cl, inception_merge, inception_periods, inception_periods_ok, layer_norm, linear,
+                        period_aggregate, period_rows)
 from layers.Conv_Blocks import Inception_Block_V1
 from layers.Embed import DataEmbedding
 from models._common import pad_history, plain_instance_norm
@@ -50,7 +51,9 @@ class TimesBlock(nn.Module):
         inc1, act, inc2 = self.conv[0], self.conv[1], self.conv[2]
         merged = (x.is_cuda and isinstance(inc1, Inception_Block_V1) and isinstance(inc2, Inception_Block_V1) and isinstance(act, nn.GELU)
                   and getattr(act, "approximate", "none") == "none" and max(len(inc1.kernels), len(inc2.kernels)) <= INCEPTION_MAX)
-        if merged:      # one averaged kernel per block and step, shared by all periods
+        Lmax = 2 * total                   # (an image's length < total + period <= 2 total)
+        implicit = merged and T == total and inception_periods_ok(inc1, Lmax) and inception_periods_ok(inc2, Lmax)
+        if merged and not implicit:      # one averaged kernel per block and step, shared by all periods
             W1, b1, K1 = inception_merge(inc1)
             W2, b2, K2 = inception_merge(inc2)
         if merged and T == total:
@@ -60,11 +63,15 @@ class TimesBlock(nn.Module):
             # number (csrc/conv.hip conv2d_period_*): every host-side shape is static.
             top, weight = fft_for_period_device(x, self.k)
             period, rows = period_rows(top, total, B)
-            Lmax = 2 * total                   # length < total + period <= 2 total
             xl = F.pad(x.transpose(0, 1), (0, 0, 0, 0, 0, Lmax - total)).reshape(Lmax * B, N)
             # the k period images in ONE call per convolution (the same merged kernel for each), then the aggregation + residual as one launch
-            img = conv2d_periods(xl, period, rows, W1, b1, K1, B, Lmax, act="gelu")            # (k, Lmax B, d_ff)
-            out = conv2d_periods(img, period, rows, W2, b2, K2, B, Lmax)                       # (k, Lmax B, N)
+            if implicit:
+                # bf16 mode: no im2col image -- a workgroup holds a (window, period) image in LDS (ops.InceptionPeriodsFn)
+                img = inception_periods(xl, period, rows, inc1, B, Lmax, act="gelu")             # (k, Lmax B, d_ff)
+                out = inception_periods(img, period, rows, inc2, B, Lmax)                        # (k, Lmax B, N)
+            else:
+                img = conv2d_periods(xl, period, rows, W1, b1, K1, B, Lmax, act="gelu")
+                out = conv2d_periods(img, period, rows, W2, b2, K2, B, Lmax)
             return period_aggregate(out, F.softmax(weight, dim=1), x, B, total, Lmax)
         periods, weight = FFT_for_Period(x, self.k)
         res = []
@@ -86,6 +93,17 @@ class TimesBlock(nn.Module):
 
 class TimesNet(nn.Module):
     immtsf_graphable = True      # (on the GPU: the period selection stays on the device -- TimesBlock.forward -- no host sync in forecasting())
+
+    def immtsf_sink_params(self):
+        """the parameters whose gradients the HIP backward writes in place when they are gradient sinks (immtsf.train.FlatTrainer): the
+        Inception kernels of every TimesBlock -- what lets a step with a parameter branch take their gradient (an im2col image, the summed
+        product, the un-merge) off the backbone's dependent chain (ops.InceptionPeriodsFn)"""
+        out = []
+        for blk in self.model:
+            for inc in (blk.conv[0], blk.conv[2]):
+                for c in inc.kernels:
+                    out += [c.weight, c.bias]
+        return out
 
     def __init__(self, configs):
         super().__init__()

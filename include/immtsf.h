@@ -870,6 +870,19 @@ int immtsf_conv2d_periods_backward(int32_t precision, const float* col, const fl
                                    const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff, int32_t Cout,
                                    int32_t act, float* dx, int32_t dx_shared, float* dW_eff, float* db_eff, float* scratch, void* w16,
                                    immtsf_stream_t stream);
+/* the IMPLICIT form of the batched period convolution (bf16 mode; channel counts multiples of 8 up to 64, Lmax <= 128:
+ * immtsf_conv2d_periods_implicit_ok): a period image is small enough for a workgroup to hold in LDS, so the rows of the im2col matrix are
+ * formed there as MFMA operands and the image itself (161 MB bf16 per convolution at TimesNet's cfg4 shape, written and read back at HBM
+ * rate) never exists -- immtsf_conv2d_periods_forward with col == NULL.  Its backward works from the INPUT x: phase bit 0 = the data
+ * path (dx through the same kernel with the flipped kernel matrix), bit 1 = the kernel's gradient (an im2col image of x in scratch for
+ * this one product; dW_eff / db_eff handed in ZEROED), from the images the bit-0 call left in `scratch`, on any stream ordered behind it.
+ * (ABI 6) */
+int immtsf_conv2d_periods_implicit_ok(int32_t precision, int32_t Lmax, int32_t Cin, int32_t KS, int32_t Cout);
+size_t immtsf_conv2d_periods_backward_x_scratch_floats(int32_t B, int32_t Lmax, int32_t k, int32_t Cin, int32_t KS, int32_t Cout);
+int immtsf_conv2d_periods_backward_x(int32_t precision, const float* x, int64_t x_stride, const float* z_pre, const float* dy, int32_t B, int32_t Lmax,
+                                     int32_t k, const int32_t* period, const int32_t* rows, int32_t Cin, int32_t KS, const float* W_eff,
+                                     int32_t Cout, int32_t act, float* dx, int32_t dx_shared, float* dW_eff, float* db_eff, float* scratch,
+                                     int32_t phase, immtsf_stream_t stream);
 /* TimesBlock's adaptive aggregation on the position-major images (reference models/TimesNet.py:80-86: stack the cropped images, weight them
  * with softmax(amplitude), sum, add the residual): out[b, t, :] = x[b, t, :] + sum_j w[b, j] Y[j, t B + b, :], t < total; Y (k, Lmax*B, N), w
  * (B, k) the softmax weights, x / out (B, total, N).  Backward: dY (k, Lmax*B, N) -- zero on the rows the crop dropped --, dw (B, k); the

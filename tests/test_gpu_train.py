@@ -1075,13 +1075,14 @@ def test_timesnet_graph_step_trains_like_eager():
     assert err < 2e-4, err
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
-def test_cfg3_flag_step_trains_like_eager(precision):
+@pytest.mark.parametrize("cfg,precision", [("cfg3", "fp32"), ("cfg3", "bf16"), ("cfg4", "bf16")])
+def test_cfg3_flag_step_trains_like_eager(cfg, precision):
     """The cfg3 composition (PatchTST + TTF_T2V_XAttn + MMF_GR_Add) on immtsf.train.FlagStep -- possible since MMF_GR_Add has a text-only
     half and a one-launch head (fusions/MMF_GR_Add.py project_kv / forward_loss, csrc/gr_train.hip), with the weight gradients of
     PatchTST's large linear layers deferred to the parameter branch in bf16 mode (immtsf.ops.LinearBf16Fn) -- trains like the eager
-    step: the same losses, the same parameters after eight steps.  reference: main.py:1093-1101 over models/PatchTST.py,
-    fusions/MMF_GR_Add.py:31-61."""
+    step: the same losses, the same parameters after eight steps.  cfg4 in bf16 mode: TimesNet's Inception convolutions in the implicit
+    form with their kernel gradients on the parameter branch (immtsf.ops.InceptionPeriodsFn).  reference: main.py:1093-1101 over
+    models/PatchTST.py, models/TimesNet.py, fusions/MMF_GR_Add.py:31-61."""
     dev = _dev()
     sys.path.insert(0, ROOT)
     import bench
@@ -1091,14 +1092,14 @@ def test_cfg3_flag_step_trains_like_eager(precision):
     bench.P_DROP = 0.0
 
     def run(flags):
-        w = bench.Workload("cfg3", dev, 16, precision, device_step=True)
+        w = bench.Workload(cfg, dev, 16, precision, device_step=True)
         w.trainer.eps = 1e-3
         for mm in w.model.modules():
             if isinstance(mm, torch.nn.Dropout):
                 mm.p = 0.0
         if flags:
             step = bench.flag_step(w)
-            assert step is not None, "FlagStep was rejected for the cfg3 workload"
+            assert step is not None, "FlagStep was rejected for the %s workload" % cfg
         else:
             step = w.eager_step
         losses = [float(step()) for _ in range(8)]

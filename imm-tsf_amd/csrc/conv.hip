@@ -247,15 +247,21 @@ __global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int
 // fragments, one k-step ahead.  Per convolution that replaces a 161 MB bf16 image written by im2col and read back by the product (both
 // HBM-bound: 39 + 44 us) with ~2 000 MFMAs per workgroup.  grid (B, k images), 256 threads: wave w owns row tiles w, w + 4 (Lmax <= 128)
 // and every column tile (Cout <= 64).  Output y[z][(l B + b) Cout + n] (+ z_pre, GELU) for the image's rows only.
-constexpr int CPM_RT = 2, CPM_CT = 4;      // row tiles per wave, column tiles (of 16)
+constexpr int CPM_RT = 2, CPM_CT = 4;      // row tiles per wave, column tiles (of 16) at most
+// NCT: column tiles, a compile-time number (with run-time guards around every MFMA the loop was a chain of scalar branches and
+// exec-masked LDS reads: ~900 cycles per k-step); operand rows outside the image read a 16-byte block of zeros instead of branching
+template <int NCT>
 __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, int C, int KS, const int* __restrict__ period,
                                                                 const int* __restrict__ rows, const float* __restrict__ x, long xs,
                                                                 const bf16_t* __restrict__ W16, const float* __restrict__ bias, int Cout, int act,
-                                                                float* __restrict__ zpre, float* __restrict__ y, long ys) {
+                                                                float* __restrict__ zpre, float* __restrict__ y, long ys, int ks_inv, int c8_shift) {
+    // ks_inv: tap / KS == (tap * ks_inv) >> 16 for every tap (checked by the launcher); c8_shift: log2(C / 8) or -1
     extern __shared__ __attribute__((aligned(16))) unsigned char cpm_lds[];
     bf16_t* img = reinterpret_cast<bf16_t*>(cpm_lds);                       // [Lmax][C]
-    short* tapd = reinterpret_cast<short*>(img + (size_t)Lmax * C);         // [KS * KS][2]: (dy - r, dx - r)
+    short* tapd = reinterpret_cast<short*>(img + (size_t)Lmax * C);         // a 16-byte block of zeros (what an operand row outside the image reads), then the kernel chunk
+    const int zoff = Lmax * C;                                               // (its offset in elements of `img`)
     const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    if (tid < 8) tapd[tid] = 0;
     const int nrows = rows[z], p = period[z], len = nrows / B, H = len / p, rad = KS >> 1, taps = KS * KS;
     const int c8 = C >> 3, nch = taps * c8, K = taps * C;
     x += (size_t)z * xs;
@@ -267,10 +273,9 @@ __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, 
         const bf16x8 h = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)c.x, (bf16_t)c.y, (bf16_t)c.z, (bf16_t)c.w};
         *reinterpret_cast<bf16x8*>(img + (size_t)l * C + cc) = h;
     }
-    for (int i = tid; i < taps; i += 256) { tapd[2 * i] = (short)(i / KS - rad); tapd[2 * i + 1] = (short)(i % KS - rad); }
     __syncthreads();
     // this lane's rows: position -> (h, w)
-    int hh0[CPM_RT], ww0[CPM_RT];
+    int hh0[CPM_RT], ww0[CPM_RT], base0[CPM_RT];
     bool rok[CPM_RT];
 #pragma unroll
     for (int i = 0; i < CPM_RT; ++i) {
@@ -278,46 +283,101 @@ __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, 
         rok[i] = r < len;
         hh0[i] = r / p;
         ww0[i] = r - hh0[i] * p;
+        base0[i] = r * C;                           // (= (h p + w) C: a tap's source is this + (dy p + dx) C + the chunk's channel offset)
     }
-    const int nct = (Cout + 15) >> 4;
-    f32x4 acc[CPM_RT][CPM_CT];
+    constexpr int nct = NCT;
+    f32x4 acc[CPM_RT][NCT];
 #pragma unroll
     for (int i = 0; i < CPM_RT; ++i)
 #pragma unroll
-        for (int j = 0; j < CPM_CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    const bool any_rows = (wave * 16) < len;       // (wave-uniform: a wave whose first tile lies beyond the image has nothing to do)
+    // The kernel matrix comes through LDS in chunks of KC k-steps (all Cout rows of a K range, 64 KB at most): read from L2 one k-step
+    // ahead into registers, every k-step waited out an L2 round trip -- 0.6 us x 121 steps, 46 - 94 us per launch, no faster than the
+    // im2col + product pair it replaced.
     const int nks = (nch + 3) >> 2;
-    bf16x8 bn[CPM_CT];
-    auto load_b = [&](int ks) {
-        const int q = ks * 4 + fq;
+    const int ncol = nct * 16;
+    int KC = (32 * 1024) / (ncol * 32);                   // k-steps per chunk: ncol rows x KC x 32 bf16 <= 64 KB
+    KC = KC < 1 ? 1 : (KC > nks ? nks : KC);
+    const int pitch = KC * 32 + 8;                        // (elements; + 16 bytes: rows start in different banks)
+    bf16_t* wl = reinterpret_cast<bf16_t*>(tapd + 2 * ((taps + 7) & ~7));
+    for (int k0 = 0; k0 < nks; k0 += KC) {
+        const int kc = min(KC, nks - k0);
+        if (k0 > 0) __syncthreads();                     // the previous chunk has been read
+        {   // eight 16-byte loads in flight per thread before the first LDS store (a load -> store loop waits out every round trip)
+            const int items = ncol * kc * 4, kc4 = kc * 4;
+            for (int base = tid; base < items; base += 256 * 8) {
+                bf16x8 v[8];
 #pragma unroll
-        for (int j = 0; j < CPM_CT; ++j) {
-            const int n = j * 16 + fr;
-            bn[j] = (j < nct && n < Cout && q < nch) ? *reinterpret_cast<const bf16x8*>(W16 + (size_t)n * K + (size_t)q * 8) : zero8;
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256;
+                    const int n = i / kc4, qq = i - n * kc4, q = k0 * 4 + qq;
+                    v[u] = (i < items && n < Cout && q < nch) ? *reinterpret_cast<const bf16x8*>(W16 + (size_t)n * K + (size_t)q * 8) : zero8;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = base + u * 256;
+                    if (i < items) { const int n = i / kc4, qq = i - n * kc4; *reinterpret_cast<bf16x8*>(wl + (size_t)n * pitch + qq * 8) = v[u]; }
+                }
+            }
         }
-    };
-    if (any_rows) {
-        load_b(0);
-        for (int ks = 0; ks < nks; ++ks) {
-            bf16x8 bc[CPM_CT];
+        __syncthreads();
+        if ((wave * 16) >= len) continue;                // (wave-uniform: this wave's first tile lies beyond the image)
+        // one k-step ahead: the operands of step ks + 1 are read from LDS while the MFMAs of step ks run (a step's own chain -- tap ->
+        // source position -> LDS read -> MFMA -- is ~400 cycles against 128 of MFMA work)
+        bf16x8 an[CPM_RT], bnx[NCT];
+        // The taps of a k-step are wave-uniform numbers (scalar arithmetic): with C >= 32 its four 8-channel chunks belong to ONE tap,
+        // with C = 16 to two, with C = 8 to four -- a lane picks its tap's (dy, dx, source offset) by its chunk index, adds the
+        // offset to its rows' base addresses and tests the two bounds; everything per-lane-and-tap was ~100 instructions a k-step
+        // on one wave per SIMD (0.45 us), most of them address arithmetic.
+        auto fetch = [&](int ks) {
+            const int q0 = (k0 + ks) * 4;
+            int dyl, dxl, offl;
+            bool qok;
+            if (c8_shift >= 2) {                          // one tap per k-step (uniform)
+                const int tap = q0 >> c8_shift, dyq = (tap * ks_inv) >> 16;
+                dyl = dyq - rad; dxl = tap - dyq * KS - rad; offl = (dyl * p + dxl) * C + ((q0 & (c8 - 1)) + fq) * 8;
+                qok = q0 < nch;
+            } else if (c8_shift >= 0) {                   // two or four taps per k-step: each uniform, a lane selects by fq
+                const int per = 4 >> c8_shift;            // taps per k-step (2 or 4)
+                const int sel = fq >> c8_shift;           // this lane's tap within the step
+                dyl = dxl = offl = 0;
 #pragma unroll
-            for (int j = 0; j < CPM_CT; ++j) bc[j] = bn[j];
-            if (ks + 1 < nks) load_b(ks + 1);
-            const int q = ks * 4 + fq;
-            const bool qok = q < nch;
-            const int tap = qok ? q / c8 : 0, cc = (q - tap * c8) * 8;
-            const int dy = tapd[2 * tap], dx = tapd[2 * tap + 1];
+                for (int u = 0; u < 4; ++u) {
+                    if (u < per) {
+                        const int tap = (q0 >> c8_shift) + u, dyq = (tap * ks_inv) >> 16, dy = dyq - rad, dx = tap - dyq * KS - rad;
+                        if (sel == u) { dyl = dy; dxl = dx; offl = (dy * p + dx) * C; }
+                    }
+                }
+                offl += (fq & (c8 - 1)) * 8;
+                qok = q0 + fq < nch;
+            } else {                                       // channel counts that are not 8 x a power of two: per-lane arithmetic
+                const int q = q0 + fq, tap = q / c8, dyq = (tap * ks_inv) >> 16;
+                dyl = dyq - rad; dxl = tap - dyq * KS - rad; offl = (dyl * p + dxl) * C + (q - tap * c8) * 8;
+                qok = q < nch;
+            }
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) bnx[j] = *reinterpret_cast<const bf16x8*>(wl + (size_t)(j * 16 + fr) * pitch + (ks * 4 + fq) * 8);
 #pragma unroll
             for (int i = 0; i < CPM_RT; ++i) {
-                if ((wave + 4 * i) * 16 >= len) continue;       // (wave-uniform)
-                const int hh = hh0[i] + dy, ww = ww0[i] + dx;
-                const bool ok = qok && rok[i] && hh >= 0 && hh < H && ww >= 0 && ww < p;
-                const bf16x8 a = ok ? *reinterpret_cast<const bf16x8*>(img + (size_t)(hh * p + ww) * C + cc) : zero8;
-#pragma unroll
-                for (int j = 0; j < CPM_CT; ++j)
-                    if (j < nct) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bc[j], acc[i][j], 0, 0, 0);
+                const bool ok = qok && rok[i] && (unsigned)(hh0[i] + dyl) < (unsigned)H && (unsigned)(ww0[i] + dxl) < (unsigned)p;
+                an[i] = *reinterpret_cast<const bf16x8*>(img + (ok ? base0[i] + offl : zoff));
             }
+        };
+        fetch(0);
+        for (int ks = 0; ks < kc; ++ks) {
+            bf16x8 ac[CPM_RT], bc[NCT];
+#pragma unroll
+            for (int i = 0; i < CPM_RT; ++i) ac[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) bc[j] = bnx[j];
+            if (ks + 1 < kc) fetch(ks + 1);
+            // (both row tiles unconditionally: a tile beyond the image multiplies zeros -- a branch here made the compiler shuttle the
+            // accumulators between register files around every MFMA)
+#pragma unroll
+            for (int i = 0; i < CPM_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[j], acc[i][j], 0, 0, 0);
         }
     }
     // epilogue: C / D map col = fr, row = fq * 4 + reg
@@ -326,9 +386,9 @@ __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, 
 #pragma unroll
     for (int i = 0; i < CPM_RT; ++i) {
 #pragma unroll
-        for (int j = 0; j < CPM_CT; ++j) {
+        for (int j = 0; j < NCT; ++j) {
             const int n = j * 16 + fr;
-            if (j >= nct || n >= Cout) continue;
+            if (n >= Cout) continue;
             const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -345,12 +405,33 @@ __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, 
 }
 static bool conv_period_mfma_ok(int Lmax, int C, int Cout, int KS) {
     return (C % 8) == 0 && C >= 8 && Cout >= 1 && Cout <= 16 * CPM_CT && Lmax <= 16 * 4 * CPM_RT && KS * KS <= 1024 &&
-           (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64 <= 64 * 1024;
+           (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64 <= 48 * 1024;
 }
 static int launch_conv_period_mfma(int B, int Lmax, int k, int C, int KS, const int* period, const int* rows, const float* x, long xs,
                                    const bf16_t* W16, const float* bias, int Cout, int act, float* zpre, float* y, long ys, hipStream_t s) {
-    const size_t lds = (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64;
-    hipLaunchKernelGGL(conv_period_mfma_kernel, dim3(B, k), dim3(256), lds, s, B, Lmax, C, KS, period, rows, x, xs, W16, bias, Cout, act, zpre, y, ys);
+    // image | tap table (rounded to 16 bytes) | one chunk of the kernel matrix: ncol rows x (KC x 32 + 8) bf16
+    const int taps = KS * KS, nks = (taps * (C / 8) + 3) / 4;
+    const int ncol = Cout <= 16 ? 16 : Cout <= 32 ? 32 : 64;        // (the kernel's column tiles: 1, 2 or 4)
+    int KC = (32 * 1024) / (ncol * 32);
+    KC = KC < 1 ? 1 : (KC > nks ? nks : KC);
+    const size_t lds = (size_t)Lmax * C * 2 + (size_t)((taps + 7) & ~7) * 4 + (size_t)ncol * (KC * 32 + 8) * 2 + 64;
+    static const hipError_t attr[3] = {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_period_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_period_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_period_mfma_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)};
+    for (int i = 0; i < 3; ++i)
+        if (attr[i] != hipSuccess) return (int)attr[i];
+    const int ks_inv = (65536 + KS - 1) / KS;
+    for (int t = 0; t < taps; ++t)
+        if (((t * ks_inv) >> 16) != t / KS) return IMMTSF_EUNSUPPORTED;       // (never for KS <= 31)
+    const int c8 = C / 8;
+    int c8_shift = -1;
+    for (int sh = 0; sh < 8; ++sh)
+        if ((1 << sh) == c8) c8_shift = sh;
+#define CPM(NCT) hipLaunchKernelGGL(conv_period_mfma_kernel<NCT>, dim3(B, k), dim3(256), lds, s, B, Lmax, C, KS, period, rows, x, xs, W16, bias, Cout, act, \
+                                    zpre, y, ys, ks_inv, c8_shift)
+    if (ncol <= 16) CPM(1); else if (ncol <= 32) CPM(2); else CPM(4);
+#undef CPM
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

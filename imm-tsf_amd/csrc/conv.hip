@@ -247,154 +247,144 @@ __global__ __launch_bounds__(256) void flip_weight_kernel(int Cin, int Cout, int
 // fragments, one k-step ahead.  Per convolution that replaces a 161 MB bf16 image written by im2col and read back by the product (both
 // HBM-bound: 39 + 44 us) with ~2 000 MFMAs per workgroup.  grid (B, k images), 256 threads: wave w owns row tiles w, w + 4 (Lmax <= 128)
 // and every column tile (Cout <= 64).  Output y[z][(l B + b) Cout + n] (+ z_pre, GELU) for the image's rows only.
-constexpr int CPM_RT = 2, CPM_CT = 4;      // row tiles per wave, column tiles (of 16) at most
-// NCT: column tiles, a compile-time number (with run-time guards around every MFMA the loop was a chain of scalar branches and
-// exec-masked LDS reads: ~900 cycles per k-step); operand rows outside the image read a 16-byte block of zeros instead of branching
-template <int NCT>
-__global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, int C, int KS, const int* __restrict__ period,
-                                                                const int* __restrict__ rows, const float* __restrict__ x, long xs,
-                                                                const bf16_t* __restrict__ W16, const float* __restrict__ bias, int Cout, int act,
-                                                                float* __restrict__ zpre, float* __restrict__ y, long ys, int ks_inv, int c8_shift) {
-    // ks_inv: tap / KS == (tap * ks_inv) >> 16 for every tap (checked by the launcher); c8_shift: log2(C / 8) or -1
-    extern __shared__ __attribute__((aligned(16))) unsigned char cpm_lds[];
-    bf16_t* img = reinterpret_cast<bf16_t*>(cpm_lds);                       // [Lmax][C]
-    short* tapd = reinterpret_cast<short*>(img + (size_t)Lmax * C);         // a 16-byte block of zeros (what an operand row outside the image reads), then the kernel chunk
-    const int zoff = Lmax * C;                                               // (its offset in elements of `img`)
-    const int b = blockIdx.x, z = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-    if (tid < 8) tapd[tid] = 0;
-    const int nrows = rows[z], p = period[z], len = nrows / B, H = len / p, rad = KS >> 1, taps = KS * KS;
-    const int c8 = C >> 3, nch = taps * c8, K = taps * C;
-    x += (size_t)z * xs;
-    // the image, cast once
-    for (int i = tid; i < len * c8; i += 256) {
-        const int l = i / c8, cc = (i - l * c8) * 8;
-        const float* src = x + ((size_t)l * B + b) * C + cc;
-        const float4 a = reinterpret_cast<const float4*>(src)[0], c = reinterpret_cast<const float4*>(src)[1];
-        const bf16x8 h = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w, (bf16_t)c.x, (bf16_t)c.y, (bf16_t)c.z, (bf16_t)c.w};
-        *reinterpret_cast<bf16x8*>(img + (size_t)l * C + cc) = h;
-    }
-    __syncthreads();
-    // this lane's rows: position -> (h, w)
-    int hh0[CPM_RT], ww0[CPM_RT], base0[CPM_RT];
-    bool rok[CPM_RT];
-#pragma unroll
-    for (int i = 0; i < CPM_RT; ++i) {
-        const int r = (wave + 4 * i) * 16 + fr;
-        rok[i] = r < len;
-        hh0[i] = r / p;
-        ww0[i] = r - hh0[i] * p;
-        base0[i] = r * C;                           // (= (h p + w) C: a tap's source is this + (dy p + dx) C + the chunk's channel offset)
-    }
-    constexpr int nct = NCT;
-    f32x4 acc[CPM_RT][NCT];
-#pragma unroll
-    for (int i = 0; i < CPM_RT; ++i)
-#pragma unroll
-        for (int j = 0; j < NCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+constexpr int CPM_CT = 4;      // column tiles (of 16) at most
+constexpr int CPM_ITEMS = 2048;  // 16-byte pieces of the kernel matrix a chunk holds: eight per thread
+// NCT column tiles and RT row tiles (the whole image: 4 / 5 / 6 / 8 for <= 64 / 80 / 96 / 128 positions) are compile-time numbers; the FOUR
+// WAVES SPLIT THE REDUCTION -- wave w takes the k-steps ks = w (mod 4) for every row tile and the partial accumulators meet in LDS at the
+// end -- so that a k-step's tap arithmetic and B fragment serve RT A fragments instead of one or two (with a wave per row tile the loop
+// was ~100 instructions a k-step on one wave per SIMD, mostly address arithmetic: 33 - 40 us a launch; this form 18 - 22).  The kernel
+// matrix comes through LDS in chunks of CPM_ITEMS 16-byte pieces, each fetched into registers while the previous one is multiplied (the
+// first before the period and the image are known); operand rows outside the image read a 16-byte block of zeros instead of branching.
+// Measured inside one workgroup (device clock, C = 32 -> 16, 11 x 11 taps): image + first chunk 4 us, k loop 7 - 9 us, reduction and
+// epilogue 1.5 us -- 8 MFMAs and ~80 other instructions a k-step per wave, on one wave per SIMD (320 workgroups: nothing to overlap with).
+template <int NCT, int RT>
+__device__ __forceinline__ void cpm_body(int B, int Lmax, int C, int KS, int p, int len, int b, const float* __restrict__ x,
+                                         const bf16_t* __restrict__ W16, const float* __restrict__ bias, int Cout, int act,
+                                         float* __restrict__ zpre, float* __restrict__ y, int ks_inv, int c8_shift, unsigned char* lds,
+                                         bf16x8 (&wv)[8]) {
+    constexpr int ncol = NCT * 16, KC = CPM_ITEMS / (ncol * 4), KC4 = KC * 4, pitch = KC * 32 + 32;
+    bf16_t* img = reinterpret_cast<bf16_t*>(lds);                            // [Lmax][C], then a 16-byte block of zeros
+    bf16_t* wl = img + (size_t)Lmax * C + 8;                                 // one chunk of the kernel matrix / at the end the partial tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+    const int rad = KS >> 1, taps = KS * KS, c8 = C >> 3, nch = taps * c8, K = taps * C, zoff = Lmax * C;
     const bf16x8 zero8 = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    // The kernel matrix comes through LDS in chunks of KC k-steps (all Cout rows of a K range, 64 KB at most): read from L2 one k-step
-    // ahead into registers, every k-step waited out an L2 round trip -- 0.6 us x 121 steps, 46 - 94 us per launch, no faster than the
-    // im2col + product pair it replaced.
-    const int nks = (nch + 3) >> 2;
-    const int ncol = nct * 16;
-    int KC = (32 * 1024) / (ncol * 32);                   // k-steps per chunk: ncol rows x KC x 32 bf16 <= 64 KB
-    KC = KC < 1 ? 1 : (KC > nks ? nks : KC);
-    const int pitch = KC * 32 + 8;                        // (elements; + 16 bytes: rows start in different banks)
-    bf16_t* wl = reinterpret_cast<bf16_t*>(tapd + 2 * ((taps + 7) & ~7));
-    for (int k0 = 0; k0 < nks; k0 += KC) {
-        const int kc = min(KC, nks - k0);
-        if (k0 > 0) __syncthreads();                     // the previous chunk has been read
-        {   // eight 16-byte loads in flight per thread before the first LDS store (a load -> store loop waits out every round trip)
-            const int items = ncol * kc * 4, kc4 = kc * 4;
-            for (int base = tid; base < items; base += 256 * 8) {
-                bf16x8 v[8];
+    if (tid < 8) img[zoff + tid] = (bf16_t)0.f;
+    {   // the image, cast once: every load of a pair of passes in flight before the first store
+        const int items = len * c8;
+        for (int base = tid; base < items; base += 512) {
+            float4 lo[2], hi[2];
+            int at[2];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * 256;
-                    const int n = i / kc4, qq = i - n * kc4, q = k0 * 4 + qq;
-                    v[u] = (i < items && n < Cout && q < nch) ? *reinterpret_cast<const bf16x8*>(W16 + (size_t)n * K + (size_t)q * 8) : zero8;
-                }
+            for (int u = 0; u < 2; ++u) {
+                const int i = base + u * 256, ii = i < items ? i : 0, l = ii / c8, cc = (ii - l * c8) * 8;
+                const float* src = x + ((size_t)l * B + b) * C + cc;
+                lo[u] = reinterpret_cast<const float4*>(src)[0];
+                hi[u] = reinterpret_cast<const float4*>(src)[1];
+                at[u] = i < items ? l * C + cc : -1;
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = base + u * 256;
-                    if (i < items) { const int n = i / kc4, qq = i - n * kc4; *reinterpret_cast<bf16x8*>(wl + (size_t)n * pitch + qq * 8) = v[u]; }
-                }
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 h = {(bf16_t)lo[u].x, (bf16_t)lo[u].y, (bf16_t)lo[u].z, (bf16_t)lo[u].w,
+                                  (bf16_t)hi[u].x, (bf16_t)hi[u].y, (bf16_t)hi[u].z, (bf16_t)hi[u].w};
+                if (at[u] >= 0) *reinterpret_cast<bf16x8*>(img + at[u]) = h;
             }
         }
-        __syncthreads();
-        if ((wave * 16) >= len) continue;                // (wave-uniform: this wave's first tile lies beyond the image)
-        // one k-step ahead: the operands of step ks + 1 are read from LDS while the MFMAs of step ks run (a step's own chain -- tap ->
-        // source position -> LDS read -> MFMA -- is ~400 cycles against 128 of MFMA work)
-        bf16x8 an[CPM_RT], bnx[NCT];
-        // The taps of a k-step are wave-uniform numbers (scalar arithmetic): with C >= 32 its four 8-channel chunks belong to ONE tap,
-        // with C = 16 to two, with C = 8 to four -- a lane picks its tap's (dy, dx, source offset) by its chunk index, adds the
-        // offset to its rows' base addresses and tests the two bounds; everything per-lane-and-tap was ~100 instructions a k-step
-        // on one wave per SIMD (0.45 us), most of them address arithmetic.
-        auto fetch = [&](int ks) {
+    }
+    // a tap (dy, dx) of output position r reads position r + dy * p + dx when its column ww + dx stays inside the period and that
+    // position is inside the image (the column test makes "row inside" and "position inside" the same statement); anything else reads
+    // the zero block.  Rows r >= len of the last tile read whatever is valid for them and are never stored.
+    int ww0[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int r = i * 16 + fr;
+        ww0[i] = r - (r / p) * p;
+    }
+    f32x4 acc[RT][NCT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = (nch + 3) >> 2;
+    for (int k0 = 0; k0 < nks; k0 += KC) {
+        const int kc = min(KC, nks - k0);
+        // this chunk waits in registers (the kernel fetched the first before it knew its image; the next is fetched below, before this
+        // one is multiplied): thread t holds the 16-byte pieces t, t + 256, ... of the chunk's ncol x KC4 grid
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256, n = i / KC4, qq = i - n * KC4;
+            *reinterpret_cast<bf16x8*>(wl + (size_t)n * pitch + qq * 8) = (n < Cout && k0 * 4 + qq < nch) ? wv[u] : zero8;
+        }
+        __syncthreads();                                  // the image and the chunk are in place
+        if (k0 + KC < nks) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = tid + u * 256, n = i / KC4, q = (k0 + KC) * 4 + (i - n * KC4);
+                wv[u] = *reinterpret_cast<const bf16x8*>(W16 + (size_t)min(n, Cout - 1) * K + (size_t)min(q, nch - 1) * 8);   // (masked at the store)
+            }
+        }
+        for (int ks = wave; ks < kc; ks += 4) {           // this wave's share of the reduction
+            // the taps of a k-step are wave-uniform numbers: with C >= 32 its four 8-channel chunks belong to ONE tap, with C = 16 to
+            // two, with C = 8 to four -- a lane picks its tap's (dy, dx, source offset) by its chunk index
             const int q0 = (k0 + ks) * 4;
-            int dyl, dxl, offl;
-            bool qok;
-            if (c8_shift >= 2) {                          // one tap per k-step (uniform)
+            int dxl, posl, chl;                            // tap column offset, position offset dy * p + dx, channel offset (elements)
+            if (c8_shift >= 2) {
                 const int tap = q0 >> c8_shift, dyq = (tap * ks_inv) >> 16;
-                dyl = dyq - rad; dxl = tap - dyq * KS - rad; offl = (dyl * p + dxl) * C + ((q0 & (c8 - 1)) + fq) * 8;
-                qok = q0 < nch;
-            } else if (c8_shift >= 0) {                   // two or four taps per k-step: each uniform, a lane selects by fq
-                const int per = 4 >> c8_shift;            // taps per k-step (2 or 4)
-                const int sel = fq >> c8_shift;           // this lane's tap within the step
-                dyl = dxl = offl = 0;
+                dxl = tap - dyq * KS - rad; posl = (dyq - rad) * p + dxl; chl = ((q0 & (c8 - 1)) + fq) * 8;
+            } else if (c8_shift >= 0) {
+                const int per = 4 >> c8_shift, sel = fq >> c8_shift;
+                dxl = posl = 0;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (u < per) {
-                        const int tap = (q0 >> c8_shift) + u, dyq = (tap * ks_inv) >> 16, dy = dyq - rad, dx = tap - dyq * KS - rad;
-                        if (sel == u) { dyl = dy; dxl = dx; offl = (dy * p + dx) * C; }
+                        const int tap = (q0 >> c8_shift) + u, dyq = (tap * ks_inv) >> 16, dx = tap - dyq * KS - rad;
+                        if (sel == u) { dxl = dx; posl = (dyq - rad) * p + dx; }
                     }
                 }
-                offl += (fq & (c8 - 1)) * 8;
-                qok = q0 + fq < nch;
-            } else {                                       // channel counts that are not 8 x a power of two: per-lane arithmetic
+                chl = (fq & (c8 - 1)) * 8;
+            } else {
                 const int q = q0 + fq, tap = q / c8, dyq = (tap * ks_inv) >> 16;
-                dyl = dyq - rad; dxl = tap - dyq * KS - rad; offl = (dyl * p + dxl) * C + (q - tap * c8) * 8;
-                qok = q < nch;
+                dxl = tap - dyq * KS - rad; posl = (dyq - rad) * p + dxl; chl = (q - tap * c8) * 8;
+            }
+            posl += fr;
+            bf16x8 bc[NCT], av[RT];
+#pragma unroll
+            for (int j = 0; j < NCT; ++j) bc[j] = *reinterpret_cast<const bf16x8*>(wl + (size_t)(j * 16 + fr) * pitch + (ks * 4 + fq) * 8);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const int src = i * 16 + posl;
+                const bool ok = (unsigned)(ww0[i] + dxl) < (unsigned)p && (unsigned)src < (unsigned)len;
+                av[i] = *reinterpret_cast<const bf16x8*>(img + (ok ? __mul24(src, C) + chl : zoff));
             }
 #pragma unroll
-            for (int j = 0; j < NCT; ++j) bnx[j] = *reinterpret_cast<const bf16x8*>(wl + (size_t)(j * 16 + fr) * pitch + (ks * 4 + fq) * 8);
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int i = 0; i < CPM_RT; ++i) {
-                const bool ok = qok && rok[i] && (unsigned)(hh0[i] + dyl) < (unsigned)H && (unsigned)(ww0[i] + dxl) < (unsigned)p;
-                an[i] = *reinterpret_cast<const bf16x8*>(img + (ok ? base0[i] + offl : zoff));
-            }
-        };
-        fetch(0);
-        for (int ks = 0; ks < kc; ++ks) {
-            bf16x8 ac[CPM_RT], bc[NCT];
-#pragma unroll
-            for (int i = 0; i < CPM_RT; ++i) ac[i] = an[i];
-#pragma unroll
-            for (int j = 0; j < NCT; ++j) bc[j] = bnx[j];
-            if (ks + 1 < kc) fetch(ks + 1);
-            // (both row tiles unconditionally: a tile beyond the image multiplies zeros -- a branch here made the compiler shuttle the
-            // accumulators between register files around every MFMA)
-#pragma unroll
-            for (int i = 0; i < CPM_RT; ++i)
-#pragma unroll
-                for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bc[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NCT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bc[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();                                  // the chunk has been read
     }
-    // epilogue: C / D map col = fr, row = fq * 4 + reg
-    y += (size_t)z * ys;
-    if (zpre) zpre += (size_t)z * ys;
+    // the four waves' partial tiles meet in LDS; wave w finishes the row tiles i = w (mod 4)
+    f32x4* red = reinterpret_cast<f32x4*>(wl);            // [wave][RT][NCT][64 lanes]
 #pragma unroll
-    for (int i = 0; i < CPM_RT; ++i) {
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NCT; ++j) red[((wave * RT + i) * NCT + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        if ((i & 3) != wave || i * 16 >= len) continue;    // (wave-uniform)
 #pragma unroll
         for (int j = 0; j < NCT; ++j) {
+            f32x4 t = red[((0 * RT + i) * NCT + j) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const f32x4 u = red[((w * RT + i) * NCT + j) * 64 + lane]; t += u; }
             const int n = j * 16 + fr;
             if (n >= Cout) continue;
             const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = (wave + 4 * i) * 16 + fq * 4 + e;
+            for (int e = 0; e < 4; ++e) {                  // C / D map: col = fr, row = fq * 4 + e
+                const int r = i * 16 + fq * 4 + e;
                 if (r >= len) continue;
-                float v = acc[i][j][e] + bv;
+                float v = t[e] + bv;
                 const size_t at = ((size_t)r * B + b) * Cout + n;
                 if (zpre) zpre[at] = v;
                 if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
@@ -403,18 +393,47 @@ __global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, 
         }
     }
 }
+template <int NCT>
+__global__ __launch_bounds__(256) void conv_period_mfma_kernel(int B, int Lmax, int C, int KS, const int* __restrict__ period,
+                                                                const int* __restrict__ rows, const float* __restrict__ x, long xs,
+                                                                const bf16_t* __restrict__ W16, const float* __restrict__ bias, int Cout, int act,
+                                                                float* __restrict__ zpre, float* __restrict__ y, long ys, int ks_inv, int c8_shift) {
+    // ks_inv: tap / KS == (tap * ks_inv) >> 16 for every tap (checked by the launcher); c8_shift: log2(C / 8) or -1
+    extern __shared__ __attribute__((aligned(16))) unsigned char cpm_lds[];
+    const int b = blockIdx.x, z = blockIdx.y;
+    bf16x8 wv[8];
+    {   // the first chunk of the kernel matrix is on its way before the period and the image are known
+        constexpr int KC4 = CPM_ITEMS / (NCT * 16 * 4) * 4;
+        const int nch = KS * KS * (C >> 3), K = KS * KS * C;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 256, n = i / KC4, q = i - n * KC4;
+            wv[u] = *reinterpret_cast<const bf16x8*>(W16 + (size_t)min(n, Cout - 1) * K + (size_t)min(q, nch - 1) * 8);
+        }
+    }
+    const int p = period[z], len = rows[z] / B;
+    x += (size_t)z * xs;
+    y += (size_t)z * ys;
+    if (zpre) zpre += (size_t)z * ys;
+#define CPM_BODY(RT) cpm_body<NCT, RT>(B, Lmax, C, KS, p, len, b, x, W16, bias, Cout, act, zpre, y, ks_inv, c8_shift, cpm_lds, wv)
+    if (len <= 64) CPM_BODY(4);
+    else if (len <= 80) CPM_BODY(5);
+    else if (len <= 96) CPM_BODY(6);
+    else CPM_BODY(8);
+#undef CPM_BODY
+}
+
 static bool conv_period_mfma_ok(int Lmax, int C, int Cout, int KS) {
-    return (C % 8) == 0 && C >= 8 && Cout >= 1 && Cout <= 16 * CPM_CT && Lmax <= 16 * 4 * CPM_RT && KS * KS <= 1024 &&
-           (size_t)Lmax * C * 2 + (size_t)KS * KS * 4 + 64 <= 48 * 1024;
+    return (C % 8) == 0 && C >= 8 && Cout >= 1 && Cout <= 16 * CPM_CT && Lmax <= 128 && KS * KS <= 1024 && (size_t)Lmax * C * 2 <= 16 * 1024;
 }
 static int launch_conv_period_mfma(int B, int Lmax, int k, int C, int KS, const int* period, const int* rows, const float* x, long xs,
                                    const bf16_t* W16, const float* bias, int Cout, int act, float* zpre, float* y, long ys, hipStream_t s) {
-    // image | tap table (rounded to 16 bytes) | one chunk of the kernel matrix: ncol rows x (KC x 32 + 8) bf16
-    const int taps = KS * KS, nks = (taps * (C / 8) + 3) / 4;
+    const int taps = KS * KS;
     const int ncol = Cout <= 16 ? 16 : Cout <= 32 ? 32 : 64;        // (the kernel's column tiles: 1, 2 or 4)
-    int KC = (32 * 1024) / (ncol * 32);
-    KC = KC < 1 ? 1 : (KC > nks ? nks : KC);
-    const size_t lds = (size_t)Lmax * C * 2 + (size_t)((taps + 7) & ~7) * 4 + (size_t)ncol * (KC * 32 + 8) * 2 + 64;
+    // image | 16 bytes of zeros | max(one chunk of the kernel matrix: ncol rows x (KC x 32 + 32) bf16, the four waves' partial tiles)
+    const int KC = CPM_ITEMS / (ncol * 4), rt = Lmax <= 64 ? 4 : Lmax <= 80 ? 5 : Lmax <= 96 ? 6 : 8;
+    const size_t chunk = (size_t)ncol * (KC * 32 + 32) * 2, red = (size_t)4 * rt * (ncol / 16) * 64 * 16;
+    const size_t lds = (size_t)Lmax * C * 2 + 16 + (chunk > red ? chunk : red) + 64;
     static const hipError_t attr[3] = {
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_period_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),
         hipFuncSetAttribute(reinterpret_cast<const void*>(conv_period_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024),

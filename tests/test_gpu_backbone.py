@@ -187,6 +187,55 @@ def test_timesnet_bf16_period_images_vs_fp32():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("Cin,Cout,n,B,total,periods", [
+    (32, 16, 6, 5, 64, [2, 3, 7, 64, 33]),       # cfg4's second convolution; images of 4 and 5 row tiles
+    (16, 32, 6, 3, 64, [5, 9, 13, 17, 31]),      # cfg4's first (two taps per k-step); 5 and 6 row tiles
+    (8, 40, 2, 4, 50, [4, 7, 11]),               # four taps per k-step, three column tiles of four
+    (24, 40, 3, 2, 60, [1, 60, 8]),              # channel counts that are not powers of two; one-column and one-row images
+    (64, 64, 4, 2, 64, [6, 64, 50, 63]),         # the widest case: four column tiles, 8 row tiles
+])
+def test_inception_periods_implicit_vs_conv2d(Cin, Cout, n, B, total, periods):
+    """csrc/conv.hip conv_period_mfma_kernel (ops.inception_periods: an Inception_Block_V1 over the k period images of a TimesBlock, no
+    im2col image) against torch's conv2d on the same images, layers/Conv_Blocks.py:8-31 + models/TimesNet.py:50-66: output (+ GELU),
+    data gradient and the n kernels' gradients; bf16 operands, 3e-2 of the largest value."""
+    dev = _dev()
+    from immtsf import config, ops
+    torch.manual_seed(Cin * 7 + Cout)
+    block = types.SimpleNamespace(kernels=torch.nn.ModuleList([torch.nn.Conv2d(Cin, Cout, 2 * i + 1, padding=i) for i in range(n)]).to(dev))
+    k, Lmax = len(periods), 2 * total
+    lens = [-(-total // p) * p for p in periods]
+    period = torch.tensor(periods, dtype=torch.int32, device=dev)
+    rows = torch.tensor([B * l for l in lens], dtype=torch.int32, device=dev)
+    assert ops.inception_periods_ok(block, Lmax, "bf16")
+    x = torch.randn(k, Lmax * B, Cin, device=dev, requires_grad=True)
+    up = torch.randn(k, Lmax * B, Cout, device=dev)
+    y = ops.inception_periods(x, period, rows, block, B, Lmax, act="gelu", precision="bf16")
+    valid = torch.zeros(k, Lmax * B, 1, device=dev)
+    for j, l in enumerate(lens):
+        valid[j, :l * B] = 1
+    (y * up * valid).sum().backward()
+    got = (y.detach() * valid, x.grad.clone() * valid, [c.weight.grad.clone() for c in block.kernels], [c.bias.grad.clone() for c in block.kernels])
+    x.grad = None
+    for c in block.kernels:
+        c.weight.grad = c.bias.grad = None
+    ref = torch.zeros(k, Lmax * B, Cout, device=dev)
+    outs = []
+    for j, (p, l) in enumerate(zip(periods, lens)):
+        img = x[j, :l * B].view(l, B, Cin).permute(1, 2, 0).reshape(B, Cin, l // p, p)
+        o = torch.nn.functional.gelu(torch.stack([c(img) for c in block.kernels], -1).mean(-1))
+        outs.append(o.reshape(B, Cout, l).permute(2, 0, 1).reshape(l * B, Cout))
+    loss = sum((o * up[j, :o.shape[0]]).sum() for j, o in enumerate(outs))
+    loss.backward()
+    for j, o in enumerate(outs):
+        ref[j, :o.shape[0]] = o.detach()
+    assert _rel(got[0], ref) < 3e-2
+    assert _rel(got[1], x.grad * valid) < 3e-2
+    gmax = max(float(c.weight.grad.abs().max()) for c in block.kernels)
+    for i, c in enumerate(block.kernels):
+        assert _rel(got[2][i], c.weight.grad, floor=1e-2 * gmax) < 3e-2, i
+        assert _rel(got[3][i], c.bias.grad) < 3e-2, i
+
+
 @pytest.mark.parametrize("B,N,M,D,nd,hop", [(64, 8, 2, 32, 10, 1), (3, 5, 3, 16, 4, 2), (2, 41, 2, 64, 10, 1), (1, 1, 1, 8, 2, 3)])
 def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
     """the one-workgroup-per-cell adaptive-graph kernel (forward, and the recomputing backward with atomically

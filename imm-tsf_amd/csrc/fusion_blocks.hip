@@ -138,7 +138,16 @@ int t2v_weights(const immtsf_fusion_cfg* c, const immtsf_t2v_params* p, const T2
 // ================================================================================================ TTF_T2V_XAttn, folded form
 // (csrc/t2v_fold.hip has the algebra and the non-GEMM kernels; this is the launch sequence.)  Taken wherever its limits hold unless the
 // caller asks for the chain as written (immtsf_fusion_cfg.form = 1, the cross-check).
+// the MIX-FIRST variant of the folded form (t2v_premix.hip): windows with more notes than the fold's mix kernels hold (N > 64) in bf16
+// mode, one head, T <= 32 -- or form = 3 at any N
+inline bool t2v_premix_on(const immtsf_fusion_cfg* c) {
+    const int form = c->form & 3;
+    if (form == 1 || form == 2) return false;
+    if (!(c->precision == 1 && t2v_hf(c)) || !t2v_premix_shape_ok(c->T, c->d, c->H, c->d_m)) return false;
+    return form == 3 || c->N > 64;
+}
 inline bool t2v_fold_on(const immtsf_fusion_cfg* c) {
+    if (t2v_premix_on(c)) return true;
     const int form = c->form & 3;
     if (form == 1 || !t2v_fold_shape_ok(c->N, c->T, c->d, c->H)) return false;
     if (form == 0 && (long)c->B * c->N < IMMTSF_T2V_FOLD_MIN_ROWS) return false;      // small batches: the chain's GEMMs are as cheap as the fold's fixed cost
@@ -152,6 +161,9 @@ struct T2VFoldWs {
     Mat X, z, zln;            // [R, dmc] notes | Time2Vec ; [R, H d] folded value rows ; [BT, d] LayerNorm output
     float *S, *P, *q, *qs, *xpre, *xhat, *rstd;
     unsigned long long* keep;      // the output dropout's keep bits (the wide mix + LayerNorm kernel writes, the low-rank LayerNorm backward reads)
+    void* At;                 // mix-first: [R, 32] bf16, the dropped attention weights of (note, step)
+    float* wbar;              // mix-first: [BT] their sums
+    Mat xbar;                 // mix-first: [BT, dmc] bf16, the mix of the raw rows
     Mat OVa;                  // [H d + 8, d]: W_o[:, h] W_v[h, :] per head, then G_h = (scale q_h)^T W_k,h, then zero rows
     Mat Ab;                   // [d, dmc] = [W_KV[:, :d] W_in | W_KV[:, d:]] (with an input projection; else W_KV itself)
     Mat Wa;                   // [H d + 8, dmc]: W_tot per head, then the score vectors u_h, then zero rows
@@ -171,16 +183,21 @@ T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
     w.offsets = k.take<int>(B + 1);
     w.rowmap = k.take<int>(R);
     w.seg = k.take<int>(R);
+    const bool pm = t2v_premix_on(c);
     w.X = k.take_mat(R * dmc, !hf, hf);
-    w.z = k.take_mat(R * Hd, !hf, hf);
+    w.z = pm ? Mat{nullptr, nullptr} : k.take_mat(R * Hd, !hf, hf);
     w.S = k.take<float>(R * H);
     w.P = k.take<float>(R * H);
     w.q = k.take<float>(d);
     w.qs = k.take<float>(d);
-    w.xpre = t2v_mix_wide_ok((int)d) ? nullptr : k.take<float>(BT * d);      // (the wide mix + LayerNorm kernel keeps x_pre in registers)
+    const bool wide = t2v_mix_wide_ok((int)d) && !pm;
+    w.xpre = wide ? nullptr : k.take<float>(BT * d);      // (the wide mix + LayerNorm kernel keeps x_pre in registers)
     w.xhat = k.take<float>(BT * d);
     w.rstd = k.take<float>(BT);
-    w.keep = t2v_mix_wide_ok((int)d) ? k.take<unsigned long long>(B * 2 * 256) : nullptr;
+    w.keep = wide ? k.take<unsigned long long>(B * 2 * 256) : nullptr;
+    w.At = pm ? k.take<unsigned short>(R * 32) : nullptr;
+    w.wbar = pm ? k.take<float>(BT) : nullptr;
+    w.xbar = pm ? k.take_mat(BT * dmc, false, true) : Mat{nullptr, nullptr};
     w.zln = k.take_mat(BT * d, !hf, hf);
     w.OVa = k.take_mat(Ma * d, true, hf);
     w.Ab = k.take_mat(d * dmc, true, hf);
@@ -202,6 +219,9 @@ T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
 struct T2VFoldScratch {
     Mat dE, dza, dWa, dOVa, dA;
     float *dzln, *dx, *dbo_part, *dXt, *dcv, *dbvec1, *dbvec2, *dqs, *red, *red_t2v, *red_bo;
+    void* dxh;                // mix-first: bf16 image of dx, [BT, d]
+    Mat dxbar;                // mix-first: [BT, dmc] bf16
+    float *dwbar, *g, *ds, *du_slab;      // mix-first: [BT], [R], [R], the score vector's gradient per row block
     int t2v_slabs;
     void* sk[2];
     size_t skb[2];
@@ -216,7 +236,14 @@ T2VFoldScratch carve_t2v_fold_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.dE = k.take_mat(BT * d, false, hf);
     s.dzln = k.take<float>(BT * d);
     s.dx = k.take<float>(BT * d);
-    s.dza = k.take_mat(R * Ma, !hf, hf);
+    const bool pm = t2v_premix_on(c);
+    s.dza = pm ? Mat{nullptr, nullptr} : k.take_mat(R * Ma, !hf, hf);
+    s.dxh = pm ? k.take<unsigned short>(BT * d) : nullptr;
+    s.dxbar = pm ? k.take_mat(BT * dmc, false, true) : Mat{nullptr, nullptr};
+    s.dwbar = pm ? k.take<float>(BT) : nullptr;
+    s.g = pm ? k.take<float>(R) : nullptr;
+    s.ds = pm ? k.take<float>(R) : nullptr;
+    s.du_slab = pm ? k.take<float>(t2v_premix_du_scratch_floats((int)dmc)) : nullptr;
     s.dbo_part = k.take<float>(B * d);
     s.dXt = k.take<float>(R * dt);
     s.dWa = k.take_mat(Ma * dmc, true, hf);
@@ -231,7 +258,8 @@ T2VFoldScratch carve_t2v_fold_scratch(const immtsf_fusion_cfg* c, void* base) {
     s.t2v_slabs = (int)(R / 256 < 32 ? 32 : (R / 256 > 1024 ? 1024 : R / 256));
     s.red_t2v = k.take<float>((size_t)s.t2v_slabs * 2 * dt);
     {
-        const size_t need[2] = {hf ? immtsf_gemm3_tn_ws_bytes((int)d, (int)d, (int)BT) : 0, hf ? immtsf_gemm3_tn_ws_bytes((int)Ma, (int)dmc, (int)R) : 0};
+        const size_t need[2] = {hf ? immtsf_gemm3_tn_ws_bytes((int)d, (int)d, (int)BT) : 0,
+                                (hf && !pm) ? immtsf_gemm3_tn_ws_bytes((int)Ma, (int)dmc, (int)R) : 0};
         for (int i = 0; i < 2; ++i) {
             s.skb[i] = need[i];
             s.sk[i] = need[i] ? k.take<unsigned char>(need[i]) : nullptr;
@@ -330,8 +358,14 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
         CHECK(launch_vecjobs(l, s));
     }
     // ---- the data path
+    const bool pm = t2v_premix_on(cfg);
     CHECK(launch_t2v_scores(hf ? w.X.h : (const void*)w.X.f, hf ? 1 : 0, dmc, w.Wa.f + (size_t)Hd * dmc, dmc, H, total, R, w.S, s));
-    {
+    if (pm) {   // mix first (raw rows), then ONE B T-row product with W_tot
+        CHECK(launch_t2v_premix_weights(B, T, N, w.offsets, w.rowmap, w.S, w.P, w.At, w.wbar, drop, SITE_T2V_ATTN, s));
+        CHECK(launch_t2v_premix_fwd(B, T, dmc, w.offsets, w.X.h, w.At, w.xbar.h, s));
+        CHECK(fold_gemm(GEMM_NT, prec, BT, d, dmc, w.xbar, dmc, w.Wa, dmc, mat(w.xpre), d, nullptr, s));
+        CHECK(launch_t2v_premix_finish(BT, T, d, w.xpre, p->attn_out_b, w.cvec, w.wbar, p->Q_param, w.mtxt, s));
+    } else {
         GemmArgs g = gemm_args(R, Hd, dmc, dmc, dmc, Hd);
         set_problem2(g, 0, w.X, w.Wa, w.z, w.cvec);
         g.dyn = total; g.dyn_which = 0;
@@ -348,7 +382,10 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     // caller reads the bf16 image only (IMMTSF_FORM_HALF_OUT) -- or the operand of proj_out
     void* z_h = noproj ? (hf ? (cfg->out_h ? cfg->out_h : w.zln.h) : nullptr) : w.zln.h;
     float* z_f = noproj ? (((cfg->form & IMMTSF_FORM_HALF_OUT) && hf && cfg->out_h) ? nullptr : E_txt) : w.zln.f;
-    if (t2v_mix_wide_ok(d)) {
+    if (pm) {
+        const DropCfg nodrop = DropCfg{0, 0.f, 1.f, nullptr};
+        CHECK(launch_layernorm_fwd(w.xpre, BT, d, p->ln_w, p->ln_b, 1e-5f, xhat_f, w.rstd, z_f, drop, SITE_T2V_OUT, s, z_h, nullptr, nodrop, 0, xhat_h));
+    } else if (t2v_mix_wide_ok(d)) {
         CHECK(launch_t2v_mix_ln_fwd(dm, w.offsets, w.rowmap, w.S, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, p->attn_out_b, p->Q_param, w.P,
                                     p->ln_w, p->ln_b, 1e-5f, xhat_f, xhat_h, w.rstd, z_f, z_h, drop, SITE_T2V_ATTN, drop, SITE_T2V_OUT, s, w.keep));
     } else {
@@ -412,7 +449,8 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
     // compact: the forward stored x_hat as bf16 alone.  dx: as bf16 alone for the WIDE mix backward (8-byte loads; the narrow kernel's
     // two-byte loads made it slower on a bf16 dx -- 421 us instead of 291 at 4096 windows -- and keeps the fp32 one)
     const bool compact = hf && ln_sums_compact_ok(BT, d);
-    const bool dx_half = compact && t2v_mix_wide_ok(d) && t2v_mix_bwd_wide;
+    const bool pm = t2v_premix_on(cfg);
+    const bool dx_half = compact && t2v_mix_wide_ok(d) && t2v_mix_bwd_wide && !pm;
     float* dx_f = dx_half ? nullptr : sc.dx;
     void* dx_h = dx_half ? static_cast<void*>(sc.dx) : nullptr;
     const immtsf_lowrank_grad* lr = cfg->lr_grad;
@@ -420,7 +458,7 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         if (!noproj || !lr->coef || !lr->basis || lr->rank <= 0 || lr->ld < lr->rank || !compact) return IMMTSF_EINVAL;
         const int rc = launch_layernorm_bwd_lr(lr->coef, lr->ld, lr->rank, lr->basis, BT, d, p->ln_w, nullptr, w.xhat, w.rstd, dx_f, dx_h, drop,
                                                SITE_T2V_OUT, gr->ln_w, gr->ln_b, gr->Q_param, sc.red, w.mtxt, T, s,
-                                               t2v_mix_wide_ok(d) ? w.keep : nullptr, T);
+                                               (t2v_mix_wide_ok(d) && !pm) ? w.keep : nullptr, T);
         if (rc != IMMTSF_OK) return rc == IMMTSF_EUNSUPPORTED ? IMMTSF_EINVAL : rc;      // (immtsf_ttf_t2v_xattn_accepts_lowrank said otherwise)
     } else {   // LayerNorm backward + its parameter gradients + dQ_param = sum of dx over ALL rows; rows of windows without notes zeroed after
         const int rc = compact ? launch_layernorm_bwd_sums(dzln, BT, d, p->ln_w, nullptr, w.rstd, dx_f, drop, SITE_T2V_OUT, gr->ln_w, gr->ln_b,
@@ -436,6 +474,27 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         }
     }
     T2VFoldDims dm; dm.B = B; dm.T = T; dm.H = H; dm.d = d; dm.N = N; dm.dmc = dmc;
+    if (pm) {
+        // mix-first: everything with d in it on B T rows -- dc = dx^T wbar, dwbar = dx c, dxbar = dx W_tot, dW_tot = dx^T xbar -- then the
+        // per-note half (t2v_premix.hip): g, ds, the Time2Vec columns' gradient, du
+        {
+            VecJobList l;
+            l.add(VJ_MVT, sc.dx, d, w.wbar, nullptr, sc.dcv, BT, d);
+            l.add(VJ_MV, sc.dx, d, w.cvec, nullptr, sc.dwbar, BT, d);
+            CHECK(launch_vecjobs(l, s));
+        }
+        CHECK(launch_f32_to_bf16(sc.dx, sc.dxh, (size_t)BT * d, s));
+        const Mat dxm = mat(sc.dx, sc.dxh);
+        CHECK(fold_gemm(GEMM_NN, prec, BT, dmc, d, dxm, d, w.Wa, dmc, sc.dxbar, dmc, nullptr, s));
+        if (cfg->sched_flag) CHECK(immtsf_flag_set(cfg->sched_flag, s));
+        CHECK(fold_gemm(GEMM_TN, prec, d, dmc, BT, dxm, d, w.xbar, dmc, mat(sc.dWa.f), dmc, nullptr, s));
+        { const hipError_t e = hipMemsetAsync(sc.dWa.f + (size_t)Hd * dmc, 0, (size_t)8 * dmc * sizeof(float), s); if (e != hipSuccess) return (int)e; }
+        CHECK(launch_t2v_premix_bwd(B, T, N, dmc, d_m, w.offsets, total, w.X.h, w.At, w.P, sc.dxbar.h, sc.dwbar, w.Wa.f + (size_t)Hd * dmc, sc.g,
+                                    sc.ds, sc.dXt, sc.dWa.f + (size_t)Hd * dmc, sc.du_slab, s));
+        CHECK(launch_time2vec_bwd(tau, w.rowmap, total, R, dt, p->t2v_per_w, p->t2v_per_b, sc.dXt, dt, gr->t2v_lin_w, gr->t2v_lin_b, gr->t2v_per_w,
+                                  gr->t2v_per_b, sc.red_t2v, sc.t2v_slabs, s));
+        CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
+    } else {
     CHECK(launch_t2v_mix_bwd(dm, w.offsets, w.rowmap, w.P, hf ? w.z.h : (const void*)w.z.f, hf ? 1 : 0, dx_half ? dx_h : (const void*)sc.dx,
                              dx_half ? 1 : 0, hf ? sc.dza.h : (void*)sc.dza.f, sc.dbo_part, drop, SITE_T2V_ATTN, s));
     // (the row-bound kernels of the block are behind us: see the header.  Measured at 4096 windows: no hint 4.75 ms, here 4.63, in front
@@ -458,14 +517,18 @@ int t2v_fold_backward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, 
         wg[nwg++] = h;
     }
     CHECK(immtsf_launch_gemm_tn_list(prec, wg, nwg, s));
+    }
     // ---- chain rule through the fold (parameters only): vector jobs, two products, vector jobs, 2 H + 2 products, one last launch
     {
         VecJobList l;
         for (int h = 0; h < H; ++h) l.add(VJ_MVT, p->attn_out_w + h * hd, d, sc.dcv + h * d, nullptr, sc.dbvec2 + h * hd, d, hd);
         // d b_o = sum over the windows: as a job of this launch for a few hundred windows; beyond that the job's 12 workgroups walked
         // thousands of rows each (92 us at 4096 windows, the longest launch of the parameter chain) -- the slabbed column sum instead
-        if (B < 512) l.add(VJ_MVT, sc.dbo_part, d, nullptr, nullptr, gr->attn_out_b, B, d);
-        else CHECK(launch_colsum(sc.dbo_part, nullptr, B, nullptr, d, d, gr->attn_out_b, 0, sc.red_bo, s, true));
+        // (mix-first: straight from dx, whose rows of windows without notes are zero)
+        const float* bo_src = pm ? sc.dx : sc.dbo_part;
+        const int bo_rows = pm ? BT : B;
+        if (bo_rows < 512) l.add(VJ_MVT, bo_src, d, nullptr, nullptr, gr->attn_out_b, bo_rows, d);
+        else CHECK(launch_colsum(bo_src, nullptr, bo_rows, nullptr, d, d, gr->attn_out_b, 0, sc.red_bo, s, true));
         if (hf) {
             VecJob& c = l.add(VJ_COPY, sc.dWa.f, dmc, nullptr, nullptr, nullptr, Ma, dmc);      // bf16 image of dW_aug for the two products
             c.yh = sc.dWa.h; c.ldy = dmc;

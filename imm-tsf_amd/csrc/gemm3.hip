@@ -85,7 +85,7 @@ struct G3Args {
                               // an XCD's share of a round -- are the tiles of ONE K-range and find each other's A / B panels in L2)
     float* slab_b;            // split mode, bias gradient requested: [items][BM] partial column sums of A (tiles of column 0 only)
     int splits;               // split mode: K-ranges per tile
-    unsigned s_magic;         // id / tiles as __umulhi(id, magic) (split mode)
+    unsigned s_magic;         // id / tiles as __umulhi(id, magic) (split mode); 0: one tile
     int tiles_total;          // split mode: tiles (items = tiles_total * splits)
     int row_flag_div;
     unsigned rf_magic;        // floor(2^32 / row_flag_div) (0: div == 1): m / div = __umulhi(m, magic) (+1 after one check)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         c.kt = 0;
         const bool ok = id < nt;
         const int idc = ok ? id : 0;
-        const int split = SPLIT ? (int)__umulhi((unsigned)idc, g.s_magic) : 0;
+        const int split = SPLIT ? (g.s_magic ? (int)__umulhi((unsigned)idc, g.s_magic) : idc) : 0;      // (magic 0: one tile, id / 1)
         const int tile = SPLIT ? idc - split * g.tiles_total : idc;
         const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
         const int tn = tile - tm * tiles_n;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const G3Args g) {
         const bool pstore = kt == 1 && have_prev;
         if (first) {
             if (SPLIT) {        // store coordinates = the item's slab rows; the tile's column decides who sums A's columns
-                const int tile = id - (int)__umulhi((unsigned)id, g.s_magic) * g.tiles_total;
+                const int tile = g.s_magic ? id - (int)__umulhi((unsigned)id, g.s_magic) * g.tiles_total : 0;
                 const int tm = g.tn_magic ? (int)__umulhi((unsigned)tile, g.tn_magic) : tile;
                 row0 = id * BM;
                 col0 = 0;
@@ -799,7 +799,8 @@ int immtsf_launch_gemm3_tn(const void* A, int lda, const void* B, int ldb, float
     g.tn_magic = g.tiles_n <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_n - 1) / (unsigned)g.tiles_n);
     g.splits = S;
     g.tiles_total = cdiv(M, 256) * g.tiles_n;
-    g.s_magic = (unsigned)((0x100000000ull + (unsigned)g.tiles_total - 1) / (unsigned)g.tiles_total);
+    // (one tile: 2^32 / 1 does not fit the magic -- 0 there, the kernel takes id / 1 = id)
+    g.s_magic = g.tiles_total <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)g.tiles_total - 1) / (unsigned)g.tiles_total);
     g.dynk = dynk;
     const long items = (long)cdiv(M, 256) * g.tiles_n * S;
     g.slab = static_cast<float*>(ws);

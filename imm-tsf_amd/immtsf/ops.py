@@ -238,7 +238,7 @@ class TTFT2VXAttnFn(torch.autograd.Function):
         d_m = notes.shape[-1]
         d = params[0].numel()
         cfg = make_cfg(B, N, T, 0, d_m, d, H, precision, training, p_drop, 0.0, seed, notes.device)
-        cfg.form = {"auto": 0, "chain": 1, "fold": 2}[config.t2v_form]        # (the backward reads the same cfg: one form per call pair)
+        cfg.form = {"auto": 0, "chain": 1, "fold": 2, "mix": 3}[config.t2v_form]        # (the backward reads the same cfg: one form per call pair)
         if no_proj:             # proj_out is left to the consumer (MMFXRankPFn's "_z" form): the output is Z, the LayerNorm + dropout result
             cfg.form |= _lib.FORM_NO_PROJ
         ctx.no_proj = bool(no_proj)

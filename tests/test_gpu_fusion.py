@@ -912,6 +912,71 @@ def test_t2v_folded_form_equals_the_chain_as_written(B, N, T, d_m, d, H, pd, pac
         assert err <= tol, (k, err)
 
 
+@pytest.mark.parametrize("B,N,T,d_m,d,pd,packed", [(5, 100, 7, 48, 32, 0.0, False), (4, 300, 32, 96, 64, 0.2, False), (3, 517, 13, 64, 64, 0.3, True),
+                                                    (6, 32, 32, 768, 768, 0.1, True), (3, 1100, 32, 4096, 128, 0.1, False),
+                                                    (7, 70, 32, 80, None, 0.15, False), (2, 4096, 32, 256, 64, 0.1, True)])
+def test_t2v_mix_first_form_equals_the_chain_as_written(B, N, T, d_m, d, pd, packed):
+    """TTF_T2V_XAttn's MIX-FIRST form for long windows (csrc/t2v_premix.hip: softmax weights as a bf16 matrix, the window's raw rows
+    [embedding ; Time2Vec] mixed per forecast step on the MFMA, ONE B T-row product with the folded W_tot; backward: the weights'
+    gradient as note x step products against dx W_tot, the score vector's gradient as one pass over the notes) against the reference's
+    GEMM chain as written (config.t2v_form = "chain"), bf16 mode, same Philox sites and indices (so also under dropout): E_txt, M_txt,
+    every parameter gradient; padded and packed notes, with and without an input projection, a window without notes, windows of one
+    note and of N notes.  reference: fusions/TTF_T2V_XAttn.py:120-182."""
+    dev = _dev()
+    import ctypes as C
+    from fusions.TTF_T2V_XAttn import TTF_T2V_XAttn
+    from fusions.load_llm import register_d_model
+    from immtsf import _lib, config
+    from immtsf.ops import PackedNotes, make_cfg
+    register_d_model(f"FOLD{d_m}", d_m)
+    config.precision = "bf16"
+    torch.manual_seed(B * 100 + N)
+    ttf = TTF_T2V_XAttn(f"FOLD{d_m}", 6, n_heads_fusion=1, dropout=pd, d_txt=d).to(dev).train()
+    dd = ttf.d_txt
+    with torch.no_grad():
+        for p_ in ttf.parameters():
+            if p_.dim() == 1:
+                p_.add_(0.1 * torch.randn_like(p_))
+    g = torch.Generator().manual_seed(B + 17 * T)
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    lengths[0] = N
+    if B > 2:
+        lengths[1] = 0            # a window without notes
+        lengths[2] = 1
+    keep = torch.arange(N).view(1, -1) < lengths.view(-1, 1)
+    notes = (torch.randn(B, N, d_m, generator=g) * keep.unsqueeze(-1)).to(dev)
+    tau = (torch.sort(torch.rand(B, N, generator=g) * 24.0, dim=1).values * keep).to(dev)
+    t_hat = torch.rand(B, T, generator=g).to(dev)
+    up = torch.randn(B, T, dd, generator=g).to(dev)
+    src = notes
+    if packed:
+        rows = torch.arange(B * N, device=dev, dtype=torch.int32).view(B, N)[keep.to(dev)].contiguous()
+        src = PackedNotes(notes.reshape(B * N, d_m).contiguous(), rows, lengths.to(dev).to(torch.int32), N)
+    cfg = make_cfg(B, N, T, 0, d_m, dd, 1, 1, True, pd, 0.0, 0, None)
+    cfg.form = 3
+    assert _lib.load().immtsf_ttf_t2v_xattn_folded(C.byref(cfg)) == 1
+    res, seed0 = [], config.next_seed
+    try:
+        config.next_seed = lambda: 9191
+        for form in ("mix", "chain"):
+            config.t2v_form = form
+            ttf.zero_grad()
+            E, M = ttf(src, tau, t_hat)
+            (E * up).sum().backward()
+            res.append([("E", E.detach()), ("M", M.float())] + [(k, p_.grad.clone()) for k, p_ in ttf.named_parameters()])
+    finally:
+        config.next_seed, config.t2v_form, config.precision = seed0, "auto", "fp32"
+    gmax = max(float(b.abs().max()) for k, b in res[1][2:])
+    for (k, a), (_, b) in zip(*res):
+        assert torch.isfinite(a).all(), k
+        if k == "M":
+            assert torch.equal(a, b)
+            continue
+        den = float(b.norm()) + (1e-3 * gmax * b.numel() ** 0.5 if k != "E" else 1e-6) + 1e-30
+        err = float((a - b).norm()) / den
+        assert err <= 4e-2, (k, err)
+
+
 @pytest.mark.parametrize("form", ["fold", "chain"])
 def test_prebuilt_note_index_equals_the_derived_one(form):
     """PackedNotes.index() (immtsf_note_index_build: the batch's ragged index built once, by whoever builds the batch) is, array by array

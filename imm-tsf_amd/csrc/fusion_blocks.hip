@@ -162,7 +162,7 @@ struct T2VFoldWs {
     float *S, *P, *q, *qs, *xpre, *xhat, *rstd;
     unsigned long long* keep;      // the output dropout's keep bits (the wide mix + LayerNorm kernel writes, the low-rank LayerNorm backward reads)
     void* At;                 // mix-first: [R, 32] bf16, the dropped attention weights of (note, step)
-    float* wbar;              // mix-first: [BT] their sums
+    float *wbar, *wpart;      // mix-first: [BT] their sums; [B, chunks, 32] the sums per chunk of notes
     Mat xbar;                 // mix-first: [BT, dmc] bf16, the mix of the raw rows
     Mat OVa;                  // [H d + 8, d]: W_o[:, h] W_v[h, :] per head, then G_h = (scale q_h)^T W_k,h, then zero rows
     Mat Ab;                   // [d, dmc] = [W_KV[:, :d] W_in | W_KV[:, d:]] (with an input projection; else W_KV itself)
@@ -197,6 +197,7 @@ T2VFoldWs carve_t2v_fold(const immtsf_fusion_cfg* c, void* base) {
     w.keep = wide ? k.take<unsigned long long>(B * 2 * 256) : nullptr;
     w.At = pm ? k.take<unsigned short>(R * 32) : nullptr;
     w.wbar = pm ? k.take<float>(BT) : nullptr;
+    w.wpart = pm ? k.take<float>(B * (size_t)t2v_premix_chunks((int)N) * 32) : nullptr;
     w.xbar = pm ? k.take_mat(BT * dmc, false, true) : Mat{nullptr, nullptr};
     w.zln = k.take_mat(BT * d, !hf, hf);
     w.OVa = k.take_mat(Ma * d, true, hf);
@@ -309,10 +310,19 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
     const float scale = sqrtf(1.0f / (float)hd);
     // X = [V ; Time2Vec(tau)] on the packed rows; in the same launch the two parameter-only mat-vecs the fold starts from: the learned
     // query's in-projection and bvec1 = W_KV[:, :d] b_in + b_KV
-    if (hf) {
+    const bool pm = t2v_premix_on(cfg);
+    if (hf && !pm) {
         CHECK(launch_notes_stage(notes, d_m, gather, total, R, d_m, w.X.h, dmc, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w,
                                  p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, p->attn_in_w, d, p->Q_param, p->attn_in_b, d, d, w.q, w.qs, scale, s,
                                  inp ? p->kv_w : nullptr, dcat, p->input_proj_b, p->kv_b, d, d, w.bvec1));
+    } else if (pm) {
+        // mix-first: the notes are staged BEHIND the fold, with the score u . x fused into the staging pass (one read of X less); the two
+        // mat-vecs the fold starts from go first
+        VecJobList l;
+        VecJob& q = l.add(VJ_MV, p->attn_in_w, d, p->Q_param, p->attn_in_b, w.qs, d, d);
+        q.scale = scale;
+        if (inp) l.add(VJ_MV, p->kv_w, dcat, p->input_proj_b, p->kv_b, w.bvec1, d, d);
+        CHECK(launch_vecjobs(l, s));
     } else {
         CHECK(launch_gather_rows(notes, d_m, gather, total, R, d_m, w.X.f, dmc, s, nullptr));
         CHECK(launch_time2vec_fwd(tau, w.rowmap, total, R, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w, p->t2v_per_b, w.X.f + d_m, dmc, s, nullptr));
@@ -358,14 +368,23 @@ int t2v_fold_forward(const immtsf_fusion_cfg* cfg, const immtsf_t2v_params* p, c
         CHECK(launch_vecjobs(l, s));
     }
     // ---- the data path
-    const bool pm = t2v_premix_on(cfg);
-    CHECK(launch_t2v_scores(hf ? w.X.h : (const void*)w.X.f, hf ? 1 : 0, dmc, w.Wa.f + (size_t)Hd * dmc, dmc, H, total, R, w.S, s));
     if (pm) {   // mix first (raw rows), then ONE B T-row product with W_tot
-        CHECK(launch_t2v_premix_weights(B, T, N, w.offsets, w.rowmap, w.S, w.P, w.At, w.wbar, drop, SITE_T2V_ATTN, s));
+        const int rc = launch_notes_stage(notes, d_m, gather, total, R, d_m, w.X.h, dmc, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w,
+                                          p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 1.f, s,
+                                          nullptr, 0, nullptr, nullptr, 0, 0, nullptr, w.Wa.f + (size_t)Hd * dmc, w.S);
+        if (rc == IMMTSF_EUNSUPPORTED) {   // (rows that are not 16-byte aligned: staging and score as two passes)
+            CHECK(launch_notes_stage(notes, d_m, gather, total, R, d_m, w.X.h, dmc, tau, w.rowmap, dt, p->t2v_lin_w, p->t2v_lin_b, p->t2v_per_w,
+                                     p->t2v_per_b, nullptr, dmc, mat_off(w.X, d_m).h, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, 1.f, s));
+            CHECK(launch_t2v_scores(w.X.h, 1, dmc, w.Wa.f + (size_t)Hd * dmc, dmc, H, total, R, w.S, s));
+        } else {
+            CHECK(rc);
+        }
+        CHECK(launch_t2v_premix_weights(B, T, N, w.offsets, w.rowmap, w.S, w.P, w.At, w.wpart, drop, SITE_T2V_ATTN, s));
         CHECK(launch_t2v_premix_fwd(B, T, dmc, w.offsets, w.X.h, w.At, w.xbar.h, s));
         CHECK(fold_gemm(GEMM_NT, prec, BT, d, dmc, w.xbar, dmc, w.Wa, dmc, mat(w.xpre), d, nullptr, s));
-        CHECK(launch_t2v_premix_finish(BT, T, d, w.xpre, p->attn_out_b, w.cvec, w.wbar, p->Q_param, w.mtxt, s));
+        CHECK(launch_t2v_premix_finish(BT, T, N, d, w.xpre, p->attn_out_b, w.cvec, w.wpart, w.wbar, p->Q_param, w.mtxt, s));
     } else {
+        CHECK(launch_t2v_scores(hf ? w.X.h : (const void*)w.X.f, hf ? 1 : 0, dmc, w.Wa.f + (size_t)Hd * dmc, dmc, H, total, R, w.S, s));
         GemmArgs g = gemm_args(R, Hd, dmc, dmc, dmc, Hd);
         set_problem2(g, 0, w.X, w.Wa, w.z, w.cvec);
         g.dyn = total; g.dyn_which = 0;

@@ -1245,7 +1245,8 @@ __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ W
 // Three independent row jobs at the head of TTF_T2V_XAttn's forward -- pack + cast the notes, Time2Vec of their time stamps, the
 // learned query's in-projection (parameters only) -- as ONE launch: workgroups [0, na) gather, [na, na + nb) Time2Vec, the rest
 // the mat-vec.  (Each was a launch of its own on the text side's forward chain; a dependent launch costs ~5 us whatever it does.)
-struct GatherJob { const float* src; int ld_src; const int* rowmap; const int* total; int width; float* dst; int ld_dst; bf16_t* dst_h; int vec; };
+struct GatherJob { const float* src; int ld_src; const int* rowmap; const int* total; int width; float* dst; int ld_dst; bf16_t* dst_h; int vec;
+                   const float* score_u; float* score_out; };      // vec == 2, optional: score_out[r] = (the bf16 row | its Time2Vec columns) . score_u
 struct T2VJob { const float* tau_pad; const int* rowmap; const int* total; int d_tau; const float *w0, *b0, *w, *b; float* dst; int ld_dst, max_rows; bf16_t* dst_h; };
 struct MatvecJob { const float* W; int ldw; const float *x, *b; int rows, cols; float *y, *ys; float scale; };
 // a packed row per WAVE (vec == 2: 16-byte-aligned rows, bf16 destination): the row's gather + cast with up to four 16-byte loads per
@@ -1258,6 +1259,8 @@ __device__ __forceinline__ void notes_row_wave_body(int r, const GatherJob& a, c
     bf16x4* d4 = reinterpret_cast<bf16x4*>(a.dst_h + (size_t)r * a.ld_dst);
     const float tv = t.tau_pad[t.rowmap ? t.rowmap[r] : r];
     const int n4 = a.width >> 2;
+    const float4* u4 = reinterpret_cast<const float4*>(a.score_u);
+    float dot = 0.f;
     for (int i0 = lane; i0 < n4; i0 += 256) {
         float4 v[4];
 #pragma unroll
@@ -1272,6 +1275,10 @@ __device__ __forceinline__ void notes_row_wave_body(int r, const GatherJob& a, c
                 bf16x4 h;
                 h[0] = (bf16_t)v[u].x; h[1] = (bf16_t)v[u].y; h[2] = (bf16_t)v[u].z; h[3] = (bf16_t)v[u].w;
                 d4[i] = h;
+                if (u4) {       // the score reads the values the other passes will read: the bf16 image
+                    const float4 w = u4[i];
+                    dot = fmaf((float)h[0], w.x, dot); dot = fmaf((float)h[1], w.y, dot); dot = fmaf((float)h[2], w.z, dot); dot = fmaf((float)h[3], w.w, dot);
+                }
             }
         }
     }
@@ -1279,6 +1286,11 @@ __device__ __forceinline__ void notes_row_wave_body(int r, const GatherJob& a, c
         const float v = (j == 0) ? fmaf(t.w0[0], tv, t.b0[0]) : sinf(fmaf(t.w[j - 1], tv, t.b[j - 1]));
         if (t.dst) t.dst[(size_t)r * t.ld_dst + j] = v;
         if (t.dst_h) t.dst_h[(size_t)r * t.ld_dst + j] = (bf16_t)v;
+        if (a.score_u) dot = fmaf((float)(bf16_t)v, a.score_u[a.width + j], dot);
+    }
+    if (a.score_u) {
+        dot = wave_sum(dot);
+        if (lane == 0) a.score_out[r] = dot;
     }
 }
 __global__ __launch_bounds__(256) void notes_stage_kernel(GatherJob a, int na, T2VJob t, int nb, MatvecJob m, int nc, MatvecJob m2) {
@@ -1458,12 +1470,15 @@ int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int*
                        const float* tau_pad, const int* rowmap, int d_tau, const float* w0, const float* b0, const float* w, const float* b,
                        float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
                        float* y, float* ys, float scale, hipStream_t s, const float* W2, int ldw2, const float* x2, const float* bias2, int rows2,
-                       int cols2, float* y2) {
+                       int cols2, float* y2, const float* score_u, float* score_out) {
     if (max_rows <= 0) return IMMTSF_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst_h);
     int vec = ((width | ld_src | ld_dst) & 3) == 0 && (al & 15) == 0;
     if (vec && dst_h && gmap && total) vec = 2;          // a packed row per wave, gather + Time2Vec together
-    const GatherJob a{src, ld_src, gmap, total, width, nullptr, ld_dst, static_cast<bf16_t*>(dst_h), vec};
+    // the fused score rides on the row-per-wave form only, with the Time2Vec columns right behind the row (one vector u for both)
+    if (score_u && (vec != 2 || !score_out || (reinterpret_cast<uintptr_t>(score_u) & 15) || t_dst_h != static_cast<bf16_t*>(dst_h) + width || t_ld != ld_dst))
+        return IMMTSF_EUNSUPPORTED;
+    const GatherJob a{src, ld_src, gmap, total, width, nullptr, ld_dst, static_cast<bf16_t*>(dst_h), vec, score_u, score_out};
     const T2VJob t{tau_pad, rowmap, total, d_tau, w0, b0, w, b, t_dst, t_ld, max_rows, static_cast<bf16_t*>(t_dst_h)};
     const MatvecJob m{W, ldw, x, bias, rows, cols, y, ys, scale};
     const MatvecJob m2{W2, ldw2, x2, bias2, W2 ? rows2 : 0, cols2, y2, nullptr, 1.f};

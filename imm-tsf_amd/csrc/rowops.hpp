@@ -25,7 +25,8 @@ int launch_notes_stage(const float* src, int ld_src, const int* gmap, const int*
                        float* t_dst, int t_ld, void* t_dst_h, const float* W, int ldw, const float* x, const float* bias, int rows, int cols,
                        float* y, float* ys, float scale, hipStream_t s,
                        const float* W2 = nullptr, int ldw2 = 0, const float* x2 = nullptr, const float* bias2 = nullptr, int rows2 = 0,
-                       int cols2 = 0, float* y2 = nullptr);      // (W2 ...: an optional second mat-vec y2 = W2 x2 + bias2 in the same launch)
+                       int cols2 = 0, float* y2 = nullptr,
+                       const float* score_u = nullptr, float* score_out = nullptr);      // (W2 ...: an optional second mat-vec y2 = W2 x2 + bias2 in the same launch)
 int launch_query_t2v_bwd(const float* dqs_part, int B, int d, float scale, const float* Wq, int ldw, const float* Q, float* dWq, int ldg,
                          float* dbq, float* dQ, const float* tau_pad, const int* rowmap, const int* total, int max_rows, int d_tau,
                          const float* w, const float* b, const float* dfeat, int ld, float* dw0, float* db0, float* dw, float* db,

@@ -67,12 +67,14 @@ int launch_t2v_mix_bwd(T2VFoldDims dm, const int* offsets, const int* rowmap, co
 // weights of (note, step); xbar (B T, dmc) bf16 = the mix of the raw rows; wbar (B T) = the weights' sums
 bool t2v_premix_shape_ok(int T, int d, int H, int d_m);
 size_t t2v_premix_du_scratch_floats(int dmc);
-int launch_t2v_premix_weights(int B, int T, int N, const int* offsets, const int* rowmap, const float* S, float* P, void* At, float* wbar,
+int t2v_premix_chunks(int N);      // note chunks of the weights kernel: wpart is (B, chunks, 32) floats
+int launch_t2v_premix_weights(int B, int T, int N, const int* offsets, const int* rowmap, const float* S, float* P, void* At, float* wpart,
                               DropCfg drop, uint64_t site, hipStream_t s);
 int launch_t2v_premix_fwd(int B, int T, int dmc, const int* offsets, const void* X, const void* At, void* xbar, hipStream_t s);
-// x_pre (in place on the B T x d product x_bar W_tot^T): + b_o + c wbar + the residual query; windows without notes: the query alone
-int launch_t2v_premix_finish(int BT, int T, int d, float* xpre, const float* b_o, const float* cvec, const float* wbar, const float* q_res,
-                             const unsigned char* mtxt, hipStream_t s);
+// x_pre (in place on the B T x d product x_bar W_tot^T): + b_o + c wbar + the residual query; windows without notes: the query alone;
+// wbar (B T) = the chunks of wpart added up, written
+int launch_t2v_premix_finish(int BT, int T, int N, int d, float* xpre, const float* b_o, const float* cvec, const float* wpart, float* wbar,
+                             const float* q_res, const unsigned char* mtxt, hipStream_t s);
 // from dxbar (B T, dmc) bf16 and dwbar (B T): g, ds (R), dXt (R, dmc - d_m) and du (dmc) -- four launches
 int launch_t2v_premix_bwd(int B, int T, int N, int dmc, int d_m, const int* offsets, const int* total, const void* X, const void* At,
                           const float* P, const void* dxbar, const float* dwbar, const float* u, float* g, float* ds, float* dXt, float* du,

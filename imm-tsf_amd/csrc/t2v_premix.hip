@@ -37,17 +37,19 @@ __device__ __forceinline__ bf16x8 pm_zero8() {
 }
 
 // ------------------------------------------------------------------------------------------------ weights
-// grid (B), 256 threads: softmax over the window's scores (P written), the dropped weights of every (step, note) as bf16 rows of At
-// (steps past T: 0), wbar[b, t] = the sum of those bf16 values
+// grid (B, ceil(N / 256)), 256 threads, a note per thread: softmax over the window's scores (every workgroup of the window derives the
+// same maximum and sum from the whole score row; P written), the dropped weights of every (step, note) as bf16 rows of At (steps past T:
+// 0), and the chunk's share of wbar[b, t] = the sum of those bf16 values (wpart (B, chunks, 32); premix_finish adds the chunks up)
 __global__ __launch_bounds__(256) void premix_weights_kernel(int T, int N, const int* __restrict__ offsets, const int* __restrict__ rowmap,
                                                               const float* __restrict__ S, float* __restrict__ P, bf16_t* __restrict__ At,
-                                                              float* __restrict__ wbar, DropCfg drop, uint64_t site) {
+                                                              float* __restrict__ wpart, DropCfg drop, uint64_t site) {
     __shared__ float red[16];
     __shared__ float wsum[4][PT];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ob = offsets[b], n = offsets[b + 1] - ob;
-    if (n == 0) {
-        if (tid < T) wbar[b * T + tid] = 0.f;
+    float* wp = wpart + ((size_t)b * gridDim.y + ch) * PT;
+    if (ch * 256 >= n) {
+        if (tid < PT) wp[tid] = 0.f;
         return;
     }
     float m = -INFINITY;
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(256) void premix_weights_kernel(int T, int N, const
     float wl[PT];
 #pragma unroll
     for (int t = 0; t < PT; ++t) wl[t] = 0.f;
-    for (int i = tid; i < n; i += 256) {
+    const int i = ch * 256 + tid;
+    if (i < n) {
         const float p = expf(S[ob + i] - m) * inv;
         P[ob + i] = p;
         const int n_orig = rowmap[ob + i] - b * N;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void premix_weights_kernel(int T, int N, const
             }
             const bf16_t h = (bf16_t)v;
             a[t >> 3][t & 7] = h;
-            wl[t] += (float)h;
+            wl[t] = (float)h;
         }
         bf16x8* dst = reinterpret_cast<bf16x8*>(At + (size_t)(ob + i) * PT);
 #pragma unroll
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void premix_weights_kernel(int T, int N, const
         if (lane == 0) wsum[wave][t] = v;
     }
     __syncthreads();
-    if (tid < T) wbar[b * T + tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+    if (tid < PT) wp[tid] = (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
 }
 
 // ------------------------------------------------------------------------------------------------ mix, forward
@@ -161,15 +164,18 @@ __global__ __launch_bounds__(256) void premix_fwd_kernel(int T, int dmc, const i
         }
 }
 
-// x_pre[r, :] = window has notes ? acc[r, :] + b_o + c wbar[r] + q : q        (in place on the product's output)
-__global__ __launch_bounds__(256) void premix_finish_kernel(int BT, int T, int d, float* __restrict__ xpre, const float* __restrict__ b_o,
-                                                             const float* __restrict__ cvec, const float* __restrict__ wbar,
+// x_pre[r, :] = window has notes ? acc[r, :] + b_o + c wbar[r] + q : q   (in place on the product's output); wbar[r] = the chunks' sum, written
+__global__ __launch_bounds__(256) void premix_finish_kernel(int BT, int T, int d, int chunks, float* __restrict__ xpre, const float* __restrict__ b_o,
+                                                             const float* __restrict__ cvec, const float* __restrict__ wpart, float* __restrict__ wbar,
                                                              const float* __restrict__ q_res, const unsigned char* __restrict__ mtxt) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (size_t)BT * d) return;
-    const int r = (int)(idx / d), j = (int)(idx - (size_t)r * d);
+    const int r = (int)(idx / d), j = (int)(idx - (size_t)r * d), b = r / T, t = r - b * T;
+    float w = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) w += wpart[((size_t)b * chunks + ch) * PT + t];
+    if (j == 0) wbar[r] = w;
     const float q = q_res[j];
-    xpre[idx] = mtxt[r / T] ? xpre[idx] + b_o[j] + cvec[j] * wbar[r] + q : q;
+    xpre[idx] = mtxt[b] ? xpre[idx] + b_o[j] + cvec[j] * w + q : q;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -242,24 +248,24 @@ __global__ __launch_bounds__(256) void premix_bwd_da_kernel(int T, int dmc, cons
 }
 
 // grid (B, ceil(N / 64)), 256 threads: ds[note] = g[note] - P[note] sum_m g[m] (written), and the Time2Vec columns' gradient
-// dXt[note, c] = sum_t At[note, t] dxbar[b, t, d_m + c] + ds[note] u[d_m + c]  (c < dt <= 512: two columns per thread)
-__global__ __launch_bounds__(256) void premix_bwd_ds_kernel(int T, int dmc, int d_m, int dt, const int* __restrict__ offsets,
+// dXt[note, c] = sum_t At[note, t] dxbar[b, t, d_m + c] + ds[note] u[d_m + c]: a 64 x dt x 32 product per workgroup -- ONE k-step: the
+// weights' fragment straight from memory, dxbar's Time2Vec columns as a [t][column] LDS image read transposed; a wave = 16 notes, every
+// column tile.  LDS: 32 x (dtp + 8) bf16 (dtp = dt rounded up to 16).
+__global__ __launch_bounds__(256) void premix_bwd_ds_kernel(int T, int dmc, int d_m, int dt, int dtp, const int* __restrict__ offsets,
                                                              const bf16_t* __restrict__ At, const float* __restrict__ P,
                                                              const float* __restrict__ g, const bf16_t* __restrict__ dxbar,
                                                              const float* __restrict__ u, float* __restrict__ ds, float* __restrict__ dXt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pm_smem[];
     __shared__ float red[16];
-    __shared__ __attribute__((aligned(16))) float at_s[PSB][PT];
     __shared__ float ds_s[PSB];
-    const int b = blockIdx.x, i0 = blockIdx.y * PSB, tid = threadIdx.x;
+    bf16_t* imD = reinterpret_cast<bf16_t*>(pm_smem);
+    const int pD = dtp + 8;
+    const int b = blockIdx.x, i0 = blockIdx.y * PSB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
     const int ob = offsets[b], n = offsets[b + 1] - ob;
     if (i0 >= n) return;
     float G = 0.f;
     for (int i = tid; i < n; i += 256) G += g[ob + i];
     G = block_sum(G, red);
-    for (int x = tid; x < PSB * PT; x += 256) {
-        const int row = x >> 5, t = x & 31;
-        at_s[row][t] = i0 + row < n ? (float)At[(size_t)(ob + i0 + row) * PT + t] : 0.f;
-    }
     if (tid < PSB) {
         const int note = i0 + tid;
         float v = 0.f;
@@ -269,21 +275,27 @@ __global__ __launch_bounds__(256) void premix_bwd_ds_kernel(int T, int dmc, int 
         }
         ds_s[tid] = v;
     }
+    const int p8 = dtp >> 3;
+    for (int x = tid; x < PT * p8; x += 256) {
+        const int t = x / p8, c = (x - t * p8) * 8;
+        bf16x8 v = pm_zero8();
+        if (t < T && c < dt) v = *reinterpret_cast<const bf16x8*>(dxbar + (size_t)(b * T + t) * dmc + d_m + c);       // (dt % 8 == 0)
+        *reinterpret_cast<bf16x8*>(imD + t * pD + c) = v;
+    }
+    const int note_a = i0 + wave * 16 + fr;
+    bf16x8 a = pm_zero8();
+    if (note_a < n) a = *reinterpret_cast<const bf16x8*>(At + (size_t)(ob + note_a) * PT + fq * 8);
     __syncthreads();
-    const int cnt = min(PSB, n - i0);
-    for (int c = tid; c < dt; c += 256) {
-        float dxr[PT];
+    for (int ct = 0; ct < (dtp >> 4); ++ct) {
+        const bf16x8 bb = pm_frag_kmajor(imD, pD, ct * 16, 0, fr, fq);
+        const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const int col = ct * 16 + fr;
+        if (col >= dt) continue;
+        const float uc = u[d_m + col];
 #pragma unroll
-        for (int t = 0; t < PT; ++t) dxr[t] = t < T ? (float)dxbar[(size_t)(b * T + t) * dmc + d_m + c] : 0.f;
-        const float uc = u[d_m + c];
-        for (int r = 0; r < cnt; ++r) {
-            float v = ds_s[r] * uc;
-#pragma unroll
-            for (int t = 0; t < PT; t += 4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(&at_s[r][t]);
-                v = fmaf(a4.x, dxr[t], v); v = fmaf(a4.y, dxr[t + 1], v); v = fmaf(a4.z, dxr[t + 2], v); v = fmaf(a4.w, dxr[t + 3], v);
-            }
-            dXt[(size_t)(ob + i0 + r) * dt + c] = v;
+        for (int e = 0; e < 4; ++e) {       // D[note = 16 wave + 4 fq + e][column = 16 ct + fr]
+            const int rl = wave * 16 + fq * 4 + e;
+            if (i0 + rl < n) dXt[(size_t)(ob + i0 + rl) * dt + col] = acc[e] + ds_s[rl] * uc;
         }
     }
 }
@@ -320,15 +332,22 @@ __global__ __launch_bounds__(256) void premix_du_kernel(int dmc, const int* __re
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = acc[e];
 }
-__global__ __launch_bounds__(256) void premix_du_reduce_kernel(int dmc, int nrb, const float* __restrict__ slab, float* __restrict__ du) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void premix_du_reduce_kernel(int dmc, int nrb, const float* __restrict__ slab, float* __restrict__ du) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= dmc) return;
-    float s = 0.f;
-    for (int b = 0; b < nrb; ++b) s += slab[(size_t)b * dmc + c];
-    du[c] = s;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    int b = 0;
+    for (; b + 8 <= nrb; b += 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += slab[(size_t)(b + e) * dmc + c];
+    }
+    for (; b < nrb; ++b) s[0] += slab[(size_t)b * dmc + c];
+    du[c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
-constexpr int PM_DU_BLOCKS = 512;
+constexpr int PM_DU_BLOCKS = 128;      // row blocks of the score vector's gradient (x ceil(dmc / 2048) column groups of workgroups)
 
 }  // namespace
 
@@ -337,10 +356,12 @@ bool t2v_premix_shape_ok(int T, int d, int H, int d_m) {
 }
 size_t t2v_premix_du_scratch_floats(int dmc) { return (size_t)PM_DU_BLOCKS * dmc; }
 
-int launch_t2v_premix_weights(int B, int T, int N, const int* offsets, const int* rowmap, const float* S, float* P, void* At, float* wbar,
+int t2v_premix_chunks(int N) { return cdiv(N, 256); }
+int launch_t2v_premix_weights(int B, int T, int N, const int* offsets, const int* rowmap, const float* S, float* P, void* At, float* wpart,
                               DropCfg drop, uint64_t site, hipStream_t s) {
     if (T > PT) return IMMTSF_EUNSUPPORTED;
-    hipLaunchKernelGGL(premix_weights_kernel, dim3(B), dim3(256), 0, s, T, N, offsets, rowmap, S, P, static_cast<bf16_t*>(At), wbar, drop, site);
+    hipLaunchKernelGGL(premix_weights_kernel, dim3(B, cdiv(N, 256)), dim3(256), 0, s, T, N, offsets, rowmap, S, P, static_cast<bf16_t*>(At), wpart, drop,
+                       site);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -352,9 +373,10 @@ int launch_t2v_premix_fwd(int B, int T, int dmc, const int* offsets, const void*
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
-int launch_t2v_premix_finish(int BT, int T, int d, float* xpre, const float* b_o, const float* cvec, const float* wbar, const float* q_res,
-                             const unsigned char* mtxt, hipStream_t s) {
-    hipLaunchKernelGGL(premix_finish_kernel, dim3((unsigned)(((size_t)BT * d + 255) / 256)), dim3(256), 0, s, BT, T, d, xpre, b_o, cvec, wbar, q_res, mtxt);
+int launch_t2v_premix_finish(int BT, int T, int N, int d, float* xpre, const float* b_o, const float* cvec, const float* wpart, float* wbar,
+                             const float* q_res, const unsigned char* mtxt, hipStream_t s) {
+    hipLaunchKernelGGL(premix_finish_kernel, dim3((unsigned)(((size_t)BT * d + 255) / 256)), dim3(256), 0, s, BT, T, d, cdiv(N, 256), xpre, b_o, cvec,
+                       wpart, wbar, q_res, mtxt);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
@@ -367,11 +389,12 @@ int launch_t2v_premix_bwd(int B, int T, int N, int dmc, int d_m, const int* offs
     const size_t lds = ((size_t)PSB * (PCS + 8) + (size_t)PT * (PCS + 8)) * sizeof(bf16_t);
     hipLaunchKernelGGL(premix_bwd_da_kernel, grid, dim3(256), lds, s, T, dmc, offsets, static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(At),
                        static_cast<const bf16_t*>(dxbar), dwbar, g);
-    hipLaunchKernelGGL(premix_bwd_ds_kernel, grid, dim3(256), 0, s, T, dmc, d_m, dt, offsets, static_cast<const bf16_t*>(At), P, g,
-                       static_cast<const bf16_t*>(dxbar), u, ds, dXt);
+    const int dtp = (dt + 15) & ~15;
+    hipLaunchKernelGGL(premix_bwd_ds_kernel, grid, dim3(256), (size_t)PT * (dtp + 8) * sizeof(bf16_t), s, T, dmc, d_m, dt, dtp, offsets,
+                       static_cast<const bf16_t*>(At), P, g, static_cast<const bf16_t*>(dxbar), u, ds, dXt);
     const int rpb = cdiv(B * N, PM_DU_BLOCKS);
     hipLaunchKernelGGL(premix_du_kernel, dim3(cdiv(dmc, 2048), PM_DU_BLOCKS), dim3(256), 0, s, dmc, total, rpb, static_cast<const bf16_t*>(X), ds, du_slab);
-    hipLaunchKernelGGL(premix_du_reduce_kernel, dim3(cdiv(dmc, 256)), dim3(256), 0, s, dmc, PM_DU_BLOCKS, du_slab, du);
+    hipLaunchKernelGGL(premix_du_reduce_kernel, dim3(cdiv(dmc, 64)), dim3(64), 0, s, dmc, PM_DU_BLOCKS, du_slab, du);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }

@@ -935,7 +935,7 @@ def main():
     ap.add_argument("--fuse-tail", default="auto", choices=["auto", "on", "off"],
                     help="A/B measurements only: TTF_T2V_XAttn's proj_out composed into MMF_XAttn_Add's low-rank projection "
                          "(immtsf.config.fuse_tail; auto = on)")
-    ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold"],
+    ap.add_argument("--t2v-form", default="auto", choices=["auto", "chain", "fold", "mix"],
                     help="A/B measurements only: TTF_T2V_XAttn in its folded form wherever its limits hold (auto, the default) or as the "
                          "reference's GEMM chain (immtsf.config.t2v_form)")
     ap.add_argument("--windows-per-gpu", type=int, default=B_PER_GPU,

@@ -103,8 +103,9 @@ fuse_tail = "auto"
 # nan_check is "deferred" (no host syncs inside the step); False: every call is launched eagerly
 seam_graph = True
 # TTF_T2V_XAttn: "auto" = the library chooses by batch size (the folded form, csrc/t2v_fold.hip, from IMMTSF_T2V_FOLD_MIN_ROWS padded note
-# rows on -- its parameter-only chains are a fixed cost), "fold" = the folded form wherever its limits hold, "chain" = the reference's
-# GEMM chain as written
+# rows on -- its parameter-only chains are a fixed cost; its mix-first variant, csrc/t2v_premix.hip, for windows of more than 64 padded
+# notes in bf16 mode), "fold" = the folded form wherever its limits hold, "mix" = the mix-first variant wherever ITS limits hold (bf16
+# mode, one head, T <= 32), "chain" = the reference's GEMM chain as written
 t2v_form = "auto"
 # immtsf.train.FlagStep <-> MMFXRankQLossFn: address of the device flag that says "dY_ts is ready" (None: nobody is waiting)
 head_done_flag = None

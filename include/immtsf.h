@@ -93,8 +93,11 @@ typedef struct immtsf_fusion_cfg {
                                       IMMTSF_T2V_FOLD_MIN_ROWS padded note rows B*N on, where its limits hold: N <= 64 padded notes,
                                       T <= 32, d <= 1024, H <= 4; below that the fixed cost of its parameter-only chains outweighs the
                                       rows it saves), 1 = the reference's GEMM chain as written, 2 = the folded form wherever its limits
-                                      hold.  Same function, same parameters, same dropout masks either way; forward and backward of one
-                                      call pair must be given the same value.  (ABI 3; occupies former padding) */
+                                      hold, 3 = the MIX-FIRST variant of the folded form (csrc/t2v_premix.hip: the window's raw rows are
+                                      mixed per forecast step, then ONE B*T-row product; bf16 mode, one head, T <= 32) wherever ITS limits
+                                      hold -- what 0 chooses for windows of more than 64 padded notes.  Same function, same parameters,
+                                      same dropout masks either way; forward and backward of one call pair must be given the same
+                                      value.  (ABI 3; occupies former padding) */
     /* bf16 mode, optional (NULL = off): bf16 images of the activations that cross a block boundary, so that the consumer's
      * GEMMs read them by LDS-DMA without a cast kernel of their own.  out_h: the call also writes its main activation
      * output there (ttf forward: E_txt (B*T*d); mmf q backward: dKV (B*T*2d); mmf kv backward: dE_txt).  in_h: image of

@@ -85,3 +85,29 @@ def test_two_writers_of_one_undeclared_sink_raise_on_the_host():
     q._immtsf_grad_shared = True                                     # declared shared: every writer accumulates
     ops._claim_sinks([q], [q._immtsf_grad_sink], "a")
     ops._claim_sinks([q], [q._immtsf_grad_sink], "b")
+
+
+def test_t2v_form_selection_is_a_host_decision():
+    """immtsf_ttf_t2v_xattn_folded (no kernel, no GPU): which formulation of TTF_T2V_XAttn a cfg gets -- the folded form from 8192 padded
+    note rows on inside its limits (N <= 64), its mix-first variant for longer windows in bf16 mode with one head (or form 3), the chain
+    as written otherwise (form 1, fp32 with long windows, several heads with long windows).  include/immtsf.h immtsf_fusion_cfg.form."""
+    import ctypes as C
+    from immtsf import _lib
+    from immtsf.ops import make_cfg
+    lib = _lib.load()
+
+    def folded(B, N, T, d_m, d, H, bf16, form):
+        cfg = make_cfg(B, N, T, 0, d_m, d, H, 1 if bf16 else 0, True, 0.1, 0.0, 0, None)
+        cfg.form = form
+        return lib.immtsf_ttf_t2v_xattn_folded(C.byref(cfg))
+
+    assert folded(64, 32, 32, 768, 768, 1, True, 0) == 0            # 2048 padded rows: below the fold's fixed cost
+    assert folded(256, 32, 32, 768, 768, 1, True, 0) == 1           # 8192 rows: folded
+    assert folded(64, 32, 32, 768, 768, 1, True, 2) == 1
+    assert folded(256, 32, 32, 768, 768, 1, True, 1) == 0           # the chain on request
+    assert folded(64, 4096, 32, 4096, 768, 1, True, 0) == 1         # cfg5: long windows, bf16, one head -> mix-first
+    assert folded(64, 4096, 32, 4096, 768, 1, False, 0) == 0        # fp32 mode: the chain
+    assert folded(64, 4096, 32, 4096, 768, 2, True, 0) == 0         # two heads: the chain
+    assert folded(64, 4096, 33, 4096, 768, 1, True, 3) == 0         # T > 32: outside both folded forms
+    assert folded(4, 16, 8, 64, 32, 1, True, 3) == 1                # form 3 at any N inside its limits
+    assert folded(4, 16, 8, 64, 32, 1, True, 1) == 0

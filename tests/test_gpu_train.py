@@ -1223,6 +1223,7 @@ def test_cfg2_flag_step_with_dropout_vs_oracle():
         for k in range(3):
             got = float(step())
             torch.cuda.synchronize()
+            step.check()        # (a spin that timed out -- a stalled GPU -- drops the optimizer step by design: say so instead of a parity failure)
             ctr = int(w.trainer.drop_dev.item())               # the counter value this replay's kernels added to the modules' seeds
             drop = {"ttf": {"attn": keep(ttf.last_seed + ctr, 1, (B, T, H, N)), "out": keep(ttf.last_seed + ctr, 2, (B, T, d))},
                     "mmf": {"attn": keep(mmf.last_seed + ctr, 4, (B, H, T, T)), "out": keep(mmf.last_seed + ctr, 5, (B, T, Cc))}}

@@ -79,12 +79,12 @@ __device__ __forceinline__ void stage(const DecDims& d, const DecP& p, const flo
 }
 // u[n][k] = b1[k] + sum_d W1[k][d] h[b, n, d];  v[lp][k] = sum_e W1[k][D + e] te[b, lp, e]   (operands staged by stage())
 template <int H>
-__device__ __forceinline__ void first_layer(const DecDims& d, const float* __restrict__ b1, const float* st, float* u, float* v) {
+__device__ __forceinline__ void first_layer(const DecDims& d, const float* __restrict__ b1, const float* st, float* u, float* v, int nthreads = 256) {
     constexpr int P1 = Geo<H>::P1;
     const int pw = d.D + d.E + 1;
     const float* hs = st + H * pw;
     const float* tes = hs + d.N * d.D;
-    for (int i = threadIdx.x; i < (d.N + d.Lp) * H; i += 256) {
+    for (int i = threadIdx.x; i < (d.N + d.Lp) * H; i += nthreads) {
         const int r = i / H, k = i - r * H;
         const float* w = st + k * pw;
         float a;
@@ -498,11 +498,17 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
     float* gtes = gb1s + H;                   // [2][16]: running d w | d b of the fused LearnableTE
     if (tid < 32) gtes[tid] = 0.f;
     float* red = gtes + 32;
+    float te_gw = 0.f, te_gb = 0.f;          // this thread's share of the fused LearnableTE's d w[e] / d b[e], e = tid % 16
+    // (its frequency and phase are loaded once, its step's time at the top of a window: nothing of that phase waits for memory)
+    const int te_e = tid & 15;
+    const bool te_on = tq.t != nullptr && te_e < d.E;
+    const float te_w = (te_on && te_e > 0) ? tq.w[te_e - 1] : 0.f, te_b = (te_on && te_e > 0) ? tq.b[te_e - 1] : 0.f;
     const bool priv = use_slabs != 0;       // (the host: Lp > 12 and the slabs fit)
     const int slab_floats = (d.Lp + 1) * P1;
     float* slab = red + (size_t)wave * slab_floats;
 
     for (int b = blockIdx.x; b < d.B; b += gridDim.x) {
+        const float te_t0 = (te_on && (tid >> 4) < d.Lp) ? tq.t[(size_t)b * d.Lp + (tid >> 4)] : 0.f;
         for (int i = tid; i < (d.N + d.Lp) * P1; i += NT) du[i] = 0.f;      // du and dv are contiguous
         for (int r = tid; r < pairs * 32; r += NT) {            // (padded to whole tile pairs with zeros)
             const int n = r / d.Lp, lp = r - n * d.Lp;
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             for (int i = lane; i < slab_floats; i += 64) slab[i] = 0.f;
         stage<H>(d, p, h, te, b, Xs, tq, NT);
         __syncthreads();
-        first_layer<H>(d, p.b1, Xs, u, v);
+        first_layer<H>(d, p.b1, Xs, u, v, NT);      // (every thread once: with the default stride the upper half of the 512 repeated the lower's rows)
         __syncthreads();
         for (int pr = wave; pr < pairs; pr += NW) {
             bf16x8 hb[2];
@@ -637,17 +643,21 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
         const int ld = d.D + d.E, pw = ld + 1;
         const float* hs = Xs + H * pw;
         const float* tes = hs + d.N * d.D;
-        for (int i = tid; i < H * ld; i += NT) {
-            const int k = i / ld, c = i - k * ld;
+        // dW1 in two loops of uniform trip count (as one loop over (k, c) a wave walked BOTH sums -- N terms for the h columns, Lp for the
+        // time-embedding columns -- for every output: 5.1 us of a window's 24 on the device clock)
+        for (int i = tid; i < H * d.D; i += NT) {
+            const int k = i / d.D, c = i - k * d.D;
             float a = 0.f;
-            if (c < d.D) {
 #pragma unroll 8
-                for (int n = 0; n < d.N; ++n) a = fmaf(du[n * P1 + k], hs[n * d.D + c], a);
-            } else {
+            for (int n = 0; n < d.N; ++n) a = fmaf(du[n * P1 + k], hs[n * d.D + c], a);
+            gW1s[k * ld + c] += a;
+        }
+        for (int i = tid; i < H * d.E; i += NT) {
+            const int k = i / d.E, e = i - k * d.E;
+            float a = 0.f;
 #pragma unroll 8
-                for (int lp = 0; lp < d.Lp; ++lp) a = fmaf(dv[lp * P1 + k], tes[lp * d.E + c - d.D], a);
-            }
-            gW1s[i] += a;
+            for (int lp = 0; lp < d.Lp; ++lp) a = fmaf(dv[lp * P1 + k], tes[lp * d.E + e], a);
+            gW1s[k * ld + d.D + e] += a;
         }
         for (int i = tid; i < d.N * d.D; i += NT) {
             const int n = i / d.D, c = i - n * d.D;
@@ -656,13 +666,43 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
             for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + c], du[n * P1 + k], a);
             dh[(size_t)b * d.N * d.D + i] = a;
         }
-        for (int i = tid; i < d.Lp * d.E; i += NT) {
-            const int lp = i / d.E, e = i - lp * d.E;
-            float a = 0.f;
+        if (tq.t) {
+            // the fused LearnableTE's gradients: a thread = (step lp, element e = tid % 16), its sums stay in registers over the
+            // workgroup's windows and meet once behind the loop.  (As two LDS atomics per (lp, e) onto 2 E addresses this phase was
+            // 8.7 us of a window's 24 -- the atomics queue per address.)
+            const int e = te_e;
+            if (te_on) {
+                for (int lp = tid >> 4; lp < d.Lp; lp += NT / 16) {
+                    float a = 0.f;
 #pragma unroll
-            for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
-            if (tq.t) dec_te_grad(tq, tq.t[(size_t)b * d.Lp + lp], e, a, gtes);
-            else dte[(size_t)b * d.Lp * d.E + i] = a;
+                    for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
+                    const float t = lp == (tid >> 4) ? te_t0 : tq.t[(size_t)b * d.Lp + lp];
+                    const float gv = e == 0 ? a : a * cosf(fmaf(te_w, t, te_b));
+                    te_gw = fmaf(gv, t, te_gw);
+                    te_gb += gv;
+                }
+            }
+        } else {
+            for (int i = tid; i < d.Lp * d.E; i += NT) {
+                const int lp = i / d.E, e = i - lp * d.E;
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < H; ++k) a = fmaf(Xs[k * pw + d.D + e], dv[lp * P1 + k], a);
+                dte[(size_t)b * d.Lp * d.E + i] = a;
+            }
+        }
+        __syncthreads();
+    }
+    if (tq.t) {     // the waves' LearnableTE sums -> gtes (lanes with the same e: lane ^ 16, lane ^ 32; then the eight waves in order)
+        te_gw = xor32_sum(xor16_sum(te_gw));
+        te_gb = xor32_sum(xor16_sum(te_gb));
+        if (lane < 16) { red[wave * 32 + lane] = te_gw; red[wave * 32 + 16 + lane] = te_gb; }
+        __syncthreads();
+        if (tid < 32) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sacc += red[w * 32 + tid];
+            gtes[tid] = sacc;
         }
         __syncthreads();
     }

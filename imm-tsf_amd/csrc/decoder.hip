@@ -65,11 +65,12 @@ size_t bwd_lds(int N, int Lp, int D, int E) {       // ... + the workgroup's run
 // coalesced copies: W1s[k][D+E+1], hs[n][D], tes[lp][E] (contiguous, in this order, at `st`)
 template <int H>
 __device__ __forceinline__ void stage(const DecDims& d, const DecP& p, const float* __restrict__ h, const float* __restrict__ te, int b,
-                                      float* st, const DecTE& tq, int nthreads = 256) {
+                                      float* st, const DecTE& tq, int nthreads = 256, bool with_w1 = true) {
     const int ld = d.D + d.E, pw = ld + 1;
     float* hs = st + H * pw;
     float* tes = hs + d.N * d.D;
-    for (int i = threadIdx.x; i < H * ld; i += nthreads) st[(i / ld) * pw + i % ld] = p.W1[i];
+    if (with_w1)        // (a persistent workgroup whose image of W1 survives its windows stages it once)
+        for (int i = threadIdx.x; i < H * ld; i += nthreads) st[(i / ld) * pw + i % ld] = p.W1[i];
     for (int i = threadIdx.x; i < d.N * d.D; i += nthreads) hs[i] = h[(size_t)b * d.N * d.D + i];
     if (tq.t) {
         for (int i = threadIdx.x; i < d.Lp * d.E; i += nthreads) tes[i] = dec_te_value(tq, tq.t[(size_t)b * d.Lp + i / d.E], i % d.E);
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(512) void dec_bwd_mfma_kernel(DecDims d, DecP p, co
         }
         if (priv)
             for (int i = lane; i < slab_floats; i += 64) slab[i] = 0.f;
-        stage<H>(d, p, h, te, b, Xs, tq, NT);
+        stage<H>(d, p, h, te, b, Xs, tq, NT, b == (int)blockIdx.x);      // (nothing else is written to Xs in this kernel)
         __syncthreads();
         first_layer<H>(d, p.b1, Xs, u, v, NT);      // (every thread once: with the default stride the upper half of the 512 repeated the lower's rows)
         __syncthreads();

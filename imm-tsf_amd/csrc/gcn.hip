@@ -17,6 +17,8 @@ struct Dims {
 struct Lds {
     int X, Xk, Z, dfeat, L1, L2, dL1, dL2, NV1, NV2, dNV1, dNV2, A, S, dA, Wm, vec, total, ldw, F;
     int fwd_total, g_mb, g_mw, g_nv1, g_nv2, g_g1w, g_g2w, g_gb, g_l1w, g_l2w, g_l1b, g_l2b;
+    int p_l1w, p_l2w, p_g1w, p_g2w, p_nv1, p_nv2;      // backward: the parameters its phases read, staged once per workgroup
+    int saved;           // floats a cell hands from the forward to the backward: X | X_k | Z | L1 | L2 | NV1 | NV2 | A | S | t, g (4 N)
     __host__ __device__ explicit Lds(const Dims& d) {
         const int ND = d.N * d.D, Nn = d.N * d.nd, NN = d.N * d.N;
         F = (d.order + 1) * d.D;            // concatenated feature width
@@ -52,7 +54,14 @@ struct Lds {
         g_l2w = o;  o += d.nd * d.D;
         g_l1b = o;  o += d.nd;
         g_l2b = o;  o += d.nd;
+        p_l1w = o;  o += d.nd * d.D;
+        p_l2w = o;  o += d.nd * d.D;
+        p_g1w = o;  o += d.D + d.nd;
+        p_g2w = o;  o += d.D + d.nd;
+        p_nv1 = o;  o += Nn;
+        p_nv2 = o;  o += Nn;
         total = o;
+        saved = (d.order + 2) * ND + 4 * Nn + 2 * NN + 4 * d.N;
     }
 };
 
@@ -161,7 +170,27 @@ __device__ void cell_forward(float* sm, const Lds& l, const Dims& d, const Param
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void gcn_fwd_kernel(Dims d, Params p, const float* __restrict__ x, float* __restrict__ out) {
+// what cell_forward leaves behind that the backward reads, as one contiguous record per cell (`store`: LDS -> memory, else back).  The
+// backward used to recompute the cell: 11.7 of its 33 us on the device clock -- every phase of the forward is a barrier and a chain of
+// dependent LDS reads, 5 KB per cell come back in one round trip
+template <bool STORE>
+__device__ __forceinline__ void cell_record(float* sm, const Lds& l, const Dims& d, float* rec) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int ND = d.N * d.D, Nn = d.N * d.nd, NN = d.N * d.N;
+    const int off[7] = {l.X, l.L1, l.NV1, l.A, l.S, l.vec, 0}, len[6] = {(d.order + 2) * ND, 2 * Nn, 2 * Nn, NN, NN, 4 * d.N};
+    int at = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {           // (X, X_k, Z are contiguous in LDS; so are L1 | L2 and NV1 | NV2)
+        for (int i = tid; i < len[q]; i += nt) {
+            if (STORE) rec[at + i] = sm[off[q] + i];
+            else sm[off[q] + i] = rec[at + i];
+        }
+        at += len[q];
+    }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(256) void gcn_fwd_kernel(Dims d, Params p, const float* __restrict__ x, float* __restrict__ out, float* __restrict__ saved) {
     extern __shared__ float sm[];
     const Lds l(d);
     const int b = blockIdx.x / d.M, m = blockIdx.x - b * d.M;
@@ -170,21 +199,38 @@ __global__ __launch_bounds__(256) void gcn_fwd_kernel(Dims d, Params p, const fl
         const int v = i / d.D, o = i - v * d.D;
         out[(((size_t)b * d.N + v) * d.M + m) * d.D + o] = fmaxf(sm[l.Z + i], 0.f);
     }
+    if (SAVE) cell_record<true>(sm, l, d, saved + (size_t)blockIdx.x * l.saved);
 }
 
+template <bool SAVED>
 __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const float* __restrict__ x,
-                                                       const float* __restrict__ dout, float* __restrict__ dx, Grads g) {
+                                                       const float* __restrict__ dout, float* __restrict__ dx, Grads g, const float* __restrict__ saved) {
     extern __shared__ float sm[];
     const Lds l(d);
     const int tid = threadIdx.x, nt = blockDim.x;
     const int N = d.N, D = d.D, nd = d.nd;
-    for (int i = l.g_mb + tid; i < l.total; i += nt) sm[i] = 0.f;
+    for (int i = l.g_mb + tid; i < l.p_l1w; i += nt) sm[i] = 0.f;
+    // the parameters the phases below read, once per workgroup (from global memory inside the loops they were chains of dependent L2
+    // round trips: the gate-weight and dx phases 2.4 us each of a cell's 33 on the device clock)
+    for (int i = tid; i < nd * D; i += nt) { sm[l.p_l1w + i] = p.l1w[i]; sm[l.p_l2w + i] = p.l2w[i]; }
+    for (int i = tid; i < D + nd; i += nt) { sm[l.p_g1w + i] = p.g1w[i]; sm[l.p_g2w + i] = p.g2w[i]; }
+    for (int i = tid; i < N * nd; i += nt) { sm[l.p_nv1 + i] = p.nv1[i]; sm[l.p_nv2 + i] = p.nv2[i]; }
+    if (SAVED)          // the mixing weight once per workgroup (cell_forward stages it per cell)
+        for (int i = tid; i < D * l.F; i += nt) {
+            const int o = i / l.F, c = i - o * l.F;
+            sm[l.Wm + o * l.ldw + c] = p.mw[i];
+        }
     // a workgroup walks cells blockIdx.x, + gridDim.x, ...: every parameter-gradient element below is owned by one thread
     // (same loop shape in every cell), accumulated in LDS and added to global memory once per workgroup -- with one workgroup
     // per cell the ~3.5 k atomics of each of B * M cells queue up per address and were the whole run time of this kernel
     for (int cell = blockIdx.x; cell < d.B * d.M; cell += gridDim.x) {
     const int b = cell / d.M, m = cell - b * d.M;
-    cell_forward(sm, l, d, p, x, b, m);
+    if (SAVED) {
+        cell_record<false>(sm, l, d, const_cast<float*>(saved) + (size_t)cell * l.saved);
+        __syncthreads();
+    } else {
+        cell_forward(sm, l, d, p, x, b, m);
+    }
     // dZ = dout * relu'(Z)
     for (int i = tid; i < N * D; i += nt) {
         const int v = i / D, o = i - v * D;
@@ -201,10 +247,11 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         sm[l.g_mb + o] += acc;
     }
     for (int i = tid; i < D * l.F; i += nt) {
-        const int o = i / l.F, c = i - o * l.F;
+        const int o = i / l.F, c = i - o * l.F, k = c / D, f = c - k * D;
+        const float* fx = sm + l.X + k * N * D + f;          // feat[v, c] = X_k[v, f]
         float acc = 0.f;
 #pragma unroll 8
-        for (int v = 0; v < N; ++v) acc = fmaf(sm[l.Z + v * D + o], feat_at(sm, l, d, v, c), acc);
+        for (int v = 0; v < N; ++v) acc = fmaf(sm[l.Z + v * D + o], fx[v * D], acc);
         sm[l.g_mw + i] += acc;
     }
     // dfeat[k][v, f] = sum_o Wm[o, k*D + f] dZ[v, o]     (stored as order+1 slabs of N x D, like X/Xk)
@@ -279,8 +326,8 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     // node vectors
     for (int i = tid; i < N * nd; i += nt) {
         const int n = i / nd, k = i - n * nd;
-        sm[l.g_nv1 + n * nd + k] += sm[l.dNV1 + i] + da1[n] * p.g1w[D + k];
-        sm[l.g_nv2 + k * N + n] += sm[l.dNV2 + i] + da2[n] * p.g2w[D + k];
+        sm[l.g_nv1 + n * nd + k] += sm[l.dNV1 + i] + da1[n] * sm[l.p_g1w + D + k];
+        sm[l.g_nv2 + k * N + n] += sm[l.dNV2 + i] + da2[n] * sm[l.p_g2w + D + k];
     }
     // gate weights / biases
     for (int i = tid; i < 2 * (D + nd + 1); i += nt) {
@@ -288,7 +335,7 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
         const float* da = which ? da2 : da1;
         float acc = 0.f;
         if (j < D) for (int n = 0; n < N; ++n) acc = fmaf(da[n], sm[l.X + n * D + j], acc);
-        else if (j < D + nd) for (int n = 0; n < N; ++n) acc = fmaf(da[n], which ? p.nv2[(j - D) * N + n] : p.nv1[n * nd + (j - D)], acc);
+        else if (j < D + nd) for (int n = 0; n < N; ++n) acc = fmaf(da[n], which ? sm[l.p_nv2 + (j - D) * N + n] : sm[l.p_nv1 + n * nd + (j - D)], acc);
         else for (int n = 0; n < N; ++n) acc += da[n];
         if (j < D + nd) sm[(which ? l.g_g2w : l.g_g1w) + j] += acc;
         else sm[l.g_gb + which] += acc;
@@ -312,11 +359,12 @@ __global__ __launch_bounds__(256) void gcn_bwd_kernel(Dims d, Params p, const fl
     for (int i = tid; i < N * D; i += nt) {
         const int n = i / D, f = i - n * D;
         float acc = sm[l.dfeat + i];
-        acc = fmaf(da1[n], p.g1w[f], acc);
-        acc = fmaf(da2[n], p.g2w[f], acc);
+        acc = fmaf(da1[n], sm[l.p_g1w + f], acc);
+        acc = fmaf(da2[n], sm[l.p_g2w + f], acc);
+#pragma unroll 2
         for (int k = 0; k < nd; ++k) {
-            acc = fmaf(sm[l.dL1 + n * nd + k], p.l1w[k * D + f], acc);
-            acc = fmaf(sm[l.dL2 + n * nd + k], p.l2w[k * D + f], acc);
+            acc = fmaf(sm[l.dL1 + n * nd + k], sm[l.p_l1w + k * D + f], acc);
+            acc = fmaf(sm[l.dL2 + n * nd + k], sm[l.p_l2w + k * D + f], acc);
         }
         dx[(((size_t)b * N + n) * d.M + m) * D + f] = acc;
     }
@@ -367,32 +415,47 @@ size_t immtsf_tpatchgnn_gcn_lds_bytes(int32_t N, int32_t D, int32_t nd, int32_t 
     return check_dims(d, &bytes) == IMMTSF_OK ? bytes : 0;
 }
 
-int immtsf_tpatchgnn_gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
-                                 const immtsf_gcn_params* p, float* out, immtsf_stream_t stream) {
+size_t immtsf_tpatchgnn_gcn_saved_floats(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order) {
+    size_t bytes = 0;
+    const Dims d{B, N, M, D, nd, order};
+    return check_dims(d, &bytes) == IMMTSF_OK ? (size_t)B * M * Lds(d).saved : 0;
+}
+
+static int gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x, const immtsf_gcn_params* p,
+                       float* out, float* saved, immtsf_stream_t stream) {
     const Dims d{B, N, M, D, nd, order};
     size_t bytes = 0;
     if (!x || !out || !all_set(p)) return IMMTSF_EINVAL;
     if (int rc = check_dims(d, &bytes)) return rc;
     bytes = (size_t)Lds(d).fwd_total * sizeof(float);       // (the backward's gradient accumulators are not needed)
     if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_fwd_kernel),
+        hipError_t e = hipFuncSetAttribute(saved ? reinterpret_cast<const void*>(gcn_fwd_kernel<true>) : reinterpret_cast<const void*>(gcn_fwd_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(gcn_fwd_kernel, dim3(B * M), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, out);
+    if (saved) hipLaunchKernelGGL(gcn_fwd_kernel<true>, dim3(B * M), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, out, saved);
+    else hipLaunchKernelGGL(gcn_fwd_kernel<false>, dim3(B * M), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, out, saved);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
 }
+int immtsf_tpatchgnn_gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                 const immtsf_gcn_params* p, float* out, immtsf_stream_t stream) {
+    return gcn_forward(B, N, M, D, nd, order, x, p, out, nullptr, stream);
+}
+int immtsf_tpatchgnn_gcn_forward_saved(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                       const immtsf_gcn_params* p, float* out, float* saved, immtsf_stream_t stream) {
+    if (!saved) return IMMTSF_EINVAL;
+    return gcn_forward(B, N, M, D, nd, order, x, p, out, saved, stream);
+}
 
-int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
-                                  const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
-                                  immtsf_stream_t stream) {
+static int gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x, const immtsf_gcn_params* p,
+                        const float* dout, float* dx, const immtsf_gcn_params* grads, const float* saved, immtsf_stream_t stream) {
     const Dims d{B, N, M, D, nd, order};
     size_t bytes = 0;
-    if (!x || !dout || !dx || !all_set(p) || !all_set(grads)) return IMMTSF_EINVAL;
+    if ((!x && !saved) || !dout || !dx || !all_set(p) || !all_set(grads)) return IMMTSF_EINVAL;
     if (int rc = check_dims(d, &bytes)) return rc;
     if (bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gcn_bwd_kernel),
+        hipError_t e = hipFuncSetAttribute(saved ? reinterpret_cast<const void*>(gcn_bwd_kernel<true>) : reinterpret_cast<const void*>(gcn_bwd_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return (int)e;
     }
@@ -401,10 +464,22 @@ int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, in
     int per_cu = (int)((160 * 1024) / bytes);      // resident workgroups per CU by LDS, at most 4: the grid is the atomics' fan-in
     per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
     const int cells = B * M, grid = cells < 256 * per_cu ? cells : 256 * per_cu;
-    hipLaunchKernelGGL(gcn_bwd_kernel, dim3(grid), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, dout,
-                       dx, g);
+    if (saved) hipLaunchKernelGGL(gcn_bwd_kernel<true>, dim3(grid), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, dout, dx, g, saved);
+    else hipLaunchKernelGGL(gcn_bwd_kernel<false>, dim3(grid), dim3(256), bytes, static_cast<hipStream_t>(stream), d, to_params(p), x, dout, dx, g, saved);
     IMMTSF_LAUNCH_CHECK();
     return IMMTSF_OK;
+}
+int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                  const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
+                                  immtsf_stream_t stream) {
+    if (!x) return IMMTSF_EINVAL;
+    return gcn_backward(B, N, M, D, nd, order, x, p, dout, dx, grads, nullptr, stream);
+}
+int immtsf_tpatchgnn_gcn_backward_saved(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* saved,
+                                        const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
+                                        immtsf_stream_t stream) {
+    if (!saved) return IMMTSF_EINVAL;
+    return gcn_backward(B, N, M, D, nd, order, nullptr, p, dout, dx, grads, saved, stream);
 }
 
 }  // extern "C"

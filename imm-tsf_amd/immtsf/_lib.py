@@ -248,6 +248,9 @@ _PROTOS = {
     "immtsf_conv2d_period_backward": (C.c_int, [C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                                 c_f32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_stream]),
     "immtsf_tpatchgnn_gcn_forward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_stream]),
+    "immtsf_tpatchgnn_gcn_saved_floats": (C.c_size_t, [C.c_int32] * 6),
+    "immtsf_tpatchgnn_gcn_forward_saved": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, c_stream]),
+    "immtsf_tpatchgnn_gcn_backward_saved": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams), c_stream]),
     "immtsf_tpatchgnn_gcn_backward": (C.c_int, [C.c_int32] * 6 + [c_f32p, _P(GCNParams), c_f32p, c_f32p, _P(GCNParams),
                                                 c_stream]),
     "immtsf_tpatchgnn_decoder_lds_bytes": (C.c_size_t, [C.c_int32] * 5),

@@ -1162,24 +1162,31 @@ class GCNAdaptiveFn(torch.autograd.Function):
         nd = params[0].shape[1]
         out = torch.empty_like(x)
         ps = _struct(GCNParams, params)
-        check(lib.immtsf_tpatchgnn_gcn_forward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out), stream_ptr()),
-              "tpatchgnn_gcn_forward")
         ctx.dims = (B, N, M, D, nd, order)
         ctx.sinks = _sinks_of(params)
-        ctx.save_for_backward(x, *params)
+        if any(ctx.needs_input_grad):
+            # a training forward leaves every cell's intermediates for the backward (5 KB per cell) instead of having it recompute them
+            saved = torch.empty(lib.immtsf_tpatchgnn_gcn_saved_floats(B, N, M, D, nd, order), dtype=torch.float32, device=x.device)
+            check(lib.immtsf_tpatchgnn_gcn_forward_saved(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out), ptr(saved), stream_ptr()),
+                  "tpatchgnn_gcn_forward_saved")
+            ctx.save_for_backward(saved, *params)
+        else:
+            check(lib.immtsf_tpatchgnn_gcn_forward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out), stream_ptr()),
+                  "tpatchgnn_gcn_forward")
+            ctx.save_for_backward(x, *params)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        x, *params = ctx.saved_tensors
+        saved, *params = ctx.saved_tensors
         B, N, M, D, nd, order = ctx.dims
         dout = dout.contiguous()
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(dout)
         grads, rets = _zeroed_grad_buffers(params, ctx.sinks)
         ps, gs = _struct(GCNParams, params), _struct(GCNParams, grads)
-        check(lib.immtsf_tpatchgnn_gcn_backward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs),
-                                                stream_ptr()), "tpatchgnn_gcn_backward")
+        check(lib.immtsf_tpatchgnn_gcn_backward_saved(B, N, M, D, nd, order, ptr(saved), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs),
+                                                      stream_ptr()), "tpatchgnn_gcn_backward_saved")
         return (dx, None) + tuple(rets)
 
 

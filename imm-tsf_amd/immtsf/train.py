@@ -1057,15 +1057,14 @@ class FlagStep(PhasedStep):
                         fset(F_P2, P)
                 with torch.cuda.stream(B):
                     fset(F_B2, B)
-                # join: the parameter branch FIRST -- a stream join costs 7 - 9 us on this stack even when the joined branch ended long ago
-                # (profiles/r05_flag_timeline.txt: 9.5 us between "backbone backward done" and the next wait), and the text branch is idle
-                # here while the backbone's backward, the longest chain at every measured size, still runs: only ONE join is left behind it
-                # (same box, three alternating pairs of 40-step timelines: median 438.1 us against 441.8 with the backbone joined first)
+                # join: both branches as dependencies of ONE node (the flags_clear_set below).  A stream join costs 7 - 10 us on this stack
+                # even when the joined branch ended long ago (profiles/r05_flag_timeline.txt); with a flag wait in front of each -- the
+                # round-4 form: "the flag says so" -- the two joins were two barriers in a row behind the last branch: 18 us of a 440 us
+                # step.  Back to back they become one barrier with two signals: same box, three alternating pairs of 40-step timelines,
+                # median 425.6 us against 442.0.  (The two flags are still set: the timeline tool reads them.)
                 if P is not B:
-                    fwait(F_P2, T)
                     T.wait_stream(P)
-                fwait(F_B2, T)
-                T.wait_stream(B)                      # (B's last kernel has run: the flag says so)
+                T.wait_stream(B)
                 if self.dist:
                     # what nobody announced is complete now: contiguous runs of the remaining buckets, announced behind the join
                     branch_now[0] = "J"

@@ -473,6 +473,16 @@ typedef struct immtsf_gcn_params {
 size_t immtsf_tpatchgnn_gcn_lds_bytes(int32_t N, int32_t D, int32_t nd, int32_t order);
 int immtsf_tpatchgnn_gcn_forward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
                                  const immtsf_gcn_params* p, float* out, immtsf_stream_t stream);
+/* the same forward, also leaving what the backward reads of every cell -- X, the hop slabs, the mixing layer's pre-activation, the
+ * node-vector intermediates, adjacency and gates: immtsf_tpatchgnn_gcn_saved_floats(...) floats (5 KB per cell at N 8, D 32, nd 10) -- in
+ * `saved`; immtsf_tpatchgnn_gcn_backward_saved reads them back instead of recomputing the cell (a third of the recomputing backward's
+ * time: every phase of the cell is a barrier and a chain of dependent LDS reads) */
+size_t immtsf_tpatchgnn_gcn_saved_floats(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order);
+int immtsf_tpatchgnn_gcn_forward_saved(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,
+                                       const immtsf_gcn_params* p, float* out, float* saved, immtsf_stream_t stream);
+int immtsf_tpatchgnn_gcn_backward_saved(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* saved,
+                                        const immtsf_gcn_params* p, const float* dout, float* dx, const immtsf_gcn_params* grads,
+                                        immtsf_stream_t stream);
 /* recomputes the cell's forward from x; dx overwritten; parameter gradients are ACCUMULATED (atomics) into `grads`,
  * which the caller zeroes (or lets run on as a running sum) */
 int immtsf_tpatchgnn_gcn_backward(int32_t B, int32_t N, int32_t M, int32_t D, int32_t nd, int32_t order, const float* x,

@@ -267,6 +267,44 @@ def test_fused_graph_stage_vs_eager(B, N, M, D, nd, hop):
         assert _rel(res["hip"][2][n], res["torch"][2][n], floor=1e-3 * gmax) < 2e-4, n
 
 
+def test_graph_stage_backward_from_saved_cells_equals_the_recomputing_one():
+    """immtsf_tpatchgnn_gcn_backward_saved (the cells' intermediates left by immtsf_tpatchgnn_gcn_forward_saved: what a training forward of
+    the module uses) against immtsf_tpatchgnn_gcn_backward (recomputes every cell from x): the same kernels behind the recompute, so dx
+    and all twelve parameter gradients agree to round-off of the atomics' order; the forwards' outputs bit for bit."""
+    dev = _dev()
+    import ctypes as C
+    from immtsf import _lib
+    from immtsf.ops import _struct, ptr, stream_ptr
+    lib = _lib.load()
+    torch.manual_seed(5)
+    B, N, M, D, nd, order = 7, 8, 2, 32, 10, 1
+    shapes = [(N, nd), (nd, N), (1, D + nd), (1,), (1, D + nd), (1,), (nd, D), (nd,), (nd, D), (nd,), (D, (order + 1) * D), (D,)]
+    params = [0.3 * torch.randn(*sh, device=dev) for sh in shapes]
+    x, dout = torch.randn(B, N, M, D, device=dev), torch.randn(B, N, M, D, device=dev)
+    ps = _struct(_lib.GCNParams, params)
+    out_a, out_b = torch.empty_like(x), torch.empty_like(x)
+    saved = torch.empty(lib.immtsf_tpatchgnn_gcn_saved_floats(B, N, M, D, nd, order), dtype=torch.float32, device=dev)
+    assert saved.numel() == B * M * ((order + 2) * N * D + 4 * N * nd + 2 * N * N + 4 * N)
+    _lib.check(lib.immtsf_tpatchgnn_gcn_forward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out_a), stream_ptr()), "gcn_forward")
+    _lib.check(lib.immtsf_tpatchgnn_gcn_forward_saved(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(out_b), ptr(saved), stream_ptr()), "gcn_forward_saved")
+    assert torch.equal(out_a, out_b)
+    res = []
+    for use_saved in (False, True):
+        grads = [torch.zeros_like(t) for t in params]
+        gs = _struct(_lib.GCNParams, grads)
+        dx = torch.empty_like(x)
+        if use_saved:
+            _lib.check(lib.immtsf_tpatchgnn_gcn_backward_saved(B, N, M, D, nd, order, ptr(saved), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs), stream_ptr()),
+                       "gcn_backward_saved")
+        else:
+            _lib.check(lib.immtsf_tpatchgnn_gcn_backward(B, N, M, D, nd, order, ptr(x), C.byref(ps), ptr(dout), ptr(dx), C.byref(gs), stream_ptr()),
+                       "gcn_backward")
+        torch.cuda.synchronize()
+        res.append([dx] + grads)
+    for a, b in zip(*res):
+        assert _rel(b, a, floor=1e-6) < 1e-5
+
+
 def test_out_of_limit_shapes_take_the_tested_unfused_paths():
     """Shapes outside the fused kernels' limits -- more variables than one graph cell's LDS image holds (adaptive-graph stage), more
     than 8 patches per variable (transformer block) -- run the module's UNFUSED formulations: `_graph_stage`'s stock-torch branch and

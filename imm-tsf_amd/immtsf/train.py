@@ -806,8 +806,8 @@ class FlagStep(PhasedStep):
     producer has finished (the text-side backward of the cfg2 step: profiles/r03_step_kernel_sequence.txt), whereas a wait that is
     already satisfied costs nothing.  A one-lane spin kernel resumes within a microsecond and occupies one wave slot.
 
-        stream T:  norm + step decision | Adam(T's buckets), text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ... wait(B2) | join | clear
-        stream B:  (forked behind the norm)  Adam(B's buckets), backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2)
+        stream T:  norm + step decision | Adam(T's buckets), text fwd .. wait(B1) head fwd + bwd, set(T2) .. text bwd ... | join(P, B): one barrier | clear
+        stream B:  (forked behind the norm)  Adam(B's buckets), backbone fwd, set(B1) .. wait(T2) backbone bwd, collect, set(B2: for the timeline tool)
         stream P:  (forked behind T's Adam)  Adam(P's buckets), fold, set .......... wait(tail inputs) parameter-gradient chain, set(P2)
 
     THE OPTIMIZER SITS AT THE HEAD OF THE NEXT REPLAY (round 5).  clip + Adam of step k run at the head of replay k + 1 (`flush()`
